@@ -1,0 +1,251 @@
+/*
+ * mom6x.h -- C ABI of the MI355X-native MOM6 split-explicit dynamical core.
+ *
+ * This is the drop-in boundary: every entry point below
+ * is what a Fortran `bind(C)` interface in MOM6 binds to replace one module
+ * procedure of the reference.  Each declaration cites the reference interface
+ * (file:line under /root/reference) that it stands in for.  No torch / C++ types
+ * appear in any signature: plain pointers, ints and doubles only.
+ *
+ * Memory model
+ * ------------
+ * All field pointers handed to the `mom6x_*` compute entry points are DEVICE
+ * pointers (HBM) to FP64 arrays in the "pitched tile layout" described by
+ * mom6x_dims.  The Fortran host keeps its own (i,j,k) column-major arrays
+ * (i fastest); mom6x_upload_* / mom6x_download_* convert between a Fortran array
+ * with MOM6's symmetric-memory extents and the pitched device layout with one
+ * strided DMA (hipMemcpy3DAsync), so i stays the coalesced index on the device
+ * exactly as in the reference's `do i` inner loops.
+ *
+ * Pitched tile layout (one layout for h-, u-, v- and q-point arrays):
+ *   local C indices: compute domain i = 0..ni-1, j = 0..nj-1 (MOM6 isc..iec,
+ *   jsc..jec); data domain i = -halo..ni-1+halo; the symmetric-memory extra
+ *   row/column of u-, v-, q-point arrays is I = -halo-1 (MOM6 IsdB = isd-1).
+ *   A vertex/face index I (capital in MOM6) refers to the east/north face of
+ *   cell i, as in MOM6.
+ *   flat(i,j,k) = (i + ioff) + (j + joff)*pitch + k*slab,
+ *   with ioff >= halo+1, joff = halo+1, pitch >= ioff+ni+halo (multiple of 16
+ *   doubles so that i = 0 starts a 128-byte line), slab = pitch*(nj+2*halo+1).
+ *   All four staggerings use the same flat(); 2-D arrays are one slab.
+ */
+#ifndef MOM6X_H
+#define MOM6X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOM6X_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------- */
+/* Tile dimensions and layout (MOM_hor_index.F90:14-44 hor_index_type +
+ * config_src/memory/dynamic_symmetric/MOM_memory.h extents).                */
+typedef struct mom6x_dims {
+  int ni, nj, nk;   /* compute-domain size of this tile and number of layers  */
+  int halo;         /* NIHALO = NJHALO (MOM_domains.F90:221), >= 4 for PPM+BT */
+  int ioff, joff;   /* memory column/row of local index i = 0 / j = 0         */
+  int pitch;        /* doubles per memory row                                 */
+  int slab;         /* doubles per 2-D plane = pitch * (nj + 2*halo + 1)      */
+  /* Position of this tile in the global (ni_glob x nj_glob) domain and the
+   * 2-D processor layout (MOM_domains LAYOUT = npx,npy).                     */
+  int i_glob0, j_glob0;       /* global index of local (0,0)                  */
+  int ni_glob, nj_glob;
+  int reentrant_x, reentrant_y; /* REENTRANT_X / REENTRANT_Y                  */
+} mom6x_dims;
+
+/* Fill ioff/joff/pitch/slab from ni,nj,nk,halo.  Returns 0 on success.       */
+int mom6x_dims_init(mom6x_dims *d, int ni, int nj, int nk, int halo);
+
+/* ------------------------------------------------------------------------- */
+/* Grid metrics: ocean_grid_type (src/core/MOM_grid.F90:30-200).  All planes
+ * live in ONE contiguous block `metrics[MOM6X_G_COUNT][slab]`.               */
+enum mom6x_metric {
+  MOM6X_G_mask2dT = 0, MOM6X_G_mask2dCu, MOM6X_G_mask2dCv, MOM6X_G_mask2dBu,
+  MOM6X_G_dxT, MOM6X_G_dyT, MOM6X_G_IdxT, MOM6X_G_IdyT,
+  MOM6X_G_dxCu, MOM6X_G_dyCu, MOM6X_G_IdxCu, MOM6X_G_IdyCu,
+  MOM6X_G_dxCv, MOM6X_G_dyCv, MOM6X_G_IdxCv, MOM6X_G_IdyCv,
+  MOM6X_G_dxBu, MOM6X_G_dyBu, MOM6X_G_IdxBu, MOM6X_G_IdyBu,
+  MOM6X_G_areaT, MOM6X_G_IareaT, MOM6X_G_areaBu, MOM6X_G_IareaBu,
+  MOM6X_G_areaCu, MOM6X_G_areaCv, MOM6X_G_IareaCu, MOM6X_G_IareaCv,
+  MOM6X_G_dy_Cu, MOM6X_G_dx_Cv,     /* open face widths                      */
+  MOM6X_G_bathyT,                   /* depth of the bottom, positive down [Z] */
+  MOM6X_G_CoriolisBu, MOM6X_G_Coriolis2Bu,
+  MOM6X_G_COUNT
+};
+
+/* ------------------------------------------------------------------------- */
+/* verticalGrid_type (src/core/MOM_verticalGrid.F90:25-90) -- scalars only;
+ * Rlay/g_prime are passed as arrays of nk doubles where needed.              */
+typedef struct mom6x_vgrid {
+  double g_Earth;        /* G_EARTH [L2 Z-1 T-2]                              */
+  double Rho0;           /* RHO_0                                             */
+  double Angstrom_H;     /* ANGSTROM in thickness units                       */
+  double H_subroundoff;  /* verticalGrid.F90:214-218                          */
+  double dZ_subroundoff;
+  double H_to_Z, Z_to_H, H_to_RZ, RZ_to_H;  /* all 1 / 1 / Rho0 / 1/Rho0 (Bouss) */
+  int    Boussinesq;     /* only 1 is supported            */
+} mom6x_vgrid;
+
+/* ------------------------------------------------------------------------- */
+/* continuity_PPM_CS (src/core/MOM_continuity_PPM.F90:35-68); defaults from
+ * continuity_PPM_init :2674-2754.                                            */
+typedef struct mom6x_continuity_params {
+  int    upwind_1st;       /* UPWIND_1ST_CONTINUITY      (F)                  */
+  int    monotonic;        /* MONOTONIC_CONTINUITY       (F)                  */
+  int    simple_2nd;       /* SIMPLE_2ND_PPM_CONTINUITY  (F)                  */
+  double tol_eta;          /* ETA_TOLERANCE  (0.5*NK*ANGSTROM)                */
+  double tol_vel;          /* VELOCITY_TOLERANCE (3e8 m/s)                    */
+  double CFL_limit_adjust; /* CONTINUITY_CFL_LIMIT (0.5)                      */
+  int    aggress_adjust;   /* CONT_PPM_AGGRESS_ADJUST (F)  -- only F supported */
+  int    vol_CFL;          /* CONT_PPM_VOLUME_BASED_CFL (F) -- only F supported */
+  int    better_iter;      /* CONT_PPM_BETTER_ITER (T)                        */
+  int    use_visc_rem_max; /* CONT_PPM_USE_VISC_REM_MAX (T)                   */
+  int    marginal_faces;   /* CONT_PPM_MARGINAL_FACE_AREAS (T)                */
+} mom6x_continuity_params;
+
+/* BT_cont_type (src/core/MOM_variables.F90:315-350): 12 2-D planes + h_u,h_v.
+ * Any pointer may be NULL only if the whole struct pointer is NULL.          */
+typedef struct mom6x_BT_cont {
+  double *FA_u_EE, *FA_u_E0, *FA_u_W0, *FA_u_WW, *uBT_WW, *uBT_EE;
+  double *FA_v_NN, *FA_v_N0, *FA_v_S0, *FA_v_SS, *vBT_SS, *vBT_NN;
+  double *h_u, *h_v;   /* 3-D; may be NULL (allocated(BT_cont%h_u) false)     */
+} mom6x_BT_cont;
+
+/* barotropic_CS parameters (src/core/MOM_barotropic.F90:108-330, read in
+ * barotropic_init :5403-5713).  Only the default-path flags listed in
+ * SURVEY.md 8(b.1) are implemented; others must keep their default.          */
+typedef struct mom6x_barotropic_params {
+  double bebt;                 /* BEBT (0.1)                                  */
+  double dtbt;                 /* CS%dtbt [T]: the stable BT step (set_dtbt)  */
+  double dt_bt_filter;         /* DT_BT_FILTER (-0.25)                        */
+  int    BT_project_velocity;  /* BT_PROJECT_VELOCITY (F)                     */
+  int    Sadourny;             /* SADOURNY (T)                                */
+  int    strong_drag;          /* BT_STRONG_DRAG (F)                          */
+  int    wt_uv_bug;            /* VISC_REM_BT_WEIGHT_BUG (T)                  */
+  int    use_old_coriolis_bracket_bug; /* BT_USE_OLD_CORIOLIS_BRACKET_BUG (F) */
+  int    visc_rem_u_uh0;       /* BT_USE_VISC_REM_U_UH0 (F)                   */
+  int    clip_velocity;        /* CLIP_BT_VELOCITY (F)                        */
+  double CFL_trunc;            /* CFL_TRUNCATE (0.5)                          */
+  double vel_underflow;        /* VEL_UNDERFLOW (0)                           */
+  double G_extra;              /* G_BT_EXTRA (0)                              */
+  double BT_Coriolis_scale;    /* BT_CORIOLIS_SCALE (1)                       */
+  double maxCFL_BT_cont;       /* MAXCFL_BT_CONT (0.25)                       */
+  int    bound_BT_corr;        /* BOUND_BT_CORRECTION (F)                     */
+  int    BT_cont_bounds;       /* BT_CONT_CORR_BOUNDS (T)                     */
+  double dtbt_fraction;        /* |DTBT| when DTBT<0 (0.98)                   */
+  double Z_ref;                /* G%Z_ref (0)                                 */
+} mom6x_barotropic_params;
+
+/* ------------------------------------------------------------------------- */
+/* Context: owns the device copy of the metrics, the parameter structs, scratch
+ * HBM, two HIP streams (compute + halo) and the RCCL communicator handle.    */
+typedef struct mom6x_ctx mom6x_ctx;
+
+/* Status codes.  The reference calls MOM_error(FATAL,...) (never returns); the
+ * C side returns nonzero and mom6x_last_error() holds the message the Fortran
+ * shim forwards to MOM_error.                                                */
+#define MOM6X_OK          0
+#define MOM6X_EINVAL      1
+#define MOM6X_EHIP        2
+#define MOM6X_EUNSUPPORTED 3
+#define MOM6X_ENUMERIC    4   /* device-side flag: NaN / negative thickness   */
+
+const char *mom6x_last_error(void);
+int  mom6x_abi_version(void);
+
+/* Create a context for one tile on HIP device `device`.  `metrics_host` is a
+ * HOST block of MOM6X_G_COUNT pitched planes (copied to HBM once; replaces the
+ * `G` argument of every reference routine).                                  */
+int mom6x_ctx_create(mom6x_ctx **ctx, const mom6x_dims *dims, int device,
+                     const double *metrics_host, const mom6x_vgrid *GV,
+                     int first_direction);
+int mom6x_ctx_destroy(mom6x_ctx *ctx);
+/* The stream all compute entry points launch on (a hipStream_t).            */
+void *mom6x_ctx_stream(mom6x_ctx *ctx);
+int  mom6x_ctx_sync(mom6x_ctx *ctx);
+const mom6x_dims *mom6x_ctx_dims(const mom6x_ctx *ctx);
+const double *mom6x_ctx_metrics_dev(const mom6x_ctx *ctx);
+
+/* Device memory helpers for non-torch hosts (Fortran).                       */
+int mom6x_dev_alloc(mom6x_ctx *ctx, double **p, size_t n_doubles);
+int mom6x_dev_free(mom6x_ctx *ctx, double *p);
+/* Fortran array <-> pitched device array.  `stagger`: 0 = h-point
+ * (SZI_,SZJ_), 1 = u-point (SZIB_,SZJ_), 2 = v-point (SZI_,SZJB_), 3 = q-point
+ * (SZIB_,SZJB_), with MOM6 symmetric-memory extents; nk = 1 for 2-D.         */
+int mom6x_upload(mom6x_ctx *ctx, double *dev, const double *host_f, int stagger, int nk);
+int mom6x_download(mom6x_ctx *ctx, double *host_f, const double *dev, int stagger, int nk);
+
+/* ------------------------------------------------------------------------- */
+/* MOM_continuity_PPM                                                          */
+
+int mom6x_continuity_init(mom6x_ctx *ctx, const mom6x_continuity_params *p);
+  /* continuity_PPM_init, MOM_continuity_PPM.F90:2674                          */
+
+/* continuity_PPM(u, v, hin, h, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt,
+ *   visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont, du_cor, dv_cor)
+ * MOM_continuity_PPM.F90:86-194.  Optional Fortran arguments are nullable
+ * pointers; presence changes behaviour exactly as in the reference
+ * (:590-592, :637, :737, :756).  OBC must be unassociated and pbv all ones
+ * (USE_POROUS_BARRIER=False).  h may alias hin.                              */
+int mom6x_continuity_PPM(mom6x_ctx *ctx,
+    const double *u, const double *v, const double *hin, double *h,
+    double *uh, double *vh, double dt,
+    const double *uhbt, const double *vhbt,
+    const double *visc_rem_u, const double *visc_rem_v,
+    double *u_cor, double *v_cor, const mom6x_BT_cont *BT_cont,
+    double *du_cor, double *dv_cor);
+
+/* ------------------------------------------------------------------------- */
+/* MOM_barotropic                                                              */
+
+int mom6x_barotropic_init(mom6x_ctx *ctx, const mom6x_barotropic_params *p);
+  /* barotropic_init, MOM_barotropic.F90:5301 (static fields :5784-5896,
+   * :6146-6163).                                                              */
+
+/* btcalc(h, G, GV, CS, h_u, h_v, may_use_default, OBC)  :4360.  h_u/h_v are the
+ * BT_cont%h_u/h_v face thicknesses (BT_THICK_SCHEME=FROM_BT_CONT, the default);
+ * when NULL the HYBRID default of `may_use_default` is used.  Writes the
+ * context's frhatu/frhatv.                                                   */
+int mom6x_btcalc(mom6x_ctx *ctx, const double *h, const double *h_u, const double *h_v);
+
+/* bt_mass_source(h, eta, set_cor, G, GV, CS)  :5243                           */
+int mom6x_bt_mass_source(mom6x_ctx *ctx, const double *h, const double *eta, int set_cor);
+
+/* set_dtbt(G, GV, US, CS, pbce=, gtot_est=, SSH_add=)  :3509.  Result goes to
+ * the context's dtbt (and *dtbt_out if non-NULL).                            */
+int mom6x_set_dtbt(mom6x_ctx *ctx, const double *pbce, double gtot_est, double SSH_add,
+                   double *dtbt_out);
+
+/* btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, eta_PF_in,
+ *   U_Cor, V_Cor, accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, G, GV, US,
+ *   CS, visc_rem_u, visc_rem_v, SpV_avg, ADp, OBC, BT_cont, eta_PF_start, taux_bot,
+ *   tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav)          MOM_barotropic.F90:455-459.
+ * forces%taux/tauy are passed as 2-D planes; SpV_avg/ADp/OBC/eta_PF_start are
+ * not supported (must be absent in the caller); taux_bot/tauy_bot, the uh0 quad
+ * and etaav are nullable.  Mutates the context's ubtav, vbtav, eta_cor.      */
+int mom6x_btstep(mom6x_ctx *ctx,
+    const double *U_in, const double *V_in, const double *eta_in, double dt,
+    const double *bc_accel_u, const double *bc_accel_v,
+    const double *taux, const double *tauy, const double *pbce,
+    const double *eta_PF_in, const double *U_Cor, const double *V_Cor,
+    double *accel_layer_u, double *accel_layer_v, double *eta_out,
+    double *uhbtav, double *vhbtav,
+    const double *visc_rem_u, const double *visc_rem_v,
+    const mom6x_BT_cont *BT_cont,
+    const double *taux_bot, const double *tauy_bot,
+    const double *uh0, const double *vh0, const double *u_uh0, const double *v_vh0,
+    double *etaav);
+
+/* Access to barotropic_CS state that MOM_restart registers by pointer
+ * (register_barotropic_restarts :6253: ubtav, vbtav) and that tests inspect.
+ * `which`: 0 ubtav, 1 vbtav, 2 eta_cor, 3 frhatu (3-D), 4 frhatv (3-D),
+ * 5 IDatu, 6 IDatv.  Returns a device pointer owned by the context.          */
+double *mom6x_barotropic_field(mom6x_ctx *ctx, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOM6X_H */

@@ -1,0 +1,189 @@
+"""ctypes mirror of include/mom6x.h and loader of the HIP C-ABI library.
+
+The product path has NO CPU fallback: `load_library()` raises if
+mom6_amd/lib/libmom6x.so is missing, and every compute entry point needs a GPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmom6x.so")
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class Dims(C.Structure):
+    """mom6x_dims (include/mom6x.h); MOM_hor_index.F90:14-44 extents."""
+    _fields_ = [
+        ("ni", C.c_int), ("nj", C.c_int), ("nk", C.c_int), ("halo", C.c_int),
+        ("ioff", C.c_int), ("joff", C.c_int), ("pitch", C.c_int), ("slab", C.c_int),
+        ("i_glob0", C.c_int), ("j_glob0", C.c_int), ("ni_glob", C.c_int), ("nj_glob", C.c_int),
+        ("reentrant_x", C.c_int), ("reentrant_y", C.c_int),
+    ]
+
+    @property
+    def nrows(self):
+        return self.nj + 2 * self.halo + 1
+
+    def shape2(self):
+        return (self.nrows, self.pitch)
+
+    def shape3(self, nk=None):
+        return (self.nk if nk is None else nk, self.nrows, self.pitch)
+
+    def sl(self, i0, i1, j0, j1):
+        """numpy slices [j, i] for local inclusive ranges i0..i1, j0..j1."""
+        return (slice(j0 + self.joff, j1 + self.joff + 1), slice(i0 + self.ioff, i1 + self.ioff + 1))
+
+
+def dims_init(ni, nj, nk, halo=4, ni_glob=None, nj_glob=None, i_glob0=0, j_glob0=0,
+              reentrant_x=False, reentrant_y=False):
+    """Python twin of mom6x_dims_init (tested equal to the C one)."""
+    if halo + 1 > 16:
+        raise ValueError("halo too wide")
+    d = Dims()
+    d.ni, d.nj, d.nk, d.halo = ni, nj, nk, halo
+    d.ioff = 16
+    d.joff = halo + 1
+    d.pitch = ((d.ioff + ni + halo + 15) // 16) * 16
+    d.slab = d.pitch * (nj + 2 * halo + 1)
+    d.ni_glob = ni if ni_glob is None else ni_glob
+    d.nj_glob = nj if nj_glob is None else nj_glob
+    d.i_glob0, d.j_glob0 = i_glob0, j_glob0
+    d.reentrant_x, d.reentrant_y = int(reentrant_x), int(reentrant_y)
+    return d
+
+
+class VGrid(C.Structure):
+    """mom6x_vgrid; MOM_verticalGrid.F90:25-90."""
+    _fields_ = [
+        ("g_Earth", C.c_double), ("Rho0", C.c_double), ("Angstrom_H", C.c_double),
+        ("H_subroundoff", C.c_double), ("dZ_subroundoff", C.c_double),
+        ("H_to_Z", C.c_double), ("Z_to_H", C.c_double), ("H_to_RZ", C.c_double),
+        ("RZ_to_H", C.c_double), ("Boussinesq", C.c_int),
+    ]
+
+
+def vgrid_default(g_Earth=9.80, Rho0=1035.0, Angstrom=1e-10):
+    """Defaults of verticalGridInit (MOM_verticalGrid.F90:100-230) with all US scalings = 1."""
+    gv = VGrid()
+    gv.g_Earth, gv.Rho0, gv.Angstrom_H = g_Earth, Rho0, Angstrom
+    # verticalGrid.F90:214-218: H_subroundoff = 1e-20 * max(Angstrom_H, m_to_H*1e-17)
+    gv.H_subroundoff = 1e-20 * max(Angstrom, 1e-17)
+    gv.dZ_subroundoff = 1e-20 * max(Angstrom, 1e-17)
+    gv.H_to_Z = gv.Z_to_H = 1.0
+    gv.H_to_RZ = Rho0
+    gv.RZ_to_H = 1.0 / Rho0
+    gv.Boussinesq = 1
+    return gv
+
+
+class ContinuityParams(C.Structure):
+    """mom6x_continuity_params; continuity_PPM_CS (MOM_continuity_PPM.F90:35-68)."""
+    _fields_ = [
+        ("upwind_1st", C.c_int), ("monotonic", C.c_int), ("simple_2nd", C.c_int),
+        ("tol_eta", C.c_double), ("tol_vel", C.c_double), ("CFL_limit_adjust", C.c_double),
+        ("aggress_adjust", C.c_int), ("vol_CFL", C.c_int), ("better_iter", C.c_int),
+        ("use_visc_rem_max", C.c_int), ("marginal_faces", C.c_int),
+    ]
+
+
+def continuity_params_default(nk, Angstrom=1e-10):
+    """Defaults of continuity_PPM_init (MOM_continuity_PPM.F90:2674-2754)."""
+    p = ContinuityParams()
+    p.upwind_1st = p.monotonic = p.simple_2nd = 0
+    p.tol_eta = 0.5 * nk * Angstrom
+    p.tol_vel = 3.0e8
+    p.CFL_limit_adjust = 0.5
+    p.aggress_adjust = p.vol_CFL = 0
+    p.better_iter = p.use_visc_rem_max = p.marginal_faces = 1
+    return p
+
+
+class BTCont(C.Structure):
+    """mom6x_BT_cont; BT_cont_type (MOM_variables.F90:315-350)."""
+    _names = ["FA_u_EE", "FA_u_E0", "FA_u_W0", "FA_u_WW", "uBT_WW", "uBT_EE",
+              "FA_v_NN", "FA_v_N0", "FA_v_S0", "FA_v_SS", "vBT_SS", "vBT_NN", "h_u", "h_v"]
+    _fields_ = [(n, C.c_void_p) for n in _names]
+
+
+class BarotropicParams(C.Structure):
+    """mom6x_barotropic_params; barotropic_CS (MOM_barotropic.F90:108-330)."""
+    _fields_ = [
+        ("bebt", C.c_double), ("dtbt", C.c_double), ("dt_bt_filter", C.c_double),
+        ("BT_project_velocity", C.c_int), ("Sadourny", C.c_int), ("strong_drag", C.c_int),
+        ("wt_uv_bug", C.c_int), ("use_old_coriolis_bracket_bug", C.c_int),
+        ("visc_rem_u_uh0", C.c_int), ("clip_velocity", C.c_int),
+        ("CFL_trunc", C.c_double), ("vel_underflow", C.c_double), ("G_extra", C.c_double),
+        ("BT_Coriolis_scale", C.c_double), ("maxCFL_BT_cont", C.c_double),
+        ("bound_BT_corr", C.c_int), ("BT_cont_bounds", C.c_int),
+        ("dtbt_fraction", C.c_double), ("Z_ref", C.c_double),
+    ]
+
+
+def barotropic_params_default(dtbt):
+    """Defaults read in barotropic_init (MOM_barotropic.F90:5403-5713)."""
+    p = BarotropicParams()
+    p.bebt, p.dtbt, p.dt_bt_filter = 0.1, dtbt, -0.25
+    p.BT_project_velocity = 0
+    p.Sadourny = 1
+    p.strong_drag = 0
+    p.wt_uv_bug = 1
+    p.use_old_coriolis_bracket_bug = 0
+    p.visc_rem_u_uh0 = 0
+    p.clip_velocity = 0
+    p.CFL_trunc, p.vel_underflow, p.G_extra = 0.5, 0.0, 0.0
+    p.BT_Coriolis_scale, p.maxCFL_BT_cont = 1.0, 0.25
+    p.bound_BT_corr, p.BT_cont_bounds = 0, 1
+    p.dtbt_fraction, p.Z_ref = 0.98, 0.0
+    return p
+
+
+# Metric plane indices: enum mom6x_metric
+METRICS = [
+    "mask2dT", "mask2dCu", "mask2dCv", "mask2dBu",
+    "dxT", "dyT", "IdxT", "IdyT",
+    "dxCu", "dyCu", "IdxCu", "IdyCu",
+    "dxCv", "dyCv", "IdxCv", "IdyCv",
+    "dxBu", "dyBu", "IdxBu", "IdyBu",
+    "areaT", "IareaT", "areaBu", "IareaBu",
+    "areaCu", "areaCv", "IareaCu", "IareaCv",
+    "dy_Cu", "dx_Cv", "bathyT", "CoriolisBu", "Coriolis2Bu",
+]
+G = {n: i for i, n in enumerate(METRICS)}
+G_COUNT = len(METRICS)
+
+MOM6X_OK = 0
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load the HIP C-ABI shared library.  Raises (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"mom6_amd: HIP extension {p} is missing; run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU fallback for the product path.")
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    lib.mom6x_last_error.restype = C.c_char_p
+    lib.mom6x_ctx_stream.restype = C.c_void_p
+    lib.mom6x_ctx_dims.restype = C.POINTER(Dims)
+    lib.mom6x_ctx_metrics_dev.restype = C.c_void_p
+    lib.mom6x_barotropic_field.restype = C.c_void_p
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class Mom6xError(RuntimeError):
+    pass
+
+
+def check(lib, rc):
+    if rc != MOM6X_OK:
+        msg = lib.mom6x_last_error()
+        raise Mom6xError(f"mom6x error {rc}: {msg.decode() if msg else ''}")
