@@ -173,7 +173,9 @@ def load_library(path=None):
     lib.mom6x_ctx_stream.restype = C.c_void_p
     lib.mom6x_ctx_dims.restype = C.POINTER(Dims)
     lib.mom6x_ctx_metrics_dev.restype = C.c_void_p
-    lib.mom6x_barotropic_field.restype = C.c_void_p
+    for name in ("mom6x_barotropic_field", "mom6x_rk2_field"):
+        if hasattr(lib, name):
+            getattr(lib, name).restype = C.c_void_p
     if path is None:
         _lib = lib
     return lib

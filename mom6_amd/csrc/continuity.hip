@@ -1,0 +1,491 @@
+// continuity.hip -- PPM layer continuity with barotropic flux reconciliation on gfx950.
+//
+// Replaces continuity_PPM and its callees (MOM_continuity_PPM.F90:86-2657).  The zonal and
+// meridional halves of the reference are mirror images; one templated kernel set handles both
+// with DIR = 0 (faces between cell f and f+1) or DIR = 1 (faces between f and f+pitch).  In
+// both directions the lane index is i, so every access is coalesced along the contiguous axis.
+//
+// Kernels (all FP64, HBM-bandwidth bound):
+//   k_edge<DIR>        PPM_reconstruction_x/y + PPM_limit_pos/CW84   (3-D, one thread per cell)
+//   k_mass_flux<DIR>   zonal/meridional_mass_flux incl. flux_adjust Newton iteration and
+//                      set_*_BT_cont                                  (2-D, one thread per face
+//                      column; the k loops are walked sequentially in the reference's order so
+//                      the column sums are bit-identical to the Fortran loop nests)
+//   k_flux_thickness<DIR>  zonal/merid_flux_thickness                 (3-D)
+//   k_convergence<DIR> continuity_zonal/merdional_convergence         (3-D)
+#include "mom6x_dev.h"
+
+namespace {
+
+struct DirMetrics {
+  const double *Lface, *IdT, *dT, *dC, *maskC, *IareaT, *mask2dT;
+};
+
+template <int DIR>
+__device__ __forceinline__ DirMetrics dir_metrics(const double *G, const Dm &d) {
+  DirMetrics D;
+  D.Lface = gm(G, d, DIR ? MOM6X_G_dx_Cv : MOM6X_G_dy_Cu);
+  D.IdT = gm(G, d, DIR ? MOM6X_G_IdyT : MOM6X_G_IdxT);
+  D.dT = gm(G, d, DIR ? MOM6X_G_dyT : MOM6X_G_dxT);
+  D.dC = gm(G, d, DIR ? MOM6X_G_dyCv : MOM6X_G_dxCu);
+  D.maskC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu);
+  D.IareaT = gm(G, d, MOM6X_G_IareaT);
+  D.mask2dT = gm(G, d, MOM6X_G_mask2dT);
+  return D;
+}
+
+// PPM_limit_pos :2578-2616
+__device__ __forceinline__ void ppm_limit_pos(double h_in, double &h_L, double &h_R, double h_min) {
+  const double curv = 3.0 * ((h_L + h_R) - 2.0 * h_in);
+  if (curv > 0.0) {
+    const double dh = h_R - h_L;
+    if (fabs(dh) < curv) {
+      if (h_in <= h_min) {
+        h_L = h_in; h_R = h_in;
+      } else if (12.0 * curv * (h_in - h_min) < (curv * curv + 3.0 * (dh * dh))) {
+        const double scale = 12.0 * curv * (h_in - h_min) / (curv * curv + 3.0 * (dh * dh));
+        h_L = h_in + scale * (h_L - h_in);
+        h_R = h_in + scale * (h_R - h_in);
+      }
+    }
+  }
+}
+
+// PPM_limit_CW84 :2620-2657
+__device__ __forceinline__ void ppm_limit_cw84(double h_i, double &h_L, double &h_R) {
+  if ((h_R - h_i) * (h_i - h_L) <= 0.0) {
+    h_L = h_i; h_R = h_i;
+  } else {
+    const double RLdiff = h_R - h_L;
+    const double RLmean = 0.5 * (h_R + h_L);
+    const double FunFac = 6.0 * RLdiff * (h_i - RLmean);
+    const double RLdiff2 = RLdiff * RLdiff;
+    if (FunFac > RLdiff2) h_L = 3.0 * h_i - 2.0 * h_R;
+    if (FunFac < -RLdiff2) h_R = 3.0 * h_i - 2.0 * h_L;
+  }
+}
+
+// Lin (1994) B2 limited slope at cell c (:2368-2378)
+__device__ __forceinline__ double ppm_slope(const double *h, const double *m, size_t c, int st) {
+  const double hm = h[c - st], h0 = h[c], hp = h[c + st];
+  if ((m[c - st] * m[c] * m[c + st]) == 0.0) return 0.0;
+  const double s = 0.5 * (hp - hm);
+  const double dMx = dmax(dmax(hp, hm), h0) - h0;
+  const double dMn = h0 - dmin(dmin(hp, hm), h0);
+  return dsign(1.0, s) * dmin(fabs(s), 2.0 * dmin(dMx, dMn));
+}
+
+// PPM_reconstruction_x :2307 / _y :2442 over cells (i0..i1, j0..j1) of every layer.
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_edge(Dm d, const double *__restrict__ G, const double *__restrict__ h_in, double *__restrict__ h_L,
+       double *__restrict__ h_R, double h_min, int scheme /*0 ppm,1 simple_2nd,2 upwind*/, int monotonic,
+       int i0, int i1, int j0, int j1) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > i1 || j > j1) return;
+  const int st = DIR ? d.pitch : 1;
+  const double *m = gm(G, d, MOM6X_G_mask2dT);
+  const size_t c2 = ix2(d, i, j);
+  const double *h = h_in + (size_t)k * d.slab;
+  const size_t c = c2 + (size_t)k * d.slab;
+  const double h0 = h[c2];
+  double hl, hr;
+  if (scheme == 2) {
+    hl = h0; hr = h0;
+    h_L[c] = hl; h_R[c] = hr;
+    return;
+  }
+  const double mm = m[c2 - st], mp = m[c2 + st];
+  const double h_im1 = mm * h[c2 - st] + (1.0 - mm) * h0;
+  const double h_ip1 = mp * h[c2 + st] + (1.0 - mp) * h0;
+  if (scheme == 1) {
+    hl = 0.5 * (h_im1 + h0);
+    hr = 0.5 * (h_ip1 + h0);
+  } else {
+    const double oneSixth = 1.0 / 6.0;
+    const double sm = ppm_slope(h, m, c2 - st, st);
+    const double s0 = ppm_slope(h, m, c2, st);
+    const double sp = ppm_slope(h, m, c2 + st, st);
+    hl = 0.5 * (h_im1 + h0) + oneSixth * (sm - s0);
+    hr = 0.5 * (h_ip1 + h0) + oneSixth * (s0 - sp);
+  }
+  if (monotonic) ppm_limit_cw84(h0, hl, hr);
+  else ppm_limit_pos(h0, hl, hr, h_min);
+  h_L[c] = hl; h_R[c] = hr;
+}
+
+// zonal_flux_layer :896 / merid_flux_layer :1787 for one face of one layer.
+// f = flat 3-D index of the face (= its minus cell), f2 = its 2-D index.
+__device__ __forceinline__ void flux_layer(const DirMetrics &D, int st, size_t f, size_t f2, double u,
+                                           const double *__restrict__ h, const double *__restrict__ hL,
+                                           const double *__restrict__ hR, double dt, double visc_rem,
+                                           double Lf, double &uh, double &duhdu) {
+  double h_marg;
+  if (u > 0.0) {
+    const double CFL = u * dt * D.IdT[f2];
+    const double l = hL[f], r = hR[f];
+    const double curv_3 = (l + r) - 2.0 * h[f];
+    uh = Lf * u * (r + CFL * (0.5 * (l - r) + curv_3 * (CFL - 1.5)));
+    h_marg = r + CFL * ((l - r) + 3.0 * curv_3 * (CFL - 1.0));
+  } else if (u < 0.0) {
+    const size_t p = f + st;
+    const double CFL = -u * dt * D.IdT[f2 + st];
+    const double l = hL[p], r = hR[p];
+    const double curv_3 = (l + r) - 2.0 * h[p];
+    uh = Lf * u * (l + CFL * (0.5 * (r - l) + curv_3 * (CFL - 1.5)));
+    h_marg = l + CFL * ((r - l) + 3.0 * curv_3 * (CFL - 1.0));
+  } else {
+    uh = 0.0;
+    h_marg = 0.5 * (hL[f + st] + hR[f]);
+  }
+  duhdu = Lf * h_marg * visc_rem;
+}
+
+struct ColIn {   // everything a face column needs
+  const double *u, *h, *hL, *hR, *vr;   // vr may be null (visc_rem == 1)
+  double dt;
+  int nk; size_t slab;
+};
+
+// zonal_flux_adjust :1093-1242 / meridional_flux_adjust :1992-2140 for ONE face column.
+// The reference iterates a whole row with a row-wide `domore`, but a face whose do_I is false is
+// frozen, so iterating each face until its own do_I clears gives identical results.
+// If uh_store != nullptr the layer transports are (re)written there (uh_3d present).
+template <int DIR>
+__device__ double flux_adjust(const DirMetrics &D, int st, const ColIn &C, size_t f2, double Lf,
+                              double uhbt, double uh_tot_0, double duhdu_tot_0, double du_max_CFL,
+                              double du_min_CFL, double tol_eta_cs, double tol_vel, int better_iter,
+                              bool do_I, double *uh_store) {
+  const int max_itts = 20;
+  double du = 0.0, du_max = du_max_CFL, du_min = du_min_CFL;
+  double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0;
+  double uh_err_best = fabs(uh_err);
+  const double IareaMin = dmin(D.IareaT[f2], D.IareaT[f2 + st]);
+  for (int itt = 1; itt <= max_itts; itt++) {
+    double tol_eta;
+    if (itt <= 1) tol_eta = 1e-6 * tol_eta_cs;
+    else if (itt == 2) tol_eta = 1e-4 * tol_eta_cs;
+    else if (itt == 3) tol_eta = 1e-2 * tol_eta_cs;
+    else tol_eta = tol_eta_cs;
+
+    if (uh_err > 0.0) du_max = du;
+    else if (uh_err < 0.0) du_min = du;
+    else do_I = false;
+
+    if (do_I) {
+      if ((C.dt * IareaMin * fabs(uh_err) > tol_eta) ||
+          (better_iter && ((fabs(uh_err) > tol_vel * duhdu_tot) || (fabs(uh_err) > uh_err_best)))) {
+        const double ddu = -uh_err / duhdu_tot;
+        const double du_prev = du;
+        du = du + ddu;
+        if (fabs(ddu) < 1.0e-15 * fabs(du)) {
+          do_I = false;
+        } else if (ddu > 0.0) {
+          if (du >= du_max) {
+            du = 0.5 * (du_prev + du_max);
+            if (du_max - du_prev < 1.0e-15 * fabs(du)) do_I = false;
+          }
+        } else {
+          if (du <= du_min) {
+            du = 0.5 * (du_prev + du_min);
+            if (du_prev - du_min < 1.0e-15 * fabs(du)) do_I = false;
+          }
+        }
+      } else {
+        do_I = false;
+      }
+    }
+    if (!do_I) break;
+
+    if ((itt < max_itts) || uh_store) {
+      double err = -uhbt, dtot = 0.0;
+      for (int k = 0; k < C.nk; k++) {
+        const size_t f = f2 + (size_t)k * C.slab;
+        const double vrem = C.vr ? C.vr[f] : 1.0;
+        const double u_new = C.u[f] + du * vrem;
+        double uh, duhdu;
+        flux_layer(D, st, f, f2, u_new, C.h, C.hL, C.hR, C.dt, vrem, Lf, uh, duhdu);
+        if (uh_store) uh_store[f] = uh;
+        err = err + uh;
+        dtot = dtot + duhdu;
+      }
+      if (itt < max_itts) {
+        uh_err = err; duhdu_tot = dtot;
+        uh_err_best = dmin(uh_err_best, fabs(uh_err));
+      }
+    }
+  }
+  return du;
+}
+
+struct FluxArgs {
+  const double *u, *h_in, *hL, *hR;
+  double *uh;
+  const double *uhbt;        // 2-D or null
+  const double *visc_rem;    // 3-D or null
+  double *u_cor;             // 3-D or null
+  double *du_cor;            // 2-D or null
+  // BT_cont planes for this direction ("m" = from the minus side: W|S, "p" = plus side: E|N)
+  double *FA_m0, *FA_mm, *uBT_mm, *FA_p0, *FA_pp, *uBT_pp;
+  int set_BT_cont;
+  double dt, CFL_limit_adjust, tol_eta, tol_vel;
+  int better_iter, use_visc_rem_max;
+  int a0, a1, b0, b1;        // face index ranges (i-range, j-range)
+};
+
+// zonal_mass_flux :519-819 / meridional_mass_flux :1412-1711: one thread per face column.
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_mass_flux(Dm d, const double *__restrict__ G, FluxArgs A) {
+  const int i = A.a0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = A.b0 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > A.a1 || j > A.b1) return;
+  const int st = DIR ? d.pitch : 1;
+  const DirMetrics D = dir_metrics<DIR>(G, d);
+  const size_t f2 = ix2(d, i, j);
+  const size_t slab = (size_t)d.slab;
+  const int nk = d.nk;
+  const double dt = A.dt;
+  const double Lf = D.Lface[f2] * 1.0;   // G%dy_Cu * por_face_areaU (== 1)
+  ColIn C; C.u = A.u; C.h = A.h_in; C.hL = A.hL; C.hR = A.hR; C.vr = A.visc_rem; C.dt = dt; C.nk = nk; C.slab = slab;
+  const bool use_visc_rem = (A.visc_rem != nullptr);
+  const bool need_adjust = (A.uhbt != nullptr) || A.set_BT_cont;
+  const double CFL_dt = A.CFL_limit_adjust / dt;
+
+  // First sweep: layer transports and the column sums (:615-668)
+  double duhdu_tot_0 = 0.0, uh_tot_0 = 0.0, visc_rem_max = 0.0;
+  const double dx_W = D.dT[f2], dx_E = D.dT[f2 + st];
+  for (int k = 0; k < nk; k++) {
+    const size_t f = f2 + (size_t)k * slab;
+    const double vrem = use_visc_rem ? A.visc_rem[f] : 1.0;
+    double uh, duhdu;
+    flux_layer(D, st, f, f2, A.u[f], A.h_in, A.hL, A.hR, dt, vrem, Lf, uh, duhdu);
+    A.uh[f] = uh;
+    duhdu_tot_0 = duhdu_tot_0 + duhdu;
+    uh_tot_0 = uh_tot_0 + uh;
+    visc_rem_max = dmax(visc_rem_max, vrem);
+  }
+  if (!need_adjust) return;
+  if (!(use_visc_rem && A.use_visc_rem_max)) visc_rem_max = 1.0;
+
+  // Limits on du that keep the CFL number between -1 and 1 (:646-723)
+  double I_vrm = 0.0;
+  if (visc_rem_max > 0.0) I_vrm = 1.0 / visc_rem_max;
+  double du_max_CFL = 2.0 * (CFL_dt * dx_W) * I_vrm;
+  double du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
+  const double maskC = D.maskC[f2];
+  if (use_visc_rem) {
+    for (int k = 0; k < nk; k++) {
+      const size_t f = f2 + (size_t)k * slab;
+      const double uk = A.u[f], vrem = A.visc_rem[f];
+      if (du_max_CFL * vrem > dx_W * CFL_dt - uk * maskC) du_max_CFL = (dx_W * CFL_dt - uk) / vrem;
+      if (du_min_CFL * vrem < -dx_E * CFL_dt - uk * maskC) du_min_CFL = -(dx_E * CFL_dt + uk) / vrem;
+    }
+  } else {
+    for (int k = 0; k < nk; k++) {
+      const double uk = A.u[f2 + (size_t)k * slab];
+      du_max_CFL = dmin(du_max_CFL, dx_W * CFL_dt - uk);
+      du_min_CFL = dmax(du_min_CFL, -(dx_E * CFL_dt + uk));
+    }
+  }
+  du_max_CFL = dmax(du_max_CFL, 0.0);
+  du_min_CFL = dmin(du_min_CFL, 0.0);
+
+  if (A.uhbt) {
+    const double du = flux_adjust<DIR>(D, st, C, f2, Lf, A.uhbt[f2], uh_tot_0, duhdu_tot_0, du_max_CFL,
+                                       du_min_CFL, A.tol_eta, A.tol_vel, A.better_iter, true, A.uh);
+    if (A.u_cor) {
+      for (int k = 0; k < nk; k++) {
+        const size_t f = f2 + (size_t)k * slab;
+        const double vrem = use_visc_rem ? A.visc_rem[f] : 1.0;
+        A.u_cor[f] = A.u[f] + du * vrem;
+      }
+    }
+    if (A.du_cor) A.du_cor[f2] = du;
+  }
+
+  if (A.set_BT_cont) {   // set_zonal_BT_cont :1246-1409 / set_merid_BT_cont :2143-2304
+    const double Idt = 1.0 / dt, min_visc_rem = 0.1, CFL_min = 1e-6;
+    const double du0 = flux_adjust<DIR>(D, st, C, f2, Lf, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
+                                        A.tol_eta, A.tol_vel, A.better_iter, true, nullptr);
+    const double du_CFL = (CFL_min * Idt) * D.dC[f2];
+    double duR = dmin(0.0, du0 - du_CFL);
+    double duL = dmax(0.0, du0 + du_CFL);
+    for (int k = 0; k < nk; k++) {
+      const size_t f = f2 + (size_t)k * slab;
+      const double vrem = use_visc_rem ? A.visc_rem[f] : 1.0, uk = A.u[f];
+      const double visc_rem_lim = dmax(vrem, min_visc_rem * visc_rem_max);
+      if (visc_rem_lim > 0.0) {
+        if (uk + duR * visc_rem_lim > -du_CFL * vrem) duR = -(uk + du_CFL * vrem) / visc_rem_lim;
+        if (uk + duL * visc_rem_lim < du_CFL * vrem) duL = -(uk - du_CFL * vrem) / visc_rem_lim;
+      }
+    }
+    double FAmt_L = 0.0, FAmt_R = 0.0, FAmt_0 = 0.0, uhtot_L = 0.0, uhtot_R = 0.0;
+    for (int k = 0; k < nk; k++) {
+      const size_t f = f2 + (size_t)k * slab;
+      const double vrem = use_visc_rem ? A.visc_rem[f] : 1.0, uk = A.u[f];
+      const double u_L = uk + duL * vrem, u_R = uk + duR * vrem, u_0 = uk + du0 * vrem;
+      double uh_0, uh_L, uh_R, d_0, d_L, d_R;
+      flux_layer(D, st, f, f2, u_0, A.h_in, A.hL, A.hR, dt, vrem, Lf, uh_0, d_0);
+      flux_layer(D, st, f, f2, u_L, A.h_in, A.hL, A.hR, dt, vrem, Lf, uh_L, d_L);
+      flux_layer(D, st, f, f2, u_R, A.h_in, A.hL, A.hR, dt, vrem, Lf, uh_R, d_R);
+      FAmt_0 = FAmt_0 + d_0; FAmt_L = FAmt_L + d_L; FAmt_R = FAmt_R + d_R;
+      uhtot_L = uhtot_L + uh_L; uhtot_R = uhtot_R + uh_R;
+    }
+    double FA_0 = FAmt_0, FA_avg = FAmt_0;
+    if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
+    if (FA_avg > dmax(FA_0, FAmt_L)) FA_avg = dmax(FA_0, FAmt_L);
+    else if (FA_avg < dmin(FA_0, FAmt_L)) FA_0 = FA_avg;
+    A.FA_m0[f2] = FA_0; A.FA_mm[f2] = FAmt_L;
+    if (fabs(FA_0 - FAmt_L) <= 1e-12 * FA_0) A.uBT_mm[f2] = 0.0;
+    else A.uBT_mm[f2] = (1.5 * (duL - du0)) * ((FAmt_L - FA_avg) / (FAmt_L - FA_0));
+
+    FA_0 = FAmt_0; FA_avg = FAmt_0;
+    if ((duR - du0) != 0.0) FA_avg = uhtot_R / (duR - du0);
+    if (FA_avg > dmax(FA_0, FAmt_R)) FA_avg = dmax(FA_0, FAmt_R);
+    else if (FA_avg < dmin(FA_0, FAmt_R)) FA_0 = FA_avg;
+    A.FA_p0[f2] = FA_0; A.FA_pp[f2] = FAmt_R;
+    if (fabs(FAmt_R - FA_0) <= 1e-12 * FA_0) A.uBT_pp[f2] = 0.0;
+    else A.uBT_pp[f2] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
+  }
+}
+
+// zonal_flux_thickness :975-1089 / merid_flux_thickness :1866-1988
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_flux_thickness(Dm d, const double *__restrict__ G, const double *__restrict__ u,
+                 const double *__restrict__ h, const double *__restrict__ hL,
+                 const double *__restrict__ hR, double *__restrict__ h_u, double dt, int marginal,
+                 const double *__restrict__ visc_rem, int a0, int a1, int b0, int b1) {
+  const int i = a0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = b0 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > a1 || j > b1) return;
+  const int st = DIR ? d.pitch : 1;
+  const double *IdT = gm(G, d, DIR ? MOM6X_G_IdyT : MOM6X_G_IdxT);
+  const size_t f2 = ix2(d, i, j), f = f2 + (size_t)k * d.slab, p = f + st;
+  const double uf = u[f];
+  double h_avg, h_marg;
+  if (uf > 0.0) {
+    const double CFL = uf * dt * IdT[f2];
+    const double curv_3 = (hL[f] + hR[f]) - 2.0 * h[f];
+    h_avg = hR[f] + CFL * (0.5 * (hL[f] - hR[f]) + curv_3 * (CFL - 1.5));
+    h_marg = hR[f] + CFL * ((hL[f] - hR[f]) + 3.0 * curv_3 * (CFL - 1.0));
+  } else if (uf < 0.0) {
+    const double CFL = -uf * dt * IdT[f2 + st];
+    const double curv_3 = (hL[p] + hR[p]) - 2.0 * h[p];
+    h_avg = hL[p] + CFL * (0.5 * (hR[p] - hL[p]) + curv_3 * (CFL - 1.5));
+    h_marg = hL[p] + CFL * ((hR[p] - hL[p]) + 3.0 * curv_3 * (CFL - 1.0));
+  } else {
+    h_avg = 0.5 * (hL[p] + hR[f]);
+    h_marg = 0.5 * (hL[p] + hR[f]);
+  }
+  double hu = marginal ? h_marg : h_avg;
+  if (visc_rem) hu = hu * (visc_rem[f] * 1.0);
+  else hu = hu * 1.0;
+  h_u[f] = hu;
+}
+
+// continuity_zonal_convergence :348 / continuity_merdional_convergence :386
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_convergence(Dm d, const double *__restrict__ G, double *h, const double *__restrict__ uh, double dt,
+              const double *hin, double h_min, int i0, int i1, int j0, int j1) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > i1 || j > j1) return;
+  const int st = DIR ? d.pitch : 1;
+  const size_t c2 = ix2(d, i, j), c = c2 + (size_t)k * d.slab;
+  const double IareaT = gm(G, d, MOM6X_G_IareaT)[c2];
+  h[c] = dmax(hin[c] - dt * IareaT * (uh[c] - uh[c - st]), h_min);
+}
+
+template <int DIR>
+int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h, double *uh, double dt,
+                  int ish, int ieh, int jsh, int jeh, const double *uhbt, const double *visc_rem,
+                  double *u_cor, const mom6x_BT_cont *BT, double *du_cor, const double *hin_conv,
+                  double h_min_conv) {
+  const Dm d = c->d;
+  const mom6x_continuity_params &P = c->cont;
+  const dim3 blk(64, 4, 1);
+  // edge thicknesses: one cell beyond the LB bounds in the sweep direction
+  int ei0 = ish, ei1 = ieh, ej0 = jsh, ej1 = jeh;
+  if (DIR == 0) { ei0 = ish - 1; ei1 = ieh + 1; } else { ej0 = jsh - 1; ej1 = jeh + 1; }
+  const int scheme = P.upwind_1st ? 2 : (P.simple_2nd ? 1 : 0);
+  hipLaunchKernelGGL(k_edge<DIR>, grid3(ei1 - ei0 + 1, ej1 - ej0 + 1, d.nk, blk), blk, 0, c->stream, d, c->G, h_src,
+                     c->hL, c->hR, 2.0 * c->GV.Angstrom_H, scheme, P.monotonic, ei0, ei1, ej0, ej1);
+  FluxArgs A;
+  memset(&A, 0, sizeof(A));
+  A.u = u; A.h_in = h_src; A.hL = c->hL; A.hR = c->hR; A.uh = uh; A.uhbt = uhbt; A.visc_rem = visc_rem;
+  A.u_cor = u_cor; A.du_cor = du_cor; A.set_BT_cont = (BT != nullptr);
+  if (BT) {
+    if (DIR == 0) { A.FA_m0 = BT->FA_u_W0; A.FA_mm = BT->FA_u_WW; A.uBT_mm = BT->uBT_WW;
+                    A.FA_p0 = BT->FA_u_E0; A.FA_pp = BT->FA_u_EE; A.uBT_pp = BT->uBT_EE; }
+    else          { A.FA_m0 = BT->FA_v_S0; A.FA_mm = BT->FA_v_SS; A.uBT_mm = BT->vBT_SS;
+                    A.FA_p0 = BT->FA_v_N0; A.FA_pp = BT->FA_v_NN; A.uBT_pp = BT->vBT_NN; }
+  }
+  A.dt = dt; A.CFL_limit_adjust = P.CFL_limit_adjust; A.tol_eta = P.tol_eta; A.tol_vel = P.tol_vel;
+  A.better_iter = P.better_iter; A.use_visc_rem_max = P.use_visc_rem_max;
+  if (DIR == 0) { A.a0 = ish - 1; A.a1 = ieh; A.b0 = jsh; A.b1 = jeh; }
+  else          { A.a0 = ish; A.a1 = ieh; A.b0 = jsh - 1; A.b1 = jeh; }
+  if (du_cor) HIPCHK(hipMemsetAsync(du_cor, 0, sizeof(double) * d.slab, c->stream));
+  hipLaunchKernelGGL(k_mass_flux<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, 1, blk), blk, 0, c->stream, d, c->G, A);
+  double *BT_h = BT ? (DIR == 0 ? BT->h_u : BT->h_v) : nullptr;
+  if (BT_h) {
+    hipLaunchKernelGGL(k_flux_thickness<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, d.nk, blk), blk, 0, c->stream,
+                       d, c->G, (u_cor ? (const double *)u_cor : u), h_src, c->hL, c->hR, BT_h, dt,
+                       P.marginal_faces, visc_rem, A.a0, A.a1, A.b0, A.b1);
+  }
+  hipLaunchKernelGGL(k_convergence<DIR>, grid3(ieh - ish + 1, jeh - jsh + 1, d.nk, blk), blk, 0, c->stream, d, c->G,
+                     h, uh, dt, hin_conv, h_min_conv, ish, ieh, jsh, jeh);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+}  // namespace
+
+extern "C" int mom6x_continuity_init(mom6x_ctx *c, const mom6x_continuity_params *p) {
+  REQUIRE(c && p, MOM6X_EINVAL, "mom6x_continuity_init: null argument");
+  REQUIRE(!p->aggress_adjust && !p->vol_CFL, MOM6X_EUNSUPPORTED,
+          "continuity_PPM: CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL are not supported");
+  c->cont = *p;
+  c->cont_init = true;
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_continuity_PPM(mom6x_ctx *c, const double *u, const double *v, const double *hin,
+                                    double *h, double *uh, double *vh, double dt, const double *uhbt,
+                                    const double *vhbt, const double *visc_rem_u, const double *visc_rem_v,
+                                    double *u_cor, double *v_cor, const mom6x_BT_cont *BT, double *du_cor,
+                                    double *dv_cor) {
+  REQUIRE(c && c->cont_init, MOM6X_EINVAL,
+          "MOM_continuity_PPM: Module must be initialized before it is used.");
+  REQUIRE(u && v && hin && h && uh && vh, MOM6X_EINVAL, "continuity_PPM: null mandatory array");
+  REQUIRE((visc_rem_u != nullptr) == (visc_rem_v != nullptr), MOM6X_EINVAL,
+          "MOM_continuity_PPM: Either both visc_rem_u and visc_rem_v or neither one must be present "
+          "in call to continuity_PPM.");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  const mom6x_continuity_params &P = c->cont;
+  const double h_min = c->GV.Angstrom_H;
+  int stencil = 3; if (P.simple_2nd) stencil = 2; if (P.upwind_1st) stencil = 1;
+  REQUIRE(d.halo >= stencil, MOM6X_EINVAL, "continuity_PPM: halo smaller than the continuity stencil");
+  const bool x_first = ((c->first_direction % 2) == 0);
+  const int is = 0, ie = d.ni - 1, js = 0, je = d.nj - 1;
+  int rc;
+  if (x_first) {
+    rc = run_direction<0>(c, u, hin, h, uh, dt, is, ie, js - stencil, je + stencil, uhbt, visc_rem_u, u_cor, BT,
+                          du_cor, hin, 0.0);
+    if (rc) return rc;
+    rc = run_direction<1>(c, v, h, h, vh, dt, is, ie, js, je, vhbt, visc_rem_v, v_cor, BT, dv_cor, h, h_min);
+  } else {
+    rc = run_direction<1>(c, v, hin, h, vh, dt, is - stencil, ie + stencil, js, je, vhbt, visc_rem_v, v_cor, BT,
+                          dv_cor, hin, 0.0);
+    if (rc) return rc;
+    rc = run_direction<0>(c, u, h, h, uh, dt, is, ie, js, je, uhbt, visc_rem_u, u_cor, BT, du_cor, h, h_min);
+  }
+  return rc;
+}

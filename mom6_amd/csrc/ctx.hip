@@ -1,0 +1,151 @@
+// ctx.hip -- context, layout and host<->device transfer entry points of the C ABI.
+#include <cstdarg>
+#include <vector>
+#include "mom6x_dev.h"
+
+static thread_local char g_err[512] = "";
+
+void mom6x_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *mom6x_last_error(void) { return g_err; }
+extern "C" int mom6x_abi_version(void) { return MOM6X_ABI_VERSION; }
+
+extern "C" int mom6x_dims_init(mom6x_dims *d, int ni, int nj, int nk, int halo) {
+  REQUIRE(d && ni > 0 && nj > 0 && nk > 0, MOM6X_EINVAL, "mom6x_dims_init: bad sizes");
+  REQUIRE(halo >= 1 && halo + 1 <= 16, MOM6X_EINVAL, "mom6x_dims_init: halo must be in 1..15");
+  d->ni = ni; d->nj = nj; d->nk = nk; d->halo = halo;
+  d->ioff = 16;               // local i = 0 starts a 128-byte line
+  d->joff = halo + 1;
+  d->pitch = ((d->ioff + ni + halo + 15) / 16) * 16;
+  d->slab = d->pitch * (nj + 2 * halo + 1);
+  d->i_glob0 = 0; d->j_glob0 = 0; d->ni_glob = ni; d->nj_glob = nj;
+  d->reentrant_x = 0; d->reentrant_y = 0;
+  return MOM6X_OK;
+}
+
+void bt_state_free(mom6x_ctx *ctx);   // barotropic.hip
+void rk2_state_free(mom6x_ctx *ctx);  // dyn_split_RK2.hip
+
+extern "C" int mom6x_ctx_create(mom6x_ctx **out, const mom6x_dims *dims, int device,
+                                const double *metrics_host, const mom6x_vgrid *GV,
+                                int first_direction) {
+  REQUIRE(out && dims && metrics_host && GV, MOM6X_EINVAL, "mom6x_ctx_create: null argument");
+  REQUIRE(dims->halo >= 3, MOM6X_EINVAL, "mom6x_ctx_create: halo >= 3 is required by continuity_PPM");
+  REQUIRE(dims->ioff >= dims->halo + 1 && dims->joff >= dims->halo + 1 &&
+          dims->pitch >= dims->ioff + dims->ni + dims->halo &&
+          dims->slab == dims->pitch * (dims->nj + 2 * dims->halo + 1),
+          MOM6X_EINVAL, "mom6x_ctx_create: inconsistent layout in dims");
+  REQUIRE(GV->Boussinesq == 1, MOM6X_EUNSUPPORTED, "mom6x: only BOUSSINESQ=True is supported");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  REQUIRE(ndev > 0 && device >= 0 && device < ndev, MOM6X_EHIP,
+          "mom6x_ctx_create: no such HIP device (the product path has no CPU fallback)");
+  HIPCHK(hipSetDevice(device));
+  mom6x_ctx *c = new mom6x_ctx();
+  c->dims = *dims;
+  c->d = make_dm(*dims);
+  c->device = device;
+  c->GV = *GV;
+  c->first_direction = first_direction;
+  c->cont_init = false; c->bt_init = false;
+  c->hL = c->hR = nullptr; c->bts = nullptr; c->rk2 = nullptr; c->flag = nullptr; c->G = nullptr;
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
+  size_t nG = (size_t)MOM6X_G_COUNT * dims->slab;
+  HIPCHK(hipMalloc(&c->G, nG * sizeof(double)));
+  HIPCHK(hipMemcpy(c->G, metrics_host, nG * sizeof(double), hipMemcpyHostToDevice));
+  size_t n3 = (size_t)dims->slab * dims->nk;
+  HIPCHK(hipMalloc(&c->hL, n3 * sizeof(double)));
+  HIPCHK(hipMalloc(&c->hR, n3 * sizeof(double)));
+  HIPCHK(hipMemset(c->hL, 0, n3 * sizeof(double)));
+  HIPCHK(hipMemset(c->hR, 0, n3 * sizeof(double)));
+  HIPCHK(hipMalloc(&c->flag, sizeof(int)));
+  HIPCHK(hipMemset(c->flag, 0, sizeof(int)));
+  *out = c;
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
+  if (!c) return MOM6X_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  hipStreamSynchronize(c->halo_stream);
+  bt_state_free(c);
+  rk2_state_free(c);
+  hipFree(c->G); hipFree(c->hL); hipFree(c->hR); hipFree(c->flag);
+  hipStreamDestroy(c->stream); hipStreamDestroy(c->halo_stream);
+  delete c;
+  return MOM6X_OK;
+}
+
+extern "C" void *mom6x_ctx_stream(mom6x_ctx *c) { return (void *)c->stream; }
+extern "C" const mom6x_dims *mom6x_ctx_dims(const mom6x_ctx *c) { return &c->dims; }
+extern "C" const double *mom6x_ctx_metrics_dev(const mom6x_ctx *c) { return c->G; }
+
+extern "C" int mom6x_ctx_sync(mom6x_ctx *c) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(c->halo_stream));
+  int flag = 0;
+  HIPCHK(hipMemcpy(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) {
+    HIPCHK(hipMemset(c->flag, 0, sizeof(int)));
+    mom6x_set_error("device-side numeric error flag = %d (NaN or negative thickness)", flag);
+    return MOM6X_ENUMERIC;
+  }
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_dev_alloc(mom6x_ctx *c, double **p, size_t n) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMalloc(p, n * sizeof(double)));
+  HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(double), c->stream));
+  return MOM6X_OK;
+}
+extern "C" int mom6x_dev_free(mom6x_ctx *c, double *p) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipFree(p));
+  return MOM6X_OK;
+}
+
+// Fortran symmetric-memory extents of the four staggerings (MOM_memory_macros.h, dynamic
+// symmetric branch): h (isd:ied, jsd:jed), u (isd-1:ied, jsd:jed), v (isd:ied, jsd-1:jed),
+// q (isd-1:ied, jsd-1:jed).
+static void f_extent(const mom6x_dims &d, int stagger, int &nx, int &ny, int &i0, int &j0) {
+  const int xB = (stagger == 1 || stagger == 3), yB = (stagger == 2 || stagger == 3);
+  nx = d.ni + 2 * d.halo + xB; ny = d.nj + 2 * d.halo + yB;
+  i0 = -d.halo - xB; j0 = -d.halo - yB;
+}
+
+static int xfer(mom6x_ctx *c, double *dev, double *host, int stagger, int nk, bool up) {
+  REQUIRE(stagger >= 0 && stagger <= 3 && nk >= 1, MOM6X_EINVAL, "mom6x_upload/download: bad stagger or nk");
+  HIPCHK(hipSetDevice(c->device));
+  const mom6x_dims &d = c->dims;
+  int nx, ny, i0, j0;
+  f_extent(d, stagger, nx, ny, i0, j0);
+  const int nrows = d.nj + 2 * d.halo + 1;
+  hipMemcpy3DParms p;
+  memset(&p, 0, sizeof(p));
+  hipPitchedPtr hp = make_hipPitchedPtr(host, (size_t)nx * sizeof(double), nx, ny);
+  hipPitchedPtr dp = make_hipPitchedPtr(dev, (size_t)d.pitch * sizeof(double), d.pitch, nrows);
+  hipPos hpos = make_hipPos(0, 0, 0);
+  hipPos dpos = make_hipPos((size_t)(i0 + d.ioff) * sizeof(double), (size_t)(j0 + d.joff), 0);
+  if (up) { p.srcPtr = hp; p.srcPos = hpos; p.dstPtr = dp; p.dstPos = dpos; p.kind = hipMemcpyHostToDevice; }
+  else    { p.srcPtr = dp; p.srcPos = dpos; p.dstPtr = hp; p.dstPos = hpos; p.kind = hipMemcpyDeviceToHost; }
+  p.extent = make_hipExtent((size_t)nx * sizeof(double), ny, nk);
+  HIPCHK(hipMemcpy3DAsync(&p, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_upload(mom6x_ctx *c, double *dev, const double *host_f, int stagger, int nk) {
+  return xfer(c, dev, const_cast<double *>(host_f), stagger, nk, true);
+}
+extern "C" int mom6x_download(mom6x_ctx *c, double *host_f, const double *dev, int stagger, int nk) {
+  return xfer(c, const_cast<double *>(dev), host_f, stagger, nk, false);
+}

@@ -1,0 +1,77 @@
+// mom6x_dev.h -- device-side helpers shared by all HIP kernels of the dycore (gfx950 only).
+//
+// Layout: see include/mom6x.h.  Every kernel gets the tile dims by value (`Dm`), a pointer to
+// the metric block and plain FP64 device pointers.  i is the coalesced (lane) index in every
+// kernel, exactly as the reference's inner `do i` loops; columns (k) are walked per thread.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "../../include/mom6x.h"
+
+struct Dm {            // device copy of the layout part of mom6x_dims
+  int ni, nj, nk, halo, ioff, joff, pitch, slab;
+};
+
+__host__ __device__ inline Dm make_dm(const mom6x_dims &d) {
+  Dm m; m.ni = d.ni; m.nj = d.nj; m.nk = d.nk; m.halo = d.halo; m.ioff = d.ioff; m.joff = d.joff;
+  m.pitch = d.pitch; m.slab = d.slab; return m;
+}
+
+__device__ __forceinline__ size_t ix2(const Dm &d, int i, int j) {
+  return (size_t)(i + d.ioff) + (size_t)(j + d.joff) * (size_t)d.pitch;
+}
+__device__ __forceinline__ size_t ix3(const Dm &d, int i, int j, int k) {
+  return ix2(d, i, j) + (size_t)k * (size_t)d.slab;
+}
+__device__ __forceinline__ const double *gm(const double *G, const Dm &d, int m) {
+  return G + (size_t)m * (size_t)d.slab;
+}
+
+__device__ __forceinline__ double dmax(double a, double b) { return (a > b) ? a : b; }
+__device__ __forceinline__ double dmin(double a, double b) { return (a < b) ? a : b; }
+__device__ __forceinline__ double dsign(double a, double b) { return (b >= 0.0) ? fabs(a) : -fabs(a); }
+
+// ---------------------------------------------------------------------------------------------
+// host-side error plumbing
+void mom6x_set_error(const char *fmt, ...);
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      mom6x_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return MOM6X_EHIP;                                                                   \
+    }                                                                                      \
+  } while (0)
+#define REQUIRE(cond, code, msg)                  \
+  do {                                            \
+    if (!(cond)) { mom6x_set_error("%s", msg); return code; } \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// The context (opaque to C callers).
+struct BTState;   // barotropic.hip
+struct RK2State;  // dyn_split_RK2.hip
+
+struct mom6x_ctx {
+  mom6x_dims dims;
+  Dm d;
+  int device;
+  hipStream_t stream;       // compute stream
+  hipStream_t halo_stream;  // halo pack / RCCL send-recv / unpack
+  double *G;                // device metric block [MOM6X_G_COUNT][slab]
+  mom6x_vgrid GV;
+  int first_direction;
+  mom6x_continuity_params cont; bool cont_init;
+  mom6x_barotropic_params bt; bool bt_init;
+  // continuity scratch: edge values of the PPM reconstruction for one direction at a time
+  double *hL, *hR;
+  BTState *bts;
+  RK2State *rk2;
+  int *flag;                // device-side error flag (NaN / negative thickness)
+};
+
+inline dim3 grid3(int nx, int ny, int nz, dim3 b) {
+  return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z);
+}

@@ -1,0 +1,62 @@
+"""Shared test configurations (grids / states) -- mirrors of BASELINE.json's configs at sizes
+the oracle finishes in seconds."""
+import numpy as np
+
+from mom6_amd import abi, grid, synth
+
+
+def double_gyre(nk=2, ni=44, nj=40, halo=4, layout=(1, 1), pe=(0, 0)):
+    """config 2: double_gyre-like 44x40x2 closed basin on a spherical sector (bowl bathymetry)."""
+    gg = grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=30.0, dlon=22.0 / ni, dlat=20.0 / nj,
+                         depth_fn=grid.bowl_depth(ni, nj, 2000.0))
+    d, M = gg.tile(nk, halo, layout, pe)
+    return gg, d, M
+
+
+def channel(nk=3, ni=32, nj=24, halo=4, layout=(1, 1), pe=(0, 0)):
+    """zonally re-entrant channel, flat bottom with N/S walls (exercises REENTRANT_X wrap)."""
+    gg = grid.GlobalGrid(ni, nj, kind="cartesian", dx=2.0e4, dy=2.0e4, f0=1.0e-4, beta=2e-11,
+                         reentrant_x=True, depth_fn=grid.flat_depth(ni, nj, 1000.0, rim=1, rim_x=False))
+    d, M = gg.tile(nk, halo, layout, pe)
+    return gg, d, M
+
+
+def benchmark_small(nk=8, ni=40, nj=24, halo=4, layout=(1, 1), pe=(0, 0)):
+    """config 3 in miniature: benchmark-like bowl, nk layers."""
+    gg = grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-40.0, dlon=1.0, dlat=1.0,
+                         depth_fn=grid.bowl_depth(ni, nj, 4000.0))
+    d, M = gg.tile(nk, halo, layout, pe)
+    return gg, d, M
+
+
+def interior(d, stagger="h", extra=0):
+    """numpy slices of the computational domain for a staggering (symmetric memory)."""
+    e = extra
+    if stagger == "h":
+        return d.sl(-e, d.ni - 1 + e, -e, d.nj - 1 + e)
+    if stagger == "u":
+        return d.sl(-1 - e, d.ni - 1 + e, -e, d.nj - 1 + e)
+    if stagger == "v":
+        return d.sl(-e, d.ni - 1 + e, -1 - e, d.nj - 1 + e)
+    return d.sl(-1 - e, d.ni - 1 + e, -1 - e, d.nj - 1 + e)
+
+
+def assert_bitwise(a, b, name, sl=None):
+    a = np.asarray(a); b = np.asarray(b)
+    if sl is not None:
+        a = a[(Ellipsis,) + tuple(sl)]; b = b[(Ellipsis,) + tuple(sl)]
+    if not np.array_equal(a, b):
+        diff = np.abs(a - b)
+        idx = np.unravel_index(np.argmax(diff), diff.shape)
+        scale = max(np.abs(b).max(), 1e-300)
+        raise AssertionError(f"{name}: not bit-identical; max|diff|={diff.max():.3e} (rel {diff.max()/scale:.3e}) "
+                             f"at {idx}: {a[idx]!r} vs {b[idx]!r}; n_diff={np.count_nonzero(a != b)}")
+
+
+def assert_close(a, b, name, rtol, sl=None):
+    a = np.asarray(a); b = np.asarray(b)
+    if sl is not None:
+        a = a[(Ellipsis,) + tuple(sl)]; b = b[(Ellipsis,) + tuple(sl)]
+    scale = max(np.abs(b).max(), 1e-300)
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol, f"{name}: max rel-to-range error {err:.3e} > {rtol:.1e}"

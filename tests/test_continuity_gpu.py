@@ -1,0 +1,94 @@
+"""GPU parity: HIP continuity_PPM (through the C ABI) vs the oracle, bit for bit.
+
+FP64, no FMA contraction on either side, identical operation order => bit-exact is the bar
+(integer-like strictness; any index or ordering bug shows up immediately)."""
+import numpy as np
+import pytest
+
+from mom6_amd import abi, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0):
+    import torch
+    from mom6_amd.dycore import Dycore, BTContDev
+    gg, d, M = cfg
+    GV = abi.vgrid_default()
+    CS = abi.continuity_params_default(d.nk, GV.Angstrom_H)
+    if cs_mod:
+        for k, v in cs_mod.items():
+            setattr(CS, k, v)
+    h, u, v = synth.make_state(d, M, thin_frac=thin)
+    dt = 1200.0
+    rng = np.random.default_rng(5)
+    vr_u = np.clip(0.5 + 0.6 * synth.smooth_field(d, 11, nk=d.nk, ox=1.0, oy=0.5), 0.0, 1.0)
+    vr_v = np.clip(0.5 + 0.6 * synth.smooth_field(d, 12, nk=d.nk, ox=0.5, oy=1.0), 0.0, 1.0)
+    # reference transports to perturb into uhbt/vhbt
+    h0 = np.zeros_like(h); uh0 = np.zeros_like(h); vh0 = np.zeros_like(h)
+    orc.continuity_PPM(d, M, GV, CS, first_direction, u, v, h, h0, uh0, vh0, dt)
+    uhbt = uh0.sum(0) * (1.0 + 0.05 * synth.smooth_field(d, 13, ox=1.0, oy=0.5))
+    vhbt = vh0.sum(0) * (1.0 - 0.05 * synth.smooth_field(d, 14, ox=0.5, oy=1.0))
+
+    kw_o, kw_g = {}, {}
+    dyc = Dycore(d, M, GV, first_direction)
+    dyc.continuity_init(CS)
+    names3 = ["h", "uh", "vh"]
+    out_o = {n: np.zeros_like(h) for n in names3}
+    bt_o = None; bt_g = None
+    if mode in ("bt_cont", "full"):
+        bt_o = orc.new_bt_cont(d); bt_g = BTContDev(dyc)
+        kw_o["BT_cont"] = bt_o; kw_g["BT_cont"] = bt_g
+    if mode in ("visc", "bt_cont", "full", "adjust"):
+        kw_o.update(visc_rem_u=vr_u, visc_rem_v=vr_v)
+        kw_g.update(visc_rem_u=dyc.to_dev(vr_u), visc_rem_v=dyc.to_dev(vr_v))
+    if mode in ("adjust", "full", "adjust_novisc"):
+        out_o.update(u_cor=np.zeros_like(h), v_cor=np.zeros_like(h))
+        kw_o.update(uhbt=uhbt, vhbt=vhbt, u_cor=out_o["u_cor"], v_cor=out_o["v_cor"])
+        du_o = np.zeros(d.shape2()); dv_o = np.zeros(d.shape2())
+        kw_o.update(du_cor=du_o, dv_cor=dv_o)
+        out_o.update(du_cor=du_o, dv_cor=dv_o)
+    orc.continuity_PPM(d, M, GV, CS, first_direction, u, v, h, out_o["h"], out_o["uh"], out_o["vh"], dt, **kw_o)
+
+    out_g = {n: dyc.zeros3() for n in names3}
+    if "u_cor" in out_o:
+        out_g.update(u_cor=dyc.zeros3(), v_cor=dyc.zeros3(), du_cor=dyc.zeros2(), dv_cor=dyc.zeros2())
+        kw_g.update(uhbt=dyc.to_dev(uhbt), vhbt=dyc.to_dev(vhbt), u_cor=out_g["u_cor"], v_cor=out_g["v_cor"],
+                    du_cor=out_g["du_cor"], dv_cor=out_g["dv_cor"])
+    ud, vd, hd = dyc.to_dev(u), dyc.to_dev(v), dyc.to_dev(h)
+    torch.cuda.synchronize()
+    dyc.continuity_PPM(ud, vd, hd, out_g["h"], out_g["uh"], out_g["vh"], dt, **kw_g)
+    dyc.sync()
+
+    sl = {"h": H.interior(d, "h"), "uh": H.interior(d, "u"), "vh": H.interior(d, "v"),
+          "u_cor": H.interior(d, "u"), "v_cor": H.interior(d, "v"),
+          "du_cor": H.interior(d, "u"), "dv_cor": H.interior(d, "v")}
+    for n, a in out_o.items():
+        H.assert_bitwise(out_g[n].cpu().numpy(), a, f"{mode}:{n}", sl[n])
+    if bt_o is not None:
+        for n in abi.BTCont._names:
+            st = "u" if ("_u" in n or n.startswith("uBT")) else "v"
+            H.assert_bitwise(bt_g[n].cpu().numpy(), bt_o[n], f"{mode}:BT_cont%{n}", H.interior(d, st))
+    dyc.close()
+
+
+@pytest.mark.parametrize("mode", ["plain", "visc", "adjust_novisc", "adjust", "bt_cont", "full"])
+@pytest.mark.parametrize("first_direction", [0, 1])
+def test_continuity_double_gyre(orc, mode, first_direction):
+    _run_case(orc, H.double_gyre(), first_direction, mode)
+
+
+@pytest.mark.parametrize("mode", ["plain", "full"])
+def test_continuity_channel_reentrant(orc, mode):
+    _run_case(orc, H.channel(), 0, mode)
+
+
+def test_continuity_thin_layers_and_tc1_tolerances(orc):
+    # tc1 / p0 settings: ETA_TOLERANCE=1e-6, VELOCITY_TOLERANCE=1e-3 (.testing/tc1/MOM_input)
+    _run_case(orc, H.benchmark_small(), 0, "full", cs_mod=dict(tol_eta=1e-6, tol_vel=1e-3), thin=0.15)
+
+
+@pytest.mark.parametrize("flag", ["monotonic", "simple_2nd", "upwind_1st"])
+def test_continuity_scheme_flags(orc, flag):
+    _run_case(orc, H.benchmark_small(), 0, "full", cs_mod={flag: 1})
