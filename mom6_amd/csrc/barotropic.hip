@@ -1,0 +1,859 @@
+// barotropic.hip -- the split-explicit barotropic solver (btstep) on gfx950.
+//
+// Replaces btstep / btstep_timeloop / btloop_* / btcalc / bt_mass_source / set_dtbt and the static
+// part of barotropic_init (MOM_barotropic.F90), on the default-flag path of SURVEY.md 8(b.1)
+// (USE_BT_CONT_TYPE=T, LINEARIZED_BT_CORIOLIS=T, BT_NONLIN_STRESS=F, no OBC/SAL/filters,
+// BT_USE_WIDE_HALOS=T with BTHALO=0).
+//
+// Structure on the device:
+//  * k_bt_col<DIR>: ONE pass over the 3-D inputs per direction.  One thread per face column walks k
+//    in the reference's order and produces every 3-D -> 2-D reduction btstep needs (wt_u is never
+//    stored): ubt_Cor, gtot_E/W, uhbt(uh0), ubt(u_uh0), ubt, BT_force, av_rem -> bt_rem.
+//  * small 2-D kernels for the Coriolis weights f_4_u/v, Cor_ref, the BT_cont cubic fits
+//    (set_local_BT_cont_types) as SoA planes, eta_src.
+//  * the sub-cycle: 3 kernels per barotropic step (first velocity component, second component,
+//    eta corrector fused with the next step's eta predictor).  The pressure force is evaluated inside
+//    the velocity kernels; transports, running means and weighted sums are accumulated in the same
+//    kernels, so each 2-D coefficient plane is read exactly once per sub-step.
+//  * k_layer_accel: btstep_layer_accel (3-D write of accel_layer_u/v).
+// All 2-D work planes live in one HBM block that is cleared with a single memset per call.
+#include <vector>
+#include <cmath>
+#include "mom6x_dev.h"
+
+void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);  // halo.hip
+
+enum BTW {   // 2-D work planes
+  W_q = 0, W_DCor_u, W_DCor_v, W_gtot_E, W_gtot_W, W_gtot_N, W_gtot_S, W_eta, W_eta_PF,
+  W_Cor_ref_u, W_Cor_ref_v, W_BT_force_u, W_BT_force_v, W_ubt, W_vbt, W_bt_rem_u, W_bt_rem_v,
+  W_uhbt0, W_vhbt0, W_ubt_Cor, W_vbt_Cor, W_uhbt, W_vhbt, W_u_accel_bt, W_v_accel_bt,
+  W_eta_src, W_e_anom, W_eta_sum, W_eta_wtd, W_ubt_wtd, W_vbt_wtd, W_eta_pred,
+  W_uh0sum, W_vh0sum, W_ubt0, W_vbt0,
+  W_f4u, W_f4u_2, W_f4u_3, W_f4u_4, W_f4v, W_f4v_2, W_f4v_3, W_f4v_4,
+  W_BTCu,   // 10 planes
+  W_BTCv = W_BTCu + 10,   // 10 planes
+  W_BTtmp = W_BTCv + 10,  // 12 planes: halo-updated copies of the BT_cont arrays
+  W_COUNT = W_BTtmp + 12
+};
+
+enum BTC { B_FA_EE = 0, B_FA_E0, B_FA_W0, B_FA_WW, B_uBT_WW, B_uBT_EE, B_crvW, B_crvE, B_uh_WW, B_uh_EE };
+
+struct BTState {
+  // persistent barotropic_CS members
+  double *frhatu, *frhatv, *IDatu, *IDatv, *ubtav, *vbtav, *eta_cor, *q_D, *D_u_Cor, *D_v_Cor;
+  double *work;   // W_COUNT planes
+  int nstep_last;
+};
+
+namespace {
+
+__device__ __forceinline__ double *wp(double *work, const Dm &d, int m) { return work + (size_t)m * d.slab; }
+
+// find_uhbt :4610-4629 / find_vhbt :4744 on SoA fit planes
+__device__ __forceinline__ double find_uhbt(double u, const double *__restrict__ B, size_t c, size_t slab) {
+  if (u == 0.0) return 0.0;
+  const double uEE = B[B_uBT_EE * slab + c];
+  if (u < uEE) return (u - uEE) * B[B_FA_EE * slab + c] + B[B_uh_EE * slab + c];
+  if (u < 0.0) return u * (B[B_FA_E0 * slab + c] + B[B_crvE * slab + c] * (u * u));
+  const double uWW = B[B_uBT_WW * slab + c];
+  if (u <= uWW) return u * (B[B_FA_W0 * slab + c] + B[B_crvW * slab + c] * (u * u));
+  return (u - uWW) * B[B_FA_WW * slab + c] + B[B_uh_WW * slab + c];
+}
+
+// ---- barotropic_init static fields :5865-5896, :6146-6163 ---------------------------------
+__global__ void k_bt_init_static(Dm d, const double *__restrict__ G, double Z_to_H, double Mean_SL,
+                                 double cor_scale, double H_subroundoff, double *q_D, double *D_u_Cor,
+                                 double *D_v_Cor, double *IDatu, double *IDatv) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j);
+  const double *bathyT = gm(G, d, MOM6X_G_bathyT), *areaT = gm(G, d, MOM6X_G_areaT), *mT = gm(G, d, MOM6X_G_mask2dT);
+  const double *mCu = gm(G, d, MOM6X_G_mask2dCu), *mCv = gm(G, d, MOM6X_G_mask2dCv), *fBu = gm(G, d, MOM6X_G_CoriolisBu);
+  if (j >= 0) {
+    D_u_Cor[c] = 0.5 * (dmax(Mean_SL + bathyT[c + 1], 0.0) + dmax(Mean_SL + bathyT[c], 0.0)) * Z_to_H;
+    if (mCu[c] > 0.) IDatu[c] = mCu[c] * 2.0 / (Z_to_H * ((bathyT[c + 1] + bathyT[c]) + 2.0 * Mean_SL));
+    else IDatu[c] = 0.;
+  }
+  if (i >= 0) {
+    D_v_Cor[c] = 0.5 * (dmax(Mean_SL + bathyT[c + st], 0.0) + dmax(Mean_SL + bathyT[c], 0.0)) * Z_to_H;
+    if (mCv[c] > 0.) IDatv[c] = mCv[c] * 2.0 / (Z_to_H * ((bathyT[c + st] + bathyT[c]) + 2.0 * Mean_SL));
+    else IDatv[c] = 0.;
+  }
+  if (mT[c] + mT[c + st] + mT[c + 1] + mT[c + 1 + st] > 0.) {
+    q_D[c] = 0.25 * (cor_scale * fBu[c]) * ((areaT[c] + areaT[c + 1 + st]) + (areaT[c + 1] + areaT[c + st])) /
+        (Z_to_H * dmax((((areaT[c] * dmax(Mean_SL + bathyT[c], 0.0)) +
+                         (areaT[c + 1 + st] * dmax(Mean_SL + bathyT[c + 1 + st], 0.0))) +
+                        ((areaT[c + 1] * dmax(Mean_SL + bathyT[c + 1], 0.0)) +
+                         (areaT[c + st] * dmax(Mean_SL + bathyT[c + st], 0.0)))), H_subroundoff));
+  } else {
+    q_D[c] = 0.;
+  }
+}
+
+// ---- btcalc :4360-4605 --------------------------------------------------------------------
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_btcalc(Dm d, const double *__restrict__ G, const double *__restrict__ h, const double *__restrict__ hf,
+         double *__restrict__ fr, double h_neglect, double Z_to_H) {
+  const int i = (DIR ? 0 : -1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int st = DIR ? d.pitch : 1, nz = d.nk;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[c];
+  double hattot = 0.0;
+  if (hf) {
+    for (int k = 0; k < nz; k++) hattot = hattot + hf[c + k * slab];
+    const double Ihattot = mC / (hattot + h_neglect);
+    for (int k = 0; k < nz; k++) fr[c + k * slab] = hf[c + k * slab] * Ihattot;
+  } else {   // HYBRID (may_use_default) :4447-4468; hat is staged in fr and rescaled afterwards
+    const double *bathyT = gm(G, d, MOM6X_G_bathyT);
+    double e_below = -0.5 * Z_to_H * (bathyT[c + st] + bathyT[c]);
+    const double D_shallow = -Z_to_H * dmin(bathyT[c + st], bathyT[c]);
+    for (int k = nz - 1; k >= 0; k--) {
+      const double hp = h[c + st + k * slab], hm = h[c + k * slab];
+      const double e_k = e_below + 0.5 * (hp + hm);
+      const double h_arith = 0.5 * (hp + hm);
+      double hat;
+      if (e_below >= D_shallow) {
+        hat = h_arith;
+      } else {
+        const double h_harm = (hp * hm) / (h_arith + h_neglect);
+        if (e_k <= D_shallow) hat = h_harm;
+        else {
+          const double wt_arith = (e_k - D_shallow) / (h_arith + h_neglect);
+          hat = wt_arith * h_arith + (1.0 - wt_arith) * h_harm;
+        }
+      }
+      fr[c + k * slab] = hat;
+      hattot = hattot + hat;
+      e_below = e_k;
+    }
+    const double Ihattot = mC / (hattot + h_neglect);
+    for (int k = 0; k < nz; k++) fr[c + k * slab] = fr[c + k * slab] * Ihattot;
+  }
+}
+
+// ---- bt_mass_source :5243-5296 ---------------------------------------------------------------
+__global__ void k_bt_mass_source(Dm d, const double *__restrict__ G, const double *__restrict__ h,
+                                 const double *__restrict__ eta, double *eta_cor, int set_cor, double Z_to_H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const size_t c = ix2(d, i, j);
+  double eta_h = h[c] - gm(G, d, MOM6X_G_bathyT)[c] * Z_to_H;
+  for (int k = 1; k < d.nk; k++) eta_h = eta_h + h[c + (size_t)k * d.slab];
+  const double d_eta = eta_h - eta[c];
+  eta_cor[c] = set_cor ? d_eta : (eta_cor[c] + d_eta);
+}
+
+// ---- set_dtbt :3509-3633 (find_face_areas add_max branch :5208-5219) -------------------------
+__global__ void k_set_dtbt(Dm d, const double *__restrict__ G, const double *__restrict__ pbce,
+                           const double *__restrict__ frhatu, const double *__restrict__ frhatv,
+                           double gtot_est, double Z_to_H, double zadd, double bebt, double cor_scale2,
+                           double *Idt_max2_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double *bathyT = gm(G, d, MOM6X_G_bathyT), *dy_Cu = gm(G, d, MOM6X_G_dy_Cu), *dx_Cv = gm(G, d, MOM6X_G_dx_Cv);
+  const double *IdxCu = gm(G, d, MOM6X_G_IdxCu), *IdyCv = gm(G, d, MOM6X_G_IdyCv), *f2 = gm(G, d, MOM6X_G_Coriolis2Bu);
+  const double DatuE = dy_Cu[c] * Z_to_H * dmax(dmax(bathyT[c + 1], bathyT[c]) + zadd, 0.0);
+  const double DatuW = dy_Cu[c - 1] * Z_to_H * dmax(dmax(bathyT[c], bathyT[c - 1]) + zadd, 0.0);
+  const double DatvN = dx_Cv[c] * Z_to_H * dmax(dmax(bathyT[c + st], bathyT[c]) + zadd, 0.0);
+  const double DatvS = dx_Cv[c - st] * Z_to_H * dmax(dmax(bathyT[c], bathyT[c - st]) + zadd, 0.0);
+  double gE = gtot_est, gW = gtot_est, gN = gtot_est, gS = gtot_est;
+  if (pbce) {
+    gE = gW = gN = gS = 0.0;
+    for (int k = 0; k < d.nk; k++) {
+      const double pb = pbce[c + k * slab];
+      gE = gE + pb * frhatu[c + k * slab];
+      gW = gW + pb * frhatu[c - 1 + k * slab];
+      gN = gN + pb * frhatv[c + k * slab];
+      gS = gS + pb * frhatv[c - st + k * slab];
+    }
+  }
+  Idt_max2_out[c] = 0.5 * (1.0 + 2.0 * bebt) * (gm(G, d, MOM6X_G_IareaT)[c] *
+      (((gE * DatuE * IdxCu[c]) + (gW * DatuW * IdxCu[c - 1])) + ((gN * DatvN * IdyCv[c]) + (gS * DatvS * IdyCv[c - st]))) +
+      ((f2[c] + f2[c - 1 - st]) + (f2[c - 1] + f2[c - st])) * cor_scale2);
+}
+
+// ---- the single 3-D -> 2-D pass of btstep :1011-1330, :1473-1509 -----------------------------
+struct ColArgs {
+  const double *visc_rem, *frhat, *U_Cor, *pbce, *uh0, *u_uh0, *U_in, *bc_accel, *tau, *tau_bot, *IDat;
+  double *ubt_Cor, *gtot_m /*E|N at cell c*/, *gtot_p /*W|S at cell c+st*/, *uh0sum, *ubt0, *ubt, *BT_force, *bt_rem;
+  double Instep, RZ_to_H, vel_underflow;
+  int nstep, wt_uv_bug, visc_rem_u_uh0, strong_drag;
+};
+
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_bt_col(Dm d, const double *__restrict__ G, ColArgs A) {
+  const int i = (DIR ? 0 : -1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int st = DIR ? d.pitch : 1, nz = d.nk;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double subroundoff = 1e-30;
+  const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[c];
+  double Iwt_tot = 1.0;
+  if (!A.wt_uv_bug) {   // :1032-1059
+    double tot = 0.0;
+    for (int k = 0; k < nz; k++) {
+      double vr = dmin(A.visc_rem[c + k * slab], 1.);
+      vr = dmax(vr, 1. - 0.5 * A.Instep / (vr + subroundoff));
+      vr = dmax(vr, 0.);
+      const double w = A.frhat[c + k * slab] * vr;
+      tot = (k == 0) ? w : (tot + w);
+    }
+    Iwt_tot = tot;
+    if (fabs(tot) > 0.0) Iwt_tot = mC / tot;
+  }
+  double ubt_Cor = 0.0, gm_ = 0.0, gp_ = 0.0, uh0sum = 0.0, ubt0 = 0.0, ubt = 0.0, av_rem = 0.0;
+  // BT_force starts from the surface (and bottom) stress term :1259-1320
+  double BT_force = 0.0;
+  if (mC > 0.0) {
+    BT_force = A.tau[c] * A.RZ_to_H * A.IDat[c] * A.visc_rem[c];
+    if (A.tau_bot) BT_force = BT_force - A.tau_bot[c] * A.RZ_to_H * A.IDat[c];
+  }
+  for (int k = 0; k < nz; k++) {
+    const size_t f = c + k * slab;
+    const double vrem = A.visc_rem[f], frh = A.frhat[f];
+    double vr = dmin(vrem, 1.);
+    vr = dmax(vr, 1. - 0.5 * A.Instep / (vr + subroundoff));
+    vr = dmax(vr, 0.);
+    double wt = frh * vr;
+    if (!A.wt_uv_bug) wt = wt * Iwt_tot;
+    ubt_Cor = ubt_Cor + wt * A.U_Cor[f];
+    gm_ = gm_ + A.pbce[f] * wt;
+    gp_ = gp_ + A.pbce[f + st] * wt;
+    if (A.uh0) {
+      uh0sum = uh0sum + A.uh0[f];
+      ubt0 = ubt0 + (A.visc_rem_u_uh0 ? wt : frh) * A.u_uh0[f];
+    }
+    ubt = ubt + wt * A.U_in[f];
+    BT_force = BT_force + wt * A.bc_accel[f];
+    av_rem = av_rem + frh * vrem;
+  }
+  A.ubt_Cor[c] = ubt_Cor;
+  A.gtot_m[c] = gm_;
+  A.gtot_p[c + st] = gp_;
+  if (A.uh0) { A.uh0sum[c] = uh0sum; A.ubt0[c] = ubt0; }
+  if (fabs(ubt) < A.vel_underflow) ubt = 0.0;
+  A.ubt[c] = ubt;
+  A.BT_force[c] = BT_force;
+  double bt_rem;
+  if (A.strong_drag) {
+    bt_rem = mC * ((A.nstep * av_rem) / (1.0 + (A.nstep - 1) * av_rem));
+  } else {
+    bt_rem = 0.0;
+    if (mC * av_rem > 0.0) bt_rem = mC * pow(av_rem, A.Instep);
+  }
+  A.bt_rem[c] = bt_rem;
+}
+
+// ---- set_local_BT_cont_types :4876-5003 -------------------------------------------------------
+// step 1: copy the computational-domain values of the 12 BT_cont planes into zeroed temporaries
+__global__ void k_btcont_copy(Dm d, mom6x_BT_cont BT, double *tmp) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  if (j >= 0) {
+    tmp[0 * slab + c] = BT.uBT_EE[c]; tmp[1 * slab + c] = BT.uBT_WW[c]; tmp[2 * slab + c] = BT.FA_u_EE[c];
+    tmp[3 * slab + c] = BT.FA_u_E0[c]; tmp[4 * slab + c] = BT.FA_u_W0[c]; tmp[5 * slab + c] = BT.FA_u_WW[c];
+  }
+  if (i >= 0) {
+    tmp[6 * slab + c] = BT.vBT_NN[c]; tmp[7 * slab + c] = BT.vBT_SS[c]; tmp[8 * slab + c] = BT.FA_v_NN[c];
+    tmp[9 * slab + c] = BT.FA_v_N0[c]; tmp[10 * slab + c] = BT.FA_v_S0[c]; tmp[11 * slab + c] = BT.FA_v_SS[c];
+  }
+}
+// step 2 (after the halo update): the cubic-fit parameters as SoA planes
+__global__ void k_btcl(Dm d, const double *__restrict__ tmp, double *Bu, double *Bv, int hs) {
+  const int i = -hs - 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -hs - 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 + hs || j > d.nj - 1 + hs) return;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double C1_3 = 1.0 / 3.0;
+  for (int dir = 0; dir < 2; dir++) {
+    if (dir == 0 && j < -hs) continue;
+    if (dir == 1 && i < -hs) continue;
+    const double *t = tmp + (size_t)(dir * 6) * slab;
+    double *B = dir ? Bv : Bu;
+    const double FA_EE = t[2 * slab + c], FA_E0 = t[3 * slab + c], FA_W0 = t[4 * slab + c], FA_WW = t[5 * slab + c];
+    const double uBT_EE = 1.0 * t[0 * slab + c], uBT_WW = 1.0 * t[1 * slab + c];
+    B[B_FA_EE * slab + c] = FA_EE; B[B_FA_E0 * slab + c] = FA_E0; B[B_FA_W0 * slab + c] = FA_W0; B[B_FA_WW * slab + c] = FA_WW;
+    B[B_uBT_EE * slab + c] = uBT_EE; B[B_uBT_WW * slab + c] = uBT_WW;
+    B[B_uh_EE * slab + c] = uBT_EE * (C1_3 * (2.0 * FA_E0 + FA_EE));
+    B[B_uh_WW * slab + c] = uBT_WW * (C1_3 * (2.0 * FA_W0 + FA_WW));
+    double crvW = 0.0, crvE = 0.0;
+    if (fabs(uBT_WW) > 0.0) crvW = (C1_3 * (FA_WW - FA_W0)) / (uBT_WW * uBT_WW);
+    if (fabs(uBT_EE) > 0.0) crvE = (C1_3 * (FA_EE - FA_E0)) / (uBT_EE * uBT_EE);
+    B[B_crvW * slab + c] = crvW; B[B_crvE * slab + c] = crvE;
+  }
+}
+
+// uhbt0 = sum(uh0) - find_uhbt(ubt(u_uh0))  :1203-1209
+__global__ void k_uhbt0(Dm d, const double *__restrict__ work_c, double *work) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  if (j >= 0) work[W_uhbt0 * slab + c] = work_c[W_uh0sum * slab + c] - find_uhbt(work_c[W_ubt0 * slab + c], work_c + W_BTCu * slab, c, slab);
+  if (i >= 0) work[W_vhbt0 * slab + c] = work_c[W_vh0sum * slab + c] - find_uhbt(work_c[W_vbt0 * slab + c], work_c + W_BTCv * slab, c, slab);
+}
+
+// btstep_find_Cor :2836-2894 (OBCmask == 1)
+__global__ void k_find_Cor(Dm d, double *work, int Sadourny, int isvf, int ievf, int jsvf, int jevf) {
+  const int i = isvf - 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = jsvf - 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > ievf + 1 || j > jevf + 1) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double *q = work + W_q * slab, *DCor_u = work + W_DCor_u * slab, *DCor_v = work + W_DCor_v * slab;
+  double *f4u = work + W_f4u * slab, *f4v = work + W_f4v * slab;
+  if (j <= jevf) {   // f_4_v on J=jsvf-1..jevf, i=isvf-1..ievf+1
+    if (Sadourny) {
+      f4v[0 * slab + c] = 1.0 * DCor_u[c - 1] * q[c - 1];
+      f4v[1 * slab + c] = 1.0 * DCor_u[c] * q[c];
+      f4v[3 * slab + c] = 1.0 * DCor_u[c + st] * q[c];
+      f4v[2 * slab + c] = 1.0 * DCor_u[c - 1 + st] * q[c - 1];
+    } else {
+      f4v[0 * slab + c] = 1.0 * DCor_u[c - 1] * ((q[c] + q[c - 1 - st]) + q[c - 1]) / 3.0;
+      f4v[1 * slab + c] = 1.0 * DCor_u[c] * (q[c] + (q[c - 1] + q[c - st])) / 3.0;
+      f4v[3 * slab + c] = 1.0 * DCor_u[c + st] * (q[c] + (q[c - 1] + q[c + st])) / 3.0;
+      f4v[2 * slab + c] = 1.0 * DCor_u[c - 1 + st] * ((q[c] + q[c - 1 + st]) + q[c - 1]) / 3.0;
+    }
+  }
+  if (i <= ievf) {   // f_4_u on j=jsvf-1..jevf+1, I=isvf-1..ievf
+    if (Sadourny) {
+      f4u[3 * slab + c] = 1.0 * DCor_v[c + 1] * q[c];
+      f4u[2 * slab + c] = 1.0 * DCor_v[c] * q[c];
+      f4u[0 * slab + c] = 1.0 * DCor_v[c - st] * q[c - st];
+      f4u[1 * slab + c] = 1.0 * DCor_v[c + 1 - st] * q[c - st];
+    } else {
+      f4u[3 * slab + c] = 1.0 * DCor_v[c + 1] * (q[c] + (q[c + 1] + q[c - st])) / 3.0;
+      f4u[2 * slab + c] = 1.0 * DCor_v[c] * (q[c] + (q[c - 1] + q[c - st])) / 3.0;
+      f4u[0 * slab + c] = 1.0 * DCor_v[c - st] * ((q[c] + q[c - 1 - st]) + q[c - st]) / 3.0;
+      f4u[1 * slab + c] = 1.0 * DCor_v[c + 1 - st] * ((q[c] + q[c + 1 - st]) + q[c - st]) / 3.0;
+    }
+  }
+}
+
+// Cor_ref :1451-1461 and eta_src :1548-1587
+__global__ void k_cor_ref_eta_src(Dm d, const double *__restrict__ G, double *work, double *eta_cor, double Instep,
+                                  int bound_BT_corr, double maxCFL_Idt, double dt, double Z_to_H) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double *f4u = work + W_f4u * slab, *f4v = work + W_f4v * slab;
+  const double *ubt_Cor = work + W_ubt_Cor * slab, *vbt_Cor = work + W_vbt_Cor * slab;
+  if (j >= 0)
+    work[W_Cor_ref_u * slab + c] = (((f4u[3 * slab + c] * vbt_Cor[c + 1]) + (f4u[0 * slab + c] * vbt_Cor[c - st])) +
+                                    ((f4u[2 * slab + c] * vbt_Cor[c]) + (f4u[1 * slab + c] * vbt_Cor[c + 1 - st])));
+  if (i >= 0)
+    work[W_Cor_ref_v * slab + c] = -1.0 * (((f4v[0 * slab + c] * ubt_Cor[c - 1]) + (f4v[3 * slab + c] * ubt_Cor[c + st])) +
+                                           ((f4v[1 * slab + c] * ubt_Cor[c]) + (f4v[2 * slab + c] * ubt_Cor[c - 1 + st])));
+  if (i >= 0 && j >= 0) {
+    const double mT = gm(G, d, MOM6X_G_mask2dT)[c];
+    double ec = eta_cor[c];
+    if (bound_BT_corr && mT > 0.0) {
+      if (ec > 0.0) {
+        const double u_max_cor = gm(G, d, MOM6X_G_dxT)[c] * maxCFL_Idt, v_max_cor = gm(G, d, MOM6X_G_dyT)[c] * maxCFL_Idt;
+        const double *Bu = work + W_BTCu * slab, *Bv = work + W_BTCv * slab;
+        const double *uhbt0 = work + W_uhbt0 * slab, *vhbt0 = work + W_vhbt0 * slab;
+        const double eta_cor_max = dt * (gm(G, d, MOM6X_G_IareaT)[c] *
+            (((find_uhbt(u_max_cor, Bu, c, slab) + uhbt0[c]) - (find_uhbt(-u_max_cor, Bu, c - 1, slab) + uhbt0[c - 1])) +
+             ((find_uhbt(v_max_cor, Bv, c, slab) + vhbt0[c]) - (find_uhbt(-v_max_cor, Bv, c - st, slab) + vhbt0[c - st]))));
+        ec = dmin(ec, dmax(0.0, eta_cor_max));
+      } else {
+        const double Htot = gm(G, d, MOM6X_G_bathyT)[c] * Z_to_H + work[W_eta * slab + c];
+        ec = dmax(ec, -dmax(0.0, Htot));
+      }
+      eta_cor[c] = ec;
+    }
+    work[W_eta_src * slab + c] = mT * (Instep * ec);
+  }
+}
+
+// copy eta_in / eta_PF_in / q_D / D_Cor into the work block :880-893, :996-1001
+__global__ void k_bt_copy_in(Dm d, double *work, const double *__restrict__ eta_in, const double *__restrict__ eta_PF_in,
+                             const double *__restrict__ q_D, const double *__restrict__ D_u_Cor,
+                             const double *__restrict__ D_v_Cor) {
+  const int i = -d.halo - 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -d.halo - 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 + d.halo || j > d.nj - 1 + d.halo) return;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  if (i >= -d.halo && j >= -d.halo) { work[W_eta * slab + c] = eta_in[c]; work[W_eta_PF * slab + c] = eta_PF_in[c]; }
+  work[W_q * slab + c] = q_D[c]; work[W_DCor_u * slab + c] = D_u_Cor[c]; work[W_DCor_v * slab + c] = D_v_Cor[c];
+}
+
+// ---- the sub-cycle ---------------------------------------------------------------------------
+struct LoopArgs {
+  double dtbt, dgeo_de, vel_underflow, trans_wt1, trans_wt2;
+  double wt_accel, wt_trans, wt_vel, wt_eta, wt_accel2;
+  int project, bracket_bug, find_etaav;
+  int isv, iev, jsv, jev;   // valid range of this step
+};
+
+// btloop_eta_predictor :2956-3018 (use_BT_cont branch) over (isv-1..iev+1, jsv-1..jev+1), plus the
+// eta_sum accumulation of btloop_find_PF :3104-3108 over the computational domain.
+__global__ void __launch_bounds__(256)
+k_bt_pred(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
+  const int i = A.isv - 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = A.jsv - 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > A.iev + 1 || j > A.jev + 1) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  double eta_PF_BT;
+  if (A.project) {
+    eta_PF_BT = work[W_eta * slab + c];
+  } else {
+    const double *ubt = work + W_ubt * slab, *vbt = work + W_vbt * slab;
+    const double *Bu = work + W_BTCu * slab, *Bv = work + W_BTCv * slab;
+    const double *uhbt0 = work + W_uhbt0 * slab, *vhbt0 = work + W_vhbt0 * slab;
+    const double uW = find_uhbt(ubt[c - 1], Bu, c - 1, slab) + uhbt0[c - 1];
+    const double uE = find_uhbt(ubt[c], Bu, c, slab) + uhbt0[c];
+    const double vS = find_uhbt(vbt[c - st], Bv, c - st, slab) + vhbt0[c - st];
+    const double vN = find_uhbt(vbt[c], Bv, c, slab) + vhbt0[c];
+    eta_PF_BT = (work[W_eta * slab + c] + work[W_eta_src * slab + c]) +
+                (A.dtbt * gm(G, d, MOM6X_G_IareaT)[c]) * ((uW - uE) + (vS - vN));
+    work[W_eta_pred * slab + c] = eta_PF_BT;
+  }
+  if (A.find_etaav && (fabs(A.wt_accel2) > 0.0) && i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1)
+    work[W_eta_sum * slab + c] = work[W_eta_sum * slab + c] + A.wt_accel2 * eta_PF_BT;
+}
+
+// btloop_find_PF + btloop_update_u/v + transports + running sums for ONE velocity component.
+// DIR = 0: u (faces I), DIR = 1: v (faces J).  (a0..a1, b0..b1) is the update range.
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_bt_vel(Dm d, const double *__restrict__ G, double *work, double *btav, double *hbtav, LoopArgs A,
+         int a0, int a1, int b0, int b1, int bracket_bug) {
+  const int i = a0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = b0 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > a1 || j > b1) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double *etaB = work + (A.project ? W_eta : W_eta_pred) * slab;
+  const double *eta_PF = work + W_eta_PF * slab;
+  double vel, Cor, PF, newv;
+  if (DIR == 0) {
+    const double *gE = work + W_gtot_E * slab, *gW = work + W_gtot_W * slab, *vbt = work + W_vbt * slab;
+    const double *f4u = work + W_f4u * slab;
+    PF = (((etaB[c] - eta_PF[c]) * gE[c]) - ((etaB[c + 1] - eta_PF[c + 1]) * gW[c + 1])) * A.dgeo_de * gm(G, d, MOM6X_G_IdxCu)[c];
+    Cor = (((f4u[3 * slab + c] * vbt[c + 1]) + (f4u[0 * slab + c] * vbt[c - st])) +
+           ((f4u[2 * slab + c] * vbt[c]) + (f4u[1 * slab + c] * vbt[c + 1 - st]))) - work[W_Cor_ref_u * slab + c];
+    vel = work[W_ubt * slab + c];
+    newv = work[W_bt_rem_u * slab + c] * (vel + A.dtbt * ((work[W_BT_force_u * slab + c] + Cor) + PF));
+    if (fabs(newv) < A.vel_underflow) newv = 0.0;
+    work[W_ubt * slab + c] = newv;
+    work[W_u_accel_bt * slab + c] = work[W_u_accel_bt * slab + c] + A.wt_accel * (Cor + PF);
+  } else {
+    const double *gN = work + W_gtot_N * slab, *gS = work + W_gtot_S * slab, *ubt = work + W_ubt * slab;
+    const double *f4v = work + W_f4v * slab;
+    PF = (((etaB[c] - eta_PF[c]) * gN[c]) - ((etaB[c + st] - eta_PF[c + st]) * gS[c + st])) * A.dgeo_de * gm(G, d, MOM6X_G_IdyCv)[c];
+    if (bracket_bug)
+      Cor = -1.0 * (((f4v[0 * slab + c] * ubt[c - 1]) + (f4v[1 * slab + c] * ubt[c])) +
+                    ((f4v[3 * slab + c] * ubt[c + st]) + (f4v[2 * slab + c] * ubt[c - 1 + st]))) - work[W_Cor_ref_v * slab + c];
+    else
+      Cor = -1.0 * (((f4v[0 * slab + c] * ubt[c - 1]) + (f4v[3 * slab + c] * ubt[c + st])) +
+                    ((f4v[1 * slab + c] * ubt[c]) + (f4v[2 * slab + c] * ubt[c - 1 + st]))) - work[W_Cor_ref_v * slab + c];
+    vel = work[W_vbt * slab + c];
+    newv = work[W_bt_rem_v * slab + c] * (vel + A.dtbt * ((work[W_BT_force_v * slab + c] + Cor) + PF));
+    if (fabs(newv) < A.vel_underflow) newv = 0.0;
+    work[W_vbt * slab + c] = newv;
+    work[W_v_accel_bt * slab + c] = work[W_v_accel_bt * slab + c] + A.wt_accel * (Cor + PF);
+  }
+  // transports on (isv-1..iev, jsv..jev) | (isv..iev, jsv-1..jev)  :2624-2632
+  const bool in_trans = DIR ? (i >= A.isv && i <= A.iev && j >= A.jsv - 1 && j <= A.jev)
+                            : (i >= A.isv - 1 && i <= A.iev && j >= A.jsv && j <= A.jev);
+  if (in_trans) {
+    const double trans = A.trans_wt1 * newv + A.trans_wt2 * vel;
+    const double hbt = find_uhbt(trans, work + (DIR ? W_BTCv : W_BTCu) * slab, c, slab) + work[(DIR ? W_vhbt0 : W_uhbt0) * slab + c];
+    work[(DIR ? W_vhbt : W_uhbt) * slab + c] = hbt;
+    const bool in_c = DIR ? (i >= 0 && i <= d.ni - 1 && j >= -1 && j <= d.nj - 1) : (i >= -1 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1);
+    if (in_c) {   // running sums :2690-2700
+      btav[c] = btav[c] + A.wt_trans * trans;
+      hbtav[c] = hbtav[c] + A.wt_trans * hbt;
+      double *wtd = work + (DIR ? W_vbt_wtd : W_ubt_wtd) * slab;
+      wtd[c] = wtd[c] + A.wt_vel * newv;
+    }
+  }
+}
+
+// eta corrector :2721-2727
+__global__ void __launch_bounds__(256)
+k_bt_eta(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
+  const int i = A.isv + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = A.jsv + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > A.iev || j > A.jev) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double *uhbt = work + W_uhbt * slab, *vhbt = work + W_vhbt * slab;
+  const double e = (work[W_eta * slab + c] + work[W_eta_src * slab + c]) +
+                   (A.dtbt * gm(G, d, MOM6X_G_IareaT)[c]) * ((uhbt[c - 1] - uhbt[c]) + (vhbt[c - st] - vhbt[c]));
+  work[W_eta * slab + c] = e;
+  work[W_eta_wtd * slab + c] = work[W_eta_wtd * slab + c] + e * A.wt_eta;
+}
+
+// truncate_velocities :2918-2944
+__global__ void k_bt_clip(Dm d, const double *__restrict__ G, double *work, double dt, double CFL_trunc,
+                          int isv, int iev, int jsv, int jev) {
+  const int i = isv - 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = jsv - 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > iev || j > jev) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double *IareaT = gm(G, d, MOM6X_G_IareaT), *areaT = gm(G, d, MOM6X_G_areaT);
+  if (j >= jsv) {
+    const double dy = gm(G, d, MOM6X_G_dy_Cu)[c];
+    double u = work[W_ubt * slab + c];
+    if ((u * (dt * dy)) * IareaT[c + 1] < -CFL_trunc) u = (-0.95 * CFL_trunc) * (areaT[c + 1] / (dt * dy));
+    else if ((u * (dt * dy)) * IareaT[c] > CFL_trunc) u = (0.95 * CFL_trunc) * (areaT[c] / (dt * dy));
+    work[W_ubt * slab + c] = u;
+  }
+  if (i >= isv) {
+    const double dx = gm(G, d, MOM6X_G_dx_Cv)[c];
+    double v = work[W_vbt * slab + c];
+    if ((v * (dt * dx)) * IareaT[c + st] < -CFL_trunc) v = (-0.9 * CFL_trunc) * (areaT[c + st] / (dt * dx));
+    else if ((v * (dt * dx)) * IareaT[c] > CFL_trunc) v = (0.9 * CFL_trunc) * (areaT[c] / (dt * dx));
+    work[W_vbt * slab + c] = v;
+  }
+}
+
+// after the loop :1807-1847
+__global__ void k_bt_post(Dm d, double *work, const double *__restrict__ eta_in, double *eta_out, double *etaav,
+                          double dgeo_de, double I_sum_wt_accel, double I_sum_wt_eta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  if (etaav) etaav[c] = work[W_eta_sum * slab + c] * I_sum_wt_accel;
+  work[W_e_anom * slab + c] = dgeo_de * (0.5 * (work[W_eta * slab + c] + eta_in[c]) - work[W_eta_PF * slab + c]);
+  eta_out[c] = work[W_eta_wtd * slab + c] * I_sum_wt_eta;
+}
+
+// btstep_layer_accel :3432-3504
+__global__ void __launch_bounds__(256)
+k_layer_accel(Dm d, const double *__restrict__ G, const double *__restrict__ work, const double *__restrict__ pbce,
+              double *__restrict__ accel_layer_u, double *__restrict__ accel_layer_v, double accel_underflow) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab, c3 = c + (size_t)k * slab;
+  const double *e_anom = work + W_e_anom * slab;
+  const double pb = pbce[c3], ea = e_anom[c];
+  if (j >= 0) {
+    double a = (work[W_u_accel_bt * slab + c] -
+                (((pbce[c3 + 1] - work[W_gtot_W * slab + c + 1]) * e_anom[c + 1]) - ((pb - work[W_gtot_E * slab + c]) * ea)) *
+                    gm(G, d, MOM6X_G_IdxCu)[c]);
+    if (fabs(a) < accel_underflow) a = 0.0;
+    accel_layer_u[c3] = a;
+  }
+  if (i >= 0) {
+    double a = (work[W_v_accel_bt * slab + c] -
+                (((pbce[c3 + st] - work[W_gtot_S * slab + c + st]) * e_anom[c + st]) - ((pb - work[W_gtot_N * slab + c]) * ea)) *
+                    gm(G, d, MOM6X_G_IdyCv)[c]);
+    if (fabs(a) < accel_underflow) a = 0.0;
+    accel_layer_v[c3] = a;
+  }
+}
+
+inline dim3 blk2() { return dim3(64, 4, 1); }
+
+}  // namespace
+
+void bt_state_free(mom6x_ctx *c) {
+  if (!c->bts) return;
+  BTState *s = c->bts;
+  double *ptrs[] = { s->frhatu, s->frhatv, s->IDatu, s->IDatv, s->ubtav, s->vbtav, s->eta_cor, s->q_D, s->D_u_Cor,
+                     s->D_v_Cor, s->work };
+  for (double *p : ptrs) (void)hipFree(p);
+  delete s;
+  c->bts = nullptr;
+}
+
+extern "C" int mom6x_barotropic_init(mom6x_ctx *c, const mom6x_barotropic_params *p) {
+  REQUIRE(c && p, MOM6X_EINVAL, "mom6x_barotropic_init: null argument");
+  REQUIRE(!(p->bound_BT_corr && !p->BT_cont_bounds), MOM6X_EUNSUPPORTED,
+          "barotropic: BOUND_BT_CORRECTION without BT_CONT_CORR_BOUNDS is not supported");
+  REQUIRE(c->dims.halo >= 2, MOM6X_EINVAL, "barotropic: halo >= 2 required");
+  HIPCHK(hipSetDevice(c->device));
+  c->bt = *p;
+  const Dm d = c->d;
+  if (!c->bts) {
+    BTState *s = new BTState();
+    memset(s, 0, sizeof(*s));
+    const size_t n2 = (size_t)d.slab, n3 = n2 * d.nk;
+    double **p3[] = { &s->frhatu, &s->frhatv };
+    for (double **q : p3) { HIPCHK(hipMalloc(q, n3 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, 0, n3 * sizeof(double), c->stream)); }
+    double **p2[] = { &s->IDatu, &s->IDatv, &s->ubtav, &s->vbtav, &s->eta_cor, &s->q_D, &s->D_u_Cor, &s->D_v_Cor };
+    for (double **q : p2) { HIPCHK(hipMalloc(q, n2 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, 0, n2 * sizeof(double), c->stream)); }
+    HIPCHK(hipMalloc(&s->work, (size_t)W_COUNT * n2 * sizeof(double)));
+    c->bts = s;
+  }
+  BTState *s = c->bts;
+  s->nstep_last = 0;
+  const dim3 b = blk2();
+  hipLaunchKernelGGL(k_bt_init_static, grid3(d.ni + 1, d.nj + 1, 1, b), b, 0, c->stream, d, c->G, c->GV.Z_to_H, p->Z_ref,
+                     p->BT_Coriolis_scale, c->GV.H_subroundoff, s->q_D, s->D_u_Cor, s->D_v_Cor, s->IDatu, s->IDatv);
+  double *f[] = { s->q_D, s->D_u_Cor, s->D_v_Cor };
+  const int stg[] = { 3, 1, 2 }, nks[] = { 1, 1, 1 };
+  halo_wrap(c, f, stg, nks, 3);
+  HIPCHK(hipGetLastError());
+  c->bt_init = true;
+  return MOM6X_OK;
+}
+
+extern "C" double *mom6x_barotropic_field(mom6x_ctx *c, int which) {
+  if (!c || !c->bts) return nullptr;
+  BTState *s = c->bts;
+  switch (which) {
+    case 0: return s->ubtav; case 1: return s->vbtav; case 2: return s->eta_cor; case 3: return s->frhatu;
+    case 4: return s->frhatv; case 5: return s->IDatu; case 6: return s->IDatv; case 7: return s->q_D;
+    case 8: return s->D_u_Cor; case 9: return s->D_v_Cor; case 10: return s->work;
+    default: return nullptr;
+  }
+}
+
+extern "C" int mom6x_btcalc(mom6x_ctx *c, const double *h, const double *h_u, const double *h_v) {
+  REQUIRE(c && c->bt_init, MOM6X_EINVAL, "btcalc: Module MOM_barotropic must be initialized before it is used.");
+  REQUIRE((h_u != nullptr) == (h_v != nullptr), MOM6X_EINVAL, "btcalc: Inconsistent settings of optional arguments");
+  REQUIRE(h_u || h, MOM6X_EINVAL, "btcalc: h is required when h_u/h_v are absent");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  const dim3 b = blk2();
+  hipLaunchKernelGGL(k_btcalc<0>, grid3(d.ni + 1, d.nj, 1, b), b, 0, c->stream, d, c->G, h, h_u, c->bts->frhatu,
+                     c->GV.H_subroundoff, c->GV.Z_to_H);
+  hipLaunchKernelGGL(k_btcalc<1>, grid3(d.ni, d.nj + 1, 1, b), b, 0, c->stream, d, c->G, h, h_v, c->bts->frhatv,
+                     c->GV.H_subroundoff, c->GV.Z_to_H);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_bt_mass_source(mom6x_ctx *c, const double *h, const double *eta, int set_cor) {
+  REQUIRE(c && c->bt_init, MOM6X_EINVAL, "bt_mass_source: Module MOM_barotropic must be initialized before it is used.");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  const dim3 b = blk2();
+  hipLaunchKernelGGL(k_bt_mass_source, grid3(d.ni, d.nj, 1, b), b, 0, c->stream, d, c->G, h, eta, c->bts->eta_cor, set_cor,
+                     c->GV.Z_to_H);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_set_dtbt(mom6x_ctx *c, const double *pbce, double gtot_est, double SSH_add, double *dtbt_out) {
+  REQUIRE(c && c->bt_init, MOM6X_EINVAL, "set_dtbt: Module MOM_barotropic must be initialized before it is used.");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  const dim3 b = blk2();
+  BTState *s = c->bts;
+  double *tmp = s->work + (size_t)W_eta_pred * d.slab;   // scratch plane
+  HIPCHK(hipMemsetAsync(tmp, 0, sizeof(double) * d.slab, c->stream));
+  hipLaunchKernelGGL(k_set_dtbt, grid3(d.ni, d.nj, 1, b), b, 0, c->stream, d, c->G, pbce, s->frhatu, s->frhatv, gtot_est,
+                     c->GV.Z_to_H, c->bt.Z_ref + SSH_add, c->bt.bebt, c->bt.BT_Coriolis_scale * c->bt.BT_Coriolis_scale, tmp);
+  HIPCHK(hipGetLastError());
+  // min over the tile in the reference's (j outer, i inner) order is order-independent for min():
+  std::vector<double> host((size_t)d.slab);
+  HIPCHK(hipMemcpyAsync(host.data(), tmp, sizeof(double) * d.slab, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double min_max_dt2 = 1.0e38;
+  for (int j = 0; j < d.nj; j++) for (int i = 0; i < d.ni; i++) {
+    const double I2 = host[(size_t)(i + d.ioff) + (size_t)(j + d.joff) * d.pitch];
+    if (I2 * min_max_dt2 > 1.0) min_max_dt2 = 1.0 / I2;
+  }
+  const double dgeo_de = 1.0 + fmax(0.0, c->bt.G_extra);
+  const double dtbt_max = sqrt(min_max_dt2 / dgeo_de);
+  // TODO(multi-GPU): min_across_PEs(dtbt_max) :3622 via ncclAllReduce(min)
+  c->bt.dtbt = c->bt.dtbt_fraction * dtbt_max;
+  if (dtbt_out) *dtbt_out = c->bt.dtbt;
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in, const double *eta_in, double dt,
+                            const double *bc_accel_u, const double *bc_accel_v, const double *taux, const double *tauy,
+                            const double *pbce, const double *eta_PF_in, const double *U_Cor, const double *V_Cor,
+                            double *accel_layer_u, double *accel_layer_v, double *eta_out, double *uhbtav,
+                            double *vhbtav, const double *visc_rem_u, const double *visc_rem_v,
+                            const mom6x_BT_cont *BT_cont, const double *taux_bot, const double *tauy_bot,
+                            const double *uh0, const double *vh0, const double *u_uh0, const double *v_vh0,
+                            double *etaav) {
+  REQUIRE(c && c->bt_init, MOM6X_EINVAL, "btstep: Module MOM_barotropic must be initialized before it is used.");
+  REQUIRE(BT_cont, MOM6X_EUNSUPPORTED, "btstep: only USE_BT_CONT_TYPE=True (BT_cont associated) is supported");
+  REQUIRE(U_in && V_in && eta_in && bc_accel_u && bc_accel_v && taux && tauy && pbce && eta_PF_in && U_Cor && V_Cor &&
+          accel_layer_u && accel_layer_v && eta_out && uhbtav && vhbtav && visc_rem_u && visc_rem_v,
+          MOM6X_EINVAL, "btstep: null mandatory array");
+  const bool add_uh0 = (uh0 != nullptr);
+  REQUIRE(!add_uh0 || (vh0 && u_uh0 && v_vh0), MOM6X_EINVAL,
+          "btstep: vh0, u_uh0, and v_vh0 must be associated if uh0 is used.");
+  REQUIRE((taux_bot != nullptr) == (tauy_bot != nullptr), MOM6X_EINVAL, "btstep: taux_bot and tauy_bot come together");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  const mom6x_barotropic_params &P = c->bt;
+  BTState *s = c->bts;
+  double *work = s->work;
+  const size_t slab = (size_t)d.slab;
+  const dim3 b = blk2();
+  hipStream_t st = c->stream;
+  const int is = 0, ie = d.ni - 1, js = 0, je = d.nj - 1;
+
+  const double Idt = 1.0 / dt;
+  const int stencil = 1;
+  const int num_cycles = d.halo / stencil;
+  const int isvf = is - (num_cycles - 1) * stencil, ievf = ie + (num_cycles - 1) * stencil;
+  const int jsvf = js - (num_cycles - 1) * stencil, jevf = je + (num_cycles - 1) * stencil;
+  REQUIRE(P.dtbt > 0.0, MOM6X_EINVAL, "btstep: dtbt must be positive (call set_dtbt or set params.dtbt)");
+  const int nstep = (int)ceil(dt / P.dtbt - 0.0001);
+  s->nstep_last = nstep;
+  const double Instep = 1.0 / (double)nstep;
+  const double dtbt = dt * Instep;
+  const double dgeo_de = 1.0 + P.G_extra;
+
+  HIPCHK(hipMemsetAsync(work, 0, (size_t)W_COUNT * slab * sizeof(double), st));
+  hipLaunchKernelGGL(k_bt_copy_in, grid3(d.ni + 2 * d.halo + 1, d.nj + 2 * d.halo + 1, 1, b), b, 0, st, d, work, eta_in,
+                     eta_PF_in, s->q_D, s->D_u_Cor, s->D_v_Cor);
+
+  // ---- 3-D -> 2-D column pass
+  ColArgs Au;
+  memset(&Au, 0, sizeof(Au));
+  Au.visc_rem = visc_rem_u; Au.frhat = s->frhatu; Au.U_Cor = U_Cor; Au.pbce = pbce; Au.uh0 = uh0; Au.u_uh0 = u_uh0;
+  Au.U_in = U_in; Au.bc_accel = bc_accel_u; Au.tau = taux; Au.tau_bot = taux_bot; Au.IDat = s->IDatu;
+  Au.ubt_Cor = work + W_ubt_Cor * slab; Au.gtot_m = work + W_gtot_E * slab; Au.gtot_p = work + W_gtot_W * slab;
+  Au.uh0sum = work + W_uh0sum * slab; Au.ubt0 = work + W_ubt0 * slab; Au.ubt = work + W_ubt * slab;
+  Au.BT_force = work + W_BT_force_u * slab; Au.bt_rem = work + W_bt_rem_u * slab;
+  Au.Instep = Instep; Au.RZ_to_H = c->GV.RZ_to_H; Au.vel_underflow = P.vel_underflow; Au.nstep = nstep;
+  Au.wt_uv_bug = P.wt_uv_bug; Au.visc_rem_u_uh0 = P.visc_rem_u_uh0; Au.strong_drag = P.strong_drag;
+  ColArgs Av = Au;
+  Av.visc_rem = visc_rem_v; Av.frhat = s->frhatv; Av.U_Cor = V_Cor; Av.uh0 = vh0; Av.u_uh0 = v_vh0; Av.U_in = V_in;
+  Av.bc_accel = bc_accel_v; Av.tau = tauy; Av.tau_bot = tauy_bot; Av.IDat = s->IDatv;
+  Av.ubt_Cor = work + W_vbt_Cor * slab; Av.gtot_m = work + W_gtot_N * slab; Av.gtot_p = work + W_gtot_S * slab;
+  Av.uh0sum = work + W_vh0sum * slab; Av.ubt0 = work + W_vbt0 * slab; Av.ubt = work + W_vbt * slab;
+  Av.BT_force = work + W_BT_force_v * slab; Av.bt_rem = work + W_bt_rem_v * slab;
+  hipLaunchKernelGGL(k_bt_col<0>, grid3(d.ni + 1, d.nj, 1, b), b, 0, st, d, c->G, Au);
+  hipLaunchKernelGGL(k_bt_col<1>, grid3(d.ni, d.nj + 1, 1, b), b, 0, st, d, c->G, Av);
+
+  // ---- BT_cont fits (set_local_BT_cont_types, halo = 1+ievf-ie)
+  double *tmp = work + W_BTtmp * slab;
+  hipLaunchKernelGGL(k_btcont_copy, grid3(d.ni + 1, d.nj + 1, 1, b), b, 0, st, d, *BT_cont, tmp);
+  {
+    double *f[12]; int stg[12], nks[12];
+    for (int m = 0; m < 12; m++) { f[m] = tmp + (size_t)m * slab; stg[m] = (m < 6) ? 1 : 2; nks[m] = 1; }
+    halo_wrap(c, f, stg, nks, 12);
+  }
+  const int hs = 1 + ievf - ie;
+  hipLaunchKernelGGL(k_btcl, grid3(d.ni + 2 * hs + 1, d.nj + 2 * hs + 1, 1, b), b, 0, st, d, tmp, work + W_BTCu * slab,
+                     work + W_BTCv * slab, hs);
+  if (add_uh0) hipLaunchKernelGGL(k_uhbt0, grid3(d.ni + 1, d.nj + 1, 1, b), b, 0, st, d, work, work);
+
+  hipLaunchKernelGGL(k_find_Cor, grid3(ievf - isvf + 3, jevf - jsvf + 3, 1, b), b, 0, st, d, work, P.Sadourny, isvf, ievf, jsvf, jevf);
+  {
+    double *f[] = { work + W_gtot_E * slab, work + W_gtot_N * slab, work + W_gtot_W * slab, work + W_gtot_S * slab,
+                    work + W_ubt_Cor * slab, work + W_vbt_Cor * slab };
+    const int stg[] = { 0, 0, 0, 0, 1, 2 }, nks[] = { 1, 1, 1, 1, 1, 1 };
+    halo_wrap(c, f, stg, nks, 6);
+  }
+  hipLaunchKernelGGL(k_cor_ref_eta_src, grid3(d.ni + 1, d.nj + 1, 1, b), b, 0, st, d, c->G, work, s->eta_cor, Instep,
+                     P.bound_BT_corr, P.maxCFL_BT_cont * Idt, dt, c->GV.Z_to_H);
+  {
+    std::vector<double *> f = { work + W_eta_PF * slab, work + W_eta_src * slab, work + W_bt_rem_u * slab, work + W_bt_rem_v * slab,
+                                work + W_BT_force_u * slab, work + W_BT_force_v * slab };
+    std::vector<int> stg = { 0, 0, 1, 2, 1, 2 };
+    if (add_uh0) { f.push_back(work + W_uhbt0 * slab); stg.push_back(1); f.push_back(work + W_vhbt0 * slab); stg.push_back(2); }
+    f.push_back(work + W_Cor_ref_u * slab); stg.push_back(1); f.push_back(work + W_Cor_ref_v * slab); stg.push_back(2);
+    std::vector<int> nks(f.size(), 1);
+    halo_wrap(c, f.data(), stg.data(), nks.data(), (int)f.size());
+  }
+
+  // ---- filter weights :1726-1795 (host, 1-based)
+  double dt_filt;
+  if (P.dt_bt_filter >= 0.0) dt_filt = 0.5 * fmax(0.0, fmin(P.dt_bt_filter, 2.0 * dt));
+  else dt_filt = 0.5 * fmax(0.0, dt * fmin(-P.dt_bt_filter, 2.0));
+  const int nfilter = (int)ceil(dt_filt / dtbt);
+  const int nt = nstep + nfilter;
+  REQUIRE(nt > 0, MOM6X_EINVAL, "btstep: number of barotropic step (nstep+nfilter) is 0");
+  std::vector<double> wt_vel(nt + 2, 0.0), wt_eta(nt + 2, 0.0), wt_trans(nt + 2, 0.0), wt_accel(nt + 2, 0.0), wt_accel2(nt + 2, 0.0);
+  double sum_wt_vel = 0.0, sum_wt_eta = 0.0, sum_wt_accel = 0.0, sum_wt_trans = 0.0;
+  for (int n = 1; n <= nt; n++) {
+    if ((n == nstep) || (dt_filt - abs(n - nstep) * dtbt >= 0.0)) { wt_vel[n] = 1.0; wt_eta[n] = 1.0; }
+    else if (dtbt + dt_filt - abs(n - nstep) * dtbt > 0.0) { wt_vel[n] = 1.0 + (dt_filt / dtbt) - abs(n - nstep); wt_eta[n] = wt_vel[n]; }
+    else { wt_vel[n] = 0.0; wt_eta[n] = 0.0; }
+    sum_wt_vel = sum_wt_vel + wt_vel[n]; sum_wt_eta = sum_wt_eta + wt_eta[n];
+  }
+  for (int n = nt; n >= 1; n--) {
+    wt_trans[n] = wt_trans[n + 1] + wt_eta[n];
+    wt_accel[n] = wt_accel[n + 1] + wt_vel[n];
+    sum_wt_accel = sum_wt_accel + wt_accel[n]; sum_wt_trans = sum_wt_trans + wt_trans[n];
+  }
+  const double I_sum_wt_vel = 1.0 / sum_wt_vel, I_sum_wt_accel = 1.0 / sum_wt_accel;
+  const double I_sum_wt_eta = 1.0 / sum_wt_eta, I_sum_wt_trans = 1.0 / sum_wt_trans;
+  for (int n = 1; n <= nt; n++) {
+    wt_vel[n] = wt_vel[n] * I_sum_wt_vel;
+    wt_accel2[n] = wt_accel[n] * I_sum_wt_accel;
+    wt_trans[n] = wt_trans[n] * I_sum_wt_trans;
+    wt_accel[n] = wt_accel[n] * I_sum_wt_accel;
+    wt_eta[n] = wt_eta[n] * I_sum_wt_eta;
+  }
+
+  // ---- the time loop :2175-2834
+  HIPCHK(hipMemsetAsync(s->ubtav, 0, slab * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(s->vbtav, 0, slab * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(uhbtav, 0, slab * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(vhbtav, 0, slab * sizeof(double), st));
+  LoopArgs L;
+  memset(&L, 0, sizeof(L));
+  L.dtbt = dtbt; L.dgeo_de = dgeo_de; L.vel_underflow = P.vel_underflow;
+  if (P.BT_project_velocity) { L.trans_wt1 = (1.0 + P.bebt); L.trans_wt2 = -P.bebt; }
+  else { L.trans_wt1 = P.bebt; L.trans_wt2 = (1.0 - P.bebt); }
+  L.project = P.BT_project_velocity; L.find_etaav = (etaav != nullptr);
+  int isv = is, iev = ie, jsv = js, jev = je;
+  double *loop_f[] = { work + W_eta * slab, work + W_ubt * slab, work + W_vbt * slab };
+  const int loop_stg[] = { 0, 1, 2 }, loop_nk[] = { 1, 1, 1 };
+  for (int n = 1; n <= nt; n++) {
+    if (P.clip_velocity)
+      hipLaunchKernelGGL(k_bt_clip, grid3(iev - isv + 2, jev - jsv + 2, 1, b), b, 0, st, d, c->G, work, dt, P.CFL_trunc, isv, iev, jsv, jev);
+    if ((iev - stencil < ie) || (jev - stencil < je)) {
+      halo_wrap(c, loop_f, loop_stg, loop_nk, 3);
+      isv = isvf; iev = ievf; jsv = jsvf; jev = jevf;
+    } else {
+      isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil;
+    }
+    L.isv = isv; L.iev = iev; L.jsv = jsv; L.jev = jev;
+    L.wt_accel = wt_accel[n]; L.wt_trans = wt_trans[n]; L.wt_vel = wt_vel[n]; L.wt_eta = wt_eta[n]; L.wt_accel2 = wt_accel2[n];
+    if (!P.BT_project_velocity || L.find_etaav)
+      hipLaunchKernelGGL(k_bt_pred, grid3(iev - isv + 3, jev - jsv + 3, 1, b), b, 0, st, d, c->G, work, L);
+    const bool v_first = (((n + c->first_direction) % 2) == 1);
+    if (v_first) {
+      hipLaunchKernelGGL(k_bt_vel<1>, grid3(iev - isv + 3, jev - jsv + 2, 1, b), b, 0, st, d, c->G, work, s->vbtav, vhbtav, L,
+                         isv - 1, iev + 1, jsv - 1, jev, 0);
+      hipLaunchKernelGGL(k_bt_vel<0>, grid3(iev - isv + 2, jev - jsv + 1, 1, b), b, 0, st, d, c->G, work, s->ubtav, uhbtav, L,
+                         isv - 1, iev, jsv, jev, 0);
+    } else {
+      hipLaunchKernelGGL(k_bt_vel<0>, grid3(iev - isv + 2, jev - jsv + 3, 1, b), b, 0, st, d, c->G, work, s->ubtav, uhbtav, L,
+                         isv - 1, iev, jsv - 1, jev + 1, 0);
+      hipLaunchKernelGGL(k_bt_vel<1>, grid3(iev - isv + 1, jev - jsv + 2, 1, b), b, 0, st, d, c->G, work, s->vbtav, vhbtav, L,
+                         isv, iev, jsv - 1, jev, P.use_old_coriolis_bracket_bug);
+    }
+    hipLaunchKernelGGL(k_bt_eta, grid3(iev - isv + 1, jev - jsv + 1, 1, b), b, 0, st, d, c->G, work, L);
+  }
+
+  // ---- after the loop
+  hipLaunchKernelGGL(k_bt_post, grid3(d.ni, d.nj, 1, b), b, 0, st, d, work, eta_in, eta_out, etaav, dgeo_de, 1.0, 1.0);
+  {
+    std::vector<double *> f; std::vector<int> stg;
+    if (etaav) { f.push_back(etaav); stg.push_back(0); }
+    f.push_back(work + W_e_anom * slab); stg.push_back(0);
+    f.push_back(s->ubtav); stg.push_back(1); f.push_back(s->vbtav); stg.push_back(2);
+    f.push_back(uhbtav); stg.push_back(1); f.push_back(vhbtav); stg.push_back(2);
+    std::vector<int> nks(f.size(), 1);
+    halo_wrap(c, f.data(), stg.data(), nks.data(), (int)f.size());
+  }
+  hipLaunchKernelGGL(k_layer_accel, grid3(d.ni + 1, d.nj + 1, d.nk, b), b, 0, st, d, c->G, work, pbce, accel_layer_u,
+                     accel_layer_v, P.vel_underflow * Idt);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}

@@ -104,3 +104,55 @@ class Dycore:
             _ptr(du_cor), _ptr(dv_cor)))
 
     continuity = continuity_PPM  # MOM_continuity.F90:6-28 pass-through name
+
+    # -- MOM_barotropic ----------------------------------------------------------------------
+    def barotropic_init(self, params):
+        """barotropic_init (MOM_barotropic.F90:5301): static fields q_D, D_[uv]_Cor, IDat[uv]."""
+        self.bt_params = params
+        check(self.lib, self.lib.mom6x_barotropic_init(self.ctx, C.byref(params)))
+
+    _BT_FIELDS = {"ubtav": (0, 2), "vbtav": (1, 2), "eta_cor": (2, 2), "frhatu": (3, 3), "frhatv": (4, 3),
+                  "IDatu": (5, 2), "IDatv": (6, 2), "q_D": (7, 2), "D_u_Cor": (8, 2), "D_v_Cor": (9, 2)}
+
+    def barotropic_field(self, name):
+        """A zero-copy torch view of a barotropic_CS array owned by the context."""
+        which, nd = self._BT_FIELDS[name]
+        ptr = self.lib.mom6x_barotropic_field(self.ctx, C.c_int(which))
+        shape = self.dims.shape2() if nd == 2 else self.dims.shape3()
+        return _view(ptr, shape, self.device)
+
+    def btcalc(self, h, h_u=None, h_v=None):
+        """btcalc (MOM_barotropic.F90:4360)."""
+        check(self.lib, self.lib.mom6x_btcalc(self.ctx, _ptr(h), _ptr(h_u), _ptr(h_v)))
+
+    def bt_mass_source(self, h, eta, set_cor):
+        """bt_mass_source (MOM_barotropic.F90:5243)."""
+        check(self.lib, self.lib.mom6x_bt_mass_source(self.ctx, _ptr(h), _ptr(eta), C.c_int(int(set_cor))))
+
+    def set_dtbt(self, pbce=None, gtot_est=0.0, SSH_add=0.0):
+        """set_dtbt (MOM_barotropic.F90:3509); returns CS%dtbt."""
+        out = C.c_double(0.0)
+        check(self.lib, self.lib.mom6x_set_dtbt(self.ctx, _ptr(pbce), C.c_double(gtot_est), C.c_double(SSH_add), C.byref(out)))
+        return out.value
+
+    def btstep(self, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, pbce, eta_PF_in, U_Cor, V_Cor,
+               accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v, BT_cont,
+               taux_bot=None, tauy_bot=None, uh0=None, vh0=None, u_uh0=None, v_vh0=None, etaav=None):
+        """btstep (MOM_barotropic.F90:455); forces%taux/tauy are passed as planes."""
+        check(self.lib, self.lib.mom6x_btstep(
+            self.ctx, _ptr(U_in), _ptr(V_in), _ptr(eta_in), C.c_double(dt), _ptr(bc_accel_u), _ptr(bc_accel_v),
+            _ptr(taux), _ptr(tauy), _ptr(pbce), _ptr(eta_PF_in), _ptr(U_Cor), _ptr(V_Cor), _ptr(accel_layer_u),
+            _ptr(accel_layer_v), _ptr(eta_out), _ptr(uhbtav), _ptr(vhbtav), _ptr(visc_rem_u), _ptr(visc_rem_v),
+            C.byref(BT_cont.struct), _ptr(taux_bot), _ptr(tauy_bot), _ptr(uh0), _ptr(vh0), _ptr(u_uh0), _ptr(v_vh0),
+            _ptr(etaav)))
+
+
+def _view(ptr, shape, device):
+    """torch tensor aliasing device memory owned by the C library."""
+    n = int(np.prod(shape))
+
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device=device).view(shape)

@@ -64,3 +64,63 @@ def continuity_PPM(d, G, GV, CS, first_direction, u, v, hin, h, uh, vh, dt, uhbt
                                   C.byref(bts) if bts is not None else None, _p(du_cor), _p(dv_cor))
     if rc != 0:
         raise RuntimeError(f"orc_continuity_PPM rc={rc}")
+
+
+# ------------------------------------------------------------------------------------------
+# MOM_barotropic
+class BtCS(C.Structure):
+    """orc_bt_cs: the persistent part of barotropic_CS (host arrays)."""
+    _names = ["frhatu", "frhatv", "IDatu", "IDatv", "ubtav", "vbtav", "eta_cor", "q_D", "D_u_Cor", "D_v_Cor"]
+    _fields_ = [(n, C.c_void_p) for n in _names]
+
+
+class BtState:
+    def __init__(self, d):
+        self.f = {}
+        for n in BtCS._names:
+            self.f[n] = np.zeros(d.shape3() if n.startswith("frhat") else d.shape2())
+        self.struct = BtCS()
+        for n in BtCS._names:
+            setattr(self.struct, n, self.f[n].ctypes.data)
+
+    def __getitem__(self, n):
+        return self.f[n]
+
+
+def barotropic_init(d, G, GV, P, cs):
+    rc = lib().orc_barotropic_init(C.byref(d), _p(G), C.byref(GV), C.byref(P), C.byref(cs.struct))
+    assert rc == 0, rc
+
+
+def btcalc(d, G, GV, h, h_u, h_v, cs):
+    rc = lib().orc_btcalc(C.byref(d), _p(G), C.byref(GV), _p(h), _p(h_u), _p(h_v), C.byref(cs.struct))
+    assert rc == 0, rc
+
+
+def bt_mass_source(d, G, GV, h, eta, set_cor, cs):
+    rc = lib().orc_bt_mass_source(C.byref(d), _p(G), C.byref(GV), _p(h), _p(eta), C.c_int(int(set_cor)), C.byref(cs.struct))
+    assert rc == 0, rc
+
+
+def set_dtbt(d, G, GV, P, cs, pbce=None, gtot_est=0.0, SSH_add=0.0):
+    dtbt = C.c_double(0.0); dtbt_max = C.c_double(0.0)
+    rc = lib().orc_set_dtbt(C.byref(d), _p(G), C.byref(GV), C.byref(P), C.byref(cs.struct), _p(pbce),
+                            C.c_double(gtot_est), C.c_double(SSH_add), C.byref(dtbt), C.byref(dtbt_max))
+    assert rc == 0, rc
+    return dtbt.value, dtbt_max.value
+
+
+def btstep(d, G, GV, P, cs, first_direction, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, pbce,
+           eta_PF_in, U_Cor, V_Cor, accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v,
+           BT_cont, taux_bot=None, tauy_bot=None, uh0=None, vh0=None, u_uh0=None, v_vh0=None, etaav=None):
+    bts = bt_cont_struct(BT_cont)
+    nstep = C.c_int(0)
+    rc = lib().orc_btstep(C.byref(d), _p(G), C.byref(GV), C.byref(P), C.byref(cs.struct), C.c_int(first_direction),
+                          _p(U_in), _p(V_in), _p(eta_in), C.c_double(dt), _p(bc_accel_u), _p(bc_accel_v),
+                          _p(taux), _p(tauy), _p(pbce), _p(eta_PF_in), _p(U_Cor), _p(V_Cor),
+                          _p(accel_layer_u), _p(accel_layer_v), _p(eta_out), _p(uhbtav), _p(vhbtav),
+                          _p(visc_rem_u), _p(visc_rem_v), C.byref(bts), _p(taux_bot), _p(tauy_bot),
+                          _p(uh0), _p(vh0), _p(u_uh0), _p(v_vh0), _p(etaav), C.byref(nstep))
+    if rc != 0:
+        raise RuntimeError(f"orc_btstep rc={rc}")
+    return nstep.value
