@@ -169,6 +169,13 @@ int  mom6x_ctx_sync(mom6x_ctx *ctx);
 const mom6x_dims *mom6x_ctx_dims(const mom6x_ctx *ctx);
 const double *mom6x_ctx_metrics_dev(const mom6x_ctx *ctx);
 
+/* Per-kernel timing (HIP events on the compute stream around every launch).  Mirrors the
+ * reference's cpu_clock_begin/end brackets (e.g. MOM_dynamics_split_RK2.F90:502/538) at kernel
+ * granularity.  mom6x_prof_report writes "name<TAB>count<TAB>total_ms" lines into buf.       */
+int mom6x_prof_enable(mom6x_ctx *ctx, int on);
+int mom6x_prof_reset(mom6x_ctx *ctx);
+int mom6x_prof_report(mom6x_ctx *ctx, char *buf, int buflen);
+
 /* Device memory helpers for non-torch hosts (Fortran).                       */
 int mom6x_dev_alloc(mom6x_ctx *ctx, double **p, size_t n_doubles);
 int mom6x_dev_free(mom6x_ctx *ctx, double *p);

@@ -600,7 +600,7 @@ extern "C" int mom6x_barotropic_init(mom6x_ctx *c, const mom6x_barotropic_params
   BTState *s = c->bts;
   s->nstep_last = 0;
   const dim3 b = blk2();
-  hipLaunchKernelGGL(k_bt_init_static, grid3(d.ni + 1, d.nj + 1, 1, b), b, 0, c->stream, d, c->G, c->GV.Z_to_H, p->Z_ref,
+  KLAUNCH(c, "k_bt_init_static", k_bt_init_static, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, c->G, c->GV.Z_to_H, p->Z_ref,
                      p->BT_Coriolis_scale, c->GV.H_subroundoff, s->q_D, s->D_u_Cor, s->D_v_Cor, s->IDatu, s->IDatv);
   double *f[] = { s->q_D, s->D_u_Cor, s->D_v_Cor };
   const int stg[] = { 3, 1, 2 }, nks[] = { 1, 1, 1 };
@@ -628,9 +628,9 @@ extern "C" int mom6x_btcalc(mom6x_ctx *c, const double *h, const double *h_u, co
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   const dim3 b = blk2();
-  hipLaunchKernelGGL(k_btcalc<0>, grid3(d.ni + 1, d.nj, 1, b), b, 0, c->stream, d, c->G, h, h_u, c->bts->frhatu,
+  KLAUNCH(c, "k_btcalc<0>", k_btcalc<0>, grid3(d.ni + 1, d.nj, 1, b), b, d, c->G, h, h_u, c->bts->frhatu,
                      c->GV.H_subroundoff, c->GV.Z_to_H);
-  hipLaunchKernelGGL(k_btcalc<1>, grid3(d.ni, d.nj + 1, 1, b), b, 0, c->stream, d, c->G, h, h_v, c->bts->frhatv,
+  KLAUNCH(c, "k_btcalc<1>", k_btcalc<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, h, h_v, c->bts->frhatv,
                      c->GV.H_subroundoff, c->GV.Z_to_H);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
@@ -641,7 +641,7 @@ extern "C" int mom6x_bt_mass_source(mom6x_ctx *c, const double *h, const double 
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   const dim3 b = blk2();
-  hipLaunchKernelGGL(k_bt_mass_source, grid3(d.ni, d.nj, 1, b), b, 0, c->stream, d, c->G, h, eta, c->bts->eta_cor, set_cor,
+  KLAUNCH(c, "k_bt_mass_source", k_bt_mass_source, grid3(d.ni, d.nj, 1, b), b, d, c->G, h, eta, c->bts->eta_cor, set_cor,
                      c->GV.Z_to_H);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
@@ -655,7 +655,7 @@ extern "C" int mom6x_set_dtbt(mom6x_ctx *c, const double *pbce, double gtot_est,
   BTState *s = c->bts;
   double *tmp = s->work + (size_t)W_eta_pred * d.slab;   // scratch plane
   HIPCHK(hipMemsetAsync(tmp, 0, sizeof(double) * d.slab, c->stream));
-  hipLaunchKernelGGL(k_set_dtbt, grid3(d.ni, d.nj, 1, b), b, 0, c->stream, d, c->G, pbce, s->frhatu, s->frhatv, gtot_est,
+  KLAUNCH(c, "k_set_dtbt", k_set_dtbt, grid3(d.ni, d.nj, 1, b), b, d, c->G, pbce, s->frhatu, s->frhatv, gtot_est,
                      c->GV.Z_to_H, c->bt.Z_ref + SSH_add, c->bt.bebt, c->bt.BT_Coriolis_scale * c->bt.BT_Coriolis_scale, tmp);
   HIPCHK(hipGetLastError());
   // min over the tile in the reference's (j outer, i inner) order is order-independent for min():
@@ -715,7 +715,7 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   const double dgeo_de = 1.0 + P.G_extra;
 
   HIPCHK(hipMemsetAsync(work, 0, (size_t)W_COUNT * slab * sizeof(double), st));
-  hipLaunchKernelGGL(k_bt_copy_in, grid3(d.ni + 2 * d.halo + 1, d.nj + 2 * d.halo + 1, 1, b), b, 0, st, d, work, eta_in,
+  KLAUNCH(c, "k_bt_copy_in", k_bt_copy_in, grid3(d.ni + 2 * d.halo + 1, d.nj + 2 * d.halo + 1, 1, b), b, d, work, eta_in,
                      eta_PF_in, s->q_D, s->D_u_Cor, s->D_v_Cor);
 
   // ---- 3-D -> 2-D column pass
@@ -734,30 +734,30 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   Av.ubt_Cor = work + W_vbt_Cor * slab; Av.gtot_m = work + W_gtot_N * slab; Av.gtot_p = work + W_gtot_S * slab;
   Av.uh0sum = work + W_vh0sum * slab; Av.ubt0 = work + W_vbt0 * slab; Av.ubt = work + W_vbt * slab;
   Av.BT_force = work + W_BT_force_v * slab; Av.bt_rem = work + W_bt_rem_v * slab;
-  hipLaunchKernelGGL(k_bt_col<0>, grid3(d.ni + 1, d.nj, 1, b), b, 0, st, d, c->G, Au);
-  hipLaunchKernelGGL(k_bt_col<1>, grid3(d.ni, d.nj + 1, 1, b), b, 0, st, d, c->G, Av);
+  KLAUNCH(c, "k_bt_col<0>", k_bt_col<0>, grid3(d.ni + 1, d.nj, 1, b), b, d, c->G, Au);
+  KLAUNCH(c, "k_bt_col<1>", k_bt_col<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, Av);
 
   // ---- BT_cont fits (set_local_BT_cont_types, halo = 1+ievf-ie)
   double *tmp = work + W_BTtmp * slab;
-  hipLaunchKernelGGL(k_btcont_copy, grid3(d.ni + 1, d.nj + 1, 1, b), b, 0, st, d, *BT_cont, tmp);
+  KLAUNCH(c, "k_btcont_copy", k_btcont_copy, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, *BT_cont, tmp);
   {
     double *f[12]; int stg[12], nks[12];
     for (int m = 0; m < 12; m++) { f[m] = tmp + (size_t)m * slab; stg[m] = (m < 6) ? 1 : 2; nks[m] = 1; }
     halo_wrap(c, f, stg, nks, 12);
   }
   const int hs = 1 + ievf - ie;
-  hipLaunchKernelGGL(k_btcl, grid3(d.ni + 2 * hs + 1, d.nj + 2 * hs + 1, 1, b), b, 0, st, d, tmp, work + W_BTCu * slab,
+  KLAUNCH(c, "k_btcl", k_btcl, grid3(d.ni + 2 * hs + 1, d.nj + 2 * hs + 1, 1, b), b, d, tmp, work + W_BTCu * slab,
                      work + W_BTCv * slab, hs);
-  if (add_uh0) hipLaunchKernelGGL(k_uhbt0, grid3(d.ni + 1, d.nj + 1, 1, b), b, 0, st, d, work, work);
+  if (add_uh0) KLAUNCH(c, "k_uhbt0", k_uhbt0, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, work, work);
 
-  hipLaunchKernelGGL(k_find_Cor, grid3(ievf - isvf + 3, jevf - jsvf + 3, 1, b), b, 0, st, d, work, P.Sadourny, isvf, ievf, jsvf, jevf);
+  KLAUNCH(c, "k_find_Cor", k_find_Cor, grid3(ievf - isvf + 3, jevf - jsvf + 3, 1, b), b, d, work, P.Sadourny, isvf, ievf, jsvf, jevf);
   {
     double *f[] = { work + W_gtot_E * slab, work + W_gtot_N * slab, work + W_gtot_W * slab, work + W_gtot_S * slab,
                     work + W_ubt_Cor * slab, work + W_vbt_Cor * slab };
     const int stg[] = { 0, 0, 0, 0, 1, 2 }, nks[] = { 1, 1, 1, 1, 1, 1 };
     halo_wrap(c, f, stg, nks, 6);
   }
-  hipLaunchKernelGGL(k_cor_ref_eta_src, grid3(d.ni + 1, d.nj + 1, 1, b), b, 0, st, d, c->G, work, s->eta_cor, Instep,
+  KLAUNCH(c, "k_cor_ref_eta_src", k_cor_ref_eta_src, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, c->G, work, s->eta_cor, Instep,
                      P.bound_BT_corr, P.maxCFL_BT_cont * Idt, dt, c->GV.Z_to_H);
   {
     std::vector<double *> f = { work + W_eta_PF * slab, work + W_eta_src * slab, work + W_bt_rem_u * slab, work + W_bt_rem_v * slab,
@@ -815,7 +815,7 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   const int loop_stg[] = { 0, 1, 2 }, loop_nk[] = { 1, 1, 1 };
   for (int n = 1; n <= nt; n++) {
     if (P.clip_velocity)
-      hipLaunchKernelGGL(k_bt_clip, grid3(iev - isv + 2, jev - jsv + 2, 1, b), b, 0, st, d, c->G, work, dt, P.CFL_trunc, isv, iev, jsv, jev);
+      KLAUNCH(c, "k_bt_clip", k_bt_clip, grid3(iev - isv + 2, jev - jsv + 2, 1, b), b, d, c->G, work, dt, P.CFL_trunc, isv, iev, jsv, jev);
     if ((iev - stencil < ie) || (jev - stencil < je)) {
       halo_wrap(c, loop_f, loop_stg, loop_nk, 3);
       isv = isvf; iev = ievf; jsv = jsvf; jev = jevf;
@@ -825,24 +825,24 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     L.isv = isv; L.iev = iev; L.jsv = jsv; L.jev = jev;
     L.wt_accel = wt_accel[n]; L.wt_trans = wt_trans[n]; L.wt_vel = wt_vel[n]; L.wt_eta = wt_eta[n]; L.wt_accel2 = wt_accel2[n];
     if (!P.BT_project_velocity || L.find_etaav)
-      hipLaunchKernelGGL(k_bt_pred, grid3(iev - isv + 3, jev - jsv + 3, 1, b), b, 0, st, d, c->G, work, L);
+      KLAUNCH(c, "k_bt_pred", k_bt_pred, grid3(iev - isv + 3, jev - jsv + 3, 1, b), b, d, c->G, work, L);
     const bool v_first = (((n + c->first_direction) % 2) == 1);
     if (v_first) {
-      hipLaunchKernelGGL(k_bt_vel<1>, grid3(iev - isv + 3, jev - jsv + 2, 1, b), b, 0, st, d, c->G, work, s->vbtav, vhbtav, L,
+      KLAUNCH(c, "k_bt_vel<1>", k_bt_vel<1>, grid3(iev - isv + 3, jev - jsv + 2, 1, b), b, d, c->G, work, s->vbtav, vhbtav, L,
                          isv - 1, iev + 1, jsv - 1, jev, 0);
-      hipLaunchKernelGGL(k_bt_vel<0>, grid3(iev - isv + 2, jev - jsv + 1, 1, b), b, 0, st, d, c->G, work, s->ubtav, uhbtav, L,
+      KLAUNCH(c, "k_bt_vel<0>", k_bt_vel<0>, grid3(iev - isv + 2, jev - jsv + 1, 1, b), b, d, c->G, work, s->ubtav, uhbtav, L,
                          isv - 1, iev, jsv, jev, 0);
     } else {
-      hipLaunchKernelGGL(k_bt_vel<0>, grid3(iev - isv + 2, jev - jsv + 3, 1, b), b, 0, st, d, c->G, work, s->ubtav, uhbtav, L,
+      KLAUNCH(c, "k_bt_vel<0>", k_bt_vel<0>, grid3(iev - isv + 2, jev - jsv + 3, 1, b), b, d, c->G, work, s->ubtav, uhbtav, L,
                          isv - 1, iev, jsv - 1, jev + 1, 0);
-      hipLaunchKernelGGL(k_bt_vel<1>, grid3(iev - isv + 1, jev - jsv + 2, 1, b), b, 0, st, d, c->G, work, s->vbtav, vhbtav, L,
+      KLAUNCH(c, "k_bt_vel<1>", k_bt_vel<1>, grid3(iev - isv + 1, jev - jsv + 2, 1, b), b, d, c->G, work, s->vbtav, vhbtav, L,
                          isv, iev, jsv - 1, jev, P.use_old_coriolis_bracket_bug);
     }
-    hipLaunchKernelGGL(k_bt_eta, grid3(iev - isv + 1, jev - jsv + 1, 1, b), b, 0, st, d, c->G, work, L);
+    KLAUNCH(c, "k_bt_eta", k_bt_eta, grid3(iev - isv + 1, jev - jsv + 1, 1, b), b, d, c->G, work, L);
   }
 
   // ---- after the loop
-  hipLaunchKernelGGL(k_bt_post, grid3(d.ni, d.nj, 1, b), b, 0, st, d, work, eta_in, eta_out, etaav, dgeo_de, 1.0, 1.0);
+  KLAUNCH(c, "k_bt_post", k_bt_post, grid3(d.ni, d.nj, 1, b), b, d, work, eta_in, eta_out, etaav, dgeo_de, 1.0, 1.0);
   {
     std::vector<double *> f; std::vector<int> stg;
     if (etaav) { f.push_back(etaav); stg.push_back(0); }
@@ -852,7 +852,7 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     std::vector<int> nks(f.size(), 1);
     halo_wrap(c, f.data(), stg.data(), nks.data(), (int)f.size());
   }
-  hipLaunchKernelGGL(k_layer_accel, grid3(d.ni + 1, d.nj + 1, d.nk, b), b, 0, st, d, c->G, work, pbce, accel_layer_u,
+  KLAUNCH(c, "k_layer_accel", k_layer_accel, grid3(d.ni + 1, d.nj + 1, d.nk, b), b, d, c->G, work, pbce, accel_layer_u,
                      accel_layer_v, P.vel_underflow * Idt);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;

@@ -415,7 +415,7 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
   int ei0 = ish, ei1 = ieh, ej0 = jsh, ej1 = jeh;
   if (DIR == 0) { ei0 = ish - 1; ei1 = ieh + 1; } else { ej0 = jsh - 1; ej1 = jeh + 1; }
   const int scheme = P.upwind_1st ? 2 : (P.simple_2nd ? 1 : 0);
-  hipLaunchKernelGGL(k_edge<DIR>, grid3(ei1 - ei0 + 1, ej1 - ej0 + 1, d.nk, blk), blk, 0, c->stream, d, c->G, h_src,
+  KLAUNCH(c, "k_edge<DIR>", k_edge<DIR>, grid3(ei1 - ei0 + 1, ej1 - ej0 + 1, d.nk, blk), blk, d, c->G, h_src,
                      c->hL, c->hR, 2.0 * c->GV.Angstrom_H, scheme, P.monotonic, ei0, ei1, ej0, ej1);
   FluxArgs A;
   memset(&A, 0, sizeof(A));
@@ -432,14 +432,14 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
   if (DIR == 0) { A.a0 = ish - 1; A.a1 = ieh; A.b0 = jsh; A.b1 = jeh; }
   else          { A.a0 = ish; A.a1 = ieh; A.b0 = jsh - 1; A.b1 = jeh; }
   if (du_cor) HIPCHK(hipMemsetAsync(du_cor, 0, sizeof(double) * d.slab, c->stream));
-  hipLaunchKernelGGL(k_mass_flux<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, 1, blk), blk, 0, c->stream, d, c->G, A);
+  KLAUNCH(c, "k_mass_flux<DIR>", k_mass_flux<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, 1, blk), blk, d, c->G, A);
   double *BT_h = BT ? (DIR == 0 ? BT->h_u : BT->h_v) : nullptr;
   if (BT_h) {
-    hipLaunchKernelGGL(k_flux_thickness<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, d.nk, blk), blk, 0, c->stream,
+    KLAUNCH(c, "k_flux_thickness<DIR>", k_flux_thickness<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, d.nk, blk), blk,
                        d, c->G, (u_cor ? (const double *)u_cor : u), h_src, c->hL, c->hR, BT_h, dt,
                        P.marginal_faces, visc_rem, A.a0, A.a1, A.b0, A.b1);
   }
-  hipLaunchKernelGGL(k_convergence<DIR>, grid3(ieh - ish + 1, jeh - jsh + 1, d.nk, blk), blk, 0, c->stream, d, c->G,
+  KLAUNCH(c, "k_convergence<DIR>", k_convergence<DIR>, grid3(ieh - ish + 1, jeh - jsh + 1, d.nk, blk), blk, d, c->G,
                      h, uh, dt, hin_conv, h_min_conv, ish, ieh, jsh, jeh);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;

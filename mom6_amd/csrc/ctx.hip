@@ -3,7 +3,90 @@
 #include <vector>
 #include "mom6x_dev.h"
 
+#include <map>
 static thread_local char g_err[512] = "";
+
+struct ProfRec { int id; hipEvent_t a, b; };
+struct Prof {
+  std::vector<std::string> names;
+  std::map<std::string, int> ids;
+  std::vector<ProfRec> recs;
+  std::vector<double> ms;
+  std::vector<long> count;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t cur_a;
+  int cur_id;
+};
+
+static hipEvent_t prof_event(Prof *p) {
+  if (!p->pool.empty()) { hipEvent_t e = p->pool.back(); p->pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(mom6x_ctx *c, const char *name) {
+  Prof *p = c->prof;
+  auto it = p->ids.find(name);
+  int id;
+  if (it == p->ids.end()) {
+    id = (int)p->names.size();
+    p->names.push_back(name); p->ids[name] = id; p->ms.push_back(0.0); p->count.push_back(0);
+  } else id = it->second;
+  p->cur_id = id;
+  p->cur_a = prof_event(p);
+  (void)hipEventRecord(p->cur_a, c->stream);
+}
+
+void prof_end(mom6x_ctx *c) {
+  Prof *p = c->prof;
+  ProfRec r; r.id = p->cur_id; r.a = p->cur_a; r.b = prof_event(p);
+  (void)hipEventRecord(r.b, c->stream);
+  p->recs.push_back(r);
+}
+
+static void prof_collect(mom6x_ctx *c) {
+  Prof *p = c->prof;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &r : p->recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { p->ms[r.id] += ms; p->count[r.id] += 1; }
+    p->pool.push_back(r.a); p->pool.push_back(r.b);
+  }
+  p->recs.clear();
+}
+
+extern "C" int mom6x_prof_enable(mom6x_ctx *c, int on) {
+  REQUIRE(c, MOM6X_EINVAL, "mom6x_prof_enable: null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->prof) c->prof = new Prof();
+  if (!on && c->prof_on) prof_collect(c);
+  c->prof_on = (on != 0);
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_prof_reset(mom6x_ctx *c) {
+  REQUIRE(c, MOM6X_EINVAL, "mom6x_prof_reset: null ctx");
+  if (!c->prof) return MOM6X_OK;
+  prof_collect(c);
+  for (auto &m : c->prof->ms) m = 0.0;
+  for (auto &n : c->prof->count) n = 0;
+  return MOM6X_OK;
+}
+
+// Writes "name\tcount\ttotal_ms\n" lines into buf; returns the number of bytes needed.
+extern "C" int mom6x_prof_report(mom6x_ctx *c, char *buf, int buflen) {
+  if (!c || !c->prof) { if (buf && buflen > 0) buf[0] = 0; return 0; }
+  prof_collect(c);
+  std::string out;
+  char line[256];
+  for (size_t i = 0; i < c->prof->names.size(); i++) {
+    snprintf(line, sizeof(line), "%s\t%ld\t%.6f\n", c->prof->names[i].c_str(), c->prof->count[i], c->prof->ms[i]);
+    out += line;
+  }
+  if (buf && buflen > 0) { strncpy(buf, out.c_str(), (size_t)buflen - 1); buf[buflen - 1] = 0; }
+  return (int)out.size() + 1;
+}
 
 void mom6x_set_error(const char *fmt, ...) {
   va_list ap;
@@ -53,6 +136,7 @@ extern "C" int mom6x_ctx_create(mom6x_ctx **out, const mom6x_dims *dims, int dev
   c->GV = *GV;
   c->first_direction = first_direction;
   c->cont_init = false; c->bt_init = false;
+  c->prof_on = false; c->prof = nullptr;
   c->hL = c->hR = nullptr; c->bts = nullptr; c->rk2 = nullptr; c->flag = nullptr; c->G = nullptr;
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
@@ -72,13 +156,13 @@ extern "C" int mom6x_ctx_create(mom6x_ctx **out, const mom6x_dims *dims, int dev
 
 extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
   if (!c) return MOM6X_OK;
-  hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
-  hipStreamSynchronize(c->halo_stream);
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->halo_stream);
   bt_state_free(c);
   rk2_state_free(c);
-  hipFree(c->G); hipFree(c->hL); hipFree(c->hR); hipFree(c->flag);
-  hipStreamDestroy(c->stream); hipStreamDestroy(c->halo_stream);
+  (void)hipFree(c->G); (void)hipFree(c->hL); (void)hipFree(c->hR); (void)hipFree(c->flag);
+  (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->halo_stream);
   delete c;
   return MOM6X_OK;
 }

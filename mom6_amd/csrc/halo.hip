@@ -65,11 +65,11 @@ void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const i
     const dim3 b(64, d.halo, 1);
     if (c->dims.reentrant_x) {
       const int rows = d.nj + 2 * d.halo + 1;
-      hipLaunchKernelGGL(k_wrap_x, dim3((rows + 63) / 64, 1, nkmax), b, 0, c->stream, d, A);
+      KLAUNCH(c, "k_wrap_x", k_wrap_x, dim3((rows + 63) / 64, 1, nkmax), b, d, A);
     }
     if (c->dims.reentrant_y) {
       const int cols = d.ni + 2 * d.halo + 1;
-      hipLaunchKernelGGL(k_wrap_y, dim3((cols + 63) / 64, 1, nkmax), b, 0, c->stream, d, A);
+      KLAUNCH(c, "k_wrap_y", k_wrap_y, dim3((cols + 63) / 64, 1, nkmax), b, d, A);
     }
   }
 }

@@ -70,7 +70,21 @@ struct mom6x_ctx {
   BTState *bts;
   RK2State *rk2;
   int *flag;                // device-side error flag (NaN / negative thickness)
+  bool prof_on;
+  struct Prof *prof;
 };
+
+// ---------------------------------------------------------------------------------------------
+// Per-kernel timing with HIP events on the compute stream (mom6x_prof_* in include/mom6x.h).
+// Off by default; when on, every KLAUNCH is bracketed by two events from a pool.
+void prof_begin(mom6x_ctx *c, const char *name);
+void prof_end(mom6x_ctx *c);
+#define KLAUNCH(c, name, kern, grid, blk, ...)                              \
+  do {                                                                      \
+    if ((c)->prof_on) prof_begin((c), name);                                \
+    hipLaunchKernelGGL(kern, grid, blk, 0, (c)->stream, __VA_ARGS__);       \
+    if ((c)->prof_on) prof_end((c));                                        \
+  } while (0)
 
 inline dim3 grid3(int nx, int ny, int nz, dim3 b) {
   return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z);

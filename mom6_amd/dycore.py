@@ -156,3 +156,23 @@ def _view(ptr, shape, device):
     h = _Holder()
     h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
     return torch.as_tensor(h, device=device).view(shape)
+
+
+def prof_enable(dyc, on=True):
+    check(dyc.lib, dyc.lib.mom6x_prof_enable(dyc.ctx, C.c_int(int(on))))
+
+
+def prof_reset(dyc):
+    check(dyc.lib, dyc.lib.mom6x_prof_reset(dyc.ctx))
+
+
+def prof_report(dyc):
+    """dict kernel-name -> (launch count, total ms) measured with HIP events on the compute stream."""
+    n = dyc.lib.mom6x_prof_report(dyc.ctx, None, C.c_int(0))
+    buf = C.create_string_buffer(max(n, 1) + 16)
+    dyc.lib.mom6x_prof_report(dyc.ctx, buf, C.c_int(len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split("\t")
+        out[name] = (int(cnt), float(ms))
+    return out
