@@ -139,6 +139,31 @@ typedef struct mom6x_barotropic_params {
   double Z_ref;                /* G%Z_ref (0)                                 */
 } mom6x_barotropic_params;
 
+/* CoriolisAdv_CS (src/core/MOM_CoriolisAdv.F90:29-100; CoriolisAdv_init :1054).            */
+enum mom6x_coriolis_scheme {       /* CORIOLIS_SCHEME, values as in MOM_CoriolisAdv.F90:82-90       */
+  MOM6X_SADOURNY75_ENERGY = 1,     /* default                                                   */
+  MOM6X_ARAKAWA_HSU90 = 2,
+  MOM6X_ROBUST_ENSTRO = 3,         /* not implemented                                           */
+  MOM6X_SADOURNY75_ENSTRO = 4,
+  MOM6X_ARAKAWA_LAMB81 = 5,        /* not implemented                                           */
+  MOM6X_AL_BLEND = 6               /* not implemented                                           */
+};
+enum mom6x_ke_scheme { MOM6X_KE_ARAKAWA = 10, MOM6X_KE_SIMPLE_GUDONOV = 11, MOM6X_KE_GUDONOV = 12 };
+typedef struct mom6x_coriolis_params {
+  int Coriolis_Scheme;   /* SADOURNY75_ENERGY                                                   */
+  int KE_Scheme;         /* KE_ARAKAWA                                                          */
+  int bound_Coriolis;    /* BOUND_CORIOLIS (F; tc1/p0: T)                                       */
+  int no_slip;           /* NOSLIP (F)                                                          */
+  int Coriolis_En_Dis;   /* CORIOLIS_EN_DIS (F) -- only F supported                             */
+} mom6x_coriolis_params;
+
+/* PressureForce_FV_CS (src/core/MOM_PressureForce_FV.F90:40-110; PressureForce_FV_init :2020). */
+typedef struct mom6x_pgf_params {
+  double rho_ref;        /* RHO_PGF_REF (= RHO_0)                                               */
+  int    rho_ref_bug;    /* RHO_PGF_REF_BUG (T)                                                 */
+  double Z_ref;          /* G%Z_ref (0)                                                         */
+} mom6x_pgf_params;
+
 /* ------------------------------------------------------------------------- */
 /* Context: owns the device copy of the metrics, the parameter structs, scratch
  * HBM, two HIP streams (compute + halo) and the RCCL communicator handle.    */
@@ -251,6 +276,40 @@ int mom6x_btstep(mom6x_ctx *ctx,
  * `which`: 0 ubtav, 1 vbtav, 2 eta_cor, 3 frhatu (3-D), 4 frhatv (3-D),
  * 5 IDatu, 6 IDatv.  Returns a device pointer owned by the context.          */
 double *mom6x_barotropic_field(mom6x_ctx *ctx, int which);
+
+/* ------------------------------------------------------------------------- */
+/* MOM_CoriolisAdv                                                             */
+int mom6x_CoriolisAdv_init(mom6x_ctx *ctx, const mom6x_coriolis_params *p);
+  /* CoriolisAdv_init, MOM_CoriolisAdv.F90:1054                                */
+/* CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv, Waves)   :125.
+ * OBC unassociated, no Stokes drift, pbv == 1.  Input halos as documented at :229-233. */
+int mom6x_CorAdCalc(mom6x_ctx *ctx, const double *u, const double *v, const double *h,
+                    const double *uh, const double *vh, double *CAu, double *CAv);
+
+/* ------------------------------------------------------------------------- */
+/* MOM_PressureForce (dispatcher :41 -> PressureForce_FV_Bouss, FV.F90:947)    */
+int mom6x_PressureForce_init(mom6x_ctx *ctx, const mom6x_pgf_params *p, const double *Rlay,
+                             const double *g_prime);
+  /* PressureForce_init :85; Rlay/g_prime are HOST arrays of nk doubles
+   * (GV%Rlay, GV%g_prime of verticalGrid_type).                               */
+/* PressureForce(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, ADp, p_atm, pbce, eta).  Layered
+ * (tv%eqn_of_state unassociated) Boussinesq path; p_atm absent; pbce/eta nullable.       */
+int mom6x_PressureForce(mom6x_ctx *ctx, const double *h, double *PFu, double *PFv,
+                        double *pbce, double *eta);
+
+/* ------------------------------------------------------------------------- */
+/* MOM_vert_friction                                                           */
+/* The coupling coefficients CS%a_u, CS%a_v [(nk+1) levels], CS%h_u, CS%h_v and the optional
+ * visc%Ray_u/Ray_v are produced by vertvisc_coef (:1357, not ported: SURVEY 8f-1); the host
+ * hands their DEVICE copies to the context before vertvisc / vertvisc_remnant.             */
+int mom6x_vertvisc_set_coef(mom6x_ctx *ctx, const double *a_u, const double *a_v,
+                            const double *h_u, const double *h_v,
+                            const double *Ray_u, const double *Ray_v);
+/* vertvisc(u, v, h, forces, visc, dt, OBC, ADp, CDp, G, GV, US, CS, taux_bot, tauy_bot)  :557 */
+int mom6x_vertvisc(mom6x_ctx *ctx, double *u, double *v, const double *taux, const double *tauy,
+                   double dt, double *taux_bot, double *tauy_bot);
+/* vertvisc_remnant(visc, visc_rem_u, visc_rem_v, dt, G, GV, US, CS)  :1229                   */
+int mom6x_vertvisc_remnant(mom6x_ctx *ctx, double *visc_rem_u, double *visc_rem_v, double dt);
 
 #ifdef __cplusplus
 }

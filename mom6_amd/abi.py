@@ -139,6 +139,47 @@ def barotropic_params_default(dtbt):
     return p
 
 
+SADOURNY75_ENERGY, ARAKAWA_HSU90, ROBUST_ENSTRO, SADOURNY75_ENSTRO, ARAKAWA_LAMB81, AL_BLEND = 1, 2, 3, 4, 5, 6
+KE_ARAKAWA, KE_SIMPLE_GUDONOV, KE_GUDONOV = 10, 11, 12
+
+
+class CoriolisParams(C.Structure):
+    """mom6x_coriolis_params; CoriolisAdv_CS (MOM_CoriolisAdv.F90:29-100)."""
+    _fields_ = [("Coriolis_Scheme", C.c_int), ("KE_Scheme", C.c_int), ("bound_Coriolis", C.c_int),
+                ("no_slip", C.c_int), ("Coriolis_En_Dis", C.c_int)]
+
+
+def coriolis_params_default():
+    """Defaults of CoriolisAdv_init (MOM_CoriolisAdv.F90:1054-1320)."""
+    p = CoriolisParams()
+    p.Coriolis_Scheme, p.KE_Scheme = SADOURNY75_ENERGY, KE_ARAKAWA
+    p.bound_Coriolis = p.no_slip = p.Coriolis_En_Dis = 0
+    return p
+
+
+class PGFParams(C.Structure):
+    """mom6x_pgf_params; PressureForce_FV_CS (MOM_PressureForce_FV.F90:40-110)."""
+    _fields_ = [("rho_ref", C.c_double), ("rho_ref_bug", C.c_int), ("Z_ref", C.c_double)]
+
+
+def pgf_params_default(Rho0=1035.0):
+    p = PGFParams()
+    p.rho_ref, p.rho_ref_bug, p.Z_ref = Rho0, 1, 0.0
+    return p
+
+
+def layer_densities(nk, Rho0=1035.0, g_Earth=9.80, drho=2.0):
+    """GV%Rlay and GV%g_prime for a simple linear layer-density profile (COORD_CONFIG="linear",
+    MOM_coord_initialization.F90:126-170): Rlay(k) = Rlay(1) + (k-1)*drho/(nk-1) style spacing and
+    g_prime(k) = g*(Rlay(k)-Rlay(k-1))/Rho0, g_prime(1) = g (free surface)."""
+    import numpy as np
+    Rlay = Rho0 - 0.5 * drho + drho * (np.arange(nk) / max(nk - 1, 1))
+    g_prime = np.empty(nk)
+    g_prime[0] = g_Earth
+    g_prime[1:] = (g_Earth / Rho0) * (Rlay[1:] - Rlay[:-1])
+    return np.ascontiguousarray(Rlay), np.ascontiguousarray(g_prime)
+
+
 # Metric plane indices: enum mom6x_metric
 METRICS = [
     "mask2dT", "mask2dCu", "mask2dCv", "mask2dBu",

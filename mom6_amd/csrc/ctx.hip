@@ -137,6 +137,9 @@ extern "C" int mom6x_ctx_create(mom6x_ctx **out, const mom6x_dims *dims, int dev
   c->first_direction = first_direction;
   c->cont_init = false; c->bt_init = false;
   c->prof_on = false; c->prof = nullptr;
+  c->cor_init = false; c->pgf_init = false; c->Rlay = c->g_prime = nullptr;
+  c->a_u = c->a_v = c->h_u = c->h_v = c->Ray_u = c->Ray_v = nullptr;
+  for (int m = 0; m < MOM6X_NSCR; m++) { c->scr[m] = nullptr; c->scr_nlev[m] = 0; }
   c->hL = c->hR = nullptr; c->bts = nullptr; c->rk2 = nullptr; c->flag = nullptr; c->G = nullptr;
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
@@ -161,9 +164,24 @@ extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
   (void)hipStreamSynchronize(c->halo_stream);
   bt_state_free(c);
   rk2_state_free(c);
+  for (int m = 0; m < MOM6X_NSCR; m++) (void)hipFree(c->scr[m]);
+  (void)hipFree(c->Rlay); (void)hipFree(c->g_prime);
   (void)hipFree(c->G); (void)hipFree(c->hL); (void)hipFree(c->hR); (void)hipFree(c->flag);
   (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->halo_stream);
   delete c;
+  return MOM6X_OK;
+}
+
+int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out) {
+  REQUIRE(slot >= 0 && slot < MOM6X_NSCR, MOM6X_EINVAL, "ctx_scratch: bad slot");
+  if (c->scr[slot] && c->scr_nlev[slot] < nlev) { HIPCHK(hipFree(c->scr[slot])); c->scr[slot] = nullptr; }
+  if (!c->scr[slot]) {
+    const size_t n = (size_t)c->dims.slab * nlev;
+    HIPCHK(hipMalloc(&c->scr[slot], n * sizeof(double)));
+    HIPCHK(hipMemsetAsync(c->scr[slot], 0, n * sizeof(double), c->stream));
+    c->scr_nlev[slot] = nlev;
+  }
+  *out = c->scr[slot];
   return MOM6X_OK;
 }
 

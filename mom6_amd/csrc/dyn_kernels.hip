@@ -1,0 +1,433 @@
+// dyn_kernels.hip -- Coriolis/momentum advection, finite-volume pressure-gradient force and the
+// vertical-viscosity tridiagonal solves on gfx950.
+//
+//   CorAdCalc + gradKE        <- MOM_CoriolisAdv.F90:125-1052
+//   PressureForce_FV_Bouss    <- MOM_PressureForce_FV.F90:947-2017 (layered / no-EOS path)
+//     + Set_pbce_Bouss        <- MOM_PressureForce_Montgomery.F90:649-748
+//   vertvisc, vertvisc_remnant<- MOM_vert_friction.F90:557-1356
+//
+// Horizontal-stencil kernels are "column-walk" kernels: lane index = i (coalesced), each thread keeps
+// the 2-D metric coefficients of its point in registers and walks KCHUNK layers, so the metric planes
+// are read nk/KCHUNK times instead of nk times.  Vertical solves are one thread per column with
+// sequential k (Thomas algorithm in the Schopf & Loughe form used by the reference).
+#include "mom6x_dev.h"
+
+namespace {
+
+inline dim3 blk2() { return dim3(64, 4, 1); }
+
+// ---------------------------------------------------------------------------------------------
+// CorAdCalc, pass 1: potential vorticity q (and abs_vort) at vertices, kinetic energy at cells.
+__global__ void __launch_bounds__(256)
+k_corad_q(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
+          const double *__restrict__ h, double *__restrict__ q, double *__restrict__ absv, double *__restrict__ KE,
+          int no_slip, int ke_scheme, double vol_neglect) {
+  const int i = -2 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -2 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni || j > d.nj) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const double *mT = gm(G, d, MOM6X_G_mask2dT), *areaT = gm(G, d, MOM6X_G_areaT);
+  // Area_h :239-241, Area_q :265-268
+  const double A00 = mT[x] * areaT[x], A10 = mT[x + 1] * areaT[x + 1];
+  const double A01 = mT[x + st] * areaT[x + st], A11 = mT[x + 1 + st] * areaT[x + 1 + st];
+  const double Area_q = (A00 + A11) + (A10 + A01);
+  const double dyCv0 = gm(G, d, MOM6X_G_dyCv)[x], dyCv1 = gm(G, d, MOM6X_G_dyCv)[x + 1];
+  const double dxCu0 = gm(G, d, MOM6X_G_dxCu)[x], dxCu1 = gm(G, d, MOM6X_G_dxCu)[x + st];
+  const double mBu = gm(G, d, MOM6X_G_mask2dBu)[x], IareaBu = gm(G, d, MOM6X_G_IareaBu)[x];
+  const double fBu = gm(G, d, MOM6X_G_CoriolisBu)[x];
+  const double vfac = no_slip ? (2.0 - mBu) : mBu;
+  const bool do_KE = (i >= -1 && j >= -1);
+  double aCu0 = 0, aCu1 = 0, aCv0 = 0, aCv1 = 0, IareaT = 0;
+  if (do_KE) {
+    aCu0 = gm(G, d, MOM6X_G_areaCu)[x]; aCu1 = gm(G, d, MOM6X_G_areaCu)[x - 1];
+    aCv0 = gm(G, d, MOM6X_G_areaCv)[x]; aCv1 = gm(G, d, MOM6X_G_areaCv)[x - st];
+    IareaT = gm(G, d, MOM6X_G_IareaT)[x];
+  }
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double u0 = u[c], v0 = v[c];
+    const double dvdx = (v[c + 1] * dyCv1) - (v0 * dyCv0);
+    const double dudy = (u[c + st] * dxCu1) - (u0 * dxCu0);
+    const double h00 = h[c], h10 = h[c + 1], h01 = h[c + st], h11 = h[c + 1 + st];
+    const double hAu0 = 0.5 * ((A00 * h00) + (A10 * h10));      // hArea_u(I,j)
+    const double hAu1 = 0.5 * ((A01 * h01) + (A11 * h11));      // hArea_u(I,j+1)
+    const double hAv0 = 0.5 * ((A00 * h00) + (A01 * h01));      // hArea_v(i,J)
+    const double hAv1 = 0.5 * ((A10 * h10) + (A11 * h11));      // hArea_v(i+1,J)
+    const double rel_vort = vfac * (dvdx - dudy) * IareaBu;
+    const double abs_vort = fBu + rel_vort;
+    const double hArea_q = (hAu0 + hAu1) + (hAv0 + hAv1);
+    const double Ih_q = Area_q / (hArea_q + vol_neglect);
+    q[c] = abs_vort * Ih_q;
+    if (absv) absv[c] = abs_vort;
+    if (do_KE) {
+      const double um1 = u[c - 1], vm1 = v[c - st];
+      double ke;
+      if (ke_scheme == MOM6X_KE_ARAKAWA) {
+        ke = (((aCu0 * (u0 * u0)) + (aCu1 * (um1 * um1))) + ((aCv0 * (v0 * v0)) + (aCv1 * (vm1 * vm1)))) * 0.25 * IareaT;
+      } else if (ke_scheme == MOM6X_KE_SIMPLE_GUDONOV) {
+        const double up = 0.5 * (um1 + fabs(um1)), up2 = up * up;
+        const double um = 0.5 * (u0 - fabs(u0)), um2 = um * um;
+        const double vp = 0.5 * (vm1 + fabs(vm1)), vp2 = vp * vp;
+        const double vm = 0.5 * (v0 - fabs(v0)), vm2 = vm * vm;
+        ke = (dmax(up2, um2) + dmax(vp2, vm2)) * 0.5;
+      } else {
+        const double up = 0.5 * (um1 + fabs(um1)), up2a = up * up * aCu1;
+        const double um = 0.5 * (u0 - fabs(u0)), um2a = um * um * aCu0;
+        const double vp = 0.5 * (vm1 + fabs(vm1)), vp2a = vp * vp * aCv1;
+        const double vm = 0.5 * (v0 - fabs(v0)), vm2a = vm * vm * aCv0;
+        ke = (dmax(um2a, up2a) + dmax(vm2a, vp2a)) * 0.5 * IareaT;
+      }
+      KE[c] = ke;
+    }
+  }
+}
+
+__device__ __forceinline__ double max4(double a, double b, double c, double d) { return dmax(dmax(dmax(a, b), c), d); }
+__device__ __forceinline__ double min4(double a, double b, double c, double d) { return dmin(dmin(dmin(a, b), c), d); }
+
+// CorAdCalc, pass 2: the accelerations CAu (I=-1..ni-1, j=0..nj-1) and CAv (i=0..ni-1, J=-1..nj-1).
+__global__ void __launch_bounds__(256)
+k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
+            const double *__restrict__ uh, const double *__restrict__ vh, const double *__restrict__ q,
+            const double *__restrict__ absv, const double *__restrict__ KE, double *__restrict__ CAu,
+            double *__restrict__ CAv, int scheme, int bound) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const bool do_u = (j >= 0), do_v = (i >= 0);
+  const double IdxCu = gm(G, d, MOM6X_G_IdxCu)[x], IdyCv = gm(G, d, MOM6X_G_IdyCv)[x];
+  const double C1_12 = 1.0 / 12.0;
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double q00 = q[c];
+    if (do_u) {
+      const double q0m = q[c - st];
+      double ca;
+      if (scheme == MOM6X_SADOURNY75_ENERGY) {
+        ca = 0.25 * ((q00 * (vh[c + 1] + vh[c])) + (q0m * (vh[c - st] + vh[c + 1 - st]))) * IdxCu;
+      } else if (scheme == MOM6X_SADOURNY75_ENSTRO) {
+        ca = 0.125 * (IdxCu * (q00 + q0m)) * ((vh[c + 1] + vh[c]) + (vh[c - st] + vh[c + 1 - st]));
+      } else {   // ARAKAWA_HSU90 :523-533, :683-686
+        const double a = (q00 + (q[c + 1] + q0m)) * C1_12;
+        const double dd = ((q00 + q[c + 1 - st]) + q0m) * C1_12;
+        const double b = (q00 + (q[c - 1] + q0m)) * C1_12;
+        const double cc = ((q00 + q[c - 1 - st]) + q0m) * C1_12;
+        ca = (((a * vh[c + 1]) + (cc * vh[c - st])) + ((b * vh[c]) + (dd * vh[c + 1 - st]))) * IdxCu;
+      }
+      if (bound) {   // :734-747
+        const double av0 = absv[c], avm = absv[c - st];
+        const double fv1 = av0 * v[c + 1], fv2 = av0 * v[c], fv3 = avm * v[c + 1 - st], fv4 = avm * v[c - st];
+        ca = dmin(ca, max4(fv1, fv2, fv3, fv4));
+        ca = dmax(ca, min4(fv1, fv2, fv3, fv4));
+      }
+      CAu[c] = ca - (KE[c + 1] - KE[c]) * IdxCu;
+    }
+    if (do_v) {
+      const double qm0 = q[c - 1];
+      double ca;
+      if (scheme == MOM6X_SADOURNY75_ENERGY) {
+        ca = -0.25 * ((qm0 * (uh[c - 1] + uh[c - 1 + st])) + (q00 * (uh[c] + uh[c + st]))) * IdyCv;
+      } else if (scheme == MOM6X_SADOURNY75_ENSTRO) {
+        ca = -0.125 * (IdyCv * (qm0 + q00)) * ((uh[c - 1] + uh[c - 1 + st]) + (uh[c] + uh[c + st]));
+      } else {
+        // a(I-1,j), c(I,j+1), b(I,j), d(I-1,j+1)
+        const double a_m = (qm0 + (q00 + q[c - 1 - st])) * C1_12;
+        const double c_p = ((q[c + st] + q[c - 1]) + q00) * C1_12;
+        const double b_0 = (q00 + (qm0 + q[c - st])) * C1_12;
+        const double d_mp = ((q[c - 1 + st] + q00) + qm0) * C1_12;
+        ca = -(((a_m * uh[c - 1]) + (c_p * uh[c + st])) + ((b_0 * uh[c]) + (d_mp * uh[c - 1 + st]))) * IdyCv;
+      }
+      if (bound) {
+        const double av0 = absv[c], avm = absv[c - 1];
+        const double fu1 = -av0 * u[c + st], fu2 = -av0 * u[c], fu3 = -avm * u[c - 1 + st], fu4 = -avm * u[c - 1];
+        ca = dmin(ca, max4(fu1, fu2, fu3, fu4));
+        ca = dmax(ca, min4(fu1, fu2, fu3, fu4));
+      }
+      CAv[c] = ca - (KE[c + st] - KE[c]) * IdyCv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PressureForce_FV_Bouss, pass 1: interface heights bottom-up (:1200-1202) on (-1..ni, -1..nj).
+__global__ void __launch_bounds__(256)
+k_pgf_e(Dm d, const double *__restrict__ G, const double *__restrict__ h, double *__restrict__ e, double H_to_Z) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni || j > d.nj) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  double ek = -gm(G, d, MOM6X_G_bathyT)[x];
+  e[x + (size_t)d.nk * slab] = ek;
+  for (int k = d.nk - 1; k >= 0; k--) {
+    ek = ek + h[x + (size_t)k * slab] * H_to_Z;
+    e[x + (size_t)k * slab] = ek;
+  }
+}
+
+// pass 2: top-down pressure anomalies and the accelerations (:1323-1345, :1539-1552, :1794-1813),
+// Set_pbce_Bouss (no-EOS :735-746) and eta (:1886).
+__global__ void __launch_bounds__(256)
+k_pgf_main(Dm d, const double *__restrict__ G, const double *__restrict__ h, const double *__restrict__ e,
+           const double *__restrict__ Rlay, const double *__restrict__ g_prime, double *__restrict__ PFu,
+           double *__restrict__ PFv, double *__restrict__ pbce, double *__restrict__ eta, double g_Earth,
+           double H_to_Z, double Z_to_H, double rho_ref, double GxRho_ref, double Z_ref, double I_Rho0,
+           double h_neglect, double dz_neglect) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni || j > d.nj) return;
+  const int st = d.pitch, nz = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const bool do_u = (i <= d.ni - 1) && (j >= 0) && (j <= d.nj - 1);
+  const bool do_v = (j <= d.nj - 1) && (i >= 0) && (i <= d.ni - 1);
+  const double e_top = e[x], e_bot = e[x + (size_t)nz * slab];
+  if (eta) eta[x] = e_top * Z_to_H;
+  const double Ihtot = 1.0 / ((e_top - e_bot) + dz_neglect);
+  double pa0 = GxRho_ref * (e_top - Z_ref), pa1 = 0.0, pa2 = 0.0, intx_pa = 0.0, inty_pa = 0.0;
+  double cu = 0.0, cv = 0.0;
+  if (do_u) { pa1 = GxRho_ref * (e[x + 1] - Z_ref); intx_pa = 0.5 * (pa0 + pa1); cu = (2.0 * I_Rho0 * gm(G, d, MOM6X_G_IdxCu)[x]); }
+  if (do_v) { pa2 = GxRho_ref * (e[x + st] - Z_ref); inty_pa = 0.5 * (pa0 + pa2); cv = (2.0 * I_Rho0 * gm(G, d, MOM6X_G_IdyCv)[x]); }
+  double pb = 0.0;
+  for (int k = 0; k < nz; k++) {
+    const size_t c = x + (size_t)k * slab, cb = c + slab;
+    const double R = Rlay[k] - rho_ref;
+    const double h0 = h[c];
+    const double dz0 = g_Earth * H_to_Z * h0;
+    const double dpa0 = R * dz0, iz0 = 0.5 * R * dz0 * h0;
+    const double eb0 = e[cb];
+    if (do_u) {
+      const double h1 = h[c + 1];
+      const double dz1 = g_Earth * H_to_Z * h1;
+      const double iz1 = 0.5 * R * dz1 * h1;
+      const double intx_dpa = 0.5 * R * (dz0 + dz1);
+      PFu[c] = (((pa0 * h0 + iz0) - (pa1 * h1 + iz1)) + ((h1 - h0) * intx_pa - (e[cb + 1] - eb0) * intx_dpa * Z_to_H)) *
+               (cu / ((h0 + h1) + h_neglect));
+      pa1 = pa1 + R * dz1;
+      intx_pa = intx_pa + intx_dpa;
+    }
+    if (do_v) {
+      const double h2 = h[c + st];
+      const double dz2 = g_Earth * H_to_Z * h2;
+      const double iz2 = 0.5 * R * dz2 * h2;
+      const double inty_dpa = 0.5 * R * (dz0 + dz2);
+      PFv[c] = (((pa0 * h0 + iz0) - (pa2 * h2 + iz2)) + ((h2 - h0) * inty_pa - (e[cb + st] - eb0) * inty_dpa * Z_to_H)) *
+               (cv / ((h0 + h2) + h_neglect));
+      pa2 = pa2 + R * dz2;
+      inty_pa = inty_pa + inty_dpa;
+    }
+    pa0 = pa0 + dpa0;
+    if (pbce) {
+      if (k == 0) pb = g_prime[0] * H_to_Z;
+      else pb = pb + (g_prime[k] * H_to_Z) * ((e[c] - e_bot) * Ihtot);
+      pbce[c] = pb;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// vertvisc :557-1228 (one direction); c1 is a 3-D scratch array.
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_vertvisc(Dm d, const double *__restrict__ G, double *__restrict__ u, const double *__restrict__ a_u,
+           const double *__restrict__ h_u, const double *__restrict__ Ray_u, const double *__restrict__ tau,
+           double *__restrict__ c1, double dt, double dt_Rho0, double H_to_RZ, double *__restrict__ tau_bot) {
+  const int i = (DIR ? 0 : -1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int nz = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
+  if (mC > 0.) {
+    const double surface_stress = dt_Rho0 * (mC * tau[x]);
+    double Ray = Ray_u ? Ray_u[x] : 0.;
+    double a_k = a_u[x], a_kp = a_u[x + slab];
+    double hu = h_u[x];
+    double b_denom_1 = hu + dt * (Ray + a_k);
+    double b1 = 1.0 / (b_denom_1 + dt * a_kp);
+    double d1 = b_denom_1 * b1;
+    double uprev = b1 * (hu * u[x] + surface_stress);
+    u[x] = uprev;
+    for (int k = 1; k < nz; k++) {
+      const size_t x3 = x + (size_t)k * slab;
+      if (Ray_u) Ray = Ray_u[x3];
+      a_k = a_kp; a_kp = a_u[x3 + slab];
+      hu = h_u[x3];
+      c1[x3] = dt * a_k * b1;
+      b_denom_1 = hu + dt * (Ray + a_k * d1);
+      b1 = 1.0 / (b_denom_1 + dt * a_kp);
+      d1 = b_denom_1 * b1;
+      uprev = (hu * u[x3] + dt * a_k * uprev) * b1;
+      u[x3] = uprev;
+    }
+    for (int k = nz - 2; k >= 0; k--) {
+      const size_t x3 = x + (size_t)k * slab;
+      uprev = u[x3] + c1[x3 + slab] * uprev;
+      u[x3] = uprev;
+    }
+  }
+  if (tau_bot) {
+    double tb = H_to_RZ * (u[x + (size_t)(nz - 1) * slab] * a_u[x + (size_t)nz * slab]);
+    if (Ray_u) for (int k = 0; k < nz; k++) tb = tb + H_to_RZ * (Ray_u[x + (size_t)k * slab] * u[x + (size_t)k * slab]);
+    tau_bot[x] = tb;
+  }
+}
+
+// vertvisc_remnant :1229-1356 (one direction)
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_vertvisc_remnant(Dm d, const double *__restrict__ G, double *__restrict__ vr, const double *__restrict__ a_u,
+                   const double *__restrict__ h_u, const double *__restrict__ Ray_u, double *__restrict__ c1, double dt) {
+  const int i = (DIR ? 0 : -1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int nz = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
+  if (!(mC > 0.)) return;
+  double Ray = Ray_u ? Ray_u[x] : 0.;
+  double a_k = a_u[x], a_kp = a_u[x + slab];
+  double hu = h_u[x];
+  double b_denom_1 = hu + dt * (Ray + a_k);
+  double b1 = 1.0 / (b_denom_1 + dt * a_kp);
+  double d1 = b_denom_1 * b1;
+  double prev = b1 * hu;
+  vr[x] = prev;
+  for (int k = 1; k < nz; k++) {
+    const size_t x3 = x + (size_t)k * slab;
+    if (Ray_u) Ray = Ray_u[x3];
+    a_k = a_kp; a_kp = a_u[x3 + slab];
+    hu = h_u[x3];
+    c1[x3] = dt * a_k * b1;
+    b_denom_1 = hu + dt * (Ray + a_k * d1);
+    b1 = 1.0 / (b_denom_1 + dt * a_kp);
+    d1 = b_denom_1 * b1;
+    prev = (hu + dt * a_k * prev) * b1;
+    vr[x3] = prev;
+  }
+  for (int k = nz - 2; k >= 0; k--) {
+    const size_t x3 = x + (size_t)k * slab;
+    prev = vr[x3] + c1[x3 + slab] * prev;
+    vr[x3] = prev;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int mom6x_CoriolisAdv_init(mom6x_ctx *c, const mom6x_coriolis_params *p) {
+  REQUIRE(c && p, MOM6X_EINVAL, "mom6x_CoriolisAdv_init: null argument");
+  REQUIRE(!p->Coriolis_En_Dis, MOM6X_EUNSUPPORTED, "CoriolisAdv: CORIOLIS_EN_DIS is not supported");
+  REQUIRE(p->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY || p->Coriolis_Scheme == MOM6X_SADOURNY75_ENSTRO ||
+          p->Coriolis_Scheme == MOM6X_ARAKAWA_HSU90, MOM6X_EUNSUPPORTED,
+          "CoriolisAdv: only SADOURNY75_ENERGY, SADOURNY75_ENSTRO and ARAKAWA_HSU90 are implemented");
+  REQUIRE(p->KE_Scheme >= MOM6X_KE_ARAKAWA && p->KE_Scheme <= MOM6X_KE_GUDONOV, MOM6X_EINVAL, "CoriolisAdv: bad KE_SCHEME");
+  c->cor = *p;
+  c->cor_init = true;
+  return MOM6X_OK;
+}
+
+static inline dim3 gridk(int nx, int ny, int nk, dim3 b) {
+  return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, nchunks(nk));
+}
+
+extern "C" int mom6x_CorAdCalc(mom6x_ctx *c, const double *u, const double *v, const double *h, const double *uh,
+                               const double *vh, double *CAu, double *CAv) {
+  REQUIRE(c && c->cor_init, MOM6X_EINVAL, "MOM_CoriolisAdv: Module must be initialized before it is used.");
+  REQUIRE(u && v && h && uh && vh && CAu && CAv, MOM6X_EINVAL, "CorAdCalc: null array");
+  REQUIRE(c->dims.halo >= 3, MOM6X_EINVAL, "CorAdCalc: halo >= 3 required");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  double *q, *KE, *absv = nullptr;
+  int rc;
+  if ((rc = ctx_scratch(c, SCR_q, d.nk, &q))) return rc;
+  if ((rc = ctx_scratch(c, SCR_KE, d.nk, &KE))) return rc;
+  if (c->cor.bound_Coriolis && (rc = ctx_scratch(c, SCR_absv, d.nk, &absv))) return rc;
+  const dim3 b = blk2();
+  const double vol_neglect = c->GV.H_subroundoff * ((1e-4 * 1.0) * (1e-4 * 1.0));
+  KLAUNCH(c, "k_corad_q", k_corad_q, gridk(d.ni + 3, d.nj + 3, d.nk, b), b, d, c->G, u, v, h, q, absv, KE,
+          c->cor.no_slip, c->cor.KE_Scheme, vol_neglect);
+  KLAUNCH(c, "k_corad_acc", k_corad_acc, gridk(d.ni + 1, d.nj + 1, d.nk, b), b, d, c->G, u, v, uh, vh, q, absv, KE,
+          CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_PressureForce_init(mom6x_ctx *c, const mom6x_pgf_params *p, const double *Rlay, const double *g_prime) {
+  REQUIRE(c && p && Rlay && g_prime, MOM6X_EINVAL, "mom6x_PressureForce_init: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  c->pgf = *p;
+  const size_t n = (size_t)c->dims.nk * sizeof(double);
+  if (!c->Rlay) { HIPCHK(hipMalloc(&c->Rlay, n)); HIPCHK(hipMalloc(&c->g_prime, n)); }
+  HIPCHK(hipMemcpy(c->Rlay, Rlay, n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->g_prime, g_prime, n, hipMemcpyHostToDevice));
+  c->pgf_init = true;
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, double *PFv, double *pbce, double *eta) {
+  REQUIRE(c && c->pgf_init, MOM6X_EINVAL, "MOM_PressureForce_FV_Bouss: Module must be initialized before it is used.");
+  REQUIRE(h && PFu && PFv, MOM6X_EINVAL, "PressureForce: null array");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  double *e;
+  int rc;
+  if ((rc = ctx_scratch(c, SCR_e, d.nk + 1, &e))) return rc;
+  const dim3 b = blk2();
+  const mom6x_vgrid &GV = c->GV;
+  const double GxRho0 = GV.g_Earth * GV.Rho0;
+  const double GxRho_ref = c->pgf.rho_ref_bug ? GxRho0 : GV.g_Earth * c->pgf.rho_ref;
+  KLAUNCH(c, "k_pgf_e", k_pgf_e, grid3(d.ni + 2, d.nj + 2, 1, b), b, d, c->G, h, e, GV.H_to_Z);
+  KLAUNCH(c, "k_pgf_main", k_pgf_main, grid3(d.ni + 2, d.nj + 2, 1, b), b, d, c->G, h, e, c->Rlay, c->g_prime, PFu, PFv,
+          pbce, eta, GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, 1.0 / GV.Rho0,
+          GV.H_subroundoff, GV.dZ_subroundoff);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_vertvisc_set_coef(mom6x_ctx *c, const double *a_u, const double *a_v, const double *h_u,
+                                       const double *h_v, const double *Ray_u, const double *Ray_v) {
+  REQUIRE(c && a_u && a_v && h_u && h_v, MOM6X_EINVAL, "mom6x_vertvisc_set_coef: null mandatory array");
+  REQUIRE((Ray_u != nullptr) == (Ray_v != nullptr), MOM6X_EINVAL, "mom6x_vertvisc_set_coef: Ray_u and Ray_v come together");
+  c->a_u = a_u; c->a_v = a_v; c->h_u = h_u; c->h_v = h_v; c->Ray_u = Ray_u; c->Ray_v = Ray_v;
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_vertvisc(mom6x_ctx *c, double *u, double *v, const double *taux, const double *tauy, double dt,
+                              double *taux_bot, double *tauy_bot) {
+  REQUIRE(c && c->a_u, MOM6X_EINVAL, "MOM_vert_friction(visc): Module must be initialized before it is used.");
+  REQUIRE(u && v && taux && tauy, MOM6X_EINVAL, "vertvisc: null array");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  double *c1;
+  int rc;
+  if ((rc = ctx_scratch(c, SCR_c1, d.nk, &c1))) return rc;
+  const dim3 b = blk2();
+  const double dt_Rho0 = dt / c->GV.H_to_RZ;
+  KLAUNCH(c, "k_vertvisc<0>", k_vertvisc<0>, grid3(d.ni + 1, d.nj, 1, b), b, d, c->G, u, c->a_u, c->h_u, c->Ray_u, taux, c1, dt,
+          dt_Rho0, c->GV.H_to_RZ, taux_bot);
+  KLAUNCH(c, "k_vertvisc<1>", k_vertvisc<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, v, c->a_v, c->h_v, c->Ray_v, tauy, c1, dt,
+          dt_Rho0, c->GV.H_to_RZ, tauy_bot);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_vertvisc_remnant(mom6x_ctx *c, double *visc_rem_u, double *visc_rem_v, double dt) {
+  REQUIRE(c && c->a_u, MOM6X_EINVAL, "MOM_vert_friction(remant): Module must be initialized before it is used.");
+  REQUIRE(visc_rem_u && visc_rem_v, MOM6X_EINVAL, "vertvisc_remnant: null array");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  double *c1;
+  int rc;
+  if ((rc = ctx_scratch(c, SCR_c1, d.nk, &c1))) return rc;
+  const dim3 b = blk2();
+  KLAUNCH(c, "k_vertvisc_remnant<0>", k_vertvisc_remnant<0>, grid3(d.ni + 1, d.nj, 1, b), b, d, c->G, visc_rem_u, c->a_u, c->h_u,
+          c->Ray_u, c1, dt);
+  KLAUNCH(c, "k_vertvisc_remnant<1>", k_vertvisc_remnant<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, visc_rem_v, c->a_v, c->h_v,
+          c->Ray_v, c1, dt);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}

@@ -51,6 +51,8 @@ void mom6x_set_error(const char *fmt, ...);
 
 // ---------------------------------------------------------------------------------------------
 // The context (opaque to C callers).
+#define MOM6X_NSCR 12
+enum Scr { SCR_q = 0, SCR_KE, SCR_absv, SCR_e, SCR_c1, SCR_t0, SCR_t1, SCR_t2, SCR_t3 };
 struct BTState;   // barotropic.hip
 struct RK2State;  // dyn_split_RK2.hip
 
@@ -70,6 +72,13 @@ struct mom6x_ctx {
   BTState *bts;
   RK2State *rk2;
   int *flag;                // device-side error flag (NaN / negative thickness)
+  // MOM_CoriolisAdv / MOM_PressureForce / MOM_vert_friction
+  mom6x_coriolis_params cor; bool cor_init;
+  mom6x_pgf_params pgf; bool pgf_init;
+  double *Rlay, *g_prime;   // device copies of GV%Rlay, GV%g_prime (nk)
+  const double *a_u, *a_v, *h_u, *h_v, *Ray_u, *Ray_v;   // vertvisc coefficients (host-owned device arrays)
+  // lazily allocated 3-D scratch arrays (slot -> nlev levels)
+  double *scr[MOM6X_NSCR]; int scr_nlev[MOM6X_NSCR];
   bool prof_on;
   struct Prof *prof;
 };
@@ -85,6 +94,13 @@ void prof_end(mom6x_ctx *c);
     hipLaunchKernelGGL(kern, grid, blk, 0, (c)->stream, __VA_ARGS__);       \
     if ((c)->prof_on) prof_end((c));                                        \
   } while (0)
+
+int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out);   // ctx.hip
+
+// k-chunking for "column-walk" kernels: a thread keeps its 2-D coefficients in registers and walks
+// KCHUNK consecutive layers, so the 2-D metric planes are read nk/KCHUNK times instead of nk times.
+#define KCHUNK 15
+inline int nchunks(int nk) { return (nk + KCHUNK - 1) / KCHUNK; }
 
 inline dim3 grid3(int nx, int ny, int nz, dim3 b) {
   return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z);

@@ -146,6 +146,44 @@ class Dycore:
             C.byref(BT_cont.struct), _ptr(taux_bot), _ptr(tauy_bot), _ptr(uh0), _ptr(vh0), _ptr(u_uh0), _ptr(v_vh0),
             _ptr(etaav)))
 
+    # -- MOM_CoriolisAdv ---------------------------------------------------------------------
+    def CoriolisAdv_init(self, params=None):
+        """CoriolisAdv_init (MOM_CoriolisAdv.F90:1054)."""
+        self.cor_params = params if params is not None else abi.coriolis_params_default()
+        check(self.lib, self.lib.mom6x_CoriolisAdv_init(self.ctx, C.byref(self.cor_params)))
+
+    def CorAdCalc(self, u, v, h, uh, vh, CAu, CAv):
+        """CorAdCalc (MOM_CoriolisAdv.F90:125)."""
+        check(self.lib, self.lib.mom6x_CorAdCalc(self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(uh), _ptr(vh), _ptr(CAu), _ptr(CAv)))
+
+    # -- MOM_PressureForce -------------------------------------------------------------------
+    def PressureForce_init(self, params, Rlay, g_prime):
+        """PressureForce_init (MOM_PressureForce.F90:85) for the analytic FV Boussinesq PGF."""
+        self.pgf_params = params
+        self._Rlay = np.ascontiguousarray(Rlay, dtype=np.float64)
+        self._g_prime = np.ascontiguousarray(g_prime, dtype=np.float64)
+        check(self.lib, self.lib.mom6x_PressureForce_init(self.ctx, C.byref(params), self._Rlay.ctypes.data_as(C.c_void_p),
+                                                          self._g_prime.ctypes.data_as(C.c_void_p)))
+
+    def PressureForce(self, h, PFu, PFv, pbce=None, eta=None):
+        """PressureForce (MOM_PressureForce.F90:41) -> PressureForce_FV_Bouss (FV.F90:947)."""
+        check(self.lib, self.lib.mom6x_PressureForce(self.ctx, _ptr(h), _ptr(PFu), _ptr(PFv), _ptr(pbce), _ptr(eta)))
+
+    # -- MOM_vert_friction -------------------------------------------------------------------
+    def vertvisc_set_coef(self, a_u, a_v, h_u, h_v, Ray_u=None, Ray_v=None):
+        """Hand CS%a_u, CS%a_v, CS%h_u, CS%h_v (and visc%Ray_u/v) of vertvisc_coef to the context."""
+        self._vv = (a_u, a_v, h_u, h_v, Ray_u, Ray_v)
+        check(self.lib, self.lib.mom6x_vertvisc_set_coef(self.ctx, _ptr(a_u), _ptr(a_v), _ptr(h_u), _ptr(h_v), _ptr(Ray_u), _ptr(Ray_v)))
+
+    def vertvisc(self, u, v, taux, tauy, dt, taux_bot=None, tauy_bot=None):
+        """vertvisc (MOM_vert_friction.F90:557)."""
+        check(self.lib, self.lib.mom6x_vertvisc(self.ctx, _ptr(u), _ptr(v), _ptr(taux), _ptr(tauy), C.c_double(dt),
+                                                _ptr(taux_bot), _ptr(tauy_bot)))
+
+    def vertvisc_remnant(self, visc_rem_u, visc_rem_v, dt):
+        """vertvisc_remnant (MOM_vert_friction.F90:1229)."""
+        check(self.lib, self.lib.mom6x_vertvisc_remnant(self.ctx, _ptr(visc_rem_u), _ptr(visc_rem_v), C.c_double(dt)))
+
 
 def _view(ptr, shape, device):
     """torch tensor aliasing device memory owned by the C library."""

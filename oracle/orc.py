@@ -124,3 +124,30 @@ def btstep(d, G, GV, P, cs, first_direction, U_in, V_in, eta_in, dt, bc_accel_u,
     if rc != 0:
         raise RuntimeError(f"orc_btstep rc={rc}")
     return nstep.value
+
+
+# ------------------------------------------------------------------------------------------
+# MOM_CoriolisAdv / MOM_PressureForce_FV / MOM_vert_friction
+def CorAdCalc(d, G, GV, CS, u, v, h, uh, vh, CAu, CAv):
+    rc = lib().orc_CorAdCalc(C.byref(d), _p(G), C.byref(GV), C.byref(CS), _p(u), _p(v), _p(h), _p(uh), _p(vh), _p(CAu), _p(CAv))
+    if rc != 0:
+        raise RuntimeError(f"orc_CorAdCalc rc={rc}")
+
+
+def PressureForce(d, G, GV, CS, Rlay, g_prime, h, PFu, PFv, pbce=None, eta=None):
+    rc = lib().orc_PressureForce_FV_Bouss(C.byref(d), _p(G), C.byref(GV), C.byref(CS), _p(Rlay), _p(g_prime), _p(h),
+                                          _p(PFu), _p(PFv), _p(pbce), _p(eta))
+    if rc != 0:
+        raise RuntimeError(f"orc_PressureForce rc={rc}")
+
+
+def vertvisc(d, G, GV, u, v, a_u, a_v, h_u, h_v, Ray_u, Ray_v, taux, tauy, dt, taux_bot=None, tauy_bot=None):
+    rc = lib().orc_vertvisc(C.byref(d), _p(G), C.byref(GV), _p(u), _p(v), _p(a_u), _p(a_v), _p(h_u), _p(h_v), _p(Ray_u),
+                            _p(Ray_v), _p(taux), _p(tauy), C.c_double(dt), _p(taux_bot), _p(tauy_bot))
+    assert rc == 0, rc
+
+
+def vertvisc_remnant(d, G, visc_rem_u, visc_rem_v, a_u, a_v, h_u, h_v, Ray_u, Ray_v, dt):
+    rc = lib().orc_vertvisc_remnant(C.byref(d), _p(G), _p(visc_rem_u), _p(visc_rem_v), _p(a_u), _p(a_v), _p(h_u), _p(h_v),
+                                    _p(Ray_u), _p(Ray_v), C.c_double(dt))
+    assert rc == 0, rc

@@ -1,0 +1,320 @@
+/*
+ * ORACLE (test infrastructure only; see orc_common.h header).  PARITY UNPINNED.
+ *
+ * CorAdCalc / gradKE          <- src/core/MOM_CoriolisAdv.F90:125-1052
+ * PressureForce_FV_Bouss      <- src/core/MOM_PressureForce_FV.F90:947-2017 (layered, no-EOS path) with
+ *   Set_pbce_Bouss            <- src/core/MOM_PressureForce_Montgomery.F90:649-748 (no-EOS branch)
+ * vertvisc / vertvisc_remnant <- src/parameterizations/vertical/MOM_vert_friction.F90:557-1356
+ *
+ * Supported options (others return MOM6X_EUNSUPPORTED):
+ *   CORIOLIS_SCHEME = SADOURNY75_ENERGY (default) | SADOURNY75_ENSTRO | ARAKAWA_HSU90, BOUND_CORIOLIS,
+ *   NOSLIP, KE_SCHEME = KE_ARAKAWA (default) | KE_SIMPLE_GUDONOV | KE_GUDONOV; CORIOLIS_EN_DIS=False;
+ *   no OBC, no Stokes drift; PGF: use_EOS=False, no p_atm, no tides/SAL, GFS_scale=1;
+ *   vertvisc: DIRECT_STRESS=False, no Stokes mixing / fpmix / GL90; optional Ray_u/Ray_v.
+ */
+#include "orc_common.h"
+
+void orc_pass_var(const mom6x_dims *d, double *a, int stagger, int nk);
+
+/* ------------------------------------------------------------------------------------------ */
+/* CorAdCalc                                                                                   */
+int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_coriolis_params *CS,
+                  const double *u, const double *v, const double *h, const double *uh, const double *vh,
+                  double *CAu, double *CAv) {
+  if (CS->Coriolis_En_Dis) return MOM6X_EUNSUPPORTED;
+  if (CS->Coriolis_Scheme != MOM6X_SADOURNY75_ENERGY && CS->Coriolis_Scheme != MOM6X_SADOURNY75_ENSTRO &&
+      CS->Coriolis_Scheme != MOM6X_ARAKAWA_HSU90) return MOM6X_EUNSUPPORTED;
+  const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1, nz = d->nk, st = d->pitch;
+  const int Isq = -1, Ieq = ie, Jsq = -1, Jeq = je;
+  const size_t slab = (size_t)d->slab;
+  const double *mT = GM(G, d, MOM6X_G_mask2dT), *areaT = GM(G, d, MOM6X_G_areaT), *IareaT = GM(G, d, MOM6X_G_IareaT);
+  const double *dyCv = GM(G, d, MOM6X_G_dyCv), *dxCu = GM(G, d, MOM6X_G_dxCu);
+  const double *mBu = GM(G, d, MOM6X_G_mask2dBu), *IareaBu = GM(G, d, MOM6X_G_IareaBu), *fBu = GM(G, d, MOM6X_G_CoriolisBu);
+  const double *IdxCu = GM(G, d, MOM6X_G_IdxCu), *IdyCv = GM(G, d, MOM6X_G_IdyCv);
+  const double *areaCu = GM(G, d, MOM6X_G_areaCu), *areaCv = GM(G, d, MOM6X_G_areaCv);
+  const double vol_neglect = GV->H_subroundoff * ((1e-4 * 1.0) * (1e-4 * 1.0));
+  const double C1_12 = 1.0 / 12.0;
+#define NEW2(x) double *x = (double *)calloc(slab, sizeof(double))
+  NEW2(Area_h); NEW2(Area_q); NEW2(dvdx); NEW2(dudy); NEW2(hArea_u); NEW2(hArea_v); NEW2(rel_vort); NEW2(abs_vort);
+  NEW2(q); NEW2(a); NEW2(b); NEW2(c); NEW2(dd); NEW2(KE); NEW2(KEx); NEW2(KEy);
+
+  for (int j = Jsq - 1; j <= Jeq + 2; j++) for (int i = Isq - 1; i <= Ieq + 2; i++) {
+    size_t x = IX2(d, i, j); Area_h[x] = mT[x] * areaT[x];
+  }
+  for (int j = Jsq - 1; j <= Jeq + 1; j++) for (int i = Isq - 1; i <= Ieq + 1; i++) {
+    size_t x = IX2(d, i, j);
+    Area_q[x] = (Area_h[x] + Area_h[x + 1 + st]) + (Area_h[x + 1] + Area_h[x + st]);
+  }
+
+  for (int k = 0; k < nz; k++) {
+    const double *uk = u + k * slab, *vk = v + k * slab, *hk = h + k * slab, *uhk = uh + k * slab, *vhk = vh + k * slab;
+    double *CAuk = CAu + k * slab, *CAvk = CAv + k * slab;
+    for (int j = Jsq - 1; j <= Jeq + 1; j++) for (int i = Isq - 1; i <= Ieq + 1; i++) { /* :314-317 */
+      size_t x = IX2(d, i, j);
+      dvdx[x] = (vk[x + 1] * dyCv[x + 1]) - (vk[x] * dyCv[x]);
+      dudy[x] = (uk[x + st] * dxCu[x + st]) - (uk[x] * dxCu[x]);
+    }
+    for (int j = Jsq - 1; j <= Jeq + 1; j++) for (int i = Isq - 1; i <= Ieq + 2; i++) { /* :319-321 */
+      size_t x = IX2(d, i, j);
+      hArea_v[x] = 0.5 * ((Area_h[x] * hk[x]) + (Area_h[x + st] * hk[x + st]));
+    }
+    for (int j = Jsq - 1; j <= Jeq + 2; j++) for (int i = Isq - 1; i <= Ieq + 1; i++) { /* :322-324 */
+      size_t x = IX2(d, i, j);
+      hArea_u[x] = 0.5 * ((Area_h[x] * hk[x]) + (Area_h[x + 1] * hk[x + 1]));
+    }
+    for (int j = Jsq - 1; j <= Jeq + 1; j++) for (int i = Isq - 1; i <= Ieq + 1; i++) { /* :470-491 */
+      size_t x = IX2(d, i, j);
+      if (CS->no_slip) rel_vort[x] = (2.0 - mBu[x]) * (dvdx[x] - dudy[x]) * IareaBu[x];
+      else rel_vort[x] = mBu[x] * (dvdx[x] - dudy[x]) * IareaBu[x];
+      abs_vort[x] = fBu[x] + rel_vort[x];
+      double hArea_q = (hArea_u[x] + hArea_u[x + st]) + (hArea_v[x] + hArea_v[x + 1]);
+      double Ih_q = Area_q[x] / (hArea_q + vol_neglect);
+      q[x] = abs_vort[x] * Ih_q;
+    }
+    if (CS->Coriolis_Scheme == MOM6X_ARAKAWA_HSU90) { /* :523-533 */
+      for (int j = Jsq; j <= Jeq + 1; j++) {
+        for (int i = is - 1; i <= Ieq; i++) {
+          size_t x = IX2(d, i, j);
+          a[x] = (q[x] + (q[x + 1] + q[x - st])) * C1_12;
+          dd[x] = ((q[x] + q[x + 1 - st]) + q[x - st]) * C1_12;
+        }
+        for (int i = Isq; i <= Ieq; i++) {
+          size_t x = IX2(d, i, j);
+          b[x] = (q[x] + (q[x - 1] + q[x - st])) * C1_12;
+          c[x] = ((q[x] + q[x - 1 - st]) + q[x - st]) * C1_12;
+        }
+      }
+    }
+    /* gradKE :969-1052 */
+    for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+      size_t x = IX2(d, i, j);
+      if (CS->KE_Scheme == MOM6X_KE_ARAKAWA) {
+        KE[x] = (((areaCu[x] * (uk[x] * uk[x])) + (areaCu[x - 1] * (uk[x - 1] * uk[x - 1]))) +
+                 ((areaCv[x] * (vk[x] * vk[x])) + (areaCv[x - st] * (vk[x - st] * vk[x - st])))) * 0.25 * IareaT[x];
+      } else if (CS->KE_Scheme == MOM6X_KE_SIMPLE_GUDONOV) {
+        double up = 0.5 * (uk[x - 1] + fabs(uk[x - 1])), up2 = up * up;
+        double um = 0.5 * (uk[x] - fabs(uk[x])), um2 = um * um;
+        double vp = 0.5 * (vk[x - st] + fabs(vk[x - st])), vp2 = vp * vp;
+        double vm = 0.5 * (vk[x] - fabs(vk[x])), vm2 = vm * vm;
+        KE[x] = (orc_max(up2, um2) + orc_max(vp2, vm2)) * 0.5;
+      } else {
+        double up = 0.5 * (uk[x - 1] + fabs(uk[x - 1])), up2a = up * up * areaCu[x - 1];
+        double um = 0.5 * (uk[x] - fabs(uk[x])), um2a = um * um * areaCu[x];
+        double vp = 0.5 * (vk[x - st] + fabs(vk[x - st])), vp2a = vp * vp * areaCv[x - st];
+        double vm = 0.5 * (vk[x] - fabs(vk[x])), vm2a = vm * vm * areaCv[x];
+        KE[x] = (orc_max(um2a, up2a) + orc_max(vm2a, vp2a)) * 0.5 * IareaT[x];
+      }
+    }
+    for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) { size_t x = IX2(d, i, j); KEx[x] = (KE[x + 1] - KE[x]) * IdxCu[x]; }
+    for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) { size_t x = IX2(d, i, j); KEy[x] = (KE[x + st] - KE[x]) * IdyCv[x]; }
+
+    /* CAu :664-754 */
+    for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
+      size_t x = IX2(d, i, j);
+      double ca;
+      if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY)
+        ca = 0.25 * ((q[x] * (vhk[x + 1] + vhk[x])) + (q[x - st] * (vhk[x - st] + vhk[x + 1 - st]))) * IdxCu[x];
+      else if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENSTRO)
+        ca = 0.125 * (IdxCu[x] * (q[x] + q[x - st])) * ((vhk[x + 1] + vhk[x]) + (vhk[x - st] + vhk[x + 1 - st]));
+      else
+        ca = (((a[x] * vhk[x + 1]) + (c[x] * vhk[x - st])) + ((b[x] * vhk[x]) + (dd[x] * vhk[x + 1 - st]))) * IdxCu[x];
+      if (CS->bound_Coriolis) {
+        double fv1 = abs_vort[x] * vk[x + 1], fv2 = abs_vort[x] * vk[x];
+        double fv3 = abs_vort[x - st] * vk[x + 1 - st], fv4 = abs_vort[x - st] * vk[x - st];
+        double max_fv = orc_max(orc_max(orc_max(fv1, fv2), fv3), fv4), min_fv = orc_min(orc_min(orc_min(fv1, fv2), fv3), fv4);
+        ca = orc_min(ca, max_fv); ca = orc_max(ca, min_fv);
+      }
+      CAuk[x] = ca - KEx[x];
+    }
+    /* CAv :775-884 */
+    for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) {
+      size_t x = IX2(d, i, j);
+      double ca;
+      if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY)
+        ca = -0.25 * ((q[x - 1] * (uhk[x - 1] + uhk[x - 1 + st])) + (q[x] * (uhk[x] + uhk[x + st]))) * IdyCv[x];
+      else if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENSTRO)
+        ca = -0.125 * (IdyCv[x] * (q[x - 1] + q[x])) * ((uhk[x - 1] + uhk[x - 1 + st]) + (uhk[x] + uhk[x + st]));
+      else
+        ca = -(((a[x - 1] * uhk[x - 1]) + (c[x + st] * uhk[x + st])) + ((b[x] * uhk[x]) + (dd[x - 1 + st] * uhk[x - 1 + st]))) * IdyCv[x];
+      if (CS->bound_Coriolis) {
+        double fu1 = -abs_vort[x] * uk[x + st], fu2 = -abs_vort[x] * uk[x];
+        double fu3 = -abs_vort[x - 1] * uk[x - 1 + st], fu4 = -abs_vort[x - 1] * uk[x - 1];
+        double max_fu = orc_max(orc_max(orc_max(fu1, fu2), fu3), fu4), min_fu = orc_min(orc_min(orc_min(fu1, fu2), fu3), fu4);
+        ca = orc_min(ca, max_fu); ca = orc_max(ca, min_fu);
+      }
+      CAvk[x] = ca - KEy[x];
+    }
+  }
+  double *all[] = { Area_h, Area_q, dvdx, dudy, hArea_u, hArea_v, rel_vort, abs_vort, q, a, b, c, dd, KE, KEx, KEy };
+  for (size_t m = 0; m < sizeof(all) / sizeof(all[0]); m++) free(all[m]);
+  return MOM6X_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* PressureForce_FV_Bouss, layered (no equation of state) path                                  */
+int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
+                               const mom6x_pgf_params *CS, const double *Rlay, const double *g_prime,
+                               const double *h, double *PFu, double *PFv, double *pbce, double *eta) {
+  const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1, nz = d->nk, st = d->pitch;
+  const int Isq = -1, Ieq = ie, Jsq = -1, Jeq = je;
+  const size_t slab = (size_t)d->slab;
+  const double *bathyT = GM(G, d, MOM6X_G_bathyT), *IdxCu = GM(G, d, MOM6X_G_IdxCu), *IdyCv = GM(G, d, MOM6X_G_IdyCv);
+  const double h_neglect = GV->H_subroundoff, dz_neglect = GV->dZ_subroundoff;
+  const double I_Rho0 = 1.0 / GV->Rho0;
+  const double GxRho0 = GV->g_Earth * GV->Rho0;
+  const double rho_ref = CS->rho_ref;
+  const double GxRho_ref = CS->rho_ref_bug ? GxRho0 : GV->g_Earth * rho_ref;
+  const double Z_ref = CS->Z_ref;
+  double *e = (double *)calloc(slab * (nz + 1), sizeof(double)), *pa = (double *)calloc(slab * (nz + 1), sizeof(double));
+  double *dpa = (double *)calloc(slab * nz, sizeof(double)), *intz_dpa = (double *)calloc(slab * nz, sizeof(double));
+  double *intx_pa = (double *)calloc(slab * (nz + 1), sizeof(double)), *inty_pa = (double *)calloc(slab * (nz + 1), sizeof(double));
+  double *intx_dpa = (double *)calloc(slab * nz, sizeof(double)), *inty_dpa = (double *)calloc(slab * nz, sizeof(double));
+  double *dz_geo = (double *)calloc(slab, sizeof(double));
+
+  for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) e[IX2(d, i, j) + nz * slab] = -bathyT[IX2(d, i, j)];
+  for (int j = Jsq; j <= Jeq + 1; j++) for (int k = nz - 1; k >= 0; k--) for (int i = Isq; i <= Ieq + 1; i++) {
+    size_t x = IX2(d, i, j);
+    e[x + k * slab] = e[x + (k + 1) * slab] + h[x + k * slab] * GV->H_to_Z;
+  }
+  for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+    size_t x = IX2(d, i, j);
+    pa[x] = GxRho_ref * (e[x] - Z_ref);
+  }
+  for (int k = 0; k < nz; k++) { /* :1323-1333 */
+    for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+      size_t x = IX2(d, i, j), x3 = x + k * slab;
+      dz_geo[x] = GV->g_Earth * GV->H_to_Z * h[x3];
+      dpa[x3] = (Rlay[k] - rho_ref) * dz_geo[x];
+      intz_dpa[x3] = 0.5 * (Rlay[k] - rho_ref) * dz_geo[x] * h[x3];
+    }
+    for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
+      size_t x = IX2(d, i, j);
+      intx_dpa[x + k * slab] = 0.5 * (Rlay[k] - rho_ref) * (dz_geo[x] + dz_geo[x + 1]);
+    }
+    for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) {
+      size_t x = IX2(d, i, j);
+      inty_dpa[x + k * slab] = 0.5 * (Rlay[k] - rho_ref) * (dz_geo[x] + dz_geo[x + st]);
+    }
+  }
+  for (int k = 0; k < nz; k++) for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+    size_t x = IX2(d, i, j);
+    pa[x + (k + 1) * slab] = pa[x + k * slab] + dpa[x + k * slab];
+  }
+  for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) { size_t x = IX2(d, i, j); intx_pa[x] = 0.5 * (pa[x] + pa[x + 1]); }
+  for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) { size_t x = IX2(d, i, j); inty_pa[x] = 0.5 * (pa[x] + pa[x + st]); }
+  for (int k = 0; k < nz; k++) for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
+    size_t x = IX2(d, i, j);
+    intx_pa[x + (k + 1) * slab] = intx_pa[x + k * slab] + intx_dpa[x + k * slab];
+  }
+  for (int k = 0; k < nz; k++) for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) {
+    size_t x = IX2(d, i, j);
+    inty_pa[x + (k + 1) * slab] = inty_pa[x + k * slab] + inty_dpa[x + k * slab];
+  }
+  /* PFu, PFv :1794-1813 */
+  for (int k = 0; k < nz; k++) for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
+    size_t x = IX2(d, i, j), x3 = x + k * slab, xb = x + (k + 1) * slab;
+    PFu[x3] = (((pa[x3] * h[x3] + intz_dpa[x3]) - (pa[x3 + 1] * h[x3 + 1] + intz_dpa[x3 + 1])) +
+               ((h[x3 + 1] - h[x3]) * intx_pa[x3] - (e[xb + 1] - e[xb]) * intx_dpa[x3] * GV->Z_to_H)) *
+              ((2.0 * I_Rho0 * IdxCu[x]) / ((h[x3] + h[x3 + 1]) + h_neglect));
+  }
+  for (int k = 0; k < nz; k++) for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) {
+    size_t x = IX2(d, i, j), x3 = x + k * slab, xb = x + (k + 1) * slab;
+    PFv[x3] = (((pa[x3] * h[x3] + intz_dpa[x3]) - (pa[x3 + st] * h[x3 + st] + intz_dpa[x3 + st])) +
+               ((h[x3 + st] - h[x3]) * inty_pa[x3] - (e[xb + st] - e[xb]) * inty_dpa[x3] * GV->Z_to_H)) *
+              ((2.0 * I_Rho0 * IdyCv[x]) / ((h[x3] + h[x3 + st]) + h_neglect));
+  }
+  if (pbce) { /* Set_pbce_Bouss, not use_EOS :735-746 */
+    for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+      size_t x = IX2(d, i, j);
+      double Ihtot = 1.0 / ((e[x] - e[x + nz * slab]) + dz_neglect);
+      pbce[x] = g_prime[0] * GV->H_to_Z;
+      for (int k = 1; k < nz; k++)
+        pbce[x + k * slab] = pbce[x + (k - 1) * slab] + (g_prime[k] * GV->H_to_Z) * ((e[x + k * slab] - e[x + nz * slab]) * Ihtot);
+    }
+  }
+  if (eta) for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) eta[IX2(d, i, j)] = e[IX2(d, i, j)] * GV->Z_to_H;
+  free(e); free(pa); free(dpa); free(intz_dpa); free(intx_pa); free(inty_pa); free(intx_dpa); free(inty_dpa); free(dz_geo);
+  return MOM6X_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* vertvisc :557-1228 (one direction at a time; the reference does u then v with identical code) */
+static void vertvisc_dir(const mom6x_dims *d, const double *maskC, int a0, int a1, int b0, int b1, double *u,
+                         const double *a_u, const double *h_u, const double *Ray_u, const double *tau,
+                         double dt, double dt_Rho0, double H_to_RZ, double *tau_bot) {
+  const int nz = d->nk;
+  const size_t slab = (size_t)d->slab;
+  double *c1 = (double *)calloc((size_t)nz, sizeof(double));
+  for (int j = b0; j <= b1; j++) for (int i = a0; i <= a1; i++) {
+    size_t x = IX2(d, i, j);
+    if (maskC[x] > 0.) {
+      double surface_stress = dt_Rho0 * (maskC[x] * tau[x]);
+      double Ray = Ray_u ? Ray_u[x] : 0.;
+      double b_denom_1 = h_u[x] + dt * (Ray + a_u[x]);
+      double b1 = 1.0 / (b_denom_1 + dt * a_u[x + slab]);
+      double d1 = b_denom_1 * b1;
+      u[x] = b1 * (h_u[x] * u[x] + surface_stress);
+      for (int k = 1; k < nz; k++) {
+        size_t x3 = x + k * slab;
+        if (Ray_u) Ray = Ray_u[x3];
+        c1[k] = dt * a_u[x3] * b1;
+        b_denom_1 = h_u[x3] + dt * (Ray + a_u[x3] * d1);
+        b1 = 1.0 / (b_denom_1 + dt * a_u[x3 + slab]);
+        d1 = b_denom_1 * b1;
+        u[x3] = (h_u[x3] * u[x3] + dt * a_u[x3] * u[x3 - slab]) * b1;
+      }
+      for (int k = nz - 2; k >= 0; k--) u[x + k * slab] = u[x + k * slab] + c1[k + 1] * u[x + (k + 1) * slab];
+    }
+    if (tau_bot) {
+      tau_bot[x] = H_to_RZ * (u[x + (nz - 1) * slab] * a_u[x + nz * slab]);
+      if (Ray_u) for (int k = 0; k < nz; k++) tau_bot[x] = tau_bot[x] + H_to_RZ * (Ray_u[x + k * slab] * u[x + k * slab]);
+    }
+  }
+  free(c1);
+}
+
+int orc_vertvisc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, double *u, double *v,
+                 const double *a_u, const double *a_v, const double *h_u, const double *h_v,
+                 const double *Ray_u, const double *Ray_v, const double *taux, const double *tauy, double dt,
+                 double *taux_bot, double *tauy_bot) {
+  const double dt_Rho0 = dt / GV->H_to_RZ;
+  vertvisc_dir(d, GM(G, d, MOM6X_G_mask2dCu), -1, d->ni - 1, 0, d->nj - 1, u, a_u, h_u, Ray_u, taux, dt, dt_Rho0, GV->H_to_RZ, taux_bot);
+  vertvisc_dir(d, GM(G, d, MOM6X_G_mask2dCv), 0, d->ni - 1, -1, d->nj - 1, v, a_v, h_v, Ray_v, tauy, dt, dt_Rho0, GV->H_to_RZ, tauy_bot);
+  return MOM6X_OK;
+}
+
+/* vertvisc_remnant :1229-1356 */
+static void remnant_dir(const mom6x_dims *d, const double *maskC, int a0, int a1, int b0, int b1, double *vr,
+                        const double *a_u, const double *h_u, const double *Ray_u, double dt) {
+  const int nz = d->nk;
+  const size_t slab = (size_t)d->slab;
+  double *c1 = (double *)calloc((size_t)nz, sizeof(double));
+  for (int j = b0; j <= b1; j++) for (int i = a0; i <= a1; i++) {
+    size_t x = IX2(d, i, j);
+    if (!(maskC[x] > 0.)) continue;
+    double Ray = Ray_u ? Ray_u[x] : 0.;
+    double b_denom_1 = h_u[x] + dt * (Ray + a_u[x]);
+    double b1 = 1.0 / (b_denom_1 + dt * a_u[x + slab]);
+    double d1 = b_denom_1 * b1;
+    vr[x] = b1 * h_u[x];
+    for (int k = 1; k < nz; k++) {
+      size_t x3 = x + k * slab;
+      if (Ray_u) Ray = Ray_u[x3];
+      c1[k] = dt * a_u[x3] * b1;
+      b_denom_1 = h_u[x3] + dt * (Ray + a_u[x3] * d1);
+      b1 = 1.0 / (b_denom_1 + dt * a_u[x3 + slab]);
+      d1 = b_denom_1 * b1;
+      vr[x3] = (h_u[x3] + dt * a_u[x3] * vr[x3 - slab]) * b1;
+    }
+    for (int k = nz - 2; k >= 0; k--) vr[x + k * slab] = vr[x + k * slab] + c1[k + 1] * vr[x + (k + 1) * slab];
+  }
+  free(c1);
+}
+
+int orc_vertvisc_remnant(const mom6x_dims *d, const double *G, double *visc_rem_u, double *visc_rem_v,
+                         const double *a_u, const double *a_v, const double *h_u, const double *h_v,
+                         const double *Ray_u, const double *Ray_v, double dt) {
+  remnant_dir(d, GM(G, d, MOM6X_G_mask2dCu), -1, d->ni - 1, 0, d->nj - 1, visc_rem_u, a_u, h_u, Ray_u, dt);
+  remnant_dir(d, GM(G, d, MOM6X_G_mask2dCv), 0, d->ni - 1, -1, d->nj - 1, visc_rem_v, a_v, h_v, Ray_v, dt);
+  return MOM6X_OK;
+}
