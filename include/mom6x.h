@@ -164,6 +164,17 @@ typedef struct mom6x_pgf_params {
   double Z_ref;          /* G%Z_ref (0)                                                         */
 } mom6x_pgf_params;
 
+/* MOM_dyn_split_RK2_CS parameters (src/core/MOM_dynamics_split_RK2.F90:85-273, read in
+ * initialize_dyn_split_RK2 :1427-1495).                                                     */
+typedef struct mom6x_rk2_params {
+  double be;                   /* BE (0.6)                                                    */
+  double begw;                 /* BEGW (0)                                                    */
+  int    split_bottom_stress;  /* SPLIT_BOTTOM_STRESS (F)                                     */
+  int    BT_use_layer_fluxes;  /* BT_USE_LAYER_FLUXES (T) -- only T supported                 */
+  int    store_CAu;            /* STORE_CORIOLIS_ACCEL (T) -- only T supported                */
+  int    visc_rem_dt_bug;      /* VISC_REM_TIMESTEP_BUG (T with ENABLE_BUGS_BY_DEFAULT)       */
+} mom6x_rk2_params;
+
 /* ------------------------------------------------------------------------- */
 /* Context: owns the device copy of the metrics, the parameter structs, scratch
  * HBM, two HIP streams (compute + halo) and the RCCL communicator handle.    */
@@ -251,6 +262,10 @@ int mom6x_bt_mass_source(mom6x_ctx *ctx, const double *h, const double *eta, int
 int mom6x_set_dtbt(mom6x_ctx *ctx, const double *pbce, double gtot_est, double SSH_add,
                    double *dtbt_out);
 
+/* set_dtbt(G, GV, US, CS, pbce, eta=eta) as called at MOM_dynamics_split_RK2.F90:667 (face areas
+ * from the resting depths, find_face_areas :5221-5236).                                      */
+int mom6x_set_dtbt_pbce(mom6x_ctx *ctx, const double *pbce, double *dtbt_out);
+
 /* btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, eta_PF_in,
  *   U_Cor, V_Cor, accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, G, GV, US,
  *   CS, visc_rem_u, visc_rem_v, SpV_avg, ADp, OBC, BT_cont, eta_PF_start, taux_bot,
@@ -310,6 +325,48 @@ int mom6x_vertvisc(mom6x_ctx *ctx, double *u, double *v, const double *taux, con
                    double dt, double *taux_bot, double *tauy_bot);
 /* vertvisc_remnant(visc, visc_rem_u, visc_rem_v, dt, G, GV, US, CS)  :1229                   */
 int mom6x_vertvisc_remnant(mom6x_ctx *ctx, double *visc_rem_u, double *visc_rem_v, double dt);
+
+/* ------------------------------------------------------------------------- */
+/* MOM_dynamics_split_RK2                                                      */
+
+/* Host callbacks for the callees of step_MOM_dyn_split_RK2 that are NOT on the ported hot path
+ * (SURVEY.md 8f).  All array arguments are DEVICE pointers.  A NULL callback means "keep what the
+ * context already holds" (coefficients / diffu,diffv frozen over the step).                    */
+typedef struct mom6x_rk2_hooks {
+  void *user;
+  /* set_viscous_ML + thickness_to_dz + vertvisc_coef (RK2.F90:602-609 stage 0, :737-738 stage 1,
+   * :1002-1003 stage 2): must leave updated coefficients behind via mom6x_vertvisc_set_coef.   */
+  int (*vertvisc_coef)(void *user, int stage, const double *u, const double *v, const double *h, double dt);
+  /* horizontal_viscosity (RK2.F90:886): fills diffu, diffv.                                     */
+  int (*horizontal_viscosity)(void *user, const double *u_av, const double *v_av, const double *h_av,
+                              const double *uh, const double *vh, double *diffu, double *diffv);
+} mom6x_rk2_hooks;
+
+/* initialize_dyn_split_RK2 (RK2.F90:1346): allocates MOM_dyn_split_RK2_CS on the device (incl. the
+ * BT_cont_type).  continuity, barotropic, CoriolisAdv, PressureForce must be initialised first,
+ * as in :1552-1596.                                                                           */
+int mom6x_initialize_dyn_split_RK2(mom6x_ctx *ctx, const mom6x_rk2_params *p);
+/* The new-run fills of initialize_dyn_split_RK2 :1577-1650 (eta from h; u_av,v_av = u,v; h_av and
+ * CAu_pred from one continuity + CorAdCalc pass).  A restarted run uploads the fields instead
+ * (mom6x_rk2_field) and calls mom6x_rk2_set_CAu_pred_stored.                                   */
+int mom6x_dyn_split_RK2_new_run(mom6x_ctx *ctx, const double *u, const double *v, const double *h,
+                                double *uh, double *vh, double dt);
+int mom6x_rk2_set_CAu_pred_stored(mom6x_ctx *ctx, int stored);
+/* Device pointers to the CS arrays MOM_restart registers (register_restarts_dyn_split_RK2 :1210:
+ * sfc=eta, u2=u_av, v2=v_av, CAu, CAv, diffu, diffv) and the others, by name index:
+ * 0 CAu, 1 CAv, 2 CAu_pred, 3 CAv_pred, 4 PFu, 5 PFv, 6 diffu, 7 diffv, 8 visc_rem_u, 9 visc_rem_v,
+ * 10 u_accel_bt, 11 v_accel_bt, 12 u_av, 13 v_av, 14 h_av, 15 pbce, 16 eta, 17 eta_PF, 18 uhbt,
+ * 19 vhbt, 20 taux_bot, 21 tauy_bot, 22 BT_cont%h_u, 23 BT_cont%h_v.                            */
+double *mom6x_rk2_field(mom6x_ctx *ctx, int which);
+
+/* step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, p_surf_begin,
+ *   p_surf_end, uh, vh, uhtr, vhtr, eta_av, G, GV, US, CS, calc_dtbt, VarMix, MEKE,
+ *   thickness_diffuse_CSp, pbv, STOCH, Waves)                       RK2.F90:294-296.
+ * forces%taux/tauy are planes; tv (layered: no T,S), p_surf_*, VarMix, MEKE, STOCH, Waves absent. */
+int mom6x_step_dyn_split_RK2(mom6x_ctx *ctx, double *u_inst, double *v_inst, double *h,
+                             double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av,
+                             const double *taux, const double *tauy, double dt, int calc_dtbt,
+                             const mom6x_rk2_hooks *hooks);
 
 #ifdef __cplusplus
 }

@@ -180,6 +180,37 @@ def layer_densities(nk, Rho0=1035.0, g_Earth=9.80, drho=2.0):
     return np.ascontiguousarray(Rlay), np.ascontiguousarray(g_prime)
 
 
+class RK2Params(C.Structure):
+    """mom6x_rk2_params; MOM_dyn_split_RK2_CS (MOM_dynamics_split_RK2.F90:85-273)."""
+    _fields_ = [("be", C.c_double), ("begw", C.c_double), ("split_bottom_stress", C.c_int),
+                ("BT_use_layer_fluxes", C.c_int), ("store_CAu", C.c_int), ("visc_rem_dt_bug", C.c_int)]
+
+
+def rk2_params_default():
+    """Defaults read in initialize_dyn_split_RK2 (MOM_dynamics_split_RK2.F90:1427-1495)."""
+    p = RK2Params()
+    p.be, p.begw = 0.6, 0.0
+    p.split_bottom_stress = 0
+    p.BT_use_layer_fluxes = p.store_CAu = p.visc_rem_dt_bug = 1
+    return p
+
+
+VERTVISC_COEF_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double)
+HOR_VISC_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_void_p)
+
+
+class RK2Hooks(C.Structure):
+    """mom6x_rk2_hooks."""
+    _fields_ = [("user", C.c_void_p), ("vertvisc_coef", VERTVISC_COEF_HOOK), ("horizontal_viscosity", HOR_VISC_HOOK)]
+
+
+RK2_FIELDS = ["CAu", "CAv", "CAu_pred", "CAv_pred", "PFu", "PFv", "diffu", "diffv", "visc_rem_u", "visc_rem_v",
+              "u_accel_bt", "v_accel_bt", "u_av", "v_av", "h_av", "pbce", "eta", "eta_PF", "uhbt", "vhbt",
+              "taux_bot", "tauy_bot", "BT_h_u", "BT_h_v"]
+RK2_FIELDS_2D = {"eta", "eta_PF", "uhbt", "vhbt", "taux_bot", "tauy_bot"}
+
+
 # Metric plane indices: enum mom6x_metric
 METRICS = [
     "mask2dT", "mask2dCu", "mask2dCv", "mask2dBu",

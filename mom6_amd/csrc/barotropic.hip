@@ -151,7 +151,7 @@ __global__ void k_bt_mass_source(Dm d, const double *__restrict__ G, const doubl
 // ---- set_dtbt :3509-3633 (find_face_areas add_max branch :5208-5219) -------------------------
 __global__ void k_set_dtbt(Dm d, const double *__restrict__ G, const double *__restrict__ pbce,
                            const double *__restrict__ frhatu, const double *__restrict__ frhatv,
-                           double gtot_est, double Z_to_H, double zadd, double bebt, double cor_scale2,
+                           double gtot_est, double Z_to_H, double zadd, int add_max, double bebt, double cor_scale2,
                            double *Idt_max2_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -159,10 +159,20 @@ __global__ void k_set_dtbt(Dm d, const double *__restrict__ G, const double *__r
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   const double *bathyT = gm(G, d, MOM6X_G_bathyT), *dy_Cu = gm(G, d, MOM6X_G_dy_Cu), *dx_Cv = gm(G, d, MOM6X_G_dx_Cv);
   const double *IdxCu = gm(G, d, MOM6X_G_IdxCu), *IdyCv = gm(G, d, MOM6X_G_IdyCv), *f2 = gm(G, d, MOM6X_G_Coriolis2Bu);
-  const double DatuE = dy_Cu[c] * Z_to_H * dmax(dmax(bathyT[c + 1], bathyT[c]) + zadd, 0.0);
-  const double DatuW = dy_Cu[c - 1] * Z_to_H * dmax(dmax(bathyT[c], bathyT[c - 1]) + zadd, 0.0);
-  const double DatvN = dx_Cv[c] * Z_to_H * dmax(dmax(bathyT[c + st], bathyT[c]) + zadd, 0.0);
-  const double DatvS = dx_Cv[c - st] * Z_to_H * dmax(dmax(bathyT[c], bathyT[c - st]) + zadd, 0.0);
+  double DatuE, DatuW, DatvN, DatvS;
+  if (add_max) {   // find_face_areas(add_max=) :5208-5219
+    DatuE = dy_Cu[c] * Z_to_H * dmax(dmax(bathyT[c + 1], bathyT[c]) + zadd, 0.0);
+    DatuW = dy_Cu[c - 1] * Z_to_H * dmax(dmax(bathyT[c], bathyT[c - 1]) + zadd, 0.0);
+    DatvN = dx_Cv[c] * Z_to_H * dmax(dmax(bathyT[c + st], bathyT[c]) + zadd, 0.0);
+    DatvS = dx_Cv[c - st] * Z_to_H * dmax(dmax(bathyT[c], bathyT[c - st]) + zadd, 0.0);
+  } else {         // find_face_areas without eta / add_max :5221-5236 (zadd = G%Z_ref)
+    const double H0 = (bathyT[c] + zadd) * Z_to_H, HE = (bathyT[c + 1] + zadd) * Z_to_H, HW = (bathyT[c - 1] + zadd) * Z_to_H;
+    const double HN = (bathyT[c + st] + zadd) * Z_to_H, HS = (bathyT[c - st] + zadd) * Z_to_H;
+    DatuE = 0.0; if ((H0 > 0.0) && (HE > 0.0)) DatuE = dy_Cu[c] * (2.0 * H0 * HE) / (H0 + HE);
+    DatuW = 0.0; if ((HW > 0.0) && (H0 > 0.0)) DatuW = dy_Cu[c - 1] * (2.0 * HW * H0) / (HW + H0);
+    DatvN = 0.0; if ((H0 > 0.0) && (HN > 0.0)) DatvN = dx_Cv[c] * (2.0 * H0 * HN) / (H0 + HN);
+    DatvS = 0.0; if ((HS > 0.0) && (H0 > 0.0)) DatvS = dx_Cv[c - st] * (2.0 * HS * H0) / (HS + H0);
+  }
   double gE = gtot_est, gW = gtot_est, gN = gtot_est, gS = gtot_est;
   if (pbce) {
     gE = gW = gN = gS = 0.0;
@@ -647,7 +657,16 @@ extern "C" int mom6x_bt_mass_source(mom6x_ctx *c, const double *h, const double 
   return MOM6X_OK;
 }
 
+static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int add_max, double SSH_add, double *dtbt_out);
 extern "C" int mom6x_set_dtbt(mom6x_ctx *c, const double *pbce, double gtot_est, double SSH_add, double *dtbt_out) {
+  return set_dtbt_impl(c, pbce, gtot_est, 1, SSH_add, dtbt_out);
+}
+// set_dtbt(G, GV, US, CS, pbce, eta=eta) as called from step_MOM_dyn_split_RK2 :667
+extern "C" int mom6x_set_dtbt_pbce(mom6x_ctx *c, const double *pbce, double *dtbt_out) {
+  REQUIRE(pbce, MOM6X_EINVAL, "set_dtbt: Either pbce or gtot_est must be present.");
+  return set_dtbt_impl(c, pbce, 0.0, 0, 0.0, dtbt_out);
+}
+static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int add_max, double SSH_add, double *dtbt_out) {
   REQUIRE(c && c->bt_init, MOM6X_EINVAL, "set_dtbt: Module MOM_barotropic must be initialized before it is used.");
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
@@ -656,7 +675,7 @@ extern "C" int mom6x_set_dtbt(mom6x_ctx *c, const double *pbce, double gtot_est,
   double *tmp = s->work + (size_t)W_eta_pred * d.slab;   // scratch plane
   HIPCHK(hipMemsetAsync(tmp, 0, sizeof(double) * d.slab, c->stream));
   KLAUNCH(c, "k_set_dtbt", k_set_dtbt, grid3(d.ni, d.nj, 1, b), b, d, c->G, pbce, s->frhatu, s->frhatv, gtot_est,
-                     c->GV.Z_to_H, c->bt.Z_ref + SSH_add, c->bt.bebt, c->bt.BT_Coriolis_scale * c->bt.BT_Coriolis_scale, tmp);
+                     c->GV.Z_to_H, c->bt.Z_ref + SSH_add, add_max, c->bt.bebt, c->bt.BT_Coriolis_scale * c->bt.BT_Coriolis_scale, tmp);
   HIPCHK(hipGetLastError());
   // min over the tile in the reference's (j outer, i inner) order is order-independent for min():
   std::vector<double> host((size_t)d.slab);

@@ -1,0 +1,326 @@
+// dyn_split_RK2.hip -- the split-explicit RK2 baroclinic step, device-resident and stream-ordered.
+//
+// Replaces step_MOM_dyn_split_RK2 (MOM_dynamics_split_RK2.F90:294-1205) and the new-run fills of
+// initialize_dyn_split_RK2 (:1577-1650).  The whole step is enqueued on the context's compute stream
+// with no host synchronisation except inside the optional host callbacks (vertvisc_coef,
+// horizontal_viscosity: callees that are not on the ported hot path) and set_dtbt's scalar reduction.
+// Every `[halo]` mark of the reference (do_group_pass) is a halo_update() call; on one tile that is
+// the periodic wrap kernel, on several tiles the RCCL exchange (halo.hip).
+#include "mom6x_dev.h"
+
+void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);
+
+struct RK2State {
+  mom6x_rk2_params P;
+  // MOM_dyn_split_RK2_CS arrays (RK2.F90:85-273)
+  double *CAu, *CAv, *CAu_pred, *CAv_pred, *PFu, *PFv, *diffu, *diffv, *visc_rem_u, *visc_rem_v;
+  double *u_accel_bt, *v_accel_bt, *u_av, *v_av, *h_av, *pbce;
+  double *eta, *eta_PF, *uhbt, *vhbt, *taux_bot, *tauy_bot;
+  mom6x_BT_cont BT;
+  bool CAu_pred_stored;
+  // the routine's stack temporaries :341-357
+  double *up, *vp, *hp, *u_bc_accel, *v_bc_accel, *uh_in, *vh_in, *eta_pred;
+};
+
+namespace {
+
+inline dim3 blk2() { return dim3(64, 4, 1); }
+inline dim3 gridk(int nx, int ny, int nk, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, nchunks(nk)); }
+
+// u_bc_accel = (CAu + PFu) + diffu  (:565-572, :900-907) and optionally up = mask*(u + dt*u_bc_accel) (:591-598)
+__global__ void __launch_bounds__(256)
+k_bc_accel(Dm d, const double *__restrict__ G, const double *__restrict__ CAu, const double *__restrict__ CAv,
+           const double *__restrict__ PFu, const double *__restrict__ PFv, const double *__restrict__ diffu,
+           const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc,
+           const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ up, double *__restrict__ vp,
+           double dt) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const bool do_u = (j >= 0), do_v = (i >= 0);
+  const double mCu = gm(G, d, MOM6X_G_mask2dCu)[x], mCv = gm(G, d, MOM6X_G_mask2dCv)[x];
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    if (do_u) {
+      const double a = (CAu[c] + PFu[c]) + diffu[c];
+      u_bc[c] = a;
+      if (up) up[c] = mCu * (u[c] + dt * a);
+    }
+    if (do_v) {
+      const double a = (CAv[c] + PFv[c]) + diffv[c];
+      v_bc[c] = a;
+      if (vp) vp[c] = mCv * (v[c] + dt * a);
+    }
+  }
+}
+
+// out = mask * (u + dtx * (bc_accel + accel_bt))   (:681-694, :957-966); out may alias u
+__global__ void __launch_bounds__(256)
+k_vel_update(Dm d, const double *__restrict__ G, const double *u, const double *v, const double *__restrict__ u_bc,
+             const double *__restrict__ v_bc, const double *__restrict__ u_abt, const double *__restrict__ v_abt,
+             double *uo, double *vo, double dtx) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const bool do_u = (j >= 0), do_v = (i >= 0);
+  const double mCu = gm(G, d, MOM6X_G_mask2dCu)[x], mCv = gm(G, d, MOM6X_G_mask2dCv)[x];
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    if (do_v) vo[c] = mCv * (v[c] + dtx * (v_bc[c] + v_abt[c]));
+    if (do_u) uo[c] = mCu * (u[c] + dtx * (u_bc[c] + u_abt[c]));
+  }
+}
+
+// h_av updates on (is-2..ie+2, js-2..je+2): mode 0: 0.5*(a+b) (:808-810); 1: copy a (:1025-1027);
+// 2: 0.5*(h_av + a) (:1064-1066); 3: hp = (1-w)*a + w*hp on (is-1..ie+1) (:828-830)
+__global__ void __launch_bounds__(256)
+k_h_av(Dm d, double *h_av, const double *__restrict__ a, const double *__restrict__ b, int mode, double w, int ext) {
+  const int i = -ext + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -ext + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 + ext || j > d.nj - 1 + ext) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    if (mode == 0) h_av[c] = 0.5 * (a[c] + b[c]);
+    else if (mode == 1) h_av[c] = a[c];
+    else if (mode == 2) h_av[c] = 0.5 * (h_av[c] + a[c]);
+    else h_av[c] = (1.0 - w) * a[c] + w * h_av[c];
+  }
+}
+
+// uhtr += uh*dt, vhtr += vh*dt  :1072-1079
+__global__ void __launch_bounds__(256)
+k_uhtr(Dm d, double *__restrict__ uhtr, double *__restrict__ vhtr, const double *__restrict__ uh,
+       const double *__restrict__ vh, double dt) {
+  const int i = -3 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -3 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni + 1 || j > d.nj + 1) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const bool do_u = (j >= -2), do_v = (i >= -2);
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    if (do_u) uhtr[c] = uhtr[c] + uh[c] * dt;
+    if (do_v) vhtr[c] = vhtr[c] + vh[c] * dt;
+  }
+}
+
+// eta = eta_pred on the computational domain :946 ; or eta = sum_k h - Z_to_H*bathyT :1577-1590
+__global__ void k_eta(Dm d, const double *__restrict__ G, double *eta, const double *__restrict__ src,
+                      const double *__restrict__ h, double Z_to_H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const size_t x = ix2(d, i, j);
+  if (src) { eta[x] = src[x]; return; }
+  double e = -Z_to_H * gm(G, d, MOM6X_G_bathyT)[x];
+  for (int k = 0; k < d.nk; k++) e = e + h[x + (size_t)k * d.slab];
+  eta[x] = e;
+}
+
+int pass3(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list<int> stg, int nk) {
+  double *ff[16]; int ss[16], nn[16]; int n = 0;
+  auto s = stg.begin();
+  for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = nk; n++; }
+  halo_wrap(c, ff, ss, nn, n);
+  return MOM6X_OK;
+}
+
+}  // namespace
+
+void rk2_state_free(mom6x_ctx *c) {
+  if (!c->rk2) return;
+  RK2State *s = c->rk2;
+  double *p3[] = { s->CAu, s->CAv, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv, s->diffu, s->diffv, s->visc_rem_u, s->visc_rem_v,
+                   s->u_accel_bt, s->v_accel_bt, s->u_av, s->v_av, s->h_av, s->pbce, s->up, s->vp, s->hp, s->u_bc_accel,
+                   s->v_bc_accel, s->uh_in, s->vh_in, s->BT.h_u, s->BT.h_v, s->eta, s->eta_PF, s->uhbt, s->vhbt, s->taux_bot,
+                   s->tauy_bot, s->eta_pred, s->BT.FA_u_EE, s->BT.FA_u_E0, s->BT.FA_u_W0, s->BT.FA_u_WW, s->BT.uBT_WW,
+                   s->BT.uBT_EE, s->BT.FA_v_NN, s->BT.FA_v_N0, s->BT.FA_v_S0, s->BT.FA_v_SS, s->BT.vBT_SS, s->BT.vBT_NN };
+  for (double *p : p3) (void)hipFree(p);
+  delete s;
+  c->rk2 = nullptr;
+}
+
+extern "C" int mom6x_initialize_dyn_split_RK2(mom6x_ctx *c, const mom6x_rk2_params *p) {
+  REQUIRE(c && p, MOM6X_EINVAL, "mom6x_initialize_dyn_split_RK2: null argument");
+  REQUIRE(c->cont_init && c->bt_init && c->cor_init && c->pgf_init, MOM6X_EINVAL,
+          "initialize_dyn_split_RK2: continuity, barotropic, CoriolisAdv and PressureForce must be initialised first");
+  REQUIRE(p->BT_use_layer_fluxes && p->store_CAu, MOM6X_EUNSUPPORTED,
+          "dyn_split_RK2: only BT_USE_LAYER_FLUXES=True and STORE_CORIOLIS_ACCEL=True are supported");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->rk2) rk2_state_free(c);
+  RK2State *s = new RK2State();
+  memset(s, 0, sizeof(*s));
+  s->P = *p;
+  const size_t n2 = (size_t)c->dims.slab, n3 = n2 * c->dims.nk;
+  double **p3[] = { &s->CAu, &s->CAv, &s->CAu_pred, &s->CAv_pred, &s->PFu, &s->PFv, &s->diffu, &s->diffv, &s->visc_rem_u,
+                    &s->visc_rem_v, &s->u_accel_bt, &s->v_accel_bt, &s->u_av, &s->v_av, &s->h_av, &s->pbce, &s->up, &s->vp,
+                    &s->hp, &s->u_bc_accel, &s->v_bc_accel, &s->uh_in, &s->vh_in, &s->BT.h_u, &s->BT.h_v };
+  for (double **q : p3) { HIPCHK(hipMalloc(q, n3 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, 0, n3 * sizeof(double), c->stream)); }
+  double **p2[] = { &s->eta, &s->eta_PF, &s->uhbt, &s->vhbt, &s->taux_bot, &s->tauy_bot, &s->eta_pred, &s->BT.FA_u_EE,
+                    &s->BT.FA_u_E0, &s->BT.FA_u_W0, &s->BT.FA_u_WW, &s->BT.uBT_WW, &s->BT.uBT_EE, &s->BT.FA_v_NN, &s->BT.FA_v_N0,
+                    &s->BT.FA_v_S0, &s->BT.FA_v_SS, &s->BT.vBT_SS, &s->BT.vBT_NN };
+  for (double **q : p2) { HIPCHK(hipMalloc(q, n2 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, 0, n2 * sizeof(double), c->stream)); }
+  s->CAu_pred_stored = false;
+  c->rk2 = s;
+  return MOM6X_OK;
+}
+
+extern "C" double *mom6x_rk2_field(mom6x_ctx *c, int which) {
+  if (!c || !c->rk2) return nullptr;
+  RK2State *s = c->rk2;
+  double *t[] = { s->CAu, s->CAv, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv, s->diffu, s->diffv, s->visc_rem_u, s->visc_rem_v,
+                  s->u_accel_bt, s->v_accel_bt, s->u_av, s->v_av, s->h_av, s->pbce, s->eta, s->eta_PF, s->uhbt, s->vhbt,
+                  s->taux_bot, s->tauy_bot, s->BT.h_u, s->BT.h_v };
+  if (which < 0 || which >= (int)(sizeof(t) / sizeof(t[0]))) return nullptr;
+  return t[which];
+}
+
+extern "C" int mom6x_rk2_set_CAu_pred_stored(mom6x_ctx *c, int stored) {
+  REQUIRE(c && c->rk2, MOM6X_EINVAL, "mom6x_rk2_set_CAu_pred_stored: dyn_split_RK2 not initialised");
+  c->rk2->CAu_pred_stored = (stored != 0);
+  return MOM6X_OK;
+}
+
+#define CHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+extern "C" int mom6x_dyn_split_RK2_new_run(mom6x_ctx *c, const double *u, const double *v, const double *h, double *uh,
+                                           double *vh, double dt) {
+  REQUIRE(c && c->rk2, MOM6X_EINVAL, "dyn_split_RK2_new_run: initialize_dyn_split_RK2 must be called first");
+  HIPCHK(hipSetDevice(c->device));
+  RK2State *s = c->rk2;
+  const Dm d = c->d;
+  const size_t n3 = (size_t)d.slab * d.nk;
+  const dim3 b = blk2();
+  KLAUNCH(c, "k_eta", k_eta, grid3(d.ni, d.nj, 1, b), b, d, c->G, s->eta, (const double *)nullptr, h, c->GV.Z_to_H);
+  HIPCHK(hipMemcpyAsync(s->u_av, u, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(s->v_av, v, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  // h_tmp = h ; continuity(u_av, v_av, h, h_tmp, uh, vh, dt) ; h_av = 0.5*(h + h_tmp)  :1626-1633
+  double *h_tmp = s->hp;
+  HIPCHK(hipMemcpyAsync(h_tmp, h, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  CHK(mom6x_continuity_PPM(c, s->u_av, s->v_av, h, h_tmp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr));
+  pass3(c, { h_tmp }, { 0 }, d.nk);
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 2 * d.halo, d.nj + 2 * d.halo, d.nk, b), b, d, s->h_av, h, (const double *)h_tmp, 0, 0.0, d.halo);
+  pass3(c, { s->u_av, s->v_av, uh, vh }, { 1, 2, 1, 2 }, d.nk);
+  CHK(mom6x_CorAdCalc(c, s->u_av, s->v_av, s->h_av, uh, vh, s->CAu_pred, s->CAv_pred));
+  s->CAu_pred_stored = true;
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_inst, double *h, double *uh, double *vh,
+                                        double *uhtr, double *vhtr, double *eta_av, const double *taux, const double *tauy,
+                                        double dt, int calc_dtbt, const mom6x_rk2_hooks *hooks) {
+  REQUIRE(c && c->rk2, MOM6X_EINVAL, "step_MOM_dyn_split_RK2: initialize_dyn_split_RK2 must be called first");
+  REQUIRE(u_inst && v_inst && h && uh && vh && uhtr && vhtr && eta_av && taux && tauy, MOM6X_EINVAL,
+          "step_MOM_dyn_split_RK2: null mandatory array");
+  REQUIRE(c->a_u, MOM6X_EINVAL, "step_MOM_dyn_split_RK2: vertical viscosity coefficients have not been set");
+  HIPCHK(hipSetDevice(c->device));
+  RK2State *s = c->rk2;
+  const mom6x_rk2_params &R = s->P;
+  const Dm d = c->d;
+  const size_t n2 = (size_t)d.slab, n3 = n2 * d.nk;
+  const dim3 b = blk2();
+  const int nk = d.nk;
+  double *u_av = s->u_av, *v_av = s->v_av, *h_av = s->h_av, *eta = s->eta;
+  double *up = s->up, *vp = s->vp, *hp = s->hp, *u_bc = s->u_bc_accel, *v_bc = s->v_bc_accel;
+  const double *taux_bot = R.split_bottom_stress ? s->taux_bot : nullptr;
+  const double *tauy_bot = R.split_bottom_stress ? s->tauy_bot : nullptr;
+  auto coef_hook = [&](int stage, const double *uu, const double *vv, double dtt) -> int {
+    if (hooks && hooks->vertvisc_coef) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      int rc = hooks->vertvisc_coef(hooks->user, stage, uu, vv, h, dtt);
+      REQUIRE(rc == 0, MOM6X_EINVAL, "step_MOM_dyn_split_RK2: vertvisc_coef callback failed");
+    }
+    return MOM6X_OK;
+  };
+
+  // up = vp = 0 ; hp = h  :421-425 (up, vp are fully overwritten where they are used; the halo update fills the rest)
+  HIPCHK(hipMemsetAsync(up, 0, n3 * sizeof(double), c->stream));
+  HIPCHK(hipMemsetAsync(vp, 0, n3 * sizeof(double), c->stream));
+  HIPCHK(hipMemcpyAsync(hp, h, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+
+  // PFu = d/dx M(h,T,S) ; pbce = dM/deta  :503
+  CHK(mom6x_PressureForce(c, h, s->PFu, s->PFv, s->pbce, s->eta_PF));
+  if (!s->CAu_pred_stored) CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));   // :552-557
+  // u_bc_accel = CAu_pred + PFu + diffu ; up = mask*(u + dt*u_bc_accel)  :564-598
+  KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv,
+          s->diffu, s->diffv, u_bc, v_bc, (const double *)u_inst, (const double *)v_inst, up, vp, dt);
+  CHK(coef_hook(0, up, vp, dt));                                        // :602-609
+  CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :610
+  pass3(c, { eta }, { 0 }, 1);                                          // pass_eta :620
+  pass3(c, { s->visc_rem_u, s->visc_rem_v }, { 1, 2 }, nk);             // pass_visc_rem :621
+
+  CHK(mom6x_bt_mass_source(c, h, eta, 1));                              // :629
+  // continuity(u, v, h, hp, uh_in, vh_in, dt, visc_rem_u, visc_rem_v, BT_cont)  :646
+  CHK(mom6x_continuity_PPM(c, u_inst, v_inst, h, hp, s->uh_in, s->vh_in, dt, nullptr, nullptr, s->visc_rem_u, s->visc_rem_v,
+                           nullptr, nullptr, &s->BT, nullptr, nullptr));
+  CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :649-652
+  if (calc_dtbt) CHK(mom6x_set_dtbt_pbce(c, s->pbce, nullptr));         // :659-668
+  // predictor btstep :673-676
+  CHK(mom6x_btstep(c, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, s->pbce, s->eta_PF, u_av, v_av, s->u_accel_bt,
+                   s->v_accel_bt, s->eta_pred, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, &s->BT, taux_bot, tauy_bot,
+                   s->uh_in, s->vh_in, u_inst, v_inst, nullptr));
+
+  const double dt_pred = dt * R.be;                                     // :679
+  KLAUNCH(c, "k_vel_update", k_vel_update, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
+          (const double *)v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, up, vp, dt_pred);   // :681-694
+  CHK(coef_hook(1, up, vp, dt_pred));                                   // :737-738
+  CHK(mom6x_vertvisc(c, up, vp, taux, tauy, dt_pred, s->taux_bot, s->tauy_bot));                 // :754
+  CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, R.visc_rem_dt_bug ? dt_pred : dt));   // :763-767
+  pass3(c, { s->visc_rem_u, s->visc_rem_v }, { 1, 2 }, nk);             // :769
+  pass3(c, { up, vp }, { 1, 2 }, nk);                                   // pass_uvp :773
+
+  // uh = u_av * h ; hp = h + dt * div . uh  :779-781
+  CHK(mom6x_continuity_PPM(c, up, vp, h, hp, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av, &s->BT,
+                           nullptr, nullptr));
+  pass3(c, { hp, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);          // pass_hp_uv :785
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 4, d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)hp, 0, 0.0, 2);   // :808-810
+
+  // ---- corrector
+  CHK(mom6x_bt_mass_source(c, hp, s->eta_pred, 0));                     // :820
+  if (R.begw != 0.0) {                                                  // :822-833
+    KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 2, d.nj + 2, nk, b), b, d, hp, (const double *)h, (const double *)nullptr, 3, R.begw, 1);
+    CHK(mom6x_PressureForce(c, hp, s->PFu, s->PFv, s->pbce, s->eta_PF));
+  }
+  CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :864-867
+  if (hooks && hooks->horizontal_viscosity) {                           // :884-888
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = hooks->horizontal_viscosity(hooks->user, u_av, v_av, h_av, uh, vh, s->diffu, s->diffv);
+    REQUIRE(rc == 0, MOM6X_EINVAL, "step_MOM_dyn_split_RK2: horizontal_viscosity callback failed");
+  }
+  CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu, s->CAv));    // :893
+  KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, s->CAu, s->CAv, s->PFu, s->PFv, s->diffu,
+          s->diffv, u_bc, v_bc, (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, dt);   // :900-907
+  // corrector btstep :939-942
+  CHK(mom6x_btstep(c, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, s->pbce, s->eta_PF, u_av, v_av, s->u_accel_bt,
+                   s->v_accel_bt, s->eta_pred, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, &s->BT, taux_bot, tauy_bot, uh, vh,
+                   u_av, v_av, eta_av));
+  KLAUNCH(c, "k_eta", k_eta, grid3(d.ni, d.nj, 1, b), b, d, c->G, eta, (const double *)s->eta_pred, (const double *)nullptr, 0.0);   // :946
+  // u = mask*(u + dt*(u_bc_accel + u_accel_bt))  :957-966
+  KLAUNCH(c, "k_vel_update", k_vel_update, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
+          (const double *)v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, u_inst, v_inst, dt);
+  CHK(coef_hook(2, u_inst, v_inst, dt));                                // :1002-1003
+  CHK(mom6x_vertvisc(c, u_inst, v_inst, taux, tauy, dt, s->taux_bot, s->tauy_bot));   // :1013
+  CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :1022
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 4, d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2);   // :1025-1027
+  pass3(c, { s->visc_rem_u, s->visc_rem_v }, { 1, 2 }, nk);             // :1030
+  pass3(c, { u_inst, v_inst }, { 1, 2 }, nk);                           // pass_uv :1034
+  // uh = u_av * h ; h = h + dt * div . uh  :1041-1043
+  CHK(mom6x_continuity_PPM(c, u_inst, v_inst, h, h, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av,
+                           nullptr, nullptr, nullptr));
+  pass3(c, { h }, { 0 }, nk);                                           // pass_h :1045
+  pass3(c, { u_av, v_av, uh, vh }, { 1, 2, 1, 2 }, nk);                 // pass_av_uvh :1053
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 4, d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2);   // :1064-1066
+  KLAUNCH(c, "k_uhtr", k_uhtr, gridk(d.ni + 5, d.nj + 5, nk, b), b, d, uhtr, vhtr, (const double *)uh, (const double *)vh, dt);   // :1072-1079
+  // CAu_pred for the next step :1081-1090
+  CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));
+  s->CAu_pred_stored = true;
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}

@@ -184,6 +184,42 @@ class Dycore:
         """vertvisc_remnant (MOM_vert_friction.F90:1229)."""
         check(self.lib, self.lib.mom6x_vertvisc_remnant(self.ctx, _ptr(visc_rem_u), _ptr(visc_rem_v), C.c_double(dt)))
 
+    # -- MOM_dynamics_split_RK2 --------------------------------------------------------------
+    def initialize_dyn_split_RK2(self, params=None):
+        """initialize_dyn_split_RK2 (MOM_dynamics_split_RK2.F90:1346): allocate the CS on the device."""
+        self.rk2_params = params if params is not None else abi.rk2_params_default()
+        check(self.lib, self.lib.mom6x_initialize_dyn_split_RK2(self.ctx, C.byref(self.rk2_params)))
+
+    def dyn_split_RK2_new_run(self, u, v, h, uh, vh, dt):
+        """The new-run fills of initialize_dyn_split_RK2 (:1577-1650)."""
+        check(self.lib, self.lib.mom6x_dyn_split_RK2_new_run(self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(uh), _ptr(vh), C.c_double(dt)))
+
+    def rk2_field(self, name):
+        """Zero-copy torch view of a MOM_dyn_split_RK2_CS array (restart / diagnostics access)."""
+        which = abi.RK2_FIELDS.index(name)
+        ptr = self.lib.mom6x_rk2_field(self.ctx, C.c_int(which))
+        shape = self.dims.shape2() if name in abi.RK2_FIELDS_2D else self.dims.shape3()
+        return _view(ptr, shape, self.device)
+
+    def step_MOM_dyn_split_RK2(self, u, v, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy, dt, calc_dtbt=False,
+                               vertvisc_coef=None, horizontal_viscosity=None):
+        """step_MOM_dyn_split_RK2 (MOM_dynamics_split_RK2.F90:294).
+
+        vertvisc_coef(stage, u_ptr, v_ptr, h_ptr, dt) / horizontal_viscosity(u_av, v_av, h_av, uh, vh, diffu, diffv)
+        are optional host callbacks (device pointers as ints) for the un-ported callees."""
+        hooks = None
+        if vertvisc_coef is not None or horizontal_viscosity is not None:
+            hk = abi.RK2Hooks()
+            if vertvisc_coef is not None:
+                hk.vertvisc_coef = abi.VERTVISC_COEF_HOOK(lambda user, stage, pu, pv, ph, dtt: int(vertvisc_coef(stage, pu, pv, ph, dtt) or 0))
+            if horizontal_viscosity is not None:
+                hk.horizontal_viscosity = abi.HOR_VISC_HOOK(lambda user, a, b2, c2, d2, e2, f2, g2: int(horizontal_viscosity(a, b2, c2, d2, e2, f2, g2) or 0))
+            self._hooks = hk
+            hooks = C.byref(hk)
+        check(self.lib, self.lib.mom6x_step_dyn_split_RK2(
+            self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(uh), _ptr(vh), _ptr(uhtr), _ptr(vhtr), _ptr(eta_av), _ptr(taux),
+            _ptr(tauy), C.c_double(dt), C.c_int(int(calc_dtbt)), hooks))
+
 
 def _view(ptr, shape, device):
     """torch tensor aliasing device memory owned by the C library."""

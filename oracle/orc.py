@@ -151,3 +151,72 @@ def vertvisc_remnant(d, G, visc_rem_u, visc_rem_v, a_u, a_v, h_u, h_v, Ray_u, Ra
     rc = lib().orc_vertvisc_remnant(C.byref(d), _p(G), _p(visc_rem_u), _p(visc_rem_v), _p(a_u), _p(a_v), _p(h_u), _p(h_v),
                                     _p(Ray_u), _p(Ray_v), C.c_double(dt))
     assert rc == 0, rc
+
+
+# ------------------------------------------------------------------------------------------
+# MOM_dynamics_split_RK2
+from mom6_amd import abi as _abi
+
+
+class ViscCoef(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("a_u", "a_v", "h_u", "h_v", "Ray_u", "Ray_v")]
+
+
+class Rk2CS(C.Structure):
+    _names3 = ["CAu", "CAv", "CAu_pred", "CAv_pred", "PFu", "PFv", "diffu", "diffv", "visc_rem_u", "visc_rem_v",
+               "u_accel_bt", "v_accel_bt", "u_av", "v_av", "h_av", "pbce"]
+    _names2 = ["eta", "eta_PF", "uhbt", "vhbt", "taux_bot", "tauy_bot"]
+    _fields_ = [(n, C.c_void_p) for n in _names3 + _names2] + [("CAu_pred_stored", C.c_int)]
+
+
+class Rk2All(C.Structure):
+    _fields_ = [("d", C.c_void_p), ("G", C.c_void_p), ("GV", C.c_void_p), ("cont", C.c_void_p), ("bt", C.c_void_p),
+                ("cor", C.c_void_p), ("pgf", C.c_void_p), ("rk2", C.c_void_p), ("Rlay", C.c_void_p), ("g_prime", C.c_void_p),
+                ("CS", C.c_void_p), ("BTCS", C.c_void_p), ("BT_cont", C.c_void_p), ("first_direction", C.c_int)]
+
+
+class OrcModel:
+    """The oracle's model instance: every control structure step_MOM_dyn_split_RK2 reaches."""
+
+    def __init__(self, d, M, GV, cont, bt, cor, pgf, rk2, Rlay, g_prime, first_direction=0):
+        self.d, self.M, self.GV = d, M, GV
+        self.cont, self.bt, self.cor, self.pgf, self.rk2 = cont, bt, cor, pgf, rk2
+        self.Rlay = np.ascontiguousarray(Rlay); self.g_prime = np.ascontiguousarray(g_prime)
+        self.f = {n: np.zeros(d.shape3()) for n in Rk2CS._names3}
+        self.f.update({n: np.zeros(d.shape2()) for n in Rk2CS._names2})
+        self.cs = Rk2CS()
+        for n in Rk2CS._names3 + Rk2CS._names2:
+            setattr(self.cs, n, self.f[n].ctypes.data)
+        self.cs.CAu_pred_stored = 0
+        self.btcs = BtState(d)
+        barotropic_init(d, M, GV, bt, self.btcs)
+        self.bt_cont = new_bt_cont(d)
+        self.bt_cont_s = bt_cont_struct(self.bt_cont)
+        A = Rk2All()
+        A.d = C.addressof(d); A.G = M.ctypes.data; A.GV = C.addressof(GV); A.cont = C.addressof(cont); A.bt = C.addressof(bt)
+        A.cor = C.addressof(cor); A.pgf = C.addressof(pgf); A.rk2 = C.addressof(rk2)
+        A.Rlay = self.Rlay.ctypes.data; A.g_prime = self.g_prime.ctypes.data
+        A.CS = C.addressof(self.cs); A.BTCS = C.addressof(self.btcs.struct); A.BT_cont = C.addressof(self.bt_cont_s)
+        A.first_direction = first_direction
+        self.A = A
+
+    def __getitem__(self, n):
+        return self.f[n]
+
+    def initialize(self, u, v, h, uh, vh, dt):
+        rc = lib().orc_initialize_dyn_split_RK2(C.byref(self.A), _p(u), _p(v), _p(h), _p(uh), _p(vh), C.c_double(dt))
+        if rc != 0:
+            raise RuntimeError(f"orc_initialize_dyn_split_RK2 rc={rc}")
+
+    def step(self, u, v, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy, dt, coefs, calc_dtbt=False, diffu_new=None, diffv_new=None):
+        """coefs: list of 3 tuples (a_u, a_v, h_u, h_v, Ray_u, Ray_v) or a single tuple used for all stages."""
+        if not isinstance(coefs, list):
+            coefs = [coefs] * 3
+        arr = (ViscCoef * 3)()
+        for s in range(3):
+            for n, a in zip(("a_u", "a_v", "h_u", "h_v", "Ray_u", "Ray_v"), coefs[s]):
+                setattr(arr[s], n, a.ctypes.data if a is not None else None)
+        rc = lib().orc_step_dyn_split_RK2(C.byref(self.A), _p(u), _p(v), _p(h), _p(uh), _p(vh), _p(uhtr), _p(vhtr), _p(eta_av),
+                                          _p(taux), _p(tauy), C.c_double(dt), C.c_int(int(calc_dtbt)), arr, _p(diffu_new), _p(diffv_new))
+        if rc != 0:
+            raise RuntimeError(f"orc_step_dyn_split_RK2 rc={rc}")

@@ -1,0 +1,139 @@
+"""GPU parity of the whole split RK2 baroclinic step (step_MOM_dyn_split_RK2) against the oracle.
+
+BT_STRONG_DRAG=True removes the only transcendental on the path (av_rem**(1/nstep)), so several
+consecutive steps must stay BIT-IDENTICAL in every prognostic and restart field; on the default
+path the fields must agree to 1e-11 of their range after 3 steps."""
+import numpy as np
+import pytest
+
+from mom6_amd import abi, synth
+from tests import helpers as H
+from tests.test_dyn_gpu import visc_coefs
+
+pytestmark = pytest.mark.gpu
+G = abi.G
+
+STATE = ["u", "v", "h", "uh", "vh", "uhtr", "vhtr", "eta_av"]
+STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h", CAu="u", CAv="v", CAu_pred="u", CAv_pred="v",
+            PFu="u", PFv="v", visc_rem_u="u", visc_rem_v="v", u_accel_bt="u", v_accel_bt="v", u_av="u", v_av="v", h_av="h",
+            eta="h", eta_PF="h", uhbt="u", vhbt="v", taux_bot="u", tauy_bot="v", BT_h_u="u", BT_h_v="v", pbce="h")
+
+
+def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, per_stage=False, new_diff=False,
+        exact=True, rtol=1e-11):
+    import torch
+    from mom6_amd.dycore import Dycore
+    gg, d, M = cfg
+    GV = abi.vgrid_default()
+    Rlay, gp = abi.layer_densities(d.nk)
+    dt = 1200.0
+
+    def params():
+        bt = abi.barotropic_params_default(30.0)
+        for k, v in (bt_mod or {}).items():
+            setattr(bt, k, v)
+        rk2 = abi.rk2_params_default()
+        for k, v in (rk2_mod or {}).items():
+            setattr(rk2, k, v)
+        cor = abi.coriolis_params_default()
+        for k, v in (cor_mod or {}).items():
+            setattr(cor, k, v)
+        return abi.continuity_params_default(d.nk, GV.Angstrom_H), bt, cor, abi.pgf_params_default(GV.Rho0), rk2
+
+    h, u, v = synth.make_state(d, M, u_max=0.05, h_pert=0.001)
+    base = visc_coefs(d, M)
+    if per_stage:
+        coefs = [tuple(base), tuple([base[0] * 1.1, base[1] * 1.1] + base[2:]), tuple([base[0] * 0.9, base[1] * 0.9] + base[2:])]
+        coefs = [tuple(np.ascontiguousarray(a) for a in c) for c in coefs]
+    else:
+        coefs = [tuple(base)] * 3
+    taux = np.ascontiguousarray(0.1 * synth.smooth_field(d, 41, ox=1, oy=.5) * M[G["mask2dCu"]])
+    tauy = np.ascontiguousarray(0.05 * synth.smooth_field(d, 42, ox=.5, oy=1) * M[G["mask2dCv"]])
+    diff_new = None
+    if new_diff:
+        diff_new = (np.ascontiguousarray(1e-7 * synth.smooth_field(d, 61, nk=d.nk, ox=1, oy=.5) * M[G["mask2dCu"]][None]),
+                    np.ascontiguousarray(1e-7 * synth.smooth_field(d, 62, nk=d.nk, ox=.5, oy=1) * M[G["mask2dCv"]][None]))
+
+    # ---------------- oracle
+    cont, bt, cor, pgf, rk2 = params()
+    m = orc.OrcModel(d, M, GV, cont, bt, cor, pgf, rk2, Rlay, gp, first_direction)
+    so = dict(u=u.copy(), v=v.copy(), h=h.copy(), uh=np.zeros_like(h), vh=np.zeros_like(h), uhtr=np.zeros_like(h),
+              vhtr=np.zeros_like(h), eta_av=np.zeros(d.shape2()))
+    m.initialize(so["u"], so["v"], so["h"], so["uh"], so["vh"], dt)
+    for n in range(nsteps):
+        m.step(so["u"], so["v"], so["h"], so["uh"], so["vh"], so["uhtr"], so["vhtr"], so["eta_av"], taux, tauy, dt, coefs,
+               calc_dtbt=(n == 0), diffu_new=diff_new[0] if diff_new else None, diffv_new=diff_new[1] if diff_new else None)
+
+    # ---------------- device
+    cont2, bt2, cor2, pgf2, rk22 = params()
+    dyc = Dycore(d, M, GV, first_direction)
+    dyc.continuity_init(cont2); dyc.barotropic_init(bt2); dyc.CoriolisAdv_init(cor2); dyc.PressureForce_init(pgf2, Rlay, gp)
+    dyc.initialize_dyn_split_RK2(rk22)
+    sg = dict(u=dyc.to_dev(u), v=dyc.to_dev(v), h=dyc.to_dev(h), uh=dyc.zeros3(), vh=dyc.zeros3(), uhtr=dyc.zeros3(),
+              vhtr=dyc.zeros3(), eta_av=dyc.zeros2())
+    cdev = [tuple(dyc.to_dev(a) if a is not None else None for a in c) for c in (coefs if per_stage else coefs[:1])]
+    dyc.vertvisc_set_coef(*cdev[0])
+    txd, tyd = dyc.to_dev(taux), dyc.to_dev(tauy)
+    dnew = tuple(dyc.to_dev(a) for a in diff_new) if diff_new else None
+    torch.cuda.synchronize()
+    dyc.dyn_split_RK2_new_run(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], dt)
+    stages = []
+
+    def coef_hook(stage, pu, pv, ph, dtt):
+        stages.append((stage, dtt))
+        dyc.vertvisc_set_coef(*cdev[stage])
+        return 0
+
+    def hv_hook(pu, pv, ph, puh, pvh, pdu, pdv):
+        dyc.rk2_field("diffu").copy_(dnew[0]); dyc.rk2_field("diffv").copy_(dnew[1])
+        torch.cuda.synchronize()
+        return 0
+
+    for n in range(nsteps):
+        dyc.step_MOM_dyn_split_RK2(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], sg["uhtr"], sg["vhtr"], sg["eta_av"], txd, tyd,
+                                   dt, calc_dtbt=(n == 0), vertvisc_coef=coef_hook if per_stage else None,
+                                   horizontal_viscosity=hv_hook if new_diff else None)
+    dyc.sync()
+    if per_stage:
+        assert [s for s, _ in stages[:3]] == [0, 1, 2] and stages[1][1] == dt * rk22.be
+
+    def cmp(name, a, b):
+        sl = H.interior(d, STAG[name])
+        if exact:
+            H.assert_bitwise(a, b, name, sl)
+        else:
+            H.assert_close(a, b, name, rtol, sl)
+
+    for n in STATE:
+        cmp(n, sg[n].cpu().numpy(), so[n])
+    for n in ("CAu", "CAv", "CAu_pred", "CAv_pred", "PFu", "PFv", "visc_rem_u", "visc_rem_v", "u_accel_bt", "v_accel_bt",
+              "u_av", "v_av", "h_av", "eta", "eta_PF", "uhbt", "vhbt", "taux_bot", "tauy_bot"):
+        cmp(n, dyc.rk2_field(n).cpu().numpy(), m[n])
+    cmp("BT_h_u", dyc.rk2_field("BT_h_u").cpu().numpy(), m.bt_cont["h_u"])
+    assert np.isfinite(so["u"]).all() and np.abs(so["u"]).max() > 0
+    # volume conservation of the device result (closed basins): sum(h*area) unchanged to round-off
+    sl = H.interior(d, "h")
+    A = M[G["areaT"]][sl]
+    vol0 = (h[(Ellipsis,) + sl] * A).sum(); vol1 = (sg["h"].cpu().numpy()[(Ellipsis,) + sl] * A).sum()
+    assert abs(vol1 / vol0 - 1.0) < 1e-13
+    dyc.close()
+
+
+@pytest.mark.parametrize("first_direction", [0, 1])
+def test_rk2_double_gyre_bitexact(orc, first_direction):
+    run(orc, H.double_gyre(), nsteps=3, bt_mod=dict(strong_drag=1), first_direction=first_direction)
+
+
+def test_rk2_channel_bitexact_tc1_like(orc):
+    # tc1-like switches: BT_PROJECT_VELOCITY, BEBT=0.2, BOUND_CORIOLIS; re-entrant channel exercises every halo pass
+    run(orc, H.channel(), nsteps=3, bt_mod=dict(strong_drag=1, BT_project_velocity=1, bebt=0.2, dtbt_fraction=0.95),
+        cor_mod=dict(bound_Coriolis=1))
+
+
+def test_rk2_benchmark_small_hooks_and_flags(orc):
+    run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(begw=0.25, split_bottom_stress=1, visc_rem_dt_bug=0),
+        per_stage=True, new_diff=True)
+
+
+def test_rk2_default_path_tolerance(orc):
+    run(orc, H.double_gyre(), nsteps=3, exact=False)
