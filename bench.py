@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- the headline benchmark of BASELINE.json: simulated days per wall-second of the MOM6
+split-explicit dynamical core (step_MOM_dyn_split_RK2) on a synthetic 0.25-degree-class
+1440 x 1080 x 75 grid, at 1 / 2 / 4 / 8 MI355X (strong scaling: the global grid is fixed and cut into
+MOM6's 2-D tile layout, one tile per GPU).
+
+A "step" is ONE baroclinic step of step_MOM_dyn_split_RK2: PressureForce, CorAdCalc x2, continuity_PPM
+x3, btstep x2 (each a full barotropic sub-cycle), vertvisc x2, vertvisc_remnant x3 and the RK2 glue, on
+state that already resides in HBM.  The un-ported callees (vertvisc_coef, horizontal_viscosity: SURVEY.md
+8f) are represented by coefficients frozen over the run (constant Kv, diffu = 0), stated in `config`.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_mass_flux: zonal/meridional
+mass flux + Newton flux adjustment + BT_cont fits), timed live with HIP events on the compute stream
+inside the timed region; `cpu_baseline` is the oracle (plain-C port of the reference algorithm, one
+core) timed on a bounded 180x136x75 tile of the same workload and scaled by the cell count.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LAYOUTS = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.3 TB/s achievable)
+
+
+def global_grid(ni, nj):
+    from mom6_amd import grid
+    return grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-65.0, dlon=360.0 / ni, dlat=130.0 / nj,
+                           reentrant_x=True, depth_fn=grid.bowl_depth(ni, nj, 4000.0, rim=2))
+
+
+def algorithmic_bytes_per_step(N3, N2, nsub_total):
+    """SURVEY.md section 8(d) / BASELINE.md section 3: compulsory FP64 traffic of one baroclinic step."""
+    per_N3 = {"continuity_PPM x3": 256, "CorAdCalc x3": 168, "PressureForce": 32, "btstep 3-D setup/teardown x2": 272,
+              "btcalc + bt_mass_source": 24, "vertvisc x2 + remnant x3": 480, "RK2 pointwise glue": 384}
+    total = sum(per_N3.values()) * N3 + 570.0 * N2 * nsub_total
+    return total, per_N3
+
+
+def build_model(args, layout, pe, device):
+    """Create the device model for tile `pe` of `layout` and a synthetic state in HBM."""
+    import torch
+    from mom6_amd import abi, synth_dev
+    from mom6_amd.dycore import Dycore
+    G = abi.G
+    gg = global_grid(args.ni, args.nj)
+    d, M = gg.tile(args.nk, 4, layout, pe)
+    GV = abi.vgrid_default()
+    dyc = Dycore(d, M, GV, 0, device)
+    dyc.continuity_init(abi.continuity_params_default(args.nk, GV.Angstrom_H))
+    bt = abi.barotropic_params_default(20.0)
+    dyc.barotropic_init(bt)
+    dyc.CoriolisAdv_init(abi.coriolis_params_default())
+    Rlay, gp = abi.layer_densities(args.nk, GV.Rho0, GV.g_Earth)
+    dyc.PressureForce_init(abi.pgf_params_default(GV.Rho0), Rlay, gp)
+    dyc.initialize_dyn_split_RK2(abi.rk2_params_default())
+    Md = dyc.to_dev(M)
+    h, u, v = synth_dev.make_state(d, Md, u_max=0.05, h_pert=0.001)
+    st = dict(u=u, v=v, h=h, uh=dyc.zeros3(), vh=dyc.zeros3(), uhtr=dyc.zeros3(), vhtr=dyc.zeros3(), eta_av=dyc.zeros2())
+    # frozen vertvisc_coef outputs: Kv = 1e-4 m2/s over the local interface spacing, quadratic-drag-like bottom value
+    Kv = 1.0e-4
+    a = torch.zeros((args.nk + 1,) + d.shape2(), dtype=torch.float64, device=dyc.device)
+    hm = torch.clamp(0.5 * (h[:-1] + h[1:]), min=1e-3)
+    a[1:args.nk] = Kv / hm
+    a[args.nk] = 3.0e-4
+    del hm
+    a_u = (a * Md[G["mask2dCu"]][None]).contiguous(); a_v = (a * Md[G["mask2dCv"]][None]).contiguous()
+    del a
+    h_u = torch.clamp(0.5 * (h + torch.roll(h, -1, 2)), min=1e-9).contiguous()
+    h_v = torch.clamp(0.5 * (h + torch.roll(h, -1, 1)), min=1e-9).contiguous()
+    dyc.vertvisc_set_coef(a_u, a_v, h_u, h_v)
+    taux = (0.1 * synth_dev.smooth_field(d, dyc.device, 41, ox=1.0, oy=0.5) * Md[G["mask2dCu"]]).contiguous()
+    tauy = torch.zeros_like(taux)
+    torch.cuda.synchronize()
+    dyc.dyn_split_RK2_new_run(st["u"], st["v"], st["h"], st["uh"], st["vh"], args.dt)
+    dyc.sync()
+    keep = (a_u, a_v, h_u, h_v, Md)
+    return dyc, d, st, taux, tauy, keep
+
+
+def cpu_baseline(args):
+    """The oracle (kind='port': plain-C restatement of the reference Fortran, one core) on a bounded tile."""
+    from mom6_amd import abi, grid, synth
+    from oracle import orc
+    ni, nj, nk = 180, 136, args.nk
+    gg = grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-65.0, dlon=360.0 / args.ni, dlat=130.0 / args.nj,
+                         depth_fn=grid.bowl_depth(ni, nj, 4000.0, rim=2))
+    d, M = gg.tile(nk)
+    GV = abi.vgrid_default()
+    Rlay, gp = abi.layer_densities(nk)
+    bt = abi.barotropic_params_default(20.0)
+    m = orc.OrcModel(d, M, GV, abi.continuity_params_default(nk), bt, abi.coriolis_params_default(), abi.pgf_params_default(),
+                     abi.rk2_params_default(), Rlay, gp)
+    h, u, v = synth.make_state(d, M, u_max=0.05, h_pert=0.001)
+    a = np.zeros((nk + 1,) + d.shape2()); a[1:nk] = 1e-4 / 53.0; a[nk] = 3e-4
+    hu = np.maximum(h, 1e-9)
+    coefs = tuple(np.ascontiguousarray(x) if x is not None else None for x in
+                  (a * M[abi.G["mask2dCu"]][None], a * M[abi.G["mask2dCv"]][None], hu, hu.copy(), None, None))
+    z3 = lambda: np.zeros_like(h)
+    uh, vh, uhtr, vhtr, eta_av = z3(), z3(), z3(), z3(), np.zeros(d.shape2())
+    taux = np.ascontiguousarray(0.1 * synth.smooth_field(d, 41, ox=1, oy=.5) * M[abi.G["mask2dCu"]]); tauy = np.zeros(d.shape2())
+    m.initialize(u, v, h, uh, vh, args.dt)
+    m.step(u, v, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy, args.dt, coefs, calc_dtbt=True)   # warm-up, sets dtbt
+    nst = args.cpu_steps
+    t0 = time.time()
+    for _ in range(nst):
+        m.step(u, v, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy, args.dt, coefs)
+    t = (time.time() - t0) / nst
+    scale = (args.ni * args.nj) / float(ni * nj)
+    t_full = t * scale
+    return {"value": (args.dt / 86400.0) / t_full, "unit": "simulated-days/wall-sec", "cores": 1, "kind": "port",
+            "sample": f"{nst} oracle steps of step_MOM_dyn_split_RK2 on a {ni}x{nj}x{nk} tile ({t:.2f} s/step), "
+                      f"scaled x{scale:.1f} to {args.ni}x{args.nj}x{nk}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ni", type=int, default=1440)
+    ap.add_argument("--nj", type=int, default=1080)
+    ap.add_argument("--nk", type=int, default=75)
+    ap.add_argument("--dt", type=float, default=900.0)
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    import torch
+    from mom6_amd.dycore import prof_enable, prof_report, prof_reset
+    import ctypes as C
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus not in LAYOUTS:
+        raise SystemExit(f"--gpus must be one of {sorted(LAYOUTS)}")
+    layout = LAYOUTS[args.gpus]
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    pe = (rank % layout[0], rank // layout[0])
+    dyc, d, st, taux, tauy, keep = build_model(args, layout, pe, local_rank)
+    if world > 1:
+        from mom6_amd.parallel import attach_comm
+        attach_comm(dyc, layout, pe, dist)
+
+    def step(calc_dtbt=False):
+        dyc.step_MOM_dyn_split_RK2(st["u"], st["v"], st["h"], st["uh"], st["vh"], st["uhtr"], st["vhtr"], st["eta_av"],
+                                   taux, tauy, args.dt, calc_dtbt=calc_dtbt)
+
+    def barrier():
+        dyc.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    step(calc_dtbt=True)                    # sets dtbt (untimed; part of warm-up)
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    # time EXACTLY K steps; HIP events only around the dominant kernel inside the timed region
+    dyc.lib.mom6x_prof_filter(dyc.ctx, b"k_mass_flux")
+    prof_enable(dyc, True); prof_reset(dyc)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dyc.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dom = prof_report(dyc)
+    prof_enable(dyc, False)
+    # a second, un-timed pass with events around EVERY kernel: the per-kernel breakdown
+    dyc.lib.mom6x_prof_filter(dyc.ctx, None)
+    prof_enable(dyc, True); prof_reset(dyc)
+    step(); dyc.sync()
+    full = prof_report(dyc)
+    prof_enable(dyc, False)
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = (args.steps * args.dt / 86400.0) / elapsed
+    N3g, N2g = args.ni * args.nj * args.nk, args.ni * args.nj
+    nsub = sum(v[0] for k, v in full.items() if k == "k_bt_eta")   # barotropic sub-steps per baroclinic step (both btstep calls)
+    bytes_step, per_N3 = algorithmic_bytes_per_step(N3g, N2g, nsub)
+    # dominant kernel: k_mass_flux<DIR>.  Algorithmic bytes per launch = (u + visc_rem + h + uh [+ u_cor]) of one
+    # direction = 4 words (call 1) or 5 words (calls 2, 3) per cell-layer of the LOCAL tile: 14/3 on average.
+    N3_tile = d.ni * d.nj * d.nk
+    n_dom = sum(v[0] for v in dom.values()); ms_dom = sum(v[1] for v in dom.values())
+    roofline = None
+    if n_dom:
+        avg_ms = ms_dom / n_dom
+        bytes_launch = (14.0 / 3.0) * 8.0 * N3_tile
+        ach = bytes_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_mass_flux<DIR>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                    "launches_per_step": n_dom / args.steps, "algorithmic_bytes_per_launch": bytes_launch}
+    out = {
+        "metric": "simulated-days/wall-sec", "value": value, "unit": "simulated-days/wall-sec", "n_gpus": args.gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"step_MOM_dyn_split_RK2 on {args.ni}x{args.nj}x{args.nk} (0.25-degree-class synthetic global, "
+                               f"BASELINE.json configs[3] grid), DT={args.dt:g} s, layout {layout[0]}x{layout[1]}, "
+                               f"{nsub} barotropic sub-steps per step",
+                   "frozen_inputs": "vertvisc_coef outputs (Kv=1e-4) and diffu=diffv=0 are held constant (SURVEY 8f callees)",
+                   "tile": [d.ni, d.nj, d.nk], "halo": d.halo},
+        "roofline": roofline,
+        "hbm_step": {"algorithmic_GB_per_step": round(bytes_step / 1e9, 2), "achieved_GBps": round(bytes_step / 1e9 / (ms_per_step * 1e-3), 1),
+                     "frac_of_peak": round(bytes_step / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * args.gpus), 4),
+                     "model": "SURVEY.md 8(d): 1616 B x N3 + 570 B x N2 x sub-steps"},
+    }
+    if rank == 0:
+        tot = sum(v[1] for v in full.values())
+        out["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]}
+        out["kernel_sum_ms"] = round(tot, 2)
+        if args.breakdown:
+            for k, (cnt, ms) in sorted(full.items(), key=lambda kv: -kv[1][1]):
+                print(f"{k:28s} n={cnt:5d} total={ms:9.3f} ms avg={ms / cnt * 1e3:9.1f} us ({100 * ms / tot:5.1f}%)", file=sys.stderr)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -210,6 +210,7 @@ const double *mom6x_ctx_metrics_dev(const mom6x_ctx *ctx);
  * granularity.  mom6x_prof_report writes "name<TAB>count<TAB>total_ms" lines into buf.       */
 int mom6x_prof_enable(mom6x_ctx *ctx, int on);
 int mom6x_prof_reset(mom6x_ctx *ctx);
+int mom6x_prof_filter(mom6x_ctx *ctx, const char *prefix);  /* time only kernels named prefix*; NULL = all */
 int mom6x_prof_report(mom6x_ctx *ctx, char *buf, int buflen);
 
 /* Device memory helpers for non-torch hosts (Fortran).                       */

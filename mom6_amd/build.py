@@ -41,9 +41,10 @@ def build(force=False, verbose=False):
         objs.append(o)
     if force or _newer(objs, LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        rccl = "/opt/rocm/lib/librccl.so"
-        if os.path.exists(rccl):
-            cmd += ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        # RCCL is NOT linked: halo.hip resolves ncclSend/ncclRecv/... at run time from the RCCL already in
+        # the process (torch's bundled librccl under Python, or the one the Fortran host links), so that a
+        # single RCCL instance exists per process.
+        cmd += ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

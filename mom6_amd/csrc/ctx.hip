@@ -16,6 +16,7 @@ struct Prof {
   std::vector<hipEvent_t> pool;
   hipEvent_t cur_a;
   int cur_id;
+  std::string filter;   // record only kernels whose name starts with this prefix ("" = all)
 };
 
 static hipEvent_t prof_event(Prof *p) {
@@ -25,8 +26,17 @@ static hipEvent_t prof_event(Prof *p) {
   return e;
 }
 
+extern "C" int mom6x_prof_filter(mom6x_ctx *c, const char *prefix) {
+  REQUIRE(c, MOM6X_EINVAL, "mom6x_prof_filter: null ctx");
+  if (!c->prof) c->prof = new Prof();
+  c->prof->filter = prefix ? prefix : "";
+  return MOM6X_OK;
+}
+
 void prof_begin(mom6x_ctx *c, const char *name) {
   Prof *p = c->prof;
+  p->cur_id = -1;
+  if (!p->filter.empty() && strncmp(name, p->filter.c_str(), p->filter.size()) != 0) return;
   auto it = p->ids.find(name);
   int id;
   if (it == p->ids.end()) {
@@ -40,6 +50,7 @@ void prof_begin(mom6x_ctx *c, const char *name) {
 
 void prof_end(mom6x_ctx *c) {
   Prof *p = c->prof;
+  if (p->cur_id < 0) return;
   ProfRec r; r.id = p->cur_id; r.a = p->cur_a; r.b = prof_event(p);
   (void)hipEventRecord(r.b, c->stream);
   p->recs.push_back(r);
