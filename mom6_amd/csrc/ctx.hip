@@ -109,6 +109,22 @@ void mom6x_set_error(const char *fmt, ...) {
 extern "C" const char *mom6x_last_error(void) { return g_err; }
 extern "C" int mom6x_abi_version(void) { return MOM6X_ABI_VERSION; }
 
+// sizeof() of the public structs, so that non-C hosts (ctypes, ISO_C_BINDING) can verify their mirrors.
+extern "C" int mom6x_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(mom6x_dims);
+    case 1: return (int)sizeof(mom6x_vgrid);
+    case 2: return (int)sizeof(mom6x_continuity_params);
+    case 3: return (int)sizeof(mom6x_BT_cont);
+    case 4: return (int)sizeof(mom6x_barotropic_params);
+    case 5: return (int)sizeof(mom6x_coriolis_params);
+    case 6: return (int)sizeof(mom6x_pgf_params);
+    case 7: return (int)sizeof(mom6x_rk2_params);
+    case 8: return (int)sizeof(mom6x_rk2_hooks);
+    default: return -1;
+  }
+}
+
 extern "C" int mom6x_dims_init(mom6x_dims *d, int ni, int nj, int nk, int halo) {
   REQUIRE(d && ni > 0 && nj > 0 && nk > 0, MOM6X_EINVAL, "mom6x_dims_init: bad sizes");
   REQUIRE(halo >= 1 && halo + 1 <= 16, MOM6X_EINVAL, "mom6x_dims_init: halo must be in 1..15");
