@@ -373,6 +373,25 @@ int mom6x_step_dyn_split_RK2(mom6x_ctx *ctx, double *u_inst, double *v_inst, dou
                              const double *taux, const double *tauy, double dt, int calc_dtbt,
                              const mom6x_rk2_hooks *hooks);
 
+/* ------------------------------------------------------------------------- */
+/* MOM_domains: 2-D tile decomposition and halo updates over RCCL / xGMI         */
+
+/* Index range (inclusive, local indices) of the region of a `stagger` field that is SENT to (send=1)
+ * or RECEIVED from (send=0) the neighbour in direction dir = 0..7 (W,E,S,N,SW,SE,NW,NE).  Host-only,
+ * no GPU needed: this is the exchange plan, tested on CPU with gloo.                              */
+int mom6x_halo_region(const mom6x_dims *d, int stagger, int dir, int send, int *i0, int *i1, int *j0, int *j1);
+/* Rank (px + npx*py) of the neighbour of tile (px,py) in direction dir, or -1 at a closed boundary. */
+int mom6x_halo_neighbor(int npx, int npy, int px, int py, int dir, int reentrant_x, int reentrant_y);
+/* ncclGetUniqueId on the calling rank: 128 bytes the host broadcasts (MPI_Bcast / torch.distributed). */
+int mom6x_comm_unique_id(char *id128);
+/* Attach LAYOUT = npx,npy (MOM_domains.F90:155) with this tile at (px,py) and create the RCCL
+ * communicator (clone of MOM_domains_init / create_group_pass's message plan).  After this call every
+ * halo update inside the mom6x_* routines is a packed ncclSend/ncclRecv group exchange.            */
+int mom6x_comm_init(mom6x_ctx *ctx, int npx, int npy, int px, int py, const char *id128, int force_nccl_self);
+int mom6x_comm_rank(const mom6x_ctx *ctx);
+/* do_group_pass of n fields (pass_var / pass_vector, MOM_domain_infra.F90:171-560, :1141).          */
+int mom6x_pass_fields(mom6x_ctx *ctx, double *const *fields, const int *staggers, const int *nks, int n);
+
 #ifdef __cplusplus
 }
 #endif

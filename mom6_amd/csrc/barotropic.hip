@@ -687,8 +687,8 @@ static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int 
     if (I2 * min_max_dt2 > 1.0) min_max_dt2 = 1.0 / I2;
   }
   const double dgeo_de = 1.0 + fmax(0.0, c->bt.G_extra);
-  const double dtbt_max = sqrt(min_max_dt2 / dgeo_de);
-  // TODO(multi-GPU): min_across_PEs(dtbt_max) :3622 via ncclAllReduce(min)
+  double dtbt_max = sqrt(min_max_dt2 / dgeo_de);
+  { int rc_ = comm_allreduce_scalar(c, &dtbt_max, 0); if (rc_) return rc_; }   // min_across_PEs(dtbt_max) :3622
   c->bt.dtbt = c->bt.dtbt_fraction * dtbt_max;
   if (dtbt_out) *dtbt_out = c->bt.dtbt;
   return MOM6X_OK;
@@ -874,5 +874,6 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   KLAUNCH(c, "k_layer_accel", k_layer_accel, grid3(d.ni + 1, d.nj + 1, d.nk, b), b, d, c->G, work, pbce, accel_layer_u,
                      accel_layer_v, P.vel_underflow * Idt);
   HIPCHK(hipGetLastError());
+  REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
   return MOM6X_OK;
 }

@@ -210,6 +210,7 @@ extern "C" int mom6x_dyn_split_RK2_new_run(mom6x_ctx *c, const double *u, const 
   CHK(mom6x_CorAdCalc(c, s->u_av, s->v_av, s->h_av, uh, vh, s->CAu_pred, s->CAv_pred));
   s->CAu_pred_stored = true;
   HIPCHK(hipGetLastError());
+  REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
   return MOM6X_OK;
 }
 
@@ -322,5 +323,6 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));
   s->CAu_pred_stored = true;
   HIPCHK(hipGetLastError());
+  REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
   return MOM6X_OK;
 }

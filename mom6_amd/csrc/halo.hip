@@ -1,28 +1,115 @@
-// halo.hip -- halo updates (pass_var / pass_vector / do_group_pass, MOM_domain_infra.F90:171-1190).
+// halo.hip -- halo updates: pass_var / pass_vector / create_group_pass + do_group_pass
+// (config_src/infra/FMS2/MOM_domain_infra.F90:171-560, :1141-1190) for MOM6's 2-D tile decomposition,
+// one tile per MI355X.
 //
-// Single-tile part: a re-entrant direction is a wrap copy from the tile's own opposite edge (what
-// mpp_update_domains does on one PE); closed directions leave the halo untouched.  With MOM6's
-// symmetric memory the u-point computational domain is I = -1..ni-1 (both ends owned by the tile), so
-// only I <= -2 and I >= ni are halo points; likewise for v/q points in j.  A whole group pass (many
-// fields) is one launch per direction.  x is wrapped before y so that corners are filled from wrapped
-// data (To_All without Omit_Corners).
+// A group pass (any number of 2-D/3-D fields of any staggering) is ONE packed message per neighbour:
+//   pack kernel(s) -> ncclGroupStart; ncclSend/ncclRecv to the <= 8 neighbours (edges + corners: To_All
+//   without Omit_Corners); ncclGroupEnd -> unpack kernel(s), all stream-ordered on the context's stream.
+// xGMI is point-to-point and these messages are latency-dominated, so aggregating a
+// whole group pass into one message per peer is the lever, exactly as mpp_create_group_update does.
+// Re-entrant directions whose neighbour is the tile itself are device-to-device copies; closed
+// boundaries have no neighbour (halo untouched, as mpp_update_domains on land-bounded edges).
+//
+// Symmetric memory: the u-point computational domain is I = -1..ni-1 (both shared edges owned), so only
+// I <= -2 and I >= ni are halo points; likewise for v/q points in j.
+//
+// RCCL is resolved at run time (dlsym) from the RCCL instance already present in the process (torch's
+// bundled librccl under Python; the host's own under Fortran) so that only one RCCL exists per process.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <vector>
 #include "mom6x_dev.h"
 
 #define MAXF 16
-struct WrapArgs { double *f[MAXF]; int stg[MAXF]; int nk[MAXF]; int n; };
+struct WrapArgs { double *f[MAXF]; int stg[MAXF]; int nk[MAXF]; int n; int rx; };
 
+// ---- region logic (host + device) ------------------------------------------------------------------
+// Directions d = 0..7: W, E, S, N, SW, SE, NW, NE.
+__host__ __device__ inline void dir_dxdy(int d, int &dx, int &dy) {
+  const int DX[8] = { -1, 1, 0, 0, -1, 1, -1, 1 }, DY[8] = { 0, 0, -1, 1, -1, -1, 1, 1 };
+  dx = DX[d]; dy = DY[d];
+}
+__host__ __device__ inline int dir_opp(int d) { const int O[8] = { 1, 0, 3, 2, 7, 6, 5, 4 }; return O[d]; }
+
+// Inclusive index range along one axis.  n = ni|nj, w = halo, B = 1 for a B-staggered (face/vertex) axis.
+// send: the part of MY computational domain the neighbour in direction s (-1,0,+1) needs;
+// recv: the part of MY halo that the neighbour in direction s fills.
+__host__ __device__ inline void axis_range(int n, int w, int B, int s, int send, int &a0, int &a1) {
+  if (s == 0) { a0 = -B; a1 = n - 1; }
+  else if (send) { if (s > 0) { a0 = n - w - B; a1 = n - 1 - B; } else { a0 = 0; a1 = w - 1; } }
+  else { if (s > 0) { a0 = n; a1 = n + w - 1; } else { a0 = -w - B; a1 = -1 - B; } }
+}
+
+extern "C" int mom6x_halo_region(const mom6x_dims *d, int stagger, int dir, int send, int *i0, int *i1, int *j0, int *j1) {
+  if (!d || dir < 0 || dir > 7 || stagger < 0 || stagger > 3) return MOM6X_EINVAL;
+  int dx, dy; dir_dxdy(dir, dx, dy);
+  const int xB = (stagger == 1 || stagger == 3), yB = (stagger == 2 || stagger == 3);
+  axis_range(d->ni, d->halo, xB, dx, send, *i0, *i1);
+  axis_range(d->nj, d->halo, yB, dy, send, *j0, *j1);
+  return MOM6X_OK;
+}
+
+// Rank of the neighbour of tile (px,py) in direction dir, or -1 (closed boundary).  Rank = px + npx*py.
+extern "C" int mom6x_halo_neighbor(int npx, int npy, int px, int py, int dir, int reentrant_x, int reentrant_y) {
+  int dx, dy; dir_dxdy(dir, dx, dy);
+  int qx = px + dx, qy = py + dy;
+  if (qx < 0 || qx >= npx) { if (!reentrant_x) return -1; qx = (qx + npx) % npx; }
+  if (qy < 0 || qy >= npy) { if (!reentrant_y) return -1; qy = (qy + npy) % npy; }
+  return qx + npx * qy;
+}
+
+// ---- pack / unpack ----------------------------------------------------------------------------------
+// One launch moves the region of direction `dir` of every field of the group between the fields and a
+// contiguous buffer (field-major, then k, j, i).
+__global__ void __launch_bounds__(256)
+k_halo_pack(Dm d, WrapArgs A, double *__restrict__ buf, int dir, int send /*1: pack send region, 0: unpack recv region*/) {
+  int dx, dy; dir_dxdy(dir, dx, dy);
+  size_t off = 0;
+  for (int m = 0; m < A.n; m++) {
+    const int xB = (A.stg[m] == 1 || A.stg[m] == 3), yB = (A.stg[m] == 2 || A.stg[m] == 3);
+    int i0, i1, j0, j1;
+    axis_range(d.ni, d.halo, xB, dx, send, i0, i1);
+    axis_range(d.nj, d.halo, yB, dy, send, j0, j1);
+    const int nx = i1 - i0 + 1, ny = j1 - j0 + 1;
+    const size_t per_k = (size_t)nx * ny, tot = per_k * A.nk[m];
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+      const int k = (int)(t / per_k);
+      const int r = (int)(t - (size_t)k * per_k);
+      const int jj = r / nx, ii = r - jj * nx;
+      const size_t x = ix3(d, i0 + ii, j0 + jj, k);
+      if (send) buf[off + t] = A.f[m][x];
+      else A.f[m][x] = buf[off + t];
+    }
+    off += tot;
+  }
+}
+
+static size_t region_count(const mom6x_dims &d, const WrapArgs &A, int dir) {
+  int dx, dy; dir_dxdy(dir, dx, dy);
+  size_t tot = 0;
+  for (int m = 0; m < A.n; m++) {
+    const int xB = (A.stg[m] == 1 || A.stg[m] == 3), yB = (A.stg[m] == 2 || A.stg[m] == 3);
+    int i0, i1, j0, j1;
+    axis_range(d.ni, d.halo, xB, dx, 1, i0, i1);
+    axis_range(d.nj, d.halo, yB, dy, 1, j0, j1);
+    tot += (size_t)(i1 - i0 + 1) * (j1 - j0 + 1) * A.nk[m];
+  }
+  return tot;
+}
+
+// ---- single-tile wrap (no communicator attached) ---------------------------------------------------
 __global__ void k_wrap_x(Dm d, WrapArgs A) {
-  const int jj = blockIdx.x * blockDim.x + threadIdx.x;   // row index within the data domain
-  const int hh = threadIdx.y;                             // halo column 0..halo (extra one for B-points)
+  const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+  const int hh = threadIdx.y;
   const int k = blockIdx.z;
   const int w = d.halo, ni = d.ni;
   for (int m = 0; m < A.n; m++) {
     if (k >= A.nk[m]) continue;
     const int xB = (A.stg[m] == 1 || A.stg[m] == 3), yB = (A.stg[m] == 2 || A.stg[m] == 3);
-    const int j = -w - yB + jj;
-    if (j > d.nj - 1 + w) continue;
+    const int j = -yB + jj;                       // computational rows only: corners come from the y pass
+    if (j > d.nj - 1) continue;
     double *p = A.f[m] + (size_t)k * d.slab;
-    if (hh < w) {   // west halo: i = -w-xB .. -1-xB   <- i+ni ; east halo: i = ni .. ni-1+w <- i-ni
+    if (hh < w) {
       const int iw = -w - xB + hh;
       p[ix2(d, iw, j)] = p[ix2(d, iw + ni, j)];
       const int ie = ni + hh;
@@ -39,8 +126,9 @@ __global__ void k_wrap_y(Dm d, WrapArgs A) {
   for (int m = 0; m < A.n; m++) {
     if (k >= A.nk[m]) continue;
     const int xB = (A.stg[m] == 1 || A.stg[m] == 3), yB = (A.stg[m] == 2 || A.stg[m] == 3);
-    const int i = -w - xB + ii;
-    if (i > d.ni - 1 + w) continue;
+    // with a re-entrant x the (already wrapped) x-halo columns are included, which fills the corners
+    const int i = (A.rx ? -w - xB : -xB) + ii;
+    if (i > d.ni - 1 + (A.rx ? w : 0)) continue;
     double *p = A.f[m] + (size_t)k * d.slab;
     if (hh < w) {
       const int js = -w - yB + hh;
@@ -51,16 +139,186 @@ __global__ void k_wrap_y(Dm d, WrapArgs A) {
   }
 }
 
+// ---- the communicator -------------------------------------------------------------------------------
+struct NcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*GroupStart)();
+  ncclResult_t (*GroupEnd)();
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  const char *(*GetErrorString)(ncclResult_t);
+  bool ok;
+};
+
+static NcclApi g_nccl = {};
+
+static int nccl_load() {
+  if (g_nccl.ok) return MOM6X_OK;
+  void *h = RTLD_DEFAULT;
+  if (!dlsym(h, "ncclSend")) {   // no RCCL in the process yet: load the system one
+    h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    REQUIRE(h, MOM6X_EHIP, "mom6x: cannot find RCCL (librccl.so) in the process or on the system");
+  }
+#define LOADSYM(field, name) *(void **)(&g_nccl.field) = dlsym(h, name); REQUIRE(g_nccl.field, MOM6X_EHIP, "mom6x: RCCL symbol " name " not found")
+  LOADSYM(GetUniqueId, "ncclGetUniqueId"); LOADSYM(CommInitRank, "ncclCommInitRank"); LOADSYM(CommDestroy, "ncclCommDestroy");
+  LOADSYM(Send, "ncclSend"); LOADSYM(Recv, "ncclRecv"); LOADSYM(GroupStart, "ncclGroupStart"); LOADSYM(GroupEnd, "ncclGroupEnd");
+  LOADSYM(AllReduce, "ncclAllReduce"); LOADSYM(GetErrorString, "ncclGetErrorString");
+#undef LOADSYM
+  g_nccl.ok = true;
+  return MOM6X_OK;
+}
+
+#define NCCLCHK(expr)                                                                                   \
+  do {                                                                                                  \
+    ncclResult_t r_ = (expr);                                                                           \
+    if (r_ != ncclSuccess) { mom6x_set_error("%s failed: %s", #expr, g_nccl.GetErrorString(r_)); return MOM6X_EHIP; } \
+  } while (0)
+
+struct Comm {
+  int npx, npy, px, py, nranks, rank;
+  int nbr[8];
+  ncclComm_t comm;           // null when every neighbour is the tile itself (single rank)
+  bool force_nccl_self;      // test mode: route self-neighbour messages through ncclSend/ncclRecv too
+  double *sbuf[8], *rbuf[8];
+  size_t cap[8];
+  double *red;               // 1-element device buffer for scalar all-reduces
+};
+
+extern "C" int mom6x_comm_unique_id(char *id128) {
+  REQUIRE(id128, MOM6X_EINVAL, "mom6x_comm_unique_id: null buffer");
+  int rc = nccl_load(); if (rc) return rc;
+  ncclUniqueId id;
+  NCCLCHK(g_nccl.GetUniqueId(&id));
+  memcpy(id128, &id, NCCL_UNIQUE_ID_BYTES);
+  return MOM6X_OK;
+}
+
+void comm_free(mom6x_ctx *c) {
+  Comm *m = (Comm *)c->comm;
+  if (!m) return;
+  for (int d = 0; d < 8; d++) { (void)hipFree(m->sbuf[d]); (void)hipFree(m->rbuf[d]); }
+  (void)hipFree(m->red);
+  if (m->comm) (void)g_nccl.CommDestroy(m->comm);
+  delete m;
+  c->comm = nullptr;
+}
+
+// Attach the 2-D tile layout (MOM_domains LAYOUT = npx,npy; this tile = (px,py), rank = px + npx*py) and
+// an RCCL communicator created from `id128` (from mom6x_comm_unique_id on rank 0, broadcast by the host
+// with MPI_Bcast / torch.distributed).  id128 may be NULL when nranks == 1.
+extern "C" int mom6x_comm_init(mom6x_ctx *c, int npx, int npy, int px, int py, const char *id128, int force_nccl_self) {
+  REQUIRE(c && npx >= 1 && npy >= 1 && px >= 0 && px < npx && py >= 0 && py < npy, MOM6X_EINVAL, "mom6x_comm_init: bad layout");
+  HIPCHK(hipSetDevice(c->device));
+  comm_free(c);
+  Comm *m = new Comm();
+  memset(m, 0, sizeof(*m));
+  m->npx = npx; m->npy = npy; m->px = px; m->py = py; m->nranks = npx * npy; m->rank = px + npx * py;
+  m->force_nccl_self = (force_nccl_self != 0);
+  bool need_nccl = m->force_nccl_self;
+  for (int d = 0; d < 8; d++) {
+    m->nbr[d] = mom6x_halo_neighbor(npx, npy, px, py, d, c->dims.reentrant_x, c->dims.reentrant_y);
+    if (m->nbr[d] >= 0 && m->nbr[d] != m->rank) need_nccl = true;
+  }
+  if (m->nranks > 1) need_nccl = true;
+  if (need_nccl) {
+    REQUIRE(id128, MOM6X_EINVAL, "mom6x_comm_init: a unique id is required for a multi-rank layout");
+    int rc = nccl_load(); if (rc) { delete m; return rc; }
+    ncclUniqueId id;
+    memcpy(&id, id128, NCCL_UNIQUE_ID_BYTES);
+    NCCLCHK(g_nccl.CommInitRank(&m->comm, m->nranks, id, m->rank));
+  }
+  HIPCHK(hipMalloc(&m->red, 2 * sizeof(double)));
+  c->comm = m;
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_comm_rank(const mom6x_ctx *c) { return (c && c->comm) ? ((Comm *)c->comm)->rank : 0; }
+
+// min_across_PEs / max_across_PEs / sum_across_PEs of one scalar (MOM_coms.F90): op 0 min, 1 max, 2 sum.
+int comm_allreduce_scalar(mom6x_ctx *c, double *value, int op) {
+  Comm *m = (Comm *)c->comm;
+  if (!m || !m->comm || m->nranks == 1) return MOM6X_OK;
+  HIPCHK(hipMemcpyAsync(m->red, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const ncclRedOp_t rop = (op == 0) ? ncclMin : ((op == 1) ? ncclMax : ncclSum);
+  NCCLCHK(g_nccl.AllReduce(m->red, m->red + 1, 1, ncclDouble, rop, m->comm, c->stream));
+  HIPCHK(hipMemcpyAsync(value, m->red + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MOM6X_OK;
+}
+
+static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
+  const Dm d = c->d;
+  size_t cnt[8];
+  for (int dir = 0; dir < 8; dir++) {
+    cnt[dir] = 0;
+    if (m->nbr[dir] < 0) continue;
+    cnt[dir] = region_count(c->dims, A, dir);
+    if (cnt[dir] > m->cap[dir]) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      (void)hipFree(m->sbuf[dir]); (void)hipFree(m->rbuf[dir]);
+      m->cap[dir] = cnt[dir] + cnt[dir] / 4;
+      HIPCHK(hipMalloc(&m->sbuf[dir], m->cap[dir] * sizeof(double)));
+      HIPCHK(hipMalloc(&m->rbuf[dir], m->cap[dir] * sizeof(double)));
+    }
+    const int blocks = (int)((cnt[dir] + 255) / 256 > 1024 ? 1024 : (cnt[dir] + 255) / 256);
+    KLAUNCH(c, "k_halo_pack", k_halo_pack, dim3(blocks), dim3(256), d, A, m->sbuf[dir], dir, 1);
+  }
+  // sends in direction order; receives in the order of the OPPOSITE directions, so that the j-th send to a
+  // peer pairs with the peer's j-th receive from us even when one rank is the neighbour in several directions.
+  bool in_group = false;
+  for (int dir = 0; dir < 8; dir++) {
+    if (m->nbr[dir] < 0) continue;
+    const bool self = (m->nbr[dir] == m->rank);
+    if (self && !m->force_nccl_self) {
+      // my message toward `dir` arrives as my own receive from direction opp(dir)
+      HIPCHK(hipMemcpyAsync(m->rbuf[dir_opp(dir)], m->sbuf[dir], cnt[dir] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+  }
+  if (m->comm) {
+    NCCLCHK(g_nccl.GroupStart());
+    in_group = true;
+    for (int dir = 0; dir < 8; dir++) {
+      if (m->nbr[dir] < 0) continue;
+      if (m->nbr[dir] == m->rank && !m->force_nccl_self) continue;
+      NCCLCHK(g_nccl.Send(m->sbuf[dir], cnt[dir], ncclDouble, m->nbr[dir], m->comm, c->stream));
+    }
+    for (int dir = 0; dir < 8; dir++) {
+      const int r = dir_opp(dir);
+      if (m->nbr[r] < 0) continue;
+      if (m->nbr[r] == m->rank && !m->force_nccl_self) continue;
+      NCCLCHK(g_nccl.Recv(m->rbuf[r], cnt[r], ncclDouble, m->nbr[r], m->comm, c->stream));
+    }
+    NCCLCHK(g_nccl.GroupEnd());
+  }
+  (void)in_group;
+  for (int dir = 0; dir < 8; dir++) {
+    if (m->nbr[dir] < 0) continue;
+    const int blocks = (int)((cnt[dir] + 255) / 256 > 1024 ? 1024 : (cnt[dir] + 255) / 256);
+    KLAUNCH(c, "k_halo_unpack", k_halo_pack, dim3(blocks), dim3(256), d, A, m->rbuf[dir], dir, 0);
+  }
+  return MOM6X_OK;
+}
+
 void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n) {
   const Dm d = c->d;
-  if (!c->dims.reentrant_x && !c->dims.reentrant_y) return;
+  Comm *m = (Comm *)c->comm;
+  if (!m && !c->dims.reentrant_x && !c->dims.reentrant_y) return;
   for (int base = 0; base < n; base += MAXF) {
     WrapArgs A;
     A.n = (n - base < MAXF) ? (n - base) : MAXF;
+    A.rx = c->dims.reentrant_x;
     int nkmax = 1;
-    for (int m = 0; m < A.n; m++) {
-      A.f[m] = fields[base + m]; A.stg[m] = staggers[base + m]; A.nk[m] = nks[base + m];
-      if (A.nk[m] > nkmax) nkmax = A.nk[m];
+    for (int q = 0; q < A.n; q++) {
+      A.f[q] = fields[base + q]; A.stg[q] = staggers[base + q]; A.nk[q] = nks[base + q];
+      if (A.nk[q] > nkmax) nkmax = A.nk[q];
+    }
+    if (m) {
+      if (exchange(c, m, A) != MOM6X_OK) c->halo_error = true;
+      continue;
     }
     const dim3 b(64, d.halo, 1);
     if (c->dims.reentrant_x) {
@@ -72,4 +330,15 @@ void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const i
       KLAUNCH(c, "k_wrap_y", k_wrap_y, dim3((cols + 63) / 64, 1, nkmax), b, d, A);
     }
   }
+}
+
+// pass_var / pass_vector for non-torch hosts and tests: one group pass of n fields.
+extern "C" int mom6x_pass_fields(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n) {
+  REQUIRE(c && fields && staggers && nks && n > 0, MOM6X_EINVAL, "mom6x_pass_fields: bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  c->halo_error = false;
+  halo_wrap(c, fields, staggers, nks, n);
+  REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
 }

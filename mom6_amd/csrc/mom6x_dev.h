@@ -81,7 +81,11 @@ struct mom6x_ctx {
   double *scr[MOM6X_NSCR]; int scr_nlev[MOM6X_NSCR];
   bool prof_on;
   struct Prof *prof;
+  void *comm;               // halo.hip: tile layout + RCCL communicator (null: single tile, wrap only)
+  bool halo_error;          // set by a failed halo exchange inside a stream-ordered sequence
 };
+void comm_free(mom6x_ctx *c);                                         // halo.hip
+int comm_allreduce_scalar(mom6x_ctx *c, double *value, int op);       // halo.hip: 0 min, 1 max, 2 sum
 
 // ---------------------------------------------------------------------------------------------
 // Per-kernel timing with HIP events on the compute stream (mom6x_prof_* in include/mom6x.h).

@@ -23,14 +23,15 @@ void orc_pass_var(const mom6x_dims *d, double *a, int stagger, int nk) {
   const int w = d->halo, ni = d->ni, nj = d->nj;
   for (int k = 0; k < nk; k++) {
     double *p = a + (size_t)k * d->slab;
-    if (d->reentrant_x) {
-      for (int j = -w - yB; j <= nj - 1 + w; j++) {
+    if (d->reentrant_x) { /* computational rows only; the corners are filled by the y pass (as the 8-neighbour exchange does) */
+      for (int j = -yB; j <= nj - 1; j++) {
         for (int i = -w - xB; i <= -1 - xB; i++) p[IX2(d, i, j)] = p[IX2(d, i + ni, j)];
         for (int i = ni; i <= ni - 1 + w; i++) p[IX2(d, i, j)] = p[IX2(d, i - ni, j)];
       }
     }
     if (d->reentrant_y) {
-      for (int i = -w - xB; i <= ni - 1 + w; i++) {
+      const int ia = d->reentrant_x ? -w - xB : -xB, ib = d->reentrant_x ? ni - 1 + w : ni - 1;
+      for (int i = ia; i <= ib; i++) {
         for (int j = -w - yB; j <= -1 - yB; j++) p[IX2(d, i, j)] = p[IX2(d, i, j + nj)];
         for (int j = nj; j <= nj - 1 + w; j++) p[IX2(d, i, j)] = p[IX2(d, i, j - nj)];
       }
