@@ -1,0 +1,45 @@
+!> Start-up check a Fortran host performs: the bind(C) mirrors have the sizes the C library was built with.
+program check_abi
+  use, intrinsic :: iso_c_binding
+  use mom6x_c_api
+  implicit none
+  type(mom6x_dims) :: d
+  type(mom6x_vgrid) :: gv
+  type(mom6x_continuity_params) :: cp
+  type(mom6x_BT_cont) :: btc
+  type(mom6x_barotropic_params) :: bp
+  type(mom6x_coriolis_params) :: co
+  type(mom6x_pgf_params) :: pg
+  type(mom6x_rk2_params) :: rk
+  type(mom6x_rk2_hooks) :: hk
+  integer :: nbad, rc
+  nbad = 0
+  call chk(0, int(c_sizeof(d)), "mom6x_dims")
+  call chk(1, int(c_sizeof(gv)), "mom6x_vgrid")
+  call chk(2, int(c_sizeof(cp)), "mom6x_continuity_params")
+  call chk(3, int(c_sizeof(btc)), "mom6x_BT_cont")
+  call chk(4, int(c_sizeof(bp)), "mom6x_barotropic_params")
+  call chk(5, int(c_sizeof(co)), "mom6x_coriolis_params")
+  call chk(6, int(c_sizeof(pg)), "mom6x_pgf_params")
+  call chk(7, int(c_sizeof(rk)), "mom6x_rk2_params")
+  call chk(8, int(c_sizeof(hk)), "mom6x_rk2_hooks")
+  rc = mom6x_dims_init(d, 1440, 1080, 75, 4)
+  if (rc /= 0 .or. d%pitch /= 1472 .or. d%ioff /= 16) then
+    print *, "mom6x_dims_init mismatch", rc, d%pitch, d%ioff ; nbad = nbad + 1
+  endif
+  if (nbad == 0) then
+    print '(a)', "fortran ABI check OK"
+  else
+    print '(a,i0)', "fortran ABI check FAILED: ", nbad
+    stop 1
+  endif
+contains
+  subroutine chk(which, fsize, name)
+    integer, intent(in) :: which, fsize
+    character(len=*), intent(in) :: name
+    if (mom6x_struct_size(int(which, c_int)) /= fsize) then
+      print *, "size mismatch for ", name, mom6x_struct_size(int(which, c_int)), fsize
+      nbad = nbad + 1
+    endif
+  end subroutine chk
+end program check_abi

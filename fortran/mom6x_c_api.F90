@@ -1,0 +1,227 @@
+!> ISO_C_BINDING interfaces to the MI355X-native dynamical core (include/mom6x.h).
+!!
+!! This module is what a MOM6 build adds to bind the reference's Fortran host to the HIP library
+!! (libmom6x.so).  It follows the only in-tree precedent for C interop, src/framework/posix.F90:52-229.
+!! Every derived type mirrors a C struct of include/mom6x.h field for field (bind(C)); every interface
+!! names the C entry point and, in its comment, the reference procedure it stands in for.
+module mom6x_c_api
+  use, intrinsic :: iso_c_binding
+  implicit none ; private
+
+  public :: mom6x_dims, mom6x_vgrid, mom6x_continuity_params, mom6x_BT_cont, mom6x_barotropic_params
+  public :: mom6x_coriolis_params, mom6x_pgf_params, mom6x_rk2_params, mom6x_rk2_hooks
+  public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
+  public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
+  public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc
+  public :: mom6x_bt_mass_source, mom6x_set_dtbt, mom6x_set_dtbt_pbce, mom6x_btstep
+  public :: mom6x_CoriolisAdv_init, mom6x_CorAdCalc, mom6x_PressureForce_init, mom6x_PressureForce
+  public :: mom6x_vertvisc_set_coef, mom6x_vertvisc, mom6x_vertvisc_remnant
+  public :: mom6x_initialize_dyn_split_RK2, mom6x_dyn_split_RK2_new_run, mom6x_rk2_field
+  public :: mom6x_step_dyn_split_RK2, mom6x_comm_unique_id, mom6x_comm_init, mom6x_pass_fields
+
+  !> mom6x_dims: hor_index_type extents (MOM_hor_index.F90:14-44) + the device layout
+  type, bind(C) :: mom6x_dims
+    integer(c_int) :: ni, nj, nk, halo, ioff, joff, pitch, slab
+    integer(c_int) :: i_glob0, j_glob0, ni_glob, nj_glob, reentrant_x, reentrant_y
+  end type mom6x_dims
+
+  !> mom6x_vgrid: the scalars of verticalGrid_type (MOM_verticalGrid.F90:25-90)
+  type, bind(C) :: mom6x_vgrid
+    real(c_double) :: g_Earth, Rho0, Angstrom_H, H_subroundoff, dZ_subroundoff
+    real(c_double) :: H_to_Z, Z_to_H, H_to_RZ, RZ_to_H
+    integer(c_int) :: Boussinesq
+  end type mom6x_vgrid
+
+  !> continuity_PPM_CS (MOM_continuity_PPM.F90:35-68)
+  type, bind(C) :: mom6x_continuity_params
+    integer(c_int) :: upwind_1st, monotonic, simple_2nd
+    real(c_double) :: tol_eta, tol_vel, CFL_limit_adjust
+    integer(c_int) :: aggress_adjust, vol_CFL, better_iter, use_visc_rem_max, marginal_faces
+  end type mom6x_continuity_params
+
+  !> BT_cont_type (MOM_variables.F90:315-350): device pointers
+  type, bind(C) :: mom6x_BT_cont
+    type(c_ptr) :: FA_u_EE, FA_u_E0, FA_u_W0, FA_u_WW, uBT_WW, uBT_EE
+    type(c_ptr) :: FA_v_NN, FA_v_N0, FA_v_S0, FA_v_SS, vBT_SS, vBT_NN
+    type(c_ptr) :: h_u, h_v
+  end type mom6x_BT_cont
+
+  !> barotropic_CS parameters (MOM_barotropic.F90:108-330)
+  type, bind(C) :: mom6x_barotropic_params
+    real(c_double) :: bebt, dtbt, dt_bt_filter
+    integer(c_int) :: BT_project_velocity, Sadourny, strong_drag, wt_uv_bug, use_old_coriolis_bracket_bug
+    integer(c_int) :: visc_rem_u_uh0, clip_velocity
+    real(c_double) :: CFL_trunc, vel_underflow, G_extra, BT_Coriolis_scale, maxCFL_BT_cont
+    integer(c_int) :: bound_BT_corr, BT_cont_bounds
+    real(c_double) :: dtbt_fraction, Z_ref
+  end type mom6x_barotropic_params
+
+  type, bind(C) :: mom6x_coriolis_params   !< CoriolisAdv_CS (MOM_CoriolisAdv.F90:29-100)
+    integer(c_int) :: Coriolis_Scheme, KE_Scheme, bound_Coriolis, no_slip, Coriolis_En_Dis
+  end type mom6x_coriolis_params
+
+  type, bind(C) :: mom6x_pgf_params        !< PressureForce_FV_CS (MOM_PressureForce_FV.F90:40-110)
+    real(c_double) :: rho_ref
+    integer(c_int) :: rho_ref_bug
+    real(c_double) :: Z_ref
+  end type mom6x_pgf_params
+
+  type, bind(C) :: mom6x_rk2_params        !< MOM_dyn_split_RK2_CS (MOM_dynamics_split_RK2.F90:85-273)
+    real(c_double) :: be, begw
+    integer(c_int) :: split_bottom_stress, BT_use_layer_fluxes, store_CAu, visc_rem_dt_bug
+  end type mom6x_rk2_params
+
+  type, bind(C) :: mom6x_rk2_hooks         !< host callbacks for the un-ported callees (SURVEY 8f)
+    type(c_ptr)    :: user
+    type(c_funptr) :: vertvisc_coef
+    type(c_funptr) :: horizontal_viscosity
+  end type mom6x_rk2_hooks
+
+  interface
+    integer(c_int) function mom6x_struct_size(which) bind(C, name="mom6x_struct_size")
+      import :: c_int ; integer(c_int), value :: which
+    end function
+    integer(c_int) function mom6x_dims_init(d, ni, nj, nk, halo) bind(C, name="mom6x_dims_init")
+      import :: c_int, mom6x_dims
+      type(mom6x_dims), intent(out) :: d ; integer(c_int), value :: ni, nj, nk, halo
+    end function
+    !> replaces the `G`, `GV` arguments of every routine: metrics are uploaded once
+    integer(c_int) function mom6x_ctx_create(ctx, dims, device, metrics_host, GV, first_direction) &
+        bind(C, name="mom6x_ctx_create")
+      import :: c_int, c_ptr, c_double, mom6x_dims, mom6x_vgrid
+      type(c_ptr), intent(out) :: ctx ; type(mom6x_dims), intent(in) :: dims ; integer(c_int), value :: device
+      real(c_double), intent(in) :: metrics_host(*) ; type(mom6x_vgrid), intent(in) :: GV
+      integer(c_int), value :: first_direction
+    end function
+    integer(c_int) function mom6x_ctx_destroy(ctx) bind(C, name="mom6x_ctx_destroy")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function mom6x_ctx_sync(ctx) bind(C, name="mom6x_ctx_sync")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx
+    end function
+    type(c_ptr) function mom6x_last_error() bind(C, name="mom6x_last_error")
+      import :: c_ptr
+    end function
+    integer(c_int) function mom6x_dev_alloc(ctx, p, n) bind(C, name="mom6x_dev_alloc")
+      import :: c_int, c_ptr, c_size_t ; type(c_ptr), value :: ctx ; type(c_ptr), intent(out) :: p
+      integer(c_size_t), value :: n
+    end function
+    integer(c_int) function mom6x_dev_free(ctx, p) bind(C, name="mom6x_dev_free")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx, p
+    end function
+    !> Fortran array with MOM6 symmetric-memory extents -> pitched device array (stagger 0 h, 1 u, 2 v, 3 q)
+    integer(c_int) function mom6x_upload(ctx, dev, host_f, stagger, nk) bind(C, name="mom6x_upload")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, dev ; real(c_double), intent(in) :: host_f(*)
+      integer(c_int), value :: stagger, nk
+    end function
+    integer(c_int) function mom6x_download(ctx, host_f, dev, stagger, nk) bind(C, name="mom6x_download")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, dev ; real(c_double), intent(inout) :: host_f(*)
+      integer(c_int), value :: stagger, nk
+    end function
+
+    !> continuity_PPM_init, MOM_continuity_PPM.F90:2674
+    integer(c_int) function mom6x_continuity_init(ctx, p) bind(C, name="mom6x_continuity_init")
+      import :: c_int, c_ptr, mom6x_continuity_params ; type(c_ptr), value :: ctx
+      type(mom6x_continuity_params), intent(in) :: p
+    end function
+    !> continuity_PPM, MOM_continuity_PPM.F90:86 (optional arguments: c_null_ptr when absent)
+    integer(c_int) function mom6x_continuity_PPM(ctx, u, v, hin, h, uh, vh, dt, uhbt, vhbt, visc_rem_u, visc_rem_v, &
+        u_cor, v_cor, BT_cont, du_cor, dv_cor) bind(C, name="mom6x_continuity_PPM")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, u, v, hin, h, uh, vh ; real(c_double), value :: dt
+      type(c_ptr), value :: uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont, du_cor, dv_cor
+    end function
+
+    !> barotropic_init, MOM_barotropic.F90:5301
+    integer(c_int) function mom6x_barotropic_init(ctx, p) bind(C, name="mom6x_barotropic_init")
+      import :: c_int, c_ptr, mom6x_barotropic_params ; type(c_ptr), value :: ctx
+      type(mom6x_barotropic_params), intent(in) :: p
+    end function
+    !> btcalc, MOM_barotropic.F90:4360
+    integer(c_int) function mom6x_btcalc(ctx, h, h_u, h_v) bind(C, name="mom6x_btcalc")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx, h, h_u, h_v
+    end function
+    !> bt_mass_source, MOM_barotropic.F90:5243
+    integer(c_int) function mom6x_bt_mass_source(ctx, h, eta, set_cor) bind(C, name="mom6x_bt_mass_source")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx, h, eta ; integer(c_int), value :: set_cor
+    end function
+    !> set_dtbt, MOM_barotropic.F90:3509
+    integer(c_int) function mom6x_set_dtbt(ctx, pbce, gtot_est, SSH_add, dtbt_out) bind(C, name="mom6x_set_dtbt")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, pbce ; real(c_double), value :: gtot_est, SSH_add
+      real(c_double), intent(out) :: dtbt_out
+    end function
+    integer(c_int) function mom6x_set_dtbt_pbce(ctx, pbce, dtbt_out) bind(C, name="mom6x_set_dtbt_pbce")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, pbce ; real(c_double), intent(out) :: dtbt_out
+    end function
+    !> btstep, MOM_barotropic.F90:455
+    integer(c_int) function mom6x_btstep(ctx, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, pbce, &
+        eta_PF_in, U_Cor, V_Cor, accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v, &
+        BT_cont, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav) bind(C, name="mom6x_btstep")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, U_in, V_in, eta_in ; real(c_double), value :: dt
+      type(c_ptr), value :: bc_accel_u, bc_accel_v, taux, tauy, pbce, eta_PF_in, U_Cor, V_Cor
+      type(c_ptr), value :: accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v
+      type(c_ptr), value :: BT_cont, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav
+    end function
+
+    !> CoriolisAdv_init :1054 / CorAdCalc :125 (MOM_CoriolisAdv.F90)
+    integer(c_int) function mom6x_CoriolisAdv_init(ctx, p) bind(C, name="mom6x_CoriolisAdv_init")
+      import :: c_int, c_ptr, mom6x_coriolis_params ; type(c_ptr), value :: ctx
+      type(mom6x_coriolis_params), intent(in) :: p
+    end function
+    integer(c_int) function mom6x_CorAdCalc(ctx, u, v, h, uh, vh, CAu, CAv) bind(C, name="mom6x_CorAdCalc")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx, u, v, h, uh, vh, CAu, CAv
+    end function
+    !> PressureForce_init :85 / PressureForce :41 (MOM_PressureForce.F90 -> PressureForce_FV_Bouss)
+    integer(c_int) function mom6x_PressureForce_init(ctx, p, Rlay, g_prime) bind(C, name="mom6x_PressureForce_init")
+      import :: c_int, c_ptr, c_double, mom6x_pgf_params ; type(c_ptr), value :: ctx
+      type(mom6x_pgf_params), intent(in) :: p ; real(c_double), intent(in) :: Rlay(*), g_prime(*)
+    end function
+    integer(c_int) function mom6x_PressureForce(ctx, h, PFu, PFv, pbce, eta) bind(C, name="mom6x_PressureForce")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx, h, PFu, PFv, pbce, eta
+    end function
+    !> vertvisc :557 / vertvisc_remnant :1229 (MOM_vert_friction.F90); coefficients from vertvisc_coef :1357
+    integer(c_int) function mom6x_vertvisc_set_coef(ctx, a_u, a_v, h_u, h_v, Ray_u, Ray_v) &
+        bind(C, name="mom6x_vertvisc_set_coef")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx, a_u, a_v, h_u, h_v, Ray_u, Ray_v
+    end function
+    integer(c_int) function mom6x_vertvisc(ctx, u, v, taux, tauy, dt, taux_bot, tauy_bot) bind(C, name="mom6x_vertvisc")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, u, v, taux, tauy ; real(c_double), value :: dt
+      type(c_ptr), value :: taux_bot, tauy_bot
+    end function
+    integer(c_int) function mom6x_vertvisc_remnant(ctx, visc_rem_u, visc_rem_v, dt) bind(C, name="mom6x_vertvisc_remnant")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, visc_rem_u, visc_rem_v ; real(c_double), value :: dt
+    end function
+
+    !> initialize_dyn_split_RK2 :1346 / step_MOM_dyn_split_RK2 :294 (MOM_dynamics_split_RK2.F90)
+    integer(c_int) function mom6x_initialize_dyn_split_RK2(ctx, p) bind(C, name="mom6x_initialize_dyn_split_RK2")
+      import :: c_int, c_ptr, mom6x_rk2_params ; type(c_ptr), value :: ctx ; type(mom6x_rk2_params), intent(in) :: p
+    end function
+    integer(c_int) function mom6x_dyn_split_RK2_new_run(ctx, u, v, h, uh, vh, dt) bind(C, name="mom6x_dyn_split_RK2_new_run")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, u, v, h, uh, vh ; real(c_double), value :: dt
+    end function
+    type(c_ptr) function mom6x_rk2_field(ctx, which) bind(C, name="mom6x_rk2_field")
+      import :: c_ptr, c_int ; type(c_ptr), value :: ctx ; integer(c_int), value :: which
+    end function
+    integer(c_int) function mom6x_step_dyn_split_RK2(ctx, u_inst, v_inst, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy, &
+        dt, calc_dtbt, hooks) bind(C, name="mom6x_step_dyn_split_RK2")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, u_inst, v_inst, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy
+      real(c_double), value :: dt ; integer(c_int), value :: calc_dtbt ; type(c_ptr), value :: hooks
+    end function
+
+    !> MOM_domains: LAYOUT and halo updates over RCCL
+    integer(c_int) function mom6x_comm_unique_id(id128) bind(C, name="mom6x_comm_unique_id")
+      import :: c_int, c_char ; character(kind=c_char), intent(out) :: id128(128)
+    end function
+    integer(c_int) function mom6x_comm_init(ctx, npx, npy, px, py, id128, force_nccl_self) bind(C, name="mom6x_comm_init")
+      import :: c_int, c_ptr, c_char ; type(c_ptr), value :: ctx ; integer(c_int), value :: npx, npy, px, py
+      character(kind=c_char), intent(in) :: id128(128) ; integer(c_int), value :: force_nccl_self
+    end function
+    integer(c_int) function mom6x_pass_fields(ctx, fields, staggers, nks, n) bind(C, name="mom6x_pass_fields")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx ; type(c_ptr), intent(in) :: fields(*)
+      integer(c_int), intent(in) :: staggers(*), nks(*) ; integer(c_int), value :: n
+    end function
+  end interface
+
+end module mom6x_c_api

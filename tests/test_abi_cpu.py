@@ -77,3 +77,14 @@ def test_metric_enum_matches_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = re.findall(r"MOM6X_G_([A-Za-z0-9_]+)", body)
     assert names == abi.METRICS
+
+
+def test_fortran_binding(lib):
+    """The ISO_C_BINDING mirror (fortran/mom6x_c_api.F90) compiles with amdflang, links to the library and
+    agrees with it on every struct size (north_star: "Fortran host via ISO_C_BINDING")."""
+    import subprocess
+    import __graft_entry__ as g
+    if not g._build_fortran_binding():
+        pytest.skip("amdflang not available")
+    out = subprocess.run([os.path.join(ROOT, "fortran", "check_abi")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "fortran ABI check OK" in out.stdout, out.stdout + out.stderr
