@@ -374,6 +374,44 @@ int mom6x_step_dyn_split_RK2(mom6x_ctx *ctx, double *u_inst, double *v_inst, dou
                              const mom6x_rk2_hooks *hooks);
 
 /* ------------------------------------------------------------------------- */
+/* MOM_tracer_advect / MOM_diabatic_aux / MOM_tracer_diabatic                    */
+
+/* TRACER_ADVECTION_SCHEME values (MOM_tracer_advect_schemes.F90:11-13)          */
+#define MOM6X_ADVECT_PLM   0
+#define MOM6X_ADVECT_PPMH3 1
+#define MOM6X_ADVECT_PPM   2
+/* tracer_advect_init (MOM_tracer_advect.F90:1155): DT, TRACER_ADVECTION_SCHEME ('PLM' default),
+ * USE_HUYNH_STENCIL_BUG (F).                                                                       */
+int mom6x_tracer_advect_init(mom6x_ctx *ctx, double dt_dyn, int default_scheme, int useHuynhStencilBug);
+/* advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first_in, vol_prev, max_iter_in,
+ *   update_vol_prev, uhr_out, vhr_out)                                MOM_tracer_advect.F90:53-54.
+ * The registry Reg is an array of ntr device pointers (Reg%Tr(m)%t) with per-tracer schemes
+ * (Reg%Tr(m)%advect_scheme; < 0 = the default).  x_first_in: -1 absent; max_iter_in: 0 absent;
+ * uhr_out/vhr_out/iters_out nullable.  OBC unassociated; the offline-transport arguments (vol_prev,
+ * update_vol_prev) are not supported.                                                              */
+int mom6x_advect_tracer(mom6x_ctx *ctx, const double *h_end, const double *uhtr, const double *vhtr, double dt,
+                        double *const *tracers, const int *schemes, int ntr, int x_first_in, int max_iter_in,
+                        double *uhr_out, double *vhr_out, int *iters_out);
+/* triDiagTS(G, GV, is, ie, js, je, hold, ea, eb, T, S)            MOM_diabatic_aux.F90:394; S may be NULL.
+ * is..je are LOCAL 0-based indices (MOM6 is-isc etc.).                                             */
+int mom6x_triDiagTS(mom6x_ctx *ctx, int is, int ie, int js, int je, const double *hold, const double *ea,
+                    const double *eb, double *T, double *S);
+/* triDiagTS_Eulerian(G, GV, is, ie, js, je, hold, ent, T, S)      :444; ent has nk+1 interfaces.     */
+int mom6x_triDiagTS_Eulerian(mom6x_ctx *ctx, int is, int ie, int js, int je, const double *hold, const double *ent,
+                             double *T, double *S);
+/* tracer_vertdiff(h_old, ea, eb, dt, tr, G, GV, sfc_flux, btm_flux, btm_reservoir, sink_rate, convert_flux_in)
+ * MOM_tracer_diabatic.F90:25 -- the branch without sink_rate / btm_reservoir (:181-214).            */
+int mom6x_tracer_vertdiff(mom6x_ctx *ctx, const double *h_old, const double *ea, const double *eb, double dt,
+                          double *tr, const double *sfc_flux, const double *btm_flux, int convert_flux);
+/* tracer_vertdiff_Eulerian(h_old, ent, dt, tr, G, GV, ...)         :224 (no-sink branch :382-414).     */
+int mom6x_tracer_vertdiff_Eulerian(mom6x_ctx *ctx, const double *h_old, const double *ent, double dt, double *tr,
+                                   const double *sfc_flux, const double *btm_flux, int convert_flux);
+/* diabatic (MOM_diabatic_driver.F90:277) is a host-side dispatcher over mixing physics that is out of
+ * scope; its only device-relevant behaviour is the early return for GV%ke == 1 (:330) -- the solvers
+ * above are what it (and the tracer packages, e.g. DOME_tracer.F90:338) call.                       */
+int mom6x_diabatic_is_trivial(const mom6x_ctx *ctx);
+
+/* ------------------------------------------------------------------------- */
 /* MOM_domains: 2-D tile decomposition and halo updates over RCCL / xGMI         */
 
 /* Index range (inclusive, local indices) of the region of a `stagger` field that is SENT to (send=1)

@@ -140,6 +140,7 @@ extern "C" int mom6x_dims_init(mom6x_dims *d, int ni, int nj, int nk, int halo) 
 
 void bt_state_free(mom6x_ctx *ctx);   // barotropic.hip
 void rk2_state_free(mom6x_ctx *ctx);  // dyn_split_RK2.hip
+void ta_state_free(mom6x_ctx *ctx);   // tracer.hip
 
 extern "C" int mom6x_ctx_create(mom6x_ctx **out, const mom6x_dims *dims, int device,
                                 const double *metrics_host, const mom6x_vgrid *GV,
@@ -163,7 +164,7 @@ extern "C" int mom6x_ctx_create(mom6x_ctx **out, const mom6x_dims *dims, int dev
   c->GV = *GV;
   c->first_direction = first_direction;
   c->cont_init = false; c->bt_init = false;
-  c->prof_on = false; c->prof = nullptr; c->comm = nullptr; c->halo_error = false;
+  c->prof_on = false; c->prof = nullptr; c->comm = nullptr; c->halo_error = false; c->ta = nullptr;
   c->cor_init = false; c->pgf_init = false; c->Rlay = c->g_prime = nullptr;
   c->a_u = c->a_v = c->h_u = c->h_v = c->Ray_u = c->Ray_v = nullptr;
   for (int m = 0; m < MOM6X_NSCR; m++) { c->scr[m] = nullptr; c->scr_nlev[m] = 0; }
@@ -192,6 +193,7 @@ extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
   bt_state_free(c);
   rk2_state_free(c);
   comm_free(c);
+  ta_state_free(c);
   for (int m = 0; m < MOM6X_NSCR; m++) (void)hipFree(c->scr[m]);
   (void)hipFree(c->Rlay); (void)hipFree(c->g_prime);
   (void)hipFree(c->G); (void)hipFree(c->hL); (void)hipFree(c->hR); (void)hipFree(c->flag);

@@ -342,3 +342,11 @@ extern "C" int mom6x_pass_fields(mom6x_ctx *c, double *const *fields, const int 
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }
+
+// sum_across_PEs of an int array that lives on the device (MOM_coms.F90; advect_tracer :331), in place.
+int comm_allreduce_int_sum(mom6x_ctx *c, int *dev, int n) {
+  Comm *m = (Comm *)c->comm;
+  if (!m || !m->comm || m->nranks == 1) return MOM6X_OK;
+  NCCLCHK(g_nccl.AllReduce(dev, dev, (size_t)n, ncclInt, ncclSum, m->comm, c->stream));
+  return MOM6X_OK;
+}

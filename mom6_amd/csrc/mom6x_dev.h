@@ -81,6 +81,7 @@ struct mom6x_ctx {
   double *scr[MOM6X_NSCR]; int scr_nlev[MOM6X_NSCR];
   bool prof_on;
   struct Prof *prof;
+  void *ta;                 // tracer.hip: tracer-advection state (TAState)
   void *comm;               // halo.hip: tile layout + RCCL communicator (null: single tile, wrap only)
   bool halo_error;          // set by a failed halo exchange inside a stream-ordered sequence
 };

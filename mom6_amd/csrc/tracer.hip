@@ -1,0 +1,467 @@
+// tracer.hip -- tracer advection and the vertical tridiagonal solves on gfx950.
+//
+//   advect_tracer / advect_x / advect_y   <- src/tracer/MOM_tracer_advect.F90:53-1153 (PLM, PPM:H3, PPM)
+//   triDiagTS, triDiagTS_Eulerian         <- src/parameterizations/vertical/MOM_diabatic_aux.F90:394-488
+//   tracer_vertdiff(_Eulerian)            <- src/tracer/MOM_tracer_diabatic.F90:25-420 (no-sinking branch)
+//
+// advect_tracer is an iteration: each pass moves as much of the remaining transport (uhr, vhr) as keeps the
+// upwind cell non-empty, until nothing remains.  The reference's row flags domore_u(j,k)/domore_v(J,k) and
+// layer flags domore_k(k) decide which rows are touched at all, so they are kept (int arrays in HBM) and the
+// exit test reads domore_k back once per halo cycle -- the same global synchronisation point as the
+// reference's sum_across_PEs (:331).  Per direction and pass there are two kernels, because all fluxes of a
+// pass must be formed from the un-updated hprev/uhr/tracer values:
+//   k_ta_face<DIR>: limited transport uhh and the tracer fluxes of every face   -> scratch
+//   k_ta_cell<DIR>: uhr -= uhh ; hprev and every tracer updated from the face fluxes
+#include <cfloat>
+#include <vector>
+#include "mom6x_dev.h"
+
+void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);
+int comm_allreduce_int_sum(mom6x_ctx *c, int *dev, int n);   // halo.hip
+
+#define MAXTR 8
+enum { ADVECT_PLM = 0, ADVECT_PPMH3 = 1, ADVECT_PPM = 2 };
+
+struct TAState {
+  double dt_dyn; int default_scheme, useHuynhStencilBug;
+  double *hprev, *uhr, *vhr, *uhh, *flux[MAXTR];
+  int nflux;
+  int *dmu, *dmv, *limu, *limv, *dmk;   // [nk*nrows] row flags, "a flux was limited" marks, [nk] layer flags
+};
+
+struct TrList { double *t[MAXTR]; int scheme[MAXTR]; int n; };
+struct FluxList { double *f[MAXTR]; };
+
+namespace {
+
+inline dim3 blk2() { return dim3(64, 4, 1); }
+
+__device__ __forceinline__ double dmax3(double a, double b, double c) { return dmax(dmax(a, b), c); }
+__device__ __forceinline__ double dmin3(double a, double b, double c) { return dmin(dmin(a, b), c); }
+
+// PLM slope at cell c :445-449 / :824-828
+__device__ __forceinline__ double plm_slope(const double *__restrict__ T, const double *__restrict__ mC, size_t c, size_t c2, int st) {
+  const double tp = T[c + st], tc = T[c], tm = T[c - st];
+  const double dMx = dmax3(tp, tc, tm) - tc, dMn = tc - dmin3(tp, tc, tm);
+  return mC[c2] * mC[c2 - st] * dsign(dmin3(0.5 * fabs(tp - tm), 2.0 * dMx, 2.0 * dMn), tp - tm);
+}
+
+// tracer flux through one face :546-607 / :951-1010.  f = 3-D index of the face, f2 = its 2-D index.
+__device__ double face_flux(int scheme, const double *__restrict__ T, const double *__restrict__ mC, size_t f, size_t f2,
+                            int st, double uhh, double CFL) {
+  if (scheme == ADVECT_PPM || scheme == ADVECT_PPMH3) {
+    const size_t up = (uhh >= 0.0) ? f : f + st, up2 = (uhh >= 0.0) ? f2 : f2 + st;
+    const double Tp = T[up + st], Tc = T[up], Tm = T[up - st];
+    double aL, aR;
+    if (scheme == ADVECT_PPMH3) {
+      aL = (5. * Tc + (2. * Tm - Tp)) / 6.;
+      aL = dmax(dmin(Tc, Tm), aL); aL = dmin(dmax(Tc, Tm), aL);
+      aR = (5. * Tc + (2. * Tp - Tm)) / 6.;
+      aR = dmax(dmin(Tc, Tp), aR); aR = dmin(dmax(Tc, Tp), aR);
+    } else {
+      const double s0 = plm_slope(T, mC, up - st, up2 - st, st), s1 = plm_slope(T, mC, up, up2, st),
+                   s2 = plm_slope(T, mC, up + st, up2 + st, st);
+      aL = 0.5 * ((Tm + Tc) + (s0 - s1) / 3.);
+      aR = 0.5 * ((Tc + Tp) + (s1 - s2) / 3.);
+    }
+    const double dA = aR - aL, mA = 0.5 * (aR + aL);
+    if (mC[up2] * mC[up2 - st] * (Tp - Tc) * (Tc - Tm) <= 0.) { aL = Tc; aR = Tc; }
+    else if (dA * (Tc - mA) > (dA * dA) / 6.) aL = (3. * Tc) - 2. * aR;
+    else if (dA * (Tc - mA) < -(dA * dA) / 6.) aR = (3. * Tc) - 2. * aL;
+    const double a6 = 6. * Tc - 3. * (aR + aL);
+    if (uhh >= 0.0) return uhh * (aR - 0.5 * CFL * ((aR - aL) - a6 * (1. - 2. / 3. * CFL)));
+    return uhh * (aL + 0.5 * CFL * ((aR - aL) + a6 * (1. - 2. / 3. * CFL)));
+  }
+  const size_t c = (uhh >= 0.0) ? f : f + st, c2 = (uhh >= 0.0) ? f2 : f2 + st;
+  const double slope = plm_slope(T, mC, c, c2, st);
+  if (uhh >= 0.0) return uhh * (T[c] + 0.5 * slope * (1. - CFL));
+  return uhh * (T[c] - 0.5 * slope * (1. - CFL));
+}
+
+// setup :170-206: remaining transports, reconstructed previous cell volume, flags
+__global__ void __launch_bounds__(256)
+k_ta_init(Dm d, const double *__restrict__ G, const double *__restrict__ h_end, const double *__restrict__ uhtr,
+          const double *__restrict__ vhtr, double *__restrict__ hprev, double *__restrict__ uhr, double *__restrict__ vhr) {
+  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int st = d.pitch;
+  const size_t c2 = ix2(d, i, j), c = c2 + (size_t)k * d.slab;
+  if (j >= 0) uhr[c] = uhtr[c];
+  if (i >= 0) vhr[c] = vhtr[c];
+  if (i >= 0 && j >= 0) {
+    const double aT = gm(G, d, MOM6X_G_areaT)[c2];
+    double hp = dmax(0.0, aT * h_end[c] + ((uhtr[c] - uhtr[c - 1]) + (vhtr[c] - vhtr[c - st])));
+    hp = hp + dmax(0.0, 1.0e-13 * hp - aT * h_end[c]);
+    hprev[c] = hp;
+  }
+}
+
+// Re-evaluation of the row flags :242-253.  One wave per (row, layer).
+template <int DIR>
+__global__ void k_ta_flags_eval(Dm d, const double *__restrict__ uhr, int *__restrict__ dm, const int *__restrict__ dmk,
+                                int r0, int r1, int i0, int i1) {
+  const int r = r0 + blockIdx.x, k = blockIdx.y;
+  if (r > r1 || dmk[k] <= 0) return;
+  const int nrows = d.nj + 2 * d.halo + 1;
+  int *flag = &dm[k * nrows + r + d.joff];
+  if (*flag) return;
+  int any = 0;
+  for (int i = i0 + threadIdx.x; i <= i1; i += 64) if (uhr[ix3(d, i, r, k)] != 0.0) any = 1;
+  if (__any(any) && threadIdx.x == 0) *flag = 1;
+}
+
+// domore_k(k) from the row flags (:257-259, :291-294, :310-313): any(dmu[ju0..ju1]) or any(dmv[jv0..jv1]).
+// mode 0: only layers with dmk > 0 are recomputed.
+__global__ void k_ta_dmk(Dm d, const int *__restrict__ dmu, const int *__restrict__ dmv, int *__restrict__ dmk,
+                         int ju0, int ju1, int jv0, int jv1) {
+  const int k = blockIdx.x;
+  if (dmk[k] <= 0) return;
+  const int nrows = d.nj + 2 * d.halo + 1;
+  int any = 0;
+  for (int j = ju0 + threadIdx.x; j <= ju1; j += 64) if (dmu[k * nrows + j + d.joff]) any = 1;
+  for (int j = jv0 + threadIdx.x; j <= jv1; j += 64) if (dmv[k * nrows + j + d.joff]) any = 1;
+  const int r = __any(any) ? 1 : 0;
+  if (threadIdx.x == 0) dmk[k] = r;
+}
+
+// After a direction's pass: processed rows take "was any flux limited" as their new flag.
+__global__ void k_ta_flag_commit(Dm d, int *__restrict__ dm, int *__restrict__ lim, const int *__restrict__ dmk, int r0, int r1) {
+  const int r = r0 + blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (r > r1 || dmk[k] <= 0) return;
+  const int nrows = d.nj + 2 * d.halo + 1;
+  const int idx = k * nrows + r + d.joff;
+  if (dm[idx]) { dm[idx] = lim[idx]; }
+  lim[idx] = 0;
+}
+
+// limited transports and tracer fluxes of the faces (a0..a1, b0..b1) :490-607 / :915-1010
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_ta_face(Dm d, const double *__restrict__ G, const double *__restrict__ uhr, const double *__restrict__ hprev, TrList Tr,
+          double *__restrict__ uhh_out, FluxList F, const int *__restrict__ dm, int *__restrict__ lim,
+          const int *__restrict__ dmk, double min_h, int a0, int a1, int b0, int b1) {
+  const int i = a0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = b0 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > a1 || j > b1 || dmk[k] <= 0) return;
+  const int st = DIR ? d.pitch : 1;
+  const int nrows = d.nj + 2 * d.halo + 1;
+  const size_t f2 = ix2(d, i, j), f = f2 + (size_t)k * d.slab;
+  if (!dm[k * nrows + j + d.joff]) {       // a row that is not being worked on moves nothing (:1065-1067)
+    uhh_out[f] = 0.0;
+    for (int m = 0; m < Tr.n; m++) F.f[m][f] = 0.0;
+    return;
+  }
+  const double *areaT = gm(G, d, MOM6X_G_areaT);
+  const double *mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu);
+  const double tiny_h = DBL_MIN;
+  const double ur = uhr[f];
+  double uhh, CFL;
+  if ((ur == 0.0) || ((ur < 0.0) && (hprev[f + st] <= tiny_h)) || ((ur > 0.0) && (hprev[f] <= tiny_h))) {
+    uhh = 0.0; CFL = 0.0;
+  } else if (ur < 0.0) {
+    const double hup = hprev[f + st] - areaT[f2 + st] * min_h;
+    const double hlos = dmax(0.0, uhr[f + st]);
+    if ((((hup - hlos) + ur) < 0.0) && ((0.5 * hup + ur) < 0.0)) {
+      uhh = dmin3(-0.5 * hup, -hup + hlos, 0.0);
+      lim[k * nrows + j + d.joff] = 1;
+    } else uhh = ur;
+    CFL = -uhh / (hprev[f + st]);
+  } else {
+    const double hup = hprev[f] - areaT[f2] * min_h;
+    const double hlos = dmax(0.0, -uhr[f - st]);
+    if ((((hup - hlos) - ur) < 0.0) && ((0.5 * hup - ur) < 0.0)) {
+      uhh = dmax3(0.5 * hup, hup - hlos, 0.0);
+      lim[k * nrows + j + d.joff] = 1;
+    } else uhh = ur;
+    CFL = uhh / (hprev[f]);
+  }
+  uhh_out[f] = uhh;
+  for (int m = 0; m < Tr.n; m++) F.f[m][f] = face_flux(Tr.scheme[m], Tr.t[m], mC, f, f2, st, uhh, CFL);
+}
+
+// uhr -= uhh and the cell updates :668-711 / :1073-1125.  Threads run over the faces (a0..a1, b0..b1); the
+// cell on the plus side of... no: thread (i,j) owns face (i,j) [its remaining transport] and cell (i,j).
+template <int DIR>
+__global__ void __launch_bounds__(256)
+k_ta_cell(Dm d, const double *__restrict__ G, double *__restrict__ uhr, double *__restrict__ hprev, TrList Tr,
+          const double *__restrict__ uhh, FluxList F, const int *__restrict__ dm, const int *__restrict__ dmk,
+          double h_neglect, double H_subroundoff, int a0, int a1, int b0, int b1, int ci0, int cj0) {
+  const int i = a0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = b0 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > a1 || j > b1 || dmk[k] <= 0) return;
+  const int st = DIR ? d.pitch : 1;
+  const int nrows = d.nj + 2 * d.halo + 1;
+  const size_t c2 = ix2(d, i, j), c = c2 + (size_t)k * d.slab;
+  const double *areaT = gm(G, d, MOM6X_G_areaT);
+  // In x only the rows being worked on are touched at all (:417); in y every face has its remaining
+  // transport updated (:1073-1076) and a cell changes only if one of its faces moved something.
+  if (DIR == 0 && !dm[k * nrows + j + d.joff]) return;
+  const double uh_here = uhh[c];
+  {
+    double r = uhr[c] - uh_here;
+    const double neglect = H_subroundoff * dmin(areaT[c2], areaT[c2 + st]);
+    if (fabs(r) < neglect) r = 0.0;
+    uhr[c] = r;
+  }
+  if (i < ci0 || j < cj0) return;            // the first face of the range has no cell of this range behind it
+  const double uh_m = uhh[c - st];
+  if ((uh_here != 0.0) || (uh_m != 0.0)) {
+    double hlst = hprev[c], Ihnew = 0.0;
+    double hp = hlst - (uh_here - uh_m);
+    if (DIR == 1) hp = dmax(hp, 0.0);
+    hprev[c] = hp;
+    bool do_i = true;
+    if (hp <= 0.0) do_i = false;
+    else if (hp < h_neglect * areaT[c2]) {
+      hlst = hlst + (h_neglect * areaT[c2] - hp);
+      Ihnew = 1.0 / (h_neglect * areaT[c2]);
+    } else Ihnew = 1.0 / hp;
+    if (do_i && (DIR == 1 || Ihnew > 0.0)) {
+      for (int m = 0; m < Tr.n; m++) Tr.t[m][c] = (Tr.t[m][c] * hlst - (F.f[m][c] - F.f[m][c - st])) * Ihnew;
+    }
+  }
+}
+
+// triDiagTS :394-440 / triDiagTS_Eulerian :444-488 / tracer_vertdiff(_Eulerian) no-sink branch, one column per thread.
+// vertdiff = 1 adds the land mask, ea(1) in the first denominator and the surface/bottom sources.
+__global__ void __launch_bounds__(256)
+k_tridiag(Dm d, const double *__restrict__ G, const double *__restrict__ hold, const double *__restrict__ ea,
+          const double *__restrict__ eb, double *__restrict__ T, double *__restrict__ c1, double h_neglect, int vertdiff,
+          const double *__restrict__ sfc_flux, const double *__restrict__ btm_flux, double flux_scale, int i0, int i1,
+          int j0, int j1) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > i1 || j > j1) return;
+  const int nz = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  double sfc_src = 0.0, btm_src = 0.0;
+  if (vertdiff) {
+    if (!(gm(G, d, MOM6X_G_mask2dT)[x] > 0.0)) return;
+    if (sfc_flux) sfc_src = (flux_scale != 0.0) ? (sfc_flux[x] * flux_scale) : sfc_flux[x];
+    if (btm_flux) btm_src = (flux_scale != 0.0) ? (btm_flux[x] * flux_scale) : btm_flux[x];
+  }
+  double h_tr = hold[x] + h_neglect;
+  double b1 = vertdiff ? 1.0 / ((h_tr + ea[x]) + eb[x]) : 1.0 / (h_tr + eb[x]);
+  double d1 = h_tr * b1;
+  double prev = (b1 * h_tr) * T[x];
+  if (vertdiff) prev = prev + b1 * sfc_src;
+  T[x] = prev;
+  for (int k = 1; k < nz; k++) {
+    const size_t c = x + (size_t)k * slab;
+    c1[c] = eb[c - slab] * b1;
+    h_tr = hold[c] + h_neglect;
+    const double eak = ea[c];
+    const double b_denom_1 = h_tr + d1 * eak;
+    b1 = 1.0 / (b_denom_1 + eb[c]);
+    d1 = b_denom_1 * b1;
+    if (vertdiff && k == nz - 1) prev = b1 * ((h_tr * T[c] + btm_src) + eak * prev);
+    else prev = b1 * (h_tr * T[c] + eak * prev);
+    T[c] = prev;
+  }
+  for (int k = nz - 2; k >= 0; k--) {
+    const size_t c = x + (size_t)k * slab;
+    prev = T[c] + c1[c + slab] * prev;
+    T[c] = prev;
+  }
+}
+
+}  // namespace
+
+void ta_state_free(mom6x_ctx *c) {
+  TAState *s = (TAState *)c->ta;
+  if (!s) return;
+  (void)hipFree(s->hprev); (void)hipFree(s->uhr); (void)hipFree(s->vhr); (void)hipFree(s->uhh);
+  for (int m = 0; m < MAXTR; m++) (void)hipFree(s->flux[m]);
+  (void)hipFree(s->dmu); (void)hipFree(s->dmv); (void)hipFree(s->limu); (void)hipFree(s->limv); (void)hipFree(s->dmk);
+  delete s;
+  c->ta = nullptr;
+}
+
+// tracer_advect_init :1155 (DT, TRACER_ADVECTION_SCHEME, USE_HUYNH_STENCIL_BUG)
+extern "C" int mom6x_tracer_advect_init(mom6x_ctx *c, double dt_dyn, int default_scheme, int useHuynhStencilBug) {
+  REQUIRE(c && dt_dyn > 0.0, MOM6X_EINVAL, "mom6x_tracer_advect_init: bad arguments");
+  REQUIRE(default_scheme >= 0 && default_scheme <= 2, MOM6X_EINVAL, "tracer_advect_init: unknown TRACER_ADVECTION_SCHEME");
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->ta) {
+    TAState *s = new TAState();
+    memset(s, 0, sizeof(*s));
+    const size_t n3 = (size_t)c->dims.slab * c->dims.nk;
+    const size_t nf = (size_t)(c->dims.nj + 2 * c->dims.halo + 1) * c->dims.nk;
+    double **p3[] = { &s->hprev, &s->uhr, &s->vhr, &s->uhh };
+    for (double **q : p3) { HIPCHK(hipMalloc(q, n3 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, 0, n3 * sizeof(double), c->stream)); }
+    int **pf[] = { &s->dmu, &s->dmv, &s->limu, &s->limv };
+    for (int **q : pf) { HIPCHK(hipMalloc(q, nf * sizeof(int))); HIPCHK(hipMemsetAsync(*q, 0, nf * sizeof(int), c->stream)); }
+    HIPCHK(hipMalloc(&s->dmk, c->dims.nk * sizeof(int)));
+    c->ta = s;
+  }
+  TAState *s = (TAState *)c->ta;
+  s->dt_dyn = dt_dyn; s->default_scheme = default_scheme; s->useHuynhStencilBug = useHuynhStencilBug;
+  return MOM6X_OK;
+}
+
+// advect_tracer :53
+extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const double *uhtr, const double *vhtr, double dt,
+                                   double *const *tracers, const int *schemes, int ntr, int x_first_in, int max_iter_in,
+                                   double *uhr_out, double *vhr_out, int *iters_out) {
+  REQUIRE(c && c->ta, MOM6X_EINVAL, "MOM_tracer_advect: tracer_advect_init must be called before advect_tracer.");
+  REQUIRE(h_end && uhtr && vhtr && (ntr == 0 || tracers), MOM6X_EINVAL, "advect_tracer: null array");
+  REQUIRE(ntr <= MAXTR, MOM6X_EUNSUPPORTED, "advect_tracer: at most 8 tracers per call");
+  if (ntr == 0) return MOM6X_OK;
+  HIPCHK(hipSetDevice(c->device));
+  TAState *s = (TAState *)c->ta;
+  const Dm d = c->d;
+  const int is = 0, ie = d.ni - 1, js = 0, je = d.nj - 1, nz = d.nk, w = d.halo;
+  const size_t n3 = (size_t)d.slab * nz;
+  const int nrows = d.nj + 2 * d.halo + 1;
+  const size_t nf = (size_t)nrows * nz;
+  hipStream_t st = c->stream;
+  TrList Tr; Tr.n = ntr;
+  int stencil = 2;
+  for (int m = 0; m < ntr; m++) {
+    Tr.t[m] = tracers[m];
+    Tr.scheme[m] = (schemes && schemes[m] >= 0) ? schemes[m] : s->default_scheme;
+    REQUIRE(Tr.scheme[m] >= 0 && Tr.scheme[m] <= 2, MOM6X_EINVAL, "advect_tracer: unknown advection scheme");
+    int sl = 2;
+    if (Tr.scheme[m] == ADVECT_PPM) sl = 3;
+    else if (Tr.scheme[m] == ADVECT_PPMH3) sl = s->useHuynhStencilBug ? 2 : 3;
+    if (sl > stencil) stencil = sl;
+  }
+  REQUIRE(w >= stencil, MOM6X_EINVAL, "MOM_tracer_advect: stencil is wider than the halo.");
+  FluxList F;
+  for (int m = 0; m < MAXTR; m++) F.f[m] = nullptr;
+  for (int m = 0; m < ntr; m++) {
+    if (!s->flux[m]) { HIPCHK(hipMalloc(&s->flux[m], n3 * sizeof(double))); HIPCHK(hipMemsetAsync(s->flux[m], 0, n3 * sizeof(double), st)); }
+    F.f[m] = s->flux[m];
+  }
+  bool x_first = ((c->first_direction % 2) == 0);
+  int max_iter = 2 * (int)ceil(dt / s->dt_dyn) + 1;
+  if (max_iter_in > 0) max_iter = max_iter_in;
+  if (x_first_in >= 0) x_first = (x_first_in != 0);
+  const dim3 b = blk2();
+  const double min_h = 0.1 * c->GV.Angstrom_H, h_neglect = c->GV.H_subroundoff;
+
+  HIPCHK(hipMemsetAsync(s->hprev, 0, n3 * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(s->uhr, 0, n3 * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(s->vhr, 0, n3 * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(s->uhh, 0, n3 * sizeof(double), st));
+  for (int *p : { s->dmu, s->dmv, s->limu, s->limv }) HIPCHK(hipMemsetAsync(p, 0, nf * sizeof(int), st));
+  std::vector<int> ones(nz, 1), dmk_h(nz, 1);
+  HIPCHK(hipMemcpyAsync(s->dmk, ones.data(), nz * sizeof(int), hipMemcpyHostToDevice, st));
+  KLAUNCH(c, "k_ta_init", k_ta_init, grid3(d.ni + 1, d.nj + 1, nz, b), b, d, c->G, h_end, uhtr, vhtr, s->hprev, s->uhr, s->vhr);
+
+  auto advect = [&](int dir, int i0, int i1, int j0, int j1) {
+    // faces: x: (i0-1..i1, j0..j1); y: (i0..i1, j0-1..j1)
+    const int a0 = dir ? i0 : i0 - 1, b0 = dir ? j0 - 1 : j0;
+    const dim3 g = grid3(i1 - a0 + 1, j1 - b0 + 1, nz, b);
+    if (dir == 0) {
+      KLAUNCH(c, "k_ta_face<0>", k_ta_face<0>, g, b, d, c->G, (const double *)s->uhr, (const double *)s->hprev, Tr, s->uhh, F,
+              (const int *)s->dmu, s->limu, (const int *)s->dmk, min_h, a0, i1, b0, j1);
+      KLAUNCH(c, "k_ta_cell<0>", k_ta_cell<0>, g, b, d, c->G, s->uhr, s->hprev, Tr, (const double *)s->uhh, F, (const int *)s->dmu,
+              (const int *)s->dmk, h_neglect, c->GV.H_subroundoff, a0, i1, b0, j1, i0, j0);
+      KLAUNCH(c, "k_ta_flag_commit", k_ta_flag_commit, dim3((j1 - j0 + 64) / 64, nz), dim3(64), d, s->dmu, s->limu, (const int *)s->dmk, j0, j1);
+    } else {
+      KLAUNCH(c, "k_ta_face<1>", k_ta_face<1>, g, b, d, c->G, (const double *)s->vhr, (const double *)s->hprev, Tr, s->uhh, F,
+              (const int *)s->dmv, s->limv, (const int *)s->dmk, min_h, a0, i1, b0, j1);
+      KLAUNCH(c, "k_ta_cell<1>", k_ta_cell<1>, g, b, d, c->G, s->vhr, s->hprev, Tr, (const double *)s->uhh, F, (const int *)s->dmv,
+              (const int *)s->dmk, h_neglect, c->GV.H_subroundoff, a0, i1, b0, j1, i0, j0);
+      KLAUNCH(c, "k_ta_flag_commit", k_ta_flag_commit, dim3((j1 - b0 + 64) / 64, nz), dim3(64), d, s->dmv, s->limv, (const int *)s->dmk, b0, j1);
+    }
+  };
+
+  int isv = is, iev = ie, jsv = js, jev = je, itt;
+  for (itt = 1; itt <= max_iter; itt++) {
+    if (isv > is - stencil) {   // :229-262
+      std::vector<double *> f = { s->uhr, s->vhr, s->hprev };
+      std::vector<int> stg = { 1, 2, 0 };
+      for (int m = 0; m < ntr; m++) { f.push_back(Tr.t[m]); stg.push_back(0); }
+      std::vector<int> nks(f.size(), nz);
+      halo_wrap(c, f.data(), stg.data(), nks.data(), (int)f.size());
+      const int nsten_halo = w / stencil;
+      isv = is - nsten_halo * stencil; jsv = js - nsten_halo * stencil;
+      iev = ie + nsten_halo * stencil; jev = je + nsten_halo * stencil;
+      if ((nsten_halo > 1) || (itt == 1)) {
+        KLAUNCH(c, "k_ta_flags_eval<0>", k_ta_flags_eval<0>, dim3(jev - jsv + 1, nz), dim3(64), d, (const double *)s->uhr, s->dmu,
+                (const int *)s->dmk, jsv, jev, isv + stencil - 1, iev - stencil);
+        KLAUNCH(c, "k_ta_flags_eval<1>", k_ta_flags_eval<1>, dim3(jev - jsv - 2 * stencil + 2, nz), dim3(64), d, (const double *)s->vhr, s->dmv,
+                (const int *)s->dmk, jsv + stencil - 1, jev - stencil, isv + stencil, iev - stencil);
+        KLAUNCH(c, "k_ta_dmk", k_ta_dmk, dim3(nz), dim3(64), d, (const int *)s->dmu, (const int *)s->dmv, s->dmk, jsv, jev,
+                jsv + stencil - 1, jev - stencil);
+      }
+    }
+    isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil;
+    if (x_first) {
+      advect(0, isv, iev, jsv - stencil, jev + stencil);
+      advect(1, isv, iev, jsv, jev);
+      KLAUNCH(c, "k_ta_dmk", k_ta_dmk, dim3(nz), dim3(64), d, (const int *)s->dmu, (const int *)s->dmv, s->dmk, jsv - stencil,
+              jev + stencil, jsv - 1, jev);
+    } else {
+      advect(1, isv - stencil, iev + stencil, jsv, jev);
+      advect(0, isv, iev, jsv, jev);
+      KLAUNCH(c, "k_ta_dmk", k_ta_dmk, dim3(nz), dim3(64), d, (const int *)s->dmu, (const int *)s->dmv, s->dmk, jsv, jev, jsv - 1, jev);
+    }
+    if (itt >= max_iter) break;
+    if (isv > is - stencil) {   // sum_across_PEs(domore_k) :331
+      { int rc_ = comm_allreduce_int_sum(c, s->dmk, nz); if (rc_) return rc_; }
+      HIPCHK(hipMemcpyAsync(dmk_h.data(), s->dmk, nz * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      int do_any = 0;
+      for (int k = 0; k < nz; k++) do_any += dmk_h[k];
+      if (do_any == 0) break;
+    }
+  }
+  if (iters_out) *iters_out = itt;
+  if (uhr_out) HIPCHK(hipMemcpyAsync(uhr_out, s->uhr, n3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (vhr_out) HIPCHK(hipMemcpyAsync(vhr_out, s->vhr, n3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipGetLastError());
+  REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
+  return MOM6X_OK;
+}
+
+static int tridiag(mom6x_ctx *c, const double *hold, const double *ea, const double *eb, double *T, int vertdiff,
+                   const double *sfc_flux, const double *btm_flux, double flux_scale, int is, int ie, int js, int je) {
+  REQUIRE(c && hold && ea && eb && T, MOM6X_EINVAL, "tridiagonal solve: null array");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  double *c1;
+  int rc;
+  if ((rc = ctx_scratch(c, SCR_c1, d.nk, &c1))) return rc;
+  const dim3 b = blk2();
+  KLAUNCH(c, "k_tridiag", k_tridiag, grid3(ie - is + 1, je - js + 1, 1, b), b, d, c->G, hold, ea, eb, T, c1, c->GV.H_subroundoff,
+          vertdiff, sfc_flux, btm_flux, flux_scale, is, ie, js, je);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+// triDiagTS(G, GV, is, ie, js, je, hold, ea, eb, T, S)  diabatic_aux.F90:394 (one field per call; S = second call)
+extern "C" int mom6x_triDiagTS(mom6x_ctx *c, int is, int ie, int js, int je, const double *hold, const double *ea,
+                               const double *eb, double *T, double *S) {
+  int rc = tridiag(c, hold, ea, eb, T, 0, nullptr, nullptr, 0.0, is, ie, js, je);
+  if (rc || !S) return rc;
+  return tridiag(c, hold, ea, eb, S, 0, nullptr, nullptr, 0.0, is, ie, js, je);
+}
+// triDiagTS_Eulerian(G, GV, is, ie, js, je, hold, ent, T, S)  :444 ; ent has nk+1 interfaces
+extern "C" int mom6x_triDiagTS_Eulerian(mom6x_ctx *c, int is, int ie, int js, int je, const double *hold, const double *ent,
+                                        double *T, double *S) {
+  REQUIRE(ent, MOM6X_EINVAL, "triDiagTS_Eulerian: null ent");
+  return mom6x_triDiagTS(c, is, ie, js, je, hold, ent, ent + c->dims.slab, T, S);
+}
+// tracer_vertdiff(h_old, ea, eb, dt, tr, G, GV, sfc_flux, btm_flux, ..., convert_flux_in)  tracer_diabatic.F90:25
+extern "C" int mom6x_tracer_vertdiff(mom6x_ctx *c, const double *h_old, const double *ea, const double *eb, double dt,
+                                     double *tr, const double *sfc_flux, const double *btm_flux, int convert_flux) {
+  if (c && c->dims.nk == 1) return MOM6X_OK;   // the reference warns and returns
+  const double scale = convert_flux ? dt * c->GV.RZ_to_H : 0.0;
+  return tridiag(c, h_old, ea, eb, tr, 1, sfc_flux, btm_flux, scale, 0, c->dims.ni - 1, 0, c->dims.nj - 1);
+}
+extern "C" int mom6x_tracer_vertdiff_Eulerian(mom6x_ctx *c, const double *h_old, const double *ent, double dt, double *tr,
+                                              const double *sfc_flux, const double *btm_flux, int convert_flux) {
+  REQUIRE(ent, MOM6X_EINVAL, "tracer_vertdiff_Eulerian: null ent");
+  return mom6x_tracer_vertdiff(c, h_old, ent, ent + c->dims.slab, dt, tr, sfc_flux, btm_flux, convert_flux);
+}
+// diabatic(u, v, h, tv, BLD, fluxes, visc, ADp, CDp, dt, Time_end, G, GV, US, CS, ...)  diabatic_driver.F90:277
+// Only the part of the dispatcher that is on the ported path: with GV%ke == 1 it returns immediately (:330),
+// otherwise the host's mixing-coefficient physics (out of scope) supplies ea/eb or ent and calls the solvers above.
+extern "C" int mom6x_diabatic_is_trivial(const mom6x_ctx *c) { return (c && c->dims.nk == 1) ? 1 : 0; }

@@ -220,6 +220,41 @@ class Dycore:
             self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(uh), _ptr(vh), _ptr(uhtr), _ptr(vhtr), _ptr(eta_av), _ptr(taux),
             _ptr(tauy), C.c_double(dt), C.c_int(int(calc_dtbt)), hooks))
 
+    # -- MOM_tracer_advect / tridiagonal solvers ----------------------------------------------
+    def tracer_advect_init(self, dt_dyn, scheme=0, useHuynhStencilBug=False):
+        """tracer_advect_init (MOM_tracer_advect.F90:1155); scheme: 0 PLM (default), 1 PPM:H3, 2 PPM."""
+        check(self.lib, self.lib.mom6x_tracer_advect_init(self.ctx, C.c_double(dt_dyn), C.c_int(scheme), C.c_int(int(useHuynhStencilBug))))
+
+    def advect_tracer(self, h_end, uhtr, vhtr, dt, tracers, schemes=None, x_first_in=-1, max_iter_in=0, uhr_out=None, vhr_out=None):
+        """advect_tracer (MOM_tracer_advect.F90:53); `tracers` is the registry as a list of 3-D fields."""
+        n = len(tracers)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tracers])
+        sch = (C.c_int * n)(*(schemes if schemes is not None else [-1] * n))
+        iters = C.c_int(0)
+        check(self.lib, self.lib.mom6x_advect_tracer(self.ctx, _ptr(h_end), _ptr(uhtr), _ptr(vhtr), C.c_double(dt), ptrs, sch, n,
+                                                     C.c_int(x_first_in), C.c_int(max_iter_in), _ptr(uhr_out), _ptr(vhr_out), C.byref(iters)))
+        return iters.value
+
+    def triDiagTS(self, hold, ea, eb, T, S=None, rng=None):
+        """triDiagTS (MOM_diabatic_aux.F90:394)."""
+        is_, ie, js, je = rng if rng else (0, self.dims.ni - 1, 0, self.dims.nj - 1)
+        check(self.lib, self.lib.mom6x_triDiagTS(self.ctx, is_, ie, js, je, _ptr(hold), _ptr(ea), _ptr(eb), _ptr(T), _ptr(S)))
+
+    def triDiagTS_Eulerian(self, hold, ent, T, S=None, rng=None):
+        """triDiagTS_Eulerian (MOM_diabatic_aux.F90:444)."""
+        is_, ie, js, je = rng if rng else (0, self.dims.ni - 1, 0, self.dims.nj - 1)
+        check(self.lib, self.lib.mom6x_triDiagTS_Eulerian(self.ctx, is_, ie, js, je, _ptr(hold), _ptr(ent), _ptr(T), _ptr(S)))
+
+    def tracer_vertdiff(self, h_old, ea, eb, dt, tr, sfc_flux=None, btm_flux=None, convert_flux=True):
+        """tracer_vertdiff (MOM_tracer_diabatic.F90:25), no-sinking branch."""
+        check(self.lib, self.lib.mom6x_tracer_vertdiff(self.ctx, _ptr(h_old), _ptr(ea), _ptr(eb), C.c_double(dt), _ptr(tr),
+                                                       _ptr(sfc_flux), _ptr(btm_flux), C.c_int(int(convert_flux))))
+
+    def tracer_vertdiff_Eulerian(self, h_old, ent, dt, tr, sfc_flux=None, btm_flux=None, convert_flux=True):
+        """tracer_vertdiff_Eulerian (MOM_tracer_diabatic.F90:224), no-sinking branch."""
+        check(self.lib, self.lib.mom6x_tracer_vertdiff_Eulerian(self.ctx, _ptr(h_old), _ptr(ent), C.c_double(dt), _ptr(tr),
+                                                                _ptr(sfc_flux), _ptr(btm_flux), C.c_int(int(convert_flux))))
+
 
 def _view(ptr, shape, device):
     """torch tensor aliasing device memory owned by the C library."""

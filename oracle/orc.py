@@ -220,3 +220,33 @@ class OrcModel:
                                           _p(taux), _p(tauy), C.c_double(dt), C.c_int(int(calc_dtbt)), arr, _p(diffu_new), _p(diffv_new))
         if rc != 0:
             raise RuntimeError(f"orc_step_dyn_split_RK2 rc={rc}")
+
+
+# ------------------------------------------------------------------------------------------
+# MOM_tracer_advect / MOM_diabatic_aux / MOM_tracer_diabatic
+def advect_tracer(d, G, GV, first_direction, dt_dyn, default_scheme, h_end, uhtr, vhtr, dt, tracers, schemes=None,
+                  useHuynhStencilBug=False, x_first_in=-1, max_iter_in=0, uhr_out=None, vhr_out=None):
+    ntr = len(tracers)
+    ptrs = (C.c_void_p * ntr)(*[t.ctypes.data for t in tracers])
+    sch = (C.c_int * ntr)(*(schemes if schemes is not None else [-1] * ntr))
+    iters = C.c_int(0)
+    rc = lib().orc_advect_tracer(C.byref(d), _p(G), C.byref(GV), C.c_int(first_direction), C.c_double(dt_dyn),
+                                 C.c_int(default_scheme), C.c_int(int(useHuynhStencilBug)), _p(h_end), _p(uhtr), _p(vhtr),
+                                 C.c_double(dt), ptrs, sch, C.c_int(ntr), C.c_int(x_first_in), C.c_int(max_iter_in),
+                                 _p(uhr_out), _p(vhr_out), C.byref(iters))
+    if rc != 0:
+        raise RuntimeError(f"orc_advect_tracer rc={rc}")
+    return iters.value
+
+
+def triDiagTS(d, hold, ea, eb, T, h_neglect):
+    assert lib().orc_triDiagTS(C.byref(d), _p(hold), _p(ea), _p(eb), _p(T), C.c_double(h_neglect)) == 0
+
+
+def triDiagTS_Eulerian(d, hold, ent, T, h_neglect):
+    assert lib().orc_triDiagTS_Eulerian(C.byref(d), _p(hold), _p(ent), _p(T), C.c_double(h_neglect)) == 0
+
+
+def tracer_vertdiff(d, G, GV, h_old, ea, eb, dt, tr, sfc_flux=None, btm_flux=None, convert_flux=True):
+    assert lib().orc_tracer_vertdiff(C.byref(d), _p(G), C.byref(GV), _p(h_old), _p(ea), _p(eb), C.c_double(dt), _p(tr),
+                                     _p(sfc_flux), _p(btm_flux), C.c_int(int(convert_flux))) == 0

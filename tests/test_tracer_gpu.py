@@ -1,0 +1,96 @@
+"""GPU parity, bit for bit: advect_tracer (PLM / PPM:H3 / PPM, x- and y-first) and the tridiagonal solvers."""
+import numpy as np
+import pytest
+
+from mom6_amd import abi, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+G = abi.G
+
+
+def transports(orc, d, M, GV, dt, scale, post=1.0):
+    """Accumulated transports uhtr, vhtr consistent with a thickness change (one continuity step), scaled up so
+    that some fluxes must be limited and several iterations are needed."""
+    CS = abi.continuity_params_default(d.nk)
+    h, u, v = synth.make_state(d, M, u_max=0.4, thin_frac=0.08)
+    hn = np.zeros_like(h); uh = np.zeros_like(h); vh = np.zeros_like(h)
+    orc.continuity_PPM(d, M, GV, CS, 0, u * scale, v * scale, h, hn, uh, vh, dt)
+    for a, s in ((hn, 0), (uh, 1), (vh, 2)):
+        orc.lib().orc_pass_var(__import__("ctypes").byref(d), a.ctypes.data_as(__import__("ctypes").c_void_p), s, d.nk)
+    # `post` > 1 exaggerates the accumulated transports so that cells would be emptied in one pass: the flux
+    # limiter (hup/hlos logic) and several iterations are exercised.
+    return hn, np.ascontiguousarray(uh * dt * post), np.ascontiguousarray(vh * dt * post)
+
+
+@pytest.mark.parametrize("cfg", ["double_gyre", "channel", "benchmark_small"])
+@pytest.mark.parametrize("schemes,first,post", [([0, 0], 0, 1.0), ([1, 1, 2], 0, 60.0), ([2, 0, 1], 1, 60.0), ([1], 1, 1.0), ([0], 0, 60.0)])
+def test_advect_tracer(orc, cfg, schemes, first, post):
+    import torch
+    from mom6_amd.dycore import Dycore
+    gg, d, M = getattr(H, cfg)()
+    GV = abi.vgrid_default()
+    dt_dyn, dt = 900.0, 3600.0
+    h_end, uhtr, vhtr = transports(orc, d, M, GV, dt, scale=3.0, post=post)
+    trs = [np.ascontiguousarray(10.0 + 5.0 * synth.smooth_field(d, 70 + m, nk=d.nk, ox=0.5, oy=0.5) * M[G["mask2dT"]][None])
+           for m in range(len(schemes))]
+    tro = [t.copy() for t in trs]
+    uhr_o = np.zeros_like(h_end); vhr_o = np.zeros_like(h_end)
+    it_o = orc.advect_tracer(d, M, GV, first, dt_dyn, 0, h_end, uhtr, vhtr, dt, tro, schemes, uhr_out=uhr_o, vhr_out=vhr_o)
+    dyc = Dycore(d, M, GV, first)
+    dyc.tracer_advect_init(dt_dyn, 0)
+    trg = [dyc.to_dev(t) for t in trs]
+    uhr_g, vhr_g = dyc.zeros3(), dyc.zeros3()
+    hd, ud, vd = dyc.to_dev(h_end), dyc.to_dev(uhtr), dyc.to_dev(vhtr)
+    torch.cuda.synchronize()
+    it_g = dyc.advect_tracer(hd, ud, vd, dt, trg, schemes, uhr_out=uhr_g, vhr_out=vhr_g)
+    dyc.sync()
+    assert it_g == it_o, (it_g, it_o)
+    if post > 1.0:
+        assert it_o >= 3, it_o      # the limiter was active: more passes than the halo cycle alone needs
+    sl = H.interior(d, "h")
+    for m in range(len(schemes)):
+        H.assert_bitwise(trg[m].cpu().numpy(), tro[m], f"tracer {m}", sl)
+        assert np.abs(tro[m] - trs[m])[(Ellipsis,) + sl].max() > 1e-6
+    H.assert_bitwise(uhr_g.cpu().numpy(), uhr_o, "uhr", H.interior(d, "u"))
+    H.assert_bitwise(vhr_g.cpu().numpy(), vhr_o, "vhr", H.interior(d, "v"))
+    dyc.close()
+
+
+@pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
+def test_tridiagonal_solvers(orc, cfg):
+    import torch
+    from mom6_amd.dycore import Dycore
+    gg, d, M = getattr(H, cfg)()
+    GV = abi.vgrid_default()
+    nk = d.nk
+    h, _, _ = synth.make_state(d, M, thin_frac=0.05)
+    ent = np.abs(synth.smooth_field(d, 81, nk=nk + 1, ox=0.5, oy=0.5)) * 5.0
+    ent[0] = 0.0; ent[nk] = 0.0
+    ent = np.ascontiguousarray(ent)
+    ea = np.ascontiguousarray(ent[:nk]); eb = np.ascontiguousarray(ent[1:])
+    T = np.ascontiguousarray(10.0 + 5.0 * synth.smooth_field(d, 82, nk=nk, ox=0.5, oy=0.5))
+    sfc = np.ascontiguousarray(1e-3 * synth.smooth_field(d, 83, ox=0.5, oy=0.5)); btm = np.ascontiguousarray(0.5 * sfc)
+    dt = 3600.0
+    o = {}
+    o["ts"] = T.copy(); orc.triDiagTS(d, h, ea, eb, o["ts"], GV.H_subroundoff)
+    o["tse"] = T.copy(); orc.triDiagTS_Eulerian(d, h, ent, o["tse"], GV.H_subroundoff)
+    o["vd"] = T.copy(); orc.tracer_vertdiff(d, M, GV, h, ea, eb, dt, o["vd"], sfc, btm, True)
+    o["vde"] = T.copy(); orc.tracer_vertdiff(d, M, GV, h, np.ascontiguousarray(ent[:nk]), np.ascontiguousarray(ent[1:]), dt, o["vde"], None, None, True)
+    dyc = Dycore(d, M, GV)
+    hd, ead, ebd, entd = dyc.to_dev(h), dyc.to_dev(ea), dyc.to_dev(eb), dyc.to_dev(ent)
+    g = {k: dyc.to_dev(T) for k in o}
+    S2 = dyc.to_dev(T)
+    sd, bd = dyc.to_dev(sfc), dyc.to_dev(btm)
+    torch.cuda.synchronize()
+    dyc.triDiagTS(hd, ead, ebd, g["ts"], S2)
+    dyc.triDiagTS_Eulerian(hd, entd, g["tse"])
+    dyc.tracer_vertdiff(hd, ead, ebd, dt, g["vd"], sd, bd, True)
+    dyc.tracer_vertdiff_Eulerian(hd, entd, dt, g["vde"])
+    dyc.sync()
+    sl = H.interior(d, "h")
+    for k in o:
+        H.assert_bitwise(g[k].cpu().numpy(), o[k], k, sl)
+    H.assert_bitwise(S2.cpu().numpy(), o["ts"], "S", sl)
+    np.testing.assert_array_equal(o["ts"], o["tse"])
+    dyc.close()
