@@ -9,9 +9,10 @@ x3, btstep x2 (each a full barotropic sub-cycle), vertvisc x2, vertvisc_remnant 
 state that already resides in HBM.  The un-ported callees (vertvisc_coef, horizontal_viscosity: SURVEY.md
 8f) are represented by coefficients frozen over the run (constant Kv, diffu = 0), stated in `config`.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_mass_flux: zonal/meridional
-mass flux + Newton flux adjustment + BT_cont fits), timed live with HIP events on the compute stream
-inside the timed region; `cpu_baseline` is the oracle (plain-C port of the reference algorithm, one
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel -- the one with the largest
+total time in the last warm-up step (k_mass_flux_lds: PPM reconstruction + zonal/meridional mass flux +
+Newton flux adjustment + BT_cont fits) -- timed live with HIP events on the compute stream inside the
+timed region; `cpu_baseline` is the oracle (plain-C port of the reference algorithm, one
 core) timed on a bounded 180x136x75 tile of the same workload and scaled by the cell count.
 """
 import argparse
@@ -83,6 +84,22 @@ def build_model(args, layout, pe, device):
     dyc.sync()
     keep = (a_u, a_v, h_u, h_v, Md)
     return dyc, d, st, taux, tauy, keep
+
+
+# 8-byte words of unavoidable HBM traffic per cell-layer and launch of the kernels that can dominate a step
+# (reads + writes of 3-D arrays; 2-D planes are noise at nk = 75).  DESIGN.md section 5 derives them.
+KERNEL_WORDS = {
+    # h, u, visc_rem in; uh out; plus u_cor (calls with uhbt) or BT_cont%h_u (the call that sets BT_cont): 5 either way
+    "k_mass_flux_lds": 5.0,
+    # thread-per-column path (MOM6X_MASSFLUX=legacy): u, visc_rem, h, (h_L, h_R from k_edge) in; uh [+ u_cor] out
+    "k_mass_flux<": 14.0 / 3.0,
+    "k_vertvisc_remnant": 3.0,   # a(k), h in; visc_rem out
+    "k_vertvisc<": 4.0,          # u, a(k), h in; u out
+    "k_bc_accel": 7.0,           # CAu, PFu, diffu in + u_bc_accel out, both directions less shared reads
+    "k_vel_update": 6.0,
+    "k_layer_accel": 5.0,
+    "k_convergence": 3.0,        # h_in, uh in; h out
+}
 
 
 def cpu_baseline(args):
@@ -170,10 +187,17 @@ def main():
             dist.barrier()
 
     step(calc_dtbt=True)                    # sets dtbt (untimed; part of warm-up)
-    for _ in range(max(args.warmup - 1, 0)):
+    for _ in range(max(args.warmup - 2, 0)):
         step()
+    # last warm-up step, with HIP events around EVERY kernel: the per-kernel breakdown, and which kernel dominates
+    dyc.lib.mom6x_prof_filter(dyc.ctx, None)
+    prof_enable(dyc, True); prof_reset(dyc)
+    step(); dyc.sync()
+    full = prof_report(dyc)
+    prof_enable(dyc, False)
+    dom_name = max(full.items(), key=lambda kv: kv[1][1])[0]
     # time EXACTLY K steps; HIP events only around the dominant kernel inside the timed region
-    dyc.lib.mom6x_prof_filter(dyc.ctx, b"k_mass_flux")
+    dyc.lib.mom6x_prof_filter(dyc.ctx, dom_name.encode())
     prof_enable(dyc, True); prof_reset(dyc)
     barrier()
     t0 = time.perf_counter()
@@ -187,30 +211,27 @@ def main():
         elapsed = float(t.item())
     dom = prof_report(dyc)
     prof_enable(dyc, False)
-    # a second, un-timed pass with events around EVERY kernel: the per-kernel breakdown
     dyc.lib.mom6x_prof_filter(dyc.ctx, None)
-    prof_enable(dyc, True); prof_reset(dyc)
-    step(); dyc.sync()
-    full = prof_report(dyc)
-    prof_enable(dyc, False)
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = (args.steps * args.dt / 86400.0) / elapsed
     N3g, N2g = args.ni * args.nj * args.nk, args.ni * args.nj
     nsub = sum(v[0] for k, v in full.items() if k == "k_bt_eta")   # barotropic sub-steps per baroclinic step (both btstep calls)
     bytes_step, per_N3 = algorithmic_bytes_per_step(N3g, N2g, nsub)
-    # dominant kernel: k_mass_flux<DIR>.  Algorithmic bytes per launch = (u + visc_rem + h + uh [+ u_cor]) of one
-    # direction = 4 words (call 1) or 5 words (calls 2, 3) per cell-layer of the LOCAL tile: 14/3 on average.
+    # dominant kernel: algorithmic bytes per launch = KERNEL_WORDS (8-byte words per cell-layer of the LOCAL tile,
+    # DESIGN.md section 5) x 8 B x N3_tile
     N3_tile = d.ni * d.nj * d.nk
     n_dom = sum(v[0] for v in dom.values()); ms_dom = sum(v[1] for v in dom.values())
     roofline = None
-    if n_dom:
+    words = next((w for pre, w in KERNEL_WORDS.items() if dom_name.startswith(pre)), None)
+    if n_dom and words is not None:
         avg_ms = ms_dom / n_dom
-        bytes_launch = (14.0 / 3.0) * 8.0 * N3_tile
+        bytes_launch = words * 8.0 * N3_tile
         ach = bytes_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_mass_flux<DIR>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                    "launches_per_step": n_dom / args.steps, "algorithmic_bytes_per_launch": bytes_launch}
+                    "launches_per_step": n_dom / args.steps, "algorithmic_bytes_per_launch": bytes_launch,
+                    "words_per_cell_layer": words}
     out = {
         "metric": "simulated-days/wall-sec", "value": value, "unit": "simulated-days/wall-sec", "n_gpus": args.gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",

@@ -13,67 +13,20 @@
 //                      the column sums are bit-identical to the Fortran loop nests)
 //   k_flux_thickness<DIR>  zonal/merid_flux_thickness                 (3-D)
 //   k_convergence<DIR> continuity_zonal/merdional_convergence         (3-D)
-#include "mom6x_dev.h"
+#include "continuity_dev.h"
+#include "continuity_lds.h"
+#include <cstdlib>
 
 namespace {
 
-struct DirMetrics {
-  const double *Lface, *IdT, *dT, *dC, *maskC, *IareaT, *mask2dT;
-};
-
-template <int DIR>
-__device__ __forceinline__ DirMetrics dir_metrics(const double *G, const Dm &d) {
-  DirMetrics D;
-  D.Lface = gm(G, d, DIR ? MOM6X_G_dx_Cv : MOM6X_G_dy_Cu);
-  D.IdT = gm(G, d, DIR ? MOM6X_G_IdyT : MOM6X_G_IdxT);
-  D.dT = gm(G, d, DIR ? MOM6X_G_dyT : MOM6X_G_dxT);
-  D.dC = gm(G, d, DIR ? MOM6X_G_dyCv : MOM6X_G_dxCu);
-  D.maskC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu);
-  D.IareaT = gm(G, d, MOM6X_G_IareaT);
-  D.mask2dT = gm(G, d, MOM6X_G_mask2dT);
-  return D;
+// MOM6X_MASSFLUX=legacy selects the thread-per-column kernels (k_edge, k_mass_flux, k_flux_thickness) instead
+// of the LDS-resident kernel of continuity_lds.hip; both give bit-identical results (tests run both).
+bool use_lds_path(int nk) {
+  const char *e = getenv("MOM6X_MASSFLUX");
+  if (e && !strcmp(e, "legacy")) return false;
+  return mass_flux_lds_usable(nk);
 }
 
-// PPM_limit_pos :2578-2616
-__device__ __forceinline__ void ppm_limit_pos(double h_in, double &h_L, double &h_R, double h_min) {
-  const double curv = 3.0 * ((h_L + h_R) - 2.0 * h_in);
-  if (curv > 0.0) {
-    const double dh = h_R - h_L;
-    if (fabs(dh) < curv) {
-      if (h_in <= h_min) {
-        h_L = h_in; h_R = h_in;
-      } else if (12.0 * curv * (h_in - h_min) < (curv * curv + 3.0 * (dh * dh))) {
-        const double scale = 12.0 * curv * (h_in - h_min) / (curv * curv + 3.0 * (dh * dh));
-        h_L = h_in + scale * (h_L - h_in);
-        h_R = h_in + scale * (h_R - h_in);
-      }
-    }
-  }
-}
-
-// PPM_limit_CW84 :2620-2657
-__device__ __forceinline__ void ppm_limit_cw84(double h_i, double &h_L, double &h_R) {
-  if ((h_R - h_i) * (h_i - h_L) <= 0.0) {
-    h_L = h_i; h_R = h_i;
-  } else {
-    const double RLdiff = h_R - h_L;
-    const double RLmean = 0.5 * (h_R + h_L);
-    const double FunFac = 6.0 * RLdiff * (h_i - RLmean);
-    const double RLdiff2 = RLdiff * RLdiff;
-    if (FunFac > RLdiff2) h_L = 3.0 * h_i - 2.0 * h_R;
-    if (FunFac < -RLdiff2) h_R = 3.0 * h_i - 2.0 * h_L;
-  }
-}
-
-// Lin (1994) B2 limited slope at cell c (:2368-2378)
-__device__ __forceinline__ double ppm_slope(const double *h, const double *m, size_t c, int st) {
-  const double hm = h[c - st], h0 = h[c], hp = h[c + st];
-  if ((m[c - st] * m[c] * m[c + st]) == 0.0) return 0.0;
-  const double s = 0.5 * (hp - hm);
-  const double dMx = dmax(dmax(hp, hm), h0) - h0;
-  const double dMn = h0 - dmin(dmin(hp, hm), h0);
-  return dsign(1.0, s) * dmin(fabs(s), 2.0 * dmin(dMx, dMn));
-}
 
 // PPM_reconstruction_x :2307 / _y :2442 over cells (i0..i1, j0..j1) of every layer.
 template <int DIR>
@@ -114,33 +67,6 @@ k_edge(Dm d, const double *__restrict__ G, const double *__restrict__ h_in, doub
   if (monotonic) ppm_limit_cw84(h0, hl, hr);
   else ppm_limit_pos(h0, hl, hr, h_min);
   h_L[c] = hl; h_R[c] = hr;
-}
-
-// zonal_flux_layer :896 / merid_flux_layer :1787 for one face of one layer.
-// f = flat 3-D index of the face (= its minus cell), f2 = its 2-D index.
-__device__ __forceinline__ void flux_layer(const DirMetrics &D, int st, size_t f, size_t f2, double u,
-                                           const double *__restrict__ h, const double *__restrict__ hL,
-                                           const double *__restrict__ hR, double dt, double visc_rem,
-                                           double Lf, double &uh, double &duhdu) {
-  double h_marg;
-  if (u > 0.0) {
-    const double CFL = u * dt * D.IdT[f2];
-    const double l = hL[f], r = hR[f];
-    const double curv_3 = (l + r) - 2.0 * h[f];
-    uh = Lf * u * (r + CFL * (0.5 * (l - r) + curv_3 * (CFL - 1.5)));
-    h_marg = r + CFL * ((l - r) + 3.0 * curv_3 * (CFL - 1.0));
-  } else if (u < 0.0) {
-    const size_t p = f + st;
-    const double CFL = -u * dt * D.IdT[f2 + st];
-    const double l = hL[p], r = hR[p];
-    const double curv_3 = (l + r) - 2.0 * h[p];
-    uh = Lf * u * (l + CFL * (0.5 * (r - l) + curv_3 * (CFL - 1.5)));
-    h_marg = l + CFL * ((r - l) + 3.0 * curv_3 * (CFL - 1.0));
-  } else {
-    uh = 0.0;
-    h_marg = 0.5 * (hL[f + st] + hR[f]);
-  }
-  duhdu = Lf * h_marg * visc_rem;
 }
 
 struct ColIn {   // everything a face column needs
@@ -219,21 +145,6 @@ __device__ double flux_adjust(const DirMetrics &D, int st, const ColIn &C, size_
   }
   return du;
 }
-
-struct FluxArgs {
-  const double *u, *h_in, *hL, *hR;
-  double *uh;
-  const double *uhbt;        // 2-D or null
-  const double *visc_rem;    // 3-D or null
-  double *u_cor;             // 3-D or null
-  double *du_cor;            // 2-D or null
-  // BT_cont planes for this direction ("m" = from the minus side: W|S, "p" = plus side: E|N)
-  double *FA_m0, *FA_mm, *uBT_mm, *FA_p0, *FA_pp, *uBT_pp;
-  int set_BT_cont;
-  double dt, CFL_limit_adjust, tol_eta, tol_vel;
-  int better_iter, use_visc_rem_max;
-  int a0, a1, b0, b1;        // face index ranges (i-range, j-range)
-};
 
 // zonal_mass_flux :519-819 / meridional_mass_flux :1412-1711: one thread per face column.
 template <int DIR>
@@ -415,8 +326,10 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
   int ei0 = ish, ei1 = ieh, ej0 = jsh, ej1 = jeh;
   if (DIR == 0) { ei0 = ish - 1; ei1 = ieh + 1; } else { ej0 = jsh - 1; ej1 = jeh + 1; }
   const int scheme = P.upwind_1st ? 2 : (P.simple_2nd ? 1 : 0);
-  KLAUNCH(c, "k_edge<DIR>", k_edge<DIR>, grid3(ei1 - ei0 + 1, ej1 - ej0 + 1, d.nk, blk), blk, d, c->G, h_src,
-                     c->hL, c->hR, 2.0 * c->GV.Angstrom_H, scheme, P.monotonic, ei0, ei1, ej0, ej1);
+  const bool lds = use_lds_path(d.nk);
+  if (!lds)
+    KLAUNCH(c, "k_edge<DIR>", k_edge<DIR>, grid3(ei1 - ei0 + 1, ej1 - ej0 + 1, d.nk, blk), blk, d, c->G, h_src,
+                       c->hL, c->hR, 2.0 * c->GV.Angstrom_H, scheme, P.monotonic, ei0, ei1, ej0, ej1);
   FluxArgs A;
   memset(&A, 0, sizeof(A));
   A.u = u; A.h_in = h_src; A.hL = c->hL; A.hR = c->hR; A.uh = uh; A.uhbt = uhbt; A.visc_rem = visc_rem;
@@ -432,12 +345,20 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
   if (DIR == 0) { A.a0 = ish - 1; A.a1 = ieh; A.b0 = jsh; A.b1 = jeh; }
   else          { A.a0 = ish; A.a1 = ieh; A.b0 = jsh - 1; A.b1 = jeh; }
   if (du_cor) HIPCHK(hipMemsetAsync(du_cor, 0, sizeof(double) * d.slab, c->stream));
-  KLAUNCH(c, "k_mass_flux<DIR>", k_mass_flux<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, 1, blk), blk, d, c->G, A);
   double *BT_h = BT ? (DIR == 0 ? BT->h_u : BT->h_v) : nullptr;
-  if (BT_h) {
-    KLAUNCH(c, "k_flux_thickness<DIR>", k_flux_thickness<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, d.nk, blk), blk,
-                       d, c->G, (u_cor ? (const double *)u_cor : u), h_src, c->hL, c->hR, BT_h, dt,
-                       P.marginal_faces, visc_rem, A.a0, A.a1, A.b0, A.b1);
+  if (lds) {
+    LdsArgs E;
+    E.h_min = 2.0 * c->GV.Angstrom_H; E.scheme = scheme; E.monotonic = P.monotonic;
+    E.marginal = P.marginal_faces; E.h_face = BT_h;
+    const int rc = mass_flux_lds(c, DIR, A, E);
+    if (rc) return rc;
+  } else {
+    KLAUNCH(c, "k_mass_flux<DIR>", k_mass_flux<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, 1, blk), blk, d, c->G, A);
+    if (BT_h) {
+      KLAUNCH(c, "k_flux_thickness<DIR>", k_flux_thickness<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, d.nk, blk), blk,
+                         d, c->G, (u_cor ? (const double *)u_cor : u), h_src, c->hL, c->hR, BT_h, dt,
+                         P.marginal_faces, visc_rem, A.a0, A.a1, A.b0, A.b1);
+    }
   }
   KLAUNCH(c, "k_convergence<DIR>", k_convergence<DIR>, grid3(ieh - ish + 1, jeh - jsh + 1, d.nk, blk), blk, d, c->G,
                      h, uh, dt, hin_conv, h_min_conv, ish, ieh, jsh, jeh);

@@ -1,0 +1,15 @@
+// continuity_lds.h -- host interface of the LDS-resident mass-flux kernel (continuity_lds.hip).
+#pragma once
+#include "continuity_dev.h"
+
+struct LdsArgs {
+  double h_min;        // 2*Angstrom_H, the positive-definiteness floor of PPM_limit_pos
+  int scheme;          // 0 PPM, 1 simple_2nd, 2 upwind_1st
+  int monotonic;       // PPM_limit_CW84 instead of PPM_limit_pos
+  int marginal;        // BT_cont%h_u from the marginal (not the average) face thickness
+  double *h_face;      // BT_cont%h_u | h_v (3-D) or null
+};
+
+size_t mass_flux_lds_bytes(int dir, int nk);
+bool mass_flux_lds_usable(int nk);
+int mass_flux_lds(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E);

@@ -1,0 +1,609 @@
+// continuity_lds.hip -- the mass-flux half of continuity_PPM as ONE LDS-resident kernel per direction.
+//
+// Replaces, for a tile of NF face columns, the sequence k_edge -> k_mass_flux -> k_flux_thickness of
+// continuity.hip (PPM_reconstruction_x/y :2307/:2442, zonal/meridional_mass_flux :519/:1412 with
+// zonal/meridional_flux_adjust :1093/:1992 and set_zonal/merid_BT_cont :1246/:2143,
+// zonal/merid_flux_thickness :975/:1866 of MOM_continuity_PPM.F90).
+//
+// Why: the Newton iteration of flux_adjust re-reads every layer of a face column up to 20 times (and
+// set_*_BT_cont sweeps it another ~8 times).  The thread-per-column kernel did those re-reads through
+// L2/HBM.  Here a work-group of NF(16 faces along i) x KL(16 layer lanes) threads
+//   * reconstructs the PPM edge values of the cells it needs straight from h (all global loads of a lane
+//     are issued back to back) and parks (h_L, h_R, curvature) of all nk layers in LDS
+//     (<= 77 KB at nk = 75; 160 KB per CU on gfx950),
+//   * keeps u and visc_rem of its own layers in registers,
+//   * evaluates the layer fluxes with all 256 lanes, and lets 16 "face lanes" of ONE wavefront do the
+//     column sums and recurrences SEQUENTIALLY in k -- the reference's order, so the result is
+//     bit-identical to the Fortran loop nest (and to the thread-per-column kernel).  Everything that
+//     does not carry a k-dependence (the divisions of the CFL / duL / duR recurrences, visc_rem_max)
+//     is computed by all lanes first, so the sequential walks are a few instructions per layer,
+//   * runs the Newton loop work-group-uniformly: a face whose do_I is false is frozen exactly as in the
+//     reference's row-wide loop,
+//   * writes uh, u_cor, du_cor, the BT_cont fits and h_u/h_v once.
+// HBM traffic per face-layer: read h (+halo re-reads from L2), u, visc_rem; write uh, u_cor, h_u.
+#include "continuity_dev.h"
+#include "continuity_lds.h"
+
+namespace {
+
+constexpr int NF = 16;        // faces along i per work-group (the coalesced axis)
+constexpr int KL = 16;        // layer lanes per face
+constexpr int NT = NF * KL;   // 256 threads = 4 wavefronts
+
+// zonal_flux_layer :896 / merid_flux_layer :1787 with the cell data in LDS.
+// m / p: LDS slots of the minus / plus cell of the face.
+__device__ __forceinline__ void flux_lds(double u, double dt, double IdT_m, double IdT_p, double vrem, double Lf,
+                                         const double *sL, const double *sR, const double *sC, int m, int p,
+                                         double &uh, double &duhdu) {
+  // The two upwind branches of the reference are mirror images: with a = the edge value on the face side
+  // of the upwind cell and b = the far one, both read  a + CFL*(0.5*(b-a) + curv_3*(CFL-1.5)).  Selecting
+  // the operands instead of branching keeps a wavefront with mixed flow directions from running both.
+  double h_marg;
+  if (u != 0.0) {
+    const bool pos = (u > 0.0);
+    const int c = pos ? m : p;
+    const double l = sL[c], r = sR[c], curv_3 = sC[c];
+    const double a = pos ? r : l, b = pos ? l : r;
+    const double CFL = (pos ? u : -u) * dt * (pos ? IdT_m : IdT_p);
+    uh = Lf * u * (a + CFL * (0.5 * (b - a) + curv_3 * (CFL - 1.5)));
+    h_marg = a + CFL * ((b - a) + 3.0 * curv_3 * (CFL - 1.0));
+  } else {
+    uh = 0.0;
+    h_marg = 0.5 * (sL[p] + sR[m]);
+  }
+  duhdu = Lf * h_marg * vrem;
+}
+
+// Lin (1994) B2 limited slope (:2368-2378) from registers; mprod = product of the three masks.
+__device__ __forceinline__ double slope3(double hm, double h0, double hp, double mprod) {
+  if (mprod == 0.0) return 0.0;
+  const double s = 0.5 * (hp - hm);
+  const double dMx = dmax(dmax(hp, hm), h0) - h0;
+  const double dMn = h0 - dmin(dmin(hp, hm), h0);
+  return dsign(1.0, s) * dmin(fabs(s), 2.0 * dmin(dMx, dMn));
+}
+
+// PPM_reconstruction_x/y + limiter for one cell from its 5-point stencil hh[0..4] (cell = hh[2]).
+__device__ __forceinline__ void edge5(const double *hh, const double *mm, int scheme, int monotonic, double h_min,
+                                      double &hl, double &hr, double &c3) {
+  const double h0 = hh[2];
+  if (scheme == 2) {
+    hl = h0; hr = h0;
+  } else {
+    const double h_im1 = mm[1] * hh[1] + (1.0 - mm[1]) * h0;
+    const double h_ip1 = mm[3] * hh[3] + (1.0 - mm[3]) * h0;
+    if (scheme == 1) {
+      hl = 0.5 * (h_im1 + h0);
+      hr = 0.5 * (h_ip1 + h0);
+    } else {
+      const double oneSixth = 1.0 / 6.0;
+      const double sm = slope3(hh[0], hh[1], hh[2], mm[0] * mm[1] * mm[2]);
+      const double s0 = slope3(hh[1], hh[2], hh[3], mm[1] * mm[2] * mm[3]);
+      const double sp = slope3(hh[2], hh[3], hh[4], mm[2] * mm[3] * mm[4]);
+      hl = 0.5 * (h_im1 + h0) + oneSixth * (sm - s0);
+      hr = 0.5 * (h_ip1 + h0) + oneSixth * (s0 - sp);
+    }
+    if (monotonic) ppm_limit_cw84(h0, hl, hr);
+    else ppm_limit_pos(h0, hl, hr, h_min);
+  }
+  c3 = (hl + hr) - 2.0 * h0;
+}
+
+// ---- sequential walks of one face column through the LDS transit arrays -----------------------------
+// The loads of a batch are independent and issued together; the caller's recurrence then runs on
+// registers, so the LDS latency is paid once per batch instead of once per layer.
+template <int U, typename F>
+__device__ __forceinline__ void batch2(const double *a, const double *b, int k0, F &f) {
+  double x[U], y[U];
+#pragma unroll
+  for (int q = 0; q < U; q++) { x[q] = a[(k0 + q) * NF]; y[q] = b[(k0 + q) * NF]; }
+#pragma unroll
+  for (int q = 0; q < U; q++) f(x[q], y[q]);
+}
+template <typename F>
+__device__ __forceinline__ void col_walk2(const double *a, const double *b, int n, F f) {   // a, b already offset by fl
+  int k = 0;
+  for (; k + 16 <= n; k += 16) batch2<16>(a, b, k, f);
+  for (; k + 4 <= n; k += 4) batch2<4>(a, b, k, f);
+  for (; k < n; k++) batch2<1>(a, b, k, f);
+}
+template <int U, typename F>
+__device__ __forceinline__ void batch4(const double *a, int str, int k0, F &f) {
+  double x[U], y[U], z[U], w[U];
+#pragma unroll
+  for (int q = 0; q < U; q++) {
+    const double *p = a + (k0 + q) * NF;
+    x[q] = p[0]; y[q] = p[str]; z[q] = p[2 * str]; w[q] = p[3 * str];
+  }
+#pragma unroll
+  for (int q = 0; q < U; q++) f(x[q], y[q], z[q], w[q]);
+}
+template <typename F>
+__device__ __forceinline__ void col_walk4(const double *a, int str, int n, F f) {   // 4 arrays, `str` apart
+  int k = 0;
+  for (; k + 8 <= n; k += 8) batch4<8>(a, str, k, f);
+  for (; k + 2 <= n; k += 2) batch4<2>(a, str, k, f);
+  for (; k < n; k++) batch4<1>(a, str, k, f);
+}
+
+struct Tile {   // what every lane knows about its face and the LDS arrays
+  const double *sL, *sR, *sC;
+  double *sA, *sB;
+  double *s_du; int *s_doI;
+  int fl, kl, nk, NC, cm, cp;   // cm/cp: cell slots (within one layer) of the minus / plus cell
+  bool lead;                    // this lane is the face lane of column fl (whether or not the face is active)
+  double dt, IdT_m, IdT_p, Lf;
+};
+
+// A k-recurrence whose per-layer operands (4 of them) are produced by all lanes and consumed in k order
+// by the face lane.  The 4 x [nk] operands go through the sA|sB space in two halves of KH = ceil(nk/2).
+// Every lane of the work-group must call this.
+template <int MAXL, typename P, typename S>
+__device__ __forceinline__ void recurrence4(const Tile &T, bool face, P produce, S step) {
+  const int KH = (T.nk + 1) >> 1, str = KH * NF;
+  double *t = T.sA;   // sA and sB are contiguous: 2 * nkp * NF >= 4 * KH * NF
+  for (int c = 0; c < 2; c++) {
+    const int k_lo = c * KH, k_hi = (k_lo + KH < T.nk) ? k_lo + KH : T.nk;
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = T.kl + KL * n;
+      if (k >= k_lo && k < k_hi) {
+        double o[4];
+        produce(n, o);
+        double *p = t + (k - k_lo) * NF + T.fl;
+        p[0] = o[0]; p[str] = o[1]; p[2 * str] = o[2]; p[3 * str] = o[3];
+      }
+    }
+    __syncthreads();
+    if (face) col_walk4(t + T.fl, str, k_hi - k_lo, step);
+    __syncthreads();
+  }
+}
+
+// zonal_flux_adjust :1093-1242 / meridional_flux_adjust :1992-2140, iterated work-group-uniformly.
+// Every lane of the work-group must call this.  Face lanes (face == true) carry the Newton state; all
+// lanes re-evaluate the layer fluxes of the faces that are still iterating.  With store == true the
+// last evaluated transports stay in sA (the uh_3d argument of the reference).
+template <int MAXL>
+__device__ __forceinline__ double wg_flux_adjust(const Tile &T, bool face, const double (&u_r)[MAXL],
+                                                 const double (&v_r)[MAXL], double IareaMin, double uhbt,
+                                                 double uh_tot_0, double duhdu_tot_0, double du_max,
+                                                 double du_min, double tol_eta_cs, double tol_vel,
+                                                 int better_iter, bool store) {
+  const int max_itts = 20;
+  double du = 0.0;
+  double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0;
+  double uh_err_best = fabs(uh_err);
+  bool do_I = face;
+  for (int itt = 1; itt <= max_itts; itt++) {
+    if (do_I) {
+      double tol_eta;
+      if (itt <= 1) tol_eta = 1e-6 * tol_eta_cs;
+      else if (itt == 2) tol_eta = 1e-4 * tol_eta_cs;
+      else if (itt == 3) tol_eta = 1e-2 * tol_eta_cs;
+      else tol_eta = tol_eta_cs;
+
+      if (uh_err > 0.0) du_max = du;
+      else if (uh_err < 0.0) du_min = du;
+      else do_I = false;
+
+      if (do_I) {
+        if ((T.dt * IareaMin * fabs(uh_err) > tol_eta) ||
+            (better_iter && ((fabs(uh_err) > tol_vel * duhdu_tot) || (fabs(uh_err) > uh_err_best)))) {
+          const double ddu = -uh_err / duhdu_tot;
+          const double du_prev = du;
+          du = du + ddu;
+          if (fabs(ddu) < 1.0e-15 * fabs(du)) {
+            do_I = false;
+          } else if (ddu > 0.0) {
+            if (du >= du_max) {
+              du = 0.5 * (du_prev + du_max);
+              if (du_max - du_prev < 1.0e-15 * fabs(du)) do_I = false;
+            }
+          } else {
+            if (du <= du_min) {
+              du = 0.5 * (du_prev + du_min);
+              if (du_prev - du_min < 1.0e-15 * fabs(du)) do_I = false;
+            }
+          }
+        } else {
+          do_I = false;
+        }
+      }
+    }
+    if (T.lead) { T.s_du[T.fl] = du; T.s_doI[T.fl] = do_I ? 1 : 0; }
+    if (!__syncthreads_or(do_I ? 1 : 0)) break;
+
+    if ((itt < max_itts) || store) {
+      if (T.s_doI[T.fl]) {
+        const double dul = T.s_du[T.fl];
+#pragma unroll
+        for (int n = 0; n < MAXL; n++) {
+          const int k = T.kl + KL * n;
+          if (k < T.nk) {
+            double uh, duhdu;
+            flux_lds(u_r[n] + dul * v_r[n], T.dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, T.sL, T.sR, T.sC,
+                     k * T.NC + T.cm, k * T.NC + T.cp, uh, duhdu);
+            T.sA[k * NF + T.fl] = uh; T.sB[k * NF + T.fl] = duhdu;
+          }
+        }
+      }
+      __syncthreads();
+      if ((itt < max_itts) && do_I) {
+        double err = -uhbt, dtot = 0.0;
+        col_walk2(T.sA + T.fl, T.sB + T.fl, T.nk, [&](double a, double b) { err = err + a; dtot = dtot + b; });
+        uh_err = err; duhdu_tot = dtot;
+        uh_err_best = dmin(uh_err_best, fabs(uh_err));
+      }
+    }
+  }
+  return du;
+}
+
+template <int DIR, int MAXL>
+__global__ void __launch_bounds__(NT, MAXL > 5 ? 1 : (DIR ? 2 : 3))   // LDS lets 3 (x) | 2 (y) work-groups share a CU at nk = 75
+k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
+  extern __shared__ double smem[];
+  constexpr int NC = DIR ? 2 * NF : NF + 1;
+  const int nk = d.nk, nkp = (nk + 1) & ~1;
+  double *sL = smem, *sR = sL + nk * NC, *sC = sR + nk * NC, *sA = sC + nk * NC, *sB = sA + nkp * NF;
+  __shared__ double s_du[NF], s_duL[NF], s_duR[NF], s_red[KL][NF];
+  __shared__ int s_doI[NF];
+
+  const int tid = threadIdx.x, fl = tid % NF, kl = tid / NF;
+  // the wavefront that carries the sequential walks rotates with the tile so that the walks of the
+  // work-groups sharing a CU do not all queue on the same SIMD
+  const int kl_face = ((blockIdx.x + blockIdx.y) & 3) * (KL / 4);
+  const int i0 = A.a0 + blockIdx.x * NF, j = A.b0 + blockIdx.y;
+  const int i = i0 + fl;
+  const bool active = (i <= A.a1);
+  const bool lead = (kl == kl_face);
+  const bool face = active && lead;
+  const int st = DIR ? d.pitch : 1;
+  const size_t slab = (size_t)d.slab;
+  const DirMetrics D = dir_metrics<DIR>(G, d);
+  const size_t f2 = ix2(d, active ? i : A.a1, j);   // inactive lanes alias the last face (never written)
+  const double dt = A.dt;
+  const bool use_visc_rem = (A.visc_rem != nullptr);
+  const bool need_adjust = (A.uhbt != nullptr) || A.set_BT_cont;
+
+  // ---- this lane's layers of u and visc_rem stay in registers ---------------------------------------
+  double u_r[MAXL], v_r[MAXL];
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) {
+    const int k = kl + KL * n;
+    u_r[n] = 0.0; v_r[n] = 1.0;
+    if (active && k < nk) {
+      const size_t f = f2 + (size_t)k * slab;
+      u_r[n] = A.u[f];
+      if (use_visc_rem) v_r[n] = A.visc_rem[f];
+    }
+  }
+
+  // ---- PPM_reconstruction + limiter for the cells of this tile, all layers, into LDS ---------------
+  if (DIR == 0) {
+    // the 21 h values a layer of the tile needs (cells i0-2 .. i0+NF+2) are staged through the sA|sB space
+    constexpr int NR = NF + 5;
+    const double *m = D.mask2dT;
+    const int g1 = i0 - 2 + fl, g2 = i0 + NF - 2 + fl;
+    const bool ok1 = (g1 <= A.a1 + 3), ok2 = (fl < 5) && (g2 <= A.a1 + 3);
+    const size_t c1 = ix2(d, ok1 ? g1 : A.a1, j), c2 = ix2(d, ok2 ? g2 : A.a1, j);
+    double r1[MAXL], r2[MAXL];
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = kl + KL * n;
+      r1[n] = 0.0; r2[n] = 0.0;
+      if (k < nk) {
+        const double *h = A.h_in + (size_t)k * slab;
+        if (ok1) r1[n] = h[c1];
+        if (ok2) r2[n] = h[c2];
+      }
+    }
+    double mm[5], mx[5];   // masks of this lane's cell (i0+fl) and of the extra cell (i0+NF)
+    const bool cell_ok = (i0 + fl <= A.a1 + 1), extra_ok = (fl < MAXL) && (i0 + NF <= A.a1 + 1);
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      mm[q] = cell_ok ? m[ix2(d, i0 + fl - 2 + q, j)] : 0.0;
+      mx[q] = extra_ok ? m[ix2(d, i0 + NF - 2 + q, j)] : 0.0;
+    }
+    double *raw = sA;
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = kl + KL * n;
+      if (k < nk) {
+        raw[k * NR + fl] = r1[n];
+        if (fl < 5) raw[k * NR + NF + fl] = r2[n];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = kl + KL * n;
+      if (k < nk) {
+        double hh[5], hl = 0.0, hr = 0.0, c3 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) hh[q] = raw[k * NR + fl + q];
+        if (cell_ok) edge5(hh, mm, E.scheme, E.monotonic, E.h_min, hl, hr, c3);
+        sL[k * NC + fl] = hl; sR[k * NC + fl] = hr; sC[k * NC + fl] = c3;
+        if (fl == n) {   // the 17th cell of layer k is done by lane n of the layer's 16 lanes
+          hl = 0.0; hr = 0.0; c3 = 0.0;
+#pragma unroll
+          for (int q = 0; q < 5; q++) hh[q] = raw[k * NR + NF + q];
+          if (extra_ok) edge5(hh, mx, E.scheme, E.monotonic, E.h_min, hl, hr, c3);
+          sL[k * NC + NF] = hl; sR[k * NC + NF] = hr; sC[k * NC + NF] = c3;
+        }
+      }
+    }
+  } else {
+    // rows j-2 .. j+3 of column i: the 5-point stencils of the cells (i,j) and (i,j+1) share 4 of them
+    const double *m = D.mask2dT;
+    const size_t cc = ix2(d, active ? i : A.a1, j);
+    double m6[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) m6[q] = active ? m[cc + (size_t)(q - 2) * st] : 0.0;
+    double h6[MAXL][6];
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = kl + KL * n;
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        h6[n][q] = 0.0;
+        if (active && k < nk) h6[n][q] = A.h_in[(size_t)k * slab + cc + (size_t)(q - 2) * st];
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = kl + KL * n;
+      if (k < nk) {
+        double hl = 0.0, hr = 0.0, c3 = 0.0;
+        if (active) edge5(&h6[n][0], &m6[0], E.scheme, E.monotonic, E.h_min, hl, hr, c3);
+        sL[k * NC + fl] = hl; sR[k * NC + fl] = hr; sC[k * NC + fl] = c3;
+        hl = 0.0; hr = 0.0; c3 = 0.0;
+        if (active) edge5(&h6[n][1], &m6[1], E.scheme, E.monotonic, E.h_min, hl, hr, c3);
+        sL[k * NC + NF + fl] = hl; sR[k * NC + NF + fl] = hr; sC[k * NC + NF + fl] = c3;
+      }
+    }
+  }
+  __syncthreads();   // cell arrays complete; the sA|sB space is free again
+
+  Tile T;
+  T.sL = sL; T.sR = sR; T.sC = sC; T.sA = sA; T.sB = sB; T.s_du = s_du; T.s_doI = s_doI;
+  T.fl = fl; T.kl = kl; T.nk = nk; T.NC = NC; T.cm = fl; T.cp = DIR ? NF + fl : fl + 1; T.lead = lead;
+  T.dt = dt; T.IdT_m = D.IdT[f2]; T.IdT_p = D.IdT[f2 + st];
+  T.Lf = D.Lface[f2] * 1.0;   // G%dy_Cu * por_face_areaU (== 1)
+
+  // ---- limits on du that keep the CFL number between -1 and 1 (:646-723) ----------------------------
+  double visc_rem_max = 1.0, du_max_CFL = 0.0, du_min_CFL = 0.0;
+  if (need_adjust) {
+    if (use_visc_rem && A.use_visc_rem_max) {   // max is order-independent: reduce over the layer lanes
+      double pm = 0.0;
+#pragma unroll
+      for (int n = 0; n < MAXL; n++)
+        if (kl + KL * n < nk) pm = dmax(pm, v_r[n]);
+      s_red[kl][fl] = pm;
+      __syncthreads();
+      visc_rem_max = 0.0;
+#pragma unroll
+      for (int q = 0; q < KL; q++) visc_rem_max = dmax(visc_rem_max, s_red[q][fl]);
+    }
+    const double CFL_dt = A.CFL_limit_adjust / dt;
+    const double dx_W = D.dT[f2], dx_E = D.dT[f2 + st];
+    double I_vrm = 0.0;
+    if (visc_rem_max > 0.0) I_vrm = 1.0 / visc_rem_max;
+    du_max_CFL = 2.0 * (CFL_dt * dx_W) * I_vrm;
+    du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
+    const double maskC = D.maskC[f2];
+    if (use_visc_rem) {
+      recurrence4<MAXL>(T, face,
+        [&](int n, double *o) {
+          o[0] = u_r[n]; o[1] = v_r[n];
+          o[2] = (dx_W * CFL_dt - u_r[n]) / v_r[n];
+          o[3] = -(dx_E * CFL_dt + u_r[n]) / v_r[n];
+        },
+        [&](double uk, double vrem, double q_max, double q_min) {
+          if (du_max_CFL * vrem > dx_W * CFL_dt - uk * maskC) du_max_CFL = q_max;
+          if (du_min_CFL * vrem < -dx_E * CFL_dt - uk * maskC) du_min_CFL = q_min;
+        });
+    } else {
+      recurrence4<MAXL>(T, face,
+        [&](int n, double *o) { o[0] = u_r[n]; o[1] = 0.0; o[2] = 0.0; o[3] = 0.0; },
+        [&](double uk, double, double, double) {
+          du_max_CFL = dmin(du_max_CFL, dx_W * CFL_dt - uk);
+          du_min_CFL = dmax(du_min_CFL, -(dx_E * CFL_dt + uk));
+        });
+    }
+    du_max_CFL = dmax(du_max_CFL, 0.0);
+    du_min_CFL = dmin(du_min_CFL, 0.0);
+  }
+
+  // ---- first sweep: layer transports and their column sums (:615-668) -------------------------------
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) {
+    const int k = kl + KL * n;
+    if (k < nk) {
+      double uh, duhdu;
+      flux_lds(u_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh, duhdu);
+      sA[k * NF + fl] = uh; sB[k * NF + fl] = duhdu;
+    }
+  }
+  double uh_tot_0 = 0.0, duhdu_tot_0 = 0.0;
+  if (need_adjust) {
+    __syncthreads();
+    if (face)
+      col_walk2(sA + fl, sB + fl, nk, [&](double a, double b) { duhdu_tot_0 = duhdu_tot_0 + b; uh_tot_0 = uh_tot_0 + a; });
+  }
+
+  // ---- flux_adjust towards uhbt; uh, u_cor, du_cor ---------------------------------------------------
+  const double IareaMin = dmin(D.IareaT[f2], D.IareaT[f2 + st]);
+  double du_fin = 0.0;
+  const bool corrected = (A.uhbt != nullptr);
+  if (corrected) {
+    const double uhbt = face ? A.uhbt[f2] : 0.0;
+    const double du = wg_flux_adjust<MAXL>(T, face, u_r, v_r, IareaMin, uhbt, uh_tot_0, duhdu_tot_0, du_max_CFL,
+                                           du_min_CFL, A.tol_eta, A.tol_vel, A.better_iter, true);
+    if (face && A.du_cor) A.du_cor[f2] = du;
+    du_fin = s_du[fl];   // published by the face lane before the last barrier of the loop
+  }
+  if (active) {
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = kl + KL * n;
+      if (k < nk) {
+        const size_t f = f2 + (size_t)k * slab;
+        A.uh[f] = sA[k * NF + fl];
+        if (corrected && A.u_cor) A.u_cor[f] = u_r[n] + du_fin * v_r[n];
+      }
+    }
+  }
+
+  // ---- zonal/merid_flux_thickness (:975 / :1866) at the corrected velocities ------------------------
+  if (E.h_face && active) {
+    const bool use_cor = corrected && (A.u_cor != nullptr);
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = kl + KL * n;
+      if (k < nk) {
+        const double uf = use_cor ? (u_r[n] + du_fin * v_r[n]) : u_r[n];
+        const int m = k * NC + T.cm, p = k * NC + T.cp;
+        double h_avg, h_marg;
+        if (uf > 0.0) {
+          const double CFL = uf * dt * T.IdT_m;
+          const double l = sL[m], r = sR[m], curv_3 = sC[m];
+          h_avg = r + CFL * (0.5 * (l - r) + curv_3 * (CFL - 1.5));
+          h_marg = r + CFL * ((l - r) + 3.0 * curv_3 * (CFL - 1.0));
+        } else if (uf < 0.0) {
+          const double CFL = -uf * dt * T.IdT_p;
+          const double l = sL[p], r = sR[p], curv_3 = sC[p];
+          h_avg = l + CFL * (0.5 * (r - l) + curv_3 * (CFL - 1.5));
+          h_marg = l + CFL * ((r - l) + 3.0 * curv_3 * (CFL - 1.0));
+        } else {
+          h_avg = 0.5 * (sL[p] + sR[m]);
+          h_marg = 0.5 * (sL[p] + sR[m]);
+        }
+        double hu = E.marginal ? h_marg : h_avg;
+        if (use_visc_rem) hu = hu * (v_r[n] * 1.0);
+        else hu = hu * 1.0;
+        E.h_face[f2 + (size_t)k * slab] = hu;
+      }
+    }
+  }
+  if (!A.set_BT_cont) return;
+
+  // ---- set_zonal_BT_cont :1246-1409 / set_merid_BT_cont :2143-2304 -----------------------------------
+  __syncthreads();
+  const double Idt = 1.0 / dt, min_visc_rem = 0.1, CFL_min = 1e-6;
+  const double du0f = wg_flux_adjust<MAXL>(T, face, u_r, v_r, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL,
+                                           du_min_CFL, A.tol_eta, A.tol_vel, A.better_iter, false);
+  const double du0 = face ? du0f : 0.0;
+  const double du_CFL = (CFL_min * Idt) * D.dC[f2];
+  double duR = dmin(0.0, du0 - du_CFL);
+  double duL = dmax(0.0, du0 + du_CFL);
+  recurrence4<MAXL>(T, face,
+    [&](int n, double *o) {
+      const double uk = u_r[n], vrem = v_r[n];
+      const double visc_rem_lim = dmax(vrem, min_visc_rem * visc_rem_max);
+      o[0] = uk; o[1] = vrem;
+      o[2] = -(uk + du_CFL * vrem) / visc_rem_lim;
+      o[3] = -(uk - du_CFL * vrem) / visc_rem_lim;
+    },
+    [&](double uk, double vrem, double q_R, double q_L) {
+      const double visc_rem_lim = dmax(vrem, min_visc_rem * visc_rem_max);
+      if (visc_rem_lim > 0.0) {
+        if (uk + duR * visc_rem_lim > -du_CFL * vrem) duR = q_R;
+        if (uk + duL * visc_rem_lim < du_CFL * vrem) duL = q_L;
+      }
+    });
+  if (lead) { s_du[fl] = du0; s_duL[fl] = duL; s_duR[fl] = duR; }
+  __syncthreads();
+  const double a_du0 = s_du[fl], a_duL = s_duL[fl], a_duR = s_duR[fl];
+  double FAmt_L = 0.0, FAmt_R = 0.0, FAmt_0 = 0.0, uhtot_L = 0.0, uhtot_R = 0.0;
+  // the three evaluations (:1330-1349) are done once; the five column sums go through the two transit arrays
+  double k_dR[MAXL], k_uhL[MAXL], k_uhR[MAXL];
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) {
+    const int k = kl + KL * n;
+    k_dR[n] = 0.0; k_uhL[n] = 0.0; k_uhR[n] = 0.0;
+    if (k < nk) {
+      double uh_0, d_0, d_L;
+      flux_lds(u_r[n] + a_du0 * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh_0, d_0);
+      flux_lds(u_r[n] + a_duL * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, k_uhL[n], d_L);
+      flux_lds(u_r[n] + a_duR * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, k_uhR[n], k_dR[n]);
+      sA[k * NF + fl] = d_0; sB[k * NF + fl] = d_L;
+    }
+  }
+  __syncthreads();
+  if (face) col_walk2(sA + fl, sB + fl, nk, [&](double a, double b) { FAmt_0 = FAmt_0 + a; FAmt_L = FAmt_L + b; });
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) {
+    const int k = kl + KL * n;
+    if (k < nk) { sA[k * NF + fl] = k_uhL[n]; sB[k * NF + fl] = k_uhR[n]; }
+  }
+  __syncthreads();
+  if (face) col_walk2(sA + fl, sB + fl, nk, [&](double a, double b) { uhtot_L = uhtot_L + a; uhtot_R = uhtot_R + b; });
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) {
+    const int k = kl + KL * n;
+    if (k < nk) sA[k * NF + fl] = k_dR[n];
+  }
+  __syncthreads();
+  if (!face) return;
+  col_walk2(sA + fl, sA + fl, nk, [&](double a, double) { FAmt_R = FAmt_R + a; });
+
+  double FA_0 = FAmt_0, FA_avg = FAmt_0;
+  if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
+  if (FA_avg > dmax(FA_0, FAmt_L)) FA_avg = dmax(FA_0, FAmt_L);
+  else if (FA_avg < dmin(FA_0, FAmt_L)) FA_0 = FA_avg;
+  A.FA_m0[f2] = FA_0; A.FA_mm[f2] = FAmt_L;
+  if (fabs(FA_0 - FAmt_L) <= 1e-12 * FA_0) A.uBT_mm[f2] = 0.0;
+  else A.uBT_mm[f2] = (1.5 * (duL - du0)) * ((FAmt_L - FA_avg) / (FAmt_L - FA_0));
+
+  FA_0 = FAmt_0; FA_avg = FAmt_0;
+  if ((duR - du0) != 0.0) FA_avg = uhtot_R / (duR - du0);
+  if (FA_avg > dmax(FA_0, FAmt_R)) FA_avg = dmax(FA_0, FAmt_R);
+  else if (FA_avg < dmin(FA_0, FAmt_R)) FA_0 = FA_avg;
+  A.FA_p0[f2] = FA_0; A.FA_pp[f2] = FAmt_R;
+  if (fabs(FAmt_R - FA_0) <= 1e-12 * FA_0) A.uBT_pp[f2] = 0.0;
+  else A.uBT_pp[f2] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
+}
+
+template <int DIR, int MAXL>
+int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E, size_t lds_bytes) {
+  const Dm d = c->d;
+  auto kern = k_mass_flux_lds<DIR, MAXL>;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds_bytes));
+  const dim3 grid((A.a1 - A.a0 + NF) / NF, A.b1 - A.b0 + 1, 1);
+  if (c->prof_on) prof_begin(c, DIR ? "k_mass_flux_lds<1>" : "k_mass_flux_lds<0>");
+  hipLaunchKernelGGL(kern, grid, dim3(NT, 1, 1), lds_bytes, c->stream, d, c->G, A, E);
+  if (c->prof_on) prof_end(c);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+}  // namespace
+
+size_t mass_flux_lds_bytes(int dir, int nk) {
+  const int NC = dir ? 2 * NF : NF + 1;
+  const int nkp = (nk + 1) & ~1;
+  return sizeof(double) * ((size_t)nk * (size_t)(3 * NC) + (size_t)nkp * (size_t)(2 * NF));
+}
+
+bool mass_flux_lds_usable(int nk) {
+  return nk <= 8 * KL && mass_flux_lds_bytes(1, nk) <= 156 * 1024;
+}
+
+int mass_flux_lds(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E) {
+  const int nk = c->d.nk;
+  const size_t bytes = mass_flux_lds_bytes(dir, nk);
+  const int maxl = (nk + KL - 1) / KL;
+  if (dir == 0) {
+    if (maxl <= 2) return launch<0, 2>(c, A, E, bytes);
+    if (maxl <= 5) return launch<0, 5>(c, A, E, bytes);
+    return launch<0, 8>(c, A, E, bytes);
+  }
+  if (maxl <= 2) return launch<1, 2>(c, A, E, bytes);
+  if (maxl <= 5) return launch<1, 5>(c, A, E, bytes);
+  return launch<1, 8>(c, A, E, bytes);
+}

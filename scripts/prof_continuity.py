@@ -1,0 +1,39 @@
+"""Per-mode timing of continuity_PPM's kernels at a chosen size, on both device paths (dev tool)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+from mom6_amd import abi, grid, synth_dev
+from mom6_amd.dycore import Dycore, BTContDev, prof_enable, prof_report, prof_reset
+
+ni, nj, nk = [int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (1440, 1080, 75))]
+gg = grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-65.0, dlon=360.0 / ni, dlat=130.0 / nj,
+                     reentrant_x=True, depth_fn=grid.bowl_depth(ni, nj, 4000.0, rim=2))
+d, M = gg.tile(nk)
+GV = abi.vgrid_default()
+dyc = Dycore(d, M, GV, 0)
+dyc.continuity_init(abi.continuity_params_default(nk, GV.Angstrom_H))
+Md = dyc.to_dev(M)
+h, u, v = synth_dev.make_state(d, Md, u_max=0.05, h_pert=0.001)
+vr = torch.clamp(0.85 + 0.2 * synth_dev.smooth_field(d, dyc.device, 11, nk=nk), 0, 1)
+vru = (vr * Md[abi.G["mask2dCu"]][None]).contiguous(); vrv = (vr * Md[abi.G["mask2dCv"]][None]).contiguous(); del vr
+bt = BTContDev(dyc)
+hp, uh, vh, ucor, vcor = (dyc.zeros3() for _ in range(5))
+dt = 900.0
+dyc.continuity_PPM(u, v, h, hp, uh, vh, dt)
+uhbt = (uh.sum(0) * (1.0 + 0.02 * synth_dev.smooth_field(d, dyc.device, 13))).contiguous()
+vhbt = (vh.sum(0) * (1.0 - 0.02 * synth_dev.smooth_field(d, dyc.device, 14))).contiguous()
+modes = {
+    "plain": dict(),
+    "visc": dict(visc_rem_u=vru, visc_rem_v=vrv),
+    "bt_cont": dict(visc_rem_u=vru, visc_rem_v=vrv, BT_cont=bt),
+    "adjust": dict(visc_rem_u=vru, visc_rem_v=vrv, uhbt=uhbt, vhbt=vhbt, u_cor=ucor, v_cor=vcor),
+    "full": dict(visc_rem_u=vru, visc_rem_v=vrv, uhbt=uhbt, vhbt=vhbt, u_cor=ucor, v_cor=vcor, BT_cont=bt),
+}
+for path in ("lds", "legacy"):
+    os.environ["MOM6X_MASSFLUX"] = path
+    for name, kw in modes.items():
+        dyc.continuity_PPM(u, v, h, hp, uh, vh, dt, **kw); dyc.sync()
+        prof_enable(dyc, True); prof_reset(dyc)
+        dyc.continuity_PPM(u, v, h, hp, uh, vh, dt, **kw); dyc.sync()
+        rep = prof_report(dyc); prof_enable(dyc, False)
+        print(path, name, " ".join(f"{k}={v[1]:.2f}" for k, v in sorted(rep.items())), "sum=%.2f ms" % sum(v[1] for v in rep.values()), flush=True)

@@ -11,6 +11,14 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["lds", "legacy"])
+def massflux_path(request, monkeypatch):
+    """Every case runs on both device paths: the LDS-resident fused kernel (default) and the
+    thread-per-column kernels (MOM6X_MASSFLUX=legacy).  Both must equal the oracle bit for bit."""
+    monkeypatch.setenv("MOM6X_MASSFLUX", request.param)
+    return request.param
+
+
 def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0):
     import torch
     from mom6_amd.dycore import Dycore, BTContDev
@@ -92,3 +100,9 @@ def test_continuity_thin_layers_and_tc1_tolerances(orc):
 @pytest.mark.parametrize("flag", ["monotonic", "simple_2nd", "upwind_1st"])
 def test_continuity_scheme_flags(orc, flag):
     _run_case(orc, H.benchmark_small(), 0, "full", cs_mod={flag: 1})
+
+
+@pytest.mark.parametrize("nk", [20, 75, 90])
+def test_continuity_many_layers(orc, nk):
+    # the LDS kernel gives every layer lane ceil(nk/16) layers: 2, 5 and 8-layer instantiations
+    _run_case(orc, H.benchmark_small(nk=nk), 1, "full", thin=0.1)
