@@ -23,12 +23,12 @@
 // HBM traffic per face-layer: read h (+halo re-reads from L2), u, visc_rem; write uh, u_cor, h_u.
 #include "continuity_dev.h"
 #include "continuity_lds.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int NF = 16;        // faces along i per work-group (the coalesced axis)
-constexpr int KL = 16;        // layer lanes per face
-constexpr int NT = NF * KL;   // 256 threads = 4 wavefronts
+// KL = layer lanes per face (template parameter): 16 (4 wavefronts) or 32 (8 wavefronts) per work-group
 
 // zonal_flux_layer :896 / merid_flux_layer :1787 with the cell data in LDS.
 // m / p: LDS slots of the minus / plus cell of the face.
@@ -138,7 +138,7 @@ struct Tile {   // what every lane knows about its face and the LDS arrays
 // A k-recurrence whose per-layer operands (4 of them) are produced by all lanes and consumed in k order
 // by the face lane.  The 4 x [nk] operands go through the sA|sB space in two halves of KH = ceil(nk/2).
 // Every lane of the work-group must call this.
-template <int MAXL, typename P, typename S>
+template <int KL, int MAXL, typename P, typename S>
 __device__ __forceinline__ void recurrence4(const Tile &T, bool face, P produce, S step) {
   const int KH = (T.nk + 1) >> 1, str = KH * NF;
   double *t = T.sA;   // sA and sB are contiguous: 2 * nkp * NF >= 4 * KH * NF
@@ -164,7 +164,7 @@ __device__ __forceinline__ void recurrence4(const Tile &T, bool face, P produce,
 // Every lane of the work-group must call this.  Face lanes (face == true) carry the Newton state; all
 // lanes re-evaluate the layer fluxes of the faces that are still iterating.  With store == true the
 // last evaluated transports stay in sA (the uh_3d argument of the reference).
-template <int MAXL>
+template <int KL, int MAXL>
 __device__ __forceinline__ double wg_flux_adjust(const Tile &T, bool face, const double (&u_r)[MAXL],
                                                  const double (&v_r)[MAXL], double IareaMin, double uhbt,
                                                  double uh_tot_0, double duhdu_tot_0, double du_max,
@@ -240,8 +240,8 @@ __device__ __forceinline__ double wg_flux_adjust(const Tile &T, bool face, const
   return du;
 }
 
-template <int DIR, int MAXL>
-__global__ void __launch_bounds__(NT, MAXL > 5 ? 1 : (DIR ? 2 : 3))   // LDS lets 3 (x) | 2 (y) work-groups share a CU at nk = 75
+template <int DIR, int KL, int MAXL>
+__global__ void __launch_bounds__(NF * KL, (KL * MAXL > 96) ? 1 : (KL == 32 ? 4 : (DIR ? 2 : 3)))   // LDS lets 3 (x) | 2 (y) work-groups share a CU at nk = 75
 k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   extern __shared__ double smem[];
   constexpr int NC = DIR ? 2 * NF : NF + 1;
@@ -253,7 +253,7 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   const int tid = threadIdx.x, fl = tid % NF, kl = tid / NF;
   // the wavefront that carries the sequential walks rotates with the tile so that the walks of the
   // work-groups sharing a CU do not all queue on the same SIMD
-  const int kl_face = ((blockIdx.x + blockIdx.y) & 3) * (KL / 4);
+  const int kl_face = ((blockIdx.x + blockIdx.y) % (KL / 4)) * 4;
   const int i0 = A.a0 + blockIdx.x * NF, j = A.b0 + blockIdx.y;
   const int i = i0 + fl;
   const bool active = (i <= A.a1);
@@ -394,7 +394,7 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
     const double maskC = D.maskC[f2];
     if (use_visc_rem) {
-      recurrence4<MAXL>(T, face,
+      recurrence4<KL, MAXL>(T, face,
         [&](int n, double *o) {
           o[0] = u_r[n]; o[1] = v_r[n];
           o[2] = (dx_W * CFL_dt - u_r[n]) / v_r[n];
@@ -405,7 +405,7 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
           if (du_min_CFL * vrem < -dx_E * CFL_dt - uk * maskC) du_min_CFL = q_min;
         });
     } else {
-      recurrence4<MAXL>(T, face,
+      recurrence4<KL, MAXL>(T, face,
         [&](int n, double *o) { o[0] = u_r[n]; o[1] = 0.0; o[2] = 0.0; o[3] = 0.0; },
         [&](double uk, double, double, double) {
           du_max_CFL = dmin(du_max_CFL, dx_W * CFL_dt - uk);
@@ -439,7 +439,7 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   const bool corrected = (A.uhbt != nullptr);
   if (corrected) {
     const double uhbt = face ? A.uhbt[f2] : 0.0;
-    const double du = wg_flux_adjust<MAXL>(T, face, u_r, v_r, IareaMin, uhbt, uh_tot_0, duhdu_tot_0, du_max_CFL,
+    const double du = wg_flux_adjust<KL, MAXL>(T, face, u_r, v_r, IareaMin, uhbt, uh_tot_0, duhdu_tot_0, du_max_CFL,
                                            du_min_CFL, A.tol_eta, A.tol_vel, A.better_iter, true);
     if (face && A.du_cor) A.du_cor[f2] = du;
     du_fin = s_du[fl];   // published by the face lane before the last barrier of the loop
@@ -492,13 +492,13 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   // ---- set_zonal_BT_cont :1246-1409 / set_merid_BT_cont :2143-2304 -----------------------------------
   __syncthreads();
   const double Idt = 1.0 / dt, min_visc_rem = 0.1, CFL_min = 1e-6;
-  const double du0f = wg_flux_adjust<MAXL>(T, face, u_r, v_r, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL,
+  const double du0f = wg_flux_adjust<KL, MAXL>(T, face, u_r, v_r, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL,
                                            du_min_CFL, A.tol_eta, A.tol_vel, A.better_iter, false);
   const double du0 = face ? du0f : 0.0;
   const double du_CFL = (CFL_min * Idt) * D.dC[f2];
   double duR = dmin(0.0, du0 - du_CFL);
   double duL = dmax(0.0, du0 + du_CFL);
-  recurrence4<MAXL>(T, face,
+  recurrence4<KL, MAXL>(T, face,
     [&](int n, double *o) {
       const double uk = u_r[n], vrem = v_r[n];
       const double visc_rem_lim = dmax(vrem, min_visc_rem * visc_rem_max);
@@ -568,15 +568,15 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   else A.uBT_pp[f2] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
 }
 
-template <int DIR, int MAXL>
+template <int DIR, int KL, int MAXL>
 int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E, size_t lds_bytes) {
   const Dm d = c->d;
-  auto kern = k_mass_flux_lds<DIR, MAXL>;
+  auto kern = k_mass_flux_lds<DIR, KL, MAXL>;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds_bytes));
   const dim3 grid((A.a1 - A.a0 + NF) / NF, A.b1 - A.b0 + 1, 1);
   if (c->prof_on) prof_begin(c, DIR ? "k_mass_flux_lds<1>" : "k_mass_flux_lds<0>");
-  hipLaunchKernelGGL(kern, grid, dim3(NT, 1, 1), lds_bytes, c->stream, d, c->G, A, E);
+  hipLaunchKernelGGL(kern, grid, dim3(NF * KL, 1, 1), lds_bytes, c->stream, d, c->G, A, E);
   if (c->prof_on) prof_end(c);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
@@ -591,19 +591,27 @@ size_t mass_flux_lds_bytes(int dir, int nk) {
 }
 
 bool mass_flux_lds_usable(int nk) {
-  return nk <= 8 * KL && mass_flux_lds_bytes(1, nk) <= 156 * 1024;
+  return nk <= 128 && mass_flux_lds_bytes(1, nk) <= 156 * 1024;
+}
+
+// layer lanes per face: MOM6X_LDS_KL=16|32 overrides the default
+static int pick_kl(int nk) {
+  const char *e = getenv("MOM6X_LDS_KL");
+  if (e) return atoi(e) == 32 ? 32 : 16;
+  return 16;
 }
 
 int mass_flux_lds(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E) {
   const int nk = c->d.nk;
   const size_t bytes = mass_flux_lds_bytes(dir, nk);
-  const int maxl = (nk + KL - 1) / KL;
-  if (dir == 0) {
-    if (maxl <= 2) return launch<0, 2>(c, A, E, bytes);
-    if (maxl <= 5) return launch<0, 5>(c, A, E, bytes);
-    return launch<0, 8>(c, A, E, bytes);
+  const int KLr = pick_kl(nk);
+  const int maxl = (nk + KLr - 1) / KLr;
+#define GO(D, K, M) return launch<D, K, M>(c, A, E, bytes)
+  if (KLr == 32) {
+    if (dir == 0) { if (maxl <= 1) GO(0, 32, 1); if (maxl <= 3) GO(0, 32, 3); GO(0, 32, 4); }
+    if (maxl <= 1) GO(1, 32, 1); if (maxl <= 3) GO(1, 32, 3); GO(1, 32, 4);
   }
-  if (maxl <= 2) return launch<1, 2>(c, A, E, bytes);
-  if (maxl <= 5) return launch<1, 5>(c, A, E, bytes);
-  return launch<1, 8>(c, A, E, bytes);
+  if (dir == 0) { if (maxl <= 2) GO(0, 16, 2); if (maxl <= 5) GO(0, 16, 5); GO(0, 16, 8); }
+  if (maxl <= 2) GO(1, 16, 2); if (maxl <= 5) GO(1, 16, 5); GO(1, 16, 8);
+#undef GO
 }

@@ -388,6 +388,107 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
   return MOM6X_OK;
 }
 
+// The velocity update of the RK2 step (:681-694 / :957-966), vertvisc (:557) and vertvisc_remnant (:1231)
+// of one direction in ONE column sweep.  The three share the tridiagonal coefficients (b1, d1, c1 depend
+// only on a, h, Ray and dt), so the fused kernel reads a_u and h_u once instead of twice, never writes
+// and re-reads the un-diffused velocity, and keeps a single c1 array.  Each quantity goes through
+// exactly the operations of the separate kernels, in the same order: results are bit-identical.
+//   UPD: u_start = mask * (u_in + dtx * (u_bc + u_abt)) is formed on the fly (else u is updated in place)
+//   REM: visc_rem is computed alongside (needs the same dt as the velocity solve)
+template <int DIR, bool UPD, bool REM>
+__global__ void __launch_bounds__(256)
+k_vertvisc_fused(Dm d, const double *__restrict__ G, const double *u_in, const double *__restrict__ u_bc,
+                 const double *__restrict__ u_abt, double dtx, double *u, double *__restrict__ vr,
+                 const double *__restrict__ a_u, const double *__restrict__ h_u, const double *__restrict__ Ray_u,
+                 const double *__restrict__ tau, double *__restrict__ c1, double dt, double dt_Rho0, double H_to_RZ,
+                 double *__restrict__ tau_bot) {
+  const int i = (DIR ? 0 : -1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int nz = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
+  if (mC > 0.) {
+    const double surface_stress = dt_Rho0 * (mC * tau[x]);
+    double Ray = Ray_u ? Ray_u[x] : 0.;
+    double a_k = a_u[x], a_kp = a_u[x + slab];
+    double hu = h_u[x];
+    double b_denom_1 = hu + dt * (Ray + a_k);
+    double b1 = 1.0 / (b_denom_1 + dt * a_kp);
+    double d1 = b_denom_1 * b1;
+    double u0 = UPD ? mC * (u_in[x] + dtx * (u_bc[x] + u_abt[x])) : u_in[x];
+    double uprev = b1 * (hu * u0 + surface_stress);
+    u[x] = uprev;
+    double rprev = b1 * hu;
+    if (REM) vr[x] = rprev;
+    for (int k = 1; k < nz; k++) {
+      const size_t x3 = x + (size_t)k * slab;
+      if (Ray_u) Ray = Ray_u[x3];
+      a_k = a_kp; a_kp = a_u[x3 + slab];
+      hu = h_u[x3];
+      u0 = UPD ? mC * (u_in[x3] + dtx * (u_bc[x3] + u_abt[x3])) : u_in[x3];
+      c1[x3] = dt * a_k * b1;
+      b_denom_1 = hu + dt * (Ray + a_k * d1);
+      b1 = 1.0 / (b_denom_1 + dt * a_kp);
+      d1 = b_denom_1 * b1;
+      uprev = (hu * u0 + dt * a_k * uprev) * b1;
+      u[x3] = uprev;
+      if (REM) { rprev = (hu + dt * a_k * rprev) * b1; vr[x3] = rprev; }
+    }
+    for (int k = nz - 2; k >= 0; k--) {
+      const size_t x3 = x + (size_t)k * slab;
+      const double ck = c1[x3 + slab];
+      uprev = u[x3] + ck * uprev;
+      u[x3] = uprev;
+      if (REM) { rprev = vr[x3] + ck * rprev; vr[x3] = rprev; }
+    }
+  } else if (UPD) {
+    for (int k = 0; k < nz; k++) {
+      const size_t x3 = x + (size_t)k * slab;
+      u[x3] = mC * (u_in[x3] + dtx * (u_bc[x3] + u_abt[x3]));
+    }
+  }
+  if (tau_bot) {
+    double tb = H_to_RZ * (u[x + (size_t)(nz - 1) * slab] * a_u[x + (size_t)nz * slab]);
+    if (Ray_u) for (int k = 0; k < nz; k++) tb = tb + H_to_RZ * (Ray_u[x + (size_t)k * slab] * u[x + (size_t)k * slab]);
+    tau_bot[x] = tb;
+  }
+}
+
+template <int DIR>
+static void launch_vertvisc_fused(mom6x_ctx *c, bool upd, bool rem, const double *u_in, const double *u_bc,
+                                  const double *u_abt, double dtx, double *u, double *vr, const double *a, const double *h,
+                                  const double *Ray, const double *tau, double *c1, double dt, double *tau_bot) {
+  const Dm d = c->d;
+  const dim3 b = blk2();
+  const dim3 g = DIR ? grid3(d.ni, d.nj + 1, 1, b) : grid3(d.ni + 1, d.nj, 1, b);
+  const double dt_Rho0 = dt / c->GV.H_to_RZ, HR = c->GV.H_to_RZ;
+  const char *nm = DIR ? "k_vertvisc_fused<1>" : "k_vertvisc_fused<0>";
+#define VVF(U, R) KLAUNCH(c, nm, (k_vertvisc_fused<DIR, U, R>), g, b, d, c->G, u_in, u_bc, u_abt, dtx, u, vr, a, h, Ray, tau, c1, dt, dt_Rho0, HR, tau_bot)
+  if (upd && rem) VVF(true, true);
+  else if (upd) VVF(true, false);
+  else if (rem) VVF(false, true);
+  else VVF(false, false);
+#undef VVF
+}
+
+// [u = mask*(u_in + dtx*(u_bc + u_abt));] vertvisc(u, dt); [vertvisc_remnant(vr, dt)] -- see k_vertvisc_fused.
+// u_bc == nullptr: no velocity update (u_in is ignored, u is updated in place); vr_u == nullptr: no remnant.
+int vertvisc_fused(mom6x_ctx *c, const double *u_in, const double *v_in, const double *u_bc, const double *v_bc,
+                   const double *u_abt, const double *v_abt, double dtx, double *u, double *v, const double *taux,
+                   const double *tauy, double dt, double *taux_bot, double *tauy_bot, double *vr_u, double *vr_v) {
+  REQUIRE(c && c->a_u, MOM6X_EINVAL, "MOM_vert_friction(visc): Module must be initialized before it is used.");
+  HIPCHK(hipSetDevice(c->device));
+  double *c1;
+  int rc;
+  if ((rc = ctx_scratch(c, SCR_c1, c->d.nk, &c1))) return rc;
+  const bool upd = (u_bc != nullptr), rem = (vr_u != nullptr);
+  launch_vertvisc_fused<0>(c, upd, rem, upd ? u_in : u, u_bc, u_abt, dtx, u, vr_u, c->a_u, c->h_u, c->Ray_u, taux, c1, dt, taux_bot);
+  launch_vertvisc_fused<1>(c, upd, rem, upd ? v_in : v, v_bc, v_abt, dtx, v, vr_v, c->a_v, c->h_v, c->Ray_v, tauy, c1, dt, tauy_bot);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
 extern "C" int mom6x_vertvisc_set_coef(mom6x_ctx *c, const double *a_u, const double *a_v, const double *h_u,
                                        const double *h_v, const double *Ray_u, const double *Ray_v) {
   REQUIRE(c && a_u && a_v && h_u && h_v, MOM6X_EINVAL, "mom6x_vertvisc_set_coef: null mandatory array");

@@ -269,11 +269,20 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
                    s->uh_in, s->vh_in, u_inst, v_inst, nullptr));
 
   const double dt_pred = dt * R.be;                                     // :679
-  KLAUNCH(c, "k_vel_update", k_vel_update, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
-          (const double *)v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, up, vp, dt_pred);   // :681-694
-  CHK(coef_hook(1, up, vp, dt_pred));                                   // :737-738
-  CHK(mom6x_vertvisc(c, up, vp, taux, tauy, dt_pred, s->taux_bot, s->tauy_bot));                 // :754
-  CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, R.visc_rem_dt_bug ? dt_pred : dt));   // :763-767
+  const bool host_coef = (hooks && hooks->vertvisc_coef);   // the callback needs up/vp before the solve: no fusion
+  if (!host_coef) {
+    // :681-694 + :754 + :763-767 in one column sweep per direction (k_vertvisc_fused)
+    const bool same_dt = (R.visc_rem_dt_bug != 0);
+    CHK(vertvisc_fused(c, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt_pred, up, vp, taux, tauy, dt_pred,
+                       s->taux_bot, s->tauy_bot, same_dt ? s->visc_rem_u : nullptr, same_dt ? s->visc_rem_v : nullptr));
+    if (!same_dt) CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));
+  } else {
+    KLAUNCH(c, "k_vel_update", k_vel_update, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
+            (const double *)v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, up, vp, dt_pred);   // :681-694
+    CHK(coef_hook(1, up, vp, dt_pred));                                   // :737-738
+    CHK(mom6x_vertvisc(c, up, vp, taux, tauy, dt_pred, s->taux_bot, s->tauy_bot));                 // :754
+    CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, R.visc_rem_dt_bug ? dt_pred : dt));   // :763-767
+  }
   pass3(c, { s->visc_rem_u, s->visc_rem_v }, { 1, 2 }, nk);             // :769
   pass3(c, { up, vp }, { 1, 2 }, nk);                                   // pass_uvp :773
 
@@ -304,11 +313,16 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
                    u_av, v_av, eta_av));
   KLAUNCH(c, "k_eta", k_eta, grid3(d.ni, d.nj, 1, b), b, d, c->G, eta, (const double *)s->eta_pred, (const double *)nullptr, 0.0);   // :946
   // u = mask*(u + dt*(u_bc_accel + u_accel_bt))  :957-966
-  KLAUNCH(c, "k_vel_update", k_vel_update, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
-          (const double *)v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, u_inst, v_inst, dt);
-  CHK(coef_hook(2, u_inst, v_inst, dt));                                // :1002-1003
-  CHK(mom6x_vertvisc(c, u_inst, v_inst, taux, tauy, dt, s->taux_bot, s->tauy_bot));   // :1013
-  CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :1022
+  if (!host_coef) {   // :957-966 + :1013 + :1022 in one column sweep per direction
+    CHK(vertvisc_fused(c, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt, u_inst, v_inst, taux, tauy, dt,
+                       s->taux_bot, s->tauy_bot, s->visc_rem_u, s->visc_rem_v));
+  } else {
+    KLAUNCH(c, "k_vel_update", k_vel_update, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
+            (const double *)v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, u_inst, v_inst, dt);
+    CHK(coef_hook(2, u_inst, v_inst, dt));                                // :1002-1003
+    CHK(mom6x_vertvisc(c, u_inst, v_inst, taux, tauy, dt, s->taux_bot, s->tauy_bot));   // :1013
+    CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :1022
+  }
   KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 4, d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2);   // :1025-1027
   pass3(c, { s->visc_rem_u, s->visc_rem_v }, { 1, 2 }, nk);             // :1030
   pass3(c, { u_inst, v_inst }, { 1, 2 }, nk);                           // pass_uv :1034

@@ -101,6 +101,10 @@ void prof_end(mom6x_ctx *c);
   } while (0)
 
 int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out);   // ctx.hip
+// dyn_kernels.hip: [u = mask*(u_in + dtx*(u_bc + u_abt));] vertvisc(u, v, dt); [vertvisc_remnant(vr_u, vr_v, dt)] in one sweep
+int vertvisc_fused(mom6x_ctx *c, const double *u_in, const double *v_in, const double *u_bc, const double *v_bc,
+                   const double *u_abt, const double *v_abt, double dtx, double *u, double *v, const double *taux,
+                   const double *tauy, double dt, double *taux_bot, double *tauy_bot, double *vr_u, double *vr_v);
 
 // k-chunking for "column-walk" kernels: a thread keeps its 2-D coefficients in registers and walks
 // KCHUNK consecutive layers, so the 2-D metric planes are read nk/KCHUNK times instead of nk times.
