@@ -552,25 +552,30 @@ k_layer_accel(Dm d, const double *__restrict__ G, const double *__restrict__ wor
               double *__restrict__ accel_layer_u, double *__restrict__ accel_layer_v, double accel_underflow) {
   const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
   if (i > d.ni - 1 || j > d.nj - 1) return;
   const int st = d.pitch;
-  const size_t c = ix2(d, i, j), slab = (size_t)d.slab, c3 = c + (size_t)k * slab;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  // the eleven 2-D operands stay in registers while the thread walks KCHUNK layers of pbce
   const double *e_anom = work + W_e_anom * slab;
-  const double pb = pbce[c3], ea = e_anom[c];
-  if (j >= 0) {
-    double a = (work[W_u_accel_bt * slab + c] -
-                (((pbce[c3 + 1] - work[W_gtot_W * slab + c + 1]) * e_anom[c + 1]) - ((pb - work[W_gtot_E * slab + c]) * ea)) *
-                    gm(G, d, MOM6X_G_IdxCu)[c]);
-    if (fabs(a) < accel_underflow) a = 0.0;
-    accel_layer_u[c3] = a;
-  }
-  if (i >= 0) {
-    double a = (work[W_v_accel_bt * slab + c] -
-                (((pbce[c3 + st] - work[W_gtot_S * slab + c + st]) * e_anom[c + st]) - ((pb - work[W_gtot_N * slab + c]) * ea)) *
-                    gm(G, d, MOM6X_G_IdyCv)[c]);
-    if (fabs(a) < accel_underflow) a = 0.0;
-    accel_layer_v[c3] = a;
+  const double ea = e_anom[c], ea_E = e_anom[c + 1], ea_N = e_anom[c + st];
+  const double g_E = work[W_gtot_E * slab + c], g_W = work[W_gtot_W * slab + c + 1];
+  const double g_N = work[W_gtot_N * slab + c], g_S = work[W_gtot_S * slab + c + st];
+  const double ua = work[W_u_accel_bt * slab + c], va = work[W_v_accel_bt * slab + c];
+  const double IdxCu = gm(G, d, MOM6X_G_IdxCu)[c], IdyCv = gm(G, d, MOM6X_G_IdyCv)[c];
+  for (int k = k0; k < k1; k++) {
+    const size_t c3 = c + (size_t)k * slab;
+    const double pb = pbce[c3];
+    if (j >= 0) {
+      double a = (ua - (((pbce[c3 + 1] - g_W) * ea_E) - ((pb - g_E) * ea)) * IdxCu);
+      if (fabs(a) < accel_underflow) a = 0.0;
+      accel_layer_u[c3] = a;
+    }
+    if (i >= 0) {
+      double a = (va - (((pbce[c3 + st] - g_S) * ea_N) - ((pb - g_N) * ea)) * IdyCv);
+      if (fabs(a) < accel_underflow) a = 0.0;
+      accel_layer_v[c3] = a;
+    }
   }
 }
 
@@ -871,7 +876,7 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     std::vector<int> nks(f.size(), 1);
     halo_wrap(c, f.data(), stg.data(), nks.data(), (int)f.size());
   }
-  KLAUNCH(c, "k_layer_accel", k_layer_accel, grid3(d.ni + 1, d.nj + 1, d.nk, b), b, d, c->G, work, pbce, accel_layer_u,
+  KLAUNCH(c, "k_layer_accel", k_layer_accel, grid3(d.ni + 1, d.nj + 1, nchunks(d.nk), b), b, d, c->G, work, pbce, accel_layer_u,
                      accel_layer_v, P.vel_underflow * Idt);
   HIPCHK(hipGetLastError());
   REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());

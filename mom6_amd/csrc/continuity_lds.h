@@ -8,6 +8,7 @@ struct LdsArgs {
   int monotonic;       // PPM_limit_CW84 instead of PPM_limit_pos
   int marginal;        // BT_cont%h_u from the marginal (not the average) face thickness
   double *h_face;      // BT_cont%h_u | h_v (3-D) or null
+  int i_base;          // first i of the tile grid (set by mass_flux_lds: 128-byte aligned, <= a0)
 };
 
 size_t mass_flux_lds_bytes(int dir, int nk);

@@ -254,9 +254,11 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   // the wavefront that carries the sequential walks rotates with the tile so that the walks of the
   // work-groups sharing a CU do not all queue on the same SIMD
   const int kl_face = ((blockIdx.x + blockIdx.y) % (KL / 4)) * 4;
-  const int i0 = A.a0 + blockIdx.x * NF, j = A.b0 + blockIdx.y;
+  // tiles start on 128-byte lines of the pitched rows (E.i_base <= A.a0): every row segment a work-group
+  // reads or writes is then exactly one cache line instead of two half lines shared with its neighbours
+  const int i0 = E.i_base + blockIdx.x * NF, j = A.b0 + blockIdx.y;
   const int i = i0 + fl;
-  const bool active = (i <= A.a1);
+  const bool active = (i >= A.a0 && i <= A.a1);
   const bool lead = (kl == kl_face);
   const bool face = active && lead;
   const int st = DIR ? d.pitch : 1;
@@ -286,7 +288,7 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     constexpr int NR = NF + 5;
     const double *m = D.mask2dT;
     const int g1 = i0 - 2 + fl, g2 = i0 + NF - 2 + fl;
-    const bool ok1 = (g1 <= A.a1 + 3), ok2 = (fl < 5) && (g2 <= A.a1 + 3);
+    const bool ok1 = (g1 >= A.a0 - 2 && g1 <= A.a1 + 3), ok2 = (fl < 5) && (g2 >= A.a0 - 2 && g2 <= A.a1 + 3);
     const size_t c1 = ix2(d, ok1 ? g1 : A.a1, j), c2 = ix2(d, ok2 ? g2 : A.a1, j);
     double r1[MAXL], r2[MAXL];
 #pragma unroll
@@ -300,7 +302,8 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
       }
     }
     double mm[5], mx[5];   // masks of this lane's cell (i0+fl) and of the extra cell (i0+NF)
-    const bool cell_ok = (i0 + fl <= A.a1 + 1), extra_ok = (fl < MAXL) && (i0 + NF <= A.a1 + 1);
+    const bool cell_ok = (i0 + fl >= A.a0 && i0 + fl <= A.a1 + 1);
+    const bool extra_ok = (fl < MAXL) && (i0 + NF >= A.a0 && i0 + NF <= A.a1 + 1);
 #pragma unroll
     for (int q = 0; q < 5; q++) {
       mm[q] = cell_ok ? m[ix2(d, i0 + fl - 2 + q, j)] : 0.0;
@@ -574,7 +577,7 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E, size_t lds_bytes) 
   auto kern = k_mass_flux_lds<DIR, KL, MAXL>;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds_bytes));
-  const dim3 grid((A.a1 - A.a0 + NF) / NF, A.b1 - A.b0 + 1, 1);
+  const dim3 grid((A.a1 - E.i_base + NF) / NF, A.b1 - A.b0 + 1, 1);
   if (c->prof_on) prof_begin(c, DIR ? "k_mass_flux_lds<1>" : "k_mass_flux_lds<0>");
   hipLaunchKernelGGL(kern, grid, dim3(NF * KL, 1, 1), lds_bytes, c->stream, d, c->G, A, E);
   if (c->prof_on) prof_end(c);
@@ -601,8 +604,10 @@ static int pick_kl(int nk) {
   return 16;
 }
 
-int mass_flux_lds(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E) {
+int mass_flux_lds(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E0) {
   const int nk = c->d.nk;
+  LdsArgs E = E0;
+  E.i_base = A.a0 - (((A.a0 + c->d.ioff) % NF) + NF) % NF;   // (i_base + ioff) is a multiple of 16 doubles = 128 B
   const size_t bytes = mass_flux_lds_bytes(dir, nk);
   const int KLr = pick_kl(nk);
   const int maxl = (nk + KLr - 1) / KLr;
