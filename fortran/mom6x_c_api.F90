@@ -222,6 +222,44 @@ module mom6x_c_api
       import :: c_int, c_ptr ; type(c_ptr), value :: ctx ; type(c_ptr), intent(in) :: fields(*)
       integer(c_int), intent(in) :: staggers(*), nks(*) ; integer(c_int), value :: n
     end function
+    ! ---- MOM_tracer_advect / MOM_diabatic_aux / MOM_tracer_diabatic ------------------------------------
+    integer(c_int) function mom6x_tracer_advect_init(ctx, dt_dyn, default_scheme, useHuynhStencilBug) &
+        bind(C, name="mom6x_tracer_advect_init")
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx ; real(c_double), value :: dt_dyn ; integer(c_int), value :: default_scheme, useHuynhStencilBug
+    end function
+    !> advect_tracer (MOM_tracer_advect.F90:53): tracers = array of ntr device pointers (Reg%Tr(m)%t)
+    integer(c_int) function mom6x_advect_tracer(ctx, h_end, uhtr, vhtr, dt, tracers, schemes, ntr, x_first_in, max_iter_in, &
+        uhr_out, vhr_out, iters_out) bind(C, name="mom6x_advect_tracer")
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, h_end, uhtr, vhtr, tracers, schemes, uhr_out, vhr_out, iters_out
+      real(c_double), value :: dt ; integer(c_int), value :: ntr, x_first_in, max_iter_in
+    end function
+    integer(c_int) function mom6x_triDiagTS(ctx, is, ie, js, je, hold, ea, eb, T, S) bind(C, name="mom6x_triDiagTS")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, hold, ea, eb, T, S ; integer(c_int), value :: is, ie, js, je
+    end function
+    integer(c_int) function mom6x_triDiagTS_Eulerian(ctx, is, ie, js, je, hold, ent, T, S) &
+        bind(C, name="mom6x_triDiagTS_Eulerian")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, hold, ent, T, S ; integer(c_int), value :: is, ie, js, je
+    end function
+    integer(c_int) function mom6x_tracer_vertdiff(ctx, h_old, ea, eb, dt, tr, sfc_flux, btm_flux, convert_flux) &
+        bind(C, name="mom6x_tracer_vertdiff")
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, h_old, ea, eb, tr, sfc_flux, btm_flux ; real(c_double), value :: dt
+      integer(c_int), value :: convert_flux
+    end function
+    integer(c_int) function mom6x_tracer_vertdiff_Eulerian(ctx, h_old, ent, dt, tr, sfc_flux, btm_flux, convert_flux) &
+        bind(C, name="mom6x_tracer_vertdiff_Eulerian")
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, h_old, ent, tr, sfc_flux, btm_flux ; real(c_double), value :: dt
+      integer(c_int), value :: convert_flux
+    end function
+    integer(c_int) function mom6x_diabatic_is_trivial(ctx) bind(C, name="mom6x_diabatic_is_trivial")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
+    end function
   end interface
 
 end module mom6x_c_api

@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Writes the fixtures under tests/golden/ from the ORACLE (oracle/liborc.so) on the seeded cases of tests/cases.py.
+
+These are regression fixtures of this repository's own CPU restatement -- NOT outputs of the reference Fortran
+(which cannot be built in this image; DESIGN.md section 2: parity unpinned).  They pin today's oracle so that
+ (a) `pytest -m "not gpu"` notices any drift of the oracle (compiler, refactoring), and
+ (b) the GPU parity tests can compare the HIP path with data that is under version control.
+Only computational-domain slices are stored (a few hundred kB).  Run:  python scripts/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import orc          # noqa: E402
+from tests import cases         # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h", u_cor="u", v_cor="v")
+
+
+def main():
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    cfg = H.double_gyre()
+    d = cfg[1]
+    so, _ = cases.oracle_rk2(orc, cfg, cases.rk2_inputs(cfg), 3, bt_mod=dict(strong_drag=1))
+    np.savez_compressed(H.golden_path("rk2_double_gyre_strong_drag_3steps"),
+                        **{n: so[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))] for n in so})
+    cfg = H.benchmark_small()
+    d = cfg[1]
+    out, _, _ = cases.oracle_continuity(orc, cfg, cases.continuity_inputs(cfg))
+    np.savez_compressed(H.golden_path("continuity_benchmark_small_corrector"),
+                        **{n: out[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))] for n in out})
+    for f in sorted(os.listdir(os.path.join(ROOT, "tests", "golden"))):
+        print(f, os.path.getsize(os.path.join(ROOT, "tests", "golden", f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

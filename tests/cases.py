@@ -1,0 +1,86 @@
+"""Seeded inputs and oracle runs shared by the GPU parity tests, the CPU golden-fixture tests and
+scripts/make_golden.py (so that the three always talk about the same case)."""
+import numpy as np
+
+from mom6_amd import abi, synth
+
+G = abi.G
+
+
+def visc_coefs(d, M):
+    from tests.test_dyn_gpu import visc_coefs as vc
+    return vc(d, M)
+
+
+def rk2_params(d, GV, bt_mod=None, rk2_mod=None, cor_mod=None):
+    bt = abi.barotropic_params_default(30.0)
+    for k, v in (bt_mod or {}).items():
+        setattr(bt, k, v)
+    rk2 = abi.rk2_params_default()
+    for k, v in (rk2_mod or {}).items():
+        setattr(rk2, k, v)
+    cor = abi.coriolis_params_default()
+    for k, v in (cor_mod or {}).items():
+        setattr(cor, k, v)
+    return abi.continuity_params_default(d.nk, GV.Angstrom_H), bt, cor, abi.pgf_params_default(GV.Rho0), rk2
+
+
+def rk2_inputs(cfg, per_stage=False, new_diff=False):
+    gg, d, M = cfg
+    GV = abi.vgrid_default()
+    Rlay, gp = abi.layer_densities(d.nk)
+    h, u, v = synth.make_state(d, M, u_max=0.05, h_pert=0.001)
+    base = visc_coefs(d, M)
+    if per_stage:
+        coefs = [tuple(base), tuple([base[0] * 1.1, base[1] * 1.1] + base[2:]), tuple([base[0] * 0.9, base[1] * 0.9] + base[2:])]
+        coefs = [tuple(np.ascontiguousarray(a) for a in c) for c in coefs]
+    else:
+        coefs = [tuple(base)] * 3
+    taux = np.ascontiguousarray(0.1 * synth.smooth_field(d, 41, ox=1, oy=.5) * M[G["mask2dCu"]])
+    tauy = np.ascontiguousarray(0.05 * synth.smooth_field(d, 42, ox=.5, oy=1) * M[G["mask2dCv"]])
+    diff_new = None
+    if new_diff:
+        diff_new = (np.ascontiguousarray(1e-7 * synth.smooth_field(d, 61, nk=d.nk, ox=1, oy=.5) * M[G["mask2dCu"]][None]),
+                    np.ascontiguousarray(1e-7 * synth.smooth_field(d, 62, nk=d.nk, ox=.5, oy=1) * M[G["mask2dCv"]][None]))
+    return dict(GV=GV, Rlay=Rlay, gp=gp, dt=1200.0, h=h, u=u, v=v, coefs=coefs, taux=taux, tauy=tauy, diff_new=diff_new)
+
+
+def oracle_rk2(orc, cfg, inp, nsteps, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0):
+    """nsteps of orc_step_dyn_split_RK2 from the seeded state; returns (final state dict, OrcModel)."""
+    gg, d, M = cfg
+    GV, dt, h, u, v = inp["GV"], inp["dt"], inp["h"], inp["u"], inp["v"]
+    cont, bt, cor, pgf, rk2 = rk2_params(d, GV, bt_mod, rk2_mod, cor_mod)
+    m = orc.OrcModel(d, M, GV, cont, bt, cor, pgf, rk2, inp["Rlay"], inp["gp"], first_direction)
+    so = dict(u=u.copy(), v=v.copy(), h=h.copy(), uh=np.zeros_like(h), vh=np.zeros_like(h), uhtr=np.zeros_like(h),
+              vhtr=np.zeros_like(h), eta_av=np.zeros(d.shape2()))
+    m.initialize(so["u"], so["v"], so["h"], so["uh"], so["vh"], dt)
+    dn = inp["diff_new"]
+    for n in range(nsteps):
+        m.step(so["u"], so["v"], so["h"], so["uh"], so["vh"], so["uhtr"], so["vhtr"], so["eta_av"], inp["taux"], inp["tauy"], dt,
+               inp["coefs"], calc_dtbt=(n == 0), diffu_new=dn[0] if dn else None, diffv_new=dn[1] if dn else None)
+    return so, m
+
+
+def continuity_inputs(cfg):
+    gg, d, M = cfg
+    GV = abi.vgrid_default()
+    CS = abi.continuity_params_default(d.nk, GV.Angstrom_H)
+    h, u, v = synth.make_state(d, M, thin_frac=0.1)
+    vr_u = np.clip(0.5 + 0.6 * synth.smooth_field(d, 11, nk=d.nk, ox=1.0, oy=0.5), 0.0, 1.0)
+    vr_v = np.clip(0.5 + 0.6 * synth.smooth_field(d, 12, nk=d.nk, ox=0.5, oy=1.0), 0.0, 1.0)
+    return dict(GV=GV, CS=CS, h=h, u=u, v=v, vr_u=np.ascontiguousarray(vr_u), vr_v=np.ascontiguousarray(vr_v), dt=1200.0)
+
+
+def oracle_continuity(orc, cfg, inp):
+    """continuity_PPM with uhbt/vhbt (5 % off the unadjusted sums), visc_rem, u_cor/v_cor: the corrector-call shape."""
+    gg, d, M = cfg
+    GV, CS, h, u, v, dt = (inp[k] for k in ("GV", "CS", "h", "u", "v", "dt"))
+    z = lambda: np.zeros_like(h)
+    h0, uh0, vh0 = z(), z(), z()
+    orc.continuity_PPM(d, M, GV, CS, 0, u, v, h, h0, uh0, vh0, dt)
+    uhbt = np.ascontiguousarray(uh0.sum(0) * (1.0 + 0.05 * synth.smooth_field(d, 13, ox=1.0, oy=0.5)))
+    vhbt = np.ascontiguousarray(vh0.sum(0) * (1.0 - 0.05 * synth.smooth_field(d, 14, ox=0.5, oy=1.0)))
+    out = dict(h=z(), uh=z(), vh=z(), u_cor=z(), v_cor=z())
+    orc.continuity_PPM(d, M, GV, CS, 0, u, v, h, out["h"], out["uh"], out["vh"], dt, uhbt=uhbt, vhbt=vhbt,
+                       visc_rem_u=inp["vr_u"], visc_rem_v=inp["vr_v"], u_cor=out["u_cor"], v_cor=out["v_cor"])
+    return out, uhbt, vhbt

@@ -60,3 +60,14 @@ def assert_close(a, b, name, rtol, sl=None):
     scale = max(np.abs(b).max(), 1e-300)
     err = np.abs(a - b).max() / scale
     assert err <= rtol, f"{name}: max rel-to-range error {err:.3e} > {rtol:.1e}"
+
+
+# ---- committed fixtures (tests/golden/*.npz): computational-domain slices of oracle outputs on seeded inputs
+def golden_path(name):
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")
+
+
+def load_golden(name):
+    with np.load(golden_path(name)) as z:
+        return {k: z[k] for k in z.files}

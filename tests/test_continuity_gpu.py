@@ -106,3 +106,26 @@ def test_continuity_scheme_flags(orc, flag):
 def test_continuity_many_layers(orc, nk):
     # the LDS kernel gives every layer lane ceil(nk/16) layers: 2, 5 and 8-layer instantiations
     _run_case(orc, H.benchmark_small(nk=nk), 1, "full", thin=0.1)
+
+
+def test_continuity_device_matches_committed_golden(orc):
+    """HIP continuity_PPM (corrector-call shape) against tests/golden/continuity_benchmark_small_corrector.npz."""
+    import torch
+    from mom6_amd.dycore import Dycore
+    from tests import cases
+    cfg = H.benchmark_small()
+    gg, d, M = cfg
+    inp = cases.continuity_inputs(cfg)
+    _, uhbt, vhbt = cases.oracle_continuity(orc, cfg, inp)     # only for the uhbt/vhbt inputs
+    dyc = Dycore(d, M, inp["GV"], 0)
+    dyc.continuity_init(inp["CS"])
+    out = {n: dyc.zeros3() for n in ("h", "uh", "vh", "u_cor", "v_cor")}
+    dyc.continuity_PPM(dyc.to_dev(inp["u"]), dyc.to_dev(inp["v"]), dyc.to_dev(inp["h"]), out["h"], out["uh"], out["vh"], inp["dt"],
+                       uhbt=dyc.to_dev(uhbt), vhbt=dyc.to_dev(vhbt), visc_rem_u=dyc.to_dev(inp["vr_u"]),
+                       visc_rem_v=dyc.to_dev(inp["vr_v"]), u_cor=out["u_cor"], v_cor=out["v_cor"])
+    dyc.sync()
+    gold = H.load_golden("continuity_benchmark_small_corrector")
+    stag = dict(h="h", uh="u", vh="v", u_cor="u", v_cor="v")
+    for n in out:
+        H.assert_bitwise(out[n].cpu().numpy()[(Ellipsis,) + tuple(H.interior(d, stag[n]))], gold[n], "golden:" + n)
+    dyc.close()

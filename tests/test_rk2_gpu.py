@@ -23,46 +23,17 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
         exact=True, rtol=1e-11):
     import torch
     from mom6_amd.dycore import Dycore
+    from tests import cases
     gg, d, M = cfg
-    GV = abi.vgrid_default()
-    Rlay, gp = abi.layer_densities(d.nk)
-    dt = 1200.0
+    inp = cases.rk2_inputs(cfg, per_stage, new_diff)
+    GV, Rlay, gp, dt = inp["GV"], inp["Rlay"], inp["gp"], inp["dt"]
+    h, u, v, coefs, taux, tauy, diff_new = (inp[k] for k in ("h", "u", "v", "coefs", "taux", "tauy", "diff_new"))
 
     def params():
-        bt = abi.barotropic_params_default(30.0)
-        for k, v in (bt_mod or {}).items():
-            setattr(bt, k, v)
-        rk2 = abi.rk2_params_default()
-        for k, v in (rk2_mod or {}).items():
-            setattr(rk2, k, v)
-        cor = abi.coriolis_params_default()
-        for k, v in (cor_mod or {}).items():
-            setattr(cor, k, v)
-        return abi.continuity_params_default(d.nk, GV.Angstrom_H), bt, cor, abi.pgf_params_default(GV.Rho0), rk2
-
-    h, u, v = synth.make_state(d, M, u_max=0.05, h_pert=0.001)
-    base = visc_coefs(d, M)
-    if per_stage:
-        coefs = [tuple(base), tuple([base[0] * 1.1, base[1] * 1.1] + base[2:]), tuple([base[0] * 0.9, base[1] * 0.9] + base[2:])]
-        coefs = [tuple(np.ascontiguousarray(a) for a in c) for c in coefs]
-    else:
-        coefs = [tuple(base)] * 3
-    taux = np.ascontiguousarray(0.1 * synth.smooth_field(d, 41, ox=1, oy=.5) * M[G["mask2dCu"]])
-    tauy = np.ascontiguousarray(0.05 * synth.smooth_field(d, 42, ox=.5, oy=1) * M[G["mask2dCv"]])
-    diff_new = None
-    if new_diff:
-        diff_new = (np.ascontiguousarray(1e-7 * synth.smooth_field(d, 61, nk=d.nk, ox=1, oy=.5) * M[G["mask2dCu"]][None]),
-                    np.ascontiguousarray(1e-7 * synth.smooth_field(d, 62, nk=d.nk, ox=.5, oy=1) * M[G["mask2dCv"]][None]))
+        return cases.rk2_params(d, GV, bt_mod, rk2_mod, cor_mod)
 
     # ---------------- oracle
-    cont, bt, cor, pgf, rk2 = params()
-    m = orc.OrcModel(d, M, GV, cont, bt, cor, pgf, rk2, Rlay, gp, first_direction)
-    so = dict(u=u.copy(), v=v.copy(), h=h.copy(), uh=np.zeros_like(h), vh=np.zeros_like(h), uhtr=np.zeros_like(h),
-              vhtr=np.zeros_like(h), eta_av=np.zeros(d.shape2()))
-    m.initialize(so["u"], so["v"], so["h"], so["uh"], so["vh"], dt)
-    for n in range(nsteps):
-        m.step(so["u"], so["v"], so["h"], so["uh"], so["vh"], so["uhtr"], so["vhtr"], so["eta_av"], taux, tauy, dt, coefs,
-               calc_dtbt=(n == 0), diffu_new=diff_new[0] if diff_new else None, diffv_new=diff_new[1] if diff_new else None)
+    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction)
 
     # ---------------- device
     cont2, bt2, cor2, pgf2, rk22 = params()
@@ -116,7 +87,9 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
     A = M[G["areaT"]][sl]
     vol0 = (h[(Ellipsis,) + sl] * A).sum(); vol1 = (sg["h"].cpu().numpy()[(Ellipsis,) + sl] * A).sum()
     assert abs(vol1 / vol0 - 1.0) < 1e-13
+    out = {n: sg[n].cpu().numpy() for n in STATE}
     dyc.close()
+    return out
 
 
 @pytest.mark.parametrize("first_direction", [0, 1])
@@ -133,6 +106,16 @@ def test_rk2_channel_bitexact_tc1_like(orc):
 def test_rk2_benchmark_small_hooks_and_flags(orc):
     run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(begw=0.25, split_bottom_stress=1, visc_rem_dt_bug=0),
         per_stage=True, new_diff=True)
+
+
+def test_rk2_device_matches_committed_golden(orc):
+    """The device result against the fixture committed under tests/golden/ (made by scripts/make_golden.py from the
+    oracle; the CPU suite checks that today's oracle still reproduces it): bit for bit."""
+    out = run(orc, H.double_gyre(), nsteps=3, bt_mod=dict(strong_drag=1))
+    gold = H.load_golden("rk2_double_gyre_strong_drag_3steps")
+    d = H.double_gyre()[1]
+    for n in STATE:
+        H.assert_bitwise(out[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))], gold[n], "golden:" + n)
 
 
 def test_rk2_default_path_tolerance(orc):
