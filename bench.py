@@ -102,6 +102,66 @@ KERNEL_WORDS = {
 }
 
 
+def tracer_leg(args, dyc, d, st, step, barrier, dist):
+    """One tracer step of BASELINE.json configs[2] after the timed region (NOT part of `value`): two more dynamics
+    steps accumulate uhtr/vhtr (DT_THERM = 2 DT), then advect_tracer moves `--tracers` PPM tracers with them and
+    tracer_vertdiff / triDiagTS run the vertical tridiagonal solves on the tracers and on T, S."""
+    import torch
+    from mom6_amd import synth_dev
+    ntr, nk = args.tracers, args.nk
+    st["uhtr"].zero_(); st["vhtr"].zero_()
+    step(); step()
+    dyc.tracer_advect_init(args.dt, scheme=2)                          # TRACER_ADVECTION_SCHEME = "PPM"
+    tr = [(10.0 + 5.0 * synth_dev.smooth_field(d, dyc.device, 71 + m, nk=nk, ox=0.5, oy=0.5)).contiguous() for m in range(ntr)]
+    h = st["h"]
+    dyc.advect_tracer(h, st["uhtr"], st["vhtr"], 2.0 * args.dt, [t.clone() for t in tr])   # untimed: allocates the work arrays
+    barrier(); t0 = time.perf_counter()
+    iters = dyc.advect_tracer(h, st["uhtr"], st["vhtr"], 2.0 * args.dt, tr)
+    barrier(); t_adv = time.perf_counter() - t0
+    ea = (1.0e-3 * h).contiguous(); eb = (2.0e-3 * h).contiguous()
+    T = (10.0 + synth_dev.smooth_field(d, dyc.device, 81, nk=nk)).contiguous(); S = (35.0 + 0.0 * T).contiguous()
+    dyc.tracer_vertdiff(h, ea, eb, 2.0 * args.dt, tr[0].clone())      # untimed warm-up
+    barrier(); t0 = time.perf_counter()
+    for m in range(ntr):
+        dyc.tracer_vertdiff(h, ea, eb, 2.0 * args.dt, tr[m])
+    dyc.triDiagTS(h, ea, eb, T, S)
+    barrier(); t_tri = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([t_adv, t_tri], dtype=torch.float64, device=dyc.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_adv, t_tri = (float(x) for x in t)
+    N3 = args.ni * args.nj * args.nk
+    # compulsory words per cell-layer: set-up (h_end, uhtr, vhtr in; hprev, uhr, vhr out) + per iteration and direction
+    # (uhr, hprev in/out + every tracer in/out)
+    b_adv = 8.0 * N3 * (6 + iters * 2 * (4 + 2 * ntr))
+    b_tri = 8.0 * N3 * (ntr * 5 + 7)                                   # h, ea, eb + tracer in/out each; T and S share one sweep
+    return {"tracers": ntr, "scheme": "PPM", "advect_tracer_ms": round(1e3 * t_adv, 3), "advect_iterations": iters,
+            "advect_algorithmic_GB": round(b_adv / 1e9, 2), "advect_GBps": round(b_adv / 1e9 / t_adv, 1),
+            "advect_frac_of_hbm_peak": round(b_adv / 1e9 / t_adv / (HBM_PEAK_GBS * args.gpus), 4),
+            "tridiag_ms": round(1e3 * t_tri, 3), "tridiag_algorithmic_GB": round(b_tri / 1e9, 2),
+            "tridiag_GBps": round(b_tri / 1e9 / t_tri, 1),
+            "tridiag_frac_of_hbm_peak": round(b_tri / 1e9 / t_tri / (HBM_PEAK_GBS * args.gpus), 4),
+            "note": "reported next to, not inside, the headline metric: one tracer step per two dynamics steps (DT_THERM = 2 DT)"}
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_hbm_pmc.json,
+    written by scripts/rocprof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; the
+    counters cannot be collected from inside the timed run).  None if there is no summary for this kernel."""
+    import glob
+    import re
+    key = lambda n: (re.match(r"\w+(<\d+)?", n.replace(" ", "")) or [n])[0]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")), reverse=True):
+        try:
+            tab = json.load(open(path))["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for n, v in tab.items():
+            if key(n) == key(kernel):
+                return float(v), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def cpu_baseline(args):
     """The oracle (kind='port': plain-C restatement of the reference Fortran, one core) on a bounded tile."""
     from mom6_amd import abi, grid, synth
@@ -149,6 +209,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--tracers", type=int, default=2, help="PPM tracers of the (separately reported) tracer leg; 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -223,13 +284,14 @@ def main():
     N3_tile = d.ni * d.nj * d.nk
     n_dom = sum(v[0] for v in dom.values()); ms_dom = sum(v[1] for v in dom.values())
     roofline = None
+    traffic, traffic_src = pmc_traffic(dom_name) if args.gpus == 1 and (args.ni, args.nj, args.nk) == (1440, 1080, 75) else (None, None)
     words = next((w for pre, w in KERNEL_WORDS.items() if dom_name.startswith(pre)), None)
     if n_dom and words is not None:
         avg_ms = ms_dom / n_dom
         bytes_launch = words * 8.0 * N3_tile
         ach = bytes_launch / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4),
                     "launches_per_step": n_dom / args.steps, "algorithmic_bytes_per_launch": bytes_launch,
                     "words_per_cell_layer": words}
     out = {
@@ -246,6 +308,8 @@ def main():
                      "frac_of_peak": round(bytes_step / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * args.gpus), 4),
                      "model": "SURVEY.md 8(d): 1616 B x N3 + 570 B x N2 x sub-steps"},
     }
+    if args.tracers > 0:
+        out["tracer_leg"] = tracer_leg(args, dyc, d, st, step, barrier, dist)
     if rank == 0:
         tot = sum(v[1] for v in full.values())
         out["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]}
