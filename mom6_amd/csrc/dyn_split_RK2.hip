@@ -130,6 +130,16 @@ int pass3(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list
   return MOM6X_OK;
 }
 
+// One group pass of fields with different numbers of levels: consecutive do_group_pass calls of the reference
+// that no computation separates are sent as ONE packed message per neighbour.
+int passn(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list<int> stg, std::initializer_list<int> nks) {
+  double *ff[16]; int ss[16], nn[16]; int n = 0;
+  auto s = stg.begin(); auto q = nks.begin();
+  for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = *q++; n++; }
+  halo_wrap(c, ff, ss, nn, n);
+  return MOM6X_OK;
+}
+
 }  // namespace
 
 void rk2_state_free(mom6x_ctx *c) {
@@ -254,8 +264,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
           s->diffu, s->diffv, u_bc, v_bc, (const double *)u_inst, (const double *)v_inst, up, vp, dt);
   CHK(coef_hook(0, up, vp, dt));                                        // :602-609
   CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :610
-  pass3(c, { eta }, { 0 }, 1);                                          // pass_eta :620
-  pass3(c, { s->visc_rem_u, s->visc_rem_v }, { 1, 2 }, nk);             // pass_visc_rem :621
+  passn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk });   // pass_eta :620 + pass_visc_rem :621
 
   CHK(mom6x_bt_mass_source(c, h, eta, 1));                              // :629
   // continuity(u, v, h, hp, uh_in, vh_in, dt, visc_rem_u, visc_rem_v, BT_cont)  :646
@@ -283,8 +292,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     CHK(mom6x_vertvisc(c, up, vp, taux, tauy, dt_pred, s->taux_bot, s->tauy_bot));                 // :754
     CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, R.visc_rem_dt_bug ? dt_pred : dt));   // :763-767
   }
-  pass3(c, { s->visc_rem_u, s->visc_rem_v }, { 1, 2 }, nk);             // :769
-  pass3(c, { up, vp }, { 1, 2 }, nk);                                   // pass_uvp :773
+  pass3(c, { s->visc_rem_u, s->visc_rem_v, up, vp }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :769 + pass_uvp :773
 
   // uh = u_av * h ; hp = h + dt * div . uh  :779-781
   CHK(mom6x_continuity_PPM(c, up, vp, h, hp, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av, &s->BT,
@@ -324,13 +332,11 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :1022
   }
   KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 4, d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2);   // :1025-1027
-  pass3(c, { s->visc_rem_u, s->visc_rem_v }, { 1, 2 }, nk);             // :1030
-  pass3(c, { u_inst, v_inst }, { 1, 2 }, nk);                           // pass_uv :1034
+  pass3(c, { s->visc_rem_u, s->visc_rem_v, u_inst, v_inst }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :1030 + pass_uv :1034
   // uh = u_av * h ; h = h + dt * div . uh  :1041-1043
   CHK(mom6x_continuity_PPM(c, u_inst, v_inst, h, h, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av,
                            nullptr, nullptr, nullptr));
-  pass3(c, { h }, { 0 }, nk);                                           // pass_h :1045
-  pass3(c, { u_av, v_av, uh, vh }, { 1, 2, 1, 2 }, nk);                 // pass_av_uvh :1053
+  pass3(c, { h, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);           // pass_h :1045 + pass_av_uvh :1053
   KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 4, d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2);   // :1064-1066
   KLAUNCH(c, "k_uhtr", k_uhtr, gridk(d.ni + 5, d.nj + 5, nk, b), b, d, uhtr, vhtr, (const double *)uh, (const double *)vh, dt);   // :1072-1079
   // CAu_pred for the next step :1081-1090

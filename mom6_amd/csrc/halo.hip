@@ -59,10 +59,15 @@ extern "C" int mom6x_halo_neighbor(int npx, int npy, int px, int py, int dir, in
 }
 
 // ---- pack / unpack ----------------------------------------------------------------------------------
-// One launch moves the region of direction `dir` of every field of the group between the fields and a
-// contiguous buffer (field-major, then k, j, i).
+// ONE launch moves the regions of all (up to 8) directions of every field of the group between the fields
+// and the per-direction contiguous buffers (field-major, then k, j, i); blockIdx.y is the direction.
+struct Bufs8 { double *p[8]; };
+
 __global__ void __launch_bounds__(256)
-k_halo_pack(Dm d, WrapArgs A, double *__restrict__ buf, int dir, int send /*1: pack send region, 0: unpack recv region*/) {
+k_halo_pack(Dm d, WrapArgs A, Bufs8 B, int send /*1: pack send regions, 0: unpack recv regions*/) {
+  const int dir = blockIdx.y;
+  double *__restrict__ buf = B.p[dir];
+  if (!buf) return;   // no neighbour in this direction
   int dx, dy; dir_dxdy(dir, dx, dy);
   size_t off = 0;
   for (int m = 0; m < A.n; m++) {
@@ -264,9 +269,17 @@ static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
       HIPCHK(hipMalloc(&m->sbuf[dir], m->cap[dir] * sizeof(double)));
       HIPCHK(hipMalloc(&m->rbuf[dir], m->cap[dir] * sizeof(double)));
     }
-    const int blocks = (int)((cnt[dir] + 255) / 256 > 1024 ? 1024 : (cnt[dir] + 255) / 256);
-    KLAUNCH(c, "k_halo_pack", k_halo_pack, dim3(blocks), dim3(256), d, A, m->sbuf[dir], dir, 1);
   }
+  size_t cmax = 0;
+  Bufs8 SB, RB;
+  for (int dir = 0; dir < 8; dir++) {
+    SB.p[dir] = (m->nbr[dir] >= 0) ? m->sbuf[dir] : nullptr;
+    RB.p[dir] = (m->nbr[dir] >= 0) ? m->rbuf[dir] : nullptr;
+    if (cnt[dir] > cmax) cmax = cnt[dir];
+  }
+  if (cmax == 0) return MOM6X_OK;
+  const int blocks = (int)((cmax + 255) / 256 > 512 ? 512 : (cmax + 255) / 256);
+  KLAUNCH(c, "k_halo_pack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, SB, 1);
   // sends in direction order; receives in the order of the OPPOSITE directions, so that the j-th send to a
   // peer pairs with the peer's j-th receive from us even when one rank is the neighbour in several directions.
   bool in_group = false;
@@ -295,11 +308,7 @@ static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
     NCCLCHK(g_nccl.GroupEnd());
   }
   (void)in_group;
-  for (int dir = 0; dir < 8; dir++) {
-    if (m->nbr[dir] < 0) continue;
-    const int blocks = (int)((cnt[dir] + 255) / 256 > 1024 ? 1024 : (cnt[dir] + 255) / 256);
-    KLAUNCH(c, "k_halo_unpack", k_halo_pack, dim3(blocks), dim3(256), d, A, m->rbuf[dir], dir, 0);
-  }
+  KLAUNCH(c, "k_halo_unpack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, RB, 0);
   return MOM6X_OK;
 }
 
