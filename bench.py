@@ -118,6 +118,13 @@ def tracer_leg(args, dyc, d, st, step, barrier, dist):
     barrier(); t0 = time.perf_counter()
     iters = dyc.advect_tracer(h, st["uhtr"], st["vhtr"], 2.0 * args.dt, tr)
     barrier(); t_adv = time.perf_counter() - t0
+    if args.breakdown:
+        from mom6_amd.dycore import prof_enable, prof_report, prof_reset
+        prof_enable(dyc, True); prof_reset(dyc)
+        dyc.advect_tracer(h, st["uhtr"], st["vhtr"], 2.0 * args.dt, [t.clone() for t in tr]); dyc.sync()
+        for k, (cnt, ms) in sorted(prof_report(dyc).items(), key=lambda kv: -kv[1][1]):
+            print(f"[tracer] {k:22s} n={cnt:5d} total={ms:9.3f} ms avg={ms / cnt * 1e3:9.1f} us", file=sys.stderr)
+        prof_enable(dyc, False)
     ea = (1.0e-3 * h).contiguous(); eb = (2.0e-3 * h).contiguous()
     T = (10.0 + synth_dev.smooth_field(d, dyc.device, 81, nk=nk)).contiguous(); S = (35.0 + 0.0 * T).contiguous()
     dyc.tracer_vertdiff(h, ea, eb, 2.0 * args.dt, tr[0].clone())      # untimed warm-up
