@@ -97,9 +97,10 @@ template <int DIR>
 __global__ void __launch_bounds__(256)
 k_btcalc(Dm d, const double *__restrict__ G, const double *__restrict__ h, const double *__restrict__ hf,
          double *__restrict__ fr, double h_neglect, double Z_to_H) {
-  const int i = (DIR ? 0 : -1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < ((DIR ? 0 : -1))) return;
   const int st = DIR ? d.pitch : 1, nz = d.nk;
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[c];
@@ -200,9 +201,10 @@ struct ColArgs {
 template <int DIR>
 __global__ void __launch_bounds__(256)
 k_bt_col(Dm d, const double *__restrict__ G, ColArgs A) {
-  const int i = (DIR ? 0 : -1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < ((DIR ? 0 : -1))) return;
   const int st = DIR ? d.pitch : 1, nz = d.nk;
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   const double subroundoff = 1e-30;
@@ -550,9 +552,10 @@ __global__ void k_bt_post(Dm d, double *work, const double *__restrict__ eta_in,
 __global__ void __launch_bounds__(256)
 k_layer_accel(Dm d, const double *__restrict__ G, const double *__restrict__ work, const double *__restrict__ pbce,
               double *__restrict__ accel_layer_u, double *__restrict__ accel_layer_v, double accel_underflow) {
-  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < (-1)) return;
   const int st = d.pitch;
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
@@ -643,7 +646,7 @@ extern "C" int mom6x_btcalc(mom6x_ctx *c, const double *h, const double *h_u, co
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   const dim3 b = blk2();
-  KLAUNCH(c, "k_btcalc<0>", k_btcalc<0>, grid3(d.ni + 1, d.nj, 1, b), b, d, c->G, h, h_u, c->bts->frhatu,
+  KLAUNCH(c, "k_btcalc<0>", k_btcalc<0>, grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, h, h_u, c->bts->frhatu,
                      c->GV.H_subroundoff, c->GV.Z_to_H);
   KLAUNCH(c, "k_btcalc<1>", k_btcalc<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, h, h_v, c->bts->frhatv,
                      c->GV.H_subroundoff, c->GV.Z_to_H);
@@ -758,7 +761,7 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   Av.ubt_Cor = work + W_vbt_Cor * slab; Av.gtot_m = work + W_gtot_N * slab; Av.gtot_p = work + W_gtot_S * slab;
   Av.uh0sum = work + W_vh0sum * slab; Av.ubt0 = work + W_vbt0 * slab; Av.ubt = work + W_vbt * slab;
   Av.BT_force = work + W_BT_force_v * slab; Av.bt_rem = work + W_bt_rem_v * slab;
-  KLAUNCH(c, "k_bt_col<0>", k_bt_col<0>, grid3(d.ni + 1, d.nj, 1, b), b, d, c->G, Au);
+  KLAUNCH(c, "k_bt_col<0>", k_bt_col<0>, grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, Au);
   KLAUNCH(c, "k_bt_col<1>", k_bt_col<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, Av);
 
   // ---- BT_cont fits (set_local_BT_cont_types, halo = 1+ievf-ie)
@@ -876,7 +879,7 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     std::vector<int> nks(f.size(), 1);
     halo_wrap(c, f.data(), stg.data(), nks.data(), (int)f.size());
   }
-  KLAUNCH(c, "k_layer_accel", k_layer_accel, grid3(d.ni + 1, d.nj + 1, nchunks(d.nk), b), b, d, c->G, work, pbce, accel_layer_u,
+  KLAUNCH(c, "k_layer_accel", k_layer_accel, grid3(nxa(d.ni + 1, -1), d.nj + 1, nchunks(d.nk), b), b, d, c->G, work, pbce, accel_layer_u,
                      accel_layer_v, P.vel_underflow * Idt);
   HIPCHK(hipGetLastError());
   REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());

@@ -22,9 +22,10 @@ __global__ void __launch_bounds__(256)
 k_corad_q(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
           const double *__restrict__ h, double *__restrict__ q, double *__restrict__ absv, double *__restrict__ KE,
           int no_slip, int ke_scheme, double vol_neglect) {
-  const int i = -2 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(-2) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -2 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni || j > d.nj) return;
+  if (i < (-2)) return;
   const int st = d.pitch;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
@@ -93,9 +94,10 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
             const double *__restrict__ uh, const double *__restrict__ vh, const double *__restrict__ q,
             const double *__restrict__ absv, const double *__restrict__ KE, double *__restrict__ CAu,
             double *__restrict__ CAv, int scheme, int bound) {
-  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < (-1)) return;
   const int st = d.pitch;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
@@ -157,9 +159,10 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
 // PressureForce_FV_Bouss, pass 1: interface heights bottom-up (:1200-1202) on (-1..ni, -1..nj).
 __global__ void __launch_bounds__(256)
 k_pgf_e(Dm d, const double *__restrict__ G, const double *__restrict__ h, double *__restrict__ e, double H_to_Z) {
-  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni || j > d.nj) return;
+  if (i < (-1)) return;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   double ek = -gm(G, d, MOM6X_G_bathyT)[x];
   e[x + (size_t)d.nk * slab] = ek;
@@ -177,9 +180,10 @@ k_pgf_main(Dm d, const double *__restrict__ G, const double *__restrict__ h, con
            double *__restrict__ PFv, double *__restrict__ pbce, double *__restrict__ eta, double g_Earth,
            double H_to_Z, double Z_to_H, double rho_ref, double GxRho_ref, double Z_ref, double I_Rho0,
            double h_neglect, double dz_neglect) {
-  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni || j > d.nj) return;
+  if (i < (-1)) return;
   const int st = d.pitch, nz = d.nk;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const bool do_u = (i <= d.ni - 1) && (j >= 0) && (j <= d.nj - 1);
@@ -235,9 +239,10 @@ __global__ void __launch_bounds__(256)
 k_vertvisc(Dm d, const double *__restrict__ G, double *__restrict__ u, const double *__restrict__ a_u,
            const double *__restrict__ h_u, const double *__restrict__ Ray_u, const double *__restrict__ tau,
            double *__restrict__ c1, double dt, double dt_Rho0, double H_to_RZ, double *__restrict__ tau_bot) {
-  const int i = (DIR ? 0 : -1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < ((DIR ? 0 : -1))) return;
   const int nz = d.nk;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
@@ -281,9 +286,10 @@ template <int DIR>
 __global__ void __launch_bounds__(256)
 k_vertvisc_remnant(Dm d, const double *__restrict__ G, double *__restrict__ vr, const double *__restrict__ a_u,
                    const double *__restrict__ h_u, const double *__restrict__ Ray_u, double *__restrict__ c1, double dt) {
-  const int i = (DIR ? 0 : -1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < ((DIR ? 0 : -1))) return;
   const int nz = d.nk;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
@@ -348,9 +354,9 @@ extern "C" int mom6x_CorAdCalc(mom6x_ctx *c, const double *u, const double *v, c
   if (c->cor.bound_Coriolis && (rc = ctx_scratch(c, SCR_absv, d.nk, &absv))) return rc;
   const dim3 b = blk2();
   const double vol_neglect = c->GV.H_subroundoff * ((1e-4 * 1.0) * (1e-4 * 1.0));
-  KLAUNCH(c, "k_corad_q", k_corad_q, gridk(d.ni + 3, d.nj + 3, d.nk, b), b, d, c->G, u, v, h, q, absv, KE,
+  KLAUNCH(c, "k_corad_q", k_corad_q, gridk(nxa(d.ni + 3, -2), d.nj + 3, d.nk, b), b, d, c->G, u, v, h, q, absv, KE,
           c->cor.no_slip, c->cor.KE_Scheme, vol_neglect);
-  KLAUNCH(c, "k_corad_acc", k_corad_acc, gridk(d.ni + 1, d.nj + 1, d.nk, b), b, d, c->G, u, v, uh, vh, q, absv, KE,
+  KLAUNCH(c, "k_corad_acc", k_corad_acc, gridk(nxa(d.ni + 1, -1), d.nj + 1, d.nk, b), b, d, c->G, u, v, uh, vh, q, absv, KE,
           CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
@@ -380,8 +386,8 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
   const mom6x_vgrid &GV = c->GV;
   const double GxRho0 = GV.g_Earth * GV.Rho0;
   const double GxRho_ref = c->pgf.rho_ref_bug ? GxRho0 : GV.g_Earth * c->pgf.rho_ref;
-  KLAUNCH(c, "k_pgf_e", k_pgf_e, grid3(d.ni + 2, d.nj + 2, 1, b), b, d, c->G, h, e, GV.H_to_Z);
-  KLAUNCH(c, "k_pgf_main", k_pgf_main, grid3(d.ni + 2, d.nj + 2, 1, b), b, d, c->G, h, e, c->Rlay, c->g_prime, PFu, PFv,
+  KLAUNCH(c, "k_pgf_e", k_pgf_e, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, c->G, h, e, GV.H_to_Z);
+  KLAUNCH(c, "k_pgf_main", k_pgf_main, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, c->G, h, e, c->Rlay, c->g_prime, PFu, PFv,
           pbce, eta, GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, 1.0 / GV.Rho0,
           GV.H_subroundoff, GV.dZ_subroundoff);
   HIPCHK(hipGetLastError());
@@ -402,9 +408,10 @@ k_vertvisc_fused(Dm d, const double *__restrict__ G, const double *u_in, const d
                  const double *__restrict__ a_u, const double *__restrict__ h_u, const double *__restrict__ Ray_u,
                  const double *__restrict__ tau, double *__restrict__ c1, double dt, double dt_Rho0, double H_to_RZ,
                  double *__restrict__ tau_bot) {
-  const int i = (DIR ? 0 : -1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < ((DIR ? 0 : -1))) return;
   const int nz = d.nk;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
@@ -421,6 +428,7 @@ k_vertvisc_fused(Dm d, const double *__restrict__ G, const double *u_in, const d
     u[x] = uprev;
     double rprev = b1 * hu;
     if (REM) vr[x] = rprev;
+#pragma unroll 4
     for (int k = 1; k < nz; k++) {
       const size_t x3 = x + (size_t)k * slab;
       if (Ray_u) Ray = Ray_u[x3];
@@ -435,6 +443,7 @@ k_vertvisc_fused(Dm d, const double *__restrict__ G, const double *u_in, const d
       u[x3] = uprev;
       if (REM) { rprev = (hu + dt * a_k * rprev) * b1; vr[x3] = rprev; }
     }
+#pragma unroll 4
     for (int k = nz - 2; k >= 0; k--) {
       const size_t x3 = x + (size_t)k * slab;
       const double ck = c1[x3 + slab];
@@ -461,7 +470,7 @@ static void launch_vertvisc_fused(mom6x_ctx *c, bool upd, bool rem, const double
                                   const double *Ray, const double *tau, double *c1, double dt, double *tau_bot) {
   const Dm d = c->d;
   const dim3 b = blk2();
-  const dim3 g = DIR ? grid3(d.ni, d.nj + 1, 1, b) : grid3(d.ni + 1, d.nj, 1, b);
+  const dim3 g = DIR ? grid3(d.ni, d.nj + 1, 1, b) : grid3(nxa(d.ni + 1, -1), d.nj, 1, b);
   const double dt_Rho0 = dt / c->GV.H_to_RZ, HR = c->GV.H_to_RZ;
   const char *nm = DIR ? "k_vertvisc_fused<1>" : "k_vertvisc_fused<0>";
 #define VVF(U, R) KLAUNCH(c, nm, (k_vertvisc_fused<DIR, U, R>), g, b, d, c->G, u_in, u_bc, u_abt, dtx, u, vr, a, h, Ray, tau, c1, dt, dt_Rho0, HR, tau_bot)
@@ -508,7 +517,7 @@ extern "C" int mom6x_vertvisc(mom6x_ctx *c, double *u, double *v, const double *
   if ((rc = ctx_scratch(c, SCR_c1, d.nk, &c1))) return rc;
   const dim3 b = blk2();
   const double dt_Rho0 = dt / c->GV.H_to_RZ;
-  KLAUNCH(c, "k_vertvisc<0>", k_vertvisc<0>, grid3(d.ni + 1, d.nj, 1, b), b, d, c->G, u, c->a_u, c->h_u, c->Ray_u, taux, c1, dt,
+  KLAUNCH(c, "k_vertvisc<0>", k_vertvisc<0>, grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, u, c->a_u, c->h_u, c->Ray_u, taux, c1, dt,
           dt_Rho0, c->GV.H_to_RZ, taux_bot);
   KLAUNCH(c, "k_vertvisc<1>", k_vertvisc<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, v, c->a_v, c->h_v, c->Ray_v, tauy, c1, dt,
           dt_Rho0, c->GV.H_to_RZ, tauy_bot);
@@ -525,7 +534,7 @@ extern "C" int mom6x_vertvisc_remnant(mom6x_ctx *c, double *visc_rem_u, double *
   int rc;
   if ((rc = ctx_scratch(c, SCR_c1, d.nk, &c1))) return rc;
   const dim3 b = blk2();
-  KLAUNCH(c, "k_vertvisc_remnant<0>", k_vertvisc_remnant<0>, grid3(d.ni + 1, d.nj, 1, b), b, d, c->G, visc_rem_u, c->a_u, c->h_u,
+  KLAUNCH(c, "k_vertvisc_remnant<0>", k_vertvisc_remnant<0>, grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, visc_rem_u, c->a_u, c->h_u,
           c->Ray_u, c1, dt);
   KLAUNCH(c, "k_vertvisc_remnant<1>", k_vertvisc_remnant<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, visc_rem_v, c->a_v, c->h_v,
           c->Ray_v, c1, dt);

@@ -34,9 +34,10 @@ k_bc_accel(Dm d, const double *__restrict__ G, const double *__restrict__ CAu, c
            const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc,
            const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ up, double *__restrict__ vp,
            double dt) {
-  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < (-1)) return;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
   const bool do_u = (j >= 0), do_v = (i >= 0);
@@ -61,9 +62,10 @@ __global__ void __launch_bounds__(256)
 k_vel_update(Dm d, const double *__restrict__ G, const double *u, const double *v, const double *__restrict__ u_bc,
              const double *__restrict__ v_bc, const double *__restrict__ u_abt, const double *__restrict__ v_abt,
              double *uo, double *vo, double dtx) {
-  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < (-1)) return;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
   const bool do_u = (j >= 0), do_v = (i >= 0);
@@ -79,9 +81,10 @@ k_vel_update(Dm d, const double *__restrict__ G, const double *u, const double *
 // 2: 0.5*(h_av + a) (:1064-1066); 3: hp = (1-w)*a + w*hp on (is-1..ie+1) (:828-830)
 __global__ void __launch_bounds__(256)
 k_h_av(Dm d, double *h_av, const double *__restrict__ a, const double *__restrict__ b, int mode, double w, int ext) {
-  const int i = -ext + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(-ext) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -ext + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 + ext || j > d.nj - 1 + ext) return;
+  if (i < (-ext)) return;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
   for (int k = k0; k < k1; k++) {
@@ -97,9 +100,10 @@ k_h_av(Dm d, double *h_av, const double *__restrict__ a, const double *__restric
 __global__ void __launch_bounds__(256)
 k_uhtr(Dm d, double *__restrict__ uhtr, double *__restrict__ vhtr, const double *__restrict__ uh,
        const double *__restrict__ vh, double dt) {
-  const int i = -3 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(-3) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -3 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni + 1 || j > d.nj + 1) return;
+  if (i < (-3)) return;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
   const bool do_u = (j >= -2), do_v = (i >= -2);
@@ -215,7 +219,7 @@ extern "C" int mom6x_dyn_split_RK2_new_run(mom6x_ctx *c, const double *u, const 
   CHK(mom6x_continuity_PPM(c, s->u_av, s->v_av, h, h_tmp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            nullptr, nullptr, nullptr));
   pass3(c, { h_tmp }, { 0 }, d.nk);
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 2 * d.halo, d.nj + 2 * d.halo, d.nk, b), b, d, s->h_av, h, (const double *)h_tmp, 0, 0.0, d.halo);
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2 * d.halo, -d.halo), d.nj + 2 * d.halo, d.nk, b), b, d, s->h_av, h, (const double *)h_tmp, 0, 0.0, d.halo);
   pass3(c, { s->u_av, s->v_av, uh, vh }, { 1, 2, 1, 2 }, d.nk);
   CHK(mom6x_CorAdCalc(c, s->u_av, s->v_av, s->h_av, uh, vh, s->CAu_pred, s->CAv_pred));
   s->CAu_pred_stored = true;
@@ -259,9 +263,12 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   // PFu = d/dx M(h,T,S) ; pbce = dM/deta  :503
   CHK(mom6x_PressureForce(c, h, s->PFu, s->PFv, s->pbce, s->eta_PF));
   if (!s->CAu_pred_stored) CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));   // :552-557
-  // u_bc_accel = CAu_pred + PFu + diffu ; up = mask*(u + dt*u_bc_accel)  :564-598
-  KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv,
-          s->diffu, s->diffv, u_bc, v_bc, (const double *)u_inst, (const double *)v_inst, up, vp, dt);
+  // u_bc_accel = CAu_pred + PFu + diffu ; up = mask*(u + dt*u_bc_accel)  :564-598.  up/vp at this point only feed
+  // vertvisc_coef (:602-609) and are recomputed at :681-694, so they are formed only when that callback exists.
+  const bool host_coef = (hooks && hooks->vertvisc_coef);
+  KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv,
+          s->diffu, s->diffv, u_bc, v_bc, (const double *)u_inst, (const double *)v_inst, host_coef ? up : (double *)nullptr,
+          host_coef ? vp : (double *)nullptr, dt);
   CHK(coef_hook(0, up, vp, dt));                                        // :602-609
   CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :610
   passn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk });   // pass_eta :620 + pass_visc_rem :621
@@ -278,15 +285,14 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
                    s->uh_in, s->vh_in, u_inst, v_inst, nullptr));
 
   const double dt_pred = dt * R.be;                                     // :679
-  const bool host_coef = (hooks && hooks->vertvisc_coef);   // the callback needs up/vp before the solve: no fusion
-  if (!host_coef) {
+  if (!host_coef) {   // (with the callback, it needs up/vp before the solve: no fusion)
     // :681-694 + :754 + :763-767 in one column sweep per direction (k_vertvisc_fused)
     const bool same_dt = (R.visc_rem_dt_bug != 0);
     CHK(vertvisc_fused(c, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt_pred, up, vp, taux, tauy, dt_pred,
                        s->taux_bot, s->tauy_bot, same_dt ? s->visc_rem_u : nullptr, same_dt ? s->visc_rem_v : nullptr));
     if (!same_dt) CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));
   } else {
-    KLAUNCH(c, "k_vel_update", k_vel_update, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
+    KLAUNCH(c, "k_vel_update", k_vel_update, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
             (const double *)v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, up, vp, dt_pred);   // :681-694
     CHK(coef_hook(1, up, vp, dt_pred));                                   // :737-738
     CHK(mom6x_vertvisc(c, up, vp, taux, tauy, dt_pred, s->taux_bot, s->tauy_bot));                 // :754
@@ -298,12 +304,12 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   CHK(mom6x_continuity_PPM(c, up, vp, h, hp, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av, &s->BT,
                            nullptr, nullptr));
   pass3(c, { hp, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);          // pass_hp_uv :785
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 4, d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)hp, 0, 0.0, 2);   // :808-810
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)hp, 0, 0.0, 2);   // :808-810
 
   // ---- corrector
   CHK(mom6x_bt_mass_source(c, hp, s->eta_pred, 0));                     // :820
   if (R.begw != 0.0) {                                                  // :822-833
-    KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 2, d.nj + 2, nk, b), b, d, hp, (const double *)h, (const double *)nullptr, 3, R.begw, 1);
+    KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2, -1), d.nj + 2, nk, b), b, d, hp, (const double *)h, (const double *)nullptr, 3, R.begw, 1);
     CHK(mom6x_PressureForce(c, hp, s->PFu, s->PFv, s->pbce, s->eta_PF));
   }
   CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :864-867
@@ -313,7 +319,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     REQUIRE(rc == 0, MOM6X_EINVAL, "step_MOM_dyn_split_RK2: horizontal_viscosity callback failed");
   }
   CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu, s->CAv));    // :893
-  KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, s->CAu, s->CAv, s->PFu, s->PFv, s->diffu,
+  KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, s->CAu, s->CAv, s->PFu, s->PFv, s->diffu,
           s->diffv, u_bc, v_bc, (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, dt);   // :900-907
   // corrector btstep :939-942
   CHK(mom6x_btstep(c, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, s->pbce, s->eta_PF, u_av, v_av, s->u_accel_bt,
@@ -325,20 +331,20 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     CHK(vertvisc_fused(c, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt, u_inst, v_inst, taux, tauy, dt,
                        s->taux_bot, s->tauy_bot, s->visc_rem_u, s->visc_rem_v));
   } else {
-    KLAUNCH(c, "k_vel_update", k_vel_update, gridk(d.ni + 1, d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
+    KLAUNCH(c, "k_vel_update", k_vel_update, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
             (const double *)v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, u_inst, v_inst, dt);
     CHK(coef_hook(2, u_inst, v_inst, dt));                                // :1002-1003
     CHK(mom6x_vertvisc(c, u_inst, v_inst, taux, tauy, dt, s->taux_bot, s->tauy_bot));   // :1013
     CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :1022
   }
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 4, d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2);   // :1025-1027
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2);   // :1025-1027
   pass3(c, { s->visc_rem_u, s->visc_rem_v, u_inst, v_inst }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :1030 + pass_uv :1034
   // uh = u_av * h ; h = h + dt * div . uh  :1041-1043
   CHK(mom6x_continuity_PPM(c, u_inst, v_inst, h, h, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av,
                            nullptr, nullptr, nullptr));
   pass3(c, { h, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);           // pass_h :1045 + pass_av_uvh :1053
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(d.ni + 4, d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2);   // :1064-1066
-  KLAUNCH(c, "k_uhtr", k_uhtr, gridk(d.ni + 5, d.nj + 5, nk, b), b, d, uhtr, vhtr, (const double *)uh, (const double *)vh, dt);   // :1072-1079
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2);   // :1064-1066
+  KLAUNCH(c, "k_uhtr", k_uhtr, gridk(nxa(d.ni + 5, -3), d.nj + 5, nk, b), b, d, uhtr, vhtr, (const double *)uh, (const double *)vh, dt);   // :1072-1079
   // CAu_pred for the next step :1081-1090
   CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));
   s->CAu_pred_stored = true;

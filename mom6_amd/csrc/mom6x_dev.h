@@ -111,6 +111,14 @@ int vertvisc_fused(mom6x_ctx *c, const double *u_in, const double *v_in, const d
 #define KCHUNK 15
 inline int nchunks(int nk) { return (nk + KCHUNK - 1) / KCHUNK; }
 
+// The i-parallel kernels whose first index I0 is negative (u-points start at -1, widened loops at -2, -3) start
+// their blocks at i = -IAL, a 128-byte line of the pitched rows (ioff = 16): every wavefront then reads and writes
+// whole cache lines instead of sharing its first and last line with the neighbouring block (which usually runs
+// on another XCD, i.e. behind another L2).  Lanes below I0 exit.  nxa() is the matching grid extent.
+#define IAL 16
+#define I_BASE(I0) (((I0) < 0) ? -IAL : (I0))
+inline int nxa(int nx, int I0) { return (I0 < 0) ? nx + IAL + I0 : nx; }
+
 inline dim3 grid3(int nx, int ny, int nz, dim3 b) {
   return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z);
 }
