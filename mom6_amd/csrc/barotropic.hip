@@ -415,9 +415,9 @@ struct LoopArgs {
 // eta_sum accumulation of btloop_find_PF :3104-3108 over the computational domain.
 __global__ void __launch_bounds__(256)
 k_bt_pred(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
-  const int i = A.isv - 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(A.isv - 1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = A.jsv - 1 + blockIdx.y * blockDim.y + threadIdx.y;
-  if (i > A.iev + 1 || j > A.jev + 1) return;
+  if (i < A.isv - 1 || i > A.iev + 1 || j > A.jev + 1) return;
   const int st = d.pitch;
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   double eta_PF_BT;
@@ -445,9 +445,9 @@ template <int DIR>
 __global__ void __launch_bounds__(256)
 k_bt_vel(Dm d, const double *__restrict__ G, double *work, double *btav, double *hbtav, LoopArgs A,
          int a0, int a1, int b0, int b1, int bracket_bug) {
-  const int i = a0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(a0) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = b0 + blockIdx.y * blockDim.y + threadIdx.y;
-  if (i > a1 || j > b1) return;
+  if (i < a0 || i > a1 || j > b1) return;
   const int st = d.pitch;
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   const double *etaB = work + (A.project ? W_eta : W_eta_pred) * slab;
@@ -500,9 +500,9 @@ k_bt_vel(Dm d, const double *__restrict__ G, double *work, double *btav, double 
 // eta corrector :2721-2727
 __global__ void __launch_bounds__(256)
 k_bt_eta(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
-  const int i = A.isv + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(A.isv) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = A.jsv + blockIdx.y * blockDim.y + threadIdx.y;
-  if (i > A.iev || j > A.jev) return;
+  if (i < A.isv || i > A.iev || j > A.jev) return;
   const int st = d.pitch;
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   const double *uhbt = work + W_uhbt * slab, *vhbt = work + W_vhbt * slab;
@@ -852,20 +852,20 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     L.isv = isv; L.iev = iev; L.jsv = jsv; L.jev = jev;
     L.wt_accel = wt_accel[n]; L.wt_trans = wt_trans[n]; L.wt_vel = wt_vel[n]; L.wt_eta = wt_eta[n]; L.wt_accel2 = wt_accel2[n];
     if (!P.BT_project_velocity || L.find_etaav)
-      KLAUNCH(c, "k_bt_pred", k_bt_pred, grid3(iev - isv + 3, jev - jsv + 3, 1, b), b, d, c->G, work, L);
+      KLAUNCH(c, "k_bt_pred", k_bt_pred, grid3(nxa(iev - isv + 3, isv - 1), jev - jsv + 3, 1, b), b, d, c->G, work, L);
     const bool v_first = (((n + c->first_direction) % 2) == 1);
     if (v_first) {
-      KLAUNCH(c, "k_bt_vel<1>", k_bt_vel<1>, grid3(iev - isv + 3, jev - jsv + 2, 1, b), b, d, c->G, work, s->vbtav, vhbtav, L,
+      KLAUNCH(c, "k_bt_vel<1>", k_bt_vel<1>, grid3(nxa(iev - isv + 3, isv - 1), jev - jsv + 2, 1, b), b, d, c->G, work, s->vbtav, vhbtav, L,
                          isv - 1, iev + 1, jsv - 1, jev, 0);
-      KLAUNCH(c, "k_bt_vel<0>", k_bt_vel<0>, grid3(iev - isv + 2, jev - jsv + 1, 1, b), b, d, c->G, work, s->ubtav, uhbtav, L,
+      KLAUNCH(c, "k_bt_vel<0>", k_bt_vel<0>, grid3(nxa(iev - isv + 2, isv - 1), jev - jsv + 1, 1, b), b, d, c->G, work, s->ubtav, uhbtav, L,
                          isv - 1, iev, jsv, jev, 0);
     } else {
-      KLAUNCH(c, "k_bt_vel<0>", k_bt_vel<0>, grid3(iev - isv + 2, jev - jsv + 3, 1, b), b, d, c->G, work, s->ubtav, uhbtav, L,
+      KLAUNCH(c, "k_bt_vel<0>", k_bt_vel<0>, grid3(nxa(iev - isv + 2, isv - 1), jev - jsv + 3, 1, b), b, d, c->G, work, s->ubtav, uhbtav, L,
                          isv - 1, iev, jsv - 1, jev + 1, 0);
-      KLAUNCH(c, "k_bt_vel<1>", k_bt_vel<1>, grid3(iev - isv + 1, jev - jsv + 2, 1, b), b, d, c->G, work, s->vbtav, vhbtav, L,
+      KLAUNCH(c, "k_bt_vel<1>", k_bt_vel<1>, grid3(nxa(iev - isv + 1, isv), jev - jsv + 2, 1, b), b, d, c->G, work, s->vbtav, vhbtav, L,
                          isv, iev, jsv - 1, jev, P.use_old_coriolis_bracket_bug);
     }
-    KLAUNCH(c, "k_bt_eta", k_bt_eta, grid3(iev - isv + 1, jev - jsv + 1, 1, b), b, d, c->G, work, L);
+    KLAUNCH(c, "k_bt_eta", k_bt_eta, grid3(nxa(iev - isv + 1, isv), jev - jsv + 1, 1, b), b, d, c->G, work, L);
   }
 
   // ---- after the loop

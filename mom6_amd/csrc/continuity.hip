@@ -304,10 +304,10 @@ template <int DIR>
 __global__ void __launch_bounds__(256)
 k_convergence(Dm d, const double *__restrict__ G, double *h, const double *__restrict__ uh, double dt,
               const double *hin, double h_min, int i0, int i1, int j0, int j1) {
-  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
-  if (i > i1 || j > j1) return;
+  if (i < i0 || i > i1 || j > j1) return;
   const int st = DIR ? d.pitch : 1;
   const size_t c2 = ix2(d, i, j), c = c2 + (size_t)k * d.slab;
   const double IareaT = gm(G, d, MOM6X_G_IareaT)[c2];
@@ -360,7 +360,7 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
                          P.marginal_faces, visc_rem, A.a0, A.a1, A.b0, A.b1);
     }
   }
-  KLAUNCH(c, "k_convergence<DIR>", k_convergence<DIR>, grid3(ieh - ish + 1, jeh - jsh + 1, d.nk, blk), blk, d, c->G,
+  KLAUNCH(c, "k_convergence<DIR>", k_convergence<DIR>, grid3(nxa(ieh - ish + 1, ish), jeh - jsh + 1, d.nk, blk), blk, d, c->G,
                      h, uh, dt, hin_conv, h_min_conv, ish, ieh, jsh, jeh);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;

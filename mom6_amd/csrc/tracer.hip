@@ -82,10 +82,10 @@ __device__ double face_flux(int scheme, const double *__restrict__ T, const doub
 __global__ void __launch_bounds__(256)
 k_ta_init(Dm d, const double *__restrict__ G, const double *__restrict__ h_end, const double *__restrict__ uhtr,
           const double *__restrict__ vhtr, double *__restrict__ hprev, double *__restrict__ uhr, double *__restrict__ vhr) {
-  const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
-  if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < -1 || i > d.ni - 1 || j > d.nj - 1) return;
   const int st = d.pitch;
   const size_t c2 = ix2(d, i, j), c = c2 + (size_t)k * d.slab;
   if (j >= 0) uhr[c] = uhtr[c];
@@ -142,10 +142,10 @@ __global__ void __launch_bounds__(256)
 k_ta_face(Dm d, const double *__restrict__ G, const double *__restrict__ uhr, const double *__restrict__ hprev, TrList Tr,
           double *__restrict__ uhh_out, FluxList F, const int *__restrict__ dm, int *__restrict__ lim,
           const int *__restrict__ dmk, double min_h, int a0, int a1, int b0, int b1) {
-  const int i = a0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(a0) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = b0 + blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
-  if (i > a1 || j > b1 || dmk[k] <= 0) return;
+  if (i < a0 || i > a1 || j > b1 || dmk[k] <= 0) return;
   const int st = DIR ? d.pitch : 1;
   const int nrows = d.nj + 2 * d.halo + 1;
   const size_t f2 = ix2(d, i, j), f = f2 + (size_t)k * d.slab;
@@ -189,10 +189,10 @@ __global__ void __launch_bounds__(256)
 k_ta_cell(Dm d, const double *__restrict__ G, double *__restrict__ uhr, double *__restrict__ hprev, TrList Tr,
           const double *__restrict__ uhh, FluxList F, const int *__restrict__ dm, const int *__restrict__ dmk,
           double h_neglect, double H_subroundoff, int a0, int a1, int b0, int b1, int ci0, int cj0) {
-  const int i = a0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = I_BASE(a0) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = b0 + blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
-  if (i > a1 || j > b1 || dmk[k] <= 0) return;
+  if (i < a0 || i > a1 || j > b1 || dmk[k] <= 0) return;
   const int st = DIR ? d.pitch : 1;
   const int nrows = d.nj + 2 * d.halo + 1;
   const size_t c2 = ix2(d, i, j), c = c2 + (size_t)k * d.slab;
@@ -351,12 +351,12 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
   for (int *p : { s->dmu, s->dmv, s->limu, s->limv }) HIPCHK(hipMemsetAsync(p, 0, nf * sizeof(int), st));
   std::vector<int> ones(nz, 1), dmk_h(nz, 1);
   HIPCHK(hipMemcpyAsync(s->dmk, ones.data(), nz * sizeof(int), hipMemcpyHostToDevice, st));
-  KLAUNCH(c, "k_ta_init", k_ta_init, grid3(d.ni + 1, d.nj + 1, nz, b), b, d, c->G, h_end, uhtr, vhtr, s->hprev, s->uhr, s->vhr);
+  KLAUNCH(c, "k_ta_init", k_ta_init, grid3(nxa(d.ni + 1, -1), d.nj + 1, nz, b), b, d, c->G, h_end, uhtr, vhtr, s->hprev, s->uhr, s->vhr);
 
   auto advect = [&](int dir, int i0, int i1, int j0, int j1) {
     // faces: x: (i0-1..i1, j0..j1); y: (i0..i1, j0-1..j1)
     const int a0 = dir ? i0 : i0 - 1, b0 = dir ? j0 - 1 : j0;
-    const dim3 g = grid3(i1 - a0 + 1, j1 - b0 + 1, nz, b);
+    const dim3 g = grid3(nxa(i1 - a0 + 1, a0), j1 - b0 + 1, nz, b);
     if (dir == 0) {
       KLAUNCH(c, "k_ta_face<0>", k_ta_face<0>, g, b, d, c->G, (const double *)s->uhr, (const double *)s->hprev, Tr, s->uhh, F,
               (const int *)s->dmu, s->limu, (const int *)s->dmk, min_h, a0, i1, b0, j1);
