@@ -9,7 +9,8 @@ module mom6x_c_api
   implicit none ; private
 
   public :: mom6x_dims, mom6x_vgrid, mom6x_continuity_params, mom6x_BT_cont, mom6x_barotropic_params
-  public :: mom6x_coriolis_params, mom6x_pgf_params, mom6x_rk2_params, mom6x_rk2_hooks
+  public :: mom6x_coriolis_params, mom6x_pgf_params, mom6x_eos_params, mom6x_rk2_params, mom6x_rk2_hooks
+  public :: mom6x_PressureForce_set_tv
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
   public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
   public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc
@@ -65,6 +66,12 @@ module mom6x_c_api
     integer(c_int) :: rho_ref_bug
     real(c_double) :: Z_ref
   end type mom6x_pgf_params
+
+  type, bind(C) :: mom6x_eos_params        !< tv%eqn_of_state (MOM_EOS.F90:99-150) + EOS-only switches of PressureForce_FV_CS
+    integer(c_int) :: form                 !< 1 EOS_LINEAR, 2 EOS_WRIGHT
+    real(c_double) :: Rho_T0_S0, dRho_dT, dRho_dS, dRho_dp
+    integer(c_int) :: MassWghtInterp, use_SSH_in_Z0p
+  end type mom6x_eos_params
 
   type, bind(C) :: mom6x_rk2_params        !< MOM_dyn_split_RK2_CS (MOM_dynamics_split_RK2.F90:85-273)
     real(c_double) :: be, begw
@@ -181,6 +188,11 @@ module mom6x_c_api
       import :: c_int, c_ptr ; type(c_ptr), value :: ctx, h, PFu, PFv, pbce, eta
     end function
     !> vertvisc :557 / vertvisc_remnant :1229 (MOM_vert_friction.F90); coefficients from vertvisc_coef :1357
+    !> tv%T, tv%S (device), tv%eqn_of_state for the use_EOS branch of PressureForce_FV_Bouss (FV.F90:1206)
+    integer(c_int) function mom6x_PressureForce_set_tv(ctx, T, S, eos) bind(C, name="mom6x_PressureForce_set_tv")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, T, S, eos
+    end function
     integer(c_int) function mom6x_vertvisc_set_coef(ctx, a_u, a_v, h_u, h_v, Ray_u, Ray_v) &
         bind(C, name="mom6x_vertvisc_set_coef")
       import :: c_int, c_ptr ; type(c_ptr), value :: ctx, a_u, a_v, h_u, h_v, Ray_u, Ray_v

@@ -164,6 +164,22 @@ typedef struct mom6x_pgf_params {
   double Z_ref;          /* G%Z_ref (0)                                                         */
 } mom6x_pgf_params;
 
+/* tv%eqn_of_state (EOS_type, src/equation_of_state/MOM_EOS.F90:99-150) and the switches of
+ * PressureForce_FV_CS that only matter with an equation of state.  Analytic density integrals
+ * (analytic_int_density_dz, MOM_EOS.F90:1384) exist for EOS_LINEAR and the WRIGHT family; LINEAR and
+ * WRIGHT (the default, MOM_EOS_Wright.F90) are implemented, WRIGHT_FULL / WRIGHT_REDUCED differ in
+ * constants and parenthesisation only and are rejected for now, as is EOS_QUADRATURE.          */
+enum mom6x_eos_form { MOM6X_EOS_LINEAR = 1, MOM6X_EOS_WRIGHT = 2 };
+typedef struct mom6x_eos_params {
+  int    form;            /* EQN_OF_STATE                                                       */
+  double Rho_T0_S0;       /* RHO_T0_S0 (1000)  } EOS_LINEAR                                     */
+  double dRho_dT;         /* DRHO_DT (-0.2)    }                                                */
+  double dRho_dS;         /* DRHO_DS (0.8)     }                                                */
+  double dRho_dp;         /* linear_EOS%dRho_dp (0)                                             */
+  int    MassWghtInterp;  /* bit 0: MASS_WEIGHT_IN_PRESSURE_GRADIENT, bit 1: ..._TOP (F, F)     */
+  int    use_SSH_in_Z0p;  /* SSH_IN_EOS_PRESSURE_FOR_PGF (F)                                    */
+} mom6x_eos_params;
+
 /* MOM_dyn_split_RK2_CS parameters (src/core/MOM_dynamics_split_RK2.F90:85-273, read in
  * initialize_dyn_split_RK2 :1427-1495).                                                     */
 typedef struct mom6x_rk2_params {
@@ -316,6 +332,12 @@ int mom6x_PressureForce_init(mom6x_ctx *ctx, const mom6x_pgf_params *p, const do
  * (tv%eqn_of_state unassociated) Boussinesq path; p_atm absent; pbce/eta nullable.       */
 int mom6x_PressureForce(mom6x_ctx *ctx, const double *h, double *PFu, double *PFv,
                         double *pbce, double *eta);
+/* The thermo_var_ptrs argument `tv` of PressureForce (:947): tv%T, tv%S (device, 3-D h-point arrays that
+ * stay owned by the caller) and tv%eqn_of_state.  Once set, mom6x_PressureForce -- and the PressureForce
+ * calls inside mom6x_step_dyn_split_RK2 -- take the use_EOS branch (:1206, :1289-1309: int_density_dz,
+ * and Set_pbce_Bouss :692-722).  T == NULL dissociates tv%eqn_of_state again (layered path).  Bulk mixed
+ * layers (GV%nk_rho_varies > 0) and ALE reconstructions are not on this path.                        */
+int mom6x_PressureForce_set_tv(mom6x_ctx *ctx, const double *T, const double *S, const mom6x_eos_params *eos);
 
 /* ------------------------------------------------------------------------- */
 /* MOM_vert_friction                                                           */

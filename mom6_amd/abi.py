@@ -162,6 +162,24 @@ class PGFParams(C.Structure):
     _fields_ = [("rho_ref", C.c_double), ("rho_ref_bug", C.c_int), ("Z_ref", C.c_double)]
 
 
+LINEAR, WRIGHT = 1, 2   # enum mom6x_eos_form
+
+
+class EOSParams(C.Structure):
+    """mom6x_eos_params: tv%eqn_of_state + the EOS-only switches of PressureForce_FV_CS."""
+    _fields_ = [("form", C.c_int), ("Rho_T0_S0", C.c_double), ("dRho_dT", C.c_double), ("dRho_dS", C.c_double),
+                ("dRho_dp", C.c_double), ("MassWghtInterp", C.c_int), ("use_SSH_in_Z0p", C.c_int)]
+
+
+def eos_params_default(form=WRIGHT):
+    """EQN_OF_STATE (default WRIGHT), RHO_T0_S0 = 1000, DRHO_DT = -0.2, DRHO_DS = 0.8 (MOM_EOS.F90:1562-1600)."""
+    p = EOSParams()
+    p.form = form
+    p.Rho_T0_S0 = 1000.0; p.dRho_dT = -0.2; p.dRho_dS = 0.8; p.dRho_dp = 0.0
+    p.MassWghtInterp = 0; p.use_SSH_in_Z0p = 0
+    return p
+
+
 def pgf_params_default(Rho0=1035.0):
     p = PGFParams()
     p.rho_ref, p.rho_ref_bug, p.Z_ref = Rho0, 1, 0.0

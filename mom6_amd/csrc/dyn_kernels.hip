@@ -362,6 +362,217 @@ extern "C" int mom6x_CorAdCalc(mom6x_ctx *c, const double *u, const double *v, c
   return MOM6X_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// PressureForce_FV_Bouss with an equation of state (:1206, :1289-1316): analytic_int_density_dz
+// (MOM_EOS.F90:1384) for EOS_LINEAR (MOM_EOS_linear.F90:275-475) and EOS_WRIGHT (MOM_EOS_Wright.F90:389-655),
+// and the use_EOS branch of Set_pbce_Bouss (MOM_PressureForce_Montgomery.F90:704-733).
+struct EosDev { int form; double Rho_T0_S0, dRho_dT, dRho_dS, dRho_dp; int do_mw, top_mw, ssh_z0; };
+
+namespace {
+constexpr double W_a0 = 7.057924e-4, W_a1 = 3.480336e-7, W_a2 = -1.112733e-7;
+constexpr double W_b0 = 5.790749e8, W_b1 = 3.516535e6, W_b2 = -4.002714e4, W_b3 = 2.084372e2, W_b4 = 5.944068e5, W_b5 = -9.643486e3;
+constexpr double W_c0 = 1.704853e5, W_c1 = 7.904722e2, W_c2 = -7.984422, W_c3 = 5.140652e-2, W_c4 = -2.302158e2, W_c5 = -3.079464;
+
+__device__ __forceinline__ void wright_coefs(double T, double S, double &al0, double &p0, double &lambda) {
+  al0 = (W_a0 + W_a1 * T) + W_a2 * S;
+  p0 = (W_b0 + W_b4 * S) + T * (W_b1 + T * ((W_b2 + W_b3 * T)) + W_b5 * S);
+  lambda = (W_c0 + W_c4 * S) + T * (W_c1 + T * ((W_c2 + W_c3 * T)) + W_c5 * S);
+}
+
+// dpa and intz_dpa of one cell (the first loop of int_density_dz_linear :373-384 / _wright :554-577)
+template <int FORM>
+__device__ __forceinline__ void cell_int(const EosDev &E, double rho_ref, double G_e, double GxRho, double I_Rho, double T,
+                                         double S, double zt, double zb, double z0, double &dpa, double &intz) {
+  const double dz = zt - zb;
+  const double p_ave = -GxRho * (0.5 * (zt + zb) - z0);
+  if (FORM == MOM6X_EOS_LINEAR) {
+    const double C1_6 = 1.0 / 6.0;
+    const double rho_anom = (E.Rho_T0_S0 - rho_ref) + E.dRho_dT * T + E.dRho_dS * S + E.dRho_dp * p_ave;
+    dpa = G_e * rho_anom * dz;
+    intz = 0.5 * G_e * (rho_anom - C1_6 * E.dRho_dp * (GxRho * dz)) * (dz * dz);
+  } else {
+    const double C1_3 = 1.0 / 3.0, C1_7 = 1.0 / 7.0, C1_9 = 1.0 / 9.0;
+    double al0, p0, lambda;
+    wright_coefs(T, S, al0, p0, lambda);
+    const double I_al0 = 1.0 / al0;
+    const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+    const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
+    const double rho_anom = (p0 + p_ave) * (I_Lzz * I_al0) - rho_ref;
+    const double rem = I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2)));
+    dpa = 1.0 * (G_e * rho_anom * dz - 2.0 * eps * rem);
+    intz = 1.0 * (0.5 * G_e * rho_anom * (dz * dz) - dz * (1.0 + eps) * rem);
+  }
+}
+
+// intx_dpa | inty_dpa of the face between columns L and R (:386-430 / :560-607)
+template <int FORM>
+__device__ __forceinline__ double face_int(const EosDev &E, double rho_ref, double G_e, double GxRho, double I_Rho, double TL,
+                                           double SL, double TR, double SR, double ztL, double zbL, double ztR, double zbR,
+                                           double z0L, double z0R, double bathyL, double bathyR, double sshL, double sshR,
+                                           double dz_neglect, double dpaL, double dpaR) {
+  const double C1_90 = 1.0 / 90.0;
+  double hWght = 0.0;
+  if (E.do_mw) hWght = dmax(dmax(0., -bathyL - ztR), -bathyR - ztL);
+  if (E.top_mw) hWght = dmax(dmax(hWght, zbR - sshL), zbL - sshR);
+  if (FORM == MOM6X_EOS_LINEAR && hWght <= 0.0) {
+    const double C1_6 = 1.0 / 6.0;
+    const double dzL = ztL - zbL, dzR = ztR - zbR;
+    double p_ave = -GxRho * (0.5 * (ztL + zbL) - z0L);
+    const double raL = (E.Rho_T0_S0 - rho_ref) + ((E.dRho_dT * TL + E.dRho_dS * SL) + E.dRho_dp * p_ave);
+    p_ave = -GxRho * (0.5 * (ztR + zbR) - z0R);
+    const double raR = (E.Rho_T0_S0 - rho_ref) + ((E.dRho_dT * TR + E.dRho_dS * SR) + E.dRho_dp * p_ave);
+    return G_e * C1_6 * ((dzL * (2.0 * raL + raR)) + (dzR * (2.0 * raR + raL)));
+  }
+  double LL = 1.0, LR = 0.0, RR = 1.0, RL = 0.0;
+  if (hWght > 0.) {
+    const double hL = (ztL - zbL) + dz_neglect, hR = (ztR - zbR) + dz_neglect;
+    const double q = (hL - hR) / (hL + hR);
+    hWght = hWght * (q * q);
+    const double iDenom = 1.0 / (hWght * (hR + hL) + hL * hR);
+    LL = (hWght * hL + hR * hL) * iDenom; LR = (hWght * hR) * iDenom;
+    RR = (hWght * hR + hR * hL) * iDenom; RL = (hWght * hL) * iDenom;
+  }
+  double al0L = 0., p0L = 0., lamL = 0., al0R = 0., p0R = 0., lamR = 0.;
+  if (FORM == MOM6X_EOS_WRIGHT) { wright_coefs(TL, SL, al0L, p0L, lamL); wright_coefs(TR, SR, al0R, p0R, lamR); }
+  double intz[5];
+  intz[0] = dpaL; intz[4] = dpaR;
+#pragma unroll
+  for (int m = 2; m <= 4; m++) {
+    const double wt_L = 0.25 * (double)(5 - m), wt_R = 1.0 - wt_L;
+    const double wtT_L = (wt_L * LL) + (wt_R * RL), wtT_R = (wt_L * LR) + (wt_R * RR);
+    const double dz = (wt_L * (ztL - zbL)) + (wt_R * (ztR - zbR));
+    const double p_ave = -GxRho * ((wt_L * (0.5 * (ztL + zbL) - z0L)) + (wt_R * (0.5 * (ztR + zbR) - z0R)));
+    if (FORM == MOM6X_EOS_LINEAR) {
+      const double rho_anom = (E.Rho_T0_S0 - rho_ref) +
+                              ((E.dRho_dT * ((wtT_L * TL) + (wtT_R * TR)) + E.dRho_dS * ((wtT_L * SL) + (wtT_R * SR))) + E.dRho_dp * p_ave);
+      intz[m - 1] = G_e * rho_anom * dz;
+    } else {
+      const double C1_3 = 1.0 / 3.0, C1_7 = 1.0 / 7.0, C1_9 = 1.0 / 9.0;
+      const double al0 = (wtT_L * al0L) + (wtT_R * al0R);
+      const double p0 = (wtT_L * p0L) + (wtT_R * p0R);
+      const double lambda = (wtT_L * lamL) + (wtT_R * lamR);
+      const double I_al0 = 1.0 / al0;
+      const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+      const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
+      intz[m - 1] = 1.0 * (G_e * dz * ((p0 + p_ave) * (I_Lzz * I_al0) - rho_ref) - 2.0 * eps *
+                           I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2))));
+    }
+  }
+  return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
+}
+
+// One thread per (i,j) column, top-down like k_pgf_main; the integrals of the east and north neighbours are
+// recomputed by this thread (no 3-D dpa / intz_dpa / intx_dpa arrays).
+template <int FORM>
+__global__ void __launch_bounds__(256)
+k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h, const double *__restrict__ e,
+               const double *__restrict__ Tv, const double *__restrict__ Sv, EosDev E, double *__restrict__ PFu,
+               double *__restrict__ PFv, double *__restrict__ pbce, double *__restrict__ eta, double g_Earth, double H_to_Z,
+               double Z_to_H, double rho_ref, double GxRho_ref, double Z_ref, double Rho0, double rho0_alt, double h_neglect,
+               double dz_neglect) {
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni || j > d.nj) return;
+  if (i < (-1)) return;
+  const int st = d.pitch, nz = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const bool do_u = (i <= d.ni - 1) && (j >= 0) && (j <= d.nj - 1);
+  const bool do_v = (j <= d.nj - 1) && (i >= 0) && (i <= d.ni - 1);
+  const double *bathyT = gm(G, d, MOM6X_G_bathyT);
+  const double I_Rho0 = 1.0 / Rho0;
+  const double G_e = g_Earth, GxRho = G_e * rho0_alt, I_Rho = 1.0 / rho0_alt;   // rho0_int_density :1134-1144
+  const double e_top = e[x], e_bot = e[x + (size_t)nz * slab];
+  if (eta) eta[x] = e_top * Z_to_H;
+  const double ssh0 = e_top, ssh1 = do_u ? e[x + 1] : 0.0, ssh2 = do_v ? e[x + st] : 0.0;
+  const double z00 = E.ssh_z0 ? ssh0 : Z_ref, z01 = E.ssh_z0 ? ssh1 : Z_ref, z02 = E.ssh_z0 ? ssh2 : Z_ref;   // Z_0p :1264-1276
+  const double b0 = bathyT[x], b1 = do_u ? bathyT[x + 1] : 0.0, b2 = do_v ? bathyT[x + st] : 0.0;
+  double pa0 = GxRho_ref * (e_top - Z_ref), pa1 = 0.0, pa2 = 0.0, intx_pa = 0.0, inty_pa = 0.0;
+  double cu = 0.0, cv = 0.0;
+  if (do_u) { pa1 = GxRho_ref * (ssh1 - Z_ref); intx_pa = 0.5 * (pa0 + pa1); cu = (2.0 * I_Rho0 * gm(G, d, MOM6X_G_IdxCu)[x]); }
+  if (do_v) { pa2 = GxRho_ref * (ssh2 - Z_ref); inty_pa = 0.5 * (pa0 + pa2); cv = (2.0 * I_Rho0 * gm(G, d, MOM6X_G_IdyCv)[x]); }
+  // Set_pbce_Bouss, use_EOS, no rho_star :704-733 (Rho0 argument = rho0_set_pbce = rho0_alt)
+  const double Rho0xG = rho0_alt * g_Earth, G_Rho0 = g_Earth / Rho0;
+  const double Ihtot = H_to_Z / ((e_top - e_bot) + dz_neglect);
+  double pb = 0.0, T_prev = 0.0, S_prev = 0.0;
+  double zt0 = e_top, zt1 = ssh1, zt2 = ssh2;
+  for (int k = 0; k < nz; k++) {
+    const size_t c = x + (size_t)k * slab, cb = c + slab;
+    const double h0 = h[c], T0 = Tv[c], S0 = Sv[c];
+    const double zb0 = e[cb];
+    double dpa0, iz0;
+    cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, zt0, zb0, z00, dpa0, iz0);
+    if (Z_to_H != 1.0) iz0 = iz0 * Z_to_H;
+    if (do_u) {
+      const double h1 = h[c + 1], T1 = Tv[c + 1], S1 = Sv[c + 1], zb1 = e[cb + 1];
+      double dpa1, iz1;
+      cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T1, S1, zt1, zb1, z01, dpa1, iz1);
+      if (Z_to_H != 1.0) iz1 = iz1 * Z_to_H;
+      const double intx_dpa = face_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, T1, S1, zt0, zb0, zt1, zb1, z00, z01, b0, b1,
+                                             ssh0, ssh1, dz_neglect, dpa0, dpa1);
+      PFu[c] = (((pa0 * h0 + iz0) - (pa1 * h1 + iz1)) + ((h1 - h0) * intx_pa - (zb1 - zb0) * intx_dpa * Z_to_H)) *
+               (cu / ((h0 + h1) + h_neglect));
+      pa1 = pa1 + dpa1;
+      intx_pa = intx_pa + intx_dpa;
+      zt1 = zb1;
+    }
+    if (do_v) {
+      const double h2 = h[c + st], T2 = Tv[c + st], S2 = Sv[c + st], zb2 = e[cb + st];
+      double dpa2, iz2;
+      cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T2, S2, zt2, zb2, z02, dpa2, iz2);
+      if (Z_to_H != 1.0) iz2 = iz2 * Z_to_H;
+      const double inty_dpa = face_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, T2, S2, zt0, zb0, zt2, zb2, z00, z02, b0, b2,
+                                             ssh0, ssh2, dz_neglect, dpa0, dpa2);
+      PFv[c] = (((pa0 * h0 + iz0) - (pa2 * h2 + iz2)) + ((h2 - h0) * inty_pa - (zb2 - zb0) * inty_dpa * Z_to_H)) *
+               (cv / ((h0 + h2) + h_neglect));
+      pa2 = pa2 + dpa2;
+      inty_pa = inty_pa + inty_dpa;
+      zt2 = zb2;
+    }
+    pa0 = pa0 + dpa0;
+    if (pbce) {
+      const double press = -Rho0xG * (zt0 - Z_ref);
+      if (k == 0) {
+        double rho_in_situ;
+        if (FORM == MOM6X_EOS_LINEAR) rho_in_situ = E.Rho_T0_S0 + E.dRho_dT * T0 + E.dRho_dS * S0 + E.dRho_dp * press;
+        else {
+          double al0, p0, lambda;
+          wright_coefs(T0, S0, al0, p0, lambda);
+          rho_in_situ = (press + p0) / (lambda + al0 * (press + p0));
+        }
+        pb = G_Rho0 * (1.0 * rho_in_situ) * H_to_Z;
+      } else {
+        const double T_int = 0.5 * (T_prev + T0), S_int = 0.5 * (S_prev + S0);
+        double dR_dT, dR_dS;
+        if (FORM == MOM6X_EOS_LINEAR) { dR_dT = E.dRho_dT; dR_dS = E.dRho_dS; }
+        else {
+          double al0, p0, lambda;
+          wright_coefs(T_int, S_int, al0, p0, lambda);
+          double I_denom2 = 1.0 / (lambda + al0 * (press + p0));
+          I_denom2 = I_denom2 * I_denom2;
+          dR_dT = I_denom2 * (lambda * (W_b1 + T_int * (2.0 * W_b2 + 3.0 * W_b3 * T_int) + W_b5 * S_int) -
+                              (press + p0) * ((press + p0) * W_a1 + (W_c1 + T_int * (W_c2 * 2.0 + W_c3 * 3.0 * T_int) + W_c5 * S_int)));
+          dR_dS = I_denom2 * (lambda * (W_b4 + W_b5 * T_int) - (press + p0) * ((press + p0) * W_a2 + (W_c4 + W_c5 * T_int)));
+        }
+        pb = pb + G_Rho0 * ((zt0 - e_bot) * Ihtot) * (dR_dT * (T0 - T_prev) + dR_dS * (S0 - S_prev));
+      }
+      pbce[c] = pb;
+    }
+    T_prev = T0; S_prev = S0;
+    zt0 = zb0;
+  }
+}
+}  // namespace
+
+extern "C" int mom6x_PressureForce_set_tv(mom6x_ctx *c, const double *T, const double *S, const mom6x_eos_params *eos) {
+  REQUIRE(c, MOM6X_EINVAL, "mom6x_PressureForce_set_tv: null ctx");
+  if (!T) { c->tv_T = nullptr; c->tv_S = nullptr; return MOM6X_OK; }
+  REQUIRE(S && eos, MOM6X_EINVAL, "mom6x_PressureForce_set_tv: tv%T without tv%S or tv%eqn_of_state");
+  REQUIRE(eos->form == MOM6X_EOS_LINEAR || eos->form == MOM6X_EOS_WRIGHT, MOM6X_EUNSUPPORTED,
+          "No analytic integration option is available with this EOS!");
+  c->tv_T = T; c->tv_S = S; c->eos = *eos;
+  return MOM6X_OK;
+}
+
 extern "C" int mom6x_PressureForce_init(mom6x_ctx *c, const mom6x_pgf_params *p, const double *Rlay, const double *g_prime) {
   REQUIRE(c && p && Rlay && g_prime, MOM6X_EINVAL, "mom6x_PressureForce_init: null argument");
   HIPCHK(hipSetDevice(c->device));
@@ -387,6 +598,24 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
   const double GxRho0 = GV.g_Earth * GV.Rho0;
   const double GxRho_ref = c->pgf.rho_ref_bug ? GxRho0 : GV.g_Earth * c->pgf.rho_ref;
   KLAUNCH(c, "k_pgf_e", k_pgf_e, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, c->G, h, e, GV.H_to_Z);
+  if (c->tv_T) {   // use_EOS = associated(tv%eqn_of_state) :1125
+    EosDev E;
+    E.form = c->eos.form; E.Rho_T0_S0 = c->eos.Rho_T0_S0; E.dRho_dT = c->eos.dRho_dT; E.dRho_dS = c->eos.dRho_dS;
+    E.dRho_dp = c->eos.dRho_dp; E.do_mw = c->eos.MassWghtInterp & 1; E.top_mw = (c->eos.MassWghtInterp >> 1) & 1;
+    E.ssh_z0 = c->eos.use_SSH_in_Z0p;
+    const double rho0_alt = c->pgf.rho_ref_bug ? c->pgf.rho_ref : GV.Rho0;   // rho0_int_density = rho0_set_pbce
+    const dim3 g = grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b);
+    if (E.form == MOM6X_EOS_LINEAR)
+      KLAUNCH(c, "k_pgf_main_eos<linear>", k_pgf_main_eos<MOM6X_EOS_LINEAR>, g, b, d, c->G, h, e, c->tv_T, c->tv_S, E, PFu, PFv, pbce, eta,
+              GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, GV.Rho0, rho0_alt, GV.H_subroundoff,
+              GV.dZ_subroundoff);
+    else
+      KLAUNCH(c, "k_pgf_main_eos<wright>", k_pgf_main_eos<MOM6X_EOS_WRIGHT>, g, b, d, c->G, h, e, c->tv_T, c->tv_S, E, PFu, PFv, pbce, eta,
+              GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, GV.Rho0, rho0_alt, GV.H_subroundoff,
+              GV.dZ_subroundoff);
+    HIPCHK(hipGetLastError());
+    return MOM6X_OK;
+  }
   KLAUNCH(c, "k_pgf_main", k_pgf_main, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, c->G, h, e, c->Rlay, c->g_prime, PFu, PFv,
           pbce, eta, GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, 1.0 / GV.Rho0,
           GV.H_subroundoff, GV.dZ_subroundoff);

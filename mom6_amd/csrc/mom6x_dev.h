@@ -76,6 +76,7 @@ struct mom6x_ctx {
   mom6x_coriolis_params cor; bool cor_init;
   mom6x_pgf_params pgf; bool pgf_init;
   double *Rlay, *g_prime;   // device copies of GV%Rlay, GV%g_prime (nk)
+  const double *tv_T, *tv_S; mom6x_eos_params eos;   // tv%T, tv%S, tv%eqn_of_state (null: layered PressureForce path)
   const double *a_u, *a_v, *h_u, *h_v, *Ray_u, *Ray_v;   // vertvisc coefficients (host-owned device arrays)
   // lazily allocated 3-D scratch arrays (slot -> nlev levels)
   double *scr[MOM6X_NSCR]; int scr_nlev[MOM6X_NSCR];

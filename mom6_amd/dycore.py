@@ -169,6 +169,11 @@ class Dycore:
         """PressureForce (MOM_PressureForce.F90:41) -> PressureForce_FV_Bouss (FV.F90:947)."""
         check(self.lib, self.lib.mom6x_PressureForce(self.ctx, _ptr(h), _ptr(PFu), _ptr(PFv), _ptr(pbce), _ptr(eta)))
 
+    def PressureForce_set_tv(self, T, S, eos):
+        """tv%T, tv%S, tv%eqn_of_state of PressureForce's thermo_var_ptrs argument; T=None: layered path."""
+        self._tv = (T, S, eos)
+        check(self.lib, self.lib.mom6x_PressureForce_set_tv(self.ctx, _ptr(T), _ptr(S), C.byref(eos) if eos is not None else None))
+
     # -- MOM_vert_friction -------------------------------------------------------------------
     def vertvisc_set_coef(self, a_u, a_v, h_u, h_v, Ray_u=None, Ray_v=None):
         """Hand CS%a_u, CS%a_v, CS%h_u, CS%h_v (and visc%Ray_u/v) of vertvisc_coef to the context."""

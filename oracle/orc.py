@@ -134,9 +134,10 @@ def CorAdCalc(d, G, GV, CS, u, v, h, uh, vh, CAu, CAv):
         raise RuntimeError(f"orc_CorAdCalc rc={rc}")
 
 
-def PressureForce(d, G, GV, CS, Rlay, g_prime, h, PFu, PFv, pbce=None, eta=None):
+def PressureForce(d, G, GV, CS, Rlay, g_prime, h, PFu, PFv, pbce=None, eta=None, T=None, S=None, eos=None):
     rc = lib().orc_PressureForce_FV_Bouss(C.byref(d), _p(G), C.byref(GV), C.byref(CS), _p(Rlay), _p(g_prime), _p(h),
-                                          _p(PFu), _p(PFv), _p(pbce), _p(eta))
+                                          _p(PFu), _p(PFv), _p(pbce), _p(eta), _p(T), _p(S),
+                                          C.byref(eos) if eos is not None else None)
     if rc != 0:
         raise RuntimeError(f"orc_PressureForce rc={rc}")
 
@@ -172,7 +173,8 @@ class Rk2CS(C.Structure):
 class Rk2All(C.Structure):
     _fields_ = [("d", C.c_void_p), ("G", C.c_void_p), ("GV", C.c_void_p), ("cont", C.c_void_p), ("bt", C.c_void_p),
                 ("cor", C.c_void_p), ("pgf", C.c_void_p), ("rk2", C.c_void_p), ("Rlay", C.c_void_p), ("g_prime", C.c_void_p),
-                ("CS", C.c_void_p), ("BTCS", C.c_void_p), ("BT_cont", C.c_void_p), ("first_direction", C.c_int)]
+                ("CS", C.c_void_p), ("BTCS", C.c_void_p), ("BT_cont", C.c_void_p), ("first_direction", C.c_int),
+                ("T", C.c_void_p), ("S", C.c_void_p), ("eos", C.c_void_p)]
 
 
 class OrcModel:
@@ -198,7 +200,15 @@ class OrcModel:
         A.Rlay = self.Rlay.ctypes.data; A.g_prime = self.g_prime.ctypes.data
         A.CS = C.addressof(self.cs); A.BTCS = C.addressof(self.btcs.struct); A.BT_cont = C.addressof(self.bt_cont_s)
         A.first_direction = first_direction
+        A.T = None; A.S = None; A.eos = None
         self.A = A
+
+    def set_tv(self, T, S, eos):
+        """tv%T, tv%S, tv%eqn_of_state for the PressureForce calls of the step (None: layered path)."""
+        self._tv = (T, S, eos)
+        self.A.T = T.ctypes.data if T is not None else None
+        self.A.S = S.ctypes.data if S is not None else None
+        self.A.eos = C.addressof(eos) if eos is not None else None
 
     def __getitem__(self, n):
         return self.f[n]

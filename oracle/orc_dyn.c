@@ -151,10 +151,126 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* PressureForce_FV_Bouss, layered (no equation of state) path                                  */
+/* Equation of state pieces used by the pressure force                                           */
+/* Wright (1997) constants of MOM_EOS_Wright.F90:23-37 (EQN_OF_STATE = "WRIGHT")                  */
+static const double W_a0 = 7.057924e-4, W_a1 = 3.480336e-7, W_a2 = -1.112733e-7;
+static const double W_b0 = 5.790749e8, W_b1 = 3.516535e6, W_b2 = -4.002714e4, W_b3 = 2.084372e2, W_b4 = 5.944068e5, W_b5 = -9.643486e3;
+static const double W_c0 = 1.704853e5, W_c1 = 7.904722e2, W_c2 = -7.984422, W_c3 = 5.140652e-2, W_c4 = -2.302158e2, W_c5 = -3.079464;
+
+static void wright_coefs(double T, double S, double *al0, double *p0, double *lambda) {   /* :555-557 */
+  *al0 = (W_a0 + W_a1 * T) + W_a2 * S;
+  *p0 = (W_b0 + W_b4 * S) + T * (W_b1 + T * ((W_b2 + W_b3 * T)) + W_b5 * S);
+  *lambda = (W_c0 + W_c4 * S) + T * (W_c1 + T * ((W_c2 + W_c3 * T)) + W_c5 * S);
+}
+
+/* calculate_density (no rho_ref): density_elem_linear MOM_EOS_linear.F90:66, density_elem_buggy_Wright :80-96 */
+static double eos_density(const mom6x_eos_params *E, double T, double S, double p) {
+  if (E->form == MOM6X_EOS_LINEAR) return E->Rho_T0_S0 + E->dRho_dT * T + E->dRho_dS * S + E->dRho_dp * p;
+  double al0, p0, lambda;
+  wright_coefs(T, S, &al0, &p0, &lambda);
+  return (p + p0) / (lambda + al0 * (p + p0));
+}
+
+/* calculate_density_derivs: linear :117-134, Wright :178-206 */
+static void eos_density_derivs(const mom6x_eos_params *E, double T, double S, double p, double *dRdT, double *dRdS) {
+  if (E->form == MOM6X_EOS_LINEAR) { *dRdT = E->dRho_dT; *dRdS = E->dRho_dS; return; }
+  double al0, p0, lambda;
+  wright_coefs(T, S, &al0, &p0, &lambda);
+  double I_denom2 = 1.0 / (lambda + al0 * (p + p0));
+  I_denom2 = I_denom2 * I_denom2;
+  *dRdT = I_denom2 * (lambda * (W_b1 + T * (2.0 * W_b2 + 3.0 * W_b3 * T) + W_b5 * S) -
+                      (p + p0) * ((p + p0) * W_a1 + (W_c1 + T * (W_c2 * 2.0 + W_c3 * 3.0 * T) + W_c5 * S)));
+  *dRdS = I_denom2 * (lambda * (W_b4 + W_b5 * T) - (p + p0) * ((p + p0) * W_a2 + (W_c4 + W_c5 * T)));
+}
+
+/* hWght and the four T/S interpolation weights of a face between columns L and R
+ * (int_density_dz_linear :392-416 / int_density_dz_wright :566-583).  Returns hWght (> 0: weighted).  */
+static double face_weights(int do_mw, int top_mw, double bathyL, double bathyR, double ztL, double ztR, double zbL, double zbR,
+                           double sshL, double sshR, double dz_neglect, double *LL, double *LR, double *RR, double *RL) {
+  double hWght = 0.0;
+  if (do_mw) hWght = orc_max(orc_max(0., -bathyL - ztR), -bathyR - ztL);
+  if (top_mw) hWght = orc_max(orc_max(hWght, zbR - sshL), zbL - sshR);
+  if (hWght > 0.) {
+    const double hL = (ztL - zbL) + dz_neglect, hR = (ztR - zbR) + dz_neglect;
+    const double q = (hL - hR) / (hL + hR);
+    hWght = hWght * (q * q);
+    const double iDenom = 1.0 / (hWght * (hR + hL) + hL * hR);
+    *LL = (hWght * hL + hR * hL) * iDenom; *LR = (hWght * hR) * iDenom;
+    *RR = (hWght * hR + hR * hL) * iDenom; *RL = (hWght * hL) * iDenom;
+  } else { *LL = 1.0; *LR = 0.0; *RR = 1.0; *RL = 0.0; }
+  return hWght;
+}
+
+/* One column pair of int_density_dz_linear :386-430 (x) / :432-476 (y): the face integral intx_dpa|inty_dpa. */
+static double face_int_linear(const mom6x_eos_params *E, double rho_ref, double G_e, double GxRho, int do_mw, int top_mw,
+                              double TL, double SL, double TR, double SR, double ztL, double zbL, double ztR, double zbR,
+                              double z0L, double z0R, double bathyL, double bathyR, double sshL, double sshR, double dz_neglect,
+                              double dpaL, double dpaR) {
+  const double C1_6 = 1.0 / 6.0, C1_90 = 1.0 / 90.0;
+  double hWght = 0.0;
+  if (do_mw) hWght = orc_max(orc_max(0., -bathyL - ztR), -bathyR - ztL);
+  if (top_mw) hWght = orc_max(orc_max(hWght, zbR - sshL), zbL - sshR);
+  if (hWght <= 0.0) {
+    const double dzL = ztL - zbL, dzR = ztR - zbR;
+    double p_ave = -GxRho * (0.5 * (ztL + zbL) - z0L);
+    const double raL = (E->Rho_T0_S0 - rho_ref) + ((E->dRho_dT * TL + E->dRho_dS * SL) + E->dRho_dp * p_ave);
+    p_ave = -GxRho * (0.5 * (ztR + zbR) - z0R);
+    const double raR = (E->Rho_T0_S0 - rho_ref) + ((E->dRho_dT * TR + E->dRho_dS * SR) + E->dRho_dp * p_ave);
+    return G_e * C1_6 * ((dzL * (2.0 * raL + raR)) + (dzR * (2.0 * raR + raL)));
+  }
+  double LL, LR, RR, RL;
+  face_weights(do_mw, top_mw, bathyL, bathyR, ztL, ztR, zbL, zbR, sshL, sshR, dz_neglect, &LL, &LR, &RR, &RL);
+  double intz[5];
+  intz[0] = dpaL; intz[4] = dpaR;
+  for (int m = 2; m <= 4; m++) {
+    const double wt_L = 0.25 * (double)(5 - m), wt_R = 1.0 - wt_L;
+    const double wtT_L = (wt_L * LL) + (wt_R * RL), wtT_R = (wt_L * LR) + (wt_R * RR);
+    const double dz = (wt_L * (ztL - zbL)) + (wt_R * (ztR - zbR));
+    const double p_ave = -GxRho * ((wt_L * (0.5 * (ztL + zbL) - z0L)) + (wt_R * (0.5 * (ztR + zbR) - z0R)));
+    const double rho_anom = (E->Rho_T0_S0 - rho_ref) +
+                            ((E->dRho_dT * ((wtT_L * TL) + (wtT_R * TR)) + E->dRho_dS * ((wtT_L * SL) + (wtT_R * SR))) + E->dRho_dp * p_ave);
+    intz[m - 1] = G_e * rho_anom * dz;
+  }
+  return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
+}
+
+/* One column pair of int_density_dz_wright :560-607 (x) / :609-653 (y). */
+static double face_int_wright(double rho_ref, double G_e, double GxRho, double I_Rho, int do_mw, int top_mw,
+                              double TL, double SL, double TR, double SR, double ztL, double zbL, double ztR, double zbR,
+                              double z0L, double z0R, double bathyL, double bathyR, double sshL, double sshR, double dz_neglect,
+                              double dpaL, double dpaR) {
+  const double C1_3 = 1.0 / 3.0, C1_7 = 1.0 / 7.0, C1_9 = 1.0 / 9.0, C1_90 = 1.0 / 90.0;
+  double LL, LR, RR, RL;
+  face_weights(do_mw, top_mw, bathyL, bathyR, ztL, ztR, zbL, zbR, sshL, sshR, dz_neglect, &LL, &LR, &RR, &RL);
+  double al0L, p0L, lamL, al0R, p0R, lamR;
+  wright_coefs(TL, SL, &al0L, &p0L, &lamL);
+  wright_coefs(TR, SR, &al0R, &p0R, &lamR);
+  double intz[5];
+  intz[0] = dpaL; intz[4] = dpaR;
+  for (int m = 2; m <= 4; m++) {
+    const double wt_L = 0.25 * (double)(5 - m), wt_R = 1.0 - wt_L;
+    const double wtT_L = (wt_L * LL) + (wt_R * RL), wtT_R = (wt_L * LR) + (wt_R * RR);
+    const double al0 = (wtT_L * al0L) + (wtT_R * al0R);
+    const double p0 = (wtT_L * p0L) + (wtT_R * p0R);
+    const double lambda = (wtT_L * lamL) + (wtT_R * lamR);
+    const double dz = (wt_L * (ztL - zbL)) + (wt_R * (ztR - zbR));
+    const double p_ave = -GxRho * ((wt_L * (0.5 * (ztL + zbL) - z0L)) + (wt_R * (0.5 * (ztR + zbR) - z0R)));
+    const double I_al0 = 1.0 / al0;
+    const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+    const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
+    intz[m - 1] = 1.0 * (G_e * dz * ((p0 + p_ave) * (I_Lzz * I_al0) - rho_ref) - 2.0 * eps *
+                         I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2))));
+  }
+  return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* PressureForce_FV_Bouss :947-2017.  T == NULL: layered (no equation of state) path; else the use_EOS path with
+ * analytic_int_density_dz (MOM_EOS.F90:1384) for EOS_LINEAR / EOS_WRIGHT and Set_pbce_Bouss's use_EOS branch.      */
 int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
                                const mom6x_pgf_params *CS, const double *Rlay, const double *g_prime,
-                               const double *h, double *PFu, double *PFv, double *pbce, double *eta) {
+                               const double *h, double *PFu, double *PFv, double *pbce, double *eta,
+                               const double *T, const double *S, const mom6x_eos_params *EOS) {
   const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1, nz = d->nk, st = d->pitch;
   const int Isq = -1, Ieq = ie, Jsq = -1, Jeq = je;
   const size_t slab = (size_t)d->slab;
@@ -180,6 +296,64 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
     size_t x = IX2(d, i, j);
     pa[x] = GxRho_ref * (e[x] - Z_ref);
   }
+  const int use_EOS = (T != NULL);
+  if (use_EOS && !(EOS && S && (EOS->form == MOM6X_EOS_LINEAR || EOS->form == MOM6X_EOS_WRIGHT))) {
+    free(e); free(pa); free(dpa); free(intz_dpa); free(intx_pa); free(inty_pa); free(intx_dpa); free(inty_dpa); free(dz_geo);
+    return MOM6X_EUNSUPPORTED;
+  }
+  if (use_EOS) {   /* :1289-1316 with int_density_dz -> analytic_int_density_dz */
+    const double rho0_int = CS->rho_ref_bug ? rho_ref : GV->Rho0;    /* rho0_int_density :1134-1144 */
+    const double G_e = GV->g_Earth, GxRho = G_e * rho0_int, I_Rho = 1.0 / rho0_int;
+    const int do_mw = EOS->MassWghtInterp & 1, top_mw = (EOS->MassWghtInterp >> 1) & 1;
+    const double C1_6 = 1.0 / 6.0, C1_3 = 1.0 / 3.0, C1_7 = 1.0 / 7.0, C1_9 = 1.0 / 9.0;
+    double *z0 = (double *)calloc(slab, sizeof(double));
+    for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {   /* Z_0p :1264-1276 (p_atm absent) */
+      size_t x = IX2(d, i, j);
+      z0[x] = EOS->use_SSH_in_Z0p ? e[x] : Z_ref;
+    }
+    for (int k = 0; k < nz; k++) {
+      const double *zt = e + k * slab, *zb = e + (k + 1) * slab, *Tk = T + k * slab, *Sk = S + k * slab;
+      for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+        size_t x = IX2(d, i, j), x3 = x + k * slab;
+        const double dz = zt[x] - zb[x];
+        const double p_ave = -GxRho * (0.5 * (zt[x] + zb[x]) - z0[x]);
+        if (EOS->form == MOM6X_EOS_LINEAR) {   /* MOM_EOS_linear.F90:377-384 */
+          const double rho_anom = (EOS->Rho_T0_S0 - rho_ref) + EOS->dRho_dT * Tk[x] + EOS->dRho_dS * Sk[x] + EOS->dRho_dp * p_ave;
+          dpa[x3] = G_e * rho_anom * dz;
+          intz_dpa[x3] = 0.5 * G_e * (rho_anom - C1_6 * EOS->dRho_dp * (GxRho * dz)) * (dz * dz);
+        } else {                               /* MOM_EOS_Wright.F90:554-577 */
+          double al0, p0, lambda;
+          wright_coefs(Tk[x], Sk[x], &al0, &p0, &lambda);
+          const double I_al0 = 1.0 / al0;
+          const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+          const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
+          const double rho_anom = (p0 + p_ave) * (I_Lzz * I_al0) - rho_ref;
+          const double rem = I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2)));
+          dpa[x3] = 1.0 * (G_e * rho_anom * dz - 2.0 * eps * rem);
+          intz_dpa[x3] = 1.0 * (0.5 * G_e * rho_anom * (dz * dz) - dz * (1.0 + eps) * rem);
+        }
+      }
+      for (int dir = 0; dir < 2; dir++) {
+        const int s2 = dir ? st : 1;
+        const int a0 = dir ? is : Isq, a1 = dir ? ie : Ieq, b0 = dir ? Jsq : js, b1 = dir ? Jeq : je;
+        double *out = dir ? inty_dpa : intx_dpa;
+        for (int j = b0; j <= b1; j++) for (int i = a0; i <= a1; i++) {
+          size_t x = IX2(d, i, j), y = x + s2;
+          if (EOS->form == MOM6X_EOS_LINEAR)
+            out[x + k * slab] = face_int_linear(EOS, rho_ref, G_e, GxRho, do_mw, top_mw, Tk[x], Sk[x], Tk[y], Sk[y], zt[x], zb[x], zt[y],
+                                                zb[y], z0[x], z0[y], bathyT[x], bathyT[y], e[x], e[y], dz_neglect, dpa[x + k * slab],
+                                                dpa[y + k * slab]);
+          else
+            out[x + k * slab] = face_int_wright(rho_ref, G_e, GxRho, I_Rho, do_mw, top_mw, Tk[x], Sk[x], Tk[y], Sk[y], zt[x], zb[x], zt[y],
+                                                zb[y], z0[x], z0[y], bathyT[x], bathyT[y], e[x], e[y], dz_neglect, dpa[x + k * slab],
+                                                dpa[y + k * slab]);
+        }
+      }
+      if (GV->Z_to_H != 1.0)
+        for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) intz_dpa[IX2(d, i, j) + k * slab] *= GV->Z_to_H;
+    }
+    free(z0);
+  } else
   for (int k = 0; k < nz; k++) { /* :1323-1333 */
     for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
       size_t x = IX2(d, i, j), x3 = x + k * slab;
@@ -223,6 +397,26 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
                ((h[x3 + st] - h[x3]) * inty_pa[x3] - (e[xb + st] - e[xb]) * inty_dpa[x3] * GV->Z_to_H)) *
               ((2.0 * I_Rho0 * IdyCv[x]) / ((h[x3] + h[x3 + st]) + h_neglect));
   }
+  if (pbce && use_EOS) { /* Set_pbce_Bouss, use_EOS without rho_star :704-733; Rho0 argument = rho0_set_pbce */
+    const double Rho0_arg = CS->rho_ref_bug ? rho_ref : GV->Rho0;
+    const double Rho0xG = Rho0_arg * GV->g_Earth, G_Rho0 = GV->g_Earth / GV->Rho0, GFS_scale = 1.0;
+    for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+      size_t x = IX2(d, i, j);
+      const double Ihtot = GV->H_to_Z / ((e[x] - e[x + nz * slab]) + dz_neglect);
+      double press = -Rho0xG * (e[x] - Z_ref);
+      const double rho_in_situ = eos_density(EOS, T[x], S[x], press);
+      pbce[x] = G_Rho0 * (GFS_scale * rho_in_situ) * GV->H_to_Z;
+      for (int k = 1; k < nz; k++) {
+        size_t x3 = x + k * slab;
+        press = -Rho0xG * (e[x3] - Z_ref);
+        const double T_int = 0.5 * (T[x3 - slab] + T[x3]), S_int = 0.5 * (S[x3 - slab] + S[x3]);
+        double dR_dT, dR_dS;
+        eos_density_derivs(EOS, T_int, S_int, press, &dR_dT, &dR_dS);
+        pbce[x3] = pbce[x3 - slab] + G_Rho0 * ((e[x3] - e[x + nz * slab]) * Ihtot) *
+                   (dR_dT * (T[x3] - T[x3 - slab]) + dR_dS * (S[x3] - S[x3 - slab]));
+      }
+    }
+  } else
   if (pbce) { /* Set_pbce_Bouss, not use_EOS :735-746 */
     for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
       size_t x = IX2(d, i, j);

@@ -39,7 +39,7 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
                   double *CAv);
 int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_pgf_params *CS,
                                const double *Rlay, const double *g_prime, const double *h, double *PFu, double *PFv,
-                               double *pbce, double *eta);
+                               double *pbce, double *eta, const double *T, const double *S, const mom6x_eos_params *EOS);
 int orc_vertvisc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, double *u, double *v, const double *a_u,
                  const double *a_v, const double *h_u, const double *h_v, const double *Ray_u, const double *Ray_v,
                  const double *taux, const double *tauy, double dt, double *taux_bot, double *tauy_bot);
@@ -62,6 +62,7 @@ typedef struct orc_rk2_all {   /* everything step_MOM_dyn_split_RK2 reaches thro
   const mom6x_continuity_params *cont; mom6x_barotropic_params *bt; const mom6x_coriolis_params *cor;
   const mom6x_pgf_params *pgf; const mom6x_rk2_params *rk2; const double *Rlay, *g_prime;
   orc_rk2_cs *CS; orc_bt_cs *BTCS; const mom6x_BT_cont *BT_cont; int first_direction;
+  const double *T, *S; const mom6x_eos_params *eos;   /* tv%T, tv%S, tv%eqn_of_state (NULL: layered) */
 } orc_rk2_all;
 
 /* the new-run branch of initialize_dyn_split_RK2 :1577-1650 (+ barotropic_init ubtav :6124-6135 is done by the
@@ -122,7 +123,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   memcpy(hp, h, n3 * sizeof(double)); /* :421-425 */
 
   /* PFu = d/dx M(h,T,S); pbce = dM/deta  :503 */
-  rc = orc_PressureForce_FV_Bouss(d, G, GV, A->pgf, A->Rlay, A->g_prime, h, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF);
+  rc = orc_PressureForce_FV_Bouss(d, G, GV, A->pgf, A->Rlay, A->g_prime, h, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF, A->T, A->S, A->eos);
   if (rc) return rc;
   if (!CS->CAu_pred_stored) { /* :552-557 */
     rc = orc_CorAdCalc(d, G, GV, A->cor, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred);
@@ -205,7 +206,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
       size_t x = IX3(d, i, j, k);
       hp[x] = (1.0 - R->begw) * h[x] + R->begw * hp[x];
     }
-    rc = orc_PressureForce_FV_Bouss(d, G, GV, A->pgf, A->Rlay, A->g_prime, hp, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF);
+    rc = orc_PressureForce_FV_Bouss(d, G, GV, A->pgf, A->Rlay, A->g_prime, hp, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF, A->T, A->S, A->eos);
     if (rc) return rc;
   }
   orc_btcalc(d, G, GV, h, A->BT_cont->h_u, A->BT_cont->h_v, A->BTCS); /* :864-867 */

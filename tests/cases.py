@@ -45,12 +45,14 @@ def rk2_inputs(cfg, per_stage=False, new_diff=False):
     return dict(GV=GV, Rlay=Rlay, gp=gp, dt=1200.0, h=h, u=u, v=v, coefs=coefs, taux=taux, tauy=tauy, diff_new=diff_new)
 
 
-def oracle_rk2(orc, cfg, inp, nsteps, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0):
+def oracle_rk2(orc, cfg, inp, nsteps, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, tv=None):
     """nsteps of orc_step_dyn_split_RK2 from the seeded state; returns (final state dict, OrcModel)."""
     gg, d, M = cfg
     GV, dt, h, u, v = inp["GV"], inp["dt"], inp["h"], inp["u"], inp["v"]
     cont, bt, cor, pgf, rk2 = rk2_params(d, GV, bt_mod, rk2_mod, cor_mod)
     m = orc.OrcModel(d, M, GV, cont, bt, cor, pgf, rk2, inp["Rlay"], inp["gp"], first_direction)
+    if tv is not None:
+        m.set_tv(*tv)
     so = dict(u=u.copy(), v=v.copy(), h=h.copy(), uh=np.zeros_like(h), vh=np.zeros_like(h), uhtr=np.zeros_like(h),
               vhtr=np.zeros_like(h), eta_av=np.zeros(d.shape2()))
     m.initialize(so["u"], so["v"], so["h"], so["uh"], so["vh"], dt)
@@ -84,3 +86,13 @@ def oracle_continuity(orc, cfg, inp):
     orc.continuity_PPM(d, M, GV, CS, 0, u, v, h, out["h"], out["uh"], out["vh"], dt, uhbt=uhbt, vhbt=vhbt,
                        visc_rem_u=inp["vr_u"], visc_rem_v=inp["vr_v"], u_cor=out["u_cor"], v_cor=out["v_cor"])
     return out, uhbt, vhbt
+
+
+def thermo_state(d, M, seed=7):
+    """A stably stratified T, S pair with horizontal structure (tv%T, tv%S)."""
+    h, _, _ = synth.make_state(d, M)
+    T = np.zeros_like(h); S = np.zeros_like(h)
+    for k in range(d.nk):
+        T[k] = 20.0 - 15.0 * k / max(d.nk - 1, 1) + 0.8 * synth.smooth_field(d, seed + k, ox=0.5, oy=0.5)
+        S[k] = 34.0 + 1.0 * k / max(d.nk - 1, 1) + 0.2 * synth.smooth_field(d, seed + 100 + k, ox=0.5, oy=0.5)
+    return np.ascontiguousarray(T), np.ascontiguousarray(S)

@@ -86,6 +86,52 @@ def test_PressureForce(orc, cfg, bug):
 
 
 @pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
+@pytest.mark.parametrize("form", ["LINEAR", "WRIGHT"])
+@pytest.mark.parametrize("mods", [dict(), dict(MassWghtInterp=1), dict(MassWghtInterp=3, use_SSH_in_Z0p=1, bug=0, dRho_dp=4.5e-7)])
+def test_PressureForce_with_equation_of_state(orc, cfg, form, mods):
+    """The use_EOS branch (int_density_dz -> analytic linear / Wright integrals, Set_pbce_Bouss with T and S)."""
+    import torch
+    from mom6_amd.dycore import Dycore
+    from tests import cases
+    gg, d, M = getattr(H, cfg)()
+    GV = abi.vgrid_default()
+    CS = abi.pgf_params_default(GV.Rho0)
+    eos = abi.eos_params_default(getattr(abi, form))
+    for k, v in mods.items():
+        if k == "bug":
+            CS.rho_ref_bug = v; CS.rho_ref = 1030.0
+        else:
+            setattr(eos, k, v)
+    Rlay, gp = abi.layer_densities(d.nk, GV.Rho0, GV.g_Earth)
+    h, _, _ = synth.make_state(d, M, thin_frac=0.05)
+    T, S = cases.thermo_state(d, M)
+    o = dict(PFu=np.zeros_like(h), PFv=np.zeros_like(h), pbce=np.zeros_like(h), eta=np.zeros(d.shape2()))
+    orc.PressureForce(d, M, GV, CS, Rlay, gp, h, o["PFu"], o["PFv"], o["pbce"], o["eta"], T=T, S=S, eos=eos)
+    dyc = Dycore(d, M, GV)
+    dyc.PressureForce_init(CS, Rlay, gp)
+    Td, Sd = dyc.to_dev(T), dyc.to_dev(S)
+    dyc.PressureForce_set_tv(Td, Sd, eos)
+    g = dict(PFu=dyc.zeros3(), PFv=dyc.zeros3(), pbce=dyc.zeros3(), eta=dyc.zeros2())
+    hd = dyc.to_dev(h)
+    torch.cuda.synchronize()
+    dyc.PressureForce(hd, g["PFu"], g["PFv"], g["pbce"], g["eta"])
+    dyc.sync()
+    H.assert_bitwise(g["PFu"].cpu().numpy(), o["PFu"], "PFu", H.interior(d, "u"))
+    H.assert_bitwise(g["PFv"].cpu().numpy(), o["PFv"], "PFv", H.interior(d, "v"))
+    sl = d.sl(-1, d.ni, -1, d.nj)
+    H.assert_bitwise(g["pbce"].cpu().numpy(), o["pbce"], "pbce", sl)
+    H.assert_bitwise(g["eta"].cpu().numpy(), o["eta"], "eta", sl)
+    assert np.abs(o["PFu"]).max() > 0 and np.isfinite(o["PFu"]).all()
+    # back to the layered path
+    dyc.PressureForce_set_tv(None, None, None)
+    o2 = dict(PFu=np.zeros_like(h), PFv=np.zeros_like(h))
+    orc.PressureForce(d, M, GV, CS, Rlay, gp, h, o2["PFu"], o2["PFv"])
+    dyc.PressureForce(hd, g["PFu"], g["PFv"]); dyc.sync()
+    H.assert_bitwise(g["PFu"].cpu().numpy(), o2["PFu"], "PFu layered", H.interior(d, "u"))
+    dyc.close()
+
+
+@pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
 @pytest.mark.parametrize("use_ray", [False, True])
 def test_vertvisc_and_remnant(orc, cfg, use_ray):
     import torch

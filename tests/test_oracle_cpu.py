@@ -131,3 +131,42 @@ def test_rk2_conserves_volume_and_btstep_is_consistent(orc):
         eta_h = (h.sum(0) - M[G["bathyT"]])[sl]
         assert np.abs(eta_h - m["eta"][sl]).max() < 1e-3
     assert np.isfinite(u).all() and np.abs(u).max() < 1.0
+
+
+def test_pressure_force_eos_consistency(orc):
+    """The use_EOS branch of PressureForce_FV_Bouss against the layered branch: with a linear equation of state,
+    dRho_dp = 0 and T, S chosen so that every layer has exactly its target density Rlay(k), the analytic density
+    integrals reduce to the layered formulas, so PFu/PFv agree to round-off; and a level, horizontally uniform
+    ocean feels no force under either equation of state."""
+    gg, d, M = H.benchmark_small()
+    GV = abi.vgrid_default(); CS = abi.pgf_params_default(GV.Rho0)
+    Rlay, gp = abi.layer_densities(d.nk, GV.Rho0, GV.g_Earth)
+    h, _, _ = synth.make_state(d, M, thin_frac=0.05)
+    z = lambda: np.zeros_like(h)
+    P0u, P0v = z(), z()
+    orc.PressureForce(d, M, GV, CS, Rlay, gp, h, P0u, P0v)
+    eos = abi.eos_params_default(abi.LINEAR)
+    T = np.full_like(h, 10.0); S = z()
+    for k in range(d.nk):
+        S[k] = (Rlay[k] - eos.Rho_T0_S0 - eos.dRho_dT * 10.0) / eos.dRho_dS
+    P1u, P1v = z(), z()
+    orc.PressureForce(d, M, GV, CS, Rlay, gp, h, P1u, P1v, T=T, S=S, eos=eos)
+    su, sv = H.interior(d, "u"), H.interior(d, "v")
+    scale = np.abs(P0u[(Ellipsis,) + su]).max()
+    assert scale > 0
+    assert np.abs(P1u - P0u)[(Ellipsis,) + su].max() < 1e-9 * scale
+    assert np.abs(P1v - P0v)[(Ellipsis,) + sv].max() < 1e-9 * scale
+    # resting, level ocean (flat bottom): no pressure force with either EOS
+    gg2, d2, M2 = H.channel()
+    h2 = np.full(d2.shape3(), 1000.0 / d2.nk)
+    T2 = np.zeros_like(h2); S2 = np.zeros_like(h2)
+    for k in range(d2.nk):
+        T2[k] = 18.0 - 4.0 * k; S2[k] = 34.0 + 0.3 * k
+    Rl2, gp2 = abi.layer_densities(d2.nk, GV.Rho0, GV.g_Earth)
+    for form in (abi.LINEAR, abi.WRIGHT):
+        e2 = abi.eos_params_default(form)
+        Pu, Pv = np.zeros_like(h2), np.zeros_like(h2)
+        orc.PressureForce(d2, M2, GV, CS, Rl2, gp2, h2, Pu, Pv, T=T2, S=S2, eos=e2)
+        su2, sv2 = H.interior(d2, "u"), H.interior(d2, "v")
+        assert np.abs(Pu[(Ellipsis,) + su2] * M2[G["mask2dCu"]][su2]).max() < 1e-12
+        assert np.abs(Pv[(Ellipsis,) + sv2] * M2[G["mask2dCv"]][sv2]).max() < 1e-12

@@ -20,7 +20,7 @@ STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h",
 
 
 def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, per_stage=False, new_diff=False,
-        exact=True, rtol=1e-11):
+        exact=True, rtol=1e-11, eos_form=None):
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
@@ -32,14 +32,21 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
     def params():
         return cases.rk2_params(d, GV, bt_mod, rk2_mod, cor_mod)
 
+    tv = None
+    if eos_form is not None:   # tv%T, tv%S, tv%eqn_of_state: the PressureForce calls take the use_EOS branch
+        Tt, St = cases.thermo_state(d, M)
+        tv = (Tt, St, abi.eos_params_default(eos_form))
     # ---------------- oracle
-    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction)
+    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction, tv=tv)
 
     # ---------------- device
     cont2, bt2, cor2, pgf2, rk22 = params()
     dyc = Dycore(d, M, GV, first_direction)
     dyc.continuity_init(cont2); dyc.barotropic_init(bt2); dyc.CoriolisAdv_init(cor2); dyc.PressureForce_init(pgf2, Rlay, gp)
     dyc.initialize_dyn_split_RK2(rk22)
+    if tv is not None:
+        tvd = (dyc.to_dev(tv[0]), dyc.to_dev(tv[1]))
+        dyc.PressureForce_set_tv(tvd[0], tvd[1], tv[2])
     sg = dict(u=dyc.to_dev(u), v=dyc.to_dev(v), h=dyc.to_dev(h), uh=dyc.zeros3(), vh=dyc.zeros3(), uhtr=dyc.zeros3(),
               vhtr=dyc.zeros3(), eta_av=dyc.zeros2())
     cdev = [tuple(dyc.to_dev(a) if a is not None else None for a in c) for c in (coefs if per_stage else coefs[:1])]
@@ -116,6 +123,11 @@ def test_rk2_device_matches_committed_golden(orc):
     d = H.double_gyre()[1]
     for n in STATE:
         H.assert_bitwise(out[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))], gold[n], "golden:" + n)
+
+
+@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
+def test_rk2_with_equation_of_state(orc, form):
+    run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(begw=0.2), eos_form=form)
 
 
 def test_rk2_default_path_tolerance(orc):
