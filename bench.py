@@ -5,9 +5,9 @@ split-explicit dynamical core (step_MOM_dyn_split_RK2) on a synthetic 0.25-degre
 MOM6's 2-D tile layout, one tile per GPU).
 
 A "step" is ONE baroclinic step of step_MOM_dyn_split_RK2: PressureForce, CorAdCalc x2, continuity_PPM
-x3, btstep x2 (each a full barotropic sub-cycle), vertvisc x2, vertvisc_remnant x3 and the RK2 glue, on
-state that already resides in HBM.  The un-ported callees (vertvisc_coef, horizontal_viscosity: SURVEY.md
-8f) are represented by coefficients frozen over the run (constant Kv, diffu = 0), stated in `config`.
+x3, btstep x2 (each a full barotropic sub-cycle), vertvisc_coef x3, vertvisc x2, vertvisc_remnant x3 and the
+RK2 glue, on state that already resides in HBM.  The one un-ported callee (horizontal_viscosity: SURVEY.md
+8f) is represented by diffu = diffv = 0, stated in `config`.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel -- the one with the largest
 total time in the last warm-up step (k_mass_flux_lds: PPM reconstruction + zonal/meridional mass flux +
@@ -40,7 +40,9 @@ def global_grid(ni, nj):
 def algorithmic_bytes_per_step(N3, N2, nsub_total):
     """SURVEY.md section 8(d) / BASELINE.md section 3: compulsory FP64 traffic of one baroclinic step."""
     per_N3 = {"continuity_PPM x3": 256, "CorAdCalc x3": 168, "PressureForce": 32, "btstep 3-D setup/teardown x2": 272,
-              "btcalc + bt_mass_source": 24, "vertvisc x2 + remnant x3": 480, "RK2 pointwise glue": 384}
+              "btcalc + bt_mass_source": 24, "vertvisc x2 + remnant x3": 480, "RK2 pointwise glue": 384,
+              # not in SURVEY 8(d) (a "next" row there): u, h in; a_u, h_u out, per direction and call
+              "vertvisc_coef x3": 192}
     total = sum(per_N3.values()) * N3 + 570.0 * N2 * nsub_total
     return total, per_N3
 
@@ -65,24 +67,20 @@ def build_model(args, layout, pe, device):
     Md = dyc.to_dev(M)
     h, u, v = synth_dev.make_state(d, Md, u_max=0.05, h_pert=0.001)
     st = dict(u=u, v=v, h=h, uh=dyc.zeros3(), vh=dyc.zeros3(), uhtr=dyc.zeros3(), vhtr=dyc.zeros3(), eta_av=dyc.zeros2())
-    # frozen vertvisc_coef outputs: Kv = 1e-4 m2/s over the local interface spacing, quadratic-drag-like bottom value
-    Kv = 1.0e-4
-    a = torch.zeros((args.nk + 1,) + d.shape2(), dtype=torch.float64, device=dyc.device)
-    hm = torch.clamp(0.5 * (h[:-1] + h[1:]), min=1e-3)
-    a[1:args.nk] = Kv / hm
-    a[args.nk] = 3.0e-4
-    del hm
-    a_u = (a * Md[G["mask2dCu"]][None]).contiguous(); a_v = (a * Md[G["mask2dCv"]][None]).contiguous()
-    del a
-    h_u = torch.clamp(0.5 * (h + torch.roll(h, -1, 2)), min=1e-9).contiguous()
-    h_v = torch.clamp(0.5 * (h + torch.roll(h, -1, 1)), min=1e-9).contiguous()
-    dyc.vertvisc_set_coef(a_u, a_v, h_u, h_v)
+    # vertvisc_coef runs on the device three times per step (RK2.F90:609, :738, :1003); its vertvisc_type inputs
+    # (set_viscous_BBL outputs: a drag-law bottom viscosity over a 10 m boundary layer) are synthetic and constant
+    dyc.vertvisc_init(abi.vertvisc_params_default(Kv=1.0e-4, Hmix=20.0, Hbbl=10.0))
+    Kv_bbl_u = (2.0e-3 * (1.0 + 0.5 * synth_dev.smooth_field(d, dyc.device, 91, ox=1.0, oy=0.5)) * Md[G["mask2dCu"]]).contiguous()
+    Kv_bbl_v = (2.0e-3 * (1.0 + 0.5 * synth_dev.smooth_field(d, dyc.device, 92, ox=0.5, oy=1.0)) * Md[G["mask2dCv"]]).contiguous()
+    bbl_u = torch.full_like(Kv_bbl_u, 10.0); bbl_v = torch.full_like(Kv_bbl_v, 10.0)
+    dyc.vertvisc_set_visc(Kv_bbl_u, Kv_bbl_v, bbl_u, bbl_v)
+    dyc.vertvisc_coef(u, v, h, args.dt)
     taux = (0.1 * synth_dev.smooth_field(d, dyc.device, 41, ox=1.0, oy=0.5) * Md[G["mask2dCu"]]).contiguous()
     tauy = torch.zeros_like(taux)
     torch.cuda.synchronize()
     dyc.dyn_split_RK2_new_run(st["u"], st["v"], st["h"], st["uh"], st["vh"], args.dt)
     dyc.sync()
-    keep = (a_u, a_v, h_u, h_v, Md)
+    keep = (Kv_bbl_u, Kv_bbl_v, bbl_u, bbl_v, Md)
     return dyc, d, st, taux, tauy, keep
 
 
@@ -183,10 +181,12 @@ def cpu_baseline(args):
     m = orc.OrcModel(d, M, GV, abi.continuity_params_default(nk), bt, abi.coriolis_params_default(), abi.pgf_params_default(),
                      abi.rk2_params_default(), Rlay, gp)
     h, u, v = synth.make_state(d, M, u_max=0.05, h_pert=0.001)
-    a = np.zeros((nk + 1,) + d.shape2()); a[1:nk] = 1e-4 / 53.0; a[nk] = 3e-4
-    hu = np.maximum(h, 1e-9)
-    coefs = tuple(np.ascontiguousarray(x) if x is not None else None for x in
-                  (a * M[abi.G["mask2dCu"]][None], a * M[abi.G["mask2dCv"]][None], hu, hu.copy(), None, None))
+    # the same vertvisc_coef set-up as the device run: the oracle's step calls orc_vertvisc_coef three times
+    kbu = np.ascontiguousarray(2.0e-3 * (1.0 + 0.5 * synth.smooth_field(d, 91, ox=1.0, oy=0.5)) * M[abi.G["mask2dCu"]])
+    kbv = np.ascontiguousarray(2.0e-3 * (1.0 + 0.5 * synth.smooth_field(d, 92, ox=0.5, oy=1.0)) * M[abi.G["mask2dCv"]])
+    bbl = np.full(d.shape2(), 10.0)
+    m.set_vertvisc(abi.vertvisc_params_default(Kv=1.0e-4, Hmix=20.0, Hbbl=10.0), kbu, kbv, bbl, bbl.copy())
+    coefs = (None,) * 6
     z3 = lambda: np.zeros_like(h)
     uh, vh, uhtr, vhtr, eta_av = z3(), z3(), z3(), z3(), np.zeros(d.shape2())
     taux = np.ascontiguousarray(0.1 * synth.smooth_field(d, 41, ox=1, oy=.5) * M[abi.G["mask2dCu"]]); tauy = np.zeros(d.shape2())
@@ -308,12 +308,12 @@ def main():
         "config": {"workload": f"step_MOM_dyn_split_RK2 on {args.ni}x{args.nj}x{args.nk} (0.25-degree-class synthetic global, "
                                f"BASELINE.json configs[3] grid), DT={args.dt:g} s, layout {layout[0]}x{layout[1]}, "
                                f"{nsub} barotropic sub-steps per step",
-                   "frozen_inputs": "vertvisc_coef outputs (Kv=1e-4) and diffu=diffv=0 are held constant (SURVEY 8f callees)",
+                   "frozen_inputs": "horizontal_viscosity (SURVEY 8f) is not ported: diffu = diffv = 0; vertvisc_coef runs on the device with constant synthetic set_viscous_BBL inputs",
                    "tile": [d.ni, d.nj, d.nk], "halo": d.halo},
         "roofline": roofline,
         "hbm_step": {"algorithmic_GB_per_step": round(bytes_step / 1e9, 2), "achieved_GBps": round(bytes_step / 1e9 / (ms_per_step * 1e-3), 1),
                      "frac_of_peak": round(bytes_step / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * args.gpus), 4),
-                     "model": "SURVEY.md 8(d): 1616 B x N3 + 570 B x N2 x sub-steps"},
+                     "model": "SURVEY.md 8(d): 1616 B x N3 + 570 B x N2 x sub-steps, + 192 B x N3 for vertvisc_coef x3"},
     }
     if args.tracers > 0:
         out["tracer_leg"] = tracer_leg(args, dyc, d, st, step, barrier, dist)

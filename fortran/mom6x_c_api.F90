@@ -10,7 +10,7 @@ module mom6x_c_api
 
   public :: mom6x_dims, mom6x_vgrid, mom6x_continuity_params, mom6x_BT_cont, mom6x_barotropic_params
   public :: mom6x_coriolis_params, mom6x_pgf_params, mom6x_eos_params, mom6x_rk2_params, mom6x_rk2_hooks
-  public :: mom6x_PressureForce_set_tv
+  public :: mom6x_PressureForce_set_tv, mom6x_vertvisc_params, mom6x_vertvisc_init, mom6x_vertvisc_set_visc, mom6x_vertvisc_coef
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
   public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
   public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc
@@ -66,6 +66,11 @@ module mom6x_c_api
     integer(c_int) :: rho_ref_bug
     real(c_double) :: Z_ref
   end type mom6x_pgf_params
+
+  type, bind(C) :: mom6x_vertvisc_params   !< vertvisc_CS (MOM_vert_friction.F90:39-180)
+    real(c_double) :: Kv, Kvml_invZ2, Hmix, Hbbl, harm_BL_val, Kv_extra_bbl
+    integer(c_int) :: harmonic_visc, bottomdraglaw, answer_date
+  end type mom6x_vertvisc_params
 
   type, bind(C) :: mom6x_eos_params        !< tv%eqn_of_state (MOM_EOS.F90:99-150) + EOS-only switches of PressureForce_FV_CS
     integer(c_int) :: form                 !< 1 EOS_LINEAR, 2 EOS_WRIGHT
@@ -192,6 +197,20 @@ module mom6x_c_api
     integer(c_int) function mom6x_PressureForce_set_tv(ctx, T, S, eos) bind(C, name="mom6x_PressureForce_set_tv")
       import :: c_ptr, c_int
       type(c_ptr), value :: ctx, T, S, eos
+    end function
+    !> vertvisc_init :3135 / the vertvisc_type inputs / vertvisc_coef :1357 on the device
+    integer(c_int) function mom6x_vertvisc_init(ctx, p) bind(C, name="mom6x_vertvisc_init")
+      import :: c_ptr, c_int, mom6x_vertvisc_params
+      type(c_ptr), value :: ctx ; type(mom6x_vertvisc_params), intent(in) :: p
+    end function
+    integer(c_int) function mom6x_vertvisc_set_visc(ctx, Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v, Kv_shear, Ray_u, Ray_v) &
+        bind(C, name="mom6x_vertvisc_set_visc")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v, Kv_shear, Ray_u, Ray_v
+    end function
+    integer(c_int) function mom6x_vertvisc_coef(ctx, u, v, h, dt) bind(C, name="mom6x_vertvisc_coef")
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, u, v, h ; real(c_double), value :: dt
     end function
     integer(c_int) function mom6x_vertvisc_set_coef(ctx, a_u, a_v, h_u, h_v, Ray_u, Ray_v) &
         bind(C, name="mom6x_vertvisc_set_coef")

@@ -164,6 +164,24 @@ typedef struct mom6x_pgf_params {
   double Z_ref;          /* G%Z_ref (0)                                                         */
 } mom6x_pgf_params;
 
+/* vertvisc_CS (src/parameterizations/vertical/MOM_vert_friction.F90:39-180; vertvisc_init :3135).  The
+ * branches of vertvisc_coef / find_coupling_coef that are on the device path: HARMONIC_VISC on or off,
+ * BOTTOMDRAGLAW on (visc%Kv_bbl_u/v, visc%bbl_thick_u/v from set_viscous_BBL are inputs) or off
+ * (KV_EXTRA_BBL), KV_ML_INVZ2, visc%Kv_shear.  Ice shelves, open boundaries, GL90, visc%Kv_shear_Bu and
+ * the dynamic / law-of-the-wall mixed-layer viscosities (DYNAMIC_VISCOUS_ML, FIXED_DEPTH_LOTW_ML,
+ * LOTW_VISCOUS_ML_FLOOR, a bulk mixed layer) are not.                                               */
+typedef struct mom6x_vertvisc_params {
+  double Kv;            /* KV           [H Z T-1]                                                 */
+  double Kvml_invZ2;    /* KV_ML_INVZ2  (0)                                                       */
+  double Hmix;          /* HMIX_FIXED   [Z]                                                       */
+  double Hbbl;          /* HBBL         [Z]                                                       */
+  double harm_BL_val;   /* HARMONIC_BL_SCALE (0)                                                  */
+  double Kv_extra_bbl;  /* KV_EXTRA_BBL (0); only without BOTTOMDRAGLAW                           */
+  int    harmonic_visc; /* HARMONIC_VISC (F)                                                      */
+  int    bottomdraglaw; /* BOTTOMDRAGLAW (T)                                                      */
+  int    answer_date;   /* VERT_FRICTION_ANSWER_DATE (99991231)                                   */
+} mom6x_vertvisc_params;
+
 /* tv%eqn_of_state (EOS_type, src/equation_of_state/MOM_EOS.F90:99-150) and the switches of
  * PressureForce_FV_CS that only matter with an equation of state.  Analytic density integrals
  * (analytic_int_density_dz, MOM_EOS.F90:1384) exist for EOS_LINEAR and the WRIGHT family; LINEAR and
@@ -348,6 +366,22 @@ int mom6x_vertvisc_set_coef(mom6x_ctx *ctx, const double *a_u, const double *a_v
                             const double *h_u, const double *h_v,
                             const double *Ray_u, const double *Ray_v);
 /* vertvisc(u, v, h, forces, visc, dt, OBC, ADp, CDp, G, GV, US, CS, taux_bot, tauy_bot)  :557 */
+/* vertvisc_init :3135: keeps the parameters and allocates CS%a_u, CS%a_v [(nk+1) levels], CS%h_u, CS%h_v on
+ * the device; the context's coefficient set (mom6x_vertvisc_set_coef) then points at them.           */
+int mom6x_vertvisc_init(mom6x_ctx *ctx, const mom6x_vertvisc_params *p);
+/* The members of vertvisc_type (MOM_variables.F90) that vertvisc_coef / vertvisc read: visc%Kv_bbl_u/v and
+ * visc%bbl_thick_u/v (2-D; required with BOTTOMDRAGLAW), visc%Kv_shear (3-D, nk+1 interfaces at h points,
+ * nullable), visc%Ray_u/v (3-D, nullable).  Device arrays owned by the caller (set_viscous_BBL and the
+ * shear-mixing schemes stay on the host).                                                            */
+int mom6x_vertvisc_set_visc(mom6x_ctx *ctx, const double *Kv_bbl_u, const double *Kv_bbl_v, const double *bbl_thick_u,
+                            const double *bbl_thick_v, const double *Kv_shear, const double *Ray_u, const double *Ray_v);
+/* vertvisc_coef(u, v, h, dz, forces, visc, tv, dt, G, GV, US, CS, OBC, VarMix) :1357, with dz = H_to_Z*h
+ * (thickness_to_dz, MOM_interface_heights.F90:855, Boussinesq).  Fills CS%a_u, a_v, h_u, h_v.  After
+ * mom6x_vertvisc_init, mom6x_step_dyn_split_RK2 calls this itself at :609, :738 and :1003 unless a
+ * vertvisc_coef callback is given.                                                                   */
+int mom6x_vertvisc_coef(mom6x_ctx *ctx, const double *u, const double *v, const double *h, double dt);
+/* CS%a_u (0), CS%a_v (1) [nk+1 levels], CS%h_u (2), CS%h_v (3) of the device vertvisc_CS (diagnostics, restarts of Kv_u). */
+double *mom6x_vertvisc_field(mom6x_ctx *ctx, int which);
 int mom6x_vertvisc(mom6x_ctx *ctx, double *u, double *v, const double *taux, const double *tauy,
                    double dt, double *taux_bot, double *tauy_bot);
 /* vertvisc_remnant(visc, visc_rem_u, visc_rem_v, dt, G, GV, US, CS)  :1229                   */

@@ -162,6 +162,21 @@ class PGFParams(C.Structure):
     _fields_ = [("rho_ref", C.c_double), ("rho_ref_bug", C.c_int), ("Z_ref", C.c_double)]
 
 
+class VertviscParams(C.Structure):
+    """mom6x_vertvisc_params; vertvisc_CS (MOM_vert_friction.F90:39-180)."""
+    _fields_ = [("Kv", C.c_double), ("Kvml_invZ2", C.c_double), ("Hmix", C.c_double), ("Hbbl", C.c_double),
+                ("harm_BL_val", C.c_double), ("Kv_extra_bbl", C.c_double), ("harmonic_visc", C.c_int),
+                ("bottomdraglaw", C.c_int), ("answer_date", C.c_int)]
+
+
+def vertvisc_params_default(Kv=1.0e-4, Hmix=20.0, Hbbl=10.0):
+    """vertvisc_init :3135 defaults; KV, HMIX_FIXED and HBBL have none in MOM6 (fail_if_missing)."""
+    p = VertviscParams()
+    p.Kv = Kv; p.Kvml_invZ2 = 0.0; p.Hmix = Hmix; p.Hbbl = Hbbl; p.harm_BL_val = 0.0; p.Kv_extra_bbl = 0.0
+    p.harmonic_visc = 0; p.bottomdraglaw = 1; p.answer_date = 99991231
+    return p
+
+
 LINEAR, WRIGHT = 1, 2   # enum mom6x_eos_form
 
 

@@ -727,6 +727,204 @@ int vertvisc_fused(mom6x_ctx *c, const double *u_in, const double *v_in, const d
   return MOM6X_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// vertvisc_coef :1357 + find_coupling_coef :2314 for one direction: one thread per face column.
+// Everything the coupling coefficient of interface K needs (z_i(K), dz_vel of the layers above and below) is
+// available while the column is walked bottom-up, so a_cpl is formed in the same sweep and no 3-D temporaries
+// (hvel, dz_vel, dz_harm, z_i, a_cpl of the reference) exist.  The only top-down quantity is the mixed-layer
+// coordinate z_t of KV_ML_INVZ2 (:2420-2436): when that option is on, a first top-down walk leaves z_t(K) in
+// the a array, where the main sweep picks it up before overwriting it.
+// dz = H_to_Z*h (thickness_to_dz, MOM_interface_heights.F90:892).
+// MODE selects the velocity the upwinding looks at: 0: u as given; 1: the predictor estimate of :591-598,
+// mask*(u + dtx*u_bc); 2: that of :681-694 / :957-966, mask*(u + dtx*(u_bc + u_abt)) -- formed on the fly with the
+// reference's expression, so the step never has to write and re-read up/vp just for this routine.
+template <int DIR, int MODE>
+__global__ void __launch_bounds__(256)
+k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, const double *__restrict__ u,
+                const double *__restrict__ u_bc, const double *__restrict__ u_abt, double dtx,
+                const double *__restrict__ h, const double *__restrict__ Kv_bbl, const double *__restrict__ bbl_thick_in,
+                const double *__restrict__ Kv_shear, double *__restrict__ a_out, double *__restrict__ h_out, double H_to_Z,
+                double h_neglect, double dz_neglect, double a_cpl_max, double I_amax) {
+  const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < ((DIR ? 0 : -1))) return;
+  const int nz = d.nk, st = DIR ? d.pitch : 1;
+  const size_t x = ix2(d, i, j), y = x + st, slab = (size_t)d.slab;
+  const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
+  if (!(mC > 0.)) return;   // do_i :1514-1516
+  const double *bathyT = gm(G, d, MOM6X_G_bathyT);
+  double I_valBL = 0.0; if (CS.harm_BL_val > 0.0) I_valBL = 1.0 / CS.harm_BL_val;
+  double I_Hbbl = 1. / (CS.Hbbl + dz_neglect), kv_bbl = 0.0, bbl_thick = 0.0;
+  if (CS.bottomdraglaw) {
+    kv_bbl = Kv_bbl[x];
+    bbl_thick = bbl_thick_in[x] + dz_neglect;
+    I_Hbbl = 1. / bbl_thick;
+  }
+  const double hn = dz_neglect;   // h_neglect of find_coupling_coef :2390
+  if (CS.Kvml_invZ2 > 0.) {       // z_t(K), K = 2..nz, top-down
+    const double I_Hmix = 1. / (CS.Hmix + hn);
+    double z_t = hn * I_Hmix;
+    for (int K = 1; K < nz; K++) {
+      const double dz0 = H_to_Z * h[x + (size_t)(K - 1) * slab], dz1 = H_to_Z * h[y + (size_t)(K - 1) * slab];
+      z_t = z_t + (2. * dz0 * dz1 / (dz0 + dz1 + dz_neglect)) * I_Hmix;
+      a_out[x + (size_t)K * slab] = z_t;
+    }
+  }
+  const double Dmin = dmin(bathyT[x], bathyT[y]);
+  double zh = 0., zcol0 = -bathyT[x], zcol1 = -bathyT[y];
+  double z_i_below = 0.;          // z_i(k+1): the interface below the layer being worked on
+  double dz_vel_below = 0.;       // dz_vel(k+1)
+  for (int k = nz - 1; k >= 0; k--) {
+    const size_t c = x + (size_t)k * slab;
+    const double h0 = h[c], h1 = h[c + st];
+    const double dz0 = H_to_Z * h0, dz1 = H_to_Z * h1;
+    const double h_harm = 2. * h0 * h1 / (h0 + h1 + h_neglect);
+    const double h_arith = 0.5 * (h1 + h0);
+    const double h_delta = h1 - h0;
+    const double dz_harm = 2. * dz0 * dz1 / (dz0 + dz1 + dz_neglect);
+    const double dz_arith = 0.5 * (dz1 + dz0);
+    double uk = u[c];
+    if (MODE == 1) uk = mC * (uk + dtx * u_bc[c]);
+    if (MODE == 2) uk = mC * (uk + dtx * (u_bc[c] + u_abt[c]));
+    double hvel, dz_vel, z_i_top;
+    if (CS.harmonic_visc) {
+      hvel = h_harm; dz_vel = dz_harm;
+      if (uk * h_delta < 0) {
+        const double z2 = z_i_below;
+        const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        hvel = (1. - botfn) * h_harm + botfn * h_arith;
+        dz_vel = (1. - botfn) * dz_harm + botfn * dz_arith;
+      }
+      z_i_top = z_i_below + dz_harm * I_Hbbl;
+    } else {
+      zcol0 = zcol0 + dz0; zcol1 = zcol1 + dz1;
+      zh = zh + dz_harm;
+      const double z_clear = dmax(zcol0, zcol1) + Dmin;
+      z_i_top = dmax(zh, z_clear) * I_Hbbl;
+      hvel = h_arith; dz_vel = dz_arith;
+      if (uk * h_delta > 0.) {
+        if (zh * I_Hbbl < CS.harm_BL_val) {
+          hvel = h_harm; dz_vel = dz_harm;
+        } else {
+          double z2_wt = 1.;
+          if (zh * I_Hbbl < 2. * CS.harm_BL_val) z2_wt = dmax(0., dmin(1., zh * I_Hbbl * I_valBL - 1.));
+          const double z2 = z2_wt * (dmax(zh, z_clear) * I_Hbbl);
+          const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+          hvel = (1. - botfn) * h_arith + botfn * h_harm;
+          dz_vel = (1. - botfn) * dz_arith + botfn * dz_harm;
+        }
+      }
+    }
+    h_out[c] = hvel + h_neglect;                                   // CS%h_u :1868-1872
+    // the interface below this layer: K = k+1 (bottom: K = nz)
+    const int K = k + 1;
+    double a_cpl;
+    if (K == nz) {                                                 // :2543-2558
+      if (CS.bottomdraglaw) {
+        const double dhc = dz_vel * 0.5;
+        a_cpl = kv_bbl / ((dmin(dhc, bbl_thick) + hn) + I_amax * kv_bbl);
+      } else if (fabs(CS.Kv_extra_bbl) > 0.0) {
+        a_cpl = (CS.Kv + CS.Kv_extra_bbl) / ((0.5 * dz_vel + hn) + I_amax * (CS.Kv + CS.Kv_extra_bbl));
+      } else {
+        a_cpl = CS.Kv / ((0.5 * dz_vel + hn) + I_amax * CS.Kv);
+      }
+    } else {                                                       // :2418-2540, Fortran K+1 between layers k and k+1
+      double Kv_tot = CS.Kv;
+      if (CS.Kvml_invZ2 > 0.) {
+        const double z_t = a_out[x + (size_t)K * slab];
+        Kv_tot = CS.Kv + CS.Kvml_invZ2 / ((z_t * z_t) * (1. + 0.09 * z_t * z_t * z_t * z_t * z_t * z_t));
+      }
+      if (Kv_shear) {
+        const double Kv_add = 0.5 * (Kv_shear[x + (size_t)K * slab] + Kv_shear[y + (size_t)K * slab]);
+        Kv_tot = Kv_tot + Kv_add;
+      }
+      if (CS.bottomdraglaw) {
+        const double z2 = z_i_below;
+        const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        Kv_tot = Kv_tot + (kv_bbl - CS.Kv) * botfn;
+        const double dhc = 0.5 * (dz_vel_below + dz_vel);
+        double h_shear;
+        if (dhc > bbl_thick) h_shear = ((1. - botfn) * dhc + botfn * bbl_thick) + hn;
+        else h_shear = dhc + hn;
+        a_cpl = Kv_tot / (h_shear + (I_amax * Kv_tot));
+      } else if (fabs(CS.Kv_extra_bbl) > 0.0) {
+        const double z2 = z_i_below;
+        const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        Kv_tot = Kv_tot + CS.Kv_extra_bbl * botfn;
+        const double h_shear = 0.5 * (dz_vel_below + dz_vel + hn);
+        a_cpl = Kv_tot / (h_shear + I_amax * Kv_tot);
+      } else {
+        const double h_shear = 0.5 * (dz_vel_below + dz_vel + hn);
+        a_cpl = Kv_tot / (h_shear + I_amax * Kv_tot);
+      }
+    }
+    a_out[x + (size_t)K * slab] = dmin(a_cpl_max, a_cpl);          // CS%a_u :1863-1867
+    z_i_below = z_i_top; dz_vel_below = dz_vel;
+  }
+  a_out[x] = dmin(a_cpl_max, 0.0);   // a_cpl(:,:,1) stays 0 without shelves / dynamic mixed-layer viscosity
+}
+
+extern "C" int mom6x_vertvisc_init(mom6x_ctx *c, const mom6x_vertvisc_params *p) {
+  REQUIRE(c && p, MOM6X_EINVAL, "mom6x_vertvisc_init: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  c->vv = *p;
+  const size_t n3 = (size_t)c->dims.slab * c->dims.nk, n3i = (size_t)c->dims.slab * (c->dims.nk + 1);
+  if (!c->vv_a_u) {
+    HIPCHK(hipMalloc(&c->vv_a_u, n3i * sizeof(double))); HIPCHK(hipMalloc(&c->vv_a_v, n3i * sizeof(double)));
+    HIPCHK(hipMalloc(&c->vv_h_u, n3 * sizeof(double))); HIPCHK(hipMalloc(&c->vv_h_v, n3 * sizeof(double)));
+  }
+  HIPCHK(hipMemsetAsync(c->vv_a_u, 0, n3i * sizeof(double), c->stream)); HIPCHK(hipMemsetAsync(c->vv_a_v, 0, n3i * sizeof(double), c->stream));
+  HIPCHK(hipMemsetAsync(c->vv_h_u, 0, n3 * sizeof(double), c->stream)); HIPCHK(hipMemsetAsync(c->vv_h_v, 0, n3 * sizeof(double), c->stream));
+  c->a_u = c->vv_a_u; c->a_v = c->vv_a_v; c->h_u = c->vv_h_u; c->h_v = c->vv_h_v;
+  c->vv_init = true;
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_vertvisc_set_visc(mom6x_ctx *c, const double *Kv_bbl_u, const double *Kv_bbl_v, const double *bbl_thick_u,
+                                       const double *bbl_thick_v, const double *Kv_shear, const double *Ray_u, const double *Ray_v) {
+  REQUIRE(c, MOM6X_EINVAL, "mom6x_vertvisc_set_visc: null ctx");
+  REQUIRE((Ray_u != nullptr) == (Ray_v != nullptr), MOM6X_EINVAL, "mom6x_vertvisc_set_visc: Ray_u and Ray_v come together");
+  c->Kv_bbl_u = Kv_bbl_u; c->Kv_bbl_v = Kv_bbl_v; c->bbl_thick_u = bbl_thick_u; c->bbl_thick_v = bbl_thick_v;
+  c->Kv_shear = Kv_shear; c->Ray_u = Ray_u; c->Ray_v = Ray_v;
+  return MOM6X_OK;
+}
+
+extern "C" double *mom6x_vertvisc_field(mom6x_ctx *c, int which) {
+  if (!c || !c->vv_init) return nullptr;
+  double *t[] = { c->vv_a_u, c->vv_a_v, c->vv_h_u, c->vv_h_v };
+  return (which >= 0 && which < 4) ? t[which] : nullptr;
+}
+
+// vertvisc_coef on u, v themselves (mode 0) or on the velocity estimates the RK2 step would hand over (modes 1, 2)
+int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, const double *u_bc, const double *v_bc,
+                      const double *u_abt, const double *v_abt, double dtx, const double *h, double dt) {
+  REQUIRE(c && c->vv_init, MOM6X_EINVAL, "MOM_vert_friction(coef): Module must be initialized before it is used.");
+  REQUIRE(u && v && h, MOM6X_EINVAL, "vertvisc_coef: null array");
+  REQUIRE(!c->vv.bottomdraglaw || (c->Kv_bbl_u && c->Kv_bbl_v && c->bbl_thick_u && c->bbl_thick_v), MOM6X_EINVAL,
+          "vertvisc_coef: BOTTOMDRAGLAW needs visc%Kv_bbl_u/v and visc%bbl_thick_u/v (mom6x_vertvisc_set_visc)");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  const dim3 b = blk2();
+  const mom6x_vgrid &GV = c->GV;
+  const double a_cpl_max = 1.0e37 * GV.Z_to_H;
+  const double I_amax = (c->vv.answer_date < 20190101) ? (1.0e-10 * GV.H_to_Z) * dt : 0.0;
+  const dim3 gu = grid3(nxa(d.ni + 1, -1), d.nj, 1, b), gv = grid3(d.ni, d.nj + 1, 1, b);
+#define VVC(M)                                                                                                                  \
+  KLAUNCH(c, "k_vertvisc_coef<0>", (k_vertvisc_coef<0, M>), gu, b, d, c->G, c->vv, u, u_bc, u_abt, dtx, h, c->Kv_bbl_u, c->bbl_thick_u, \
+          c->Kv_shear, c->vv_a_u, c->vv_h_u, GV.H_to_Z, GV.H_subroundoff, GV.dZ_subroundoff, a_cpl_max, I_amax);                \
+  KLAUNCH(c, "k_vertvisc_coef<1>", (k_vertvisc_coef<1, M>), gv, b, d, c->G, c->vv, v, v_bc, v_abt, dtx, h, c->Kv_bbl_v, c->bbl_thick_v, \
+          c->Kv_shear, c->vv_a_v, c->vv_h_v, GV.H_to_Z, GV.H_subroundoff, GV.dZ_subroundoff, a_cpl_max, I_amax)
+  if (mode == 0) { VVC(0); } else if (mode == 1) { VVC(1); } else { VVC(2); }
+#undef VVC
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_vertvisc_coef(mom6x_ctx *c, const double *u, const double *v, const double *h, double dt) {
+  return vertvisc_coef_upd(c, 0, u, v, nullptr, nullptr, nullptr, nullptr, 0.0, h, dt);
+}
+
 extern "C" int mom6x_vertvisc_set_coef(mom6x_ctx *c, const double *a_u, const double *a_v, const double *h_u,
                                        const double *h_v, const double *Ray_u, const double *Ray_v) {
   REQUIRE(c && a_u && a_v && h_u && h_v, MOM6X_EINVAL, "mom6x_vertvisc_set_coef: null mandatory array");

@@ -246,6 +246,9 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   double *up = s->up, *vp = s->vp, *hp = s->hp, *u_bc = s->u_bc_accel, *v_bc = s->v_bc_accel;
   const double *taux_bot = R.split_bottom_stress ? s->taux_bot : nullptr;
   const double *tauy_bot = R.split_bottom_stress ? s->tauy_bot : nullptr;
+  // vertvisc_coef at the three places of the step: the host callback if one is given, else the device routine if
+  // vertvisc_init was called, else nothing (the coefficient arrays handed to mom6x_vertvisc_set_coef stay as they are)
+  const bool dev_coef = c->vv_init && !(hooks && hooks->vertvisc_coef);
   auto coef_hook = [&](int stage, const double *uu, const double *vv, double dtt) -> int {
     if (hooks && hooks->vertvisc_coef) {
       HIPCHK(hipStreamSynchronize(c->stream));
@@ -265,11 +268,12 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   if (!s->CAu_pred_stored) CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));   // :552-557
   // u_bc_accel = CAu_pred + PFu + diffu ; up = mask*(u + dt*u_bc_accel)  :564-598.  up/vp at this point only feed
   // vertvisc_coef (:602-609) and are recomputed at :681-694, so they are formed only when that callback exists.
-  const bool host_coef = (hooks && hooks->vertvisc_coef);
+  const bool host_coef = (hooks && hooks->vertvisc_coef);   // up/vp are needed on the host before the solve
   KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv,
           s->diffu, s->diffv, u_bc, v_bc, (const double *)u_inst, (const double *)v_inst, host_coef ? up : (double *)nullptr,
           host_coef ? vp : (double *)nullptr, dt);
-  CHK(coef_hook(0, up, vp, dt));                                        // :602-609
+  if (dev_coef) CHK(vertvisc_coef_upd(c, 1, u_inst, v_inst, u_bc, v_bc, nullptr, nullptr, dt, h, dt));   // :591-609, up/vp on the fly
+  else CHK(coef_hook(0, up, vp, dt));                                   // :602-609
   CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :610
   passn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk });   // pass_eta :620 + pass_visc_rem :621
 
@@ -286,6 +290,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
 
   const double dt_pred = dt * R.be;                                     // :679
   if (!host_coef) {   // (with the callback, it needs up/vp before the solve: no fusion)
+    if (dev_coef) CHK(vertvisc_coef_upd(c, 2, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt_pred, h, dt_pred));   // :737-738
     // :681-694 + :754 + :763-767 in one column sweep per direction (k_vertvisc_fused)
     const bool same_dt = (R.visc_rem_dt_bug != 0);
     CHK(vertvisc_fused(c, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt_pred, up, vp, taux, tauy, dt_pred,
@@ -295,8 +300,13 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     KLAUNCH(c, "k_vel_update", k_vel_update, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
             (const double *)v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, up, vp, dt_pred);   // :681-694
     CHK(coef_hook(1, up, vp, dt_pred));                                   // :737-738
-    CHK(mom6x_vertvisc(c, up, vp, taux, tauy, dt_pred, s->taux_bot, s->tauy_bot));                 // :754
-    CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, R.visc_rem_dt_bug ? dt_pred : dt));   // :763-767
+    if (R.visc_rem_dt_bug) {   // :754 + :763-767 share dt: one sweep
+      CHK(vertvisc_fused(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, up, vp, taux, tauy, dt_pred, s->taux_bot,
+                         s->tauy_bot, s->visc_rem_u, s->visc_rem_v));
+    } else {
+      CHK(mom6x_vertvisc(c, up, vp, taux, tauy, dt_pred, s->taux_bot, s->tauy_bot));               // :754
+      CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));                            // :763-767
+    }
   }
   pass3(c, { s->visc_rem_u, s->visc_rem_v, up, vp }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :769 + pass_uvp :773
 
@@ -328,14 +338,15 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   KLAUNCH(c, "k_eta", k_eta, grid3(d.ni, d.nj, 1, b), b, d, c->G, eta, (const double *)s->eta_pred, (const double *)nullptr, 0.0);   // :946
   // u = mask*(u + dt*(u_bc_accel + u_accel_bt))  :957-966
   if (!host_coef) {   // :957-966 + :1013 + :1022 in one column sweep per direction
+    if (dev_coef) CHK(vertvisc_coef_upd(c, 2, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt, h, dt));   // :1002-1003
     CHK(vertvisc_fused(c, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt, u_inst, v_inst, taux, tauy, dt,
                        s->taux_bot, s->tauy_bot, s->visc_rem_u, s->visc_rem_v));
   } else {
     KLAUNCH(c, "k_vel_update", k_vel_update, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, (const double *)u_inst,
             (const double *)v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, u_inst, v_inst, dt);
     CHK(coef_hook(2, u_inst, v_inst, dt));                                // :1002-1003
-    CHK(mom6x_vertvisc(c, u_inst, v_inst, taux, tauy, dt, s->taux_bot, s->tauy_bot));   // :1013
-    CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :1022
+    CHK(vertvisc_fused(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, u_inst, v_inst, taux, tauy, dt, s->taux_bot,
+                       s->tauy_bot, s->visc_rem_u, s->visc_rem_v));       // :1013 + :1022
   }
   KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2);   // :1025-1027
   pass3(c, { s->visc_rem_u, s->visc_rem_v, u_inst, v_inst }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :1030 + pass_uv :1034

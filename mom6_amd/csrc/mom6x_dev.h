@@ -77,7 +77,11 @@ struct mom6x_ctx {
   mom6x_pgf_params pgf; bool pgf_init;
   double *Rlay, *g_prime;   // device copies of GV%Rlay, GV%g_prime (nk)
   const double *tv_T, *tv_S; mom6x_eos_params eos;   // tv%T, tv%S, tv%eqn_of_state (null: layered PressureForce path)
-  const double *a_u, *a_v, *h_u, *h_v, *Ray_u, *Ray_v;   // vertvisc coefficients (host-owned device arrays)
+  const double *a_u, *a_v, *h_u, *h_v, *Ray_u, *Ray_v;   // vertvisc coefficients (host-owned device arrays, or vv_* below)
+  // vertvisc_init / vertvisc_coef on the device: parameters, vertvisc_type inputs, CS%a_u.. owned by the context
+  mom6x_vertvisc_params vv; bool vv_init;
+  const double *Kv_bbl_u, *Kv_bbl_v, *bbl_thick_u, *bbl_thick_v, *Kv_shear;
+  double *vv_a_u, *vv_a_v, *vv_h_u, *vv_h_v;
   // lazily allocated 3-D scratch arrays (slot -> nlev levels)
   double *scr[MOM6X_NSCR]; int scr_nlev[MOM6X_NSCR];
   bool prof_on;
@@ -102,6 +106,9 @@ void prof_end(mom6x_ctx *c);
   } while (0)
 
 int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out);   // ctx.hip
+// dyn_kernels.hip: vertvisc_coef looking at u (mode 0), mask*(u + dtx*u_bc) (1) or mask*(u + dtx*(u_bc + u_abt)) (2)
+int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, const double *u_bc, const double *v_bc,
+                      const double *u_abt, const double *v_abt, double dtx, const double *h, double dt);
 // dyn_kernels.hip: [u = mask*(u_in + dtx*(u_bc + u_abt));] vertvisc(u, v, dt); [vertvisc_remnant(vr_u, vr_v, dt)] in one sweep
 int vertvisc_fused(mom6x_ctx *c, const double *u_in, const double *v_in, const double *u_bc, const double *v_bc,
                    const double *u_abt, const double *v_abt, double dtx, double *u, double *v, const double *taux,

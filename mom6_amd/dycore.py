@@ -180,6 +180,28 @@ class Dycore:
         self._vv = (a_u, a_v, h_u, h_v, Ray_u, Ray_v)
         check(self.lib, self.lib.mom6x_vertvisc_set_coef(self.ctx, _ptr(a_u), _ptr(a_v), _ptr(h_u), _ptr(h_v), _ptr(Ray_u), _ptr(Ray_v)))
 
+    def vertvisc_init(self, params):
+        """vertvisc_init (MOM_vert_friction.F90:3135): CS%a_u, a_v, h_u, h_v now live in the context."""
+        self.vv_params = params
+        check(self.lib, self.lib.mom6x_vertvisc_init(self.ctx, C.byref(params)))
+
+    def vertvisc_set_visc(self, Kv_bbl_u=None, Kv_bbl_v=None, bbl_thick_u=None, bbl_thick_v=None, Kv_shear=None, Ray_u=None, Ray_v=None):
+        """The vertvisc_type members vertvisc_coef / vertvisc read (set_viscous_BBL etc. stay on the host)."""
+        self._visc = (Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v, Kv_shear, Ray_u, Ray_v)
+        check(self.lib, self.lib.mom6x_vertvisc_set_visc(self.ctx, *[_ptr(a) for a in self._visc]))
+
+    def vertvisc_field(self, name):
+        """CS%a_u / a_v / h_u / h_v of the device vertvisc_CS as a torch view."""
+        which = ["a_u", "a_v", "h_u", "h_v"].index(name)
+        self.lib.mom6x_vertvisc_field.restype = C.c_void_p
+        p = self.lib.mom6x_vertvisc_field(self.ctx, which)
+        nlev = self.dims.nk + (1 if which < 2 else 0)
+        return _view(p, (nlev,) + self.dims.shape2(), self.device)
+
+    def vertvisc_coef(self, u, v, h, dt):
+        """vertvisc_coef (MOM_vert_friction.F90:1357) with dz = H_to_Z*h."""
+        check(self.lib, self.lib.mom6x_vertvisc_coef(self.ctx, _ptr(u), _ptr(v), _ptr(h), C.c_double(dt)))
+
     def vertvisc(self, u, v, taux, tauy, dt, taux_bot=None, tauy_bot=None):
         """vertvisc (MOM_vert_friction.F90:557)."""
         check(self.lib, self.lib.mom6x_vertvisc(self.ctx, _ptr(u), _ptr(v), _ptr(taux), _ptr(tauy), C.c_double(dt),

@@ -142,6 +142,14 @@ def PressureForce(d, G, GV, CS, Rlay, g_prime, h, PFu, PFv, pbce=None, eta=None,
         raise RuntimeError(f"orc_PressureForce rc={rc}")
 
 
+def vertvisc_coef(d, G, GV, CS, u, v, h, dt, a_u, a_v, h_u, h_v, Kv_bbl_u=None, Kv_bbl_v=None, bbl_thick_u=None,
+                  bbl_thick_v=None, Kv_shear=None):
+    rc = lib().orc_vertvisc_coef(C.byref(d), _p(G), C.byref(GV), C.byref(CS), _p(u), _p(v), _p(h), C.c_double(dt), _p(Kv_bbl_u),
+                                 _p(Kv_bbl_v), _p(bbl_thick_u), _p(bbl_thick_v), _p(Kv_shear), _p(a_u), _p(a_v), _p(h_u), _p(h_v))
+    if rc != 0:
+        raise RuntimeError(f"orc_vertvisc_coef rc={rc}")
+
+
 def vertvisc(d, G, GV, u, v, a_u, a_v, h_u, h_v, Ray_u, Ray_v, taux, tauy, dt, taux_bot=None, tauy_bot=None):
     rc = lib().orc_vertvisc(C.byref(d), _p(G), C.byref(GV), _p(u), _p(v), _p(a_u), _p(a_v), _p(h_u), _p(h_v), _p(Ray_u),
                             _p(Ray_v), _p(taux), _p(tauy), C.c_double(dt), _p(taux_bot), _p(tauy_bot))
@@ -174,7 +182,10 @@ class Rk2All(C.Structure):
     _fields_ = [("d", C.c_void_p), ("G", C.c_void_p), ("GV", C.c_void_p), ("cont", C.c_void_p), ("bt", C.c_void_p),
                 ("cor", C.c_void_p), ("pgf", C.c_void_p), ("rk2", C.c_void_p), ("Rlay", C.c_void_p), ("g_prime", C.c_void_p),
                 ("CS", C.c_void_p), ("BTCS", C.c_void_p), ("BT_cont", C.c_void_p), ("first_direction", C.c_int),
-                ("T", C.c_void_p), ("S", C.c_void_p), ("eos", C.c_void_p)]
+                ("T", C.c_void_p), ("S", C.c_void_p), ("eos", C.c_void_p), ("vv", C.c_void_p),
+                ("Kv_bbl_u", C.c_void_p), ("Kv_bbl_v", C.c_void_p), ("bbl_thick_u", C.c_void_p), ("bbl_thick_v", C.c_void_p),
+                ("Kv_shear", C.c_void_p), ("Ray_u", C.c_void_p), ("Ray_v", C.c_void_p),
+                ("vv_a_u", C.c_void_p), ("vv_a_v", C.c_void_p), ("vv_h_u", C.c_void_p), ("vv_h_v", C.c_void_p)]
 
 
 class OrcModel:
@@ -200,8 +211,23 @@ class OrcModel:
         A.Rlay = self.Rlay.ctypes.data; A.g_prime = self.g_prime.ctypes.data
         A.CS = C.addressof(self.cs); A.BTCS = C.addressof(self.btcs.struct); A.BT_cont = C.addressof(self.bt_cont_s)
         A.first_direction = first_direction
-        A.T = None; A.S = None; A.eos = None
+        A.T = None; A.S = None; A.eos = None; A.vv = None
         self.A = A
+
+    def set_vertvisc(self, vv, Kv_bbl_u=None, Kv_bbl_v=None, bbl_thick_u=None, bbl_thick_v=None, Kv_shear=None,
+                     Ray_u=None, Ray_v=None):
+        """vertvisc_init + the vertvisc_type inputs: the step then calls vertvisc_coef itself (coefs argument ignored)."""
+        d = self.d
+        self._vv = (vv, Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v, Kv_shear, Ray_u, Ray_v)
+        self.vv_out = dict(a_u=np.zeros((d.nk + 1,) + d.shape2()), a_v=np.zeros((d.nk + 1,) + d.shape2()),
+                           h_u=np.zeros(d.shape3()), h_v=np.zeros(d.shape3()))
+        A = self.A
+        A.vv = C.addressof(vv)
+        for n, a in (("Kv_bbl_u", Kv_bbl_u), ("Kv_bbl_v", Kv_bbl_v), ("bbl_thick_u", bbl_thick_u), ("bbl_thick_v", bbl_thick_v),
+                     ("Kv_shear", Kv_shear), ("Ray_u", Ray_u), ("Ray_v", Ray_v)):
+            setattr(A, n, a.ctypes.data if a is not None else None)
+        A.vv_a_u = self.vv_out["a_u"].ctypes.data; A.vv_a_v = self.vv_out["a_v"].ctypes.data
+        A.vv_h_u = self.vv_out["h_u"].ctypes.data; A.vv_h_v = self.vv_out["h_v"].ctypes.data
 
     def set_tv(self, T, S, eos):
         """tv%T, tv%S, tv%eqn_of_state for the PressureForce calls of the step (None: layered path)."""

@@ -48,6 +48,10 @@ int orc_vertvisc_remnant(const mom6x_dims *d, const double *G, double *visc_rem_
                          const double *Ray_v, double dt);
 
 typedef struct { const double *a_u, *a_v, *h_u, *h_v, *Ray_u, *Ray_v; } orc_visc_coef;
+int orc_vertvisc_coef(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_vertvisc_params *CS,
+                      const double *u, const double *v, const double *h, double dt, const double *Kv_bbl_u,
+                      const double *Kv_bbl_v, const double *bbl_thick_u, const double *bbl_thick_v, const double *Kv_shear,
+                      double *a_u, double *a_v, double *h_u, double *h_v);
 
 /* MOM_dyn_split_RK2_CS (RK2.F90:85-273): the arrays, all HOST pitched */
 typedef struct orc_rk2_cs {
@@ -63,6 +67,11 @@ typedef struct orc_rk2_all {   /* everything step_MOM_dyn_split_RK2 reaches thro
   const mom6x_pgf_params *pgf; const mom6x_rk2_params *rk2; const double *Rlay, *g_prime;
   orc_rk2_cs *CS; orc_bt_cs *BTCS; const mom6x_BT_cont *BT_cont; int first_direction;
   const double *T, *S; const mom6x_eos_params *eos;   /* tv%T, tv%S, tv%eqn_of_state (NULL: layered) */
+  /* vertvisc_CS + vertvisc_type inputs: when vv != NULL the three vertvisc_coef calls of the step are made here and
+   * fill vv_a_u..vv_h_v (caller-allocated); otherwise the caller's coef[stage] sets are used. */
+  const mom6x_vertvisc_params *vv;
+  const double *Kv_bbl_u, *Kv_bbl_v, *bbl_thick_u, *bbl_thick_v, *Kv_shear, *Ray_u, *Ray_v;
+  double *vv_a_u, *vv_a_v, *vv_h_u, *vv_h_v;
 } orc_rk2_all;
 
 /* the new-run branch of initialize_dyn_split_RK2 :1577-1650 (+ barotropic_init ubtav :6124-6135 is done by the
@@ -103,8 +112,15 @@ int orc_initialize_dyn_split_RK2(const orc_rk2_all *A, const double *u, const do
 
 int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst, double *h, double *uh, double *vh,
                            double *uhtr, double *vhtr, double *eta_av, const double *taux, const double *tauy,
-                           double dt, int calc_dtbt, const orc_visc_coef coef[3], const double *diffu_new,
+                           double dt, int calc_dtbt, const orc_visc_coef coef_in[3], const double *diffu_new,
                            const double *diffv_new) {
+  orc_visc_coef coef[3];
+  for (int s_ = 0; s_ < 3; s_++) {
+    if (A->vv) { orc_visc_coef c_ = { A->vv_a_u, A->vv_a_v, A->vv_h_u, A->vv_h_v, A->Ray_u, A->Ray_v }; coef[s_] = c_; }
+    else coef[s_] = coef_in[s_];
+  }
+#define VV_COEF(uu, vv_, dtt) do { if (A->vv) { int rc_ = orc_vertvisc_coef(A->d, A->G, A->GV, A->vv, uu, vv_, h, dtt, A->Kv_bbl_u, A->Kv_bbl_v, \
+    A->bbl_thick_u, A->bbl_thick_v, A->Kv_shear, A->vv_a_u, A->vv_a_v, A->vv_h_u, A->vv_h_v); if (rc_) return rc_; } } while (0)
   const mom6x_dims *d = A->d; const double *G = A->G; const mom6x_vgrid *GV = A->GV; orc_rk2_cs *CS = A->CS;
   const mom6x_rk2_params *R = A->rk2;
   const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1, nz = d->nk;
@@ -150,6 +166,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
     }
   }
   /* vertvisc_coef(up, vp, h, dt) -> coef[0]; vertvisc_remnant :609-610 */
+  VV_COEF(up, vp, dt);
   orc_vertvisc_remnant(d, G, CS->visc_rem_u, CS->visc_rem_v, coef[0].a_u, coef[0].a_v, coef[0].h_u, coef[0].h_v,
                        coef[0].Ray_u, coef[0].Ray_v, dt);
   orc_pass_var(d, eta, 0, 1); /* pass_eta :620 */
@@ -181,6 +198,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
     }
   }
   /* vertvisc_coef(up, vp, h, dt_pred) -> coef[1]; vertvisc :738-755 */
+  VV_COEF(up, vp, dt_pred);
   orc_vertvisc(d, G, GV, up, vp, coef[1].a_u, coef[1].a_v, coef[1].h_u, coef[1].h_v, coef[1].Ray_u, coef[1].Ray_v, taux,
                tauy, dt_pred, CS->taux_bot, CS->tauy_bot);
   orc_vertvisc_remnant(d, G, CS->visc_rem_u, CS->visc_rem_v, coef[1].a_u, coef[1].a_v, coef[1].h_u, coef[1].h_v,
@@ -245,6 +263,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
     }
   }
   /* vertvisc_coef(u, v, h, dt) -> coef[2]; vertvisc; vertvisc_remnant :1003-1022 */
+  VV_COEF(u_inst, v_inst, dt);
   orc_vertvisc(d, G, GV, u_inst, v_inst, coef[2].a_u, coef[2].a_v, coef[2].h_u, coef[2].h_v, coef[2].Ray_u, coef[2].Ray_v,
                taux, tauy, dt, CS->taux_bot, CS->tauy_bot);
   orc_vertvisc_remnant(d, G, CS->visc_rem_u, CS->visc_rem_v, coef[2].a_u, coef[2].a_v, coef[2].h_u, coef[2].h_v,

@@ -165,3 +165,45 @@ def test_vertvisc_and_remnant(orc, cfg, use_ray):
         H.assert_bitwise(a.cpu().numpy(), b, name, H.interior(d, st))
     assert 0 < vru[(Ellipsis,) + H.interior(d, "u")].max() <= 1.0 + 1e-12
     dyc.close()
+
+
+def visc_inputs(d, M, with_shear=True):
+    """visc%Kv_bbl_u/v, visc%bbl_thick_u/v (set_viscous_BBL outputs) and visc%Kv_shear: plausible fields."""
+    Kv_bbl_u = np.ascontiguousarray((2e-3 * (1 + 0.5 * synth.smooth_field(d, 91, ox=1, oy=.5))) * M[G["mask2dCu"]])
+    Kv_bbl_v = np.ascontiguousarray((2e-3 * (1 + 0.5 * synth.smooth_field(d, 92, ox=.5, oy=1))) * M[G["mask2dCv"]])
+    bt_u = np.ascontiguousarray(8.0 * (1 + 0.6 * synth.smooth_field(d, 93, ox=1, oy=.5)))
+    bt_v = np.ascontiguousarray(8.0 * (1 + 0.6 * synth.smooth_field(d, 94, ox=.5, oy=1)))
+    Kv_shear = None
+    if with_shear:
+        Kv_shear = np.ascontiguousarray(1e-3 * np.abs(synth.smooth_field(d, 95, nk=d.nk + 1, ox=.5, oy=.5)))
+    return Kv_bbl_u, Kv_bbl_v, bt_u, bt_v, Kv_shear
+
+
+@pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
+@pytest.mark.parametrize("mods", [dict(), dict(harmonic_visc=1), dict(bottomdraglaw=0, Kv_extra_bbl=5e-4, harm_BL_val=0.5),
+                                  dict(bottomdraglaw=0), dict(Kvml_invZ2=1e-3, answer_date=20181231, harm_BL_val=1.0)])
+def test_vertvisc_coef(orc, cfg, mods):
+    """vertvisc_coef + find_coupling_coef on the device against the oracle, bit for bit."""
+    import torch
+    from mom6_amd.dycore import Dycore
+    gg, d, M = getattr(H, cfg)()
+    GV = abi.vgrid_default()
+    P = abi.vertvisc_params_default()
+    for k, v in mods.items():
+        setattr(P, k, v)
+    h, u, v = synth.make_state(d, M, thin_frac=0.1)
+    Kbu, Kbv, btu, btv, Ksh = visc_inputs(d, M, with_shear=("harmonic_visc" not in mods))
+    o = dict(a_u=np.zeros((d.nk + 1,) + d.shape2()), a_v=np.zeros((d.nk + 1,) + d.shape2()), h_u=np.zeros_like(h), h_v=np.zeros_like(h))
+    orc.vertvisc_coef(d, M, GV, P, u, v, h, 1200.0, o["a_u"], o["a_v"], o["h_u"], o["h_v"], Kbu, Kbv, btu, btv, Ksh)
+    dyc = Dycore(d, M, GV)
+    dyc.vertvisc_init(P)
+    dev = [dyc.to_dev(a) if a is not None else None for a in (Kbu, Kbv, btu, btv, Ksh)]
+    dyc.vertvisc_set_visc(*dev)
+    ud, vd, hd = dyc.to_dev(u), dyc.to_dev(v), dyc.to_dev(h)
+    torch.cuda.synchronize()
+    dyc.vertvisc_coef(ud, vd, hd, 1200.0)
+    dyc.sync()
+    for n, stg in (("a_u", "u"), ("a_v", "v"), ("h_u", "u"), ("h_v", "v")):
+        H.assert_bitwise(dyc.vertvisc_field(n).cpu().numpy(), o[n], n, H.interior(d, stg))
+    assert o["a_u"][1:].max() > 0 and np.isfinite(o["a_u"]).all() and o["h_u"].max() > 0
+    dyc.close()

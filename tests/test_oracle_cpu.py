@@ -170,3 +170,29 @@ def test_pressure_force_eos_consistency(orc):
         su2, sv2 = H.interior(d2, "u"), H.interior(d2, "v")
         assert np.abs(Pu[(Ellipsis,) + su2] * M2[G["mask2dCu"]][su2]).max() < 1e-12
         assert np.abs(Pv[(Ellipsis,) + sv2] * M2[G["mask2dCv"]][sv2]).max() < 1e-12
+
+
+def test_vertvisc_coef_known_answers(orc):
+    """vertvisc_coef on uniform layers at rest: hvel is the (arithmetic = harmonic) thickness, the interior coupling
+    coefficient is Kv / (h + dz_neglect) (find_coupling_coef :2536-2539) and the bottom one Kv / (h/2 + dz_neglect);
+    with BOTTOMDRAGLAW the bottom coefficient is kv_bbl / (min(h/2, bbl_thick) + dz_neglect) (:2543-2547)."""
+    gg, d, M = H.channel()
+    GV = abi.vgrid_default()
+    hk = 1000.0 / d.nk
+    h = np.full(d.shape3(), hk); u = np.zeros_like(h); v = np.zeros_like(h)
+    P = abi.vertvisc_params_default(Kv=1e-3)
+    P.bottomdraglaw = 0
+    out = dict(a_u=np.zeros((d.nk + 1,) + d.shape2()), a_v=np.zeros((d.nk + 1,) + d.shape2()), h_u=np.zeros_like(h), h_v=np.zeros_like(h))
+    orc.vertvisc_coef(d, M, GV, P, u, v, h, 600.0, out["a_u"], out["a_v"], out["h_u"], out["h_v"])
+    su = H.interior(d, "u"); wet = M[G["mask2dCu"]][su] > 0
+    assert np.all(out["h_u"][(Ellipsis,) + su][:, wet] == hk + GV.H_subroundoff)
+    assert np.all(out["a_u"][(0,) + su] == 0.0)
+    for K in range(1, d.nk):
+        np.testing.assert_allclose(out["a_u"][(K,) + su][wet], 1e-3 / (hk + GV.dZ_subroundoff), rtol=1e-15)
+    np.testing.assert_allclose(out["a_u"][(d.nk,) + su][wet], 1e-3 / (0.5 * hk + GV.dZ_subroundoff), rtol=1e-15)
+    P.bottomdraglaw = 1
+    kvb = np.full(d.shape2(), 5e-3); bth = np.full(d.shape2(), 20.0)
+    orc.vertvisc_coef(d, M, GV, P, u, v, h, 600.0, out["a_u"], out["a_v"], out["h_u"], out["h_v"], kvb, kvb, bth, bth)
+    np.testing.assert_allclose(out["a_u"][(d.nk,) + su][wet], 5e-3 / (min(0.5 * hk, 20.0 + GV.dZ_subroundoff) + GV.dZ_subroundoff), rtol=1e-15)
+    # far above the bottom boundary layer the drag-law correction vanishes: botfn = 1/(1+0.09 z^6) with z >> 1
+    np.testing.assert_allclose(out["a_u"][(1,) + su][wet], 1e-3 / (hk + GV.dZ_subroundoff), rtol=1e-6)

@@ -20,7 +20,7 @@ STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h",
 
 
 def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, per_stage=False, new_diff=False,
-        exact=True, rtol=1e-11, eos_form=None):
+        exact=True, rtol=1e-11, eos_form=None, dev_vv=None):
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
@@ -37,7 +37,14 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
         Tt, St = cases.thermo_state(d, M)
         tv = (Tt, St, abi.eos_params_default(eos_form))
     # ---------------- oracle
-    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction, tv=tv)
+    vvset = None
+    if dev_vv is not None:   # vertvisc_coef inside the step (no coefficient sets from outside)
+        from tests.test_dyn_gpu import visc_inputs
+        P = abi.vertvisc_params_default()
+        for k_, v_ in dev_vv.items():
+            setattr(P, k_, v_)
+        vvset = (P,) + tuple(visc_inputs(d, M)) + (coefs[0][4], coefs[0][5])
+    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction, tv=tv, vv=vvset)
 
     # ---------------- device
     cont2, bt2, cor2, pgf2, rk22 = params()
@@ -50,7 +57,12 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
     sg = dict(u=dyc.to_dev(u), v=dyc.to_dev(v), h=dyc.to_dev(h), uh=dyc.zeros3(), vh=dyc.zeros3(), uhtr=dyc.zeros3(),
               vhtr=dyc.zeros3(), eta_av=dyc.zeros2())
     cdev = [tuple(dyc.to_dev(a) if a is not None else None for a in c) for c in (coefs if per_stage else coefs[:1])]
-    dyc.vertvisc_set_coef(*cdev[0])
+    if vvset is None:
+        dyc.vertvisc_set_coef(*cdev[0])
+    else:
+        dyc.vertvisc_init(vvset[0])
+        vdev = [dyc.to_dev(a) if a is not None else None for a in vvset[1:]]
+        dyc.vertvisc_set_visc(*vdev)
     txd, tyd = dyc.to_dev(taux), dyc.to_dev(tauy)
     dnew = tuple(dyc.to_dev(a) for a in diff_new) if diff_new else None
     torch.cuda.synchronize()
@@ -128,6 +140,12 @@ def test_rk2_device_matches_committed_golden(orc):
 @pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
 def test_rk2_with_equation_of_state(orc, form):
     run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(begw=0.2), eos_form=form)
+
+
+@pytest.mark.parametrize("mods", [dict(), dict(harmonic_visc=1, bottomdraglaw=0)])
+def test_rk2_with_device_vertvisc_coef(orc, mods):
+    """vertvisc_coef called by the step itself at :609, :738, :1003 (mom6x_vertvisc_init), no host callback."""
+    run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), dev_vv=mods)
 
 
 def test_rk2_default_path_tolerance(orc):
