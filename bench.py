@@ -121,6 +121,8 @@ def tracer_leg(args, dyc, d, st, step, barrier, dist):
         prof_enable(dyc, True); prof_reset(dyc)
         dyc.advect_tracer(h, st["uhtr"], st["vhtr"], 2.0 * args.dt, [t.clone() for t in tr]); dyc.sync()
         for k, (cnt, ms) in sorted(prof_report(dyc).items(), key=lambda kv: -kv[1][1]):
+            if cnt == 0:
+                continue
             print(f"[tracer] {k:22s} n={cnt:5d} total={ms:9.3f} ms avg={ms / cnt * 1e3:9.1f} us", file=sys.stderr)
         prof_enable(dyc, False)
     ea = (1.0e-3 * h).contiguous(); eb = (2.0e-3 * h).contiguous()
@@ -323,6 +325,8 @@ def main():
         out["kernel_sum_ms"] = round(tot, 2)
         if args.breakdown:
             for k, (cnt, ms) in sorted(full.items(), key=lambda kv: -kv[1][1]):
+                if cnt == 0:
+                    continue
                 print(f"{k:28s} n={cnt:5d} total={ms:9.3f} ms avg={ms / cnt * 1e3:9.1f} us ({100 * ms / tot:5.1f}%)", file=sys.stderr)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
