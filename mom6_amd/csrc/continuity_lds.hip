@@ -23,6 +23,7 @@
 // HBM traffic per face-layer: read h (+halo re-reads from L2), u, visc_rem; write uh, u_cor, h_u.
 #include "continuity_dev.h"
 #include "continuity_lds.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -169,12 +170,18 @@ __device__ __forceinline__ double wg_flux_adjust(const Tile &T, bool face, const
                                                  const double (&v_r)[MAXL], double IareaMin, double uhbt,
                                                  double uh_tot_0, double duhdu_tot_0, double du_max,
                                                  double du_min, double tol_eta_cs, double tol_vel,
-                                                 int better_iter, bool store) {
+                                                 int better_iter, bool store, bool lazy, bool &need_exact) {
+  // `lazy`: du_max / du_min are not the CFL limits themselves but a lower / an upper bound of them (see the
+  // caller).  The limits only matter in the tests "du >= du_max" / "du <= du_min"; as long as every such test is
+  // decided by the bound alone the result is the one the exact limits give.  The first test that is not ends the
+  // solve for the whole work-group with need_exact = true, and the caller repeats it with the exact limits.
   const int max_itts = 20;
   double du = 0.0;
   double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0;
   double uh_err_best = fabs(uh_err);
   bool do_I = face;
+  bool max_lazy = lazy, min_lazy = lazy, undecided = false;
+  need_exact = false;
   for (int itt = 1; itt <= max_itts; itt++) {
     if (do_I) {
       double tol_eta;
@@ -183,8 +190,8 @@ __device__ __forceinline__ double wg_flux_adjust(const Tile &T, bool face, const
       else if (itt == 3) tol_eta = 1e-2 * tol_eta_cs;
       else tol_eta = tol_eta_cs;
 
-      if (uh_err > 0.0) du_max = du;
-      else if (uh_err < 0.0) du_min = du;
+      if (uh_err > 0.0) { du_max = du; max_lazy = false; }
+      else if (uh_err < 0.0) { du_min = du; min_lazy = false; }
       else do_I = false;
 
       if (do_I) {
@@ -196,11 +203,13 @@ __device__ __forceinline__ double wg_flux_adjust(const Tile &T, bool face, const
           if (fabs(ddu) < 1.0e-15 * fabs(du)) {
             do_I = false;
           } else if (ddu > 0.0) {
+            if (max_lazy && !(du < du_max)) undecided = true;
             if (du >= du_max) {
               du = 0.5 * (du_prev + du_max);
               if (du_max - du_prev < 1.0e-15 * fabs(du)) do_I = false;
             }
           } else {
+            if (min_lazy && !(du > du_min)) undecided = true;
             if (du <= du_min) {
               du = 0.5 * (du_prev + du_min);
               if (du_prev - du_min < 1.0e-15 * fabs(du)) do_I = false;
@@ -212,7 +221,9 @@ __device__ __forceinline__ double wg_flux_adjust(const Tile &T, bool face, const
       }
     }
     if (T.lead) { T.s_du[T.fl] = du; T.s_doI[T.fl] = do_I ? 1 : 0; }
-    if (!__syncthreads_or(do_I ? 1 : 0)) break;
+    const int wg = __ockl_wgred_or_i32((do_I ? 1 : 0) | (undecided ? 2 : 0));   // barrier + bitwise OR over the work-group
+    if (wg & 2) { need_exact = true; break; }
+    if (!(wg & 1)) break;
 
     if ((itt < max_itts) || store) {
       if (T.s_doI[T.fl]) {
@@ -240,12 +251,17 @@ __device__ __forceinline__ double wg_flux_adjust(const Tile &T, bool face, const
   return du;
 }
 
-template <int DIR, int KL, int MAXL>
+template <int DIR, int KL, int MAXL, bool LAZY>
 __global__ void __launch_bounds__(NF * KL, (KL * MAXL > 96) ? 1 : (KL == 32 ? 4 : (DIR ? 2 : 3)))   // LDS lets 3 (x) | 2 (y) work-groups share a CU at nk = 75
 k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
+  // The LAZY kernel runs flux_adjust with cheap bounds of the CFL limits; a work-group whose Newton steps come within
+  // reach of them marks its tile in E.retry and stops.  The exact kernel (second launch, same grid) only works on the
+  // marked tiles, with the limits from the k-recurrence, and rewrites all of the tile's outputs.
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  if (!LAZY && E.retry && !E.retry[tile]) return;
   extern __shared__ double smem[];
   constexpr int NC = DIR ? 2 * NF : NF + 1;
-  const int nk = d.nk, nkp = (nk + 1) & ~1;
+  const int nk = d.nk, nkp = max((nk + 1) & ~1, KL);   // the transit arrays double as [KL][NF] reduction scratch
   double *sL = smem, *sR = sL + nk * NC, *sC = sR + nk * NC, *sA = sC + nk * NC, *sB = sA + nkp * NF;
   __shared__ double s_du[NF], s_duL[NF], s_duR[NF], s_red[KL][NF];
   __shared__ int s_doI[NF];
@@ -389,46 +405,82 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
 #pragma unroll
       for (int q = 0; q < KL; q++) visc_rem_max = dmax(visc_rem_max, s_red[q][fl]);
     }
-    const double CFL_dt = A.CFL_limit_adjust / dt;
-    const double dx_W = D.dT[f2], dx_E = D.dT[f2 + st];
-    double I_vrm = 0.0;
-    if (visc_rem_max > 0.0) I_vrm = 1.0 / visc_rem_max;
+  }
+  const double CFL_dt = A.CFL_limit_adjust / dt;
+  const double dx_W = D.dT[f2], dx_E = D.dT[f2 + st];
+  const double maskC = D.maskC[f2];
+  double I_vrm = 0.0;
+  if (visc_rem_max > 0.0) I_vrm = 1.0 / visc_rem_max;
+  // The exact limits (:646-723): with visc_rem a k-recurrence with two divisions per layer.  All lanes must call.
+  auto exact_bounds = [&]() {
     du_max_CFL = 2.0 * (CFL_dt * dx_W) * I_vrm;
     du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
-    const double maskC = D.maskC[f2];
-    if (use_visc_rem) {
-      recurrence4<KL, MAXL>(T, face,
-        [&](int n, double *o) {
-          o[0] = u_r[n]; o[1] = v_r[n];
-          o[2] = (dx_W * CFL_dt - u_r[n]) / v_r[n];
-          o[3] = -(dx_E * CFL_dt + u_r[n]) / v_r[n];
-        },
-        [&](double uk, double vrem, double q_max, double q_min) {
-          if (du_max_CFL * vrem > dx_W * CFL_dt - uk * maskC) du_max_CFL = q_max;
-          if (du_min_CFL * vrem < -dx_E * CFL_dt - uk * maskC) du_min_CFL = q_min;
-        });
-    } else {
-      recurrence4<KL, MAXL>(T, face,
-        [&](int n, double *o) { o[0] = u_r[n]; o[1] = 0.0; o[2] = 0.0; o[3] = 0.0; },
-        [&](double uk, double, double, double) {
-          du_max_CFL = dmin(du_max_CFL, dx_W * CFL_dt - uk);
-          du_min_CFL = dmax(du_min_CFL, -(dx_E * CFL_dt + uk));
-        });
-    }
+    recurrence4<KL, MAXL>(T, face,
+      [&](int n, double *o) {
+        o[0] = u_r[n]; o[1] = v_r[n];
+        o[2] = (dx_W * CFL_dt - u_r[n]) / v_r[n];
+        o[3] = -(dx_E * CFL_dt + u_r[n]) / v_r[n];
+      },
+      [&](double uk, double vrem, double q_max, double q_min) {
+        if (du_max_CFL * vrem > dx_W * CFL_dt - uk * maskC) du_max_CFL = q_max;
+        if (du_min_CFL * vrem < -dx_E * CFL_dt - uk * maskC) du_min_CFL = q_min;
+      });
     du_max_CFL = dmax(du_max_CFL, 0.0);
     du_min_CFL = dmin(du_min_CFL, 0.0);
-  }
-
-  // ---- first sweep: layer transports and their column sums (:615-668) -------------------------------
+  };
+  if (need_adjust) {
+    // min_k (dx_W*CFL_dt - u_k) and min_k (dx_E*CFL_dt + u_k) over the layer lanes (order-independent, exact)
+    double nmin = 1.0e300, mmin = 1.0e300;
+    bool vr_ok = true;
 #pragma unroll
-  for (int n = 0; n < MAXL; n++) {
-    const int k = kl + KL * n;
-    if (k < nk) {
-      double uh, duhdu;
-      flux_lds(u_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh, duhdu);
-      sA[k * NF + fl] = uh; sB[k * NF + fl] = duhdu;
+    for (int n = 0; n < MAXL; n++) {
+      if (kl + KL * n < nk) {
+        nmin = dmin(nmin, dx_W * CFL_dt - u_r[n]);
+        mmin = dmin(mmin, dx_E * CFL_dt + u_r[n]);
+        if (!(v_r[n] >= 0.0 && v_r[n] <= 1.0 + 1.0e-10)) vr_ok = false;   // (visc_rem can exceed 1 by round-off)
+      }
+    }
+    if (!vr_ok) { nmin = -1.0; mmin = -1.0; }
+    __syncthreads();                       // (s_red readers of the visc_rem_max reduction are done)
+    sA[kl * NF + fl] = nmin; sB[kl * NF + fl] = mmin;
+    __syncthreads();
+    nmin = 1.0e300; mmin = 1.0e300;
+#pragma unroll
+    for (int q = 0; q < KL; q++) { nmin = dmin(nmin, sA[q * NF + fl]); mmin = dmin(mmin, sB[q * NF + fl]); }
+    __syncthreads();                       // sA|sB are free again
+    const double D0max = 2.0 * (CFL_dt * dx_W) * I_vrm, D0min = -2.0 * (CFL_dt * dx_E) * I_vrm;
+    if (!use_visc_rem) {
+      // :709-716: plain min / max chains, exact in any order
+      du_max_CFL = dmax(dmin(D0max, nmin), 0.0);
+      du_min_CFL = dmin(dmax(D0min, -mmin), 0.0);
+    } else if (!LAZY) {
+      exact_bounds();
+    } else {
+      // With visc_rem the recurrence leaves du_max_CFL equal to D0max or to one of q_k = (dx_W*CFL_dt - u_k)/visc_rem_k,
+      // and q_k >= (1 - 1e-10)*(dx_W*CFL_dt - u_k) whenever that is >= 0 and 0 <= visc_rem_k <= 1 + 1e-10: so
+      // (1 - 1e-9)*min(D0max, nmin) is a lower bound of du_max_CFL, and likewise for du_min_CFL from above.  flux_adjust is run with
+      // these bounds first (see wg_flux_adjust); the recurrence itself is only needed if a Newton step reaches them.
+      const double shrink = 1.0 - 1.0e-9;
+      du_max_CFL = (nmin >= 0.0) ? shrink * dmax(dmin(D0max, nmin), 0.0) : -1.0e300;
+      du_min_CFL = (mmin >= 0.0) ? shrink * dmin(dmax(D0min, -mmin), 0.0) : 1.0e300;
     }
   }
+  const bool lazy = LAZY && use_visc_rem && (E.retry != nullptr);   // flux_adjust runs with bounds of the limits
+  // The first sweep (:615-668): layer transports and their derivatives of this lane's layers into the transit arrays
+  auto first_sweep = [&]() {
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = kl + KL * n;
+      if (k < nk) {
+        double uh, duhdu;
+        flux_lds(u_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh, duhdu);
+        sA[k * NF + fl] = uh; sB[k * NF + fl] = duhdu;
+      }
+    }
+  };
+
+  // ---- first sweep: layer transports and their column sums (:615-668) -------------------------------
+  first_sweep();
   double uh_tot_0 = 0.0, duhdu_tot_0 = 0.0;
   if (need_adjust) {
     __syncthreads();
@@ -442,8 +494,10 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   const bool corrected = (A.uhbt != nullptr);
   if (corrected) {
     const double uhbt = face ? A.uhbt[f2] : 0.0;
-    const double du = wg_flux_adjust<KL, MAXL>(T, face, u_r, v_r, IareaMin, uhbt, uh_tot_0, duhdu_tot_0, du_max_CFL,
-                                           du_min_CFL, A.tol_eta, A.tol_vel, A.better_iter, true);
+    bool redo;
+    const double du = wg_flux_adjust<KL, MAXL>(T, face, u_r, v_r, IareaMin, uhbt, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
+                                               A.tol_eta, A.tol_vel, A.better_iter, true, lazy, redo);
+    if (lazy && redo) { if (tid == 0) E.retry[tile] = 1; return; }   // work-group-uniform
     if (face && A.du_cor) A.du_cor[f2] = du;
     du_fin = s_du[fl];   // published by the face lane before the last barrier of the loop
   }
@@ -495,8 +549,10 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   // ---- set_zonal_BT_cont :1246-1409 / set_merid_BT_cont :2143-2304 -----------------------------------
   __syncthreads();
   const double Idt = 1.0 / dt, min_visc_rem = 0.1, CFL_min = 1e-6;
-  const double du0f = wg_flux_adjust<KL, MAXL>(T, face, u_r, v_r, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL,
-                                           du_min_CFL, A.tol_eta, A.tol_vel, A.better_iter, false);
+  bool redo0;
+  const double du0f = wg_flux_adjust<KL, MAXL>(T, face, u_r, v_r, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
+                                               A.tol_eta, A.tol_vel, A.better_iter, false, lazy, redo0);
+  if (lazy && redo0) { if (tid == 0) E.retry[tile] = 1; return; }
   const double du0 = face ? du0f : 0.0;
   const double du_CFL = (CFL_min * Idt) * D.dC[f2];
   double duR = dmin(0.0, du0 - du_CFL);
@@ -520,17 +576,16 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   __syncthreads();
   const double a_du0 = s_du[fl], a_duL = s_duL[fl], a_duR = s_duR[fl];
   double FAmt_L = 0.0, FAmt_R = 0.0, FAmt_0 = 0.0, uhtot_L = 0.0, uhtot_R = 0.0;
-  // the three evaluations (:1330-1349) are done once; the five column sums go through the two transit arrays
-  double k_dR[MAXL], k_uhL[MAXL], k_uhR[MAXL];
+  // three trial velocities (:1330-1349), five column sums through the two transit arrays.  The evaluations at u_L
+  // and u_R are repeated rather than kept: their results would cost 6 registers per layer at the kernel's
+  // register-pressure peak.
 #pragma unroll
   for (int n = 0; n < MAXL; n++) {
     const int k = kl + KL * n;
-    k_dR[n] = 0.0; k_uhL[n] = 0.0; k_uhR[n] = 0.0;
     if (k < nk) {
-      double uh_0, d_0, d_L;
-      flux_lds(u_r[n] + a_du0 * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh_0, d_0);
-      flux_lds(u_r[n] + a_duL * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, k_uhL[n], d_L);
-      flux_lds(u_r[n] + a_duR * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, k_uhR[n], k_dR[n]);
+      double uh, d_0, d_L;
+      flux_lds(u_r[n] + a_du0 * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh, d_0);
+      flux_lds(u_r[n] + a_duL * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh, d_L);
       sA[k * NF + fl] = d_0; sB[k * NF + fl] = d_L;
     }
   }
@@ -540,7 +595,12 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
 #pragma unroll
   for (int n = 0; n < MAXL; n++) {
     const int k = kl + KL * n;
-    if (k < nk) { sA[k * NF + fl] = k_uhL[n]; sB[k * NF + fl] = k_uhR[n]; }
+    if (k < nk) {
+      double uh_L, uh_R, dd;
+      flux_lds(u_r[n] + a_duL * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh_L, dd);
+      flux_lds(u_r[n] + a_duR * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh_R, dd);
+      sA[k * NF + fl] = uh_L; sB[k * NF + fl] = uh_R;
+    }
   }
   __syncthreads();
   if (face) col_walk2(sA + fl, sB + fl, nk, [&](double a, double b) { uhtot_L = uhtot_L + a; uhtot_R = uhtot_R + b; });
@@ -548,7 +608,11 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
 #pragma unroll
   for (int n = 0; n < MAXL; n++) {
     const int k = kl + KL * n;
-    if (k < nk) sA[k * NF + fl] = k_dR[n];
+    if (k < nk) {
+      double uh, d_R;
+      flux_lds(u_r[n] + a_duR * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh, d_R);
+      sA[k * NF + fl] = d_R;
+    }
   }
   __syncthreads();
   if (!face) return;
@@ -572,15 +636,36 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
 }
 
 template <int DIR, int KL, int MAXL>
-int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E, size_t lds_bytes) {
+int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0, size_t lds_bytes) {
   const Dm d = c->d;
-  auto kern = k_mass_flux_lds<DIR, KL, MAXL>;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)lds_bytes));
+  LdsArgs E = E0;
   const dim3 grid((A.a1 - E.i_base + NF) / NF, A.b1 - A.b0 + 1, 1);
+  const bool need_adjust = (A.uhbt != nullptr) || A.set_BT_cont;
+  const bool two_pass = need_adjust && (A.visc_rem != nullptr);   // only then are the cheap bounds not the limits themselves
+  E.retry = nullptr;
+  if (two_pass) {
+    const size_t ntile = (size_t)grid.x * grid.y;
+    if (c->retry_cap < ntile) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      (void)hipFree(c->retry);
+      HIPCHK(hipMalloc(&c->retry, ntile * sizeof(int)));
+      c->retry_cap = ntile;
+    }
+    HIPCHK(hipMemsetAsync(c->retry, 0, ntile * sizeof(int), c->stream));
+    E.retry = c->retry;
+  }
+  auto k_lazy = k_mass_flux_lds<DIR, KL, MAXL, true>;
+  auto k_exact = k_mass_flux_lds<DIR, KL, MAXL, false>;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lazy), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   if (c->prof_on) prof_begin(c, DIR ? "k_mass_flux_lds<1>" : "k_mass_flux_lds<0>");
-  hipLaunchKernelGGL(kern, grid, dim3(NF * KL, 1, 1), lds_bytes, c->stream, d, c->G, A, E);
+  hipLaunchKernelGGL(k_lazy, grid, dim3(NF * KL, 1, 1), lds_bytes, c->stream, d, c->G, A, E);
   if (c->prof_on) prof_end(c);
+  if (two_pass) {
+    if (c->prof_on) prof_begin(c, DIR ? "k_mass_flux_lds_exact<1>" : "k_mass_flux_lds_exact<0>");
+    hipLaunchKernelGGL(k_exact, grid, dim3(NF * KL, 1, 1), lds_bytes, c->stream, d, c->G, A, E);
+    if (c->prof_on) prof_end(c);
+  }
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }
@@ -589,7 +674,7 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E, size_t lds_bytes) 
 
 size_t mass_flux_lds_bytes(int dir, int nk) {
   const int NC = dir ? 2 * NF : NF + 1;
-  const int nkp = (nk + 1) & ~1;
+  const int nkp = std::max((nk + 1) & ~1, 32);   // >= the largest KL
   return sizeof(double) * ((size_t)nk * (size_t)(3 * NC) + (size_t)nkp * (size_t)(2 * NF));
 }
 

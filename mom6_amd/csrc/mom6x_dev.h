@@ -69,6 +69,7 @@ struct mom6x_ctx {
   mom6x_barotropic_params bt; bool bt_init;
   // continuity scratch: edge values of the PPM reconstruction for one direction at a time
   double *hL, *hR;
+  int *retry; size_t retry_cap;   // continuity_lds.hip: tiles whose Newton solve needs the exact CFL limits
   BTState *bts;
   RK2State *rk2;
   int *flag;                // device-side error flag (NaN / negative thickness)

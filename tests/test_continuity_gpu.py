@@ -19,7 +19,7 @@ def massflux_path(request, monkeypatch):
     return request.param
 
 
-def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0):
+def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0, u_scale=1.0, bt_pert=0.05):
     import torch
     from mom6_amd.dycore import Dycore, BTContDev
     gg, d, M = cfg
@@ -29,6 +29,7 @@ def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0):
         for k, v in cs_mod.items():
             setattr(CS, k, v)
     h, u, v = synth.make_state(d, M, thin_frac=thin)
+    u = np.ascontiguousarray(u * u_scale); v = np.ascontiguousarray(v * u_scale)
     dt = 1200.0
     rng = np.random.default_rng(5)
     vr_u = np.clip(0.5 + 0.6 * synth.smooth_field(d, 11, nk=d.nk, ox=1.0, oy=0.5), 0.0, 1.0)
@@ -36,8 +37,8 @@ def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0):
     # reference transports to perturb into uhbt/vhbt
     h0 = np.zeros_like(h); uh0 = np.zeros_like(h); vh0 = np.zeros_like(h)
     orc.continuity_PPM(d, M, GV, CS, first_direction, u, v, h, h0, uh0, vh0, dt)
-    uhbt = uh0.sum(0) * (1.0 + 0.05 * synth.smooth_field(d, 13, ox=1.0, oy=0.5))
-    vhbt = vh0.sum(0) * (1.0 - 0.05 * synth.smooth_field(d, 14, ox=0.5, oy=1.0))
+    uhbt = uh0.sum(0) * (1.0 + bt_pert * synth.smooth_field(d, 13, ox=1.0, oy=0.5))
+    vhbt = vh0.sum(0) * (1.0 - bt_pert * synth.smooth_field(d, 14, ox=0.5, oy=1.0))
 
     kw_o, kw_g = {}, {}
     dyc = Dycore(d, M, GV, first_direction)
@@ -129,3 +130,11 @@ def test_continuity_device_matches_committed_golden(orc):
     for n in out:
         H.assert_bitwise(out[n].cpu().numpy()[(Ellipsis,) + tuple(H.interior(d, stag[n]))], gold[n], "golden:" + n)
     dyc.close()
+
+
+@pytest.mark.parametrize("u_scale,bt_pert", [(8.0, 0.9), (20.0, 3.0)])
+def test_continuity_newton_reaches_cfl_limits(orc, u_scale, bt_pert):
+    """Fast flow and a barotropic transport far from the layer sum: the Newton steps of flux_adjust run into the CFL
+    limits du_max_CFL / du_min_CFL (bisection branch :1198-1214), which on the LDS path forces the exact limit
+    recurrence after the first attempt with cheap bounds."""
+    _run_case(orc, H.benchmark_small(nk=20), 0, "full", u_scale=u_scale, bt_pert=bt_pert)
