@@ -142,6 +142,17 @@ def PressureForce(d, G, GV, CS, Rlay, g_prime, h, PFu, PFv, pbce=None, eta=None,
         raise RuntimeError(f"orc_PressureForce rc={rc}")
 
 
+def eos_density(eos, T, S, p):
+    L = lib(); L.orc_eos_density.restype = C.c_double
+    return L.orc_eos_density(C.byref(eos), C.c_double(T), C.c_double(S), C.c_double(p))
+
+
+def eos_density_derivs(eos, T, S, p):
+    a, b = C.c_double(), C.c_double()
+    lib().orc_eos_density_derivs(C.byref(eos), C.c_double(T), C.c_double(S), C.c_double(p), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def vertvisc_coef(d, G, GV, CS, u, v, h, dt, a_u, a_v, h_u, h_v, Kv_bbl_u=None, Kv_bbl_v=None, bbl_thick_u=None,
                   bbl_thick_v=None, Kv_shear=None):
     rc = lib().orc_vertvisc_coef(C.byref(d), _p(G), C.byref(GV), C.byref(CS), _p(u), _p(v), _p(h), C.c_double(dt), _p(Kv_bbl_u),

@@ -183,6 +183,13 @@ static void eos_density_derivs(const mom6x_eos_params *E, double T, double S, do
   *dRdS = I_denom2 * (lambda * (W_b4 + W_b5 * T) - (p + p0) * ((p + p0) * W_a2 + (W_c4 + W_c5 * T)));
 }
 
+/* exported for the known-answer tests against the reference's own EOS_unit_tests values (MOM_EOS.F90:2077-2079 WRIGHT,
+ * :2129-2131 LINEAR) */
+double orc_eos_density(const mom6x_eos_params *E, double T, double S, double p) { return eos_density(E, T, S, p); }
+void orc_eos_density_derivs(const mom6x_eos_params *E, double T, double S, double p, double *dRdT, double *dRdS) {
+  eos_density_derivs(E, T, S, p, dRdT, dRdS);
+}
+
 /* hWght and the four T/S interpolation weights of a face between columns L and R
  * (int_density_dz_linear :392-416 / int_density_dz_wright :566-583).  Returns hWght (> 0: weighted).  */
 static double face_weights(int do_mw, int top_mw, double bathyL, double bathyR, double ztL, double ztR, double zbL, double zbR,

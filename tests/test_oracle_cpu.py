@@ -196,3 +196,24 @@ def test_vertvisc_coef_known_answers(orc):
     np.testing.assert_allclose(out["a_u"][(d.nk,) + su][wet], 5e-3 / (min(0.5 * hk, 20.0 + GV.dZ_subroundoff) + GV.dZ_subroundoff), rtol=1e-15)
     # far above the bottom boundary layer the drag-law correction vanishes: botfn = 1/(1+0.09 z^6) with z >> 1
     np.testing.assert_allclose(out["a_u"][(1,) + su][wet], 1e-3 / (hk + GV.dZ_subroundoff), rtol=1e-6)
+
+
+def test_equation_of_state_against_reference_known_answers(orc):
+    """PINNED: the reference's own unit test EOS_unit_tests holds check values for the in-situ density
+    (MOM_EOS.F90:2077-2079: WRIGHT at T=25, S=35, p=1e7 Pa -> 1027.54303596346 kg m-3; :2129-2131: LINEAR with
+    Rho_T0_S0=1000, dRho_dT=-0.2, dRho_dS=0.8, dRho_dp=5e-7 -> 1028.0), tolerance 1000*epsilon relative (:2469-2473).
+    The same routine also holds the analytic T and S derivatives to centred differences (:2401-2460): repeated here."""
+    tol = 1000.0 * np.finfo(float).eps
+    w = abi.eos_params_default(abi.WRIGHT)
+    rho = orc.eos_density(w, 25.0, 35.0, 1.0e7)
+    assert abs(rho - 1027.54303596346) < tol * rho
+    lin = abi.eos_params_default(abi.LINEAR)
+    lin.Rho_T0_S0 = 1000.0; lin.dRho_dT = -0.2; lin.dRho_dS = 0.8; lin.dRho_dp = 5.0e-7
+    rho = orc.eos_density(lin, 25.0, 35.0, 1.0e7)
+    assert abs(rho - 1028.0) < tol * rho
+    for e in (w, lin):
+        dT, dS = 0.1, 0.5
+        a, b = orc.eos_density_derivs(e, 25.0, 35.0, 1.0e7)
+        fd_T = (orc.eos_density(e, 25.0 + dT, 35.0, 1e7) - orc.eos_density(e, 25.0 - dT, 35.0, 1e7)) / (2 * dT)
+        fd_S = (orc.eos_density(e, 25.0, 35.0 + dS, 1e7) - orc.eos_density(e, 25.0, 35.0 - dS, 1e7)) / (2 * dS)
+        assert abs(a - fd_T) < 1e-4 * abs(a) and abs(b - fd_S) < 1e-4 * abs(b)
