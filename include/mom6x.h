@@ -182,6 +182,39 @@ typedef struct mom6x_vertvisc_params {
   int    answer_date;   /* VERT_FRICTION_ANSWER_DATE (99991231)                                   */
 } mom6x_vertvisc_params;
 
+/* hor_visc_CS (src/parameterizations/lateral/MOM_hor_visc.F90:36-259; hor_visc_init :2322).  On the device path:
+ * LAPLACIAN and/or BIHARMONIC with constant / velocity-scale / time-scale background coefficients, SMAGORINSKY_KH,
+ * SMAGORINSKY_AH (+ BOUND_CORIOLIS_BIHARM), BOUND_KH / BOUND_AH in both the "better" and the legacy form,
+ * ADD_LES_VISCOSITY, USE_LAND_MASK_FOR_HVISC, NOSLIP (Laplacian only, as in the reference).  Not on it (rejected):
+ * Leith / Leith+E, MEKE, GME, backscatter, anisotropic viscosity, KH_SIN_LAT, 2-D background files, RE_AH,
+ * USE_CONT_THICKNESS, open boundaries, the FrictWork diagnostics.                                              */
+typedef struct mom6x_hor_visc_params {
+  int    Laplacian;        /* LAPLACIAN (F)                                                     */
+  int    biharmonic;       /* BIHARMONIC (T)                                                    */
+  double Kh;               /* KH (0)              [L2 T-1]                                      */
+  double Kh_bg_min;        /* KH_BG_MIN (0)                                                     */
+  double Kh_vel_scale;     /* KH_VEL_SCALE (0)    [L T-1]                                       */
+  int    Smagorinsky_Kh;   /* SMAGORINSKY_KH (F)                                                */
+  double Smag_Lap_const;   /* SMAG_LAP_CONST (0)                                                */
+  int    bound_Kh;         /* BOUND_KH (T)                                                      */
+  int    better_bound_Kh;  /* BETTER_BOUND_KH (= BOUND_KH)                                      */
+  int    add_LES_viscosity;/* ADD_LES_VISCOSITY (F)                                             */
+  double Ah;               /* AH (0)              [L4 T-1]                                      */
+  double Ah_vel_scale;     /* AH_VEL_SCALE (0)                                                  */
+  double Ah_time_scale;    /* AH_TIME_SCALE (0)                                                 */
+  int    Smagorinsky_Ah;   /* SMAGORINSKY_AH (F)                                                */
+  double Smag_bi_const;    /* SMAG_BI_CONST (0)                                                 */
+  int    bound_Ah;         /* BOUND_AH (T)                                                      */
+  int    better_bound_Ah;  /* BETTER_BOUND_AH (= BOUND_AH)                                      */
+  int    bound_Coriolis;   /* BOUND_CORIOLIS_BIHARM (= BOUND_CORIOLIS, F); only with SMAGORINSKY_AH */
+  double bound_Cor_vel;    /* BOUND_CORIOLIS_VEL (= MAXVEL = 3e8)                               */
+  int    use_land_mask;    /* USE_LAND_MASK_FOR_HVISC (T)                                       */
+  double bound_coef;       /* HORVISC_BOUND_COEF (0.8)                                          */
+  int    no_slip;          /* NOSLIP (F)                                                        */
+  int    backscatter_underbound; /* BACKSCATTER_UNDERBOUND (T)                                  */
+  double dt;               /* DT: the time step the stability bounds are made for (:2714)       */
+} mom6x_hor_visc_params;
+
 /* tv%eqn_of_state (EOS_type, src/equation_of_state/MOM_EOS.F90:99-150) and the switches of
  * PressureForce_FV_CS that only matter with an equation of state.  Analytic density integrals
  * (analytic_int_density_dz, MOM_EOS.F90:1384) exist for EOS_LINEAR and the WRIGHT family; LINEAR and
@@ -356,6 +389,18 @@ int mom6x_PressureForce(mom6x_ctx *ctx, const double *h, double *PFu, double *PF
  * and Set_pbce_Bouss :692-722).  T == NULL dissociates tv%eqn_of_state again (layered path).  Bulk mixed
  * layers (GV%nk_rho_varies > 0) and ALE reconstructions are not on this path.                        */
 int mom6x_PressureForce_set_tv(mom6x_ctx *ctx, const double *T, const double *S, const mom6x_eos_params *eos);
+
+/* ------------------------------------------------------------------------- */
+/* MOM_hor_visc                                                    */
+/* hor_visc_init :2322: the 2-D coefficient fields (background and maximum viscosities, Smagorinsky
+ * constants, metric products) are computed on the device from the metric block.                 */
+int mom6x_hor_visc_init(mom6x_ctx *ctx, const mom6x_hor_visc_params *p);
+/* horizontal_viscosity(u, v, h, uh, vh, diffu, diffv, MEKE, VarMix, G, GV, US, CS, tv, dt, ...) :266.
+ * uh, vh only feed the FrictWork diagnostics and are not arguments here.  After mom6x_hor_visc_init,
+ * mom6x_step_dyn_split_RK2 calls this itself at :886 (and the new-run initialisation at :1601) unless a
+ * horizontal_viscosity callback is given.                                                      */
+int mom6x_horizontal_viscosity(mom6x_ctx *ctx, const double *u, const double *v, const double *h,
+                               double *diffu, double *diffv);
 
 /* ------------------------------------------------------------------------- */
 /* MOM_vert_friction                                                           */

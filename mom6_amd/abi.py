@@ -177,6 +177,28 @@ def vertvisc_params_default(Kv=1.0e-4, Hmix=20.0, Hbbl=10.0):
     return p
 
 
+class HorViscParams(C.Structure):
+    """mom6x_hor_visc_params; hor_visc_CS (MOM_hor_visc.F90:36-259)."""
+    _fields_ = [("Laplacian", C.c_int), ("biharmonic", C.c_int), ("Kh", C.c_double), ("Kh_bg_min", C.c_double),
+                ("Kh_vel_scale", C.c_double), ("Smagorinsky_Kh", C.c_int), ("Smag_Lap_const", C.c_double), ("bound_Kh", C.c_int),
+                ("better_bound_Kh", C.c_int), ("add_LES_viscosity", C.c_int), ("Ah", C.c_double), ("Ah_vel_scale", C.c_double),
+                ("Ah_time_scale", C.c_double), ("Smagorinsky_Ah", C.c_int), ("Smag_bi_const", C.c_double), ("bound_Ah", C.c_int),
+                ("better_bound_Ah", C.c_int), ("bound_Coriolis", C.c_int), ("bound_Cor_vel", C.c_double), ("use_land_mask", C.c_int),
+                ("bound_coef", C.c_double), ("no_slip", C.c_int), ("backscatter_underbound", C.c_int), ("dt", C.c_double)]
+
+
+def hor_visc_params_default(dt, Laplacian=False, biharmonic=True):
+    """hor_visc_init :2403-2720 defaults (LAPLACIAN F, BIHARMONIC T, bounds on, everything else off / zero)."""
+    p = HorViscParams()
+    p.Laplacian = int(Laplacian); p.biharmonic = int(biharmonic)
+    p.Kh = 0.0; p.Kh_bg_min = 0.0; p.Kh_vel_scale = 0.0; p.Smagorinsky_Kh = 0; p.Smag_Lap_const = 0.0
+    p.bound_Kh = 1; p.better_bound_Kh = 1; p.add_LES_viscosity = 0
+    p.Ah = 0.0; p.Ah_vel_scale = 0.0; p.Ah_time_scale = 0.0; p.Smagorinsky_Ah = 0; p.Smag_bi_const = 0.0
+    p.bound_Ah = 1; p.better_bound_Ah = 1; p.bound_Coriolis = 0; p.bound_Cor_vel = 3.0e8
+    p.use_land_mask = 1; p.bound_coef = 0.8; p.no_slip = 0; p.backscatter_underbound = 1; p.dt = dt
+    return p
+
+
 LINEAR, WRIGHT = 1, 2   # enum mom6x_eos_form
 
 

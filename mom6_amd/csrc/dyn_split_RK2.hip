@@ -211,6 +211,7 @@ extern "C" int mom6x_dyn_split_RK2_new_run(mom6x_ctx *c, const double *u, const 
   const size_t n3 = (size_t)d.slab * d.nk;
   const dim3 b = blk2();
   KLAUNCH(c, "k_eta", k_eta, grid3(d.ni, d.nj, 1, b), b, d, c->G, s->eta, (const double *)nullptr, h, c->GV.Z_to_H);
+  if (c->hv_init) CHK(mom6x_horizontal_viscosity(c, u, v, h, s->diffu, s->diffv));   // :1599-1606 (diffu not in the restart)
   HIPCHK(hipMemcpyAsync(s->u_av, u, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(s->v_av, v, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   // h_tmp = h ; continuity(u_av, v_av, h, h_tmp, uh, vh, dt) ; h_av = 0.5*(h + h_tmp)  :1626-1633
@@ -327,6 +328,8 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = hooks->horizontal_viscosity(hooks->user, u_av, v_av, h_av, uh, vh, s->diffu, s->diffv);
     REQUIRE(rc == 0, MOM6X_EINVAL, "step_MOM_dyn_split_RK2: horizontal_viscosity callback failed");
+  } else if (c->hv_init) {
+    CHK(mom6x_horizontal_viscosity(c, u_av, v_av, h_av, s->diffu, s->diffv));
   }
   CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu, s->CAv));    // :893
   KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, s->CAu, s->CAv, s->PFu, s->PFv, s->diffu,

@@ -1,0 +1,521 @@
+// hor_visc.hip -- hor_visc_init and horizontal_viscosity on gfx950 (MOM_hor_visc.F90:2322-3290 / :266-2317).
+//
+// On the path: LAPLACIAN and/or BIHARMONIC with background coefficients, SMAGORINSKY_KH / _AH
+// (+ BOUND_CORIOLIS_BIHARM), ADD_LES_VISCOSITY, BOUND_KH / BOUND_AH ("better" and legacy form),
+// USE_LAND_MASK_FOR_HVISC, NOSLIP.  Everything else of the module is rejected by mom6x_hor_visc_init's caller
+// contract (include/mom6x.h).
+//
+// The reference works one layer at a time on 2-D temporaries.  Here the chain
+//     (u, v) -> sh_xx, sh_xy -> Del2u, Del2v -> str_xx, str_xy -> diffu, diffv
+// is four 3-D kernels (column walk over KCHUNK layers with the 2-D coefficient planes in registers where it
+// pays); every stage reads its predecessor's output at neighbouring points, so the stages cannot be fused without
+// tile halos -- that (LDS tiles with a 3-cell halo) is the obvious next step, it would take the 20 words per
+// cell-layer moved now down to ~6.  h_u, h_v, hq, Shear_mag, hrat_min, the viscosities and the strain
+// derivatives are recomputed where they are needed instead of being stored.
+#include "mom6x_dev.h"
+
+enum HV {
+  HV_dx2h = 0, HV_dy2h, HV_dx2q, HV_dy2q, HV_DX_dyT, HV_DY_dxT, HV_DX_dyBu, HV_DY_dxBu, HV_red_xx, HV_red_xy,
+  HV_Kh_bg_xx, HV_Kh_bg_xy, HV_Kh_Max_xx, HV_Kh_Max_xy, HV_Lap2_xx, HV_Lap2_xy,
+  HV_Idx2dyCu, HV_Idxdy2u, HV_Idx2dyCv, HV_Idxdy2v, HV_Ah_bg_xx, HV_Ah_bg_xy, HV_Ah_Max_xx, HV_Ah_Max_xy,
+  HV_Bih_xx, HV_Bih_xy, HV_Bih2_xx, HV_Bih2_xy, HV_u0u, HV_u0v, HV_v0u, HV_v0v, HV_COUNT
+};
+
+namespace {
+
+inline dim3 blk2() { return dim3(64, 4, 1); }
+#define MG(n) gm(G, d, MOM6X_G_##n)
+#define PLN(n) (P + (size_t)(n) * slab)
+
+__device__ __forceinline__ double dmax4(double a, double b, double c, double e) { return dmax(dmax(dmax(a, b), c), e); }
+__device__ __forceinline__ double dmin4(double a, double b, double c, double e) { return dmin(dmin(dmin(a, b), c), e); }
+
+__device__ __forceinline__ bool in_box(int i, int j, int i0, int i1, int j0, int j1) { return i >= i0 && i <= i1 && j >= j0 && j <= j1; }
+
+// ---- hor_visc_init :2869-3024: metric products, reductions, background coefficients, Smagorinsky constants ------
+__global__ void __launch_bounds__(256)
+k_hv_init1(Dm d, const double *__restrict__ G, mom6x_hor_visc_params CS, double *__restrict__ P) {
+  const int i = -d.halo + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -d.halo + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 + d.halo || j > d.nj - 1 + d.halo) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int is = 0, ie = d.ni - 1, js = 0, je = d.nj - 1, Isq = -1, Ieq = ie, Jsq = -1, Jeq = je;
+  const double *dxBu = MG(dxBu), *dyBu = MG(dyBu), *IdxBu = MG(IdxBu), *IdyBu = MG(IdyBu), *dxT = MG(dxT), *dyT = MG(dyT);
+  const double *IdxT = MG(IdxT), *IdyT = MG(IdyT), *IdxCu = MG(IdxCu), *IdyCu = MG(IdyCu), *IdxCv = MG(IdxCv), *IdyCv = MG(IdyCv);
+  const double *dy_Cu = MG(dy_Cu), *dyCu = MG(dyCu), *dx_Cv = MG(dx_Cv), *dxCv = MG(dxCv), *fBu = MG(CoriolisBu);
+  double dx2q = 0., dy2q = 0., dx2h = 0., dy2h = 0.;
+  if (in_box(i, j, is - 2, Ieq + 1, js - 2, Jeq + 1)) {
+    dx2q = dxBu[x] * dxBu[x]; dy2q = dyBu[x] * dyBu[x];
+    PLN(HV_dx2q)[x] = dx2q; PLN(HV_dy2q)[x] = dy2q;
+    PLN(HV_DX_dyBu)[x] = dxBu[x] * IdyBu[x]; PLN(HV_DY_dxBu)[x] = dyBu[x] * IdxBu[x];
+  }
+  if (in_box(i, j, is - 2, Ieq + 2, js - 2, Jeq + 2)) {
+    dx2h = dxT[x] * dxT[x]; dy2h = dyT[x] * dyT[x];
+    PLN(HV_dx2h)[x] = dx2h; PLN(HV_dy2h)[x] = dy2h;
+    PLN(HV_DX_dyT)[x] = dxT[x] * IdyT[x]; PLN(HV_DY_dxT)[x] = dyT[x] * IdxT[x];
+  }
+  if (in_box(i, j, Isq, Ieq + 1, Jsq, Jeq + 1)) {   // reduction_xx :2894-2908
+    double r = 1.0;
+    if ((dy_Cu[x] > 0.0) && (dy_Cu[x] < dyCu[x]) && (dy_Cu[x] < dyCu[x] * r)) r = dy_Cu[x] / (dyCu[x]);
+    if ((dy_Cu[x - 1] > 0.0) && (dy_Cu[x - 1] < dyCu[x - 1]) && (dy_Cu[x - 1] < dyCu[x - 1] * r)) r = dy_Cu[x - 1] / (dyCu[x - 1]);
+    if ((dx_Cv[x] > 0.0) && (dx_Cv[x] < dxCv[x]) && (dx_Cv[x] < dxCv[x] * r)) r = dx_Cv[x] / (dxCv[x]);
+    if ((dx_Cv[x - st] > 0.0) && (dx_Cv[x - st] < dxCv[x - st]) && (dx_Cv[x - st] < dxCv[x - st] * r)) r = dx_Cv[x - st] / (dxCv[x - st]);
+    PLN(HV_red_xx)[x] = r;
+  }
+  if (in_box(i, j, is - 1, Ieq, js - 1, Jeq)) {     // reduction_xy :2909-2923
+    double r = 1.0;
+    if ((dy_Cu[x] > 0.0) && (dy_Cu[x] < dyCu[x]) && (dy_Cu[x] < dyCu[x] * r)) r = dy_Cu[x] / (dyCu[x]);
+    if ((dy_Cu[x + st] > 0.0) && (dy_Cu[x + st] < dyCu[x + st]) && (dy_Cu[x + st] < dyCu[x + st] * r)) r = dy_Cu[x + st] / (dyCu[x + st]);
+    if ((dx_Cv[x] > 0.0) && (dx_Cv[x] < dxCv[x]) && (dx_Cv[x] < dxCv[x] * r)) r = dx_Cv[x] / (dxCv[x]);
+    if ((dx_Cv[x + 1] > 0.0) && (dx_Cv[x + 1] < dxCv[x + 1]) && (dx_Cv[x + 1] < dxCv[x + 1] * r)) r = dx_Cv[x + 1] / (dxCv[x + 1]);
+    PLN(HV_red_xy)[x] = r;
+  }
+  const bool h_box = in_box(i, j, is - 1, Ieq + 1, js - 1, Jeq + 1), q_box = in_box(i, j, is - 1, Ieq, js - 1, Jeq);
+  if (CS.Laplacian) {                               // :2924-2976
+    const double Kh_Limit = 0.3 / (CS.dt * 4.0);
+    if (h_box) {
+      const double g2 = (2.0 * dx2h * dy2h) / (dx2h + dy2h);
+      if (CS.Smagorinsky_Kh) PLN(HV_Lap2_xx)[x] = CS.Smag_Lap_const * g2;
+      double K = dmax(CS.Kh, CS.Kh_vel_scale * sqrt(g2));
+      if (CS.bound_Kh && !CS.better_bound_Kh) { PLN(HV_Kh_Max_xx)[x] = Kh_Limit * g2; K = dmin(K, Kh_Limit * g2); }
+      PLN(HV_Kh_bg_xx)[x] = K;
+    }
+    if (q_box) {
+      const double g2 = (2.0 * dx2q * dy2q) / (dx2q + dy2q);
+      if (CS.Smagorinsky_Kh) PLN(HV_Lap2_xy)[x] = CS.Smag_Lap_const * g2;
+      double K = dmax(CS.Kh, CS.Kh_vel_scale * sqrt(g2));
+      if (CS.bound_Kh && !CS.better_bound_Kh) { PLN(HV_Kh_Max_xy)[x] = Kh_Limit * g2; K = dmin(K, Kh_Limit * g2); }
+      PLN(HV_Kh_bg_xy)[x] = K;
+    }
+  }
+  if (CS.biharmonic) {                              // :2977-3024
+    if (in_box(i, j, is - 2, Ieq + 1, js - 1, Jeq + 1)) {
+      PLN(HV_Idx2dyCu)[x] = (IdxCu[x] * IdxCu[x]) * IdyCu[x];
+      PLN(HV_Idxdy2u)[x] = IdxCu[x] * (IdyCu[x] * IdyCu[x]);
+    }
+    if (in_box(i, j, is - 1, Ieq + 1, js - 2, Jeq + 1)) {
+      PLN(HV_Idx2dyCv)[x] = (IdxCv[x] * IdxCv[x]) * IdyCv[x];
+      PLN(HV_Idxdy2v)[x] = IdxCv[x] * (IdyCv[x] * IdyCv[x]);
+    }
+    const double Ah_Limit = 0.3 / (CS.dt * 64.0);
+    double BoundCorConst = 0.0;
+    if (CS.Smagorinsky_Ah && CS.bound_Coriolis) BoundCorConst = 1.0 / (5.0 * (CS.bound_Cor_vel * CS.bound_Cor_vel));
+    if (h_box) {
+      const double g2 = (2.0 * dx2h * dy2h) / (dx2h + dy2h);
+      if (CS.Smagorinsky_Ah) {
+        PLN(HV_Bih_xx)[x] = CS.Smag_bi_const * (g2 * g2);
+        if (CS.bound_Coriolis) {
+          const double fmax = dmax4(fabs(fBu[x - 1 - st]), fabs(fBu[x - st]), fabs(fBu[x - 1]), fabs(fBu[x]));
+          PLN(HV_Bih2_xx)[x] = (g2 * g2 * g2) * (fmax * BoundCorConst);
+        }
+      }
+      double A = dmax(CS.Ah, CS.Ah_vel_scale * g2 * sqrt(g2));
+      if (CS.Ah_time_scale > 0.) A = dmax(A, (g2 * g2) / CS.Ah_time_scale);
+      if (CS.bound_Ah && !CS.better_bound_Ah) { PLN(HV_Ah_Max_xx)[x] = Ah_Limit * (g2 * g2); A = dmin(A, Ah_Limit * (g2 * g2)); }
+      PLN(HV_Ah_bg_xx)[x] = A;
+    }
+    if (q_box) {
+      const double g2 = (2.0 * dx2q * dy2q) / (dx2q + dy2q);
+      if (CS.Smagorinsky_Ah) {
+        PLN(HV_Bih_xy)[x] = CS.Smag_bi_const * (g2 * g2);
+        if (CS.bound_Coriolis) PLN(HV_Bih2_xy)[x] = (g2 * g2 * g2) * (fabs(fBu[x]) * BoundCorConst);
+      }
+      double A = dmax(CS.Ah, CS.Ah_vel_scale * g2 * sqrt(g2));
+      if (CS.Ah_time_scale > 0.) A = dmax(A, (g2 * g2) / CS.Ah_time_scale);
+      if (CS.bound_Ah && !CS.better_bound_Ah) { PLN(HV_Ah_Max_xy)[x] = Ah_Limit * (g2 * g2); A = dmin(A, Ah_Limit * (g2 * g2)); }
+      PLN(HV_Ah_bg_xy)[x] = A;
+    }
+  }
+}
+
+// ---- :3025-3048 (Kh_Max) and :3054-3070 (u0u, u0v, v0u, v0v) -- need the planes of k_hv_init1 at neighbours -----
+__global__ void __launch_bounds__(256)
+k_hv_init2(Dm d, const double *__restrict__ G, mom6x_hor_visc_params CS, double *__restrict__ P) {
+  const int i = -d.halo + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -d.halo + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 + d.halo || j > d.nj - 1 + d.halo) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int is = 0, ie = d.ni - 1, js = 0, je = d.nj - 1, Ieq = ie, Jeq = je;
+  const double *IdxCu = MG(IdxCu), *IdyCu = MG(IdyCu), *IdxCv = MG(IdxCv), *IdyCv = MG(IdyCv), *IareaCu = MG(IareaCu), *IareaCv = MG(IareaCv);
+  const double *dx2h = PLN(HV_dx2h), *dy2h = PLN(HV_dy2h), *dx2q = PLN(HV_dx2q), *dy2q = PLN(HV_dy2q);
+  const double *DX_dyT = PLN(HV_DX_dyT), *DY_dxT = PLN(HV_DY_dxT), *DX_dyBu = PLN(HV_DX_dyBu), *DY_dxBu = PLN(HV_DY_dxBu);
+  const double Idt = 1.0 / CS.dt;
+  if (CS.Laplacian && CS.better_bound_Kh) {
+    if (in_box(i, j, is - 1, Ieq + 1, js - 1, Jeq + 1)) {
+      const double denom = dmax(
+          (dy2h[x] * DY_dxT[x] * (IdyCu[x] + IdyCu[x - 1]) * dmax(IdyCu[x] * IareaCu[x], IdyCu[x - 1] * IareaCu[x - 1])),
+          (dx2h[x] * DX_dyT[x] * (IdxCv[x] + IdxCv[x - st]) * dmax(IdxCv[x] * IareaCv[x], IdxCv[x - st] * IareaCv[x - st])));
+      double r = 0.0;
+      if (denom > 0.0) r = CS.bound_coef * 0.25 * Idt / denom;
+      PLN(HV_Kh_Max_xx)[x] = r;
+    }
+    if (in_box(i, j, is - 1, Ieq, js - 1, Jeq)) {
+      const double denom = dmax(
+          (dx2q[x] * DX_dyBu[x] * (IdxCu[x + st] + IdxCu[x]) * dmax(IdxCu[x] * IareaCu[x], IdxCu[x + st] * IareaCu[x + st])),
+          (dy2q[x] * DY_dxBu[x] * (IdyCv[x + 1] + IdyCv[x]) * dmax(IdyCv[x] * IareaCv[x], IdyCv[x + 1] * IareaCv[x + 1])));
+      double r = 0.0;
+      if (denom > 0.0) r = CS.bound_coef * 0.25 * Idt / denom;
+      PLN(HV_Kh_Max_xy)[x] = r;
+    }
+  }
+  if (CS.biharmonic && CS.better_bound_Ah) {
+    const double *Idxdy2u = PLN(HV_Idxdy2u), *Idx2dyCu = PLN(HV_Idx2dyCu), *Idxdy2v = PLN(HV_Idxdy2v), *Idx2dyCv = PLN(HV_Idx2dyCv);
+    if (in_box(i, j, is - 2, Ieq + 1, js - 1, Jeq + 1)) {
+      PLN(HV_u0u)[x] = ((Idxdy2u[x] * ((dy2h[x + 1] * DY_dxT[x + 1] * (IdyCu[x + 1] + IdyCu[x])) + (dy2h[x] * DY_dxT[x] * (IdyCu[x] + IdyCu[x - 1])))) +
+                        (Idx2dyCu[x] * ((dx2q[x] * DX_dyBu[x] * (IdxCu[x + st] + IdxCu[x])) + (dx2q[x - st] * DX_dyBu[x - st] * (IdxCu[x] + IdxCu[x - st])))));
+      PLN(HV_u0v)[x] = ((Idxdy2u[x] * ((dy2h[x + 1] * DX_dyT[x + 1] * (IdxCv[x + 1] + IdxCv[x + 1 - st])) + (dy2h[x] * DX_dyT[x] * (IdxCv[x] + IdxCv[x - st])))) +
+                        (Idx2dyCu[x] * ((dx2q[x] * DY_dxBu[x] * (IdyCv[x + 1] + IdyCv[x])) + (dx2q[x - st] * DY_dxBu[x - st] * (IdyCv[x + 1 - st] + IdyCv[x - st])))));
+    }
+    if (in_box(i, j, is - 1, Ieq + 1, js - 2, Jeq + 1)) {
+      PLN(HV_v0u)[x] = ((Idxdy2v[x] * ((dy2q[x] * DX_dyBu[x] * (IdxCu[x + st] + IdxCu[x])) + (dy2q[x - 1] * DX_dyBu[x - 1] * (IdxCu[x - 1 + st] + IdxCu[x - 1])))) +
+                        (Idx2dyCv[x] * ((dx2h[x + st] * DY_dxT[x + st] * (IdyCu[x + st] + IdyCu[x - 1 + st])) + (dx2h[x] * DY_dxT[x] * (IdyCu[x] + IdyCu[x - 1])))));
+      PLN(HV_v0v)[x] = ((Idxdy2v[x] * ((dy2q[x] * DY_dxBu[x] * (IdyCv[x + 1] + IdyCv[x])) + (dy2q[x - 1] * DY_dxBu[x - 1] * (IdyCv[x] + IdyCv[x - 1])))) +
+                        (Idx2dyCv[x] * ((dx2h[x + st] * DX_dyT[x + st] * (IdxCv[x + st] + IdxCv[x])) + (dx2h[x] * DX_dyT[x] * (IdxCv[x] + IdxCv[x - st])))));
+    }
+  }
+}
+
+// ---- :3071-3110: Ah_Max_xx, Ah_Max_xy from u0u .. v0v at neighbours ---------------------------------------------
+__global__ void __launch_bounds__(256)
+k_hv_init3(Dm d, const double *__restrict__ G, mom6x_hor_visc_params CS, double *__restrict__ P) {
+  const int i = -d.halo + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -d.halo + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 + d.halo || j > d.nj - 1 + d.halo) return;
+  if (!(CS.biharmonic && CS.better_bound_Ah)) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int is = 0, ie = d.ni - 1, js = 0, je = d.nj - 1, Ieq = ie, Jeq = je;
+  const double *IdxCu = MG(IdxCu), *IdyCu = MG(IdyCu), *IdxCv = MG(IdxCv), *IdyCv = MG(IdyCv), *IareaCu = MG(IareaCu), *IareaCv = MG(IareaCv);
+  const double *dx2h = PLN(HV_dx2h), *dy2h = PLN(HV_dy2h), *dx2q = PLN(HV_dx2q), *dy2q = PLN(HV_dy2q);
+  const double *DX_dyT = PLN(HV_DX_dyT), *DY_dxT = PLN(HV_DY_dxT), *DX_dyBu = PLN(HV_DX_dyBu), *DY_dxBu = PLN(HV_DY_dxBu);
+  const double *u0u = PLN(HV_u0u), *u0v = PLN(HV_u0v), *v0u = PLN(HV_v0u), *v0v = PLN(HV_v0v);
+  const double Idt = 1.0 / CS.dt;
+  if (in_box(i, j, is - 1, Ieq + 1, js - 1, Jeq + 1)) {
+    const double denom = dmax(
+        (dy2h[x] * ((DY_dxT[x] * ((IdyCu[x] * u0u[x]) + (IdyCu[x - 1] * u0u[x - 1]))) + (DX_dyT[x] * ((IdxCv[x] * v0u[x]) + (IdxCv[x - st] * v0u[x - st])))) *
+         dmax(IdyCu[x] * IareaCu[x], IdyCu[x - 1] * IareaCu[x - 1])),
+        (dx2h[x] * ((DY_dxT[x] * ((IdyCu[x] * u0v[x]) + (IdyCu[x - 1] * u0v[x - 1]))) + (DX_dyT[x] * ((IdxCv[x] * v0v[x]) + (IdxCv[x - st] * v0v[x - st])))) *
+         dmax(IdxCv[x] * IareaCv[x], IdxCv[x - st] * IareaCv[x - st])));
+    double r = 0.0;
+    if (denom > 0.0) r = CS.bound_coef * 0.5 * Idt / denom;
+    PLN(HV_Ah_Max_xx)[x] = r;
+  }
+  if (in_box(i, j, is - 1, Ieq, js - 1, Jeq)) {
+    const double denom = dmax(
+        (dx2q[x] * ((DX_dyBu[x] * ((u0u[x + st] * IdxCu[x + st]) + (u0u[x] * IdxCu[x]))) + (DY_dxBu[x] * ((v0u[x + 1] * IdyCv[x + 1]) + (v0u[x] * IdyCv[x])))) *
+         dmax(IdxCu[x] * IareaCu[x], IdxCu[x + st] * IareaCu[x + st])),
+        (dy2q[x] * ((DX_dyBu[x] * ((u0v[x + st] * IdxCu[x + st]) + (u0v[x] * IdxCu[x]))) + (DY_dxBu[x] * ((v0v[x + 1] * IdyCv[x + 1]) + (v0v[x] * IdyCv[x])))) *
+         dmax(IdyCv[x] * IareaCv[x], IdyCv[x + 1] * IareaCv[x + 1])));
+    double r = 0.0;
+    if (denom > 0.0) r = CS.bound_coef * 0.5 * Idt / denom;
+    PLN(HV_Ah_Max_xy)[x] = r;
+  }
+}
+
+// =================================================================================================================
+// horizontal_viscosity, stage 1 :724-737, :907-917: sh_xx at h points (Isq-1..Ieq+2), sh_xy at q points (is-2..Ieq+1)
+__global__ void __launch_bounds__(256)
+k_hv_strain(Dm d, const double *__restrict__ G, const double *__restrict__ P, const double *__restrict__ u,
+            const double *__restrict__ v, double *__restrict__ sh_xx, double *__restrict__ sh_xy, int no_slip) {
+  const int i = I_BASE(-2) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -2 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -2 || i > d.ni + 1 || j > d.nj + 1) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const bool do_h = true;                                     // (Isq-1..Ieq+2, Jsq-1..Jeq+2) = (-2..ni+1, -2..nj+1)
+  const bool do_q = (i <= d.ni) && (j <= d.nj);               // (is-2..Ieq+1, js-2..Jeq+1) = (-2..ni, -2..nj)
+  const double DY_dxT = PLN(HV_DY_dxT)[x], DX_dyT = PLN(HV_DX_dyT)[x];
+  const double IdyCu0 = MG(IdyCu)[x], IdyCum = MG(IdyCu)[x - 1], IdxCv0 = MG(IdxCv)[x], IdxCvm = MG(IdxCv)[x - st];
+  double DY_dxBu = 0., DX_dyBu = 0., IdyCvp = 0., IdyCv0 = 0., IdxCup = 0., IdxCu0 = 0., mfac = 0.;
+  if (do_q) {
+    DY_dxBu = PLN(HV_DY_dxBu)[x]; DX_dyBu = PLN(HV_DX_dyBu)[x];
+    IdyCvp = MG(IdyCv)[x + 1]; IdyCv0 = MG(IdyCv)[x]; IdxCup = MG(IdxCu)[x + st]; IdxCu0 = MG(IdxCu)[x];
+    const double mBu = MG(mask2dBu)[x];
+    mfac = no_slip ? (2.0 - mBu) : mBu;
+  }
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double u0 = u[c], v0 = v[c];
+    if (do_h) {
+      const double dudx = DY_dxT * ((IdyCu0 * u0) - (IdyCum * u[c - 1]));
+      const double dvdy = DX_dyT * ((IdxCv0 * v0) - (IdxCvm * v[c - st]));
+      sh_xx[c] = dudx - dvdy;
+    }
+    if (do_q) {
+      const double dvdx = DY_dxBu * ((v[c + 1] * IdyCvp) - (v0 * IdyCv0));
+      const double dudy = DX_dyBu * ((u[c + st] * IdxCup) - (u0 * IdxCu0));
+      sh_xy[c] = mfac * (dvdx + dudy);
+    }
+  }
+}
+
+// stage 2 :934-943: Del2u on (Isq-1..Ieq+1, js-1..Jeq+1), Del2v on (is-1..Ieq+1, Jsq-1..Jeq+1)
+__global__ void __launch_bounds__(256)
+k_hv_del2(Dm d, const double *__restrict__ G, const double *__restrict__ P, const double *__restrict__ sh_xx,
+          const double *__restrict__ sh_xy, double *__restrict__ Del2u, double *__restrict__ Del2v) {
+  const int i = I_BASE(-2) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -2 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -2 || i > d.ni || j > d.nj) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const bool do_u = (j >= -1);                 // I = -2..ni, j = -1..nj
+  const bool do_v = (i >= -1);                 // i = -1..ni, J = -2..nj
+  const double Idx2dyCu = PLN(HV_Idx2dyCu)[x], Idxdy2u = PLN(HV_Idxdy2u)[x], Idx2dyCv = PLN(HV_Idx2dyCv)[x], Idxdy2v = PLN(HV_Idxdy2v)[x];
+  const double dx2q0 = PLN(HV_dx2q)[x], dy2q0 = PLN(HV_dy2q)[x];
+  const double dx2q_s = do_u ? PLN(HV_dx2q)[x - st] : 0., dy2q_w = do_v ? PLN(HV_dy2q)[x - 1] : 0.;
+  const double dy2h0 = PLN(HV_dy2h)[x], dy2h_e = PLN(HV_dy2h)[x + 1], dx2h0 = PLN(HV_dx2h)[x], dx2h_n = PLN(HV_dx2h)[x + st];
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double sxy = sh_xy[c], sxx = sh_xx[c];
+    if (do_u) Del2u[c] = Idx2dyCu * ((dx2q0 * sxy) - (dx2q_s * sh_xy[c - st])) + Idxdy2u * ((dy2h_e * sh_xx[c + 1]) - (dy2h0 * sxx));
+    if (do_v) Del2v[c] = Idxdy2v * ((dy2q0 * sxy) - (dy2q_w * sh_xy[c - 1])) - Idx2dyCv * ((dx2h_n * sh_xx[c + st]) - (dx2h0 * sxx));
+  }
+}
+
+// h_u, h_v :767-781
+__device__ __forceinline__ double hface(const double *__restrict__ h, const double *__restrict__ mT, size_t c, size_t c2, int s,
+                                        int land_mask) {
+  if (land_mask) return 0.5 * (mT[c2] * h[c] + mT[c2 + s] * h[c + s]);
+  return 0.5 * (h[c] + h[c + s]);
+}
+
+// stage 3: str_xx at h points (Isq..Ieq+1, Jsq..Jeq+1) :1112-1448, :1893 and str_xy at q points (is-1..Ieq, js-1..Jeq)
+// :1483-1826, :1896-1906 -- both already multiplied by the thickness and reduction factors.
+__global__ void __launch_bounds__(256)
+k_hv_stress(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom6x_hor_visc_params CS,
+            const double *__restrict__ h, const double *__restrict__ sh_xx, const double *__restrict__ sh_xy,
+            const double *__restrict__ Del2u, const double *__restrict__ Del2v, double *__restrict__ str_xx,
+            double *__restrict__ str_xy, double h_neglect) {
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -1 || i > d.ni || j > d.nj) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k = blockIdx.z;
+  const size_t c = x + (size_t)k * slab;
+  const double *mT = MG(mask2dT), *IdyCu = MG(IdyCu), *IdxCv = MG(IdxCv), *IdxCu = MG(IdxCu), *IdyCv = MG(IdyCv);
+  const bool smag = CS.Smagorinsky_Kh || CS.Smagorinsky_Ah, better = CS.better_bound_Ah || CS.better_bound_Kh;
+  const bool legacy_bound = CS.Smagorinsky_Kh && (CS.bound_Kh && !CS.better_bound_Kh);
+  const double h_neglect3 = h_neglect * h_neglect * h_neglect;
+  const int lm = CS.use_land_mask;
+  {   // ---- h point (always inside Isq..Ieq+1, Jsq..Jeq+1)
+    double Shear = 0., hrat = 0., vbr = 0., sxx_out;
+    const double sxx = sh_xx[c];
+    if (smag) {
+      const double sh_xx_sq = sxx * sxx;
+      const double a = sh_xy[c - 1 - st], b = sh_xy[c], e = sh_xy[c - 1], f = sh_xy[c - st];
+      const double sh_xy_sq = 0.25 * (((a * a) + (b * b)) + ((e * e) + (f * f)));
+      Shear = sqrt(sh_xx_sq + sh_xy_sq);
+    }
+    const double hk = h[c];
+    if (better) {
+      const double h_min = dmin4(hface(h, mT, c, x, 1, lm), hface(h, mT, c - 1, x - 1, 1, lm), hface(h, mT, c, x, st, lm),
+                                 hface(h, mT, c - st, x - st, st, lm));
+      hrat = dmin(1.0, h_min / (hk + h_neglect));
+    }
+    if (CS.Laplacian) {
+      double K = PLN(HV_Kh_bg_xx)[x];
+      if (CS.add_LES_viscosity) { if (CS.Smagorinsky_Kh) K = K + PLN(HV_Lap2_xx)[x] * Shear; }
+      else { if (CS.Smagorinsky_Kh) K = dmax(K, PLN(HV_Lap2_xx)[x] * Shear); }
+      if (legacy_bound) K = dmin(K, PLN(HV_Kh_Max_xx)[x]);
+      K = dmax(K, CS.Kh_bg_min);
+      if (CS.better_bound_Kh && CS.better_bound_Ah) {
+        vbr = 1.0;
+        const double Kh_max_here = hrat * PLN(HV_Kh_Max_xx)[x];
+        if (K >= Kh_max_here) { vbr = 0.0; K = Kh_max_here; }
+        else if ((K > 0.0) || (CS.backscatter_underbound && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
+      } else if (CS.better_bound_Kh) {
+        K = dmin(K, hrat * PLN(HV_Kh_Max_xx)[x]);
+      }
+      sxx_out = -K * sxx;
+    } else sxx_out = 0.0;
+    if (CS.biharmonic) {
+      double A = PLN(HV_Ah_bg_xx)[x];
+      if (CS.Smagorinsky_Ah) {
+        double AhSm;
+        if (CS.bound_Coriolis) AhSm = Shear * (PLN(HV_Bih_xx)[x] + PLN(HV_Bih2_xx)[x] * Shear);
+        else AhSm = PLN(HV_Bih_xx)[x] * Shear;
+        A = dmax(A, AhSm);
+        if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, PLN(HV_Ah_Max_xx)[x]);
+      }
+      if (CS.better_bound_Ah) {
+        if (CS.better_bound_Kh) A = dmin(A, vbr * hrat * PLN(HV_Ah_Max_xx)[x]);
+        else A = dmin(A, hrat * PLN(HV_Ah_Max_xx)[x]);
+      }
+      const double d_del2u = (IdyCu[x] * Del2u[c]) - (IdyCu[x - 1] * Del2u[c - 1]);
+      const double d_del2v = (IdxCv[x] * Del2v[c]) - (IdxCv[x - st] * Del2v[c - st]);
+      const double d_str = A * ((PLN(HV_DY_dxT)[x] * d_del2u) - (PLN(HV_DX_dyT)[x] * d_del2v));
+      sxx_out = sxx_out + d_str;
+    }
+    str_xx[c] = sxx_out * (hk * PLN(HV_red_xx)[x]);
+  }
+  if (i <= d.ni - 1 && j <= d.nj - 1) {   // ---- q point (is-1..Ieq, js-1..Jeq)
+    double Shear = 0., hrat = 0., vbr = 0., sxy_out;
+    const double sxy = sh_xy[c];
+    if (smag) {
+      const double sh_xy_sq = sxy * sxy;
+      const double a = sh_xx[c], b = sh_xx[c + 1 + st], e = sh_xx[c + st], f = sh_xx[c + 1];
+      const double sh_xx_sq = 0.25 * (((a * a) + (b * b)) + ((e * e) + (f * f)));
+      Shear = sqrt(sh_xy_sq + sh_xx_sq);
+    }
+    const double hu0 = hface(h, mT, c, x, 1, lm), hu1 = hface(h, mT, c + st, x + st, 1, lm);
+    const double hv0 = hface(h, mT, c, x, st, lm), hv1 = hface(h, mT, c + 1, x + 1, st, lm);
+    const double h2uq = 4.0 * (hu0 * hu1), h2vq = 4.0 * (hv0 * hv1);
+    double hq = (2.0 * (h2uq * h2vq)) / (h_neglect3 + (h2uq + h2vq) * ((hu0 + hu1) + (hv0 + hv1)));
+    if (better) {
+      const double h_min = dmin4(hu0, hu1, hv0, hv1);
+      hrat = dmin(1.0, h_min / (hq + h_neglect));
+    }
+    const double mBu = MG(mask2dBu)[x];
+    if (CS.no_slip && (mBu < 0.5)) {
+      const double mu0 = MG(mask2dCu)[x], mu1 = MG(mask2dCu)[x + st], mv0 = MG(mask2dCv)[x], mv1 = MG(mask2dCv)[x + 1];
+      if ((mu0 + mu1) + (mv0 + mv1) > 0.0) {
+        const double hu = mu0 * hu0 + mu1 * hu1;
+        const double hv = mv0 * hv0 + mv1 * hv1;
+        if ((mu0 + mu1) * (mv0 + mv1) == 0.0) {
+          hq = hu + hv;
+          hrat = 1.0;
+        } else {
+          hq = 2.0 * (hu * hv) / ((hu + hv) + h_neglect);
+          hrat = dmin(1.0, dmin(hu, hv) / (hq + h_neglect));
+        }
+      }
+    }
+    if (CS.Laplacian) {
+      double K = PLN(HV_Kh_bg_xy)[x];
+      if (CS.Smagorinsky_Kh) {
+        if (CS.add_LES_viscosity) K = K + PLN(HV_Lap2_xy)[x] * Shear;
+        else K = dmax(K, PLN(HV_Lap2_xy)[x] * Shear);
+      }
+      if (legacy_bound) K = dmin(K, PLN(HV_Kh_Max_xy)[x]);
+      K = dmax(K, CS.Kh_bg_min);
+      if (CS.better_bound_Kh && CS.better_bound_Ah) {
+        vbr = 1.0;
+        const double Kh_max_here = hrat * PLN(HV_Kh_Max_xy)[x];
+        if (K >= Kh_max_here) { vbr = 0.0; K = Kh_max_here; }
+        else if ((K > 0.0) || (CS.backscatter_underbound && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
+      } else if (CS.better_bound_Kh) {
+        K = dmin(K, hrat * PLN(HV_Kh_Max_xy)[x]);
+      }
+      sxy_out = -K * sxy;
+    } else sxy_out = 0.;
+    if (CS.biharmonic) {
+      double A = PLN(HV_Ah_bg_xy)[x];
+      if (CS.Smagorinsky_Ah) {
+        double AhSm;
+        if (CS.bound_Coriolis) AhSm = Shear * (PLN(HV_Bih_xy)[x] + PLN(HV_Bih2_xy)[x] * Shear);
+        else AhSm = PLN(HV_Bih_xy)[x] * Shear;
+        A = dmax(A, AhSm);
+        if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, PLN(HV_Ah_Max_xy)[x]);
+      }
+      if (CS.better_bound_Ah) {
+        if (CS.better_bound_Kh) A = dmin(A, vbr * hrat * PLN(HV_Ah_Max_xy)[x]);
+        else A = dmin(A, hrat * PLN(HV_Ah_Max_xy)[x]);
+      }
+      const double dDel2vdx = PLN(HV_DY_dxBu)[x] * ((Del2v[c + 1] * IdyCv[x + 1]) - (Del2v[c] * IdyCv[x]));
+      const double dDel2udy = PLN(HV_DX_dyBu)[x] * ((Del2u[c + st] * IdxCu[x + st]) - (Del2u[c] * IdxCu[x]));
+      const double d_str = A * (dDel2vdx + dDel2udy);
+      sxy_out = sxy_out + d_str;
+    }
+    if (CS.no_slip) str_xy[c] = sxy_out * (hq * PLN(HV_red_xy)[x]);
+    else str_xy[c] = sxy_out * (hq * mBu * PLN(HV_red_xy)[x]);
+  }
+}
+
+// stage 4 :1910-1931: diffu on (Isq..Ieq, js..je), diffv on (is..ie, Jsq..Jeq)
+__global__ void __launch_bounds__(256)
+k_hv_accel(Dm d, const double *__restrict__ G, const double *__restrict__ P, const double *__restrict__ h,
+           const double *__restrict__ str_xx, const double *__restrict__ str_xy, double *__restrict__ diffu,
+           double *__restrict__ diffv, int land_mask, double h_neglect) {
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -1 || i > d.ni - 1 || j > d.nj - 1) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const bool do_u = (j >= 0), do_v = (i >= 0);
+  const double *mT = MG(mask2dT);
+  const double IdxCu = MG(IdxCu)[x], IdyCu = MG(IdyCu)[x], IareaCu = MG(IareaCu)[x];
+  const double IdxCv = MG(IdxCv)[x], IdyCv = MG(IdyCv)[x], IareaCv = MG(IareaCv)[x];
+  const double dx2q0 = PLN(HV_dx2q)[x], dy2q0 = PLN(HV_dy2q)[x];
+  const double dx2q_s = do_u ? PLN(HV_dx2q)[x - st] : 0., dy2q_w = do_v ? PLN(HV_dy2q)[x - 1] : 0.;
+  const double dy2h0 = PLN(HV_dy2h)[x], dy2h_e = PLN(HV_dy2h)[x + 1], dx2h0 = PLN(HV_dx2h)[x], dx2h_n = PLN(HV_dx2h)[x + st];
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double sxy = str_xy[c], sxx = str_xx[c];
+    if (do_u) {
+      const double h_u = hface(h, mT, c, x, 1, land_mask);
+      diffu[c] = ((IdxCu * ((dx2q_s * str_xy[c - st]) - (dx2q0 * sxy)) + IdyCu * ((dy2h0 * sxx) - (dy2h_e * str_xx[c + 1]))) * IareaCu) /
+                 (h_u + h_neglect);
+    }
+    if (do_v) {
+      const double h_v = hface(h, mT, c, x, st, land_mask);
+      diffv[c] = ((IdyCv * ((dy2q_w * str_xy[c - 1]) - (dy2q0 * sxy)) - IdxCv * ((dx2h0 * sxx) - (dx2h_n * str_xx[c + st]))) * IareaCv) /
+                 (h_v + h_neglect);
+    }
+  }
+}
+
+}  // namespace
+
+void hor_visc_free(mom6x_ctx *c) { (void)hipFree(c->hv_planes); c->hv_planes = nullptr; }
+
+extern "C" int mom6x_hor_visc_init(mom6x_ctx *c, const mom6x_hor_visc_params *p) {
+  REQUIRE(c && p, MOM6X_EINVAL, "mom6x_hor_visc_init: null argument");
+  REQUIRE(p->dt > 0.0, MOM6X_EINVAL, "hor_visc_init: DT must be positive");
+  mom6x_hor_visc_params cs = *p;   // hor_visc_init :2465, :2495-2496, :2555-2571, :2624
+  if (!cs.Laplacian) { cs.Smagorinsky_Kh = 0; cs.bound_Kh = 0; cs.better_bound_Kh = 0; }
+  if (!cs.biharmonic) { cs.Smagorinsky_Ah = 0; cs.bound_Ah = 0; cs.better_bound_Ah = 0; }
+  if (!cs.Smagorinsky_Ah) cs.bound_Coriolis = 0;
+  REQUIRE(!(cs.no_slip && cs.biharmonic), MOM6X_EINVAL,
+          "ERROR: NOSLIP and BIHARMONIC cannot be defined at the same time in MOM.");
+  REQUIRE(c->dims.halo >= 3, MOM6X_EINVAL, "hor_visc_init: halo >= 3 required");
+  HIPCHK(hipSetDevice(c->device));
+  c->hv = cs;
+  const Dm d = c->d;
+  const size_t bytes = (size_t)HV_COUNT * d.slab * sizeof(double);
+  if (!c->hv_planes) HIPCHK(hipMalloc(&c->hv_planes, bytes));
+  HIPCHK(hipMemsetAsync(c->hv_planes, 0, bytes, c->stream));
+  if (cs.Laplacian || cs.biharmonic) {
+    const dim3 b = blk2();
+    const dim3 g = grid3(d.ni + 2 * d.halo, d.nj + 2 * d.halo, 1, b);
+    KLAUNCH(c, "k_hv_init1", k_hv_init1, g, b, d, c->G, cs, c->hv_planes);
+    KLAUNCH(c, "k_hv_init2", k_hv_init2, g, b, d, c->G, cs, c->hv_planes);
+    KLAUNCH(c, "k_hv_init3", k_hv_init3, g, b, d, c->G, cs, c->hv_planes);
+    HIPCHK(hipGetLastError());
+  }
+  c->hv_init = true;
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const double *v, const double *h, double *diffu,
+                                          double *diffv) {
+  REQUIRE(c && c->hv_init, MOM6X_EINVAL, "MOM_hor_visc: Module must be initialized before it is used.");
+  REQUIRE(u && v && h && diffu && diffv, MOM6X_EINVAL, "horizontal_viscosity: null array");
+  const mom6x_hor_visc_params &CS = c->hv;
+  if (!(CS.Laplacian || CS.biharmonic)) return MOM6X_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  double *sh_xx, *sh_xy, *Del2u, *Del2v, *str_xx, *str_xy;
+  int rc;
+  if ((rc = ctx_scratch(c, SCR_t0, d.nk, &sh_xx)) || (rc = ctx_scratch(c, SCR_t1, d.nk, &sh_xy)) ||
+      (rc = ctx_scratch(c, SCR_t2, d.nk, &Del2u)) || (rc = ctx_scratch(c, SCR_t3, d.nk, &Del2v)) ||
+      (rc = ctx_scratch(c, SCR_q, d.nk, &str_xx)) || (rc = ctx_scratch(c, SCR_KE, d.nk, &str_xy)))
+    return rc;
+  const dim3 b = blk2();
+  const double *P = c->hv_planes;
+  KLAUNCH(c, "k_hv_strain", k_hv_strain, grid3(nxa(d.ni + 4, -2), d.nj + 4, nchunks(d.nk), b), b, d, c->G, P, u, v, sh_xx, sh_xy, CS.no_slip);
+  if (CS.biharmonic)
+    KLAUNCH(c, "k_hv_del2", k_hv_del2, grid3(nxa(d.ni + 3, -2), d.nj + 3, nchunks(d.nk), b), b, d, c->G, P, (const double *)sh_xx,
+            (const double *)sh_xy, Del2u, Del2v);
+  KLAUNCH(c, "k_hv_stress", k_hv_stress, grid3(nxa(d.ni + 2, -1), d.nj + 2, d.nk, b), b, d, c->G, P, CS, h, (const double *)sh_xx,
+          (const double *)sh_xy, (const double *)Del2u, (const double *)Del2v, str_xx, str_xy, c->GV.H_subroundoff);
+  KLAUNCH(c, "k_hv_accel", k_hv_accel, grid3(nxa(d.ni + 1, -1), d.nj + 1, nchunks(d.nk), b), b, d, c->G, P, h, (const double *)str_xx,
+          (const double *)str_xy, diffu, diffv, CS.use_land_mask, c->GV.H_subroundoff);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}

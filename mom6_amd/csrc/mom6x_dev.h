@@ -83,6 +83,8 @@ struct mom6x_ctx {
   mom6x_vertvisc_params vv; bool vv_init;
   const double *Kv_bbl_u, *Kv_bbl_v, *bbl_thick_u, *bbl_thick_v, *Kv_shear;
   double *vv_a_u, *vv_a_v, *vv_h_u, *vv_h_v;
+  // hor_visc.hip: hor_visc_CS parameters and the 2-D coefficient planes of hor_visc_init
+  mom6x_hor_visc_params hv; bool hv_init; double *hv_planes;
   // lazily allocated 3-D scratch arrays (slot -> nlev levels)
   double *scr[MOM6X_NSCR]; int scr_nlev[MOM6X_NSCR];
   bool prof_on;
@@ -107,6 +109,7 @@ void prof_end(mom6x_ctx *c);
   } while (0)
 
 int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out);   // ctx.hip
+void hor_visc_free(mom6x_ctx *c);                                  // hor_visc.hip
 // dyn_kernels.hip: vertvisc_coef looking at u (mode 0), mask*(u + dtx*u_bc) (1) or mask*(u + dtx*(u_bc + u_abt)) (2)
 int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, const double *u_bc, const double *v_bc,
                       const double *u_abt, const double *v_abt, double dtx, const double *h, double dt);

@@ -202,6 +202,16 @@ class Dycore:
         """vertvisc_coef (MOM_vert_friction.F90:1357) with dz = H_to_Z*h."""
         check(self.lib, self.lib.mom6x_vertvisc_coef(self.ctx, _ptr(u), _ptr(v), _ptr(h), C.c_double(dt)))
 
+    def hor_visc_init(self, params):
+        """hor_visc_init (MOM_hor_visc.F90:2322): the 2-D viscosity planes are computed on the device.  From here on
+        step_dyn_split_RK2 calls horizontal_viscosity itself unless a host callback is given."""
+        self.hv_params = params
+        check(self.lib, self.lib.mom6x_hor_visc_init(self.ctx, C.byref(params)))
+
+    def horizontal_viscosity(self, u, v, h, diffu, diffv):
+        """horizontal_viscosity (MOM_hor_visc.F90:266)."""
+        check(self.lib, self.lib.mom6x_horizontal_viscosity(self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(diffu), _ptr(diffv)))
+
     def vertvisc(self, u, v, taux, tauy, dt, taux_bot=None, tauy_bot=None):
         """vertvisc (MOM_vert_friction.F90:557)."""
         check(self.lib, self.lib.mom6x_vertvisc(self.ctx, _ptr(u), _ptr(v), _ptr(taux), _ptr(tauy), C.c_double(dt),

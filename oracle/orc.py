@@ -142,6 +142,22 @@ def PressureForce(d, G, GV, CS, Rlay, g_prime, h, PFu, PFv, pbce=None, eta=None,
         raise RuntimeError(f"orc_PressureForce rc={rc}")
 
 
+def hor_visc_init(d, G, CS):
+    """The 2-D coefficient planes of hor_visc_CS as one block [nplanes][slab]."""
+    n = lib().orc_hor_visc_nplanes()
+    P = np.zeros((n,) + d.shape2())
+    rc = lib().orc_hor_visc_init(C.byref(d), _p(G), C.byref(CS), _p(P))
+    if rc != 0:
+        raise RuntimeError(f"orc_hor_visc_init rc={rc}")
+    return P
+
+
+def horizontal_viscosity(d, G, GV, CS, P, u, v, h, diffu, diffv):
+    rc = lib().orc_horizontal_viscosity(C.byref(d), _p(G), C.byref(GV), C.byref(CS), _p(P), _p(u), _p(v), _p(h), _p(diffu), _p(diffv))
+    if rc != 0:
+        raise RuntimeError(f"orc_horizontal_viscosity rc={rc}")
+
+
 def eos_density(eos, T, S, p):
     L = lib(); L.orc_eos_density.restype = C.c_double
     return L.orc_eos_density(C.byref(eos), C.c_double(T), C.c_double(S), C.c_double(p))
@@ -196,7 +212,8 @@ class Rk2All(C.Structure):
                 ("T", C.c_void_p), ("S", C.c_void_p), ("eos", C.c_void_p), ("vv", C.c_void_p),
                 ("Kv_bbl_u", C.c_void_p), ("Kv_bbl_v", C.c_void_p), ("bbl_thick_u", C.c_void_p), ("bbl_thick_v", C.c_void_p),
                 ("Kv_shear", C.c_void_p), ("Ray_u", C.c_void_p), ("Ray_v", C.c_void_p),
-                ("vv_a_u", C.c_void_p), ("vv_a_v", C.c_void_p), ("vv_h_u", C.c_void_p), ("vv_h_v", C.c_void_p)]
+                ("vv_a_u", C.c_void_p), ("vv_a_v", C.c_void_p), ("vv_h_u", C.c_void_p), ("vv_h_v", C.c_void_p),
+                ("hv", C.c_void_p), ("hv_planes", C.c_void_p)]
 
 
 class OrcModel:
@@ -222,7 +239,7 @@ class OrcModel:
         A.Rlay = self.Rlay.ctypes.data; A.g_prime = self.g_prime.ctypes.data
         A.CS = C.addressof(self.cs); A.BTCS = C.addressof(self.btcs.struct); A.BT_cont = C.addressof(self.bt_cont_s)
         A.first_direction = first_direction
-        A.T = None; A.S = None; A.eos = None; A.vv = None
+        A.T = None; A.S = None; A.eos = None; A.vv = None; A.hv = None; A.hv_planes = None
         self.A = A
 
     def set_vertvisc(self, vv, Kv_bbl_u=None, Kv_bbl_v=None, bbl_thick_u=None, bbl_thick_v=None, Kv_shear=None,
@@ -239,6 +256,12 @@ class OrcModel:
             setattr(A, n, a.ctypes.data if a is not None else None)
         A.vv_a_u = self.vv_out["a_u"].ctypes.data; A.vv_a_v = self.vv_out["a_v"].ctypes.data
         A.vv_h_u = self.vv_out["h_u"].ctypes.data; A.vv_h_v = self.vv_out["h_v"].ctypes.data
+
+    def set_hor_visc(self, hv):
+        """hor_visc_init: the step and the new-run initialisation then call horizontal_viscosity themselves."""
+        self._hv = hv
+        self.hv_planes = hor_visc_init(self.d, self.M, hv)
+        self.A.hv = C.addressof(hv); self.A.hv_planes = self.hv_planes.ctypes.data
 
     def set_tv(self, T, S, eos):
         """tv%T, tv%S, tv%eqn_of_state for the PressureForce calls of the step (None: layered path)."""

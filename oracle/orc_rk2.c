@@ -48,6 +48,8 @@ int orc_vertvisc_remnant(const mom6x_dims *d, const double *G, double *visc_rem_
                          const double *Ray_v, double dt);
 
 typedef struct { const double *a_u, *a_v, *h_u, *h_v, *Ray_u, *Ray_v; } orc_visc_coef;
+int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_hor_visc_params *CS,
+                             const double *P, const double *u, const double *v, const double *h, double *diffu, double *diffv);
 int orc_vertvisc_coef(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_vertvisc_params *CS,
                       const double *u, const double *v, const double *h, double dt, const double *Kv_bbl_u,
                       const double *Kv_bbl_v, const double *bbl_thick_u, const double *bbl_thick_v, const double *Kv_shear,
@@ -72,6 +74,9 @@ typedef struct orc_rk2_all {   /* everything step_MOM_dyn_split_RK2 reaches thro
   const mom6x_vertvisc_params *vv;
   const double *Kv_bbl_u, *Kv_bbl_v, *bbl_thick_u, *bbl_thick_v, *Kv_shear, *Ray_u, *Ray_v;
   double *vv_a_u, *vv_a_v, *vv_h_u, *vv_h_v;
+  /* hor_visc_CS: when hv != NULL horizontal_viscosity is called by the step (:886) and by the new-run initialisation
+   * (:1601) with the coefficient planes hv_planes (orc_hor_visc_init); otherwise diffu/diffv stay as given. */
+  const mom6x_hor_visc_params *hv; const double *hv_planes;
 } orc_rk2_all;
 
 /* the new-run branch of initialize_dyn_split_RK2 :1577-1650 (+ barotropic_init ubtav :6124-6135 is done by the
@@ -88,6 +93,10 @@ int orc_initialize_dyn_split_RK2(const orc_rk2_all *A, const double *u, const do
   for (int k = 0; k < d->nk; k++) for (int j = 0; j < d->nj; j++) for (int i = 0; i < d->ni; i++) {
     size_t x = IX2(d, i, j);
     CS->eta[x] = CS->eta[x] + h[x + k * slab];
+  }
+  if (A->hv) {   /* :1599-1606: diffu, diffv are not in the restart file of a new run */
+    int rc_ = orc_horizontal_viscosity(d, A->G, A->GV, A->hv, A->hv_planes, u, v, h, CS->diffu, CS->diffv);
+    if (rc_) return rc_;
   }
   memcpy(CS->u_av, u, n3 * sizeof(double)); memcpy(CS->v_av, v, n3 * sizeof(double));
   if (A->rk2->store_CAu) {
@@ -232,6 +241,10 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   /* diffu = horizontal viscosity terms (u_av) :884-888 -> replaced arrays, if supplied */
   if (diffu_new) memcpy(CS->diffu, diffu_new, n3 * sizeof(double));
   if (diffv_new) memcpy(CS->diffv, diffv_new, n3 * sizeof(double));
+  if (A->hv) {   /* :886 */
+    rc = orc_horizontal_viscosity(d, G, GV, A->hv, A->hv_planes, CS->u_av, CS->v_av, CS->h_av, CS->diffu, CS->diffv);
+    if (rc) return rc;
+  }
 
   rc = orc_CorAdCalc(d, G, GV, A->cor, u_av, v_av, h_av, uh, vh, CS->CAu, CS->CAv); /* :893 */
   if (rc) return rc;

@@ -29,6 +29,37 @@ def benchmark_small(nk=8, ni=40, nj=24, halo=4, layout=(1, 1), pe=(0, 0)):
     return gg, d, M
 
 
+def island_basin(nk=4, ni=36, nj=28, halo=4, layout=(1, 1), pe=(0, 0)):
+    """Closed spherical basin with an island and a one-cell peninsula: corners and faces of every orientation
+    (exercises NOSLIP, the land-mask thickness averages and the reduction factors of hor_visc)."""
+    bowl = grid.bowl_depth(ni, nj, 3000.0)
+
+    def depth(ig, jg):
+        D = bowl(ig, jg)
+        island = ((ig >= 14) & (ig <= 17) & (jg >= 10) & (jg <= 12)) | ((ig == 18) & (jg == 11))
+        spit = (ig >= 1) & (ig <= 6) & (jg == 20)
+        return np.where(island | spit, 0.0, D)
+    gg = grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=20.0, dlon=0.5, dlat=0.5, depth_fn=depth)
+    d, M = gg.tile(nk, halo, layout, pe)
+    return gg, d, M
+
+
+def partial_faces(d, M, seed=11, frac=0.3):
+    """Partially blocked faces: dy_Cu < dyCu, dx_Cv < dxCv at a fraction of the open faces (channel-width metrics
+    of a real grid); areas are kept consistent as in set_grid_metrics (MOM_grid_initialize.F90:1185-1230)."""
+    G = abi.G
+    rng = np.random.default_rng(seed)
+    M = M.copy()
+    for open_, full, area, Iarea, other, mask in (("dy_Cu", "dyCu", "areaCu", "IareaCu", "dxCu", "mask2dCu"),
+                                                  ("dx_Cv", "dxCv", "areaCv", "IareaCv", "dyCv", "mask2dCv")):
+        f = np.where(rng.random(M[G[full]].shape) < frac, rng.uniform(0.2, 0.95, M[G[full]].shape), 1.0)
+        M[G[open_]] = M[G[mask]] * M[G[full]] * f
+        M[G[area]] = M[G[other]] * M[G[open_]]
+        with np.errstate(divide="ignore"):
+            M[G[Iarea]] = np.where(M[G[area]] > 0, M[G[mask]] / np.where(M[G[area]] > 0, M[G[area]], 1.0), 0.0)
+    return np.ascontiguousarray(M)
+
+
 def interior(d, stagger="h", extra=0):
     """numpy slices of the computational domain for a staggering (symmetric memory)."""
     e = extra

@@ -217,3 +217,81 @@ def test_equation_of_state_against_reference_known_answers(orc):
         fd_T = (orc.eos_density(e, 25.0 + dT, 35.0, 1e7) - orc.eos_density(e, 25.0 - dT, 35.0, 1e7)) / (2 * dT)
         fd_S = (orc.eos_density(e, 25.0, 35.0 + dS, 1e7) - orc.eos_density(e, 25.0, 35.0 - dS, 1e7)) / (2 * dS)
         assert abs(a - fd_T) < 1e-4 * abs(a) and abs(b - fd_S) < 1e-4 * abs(b)
+
+
+def _hv(orc, d, M, GV, P, u, v, h):
+    planes = orc.hor_visc_init(d, M, P)
+    du, dv = np.zeros_like(u), np.zeros_like(v)
+    orc.horizontal_viscosity(d, M, GV, P, planes, u, v, h, du, dv)
+    return du, dv, planes
+
+
+def test_horizontal_viscosity_known_answers(orc):
+    """hor_visc on a Cartesian channel with flat layers: (a) uniform flow feels no stress; (b) a zonal jet
+    u = U sin(l y) is damped as -Kh l^2 s u (Laplacian) and -Ah l^4 s^2 u (biharmonic), with the second-difference
+    factor s = (sin(l dy/2)/(l dy/2))^2 -- the discrete operator's exact answer (tolerance 1e-10 relative)."""
+    gg, d, M = H.channel(nk=2, nj=36)
+    GV = abi.vgrid_default()
+    h = np.zeros((d.nk,) + d.shape2()); h[:] = 400.0 * M[abi.G["mask2dT"]] + GV.Angstrom_H
+    h[:, M[abi.G["mask2dT"]] == 0] = GV.Angstrom_H
+    dy = 2.0e4
+    l = 2.0 * np.pi / (12.0 * dy)
+    s = (np.sin(0.5 * l * dy) / (0.5 * l * dy)) ** 2
+    jj = (np.arange(d.shape2()[0]) - d.joff + 0.5) * dy
+    u = np.zeros_like(h); v = np.zeros_like(h)
+    rows = d.sl(-1, d.ni - 1, 8, d.nj - 9)     # far enough from the walls for a 5-row stencil
+    off = dict(bound_Kh=0, bound_Ah=0, better_bound_Kh=0, better_bound_Ah=0, use_land_mask=0)
+    # (a)
+    u[:] = 0.3 * M[abi.G["mask2dCu"]]
+    P = abi.hor_visc_params_default(1200.0, Laplacian=True, biharmonic=True)
+    P.Kh = 1.0e3; P.Ah = 1.0e11
+    for k_, v_ in off.items():
+        setattr(P, k_, v_)
+    du, dv, _ = _hv(orc, d, M, GV, P, u, v, h)
+    assert np.abs(du[(Ellipsis,) + tuple(rows)]).max() == 0.0 and np.abs(dv[(Ellipsis,) + tuple(rows)]).max() == 0.0
+    # (b)
+    u[:] = (0.3 * np.sin(l * jj))[None, :, None] * M[abi.G["mask2dCu"]]
+    for lap, bih, expect in ((True, False, -1.0e3 * l ** 2 * s), (False, True, -1.0e11 * l ** 4 * s ** 2)):
+        P = abi.hor_visc_params_default(1200.0, Laplacian=lap, biharmonic=bih)
+        P.Kh = 1.0e3; P.Ah = 1.0e11
+        for k_, v_ in off.items():
+            setattr(P, k_, v_)
+        du, dv, _ = _hv(orc, d, M, GV, P, u, v, h)
+        a, b = du[(Ellipsis,) + tuple(rows)], expect * u[(Ellipsis,) + tuple(rows)]
+        assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max(), (lap, bih, np.abs(a - b).max(), np.abs(b).max())
+        assert np.abs(dv[(Ellipsis,) + tuple(rows)]).max() <= 1e-25
+
+
+def test_horizontal_viscosity_better_bounds_are_stable(orc):
+    """BETTER_BOUND_KH / BETTER_BOUND_AH (:3025-3114) exist so that a forward step with any requested viscosity
+    cannot amplify grid-scale noise: with absurdly large KH and AH, one step of u + dt*diffu of a checkerboard must
+    not grow, and the maximum-viscosity planes must be positive at wet points and zero on land."""
+    gg, d, M = H.island_basin()
+    M = H.partial_faces(d, M)
+    GV = abi.vgrid_default()
+    dt = 1200.0
+    rng = np.random.default_rng(5)
+    h, u, v = synth.make_state(d, M, thin_frac=0.2)
+    sgn = (-1.0) ** (np.add.outer(np.arange(d.shape2()[0]), np.arange(d.shape2()[1])))
+    u = 0.2 * sgn[None] * M[abi.G["mask2dCu"]] * (1.0 + 0.2 * rng.random(u.shape))
+    v = -0.2 * sgn[None] * M[abi.G["mask2dCv"]] * (1.0 + 0.2 * rng.random(v.shape))
+    for lap, bih in ((True, False), (False, True), (True, True)):
+        P = abi.hor_visc_params_default(dt, Laplacian=lap, biharmonic=bih)
+        P.Kh = 1.0e12; P.Ah = 1.0e24
+        du, dv, planes = _hv(orc, d, M, GV, P, u, v, h)
+        su, sv = H.interior(d, "u"), H.interior(d, "v")
+        un, vn = (u + dt * du)[(Ellipsis,) + tuple(su)], (v + dt * dv)[(Ellipsis,) + tuple(sv)]
+        ke0 = (u[(Ellipsis,) + tuple(su)] ** 2).sum() + (v[(Ellipsis,) + tuple(sv)] ** 2).sum()
+        ke1 = (un ** 2).sum() + (vn ** 2).sum()
+        assert np.isfinite(du).all() and ke1 < ke0, (lap, bih, ke1 / ke0)
+        assert np.abs(un).max() <= 1.05 * np.abs(u).max() and np.abs(vn).max() <= 1.05 * np.abs(v).max()
+        names = ["dx2h", "dy2h", "dx2q", "dy2q", "DX_dyT", "DY_dxT", "DX_dyBu", "DY_dxBu", "red_xx", "red_xy", "Kh_bg_xx", "Kh_bg_xy",
+                 "Kh_Max_xx", "Kh_Max_xy", "Lap2_xx", "Lap2_xy", "Idx2dyCu", "Idxdy2u", "Idx2dyCv", "Idxdy2v", "Ah_bg_xx", "Ah_bg_xy",
+                 "Ah_Max_xx", "Ah_Max_xy"]
+        pl = dict(zip(names, planes))
+        hs = H.interior(d, "h")
+        wet = M[abi.G["mask2dT"]][tuple(hs)] > 0
+        for nm, on in (("Kh_Max_xx", lap), ("Ah_Max_xx", bih)):
+            if on:
+                assert (pl[nm][tuple(hs)][wet] > 0).all()
+        assert (pl["red_xx"][tuple(hs)] <= 1.0).all() and (pl["red_xx"][tuple(hs)] < 1.0).any()

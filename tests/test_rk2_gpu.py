@@ -15,12 +15,12 @@ G = abi.G
 
 STATE = ["u", "v", "h", "uh", "vh", "uhtr", "vhtr", "eta_av"]
 STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h", CAu="u", CAv="v", CAu_pred="u", CAv_pred="v",
-            PFu="u", PFv="v", visc_rem_u="u", visc_rem_v="v", u_accel_bt="u", v_accel_bt="v", u_av="u", v_av="v", h_av="h",
+            PFu="u", PFv="v", diffu="u", diffv="v", visc_rem_u="u", visc_rem_v="v", u_accel_bt="u", v_accel_bt="v", u_av="u", v_av="v", h_av="h",
             eta="h", eta_PF="h", uhbt="u", vhbt="v", taux_bot="u", tauy_bot="v", BT_h_u="u", BT_h_v="v", pbce="h")
 
 
 def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, per_stage=False, new_diff=False,
-        exact=True, rtol=1e-11, eos_form=None, dev_vv=None):
+        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None):
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
@@ -44,7 +44,7 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
         for k_, v_ in dev_vv.items():
             setattr(P, k_, v_)
         vvset = (P,) + tuple(visc_inputs(d, M)) + (coefs[0][4], coefs[0][5])
-    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction, tv=tv, vv=vvset)
+    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction, tv=tv, vv=vvset, hv=hv)
 
     # ---------------- device
     cont2, bt2, cor2, pgf2, rk22 = params()
@@ -63,6 +63,8 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
         dyc.vertvisc_init(vvset[0])
         vdev = [dyc.to_dev(a) if a is not None else None for a in vvset[1:]]
         dyc.vertvisc_set_visc(*vdev)
+    if hv is not None:   # horizontal_viscosity inside the step and in the new-run initialisation
+        dyc.hor_visc_init(hv)
     txd, tyd = dyc.to_dev(taux), dyc.to_dev(tauy)
     dnew = tuple(dyc.to_dev(a) for a in diff_new) if diff_new else None
     torch.cuda.synchronize()
@@ -96,6 +98,9 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
 
     for n in STATE:
         cmp(n, sg[n].cpu().numpy(), so[n])
+    if hv is not None:
+        cmp("diffu", dyc.rk2_field("diffu").cpu().numpy(), m["diffu"]); cmp("diffv", dyc.rk2_field("diffv").cpu().numpy(), m["diffv"])
+        assert np.abs(m["diffu"]).max() > 0
     for n in ("CAu", "CAv", "CAu_pred", "CAv_pred", "PFu", "PFv", "visc_rem_u", "visc_rem_v", "u_accel_bt", "v_accel_bt",
               "u_av", "v_av", "h_av", "eta", "eta_PF", "uhbt", "vhbt", "taux_bot", "tauy_bot"):
         cmp(n, dyc.rk2_field(n).cpu().numpy(), m[n])
@@ -150,3 +155,18 @@ def test_rk2_with_device_vertvisc_coef(orc, mods):
 
 def test_rk2_default_path_tolerance(orc):
     run(orc, H.double_gyre(), nsteps=3, exact=False)
+
+
+@pytest.mark.parametrize("cfg,mods", [("double_gyre", dict(Ah_vel_scale=0.02)),
+                                      ("island_basin", dict(Laplacian=1, Kh=500.0, Smagorinsky_Kh=1, Smag_Lap_const=0.15, Smagorinsky_Ah=1,
+                                                            Smag_bi_const=0.06, Ah_vel_scale=0.02))])
+def test_rk2_with_device_horizontal_viscosity(orc, cfg, mods):
+    """hor_visc_init given: the step (:886) and the new-run initialisation (:1601) call horizontal_viscosity
+    themselves (device vertvisc_coef as well: nothing comes from callbacks).  Bit for bit over 3 steps."""
+    c = getattr(H, cfg)()
+    P = abi.hor_visc_params_default(1200.0)
+    for k_, v_ in mods.items():
+        setattr(P, k_, v_)
+    from tests import cases
+    P.dt = cases.rk2_inputs(c, False, False)["dt"]
+    run(orc, c, nsteps=3, bt_mod=dict(strong_drag=1), dev_vv=dict(), hv=P)
