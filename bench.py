@@ -5,9 +5,9 @@ split-explicit dynamical core (step_MOM_dyn_split_RK2) on a synthetic 0.25-degre
 MOM6's 2-D tile layout, one tile per GPU).
 
 A "step" is ONE baroclinic step of step_MOM_dyn_split_RK2: PressureForce, CorAdCalc x2, continuity_PPM
-x3, btstep x2 (each a full barotropic sub-cycle), vertvisc_coef x3, vertvisc x2, vertvisc_remnant x3 and the
-RK2 glue, on state that already resides in HBM.  The one un-ported callee (horizontal_viscosity: SURVEY.md
-8f) is represented by diffu = diffv = 0, stated in `config`.
+x3, btstep x2 (each a full barotropic sub-cycle), horizontal_viscosity, vertvisc_coef x3, vertvisc x2,
+vertvisc_remnant x3 and the RK2 glue, on state that already resides in HBM -- every callee of the step runs on
+the device; only the set_viscous_BBL inputs of vertvisc_coef are synthetic constants (stated in `config`).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel -- the one with the largest
 total time in the last warm-up step (k_mass_flux_lds: PPM reconstruction + zonal/meridional mass flux +
@@ -42,9 +42,19 @@ def algorithmic_bytes_per_step(N3, N2, nsub_total):
     per_N3 = {"continuity_PPM x3": 256, "CorAdCalc x3": 168, "PressureForce": 32, "btstep 3-D setup/teardown x2": 272,
               "btcalc + bt_mass_source": 24, "vertvisc x2 + remnant x3": 480, "RK2 pointwise glue": 384,
               # not in SURVEY 8(d) (a "next" row there): u, h in; a_u, h_u out, per direction and call
-              "vertvisc_coef x3": 192}
+              "vertvisc_coef x3": 192,
+              # also a "next" row: u, v, h in; diffu, diffv out
+              "horizontal_viscosity": 40}
     total = sum(per_N3.values()) * N3 + 570.0 * N2 * nsub_total
     return total, per_N3
+
+
+def hor_visc_params(abi, dt):
+    """OM4_025-class lateral friction switches: LAPLACIAN with KH_VEL_SCALE, BIHARMONIC with AH_VEL_SCALE and
+    SMAGORINSKY_AH (SMAG_BI_CONST = 0.06), the better bounds on both (defaults)."""
+    P = abi.hor_visc_params_default(dt, Laplacian=True, biharmonic=True)
+    P.Kh_vel_scale = 0.01; P.Ah_vel_scale = 0.01; P.Smagorinsky_Ah = 1; P.Smag_bi_const = 0.06
+    return P
 
 
 def build_model(args, layout, pe, device):
@@ -75,6 +85,7 @@ def build_model(args, layout, pe, device):
     bbl_u = torch.full_like(Kv_bbl_u, 10.0); bbl_v = torch.full_like(Kv_bbl_v, 10.0)
     dyc.vertvisc_set_visc(Kv_bbl_u, Kv_bbl_v, bbl_u, bbl_v)
     dyc.vertvisc_coef(u, v, h, args.dt)
+    dyc.hor_visc_init(hor_visc_params(abi, args.dt))   # the step and the new-run initialisation call horizontal_viscosity
     taux = (0.1 * synth_dev.smooth_field(d, dyc.device, 41, ox=1.0, oy=0.5) * Md[G["mask2dCu"]]).contiguous()
     tauy = torch.zeros_like(taux)
     torch.cuda.synchronize()
@@ -97,6 +108,7 @@ KERNEL_WORDS = {
     "k_vel_update": 6.0,
     "k_layer_accel": 5.0,
     "k_convergence": 3.0,        # h_in, uh in; h out
+    "k_hv_stress": 7.0,          # h, sh_xx, sh_xy, Del2u, Del2v in; str_xx, str_xy out
 }
 
 
@@ -188,6 +200,7 @@ def cpu_baseline(args):
     kbv = np.ascontiguousarray(2.0e-3 * (1.0 + 0.5 * synth.smooth_field(d, 92, ox=0.5, oy=1.0)) * M[abi.G["mask2dCv"]])
     bbl = np.full(d.shape2(), 10.0)
     m.set_vertvisc(abi.vertvisc_params_default(Kv=1.0e-4, Hmix=20.0, Hbbl=10.0), kbu, kbv, bbl, bbl.copy())
+    m.set_hor_visc(hor_visc_params(abi, args.dt))
     coefs = (None,) * 6
     z3 = lambda: np.zeros_like(h)
     uh, vh, uhtr, vhtr, eta_av = z3(), z3(), z3(), z3(), np.zeros(d.shape2())
@@ -310,12 +323,12 @@ def main():
         "config": {"workload": f"step_MOM_dyn_split_RK2 on {args.ni}x{args.nj}x{args.nk} (0.25-degree-class synthetic global, "
                                f"BASELINE.json configs[3] grid), DT={args.dt:g} s, layout {layout[0]}x{layout[1]}, "
                                f"{nsub} barotropic sub-steps per step",
-                   "frozen_inputs": "horizontal_viscosity (SURVEY 8f) is not ported: diffu = diffv = 0; vertvisc_coef runs on the device with constant synthetic set_viscous_BBL inputs",
+                   "frozen_inputs": "none of the step's callees; vertvisc_coef and horizontal_viscosity run on the device inside the step (the set_viscous_BBL inputs of vertvisc_coef are constant synthetic fields)",
                    "tile": [d.ni, d.nj, d.nk], "halo": d.halo},
         "roofline": roofline,
         "hbm_step": {"algorithmic_GB_per_step": round(bytes_step / 1e9, 2), "achieved_GBps": round(bytes_step / 1e9 / (ms_per_step * 1e-3), 1),
                      "frac_of_peak": round(bytes_step / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * args.gpus), 4),
-                     "model": "SURVEY.md 8(d): 1616 B x N3 + 570 B x N2 x sub-steps, + 192 B x N3 for vertvisc_coef x3"},
+                     "model": "SURVEY.md 8(d): 1616 B x N3 + 570 B x N2 x sub-steps, + 192 B x N3 for vertvisc_coef x3 + 40 B x N3 for horizontal_viscosity"},
     }
     if args.tracers > 0:
         out["tracer_leg"] = tracer_leg(args, dyc, d, st, step, barrier, dist)

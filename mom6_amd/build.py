@@ -16,7 +16,7 @@ LIB = os.path.join(LIBDIR, "libmom6x.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"] + os.environ.get("MOM6X_CFLAGS", "").split()
 
 
 def _newer(srcs, target):

@@ -29,7 +29,21 @@
 namespace {
 
 constexpr int NF = 16;        // faces along i per work-group (the coalesced axis)
-// KL = layer lanes per face (template parameter): 16 (4 wavefronts) or 32 (8 wavefronts) per work-group
+#ifndef MOM6X_X_WG
+#define MOM6X_X_WG 3   // work-groups per CU the zonal kernel is compiled for (LDS allows 3 at nk = 75)
+#endif
+
+// Dev tool (MOM6X_CFLAGS=-DMOM6X_MFL_TIMING python -m mom6_amd.build --force; scripts/prof_continuity.py): shader-clock
+// cycles lane 0 of every work-group spends in each phase of the kernel, summed over the work-groups.
+#ifdef MOM6X_MFL_TIMING
+__device__ unsigned long long g_mfl_t[2][16];
+#define TICK_INIT long long t_prev_ = clock64()
+#define TICK(p) do { if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_mfl_t[DIR][p], (unsigned long long)(t_ - t_prev_)); t_prev_ = t_; } } while (0)
+#else
+#define TICK_INIT
+#define TICK(p)
+#endif
+// KL = layer lanes per face (template parameter): 16, i.e. 4 wavefronts per work-group
 
 // zonal_flux_layer :896 / merid_flux_layer :1787 with the cell data in LDS.
 // m / p: LDS slots of the minus / plus cell of the face.
@@ -125,6 +139,25 @@ __device__ __forceinline__ void col_walk4(const double *a, int str, int n, F f) 
   for (; k + 8 <= n; k += 8) batch4<8>(a, str, k, f);
   for (; k + 2 <= n; k += 2) batch4<2>(a, str, k, f);
   for (; k < n; k++) batch4<1>(a, str, k, f);
+}
+
+template <int U, typename F>
+__device__ __forceinline__ void batch5(const double *a, const double *b, const double *c, int str, int k0, F &f) {
+  double x[U], y[U], z[U], w[U], v[U];
+#pragma unroll
+  for (int q = 0; q < U; q++) {
+    const int o = (k0 + q) * NF;
+    x[q] = a[o]; y[q] = b[o]; z[q] = c[o]; w[q] = c[o + str]; v[q] = c[o + 2 * str];
+  }
+#pragma unroll
+  for (int q = 0; q < U; q++) f(x[q], y[q], z[q], w[q], v[q]);
+}
+template <typename F>
+__device__ __forceinline__ void col_walk5(const double *a, const double *b, const double *c, int str, int n, F f) {
+  int k = 0;
+  for (; k + 8 <= n; k += 8) batch5<8>(a, b, c, str, k, f);
+  for (; k + 2 <= n; k += 2) batch5<2>(a, b, c, str, k, f);
+  for (; k < n; k++) batch5<1>(a, b, c, str, k, f);
 }
 
 struct Tile {   // what every lane knows about its face and the LDS arrays
@@ -252,16 +285,17 @@ __device__ __forceinline__ double wg_flux_adjust(const Tile &T, bool face, const
 }
 
 template <int DIR, int KL, int MAXL, bool LAZY>
-__global__ void __launch_bounds__(NF * KL, (KL * MAXL > 96) ? 1 : (KL == 32 ? 4 : (DIR ? 2 : 3)))   // LDS lets 3 (x) | 2 (y) work-groups share a CU at nk = 75
+__global__ void __launch_bounds__(NF * KL, (KL * MAXL > 96) ? 1 : (DIR ? 2 : MOM6X_X_WG))   // LDS lets 3 (x) | 2 (y) work-groups share a CU at nk = 75
 k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   // The LAZY kernel runs flux_adjust with cheap bounds of the CFL limits; a work-group whose Newton steps come within
   // reach of them marks its tile in E.retry and stops.  The exact kernel (second launch, same grid) only works on the
   // marked tiles, with the limits from the k-recurrence, and rewrites all of the tile's outputs.
   const int tile = blockIdx.y * gridDim.x + blockIdx.x;
   if (!LAZY && E.retry && !E.retry[tile]) return;
+  TICK_INIT;
   extern __shared__ double smem[];
   constexpr int NC = DIR ? 2 * NF : NF + 1;
-  const int nk = d.nk, nkp = max((nk + 1) & ~1, KL);   // the transit arrays double as [KL][NF] reduction scratch
+  const int nk = d.nk, nkp = max((nk + 1) & ~1, 3 * KL);   // the transit arrays double as 6 x [KL][NF] reduction scratch
   double *sL = smem, *sR = sL + nk * NC, *sC = sR + nk * NC, *sA = sC + nk * NC, *sB = sA + nkp * NF;
   __shared__ double s_du[NF], s_duL[NF], s_duR[NF], s_red[KL][NF];
   __shared__ int s_doI[NF];
@@ -297,6 +331,12 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
       if (use_visc_rem) v_r[n] = A.visc_rem[f];
     }
   }
+
+  // every other global load of the kernel is issued here as well: a load after the stores of uh / u_cor / h_face
+  // would have to wait for those to drain (the memory counter is in order)
+  const double IareaMin = dmin(D.IareaT[f2], D.IareaT[f2 + st]);
+  const double uhbt_f = (A.uhbt != nullptr && face) ? A.uhbt[f2] : 0.0;
+  const double dC_f = A.set_BT_cont ? D.dC[f2] : 0.0;
 
   // ---- PPM_reconstruction + limiter for the cells of this tile, all layers, into LDS ---------------
   if (DIR == 0) {
@@ -384,6 +424,7 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     }
   }
   __syncthreads();   // cell arrays complete; the sA|sB space is free again
+  TICK(0);
 
   Tile T;
   T.sL = sL; T.sR = sR; T.sC = sC; T.sA = sA; T.sB = sB; T.s_du = s_du; T.s_doI = s_doI;
@@ -466,6 +507,7 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     }
   }
   const bool lazy = LAZY && use_visc_rem && (E.retry != nullptr);   // flux_adjust runs with bounds of the limits
+  TICK(1);
   // The first sweep (:615-668): layer transports and their derivatives of this lane's layers into the transit arrays
   auto first_sweep = [&]() {
 #pragma unroll
@@ -488,12 +530,12 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
       col_walk2(sA + fl, sB + fl, nk, [&](double a, double b) { duhdu_tot_0 = duhdu_tot_0 + b; uh_tot_0 = uh_tot_0 + a; });
   }
 
+  TICK(2);
   // ---- flux_adjust towards uhbt; uh, u_cor, du_cor ---------------------------------------------------
-  const double IareaMin = dmin(D.IareaT[f2], D.IareaT[f2 + st]);
   double du_fin = 0.0;
   const bool corrected = (A.uhbt != nullptr);
   if (corrected) {
-    const double uhbt = face ? A.uhbt[f2] : 0.0;
+    const double uhbt = uhbt_f;
     bool redo;
     const double du = wg_flux_adjust<KL, MAXL>(T, face, u_r, v_r, IareaMin, uhbt, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
                                                A.tol_eta, A.tol_vel, A.better_iter, true, lazy, redo);
@@ -501,6 +543,7 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     if (face && A.du_cor) A.du_cor[f2] = du;
     du_fin = s_du[fl];   // published by the face lane before the last barrier of the loop
   }
+  TICK(3);
   if (active) {
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
@@ -544,6 +587,7 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
       }
     }
   }
+  TICK(4);
   if (!A.set_BT_cont) return;
 
   // ---- set_zonal_BT_cont :1246-1409 / set_merid_BT_cont :2143-2304 -----------------------------------
@@ -554,69 +598,130 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
                                                A.tol_eta, A.tol_vel, A.better_iter, false, lazy, redo0);
   if (lazy && redo0) { if (tid == 0) E.retry[tile] = 1; return; }
   const double du0 = face ? du0f : 0.0;
-  const double du_CFL = (CFL_min * Idt) * D.dC[f2];
-  double duR = dmin(0.0, du0 - du_CFL);
-  double duL = dmax(0.0, du0 + du_CFL);
-  recurrence4<KL, MAXL>(T, face,
-    [&](int n, double *o) {
-      const double uk = u_r[n], vrem = v_r[n];
-      const double visc_rem_lim = dmax(vrem, min_visc_rem * visc_rem_max);
-      o[0] = uk; o[1] = vrem;
-      o[2] = -(uk + du_CFL * vrem) / visc_rem_lim;
-      o[3] = -(uk - du_CFL * vrem) / visc_rem_lim;
-    },
-    [&](double uk, double vrem, double q_R, double q_L) {
-      const double visc_rem_lim = dmax(vrem, min_visc_rem * visc_rem_max);
-      if (visc_rem_lim > 0.0) {
-        if (uk + duR * visc_rem_lim > -du_CFL * vrem) duR = q_R;
-        if (uk + duL * visc_rem_lim < du_CFL * vrem) duL = q_L;
+  TICK(5);
+  const double du_CFL = (CFL_min * Idt) * dC_f;
+  // duR / duL (:1293-1316): a k-recurrence "if (u_k + duR*vrl_k > -du_CFL*vrem_k) duR = q_k" whose state only ever
+  // holds duR_0 or one of the quotients q_k.  In exact arithmetic it returns min(duR_0, min_k q_k); in floating
+  // point the comparison is made in the un-divided form and may disagree with that for near-ties.  So all lanes
+  // compute the candidate F = min (first index k*) and a certificate that the reference's loop returns exactly F:
+  //   - the test of layer k* is true for the smallest value s2 > F the state can hold before it (the test is monotone
+  //     in the state), and
+  //   - the test is false at F for every k > k*, unless q_k is bit-identical to F.
+  // Only if a certificate fails (it does not unless quotients nearly tie) does the work-group walk the recurrence.
+  const double a_du0 = s_du[fl];   // published by the face lane inside wg_flux_adjust
+  const double x0R = dmin(0.0, a_du0 - du_CFL), x0L = dmax(0.0, a_du0 + du_CFL);
+  const double vrl_floor = min_visc_rem * visc_rem_max;
+  double a_duR, a_duL;
+  {
+    const double BIG = 1.0e300;
+    double qR[MAXL], qL[MAXL], vl[MAXL];
+    double r1 = BIG, r2 = BIG, l1 = -BIG, l2 = -BIG, ri = 1.0e9, li = 1.0e9;   // two smallest / largest distinct quotients
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = kl + KL * n;
+      vl[n] = 0.0; qR[n] = 0.0; qL[n] = 0.0;
+      if (k < nk) {
+        const double uk = u_r[n], vrem = v_r[n];
+        const double visc_rem_lim = dmax(vrem, vrl_floor);
+        if (visc_rem_lim > 0.0) {
+          vl[n] = visc_rem_lim;
+          qR[n] = -(uk + du_CFL * vrem) / visc_rem_lim;
+          qL[n] = -(uk - du_CFL * vrem) / visc_rem_lim;
+          if (qR[n] < r1) { r2 = r1; r1 = qR[n]; ri = (double)k; } else if (qR[n] > r1 && qR[n] < r2) r2 = qR[n];
+          if (qL[n] > l1) { l2 = l1; l1 = qL[n]; li = (double)k; } else if (qL[n] < l1 && qL[n] > l2) l2 = qL[n];
+        }
       }
-    });
-  if (lead) { s_du[fl] = du0; s_duL[fl] = duL; s_duR[fl] = duR; }
-  __syncthreads();
-  const double a_du0 = s_du[fl], a_duL = s_duL[fl], a_duR = s_duR[fl];
+    }
+    double *pr = sA;   // 6 x [KL][NF] <= 2 * nkp * NF
+    const int o = kl * NF + fl, ps = KL * NF;
+    pr[o] = r1; pr[ps + o] = ri; pr[2 * ps + o] = r2; pr[3 * ps + o] = l1; pr[4 * ps + o] = li; pr[5 * ps + o] = l2;
+    __syncthreads();
+    double FR = BIG, kR = 1.0e9, FL = -BIG, kL = 1.0e9;
+#pragma unroll
+    for (int q = 0; q < KL; q++) {
+      const double v = pr[q * NF + fl], iv = pr[ps + q * NF + fl], w = pr[3 * ps + q * NF + fl], iw = pr[4 * ps + q * NF + fl];
+      if (v < FR || (v == FR && iv < kR)) { FR = v; kR = iv; }
+      if (w > FL || (w == FL && iw < kL)) { FL = w; kL = iw; }
+    }
+    double sR2 = BIG, sL2 = -BIG;
+#pragma unroll
+    for (int q = 0; q < KL; q++) {
+      const double v = pr[q * NF + fl], v2 = pr[2 * ps + q * NF + fl], w = pr[3 * ps + q * NF + fl], w2 = pr[5 * ps + q * NF + fl];
+      sR2 = dmin(sR2, (v > FR) ? v : v2);
+      sL2 = dmax(sL2, (w < FL) ? w : w2);
+    }
+    if (FR < x0R) sR2 = dmin(sR2, x0R); else { FR = x0R; kR = -1.0; }
+    if (FL > x0L) sL2 = dmax(sL2, x0L); else { FL = x0L; kL = -1.0; }
+    bool bad = false;
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      const int k = kl + KL * n;
+      if (k < nk && vl[n] > 0.0) {
+        const double uk = u_r[n], vrem = v_r[n], kd = (double)k;
+        if (kd > kR) bad = bad || ((uk + FR * vl[n] > -du_CFL * vrem) && (__double_as_longlong(qR[n]) != __double_as_longlong(FR)));
+        else if (kd == kR) bad = bad || !(uk + sR2 * vl[n] > -du_CFL * vrem);
+        if (kd > kL) bad = bad || ((uk + FL * vl[n] < du_CFL * vrem) && (__double_as_longlong(qL[n]) != __double_as_longlong(FL)));
+        else if (kd == kL) bad = bad || !(uk + sL2 * vl[n] < du_CFL * vrem);
+      }
+    }
+    a_duR = FR; a_duL = FL;
+    if (__ockl_wgred_or_i32(((bad && active) || E.force_walk) ? 1 : 0)) {   // barrier; work-group-uniform
+      double duR = x0R, duL = x0L;
+      recurrence4<KL, MAXL>(T, face,
+        [&](int n, double *o4) {
+          const double uk = u_r[n], vrem = v_r[n];
+          const double visc_rem_lim = dmax(vrem, vrl_floor);
+          o4[0] = uk; o4[1] = vrem;
+          o4[2] = -(uk + du_CFL * vrem) / visc_rem_lim;
+          o4[3] = -(uk - du_CFL * vrem) / visc_rem_lim;
+        },
+        [&](double uk, double vrem, double q_R, double q_L) {
+          const double visc_rem_lim = dmax(vrem, vrl_floor);
+          if (visc_rem_lim > 0.0) {
+            if (uk + duR * visc_rem_lim > -du_CFL * vrem) duR = q_R;
+            if (uk + duL * visc_rem_lim < du_CFL * vrem) duL = q_L;
+          }
+        });
+      if (lead) { s_duL[fl] = duL; s_duR[fl] = duR; }
+      __syncthreads();
+      a_duL = s_duL[fl]; a_duR = s_duR[fl];
+    }
+  }
+  const double duR = a_duR, duL = a_duL;
+  TICK(6);
   double FAmt_L = 0.0, FAmt_R = 0.0, FAmt_0 = 0.0, uhtot_L = 0.0, uhtot_R = 0.0;
-  // three trial velocities (:1330-1349), five column sums through the two transit arrays.  The evaluations at u_L
-  // and u_R are repeated rather than kept: their results would cost 6 registers per layer at the kernel's
-  // register-pressure peak.
+  // three trial velocities (:1330-1349), five column sums.  Every layer is evaluated once per trial velocity; the
+  // five results wait in registers until all lanes are done with the cell arrays, whose space then serves as the
+  // third to fifth transit array, and the face lanes run the five sums as independent chains of ONE walk.
+  double t_d0[MAXL], t_dL[MAXL], t_uL[MAXL], t_uR[MAXL], t_dR[MAXL];
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) {
+    const int k = kl + KL * n;
+    t_d0[n] = 0.0; t_dL[n] = 0.0; t_uL[n] = 0.0; t_uR[n] = 0.0; t_dR[n] = 0.0;
+    if (k < nk) {
+      double uh;
+      flux_lds(u_r[n] + a_du0 * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh, t_d0[n]);
+      flux_lds(u_r[n] + a_duL * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, t_uL[n], t_dL[n]);
+      flux_lds(u_r[n] + a_duR * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, t_uR[n], t_dR[n]);
+    }
+  }
+  __syncthreads();   // nobody reads the cell arrays any more
+  double *sX = smem;   // 3 x [nk][NF] <= 3 x [nk][NC]
+  const int strX = nk * NF;
 #pragma unroll
   for (int n = 0; n < MAXL; n++) {
     const int k = kl + KL * n;
     if (k < nk) {
-      double uh, d_0, d_L;
-      flux_lds(u_r[n] + a_du0 * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh, d_0);
-      flux_lds(u_r[n] + a_duL * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh, d_L);
-      sA[k * NF + fl] = d_0; sB[k * NF + fl] = d_L;
+      const int o = k * NF + fl;
+      sA[o] = t_d0[n]; sB[o] = t_dL[n]; sX[o] = t_uL[n]; sX[o + strX] = t_uR[n]; sX[o + 2 * strX] = t_dR[n];
     }
   }
   __syncthreads();
-  if (face) col_walk2(sA + fl, sB + fl, nk, [&](double a, double b) { FAmt_0 = FAmt_0 + a; FAmt_L = FAmt_L + b; });
-  __syncthreads();
-#pragma unroll
-  for (int n = 0; n < MAXL; n++) {
-    const int k = kl + KL * n;
-    if (k < nk) {
-      double uh_L, uh_R, dd;
-      flux_lds(u_r[n] + a_duL * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh_L, dd);
-      flux_lds(u_r[n] + a_duR * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh_R, dd);
-      sA[k * NF + fl] = uh_L; sB[k * NF + fl] = uh_R;
-    }
-  }
-  __syncthreads();
-  if (face) col_walk2(sA + fl, sB + fl, nk, [&](double a, double b) { uhtot_L = uhtot_L + a; uhtot_R = uhtot_R + b; });
-  __syncthreads();
-#pragma unroll
-  for (int n = 0; n < MAXL; n++) {
-    const int k = kl + KL * n;
-    if (k < nk) {
-      double uh, d_R;
-      flux_lds(u_r[n] + a_duR * v_r[n], dt, T.IdT_m, T.IdT_p, v_r[n], T.Lf, sL, sR, sC, k * NC + T.cm, k * NC + T.cp, uh, d_R);
-      sA[k * NF + fl] = d_R;
-    }
-  }
-  __syncthreads();
+  TICK(7);
   if (!face) return;
-  col_walk2(sA + fl, sA + fl, nk, [&](double a, double) { FAmt_R = FAmt_R + a; });
+  col_walk5(sA + fl, sB + fl, sX + fl, strX, nk, [&](double d0, double dL, double uL, double uR, double dR) {
+    FAmt_0 = FAmt_0 + d0; FAmt_L = FAmt_L + dL; uhtot_L = uhtot_L + uL; uhtot_R = uhtot_R + uR; FAmt_R = FAmt_R + dR;
+  });
 
   double FA_0 = FAmt_0, FA_avg = FAmt_0;
   if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
@@ -672,9 +777,17 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0, size_t lds_bytes)
 
 }  // namespace
 
+#ifdef MOM6X_MFL_TIMING
+extern "C" int mom6x_debug_mfl_timing(unsigned long long *out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mfl_t), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mfl_t), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
+
 size_t mass_flux_lds_bytes(int dir, int nk) {
   const int NC = dir ? 2 * NF : NF + 1;
-  const int nkp = std::max((nk + 1) & ~1, 32);   // >= the largest KL
+  const int nkp = std::max((nk + 1) & ~1, 48);   // the kernel's nkp (KL = 16)
   return sizeof(double) * ((size_t)nk * (size_t)(3 * NC) + (size_t)nkp * (size_t)(2 * NF));
 }
 
@@ -682,25 +795,15 @@ bool mass_flux_lds_usable(int nk) {
   return nk <= 128 && mass_flux_lds_bytes(1, nk) <= 156 * 1024;
 }
 
-// layer lanes per face: MOM6X_LDS_KL=16|32 overrides the default
-static int pick_kl(int nk) {
-  const char *e = getenv("MOM6X_LDS_KL");
-  if (e) return atoi(e) == 32 ? 32 : 16;
-  return 16;
-}
-
 int mass_flux_lds(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E0) {
   const int nk = c->d.nk;
   LdsArgs E = E0;
+  const char *env = getenv("MOM6X_MASSFLUX");
+  E.force_walk = (env && !strcmp(env, "lds_walk")) ? 1 : 0;
   E.i_base = A.a0 - (((A.a0 + c->d.ioff) % NF) + NF) % NF;   // (i_base + ioff) is a multiple of 16 doubles = 128 B
   const size_t bytes = mass_flux_lds_bytes(dir, nk);
-  const int KLr = pick_kl(nk);
-  const int maxl = (nk + KLr - 1) / KLr;
+  const int maxl = (nk + 15) / 16;   // 16 layer lanes per face (32 was measured slower at nk = 75)
 #define GO(D, K, M) return launch<D, K, M>(c, A, E, bytes)
-  if (KLr == 32) {
-    if (dir == 0) { if (maxl <= 1) GO(0, 32, 1); if (maxl <= 3) GO(0, 32, 3); GO(0, 32, 4); }
-    if (maxl <= 1) GO(1, 32, 1); if (maxl <= 3) GO(1, 32, 3); GO(1, 32, 4);
-  }
   if (dir == 0) { if (maxl <= 2) GO(0, 16, 2); if (maxl <= 5) GO(0, 16, 5); GO(0, 16, 8); }
   if (maxl <= 2) GO(1, 16, 2); if (maxl <= 5) GO(1, 16, 5); GO(1, 16, 8);
 #undef GO

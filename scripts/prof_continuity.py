@@ -22,6 +22,7 @@ dt = 900.0
 dyc.continuity_PPM(u, v, h, hp, uh, vh, dt)
 uhbt = (uh.sum(0) * (1.0 + 0.02 * synth_dev.smooth_field(d, dyc.device, 13))).contiguous()
 vhbt = (vh.sum(0) * (1.0 - 0.02 * synth_dev.smooth_field(d, dyc.device, 14))).contiguous()
+torch.cuda.synchronize()   # uhbt, vhbt are made on torch's stream, the dycore has its own
 modes = {
     "plain": dict(),
     "visc": dict(visc_rem_u=vru, visc_rem_v=vrv),
@@ -29,11 +30,25 @@ modes = {
     "adjust": dict(visc_rem_u=vru, visc_rem_v=vrv, uhbt=uhbt, vhbt=vhbt, u_cor=ucor, v_cor=vcor),
     "full": dict(visc_rem_u=vru, visc_rem_v=vrv, uhbt=uhbt, vhbt=vhbt, u_cor=ucor, v_cor=vcor, BT_cont=bt),
 }
-for path in ("lds", "legacy"):
+import ctypes
+timing = hasattr(dyc.lib, "mom6x_debug_mfl_timing")   # library built with -DMOM6X_MFL_TIMING
+PH = ["load+PPM", "bounds", "sweep0+sum", "adjust(uhbt)", "store+h_face", "adjust(du0)", "duL/duR rec", "3 trial sweeps",
+      "rec:produce0", "rec:barrier0", "rec:walk0", "rec:produce1", "rec:barrier1", "rec:walk1", "-", "-"]
+only = os.environ.get("PROF_MODES")   # e.g. PROF_MODES=full,adjust
+if only:
+    modes = {k: v for k, v in modes.items() if k in only.split(",")}
+for path in ("lds",) if (timing or only) else ("lds", "legacy"):
     os.environ["MOM6X_MASSFLUX"] = path
     for name, kw in modes.items():
         dyc.continuity_PPM(u, v, h, hp, uh, vh, dt, **kw); dyc.sync()
+        if timing:
+            buf = (ctypes.c_ulonglong * 32)(); dyc.lib.mom6x_debug_mfl_timing(buf, 1)
         prof_enable(dyc, True); prof_reset(dyc)
         dyc.continuity_PPM(u, v, h, hp, uh, vh, dt, **kw); dyc.sync()
         rep = prof_report(dyc); prof_enable(dyc, False)
+        if timing:
+            dyc.lib.mom6x_debug_mfl_timing(buf, 1)
+            for dr in (0, 1):
+                tot = float(sum(buf[dr * 16:dr * 16 + 8])) or 1.0
+                print("   phases dir", dr, " ".join(f"{PH[q]}={100 * buf[dr * 16 + q] / tot:.1f}%" for q in range(14)), f"total={tot:.3e} cyc")
         print(path, name, " ".join(f"{k}={v[1]:.2f}" for k, v in sorted(rep.items())), "sum=%.2f ms" % sum(v[1] for v in rep.values()), flush=True)

@@ -11,15 +11,16 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["lds", "legacy"])
+@pytest.fixture(autouse=True, params=["lds", "lds_walk", "legacy"])
 def massflux_path(request, monkeypatch):
-    """Every case runs on both device paths: the LDS-resident fused kernel (default) and the
-    thread-per-column kernels (MOM6X_MASSFLUX=legacy).  Both must equal the oracle bit for bit."""
+    """Every case runs on all device paths: the LDS-resident fused kernel (default), the same with the sequential
+    duL/duR recurrence forced (lds_walk: the fall-back of the parallel min + certificate) and the thread-per-column
+    kernels (MOM6X_MASSFLUX=legacy).  All must equal the oracle bit for bit."""
     monkeypatch.setenv("MOM6X_MASSFLUX", request.param)
     return request.param
 
 
-def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0, u_scale=1.0, bt_pert=0.05):
+def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0, u_scale=1.0, bt_pert=0.05, ties=False):
     import torch
     from mom6_amd.dycore import Dycore, BTContDev
     gg, d, M = cfg
@@ -34,6 +35,12 @@ def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0, u_scale=1.
     rng = np.random.default_rng(5)
     vr_u = np.clip(0.5 + 0.6 * synth.smooth_field(d, 11, nk=d.nk, ox=1.0, oy=0.5), 0.0, 1.0)
     vr_v = np.clip(0.5 + 0.6 * synth.smooth_field(d, 12, nk=d.nk, ox=0.5, oy=1.0), 0.0, 1.0)
+    if ties:   # depth-independent velocity and visc_rem over most of the column: the duL/duR quotients tie exactly
+        kt = max(d.nk - 2, 1)
+        u[:kt] = u[0]; v[:kt] = v[0]; vr_u[:kt] = vr_u[0]; vr_v[:kt] = vr_v[0]
+        vr_u[:, ::3, :] = 0.0; vr_v[:, :, ::4] = 0.0   # and columns without any viscous remnant
+        u = np.ascontiguousarray(u); v = np.ascontiguousarray(v)
+    vr_u = np.ascontiguousarray(vr_u); vr_v = np.ascontiguousarray(vr_v)
     # reference transports to perturb into uhbt/vhbt
     h0 = np.zeros_like(h); uh0 = np.zeros_like(h); vh0 = np.zeros_like(h)
     orc.continuity_PPM(d, M, GV, CS, first_direction, u, v, h, h0, uh0, vh0, dt)
@@ -101,6 +108,14 @@ def test_continuity_thin_layers_and_tc1_tolerances(orc):
 @pytest.mark.parametrize("flag", ["monotonic", "simple_2nd", "upwind_1st"])
 def test_continuity_scheme_flags(orc, flag):
     _run_case(orc, H.benchmark_small(), 0, "full", cs_mod={flag: 1})
+
+
+@pytest.mark.parametrize("mode", ["bt_cont", "full"])
+@pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
+def test_continuity_tied_quotients(orc, mode, cfg):
+    """Barotropic columns: the candidates of the duL / duR recurrences of set_*_BT_cont tie exactly, the case in
+    which the parallel min must reproduce the sequential loop's value (and zero visc_rem columns skip it)."""
+    _run_case(orc, getattr(H, cfg)(nk=6), 0, mode, ties=True)
 
 
 @pytest.mark.parametrize("nk", [20, 75, 90])
