@@ -666,6 +666,9 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     }
     a_duR = FR; a_duL = FL;
     if (__ockl_wgred_or_i32(((bad && active) || E.force_walk) ? 1 : 0)) {   // barrier; work-group-uniform
+#ifdef MOM6X_MFL_TIMING
+      if (threadIdx.x == 0) atomicAdd(&g_mfl_t[DIR][15], 1ull);
+#endif
       double duR = x0R, duL = x0L;
       recurrence4<KL, MAXL>(T, face,
         [&](int n, double *o4) {

@@ -276,15 +276,19 @@ k_hv_del2(Dm d, const double *__restrict__ G, const double *__restrict__ P, cons
   }
 }
 
-// h_u, h_v :767-781
+// h_u, h_v :767-781 from the thicknesses and T-point masks of the two cells
+__device__ __forceinline__ double hface2(double ha, double hb, double ma, double mb, int land_mask) {
+  if (land_mask) return 0.5 * (ma * ha + mb * hb);
+  return 0.5 * (ha + hb);
+}
 __device__ __forceinline__ double hface(const double *__restrict__ h, const double *__restrict__ mT, size_t c, size_t c2, int s,
                                         int land_mask) {
-  if (land_mask) return 0.5 * (mT[c2] * h[c] + mT[c2 + s] * h[c + s]);
-  return 0.5 * (h[c] + h[c + s]);
+  return hface2(h[c], h[c + s], mT[c2], mT[c2 + s], land_mask);
 }
 
 // stage 3: str_xx at h points (Isq..Ieq+1, Jsq..Jeq+1) :1112-1448, :1893 and str_xy at q points (is-1..Ieq, js-1..Jeq)
-// :1483-1826, :1896-1906 -- both already multiplied by the thickness and reduction factors.
+// :1483-1826, :1896-1906 -- both already multiplied by the thickness and reduction factors.  Column walk: the ~40
+// coefficient values of the two points stay in registers over KCHUNK layers.
 __global__ void __launch_bounds__(256)
 k_hv_stress(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom6x_hor_visc_params CS,
             const double *__restrict__ h, const double *__restrict__ sh_xx, const double *__restrict__ sh_xy,
@@ -295,134 +299,164 @@ k_hv_stress(Dm d, const double *__restrict__ G, const double *__restrict__ P, mo
   if (i < -1 || i > d.ni || j > d.nj) return;
   const int st = d.pitch;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
-  const int k = blockIdx.z;
-  const size_t c = x + (size_t)k * slab;
-  const double *mT = MG(mask2dT), *IdyCu = MG(IdyCu), *IdxCv = MG(IdxCv), *IdxCu = MG(IdxCu), *IdyCv = MG(IdyCv);
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
   const bool smag = CS.Smagorinsky_Kh || CS.Smagorinsky_Ah, better = CS.better_bound_Ah || CS.better_bound_Kh;
   const bool legacy_bound = CS.Smagorinsky_Kh && (CS.bound_Kh && !CS.better_bound_Kh);
+  const bool lap = CS.Laplacian, bih = CS.biharmonic;
+  const bool do_q = (i <= d.ni - 1 && j <= d.nj - 1);
   const double h_neglect3 = h_neglect * h_neglect * h_neglect;
   const int lm = CS.use_land_mask;
-  {   // ---- h point (always inside Isq..Ieq+1, Jsq..Jeq+1)
-    double Shear = 0., hrat = 0., vbr = 0., sxx_out;
-    const double sxx = sh_xx[c];
-    if (smag) {
-      const double sh_xx_sq = sxx * sxx;
-      const double a = sh_xy[c - 1 - st], b = sh_xy[c], e = sh_xy[c - 1], f = sh_xy[c - st];
-      const double sh_xy_sq = 0.25 * (((a * a) + (b * b)) + ((e * e) + (f * f)));
-      Shear = sqrt(sh_xx_sq + sh_xy_sq);
+  const double *mT = MG(mask2dT);
+  // T-point masks of the 3 x 3 block the two points touch (only with the land mask)
+  double m00 = 1., mE = 1., mW = 1., mN = 1., mS = 1., mNE = 1.;
+  if (lm) { m00 = mT[x]; mE = mT[x + 1]; mW = mT[x - 1]; mN = mT[x + st]; mS = mT[x - st]; mNE = mT[x + st + 1]; }
+  // h point
+  const double red_xx = PLN(HV_red_xx)[x];
+  const double Kh_bg_xx = lap ? PLN(HV_Kh_bg_xx)[x] : 0., Kh_Max_xx = lap ? PLN(HV_Kh_Max_xx)[x] : 0.;
+  const double Lap2_xx = CS.Smagorinsky_Kh ? PLN(HV_Lap2_xx)[x] : 0.;
+  const double Ah_bg_xx = bih ? PLN(HV_Ah_bg_xx)[x] : 0., Ah_Max_xx = bih ? PLN(HV_Ah_Max_xx)[x] : 0.;
+  const double Bih_xx = CS.Smagorinsky_Ah ? PLN(HV_Bih_xx)[x] : 0., Bih2_xx = CS.bound_Coriolis ? PLN(HV_Bih2_xx)[x] : 0.;
+  const double IdyCu0 = bih ? MG(IdyCu)[x] : 0., IdyCuW = bih ? MG(IdyCu)[x - 1] : 0.;
+  const double IdxCv0 = bih ? MG(IdxCv)[x] : 0., IdxCvS = bih ? MG(IdxCv)[x - st] : 0.;
+  const double DY_dxT = bih ? PLN(HV_DY_dxT)[x] : 0., DX_dyT = bih ? PLN(HV_DX_dyT)[x] : 0.;
+  // q point
+  double red_xy = 0., Kh_bg_xy = 0., Kh_Max_xy = 0., Lap2_xy = 0., Ah_bg_xy = 0., Ah_Max_xy = 0., Bih_xy = 0., Bih2_xy = 0.;
+  double DY_dxBu = 0., DX_dyBu = 0., IdyCvE = 0., IdyCv0 = 0., IdxCuN = 0., IdxCu0 = 0., mBu = 0., mu0 = 0., mu1 = 0., mv0 = 0., mv1 = 0.;
+  if (do_q) {
+    red_xy = PLN(HV_red_xy)[x]; mBu = MG(mask2dBu)[x];
+    if (lap) { Kh_bg_xy = PLN(HV_Kh_bg_xy)[x]; Kh_Max_xy = PLN(HV_Kh_Max_xy)[x]; }
+    if (CS.Smagorinsky_Kh) Lap2_xy = PLN(HV_Lap2_xy)[x];
+    if (bih) {
+      Ah_bg_xy = PLN(HV_Ah_bg_xy)[x]; Ah_Max_xy = PLN(HV_Ah_Max_xy)[x];
+      DY_dxBu = PLN(HV_DY_dxBu)[x]; DX_dyBu = PLN(HV_DX_dyBu)[x];
+      IdyCvE = MG(IdyCv)[x + 1]; IdyCv0 = MG(IdyCv)[x]; IdxCuN = MG(IdxCu)[x + st]; IdxCu0 = MG(IdxCu)[x];
     }
-    const double hk = h[c];
-    if (better) {
-      const double h_min = dmin4(hface(h, mT, c, x, 1, lm), hface(h, mT, c - 1, x - 1, 1, lm), hface(h, mT, c, x, st, lm),
-                                 hface(h, mT, c - st, x - st, st, lm));
-      hrat = dmin(1.0, h_min / (hk + h_neglect));
-    }
-    if (CS.Laplacian) {
-      double K = PLN(HV_Kh_bg_xx)[x];
-      if (CS.add_LES_viscosity) { if (CS.Smagorinsky_Kh) K = K + PLN(HV_Lap2_xx)[x] * Shear; }
-      else { if (CS.Smagorinsky_Kh) K = dmax(K, PLN(HV_Lap2_xx)[x] * Shear); }
-      if (legacy_bound) K = dmin(K, PLN(HV_Kh_Max_xx)[x]);
-      K = dmax(K, CS.Kh_bg_min);
-      if (CS.better_bound_Kh && CS.better_bound_Ah) {
-        vbr = 1.0;
-        const double Kh_max_here = hrat * PLN(HV_Kh_Max_xx)[x];
-        if (K >= Kh_max_here) { vbr = 0.0; K = Kh_max_here; }
-        else if ((K > 0.0) || (CS.backscatter_underbound && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
-      } else if (CS.better_bound_Kh) {
-        K = dmin(K, hrat * PLN(HV_Kh_Max_xx)[x]);
-      }
-      sxx_out = -K * sxx;
-    } else sxx_out = 0.0;
-    if (CS.biharmonic) {
-      double A = PLN(HV_Ah_bg_xx)[x];
-      if (CS.Smagorinsky_Ah) {
-        double AhSm;
-        if (CS.bound_Coriolis) AhSm = Shear * (PLN(HV_Bih_xx)[x] + PLN(HV_Bih2_xx)[x] * Shear);
-        else AhSm = PLN(HV_Bih_xx)[x] * Shear;
-        A = dmax(A, AhSm);
-        if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, PLN(HV_Ah_Max_xx)[x]);
-      }
-      if (CS.better_bound_Ah) {
-        if (CS.better_bound_Kh) A = dmin(A, vbr * hrat * PLN(HV_Ah_Max_xx)[x]);
-        else A = dmin(A, hrat * PLN(HV_Ah_Max_xx)[x]);
-      }
-      const double d_del2u = (IdyCu[x] * Del2u[c]) - (IdyCu[x - 1] * Del2u[c - 1]);
-      const double d_del2v = (IdxCv[x] * Del2v[c]) - (IdxCv[x - st] * Del2v[c - st]);
-      const double d_str = A * ((PLN(HV_DY_dxT)[x] * d_del2u) - (PLN(HV_DX_dyT)[x] * d_del2v));
-      sxx_out = sxx_out + d_str;
-    }
-    str_xx[c] = sxx_out * (hk * PLN(HV_red_xx)[x]);
+    if (CS.Smagorinsky_Ah) Bih_xy = PLN(HV_Bih_xy)[x];
+    if (CS.bound_Coriolis) Bih2_xy = PLN(HV_Bih2_xy)[x];
+    if (CS.no_slip) { mu0 = MG(mask2dCu)[x]; mu1 = MG(mask2dCu)[x + st]; mv0 = MG(mask2dCv)[x]; mv1 = MG(mask2dCv)[x + 1]; }
   }
-  if (i <= d.ni - 1 && j <= d.nj - 1) {   // ---- q point (is-1..Ieq, js-1..Jeq)
-    double Shear = 0., hrat = 0., vbr = 0., sxy_out;
-    const double sxy = sh_xy[c];
-    if (smag) {
-      const double sh_xy_sq = sxy * sxy;
-      const double a = sh_xx[c], b = sh_xx[c + 1 + st], e = sh_xx[c + st], f = sh_xx[c + 1];
-      const double sh_xx_sq = 0.25 * (((a * a) + (b * b)) + ((e * e) + (f * f)));
-      Shear = sqrt(sh_xy_sq + sh_xx_sq);
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double h00 = h[c], hE = h[c + 1], hN = h[c + st];
+    // face thicknesses shared by the two points: h_u(I,j), h_v(i,J)
+    const double hu0 = hface2(h00, hE, m00, mE, lm), hv0 = hface2(h00, hN, m00, mN, lm);
+    const double sxx = sh_xx[c], sxy = sh_xy[c];
+    {   // ---- h point (always inside Isq..Ieq+1, Jsq..Jeq+1)
+      double Shear = 0., hrat = 0., vbr = 0., sxx_out;
+      if (smag) {
+        const double sh_xx_sq = sxx * sxx;
+        const double a = sh_xy[c - 1 - st], e = sh_xy[c - 1], f = sh_xy[c - st];
+        const double sh_xy_sq = 0.25 * (((a * a) + (sxy * sxy)) + ((e * e) + (f * f)));
+        Shear = sqrt(sh_xx_sq + sh_xy_sq);
+      }
+      if (better) {
+        const double h_min = dmin4(hu0, hface2(h[c - 1], h00, mW, m00, lm), hv0, hface2(h[c - st], h00, mS, m00, lm));
+        hrat = dmin(1.0, h_min / (h00 + h_neglect));
+      }
+      if (lap) {
+        double K = Kh_bg_xx;
+        if (CS.add_LES_viscosity) { if (CS.Smagorinsky_Kh) K = K + Lap2_xx * Shear; }
+        else { if (CS.Smagorinsky_Kh) K = dmax(K, Lap2_xx * Shear); }
+        if (legacy_bound) K = dmin(K, Kh_Max_xx);
+        K = dmax(K, CS.Kh_bg_min);
+        if (CS.better_bound_Kh && CS.better_bound_Ah) {
+          vbr = 1.0;
+          const double Kh_max_here = hrat * Kh_Max_xx;
+          if (K >= Kh_max_here) { vbr = 0.0; K = Kh_max_here; }
+          else if ((K > 0.0) || (CS.backscatter_underbound && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
+        } else if (CS.better_bound_Kh) {
+          K = dmin(K, hrat * Kh_Max_xx);
+        }
+        sxx_out = -K * sxx;
+      } else sxx_out = 0.0;
+      if (bih) {
+        double A = Ah_bg_xx;
+        if (CS.Smagorinsky_Ah) {
+          double AhSm;
+          if (CS.bound_Coriolis) AhSm = Shear * (Bih_xx + Bih2_xx * Shear);
+          else AhSm = Bih_xx * Shear;
+          A = dmax(A, AhSm);
+          if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, Ah_Max_xx);
+        }
+        if (CS.better_bound_Ah) {
+          if (CS.better_bound_Kh) A = dmin(A, vbr * hrat * Ah_Max_xx);
+          else A = dmin(A, hrat * Ah_Max_xx);
+        }
+        const double d_del2u = (IdyCu0 * Del2u[c]) - (IdyCuW * Del2u[c - 1]);
+        const double d_del2v = (IdxCv0 * Del2v[c]) - (IdxCvS * Del2v[c - st]);
+        const double d_str = A * ((DY_dxT * d_del2u) - (DX_dyT * d_del2v));
+        sxx_out = sxx_out + d_str;
+      }
+      str_xx[c] = sxx_out * (h00 * red_xx);
     }
-    const double hu0 = hface(h, mT, c, x, 1, lm), hu1 = hface(h, mT, c + st, x + st, 1, lm);
-    const double hv0 = hface(h, mT, c, x, st, lm), hv1 = hface(h, mT, c + 1, x + 1, st, lm);
-    const double h2uq = 4.0 * (hu0 * hu1), h2vq = 4.0 * (hv0 * hv1);
-    double hq = (2.0 * (h2uq * h2vq)) / (h_neglect3 + (h2uq + h2vq) * ((hu0 + hu1) + (hv0 + hv1)));
-    if (better) {
-      const double h_min = dmin4(hu0, hu1, hv0, hv1);
-      hrat = dmin(1.0, h_min / (hq + h_neglect));
-    }
-    const double mBu = MG(mask2dBu)[x];
-    if (CS.no_slip && (mBu < 0.5)) {
-      const double mu0 = MG(mask2dCu)[x], mu1 = MG(mask2dCu)[x + st], mv0 = MG(mask2dCv)[x], mv1 = MG(mask2dCv)[x + 1];
-      if ((mu0 + mu1) + (mv0 + mv1) > 0.0) {
-        const double hu = mu0 * hu0 + mu1 * hu1;
-        const double hv = mv0 * hv0 + mv1 * hv1;
-        if ((mu0 + mu1) * (mv0 + mv1) == 0.0) {
-          hq = hu + hv;
-          hrat = 1.0;
-        } else {
-          hq = 2.0 * (hu * hv) / ((hu + hv) + h_neglect);
-          hrat = dmin(1.0, dmin(hu, hv) / (hq + h_neglect));
+    if (do_q) {   // ---- q point (is-1..Ieq, js-1..Jeq)
+      double Shear = 0., hrat = 0., vbr = 0., sxy_out;
+      if (smag) {
+        const double sh_xy_sq = sxy * sxy;
+        const double b = sh_xx[c + 1 + st], e = sh_xx[c + st], f = sh_xx[c + 1];
+        const double sh_xx_sq = 0.25 * (((sxx * sxx) + (b * b)) + ((e * e) + (f * f)));
+        Shear = sqrt(sh_xy_sq + sh_xx_sq);
+      }
+      const double hNE = h[c + st + 1];
+      const double hu1 = hface2(hN, hNE, mN, mNE, lm), hv1 = hface2(hE, hNE, mE, mNE, lm);
+      const double h2uq = 4.0 * (hu0 * hu1), h2vq = 4.0 * (hv0 * hv1);
+      double hq = (2.0 * (h2uq * h2vq)) / (h_neglect3 + (h2uq + h2vq) * ((hu0 + hu1) + (hv0 + hv1)));
+      if (better) {
+        const double h_min = dmin4(hu0, hu1, hv0, hv1);
+        hrat = dmin(1.0, h_min / (hq + h_neglect));
+      }
+      if (CS.no_slip && (mBu < 0.5)) {
+        if ((mu0 + mu1) + (mv0 + mv1) > 0.0) {
+          const double hu = mu0 * hu0 + mu1 * hu1;
+          const double hv = mv0 * hv0 + mv1 * hv1;
+          if ((mu0 + mu1) * (mv0 + mv1) == 0.0) {
+            hq = hu + hv;
+            hrat = 1.0;
+          } else {
+            hq = 2.0 * (hu * hv) / ((hu + hv) + h_neglect);
+            hrat = dmin(1.0, dmin(hu, hv) / (hq + h_neglect));
+          }
         }
       }
+      if (lap) {
+        double K = Kh_bg_xy;
+        if (CS.Smagorinsky_Kh) {
+          if (CS.add_LES_viscosity) K = K + Lap2_xy * Shear;
+          else K = dmax(K, Lap2_xy * Shear);
+        }
+        if (legacy_bound) K = dmin(K, Kh_Max_xy);
+        K = dmax(K, CS.Kh_bg_min);
+        if (CS.better_bound_Kh && CS.better_bound_Ah) {
+          vbr = 1.0;
+          const double Kh_max_here = hrat * Kh_Max_xy;
+          if (K >= Kh_max_here) { vbr = 0.0; K = Kh_max_here; }
+          else if ((K > 0.0) || (CS.backscatter_underbound && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
+        } else if (CS.better_bound_Kh) {
+          K = dmin(K, hrat * Kh_Max_xy);
+        }
+        sxy_out = -K * sxy;
+      } else sxy_out = 0.;
+      if (bih) {
+        double A = Ah_bg_xy;
+        if (CS.Smagorinsky_Ah) {
+          double AhSm;
+          if (CS.bound_Coriolis) AhSm = Shear * (Bih_xy + Bih2_xy * Shear);
+          else AhSm = Bih_xy * Shear;
+          A = dmax(A, AhSm);
+          if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, Ah_Max_xy);
+        }
+        if (CS.better_bound_Ah) {
+          if (CS.better_bound_Kh) A = dmin(A, vbr * hrat * Ah_Max_xy);
+          else A = dmin(A, hrat * Ah_Max_xy);
+        }
+        const double dDel2vdx = DY_dxBu * ((Del2v[c + 1] * IdyCvE) - (Del2v[c] * IdyCv0));
+        const double dDel2udy = DX_dyBu * ((Del2u[c + st] * IdxCuN) - (Del2u[c] * IdxCu0));
+        const double d_str = A * (dDel2vdx + dDel2udy);
+        sxy_out = sxy_out + d_str;
+      }
+      if (CS.no_slip) str_xy[c] = sxy_out * (hq * red_xy);
+      else str_xy[c] = sxy_out * (hq * mBu * red_xy);
     }
-    if (CS.Laplacian) {
-      double K = PLN(HV_Kh_bg_xy)[x];
-      if (CS.Smagorinsky_Kh) {
-        if (CS.add_LES_viscosity) K = K + PLN(HV_Lap2_xy)[x] * Shear;
-        else K = dmax(K, PLN(HV_Lap2_xy)[x] * Shear);
-      }
-      if (legacy_bound) K = dmin(K, PLN(HV_Kh_Max_xy)[x]);
-      K = dmax(K, CS.Kh_bg_min);
-      if (CS.better_bound_Kh && CS.better_bound_Ah) {
-        vbr = 1.0;
-        const double Kh_max_here = hrat * PLN(HV_Kh_Max_xy)[x];
-        if (K >= Kh_max_here) { vbr = 0.0; K = Kh_max_here; }
-        else if ((K > 0.0) || (CS.backscatter_underbound && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
-      } else if (CS.better_bound_Kh) {
-        K = dmin(K, hrat * PLN(HV_Kh_Max_xy)[x]);
-      }
-      sxy_out = -K * sxy;
-    } else sxy_out = 0.;
-    if (CS.biharmonic) {
-      double A = PLN(HV_Ah_bg_xy)[x];
-      if (CS.Smagorinsky_Ah) {
-        double AhSm;
-        if (CS.bound_Coriolis) AhSm = Shear * (PLN(HV_Bih_xy)[x] + PLN(HV_Bih2_xy)[x] * Shear);
-        else AhSm = PLN(HV_Bih_xy)[x] * Shear;
-        A = dmax(A, AhSm);
-        if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, PLN(HV_Ah_Max_xy)[x]);
-      }
-      if (CS.better_bound_Ah) {
-        if (CS.better_bound_Kh) A = dmin(A, vbr * hrat * PLN(HV_Ah_Max_xy)[x]);
-        else A = dmin(A, hrat * PLN(HV_Ah_Max_xy)[x]);
-      }
-      const double dDel2vdx = PLN(HV_DY_dxBu)[x] * ((Del2v[c + 1] * IdyCv[x + 1]) - (Del2v[c] * IdyCv[x]));
-      const double dDel2udy = PLN(HV_DX_dyBu)[x] * ((Del2u[c + st] * IdxCu[x + st]) - (Del2u[c] * IdxCu[x]));
-      const double d_str = A * (dDel2vdx + dDel2udy);
-      sxy_out = sxy_out + d_str;
-    }
-    if (CS.no_slip) str_xy[c] = sxy_out * (hq * PLN(HV_red_xy)[x]);
-    else str_xy[c] = sxy_out * (hq * mBu * PLN(HV_red_xy)[x]);
   }
 }
 
@@ -512,7 +546,7 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
   if (CS.biharmonic)
     KLAUNCH(c, "k_hv_del2", k_hv_del2, grid3(nxa(d.ni + 3, -2), d.nj + 3, nchunks(d.nk), b), b, d, c->G, P, (const double *)sh_xx,
             (const double *)sh_xy, Del2u, Del2v);
-  KLAUNCH(c, "k_hv_stress", k_hv_stress, grid3(nxa(d.ni + 2, -1), d.nj + 2, d.nk, b), b, d, c->G, P, CS, h, (const double *)sh_xx,
+  KLAUNCH(c, "k_hv_stress", k_hv_stress, grid3(nxa(d.ni + 2, -1), d.nj + 2, nchunks(d.nk), b), b, d, c->G, P, CS, h, (const double *)sh_xx,
           (const double *)sh_xy, (const double *)Del2u, (const double *)Del2v, str_xx, str_xy, c->GV.H_subroundoff);
   KLAUNCH(c, "k_hv_accel", k_hv_accel, grid3(nxa(d.ni + 1, -1), d.nj + 1, nchunks(d.nk), b), b, d, c->G, P, h, (const double *)str_xx,
           (const double *)str_xy, diffu, diffv, CS.use_land_mask, c->GV.H_subroundoff);

@@ -2,13 +2,10 @@
 # Instruction mix of k_mass_flux_lds in one mode (dev tool): PROF_MODES=full bash scripts/pmc_massflux.sh
 ROOT=$(pwd); export TMPDIR=/tmp; OUT=$ROOT/gpurun_out; mkdir -p $OUT; cd /tmp
 export PROF_MODES=${PROF_MODES:-full}
-rocprofv3 --list-avail > $OUT/avail.txt 2>&1
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" \
-           "SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU" \
-           "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"; do
+for set in ${PMC_SETS:-"SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD"}; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_mf$i -o mf -- env PYTHONPATH=$ROOT python $ROOT/scripts/prof_continuity.py > $OUT/pmc_mf$i.log 2>&1
+  timeout 100 rocprofv3 --pmc ${set//,/ } --output-format csv -d $OUT/pmc_mf$i -o mf -- env PYTHONPATH=$ROOT python $ROOT/scripts/prof_continuity.py > $OUT/pmc_mf$i.log 2>&1
 done
 cd $ROOT
 python - <<'PY'

@@ -33,7 +33,7 @@ modes = {
 import ctypes
 timing = hasattr(dyc.lib, "mom6x_debug_mfl_timing")   # library built with -DMOM6X_MFL_TIMING
 PH = ["load+PPM", "bounds", "sweep0+sum", "adjust(uhbt)", "store+h_face", "adjust(du0)", "duL/duR rec", "3 trial sweeps",
-      "rec:produce0", "rec:barrier0", "rec:walk0", "rec:produce1", "rec:barrier1", "rec:walk1", "-", "-"]
+      "-", "-", "-", "-", "-", "-", "-", "-"]
 only = os.environ.get("PROF_MODES")   # e.g. PROF_MODES=full,adjust
 if only:
     modes = {k: v for k, v in modes.items() if k in only.split(",")}
@@ -50,5 +50,5 @@ for path in ("lds",) if (timing or only) else ("lds", "legacy"):
             dyc.lib.mom6x_debug_mfl_timing(buf, 1)
             for dr in (0, 1):
                 tot = float(sum(buf[dr * 16:dr * 16 + 8])) or 1.0
-                print("   phases dir", dr, " ".join(f"{PH[q]}={100 * buf[dr * 16 + q] / tot:.1f}%" for q in range(14)), f"total={tot:.3e} cyc")
+                print("   phases dir", dr, " ".join(f"{PH[q]}={100 * buf[dr * 16 + q] / tot:.1f}%" for q in range(8)), f"total={tot:.3e} cyc", f"walk fall-backs={buf[dr * 16 + 15]}")
         print(path, name, " ".join(f"{k}={v[1]:.2f}" for k, v in sorted(rep.items())), "sum=%.2f ms" % sum(v[1] for v in rep.values()), flush=True)
