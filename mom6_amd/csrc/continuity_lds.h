@@ -8,6 +8,7 @@ struct LdsArgs {
   int monotonic;       // PPM_limit_CW84 instead of PPM_limit_pos
   int marginal;        // BT_cont%h_u from the marginal (not the average) face thickness
   double *h_face;      // BT_cont%h_u | h_v (3-D) or null
+  int gx, gy, rows;    // tile grid and tile rows per XCD band (set by mass_flux_lds)
   int i_base;          // first i of the tile grid (set by mass_flux_lds: 128-byte aligned, <= a0)
   int force_walk;      // tests (MOM6X_MASSFLUX=lds_walk): take the sequential duL/duR recurrence even when the certificate holds
   int *retry;          // per tile: the cheap-bounds pass asks for the exact pass (set by mass_flux_lds), or null

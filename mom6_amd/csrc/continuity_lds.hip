@@ -290,7 +290,15 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   // The LAZY kernel runs flux_adjust with cheap bounds of the CFL limits; a work-group whose Newton steps come within
   // reach of them marks its tile in E.retry and stops.  The exact kernel (second launch, same grid) only works on the
   // marked tiles, with the limits from the k-recurrence, and rewrites all of the tile's outputs.
-  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  // Tile <-> block id: block b is observed to run on XCD b % 8, each XCD with its own L2.  Every XCD gets a band of
+  // E.rows tile rows; inside the band the tiles follow each other along i for the zonal kernel (neighbours share the
+  // halo cells' cache lines) and along j for the meridional one (neighbours share 5 of their 6 rows of h), so the
+  // re-reads hit that XCD's L2 instead of going to the fabric once per tile.  Placement is a speed matter only.
+  const int tile = blockIdx.x;
+  const int band = tile & 7, slot = tile >> 3;
+  const int bx = DIR ? slot / E.rows : slot % E.gx;
+  const int by = band * E.rows + (DIR ? slot % E.rows : slot / E.gx);
+  if (by >= E.gy) return;
   if (!LAZY && E.retry && !E.retry[tile]) return;
   TICK_INIT;
   extern __shared__ double smem[];
@@ -303,10 +311,10 @@ k_mass_flux_lds(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   const int tid = threadIdx.x, fl = tid % NF, kl = tid / NF;
   // the wavefront that carries the sequential walks rotates with the tile so that the walks of the
   // work-groups sharing a CU do not all queue on the same SIMD
-  const int kl_face = ((blockIdx.x + blockIdx.y) % (KL / 4)) * 4;
+  const int kl_face = ((bx + by) % (KL / 4)) * 4;
   // tiles start on 128-byte lines of the pitched rows (E.i_base <= A.a0): every row segment a work-group
   // reads or writes is then exactly one cache line instead of two half lines shared with its neighbours
-  const int i0 = E.i_base + blockIdx.x * NF, j = A.b0 + blockIdx.y;
+  const int i0 = E.i_base + bx * NF, j = A.b0 + by;
   const int i = i0 + fl;
   const bool active = (i >= A.a0 && i <= A.a1);
   const bool lead = (kl == kl_face);
@@ -747,12 +755,14 @@ template <int DIR, int KL, int MAXL>
 int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0, size_t lds_bytes) {
   const Dm d = c->d;
   LdsArgs E = E0;
-  const dim3 grid((A.a1 - E.i_base + NF) / NF, A.b1 - A.b0 + 1, 1);
+  E.gx = (A.a1 - E.i_base + NF) / NF; E.gy = A.b1 - A.b0 + 1;
+  E.rows = (E.gy + 7) / 8;
+  const dim3 grid(8 * E.gx * E.rows, 1, 1);
   const bool need_adjust = (A.uhbt != nullptr) || A.set_BT_cont;
   const bool two_pass = need_adjust && (A.visc_rem != nullptr);   // only then are the cheap bounds not the limits themselves
   E.retry = nullptr;
   if (two_pass) {
-    const size_t ntile = (size_t)grid.x * grid.y;
+    const size_t ntile = (size_t)grid.x;
     if (c->retry_cap < ntile) {
       HIPCHK(hipStreamSynchronize(c->stream));
       (void)hipFree(c->retry);
@@ -766,6 +776,17 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0, size_t lds_bytes)
   auto k_exact = k_mass_flux_lds<DIR, KL, MAXL, false>;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lazy), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+#ifdef MOM6X_MFL_TIMING
+  {
+    static bool once[2] = {false, false};
+    if (!once[DIR]) {
+      once[DIR] = true;
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lazy, NF * KL, lds_bytes);
+      fprintf(stderr, "[mfl] dir %d: %zu B dynamic LDS, occupancy %d work-groups per CU\n", DIR, lds_bytes, nb);
+    }
+  }
+#endif
   if (c->prof_on) prof_begin(c, DIR ? "k_mass_flux_lds<1>" : "k_mass_flux_lds<0>");
   hipLaunchKernelGGL(k_lazy, grid, dim3(NF * KL, 1, 1), lds_bytes, c->stream, d, c->G, A, E);
   if (c->prof_on) prof_end(c);
