@@ -11,6 +11,7 @@ module mom6x_c_api
   public :: mom6x_dims, mom6x_vgrid, mom6x_continuity_params, mom6x_BT_cont, mom6x_barotropic_params
   public :: mom6x_coriolis_params, mom6x_pgf_params, mom6x_eos_params, mom6x_rk2_params, mom6x_rk2_hooks
   public :: mom6x_PressureForce_set_tv, mom6x_vertvisc_params, mom6x_vertvisc_init, mom6x_vertvisc_set_visc, mom6x_vertvisc_coef
+  public :: mom6x_hor_visc_params, mom6x_hor_visc_init, mom6x_horizontal_viscosity
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
   public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
   public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc
@@ -71,6 +72,23 @@ module mom6x_c_api
     real(c_double) :: Kv, Kvml_invZ2, Hmix, Hbbl, harm_BL_val, Kv_extra_bbl
     integer(c_int) :: harmonic_visc, bottomdraglaw, answer_date
   end type mom6x_vertvisc_params
+
+  type, bind(C) :: mom6x_hor_visc_params   !< hor_visc_CS (MOM_hor_visc.F90:36-259), the members the device path reads
+    integer(c_int) :: Laplacian, biharmonic
+    real(c_double) :: Kh, Kh_bg_min, Kh_vel_scale
+    integer(c_int) :: Smagorinsky_Kh
+    real(c_double) :: Smag_Lap_const
+    integer(c_int) :: bound_Kh, better_bound_Kh, add_LES_viscosity
+    real(c_double) :: Ah, Ah_vel_scale, Ah_time_scale
+    integer(c_int) :: Smagorinsky_Ah
+    real(c_double) :: Smag_bi_const
+    integer(c_int) :: bound_Ah, better_bound_Ah, bound_Coriolis
+    real(c_double) :: bound_Cor_vel
+    integer(c_int) :: use_land_mask
+    real(c_double) :: bound_coef
+    integer(c_int) :: no_slip, backscatter_underbound
+    real(c_double) :: dt
+  end type mom6x_hor_visc_params
 
   type, bind(C) :: mom6x_eos_params        !< tv%eqn_of_state (MOM_EOS.F90:99-150) + EOS-only switches of PressureForce_FV_CS
     integer(c_int) :: form                 !< 1 EOS_LINEAR, 2 EOS_WRIGHT
@@ -207,6 +225,16 @@ module mom6x_c_api
         bind(C, name="mom6x_vertvisc_set_visc")
       import :: c_ptr, c_int
       type(c_ptr), value :: ctx, Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v, Kv_shear, Ray_u, Ray_v
+    end function
+    !> hor_visc_init (MOM_hor_visc.F90:2322): the 2-D viscosity planes are made on the device from the metric block
+    integer(c_int) function mom6x_hor_visc_init(ctx, p) bind(C, name="mom6x_hor_visc_init")
+      import :: c_ptr, c_int, mom6x_hor_visc_params
+      type(c_ptr), value :: ctx ; type(mom6x_hor_visc_params), intent(in) :: p
+    end function
+    !> horizontal_viscosity(u, v, h, uh, vh, diffu, diffv, ...) (MOM_hor_visc.F90:266); uh, vh only feed FrictWork
+    integer(c_int) function mom6x_horizontal_viscosity(ctx, u, v, h, diffu, diffv) bind(C, name="mom6x_horizontal_viscosity")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, u, v, h, diffu, diffv
     end function
     integer(c_int) function mom6x_vertvisc_coef(ctx, u, v, h, dt) bind(C, name="mom6x_vertvisc_coef")
       import :: c_ptr, c_int, c_double

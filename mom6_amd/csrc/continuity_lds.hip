@@ -30,7 +30,7 @@ namespace {
 
 constexpr int NF = 16;        // faces along i per work-group (the coalesced axis)
 #ifndef MOM6X_X_WG
-#define MOM6X_X_WG 3   // work-groups per CU the zonal kernel is compiled for (LDS allows 3 at nk = 75)
+#define MOM6X_X_WG 2   // work-groups per CU the zonal kernel is compiled for: LDS allows 3 at nk = 75, but 168 VGPRs spill (same speed, +1 GB of scratch traffic per launch)
 #endif
 
 // Dev tool (MOM6X_CFLAGS=-DMOM6X_MFL_TIMING python -m mom6_amd.build --force; scripts/prof_continuity.py): shader-clock
