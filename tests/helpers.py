@@ -29,6 +29,14 @@ def benchmark_small(nk=8, ni=40, nj=24, halo=4, layout=(1, 1), pe=(0, 0)):
     return gg, d, M
 
 
+def benchmark_360(nk=75, ni=360, nj=180, halo=4, layout=(1, 1), pe=(0, 0)):
+    """BASELINE.json configs[2]: the benchmark case's 360 x 180 x 75 grid (1 degree in longitude, 70S-70N bowl)."""
+    gg = grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-70.0, dlon=1.0, dlat=140.0 / nj,
+                         depth_fn=grid.bowl_depth(ni, nj, 4000.0))
+    d, M = gg.tile(nk, halo, layout, pe)
+    return gg, d, M
+
+
 def island_basin(nk=4, ni=36, nj=28, halo=4, layout=(1, 1), pe=(0, 0)):
     """Closed spherical basin with an island and a one-cell peninsula: corners and faces of every orientation
     (exercises NOSLIP, the land-mask thickness averages and the reduction factors of hor_visc)."""
