@@ -403,6 +403,40 @@ int mom6x_horizontal_viscosity(mom6x_ctx *ctx, const double *u, const double *v,
                                double *diffu, double *diffv);
 
 /* ------------------------------------------------------------------------- */
+/* MOM_remapping / the remapping half of MOM_ALE                   */
+/* remapping_CS (src/ALE/MOM_remapping.F90:47-84) as set by initialize_remapping :1654 / remapping_set_param :122.
+ * On the device path: the OM4-era reconstruction functions PCM, PLM, PPM_H4 (build_reconstructions_1d :410) with
+ * REMAPPING_ANSWER_DATE >= 20190101, with or without boundary extrapolation, both sub-cell integrators
+ * (remap_src_to_sub_grid_om4 :845 / remap_src_to_sub_grid :962) and remap_sub_to_tgt_grid_om4 :1103.
+ * Not on it (rejected): PPM_CW, PPM_IH4, the hybgen and PQM schemes, the Recon1d class ("C_*") schemes,
+ * the 2018 answers, PCM_cell masks, check_reconstruction / check_remapping.                        */
+enum mom6x_remap_scheme { MOM6X_REMAP_PCM = 0, MOM6X_REMAP_PLM = 2, MOM6X_REMAP_PPM_H4 = 4 };   /* :86-96 */
+typedef struct mom6x_remapping_params {
+  int    scheme;                    /* REMAPPING_SCHEME: PCM, PLM (the module default), PPM_H4            */
+  int    boundary_extrapolation;    /* REMAP_BOUNDARY_EXTRAP (type default .true.; ALE_init passes F)     */
+  int    force_bounds_in_subcell;   /* REMAP_BOUND_INTERMEDIATE_VALUES (F)                                */
+  int    force_bounds_in_target;    /* (T)                                                                */
+  int    om4_remap_via_sub_cells;   /* REMAPPING_USE_OM4_SUBCELLS (type default F; ALE_init default T)    */
+  int    answer_date;               /* REMAPPING_ANSWER_DATE; must be >= 20190101                         */
+  double h_neglect;                 /* GV%H_subroundoff (or GV%kg_m2_to_H*1e-30 ...)                      */
+  double h_neglect_edge;            /* = h_neglect for answer dates >= 20190101                           */
+} mom6x_remapping_params;
+
+/* ALE_remap_scalar-style column remap of `nfields` T-point fields in place (MOM_ALE.F90:760 ALE_remap_tracers,
+ * without the diagnostics): for every wet column remapping_core_h(CS, nk, h_old, field, nk, h_new, field).   */
+int mom6x_ALE_remap_tracers(mom6x_ctx *ctx, const mom6x_remapping_params *p, const double *h_old, const double *h_new,
+                            double *const *fields, int nfields);
+/* ALE_remap_set_h_vel :882 (no partial cells, no OBC): h_u = 0.5*(h(i)+h(i+1)) at open faces, else untouched.  */
+int mom6x_ALE_remap_set_h_vel(mom6x_ctx *ctx, const double *h_new, double *h_u, double *h_v);
+/* ALE_remap_velocities :1089 (REMAP_VEL_CONSERVE_KE off, no near-bottom masking, no diagnostics).              */
+int mom6x_ALE_remap_velocities(mom6x_ctx *ctx, const mom6x_remapping_params *p, const double *h_old_u, const double *h_old_v,
+                               const double *h_new_u, const double *h_new_v, double *u, double *v);
+/* remapping_core_h :234 for `ncol` independent columns stored back to back (n0 | n1 values each): the entry the
+ * reference's own unit tests (remapping_unit_tests :2072) exercise.  Device pointers.                          */
+int mom6x_remapping_core_h(mom6x_ctx *ctx, const mom6x_remapping_params *p, int ncol, int n0, const double *h0,
+                           const double *u0, int n1, const double *h1, double *u1);
+
+/* ------------------------------------------------------------------------- */
 /* MOM_vert_friction                                                           */
 /* The coupling coefficients CS%a_u, CS%a_v [(nk+1) levels], CS%h_u, CS%h_v and the optional
  * visc%Ray_u/Ray_v are produced by vertvisc_coef (:1357, not ported: SURVEY 8f-1); the host

@@ -199,6 +199,27 @@ def hor_visc_params_default(dt, Laplacian=False, biharmonic=True):
     return p
 
 
+REMAP_PCM, REMAP_PLM, REMAP_PPM_H4 = 0, 2, 4   # enum mom6x_remap_scheme
+
+
+class RemappingParams(C.Structure):
+    """mom6x_remapping_params; remapping_CS (MOM_remapping.F90:47-84)."""
+    _fields_ = [("scheme", C.c_int), ("boundary_extrapolation", C.c_int), ("force_bounds_in_subcell", C.c_int),
+                ("force_bounds_in_target", C.c_int), ("om4_remap_via_sub_cells", C.c_int), ("answer_date", C.c_int),
+                ("h_neglect", C.c_double), ("h_neglect_edge", C.c_double)]
+
+
+def remapping_params_default(scheme=REMAP_PLM, h_neglect=1.0e-30, **kw):
+    """initialize_remapping :1654 with the type's defaults (:47-84): boundary extrapolation on, target values bounded,
+    sub-cell values not, the non-OM4 sub-cell integrator; h_neglect as in remapping_unit_tests (1e-30 H)."""
+    p = RemappingParams()
+    p.scheme = scheme; p.boundary_extrapolation = 1; p.force_bounds_in_subcell = 0; p.force_bounds_in_target = 1
+    p.om4_remap_via_sub_cells = 0; p.answer_date = 99991231; p.h_neglect = h_neglect; p.h_neglect_edge = h_neglect
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
 LINEAR, WRIGHT = 1, 2   # enum mom6x_eos_form
 
 

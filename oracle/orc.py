@@ -32,7 +32,7 @@ def lib():
 def _p(a):
     if a is None:
         return None
-    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    assert a.dtype in (np.float64, np.int32) and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
 
 
@@ -156,6 +156,108 @@ def horizontal_viscosity(d, G, GV, CS, P, u, v, h, diffu, diffv):
     rc = lib().orc_horizontal_viscosity(C.byref(d), _p(G), C.byref(GV), C.byref(CS), _p(P), _p(u), _p(v), _p(h), _p(diffu), _p(diffv))
     if rc != 0:
         raise RuntimeError(f"orc_horizontal_viscosity rc={rc}")
+
+
+# ---- MOM_remapping / MOM_ALE (orc_remap.c: 1-based arrays inside, element 0 unused) ----------------------------------
+def _one(a, n=None):
+    a = np.asarray(a, dtype=np.float64)
+    out = np.zeros((len(a) if n is None else n) + 2)
+    out[1:len(a) + 1] = a
+    return out
+
+
+def remapping_core_h(CS, h0, u0, h1):
+    h0, u0, h1 = (np.ascontiguousarray(a, dtype=np.float64) for a in (h0, u0, h1))
+    u1 = np.zeros(len(h1)); err = C.c_double(0.0)
+    rc = lib().orc_remapping_core_h(C.byref(CS), len(h0), _p(h0), _p(u0), len(h1), _p(h1), _p(u1), C.byref(err))
+    if rc != 0:
+        raise RuntimeError(f"orc_remapping_core_h rc={rc}")
+    return u1, err.value
+
+
+def remapping_core_h_cols(CS, h0, u0, h1):
+    """h0, u0: [ncol][n0]; h1: [ncol][n1]"""
+    h0, u0, h1 = (np.ascontiguousarray(a, dtype=np.float64) for a in (h0, u0, h1))
+    u1 = np.zeros_like(h1)
+    rc = lib().orc_remapping_core_h_cols(C.byref(CS), h0.shape[0], h0.shape[1], _p(h0), _p(u0), h1.shape[1], _p(h1), _p(u1))
+    if rc != 0:
+        raise RuntimeError(f"orc_remapping_core_h_cols rc={rc}")
+    return u1
+
+
+def PLM_reconstruction(h, u, h_neglect, extrapolate=False):
+    n = len(h); h1, u1 = _one(h), _one(u)
+    E1, E2, C1, C2 = (np.zeros(n + 2) for _ in range(4))
+    lib().orc_PLM_reconstruction(n, _p(h1), _p(u1), _p(E1), _p(E2), _p(C1), _p(C2), C.c_double(h_neglect))
+    if extrapolate:
+        lib().orc_PLM_boundary_extrapolation(n, _p(h1), _p(u1), _p(E1), _p(E2), _p(C1), _p(C2), C.c_double(h_neglect))
+    return E1[1:n + 1], E2[1:n + 1], C1[1:n + 1], C2[1:n + 1]
+
+
+def edge_values_explicit_h4(h, u, h_neglect):
+    n = len(h); h1, u1 = _one(h), _one(u)
+    E1, E2 = np.zeros(n + 2), np.zeros(n + 2)
+    lib().orc_edge_values_explicit_h4(n, _p(h1), _p(u1), _p(E1), _p(E2), C.c_double(h_neglect))
+    return E1[1:n + 1], E2[1:n + 1]
+
+
+def PPM_reconstruction(h, u, E1, E2, h_neglect):
+    n = len(h); h1, u1 = _one(h), _one(u)
+    e1, e2 = _one(E1), _one(E2)
+    C1, C2, C3 = (np.zeros(n + 2) for _ in range(3))
+    lib().orc_PPM_reconstruction(n, _p(h1), _p(u1), _p(e1), _p(e2), _p(C1), _p(C2), _p(C3), C.c_double(h_neglect))
+    return e1[1:n + 1], e2[1:n + 1], C1[1:n + 1], C2[1:n + 1], C3[1:n + 1]
+
+
+def intersect_src_tgt_grids(h0, h1):
+    n0, n1 = len(h0), len(h1); ns = n0 + n1 + 1
+    a0, a1 = _one(h0), _one(h1)
+    h_sub, h0_eff = np.zeros(ns + 2), np.zeros(n0 + 2)
+    I = lambda n: np.zeros(n + 2, dtype=np.int32)
+    isrc_start, isrc_end, isrc_max, itgt_start, itgt_end, isub_src = I(n0), I(n0), I(n0), I(n1), I(n1), I(ns)
+    lib().orc_intersect_src_tgt_grids(n0, _p(a0), n1, _p(a1), _p(h_sub), _p(h0_eff), _p(isrc_start), _p(isrc_end), _p(isrc_max),
+                                      _p(itgt_start), _p(itgt_end), _p(isub_src))
+    return dict(h_sub=h_sub[1:ns + 1], h0_eff=h0_eff[1:n0 + 1], isrc_start=isrc_start[1:n0 + 1], isrc_end=isrc_end[1:n0 + 1],
+                isrc_max=isrc_max[1:n0 + 1], itgt_start=itgt_start[1:n1 + 1], itgt_end=itgt_end[1:n1 + 1], isub_src=isub_src[1:ns + 1])
+
+
+def remap_src_to_sub_grid_plm(h0, u0, h1, om4, h_neglect, force_bounds=False):
+    """PLM_reconstruction + PLM_boundary_extrapolation + remap_src_to_sub_grid(_om4) + remap_sub_to_tgt_grid_om4, as the
+    reference's unit tests chain them; returns (u_sub, u1)."""
+    n0, n1 = len(h0), len(h1); ns = n0 + n1 + 1
+    a0, a1, b0 = _one(h0), _one(h1), _one(u0)
+    h_sub, h0_eff = np.zeros(ns + 2), np.zeros(n0 + 2)
+    I = lambda n: np.zeros(n + 2, dtype=np.int32)
+    isrc_start, isrc_end, isrc_max, itgt_start, itgt_end, isub_src = I(n0), I(n0), I(n0), I(n1), I(n1), I(ns + 1)
+    lib().orc_intersect_src_tgt_grids(n0, _p(a0), n1, _p(a1), _p(h_sub), _p(h0_eff), _p(isrc_start), _p(isrc_end), _p(isrc_max),
+                                      _p(itgt_start), _p(itgt_end), _p(isub_src))
+    E1, E2, C1, C2 = (np.zeros(n0 + 2) for _ in range(4))
+    lib().orc_PLM_reconstruction(n0, _p(a0), _p(b0), _p(E1), _p(E2), _p(C1), _p(C2), C.c_double(h_neglect))
+    lib().orc_PLM_boundary_extrapolation(n0, _p(a0), _p(b0), _p(E1), _p(E2), _p(C1), _p(C2), C.c_double(h_neglect))
+    u_sub, uh_sub = np.zeros(ns + 2), np.zeros(ns + 2); err = C.c_double(0.0)
+    lib().orc_remap_src_to_sub_grid(int(om4), n0, _p(a0), _p(b0), _p(E1), _p(E2), _p(C1), _p(C2), n1, _p(h_sub), _p(h0_eff), _p(isrc_start),
+                                    _p(isrc_end), _p(isrc_max), _p(isub_src), 1, int(force_bounds), _p(u_sub), _p(uh_sub), C.byref(err))
+    u1 = np.zeros(n1 + 2); err2 = C.c_double(0.0)
+    lib().orc_remap_sub_to_tgt_grid_om4(n0, n1, _p(a1), _p(h_sub), _p(u_sub), _p(uh_sub), _p(itgt_start), _p(itgt_end), int(force_bounds),
+                                        _p(u1), C.byref(err2))
+    return u_sub[1:ns + 1], u1[1:n1 + 1]
+
+
+def ALE_remap_tracers(d, G, CS, h_old, h_new, fields):
+    ptrs = (C.c_void_p * len(fields))(*[f.ctypes.data for f in fields])
+    rc = lib().orc_ALE_remap_tracers(C.byref(d), _p(G), C.byref(CS), _p(h_old), _p(h_new), ptrs, len(fields))
+    if rc != 0:
+        raise RuntimeError(f"orc_ALE_remap_tracers rc={rc}")
+
+
+def ALE_remap_set_h_vel(d, G, h_new, h_u, h_v):
+    assert lib().orc_ALE_remap_set_h_vel(C.byref(d), _p(G), _p(h_new), _p(h_u), _p(h_v)) == 0
+
+
+def ALE_remap_velocities(d, G, CS, h_old_u, h_old_v, h_new_u, h_new_v, u, v):
+    rc = lib().orc_ALE_remap_velocities(C.byref(d), _p(G), C.byref(CS), _p(h_old_u), _p(h_old_v), _p(h_new_u), _p(h_new_v), _p(u), _p(v))
+    if rc != 0:
+        raise RuntimeError(f"orc_ALE_remap_velocities rc={rc}")
 
 
 def eos_density(eos, T, S, p):

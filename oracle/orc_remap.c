@@ -1,0 +1,540 @@
+/* orc_remap.c -- MOM_remapping's remapping_core_h with the OM4-era reconstruction functions PCM, PLM and PPM_H4
+ * (answer dates >= 20190101), and the remapping half of MOM_ALE (ALE_remap_tracers, ALE_remap_set_h_vel,
+ * ALE_remap_velocities).  ORACLE (test infrastructure only; see orc_common.h).
+ *
+ * PARITY PINNED: unlike the rest of the oracle, the reference holds known answers for these routines
+ * (remapping_unit_tests, src/ALE/MOM_remapping.F90:2072-2943); tests/test_remap_cpu.py replays them.
+ *
+ * Arrays are 1-based inside this file (index 0 unused) so that the index arithmetic of intersect_src_tgt_grids and
+ * the sub-cell loops reads exactly as in the reference. */
+#include "orc_common.h"
+#include <float.h>
+
+static inline double fsign(double a, double b) { return copysign(fabs(a), b); }   /* Fortran sign() with signed zeros */
+static inline double max3(double a, double b, double c) { return orc_max(orc_max(a, b), c); }
+static inline double min3(double a, double b, double c) { return orc_min(orc_min(a, b), c); }
+
+enum { INTEGRATION_PCM = 0, INTEGRATION_PLM = 1, INTEGRATION_PPM = 3 };
+
+/* ---- PLM_functions.F90 ------------------------------------------------------------------------------------- */
+static double PLM_slope_wa(double h_l, double h_c, double h_r, double h_neglect, double u_l, double u_c, double u_r) {   /* :27-66 */
+  const double sigma_r = u_r - u_c, sigma_l = u_c - u_l;
+  const double sigma_c = 2.0 * (u_r - u_l) * (h_c / (h_l + 2.0 * h_c + h_r + h_neglect));
+  const double u_min = min3(u_l, u_c, u_r), u_max = max3(u_l, u_c, u_r);
+  double s;
+  if ((sigma_l * sigma_r) > 0.0) s = fsign(orc_min(fabs(sigma_c), 2. * orc_min(u_c - u_min, u_max - u_c)), sigma_c);
+  else s = 0.0;
+  if (u_c - 0.5 * fabs(s) < u_min || u_c + 0.5 * fabs(s) > u_max) s = s * (1. - DBL_EPSILON);
+  if (fabs(s) < 1.E-140) s = 0.;
+  return s;
+}
+static double PLM_monotonized_slope(double u_l, double u_c, double u_r, double s_l, double s_c, double s_r) {   /* :124-162 */
+  const double almost_two = 2. * (1. - DBL_EPSILON);
+  const double e_r = u_l + 0.5 * s_l, e_l = u_r - 0.5 * s_r;
+  double slp = fabs(s_c);
+  double edge = u_c - 0.5 * s_c;
+  if ((edge - e_r) * (u_c - edge) < 0.) { edge = 0.5 * (edge + e_r); slp = orc_min(slp, fabs(edge - u_c) * almost_two); }
+  edge = u_c + 0.5 * s_c;
+  if ((edge - u_c) * (e_l - edge) < 0.) { edge = 0.5 * (edge + e_l); slp = orc_min(slp, fabs(edge - u_c) * almost_two); }
+  return fsign(slp, s_c);
+}
+static double PLM_extrapolate_slope(double h_l, double h_c, double h_neglect, double u_l, double u_c) {   /* :170-191 */
+  const double hl = h_l + h_neglect, hc = h_c + h_neglect;
+  const double left_edge = (u_l * hc + u_c * hl) / (hl + hc);
+  return 2.0 * (u_c - left_edge);
+}
+/* PLM_reconstruction :197-262 */
+void orc_PLM_reconstruction(int N, const double *h, const double *u, double *E1, double *E2, double *C1, double *C2, double h_neglect) {
+  const double almost_one = 1. - DBL_EPSILON;
+  double *slp = (double *)calloc(N + 2, sizeof(double)), *mslp = (double *)calloc(N + 2, sizeof(double));
+  for (int k = 2; k <= N - 1; k++) slp[k] = PLM_slope_wa(h[k - 1], h[k], h[k + 1], h_neglect, u[k - 1], u[k], u[k + 1]);
+  slp[1] = 0.; slp[N] = 0.;
+  for (int k = 2; k <= N - 1; k++) mslp[k] = PLM_monotonized_slope(u[k - 1], u[k], u[k + 1], slp[k - 1], slp[k], slp[k + 1]);
+  mslp[1] = 0.; mslp[N] = 0.;
+  E1[1] = u[1]; E2[1] = u[1]; C1[1] = u[1]; C2[1] = 0.;
+  for (int k = 2; k <= N - 1; k++) {
+    const double slope = mslp[k];
+    const double u_l = u[k] - 0.5 * slope, u_r = u[k] + 0.5 * slope;
+    E1[k] = u_l; E2[k] = u_r;
+    C1[k] = u_l; C2[k] = (u_r - u_l);
+    const double edge = C2[k] + C1[k];
+    const double e_r = u[k + 1] - 0.5 * fsign(mslp[k + 1], slp[k + 1]);
+    if ((edge - u[k]) * (e_r - edge) < 0.) C2[k] = C2[k] * almost_one;
+  }
+  E1[N] = u[N]; E2[N] = u[N]; C1[N] = u[N]; C2[N] = 0.;
+  free(slp); free(mslp);
+}
+/* PLM_boundary_extrapolation :274-308 */
+void orc_PLM_boundary_extrapolation(int N, const double *h, const double *u, double *E1, double *E2, double *C1, double *C2, double h_neglect) {
+  double slope = -PLM_extrapolate_slope(h[2], h[1], h_neglect, u[2], u[1]);
+  E1[1] = u[1] - 0.5 * slope; E2[1] = u[1] + 0.5 * slope;
+  C1[1] = E1[1]; C2[1] = E2[1] - E1[1];
+  slope = PLM_extrapolate_slope(h[N - 1], h[N], h_neglect, u[N - 1], u[N]);
+  E1[N] = u[N] - 0.5 * slope; E2[N] = u[N] + 0.5 * slope;
+  C1[N] = E1[N]; C2[N] = E2[N] - E1[N];
+}
+
+/* ---- regrid_edge_values.F90 -------------------------------------------------------------------------------- */
+static const double hMinFrac = 1.e-5;   /* :25 */
+/* bound_edge_values :39-101 (answer dates >= 20190101) */
+static void bound_edge_values(int N, const double *h, const double *u, double *E1, double *E2, double h_neglect) {
+  (void)h_neglect;
+  for (int k = 1; k <= N; k++) {
+    const int km1 = (k - 1 > 1) ? k - 1 : 1, kp1 = (k + 1 < N) ? k + 1 : N;
+    double slope_x_h = 0.0;
+    if (((h[km1] + h[kp1]) + 2.0 * h[k]) > 0.0) {
+      const double sigma_l = (u[k] - u[km1]);
+      const double sigma_c = (u[kp1] - u[km1]) * (h[k] / ((h[km1] + h[kp1]) + 2.0 * h[k]));
+      const double sigma_r = (u[kp1] - u[k]);
+      if ((sigma_l * sigma_r) > 0.0) slope_x_h = fsign(min3(fabs(sigma_l), fabs(sigma_c), fabs(sigma_r)), sigma_c);
+    }
+    if ((u[km1] - E1[k]) * (E1[k] - u[k]) < 0.0) E1[k] = u[k] - fsign(orc_min(fabs(slope_x_h), fabs(E1[k] - u[k])), slope_x_h);
+    if ((u[kp1] - E2[k]) * (E2[k] - u[k]) < 0.0) E2[k] = u[k] + fsign(orc_min(fabs(slope_x_h), fabs(E2[k] - u[k])), slope_x_h);
+    E1[k] = orc_max(orc_min(E1[k], orc_max(u[km1], u[k])), orc_min(u[km1], u[k]));
+    E2[k] = orc_max(orc_min(E2[k], orc_max(u[kp1], u[k])), orc_min(u[kp1], u[k]));
+  }
+}
+/* check_discontinuous_edge_values :132-150 */
+static void check_discontinuous_edge_values(int N, const double *u, double *E1, double *E2) {
+  for (int k = 1; k <= N - 1; k++) {
+    if ((E1[k + 1] - E2[k]) * (u[k + 1] - u[k]) < 0.0) {
+      double u0_avg = 0.5 * (E2[k] + E1[k + 1]);
+      u0_avg = orc_max(orc_min(u0_avg, orc_max(u[k], u[k + 1])), orc_min(u[k], u[k + 1]));
+      E2[k] = u0_avg; E1[k + 1] = u0_avg;
+    }
+  }
+}
+/* end_value_h4 :634-747; dz, u, Csys are 0-based arrays of 4 */
+static void end_value_h4(const double *dz, const double *u, double *Csys) {
+  const double min_frac = 1.0e-6;
+  double h1 = dz[0], h2 = dz[1], h3 = dz[2], h4 = dz[3];
+  if ((h2 + h3) < min_frac * h1) h3 = min_frac * h1 - h2;
+  if ((h3 + h4) < min_frac * h1) h4 = min_frac * h1 - h3;
+  const double h12 = h1 + h2, h23 = h2 + h3, h34 = h3 + h4;
+  const double h123 = h12 + h3, h234 = h2 + h34, h1234 = h12 + h34;
+  const double I_denB3 = 1.0 / (h123 * h12 * h23);
+  const double I_h12 = (h123 * h23) * I_denB3;
+  const double I_h23 = (h12 * h123) * I_denB3;
+  const double I_h123 = (h12 * h23) * I_denB3;
+  const double I_denom = 1.0 / (h1234 * (h234 * h34));
+  const double I_h34 = (h1234 * h234) * I_denom;
+  const double I_h234 = (h1234 * h34) * I_denom;
+  const double I_h1234 = (h234 * h34) * I_denom;
+  (void)I_h34;
+  double Wt[3][4];
+  Wt[0][0] = -h1 * (I_h1234 + I_h123 + I_h12);
+  Wt[1][0] = h1 * h12 * (I_h234 * I_h1234 + I_h23 * (I_h234 + I_h123));
+  Wt[2][0] = -h1 * h12 * h123 * I_denom;
+  Wt[0][1] = 2.0 * (I_h12 * (1.0 + (h1 + h12) * (I_h1234 + I_h123)) + h1 * I_h1234 * I_h123);
+  Wt[1][1] = -2.0 * ((h1 * h12 * I_h1234) * (I_h23 * (I_h234 + I_h123)) + (h1 + h12) * (I_h1234 * I_h234 + I_h23 * (I_h234 + I_h123)));
+  Wt[2][1] = 2.0 * ((h1 + h12) * h123 + h1 * h12) * I_denom;
+  Wt[0][2] = -3.0 * I_h12 * I_h123 * (1.0 + I_h1234 * ((h1 + h12) + h123));
+  Wt[1][2] = 3.0 * I_h23 * (I_h123 + I_h1234 * ((h1 + h12) + h123) * (I_h123 + I_h234));
+  Wt[2][2] = -3.0 * ((h1 + h12) + h123) * I_denom;
+  Wt[0][3] = 4.0 * I_h1234 * I_h123 * I_h12;
+  Wt[1][3] = -4.0 * I_h1234 * (I_h23 * (I_h123 + I_h234));
+  Wt[2][3] = 4.0 * I_denom;
+  Csys[0] = ((u[0] + (Wt[0][0] * (u[1] - u[0]))) + (Wt[1][0] * (u[2] - u[1]))) + (Wt[2][0] * (u[3] - u[2]));
+  Csys[1] = ((Wt[0][1] * (u[1] - u[0])) + (Wt[1][1] * (u[2] - u[1]))) + (Wt[2][1] * (u[3] - u[2]));
+  Csys[2] = ((Wt[0][2] * (u[1] - u[0])) + (Wt[1][2] * (u[2] - u[1]))) + (Wt[2][2] * (u[3] - u[2]));
+  Csys[3] = ((Wt[0][3] * (u[1] - u[0])) + (Wt[1][3] * (u[2] - u[1]))) + (Wt[2][3] * (u[3] - u[2]));
+}
+/* edge_values_explicit_h4 :213-348 (answer dates >= 20190101); N >= 4 */
+void orc_edge_values_explicit_h4(int N, const double *h, const double *u, double *E1, double *E2, double h_neglect) {
+  for (int i = 3; i <= N - 1; i++) {
+    double h0 = h[i - 2], h1 = h[i - 1], h2 = h[i], h3 = h[i + 1];
+    if (h0 + h1 == 0.0 || h1 + h2 == 0.0 || h2 + h3 == 0.0) {
+      const double h_min = hMinFrac * orc_max(h_neglect, (h0 + h1) + (h2 + h3));
+      h0 = orc_max(h_min, h[i - 2]); h1 = orc_max(h_min, h[i - 1]); h2 = orc_max(h_min, h[i]); h3 = orc_max(h_min, h[i + 1]);
+    }
+    const double I_h12 = 1.0 / (h1 + h2);
+    const double I_den_et2 = 1.0 / (((h0 + h1) + h2) * (h0 + h1)), I_h012 = (h0 + h1) * I_den_et2;
+    const double I_den_et3 = 1.0 / ((h1 + (h2 + h3)) * (h2 + h3)), I_h123 = (h2 + h3) * I_den_et3;
+    const double et1 = (1.0 + (h1 * I_h012 + (h0 + h1) * I_h123)) * I_h12 * (h2 * (h2 + h3)) * u[i - 1] +
+                       (1.0 + (h2 * I_h123 + (h2 + h3) * I_h012)) * I_h12 * (h1 * (h0 + h1)) * u[i];
+    const double et2 = (h1 * (h2 * (h2 + h3)) * I_den_et2) * (u[i - 1] - u[i - 2]);
+    const double et3 = (h2 * (h1 * (h0 + h1)) * I_den_et3) * (u[i] - u[i + 1]);
+    E1[i] = (et1 + (et2 + et3)) / ((h0 + h1) + (h2 + h3));
+    E2[i - 1] = E1[i];
+  }
+  double dz[4], ut[4], C[4];
+  for (int i = 1; i <= 4; i++) { dz[i - 1] = orc_max(h_neglect, h[i]); ut[i - 1] = u[i]; }
+  end_value_h4(dz, ut, C);
+  E1[1] = C[0];
+  E2[1] = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
+  E1[2] = E2[1];
+  for (int i = 1; i <= 4; i++) { dz[i - 1] = orc_max(h_neglect, h[N + 1 - i]); ut[i - 1] = u[N + 1 - i]; }
+  end_value_h4(dz, ut, C);
+  E2[N] = C[0];
+  E1[N] = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
+  E2[N - 1] = E1[N];
+}
+
+/* ---- PPM_functions.F90 ------------------------------------------------------------------------------------- */
+/* PPM_limiter_standard :62-121 */
+static void PPM_limiter_standard(int N, const double *h, const double *u, double *E1, double *E2, double h_neglect) {
+  bound_edge_values(N, h, u, E1, E2, h_neglect);
+  check_discontinuous_edge_values(N, u, E1, E2);
+  for (int k = 2; k <= N - 1; k++) {
+    const double u_l = u[k - 1], u_c = u[k], u_r = u[k + 1];
+    double edge_l = E1[k], edge_r = E2[k];
+    if ((u_r - u_c) * (u_c - u_l) <= 0.0) {
+      edge_l = u_c; edge_r = u_c;
+    } else {
+      const double expr1 = 3.0 * (edge_r - edge_l) * ((u_c - edge_l) + (u_c - edge_r));
+      const double expr2 = (edge_r - edge_l) * (edge_r - edge_l);
+      if (expr1 > expr2) {
+        edge_l = u_c + 2.0 * (u_c - edge_r);
+        edge_l = orc_max(orc_min(edge_l, orc_max(u_l, u_c)), orc_min(u_l, u_c));
+      } else if (expr1 < -expr2) {
+        edge_r = u_c + 2.0 * (u_c - edge_l);
+        edge_r = orc_max(orc_min(edge_r, orc_max(u_r, u_c)), orc_min(u_r, u_c));
+      }
+    }
+    if (fabs(edge_r - edge_l) < orc_max(1.e-60, DBL_EPSILON * fabs(u_c))) { edge_l = u_c; edge_r = u_c; }
+    E1[k] = edge_l; E2[k] = edge_r;
+  }
+  E1[1] = u[1]; E2[1] = u[1];
+  E1[N] = u[N]; E2[N] = u[N];
+}
+/* PPM_reconstruction :25-55 */
+void orc_PPM_reconstruction(int N, const double *h, const double *u, double *E1, double *E2, double *C1, double *C2, double *C3, double h_neglect) {
+  PPM_limiter_standard(N, h, u, E1, E2, h_neglect);
+  for (int k = 1; k <= N; k++) {
+    const double edge_l = E1[k], edge_r = E2[k];
+    C1[k] = edge_l;
+    C2[k] = 4.0 * (u[k] - edge_l) + 2.0 * (u[k] - edge_r);
+    C3[k] = 3.0 * ((edge_r - u[k]) + (edge_l - u[k]));
+  }
+}
+/* PPM_boundary_extrapolation :166-296 */
+void orc_PPM_boundary_extrapolation(int N, const double *h, const double *u, double *E1, double *E2, double *C1, double *C2, double *C3, double h_neglect) {
+  int i0 = 1, i1 = 2;
+  double h0 = h[i0], h1 = h[i1], u0 = u[i0], u1 = u[i1];
+  double b = C2[i1];
+  double u1_r = b * ((h0 + h_neglect) / (h1 + h_neglect));
+  double slope = 2.0 * (u1 - u0);
+  if (fabs(u1_r) > fabs(slope)) u1_r = slope;
+  double u0_r = E1[i1];
+  double u0_l = 3.0 * u0 + 0.5 * u1_r - 2.0 * u0_r;
+  double exp1 = (u0_r - u0_l) * (u0 - 0.5 * (u0_l + u0_r));
+  double exp2 = (u0_r - u0_l) * (u0_r - u0_l) / 6.0;
+  if (exp1 > exp2) u0_l = 3.0 * u0 - 2.0 * u0_r;
+  if (exp1 < -exp2) u0_r = 3.0 * u0 - 2.0 * u0_l;
+  E1[i0] = u0_l; E2[i0] = u0_r;
+  C1[i0] = u0_l; C2[i0] = 6.0 * u0 - 4.0 * u0_l - 2.0 * u0_r; C3[i0] = 3.0 * (u0_r + u0_l - 2.0 * u0);
+
+  i0 = N - 1; i1 = N;
+  h0 = h[i0]; h1 = h[i1]; u0 = u[i0]; u1 = u[i1];
+  b = C2[i0];
+  const double c = C3[i0];
+  double u1_l = (b + 2 * c);
+  u1_l = u1_l * ((h1 + h_neglect) / (h0 + h_neglect));
+  slope = 2.0 * (u1 - u0);
+  if (fabs(u1_l) > fabs(slope)) u1_l = slope;
+  u0_l = E2[i0];
+  u0_r = 3.0 * u1 - 0.5 * u1_l - 2.0 * u0_l;
+  exp1 = (u0_r - u0_l) * (u1 - 0.5 * (u0_l + u0_r));
+  exp2 = (u0_r - u0_l) * (u0_r - u0_l) / 6.0;
+  if (exp1 > exp2) u0_l = 3.0 * u1 - 2.0 * u0_r;
+  if (exp1 < -exp2) u0_r = 3.0 * u1 - 2.0 * u0_l;
+  E1[i1] = u0_l; E2[i1] = u0_r;
+  C1[i1] = u0_l; C2[i1] = 6.0 * u1 - 4.0 * u0_l - 2.0 * u0_r; C3[i1] = 3.0 * (u0_r + u0_l - 2.0 * u1);
+}
+
+/* ---- MOM_remapping.F90 ------------------------------------------------------------------------------------- */
+/* build_reconstructions_1d :410-550 for PCM, PLM, PPM_H4 */
+static int build_reconstructions_1d(const mom6x_remapping_params *CS, int n0, const double *h0, const double *u0, double *E1,
+                                    double *E2, double *C1, double *C2, double *C3, int *iMethod) {
+  for (int k = 0; k <= n0 + 1; k++) { E1[k] = 0.; E2[k] = 0.; C1[k] = 0.; C2[k] = 0.; C3[k] = 0.; }
+  int scheme = CS->scheme;
+  if (n0 <= 1) scheme = MOM6X_REMAP_PCM;
+  else if (n0 <= 3) scheme = (scheme < MOM6X_REMAP_PLM) ? scheme : MOM6X_REMAP_PLM;
+  else if (n0 <= 4) scheme = (scheme < MOM6X_REMAP_PPM_H4) ? scheme : MOM6X_REMAP_PPM_H4;
+  switch (scheme) {
+    case MOM6X_REMAP_PCM:
+      for (int k = 1; k <= n0; k++) { C1[k] = u0[k]; E1[k] = u0[k]; E2[k] = u0[k]; }   /* PCM_functions.F90:16-35 */
+      *iMethod = INTEGRATION_PCM;
+      break;
+    case MOM6X_REMAP_PLM:
+      orc_PLM_reconstruction(n0, h0, u0, E1, E2, C1, C2, CS->h_neglect);
+      if (CS->boundary_extrapolation) orc_PLM_boundary_extrapolation(n0, h0, u0, E1, E2, C1, C2, CS->h_neglect);
+      *iMethod = INTEGRATION_PLM;
+      break;
+    case MOM6X_REMAP_PPM_H4:
+      orc_edge_values_explicit_h4(n0, h0, u0, E1, E2, CS->h_neglect_edge);
+      orc_PPM_reconstruction(n0, h0, u0, E1, E2, C1, C2, C3, CS->h_neglect);
+      if (CS->boundary_extrapolation) orc_PPM_boundary_extrapolation(n0, h0, u0, E1, E2, C1, C2, C3, CS->h_neglect);
+      *iMethod = INTEGRATION_PPM;
+      break;
+    default:
+      return MOM6X_EUNSUPPORTED;
+  }
+  return MOM6X_OK;
+}
+
+/* intersect_src_tgt_grids :642-798 */
+void orc_intersect_src_tgt_grids(int n0, const double *h0, int n1, const double *h1, double *h_sub, double *h0_eff, int *isrc_start,
+                                 int *isrc_end, int *isrc_max, int *itgt_start, int *itgt_end, int *isub_src) {
+  double h0_supply = h0[1], h1_supply = h1[1];
+  int src_has_volume = 1, tgt_has_volume = 1;
+  int i0 = 1, i1 = 1, i_start0 = 1, i_start1 = 1, i_max = 1;
+  double dh_max = 0., dh0_eff = 0.;
+  h_sub[1] = 0.;
+  isrc_start[1] = 1; isrc_end[1] = 1; isrc_max[1] = 1; isub_src[1] = 1;
+  for (int i_sub = 2; i_sub <= n0 + n1 + 1; i_sub++) {
+    const double dh = orc_min(h0_supply, h1_supply);
+    dh0_eff = dh0_eff + orc_min(dh, h0_supply);
+    isub_src[i_sub] = i0;
+    h_sub[i_sub] = dh;
+    if (dh >= dh_max) { i_max = i_sub; dh_max = dh; }
+    if (h0_supply <= h1_supply && src_has_volume) {
+      h1_supply = h1_supply - dh;
+      isrc_start[i0] = i_start0; isrc_end[i0] = i_sub; i_start0 = i_sub + 1;
+      isrc_max[i0] = i_max; i_max = i_sub + 1; dh_max = 0.;
+      h0_eff[i0] = dh0_eff;
+      if (i0 < n0) { i0 = i0 + 1; h0_supply = h0[i0]; dh0_eff = 0.; }
+      else { h0_supply = 0.; src_has_volume = 0; }
+    } else if (h0_supply >= h1_supply && tgt_has_volume) {
+      h0_supply = h0_supply - dh;
+      itgt_start[i1] = i_start1; itgt_end[i1] = i_sub; i_start1 = i_sub + 1;
+      if (i1 < n1) { i1 = i1 + 1; h1_supply = h1[i1]; }
+      else { h1_supply = 0.; tgt_has_volume = 0; }
+    } else if (src_has_volume) {
+      h_sub[i_sub] = h0_supply;
+      isrc_start[i0] = i_start0; isrc_end[i0] = i_sub; i_start0 = i_sub + 1;
+      isrc_max[i0] = i_max; i_max = i_sub + 1; dh_max = 0.;
+      h0_eff[i0] = dh0_eff;
+      if (i0 < n0) { i0 = i0 + 1; h0_supply = h0[i0]; dh0_eff = 0.; }
+      else { h0_supply = 0.; src_has_volume = 0; }
+    } else if (tgt_has_volume) {
+      h_sub[i_sub] = h1_supply;
+      itgt_start[i1] = i_start1; itgt_end[i1] = i_sub; i_start1 = i_sub + 1;
+      if (i1 < n1) { i1 = i1 + 1; h1_supply = h1[i1]; }
+      else { h1_supply = 0.; tgt_has_volume = 0; }
+    }
+  }
+}
+
+/* average_value_ppoly :1391-1494 for PCM / PLM / PPM */
+static double average_value_ppoly(const double *u0, const double *E1, const double *E2, const double *C1, const double *C2, int method,
+                                  int i0, double xa, double xb) {
+  double u_ave = 0.;
+  if (xb > xa) {
+    if (method == INTEGRATION_PCM) u_ave = u0[i0];
+    else if (method == INTEGRATION_PLM) u_ave = (C1[i0] + C2[i0] * 0.5 * (xb + xa));
+    else {
+      const double mx = 0.5 * (xa + xb);
+      const double a_L = E1[i0], a_R = E2[i0], u_c = u0[i0];
+      const double a_c = 0.5 * ((u_c - a_L) + (u_c - a_R));
+      if (mx < 0.5) {
+        const double xa2b2ab = (xa * xa + xb * xb) + xa * xb;
+        u_ave = a_L + ((a_R - a_L) * mx + a_c * (3. * (xb + xa) - 2. * xa2b2ab));
+      } else {
+        const double Ya = 1. - xa, Yb = 1. - xb, my = 0.5 * (Ya + Yb);
+        const double Ya2b2ab = (Ya * Ya + Yb * Yb) + Ya * Yb;
+        u_ave = a_R + ((a_L - a_R) * my + a_c * (3. * (Yb + Ya) - 2. * Ya2b2ab));
+      }
+    }
+  } else {
+    if (method == INTEGRATION_PCM) u_ave = C1[i0];
+    else if (method == INTEGRATION_PLM) {
+      const double a_L = E1[i0], a_R = E2[i0], Ya = 1. - xa;
+      if (xa < 0.5) u_ave = a_L + xa * (a_R - a_L);
+      else u_ave = a_R + Ya * (a_L - a_R);
+    } else {
+      const double a_L = E1[i0], a_R = E2[i0], u_c = u0[i0];
+      const double a_c = 3. * ((u_c - a_L) + (u_c - a_R));
+      const double Ya = 1. - xa;
+      if (xa < 0.5) u_ave = a_L + xa * ((a_R - a_L) + a_c * Ya);
+      else u_ave = a_R + Ya * ((a_L - a_R) + a_c * xa);
+    }
+  }
+  return u_ave;
+}
+
+/* remap_src_to_sub_grid_om4 :845-959 (om4 != 0) / remap_src_to_sub_grid :962-1099 */
+void orc_remap_src_to_sub_grid(int om4, int n0, const double *h0, const double *u0, const double *E1, const double *E2, const double *C1,
+                               const double *C2, int n1, const double *h_sub, const double *h0_eff, const int *isrc_start,
+                               const int *isrc_end, const int *isrc_max, const int *isub_src, int method, int force_bounds_in_subcell,
+                               double *u_sub, double *uh_sub, double *u02_err) {
+  double *u0_min = (double *)calloc(n0 + 2, sizeof(double)), *u0_max = (double *)calloc(n0 + 2, sizeof(double));
+  int i0_last_thick_cell = 0;
+  for (int i0 = 1; i0 <= n0; i0++) {
+    u0_min[i0] = orc_min(E1[i0], E2[i0]); u0_max[i0] = orc_max(E1[i0], E2[i0]);
+    if (h0[i0] > 0.) i0_last_thick_cell = i0;
+  }
+  double xa = 0., dh0_eff = 0.;
+  *u02_err = 0.;
+  int first = 1;
+  if (om4) { uh_sub[1] = 0.; u_sub[1] = E1[1]; first = 2; }
+  const int last = om4 ? n0 + n1 : n0 + n1 + 1;
+  for (int i_sub = first; i_sub <= last; i_sub++) {
+    const double dh = h_sub[i_sub];
+    const int i0 = isub_src[i_sub];
+    double xb;
+    dh0_eff = dh0_eff + dh;
+    const double hden = om4 ? h0_eff[i0] : h0[i0];
+    if (hden > 0.) {
+      xb = dh0_eff / hden;
+      xb = orc_min(1., xb);
+      u_sub[i_sub] = average_value_ppoly(u0, E1, E2, C1, C2, method, i0, xa, xb);
+    } else {
+      xb = 1.;
+      u_sub[i_sub] = u0[i0];
+    }
+    if (force_bounds_in_subcell) {
+      const double u_orig = u_sub[i_sub];
+      u_sub[i_sub] = orc_max(u_sub[i_sub], u0_min[i0]);
+      u_sub[i_sub] = orc_min(u_sub[i_sub], u0_max[i0]);
+      *u02_err = *u02_err + dh * fabs(u_sub[i_sub] - u_orig);
+    }
+    uh_sub[i_sub] = dh * u_sub[i_sub];
+    if (i_sub <= n0 + n1) {   /* (the non-OM4 code repeats the body once more for the last sub-cell, without this tail) */
+      if (isub_src[i_sub + 1] != i0) { dh0_eff = 0.; xa = 0.; }
+      else xa = xb;
+    }
+  }
+  if (om4) {
+    u_sub[n0 + n1 + 1] = E2[n0];
+    uh_sub[n0 + n1 + 1] = E2[n0] * h_sub[n0 + n1 + 1];
+  }
+  for (int i0 = 1; i0 <= i0_last_thick_cell; i0++) {   /* adjust_thickest_subcell */
+    const int i_max = isrc_max[i0];
+    const double dh_max = h_sub[i_max];
+    if (dh_max > 0.) {
+      double duh = 0.;
+      for (int i_sub = isrc_start[i0]; i_sub <= isrc_end[i0]; i_sub++)
+        if (i_sub != i_max) duh = duh + uh_sub[i_sub];
+      uh_sub[i_max] = u0[i0] * h0[i0] - duh;
+      *u02_err = *u02_err + max3(fabs(uh_sub[i_max]), fabs(u0[i0] * h0[i0]), fabs(duh));
+    }
+  }
+  free(u0_min); free(u0_max);
+}
+
+/* remap_sub_to_tgt_grid_om4 :1103-1163 */
+void orc_remap_sub_to_tgt_grid_om4(int n0, int n1, const double *h1, const double *h_sub, const double *u_sub, const double *uh_sub,
+                                   const int *itgt_start, const int *itgt_end, int force_bounds_in_target, double *u1, double *uh_err) {
+  (void)n0;
+  double u1min = 0., u1max = 0.;
+  *uh_err = 0.;
+  for (int i1 = 1; i1 <= n1; i1++) {
+    if (h1[i1] > 0.) {
+      double duh = 0., dh = 0.;
+      int i_sub = itgt_start[i1];
+      if (force_bounds_in_target) { u1min = u_sub[i_sub]; u1max = u_sub[i_sub]; }
+      for (i_sub = itgt_start[i1]; i_sub <= itgt_end[i1]; i_sub++) {
+        if (force_bounds_in_target) { u1min = orc_min(u1min, u_sub[i_sub]); u1max = orc_max(u1max, u_sub[i_sub]); }
+        dh = dh + h_sub[i_sub];
+        duh = duh + uh_sub[i_sub];
+        *uh_err = *uh_err + orc_max(fabs(duh), fabs(uh_sub[i_sub])) * DBL_EPSILON;
+      }
+      u1[i1] = duh / dh;
+      *uh_err = *uh_err + fabs(duh) * DBL_EPSILON;
+      if (force_bounds_in_target) {
+        const double u_orig = u1[i1];
+        u1[i1] = orc_max(u1min, orc_min(u1max, u1[i1]));
+        *uh_err = *uh_err + dh * fabs(u1[i1] - u_orig);
+      }
+    } else {
+      u1[i1] = u_sub[itgt_start[i1]];
+    }
+  }
+}
+
+/* remapping_core_h :234-335 (OM4-era reconstruction branch).  h0, u0, h1, u1 are 0-based C arrays. */
+int orc_remapping_core_h(const mom6x_remapping_params *CS, int n0, const double *h0c, const double *u0c, int n1, const double *h1c,
+                         double *u1c, double *net_err) {
+  if (CS->answer_date < 20190101) return MOM6X_EUNSUPPORTED;
+  const int ns = n0 + n1 + 1;
+  double *w = (double *)calloc((size_t)(7 * (n0 + 2) + 2 * (n1 + 2) + 3 * (ns + 2)), sizeof(double));
+  int *iw = (int *)calloc((size_t)(3 * (n0 + 2) + 2 * (n1 + 2) + (ns + 2)), sizeof(int));
+  double *h0 = w, *u0 = h0 + n0 + 2, *E1 = u0 + n0 + 2, *E2 = E1 + n0 + 2, *C1 = E2 + n0 + 2, *C2 = C1 + n0 + 2, *C3 = C2 + n0 + 2;
+  /* h0_eff shares C3's successor */
+  double *h1 = C3 + n0 + 2, *u1 = h1 + n1 + 2, *h_sub = u1 + n1 + 2, *uh_sub = h_sub + ns + 2, *u_sub = uh_sub + ns + 2;
+  double *h0_eff = (double *)calloc((size_t)(n0 + 2), sizeof(double));
+  int *isrc_start = iw, *isrc_end = isrc_start + n0 + 2, *isrc_max = isrc_end + n0 + 2, *itgt_start = isrc_max + n0 + 2,
+      *itgt_end = itgt_start + n1 + 2, *isub_src = itgt_end + n1 + 2;
+  for (int k = 1; k <= n0; k++) { h0[k] = h0c[k - 1]; u0[k] = u0c[k - 1]; }
+  for (int k = 1; k <= n1; k++) h1[k] = h1c[k - 1];
+  orc_intersect_src_tgt_grids(n0, h0, n1, h1, h_sub, h0_eff, isrc_start, isrc_end, isrc_max, itgt_start, itgt_end, isub_src);
+  int iMethod = -999;
+  int rc = build_reconstructions_1d(CS, n0, h0, u0, E1, E2, C1, C2, C3, &iMethod);
+  double u02_err = 0., uh_err = 0.;
+  if (rc == MOM6X_OK) {
+    orc_remap_src_to_sub_grid(CS->om4_remap_via_sub_cells, n0, h0, u0, E1, E2, C1, C2, n1, h_sub, h0_eff, isrc_start, isrc_end, isrc_max,
+                              isub_src, iMethod, CS->force_bounds_in_subcell, u_sub, uh_sub, &u02_err);
+    orc_remap_sub_to_tgt_grid_om4(n0, n1, h1, h_sub, u_sub, uh_sub, itgt_start, itgt_end, CS->force_bounds_in_target, u1, &uh_err);
+    uh_err = uh_err + u02_err;
+    for (int k = 1; k <= n1; k++) u1c[k - 1] = u1[k];
+    if (net_err) *net_err = uh_err;
+  }
+  free(w); free(iw); free(h0_eff);
+  return rc;
+}
+
+/* `ncol` columns stored back to back */
+int orc_remapping_core_h_cols(const mom6x_remapping_params *CS, int ncol, int n0, const double *h0, const double *u0, int n1,
+                              const double *h1, double *u1) {
+  for (int c = 0; c < ncol; c++) {
+    int rc = orc_remapping_core_h(CS, n0, h0 + (size_t)c * n0, u0 + (size_t)c * n0, n1, h1 + (size_t)c * n1, u1 + (size_t)c * n1, NULL);
+    if (rc) return rc;
+  }
+  return MOM6X_OK;
+}
+
+/* ---- MOM_ALE.F90 ------------------------------------------------------------------------------------------- */
+static int remap_points(const mom6x_dims *d, const double *mask, int i_lo, int i_hi, int j_lo, int j_hi, const mom6x_remapping_params *CS,
+                        const double *h_old, const double *h_new, double *f) {
+  const int nz = d->nk;
+  const size_t slab = (size_t)d->slab;
+  int rc_all = MOM6X_OK;
+#pragma omp parallel for schedule(static)
+  for (int j = j_lo; j <= j_hi; j++) {
+    double *h1 = (double *)malloc(sizeof(double) * 4 * (size_t)nz), *h2 = h1 + nz, *src = h2 + nz, *col = src + nz;
+    for (int i = i_lo; i <= i_hi; i++) {
+      const size_t x = IX2(d, i, j);
+      if (!(mask[x] > 0.)) continue;
+      for (int k = 0; k < nz; k++) { h1[k] = h_old[x + k * slab]; h2[k] = h_new[x + k * slab]; src[k] = f[x + k * slab]; }
+      const int rc = orc_remapping_core_h(CS, nz, h1, src, nz, h2, col, NULL);
+      if (rc) { rc_all = rc; continue; }
+      for (int k = 0; k < nz; k++) f[x + k * slab] = col[k];
+    }
+    free(h1);
+  }
+  return rc_all;
+}
+/* ALE_remap_tracers :760-879 (no diagnostics, no conc_underflow) */
+int orc_ALE_remap_tracers(const mom6x_dims *d, const double *G, const mom6x_remapping_params *CS, const double *h_old, const double *h_new,
+                          double *const *fields, int nfields) {
+  for (int m = 0; m < nfields; m++) {
+    int rc = remap_points(d, GM(G, d, MOM6X_G_mask2dT), 0, d->ni - 1, 0, d->nj - 1, CS, h_old, h_new, fields[m]);
+    if (rc) return rc;
+  }
+  return MOM6X_OK;
+}
+/* ALE_remap_set_h_vel :882-925 */
+int orc_ALE_remap_set_h_vel(const mom6x_dims *d, const double *G, const double *h_new, double *h_u, double *h_v) {
+  const double *mCu = GM(G, d, MOM6X_G_mask2dCu), *mCv = GM(G, d, MOM6X_G_mask2dCv);
+  const size_t slab = (size_t)d->slab;
+  const int st = d->pitch;
+  for (int k = 0; k < d->nk; k++) {
+    for (int j = 0; j < d->nj; j++) for (int I = -1; I < d->ni; I++) {
+      const size_t x = IX2(d, I, j);
+      if (mCu[x] > 0.) h_u[x + k * slab] = 0.5 * (h_new[x + k * slab] + h_new[x + 1 + k * slab]);
+    }
+    for (int J = -1; J < d->nj; J++) for (int i = 0; i < d->ni; i++) {
+      const size_t x = IX2(d, i, J);
+      if (mCv[x] > 0.) h_v[x + k * slab] = 0.5 * (h_new[x + k * slab] + h_new[x + st + k * slab]);
+    }
+  }
+  return MOM6X_OK;
+}
+/* ALE_remap_velocities :1089-1300 (conserve_ke off, no near-bottom masking, no diagnostics) */
+int orc_ALE_remap_velocities(const mom6x_dims *d, const double *G, const mom6x_remapping_params *CS, const double *h_old_u,
+                             const double *h_old_v, const double *h_new_u, const double *h_new_v, double *u, double *v) {
+  int rc = remap_points(d, GM(G, d, MOM6X_G_mask2dCu), -1, d->ni - 1, 0, d->nj - 1, CS, h_old_u, h_new_u, u);
+  if (rc) return rc;
+  return remap_points(d, GM(G, d, MOM6X_G_mask2dCv), 0, d->ni - 1, -1, d->nj - 1, CS, h_old_v, h_new_v, v);
+}

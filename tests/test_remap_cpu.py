@@ -1,0 +1,130 @@
+"""The oracle's restatement of MOM_remapping replayed against the reference's OWN known answers: every value below
+is copied from remapping_unit_tests (src/ALE/MOM_remapping.F90:2072-2943, the tests that `MOM6 unit_tests` runs), as
+data -- inputs and expected outputs -- with the line it comes from.  This pins orc_remap.c (PCM / PLM / PPM_H4,
+answer date 20190101) to the reference's numbers; the GPU tests then hold the HIP kernels to orc_remap.c bit for bit."""
+import numpy as np
+import pytest
+
+from mom6_amd import abi
+
+H_NEGLECT = 1.0e-30       # :2121
+A = np.array
+
+
+def eq(a, b, tol=0.0, what=""):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    assert a.shape == b.shape, what
+    assert np.abs(a - b).max() <= tol, f"{what}: {a} vs {b}"
+
+
+def test_remapping_core_h_PPM_H4_first_generation(orc):
+    """:2125-2166 'remapping_core_h() 2', '3', '4' (4 layers of 0.75 with du/dz = 8)."""
+    CS = abi.remapping_params_default(abi.REMAP_PPM_H4, H_NEGLECT, answer_date=20190101)
+    h0, u0 = [0.75] * 4, [9., 3., -3., -9.]
+    eq(orc.remapping_core_h(CS, h0, u0, [0.5] * 6)[0], [10., 6., 2., -2., -6., -10.], what="core_h 2")
+    eq(orc.remapping_core_h(CS, h0, u0, [.125] * 6)[0], [11.5, 10.5, 9.5, 8.5, 7.5, 6.5], what="core_h 3")
+    eq(orc.remapping_core_h(CS, h0, u0, [2.25, 1.5, 1.])[0], [3., -10.5, -12.], what="core_h 4")
+
+
+def test_reconstructions_PLM(orc):
+    """:2184-2208 'Unlim PLM', 'Left lim PLM', 'Right lim PLM', 'Non-uniform line PLM'."""
+    for h, u, eL, eR, p1 in (([1., 1., 1.], [1., 3., 5.], [1., 2., 5.], [1., 4., 5.], [0., 2., 0.]),
+                             ([1., 1., 1.], [1., 2., 7.], [1., 1., 7.], [1., 3., 7.], [0., 2., 0.]),
+                             ([1., 1., 1.], [1., 6., 7.], [1., 5., 7.], [1., 7., 7.], [0., 2., 0.]),
+                             ([1., 2., 3.], [1., 4., 9.], [1., 2., 9.], [1., 6., 9.], [0., 4., 0.])):
+        E1, E2, C1, C2 = orc.PLM_reconstruction(h, u, H_NEGLECT)
+        eq(E1, eL, what="PLM left edges"); eq(E2, eR, what="PLM right edges"); eq(C1, eL, what="PLM P0"); eq(C2, p1, what="PLM P1")
+
+
+def test_reconstructions_H4_and_PPM(orc):
+    """:2210-2248 'Line H4' (tol 8e-15 / 1e-14), 'Line PPM', 'Parabola H4' (2.7e-14 / 4.8e-14), 'Parabola PPM', 'Limits PPM'."""
+    one = [1.] * 5
+    E1, E2 = orc.edge_values_explicit_h4(one, [1., 3., 5., 7., 9.], 1e-10)
+    eq(E1, [0., 2., 4., 6., 8.], 8.0e-15, "Line H4: left edges"); eq(E2, [2., 4., 6., 8., 10.], 1.0e-14, "Line H4: right edges")
+    e1, e2, c1, c2, c3 = orc.PPM_reconstruction(one, [1., 3., 5., 7., 9.], [0., 2., 4., 6., 8.], [2., 4., 6., 8., 10.], H_NEGLECT)
+    eq(c1, [1., 2., 4., 6., 9.], what="Line PPM: P0"); eq(c2, [0., 2., 2., 2., 0.], what="Line PPM: P1"); eq(c3, [0.] * 5, what="Line PPM: P2")
+    E1, E2 = orc.edge_values_explicit_h4(one, [1., 1., 7., 19., 37.], 1e-10)
+    eq(E1, [3., 0., 3., 12., 27.], 2.7e-14, "Parabola H4: left edges"); eq(E2, [0., 3., 12., 27., 48.], 4.8e-14, "Parabola H4: right edges")
+    e1, e2, c1, c2, c3 = orc.PPM_reconstruction(one, [0., 1., 7., 19., 37.], [0., 0., 3., 12., 27.], [0., 3., 12., 27., 48.], H_NEGLECT)
+    eq(e1, [0., 0., 3., 12., 37.], what="Parabola PPM: left edges"); eq(e2, [0., 3., 12., 27., 37.], what="Parabola PPM: right edges")
+    eq(c1, [0., 0., 3., 12., 37.], what="Parabola PPM: P0"); eq(c2, [0., 0., 6., 12., 0.], what="P1"); eq(c3, [0., 3., 3., 3., 0.], what="P2")
+    e1, e2, c1, c2, c3 = orc.PPM_reconstruction(one, [0., 5., 7., 16., 15.], [0., 0., 6., 10., 15.], [0., 6., 12., 17., 15.], H_NEGLECT)
+    eq(e1, [0., 3., 6., 16., 15.], what="Limits PPM: left edges"); eq(e2, [0., 6., 9., 16., 15.], what="Limits PPM: right edges")
+    eq(c1, [0., 3., 6., 16., 15.], what="Limits PPM: P0"); eq(c2, [0., 6., 0., 0., 0.], what="P1"); eq(c3, [0., -3., 3., 0., 0.], what="P2")
+
+
+INTERSECT = [   # :2255-2478 tests 1-6: (h0, h1, h_sub, h0_eff, isrc_start, isrc_end, isrc_max, itgt_start, itgt_end, isub_src)
+    ([3., 3.], [2., 2., 2.], [0., 2., 1., 1., 2., 0.], [3., 3.], [1, 4], [3, 5], [2, 5], [1, 3, 5], [2, 4, 6], [1, 1, 1, 2, 2, 2]),
+    ([2., 2., 2.], [3., 3.], [0., 2., 1., 1., 2., 0.], [2., 2., 2.], [1, 3, 5], [2, 4, 5], [2, 4, 5], [1, 4], [3, 6], [1, 1, 2, 2, 3, 3]),
+    ([2., 4.], [2., 2., 2.], [0., 2., 0., 2., 2., 0.], [2., 4.], [1, 3], [2, 5], [2, 5], [1, 4, 5], [3, 4, 6], [1, 1, 2, 2, 2, 2]),
+    ([2., 4.], [2., 2., 1.], [0., 2., 0., 2., 1., 1.], [2., 3.], [1, 3], [2, 6], [2, 4], [1, 4, 5], [3, 4, 5], [1, 1, 2, 2, 2, 2]),
+    ([2., 2., 1.], [2., 4.], [0., 2., 0., 2., 1., 1.], [2., 2., 1.], [1, 3, 5], [2, 4, 5], [2, 4, 5], [1, 4], [3, 6], [1, 1, 2, 2, 3, 3]),
+    ([2., 0., 2.], [1., 0., 1., 0., 2.], [0., 1., 0., 1., 0., 0., 0., 2., 0.], [2., 0., 2.], [1, 5, 6], [4, 5, 8], [4, 5, 8],
+     [1, 3, 4, 7, 8], [2, 3, 6, 7, 9], [1, 1, 1, 1, 2, 3, 3, 3, 3]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(INTERSECT)))
+def test_intersect_src_tgt_grids(orc, case):
+    h0, h1, h_sub, h0_eff, s0, e0, m0, s1, e1, src = INTERSECT[case]
+    r = orc.intersect_src_tgt_grids(h0, h1)
+    eq(r["h_sub"], h_sub, what="h_sub"); eq(r["h0_eff"], h0_eff, what="h0_eff")
+    for n, v in (("isrc_start", s0), ("isrc_end", e0), ("isrc_max", m0), ("itgt_start", s1), ("itgt_end", e1), ("isub_src", src)):
+        assert list(r[n]) == v, (n, list(r[n]), v)
+
+
+SUBGRID = [   # :2330-2478 tests 3-6: (h0, u0, h1, u_sub, u1 or None, which integrators the reference checks)
+    ([2., 4.], [2., 5.], [2., 2., 2.], [1., 2., 3., 4., 6., 7.], [2., 4., 6.], (1, 0)),
+    ([2., 4.], [2., 5.], [2., 2., 1.], [1., 2., 3., 4., 5.5, 6.5], None, (0,)),
+    ([2., 2., 1.], [2., 4., 5.5], [2., 4.], [1., 2., 3., 4., 5.5, 6.], [2., 4.875], (1, 0)),
+    ([2., 0., 2.], [2., 3., 4.], [1., 0., 1., 0., 2.], [1., 1.5, 2., 2.5, 3., 3., 3., 4., 5.], [1.5, 2., 2.5, 3., 4.], (1, 0)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SUBGRID)))
+def test_remap_src_to_sub_grid_and_back(orc, case):
+    h0, u0, h1, u_sub, u1, which = SUBGRID[case]
+    for om4 in which:
+        for bounds in (False, True):   # 'u1' and 'u1.b'
+            us, ut = orc.remap_src_to_sub_grid_plm(h0, u0, h1, om4, H_NEGLECT, force_bounds=False)
+            eq(us, u_sub, what=f"u_sub om4={om4}")
+            if u1 is not None:
+                eq(ut, u1, what=f"u1 om4={om4}")
+
+
+def test_remapping_core_h_PLM(orc):
+    """:2484-2502 'PLM: remapped h=0110->h=11' and 'h=0110->h=14' (interior layers between vanished ones)."""
+    for om4 in (1, 0):
+        CS = abi.remapping_params_default(abi.REMAP_PLM, H_NEGLECT, answer_date=20190101, om4_remap_via_sub_cells=om4)
+        eq(orc.remapping_core_h(CS, [0., 1., 1., 0.], [5., 4., 2., 1.], [1., 1.])[0], [4., 2.], what="h=0110->h=11")
+        eq(orc.remapping_core_h(CS, [0., 1., 1., 0.], [5., 4., 2., 1.], [1., 4.])[0], [4., 1.25], what="h=0110->h=14")
+
+
+@pytest.mark.parametrize("scheme", [abi.REMAP_PCM, abi.REMAP_PLM, abi.REMAP_PPM_H4])
+@pytest.mark.parametrize("om4", [0, 1])
+def test_invariants_of_the_reference_brute_force_tests(orc, scheme, om4):
+    """test_preserve_uniform :1900, test_unchanged_grid :1961 and conservation (check_remapped_values :1498) on random
+    columns, as the reference's brute-force loops do: with the bounds forced in sub-cells and targets (the switches
+    test_preserve_uniform sets) a uniform profile stays uniform (exactly for PCM; to 4 ulp with the
+    boundary-extrapolated edge values of PLM / PPM_H4, whose weighted means of equal numbers may round); an unchanged grid returns the source values to
+    round-off; the column integral is conserved to the routine's own error bound; no new extrema."""
+    rng = np.random.default_rng(42 + scheme + 10 * om4)
+    CS = abi.remapping_params_default(scheme, H_NEGLECT, om4_remap_via_sub_cells=om4)
+    CSb = abi.remapping_params_default(scheme, H_NEGLECT, om4_remap_via_sub_cells=om4, force_bounds_in_subcell=1)
+    CSn = abi.remapping_params_default(scheme, H_NEGLECT, om4_remap_via_sub_cells=om4, boundary_extrapolation=0)
+    for it in range(200):
+        n0, n1 = rng.integers(4, 12), rng.integers(2, 12)
+        h0 = rng.random(n0); h0[rng.random(n0) < 0.2] = 0.0
+        h1 = rng.random(n1); h1[rng.random(n1) < 0.2] = 0.0
+        if h0.sum() == 0 or h1.sum() == 0:
+            continue
+        h1 *= h0.sum() / h1.sum()
+        u1, err = orc.remapping_core_h(CSb, h0, np.full(n0, 3.25), h1)
+        assert np.abs(u1 - 3.25).max() <= (0.0 if scheme == abi.REMAP_PCM else 4 * np.finfo(float).eps * 3.25), (scheme, om4, u1 - 3.25)
+        u0 = rng.random(n0) * 10 - 5
+        u1, err = orc.remapping_core_h(CS, h0, u0, h0)
+        assert np.abs(u1 - u0)[h0 > 0].max() < 1e-13
+        u1, err = orc.remapping_core_h(CS, h0, u0, h1)
+        assert abs((u1 * h1).sum() - (u0 * h0).sum()) <= max(err, 1e-15) * 4 + 1e-14
+        u1, err = orc.remapping_core_h(CSn, h0, u0, h1)     # without boundary extrapolation the schemes are monotone
+        assert u1.min() >= u0.min() - 1e-12 and u1.max() <= u0.max() + 1e-12
