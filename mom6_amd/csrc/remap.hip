@@ -1,0 +1,617 @@
+// remap.hip -- MOM_remapping's remapping_core_h (OM4-era reconstructions PCM / PLM / PPM_H4, answer dates >= 20190101)
+// and the remapping half of MOM_ALE on gfx950.
+//
+//   remapping_core_h :234, build_reconstructions_1d :410, intersect_src_tgt_grids :642, remap_src_to_sub_grid_om4 :845,
+//   remap_src_to_sub_grid :962, remap_sub_to_tgt_grid_om4 :1103, average_value_ppoly :1391   (src/ALE/MOM_remapping.F90)
+//   PLM_functions.F90, PPM_functions.F90, regrid_edge_values.F90 (bound_edge_values, check_discontinuous_edge_values,
+//   edge_values_explicit_h4, end_value_h4), ALE_remap_tracers :760, ALE_remap_set_h_vel :882, ALE_remap_velocities :1089
+//
+// One thread per column, two kernels:
+//  k_remap_recon   the reconstruction (edge values, PLM slope) of every source cell.  All loops run over k with the same k
+//                  in every lane, so the column arrays (3-D scratch fields, [k][column]) are read and written coalesced.
+//  k_remap_apply   the reference builds the n0+n1+1 sub-cells of the two grids' intersection in arrays, integrates the
+//                  reconstruction over each, corrects the thickest sub-cell of every source cell so that the cell's
+//                  integral is conserved to the last bit, and sums the sub-cells of each target cell.  Per-thread arrays
+//                  of that size would live in scratch memory; here the merge is STREAMED instead: the sub-cells of one
+//                  source cell are replayed three times from a saved merge state (1: effective width and the thickest
+//                  sub-cell, 2: the sum of the other sub-cells' integrals, 3: emission into the running target sums),
+//                  so a thread carries O(1) state.  Every quantity is formed by the reference's expression in the
+//                  reference's order, so the results are bit-identical to orc_remap.c (which keeps the arrays).
+#include "mom6x_dev.h"
+#include <cfloat>
+
+namespace {
+
+struct View { size_t base, lev; };                       // element k (1-based) of a column: p[base + (k-1)*lev]
+#define AT(p, v, k) (p)[(v).base + (size_t)((k) - 1) * (v).lev]
+
+__device__ __forceinline__ double fsign(double a, double b) { return copysign(fabs(a), b); }   // Fortran sign()
+__device__ __forceinline__ double dmax3(double a, double b, double c) { return dmax(dmax(a, b), c); }
+__device__ __forceinline__ double dmin3(double a, double b, double c) { return dmin(dmin(a, b), c); }
+
+enum { INTEGRATION_PCM = 0, INTEGRATION_PLM = 1, INTEGRATION_PPM = 3 };
+
+// ---- PLM_functions.F90 --------------------------------------------------------------------------------------------
+__device__ double PLM_slope_wa(double h_l, double h_c, double h_r, double h_neglect, double u_l, double u_c, double u_r) {   // :27-66
+  const double sigma_r = u_r - u_c, sigma_l = u_c - u_l;
+  const double sigma_c = 2.0 * (u_r - u_l) * (h_c / (h_l + 2.0 * h_c + h_r + h_neglect));
+  const double u_min = dmin3(u_l, u_c, u_r), u_max = dmax3(u_l, u_c, u_r);
+  double s;
+  if ((sigma_l * sigma_r) > 0.0) s = fsign(dmin(fabs(sigma_c), 2. * dmin(u_c - u_min, u_max - u_c)), sigma_c);
+  else s = 0.0;
+  if (u_c - 0.5 * fabs(s) < u_min || u_c + 0.5 * fabs(s) > u_max) s = s * (1. - DBL_EPSILON);
+  if (fabs(s) < 1.E-140) s = 0.;
+  return s;
+}
+__device__ double PLM_monotonized_slope(double u_l, double u_c, double u_r, double s_l, double s_c, double s_r) {   // :124-162
+  const double almost_two = 2. * (1. - DBL_EPSILON);
+  const double e_r = u_l + 0.5 * s_l, e_l = u_r - 0.5 * s_r;
+  double slp = fabs(s_c);
+  double edge = u_c - 0.5 * s_c;
+  if ((edge - e_r) * (u_c - edge) < 0.) { edge = 0.5 * (edge + e_r); slp = dmin(slp, fabs(edge - u_c) * almost_two); }
+  edge = u_c + 0.5 * s_c;
+  if ((edge - u_c) * (e_l - edge) < 0.) { edge = 0.5 * (edge + e_l); slp = dmin(slp, fabs(edge - u_c) * almost_two); }
+  return fsign(slp, s_c);
+}
+__device__ double PLM_extrapolate_slope(double h_l, double h_c, double h_neglect, double u_l, double u_c) {   // :170-191
+  const double hl = h_l + h_neglect, hc = h_c + h_neglect;
+  const double left_edge = (u_l * hc + u_c * hl) / (hl + hc);
+  return 2.0 * (u_c - left_edge);
+}
+
+// ---- regrid_edge_values.F90: end_value_h4 :634-747 ------------------------------------------------------------------
+__device__ void end_value_h4(const double *dz, const double *u, double *Csys) {
+  const double min_frac = 1.0e-6;
+  double h1 = dz[0], h2 = dz[1], h3 = dz[2], h4 = dz[3];
+  if ((h2 + h3) < min_frac * h1) h3 = min_frac * h1 - h2;
+  if ((h3 + h4) < min_frac * h1) h4 = min_frac * h1 - h3;
+  const double h12 = h1 + h2, h23 = h2 + h3, h34 = h3 + h4;
+  const double h123 = h12 + h3, h234 = h2 + h34, h1234 = h12 + h34;
+  const double I_denB3 = 1.0 / (h123 * h12 * h23);
+  const double I_h12 = (h123 * h23) * I_denB3;
+  const double I_h23 = (h12 * h123) * I_denB3;
+  const double I_h123 = (h12 * h23) * I_denB3;
+  const double I_denom = 1.0 / (h1234 * (h234 * h34));
+  const double I_h234 = (h1234 * h34) * I_denom;
+  const double I_h1234 = (h234 * h34) * I_denom;
+  const double W11 = -h1 * (I_h1234 + I_h123 + I_h12);
+  const double W21 = h1 * h12 * (I_h234 * I_h1234 + I_h23 * (I_h234 + I_h123));
+  const double W31 = -h1 * h12 * h123 * I_denom;
+  const double W12 = 2.0 * (I_h12 * (1.0 + (h1 + h12) * (I_h1234 + I_h123)) + h1 * I_h1234 * I_h123);
+  const double W22 = -2.0 * ((h1 * h12 * I_h1234) * (I_h23 * (I_h234 + I_h123)) + (h1 + h12) * (I_h1234 * I_h234 + I_h23 * (I_h234 + I_h123)));
+  const double W32 = 2.0 * ((h1 + h12) * h123 + h1 * h12) * I_denom;
+  const double W13 = -3.0 * I_h12 * I_h123 * (1.0 + I_h1234 * ((h1 + h12) + h123));
+  const double W23 = 3.0 * I_h23 * (I_h123 + I_h1234 * ((h1 + h12) + h123) * (I_h123 + I_h234));
+  const double W33 = -3.0 * ((h1 + h12) + h123) * I_denom;
+  const double W14 = 4.0 * I_h1234 * I_h123 * I_h12;
+  const double W24 = -4.0 * I_h1234 * (I_h23 * (I_h123 + I_h234));
+  const double W34 = 4.0 * I_denom;
+  Csys[0] = ((u[0] + (W11 * (u[1] - u[0]))) + (W21 * (u[2] - u[1]))) + (W31 * (u[3] - u[2]));
+  Csys[1] = ((W12 * (u[1] - u[0])) + (W22 * (u[2] - u[1]))) + (W32 * (u[3] - u[2]));
+  Csys[2] = ((W13 * (u[1] - u[0])) + (W23 * (u[2] - u[1]))) + (W33 * (u[3] - u[2]));
+  Csys[3] = ((W14 * (u[1] - u[0])) + (W24 * (u[2] - u[1]))) + (W34 * (u[3] - u[2]));
+}
+
+struct ReconArgs {
+  int scheme;                 // the scheme after build_reconstructions_1d's small-n0 demotion
+  int boundary_extrapolation;
+  double h_neglect, h_neglect_edge;
+  int n0;
+};
+
+// build_reconstructions_1d :410-550 for one column.  h, u: the source column; E1, E2, C2: outputs (C2 only for PLM);
+// S1, S2: two more column arrays for PLM's first-guess and monotonized slopes.  All 1-based.
+__device__ void reconstruct_column(const ReconArgs &A, const double *__restrict__ h, const double *__restrict__ u, View vs,
+                                   double *E1, double *E2, double *C2, double *S1, double *S2, View vw) {
+  const int N = A.n0;
+#define H(k) AT(h, vs, k)
+#define U(k) AT(u, vs, k)
+#define e1(k) AT(E1, vw, k)
+#define e2(k) AT(E2, vw, k)
+  if (A.scheme == MOM6X_REMAP_PCM) {                                          // PCM_functions.F90:16-35
+    for (int k = 1; k <= N; k++) { const double v = U(k); e1(k) = v; e2(k) = v; }
+    return;
+  }
+  if (A.scheme == MOM6X_REMAP_PLM) {                                          // PLM_reconstruction :197-262
+    const double almost_one = 1. - DBL_EPSILON, hn = A.h_neglect;
+#define slp(k) AT(S1, vw, k)
+#define mslp(k) AT(S2, vw, k)
+#define c2(k) AT(C2, vw, k)
+    for (int k = 2; k <= N - 1; k++) slp(k) = PLM_slope_wa(H(k - 1), H(k), H(k + 1), hn, U(k - 1), U(k), U(k + 1));
+    slp(1) = 0.; slp(N) = 0.;
+    for (int k = 2; k <= N - 1; k++) mslp(k) = PLM_monotonized_slope(U(k - 1), U(k), U(k + 1), slp(k - 1), slp(k), slp(k + 1));
+    mslp(1) = 0.; mslp(N) = 0.;
+    e1(1) = U(1); e2(1) = U(1); c2(1) = 0.;
+    for (int k = 2; k <= N - 1; k++) {
+      const double slope = mslp(k), uk = U(k);
+      const double u_l = uk - 0.5 * slope, u_r = uk + 0.5 * slope;
+      e1(k) = u_l; e2(k) = u_r;
+      double p2 = (u_r - u_l);
+      const double edge = p2 + u_l;
+      const double e_r = U(k + 1) - 0.5 * fsign(mslp(k + 1), slp(k + 1));
+      if ((edge - uk) * (e_r - edge) < 0.) p2 = p2 * almost_one;
+      c2(k) = p2;
+    }
+    e1(N) = U(N); e2(N) = U(N); c2(N) = 0.;
+    if (A.boundary_extrapolation) {                                           // PLM_boundary_extrapolation :274-308
+      double slope = -PLM_extrapolate_slope(H(2), H(1), hn, U(2), U(1));
+      e1(1) = U(1) - 0.5 * slope; e2(1) = U(1) + 0.5 * slope;
+      c2(1) = e2(1) - e1(1);
+      slope = PLM_extrapolate_slope(H(N - 1), H(N), hn, U(N - 1), U(N));
+      e1(N) = U(N) - 0.5 * slope; e2(N) = U(N) + 0.5 * slope;
+      c2(N) = e2(N) - e1(N);
+    }
+#undef slp
+#undef mslp
+#undef c2
+    return;
+  }
+  // ---- PPM_H4: edge_values_explicit_h4 :213-348 (N >= 4)
+  {
+    const double hne = A.h_neglect_edge, hMinFrac = 1.e-5;
+    for (int i = 3; i <= N - 1; i++) {
+      double h0 = H(i - 2), h1 = H(i - 1), h2 = H(i), h3 = H(i + 1);
+      if (h0 + h1 == 0.0 || h1 + h2 == 0.0 || h2 + h3 == 0.0) {
+        const double h_min = hMinFrac * dmax(hne, (h0 + h1) + (h2 + h3));
+        h0 = dmax(h_min, H(i - 2)); h1 = dmax(h_min, H(i - 1)); h2 = dmax(h_min, H(i)); h3 = dmax(h_min, H(i + 1));
+      }
+      const double I_h12 = 1.0 / (h1 + h2);
+      const double I_den_et2 = 1.0 / (((h0 + h1) + h2) * (h0 + h1)), I_h012 = (h0 + h1) * I_den_et2;
+      const double I_den_et3 = 1.0 / ((h1 + (h2 + h3)) * (h2 + h3)), I_h123 = (h2 + h3) * I_den_et3;
+      const double et1 = (1.0 + (h1 * I_h012 + (h0 + h1) * I_h123)) * I_h12 * (h2 * (h2 + h3)) * U(i - 1) +
+                         (1.0 + (h2 * I_h123 + (h2 + h3) * I_h012)) * I_h12 * (h1 * (h0 + h1)) * U(i);
+      const double et2 = (h1 * (h2 * (h2 + h3)) * I_den_et2) * (U(i - 1) - U(i - 2));
+      const double et3 = (h2 * (h1 * (h0 + h1)) * I_den_et3) * (U(i) - U(i + 1));
+      const double ev = (et1 + (et2 + et3)) / ((h0 + h1) + (h2 + h3));
+      e1(i) = ev; e2(i - 1) = ev;
+    }
+    double dz[4], ut[4], C[4];
+    for (int i = 1; i <= 4; i++) { dz[i - 1] = dmax(hne, H(i)); ut[i - 1] = U(i); }
+    end_value_h4(dz, ut, C);
+    e1(1) = C[0];
+    e2(1) = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
+    e1(2) = e2(1);
+    for (int i = 1; i <= 4; i++) { dz[i - 1] = dmax(hne, H(N + 1 - i)); ut[i - 1] = U(N + 1 - i); }
+    end_value_h4(dz, ut, C);
+    e2(N) = C[0];
+    e1(N) = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
+    e2(N - 1) = e1(N);
+  }
+  // ---- PPM_limiter_standard :62-121: bound_edge_values :39-101
+  for (int k = 1; k <= N; k++) {
+    const int km1 = (k - 1 > 1) ? k - 1 : 1, kp1 = (k + 1 < N) ? k + 1 : N;
+    const double um = U(km1), uk = U(k), up = U(kp1), hm = H(km1), hk = H(k), hp = H(kp1);
+    double slope_x_h = 0.0;
+    if (((hm + hp) + 2.0 * hk) > 0.0) {
+      const double sigma_l = (uk - um);
+      const double sigma_c = (up - um) * (hk / ((hm + hp) + 2.0 * hk));
+      const double sigma_r = (up - uk);
+      if ((sigma_l * sigma_r) > 0.0) slope_x_h = fsign(dmin3(fabs(sigma_l), fabs(sigma_c), fabs(sigma_r)), sigma_c);
+    }
+    double a = e1(k), b = e2(k);
+    if ((um - a) * (a - uk) < 0.0) a = uk - fsign(dmin(fabs(slope_x_h), fabs(a - uk)), slope_x_h);
+    if ((up - b) * (b - uk) < 0.0) b = uk + fsign(dmin(fabs(slope_x_h), fabs(b - uk)), slope_x_h);
+    a = dmax(dmin(a, dmax(um, uk)), dmin(um, uk));
+    b = dmax(dmin(b, dmax(up, uk)), dmin(up, uk));
+    e1(k) = a; e2(k) = b;
+  }
+  for (int k = 1; k <= N - 1; k++) {                                          // check_discontinuous_edge_values :132-150
+    const double uk = U(k), up = U(k + 1);
+    if ((e1(k + 1) - e2(k)) * (up - uk) < 0.0) {
+      double u0_avg = 0.5 * (e2(k) + e1(k + 1));
+      u0_avg = dmax(dmin(u0_avg, dmax(uk, up)), dmin(uk, up));
+      e2(k) = u0_avg; e1(k + 1) = u0_avg;
+    }
+  }
+  for (int k = 2; k <= N - 1; k++) {                                          // :80-116
+    const double u_l = U(k - 1), u_c = U(k), u_r = U(k + 1);
+    double edge_l = e1(k), edge_r = e2(k);
+    if ((u_r - u_c) * (u_c - u_l) <= 0.0) {
+      edge_l = u_c; edge_r = u_c;
+    } else {
+      const double expr1 = 3.0 * (edge_r - edge_l) * ((u_c - edge_l) + (u_c - edge_r));
+      const double expr2 = (edge_r - edge_l) * (edge_r - edge_l);
+      if (expr1 > expr2) {
+        edge_l = u_c + 2.0 * (u_c - edge_r);
+        edge_l = dmax(dmin(edge_l, dmax(u_l, u_c)), dmin(u_l, u_c));
+      } else if (expr1 < -expr2) {
+        edge_r = u_c + 2.0 * (u_c - edge_l);
+        edge_r = dmax(dmin(edge_r, dmax(u_r, u_c)), dmin(u_r, u_c));
+      }
+    }
+    if (fabs(edge_r - edge_l) < dmax(1.e-60, DBL_EPSILON * fabs(u_c))) { edge_l = u_c; edge_r = u_c; }
+    e1(k) = edge_l; e2(k) = edge_r;
+  }
+  e1(1) = U(1); e2(1) = U(1);
+  e1(N) = U(N); e2(N) = U(N);
+  if (A.boundary_extrapolation) {                                             // PPM_boundary_extrapolation :166-296
+    const double hn = A.h_neglect;
+    {
+      const double h0 = H(1), h1 = H(2), u0 = U(1), u1 = U(2);
+      const double b = 4.0 * (u1 - e1(2)) + 2.0 * (u1 - e2(2));               // ppoly_coef(2,2) of PPM_reconstruction :49
+      double u1_r = b * ((h0 + hn) / (h1 + hn));
+      const double slope = 2.0 * (u1 - u0);
+      if (fabs(u1_r) > fabs(slope)) u1_r = slope;
+      double u0_r = e1(2);
+      double u0_l = 3.0 * u0 + 0.5 * u1_r - 2.0 * u0_r;
+      const double exp1 = (u0_r - u0_l) * (u0 - 0.5 * (u0_l + u0_r));
+      const double exp2 = (u0_r - u0_l) * (u0_r - u0_l) / 6.0;
+      if (exp1 > exp2) u0_l = 3.0 * u0 - 2.0 * u0_r;
+      if (exp1 < -exp2) u0_r = 3.0 * u0 - 2.0 * u0_l;
+      e1(1) = u0_l; e2(1) = u0_r;
+    }
+    {
+      const double h0 = H(N - 1), h1 = H(N), u0 = U(N - 1), u1 = U(N);
+      const double b = 4.0 * (u0 - e1(N - 1)) + 2.0 * (u0 - e2(N - 1));       // ppoly_coef(N-1,2)
+      const double c = 3.0 * ((e2(N - 1) - u0) + (e1(N - 1) - u0));           // ppoly_coef(N-1,3)
+      double u1_l = (b + 2 * c);
+      u1_l = u1_l * ((h1 + hn) / (h0 + hn));
+      const double slope = 2.0 * (u1 - u0);
+      if (fabs(u1_l) > fabs(slope)) u1_l = slope;
+      double u0_l = e2(N - 1);
+      double u0_r = 3.0 * u1 - 0.5 * u1_l - 2.0 * u0_l;
+      const double exp1 = (u0_r - u0_l) * (u1 - 0.5 * (u0_l + u0_r));
+      const double exp2 = (u0_r - u0_l) * (u0_r - u0_l) / 6.0;
+      if (exp1 > exp2) u0_l = 3.0 * u1 - 2.0 * u0_r;
+      if (exp1 < -exp2) u0_r = 3.0 * u1 - 2.0 * u0_l;
+      e1(N) = u0_l; e2(N) = u0_r;
+    }
+  }
+#undef H
+#undef U
+#undef e1
+#undef e2
+}
+
+// average_value_ppoly :1391-1494 for PCM / PLM / PPM; a_L, a_R, u_c, p2 = E(i0,1), E(i0,2), u0(i0), coefs(i0,2) [PLM]
+__device__ __forceinline__ double average_value(int method, double a_L, double a_R, double u_c, double p2, double xa, double xb) {
+  if (xb > xa) {
+    if (method == INTEGRATION_PCM) return u_c;
+    if (method == INTEGRATION_PLM) return (a_L + p2 * 0.5 * (xb + xa));
+    const double mx = 0.5 * (xa + xb);
+    const double a_c = 0.5 * ((u_c - a_L) + (u_c - a_R));
+    if (mx < 0.5) {
+      const double xa2b2ab = (xa * xa + xb * xb) + xa * xb;
+      return a_L + ((a_R - a_L) * mx + a_c * (3. * (xb + xa) - 2. * xa2b2ab));
+    }
+    const double Ya = 1. - xa, Yb = 1. - xb, my = 0.5 * (Ya + Yb);
+    const double Ya2b2ab = (Ya * Ya + Yb * Yb) + Ya * Yb;
+    return a_R + ((a_L - a_R) * my + a_c * (3. * (Yb + Ya) - 2. * Ya2b2ab));
+  }
+  if (method == INTEGRATION_PCM) return u_c;       // ppoly0_coefs(i0,1) of PCM = u0(i0)
+  const double Ya = 1. - xa;
+  if (method == INTEGRATION_PLM) {
+    if (xa < 0.5) return a_L + xa * (a_R - a_L);
+    return a_R + Ya * (a_L - a_R);
+  }
+  const double a_c = 3. * ((u_c - a_L) + (u_c - a_R));
+  if (xa < 0.5) return a_L + xa * ((a_R - a_L) + a_c * Ya);
+  return a_R + Ya * ((a_L - a_R) + a_c * xa);
+}
+
+struct Merge {            // the running state of intersect_src_tgt_grids' loop :688-795
+  double h0s, h1s;        // h0_supply, h1_supply
+  int i0, i1;
+  bool src, tgt;          // src_has_volume, tgt_has_volume
+};
+enum { EV_SRC = 1, EV_TGT = 2 };
+
+struct ApplyArgs {
+  int n0, n1, method, om4, fb_sub, fb_tgt;
+};
+
+// one iteration of the loop: the new sub-cell's raw width dh (for h0_eff and the thickest-sub-cell test), its stored
+// width h_sub, and which cell it closes
+__device__ __forceinline__ int merge_step(Merge &m, const double *__restrict__ h0, View v0, const double *__restrict__ h1, View v1,
+                                          int n0, int n1, double &dh, double &h_sub, double &eff) {
+  dh = dmin(m.h0s, m.h1s);
+  eff = dmin(dh, m.h0s);
+  h_sub = dh;
+  int ev;
+  if (m.h0s <= m.h1s && m.src) { m.h1s = m.h1s - dh; ev = EV_SRC; }
+  else if (m.h0s >= m.h1s && m.tgt) { m.h0s = m.h0s - dh; ev = EV_TGT; }
+  else if (m.src) { h_sub = m.h0s; ev = EV_SRC; }
+  else { h_sub = m.h1s; ev = EV_TGT; }
+  if (ev == EV_SRC) {
+    if (m.i0 < n0) { m.i0 = m.i0 + 1; m.h0s = AT(h0, v0, m.i0); }
+    else { m.h0s = 0.; m.src = false; }
+  } else {
+    if (m.i1 < n1) { m.i1 = m.i1 + 1; m.h1s = AT(h1, v1, m.i1); }
+    else { m.h1s = 0.; m.tgt = false; }
+  }
+  return ev;
+}
+
+struct Target {           // remap_sub_to_tgt_grid_om4 :1125-1160, one target cell at a time
+  double dh, duh, umin, umax, ufirst;
+  bool started;
+};
+__device__ __forceinline__ void tgt_reset(Target &t) { t.dh = 0.; t.duh = 0.; t.umin = 0.; t.umax = 0.; t.ufirst = 0.; t.started = false; }
+__device__ __forceinline__ void tgt_feed(Target &t, double hs, double u, double uh, int fb) {
+  if (!t.started) { t.ufirst = u; t.umin = u; t.umax = u; t.started = true; }
+  if (fb) { t.umin = dmin(t.umin, u); t.umax = dmax(t.umax, u); }
+  t.dh = t.dh + hs;
+  t.duh = t.duh + uh;
+}
+__device__ __forceinline__ double tgt_close(Target &t, double h1, int fb) {
+  double r;
+  if (h1 > 0.) {
+    r = t.duh / t.dh;
+    if (fb) r = dmax(t.umin, dmin(t.umax, r));
+  } else r = t.ufirst;
+  tgt_reset(t);
+  return r;
+}
+
+// remapping_core_h :234 for one column (after reconstruct_column).  u1 may alias the array the source values came from
+// as long as `u0` points to a copy.
+__device__ void apply_column(const ApplyArgs &A, const double *__restrict__ h0, const double *__restrict__ u0, View v0,
+                             const double *__restrict__ E1, const double *__restrict__ E2, const double *__restrict__ C2, View vw,
+                             const double *__restrict__ h1, double *u1, View v1) {
+  const int n0 = A.n0, n1 = A.n1, ns = n0 + n1 + 1, method = A.method;
+  int last_thick = 0;
+  for (int k = 1; k <= n0; k++) if (AT(h0, v0, k) > 0.) last_thick = k;          // i0_last_thick_cell :884-889
+  Merge m; m.h0s = AT(h0, v0, 1); m.h1s = AT(h1, v1, 1); m.i0 = 1; m.i1 = 1; m.src = true; m.tgt = true;
+  Target T; tgt_reset(T);
+  int i_sub = 1;            // the index of the last sub-cell made
+  // the source cell being integrated
+  double a_L = AT(E1, vw, 1), a_R = AT(E2, vw, 1), u_c = AT(u0, v0, 1), p2 = (method == INTEGRATION_PLM) ? AT(C2, vw, 1) : 0.;
+  double hsrc = AT(h0, v0, 1);
+  // sub-cell 1 (zero width, top edge): :716-720, :893-894 / :1012-1030
+  double u_s1 = A.om4 ? a_L : ((hsrc > 0.) ? average_value(method, a_L, a_R, u_c, p2, 0., 0.) : u_c);
+  if (A.fb_sub && !A.om4) { u_s1 = dmax(u_s1, dmin(a_L, a_R)); u_s1 = dmin(u_s1, dmax(a_L, a_R)); }
+  const double uh_s1 = A.om4 ? 0. : 0. * u_s1;
+  tgt_feed(T, 0., u_s1, uh_s1, A.fb_tgt);
+  double xa = 0., cum = 0., h0_eff_last = 0.;
+  // xa, cum after the zero-width sub-cell: non-OM4 runs it through the loop (dh0_eff += 0, xb = 0 or, for a vanished
+  // first cell, 1); OM4 starts the loop at sub-cell 2 with xa = 0
+  if (!A.om4) { xa = (hsrc > 0.) ? dmin(1., 0. / hsrc) : 1.; }
+  while (m.src) {
+    const Merge s = m;
+    const int i0 = m.i0;
+    const double umin0 = dmin(a_L, a_R), umax0 = dmax(a_L, a_R);
+    // ---- pass 1: the cell's sub-cells, its effective width h0_eff :722-747 and the thickest sub-cell :726-729
+    Merge t = s;
+    int cnt = 0, imax = -1;
+    double dh_max = 0., h0_eff = 0., hsub_imax = 0.;
+    {
+      int ev;
+      do {
+        double dh, hs, eff;
+        ev = merge_step(t, h0, v0, h1, v1, n0, n1, dh, hs, eff);
+        h0_eff = h0_eff + eff;
+        if (dh >= dh_max) { imax = cnt; dh_max = dh; hsub_imax = hs; }
+        cnt++;
+      } while (ev != EV_SRC);
+    }
+    const double den = A.om4 ? h0_eff : hsrc;
+    h0_eff_last = h0_eff;
+    // ---- pass 2: sum of u*h over the sub-cells other than the thickest :939-957
+    double duh = 0.;
+    if (i0 == 1) duh = duh + uh_s1;
+    {
+      t = s;
+      double xa2 = xa, cum2 = cum;
+      for (int c = 0; c < cnt; c++) {
+        double dh, hs, eff;
+        merge_step(t, h0, v0, h1, v1, n0, n1, dh, hs, eff);
+        double u, uh;
+        if (A.om4 && (i_sub + 1 + c) == ns) { u = AT(E2, vw, n0); uh = u * hs; }
+        else {
+          cum2 = cum2 + hs;
+          double xb;
+          if (den > 0.) { xb = dmin(1., cum2 / den); u = average_value(method, a_L, a_R, u_c, p2, xa2, xb); }
+          else { xb = 1.; u = u_c; }
+          if (A.fb_sub) { u = dmax(u, umin0); u = dmin(u, umax0); }
+          uh = hs * u;
+          xa2 = xb;
+        }
+        if (c != imax) duh = duh + uh;
+      }
+    }
+    const bool adjust = (i0 <= last_thick) && (hsub_imax > 0.);
+    const double uh_adj = u_c * hsrc - duh;
+    // ---- pass 3: emit the sub-cells into the target sums
+    {
+      t = s;
+      for (int c = 0; c < cnt; c++) {
+        const bool has_tgt = t.tgt;
+        const int i1 = t.i1;
+        double dh, hs, eff;
+        const int ev = merge_step(t, h0, v0, h1, v1, n0, n1, dh, hs, eff);
+        i_sub++;
+        double u, uh;
+        if (A.om4 && i_sub == ns) { u = AT(E2, vw, n0); uh = u * hs; }
+        else {
+          cum = cum + hs;
+          double xb;
+          if (den > 0.) { xb = dmin(1., cum / den); u = average_value(method, a_L, a_R, u_c, p2, xa, xb); }
+          else { xb = 1.; u = u_c; }
+          if (A.fb_sub) { u = dmax(u, umin0); u = dmin(u, umax0); }
+          uh = hs * u;
+          xa = xb;
+        }
+        if (adjust && c == imax) uh = uh_adj;
+        if (has_tgt) {
+          tgt_feed(T, hs, u, uh, A.fb_tgt);
+          if (ev == EV_TGT) AT(u1, v1, i1) = tgt_close(T, AT(h1, v1, i1), A.fb_tgt);
+        }
+      }
+    }
+    m = t;
+    if (m.src) {          // the next source cell: "dh0_eff = 0 ; xa = 0" :932-934
+      xa = 0.; cum = 0.;
+      a_L = AT(E1, vw, m.i0); a_R = AT(E2, vw, m.i0); u_c = AT(u0, v0, m.i0); hsrc = AT(h0, v0, m.i0);
+      if (method == INTEGRATION_PLM) p2 = AT(C2, vw, m.i0);
+    }
+  }
+  // ---- the target column is deeper than the source column: the remaining sub-cells continue the last source cell
+  {
+    const double dd = A.om4 ? h0_eff_last : hsrc;   // h0_eff(n0) | h0(n0)
+    const double umin0 = dmin(a_L, a_R), umax0 = dmax(a_L, a_R);
+    while (m.tgt) {
+      const int i1 = m.i1;
+      double dh, hs, eff;
+      merge_step(m, h0, v0, h1, v1, n0, n1, dh, hs, eff);
+      i_sub++;
+      double u, uh;
+      if (A.om4 && i_sub == ns) { u = AT(E2, vw, n0); uh = u * hs; }
+      else {
+        cum = cum + hs;
+        double xb;
+        if (dd > 0.) { xb = dmin(1., cum / dd); u = average_value(method, a_L, a_R, u_c, p2, xa, xb); }
+        else { xb = 1.; u = u_c; }
+        if (A.fb_sub) { u = dmax(u, umin0); u = dmin(u, umax0); }
+        uh = hs * u;
+        xa = xb;
+      }
+      tgt_feed(T, hs, u, uh, A.fb_tgt);
+      AT(u1, v1, i1) = tgt_close(T, AT(h1, v1, i1), A.fb_tgt);
+    }
+  }
+}
+
+struct Fields { double *p[8]; };
+
+// the 3-D form: columns (i0..i1, j0..j1) with mask > 0; h_old / h_new / fields on the same staggering
+__global__ void __launch_bounds__(256)
+k_remap_recon(Dm d, const double *__restrict__ mask, ReconArgs A, const double *__restrict__ h_old, const double *__restrict__ f,
+              double *E1, double *E2, double *C2, double *S1, double *S2, double *Ucopy, int i0, int i1, int j0, int j1) {
+  const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < i0 || i > i1 || j > j1) return;
+  const size_t x = ix2(d, i, j);
+  if (!(mask[x] > 0.)) return;
+  View v; v.base = x; v.lev = (size_t)d.slab;
+  reconstruct_column(A, h_old, f, v, E1, E2, C2, S1, S2, v);
+  for (int k = 1; k <= A.n0; k++) AT(Ucopy, v, k) = AT(f, v, k);
+}
+__global__ void __launch_bounds__(256)
+k_remap_apply(Dm d, const double *__restrict__ mask, ApplyArgs A, const double *__restrict__ h_old, const double *__restrict__ h_new,
+              const double *__restrict__ E1, const double *__restrict__ E2, const double *__restrict__ C2,
+              const double *__restrict__ Ucopy, double *f, int i0, int i1, int j0, int j1) {
+  const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < i0 || i > i1 || j > j1) return;
+  const size_t x = ix2(d, i, j);
+  if (!(mask[x] > 0.)) return;
+  View v; v.base = x; v.lev = (size_t)d.slab;
+  apply_column(A, h_old, Ucopy, v, E1, E2, C2, v, h_new, f, v);
+}
+// the packed form of the unit tests: column c holds n0 | n1 values back to back; work arrays are [k][ncol]
+__global__ void __launch_bounds__(64)
+k_remap_packed(int ncol, ReconArgs R, ApplyArgs A, const double *__restrict__ h0, const double *__restrict__ u0,
+               const double *__restrict__ h1, double *u1, double *E1, double *E2, double *C2, double *S1, double *S2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncol) return;
+  View v0, v1, vw;
+  v0.base = (size_t)c * A.n0; v0.lev = 1; v1.base = (size_t)c * A.n1; v1.lev = 1; vw.base = c; vw.lev = ncol;
+  reconstruct_column(R, h0, u0, v0, E1, E2, C2, S1, S2, vw);
+  apply_column(A, h0, u0, v0, E1, E2, C2, vw, h1, u1, v1);
+}
+
+__global__ void __launch_bounds__(256)
+k_set_h_vel(Dm d, const double *__restrict__ G, const double *__restrict__ h_new, double *__restrict__ h_u, double *__restrict__ h_v) {
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -1 || i > d.ni - 1 || j > d.nj - 1) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const bool do_u = (j >= 0) && (gm(G, d, MOM6X_G_mask2dCu)[x] > 0.), do_v = (i >= 0) && (gm(G, d, MOM6X_G_mask2dCv)[x] > 0.);
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double hc = h_new[c];
+    if (do_u) h_u[c] = 0.5 * (hc + h_new[c + 1]);
+    if (do_v) h_v[c] = 0.5 * (hc + h_new[c + d.pitch]);
+  }
+}
+
+int check_params(const mom6x_remapping_params *p, int n0, ReconArgs &R, ApplyArgs &A, int n1) {
+  REQUIRE(p, MOM6X_EINVAL, "remapping: null parameters");
+  REQUIRE(p->scheme == MOM6X_REMAP_PCM || p->scheme == MOM6X_REMAP_PLM || p->scheme == MOM6X_REMAP_PPM_H4, MOM6X_EUNSUPPORTED,
+          "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid");
+  REQUIRE(p->answer_date >= 20190101, MOM6X_EUNSUPPORTED, "remapping: REMAPPING_ANSWER_DATE < 20190101 is not on the device path");
+  REQUIRE(n0 >= 1 && n1 >= 1, MOM6X_EINVAL, "remapping: empty column");
+  int scheme = p->scheme;                                   // :441-447
+  if (n0 <= 1) scheme = MOM6X_REMAP_PCM;
+  else if (n0 <= 3) scheme = std::min(scheme, (int)MOM6X_REMAP_PLM);
+  else if (n0 <= 4) scheme = std::min(scheme, (int)MOM6X_REMAP_PPM_H4);
+  R.scheme = scheme; R.boundary_extrapolation = p->boundary_extrapolation; R.h_neglect = p->h_neglect;
+  R.h_neglect_edge = p->h_neglect_edge; R.n0 = n0;
+  A.n0 = n0; A.n1 = n1; A.om4 = p->om4_remap_via_sub_cells; A.fb_sub = p->force_bounds_in_subcell; A.fb_tgt = p->force_bounds_in_target;
+  A.method = (scheme == MOM6X_REMAP_PCM) ? INTEGRATION_PCM : (scheme == MOM6X_REMAP_PLM ? INTEGRATION_PLM : INTEGRATION_PPM);
+  return MOM6X_OK;
+}
+
+// remap one 3-D field in place on the points (i0..i1, j0..j1) where mask > 0
+int remap_field(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int i0, int i1, int j0, int j1, const double *h_old,
+                const double *h_new, double *f) {
+  const Dm d = c->d;
+  ReconArgs R; ApplyArgs A;
+  int rc = check_params(p, d.nk, R, A, d.nk);
+  if (rc) return rc;
+  double *E1, *E2, *C2, *S1, *S2, *Uc;
+  if ((rc = ctx_scratch(c, SCR_t0, d.nk, &E1)) || (rc = ctx_scratch(c, SCR_t1, d.nk, &E2)) || (rc = ctx_scratch(c, SCR_t2, d.nk, &C2)) ||
+      (rc = ctx_scratch(c, SCR_t3, d.nk, &S1)) || (rc = ctx_scratch(c, SCR_q, d.nk, &S2)) || (rc = ctx_scratch(c, SCR_KE, d.nk, &Uc)))
+    return rc;
+  const dim3 b(64, 4, 1);
+  const dim3 g = grid3(nxa(i1 - i0 + 1, i0), j1 - j0 + 1, 1, b);
+  const double *mask = c->G + (size_t)mask_id * d.slab;
+  KLAUNCH(c, "k_remap_recon", k_remap_recon, g, b, d, mask, R, h_old, (const double *)f, E1, E2, C2, S1, S2, Uc, i0, i1, j0, j1);
+  KLAUNCH(c, "k_remap_apply", k_remap_apply, g, b, d, mask, A, h_old, h_new, (const double *)E1, (const double *)E2, (const double *)C2,
+          (const double *)Uc, f, i0, i1, j0, j1);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+}  // namespace
+
+extern "C" int mom6x_ALE_remap_tracers(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old, const double *h_new,
+                                       double *const *fields, int nfields) {
+  REQUIRE(c && p && h_old && h_new && (fields || nfields == 0), MOM6X_EINVAL, "ALE_remap_tracers: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  for (int m = 0; m < nfields; m++) {
+    REQUIRE(fields[m], MOM6X_EINVAL, "ALE_remap_tracers: null tracer array");
+    int rc = remap_field(c, p, MOM6X_G_mask2dT, 0, c->d.ni - 1, 0, c->d.nj - 1, h_old, h_new, fields[m]);
+    if (rc) return rc;
+  }
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_ALE_remap_set_h_vel(mom6x_ctx *c, const double *h_new, double *h_u, double *h_v) {
+  REQUIRE(c && h_new && h_u && h_v, MOM6X_EINVAL, "ALE_remap_set_h_vel: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  const dim3 b(64, 4, 1);
+  KLAUNCH(c, "k_set_h_vel", k_set_h_vel, grid3(nxa(d.ni + 1, -1), d.nj + 1, nchunks(d.nk), b), b, d, c->G, h_new, h_u, h_v);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_ALE_remap_velocities(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old_u, const double *h_old_v,
+                                          const double *h_new_u, const double *h_new_v, double *u, double *v) {
+  REQUIRE(c && p && h_old_u && h_old_v && h_new_u && h_new_v && u && v, MOM6X_EINVAL, "ALE_remap_velocities: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = remap_field(c, p, MOM6X_G_mask2dCu, -1, c->d.ni - 1, 0, c->d.nj - 1, h_old_u, h_new_u, u);
+  if (rc) return rc;
+  return remap_field(c, p, MOM6X_G_mask2dCv, 0, c->d.ni - 1, -1, c->d.nj - 1, h_old_v, h_new_v, v);
+}
+
+extern "C" int mom6x_remapping_core_h(mom6x_ctx *c, const mom6x_remapping_params *p, int ncol, int n0, const double *h0,
+                                      const double *u0, int n1, const double *h1, double *u1) {
+  REQUIRE(c && h0 && u0 && h1 && u1 && ncol >= 1, MOM6X_EINVAL, "remapping_core_h: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  ReconArgs R; ApplyArgs A;
+  int rc = check_params(p, n0, R, A, n1);
+  if (rc) return rc;
+  double *w = nullptr;
+  const size_t per = (size_t)n0 * ncol;
+  HIPCHK(hipMalloc(&w, 5 * per * sizeof(double)));
+  KLAUNCH(c, "k_remap_packed", k_remap_packed, dim3((ncol + 63) / 64), dim3(64), ncol, R, A, h0, u0, h1, u1, w, w + per, w + 2 * per,
+          w + 3 * per, w + 4 * per);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  (void)hipFree(w);
+  HIPCHK(e);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}

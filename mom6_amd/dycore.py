@@ -212,6 +212,26 @@ class Dycore:
         """horizontal_viscosity (MOM_hor_visc.F90:266)."""
         check(self.lib, self.lib.mom6x_horizontal_viscosity(self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(diffu), _ptr(diffv)))
 
+    # ---- MOM_remapping / MOM_ALE (SURVEY 8f-3)
+    def ALE_remap_tracers(self, CS, h_old, h_new, fields):
+        """ALE_remap_tracers (MOM_ALE.F90:760): remapping_core_h of every wet column of every field, in place."""
+        ptrs = (C.c_void_p * len(fields))(*[f.data_ptr() for f in fields])
+        check(self.lib, self.lib.mom6x_ALE_remap_tracers(self.ctx, C.byref(CS), _ptr(h_old), _ptr(h_new), ptrs, len(fields)))
+
+    def ALE_remap_set_h_vel(self, h_new, h_u, h_v):
+        """ALE_remap_set_h_vel (MOM_ALE.F90:882)."""
+        check(self.lib, self.lib.mom6x_ALE_remap_set_h_vel(self.ctx, _ptr(h_new), _ptr(h_u), _ptr(h_v)))
+
+    def ALE_remap_velocities(self, CS, h_old_u, h_old_v, h_new_u, h_new_v, u, v):
+        """ALE_remap_velocities (MOM_ALE.F90:1089)."""
+        check(self.lib, self.lib.mom6x_ALE_remap_velocities(self.ctx, C.byref(CS), _ptr(h_old_u), _ptr(h_old_v), _ptr(h_new_u),
+                                                            _ptr(h_new_v), _ptr(u), _ptr(v)))
+
+    def remapping_core_h(self, CS, h0, u0, h1, u1):
+        """remapping_core_h (MOM_remapping.F90:234) for [ncol][n0] | [ncol][n1] device arrays."""
+        ncol, n0 = h0.shape; n1 = h1.shape[1]
+        check(self.lib, self.lib.mom6x_remapping_core_h(self.ctx, C.byref(CS), ncol, n0, _ptr(h0), _ptr(u0), n1, _ptr(h1), _ptr(u1)))
+
     def vertvisc(self, u, v, taux, tauy, dt, taux_bot=None, tauy_bot=None):
         """vertvisc (MOM_vert_friction.F90:557)."""
         check(self.lib, self.lib.mom6x_vertvisc(self.ctx, _ptr(u), _ptr(v), _ptr(taux), _ptr(tauy), C.c_double(dt),

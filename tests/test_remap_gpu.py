@@ -1,0 +1,131 @@
+"""MOM_remapping / ALE remapping on the device: the reference's own known answers (remapping_unit_tests) through the
+C ABI, and bit-for-bit parity with the oracle (which tests/test_remap_cpu.py pins to the same known answers)."""
+import numpy as np
+import pytest
+
+from mom6_amd import abi, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+G = abi.G
+H_NEGLECT = 1.0e-30
+
+
+def dev_core_h(dyc, CS, h0, u0, h1):
+    import torch
+    t = lambda a: torch.tensor(np.atleast_2d(np.asarray(a, dtype=np.float64)), device=dyc.device)
+    h0d, u0d, h1d = t(h0), t(u0), t(h1)
+    u1d = torch.zeros_like(h1d)
+    torch.cuda.synchronize()
+    dyc.remapping_core_h(CS, h0d, u0d, h1d, u1d)
+    dyc.sync()
+    return u1d.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def dyc():
+    from mom6_amd.dycore import Dycore
+    gg, d, M = H.double_gyre()
+    x = Dycore(d, M, abi.vgrid_default())
+    yield x
+    x.close()
+
+
+def test_reference_known_answers_on_the_device(dyc):
+    """remapping_unit_tests :2125-2166 (PPM_H4 'remapping_core_h() 2/3/4') and :2484-2502 (PLM h=0110) through
+    mom6x_remapping_core_h -- the expected values are the reference's."""
+    CS = abi.remapping_params_default(abi.REMAP_PPM_H4, H_NEGLECT, answer_date=20190101)
+    h0, u0 = [0.75] * 4, [9., 3., -3., -9.]
+    assert np.array_equal(dev_core_h(dyc, CS, h0, u0, [0.5] * 6)[0], [10., 6., 2., -2., -6., -10.])
+    assert np.array_equal(dev_core_h(dyc, CS, h0, u0, [.125] * 6)[0], [11.5, 10.5, 9.5, 8.5, 7.5, 6.5])
+    assert np.array_equal(dev_core_h(dyc, CS, h0, u0, [2.25, 1.5, 1.])[0], [3., -10.5, -12.])
+    for om4 in (1, 0):
+        CS = abi.remapping_params_default(abi.REMAP_PLM, H_NEGLECT, answer_date=20190101, om4_remap_via_sub_cells=om4)
+        assert np.array_equal(dev_core_h(dyc, CS, [0., 1., 1., 0.], [5., 4., 2., 1.], [1., 1.])[0], [4., 2.])
+        assert np.array_equal(dev_core_h(dyc, CS, [0., 1., 1., 0.], [5., 4., 2., 1.], [1., 4.])[0], [4., 1.25])
+    # sub-grid tests 3, 5, 6 (:2330-2478): PLM with boundary extrapolation, final target values
+    CS = abi.remapping_params_default(abi.REMAP_PLM, H_NEGLECT, answer_date=20190101, force_bounds_in_target=0)
+    assert np.array_equal(dev_core_h(dyc, CS, [2., 4.], [2., 5.], [2., 2., 2.])[0], [2., 4., 6.])
+    assert np.array_equal(dev_core_h(dyc, CS, [2., 2., 1.], [2., 4., 5.5], [2., 4.])[0], [2., 4.875])
+    assert np.array_equal(dev_core_h(dyc, CS, [2., 0., 2.], [2., 3., 4.], [1., 0., 1., 0., 2.])[0], [1.5, 2., 2.5, 3., 4.])
+
+
+@pytest.mark.parametrize("scheme", [abi.REMAP_PCM, abi.REMAP_PLM, abi.REMAP_PPM_H4])
+@pytest.mark.parametrize("mods", [dict(), dict(om4_remap_via_sub_cells=1), dict(boundary_extrapolation=0, force_bounds_in_subcell=1),
+                                  dict(om4_remap_via_sub_cells=1, force_bounds_in_target=0, boundary_extrapolation=0)])
+def test_random_columns_bitwise(orc, dyc, scheme, mods):
+    """Ragged columns as the reference's brute-force tests draw them: vanished layers in both grids, target columns
+    shallower and deeper than the source, n0 != n1 from 1 to 40 layers."""
+    rng = np.random.default_rng(7 + scheme)
+    CS = abi.remapping_params_default(scheme, H_NEGLECT, **mods)
+    for n0, n1 in ((1, 3), (2, 2), (3, 7), (4, 4), (5, 2), (9, 12), (25, 40), (40, 17), (75, 75)):
+        ncol = 193
+        h0 = rng.random((ncol, n0)); h0[rng.random((ncol, n0)) < 0.15] = 0.0
+        h1 = rng.random((ncol, n1)); h1[rng.random((ncol, n1)) < 0.15] = 0.0
+        h0[:, 0] += 1e-3; h1[:, 0] += 1e-3
+        scale = h0.sum(1) / h1.sum(1)
+        h1 *= scale[:, None] * np.where(np.arange(ncol) % 3 == 0, 1.0, np.where(np.arange(ncol) % 3 == 1, 0.8, 1.3))[:, None]
+        h1[::7] = h0[::7, :1] * 0 + h1[::7]          # (no-op; keeps the generator's stream aligned)
+        if n0 == n1:
+            h1[::5] = h0[::5]                          # unchanged grids
+        u0 = rng.random((ncol, n0)) * 20 - 5
+        u0[::11] = 3.25                                # uniform columns
+        ref = orc.remapping_core_h_cols(CS, h0, u0, h1)
+        got = dev_core_h(dyc, CS, h0, u0, h1)
+        H.assert_bitwise(got, ref, f"remapping_core_h n0={n0} n1={n1}")
+
+
+@pytest.mark.parametrize("cfg", ["island_basin", "benchmark_small"])
+@pytest.mark.parametrize("scheme,mods", [(abi.REMAP_PPM_H4, dict(om4_remap_via_sub_cells=1, boundary_extrapolation=0)),
+                                         (abi.REMAP_PLM, dict()), (abi.REMAP_PCM, dict())])
+def test_ALE_remap_tracers_and_velocities(orc, cfg, scheme, mods):
+    """The 3-D entry points on a basin with land: two tracers remapped in place from the model's layers to a z*-like
+    grid with the same column thickness, then the velocities with ALE_remap_set_h_vel's face thicknesses."""
+    import torch
+    from mom6_amd.dycore import Dycore
+    gg, d, M = getattr(H, cfg)(nk=12)
+    GV = abi.vgrid_default()
+    CS = abi.remapping_params_default(scheme, GV.H_subroundoff, **mods)
+    h_old, u, v = synth.make_state(d, M, thin_frac=0.15)
+    tot = h_old.sum(0)
+    w = np.linspace(1.0, 3.0, d.nk)[:, None, None] * (1.0 + 0.3 * synth.smooth_field(d, 5, nk=d.nk, ox=0.5, oy=0.5))
+    h_new = np.ascontiguousarray(w / w.sum(0) * tot)
+    trs = [np.ascontiguousarray(10.0 + 5.0 * synth.smooth_field(d, 70 + m, nk=d.nk, ox=0.5, oy=0.5)) for m in range(2)]
+    tro = [t.copy() for t in trs]
+    orc.ALE_remap_tracers(d, M, CS, h_old, h_new, tro)
+    hu_o, hv_o, hu_n, hv_n = (np.full_like(h_old, 1.0e-3) for _ in range(4))
+    orc.ALE_remap_set_h_vel(d, M, h_old, hu_o, hv_o); orc.ALE_remap_set_h_vel(d, M, h_new, hu_n, hv_n)
+    uo, vo = u.copy(), v.copy()
+    orc.ALE_remap_velocities(d, M, CS, hu_o, hv_o, hu_n, hv_n, uo, vo)
+
+    dyc = Dycore(d, M, GV)
+    hod, hnd = dyc.to_dev(h_old), dyc.to_dev(h_new)
+    trg = [dyc.to_dev(t) for t in trs]
+    ud, vd = dyc.to_dev(u), dyc.to_dev(v)
+    g = [torch.full_like(hod, 1.0e-3) for _ in range(4)]
+    torch.cuda.synchronize()
+    dyc.ALE_remap_tracers(CS, hod, hnd, trg)
+    dyc.ALE_remap_set_h_vel(hod, g[0], g[1]); dyc.ALE_remap_set_h_vel(hnd, g[2], g[3])
+    dyc.ALE_remap_velocities(CS, g[0], g[1], g[2], g[3], ud, vd)
+    dyc.sync()
+    sl = H.interior(d, "h")
+    for m in range(2):
+        H.assert_bitwise(trg[m].cpu().numpy(), tro[m], f"tracer {m}", sl)
+        wet = M[G["mask2dT"]][tuple(sl)] > 0
+        a, b = tro[m][(Ellipsis,) + tuple(sl)][:, wet], trs[m][(Ellipsis,) + tuple(sl)][:, wet]
+        assert np.abs(a - b).max() > 1e-3
+        # the column integral of every wet column is conserved to round-off
+        ho, hn = h_old[(Ellipsis,) + tuple(sl)][:, wet], h_new[(Ellipsis,) + tuple(sl)][:, wet]
+        assert np.abs((a * hn).sum(0) - (b * ho).sum(0)).max() <= 1e-12 * np.abs(b * ho).sum(0).max()
+    H.assert_bitwise(g[0].cpu().numpy(), hu_o, "h_u", H.interior(d, "u")); H.assert_bitwise(g[3].cpu().numpy(), hv_n, "h_v", H.interior(d, "v"))
+    H.assert_bitwise(ud.cpu().numpy(), uo, "u", H.interior(d, "u")); H.assert_bitwise(vd.cpu().numpy(), vo, "v", H.interior(d, "v"))
+    dyc.close()
+
+
+def test_rejects_what_is_not_on_the_path(dyc):
+    CS = abi.remapping_params_default(abi.REMAP_PPM_H4, H_NEGLECT, answer_date=20181231)
+    with pytest.raises(RuntimeError, match="20190101"):
+        dev_core_h(dyc, CS, [1., 1., 1., 1.], [1., 2., 3., 4.], [2., 2.])
+    CS = abi.remapping_params_default(9, H_NEGLECT)       # PQM_IH6IH5
+    with pytest.raises(RuntimeError, match="remapping method is invalid"):
+        dev_core_h(dyc, CS, [1., 1., 1., 1.], [1., 2., 3., 4.], [2., 2.])
