@@ -163,6 +163,39 @@ def tracer_leg(args, dyc, d, st, step, barrier, dist):
             "note": "reported next to, not inside, the headline metric: one tracer step per two dynamics steps (DT_THERM = 2 DT)"}
 
 
+def ale_remap_leg(args, dyc, d, st, barrier, dist):
+    """The remapping half of an ALE step (BASELINE.json configs[4]: "ALE remap included") after the timed region, NOT
+    part of `value`: T and S remapped with OM4's switches (PPM_H4, OM4 sub-cells, no boundary extrapolation) from the
+    model's layers to a grid whose interfaces moved by a few per cent of a layer, then u and v with
+    ALE_remap_set_h_vel's face thicknesses."""
+    import torch
+    from mom6_amd import abi, synth_dev
+    nk = args.nk
+    CS = abi.remapping_params_default(abi.REMAP_PPM_H4, dyc.GV.H_subroundoff, om4_remap_via_sub_cells=1, boundary_extrapolation=0)
+    h = st["h"]
+    w = 1.0 + 0.05 * synth_dev.smooth_field(d, dyc.device, 5, nk=nk, ox=0.5, oy=0.5)
+    h_new = h * w; h_new = (h_new * (h.sum(0) / h_new.sum(0))[None]).contiguous(); del w
+    T = (10.0 + 5.0 * synth_dev.smooth_field(d, dyc.device, 71, nk=nk, ox=0.5, oy=0.5)).contiguous()
+    S = (35.0 + synth_dev.smooth_field(d, dyc.device, 72, nk=nk, ox=0.5, oy=0.5)).contiguous()
+    u, v = st["u"].clone(), st["v"].clone()
+    hu_o, hv_o, hu_n, hv_n = (torch.full_like(h, 1.0e-3) for _ in range(4))
+    dyc.ALE_remap_tracers(CS, h, h_new, [T.clone()])                    # untimed: allocates the work arrays
+    barrier(); t0 = time.perf_counter()
+    dyc.ALE_remap_tracers(CS, h, h_new, [T, S])
+    dyc.ALE_remap_set_h_vel(h, hu_o, hv_o); dyc.ALE_remap_set_h_vel(h_new, hu_n, hv_n)
+    dyc.ALE_remap_velocities(CS, hu_o, hv_o, hu_n, hv_n, u, v)
+    barrier(); t = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([t], dtype=torch.float64, device=dyc.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+    N3 = args.ni * args.nj * args.nk
+    b = 8.0 * N3 * (4 * 4 + 2 * 3)      # per field: h_old, h_new, field in, field out; set_h_vel x2: h in, h_u, h_v out
+    return {"fields": "T, S, u, v", "scheme": "PPM_H4 (OM4 sub-cells, no boundary extrapolation)", "remap_ms": round(1e3 * t, 3),
+            "algorithmic_GB": round(b / 1e9, 2), "GBps": round(b / 1e9 / t, 1), "frac_of_hbm_peak": round(b / 1e9 / t / (HBM_PEAK_GBS * args.gpus), 4),
+            "note": "reported next to, not inside, the headline metric: the regridding that produces h_new stays on the host"}
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_hbm_pmc.json,
     written by scripts/rocprof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; the
@@ -332,6 +365,7 @@ def main():
     }
     if args.tracers > 0:
         out["tracer_leg"] = tracer_leg(args, dyc, d, st, step, barrier, dist)
+        out["ale_remap_leg"] = ale_remap_leg(args, dyc, d, st, barrier, dist)
     if rank == 0:
         tot = sum(v[1] for v in full.values())
         out["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]}

@@ -12,6 +12,8 @@ module mom6x_c_api
   public :: mom6x_coriolis_params, mom6x_pgf_params, mom6x_eos_params, mom6x_rk2_params, mom6x_rk2_hooks
   public :: mom6x_PressureForce_set_tv, mom6x_vertvisc_params, mom6x_vertvisc_init, mom6x_vertvisc_set_visc, mom6x_vertvisc_coef
   public :: mom6x_hor_visc_params, mom6x_hor_visc_init, mom6x_horizontal_viscosity
+  public :: mom6x_remapping_params, mom6x_ALE_remap_tracers, mom6x_ALE_remap_set_h_vel, mom6x_ALE_remap_velocities
+  public :: mom6x_remapping_core_h
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
   public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
   public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc
@@ -89,6 +91,13 @@ module mom6x_c_api
     integer(c_int) :: no_slip, backscatter_underbound
     real(c_double) :: dt
   end type mom6x_hor_visc_params
+
+  type, bind(C) :: mom6x_remapping_params   !< remapping_CS (MOM_remapping.F90:47-84), the members the device path reads
+    integer(c_int) :: scheme                !< 0 PCM, 2 PLM, 4 PPM_H4 (the module's REMAPPING_* parameters :86-96)
+    integer(c_int) :: boundary_extrapolation, force_bounds_in_subcell, force_bounds_in_target
+    integer(c_int) :: om4_remap_via_sub_cells, answer_date
+    real(c_double) :: h_neglect, h_neglect_edge
+  end type mom6x_remapping_params
 
   type, bind(C) :: mom6x_eos_params        !< tv%eqn_of_state (MOM_EOS.F90:99-150) + EOS-only switches of PressureForce_FV_CS
     integer(c_int) :: form                 !< 1 EOS_LINEAR, 2 EOS_WRIGHT
@@ -225,6 +234,29 @@ module mom6x_c_api
         bind(C, name="mom6x_vertvisc_set_visc")
       import :: c_ptr, c_int
       type(c_ptr), value :: ctx, Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v, Kv_shear, Ray_u, Ray_v
+    end function
+    !> ALE_remap_tracers (MOM_ALE.F90:760): fields = array of nfields device pointers (Reg%Tr(m)%t)
+    integer(c_int) function mom6x_ALE_remap_tracers(ctx, p, h_old, h_new, fields, nfields) bind(C, name="mom6x_ALE_remap_tracers")
+      import :: c_ptr, c_int, mom6x_remapping_params
+      type(c_ptr), value :: ctx, h_old, h_new, fields ; type(mom6x_remapping_params), intent(in) :: p
+      integer(c_int), value :: nfields
+    end function
+    !> ALE_remap_set_h_vel (MOM_ALE.F90:882)
+    integer(c_int) function mom6x_ALE_remap_set_h_vel(ctx, h_new, h_u, h_v) bind(C, name="mom6x_ALE_remap_set_h_vel")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, h_new, h_u, h_v
+    end function
+    !> ALE_remap_velocities (MOM_ALE.F90:1089)
+    integer(c_int) function mom6x_ALE_remap_velocities(ctx, p, h_old_u, h_old_v, h_new_u, h_new_v, u, v) &
+        bind(C, name="mom6x_ALE_remap_velocities")
+      import :: c_ptr, c_int, mom6x_remapping_params
+      type(c_ptr), value :: ctx, h_old_u, h_old_v, h_new_u, h_new_v, u, v ; type(mom6x_remapping_params), intent(in) :: p
+    end function
+    !> remapping_core_h (MOM_remapping.F90:234) for ncol packed columns
+    integer(c_int) function mom6x_remapping_core_h(ctx, p, ncol, n0, h0, u0, n1, h1, u1) bind(C, name="mom6x_remapping_core_h")
+      import :: c_ptr, c_int, mom6x_remapping_params
+      type(c_ptr), value :: ctx, h0, u0, h1, u1 ; type(mom6x_remapping_params), intent(in) :: p
+      integer(c_int), value :: ncol, n0, n1
     end function
     !> hor_visc_init (MOM_hor_visc.F90:2322): the 2-D viscosity planes are made on the device from the metric block
     integer(c_int) function mom6x_hor_visc_init(ctx, p) bind(C, name="mom6x_hor_visc_init")

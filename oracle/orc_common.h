@@ -14,9 +14,12 @@
  * by the reference's own differential invariants (tests/test_oracle_*.py):
  * conservation, rotation (ROTATE_INDEX-style), dimensional rescaling by powers of
  * two (bit-identical, as .testing dim.* requires), layout (1 vs 2 tiles).
- * The one exception: the equation-of-state functions used by the pressure force ARE pinned, to the check values
- * of the reference's own EOS_unit_tests (MOM_EOS.F90:2077-2079 WRIGHT, :2129-2131 LINEAR) --
- * tests/test_oracle_cpu.py::test_equation_of_state_against_reference_known_answers.
+ * Two exceptions ARE pinned to numbers the reference itself holds:
+ *  - orc_remap.c (MOM_remapping / ALE remapping): the known answers of remapping_unit_tests
+ *    (src/ALE/MOM_remapping.F90:2072-2943), replayed by tests/test_remap_cpu.py;
+ *  - the equation-of-state functions used by the pressure force: the check values of EOS_unit_tests
+ *    (MOM_EOS.F90:2077-2079 WRIGHT, :2129-2131 LINEAR) --
+ *    tests/test_oracle_cpu.py::test_equation_of_state_against_reference_known_answers.
  *
  * Index conventions follow include/mom6x.h (local 0-based compute indices,
  * capital I/J = east/north face or vertex of cell i/j).
