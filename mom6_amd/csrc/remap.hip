@@ -7,8 +7,9 @@
 //   edge_values_explicit_h4, end_value_h4), ALE_remap_tracers :760, ALE_remap_set_h_vel :882, ALE_remap_velocities :1089
 //
 // One thread per column, two kernels:
-//  k_remap_recon   the reconstruction (edge values, PLM slope) of every source cell.  All loops run over k with the same k
-//                  in every lane, so the column arrays (3-D scratch fields, [k][column]) are read and written coalesced.
+//  k_remap_recon   the reconstruction (edge values, PLM slope) of every source cell in ONE sweep over k with a register
+//                  window (the reference makes a pass per stage); same k in every lane, so the column arrays (3-D scratch
+//                  fields, [k][column]) are read once and written once, coalesced.
 //  k_remap_apply   the reference builds the n0+n1+1 sub-cells of the two grids' intersection in arrays, integrates the
 //                  reconstruction over each, corrects the thickest sub-cell of every source cell so that the cell's
 //                  integral is conserved to the last bit, and sums the sub-cells of each target cell.  Per-thread arrays
@@ -99,40 +100,113 @@ struct ReconArgs {
   int n0;
 };
 
+// interior edge value of edge_values_explicit_h4 :246-279 between cells (h1,u1) and (h2,u2), with their outer neighbours
+__device__ __forceinline__ double edge_h4(double h0, double h1, double h2, double h3, double u0, double u1, double u2, double u3, double hne) {
+  const double hMinFrac = 1.e-5;
+  if (h0 + h1 == 0.0 || h1 + h2 == 0.0 || h2 + h3 == 0.0) {
+    const double h_min = hMinFrac * dmax(hne, (h0 + h1) + (h2 + h3));
+    h0 = dmax(h_min, h0); h1 = dmax(h_min, h1); h2 = dmax(h_min, h2); h3 = dmax(h_min, h3);
+  }
+  const double I_h12 = 1.0 / (h1 + h2);
+  const double I_den_et2 = 1.0 / (((h0 + h1) + h2) * (h0 + h1)), I_h012 = (h0 + h1) * I_den_et2;
+  const double I_den_et3 = 1.0 / ((h1 + (h2 + h3)) * (h2 + h3)), I_h123 = (h2 + h3) * I_den_et3;
+  const double et1 = (1.0 + (h1 * I_h012 + (h0 + h1) * I_h123)) * I_h12 * (h2 * (h2 + h3)) * u1 +
+                     (1.0 + (h2 * I_h123 + (h2 + h3) * I_h012)) * I_h12 * (h1 * (h0 + h1)) * u2;
+  const double et2 = (h1 * (h2 * (h2 + h3)) * I_den_et2) * (u1 - u0);
+  const double et3 = (h2 * (h1 * (h0 + h1)) * I_den_et3) * (u2 - u3);
+  return (et1 + (et2 + et3)) / ((h0 + h1) + (h2 + h3));
+}
+// bound_edge_values :39-101 for one cell (a, b: its edge values; m / p: the neighbour, or the cell itself at the ends)
+__device__ __forceinline__ void bound_edges(double um, double uk, double up, double hm, double hk, double hp, double &a, double &b) {
+  double slope_x_h = 0.0;
+  if (((hm + hp) + 2.0 * hk) > 0.0) {
+    const double sigma_l = (uk - um);
+    const double sigma_c = (up - um) * (hk / ((hm + hp) + 2.0 * hk));
+    const double sigma_r = (up - uk);
+    if ((sigma_l * sigma_r) > 0.0) slope_x_h = fsign(dmin3(fabs(sigma_l), fabs(sigma_c), fabs(sigma_r)), sigma_c);
+  }
+  if ((um - a) * (a - uk) < 0.0) a = uk - fsign(dmin(fabs(slope_x_h), fabs(a - uk)), slope_x_h);
+  if ((up - b) * (b - uk) < 0.0) b = uk + fsign(dmin(fabs(slope_x_h), fabs(b - uk)), slope_x_h);
+  a = dmax(dmin(a, dmax(um, uk)), dmin(um, uk));
+  b = dmax(dmin(b, dmax(up, uk)), dmin(up, uk));
+}
+// the interior-cell part of PPM_limiter_standard :80-116
+__device__ __forceinline__ void ppm_limit(double u_l, double u_c, double u_r, double &edge_l, double &edge_r) {
+  if ((u_r - u_c) * (u_c - u_l) <= 0.0) {
+    edge_l = u_c; edge_r = u_c;
+  } else {
+    const double expr1 = 3.0 * (edge_r - edge_l) * ((u_c - edge_l) + (u_c - edge_r));
+    const double expr2 = (edge_r - edge_l) * (edge_r - edge_l);
+    if (expr1 > expr2) {
+      edge_l = u_c + 2.0 * (u_c - edge_r);
+      edge_l = dmax(dmin(edge_l, dmax(u_l, u_c)), dmin(u_l, u_c));
+    } else if (expr1 < -expr2) {
+      edge_r = u_c + 2.0 * (u_c - edge_l);
+      edge_r = dmax(dmin(edge_r, dmax(u_r, u_c)), dmin(u_r, u_c));
+    }
+  }
+  if (fabs(edge_r - edge_l) < dmax(1.e-60, DBL_EPSILON * fabs(u_c))) { edge_l = u_c; edge_r = u_c; }
+}
+
 // build_reconstructions_1d :410-550 for one column.  h, u: the source column; E1, E2, C2: outputs (C2 only for PLM);
-// S1, S2: two more column arrays for PLM's first-guess and monotonized slopes.  All 1-based.
+// Ucopy: a copy of u (the field itself may be overwritten by the remapped values).  All 1-based.
+// The reference makes one pass over the column per stage (edge values, bounding, discontinuity check, limiter; first-guess
+// slopes, monotonized slopes, coefficients).  Every stage only looks one or two cells away, so here ONE sweep carries a
+// register window of the cells and of the intermediate values and finishes cell k-1 when cell k has been bounded: the
+// column arrays are read once and the results written once, all with the same k in every lane (coalesced).
 __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict__ h, const double *__restrict__ u, View vs,
-                                   double *E1, double *E2, double *C2, double *S1, double *S2, View vw) {
+                                   double *E1, double *E2, double *C2, double *Ucopy, View vw) {
   const int N = A.n0;
 #define H(k) AT(h, vs, k)
 #define U(k) AT(u, vs, k)
 #define e1(k) AT(E1, vw, k)
 #define e2(k) AT(E2, vw, k)
+#define c2(k) AT(C2, vw, k)
   if (A.scheme == MOM6X_REMAP_PCM) {                                          // PCM_functions.F90:16-35
-    for (int k = 1; k <= N; k++) { const double v = U(k); e1(k) = v; e2(k) = v; }
+    for (int k = 1; k <= N; k++) { const double v = U(k); e1(k) = v; e2(k) = v; if (Ucopy) AT(Ucopy, vw, k) = v; }
     return;
   }
-  if (A.scheme == MOM6X_REMAP_PLM) {                                          // PLM_reconstruction :197-262
+  if (A.scheme == MOM6X_REMAP_PLM) {                                          // PLM_reconstruction :197-262 (N >= 2)
     const double almost_one = 1. - DBL_EPSILON, hn = A.h_neglect;
-#define slp(k) AT(S1, vw, k)
-#define mslp(k) AT(S2, vw, k)
-#define c2(k) AT(C2, vw, k)
-    for (int k = 2; k <= N - 1; k++) slp(k) = PLM_slope_wa(H(k - 1), H(k), H(k + 1), hn, U(k - 1), U(k), U(k + 1));
-    slp(1) = 0.; slp(N) = 0.;
-    for (int k = 2; k <= N - 1; k++) mslp(k) = PLM_monotonized_slope(U(k - 1), U(k), U(k + 1), slp(k - 1), slp(k), slp(k + 1));
-    mslp(1) = 0.; mslp(N) = 0.;
-    e1(1) = U(1); e2(1) = U(1); c2(1) = 0.;
+    // window at step k: cells k-1 (m), k (c), k+1 (p), k+2 (q); slopes slp(k-1..k+1), mslp(k-1..k)
+    double um = U(1), uc = U(1), up = (N >= 2) ? U(2) : 0., hm = H(1), hc = H(1), hp = (N >= 2) ? H(2) : 0.;
+    double s_m = 0., s_c = 0., s_p = 0., ms_m = 0., ms_c = 0.;   // slp(k-1), slp(k), slp(k+1), mslp(k-1), mslp(k)
+    // step k finishes cell k-1; cell 1 and N are written explicitly
+    // prime: k = 1: slp(1) = 0, slp(2)
+    if (N >= 3) s_p = PLM_slope_wa(H(1), H(2), H(3), hn, U(1), U(2), U(3));
+    e1(1) = uc; e2(1) = uc; c2(1) = 0.;
+    if (Ucopy) AT(Ucopy, vw, 1) = uc;
     for (int k = 2; k <= N - 1; k++) {
-      const double slope = mslp(k), uk = U(k);
-      const double u_l = uk - 0.5 * slope, u_r = uk + 0.5 * slope;
-      e1(k) = u_l; e2(k) = u_r;
+      // shift the window to cell k
+      um = uc; uc = up; hm = hc; hc = hp; up = U(k + 1); hp = H(k + 1);
+      s_m = s_c; s_c = s_p; ms_m = ms_c;
+      s_p = (k + 1 <= N - 1) ? PLM_slope_wa(hc, hp, H(k + 2), hn, uc, up, U(k + 2)) : 0.;     // slp(k+1)
+      ms_c = PLM_monotonized_slope(um, uc, up, s_m, s_c, s_p);                                   // mslp(k)
+      if (Ucopy) AT(Ucopy, vw, k) = uc;
+      if (k >= 3) {   // finish cell k-1 (an interior cell): needs mslp(k-1), mslp(k), slp(k)
+        const double slope = ms_m, ukm = um;
+        const double u_l = ukm - 0.5 * slope, u_r = ukm + 0.5 * slope;
+        e1(k - 1) = u_l; e2(k - 1) = u_r;
+        double p2 = (u_r - u_l);
+        const double edge = p2 + u_l;
+        const double e_r = uc - 0.5 * fsign(ms_c, s_c);
+        if ((edge - ukm) * (e_r - edge) < 0.) p2 = p2 * almost_one;
+        c2(k - 1) = p2;
+      }
+    }
+    if (N >= 3) {   // finish cell N-1: mslp(N) = slp(N) = 0
+      const double slope = ms_c, ukm = uc;
+      const double u_l = ukm - 0.5 * slope, u_r = ukm + 0.5 * slope;
+      e1(N - 1) = u_l; e2(N - 1) = u_r;
       double p2 = (u_r - u_l);
       const double edge = p2 + u_l;
-      const double e_r = U(k + 1) - 0.5 * fsign(mslp(k + 1), slp(k + 1));
-      if ((edge - uk) * (e_r - edge) < 0.) p2 = p2 * almost_one;
-      c2(k) = p2;
+      const double e_r = up - 0.5 * fsign(0., 0.);
+      if ((edge - ukm) * (e_r - edge) < 0.) p2 = p2 * almost_one;
+      c2(N - 1) = p2;
     }
-    e1(N) = U(N); e2(N) = U(N); c2(N) = 0.;
+    const double uN = U(N);
+    e1(N) = uN; e2(N) = uN; c2(N) = 0.;
+    if (Ucopy) AT(Ucopy, vw, N) = uN;
     if (A.boundary_extrapolation) {                                           // PLM_boundary_extrapolation :274-308
       double slope = -PLM_extrapolate_slope(H(2), H(1), hn, U(2), U(1));
       e1(1) = U(1) - 0.5 * slope; e2(1) = U(1) + 0.5 * slope;
@@ -141,89 +215,54 @@ __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict_
       e1(N) = U(N) - 0.5 * slope; e2(N) = U(N) + 0.5 * slope;
       c2(N) = e2(N) - e1(N);
     }
-#undef slp
-#undef mslp
-#undef c2
     return;
   }
-  // ---- PPM_H4: edge_values_explicit_h4 :213-348 (N >= 4)
+  // ---- PPM_H4 (N >= 4): edge_values_explicit_h4 :213-348, PPM_limiter_standard :62-121
+  const double hne = A.h_neglect_edge;
+  double edge_1, edge_2, edge_N, edge_N1;        // the two edge values at either end come from end_value_h4 :314-346
   {
-    const double hne = A.h_neglect_edge, hMinFrac = 1.e-5;
-    for (int i = 3; i <= N - 1; i++) {
-      double h0 = H(i - 2), h1 = H(i - 1), h2 = H(i), h3 = H(i + 1);
-      if (h0 + h1 == 0.0 || h1 + h2 == 0.0 || h2 + h3 == 0.0) {
-        const double h_min = hMinFrac * dmax(hne, (h0 + h1) + (h2 + h3));
-        h0 = dmax(h_min, H(i - 2)); h1 = dmax(h_min, H(i - 1)); h2 = dmax(h_min, H(i)); h3 = dmax(h_min, H(i + 1));
-      }
-      const double I_h12 = 1.0 / (h1 + h2);
-      const double I_den_et2 = 1.0 / (((h0 + h1) + h2) * (h0 + h1)), I_h012 = (h0 + h1) * I_den_et2;
-      const double I_den_et3 = 1.0 / ((h1 + (h2 + h3)) * (h2 + h3)), I_h123 = (h2 + h3) * I_den_et3;
-      const double et1 = (1.0 + (h1 * I_h012 + (h0 + h1) * I_h123)) * I_h12 * (h2 * (h2 + h3)) * U(i - 1) +
-                         (1.0 + (h2 * I_h123 + (h2 + h3) * I_h012)) * I_h12 * (h1 * (h0 + h1)) * U(i);
-      const double et2 = (h1 * (h2 * (h2 + h3)) * I_den_et2) * (U(i - 1) - U(i - 2));
-      const double et3 = (h2 * (h1 * (h0 + h1)) * I_den_et3) * (U(i) - U(i + 1));
-      const double ev = (et1 + (et2 + et3)) / ((h0 + h1) + (h2 + h3));
-      e1(i) = ev; e2(i - 1) = ev;
-    }
     double dz[4], ut[4], C[4];
     for (int i = 1; i <= 4; i++) { dz[i - 1] = dmax(hne, H(i)); ut[i - 1] = U(i); }
     end_value_h4(dz, ut, C);
-    e1(1) = C[0];
-    e2(1) = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
-    e1(2) = e2(1);
+    edge_1 = C[0];
+    edge_2 = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
     for (int i = 1; i <= 4; i++) { dz[i - 1] = dmax(hne, H(N + 1 - i)); ut[i - 1] = U(N + 1 - i); }
     end_value_h4(dz, ut, C);
-    e2(N) = C[0];
-    e1(N) = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
-    e2(N - 1) = e1(N);
+    edge_N1 = C[0];
+    edge_N = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
   }
-  // ---- PPM_limiter_standard :62-121: bound_edge_values :39-101
+  // window at step k (bounding cell k, finishing cell k-1): cells k-2 (mm), k-1 (m), k (c), k+1 (p), k+2 (q)
+  double umm = 0., um = 0., uc = 0., up = U(1), uq = U(2), hmm = 0., hm = 0., hc = 0., hp = H(1), hq = H(2);
+  double ed_c = 0., ed_p = edge_1;               // edge(k), edge(k+1)
+  double a_m = 0., b_m = 0.;                     // bounded edge values of cell k-1 (a_m already through its pair check with k-2)
   for (int k = 1; k <= N; k++) {
-    const int km1 = (k - 1 > 1) ? k - 1 : 1, kp1 = (k + 1 < N) ? k + 1 : N;
-    const double um = U(km1), uk = U(k), up = U(kp1), hm = H(km1), hk = H(k), hp = H(kp1);
-    double slope_x_h = 0.0;
-    if (((hm + hp) + 2.0 * hk) > 0.0) {
-      const double sigma_l = (uk - um);
-      const double sigma_c = (up - um) * (hk / ((hm + hp) + 2.0 * hk));
-      const double sigma_r = (up - uk);
-      if ((sigma_l * sigma_r) > 0.0) slope_x_h = fsign(dmin3(fabs(sigma_l), fabs(sigma_c), fabs(sigma_r)), sigma_c);
-    }
-    double a = e1(k), b = e2(k);
-    if ((um - a) * (a - uk) < 0.0) a = uk - fsign(dmin(fabs(slope_x_h), fabs(a - uk)), slope_x_h);
-    if ((up - b) * (b - uk) < 0.0) b = uk + fsign(dmin(fabs(slope_x_h), fabs(b - uk)), slope_x_h);
-    a = dmax(dmin(a, dmax(um, uk)), dmin(um, uk));
-    b = dmax(dmin(b, dmax(up, uk)), dmin(up, uk));
-    e1(k) = a; e2(k) = b;
-  }
-  for (int k = 1; k <= N - 1; k++) {                                          // check_discontinuous_edge_values :132-150
-    const double uk = U(k), up = U(k + 1);
-    if ((e1(k + 1) - e2(k)) * (up - uk) < 0.0) {
-      double u0_avg = 0.5 * (e2(k) + e1(k + 1));
-      u0_avg = dmax(dmin(u0_avg, dmax(uk, up)), dmin(uk, up));
-      e2(k) = u0_avg; e1(k + 1) = u0_avg;
-    }
-  }
-  for (int k = 2; k <= N - 1; k++) {                                          // :80-116
-    const double u_l = U(k - 1), u_c = U(k), u_r = U(k + 1);
-    double edge_l = e1(k), edge_r = e2(k);
-    if ((u_r - u_c) * (u_c - u_l) <= 0.0) {
-      edge_l = u_c; edge_r = u_c;
-    } else {
-      const double expr1 = 3.0 * (edge_r - edge_l) * ((u_c - edge_l) + (u_c - edge_r));
-      const double expr2 = (edge_r - edge_l) * (edge_r - edge_l);
-      if (expr1 > expr2) {
-        edge_l = u_c + 2.0 * (u_c - edge_r);
-        edge_l = dmax(dmin(edge_l, dmax(u_l, u_c)), dmin(u_l, u_c));
-      } else if (expr1 < -expr2) {
-        edge_r = u_c + 2.0 * (u_c - edge_l);
-        edge_r = dmax(dmin(edge_r, dmax(u_r, u_c)), dmin(u_r, u_c));
+    umm = um; um = uc; uc = up; up = uq; hmm = hm; hm = hc; hc = hp; hp = hq;
+    if (k + 2 <= N) { uq = U(k + 2); hq = H(k + 2); }
+    ed_c = ed_p;
+    const int e = k + 1;                         // the edge below cell k
+    if (e <= 2) ed_p = edge_2;
+    else if (e >= N) ed_p = (e == N) ? edge_N : edge_N1;
+    else ed_p = edge_h4(hm, hc, hp, hq, um, uc, up, uq, hne);      // i = e: cells e-2 .. e+1 = k-1 .. k+2
+    if (Ucopy) AT(Ucopy, vw, k) = uc;
+    double a = ed_c, b = ed_p;
+    bound_edges((k > 1) ? um : uc, uc, (k < N) ? up : uc, (k > 1) ? hm : hc, hc, (k < N) ? hp : hc, a, b);
+    if (k > 1) {
+      // check_discontinuous_edge_values :132-150 for the pair (k-1, k)
+      if ((a - b_m) * (uc - um) < 0.0) {
+        double u0_avg = 0.5 * (b_m + a);
+        u0_avg = dmax(dmin(u0_avg, dmax(um, uc)), dmin(um, uc));
+        b_m = u0_avg; a = u0_avg;
+      }
+      // cell k-1 is complete
+      if (k - 1 == 1) { e1(1) = um; e2(1) = um; }
+      else {
+        ppm_limit(umm, um, uc, a_m, b_m);
+        e1(k - 1) = a_m; e2(k - 1) = b_m;
       }
     }
-    if (fabs(edge_r - edge_l) < dmax(1.e-60, DBL_EPSILON * fabs(u_c))) { edge_l = u_c; edge_r = u_c; }
-    e1(k) = edge_l; e2(k) = edge_r;
+    a_m = a; b_m = b;
   }
-  e1(1) = U(1); e2(1) = U(1);
-  e1(N) = U(N); e2(N) = U(N);
+  e1(N) = uc; e2(N) = uc;
   if (A.boundary_extrapolation) {                                             // PPM_boundary_extrapolation :166-296
     const double hn = A.h_neglect;
     {
@@ -261,6 +300,7 @@ __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict_
 #undef U
 #undef e1
 #undef e2
+#undef c2
 }
 
 // average_value_ppoly :1391-1494 for PCM / PLM / PPM; a_L, a_R, u_c, p2 = E(i0,1), E(i0,2), u0(i0), coefs(i0,2) [PLM]
@@ -291,6 +331,7 @@ __device__ __forceinline__ double average_value(int method, double a_L, double a
 
 struct Merge {            // the running state of intersect_src_tgt_grids' loop :688-795
   double h0s, h1s;        // h0_supply, h1_supply
+  double h1full;          // h1(i1), the whole width of the current target cell
   int i0, i1;
   bool src, tgt;          // src_has_volume, tgt_has_volume
 };
@@ -316,7 +357,7 @@ __device__ __forceinline__ int merge_step(Merge &m, const double *__restrict__ h
     if (m.i0 < n0) { m.i0 = m.i0 + 1; m.h0s = AT(h0, v0, m.i0); }
     else { m.h0s = 0.; m.src = false; }
   } else {
-    if (m.i1 < n1) { m.i1 = m.i1 + 1; m.h1s = AT(h1, v1, m.i1); }
+    if (m.i1 < n1) { m.i1 = m.i1 + 1; m.h1s = AT(h1, v1, m.i1); m.h1full = m.h1s; }
     else { m.h1s = 0.; m.tgt = false; }
   }
   return ev;
@@ -352,6 +393,7 @@ __device__ void apply_column(const ApplyArgs &A, const double *__restrict__ h0, 
   int last_thick = 0;
   for (int k = 1; k <= n0; k++) if (AT(h0, v0, k) > 0.) last_thick = k;          // i0_last_thick_cell :884-889
   Merge m; m.h0s = AT(h0, v0, 1); m.h1s = AT(h1, v1, 1); m.i0 = 1; m.i1 = 1; m.src = true; m.tgt = true;
+  m.h1full = m.h1s;
   Target T; tgt_reset(T);
   int i_sub = 1;            // the index of the last sub-cell made
   // the source cell being integrated
@@ -370,78 +412,126 @@ __device__ void apply_column(const ApplyArgs &A, const double *__restrict__ h0, 
     const Merge s = m;
     const int i0 = m.i0;
     const double umin0 = dmin(a_L, a_R), umax0 = dmax(a_L, a_R);
-    // ---- pass 1: the cell's sub-cells, its effective width h0_eff :722-747 and the thickest sub-cell :726-729
+    // ---- pass 1: the cell's sub-cells, its effective width h0_eff :722-747 and the thickest sub-cell :726-729.
+    // The first NB sub-cells are also kept in registers: a source cell rarely has more, and then passes 2 and 3 work
+    // from that buffer instead of replaying the merge.
+    constexpr int NB = 4;
+    double b_hs[NB], b_h1[NB]; int b_i1[NB]; bool b_has[NB], b_tev[NB];
     Merge t = s;
     int cnt = 0, imax = -1;
     double dh_max = 0., h0_eff = 0., hsub_imax = 0.;
     {
       int ev;
       do {
+        const bool has = t.tgt;
+        const int i1 = t.i1;
+        const double h1f = t.h1full;
         double dh, hs, eff;
         ev = merge_step(t, h0, v0, h1, v1, n0, n1, dh, hs, eff);
         h0_eff = h0_eff + eff;
         if (dh >= dh_max) { imax = cnt; dh_max = dh; hsub_imax = hs; }
+#pragma unroll
+        for (int q = 0; q < NB; q++)
+          if (q == cnt) { b_hs[q] = hs; b_h1[q] = h1f; b_i1[q] = i1; b_has[q] = has; b_tev[q] = (ev == EV_TGT); }
         cnt++;
       } while (ev != EV_SRC);
     }
     const double den = A.om4 ? h0_eff : hsrc;
     h0_eff_last = h0_eff;
-    // ---- pass 2: sum of u*h over the sub-cells other than the thickest :939-957
+    const bool adjust = (i0 <= last_thick) && (hsub_imax > 0.);
     double duh = 0.;
     if (i0 == 1) duh = duh + uh_s1;
-    {
-      t = s;
-      double xa2 = xa, cum2 = cum;
-      for (int c = 0; c < cnt; c++) {
-        double dh, hs, eff;
-        merge_step(t, h0, v0, h1, v1, n0, n1, dh, hs, eff);
-        double u, uh;
-        if (A.om4 && (i_sub + 1 + c) == ns) { u = AT(E2, vw, n0); uh = u * hs; }
-        else {
-          cum2 = cum2 + hs;
-          double xb;
-          if (den > 0.) { xb = dmin(1., cum2 / den); u = average_value(method, a_L, a_R, u_c, p2, xa2, xb); }
-          else { xb = 1.; u = u_c; }
-          if (A.fb_sub) { u = dmax(u, umin0); u = dmin(u, umax0); }
-          uh = hs * u;
-          xa2 = xb;
+    if (cnt <= NB) {
+      // ---- passes 2 and 3 from the register buffer
+      double b_u[NB], b_uh[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        if (c < cnt) {
+          const double hs = b_hs[c];
+          double u, uh;
+          if (A.om4 && (i_sub + 1 + c) == ns) { u = AT(E2, vw, n0); uh = u * hs; }
+          else {
+            cum = cum + hs;
+            double xb;
+            if (den > 0.) { xb = dmin(1., cum / den); u = average_value(method, a_L, a_R, u_c, p2, xa, xb); }
+            else { xb = 1.; u = u_c; }
+            if (A.fb_sub) { u = dmax(u, umin0); u = dmin(u, umax0); }
+            uh = hs * u;
+            xa = xb;
+          }
+          b_u[c] = u; b_uh[c] = uh;
+          if (c != imax) duh = duh + uh;
         }
-        if (c != imax) duh = duh + uh;
       }
-    }
-    const bool adjust = (i0 <= last_thick) && (hsub_imax > 0.);
-    const double uh_adj = u_c * hsrc - duh;
-    // ---- pass 3: emit the sub-cells into the target sums
-    {
-      t = s;
-      for (int c = 0; c < cnt; c++) {
-        const bool has_tgt = t.tgt;
-        const int i1 = t.i1;
-        double dh, hs, eff;
-        const int ev = merge_step(t, h0, v0, h1, v1, n0, n1, dh, hs, eff);
-        i_sub++;
-        double u, uh;
-        if (A.om4 && i_sub == ns) { u = AT(E2, vw, n0); uh = u * hs; }
-        else {
-          cum = cum + hs;
-          double xb;
-          if (den > 0.) { xb = dmin(1., cum / den); u = average_value(method, a_L, a_R, u_c, p2, xa, xb); }
-          else { xb = 1.; u = u_c; }
-          if (A.fb_sub) { u = dmax(u, umin0); u = dmin(u, umax0); }
-          uh = hs * u;
-          xa = xb;
+      const double uh_adj = u_c * hsrc - duh;
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        if (c < cnt) {
+          double uh = b_uh[c];
+          if (adjust && c == imax) uh = uh_adj;
+          if (b_has[c]) {
+            tgt_feed(T, b_hs[c], b_u[c], uh, A.fb_tgt);
+            if (b_tev[c]) AT(u1, v1, b_i1[c]) = tgt_close(T, b_h1[c], A.fb_tgt);
+          }
         }
-        if (adjust && c == imax) uh = uh_adj;
-        if (has_tgt) {
-          tgt_feed(T, hs, u, uh, A.fb_tgt);
-          if (ev == EV_TGT) AT(u1, v1, i1) = tgt_close(T, AT(h1, v1, i1), A.fb_tgt);
+      }
+      i_sub += cnt;
+    } else {
+      // ---- pass 2: sum of u*h over the sub-cells other than the thickest :939-957
+      {
+        t = s;
+        double xa2 = xa, cum2 = cum;
+        for (int c = 0; c < cnt; c++) {
+          double dh, hs, eff;
+          merge_step(t, h0, v0, h1, v1, n0, n1, dh, hs, eff);
+          double u, uh;
+          if (A.om4 && (i_sub + 1 + c) == ns) { u = AT(E2, vw, n0); uh = u * hs; }
+          else {
+            cum2 = cum2 + hs;
+            double xb;
+            if (den > 0.) { xb = dmin(1., cum2 / den); u = average_value(method, a_L, a_R, u_c, p2, xa2, xb); }
+            else { xb = 1.; u = u_c; }
+            if (A.fb_sub) { u = dmax(u, umin0); u = dmin(u, umax0); }
+            uh = hs * u;
+            xa2 = xb;
+          }
+          if (c != imax) duh = duh + uh;
+        }
+      }
+      const double uh_adj = u_c * hsrc - duh;
+      // ---- pass 3: emit the sub-cells into the target sums
+      {
+        t = s;
+        for (int c = 0; c < cnt; c++) {
+          const bool has_tgt = t.tgt;
+          const int i1 = t.i1;
+          const double h1f = t.h1full;
+          double dh, hs, eff;
+          const int ev = merge_step(t, h0, v0, h1, v1, n0, n1, dh, hs, eff);
+          i_sub++;
+          double u, uh;
+          if (A.om4 && i_sub == ns) { u = AT(E2, vw, n0); uh = u * hs; }
+          else {
+            cum = cum + hs;
+            double xb;
+            if (den > 0.) { xb = dmin(1., cum / den); u = average_value(method, a_L, a_R, u_c, p2, xa, xb); }
+            else { xb = 1.; u = u_c; }
+            if (A.fb_sub) { u = dmax(u, umin0); u = dmin(u, umax0); }
+            uh = hs * u;
+            xa = xb;
+          }
+          if (adjust && c == imax) uh = uh_adj;
+          if (has_tgt) {
+            tgt_feed(T, hs, u, uh, A.fb_tgt);
+            if (ev == EV_TGT) AT(u1, v1, i1) = tgt_close(T, h1f, A.fb_tgt);
+          }
         }
       }
     }
     m = t;
     if (m.src) {          // the next source cell: "dh0_eff = 0 ; xa = 0" :932-934
       xa = 0.; cum = 0.;
-      a_L = AT(E1, vw, m.i0); a_R = AT(E2, vw, m.i0); u_c = AT(u0, v0, m.i0); hsrc = AT(h0, v0, m.i0);
+      a_L = AT(E1, vw, m.i0); a_R = AT(E2, vw, m.i0); u_c = AT(u0, v0, m.i0); hsrc = m.h0s;
       if (method == INTEGRATION_PLM) p2 = AT(C2, vw, m.i0);
     }
   }
@@ -451,6 +541,7 @@ __device__ void apply_column(const ApplyArgs &A, const double *__restrict__ h0, 
     const double umin0 = dmin(a_L, a_R), umax0 = dmax(a_L, a_R);
     while (m.tgt) {
       const int i1 = m.i1;
+      const double h1f = m.h1full;
       double dh, hs, eff;
       merge_step(m, h0, v0, h1, v1, n0, n1, dh, hs, eff);
       i_sub++;
@@ -466,7 +557,7 @@ __device__ void apply_column(const ApplyArgs &A, const double *__restrict__ h0, 
         xa = xb;
       }
       tgt_feed(T, hs, u, uh, A.fb_tgt);
-      AT(u1, v1, i1) = tgt_close(T, AT(h1, v1, i1), A.fb_tgt);
+      AT(u1, v1, i1) = tgt_close(T, h1f, A.fb_tgt);
     }
   }
 }
@@ -476,15 +567,14 @@ struct Fields { double *p[8]; };
 // the 3-D form: columns (i0..i1, j0..j1) with mask > 0; h_old / h_new / fields on the same staggering
 __global__ void __launch_bounds__(256)
 k_remap_recon(Dm d, const double *__restrict__ mask, ReconArgs A, const double *__restrict__ h_old, const double *__restrict__ f,
-              double *E1, double *E2, double *C2, double *S1, double *S2, double *Ucopy, int i0, int i1, int j0, int j1) {
+              double *E1, double *E2, double *C2, double *Ucopy, int i0, int i1, int j0, int j1) {
   const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i < i0 || i > i1 || j > j1) return;
   const size_t x = ix2(d, i, j);
   if (!(mask[x] > 0.)) return;
   View v; v.base = x; v.lev = (size_t)d.slab;
-  reconstruct_column(A, h_old, f, v, E1, E2, C2, S1, S2, v);
-  for (int k = 1; k <= A.n0; k++) AT(Ucopy, v, k) = AT(f, v, k);
+  reconstruct_column(A, h_old, f, v, E1, E2, C2, Ucopy, v);
 }
 __global__ void __launch_bounds__(256)
 k_remap_apply(Dm d, const double *__restrict__ mask, ApplyArgs A, const double *__restrict__ h_old, const double *__restrict__ h_new,
@@ -501,12 +591,12 @@ k_remap_apply(Dm d, const double *__restrict__ mask, ApplyArgs A, const double *
 // the packed form of the unit tests: column c holds n0 | n1 values back to back; work arrays are [k][ncol]
 __global__ void __launch_bounds__(64)
 k_remap_packed(int ncol, ReconArgs R, ApplyArgs A, const double *__restrict__ h0, const double *__restrict__ u0,
-               const double *__restrict__ h1, double *u1, double *E1, double *E2, double *C2, double *S1, double *S2) {
+               const double *__restrict__ h1, double *u1, double *E1, double *E2, double *C2) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncol) return;
   View v0, v1, vw;
   v0.base = (size_t)c * A.n0; v0.lev = 1; v1.base = (size_t)c * A.n1; v1.lev = 1; vw.base = c; vw.lev = ncol;
-  reconstruct_column(R, h0, u0, v0, E1, E2, C2, S1, S2, vw);
+  reconstruct_column(R, h0, u0, v0, E1, E2, C2, nullptr, vw);
   apply_column(A, h0, u0, v0, E1, E2, C2, vw, h1, u1, v1);
 }
 
@@ -550,14 +640,14 @@ int remap_field(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int 
   ReconArgs R; ApplyArgs A;
   int rc = check_params(p, d.nk, R, A, d.nk);
   if (rc) return rc;
-  double *E1, *E2, *C2, *S1, *S2, *Uc;
+  double *E1, *E2, *C2, *Uc;
   if ((rc = ctx_scratch(c, SCR_t0, d.nk, &E1)) || (rc = ctx_scratch(c, SCR_t1, d.nk, &E2)) || (rc = ctx_scratch(c, SCR_t2, d.nk, &C2)) ||
-      (rc = ctx_scratch(c, SCR_t3, d.nk, &S1)) || (rc = ctx_scratch(c, SCR_q, d.nk, &S2)) || (rc = ctx_scratch(c, SCR_KE, d.nk, &Uc)))
+      (rc = ctx_scratch(c, SCR_t3, d.nk, &Uc)))
     return rc;
   const dim3 b(64, 4, 1);
   const dim3 g = grid3(nxa(i1 - i0 + 1, i0), j1 - j0 + 1, 1, b);
   const double *mask = c->G + (size_t)mask_id * d.slab;
-  KLAUNCH(c, "k_remap_recon", k_remap_recon, g, b, d, mask, R, h_old, (const double *)f, E1, E2, C2, S1, S2, Uc, i0, i1, j0, j1);
+  KLAUNCH(c, "k_remap_recon", k_remap_recon, g, b, d, mask, R, h_old, (const double *)f, E1, E2, C2, Uc, i0, i1, j0, j1);
   KLAUNCH(c, "k_remap_apply", k_remap_apply, g, b, d, mask, A, h_old, h_new, (const double *)E1, (const double *)E2, (const double *)C2,
           (const double *)Uc, f, i0, i1, j0, j1);
   HIPCHK(hipGetLastError());
@@ -606,9 +696,8 @@ extern "C" int mom6x_remapping_core_h(mom6x_ctx *c, const mom6x_remapping_params
   if (rc) return rc;
   double *w = nullptr;
   const size_t per = (size_t)n0 * ncol;
-  HIPCHK(hipMalloc(&w, 5 * per * sizeof(double)));
-  KLAUNCH(c, "k_remap_packed", k_remap_packed, dim3((ncol + 63) / 64), dim3(64), ncol, R, A, h0, u0, h1, u1, w, w + per, w + 2 * per,
-          w + 3 * per, w + 4 * per);
+  HIPCHK(hipMalloc(&w, 3 * per * sizeof(double)));
+  KLAUNCH(c, "k_remap_packed", k_remap_packed, dim3((ncol + 63) / 64), dim3(64), ncol, R, A, h0, u0, h1, u1, w, w + per, w + 2 * per);
   hipError_t e = hipStreamSynchronize(c->stream);
   (void)hipFree(w);
   HIPCHK(e);
