@@ -13,7 +13,7 @@ module mom6x_c_api
   public :: mom6x_PressureForce_set_tv, mom6x_vertvisc_params, mom6x_vertvisc_init, mom6x_vertvisc_set_visc, mom6x_vertvisc_coef
   public :: mom6x_hor_visc_params, mom6x_hor_visc_init, mom6x_horizontal_viscosity
   public :: mom6x_remapping_params, mom6x_ALE_remap_tracers, mom6x_ALE_remap_set_h_vel, mom6x_ALE_remap_velocities
-  public :: mom6x_remapping_core_h
+  public :: mom6x_remapping_core_h, mom6x_regrid_zstar_params, mom6x_ALE_regrid_zstar
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
   public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
   public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc
@@ -98,6 +98,10 @@ module mom6x_c_api
     integer(c_int) :: om4_remap_via_sub_cells, answer_date
     real(c_double) :: h_neglect, h_neglect_edge
   end type mom6x_remapping_params
+
+  type, bind(C) :: mom6x_regrid_zstar_params   !< the members of regridding_CS (MOM_regridding.F90:40-140) the z* branch reads
+    real(c_double) :: min_thickness, old_grid_weight, depth_of_time_filter_shallow, depth_of_time_filter_deep, Z_ref
+  end type mom6x_regrid_zstar_params
 
   type, bind(C) :: mom6x_eos_params        !< tv%eqn_of_state (MOM_EOS.F90:99-150) + EOS-only switches of PressureForce_FV_CS
     integer(c_int) :: form                 !< 1 EOS_LINEAR, 2 EOS_WRIGHT
@@ -251,6 +255,12 @@ module mom6x_c_api
         bind(C, name="mom6x_ALE_remap_velocities")
       import :: c_ptr, c_int, mom6x_remapping_params
       type(c_ptr), value :: ctx, h_old_u, h_old_v, h_new_u, h_new_v, u, v ; type(mom6x_remapping_params), intent(in) :: p
+    end function
+    !> ALE_regrid (MOM_ALE.F90:518) for REGRIDDING_ZSTAR; coordinateResolution: nk host values
+    integer(c_int) function mom6x_ALE_regrid_zstar(ctx, p, coordinateResolution, h, h_new, dzRegrid) bind(C, name="mom6x_ALE_regrid_zstar")
+      import :: c_ptr, c_int, c_double, mom6x_regrid_zstar_params
+      type(c_ptr), value :: ctx, h, h_new, dzRegrid ; type(mom6x_regrid_zstar_params), intent(in) :: p
+      real(c_double), intent(in) :: coordinateResolution(*)
     end function
     !> remapping_core_h (MOM_remapping.F90:234) for ncol packed columns
     integer(c_int) function mom6x_remapping_core_h(ctx, p, ncol, n0, h0, u0, n1, h1, u1) bind(C, name="mom6x_remapping_core_h")

@@ -431,6 +431,21 @@ int mom6x_ALE_remap_set_h_vel(mom6x_ctx *ctx, const double *h_new, double *h_u, 
 /* ALE_remap_velocities :1089 (REMAP_VEL_CONSERVE_KE off, no near-bottom masking, no diagnostics).              */
 int mom6x_ALE_remap_velocities(mom6x_ctx *ctx, const mom6x_remapping_params *p, const double *h_old_u, const double *h_old_v,
                                const double *h_new_u, const double *h_new_v, double *u, double *v);
+/* ALE_regrid (MOM_ALE.F90:518) -> regridding_main (MOM_regridding.F90:862) for REGRIDDING_ZSTAR without ice shelves
+ * and with CS%nk == GV%ke (Boussinesq): nom_depth_H :920-922, build_zstar_grid :1257 (build_zstar_column,
+ * coord_zlike.F90:63; filtered_grid_motion :1105 incl. the old-grid weight and its depth-dependent transition),
+ * calc_h_new_by_dz :1008.  h needs one valid halo point (the reference regrids isc-1..iec+1).
+ * coordinateResolution: nk host values (the nominal layer thicknesses ALE_COORDINATE_CONFIG gives, in Z units). */
+typedef struct mom6x_regrid_zstar_params {
+  double min_thickness;                 /* MIN_THICKNESS (0.001 m) [H]                                        */
+  double old_grid_weight;               /* from REGRID_TIME_SCALE: exp(-dt/timescale) or 0 (:96)              */
+  double depth_of_time_filter_shallow;  /* REGRID_FILTER_SHALLOW_DEPTH (0) [H]                                */
+  double depth_of_time_filter_deep;     /* REGRID_FILTER_DEEP_DEPTH (0) [H]                                   */
+  double Z_ref;                         /* G%Z_ref (0)                                                        */
+} mom6x_regrid_zstar_params;
+int mom6x_ALE_regrid_zstar(mom6x_ctx *ctx, const mom6x_regrid_zstar_params *p, const double *coordinateResolution,
+                           const double *h, double *h_new, double *dzRegrid);
+
 /* remapping_core_h :234 for `ncol` independent columns stored back to back (n0 | n1 values each): the entry the
  * reference's own unit tests (remapping_unit_tests :2072) exercise.  Device pointers.                          */
 int mom6x_remapping_core_h(mom6x_ctx *ctx, const mom6x_remapping_params *p, int ncol, int n0, const double *h0,

@@ -220,6 +220,22 @@ def remapping_params_default(scheme=REMAP_PLM, h_neglect=1.0e-30, **kw):
     return p
 
 
+class RegridZstarParams(C.Structure):
+    """mom6x_regrid_zstar_params; the members of regridding_CS (MOM_regridding.F90:40-140) the z* branch reads."""
+    _fields_ = [("min_thickness", C.c_double), ("old_grid_weight", C.c_double), ("depth_of_time_filter_shallow", C.c_double),
+                ("depth_of_time_filter_deep", C.c_double), ("Z_ref", C.c_double)]
+
+
+def regrid_zstar_params_default(**kw):
+    """MIN_THICKNESS = 0.001 m, no time filtering (REGRID_TIME_SCALE = 0), Z_ref = 0."""
+    p = RegridZstarParams()
+    p.min_thickness = 1.0e-3; p.old_grid_weight = 0.0; p.depth_of_time_filter_shallow = 0.0; p.depth_of_time_filter_deep = 0.0
+    p.Z_ref = 0.0
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
 LINEAR, WRIGHT = 1, 2   # enum mom6x_eos_form
 
 

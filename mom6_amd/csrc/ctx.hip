@@ -197,6 +197,7 @@ extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
   for (int m = 0; m < MOM6X_NSCR; m++) (void)hipFree(c->scr[m]);
   (void)hipFree(c->Rlay); (void)hipFree(c->g_prime); (void)hipFree(c->retry);
   hor_visc_free(c);
+  (void)hipFree(c->regrid_res);
   (void)hipFree(c->vv_a_u); (void)hipFree(c->vv_a_v); (void)hipFree(c->vv_h_u); (void)hipFree(c->vv_h_v);
   (void)hipFree(c->G); (void)hipFree(c->hL); (void)hipFree(c->hR); (void)hipFree(c->flag);
   (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->halo_stream);

@@ -616,6 +616,101 @@ k_set_h_vel(Dm d, const double *__restrict__ G, const double *__restrict__ h_new
   }
 }
 
+// ALE_regrid :518 -> regridding_main MOM_regridding.F90:862 (REGRIDDING_ZSTAR, no ice shelf, CS%nk == GV%ke): one thread per
+// column of (isc-1..iec+1, jsc-1..jec+1); zOld lives in a 3-D scratch array and zNew in dzRegrid until the filter turns it
+// into the interface displacement -- every loop has the same k in all lanes.
+__global__ void __launch_bounds__(256)
+k_regrid_zstar(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_params CS, double Z_to_H, const double *__restrict__ res,
+               const double *__restrict__ h, double *__restrict__ h_new, double *__restrict__ dzI, double *__restrict__ zOld,
+               int *__restrict__ flag) {
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -1 || i > d.ni || j > d.nj) return;
+  const int nz = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+#define LV(p, k) (p)[x + (size_t)((k) - 1) * slab]
+  if (gm(G, d, MOM6X_G_mask2dT)[x] == 0.) {                                           // :1300-1303, :1030-1033
+    for (int k = 1; k <= nz; k++) { LV(h_new, k) = LV(h, k); LV(dzI, k) = 0.; }
+    LV(dzI, nz + 1) = 0.;
+    return;
+  }
+  const double depth = dmax((gm(G, d, MOM6X_G_bathyT)[x] + CS.Z_ref) * Z_to_H, 0.0);   // nom_depth_H :920-922
+  double total = 0.0;
+  for (int k = 1; k <= nz; k++) total = total + LV(h, k);                             // :1309-1312
+  double zo = -depth;                                                                 // zOld :1315-1318
+  LV(zOld, nz + 1) = zo;
+  for (int k = nz; k >= 1; k--) { zo = zo + LV(h, k); LV(zOld, k) = zo; }
+  const double zOld1 = zo;
+  // build_zstar_column coord_zlike.F90:86-142
+  const double min_thickness = dmin(CS.min_thickness, total / (double)nz);
+  const double eta = total - depth;
+  const double stretching = total / (depth + 0.);
+  double zn = eta;
+  LV(dzI, 1) = zn;
+  for (int k = 1; k <= nz; k++) {
+    const double dh = stretching * res[k - 1] * Z_to_H;
+    zn = zn - dh;
+    LV(dzI, k + 1) = zn;
+  }
+  zn = -depth;
+  LV(dzI, nz + 1) = zn;
+  for (int k = nz; k >= 1; k--) {
+    double zk = LV(dzI, k);
+    if (zk < (zn + min_thickness)) { zk = zn + min_thickness; LV(dzI, k) = zk; }
+    zn = zk;
+  }
+  const double zNew1 = zn;
+  // filtered_grid_motion :1138-1232
+  const double zOldB = -depth, zNewB = -depth;
+  const double test = (zOldB - zOld1) * (zNewB - zNew1);
+  if (test < 0.0) { atomicOr(flag, 4); return; }
+  if (test == 0.0) {
+    for (int k = 1; k <= nz + 1; k++) LV(dzI, k) = 0.0;
+    for (int k = 1; k <= nz; k++) LV(h_new, k) = dmax(0., LV(h, k) + (0.0 - 0.0));
+    return;
+  }
+  const double sgn = ((zOldB - zOld1) + (zNewB - zNew1) > 0.0) ? 1.0 : -1.0;
+  const double zs = CS.depth_of_time_filter_shallow, zd = CS.depth_of_time_filter_deep;
+  const double wtd = 1.0 - CS.old_grid_weight, Iwtd = 1.0 / wtd;
+  const double dzwt = (zd - zs);
+  double Idzwt = 0.0; if (fabs(zd - zs) > 0.0) Idzwt = 1.0 / (zd - zs);
+  const double dInt_zs_zd = 0.5 * (1.0 + Iwtd) * (zd - zs);
+  const double Aq = 0.5 * (Iwtd - 1.0);
+  double dz_prev = 0.0;                     // dz_g(k-1); dz_g(1) = 0
+  LV(dzI, 1) = 0.0;
+  for (int k = 2; k <= nz + 1; k++) {
+    const double z_old_k = LV(zOld, k);
+    const double dz_tgt = sgn * (LV(dzI, k) - z_old_k);
+    const double zr1 = sgn * (z_old_k - zOld1);
+    double dz;
+    if ((zr1 > zd) && (zr1 + wtd * dz_tgt > zd)) dz = sgn * wtd * dz_tgt;
+    else if ((zr1 < zs) && (zr1 + dz_tgt < zs)) dz = sgn * dz_tgt;
+    else {
+      double Int_zd, Int_zs;
+      if (zr1 >= zd) { Int_zd = Iwtd * (zd - zr1); Int_zs = Int_zd - dInt_zs_zd; }
+      else if (zr1 <= zs) { Int_zs = (zs - zr1); Int_zd = dInt_zs_zd + (zs - zr1); }
+      else {
+        Int_zd = (zd - zr1) * (Iwtd * (0.5 * (zd + zr1) - zs) + 0.5 * (zd - zr1)) * Idzwt;
+        Int_zs = (zs - zr1) * (0.5 * Iwtd * ((zr1 - zs)) + (zd - 0.5 * (zr1 + zs))) * Idzwt;
+      }
+      if (dz_tgt >= Int_zd) dz = sgn * ((zd - zr1) + wtd * (dz_tgt - Int_zd));
+      else if (dz_tgt <= Int_zs) dz = sgn * ((zs - zr1) + (dz_tgt - Int_zs));
+      else {
+        double dz0, z0, F0;
+        if (zr1 <= zs) { dz0 = zs - zr1; z0 = zs; F0 = dz_tgt - Int_zs; }
+        else if (zr1 >= zd) { dz0 = zd - zr1; z0 = zd; F0 = dz_tgt - Int_zd; }
+        else { dz0 = 0.0; z0 = zr1; F0 = dz_tgt; }
+        const double Bq = (dzwt + 2.0 * Aq * (z0 - zs));
+        dz = sgn * (dz0 + 2.0 * F0 * dzwt / (Bq + sqrt(Bq * Bq + 4.0 * Aq * F0 * dzwt)));
+      }
+    }
+    LV(dzI, k) = dz;
+    LV(h_new, k - 1) = dmax(0., LV(h, k - 1) + (dz_prev - dz));                       // calc_h_new_by_dz :1022-1024
+    dz_prev = dz;
+  }
+#undef LV
+}
+
 int check_params(const mom6x_remapping_params *p, int n0, ReconArgs &R, ApplyArgs &A, int n1) {
   REQUIRE(p, MOM6X_EINVAL, "remapping: null parameters");
   REQUIRE(p->scheme == MOM6X_REMAP_PCM || p->scheme == MOM6X_REMAP_PLM || p->scheme == MOM6X_REMAP_PPM_H4, MOM6X_EUNSUPPORTED,
@@ -685,6 +780,29 @@ extern "C" int mom6x_ALE_remap_velocities(mom6x_ctx *c, const mom6x_remapping_pa
   int rc = remap_field(c, p, MOM6X_G_mask2dCu, -1, c->d.ni - 1, 0, c->d.nj - 1, h_old_u, h_new_u, u);
   if (rc) return rc;
   return remap_field(c, p, MOM6X_G_mask2dCv, 0, c->d.ni - 1, -1, c->d.nj - 1, h_old_v, h_new_v, v);
+}
+
+extern "C" int mom6x_ALE_regrid_zstar(mom6x_ctx *c, const mom6x_regrid_zstar_params *p, const double *coordinateResolution,
+                                      const double *h, double *h_new, double *dzRegrid) {
+  REQUIRE(c && p && coordinateResolution && h && h_new && dzRegrid, MOM6X_EINVAL, "ALE_regrid: null argument");
+  REQUIRE(p->old_grid_weight >= 0.0 && p->old_grid_weight < 1.0, MOM6X_EINVAL, "ALE_regrid: old_grid_weight must be in [0, 1)");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  REQUIRE(d.halo >= 1, MOM6X_EINVAL, "ALE_regrid: one halo point needed");
+  if (!c->regrid_res) HIPCHK(hipMalloc(&c->regrid_res, (size_t)d.nk * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(c->regrid_res, coordinateResolution, (size_t)d.nk * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  double *zOld;
+  int rc = ctx_scratch(c, SCR_e, d.nk + 1, &zOld);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(c->flag, 0, sizeof(int), c->stream));
+  const dim3 b(64, 4, 1);
+  KLAUNCH(c, "k_regrid_zstar", k_regrid_zstar, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, c->G, *p, c->GV.Z_to_H,
+          (const double *)c->regrid_res, h, h_new, dzRegrid, zOld, c->flag);
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  REQUIRE(flag == 0, MOM6X_EINVAL, "filtered_grid_motion: z_old and z_new use different sign conventions.");
+  return MOM6X_OK;
 }
 
 extern "C" int mom6x_remapping_core_h(mom6x_ctx *c, const mom6x_remapping_params *p, int ncol, int n0, const double *h0,

@@ -227,6 +227,13 @@ class Dycore:
         check(self.lib, self.lib.mom6x_ALE_remap_velocities(self.ctx, C.byref(CS), _ptr(h_old_u), _ptr(h_old_v), _ptr(h_new_u),
                                                             _ptr(h_new_v), _ptr(u), _ptr(v)))
 
+    def ALE_regrid_zstar(self, CS, coordinateResolution, h, h_new, dzRegrid):
+        """ALE_regrid (MOM_ALE.F90:518) for the z* coordinate; coordinateResolution: nk host values [Z]."""
+        cr = np.ascontiguousarray(coordinateResolution, dtype=np.float64)
+        assert cr.shape == (self.dims.nk,)
+        check(self.lib, self.lib.mom6x_ALE_regrid_zstar(self.ctx, C.byref(CS), cr.ctypes.data_as(C.c_void_p), _ptr(h), _ptr(h_new),
+                                                        _ptr(dzRegrid)))
+
     def remapping_core_h(self, CS, h0, u0, h1, u1):
         """remapping_core_h (MOM_remapping.F90:234) for [ncol][n0] | [ncol][n1] device arrays."""
         ncol, n0 = h0.shape; n1 = h1.shape[1]

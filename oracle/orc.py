@@ -260,6 +260,13 @@ def ALE_remap_velocities(d, G, CS, h_old_u, h_old_v, h_new_u, h_new_v, u, v):
         raise RuntimeError(f"orc_ALE_remap_velocities rc={rc}")
 
 
+def ALE_regrid_zstar(d, G, GV, CS, coordinateResolution, h, h_new, dzRegrid):
+    cr = np.ascontiguousarray(coordinateResolution, dtype=np.float64)
+    rc = lib().orc_ALE_regrid_zstar(C.byref(d), _p(G), C.byref(GV), C.byref(CS), _p(cr), _p(h), _p(h_new), _p(dzRegrid))
+    if rc != 0:
+        raise RuntimeError(f"orc_ALE_regrid_zstar rc={rc}")
+
+
 def eos_density(eos, T, S, p):
     L = lib(); L.orc_eos_density.restype = C.c_double
     return L.orc_eos_density(C.byref(eos), C.c_double(T), C.c_double(S), C.c_double(p))

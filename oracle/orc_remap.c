@@ -538,3 +538,93 @@ int orc_ALE_remap_velocities(const mom6x_dims *d, const double *G, const mom6x_r
   if (rc) return rc;
   return remap_points(d, GM(G, d, MOM6X_G_mask2dCv), 0, d->ni - 1, -1, d->nj - 1, CS, h_old_v, h_new_v, v);
 }
+
+/* ---- regridding: ALE_regrid :518 -> regridding_main MOM_regridding.F90:862 for REGRIDDING_ZSTAR ---------------------- */
+/* build_zstar_column coord_zlike.F90:63-144 (no rigid top); zInterface is 1-based with nk+1 entries */
+static void build_zstar_column(int nk, const double *coordinateResolution, double cs_min_thickness, double depth, double total_thickness,
+                               double *zInterface, double z_scale) {
+  const double min_thickness = orc_min(cs_min_thickness, total_thickness / (double)nk);
+  const double eta = total_thickness - depth;
+  const double stretching = total_thickness / (depth + 0.);
+  zInterface[1] = eta;
+  for (int k = 1; k <= nk; k++) {
+    const double dh = stretching * coordinateResolution[k - 1] * z_scale;
+    zInterface[k + 1] = zInterface[k] - dh;
+  }
+  zInterface[nk + 1] = -depth;
+  for (int k = nk; k >= 1; k--)
+    if (zInterface[k] < (zInterface[k + 1] + min_thickness)) zInterface[k] = zInterface[k + 1] + min_thickness;
+}
+/* filtered_grid_motion :1105-1252 (CS%nk == nk) */
+static int filtered_grid_motion(const mom6x_regrid_zstar_params *CS, int nk, const double *z_old, const double *z_new, double *dz_g) {
+  double sgn;
+  const double test = (z_old[nk + 1] - z_old[1]) * (z_new[nk + 1] - z_new[1]);
+  if (test < 0.0) return MOM6X_EINVAL;
+  else if (test == 0.0) { for (int k = 1; k <= nk + 1; k++) dz_g[k] = 0.0; return MOM6X_OK; }
+  else if ((z_old[nk + 1] - z_old[1]) + (z_new[nk + 1] - z_new[1]) > 0.0) sgn = 1.0;
+  else sgn = -1.0;
+  const double zs = CS->depth_of_time_filter_shallow, zd = CS->depth_of_time_filter_deep;
+  const double wtd = 1.0 - CS->old_grid_weight, Iwtd = 1.0 / wtd;
+  const double dzwt = (zd - zs);
+  double Idzwt = 0.0; if (fabs(zd - zs) > 0.0) Idzwt = 1.0 / (zd - zs);
+  const double dInt_zs_zd = 0.5 * (1.0 + Iwtd) * (zd - zs);
+  const double Aq = 0.5 * (Iwtd - 1.0);
+  dz_g[1] = 0.0;
+  for (int k = 2; k <= nk + 1; k++) {
+    const double z_old_k = z_old[k];
+    const double dz_tgt = sgn * (z_new[k] - z_old_k);
+    const double zr1 = sgn * (z_old_k - z_old[1]);
+    if ((zr1 > zd) && (zr1 + wtd * dz_tgt > zd)) dz_g[k] = sgn * wtd * dz_tgt;
+    else if ((zr1 < zs) && (zr1 + dz_tgt < zs)) dz_g[k] = sgn * dz_tgt;
+    else {
+      double Int_zd, Int_zs;
+      if (zr1 >= zd) { Int_zd = Iwtd * (zd - zr1); Int_zs = Int_zd - dInt_zs_zd; }
+      else if (zr1 <= zs) { Int_zs = (zs - zr1); Int_zd = dInt_zs_zd + (zs - zr1); }
+      else {
+        Int_zd = (zd - zr1) * (Iwtd * (0.5 * (zd + zr1) - zs) + 0.5 * (zd - zr1)) * Idzwt;
+        Int_zs = (zs - zr1) * (0.5 * Iwtd * ((zr1 - zs)) + (zd - 0.5 * (zr1 + zs))) * Idzwt;
+      }
+      if (dz_tgt >= Int_zd) dz_g[k] = sgn * ((zd - zr1) + wtd * (dz_tgt - Int_zd));
+      else if (dz_tgt <= Int_zs) dz_g[k] = sgn * ((zs - zr1) + (dz_tgt - Int_zs));
+      else {
+        double dz0, z0, F0;
+        if (zr1 <= zs) { dz0 = zs - zr1; z0 = zs; F0 = dz_tgt - Int_zs; }
+        else if (zr1 >= zd) { dz0 = zd - zr1; z0 = zd; F0 = dz_tgt - Int_zd; }
+        else { dz0 = 0.0; z0 = zr1; F0 = dz_tgt; }
+        const double Bq = (dzwt + 2.0 * Aq * (z0 - zs));
+        dz_g[k] = sgn * (dz0 + 2.0 * F0 * dzwt / (Bq + sqrt(Bq * Bq + 4.0 * Aq * F0 * dzwt)));
+      }
+    }
+  }
+  return MOM6X_OK;
+}
+/* regridding_main :862-987 (ZSTAR branch) + calc_h_new_by_dz :1008-1037; dzRegrid has nk+1 levels */
+int orc_ALE_regrid_zstar(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_regrid_zstar_params *CS,
+                         const double *coordinateResolution, const double *h, double *h_new, double *dzRegrid) {
+  const int nz = d->nk;
+  const size_t slab = (size_t)d->slab;
+  const double *mT = GM(G, d, MOM6X_G_mask2dT), *bathyT = GM(G, d, MOM6X_G_bathyT);
+  double *zOld = (double *)calloc((size_t)(2 * (nz + 3)), sizeof(double)), *zNew = zOld + nz + 3;
+  double *dz = (double *)calloc((size_t)(nz + 3), sizeof(double));
+  int rc = MOM6X_OK;
+  for (size_t n = 0; n < slab * (size_t)(nz + 1); n++) dzRegrid[n] = 0.0;            /* ALE_regrid :539 */
+  for (int j = -1; j <= d->nj; j++) for (int i = -1; i <= d->ni; i++) {
+    const size_t x = IX2(d, i, j);
+    if (mT[x] == 0.) {                                                                /* :1300-1303, :1030-1033 */
+      for (int k = 0; k < nz; k++) h_new[x + k * slab] = h[x + k * slab];
+      continue;
+    }
+    const double nominalDepth = orc_max((bathyT[x] + CS->Z_ref) * GV->Z_to_H, 0.0);   /* :920-922 */
+    double totalThickness = 0.0;
+    for (int k = 1; k <= nz; k++) totalThickness = totalThickness + h[x + (k - 1) * slab];
+    zOld[nz + 1] = -nominalDepth;
+    for (int k = nz; k >= 1; k--) zOld[k] = zOld[k + 1] + h[x + (k - 1) * slab];
+    build_zstar_column(nz, coordinateResolution, CS->min_thickness, nominalDepth, totalThickness, zNew, GV->Z_to_H);
+    rc = filtered_grid_motion(CS, nz, zOld, zNew, dz);
+    if (rc) break;
+    for (int k = 1; k <= nz + 1; k++) dzRegrid[x + (k - 1) * slab] = dz[k];
+    for (int k = 1; k <= nz; k++) h_new[x + (k - 1) * slab] = orc_max(0., h[x + (k - 1) * slab] + (dz[k] - dz[k + 1]));
+  }
+  free(zOld); free(dz);
+  return rc;
+}

@@ -128,3 +128,44 @@ def test_invariants_of_the_reference_brute_force_tests(orc, scheme, om4):
         assert abs((u1 * h1).sum() - (u0 * h0).sum()) <= max(err, 1e-15) * 4 + 1e-14
         u1, err = orc.remapping_core_h(CSn, h0, u0, h1)     # without boundary extrapolation the schemes are monotone
         assert u1.min() >= u0.min() - 1e-12 and u1.max() <= u0.max() + 1e-12
+
+
+# ---- regridding (z*): the reference holds no numbers for it; invariants and an exactly representable known answer ----
+def test_regrid_zstar_known_answer_and_invariants(orc):
+    from tests import helpers as H
+    from mom6_amd import grid, synth
+    G = abi.G
+    # (a) flat bottom of 100 m, four nominal layers of 25 m, SSH = +2 m, layers squeezed into the top:
+    #     z* puts the interfaces at eta - k * 25 * (102/100) and the bottom at -100 -- exactly representable quarters
+    gg = grid.GlobalGrid(12, 10, kind="cartesian", dx=1.0e4, dy=1.0e4, f0=1e-4, beta=0.0, depth_fn=grid.flat_depth(12, 10, 100.0))
+    d, M = gg.tile(4)
+    GV = abi.vgrid_default()
+    h = np.zeros((4,) + d.shape2()); h[0] = 99.0; h[1:] = 1.0
+    hn = np.zeros_like(h); dz = np.zeros((5,) + d.shape2())
+    orc.ALE_regrid_zstar(d, M, GV, abi.regrid_zstar_params_default(), [25.0] * 4, h, hn, dz)
+    x = (d.joff + 3, d.ioff + 4)
+    assert M[G["mask2dT"]][x] > 0
+    assert np.array_equal(hn[(slice(None),) + x], [25.5, 25.5, 25.5, 25.5])
+    assert np.array_equal(dz[(slice(None),) + x], [0.0, 73.5, 49.0, 24.5, 0.0])
+    # (b) random stacks over a bowl: total thickness kept to round-off, no layer thinner than MIN_THICKNESS (or H/nk),
+    #     the surface and the bottom do not move, and regridding the regridded column changes nothing (fixed point)
+    gg, d, M = H.benchmark_small(nk=10)
+    h, _, _ = synth.make_state(d, M, thin_frac=0.2)
+    cr = np.linspace(50., 800., d.nk); cr *= 4000. / cr.sum()
+    for CS in (abi.regrid_zstar_params_default(), abi.regrid_zstar_params_default(min_thickness=5.0),
+               abi.regrid_zstar_params_default(old_grid_weight=0.4, depth_of_time_filter_shallow=200., depth_of_time_filter_deep=900.)):
+        hn = np.zeros_like(h); dz = np.zeros((d.nk + 1,) + d.shape2())
+        orc.ALE_regrid_zstar(d, M, GV, CS, cr, h, hn, dz)
+        sl = H.interior(d, "h", 1)
+        wet = M[G["mask2dT"]][tuple(sl)] > 0
+        a, b = hn[(Ellipsis,) + tuple(sl)][:, wet], h[(Ellipsis,) + tuple(sl)][:, wet]
+        assert np.abs(a.sum(0) - b.sum(0)).max() <= 1e-12 * b.sum(0).max()
+        assert np.abs(dz[0][tuple(sl)]).max() == 0.0 and np.abs(dz[-1][tuple(sl)][wet]).max() <= 1e-9
+        if CS.old_grid_weight == 0.0:
+            assert a.min() >= min(CS.min_thickness, (b.sum(0) / d.nk).min()) * (1 - 1e-9)
+            hn2 = np.zeros_like(h); dz2 = np.zeros_like(dz)
+            orc.ALE_regrid_zstar(d, M, GV, CS, cr, hn, hn2, dz2)
+            assert np.abs(dz2[(Ellipsis,) + tuple(sl)][:, wet]).max() <= 1e-9
+        else:     # the time filter moves the deep interfaces only part of the way
+            dz0 = np.zeros_like(dz); orc.ALE_regrid_zstar(d, M, GV, abi.regrid_zstar_params_default(), cr, h, np.zeros_like(h), dz0)
+            assert np.abs(dz).sum() < np.abs(dz0).sum()

@@ -129,3 +129,40 @@ def test_rejects_what_is_not_on_the_path(dyc):
     CS = abi.remapping_params_default(9, H_NEGLECT)       # PQM_IH6IH5
     with pytest.raises(RuntimeError, match="remapping method is invalid"):
         dev_core_h(dyc, CS, [1., 1., 1., 1.], [1., 2., 3., 4.], [2., 2.])
+
+
+@pytest.mark.parametrize("cfg", ["island_basin", "benchmark_small", "channel"])
+@pytest.mark.parametrize("mods", [dict(), dict(min_thickness=5.0),
+                                  dict(old_grid_weight=0.4, depth_of_time_filter_shallow=200., depth_of_time_filter_deep=900.),
+                                  dict(old_grid_weight=0.7)])
+def test_ALE_regrid_zstar_then_remap(orc, cfg, mods):
+    """A whole ALE step for the z* coordinate on the device: ALE_regrid (new grid and interface displacements), then the
+    remapping of two tracers and the velocities onto it -- every array bit for bit against the oracle."""
+    import torch
+    from mom6_amd.dycore import Dycore
+    gg, d, M = getattr(H, cfg)(nk=10)
+    GV = abi.vgrid_default()
+    h, u, v = synth.make_state(d, M, thin_frac=0.2)
+    depth = float(M[G["bathyT"]].max())
+    cr = np.linspace(1.0, 6.0, d.nk); cr *= depth / cr.sum()
+    RP = abi.regrid_zstar_params_default(**mods)
+    CS = abi.remapping_params_default(abi.REMAP_PPM_H4, GV.H_subroundoff, om4_remap_via_sub_cells=1, boundary_extrapolation=0)
+    hn_o = np.zeros_like(h); dz_o = np.zeros((d.nk + 1,) + d.shape2())
+    orc.ALE_regrid_zstar(d, M, GV, RP, cr, h, hn_o, dz_o)
+    T = np.ascontiguousarray(10.0 + 5.0 * synth.smooth_field(d, 70, nk=d.nk, ox=0.5, oy=0.5)); To = T.copy()
+    orc.ALE_remap_tracers(d, M, CS, h, hn_o, [To])
+
+    dyc = Dycore(d, M, GV)
+    hd = dyc.to_dev(h)
+    hn_g = torch.zeros_like(hd); dz_g = torch.zeros((d.nk + 1,) + d.shape2(), dtype=torch.float64, device=dyc.device)
+    Tg = dyc.to_dev(T)
+    torch.cuda.synchronize()
+    dyc.ALE_regrid_zstar(RP, cr, hd, hn_g, dz_g)
+    dyc.ALE_remap_tracers(CS, hd, hn_g, [Tg])
+    dyc.sync()
+    sl1 = H.interior(d, "h", 1)
+    H.assert_bitwise(hn_g.cpu().numpy(), hn_o, "h_new", sl1)
+    H.assert_bitwise(dz_g.cpu().numpy(), dz_o, "dzRegrid", sl1)
+    H.assert_bitwise(Tg.cpu().numpy(), To, "T", H.interior(d, "h"))
+    assert np.abs(dz_o).max() > 1.0 and np.abs(To - T).max() > 1e-3
+    dyc.close()
