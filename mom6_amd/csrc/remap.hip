@@ -232,11 +232,11 @@ __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict_
     edge_N = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
   }
   // window at step k (bounding cell k, finishing cell k-1): cells k-2 (mm), k-1 (m), k (c), k+1 (p), k+2 (q)
-  double umm = 0., um = 0., uc = 0., up = U(1), uq = U(2), hmm = 0., hm = 0., hc = 0., hp = H(1), hq = H(2);
+  double umm = 0., um = 0., uc = 0., up = U(1), uq = U(2), hm = 0., hc = 0., hp = H(1), hq = H(2);
   double ed_c = 0., ed_p = edge_1;               // edge(k), edge(k+1)
   double a_m = 0., b_m = 0.;                     // bounded edge values of cell k-1 (a_m already through its pair check with k-2)
   for (int k = 1; k <= N; k++) {
-    umm = um; um = uc; uc = up; up = uq; hmm = hm; hm = hc; hc = hp; hp = hq;
+    umm = um; um = uc; uc = up; up = uq; hm = hc; hc = hp; hp = hq;
     if (k + 2 <= N) { uq = U(k + 2); hq = H(k + 2); }
     ed_c = ed_p;
     const int e = k + 1;                         // the edge below cell k
