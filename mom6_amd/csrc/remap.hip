@@ -169,7 +169,7 @@ __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict_
   if (A.scheme == MOM6X_REMAP_PLM) {                                          // PLM_reconstruction :197-262 (N >= 2)
     const double almost_one = 1. - DBL_EPSILON, hn = A.h_neglect;
     // window at step k: cells k-1 (m), k (c), k+1 (p), k+2 (q); slopes slp(k-1..k+1), mslp(k-1..k)
-    double um = U(1), uc = U(1), up = (N >= 2) ? U(2) : 0., hm = H(1), hc = H(1), hp = (N >= 2) ? H(2) : 0.;
+    double um = U(1), uc = U(1), up = (N >= 2) ? U(2) : 0., hc = H(1), hp = (N >= 2) ? H(2) : 0.;
     double s_m = 0., s_c = 0., s_p = 0., ms_m = 0., ms_c = 0.;   // slp(k-1), slp(k), slp(k+1), mslp(k-1), mslp(k)
     // step k finishes cell k-1; cell 1 and N are written explicitly
     // prime: k = 1: slp(1) = 0, slp(2)
@@ -178,7 +178,7 @@ __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict_
     if (Ucopy) AT(Ucopy, vw, 1) = uc;
     for (int k = 2; k <= N - 1; k++) {
       // shift the window to cell k
-      um = uc; uc = up; hm = hc; hc = hp; up = U(k + 1); hp = H(k + 1);
+      um = uc; uc = up; hc = hp; up = U(k + 1); hp = H(k + 1);
       s_m = s_c; s_c = s_p; ms_m = ms_c;
       s_p = (k + 1 <= N - 1) ? PLM_slope_wa(hc, hp, H(k + 2), hn, uc, up, U(k + 2)) : 0.;     // slp(k+1)
       ms_c = PLM_monotonized_slope(um, uc, up, s_m, s_c, s_p);                                   // mslp(k)
