@@ -170,3 +170,10 @@ def test_rk2_with_device_horizontal_viscosity(orc, cfg, mods):
     from tests import cases
     P.dt = cases.rk2_inputs(c, False, False)["dt"]
     run(orc, c, nsteps=3, bt_mod=dict(strong_drag=1), dev_vv=dict(), hv=P)
+
+
+@pytest.mark.parametrize("ni,nj,nk,halo", [(17, 9, 3, 4), (33, 20, 2, 3), (16, 16, 1, 4), (50, 7, 5, 4), (64, 12, 17, 4)])
+def test_rk2_ragged_tile_sizes(orc, ni, nj, nk, halo):
+    """Tile extents that are not multiples of the 16-face work-group tile or the 64-lane wavefront, a single layer, the
+    narrowest halo the stencils allow: two steps, bit for bit."""
+    run(orc, H.double_gyre(nk=nk, ni=ni, nj=nj, halo=halo), nsteps=2, bt_mod=dict(strong_drag=1))
