@@ -12,6 +12,11 @@ program check_abi
   type(mom6x_pgf_params) :: pg
   type(mom6x_rk2_params) :: rk
   type(mom6x_rk2_hooks) :: hk
+  type(mom6x_eos_params) :: eo
+  type(mom6x_vertvisc_params) :: vv
+  type(mom6x_hor_visc_params) :: hv
+  type(mom6x_remapping_params) :: rm
+  type(mom6x_regrid_zstar_params) :: rz
   integer :: nbad, rc
   nbad = 0
   call chk(0, int(c_sizeof(d)), "mom6x_dims")
@@ -23,6 +28,11 @@ program check_abi
   call chk(6, int(c_sizeof(pg)), "mom6x_pgf_params")
   call chk(7, int(c_sizeof(rk)), "mom6x_rk2_params")
   call chk(8, int(c_sizeof(hk)), "mom6x_rk2_hooks")
+  call chk(9, int(c_sizeof(eo)), "mom6x_eos_params")
+  call chk(10, int(c_sizeof(vv)), "mom6x_vertvisc_params")
+  call chk(11, int(c_sizeof(hv)), "mom6x_hor_visc_params")
+  call chk(12, int(c_sizeof(rm)), "mom6x_remapping_params")
+  call chk(13, int(c_sizeof(rz)), "mom6x_regrid_zstar_params")
   rc = mom6x_dims_init(d, 1440, 1080, 75, 4)
   if (rc /= 0 .or. d%pitch /= 1472 .or. d%ioff /= 16) then
     print *, "mom6x_dims_init mismatch", rc, d%pitch, d%ioff ; nbad = nbad + 1

@@ -259,8 +259,8 @@ typedef struct mom6x_ctx mom6x_ctx;
 const char *mom6x_last_error(void);
 int  mom6x_abi_version(void);
 /* sizeof() of the public structs (0 dims, 1 vgrid, 2 continuity_params, 3 BT_cont, 4 barotropic_params,
- * 5 coriolis_params, 6 pgf_params, 7 rk2_params, 8 rk2_hooks): lets ctypes / ISO_C_BINDING mirrors
- * be checked at start-up.                                                                            */
+ * 5 coriolis_params, 6 pgf_params, 7 rk2_params, 8 rk2_hooks, 9 eos_params, 10 vertvisc_params, 11 hor_visc_params,
+ * 12 remapping_params, 13 regrid_zstar_params): lets ctypes / ISO_C_BINDING mirrors be checked at start-up.  */
 int  mom6x_struct_size(int which);
 
 /* Create a context for one tile on HIP device `device`.  `metrics_host` is a

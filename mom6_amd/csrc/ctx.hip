@@ -121,6 +121,11 @@ extern "C" int mom6x_struct_size(int which) {
     case 6: return (int)sizeof(mom6x_pgf_params);
     case 7: return (int)sizeof(mom6x_rk2_params);
     case 8: return (int)sizeof(mom6x_rk2_hooks);
+    case 9: return (int)sizeof(mom6x_eos_params);
+    case 10: return (int)sizeof(mom6x_vertvisc_params);
+    case 11: return (int)sizeof(mom6x_hor_visc_params);
+    case 12: return (int)sizeof(mom6x_remapping_params);
+    case 13: return (int)sizeof(mom6x_regrid_zstar_params);
     default: return -1;
   }
 }
