@@ -78,24 +78,29 @@ __device__ double face_flux(int scheme, const double *__restrict__ T, const doub
   return uhh * (T[c] - 0.5 * slope * (1. - CFL));
 }
 
-// setup :170-206: remaining transports, reconstructed previous cell volume, flags
+// setup :170-206: remaining transports, reconstructed previous cell volume, flags.  The kernel covers the whole
+// allocated plane and writes zeros outside the computational ranges, so the three work arrays need no memset first.
 __global__ void __launch_bounds__(256)
 k_ta_init(Dm d, const double *__restrict__ G, const double *__restrict__ h_end, const double *__restrict__ uhtr,
           const double *__restrict__ vhtr, double *__restrict__ hprev, double *__restrict__ uhr, double *__restrict__ vhr) {
-  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int ip = blockIdx.x * blockDim.x + threadIdx.x;          // position in the pitched row
+  const int jp = blockIdx.y * blockDim.y + threadIdx.y;          // row of the plane
   const int k = blockIdx.z;
-  if (i < -1 || i > d.ni - 1 || j > d.nj - 1) return;
+  const int nrow = d.slab / d.pitch;
+  if (ip >= d.pitch || jp >= nrow) return;
+  const int i = ip - d.ioff, j = jp - d.joff;
   const int st = d.pitch;
-  const size_t c2 = ix2(d, i, j), c = c2 + (size_t)k * d.slab;
-  if (j >= 0) uhr[c] = uhtr[c];
-  if (i >= 0) vhr[c] = vhtr[c];
-  if (i >= 0 && j >= 0) {
+  const size_t c2 = (size_t)ip + (size_t)jp * (size_t)d.pitch, c = c2 + (size_t)k * d.slab;
+  const bool in_i = (i >= -1 && i <= d.ni - 1), in_j = (j >= -1 && j <= d.nj - 1);
+  uhr[c] = (in_i && in_j && j >= 0) ? uhtr[c] : 0.0;
+  vhr[c] = (in_i && in_j && i >= 0) ? vhtr[c] : 0.0;
+  double hp = 0.0;
+  if (in_i && in_j && i >= 0 && j >= 0) {
     const double aT = gm(G, d, MOM6X_G_areaT)[c2];
-    double hp = dmax(0.0, aT * h_end[c] + ((uhtr[c] - uhtr[c - 1]) + (vhtr[c] - vhtr[c - st])));
+    hp = dmax(0.0, aT * h_end[c] + ((uhtr[c] - uhtr[c - 1]) + (vhtr[c] - vhtr[c - st])));
     hp = hp + dmax(0.0, 1.0e-13 * hp - aT * h_end[c]);
-    hprev[c] = hp;
   }
+  hprev[c] = hp;
 }
 
 // Re-evaluation of the row flags :242-253.  One wave per (row, layer).
@@ -344,14 +349,11 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
   const dim3 b = blk2();
   const double min_h = 0.1 * c->GV.Angstrom_H, h_neglect = c->GV.H_subroundoff;
 
-  HIPCHK(hipMemsetAsync(s->hprev, 0, n3 * sizeof(double), st));
-  HIPCHK(hipMemsetAsync(s->uhr, 0, n3 * sizeof(double), st));
-  HIPCHK(hipMemsetAsync(s->vhr, 0, n3 * sizeof(double), st));
   HIPCHK(hipMemsetAsync(s->uhh, 0, n3 * sizeof(double), st));
   for (int *p : { s->dmu, s->dmv, s->limu, s->limv }) HIPCHK(hipMemsetAsync(p, 0, nf * sizeof(int), st));
   std::vector<int> ones(nz, 1), dmk_h(nz, 1);
   HIPCHK(hipMemcpyAsync(s->dmk, ones.data(), nz * sizeof(int), hipMemcpyHostToDevice, st));
-  KLAUNCH(c, "k_ta_init", k_ta_init, grid3(nxa(d.ni + 1, -1), d.nj + 1, nz, b), b, d, c->G, h_end, uhtr, vhtr, s->hprev, s->uhr, s->vhr);
+  KLAUNCH(c, "k_ta_init", k_ta_init, grid3(d.pitch, d.slab / d.pitch, nz, b), b, d, c->G, h_end, uhtr, vhtr, s->hprev, s->uhr, s->vhr);
 
   auto advect = [&](int dir, int i0, int i1, int j0, int j1) {
     // faces: x: (i0-1..i1, j0..j1); y: (i0..i1, j0-1..j1)
