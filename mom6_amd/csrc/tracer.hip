@@ -235,14 +235,16 @@ k_ta_cell(Dm d, const double *__restrict__ G, double *__restrict__ uhr, double *
 // vertdiff = 1 adds the land mask, ea(1) in the first denominator and the surface/bottom sources.
 __global__ void __launch_bounds__(256)
 k_tridiag(Dm d, const double *__restrict__ G, const double *__restrict__ hold, const double *__restrict__ ea,
-          const double *__restrict__ eb, double *__restrict__ T, double *__restrict__ c1, double h_neglect, int vertdiff,
-          const double *__restrict__ sfc_flux, const double *__restrict__ btm_flux, double flux_scale, int i0, int i1,
+          const double *__restrict__ eb, double *__restrict__ T, double *__restrict__ S, double *__restrict__ c1, double h_neglect,
+          int vertdiff, const double *__restrict__ sfc_flux, const double *__restrict__ btm_flux, double flux_scale, int i0, int i1,
           int j0, int j1) {
+  // S != null: triDiagTS solves for T and S with the same b1, c1, d1 (:411-438) -- one sweep for both
   const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > i1 || j > j1) return;
   const int nz = d.nk;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const bool two = (S != nullptr);
   double sfc_src = 0.0, btm_src = 0.0;
   if (vertdiff) {
     if (!(gm(G, d, MOM6X_G_mask2dT)[x] > 0.0)) return;
@@ -252,9 +254,10 @@ k_tridiag(Dm d, const double *__restrict__ G, const double *__restrict__ hold, c
   double h_tr = hold[x] + h_neglect;
   double b1 = vertdiff ? 1.0 / ((h_tr + ea[x]) + eb[x]) : 1.0 / (h_tr + eb[x]);
   double d1 = h_tr * b1;
-  double prev = (b1 * h_tr) * T[x];
+  double prev = (b1 * h_tr) * T[x], prevS = 0.0;
   if (vertdiff) prev = prev + b1 * sfc_src;
   T[x] = prev;
+  if (two) { prevS = (b1 * h_tr) * S[x]; S[x] = prevS; }
   for (int k = 1; k < nz; k++) {
     const size_t c = x + (size_t)k * slab;
     c1[c] = eb[c - slab] * b1;
@@ -266,11 +269,14 @@ k_tridiag(Dm d, const double *__restrict__ G, const double *__restrict__ hold, c
     if (vertdiff && k == nz - 1) prev = b1 * ((h_tr * T[c] + btm_src) + eak * prev);
     else prev = b1 * (h_tr * T[c] + eak * prev);
     T[c] = prev;
+    if (two) { prevS = b1 * (h_tr * S[c] + eak * prevS); S[c] = prevS; }
   }
   for (int k = nz - 2; k >= 0; k--) {
     const size_t c = x + (size_t)k * slab;
-    prev = T[c] + c1[c + slab] * prev;
+    const double c1k = c1[c + slab];
+    prev = T[c] + c1k * prev;
     T[c] = prev;
+    if (two) { prevS = S[c] + c1k * prevS; S[c] = prevS; }
   }
 }
 
@@ -423,7 +429,7 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
   return MOM6X_OK;
 }
 
-static int tridiag(mom6x_ctx *c, const double *hold, const double *ea, const double *eb, double *T, int vertdiff,
+static int tridiag(mom6x_ctx *c, const double *hold, const double *ea, const double *eb, double *T, double *S, int vertdiff,
                    const double *sfc_flux, const double *btm_flux, double flux_scale, int is, int ie, int js, int je) {
   REQUIRE(c && hold && ea && eb && T, MOM6X_EINVAL, "tridiagonal solve: null array");
   HIPCHK(hipSetDevice(c->device));
@@ -432,7 +438,7 @@ static int tridiag(mom6x_ctx *c, const double *hold, const double *ea, const dou
   int rc;
   if ((rc = ctx_scratch(c, SCR_c1, d.nk, &c1))) return rc;
   const dim3 b = blk2();
-  KLAUNCH(c, "k_tridiag", k_tridiag, grid3(ie - is + 1, je - js + 1, 1, b), b, d, c->G, hold, ea, eb, T, c1, c->GV.H_subroundoff,
+  KLAUNCH(c, "k_tridiag", k_tridiag, grid3(ie - is + 1, je - js + 1, 1, b), b, d, c->G, hold, ea, eb, T, S, c1, c->GV.H_subroundoff,
           vertdiff, sfc_flux, btm_flux, flux_scale, is, ie, js, je);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
@@ -441,9 +447,7 @@ static int tridiag(mom6x_ctx *c, const double *hold, const double *ea, const dou
 // triDiagTS(G, GV, is, ie, js, je, hold, ea, eb, T, S)  diabatic_aux.F90:394 (one field per call; S = second call)
 extern "C" int mom6x_triDiagTS(mom6x_ctx *c, int is, int ie, int js, int je, const double *hold, const double *ea,
                                const double *eb, double *T, double *S) {
-  int rc = tridiag(c, hold, ea, eb, T, 0, nullptr, nullptr, 0.0, is, ie, js, je);
-  if (rc || !S) return rc;
-  return tridiag(c, hold, ea, eb, S, 0, nullptr, nullptr, 0.0, is, ie, js, je);
+  return tridiag(c, hold, ea, eb, T, S, 0, nullptr, nullptr, 0.0, is, ie, js, je);
 }
 // triDiagTS_Eulerian(G, GV, is, ie, js, je, hold, ent, T, S)  :444 ; ent has nk+1 interfaces
 extern "C" int mom6x_triDiagTS_Eulerian(mom6x_ctx *c, int is, int ie, int js, int je, const double *hold, const double *ent,
@@ -456,7 +460,7 @@ extern "C" int mom6x_tracer_vertdiff(mom6x_ctx *c, const double *h_old, const do
                                      double *tr, const double *sfc_flux, const double *btm_flux, int convert_flux) {
   if (c && c->dims.nk == 1) return MOM6X_OK;   // the reference warns and returns
   const double scale = convert_flux ? dt * c->GV.RZ_to_H : 0.0;
-  return tridiag(c, h_old, ea, eb, tr, 1, sfc_flux, btm_flux, scale, 0, c->dims.ni - 1, 0, c->dims.nj - 1);
+  return tridiag(c, h_old, ea, eb, tr, nullptr, 1, sfc_flux, btm_flux, scale, 0, c->dims.ni - 1, 0, c->dims.nj - 1);
 }
 extern "C" int mom6x_tracer_vertdiff_Eulerian(mom6x_ctx *c, const double *h_old, const double *ent, double dt, double *tr,
                                               const double *sfc_flux, const double *btm_flux, int convert_flux) {
