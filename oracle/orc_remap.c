@@ -3,7 +3,9 @@
  * ALE_remap_velocities).  ORACLE (test infrastructure only; see orc_common.h).
  *
  * PARITY PINNED: unlike the rest of the oracle, the reference holds known answers for these routines
- * (remapping_unit_tests, src/ALE/MOM_remapping.F90:2072-2943); tests/test_remap_cpu.py replays them.
+ * (remapping_unit_tests, src/ALE/MOM_remapping.F90:2072-2943); tests/test_remap_cpu.py replays them.  The PLM and PCM
+ * reconstructions are in addition held bit for bit to the reference's own code, compiled from src/ALE/PLM_functions.F90
+ * and PCM_functions.F90 where they lie (oracle/_ref, `make ref`; the only files on this path that need no FMS).
  *
  * Arrays are 1-based inside this file (index 0 unused) so that the index arithmetic of intersect_src_tgt_grids and
  * the sub-cell loops reads exactly as in the reference. */

@@ -169,3 +169,53 @@ def test_regrid_zstar_known_answer_and_invariants(orc):
         else:     # the time filter moves the deep interfaces only part of the way
             dz0 = np.zeros_like(dz); orc.ALE_regrid_zstar(d, M, GV, abi.regrid_zstar_params_default(), cr, h, np.zeros_like(h), dz0)
             assert np.abs(dz).sum() < np.abs(dz0).sum()
+
+
+# ---- the REAL reference code, where it compiles from its own files (oracle/_ref, built by `make -C oracle ref`) ----------
+def _ref_lib():
+    import ctypes as C
+    import os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_ale.so")
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref/libref_ale.so not built (needs /root/reference and amdflang: make -C oracle ref)")
+    L = C.CDLL(p)
+    for f in ("ref_PLM_slope_wa", "ref_PLM_monotonized_slope", "ref_PLM_extrapolate_slope"):
+        getattr(L, f).restype = C.c_double
+    return L
+
+
+def test_oracle_PLM_against_the_compiled_reference(orc):
+    """src/ALE/PLM_functions.F90 and PCM_functions.F90 have no dependencies, so oracle/Makefile compiles them as they
+    lie in the reference tree (amdflang, -fdefault-real-8 as the reference's builds, no FMA contraction) behind the
+    bind(C) doors of oracle/ref_shim.F90.  The oracle's PLM reconstruction -- edge values and coefficients, with and
+    without boundary extrapolation -- must equal the reference's own code BIT FOR BIT on random ragged columns."""
+    import ctypes as C
+    L = _ref_lib()
+    rng = np.random.default_rng(20250808)
+    dbl = C.c_double
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    nchk = 0
+    for it in range(400):
+        n = int(rng.integers(2, 40))
+        h = rng.random(n); h[rng.random(n) < 0.2] = 0.0
+        u = rng.random(n) * 30 - 10
+        if it % 7 == 0:
+            u = np.round(u)                      # ties and exact extrema
+        if it % 11 == 0:
+            u[:] = u[0]
+        hn = (1e-30, 1e-10)[it % 2]
+        for extrap in (0, 1):
+            E1, E2, C1, C2 = orc.PLM_reconstruction(h, u, hn, extrapolate=bool(extrap))
+            edges = np.zeros((2, n)); coefs = np.zeros((2, n))          # Fortran (n,2) = C [2][n]
+            L.ref_PLM_reconstruction(n, ptr(np.ascontiguousarray(h)), ptr(np.ascontiguousarray(u)), ptr(edges), ptr(coefs), dbl(hn), extrap)
+            for a, b, what in ((E1, edges[0], "left edges"), (E2, edges[1], "right edges"), (C1, coefs[0], "P0"), (C2, coefs[1], "P1")):
+                assert np.array_equal(a, b) and np.isfinite(a).all(), (what, it, extrap, a - b)
+            nchk += 1
+    assert nchk == 800
+    # PCM :16-35
+    u = rng.random(9); edges = np.zeros((2, 9)); coefs = np.zeros((1, 9))
+    L.ref_PCM_reconstruction(9, ptr(u), ptr(edges), ptr(coefs))
+    CS = abi.remapping_params_default(abi.REMAP_PCM, H_NEGLECT)
+    assert np.array_equal(edges[0], u) and np.array_equal(edges[1], u) and np.array_equal(coefs[0], u)
+    u1, _ = orc.remapping_core_h(CS, np.ones(9), u, np.ones(9))
+    assert np.array_equal(u1, u)
