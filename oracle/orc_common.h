@@ -16,7 +16,8 @@
  * two (bit-identical, as .testing dim.* requires), layout (1 vs 2 tiles).
  * Two exceptions ARE pinned to numbers the reference itself holds:
  *  - orc_remap.c (MOM_remapping / ALE remapping): the known answers of remapping_unit_tests
- *    (src/ALE/MOM_remapping.F90:2072-2943), replayed by tests/test_remap_cpu.py;
+ *    (src/ALE/MOM_remapping.F90:2072-2943), replayed by tests/test_remap_cpu.py, which also holds its PLM, PPM_H4 and
+ *    sub-grid integration to the REAL reference code compiled from the dependency-free files (oracle/_ref, `make ref`);
  *  - the equation-of-state functions used by the pressure force: the check values of EOS_unit_tests
  *    (MOM_EOS.F90:2077-2079 WRIGHT, :2129-2131 LINEAR) --
  *    tests/test_oracle_cpu.py::test_equation_of_state_against_reference_known_answers.

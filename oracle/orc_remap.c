@@ -4,8 +4,9 @@
  *
  * PARITY PINNED: unlike the rest of the oracle, the reference holds known answers for these routines
  * (remapping_unit_tests, src/ALE/MOM_remapping.F90:2072-2943); tests/test_remap_cpu.py replays them.  The PLM and PCM
- * reconstructions are in addition held bit for bit to the reference's own code, compiled from src/ALE/PLM_functions.F90
- * and PCM_functions.F90 where they lie (oracle/_ref, `make ref`; the only files on this path that need no FMS).
+ * reconstructions, the PPM_H4 chain and the sub-grid integration are in addition held bit for bit to the reference's own
+ * code, compiled where it lies from the files that need no FMS (PLM_functions.F90, PCM_functions.F90,
+ * Recon1d_PPM_H4_2019.F90 + Recon1d_type.F90 + numerical_testing_type.F90): oracle/_ref, `make ref`.
  *
  * Arrays are 1-based inside this file (index 0 unused) so that the index arithmetic of intersect_src_tgt_grids and
  * the sub-cell loops reads exactly as in the reference. */

@@ -1,5 +1,6 @@
 !> ORACLE SUPPORT (test infrastructure only): bind(C) doors into the REAL reference modules that compile from their own
-!! source files without FMS / netCDF (src/ALE/PLM_functions.F90, src/ALE/PCM_functions.F90: no `use` statements at all).
+!! source files without FMS / netCDF (src/ALE/PLM_functions.F90, src/ALE/PCM_functions.F90: no `use` statements at all;
+!! src/ALE/Recon1d_PPM_H4_2019.F90 with Recon1d_type.F90 and src/framework/numerical_testing_type.F90).
 !! oracle/Makefile compiles those two files where they lie under /root/reference together with this file into
 !! oracle/_ref/libref_ale.so; tests/test_remap_cpu.py then holds orc_remap.c's PLM / PCM reconstructions to the
 !! reference's own code, bit for bit, on random columns.  Nothing of the reference is copied here.
@@ -8,8 +9,38 @@ module ref_shim
   use PLM_functions, only : PLM_reconstruction, PLM_boundary_extrapolation, PLM_slope_wa, PLM_monotonized_slope, &
                             PLM_extrapolate_slope
   use PCM_functions, only : PCM_reconstruction
+  use Recon1d_PPM_H4_2019, only : PPM_H4_2019
   implicit none
 contains
+  !> The reference's class-based PPM with explicit 4th-order edge values, 2019 expressions (Recon1d_PPM_H4_2019.F90:86):
+  !! the same algorithm as build_reconstructions_1d's REMAPPING_PPM_H4 branch without boundary extrapolation.
+  subroutine ref_PPM_H4_2019(n, h, u, h_neglect, ul, ur) bind(C, name="ref_PPM_H4_2019")
+    integer(c_int), value :: n
+    real(c_double), intent(in) :: h(n), u(n)
+    real(c_double), value :: h_neglect
+    real(c_double), intent(out) :: ul(n), ur(n)
+    type(PPM_H4_2019) :: r
+    call r%init(int(n), h_neglect=h_neglect)
+    call r%reconstruct(h, u)
+    ul(:) = r%ul(:) ; ur(:) = r%ur(:)
+    call r%destroy()
+  end subroutine
+  !> Recon1d_type.F90:173 remap_to_sub_grid with the PPM_H4_2019 reconstruction: sub-cell averages and integrals (with the
+  !! thickest-sub-cell conservation fix) on a given intersection of the source and target grids.
+  subroutine ref_PPM_H4_2019_to_sub_grid(n0, h0, u0, h_neglect, n1, h_sub, isrc_start, isrc_end, isrc_max, isub_src, &
+                                         u_sub, uh_sub) bind(C, name="ref_PPM_H4_2019_to_sub_grid")
+    integer(c_int), value :: n0, n1
+    real(c_double), intent(in) :: h0(n0), u0(n0), h_sub(n0+n1+1)
+    real(c_double), value :: h_neglect
+    integer(c_int), intent(in) :: isrc_start(n0), isrc_end(n0), isrc_max(n0), isub_src(n0+n1+1)
+    real(c_double), intent(out) :: u_sub(n0+n1+1), uh_sub(n0+n1+1)
+    type(PPM_H4_2019) :: r
+    real(c_double) :: err
+    call r%init(int(n0), h_neglect=h_neglect)
+    call r%reconstruct(h0, u0)
+    call r%remap_to_sub_grid(h0, u0, int(n1), h_sub, isrc_start, isrc_end, isrc_max, isub_src, u_sub, uh_sub, err)
+    call r%destroy()
+  end subroutine
   subroutine ref_PLM_reconstruction(n, h, u, edges, coefs, h_neglect, extrapolate) bind(C, name="ref_PLM_reconstruction")
     integer(c_int), value :: n, extrapolate
     real(c_double), intent(in) :: h(n), u(n)

@@ -219,3 +219,80 @@ def test_oracle_PLM_against_the_compiled_reference(orc):
     assert np.array_equal(edges[0], u) and np.array_equal(edges[1], u) and np.array_equal(coefs[0], u)
     u1, _ = orc.remapping_core_h(CS, np.ones(9), u, np.ones(9))
     assert np.array_equal(u1, u)
+
+
+def test_oracle_PPM_H4_against_the_compiled_reference(orc):
+    """The reference ships a second, dependency-free implementation of the same PPM_H4 (2019 expressions) as a class,
+    src/ALE/Recon1d_PPM_H4_2019.F90 (+ Recon1d_type.F90, numerical_testing_type.F90); oracle/_ref compiles it as it lies.
+    The oracle's edge_values_explicit_h4 -> bound_edge_values -> check_discontinuous_edge_values -> PPM limiter chain
+    (build_reconstructions_1d's REMAPPING_PPM_H4 branch without boundary extrapolation) must give that code's edge
+    values BIT FOR BIT on random ragged columns, vanished layers and ties included."""
+    import ctypes as C
+    L = _ref_lib()
+    if not hasattr(L, "ref_PPM_H4_2019"):
+        pytest.skip("oracle/_ref built without Recon1d_PPM_H4_2019")
+    rng = np.random.default_rng(20250809)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    for it in range(600):
+        n = int(rng.integers(4, 60))
+        h = rng.random(n); h[rng.random(n) < 0.2] = 0.0
+        if it % 13 == 0:
+            h[:] = 0.0; h[rng.integers(0, n)] = 1.0      # a column that is almost entirely vanished
+        u = rng.random(n) * 30 - 10
+        if it % 7 == 0:
+            u = np.round(u)
+        if it % 11 == 0:
+            u[:] = u[0]
+        hn = (1e-30, 1e-10)[it % 2]
+        E1, E2 = orc.edge_values_explicit_h4(h, u, hn)
+        e1, e2, c1, c2, c3 = orc.PPM_reconstruction(h, u, E1, E2, hn)
+        ul, ur = np.zeros(n), np.zeros(n)
+        L.ref_PPM_H4_2019(n, ptr(np.ascontiguousarray(h)), ptr(np.ascontiguousarray(u)), C.c_double(hn), ptr(ul), ptr(ur))
+        assert np.isfinite(ul).all() and np.isfinite(ur).all()
+        assert np.array_equal(e1, ul), (it, n, e1 - ul)
+        assert np.array_equal(e2, ur), (it, n, e2 - ur)
+
+
+def test_oracle_sub_grid_integration_against_the_compiled_reference(orc):
+    """Recon1d_type.F90:173 remap_to_sub_grid (the reference's class-based twin of remap_src_to_sub_grid :962) with the
+    compiled PPM_H4_2019 class, fed with the oracle's intersect_src_tgt_grids: the sub-cell averages of every sub-cell of
+    positive width and ALL sub-cell integrals -- including the thickest-sub-cell conservation fix -- must be bit-identical.
+    (Zero-width sub-cells are point values; the class evaluates those with the interval formula, the OM4-era function
+    with a separate one, so they agree to round-off only and carry no weight.)"""
+    import ctypes as C
+    L = _ref_lib()
+    if not hasattr(L, "ref_PPM_H4_2019_to_sub_grid"):
+        pytest.skip("oracle/_ref built without Recon1d_PPM_H4_2019")
+    rng = np.random.default_rng(20250810)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib = orc.lib()
+    for it in range(400):
+        n0, n1 = int(rng.integers(4, 30)), int(rng.integers(1, 30))
+        h0 = rng.random(n0); h0[rng.random(n0) < 0.15] = 0.0
+        h1 = rng.random(n1); h1[rng.random(n1) < 0.15] = 0.0
+        if h0.sum() == 0 or h1.sum() == 0:
+            continue
+        h1 *= h0.sum() / h1.sum() * (1.0, 0.8, 1.3)[it % 3]
+        u0 = rng.random(n0) * 30 - 10
+        hn = 1e-30
+        r = orc.intersect_src_tgt_grids(h0, h1)
+        ns = n0 + n1 + 1
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        us_ref, uhs_ref = np.zeros(ns), np.zeros(ns)
+        L.ref_PPM_H4_2019_to_sub_grid(n0, ptr(np.ascontiguousarray(h0)), ptr(np.ascontiguousarray(u0)), C.c_double(hn), n1,
+                                      ptr(np.ascontiguousarray(r["h_sub"])), ptr(i32(r["isrc_start"])), ptr(i32(r["isrc_end"])),
+                                      ptr(i32(r["isrc_max"])), ptr(i32(r["isub_src"])), ptr(us_ref), ptr(uhs_ref))
+        # the oracle's chain: PPM_H4 reconstruction (no boundary extrapolation) + remap_src_to_sub_grid (non-OM4)
+        E1, E2 = orc.edge_values_explicit_h4(h0, u0, hn)
+        e1, e2, c1, c2, c3 = orc.PPM_reconstruction(h0, u0, E1, E2, hn)
+        one = lambda a, n: np.concatenate(([0.0], np.asarray(a, dtype=np.float64), [0.0] * (n + 1 - len(a))))
+        ione = lambda a, n: np.concatenate(([0], np.asarray(a, dtype=np.int32), [0] * (n + 1 - len(a)))).astype(np.int32)
+        u_sub, uh_sub = np.zeros(ns + 2), np.zeros(ns + 2); err = C.c_double(0.0)
+        lib.orc_remap_src_to_sub_grid(0, n0, ptr(one(h0, n0)), ptr(one(u0, n0)), ptr(one(e1, n0)), ptr(one(e2, n0)), ptr(one(c1, n0)),
+                                      ptr(one(c2, n0)), n1, ptr(one(r["h_sub"], ns)), ptr(one(r["h0_eff"], n0)), ptr(ione(r["isrc_start"], n0)),
+                                      ptr(ione(r["isrc_end"], n0)), ptr(ione(r["isrc_max"], n0)), ptr(ione(r["isub_src"], ns + 1)), 3, 0,
+                                      ptr(u_sub), ptr(uh_sub), C.byref(err))
+        pos = r["h_sub"] > 0
+        assert np.array_equal(u_sub[1:ns + 1][pos], us_ref[pos]), (it, u_sub[1:ns + 1][pos] - us_ref[pos])
+        assert np.array_equal(uh_sub[1:ns + 1], uhs_ref), (it, uh_sub[1:ns + 1] - uhs_ref)
+        assert np.abs(u_sub[1:ns + 1] - us_ref).max() <= 1e-12 * max(np.abs(u0).max(), 1.0)
