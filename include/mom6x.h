@@ -154,7 +154,7 @@ typedef struct mom6x_coriolis_params {
   int KE_Scheme;         /* KE_ARAKAWA                                                          */
   int bound_Coriolis;    /* BOUND_CORIOLIS (F; tc1/p0: T)                                       */
   int no_slip;           /* NOSLIP (F)                                                          */
-  int Coriolis_En_Dis;   /* CORIOLIS_EN_DIS (F) -- only F supported                             */
+  int Coriolis_En_Dis;   /* CORIOLIS_EN_DIS (F): the energy-dissipating biased SADOURNY75_ENERGY scheme  */
 } mom6x_coriolis_params;
 
 /* PressureForce_FV_CS (src/core/MOM_PressureForce_FV.F90:40-110; PressureForce_FV_init :2020). */

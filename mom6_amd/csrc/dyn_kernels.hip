@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256)
 k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
             const double *__restrict__ uh, const double *__restrict__ vh, const double *__restrict__ q,
             const double *__restrict__ absv, const double *__restrict__ KE, double *__restrict__ CAu,
-            double *__restrict__ CAv, int scheme, int bound) {
+            double *__restrict__ CAv, int scheme, int bound, const double *__restrict__ h, int en_dis) {
   const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -104,13 +104,48 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
   const bool do_u = (j >= 0), do_v = (i >= 0);
   const double IdxCu = gm(G, d, MOM6X_G_IdxCu)[x], IdyCv = gm(G, d, MOM6X_G_IdyCv)[x];
   const double C1_12 = 1.0 / 12.0;
+  // CORIOLIS_EN_DIS (:326-333, :590-635): the centred thickness transport of a face and the one the continuity solver
+  // gave bracket the transport used by the energy-dissipating scheme; recomputed here for the four faces each point needs
+  auto bracket = [](double Lf, double vel, double hsum, double hm_in, double &mn, double &mx) {
+    const double c1 = 1.0 - 1.5 * 0.5, c2 = 1.0 - 0.5, c3 = 2.0, slope = 0.5;
+    double uhc = 0.5 * ((Lf * 1.0) * vel) * hsum, uhm = hm_in;
+    if (Lf == 0.0) uhc = uhm;
+    if (fabs(uhc) < 0.1 * fabs(uhm)) uhm = 10.0 * uhc;
+    else if (fabs(uhc) > c1 * fabs(uhm)) {
+      if (fabs(uhc) < c2 * fabs(uhm)) uhc = (3.0 * uhc + (1.0 - c2 * 3.0) * uhm);
+      else if (fabs(uhc) <= c3 * fabs(uhm)) uhc = uhm;
+      else uhc = slope * uhc + (1.0 - c3 * slope) * uhm;
+    }
+    if (uhc > uhm) { mn = uhm; mx = uhc; } else { mx = uhm; mn = uhc; }
+  };
+  double Lv[4] = {0., 0., 0., 0.}, Lu[4] = {0., 0., 0., 0.};
+  if (en_dis) {
+    const double *dx_Cv = gm(G, d, MOM6X_G_dx_Cv), *dy_Cu = gm(G, d, MOM6X_G_dy_Cu);
+    if (do_u) { Lv[0] = dx_Cv[x]; Lv[1] = dx_Cv[x + 1]; Lv[2] = dx_Cv[x - st]; Lv[3] = dx_Cv[x + 1 - st]; }
+    if (do_v) { Lu[0] = dy_Cu[x - 1]; Lu[1] = dy_Cu[x - 1 + st]; Lu[2] = dy_Cu[x]; Lu[3] = dy_Cu[x + st]; }
+  }
   for (int k = k0; k < k1; k++) {
     const size_t c = x + (size_t)k * slab;
     const double q00 = q[c];
     if (do_u) {
       const double q0m = q[c - st];
       double ca;
-      if (scheme == MOM6X_SADOURNY75_ENERGY) {
+      if (scheme == MOM6X_SADOURNY75_ENERGY && en_dis) {   // :665-684
+        double mn0, mx0, mn1, mx1, mn2, mx2, mn3, mx3;      // v faces (i,J), (i+1,J), (i,J-1), (i+1,J-1)
+        bracket(Lv[0], v[c], h[c] + h[c + st], vh[c], mn0, mx0);
+        bracket(Lv[1], v[c + 1], h[c + 1] + h[c + 1 + st], vh[c + 1], mn1, mx1);
+        bracket(Lv[2], v[c - st], h[c - st] + h[c], vh[c - st], mn2, mx2);
+        bracket(Lv[3], v[c + 1 - st], h[c + 1 - st] + h[c + 1], vh[c + 1 - st], mn3, mx3);
+        const double uk = u[c];
+        double temp1, temp2;
+        if (q00 * uk == 0.0) temp1 = q00 * ((mx0 + mx1) + (mn0 + mn1)) * 0.5;
+        else if (q00 * uk < 0.0) temp1 = q00 * (mx0 + mx1);
+        else temp1 = q00 * (mn0 + mn1);
+        if (q0m * uk == 0.0) temp2 = q0m * ((mx2 + mx3) + (mn2 + mn3)) * 0.5;
+        else if (q0m * uk < 0.0) temp2 = q0m * (mx2 + mx3);
+        else temp2 = q0m * (mn2 + mn3);
+        ca = 0.25 * IdxCu * (temp1 + temp2);
+      } else if (scheme == MOM6X_SADOURNY75_ENERGY) {
         ca = 0.25 * ((q00 * (vh[c + 1] + vh[c])) + (q0m * (vh[c - st] + vh[c + 1 - st]))) * IdxCu;
       } else if (scheme == MOM6X_SADOURNY75_ENSTRO) {
         ca = 0.125 * (IdxCu * (q00 + q0m)) * ((vh[c + 1] + vh[c]) + (vh[c - st] + vh[c + 1 - st]));
@@ -132,7 +167,22 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
     if (do_v) {
       const double qm0 = q[c - 1];
       double ca;
-      if (scheme == MOM6X_SADOURNY75_ENERGY) {
+      if (scheme == MOM6X_SADOURNY75_ENERGY && en_dis) {   // :776-795
+        double mn0, mx0, mn1, mx1, mn2, mx2, mn3, mx3;      // u faces (I-1,j), (I-1,j+1), (I,j), (I,j+1)
+        bracket(Lu[0], u[c - 1], h[c - 1] + h[c], uh[c - 1], mn0, mx0);
+        bracket(Lu[1], u[c - 1 + st], h[c - 1 + st] + h[c + st], uh[c - 1 + st], mn1, mx1);
+        bracket(Lu[2], u[c], h[c] + h[c + 1], uh[c], mn2, mx2);
+        bracket(Lu[3], u[c + st], h[c + st] + h[c + 1 + st], uh[c + st], mn3, mx3);
+        const double vk = v[c];
+        double temp1, temp2;
+        if (qm0 * vk == 0.0) temp1 = qm0 * ((mx0 + mx1) + (mn0 + mn1)) * 0.5;
+        else if (qm0 * vk > 0.0) temp1 = qm0 * (mx0 + mx1);
+        else temp1 = qm0 * (mn0 + mn1);
+        if (q00 * vk == 0.0) temp2 = q00 * ((mx2 + mx3) + (mn2 + mn3)) * 0.5;
+        else if (q00 * vk > 0.0) temp2 = q00 * (mx2 + mx3);
+        else temp2 = q00 * (mn2 + mn3);
+        ca = -0.25 * IdyCv * (temp1 + temp2);
+      } else if (scheme == MOM6X_SADOURNY75_ENERGY) {
         ca = -0.25 * ((qm0 * (uh[c - 1] + uh[c - 1 + st])) + (q00 * (uh[c] + uh[c + st]))) * IdyCv;
       } else if (scheme == MOM6X_SADOURNY75_ENSTRO) {
         ca = -0.125 * (IdyCv * (qm0 + q00)) * ((uh[c - 1] + uh[c - 1 + st]) + (uh[c] + uh[c + st]));
@@ -326,12 +376,13 @@ k_vertvisc_remnant(Dm d, const double *__restrict__ G, double *__restrict__ vr, 
 // ---------------------------------------------------------------------------------------------
 extern "C" int mom6x_CoriolisAdv_init(mom6x_ctx *c, const mom6x_coriolis_params *p) {
   REQUIRE(c && p, MOM6X_EINVAL, "mom6x_CoriolisAdv_init: null argument");
-  REQUIRE(!p->Coriolis_En_Dis, MOM6X_EUNSUPPORTED, "CoriolisAdv: CORIOLIS_EN_DIS is not supported");
   REQUIRE(p->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY || p->Coriolis_Scheme == MOM6X_SADOURNY75_ENSTRO ||
           p->Coriolis_Scheme == MOM6X_ARAKAWA_HSU90, MOM6X_EUNSUPPORTED,
           "CoriolisAdv: only SADOURNY75_ENERGY, SADOURNY75_ENSTRO and ARAKAWA_HSU90 are implemented");
   REQUIRE(p->KE_Scheme >= MOM6X_KE_ARAKAWA && p->KE_Scheme <= MOM6X_KE_GUDONOV, MOM6X_EINVAL, "CoriolisAdv: bad KE_SCHEME");
   c->cor = *p;
+  // CoriolisAdv_init :1158: with CORIOLIS_EN_DIS and SADOURNY75_ENERGY the bound is always effectively off
+  if (c->cor.Coriolis_En_Dis && c->cor.Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY) c->cor.bound_Coriolis = 0;
   c->cor_init = true;
   return MOM6X_OK;
 }
@@ -357,7 +408,7 @@ extern "C" int mom6x_CorAdCalc(mom6x_ctx *c, const double *u, const double *v, c
   KLAUNCH(c, "k_corad_q", k_corad_q, gridk(nxa(d.ni + 3, -2), d.nj + 3, d.nk, b), b, d, c->G, u, v, h, q, absv, KE,
           c->cor.no_slip, c->cor.KE_Scheme, vol_neglect);
   KLAUNCH(c, "k_corad_acc", k_corad_acc, gridk(nxa(d.ni + 1, -1), d.nj + 1, d.nk, b), b, d, c->G, u, v, uh, vh, q, absv, KE,
-          CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis);
+          CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h, c->cor.Coriolis_En_Dis);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }

@@ -21,7 +21,6 @@ void orc_pass_var(const mom6x_dims *d, double *a, int stagger, int nk);
 int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_coriolis_params *CS,
                   const double *u, const double *v, const double *h, const double *uh, const double *vh,
                   double *CAu, double *CAv) {
-  if (CS->Coriolis_En_Dis) return MOM6X_EUNSUPPORTED;
   if (CS->Coriolis_Scheme != MOM6X_SADOURNY75_ENERGY && CS->Coriolis_Scheme != MOM6X_SADOURNY75_ENSTRO &&
       CS->Coriolis_Scheme != MOM6X_ARAKAWA_HSU90) return MOM6X_EUNSUPPORTED;
   const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1, nz = d->nk, st = d->pitch;
@@ -37,6 +36,11 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
 #define NEW2(x) double *x = (double *)calloc(slab, sizeof(double))
   NEW2(Area_h); NEW2(Area_q); NEW2(dvdx); NEW2(dudy); NEW2(hArea_u); NEW2(hArea_v); NEW2(rel_vort); NEW2(abs_vort);
   NEW2(q); NEW2(a); NEW2(b); NEW2(c); NEW2(dd); NEW2(KE); NEW2(KEx); NEW2(KEy);
+  NEW2(uh_min); NEW2(uh_max); NEW2(vh_min); NEW2(vh_max);
+  const double *dy_Cu = GM(G, d, MOM6X_G_dy_Cu), *dx_Cv = GM(G, d, MOM6X_G_dx_Cv);
+  /* CoriolisAdv_init :1119, :1158: ROBUST_ENSTRO switches En_Dis off; En_Dis with SADOURNY75_ENERGY switches the bound off */
+  const int en_dis = CS->Coriolis_En_Dis;
+  const int bound_Coriolis = CS->bound_Coriolis && !(en_dis && CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY);
 
   for (int j = Jsq - 1; j <= Jeq + 2; j++) for (int i = Isq - 1; i <= Ieq + 2; i++) {
     size_t x = IX2(d, i, j); Area_h[x] = mT[x] * areaT[x];
@@ -85,6 +89,35 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
         }
       }
     }
+    if (en_dis) {   /* uh_center, vh_center :326-333 and the bracketing transports :590-635 */
+      const double c1 = 1.0 - 1.5 * 0.5, c2 = 1.0 - 0.5, c3 = 2.0, slope = 0.5;
+      for (int j = Jsq; j <= Jeq + 1; j++) for (int i = is - 1; i <= ie; i++) {
+        size_t x = IX2(d, i, j);
+        double uhc = 0.5 * ((dy_Cu[x] * 1.0) * uk[x]) * (hk[x] + hk[x + 1]);
+        double uhm = uhk[x];
+        if (dy_Cu[x] == 0.0) uhc = uhm;
+        if (fabs(uhc) < 0.1 * fabs(uhm)) uhm = 10.0 * uhc;
+        else if (fabs(uhc) > c1 * fabs(uhm)) {
+          if (fabs(uhc) < c2 * fabs(uhm)) uhc = (3.0 * uhc + (1.0 - c2 * 3.0) * uhm);
+          else if (fabs(uhc) <= c3 * fabs(uhm)) uhc = uhm;
+          else uhc = slope * uhc + (1.0 - c3 * slope) * uhm;
+        }
+        if (uhc > uhm) { uh_min[x] = uhm; uh_max[x] = uhc; } else { uh_max[x] = uhm; uh_min[x] = uhc; }
+      }
+      for (int j = js - 1; j <= je; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+        size_t x = IX2(d, i, j);
+        double vhc = 0.5 * ((dx_Cv[x] * 1.0) * vk[x]) * (hk[x] + hk[x + st]);
+        double vhm = vhk[x];
+        if (dx_Cv[x] == 0.0) vhc = vhm;
+        if (fabs(vhc) < 0.1 * fabs(vhm)) vhm = 10.0 * vhc;
+        else if (fabs(vhc) > c1 * fabs(vhm)) {
+          if (fabs(vhc) < c2 * fabs(vhm)) vhc = (3.0 * vhc + (1.0 - c2 * 3.0) * vhm);
+          else if (fabs(vhc) <= c3 * fabs(vhm)) vhc = vhm;
+          else vhc = slope * vhc + (1.0 - c3 * slope) * vhm;
+        }
+        if (vhc > vhm) { vh_min[x] = vhm; vh_max[x] = vhc; } else { vh_max[x] = vhm; vh_min[x] = vhc; }
+      }
+    }
     /* gradKE :969-1052 */
     for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
       size_t x = IX2(d, i, j);
@@ -112,13 +145,22 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
     for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
       size_t x = IX2(d, i, j);
       double ca;
-      if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY)
+      if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY && en_dis) {   /* :665-684 energy dissipating biased scheme */
+        double temp1, temp2;
+        if (q[x] * uk[x] == 0.0) temp1 = q[x] * ((vh_max[x] + vh_max[x + 1]) + (vh_min[x] + vh_min[x + 1])) * 0.5;
+        else if (q[x] * uk[x] < 0.0) temp1 = q[x] * (vh_max[x] + vh_max[x + 1]);
+        else temp1 = q[x] * (vh_min[x] + vh_min[x + 1]);
+        if (q[x - st] * uk[x] == 0.0) temp2 = q[x - st] * ((vh_max[x - st] + vh_max[x + 1 - st]) + (vh_min[x - st] + vh_min[x + 1 - st])) * 0.5;
+        else if (q[x - st] * uk[x] < 0.0) temp2 = q[x - st] * (vh_max[x - st] + vh_max[x + 1 - st]);
+        else temp2 = q[x - st] * (vh_min[x - st] + vh_min[x + 1 - st]);
+        ca = 0.25 * IdxCu[x] * (temp1 + temp2);
+      } else if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY)
         ca = 0.25 * ((q[x] * (vhk[x + 1] + vhk[x])) + (q[x - st] * (vhk[x - st] + vhk[x + 1 - st]))) * IdxCu[x];
       else if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENSTRO)
         ca = 0.125 * (IdxCu[x] * (q[x] + q[x - st])) * ((vhk[x + 1] + vhk[x]) + (vhk[x - st] + vhk[x + 1 - st]));
       else
         ca = (((a[x] * vhk[x + 1]) + (c[x] * vhk[x - st])) + ((b[x] * vhk[x]) + (dd[x] * vhk[x + 1 - st]))) * IdxCu[x];
-      if (CS->bound_Coriolis) {
+      if (bound_Coriolis) {
         double fv1 = abs_vort[x] * vk[x + 1], fv2 = abs_vort[x] * vk[x];
         double fv3 = abs_vort[x - st] * vk[x + 1 - st], fv4 = abs_vort[x - st] * vk[x - st];
         double max_fv = orc_max(orc_max(orc_max(fv1, fv2), fv3), fv4), min_fv = orc_min(orc_min(orc_min(fv1, fv2), fv3), fv4);
@@ -130,13 +172,22 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
     for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) {
       size_t x = IX2(d, i, j);
       double ca;
-      if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY)
+      if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY && en_dis) {   /* :776-795 */
+        double temp1, temp2;
+        if (q[x - 1] * vk[x] == 0.0) temp1 = q[x - 1] * ((uh_max[x - 1] + uh_max[x - 1 + st]) + (uh_min[x - 1] + uh_min[x - 1 + st])) * 0.5;
+        else if (q[x - 1] * vk[x] > 0.0) temp1 = q[x - 1] * (uh_max[x - 1] + uh_max[x - 1 + st]);
+        else temp1 = q[x - 1] * (uh_min[x - 1] + uh_min[x - 1 + st]);
+        if (q[x] * vk[x] == 0.0) temp2 = q[x] * ((uh_max[x] + uh_max[x + st]) + (uh_min[x] + uh_min[x + st])) * 0.5;
+        else if (q[x] * vk[x] > 0.0) temp2 = q[x] * (uh_max[x] + uh_max[x + st]);
+        else temp2 = q[x] * (uh_min[x] + uh_min[x + st]);
+        ca = -0.25 * IdyCv[x] * (temp1 + temp2);
+      } else if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY)
         ca = -0.25 * ((q[x - 1] * (uhk[x - 1] + uhk[x - 1 + st])) + (q[x] * (uhk[x] + uhk[x + st]))) * IdyCv[x];
       else if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENSTRO)
         ca = -0.125 * (IdyCv[x] * (q[x - 1] + q[x])) * ((uhk[x - 1] + uhk[x - 1 + st]) + (uhk[x] + uhk[x + st]));
       else
         ca = -(((a[x - 1] * uhk[x - 1]) + (c[x + st] * uhk[x + st])) + ((b[x] * uhk[x]) + (dd[x - 1 + st] * uhk[x - 1 + st]))) * IdyCv[x];
-      if (CS->bound_Coriolis) {
+      if (bound_Coriolis) {
         double fu1 = -abs_vort[x] * uk[x + st], fu2 = -abs_vort[x] * uk[x];
         double fu3 = -abs_vort[x - 1] * uk[x - 1 + st], fu4 = -abs_vort[x - 1] * uk[x - 1];
         double max_fu = orc_max(orc_max(orc_max(fu1, fu2), fu3), fu4), min_fu = orc_min(orc_min(orc_min(fu1, fu2), fu3), fu4);
@@ -145,7 +196,7 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
       CAvk[x] = ca - KEy[x];
     }
   }
-  double *all[] = { Area_h, Area_q, dvdx, dudy, hArea_u, hArea_v, rel_vort, abs_vort, q, a, b, c, dd, KE, KEx, KEy };
+  double *all[] = { Area_h, Area_q, dvdx, dudy, hArea_u, hArea_v, rel_vort, abs_vort, q, a, b, c, dd, KE, KEx, KEy, uh_min, uh_max, vh_min, vh_max };
   for (size_t m = 0; m < sizeof(all) / sizeof(all[0]); m++) free(all[m]);
   return MOM6X_OK;
 }

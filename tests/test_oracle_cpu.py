@@ -295,3 +295,31 @@ def test_horizontal_viscosity_better_bounds_are_stable(orc):
             if on:
                 assert (pl[nm][tuple(hs)][wet] > 0).all()
         assert (pl["red_xx"][tuple(hs)] <= 1.0).all() and (pl["red_xx"][tuple(hs)] < 1.0).any()
+
+
+def test_coriolis_en_dis_reduces_to_sadourny_for_centred_transports(orc):
+    """CORIOLIS_EN_DIS (.testing/tc4) brackets each face transport between the continuity solver's value and the centred
+    estimate 0.5*dy_Cu*u*(h_i + h_i+1).  When the two coincide the brackets collapse and the energy-dissipating scheme
+    must return the energy-conserving SADOURNY75_ENERGY accelerations EXACTLY; when they differ it must not."""
+    gg, d, M = H.double_gyre(nk=3)
+    GV = abi.vgrid_default()
+    h, u, v = synth.make_state(d, M, thin_frac=0.05)
+    G = abi.G
+    uh = np.ascontiguousarray(0.5 * ((M[G["dy_Cu"]][None] * 1.0) * u) * (h + np.roll(h, -1, axis=2)))
+    vh = np.ascontiguousarray(0.5 * ((M[G["dx_Cv"]][None] * 1.0) * v) * (h + np.roll(h, -1, axis=1)))
+    out = {}
+    for en in (0, 1):
+        CS = abi.coriolis_params_default(); CS.Coriolis_En_Dis = en
+        CAu, CAv = np.zeros_like(h), np.zeros_like(h)
+        orc.CorAdCalc(d, M, GV, CS, u, v, h, uh, vh, CAu, CAv)
+        out[en] = (CAu, CAv)
+    su, sv = H.interior(d, "u"), H.interior(d, "v")
+    assert np.array_equal(out[0][0][(Ellipsis,) + tuple(su)], out[1][0][(Ellipsis,) + tuple(su)])
+    assert np.array_equal(out[0][1][(Ellipsis,) + tuple(sv)], out[1][1][(Ellipsis,) + tuple(sv)])
+    CS = abi.coriolis_params_default(); CS.Coriolis_En_Dis = 1
+    CAu, CAv = np.zeros_like(h), np.zeros_like(h)
+    orc.CorAdCalc(d, M, GV, CS, u, v, h, np.ascontiguousarray(1.7 * uh), np.ascontiguousarray(0.4 * vh), CAu, CAv)
+    CS0 = abi.coriolis_params_default()
+    CAu0, CAv0 = np.zeros_like(h), np.zeros_like(h)
+    orc.CorAdCalc(d, M, GV, CS0, u, v, h, np.ascontiguousarray(1.7 * uh), np.ascontiguousarray(0.4 * vh), CAu0, CAv0)
+    assert np.abs(CAu - CAu0)[(Ellipsis,) + tuple(su)].max() > 0
