@@ -11,7 +11,7 @@ module mom6x_c_api
   public :: mom6x_dims, mom6x_vgrid, mom6x_continuity_params, mom6x_BT_cont, mom6x_barotropic_params
   public :: mom6x_coriolis_params, mom6x_pgf_params, mom6x_eos_params, mom6x_rk2_params, mom6x_rk2_hooks
   public :: mom6x_PressureForce_set_tv, mom6x_vertvisc_params, mom6x_vertvisc_init, mom6x_vertvisc_set_visc, mom6x_vertvisc_coef
-  public :: mom6x_hor_visc_params, mom6x_hor_visc_init, mom6x_horizontal_viscosity
+  public :: mom6x_hor_visc_params, mom6x_hor_visc_init, mom6x_horizontal_viscosity, mom6x_vertvisc_set_direct_stress
   public :: mom6x_remapping_params, mom6x_ALE_remap_tracers, mom6x_ALE_remap_set_h_vel, mom6x_ALE_remap_velocities
   public :: mom6x_remapping_core_h, mom6x_regrid_zstar_params, mom6x_ALE_regrid_zstar
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
@@ -267,6 +267,11 @@ module mom6x_c_api
       import :: c_ptr, c_int, mom6x_remapping_params
       type(c_ptr), value :: ctx, h0, u0, h1, u1 ; type(mom6x_remapping_params), intent(in) :: p
       integer(c_int), value :: ncol, n0, n1
+    end function
+    !> DIRECT_STRESS / HMIX_STRESS (MOM_vert_friction.F90:3208, :707); h = vertvisc's thickness argument (device pointer)
+    integer(c_int) function mom6x_vertvisc_set_direct_stress(ctx, Hmix_stress, h) bind(C, name="mom6x_vertvisc_set_direct_stress")
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, h ; real(c_double), value :: Hmix_stress
     end function
     !> hor_visc_init (MOM_hor_visc.F90:2322): the 2-D viscosity planes are made on the device from the metric block
     integer(c_int) function mom6x_hor_visc_init(ctx, p) bind(C, name="mom6x_hor_visc_init")

@@ -478,6 +478,10 @@ int mom6x_vertvisc_coef(mom6x_ctx *ctx, const double *u, const double *v, const 
 double *mom6x_vertvisc_field(mom6x_ctx *ctx, int which);
 int mom6x_vertvisc(mom6x_ctx *ctx, double *u, double *v, const double *taux, const double *tauy,
                    double dt, double *taux_bot, double *tauy_bot);
+/* DIRECT_STRESS / HMIX_STRESS (vertvisc_init :3208, :3258-3268; vertvisc :707-720, :958-971): with Hmix_stress > 0 the wind
+ * stress is distributed as a body force over the topmost Hmix_stress [H] of fluid instead of entering as the surface
+ * boundary condition.  h is vertvisc's third argument (device pointer, kept); mom6x_step_dyn_split_RK2 uses its own h. */
+int mom6x_vertvisc_set_direct_stress(mom6x_ctx *ctx, double Hmix_stress, const double *h);
 /* vertvisc_remnant(visc, visc_rem_u, visc_rem_v, dt, G, GV, US, CS)  :1229                   */
 int mom6x_vertvisc_remnant(mom6x_ctx *ctx, double *visc_rem_u, double *visc_rem_v, double dt);
 

@@ -282,29 +282,50 @@ k_pgf_main(Dm d, const double *__restrict__ G, const double *__restrict__ h, con
   }
 }
 
+// DIRECT_STRESS (:707-720 / :958-971): the wind stress as a body force over the topmost HMIX_STRESS instead of a stress
+// boundary condition.  The increment of layer k is added where the sweep picks the layer's velocity up.
+struct DirectStress { double Hmix, I_Hmix, h_neglect; const double *h; };
+struct DSWalk {
+  bool on; double zDS, stress;
+  __device__ __forceinline__ void start(const DirectStress &S, double dt_Rho0, double tau) { on = (S.Hmix > 0.0); zDS = 0.0; stress = dt_Rho0 * tau; }
+  __device__ __forceinline__ double add(const DirectStress &S, double uk, size_t x3, int st) {
+    if (!on) return uk;
+    const double h_a = 0.5 * (S.h[x3] + S.h[x3 + st]) + S.h_neglect;
+    double hfr = 1.0; if ((zDS + h_a) > S.Hmix) hfr = (S.Hmix - zDS) / h_a;
+    uk = uk + S.I_Hmix * hfr * stress;
+    zDS = zDS + h_a; if (zDS >= S.Hmix) on = false;
+    return uk;
+  }
+};
+static DirectStress direct_stress_of(const mom6x_ctx *c) {
+  DirectStress S; S.Hmix = c->ds_Hmix; S.I_Hmix = (c->ds_Hmix > 0.0) ? 1.0 / c->ds_Hmix : 0.0; S.h_neglect = c->GV.H_subroundoff; S.h = c->ds_h;
+  return S;
+}
+
 // ---------------------------------------------------------------------------------------------
 // vertvisc :557-1228 (one direction); c1 is a 3-D scratch array.
 template <int DIR>
 __global__ void __launch_bounds__(256)
 k_vertvisc(Dm d, const double *__restrict__ G, double *__restrict__ u, const double *__restrict__ a_u,
            const double *__restrict__ h_u, const double *__restrict__ Ray_u, const double *__restrict__ tau,
-           double *__restrict__ c1, double dt, double dt_Rho0, double H_to_RZ, double *__restrict__ tau_bot) {
+           double *__restrict__ c1, double dt, double dt_Rho0, double H_to_RZ, double *__restrict__ tau_bot, DirectStress S) {
   const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
   if (i < ((DIR ? 0 : -1))) return;
-  const int nz = d.nk;
+  const int nz = d.nk, st = DIR ? d.pitch : 1;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
   if (mC > 0.) {
-    const double surface_stress = dt_Rho0 * (mC * tau[x]);
+    const double surface_stress = (S.Hmix > 0.0) ? 0.0 : dt_Rho0 * (mC * tau[x]);
+    DSWalk W; W.start(S, dt_Rho0, tau[x]);
     double Ray = Ray_u ? Ray_u[x] : 0.;
     double a_k = a_u[x], a_kp = a_u[x + slab];
     double hu = h_u[x];
     double b_denom_1 = hu + dt * (Ray + a_k);
     double b1 = 1.0 / (b_denom_1 + dt * a_kp);
     double d1 = b_denom_1 * b1;
-    double uprev = b1 * (hu * u[x] + surface_stress);
+    double uprev = b1 * (hu * W.add(S, u[x], x, st) + surface_stress);
     u[x] = uprev;
     for (int k = 1; k < nz; k++) {
       const size_t x3 = x + (size_t)k * slab;
@@ -315,7 +336,7 @@ k_vertvisc(Dm d, const double *__restrict__ G, double *__restrict__ u, const dou
       b_denom_1 = hu + dt * (Ray + a_k * d1);
       b1 = 1.0 / (b_denom_1 + dt * a_kp);
       d1 = b_denom_1 * b1;
-      uprev = (hu * u[x3] + dt * a_k * uprev) * b1;
+      uprev = (hu * W.add(S, u[x3], x3, st) + dt * a_k * uprev) * b1;
       u[x3] = uprev;
     }
     for (int k = nz - 2; k >= 0; k--) {
@@ -687,16 +708,17 @@ k_vertvisc_fused(Dm d, const double *__restrict__ G, const double *u_in, const d
                  const double *__restrict__ u_abt, double dtx, double *u, double *__restrict__ vr,
                  const double *__restrict__ a_u, const double *__restrict__ h_u, const double *__restrict__ Ray_u,
                  const double *__restrict__ tau, double *__restrict__ c1, double dt, double dt_Rho0, double H_to_RZ,
-                 double *__restrict__ tau_bot) {
+                 double *__restrict__ tau_bot, DirectStress S) {
   const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
   if (i < ((DIR ? 0 : -1))) return;
-  const int nz = d.nk;
+  const int nz = d.nk, st = DIR ? d.pitch : 1;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
   if (mC > 0.) {
-    const double surface_stress = dt_Rho0 * (mC * tau[x]);
+    const double surface_stress = (S.Hmix > 0.0) ? 0.0 : dt_Rho0 * (mC * tau[x]);
+    DSWalk W; W.start(S, dt_Rho0, tau[x]);
     double Ray = Ray_u ? Ray_u[x] : 0.;
     double a_k = a_u[x], a_kp = a_u[x + slab];
     double hu = h_u[x];
@@ -704,6 +726,7 @@ k_vertvisc_fused(Dm d, const double *__restrict__ G, const double *u_in, const d
     double b1 = 1.0 / (b_denom_1 + dt * a_kp);
     double d1 = b_denom_1 * b1;
     double u0 = UPD ? mC * (u_in[x] + dtx * (u_bc[x] + u_abt[x])) : u_in[x];
+    u0 = W.add(S, u0, x, st);
     double uprev = b1 * (hu * u0 + surface_stress);
     u[x] = uprev;
     double rprev = b1 * hu;
@@ -715,6 +738,7 @@ k_vertvisc_fused(Dm d, const double *__restrict__ G, const double *u_in, const d
       a_k = a_kp; a_kp = a_u[x3 + slab];
       hu = h_u[x3];
       u0 = UPD ? mC * (u_in[x3] + dtx * (u_bc[x3] + u_abt[x3])) : u_in[x3];
+      u0 = W.add(S, u0, x3, st);
       c1[x3] = dt * a_k * b1;
       b_denom_1 = hu + dt * (Ray + a_k * d1);
       b1 = 1.0 / (b_denom_1 + dt * a_kp);
@@ -753,7 +777,8 @@ static void launch_vertvisc_fused(mom6x_ctx *c, bool upd, bool rem, const double
   const dim3 g = DIR ? grid3(d.ni, d.nj + 1, 1, b) : grid3(nxa(d.ni + 1, -1), d.nj, 1, b);
   const double dt_Rho0 = dt / c->GV.H_to_RZ, HR = c->GV.H_to_RZ;
   const char *nm = DIR ? "k_vertvisc_fused<1>" : "k_vertvisc_fused<0>";
-#define VVF(U, R) KLAUNCH(c, nm, (k_vertvisc_fused<DIR, U, R>), g, b, d, c->G, u_in, u_bc, u_abt, dtx, u, vr, a, h, Ray, tau, c1, dt, dt_Rho0, HR, tau_bot)
+  const DirectStress S = direct_stress_of(c);
+#define VVF(U, R) KLAUNCH(c, nm, (k_vertvisc_fused<DIR, U, R>), g, b, d, c->G, u_in, u_bc, u_abt, dtx, u, vr, a, h, Ray, tau, c1, dt, dt_Rho0, HR, tau_bot, S)
   if (upd && rem) VVF(true, true);
   else if (upd) VVF(true, false);
   else if (rem) VVF(false, true);
@@ -996,10 +1021,18 @@ extern "C" int mom6x_vertvisc(mom6x_ctx *c, double *u, double *v, const double *
   const dim3 b = blk2();
   const double dt_Rho0 = dt / c->GV.H_to_RZ;
   KLAUNCH(c, "k_vertvisc<0>", k_vertvisc<0>, grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, u, c->a_u, c->h_u, c->Ray_u, taux, c1, dt,
-          dt_Rho0, c->GV.H_to_RZ, taux_bot);
+          dt_Rho0, c->GV.H_to_RZ, taux_bot, direct_stress_of(c));
   KLAUNCH(c, "k_vertvisc<1>", k_vertvisc<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, v, c->a_v, c->h_v, c->Ray_v, tauy, c1, dt,
-          dt_Rho0, c->GV.H_to_RZ, tauy_bot);
+          dt_Rho0, c->GV.H_to_RZ, tauy_bot, direct_stress_of(c));
   HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_vertvisc_set_direct_stress(mom6x_ctx *c, double Hmix_stress, const double *h) {
+  REQUIRE(c, MOM6X_EINVAL, "vertvisc_set_direct_stress: null context");
+  REQUIRE(!(Hmix_stress > 0.0) || h, MOM6X_EINVAL, "vertvisc: DIRECT_STRESS needs the layer thicknesses");
+  c->ds_Hmix = (Hmix_stress > 0.0) ? Hmix_stress : 0.0;
+  c->ds_h = (Hmix_stress > 0.0) ? h : nullptr;
   return MOM6X_OK;
 }
 

@@ -249,6 +249,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   const double *tauy_bot = R.split_bottom_stress ? s->tauy_bot : nullptr;
   // vertvisc_coef at the three places of the step: the host callback if one is given, else the device routine if
   // vertvisc_init was called, else nothing (the coefficient arrays handed to mom6x_vertvisc_set_coef stay as they are)
+  if (c->ds_Hmix > 0.0) c->ds_h = h;   // vertvisc(up, vp, h, ...) :754 and vertvisc(u, v, h, ...) :1013 both carry the step's h
   const bool dev_coef = c->vv_init && !(hooks && hooks->vertvisc_coef);
   auto coef_hook = [&](int stage, const double *uu, const double *vv, double dtt) -> int {
     if (hooks && hooks->vertvisc_coef) {

@@ -85,6 +85,7 @@ struct mom6x_ctx {
   double *vv_a_u, *vv_a_v, *vv_h_u, *vv_h_v;
   // hor_visc.hip: hor_visc_CS parameters and the 2-D coefficient planes of hor_visc_init
   mom6x_hor_visc_params hv; bool hv_init; double *hv_planes;
+  double ds_Hmix; const double *ds_h;   // DIRECT_STRESS: HMIX_STRESS (0 = off) and vertvisc's h argument
   double *regrid_res;       // remap.hip: coordinateResolution of the z* coordinate (nk)
   // lazily allocated 3-D scratch arrays (slot -> nlev levels)
   double *scr[MOM6X_NSCR]; int scr_nlev[MOM6X_NSCR];

@@ -202,6 +202,11 @@ class Dycore:
         """vertvisc_coef (MOM_vert_friction.F90:1357) with dz = H_to_Z*h."""
         check(self.lib, self.lib.mom6x_vertvisc_coef(self.ctx, _ptr(u), _ptr(v), _ptr(h), C.c_double(dt)))
 
+    def vertvisc_set_direct_stress(self, Hmix_stress, h=None):
+        """DIRECT_STRESS / HMIX_STRESS (MOM_vert_friction.F90:3208, :707); h = vertvisc's thickness argument."""
+        self._ds_h = h
+        check(self.lib, self.lib.mom6x_vertvisc_set_direct_stress(self.ctx, C.c_double(Hmix_stress), _ptr(h)))
+
     def hor_visc_init(self, params):
         """hor_visc_init (MOM_hor_visc.F90:2322): the 2-D viscosity planes are computed on the device.  From here on
         step_dyn_split_RK2 calls horizontal_viscosity itself unless a host callback is given."""

@@ -286,9 +286,9 @@ def vertvisc_coef(d, G, GV, CS, u, v, h, dt, a_u, a_v, h_u, h_v, Kv_bbl_u=None, 
         raise RuntimeError(f"orc_vertvisc_coef rc={rc}")
 
 
-def vertvisc(d, G, GV, u, v, a_u, a_v, h_u, h_v, Ray_u, Ray_v, taux, tauy, dt, taux_bot=None, tauy_bot=None):
+def vertvisc(d, G, GV, u, v, a_u, a_v, h_u, h_v, Ray_u, Ray_v, taux, tauy, dt, taux_bot=None, tauy_bot=None, Hmix_stress=0.0, h=None):
     rc = lib().orc_vertvisc(C.byref(d), _p(G), C.byref(GV), _p(u), _p(v), _p(a_u), _p(a_v), _p(h_u), _p(h_v), _p(Ray_u),
-                            _p(Ray_v), _p(taux), _p(tauy), C.c_double(dt), _p(taux_bot), _p(tauy_bot))
+                            _p(Ray_v), _p(taux), _p(tauy), C.c_double(dt), _p(taux_bot), _p(tauy_bot), C.c_double(Hmix_stress), _p(h))
     assert rc == 0, rc
 
 
@@ -322,7 +322,7 @@ class Rk2All(C.Structure):
                 ("Kv_bbl_u", C.c_void_p), ("Kv_bbl_v", C.c_void_p), ("bbl_thick_u", C.c_void_p), ("bbl_thick_v", C.c_void_p),
                 ("Kv_shear", C.c_void_p), ("Ray_u", C.c_void_p), ("Ray_v", C.c_void_p),
                 ("vv_a_u", C.c_void_p), ("vv_a_v", C.c_void_p), ("vv_h_u", C.c_void_p), ("vv_h_v", C.c_void_p),
-                ("hv", C.c_void_p), ("hv_planes", C.c_void_p)]
+                ("hv", C.c_void_p), ("hv_planes", C.c_void_p), ("Hmix_stress", C.c_double)]
 
 
 class OrcModel:
@@ -348,7 +348,7 @@ class OrcModel:
         A.Rlay = self.Rlay.ctypes.data; A.g_prime = self.g_prime.ctypes.data
         A.CS = C.addressof(self.cs); A.BTCS = C.addressof(self.btcs.struct); A.BT_cont = C.addressof(self.bt_cont_s)
         A.first_direction = first_direction
-        A.T = None; A.S = None; A.eos = None; A.vv = None; A.hv = None; A.hv_planes = None
+        A.T = None; A.S = None; A.eos = None; A.vv = None; A.hv = None; A.hv_planes = None; A.Hmix_stress = 0.0
         self.A = A
 
     def set_vertvisc(self, vv, Kv_bbl_u=None, Kv_bbl_v=None, bbl_thick_u=None, bbl_thick_v=None, Kv_shear=None,
@@ -365,6 +365,10 @@ class OrcModel:
             setattr(A, n, a.ctypes.data if a is not None else None)
         A.vv_a_u = self.vv_out["a_u"].ctypes.data; A.vv_a_v = self.vv_out["a_v"].ctypes.data
         A.vv_h_u = self.vv_out["h_u"].ctypes.data; A.vv_h_v = self.vv_out["h_v"].ctypes.data
+
+    def set_direct_stress(self, Hmix_stress):
+        """DIRECT_STRESS with HMIX_STRESS = Hmix_stress [H] in the step's vertvisc calls (0: off)."""
+        self.A.Hmix_stress = float(Hmix_stress)
 
     def set_hor_visc(self, hv):
         """hor_visc_init: the step and the new-run initialisation then call horizontal_viscosity themselves."""

@@ -10,7 +10,7 @@
  *   CORIOLIS_SCHEME = SADOURNY75_ENERGY (default) | SADOURNY75_ENSTRO | ARAKAWA_HSU90, BOUND_CORIOLIS,
  *   NOSLIP, KE_SCHEME = KE_ARAKAWA (default) | KE_SIMPLE_GUDONOV | KE_GUDONOV; CORIOLIS_EN_DIS=False;
  *   no OBC, no Stokes drift; PGF: use_EOS=False, no p_atm, no tides/SAL, GFS_scale=1;
- *   vertvisc: DIRECT_STRESS=False, no Stokes mixing / fpmix / GL90; optional Ray_u/Ray_v.
+ *   vertvisc: with or without DIRECT_STRESS; no Stokes mixing / fpmix / GL90; optional Ray_u/Ray_v.
  */
 #include "orc_common.h"
 
@@ -493,7 +493,8 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
 /* vertvisc :557-1228 (one direction at a time; the reference does u then v with identical code) */
 static void vertvisc_dir(const mom6x_dims *d, const double *maskC, int a0, int a1, int b0, int b1, double *u,
                          const double *a_u, const double *h_u, const double *Ray_u, const double *tau,
-                         double dt, double dt_Rho0, double H_to_RZ, double *tau_bot) {
+                         double dt, double dt_Rho0, double H_to_RZ, double *tau_bot, double Hmix_stress, const double *h,
+                         int st, double h_neglect) {
   const int nz = d->nk;
   const size_t slab = (size_t)d->slab;
   double *c1 = (double *)calloc((size_t)nz, sizeof(double));
@@ -501,6 +502,18 @@ static void vertvisc_dir(const mom6x_dims *d, const double *maskC, int a0, int a
     size_t x = IX2(d, i, j);
     if (maskC[x] > 0.) {
       double surface_stress = dt_Rho0 * (maskC[x] * tau[x]);
+      if (Hmix_stress > 0.0) {   /* DIRECT_STRESS :707-720 / :958-971 */
+        const double Hmix = Hmix_stress, I_Hmix = 1.0 / Hmix;
+        surface_stress = 0.0;
+        double zDS = 0.0;
+        const double stress = dt_Rho0 * tau[x];
+        for (int k = 0; k < nz; k++) {
+          const double h_a = 0.5 * (h[x + k * slab] + h[x + st + k * slab]) + h_neglect;
+          double hfr = 1.0; if ((zDS + h_a) > Hmix) hfr = (Hmix - zDS) / h_a;
+          u[x + k * slab] = u[x + k * slab] + I_Hmix * hfr * stress;
+          zDS = zDS + h_a; if (zDS >= Hmix) break;
+        }
+      }
       double Ray = Ray_u ? Ray_u[x] : 0.;
       double b_denom_1 = h_u[x] + dt * (Ray + a_u[x]);
       double b1 = 1.0 / (b_denom_1 + dt * a_u[x + slab]);
@@ -528,10 +541,14 @@ static void vertvisc_dir(const mom6x_dims *d, const double *maskC, int a0, int a
 int orc_vertvisc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, double *u, double *v,
                  const double *a_u, const double *a_v, const double *h_u, const double *h_v,
                  const double *Ray_u, const double *Ray_v, const double *taux, const double *tauy, double dt,
-                 double *taux_bot, double *tauy_bot) {
+                 double *taux_bot, double *tauy_bot, double Hmix_stress, const double *h) {
+  /* Hmix_stress > 0: DIRECT_STRESS with that HMIX_STRESS [H]; h = vertvisc's layer thicknesses */
   const double dt_Rho0 = dt / GV->H_to_RZ;
-  vertvisc_dir(d, GM(G, d, MOM6X_G_mask2dCu), -1, d->ni - 1, 0, d->nj - 1, u, a_u, h_u, Ray_u, taux, dt, dt_Rho0, GV->H_to_RZ, taux_bot);
-  vertvisc_dir(d, GM(G, d, MOM6X_G_mask2dCv), 0, d->ni - 1, -1, d->nj - 1, v, a_v, h_v, Ray_v, tauy, dt, dt_Rho0, GV->H_to_RZ, tauy_bot);
+  if (Hmix_stress > 0.0 && !h) return MOM6X_EINVAL;
+  vertvisc_dir(d, GM(G, d, MOM6X_G_mask2dCu), -1, d->ni - 1, 0, d->nj - 1, u, a_u, h_u, Ray_u, taux, dt, dt_Rho0, GV->H_to_RZ, taux_bot,
+               Hmix_stress, h, 1, GV->H_subroundoff);
+  vertvisc_dir(d, GM(G, d, MOM6X_G_mask2dCv), 0, d->ni - 1, -1, d->nj - 1, v, a_v, h_v, Ray_v, tauy, dt, dt_Rho0, GV->H_to_RZ, tauy_bot,
+               Hmix_stress, h, d->pitch, GV->H_subroundoff);
   return MOM6X_OK;
 }
 

@@ -42,7 +42,8 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
                                double *pbce, double *eta, const double *T, const double *S, const mom6x_eos_params *EOS);
 int orc_vertvisc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, double *u, double *v, const double *a_u,
                  const double *a_v, const double *h_u, const double *h_v, const double *Ray_u, const double *Ray_v,
-                 const double *taux, const double *tauy, double dt, double *taux_bot, double *tauy_bot);
+                 const double *taux, const double *tauy, double dt, double *taux_bot, double *tauy_bot, double Hmix_stress,
+                 const double *h);
 int orc_vertvisc_remnant(const mom6x_dims *d, const double *G, double *visc_rem_u, double *visc_rem_v, const double *a_u,
                          const double *a_v, const double *h_u, const double *h_v, const double *Ray_u,
                          const double *Ray_v, double dt);
@@ -77,6 +78,7 @@ typedef struct orc_rk2_all {   /* everything step_MOM_dyn_split_RK2 reaches thro
   /* hor_visc_CS: when hv != NULL horizontal_viscosity is called by the step (:886) and by the new-run initialisation
    * (:1601) with the coefficient planes hv_planes (orc_hor_visc_init); otherwise diffu/diffv stay as given. */
   const mom6x_hor_visc_params *hv; const double *hv_planes;
+  double Hmix_stress;   /* > 0: DIRECT_STRESS with this HMIX_STRESS [H] in the two vertvisc calls of the step */
 } orc_rk2_all;
 
 /* the new-run branch of initialize_dyn_split_RK2 :1577-1650 (+ barotropic_init ubtav :6124-6135 is done by the
@@ -209,7 +211,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   /* vertvisc_coef(up, vp, h, dt_pred) -> coef[1]; vertvisc :738-755 */
   VV_COEF(up, vp, dt_pred);
   orc_vertvisc(d, G, GV, up, vp, coef[1].a_u, coef[1].a_v, coef[1].h_u, coef[1].h_v, coef[1].Ray_u, coef[1].Ray_v, taux,
-               tauy, dt_pred, CS->taux_bot, CS->tauy_bot);
+               tauy, dt_pred, CS->taux_bot, CS->tauy_bot, A->Hmix_stress, h);
   orc_vertvisc_remnant(d, G, CS->visc_rem_u, CS->visc_rem_v, coef[1].a_u, coef[1].a_v, coef[1].h_u, coef[1].h_v,
                        coef[1].Ray_u, coef[1].Ray_v, R->visc_rem_dt_bug ? dt_pred : dt); /* :763-767 */
   orc_pass_var(d, CS->visc_rem_u, 1, nz); orc_pass_var(d, CS->visc_rem_v, 2, nz); /* :769 */
@@ -278,7 +280,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   /* vertvisc_coef(u, v, h, dt) -> coef[2]; vertvisc; vertvisc_remnant :1003-1022 */
   VV_COEF(u_inst, v_inst, dt);
   orc_vertvisc(d, G, GV, u_inst, v_inst, coef[2].a_u, coef[2].a_v, coef[2].h_u, coef[2].h_v, coef[2].Ray_u, coef[2].Ray_v,
-               taux, tauy, dt, CS->taux_bot, CS->tauy_bot);
+               taux, tauy, dt, CS->taux_bot, CS->tauy_bot, A->Hmix_stress, h);
   orc_vertvisc_remnant(d, G, CS->visc_rem_u, CS->visc_rem_v, coef[2].a_u, coef[2].a_v, coef[2].h_u, coef[2].h_v,
                        coef[2].Ray_u, coef[2].Ray_v, dt);
   for (int k = 0; k < nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++) { /* :1025-1027 */

@@ -45,7 +45,7 @@ def rk2_inputs(cfg, per_stage=False, new_diff=False):
     return dict(GV=GV, Rlay=Rlay, gp=gp, dt=1200.0, h=h, u=u, v=v, coefs=coefs, taux=taux, tauy=tauy, diff_new=diff_new)
 
 
-def oracle_rk2(orc, cfg, inp, nsteps, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, tv=None, vv=None, hv=None):
+def oracle_rk2(orc, cfg, inp, nsteps, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, tv=None, vv=None, hv=None, Hmix_stress=0.0):
     """nsteps of orc_step_dyn_split_RK2 from the seeded state; returns (final state dict, OrcModel)."""
     gg, d, M = cfg
     GV, dt, h, u, v = inp["GV"], inp["dt"], inp["h"], inp["u"], inp["v"]
@@ -57,6 +57,8 @@ def oracle_rk2(orc, cfg, inp, nsteps, bt_mod=None, rk2_mod=None, cor_mod=None, f
         m.set_vertvisc(*vv)
     if hv is not None:
         m.set_hor_visc(hv)
+    if Hmix_stress > 0.0:
+        m.set_direct_stress(Hmix_stress)
     so = dict(u=u.copy(), v=v.copy(), h=h.copy(), uh=np.zeros_like(h), vh=np.zeros_like(h), uhtr=np.zeros_like(h),
               vhtr=np.zeros_like(h), eta_av=np.zeros(d.shape2()))
     m.initialize(so["u"], so["v"], so["h"], so["uh"], so["vh"], dt)

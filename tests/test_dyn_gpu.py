@@ -145,7 +145,10 @@ def test_PressureForce_with_equation_of_state(orc, cfg, form, mods):
 
 @pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
 @pytest.mark.parametrize("use_ray", [False, True])
-def test_vertvisc_and_remnant(orc, cfg, use_ray):
+@pytest.mark.parametrize("Hmix_stress", [0.0, 20.0, 900.0])
+def test_vertvisc_and_remnant(orc, cfg, use_ray, Hmix_stress):
+    """Hmix_stress > 0: DIRECT_STRESS (.testing/tc3, tc4) with HMIX_STRESS inside the top layer (20 m) or spanning
+    several layers (900 m)."""
     import torch
     from mom6_amd.dycore import Dycore
     gg, d, M = getattr(H, cfg)()
@@ -153,13 +156,13 @@ def test_vertvisc_and_remnant(orc, cfg, use_ray):
     a_u, a_v, h_u, h_v, Ray_u, Ray_v = visc_coefs(d, M)
     if not use_ray:
         Ray_u = Ray_v = None
-    _, u, v = synth.make_state(d, M)
+    h, u, v = synth.make_state(d, M)
     taux = np.ascontiguousarray(0.1 * synth.smooth_field(d, 41, ox=1.0, oy=0.5) * M[G["mask2dCu"]])
     tauy = np.ascontiguousarray(0.05 * synth.smooth_field(d, 42, ox=0.5, oy=1.0) * M[G["mask2dCv"]])
     dt = 600.0
     uo, vo = u.copy(), v.copy()
     tbu, tbv = np.zeros(d.shape2()), np.zeros(d.shape2())
-    orc.vertvisc(d, M, GV, uo, vo, a_u, a_v, h_u, h_v, Ray_u, Ray_v, taux, tauy, dt, tbu, tbv)
+    orc.vertvisc(d, M, GV, uo, vo, a_u, a_v, h_u, h_v, Ray_u, Ray_v, taux, tauy, dt, tbu, tbv, Hmix_stress=Hmix_stress, h=h)
     vru, vrv = np.zeros_like(u), np.zeros_like(u)
     orc.vertvisc_remnant(d, M, vru, vrv, a_u, a_v, h_u, h_v, Ray_u, Ray_v, dt)
     dyc = Dycore(d, M, GV)
@@ -168,6 +171,9 @@ def test_vertvisc_and_remnant(orc, cfg, use_ray):
     ug, vg = dyc.to_dev(u), dyc.to_dev(v)
     tbug, tbvg, vrug, vrvg = dyc.zeros2(), dyc.zeros2(), dyc.zeros3(), dyc.zeros3()
     tx, ty = dyc.to_dev(taux), dyc.to_dev(tauy)
+    hd = dyc.to_dev(h)
+    if Hmix_stress > 0.0:
+        dyc.vertvisc_set_direct_stress(Hmix_stress, hd)
     torch.cuda.synchronize()
     dyc.vertvisc(ug, vg, tx, ty, dt, tbug, tbvg)
     dyc.vertvisc_remnant(vrug, vrvg, dt)

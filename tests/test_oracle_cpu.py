@@ -323,3 +323,28 @@ def test_coriolis_en_dis_reduces_to_sadourny_for_centred_transports(orc):
     CAu0, CAv0 = np.zeros_like(h), np.zeros_like(h)
     orc.CorAdCalc(d, M, GV, CS0, u, v, h, np.ascontiguousarray(1.7 * uh), np.ascontiguousarray(0.4 * vh), CAu0, CAv0)
     assert np.abs(CAu - CAu0)[(Ellipsis,) + tuple(su)].max() > 0
+
+
+def test_direct_stress_known_answer(orc):
+    """DIRECT_STRESS (:707-720): with 10 m layers and HMIX_STRESS = 25 m the body force of the wind is 1, 1 and 0.5 times
+    stress/HMIX in the first three layers and nothing below; with zero viscosity the solve leaves exactly that."""
+    gg, d, M = H.channel(nk=6)
+    GV = abi.vgrid_default()
+    h = np.full((d.nk,) + d.shape2(), 10.0)
+    u = np.zeros_like(h); v = np.zeros_like(h)
+    a = np.zeros((d.nk + 1,) + d.shape2())
+    hu = np.full_like(h, 10.0)
+    taux = np.ascontiguousarray(0.2 * M[abi.G["mask2dCu"]]); tauy = np.zeros(d.shape2())
+    dt = 600.0
+    orc.vertvisc(d, M, GV, u, v, a, a.copy(), hu, hu.copy(), None, None, taux, tauy, dt, Hmix_stress=25.0, h=h)
+    x = (d.joff + 5, d.ioff + 7)
+    assert M[abi.G["mask2dCu"]][x] > 0
+    stress = dt / GV.H_to_RZ * 0.2
+    col = u[(slice(None),) + x]
+    assert np.allclose(col[:3], np.array([1.0, 1.0, 0.5]) * stress / 25.0, rtol=1e-15, atol=0)
+    assert (col[3:] == 0.0).all() and (v == 0.0).all()
+    # the momentum put into the column is the stress, whatever the depth it is spread over
+    assert abs((col * 10.0).sum() - stress) <= 4e-16 * stress
+    u2 = np.zeros_like(h); v2 = np.zeros_like(h)
+    orc.vertvisc(d, M, GV, u2, v2, a, a.copy(), hu, hu.copy(), None, None, taux, tauy, dt)     # stress boundary condition
+    assert abs((u2[(slice(None),) + x] * 10.0).sum() - stress) <= 4e-16 * stress and u2[(1,) + x] == 0.0

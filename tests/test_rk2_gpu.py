@@ -20,7 +20,7 @@ STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h",
 
 
 def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, per_stage=False, new_diff=False,
-        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None):
+        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None, Hmix_stress=0.0):
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
@@ -36,6 +36,8 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
     if eos_form is not None:   # tv%T, tv%S, tv%eqn_of_state: the PressureForce calls take the use_EOS branch
         Tt, St = cases.thermo_state(d, M)
         tv = (Tt, St, abi.eos_params_default(eos_form))
+        if Hmix_stress > 0.0:
+            tv[2].MassWghtInterp = 1   # the tc4-like case also has MASS_WEIGHT_IN_PRESSURE_GRADIENT
     # ---------------- oracle
     vvset = None
     if dev_vv is not None:   # vertvisc_coef inside the step (no coefficient sets from outside)
@@ -44,7 +46,7 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
         for k_, v_ in dev_vv.items():
             setattr(P, k_, v_)
         vvset = (P,) + tuple(visc_inputs(d, M)) + (coefs[0][4], coefs[0][5])
-    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction, tv=tv, vv=vvset, hv=hv)
+    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction, tv=tv, vv=vvset, hv=hv, Hmix_stress=Hmix_stress)
 
     # ---------------- device
     cont2, bt2, cor2, pgf2, rk22 = params()
@@ -65,6 +67,8 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
         dyc.vertvisc_set_visc(*vdev)
     if hv is not None:   # horizontal_viscosity inside the step and in the new-run initialisation
         dyc.hor_visc_init(hv)
+    if Hmix_stress > 0.0:
+        dyc.vertvisc_set_direct_stress(Hmix_stress, sg["h"])
     txd, tyd = dyc.to_dev(taux), dyc.to_dev(tauy)
     dnew = tuple(dyc.to_dev(a) for a in diff_new) if diff_new else None
     torch.cuda.synchronize()
@@ -177,3 +181,16 @@ def test_rk2_ragged_tile_sizes(orc, ni, nj, nk, halo):
     """Tile extents that are not multiples of the 16-face work-group tile or the 64-lane wavefront, a single layer, the
     narrowest halo the stencils allow: two steps, bit for bit."""
     run(orc, H.double_gyre(nk=nk, ni=ni, nj=nj, halo=halo), nsteps=2, bt_mod=dict(strong_drag=1))
+
+
+def test_rk2_tc4_like_switches(orc):
+    """The switches of .testing/tc4 that touch this path: CORIOLIS_EN_DIS, DIRECT_STRESS (HMIX_FIXED = 20 m), BE = 0.7,
+    EQN_OF_STATE = LINEAR with MASS_WEIGHT_IN_PRESSURE_GRADIENT, SMAGORINSKY_AH with SMAG_BI_CONST = 0.03, BEBT = 0.2,
+    KV_ML_INVZ2 -- three steps with every callee on the device, bit for bit."""
+    from tests import cases
+    c = H.island_basin()
+    P = abi.hor_visc_params_default(1200.0)
+    P.Smagorinsky_Ah = 1; P.Smag_bi_const = 0.03
+    P.dt = cases.rk2_inputs(c, False, False)["dt"]
+    run(orc, c, nsteps=3, bt_mod=dict(strong_drag=1, bebt=0.2), rk2_mod=dict(be=0.7), cor_mod=dict(Coriolis_En_Dis=1, bound_Coriolis=1),
+        eos_form=abi.LINEAR, dev_vv=dict(Kvml_invZ2=0.01), hv=P, Hmix_stress=20.0)
