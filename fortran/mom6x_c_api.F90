@@ -93,7 +93,7 @@ module mom6x_c_api
   end type mom6x_hor_visc_params
 
   type, bind(C) :: mom6x_remapping_params   !< remapping_CS (MOM_remapping.F90:47-84), the members the device path reads
-    integer(c_int) :: scheme                !< 0 PCM, 2 PLM, 4 PPM_H4 (the module's REMAPPING_* parameters :86-96)
+    integer(c_int) :: scheme                !< 0 PCM, 2 PLM, 4 PPM_H4, 5 PPM_IH4 (the module's REMAPPING_* parameters :86-96)
     integer(c_int) :: boundary_extrapolation, force_bounds_in_subcell, force_bounds_in_target
     integer(c_int) :: om4_remap_via_sub_cells, answer_date
     real(c_double) :: h_neglect, h_neglect_edge

@@ -405,14 +405,14 @@ int mom6x_horizontal_viscosity(mom6x_ctx *ctx, const double *u, const double *v,
 /* ------------------------------------------------------------------------- */
 /* MOM_remapping / the remapping half of MOM_ALE                   */
 /* remapping_CS (src/ALE/MOM_remapping.F90:47-84) as set by initialize_remapping :1654 / remapping_set_param :122.
- * On the device path: the OM4-era reconstruction functions PCM, PLM, PPM_H4 (build_reconstructions_1d :410) with
+ * On the device path: the OM4-era reconstruction functions PCM, PLM, PPM_H4, PPM_IH4 (build_reconstructions_1d :410) with
  * REMAPPING_ANSWER_DATE >= 20190101, with or without boundary extrapolation, both sub-cell integrators
  * (remap_src_to_sub_grid_om4 :845 / remap_src_to_sub_grid :962) and remap_sub_to_tgt_grid_om4 :1103.
- * Not on it (rejected): PPM_CW, PPM_IH4, the hybgen and PQM schemes, the Recon1d class ("C_*") schemes,
+ * Not on it (rejected): PPM_CW, the hybgen and PQM schemes, the Recon1d class ("C_*") schemes,
  * the 2018 answers, PCM_cell masks, check_reconstruction / check_remapping.                        */
-enum mom6x_remap_scheme { MOM6X_REMAP_PCM = 0, MOM6X_REMAP_PLM = 2, MOM6X_REMAP_PPM_H4 = 4 };   /* :86-96 */
+enum mom6x_remap_scheme { MOM6X_REMAP_PCM = 0, MOM6X_REMAP_PLM = 2, MOM6X_REMAP_PPM_H4 = 4, MOM6X_REMAP_PPM_IH4 = 5 };   /* :86-96 */
 typedef struct mom6x_remapping_params {
-  int    scheme;                    /* REMAPPING_SCHEME: PCM, PLM (the module default), PPM_H4            */
+  int    scheme;                    /* REMAPPING_SCHEME: PCM, PLM (the module default), PPM_H4, PPM_IH4   */
   int    boundary_extrapolation;    /* REMAP_BOUNDARY_EXTRAP (type default .true.; ALE_init passes F)     */
   int    force_bounds_in_subcell;   /* REMAP_BOUND_INTERMEDIATE_VALUES (F)                                */
   int    force_bounds_in_target;    /* (T)                                                                */

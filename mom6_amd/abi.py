@@ -199,7 +199,7 @@ def hor_visc_params_default(dt, Laplacian=False, biharmonic=True):
     return p
 
 
-REMAP_PCM, REMAP_PLM, REMAP_PPM_H4 = 0, 2, 4   # enum mom6x_remap_scheme
+REMAP_PCM, REMAP_PLM, REMAP_PPM_H4, REMAP_PPM_IH4 = 0, 2, 4, 5   # enum mom6x_remap_scheme
 
 
 class RemappingParams(C.Structure):

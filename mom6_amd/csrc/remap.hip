@@ -217,8 +217,10 @@ __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict_
     }
     return;
   }
-  // ---- PPM_H4 (N >= 4): edge_values_explicit_h4 :213-348, PPM_limiter_standard :62-121
+  // ---- PPM_H4 / PPM_IH4 (N >= 4): edge_values_explicit_h4 :213-348 or edge_values_implicit_h4 :473-630, then
+  // PPM_limiter_standard :62-121
   const double hne = A.h_neglect_edge;
+  const bool implicit = (A.scheme == MOM6X_REMAP_PPM_IH4);
   double edge_1, edge_2, edge_N, edge_N1;        // the two edge values at either end come from end_value_h4 :314-346
   {
     double dz[4], ut[4], C[4];
@@ -231,6 +233,39 @@ __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict_
     edge_N1 = C[0];
     edge_N = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
   }
+  if (implicit) {
+    // The N+1 interface values solve a diagonally dominant tridiagonal system (solve_diag_dominant_tridiag,
+    // regrid_solvers.F90:246-280): the forward sweep leaves X(1..N) in the E1 column and c1(1..N) in the C2 column (free
+    // for a PPM scheme), X(N+1) stays in a register; the backward sweep turns E1 into the final interface values, which
+    // the limiter sweep below then reads one interface ahead of the cell it overwrites.
+    double I_pivot = 1.0 / (1.0 + 0.0);                                       // tri_c(1) = 1, tri_u(1) = 0 :573-575
+    double d1 = 1.0 * I_pivot, x_prev = edge_1 * I_pivot;
+    c2(1) = 0.0 * I_pivot; e1(1) = x_prev;
+    double h_a = H(1), u_a = U(1);
+    for (int k = 2; k <= N; k++) {                                            // row k couples cells k-1 and k :528-552
+      const double h_b = H(k), u_b = U(k);
+      double h0 = dmax(h_a, hne), h1 = dmax(h_b, hne);
+      if (fabs(h0) < 1.0e-12 * fabs(h1)) h0 = 1.0e-12 * h1;
+      if (fabs(h1) < 1.0e-12 * fabs(h0)) h1 = 1.0e-12 * h0;
+      const double I_h2 = 1.0 / ((h0 + h1) * (h0 + h1));
+      const double alpha = (h1 * h1) * I_h2, beta = (h0 * h0) * I_h2, abmix = (h0 * h1) * I_h2;
+      const double a = 2.0 * alpha * (alpha + 2.0 * beta + 3.0 * abmix);
+      const double b = 2.0 * beta * (beta + 2.0 * alpha + 3.0 * abmix);
+      const double Ac = 2.0 * abmix, R = a * u_a + b * u_b;
+      const double denom_t1 = Ac + d1 * alpha;
+      I_pivot = 1.0 / (denom_t1 + beta);
+      d1 = denom_t1 * I_pivot;
+      c2(k) = beta * I_pivot;
+      x_prev = (R - alpha * x_prev) * I_pivot;
+      e1(k) = x_prev;
+      h_a = h_b; u_a = u_b;
+    }
+    I_pivot = 1.0 / (1.0 + d1 * 0.0);                                         // tri_c(N+1) = 1, tri_l(N+1) = 0 :608-613
+    edge_N1 = (edge_N1 - 0.0 * x_prev) * I_pivot;
+    double x_next = edge_N1;
+    for (int k = N; k >= 1; k--) { x_next = e1(k) - c2(k) * x_next; e1(k) = x_next; }
+    edge_1 = x_next;
+  }
   // window at step k (bounding cell k, finishing cell k-1): cells k-2 (mm), k-1 (m), k (c), k+1 (p), k+2 (q)
   double umm = 0., um = 0., uc = 0., up = U(1), uq = U(2), hm = 0., hc = 0., hp = H(1), hq = H(2);
   double ed_c = 0., ed_p = edge_1;               // edge(k), edge(k+1)
@@ -240,7 +275,8 @@ __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict_
     if (k + 2 <= N) { uq = U(k + 2); hq = H(k + 2); }
     ed_c = ed_p;
     const int e = k + 1;                         // the edge below cell k
-    if (e <= 2) ed_p = edge_2;
+    if (implicit) ed_p = (e <= N) ? e1(e) : edge_N1;
+    else if (e <= 2) ed_p = edge_2;
     else if (e >= N) ed_p = (e == N) ? edge_N : edge_N1;
     else ed_p = edge_h4(hm, hc, hp, hq, um, uc, up, uq, hne);      // i = e: cells e-2 .. e+1 = k-1 .. k+2
     if (Ucopy) AT(Ucopy, vw, k) = uc;
@@ -713,7 +749,8 @@ k_regrid_zstar(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_params CS,
 
 int check_params(const mom6x_remapping_params *p, int n0, ReconArgs &R, ApplyArgs &A, int n1) {
   REQUIRE(p, MOM6X_EINVAL, "remapping: null parameters");
-  REQUIRE(p->scheme == MOM6X_REMAP_PCM || p->scheme == MOM6X_REMAP_PLM || p->scheme == MOM6X_REMAP_PPM_H4, MOM6X_EUNSUPPORTED,
+  REQUIRE(p->scheme == MOM6X_REMAP_PCM || p->scheme == MOM6X_REMAP_PLM || p->scheme == MOM6X_REMAP_PPM_H4 ||
+          p->scheme == MOM6X_REMAP_PPM_IH4, MOM6X_EUNSUPPORTED,
           "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid");
   REQUIRE(p->answer_date >= 20190101, MOM6X_EUNSUPPORTED, "remapping: REMAPPING_ANSWER_DATE < 20190101 is not on the device path");
   REQUIRE(n0 >= 1 && n1 >= 1, MOM6X_EINVAL, "remapping: empty column");

@@ -201,6 +201,13 @@ def edge_values_explicit_h4(h, u, h_neglect):
     return E1[1:n + 1], E2[1:n + 1]
 
 
+def edge_values_implicit_h4(h, u, h_neglect):
+    n = len(h); h1, u1 = _one(h), _one(u)
+    E1, E2 = np.zeros(n + 2), np.zeros(n + 2)
+    lib().orc_edge_values_implicit_h4(n, _p(h1), _p(u1), _p(E1), _p(E2), C.c_double(h_neglect))
+    return E1[1:n + 1], E2[1:n + 1]
+
+
 def PPM_reconstruction(h, u, E1, E2, h_neglect):
     n = len(h); h1, u1 = _one(h), _one(u)
     e1, e2 = _one(E1), _one(E2)

@@ -173,6 +173,55 @@ void orc_edge_values_explicit_h4(int N, const double *h, const double *u, double
   E2[N - 1] = E1[N];
 }
 
+/* solve_diag_dominant_tridiag regrid_solvers.F90:246-280; 1-based arrays of N entries */
+static void solve_diag_dominant_tridiag(const double *Al, const double *Ac, const double *Au, const double *R, double *X, int N) {
+  double *c1 = (double *)calloc((size_t)N + 2, sizeof(double));
+  double I_pivot = 1.0 / (Ac[1] + Au[1]);
+  double d1 = Ac[1] * I_pivot;
+  c1[1] = Au[1] * I_pivot;
+  X[1] = R[1] * I_pivot;
+  for (int k = 2; k <= N - 1; k++) {
+    const double denom_t1 = Ac[k] + d1 * Al[k];
+    I_pivot = 1.0 / (denom_t1 + Au[k]);
+    d1 = denom_t1 * I_pivot;
+    c1[k] = Au[k] * I_pivot;
+    X[k] = (R[k] - Al[k] * X[k - 1]) * I_pivot;
+  }
+  I_pivot = 1.0 / (Ac[N] + d1 * Al[N]);
+  X[N] = (R[N] - Al[N] * X[N - 1]) * I_pivot;
+  for (int k = N - 1; k >= 1; k--) X[k] = X[k] - c1[k] * X[k + 1];
+  free(c1);
+}
+/* edge_values_implicit_h4 :473-630 (answer dates >= 20190101); N >= 4 */
+void orc_edge_values_implicit_h4(int N, const double *h, const double *u, double *E1, double *E2, double h_neglect) {
+  double *w = (double *)calloc((size_t)(5 * (N + 3)), sizeof(double));
+  double *tri_l = w, *tri_c = tri_l + N + 3, *tri_u = tri_c + N + 3, *tri_b = tri_u + N + 3, *tri_x = tri_b + N + 3;
+  for (int i = 1; i <= N - 1; i++) {
+    double h0 = orc_max(h[i], h_neglect), h1 = orc_max(h[i + 1], h_neglect);
+    if (fabs(h0) < 1.0e-12 * fabs(h1)) h0 = 1.0e-12 * h1;
+    if (fabs(h1) < 1.0e-12 * fabs(h0)) h1 = 1.0e-12 * h0;
+    const double I_h2 = 1.0 / ((h0 + h1) * (h0 + h1));
+    const double alpha = (h1 * h1) * I_h2, beta = (h0 * h0) * I_h2, abmix = (h0 * h1) * I_h2;
+    const double a = 2.0 * alpha * (alpha + 2.0 * beta + 3.0 * abmix);
+    const double b = 2.0 * beta * (beta + 2.0 * alpha + 3.0 * abmix);
+    tri_c[i + 1] = 2.0 * abmix;
+    tri_l[i + 1] = alpha; tri_u[i + 1] = beta;
+    tri_b[i + 1] = a * u[i] + b * u[i + 1];
+  }
+  double dz[4], ut[4], C[4];
+  for (int i = 1; i <= 4; i++) { dz[i - 1] = orc_max(h_neglect, h[i]); ut[i - 1] = u[i]; }
+  end_value_h4(dz, ut, C);
+  tri_b[1] = C[0]; tri_c[1] = 1.0; tri_u[1] = 0.0;
+  for (int i = 1; i <= 4; i++) { dz[i - 1] = orc_max(h_neglect, h[N + 1 - i]); ut[i - 1] = u[N + 1 - i]; }
+  end_value_h4(dz, ut, C);
+  tri_b[N + 1] = C[0]; tri_c[N + 1] = 1.0; tri_l[N + 1] = 0.0;
+  solve_diag_dominant_tridiag(tri_l, tri_c, tri_u, tri_b, tri_x, N + 1);
+  E1[1] = tri_x[1];
+  for (int i = 2; i <= N; i++) { E1[i] = tri_x[i]; E2[i - 1] = tri_x[i]; }
+  E2[N] = tri_x[N + 1];
+  free(w);
+}
+
 /* ---- PPM_functions.F90 ------------------------------------------------------------------------------------- */
 /* PPM_limiter_standard :62-121 */
 static void PPM_limiter_standard(int N, const double *h, const double *u, double *E1, double *E2, double h_neglect) {
@@ -246,7 +295,7 @@ void orc_PPM_boundary_extrapolation(int N, const double *h, const double *u, dou
 }
 
 /* ---- MOM_remapping.F90 ------------------------------------------------------------------------------------- */
-/* build_reconstructions_1d :410-550 for PCM, PLM, PPM_H4 */
+/* build_reconstructions_1d :410-550 for PCM, PLM, PPM_H4, PPM_IH4 */
 static int build_reconstructions_1d(const mom6x_remapping_params *CS, int n0, const double *h0, const double *u0, double *E1,
                                     double *E2, double *C1, double *C2, double *C3, int *iMethod) {
   for (int k = 0; k <= n0 + 1; k++) { E1[k] = 0.; E2[k] = 0.; C1[k] = 0.; C2[k] = 0.; C3[k] = 0.; }
@@ -265,7 +314,9 @@ static int build_reconstructions_1d(const mom6x_remapping_params *CS, int n0, co
       *iMethod = INTEGRATION_PLM;
       break;
     case MOM6X_REMAP_PPM_H4:
-      orc_edge_values_explicit_h4(n0, h0, u0, E1, E2, CS->h_neglect_edge);
+    case MOM6X_REMAP_PPM_IH4:
+      if (scheme == MOM6X_REMAP_PPM_IH4) orc_edge_values_implicit_h4(n0, h0, u0, E1, E2, CS->h_neglect_edge);
+      else orc_edge_values_explicit_h4(n0, h0, u0, E1, E2, CS->h_neglect_edge);
       orc_PPM_reconstruction(n0, h0, u0, E1, E2, C1, C2, C3, CS->h_neglect);
       if (CS->boundary_extrapolation) orc_PPM_boundary_extrapolation(n0, h0, u0, E1, E2, C1, C2, C3, CS->h_neglect);
       *iMethod = INTEGRATION_PPM;

@@ -50,7 +50,7 @@ def test_reference_known_answers_on_the_device(dyc):
     assert np.array_equal(dev_core_h(dyc, CS, [2., 0., 2.], [2., 3., 4.], [1., 0., 1., 0., 2.])[0], [1.5, 2., 2.5, 3., 4.])
 
 
-@pytest.mark.parametrize("scheme", [abi.REMAP_PCM, abi.REMAP_PLM, abi.REMAP_PPM_H4])
+@pytest.mark.parametrize("scheme", [abi.REMAP_PCM, abi.REMAP_PLM, abi.REMAP_PPM_H4, abi.REMAP_PPM_IH4])
 @pytest.mark.parametrize("mods", [dict(), dict(om4_remap_via_sub_cells=1), dict(boundary_extrapolation=0, force_bounds_in_subcell=1),
                                   dict(om4_remap_via_sub_cells=1, force_bounds_in_target=0, boundary_extrapolation=0)])
 def test_random_columns_bitwise(orc, dyc, scheme, mods):
@@ -77,6 +77,7 @@ def test_random_columns_bitwise(orc, dyc, scheme, mods):
 
 @pytest.mark.parametrize("cfg", ["island_basin", "benchmark_small"])
 @pytest.mark.parametrize("scheme,mods", [(abi.REMAP_PPM_H4, dict(om4_remap_via_sub_cells=1, boundary_extrapolation=0)),
+                                         (abi.REMAP_PPM_IH4, dict(boundary_extrapolation=0)),   # .testing/tc2, tc4
                                          (abi.REMAP_PLM, dict()), (abi.REMAP_PCM, dict())])
 def test_ALE_remap_tracers_and_velocities(orc, cfg, scheme, mods):
     """The 3-D entry points on a basin with land: two tracers remapped in place from the model's layers to a z*-like
