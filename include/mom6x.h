@@ -584,6 +584,47 @@ int mom6x_comm_rank(const mom6x_ctx *ctx);
 /* do_group_pass of n fields (pass_var / pass_vector, MOM_domain_infra.F90:171-560, :1141).          */
 int mom6x_pass_fields(mom6x_ctx *ctx, double *const *fields, const int *staggers, const int *nks, int n);
 
+/* ------------------------------------------------------------------------- */
+/* The order-invariant sums and checksums of the reference's regression artefacts (ocean.stats, the debugging
+ * checksum lines, the restart files' `checksum` attributes), evaluated on the device-resident fields.  Index
+ * ranges are local compute indices, inclusive (h-point computational domain: 0..ni-1, 0..nj-1).  Across tiles
+ * the integers are summed over RCCL unless only_on_PE is set.                                              */
+
+/* reproducing_sum_3d (MOM_coms.F90:349): array = nk pitched planes.  sum: the result; sums (nullable, [nk]): the
+ * sums by layer -- their presence changes how `sum` is formed (:470-477 vs :541-542), exactly as in the reference;
+ * EFP_sum (nullable, [6]) and EFP_lay_sums (nullable, [6*nk]): the extended-fixed-point integers (EFP_type%v);
+ * err (nullable): the reference's error code instead of a failure (+1 conversion overflow, +2 overflow, +2 NaN). */
+int mom6x_reproducing_sum_3d(mom6x_ctx *ctx, const double *array, int nk, int is, int ie, int js, int je, double unscale,
+                             int only_on_PE, double *sum, double *sums, int64_t *EFP_sum, int64_t *EFP_lay_sums, int *err);
+/* reproducing_sum_2d (:235, reproducing = .true.) of one pitched plane; err: +2 overflow, +4 NaN (:205-209).   */
+int mom6x_reproducing_sum_2d(mom6x_ctx *ctx, const double *array, int is, int ie, int js, int je, double unscale,
+                             int only_on_PE, double *sum, int64_t *EFP_sum, int *err);
+
+/* chksum_{h,u,v,B}_{2d,3d} (MOM_checksums.F90:387/:1413 h, :1005/:1782 u, :1209/:1986 v, :688/:1586 B; the pair
+ * routines hchksum_pair / uvchksum / Bchksum_pair are two of these calls).  rank = 2 or 3 as the reference's 2-d and
+ * 3-d routines differ for B points; stagger as in mom6x_upload; scale: nullable (absent).  The numbers of the two
+ * message lines are returned; the host prints them (chk_sum_msg :2563-2640).                                   */
+enum mom6x_chksum_kind { MOM6X_CHK_NONE = 0,      /* " c="                          (chk_sum_msg1)     */
+                         MOM6X_CHK_CORNERS = 1,   /* " c=" "sw=" "se=" "nw=" "ne="  (chk_sum_msg5)     */
+                         MOM6X_CHK_NSEW = 2,      /* " c=" "N=" "S=" "E=" "W="      (chk_sum_msg_NSEW) */
+                         MOM6X_CHK_W = 3,         /* " c=" "W="                     (chk_sum_msg_W)    */
+                         MOM6X_CHK_S = 4 };       /* " c=" "S="                     (chk_sum_msg_S)    */
+typedef struct mom6x_chksum_result {
+  double mean, amin, amax;   /* subStats: reproducing mean over the h-point domain, min and max (as printed: 0. + x) */
+  int    bc0;                /* bit count of the unshifted computational domain, mod 1 000 000 000                    */
+  int    bc[4];              /* the shifted bit counts in the order of the message                                    */
+  int    nbc;                /* how many of bc[] are set: 0, 1 or 4                                                  */
+  int    bc_kind;            /* enum mom6x_chksum_kind                                                               */
+} mom6x_chksum_result;
+int mom6x_chksum(mom6x_ctx *ctx, const double *array, int nk, int rank, int stagger, int haloshift, int symmetric,
+                 int omit_corners, const double *scale, mom6x_chksum_result *out);
+
+/* field_checksum_real_3d (MOM_checksums.F90:2480) -> field_chksum -> FMS mpp_chksum: the wrapping 64-bit integer sum
+ * of the bit patterns of unscale*field over (is..ie, js..je, all k), the value MOM_restart.F90:1741-1749 stores as
+ * the `checksum` attribute (written with Z16, MOM_io_infra.F90:1986) of every restart variable.                    */
+int mom6x_field_chksum(mom6x_ctx *ctx, const double *array, int nk, int is, int ie, int js, int je, double unscale,
+                       int64_t *chksum);
+
 #ifdef __cplusplus
 }
 #endif

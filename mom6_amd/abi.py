@@ -220,6 +220,15 @@ def remapping_params_default(scheme=REMAP_PLM, h_neglect=1.0e-30, **kw):
     return p
 
 
+class ChksumResult(C.Structure):
+    """mom6x_chksum_result: the numbers of the two message lines of chksum_{h,u,v,B}_{2d,3d} (MOM_checksums.F90)."""
+    _fields_ = [("mean", C.c_double), ("amin", C.c_double), ("amax", C.c_double), ("bc0", C.c_int), ("bc", C.c_int * 4),
+                ("nbc", C.c_int), ("bc_kind", C.c_int)]
+
+
+CHK_NONE, CHK_CORNERS, CHK_NSEW, CHK_W, CHK_S = range(5)    # enum mom6x_chksum_kind
+
+
 class RegridZstarParams(C.Structure):
     """mom6x_regrid_zstar_params; the members of regridding_CS (MOM_regridding.F90:40-140) the z* branch reads."""
     _fields_ = [("min_thickness", C.c_double), ("old_grid_weight", C.c_double), ("depth_of_time_filter_shallow", C.c_double),

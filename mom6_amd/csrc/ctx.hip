@@ -126,6 +126,7 @@ extern "C" int mom6x_struct_size(int which) {
     case 11: return (int)sizeof(mom6x_hor_visc_params);
     case 12: return (int)sizeof(mom6x_remapping_params);
     case 13: return (int)sizeof(mom6x_regrid_zstar_params);
+    case 14: return (int)sizeof(mom6x_chksum_result);
     default: return -1;
   }
 }
@@ -202,6 +203,7 @@ extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
   for (int m = 0; m < MOM6X_NSCR; m++) (void)hipFree(c->scr[m]);
   (void)hipFree(c->Rlay); (void)hipFree(c->g_prime); (void)hipFree(c->retry);
   hor_visc_free(c);
+  diag_sums_free(c);
   (void)hipFree(c->regrid_res);
   (void)hipFree(c->vv_a_u); (void)hipFree(c->vv_a_v); (void)hipFree(c->vv_h_u); (void)hipFree(c->vv_h_v);
   (void)hipFree(c->G); (void)hipFree(c->hL); (void)hipFree(c->hR); (void)hipFree(c->flag);

@@ -255,6 +255,17 @@ int comm_allreduce_scalar(mom6x_ctx *c, double *value, int op) {
   return MOM6X_OK;
 }
 
+// sum_across_PEs / min_across_PEs / max_across_PEs of 64-bit integers, in place on the device and in stream order
+// (diag_sums.hip: the limbs of the reproducing sums, bit counts, order keys): op 0 min, 1 max, 2 sum.
+int comm_allreduce_i64(mom6x_ctx *c, long long *dev, size_t n, int op) {
+  Comm *m = (Comm *)c->comm;
+  if (!m || !m->comm || m->nranks == 1 || n == 0) return MOM6X_OK;
+  const ncclRedOp_t rop = (op == 0) ? ncclMin : ((op == 1) ? ncclMax : ncclSum);
+  NCCLCHK(g_nccl.AllReduce(dev, dev, n, ncclInt64, rop, m->comm, c->stream));
+  return MOM6X_OK;
+}
+int comm_nranks(const mom6x_ctx *c) { const Comm *m = (const Comm *)c->comm; return (m && m->comm) ? m->nranks : 1; }
+
 static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
   const Dm d = c->d;
   size_t cnt[8];

@@ -92,6 +92,7 @@ struct mom6x_ctx {
   bool prof_on;
   struct Prof *prof;
   void *ta;                 // tracer.hip: tracer-advection state (TAState)
+  long long *red; size_t red_cap;   // diag_sums.hip: integer accumulators of the reproducing sums / checksums
   void *comm;               // halo.hip: tile layout + RCCL communicator (null: single tile, wrap only)
   bool halo_error;          // set by a failed halo exchange inside a stream-ordered sequence
 };
@@ -112,6 +113,7 @@ void prof_end(mom6x_ctx *c);
 
 int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out);   // ctx.hip
 void hor_visc_free(mom6x_ctx *c);                                  // hor_visc.hip
+void diag_sums_free(mom6x_ctx *c);                                 // diag_sums.hip
 // dyn_kernels.hip: vertvisc_coef looking at u (mode 0), mask*(u + dtx*u_bc) (1) or mask*(u + dtx*(u_bc + u_abt)) (2)
 int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, const double *u_bc, const double *v_bc,
                       const double *u_abt, const double *v_abt, double dtx, const double *h, double dt);

@@ -244,6 +244,62 @@ class Dycore:
         ncol, n0 = h0.shape; n1 = h1.shape[1]
         check(self.lib, self.lib.mom6x_remapping_core_h(self.ctx, C.byref(CS), ncol, n0, _ptr(h0), _ptr(u0), n1, _ptr(h1), _ptr(u1)))
 
+    # -- MOM_coms / MOM_checksums: the reproducing sums and checksums of the regression artefacts --------------
+    def _rect(self, is_, ie, js, je):
+        d = self.dims
+        return (0 if is_ is None else is_, d.ni - 1 if ie is None else ie, 0 if js is None else js, d.nj - 1 if je is None else je)
+
+    def reproducing_sum(self, array, is_=None, ie=None, js=None, je=None, unscale=1.0, layer_sums=False, only_on_PE=False,
+                        want_err=False):
+        """reproducing_sum (MOM_coms.F90:235 for a 2-D plane, :349 for nk planes) of a device array over the local
+        index range (default: the h-point computational domain).  Returns dict(sum, EFP[, sums, EFP_lay][, err])."""
+        r = self._rect(is_, ie, js, je)
+        s = C.c_double(0.0); efp = (C.c_int64 * 6)(); err = C.c_int(0)
+        perr = C.byref(err) if want_err else None
+        out = {}
+        if array.dim() == 2:
+            check(self.lib, self.lib.mom6x_reproducing_sum_2d(self.ctx, _ptr(array), *r, C.c_double(unscale), int(only_on_PE),
+                                                              C.byref(s), efp, perr))
+        else:
+            nk = array.shape[0]
+            sums = (C.c_double * nk)() if layer_sums else None
+            lay = (C.c_int64 * (6 * nk))() if layer_sums else None
+            check(self.lib, self.lib.mom6x_reproducing_sum_3d(self.ctx, _ptr(array), nk, *r, C.c_double(unscale), int(only_on_PE),
+                                                              C.byref(s), sums, efp, lay, perr))
+            if layer_sums:
+                out.update(sums=np.array(sums[:]), EFP_lay=np.array(lay[:], dtype=np.int64).reshape(nk, 6))
+        out.update(sum=s.value, EFP=np.array(efp[:], dtype=np.int64))
+        if want_err:
+            out["err"] = err.value
+        return out
+
+    def chksum(self, array, stagger, haloshift=0, symmetric=False, omit_corners=False, scale=None):
+        """chksum_{h,u,v,B}_{2d,3d} (MOM_checksums.F90); stagger in 'huvB'.  dict(mean, min, max, bc0, bc, kind)."""
+        res = abi.ChksumResult()
+        nk = 1 if array.dim() == 2 else array.shape[0]
+        sc = None if scale is None else C.byref(C.c_double(scale))
+        check(self.lib, self.lib.mom6x_chksum(self.ctx, _ptr(array), nk, array.dim(), "huvB".index(stagger), haloshift,
+                                              int(symmetric), int(omit_corners), sc, C.byref(res)))
+        return dict(mean=res.mean, min=res.amin, max=res.amax, bc0=res.bc0, bc=[res.bc[n] for n in range(res.nbc)], kind=res.bc_kind)
+
+    def chksum_lines(self, array, stagger, mesg, **kw):
+        """The two lines hchksum / uchksum / vchksum / Bchksum write (chk_sum_msg3 :2638, chk_sum_msg1/5/_NSEW/_W/_S)."""
+        r = self.chksum(array, stagger, **kw)
+        pt = {"h": "h-point:", "u": "u-point:", "v": "v-point:", "B": "B-point:"}[stagger]
+        l1 = pt + " mean=" + _es25_16(r["mean"]) + "min=" + _es25_16(r["min"]) + "max=" + _es25_16(r["max"]) + mesg
+        tags = {abi.CHK_NONE: [], abi.CHK_CORNERS: ["sw=", "se=", "nw=", "ne="], abi.CHK_NSEW: ["N=", "S=", "E=", "W="],
+                abi.CHK_W: ["W="], abi.CHK_S: ["S="]}[r["kind"]]
+        l2 = pt + " c=%10d " % r["bc0"] + "".join("%s%10d " % (t, b) for t, b in zip(tags, r["bc"])) + mesg
+        return l1, l2
+
+    def field_chksum(self, array, is_=None, ie=None, js=None, je=None, unscale=1.0):
+        """The restart files' `checksum` attribute (MOM_restart.F90:1741; FMS mpp_chksum) as a signed 64-bit integer."""
+        nk = 1 if array.dim() == 2 else array.shape[0]
+        v = C.c_int64(0)
+        check(self.lib, self.lib.mom6x_field_chksum(self.ctx, _ptr(array), nk, *self._rect(is_, ie, js, je), C.c_double(unscale),
+                                                    C.byref(v)))
+        return v.value
+
     def vertvisc(self, u, v, taux, tauy, dt, taux_bot=None, tauy_bot=None):
         """vertvisc (MOM_vert_friction.F90:557)."""
         check(self.lib, self.lib.mom6x_vertvisc(self.ctx, _ptr(u), _ptr(v), _ptr(taux), _ptr(tauy), C.c_double(dt),
@@ -354,3 +410,9 @@ def prof_report(dyc):
         name, cnt, ms = line.split("\t")
         out[name] = (int(cnt), float(ms))
     return out
+
+
+def _es25_16(x):
+    """Fortran ES25.16 followed by the 1X of chk_sum_msg3's format."""
+    m, e = ("%.16E" % x).split("E")
+    return ("%sE%+03d" % (m, int(e))).rjust(25) + " "

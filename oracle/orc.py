@@ -32,7 +32,7 @@ def lib():
 def _p(a):
     if a is None:
         return None
-    assert a.dtype in (np.float64, np.int32) and a.flags["C_CONTIGUOUS"]
+    assert a.dtype in (np.float64, np.int32, np.int64) and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
 
 
@@ -440,3 +440,83 @@ def triDiagTS_Eulerian(d, hold, ent, T, h_neglect):
 def tracer_vertdiff(d, G, GV, h_old, ea, eb, dt, tr, sfc_flux=None, btm_flux=None, convert_flux=True):
     assert lib().orc_tracer_vertdiff(C.byref(d), _p(G), C.byref(GV), _p(h_old), _p(ea), _p(eb), C.c_double(dt), _p(tr),
                                      _p(sfc_flux), _p(btm_flux), C.c_int(int(convert_flux))) == 0
+
+
+# ---- MOM_coms reproducing sums, MOM_checksums (orc_sums.c) -----------------------------------------------------------
+_EFP_FATAL = {1: "NaN in input field of reproducing_sum", 2: "Overflow in reproducing_sum conversion", 3: "Overflow in reproducing_sum"}
+
+
+def reproducing_sum(d, array, is_=None, ie=None, js=None, je=None, unscale=1.0, layer_sums=False, want_err=False):
+    """reproducing_sum_3d (array of nk planes) or reproducing_sum_2d (one plane).  Returns a dict: sum, [sums], EFP
+    (int64[6]), [EFP_lay (int64[nk,6])], [err]."""
+    a = np.ascontiguousarray(array)
+    is_ = 0 if is_ is None else is_; js = 0 if js is None else js
+    ie = d.ni - 1 if ie is None else ie; je = d.nj - 1 if je is None else je
+    out = {}
+    s = C.c_double(0.0); efp = np.zeros(6, dtype=np.int64); err = C.c_int(0)
+    perr = C.byref(err) if want_err else None
+    if a.ndim == 2:
+        lib().orc_reproducing_sum_2d.restype = C.c_int
+        rc = lib().orc_reproducing_sum_2d(C.byref(d), _p(a), is_, ie, js, je, C.c_double(unscale), C.byref(s), _p(efp), perr)
+    else:
+        nk = a.shape[0]
+        sums = np.zeros(nk) if layer_sums else None
+        lay = np.zeros((nk, 6), dtype=np.int64) if layer_sums else None
+        rc = lib().orc_reproducing_sum_3d(C.byref(d), _p(a), nk, is_, ie, js, je, C.c_double(unscale), C.byref(s), _p(sums),
+                                          _p(efp), _p(lay), perr)
+        if layer_sums:
+            out.update(sums=sums, EFP_lay=lay)
+    if rc:
+        raise RuntimeError(_EFP_FATAL[rc])
+    out.update(sum=s.value, EFP=efp)
+    if want_err:
+        out["err"] = err.value
+    return out
+
+
+def reproducing_EFP_sum_2d(d, array, is_, ie, js, je, unscale=1.0, overflow_check=True):
+    efp = np.zeros(6, dtype=np.int64)
+    rc = lib().orc_reproducing_EFP_sum_2d(C.byref(d), _p(np.ascontiguousarray(array)), is_, ie, js, je, int(overflow_check),
+                                          C.c_double(unscale), _p(efp), None)
+    if rc:
+        raise RuntimeError(_EFP_FATAL[rc])
+    return efp
+
+
+def EFP_to_real(efp):
+    lib().orc_EFP_to_real.restype = C.c_double
+    e = np.array(efp, dtype=np.int64)
+    return lib().orc_EFP_to_real(_p(e))
+
+
+def EFP_minus(a, b):
+    out = np.zeros(6, dtype=np.int64)
+    lib().orc_EFP_minus(_p(np.array(a, dtype=np.int64)), _p(np.array(b, dtype=np.int64)), _p(out))
+    return out
+
+
+def real_to_EFP(r):
+    out = np.zeros(6, dtype=np.int64); over = C.c_int(0)
+    lib().orc_real_to_ints(C.c_double(r), C.c_int64(-1), C.byref(over), _p(out))
+    if over.value:
+        raise RuntimeError("Overflow in real_to_EFP conversion")
+    return out
+
+
+def chksum(d, array, stagger, haloshift=0, symmetric=False, omit_corners=False, scale=None):
+    """chksum_{h,u,v,B}_{2d,3d}: dict(mean, min, max, bc0, bc=[shifted bitcounts in message order])."""
+    a = np.ascontiguousarray(array)
+    nk = 1 if a.ndim == 2 else a.shape[0]
+    stats = np.zeros(3); bc = np.zeros(5, dtype=np.int32)
+    n = lib().orc_chksum(C.byref(d), _p(a), nk, a.ndim, "huvB".index(stagger), haloshift, int(symmetric), int(omit_corners),
+                         int(scale is not None), C.c_double(1.0 if scale is None else scale), _p(stats), _p(bc))
+    if n < 0:
+        raise RuntimeError("NaN detected")
+    return dict(mean=stats[0], min=stats[1], max=stats[2], bc0=int(bc[0]), bc=[int(x) for x in bc[1:1 + n]])
+
+
+def field_chksum(d, array, is_, ie, js, je, unscale=1.0):
+    a = np.ascontiguousarray(array)
+    nk = 1 if a.ndim == 2 else a.shape[0]
+    lib().orc_field_chksum.restype = C.c_int64
+    return lib().orc_field_chksum(C.byref(d), _p(a), nk, is_, ie, js, je, C.c_double(unscale))
