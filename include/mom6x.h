@@ -625,6 +625,35 @@ int mom6x_chksum(mom6x_ctx *ctx, const double *array, int nk, int rank, int stag
 int mom6x_field_chksum(mom6x_ctx *ctx, const double *array, int nk, int is, int ie, int js, int je, double unscale,
                        int64_t *chksum);
 
+/* write_energy (MOM_sum_output.F90:321): the globally summed diagnostics behind ocean.stats (and ocean.stats.nc).
+ * The members of Sum_output_CS that the sums read; the write schedule (ENERGYSAVEDAYS), the values of the previous
+ * call (mass_prev_EFP ...), the accumulated surface inputs and the files stay with the host, which formats the line
+ * from the numbers returned here (:871-905).                                                                     */
+typedef struct mom6x_sum_output_params {
+  int    do_APE_calc;       /* CALCULATE_APE (T)                                                       */
+  int    use_temperature;   /* ENABLE_THERMODYNAMICS: salt and heat content from tv%T, tv%S            */
+  double dt_in_T;           /* DT: the baroclinic time step of the CFL numbers                         */
+  double D_list_min_inc;    /* DEPTH_LIST_MIN_INC (1e-10 m)                                            */
+  double Z_ref;             /* G%Z_ref                                                                 */
+  double C_p;               /* tv%C_p                                                                  */
+} mom6x_sum_output_params;
+/* MOM_sum_output_init :147 + depth_list_setup :1161 (READ_DEPTH_LIST = False: create_depth_list :1203 from the
+ * context's bathyT, areaT, mask2dT; with several tiles the global list is summed over RCCL).  g_prime: GV%g_prime(1:nk). */
+int mom6x_sum_output_init(mom6x_ctx *ctx, const mom6x_sum_output_params *p, const double *g_prime);
+/* The Depth_List (DL%depth, DL%area, DL%vol_below); the arrays (nullable) must hold listsize entries -- call once
+ * with null arrays to learn listsize.                                                                           */
+int mom6x_depth_list(const mom6x_ctx *ctx, int *listsize, double *depth, double *area, double *vol_below);
+typedef struct mom6x_energy_sums {
+  double  mass_tot, KE_tot, PE_tot;   /* :509, :674, :660                                               */
+  double  max_CFL[2];                 /* max_CFL_trans, max_CFL_lin :701-727                            */
+  int64_t mass_EFP[6];                /* mass_EFP, for mass_chg_EFP = mass_EFP - CS%mass_prev_EFP :749  */
+  int64_t salt_EFP[6], heat_EFP[6];   /* :683-686 (zero without ENABLE_THERMODYNAMICS)                  */
+} mom6x_energy_sums;
+/* u, v, h (and tv%T, tv%S, nullable without ENABLE_THERMODYNAMICS) on the device; mass_lay[nk], KE[nk], PE[nk+1],
+ * Z_0APE[nk+1] on the host: the vectors of ocean.stats.nc (Mass_lay, KE, APE, H0).                          */
+int mom6x_write_energy(mom6x_ctx *ctx, const double *u, const double *v, const double *h, const double *T, const double *S,
+                       mom6x_energy_sums *out, double *mass_lay, double *KE, double *PE, double *Z_0APE);
+
 #ifdef __cplusplus
 }
 #endif

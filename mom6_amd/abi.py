@@ -229,6 +229,27 @@ class ChksumResult(C.Structure):
 CHK_NONE, CHK_CORNERS, CHK_NSEW, CHK_W, CHK_S = range(5)    # enum mom6x_chksum_kind
 
 
+class SumOutputParams(C.Structure):
+    """mom6x_sum_output_params: the members of Sum_output_CS (MOM_sum_output.F90:60-140) the sums of write_energy read."""
+    _fields_ = [("do_APE_calc", C.c_int), ("use_temperature", C.c_int), ("dt_in_T", C.c_double), ("D_list_min_inc", C.c_double),
+                ("Z_ref", C.c_double), ("C_p", C.c_double)]
+
+
+def sum_output_params_default(dt, **kw):
+    """CALCULATE_APE = True, ENABLE_THERMODYNAMICS off unless asked, DEPTH_LIST_MIN_INC = 1e-10 m, C_P = 3991.86795711963."""
+    p = SumOutputParams()
+    p.do_APE_calc = 1; p.use_temperature = 0; p.dt_in_T = dt; p.D_list_min_inc = 1.0e-10; p.Z_ref = 0.0; p.C_p = 3991.86795711963
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class EnergySums(C.Structure):
+    """mom6x_energy_sums."""
+    _fields_ = [("mass_tot", C.c_double), ("KE_tot", C.c_double), ("PE_tot", C.c_double), ("max_CFL", C.c_double * 2),
+                ("mass_EFP", C.c_int64 * 6), ("salt_EFP", C.c_int64 * 6), ("heat_EFP", C.c_int64 * 6)]
+
+
 class RegridZstarParams(C.Structure):
     """mom6x_regrid_zstar_params; the members of regridding_CS (MOM_regridding.F90:40-140) the z* branch reads."""
     _fields_ = [("min_thickness", C.c_double), ("old_grid_weight", C.c_double), ("depth_of_time_filter_shallow", C.c_double),

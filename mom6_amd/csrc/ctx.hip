@@ -127,6 +127,8 @@ extern "C" int mom6x_struct_size(int which) {
     case 12: return (int)sizeof(mom6x_remapping_params);
     case 13: return (int)sizeof(mom6x_regrid_zstar_params);
     case 14: return (int)sizeof(mom6x_chksum_result);
+    case 15: return (int)sizeof(mom6x_sum_output_params);
+    case 16: return (int)sizeof(mom6x_energy_sums);
     default: return -1;
   }
 }

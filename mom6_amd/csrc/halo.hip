@@ -264,6 +264,13 @@ int comm_allreduce_i64(mom6x_ctx *c, long long *dev, size_t n, int op) {
   NCCLCHK(g_nccl.AllReduce(dev, dev, n, ncclInt64, rop, m->comm, c->stream));
   return MOM6X_OK;
 }
+int comm_allreduce_f64(mom6x_ctx *c, double *dev, size_t n, int op) {
+  Comm *m = (Comm *)c->comm;
+  if (!m || !m->comm || m->nranks == 1 || n == 0) return MOM6X_OK;
+  const ncclRedOp_t rop = (op == 0) ? ncclMin : ((op == 1) ? ncclMax : ncclSum);
+  NCCLCHK(g_nccl.AllReduce(dev, dev, n, ncclDouble, rop, m->comm, c->stream));
+  return MOM6X_OK;
+}
 int comm_nranks(const mom6x_ctx *c) { const Comm *m = (const Comm *)c->comm; return (m && m->comm) ? m->nranks : 1; }
 
 static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {

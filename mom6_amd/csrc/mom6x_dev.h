@@ -93,6 +93,7 @@ struct mom6x_ctx {
   struct Prof *prof;
   void *ta;                 // tracer.hip: tracer-advection state (TAState)
   long long *red; size_t red_cap;   // diag_sums.hip: integer accumulators of the reproducing sums / checksums
+  void *diag;               // diag_sums.hip: Sum_output_CS state (depth list, lH) of write_energy
   void *comm;               // halo.hip: tile layout + RCCL communicator (null: single tile, wrap only)
   bool halo_error;          // set by a failed halo exchange inside a stream-ordered sequence
 };

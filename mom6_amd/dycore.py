@@ -300,6 +300,36 @@ class Dycore:
                                                     C.byref(v)))
         return v.value
 
+    # -- MOM_sum_output ----------------------------------------------------------------------
+    def sum_output_init(self, params, g_prime):
+        """MOM_sum_output_init (MOM_sum_output.F90:147) + depth_list_setup (:1161)."""
+        gp = np.ascontiguousarray(g_prime, dtype=np.float64)
+        assert gp.size >= self.dims.nk
+        self.sum_output_params = params
+        check(self.lib, self.lib.mom6x_sum_output_init(self.ctx, C.byref(params), gp.ctypes.data_as(C.c_void_p)))
+
+    def depth_list(self):
+        """The Depth_List of create_depth_list (:1203): depth, area, vol_below."""
+        n = C.c_int(0)
+        check(self.lib, self.lib.mom6x_depth_list(self.ctx, C.byref(n), None, None, None))
+        out = [np.zeros(n.value) for _ in range(3)]
+        check(self.lib, self.lib.mom6x_depth_list(self.ctx, C.byref(n), *[a.ctypes.data_as(C.c_void_p) for a in out]))
+        return out
+
+    def write_energy(self, u, v, h, T=None, S=None):
+        """The sums of write_energy (:321): dict(mass_tot, KE_tot, PE_tot, max_CFL, mass_EFP, salt_EFP, heat_EFP, mass_lay, KE,
+        PE, Z_0APE).  mom6_amd.sum_output.SumOutput turns them into the ocean.stats line."""
+        nk = self.dims.nk
+        res = abi.EnergySums()
+        vec = dict(mass_lay=np.zeros(nk), KE=np.zeros(nk), PE=np.zeros(nk + 1), Z_0APE=np.zeros(nk + 1))
+        check(self.lib, self.lib.mom6x_write_energy(self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(T), _ptr(S), C.byref(res),
+                                                    *[vec[n].ctypes.data_as(C.c_void_p) for n in ("mass_lay", "KE", "PE", "Z_0APE")]))
+        out = dict(mass_tot=res.mass_tot, KE_tot=res.KE_tot, PE_tot=res.PE_tot, max_CFL=(res.max_CFL[0], res.max_CFL[1]),
+                   mass_EFP=np.array(res.mass_EFP[:], dtype=np.int64), salt_EFP=np.array(res.salt_EFP[:], dtype=np.int64),
+                   heat_EFP=np.array(res.heat_EFP[:], dtype=np.int64))
+        out.update(vec)
+        return out
+
     def vertvisc(self, u, v, taux, tauy, dt, taux_bot=None, tauy_bot=None):
         """vertvisc (MOM_vert_friction.F90:557)."""
         check(self.lib, self.lib.mom6x_vertvisc(self.ctx, _ptr(u), _ptr(v), _ptr(taux), _ptr(tauy), C.c_double(dt),

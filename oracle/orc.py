@@ -520,3 +520,39 @@ def field_chksum(d, array, is_, ie, js, je, unscale=1.0):
     nk = 1 if a.ndim == 2 else a.shape[0]
     lib().orc_field_chksum.restype = C.c_int64
     return lib().orc_field_chksum(C.byref(d), _p(a), nk, is_, ie, js, je, C.c_double(unscale))
+
+
+# ---- MOM_sum_output (orc_sums.c) -------------------------------------------------------------------------------------
+def create_depth_list(d, G, Z_ref=0.0, min_depth_inc=1.0e-10):
+    n = d.ni_glob * d.nj_glob + 3
+    dep, area, vol = np.zeros(n), np.zeros(n), np.zeros(n)
+    ls = lib().orc_create_depth_list(C.byref(d), _p(G), C.c_double(Z_ref), C.c_double(min_depth_inc), _p(dep), _p(area), _p(vol))
+    return dep[1:ls + 1].copy(), area[1:ls + 1].copy(), vol[1:ls + 1].copy()
+
+
+class SumOutputState:
+    """The part of Sum_output_CS the sums of write_energy read and update: the depth list and the search hints lH."""
+
+    def __init__(self, d, G, GV, g_prime, P):
+        self.d, self.G, self.GV, self.P = d, G, GV, P
+        self.g_prime = np.ascontiguousarray(g_prime, dtype=np.float64)
+        self.DL = create_depth_list(d, G, P.Z_ref, P.D_list_min_inc) if P.do_APE_calc else (np.zeros(1), np.zeros(1), np.zeros(1))
+        self.listsize = len(self.DL[0]) if P.do_APE_calc else 0
+        self.lH = np.full(d.nk, self.listsize - 1, dtype=np.int32)
+
+
+def write_energy(st, u, v, h, T=None, S=None):
+    d = st.d; nk = d.nk
+    one = [np.concatenate(([0.0], a, [0.0])) for a in st.DL]            # 1-based inside
+    vec = dict(mass_lay=np.zeros(nk), KE=np.zeros(nk), PE=np.zeros(nk + 1), Z_0APE=np.zeros(nk + 1))
+    scal = np.zeros(5); efp = [np.zeros(6, dtype=np.int64) for _ in range(3)]
+    rc = lib().orc_write_energy(C.byref(d), _p(st.G), C.byref(st.GV), _p(st.g_prime), int(st.P.do_APE_calc), C.c_double(st.P.dt_in_T),
+                                C.c_double(st.P.Z_ref), C.c_double(st.P.C_p), st.listsize, _p(one[0]), _p(one[1]), _p(one[2]),
+                                _p(st.lH), _p(u), _p(v), _p(h), _p(T), _p(S), _p(vec["mass_lay"]), _p(vec["KE"]), _p(vec["PE"]),
+                                _p(vec["Z_0APE"]), _p(scal), _p(efp[0]), _p(efp[1]), _p(efp[2]))
+    if rc:
+        raise RuntimeError(_EFP_FATAL[rc])
+    out = dict(mass_tot=scal[0], KE_tot=scal[1], PE_tot=scal[2], max_CFL=(scal[3], scal[4]), mass_EFP=efp[0], salt_EFP=efp[1],
+               heat_EFP=efp[2])
+    out.update(vec)
+    return out

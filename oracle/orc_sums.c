@@ -409,3 +409,165 @@ int64_t orc_field_chksum(const mom6x_dims *d, const double *array, int nk, int i
   }
   return (int64_t)s;
 }
+
+/* ---- MOM_sum_output.F90 ------------------------------------------------------------------------------------------ */
+/* create_depth_list :1203-1326 (one tile = the global domain).  depth/area/vol_below: 1-based arrays with room for
+ * ni*nj + 2 entries; returns DL%listsize. */
+int orc_create_depth_list(const mom6x_dims *d, const double *G, double Z_ref, double min_depth_inc,
+                          double *depth, double *area_out, double *vol_below) {
+  const int niglobal = d->ni_glob, mls = d->ni_glob * d->nj_glob;
+  double *Dlist = (double *)calloc((size_t)mls + 2, sizeof(double)), *AreaList = (double *)calloc((size_t)mls + 2, sizeof(double));
+  int *indx2 = (int *)calloc((size_t)mls + 2, sizeof(int));
+  const double *bathyT = GM(G, d, MOM6X_G_bathyT), *mask = GM(G, d, MOM6X_G_mask2dT), *areaT = GM(G, d, MOM6X_G_areaT);
+  for (int j = 0; j < d->nj; j++) for (int i = 0; i < d->ni; i++) {
+    const int list_pos = (j + d->j_glob0) * niglobal + (i + d->i_glob0) + 1;
+    Dlist[list_pos] = bathyT[IX2(d, i, j)] + Z_ref;
+    AreaList[list_pos] = mask[IX2(d, i, j)] * areaT[IX2(d, i, j)];
+  }
+  for (int j = 1; j <= mls + 1; j++) indx2[j] = j;
+  int k = mls / 2 + 1, ir = mls, indxt, i, j;
+  double Dnow;
+  for (;;) {                                                           /* the heap sort of :1246-1267 */
+    if (k > 1) { k = k - 1; indxt = indx2[k]; Dnow = Dlist[indxt]; }
+    else {
+      indxt = indx2[ir]; Dnow = Dlist[indxt];
+      indx2[ir] = indx2[1];
+      ir = ir - 1;
+      if (ir == 1) { indx2[1] = indxt; break; }
+    }
+    i = k; j = k * 2;
+    for (;;) {
+      if (j > ir) break;
+      if (j < ir && Dlist[indx2[j]] < Dlist[indx2[j + 1]]) j = j + 1;
+      if (Dnow < Dlist[indx2[j]]) { indx2[i] = indx2[j]; i = j; j = j + i; }
+      else j = ir + 1;
+    }
+    indx2[i] = indxt;
+  }
+  double D_list_prev = Dlist[indx2[mls]];
+  int list_size = 2;
+  for (k = mls - 1; k >= 1; k--) if (Dlist[indx2[k]] < D_list_prev - min_depth_inc) { list_size = list_size + 1; D_list_prev = Dlist[indx2[k]]; }
+  const int listsize = list_size + 1;
+  double vol = 0.0, area = 0.0, Dprev = Dlist[indx2[mls]];
+  D_list_prev = Dprev;
+  int kl = 0;
+  for (k = mls; k >= 1; k--) {
+    i = indx2[k];
+    vol = vol + area * (Dprev - Dlist[i]);
+    area = area + AreaList[i];
+    int add_to_list = 0;
+    if (kl == 0 || k == 1) add_to_list = 1;
+    else if (Dlist[indx2[k - 1]] < D_list_prev - min_depth_inc) { add_to_list = 1; D_list_prev = Dlist[indx2[k - 1]]; }
+    if (add_to_list) { kl = kl + 1; depth[kl] = Dlist[i]; area_out[kl] = area; vol_below[kl] = vol; }
+    Dprev = Dlist[i];
+  }
+  while (kl + 1 < listsize) {
+    kl = kl + 1;
+    vol_below[kl] = vol_below[kl - 1] * 1.000001; area_out[kl] = area_out[kl - 1]; depth[kl] = depth[kl - 1];
+  }
+  vol_below[listsize] = vol_below[listsize - 1] * 1000.0;
+  area_out[listsize] = area_out[listsize - 1];
+  depth[listsize] = depth[listsize - 1];
+  free(Dlist); free(AreaList); free(indx2);
+  return listsize;
+}
+
+/* The sums of write_energy :598-791 (Boussinesq, unit scaling factors of 1): layer masses, the zero-APE depths of the
+ * interfaces from the depth list, the interface APE, the layer KE, the salt and heat content, the two CFL maxima.
+ * lH: the search hints CS%lH (1-based values, nk of them), updated as in the reference.  T, S may be NULL.
+ * scal: mass_tot, KE_tot, PE_tot, max_CFL(1), max_CFL(2).  Returns nonzero where the reference stops. */
+int orc_write_energy(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const double *g_prime, int do_APE_calc,
+                     double dt_in_T, double Z_ref, double C_p, int listsize, const double *DL_depth, const double *DL_area,
+                     const double *DL_vol_below, int *lH, const double *u, const double *v, const double *h, const double *T,
+                     const double *S, double *mass_lay, double *KE, double *PE, double *Z_0APE, double *scal, int64_t *mass_EFP,
+                     int64_t *salt_EFP, int64_t *heat_EFP) {
+  const int nz = d->nk, ni = d->ni, nj = d->nj;
+  const double *mask = GM(G, d, MOM6X_G_mask2dT), *areaT = GM(G, d, MOM6X_G_areaT), *bathyT = GM(G, d, MOM6X_G_bathyT);
+  const double *IareaT = GM(G, d, MOM6X_G_IareaT), *dy_Cu = GM(G, d, MOM6X_G_dy_Cu), *dx_Cv = GM(G, d, MOM6X_G_dx_Cv);
+  const double *IdxCu = GM(G, d, MOM6X_G_IdxCu), *IdyCv = GM(G, d, MOM6X_G_IdyCv);
+  double *areaTm = (double *)calloc((size_t)d->slab, sizeof(double));
+  double *tmp1 = (double *)calloc((size_t)d->slab * (size_t)(nz + 1), sizeof(double));
+  int rc;
+  for (int j = 0; j < nj; j++) for (int i = 0; i < ni; i++) areaTm[IX2(d, i, j)] = mask[IX2(d, i, j)] * areaT[IX2(d, i, j)];
+  for (int k = 0; k < nz; k++) for (int j = 0; j < nj; j++) for (int i = 0; i < ni; i++)
+    tmp1[IX3(d, i, j, k)] = h[IX3(d, i, j, k)] * (GV->H_to_RZ * areaTm[IX2(d, i, j)]);
+  double mass_tot;
+  if ((rc = orc_reproducing_sum_3d(d, tmp1, nz, 0, ni - 1, 0, nj - 1, 1.0, &mass_tot, mass_lay, mass_EFP, NULL, NULL))) goto done;
+  double PE_tot = 0.0;
+  if (do_APE_calc) {
+    double *vol_lay = (double *)calloc((size_t)nz, sizeof(double));
+    for (int k = 0; k < nz; k++) vol_lay[k] = (1.0 / GV->Rho0) * mass_lay[k];
+    int lbelow = 1, li; double volbelow = 0.0;                         /* :598-620, 1-based list indices */
+    for (int k = nz; k >= 1; k--) {
+      volbelow = volbelow + vol_lay[k - 1];
+      if ((volbelow >= DL_vol_below[lH[k - 1]]) && (volbelow < DL_vol_below[lH[k - 1] + 1])) li = lH[k - 1];
+      else {
+        int labove = listsize;
+        li = (labove + lbelow) / 2;
+        while (li > lbelow) {
+          if (volbelow < DL_vol_below[li]) labove = li; else lbelow = li;
+          li = (labove + lbelow) / 2;
+        }
+        lH[k - 1] = li;
+      }
+      lbelow = li;
+      Z_0APE[k - 1] = DL_depth[li] - (volbelow - DL_vol_below[li]) / DL_area[li];
+    }
+    Z_0APE[nz] = DL_depth[2];
+    free(vol_lay);
+    memset(tmp1, 0, sizeof(double) * (size_t)d->slab * (size_t)(nz + 1));
+    for (int j = 0; j < nj; j++) for (int i = 0; i < ni; i++) {         /* :623-634 */
+      double hbelow = 0.0;
+      for (int K = nz; K >= 1; K--) {
+        hbelow = hbelow + h[IX3(d, i, j, K - 1)] * GV->H_to_Z;
+        const double hint = Z_0APE[K - 1] + (hbelow - (bathyT[IX2(d, i, j)] + Z_ref));
+        double hbot = Z_0APE[K - 1] - (bathyT[IX2(d, i, j)] + Z_ref);
+        hbot = (hbot + fabs(hbot)) * 0.5;
+        tmp1[IX3(d, i, j, K - 1)] = (0.5 * areaTm[IX2(d, i, j)]) * (GV->Rho0 * g_prime[K - 1]) * (hint * hint - hbot * hbot);
+      }
+    }
+    if ((rc = orc_reproducing_sum_3d(d, tmp1, nz + 1, 0, ni - 1, 0, nj - 1, 1.0, &PE_tot, PE, NULL, NULL, NULL))) goto done;
+  } else {
+    for (int K = 0; K <= nz; K++) { PE[K] = 0.0; Z_0APE[K] = 0.0; }
+  }
+  memset(tmp1, 0, sizeof(double) * (size_t)d->slab * (size_t)(nz + 1));
+  for (int k = 0; k < nz; k++) for (int j = 0; j < nj; j++) for (int i = 0; i < ni; i++) {   /* :669-673 */
+    const double uw = u[IX3(d, i - 1, j, k)], ue = u[IX3(d, i, j, k)], vs = v[IX3(d, i, j - 1, k)], vn = v[IX3(d, i, j, k)];
+    tmp1[IX3(d, i, j, k)] = (0.25 * GV->H_to_RZ * (areaTm[IX2(d, i, j)] * h[IX3(d, i, j, k)])) *
+                            (((uw * uw) + (ue * ue)) + ((vs * vs) + (vn * vn)));
+  }
+  double KE_tot;
+  if ((rc = orc_reproducing_sum_3d(d, tmp1, nz, 0, ni - 1, 0, nj - 1, 1.0, &KE_tot, KE, NULL, NULL, NULL))) goto done;
+  if (T && S) {                                                        /* :677-686 */
+    double *Temp_int = (double *)calloc((size_t)d->slab, sizeof(double)), *Salt_int = (double *)calloc((size_t)d->slab, sizeof(double));
+    for (int k = 0; k < nz; k++) for (int j = 0; j < nj; j++) for (int i = 0; i < ni; i++) {
+      const double hm = h[IX3(d, i, j, k)] * (GV->H_to_RZ * areaTm[IX2(d, i, j)]);
+      Salt_int[IX2(d, i, j)] = Salt_int[IX2(d, i, j)] + S[IX3(d, i, j, k)] * hm;
+      Temp_int[IX2(d, i, j)] = Temp_int[IX2(d, i, j)] + (C_p * T[IX3(d, i, j, k)]) * hm;
+    }
+    rc = orc_reproducing_EFP_sum_2d(d, Salt_int, 0, ni - 1, 0, nj - 1, 1, 1.0, salt_EFP, NULL);
+    if (!rc) rc = orc_reproducing_EFP_sum_2d(d, Temp_int, 0, ni - 1, 0, nj - 1, 1, 1.0, heat_EFP, NULL);
+    free(Temp_int); free(Salt_int);
+    if (rc) goto done;
+  }
+  double max_CFL[2] = {0.0, 0.0};                                      /* :701-722 */
+  for (int k = 0; k < nz; k++) for (int j = 0; j < nj; j++) for (int I = -1; I < ni; I++) {
+    double CFL_Iarea = IareaT[IX2(d, I, j)];
+    if (u[IX3(d, I, j, k)] < 0.0) CFL_Iarea = IareaT[IX2(d, I + 1, j)];
+    const double CFL_trans = fabs(u[IX3(d, I, j, k)] * dt_in_T) * (dy_Cu[IX2(d, I, j)] * CFL_Iarea);
+    const double CFL_lin = fabs(u[IX3(d, I, j, k)] * dt_in_T) * IdxCu[IX2(d, I, j)];
+    max_CFL[0] = orc_max(max_CFL[0], CFL_trans); max_CFL[1] = orc_max(max_CFL[1], CFL_lin);
+  }
+  for (int k = 0; k < nz; k++) for (int J = -1; J < nj; J++) for (int i = 0; i < ni; i++) {
+    double CFL_Iarea = IareaT[IX2(d, i, J)];
+    if (v[IX3(d, i, J, k)] < 0.0) CFL_Iarea = IareaT[IX2(d, i, J + 1)];
+    const double CFL_trans = fabs(v[IX3(d, i, J, k)] * dt_in_T) * (dx_Cv[IX2(d, i, J)] * CFL_Iarea);
+    const double CFL_lin = fabs(v[IX3(d, i, J, k)] * dt_in_T) * IdyCv[IX2(d, i, J)];
+    max_CFL[0] = orc_max(max_CFL[0], CFL_trans); max_CFL[1] = orc_max(max_CFL[1], CFL_lin);
+  }
+  scal[0] = mass_tot; scal[1] = KE_tot; scal[2] = PE_tot; scal[3] = max_CFL[0]; scal[4] = max_CFL[1];
+  rc = 0;
+done:
+  free(areaTm); free(tmp1);
+  return rc;
+}

@@ -1,0 +1,105 @@
+"""write_energy on the CPU: the oracle's sums (oracle/orc_sums.c; MOM_sum_output.F90:321, create_depth_list :1203) and the
+host-side bookkeeping and text of ocean.stats (mom6_amd/sum_output.py).  The reference holds no numbers for them; the
+checks are the physical identities the diagnostics are built on, exactly representable cases, and the formats."""
+import numpy as np
+import pytest
+
+from mom6_amd import abi, synth, sum_output as SO
+from tests import helpers as H
+
+G = abi.G
+
+
+def rest_state(d, M, nk):
+    """Flat interfaces: layer k fills the depth range [k, k+1] * Dmax / nk where there is water."""
+    bathy = M[G["bathyT"]]
+    Dmax = bathy.max()
+    zi = np.linspace(0.0, Dmax, nk + 1)
+    h = np.zeros((nk,) + bathy.shape)
+    for k in range(nk):
+        h[k] = np.clip(bathy - zi[k], 0.0, zi[k + 1] - zi[k])
+    return h * (M[G["mask2dT"]] > 0)
+
+
+def test_depth_list_is_the_hypsometry(orc):
+    gg, d, M = H.benchmark_small(nk=4)
+    dep, area, vol = orc.create_depth_list(d, M)
+    sl = tuple(H.interior(d, "h"))
+    D = M[G["bathyT"]][sl]; A = (M[G["mask2dT"]] * M[G["areaT"]])[sl]
+    n = len(dep)
+    assert dep[0] == D.max() and vol[0] == 0.0 and np.all(np.diff(dep[:n - 2]) <= 0) and np.all(np.diff(area[:n - 2]) >= 0)
+    # the volume below the shallowest listed depth is the integral of (D - depth) over the deeper cells
+    k = n - 3
+    want = (A * np.clip(D - dep[k], 0.0, None)).sum()
+    assert vol[k] == pytest.approx(want, rel=1e-12)
+    assert area[n - 3] == pytest.approx(A.sum(), rel=1e-13)
+    assert vol[n - 1] == vol[n - 2] * 1000.0 and dep[n - 1] == dep[n - 2]
+    # DEPTH_LIST_MIN_INC thins the list
+    assert len(orc.create_depth_list(d, M, min_depth_inc=50.0)[0]) < n
+
+
+def test_write_energy_identities(orc):
+    gg, d, M = H.benchmark_small(nk=5)
+    GV = abi.vgrid_default()
+    g_prime = np.array([9.8, 0.01, 0.012, 0.02, 0.03])
+    P = abi.sum_output_params_default(900.0, use_temperature=1)
+    st = orc.SumOutputState(d, M, GV, g_prime, P)
+    h = rest_state(d, M, 5)
+    z = np.zeros_like(h)
+    T = np.ascontiguousarray(10.0 + 0 * h); S = np.ascontiguousarray(35.0 + 0 * h)
+    r = orc.write_energy(st, z, z, h, T, S)
+    sl = tuple(H.interior(d, "h"))
+    A = (M[G["mask2dT"]] * M[G["areaT"]])[sl]
+    vol = (A * M[G["bathyT"]][sl]).sum()
+    assert r["mass_tot"] == pytest.approx(GV.Rho0 * vol, rel=1e-13) and r["mass_tot"] == pytest.approx(r["mass_lay"].sum(), rel=1e-15)
+    assert r["KE_tot"] == 0.0 and r["max_CFL"] == (0.0, 0.0)
+    # a level ocean at rest: the sea level of the depth list is the surface and there is no available potential energy
+    assert abs(r["Z_0APE"][0]) < 1e-9 * M[G["bathyT"]].max()
+    assert abs(r["PE_tot"]) <= 1e-12 * GV.Rho0 * 9.8 * vol * M[G["bathyT"]].max()
+    assert SO.EFP_to_real(r["salt_EFP"]) == pytest.approx(35.0 * r["mass_tot"], rel=1e-13)
+    assert SO.EFP_to_real(r["heat_EFP"]) == pytest.approx(P.C_p * 10.0 * r["mass_tot"], rel=1e-13)
+    # a uniform zonal flow away from the walls: KE = 1/2 m u**2 where both faces are open, CFL = u dt / dx
+    u = np.zeros_like(h); u[:] = 0.5 * M[G["mask2dCu"]]
+    r2 = orc.write_energy(st, u, z, h, T, S)
+    both = (M[G["mask2dCu"]][sl] * np.roll(M[G["mask2dCu"]], 1, axis=1)[sl]) > 0
+    ke_in = 0.5 * GV.Rho0 * ((A * h[(slice(None),) + sl].sum(0))[both]).sum() * 0.25
+    assert ke_in <= r2["KE_tot"] <= ke_in * 1.2
+    assert r2["max_CFL"][1] == pytest.approx((0.5 * 900.0 * M[G["IdxCu"]] * M[G["mask2dCu"]])[sl].max(), rel=1e-15)
+    assert r2["max_CFL"][0] >= r2["max_CFL"][1] * 0.9
+    # a raised sea surface has APE and a mean sea level above zero
+    h3 = h.copy(); h3[0] += 0.5 * (M[G["mask2dT"]] > 0) * (1.0 + synth.smooth_field(d, 3))
+    r3 = orc.write_energy(st, z, z, h3, T, S)
+    assert r3["PE_tot"] > 0.0 and -r3["Z_0APE"][0] > 0.2 and r3["PE"][0] == pytest.approx(r3["PE_tot"], rel=1e-6)
+
+
+def test_host_EFP_arithmetic_matches_the_oracle(orc):
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        a = orc.real_to_EFP(rng.standard_normal() * 10.0 ** rng.integers(-10, 25))
+        b = orc.real_to_EFP(rng.standard_normal() * 10.0 ** rng.integers(-10, 25))
+        dm = SO.EFP_minus(a, b)
+        assert dm == [int(x) for x in orc.EFP_minus(a, b)]
+        assert SO.EFP_to_real(dm) == orc.EFP_to_real(np.array(dm, dtype=np.int64))
+
+
+def test_ocean_stats_text():
+    assert SO.fortran_es(1.36404e21, 11, 5) == "1.36404E+21" and SO.fortran_es(-2.5e-7, 9, 2) == "-2.50E-07"
+    assert SO.fortran_es(0.0, 22, 16) == "0.0000000000000000E+00" and SO.fortran_es(1.0e-120, 11, 4) == "1.0000-120"[-11:].rjust(11)
+    assert SO.fortran_f(0.01234567, 8, 5) == " 0.01235" and SO.fortran_f(35.0, 8, 4) == " 35.0000" and SO.fortran_f(0.0, 12, 3) == "       0.000"
+    sums = dict(mass_tot=1.36404e21, KE_tot=0.0, PE_tot=0.0, max_CFL=(0.0, 0.0), Z_0APE=-np.zeros(3),   # SL = -Z_0APE(1) = +0
+                mass_EFP=[0, int(1.36404e21) >> 46, int(1.36404e21) & ((1 << 46) - 1), 0, 0, 0], salt_EFP=[0] * 6, heat_EFP=[0] * 6)
+    so = SO.SumOutput()
+    out, line = so.record(sums, 0.0, 0)
+    assert line == "     0,       0.000,     0, En 0.0000000000000000E+00, CFL  0.00000, SL  0.0000E+00, Mass 1.36404E+21, Me  0.00E+00"
+    assert out == "MOM Day       0.000      0: En 0.000000E+00, MaxCFL  0.00000, Mass 1.364040000000E+21"
+    assert so.lines[0] == "  Step,       Day,  Truncs,      Energy/Mass,      Maximum CFL,  Mean sea level,   Total Mass,    Frac Mass Err"
+    assert so.lines[1] == "            [days]                 [m2 s-2]           [Nondim]        [m]             [kg]           [Nondim]"
+    sums2 = dict(sums); sums2["mass_EFP"] = list(sums["mass_EFP"]); sums2["mass_EFP"][2] += 1 << 20
+    sums2["mass_tot"] = SO.EFP_to_real(sums2["mass_EFP"]); sums2["KE_tot"] = 2.0e18; sums2["max_CFL"] = (0.123456, 0.1)
+    out, line = so.record(sums2, 86400.0 * 1.5, 144)
+    assert line.startswith("   144,       1.500,     0, En ") and ", CFL  0.12346, SL " in line and line.endswith(", Me  %s" % SO.fortran_es((2.0 ** 20) / sums2["mass_tot"], 9, 2).strip())
+    sot = SO.SumOutput(use_temperature=True)
+    sums["salt_EFP"] = [0, int(35.0 * 1.36404e21) >> 46, 0, 0, 0, 0]; sums["heat_EFP"] = [0, int(3991.86795711963 * 13.5 * 1.36404e21) >> 46, 0, 0, 0, 0]
+    out, line = sot.record(sums, 0.0, 0)
+    assert ", M 1.36404E+21, S 35.0000, T 13.5" in line and line.endswith(", Me  0.00E+00, Se  0.00E+00, Te  0.00E+00")
+    assert sot.lines[0].endswith("Mean Temp, Frac Mass Err,   Salin Err,    Temp Err") and "[PSU]" in sot.lines[1]
