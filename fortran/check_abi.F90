@@ -17,6 +17,9 @@ program check_abi
   type(mom6x_hor_visc_params) :: hv
   type(mom6x_remapping_params) :: rm
   type(mom6x_regrid_zstar_params) :: rz
+  type(mom6x_chksum_result) :: cr
+  type(mom6x_sum_output_params) :: sp
+  type(mom6x_energy_sums) :: es
   integer :: nbad, rc
   nbad = 0
   call chk(0, int(c_sizeof(d)), "mom6x_dims")
@@ -33,6 +36,9 @@ program check_abi
   call chk(11, int(c_sizeof(hv)), "mom6x_hor_visc_params")
   call chk(12, int(c_sizeof(rm)), "mom6x_remapping_params")
   call chk(13, int(c_sizeof(rz)), "mom6x_regrid_zstar_params")
+  call chk(14, int(c_sizeof(cr)), "mom6x_chksum_result")
+  call chk(15, int(c_sizeof(sp)), "mom6x_sum_output_params")
+  call chk(16, int(c_sizeof(es)), "mom6x_energy_sums")
   rc = mom6x_dims_init(d, 1440, 1080, 75, 4)
   if (rc /= 0 .or. d%pitch /= 1472 .or. d%ioff /= 16) then
     print *, "mom6x_dims_init mismatch", rc, d%pitch, d%ioff ; nbad = nbad + 1

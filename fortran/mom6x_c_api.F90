@@ -14,6 +14,8 @@ module mom6x_c_api
   public :: mom6x_hor_visc_params, mom6x_hor_visc_init, mom6x_horizontal_viscosity, mom6x_vertvisc_set_direct_stress
   public :: mom6x_remapping_params, mom6x_ALE_remap_tracers, mom6x_ALE_remap_set_h_vel, mom6x_ALE_remap_velocities
   public :: mom6x_remapping_core_h, mom6x_regrid_zstar_params, mom6x_ALE_regrid_zstar
+  public :: mom6x_chksum_result, mom6x_sum_output_params, mom6x_energy_sums, mom6x_reproducing_sum_3d, mom6x_reproducing_sum_2d
+  public :: mom6x_chksum, mom6x_field_chksum, mom6x_sum_output_init, mom6x_depth_list, mom6x_write_energy, mom6x_barotropic_dtbt
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
   public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
   public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc
@@ -102,6 +104,21 @@ module mom6x_c_api
   type, bind(C) :: mom6x_regrid_zstar_params   !< the members of regridding_CS (MOM_regridding.F90:40-140) the z* branch reads
     real(c_double) :: min_thickness, old_grid_weight, depth_of_time_filter_shallow, depth_of_time_filter_deep, Z_ref
   end type mom6x_regrid_zstar_params
+
+  type, bind(C) :: mom6x_chksum_result         !< the numbers of the two lines of chksum_{h,u,v,B}_{2d,3d} (MOM_checksums.F90)
+    real(c_double) :: mean, amin, amax
+    integer(c_int) :: bc0, bc(4), nbc, bc_kind
+  end type mom6x_chksum_result
+
+  type, bind(C) :: mom6x_sum_output_params     !< the members of Sum_output_CS the sums of write_energy read
+    integer(c_int) :: do_APE_calc, use_temperature
+    real(c_double) :: dt_in_T, D_list_min_inc, Z_ref, C_p
+  end type mom6x_sum_output_params
+
+  type, bind(C) :: mom6x_energy_sums           !< write_energy (MOM_sum_output.F90:321): the global sums
+    real(c_double) :: mass_tot, KE_tot, PE_tot, max_CFL(2)
+    integer(c_int64_t) :: mass_EFP(6), salt_EFP(6), heat_EFP(6)
+  end type mom6x_energy_sums
 
   type, bind(C) :: mom6x_eos_params        !< tv%eqn_of_state (MOM_EOS.F90:99-150) + EOS-only switches of PressureForce_FV_CS
     integer(c_int) :: form                 !< 1 EOS_LINEAR, 2 EOS_WRIGHT
@@ -267,6 +284,53 @@ module mom6x_c_api
       import :: c_ptr, c_int, mom6x_remapping_params
       type(c_ptr), value :: ctx, h0, u0, h1, u1 ; type(mom6x_remapping_params), intent(in) :: p
       integer(c_int), value :: ncol, n0, n1
+    end function
+    !> reproducing_sum_3d (MOM_coms.F90:349); sums, EFP_sum, EFP_lay_sums, err: c_null_ptr when absent
+    integer(c_int) function mom6x_reproducing_sum_3d(ctx, array, nk, is, ie, js, je, unscale, only_on_PE, sum, sums, EFP_sum, &
+        EFP_lay_sums, err) bind(C, name="mom6x_reproducing_sum_3d")
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, array, sums, EFP_sum, EFP_lay_sums, err
+      integer(c_int), value :: nk, is, ie, js, je, only_on_PE ; real(c_double), value :: unscale ; real(c_double), intent(out) :: sum
+    end function
+    !> reproducing_sum_2d (MOM_coms.F90:235)
+    integer(c_int) function mom6x_reproducing_sum_2d(ctx, array, is, ie, js, je, unscale, only_on_PE, sum, EFP_sum, err) &
+        bind(C, name="mom6x_reproducing_sum_2d")
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx, array, EFP_sum, err
+      integer(c_int), value :: is, ie, js, je, only_on_PE ; real(c_double), value :: unscale ; real(c_double), intent(out) :: sum
+    end function
+    !> chksum_{h,u,v,B}_{2d,3d} (MOM_checksums.F90); scale: c_null_ptr when absent
+    integer(c_int) function mom6x_chksum(ctx, array, nk, rank, stagger, haloshift, symmetric, omit_corners, scale, res) &
+        bind(C, name="mom6x_chksum")
+      import :: c_ptr, c_int, mom6x_chksum_result
+      type(c_ptr), value :: ctx, array, scale ; integer(c_int), value :: nk, rank, stagger, haloshift, symmetric, omit_corners
+      type(mom6x_chksum_result), intent(out) :: res
+    end function
+    !> the restart `checksum` attribute (MOM_restart.F90:1741) of a device-resident field
+    integer(c_int) function mom6x_field_chksum(ctx, array, nk, is, ie, js, je, unscale, chksum) bind(C, name="mom6x_field_chksum")
+      import :: c_ptr, c_int, c_double, c_int64_t
+      type(c_ptr), value :: ctx, array ; integer(c_int), value :: nk, is, ie, js, je ; real(c_double), value :: unscale
+      integer(c_int64_t), intent(out) :: chksum
+    end function
+    !> MOM_sum_output_init (MOM_sum_output.F90:147) + depth_list_setup (:1161); g_prime: GV%g_prime(1:nk)
+    integer(c_int) function mom6x_sum_output_init(ctx, p, g_prime) bind(C, name="mom6x_sum_output_init")
+      import :: c_ptr, c_int, c_double, mom6x_sum_output_params
+      type(c_ptr), value :: ctx ; type(mom6x_sum_output_params), intent(in) :: p ; real(c_double), intent(in) :: g_prime(*)
+    end function
+    integer(c_int) function mom6x_depth_list(ctx, listsize, depth, area, vol_below) bind(C, name="mom6x_depth_list")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, depth, area, vol_below ; integer(c_int), intent(out) :: listsize
+    end function
+    !> the sums of write_energy (MOM_sum_output.F90:321); T, S: c_null_ptr without ENABLE_THERMODYNAMICS
+    integer(c_int) function mom6x_write_energy(ctx, u, v, h, T, S, sums, mass_lay, KE, PE, Z_0APE) bind(C, name="mom6x_write_energy")
+      import :: c_ptr, c_int, c_double, mom6x_energy_sums
+      type(c_ptr), value :: ctx, u, v, h, T, S ; type(mom6x_energy_sums), intent(out) :: sums
+      real(c_double), intent(out) :: mass_lay(*), KE(*), PE(*), Z_0APE(*)
+    end function
+    !> CS%dtbt, the restart scalar DTBT (MOM_barotropic.F90:6290): get / set are c_null_ptr when not wanted
+    integer(c_int) function mom6x_barotropic_dtbt(ctx, get, set) bind(C, name="mom6x_barotropic_dtbt")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, get, set
     end function
     !> DIRECT_STRESS / HMIX_STRESS (MOM_vert_friction.F90:3208, :707); h = vertvisc's thickness argument (device pointer)
     integer(c_int) function mom6x_vertvisc_set_direct_stress(ctx, Hmix_stress, h) bind(C, name="mom6x_vertvisc_set_direct_stress")

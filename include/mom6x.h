@@ -363,6 +363,9 @@ int mom6x_btstep(mom6x_ctx *ctx,
  * `which`: 0 ubtav, 1 vbtav, 2 eta_cor, 3 frhatu (3-D), 4 frhatv (3-D),
  * 5 IDatu, 6 IDatv.  Returns a device pointer owned by the context.          */
 double *mom6x_barotropic_field(mom6x_ctx *ctx, int which);
+/* CS%dtbt, the scalar restart variable "DTBT" (register_barotropic_restarts :6290): *get (nullable) receives it, *set
+ * (nullable, > 0) replaces it -- a restarted run keeps the file's DTBT as barotropic_init :5962-5970 does.         */
+int mom6x_barotropic_dtbt(mom6x_ctx *ctx, double *get, const double *set);
 
 /* ------------------------------------------------------------------------- */
 /* MOM_CoriolisAdv                                                             */

@@ -639,6 +639,15 @@ extern "C" double *mom6x_barotropic_field(mom6x_ctx *c, int which) {
   }
 }
 
+// CS%dtbt, the scalar restart variable "DTBT" (register_barotropic_restarts :6290): read it for save_restart, set it
+// after restore_state (barotropic_init :5962-5970 keeps a restart's positive DTBT instead of its own estimate).
+extern "C" int mom6x_barotropic_dtbt(mom6x_ctx *c, double *get, const double *set) {
+  REQUIRE(c && c->bt_init, MOM6X_EINVAL, "mom6x_barotropic_dtbt: Module MOM_barotropic must be initialized before it is used.");
+  if (set) { REQUIRE(*set > 0.0, MOM6X_EINVAL, "mom6x_barotropic_dtbt: DTBT must be positive"); c->bt.dtbt = *set; }
+  if (get) *get = c->bt.dtbt;
+  return MOM6X_OK;
+}
+
 extern "C" int mom6x_btcalc(mom6x_ctx *c, const double *h, const double *h_u, const double *h_v) {
   REQUIRE(c && c->bt_init, MOM6X_EINVAL, "btcalc: Module MOM_barotropic must be initialized before it is used.");
   REQUIRE((h_u != nullptr) == (h_v != nullptr), MOM6X_EINVAL, "btcalc: Inconsistent settings of optional arguments");

@@ -121,6 +121,12 @@ class Dycore:
         shape = self.dims.shape2() if nd == 2 else self.dims.shape3()
         return _view(ptr, shape, self.device)
 
+    def barotropic_dtbt(self, value=None):
+        """CS%dtbt (the restart scalar DTBT); with a value, set it (a restarted run)."""
+        out = C.c_double(0.0)
+        check(self.lib, self.lib.mom6x_barotropic_dtbt(self.ctx, C.byref(out), None if value is None else C.byref(C.c_double(value))))
+        return out.value
+
     def btcalc(self, h, h_u=None, h_v=None):
         """btcalc (MOM_barotropic.F90:4360)."""
         check(self.lib, self.lib.mom6x_btcalc(self.ctx, _ptr(h), _ptr(h_u), _ptr(h_v)))
@@ -348,6 +354,11 @@ class Dycore:
     def dyn_split_RK2_new_run(self, u, v, h, uh, vh, dt):
         """The new-run fills of initialize_dyn_split_RK2 (:1577-1650)."""
         check(self.lib, self.lib.mom6x_dyn_split_RK2_new_run(self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(uh), _ptr(vh), C.c_double(dt)))
+
+    def rk2_set_CAu_pred_stored(self, stored=True):
+        """A restarted run whose file held CAu, CAv (query_initialized, MOM_dynamics_split_RK2.F90:1616) skips the
+        CorAdCalc of :552-557 at its first step."""
+        check(self.lib, self.lib.mom6x_rk2_set_CAu_pred_stored(self.ctx, int(bool(stored))))
 
     def rk2_field(self, name):
         """Zero-copy torch view of a MOM_dyn_split_RK2_CS array (restart / diagnostics access)."""
