@@ -204,6 +204,41 @@ def ale_remap_leg(args, dyc, d, st, barrier, dist):
             "note": "reported next to, not inside, the headline metric: ALE_regrid (z*) + remapping of T, S, u, v, all on the device"}
 
 
+def diag_leg(args, dyc, d, st, barrier, dist):
+    """The regression artefacts of one output interval, after the timed region and NOT part of `value`: write_energy (the
+    line of ocean.stats: 3-D reproducing sums of mass, APE and KE, the CFL maxima) and the checksum lines of u, v, h
+    (uvchksum + hchksum) plus their restart checksums, all formed on the device-resident state."""
+    import torch
+    from mom6_amd import abi, sum_output
+    GV = dyc.GV
+    Rlay, gp = abi.layer_densities(args.nk, GV.Rho0, GV.g_Earth)
+    dyc.sum_output_init(abi.sum_output_params_default(args.dt), gp)
+    so = sum_output.SumOutput()
+    dyc.write_energy(st["u"], st["v"], st["h"])                          # untimed: allocates the work arrays
+    barrier(); t0 = time.perf_counter()
+    sums = dyc.write_energy(st["u"], st["v"], st["h"])
+    barrier(); t_en = time.perf_counter() - t0
+    out_line, _ = so.record(sums, 0.0, 0)
+    barrier(); t0 = time.perf_counter()
+    lines = [dyc.chksum_lines(st["u"], "u", "u", symmetric=True)[1], dyc.chksum_lines(st["v"], "v", "v", symmetric=True)[1],
+             dyc.chksum_lines(st["h"], "h", "h")[1]]
+    chk = [dyc.field_chksum(st[n]) for n in ("u", "v", "h")]
+    barrier(); t_ck = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([t_en, t_ck], dtype=torch.float64, device=dyc.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_en, t_ck = float(tt[0].item()), float(tt[1].item())
+    N3 = args.ni * args.nj * args.nk
+    b_en = 8.0 * N3 * (1 + 2 + 3 + 2)        # mass: h; APE: h in, PE_pt out and in; KE: h, u, v; CFL: u, v
+    b_ck = 8.0 * N3 * (3 * 3 + 3)            # per field: sum + min/max pass, bit count(s); restart checksum
+    return {"write_energy_ms": round(1e3 * t_en, 3), "write_energy_GBps": round(b_en / 1e9 / t_en, 1),
+            "write_energy_frac_of_hbm_peak": round(b_en / 1e9 / t_en / (HBM_PEAK_GBS * args.gpus), 4),
+            "chksum_ms": round(1e3 * t_ck, 3), "chksum_GBps": round(b_ck / 1e9 / t_ck, 1), "stdout_line": out_line,
+            "h_chksum_line": lines[2], "restart_checksum_h": "%016X" % (chk[2] % 2 ** 64),
+            "note": "reported next to, not inside, the headline metric: one ocean.stats line (reproducing sums) and the debugging / "
+                    "restart checksums of u, v, h from the device-resident state; host round trips included"}
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_hbm_pmc.json,
     written by scripts/rocprof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; the
@@ -374,6 +409,7 @@ def main():
     if args.tracers > 0:
         out["tracer_leg"] = tracer_leg(args, dyc, d, st, step, barrier, dist)
         out["ale_remap_leg"] = ale_remap_leg(args, dyc, d, st, barrier, dist)
+        out["diag_leg"] = diag_leg(args, dyc, d, st, barrier, dist)
     if rank == 0:
         tot = sum(v[1] for v in full.values())
         out["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]}

@@ -34,6 +34,9 @@ def main():
     out, _, _ = cases.oracle_continuity(orc, cfg, cases.continuity_inputs(cfg))
     np.savez_compressed(H.golden_path("continuity_benchmark_small_corrector"),
                         **{n: out[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))] for n in out})
+    lines = cases.oracle_ocean_stats(orc, H.double_gyre(), 3, dict(strong_drag=1))
+    with open(os.path.join(ROOT, "tests", "golden", "ocean.stats.double_gyre_strong_drag_3steps"), "w") as f:
+        f.write("\n".join(lines) + "\n")
     for f in sorted(os.listdir(os.path.join(ROOT, "tests", "golden"))):
         print(f, os.path.getsize(os.path.join(ROOT, "tests", "golden", f)), "bytes")
 

@@ -102,3 +102,20 @@ def thermo_state(d, M, seed=7):
         T[k] = 20.0 - 15.0 * k / max(d.nk - 1, 1) + 0.8 * synth.smooth_field(d, seed + k, ox=0.5, oy=0.5)
         S[k] = 34.0 + 1.0 * k / max(d.nk - 1, 1) + 0.2 * synth.smooth_field(d, seed + 100 + k, ox=0.5, oy=0.5)
     return np.ascontiguousarray(T), np.ascontiguousarray(S)
+
+
+def oracle_ocean_stats(orc, cfg, nsteps=3, bt_mod=None):
+    """The ocean.stats lines (header + one line at the start + one after each of nsteps baroclinic steps) of the oracle's
+    run of the seeded double-gyre-type case: the oracle's write_energy sums through mom6_amd.sum_output."""
+    from mom6_amd import sum_output as SO
+    gg, d, M = cfg
+    inp = rk2_inputs(cfg, False, False)
+    dt = inp["dt"]
+    P = abi.sum_output_params_default(dt)
+    st = orc.SumOutputState(d, M, inp["GV"], inp["gp"], P)
+    so = SO.SumOutput()
+    so.record(orc.write_energy(st, inp["u"], inp["v"], inp["h"]), 0.0, 0)
+    for n in range(1, nsteps + 1):
+        s = oracle_rk2(orc, cfg, inp, n, bt_mod, None, None, 0)[0]
+        so.record(orc.write_energy(st, s["u"], s["v"], s["h"]), dt * n, n)
+    return so.lines

@@ -103,3 +103,12 @@ def test_ocean_stats_text():
     out, line = sot.record(sums, 0.0, 0)
     assert ", M 1.36404E+21, S 35.0000, T 13.5" in line and line.endswith(", Me  0.00E+00, Se  0.00E+00, Te  0.00E+00")
     assert sot.lines[0].endswith("Mean Temp, Frac Mass Err,   Salin Err,    Temp Err") and "[PSU]" in sot.lines[1]
+
+
+def test_oracle_reproduces_committed_ocean_stats(orc):
+    """tests/golden/ocean.stats.double_gyre_strong_drag_3steps (scripts/make_golden.py): today's oracle writes the same file."""
+    import os
+    from tests import cases
+    lines = cases.oracle_ocean_stats(orc, H.double_gyre(), 3, dict(strong_drag=1))
+    golden = open(os.path.join(os.path.dirname(H.golden_path("x")), "ocean.stats.double_gyre_strong_drag_3steps")).read().splitlines()
+    assert lines == golden and len(lines) == 6 and lines[2].startswith("     0,       0.000,     0, En ")

@@ -81,13 +81,7 @@ def test_ocean_stats_of_a_run(orc, tmp_path):
     GV, Rlay, gp, dt = inp["GV"], inp["Rlay"], inp["gp"], inp["dt"]
     bt_mod = dict(strong_drag=1)
     P = abi.sum_output_params_default(dt)
-    # oracle run: one step at a time so that the state after every step is seen
-    st = orc.SumOutputState(d, M, GV, gp, P)
-    so_ref = SO.SumOutput()
-    so_ref.record(orc.write_energy(st, inp["u"], inp["v"], inp["h"]), 0.0, 0)
-    states = [cases.oracle_rk2(orc, cfg, inp, n, bt_mod, None, None, 0)[0] for n in (1, 2, 3)]
-    for n, s in enumerate(states):
-        so_ref.record(orc.write_energy(st, s["u"], s["v"], s["h"]), dt * (n + 1), n + 1)
+    ref_lines = cases.oracle_ocean_stats(orc, cfg, 3, bt_mod)     # the oracle's run, a line after every step
     # device run
     cont2, bt2, cor2, pgf2, rk22 = cases.rk2_params(d, GV, bt_mod, None, None)
     dyc = Dycore(d, M, GV, 0)
@@ -105,11 +99,14 @@ def test_ocean_stats_of_a_run(orc, tmp_path):
         dyc.step_MOM_dyn_split_RK2(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], sg["uhtr"], sg["vhtr"], sg["eta_av"], txd, tyd,
                                    dt, calc_dtbt=(n == 0))
         so_dev.record(dyc.write_energy(sg["u"], sg["v"], sg["h"]), dt * (n + 1), n + 1)
-    assert so_dev.lines == so_ref.lines and len(so_dev.lines) == 6
+    assert so_dev.lines == ref_lines and len(so_dev.lines) == 6
+    import os
+    golden = open(os.path.join(os.path.dirname(H.golden_path("x")), "ocean.stats.double_gyre_strong_drag_3steps")).read().splitlines()
+    assert so_dev.lines == golden                                # the committed fixture (scripts/make_golden.py)
     assert out0.startswith("MOM Day       0.000      0: En ")
     # the volume-conserving continuity solver: the mass column and the fractional mass error stay put
     errs = [float(l.split("Me")[1]) for l in so_dev.lines[2:]]
     assert max(abs(e) for e in errs) < 1e-14
     so_dev.write(tmp_path / "ocean.stats")
-    assert (tmp_path / "ocean.stats").read_text().splitlines() == so_ref.lines
+    assert (tmp_path / "ocean.stats").read_text().splitlines() == ref_lines
     dyc.close()
