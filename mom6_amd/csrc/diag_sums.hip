@@ -504,7 +504,11 @@ k_max_cfl(Dm d, const double *__restrict__ G, const double *__restrict__ u, cons
   if (!(m2 == m2)) m2 = 0.0;
   memcpy(&b1, &m1, 8); memcpy(&b2, &m2, 8);
   b1 = wave_max(b1); b2 = wave_max(b2);
-  if ((threadIdx.x & 63) == 0) { if (b1) atomicMax(&out[0], b1); if (b2) atomicMax(&out[1], b2); }
+  // one atomic per wavefront at most, and only when it can still raise the running maximum (a stale read is harmless)
+  if ((threadIdx.x & 63) == 0) {
+    if (b1 > __atomic_load_n(&out[0], __ATOMIC_RELAXED)) atomicMax(&out[0], b1);
+    if (b2 > __atomic_load_n(&out[1], __ATOMIC_RELAXED)) atomicMax(&out[1], b2);
+  }
 }
 
 void diag_state_free(DiagState *s) {
