@@ -15,6 +15,7 @@ module mom6x_c_api
   public :: mom6x_remapping_params, mom6x_ALE_remap_tracers, mom6x_ALE_remap_set_h_vel, mom6x_ALE_remap_velocities
   public :: mom6x_remapping_core_h, mom6x_regrid_zstar_params, mom6x_ALE_regrid_zstar
   public :: mom6x_chksum_result, mom6x_sum_output_params, mom6x_energy_sums, mom6x_reproducing_sum_3d, mom6x_reproducing_sum_2d
+  public :: mom6x_remap_dyn_split_RK2_aux_vars
   public :: mom6x_chksum, mom6x_field_chksum, mom6x_sum_output_init, mom6x_depth_list, mom6x_write_energy, mom6x_barotropic_dtbt
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
   public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
@@ -128,7 +129,7 @@ module mom6x_c_api
 
   type, bind(C) :: mom6x_rk2_params        !< MOM_dyn_split_RK2_CS (MOM_dynamics_split_RK2.F90:85-273)
     real(c_double) :: be, begw
-    integer(c_int) :: split_bottom_stress, BT_use_layer_fluxes, store_CAu, visc_rem_dt_bug
+    integer(c_int) :: split_bottom_stress, BT_use_layer_fluxes, store_CAu, visc_rem_dt_bug, remap_aux
   end type mom6x_rk2_params
 
   type, bind(C) :: mom6x_rk2_hooks         !< host callbacks for the un-ported callees (SURVEY 8f)
@@ -284,6 +285,12 @@ module mom6x_c_api
       import :: c_ptr, c_int, mom6x_remapping_params
       type(c_ptr), value :: ctx, h0, u0, h1, u1 ; type(mom6x_remapping_params), intent(in) :: p
       integer(c_int), value :: ncol, n0, n1
+    end function
+    !> remap_dyn_split_RK2_aux_vars (MOM_dynamics_split_RK2.F90:1302)
+    integer(c_int) function mom6x_remap_dyn_split_RK2_aux_vars(ctx, p, h_old_u, h_old_v, h_new_u, h_new_v) &
+        bind(C, name="mom6x_remap_dyn_split_RK2_aux_vars")
+      import :: c_ptr, c_int, mom6x_remapping_params
+      type(c_ptr), value :: ctx, h_old_u, h_old_v, h_new_u, h_new_v ; type(mom6x_remapping_params), intent(in) :: p
     end function
     !> reproducing_sum_3d (MOM_coms.F90:349); sums, EFP_sum, EFP_lay_sums, err: c_null_ptr when absent
     integer(c_int) function mom6x_reproducing_sum_3d(ctx, array, nk, is, ie, js, je, unscale, only_on_PE, sum, sums, EFP_sum, &

@@ -240,6 +240,7 @@ typedef struct mom6x_rk2_params {
   int    BT_use_layer_fluxes;  /* BT_USE_LAYER_FLUXES (T) -- only T supported                 */
   int    store_CAu;            /* STORE_CORIOLIS_ACCEL (T) -- only T supported                */
   int    visc_rem_dt_bug;      /* VISC_REM_TIMESTEP_BUG (T with ENABLE_BUGS_BY_DEFAULT)       */
+  int    remap_aux;            /* REMAP_AUXILIARY_VARS (F): mom6x_remap_dyn_split_RK2_aux_vars */
 } mom6x_rk2_params;
 
 /* ------------------------------------------------------------------------- */
@@ -514,6 +515,12 @@ int mom6x_initialize_dyn_split_RK2(mom6x_ctx *ctx, const mom6x_rk2_params *p);
 int mom6x_dyn_split_RK2_new_run(mom6x_ctx *ctx, const double *u, const double *v, const double *h,
                                 double *uh, double *vh, double dt);
 int mom6x_rk2_set_CAu_pred_stored(mom6x_ctx *ctx, int stored);
+/* remap_dyn_split_RK2_aux_vars (RK2.F90:1302): after an ALE regridding the auxiliary restart variables move to the
+ * new grid too -- u_av, v_av and CAu_pred, CAv_pred (STORE_CORIOLIS_ACCEL), then diffu, diffv, each pair with
+ * ALE_remap_velocities and the first two followed by their pass_vector.  Returns at once unless REMAP_AUXILIARY_VARS.
+ * p stands for ALE_CSp%vel_remapCS; the face thicknesses are those of mom6x_ALE_remap_set_h_vel.                  */
+int mom6x_remap_dyn_split_RK2_aux_vars(mom6x_ctx *ctx, const mom6x_remapping_params *p, const double *h_old_u,
+                                       const double *h_old_v, const double *h_new_u, const double *h_new_v);
 /* Device pointers to the CS arrays MOM_restart registers (register_restarts_dyn_split_RK2 :1210:
  * sfc=eta, u2=u_av, v2=v_av, CAu, CAv, diffu, diffv) and the others, by name index:
  * 0 CAu, 1 CAv, 2 CAu_pred, 3 CAv_pred, 4 PFu, 5 PFv, 6 diffu, 7 diffv, 8 visc_rem_u, 9 visc_rem_v,

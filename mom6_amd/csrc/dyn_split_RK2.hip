@@ -163,6 +163,7 @@ extern "C" int mom6x_initialize_dyn_split_RK2(mom6x_ctx *c, const mom6x_rk2_para
   REQUIRE(c && p, MOM6X_EINVAL, "mom6x_initialize_dyn_split_RK2: null argument");
   REQUIRE(c->cont_init && c->bt_init && c->cor_init && c->pgf_init, MOM6X_EINVAL,
           "initialize_dyn_split_RK2: continuity, barotropic, CoriolisAdv and PressureForce must be initialised first");
+  REQUIRE(!p->remap_aux || p->store_CAu, MOM6X_EINVAL, "REMAP_AUXILIARY_VARS requires that STORE_CORIOLIS_ACCEL = True.");   // :1474
   REQUIRE(p->BT_use_layer_fluxes && p->store_CAu, MOM6X_EUNSUPPORTED,
           "dyn_split_RK2: only BT_USE_LAYER_FLUXES=True and STORE_CORIOLIS_ACCEL=True are supported");
   HIPCHK(hipSetDevice(c->device));
@@ -201,6 +202,23 @@ extern "C" int mom6x_rk2_set_CAu_pred_stored(mom6x_ctx *c, int stored) {
 }
 
 #define CHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+// remap_dyn_split_RK2_aux_vars :1302-1330
+extern "C" int mom6x_remap_dyn_split_RK2_aux_vars(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old_u,
+                                                  const double *h_old_v, const double *h_new_u, const double *h_new_v) {
+  REQUIRE(c && c->rk2, MOM6X_EINVAL, "remap_dyn_split_RK2_aux_vars: dyn_split_RK2 not initialised");
+  RK2State *s = c->rk2;
+  if (!s->P.remap_aux) return MOM6X_OK;
+  if (s->P.store_CAu) {
+    CHK(mom6x_ALE_remap_velocities(c, p, h_old_u, h_old_v, h_new_u, h_new_v, s->u_av, s->v_av));
+    CHK(pass3(c, {s->u_av, s->v_av}, {1, 2}, c->d.nk));
+    CHK(mom6x_ALE_remap_velocities(c, p, h_old_u, h_old_v, h_new_u, h_new_v, s->CAu_pred, s->CAv_pred));
+    CHK(pass3(c, {s->CAu_pred, s->CAv_pred}, {1, 2}, c->d.nk));
+  }
+  CHK(mom6x_ALE_remap_velocities(c, p, h_old_u, h_old_v, h_new_u, h_new_v, s->diffu, s->diffv));
+  REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
+  return MOM6X_OK;
+}
 
 extern "C" int mom6x_dyn_split_RK2_new_run(mom6x_ctx *c, const double *u, const double *v, const double *h, double *uh,
                                            double *vh, double dt) {

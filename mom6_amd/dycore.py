@@ -7,6 +7,10 @@ CPU fallback: constructing a `Dycore` without the HIP library or without a GPU r
 
 Fields are torch.float64 CUDA tensors in the pitched tile layout:
   2-D: shape (nj+2*halo+1, pitch); 3-D: shape (nk, nj+2*halo+1, pitch).
+
+Streams: every call is enqueued on the context's own HIP stream (Dycore.stream_ptr), not on torch's.  A torch
+operation on an array the context is still working on (zero_(), copy_(), .cpu()) must be preceded by Dycore.sync(), and a
+call into the context after torch wrote an array by torch.cuda.synchronize().
 """
 import ctypes as C
 
@@ -354,6 +358,11 @@ class Dycore:
     def dyn_split_RK2_new_run(self, u, v, h, uh, vh, dt):
         """The new-run fills of initialize_dyn_split_RK2 (:1577-1650)."""
         check(self.lib, self.lib.mom6x_dyn_split_RK2_new_run(self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(uh), _ptr(vh), C.c_double(dt)))
+
+    def remap_dyn_split_RK2_aux_vars(self, CS, h_old_u, h_old_v, h_new_u, h_new_v):
+        """remap_dyn_split_RK2_aux_vars (MOM_dynamics_split_RK2.F90:1302); CS = ALE_CSp%vel_remapCS."""
+        check(self.lib, self.lib.mom6x_remap_dyn_split_RK2_aux_vars(self.ctx, C.byref(CS), _ptr(h_old_u), _ptr(h_old_v), _ptr(h_new_u),
+                                                                    _ptr(h_new_v)))
 
     def rk2_set_CAu_pred_stored(self, stored=True):
         """A restarted run whose file held CAu, CAv (query_initialized, MOM_dynamics_split_RK2.F90:1616) skips the

@@ -393,6 +393,16 @@ class OrcModel:
     def __getitem__(self, n):
         return self.f[n]
 
+    def remap_aux_vars(self, CS, h_old_u, h_old_v, h_new_u, h_new_v):
+        """remap_dyn_split_RK2_aux_vars (MOM_dynamics_split_RK2.F90:1302-1330); the pass_vector calls are the caller's
+        (one closed tile: nothing to exchange)."""
+        if not self.rk2.remap_aux:
+            return
+        if self.rk2.store_CAu:
+            ALE_remap_velocities(self.d, self.M, CS, h_old_u, h_old_v, h_new_u, h_new_v, self.f["u_av"], self.f["v_av"])
+            ALE_remap_velocities(self.d, self.M, CS, h_old_u, h_old_v, h_new_u, h_new_v, self.f["CAu_pred"], self.f["CAv_pred"])
+        ALE_remap_velocities(self.d, self.M, CS, h_old_u, h_old_v, h_new_u, h_new_v, self.f["diffu"], self.f["diffv"])
+
     def initialize(self, u, v, h, uh, vh, dt):
         rc = lib().orc_initialize_dyn_split_RK2(C.byref(self.A), _p(u), _p(v), _p(h), _p(uh), _p(vh), C.c_double(dt))
         if rc != 0:
