@@ -27,6 +27,7 @@ struct TAState {
   double *hprev, *uhr, *vhr, *uhh, *flux[MAXTR];
   int nflux;
   int *dmu, *dmv, *limu, *limv, *dmk;   // [nk*nrows] row flags, "a flux was limited" marks, [nk] layer flags
+  double *save; size_t save_cap;        // the old values beyond the tile / segment boundaries of the one-kernel passes
 };
 
 struct TrList { double *t[MAXTR]; int scheme[MAXTR]; int n; };
@@ -39,19 +40,19 @@ inline dim3 blk2() { return dim3(64, 4, 1); }
 __device__ __forceinline__ double dmax3(double a, double b, double c) { return dmax(dmax(a, b), c); }
 __device__ __forceinline__ double dmin3(double a, double b, double c) { return dmin(dmin(a, b), c); }
 
-// PLM slope at cell c :445-449 / :824-828
-__device__ __forceinline__ double plm_slope(const double *__restrict__ T, const double *__restrict__ mC, size_t c, size_t c2, int st) {
-  const double tp = T[c + st], tc = T[c], tm = T[c - st];
+// PLM slope of a cell from its three values and the product of the masks of its two faces :445-449 / :824-828
+__device__ __forceinline__ double plm_slope3(double tm, double tc, double tp, double mprod) {
   const double dMx = dmax3(tp, tc, tm) - tc, dMn = tc - dmin3(tp, tc, tm);
-  return mC[c2] * mC[c2 - st] * dsign(dmin3(0.5 * fabs(tp - tm), 2.0 * dMx, 2.0 * dMn), tp - tm);
+  return mprod * dsign(dmin3(0.5 * fabs(tp - tm), 2.0 * dMx, 2.0 * dMn), tp - tm);
 }
 
-// tracer flux through one face :546-607 / :951-1010.  f = 3-D index of the face, f2 = its 2-D index.
-__device__ double face_flux(int scheme, const double *__restrict__ T, const double *__restrict__ mC, size_t f, size_t f2,
-                            int st, double uhh, double CFL) {
+// Tracer flux through one face :546-607 / :951-1010 from gathered operands: T5 = the tracer in the upwind cell `up` and
+// its two neighbours on either side (up-2 .. up+2 along the direction); mk = the face masks of the faces up-2 .. up+1
+// (face n lies between the cells n and n+1).  Every variant of the advection kernels funnels into this one function, so
+// they cannot differ in arithmetic.
+__device__ __forceinline__ double face_flux5(int scheme, const double (&T5)[5], const double (&mk)[4], double uhh, double CFL) {
+  const double Tm = T5[1], Tc = T5[2], Tp = T5[3];
   if (scheme == ADVECT_PPM || scheme == ADVECT_PPMH3) {
-    const size_t up = (uhh >= 0.0) ? f : f + st, up2 = (uhh >= 0.0) ? f2 : f2 + st;
-    const double Tp = T[up + st], Tc = T[up], Tm = T[up - st];
     double aL, aR;
     if (scheme == ADVECT_PPMH3) {
       aL = (5. * Tc + (2. * Tm - Tp)) / 6.;
@@ -59,23 +60,77 @@ __device__ double face_flux(int scheme, const double *__restrict__ T, const doub
       aR = (5. * Tc + (2. * Tp - Tm)) / 6.;
       aR = dmax(dmin(Tc, Tp), aR); aR = dmin(dmax(Tc, Tp), aR);
     } else {
-      const double s0 = plm_slope(T, mC, up - st, up2 - st, st), s1 = plm_slope(T, mC, up, up2, st),
-                   s2 = plm_slope(T, mC, up + st, up2 + st, st);
+      const double s0 = plm_slope3(T5[0], T5[1], T5[2], mk[1] * mk[0]), s1 = plm_slope3(T5[1], T5[2], T5[3], mk[2] * mk[1]),
+                   s2 = plm_slope3(T5[2], T5[3], T5[4], mk[3] * mk[2]);
       aL = 0.5 * ((Tm + Tc) + (s0 - s1) / 3.);
       aR = 0.5 * ((Tc + Tp) + (s1 - s2) / 3.);
     }
     const double dA = aR - aL, mA = 0.5 * (aR + aL);
-    if (mC[up2] * mC[up2 - st] * (Tp - Tc) * (Tc - Tm) <= 0.) { aL = Tc; aR = Tc; }
+    if (mk[2] * mk[1] * (Tp - Tc) * (Tc - Tm) <= 0.) { aL = Tc; aR = Tc; }
     else if (dA * (Tc - mA) > (dA * dA) / 6.) aL = (3. * Tc) - 2. * aR;
     else if (dA * (Tc - mA) < -(dA * dA) / 6.) aR = (3. * Tc) - 2. * aL;
     const double a6 = 6. * Tc - 3. * (aR + aL);
     if (uhh >= 0.0) return uhh * (aR - 0.5 * CFL * ((aR - aL) - a6 * (1. - 2. / 3. * CFL)));
     return uhh * (aL + 0.5 * CFL * ((aR - aL) + a6 * (1. - 2. / 3. * CFL)));
   }
-  const size_t c = (uhh >= 0.0) ? f : f + st, c2 = (uhh >= 0.0) ? f2 : f2 + st;
-  const double slope = plm_slope(T, mC, c, c2, st);
-  if (uhh >= 0.0) return uhh * (T[c] + 0.5 * slope * (1. - CFL));
-  return uhh * (T[c] - 0.5 * slope * (1. - CFL));
+  const double slope = plm_slope3(Tm, Tc, Tp, mk[2] * mk[1]);
+  if (uhh >= 0.0) return uhh * (Tc + 0.5 * slope * (1. - CFL));
+  return uhh * (Tc - 0.5 * slope * (1. - CFL));
+}
+
+// The operands of face f gathered through pointers: T with stride stT (index f), the 2-D face mask with stride stM (f2).
+__device__ __forceinline__ double face_flux(int scheme, const double *T, const double *__restrict__ mC, size_t f, size_t f2,
+                                            int stT, int stM, double uhh, double CFL) {
+  const size_t up = (uhh >= 0.0) ? f : f + stT, up2 = (uhh >= 0.0) ? f2 : f2 + stM;
+  double T5[5], mk[4];
+  T5[1] = T[up - stT]; T5[2] = T[up]; T5[3] = T[up + stT];
+  mk[1] = mC[up2 - stM]; mk[2] = mC[up2];
+  if (scheme == ADVECT_PPM) {
+    T5[0] = T[up - 2 * stT]; T5[4] = T[up + 2 * stT];
+    mk[0] = mC[up2 - 2 * stM]; mk[3] = mC[up2 + stM];
+  } else { T5[0] = 0.; T5[4] = 0.; mk[0] = 0.; mk[3] = 0.; }
+  return face_flux5(scheme, T5, mk, uhh, CFL);
+}
+
+// The limited transport of a face and its CFL number :490-545 / :915-950 from the remaining transports of the face and
+// of its two neighbours, the (old) volumes and areas of its two cells.  Returns true if the transport was limited.
+__device__ __forceinline__ bool limited_transport(double ur, double ur_m, double ur_p, double hprev_m, double hprev_p, double area_m,
+                                                  double area_p, double min_h, double &uhh, double &CFL) {
+  const double tiny_h = DBL_MIN;
+  bool lim = false;
+  if ((ur == 0.0) || ((ur < 0.0) && (hprev_p <= tiny_h)) || ((ur > 0.0) && (hprev_m <= tiny_h))) {
+    uhh = 0.0; CFL = 0.0;
+  } else if (ur < 0.0) {
+    const double hup = hprev_p - area_p * min_h;
+    const double hlos = dmax(0.0, ur_p);
+    if ((((hup - hlos) + ur) < 0.0) && ((0.5 * hup + ur) < 0.0)) { uhh = dmin3(-0.5 * hup, -hup + hlos, 0.0); lim = true; }
+    else uhh = ur;
+    CFL = -uhh / hprev_p;
+  } else {
+    const double hup = hprev_m - area_m * min_h;
+    const double hlos = dmax(0.0, -ur_m);
+    if ((((hup - hlos) - ur) < 0.0) && ((0.5 * hup - ur) < 0.0)) { uhh = dmax3(0.5 * hup, hup - hlos, 0.0); lim = true; }
+    else uhh = ur;
+    CFL = uhh / hprev_m;
+  }
+  return lim;
+}
+
+// The update of one cell :668-711 / :1073-1125 from its old volume, the transports and tracer fluxes of its two faces.
+// Returns false if the cell keeps its tracers; otherwise T_new = (T * hlst - (F_p - F_m)) * Ihnew.
+template <int DIR>
+__device__ __forceinline__ bool cell_update(double uh_here, double uh_m, double hprev_old, double area, double h_neglect, double &hp,
+                                            double &hlst, double &Ihnew) {
+  hlst = hprev_old; Ihnew = 0.0;
+  hp = hlst - (uh_here - uh_m);
+  if (DIR == 1) hp = dmax(hp, 0.0);
+  bool do_i = true;
+  if (hp <= 0.0) do_i = false;
+  else if (hp < h_neglect * area) {
+    hlst = hlst + (h_neglect * area - hp);
+    Ihnew = 1.0 / (h_neglect * area);
+  } else Ihnew = 1.0 / hp;
+  return do_i && (DIR == 1 || Ihnew > 0.0);
 }
 
 // setup :170-206: remaining transports, reconstructed previous cell volume, flags.  The kernel covers the whole
@@ -161,30 +216,11 @@ k_ta_face(Dm d, const double *__restrict__ G, const double *__restrict__ uhr, co
   }
   const double *areaT = gm(G, d, MOM6X_G_areaT);
   const double *mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu);
-  const double tiny_h = DBL_MIN;
-  const double ur = uhr[f];
   double uhh, CFL;
-  if ((ur == 0.0) || ((ur < 0.0) && (hprev[f + st] <= tiny_h)) || ((ur > 0.0) && (hprev[f] <= tiny_h))) {
-    uhh = 0.0; CFL = 0.0;
-  } else if (ur < 0.0) {
-    const double hup = hprev[f + st] - areaT[f2 + st] * min_h;
-    const double hlos = dmax(0.0, uhr[f + st]);
-    if ((((hup - hlos) + ur) < 0.0) && ((0.5 * hup + ur) < 0.0)) {
-      uhh = dmin3(-0.5 * hup, -hup + hlos, 0.0);
-      lim[k * nrows + j + d.joff] = 1;
-    } else uhh = ur;
-    CFL = -uhh / (hprev[f + st]);
-  } else {
-    const double hup = hprev[f] - areaT[f2] * min_h;
-    const double hlos = dmax(0.0, -uhr[f - st]);
-    if ((((hup - hlos) - ur) < 0.0) && ((0.5 * hup - ur) < 0.0)) {
-      uhh = dmax3(0.5 * hup, hup - hlos, 0.0);
-      lim[k * nrows + j + d.joff] = 1;
-    } else uhh = ur;
-    CFL = uhh / (hprev[f]);
-  }
+  if (limited_transport(uhr[f], uhr[f - st], uhr[f + st], hprev[f], hprev[f + st], areaT[f2], areaT[f2 + st], min_h, uhh, CFL))
+    lim[k * nrows + j + d.joff] = 1;
   uhh_out[f] = uhh;
-  for (int m = 0; m < Tr.n; m++) F.f[m][f] = face_flux(Tr.scheme[m], Tr.t[m], mC, f, f2, st, uhh, CFL);
+  for (int m = 0; m < Tr.n; m++) F.f[m][f] = face_flux(Tr.scheme[m], Tr.t[m], mC, f, f2, st, st, uhh, CFL);
 }
 
 // uhr -= uhh and the cell updates :668-711 / :1073-1125.  Threads run over the faces (a0..a1, b0..b1); the
@@ -215,18 +251,241 @@ k_ta_cell(Dm d, const double *__restrict__ G, double *__restrict__ uhr, double *
   if (i < ci0 || j < cj0) return;            // the first face of the range has no cell of this range behind it
   const double uh_m = uhh[c - st];
   if ((uh_here != 0.0) || (uh_m != 0.0)) {
-    double hlst = hprev[c], Ihnew = 0.0;
-    double hp = hlst - (uh_here - uh_m);
-    if (DIR == 1) hp = dmax(hp, 0.0);
+    double hp, hlst, Ihnew;
+    const bool upd = cell_update<DIR>(uh_here, uh_m, hprev[c], areaT[c2], h_neglect, hp, hlst, Ihnew);
     hprev[c] = hp;
-    bool do_i = true;
-    if (hp <= 0.0) do_i = false;
-    else if (hp < h_neglect * areaT[c2]) {
-      hlst = hlst + (h_neglect * areaT[c2] - hp);
-      Ihnew = 1.0 / (h_neglect * areaT[c2]);
-    } else Ihnew = 1.0 / hp;
-    if (do_i && (DIR == 1 || Ihnew > 0.0)) {
+    if (upd) {
       for (int m = 0; m < Tr.n; m++) Tr.t[m][c] = (Tr.t[m][c] * hlst - (F.f[m][c] - F.f[m][c - st])) * Ihnew;
+    }
+  }
+}
+
+// ---- one kernel per direction and pass ---------------------------------------------------------------------------------
+// The face and the cell kernel above exchange uhh and one flux array per tracer through HBM ((2 + 2 ntr) array passes
+// per direction).  The kernels below keep them on chip.  All fluxes of a pass must be formed from the values BEFORE the
+// pass, and the update is in place, so a work item may only read what it alone will overwrite:
+//   x: a work-group owns TX consecutive cells of one (row, layer); everything it reads from outside them (3 tracer
+//      cells, 1 volume, up to 2 transports on either side) comes from a copy k_ta_save_x made before the pass;
+//   y: the stencil runs along j, so a thread marches along j over a segment of rows of ONE column with the old values
+//      it still needs in registers (no neighbours in i at all); what it needs from the rows beyond its segment comes
+//      from the copy of k_ta_save_y.
+constexpr int TX = 255;          // cells per work-group in x: 256 threads = 256 faces (the west face of the first cell + 255)
+constexpr int SEGY = 128;        // rows per marching thread in y
+struct SaveIdx {                 // layout of one saved boundary B (first own cell / row of the part behind it)
+  // per tracer m: cells B-3..B+2 at [6*m .. 6*m+5]; then hprev B-1, B; then the transports of faces B-2, B-1, B
+  __host__ __device__ static int nval(int ntr) { return 6 * ntr + 5; }
+  __host__ __device__ static int T(int m, int q) { return 6 * m + q; }          // q = 0..5 <-> cell B-3+q
+  __host__ __device__ static int H(int ntr, int q) { return 6 * ntr + q; }      // q = 0,1 <-> cell B-1+q
+  __host__ __device__ static int U(int ntr, int q) { return 6 * ntr + 2 + q; }  // q = 0..2 <-> face B-2+q
+};
+
+// x: boundaries nb = 0..ntile at the cells B = i0 + TX*nb (the last one at i1+1), rows b0..b1, all layers being worked on
+__global__ void __launch_bounds__(64)
+k_ta_save_x(Dm d, const double *__restrict__ uhr, const double *__restrict__ hprev, TrList Tr, const int *__restrict__ dmk,
+            double *__restrict__ save, int i0, int i1, int b0, int b1, int ntile) {
+  const int nb = blockIdx.x, j = b0 + blockIdx.y, k = blockIdx.z;
+  if (dmk[k] <= 0) return;
+  const int B = min(i0 + TX * nb, i1 + 1), nv = SaveIdx::nval(Tr.n);
+  const int v = threadIdx.x;
+  if (v >= nv) return;
+  double *out = save + (((size_t)k * (size_t)(b1 - b0 + 1) + (size_t)(j - b0)) * (size_t)(ntile + 1) + (size_t)nb) * (size_t)nv;
+  // (a scheme with a 2-point stencil never uses the outermost saved cells, which may lie beyond the row: clamp the address)
+  const int off = (v < 6 * Tr.n) ? (v % 6) - 3 : ((v < 6 * Tr.n + 2) ? (v - 6 * Tr.n) - 1 : (v - 6 * Tr.n - 2) - 2);
+  const int ci = min(max(B + off, -d.ioff), d.pitch - d.ioff - 1);
+  const size_t a = ix3(d, ci, j, k);
+  out[v] = (v < 6 * Tr.n) ? Tr.t[v / 6][a] : ((v < 6 * Tr.n + 2) ? hprev[a] : uhr[a]);
+}
+
+template <int MAXT>
+__global__ void __launch_bounds__(256)
+k_ta_x_tile(Dm d, const double *__restrict__ G, double *__restrict__ uhr, double *__restrict__ hprev, TrList Tr,
+            const int *__restrict__ dm, int *__restrict__ lim, const int *__restrict__ dmk, const double *__restrict__ save,
+            double min_h, double h_neglect, double H_subroundoff, int i0, int i1, int b0, int b1, int ntile) {
+  const int n = blockIdx.x, j = b0 + blockIdx.y, k = blockIdx.z;
+  if (dmk[k] <= 0) return;
+  const int nrows = d.nj + 2 * d.halo + 1;
+  if (!dm[k * nrows + j + d.joff]) return;          // a row that is not being worked on is not touched at all (:417)
+  const int C0 = i0 + TX * n, Cend = min(C0 + TX - 1, i1), ncell = Cend - C0 + 1;
+  const int t = threadIdx.x, ntr = Tr.n, nv = SaveIdx::nval(ntr);
+  __shared__ double sT[MAXT][TX + 7];               // cells C0-3 .. C0+TX+3  (position p <-> cell C0-3+p)
+  __shared__ double s_h[TX + 3];                    // cells C0-1 .. C0+TX+1
+  __shared__ double s_u[TX + 4];                    // faces C0-2 .. C0+TX+1
+  __shared__ double s_uhh[TX + 1];                  // faces C0-1 .. C0+TX-1
+  __shared__ double s_F[MAXT][TX + 1];
+  const double *svL = save + (((size_t)k * (size_t)(b1 - b0 + 1) + (size_t)(j - b0)) * (size_t)(ntile + 1) + (size_t)n) * (size_t)nv;
+  const double *svR = svL + nv;                     // the boundary at Cend+1
+  const size_t row = ix3(d, 0, j, k), row2 = ix2(d, 0, j);
+  // ---- everything this work-group reads, before it writes anything
+  for (int p = t; p < ncell + 6; p += 256) {        // tracer cells C0-3 .. Cend+3
+    const int ci = C0 - 3 + p;
+    for (int m = 0; m < ntr; m++) {
+      double val;
+      if (ci < C0) val = svL[SaveIdx::T(m, p)];
+      else if (ci > Cend) val = svR[SaveIdx::T(m, 3 + (ci - Cend - 1))];
+      else val = Tr.t[m][row + ci];
+      sT[m][p] = val;
+    }
+  }
+  for (int p = t; p < ncell + 2; p += 256) {        // volumes of the cells C0-1 .. Cend+1
+    const int ci = C0 - 1 + p;
+    s_h[p] = (ci < C0) ? svL[SaveIdx::H(ntr, 0)] : ((ci > Cend) ? svR[SaveIdx::H(ntr, 1)] : hprev[row + ci]);
+  }
+  for (int p = t; p < ncell + 3; p += 256) {        // transports of the faces C0-2 .. Cend+1
+    const int fi = C0 - 2 + p;
+    s_u[p] = (fi < C0) ? svL[SaveIdx::U(ntr, fi - (C0 - 2))] : ((fi > Cend) ? svR[SaveIdx::U(ntr, 2)] : uhr[row + fi]);
+  }
+  __syncthreads();
+  const double *areaT = gm(G, d, MOM6X_G_areaT), *mC = gm(G, d, MOM6X_G_mask2dCu);
+  // ---- faces C0-1 .. Cend: thread t <-> face C0-1+t
+  double uhh = 0.0;
+  if (t <= ncell) {
+    const int f = C0 - 1 + t;
+    const size_t f2 = row2 + f;
+    double CFL;
+    if (limited_transport(s_u[t + 1], s_u[t], s_u[t + 2], s_h[t], s_h[t + 1], areaT[f2], areaT[f2 + 1], min_h, uhh, CFL))
+      lim[k * nrows + j + d.joff] = 1;
+    s_uhh[t] = uhh;
+    for (int m = 0; m < ntr; m++) s_F[m][t] = face_flux(Tr.scheme[m], sT[m], mC, (size_t)(t + 2), f2, 1, 1, uhh, CFL);
+  }
+  __syncthreads();
+  // ---- the remaining transport of the faces this work-group owns (C0 .. Cend; the first one of the row also i0-1),
+  //      and the cells C0 .. Cend: thread t >= 1 <-> cell C0-1+t
+  if (t > ncell || (t == 0 && n > 0)) return;
+  const int c = C0 - 1 + t;
+  const size_t c2 = row2 + c;
+  {
+    double r = s_u[t + 1] - uhh;
+    const double neglect = H_subroundoff * dmin(areaT[c2], areaT[c2 + 1]);
+    if (fabs(r) < neglect) r = 0.0;
+    uhr[row + c] = r;
+  }
+  if (t == 0) return;
+  const double uh_m = s_uhh[t - 1];
+  if ((uhh != 0.0) || (uh_m != 0.0)) {
+    double hp, hlst, Ihnew;
+    const bool upd = cell_update<0>(uhh, uh_m, s_h[t], areaT[c2], h_neglect, hp, hlst, Ihnew);
+    hprev[row + c] = hp;
+    if (upd) for (int m = 0; m < ntr; m++) Tr.t[m][row + c] = (sT[m][t + 2] * hlst - (s_F[m][t] - s_F[m][t - 1])) * Ihnew;
+  }
+}
+
+// y: boundaries nb = 0..nseg at the rows B = j0 + SEGY*nb (the last one at j1+1), columns i0..i1
+__global__ void __launch_bounds__(256)
+k_ta_save_y(Dm d, const double *__restrict__ vhr, const double *__restrict__ hprev, TrList Tr, const int *__restrict__ dmk,
+            double *__restrict__ save, int i0, int i1, int j0, int j1, int nseg) {
+  const int i = I_BASE(i0) + blockIdx.x * 256 + threadIdx.x, nb = blockIdx.y, k = blockIdx.z;
+  if (i < i0 || i > i1 || dmk[k] <= 0) return;
+  const int B = min(j0 + SEGY * nb, j1 + 1), nv = SaveIdx::nval(Tr.n), st = d.pitch;
+  const size_t nx = (size_t)(i1 - i0 + 1);
+  // [k][nb][value][i]: coalesced along i
+  double *out = save + ((size_t)k * (size_t)(nseg + 1) + (size_t)nb) * (size_t)nv * nx + (size_t)(i - i0);
+  // (rows beyond the allocated ones are only ever asked for by stencils that do not use them: clamp the address)
+  auto at = [&](int r) -> size_t { return ix3(d, i, min(max(r, -d.halo), d.nj + d.halo), k); };
+  for (int m = 0; m < Tr.n; m++)
+    for (int q = 0; q < 6; q++) out[(size_t)SaveIdx::T(m, q) * nx] = Tr.t[m][at(B - 3 + q)];
+  for (int q = 0; q < 2; q++) out[(size_t)SaveIdx::H(Tr.n, q) * nx] = hprev[at(B - 1 + q)];
+  for (int q = 0; q < 3; q++) out[(size_t)SaveIdx::U(Tr.n, q) * nx] = vhr[at(B - 2 + q)];
+  (void)st;
+}
+
+template <int MAXT>
+__global__ void __launch_bounds__(256)
+k_ta_y_march(Dm d, const double *__restrict__ G, double *__restrict__ vhr, double *__restrict__ hprev, TrList Tr,
+             const int *__restrict__ dm, int *__restrict__ lim, const int *__restrict__ dmk, const double *__restrict__ save,
+             double min_h, double h_neglect, double H_subroundoff, int i0, int i1, int j0, int j1, int nseg) {
+  const int i = I_BASE(i0) + blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, k = blockIdx.z;
+  if (i < i0 || i > i1 || dmk[k] <= 0) return;
+  const int nrows = d.nj + 2 * d.halo + 1, st = d.pitch, ntr = Tr.n, nv = SaveIdx::nval(ntr);
+  const int R0 = j0 + SEGY * n, R1 = min(R0 + SEGY - 1, j1);
+  const size_t nx = (size_t)(i1 - i0 + 1);
+  const double *svL = save + ((size_t)k * (size_t)(nseg + 1) + (size_t)n) * (size_t)nv * nx + (size_t)(i - i0);
+  const double *svR = svL + (size_t)nv * nx;
+  const double *areaT = gm(G, d, MOM6X_G_areaT), *mC = gm(G, d, MOM6X_G_mask2dCv);
+  const size_t col = ix3(d, i, 0, k), col2 = ix2(d, i, 0);
+  auto row2 = [&](int r) -> size_t { return col2 + (size_t)((long)min(max(r, -d.halo), d.nj + d.halo) * st); };   // clamped 2-D address
+  // old values of row r of the column: own rows from the arrays, the others from the saved copy
+  auto oldT = [&](int m, int r) -> double {
+    if (r < R0) return svL[(size_t)SaveIdx::T(m, r - (R0 - 3)) * nx];
+    if (r > R1) return svR[(size_t)SaveIdx::T(m, 3 + (r - R1 - 1)) * nx];
+    return Tr.t[m][col + (size_t)((long)r * st)];
+  };
+  auto oldH = [&](int r) -> double {
+    if (r < R0) return svL[(size_t)SaveIdx::H(ntr, 0) * nx];
+    if (r > R1) return svR[(size_t)SaveIdx::H(ntr, 1) * nx];
+    return hprev[col + (size_t)((long)r * st)];
+  };
+  auto oldV = [&](int r) -> double {     // face r (north face of cell r)
+    if (r < R0) return svL[(size_t)SaveIdx::U(ntr, r - (R0 - 2)) * nx];
+    if (r > R1) return svR[(size_t)SaveIdx::U(ntr, 2) * nx];
+    return vhr[col + (size_t)((long)r * st)];
+  };
+  // windows for the face J between the cells J and J+1: Tw = T(J-2 .. J+3), mw = mask of the faces J-2 .. J+2
+  double Tw[MAXT][6], mw[5];
+  int J = R0 - 1;
+#pragma unroll
+  for (int m = 0; m < MAXT; m++)
+#pragma unroll
+    for (int q = 0; q < 6; q++) Tw[m][q] = (m < ntr) ? oldT(m, J - 2 + q) : 0.0;
+#pragma unroll
+  for (int q = 0; q < 5; q++) mw[q] = mC[row2(J - 2 + q)];
+  double h_m = oldH(J), h_p = oldH(J + 1);                       // volumes of the cells J, J+1
+  double v_m = oldV(J - 1), v_c = oldV(J), v_p = oldV(J + 1);    // transports of the faces J-1, J, J+1
+  double a_m = areaT[row2(J)], a_p = areaT[row2(J + 1)];
+  double uhh_prev = 0.0, F_prev[MAXT];
+#pragma unroll
+  for (int m = 0; m < MAXT; m++) F_prev[m] = 0.0;
+  for (; J <= R1; J++) {
+    // ---- face J from the old values
+    double uhh = 0.0, Fl[MAXT];
+#pragma unroll
+    for (int m = 0; m < MAXT; m++) Fl[m] = 0.0;
+    if (dm[k * nrows + J + d.joff]) {     // a row of faces that is not being worked on moves nothing (:1065-1067)
+      double CFL;
+      if (limited_transport(v_c, v_m, v_p, h_m, h_p, a_m, a_p, min_h, uhh, CFL)) lim[k * nrows + J + d.joff] = 1;
+      const bool pos = (uhh >= 0.0);
+      const double mk[4] = {pos ? mw[0] : mw[1], pos ? mw[1] : mw[2], pos ? mw[2] : mw[3], pos ? mw[3] : mw[4]};
+#pragma unroll
+      for (int m = 0; m < MAXT; m++) if (m < ntr) {
+        const double T5[5] = {pos ? Tw[m][0] : Tw[m][1], pos ? Tw[m][1] : Tw[m][2], pos ? Tw[m][2] : Tw[m][3],
+                              pos ? Tw[m][3] : Tw[m][4], pos ? Tw[m][4] : Tw[m][5]};
+        Fl[m] = face_flux5(Tr.scheme[m], T5, mk, uhh, CFL);
+      }
+    }
+    // ---- the face's remaining transport (every face, :1073-1076); the first face of a segment belongs to the segment before it
+    const size_t c = col + (size_t)((long)J * st);
+    if (J >= R0 || n == 0) {
+      double r = v_c - uhh;
+      const double neglect = H_subroundoff * dmin(a_m, a_p);
+      if (fabs(r) < neglect) r = 0.0;
+      vhr[c] = r;
+    }
+    // ---- cell J (between the faces J-1 and J)
+    if (J >= R0 && ((uhh != 0.0) || (uhh_prev != 0.0))) {
+      double hp, hlst, Ihnew;
+      const bool upd = cell_update<1>(uhh, uhh_prev, h_m, a_m, h_neglect, hp, hlst, Ihnew);
+      hprev[c] = hp;
+      if (upd) {
+#pragma unroll
+        for (int m = 0; m < MAXT; m++) if (m < ntr) Tr.t[m][c] = (Tw[m][2] * hlst - (Fl[m] - F_prev[m])) * Ihnew;
+      }
+    }
+    // ---- shift the windows to the face J+1
+    uhh_prev = uhh;
+#pragma unroll
+    for (int m = 0; m < MAXT; m++) F_prev[m] = Fl[m];
+    if (J < R1) {
+#pragma unroll
+      for (int m = 0; m < MAXT; m++) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) Tw[m][q] = Tw[m][q + 1];
+        Tw[m][5] = (m < ntr) ? oldT(m, J + 4) : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) mw[q] = mw[q + 1];
+      mw[4] = mC[row2(J + 3)];
+      h_m = h_p; h_p = oldH(J + 2);
+      v_m = v_c; v_c = v_p; v_p = oldV(J + 2);
+      a_m = a_p; a_p = areaT[row2(J + 2)];
     }
   }
 }
@@ -288,6 +547,7 @@ void ta_state_free(mom6x_ctx *c) {
   (void)hipFree(s->hprev); (void)hipFree(s->uhr); (void)hipFree(s->vhr); (void)hipFree(s->uhh);
   for (int m = 0; m < MAXTR; m++) (void)hipFree(s->flux[m]);
   (void)hipFree(s->dmu); (void)hipFree(s->dmv); (void)hipFree(s->limu); (void)hipFree(s->limv); (void)hipFree(s->dmk);
+  (void)hipFree(s->save);
   delete s;
   c->ta = nullptr;
 }
@@ -342,9 +602,12 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
     if (sl > stencil) stencil = sl;
   }
   REQUIRE(w >= stencil, MOM6X_EINVAL, "MOM_tracer_advect: stencil is wider than the halo.");
+  // MOM6X_TRACER=legacy: the two-kernel passes that exchange uhh and the tracer fluxes through HBM
+  const char *env = getenv("MOM6X_TRACER");
+  const bool legacy = (env && !strcmp(env, "legacy"));
   FluxList F;
   for (int m = 0; m < MAXTR; m++) F.f[m] = nullptr;
-  for (int m = 0; m < ntr; m++) {
+  for (int m = 0; legacy && m < ntr; m++) {
     if (!s->flux[m]) { HIPCHK(hipMalloc(&s->flux[m], n3 * sizeof(double))); HIPCHK(hipMemsetAsync(s->flux[m], 0, n3 * sizeof(double), st)); }
     F.f[m] = s->flux[m];
   }
@@ -355,13 +618,49 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
   const dim3 b = blk2();
   const double min_h = 0.1 * c->GV.Angstrom_H, h_neglect = c->GV.H_subroundoff;
 
-  HIPCHK(hipMemsetAsync(s->uhh, 0, n3 * sizeof(double), st));
+  if (legacy) HIPCHK(hipMemsetAsync(s->uhh, 0, n3 * sizeof(double), st));
   for (int *p : { s->dmu, s->dmv, s->limu, s->limv }) HIPCHK(hipMemsetAsync(p, 0, nf * sizeof(int), st));
   std::vector<int> ones(nz, 1), dmk_h(nz, 1);
   HIPCHK(hipMemcpyAsync(s->dmk, ones.data(), nz * sizeof(int), hipMemcpyHostToDevice, st));
   KLAUNCH(c, "k_ta_init", k_ta_init, grid3(d.pitch, d.slab / d.pitch, nz, b), b, d, c->G, h_end, uhtr, vhtr, s->hprev, s->uhr, s->vhr);
 
+  int rc_tile = MOM6X_OK;
+  auto need_save = [&](size_t n) -> int {
+    if (s->save_cap < n) {
+      if (s->save) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(s->save)); s->save = nullptr; s->save_cap = 0; }
+      HIPCHK(hipMalloc(&s->save, n * sizeof(double)));
+      s->save_cap = n;
+    }
+    return MOM6X_OK;
+  };
+  // one kernel per direction and pass (+ the copy of the old values beyond the tile / segment boundaries)
+  auto advect_tiled = [&](int dir, int i0, int i1, int j0, int j1) -> int {
+    const int nv = SaveIdx::nval(ntr);
+    if (dir == 0) {
+      const int ntile = (i1 - i0 + TX) / TX, nrw = j1 - j0 + 1;
+      int rc = need_save((size_t)nz * nrw * (ntile + 1) * nv); if (rc) return rc;
+      KLAUNCH(c, "k_ta_save_x", k_ta_save_x, dim3(ntile + 1, nrw, nz), dim3(64), d, (const double *)s->uhr, (const double *)s->hprev, Tr,
+              (const int *)s->dmk, s->save, i0, i1, j0, j1, ntile);
+#define XT(M) KLAUNCH(c, "k_ta_x_tile", k_ta_x_tile<M>, dim3(ntile, nrw, nz), dim3(256), d, c->G, s->uhr, s->hprev, Tr, (const int *)s->dmu, \
+                      s->limu, (const int *)s->dmk, (const double *)s->save, min_h, h_neglect, c->GV.H_subroundoff, i0, i1, j0, j1, ntile)
+      if (ntr <= 2) XT(2); else if (ntr <= 4) XT(4); else XT(8);
+#undef XT
+      KLAUNCH(c, "k_ta_flag_commit", k_ta_flag_commit, dim3((j1 - j0 + 64) / 64, nz), dim3(64), d, s->dmu, s->limu, (const int *)s->dmk, j0, j1);
+    } else {
+      const int nseg = (j1 - j0 + SEGY) / SEGY, nx = i1 - i0 + 1, gx = (nxa(nx, i0) + 255) / 256;
+      int rc = need_save((size_t)nz * (nseg + 1) * nv * nx); if (rc) return rc;
+      KLAUNCH(c, "k_ta_save_y", k_ta_save_y, dim3(gx, nseg + 1, nz), dim3(256), d, (const double *)s->vhr, (const double *)s->hprev, Tr,
+              (const int *)s->dmk, s->save, i0, i1, j0, j1, nseg);
+#define YM(M) KLAUNCH(c, "k_ta_y_march", k_ta_y_march<M>, dim3(gx, nseg, nz), dim3(256), d, c->G, s->vhr, s->hprev, Tr, (const int *)s->dmv, \
+                      s->limv, (const int *)s->dmk, (const double *)s->save, min_h, h_neglect, c->GV.H_subroundoff, i0, i1, j0, j1, nseg)
+      if (ntr <= 1) YM(1); else if (ntr <= 2) YM(2); else if (ntr <= 4) YM(4); else YM(8);
+#undef YM
+      KLAUNCH(c, "k_ta_flag_commit", k_ta_flag_commit, dim3((j1 - (j0 - 1) + 64) / 64, nz), dim3(64), d, s->dmv, s->limv, (const int *)s->dmk, j0 - 1, j1);
+    }
+    return MOM6X_OK;
+  };
   auto advect = [&](int dir, int i0, int i1, int j0, int j1) {
+    if (!legacy) { const int rc = advect_tiled(dir, i0, i1, j0, j1); if (rc && !rc_tile) rc_tile = rc; return; }
     // faces: x: (i0-1..i1, j0..j1); y: (i0..i1, j0-1..j1)
     const int a0 = dir ? i0 : i0 - 1, b0 = dir ? j0 - 1 : j0;
     const dim3 g = grid3(nxa(i1 - a0 + 1, a0), j1 - b0 + 1, nz, b);
@@ -421,6 +720,7 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
       if (do_any == 0) break;
     }
   }
+  if (rc_tile) return rc_tile;
   if (iters_out) *iters_out = itt;
   if (uhr_out) HIPCHK(hipMemcpyAsync(uhr_out, s->uhr, n3 * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (vhr_out) HIPCHK(hipMemcpyAsync(vhr_out, s->vhr, n3 * sizeof(double), hipMemcpyDeviceToDevice, st));

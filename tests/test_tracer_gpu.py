@@ -9,6 +9,14 @@ pytestmark = pytest.mark.gpu
 G = abi.G
 
 
+@pytest.fixture(autouse=True, params=["tiled", "legacy"])
+def tracer_path(request, monkeypatch):
+    """Every case runs on both device paths: one kernel per direction and pass (x: LDS tiles, y: a march along j with a
+    register window; the default) and the face + cell kernel pairs (MOM6X_TRACER=legacy).  Both must equal the oracle."""
+    monkeypatch.setenv("MOM6X_TRACER", request.param)
+    return request.param
+
+
 def transports(orc, d, M, GV, dt, scale, post=1.0):
     """Accumulated transports uhtr, vhtr consistent with a thickness change (one continuity step), scaled up so
     that some fluxes must be limited and several iterations are needed."""
@@ -23,12 +31,14 @@ def transports(orc, d, M, GV, dt, scale, post=1.0):
     return hn, np.ascontiguousarray(uh * dt * post), np.ascontiguousarray(vh * dt * post)
 
 
-@pytest.mark.parametrize("cfg", ["double_gyre", "channel", "benchmark_small"])
+@pytest.mark.parametrize("cfg", ["double_gyre", "channel", "benchmark_small", "wide"])
 @pytest.mark.parametrize("schemes,first,post", [([0, 0], 0, 1.0), ([1, 1, 2], 0, 60.0), ([2, 0, 1], 1, 60.0), ([1], 1, 1.0), ([0], 0, 60.0)])
 def test_advect_tracer(orc, cfg, schemes, first, post):
     import torch
     from mom6_amd.dycore import Dycore
-    gg, d, M = getattr(H, cfg)()
+    # "wide": 600 x 300 cells, i.e. three 255-cell tiles along i and three 128-row segments along j on the tiled path, whose
+    # boundaries the limiter and the 5-point stencils reach across; re-entrant in x
+    gg, d, M = H.channel(nk=2, ni=600, nj=300) if cfg == "wide" else getattr(H, cfg)()
     GV = abi.vgrid_default()
     dt_dyn, dt = 900.0, 3600.0
     h_end, uhtr, vhtr = transports(orc, d, M, GV, dt, scale=3.0, post=post)
