@@ -8,8 +8,9 @@
 // upwind cell non-empty, until nothing remains.  The reference's row flags domore_u(j,k)/domore_v(J,k) and
 // layer flags domore_k(k) decide which rows are touched at all, so they are kept (int arrays in HBM) and the
 // exit test reads domore_k back once per halo cycle -- the same global synchronisation point as the
-// reference's sum_across_PEs (:331).  Per direction and pass there are two kernels, because all fluxes of a
-// pass must be formed from the un-updated hprev/uhr/tracer values:
+// reference's sum_across_PEs (:331).  All fluxes of a pass must be formed from the un-updated hprev/uhr/tracer
+// values.  Default: one kernel per direction and pass that reads everything it needs before it writes (k_ta_x_tile,
+// k_ta_y_march, see there).  MOM6X_TRACER=legacy: two kernels per direction and pass,
 //   k_ta_face<DIR>: limited transport uhh and the tracer fluxes of every face   -> scratch
 //   k_ta_cell<DIR>: uhr -= uhh ; hprev and every tracer updated from the face fluxes
 #include <cfloat>
