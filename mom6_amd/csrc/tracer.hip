@@ -270,7 +270,8 @@ k_ta_cell(Dm d, const double *__restrict__ G, double *__restrict__ uhr, double *
 //   y: the stencil runs along j, so a thread marches along j over a segment of rows of ONE column with the old values
 //      it still needs in registers (no neighbours in i at all); what it needs from the rows beyond its segment comes
 //      from the copy of k_ta_save_y.
-constexpr int TX = 255;          // cells per work-group in x: 256 threads = 256 faces (the west face of the first cell + 255)
+constexpr int TX = 240;          // cells per work-group in x (15 x 128 B: the tiles start on cache lines); thread t < TX <-> cell C0+t and its
+                                 // east face, thread TX <-> the west face of the first cell, the other 15 threads only help loading
 constexpr int SEGY = 128;        // rows per marching thread in y
 struct SaveIdx {                 // layout of one saved boundary B (first own cell / row of the part behind it)
   // per tracer m: cells B-3..B+2 at [6*m .. 6*m+5]; then hprev B-1, B; then the transports of faces B-2, B-1, B
@@ -308,65 +309,74 @@ k_ta_x_tile(Dm d, const double *__restrict__ G, double *__restrict__ uhr, double
   if (!dm[k * nrows + j + d.joff]) return;          // a row that is not being worked on is not touched at all (:417)
   const int C0 = i0 + TX * n, Cend = min(C0 + TX - 1, i1), ncell = Cend - C0 + 1;
   const int t = threadIdx.x, ntr = Tr.n, nv = SaveIdx::nval(ntr);
-  __shared__ double sT[MAXT][TX + 7];               // cells C0-3 .. C0+TX+3  (position p <-> cell C0-3+p)
-  __shared__ double s_h[TX + 3];                    // cells C0-1 .. C0+TX+1
-  __shared__ double s_u[TX + 4];                    // faces C0-2 .. C0+TX+1
+  __shared__ double sT[MAXT][TX + 6];               // cells C0-3 .. C0+TX+2  (position p <-> cell C0-3+p)
+  __shared__ double s_h[TX + 2];                    // cells C0-1 .. C0+TX
+  __shared__ double s_u[TX + 3];                    // faces C0-2 .. C0+TX
   __shared__ double s_uhh[TX + 1];                  // faces C0-1 .. C0+TX-1
   __shared__ double s_F[MAXT][TX + 1];
   const double *svL = save + (((size_t)k * (size_t)(b1 - b0 + 1) + (size_t)(j - b0)) * (size_t)(ntile + 1) + (size_t)n) * (size_t)nv;
   const double *svR = svL + nv;                     // the boundary at Cend+1
   const size_t row = ix3(d, 0, j, k), row2 = ix2(d, 0, j);
-  // ---- everything this work-group reads, before it writes anything
-  for (int p = t; p < ncell + 6; p += 256) {        // tracer cells C0-3 .. Cend+3
-    const int ci = C0 - 3 + p;
-    for (int m = 0; m < ntr; m++) {
-      double val;
-      if (ci < C0) val = svL[SaveIdx::T(m, p)];
-      else if (ci > Cend) val = svR[SaveIdx::T(m, 3 + (ci - Cend - 1))];
-      else val = Tr.t[m][row + ci];
-      sT[m][p] = val;
-    }
+  // ---- everything this work-group reads, before it writes anything: thread t < ncell its own cell (whole cache lines per
+  //      wavefront), eleven of the other threads the saved values beyond the two ends of the tile
+  if (t < ncell) {
+    const size_t a = row + C0 + t;
+    for (int m = 0; m < ntr; m++) sT[m][t + 3] = Tr.t[m][a];
+    s_h[t + 1] = hprev[a];
+    s_u[t + 2] = uhr[a];
+  } else {
+    const int e = t - ncell;
+    if (e < 3) { for (int m = 0; m < ntr; m++) sT[m][e] = svL[SaveIdx::T(m, e)]; }                       // cells C0-3 .. C0-1
+    else if (e < 6) { for (int m = 0; m < ntr; m++) sT[m][ncell + e] = svR[SaveIdx::T(m, e)]; }         // cells Cend+1 .. Cend+3
+    else if (e == 6) s_h[0] = svL[SaveIdx::H(ntr, 0)];                                                  // cell C0-1
+    else if (e == 7) s_h[ncell + 1] = svR[SaveIdx::H(ntr, 1)];                                          // cell Cend+1
+    else if (e < 10) s_u[e - 8] = svL[SaveIdx::U(ntr, e - 8)];                                          // faces C0-2, C0-1
+    else if (e == 10) s_u[ncell + 2] = svR[SaveIdx::U(ntr, 2)];                                         // face Cend+1
   }
-  for (int p = t; p < ncell + 2; p += 256) {        // volumes of the cells C0-1 .. Cend+1
-    const int ci = C0 - 1 + p;
-    s_h[p] = (ci < C0) ? svL[SaveIdx::H(ntr, 0)] : ((ci > Cend) ? svR[SaveIdx::H(ntr, 1)] : hprev[row + ci]);
-  }
-  for (int p = t; p < ncell + 3; p += 256) {        // transports of the faces C0-2 .. Cend+1
-    const int fi = C0 - 2 + p;
-    s_u[p] = (fi < C0) ? svL[SaveIdx::U(ntr, fi - (C0 - 2))] : ((fi > Cend) ? svR[SaveIdx::U(ntr, 2)] : uhr[row + fi]);
+  // the 2-D operands of this thread's face do not depend on the tile's data: issue their loads before the barrier
+  const double *areaT = gm(G, d, MOM6X_G_areaT), *mC = gm(G, d, MOM6X_G_mask2dCu);
+  const int q = (t < ncell) ? t + 1 : 0;            // this thread's face slot (slot q of the face arrays <-> face C0-1+q)
+  const size_t f2 = row2 + (C0 - 1 + q);
+  double mw[5] = {0., 0., 0., 0., 0.}, a_m = 0.0, a_p = 0.0;
+  if (t <= ncell) {
+#pragma unroll
+    for (int e = 0; e < 5; e++) mw[e] = mC[f2 - 2 + e];                  // masks of the faces f-2 .. f+2
+    a_m = areaT[f2]; a_p = areaT[f2 + 1];
   }
   __syncthreads();
-  const double *areaT = gm(G, d, MOM6X_G_areaT), *mC = gm(G, d, MOM6X_G_mask2dCu);
-  // ---- faces C0-1 .. Cend: thread t <-> face C0-1+t
+  // ---- faces C0-1 .. Cend: thread t < ncell <-> the east face C0+t of its cell, thread ncell <-> the face C0-1
   double uhh = 0.0;
   if (t <= ncell) {
-    const int f = C0 - 1 + t;
-    const size_t f2 = row2 + f;
     double CFL;
-    if (limited_transport(s_u[t + 1], s_u[t], s_u[t + 2], s_h[t], s_h[t + 1], areaT[f2], areaT[f2 + 1], min_h, uhh, CFL))
+    if (limited_transport(s_u[q + 1], s_u[q], s_u[q + 2], s_h[q], s_h[q + 1], a_m, a_p, min_h, uhh, CFL))
       lim[k * nrows + j + d.joff] = 1;
-    s_uhh[t] = uhh;
-    for (int m = 0; m < ntr; m++) s_F[m][t] = face_flux(Tr.scheme[m], sT[m], mC, (size_t)(t + 2), f2, 1, 1, uhh, CFL);
+    s_uhh[q] = uhh;
+    const bool pos = (uhh >= 0.0);
+    const double mk[4] = {pos ? mw[0] : mw[1], pos ? mw[1] : mw[2], pos ? mw[2] : mw[3], pos ? mw[3] : mw[4]};
+    for (int m = 0; m < ntr; m++) {
+      const double *Tq = &sT[m][pos ? q : q + 1];                         // the upwind cell is at position q+2 (pos) or q+3
+      const double T5[5] = {Tq[0], Tq[1], Tq[2], Tq[3], Tq[4]};
+      s_F[m][q] = face_flux5(Tr.scheme[m], T5, mk, uhh, CFL);
+    }
   }
   __syncthreads();
-  // ---- the remaining transport of the faces this work-group owns (C0 .. Cend; the first one of the row also i0-1),
-  //      and the cells C0 .. Cend: thread t >= 1 <-> cell C0-1+t
-  if (t > ncell || (t == 0 && n > 0)) return;
-  const int c = C0 - 1 + t;
-  const size_t c2 = row2 + c;
+  // ---- the remaining transport of the faces this work-group owns (C0 .. Cend; in the first tile of a row also i0-1),
+  //      and the cells C0 .. Cend
+  if (t > ncell || (t == ncell && n > 0)) return;
+  const int c = C0 - 1 + q;
   {
-    double r = s_u[t + 1] - uhh;
-    const double neglect = H_subroundoff * dmin(areaT[c2], areaT[c2 + 1]);
+    double r = s_u[q + 1] - uhh;
+    const double neglect = H_subroundoff * dmin(a_m, a_p);
     if (fabs(r) < neglect) r = 0.0;
     uhr[row + c] = r;
   }
-  if (t == 0) return;
-  const double uh_m = s_uhh[t - 1];
+  if (t == ncell) return;
+  const double uh_m = s_uhh[q - 1];
   if ((uhh != 0.0) || (uh_m != 0.0)) {
     double hp, hlst, Ihnew;
-    const bool upd = cell_update<0>(uhh, uh_m, s_h[t], areaT[c2], h_neglect, hp, hlst, Ihnew);
+    const bool upd = cell_update<0>(uhh, uh_m, s_h[q], a_m, h_neglect, hp, hlst, Ihnew);
     hprev[row + c] = hp;
-    if (upd) for (int m = 0; m < ntr; m++) Tr.t[m][row + c] = (sT[m][t + 2] * hlst - (s_F[m][t] - s_F[m][t - 1])) * Ihnew;
+    if (upd) for (int m = 0; m < ntr; m++) Tr.t[m][row + c] = (sT[m][q + 2] * hlst - (s_F[m][q] - s_F[m][q - 1])) * Ihnew;
   }
 }
 
@@ -563,7 +573,7 @@ extern "C" int mom6x_tracer_advect_init(mom6x_ctx *c, double dt_dyn, int default
     memset(s, 0, sizeof(*s));
     const size_t n3 = (size_t)c->dims.slab * c->dims.nk;
     const size_t nf = (size_t)(c->dims.nj + 2 * c->dims.halo + 1) * c->dims.nk;
-    double **p3[] = { &s->hprev, &s->uhr, &s->vhr, &s->uhh };
+    double **p3[] = { &s->hprev, &s->uhr, &s->vhr };   // (uhh and the flux arrays belong to the legacy path: allocated on its first use)
     for (double **q : p3) { HIPCHK(hipMalloc(q, n3 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, 0, n3 * sizeof(double), c->stream)); }
     int **pf[] = { &s->dmu, &s->dmv, &s->limu, &s->limv };
     for (int **q : pf) { HIPCHK(hipMalloc(q, nf * sizeof(int))); HIPCHK(hipMemsetAsync(*q, 0, nf * sizeof(int), c->stream)); }
@@ -619,7 +629,10 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
   const dim3 b = blk2();
   const double min_h = 0.1 * c->GV.Angstrom_H, h_neglect = c->GV.H_subroundoff;
 
-  if (legacy) HIPCHK(hipMemsetAsync(s->uhh, 0, n3 * sizeof(double), st));
+  if (legacy) {
+    if (!s->uhh) HIPCHK(hipMalloc(&s->uhh, n3 * sizeof(double)));
+    HIPCHK(hipMemsetAsync(s->uhh, 0, n3 * sizeof(double), st));
+  }
   for (int *p : { s->dmu, s->dmv, s->limu, s->limv }) HIPCHK(hipMemsetAsync(p, 0, nf * sizeof(int), st));
   std::vector<int> ones(nz, 1), dmk_h(nz, 1);
   HIPCHK(hipMemcpyAsync(s->dmk, ones.data(), nz * sizeof(int), hipMemcpyHostToDevice, st));
