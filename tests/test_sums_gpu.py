@@ -119,3 +119,28 @@ def test_field_chksum_matches_oracle(orc):
         assert dyc.field_chksum(ad, *r, unscale=un) == orc.field_chksum(d, a, *r, unscale=un)
     assert dyc.field_chksum(ad[3]) == orc.field_chksum(d, a[3], 0, d.ni - 1, 0, d.nj - 1)
     dyc.close()
+
+
+def test_reproducing_sum_is_layout_invariant(orc):
+    """The reference's test.layout property for the sums: the field cut into the tiles of a 2 x 2 layout, each tile summed
+    by its own context (only_on_PE), the integers added as sum_across_PEs adds them -- the result is the one-tile sum, bit
+    for bit, for every layer."""
+    from mom6_amd.dycore import Dycore
+    from mom6_amd import sum_output as SO
+    gg, d, M = H.benchmark_small(nk=3)
+    a = wide_range_field(d, 3, 21)
+    dyc = Dycore(d, M, abi.vgrid_default())
+    whole = dyc.reproducing_sum(dyc.to_dev(a), layer_sums=True)
+    dyc.close()
+    tot = np.zeros((3, 6), dtype=object)
+    for pe in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        dt_, Mt = gg.tile(3, 4, (2, 2), pe)
+        loc = np.zeros((3,) + tuple(dt_.shape2()))
+        gl = d.sl(dt_.i_glob0, dt_.i_glob0 + dt_.ni - 1, dt_.j_glob0, dt_.j_glob0 + dt_.nj - 1)
+        loc[(Ellipsis,) + tuple(dt_.sl(0, dt_.ni - 1, 0, dt_.nj - 1))] = a[(Ellipsis,) + tuple(gl)]
+        dy = Dycore(dt_, Mt, abi.vgrid_default())
+        r = dy.reproducing_sum(dy.to_dev(loc), layer_sums=True, only_on_PE=True)
+        tot = tot + np.array([[int(x) for x in row] for row in r["EFP_lay"]], dtype=object)
+        dy.close()
+    for k in range(3):
+        assert SO.EFP_to_real(list(tot[k])) == whole["sums"][k]
