@@ -17,6 +17,11 @@
 // bundled librccl under Python; the host's own under Fortran) so that only one RCCL exists per process.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <mutex>
+#include <string>
 #include <vector>
 #include "mom6x_dev.h"
 
@@ -160,8 +165,130 @@ struct NcclApi {
 
 static NcclApi g_nccl = {};
 
+// ---- MOM6X_COMM=threads: the same API among host THREADS of one process (one tile per thread, all on the same GPU).
+// A single-GPU box cannot host two RCCL ranks, yet the multi-tile logic -- which rows and columns every kernel covers,
+// the wide-halo cycles of the barotropic solver, the global reductions -- is independent of the transport.  This backend
+// lets the tests run a 2 x 1 or 2 x 2 layout on one device and compare it with the one-tile run (the reference's
+// test.layout).  Every operation synchronises the calling tile's stream and meets the other tiles at host barriers;
+// it is slow and only meant for tests.
+namespace tcomm {
+struct Op { const void *src; void *dst; size_t bytes; int peer; bool send; };
+struct Hub {
+  std::mutex mu; std::condition_variable cv;
+  int nranks = 0, arrived = 0; long gen = 0, joined = 0;
+  std::vector<std::vector<Op>> posted;            // sends of the current group, by sending rank
+  std::vector<std::vector<char>> red;             // all-reduce contributions, by rank
+  bool barrier(std::unique_lock<std::mutex> &lk) {   // all ranks, reusable; false after 120 s (a tile has failed)
+    const long g = gen;
+    if (++arrived == nranks) { arrived = 0; gen++; cv.notify_all(); return true; }
+    return cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g; });
+  }
+};
+struct TC { Hub *hub; int rank; };
+static std::mutex g_mu;
+static std::map<std::string, Hub *> g_hubs;
+static int g_ids = 0;
+static thread_local std::vector<Op> t_ops;
+static thread_local TC *t_comm = nullptr;
+static thread_local hipStream_t t_stream = nullptr;
+static thread_local int t_depth = 0;
+
+static ncclResult_t GetUniqueId(ncclUniqueId *id) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  memset(id, 0, sizeof(*id));
+  snprintf(id->internal, sizeof(id->internal), "mom6x-threads-%d", ++g_ids);
+  return ncclSuccess;
+}
+static ncclResult_t CommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank) {
+  Hub *h;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Hub *&slot = g_hubs[std::string(id.internal)];
+    if (!slot) { slot = new Hub(); slot->nranks = nranks; slot->posted.resize(nranks); slot->red.resize(nranks); }
+    h = slot;
+  }
+  if (h->nranks != nranks || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+  *comm = (ncclComm_t) new TC{h, rank};
+  std::unique_lock<std::mutex> lk(h->mu);
+  return h->barrier(lk) ? ncclSuccess : ncclSystemError;
+}
+static ncclResult_t CommDestroy(ncclComm_t comm) { delete (TC *)comm; return ncclSuccess; }
+static size_t type_size(ncclDataType_t t) { return (t == ncclInt || t == ncclFloat) ? 4 : 8; }
+static ncclResult_t run_group() {
+  TC *c = t_comm; Hub *h = c->hub;
+  if (hipStreamSynchronize(t_stream) != hipSuccess) return ncclUnhandledCudaError;   // my packed messages are complete
+  std::unique_lock<std::mutex> lk(h->mu);
+  h->posted[c->rank].clear();
+  for (const Op &o : t_ops) if (o.send) h->posted[c->rank].push_back(o);
+  if (!h->barrier(lk)) return ncclSystemError;
+  std::vector<size_t> used(h->nranks, 0);
+  std::vector<Op> copies;
+  for (const Op &o : t_ops) {
+    if (o.send) continue;
+    const std::vector<Op> &ps = h->posted[o.peer];       // the j-th receive from a peer takes its j-th send to me
+    size_t &u = used[o.peer];
+    while (u < ps.size() && ps[u].peer != c->rank) u++;
+    if (u >= ps.size() || ps[u].bytes != o.bytes) return ncclInvalidUsage;
+    copies.push_back(Op{ps[u].src, o.dst, o.bytes, o.peer, false});
+    u++;
+  }
+  lk.unlock();
+  for (const Op &o : copies) if (hipMemcpy(o.dst, o.src, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) return ncclUnhandledCudaError;
+  lk.lock();
+  const bool ok = h->barrier(lk);                         // nobody reuses a send buffer before everybody has copied
+  t_ops.clear();
+  return ok ? ncclSuccess : ncclSystemError;
+}
+static ncclResult_t GroupStart() { t_depth++; return ncclSuccess; }
+static ncclResult_t GroupEnd() { if (--t_depth > 0 || t_ops.empty()) return ncclSuccess; return run_group(); }
+static ncclResult_t Send(const void *buf, size_t n, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) {
+  t_comm = (TC *)comm; t_stream = st;
+  t_ops.push_back(Op{buf, nullptr, n * type_size(t), peer, true});
+  return (t_depth > 0) ? ncclSuccess : run_group();
+}
+static ncclResult_t Recv(void *buf, size_t n, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) {
+  t_comm = (TC *)comm; t_stream = st;
+  t_ops.push_back(Op{nullptr, buf, n * type_size(t), peer, false});
+  return (t_depth > 0) ? ncclSuccess : run_group();
+}
+template <class T> static void reduce_into(T *acc, const T *x, size_t n, ncclRedOp_t op) {
+  for (size_t i = 0; i < n; i++) acc[i] = (op == ncclSum) ? acc[i] + x[i] : ((op == ncclMin) ? (x[i] < acc[i] ? x[i] : acc[i]) : (x[i] > acc[i] ? x[i] : acc[i]));
+}
+static ncclResult_t AllReduce(const void *send, void *recv, size_t n, ncclDataType_t t, ncclRedOp_t op, ncclComm_t comm, hipStream_t st) {
+  TC *c = (TC *)comm; Hub *h = c->hub;
+  const size_t bytes = n * type_size(t);
+  std::vector<char> mine(bytes);
+  if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
+  if (hipMemcpy(mine.data(), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+  std::unique_lock<std::mutex> lk(h->mu);
+  h->red[c->rank] = mine;
+  if (!h->barrier(lk)) return ncclSystemError;
+  std::vector<char> acc = h->red[0];                      // rank order: every tile forms the same result
+  for (int r = 1; r < h->nranks; r++) {
+    if (h->red[r].size() != bytes) return ncclInvalidUsage;
+    if (t == ncclDouble) reduce_into((double *)acc.data(), (const double *)h->red[r].data(), n, op);
+    else if (t == ncclInt64) reduce_into((long long *)acc.data(), (const long long *)h->red[r].data(), n, op);
+    else if (t == ncclInt) reduce_into((int *)acc.data(), (const int *)h->red[r].data(), n, op);
+    else return ncclInvalidArgument;
+  }
+  const bool ok = h->barrier(lk);                         // everybody has read the contributions
+  lk.unlock();
+  if (!ok) return ncclSystemError;
+  return (hipMemcpy(recv, acc.data(), bytes, hipMemcpyHostToDevice) == hipSuccess) ? ncclSuccess : ncclUnhandledCudaError;
+}
+static const char *GetErrorString(ncclResult_t) { return "the threads backend (MOM6X_COMM=threads) failed or timed out"; }
+}  // namespace tcomm
+
 static int nccl_load() {
   if (g_nccl.ok) return MOM6X_OK;
+  const char *be = getenv("MOM6X_COMM");
+  if (be && !strcmp(be, "threads")) {
+    g_nccl.GetUniqueId = tcomm::GetUniqueId; g_nccl.CommInitRank = tcomm::CommInitRank; g_nccl.CommDestroy = tcomm::CommDestroy;
+    g_nccl.Send = tcomm::Send; g_nccl.Recv = tcomm::Recv; g_nccl.GroupStart = tcomm::GroupStart; g_nccl.GroupEnd = tcomm::GroupEnd;
+    g_nccl.AllReduce = tcomm::AllReduce; g_nccl.GetErrorString = tcomm::GetErrorString;
+    g_nccl.ok = true;
+    return MOM6X_OK;
+  }
   void *h = RTLD_DEFAULT;
   if (!dlsym(h, "ncclSend")) {   // no RCCL in the process yet: load the system one
     h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);

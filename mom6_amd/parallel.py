@@ -34,14 +34,25 @@ def region(lib, dims, stagger, d, send):
     return i0.value, i1.value, j0.value, j1.value
 
 
-def attach_comm(dyc, layout, pe, dist=None, force_nccl_self=False):
-    """Give `dyc` its place in the LAYOUT and (if more than one rank, or in test mode) an RCCL communicator."""
+def unique_id(lib):
+    """A communicator id (mom6x_comm_unique_id) as 128 bytes, to be handed to every rank's attach_comm(unique_id=...)."""
+    buf = C.create_string_buffer(128)
+    abi.check(lib, lib.mom6x_comm_unique_id(buf))
+    return buf.raw
+
+
+def attach_comm(dyc, layout, pe, dist=None, force_nccl_self=False, unique_id=None):
+    """Give `dyc` its place in the LAYOUT and (if more than one rank, or in test mode) an RCCL communicator.  The
+    communicator id is made on rank 0 and broadcast with torch.distributed, unless the caller hands one over (ranks that
+    are threads of one process: MOM6X_COMM=threads)."""
     import torch
     lib = dyc.lib
     nranks = layout[0] * layout[1]
     need_id = nranks > 1 or force_nccl_self
     idbuf = None
-    if need_id:
+    if need_id and unique_id is not None:
+        idbuf = C.create_string_buffer(bytes(unique_id), 128)
+    elif need_id:
         idbuf = C.create_string_buffer(128)
         rank = pe[0] + layout[0] * pe[1]
         if rank == 0:

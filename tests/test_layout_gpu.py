@@ -1,0 +1,98 @@
+"""The reference's test.layout on ONE GPU: the same run on a 2 x 1 / 2 x 2 / 1 x 2 tile layout, one tile per host thread
+(MOM6X_COMM=threads: the halo exchanges and global reductions of mom6_amd/csrc/halo.hip go between threads instead of over
+RCCL), against the one-tile run.  Every prognostic field of every tile must equal its part of the one-tile result bit for
+bit: this is what the N-GPU runs rely on -- which rows and columns each kernel covers on an interior tile edge, the
+wide-halo cycles of the barotropic solver, the all-reduces (dtbt, tracer iteration flags, reproducing sums)."""
+import threading
+
+import numpy as np
+import pytest
+
+from mom6_amd import abi, parallel, sum_output as SO
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+STATE = ["u", "v", "h", "uh", "vh", "uhtr", "vhtr", "eta_av"]
+STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h", T="h")
+
+
+def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors):
+    """One tile of the layout: a few baroclinic steps, a tracer advection with the accumulated transports, write_energy."""
+    try:
+        import torch
+        from mom6_amd.dycore import Dycore
+        from tests import cases
+        gg, d1, M1 = cfg_fn(nk=nk)                                  # the one-tile grid: seeded inputs are made on it ...
+        inp = cases.rk2_inputs((gg, d1, M1), False, False)
+        T1 = cases.thermo_state(d1, M1)[0]
+        d, M = gg.tile(nk, 4, layout, pe)                           # ... and cut to this tile (with its halos)
+
+        def cut(a):
+            j0, i0 = d.j_glob0 - d.halo, d.i_glob0 - d.halo         # global index of the tile's first memory row / column
+            rows = np.arange(d.nrows) - d.joff + d.j_glob0
+            cols = np.arange(d.pitch) - d.ioff + d.i_glob0
+            src_r = np.clip(rows + d1.joff, 0, d1.nrows - 1); src_c = np.clip(cols + d1.ioff, 0, d1.pitch - 1)
+            return np.ascontiguousarray(a[..., src_r[:, None], src_c[None, :]])
+        GV, Rlay, gp, dt = inp["GV"], inp["Rlay"], inp["gp"], inp["dt"]
+        cont, bt, cor, pgf, rk2 = cases.rk2_params(d, GV, bt_mod, None, None)
+        dyc = Dycore(d, M, GV, 0)
+        if layout != (1, 1):
+            parallel.attach_comm(dyc, layout, pe, None, unique_id=uid)
+        dyc.continuity_init(cont); dyc.barotropic_init(bt); dyc.CoriolisAdv_init(cor); dyc.PressureForce_init(pgf, Rlay, gp)
+        dyc.initialize_dyn_split_RK2(rk2)
+        dyc.vertvisc_set_coef(*[dyc.to_dev(cut(a)) if a is not None else None for a in inp["coefs"][0]])
+        dyc.tracer_advect_init(dt, 2)
+        dyc.sum_output_init(abi.sum_output_params_default(dt), gp)
+        sg = dict(u=dyc.to_dev(cut(inp["u"])), v=dyc.to_dev(cut(inp["v"])), h=dyc.to_dev(cut(inp["h"])), uh=dyc.zeros3(), vh=dyc.zeros3(),
+                  uhtr=dyc.zeros3(), vhtr=dyc.zeros3(), eta_av=dyc.zeros2(), T=dyc.to_dev(cut(T1)))
+        txd, tyd = dyc.to_dev(cut(inp["taux"])), dyc.to_dev(cut(inp["tauy"]))
+        torch.cuda.synchronize()
+        dyc.dyn_split_RK2_new_run(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], dt)
+        lines = []
+        stats = SO.SumOutput()
+        for n in range(nsteps):
+            dyc.step_MOM_dyn_split_RK2(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], sg["uhtr"], sg["vhtr"], sg["eta_av"], txd, tyd,
+                                       dt, calc_dtbt=(n == 0))
+            lines.append(stats.record(dyc.write_energy(sg["u"], sg["v"], sg["h"]), dt * (n + 1), n + 1)[1])
+        dyc.advect_tracer(sg["h"], sg["uhtr"], sg["vhtr"], nsteps * dt, [sg["T"]])
+        dyc.sync()
+        res = {n: sg[n].cpu().numpy() for n in STATE + ["T"]}
+        res["dtbt"] = dyc.barotropic_dtbt(); res["lines"] = lines; res["dims"] = d
+        out[pe] = res
+        dyc.close()
+    except Exception as e:                                            # noqa: BLE001 -- reported by the main thread
+        import traceback
+        errors.append((pe, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("cfg_name,layout", [("channel", (2, 1)), ("double_gyre", (2, 2)), ("benchmark_small", (1, 2))])
+def test_tile_layout_gives_the_one_tile_answer(cfg_name, layout, monkeypatch):
+    monkeypatch.setenv("MOM6X_COMM", "threads")
+    from mom6_amd.abi import load_library
+    cfg_fn = getattr(H, cfg_name)
+    nk, nsteps, bt_mod = 3, 3, dict(strong_drag=1)
+    errors = []
+    ref = {}
+    run_tile(cfg_fn, nk, (1, 1), (0, 0), None, nsteps, bt_mod, ref, errors)
+    assert not errors, errors[0][1]
+    uid = parallel.unique_id(load_library())
+    out = {}
+    pes = [(px, py) for py in range(layout[1]) for px in range(layout[0])]
+    threads = [threading.Thread(target=run_tile, args=(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors)) for pe in pes]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[0][1]
+    assert len(out) == len(pes)
+    whole = ref[(0, 0)]; d1 = whole["dims"]
+    for pe in pes:
+        r = out[pe]; d = r["dims"]
+        assert r["dtbt"] == whole["dtbt"] and r["lines"] == whole["lines"], (pe, r["lines"], whole["lines"])
+        for n in STATE + ["T"]:
+            st = STAG[n]
+            i0 = -1 if st == "u" else 0; j0 = -1 if st == "v" else 0
+            mine = r[n][(Ellipsis,) + tuple(d.sl(i0, d.ni - 1, j0, d.nj - 1))]
+            part = whole[n][(Ellipsis,) + tuple(d1.sl(d.i_glob0 + i0, d.i_glob0 + d.ni - 1, d.j_glob0 + j0, d.j_glob0 + d.nj - 1))]
+            H.assert_bitwise(mine, part, f"{cfg_name} {layout} tile {pe}: {n}")
