@@ -17,7 +17,7 @@ STATE = ["u", "v", "h", "uh", "vh", "uhtr", "vhtr", "eta_av"]
 STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h", T="h")
 
 
-def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors):
+def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors, rich=False):
     """One tile of the layout: a few baroclinic steps, a tracer advection with the accumulated transports, write_energy."""
     try:
         import torch
@@ -41,7 +41,23 @@ def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors):
             parallel.attach_comm(dyc, layout, pe, None, unique_id=uid)
         dyc.continuity_init(cont); dyc.barotropic_init(bt); dyc.CoriolisAdv_init(cor); dyc.PressureForce_init(pgf, Rlay, gp)
         dyc.initialize_dyn_split_RK2(rk2)
-        dyc.vertvisc_set_coef(*[dyc.to_dev(cut(a)) if a is not None else None for a in inp["coefs"][0]])
+        if rich:   # every callee of the step on the device: vertvisc_coef, horizontal_viscosity, the EOS pressure force
+            from tests.test_dyn_gpu import visc_inputs
+            vis = list(visc_inputs(d1, M1)) + [inp["coefs"][0][4], inp["coefs"][0][5]]
+            dyc.vertvisc_init(abi.vertvisc_params_default())
+            dyc.vertvisc_set_visc(*[dyc.to_dev(cut(a)) if a is not None else None for a in vis])
+            hvP = abi.hor_visc_params_default(dt)
+            for k_, v_ in dict(Laplacian=1, Kh=500.0, Smagorinsky_Kh=1, Smag_Lap_const=0.15, Smagorinsky_Ah=1, Smag_bi_const=0.06,
+                               Ah_vel_scale=0.02).items():
+                setattr(hvP, k_, v_)
+            dyc.hor_visc_init(hvP)
+            Tt, St = cases.thermo_state(d1, M1)
+            tvd = (dyc.to_dev(cut(Tt)), dyc.to_dev(cut(St)))
+            eos = abi.eos_params_default(abi.WRIGHT); eos.MassWghtInterp = 1
+            dyc.PressureForce_set_tv(tvd[0], tvd[1], eos)
+            keep = (tvd, eos, hvP)                                    # noqa: F841 -- the context holds their addresses
+        else:
+            dyc.vertvisc_set_coef(*[dyc.to_dev(cut(a)) if a is not None else None for a in inp["coefs"][0]])
         dyc.tracer_advect_init(dt, 2)
         dyc.sum_output_init(abi.sum_output_params_default(dt), gp)
         sg = dict(u=dyc.to_dev(cut(inp["u"])), v=dyc.to_dev(cut(inp["v"])), h=dyc.to_dev(cut(inp["h"])), uh=dyc.zeros3(), vh=dyc.zeros3(),
@@ -66,20 +82,22 @@ def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors):
         errors.append((pe, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("cfg_name,layout", [("channel", (2, 1)), ("double_gyre", (2, 2)), ("benchmark_small", (1, 2))])
-def test_tile_layout_gives_the_one_tile_answer(cfg_name, layout, monkeypatch):
+@pytest.mark.parametrize("cfg_name,layout,rich", [("channel", (2, 1), False), ("double_gyre", (2, 2), False), ("benchmark_small", (1, 2), False),
+                                                  ("island_basin", (2, 2), True), ("channel", (2, 1), True),
+                                                  ("channel", (4, 2), False), ("benchmark_small", (4, 2), True)])   # the 8-GPU layout
+def test_tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich, monkeypatch):
     monkeypatch.setenv("MOM6X_COMM", "threads")
     from mom6_amd.abi import load_library
     cfg_fn = getattr(H, cfg_name)
     nk, nsteps, bt_mod = 3, 3, dict(strong_drag=1)
     errors = []
     ref = {}
-    run_tile(cfg_fn, nk, (1, 1), (0, 0), None, nsteps, bt_mod, ref, errors)
+    run_tile(cfg_fn, nk, (1, 1), (0, 0), None, nsteps, bt_mod, ref, errors, rich)
     assert not errors, errors[0][1]
     uid = parallel.unique_id(load_library())
     out = {}
     pes = [(px, py) for py in range(layout[1]) for px in range(layout[0])]
-    threads = [threading.Thread(target=run_tile, args=(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors)) for pe in pes]
+    threads = [threading.Thread(target=run_tile, args=(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors, rich)) for pe in pes]
     for t in threads:
         t.start()
     for t in threads:
