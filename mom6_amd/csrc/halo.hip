@@ -163,7 +163,8 @@ struct NcclApi {
   bool ok;
 };
 
-static NcclApi g_nccl = {};
+static NcclApi g_rccl = {};      // the RCCL of the process (dlsym)
+static NcclApi g_threads = {};   // MOM6X_COMM=threads (below)
 
 // ---- MOM6X_COMM=threads: the same API among host THREADS of one process (one tile per thread, all on the same GPU).
 // A single-GPU box cannot host two RCCL ranks, yet the multi-tile logic -- which rows and columns every kernel covers,
@@ -279,16 +280,23 @@ static ncclResult_t AllReduce(const void *send, void *recv, size_t n, ncclDataTy
 static const char *GetErrorString(ncclResult_t) { return "the threads backend (MOM6X_COMM=threads) failed or timed out"; }
 }  // namespace tcomm
 
-static int nccl_load() {
-  if (g_nccl.ok) return MOM6X_OK;
+// The transport a NEW communicator (or unique id) gets: the environment decides when it is made, the communicator keeps it.
+static int nccl_load(NcclApi **out) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
   const char *be = getenv("MOM6X_COMM");
   if (be && !strcmp(be, "threads")) {
-    g_nccl.GetUniqueId = tcomm::GetUniqueId; g_nccl.CommInitRank = tcomm::CommInitRank; g_nccl.CommDestroy = tcomm::CommDestroy;
-    g_nccl.Send = tcomm::Send; g_nccl.Recv = tcomm::Recv; g_nccl.GroupStart = tcomm::GroupStart; g_nccl.GroupEnd = tcomm::GroupEnd;
-    g_nccl.AllReduce = tcomm::AllReduce; g_nccl.GetErrorString = tcomm::GetErrorString;
-    g_nccl.ok = true;
+    NcclApi &t = g_threads;
+    t.GetUniqueId = tcomm::GetUniqueId; t.CommInitRank = tcomm::CommInitRank; t.CommDestroy = tcomm::CommDestroy;
+    t.Send = tcomm::Send; t.Recv = tcomm::Recv; t.GroupStart = tcomm::GroupStart; t.GroupEnd = tcomm::GroupEnd;
+    t.AllReduce = tcomm::AllReduce; t.GetErrorString = tcomm::GetErrorString;
+    t.ok = true;
+    *out = &g_threads;
     return MOM6X_OK;
   }
+  NcclApi &g_nccl = g_rccl;
+  *out = &g_rccl;
+  if (g_nccl.ok) return MOM6X_OK;
   void *h = RTLD_DEFAULT;
   if (!dlsym(h, "ncclSend")) {   // no RCCL in the process yet: load the system one
     h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
@@ -307,12 +315,13 @@ static int nccl_load() {
 #define NCCLCHK(expr)                                                                                   \
   do {                                                                                                  \
     ncclResult_t r_ = (expr);                                                                           \
-    if (r_ != ncclSuccess) { mom6x_set_error("%s failed: %s", #expr, g_nccl.GetErrorString(r_)); return MOM6X_EHIP; } \
+    if (r_ != ncclSuccess) { mom6x_set_error("%s failed: %s", #expr, api->GetErrorString(r_)); return MOM6X_EHIP; } \
   } while (0)
 
 struct Comm {
   int npx, npy, px, py, nranks, rank;
   int nbr[8];
+  NcclApi *api;              // the transport this communicator was made with
   ncclComm_t comm;           // null when every neighbour is the tile itself (single rank)
   bool force_nccl_self;      // test mode: route self-neighbour messages through ncclSend/ncclRecv too
   double *sbuf[8], *rbuf[8];
@@ -322,9 +331,10 @@ struct Comm {
 
 extern "C" int mom6x_comm_unique_id(char *id128) {
   REQUIRE(id128, MOM6X_EINVAL, "mom6x_comm_unique_id: null buffer");
-  int rc = nccl_load(); if (rc) return rc;
+  NcclApi *api;
+  int rc = nccl_load(&api); if (rc) return rc;
   ncclUniqueId id;
-  NCCLCHK(g_nccl.GetUniqueId(&id));
+  NCCLCHK(api->GetUniqueId(&id));
   memcpy(id128, &id, NCCL_UNIQUE_ID_BYTES);
   return MOM6X_OK;
 }
@@ -334,7 +344,7 @@ void comm_free(mom6x_ctx *c) {
   if (!m) return;
   for (int d = 0; d < 8; d++) { (void)hipFree(m->sbuf[d]); (void)hipFree(m->rbuf[d]); }
   (void)hipFree(m->red);
-  if (m->comm) (void)g_nccl.CommDestroy(m->comm);
+  if (m->comm) (void)m->api->CommDestroy(m->comm);
   delete m;
   c->comm = nullptr;
 }
@@ -358,10 +368,12 @@ extern "C" int mom6x_comm_init(mom6x_ctx *c, int npx, int npy, int px, int py, c
   if (m->nranks > 1) need_nccl = true;
   if (need_nccl) {
     REQUIRE(id128, MOM6X_EINVAL, "mom6x_comm_init: a unique id is required for a multi-rank layout");
-    int rc = nccl_load(); if (rc) { delete m; return rc; }
+    NcclApi *api;
+    int rc = nccl_load(&api); if (rc) { delete m; return rc; }
+    m->api = api;
     ncclUniqueId id;
     memcpy(&id, id128, NCCL_UNIQUE_ID_BYTES);
-    NCCLCHK(g_nccl.CommInitRank(&m->comm, m->nranks, id, m->rank));
+    NCCLCHK(api->CommInitRank(&m->comm, m->nranks, id, m->rank));
   }
   HIPCHK(hipMalloc(&m->red, 2 * sizeof(double)));
   c->comm = m;
@@ -374,9 +386,10 @@ extern "C" int mom6x_comm_rank(const mom6x_ctx *c) { return (c && c->comm) ? ((C
 int comm_allreduce_scalar(mom6x_ctx *c, double *value, int op) {
   Comm *m = (Comm *)c->comm;
   if (!m || !m->comm || m->nranks == 1) return MOM6X_OK;
+  NcclApi *api = m->api;
   HIPCHK(hipMemcpyAsync(m->red, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
   const ncclRedOp_t rop = (op == 0) ? ncclMin : ((op == 1) ? ncclMax : ncclSum);
-  NCCLCHK(g_nccl.AllReduce(m->red, m->red + 1, 1, ncclDouble, rop, m->comm, c->stream));
+  NCCLCHK(api->AllReduce(m->red, m->red + 1, 1, ncclDouble, rop, m->comm, c->stream));
   HIPCHK(hipMemcpyAsync(value, m->red + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return MOM6X_OK;
@@ -387,21 +400,24 @@ int comm_allreduce_scalar(mom6x_ctx *c, double *value, int op) {
 int comm_allreduce_i64(mom6x_ctx *c, long long *dev, size_t n, int op) {
   Comm *m = (Comm *)c->comm;
   if (!m || !m->comm || m->nranks == 1 || n == 0) return MOM6X_OK;
+  NcclApi *api = m->api;
   const ncclRedOp_t rop = (op == 0) ? ncclMin : ((op == 1) ? ncclMax : ncclSum);
-  NCCLCHK(g_nccl.AllReduce(dev, dev, n, ncclInt64, rop, m->comm, c->stream));
+  NCCLCHK(api->AllReduce(dev, dev, n, ncclInt64, rop, m->comm, c->stream));
   return MOM6X_OK;
 }
 int comm_allreduce_f64(mom6x_ctx *c, double *dev, size_t n, int op) {
   Comm *m = (Comm *)c->comm;
   if (!m || !m->comm || m->nranks == 1 || n == 0) return MOM6X_OK;
+  NcclApi *api = m->api;
   const ncclRedOp_t rop = (op == 0) ? ncclMin : ((op == 1) ? ncclMax : ncclSum);
-  NCCLCHK(g_nccl.AllReduce(dev, dev, n, ncclDouble, rop, m->comm, c->stream));
+  NCCLCHK(api->AllReduce(dev, dev, n, ncclDouble, rop, m->comm, c->stream));
   return MOM6X_OK;
 }
 int comm_nranks(const mom6x_ctx *c) { const Comm *m = (const Comm *)c->comm; return (m && m->comm) ? m->nranks : 1; }
 
 static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
   const Dm d = c->d;
+  NcclApi *api = m->api;
   size_t cnt[8];
   for (int dir = 0; dir < 8; dir++) {
     cnt[dir] = 0;
@@ -437,20 +453,20 @@ static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
     }
   }
   if (m->comm) {
-    NCCLCHK(g_nccl.GroupStart());
+    NCCLCHK(api->GroupStart());
     in_group = true;
     for (int dir = 0; dir < 8; dir++) {
       if (m->nbr[dir] < 0) continue;
       if (m->nbr[dir] == m->rank && !m->force_nccl_self) continue;
-      NCCLCHK(g_nccl.Send(m->sbuf[dir], cnt[dir], ncclDouble, m->nbr[dir], m->comm, c->stream));
+      NCCLCHK(api->Send(m->sbuf[dir], cnt[dir], ncclDouble, m->nbr[dir], m->comm, c->stream));
     }
     for (int dir = 0; dir < 8; dir++) {
       const int r = dir_opp(dir);
       if (m->nbr[r] < 0) continue;
       if (m->nbr[r] == m->rank && !m->force_nccl_self) continue;
-      NCCLCHK(g_nccl.Recv(m->rbuf[r], cnt[r], ncclDouble, m->nbr[r], m->comm, c->stream));
+      NCCLCHK(api->Recv(m->rbuf[r], cnt[r], ncclDouble, m->nbr[r], m->comm, c->stream));
     }
-    NCCLCHK(g_nccl.GroupEnd());
+    NCCLCHK(api->GroupEnd());
   }
   (void)in_group;
   KLAUNCH(c, "k_halo_unpack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, RB, 0);
@@ -501,6 +517,7 @@ extern "C" int mom6x_pass_fields(mom6x_ctx *c, double *const *fields, const int 
 int comm_allreduce_int_sum(mom6x_ctx *c, int *dev, int n) {
   Comm *m = (Comm *)c->comm;
   if (!m || !m->comm || m->nranks == 1) return MOM6X_OK;
-  NCCLCHK(g_nccl.AllReduce(dev, dev, (size_t)n, ncclInt, ncclSum, m->comm, c->stream));
+  NcclApi *api = m->api;
+  NCCLCHK(api->AllReduce(dev, dev, (size_t)n, ncclInt, ncclSum, m->comm, c->stream));
   return MOM6X_OK;
 }
