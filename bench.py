@@ -57,8 +57,9 @@ def hor_visc_params(abi, dt):
     return P
 
 
-def build_model(args, layout, pe, device):
-    """Create the device model for tile `pe` of `layout` and a synthetic state in HBM."""
+def build_model(args, layout, pe, device, dist=None, unique_id=None):
+    """Create the device model for tile `pe` of `layout` and a synthetic state in HBM.  With more than one tile the
+    communicator is attached before anything exchanges halos (the new-run initialisation does)."""
     import torch
     from mom6_amd import abi, synth_dev
     from mom6_amd.dycore import Dycore
@@ -67,6 +68,9 @@ def build_model(args, layout, pe, device):
     d, M = gg.tile(args.nk, 4, layout, pe)
     GV = abi.vgrid_default()
     dyc = Dycore(d, M, GV, 0, device)
+    if layout != (1, 1):
+        from mom6_amd.parallel import attach_comm
+        attach_comm(dyc, layout, pe, dist, unique_id=unique_id)
     dyc.continuity_init(abi.continuity_params_default(args.nk, GV.Angstrom_H))
     bt = abi.barotropic_params_default(20.0)
     dyc.barotropic_init(bt)
@@ -330,10 +334,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     pe = (rank % layout[0], rank // layout[0])
-    dyc, d, st, taux, tauy, keep = build_model(args, layout, pe, local_rank)
-    if world > 1:
-        from mom6_amd.parallel import attach_comm
-        attach_comm(dyc, layout, pe, dist)
+    dyc, d, st, taux, tauy, keep = build_model(args, layout, pe, local_rank, dist)
 
     def step(calc_dtbt=False):
         dyc.step_MOM_dyn_split_RK2(st["u"], st["v"], st["h"], st["uh"], st["vh"], st["uhtr"], st["vhtr"], st["eta_av"],
