@@ -234,7 +234,10 @@ static ncclResult_t run_group() {
     u++;
   }
   lk.unlock();
-  for (const Op &o : copies) if (hipMemcpy(o.dst, o.src, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) return ncclUnhandledCudaError;
+  // (a device-to-device hipMemcpy may return before the data has landed: copy on the tile's stream and wait for it)
+  for (const Op &o : copies)
+    if (hipMemcpyAsync(o.dst, o.src, o.bytes, hipMemcpyDeviceToDevice, t_stream) != hipSuccess) return ncclUnhandledCudaError;
+  if (hipStreamSynchronize(t_stream) != hipSuccess) return ncclUnhandledCudaError;
   lk.lock();
   const bool ok = h->barrier(lk);                         // nobody reuses a send buffer before everybody has copied
   t_ops.clear();

@@ -40,7 +40,8 @@ def main():
     ap.add_argument("npy", type=int, nargs="?", default=2)
     ap.add_argument("steps", type=int, nargs="?", default=2)
     a = ap.parse_args()
-    args = argparse.Namespace(ni=1440, nj=1080, nk=75, dt=900.0, steps=a.steps)
+    sz = [int(x) for x in os.environ.get("CHECK_SIZE", "1440,1080,75").split(",")]
+    args = argparse.Namespace(ni=sz[0], nj=sz[1], nk=sz[2], dt=900.0, steps=a.steps)
     errors, ref, out = [], {}, {}
     run(args, (1, 1), (0, 0), None, ref, errors)
     if errors:
