@@ -114,3 +114,16 @@ def test_tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich, monkeypat
             mine = r[n][(Ellipsis,) + tuple(d.sl(i0, d.ni - 1, j0, d.nj - 1))]
             part = whole[n][(Ellipsis,) + tuple(d1.sl(d.i_glob0 + i0, d.i_glob0 + d.ni - 1, d.j_glob0 + j0, d.j_glob0 + d.nj - 1))]
             H.assert_bitwise(mine, part, f"{cfg_name} {layout} tile {pe}: {n}")
+
+
+@pytest.mark.parametrize("layout", ["4 2", "2 1"])
+def test_bench_model_layouts_at_full_size(layout):
+    """bench.py's own 1440 x 1080 x 75 model on the 8-GPU (4 x 2) and the 2-GPU (2 x 1) layout against one tile
+    (scripts/check_layout_fullsize.py): messages of 13 MB, tiles of 360 x 540, the restart checksums of every field equal."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_layout_fullsize.py")] + layout.split() + ["2"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "every field checksum and dtbt identical" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
