@@ -209,6 +209,7 @@ extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
   (void)hipFree(c->regrid_res);
   (void)hipFree(c->vv_a_u); (void)hipFree(c->vv_a_v); (void)hipFree(c->vv_h_u); (void)hipFree(c->vv_h_v);
   (void)hipFree(c->G); (void)hipFree(c->hL); (void)hipFree(c->hR); (void)hipFree(c->flag);
+  if (c->ev_ready) { (void)hipEventDestroy(c->ev_ready); (void)hipEventDestroy(c->ev_done); }
   (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->halo_stream);
   delete c;
   return MOM6X_OK;

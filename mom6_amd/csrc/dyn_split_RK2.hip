@@ -134,6 +134,15 @@ int pass3(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list
   return MOM6X_OK;
 }
 
+// start_group_pass of 3-D fields on the halo stream (G%nonblocking_updates); halo_complete() is its complete_group_pass
+int start3(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list<int> stg, int nk) {
+  double *ff[16]; int ss[16], nn[16]; int n = 0;
+  auto s = stg.begin();
+  for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = nk; n++; }
+  halo_start(c, ff, ss, nn, n);
+  return MOM6X_OK;
+}
+
 // One group pass of fields with different numbers of levels: consecutive do_group_pass calls of the reference
 // that no computation separates are sent as ONE packed message per neighbour.
 int passn(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list<int> stg, std::initializer_list<int> nks) {
@@ -333,7 +342,10 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   // uh = u_av * h ; hp = h + dt * div . uh  :779-781
   CHK(mom6x_continuity_PPM(c, up, vp, h, hp, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av, &s->BT,
                            nullptr, nullptr));
-  pass3(c, { hp, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);          // pass_hp_uv :785
+  pass3(c, { hp }, { 0 }, nk);                                          // pass_hp_uv :785 (the part the next kernels read)
+  // the averaged velocities and transports travel on the halo stream while h_av, the barotropic mass source and (BEGW /= 0)
+  // the second pressure force are formed: start_group_pass(CS%pass_av_uvh) :804 ... complete_group_pass :865
+  start3(c, { u_av, v_av, uh, vh }, { 1, 2, 1, 2 }, nk);
   KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)hp, 0, 0.0, 2);   // :808-810
 
   // ---- corrector
@@ -342,6 +354,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2, -1), d.nj + 2, nk, b), b, d, hp, (const double *)h, (const double *)nullptr, 3, R.begw, 1);
     CHK(mom6x_PressureForce(c, hp, s->PFu, s->PFv, s->pbce, s->eta_PF));
   }
+  halo_complete(c);                                                     // :865
   CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :864-867
   if (hooks && hooks->horizontal_viscosity) {                           // :884-888
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -375,8 +388,10 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   // uh = u_av * h ; h = h + dt * div . uh  :1041-1043
   CHK(mom6x_continuity_PPM(c, u_inst, v_inst, h, h, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av,
                            nullptr, nullptr, nullptr));
-  pass3(c, { h, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);           // pass_h :1045 + pass_av_uvh :1053
+  pass3(c, { h }, { 0 }, nk);                                           // pass_h :1045
+  start3(c, { u_av, v_av, uh, vh }, { 1, 2, 1, 2 }, nk);                // start_group_pass(CS%pass_av_uvh) :1054
   KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2);   // :1064-1066
+  halo_complete(c);                                                     // :1072
   KLAUNCH(c, "k_uhtr", k_uhtr, gridk(nxa(d.ni + 5, -3), d.nj + 5, nk, b), b, d, uhtr, vhtr, (const double *)uh, (const double *)vh, dt);   // :1072-1079
   // CAu_pred for the next step :1081-1090
   CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));

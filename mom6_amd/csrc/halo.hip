@@ -418,7 +418,7 @@ int comm_allreduce_f64(mom6x_ctx *c, double *dev, size_t n, int op) {
 }
 int comm_nranks(const mom6x_ctx *c) { const Comm *m = (const Comm *)c->comm; return (m && m->comm) ? m->nranks : 1; }
 
-static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
+static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A, hipStream_t st) {
   const Dm d = c->d;
   NcclApi *api = m->api;
   size_t cnt[8];
@@ -427,7 +427,7 @@ static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
     if (m->nbr[dir] < 0) continue;
     cnt[dir] = region_count(c->dims, A, dir);
     if (cnt[dir] > m->cap[dir]) {
-      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->halo_stream));
       (void)hipFree(m->sbuf[dir]); (void)hipFree(m->rbuf[dir]);
       m->cap[dir] = cnt[dir] + cnt[dir] / 4;
       HIPCHK(hipMalloc(&m->sbuf[dir], m->cap[dir] * sizeof(double)));
@@ -443,7 +443,9 @@ static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
   }
   if (cmax == 0) return MOM6X_OK;
   const int blocks = (int)((cmax + 255) / 256 > 512 ? 512 : (cmax + 255) / 256);
-  KLAUNCH(c, "k_halo_pack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, SB, 1);
+  const bool own = (st == c->stream);     // (the per-kernel timing of mom6x_prof_* follows the compute stream only)
+  if (own) KLAUNCH(c, "k_halo_pack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, SB, 1);
+  else hipLaunchKernelGGL(k_halo_pack, dim3(blocks, 8), dim3(256), 0, st, d, A, SB, 1);
   // sends in direction order; receives in the order of the OPPOSITE directions, so that the j-th send to a
   // peer pairs with the peer's j-th receive from us even when one rank is the neighbour in several directions.
   bool in_group = false;
@@ -452,7 +454,7 @@ static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
     const bool self = (m->nbr[dir] == m->rank);
     if (self && !m->force_nccl_self) {
       // my message toward `dir` arrives as my own receive from direction opp(dir)
-      HIPCHK(hipMemcpyAsync(m->rbuf[dir_opp(dir)], m->sbuf[dir], cnt[dir] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(m->rbuf[dir_opp(dir)], m->sbuf[dir], cnt[dir] * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
   }
   if (m->comm) {
@@ -461,24 +463,28 @@ static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A) {
     for (int dir = 0; dir < 8; dir++) {
       if (m->nbr[dir] < 0) continue;
       if (m->nbr[dir] == m->rank && !m->force_nccl_self) continue;
-      NCCLCHK(api->Send(m->sbuf[dir], cnt[dir], ncclDouble, m->nbr[dir], m->comm, c->stream));
+      NCCLCHK(api->Send(m->sbuf[dir], cnt[dir], ncclDouble, m->nbr[dir], m->comm, st));
     }
     for (int dir = 0; dir < 8; dir++) {
       const int r = dir_opp(dir);
       if (m->nbr[r] < 0) continue;
       if (m->nbr[r] == m->rank && !m->force_nccl_self) continue;
-      NCCLCHK(api->Recv(m->rbuf[r], cnt[r], ncclDouble, m->nbr[r], m->comm, c->stream));
+      NCCLCHK(api->Recv(m->rbuf[r], cnt[r], ncclDouble, m->nbr[r], m->comm, st));
     }
     NCCLCHK(api->GroupEnd());
   }
   (void)in_group;
-  KLAUNCH(c, "k_halo_unpack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, RB, 0);
+  if (own) KLAUNCH(c, "k_halo_unpack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, RB, 0);
+  else hipLaunchKernelGGL(k_halo_pack, dim3(blocks, 8), dim3(256), 0, st, d, A, RB, 0);
   return MOM6X_OK;
 }
+
+void halo_complete(mom6x_ctx *c);
 
 void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n) {
   const Dm d = c->d;
   Comm *m = (Comm *)c->comm;
+  if (c->pass_pending) halo_complete(c);   // the message buffers are shared: one group pass at a time
   if (!m && !c->dims.reentrant_x && !c->dims.reentrant_y) return;
   for (int base = 0; base < n; base += MAXF) {
     WrapArgs A;
@@ -490,7 +496,7 @@ void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const i
       if (A.nk[q] > nkmax) nkmax = A.nk[q];
     }
     if (m) {
-      if (exchange(c, m, A) != MOM6X_OK) c->halo_error = true;
+      if (exchange(c, m, A, c->stream) != MOM6X_OK) c->halo_error = true;
       continue;
     }
     const dim3 b(64, d.halo, 1);
@@ -503,6 +509,36 @@ void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const i
       KLAUNCH(c, "k_wrap_y", k_wrap_y, dim3((cols + 63) / 64, 1, nkmax), b, d, A);
     }
   }
+}
+
+// start_group_pass / complete_group_pass (MOM_domain_infra.F90:1155 / :1173; G%nonblocking_updates): the group pass runs on
+// the context's SECOND stream -- pack, RCCL send/recv, unpack -- while the compute stream goes on with kernels that neither
+// write the passing fields nor read their halos; halo_complete makes the compute stream wait for it.  At most one pass is
+// in flight (a blocking pass completes it first).  Without a communicator (one tile) the pass is done at once.
+void halo_start(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n) {
+  Comm *m = (Comm *)c->comm;
+  if (!m || !m->comm || n > MAXF) { halo_wrap(c, fields, staggers, nks, n); return; }
+  if (c->pass_pending) halo_complete(c);
+  if (!c->ev_ready) {
+    if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { c->halo_error = true; return; }
+  }
+  WrapArgs A;
+  A.n = n; A.rx = c->dims.reentrant_x;
+  for (int q = 0; q < n; q++) { A.f[q] = fields[q]; A.stg[q] = staggers[q]; A.nk[q] = nks[q]; }
+  // the second stream starts when the compute stream has produced the fields ...
+  if (hipEventRecord(c->ev_ready, c->stream) != hipSuccess || hipStreamWaitEvent(c->halo_stream, c->ev_ready, 0) != hipSuccess ||
+      exchange(c, m, A, c->halo_stream) != MOM6X_OK || hipEventRecord(c->ev_done, c->halo_stream) != hipSuccess) {
+    c->halo_error = true;
+    return;
+  }
+  c->pass_pending = true;
+}
+// ... and the compute stream waits here for the halos
+void halo_complete(mom6x_ctx *c) {
+  if (!c->pass_pending) return;
+  c->pass_pending = false;
+  if (hipStreamWaitEvent(c->stream, c->ev_done, 0) != hipSuccess) c->halo_error = true;
 }
 
 // pass_var / pass_vector for non-torch hosts and tests: one group pass of n fields.

@@ -96,8 +96,11 @@ struct mom6x_ctx {
   void *diag;               // diag_sums.hip: Sum_output_CS state (depth list, lH) of write_energy
   void *comm;               // halo.hip: tile layout + RCCL communicator (null: single tile, wrap only)
   bool halo_error;          // set by a failed halo exchange inside a stream-ordered sequence
+  hipEvent_t ev_ready, ev_done; bool pass_pending;   // halo.hip: the group pass in flight on the halo stream (start_/complete_group_pass)
 };
 void comm_free(mom6x_ctx *c);                                         // halo.hip
+void halo_start(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);   // start_group_pass
+void halo_complete(mom6x_ctx *c);                                     // complete_group_pass
 int comm_allreduce_scalar(mom6x_ctx *c, double *value, int op);       // halo.hip: 0 min, 1 max, 2 sum
 
 // ---------------------------------------------------------------------------------------------
