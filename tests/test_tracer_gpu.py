@@ -32,7 +32,8 @@ def transports(orc, d, M, GV, dt, scale, post=1.0):
 
 
 @pytest.mark.parametrize("cfg", ["double_gyre", "channel", "benchmark_small", "wide"])
-@pytest.mark.parametrize("schemes,first,post", [([0, 0], 0, 1.0), ([1, 1, 2], 0, 60.0), ([2, 0, 1], 1, 60.0), ([1], 1, 1.0), ([0], 0, 60.0)])
+@pytest.mark.parametrize("schemes,first,post", [([0, 0], 0, 1.0), ([1, 1, 2], 0, 60.0), ([2, 0, 1], 1, 60.0), ([1], 1, 1.0), ([0], 0, 60.0),
+                                                ([0, 1, 2, 2, 1], 0, 60.0)])      # five tracers: the 8-tracer instantiations
 def test_advect_tracer(orc, cfg, schemes, first, post):
     import torch
     from mom6_amd.dycore import Dycore
