@@ -144,3 +144,19 @@ def test_reproducing_sum_is_layout_invariant(orc):
         dy.close()
     for k in range(3):
         assert SO.EFP_to_real(list(tot[k])) == whole["sums"][k]
+
+
+@pytest.mark.parametrize("ni,nj,nk,halo", [(7, 5, 1, 3), (17, 9, 3, 4), (257, 3, 2, 4), (3, 300, 2, 4)])
+def test_sums_and_checksums_on_ragged_tiles(orc, ni, nj, nk, halo):
+    """Tile extents far from the 256 x 8 blocks of the reduction kernel, one layer, the narrowest halo."""
+    d, dyc = make(H.double_gyre(nk=nk, ni=ni, nj=nj, halo=halo))
+    a = wide_range_field(d, nk, 31)
+    ad = dyc.to_dev(a)
+    same_sum(dyc.reproducing_sum(ad, layer_sums=True), orc.reproducing_sum(d, a, layer_sums=True))
+    same_sum(dyc.reproducing_sum(ad[0], -1, d.ni - 1, -1, d.nj - 1), orc.reproducing_sum(d, a[0], -1, d.ni - 1, -1, d.nj - 1))
+    for stg in "huvB":
+        for kw in (dict(), dict(haloshift=halo - 1, symmetric=(stg != "h")) if stg != "h" else dict(haloshift=halo - 1)):
+            got = dyc.chksum(ad, stg, **kw); got.pop("kind")
+            assert got == orc.chksum(d, a, stg, **kw), (stg, kw)
+    assert dyc.field_chksum(ad) == orc.field_chksum(d, a, 0, d.ni - 1, 0, d.nj - 1)
+    dyc.close()
