@@ -19,11 +19,11 @@ def same(got, ref):
 
 
 @pytest.mark.parametrize("cfg,nk,thermo", [("double_gyre", 2, False), ("benchmark_small", 7, True), ("island_basin", 5, True),
-                                           ("channel", 3, False)])
+                                           ("channel", 3, False), ("ragged", 3, True)])
 def test_write_energy_matches_oracle(orc, cfg, nk, thermo):
     from mom6_amd.dycore import Dycore
     from tests import cases
-    gg, d, M = getattr(H, cfg)(nk=nk)
+    gg, d, M = H.double_gyre(nk=nk, ni=17, nj=9, halo=3) if cfg == "ragged" else getattr(H, cfg)(nk=nk)
     GV = abi.vgrid_default()
     g_prime = np.concatenate(([GV.g_Earth], 0.01 + 0.002 * np.arange(nk - 1)))
     P = abi.sum_output_params_default(900.0, use_temperature=int(thermo))
