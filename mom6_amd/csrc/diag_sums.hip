@@ -472,36 +472,43 @@ k_ts_int(Dm d, const double *__restrict__ G, const double *__restrict__ h, const
   Salt_int[c] = si; Temp_int[c] = ti;
 }
 
-// max_CFL :701-722: u faces I = -1..ni-1 of rows 0..nj-1, v faces J = -1..nj-1 of columns 0..ni-1, all layers
+// max_CFL :701-722: u faces I = -1..ni-1 of rows 0..nj-1, v faces J = -1..nj-1 of columns 0..ni-1.  One thread per column
+// walks all layers with the five metric values of its two faces in registers (the planes are read once, not once per layer).
 __global__ void __launch_bounds__(256)
 k_max_cfl(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v, double dt,
           long long *__restrict__ out) {
-  const int i = -1 + blockIdx.x * 256 + threadIdx.x, j = -1 + blockIdx.y, k = blockIdx.z;
+  const int i = -1 + blockIdx.x * 256 + threadIdx.x, j = -1 + blockIdx.y;
   double m1 = 0.0, m2 = 0.0;
   if (i < d.ni) {
-    const size_t c = ix2(d, i, j), c3 = c + (size_t)k * d.slab;
+    const size_t c = ix2(d, i, j);
     const double *IareaT = gm(G, d, MOM6X_G_IareaT);
-    if (j >= 0) {
-      const double uu = u[c3];
-      double CFL_Iarea = IareaT[c];
-      if (uu < 0.0) CFL_Iarea = IareaT[c + 1];
-      const double CFL_trans = fabs(uu * dt) * (gm(G, d, MOM6X_G_dy_Cu)[c] * CFL_Iarea);
-      const double CFL_lin = fabs(uu * dt) * gm(G, d, MOM6X_G_IdxCu)[c];
-      m1 = dmax(m1, CFL_trans); m2 = dmax(m2, CFL_lin);
-    }
-    if (i >= 0) {
-      const double vv = v[c3];
-      double CFL_Iarea = IareaT[c];
-      if (vv < 0.0) CFL_Iarea = IareaT[c + d.pitch];
-      const double CFL_trans = fabs(vv * dt) * (gm(G, d, MOM6X_G_dx_Cv)[c] * CFL_Iarea);
-      const double CFL_lin = fabs(vv * dt) * gm(G, d, MOM6X_G_IdyCv)[c];
-      m1 = dmax(m1, CFL_trans); m2 = dmax(m2, CFL_lin);
+    const bool do_u = (j >= 0), do_v = (i >= 0);
+    const double Ia_c = IareaT[c], Ia_e = IareaT[c + 1], Ia_n = IareaT[c + d.pitch];
+    const double dyCu = gm(G, d, MOM6X_G_dy_Cu)[c], IdxCu = gm(G, d, MOM6X_G_IdxCu)[c];
+    const double dxCv = gm(G, d, MOM6X_G_dx_Cv)[c], IdyCv = gm(G, d, MOM6X_G_IdyCv)[c];
+    for (int k = 0; k < d.nk; k++) {
+      const size_t c3 = c + (size_t)k * d.slab;
+      if (do_u) {
+        const double uu = u[c3];
+        double CFL_Iarea = Ia_c;
+        if (uu < 0.0) CFL_Iarea = Ia_e;
+        const double CFL_trans = fabs(uu * dt) * (dyCu * CFL_Iarea);
+        const double CFL_lin = fabs(uu * dt) * IdxCu;
+        if (CFL_trans > m1) m1 = CFL_trans;          // (a NaN never replaces the running maximum, as in max(max_CFL, NaN))
+        if (CFL_lin > m2) m2 = CFL_lin;
+      }
+      if (do_v) {
+        const double vv = v[c3];
+        double CFL_Iarea = Ia_c;
+        if (vv < 0.0) CFL_Iarea = Ia_n;
+        const double CFL_trans = fabs(vv * dt) * (dxCv * CFL_Iarea);
+        const double CFL_lin = fabs(vv * dt) * IdyCv;
+        if (CFL_trans > m1) m1 = CFL_trans;
+        if (CFL_lin > m2) m2 = CFL_lin;
+      }
     }
   }
-  // NaNs do not take part in max(), as in the reference's max(max_CFL, ...) with a NaN second argument
   long long b1, b2;
-  if (!(m1 == m1)) m1 = 0.0;
-  if (!(m2 == m2)) m2 = 0.0;
   memcpy(&b1, &m1, 8); memcpy(&b2, &m2, 8);
   b1 = wave_max(b1); b2 = wave_max(b2);
   // one atomic per wavefront at most, and only when it can still raise the running maximum (a stale read is harmless)
@@ -696,7 +703,7 @@ extern "C" int mom6x_write_energy(mom6x_ctx *c, const double *u, const double *v
     if ((rc = reproducing_sum_finish(c, H, 1, 2, 1.0, 0, &dummy, nullptr, out->heat_EFP, nullptr, nullptr))) return rc;
   }
   HIPCHK(hipMemsetAsync(S->cfl_dev, 0, sizeof(long long) * 2, c->stream));
-  KLAUNCH(c, "k_max_cfl", k_max_cfl, dim3((ni + 1 + 255) / 256, nj + 1, nz), dim3(256), d, c->G, u, v, S->p.dt_in_T, S->cfl_dev);
+  KLAUNCH(c, "k_max_cfl", k_max_cfl, dim3((ni + 1 + 255) / 256, nj + 1, 1), dim3(256), d, c->G, u, v, S->p.dt_in_T, S->cfl_dev);
   if ((rc = comm_allreduce_i64(c, S->cfl_dev, 2, 1))) return rc;
   long long cb[2];
   HIPCHK(hipMemcpyAsync(cb, S->cfl_dev, sizeof(cb), hipMemcpyDeviceToHost, c->stream));
