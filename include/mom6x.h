@@ -104,7 +104,18 @@ typedef struct mom6x_continuity_params {
   int    better_iter;      /* CONT_PPM_BETTER_ITER (T)                        */
   int    use_visc_rem_max; /* CONT_PPM_USE_VISC_REM_MAX (T)                   */
   int    marginal_faces;   /* CONT_PPM_MARGINAL_FACE_AREAS (T)                */
+  int    sum_order;        /* order of the column (k) sums of zonal/meridional_mass_flux, *_flux_adjust and
+                            * set_*_BT_cont -- no counterpart in the reference, which sums sequentially in k:
+                            *   MOM6X_SUM_REFERENCE (0): the reference's order, results bit-identical to the Fortran loop nest;
+                            *   MOM6X_SUM_TREE16    (1): sixteen partial sums over k = q, q+16, q+32, ... (q = 0..15, each
+                            *     in increasing k) combined by a balanced binary tree in q order, and the duL / duR
+                            *     recurrences of set_*_BT_cont (:1293-1316) taken as the min / max they compute in exact
+                            *     arithmetic.  Results agree with the reference order to round-off (<= 1e-13 of each
+                            *     field's range); this is the order of a 16-lane wavefront row and lets one wavefront own a
+                            *     face column (continuity_wave.hip).  Requires nk <= 128.                               */
 } mom6x_continuity_params;
+#define MOM6X_SUM_REFERENCE 0
+#define MOM6X_SUM_TREE16    1
 
 /* BT_cont_type (src/core/MOM_variables.F90:315-350): 12 2-D planes + h_u,h_v.
  * Any pointer may be NULL only if the whole struct pointer is NULL.          */

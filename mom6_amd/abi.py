@@ -84,7 +84,7 @@ class ContinuityParams(C.Structure):
         ("upwind_1st", C.c_int), ("monotonic", C.c_int), ("simple_2nd", C.c_int),
         ("tol_eta", C.c_double), ("tol_vel", C.c_double), ("CFL_limit_adjust", C.c_double),
         ("aggress_adjust", C.c_int), ("vol_CFL", C.c_int), ("better_iter", C.c_int),
-        ("use_visc_rem_max", C.c_int), ("marginal_faces", C.c_int),
+        ("use_visc_rem_max", C.c_int), ("marginal_faces", C.c_int), ("sum_order", C.c_int),
     ]
 
 
@@ -97,7 +97,20 @@ def continuity_params_default(nk, Angstrom=1e-10):
     p.CFL_limit_adjust = 0.5
     p.aggress_adjust = p.vol_CFL = 0
     p.better_iter = p.use_visc_rem_max = p.marginal_faces = 1
+    p.sum_order = default_sum_order(nk)
     return p
+
+
+SUM_REFERENCE, SUM_TREE16 = 0, 1
+
+
+def default_sum_order(nk):
+    """Order of the column sums of the mass-flux kernels (mom6x_continuity_params.sum_order): the 16-lane tree of the
+    wave-owned kernel unless MOM6X_SUMS=exact asks for the reference's sequential order (bit-identical to the Fortran
+    loop nest, slower) or the column is deeper than that kernel carries."""
+    if os.environ.get("MOM6X_SUMS", "").lower() in ("exact", "reference", "0") or nk > 128:
+        return SUM_REFERENCE
+    return SUM_TREE16
 
 
 class BTCont(C.Structure):

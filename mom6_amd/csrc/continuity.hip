@@ -326,7 +326,8 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
   int ei0 = ish, ei1 = ieh, ej0 = jsh, ej1 = jeh;
   if (DIR == 0) { ei0 = ish - 1; ei1 = ieh + 1; } else { ej0 = jsh - 1; ej1 = jeh + 1; }
   const int scheme = P.upwind_1st ? 2 : (P.simple_2nd ? 1 : 0);
-  const bool lds = use_lds_path(d.nk);
+  const bool wave = (P.sum_order == MOM6X_SUM_TREE16);   // one wavefront row per face column, everything in registers
+  const bool lds = wave || use_lds_path(d.nk);
   if (!lds)
     KLAUNCH(c, "k_edge<DIR>", k_edge<DIR>, grid3(ei1 - ei0 + 1, ej1 - ej0 + 1, d.nk, blk), blk, d, c->G, h_src,
                        c->hL, c->hR, 2.0 * c->GV.Angstrom_H, scheme, P.monotonic, ei0, ei1, ej0, ej1);
@@ -350,7 +351,7 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
     LdsArgs E;
     E.h_min = 2.0 * c->GV.Angstrom_H; E.scheme = scheme; E.monotonic = P.monotonic;
     E.marginal = P.marginal_faces; E.h_face = BT_h;
-    const int rc = mass_flux_lds(c, DIR, A, E);
+    const int rc = wave ? mass_flux_wave(c, DIR, A, E) : mass_flux_lds(c, DIR, A, E);
     if (rc) return rc;
   } else {
     KLAUNCH(c, "k_mass_flux<DIR>", k_mass_flux<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, 1, blk), blk, d, c->G, A);
@@ -372,6 +373,10 @@ extern "C" int mom6x_continuity_init(mom6x_ctx *c, const mom6x_continuity_params
   REQUIRE(c && p, MOM6X_EINVAL, "mom6x_continuity_init: null argument");
   REQUIRE(!p->aggress_adjust && !p->vol_CFL, MOM6X_EUNSUPPORTED,
           "continuity_PPM: CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL are not supported");
+  REQUIRE(p->sum_order == MOM6X_SUM_REFERENCE || p->sum_order == MOM6X_SUM_TREE16, MOM6X_EINVAL,
+          "continuity_PPM: sum_order must be MOM6X_SUM_REFERENCE (0) or MOM6X_SUM_TREE16 (1)");
+  REQUIRE(p->sum_order != MOM6X_SUM_TREE16 || mass_flux_wave_usable(c->d.nk), MOM6X_EUNSUPPORTED,
+          "continuity_PPM: sum_order = MOM6X_SUM_TREE16 carries at most 128 layers; use MOM6X_SUM_REFERENCE");
   c->cont = *p;
   c->cont_init = true;
   return MOM6X_OK;

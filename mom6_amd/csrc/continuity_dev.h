@@ -60,6 +60,41 @@ __device__ __forceinline__ double ppm_slope(const double *h, const double *m, si
   return dsign(1.0, s) * dmin(fabs(s), 2.0 * dmin(dMx, dMn));
 }
 
+// Lin (1994) B2 limited slope (:2368-2378) from registers; mprod = product of the three masks.
+__device__ __forceinline__ double slope3(double hm, double h0, double hp, double mprod) {
+  if (mprod == 0.0) return 0.0;
+  const double s = 0.5 * (hp - hm);
+  const double dMx = dmax(dmax(hp, hm), h0) - h0;
+  const double dMn = h0 - dmin(dmin(hp, hm), h0);
+  return dsign(1.0, s) * dmin(fabs(s), 2.0 * dmin(dMx, dMn));
+}
+
+// PPM_reconstruction_x/y + limiter for one cell from its 5-point stencil hh[0..4] (cell = hh[2]).
+__device__ __forceinline__ void edge5(const double *hh, const double *mm, int scheme, int monotonic, double h_min,
+                                      double &hl, double &hr, double &c3) {
+  const double h0 = hh[2];
+  if (scheme == 2) {
+    hl = h0; hr = h0;
+  } else {
+    const double h_im1 = mm[1] * hh[1] + (1.0 - mm[1]) * h0;
+    const double h_ip1 = mm[3] * hh[3] + (1.0 - mm[3]) * h0;
+    if (scheme == 1) {
+      hl = 0.5 * (h_im1 + h0);
+      hr = 0.5 * (h_ip1 + h0);
+    } else {
+      const double oneSixth = 1.0 / 6.0;
+      const double sm = slope3(hh[0], hh[1], hh[2], mm[0] * mm[1] * mm[2]);
+      const double s0 = slope3(hh[1], hh[2], hh[3], mm[1] * mm[2] * mm[3]);
+      const double sp = slope3(hh[2], hh[3], hh[4], mm[2] * mm[3] * mm[4]);
+      hl = 0.5 * (h_im1 + h0) + oneSixth * (sm - s0);
+      hr = 0.5 * (h_ip1 + h0) + oneSixth * (s0 - sp);
+    }
+    if (monotonic) ppm_limit_cw84(h0, hl, hr);
+    else ppm_limit_pos(h0, hl, hr, h_min);
+  }
+  c3 = (hl + hr) - 2.0 * h0;
+}
+
 // zonal_flux_layer :896 / merid_flux_layer :1787 for one face of one layer.
 // f = flat 3-D index of the face (= its minus cell), f2 = its 2-D index.
 __device__ __forceinline__ void flux_layer(const DirMetrics &D, int st, size_t f, size_t f2, double u,

@@ -17,3 +17,6 @@ struct LdsArgs {
 size_t mass_flux_lds_bytes(int dir, int nk);
 bool mass_flux_lds_usable(int nk);
 int mass_flux_lds(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E);
+// continuity_wave.hip: the wave-owned kernel of sum_order == MOM6X_SUM_TREE16 (uses h_min, scheme, monotonic, marginal, h_face)
+bool mass_flux_wave_usable(int nk);
+int mass_flux_wave(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E);

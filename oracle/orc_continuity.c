@@ -153,6 +153,20 @@ static inline void flux_layer_face(const dir_t *D, size_t f, double u, const dou
   *duhdu = (D->Lface[f] * 1.0) * h_marg * visc_rem;
 }
 
+/* mom6x_continuity_params.sum_order == MOM6X_SUM_TREE16 (include/mom6x.h): NOT the reference's order.  Sixteen partial
+ * sums over k = q, q+16, q+32, ... (each started from +0.0 and walked in increasing k), then a balanced binary tree
+ * in q order.  x[k*stride], k = 0..nk-1. */
+static double tree16_sum(const double *x, size_t stride, int nk) {
+  double s[16];
+  for (int q = 0; q < 16; q++) {
+    s[q] = 0.0;
+    for (int k = q; k < nk; k += 16) s[q] = s[q] + x[(size_t)k * stride];
+  }
+  for (int w = 1; w < 16; w *= 2)
+    for (int q = 0; q < 16; q += 2 * w) s[q] = s[q] + s[q + w];
+  return s[0];
+}
+
 /* Row description: faces a = a0..a1 of row b. */
 typedef struct { int a0, a1, b; } row_t;
 static inline size_t row_face(const mom6x_dims *d, const dir_t *D, const row_t *R, int a) {
@@ -240,7 +254,14 @@ static void flux_adjust_row(const mom6x_dims *d, const dir_t *D, const mom6x_con
       }
     }
 
-    if (itt < max_itts) {
+    if ((itt < max_itts) && CS->sum_order == MOM6X_SUM_TREE16) {
+      /* (a face whose do_I is false re-sums unchanged layer values: the same bits) */
+      for (int a = R->a0; a <= R->a1; a++) {
+        uh_err[a] = tree16_sum(&uh_aux[a], (size_t)P, nz) - uhbt_row[a];
+        duhdu_tot[a] = tree16_sum(&duhdu[a], (size_t)P, nz);
+      }
+      for (int a = R->a0; a <= R->a1; a++) uh_err_best[a] = orc_min(uh_err_best[a], fabs(uh_err[a]));
+    } else if (itt < max_itts) {
       for (int a = R->a0; a <= R->a1; a++) { uh_err[a] = -uhbt_row[a]; duhdu_tot[a] = 0.0; }
       for (int k = 0; k < nz; k++) for (int a = R->a0; a <= R->a1; a++) {
         uh_err[a] = uh_err[a] + uh_aux[(size_t)k * P + a];
@@ -275,6 +296,9 @@ static void set_BT_cont_row(const mom6x_dims *d, const dir_t *D, const mom6x_con
   double *zeros = orc_row_alloc(d), *du_CFL = orc_row_alloc(d);
   double *FAmt_L = orc_row_alloc(d), *FAmt_R = orc_row_alloc(d), *FAmt_0 = orc_row_alloc(d);
   double *uhtot_L = orc_row_alloc(d), *uhtot_R = orc_row_alloc(d);
+  double *t5[5] = {NULL, NULL, NULL, NULL, NULL};   /* sum_order TREE16: the layer values of the five column sums */
+  if (CS->sum_order == MOM6X_SUM_TREE16)
+    for (int q = 0; q < 5; q++) t5[q] = (double *)calloc((size_t)P * nz, sizeof(double)) + d->ioff;
 
   flux_adjust_row(d, D, CS, R, u, h_in, hL, hR, zeros, uh_tot_0, duhdu_tot_0, du0, du_max_CFL,
                   du_min_CFL, dt, vr, do_I, NULL);
@@ -296,11 +320,17 @@ static void set_BT_cont_row(const mom6x_dims *d, const dir_t *D, const mom6x_con
     goto done;
   }
 
+  const int tree = (CS->sum_order == MOM6X_SUM_TREE16);
   for (int k = 0; k < nz; k++) for (int a = R->a0; a <= R->a1; a++) if (do_I[a]) {
     size_t f = row_face(d, D, R, a);
     double vrem = vr[(size_t)k * P + a], uk = u[f + k * slab];
     double visc_rem_lim = orc_max(vrem, min_visc_rem * visc_rem_max[a]);
     if (visc_rem_lim > 0.0) {
+      if (tree) {   /* the recurrence below in exact arithmetic: "uk + duR*lim > -du_CFL*vrem" <=> duR > the quotient */
+        duR[a] = orc_min(duR[a], -(uk + du_CFL[a] * vrem) / visc_rem_lim);
+        duL[a] = orc_max(duL[a], -(uk - du_CFL[a] * vrem) / visc_rem_lim);
+        continue;
+      }
       if (uk + duR[a] * visc_rem_lim > -du_CFL[a] * vrem)
         duR[a] = -(uk + du_CFL[a] * vrem) / visc_rem_lim;
       if (uk + duL[a] * visc_rem_lim < du_CFL[a] * vrem)
@@ -316,11 +346,21 @@ static void set_BT_cont_row(const mom6x_dims *d, const dir_t *D, const mom6x_con
     flux_layer_face(D, f, u_0, h_in + k * slab, hL + k * slab, hR + k * slab, dt, vrem, &uh_0, &duhdu_0);
     flux_layer_face(D, f, u_L, h_in + k * slab, hL + k * slab, hR + k * slab, dt, vrem, &uh_L, &duhdu_L);
     flux_layer_face(D, f, u_R, h_in + k * slab, hL + k * slab, hR + k * slab, dt, vrem, &uh_R, &duhdu_R);
+    if (tree) {
+      t5[0][(size_t)k * P + a] = duhdu_0; t5[1][(size_t)k * P + a] = duhdu_L; t5[2][(size_t)k * P + a] = duhdu_R;
+      t5[3][(size_t)k * P + a] = uh_L; t5[4][(size_t)k * P + a] = uh_R;
+      continue;
+    }
     FAmt_0[a] = FAmt_0[a] + duhdu_0;
     FAmt_L[a] = FAmt_L[a] + duhdu_L;
     FAmt_R[a] = FAmt_R[a] + duhdu_R;
     uhtot_L[a] = uhtot_L[a] + uh_L;
     uhtot_R[a] = uhtot_R[a] + uh_R;
+  }
+  if (tree) for (int a = R->a0; a <= R->a1; a++) if (do_I[a]) {
+    FAmt_0[a] = tree16_sum(&t5[0][a], (size_t)P, nz); FAmt_L[a] = tree16_sum(&t5[1][a], (size_t)P, nz);
+    FAmt_R[a] = tree16_sum(&t5[2][a], (size_t)P, nz); uhtot_L[a] = tree16_sum(&t5[3][a], (size_t)P, nz);
+    uhtot_R[a] = tree16_sum(&t5[4][a], (size_t)P, nz);
   }
   for (int a = R->a0; a <= R->a1; a++) {
     size_t f = row_face(d, D, R, a);
@@ -345,6 +385,7 @@ static void set_BT_cont_row(const mom6x_dims *d, const dir_t *D, const mom6x_con
     }
   }
 done:
+  for (int q = 0; q < 5; q++) if (t5[q]) free(t5[q] - d->ioff);
   orc_row_free(d, du0); orc_row_free(d, duL); orc_row_free(d, duR); orc_row_free(d, zeros);
   orc_row_free(d, du_CFL); orc_row_free(d, FAmt_L); orc_row_free(d, FAmt_R); orc_row_free(d, FAmt_0);
   orc_row_free(d, uhtot_L); orc_row_free(d, uhtot_R);
@@ -438,6 +479,13 @@ static void mass_flux(const mom6x_dims *d, const dir_t *D, const mom6x_continuit
         du_min_CFL[a] = -2.0 * (CFL_dt * dx_E) * I_vrm;
         uh_tot_0[a] = 0.0; duhdu_tot_0[a] = 0.0;
       }
+      if (CS->sum_order == MOM6X_SUM_TREE16) {
+        for (int a = a0; a <= a1; a++) {
+          size_t f = row_face(d, D, &R, a);
+          duhdu_tot_0[a] = tree16_sum(&duhdu[a], (size_t)P, nz);
+          uh_tot_0[a] = tree16_sum(&uh[f], slab, nz);
+        }
+      } else
       for (int k = 0; k < nz; k++) for (int a = a0; a <= a1; a++) {
         size_t f = row_face(d, D, &R, a);
         duhdu_tot_0[a] = duhdu_tot_0[a] + duhdu[(size_t)k * P + a];
@@ -517,6 +565,7 @@ int orc_continuity_PPM(const mom6x_dims *d, const double *G, const mom6x_vgrid *
                        double *u_cor, double *v_cor, const mom6x_BT_cont *BT,
                        double *du_cor, double *dv_cor) {
   if (CS->aggress_adjust || CS->vol_CFL) return MOM6X_EUNSUPPORTED;
+  if (CS->sum_order != MOM6X_SUM_REFERENCE && CS->sum_order != MOM6X_SUM_TREE16) return MOM6X_EINVAL;
   if ((visc_rem_u != NULL) != (visc_rem_v != NULL)) return MOM6X_EINVAL;
   const size_t n3 = (size_t)d->slab * d->nk;
   double *h_W = (double *)calloc(n3, sizeof(double)), *h_E = (double *)calloc(n3, sizeof(double));

@@ -24,21 +24,28 @@ STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h",
 
 def main():
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    for sums in ("exact", "tree"):   # both orders of the mass-flux column sums (mom6x_continuity_params.sum_order)
+        os.environ["MOM6X_SUMS"] = sums
+        write_set()
+    for f in sorted(os.listdir(os.path.join(ROOT, "tests", "golden"))):
+        print(f, os.path.getsize(os.path.join(ROOT, "tests", "golden", f)), "bytes")
+
+
+def write_set():
+    tag = H.golden_tag()
     cfg = H.double_gyre()
     d = cfg[1]
     so, _ = cases.oracle_rk2(orc, cfg, cases.rk2_inputs(cfg), 3, bt_mod=dict(strong_drag=1))
-    np.savez_compressed(H.golden_path("rk2_double_gyre_strong_drag_3steps"),
+    np.savez_compressed(H.golden_path("rk2_double_gyre_strong_drag_3steps" + tag),
                         **{n: so[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))] for n in so})
     cfg = H.benchmark_small()
     d = cfg[1]
     out, _, _ = cases.oracle_continuity(orc, cfg, cases.continuity_inputs(cfg))
-    np.savez_compressed(H.golden_path("continuity_benchmark_small_corrector"),
+    np.savez_compressed(H.golden_path("continuity_benchmark_small_corrector" + tag),
                         **{n: out[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))] for n in out})
     lines = cases.oracle_ocean_stats(orc, H.double_gyre(), 3, dict(strong_drag=1))
-    with open(os.path.join(ROOT, "tests", "golden", "ocean.stats.double_gyre_strong_drag_3steps"), "w") as f:
+    with open(H.golden_path("ocean.stats.double_gyre_strong_drag_3steps" + tag, ""), "w") as f:
         f.write("\n".join(lines) + "\n")
-    for f in sorted(os.listdir(os.path.join(ROOT, "tests", "golden"))):
-        print(f, os.path.getsize(os.path.join(ROOT, "tests", "golden", f)), "bytes")
 
 
 if __name__ == "__main__":

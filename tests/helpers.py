@@ -102,11 +102,17 @@ def assert_close(a, b, name, rtol, sl=None):
 
 
 # ---- committed fixtures (tests/golden/*.npz): computational-domain slices of oracle outputs on seeded inputs
-def golden_path(name):
+def golden_tag():
+    """Fixtures exist for both orders of the mass-flux column sums (mom6x_continuity_params.sum_order): the ones of the
+    16-lane tree carry the suffix _tree16.  The order in force is abi.continuity_params_default's (MOM6X_SUMS)."""
+    return "_tree16" if abi.default_sum_order(1) == abi.SUM_TREE16 else ""
+
+
+def golden_path(name, ext=".npz"):
     import os
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ext)
 
 
 def load_golden(name):
-    with np.load(golden_path(name)) as z:
+    with np.load(golden_path(name + golden_tag())) as z:
         return {k: z[k] for k in z.files}

@@ -1,7 +1,10 @@
 """GPU parity: HIP continuity_PPM (through the C ABI) vs the oracle, bit for bit.
 
 FP64, no FMA contraction on either side, identical operation order => bit-exact is the bar
-(integer-like strictness; any index or ordering bug shows up immediately)."""
+(integer-like strictness; any index or ordering bug shows up immediately).  Both orders of the column sums are
+covered (mom6x_continuity_params.sum_order): the reference's sequential order on the three device paths that keep
+it, and the 16-lane tree of the wave-owned kernel, which the oracle restates (oracle/orc_continuity.c::tree16_sum)
+and which tests/test_oracle_cpu.py holds to the sequential order within 1e-13 of each field's range."""
 import numpy as np
 import pytest
 
@@ -11,12 +14,14 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["lds", "lds_walk", "legacy"])
+@pytest.fixture(autouse=True, params=["wave", "lds", "lds_walk", "legacy"])
 def massflux_path(request, monkeypatch):
-    """Every case runs on all device paths: the LDS-resident fused kernel (default), the same with the sequential
-    duL/duR recurrence forced (lds_walk: the fall-back of the parallel min + certificate) and the thread-per-column
-    kernels (MOM6X_MASSFLUX=legacy).  All must equal the oracle bit for bit."""
+    """Every case runs on all device paths: the wave-owned kernel (sum_order = TREE16, the default), and with the
+    reference's sequential sums the LDS-resident fused kernel, the same with the sequential duL/duR recurrence forced
+    (lds_walk: the fall-back of the parallel min + certificate) and the thread-per-column kernels
+    (MOM6X_MASSFLUX=legacy).  All must equal the oracle (run with the same sum_order) bit for bit."""
     monkeypatch.setenv("MOM6X_MASSFLUX", request.param)
+    monkeypatch.setenv("MOM6X_SUMS", "tree" if request.param == "wave" else "exact")
     return request.param
 
 

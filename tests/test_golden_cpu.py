@@ -3,9 +3,16 @@
 The fixtures are regression data of the oracle itself, not reference output (parity unpinned, DESIGN.md section 2);
 this test makes sure the checker the GPU tests rely on has not drifted."""
 import numpy as np
+import pytest
 
 from tests import cases
 from tests import helpers as H
+
+@pytest.fixture(autouse=True, params=["exact", "tree"])
+def sum_order(request, monkeypatch):
+    """Both orders of the mass-flux column sums (mom6x_continuity_params.sum_order) have their own fixtures."""
+    monkeypatch.setenv("MOM6X_SUMS", request.param)
+
 
 STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h", u_cor="u", v_cor="v")
 

@@ -34,6 +34,75 @@ def test_continuity_conserves_volume_exactly_and_matches_uhbt(orc):
     assert err.max() <= CS.tol_eta * 1.0001 + 1e-12        # the Newton solve meets ETA_TOLERANCE
 
 
+@pytest.mark.parametrize("case,nk", [("double_gyre", 2), ("benchmark_small", 8), ("benchmark_small", 75)])
+def test_tree16_sum_order_agrees_with_the_reference_order(orc, case, nk):
+    """mom6x_continuity_params.sum_order = MOM6X_SUM_TREE16 (the order of the wave-owned device kernel) against the
+    reference's sequential k sums: every output of the corrector-shaped and of the BT_cont-shaped call agrees within
+    1e-13 of the field's range (north_star: "to a stated floating-point tolerance"), the adjusted transports still sum
+    to uhbt within ETA_TOLERANCE, and each layer's volume is still conserved to round-off."""
+    gg, d, M = getattr(H, case)(nk=nk)
+    GV = abi.vgrid_default()
+    h, u, v = synth.make_state(d, M, thin_frac=0.1)
+    vr_u = np.ascontiguousarray(np.clip(0.5 + 0.6 * synth.smooth_field(d, 11, nk=d.nk, ox=1.0, oy=0.5), 0.0, 1.0))
+    vr_v = np.ascontiguousarray(np.clip(0.5 + 0.6 * synth.smooth_field(d, 12, nk=d.nk, ox=0.5, oy=1.0), 0.0, 1.0))
+    dt = 1200.0
+    res = {}
+    for order in (abi.SUM_REFERENCE, abi.SUM_TREE16):
+        CS = abi.continuity_params_default(d.nk, GV.Angstrom_H); CS.sum_order = order
+        hn, uh, vh = _cont(orc, d, M, GV, CS, u, v, h, dt)
+        uhbt = np.ascontiguousarray(uh.sum(0) * (1.0 + 0.05 * synth.smooth_field(d, 13, ox=1.0, oy=0.5)))
+        vhbt = np.ascontiguousarray(vh.sum(0) * (1.0 - 0.05 * synth.smooth_field(d, 14, ox=0.5, oy=1.0)))
+        if order == abi.SUM_REFERENCE:
+            bt_in = (uhbt, vhbt)
+        uhbt, vhbt = bt_in                                   # the same target transports for both orders
+        bt = orc.new_bt_cont(d)
+        o = dict(u_cor=np.zeros_like(h), v_cor=np.zeros_like(h), du_cor=np.zeros(d.shape2()), dv_cor=np.zeros(d.shape2()))
+        o["h"], o["uh"], o["vh"] = _cont(orc, d, M, GV, CS, u, v, h, dt, uhbt=uhbt, vhbt=vhbt, visc_rem_u=vr_u, visc_rem_v=vr_v,
+                                        BT_cont=bt, **o)
+        o.update({"BT_" + n: bt[n] for n in abi.BTCont._names})
+        res[order] = o
+        su, sv = H.interior(d, "u"), H.interior(d, "v")
+        assert (np.abs((o["uh"].sum(0) - uhbt)[su]) * dt * M[G["IareaT"]][su]).max() <= CS.tol_eta * 1.0001 + 1e-12
+        assert (np.abs((o["vh"].sum(0) - vhbt)[sv]) * dt * M[G["IareaT"]][sv]).max() <= CS.tol_eta * 1.0001 + 1e-12
+    ndiff = 0
+    for n, a in res[abi.SUM_REFERENCE].items():
+        b = res[abi.SUM_TREE16][n]
+        if n.startswith(("BT_uBT", "BT_vBT")):
+            continue     # break points of the fit: see _bt_cont_transport below
+        st = "u" if (n in ("uh", "u_cor", "du_cor") or "_u" in n or n.startswith("BT_uBT")) else ("h" if n == "h" else "v")
+        sl = (Ellipsis,) + tuple(H.interior(d, st))
+        scale = np.abs(a[sl]).max()
+        assert np.abs(a[sl] - b[sl]).max() <= 1e-13 * scale, (n, np.abs(a[sl] - b[sl]).max() / scale)
+        ndiff += np.count_nonzero(a[sl] != b[sl])
+    if nk > 2:
+        assert ndiff > 0     # the two orders are different computations (with two layers the tree IS the sequence)
+    # uBT_WW .. vBT_NN are ratios of differences of nearly equal face areas (:1376-1404), i.e. ill-conditioned by
+    # construction (and zeroed by a threshold test where the areas agree to 1e-12); what btstep uses is the transport
+    # they parametrise, and that is what must agree: find_uhbt at velocities on both sides of both break points.
+    for dirn, names in (("u", ("FA_u_EE", "FA_u_E0", "FA_u_W0", "FA_u_WW", "uBT_WW", "uBT_EE")),
+                        ("v", ("FA_v_NN", "FA_v_N0", "FA_v_S0", "FA_v_SS", "vBT_SS", "vBT_NN"))):
+        sl = H.interior(d, dirn)
+        A = [res[abi.SUM_REFERENCE]["BT_" + n][sl] for n in names]
+        B = [res[abi.SUM_TREE16]["BT_" + n][sl] for n in names]
+        for t in (-3.0, -1.0, -0.3, -0.01, 0.01, 0.3, 1.0, 3.0):
+            uu = t * np.maximum(np.abs(A[4]), np.abs(A[5])) + 1e-3 * t
+            ta, tb = _bt_cont_transport(uu, *A), _bt_cont_transport(uu, *B)
+            assert np.abs(ta - tb).max() <= 1e-12 * np.abs(ta).max(), (dirn, t, np.abs(ta - tb).max() / np.abs(ta).max())
+
+
+def _bt_cont_transport(u, FA_EE, FA_E0, FA_W0, FA_WW, uBT_WW, uBT_EE):
+    """find_uhbt (MOM_barotropic.F90:4610-4631) with the local fit of set_local_BT_cont_types (:4963-4972), vectorised."""
+    C1_3 = 1.0 / 3.0
+    uh_EE = uBT_EE * (C1_3 * (2.0 * FA_E0 + FA_EE)); uh_WW = uBT_WW * (C1_3 * (2.0 * FA_W0 + FA_WW))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        crvW = np.where(np.abs(uBT_WW) > 0.0, (C1_3 * (FA_WW - FA_W0)) / uBT_WW**2, 0.0)
+        crvE = np.where(np.abs(uBT_EE) > 0.0, (C1_3 * (FA_EE - FA_E0)) / uBT_EE**2, 0.0)
+    return np.where(u == 0.0, 0.0,
+           np.where(u < uBT_EE, (u - uBT_EE) * FA_EE + uh_EE,
+           np.where(u < 0.0, u * (FA_E0 + crvE * u**2),
+           np.where(u <= uBT_WW, u * (FA_W0 + crvW * u**2), (u - uBT_WW) * FA_WW + uh_WW))))
+
+
 def test_continuity_known_answer_uniform_flow(orc):
     # uniform h and a uniform zonal velocity on a re-entrant channel: uh = dy_Cu*u*h exactly, h unchanged
     gg, d, M = H.channel()

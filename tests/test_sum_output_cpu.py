@@ -110,5 +110,5 @@ def test_oracle_reproduces_committed_ocean_stats(orc):
     import os
     from tests import cases
     lines = cases.oracle_ocean_stats(orc, H.double_gyre(), 3, dict(strong_drag=1))
-    golden = open(os.path.join(os.path.dirname(H.golden_path("x")), "ocean.stats.double_gyre_strong_drag_3steps")).read().splitlines()
+    golden = open(H.golden_path("ocean.stats.double_gyre_strong_drag_3steps" + H.golden_tag(), "")).read().splitlines()
     assert lines == golden and len(lines) == 6 and lines[2].startswith("     0,       0.000,     0, En ")
