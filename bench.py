@@ -104,6 +104,7 @@ def build_model(args, layout, pe, device, dist=None, unique_id=None):
 KERNEL_WORDS = {
     # h, u, visc_rem in; uh out; plus u_cor (calls with uhbt) or BT_cont%h_u (the call that sets BT_cont): 5 either way
     "k_mass_flux_lds": 5.0,
+    "k_mass_flux_wave": 5.0,     # the same routine with one wavefront row per face column (sum_order TREE16, the default)
     # thread-per-column path (MOM6X_MASSFLUX=legacy): u, visc_rem, h, (h_L, h_R from k_edge) in; uh [+ u_cor] out
     "k_mass_flux<": 14.0 / 3.0,
     "k_vertvisc_remnant": 3.0,   # a(k), h in; visc_rem out

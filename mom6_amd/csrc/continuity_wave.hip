@@ -24,12 +24,26 @@
 // the oracle run with the same sum_order they are bit-identical (tests/test_continuity_gpu.py).
 #include "continuity_dev.h"
 #include "continuity_lds.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
 
 constexpr int NF = 16;   // faces along i per work-group (4 wavefronts x 4 faces): one 128-byte line per row segment
 constexpr int KL = 16;   // layer lanes per face = one DPP row
+
+// Dev tool (MOM6X_CFLAGS=-DMOM6X_MFL_TIMING python -m mom6_amd.build --force; scripts/prof_continuity.py): shader-clock
+// cycles the first wavefront of every work-group spends in each phase of the kernel, summed over the work-groups.
+#ifdef MOM6X_MFL_TIMING
+__device__ unsigned long long g_mfw_t[2][16];
+#define TICK_INIT long long t_prev_ = clock64()
+#define TICK(p) do { if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_mfw_t[DIR][p], (unsigned long long)(t_ - t_prev_)); t_prev_ = t_; } } while (0)
+#define COUNT_ITT(slot, n) do { if (threadIdx.x == 0) { atomicAdd(&g_mfw_t[0][slot], (unsigned long long)(n)); atomicAdd(&g_mfw_t[1][slot], 1ull); } } while (0)
+#else
+#define TICK_INIT
+#define TICK(p)
+#define COUNT_ITT(slot, n)
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double x) {
@@ -64,6 +78,11 @@ __device__ __forceinline__ double row_max(double s) {
   s = dmax(s, dpp_mov<DPP_MIR>(s));
   return s;
 }
+// Keeps the instruction scheduler from interleaving more than two layers of an unrolled layer loop: every layer in
+// flight holds about 24 registers of temporaries, and five of them push the kernel into scratch memory -- whose
+// reloads then queue behind the next row's LDS-DMA (the memory counter is in order).  Two layers in flight plus the
+// second wavefront of the SIMD cover the latency of a dependent FP64 chain.
+#define LAYER_FENCE(n) do { if ((n) & 1) __builtin_amdgcn_sched_barrier(0); } while (0)
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 // What a lane keeps of its MAXL layers of one face column.
@@ -91,15 +110,25 @@ __device__ __forceinline__ void flux_reg(const Col<MAXL> &C, int n, double u, do
   duhdu = C.Lf * h_marg * C.v[n];
 }
 
+// The Newton loop evaluates the same unrolled layer loop again and again with a new du.  Left alone, the compiler hoists
+// everything of a layer that does not depend on du out of the loop (both upwind variants of b - a, 0.5 (b - a),
+// 3 curv_3, ...: ~28 registers per layer) and the kernel goes to scratch memory.  An empty asm that "modifies" the
+// layer's values keeps those expressions inside the loop: they cost a few instructions, not registers.
+template <int MAXL>
+__device__ __forceinline__ void keep_in_loop(Col<MAXL> &C, int n) {
+  asm volatile("" : "+v"(C.mL[n]), "+v"(C.mR[n]), "+v"(C.mC[n]), "+v"(C.pL[n]), "+v"(C.pR[n]), "+v"(C.pC[n]), "+v"(C.u[n]), "+v"(C.v[n]));
+}
+
 // zonal_flux_adjust :1093-1242 / meridional_flux_adjust :1992-2140, iterated wavefront-uniformly; the Newton state is
-// replicated over the 16 lanes of a face's row.  STORE: keep the last evaluated transports in uh_r (the reference's
-// uh_3d argument).  `lazy`: du_max / du_min are a lower / an upper bound of the CFL limits; the first test they do not
+// replicated over the 16 lanes of a face's row.  STORE: the evaluated transports are the result (the reference's
+// uh_3d argument): store_uh(n, uh, do_I) writes them out at every evaluation of a face that is still iterating
+// (ten registers per lane less than keeping them until the end).  `lazy`: du_max / du_min are a lower / an upper bound of the CFL limits; the first test they do not
 // decide ends the solve with need_exact = true (wavefront-uniform) and the caller repeats it with the limits.
-template <int MAXL, bool STORE>
-__device__ __forceinline__ double wave_flux_adjust(const Col<MAXL> &C, bool active, double IareaMin, double uhbt,
+template <int MAXL, bool STORE, typename StoreUh>
+__device__ __forceinline__ double wave_flux_adjust(Col<MAXL> &C, bool active, double IareaMin, double uhbt,
                                                    double uh_tot_0, double duhdu_tot_0, double du_max, double du_min,
                                                    double tol_eta_cs, double tol_vel, int better_iter, bool lazy,
-                                                   bool &need_exact, double (&uh_r)[MAXL]) {
+                                                   bool &need_exact, StoreUh store_uh) {
   const int max_itts = 20;
   double du = 0.0;
   double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0;
@@ -107,6 +136,7 @@ __device__ __forceinline__ double wave_flux_adjust(const Col<MAXL> &C, bool acti
   bool do_I = active;
   bool max_lazy = lazy, min_lazy = lazy, undecided = false;
   need_exact = false;
+  int n_eval = 0;
   for (int itt = 1; itt <= max_itts; itt++) {
     if (do_I) {
       double tol_eta;
@@ -149,13 +179,16 @@ __device__ __forceinline__ double wave_flux_adjust(const Col<MAXL> &C, bool acti
     if (!wave_any(do_I)) break;
 
     if ((itt < max_itts) || STORE) {
+      n_eval++;
       double s_uh = 0.0, s_dd = 0.0;
 #pragma unroll
       for (int n = 0; n < MAXL; n++) {
         double uh, dd;
+        keep_in_loop(C, n);
         flux_reg(C, n, C.u[n] + du * C.v[n], uh, dd);
-        if (STORE) uh_r[n] = do_I ? uh : uh_r[n];
+        if (STORE) store_uh(n, uh, do_I);   // straight to memory: the last evaluation of a face is the one that stays
         s_uh = s_uh + uh; s_dd = s_dd + dd;
+        LAYER_FENCE(n);
       }
       if (itt < max_itts) {
         const double err = row_sum(s_uh) - uhbt, dtot = row_sum(s_dd);
@@ -166,98 +199,107 @@ __device__ __forceinline__ double wave_flux_adjust(const Col<MAXL> &C, bool acti
       }
     }
   }
+  COUNT_ITT(STORE ? 8 : 9, n_eval);   // (slot 8 / 9 of g_mfw_t[0]: flux re-evaluations of the first / second solve; g_mfw_t[1]: solves)
+  (void)n_eval;
   return du;
 }
 
+// ---- staging through LDS ------------------------------------------------------------------------------------------
+// A wavefront (4 faces along i = 32 bytes of every pitched row) MARCHES along j.  Everything row jj needs is copied
+// HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, no registers) into the wavefront's OWN region
+// while the Newton solves of row jj-1 run from registers, and is picked up with ds_read_b64 once it has landed: no
+// barrier, no other wavefront involved (a first version staged whole 128-byte lines per work-group: the two barriers
+// per row tied four wavefronts with different Newton iteration counts together, 52 % of a wavefront's life was spent
+// waiting).  The four wavefronts of a work-group cover the four quarters of the same lines, so the lines meet in
+// that CU's L1 / that XCD's L2.  The region holds segments of 4 doubles:
+//   3-D slots [slot][k][4]:  DIR = 1:  h rows jj-1 .. jj+3 (the stencil of cell jj+1), u row jj, visc_rem row jj
+//                            DIR = 0:  h cells i0-4..i0-1 | i0..i0+3 | i0+4..i0+7 of row jj, u, visc_rem
+//   2-D segments (metrics of the row, see L2D below).
+// The 64 lanes (f, q) of a wavefront read 64 consecutive doubles of a slot (k = q, column f): no bank conflict.
+// A meridional face (i, jj) lies between the cells jj and jj+1: its minus cell is the plus cell of the previous row of
+// the march, so each step reconstructs ONE cell per face (the stand-alone kernel did two) and reads five rows of h of
+// which four come from L2.
+struct L2D { int plane, dj, dcol; };   // metric plane (MOM6X_G_*; -1: the uhbt argument), row offset, column offset in segments
+template <int DIR> struct Stage;
+template <> struct Stage<1> {
+  static constexpr int NS3 = 7, NL2 = 15, SU = 5, SV = 6;
+  __device__ static L2D line(int q) {
+    switch (q) {
+      case 0: return {MOM6X_G_IdyT, 0, 0};    case 1: return {MOM6X_G_IdyT, 1, 0};   case 2: return {MOM6X_G_dx_Cv, 0, 0};
+      case 3: return {MOM6X_G_IareaT, 0, 0};  case 4: return {MOM6X_G_IareaT, 1, 0}; case 5: return {MOM6X_G_dyT, 0, 0};
+      case 6: return {MOM6X_G_dyT, 1, 0};     case 7: return {MOM6X_G_dyCv, 0, 0};   case 8: return {MOM6X_G_mask2dCv, 0, 0};
+      case 9: return {-1, 0, 0};
+      default: return {MOM6X_G_mask2dT, q - 11, 0};   // 10..14: rows jj-1 .. jj+3
+    }
+  }
+};
+template <> struct Stage<0> {
+  static constexpr int NS3 = 5, NL2 = 13, SU = 3, SV = 4;
+  __device__ static L2D line(int q) {
+    switch (q) {
+      case 0: return {MOM6X_G_IdxT, 0, 0};    case 1: return {MOM6X_G_IdxT, 0, 1};   case 2: return {MOM6X_G_dy_Cu, 0, 0};
+      case 3: return {MOM6X_G_IareaT, 0, 0};  case 4: return {MOM6X_G_IareaT, 0, 1}; case 5: return {MOM6X_G_dxT, 0, 0};
+      case 6: return {MOM6X_G_dxT, 0, 1};     case 7: return {MOM6X_G_dxCu, 0, 0};   case 8: return {MOM6X_G_mask2dCu, 0, 0};
+      case 9: return {-1, 0, 0};
+      default: return {MOM6X_G_mask2dT, 0, q - 11};   // 10..12: segments i0-4 | i0 | i0+4
+    }
+  }
+};
+
+__device__ __forceinline__ void glds16(const double *src, double *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// Everything of one face column after the reconstruction: first sweep, flux_adjust towards uhbt, stores, flux
+// thickness, set_*_BT_cont.  All lanes of the wavefront call it (row reductions inside).
 template <int DIR, int MAXL>
-__global__ void __launch_bounds__(NF * KL, (MAXL > 5) ? 1 : 2)
-k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
-  // Tile <-> block id as in continuity_lds.hip: block b runs on XCD b % 8 (observed); every XCD gets a band of
-  // E.rows tile rows and walks it along i (zonal) or along j (meridional: neighbours share 5 of their 6 rows of h).
-  const int tile = blockIdx.x;
-  const int band = tile & 7, slot = tile >> 3;
-  const int bx = DIR ? slot / E.rows : slot % E.gx;
-  const int by = band * E.rows + (DIR ? slot % E.rows : slot / E.gx);
-  if (by >= E.gy) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int fl = (tid >> 6) * 4 + (lane >> 4), kl = lane & 15;
-  // tiles start on 128-byte lines of the pitched rows: the four wavefronts of a work-group read and write the four
-  // quarters of the same lines at about the same time
-  const int i = E.i_base + bx * NF + fl, j = A.b0 + by;
-  const bool active = (i >= A.a0 && i <= A.a1);
-  if (!wave_any(active)) return;
-  const int nk = d.nk;
-  const int st = DIR ? d.pitch : 1;
-  const size_t slab = (size_t)d.slab;
-  const DirMetrics D = dir_metrics<DIR>(G, d);
-  const size_t f2 = ix2(d, active ? i : A.a1, j);   // inactive lanes alias the last face (never written)
+__device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, const LdsArgs &E, size_t rowb, unsigned lane2,
+                                            unsigned lane3, size_t slab, bool active, int kl, int nk, double IareaMin,
+                                            double uhbt_f, double dC_f, double dx_W_in, double dx_E_in, const double *G,
+                                            int pitch) {
+  // Addresses: (uniform base pointer + uniform byte offset) + a 32-bit per-lane byte offset that never changes
+  // (lane2: the face's column in a row; lane3: + the lane's first layer) -- the scalar-base addressing mode, one
+  // register per lane instead of a 64-bit address per store that the compiler would keep alive across the march.
+  auto st2 = [&](double *base, double v) { *(double *)((char *)base + rowb + lane2) = v; };
+  auto st3 = [&](double *base, int n, double v) { *(double *)((char *)base + (rowb + (size_t)n * KL * slab * 8) + lane3) = v; };
   const double dt = A.dt;
   const bool use_visc_rem = (A.visc_rem != nullptr);
   const bool need_adjust = (A.uhbt != nullptr) || A.set_BT_cont;
 
-  Col<MAXL> C;
-  C.dt = dt; C.IdT_m = D.IdT[f2]; C.IdT_p = D.IdT[f2 + st];
-  C.Lf = D.Lface[f2] * 1.0;   // G%dy_Cu * por_face_areaU (== 1)
-
-  // ---- loads: u, visc_rem and the six h values (cells f-2 .. f+3 along the sweep direction) of every layer --------
-  {
-    double m6[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++) m6[q] = active ? D.mask2dT[f2 + (size_t)(q - 2) * st] : 0.0;
-    double h6[MAXL][6];
-#pragma unroll
-    for (int n = 0; n < MAXL; n++) {
-      const int k = kl + KL * n;
-      const bool on = active && (k < nk);
-      const size_t f = f2 + (size_t)(on ? k : 0) * slab;
-      C.u[n] = on ? A.u[f] : 0.0;
-      C.v[n] = on ? (use_visc_rem ? A.visc_rem[f] : 1.0) : 0.0;
-#pragma unroll
-      for (int q = 0; q < 6; q++) h6[n][q] = on ? A.h_in[f + (size_t)(q - 2) * st] : 0.0;
-    }
-    // PPM_reconstruction + limiter of the face's two cells (their stencils share four values and two slopes)
-#pragma unroll
-    for (int n = 0; n < MAXL; n++) {
-      const bool on = active && (kl + KL * n < nk);
-      double hl = 0.0, hr = 0.0, c3 = 0.0;
-      if (on) edge5(&h6[n][0], &m6[0], E.scheme, E.monotonic, E.h_min, hl, hr, c3);
-      C.mL[n] = hl; C.mR[n] = hr; C.mC[n] = c3;
-      hl = 0.0; hr = 0.0; c3 = 0.0;
-      if (on) edge5(&h6[n][1], &m6[1], E.scheme, E.monotonic, E.h_min, hl, hr, c3);
-      C.pL[n] = hl; C.pR[n] = hr; C.pC[n] = c3;
-    }
-  }
-  // every other global load of the kernel is issued here as well (the memory counter is in order)
-  const double IareaMin = dmin(D.IareaT[f2], D.IareaT[f2 + st]);
-  const double uhbt_f = (A.uhbt != nullptr && active) ? A.uhbt[f2] : 0.0;
-  const double dC_f = A.set_BT_cont ? D.dC[f2] : 0.0;
-  const double dx_W = D.dT[f2], dx_E = D.dT[f2 + st];
-  const double maskC = D.maskC[f2];
-
   // ---- limits on du that keep the CFL number between -1 and 1 (:646-723) --------------------------------------
-  double visc_rem_max = 1.0, du_max_CFL = 0.0, du_min_CFL = 0.0;
+  double du_max_CFL = 0.0, du_min_CFL = 0.0;
   const double CFL_dt = A.CFL_limit_adjust / dt;
   bool lazy = false;
-  if (need_adjust) {
-    if (use_visc_rem && A.use_visc_rem_max) {
+  auto calc_visc_rem_max = [&]() {   // (recomputed where it is needed: an order-independent max)
+    double vrm = 1.0;
+    if (need_adjust && use_visc_rem && A.use_visc_rem_max) {
       double pm = 0.0;
 #pragma unroll
       for (int n = 0; n < MAXL; n++)
         if (kl + KL * n < nk) pm = dmax(pm, C.v[n]);
-      visc_rem_max = row_max(pm);
+      vrm = row_max(pm);
     }
-  }
-  double I_vrm = 0.0;
-  if (visc_rem_max > 0.0) I_vrm = 1.0 / visc_rem_max;
+    return vrm;
+  };
   // The exact limits with visc_rem: a k-recurrence (two divisions per layer), walked by the wavefront: the lane that
-  // owns layer k broadcasts its operands to the row.  Wavefront-uniform; rarely needed.
+  // owns layer k broadcasts its operands to the row.  Wavefront-uniform; rarely needed, so the metrics are read again
+  // from memory here rather than kept in registers through the solves.
   auto exact_bounds = [&]() {
+    const size_t f2 = (rowb + lane2) / 8;
+    const double dx_W = gm(G, Dm{0, 0, 0, 0, 0, 0, 0, (int)slab}, DIR ? MOM6X_G_dyT : MOM6X_G_dxT)[f2];
+    const double dx_E = gm(G, Dm{0, 0, 0, 0, 0, 0, 0, (int)slab}, DIR ? MOM6X_G_dyT : MOM6X_G_dxT)[f2 + (DIR ? pitch : 1)];
+    const double maskC = gm(G, Dm{0, 0, 0, 0, 0, 0, 0, (int)slab}, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[f2];
+    const double vrm = calc_visc_rem_max();
+    double I_vrm = 0.0;
+    if (vrm > 0.0) I_vrm = 1.0 / vrm;
     du_max_CFL = 2.0 * (CFL_dt * dx_W) * I_vrm;
     du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
       const double q_max = (dx_W * CFL_dt - C.u[n]) / C.v[n];
       const double q_min = -(dx_E * CFL_dt + C.u[n]) / C.v[n];
+#pragma unroll 1
       for (int q = 0; q < KL; q++) {
         if (q + KL * n >= nk) break;
         const double uk = __shfl(C.u[n], q, KL), vrem = __shfl(C.v[n], q, KL);
@@ -270,6 +312,10 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     du_min_CFL = dmin(du_min_CFL, 0.0);
   };
   if (need_adjust) {
+    const double dx_W = dx_W_in, dx_E = dx_E_in;
+    const double vrm = calc_visc_rem_max();
+    double I_vrm = 0.0;
+    if (vrm > 0.0) I_vrm = 1.0 / vrm;
     // min_k (dx_W*CFL_dt - u_k) and min_k (dx_E*CFL_dt + u_k): order-independent, exact
     double nmin = 1.0e300, mmin = 1.0e300;
     bool vr_ok = true;
@@ -298,21 +344,25 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
       lazy = true;
     }
   }
+  TICK(1);
 
   // ---- first sweep: layer transports and their column sums (:615-668) -------------------------------------------
-  double uh_r[MAXL];
+  auto store_uh = [&](int n, double uh, bool on) { if (on && (kl + KL * n < nk)) st3(A.uh, n, uh); };
   double uh_tot_0 = 0.0, duhdu_tot_0 = 0.0;
   auto first_sweep = [&]() {
     double s_uh = 0.0, s_dd = 0.0;
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
-      double dd;
-      flux_reg(C, n, C.u[n], uh_r[n], dd);
-      s_uh = s_uh + uh_r[n]; s_dd = s_dd + dd;
+      double uh, dd;
+      flux_reg(C, n, C.u[n], uh, dd);
+      store_uh(n, uh, active);
+      s_uh = s_uh + uh; s_dd = s_dd + dd;
+      LAYER_FENCE(n);
     }
     if (need_adjust) { uh_tot_0 = row_sum(s_uh); duhdu_tot_0 = row_sum(s_dd); }
   };
   first_sweep();
+  TICK(2);
 
   // ---- flux_adjust towards uhbt; uh, u_cor, du_cor ---------------------------------------------------------------
   double du_fin = 0.0;
@@ -320,25 +370,20 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   if (corrected) {
     bool redo;
     du_fin = wave_flux_adjust<MAXL, true>(C, active, IareaMin, uhbt_f, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
-                                          A.tol_eta, A.tol_vel, A.better_iter, lazy, redo, uh_r);
+                                          A.tol_eta, A.tol_vel, A.better_iter, lazy, redo, store_uh);
     if (redo) {   // wavefront-uniform
       exact_bounds(); lazy = false;
       first_sweep();   // (the abandoned solve has overwritten some of the first transports)
       du_fin = wave_flux_adjust<MAXL, true>(C, active, IareaMin, uhbt_f, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
-                                            A.tol_eta, A.tol_vel, A.better_iter, false, redo, uh_r);
+                                            A.tol_eta, A.tol_vel, A.better_iter, false, redo, store_uh);
     }
-    if (active && kl == 0 && A.du_cor) A.du_cor[f2] = du_fin;
+    if (active && kl == 0 && A.du_cor) st2(A.du_cor, du_fin);
   }
-  if (active) {
+  TICK(3);
+  if (active && corrected && A.u_cor) {
 #pragma unroll
-    for (int n = 0; n < MAXL; n++) {
-      const int k = kl + KL * n;
-      if (k < nk) {
-        const size_t f = f2 + (size_t)k * slab;
-        A.uh[f] = uh_r[n];
-        if (corrected && A.u_cor) A.u_cor[f] = C.u[n] + du_fin * C.v[n];
-      }
-    }
+    for (int n = 0; n < MAXL; n++)
+      if (kl + KL * n < nk) st3(A.u_cor, n, C.u[n] + du_fin * C.v[n]);
   }
 
   // ---- zonal/merid_flux_thickness (:975 / :1866) at the corrected velocities ------------------------------------
@@ -358,10 +403,11 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
         double hu = E.marginal ? h_marg : h_avg;
         if (use_visc_rem) hu = hu * (C.v[n] * 1.0);
         else hu = hu * 1.0;
-        E.h_face[f2 + (size_t)k * slab] = hu;
+        st3(E.h_face, n, hu);
       }
     }
   }
+  TICK(4);
   if (!A.set_BT_cont) return;
 
   // ---- set_zonal_BT_cont :1246-1409 / set_merid_BT_cont :2143-2304 -----------------------------------------------
@@ -369,20 +415,21 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   double du0;
   {
     bool redo;
-    double dummy[MAXL];
+    auto no_store = [](int, double, bool) {};
     du0 = wave_flux_adjust<MAXL, false>(C, active, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
-                                        A.tol_eta, A.tol_vel, A.better_iter, lazy, redo, dummy);
+                                        A.tol_eta, A.tol_vel, A.better_iter, lazy, redo, no_store);
     if (redo) {
       exact_bounds(); lazy = false;
       du0 = wave_flux_adjust<MAXL, false>(C, active, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
-                                          A.tol_eta, A.tol_vel, A.better_iter, false, redo, dummy);
+                                          A.tol_eta, A.tol_vel, A.better_iter, false, redo, no_store);
     }
   }
+  TICK(5);
   const double du_CFL = (CFL_min * Idt) * dC_f;
   // duR / duL (:1293-1316): min / max of the quotients (sum_order TREE16's definition)
   double duR = dmin(0.0, du0 - du_CFL), duL = dmax(0.0, du0 + du_CFL);
   {
-    const double vrl_floor = min_visc_rem * visc_rem_max;
+    const double vrl_floor = min_visc_rem * calc_visc_rem_max();
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
       if (kl + KL * n < nk) {
@@ -396,53 +443,218 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     }
     duR = row_min(duR); duL = row_max(duL);
   }
+  TICK(6);
   // three trial velocities (:1330-1349), five column sums
   double FAmt_L = 0.0, FAmt_R = 0.0, FAmt_0 = 0.0, uhtot_L = 0.0, uhtot_R = 0.0;
 #pragma unroll
   for (int n = 0; n < MAXL; n++) {
-    double uh_0, uh_L, uh_R, d_0, d_L, d_R;
+    double uh_0, d_0;
     flux_reg(C, n, C.u[n] + du0 * C.v[n], uh_0, d_0);
+    FAmt_0 = FAmt_0 + d_0;
+    LAYER_FENCE(n);
+  }
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) {
+    double uh_L, d_L;
     flux_reg(C, n, C.u[n] + duL * C.v[n], uh_L, d_L);
+    FAmt_L = FAmt_L + d_L; uhtot_L = uhtot_L + uh_L;
+    LAYER_FENCE(n);
+  }
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) {
+    double uh_R, d_R;
     flux_reg(C, n, C.u[n] + duR * C.v[n], uh_R, d_R);
-    FAmt_0 = FAmt_0 + d_0; FAmt_L = FAmt_L + d_L; FAmt_R = FAmt_R + d_R;
-    uhtot_L = uhtot_L + uh_L; uhtot_R = uhtot_R + uh_R;
+    FAmt_R = FAmt_R + d_R; uhtot_R = uhtot_R + uh_R;
+    LAYER_FENCE(n);
   }
   FAmt_0 = row_sum(FAmt_0); FAmt_L = row_sum(FAmt_L); FAmt_R = row_sum(FAmt_R);
   uhtot_L = row_sum(uhtot_L); uhtot_R = row_sum(uhtot_R);
+  TICK(7);
   if (!(active && kl == 0)) return;
 
   double FA_0 = FAmt_0, FA_avg = FAmt_0;
   if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
   if (FA_avg > dmax(FA_0, FAmt_L)) FA_avg = dmax(FA_0, FAmt_L);
   else if (FA_avg < dmin(FA_0, FAmt_L)) FA_0 = FA_avg;
-  A.FA_m0[f2] = FA_0; A.FA_mm[f2] = FAmt_L;
-  if (fabs(FA_0 - FAmt_L) <= 1e-12 * FA_0) A.uBT_mm[f2] = 0.0;
-  else A.uBT_mm[f2] = (1.5 * (duL - du0)) * ((FAmt_L - FA_avg) / (FAmt_L - FA_0));
+  st2(A.FA_m0, FA_0); st2(A.FA_mm, FAmt_L);
+  if (fabs(FA_0 - FAmt_L) <= 1e-12 * FA_0) st2(A.uBT_mm, 0.0);
+  else st2(A.uBT_mm, (1.5 * (duL - du0)) * ((FAmt_L - FA_avg) / (FAmt_L - FA_0)));
 
   FA_0 = FAmt_0; FA_avg = FAmt_0;
   if ((duR - du0) != 0.0) FA_avg = uhtot_R / (duR - du0);
   if (FA_avg > dmax(FA_0, FAmt_R)) FA_avg = dmax(FA_0, FAmt_R);
   else if (FA_avg < dmin(FA_0, FAmt_R)) FA_0 = FA_avg;
-  A.FA_p0[f2] = FA_0; A.FA_pp[f2] = FAmt_R;
-  if (fabs(FAmt_R - FA_0) <= 1e-12 * FA_0) A.uBT_pp[f2] = 0.0;
-  else A.uBT_pp[f2] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
+  st2(A.FA_p0, FA_0); st2(A.FA_pp, FAmt_R);
+  if (fabs(FAmt_R - FA_0) <= 1e-12 * FA_0) st2(A.uBT_pp, 0.0);
+  else st2(A.uBT_pp, (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0)));
+}
+
+constexpr int SEG = 4;   // doubles per segment = faces per wavefront
+
+template <int DIR, int MAXL>
+__global__ void __launch_bounds__(NF * KL, (MAXL > 5) ? 1 : 2)
+k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
+  using ST = Stage<DIR>;
+  extern __shared__ double S_all[];
+  // A work-group = a strip of 16 faces along i (bx) and E.rows consecutive rows (chunk): E.gx strips, E.gy chunks;
+  // its wavefronts are independent of each other.
+  const int bx = blockIdx.x % E.gx, chunk = blockIdx.x / E.gx;
+  const int j0 = A.b0 + chunk * E.rows, j1 = min(j0 + E.rows - 1, A.b1);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fw = lane >> 4, kl = lane & 15;
+  const int i0 = E.i_base + bx * NF + w * SEG, i = i0 + fw;   // i0: the wavefront's first face
+  const bool active = (i >= A.a0 && i <= A.a1);
+  if (!wave_any(active)) return;
+  const int nk = d.nk;
+  const size_t slab = (size_t)d.slab;
+  const bool use_visc_rem = (A.visc_rem != nullptr);
+  const int ns3 = use_visc_rem ? ST::NS3 : ST::NS3 - 1;   // (visc_rem is the last 3-D slot)
+  // This wavefront's region: NS3 slots of KP = 16 * MAXL layers (a compile-time stride: every LDS address of a lane is
+  // ONE base register + an immediate), then the 2-D segments.
+  constexpr int KP = KL * MAXL;
+  constexpr int WAVE_LDS = SEG * (ST::NS3 * KP + 16);   // doubles (NL2 <= 16)
+  double *S = S_all + (size_t)w * WAVE_LDS;
+  double *S2 = S + (size_t)ST::NS3 * KP * SEG;
+  TICK_INIT;
+
+  // ---- DMA roles: lane = (segment sg of a round of 32, 16-byte piece pp) ----------------------------------------------
+  // Source address = uniform (array + row + 32 layers per round) + ONE per-lane 32-bit byte offset.
+  const int sg = lane >> 1, pp = lane & 1;
+  const unsigned dma3 = (unsigned)(((size_t)sg * slab + (size_t)(pp * 2)) * 8);
+  const L2D L2 = ST::line(sg < ST::NL2 ? sg : 0);
+  const unsigned dma2 = (unsigned)(((ptrdiff_t)(L2.plane >= 0 ? L2.plane : 0) * (ptrdiff_t)slab + (ptrdiff_t)(L2.dj + d.joff) * d.pitch +
+                                    (ptrdiff_t)L2.dcol * SEG + d.ioff + pp * 2) * 8);   // from G; >= 0: dj + joff >= 0, dcol*SEG + ioff >= 0
+  const bool do2 = (sg < ST::NL2) && (L2.plane >= 0);
+  const bool do_uhbt = (sg == 9) && (A.uhbt != nullptr);
+  auto issue_dma = [&](int jj) {
+    const size_t row0 = ((size_t)(i0 + d.ioff) + (size_t)(jj + d.joff) * (size_t)d.pitch) * 8;   // (i0, jj) in a plane, bytes
+#pragma unroll
+    for (int s = 0; s < ST::NS3; s++) {
+      if (s >= ns3) break;
+      const double *arr;
+      ptrdiff_t shift;
+      if (DIR) { arr = (s < 5) ? A.h_in : (s == 5 ? A.u : A.visc_rem); shift = (s < 5) ? (ptrdiff_t)(s - 1) * d.pitch * 8 : 0; }
+      else     { arr = (s < 3) ? A.h_in : (s == 3 ? A.u : A.visc_rem); shift = (s < 3) ? (ptrdiff_t)(s - 1) * SEG * 8 : 0; }
+      const char *base = (const char *)arr + (ptrdiff_t)row0 + shift;
+      for (int r = 0; r * 32 < nk; r++) {
+        if (r * 32 + sg < nk)
+          glds16((const double *)(base + (size_t)r * 32 * slab * 8 + dma3), S + (size_t)(s * KP + r * 32) * SEG);
+      }
+    }
+    const char *g2 = (const char *)G + ((size_t)i0 + (size_t)jj * (size_t)d.pitch) * 8;
+    if (do2) glds16((const double *)(g2 + dma2), S2);
+    if (do_uhbt) glds16((const double *)((const char *)A.uhbt + row0 + pp * 16), S2);   // (lane-linear: segment 9 again)
+  };
+
+  // ---- where a lane finds its values in LDS ------------------------------------------------------------------------
+  constexpr int NH = DIR ? 5 : 6;
+  const double *Sb = S + kl * SEG + fw;        // layer kl, column fw of slot 0; layer n adds n * 16 segments
+  const double *L = S2 + fw;                   // the 2-D segments
+  // DIR = 1: h row jj-1+q = slot q.  DIR = 0: cell i-2+q = column c = SEG + fw - 2 + q of the 12 cells i0-4 .. i0+7,
+  // slot c >> 2, column c & 3: relative to Sb that is a per-lane offset xo[q] (fw = 0..3, q = 0..5: c = 2..9)
+  int xo[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const int c = SEG + fw - 2 + q;
+    xo[q] = (c >> 2) * KP * SEG + (c & 3) - fw;
+  }
+  // per-lane byte offsets of the stores (see face_column)
+  const unsigned lane2 = (unsigned)((size_t)((active ? i : A.a1) + d.ioff) * 8);   // inactive lanes alias the last face (never written)
+  const unsigned lane3 = lane2 + (unsigned)((size_t)kl * slab * 8);
+
+  Col<MAXL> C;
+  C.dt = A.dt;
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) { C.pL[n] = 0.0; C.pR[n] = 0.0; C.pC[n] = 0.0; }
+
+  const int jstart = DIR ? j0 - 1 : j0;   // meridional: a first step that only reconstructs cell j0
+  issue_dma(jstart);
+  for (int jj = jstart; jj <= j1; jj++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row jj has landed
+    const bool face_row = (!DIR) || (jj >= j0);
+    // ---- LDS -> registers, layer by layer, with the PPM reconstruction + limiter on the way ---------------------------
+    double IareaMin, uhbt_f, dC_f, dx_W, dx_E;
+    {
+      double m6[6];
+#pragma unroll
+      for (int q = 0; q < NH; q++) {
+        const double mv = DIR ? L[(10 + q) * SEG] : L[10 * SEG + SEG - 2 + q];
+        m6[q] = active ? mv : 0.0;
+      }
+#pragma unroll
+      for (int n = 0; n < MAXL; n++) {
+        const bool on = active && (kl + KL * n < nk);   // (a layer beyond nk reads the segments behind its slot: discarded)
+        double hst[6];
+#pragma unroll
+        for (int q = 0; q < NH; q++) {
+          const double hv = DIR ? Sb[(q * KP + n * KL) * SEG] : Sb[xo[q] + n * KL * SEG];
+          hst[q] = on ? hv : 0.0;
+        }
+        const double uu = Sb[(ST::SU * KP + n * KL) * SEG];
+        const double vv = use_visc_rem ? Sb[(ST::SV * KP + n * KL) * SEG] : 1.0;
+        C.u[n] = on ? uu : 0.0;
+        C.v[n] = on ? vv : 0.0;
+        double hl = 0.0, hr = 0.0, c3 = 0.0;
+        if (DIR) {   // the plus cell of the last step is this step's minus cell
+          C.mL[n] = C.pL[n]; C.mR[n] = C.pR[n]; C.mC[n] = C.pC[n];
+          if (on) edge5(&hst[0], &m6[0], E.scheme, E.monotonic, E.h_min, hl, hr, c3);
+          C.pL[n] = hl; C.pR[n] = hr; C.pC[n] = c3;
+        } else {
+          if (on) edge5(&hst[0], &m6[0], E.scheme, E.monotonic, E.h_min, hl, hr, c3);
+          C.mL[n] = hl; C.mR[n] = hr; C.mC[n] = c3;
+          hl = 0.0; hr = 0.0; c3 = 0.0;
+          if (on) edge5(&hst[1], &m6[1], E.scheme, E.monotonic, E.h_min, hl, hr, c3);
+          C.pL[n] = hl; C.pR[n] = hr; C.pC[n] = c3;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      constexpr int ip = DIR ? SEG : 1;   // the plus neighbour: the next segment (DIR = 1: row jj+1) or the next column
+      C.IdT_m = L[0]; C.IdT_p = L[ip];
+      C.Lf = L[2 * SEG] * 1.0;   // G%dy_Cu * por_face_areaU (== 1)
+      IareaMin = dmin(L[3 * SEG], L[3 * SEG + ip]);
+      dx_W = L[5 * SEG]; dx_E = L[5 * SEG + ip];
+      dC_f = A.set_BT_cont ? L[7 * SEG] : 0.0;
+      uhbt_f = (A.uhbt != nullptr && active) ? L[9 * SEG] : 0.0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // row jj is in registers: its space is free ...
+    if (jj < j1) issue_dma(jj + 1);                        // ... and fills while this row's Newton solves run
+    if (!face_row) continue;
+    TICK(0);
+    const size_t rowb = (size_t)(jj + d.joff) * (size_t)d.pitch * 8;
+    face_column<DIR, MAXL>(C, A, E, rowb, lane2, lane3, slab, active, kl, nk, IareaMin, uhbt_f, dC_f, dx_W, dx_E, G, d.pitch);
+  }
 }
 
 template <int DIR, int MAXL>
 int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
+  using ST = Stage<DIR>;
   LdsArgs E = E0;
-  E.gx = (A.a1 - E.i_base + NF) / NF; E.gy = A.b1 - A.b0 + 1;
-  E.rows = (E.gy + 7) / 8;
+  const int nrow = A.b1 - A.b0 + 1;
+  E.gx = (A.a1 - E.i_base + NF) / NF;
+  E.rows = 16;                              // rows a work-group marches over
+  E.gy = (nrow + E.rows - 1) / E.rows;      // chunks
   E.retry = nullptr; E.force_walk = 0;
-  const dim3 grid(8 * E.gx * E.rows, 1, 1);
+  const size_t lds_bytes = sizeof(double) * 4 * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16));   // 4 x the kernel's WAVE_LDS
+  auto kern = k_mass_flux_wave<DIR, MAXL>;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  const dim3 grid(E.gx * E.gy, 1, 1);
   if (c->prof_on) prof_begin(c, DIR ? "k_mass_flux_wave<1>" : "k_mass_flux_wave<0>");
-  hipLaunchKernelGGL((k_mass_flux_wave<DIR, MAXL>), grid, dim3(NF * KL, 1, 1), 0, c->stream, c->d, c->G, A, E);
+  hipLaunchKernelGGL(kern, grid, dim3(NF * KL, 1, 1), lds_bytes, c->stream, c->d, c->G, A, E);
   if (c->prof_on) prof_end(c);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }
 
 }  // namespace
+
+#ifdef MOM6X_MFL_TIMING
+extern "C" int mom6x_debug_mfw_timing(unsigned long long *out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mfw_t), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mfw_t), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
 
 bool mass_flux_wave_usable(int nk) { return nk <= 8 * KL; }
 

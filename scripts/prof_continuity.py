@@ -32,23 +32,28 @@ modes = {
 }
 import ctypes
 timing = hasattr(dyc.lib, "mom6x_debug_mfl_timing")   # library built with -DMOM6X_MFL_TIMING
+wave = (dyc.cont_params.sum_order == abi.SUM_TREE16)   # the wave-owned kernel (default); MOM6X_SUMS=exact: the LDS kernel
+tfun = dyc.lib.mom6x_debug_mfw_timing if (timing and wave) else (dyc.lib.mom6x_debug_mfl_timing if timing else None)
 PH = ["load+PPM", "bounds", "sweep0+sum", "adjust(uhbt)", "store+h_face", "adjust(du0)", "duL/duR rec", "3 trial sweeps",
       "-", "-", "-", "-", "-", "-", "-", "-"]
 only = os.environ.get("PROF_MODES")   # e.g. PROF_MODES=full,adjust
 if only:
     modes = {k: v for k, v in modes.items() if k in only.split(",")}
-for path in ("lds",) if (timing or only) else ("lds", "legacy"):
+for path in ("lds",) if (timing or only or wave) else ("lds", "legacy"):
     os.environ["MOM6X_MASSFLUX"] = path
     for name, kw in modes.items():
         dyc.continuity_PPM(u, v, h, hp, uh, vh, dt, **kw); dyc.sync()
         if timing:
-            buf = (ctypes.c_ulonglong * 32)(); dyc.lib.mom6x_debug_mfl_timing(buf, 1)
+            buf = (ctypes.c_ulonglong * 32)(); tfun(buf, 1)
         prof_enable(dyc, True); prof_reset(dyc)
         dyc.continuity_PPM(u, v, h, hp, uh, vh, dt, **kw); dyc.sync()
         rep = prof_report(dyc); prof_enable(dyc, False)
         if timing:
-            dyc.lib.mom6x_debug_mfl_timing(buf, 1)
+            tfun(buf, 1)
             for dr in (0, 1):
                 tot = float(sum(buf[dr * 16:dr * 16 + 8])) or 1.0
                 print("   phases dir", dr, " ".join(f"{PH[q]}={100 * buf[dr * 16 + q] / tot:.1f}%" for q in range(8)), f"total={tot:.3e} cyc", f"walk fall-backs={buf[dr * 16 + 15]}")
+            if wave:
+                print("   flux re-evaluations per wavefront solve: towards uhbt %.2f, towards zero transport %.2f" %
+                      (buf[8] / max(buf[16 + 8], 1), buf[9] / max(buf[16 + 9], 1)))
         print(path, name, " ".join(f"{k}={v[1]:.2f}" for k, v in sorted(rep.items())), "sum=%.2f ms" % sum(v[1] for v in rep.values()), flush=True)
