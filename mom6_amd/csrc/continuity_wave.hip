@@ -38,10 +38,14 @@ constexpr int KL = 16;   // layer lanes per face = one DPP row
 __device__ unsigned long long g_mfw_t[2][16];
 #define TICK_INIT long long t_prev_ = clock64()
 #define TICK(p) do { if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_mfw_t[DIR][p], (unsigned long long)(t_ - t_prev_)); t_prev_ = t_; } } while (0)
+#define TICK_PARAM , long long &t_prev_
+#define TICK_ARG , t_prev_
 #define COUNT_ITT(slot, n) do { if (threadIdx.x == 0) { atomicAdd(&g_mfw_t[0][slot], (unsigned long long)(n)); atomicAdd(&g_mfw_t[1][slot], 1ull); } } while (0)
 #else
 #define TICK_INIT
 #define TICK(p)
+#define TICK_PARAM
+#define TICK_ARG
 #define COUNT_ITT(slot, n)
 #endif
 
@@ -257,7 +261,7 @@ template <int DIR, int MAXL>
 __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, const LdsArgs &E, size_t rowb, unsigned lane2,
                                             unsigned lane3, size_t slab, bool active, int kl, int nk, double IareaMin,
                                             double uhbt_f, double dC_f, double dx_W_in, double dx_E_in, const double *G,
-                                            int pitch) {
+                                            int pitch TICK_PARAM) {
   // Addresses: (uniform base pointer + uniform byte offset) + a 32-bit per-lane byte offset that never changes
   // (lane2: the face's column in a row; lane3: + the lane's first layer) -- the scalar-base addressing mode, one
   // register per lane instead of a 64-bit address per store that the compiler would keep alive across the march.
@@ -527,19 +531,25 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
                                     (ptrdiff_t)L2.dcol * SEG + d.ioff + pp * 2) * 8);   // from G; >= 0: dj + joff >= 0, dcol*SEG + ioff >= 0
   const bool do2 = (sg < ST::NL2) && (L2.plane >= 0);
   const bool do_uhbt = (sg == 9) && (A.uhbt != nullptr);
-  auto issue_dma = [&](int jj) {
+  // DIR = 1: the five h slots are a RING over the rows of the march: row r lives in slot (r + 10) % 5, and a step
+  // only fetches the one row that is new to it (jj + 3, into the slot row jj - 2 has just left); `all_rows`: the first
+  // step of a chunk fills the ring.
+  auto issue_dma = [&](int jj, bool all_rows) {
     const size_t row0 = ((size_t)(i0 + d.ioff) + (size_t)(jj + d.joff) * (size_t)d.pitch) * 8;   // (i0, jj) in a plane, bytes
 #pragma unroll
     for (int s = 0; s < ST::NS3; s++) {
       if (s >= ns3) break;
+      if (DIR && s < 4 && !all_rows) continue;          // rows jj-1 .. jj+2 are in the ring already
       const double *arr;
       ptrdiff_t shift;
-      if (DIR) { arr = (s < 5) ? A.h_in : (s == 5 ? A.u : A.visc_rem); shift = (s < 5) ? (ptrdiff_t)(s - 1) * d.pitch * 8 : 0; }
+      int slot = s;
+      if (DIR) { arr = (s < 5) ? A.h_in : (s == 5 ? A.u : A.visc_rem); shift = (s < 5) ? (ptrdiff_t)(s - 1) * d.pitch * 8 : 0;
+                 if (s < 5) slot = (jj + s + 9) % 5; }   // row jj - 1 + s
       else     { arr = (s < 3) ? A.h_in : (s == 3 ? A.u : A.visc_rem); shift = (s < 3) ? (ptrdiff_t)(s - 1) * SEG * 8 : 0; }
       const char *base = (const char *)arr + (ptrdiff_t)row0 + shift;
       for (int r = 0; r * 32 < nk; r++) {
         if (r * 32 + sg < nk)
-          glds16((const double *)(base + (size_t)r * 32 * slab * 8 + dma3), S + (size_t)(s * KP + r * 32) * SEG);
+          glds16((const double *)(base + (size_t)r * 32 * slab * 8 + dma3), S + (size_t)(slot * KP + r * 32) * SEG);
       }
     }
     const char *g2 = (const char *)G + ((size_t)i0 + (size_t)jj * (size_t)d.pitch) * 8;
@@ -569,13 +579,16 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   for (int n = 0; n < MAXL; n++) { C.pL[n] = 0.0; C.pR[n] = 0.0; C.pC[n] = 0.0; }
 
   const int jstart = DIR ? j0 - 1 : j0;   // meridional: a first step that only reconstructs cell j0
-  issue_dma(jstart);
+  issue_dma(jstart, true);
   for (int jj = jstart; jj <= j1; jj++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row jj has landed
     const bool face_row = (!DIR) || (jj >= j0);
     // ---- LDS -> registers, layer by layer, with the PPM reconstruction + limiter on the way ---------------------------
     double IareaMin, uhbt_f, dC_f, dx_W, dx_E;
     {
+      int ring[5];   // DIR = 1: where the rows jj-1 .. jj+3 are in the ring of h slots (uniform)
+#pragma unroll
+      for (int q = 0; q < 5; q++) ring[q] = ((jj + q + 9) % 5) * KP * SEG;
       double m6[6];
 #pragma unroll
       for (int q = 0; q < NH; q++) {
@@ -588,7 +601,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
         double hst[6];
 #pragma unroll
         for (int q = 0; q < NH; q++) {
-          const double hv = DIR ? Sb[(q * KP + n * KL) * SEG] : Sb[xo[q] + n * KL * SEG];
+          const double hv = DIR ? Sb[ring[q] + n * KL * SEG] : Sb[xo[q] + n * KL * SEG];
           hst[q] = on ? hv : 0.0;
         }
         const double uu = Sb[(ST::SU * KP + n * KL) * SEG];
@@ -618,11 +631,11 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
       uhbt_f = (A.uhbt != nullptr && active) ? L[9 * SEG] : 0.0;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // row jj is in registers: its space is free ...
-    if (jj < j1) issue_dma(jj + 1);                        // ... and fills while this row's Newton solves run
+    if (jj < j1) issue_dma(jj + 1, false);                     // ... and fills while this row's Newton solves run
     if (!face_row) continue;
     TICK(0);
     const size_t rowb = (size_t)(jj + d.joff) * (size_t)d.pitch * 8;
-    face_column<DIR, MAXL>(C, A, E, rowb, lane2, lane3, slab, active, kl, nk, IareaMin, uhbt_f, dC_f, dx_W, dx_E, G, d.pitch);
+    face_column<DIR, MAXL>(C, A, E, rowb, lane2, lane3, slab, active, kl, nk, IareaMin, uhbt_f, dC_f, dx_W, dx_E, G, d.pitch TICK_ARG);
   }
 }
 

@@ -35,7 +35,7 @@ timing = hasattr(dyc.lib, "mom6x_debug_mfl_timing")   # library built with -DMOM
 wave = (dyc.cont_params.sum_order == abi.SUM_TREE16)   # the wave-owned kernel (default); MOM6X_SUMS=exact: the LDS kernel
 tfun = dyc.lib.mom6x_debug_mfw_timing if (timing and wave) else (dyc.lib.mom6x_debug_mfl_timing if timing else None)
 PH = ["load+PPM", "bounds", "sweep0+sum", "adjust(uhbt)", "store+h_face", "adjust(du0)", "duL/duR rec", "3 trial sweeps",
-      "-", "-", "-", "-", "-", "-", "-", "-"]
+      "-", "-", "row-top wait", "LDS->reg+PPM", "DMA issue", "BT stores", "-", "-"]
 only = os.environ.get("PROF_MODES")   # e.g. PROF_MODES=full,adjust
 if only:
     modes = {k: v for k, v in modes.items() if k in only.split(",")}
@@ -51,8 +51,9 @@ for path in ("lds",) if (timing or only or wave) else ("lds", "legacy"):
         if timing:
             tfun(buf, 1)
             for dr in (0, 1):
-                tot = float(sum(buf[dr * 16:dr * 16 + 8])) or 1.0
-                print("   phases dir", dr, " ".join(f"{PH[q]}={100 * buf[dr * 16 + q] / tot:.1f}%" for q in range(8)), f"total={tot:.3e} cyc", f"walk fall-backs={buf[dr * 16 + 15]}")
+                sel = [q for q in range(16) if q not in (8, 9) and PH[q] != "-" and (not wave or q != 0)]
+                tot = float(sum(buf[dr * 16 + q] for q in sel)) or 1.0
+                print("   phases dir", dr, " ".join(f"{PH[q]}={100 * buf[dr * 16 + q] / tot:.1f}%" for q in sel), f"total={tot:.3e} cyc", f"walk fall-backs={buf[dr * 16 + 15]}")
             if wave:
                 print("   flux re-evaluations per wavefront solve: towards uhbt %.2f, towards zero transport %.2f" %
                       (buf[8] / max(buf[16 + 8], 1), buf[9] / max(buf[16 + 9], 1)))
