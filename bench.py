@@ -4,16 +4,21 @@ split-explicit dynamical core (step_MOM_dyn_split_RK2) on a synthetic 0.25-degre
 1440 x 1080 x 75 grid, at 1 / 2 / 4 / 8 MI355X (strong scaling: the global grid is fixed and cut into
 MOM6's 2-D tile layout, one tile per GPU).
 
-A "step" is ONE baroclinic step of step_MOM_dyn_split_RK2: PressureForce, CorAdCalc x2, continuity_PPM
-x3, btstep x2 (each a full barotropic sub-cycle), horizontal_viscosity, vertvisc_coef x3, vertvisc x2,
-vertvisc_remnant x3 and the RK2 glue, on state that already resides in HBM -- every callee of the step runs on
-the device; only the set_viscous_BBL inputs of vertvisc_coef are synthetic constants (stated in `config`).
+A "step" is ONE baroclinic step (DT = 900 s) of the headline configuration of SURVEY.md 8(d): step_MOM_dyn_split_RK2
+(PressureForce, CorAdCalc x2, continuity_PPM x3, btstep x2 -- each a full barotropic sub-cycle --, horizontal_viscosity,
+vertvisc_coef x3, vertvisc x2, vertvisc_remnant x3 and the RK2 glue) PLUS its share of the thermodynamic step that
+follows every DT_THERM / DT = 4 of them: advect_tracer of T, S and two passive tracers (PPM) with the transports
+accumulated over the four steps, tracer_vertdiff of the passive tracers and triDiagTS of T, S.  The thermodynamic
+step runs INSIDE the timed region after every fourth dynamics step, so `value` = simulated time / wall time of the
+whole cycle (K a multiple of 4 amortises exactly).  State resides in HBM; every callee runs on the device; only the
+set_viscous_BBL inputs of vertvisc_coef and the diffusive exchanges ea, eb of the tridiagonal solves are synthetic
+constants (stated in `config`).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel -- the one with the largest
 total time in the last warm-up step (k_mass_flux_lds: PPM reconstruction + zonal/meridional mass flux +
 Newton flux adjustment + BT_cont fits) -- timed live with HIP events on the compute stream inside the
-timed region; `cpu_baseline` is the oracle (plain-C port of the reference algorithm, one
-core) timed on a bounded 180x136x75 tile of the same workload and scaled by the cell count.
+timed region; `cpu_baseline` is the oracle (plain-C port of the reference algorithm, OpenMP over the loops the
+reference threads, all host cores) timed on a bounded 360x180x75 tile of the same workload and scaled by the cell count.
 """
 import argparse
 import json
@@ -117,55 +122,58 @@ KERNEL_WORDS = {
 }
 
 
-def tracer_leg(args, dyc, d, st, step, barrier, dist):
-    """One tracer step of BASELINE.json configs[2] after the timed region (NOT part of `value`): two more dynamics
-    steps accumulate uhtr/vhtr (DT_THERM = 2 DT), then advect_tracer moves `--tracers` PPM tracers with them and
-    tracer_vertdiff / triDiagTS run the vertical tridiagonal solves on the tracers and on T, S."""
+def make_thermo(args, dyc, d, st, nth):
+    """The thermodynamic step of the headline configuration (DT_THERM = 3600 s = 4 DT, T and S plus two
+    passive tracers): advect_tracer (PPM) moves all of them with the transports uhtr / vhtr accumulated over the last nth
+    dynamics steps (and clears the accumulators, as step_MOM does), tracer_vertdiff solves the passive tracers' vertical
+    tridiagonal systems and triDiagTS those of T and S.  Returns (the step, a function that reports what it did)."""
     import torch
     from mom6_amd import synth_dev
-    ntr, nk = args.tracers, args.nk
-    st["uhtr"].zero_(); st["vhtr"].zero_()
-    step(); step()
+    ntr, nk = max(args.tracers, 0), args.nk
+    dt_th = nth * args.dt
     dyc.tracer_advect_init(args.dt, scheme=2)                          # TRACER_ADVECTION_SCHEME = "PPM"
+    T = (10.0 + synth_dev.smooth_field(d, dyc.device, 81, nk=nk)).contiguous()
+    S = (35.0 + 0.5 * synth_dev.smooth_field(d, dyc.device, 82, nk=nk)).contiguous()
     tr = [(10.0 + 5.0 * synth_dev.smooth_field(d, dyc.device, 71 + m, nk=nk, ox=0.5, oy=0.5)).contiguous() for m in range(ntr)]
-    h = st["h"]
-    dyc.advect_tracer(h, st["uhtr"], st["vhtr"], 2.0 * args.dt, [t.clone() for t in tr])   # untimed: allocates the work arrays
-    barrier(); t0 = time.perf_counter()
-    iters = dyc.advect_tracer(h, st["uhtr"], st["vhtr"], 2.0 * args.dt, tr)
-    barrier(); t_adv = time.perf_counter() - t0
-    if args.breakdown:
-        from mom6_amd.dycore import prof_enable, prof_report, prof_reset
-        prof_enable(dyc, True); prof_reset(dyc)
-        dyc.advect_tracer(h, st["uhtr"], st["vhtr"], 2.0 * args.dt, [t.clone() for t in tr]); dyc.sync()
-        for k, (cnt, ms) in sorted(prof_report(dyc).items(), key=lambda kv: -kv[1][1]):
-            if cnt == 0:
-                continue
-            print(f"[tracer] {k:22s} n={cnt:5d} total={ms:9.3f} ms avg={ms / cnt * 1e3:9.1f} us", file=sys.stderr)
-        prof_enable(dyc, False)
-    ea = (1.0e-3 * h).contiguous(); eb = (2.0e-3 * h).contiguous()
-    T = (10.0 + synth_dev.smooth_field(d, dyc.device, 81, nk=nk)).contiguous(); S = (35.0 + 0.0 * T).contiguous()
-    dyc.tracer_vertdiff(h, ea, eb, 2.0 * args.dt, tr[0].clone())      # untimed warm-up
-    barrier(); t0 = time.perf_counter()
-    for m in range(ntr):
-        dyc.tracer_vertdiff(h, ea, eb, 2.0 * args.dt, tr[m])
-    dyc.triDiagTS(h, ea, eb, T, S)
-    barrier(); t_tri = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([t_adv, t_tri], dtype=torch.float64, device=dyc.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_adv, t_tri = (float(x) for x in t)
-    N3 = args.ni * args.nj * args.nk
-    # compulsory words per cell-layer: set-up (h_end, uhtr, vhtr in; hprev, uhr, vhr out) + per iteration and direction
-    # (uhr, hprev in/out + every tracer in/out)
-    b_adv = 8.0 * N3 * (6 + iters * 2 * (4 + 2 * ntr))
-    b_tri = 8.0 * N3 * (ntr * 5 + 7)                                   # h, ea, eb + tracer in/out each; T and S share one sweep
-    return {"tracers": ntr, "scheme": "PPM", "advect_tracer_ms": round(1e3 * t_adv, 3), "advect_iterations": iters,
-            "advect_algorithmic_GB": round(b_adv / 1e9, 2), "advect_GBps": round(b_adv / 1e9 / t_adv, 1),
-            "advect_frac_of_hbm_peak": round(b_adv / 1e9 / t_adv / (HBM_PEAK_GBS * args.gpus), 4),
-            "tridiag_ms": round(1e3 * t_tri, 3), "tridiag_algorithmic_GB": round(b_tri / 1e9, 2),
-            "tridiag_GBps": round(b_tri / 1e9 / t_tri, 1),
-            "tridiag_frac_of_hbm_peak": round(b_tri / 1e9 / t_tri / (HBM_PEAK_GBS * args.gpus), 4),
-            "note": "reported next to, not inside, the headline metric: one tracer step per two dynamics steps (DT_THERM = 2 DT)"}
+    ea = (1.0e-3 * st["h"]).contiguous(); eb = (2.0e-3 * st["h"]).contiguous()     # synthetic diffusive exchanges [H]
+    stat = {"calls": 0, "iters": 0}
+
+    def thermo():
+        h = st["h"]
+        stat["iters"] += dyc.advect_tracer(h, st["uhtr"], st["vhtr"], dt_th, [T, S] + tr)
+        for t in tr:
+            dyc.tracer_vertdiff(h, ea, eb, dt_th, t)
+        dyc.triDiagTS(h, ea, eb, T, S)
+        st["uhtr"].zero_(); st["vhtr"].zero_()                            # (on the context's stream: see main)
+        stat["calls"] += 1
+
+    def info():
+        # timed on its own after the run, for the breakdown only (the headline already contains it)
+        for _ in range(nth):
+            dyc.step_MOM_dyn_split_RK2(st["u"], st["v"], st["h"], st["uh"], st["vh"], st["uhtr"], st["vhtr"], st["eta_av"],
+                                       *info.forcing, args.dt)
+        dyc.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        it = dyc.advect_tracer(st["h"], st["uhtr"], st["vhtr"], dt_th, [T, S] + tr)
+        dyc.sync(); t_adv = time.perf_counter() - t0; t0 = time.perf_counter()
+        for t in tr:
+            dyc.tracer_vertdiff(st["h"], ea, eb, dt_th, t)
+        dyc.triDiagTS(st["h"], ea, eb, T, S)
+        dyc.sync(); t_tri = time.perf_counter() - t0
+        st["uhtr"].zero_(); st["vhtr"].zero_()
+        N3 = args.ni * args.nj * args.nk
+        nf = ntr + 2
+        # compulsory words per cell-layer: set-up (h_end, uhtr, vhtr in; hprev, uhr, vhr out) + per iteration and direction
+        # (uhr, hprev in/out + every tracer in/out); tridiagonal: h, ea, eb + each field in/out (T and S share one sweep)
+        b_adv = 8.0 * N3 * (6 + it * 2 * (4 + 2 * nf)); b_tri = 8.0 * N3 * (ntr * 5 + 7)
+        return {"fields": "T, S + %d passive tracers" % ntr, "scheme": "PPM", "dynamics_steps_per_thermo_step": nth,
+                "calls_in_run": stat["calls"], "advect_iterations_mean": round(stat["iters"] / max(stat["calls"], 1), 2),
+                "advect_tracer_ms": round(1e3 * t_adv, 3), "advect_algorithmic_GB": round(b_adv / 1e9, 2),
+                "advect_frac_of_hbm_peak": round(b_adv / 1e9 / t_adv / (HBM_PEAK_GBS * args.gpus), 4),
+                "tridiag_ms": round(1e3 * t_tri, 3), "tridiag_algorithmic_GB": round(b_tri / 1e9, 2),
+                "tridiag_frac_of_hbm_peak": round(b_tri / 1e9 / t_tri / (HBM_PEAK_GBS * args.gpus), 4),
+                "ms_per_dynamics_step_amortised": round(1e3 * (t_adv + t_tri) / nth, 3),
+                "note": "INSIDE the headline metric (one call per %d dynamics steps); this breakdown is one more call timed after the run" % nth}
+    return thermo, info
 
 
 def ale_remap_leg(args, dyc, d, st, barrier, dist):
@@ -244,6 +252,31 @@ def diag_leg(args, dyc, d, st, barrier, dist):
                     "restart checksums of u, v, h from the device-resident state; host round trips included"}
 
 
+# Which of the 1616 x N3 bytes of the un-fused model the device does NOT move, by routine (8-byte words per cell-layer and step;
+# DESIGN.md section 4).  The model keeps them so that `frac_of_peak` stays comparable between rounds; the measured
+# FETCH_SIZE + WRITE_SIZE of the same command is printed next to it.
+FUSED_WORDS = {
+    "vertvisc x2 + remnant x3 and the velocity updates of the RK2 glue": "k_vertvisc_fused does the RK2 velocity update, vertvisc and vertvisc_remnant "
+        "in one column sweep: 11 words per face-layer and call where the separate routines move 17 (DESIGN.md section 4)",
+    "continuity_PPM": "the PPM edge values h_W/h_E/h_S/h_N, the Newton iterations' layer transports and the flux thicknesses never leave the chip "
+        "(they were never part of the 256 B x N3 count either): 5 words per face-layer and launch",
+    "everything else": "moved as counted; the 2-D metric planes a kernel re-reads per layer or per 15-layer chunk come on top (not in the model)",
+}
+
+
+def pmc_step_traffic():
+    """Measured HBM-side GB per step (sum over all kernels of one step) from the newest committed PMC summary, or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+            if "bytes_per_step" in j:
+                return round(j["bytes_per_step"] / 1e9, 1), os.path.relpath(path, ROOT)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_hbm_pmc.json,
     written by scripts/rocprof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; the
@@ -263,10 +296,17 @@ def pmc_traffic(kernel):
 
 
 def cpu_baseline(args):
-    """The oracle (kind='port': plain-C restatement of the reference Fortran, one core) on a bounded tile."""
+    """The oracle (kind='port': plain-C restatement of the reference Fortran with OpenMP over the loops the reference
+    threads -- !$OMP parallel do over j or k, e.g. MOM_continuity_PPM.F90:370/:615, MOM_barotropic.F90:868 -- on all host
+    cores) on a bounded tile: BASELINE.json configs[2]'s 360 x 180 x 75, scaled by the cell count."""
     from mom6_amd import abi, grid, synth
     from oracle import orc
-    ni, nj, nk = 180, 136, args.nk
+    import ctypes
+    try:
+        cores = int(ctypes.CDLL("libgomp.so.1").omp_get_max_threads())
+    except OSError:
+        cores = 1
+    ni, nj, nk = 360, 180, args.nk
     gg = grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-65.0, dlon=360.0 / args.ni, dlat=130.0 / args.nj,
                          depth_fn=grid.bowl_depth(ni, nj, 4000.0, rim=2))
     d, M = gg.tile(nk)
@@ -295,24 +335,25 @@ def cpu_baseline(args):
     t = (time.time() - t0) / nst
     scale = (args.ni * args.nj) / float(ni * nj)
     t_full = t * scale
-    return {"value": (args.dt / 86400.0) / t_full, "unit": "simulated-days/wall-sec", "cores": 1, "kind": "port",
-            "sample": f"{nst} oracle steps of step_MOM_dyn_split_RK2 on a {ni}x{nj}x{nk} tile ({t:.2f} s/step), "
-                      f"scaled x{scale:.1f} to {args.ni}x{args.nj}x{nk}"}
+    return {"value": (args.dt / 86400.0) / t_full, "unit": "simulated-days/wall-sec", "cores": cores, "kind": "port",
+            "sample": f"{nst} oracle steps of step_MOM_dyn_split_RK2 (dynamics only) on a {ni}x{nj}x{nk} tile with {cores} OpenMP threads "
+                      f"({t:.2f} s/step), scaled x{scale:.1f} to {args.ni}x{args.nj}x{nk}"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ni", type=int, default=1440)
     ap.add_argument("--nj", type=int, default=1080)
     ap.add_argument("--nk", type=int, default=75)
     ap.add_argument("--dt", type=float, default=900.0)
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--dt-therm", type=float, default=3600.0, help="DT_THERM: a thermodynamic step follows every DT_THERM / DT dynamics steps")
+    ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
-    ap.add_argument("--tracers", type=int, default=2, help="PPM tracers of the (separately reported) tracer leg; 0 = skip")
+    ap.add_argument("--tracers", type=int, default=2, help="passive PPM tracers next to T and S in the thermodynamic step; -1 = dynamics only")
     args = ap.parse_args()
 
     import torch
@@ -321,7 +362,12 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)   # (one rank per GPU; the modulo only matters on a test box with fewer GPUs than ranks)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if world > ndev and os.environ.get("MOM6X_COMM") != "threads":
+        # RCCL cannot build a communicator with two ranks on one device, and a strong-scaling number from shared devices would be bogus
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPU(s) visible: one rank per GPU is required")
+    local_rank %= max(ndev, 1)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -347,9 +393,26 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    step(calc_dtbt=True)                    # sets dtbt (untimed; part of warm-up)
-    for _ in range(max(args.warmup - 2, 0)):
+    # every torch operation of this script is issued on the context's own stream (ordered with its kernels)
+    torch.cuda.set_stream(dyc.torch_stream())
+    nth = max(int(round(args.dt_therm / args.dt)), 1)          # dynamics steps per thermodynamic step
+    thermo, thermo_info = make_thermo(args, dyc, d, st, nth) if args.tracers >= 0 else (None, None)
+    if thermo_info is not None:
+        thermo_info.forcing = (taux, tauy)
+    n_dyn = [0]
+
+    def cycle_step():
+        """One baroclinic step of the headline configuration: the dynamics, and after every nth of them the thermodynamic step."""
         step()
+        n_dyn[0] += 1
+        if thermo is not None and n_dyn[0] % nth == 0:
+            thermo()
+
+    step(calc_dtbt=True)                    # sets dtbt (untimed; part of warm-up)
+    if thermo is not None:
+        thermo()                            # untimed: allocates the work arrays of advect_tracer
+    for _ in range(max(args.warmup - 2, 0)):
+        cycle_step()
     # last warm-up step, with HIP events around EVERY kernel: the per-kernel breakdown, and which kernel dominates
     dyc.lib.mom6x_prof_filter(dyc.ctx, None)
     prof_enable(dyc, True); prof_reset(dyc)
@@ -360,10 +423,12 @@ def main():
     # time EXACTLY K steps; HIP events only around the dominant kernel inside the timed region
     dyc.lib.mom6x_prof_filter(dyc.ctx, dom_name.encode())
     prof_enable(dyc, True); prof_reset(dyc)
+    n_dyn[0] = 0
+    st["uhtr"].zero_(); st["vhtr"].zero_()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        cycle_step()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -373,6 +438,7 @@ def main():
     dom = prof_report(dyc)
     prof_enable(dyc, False)
     dyc.lib.mom6x_prof_filter(dyc.ctx, None)
+    n_thermo = args.steps // nth if thermo is not None else 0
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = (args.steps * args.dt / 86400.0) / elapsed
@@ -398,19 +464,33 @@ def main():
         "metric": "simulated-days/wall-sec", "value": value, "unit": "simulated-days/wall-sec", "n_gpus": args.gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"step_MOM_dyn_split_RK2 on {args.ni}x{args.nj}x{args.nk} (0.25-degree-class synthetic global, "
-                               f"BASELINE.json configs[3] grid), DT={args.dt:g} s, layout {layout[0]}x{layout[1]}, "
+        "config": {"workload": f"step_MOM_dyn_split_RK2 + every {nth} steps advect_tracer (PPM) of T, S and {max(args.tracers, 0)} passive tracers "
+                               f"and their vertical tridiagonal solves, on {args.ni}x{args.nj}x{args.nk} (0.25-degree-class synthetic global, "
+                               f"BASELINE.json configs[3] grid), DT={args.dt:g} s, DT_THERM={args.dt_therm:g} s, layout {layout[0]}x{layout[1]}, "
                                f"{nsub} barotropic sub-steps per step",
+                   "thermo_steps_in_timed_region": n_thermo,
+                   "sum_order": "TREE16 (column sums of the mass-flux kernels as a 16-lane tree; MOM6X_SUMS=exact: the reference's k order)"
+                                if dyc.cont_params.sum_order else "REFERENCE (sequential in k, bit-identical to the Fortran loop nest)",
                    "frozen_inputs": "none of the step's callees; vertvisc_coef and horizontal_viscosity run on the device inside the step (the set_viscous_BBL inputs of vertvisc_coef are constant synthetic fields)",
                    "tile": [d.ni, d.nj, d.nk], "halo": d.halo},
         "roofline": roofline,
-        "hbm_step": {"algorithmic_GB_per_step": round(bytes_step / 1e9, 2), "achieved_GBps": round(bytes_step / 1e9 / (ms_per_step * 1e-3), 1),
-                     "frac_of_peak": round(bytes_step / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * args.gpus), 4),
-                     "model": "SURVEY.md 8(d): 1616 B x N3 + 570 B x N2 x sub-steps, + 192 B x N3 for vertvisc_coef x3 + 40 B x N3 for horizontal_viscosity"},
     }
-    if args.tracers > 0 and args.gpus == 1:
+    th = thermo_info() if thermo_info is not None else None
+    if th is not None:
+        out["thermo"] = th
+    th_bytes = (th["advect_algorithmic_GB"] + th["tridiag_algorithmic_GB"]) * 1e9 / nth if th else 0.0   # amortised per dynamics step
+    tot_bytes = bytes_step + th_bytes
+    measured, measured_src = pmc_step_traffic() if args.gpus == 1 and (args.ni, args.nj, args.nk) == (1440, 1080, 75) else (None, None)
+    out["hbm_step"] = {
+        "algorithmic_GB_per_step": round(tot_bytes / 1e9, 2), "dynamics_GB": round(bytes_step / 1e9, 2), "thermo_GB_amortised": round(th_bytes / 1e9, 2),
+        "achieved_GBps": round(tot_bytes / 1e9 / (ms_per_step * 1e-3), 1),
+        "frac_of_peak": round(tot_bytes / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * args.gpus), 4),
+        "model": "SURVEY.md 8(d), un-fused: 1616 B x N3 + 570 B x N2 x sub-steps, + 192 B x N3 for vertvisc_coef x3 + 40 B x N3 for horizontal_viscosity"
+                 " (+ the thermodynamic step's words / 4)",
+        "fused_away": FUSED_WORDS,
+        "measured_FETCH_plus_WRITE_GB_per_step": measured, "measured_source": measured_src}
+    if args.tracers >= 0 and args.gpus == 1:
         # the legs reported next to the headline are measured on one GPU; the scaling runs (N > 1) keep to the headline path
-        out["tracer_leg"] = tracer_leg(args, dyc, d, st, step, barrier, dist)
         out["ale_remap_leg"] = ale_remap_leg(args, dyc, d, st, barrier, dist)
         out["diag_leg"] = diag_leg(args, dyc, d, st, barrier, dist)
     if rank == 0:

@@ -46,7 +46,7 @@ __global__ void k_red_init(AccPtr A, int nk) {
   if (k >= nk) return;
   for (int n = 0; n < A_NSUM; n++) A.sum[(size_t)k * A_NSUM + n] = 0;
   A.mn[k] = LLONG_MAX;
-  A.mx[3 * k] = LLONG_MIN; A.mx[3 * k + 1] = 0; A.mx[3 * k + 2] = 0;
+  A.mx[4 * k] = LLONG_MIN; A.mx[4 * k + 1] = 0; A.mx[4 * k + 2] = 0; A.mx[4 * k + 3] = 0;
 }
 
 __device__ __forceinline__ long long wave_sum(long long v) {
@@ -145,9 +145,11 @@ k_field_reduce(Dm d, Src src, int is, int ie, int js, int je, int mode, int do_s
   if (mode & M_SUM) for (int n = 0; n < NI_EFP; n++) if (v[n]) atomicAdd((unsigned long long *)&S[n], (unsigned long long)v[n]);
   if (mode & M_BC) atomicAdd((unsigned long long *)&S[A_BC], (unsigned long long)v[6]);
   if (mode & M_CHK) atomicAdd((unsigned long long *)&S[A_CHK], (unsigned long long)v[7]);
-  if (mode & M_MINMAX) { atomicMin(&A.mn[k], v[8]); atomicMax(&A.mx[3 * k], v[9]); }
-  if (v[10]) atomicMax(&A.mx[3 * k + 1], v[10]);
-  if (v[11]) atomicOr((unsigned long long *)&A.mx[3 * k + 2], (unsigned long long)v[11]);
+  if (mode & M_MINMAX) { atomicMin(&A.mn[k], v[8]); atomicMax(&A.mx[4 * k], v[9]); }
+  if (v[10]) atomicMax(&A.mx[4 * k + 1], v[10]);
+  // one 0/1 word per flag: the tiles' words meet in a MAX all-reduce, which is an OR only for single bits
+  if (v[11] & F_NAN) atomicMax(&A.mx[4 * k + 2], 1LL);
+  if (v[11] & F_OVER) atomicMax(&A.mx[4 * k + 3], 1LL);
 }
 
 // ---- host side of the extended fixed point type ---------------------------------------------------------------------
@@ -194,7 +196,7 @@ static int reduce_src(mom6x_ctx *c, const Src &src, const char *kname, int nk, i
   REQUIRE(nk >= 1, MOM6X_EINVAL, "reduce: nk < 1");
   REQUIRE(is >= -D.halo - 1 && ie < D.ni + D.halo && js >= -D.halo - 1 && je < D.nj + D.halo && is <= ie + 1 && js <= je + 1,
           MOM6X_EINVAL, "reduce: the index range leaves the data domain");
-  const size_t nwords = (size_t)nk * (A_NSUM + 1 + 3);
+  const size_t nwords = (size_t)nk * (A_NSUM + 1 + 4);
   if (c->red_cap < nwords) {
     if (c->red) HIPCHK(hipFree(c->red));
     c->red = nullptr; c->red_cap = 0;
@@ -210,9 +212,9 @@ static int reduce_src(mom6x_ctx *c, const Src &src, const char *kname, int nk, i
   if (across_PEs && comm_nranks(c) > 1) {
     int rc;
     if ((rc = comm_allreduce_i64(c, A.sum, (size_t)nk * A_NSUM, 2)) || (rc = comm_allreduce_i64(c, A.mn, nk, 0)) ||
-        (rc = comm_allreduce_i64(c, A.mx, (size_t)nk * 3, 1))) return rc;
+        (rc = comm_allreduce_i64(c, A.mx, (size_t)nk * 4, 1))) return rc;
   }
-  H.sum.resize((size_t)nk * A_NSUM); H.mn.resize(nk); H.mx.resize((size_t)nk * 3);
+  H.sum.resize((size_t)nk * A_NSUM); H.mn.resize(nk); H.mx.resize((size_t)nk * 4);
   std::vector<long long> buf(nwords);
   HIPCHK(hipMemcpyAsync(buf.data(), c->red, nwords * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -253,9 +255,8 @@ static int reproducing_sum_finish(mom6x_ctx *c, HostAcc &H, int nk, int rank, do
   const int do_unscale = (unscale != 1.0);
   bool nan = false, over = false; double max_mag = 0.0;
   for (int k = 0; k < nk; k++) {
-    const long long f = H.mx[3 * k + 2];
-    nan |= (f & F_NAN) != 0; over |= (f & F_OVER) != 0;
-    double m; memcpy(&m, &H.mx[3 * k + 1], 8);
+    nan |= H.mx[4 * k + 2] != 0; over |= H.mx[4 * k + 3] != 0;
+    double m; memcpy(&m, &H.mx[4 * k + 1], 8);
     if (m > max_mag) max_mag = m;
   }
   const bool conv_over = (max_mag >= (double)prec_error * efp_pr(0));
@@ -351,11 +352,11 @@ extern "C" int mom6x_chksum(mom6x_ctx *c, const double *array, int nk, int rank,
   double mean;
   rc = reduce_run(c, array, nk, 0, ni - 1, 0, nj - 1, M_SUM | M_MINMAX, scale != nullptr, scaling, true, H);
   if (rc) return rc;
-  for (int k = 0; k < nk; k++) REQUIRE(!(H.mx[3 * k + 2] & F_NAN), MOM6X_ENUMERIC, "NaN detected in chksum");
+  for (int k = 0; k < nk; k++) REQUIRE(!H.mx[4 * k + 2], MOM6X_ENUMERIC, "NaN detected in chksum");
   {
     std::vector<long long> tot(NI_EFP, 0);
     for (int k = 0; k < nk; k++) { for (int n = 0; n < NI_EFP; n++) tot[n] += H.limb(k)[n]; carry_exact(tot.data()); }
-    for (int k = 0; k < nk; k++) REQUIRE(!(H.mx[3 * k + 2] & F_OVER), MOM6X_ENUMERIC, "Overflow in reproducing_sum(_3d).");
+    for (int k = 0; k < nk; k++) REQUIRE(!H.mx[4 * k + 3], MOM6X_ENUMERIC, "Overflow in reproducing_sum(_3d).");
     regularize_ints(tot.data());
     mean = ints_to_real(tot.data());
   }
@@ -370,7 +371,7 @@ extern "C" int mom6x_chksum(mom6x_ctx *c, const double *array, int nk, int rank,
     if (rc) return rc;
   }
   long long kmin = LLONG_MAX, kmax = LLONG_MIN;
-  for (int k = 0; k < nk; k++) { if (H.mn[k] < kmin) kmin = H.mn[k]; if (H.mx[3 * k] > kmax) kmax = H.mx[3 * k]; }
+  for (int k = 0; k < nk; k++) { if (H.mn[k] < kmin) kmin = H.mn[k]; if (H.mx[4 * k] > kmax) kmax = H.mx[4 * k]; }
   out->amin = 0. + key_value(kmin); out->amax = 0. + key_value(kmax);            // as chk_sum_msg3 :2638 prints them
   // the bit counts
   for (int n = 0; n < 4; n++) out->bc[n] = 0;

@@ -357,6 +357,9 @@ void comm_free(mom6x_ctx *c) {
 // with MPI_Bcast / torch.distributed).  id128 may be NULL when nranks == 1.
 extern "C" int mom6x_comm_init(mom6x_ctx *c, int npx, int npy, int px, int py, const char *id128, int force_nccl_self) {
   REQUIRE(c && npx >= 1 && npy >= 1 && px >= 0 && px < npx && py >= 0 && py < npy, MOM6X_EINVAL, "mom6x_comm_init: bad layout");
+  // a tile narrower than its halo (+ the B-point offset) would send from its own halo, i.e. stale data; FMS aborts on such a layout
+  REQUIRE(c->dims.ni >= c->dims.halo + 1 && c->dims.nj >= c->dims.halo + 1, MOM6X_EINVAL,
+          "mom6x_comm_init: the tile of this layout is narrower than the halo (ni, nj must be at least halo + 1)");
   HIPCHK(hipSetDevice(c->device));
   comm_free(c);
   Comm *m = new Comm();

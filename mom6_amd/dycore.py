@@ -92,6 +92,11 @@ class Dycore:
     def stream_ptr(self):
         return self.lib.mom6x_ctx_stream(self.ctx)
 
+    def torch_stream(self):
+        """The context's compute stream as a torch stream: torch work issued under `with torch.cuda.stream(dyc.torch_stream())`
+        is ordered with the context's kernels, so no synchronisation is needed between the two (see the module docstring)."""
+        return torch.cuda.ExternalStream(self.stream_ptr, device=self.device)
+
     # -- MOM_continuity_PPM ------------------------------------------------------------------
     def continuity_init(self, params=None):
         """continuity_PPM_init (MOM_continuity_PPM.F90:2674)."""

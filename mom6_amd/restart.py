@@ -115,9 +115,7 @@ class MOM_restart_CS:
         self.dyc.sync()
         for f in self.fields:
             if "checksum" not in atts[f.name]:
-                if self.checksum_required:
-                    raise RuntimeError("MOM_restart: checksum attribute missing for " + f.name)
-                continue
+                continue   # is_there_a_checksum = .false. (MOM_restart.F90:1916-1967): nothing to compare, never an error
             want = int(atts[f.name]["checksum"][:16], 16)
             got = self._checksum(f) % 2 ** 64
             if got != want and self.checksum_required:

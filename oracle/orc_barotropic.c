@@ -70,14 +70,17 @@ int orc_barotropic_init(const mom6x_dims *d, const double *G, const mom6x_vgrid 
   const double Z_to_H = GV->Z_to_H, Mean_SL = P->Z_ref;
   memset(CS->q_D, 0, sizeof(double) * d->slab); memset(CS->D_u_Cor, 0, sizeof(double) * d->slab);
   memset(CS->D_v_Cor, 0, sizeof(double) * d->slab);
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     CS->D_u_Cor[c] = 0.5 * (orc_max(Mean_SL + bathyT[c + 1], 0.0) + orc_max(Mean_SL + bathyT[c], 0.0)) * Z_to_H;
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     CS->D_v_Cor[c] = 0.5 * (orc_max(Mean_SL + bathyT[c + st], 0.0) + orc_max(Mean_SL + bathyT[c], 0.0)) * Z_to_H;
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     if (mT[c] + mT[c + st] + mT[c + 1] + mT[c + 1 + st] > 0.) {
@@ -93,11 +96,13 @@ int orc_barotropic_init(const mom6x_dims *d, const double *G, const mom6x_vgrid 
   }
   orc_pass_var(d, CS->q_D, 3, 1); orc_pass_var(d, CS->D_u_Cor, 1, 1); orc_pass_var(d, CS->D_v_Cor, 2, 1);
   /* .not.nonlin_stress :6146-6163 */
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     if (mCu[c] > 0.) CS->IDatu[c] = mCu[c] * 2.0 / (Z_to_H * ((bathyT[c + 1] + bathyT[c]) + 2.0 * Mean_SL));
     else CS->IDatu[c] = 0.;
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     if (mCv[c] > 0.) CS->IDatv[c] = mCv[c] * 2.0 / (Z_to_H * ((bathyT[c + st] + bathyT[c]) + 2.0 * Mean_SL));
@@ -252,16 +257,19 @@ static void set_local_BT_cont_types(const mom6x_dims *d, const mom6x_BT_cont *BT
   const double *src[12] = { BT->uBT_EE, BT->uBT_WW, BT->FA_u_EE, BT->FA_u_E0, BT->FA_u_W0, BT->FA_u_WW,
                             BT->vBT_NN, BT->vBT_SS, BT->FA_v_NN, BT->FA_v_N0, BT->FA_v_S0, BT->FA_v_SS };
   for (int m = 0; m < 12; m++) t[m] = (double *)calloc(n, sizeof(double));
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     for (int m = 0; m < 6; m++) t[m][c] = src[m][c];
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     for (int m = 6; m < 12; m++) t[m][c] = src[m][c];
   }
   for (int m = 0; m < 6; m++) orc_pass_var(d, t[m], 1, 1);
   for (int m = 6; m < 12; m++) orc_pass_var(d, t[m], 2, 1);
+#pragma omp parallel for schedule(static)
   for (int j = js - hs; j <= je + hs; j++) for (int i = is - hs - 1; i <= ie + hs; i++) {
     size_t c = IX2(d, i, j);
     btcl_t *B = &Bu[c];
@@ -273,6 +281,7 @@ static void set_local_BT_cont_types(const mom6x_dims *d, const mom6x_BT_cont *BT
     if (fabs(B->uBT_WW) > 0.0) B->uh_crvW = (C1_3 * (B->FA_WW - B->FA_W0)) / (B->uBT_WW * B->uBT_WW);
     if (fabs(B->uBT_EE) > 0.0) B->uh_crvE = (C1_3 * (B->FA_EE - B->FA_E0)) / (B->uBT_EE * B->uBT_EE);
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - hs - 1; j <= je + hs; j++) for (int i = is - hs; i <= ie + hs; i++) {
     size_t c = IX2(d, i, j);
     btcl_t *B = &Bv[c];   /* N <-> E, S <-> W */
@@ -342,6 +351,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   for (int j = jsvf - 2; j <= jevf + 1; j++) for (int i = isvf - 1; i <= ievf + 1; i++) DCor_v[IX2(d, i, j)] = CS->D_v_Cor[IX2(d, i, j)];
 
   /* copy input arrays into their wide-halo counterparts :996-1001 */
+#pragma omp parallel for schedule(static)
   for (int j = jsd; j <= jed; j++) for (int i = isd; i <= ied; i++) {
     size_t c = IX2(d, i, j);
     eta[c] = eta_in[c]; eta_PF[c] = eta_PF_in[c];
@@ -363,6 +373,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
     wt_v[c] = CS->frhatv[c] * visc_rem;
   }
   if (!P->wt_uv_bug) { /* :1032-1059 */
+#pragma omp parallel for schedule(static)
     for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       double tot = wt_u[c];
@@ -370,6 +381,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
       if (fabs(tot) > 0.0) tot = mCu[c] / tot;
       for (int k = 0; k < nz; k++) wt_u[c + k * slab] = wt_u[c + k * slab] * tot;
     }
+#pragma omp parallel for schedule(static)
     for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       double tot = wt_v[c];
@@ -380,20 +392,24 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   }
 
   /* ubt_Cor, vbt_Cor :1064-1070 */
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     ubt_Cor[c] = ubt_Cor[c] + wt_u[c + k * slab] * U_Cor[c + k * slab];
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     vbt_Cor[c] = vbt_Cor[c] + wt_v[c + k * slab] * V_Cor[c + k * slab];
   }
   /* gtot :1077-1089 */
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     gtot_E[c] = gtot_E[c] + pbce[c + k * slab] * wt_u[c + k * slab];
     gtot_W[c + 1] = gtot_W[c + 1] + pbce[c + 1 + k * slab] * wt_u[c + k * slab];
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     gtot_N[c] = gtot_N[c] + pbce[c + k * slab] * wt_v[c + k * slab];
@@ -404,20 +420,24 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   set_local_BT_cont_types(d, BT_cont, BTCL_u, BTCL_v, 1 + ievf - ie);
 
   if (add_uh0) { /* :1152-1227 */
+#pragma omp parallel for schedule(static)
     for (int j = js; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is - 1; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       uhbt[c] = uhbt[c] + uh0[c + k * slab];
       ubt[c] = ubt[c] + (P->visc_rem_u_uh0 ? wt_u[c + k * slab] : CS->frhatu[c + k * slab]) * u_uh0[c + k * slab];
     }
+#pragma omp parallel for schedule(static)
     for (int j = js - 1; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       vhbt[c] = vhbt[c] + vh0[c + k * slab];
       vbt[c] = vbt[c] + (P->visc_rem_u_uh0 ? wt_v[c + k * slab] : CS->frhatv[c + k * slab]) * v_vh0[c + k * slab];
     }
+#pragma omp parallel for schedule(static)
     for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       uhbt0[c] = uhbt[c] - find_uhbt(ubt[c], &BTCL_u[c]);
     }
+#pragma omp parallel for schedule(static)
     for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       vhbt0[c] = vhbt[c] - find_uhbt(vbt[c], &BTCL_v[c]);
@@ -426,49 +446,60 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
 
   /* btstep_ubt_from_layer :3388-3418 */
   memset(ubt, 0, sizeof(double) * slab); memset(vbt, 0, sizeof(double) * slab);
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     ubt[c] = ubt[c] + wt_u[c + k * slab] * U_in[c + k * slab];
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     vbt[c] = vbt[c] + wt_v[c + k * slab] * V_in[c + k * slab];
   }
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) if (fabs(ubt[IX2(d, i, j)]) < P->vel_underflow) ubt[IX2(d, i, j)] = 0.0;
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) if (fabs(vbt[IX2(d, i, j)]) < P->vel_underflow) vbt[IX2(d, i, j)] = 0.0;
   memset(uhbt, 0, sizeof(double) * slab); memset(vhbt, 0, sizeof(double) * slab);
 
   /* BT_force :1259-1330 */
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     if (mCu[c] > 0.0) BT_force_u[c] = taux[c] * GV->RZ_to_H * CS->IDatu[c] * visc_rem_u[c];
     else BT_force_u[c] = 0.0;
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     if (mCv[c] > 0.0) BT_force_v[c] = tauy[c] * GV->RZ_to_H * CS->IDatv[c] * visc_rem_v[c];
     else BT_force_v[c] = 0.0;
   }
   if (taux_bot && tauy_bot) {
+#pragma omp parallel for schedule(static)
     for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       if (mCu[c] > 0.0) BT_force_u[c] = BT_force_u[c] - taux_bot[c] * GV->RZ_to_H * CS->IDatu[c];
     }
+#pragma omp parallel for schedule(static)
     for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       if (mCv[c] > 0.0) BT_force_v[c] = BT_force_v[c] - tauy_bot[c] * GV->RZ_to_H * CS->IDatv[c];
     }
   }
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     BT_force_u[c] = BT_force_u[c] + wt_u[c + k * slab] * bc_accel_u[c + k * slab];
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     BT_force_v[c] = BT_force_v[c] + wt_v[c + k * slab] * bc_accel_v[c + k * slab];
   }
 
   /* btstep_find_Cor :2836-2894 */
+#pragma omp parallel for schedule(static)
   for (int j = jsvf - 1; j <= jevf; j++) for (int i = isvf - 1; i <= ievf + 1; i++) {
     size_t c = IX2(d, i, j);
     if (P->Sadourny) {
@@ -483,6 +514,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
       F4(f_4_v, 3, c) = 1.0 * DCor_u[c - 1 + st] * ((q[c] + q[c - 1 + st]) + q[c - 1]) / 3.0;
     }
   }
+#pragma omp parallel for schedule(static)
   for (int j = jsvf - 1; j <= jevf + 1; j++) for (int i = isvf - 1; i <= ievf; i++) {
     size_t c = IX2(d, i, j);
     if (P->Sadourny) {
@@ -503,11 +535,13 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   orc_pass_var(d, ubt_Cor, 1, 1); orc_pass_var(d, vbt_Cor, 2, 1);
 
   /* Cor_ref :1451-1461 */
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     Cor_ref_u[c] = (((F4(f_4_u, 4, c) * vbt_Cor[c + 1]) + (F4(f_4_u, 1, c) * vbt_Cor[c - st])) +
                     ((F4(f_4_u, 3, c) * vbt_Cor[c]) + (F4(f_4_u, 2, c) * vbt_Cor[c + 1 - st])));
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     Cor_ref_v[c] = -1.0 * (((F4(f_4_v, 1, c) * ubt_Cor[c - 1]) + (F4(f_4_v, 4, c) * ubt_Cor[c + st])) +
@@ -515,19 +549,23 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   }
 
   /* av_rem, bt_rem :1473-1509 */
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     av_rem_u[c] = av_rem_u[c] + CS->frhatu[c + k * slab] * visc_rem_u[c + k * slab];
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     av_rem_v[c] = av_rem_v[c] + CS->frhatv[c + k * slab] * visc_rem_v[c + k * slab];
   }
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     if (P->strong_drag) bt_rem_u[c] = mCu[c] * ((nstep * av_rem_u[c]) / (1.0 + (nstep - 1) * av_rem_u[c]));
     else { bt_rem_u[c] = 0.0; if (mCu[c] * av_rem_u[c] > 0.0) bt_rem_u[c] = mCu[c] * pow(av_rem_u[c], Instep); }
   }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     if (P->strong_drag) bt_rem_v[c] = mCv[c] * ((nstep * av_rem_v[c]) / (1.0 + (nstep - 1) * av_rem_v[c]));
@@ -537,6 +575,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   /* eta_src :1548-1587 */
   if (P->bound_BT_corr) {
     if (!P->BT_cont_bounds) return MOM6X_EUNSUPPORTED;
+#pragma omp parallel for schedule(static)
     for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       if (mT[c] > 0.0) {
@@ -553,6 +592,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
       }
     }
   }
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     eta_src[c] = mT[c] * (Instep * CS->eta_cor[c]);
@@ -604,12 +644,15 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   double trans_wt1, trans_wt2;
   if (P->BT_project_velocity) { trans_wt1 = (1.0 + P->bebt); trans_wt2 = -P->bebt; }
   else { trans_wt1 = P->bebt; trans_wt2 = (1.0 - P->bebt); }
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) { size_t c = IX2(d, i, j); CS->ubtav[c] = 0.0; uhbtav[c] = 0.0; ubt_wtd[c] = 0.0; }
+#pragma omp parallel for schedule(static)
   for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) { size_t c = IX2(d, i, j); CS->vbtav[c] = 0.0; vhbtav[c] = 0.0; vbt_wtd[c] = 0.0; }
 
   int isv = is, iev = ie, jsv = js, jev = je;
   for (int n = 1; n <= nt; n++) {
     if (P->clip_velocity) { /* truncate_velocities :2918-2944 */
+#pragma omp parallel for schedule(static)
       for (int j = jsv; j <= jev; j++) for (int i = isv - 1; i <= iev; i++) {
         size_t c = IX2(d, i, j);
         if ((ubt[c] * (dt * dy_Cu[c])) * IareaT[c + 1] < -P->CFL_trunc)
@@ -617,6 +660,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
         else if ((ubt[c] * (dt * dy_Cu[c])) * IareaT[c] > P->CFL_trunc)
           ubt[c] = (0.95 * P->CFL_trunc) * (areaT[c] / (dt * dy_Cu[c]));
       }
+#pragma omp parallel for schedule(static)
       for (int j = jsv - 1; j <= jev; j++) for (int i = isv; i <= iev; i++) {
         size_t c = IX2(d, i, j);
         if ((vbt[c] * (dt * dx_Cv[c])) * IareaT[c + st] < -P->CFL_trunc)
@@ -631,18 +675,23 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
     } else {
       isv = isv + stencil; iev = iev - stencil; jsv = jsv + stencil; jev = jev - stencil;
     }
+#pragma omp parallel for schedule(static)
     for (int j = jsv; j <= jev; j++) for (int i = isv - 2; i <= iev + 1; i++) ubt_prev[IX2(d, i, j)] = ubt[IX2(d, i, j)];
+#pragma omp parallel for schedule(static)
     for (int j = jsv - 2; j <= jev + 1; j++) for (int i = isv; i <= iev; i++) vbt_prev[IX2(d, i, j)] = vbt[IX2(d, i, j)];
 
     if (!P->BT_project_velocity) { /* btloop_eta_predictor :2956-3018, use_BT_cont branch */
+#pragma omp parallel for schedule(static)
       for (int j = jsv - 1; j <= jev + 1; j++) for (int i = isv - 2; i <= iev + 1; i++) {
         size_t c = IX2(d, i, j);
         uhbt[c] = find_uhbt(ubt[c], &BTCL_u[c]) + uhbt0[c];
       }
+#pragma omp parallel for schedule(static)
       for (int j = jsv - 2; j <= jev + 1; j++) for (int i = isv - 1; i <= iev + 1; i++) {
         size_t c = IX2(d, i, j);
         vhbt[c] = find_uhbt(vbt[c], &BTCL_v[c]) + vhbt0[c];
       }
+#pragma omp parallel for schedule(static)
       for (int j = jsv - 1; j <= jev + 1; j++) for (int i = isv - 1; i <= iev + 1; i++) {
         size_t c = IX2(d, i, j);
         eta_pred[c] = (eta[c] + eta_src[c]) + (dtbt * IareaT[c]) * ((uhbt[c - 1] - uhbt[c]) + (vhbt[c - st] - vhbt[c]));
@@ -654,15 +703,18 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
       int is_v, ie_v, js_u, je_u;
       if (v_first) { is_v = isv - 1; ie_v = iev + 1; js_u = jsv; je_u = jev; }
       else { is_v = isv; ie_v = iev; js_u = jsv - 1; je_u = jev + 1; }
+#pragma omp parallel for schedule(static)
       for (int j = js_u; j <= je_u; j++) for (int i = isv - 1; i <= iev; i++) {
         size_t c = IX2(d, i, j);
         PFu[c] = (((eta_PF_BT[c] - eta_PF[c]) * gtot_E[c]) - ((eta_PF_BT[c + 1] - eta_PF[c + 1]) * gtot_W[c + 1])) * dgeo_de * IdxCu[c];
       }
+#pragma omp parallel for schedule(static)
       for (int j = jsv - 1; j <= jev; j++) for (int i = is_v; i <= ie_v; i++) {
         size_t c = IX2(d, i, j);
         PFv[c] = (((eta_PF_BT[c] - eta_PF[c]) * gtot_N[c]) - ((eta_PF_BT[c + st] - eta_PF[c + st]) * gtot_S[c + st])) * dgeo_de * IdyCv[c];
       }
       if (find_etaav && (fabs(wt_accel2[n]) > 0.0))
+#pragma omp parallel for schedule(static)
         for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
           size_t c = IX2(d, i, j);
           eta_sum[c] = eta_sum[c] + wt_accel2[n] * eta_PF_BT[c];
@@ -674,6 +726,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
         int is_v, ie_v; const int Js_v = jsv - 1, Je_v = jev;
         int bracket_bug = 0;
         if (v_first) { is_v = isv - 1; ie_v = iev + 1; } else { is_v = isv; ie_v = iev; bracket_bug = P->use_old_coriolis_bracket_bug; }
+#pragma omp parallel for schedule(static)
         for (int j = Js_v; j <= Je_v; j++) for (int i = is_v; i <= ie_v; i++) {
           size_t c = IX2(d, i, j);
           if (bracket_bug)
@@ -683,6 +736,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
             Cor_v[c] = -1.0 * (((F4(f_4_v, 1, c) * ubt[c - 1]) + (F4(f_4_v, 4, c) * ubt[c + st])) +
                                ((F4(f_4_v, 2, c) * ubt[c]) + (F4(f_4_v, 3, c) * ubt[c - 1 + st]))) - Cor_ref_v[c];
         }
+#pragma omp parallel for schedule(static)
         for (int j = Js_v; j <= Je_v; j++) for (int i = is_v; i <= ie_v; i++) {
           size_t c = IX2(d, i, j);
           vbt[c] = bt_rem_v[c] * (vbt[c] + dtbt * ((BT_force_v[c] + Cor_v[c]) + PFv[c]));
@@ -692,6 +746,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
       } else { /* btloop_update_u :3306-3384 */
         int js_u, je_u; const int Is_u = isv - 1, Ie_u = iev;
         if (v_first) { js_u = jsv; je_u = jev; } else { js_u = jsv - 1; je_u = jev + 1; }
+#pragma omp parallel for schedule(static)
         for (int j = js_u; j <= je_u; j++) for (int i = Is_u; i <= Ie_u; i++) {
           size_t c = IX2(d, i, j);
           Cor_u[c] = (((F4(f_4_u, 4, c) * vbt[c + 1]) + (F4(f_4_u, 1, c) * vbt[c - st])) +
@@ -699,6 +754,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
           ubt[c] = bt_rem_u[c] * (ubt[c] + dtbt * ((BT_force_u[c] + Cor_u[c]) + PFu[c]));
           if (fabs(ubt[c]) < P->vel_underflow) ubt[c] = 0.0;
         }
+#pragma omp parallel for schedule(static)
         for (int j = js_u; j <= je_u; j++) for (int i = Is_u; i <= Ie_u; i++) {
           size_t c = IX2(d, i, j);
           u_accel_bt[c] = u_accel_bt[c] + wt_accel[n] * (Cor_u[c] + PFu[c]);
@@ -706,23 +762,27 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
       }
     }
     /* transports, use_BT_cont branch :2624-2632 */
+#pragma omp parallel for schedule(static)
     for (int j = jsv; j <= jev; j++) for (int i = isv - 1; i <= iev; i++) {
       size_t c = IX2(d, i, j);
       ubt_trans[c] = trans_wt1 * ubt[c] + trans_wt2 * ubt_prev[c];
       uhbt[c] = find_uhbt(ubt_trans[c], &BTCL_u[c]) + uhbt0[c];
     }
+#pragma omp parallel for schedule(static)
     for (int j = jsv - 1; j <= jev; j++) for (int i = isv; i <= iev; i++) {
       size_t c = IX2(d, i, j);
       vbt_trans[c] = trans_wt1 * vbt[c] + trans_wt2 * vbt_prev[c];
       vhbt[c] = find_uhbt(vbt_trans[c], &BTCL_v[c]) + vhbt0[c];
     }
     /* running sums :2690-2700 */
+#pragma omp parallel for schedule(static)
     for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       CS->ubtav[c] = CS->ubtav[c] + wt_trans[n] * ubt_trans[c];
       uhbtav[c] = uhbtav[c] + wt_trans[n] * uhbt[c];
       ubt_wtd[c] = ubt_wtd[c] + wt_vel[n] * ubt[c];
     }
+#pragma omp parallel for schedule(static)
     for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
       size_t c = IX2(d, i, j);
       CS->vbtav[c] = CS->vbtav[c] + wt_trans[n] * vbt_trans[c];
@@ -730,6 +790,7 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
       vbt_wtd[c] = vbt_wtd[c] + wt_vel[n] * vbt[c];
     }
     /* eta corrector :2721-2727 */
+#pragma omp parallel for schedule(static)
     for (int j = jsv; j <= jev; j++) for (int i = isv; i <= iev; i++) {
       size_t c = IX2(d, i, j);
       eta[c] = (eta[c] + eta_src[c]) + (dtbt * IareaT[c]) * ((uhbt[c - 1] - uhbt[c]) + (vhbt[c - st] - vhbt[c]));
@@ -739,10 +800,12 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
 
   /* ---------------- after the time loop :1807-1913 ---------------- */
   if (find_etaav) for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) etaav[IX2(d, i, j)] = eta_sum[IX2(d, i, j)] * I_sum_wt_accel;
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
     size_t c = IX2(d, i, j);
     e_anom[c] = dgeo_de * (0.5 * (eta[c] + eta_in[c]) - eta_PF[c]);
   }
+#pragma omp parallel for schedule(static)
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta_out[IX2(d, i, j)] = eta_wtd[IX2(d, i, j)] * I_sum_wt_eta;
   if (find_etaav) orc_pass_var(d, etaav, 0, 1);
   orc_pass_var(d, e_anom, 0, 1);
@@ -752,12 +815,14 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   /* btstep_layer_accel :3432-3504 */
   const double accel_underflow = P->vel_underflow * Idt;
   for (int k = 0; k < nz; k++) {
+#pragma omp parallel for schedule(static)
     for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
       size_t c = IX2(d, i, j), c3 = c + k * slab;
       accel_layer_u[c3] = (u_accel_bt[c] - (((pbce[c3 + 1] - gtot_W[c + 1]) * e_anom[c + 1]) -
                                             ((pbce[c3] - gtot_E[c]) * e_anom[c])) * IdxCu[c]);
       if (fabs(accel_layer_u[c3]) < accel_underflow) accel_layer_u[c3] = 0.0;
     }
+#pragma omp parallel for schedule(static)
     for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
       size_t c = IX2(d, i, j), c3 = c + k * slab;
       accel_layer_v[c3] = (v_accel_bt[c] - (((pbce[c3 + st] - gtot_S[c + st]) * e_anom[c + st]) -

@@ -399,6 +399,7 @@ static void flux_thickness(const mom6x_dims *d, const dir_t *D, const double *u,
   int a0, a1, b0, b1;   /* i-range, j-range of faces */
   if (D->dir == 0) { a0 = ish - 1; a1 = ieh; b0 = jsh; b1 = jeh; }
   else             { a0 = ish; a1 = ieh; b0 = jsh - 1; b1 = jeh; }
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < d->nk; k++) for (int j = b0; j <= b1; j++) for (int i = a0; i <= a1; i++) {
     size_t f = IX3(d, i, j, k), f2 = IX2(d, i, j), p = f + st;
     double CFL, curv_3, h_avg, h_marg, uf = u[f];
@@ -418,6 +419,7 @@ static void flux_thickness(const mom6x_dims *d, const dir_t *D, const double *u,
     }
     h_u[f] = marginal ? h_marg : h_avg;
   }
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < d->nk; k++) for (int j = b0; j <= b1; j++) for (int i = a0; i <= a1; i++) {
     size_t f = IX3(d, i, j, k);
     if (visc_rem_u) h_u[f] = h_u[f] * (visc_rem_u[f] * 1.0);
@@ -442,6 +444,9 @@ static void mass_flux(const mom6x_dims *d, const dir_t *D, const mom6x_continuit
 
   if (du_cor) memset(du_cor, 0, sizeof(double) * slab); /* du_cor(:,:) = 0.0 */
 
+  /* rows are independent (the reference: !$OMP parallel do over j, :615 / :1508): every thread has its own row temporaries */
+#pragma omp parallel
+  {
   double *duhdu = (double *)calloc((size_t)P * nz, sizeof(double)) + d->ioff;
   double *vr = (double *)calloc((size_t)P * nz, sizeof(double)) + d->ioff;
   double *du = orc_row_alloc(d), *du_min_CFL = orc_row_alloc(d), *du_max_CFL = orc_row_alloc(d);
@@ -451,6 +456,7 @@ static void mass_flux(const mom6x_dims *d, const dir_t *D, const mom6x_continuit
 
   if (!use_visc_rem) for (int k = 0; k < nz; k++) for (int a = -d->ioff; a < P - d->ioff; a++) vr[(size_t)k * P + a] = 1.0;
 
+#pragma omp for schedule(dynamic, 2)
   for (int b = b0; b <= b1; b++) {
     row_t R = { a0, a1, b };
     for (int a = a0; a <= a1; a++) do_I[a] = 1;
@@ -533,21 +539,23 @@ static void mass_flux(const mom6x_dims *d, const dir_t *D, const mom6x_continuit
     }
   }
 
-  if (set_BT_cont && BT_h_u) { /* :802-812 */
-    flux_thickness(d, D, (u_cor ? u_cor : u), h_in, hL, hR, BT_h_u, dt, ish, ieh, jsh, jeh,
-                   CS->marginal_faces, visc_rem_u);
-  }
-
   free(duhdu - d->ioff); free(vr - d->ioff); free(do_I - d->ioff);
   orc_row_free(d, du); orc_row_free(d, du_min_CFL); orc_row_free(d, du_max_CFL);
   orc_row_free(d, duhdu_tot_0); orc_row_free(d, uh_tot_0); orc_row_free(d, visc_rem_max);
   orc_row_free(d, uhbt_row);
+  }   /* omp parallel */
+
+  if (set_BT_cont && BT_h_u) { /* :802-812 */
+    flux_thickness(d, D, (u_cor ? u_cor : u), h_in, hL, hR, BT_h_u, dt, ish, ieh, jsh, jeh,
+                   CS->marginal_faces, visc_rem_u);
+  }
 }
 
 /* continuity_zonal_convergence :348 / continuity_merdional_convergence :386 */
 static void convergence(const mom6x_dims *d, const dir_t *D, double *h, const double *uh, double dt,
                         int ish, int ieh, int jsh, int jeh, const double *hin, double h_min) {
   const int st = D->st;
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < d->nk; k++) for (int j = jsh; j <= jeh; j++) for (int i = ish; i <= ieh; i++) {
     size_t c = IX3(d, i, j, k), c2 = IX2(d, i, j);
     double h0 = hin ? hin[c] : h[c];
@@ -585,9 +593,16 @@ int orc_continuity_PPM(const mom6x_dims *d, const double *G, const mom6x_vgrid *
     }
     const double *h_src = (pass == 0) ? hin : h;
     const dir_t *D = do_x ? &DX : &DY;
-    for (int k = 0; k < d->nk; k++)
-      edge_thickness_2d(d, D, CS, h_src + (size_t)k * d->slab, h_W + (size_t)k * d->slab,
-                        h_E + (size_t)k * d->slab, 2.0 * GV->Angstrom_H, ish, ieh, jsh, jeh, slp);
+    /* (the reference threads its k loops: !$OMP parallel do, MOM_continuity_PPM.F90:370, :615; every thread its own slope plane) */
+#pragma omp parallel
+    {
+      double *slp_t = (double *)calloc((size_t)d->slab, sizeof(double));
+#pragma omp for schedule(static)
+      for (int k = 0; k < d->nk; k++)
+        edge_thickness_2d(d, D, CS, h_src + (size_t)k * d->slab, h_W + (size_t)k * d->slab,
+                          h_E + (size_t)k * d->slab, 2.0 * GV->Angstrom_H, ish, ieh, jsh, jeh, slp_t);
+      free(slp_t);
+    }
     if (do_x)
       mass_flux(d, D, CS, u, h_src, h_W, h_E, uh, dt, ish, ieh, jsh, jeh, uhbt, visc_rem_u, u_cor,
                 set_BT ? BT->FA_u_W0 : NULL, set_BT ? BT->FA_u_WW : NULL, set_BT ? BT->uBT_WW : NULL,

@@ -34,9 +34,7 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
   const double vol_neglect = GV->H_subroundoff * ((1e-4 * 1.0) * (1e-4 * 1.0));
   const double C1_12 = 1.0 / 12.0;
 #define NEW2(x) double *x = (double *)calloc(slab, sizeof(double))
-  NEW2(Area_h); NEW2(Area_q); NEW2(dvdx); NEW2(dudy); NEW2(hArea_u); NEW2(hArea_v); NEW2(rel_vort); NEW2(abs_vort);
-  NEW2(q); NEW2(a); NEW2(b); NEW2(c); NEW2(dd); NEW2(KE); NEW2(KEx); NEW2(KEy);
-  NEW2(uh_min); NEW2(uh_max); NEW2(vh_min); NEW2(vh_max);
+  NEW2(Area_h); NEW2(Area_q);
   const double *dy_Cu = GM(G, d, MOM6X_G_dy_Cu), *dx_Cv = GM(G, d, MOM6X_G_dx_Cv);
   /* CoriolisAdv_init :1119, :1158: ROBUST_ENSTRO switches En_Dis off; En_Dis with SADOURNY75_ENERGY switches the bound off */
   const int en_dis = CS->Coriolis_En_Dis;
@@ -50,6 +48,13 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
     Area_q[x] = (Area_h[x] + Area_h[x + 1 + st]) + (Area_h[x + 1] + Area_h[x + st]);
   }
 
+  /* layers are independent (the reference: !$OMP parallel do over k, MOM_CoriolisAdv.F90:305): every thread its own 2-d work arrays */
+#pragma omp parallel
+  {
+  NEW2(dvdx); NEW2(dudy); NEW2(hArea_u); NEW2(hArea_v); NEW2(rel_vort); NEW2(abs_vort);
+  NEW2(q); NEW2(a); NEW2(b); NEW2(c); NEW2(dd); NEW2(KE); NEW2(KEx); NEW2(KEy);
+  NEW2(uh_min); NEW2(uh_max); NEW2(vh_min); NEW2(vh_max);
+#pragma omp for schedule(static)
   for (int k = 0; k < nz; k++) {
     const double *uk = u + k * slab, *vk = v + k * slab, *hk = h + k * slab, *uhk = uh + k * slab, *vhk = vh + k * slab;
     double *CAuk = CAu + k * slab, *CAvk = CAv + k * slab;
@@ -196,8 +201,10 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
       CAvk[x] = ca - KEy[x];
     }
   }
-  double *all[] = { Area_h, Area_q, dvdx, dudy, hArea_u, hArea_v, rel_vort, abs_vort, q, a, b, c, dd, KE, KEx, KEy, uh_min, uh_max, vh_min, vh_max };
+  double *all[] = { dvdx, dudy, hArea_u, hArea_v, rel_vort, abs_vort, q, a, b, c, dd, KE, KEx, KEy, uh_min, uh_max, vh_min, vh_max };
   for (size_t m = 0; m < sizeof(all) / sizeof(all[0]); m++) free(all[m]);
+  }   /* omp parallel */
+  free(Area_h); free(Area_q);
   return MOM6X_OK;
 }
 
@@ -346,6 +353,7 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
   double *dz_geo = (double *)calloc(slab, sizeof(double));
 
   for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) e[IX2(d, i, j) + nz * slab] = -bathyT[IX2(d, i, j)];
+#pragma omp parallel for schedule(static)
   for (int j = Jsq; j <= Jeq + 1; j++) for (int k = nz - 1; k >= 0; k--) for (int i = Isq; i <= Ieq + 1; i++) {
     size_t x = IX2(d, i, j);
     e[x + k * slab] = e[x + (k + 1) * slab] + h[x + k * slab] * GV->H_to_Z;
@@ -412,6 +420,10 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
     }
     free(z0);
   } else
+#pragma omp parallel
+  {
+  double *dz_geo = (double *)calloc(slab, sizeof(double));   /* (per thread; shadows the routine's plane) */
+#pragma omp for schedule(static)
   for (int k = 0; k < nz; k++) { /* :1323-1333 */
     for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
       size_t x = IX2(d, i, j), x3 = x + k * slab;
@@ -428,27 +440,35 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
       inty_dpa[x + k * slab] = 0.5 * (Rlay[k] - rho_ref) * (dz_geo[x] + dz_geo[x + st]);
     }
   }
-  for (int k = 0; k < nz; k++) for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+  free(dz_geo);
+  }   /* omp parallel */
+  /* (column recurrences: the j loop outside, as the reference's !$OMP parallel do over j) */
+#pragma omp parallel for schedule(static)
+  for (int j = Jsq; j <= Jeq + 1; j++) for (int k = 0; k < nz; k++) for (int i = Isq; i <= Ieq + 1; i++) {
     size_t x = IX2(d, i, j);
     pa[x + (k + 1) * slab] = pa[x + k * slab] + dpa[x + k * slab];
   }
   for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) { size_t x = IX2(d, i, j); intx_pa[x] = 0.5 * (pa[x] + pa[x + 1]); }
   for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) { size_t x = IX2(d, i, j); inty_pa[x] = 0.5 * (pa[x] + pa[x + st]); }
-  for (int k = 0; k < nz; k++) for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
+#pragma omp parallel for schedule(static)
+  for (int j = js; j <= je; j++) for (int k = 0; k < nz; k++) for (int i = Isq; i <= Ieq; i++) {
     size_t x = IX2(d, i, j);
     intx_pa[x + (k + 1) * slab] = intx_pa[x + k * slab] + intx_dpa[x + k * slab];
   }
-  for (int k = 0; k < nz; k++) for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) {
+#pragma omp parallel for schedule(static)
+  for (int j = Jsq; j <= Jeq; j++) for (int k = 0; k < nz; k++) for (int i = is; i <= ie; i++) {
     size_t x = IX2(d, i, j);
     inty_pa[x + (k + 1) * slab] = inty_pa[x + k * slab] + inty_dpa[x + k * slab];
   }
   /* PFu, PFv :1794-1813 */
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
     size_t x = IX2(d, i, j), x3 = x + k * slab, xb = x + (k + 1) * slab;
     PFu[x3] = (((pa[x3] * h[x3] + intz_dpa[x3]) - (pa[x3 + 1] * h[x3 + 1] + intz_dpa[x3 + 1])) +
                ((h[x3 + 1] - h[x3]) * intx_pa[x3] - (e[xb + 1] - e[xb]) * intx_dpa[x3] * GV->Z_to_H)) *
               ((2.0 * I_Rho0 * IdxCu[x]) / ((h[x3] + h[x3 + 1]) + h_neglect));
   }
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) {
     size_t x = IX2(d, i, j), x3 = x + k * slab, xb = x + (k + 1) * slab;
     PFv[x3] = (((pa[x3] * h[x3] + intz_dpa[x3]) - (pa[x3 + st] * h[x3 + st] + intz_dpa[x3 + st])) +
@@ -497,7 +517,11 @@ static void vertvisc_dir(const mom6x_dims *d, const double *maskC, int a0, int a
                          int st, double h_neglect) {
   const int nz = d->nk;
   const size_t slab = (size_t)d->slab;
+  /* columns are independent (the reference: !$OMP parallel do over j, MOM_vert_friction.F90:698) */
+#pragma omp parallel
+  {
   double *c1 = (double *)calloc((size_t)nz, sizeof(double));
+#pragma omp for schedule(static)
   for (int j = b0; j <= b1; j++) for (int i = a0; i <= a1; i++) {
     size_t x = IX2(d, i, j);
     if (maskC[x] > 0.) {
@@ -536,6 +560,7 @@ static void vertvisc_dir(const mom6x_dims *d, const double *maskC, int a0, int a
     }
   }
   free(c1);
+  }   /* omp parallel */
 }
 
 int orc_vertvisc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, double *u, double *v,
@@ -557,7 +582,10 @@ static void remnant_dir(const mom6x_dims *d, const double *maskC, int a0, int a1
                         const double *a_u, const double *h_u, const double *Ray_u, double dt) {
   const int nz = d->nk;
   const size_t slab = (size_t)d->slab;
+#pragma omp parallel
+  {
   double *c1 = (double *)calloc((size_t)nz, sizeof(double));
+#pragma omp for schedule(static)
   for (int j = b0; j <= b1; j++) for (int i = a0; i <= a1; i++) {
     size_t x = IX2(d, i, j);
     if (!(maskC[x] > 0.)) continue;
@@ -578,6 +606,7 @@ static void remnant_dir(const mom6x_dims *d, const double *maskC, int a0, int a1
     for (int k = nz - 2; k >= 0; k--) vr[x + k * slab] = vr[x + k * slab] + c1[k + 1] * vr[x + (k + 1) * slab];
   }
   free(c1);
+  }   /* omp parallel */
 }
 
 int orc_vertvisc_remnant(const mom6x_dims *d, const double *G, double *visc_rem_u, double *visc_rem_v,

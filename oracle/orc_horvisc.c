@@ -229,10 +229,14 @@ int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_v
   const double h_neglect = GV->H_subroundoff, h_neglect3 = h_neglect * h_neglect * h_neglect;
   const int legacy_bound = CS->Smagorinsky_Kh && (CS->bound_Kh && !CS->better_bound_Kh);
   const int smag = CS->Smagorinsky_Kh || CS->Smagorinsky_Ah, better = CS->better_bound_Ah || CS->better_bound_Kh;
+  /* layers are independent (the reference: !$OMP parallel do over k, MOM_hor_visc.F90:690): every thread its own work planes */
+#pragma omp parallel
+  {
   double *w = (double *)calloc(slab * 16, sizeof(double));
   double *sh_xx = w, *sh_xy = w + slab, *h_u = w + 2 * slab, *h_v = w + 3 * slab, *Del2u = w + 4 * slab, *Del2v = w + 5 * slab;
   double *str_xx = w + 6 * slab, *str_xy = w + 7 * slab, *Shear = w + 8 * slab, *hrat = w + 9 * slab, *vbr = w + 10 * slab;
   double *dDel2vdx = w + 11 * slab, *dDel2udy = w + 12 * slab, *hq = w + 13 * slab, *Kh = w + 14 * slab, *Ah = w + 15 * slab;
+#pragma omp for schedule(static)
   for (int k = 0; k < nz; k++) {
     const double *uk = u + k * slab, *vk = v + k * slab, *hk = h + k * slab;
     for (int j = Jsq - 1; j <= Jeq + 2; j++) for (int i = Isq - 1; i <= Ieq + 2; i++) {   /* :724-731 */
@@ -408,5 +412,6 @@ int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_v
     }
   }
   free(w);
+  }   /* omp parallel */
   return MOM6X_OK;
 }

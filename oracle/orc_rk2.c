@@ -156,6 +156,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
     rc = orc_CorAdCalc(d, G, GV, A->cor, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred);
     if (rc) return rc;
   }
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) { /* :564-571 */
     for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
       size_t x = IX3(d, i, j, k);
@@ -166,6 +167,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
       v_bc_accel[x] = (CS->CAv_pred[x] + CS->PFv[x]) + CS->diffv[x];
     }
   }
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) { /* :591-598 */
     for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
       size_t x = IX3(d, i, j, k);
@@ -198,6 +200,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   if (rc) return rc;
 
   const double dt_pred = dt * R->be; /* :679 */
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) { /* :681-694 */
     for (int j = Jsq; j <= Jeq; j++) for (int i = is; i <= ie; i++) {
       size_t x = IX3(d, i, j, k);
@@ -224,6 +227,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   orc_pass_var(d, hp, 0, nz); orc_pass_var(d, u_av, 1, nz); orc_pass_var(d, v_av, 2, nz);   /* pass_hp_uv :785 */
   orc_pass_var(d, uh, 1, nz); orc_pass_var(d, vh, 2, nz);
 
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++) { /* :808-810 */
     size_t x = IX3(d, i, j, k);
     h_av[x] = 0.5 * (h[x] + hp[x]);
@@ -250,6 +254,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
 
   rc = orc_CorAdCalc(d, G, GV, A->cor, u_av, v_av, h_av, uh, vh, CS->CAu, CS->CAv); /* :893 */
   if (rc) return rc;
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) { /* :900-907 */
     for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
       size_t x = IX3(d, i, j, k);
@@ -267,6 +272,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   if (rc) return rc;
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta[IX2(d, i, j)] = eta_pred[IX2(d, i, j)]; /* :946 */
 
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) { /* :957-966 */
     for (int j = js; j <= je; j++) for (int i = Isq; i <= Ieq; i++) {
       size_t x = IX3(d, i, j, k);
@@ -283,6 +289,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
                taux, tauy, dt, CS->taux_bot, CS->tauy_bot, A->Hmix_stress, h);
   orc_vertvisc_remnant(d, G, CS->visc_rem_u, CS->visc_rem_v, coef[2].a_u, coef[2].a_v, coef[2].h_u, coef[2].h_v,
                        coef[2].Ray_u, coef[2].Ray_v, dt);
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++) { /* :1025-1027 */
     size_t x = IX3(d, i, j, k);
     h_av[x] = h[x];
@@ -297,10 +304,12 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   orc_pass_var(d, h, 0, nz); /* pass_h :1045 */
   orc_pass_var(d, u_av, 1, nz); orc_pass_var(d, v_av, 2, nz); orc_pass_var(d, uh, 1, nz); orc_pass_var(d, vh, 2, nz); /* :1053 */
 
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++) { /* :1064-1066 */
     size_t x = IX3(d, i, j, k);
     h_av[x] = 0.5 * (h_av[x] + h[x]);
   }
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) { /* :1072-1079 */
     for (int j = js - 2; j <= je + 2; j++) for (int i = Isq - 2; i <= Ieq + 2; i++) {
       size_t x = IX3(d, i, j, k);

@@ -17,9 +17,13 @@ static void coef_dir(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV
   const double a_cpl_max = 1.0e37 * GV->Z_to_H;
   double I_valBL = 0.0; if (CS->harm_BL_val > 0.0) I_valBL = 1.0 / CS->harm_BL_val;
   const double I_amax = (CS->answer_date < 20190101) ? (1.0e-10 * GV->H_to_Z) * dt : 0.0;   /* :2391-2395 */
+  /* columns are independent (the reference: !$OMP parallel do over j, MOM_vert_friction.F90:1508) */
+#pragma omp parallel
+  {
   double *hvel = (double *)calloc(nz, sizeof(double)), *dz_vel = (double *)calloc(nz, sizeof(double));
   double *dz_harm = (double *)calloc(nz, sizeof(double)), *z_i = (double *)calloc(nz + 1, sizeof(double));
   double *a_cpl = (double *)calloc(nz + 1, sizeof(double));
+#pragma omp for schedule(static)
   for (int j = b0; j <= b1; j++) for (int i = a0; i <= a1; i++) {
     const size_t x = IX2(d, i, j), y = x + st;
     if (!(maskC[x] > 0.)) continue;                                   /* do_i :1514-1516 */
@@ -117,6 +121,7 @@ static void coef_dir(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV
     for (int k = 0; k < nz; k++) h_out[x + k * slab] = hvel[k] + h_neglect;             /* :1868-1872 */
   }
   free(hvel); free(dz_vel); free(dz_harm); free(z_i); free(a_cpl);
+  }   /* omp parallel */
 }
 
 int orc_vertvisc_coef(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_vertvisc_params *CS,
