@@ -302,8 +302,17 @@ def cpu_baseline(args):
     from mom6_amd import abi, grid, synth
     from oracle import orc
     import ctypes
+    # the host cores this process may use: the cgroup CPU quota where there is one (a box that shows 256 hardware threads
+    # but grants 16 CPUs runs the loops slower with 128 threads than with one), else what the scheduler allows
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
-        cores = int(ctypes.CDLL("libgomp.so.1").omp_get_max_threads())
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
     except OSError:
         cores = 1
     ni, nj, nk = 360, 180, args.nk
