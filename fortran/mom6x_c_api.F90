@@ -23,7 +23,7 @@ module mom6x_c_api
   public :: mom6x_bt_mass_source, mom6x_set_dtbt, mom6x_set_dtbt_pbce, mom6x_btstep
   public :: mom6x_CoriolisAdv_init, mom6x_CorAdCalc, mom6x_PressureForce_init, mom6x_PressureForce
   public :: mom6x_vertvisc_set_coef, mom6x_vertvisc, mom6x_vertvisc_remnant
-  public :: mom6x_initialize_dyn_split_RK2, mom6x_dyn_split_RK2_new_run, mom6x_rk2_field
+  public :: mom6x_initialize_dyn_split_RK2, mom6x_dyn_split_RK2_new_run, mom6x_rk2_field, mom6x_rk2_set_CAu_pred_stored
   public :: mom6x_step_dyn_split_RK2, mom6x_comm_unique_id, mom6x_comm_init, mom6x_pass_fields
 
   !> mom6x_dims: hor_index_type extents (MOM_hor_index.F90:14-44) + the device layout
@@ -377,6 +377,10 @@ module mom6x_c_api
     end function
     integer(c_int) function mom6x_dyn_split_RK2_new_run(ctx, u, v, h, uh, vh, dt) bind(C, name="mom6x_dyn_split_RK2_new_run")
       import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, u, v, h, uh, vh ; real(c_double), value :: dt
+    end function
+    !> a restarted run that read CAu_pred, CAv_pred from the file: the first step must not recompute them (RK2.F90:1616)
+    integer(c_int) function mom6x_rk2_set_CAu_pred_stored(ctx, stored) bind(C, name="mom6x_rk2_set_CAu_pred_stored")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx ; integer(c_int), value :: stored
     end function
     type(c_ptr) function mom6x_rk2_field(ctx, which) bind(C, name="mom6x_rk2_field")
       import :: c_ptr, c_int ; type(c_ptr), value :: ctx ; integer(c_int), value :: which
