@@ -240,6 +240,13 @@ typedef struct mom6x_eos_params {
   double dRho_dp;         /* linear_EOS%dRho_dp (0)                                             */
   int    MassWghtInterp;  /* bit 0: MASS_WEIGHT_IN_PRESSURE_GRADIENT, bit 1: ..._TOP (F, F)     */
   int    use_SSH_in_Z0p;  /* SSH_IN_EOS_PRESSURE_FOR_PGF (F)                                    */
+  /* With ALE (USE_REGRIDDING): RECONSTRUCT_FOR_PRESSURE + PRESSURE_RECONSTRUCTION_SCHEME (PressureForce_FV_init :2172-2184)  */
+  int    Recon_Scheme;    /* 0: layer-mean T, S (analytic integrals); 1: PLM edge values (TS_PLM_edge_values, MOM_ALE.F90:1495)
+                           *    and the 5-point quadrature of int_density_dz_generic_plm (MOM_density_integrals.F90:418);
+                           *    2 (PPM): not carried                                                */
+  int    boundary_extrap; /* BOUNDARY_EXTRAPOLATION_PRESSURE (T)                                   */
+  int    MassWghtInterpVanOnly; /* MASS_WEIGHT_IN_PGF_VANISHED_ONLY (F)                            */
+  double h_nonvanished;   /* RESET_INTXPA_H_NONVANISHED (1e-6 m) [H]: the thickness below which a side counts as vanished */
 } mom6x_eos_params;
 
 /* MOM_dyn_split_RK2_CS parameters (src/core/MOM_dynamics_split_RK2.F90:85-273, read in
@@ -403,6 +410,10 @@ int mom6x_PressureForce(mom6x_ctx *ctx, const double *h, double *PFu, double *PF
  * calls inside mom6x_step_dyn_split_RK2 -- take the use_EOS branch (:1206, :1289-1309: int_density_dz,
  * and Set_pbce_Bouss :692-722).  T == NULL dissociates tv%eqn_of_state again (layered path).  Bulk mixed
  * layers (GV%nk_rho_varies > 0) and ALE reconstructions are not on this path.                        */
+/* ALE_PLM_edge_values(CS, G, GV, h, Q, bdry_extrap, Q_t, Q_b), MOM_ALE.F90:1520-1577: the values of a PLM reconstruction of the
+ * tracer Q at the top and the bottom of every layer (TS_PLM_edge_values :1495 calls it for S and T); boundary cells PCM unless
+ * bdry_extrap.  Answer dates >= 20190101 (h_neglect = GV%H_subroundoff).                                                   */
+int mom6x_ALE_PLM_edge_values(mom6x_ctx *ctx, const double *h, const double *Q, int bdry_extrap, double *Q_t, double *Q_b);
 int mom6x_PressureForce_set_tv(mom6x_ctx *ctx, const double *T, const double *S, const mom6x_eos_params *eos);
 
 /* ------------------------------------------------------------------------- */

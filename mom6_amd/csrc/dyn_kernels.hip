@@ -438,7 +438,7 @@ extern "C" int mom6x_CorAdCalc(mom6x_ctx *c, const double *u, const double *v, c
 // PressureForce_FV_Bouss with an equation of state (:1206, :1289-1316): analytic_int_density_dz
 // (MOM_EOS.F90:1384) for EOS_LINEAR (MOM_EOS_linear.F90:275-475) and EOS_WRIGHT (MOM_EOS_Wright.F90:389-655),
 // and the use_EOS branch of Set_pbce_Bouss (MOM_PressureForce_Montgomery.F90:704-733).
-struct EosDev { int form; double Rho_T0_S0, dRho_dT, dRho_dS, dRho_dp; int do_mw, top_mw, ssh_z0; };
+struct EosDev { int form; double Rho_T0_S0, dRho_dT, dRho_dS, dRho_dp; int do_mw, top_mw, ssh_z0; int van_only; double dz_nv; };
 
 namespace {
 constexpr double W_a0 = 7.057924e-4, W_a1 = 3.480336e-7, W_a2 = -1.112733e-7;
@@ -533,12 +533,103 @@ __device__ __forceinline__ double face_int(const EosDev &E, double rho_ref, doub
   return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
 }
 
-// One thread per (i,j) column, top-down like k_pgf_main; the integrals of the east and north neighbours are
-// recomputed by this thread (no 3-D dpa / intz_dpa / intx_dpa arrays).
+
+// ---- use_ALE with PRESSURE_RECONSTRUCTION_SCHEME = 1 (PressureForce_FV.F90:1235-1236, :1287-1296) ---------------------
+// density_anomaly_elem_linear (MOM_EOS_linear.F90:74-84) / density_anomaly_elem_buggy_Wright (MOM_EOS_Wright.F90:101-129):
+// calculate_density(..., rho_ref=rho_ref) of the quadratures of int_density_dz_generic_plm
 template <int FORM>
+__device__ __forceinline__ double density_anomaly(const EosDev &E, double T, double S, double pressure, double rho_ref) {
+  if (FORM == MOM6X_EOS_LINEAR)
+    return (E.Rho_T0_S0 - rho_ref) + ((E.dRho_dT * T + E.dRho_dS * S) + E.dRho_dp * pressure);
+  const double pa_000 = (W_b0 * (1.0 - W_a0 * rho_ref) - rho_ref * W_c0);
+  const double al_TS = W_a1 * T + W_a2 * S;
+  const double al0 = W_a0 + al_TS;
+  const double p_TSp = pressure + (W_b4 * S + T * (W_b1 + (T * (W_b2 + W_b3 * T) + W_b5 * S)));
+  const double lam_TS = W_c4 * S + T * (W_c1 + (T * (W_c2 + W_c3 * T) + W_c5 * S));
+  return (pa_000 + (p_TSp - rho_ref * (p_TSp * al0 + (W_b0 * al_TS + lam_TS)))) / ((W_c0 + lam_TS) + al0 * (W_b0 + p_TSp));
+}
+
+// section 1 of int_density_dz_generic_plm (MOM_density_integrals.F90:587-637): dpa and intz_dpa of one cell by Boole's rule
+template <int FORM>
+__device__ __forceinline__ void cell_int_plm(const EosDev &E, double rho_ref, double G_e, double GxRho, double Tt, double Tb,
+                                             double St, double Sb, double zt, double zb, double z0, double &dpa, double &intz) {
+  const double C1_90 = 1.0 / 90.0;
+  const double dz = zt - zb;
+  double r5[6];
+#pragma unroll
+  for (int n = 1; n <= 5; n++) {
+    const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
+    const double p5 = -GxRho * ((zt - z0) - 0.25 * (double)(n - 1) * dz);
+    const double S5 = wt_t * St + wt_b * Sb;
+    const double T5 = wt_t * Tt + wt_b * Tb;
+    r5[n] = density_anomaly<FORM>(E, T5, S5, p5, rho_ref);
+  }
+  const double rho_anom = C1_90 * (7.0 * (r5[1] + r5[5]) + 32.0 * (r5[2] + r5[4]) + 12.0 * r5[3]);
+  dpa = G_e * dz * rho_anom;
+  intz = 0.5 * G_e * (dz * dz) * (rho_anom - C1_90 * (16.0 * (r5[4] - r5[2]) + 7.0 * (r5[5] - r5[1])));
+}
+
+// sections 2 / 3 (:640-742 / :745-868): intx_dpa | inty_dpa of the face between columns L and R
+template <int FORM>
+__device__ __forceinline__ double face_int_plm(const EosDev &E, double rho_ref, double G_e, double GxRho, double dz_subroundoff,
+                                               double TtL, double TbL, double StL, double SbL, double TtR, double TbR, double StR,
+                                               double SbR, double ztL, double zbL, double ztR, double zbR, double z0L, double z0R,
+                                               double bathyL, double bathyR, double sshL, double sshR, double dpaL, double dpaR) {
+  const double C1_90 = 1.0 / 90.0;
+  const double mwT = E.do_mw ? 1. : 0., topT = E.top_mw ? 1. : 0., nvT = E.van_only ? 0. : 1.;
+  double hWght = mwT * dmax(dmax(0., -bathyL - ztR), -bathyR - ztL);
+  const double hWghtTop = topT * dmax(dmax(0., zbR - sshL), zbL - sshR);
+  hWght = dmax(hWght, hWghtTop);
+  if (((ztL - zbL) > E.dz_nv) && ((ztR - zbR) > E.dz_nv)) hWght = nvT * hWght;
+  double Ttl = TtL, Tbl = TbL, Ttr = TtR, Tbr = TbR, Stl = StL, Sbl = SbL, Str = StR, Sbr = SbR;
+  if (hWght > 0.) {
+    const double hL = (ztL - zbL) + dz_subroundoff, hR = (ztR - zbR) + dz_subroundoff;
+    const double q = (hL - hR) / (hL + hR);
+    hWght = hWght * (q * q);
+    const double iDenom = 1. / (hWght * (hR + hL) + hL * hR);
+    Ttl = ((hWght * hR) * TtR + (hWght * hL + hR * hL) * TtL) * iDenom;
+    Ttr = ((hWght * hL) * TtL + (hWght * hR + hR * hL) * TtR) * iDenom;
+    Tbl = ((hWght * hR) * TbR + (hWght * hL + hR * hL) * TbL) * iDenom;
+    Tbr = ((hWght * hL) * TbL + (hWght * hR + hR * hL) * TbR) * iDenom;
+    Stl = ((hWght * hR) * StR + (hWght * hL + hR * hL) * StL) * iDenom;
+    Str = ((hWght * hL) * StL + (hWght * hR + hR * hL) * StR) * iDenom;
+    Sbl = ((hWght * hR) * SbR + (hWght * hL + hR * hL) * SbL) * iDenom;
+    Sbr = ((hWght * hL) * SbL + (hWght * hR + hR * hL) * SbR) * iDenom;
+  }
+  double intz[6];
+  intz[1] = dpaL; intz[5] = dpaR;
+#pragma unroll
+  for (int m = 2; m <= 4; m++) {
+    const double w_left = 0.25 * (double)(5 - m), w_right = 1.0 - w_left;
+    const double dz_x = (w_left * (ztL - zbL)) + (w_right * (ztR - zbR));
+    double T15[6], S15[6], p15[6], r15[6];
+    T15[1] = (w_left * Ttl) + (w_right * Ttr); T15[5] = (w_left * Tbl) + (w_right * Tbr);
+    S15[1] = (w_left * Stl) + (w_right * Str); S15[5] = (w_left * Sbl) + (w_right * Sbr);
+    p15[1] = -GxRho * ((w_left * (ztL - z0L)) + (w_right * (ztR - z0R)));
+#pragma unroll
+    for (int n = 2; n <= 5; n++) p15[n] = p15[n - 1] + GxRho * 0.25 * dz_x;
+#pragma unroll
+    for (int n = 2; n <= 4; n++) {
+      const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
+      S15[n] = wt_t * S15[1] + wt_b * S15[5];
+      T15[n] = wt_t * T15[1] + wt_b * T15[5];
+    }
+#pragma unroll
+    for (int n = 1; n <= 5; n++) r15[n] = density_anomaly<FORM>(E, T15[n], S15[n], p15[n], rho_ref);
+    intz[m] = (G_e * dz_x * (C1_90 * (7.0 * (r15[1] + r15[5]) + 32.0 * (r15[2] + r15[4]) + 12.0 * r15[3])));
+  }
+  return C1_90 * (7.0 * (intz[1] + intz[5]) + 32.0 * (intz[2] + intz[4]) + 12.0 * intz[3]);
+}
+
+// One thread per (i,j) column, top-down like k_pgf_main; the integrals of the east and north neighbours are
+// recomputed by this thread (no 3-D dpa / intz_dpa / intx_dpa arrays).  PLM: the T, S edge values of TS_PLM_edge_values
+// (Tt, Tb, St, Sb) and the generic quadratures instead of the layer means and the analytic integrals.
+template <int FORM, bool PLM>
 __global__ void __launch_bounds__(256)
 k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h, const double *__restrict__ e,
-               const double *__restrict__ Tv, const double *__restrict__ Sv, EosDev E, double *__restrict__ PFu,
+               const double *__restrict__ Tv, const double *__restrict__ Sv, const double *__restrict__ Tt,
+               const double *__restrict__ Tb, const double *__restrict__ St, const double *__restrict__ Sb, EosDev E,
+               double *__restrict__ PFu,
                double *__restrict__ PFv, double *__restrict__ pbce, double *__restrict__ eta, double g_Earth, double H_to_Z,
                double Z_to_H, double rho_ref, double GxRho_ref, double Z_ref, double Rho0, double rho0_alt, double h_neglect,
                double dz_neglect) {
@@ -572,15 +663,28 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
     const double h0 = h[c], T0 = Tv[c], S0 = Sv[c];
     const double zb0 = e[cb];
     double dpa0, iz0;
-    cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, zt0, zb0, z00, dpa0, iz0);
+    double Tt0 = 0., Tb0 = 0., St0 = 0., Sb0 = 0.;
+    if (PLM) {
+      Tt0 = Tt[c]; Tb0 = Tb[c]; St0 = St[c]; Sb0 = Sb[c];
+      cell_int_plm<FORM>(E, rho_ref, G_e, GxRho, Tt0, Tb0, St0, Sb0, zt0, zb0, z00, dpa0, iz0);
+    } else {
+      cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, zt0, zb0, z00, dpa0, iz0);
+    }
     if (Z_to_H != 1.0) iz0 = iz0 * Z_to_H;
     if (do_u) {
       const double h1 = h[c + 1], T1 = Tv[c + 1], S1 = Sv[c + 1], zb1 = e[cb + 1];
-      double dpa1, iz1;
-      cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T1, S1, zt1, zb1, z01, dpa1, iz1);
+      double dpa1, iz1, intx_dpa;
+      if (PLM) {
+        const double Tt1 = Tt[c + 1], Tb1 = Tb[c + 1], St1 = St[c + 1], Sb1 = Sb[c + 1];
+        cell_int_plm<FORM>(E, rho_ref, G_e, GxRho, Tt1, Tb1, St1, Sb1, zt1, zb1, z01, dpa1, iz1);
+        intx_dpa = face_int_plm<FORM>(E, rho_ref, G_e, GxRho, dz_neglect, Tt0, Tb0, St0, Sb0, Tt1, Tb1, St1, Sb1, zt0, zb0, zt1, zb1,
+                                      z00, z01, b0, b1, ssh0, ssh1, dpa0, dpa1);
+      } else {
+        cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T1, S1, zt1, zb1, z01, dpa1, iz1);
+        intx_dpa = face_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, T1, S1, zt0, zb0, zt1, zb1, z00, z01, b0, b1,
+                                  ssh0, ssh1, dz_neglect, dpa0, dpa1);
+      }
       if (Z_to_H != 1.0) iz1 = iz1 * Z_to_H;
-      const double intx_dpa = face_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, T1, S1, zt0, zb0, zt1, zb1, z00, z01, b0, b1,
-                                             ssh0, ssh1, dz_neglect, dpa0, dpa1);
       PFu[c] = (((pa0 * h0 + iz0) - (pa1 * h1 + iz1)) + ((h1 - h0) * intx_pa - (zb1 - zb0) * intx_dpa * Z_to_H)) *
                (cu / ((h0 + h1) + h_neglect));
       pa1 = pa1 + dpa1;
@@ -589,11 +693,18 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
     }
     if (do_v) {
       const double h2 = h[c + st], T2 = Tv[c + st], S2 = Sv[c + st], zb2 = e[cb + st];
-      double dpa2, iz2;
-      cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T2, S2, zt2, zb2, z02, dpa2, iz2);
+      double dpa2, iz2, inty_dpa;
+      if (PLM) {
+        const double Tt2 = Tt[c + st], Tb2 = Tb[c + st], St2 = St[c + st], Sb2 = Sb[c + st];
+        cell_int_plm<FORM>(E, rho_ref, G_e, GxRho, Tt2, Tb2, St2, Sb2, zt2, zb2, z02, dpa2, iz2);
+        inty_dpa = face_int_plm<FORM>(E, rho_ref, G_e, GxRho, dz_neglect, Tt0, Tb0, St0, Sb0, Tt2, Tb2, St2, Sb2, zt0, zb0, zt2, zb2,
+                                      z00, z02, b0, b2, ssh0, ssh2, dpa0, dpa2);
+      } else {
+        cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T2, S2, zt2, zb2, z02, dpa2, iz2);
+        inty_dpa = face_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, T2, S2, zt0, zb0, zt2, zb2, z00, z02, b0, b2,
+                                  ssh0, ssh2, dz_neglect, dpa0, dpa2);
+      }
       if (Z_to_H != 1.0) iz2 = iz2 * Z_to_H;
-      const double inty_dpa = face_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, T2, S2, zt0, zb0, zt2, zb2, z00, z02, b0, b2,
-                                             ssh0, ssh2, dz_neglect, dpa0, dpa2);
       PFv[c] = (((pa0 * h0 + iz0) - (pa2 * h2 + iz2)) + ((h2 - h0) * inty_pa - (zb2 - zb0) * inty_dpa * Z_to_H)) *
                (cv / ((h0 + h2) + h_neglect));
       pa2 = pa2 + dpa2;
@@ -641,6 +752,8 @@ extern "C" int mom6x_PressureForce_set_tv(mom6x_ctx *c, const double *T, const d
   REQUIRE(S && eos, MOM6X_EINVAL, "mom6x_PressureForce_set_tv: tv%T without tv%S or tv%eqn_of_state");
   REQUIRE(eos->form == MOM6X_EOS_LINEAR || eos->form == MOM6X_EOS_WRIGHT, MOM6X_EUNSUPPORTED,
           "No analytic integration option is available with this EOS!");
+  REQUIRE(eos->Recon_Scheme == 0 || eos->Recon_Scheme == 1, MOM6X_EUNSUPPORTED,
+          "PressureForce_FV: PRESSURE_RECONSTRUCTION_SCHEME = 2 (PPM) is not carried; use 1 (PLM) or 0");
   c->tv_T = T; c->tv_S = S; c->eos = *eos;
   return MOM6X_OK;
 }
@@ -675,16 +788,23 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
     E.form = c->eos.form; E.Rho_T0_S0 = c->eos.Rho_T0_S0; E.dRho_dT = c->eos.dRho_dT; E.dRho_dS = c->eos.dRho_dS;
     E.dRho_dp = c->eos.dRho_dp; E.do_mw = c->eos.MassWghtInterp & 1; E.top_mw = (c->eos.MassWghtInterp >> 1) & 1;
     E.ssh_z0 = c->eos.use_SSH_in_Z0p;
+    E.van_only = c->eos.MassWghtInterpVanOnly; E.dz_nv = GV.H_to_Z * c->eos.h_nonvanished;   // dz_nonvanished :1128
     const double rho0_alt = c->pgf.rho_ref_bug ? c->pgf.rho_ref : GV.Rho0;   // rho0_int_density = rho0_set_pbce
     const dim3 g = grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b);
-    if (E.form == MOM6X_EOS_LINEAR)
-      KLAUNCH(c, "k_pgf_main_eos<linear>", k_pgf_main_eos<MOM6X_EOS_LINEAR>, g, b, d, c->G, h, e, c->tv_T, c->tv_S, E, PFu, PFv, pbce, eta,
-              GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, GV.Rho0, rho0_alt, GV.H_subroundoff,
-              GV.dZ_subroundoff);
-    else
-      KLAUNCH(c, "k_pgf_main_eos<wright>", k_pgf_main_eos<MOM6X_EOS_WRIGHT>, g, b, d, c->G, h, e, c->tv_T, c->tv_S, E, PFu, PFv, pbce, eta,
-              GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, GV.Rho0, rho0_alt, GV.H_subroundoff,
-              GV.dZ_subroundoff);
+    const bool plm = (c->eos.Recon_Scheme == 1);
+    double *Tt = nullptr, *Tb = nullptr, *St = nullptr, *Sb = nullptr;
+    if (plm) {   // TS_PLM_edge_values (MOM_ALE.F90:1495): S first, then T
+      if ((rc = ctx_scratch(c, SCR_t0, d.nk, &Tt)) || (rc = ctx_scratch(c, SCR_t1, d.nk, &Tb)) ||
+          (rc = ctx_scratch(c, SCR_t2, d.nk, &St)) || (rc = ctx_scratch(c, SCR_t3, d.nk, &Sb))) return rc;
+      if ((rc = mom6x_ALE_PLM_edge_values(c, h, c->tv_S, c->eos.boundary_extrap, St, Sb))) return rc;
+      if ((rc = mom6x_ALE_PLM_edge_values(c, h, c->tv_T, c->eos.boundary_extrap, Tt, Tb))) return rc;
+    }
+#define PGF_EOS(F, P, NAME) KLAUNCH(c, NAME, (k_pgf_main_eos<F, P>), g, b, d, c->G, h, e, c->tv_T, c->tv_S, Tt, Tb, St, Sb, E, PFu, PFv,   \
+                                    pbce, eta, GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, GV.Rho0, \
+                                    rho0_alt, GV.H_subroundoff, GV.dZ_subroundoff)
+    if (E.form == MOM6X_EOS_LINEAR) { if (plm) PGF_EOS(MOM6X_EOS_LINEAR, true, "k_pgf_main_plm<linear>"); else PGF_EOS(MOM6X_EOS_LINEAR, false, "k_pgf_main_eos<linear>"); }
+    else                            { if (plm) PGF_EOS(MOM6X_EOS_WRIGHT, true, "k_pgf_main_plm<wright>"); else PGF_EOS(MOM6X_EOS_WRIGHT, false, "k_pgf_main_eos<wright>"); }
+#undef PGF_EOS
     HIPCHK(hipGetLastError());
     return MOM6X_OK;
   }

@@ -786,7 +786,59 @@ int remap_field(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int 
   return MOM6X_OK;
 }
 
+// ALE_PLM_edge_values, MOM_ALE.F90:1520-1577: one thread per column; slp(k-1), slp(k), slp(k+1) are carried in registers so
+// that the column is read once (h, Q) and written once (Q_t, Q_b).
+__global__ void __launch_bounds__(256)
+k_plm_edge_values(Dm d, const double *__restrict__ h, const double *__restrict__ Q, int bdry_extrap, double hn,
+                  double *__restrict__ Q_t, double *__restrict__ Q_b) {
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -1 || i > d.ni || j > d.nj) return;
+  const int N = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+#define HK(k) h[x + (size_t)((k) - 1) * slab]
+#define QK(k) Q[x + (size_t)((k) - 1) * slab]
+  if (N >= 3) {
+    double hm = HK(1), hc = HK(2), um = QK(1), uc = QK(2);
+    double s_m = 0.0, s_c, s_p;
+    {
+      const double hp = HK(3), up = QK(3);
+      s_c = PLM_slope_wa(hm, hc, hp, hn, um, uc, up);                                   // slp(2)
+    }
+    for (int k = 2; k <= N - 1; k++) {
+      const double hp = HK(k + 1), up = QK(k + 1);
+      s_p = (k + 1 <= N - 1) ? PLM_slope_wa(hc, hp, HK(k + 2), hn, uc, up, QK(k + 2)) : 0.;   // slp(k+1) (slp(N) = 0)
+      const double mslp = PLM_monotonized_slope(um, uc, up, s_m, s_c, s_p);
+      Q_t[x + (size_t)(k - 1) * slab] = uc - 0.5 * mslp;
+      Q_b[x + (size_t)(k - 1) * slab] = uc + 0.5 * mslp;
+      hm = hc; hc = hp; um = uc; uc = up; s_m = s_c; s_c = s_p;
+    }
+  }
+  if (bdry_extrap && N >= 2) {
+    double mslp = -PLM_extrapolate_slope(HK(2), HK(1), hn, QK(2), QK(1));
+    Q_t[x] = QK(1) - 0.5 * mslp; Q_b[x] = QK(1) + 0.5 * mslp;
+    mslp = PLM_extrapolate_slope(HK(N - 1), HK(N), hn, QK(N - 1), QK(N));
+    Q_t[x + (size_t)(N - 1) * slab] = QK(N) - 0.5 * mslp; Q_b[x + (size_t)(N - 1) * slab] = QK(N) + 0.5 * mslp;
+  } else {
+    Q_t[x] = QK(1); Q_b[x] = QK(1);
+    Q_t[x + (size_t)(N - 1) * slab] = QK(N); Q_b[x + (size_t)(N - 1) * slab] = QK(N);
+  }
+#undef HK
+#undef QK
+}
 }  // namespace
+
+// ALE_PLM_edge_values(CS, G, GV, h, Q, bdry_extrap, Q_t, Q_b), MOM_ALE.F90:1520 (answer dates >= 20190101)
+extern "C" int mom6x_ALE_PLM_edge_values(mom6x_ctx *c, const double *h, const double *Q, int bdry_extrap, double *Q_t, double *Q_b) {
+  REQUIRE(c && h && Q && Q_t && Q_b, MOM6X_EINVAL, "mom6x_ALE_PLM_edge_values: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  const dim3 b(64, 4, 1);
+  KLAUNCH(c, "k_plm_edge_values", k_plm_edge_values, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, h, Q, bdry_extrap,
+          c->GV.H_subroundoff, Q_t, Q_b);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
 
 extern "C" int mom6x_ALE_remap_tracers(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old, const double *h_new,
                                        double *const *fields, int nfields) {

@@ -184,6 +184,10 @@ class Dycore:
         """PressureForce (MOM_PressureForce.F90:41) -> PressureForce_FV_Bouss (FV.F90:947)."""
         check(self.lib, self.lib.mom6x_PressureForce(self.ctx, _ptr(h), _ptr(PFu), _ptr(PFv), _ptr(pbce), _ptr(eta)))
 
+    def ALE_PLM_edge_values(self, h, Q, bdry_extrap, Q_t, Q_b):
+        """ALE_PLM_edge_values (MOM_ALE.F90:1520): top and bottom values of the PLM reconstruction of Q in every layer."""
+        check(self.lib, self.lib.mom6x_ALE_PLM_edge_values(self.ctx, _ptr(h), _ptr(Q), C.c_int(int(bdry_extrap)), _ptr(Q_t), _ptr(Q_b)))
+
     def PressureForce_set_tv(self, T, S, eos):
         """tv%T, tv%S, tv%eqn_of_state of PressureForce's thermo_var_ptrs argument; T=None: layered path."""
         self._tv = (T, S, eos)

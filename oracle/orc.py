@@ -142,6 +142,18 @@ def PressureForce(d, G, GV, CS, Rlay, g_prime, h, PFu, PFv, pbce=None, eta=None,
         raise RuntimeError(f"orc_PressureForce rc={rc}")
 
 
+def ALE_PLM_edge_values(d, GV, h, Q, bdry_extrap, Q_t, Q_b):
+    """ALE_PLM_edge_values (MOM_ALE.F90:1520)."""
+    lib().orc_ALE_PLM_edge_values(C.byref(d), C.byref(GV), _p(h), _p(Q), C.c_int(int(bdry_extrap)), _p(Q_t), _p(Q_b))
+
+
+def eos_density_anomaly(eos, T, S, p, rho_ref):
+    """calculate_density(T, S, p, rho, EOS, rho_ref=rho_ref) for one point."""
+    f = lib().orc_eos_density_anomaly
+    f.restype = C.c_double
+    return f(C.byref(eos), C.c_double(T), C.c_double(S), C.c_double(p), C.c_double(rho_ref))
+
+
 def hor_visc_init(d, G, CS):
     """The 2-D coefficient planes of hor_visc_CS as one block [nplanes][slab]."""
     n = lib().orc_hor_visc_nplanes()

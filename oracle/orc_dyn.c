@@ -329,6 +329,114 @@ static double face_int_wright(double rho_ref, double G_e, double GxRho, double I
   return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
 }
 
+/* density_anomaly_elem_linear (MOM_EOS_linear.F90:74-84) / density_anomaly_elem_buggy_Wright (MOM_EOS_Wright.F90:101-129):
+ * calculate_density(T, S, p, rho, EOS, dom, rho_ref=rho_ref) of the quadratures below. */
+static double eos_density_anomaly(const mom6x_eos_params *E, double T, double S, double pressure, double rho_ref) {
+  if (E->form == MOM6X_EOS_LINEAR)
+    return (E->Rho_T0_S0 - rho_ref) + ((E->dRho_dT * T + E->dRho_dS * S) + E->dRho_dp * pressure);
+  const double pa_000 = (W_b0 * (1.0 - W_a0 * rho_ref) - rho_ref * W_c0);
+  const double al_TS = W_a1 * T + W_a2 * S;
+  const double al0 = W_a0 + al_TS;
+  const double p_TSp = pressure + (W_b4 * S + T * (W_b1 + (T * (W_b2 + W_b3 * T) + W_b5 * S)));
+  const double lam_TS = W_c4 * S + T * (W_c1 + (T * (W_c2 + W_c3 * T) + W_c5 * S));
+  return (pa_000 + (p_TSp - rho_ref * (p_TSp * al0 + (W_b0 * al_TS + lam_TS)))) / ((W_c0 + lam_TS) + al0 * (W_b0 + p_TSp));
+}
+double orc_eos_density_anomaly(const mom6x_eos_params *E, double T, double S, double p, double rho_ref) {
+  return eos_density_anomaly(E, T, S, p, rho_ref);
+}
+
+double orc_PLM_slope_wa(double h_l, double h_c, double h_r, double h_neglect, double u_l, double u_c, double u_r);
+double orc_PLM_monotonized_slope(double u_l, double u_c, double u_r, double s_l, double s_c, double s_r);
+double orc_PLM_extrapolate_slope(double h_l, double h_c, double h_neglect, double u_l, double u_c);
+
+/* ALE_PLM_edge_values, MOM_ALE.F90:1520-1577 (answer_date >= 20190101: h_neglect = GV%H_subroundoff) */
+void orc_ALE_PLM_edge_values(const mom6x_dims *d, const mom6x_vgrid *GV, const double *h, const double *Q, int bdry_extrap,
+                             double *Q_t, double *Q_b) {
+  const int nz = d->nk;
+  const size_t slab = (size_t)d->slab;
+  const double h_neglect = GV->H_subroundoff;
+#pragma omp parallel
+  {
+  double *slp = (double *)calloc((size_t)nz + 2, sizeof(double));
+#pragma omp for schedule(static)
+  for (int j = -1; j <= d->nj; j++) for (int i = -1; i <= d->ni; i++) {
+    const size_t x = IX2(d, i, j);
+#define Hk(k) h[x + (size_t)((k) - 1) * slab]
+#define Qk(k) Q[x + (size_t)((k) - 1) * slab]
+    slp[1] = 0.;
+    for (int k = 2; k <= nz - 1; k++) slp[k] = orc_PLM_slope_wa(Hk(k - 1), Hk(k), Hk(k + 1), h_neglect, Qk(k - 1), Qk(k), Qk(k + 1));
+    slp[nz] = 0.;
+    for (int k = 2; k <= nz - 1; k++) {
+      const double mslp = orc_PLM_monotonized_slope(Qk(k - 1), Qk(k), Qk(k + 1), slp[k - 1], slp[k], slp[k + 1]);
+      Q_t[x + (size_t)(k - 1) * slab] = Qk(k) - 0.5 * mslp;
+      Q_b[x + (size_t)(k - 1) * slab] = Qk(k) + 0.5 * mslp;
+    }
+    if (bdry_extrap && nz >= 2) {
+      double mslp = -orc_PLM_extrapolate_slope(Hk(2), Hk(1), h_neglect, Qk(2), Qk(1));
+      Q_t[x] = Qk(1) - 0.5 * mslp; Q_b[x] = Qk(1) + 0.5 * mslp;
+      mslp = orc_PLM_extrapolate_slope(Hk(nz - 1), Hk(nz), h_neglect, Qk(nz - 1), Qk(nz));
+      Q_t[x + (size_t)(nz - 1) * slab] = Qk(nz) - 0.5 * mslp; Q_b[x + (size_t)(nz - 1) * slab] = Qk(nz) + 0.5 * mslp;
+    } else {
+      Q_t[x] = Qk(1); Q_b[x] = Qk(1);
+      Q_t[x + (size_t)(nz - 1) * slab] = Qk(nz); Q_b[x + (size_t)(nz - 1) * slab] = Qk(nz);
+    }
+#undef Hk
+#undef Qk
+  }
+  free(slp);
+  }
+}
+
+/* One face of int_density_dz_generic_plm: section 2 (x, MOM_density_integrals.F90:640-742) or 3 (y, :745-868).  L / R: the
+ * two columns; *_t, *_b: top and bottom values of the layer; zt, zb: its interfaces; ssh: e(:,:,1). */
+static double face_int_generic_plm(const mom6x_eos_params *E, double rho_ref, double G_e, double GxRho, double mwT, double topT,
+                                   double nvT, double h_nv, double dz_subroundoff, double TtL, double TbL, double StL, double SbL,
+                                   double TtR, double TbR, double StR, double SbR, double ztL, double zbL, double ztR, double zbR,
+                                   double z0L, double z0R, double bathyL, double bathyR, double sshL, double sshR, double dpaL, double dpaR) {
+  const double C1_90 = 1.0 / 90.0;
+  double hWght = mwT * orc_max(orc_max(0., -bathyL - ztR), -bathyR - ztL);
+  const double hWghtTop = topT * orc_max(orc_max(0., zbR - sshL), zbL - sshR);
+  hWght = orc_max(hWght, hWghtTop);
+  if (((ztL - zbL) > h_nv) && ((ztR - zbR) > h_nv)) hWght = nvT * hWght;
+  double Ttl, Tbl, Ttr, Tbr, Stl, Sbl, Str, Sbr;
+  if (hWght > 0.) {
+    const double hL = (ztL - zbL) + dz_subroundoff, hR = (ztR - zbR) + dz_subroundoff;
+    const double q = (hL - hR) / (hL + hR);
+    hWght = hWght * (q * q);
+    const double iDenom = 1. / (hWght * (hR + hL) + hL * hR);
+    Ttl = ((hWght * hR) * TtR + (hWght * hL + hR * hL) * TtL) * iDenom;
+    Ttr = ((hWght * hL) * TtL + (hWght * hR + hR * hL) * TtR) * iDenom;
+    Tbl = ((hWght * hR) * TbR + (hWght * hL + hR * hL) * TbL) * iDenom;
+    Tbr = ((hWght * hL) * TbL + (hWght * hR + hR * hL) * TbR) * iDenom;
+    Stl = ((hWght * hR) * StR + (hWght * hL + hR * hL) * StL) * iDenom;
+    Str = ((hWght * hL) * StL + (hWght * hR + hR * hL) * StR) * iDenom;
+    Sbl = ((hWght * hR) * SbR + (hWght * hL + hR * hL) * SbL) * iDenom;
+    Sbr = ((hWght * hL) * SbL + (hWght * hR + hR * hL) * SbR) * iDenom;
+  } else {
+    Ttl = TtL; Tbl = TbL; Ttr = TtR; Tbr = TbR;
+    Stl = StL; Sbl = SbL; Str = StR; Sbr = SbR;
+  }
+  double intz[6];
+  intz[1] = dpaL; intz[5] = dpaR;
+  for (int m = 2; m <= 4; m++) {
+    const double w_left = 0.25 * (double)(5 - m), w_right = 1.0 - w_left;
+    const double dz_x = (w_left * (ztL - zbL)) + (w_right * (ztR - zbR));
+    double T15[6], S15[6], p15[6], r15[6];
+    T15[1] = (w_left * Ttl) + (w_right * Ttr); T15[5] = (w_left * Tbl) + (w_right * Tbr);
+    S15[1] = (w_left * Stl) + (w_right * Str); S15[5] = (w_left * Sbl) + (w_right * Sbr);
+    p15[1] = -GxRho * ((w_left * (ztL - z0L)) + (w_right * (ztR - z0R)));
+    for (int n = 2; n <= 5; n++) p15[n] = p15[n - 1] + GxRho * 0.25 * dz_x;
+    for (int n = 2; n <= 4; n++) {
+      const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
+      S15[n] = wt_t * S15[1] + wt_b * S15[5];
+      T15[n] = wt_t * T15[1] + wt_b * T15[5];
+    }
+    for (int n = 1; n <= 5; n++) r15[n] = eos_density_anomaly(E, T15[n], S15[n], p15[n], rho_ref);
+    intz[m] = (G_e * dz_x * (C1_90 * (7.0 * (r15[1] + r15[5]) + 32.0 * (r15[2] + r15[4]) + 12.0 * r15[3])));
+  }
+  return C1_90 * (7.0 * (intz[1] + intz[5]) + 32.0 * (intz[2] + intz[4]) + 12.0 * intz[3]);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* PressureForce_FV_Bouss :947-2017.  T == NULL: layered (no equation of state) path; else the use_EOS path with
  * analytic_int_density_dz (MOM_EOS.F90:1384) for EOS_LINEAR / EOS_WRIGHT and Set_pbce_Bouss's use_EOS branch.      */
@@ -363,11 +471,63 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
     pa[x] = GxRho_ref * (e[x] - Z_ref);
   }
   const int use_EOS = (T != NULL);
-  if (use_EOS && !(EOS && S && (EOS->form == MOM6X_EOS_LINEAR || EOS->form == MOM6X_EOS_WRIGHT))) {
+  if (use_EOS && !(EOS && S && (EOS->form == MOM6X_EOS_LINEAR || EOS->form == MOM6X_EOS_WRIGHT) &&
+                   (EOS->Recon_Scheme == 0 || EOS->Recon_Scheme == 1))) {
     free(e); free(pa); free(dpa); free(intz_dpa); free(intx_pa); free(inty_pa); free(intx_dpa); free(inty_dpa); free(dz_geo);
     return MOM6X_EUNSUPPORTED;
   }
-  if (use_EOS) {   /* :1289-1316 with int_density_dz -> analytic_int_density_dz */
+  if (use_EOS && EOS->Recon_Scheme == 1) {
+    /* use_ALE with PRESSURE_RECONSTRUCTION_SCHEME = 1 (:1235-1236, :1287-1296): TS_PLM_edge_values, then
+     * int_density_dz_generic_plm (MOM_density_integrals.F90:418-870) layer by layer */
+    const double rho0_int = CS->rho_ref_bug ? rho_ref : GV->Rho0;    /* rho0_int_density :1134-1144 */
+    const double G_e = GV->g_Earth, GxRho = G_e * rho0_int, C1_90 = 1.0 / 90.0;
+    const double mwT = (EOS->MassWghtInterp & 1) ? 1. : 0., topT = ((EOS->MassWghtInterp >> 1) & 1) ? 1. : 0.;
+    const double nvT = EOS->MassWghtInterpVanOnly ? 0. : 1.;
+    const double h_nv = GV->H_to_Z * EOS->h_nonvanished;             /* dz_nonvanished :1128 */
+    double *T_t = (double *)calloc(slab * nz, sizeof(double)), *T_b = (double *)calloc(slab * nz, sizeof(double));
+    double *S_t = (double *)calloc(slab * nz, sizeof(double)), *S_b = (double *)calloc(slab * nz, sizeof(double));
+    orc_ALE_PLM_edge_values(d, GV, h, S, EOS->boundary_extrap, S_t, S_b);
+    orc_ALE_PLM_edge_values(d, GV, h, T, EOS->boundary_extrap, T_t, T_b);
+    double *z0 = (double *)calloc(slab, sizeof(double));
+    for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {   /* Z_0p :1264-1276 (p_atm absent) */
+      size_t x = IX2(d, i, j);
+      z0[x] = EOS->use_SSH_in_Z0p ? e[x] : Z_ref;
+    }
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < nz; k++) {
+      const double *zt = e + k * slab, *zb = e + (k + 1) * slab;
+      const double *Tt = T_t + k * slab, *Tb = T_b + k * slab, *St = S_t + k * slab, *Sb = S_b + k * slab;
+      for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {   /* 1. vertical integrals :587-637 */
+        size_t x = IX2(d, i, j), x3 = x + k * slab;
+        const double dz = zt[x] - zb[x];
+        double r5[6];
+        for (int n = 1; n <= 5; n++) {
+          const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
+          const double p5 = -GxRho * ((zt[x] - z0[x]) - 0.25 * (double)(n - 1) * dz);
+          const double S5 = wt_t * St[x] + wt_b * Sb[x];
+          const double T5 = wt_t * Tt[x] + wt_b * Tb[x];
+          r5[n] = eos_density_anomaly(EOS, T5, S5, p5, rho_ref);
+        }
+        const double rho_anom = C1_90 * (7.0 * (r5[1] + r5[5]) + 32.0 * (r5[2] + r5[4]) + 12.0 * r5[3]);
+        dpa[x3] = G_e * dz * rho_anom;
+        intz_dpa[x3] = 0.5 * G_e * (dz * dz) * (rho_anom - C1_90 * (16.0 * (r5[4] - r5[2]) + 7.0 * (r5[5] - r5[1])));
+      }
+      for (int dir = 0; dir < 2; dir++) {                                              /* 2. x :640-742, 3. y :745-868 */
+        const int s2 = dir ? st : 1;
+        const int a0 = dir ? is : Isq, a1 = dir ? ie : Ieq, b0 = dir ? Jsq : js, b1 = dir ? Jeq : je;
+        double *out = dir ? inty_dpa : intx_dpa;
+        for (int j = b0; j <= b1; j++) for (int i = a0; i <= a1; i++) {
+          size_t x = IX2(d, i, j), y = x + s2;
+          out[x + k * slab] = face_int_generic_plm(EOS, rho_ref, G_e, GxRho, mwT, topT, nvT, h_nv, dz_neglect, Tt[x], Tb[x], St[x], Sb[x],
+                                                   Tt[y], Tb[y], St[y], Sb[y], zt[x], zb[x], zt[y], zb[y], z0[x], z0[y], bathyT[x],
+                                                   bathyT[y], e[x], e[y], dpa[x + k * slab], dpa[y + k * slab]);
+        }
+      }
+      if (GV->Z_to_H != 1.0)
+        for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) intz_dpa[IX2(d, i, j) + k * slab] *= GV->Z_to_H;
+    }
+    free(z0); free(T_t); free(T_b); free(S_t); free(S_b);
+  } else if (use_EOS) {   /* :1289-1316 with int_density_dz -> analytic_int_density_dz */
     const double rho0_int = CS->rho_ref_bug ? rho_ref : GV->Rho0;    /* rho0_int_density :1134-1144 */
     const double G_e = GV->g_Earth, GxRho = G_e * rho0_int, I_Rho = 1.0 / rho0_int;
     const int do_mw = EOS->MassWghtInterp & 1, top_mw = (EOS->MassWghtInterp >> 1) & 1;

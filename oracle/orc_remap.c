@@ -46,6 +46,15 @@ static double PLM_extrapolate_slope(double h_l, double h_c, double h_neglect, do
   const double left_edge = (u_l * hc + u_c * hl) / (hl + hc);
   return 2.0 * (u_c - left_edge);
 }
+double orc_PLM_slope_wa(double h_l, double h_c, double h_r, double h_neglect, double u_l, double u_c, double u_r) {
+  return PLM_slope_wa(h_l, h_c, h_r, h_neglect, u_l, u_c, u_r);
+}
+double orc_PLM_monotonized_slope(double u_l, double u_c, double u_r, double s_l, double s_c, double s_r) {
+  return PLM_monotonized_slope(u_l, u_c, u_r, s_l, s_c, s_r);
+}
+double orc_PLM_extrapolate_slope(double h_l, double h_c, double h_neglect, double u_l, double u_c) {
+  return PLM_extrapolate_slope(h_l, h_c, h_neglect, u_l, u_c);
+}
 /* PLM_reconstruction :197-262 */
 void orc_PLM_reconstruction(int N, const double *h, const double *u, double *E1, double *E2, double *C1, double *C2, double h_neglect) {
   const double almost_one = 1. - DBL_EPSILON;

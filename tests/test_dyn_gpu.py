@@ -99,9 +99,13 @@ def test_PressureForce(orc, cfg, bug):
 
 @pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
 @pytest.mark.parametrize("form", ["LINEAR", "WRIGHT"])
-@pytest.mark.parametrize("mods", [dict(), dict(MassWghtInterp=1), dict(MassWghtInterp=3, use_SSH_in_Z0p=1, bug=0, dRho_dp=4.5e-7)])
+@pytest.mark.parametrize("mods", [dict(), dict(MassWghtInterp=1), dict(MassWghtInterp=3, use_SSH_in_Z0p=1, bug=0, dRho_dp=4.5e-7),
+                                  # the ALE path: TS_PLM_edge_values + int_density_dz_generic_plm (PRESSURE_RECONSTRUCTION_SCHEME = 1)
+                                  dict(Recon_Scheme=1), dict(Recon_Scheme=1, boundary_extrap=0, MassWghtInterp=1),
+                                  dict(Recon_Scheme=1, MassWghtInterp=3, MassWghtInterpVanOnly=1, h_nonvanished=5.0, use_SSH_in_Z0p=1, bug=0)])
 def test_PressureForce_with_equation_of_state(orc, cfg, form, mods):
-    """The use_EOS branch (int_density_dz -> analytic linear / Wright integrals, Set_pbce_Bouss with T and S)."""
+    """The use_EOS branch (int_density_dz -> analytic linear / Wright integrals, or with Recon_Scheme = 1 the PLM edge values
+    and the generic 5-point quadratures; Set_pbce_Bouss with T and S)."""
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
@@ -134,6 +138,12 @@ def test_PressureForce_with_equation_of_state(orc, cfg, form, mods):
     H.assert_bitwise(g["pbce"].cpu().numpy(), o["pbce"], "pbce", sl)
     H.assert_bitwise(g["eta"].cpu().numpy(), o["eta"], "eta", sl)
     assert np.abs(o["PFu"]).max() > 0 and np.isfinite(o["PFu"]).all()
+    if eos.Recon_Scheme == 1:   # ALE_PLM_edge_values itself (public in MOM_ALE), through its own entry point
+        Qt_o, Qb_o = np.zeros_like(h), np.zeros_like(h)
+        orc.ALE_PLM_edge_values(d, GV, h, T, eos.boundary_extrap, Qt_o, Qb_o)
+        Qt, Qb = dyc.zeros3(), dyc.zeros3()
+        dyc.ALE_PLM_edge_values(hd, Td, eos.boundary_extrap, Qt, Qb); dyc.sync()
+        H.assert_bitwise(Qt.cpu().numpy(), Qt_o, "T_t", sl); H.assert_bitwise(Qb.cpu().numpy(), Qb_o, "T_b", sl)
     # back to the layered path
     dyc.PressureForce_set_tv(None, None, None)
     o2 = dict(PFu=np.zeros_like(h), PFv=np.zeros_like(h))

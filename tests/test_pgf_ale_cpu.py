@@ -1,0 +1,119 @@
+"""The pressure force on an ALE grid (PressureForce_FV_Bouss with RECONSTRUCT_FOR_PRESSURE, PRESSURE_RECONSTRUCTION_SCHEME = 1:
+MOM_PressureForce_FV.F90:1235-1236, :1287-1296; TS_PLM_edge_values MOM_ALE.F90:1495; int_density_dz_generic_plm
+MOM_density_integrals.F90:418-870) -- the oracle's restatement.
+
+Pins: ALE_PLM_edge_values against the REAL reference PLM code (src/ALE/PLM_functions.F90 compiled as it lies, oracle/_ref),
+bit for bit; the density anomaly against the check value of the reference's EOS_unit_tests.  Consistency: with vertically
+uniform T, S the 5-point quadratures reproduce the analytic integrals of the layer-mean path to quadrature accuracy, and a
+level, horizontally uniform ocean feels no force."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from mom6_amd import abi, synth
+from tests import cases
+from tests import helpers as H
+
+G = abi.G
+
+
+def _ref_lib():
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_ale.so")
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref is not built (needs /root/reference and amdflang; __graft_entry__.build() makes it)")
+    L = C.CDLL(p)
+    return L
+
+
+@pytest.mark.parametrize("extrap", [0, 1])
+def test_ALE_PLM_edge_values_against_the_compiled_reference(orc, extrap):
+    """Q_t, Q_b of every column equal the edge values PLM_reconstruction (+ PLM_boundary_extrapolation) of the reference
+    returns for that column: the same slopes (PLM_slope_wa, PLM_monotonized_slope, PLM_extrapolate_slope), the same
+    u -+ 0.5 slope."""
+    L = _ref_lib()
+    gg, d, M = H.benchmark_small(nk=12)
+    GV = abi.vgrid_default()
+    h, _, _ = synth.make_state(d, M, thin_frac=0.2)
+    T, S = cases.thermo_state(d, M)
+    Q_t, Q_b = np.zeros_like(h), np.zeros_like(h)
+    orc.ALE_PLM_edge_values(d, GV, h, T, extrap, Q_t, Q_b)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = d.nk
+    checked = 0
+    for j in range(-1, d.nj + 1, 3):
+        for i in range(-1, d.ni + 1, 2):
+            col = (slice(None), j + d.joff, i + d.ioff)
+            hc, uc = np.ascontiguousarray(h[col]), np.ascontiguousarray(T[col])
+            edges = np.zeros((2, n)); coefs = np.zeros((2, n))
+            L.ref_PLM_reconstruction(n, ptr(hc), ptr(uc), ptr(edges), ptr(coefs), C.c_double(GV.H_subroundoff), extrap)
+            assert np.array_equal(Q_t[col], edges[0]) and np.array_equal(Q_b[col], edges[1]), (i, j)
+            checked += 1
+    assert checked > 100 and np.abs(Q_b - Q_t).max() > 1e-3
+
+
+def test_density_anomaly_against_reference_check_values(orc):
+    """EOS_unit_tests (MOM_EOS.F90:2077-2079, :2129-2131): rho(T=25, S=35, p=1e7) = 1027.54303596346 (WRIGHT), 1028.0 (LINEAR
+    with dRho_dT = -0.2 ... ) to 1000 eps -- here through the rho_ref form the quadratures use."""
+    ew = abi.eos_params_default(abi.WRIGHT)
+    for rho_ref in (0.0, 1000.0, 1035.0):
+        r = orc.eos_density_anomaly(ew, 25.0, 35.0, 1.0e7, rho_ref)
+        assert abs((r + rho_ref) - 1027.54303596346) < 1000 * 2.2e-16 * 1027.5
+    el = abi.eos_params_default(abi.LINEAR)
+    assert orc.eos_density_anomaly(el, 10.0, 30.0, 0.0, 1000.0) == (el.Rho_T0_S0 - 1000.0) + (el.dRho_dT * 10.0 + el.dRho_dS * 30.0)
+
+
+@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
+def test_PLM_quadrature_reduces_to_the_analytic_integrals(orc, form):
+    """With T and S uniform in the vertical the PLM edge values are the layer values, and the Boole quadratures of
+    int_density_dz_generic_plm integrate the same density field the analytic routines integrate exactly: PFu, PFv of the two
+    paths agree to quadrature / round-off accuracy; with stratified T, S they differ (the reconstruction matters)."""
+    gg, d, M = H.benchmark_small()
+    GV = abi.vgrid_default(); CS = abi.pgf_params_default(GV.Rho0)
+    Rlay, gp = abi.layer_densities(d.nk, GV.Rho0, GV.g_Earth)
+    h, _, _ = synth.make_state(d, M, thin_frac=0.05)
+    T = np.ascontiguousarray(np.broadcast_to(12.0 + 3.0 * synth.smooth_field(d, 5, ox=0.5, oy=0.5), h.shape))
+    S = np.ascontiguousarray(np.broadcast_to(34.5 + 0.5 * synth.smooth_field(d, 6, ox=0.5, oy=0.5), h.shape))
+    su, sv = H.interior(d, "u"), H.interior(d, "v")
+    res = {}
+    for recon in (0, 1):
+        eos = abi.eos_params_default(form); eos.Recon_Scheme = recon
+        Pu, Pv, pb = np.zeros_like(h), np.zeros_like(h), np.zeros_like(h)
+        orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, pbce=pb, T=T, S=S, eos=eos)
+        res[recon] = (Pu, Pv, pb)
+    scale = np.abs(res[0][0][(Ellipsis,) + su]).max()
+    assert scale > 0
+    # LINEAR: the two are the same integrals.  WRIGHT: across a face the analytic routine interpolates the EOS COEFFICIENTS
+    # al0, p0, lambda (MOM_EOS_Wright.F90:585-593) where the generic one interpolates T and S and then evaluates the EOS
+    # (MOM_density_integrals.F90:700-720): two second-order approximations that differ at O(dT^2)
+    tol = 2e-7 if form == abi.LINEAR else 1e-4
+    assert np.abs(res[1][0] - res[0][0])[(Ellipsis,) + su].max() < tol * scale
+    assert np.abs(res[1][1] - res[0][1])[(Ellipsis,) + sv].max() < tol * scale
+    np.testing.assert_array_equal(res[1][2], res[0][2])           # pbce does not see the reconstruction
+    # stratified: the PLM path differs from the layer-mean one where the layers tilt
+    T2, S2 = cases.thermo_state(d, M)
+    out = {}
+    for recon in (0, 1):
+        eos = abi.eos_params_default(form); eos.Recon_Scheme = recon
+        Pu, Pv = np.zeros_like(h), np.zeros_like(h)
+        orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, T=T2, S=S2, eos=eos)
+        out[recon] = Pu
+    assert np.abs(out[1] - out[0])[(Ellipsis,) + su].max() > 1e-6 * np.abs(out[0][(Ellipsis,) + su]).max()
+
+
+@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
+def test_resting_stratified_ocean_feels_no_force_with_reconstruction(orc, form):
+    gg, d, M = H.channel()
+    GV = abi.vgrid_default(); CS = abi.pgf_params_default(GV.Rho0)
+    Rlay, gp = abi.layer_densities(d.nk, GV.Rho0, GV.g_Earth)
+    h = np.full(d.shape3(), 1000.0 / d.nk)
+    T = np.zeros_like(h); S = np.zeros_like(h)
+    for k in range(d.nk):
+        T[k] = 18.0 - 4.0 * k; S[k] = 34.0 + 0.3 * k
+    eos = abi.eos_params_default(form); eos.Recon_Scheme = 1; eos.MassWghtInterp = 3
+    Pu, Pv = np.zeros_like(h), np.zeros_like(h)
+    orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, T=T, S=S, eos=eos)
+    su, sv = H.interior(d, "u"), H.interior(d, "v")
+    assert np.abs(Pu[(Ellipsis,) + su] * M[G["mask2dCu"]][su]).max() < 1e-12
+    assert np.abs(Pv[(Ellipsis,) + sv] * M[G["mask2dCv"]][sv]).max() < 1e-12

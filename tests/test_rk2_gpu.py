@@ -20,7 +20,7 @@ STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h",
 
 
 def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, per_stage=False, new_diff=False,
-        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None, Hmix_stress=0.0):
+        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None, Hmix_stress=0.0, recon=0):
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
@@ -36,6 +36,7 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
     if eos_form is not None:   # tv%T, tv%S, tv%eqn_of_state: the PressureForce calls take the use_EOS branch
         Tt, St = cases.thermo_state(d, M)
         tv = (Tt, St, abi.eos_params_default(eos_form))
+        tv[2].Recon_Scheme = recon   # 1: the ALE path of PressureForce (PLM reconstruction of T, S)
         if Hmix_stress > 0.0:
             tv[2].MassWghtInterp = 1   # the tc4-like case also has MASS_WEIGHT_IN_PRESSURE_GRADIENT
     # ---------------- oracle
@@ -146,9 +147,10 @@ def test_rk2_device_matches_committed_golden(orc):
         H.assert_bitwise(out[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))], gold[n], "golden:" + n)
 
 
+@pytest.mark.parametrize("recon", [0, 1])
 @pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
-def test_rk2_with_equation_of_state(orc, form):
-    run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(begw=0.2), eos_form=form)
+def test_rk2_with_equation_of_state(orc, form, recon):
+    run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(begw=0.2), eos_form=form, recon=recon)
 
 
 @pytest.mark.parametrize("mods", [dict(), dict(harmonic_visc=1, bottomdraglaw=0)])
