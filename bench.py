@@ -122,6 +122,18 @@ KERNEL_WORDS = {
 }
 
 
+def synthetic_entrainment(h):
+    """ea, eb of triDiagTS / tracer_vertdiff [H]: a diffusive exchange of 1e-3 h across every interior interface -- what layer k
+    takes from below (eb(k)) is what layer k+1 gives up to above (ea(k+1)), nothing crosses the surface or the bottom, so the
+    solves conserve the column integrals."""
+    import torch
+    ea = (1.0e-3 * h).contiguous()
+    ea[0].zero_()
+    eb = torch.roll(ea, -1, 0).contiguous()
+    eb[-1].zero_()
+    return ea, eb
+
+
 def make_thermo(args, dyc, d, st, nth):
     """The thermodynamic step of the headline configuration (DT_THERM = 3600 s = 4 DT, T and S plus two
     passive tracers): advect_tracer (PPM) moves all of them with the transports uhtr / vhtr accumulated over the last nth
@@ -135,7 +147,7 @@ def make_thermo(args, dyc, d, st, nth):
     T = (10.0 + synth_dev.smooth_field(d, dyc.device, 81, nk=nk)).contiguous()
     S = (35.0 + 0.5 * synth_dev.smooth_field(d, dyc.device, 82, nk=nk)).contiguous()
     tr = [(10.0 + 5.0 * synth_dev.smooth_field(d, dyc.device, 71 + m, nk=nk, ox=0.5, oy=0.5)).contiguous() for m in range(ntr)]
-    ea = (1.0e-3 * st["h"]).contiguous(); eb = (2.0e-3 * st["h"]).contiguous()     # synthetic diffusive exchanges [H]
+    ea, eb = synthetic_entrainment(st["h"])
     stat = {"calls": 0, "iters": 0}
 
     def thermo():
@@ -264,6 +276,82 @@ FUSED_WORDS = {
 }
 
 
+def ale_cycle(args, device=0, steps=4, warm=1, check=None):
+    """BASELINE.json configs[4] on ONE of its 4 x 2 tiles (1080 x 1620 x 75 of the 4320 x 3240 grid: the per-GPU share of the
+    8-GPU run, as one stand-alone grid -- eight tiles at 53 GB each do not fit one GPU): an ALE cycle of step_MOM, i.e.
+    `steps` dynamics steps with the pressure force of an ALE grid (tv%T, tv%S, LINEAR equation of state, PLM reconstruction:
+    PRESSURE_RECONSTRUCTION_SCHEME = 1), then advect_tracer of T, S and two passive tracers with the accumulated transports,
+    their vertical tridiagonal solves, ALE_regrid to z* and the remapping of T, S, the tracers, u, v (PPM_H4) and of the
+    auxiliary restart variables.  Returns (seconds per cycle, dict of what was measured); `check(state)` is called after the
+    last cycle with the live fields (tests/test_configs_gpu.py)."""
+    import torch
+    from mom6_amd import abi, synth_dev
+
+    class A:
+        pass
+    a = A()
+    a.ni, a.nj, a.nk, a.dt, a.tracers = args.ale_ni, args.ale_nj, args.nk, args.dt, 2
+    dyc, d, st, taux, tauy, keep = build_model(a, (1, 1), (0, 0), device)
+    torch.cuda.set_stream(dyc.torch_stream())
+    nk = a.nk
+    T = (20.0 - 15.0 * torch.arange(nk, device=dyc.device, dtype=torch.float64)[:, None, None] / max(nk - 1, 1) +
+         0.8 * synth_dev.smooth_field(d, dyc.device, 7, nk=nk, ox=0.5, oy=0.5)).contiguous()
+    S = (34.0 + 1.0 * torch.arange(nk, device=dyc.device, dtype=torch.float64)[:, None, None] / max(nk - 1, 1) +
+         0.2 * synth_dev.smooth_field(d, dyc.device, 8, nk=nk, ox=0.5, oy=0.5)).contiguous()
+    eos = abi.eos_params_default(abi.LINEAR); eos.Recon_Scheme = 1
+    dyc.PressureForce_set_tv(T, S, eos)
+    tr = [(10.0 + 5.0 * synth_dev.smooth_field(d, dyc.device, 71 + m, nk=nk, ox=0.5, oy=0.5)).contiguous() for m in range(2)]
+    ea, eb = synthetic_entrainment(st["h"])
+    dyc.tracer_advect_init(a.dt, scheme=2)
+    CSr = abi.remapping_params_default(abi.REMAP_PPM_H4, dyc.GV.H_subroundoff, om4_remap_via_sub_cells=1, boundary_extrapolation=0)
+    RP = abi.regrid_zstar_params_default()
+    Hcol = st["h"].sum(0)
+    jm, im = divmod(int(torch.argmax(Hcol)), Hcol.shape[1])
+    cr = (st["h"][:, jm, im] / dyc.GV.Z_to_H).cpu().numpy().copy()
+    h_new = torch.zeros_like(st["h"]); dzI = torch.zeros((nk + 1,) + tuple(st["h"].shape[1:]), dtype=torch.float64, device=dyc.device)
+    hu_o, hv_o, hu_n, hv_n = (torch.full_like(st["h"], 1.0e-3) for _ in range(4))
+    info = {}
+
+    def cycle(first=False):
+        for n in range(steps):
+            dyc.step_MOM_dyn_split_RK2(st["u"], st["v"], st["h"], st["uh"], st["vh"], st["uhtr"], st["vhtr"], st["eta_av"], taux, tauy,
+                                       a.dt, calc_dtbt=(first and n == 0))
+        info["advect_iterations"] = dyc.advect_tracer(st["h"], st["uhtr"], st["vhtr"], steps * a.dt, [T, S] + tr)
+        for t in tr:
+            dyc.tracer_vertdiff(st["h"], ea, eb, steps * a.dt, t)
+        dyc.triDiagTS(st["h"], ea, eb, T, S)
+        st["uhtr"].zero_(); st["vhtr"].zero_()
+        # ALE_regridding_and_remapping (MOM.F90:1751): new z* grid, remap everything that lives on the old one
+        dyc.ALE_regrid_zstar(RP, cr, st["h"], h_new, dzI)
+        dyc.ALE_remap_tracers(CSr, st["h"], h_new, [T, S] + tr)
+        dyc.ALE_remap_set_h_vel(st["h"], hu_o, hv_o); dyc.ALE_remap_set_h_vel(h_new, hu_n, hv_n)
+        dyc.ALE_remap_velocities(CSr, hu_o, hv_o, hu_n, hv_n, st["u"], st["v"])
+        st["h"].copy_(h_new)
+
+    torch.cuda.synchronize()
+    for w in range(warm):
+        cycle(first=(w == 0))
+    dyc.sync(); torch.cuda.synchronize()
+    pre = dict(T=T.clone(), h=st["h"].clone(), tr0_min=tr[0].min().item(), tr0_max=tr[0].max().item()) if check is not None else None
+    t0 = time.perf_counter()
+    cycle()
+    dyc.sync(); torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    info.update(tile=[d.ni, d.nj, d.nk], dynamics_steps_per_cycle=steps, ms_per_cycle=round(1e3 * sec, 2),
+                ms_per_dynamics_step=round(1e3 * sec / steps, 2),
+                simulated_days_per_wall_sec=round((steps * a.dt / 86400.0) / sec, 5),
+                hbm_GB_resident=round(torch.cuda.memory_allocated(dyc.device) / 1e9, 1),
+                note="BASELINE.json configs[4]: one of the 4 x 2 tiles of the 4320 x 3240 x 75 grid as a stand-alone grid on one GPU; "
+                     "dynamics with the ALE pressure force (PLM reconstruction of T, S), PPM tracer advection of T, S + 2 tracers, "
+                     "tridiagonal solves, z* regridding and PPM_H4 remapping of T, S, the tracers, u, v; not part of `value`")
+    if check is not None:
+        check(dict(dyc=dyc, d=d, st=st, T=T, S=S, tr=tr, Md=keep[-1], pre=pre, info=info))
+    dyc.close()
+    del st, T, S, tr, ea, eb, h_new, dzI, hu_o, hv_o, hu_n, hv_n, keep
+    torch.cuda.empty_cache()
+    return sec, info
+
+
 def pmc_step_traffic():
     """Measured HBM-side GB per step (sum over all kernels of one step) from the newest committed PMC summary, or None."""
     import glob
@@ -360,6 +448,9 @@ def main():
     ap.add_argument("--dt", type=float, default=900.0)
     ap.add_argument("--dt-therm", type=float, default=3600.0, help="DT_THERM: a thermodynamic step follows every DT_THERM / DT dynamics steps")
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--ale-ni", type=int, default=1080, help="configs[4] leg: the tile of the 4320 x 3240 grid on a 4 x 2 layout")
+    ap.add_argument("--ale-nj", type=int, default=1620)
+    ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] tile leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--tracers", type=int, default=2, help="passive PPM tracers next to T and S in the thermodynamic step; -1 = dynamics only")
@@ -502,6 +593,10 @@ def main():
         # the legs reported next to the headline are measured on one GPU; the scaling runs (N > 1) keep to the headline path
         out["ale_remap_leg"] = ale_remap_leg(args, dyc, d, st, barrier, dist)
         out["diag_leg"] = diag_leg(args, dyc, d, st, barrier, dist)
+        if not args.no_config4 and (args.ni, args.nj) == (1440, 1080):
+            dyc.close(); del st                      # the headline model makes room for the larger tile
+            torch.cuda.empty_cache()
+            out["config4_tile_leg"] = ale_cycle(args, local_rank)[1]
     if rank == 0:
         tot = sum(v[1] for v in full.values())
         out["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]}

@@ -142,3 +142,44 @@ def test_config3_grid_resting_ocean_stays_at_rest():
     assert st["u"][sl].abs().max().item() < 1e-11 and st["v"][sl].abs().max().item() < 1e-11
     assert (st["h"][sl] - h0[sl]).abs().max().item() < 1e-9
     dyc.close()
+
+
+def test_config4_tile_1080x1620x75_ale_cycle():
+    """BASELINE.json configs[4] ("4320 x 3240 x 75, 4 x 2 tiles on 8 MI355X, overlapped halos + ALE remap included") at the size
+    ONE GPU of that run carries: bench.ale_cycle on the 1080 x 1620 x 75 tile -- dynamics with the pressure force of an ALE grid
+    (PLM-reconstructed T, S), PPM advection of T, S and two tracers, tridiagonal solves, z* regridding, PPM_H4 remapping.
+    Too large for the oracle; held to size-independent properties."""
+    import torch
+    import bench
+
+    class A:
+        ale_ni, ale_nj, nk, dt = 1080, 1620, 75, 900.0
+
+    def check(c):
+        d, st, Md, pre = c["d"], c["st"], c["Md"], c["pre"]
+        sl = (Ellipsis, slice(d.joff, d.joff + d.nj), slice(d.ioff, d.ioff + d.ni))
+        area = Md[G["areaT"]][sl[1:]]; wet = Md[G["mask2dT"]][sl[1:]] > 0
+        for n in ("u", "v", "h"):
+            assert bool(torch.isfinite(st[n]).all()), n
+        assert 1e-3 < st["u"].abs().max().item() < 5.0 and st["h"][sl].min().item() > 0.0
+        # the cycle conserves volume (dynamics in flux form; regridding only moves interfaces inside a column) ...
+        v0 = (pre["h"][sl] * area).sum(dtype=torch.float64).item(); v1 = (st["h"][sl] * area).sum(dtype=torch.float64).item()
+        assert abs(v1 / v0 - 1.0) < 1e-13, v1 / v0 - 1.0
+        # ... the new grid is z*: every wet column's interfaces sit at the nominal depths scaled by its own depth + eta
+        col = st["h"][sl].sum(0)
+        assert ((col - (pre["h"][sl].sum(0))).abs()[wet].max().item()) < 1.0      # a cycle moves the surface by < 1 m
+        # ... heat content sum(T h area) changes only through the (conservative) advection, the (conservative, no-flux)
+        # tridiagonal solve and the (conservative) remapping: conserved to round-off of the sums
+        q0 = (pre["T"][sl] * pre["h"][sl] * area).sum(dtype=torch.float64).item()
+        q1 = (c["T"][sl] * st["h"][sl] * area).sum(dtype=torch.float64).item()
+        assert abs(q1 / q0 - 1.0) < 1e-12, q1 / q0 - 1.0
+        # ... and nothing leaves the range of the initial values (monotone advection and remapping, diffusion)
+        for t in [c["T"], c["S"]] + c["tr"]:
+            a = t[sl][:, wet]
+            assert bool(torch.isfinite(a).all())
+        a = c["tr"][0][sl][:, wet]
+        assert a.min().item() >= pre["tr0_min"] - 1e-9 and a.max().item() <= pre["tr0_max"] + 1e-9
+        assert 1 <= c["info"]["advect_iterations"] <= 10
+
+    sec, info = bench.ale_cycle(A(), 0, steps=2, warm=1, check=check)
+    assert info["tile"] == [1080, 1620, 75] and info["hbm_GB_resident"] < 200.0
