@@ -36,10 +36,10 @@ LAYOUTS = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.3 TB/s achievable)
 
 
-def global_grid(ni, nj):
+def global_grid(ni, nj, reentrant_y=False):
     from mom6_amd import grid
     return grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-65.0, dlon=360.0 / ni, dlat=130.0 / nj,
-                           reentrant_x=True, depth_fn=grid.bowl_depth(ni, nj, 4000.0, rim=2))
+                           reentrant_x=True, reentrant_y=reentrant_y, depth_fn=grid.bowl_depth(ni, nj, 4000.0, rim=0 if reentrant_y else 2))
 
 
 def algorithmic_bytes_per_step(N3, N2, nsub_total):
@@ -62,20 +62,20 @@ def hor_visc_params(abi, dt):
     return P
 
 
-def build_model(args, layout, pe, device, dist=None, unique_id=None):
+def build_model(args, layout, pe, device, dist=None, unique_id=None, reentrant_y=False, force_nccl_self=False):
     """Create the device model for tile `pe` of `layout` and a synthetic state in HBM.  With more than one tile the
     communicator is attached before anything exchanges halos (the new-run initialisation does)."""
     import torch
     from mom6_amd import abi, synth_dev
     from mom6_amd.dycore import Dycore
     G = abi.G
-    gg = global_grid(args.ni, args.nj)
+    gg = global_grid(args.ni, args.nj, reentrant_y)
     d, M = gg.tile(args.nk, 4, layout, pe)
     GV = abi.vgrid_default()
     dyc = Dycore(d, M, GV, 0, device)
-    if layout != (1, 1):
+    if layout != (1, 1) or force_nccl_self:
         from mom6_amd.parallel import attach_comm
-        attach_comm(dyc, layout, pe, dist, unique_id=unique_id)
+        attach_comm(dyc, layout, pe, dist, unique_id=unique_id, force_nccl_self=force_nccl_self)
     dyc.continuity_init(abi.continuity_params_default(args.nk, GV.Angstrom_H))
     bt = abi.barotropic_params_default(20.0)
     dyc.barotropic_init(bt)
@@ -352,6 +352,54 @@ def ale_cycle(args, device=0, steps=4, warm=1, check=None):
     return sec, info
 
 
+def comm_model_leg(args, device):
+    """What the halo exchanges add to a step at 8 GPUs, measured on ONE: the tile an MI355X carries in the 4 x 2 layout of the
+    headline grid (1440 x 1080 -> 360 x 540 x 75), doubly re-entrant so that all eight neighbours exist -- and are this rank --
+    with every group pass packed and sent through RCCL (ncclSend / ncclRecv to self, force_nccl_self) on the halo stream, and
+    the same tile with local wrap copies instead.  exposed_exchange_ms = the difference of the two step times: packing, the
+    RCCL launches and the stream dependencies that the overlap (start_group_pass ... own rows ... complete ... halo rows)
+    does not hide; the wire itself is absent (a self send is a device copy), so this is the floor the xGMI latency comes on
+    top of.  launch_gap_ms = wall time minus the sum of the kernel times of a step: at this tile size the ~500 launches of a
+    step no longer stay ahead of the GPU."""
+    import torch
+    from mom6_amd.dycore import prof_enable, prof_report, prof_reset
+
+    class A:
+        pass
+    out = {}
+    for mode in ("local_wrap", "rccl_self"):
+        a = A(); a.ni, a.nj, a.nk, a.dt, a.tracers = args.ni // 4, args.nj // 2, args.nk, args.dt, 0
+        dyc, d, st, taux, tauy, keep = build_model(a, (1, 1), (0, 0), device, reentrant_y=True, force_nccl_self=(mode == "rccl_self"))
+        torch.cuda.set_stream(dyc.torch_stream())
+
+        def step(calc=False):
+            dyc.step_MOM_dyn_split_RK2(st["u"], st["v"], st["h"], st["uh"], st["vh"], st["uhtr"], st["vhtr"], st["eta_av"], taux, tauy,
+                                       a.dt, calc_dtbt=calc)
+        step(True); step(); step()
+        dyc.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        dyc.sync(); torch.cuda.synchronize()
+        ms = 1e2 * (time.perf_counter() - t0)
+        prof_enable(dyc, True); prof_reset(dyc)
+        step(); dyc.sync()
+        rep = prof_report(dyc); prof_enable(dyc, False)
+        out[mode] = {"ms_per_step": round(ms, 3), "kernel_sum_ms": round(sum(v[1] for v in rep.values()), 3),
+                     "launches_per_step": int(sum(v[0] for v in rep.values()))}
+        dyc.close()
+        del st, keep
+        torch.cuda.empty_cache()
+    out["tile"] = [args.ni // 4, args.nj // 2, args.nk]
+    out["exposed_exchange_ms"] = round(out["rccl_self"]["ms_per_step"] - out["local_wrap"]["ms_per_step"], 3)
+    out["exposed_exchange_frac_of_step"] = round(out["exposed_exchange_ms"] / out["rccl_self"]["ms_per_step"], 4)
+    out["launch_gap_ms"] = round(out["local_wrap"]["ms_per_step"] - out["local_wrap"]["kernel_sum_ms"], 3)
+    out["note"] = ("one tile of the 4 x 2 layout on one GPU, all eight neighbours = this rank; every group pass through RCCL send/recv to self "
+                   "on the halo stream (rccl_self) against local wrap copies (local_wrap); kernel_sum_ms is measured with HIP events around "
+                   "every launch (which itself serialises the streams)")
+    return out
+
+
 def pmc_step_traffic():
     """Measured HBM-side GB per step (sum over all kernels of one step) from the newest committed PMC summary, or None."""
     import glob
@@ -451,6 +499,7 @@ def main():
     ap.add_argument("--ale-ni", type=int, default=1080, help="configs[4] leg: the tile of the 4320 x 3240 grid on a 4 x 2 layout")
     ap.add_argument("--ale-nj", type=int, default=1620)
     ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] tile leg")
+    ap.add_argument("--no-comm-model", action="store_true", help="skip the 1-GPU exchange-overhead leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--tracers", type=int, default=2, help="passive PPM tracers next to T and S in the thermodynamic step; -1 = dynamics only")
@@ -593,8 +642,12 @@ def main():
         # the legs reported next to the headline are measured on one GPU; the scaling runs (N > 1) keep to the headline path
         out["ale_remap_leg"] = ale_remap_leg(args, dyc, d, st, barrier, dist)
         out["diag_leg"] = diag_leg(args, dyc, d, st, barrier, dist)
+        if not args.no_comm_model and (args.ni, args.nj) == (1440, 1080):
+            dyc.close(); st.clear()
+            torch.cuda.empty_cache()
+            out["comm_model"] = comm_model_leg(args, local_rank)
         if not args.no_config4 and (args.ni, args.nj) == (1440, 1080):
-            dyc.close(); del st                      # the headline model makes room for the larger tile
+            dyc.close(); st.clear()                  # the headline model makes room for the larger tile
             torch.cuda.empty_cache()
             out["config4_tile_leg"] = ale_cycle(args, local_rank)[1]
     if rank == 0:

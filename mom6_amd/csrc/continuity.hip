@@ -318,7 +318,7 @@ template <int DIR>
 int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h, double *uh, double dt,
                   int ish, int ieh, int jsh, int jeh, const double *uhbt, const double *visc_rem,
                   double *u_cor, const mom6x_BT_cont *BT, double *du_cor, const double *hin_conv,
-                  double h_min_conv) {
+                  double h_min_conv, bool first_pass) {
   const Dm d = c->d;
   const mom6x_continuity_params &P = c->cont;
   const dim3 blk(64, 4, 1);
@@ -347,11 +347,39 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
   else          { A.a0 = ish; A.a1 = ieh; A.b0 = jsh - 1; A.b1 = jeh; }
   if (du_cor) HIPCHK(hipMemsetAsync(du_cor, 0, sizeof(double) * d.slab, c->stream));
   double *BT_h = BT ? (DIR == 0 ? BT->h_u : BT->h_v) : nullptr;
+  // A group pass of this call's inputs may still be in flight on the halo stream (start_group_pass by the caller:
+  // the RK2 step starts pass_uvp / pass_uv / pass_visc_rem and calls continuity straight away).  The faces of the
+  // tile's own rows (columns) only read owned points of u, visc_rem -- symmetric memory: the faces on the tile edge are
+  // owned too -- so the first pass does them while the messages travel, waits (complete_group_pass), and then does the
+  // rows (columns) in the halo, which are what the pass delivers.  A face's result does not depend on the launch it is in.
+  const bool split = wave && first_pass && c->pass_pending;
+  if (!split) halo_complete(c);
   if (lds) {
     LdsArgs E;
     E.h_min = 2.0 * c->GV.Angstrom_H; E.scheme = scheme; E.monotonic = P.monotonic;
     E.marginal = P.marginal_faces; E.h_face = BT_h;
-    const int rc = wave ? mass_flux_wave(c, DIR, A, E) : mass_flux_lds(c, DIR, A, E);
+    auto part = [&](int a0, int a1, int b0, int b1) -> int {
+      if (a0 > a1 || b0 > b1) return MOM6X_OK;
+      FluxArgs S = A;
+      S.a0 = a0; S.a1 = a1; S.b0 = b0; S.b1 = b1;
+      return wave ? mass_flux_wave(c, DIR, S, E) : mass_flux_lds(c, DIR, S, E);
+    };
+    int rc;
+    if (!split) {
+      rc = part(A.a0, A.a1, A.b0, A.b1);
+    } else if (DIR == 0) {   // rows: own rows first, then the halo rows south and north of them
+      const int o0 = A.b0 > 0 ? A.b0 : 0, o1 = A.b1 < d.nj - 1 ? A.b1 : d.nj - 1;
+      rc = part(A.a0, A.a1, o0, o1);
+      halo_complete(c);
+      if (!rc) rc = part(A.a0, A.a1, A.b0, o0 - 1);
+      if (!rc) rc = part(A.a0, A.a1, o1 + 1, A.b1);
+    } else {                 // columns
+      const int o0 = A.a0 > 0 ? A.a0 : 0, o1 = A.a1 < d.ni - 1 ? A.a1 : d.ni - 1;
+      rc = part(o0, o1, A.b0, A.b1);
+      halo_complete(c);
+      if (!rc) rc = part(A.a0, o0 - 1, A.b0, A.b1);
+      if (!rc) rc = part(o1 + 1, A.a1, A.b0, A.b1);
+    }
     if (rc) return rc;
   } else {
     KLAUNCH(c, "k_mass_flux<DIR>", k_mass_flux<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, 1, blk), blk, d, c->G, A);
@@ -404,14 +432,14 @@ extern "C" int mom6x_continuity_PPM(mom6x_ctx *c, const double *u, const double 
   int rc;
   if (x_first) {
     rc = run_direction<0>(c, u, hin, h, uh, dt, is, ie, js - stencil, je + stencil, uhbt, visc_rem_u, u_cor, BT,
-                          du_cor, hin, 0.0);
+                          du_cor, hin, 0.0, true);
     if (rc) return rc;
-    rc = run_direction<1>(c, v, h, h, vh, dt, is, ie, js, je, vhbt, visc_rem_v, v_cor, BT, dv_cor, h, h_min);
+    rc = run_direction<1>(c, v, h, h, vh, dt, is, ie, js, je, vhbt, visc_rem_v, v_cor, BT, dv_cor, h, h_min, false);
   } else {
     rc = run_direction<1>(c, v, hin, h, vh, dt, is - stencil, ie + stencil, js, je, vhbt, visc_rem_v, v_cor, BT,
-                          dv_cor, hin, 0.0);
+                          dv_cor, hin, 0.0, true);
     if (rc) return rc;
-    rc = run_direction<0>(c, u, h, h, uh, dt, is, ie, js, je, uhbt, visc_rem_u, u_cor, BT, du_cor, h, h_min);
+    rc = run_direction<0>(c, u, h, h, uh, dt, is, ie, js, je, uhbt, visc_rem_u, u_cor, BT, du_cor, h, h_min, false);
   }
   return rc;
 }

@@ -80,11 +80,15 @@ k_vel_update(Dm d, const double *__restrict__ G, const double *u, const double *
 // h_av updates on (is-2..ie+2, js-2..je+2): mode 0: 0.5*(a+b) (:808-810); 1: copy a (:1025-1027);
 // 2: 0.5*(h_av + a) (:1064-1066); 3: hp = (1-w)*a + w*hp on (is-1..ie+1) (:828-830)
 __global__ void __launch_bounds__(256)
-k_h_av(Dm d, double *h_av, const double *__restrict__ a, const double *__restrict__ b, int mode, double w, int ext) {
+k_h_av(Dm d, double *h_av, const double *__restrict__ a, const double *__restrict__ b, int mode, double w, int ext, int part) {
   const int i = I_BASE(-ext) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -ext + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 + ext || j > d.nj - 1 + ext) return;
   if (i < (-ext)) return;
+  // part 1: the tile's own cells (no halo value is read: safe while a group pass of a, b is in flight); part 2: the frame
+  // of `ext` halo cells around them, after the pass has completed; 0: both
+  const bool own = (i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1);
+  if ((part == 1 && !own) || (part == 2 && own)) return;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
   for (int k = k0; k < k1; k++) {
@@ -139,6 +143,14 @@ int start3(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_lis
   double *ff[16]; int ss[16], nn[16]; int n = 0;
   auto s = stg.begin();
   for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = nk; n++; }
+  halo_start(c, ff, ss, nn, n);
+  return MOM6X_OK;
+}
+
+int startn(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list<int> stg, std::initializer_list<int> nks) {
+  double *ff[16]; int ss[16], nn[16]; int n = 0;
+  auto s = stg.begin(); auto q = nks.begin();
+  for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = *q++; n++; }
   halo_start(c, ff, ss, nn, n);
   return MOM6X_OK;
 }
@@ -247,7 +259,7 @@ extern "C" int mom6x_dyn_split_RK2_new_run(mom6x_ctx *c, const double *u, const 
   CHK(mom6x_continuity_PPM(c, s->u_av, s->v_av, h, h_tmp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            nullptr, nullptr, nullptr));
   pass3(c, { h_tmp }, { 0 }, d.nk);
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2 * d.halo, -d.halo), d.nj + 2 * d.halo, d.nk, b), b, d, s->h_av, h, (const double *)h_tmp, 0, 0.0, d.halo);
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2 * d.halo, -d.halo), d.nj + 2 * d.halo, d.nk, b), b, d, s->h_av, h, (const double *)h_tmp, 0, 0.0, d.halo, 0);
   pass3(c, { s->u_av, s->v_av, uh, vh }, { 1, 2, 1, 2 }, d.nk);
   CHK(mom6x_CorAdCalc(c, s->u_av, s->v_av, s->h_av, uh, vh, s->CAu_pred, s->CAv_pred));
   s->CAu_pred_stored = true;
@@ -304,12 +316,15 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   if (dev_coef) CHK(vertvisc_coef_upd(c, 1, u_inst, v_inst, u_bc, v_bc, nullptr, nullptr, dt, h, dt));   // :591-609, up/vp on the fly
   else CHK(coef_hook(0, up, vp, dt));                                   // :602-609
   CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :610
-  passn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk });   // pass_eta :620 + pass_visc_rem :621
+  // pass_eta :549/:617 + pass_visc_rem :618/:641 as ONE group started here; bt_mass_source (own cells only) and the own rows of
+  // the continuity call below run while it travels; continuity completes it before it touches a halo row
+  startn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk });
 
   CHK(mom6x_bt_mass_source(c, h, eta, 1));                              // :629
   // continuity(u, v, h, hp, uh_in, vh_in, dt, visc_rem_u, visc_rem_v, BT_cont)  :646
   CHK(mom6x_continuity_PPM(c, u_inst, v_inst, h, hp, s->uh_in, s->vh_in, dt, nullptr, nullptr, s->visc_rem_u, s->visc_rem_v,
                            nullptr, nullptr, &s->BT, nullptr, nullptr));
+  halo_complete(c);
   CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :649-652
   if (calc_dtbt) CHK(mom6x_set_dtbt_pbce(c, s->pbce, nullptr));         // :659-668
   // predictor btstep :673-676
@@ -337,24 +352,25 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
       CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));                            // :763-767
     }
   }
-  pass3(c, { s->visc_rem_u, s->visc_rem_v, up, vp }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :769 + pass_uvp :773
+  start3(c, { s->visc_rem_u, s->visc_rem_v, up, vp }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :769 + pass_uvp :761/:773: completed inside continuity
 
   // uh = u_av * h ; hp = h + dt * div . uh  :779-781
   CHK(mom6x_continuity_PPM(c, up, vp, h, hp, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av, &s->BT,
                            nullptr, nullptr));
-  pass3(c, { hp }, { 0 }, nk);                                          // pass_hp_uv :785 (the part the next kernels read)
-  // the averaged velocities and transports travel on the halo stream while h_av, the barotropic mass source and (BEGW /= 0)
-  // the second pressure force are formed: start_group_pass(CS%pass_av_uvh) :804 ... complete_group_pass :865
-  start3(c, { u_av, v_av, uh, vh }, { 1, 2, 1, 2 }, nk);
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)hp, 0, 0.0, 2);   // :808-810
+  halo_complete(c);
+  // hp (pass_hp_uv :785), the averaged velocities and the transports (pass_av_uvh :804 ... :865) travel on the halo stream
+  // while h_av of the tile's own cells and the barotropic mass source are formed; the frame of h_av follows the completion
+  start3(c, { hp, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)hp, 0, 0.0, 2, 1);   // :808-810
 
   // ---- corrector
   CHK(mom6x_bt_mass_source(c, hp, s->eta_pred, 0));                     // :820
+  halo_complete(c);                                                     // :865
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)hp, 0, 0.0, 2, 2);
   if (R.begw != 0.0) {                                                  // :822-833
-    KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2, -1), d.nj + 2, nk, b), b, d, hp, (const double *)h, (const double *)nullptr, 3, R.begw, 1);
+    KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2, -1), d.nj + 2, nk, b), b, d, hp, (const double *)h, (const double *)nullptr, 3, R.begw, 1, 0);
     CHK(mom6x_PressureForce(c, hp, s->PFu, s->PFv, s->pbce, s->eta_PF));
   }
-  halo_complete(c);                                                     // :865
   CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :864-867
   if (hooks && hooks->horizontal_viscosity) {                           // :884-888
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -383,15 +399,16 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     CHK(vertvisc_fused(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, u_inst, v_inst, taux, tauy, dt, s->taux_bot,
                        s->tauy_bot, s->visc_rem_u, s->visc_rem_v));       // :1013 + :1022
   }
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2);   // :1025-1027
-  pass3(c, { s->visc_rem_u, s->visc_rem_v, u_inst, v_inst }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :1030 + pass_uv :1034
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2, 0);   // :1025-1027
+  start3(c, { s->visc_rem_u, s->visc_rem_v, u_inst, v_inst }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :1030 + pass_uv :1019/:1034: completed inside continuity
   // uh = u_av * h ; h = h + dt * div . uh  :1041-1043
   CHK(mom6x_continuity_PPM(c, u_inst, v_inst, h, h, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av,
                            nullptr, nullptr, nullptr));
-  pass3(c, { h }, { 0 }, nk);                                           // pass_h :1045
-  start3(c, { u_av, v_av, uh, vh }, { 1, 2, 1, 2 }, nk);                // start_group_pass(CS%pass_av_uvh) :1054
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2);   // :1064-1066
+  halo_complete(c);
+  start3(c, { h, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);          // pass_h :1045 + start_group_pass(CS%pass_av_uvh) :1054
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2, 1);   // :1064-1066
   halo_complete(c);                                                     // :1072
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2, 2);
   KLAUNCH(c, "k_uhtr", k_uhtr, gridk(nxa(d.ni + 5, -3), d.nj + 5, nk, b), b, d, uhtr, vhtr, (const double *)uh, (const double *)vh, dt);   // :1072-1079
   // CAu_pred for the next step :1081-1090
   CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));
