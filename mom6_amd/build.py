@@ -19,6 +19,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-function"] + os.environ.get("MOM6X_CFLAGS", "").split()
 
 
+# Per-file additions.  continuity_wave.hip: min/max of the flux limiters and CFL bounds as v_min_f64 / v_max_f64
+# instead of compare + two selects (-9 % VALU instructions).  The kernel never produces or tests NaN/Inf, so
+# the only observable effect is the SIGN of a zero result (min(-0, +0)); DESIGN.md section 3.
+PER_FILE = {"continuity_wave.hip": ["-ffinite-math-only", "-fno-signed-zeros"]}
+
+
 def _newer(srcs, target):
     if not os.path.exists(target):
         return True
@@ -34,7 +40,7 @@ def build(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(LIBDIR, os.path.basename(s)[:-4] + ".o")
         if force or _newer([s] + hdrs, o):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + PER_FILE.get(os.path.basename(s), []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -392,6 +392,68 @@ k_vertvisc_remnant(Dm d, const double *__restrict__ G, double *__restrict__ vr, 
   }
 }
 
+// vertvisc_remnant with the column on chip (see k_vertvisc_cols): c1 and the un-substituted remnant stay in
+// registers, 2 words read and 1 written per face-layer instead of 6.  No Ray_u (that goes through
+// k_vertvisc_remnant); same operations in the same order.
+template <int DIR, int NK>
+__global__ void __launch_bounds__(64)
+k_vertvisc_remnant_cols(Dm d, const double *__restrict__ G, double *__restrict__ vr, const double *__restrict__ a_u,
+                        const double *__restrict__ h_u, double dt) {
+  const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? -1 : 0) + blockIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < ((DIR ? 0 : -1))) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
+  if (!(mC > 0.)) return;
+  constexpr int VV_G = 8, NG = (NK + VV_G - 1) / VV_G;
+  double rr[NK], cu[NK];
+  double q_a[2][VV_G], q_h[2][VV_G];
+  auto fetch = [&](int g, int b) {
+#pragma unroll
+    for (int m = 0; m < VV_G; m++) {
+      const int k = g * VV_G + m;
+      if (k < NK) { const size_t x3 = x + (size_t)k * slab; q_a[b][m] = a_u[x3 + slab]; q_h[b][m] = h_u[x3]; }
+    }
+  };
+  double a_kp = a_u[x];
+  double b1 = 0., d1 = 0., prev = 0.;
+  fetch(0, 0);
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < VV_G; m++) {
+      const int k = g * VV_G + m;
+      if (k < NK) {
+        const double a_k = a_kp; a_kp = q_a[g & 1][m];
+        const double hu = q_h[g & 1][m];
+        if (k == 0) {
+          const double b_denom_1 = hu + dt * (0. + a_k);
+          b1 = 1.0 / (b_denom_1 + dt * a_kp);
+          d1 = b_denom_1 * b1;
+          prev = b1 * hu;
+        } else {
+          cu[k] = dt * a_k * b1;
+          const double b_denom_1 = hu + dt * (0. + a_k * d1);
+          b1 = 1.0 / (b_denom_1 + dt * a_kp);
+          d1 = b_denom_1 * b1;
+          prev = (hu + dt * a_k * prev) * b1;
+        }
+        rr[k] = prev;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  vr[x + (size_t)(NK - 1) * slab] = prev;
+#pragma unroll
+  for (int k = NK - 2; k >= 0; k--) {
+    prev = rr[k] + cu[k + 1] * prev;
+    vr[x + (size_t)k * slab] = prev;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -888,6 +950,113 @@ k_vertvisc_fused(Dm d, const double *__restrict__ G, const double *u_in, const d
   }
 }
 
+// k_vertvisc_fused with the whole column on chip: the forward sweep keeps c1 and the un-substituted velocity
+// in registers (2*NK doubles; the 512-entry unified VGPR/AGPR file of a wave that runs alone on its SIMD)
+// and the un-substituted remnant in LDS (NK*8 B per lane, lane-minor: conflict-free), so the backward sweep
+// never goes back to HBM: 5 words read and 2 written per face-layer against 12.7 with the c1 / u / visc_rem
+// round trips.  One wave per work-group; four work-groups (4 * 64 * NK * 8 B of LDS) fill a CU.  With one
+// wave per SIMD nothing else hides the HBM latency, so the inputs are fetched VV_G layers ahead into a
+// double buffer (3..5 * VV_G loads in flight per lane while the previous group is solved); the scheduling
+// fences keep the compiler from hoisting every load of the unrolled column to the top (which spills).
+// Same operations in the same order as k_vertvisc_fused: bit-identical.  Ray_u and the direct-stress
+// option go through k_vertvisc_fused.
+template <int DIR, bool UPD, bool REM, int NK>
+__global__ void __launch_bounds__(64)
+k_vertvisc_cols(Dm d, const double *__restrict__ G, const double *u_in, const double *__restrict__ u_bc,
+                const double *__restrict__ u_abt, double dtx, double *u, double *__restrict__ vr,
+                const double *__restrict__ a_u, const double *__restrict__ h_u,
+                const double *__restrict__ tau, double dt, double dt_Rho0, double H_to_RZ,
+                double *__restrict__ tau_bot) {
+  extern __shared__ double vv_lds[];
+  const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? -1 : 0) + blockIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < ((DIR ? 0 : -1))) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  double *rr = vv_lds + threadIdx.x;
+  const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
+  constexpr int VV_G = UPD ? 4 : 6;
+  constexpr int NG = (NK + VV_G - 1) / VV_G;
+  double uu[NK], cu[NK];
+  double q_a[2][VV_G], q_h[2][VV_G], q_u[2][VV_G], q_b[2][VV_G], q_t[2][VV_G];
+  auto fetch = [&](int g, int b) {
+#pragma unroll
+    for (int m = 0; m < VV_G; m++) {
+      const int k = g * VV_G + m;
+      if (k < NK) {
+        const size_t x3 = x + (size_t)k * slab;
+        q_a[b][m] = a_u[x3 + slab];
+        q_h[b][m] = h_u[x3];
+        q_u[b][m] = u_in[x3];
+        if (UPD) { q_b[b][m] = u_bc[x3]; q_t[b][m] = u_abt[x3]; }
+      }
+    }
+  };
+  if (mC > 0.) {
+    const double surface_stress = dt_Rho0 * (mC * tau[x]);
+    double a_kp = a_u[x];
+    double b1 = 0., d1 = 0., uprev = 0., rprev = 0.;
+    fetch(0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < VV_G; m++) {
+        const int k = g * VV_G + m;
+        if (k < NK) {
+          const double a_k = a_kp; a_kp = q_a[g & 1][m];
+          const double hu = q_h[g & 1][m];
+          const double u0 = UPD ? mC * (q_u[g & 1][m] + dtx * (q_b[g & 1][m] + q_t[g & 1][m])) : q_u[g & 1][m];
+          if (k == 0) {
+            const double b_denom_1 = hu + dt * (0. + a_k);
+            b1 = 1.0 / (b_denom_1 + dt * a_kp);
+            d1 = b_denom_1 * b1;
+            uprev = b1 * (hu * u0 + surface_stress);
+            rprev = b1 * hu;
+          } else {
+            cu[k] = dt * a_k * b1;
+            const double b_denom_1 = hu + dt * (0. + a_k * d1);
+            b1 = 1.0 / (b_denom_1 + dt * a_kp);
+            d1 = b_denom_1 * b1;
+            uprev = (hu * u0 + dt * a_k * uprev) * b1;
+            if (REM) rprev = (hu + dt * a_k * rprev) * b1;
+          }
+          uu[k] = uprev;
+          if (REM) rr[k * 64] = rprev;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    u[x + (size_t)(NK - 1) * slab] = uprev;
+    if (REM) vr[x + (size_t)(NK - 1) * slab] = rprev;
+    asm volatile("" ::: "memory");   // the remnant comes back from LDS, not from 75 more live registers
+#pragma unroll
+    for (int k = NK - 2; k >= 0; k--) {
+      const size_t x3 = x + (size_t)k * slab;
+      const double ck = cu[k + 1];
+      uprev = uu[k] + ck * uprev;
+      u[x3] = uprev;
+      if (REM) { rprev = rr[k * 64] + ck * rprev; vr[x3] = rprev; }
+    }
+    if (tau_bot) tau_bot[x] = H_to_RZ * (uu[NK - 1] * a_kp);
+  } else {
+    if (UPD) {
+      for (int k = 0; k < NK; k++) {
+        const size_t x3 = x + (size_t)k * slab;
+        u[x3] = mC * (u_in[x3] + dtx * (u_bc[x3] + u_abt[x3]));
+      }
+    }
+    if (tau_bot) tau_bot[x] = H_to_RZ * (u[x + (size_t)(NK - 1) * slab] * a_u[x + (size_t)NK * slab]);
+  }
+}
+
+// The layer counts the on-chip column kernel is built for (anything else walks through HBM).
+static bool vertvisc_cols_usable(int nk, const double *Ray, const DirectStress &S) {
+  static const int mode = [] { const char *e = getenv("MOM6X_VERTVISC"); return (e && !strcmp(e, "walk")) ? 0 : 1; }();
+  return mode && nk == 75 && !Ray && !(S.Hmix > 0.0);
+}
+
 template <int DIR>
 static void launch_vertvisc_fused(mom6x_ctx *c, bool upd, bool rem, const double *u_in, const double *u_bc,
                                   const double *u_abt, double dtx, double *u, double *vr, const double *a, const double *h,
@@ -898,6 +1067,20 @@ static void launch_vertvisc_fused(mom6x_ctx *c, bool upd, bool rem, const double
   const double dt_Rho0 = dt / c->GV.H_to_RZ, HR = c->GV.H_to_RZ;
   const char *nm = DIR ? "k_vertvisc_fused<1>" : "k_vertvisc_fused<0>";
   const DirectStress S = direct_stress_of(c);
+  if (vertvisc_cols_usable(d.nk, Ray, S)) {
+    constexpr int NK = 75;
+    const dim3 bc(64, 1, 1);
+    const dim3 gc((unsigned)(((DIR ? d.ni : nxa(d.ni + 1, -1)) + 63) / 64), (unsigned)(DIR ? d.nj + 1 : d.nj), 1);
+    const size_t lds = rem ? (size_t)NK * 64 * sizeof(double) : 0;
+    const char *nc = DIR ? "k_vertvisc_cols<1>" : "k_vertvisc_cols<0>";
+#define VVC(U, R) KLAUNCH_LDS(c, nc, (k_vertvisc_cols<DIR, U, R, NK>), gc, bc, lds, d, c->G, u_in, u_bc, u_abt, dtx, u, vr, a, h, tau, dt, dt_Rho0, HR, tau_bot)
+    if (upd && rem) VVC(true, true);
+    else if (upd) VVC(true, false);
+    else if (rem) VVC(false, true);
+    else VVC(false, false);
+#undef VVC
+    return;
+  }
 #define VVF(U, R) KLAUNCH(c, nm, (k_vertvisc_fused<DIR, U, R>), g, b, d, c->G, u_in, u_bc, u_abt, dtx, u, vr, a, h, Ray, tau, c1, dt, dt_Rho0, HR, tau_bot, S)
   if (upd && rem) VVF(true, true);
   else if (upd) VVF(true, false);
@@ -1163,6 +1346,15 @@ extern "C" int mom6x_vertvisc_remnant(mom6x_ctx *c, double *visc_rem_u, double *
   const Dm d = c->d;
   double *c1;
   int rc;
+  if (vertvisc_cols_usable(d.nk, c->Ray_u, DirectStress{}) && !c->Ray_v) {
+    const dim3 bc(64, 1, 1);
+    KLAUNCH(c, "k_vertvisc_remnant_cols<0>", (k_vertvisc_remnant_cols<0, 75>), dim3((unsigned)((nxa(d.ni + 1, -1) + 63) / 64), (unsigned)d.nj, 1), bc,
+            d, c->G, visc_rem_u, c->a_u, c->h_u, dt);
+    KLAUNCH(c, "k_vertvisc_remnant_cols<1>", (k_vertvisc_remnant_cols<1, 75>), dim3((unsigned)((d.ni + 63) / 64), (unsigned)(d.nj + 1), 1), bc,
+            d, c->G, visc_rem_v, c->a_v, c->h_v, dt);
+    HIPCHK(hipGetLastError());
+    return MOM6X_OK;
+  }
   if ((rc = ctx_scratch(c, SCR_c1, d.nk, &c1))) return rc;
   const dim3 b = blk2();
   KLAUNCH(c, "k_vertvisc_remnant<0>", k_vertvisc_remnant<0>, grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, visc_rem_u, c->a_u, c->h_u,

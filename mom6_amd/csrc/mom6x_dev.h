@@ -115,6 +115,13 @@ void prof_end(mom6x_ctx *c);
     if ((c)->prof_on) prof_end((c));                                        \
   } while (0)
 
+#define KLAUNCH_LDS(c, name, kern, grid, blk, lds, ...)                     \
+  do {                                                                      \
+    if ((c)->prof_on) prof_begin((c), name);                                \
+    hipLaunchKernelGGL(kern, grid, blk, lds, (c)->stream, __VA_ARGS__);     \
+    if ((c)->prof_on) prof_end((c));                                        \
+  } while (0)
+
 int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out);   // ctx.hip
 void hor_visc_free(mom6x_ctx *c);                                  // hor_visc.hip
 void diag_sums_free(mom6x_ctx *c);                                 // diag_sums.hip

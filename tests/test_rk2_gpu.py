@@ -185,6 +185,16 @@ def test_rk2_ragged_tile_sizes(orc, ni, nj, nk, halo):
     run(orc, H.double_gyre(nk=nk, ni=ni, nj=nj, halo=halo), nsteps=2, bt_mod=dict(strong_drag=1))
 
 
+@pytest.mark.parametrize("ni,nj", [(70, 10), (24, 40)])
+def test_rk2_75_layers_on_chip_columns(orc, ni, nj):
+    """nk = 75 is the layer count the on-chip column solver (k_vertvisc_cols: c1 and u in registers, the remnant in
+    LDS) and the 5-layer-per-lane mass-flux kernel are built for; rows that are not a multiple of the 64-lane
+    work-group, with and without the bottom-stress hooks, two steps bit for bit."""
+    run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(split_bottom_stress=1),
+        per_stage=True)
+    run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), dev_vv=dict())
+
+
 def test_rk2_tc4_like_switches(orc):
     """The switches of .testing/tc4 that touch this path: CORIOLIS_EN_DIS, DIRECT_STRESS (HMIX_FIXED = 20 m), BE = 0.7,
     EQN_OF_STATE = LINEAR with MASS_WEIGHT_IN_PRESSURE_GRADIENT, SMAGORINSKY_AH with SMAG_BI_CONST = 0.03, BEBT = 0.2,
