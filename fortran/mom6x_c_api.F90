@@ -17,6 +17,7 @@ module mom6x_c_api
   public :: mom6x_chksum_result, mom6x_sum_output_params, mom6x_energy_sums, mom6x_reproducing_sum_3d, mom6x_reproducing_sum_2d
   public :: mom6x_remap_dyn_split_RK2_aux_vars
   public :: mom6x_chksum, mom6x_field_chksum, mom6x_sum_output_init, mom6x_depth_list, mom6x_write_energy, mom6x_barotropic_dtbt
+  public :: mom6x_btstep_warnings
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
   public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
   public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc
@@ -94,6 +95,11 @@ module mom6x_c_api
     real(c_double) :: bound_coef
     integer(c_int) :: no_slip, backscatter_underbound
     real(c_double) :: dt
+    integer(c_int) :: Leith_Kh
+    real(c_double) :: Leith_Lap_const
+    integer(c_int) :: Leith_Ah
+    real(c_double) :: Leith_bi_const
+    integer(c_int) :: modified_Leith, use_beta_in_Leith
   end type mom6x_hor_visc_params
 
   type, bind(C) :: mom6x_remapping_params   !< remapping_CS (MOM_remapping.F90:47-84), the members the device path reads
@@ -341,6 +347,12 @@ module mom6x_c_api
     integer(c_int) function mom6x_barotropic_dtbt(ctx, get, set) bind(C, name="mom6x_barotropic_dtbt")
       import :: c_ptr, c_int
       type(c_ptr), value :: ctx, get, set
+    end function
+    !> the count of btstep's "eta has dropped below bathyT" warnings (MOM_barotropic.F90:2738-2745) and the first offender
+    integer(c_int) function mom6x_btstep_warnings(ctx, reset, count, info) bind(C, name="mom6x_btstep_warnings")
+      import :: c_ptr, c_int, c_long_long, c_double
+      type(c_ptr), value :: ctx ; integer(c_int), value :: reset
+      integer(c_long_long), intent(out) :: count ; real(c_double), intent(out) :: info(4)
     end function
     !> DIRECT_STRESS / HMIX_STRESS (MOM_vert_friction.F90:3208, :707); h = vertvisc's thickness argument (device pointer)
     integer(c_int) function mom6x_vertvisc_set_direct_stress(ctx, Hmix_stress, h) bind(C, name="mom6x_vertvisc_set_direct_stress")

@@ -224,6 +224,15 @@ typedef struct mom6x_hor_visc_params {
   int    no_slip;          /* NOSLIP (F)                                                        */
   int    backscatter_underbound; /* BACKSCATTER_UNDERBOUND (T)                                  */
   double dt;               /* DT: the time step the stability bounds are made for (:2714)       */
+  /* Leith (1996) viscosities from the gradient of the vertical vorticity (:80-85, :987-1113);
+   * USE_LEITHY (Leith+E) and USE_QG_LEITH_VISC are not carried                                  */
+  int    Leith_Kh;         /* LEITH_KH (F); needs LAPLACIAN                                     */
+  double Leith_Lap_const;  /* LEITH_LAP_CONST (0)                                               */
+  int    Leith_Ah;         /* LEITH_AH (F); needs BIHARMONIC                                    */
+  double Leith_bi_const;   /* LEITH_BI_CONST (0)                                                */
+  int    modified_Leith;   /* MODIFIED_LEITH (F): add the gradient of the divergence            */
+  int    use_beta_in_Leith;/* USE_BETA_IN_LEITH (= LEITH_KH): grad f (G%dF_dx, G%dF_dy of
+                            * MOM_calculate_grad_Coriolis, MOM_shared_initialization.F90:91) joins grad(vorticity) */
 } mom6x_hor_visc_params;
 
 /* tv%eqn_of_state (EOS_type, src/equation_of_state/MOM_EOS.F90:99-150) and the switches of
@@ -273,7 +282,7 @@ typedef struct mom6x_ctx mom6x_ctx;
 #define MOM6X_EINVAL      1
 #define MOM6X_EHIP        2
 #define MOM6X_EUNSUPPORTED 3
-#define MOM6X_ENUMERIC    4   /* device-side flag: NaN / negative thickness   */
+#define MOM6X_ENUMERIC    4   /* device-side flag (a NaN reached the thicknesses in continuity; NaN / overflow in the reproducing sums), returned by mom6x_ctx_sync */
 
 const char *mom6x_last_error(void);
 int  mom6x_abi_version(void);
@@ -376,6 +385,13 @@ int mom6x_btstep(mom6x_ctx *ctx,
     const double *taux_bot, const double *tauy_bot,
     const double *uh0, const double *vh0, const double *u_uh0, const double *v_vh0,
     double *etaav);
+
+/* The warnings btstep issues for an unphysical sea surface height ("btstep: eta has
+ * dropped below bathyT", MOM_barotropic.F90:2738-2745; the reference prints the first two
+ * per call and counts the rest).  The device counts them over all sub-steps since the last
+ * reset and keeps the first: info[4] = eta [H], -bathyT [Z], i, j (tile indices, 0-based).
+ * Synchronises the context's stream.  `info` is nullable.                          */
+int mom6x_btstep_warnings(mom6x_ctx *ctx, int reset, long long *count, double *info);
 
 /* Access to barotropic_CS state that MOM_restart registers by pointer
  * (register_barotropic_restarts :6253: ubtav, vbtav) and that tests inspect.

@@ -197,7 +197,9 @@ class HorViscParams(C.Structure):
                 ("better_bound_Kh", C.c_int), ("add_LES_viscosity", C.c_int), ("Ah", C.c_double), ("Ah_vel_scale", C.c_double),
                 ("Ah_time_scale", C.c_double), ("Smagorinsky_Ah", C.c_int), ("Smag_bi_const", C.c_double), ("bound_Ah", C.c_int),
                 ("better_bound_Ah", C.c_int), ("bound_Coriolis", C.c_int), ("bound_Cor_vel", C.c_double), ("use_land_mask", C.c_int),
-                ("bound_coef", C.c_double), ("no_slip", C.c_int), ("backscatter_underbound", C.c_int), ("dt", C.c_double)]
+                ("bound_coef", C.c_double), ("no_slip", C.c_int), ("backscatter_underbound", C.c_int), ("dt", C.c_double),
+                ("Leith_Kh", C.c_int), ("Leith_Lap_const", C.c_double), ("Leith_Ah", C.c_int), ("Leith_bi_const", C.c_double),
+                ("modified_Leith", C.c_int), ("use_beta_in_Leith", C.c_int)]
 
 
 def hor_visc_params_default(dt, Laplacian=False, biharmonic=True):

@@ -43,6 +43,10 @@ struct BTState {
   double *frhatu, *frhatv, *IDatu, *IDatv, *ubtav, *vbtav, *eta_cor, *q_D, *D_u_Cor, *D_v_Cor;
   double *work;   // W_COUNT planes
   int nstep_last;
+  // btstep's "eta has dropped below bathyT" warnings (:2738-2745): [0] count, [1] claimed-by-the-first flag on the
+  // device; the first offender's eta, bathyT, i, j next to them
+  unsigned long long *warn;
+  double *warn_info;
 };
 
 namespace {
@@ -499,7 +503,8 @@ k_bt_vel(Dm d, const double *__restrict__ G, double *work, double *btav, double 
 
 // eta corrector :2721-2727
 __global__ void __launch_bounds__(256)
-k_bt_eta(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
+k_bt_eta(Dm d, const double *__restrict__ G, double *work, LoopArgs A, double Z_to_H, unsigned long long *warn,
+         double *warn_info) {
   const int i = I_BASE(A.isv) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = A.jsv + blockIdx.y * blockDim.y + threadIdx.y;
   if (i < A.isv || i > A.iev || j > A.jev) return;
@@ -510,6 +515,14 @@ k_bt_eta(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
                    (A.dtbt * gm(G, d, MOM6X_G_IareaT)[c]) * ((uhbt[c - 1] - uhbt[c]) + (vhbt[c - st] - vhbt[c]));
   work[W_eta * slab + c] = e;
   work[W_eta_wtd * slab + c] = work[W_eta_wtd * slab + c] + e * A.wt_eta;
+  // :2738-2745 (Boussinesq): unphysical sea surface height over the computational domain -- counted, the first one kept
+  if (i >= 0 && i < d.ni && j >= 0 && j < d.nj) {
+    const double bT = gm(G, d, MOM6X_G_bathyT)[c];
+    if ((e < -Z_to_H * bT) && (gm(G, d, MOM6X_G_mask2dT)[c] > 0.0)) {
+      atomicAdd(&warn[0], 1ULL);
+      if (atomicCAS(&warn[1], 0ULL, 1ULL) == 0ULL) { warn_info[0] = e; warn_info[1] = -bT; warn_info[2] = (double)i; warn_info[3] = (double)j; }
+    }
+  }
 }
 
 // truncate_velocities :2918-2944
@@ -590,10 +603,23 @@ void bt_state_free(mom6x_ctx *c) {
   if (!c->bts) return;
   BTState *s = c->bts;
   double *ptrs[] = { s->frhatu, s->frhatv, s->IDatu, s->IDatv, s->ubtav, s->vbtav, s->eta_cor, s->q_D, s->D_u_Cor,
-                     s->D_v_Cor, s->work };
+                     s->D_v_Cor, s->work, s->warn_info };
   for (double *p : ptrs) (void)hipFree(p);
+  (void)hipFree(s->warn);
   delete s;
   c->bts = nullptr;
+}
+
+extern "C" int mom6x_btstep_warnings(mom6x_ctx *c, int reset, long long *count, double *info) {
+  REQUIRE(c && c->bts && count, MOM6X_EINVAL, "mom6x_btstep_warnings: barotropic_init has not been called");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  unsigned long long w[2];
+  HIPCHK(hipMemcpy(w, c->bts->warn, sizeof(w), hipMemcpyDeviceToHost));
+  *count = (long long)w[0];
+  if (info) HIPCHK(hipMemcpy(info, c->bts->warn_info, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemset(c->bts->warn, 0, sizeof(w)));
+  return MOM6X_OK;
 }
 
 extern "C" int mom6x_barotropic_init(mom6x_ctx *c, const mom6x_barotropic_params *p) {
@@ -613,6 +639,8 @@ extern "C" int mom6x_barotropic_init(mom6x_ctx *c, const mom6x_barotropic_params
     double **p2[] = { &s->IDatu, &s->IDatv, &s->ubtav, &s->vbtav, &s->eta_cor, &s->q_D, &s->D_u_Cor, &s->D_v_Cor };
     for (double **q : p2) { HIPCHK(hipMalloc(q, n2 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, 0, n2 * sizeof(double), c->stream)); }
     HIPCHK(hipMalloc(&s->work, (size_t)W_COUNT * n2 * sizeof(double)));
+    HIPCHK(hipMalloc(&s->warn, 2 * sizeof(unsigned long long))); HIPCHK(hipMemsetAsync(s->warn, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMalloc(&s->warn_info, 4 * sizeof(double))); HIPCHK(hipMemsetAsync(s->warn_info, 0, 4 * sizeof(double), c->stream));
     c->bts = s;
   }
   BTState *s = c->bts;
@@ -874,7 +902,7 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
       KLAUNCH(c, "k_bt_vel<1>", k_bt_vel<1>, grid3(nxa(iev - isv + 1, isv), jev - jsv + 2, 1, b), b, d, c->G, work, s->vbtav, vhbtav, L,
                          isv, iev, jsv - 1, jev, P.use_old_coriolis_bracket_bug);
     }
-    KLAUNCH(c, "k_bt_eta", k_bt_eta, grid3(nxa(iev - isv + 1, isv), jev - jsv + 1, 1, b), b, d, c->G, work, L);
+    KLAUNCH(c, "k_bt_eta", k_bt_eta, grid3(nxa(iev - isv + 1, isv), jev - jsv + 1, 1, b), b, d, c->G, work, L, c->GV.Z_to_H, s->warn, s->warn_info);
   }
 
   // ---- after the loop

@@ -303,7 +303,7 @@ k_flux_thickness(Dm d, const double *__restrict__ G, const double *__restrict__ 
 template <int DIR>
 __global__ void __launch_bounds__(256)
 k_convergence(Dm d, const double *__restrict__ G, double *h, const double *__restrict__ uh, double dt,
-              const double *hin, double h_min, int i0, int i1, int j0, int j1) {
+              const double *hin, double h_min, int i0, int i1, int j0, int j1, int *flag) {
   const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
@@ -311,7 +311,9 @@ k_convergence(Dm d, const double *__restrict__ G, double *h, const double *__res
   const int st = DIR ? d.pitch : 1;
   const size_t c2 = ix2(d, i, j), c = c2 + (size_t)k * d.slab;
   const double IareaT = gm(G, d, MOM6X_G_IareaT)[c2];
-  h[c] = dmax(hin[c] - dt * IareaT * (uh[c] - uh[c - st]), h_min);
+  const double hn = hin[c] - dt * IareaT * (uh[c] - uh[c - st]);
+  h[c] = dmax(hn, h_min);
+  if (hn != hn) atomicOr(flag, 1);   // a NaN has reached the thicknesses: MOM6X_ENUMERIC at the next mom6x_ctx_sync
 }
 
 template <int DIR>
@@ -390,7 +392,7 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
     }
   }
   KLAUNCH(c, "k_convergence<DIR>", k_convergence<DIR>, grid3(nxa(ieh - ish + 1, ish), jeh - jsh + 1, d.nk, blk), blk, d, c->G,
-                     h, uh, dt, hin_conv, h_min_conv, ish, ieh, jsh, jeh);
+                     h, uh, dt, hin_conv, h_min_conv, ish, ieh, jsh, jeh, c->flag);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }

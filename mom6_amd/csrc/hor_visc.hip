@@ -1,8 +1,8 @@
 // hor_visc.hip -- hor_visc_init and horizontal_viscosity on gfx950 (MOM_hor_visc.F90:2322-3290 / :266-2317).
 //
 // On the path: LAPLACIAN and/or BIHARMONIC with background coefficients, SMAGORINSKY_KH / _AH
-// (+ BOUND_CORIOLIS_BIHARM), ADD_LES_VISCOSITY, BOUND_KH / BOUND_AH ("better" and legacy form),
-// USE_LAND_MASK_FOR_HVISC, NOSLIP.  Everything else of the module is rejected by mom6x_hor_visc_init's caller
+// (+ BOUND_CORIOLIS_BIHARM), LEITH_KH / LEITH_AH (+ MODIFIED_LEITH, USE_BETA_IN_LEITH), ADD_LES_VISCOSITY,
+// BOUND_KH / BOUND_AH ("better" and legacy form), USE_LAND_MASK_FOR_HVISC, NOSLIP.  Everything else of the module is rejected by mom6x_hor_visc_init's caller
 // contract (include/mom6x.h).
 //
 // The reference works one layer at a time on 2-D temporaries.  Here the chain
@@ -14,11 +14,14 @@
 // derivatives are recomputed where they are needed instead of being stored.
 #include "mom6x_dev.h"
 
+void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);  // halo.hip
+
 enum HV {
   HV_dx2h = 0, HV_dy2h, HV_dx2q, HV_dy2q, HV_DX_dyT, HV_DY_dxT, HV_DX_dyBu, HV_DY_dxBu, HV_red_xx, HV_red_xy,
   HV_Kh_bg_xx, HV_Kh_bg_xy, HV_Kh_Max_xx, HV_Kh_Max_xy, HV_Lap2_xx, HV_Lap2_xy,
   HV_Idx2dyCu, HV_Idxdy2u, HV_Idx2dyCv, HV_Idxdy2v, HV_Ah_bg_xx, HV_Ah_bg_xy, HV_Ah_Max_xx, HV_Ah_Max_xy,
-  HV_Bih_xx, HV_Bih_xy, HV_Bih2_xx, HV_Bih2_xy, HV_u0u, HV_u0v, HV_v0u, HV_v0v, HV_COUNT
+  HV_Bih_xx, HV_Bih_xy, HV_Bih2_xx, HV_Bih2_xy, HV_u0u, HV_u0v, HV_v0u, HV_v0v,
+  HV_Lap3_xx, HV_Lap3_xy, HV_Bih6_xx, HV_Bih6_xy, HV_dF_dx, HV_dF_dy, HV_COUNT
 };
 
 namespace {
@@ -77,6 +80,7 @@ k_hv_init1(Dm d, const double *__restrict__ G, mom6x_hor_visc_params CS, double 
     if (h_box) {
       const double g2 = (2.0 * dx2h * dy2h) / (dx2h + dy2h);
       if (CS.Smagorinsky_Kh) PLN(HV_Lap2_xx)[x] = CS.Smag_Lap_const * g2;
+      if (CS.Leith_Kh) PLN(HV_Lap3_xx)[x] = CS.Leith_Lap_const * (g2 * sqrt(g2));   // :2900-2902
       double K = dmax(CS.Kh, CS.Kh_vel_scale * sqrt(g2));
       if (CS.bound_Kh && !CS.better_bound_Kh) { PLN(HV_Kh_Max_xx)[x] = Kh_Limit * g2; K = dmin(K, Kh_Limit * g2); }
       PLN(HV_Kh_bg_xx)[x] = K;
@@ -84,6 +88,7 @@ k_hv_init1(Dm d, const double *__restrict__ G, mom6x_hor_visc_params CS, double 
     if (q_box) {
       const double g2 = (2.0 * dx2q * dy2q) / (dx2q + dy2q);
       if (CS.Smagorinsky_Kh) PLN(HV_Lap2_xy)[x] = CS.Smag_Lap_const * g2;
+      if (CS.Leith_Kh) PLN(HV_Lap3_xy)[x] = CS.Leith_Lap_const * (g2 * sqrt(g2));   // :2925-2927
       double K = dmax(CS.Kh, CS.Kh_vel_scale * sqrt(g2));
       if (CS.bound_Kh && !CS.better_bound_Kh) { PLN(HV_Kh_Max_xy)[x] = Kh_Limit * g2; K = dmin(K, Kh_Limit * g2); }
       PLN(HV_Kh_bg_xy)[x] = K;
@@ -110,6 +115,7 @@ k_hv_init1(Dm d, const double *__restrict__ G, mom6x_hor_visc_params CS, double 
           PLN(HV_Bih2_xx)[x] = (g2 * g2 * g2) * (fmax * BoundCorConst);
         }
       }
+      if (CS.Leith_Ah) { const double g3 = g2 * sqrt(g2); PLN(HV_Bih6_xx)[x] = CS.Leith_bi_const * (g3 * g3); }   // :2984-2986
       double A = dmax(CS.Ah, CS.Ah_vel_scale * g2 * sqrt(g2));
       if (CS.Ah_time_scale > 0.) A = dmax(A, (g2 * g2) / CS.Ah_time_scale);
       if (CS.bound_Ah && !CS.better_bound_Ah) { PLN(HV_Ah_Max_xx)[x] = Ah_Limit * (g2 * g2); A = dmin(A, Ah_Limit * (g2 * g2)); }
@@ -121,6 +127,7 @@ k_hv_init1(Dm d, const double *__restrict__ G, mom6x_hor_visc_params CS, double 
         PLN(HV_Bih_xy)[x] = CS.Smag_bi_const * (g2 * g2);
         if (CS.bound_Coriolis) PLN(HV_Bih2_xy)[x] = (g2 * g2 * g2) * (fabs(fBu[x]) * BoundCorConst);
       }
+      if (CS.Leith_Ah) { const double g3 = g2 * sqrt(g2); PLN(HV_Bih6_xy)[x] = CS.Leith_bi_const * (g3 * g3); }   // :3014-3016
       double A = dmax(CS.Ah, CS.Ah_vel_scale * g2 * sqrt(g2));
       if (CS.Ah_time_scale > 0.) A = dmax(A, (g2 * g2) / CS.Ah_time_scale);
       if (CS.bound_Ah && !CS.better_bound_Ah) { PLN(HV_Ah_Max_xy)[x] = Ah_Limit * (g2 * g2); A = dmin(A, Ah_Limit * (g2 * g2)); }
@@ -276,6 +283,132 @@ k_hv_del2(Dm d, const double *__restrict__ G, const double *__restrict__ P, cons
   }
 }
 
+// G%dF_dx, G%dF_dy of MOM_calculate_grad_Coriolis (MOM_shared_initialization.F90:91-122) over the computational domain; the
+// halo update that follows (pass_vector, AGRID) is the caller's.
+__global__ void __launch_bounds__(256)
+k_hv_grad_Coriolis(Dm d, const double *__restrict__ G, double *__restrict__ P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const double *fBu = MG(CoriolisBu);
+  double f1 = 0.5 * (fBu[x] + fBu[x - st]), f2 = 0.5 * (fBu[x - 1] + fBu[x - 1 - st]);
+  PLN(HV_dF_dx)[x] = MG(IdxT)[x] * (f1 - f2);
+  f1 = 0.5 * (fBu[x] + fBu[x - 1]); f2 = 0.5 * (fBu[x - st] + fBu[x - 1 - st]);
+  PLN(HV_dF_dy)[x] = MG(IdyT)[x] * (f1 - f2);
+}
+
+// Leith viscosities, stage L1 :730-733, :961-972, :1029-1031: the vertical vorticity at q points (is-3..Ieq+2, js-3..Jeq+2)
+// and, for MODIFIED_LEITH, the divergence at h points (Isq-1..Ieq+2, Jsq-1..Jeq+2).
+__global__ void __launch_bounds__(256)
+k_hv_vort(Dm d, const double *__restrict__ G, const double *__restrict__ P, const double *__restrict__ u,
+          const double *__restrict__ v, double *__restrict__ vort, double *__restrict__ divx, int no_slip, int modified) {
+  const int i = I_BASE(-3) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -3 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -3 || i > d.ni + 1 || j > d.nj + 1) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const bool do_h = modified && (i >= -2) && (j >= -2);
+  // CS%DY_dxBu, CS%DX_dyBu are set on (is-2..Ieq+1, js-2..Jeq+1) only and zero beyond (hor_visc_init :2869): the
+  // outermost ring of the vorticity is zero in the reference, and here
+  const double DY_dxBu = PLN(HV_DY_dxBu)[x], DX_dyBu = PLN(HV_DX_dyBu)[x];
+  const double IdyCvp = MG(IdyCv)[x + 1], IdyCv0 = MG(IdyCv)[x], IdxCup = MG(IdxCu)[x + st], IdxCu0 = MG(IdxCu)[x];
+  const double mBu = MG(mask2dBu)[x], mfac = no_slip ? (2.0 - mBu) : mBu;
+  double DY_dxT = 0., DX_dyT = 0., IdyCum = 0., IdxCvm = 0.;
+  if (do_h) { DY_dxT = PLN(HV_DY_dxT)[x]; DX_dyT = PLN(HV_DX_dyT)[x]; IdyCum = MG(IdyCu)[x - 1]; IdxCvm = MG(IdxCv)[x - st]; }
+  const double IdyCu0 = MG(IdyCu)[x], IdxCv0 = MG(IdxCv)[x];
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double u0 = u[c], v0 = v[c];
+    const double dvdx = DY_dxBu * ((v[c + 1] * IdyCvp) - (v0 * IdyCv0));
+    const double dudy = DX_dyBu * ((u[c + st] * IdxCup) - (u0 * IdxCu0));
+    vort[c] = mfac * (dvdx - dudy);
+    if (do_h) {
+      const double dudx = DY_dxT * ((IdyCu0 * u0) - (IdyCum * u[c - 1]));
+      const double dvdy = DX_dyT * ((IdxCv0 * v0) - (IdxCvm * v[c - st]));
+      divx[c] = dudx + dvdy;
+    }
+  }
+}
+
+// stage L2 :987-1111: from the vorticity (and the divergence) the three fields the viscosities need --
+//   LD = Del2vort_q on (is_Kh-1..ie_Kh, js_Kh-1..je_Kh) = (-2..ni, -2..nj)
+//   LH = grad_vort_mag_h + grad_div_mag_h on (-1..ni, -1..nj),  LQ = grad_vort_mag_q + grad_div_mag_q on (-1..ni-1, -1..nj-1).
+// vort_xy_dx / vort_xy_dy are re-formed where they are used (two vorticities each); beta joins them after Del2vort_q has
+// been taken (:1069-1076) -- every gradient LH and LQ look at lies inside the ranges the reference adds beta on.
+__global__ void __launch_bounds__(256)
+k_hv_leith(Dm d, const double *__restrict__ G, const double *__restrict__ P, const double *__restrict__ vort,
+           const double *__restrict__ divx, double *__restrict__ LD, double *__restrict__ LH, double *__restrict__ LQ,
+           int modified, int beta) {
+  const int i = I_BASE(-2) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -2 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -2 || i > d.ni || j > d.nj) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const bool do_h = (i >= -1) && (j >= -1), do_q = do_h && (i <= d.ni - 1) && (j <= d.nj - 1);
+  const double *IdyCu = MG(IdyCu), *IdxCv = MG(IdxCv), *IdyCv = MG(IdyCv), *IdxCu = MG(IdxCu);
+  auto DYX = [&](size_t y) { return MG(dyBu)[y] * MG(IdxBu)[y]; };   // G%dyBu * G%IdxBu, as :991 re-forms it
+  auto DXY = [&](size_t y) { return MG(dxBu)[y] * MG(IdyBu)[y]; };
+  // vort_xy_dx(i,J) at the v points x, x+1, x-st, and vort_xy_dy(I,j) at the u points x, x+st, x-1: coefficients
+  const double ax0 = DYX(x), ax0c = IdyCu[x], ax0w = IdyCu[x - 1];
+  const double axE = DYX(x + 1), axEc = IdyCu[x + 1];
+  const double axS = DYX(x - st), axSc = IdyCu[x - st], axSw = IdyCu[x - st - 1];
+  const double ay0 = DXY(x), ay0c = IdxCv[x], ay0s = IdxCv[x - st];
+  const double ayN = DXY(x + st), ayNc = IdxCv[x + st];
+  const double ayW = DXY(x - 1), ayWc = IdxCv[x - 1], ayWs = IdxCv[x - 1 - st];
+  const double IdyCv0 = IdyCv[x], IdyCvE = IdyCv[x + 1], IdyCu0 = IdyCu[x], IdyCuN = IdyCu[x + st];
+  double bx0 = 0., bxE = 0., bxS = 0., by0 = 0., byN = 0., byW = 0.;
+  if (beta && do_h) {
+    const double *Fx = PLN(HV_dF_dx), *Fy = PLN(HV_dF_dy);
+    bx0 = 0.5 * (Fx[x] + Fx[x + st]); bxE = 0.5 * (Fx[x + 1] + Fx[x + 1 + st]); bxS = 0.5 * (Fx[x - st] + Fx[x]);
+    by0 = 0.5 * (Fy[x] + Fy[x + 1]); byN = 0.5 * (Fy[x + st] + Fy[x + st + 1]); byW = 0.5 * (Fy[x - 1] + Fy[x]);
+  }
+  const double IdxCu0 = IdxCu[x], IdxCuW = IdxCu[x - 1], IdxCuN2 = IdxCu[x + st];
+  const double IdyCv00 = IdyCv[x], IdyCvS = IdyCv[x - st], IdyCvE2 = IdyCv[x + 1];
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double w0 = vort[c], wW = vort[c - 1], wE = vort[c + 1], wS = vort[c - st], wN = vort[c + st];
+    // gradients without beta
+    const double vdx0 = ax0 * ((w0 * ax0c) - (wW * ax0w));                    // vort_xy_dx(i, J)
+    const double vdxE = axE * ((wE * axEc) - (w0 * ax0c));                    // vort_xy_dx(i+1, J)
+    const double vdy0 = ay0 * ((w0 * ay0c) - (wS * ay0s));                    // vort_xy_dy(I, j)
+    const double vdyN = ayN * ((wN * ayNc) - (w0 * ay0c));                    // vort_xy_dy(I, j+1)
+    LD[c] = ax0 * ((vdxE * IdyCvE) - (vdx0 * IdyCv0)) + ay0 * ((vdyN * IdyCuN) - (vdy0 * IdyCu0));   // :1017-1023
+    if (do_h) {
+      const double wSW = vort[c - st - 1];
+      const double vdxS = axS * ((wS * axSc) - (wSW * axSw));                 // vort_xy_dx(i, J-1)
+      const double vdyW = ayW * ((wW * ayWc) - (wSW * ayWs));                 // vort_xy_dy(I-1, j)
+      double gdh = 0., gdq = 0.;
+      if (modified) {                                                        // :1033-1049
+        const double d0 = divx[c], dE = divx[c + 1], dW = divx[c - 1], dN = divx[c + st], dS = divx[c - st];
+        const double ddx0 = IdxCu0 * (dE - d0), ddxW = IdxCuW * (d0 - dW);
+        const double ddy0 = IdyCv00 * (dN - d0), ddyS = IdyCvS * (d0 - dS);
+        const double a = 0.5 * (ddx0 + ddxW), b = 0.5 * (ddy0 + ddyS);
+        gdh = sqrt((a * a) + (b * b));
+        if (do_q) {
+          const double dNE = divx[c + st + 1];
+          const double ddxN = IdxCuN2 * (dNE - dN), ddyE = IdyCvE2 * (dNE - dE);
+          const double a2 = 0.5 * (ddx0 + ddxN), b2 = 0.5 * (ddy0 + ddyE);
+          gdq = sqrt((a2 * a2) + (b2 * b2));
+        }
+      }
+      const double gx0 = beta ? vdx0 + bx0 : vdx0, gxS = beta ? vdxS + bxS : vdxS, gxE = beta ? vdxE + bxE : vdxE;
+      const double gy0 = beta ? vdy0 + by0 : vdy0, gyW = beta ? vdyW + byW : vdyW, gyN = beta ? vdyN + byN : vdyN;
+      {
+        const double a = 0.5 * (gx0 + gxS), b = 0.5 * (gy0 + gyW);           // :1104-1107
+        LH[c] = sqrt((a * a) + (b * b)) + gdh;
+      }
+      if (do_q) {
+        const double a = 0.5 * (gx0 + gxE), b = 0.5 * (gy0 + gyN);           // :1108-1111
+        LQ[c] = sqrt((a * a) + (b * b)) + gdq;
+      }
+    }
+  }
+}
+
 // h_u, h_v :767-781 from the thicknesses and T-point masks of the two cells
 __device__ __forceinline__ double hface2(double ha, double hb, double ma, double mb, int land_mask) {
   if (land_mask) return 0.5 * (ma * ha + mb * hb);
@@ -293,7 +426,8 @@ __global__ void __launch_bounds__(256)
 k_hv_stress(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom6x_hor_visc_params CS,
             const double *__restrict__ h, const double *__restrict__ sh_xx, const double *__restrict__ sh_xy,
             const double *__restrict__ Del2u, const double *__restrict__ Del2v, double *__restrict__ str_xx,
-            double *__restrict__ str_xy, double h_neglect) {
+            double *__restrict__ str_xy, double h_neglect, const double *__restrict__ LD, const double *__restrict__ LH,
+            const double *__restrict__ LQ) {
   const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i < -1 || i > d.ni || j > d.nj) return;
@@ -301,8 +435,10 @@ k_hv_stress(Dm d, const double *__restrict__ G, const double *__restrict__ P, mo
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
   const bool smag = CS.Smagorinsky_Kh || CS.Smagorinsky_Ah, better = CS.better_bound_Ah || CS.better_bound_Kh;
-  const bool legacy_bound = CS.Smagorinsky_Kh && (CS.bound_Kh && !CS.better_bound_Kh);
+  const bool legacy_bound = (CS.Smagorinsky_Kh || CS.Leith_Kh) && (CS.bound_Kh && !CS.better_bound_Kh);   // :556-557
   const bool lap = CS.Laplacian, bih = CS.biharmonic;
+  const double pi_ = 4.0 * atan(1.0), inv_PI3 = 1.0 / (pi_ * pi_ * pi_), inv_PI6 = inv_PI3 * inv_PI3;            // :481-483
+  const double Lap3_xx = CS.Leith_Kh ? PLN(HV_Lap3_xx)[x] : 0., Bih6_xx = CS.Leith_Ah ? PLN(HV_Bih6_xx)[x] : 0.;
   const bool do_q = (i <= d.ni - 1 && j <= d.nj - 1);
   const double h_neglect3 = h_neglect * h_neglect * h_neglect;
   const int lm = CS.use_land_mask;
@@ -321,11 +457,14 @@ k_hv_stress(Dm d, const double *__restrict__ G, const double *__restrict__ P, mo
   const double DY_dxT = bih ? PLN(HV_DY_dxT)[x] : 0., DX_dyT = bih ? PLN(HV_DX_dyT)[x] : 0.;
   // q point
   double red_xy = 0., Kh_bg_xy = 0., Kh_Max_xy = 0., Lap2_xy = 0., Ah_bg_xy = 0., Ah_Max_xy = 0., Bih_xy = 0., Bih2_xy = 0.;
+  double Lap3_xy = 0., Bih6_xy = 0.;
   double DY_dxBu = 0., DX_dyBu = 0., IdyCvE = 0., IdyCv0 = 0., IdxCuN = 0., IdxCu0 = 0., mBu = 0., mu0 = 0., mu1 = 0., mv0 = 0., mv1 = 0.;
   if (do_q) {
     red_xy = PLN(HV_red_xy)[x]; mBu = MG(mask2dBu)[x];
     if (lap) { Kh_bg_xy = PLN(HV_Kh_bg_xy)[x]; Kh_Max_xy = PLN(HV_Kh_Max_xy)[x]; }
     if (CS.Smagorinsky_Kh) Lap2_xy = PLN(HV_Lap2_xy)[x];
+    if (CS.Leith_Kh) Lap3_xy = PLN(HV_Lap3_xy)[x];
+    if (CS.Leith_Ah) Bih6_xy = PLN(HV_Bih6_xy)[x];
     if (bih) {
       Ah_bg_xy = PLN(HV_Ah_bg_xy)[x]; Ah_Max_xy = PLN(HV_Ah_Max_xy)[x];
       DY_dxBu = PLN(HV_DY_dxBu)[x]; DX_dyBu = PLN(HV_DX_dyBu)[x];
@@ -355,8 +494,14 @@ k_hv_stress(Dm d, const double *__restrict__ G, const double *__restrict__ P, mo
       }
       if (lap) {
         double K = Kh_bg_xx;
-        if (CS.add_LES_viscosity) { if (CS.Smagorinsky_Kh) K = K + Lap2_xx * Shear; }
-        else { if (CS.Smagorinsky_Kh) K = dmax(K, Lap2_xx * Shear); }
+        const double vvm = CS.Leith_Kh ? LH[c] : 0.0;
+        if (CS.add_LES_viscosity) {
+          if (CS.Smagorinsky_Kh) K = K + Lap2_xx * Shear;
+          if (CS.Leith_Kh) K = K + Lap3_xx * vvm * inv_PI3;
+        } else {
+          if (CS.Smagorinsky_Kh) K = dmax(K, Lap2_xx * Shear);
+          if (CS.Leith_Kh) K = dmax(K, Lap3_xx * vvm * inv_PI3);
+        }
         if (legacy_bound) K = dmin(K, Kh_Max_xx);
         K = dmax(K, CS.Kh_bg_min);
         if (CS.better_bound_Kh && CS.better_bound_Ah) {
@@ -371,11 +516,17 @@ k_hv_stress(Dm d, const double *__restrict__ G, const double *__restrict__ P, mo
       } else sxx_out = 0.0;
       if (bih) {
         double A = Ah_bg_xx;
-        if (CS.Smagorinsky_Ah) {
-          double AhSm;
-          if (CS.bound_Coriolis) AhSm = Shear * (Bih_xx + Bih2_xx * Shear);
-          else AhSm = Bih_xx * Shear;
-          A = dmax(A, AhSm);
+        if (CS.Smagorinsky_Ah || CS.Leith_Ah) {   // :1301-1385
+          if (CS.Smagorinsky_Ah) {
+            double AhSm;
+            if (CS.bound_Coriolis) AhSm = Shear * (Bih_xx + Bih2_xx * Shear);
+            else AhSm = Bih_xx * Shear;
+            A = dmax(A, AhSm);
+          }
+          if (CS.Leith_Ah) {
+            const double Del2vort_h = 0.25 * ((LD[c] + LD[c - 1 - st]) + (LD[c - 1] + LD[c - st]));
+            A = dmax(A, Bih6_xx * fabs(Del2vort_h) * inv_PI6);
+          }
           if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, Ah_Max_xx);
         }
         if (CS.better_bound_Ah) {
@@ -424,6 +575,10 @@ k_hv_stress(Dm d, const double *__restrict__ G, const double *__restrict__ P, mo
           if (CS.add_LES_viscosity) K = K + Lap2_xy * Shear;
           else K = dmax(K, Lap2_xy * Shear);
         }
+        if (CS.Leith_Kh) {   // :1610-1620
+          if (CS.add_LES_viscosity) K = K + Lap3_xy * LQ[c] * inv_PI3;
+          else K = dmax(K, Lap3_xy * LQ[c] * inv_PI3);
+        }
         if (legacy_bound) K = dmin(K, Kh_Max_xy);
         K = dmax(K, CS.Kh_bg_min);
         if (CS.better_bound_Kh && CS.better_bound_Ah) {
@@ -438,11 +593,14 @@ k_hv_stress(Dm d, const double *__restrict__ G, const double *__restrict__ P, mo
       } else sxy_out = 0.;
       if (bih) {
         double A = Ah_bg_xy;
-        if (CS.Smagorinsky_Ah) {
-          double AhSm;
-          if (CS.bound_Coriolis) AhSm = Shear * (Bih_xy + Bih2_xy * Shear);
-          else AhSm = Bih_xy * Shear;
-          A = dmax(A, AhSm);
+        if (CS.Smagorinsky_Ah || CS.Leith_Ah) {   // :1745-1773
+          if (CS.Smagorinsky_Ah) {
+            double AhSm;
+            if (CS.bound_Coriolis) AhSm = Shear * (Bih_xy + Bih2_xy * Shear);
+            else AhSm = Bih_xy * Shear;
+            A = dmax(A, AhSm);
+          }
+          if (CS.Leith_Ah) A = dmax(A, Bih6_xy * fabs(LD[c]) * inv_PI6);
           if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, Ah_Max_xy);
         }
         if (CS.better_bound_Ah) {
@@ -505,6 +663,8 @@ extern "C" int mom6x_hor_visc_init(mom6x_ctx *c, const mom6x_hor_visc_params *p)
   if (!cs.Laplacian) { cs.Smagorinsky_Kh = 0; cs.bound_Kh = 0; cs.better_bound_Kh = 0; }
   if (!cs.biharmonic) { cs.Smagorinsky_Ah = 0; cs.bound_Ah = 0; cs.better_bound_Ah = 0; }
   if (!cs.Smagorinsky_Ah) cs.bound_Coriolis = 0;
+  if (!cs.Laplacian) cs.Leith_Kh = 0;     // :2473
+  if (!cs.biharmonic) cs.Leith_Ah = 0;    // :2561
   REQUIRE(!(cs.no_slip && cs.biharmonic), MOM6X_EINVAL,
           "ERROR: NOSLIP and BIHARMONIC cannot be defined at the same time in MOM.");
   REQUIRE(c->dims.halo >= 3, MOM6X_EINVAL, "hor_visc_init: halo >= 3 required");
@@ -520,6 +680,12 @@ extern "C" int mom6x_hor_visc_init(mom6x_ctx *c, const mom6x_hor_visc_params *p)
     KLAUNCH(c, "k_hv_init1", k_hv_init1, g, b, d, c->G, cs, c->hv_planes);
     KLAUNCH(c, "k_hv_init2", k_hv_init2, g, b, d, c->G, cs, c->hv_planes);
     KLAUNCH(c, "k_hv_init3", k_hv_init3, g, b, d, c->G, cs, c->hv_planes);
+    if ((cs.Leith_Kh || cs.Leith_Ah) && cs.use_beta_in_Leith) {   // G%dF_dx, G%dF_dy (+ their pass_vector)
+      KLAUNCH(c, "k_hv_grad_Coriolis", k_hv_grad_Coriolis, grid3(d.ni, d.nj, 1, b), b, d, c->G, c->hv_planes);
+      double *f[] = { c->hv_planes + (size_t)HV_dF_dx * d.slab, c->hv_planes + (size_t)HV_dF_dy * d.slab };
+      const int stg[] = { 0, 0 }, nks[] = { 1, 1 };
+      halo_wrap(c, f, stg, nks, 2);
+    }
     HIPCHK(hipGetLastError());
   }
   c->hv_init = true;
@@ -546,8 +712,21 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
   if (CS.biharmonic)
     KLAUNCH(c, "k_hv_del2", k_hv_del2, grid3(nxa(d.ni + 3, -2), d.nj + 3, nchunks(d.nk), b), b, d, c->G, P, (const double *)sh_xx,
             (const double *)sh_xy, Del2u, Del2v);
+  double *LD = nullptr, *LH = nullptr, *LQ = nullptr;
+  if (CS.Leith_Kh || CS.Leith_Ah) {
+    // the vorticity and the divergence borrow the stress arrays (dead until k_hv_stress writes them)
+    double *vort = str_xx, *divx = str_xy;
+    if ((rc = ctx_scratch(c, SCR_absv, d.nk, &LD)) || (rc = ctx_scratch(c, SCR_e, d.nk + 1, &LH)) || (rc = ctx_scratch(c, SCR_c1, d.nk, &LQ)))
+      return rc;
+    KLAUNCH(c, "k_hv_vort", k_hv_vort, grid3(nxa(d.ni + 5, -3), d.nj + 5, nchunks(d.nk), b), b, d, c->G, P, u, v, vort, divx, CS.no_slip,
+            CS.modified_Leith);
+    KLAUNCH(c, "k_hv_leith", k_hv_leith, grid3(nxa(d.ni + 3, -2), d.nj + 3, nchunks(d.nk), b), b, d, c->G, P, (const double *)vort,
+            (const double *)divx, LD, LH, LQ, CS.modified_Leith, CS.use_beta_in_Leith);
+    // k_hv_stress reads LD / LH / LQ and overwrites vort / divx: the stream orders them
+  }
   KLAUNCH(c, "k_hv_stress", k_hv_stress, grid3(nxa(d.ni + 2, -1), d.nj + 2, nchunks(d.nk), b), b, d, c->G, P, CS, h, (const double *)sh_xx,
-          (const double *)sh_xy, (const double *)Del2u, (const double *)Del2v, str_xx, str_xy, c->GV.H_subroundoff);
+          (const double *)sh_xy, (const double *)Del2u, (const double *)Del2v, str_xx, str_xy, c->GV.H_subroundoff, (const double *)LD,
+          (const double *)LH, (const double *)LQ);
   KLAUNCH(c, "k_hv_accel", k_hv_accel, grid3(nxa(d.ni + 1, -1), d.nj + 1, nchunks(d.nk), b), b, d, c->G, P, h, (const double *)str_xx,
           (const double *)str_xy, diffu, diffv, CS.use_land_mask, c->GV.H_subroundoff);
   HIPCHK(hipGetLastError());

@@ -130,6 +130,20 @@ class Dycore:
         shape = self.dims.shape2() if nd == 2 else self.dims.shape3()
         return _view(ptr, shape, self.device)
 
+    def btstep_warnings(self, reset=True, warn=True):
+        """The count of btstep's "eta has dropped below bathyT" warnings (MOM_barotropic.F90:2738-2745) over all sub-steps
+        since the last reset, and the first offender (eta, -bathyT, i, j).  With `warn`, the message of the reference goes
+        out as a Python warning."""
+        n = C.c_longlong(0)
+        info = (C.c_double * 4)()
+        check(self.lib, self.lib.mom6x_btstep_warnings(self.ctx, C.c_int(int(reset)), C.byref(n), info))
+        first = dict(eta=info[0], minus_bathyT=info[1], i=int(info[2]), j=int(info[3])) if n.value else None
+        if n.value and warn:
+            import warnings
+            warnings.warn("btstep: eta has dropped below bathyT: %24.16E vs. %24.16E at i, j = %d, %d (%d occurrences)" %
+                          (info[0], info[1], int(info[2]), int(info[3]), n.value), RuntimeWarning)
+        return n.value, first
+
     def barotropic_dtbt(self, value=None):
         """CS%dtbt (the restart scalar DTBT); with a value, set it (a restarted run)."""
         out = C.c_double(0.0)

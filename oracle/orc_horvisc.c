@@ -13,9 +13,11 @@ enum {
   HV_dx2h = 0, HV_dy2h, HV_dx2q, HV_dy2q, HV_DX_dyT, HV_DY_dxT, HV_DX_dyBu, HV_DY_dxBu, HV_red_xx, HV_red_xy,
   HV_Kh_bg_xx, HV_Kh_bg_xy, HV_Kh_Max_xx, HV_Kh_Max_xy, HV_Lap2_xx, HV_Lap2_xy,
   HV_Idx2dyCu, HV_Idxdy2u, HV_Idx2dyCv, HV_Idxdy2v, HV_Ah_bg_xx, HV_Ah_bg_xy, HV_Ah_Max_xx, HV_Ah_Max_xy,
-  HV_Bih_xx, HV_Bih_xy, HV_Bih2_xx, HV_Bih2_xy, HV_u0u, HV_u0v, HV_v0u, HV_v0v, ORC_HV_COUNT
+  HV_Bih_xx, HV_Bih_xy, HV_Bih2_xx, HV_Bih2_xy, HV_u0u, HV_u0v, HV_v0u, HV_v0v,
+  HV_Lap3_xx, HV_Lap3_xy, HV_Bih6_xx, HV_Bih6_xy, HV_dF_dx, HV_dF_dy, ORC_HV_COUNT
 };
 int orc_hor_visc_nplanes(void) { return ORC_HV_COUNT; }
+void orc_pass_var(const mom6x_dims *d, double *a, int stagger, int nk);   /* orc_rk2.c: the single-tile halo update */
 
 #define PL(n) (P + (size_t)(n) * slab)
 #define M(n) GM(G, d, MOM6X_G_##n)
@@ -29,6 +31,8 @@ int orc_hor_visc_init(const mom6x_dims *d, const double *G, const mom6x_hor_visc
   if (!cs_.Laplacian) { cs_.Smagorinsky_Kh = 0; cs_.bound_Kh = 0; cs_.better_bound_Kh = 0; }
   if (!cs_.biharmonic) { cs_.Smagorinsky_Ah = 0; cs_.bound_Ah = 0; cs_.better_bound_Ah = 0; }
   if (!cs_.Smagorinsky_Ah) cs_.bound_Coriolis = 0;
+  if (!cs_.Laplacian) cs_.Leith_Kh = 0;     /* :2473 */
+  if (!cs_.biharmonic) cs_.Leith_Ah = 0;    /* :2561 */
   const mom6x_hor_visc_params *CS = &cs_;
   const size_t slab = (size_t)d->slab;
   const int st = d->pitch;
@@ -41,6 +45,18 @@ int orc_hor_visc_init(const mom6x_dims *d, const double *G, const mom6x_hor_visc
   const double *IareaCu = M(IareaCu), *IareaCv = M(IareaCv), *dy_Cu = M(dy_Cu), *dyCu = M(dyCu), *dx_Cv = M(dx_Cv), *dxCv = M(dxCv);
   const double *fBu = M(CoriolisBu);
   const double Idt = 1.0 / CS->dt;
+  if ((CS->Leith_Kh || CS->Leith_Ah) && CS->use_beta_in_Leith) {
+    /* G%dF_dx, G%dF_dy: MOM_calculate_grad_Coriolis (MOM_shared_initialization.F90:91-122) over the computational domain,
+     * then pass_vector(..., stagger=AGRID): a halo update of the two h-point planes */
+    for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
+      size_t x = IX2(d, i, j);
+      double f1 = 0.5 * (fBu[x] + fBu[x - st]), f2 = 0.5 * (fBu[x - 1] + fBu[x - 1 - st]);
+      PL(HV_dF_dx)[x] = IdxT[x] * (f1 - f2);
+      f1 = 0.5 * (fBu[x] + fBu[x - 1]); f2 = 0.5 * (fBu[x - st] + fBu[x - 1 - st]);
+      PL(HV_dF_dy)[x] = IdyT[x] * (f1 - f2);
+    }
+    orc_pass_var(d, PL(HV_dF_dx), 0, 1); orc_pass_var(d, PL(HV_dF_dy), 0, 1);
+  }
   for (int J = js - 2; J <= Jeq + 1; J++) for (int I = is - 2; I <= Ieq + 1; I++) {   /* :2869-2889 */
     size_t x = IX2(d, I, J);
     PL(HV_dx2q)[x] = dxBu[x] * dxBu[x]; PL(HV_dy2q)[x] = dyBu[x] * dyBu[x];
@@ -75,6 +91,7 @@ int orc_hor_visc_init(const mom6x_dims *d, const double *G, const mom6x_hor_visc
       size_t x = IX2(d, i, j);
       const double g2 = (2.0 * PL(HV_dx2h)[x] * PL(HV_dy2h)[x]) / (PL(HV_dx2h)[x] + PL(HV_dy2h)[x]);
       if (CS->Smagorinsky_Kh) PL(HV_Lap2_xx)[x] = CS->Smag_Lap_const * g2;
+      if (CS->Leith_Kh) PL(HV_Lap3_xx)[x] = CS->Leith_Lap_const * (g2 * sqrt(g2));            /* :2900-2902 */
       PL(HV_Kh_bg_xx)[x] = orc_max(CS->Kh, CS->Kh_vel_scale * sqrt(g2));
       if (CS->bound_Kh && !CS->better_bound_Kh) {
         PL(HV_Kh_Max_xx)[x] = Kh_Limit * g2;
@@ -85,6 +102,7 @@ int orc_hor_visc_init(const mom6x_dims *d, const double *G, const mom6x_hor_visc
       size_t x = IX2(d, I, J);
       const double g2 = (2.0 * PL(HV_dx2q)[x] * PL(HV_dy2q)[x]) / (PL(HV_dx2q)[x] + PL(HV_dy2q)[x]);
       if (CS->Smagorinsky_Kh) PL(HV_Lap2_xy)[x] = CS->Smag_Lap_const * g2;
+      if (CS->Leith_Kh) PL(HV_Lap3_xy)[x] = CS->Leith_Lap_const * (g2 * sqrt(g2));            /* :2925-2927 */
       PL(HV_Kh_bg_xy)[x] = orc_max(CS->Kh, CS->Kh_vel_scale * sqrt(g2));
       if (CS->bound_Kh && !CS->better_bound_Kh) {
         PL(HV_Kh_Max_xy)[x] = Kh_Limit * g2;
@@ -116,6 +134,7 @@ int orc_hor_visc_init(const mom6x_dims *d, const double *G, const mom6x_hor_visc
           PL(HV_Bih2_xx)[x] = (g2 * g2 * g2) * (fmax * BoundCorConst);
         }
       }
+      if (CS->Leith_Ah) { const double g3 = g2 * sqrt(g2); PL(HV_Bih6_xx)[x] = CS->Leith_bi_const * (g3 * g3); }   /* :2984-2986 */
       PL(HV_Ah_bg_xx)[x] = orc_max(CS->Ah, CS->Ah_vel_scale * g2 * sqrt(g2));
       if (CS->Ah_time_scale > 0.) PL(HV_Ah_bg_xx)[x] = orc_max(PL(HV_Ah_bg_xx)[x], (g2 * g2) / CS->Ah_time_scale);
       if (CS->bound_Ah && !CS->better_bound_Ah) {
@@ -130,6 +149,7 @@ int orc_hor_visc_init(const mom6x_dims *d, const double *G, const mom6x_hor_visc
         PL(HV_Bih_xy)[x] = CS->Smag_bi_const * (g2 * g2);
         if (CS->bound_Coriolis) PL(HV_Bih2_xy)[x] = (g2 * g2 * g2) * (fabs(fBu[x]) * BoundCorConst);
       }
+      if (CS->Leith_Ah) { const double g3 = g2 * sqrt(g2); PL(HV_Bih6_xy)[x] = CS->Leith_bi_const * (g3 * g3); }   /* :3014-3016 */
       PL(HV_Ah_bg_xy)[x] = orc_max(CS->Ah, CS->Ah_vel_scale * g2 * sqrt(g2));
       if (CS->Ah_time_scale > 0.) PL(HV_Ah_bg_xy)[x] = orc_max(PL(HV_Ah_bg_xy)[x], (g2 * g2) / CS->Ah_time_scale);
       if (CS->bound_Ah && !CS->better_bound_Ah) {
@@ -206,6 +226,8 @@ int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_v
   if (!cs_.Laplacian) { cs_.Smagorinsky_Kh = 0; cs_.bound_Kh = 0; cs_.better_bound_Kh = 0; }
   if (!cs_.biharmonic) { cs_.Smagorinsky_Ah = 0; cs_.bound_Ah = 0; cs_.better_bound_Ah = 0; }
   if (!cs_.Smagorinsky_Ah) cs_.bound_Coriolis = 0;
+  if (!cs_.Laplacian) cs_.Leith_Kh = 0;     /* :2473 */
+  if (!cs_.biharmonic) cs_.Leith_Ah = 0;    /* :2561 */
   const mom6x_hor_visc_params *CS = &cs_;
   const size_t slab = (size_t)d->slab;
   const int st = d->pitch, nz = d->nk;
@@ -227,15 +249,23 @@ int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_v
   const double *Bih_xx = P + (size_t)HV_Bih_xx * slab, *Bih_xy = P + (size_t)HV_Bih_xy * slab;
   const double *Bih2_xx = P + (size_t)HV_Bih2_xx * slab, *Bih2_xy = P + (size_t)HV_Bih2_xy * slab;
   const double h_neglect = GV->H_subroundoff, h_neglect3 = h_neglect * h_neglect * h_neglect;
-  const int legacy_bound = CS->Smagorinsky_Kh && (CS->bound_Kh && !CS->better_bound_Kh);
+  const double *Lap3_xx = P + (size_t)HV_Lap3_xx * slab, *Lap3_xy = P + (size_t)HV_Lap3_xy * slab;
+  const double *Bih6_xx = P + (size_t)HV_Bih6_xx * slab, *Bih6_xy = P + (size_t)HV_Bih6_xy * slab;
+  const double *dF_dx = P + (size_t)HV_dF_dx * slab, *dF_dy = P + (size_t)HV_dF_dy * slab;
+  const int leith = CS->Leith_Kh || CS->Leith_Ah;
+  if (leith && d->halo < 3) return MOM6X_EINVAL;   /* "The minimum halo size is 3 when a Leith viscosity is being used." :550 */
+  const double inv_PI3 = 1.0 / ((4.0 * atan(1.0)) * (4.0 * atan(1.0)) * (4.0 * atan(1.0))), inv_PI6 = inv_PI3 * inv_PI3;   /* :481-483 */
+  const int legacy_bound = (CS->Smagorinsky_Kh || CS->Leith_Kh) && (CS->bound_Kh && !CS->better_bound_Kh);   /* :556-557 */
   const int smag = CS->Smagorinsky_Kh || CS->Smagorinsky_Ah, better = CS->better_bound_Ah || CS->better_bound_Kh;
   /* layers are independent (the reference: !$OMP parallel do over k, MOM_hor_visc.F90:690): every thread its own work planes */
 #pragma omp parallel
   {
-  double *w = (double *)calloc(slab * 16, sizeof(double));
+  double *w = (double *)calloc(slab * 25, sizeof(double));
   double *sh_xx = w, *sh_xy = w + slab, *h_u = w + 2 * slab, *h_v = w + 3 * slab, *Del2u = w + 4 * slab, *Del2v = w + 5 * slab;
   double *str_xx = w + 6 * slab, *str_xy = w + 7 * slab, *Shear = w + 8 * slab, *hrat = w + 9 * slab, *vbr = w + 10 * slab;
   double *dDel2vdx = w + 11 * slab, *dDel2udy = w + 12 * slab, *hq = w + 13 * slab, *Kh = w + 14 * slab, *Ah = w + 15 * slab;
+  double *vort = w + 16 * slab, *vdx = w + 17 * slab, *vdy = w + 18 * slab, *D2q = w + 19 * slab, *divx = w + 20 * slab;
+  double *ddx = w + 21 * slab, *ddy = w + 22 * slab, *gdh = w + 23 * slab, *gdq = w + 24 * slab;   /* (zero unless MODIFIED_LEITH) */
 #pragma omp for schedule(static)
   for (int k = 0; k < nz; k++) {
     const double *uk = u + k * slab, *vk = v + k * slab, *hk = h + k * slab;
@@ -244,6 +274,7 @@ int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_v
       const double dudx = DY_dxT[x] * ((IdyCu[x] * uk[x]) - (IdyCu[x - 1] * uk[x - 1]));
       const double dvdy = DX_dyT[x] * ((IdxCv[x] * vk[x]) - (IdxCv[x - st] * vk[x - st]));
       sh_xx[x] = dudx - dvdy;
+      divx[x] = dudx + dvdy;                                                               /* :1029-1031 (same range) */
     }
     for (int J = js - 2; J <= Jeq + 1; J++) for (int I = is - 2; I <= Ieq + 1; I++) {       /* :733-737, :907-917 */
       size_t x = IX2(d, I, J);
@@ -274,6 +305,63 @@ int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_v
                    Idx2dyCv[x] * ((dx2h[x + st] * sh_xx[x + st]) - (dx2h[x] * sh_xx[x]));
       }
     }
+    if (leith) {   /* :961-1113 with js_vort = js_Kh-2 = js-3, je_vort = Jeq+2, is_vort = is-3, ie_vort = Ieq+2 (:547-552) */
+      for (int J = js - 3; J <= Jeq + 2; J++) for (int I = is - 3; I <= Ieq + 2; I++) {   /* :730-733, :962-972 */
+        size_t x = IX2(d, I, J);
+        const double dvdx = DY_dxBu[x] * ((vk[x + 1] * IdyCv[x + 1]) - (vk[x] * IdyCv[x]));
+        const double dudy = DX_dyBu[x] * ((uk[x + st] * IdxCu[x + st]) - (uk[x] * IdxCu[x]));
+        if (CS->no_slip) vort[x] = (2.0 - mBu[x]) * (dvdx - dudy);
+        else vort[x] = mBu[x] * (dvdx - dudy);
+      }
+      /* (these loops re-form DY_dxBu = G%dyBu * G%IdxBu from the grid, :991: not CS%DY_dxBu, which is zero beyond is-2..Ieq+1) */
+      const double *dxBu = M(dxBu), *dyBu = M(dyBu), *IdxBu = M(IdxBu), *IdyBu = M(IdyBu);
+      for (int J = js - 2; J <= je + 1; J++) for (int i = Isq - 1; i <= ie + 2; i++) {      /* :990-993 */
+        size_t x = IX2(d, i, J);
+        const double DYX = dyBu[x] * IdxBu[x];
+        vdx[x] = DYX * ((vort[x] * IdyCu[x]) - (vort[x - 1] * IdyCu[x - 1]));
+      }
+      for (int j = Jsq - 1; j <= je + 2; j++) for (int I = is - 2; I <= ie + 1; I++) {      /* :995-998 */
+        size_t x = IX2(d, I, j);
+        const double DXY = dxBu[x] * IdyBu[x];
+        vdy[x] = DXY * ((vort[x] * IdxCv[x]) - (vort[x - st] * IdxCv[x - st]));
+      }
+      for (int J = Jsq - 1; J <= je + 1; J++) for (int I = Isq - 1; I <= ie + 1; I++) {     /* :1017-1023 */
+        size_t x = IX2(d, I, J);
+        const double DYX = dyBu[x] * IdxBu[x], DXY = dxBu[x] * IdyBu[x];
+        D2q[x] = DYX * ((vdx[x + 1] * IdyCv[x + 1]) - (vdx[x] * IdyCv[x])) +
+                 DXY * ((vdy[x + st] * IdyCu[x + st]) - (vdy[x] * IdyCu[x]));
+      }
+      if (CS->modified_Leith) {                                                            /* :1026-1049 */
+        for (int j = js - 1; j <= je + 1; j++) for (int I = Isq - 1; I <= ie + 1; I++) {
+          size_t x = IX2(d, I, j);
+          ddx[x] = IdxCu[x] * (divx[x + 1] - divx[x]);
+        }
+        for (int J = Jsq - 1; J <= je + 1; J++) for (int i = is - 1; i <= ie + 1; i++) {
+          size_t x = IX2(d, i, J);
+          ddy[x] = IdyCv[x] * (divx[x + st] - divx[x]);
+        }
+        for (int j = Jsq; j <= je + 1; j++) for (int i = Isq; i <= ie + 1; i++) {
+          size_t x = IX2(d, i, j);
+          const double a = 0.5 * (ddx[x] + ddx[x - 1]), b = 0.5 * (ddy[x] + ddy[x - st]);
+          gdh[x] = sqrt((a * a) + (b * b));
+        }
+        for (int J = js - 1; J <= Jeq; J++) for (int I = is - 1; I <= Ieq; I++) {
+          size_t x = IX2(d, I, J);
+          const double a = 0.5 * (ddx[x] + ddx[x + st]), b = 0.5 * (ddy[x] + ddy[x + 1]);
+          gdq[x] = sqrt((a * a) + (b * b));
+        }
+      }
+      if (CS->use_beta_in_Leith) {                                                         /* :1069-1076 */
+        for (int J = js - 2; J <= Jeq + 1; J++) for (int i = is - 1; i <= ie + 1; i++) {
+          size_t x = IX2(d, i, J);
+          vdx[x] = vdx[x] + 0.5 * (dF_dx[x] + dF_dx[x + st]);
+        }
+        for (int j = js - 1; j <= je + 1; j++) for (int I = is - 2; I <= Ieq + 1; I++) {
+          size_t x = IX2(d, I, j);
+          vdy[x] = vdy[x] + 0.5 * (dF_dy[x] + dF_dy[x + 1]);
+        }
+      }
+    }
     /* ---- h points (js_Kh..je_Kh = Jsq..je+1, is_Kh..ie_Kh = Isq..ie+1) */
     for (int j = Jsq; j <= je + 1; j++) for (int i = Isq; i <= ie + 1; i++) {
       size_t x = IX2(d, i, j);
@@ -289,8 +377,18 @@ int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_v
       }
       if (CS->Laplacian) {                                                                /* :1126-1275 */
         double K = Kh_bg_xx[x];
-        if (CS->add_LES_viscosity) { if (CS->Smagorinsky_Kh) K = K + Lap2_xx[x] * Shear[x]; }
-        else { if (CS->Smagorinsky_Kh) K = orc_max(K, Lap2_xx[x] * Shear[x]); }
+        double vvm = 0.0;                                                                  /* :1104-1107, :1143-1146 */
+        if (leith) {
+          const double a = 0.5 * (vdx[x] + vdx[x - st]), b = 0.5 * (vdy[x] + vdy[x - 1]);
+          vvm = sqrt((a * a) + (b * b)) + gdh[x];
+        }
+        if (CS->add_LES_viscosity) {
+          if (CS->Smagorinsky_Kh) K = K + Lap2_xx[x] * Shear[x];
+          if (CS->Leith_Kh) K = K + Lap3_xx[x] * vvm * inv_PI3;
+        } else {
+          if (CS->Smagorinsky_Kh) K = orc_max(K, Lap2_xx[x] * Shear[x]);
+          if (CS->Leith_Kh) K = orc_max(K, Lap3_xx[x] * vvm * inv_PI3);
+        }
         if (legacy_bound) K = orc_min(K, Kh_Max_xx[x]);
         K = orc_max(K, CS->Kh_bg_min);
         if (CS->better_bound_Kh && CS->better_bound_Ah) {
@@ -306,11 +404,18 @@ int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_v
       } else str_xx[x] = 0.0;
       if (CS->biharmonic) {                                                               /* :1283-1448 */
         double A = Ah_bg_xx[x];
-        if (CS->Smagorinsky_Ah) {
-          double AhSm;
-          if (CS->bound_Coriolis) AhSm = Shear[x] * (Bih_xx[x] + Bih2_xx[x] * Shear[x]);
-          else AhSm = Bih_xx[x] * Shear[x];
-          A = orc_max(A, AhSm);
+        if (CS->Smagorinsky_Ah || CS->Leith_Ah) {                                          /* :1301-1385 */
+          if (CS->Smagorinsky_Ah) {
+            double AhSm;
+            if (CS->bound_Coriolis) AhSm = Shear[x] * (Bih_xx[x] + Bih2_xx[x] * Shear[x]);
+            else AhSm = Bih_xx[x] * Shear[x];
+            A = orc_max(A, AhSm);
+          }
+          if (CS->Leith_Ah) {
+            const double Del2vort_h = 0.25 * ((D2q[x] + D2q[x - 1 - st]) + (D2q[x - 1] + D2q[x - st]));
+            const double AhLth = Bih6_xx[x] * fabs(Del2vort_h) * inv_PI6;
+            A = orc_max(A, AhLth);
+          }
           if (CS->bound_Ah && !CS->better_bound_Ah) A = orc_min(A, Ah_Max_xx[x]);
         }
         if (CS->better_bound_Ah) {
@@ -365,6 +470,12 @@ int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_v
           if (CS->add_LES_viscosity) K = K + Lap2_xy[x] * Shear[x];
           else K = orc_max(K, Lap2_xy[x] * Shear[x]);
         }
+        if (CS->Leith_Kh) {                                                                /* :1108-1111, :1587-1590, :1610-1620 */
+          const double a = 0.5 * (vdx[x] + vdx[x + 1]), b = 0.5 * (vdy[x] + vdy[x + st]);
+          const double vvm = sqrt((a * a) + (b * b)) + gdq[x];
+          if (CS->add_LES_viscosity) K = K + Lap3_xy[x] * vvm * inv_PI3;
+          else K = orc_max(K, Lap3_xy[x] * vvm * inv_PI3);
+        }
         if (legacy_bound) K = orc_min(K, Kh_Max_xy[x]);
         K = orc_max(K, CS->Kh_bg_min);
         if (CS->better_bound_Kh && CS->better_bound_Ah) {
@@ -379,11 +490,14 @@ int orc_horizontal_viscosity(const mom6x_dims *d, const double *G, const mom6x_v
       } else str_xy[x] = 0.;
       if (CS->biharmonic) {                                                               /* :1714-1826 */
         double A = Ah_bg_xy[x];
-        if (CS->Smagorinsky_Ah) {
-          double AhSm;
-          if (CS->bound_Coriolis) AhSm = Shear[x] * (Bih_xy[x] + Bih2_xy[x] * Shear[x]);
-          else AhSm = Bih_xy[x] * Shear[x];
-          A = orc_max(A, AhSm);
+        if (CS->Smagorinsky_Ah || CS->Leith_Ah) {                                          /* :1745-1773 */
+          if (CS->Smagorinsky_Ah) {
+            double AhSm;
+            if (CS->bound_Coriolis) AhSm = Shear[x] * (Bih_xy[x] + Bih2_xy[x] * Shear[x]);
+            else AhSm = Bih_xy[x] * Shear[x];
+            A = orc_max(A, AhSm);
+          }
+          if (CS->Leith_Ah) A = orc_max(A, Bih6_xy[x] * fabs(D2q[x]) * inv_PI6);
           if (CS->bound_Ah && !CS->better_bound_Ah) A = orc_min(A, Ah_Max_xy[x]);
         }
         if (CS->better_bound_Ah) {

@@ -13,9 +13,9 @@ def double_gyre(nk=2, ni=44, nj=40, halo=4, layout=(1, 1), pe=(0, 0)):
     return gg, d, M
 
 
-def channel(nk=3, ni=32, nj=24, halo=4, layout=(1, 1), pe=(0, 0)):
+def channel(nk=3, ni=32, nj=24, halo=4, layout=(1, 1), pe=(0, 0), beta=2e-11):
     """zonally re-entrant channel, flat bottom with N/S walls (exercises REENTRANT_X wrap)."""
-    gg = grid.GlobalGrid(ni, nj, kind="cartesian", dx=2.0e4, dy=2.0e4, f0=1.0e-4, beta=2e-11,
+    gg = grid.GlobalGrid(ni, nj, kind="cartesian", dx=2.0e4, dy=2.0e4, f0=1.0e-4, beta=beta,
                          reentrant_x=True, depth_fn=grid.flat_depth(ni, nj, 1000.0, rim=1, rim_x=False))
     d, M = gg.tile(nk, halo, layout, pe)
     return gg, d, M

@@ -21,6 +21,17 @@ FLAGS = {
     "better_Ah_only": dict(Laplacian=1, Kh=300.0, Ah=5.0e12, better_bound_Kh=0, bound_Kh=0),
     "noslip_laplacian": dict(Laplacian=1, biharmonic=0, Kh=800.0, no_slip=1),
     "no_land_mask_no_backscatter": dict(Laplacian=1, Kh=2.0e4, Ah=1.0e13, use_land_mask=0, backscatter_underbound=0),
+    # Leith (1996) viscosities from the vorticity gradient: LEITH_KH with its default USE_BETA_IN_LEITH, LEITH_AH,
+    # MODIFIED_LEITH (+ the divergence gradient), ADD_LES_VISCOSITY / legacy bounds, with Smagorinsky next to them, NOSLIP
+    "leith_kh_beta": dict(Laplacian=1, Leith_Kh=1, Leith_Lap_const=1.0, use_beta_in_Leith=1, Kh=10.0, Ah=1.0e8),
+    "leith_kh_ah_modified": dict(Laplacian=1, Leith_Kh=1, Leith_Lap_const=1.5, Leith_Ah=1, Leith_bi_const=2.0, modified_Leith=1,
+                                 use_beta_in_Leith=1, Kh=10.0, Ah=1.0e8),
+    "leith_ah_only": dict(Leith_Ah=1, Leith_bi_const=5.0, Ah=1.0e7),
+    "leith_les_added_legacy_bounds_smag": dict(Laplacian=1, Leith_Kh=1, Leith_Lap_const=1.0, add_LES_viscosity=1, Smagorinsky_Kh=1,
+                                               Smag_Lap_const=0.15, better_bound_Kh=0, better_bound_Ah=0, Leith_Ah=1,
+                                               Leith_bi_const=1.0, Smagorinsky_Ah=1, Smag_bi_const=0.06, modified_Leith=1),
+    "leith_noslip_laplacian": dict(Laplacian=1, biharmonic=0, Leith_Kh=1, Leith_Lap_const=2.0, use_beta_in_Leith=1, no_slip=1,
+                                   Kh=100.0),
 }
 
 
@@ -55,6 +66,11 @@ def test_horizontal_viscosity(orc, cfg, flags):
     H.assert_bitwise(du.cpu().numpy(), o_du, "diffu", H.interior(d, "u"))
     H.assert_bitwise(dv.cpu().numpy(), o_dv, "diffv", H.interior(d, "v"))
     assert np.isfinite(o_du).all() and np.abs(o_du).max() > 0 and np.abs(o_dv).max() > 0
+    if "leith" in flags:   # the Leith terms are felt: the same call without them gives another answer
+        P0 = hv_params({k: v for k, v in FLAGS[flags].items() if "Leith" not in k and "leith" not in k.lower()})
+        r_du, r_dv = np.zeros_like(u), np.zeros_like(v)
+        orc.horizontal_viscosity(d, M, GV, P0, orc.hor_visc_init(d, M, P0), u, v, h, r_du, r_dv)
+        assert not np.array_equal(r_du, o_du)
     dyc.close()
 
 

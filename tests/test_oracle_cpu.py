@@ -331,6 +331,81 @@ def test_horizontal_viscosity_known_answers(orc):
         assert np.abs(dv[(Ellipsis,) + tuple(rows)]).max() <= 1e-25
 
 
+def test_leith_viscosity_known_answers(orc):
+    """LEITH_KH / LEITH_AH (MOM_hor_visc.F90:987-1113, :1161-1167, :1317-1323, :1610-1620, :1761-1765) on the Cartesian channel
+    with a zonal jet u = U sin(l y).  The discrete vorticity is -U l s1 cos(l y_J) (s1 = sin(l dy/2)/(l dy/2)), its
+    gradient U l^2 s1^2 sin(l y_j), the Laplacian of the vorticity U l^3 s1^3 cos(l y_J); at the corner points
+    Kh = C3 dx^3/pi^3 |grad vort| (averaged from the two faces: a factor cos(l dy/2)) and Ah = C6 dx^6/pi^6 |Del2 vort|,
+    so the acceleration is d/dy (Kh du/dy) and -d/dy (Ah d/dy Del2 u) in their discrete forms -- evaluated here in closed
+    form, row by row (1e-10 relative).  A uniform flow has no vorticity gradient: no stress.  Beta: with
+    USE_BETA_IN_LEITH on an f-plane nothing changes; on a beta-plane grad f joins the gradient."""
+    gg, d, M = H.channel(nk=2, nj=36, beta=0.0)
+    GV = abi.vgrid_default()
+    h = np.zeros((d.nk,) + d.shape2()); h[:] = 400.0 * M[abi.G["mask2dT"]] + GV.Angstrom_H
+    h[:, M[abi.G["mask2dT"]] == 0] = GV.Angstrom_H
+    dy = dx = 2.0e4
+    assert M[abi.G["dyT"]][d.joff + 5, d.ioff + 5] == dy and M[abi.G["dxT"]][d.joff + 5, d.ioff + 5] == dx
+    U = 0.3
+    l = 2.0 * np.pi / (12.0 * dy)
+    s1 = np.sin(0.5 * l * dy) / (0.5 * l * dy)
+    cavg = np.cos(0.5 * l * dy)
+    jrow = np.arange(d.shape2()[0]) - d.joff
+    yc = (jrow + 0.5) * dy            # u rows
+    yq = (jrow + 1.0) * dy            # the corner row J above u row j
+    u = np.zeros_like(h); v = np.zeros_like(h)
+    u[:] = (U * np.sin(l * yc))[None, :, None] * M[abi.G["mask2dCu"]]
+    rows = d.sl(-1, d.ni - 1, 9, d.nj - 10)
+    off = dict(bound_Kh=0, bound_Ah=0, better_bound_Kh=0, better_bound_Ah=0, use_land_mask=0)
+
+    def params(**kw):
+        P = abi.hor_visc_params_default(1200.0, Laplacian=kw.pop("Laplacian", False), biharmonic=kw.pop("biharmonic", False))
+        for k_, v_ in {**off, **kw}.items():
+            setattr(P, k_, v_)
+        return P
+
+    C3, C6 = 1.5, 0.8
+    sh = U * l * s1 * np.cos(l * yq)                                  # sh_xy = du/dy at the corners
+    Kh = C3 * dx ** 3 / np.pi ** 3 * (U * l ** 2 * s1 ** 2 * cavg * np.abs(np.sin(l * yq)))
+    expect_K = (Kh * sh - np.roll(Kh * sh, 1)) / dy                  # row j: (F(J) - F(J-1)) / dy
+    du, dv, _ = _hv(orc, d, M, GV, params(Laplacian=True, Leith_Kh=1, Leith_Lap_const=C3), u, v, h)
+    a = du[(Ellipsis,) + tuple(rows)]
+    b = np.broadcast_to(expect_K[None, :, None], du.shape)[(Ellipsis,) + tuple(rows)]
+    assert np.abs(b).max() > 0 and np.abs(a - b).max() <= 1e-10 * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
+    assert np.abs(dv[(Ellipsis,) + tuple(rows)]).max() <= 1e-25
+    # biharmonic Leith
+    Ah = C6 * dx ** 6 / np.pi ** 6 * np.abs(U * l ** 3 * s1 ** 3 * np.cos(l * yq))
+    B = -U * l ** 3 * s1 ** 3 * np.cos(l * yq)                        # d/dy Del2 u at the corners
+    expect_A = -(Ah * B - np.roll(Ah * B, 1)) / dy
+    du, dv, _ = _hv(orc, d, M, GV, params(biharmonic=True, Leith_Ah=1, Leith_bi_const=C6), u, v, h)
+    a = du[(Ellipsis,) + tuple(rows)]
+    b = np.broadcast_to(expect_A[None, :, None], du.shape)[(Ellipsis,) + tuple(rows)]
+    assert np.abs(b).max() > 0 and np.abs(a - b).max() <= 1e-10 * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
+    # ADD_LES_VISCOSITY on a background: Kh_total = Kh_bg + Kh_Leith -> the two accelerations add
+    Kb = 700.0
+    s = s1 ** 2
+    du2, _, _ = _hv(orc, d, M, GV, params(Laplacian=True, Leith_Kh=1, Leith_Lap_const=C3, Kh=Kb, add_LES_viscosity=1), u, v, h)
+    b2 = (np.broadcast_to(expect_K[None, :, None], du.shape) - Kb * l ** 2 * s * u)[(Ellipsis,) + tuple(rows)]
+    assert np.abs(du2[(Ellipsis,) + tuple(rows)] - b2).max() <= 1e-10 * np.abs(b2).max()
+    # uniform flow: nothing
+    u0 = np.zeros_like(u); u0[:] = U * M[abi.G["mask2dCu"]]
+    du0, dv0, _ = _hv(orc, d, M, GV, params(Laplacian=True, biharmonic=True, Leith_Kh=1, Leith_Lap_const=C3, Leith_Ah=1, Leith_bi_const=C6,
+                                             modified_Leith=1), u0, v, h)
+    assert np.abs(du0[(Ellipsis,) + tuple(rows)]).max() == 0.0 and np.abs(dv0[(Ellipsis,) + tuple(rows)]).max() == 0.0
+    # beta: f-plane -> identical; beta-plane -> |grad vort + beta| replaces |grad vort|
+    P0 = params(Laplacian=True, Leith_Kh=1, Leith_Lap_const=C3)
+    P1 = params(Laplacian=True, Leith_Kh=1, Leith_Lap_const=C3, use_beta_in_Leith=1)
+    assert np.array_equal(_hv(orc, d, M, GV, P0, u, v, h)[0], _hv(orc, d, M, GV, P1, u, v, h)[0])
+    beta = 2.0e-11
+    ggb, db, Mb = H.channel(nk=2, nj=36, beta=beta)
+    assert abs(np.diff(Mb[abi.G["CoriolisBu"]][d.joff + 10:d.joff + 12, d.ioff + 5])[0] / dy - beta) < 1e-6 * beta
+    Khb = C3 * dx ** 3 / np.pi ** 3 * np.abs(U * l ** 2 * s1 ** 2 * cavg * np.sin(l * yq) + beta)
+    expect_b = (Khb * sh - np.roll(Khb * sh, 1)) / dy
+    dub, _, _ = _hv(orc, db, Mb, GV, P1, u, v, h)
+    a = dub[(Ellipsis,) + tuple(rows)]
+    b = np.broadcast_to(expect_b[None, :, None], dub.shape)[(Ellipsis,) + tuple(rows)]
+    assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
+
+
 def test_horizontal_viscosity_better_bounds_are_stable(orc):
     """BETTER_BOUND_KH / BETTER_BOUND_AH (:3025-3114) exist so that a forward step with any requested viscosity
     cannot amplify grid-scale noise: with absurdly large KH and AH, one step of u + dt*diffu of a checkerboard must

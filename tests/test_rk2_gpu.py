@@ -165,7 +165,9 @@ def test_rk2_default_path_tolerance(orc):
 
 @pytest.mark.parametrize("cfg,mods", [("double_gyre", dict(Ah_vel_scale=0.02)),
                                       ("island_basin", dict(Laplacian=1, Kh=500.0, Smagorinsky_Kh=1, Smag_Lap_const=0.15, Smagorinsky_Ah=1,
-                                                            Smag_bi_const=0.06, Ah_vel_scale=0.02))])
+                                                            Smag_bi_const=0.06, Ah_vel_scale=0.02)),
+                                      ("island_basin", dict(Laplacian=1, Kh=50.0, Leith_Kh=1, Leith_Lap_const=1.0, use_beta_in_Leith=1,
+                                                            Leith_Ah=1, Leith_bi_const=1.0, modified_Leith=1, Ah_vel_scale=0.01))])
 def test_rk2_with_device_horizontal_viscosity(orc, cfg, mods):
     """hor_visc_init given: the step (:886) and the new-run initialisation (:1601) call horizontal_viscosity
     themselves (device vertvisc_coef as well: nothing comes from callbacks).  Bit for bit over 3 steps."""
@@ -206,3 +208,57 @@ def test_rk2_tc4_like_switches(orc):
     P.dt = cases.rk2_inputs(c, False, False)["dt"]
     run(orc, c, nsteps=3, bt_mod=dict(strong_drag=1, bebt=0.2), rk2_mod=dict(be=0.7), cor_mod=dict(Coriolis_En_Dis=1, bound_Coriolis=1),
         eos_form=abi.LINEAR, dev_vv=dict(Kvml_invZ2=0.01), hv=P, Hmix_stress=20.0)
+
+
+def test_btstep_warns_when_eta_drops_below_the_bottom_and_flags_nan(orc):
+    """The two run-time error paths of the device: (1) btstep's "eta has dropped below bathyT" WARNING (MOM_barotropic.F90:2738-2745):
+    a sea surface far below the bottom of a shallow basin is counted on the device, sub-step by sub-step, and the first
+    offender is reported; a healthy state reports nothing.  (2) MOM6X_ENUMERIC: a NaN that reaches the thicknesses in
+    continuity raises at the next context synchronisation."""
+    import torch, warnings
+    from mom6_amd.dycore import Dycore
+    from tests import cases
+    cfg = H.double_gyre()
+    gg, d, M = cfg
+    inp = cases.rk2_inputs(cfg, False, False)
+    GV, Rlay, gp, dt = inp["GV"], inp["Rlay"], inp["gp"], inp["dt"]
+    cont, bt, cor, pgf, rk2 = cases.rk2_params(d, GV, dict(strong_drag=1), None, None)
+    dyc = Dycore(d, M, GV, 0)
+    dyc.continuity_init(cont); dyc.barotropic_init(bt); dyc.CoriolisAdv_init(cor); dyc.PressureForce_init(pgf, Rlay, gp)
+    dyc.initialize_dyn_split_RK2(rk2)
+    coefs = inp["coefs"]
+    st = dict(u=dyc.to_dev(inp["u"]), v=dyc.to_dev(inp["v"]), h=dyc.to_dev(inp["h"]), uh=dyc.zeros3(), vh=dyc.zeros3(),
+              uhtr=dyc.zeros3(), vhtr=dyc.zeros3(), eta_av=dyc.zeros2())
+    dyc.vertvisc_set_coef(*[dyc.to_dev(x) if x is not None else None for x in coefs[0]])
+    tx, ty = dyc.to_dev(inp["taux"]), dyc.to_dev(inp["tauy"])
+    torch.cuda.synchronize()
+
+    def step():
+        dyc.step_MOM_dyn_split_RK2(st["u"], st["v"], st["h"], st["uh"], st["vh"], st["uhtr"], st["vhtr"], st["eta_av"], tx, ty, dt,
+                                   calc_dtbt=True)
+
+    dyc.dyn_split_RK2_new_run(st["u"], st["v"], st["h"], st["uh"], st["vh"], dt)
+    step()
+    dyc.sync()
+    assert dyc.btstep_warnings() == (0, None)
+    # (1) drain the basin: thicknesses of a millimetre leave eta = sum(h) - bathyT some 4 km below the bottom's mirror image
+    st["h"].mul_(1.0e-6); torch.cuda.synchronize()
+    dyc.dyn_split_RK2_new_run(st["u"], st["v"], st["h"], st["uh"], st["vh"], dt)
+    step()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        n, first = dyc.btstep_warnings()
+    assert n > 0 and first is not None and first["eta"] < first["minus_bathyT"]
+    assert 0 <= first["i"] < d.ni and 0 <= first["j"] < d.nj and M[G["mask2dT"], d.joff + first["j"], d.ioff + first["i"]] > 0
+    assert any("eta has dropped below bathyT" in str(x.message) for x in w)
+    assert dyc.btstep_warnings() == (0, None)   # reset by the previous query
+    # (2) a NaN thickness (a NaN velocity alone is swallowed by the upwind branches of the flux: neither u > 0 nor u < 0):
+    # the flag is raised by the convergence kernel and reported by the synchronisation
+    st["h"].copy_(dyc.to_dev(inp["h"])); st["u"].copy_(dyc.to_dev(inp["u"])); st["v"].copy_(dyc.to_dev(inp["v"]))
+    st["h"][0, d.joff + 15, d.ioff + 16] = float("nan"); torch.cuda.synchronize()
+    dyc.dyn_split_RK2_new_run(st["u"], st["v"], st["h"], st["uh"], st["vh"], dt)
+    step()
+    with pytest.raises(RuntimeError, match="numeric error flag"):
+        dyc.sync()
+    dyc.sync()   # the flag is cleared once reported
+    dyc.close()
