@@ -20,6 +20,7 @@ program check_abi
   type(mom6x_chksum_result) :: cr
   type(mom6x_sum_output_params) :: sp
   type(mom6x_energy_sums) :: es
+  type(mom6x_regrid_rho_params) :: rr
   integer :: nbad, rc
   nbad = 0
   call chk(0, int(c_sizeof(d)), "mom6x_dims")
@@ -39,6 +40,7 @@ program check_abi
   call chk(14, int(c_sizeof(cr)), "mom6x_chksum_result")
   call chk(15, int(c_sizeof(sp)), "mom6x_sum_output_params")
   call chk(16, int(c_sizeof(es)), "mom6x_energy_sums")
+  call chk(17, int(c_sizeof(rr)), "mom6x_regrid_rho_params")
   rc = mom6x_dims_init(d, 1440, 1080, 75, 4)
   if (rc /= 0 .or. d%pitch /= 1472 .or. d%ioff /= 16) then
     print *, "mom6x_dims_init mismatch", rc, d%pitch, d%ioff ; nbad = nbad + 1

@@ -14,6 +14,7 @@ module mom6x_c_api
   public :: mom6x_hor_visc_params, mom6x_hor_visc_init, mom6x_horizontal_viscosity, mom6x_vertvisc_set_direct_stress
   public :: mom6x_remapping_params, mom6x_ALE_remap_tracers, mom6x_ALE_remap_set_h_vel, mom6x_ALE_remap_velocities
   public :: mom6x_remapping_core_h, mom6x_regrid_zstar_params, mom6x_ALE_regrid_zstar
+  public :: mom6x_regrid_rho_params, mom6x_ALE_regrid_rho, mom6x_ALE_regrid_hycom1, mom6x_ALE_convective_adjustment
   public :: mom6x_chksum_result, mom6x_sum_output_params, mom6x_energy_sums, mom6x_reproducing_sum_3d, mom6x_reproducing_sum_2d
   public :: mom6x_remap_dyn_split_RK2_aux_vars
   public :: mom6x_chksum, mom6x_field_chksum, mom6x_sum_output_init, mom6x_depth_list, mom6x_write_energy, mom6x_barotropic_dtbt
@@ -112,6 +113,15 @@ module mom6x_c_api
   type, bind(C) :: mom6x_regrid_zstar_params   !< the members of regridding_CS (MOM_regridding.F90:40-140) the z* branch reads
     real(c_double) :: min_thickness, old_grid_weight, depth_of_time_filter_shallow, depth_of_time_filter_deep, Z_ref
   end type mom6x_regrid_zstar_params
+
+  !> what REGRIDDING_RHO / REGRIDDING_HYCOM1 read of regridding_CS on top of the z* members (INTERPOLATION_SCHEME: 0 P1M_H2,
+  !! 3 PLM, 5 PPM_H4)
+  type, bind(C) :: mom6x_regrid_rho_params
+    type(mom6x_regrid_zstar_params) :: f
+    integer(c_int) :: interp_scheme, boundary_extrapolation
+    real(c_double) :: ref_pressure, compressibility_fraction
+    integer(c_int) :: integrate_downward_for_e
+  end type mom6x_regrid_rho_params
 
   type, bind(C) :: mom6x_chksum_result         !< the numbers of the two lines of chksum_{h,u,v,B}_{2d,3d} (MOM_checksums.F90)
     real(c_double) :: mean, amin, amax
@@ -288,6 +298,26 @@ module mom6x_c_api
       import :: c_ptr, c_int, c_double, mom6x_regrid_zstar_params
       type(c_ptr), value :: ctx, h, h_new, dzRegrid ; type(mom6x_regrid_zstar_params), intent(in) :: p
       real(c_double), intent(in) :: coordinateResolution(*)
+    end function
+    !> regridding_main (MOM_regridding.F90:862) for REGRIDDING_RHO: target_density = nk+1 host values
+    integer(c_int) function mom6x_ALE_regrid_rho(ctx, p, eos, target_density, h, T, S, h_new, dzRegrid) bind(C, name="mom6x_ALE_regrid_rho")
+      import :: c_ptr, c_int, c_double, mom6x_regrid_rho_params, mom6x_eos_params
+      type(c_ptr), value :: ctx, h, T, S, h_new, dzRegrid
+      type(mom6x_regrid_rho_params), intent(in) :: p ; type(mom6x_eos_params), intent(in) :: eos
+      real(c_double), intent(in) :: target_density(*)
+    end function
+    !> regridding_main for REGRIDDING_HYCOM1; max_interface_depths / max_layer_thickness: c_loc of host arrays or c_null_ptr
+    integer(c_int) function mom6x_ALE_regrid_hycom1(ctx, p, eos, coordinateResolution, target_density, max_interface_depths, &
+                                                    max_layer_thickness, h, T, S, h_new, dzRegrid) bind(C, name="mom6x_ALE_regrid_hycom1")
+      import :: c_ptr, c_int, c_double, mom6x_regrid_rho_params, mom6x_eos_params
+      type(c_ptr), value :: ctx, max_interface_depths, max_layer_thickness, h, T, S, h_new, dzRegrid
+      type(mom6x_regrid_rho_params), intent(in) :: p ; type(mom6x_eos_params), intent(in) :: eos
+      real(c_double), intent(in) :: coordinateResolution(*), target_density(*)
+    end function
+    !> convective_adjustment (MOM_regridding.F90:1905): h, T, S (device) reordered in place
+    integer(c_int) function mom6x_ALE_convective_adjustment(ctx, eos, h, T, S) bind(C, name="mom6x_ALE_convective_adjustment")
+      import :: c_ptr, c_int, mom6x_eos_params
+      type(c_ptr), value :: ctx, h, T, S ; type(mom6x_eos_params), intent(in) :: eos
     end function
     !> remapping_core_h (MOM_remapping.F90:234) for ncol packed columns
     integer(c_int) function mom6x_remapping_core_h(ctx, p, ncol, n0, h0, u0, n1, h1, u1) bind(C, name="mom6x_remapping_core_h")

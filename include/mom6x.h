@@ -488,6 +488,39 @@ typedef struct mom6x_regrid_zstar_params {
 int mom6x_ALE_regrid_zstar(mom6x_ctx *ctx, const mom6x_regrid_zstar_params *p, const double *coordinateResolution,
                            const double *h, double *h_new, double *dzRegrid);
 
+/* The density-following coordinate generators of regridding_main (MOM_regridding.F90:862): REGRIDDING_RHO
+ * (build_rho_grid :1472 -> build_rho_column coord_rho.F90:92) and REGRIDDING_HYCOM1 (build_grid_HyCOM1 :1638 ->
+ * build_hycom1_column coord_hycom.F90:106; Bleck 2002), CS%nk == GV%ke, no ice shelf.  Both find the positions of the
+ * target interface densities in the column's (potential) density profile with regrid_interp.F90's
+ * build_and_interpolate_grid :331 (regridding_set_ppolys :80, interpolate_grid :295, the Newton iteration of
+ * get_polynomial_coordinate :376), blend old and new positions with filtered_grid_motion :1105 and hand back
+ * dzInterface and h_new = calc_h_new_by_dz :1008.  REGRIDDING_RHO wants the column statically stable first
+ * (regridding_preadjust_reqs :966): mom6x_ALE_convective_adjustment = convective_adjustment :1905.            */
+enum mom6x_interp_scheme {            /* INTERPOLATION_SCHEME (regrid_interp.F90:38-49); others are not carried */
+  MOM6X_INTERP_P1M_H2 = 0,            /* the default */
+  MOM6X_INTERP_P1M_H4 = 1, MOM6X_INTERP_PLM = 3, MOM6X_INTERP_PPM_H4 = 5
+};
+typedef struct mom6x_regrid_rho_params {
+  mom6x_regrid_zstar_params f;       /* MIN_THICKNESS, the time filter of filtered_grid_motion, G%Z_ref           */
+  int    interp_scheme;              /* INTERPOLATION_SCHEME (P1M_H2)                                             */
+  int    boundary_extrapolation;     /* BOUNDARY_EXTRAPOLATION (F)                                                */
+  double ref_pressure;               /* P_REF (2e7 Pa): CS%ref_pressure of REGRIDDING_RHO, tv%P_Ref of HYCOM1     */
+  double compressibility_fraction;   /* REGRID_COMPRESSIBILITY_FRACTION (0): HYCOM1 only                          */
+  int    integrate_downward_for_e;   /* CS%integrate_downward_for_e (T): REGRIDDING_RHO only                      */
+} mom6x_regrid_rho_params;
+/* target_density: nk+1 host values (the interface densities set_target_densities :2297 makes from the layer ones).  */
+int mom6x_ALE_regrid_rho(mom6x_ctx *ctx, const mom6x_regrid_rho_params *p, const mom6x_eos_params *eos,
+                         const double *target_density, const double *h, const double *T, const double *S,
+                         double *h_new, double *dzRegrid);
+/* coordinateResolution: nk host values [Z]; max_interface_depths (nk+1) and max_layer_thickness (nk): host, nullable
+ * (MAXIMUM_INT_DEPTH_CONFIG / MAX_LAYER_THICKNESS_CONFIG).  HYCOM1's "only improves" option is not carried.       */
+int mom6x_ALE_regrid_hycom1(mom6x_ctx *ctx, const mom6x_regrid_rho_params *p, const mom6x_eos_params *eos,
+                            const double *coordinateResolution, const double *target_density,
+                            const double *max_interface_depths, const double *max_layer_thickness,
+                            const double *h, const double *T, const double *S, double *h_new, double *dzRegrid);
+/* convective_adjustment :1905: adjacent layers swap (h, T, S) until the density at the surface pressure increases downward */
+int mom6x_ALE_convective_adjustment(mom6x_ctx *ctx, const mom6x_eos_params *eos, double *h, double *T, double *S);
+
 /* remapping_core_h :234 for `ncol` independent columns stored back to back (n0 | n1 values each): the entry the
  * reference's own unit tests (remapping_unit_tests :2072) exercise.  Device pointers.                          */
 int mom6x_remapping_core_h(mom6x_ctx *ctx, const mom6x_remapping_params *p, int ncol, int n0, const double *h0,

@@ -281,6 +281,30 @@ def regrid_zstar_params_default(**kw):
     return p
 
 
+INTERP_P1M_H2, INTERP_P1M_H4, INTERP_PLM, INTERP_PPM_H4 = 0, 1, 3, 5   # enum mom6x_interp_scheme
+
+
+class RegridRhoParams(C.Structure):
+    """mom6x_regrid_rho_params: what REGRIDDING_RHO / REGRIDDING_HYCOM1 read of regridding_CS on top of the z* members."""
+    _fields_ = [("f", RegridZstarParams), ("interp_scheme", C.c_int), ("boundary_extrapolation", C.c_int), ("ref_pressure", C.c_double),
+                ("compressibility_fraction", C.c_double), ("integrate_downward_for_e", C.c_int)]
+
+
+def regrid_rho_params_default(**kw):
+    """INTERPOLATION_SCHEME = P1M_H2, BOUNDARY_EXTRAPOLATION = F, P_REF = 2e7 Pa, no compressibility, heights integrated
+    downward from the surface (MOM_regridding.F90:90, :106, :118, :210-240)."""
+    p = RegridRhoParams()
+    p.f = regrid_zstar_params_default()
+    p.interp_scheme = INTERP_P1M_H2; p.boundary_extrapolation = 0; p.ref_pressure = 2.0e7; p.compressibility_fraction = 0.0
+    p.integrate_downward_for_e = 1
+    for k, v in kw.items():
+        if hasattr(p.f, k):
+            setattr(p.f, k, v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
 LINEAR, WRIGHT = 1, 2   # enum mom6x_eos_form
 
 

@@ -129,6 +129,7 @@ extern "C" int mom6x_struct_size(int which) {
     case 14: return (int)sizeof(mom6x_chksum_result);
     case 15: return (int)sizeof(mom6x_sum_output_params);
     case 16: return (int)sizeof(mom6x_energy_sums);
+    case 17: return (int)sizeof(mom6x_regrid_rho_params);
     default: return -1;
   }
 }
@@ -206,7 +207,7 @@ extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
   (void)hipFree(c->Rlay); (void)hipFree(c->g_prime); (void)hipFree(c->retry);
   hor_visc_free(c);
   diag_sums_free(c);
-  (void)hipFree(c->regrid_res);
+  (void)hipFree(c->regrid_res); (void)hipFree(c->regrid_vec);
   (void)hipFree(c->vv_a_u); (void)hipFree(c->vv_a_v); (void)hipFree(c->vv_h_u); (void)hipFree(c->vv_h_v);
   (void)hipFree(c->G); (void)hipFree(c->hL); (void)hipFree(c->hR); (void)hipFree(c->flag);
   if (c->ev_ready) { (void)hipEventDestroy(c->ev_ready); (void)hipEventDestroy(c->ev_done); }

@@ -11,6 +11,7 @@
 // are read nk/KCHUNK times instead of nk times.  Vertical solves are one thread per column with
 // sequential k (Thomas algorithm in the Schopf & Loughe form used by the reference).
 #include "mom6x_dev.h"
+#include "eos_dev.h"
 
 namespace {
 
@@ -503,15 +504,6 @@ extern "C" int mom6x_CorAdCalc(mom6x_ctx *c, const double *u, const double *v, c
 struct EosDev { int form; double Rho_T0_S0, dRho_dT, dRho_dS, dRho_dp; int do_mw, top_mw, ssh_z0; int van_only; double dz_nv; };
 
 namespace {
-constexpr double W_a0 = 7.057924e-4, W_a1 = 3.480336e-7, W_a2 = -1.112733e-7;
-constexpr double W_b0 = 5.790749e8, W_b1 = 3.516535e6, W_b2 = -4.002714e4, W_b3 = 2.084372e2, W_b4 = 5.944068e5, W_b5 = -9.643486e3;
-constexpr double W_c0 = 1.704853e5, W_c1 = 7.904722e2, W_c2 = -7.984422, W_c3 = 5.140652e-2, W_c4 = -2.302158e2, W_c5 = -3.079464;
-
-__device__ __forceinline__ void wright_coefs(double T, double S, double &al0, double &p0, double &lambda) {
-  al0 = (W_a0 + W_a1 * T) + W_a2 * S;
-  p0 = (W_b0 + W_b4 * S) + T * (W_b1 + T * ((W_b2 + W_b3 * T)) + W_b5 * S);
-  lambda = (W_c0 + W_c4 * S) + T * (W_c1 + T * ((W_c2 + W_c3 * T)) + W_c5 * S);
-}
 
 // dpa and intz_dpa of one cell (the first loop of int_density_dz_linear :373-384 / _wright :554-577)
 template <int FORM>

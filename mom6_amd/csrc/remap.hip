@@ -19,7 +19,10 @@
 //                  so a thread carries O(1) state.  Every quantity is formed by the reference's expression in the
 //                  reference's order, so the results are bit-identical to orc_remap.c (which keeps the arrays).
 #include "mom6x_dev.h"
+#include "eos_dev.h"
 #include <cfloat>
+#include <cstring>
+#include <vector>
 
 namespace {
 
@@ -652,59 +655,18 @@ k_set_h_vel(Dm d, const double *__restrict__ G, const double *__restrict__ h_new
   }
 }
 
-// ALE_regrid :518 -> regridding_main MOM_regridding.F90:862 (REGRIDDING_ZSTAR, no ice shelf, CS%nk == GV%ke): one thread per
-// column of (isc-1..iec+1, jsc-1..jec+1); zOld lives in a 3-D scratch array and zNew in dzRegrid until the filter turns it
-// into the interface displacement -- every loop has the same k in all lanes.
-__global__ void __launch_bounds__(256)
-k_regrid_zstar(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_params CS, double Z_to_H, const double *__restrict__ res,
-               const double *__restrict__ h, double *__restrict__ h_new, double *__restrict__ dzI, double *__restrict__ zOld,
-               int *__restrict__ flag) {
-  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
-  if (i < -1 || i > d.ni || j > d.nj) return;
-  const int nz = d.nk;
-  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+// ---- regridding: pieces shared by the coordinate generators.  A column lives in 3-D arrays ([k][slab], element k of
+// array p at p[x + (k-1)*slab]): every loop has the same k in all lanes, so the accesses are coalesced.
 #define LV(p, k) (p)[x + (size_t)((k) - 1) * slab]
-  if (gm(G, d, MOM6X_G_mask2dT)[x] == 0.) {                                           // :1300-1303, :1030-1033
-    for (int k = 1; k <= nz; k++) { LV(h_new, k) = LV(h, k); LV(dzI, k) = 0.; }
-    LV(dzI, nz + 1) = 0.;
-    return;
-  }
-  const double depth = dmax((gm(G, d, MOM6X_G_bathyT)[x] + CS.Z_ref) * Z_to_H, 0.0);   // nom_depth_H :920-922
-  double total = 0.0;
-  for (int k = 1; k <= nz; k++) total = total + LV(h, k);                             // :1309-1312
-  double zo = -depth;                                                                 // zOld :1315-1318
-  LV(zOld, nz + 1) = zo;
-  for (int k = nz; k >= 1; k--) { zo = zo + LV(h, k); LV(zOld, k) = zo; }
-  const double zOld1 = zo;
-  // build_zstar_column coord_zlike.F90:86-142
-  const double min_thickness = dmin(CS.min_thickness, total / (double)nz);
-  const double eta = total - depth;
-  const double stretching = total / (depth + 0.);
-  double zn = eta;
-  LV(dzI, 1) = zn;
-  for (int k = 1; k <= nz; k++) {
-    const double dh = stretching * res[k - 1] * Z_to_H;
-    zn = zn - dh;
-    LV(dzI, k + 1) = zn;
-  }
-  zn = -depth;
-  LV(dzI, nz + 1) = zn;
-  for (int k = nz; k >= 1; k--) {
-    double zk = LV(dzI, k);
-    if (zk < (zn + min_thickness)) { zk = zn + min_thickness; LV(dzI, k) = zk; }
-    zn = zk;
-  }
-  const double zNew1 = zn;
-  // filtered_grid_motion :1138-1232
-  const double zOldB = -depth, zNewB = -depth;
+
+// filtered_grid_motion MOM_regridding.F90:1105-1252 (CS%nk == nk): zNew comes in dzI and is replaced by dz_g, level by level.
+// Returns false for "z_old and z_new use different sign conventions" (a FATAL of the reference).
+__device__ bool filtered_grid_motion_col(const mom6x_regrid_zstar_params &CS, int nz, const double *__restrict__ zOld, double *dzI,
+                                         size_t x, size_t slab) {
+  const double zOld1 = LV(zOld, 1), zOldB = LV(zOld, nz + 1), zNew1 = LV(dzI, 1), zNewB = LV(dzI, nz + 1);
   const double test = (zOldB - zOld1) * (zNewB - zNew1);
-  if (test < 0.0) { atomicOr(flag, 4); return; }
-  if (test == 0.0) {
-    for (int k = 1; k <= nz + 1; k++) LV(dzI, k) = 0.0;
-    for (int k = 1; k <= nz; k++) LV(h_new, k) = dmax(0., LV(h, k) + (0.0 - 0.0));
-    return;
-  }
+  if (test < 0.0) return false;
+  if (test == 0.0) { for (int k = 1; k <= nz + 1; k++) LV(dzI, k) = 0.0; return true; }
   const double sgn = ((zOldB - zOld1) + (zNewB - zNew1) > 0.0) ? 1.0 : -1.0;
   const double zs = CS.depth_of_time_filter_shallow, zd = CS.depth_of_time_filter_deep;
   const double wtd = 1.0 - CS.old_grid_weight, Iwtd = 1.0 / wtd;
@@ -712,7 +674,6 @@ k_regrid_zstar(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_params CS,
   double Idzwt = 0.0; if (fabs(zd - zs) > 0.0) Idzwt = 1.0 / (zd - zs);
   const double dInt_zs_zd = 0.5 * (1.0 + Iwtd) * (zd - zs);
   const double Aq = 0.5 * (Iwtd - 1.0);
-  double dz_prev = 0.0;                     // dz_g(k-1); dz_g(1) = 0
   LV(dzI, 1) = 0.0;
   for (int k = 2; k <= nz + 1; k++) {
     const double z_old_k = LV(zOld, k);
@@ -741,11 +702,369 @@ k_regrid_zstar(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_params CS,
       }
     }
     LV(dzI, k) = dz;
-    LV(h_new, k - 1) = dmax(0., LV(h, k - 1) + (dz_prev - dz));                       // calc_h_new_by_dz :1022-1024
-    dz_prev = dz;
   }
-#undef LV
+  return true;
 }
+
+// adjust_interface_motion :1796-1857 (CS%nk == nk) on dz_int = dzI; false: "implied h<0 is larger than roundoff!"
+__device__ bool adjust_interface_motion_col(double cs_min_thickness, int nk, const double *__restrict__ h_old, double *dzI, size_t x,
+                                            size_t slab) {
+  const double eps = DBL_EPSILON;
+  double h_err = 0.;
+  double dzk = LV(dzI, 1);
+  for (int k = 1; k <= nk; k++) {
+    const double hk = LV(h_old, k), dzn = LV(dzI, k + 1);
+    h_err = h_err + dmax3(hk, fabs(dzk), fabs(dzn)) * eps;
+    const double h_new = hk + (dzk - dzn);
+    if (h_new < -3.0 * h_err) return false;
+    dzk = dzn;
+  }
+  double dzn = LV(dzI, nk + 1);
+  for (int k = nk; k >= 2; k--) {
+    const double hk = LV(h_old, k);
+    double dz = LV(dzI, k);
+    double h_new = hk + (dz - dzn);
+    if (h_new < cs_min_thickness) dz = (dzn - hk) + cs_min_thickness;
+    h_new = hk + (dz - dzn);
+    if (h_new < 0.) dz = (1. - eps) * (dzn - hk);
+    h_new = hk + (dz - dzn);
+    if (h_new < 0.) return false;
+    LV(dzI, k) = dz;
+    dzn = dz;
+  }
+  return true;
+}
+
+// calc_h_new_by_dz :1008-1037
+__device__ void calc_h_new_col(int nz, const double *__restrict__ h, const double *__restrict__ dzI, double *__restrict__ h_new, size_t x,
+                               size_t slab) {
+  double dzk = LV(dzI, 1);
+  for (int k = 1; k <= nz; k++) {
+    const double dzn = LV(dzI, k + 1);
+    LV(h_new, k) = dmax(0., LV(h, k) + (dzk - dzn));
+    dzk = dzn;
+  }
+}
+
+// ALE_regrid :518 -> regridding_main MOM_regridding.F90:862 (REGRIDDING_ZSTAR, no ice shelf, CS%nk == GV%ke): one thread per
+// column of (isc-1..iec+1, jsc-1..jec+1); zOld lives in a 3-D scratch array and zNew in dzRegrid until the filter turns it
+// into the interface displacement.  build_zstar_grid :1257-1366.
+__global__ void __launch_bounds__(256)
+k_regrid_zstar(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_params CS, double Z_to_H, const double *__restrict__ res,
+               const double *__restrict__ h, double *__restrict__ h_new, double *__restrict__ dzI, double *__restrict__ zOld,
+               int *__restrict__ flag) {
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -1 || i > d.ni || j > d.nj) return;
+  const int nz = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  if (gm(G, d, MOM6X_G_mask2dT)[x] == 0.) {                                           // :1300-1303, :1030-1033
+    for (int k = 1; k <= nz; k++) { LV(h_new, k) = LV(h, k); LV(dzI, k) = 0.; }
+    LV(dzI, nz + 1) = 0.;
+    return;
+  }
+  const double depth = dmax((gm(G, d, MOM6X_G_bathyT)[x] + CS.Z_ref) * Z_to_H, 0.0);   // nom_depth_H :920-922
+  double total = 0.0;
+  for (int k = 1; k <= nz; k++) total = total + LV(h, k);                             // :1309-1312
+  double zo = -depth;                                                                 // zOld :1315-1318
+  LV(zOld, nz + 1) = zo;
+  for (int k = nz; k >= 1; k--) { zo = zo + LV(h, k); LV(zOld, k) = zo; }
+  // build_zstar_column coord_zlike.F90:86-142
+  const double min_thickness = dmin(CS.min_thickness, total / (double)nz);
+  const double eta = total - depth;
+  const double stretching = total / (depth + 0.);
+  double zn = eta;
+  LV(dzI, 1) = zn;
+  for (int k = 1; k <= nz; k++) {
+    const double dh = stretching * res[k - 1] * Z_to_H;
+    zn = zn - dh;
+    LV(dzI, k + 1) = zn;
+  }
+  zn = -depth;
+  LV(dzI, nz + 1) = zn;
+  for (int k = nz; k >= 1; k--) {
+    double zk = LV(dzI, k);
+    if (zk < (zn + min_thickness)) { zk = zn + min_thickness; LV(dzI, k) = zk; }
+    zn = zk;
+  }
+  if (!filtered_grid_motion_col(CS, nz, zOld, dzI, x, slab)) { atomicOr(flag, 4); return; }   // :1337
+  if (!adjust_interface_motion_col(CS.min_thickness, nz, h, dzI, x, slab)) { atomicOr(flag, 8); return; }   // :1362
+  calc_h_new_col(nz, h, dzI, h_new, x, slab);
+}
+
+// ---- the density-following coordinates (REGRIDDING_RHO, REGRIDDING_HYCOM1) -------------------------------------------------
+struct DensArgs {
+  mom6x_regrid_rho_params CS;
+  int form; double Rho_T0_S0, dRho_dT, dRho_dS, dRho_dp;   // tv%eqn_of_state
+  double h_neglect;         // set_h_neglect :2602 (answer dates >= 20190101): GV%H_subroundoff, for cells and for edges
+  double Z_to_H, H_to_RZ_g; // GV%Z_to_H; GV%H_to_RZ * GV%g_Earth
+  int has_mid, has_mlt;
+};
+struct DensWork { double *zOld, *xT, *dens, *E1, *E2, *C2, *MP, *HN; };
+
+// get_polynomial_coordinate regrid_interp.F90:376-509 (answer dates >= 20190101) on the edge values E1, E2 of the n0 source
+// cells with widths hs (a 3-D array at `x`) and interfaces xg; a2, a3 of the cell that holds the target are re-formed the way
+// the reconstruction that made E1, E2 writes its coefficients.  *bad: no cell holds the target (a FATAL of the reference).
+__device__ double polynomial_coordinate(int scheme, int extrap, int N, const double *__restrict__ hs, const double *__restrict__ xg,
+                                        const double *__restrict__ us, const DensWork &W, double target_value, size_t x, size_t slab,
+                                        bool &bad) {
+  if (target_value <= LV(W.E1, 1)) return LV(xg, 1);
+  double e2m = LV(W.E2, 1);
+  for (int k = 2; k <= N; k++) {
+    const double e1 = LV(W.E1, k);
+    if ((target_value >= e2m) && (target_value <= e1)) return LV(xg, k);
+    e2m = LV(W.E2, k);
+  }
+  if (target_value >= e2m) return LV(xg, N + 1);
+  int k_found = -1;
+  for (int k = 1; k <= N; k++)
+    if ((target_value > LV(W.E1, k)) && (target_value < LV(W.E2, k))) { k_found = k; break; }
+  if (k_found == -1) { bad = true; return LV(xg, 1); }
+  const double e1 = LV(W.E1, k_found), e2 = LV(W.E2, k_found);
+  const double a1 = e1;
+  double a2, a3 = 0.;
+  if (scheme == MOM6X_INTERP_PLM) a2 = LV(W.C2, k_found);                   // PLM_reconstruction (with its almost_one factor)
+  else if (scheme == MOM6X_INTERP_PPM_H4) {
+    const double u = LV(us, k_found);
+    if (extrap && (k_found == 1 || k_found == N)) { a2 = 6.0 * u - 4.0 * e1 - 2.0 * e2; a3 = 3.0 * (e2 + e1 - 2.0 * u); }   // PPM_boundary_extrapolation
+    else { a2 = 4.0 * (u - e1) + 2.0 * (u - e2); a3 = 3.0 * ((e2 - u) + (e1 - u)); }                                        // PPM_reconstruction :46-52
+  } else a2 = e2 - e1;                                                       // P1M_interpolation
+  const double a4 = 0., a5 = 0., eps = 1e-6;
+  double xi0 = 0.5;
+  for (int iter = 1; iter <= 8; iter++) {
+    const double numerator = (a1 - target_value) + xi0 * (a2 + xi0 * (a3 + xi0 * (a4 + a5 * xi0)));
+    const double denominator = a2 + xi0 * (2. * a3 + xi0 * (3. * a4 + 4. * a5 * xi0));
+    const double delta = -numerator / denominator;
+    xi0 = xi0 + delta;
+    if (xi0 < 0.0) { xi0 = 0.0; if (a2 == 0.0) xi0 = xi0 + eps; }
+    if (xi0 > 1.0) { xi0 = 1.0; const double grad = a2 + (2. * a3 + (3. * a4 + 4. * a5)); if (grad == 0.0) xi0 = xi0 - eps; }
+    if (fabs(delta) < 1e-12) break;
+  }
+  return LV(xg, k_found) + xi0 * LV(hs, k_found);
+}
+
+// build_and_interpolate_grid :331-358: regridding_set_ppolys :80 (P1M_H2, PLM, PPM_H4) + interpolate_grid :295.  Source: n0
+// cells (hs, us = densities, xg = interfaces); result: the nk+1 new positions in X1 and the nk widths in W.HN.
+__device__ bool build_and_interpolate_col(const DensArgs &A, int n0, const double *__restrict__ hs, const double *__restrict__ us,
+                                          const double *__restrict__ xg, const double *__restrict__ tgt, int n1, double *X1,
+                                          const DensWork &W, size_t x, size_t slab) {
+  int scheme = A.CS.interp_scheme;
+  const int extrap = A.CS.boundary_extrapolation;
+  if (scheme == MOM6X_INTERP_PPM_H4 && n0 < 4) scheme = MOM6X_INTERP_P1M_H2;   // :154-170: too few cells for the h4 edges
+  if (scheme == MOM6X_INTERP_P1M_H2) {
+    // edge_values_explicit_h2 regrid_edge_values.F90:166-192
+    double um = LV(us, 1), hm = LV(hs, 1);
+    LV(W.E1, 1) = um;
+    for (int k = 2; k <= n0; k++) {
+      const double uk = LV(us, k), hk = LV(hs, k);
+      double e;
+      if (hm + hk == 0.0) e = 0.5 * (um + uk);
+      else e = (um * hk + uk * hm) / (hm + hk);
+      LV(W.E1, k) = e; LV(W.E2, k - 1) = e;
+      um = uk; hm = hk;
+    }
+    LV(W.E2, n0) = um;
+    // P1M_interpolation: bound_edge_values :39-101, average_discontinuous_edge_values :107-126
+    for (int k = 1; k <= n0; k++) {
+      const int km1 = (k - 1 > 1) ? k - 1 : 1, kp1 = (k + 1 < n0) ? k + 1 : n0;
+      const double hl = LV(hs, km1), hc = LV(hs, k), hr = LV(hs, kp1), ul = LV(us, km1), uc = LV(us, k), ur = LV(us, kp1);
+      double e1 = LV(W.E1, k), e2 = LV(W.E2, k);
+      double slope_x_h = 0.0;
+      if (((hl + hr) + 2.0 * hc) > 0.0) {
+        const double sigma_l = (uc - ul);
+        const double sigma_c = (ur - ul) * (hc / ((hl + hr) + 2.0 * hc));
+        const double sigma_r = (ur - uc);
+        if ((sigma_l * sigma_r) > 0.0) slope_x_h = fsign(dmin3(fabs(sigma_l), fabs(sigma_c), fabs(sigma_r)), sigma_c);
+      }
+      if ((ul - e1) * (e1 - uc) < 0.0) e1 = uc - fsign(dmin(fabs(slope_x_h), fabs(e1 - uc)), slope_x_h);
+      if ((ur - e2) * (e2 - uc) < 0.0) e2 = uc + fsign(dmin(fabs(slope_x_h), fabs(e2 - uc)), slope_x_h);
+      e1 = dmax(dmin(e1, dmax(ul, uc)), dmin(ul, uc));
+      e2 = dmax(dmin(e2, dmax(ur, uc)), dmin(ur, uc));
+      LV(W.E1, k) = e1; LV(W.E2, k) = e2;
+    }
+    for (int k = 1; k <= n0 - 1; k++) {
+      const double a = LV(W.E2, k), b = LV(W.E1, k + 1);
+      if (a != b) { const double m = 0.5 * (a + b); LV(W.E2, k) = m; LV(W.E1, k + 1) = m; }
+    }
+    if (extrap) {   // P1M_boundary_extrapolation P1M_functions.F90:72-160
+      double u0 = LV(us, 1), u1 = LV(us, 2);
+      double slope = 2.0 * (u1 - u0);
+      const double u0_r = u0 + 0.5 * slope;
+      if ((u1 - u0) * (LV(W.E1, 2) - u0_r) < 0.0) slope = 2.0 * (LV(W.E1, 2) - u0);
+      if (LV(hs, 1) != 0.0) LV(W.E1, 1) = u0 - 0.5 * slope; else LV(W.E1, 1) = u0;
+      u0 = LV(us, n0 - 1); u1 = LV(us, n0);
+      slope = 2.0 * (u1 - u0);
+      const double u0_l = u1 - 0.5 * slope;
+      if ((u1 - u0) * (u0_l - LV(W.E2, n0 - 1)) < 0.0) slope = 2.0 * (u1 - LV(W.E2, n0 - 1));
+      if (LV(hs, n0) != 0.0) LV(W.E2, n0) = u1 + 0.5 * slope; else LV(W.E2, n0) = u1;
+    }
+  } else {
+    ReconArgs R;
+    R.scheme = (scheme == MOM6X_INTERP_PLM) ? MOM6X_REMAP_PLM : MOM6X_REMAP_PPM_H4;
+    R.boundary_extrapolation = extrap; R.h_neglect = A.h_neglect; R.h_neglect_edge = A.h_neglect; R.n0 = n0;
+    View v; v.base = x; v.lev = slab;
+    reconstruct_column(R, hs, us, v, W.E1, W.E2, W.C2, nullptr, v);
+  }
+  // interpolate_grid :295-328
+  bool bad = false;
+  double xp = LV(xg, 1);
+  LV(X1, 1) = xp;
+  for (int k = 2; k <= n1; k++) {
+    const double xk = polynomial_coordinate(scheme, extrap, n0, hs, xg, us, W, tgt[k - 1], x, slab, bad);
+    LV(X1, k) = xk;
+    LV(W.HN, k - 1) = xk - xp;
+    xp = xk;
+  }
+  const double xb = LV(xg, n0 + 1);
+  LV(X1, n1 + 1) = xb;
+  LV(W.HN, n1) = xb - xp;
+  return !bad;
+}
+
+// regridding_main :862 for REGRIDDING_RHO (HYCOM = false: build_rho_grid :1472 + build_rho_column coord_rho.F90:92) and
+// REGRIDDING_HYCOM1 (HYCOM = true: build_grid_HyCOM1 :1638 + build_hycom1_column coord_hycom.F90:106, z positive downward),
+// then calc_h_new_by_dz.  One thread per column of (isc-1..iec+1, jsc-1..jec+1).  h_new doubles as the array of non-vanished
+// thicknesses until the end.
+template <bool HYCOM>
+__global__ void __launch_bounds__(256)
+k_regrid_density(Dm d, const double *__restrict__ G, DensArgs A, const double *__restrict__ res, const double *__restrict__ tgt,
+                 const double *__restrict__ mid, const double *__restrict__ mlt, const double *__restrict__ h,
+                 const double *__restrict__ T, const double *__restrict__ S, double *h_new, double *dzI, DensWork W, int *flag) {
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -1 || i > d.ni || j > d.nj) return;
+  const int nz = d.nk, nk = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const double mT = gm(G, d, MOM6X_G_mask2dT)[x];
+  if (HYCOM ? !(mT > 0.) : (mT == 0.)) {
+    for (int k = 1; k <= nz; k++) { LV(h_new, k) = LV(h, k); LV(dzI, k) = 0.; }
+    LV(dzI, nz + 1) = 0.;
+    return;
+  }
+  const mom6x_regrid_rho_params &CS = A.CS;
+  const double nominalDepth = dmax((gm(G, d, MOM6X_G_bathyT)[x] + CS.f.Z_ref) * A.Z_to_H, 0.0);
+  if (!HYCOM) {
+    double *HNV = h_new;
+    // copy_finite_thicknesses coord_rho.F90:316-358
+    int nout = 0, k_thickest = 1;
+    double vanished = 0.0, thickest = LV(h, 1);
+    for (int k = 1; k <= nz; k++) {
+      const double hk = LV(h, k);
+      LV(W.MP, k) = (double)nout;
+      LV(HNV, k) = 0.;
+      if (hk > CS.f.min_thickness) {
+        nout = nout + 1;
+        LV(W.MP, nout) = (double)k;
+        LV(HNV, nout) = hk;
+        if (hk > thickest) { thickest = hk; k_thickest = nout; }
+      } else vanished = vanished + hk;
+    }
+    if (nout > 1) {
+      LV(HNV, k_thickest) = LV(HNV, k_thickest) + vanished;
+      double xs = 0.0;
+      LV(W.xT, 1) = xs;
+      for (int k = 1; k <= nout; k++) { xs = xs + LV(HNV, k); LV(W.xT, k + 1) = xs; }
+      for (int k = 1; k <= nz; k++)
+        LV(W.dens, k) = eos_density(A.form, A.Rho_T0_S0, A.dRho_dT, A.dRho_dS, A.dRho_dp, LV(T, k), LV(S, k), CS.ref_pressure);
+      for (int k = 1; k <= nout; k++) LV(W.dens, k) = LV(W.dens, (int)LV(W.MP, k));   // (mapping(k) >= k: in place)
+      if (!build_and_interpolate_col(A, nout, HNV, W.dens, W.xT, tgt, nk, dzI, W, x, slab)) { atomicOr(flag, 16); return; }
+      // old_inflate_layers_1d :362-420
+      int count = 0;
+      for (int k = 1; k <= nk; k++) if (LV(W.HN, k) > CS.f.min_thickness) count = count + 1;
+      if (count == 0) { for (int k = 1; k <= nk; k++) LV(W.HN, k) = CS.f.min_thickness; }
+      else if (count != nk) {
+        double correction = 0.0;
+        for (int k = 1; k <= nk; k++) {
+          const double hk = LV(W.HN, k);
+          if (hk <= CS.f.min_thickness) { const double delta = CS.f.min_thickness - hk; correction = correction + delta; LV(W.HN, k) = hk + delta; }
+        }
+        double maxThickness = LV(W.HN, 1);
+        int k_found = 1;
+        for (int k = 1; k <= nk; k++) { const double hk = LV(W.HN, k); if (hk > maxThickness) { maxThickness = hk; k_found = k; } }
+        LV(W.HN, k_found) = LV(W.HN, k_found) - correction;
+      }
+      // :146-150: thicknesses -> positions -> thicknesses
+      double xa = 0.0;
+      for (int k = 1; k <= nk; k++) { const double xb = xa + LV(W.HN, k); LV(W.HN, k) = xb - xa; xa = xb; }
+    } else {
+      for (int k = 1; k <= nk; k++) LV(W.HN, k) = LV(h, k);   // nz == CS%nk: "This keeps old behavior"
+    }
+    if (CS.integrate_downward_for_e) {
+      double zn = 0., zo = 0.;
+      LV(dzI, 1) = zn; LV(W.zOld, 1) = zo;
+      for (int k = 1; k <= nk; k++) { zn = zn - LV(W.HN, k); LV(dzI, k + 1) = zn; zo = zo - LV(h, k); LV(W.zOld, k + 1) = zo; }
+    } else {
+      double zn = -nominalDepth, zo = -nominalDepth;
+      LV(dzI, nk + 1) = zn; LV(W.zOld, nz + 1) = zo;
+      for (int k = nk; k >= 1; k--) { zn = zn + LV(W.HN, k); LV(dzI, k) = zn; zo = zo + LV(h, k); LV(W.zOld, k) = zo; }
+    }
+    if (!filtered_grid_motion_col(CS.f, nz, W.zOld, dzI, x, slab)) { atomicOr(flag, 4); return; }
+  } else {
+    double zc = 0.0;
+    LV(W.zOld, 1) = zc;   // z_col: downward from the surface
+    for (int k = 1; k <= nz; k++) {
+      const double zt = zc;
+      zc = zc + LV(h, k);
+      LV(W.zOld, k + 1) = zc;
+      const double p_col = CS.ref_pressure + CS.compressibility_fraction * (0.5 * (zt + zc) * A.H_to_RZ_g - CS.ref_pressure);
+      LV(W.dens, k) = eos_density(A.form, A.Rho_T0_S0, A.dRho_dT, A.dRho_dS, A.dRho_dp, LV(T, k), LV(S, k), p_col);
+    }
+    const double z_bot = zc;
+    double rn = LV(W.dens, nz);
+    for (int k = nz - 1; k >= 1; k--) { rn = dmin(LV(W.dens, k), rn); LV(W.dens, k) = rn; }   // monotonic, if not single valued
+    if (!build_and_interpolate_col(A, nz, h, W.dens, W.zOld, tgt, nk, dzI, W, x, slab)) { atomicOr(flag, 16); return; }
+    // at least as deep as the nominal z* grid, at most the bottom :193-201
+    double nominal_z = 0.;
+    const double stretching = z_bot / nominalDepth;
+    for (int k = 2; k <= nk + 1; k++) {
+      nominal_z = nominal_z + (A.Z_to_H * res[k - 2]) * stretching;
+      double zk = dmax(LV(dzI, k), nominal_z);
+      zk = dmin(zk, z_bot);
+      LV(dzI, k) = zk;
+    }
+    if (A.has_mid || A.has_mlt) {   // :203-211
+      double zm = LV(dzI, 1);
+      for (int k = 2; k <= nk; k++) {
+        double zk = LV(dzI, k);
+        if (A.has_mid && A.has_mlt) zk = dmin3(zk, mid[k - 1], zm + mlt[k - 2]);
+        else if (A.has_mid) zk = dmin(zk, mid[k - 1]);
+        else zk = dmin(zk, zm + mlt[k - 2]);
+        LV(dzI, k) = zk;
+        zm = zk;
+      }
+    }
+    if (!filtered_grid_motion_col(CS.f, nz, W.zOld, dzI, x, slab)) { atomicOr(flag, 4); return; }
+    for (int k = 1; k <= nz + 1; k++) LV(dzI, k) = -LV(dzI, k);                        // :1713
+    if (!adjust_interface_motion_col(CS.f.min_thickness, nz, h, dzI, x, slab)) { atomicOr(flag, 8); return; }
+  }
+  calc_h_new_col(nz, h, dzI, h_new, x, slab);
+}
+
+// convective_adjustment MOM_regridding.F90:1905-1967 over (isc-1..iec+1, jsc-1..jec+1): bubble passes until stratified
+__global__ void __launch_bounds__(256)
+k_convective_adjustment(Dm d, DensArgs A, double *h, double *T, double *S, double *dens) {
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < -1 || i > d.ni || j > d.nj) return;
+  const int nz = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  for (int k = 1; k <= nz; k++) LV(dens, k) = eos_density(A.form, A.Rho_T0_S0, A.dRho_dT, A.dRho_dS, A.dRho_dp, LV(T, k), LV(S, k), 0.);
+  for (;;) {
+    bool stratified = true;
+    for (int k = 1; k <= nz - 1; k++) {
+      const double r0 = LV(dens, k), r1 = LV(dens, k + 1);
+      if (r0 > r1) {
+        const double T0 = LV(T, k), T1 = LV(T, k + 1), S0 = LV(S, k), S1 = LV(S, k + 1), h0 = LV(h, k), h1 = LV(h, k + 1);
+        LV(T, k) = T1; LV(T, k + 1) = T0; LV(S, k) = S1; LV(S, k + 1) = S0; LV(h, k) = h1; LV(h, k + 1) = h0;
+        LV(dens, k) = eos_density(A.form, A.Rho_T0_S0, A.dRho_dT, A.dRho_dS, A.dRho_dp, T1, S1, 0.);
+        LV(dens, k + 1) = eos_density(A.form, A.Rho_T0_S0, A.dRho_dT, A.dRho_dS, A.dRho_dp, T0, S0, 0.);
+        stratified = false;
+      }
+    }
+    if (stratified) break;
+  }
+}
+#undef LV
 
 int check_params(const mom6x_remapping_params *p, int n0, ReconArgs &R, ApplyArgs &A, int n1) {
   REQUIRE(p, MOM6X_EINVAL, "remapping: null parameters");
@@ -890,7 +1209,92 @@ extern "C" int mom6x_ALE_regrid_zstar(mom6x_ctx *c, const mom6x_regrid_zstar_par
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  REQUIRE(flag == 0, MOM6X_EINVAL, "filtered_grid_motion: z_old and z_new use different sign conventions.");
+  HIPCHK(hipMemsetAsync(c->flag, 0, sizeof(int), c->stream));
+  REQUIRE(!(flag & 4), MOM6X_EINVAL, "filtered_grid_motion: z_old and z_new use different sign conventions.");
+  REQUIRE(!(flag & 8), MOM6X_EINVAL, "MOM_regridding: adjust_interface_motion() - implied h<0 is larger than roundoff!");
+  return MOM6X_OK;
+}
+
+// REGRIDDING_RHO / REGRIDDING_HYCOM1: the host side the two entry points share
+static int regrid_density(mom6x_ctx *c, bool hycom, const mom6x_regrid_rho_params *p, const mom6x_eos_params *eos,
+                          const double *coordinateResolution, const double *target_density, const double *max_interface_depths,
+                          const double *max_layer_thickness, const double *h, const double *T, const double *S, double *h_new,
+                          double *dzRegrid) {
+  REQUIRE(c && p && eos && target_density && h && T && S && h_new && dzRegrid && (!hycom || coordinateResolution), MOM6X_EINVAL,
+          "ALE_regrid: null argument");
+  REQUIRE(p->f.old_grid_weight >= 0.0 && p->f.old_grid_weight < 1.0, MOM6X_EINVAL, "ALE_regrid: old_grid_weight must be in [0, 1)");
+  REQUIRE(p->interp_scheme == MOM6X_INTERP_P1M_H2 || p->interp_scheme == MOM6X_INTERP_PLM || p->interp_scheme == MOM6X_INTERP_PPM_H4,
+          MOM6X_EUNSUPPORTED, "regrid_interp: INTERPOLATION_SCHEME must be P1M_H2, PLM or PPM_H4 on the device path");
+  REQUIRE(eos->form == MOM6X_EOS_LINEAR || eos->form == MOM6X_EOS_WRIGHT, MOM6X_EUNSUPPORTED, "ALE_regrid: EQN_OF_STATE must be LINEAR or WRIGHT");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  REQUIRE(d.halo >= 1, MOM6X_EINVAL, "ALE_regrid: one halo point needed");
+  REQUIRE(d.nk >= 2, MOM6X_EINVAL, "ALE_regrid: a density coordinate needs at least two layers");
+  // host vectors -> one device buffer: res (nk) | target (nk+1) | max depths (nk+1) | max thickness (nk)
+  const size_t nk = (size_t)d.nk, nv = 4 * nk + 2;
+  if (!c->regrid_vec) HIPCHK(hipMalloc(&c->regrid_vec, nv * sizeof(double)));
+  std::vector<double> hv(nv, 0.0);
+  if (coordinateResolution) for (size_t k = 0; k < nk; k++) hv[k] = coordinateResolution[k];
+  for (size_t k = 0; k <= nk; k++) hv[nk + k] = target_density[k];
+  if (max_interface_depths) for (size_t k = 0; k <= nk; k++) hv[2 * nk + 1 + k] = max_interface_depths[k];
+  if (max_layer_thickness) for (size_t k = 0; k < nk; k++) hv[3 * nk + 2 + k] = max_layer_thickness[k];
+  HIPCHK(hipMemcpyAsync(c->regrid_vec, hv.data(), nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));   // (hv leaves scope)
+  DensArgs A;
+  A.CS = *p;
+  A.form = eos->form; A.Rho_T0_S0 = eos->Rho_T0_S0; A.dRho_dT = eos->dRho_dT; A.dRho_dS = eos->dRho_dS; A.dRho_dp = eos->dRho_dp;
+  A.h_neglect = c->GV.H_subroundoff; A.Z_to_H = c->GV.Z_to_H; A.H_to_RZ_g = c->GV.H_to_RZ * c->GV.g_Earth;
+  A.has_mid = max_interface_depths ? 1 : 0; A.has_mlt = max_layer_thickness ? 1 : 0;
+  DensWork W;
+  int rc;
+  if ((rc = ctx_scratch(c, SCR_e, d.nk + 1, &W.zOld)) || (rc = ctx_scratch(c, SCR_c1, d.nk + 1, &W.xT)) ||
+      (rc = ctx_scratch(c, SCR_q, d.nk, &W.dens)) || (rc = ctx_scratch(c, SCR_t0, d.nk, &W.E1)) || (rc = ctx_scratch(c, SCR_t1, d.nk, &W.E2)) ||
+      (rc = ctx_scratch(c, SCR_t2, d.nk, &W.C2)) || (rc = ctx_scratch(c, SCR_KE, d.nk, &W.MP)) || (rc = ctx_scratch(c, SCR_absv, d.nk, &W.HN)))
+    return rc;
+  HIPCHK(hipMemsetAsync(c->flag, 0, sizeof(int), c->stream));
+  const dim3 b(64, 4, 1);
+  const dim3 g = grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b);
+  const double *res = c->regrid_vec, *tgt = res + nk, *mid = tgt + nk + 1, *mlt = mid + nk + 1;
+  if (hycom) KLAUNCH(c, "k_regrid_density<hycom1>", k_regrid_density<true>, g, b, d, c->G, A, res, tgt, mid, mlt, h, T, S, h_new, dzRegrid, W, c->flag);
+  else KLAUNCH(c, "k_regrid_density<rho>", k_regrid_density<false>, g, b, d, c->G, A, res, tgt, mid, mlt, h, T, S, h_new, dzRegrid, W, c->flag);
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemsetAsync(c->flag, 0, sizeof(int), c->stream));
+  REQUIRE(!(flag & 4), MOM6X_EINVAL, "filtered_grid_motion: z_old and z_new use different sign conventions.");
+  REQUIRE(!(flag & 8), MOM6X_EINVAL, "MOM_regridding: adjust_interface_motion() - implied h<0 is larger than roundoff!");
+  REQUIRE(!(flag & 16), MOM6X_EINVAL, "Could not find target coordinate in get_polynomial_coordinate. This is caused by an inconsistent interpolant (perhaps not monotonically increasing)");
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_ALE_regrid_rho(mom6x_ctx *c, const mom6x_regrid_rho_params *p, const mom6x_eos_params *eos, const double *target_density,
+                                    const double *h, const double *T, const double *S, double *h_new, double *dzRegrid) {
+  return regrid_density(c, false, p, eos, nullptr, target_density, nullptr, nullptr, h, T, S, h_new, dzRegrid);
+}
+
+extern "C" int mom6x_ALE_regrid_hycom1(mom6x_ctx *c, const mom6x_regrid_rho_params *p, const mom6x_eos_params *eos,
+                                       const double *coordinateResolution, const double *target_density, const double *max_interface_depths,
+                                       const double *max_layer_thickness, const double *h, const double *T, const double *S, double *h_new,
+                                       double *dzRegrid) {
+  return regrid_density(c, true, p, eos, coordinateResolution, target_density, max_interface_depths, max_layer_thickness, h, T, S, h_new,
+                        dzRegrid);
+}
+
+extern "C" int mom6x_ALE_convective_adjustment(mom6x_ctx *c, const mom6x_eos_params *eos, double *h, double *T, double *S) {
+  REQUIRE(c && eos && h && T && S, MOM6X_EINVAL, "convective_adjustment: null argument");
+  REQUIRE(eos->form == MOM6X_EOS_LINEAR || eos->form == MOM6X_EOS_WRIGHT, MOM6X_EUNSUPPORTED, "convective_adjustment: EQN_OF_STATE must be LINEAR or WRIGHT");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  REQUIRE(d.halo >= 1, MOM6X_EINVAL, "convective_adjustment: one halo point needed");
+  DensArgs A;
+  memset(&A, 0, sizeof(A));
+  A.form = eos->form; A.Rho_T0_S0 = eos->Rho_T0_S0; A.dRho_dT = eos->dRho_dT; A.dRho_dS = eos->dRho_dS; A.dRho_dp = eos->dRho_dp;
+  double *dens;
+  int rc = ctx_scratch(c, SCR_q, d.nk, &dens);
+  if (rc) return rc;
+  const dim3 b(64, 4, 1);
+  KLAUNCH(c, "k_convective_adjustment", k_convective_adjustment, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, A, h, T, S, dens);
+  HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }
 

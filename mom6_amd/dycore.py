@@ -272,6 +272,36 @@ class Dycore:
         check(self.lib, self.lib.mom6x_ALE_regrid_zstar(self.ctx, C.byref(CS), cr.ctypes.data_as(C.c_void_p), _ptr(h), _ptr(h_new),
                                                         _ptr(dzRegrid)))
 
+    @staticmethod
+    def _hostvec(a, n):
+        if a is None:
+            return None, None
+        v = np.ascontiguousarray(a, dtype=np.float64)
+        assert v.shape == (n,)
+        return v, v.ctypes.data_as(C.c_void_p)
+
+    def ALE_regrid_rho(self, CS, eos, target_density, h, T, S, h_new, dzRegrid):
+        """regridding_main (MOM_regridding.F90:862) for REGRIDDING_RHO; target_density: nk+1 host values (interfaces).
+        REGRIDDING_RHO expects ALE_convective_adjustment first (regridding_preadjust_reqs :966)."""
+        td, ptd = self._hostvec(target_density, self.dims.nk + 1)
+        check(self.lib, self.lib.mom6x_ALE_regrid_rho(self.ctx, C.byref(CS), C.byref(eos), ptd, _ptr(h), _ptr(T), _ptr(S), _ptr(h_new),
+                                                      _ptr(dzRegrid)))
+
+    def ALE_regrid_hycom1(self, CS, eos, coordinateResolution, target_density, max_interface_depths, max_layer_thickness, h, T, S,
+                          h_new, dzRegrid):
+        """regridding_main (MOM_regridding.F90:862) for REGRIDDING_HYCOM1 (build_grid_HyCOM1 :1638)."""
+        nk = self.dims.nk
+        cr, pcr = self._hostvec(coordinateResolution, nk)
+        td, ptd = self._hostvec(target_density, nk + 1)
+        mid, pmid = self._hostvec(max_interface_depths, nk + 1)
+        mlt, pmlt = self._hostvec(max_layer_thickness, nk)
+        check(self.lib, self.lib.mom6x_ALE_regrid_hycom1(self.ctx, C.byref(CS), C.byref(eos), pcr, ptd, pmid, pmlt, _ptr(h), _ptr(T), _ptr(S),
+                                                         _ptr(h_new), _ptr(dzRegrid)))
+
+    def ALE_convective_adjustment(self, eos, h, T, S):
+        """convective_adjustment (MOM_regridding.F90:1905): h, T, S are reordered in place."""
+        check(self.lib, self.lib.mom6x_ALE_convective_adjustment(self.ctx, C.byref(eos), _ptr(h), _ptr(T), _ptr(S)))
+
     def remapping_core_h(self, CS, h0, u0, h1, u1):
         """remapping_core_h (MOM_remapping.F90:234) for [ncol][n0] | [ncol][n1] device arrays."""
         ncol, n0 = h0.shape; n1 = h1.shape[1]

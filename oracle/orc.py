@@ -286,6 +286,37 @@ def ALE_regrid_zstar(d, G, GV, CS, coordinateResolution, h, h_new, dzRegrid):
         raise RuntimeError(f"orc_ALE_regrid_zstar rc={rc}")
 
 
+def _opt(a):
+    return None if a is None else _p(np.ascontiguousarray(a, dtype=np.float64))
+
+
+def ALE_regrid_rho(d, G, GV, CS, eos, target_density, h, T, S, h_new, dzRegrid):
+    td = np.ascontiguousarray(target_density, dtype=np.float64)
+    rc = lib().orc_ALE_regrid_rho(C.byref(d), _p(G), C.byref(GV), C.byref(CS), C.byref(eos), _p(td), _p(h), _p(T), _p(S), _p(h_new),
+                                  _p(dzRegrid))
+    if rc != 0:
+        raise RuntimeError(f"orc_ALE_regrid_rho rc={rc}")
+
+
+def ALE_regrid_hycom1(d, G, GV, CS, eos, coordinateResolution, target_density, max_interface_depths, max_layer_thickness, h, T, S,
+                      h_new, dzRegrid):
+    cr = np.ascontiguousarray(coordinateResolution, dtype=np.float64)
+    td = np.ascontiguousarray(target_density, dtype=np.float64)
+    mid = None if max_interface_depths is None else np.ascontiguousarray(max_interface_depths, dtype=np.float64)
+    mlt = None if max_layer_thickness is None else np.ascontiguousarray(max_layer_thickness, dtype=np.float64)
+    rc = lib().orc_ALE_regrid_hycom1(C.byref(d), _p(G), C.byref(GV), C.byref(CS), C.byref(eos), _p(cr), _p(td),
+                                     None if mid is None else _p(mid), None if mlt is None else _p(mlt), _p(h), _p(T), _p(S), _p(h_new),
+                                     _p(dzRegrid))
+    if rc != 0:
+        raise RuntimeError(f"orc_ALE_regrid_hycom1 rc={rc}")
+
+
+def ALE_convective_adjustment(d, eos, h, T, S):
+    rc = lib().orc_ALE_convective_adjustment(C.byref(d), C.byref(eos), _p(h), _p(T), _p(S))
+    if rc != 0:
+        raise RuntimeError(f"orc_ALE_convective_adjustment rc={rc}")
+
+
 def eos_density(eos, T, S, p):
     L = lib(); L.orc_eos_density.restype = C.c_double
     return L.orc_eos_density(C.byref(eos), C.c_double(T), C.c_double(S), C.c_double(p))

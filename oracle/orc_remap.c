@@ -661,14 +661,15 @@ static int filtered_grid_motion(const mom6x_regrid_zstar_params *CS, int nk, con
   }
   return MOM6X_OK;
 }
-/* regridding_main :862-987 (ZSTAR branch) + calc_h_new_by_dz :1008-1037; dzRegrid has nk+1 levels */
+static int adjust_interface_motion(double cs_min_thickness, int nk, const double *h_old, double *dz_int);
+/* regridding_main :862-987 (ZSTAR branch: build_zstar_grid :1257-1366) + calc_h_new_by_dz :1008-1037; dzRegrid has nk+1 levels */
 int orc_ALE_regrid_zstar(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_regrid_zstar_params *CS,
                          const double *coordinateResolution, const double *h, double *h_new, double *dzRegrid) {
   const int nz = d->nk;
   const size_t slab = (size_t)d->slab;
   const double *mT = GM(G, d, MOM6X_G_mask2dT), *bathyT = GM(G, d, MOM6X_G_bathyT);
   double *zOld = (double *)calloc((size_t)(2 * (nz + 3)), sizeof(double)), *zNew = zOld + nz + 3;
-  double *dz = (double *)calloc((size_t)(nz + 3), sizeof(double));
+  double *dz = (double *)calloc((size_t)(2 * (nz + 3)), sizeof(double)), *hc = dz + nz + 3;
   int rc = MOM6X_OK;
   for (size_t n = 0; n < slab * (size_t)(nz + 1); n++) dzRegrid[n] = 0.0;            /* ALE_regrid :539 */
   for (int j = -1; j <= d->nj; j++) for (int i = -1; i <= d->ni; i++) {
@@ -685,9 +686,320 @@ int orc_ALE_regrid_zstar(const mom6x_dims *d, const double *G, const mom6x_vgrid
     build_zstar_column(nz, coordinateResolution, CS->min_thickness, nominalDepth, totalThickness, zNew, GV->Z_to_H);
     rc = filtered_grid_motion(CS, nz, zOld, zNew, dz);
     if (rc) break;
+    for (int k = 1; k <= nz; k++) hc[k] = h[x + (k - 1) * slab];
+    rc = adjust_interface_motion(CS->min_thickness, nz, hc, dz);                       /* :1362 */
+    if (rc) break;
     for (int k = 1; k <= nz + 1; k++) dzRegrid[x + (k - 1) * slab] = dz[k];
     for (int k = 1; k <= nz; k++) h_new[x + (k - 1) * slab] = orc_max(0., h[x + (k - 1) * slab] + (dz[k] - dz[k + 1]));
   }
   free(zOld); free(dz);
+  return rc;
+}
+
+/* ==== the density-following coordinates: REGRIDDING_RHO and REGRIDDING_HYCOM1 ========================================== */
+double orc_eos_density(const mom6x_eos_params *E, double T, double S, double p);   /* orc_dyn.c: calculate_density */
+
+/* adjust_interface_motion MOM_regridding.F90:1796-1857 (CS%nk == nk); h_old is 1-based */
+static int adjust_interface_motion(double cs_min_thickness, int nk, const double *h_old, double *dz_int) {
+  const double eps = 2.220446049250313e-16;   /* epsilon(1.) */
+  double h_total = 0., h_err = 0.;
+  for (int k = 1; k <= nk; k++) {
+    h_total = h_total + h_old[k];
+    h_err = h_err + max3(h_old[k], fabs(dz_int[k]), fabs(dz_int[k + 1])) * eps;
+    const double h_new = h_old[k] + (dz_int[k] - dz_int[k + 1]);
+    if (h_new < -3.0 * h_err) return MOM6X_EINVAL;   /* "implied h<0 is larger than roundoff!" */
+  }
+  for (int k = nk; k >= 2; k--) {
+    double h_new = h_old[k] + (dz_int[k] - dz_int[k + 1]);
+    if (h_new < cs_min_thickness) dz_int[k] = (dz_int[k + 1] - h_old[k]) + cs_min_thickness;
+    h_new = h_old[k] + (dz_int[k] - dz_int[k + 1]);
+    if (h_new < 0.) dz_int[k] = (1. - eps) * (dz_int[k + 1] - h_old[k]);
+    h_new = h_old[k] + (dz_int[k] - dz_int[k + 1]);
+    if (h_new < 0.) return MOM6X_EINVAL;
+  }
+  return MOM6X_OK;
+}
+
+/* edge_values_explicit_h2 regrid_edge_values.F90:166-192 */
+static void edge_values_explicit_h2(int N, const double *h, const double *u, double *E1, double *E2) {
+  E1[1] = u[1]; E2[N] = u[N];
+  for (int k = 2; k <= N; k++) {
+    if (h[k - 1] + h[k] == 0.0) E1[k] = 0.5 * (u[k - 1] + u[k]);
+    else E1[k] = (u[k - 1] * h[k] + u[k] * h[k - 1]) / (h[k - 1] + h[k]);
+    E2[k - 1] = E1[k];
+  }
+}
+/* average_discontinuous_edge_values :107-126 */
+static void average_discontinuous_edge_values(int N, double *E1, double *E2) {
+  for (int k = 1; k <= N - 1; k++) {
+    if (E2[k] != E1[k + 1]) { const double a = 0.5 * (E2[k] + E1[k + 1]); E2[k] = a; E1[k + 1] = a; }
+  }
+}
+/* P1M_interpolation P1M_functions.F90:25-56 and P1M_boundary_extrapolation :72-160 */
+static void P1M_interpolation(int N, const double *h, const double *u, double *E1, double *E2, double *C1, double *C2, double h_neglect) {
+  bound_edge_values(N, h, u, E1, E2, h_neglect);
+  average_discontinuous_edge_values(N, E1, E2);
+  for (int k = 1; k <= N; k++) { C1[k] = E1[k]; C2[k] = E2[k] - E1[k]; }
+}
+static void P1M_boundary_extrapolation(int N, const double *h, const double *u, double *E1, double *E2, double *C1, double *C2) {
+  double u0 = u[1], u1 = u[2];
+  double slope = 2.0 * (u1 - u0);
+  const double u0_r = u0 + 0.5 * slope;
+  if ((u1 - u0) * (E1[2] - u0_r) < 0.0) slope = 2.0 * (E1[2] - u0);
+  if (h[1] != 0.0) E1[1] = u0 - 0.5 * slope; else E1[1] = u0;
+  C1[1] = E1[1]; C2[1] = E2[1] - E1[1];
+  u0 = u[N - 1]; u1 = u[N];
+  slope = 2.0 * (u1 - u0);
+  const double u0_l = u1 - 0.5 * slope;
+  if ((u1 - u0) * (u0_l - E2[N - 1]) < 0.0) slope = 2.0 * (u1 - E2[N - 1]);
+  if (h[N] != 0.0) E2[N] = u1 + 0.5 * slope; else E2[N] = u1;
+  C1[N] = E1[N]; C2[N] = E2[N] - E1[N];
+}
+/* regridding_set_ppolys regrid_interp.F90:80-288 for P1M_H2, P1M_H4, PLM, PPM_H4; returns the degree (or < 0) */
+static int regridding_set_ppolys(int scheme, int extrapolate, const double *dens, int n0, const double *h0, double *E1, double *E2,
+                                 double *C1, double *C2, double *C3, double h_neglect, double h_neg_edge) {
+  for (int k = 0; k <= n0 + 1; k++) { E1[k] = 0.; E2[k] = 0.; C1[k] = 0.; C2[k] = 0.; C3[k] = 0.; }
+  switch (scheme) {
+    case MOM6X_INTERP_PLM:
+      orc_PLM_reconstruction(n0, h0, dens, E1, E2, C1, C2, h_neglect);
+      if (extrapolate) orc_PLM_boundary_extrapolation(n0, h0, dens, E1, E2, C1, C2, h_neglect);
+      return 1;
+    case MOM6X_INTERP_PPM_H4:
+      if (n0 >= 4) {
+        orc_edge_values_explicit_h4(n0, h0, dens, E1, E2, h_neg_edge);
+        orc_PPM_reconstruction(n0, h0, dens, E1, E2, C1, C2, C3, h_neglect);
+        if (extrapolate) orc_PPM_boundary_extrapolation(n0, h0, dens, E1, E2, C1, C2, C3, h_neglect);
+        return 2;
+      }
+      /* fall through: too few layers, the simplest continuous linear scheme */
+    case MOM6X_INTERP_P1M_H2:
+    case MOM6X_INTERP_P1M_H4:
+      if (scheme == MOM6X_INTERP_P1M_H4 && n0 >= 4) orc_edge_values_explicit_h4(n0, h0, dens, E1, E2, h_neg_edge);
+      else edge_values_explicit_h2(n0, h0, dens, E1, E2);
+      P1M_interpolation(n0, h0, dens, E1, E2, C1, C2, h_neglect);
+      if (extrapolate) P1M_boundary_extrapolation(n0, h0, dens, E1, E2, C1, C2);
+      return 1;
+    default:
+      return -1;
+  }
+}
+/* get_polynomial_coordinate :376-509 (answer dates >= 20190101); *err is set when no cell holds the target */
+static double get_polynomial_coordinate(int N, const double *h, const double *x_g, const double *E1, const double *E2, const double *C1,
+                                        const double *C2, const double *C3, double target_value, int degree, int *err) {
+  const double eps = 1e-6;   /* NR_OFFSET */
+  if (target_value <= E1[1]) return x_g[1];
+  for (int k = 2; k <= N; k++)
+    if ((target_value >= E2[k - 1]) && (target_value <= E1[k])) return x_g[k];
+  if (target_value >= E2[N]) return x_g[N + 1];
+  int k_found = -1;
+  for (int k = 1; k <= N; k++)
+    if ((target_value > E1[k]) && (target_value < E2[k])) { k_found = k; break; }
+  if (k_found == -1) { *err = 1; return x_g[1]; }
+  double a[6] = { 0., 0., 0., 0., 0., 0. };
+  a[1] = C1[k_found]; a[2] = C2[k_found];
+  if (degree >= 2) a[3] = C3[k_found];
+  double xi0 = 0.5;
+  for (int iter = 1; iter <= 8; iter++) {   /* NR_ITERATIONS */
+    const double numerator = (a[1] - target_value) + xi0 * (a[2] + xi0 * (a[3] + xi0 * (a[4] + a[5] * xi0)));
+    const double denominator = a[2] + xi0 * (2. * a[3] + xi0 * (3. * a[4] + 4. * a[5] * xi0));
+    const double delta = -numerator / denominator;
+    xi0 = xi0 + delta;
+    if (xi0 < 0.0) { xi0 = 0.0; const double grad = a[2]; if (grad == 0.0) xi0 = xi0 + eps; }
+    if (xi0 > 1.0) { xi0 = 1.0; const double grad = a[2] + (2. * a[3] + (3. * a[4] + 4. * a[5])); if (grad == 0.0) xi0 = xi0 - eps; }
+    if (fabs(delta) < 1e-12) break;         /* NR_TOLERANCE */
+  }
+  return x_g[k_found] + xi0 * h[k_found];
+}
+/* build_and_interpolate_grid :331-358 = regridding_set_ppolys + interpolate_grid :295-328.  All arrays 1-based;
+ * w: 5 * (n0 + 2) doubles of work space */
+static int build_and_interpolate_grid(int scheme, int extrapolate, const double *dens, int n0, const double *h0, const double *x0,
+                                      const double *target, int n1, double *h1, double *x1, double h_neglect, double h_neg_edge, double *w) {
+  double *E1 = w, *E2 = w + (n0 + 2), *C1 = w + 2 * (n0 + 2), *C2 = w + 3 * (n0 + 2), *C3 = w + 4 * (n0 + 2);
+  const int degree = regridding_set_ppolys(scheme, extrapolate, dens, n0, h0, E1, E2, C1, C2, C3, h_neglect, h_neg_edge);
+  if (degree < 0) return MOM6X_EUNSUPPORTED;
+  int err = 0;
+  x1[1] = x0[1]; x1[n1 + 1] = x0[n0 + 1];
+  for (int k = 2; k <= n1; k++) {
+    x1[k] = get_polynomial_coordinate(n0, h0, x0, E1, E2, C1, C2, C3, target[k], degree, &err);
+    h1[k - 1] = x1[k] - x1[k - 1];
+  }
+  h1[n1] = x1[n1 + 1] - x1[n1];
+  return err ? MOM6X_EINVAL : MOM6X_OK;
+}
+/* copy_finite_thicknesses coord_rho.F90:316-358 and old_inflate_layers_1d :362-420 */
+static void copy_finite_thicknesses(int nk, const double *h_in, double thresh, int *nout_, double *h_out, int *mapping) {
+  int nout = 0, k_thickest = 1;
+  double thickness_in_vanished = 0.0, thickest_h_out = h_in[1];
+  for (int k = 1; k <= nk; k++) {
+    mapping[k] = nout;
+    h_out[k] = 0.;
+    if (h_in[k] > thresh) {
+      nout = nout + 1;
+      mapping[nout] = k;
+      h_out[nout] = h_in[k];
+      if (h_out[nout] > thickest_h_out) { thickest_h_out = h_out[nout]; k_thickest = nout; }
+    } else thickness_in_vanished = thickness_in_vanished + h_in[k];
+  }
+  *nout_ = nout;
+  if (nout <= 1) return;
+  h_out[k_thickest] = h_out[k_thickest] + thickness_in_vanished;
+}
+static void old_inflate_layers_1d(double min_thickness, int nk, double *h) {
+  int count_nonzero_layers = 0;
+  for (int k = 1; k <= nk; k++) if (h[k] > min_thickness) count_nonzero_layers = count_nonzero_layers + 1;
+  if (count_nonzero_layers == nk) return;
+  if (count_nonzero_layers == 0) { for (int k = 1; k <= nk; k++) h[k] = min_thickness; return; }
+  double correction = 0.0;
+  for (int k = 1; k <= nk; k++) {
+    if (h[k] <= min_thickness) { const double delta = min_thickness - h[k]; correction = correction + delta; h[k] = h[k] + delta; }
+  }
+  double maxThickness = h[1];
+  int k_found = 1;
+  for (int k = 1; k <= nk; k++) if (h[k] > maxThickness) { maxThickness = h[k]; k_found = k; }
+  h[k_found] = h[k_found] - correction;
+}
+
+/* convective_adjustment MOM_regridding.F90:1905-1967 over (isc-1..iec+1, jsc-1..jec+1) */
+int orc_ALE_convective_adjustment(const mom6x_dims *d, const mom6x_eos_params *eos, double *h, double *T, double *S) {
+  const int nz = d->nk;
+  const size_t slab = (size_t)d->slab;
+  double *dens = (double *)calloc((size_t)nz + 2, sizeof(double));
+  for (int j = -1; j <= d->nj; j++) for (int i = -1; i <= d->ni; i++) {
+    const size_t x = IX2(d, i, j);
+    for (int k = 1; k <= nz; k++) dens[k] = orc_eos_density(eos, T[x + (k - 1) * slab], S[x + (k - 1) * slab], 0.);
+    for (;;) {
+      int stratified = 1;
+      for (int k = 1; k <= nz - 1; k++) {
+        const size_t c0 = x + (k - 1) * slab, c1 = x + k * slab;
+        const double T0 = T[c0], T1 = T[c1], S0 = S[c0], S1 = S[c1], r0 = dens[k], r1 = dens[k + 1], h0 = h[c0], h1 = h[c1];
+        if (r0 > r1) {
+          T[c0] = T1; T[c1] = T0; S[c0] = S1; S[c1] = S0; h[c0] = h1; h[c1] = h0;
+          dens[k] = orc_eos_density(eos, T[c0], S[c0], 0.);
+          dens[k + 1] = orc_eos_density(eos, T[c1], S[c1], 0.);
+          stratified = 0;
+        }
+      }
+      if (stratified) break;
+    }
+  }
+  free(dens);
+  return MOM6X_OK;
+}
+
+static double set_h_neglect_2019(const mom6x_vgrid *GV) { return GV->H_subroundoff; }   /* set_h_neglect :2602, answer dates >= 20190101 */
+
+/* regridding_main :862 for REGRIDDING_RHO: build_rho_grid :1472-1626 + build_rho_column coord_rho.F90:92-175 + calc_h_new_by_dz */
+int orc_ALE_regrid_rho(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_regrid_rho_params *CS,
+                       const mom6x_eos_params *eos, const double *target_density, const double *h, const double *T, const double *S,
+                       double *h_new, double *dzRegrid) {
+  const int nz = d->nk, nk = d->nk;
+  const size_t slab = (size_t)d->slab;
+  const double *mT = GM(G, d, MOM6X_G_mask2dT), *bathyT = GM(G, d, MOM6X_G_bathyT);
+  const double h_neglect = set_h_neglect_2019(GV), h_neglect_edge = h_neglect;
+  const size_t n = (size_t)nz + 3;
+  double *buf = (double *)calloc(n * 16, sizeof(double));
+  double *zOld = buf, *zNew = buf + n, *dz = buf + 2 * n, *hc = buf + 3 * n, *h_nv = buf + 4 * n, *dens = buf + 5 * n, *xTmp = buf + 6 * n;
+  double *hn = buf + 7 * n, *x1 = buf + 8 * n, *w = buf + 9 * n, *tgt = buf + 14 * n, *dnv = buf + 15 * n;
+  int *mapping = (int *)calloc(n, sizeof(int));
+  for (int k = 1; k <= nk + 1; k++) tgt[k] = target_density[k - 1];
+  int rc = MOM6X_OK;
+  for (size_t q = 0; q < slab * (size_t)(nz + 1); q++) dzRegrid[q] = 0.0;
+  for (int j = -1; j <= d->nj && !rc; j++) for (int i = -1; i <= d->ni; i++) {
+    const size_t x = IX2(d, i, j);
+    if (mT[x] == 0.) { for (int k = 0; k < nz; k++) h_new[x + k * slab] = h[x + k * slab]; continue; }   /* :1527-1530, :1030 */
+    const double nominalDepth = orc_max((bathyT[x] + CS->f.Z_ref) * GV->Z_to_H, 0.0);
+    for (int k = 1; k <= nz; k++) hc[k] = h[x + (k - 1) * slab];
+    /* ---- build_rho_column */
+    int count_nonzero_layers;
+    copy_finite_thicknesses(nz, hc, CS->f.min_thickness, &count_nonzero_layers, h_nv, mapping);
+    if (count_nonzero_layers > 1) {
+      xTmp[1] = 0.0;
+      for (int k = 1; k <= count_nonzero_layers; k++) xTmp[k + 1] = xTmp[k] + h_nv[k];
+      for (int k = 1; k <= nz; k++) dens[k] = orc_eos_density(eos, T[x + (k - 1) * slab], S[x + (k - 1) * slab], CS->ref_pressure);
+      for (int k = 1; k <= count_nonzero_layers; k++) dnv[k] = dens[mapping[k]];
+      rc = build_and_interpolate_grid(CS->interp_scheme, CS->boundary_extrapolation, dnv, count_nonzero_layers, h_nv, xTmp, tgt, nk, hn, x1,
+                                      h_neglect, h_neglect_edge, w);
+      if (rc) break;
+      old_inflate_layers_1d(CS->f.min_thickness, nk, hn);
+      x1[1] = 0.0; for (int k = 1; k <= nk; k++) x1[k + 1] = x1[k] + hn[k];
+      for (int k = 1; k <= nk; k++) hn[k] = x1[k + 1] - x1[k];
+    } else {
+      for (int k = 1; k <= nk; k++) hn[k] = hc[k];   /* nz == CS%nk: "This keeps old behavior" */
+    }
+    if (CS->integrate_downward_for_e) {
+      zNew[1] = 0.; for (int k = 1; k <= nk; k++) zNew[k + 1] = zNew[k] - hn[k];
+      zOld[1] = 0.; for (int k = 1; k <= nz; k++) zOld[k + 1] = zOld[k] - hc[k];
+    } else {
+      zNew[nk + 1] = -nominalDepth; for (int k = nk; k >= 1; k--) zNew[k] = zNew[k + 1] + hn[k];
+      zOld[nz + 1] = -nominalDepth; for (int k = nz; k >= 1; k--) zOld[k] = zOld[k + 1] + hc[k];
+    }
+    rc = filtered_grid_motion(&CS->f, nz, zOld, zNew, dz);
+    if (rc) break;
+    for (int k = 1; k <= nz + 1; k++) dzRegrid[x + (k - 1) * slab] = dz[k];
+    for (int k = 1; k <= nz; k++) h_new[x + (k - 1) * slab] = orc_max(0., hc[k] + (dz[k] - dz[k + 1]));
+  }
+  free(buf); free(mapping);
+  return rc;
+}
+
+/* regridding_main :862 for REGRIDDING_HYCOM1: build_grid_HyCOM1 :1638-1726 + build_hycom1_column coord_hycom.F90:106-213 (no
+ * "only improves") + calc_h_new_by_dz.  z is positive DOWNWARD here, as in the reference. */
+int orc_ALE_regrid_hycom1(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_regrid_rho_params *CS,
+                          const mom6x_eos_params *eos, const double *coordinateResolution, const double *target_density,
+                          const double *max_interface_depths, const double *max_layer_thickness, const double *h, const double *T,
+                          const double *S, double *h_new, double *dzRegrid) {
+  const int nz = d->nk, nk = d->nk;
+  const size_t slab = (size_t)d->slab;
+  const double *mT = GM(G, d, MOM6X_G_mask2dT), *bathyT = GM(G, d, MOM6X_G_bathyT);
+  const double h_neglect = set_h_neglect_2019(GV), h_neglect_edge = h_neglect;
+  const double z_scale = GV->Z_to_H;
+  const size_t n = (size_t)nz + 3;
+  double *buf = (double *)calloc(n * 13, sizeof(double));
+  double *z_col = buf, *z_new = buf + n, *dz = buf + 2 * n, *hc = buf + 3 * n, *rho = buf + 4 * n, *hn = buf + 5 * n, *w = buf + 6 * n;
+  double *tgt = buf + 11 * n, *p_col = buf + 12 * n;
+  for (int k = 1; k <= nk + 1; k++) tgt[k] = target_density[k - 1];
+  int rc = MOM6X_OK;
+  for (size_t q = 0; q < slab * (size_t)(nz + 1); q++) dzRegrid[q] = 0.0;
+  for (int j = -1; j <= d->nj && !rc; j++) for (int i = -1; i <= d->ni; i++) {
+    const size_t x = IX2(d, i, j);
+    if (!(mT[x] > 0.)) { for (int k = 0; k < nz; k++) h_new[x + k * slab] = h[x + k * slab]; continue; }
+    const double nominalDepth = orc_max((bathyT[x] + CS->f.Z_ref) * GV->Z_to_H, 0.0);
+    for (int k = 1; k <= nz; k++) hc[k] = h[x + (k - 1) * slab];
+    z_col[1] = 0.0;
+    for (int k = 1; k <= nz; k++) {
+      z_col[k + 1] = z_col[k] + hc[k];
+      p_col[k] = CS->ref_pressure + CS->compressibility_fraction *
+                 (0.5 * (z_col[k] + z_col[k + 1]) * (GV->H_to_RZ * GV->g_Earth) - CS->ref_pressure);
+    }
+    /* ---- build_hycom1_column */
+    for (int k = 1; k <= nz; k++) rho[k] = orc_eos_density(eos, T[x + (k - 1) * slab], S[x + (k - 1) * slab], p_col[k]);
+    for (int k = nz - 1; k >= 1; k--) rho[k] = orc_min(rho[k], rho[k + 1]);
+    rc = build_and_interpolate_grid(CS->interp_scheme, CS->boundary_extrapolation, rho, nz, hc, z_col, tgt, nk, hn, z_new, h_neglect,
+                                    h_neglect_edge, w);
+    if (rc) break;
+    double nominal_z = 0.;
+    const double stretching = z_col[nz + 1] / nominalDepth;
+    for (int k = 2; k <= nk + 1; k++) {
+      nominal_z = nominal_z + (z_scale * coordinateResolution[k - 2]) * stretching;
+      z_new[k] = orc_max(z_new[k], nominal_z);
+      z_new[k] = orc_min(z_new[k], z_col[nz + 1]);
+    }
+    if (max_interface_depths && max_layer_thickness) {
+      for (int k = 2; k <= nk; k++) z_new[k] = min3(z_new[k], max_interface_depths[k - 1], z_new[k - 1] + max_layer_thickness[k - 2]);
+    } else if (max_interface_depths) {
+      for (int k = 2; k <= nk; k++) z_new[k] = orc_min(z_new[k], max_interface_depths[k - 1]);
+    } else if (max_layer_thickness) {
+      for (int k = 2; k <= nk; k++) z_new[k] = orc_min(z_new[k], z_new[k - 1] + max_layer_thickness[k - 2]);
+    }
+    /* ---- back in build_grid_HyCOM1 */
+    rc = filtered_grid_motion(&CS->f, nz, z_col, z_new, dz);
+    if (rc) break;
+    for (int k = 1; k <= nz + 1; k++) dz[k] = -dz[k];
+    rc = adjust_interface_motion(CS->f.min_thickness, nz, hc, dz);
+    if (rc) break;
+    for (int k = 1; k <= nz + 1; k++) dzRegrid[x + (k - 1) * slab] = dz[k];
+    for (int k = 1; k <= nz; k++) h_new[x + (k - 1) * slab] = orc_max(0., hc[k] + (dz[k] - dz[k + 1]));
+  }
+  free(buf);
   return rc;
 }

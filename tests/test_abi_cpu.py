@@ -38,7 +38,7 @@ def test_struct_sizes_match_ctypes_mirrors(lib):
     mirrors = [abi.Dims, abi.VGrid, abi.ContinuityParams, abi.BTCont, abi.BarotropicParams, abi.CoriolisParams,
                abi.PGFParams, abi.RK2Params, abi.RK2Hooks, abi.EOSParams, abi.VertviscParams, abi.HorViscParams,
                abi.RemappingParams, abi.RegridZstarParams, abi.ChksumResult,
-               abi.SumOutputParams, abi.EnergySums]
+               abi.SumOutputParams, abi.EnergySums, abi.RegridRhoParams]
     for which, cls in enumerate(mirrors):
         assert lib.mom6x_struct_size(which) == C.sizeof(cls), cls.__name__
     assert lib.mom6x_abi_version() == 1

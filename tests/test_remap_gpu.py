@@ -167,3 +167,73 @@ def test_ALE_regrid_zstar_then_remap(orc, cfg, mods):
     H.assert_bitwise(Tg.cpu().numpy(), To, "T", H.interior(d, "h"))
     assert np.abs(dz_o).max() > 1.0 and np.abs(To - T).max() > 1e-3
     dyc.close()
+
+
+@pytest.mark.parametrize("cfg", ["island_basin", "benchmark_small"])
+@pytest.mark.parametrize("which", ["rho", "hycom1"])
+@pytest.mark.parametrize("mods", [dict(), dict(interp_scheme=abi.INTERP_PLM, boundary_extrapolation=1),
+                                  dict(interp_scheme=abi.INTERP_PPM_H4), dict(interp_scheme=abi.INTERP_PPM_H4, boundary_extrapolation=1),
+                                  dict(boundary_extrapolation=1, min_thickness=2.0, old_grid_weight=0.5, depth_of_time_filter_shallow=100.,
+                                       depth_of_time_filter_deep=700.),
+                                  dict(integrate_downward_for_e=0, compressibility_fraction=0.3, ref_pressure=1.0e7)])
+@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
+def test_ALE_regrid_density_coordinates(orc, cfg, which, mods, form):
+    """REGRIDDING_RHO (after convective_adjustment) and REGRIDDING_HYCOM1 on the device: the reordered column, the new
+    thicknesses and the interface displacements bit for bit against the oracle -- every interpolation scheme on the path,
+    with and without BOUNDARY_EXTRAPOLATION, the time filter, both EOS forms, HYCOM1's compressibility and caps."""
+    import torch
+    from mom6_amd.dycore import Dycore
+    from tests import cases
+    gg, d, M = getattr(H, cfg)(nk=10)
+    GV = abi.vgrid_default()
+    h, _, _ = synth.make_state(d, M, thin_frac=0.2)
+    T, S = cases.thermo_state(d, M)
+    rng = np.random.default_rng(3)
+    T = np.ascontiguousarray(T + rng.normal(0.0, 2.0, T.shape))     # some static instability for convective_adjustment
+    eos = abi.eos_params_default(form)
+    CS = abi.regrid_rho_params_default(**mods)
+    jj, ii = d.joff + d.nj // 2, d.ioff + d.ni // 2
+    rr = np.sort(np.array([orc.eos_density(eos, float(t), float(s), CS.ref_pressure) for t, s in zip(T[:, jj, ii], S[:, jj, ii])]))
+    tgt = np.concatenate(([rr[0] - 0.5], 0.5 * (rr[:-1] + rr[1:]), [rr[-1] + 0.5]))
+    depth = float(M[G["bathyT"]].max())
+    cr = np.linspace(1.0, 6.0, d.nk); cr *= depth / cr.sum()
+    mid = np.concatenate(([0.0], np.cumsum(cr) * 1.5)) if "compressibility_fraction" in mods else None
+    mlt = np.full(d.nk, 0.4 * depth) if "compressibility_fraction" in mods else None
+    ho, To, So = h.copy(), T.copy(), S.copy()
+    hn_o = np.zeros_like(h); dz_o = np.zeros((d.nk + 1,) + d.shape2())
+    if which == "rho":
+        orc.ALE_convective_adjustment(d, eos, ho, To, So)
+        orc.ALE_regrid_rho(d, M, GV, CS, eos, tgt, ho, To, So, hn_o, dz_o)
+    else:
+        orc.ALE_regrid_hycom1(d, M, GV, CS, eos, cr, tgt, mid, mlt, ho, To, So, hn_o, dz_o)
+    dyc = Dycore(d, M, GV)
+    hd, Td, Sd = dyc.to_dev(h), dyc.to_dev(T), dyc.to_dev(S)
+    hn_g = torch.zeros_like(hd); dz_g = torch.zeros((d.nk + 1,) + d.shape2(), dtype=torch.float64, device=dyc.device)
+    torch.cuda.synchronize()
+    if which == "rho":
+        dyc.ALE_convective_adjustment(eos, hd, Td, Sd)
+        dyc.ALE_regrid_rho(CS, eos, tgt, hd, Td, Sd, hn_g, dz_g)
+    else:
+        dyc.ALE_regrid_hycom1(CS, eos, cr, tgt, mid, mlt, hd, Td, Sd, hn_g, dz_g)
+    dyc.sync()
+    sl1 = H.interior(d, "h", 1)
+    if which == "rho":
+        for name, a, b in (("h", hd, ho), ("T", Td, To), ("S", Sd, So)):
+            H.assert_bitwise(a.cpu().numpy(), b, name + " after convective_adjustment", sl1)
+        assert not np.array_equal(To, T)
+    H.assert_bitwise(hn_g.cpu().numpy(), hn_o, "h_new", sl1)
+    H.assert_bitwise(dz_g.cpu().numpy(), dz_o, "dzRegrid", sl1)
+    assert np.abs(dz_o).max() > 1.0
+    dyc.close()
+
+
+def test_ALE_regrid_density_rejects_what_is_not_carried():
+    from mom6_amd.dycore import Dycore
+    import torch
+    gg, d, M = H.double_gyre(nk=4)
+    dyc = Dycore(d, M, abi.vgrid_default())
+    z = dyc.zeros3(); dz = torch.zeros((d.nk + 1,) + d.shape2(), dtype=torch.float64, device=dyc.device)
+    with pytest.raises(RuntimeError, match="INTERPOLATION_SCHEME"):
+        dyc.ALE_regrid_rho(abi.regrid_rho_params_default(interp_scheme=9), abi.eos_params_default(), np.linspace(1020., 1030., 5), z, z, z,
+                           dyc.zeros3(), dz)
+    dyc.close()
