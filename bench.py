@@ -440,17 +440,7 @@ def cpu_baseline(args):
     import ctypes
     # the host cores this process may use: the cgroup CPU quota where there is one (a box that shows 256 hardware threads
     # but grants 16 CPUs runs the loops slower with 128 threads than with one), else what the scheduler allows
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            cores = max(1, min(cores, int(float(q) / float(per))))
-    except (OSError, ValueError):
-        pass
-    try:
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
-    except OSError:
-        cores = 1
+    cores = orc.set_threads(orc.usable_cores())
     ni, nj, nk = 360, 180, args.nk
     gg = grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-65.0, dlon=360.0 / args.ni, dlat=130.0 / args.nj,
                          depth_fn=grid.bowl_depth(ni, nj, 4000.0, rim=2))

@@ -498,7 +498,7 @@ int mom6x_ALE_regrid_zstar(mom6x_ctx *ctx, const mom6x_regrid_zstar_params *p, c
  * (regridding_preadjust_reqs :966): mom6x_ALE_convective_adjustment = convective_adjustment :1905.            */
 enum mom6x_interp_scheme {            /* INTERPOLATION_SCHEME (regrid_interp.F90:38-49); others are not carried */
   MOM6X_INTERP_P1M_H2 = 0,            /* the default */
-  MOM6X_INTERP_P1M_H4 = 1, MOM6X_INTERP_PLM = 3, MOM6X_INTERP_PPM_H4 = 5
+  MOM6X_INTERP_PLM = 3, MOM6X_INTERP_PPM_H4 = 5
 };
 typedef struct mom6x_regrid_rho_params {
   mom6x_regrid_zstar_params f;       /* MIN_THICKNESS, the time filter of filtered_grid_motion, G%Z_ref           */

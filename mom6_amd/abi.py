@@ -281,7 +281,8 @@ def regrid_zstar_params_default(**kw):
     return p
 
 
-INTERP_P1M_H2, INTERP_P1M_H4, INTERP_PLM, INTERP_PPM_H4 = 0, 1, 3, 5   # enum mom6x_interp_scheme
+INTERP_P1M_H2, INTERP_PLM, INTERP_PPM_H4 = 0, 3, 5   # enum mom6x_interp_scheme
+INTERP_P1M_H4 = 1                                      # (restated in the oracle only)
 
 
 class RegridRhoParams(C.Structure):

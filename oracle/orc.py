@@ -19,6 +19,30 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def usable_cores():
+    """The cores this process may really use: the affinity mask capped by the cgroup CPU quota (a box can show 256 hardware
+    threads behind a quota of 16: an OpenMP team of 256 on such a box is slower than one thread)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def set_threads(n=None):
+    """Size of the oracle's OpenMP teams (default: usable_cores(), or OMP_NUM_THREADS when that is set)."""
+    if n is None:
+        n = int(os.environ["OMP_NUM_THREADS"]) if os.environ.get("OMP_NUM_THREADS", "").isdigit() else usable_cores()
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        return 1
+    return int(n)
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -26,6 +50,7 @@ def lib():
         if not os.path.exists(p):
             build()
         _LIB = C.CDLL(p)
+        set_threads()
     return _LIB
 
 

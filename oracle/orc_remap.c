@@ -755,6 +755,7 @@ static void P1M_boundary_extrapolation(int N, const double *h, const double *u, 
   if (h[N] != 0.0) E2[N] = u1 + 0.5 * slope; else E2[N] = u1;
   C1[N] = E1[N]; C2[N] = E2[N] - E1[N];
 }
+#define MOM6X_INTERP_P1M_H4 1   /* INTERPOLATION_P1M_H4: restated here only (the device path does not carry it) */
 /* regridding_set_ppolys regrid_interp.F90:80-288 for P1M_H2, P1M_H4, PLM, PPM_H4; returns the degree (or < 0) */
 static int regridding_set_ppolys(int scheme, int extrapolate, const double *dens, int n0, const double *h0, double *E1, double *E2,
                                  double *C1, double *C2, double *C3, double h_neglect, double h_neg_edge) {
