@@ -346,6 +346,7 @@ def ale_cycle(args, device=0, steps=4, warm=1, check=None):
                      "tridiagonal solves, z* regridding and PPM_H4 remapping of T, S, the tracers, u, v; not part of `value`")
     if check is not None:
         check(dict(dyc=dyc, d=d, st=st, T=T, S=S, tr=tr, Md=keep[-1], pre=pre, info=info))
+    torch.cuda.set_stream(torch.cuda.default_stream())   # (torch must not keep a stream the context is about to destroy)
     dyc.close()
     del st, T, S, tr, ea, eb, h_new, dzI, hu_o, hv_o, hu_n, hv_n, keep
     torch.cuda.empty_cache()
@@ -387,6 +388,7 @@ def comm_model_leg(args, device):
         rep = prof_report(dyc); prof_enable(dyc, False)
         out[mode] = {"ms_per_step": round(ms, 3), "kernel_sum_ms": round(sum(v[1] for v in rep.values()), 3),
                      "launches_per_step": int(sum(v[0] for v in rep.values()))}
+        torch.cuda.set_stream(torch.cuda.default_stream())
         dyc.close()
         del st, keep
         torch.cuda.empty_cache()
@@ -633,11 +635,11 @@ def main():
         out["ale_remap_leg"] = ale_remap_leg(args, dyc, d, st, barrier, dist)
         out["diag_leg"] = diag_leg(args, dyc, d, st, barrier, dist)
         if not args.no_comm_model and (args.ni, args.nj) == (1440, 1080):
-            dyc.close(); st.clear()
+            torch.cuda.set_stream(torch.cuda.default_stream()); dyc.close(); st.clear()
             torch.cuda.empty_cache()
             out["comm_model"] = comm_model_leg(args, local_rank)
         if not args.no_config4 and (args.ni, args.nj) == (1440, 1080):
-            dyc.close(); st.clear()                  # the headline model makes room for the larger tile
+            torch.cuda.set_stream(torch.cuda.default_stream()); dyc.close(); st.clear()                  # the headline model makes room for the larger tile
             torch.cuda.empty_cache()
             out["config4_tile_leg"] = ale_cycle(args, local_rank)[1]
     if rank == 0:

@@ -65,6 +65,12 @@ class Dycore:
 
     def close(self):
         if self.ctx:
+            try:   # torch must not keep the context's stream as its current one (see torch_stream) once it is destroyed
+                if torch.cuda.current_stream(self.device).cuda_stream == self.stream_ptr:
+                    torch.cuda.synchronize(self.device)
+                    torch.cuda.set_stream(torch.cuda.default_stream(self.device))
+            except Exception:
+                pass
             self.lib.mom6x_ctx_destroy(self.ctx)
             self.ctx = C.c_void_p()
 
