@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """Condense the rocprofv3 outputs of scripts/profile_bench.sh into the small CSVs kept under profiles/.
 
-  python scripts/rocprof_summary.py gpurun_out profiles/r01_v2
+  python scripts/rocprof_summary.py gpurun_out profiles/r02_v1
 
 writes <prefix>_kernel_stats.csv  (rocprofv3 --kernel-trace --stats: calls, total, average per kernel) and
        <prefix>_hbm_pmc.csv       (FETCH_SIZE / WRITE_SIZE per dispatch, separate --pmc passes, in bytes after the
                                    unit (KB) and gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md,
-                                   calibrated on k_h_av whose traffic is known exactly).
+                                   calibrated on k_uhtr whose traffic is known exactly).
 """
 import collections
 import csv
@@ -42,15 +42,19 @@ def main():
             a[n][0] += 1
             a[n][1] += float(r["Counter_Value"]) * 1024.0     # FETCH_SIZE / WRITE_SIZE are in KB
         agg[tag] = a
-    # calibration on k_h_av: per step three calls on (ni+4)x(nj+4)xnk cells reading 2+1+2 and writing 1+1+1 words
-    cells = (ni + 4) * (nj + 4) * nk * 8.0
-    n_hav = agg["fetch"]["k_h_av"][0]
-    exp_fetch = cells * 5.0 / 3.0
-    exp_write = cells * 1.0
-    cal_f = exp_fetch / (agg["fetch"]["k_h_av"][1] / n_hav)
-    cal_w = exp_write / (agg["write"]["k_h_av"][1] / agg["write"]["k_h_av"][0])
+    # calibration on k_uhtr (uhtr = uhtr + dt*uh, vhtr = vhtr + dt*vh: one launch per step that reads four 3-D arrays and writes
+    # two, nothing else): the guide's "calibrate on a known byte count in your own access pattern" (FETCH_SIZE counts 64 B
+    # per 128-B request on gfx950: a factor close to 2 on streaming reads; WRITE_SIZE close to 1)
+    cells = (ni + 1) * nj * nk * 8.0
+    cal_k = "k_uhtr"
+    n_cal = agg["fetch"][cal_k][0]
+    exp_fetch = cells * 4.0
+    exp_write = cells * 2.0
+    cal_f = exp_fetch / (agg["fetch"][cal_k][1] / n_cal)
+    cal_w = exp_write / (agg["write"][cal_k][1] / agg["write"][cal_k][0])
+    nsteps = n_cal     # k_uhtr runs once per step
     with open(f"{prefix}_hbm_pmc.csv", "w") as f:
-        f.write(f"# FETCH_SIZE x{cal_f:.3f}, WRITE_SIZE x{cal_w:.3f} (calibration on k_h_av: known {exp_fetch / 1e6:.1f} MB read, "
+        f.write(f"# FETCH_SIZE x{cal_f:.3f}, WRITE_SIZE x{cal_w:.3f} (calibration on k_uhtr: known {exp_fetch / 1e6:.1f} MB read, "
                 f"{exp_write / 1e6:.1f} MB written per launch on average)\n")
         f.write("kernel,dispatches,fetch_bytes_per_launch,write_bytes_per_launch,total_MB_per_launch\n")
         names = sorted((n for n in agg["fetch"] if n.startswith("k_")), key=lambda n: -(agg["fetch"][n][1] + agg["write"][n][1]))
@@ -65,7 +69,11 @@ def main():
             f.write(f"\"{n}\",{cf},{fb:.0f},{wb:.0f},{(fb + wb) / 1e6:.1f}\n")
             total += cf * (fb + wb)
     print(f"all dycore kernels, all dispatches of the PMC run: {total / 1e9:.1f} GB")
-    json.dump({"fetch_cal": cal_f, "write_cal": cal_w, "traffic_bytes_per_launch": out, "total_bytes_all_dispatches": total}, open(f"{prefix}_hbm_pmc.json", "w"), indent=1)
+    per_step = {n: agg["fetch"][n][0] / nsteps for n in out}
+    json.dump({"fetch_cal": cal_f, "write_cal": cal_w, "steps_in_run": nsteps, "traffic_bytes_per_launch": out,
+               "launches_per_step": per_step, "bytes_per_step": total / nsteps, "total_bytes_all_dispatches": total,
+               "note": "dynamics only (bench.py --tracers -1): every k_* dispatch of the run / the number of steps in it"},
+              open(f"{prefix}_hbm_pmc.json", "w"), indent=1)
     print(open(f"{prefix}_hbm_pmc.csv").read()[:3000])
 
 
