@@ -230,7 +230,7 @@ subroutine remap_dyn_split_RK2_aux_vars(G, GV, CS, h_old_u, h_old_v, h_new_u, h_
   rc = mom6x_dev_alloc(CS%ctx, d_nu, n3) ; rc = mom6x_dev_alloc(CS%ctx, d_nv, n3)
   rc = mom6x_upload(CS%ctx, d_ou, h_old_u, STG_U, nk) ; rc = mom6x_upload(CS%ctx, d_ov, h_old_v, STG_V, nk)
   rc = mom6x_upload(CS%ctx, d_nu, h_new_u, STG_U, nk) ; rc = mom6x_upload(CS%ctx, d_nv, h_new_v, STG_V, nk)
-  call remapping_params_of(ALE_CSp, RP)   ! REMAPPING_SCHEME etc. of the ALE control structure (INTEGRATION.md section 6)
+  call remapping_params_of(ALE_CSp, RP)   ! REMAPPING_SCHEME etc. of the ALE control structure (INTEGRATION.md section 7)
   rc = mom6x_remap_dyn_split_RK2_aux_vars(CS%ctx, RP, d_ou, d_ov, d_nu, d_nv)
   if (rc /= 0) call MOM_error(FATAL, "remap_dyn_split_RK2_aux_vars: "//trim(mom6x_message()))
   rc = mom6x_dev_free(CS%ctx, d_ou) ; rc = mom6x_dev_free(CS%ctx, d_ov) ; rc = mom6x_dev_free(CS%ctx, d_nu) ; rc = mom6x_dev_free(CS%ctx, d_nv)
