@@ -171,6 +171,17 @@ def make_thermo(args, dyc, d, st, nth):
             dyc.tracer_vertdiff(st["h"], ea, eb, dt_th, t)
         dyc.triDiagTS(st["h"], ea, eb, T, S)
         dyc.sync(); t_tri = time.perf_counter() - t0
+        if getattr(args, "breakdown", False):   # the kernels of one more thermodynamic call (HIP events around every launch)
+            from mom6_amd.dycore import prof_enable, prof_report, prof_reset
+            prof_enable(dyc, True); prof_reset(dyc)
+            dyc.advect_tracer(st["h"], st["uhtr"], st["vhtr"], dt_th, [T, S] + tr)
+            for t in tr:
+                dyc.tracer_vertdiff(st["h"], ea, eb, dt_th, t)
+            dyc.triDiagTS(st["h"], ea, eb, T, S)
+            dyc.sync()
+            for name, (cnt, ms) in sorted(prof_report(dyc).items(), key=lambda kv: -kv[1][1]):
+                print(f"thermo: {name:28s} n={cnt:5d} total={ms:9.3f} ms", file=sys.stderr)
+            prof_enable(dyc, False)
         st["uhtr"].zero_(); st["vhtr"].zero_()
         N3 = args.ni * args.nj * args.nk
         nf = ntr + 2

@@ -743,6 +743,88 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
   return MOM6X_OK;
 }
 
+// k_tridiag with the whole column on chip (the technique of k_vertvisc_cols, dyn_kernels.hip): c1 and the un-substituted T in
+// registers, the un-substituted S of triDiagTS in LDS, one wavefront per work-group, inputs fetched TD_G layers ahead into a
+// double buffer.  4 (5) words read and 1 (2) written per cell-layer instead of 9 (13); the same operations in the same order.
+template <int NK, bool TWO>
+__global__ void __launch_bounds__(64)
+k_tridiag_cols(Dm d, const double *__restrict__ G, const double *__restrict__ hold, const double *__restrict__ ea,
+               const double *__restrict__ eb, double *T, double *S, double h_neglect, int vertdiff,
+               const double *__restrict__ sfc_flux, const double *__restrict__ btm_flux, double flux_scale, int i0, int i1, int j0,
+               int j1) {
+  extern __shared__ double td_lds[];
+  const int i = i0 + blockIdx.x * 64 + threadIdx.x;
+  const int j = j0 + blockIdx.y;
+  if (i > i1 || j > j1) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  double *ss = td_lds + threadIdx.x;
+  double sfc_src = 0.0, btm_src = 0.0;
+  if (vertdiff) {
+    if (!(gm(G, d, MOM6X_G_mask2dT)[x] > 0.0)) return;
+    if (sfc_flux) sfc_src = (flux_scale != 0.0) ? (sfc_flux[x] * flux_scale) : sfc_flux[x];
+    if (btm_flux) btm_src = (flux_scale != 0.0) ? (btm_flux[x] * flux_scale) : btm_flux[x];
+  }
+  constexpr int TD_G = TWO ? 3 : 5, NG = (NK + TD_G - 1) / TD_G;
+  double tt[NK], cc[NK];
+  double q_h[2][TD_G], q_a[2][TD_G], q_b[2][TD_G], q_t[2][TD_G], q_s[2][TD_G];
+  auto fetch = [&](int g, int b) {
+#pragma unroll
+    for (int m = 0; m < TD_G; m++) {
+      const int k = g * TD_G + m;
+      if (k < NK) {
+        const size_t c = x + (size_t)k * slab;
+        q_h[b][m] = hold[c]; q_a[b][m] = ea[c]; q_b[b][m] = eb[c]; q_t[b][m] = T[c];
+        if (TWO) q_s[b][m] = S[c];
+      }
+    }
+  };
+  double b1 = 0., d1 = 0., prev = 0., prevS = 0., eb_prev = 0.;
+  fetch(0, 0);
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < TD_G; m++) {
+      const int k = g * TD_G + m;
+      if (k < NK) {
+        const double h_tr = q_h[g & 1][m] + h_neglect, eak = q_a[g & 1][m], ebk = q_b[g & 1][m], Tk = q_t[g & 1][m];
+        if (k == 0) {
+          b1 = vertdiff ? 1.0 / ((h_tr + eak) + ebk) : 1.0 / (h_tr + ebk);
+          d1 = h_tr * b1;
+          prev = (b1 * h_tr) * Tk;
+          if (vertdiff) prev = prev + b1 * sfc_src;
+          if (TWO) prevS = (b1 * h_tr) * q_s[g & 1][m];
+        } else {
+          cc[k] = eb_prev * b1;
+          const double b_denom_1 = h_tr + d1 * eak;
+          b1 = 1.0 / (b_denom_1 + ebk);
+          d1 = b_denom_1 * b1;
+          if (vertdiff && k == NK - 1) prev = b1 * ((h_tr * Tk + btm_src) + eak * prev);
+          else prev = b1 * (h_tr * Tk + eak * prev);
+          if (TWO) prevS = b1 * (h_tr * q_s[g & 1][m] + eak * prevS);
+        }
+        eb_prev = ebk;
+        tt[k] = prev;
+        if (TWO) ss[k * 64] = prevS;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  T[x + (size_t)(NK - 1) * slab] = prev;
+  if (TWO) S[x + (size_t)(NK - 1) * slab] = prevS;
+  asm volatile("" ::: "memory");   // (S comes back from LDS, not from NK more live registers)
+#pragma unroll
+  for (int k = NK - 2; k >= 0; k--) {
+    const size_t c = x + (size_t)k * slab;
+    const double c1k = cc[k + 1];
+    prev = tt[k] + c1k * prev;
+    T[c] = prev;
+    if (TWO) { prevS = ss[k * 64] + c1k * prevS; S[c] = prevS; }
+    if (TWO && (k % 8) == 0) __builtin_amdgcn_sched_barrier(0);   // (or all 74 LDS reads are hoisted to the top: 150 registers)
+  }
+}
+
 static int tridiag(mom6x_ctx *c, const double *hold, const double *ea, const double *eb, double *T, double *S, int vertdiff,
                    const double *sfc_flux, const double *btm_flux, double flux_scale, int is, int ie, int js, int je) {
   REQUIRE(c && hold && ea && eb && T, MOM6X_EINVAL, "tridiagonal solve: null array");
@@ -751,6 +833,17 @@ static int tridiag(mom6x_ctx *c, const double *hold, const double *ea, const dou
   double *c1;
   int rc;
   if ((rc = ctx_scratch(c, SCR_c1, d.nk, &c1))) return rc;
+  static const bool walk = [] { const char *e = getenv("MOM6X_TRIDIAG"); return e && !strcmp(e, "walk"); }();
+  if (d.nk == 75 && !walk) {   // the layer count the on-chip column kernel is built for
+    const dim3 bc(64, 1, 1), gc((unsigned)((ie - is + 1 + 63) / 64), (unsigned)(je - js + 1), 1);
+    // (triDiagTS: T and S as two sweeps -- the one-sweep form with S in LDS spills; 10 words per cell-layer instead of 13)
+    KLAUNCH_LDS(c, "k_tridiag_cols", (k_tridiag_cols<75, false>), gc, bc, (size_t)0, d, c->G, hold, ea, eb, T, (double *)nullptr,
+                c->GV.H_subroundoff, vertdiff, sfc_flux, btm_flux, flux_scale, is, ie, js, je);
+    if (S) KLAUNCH_LDS(c, "k_tridiag_cols", (k_tridiag_cols<75, false>), gc, bc, (size_t)0, d, c->G, hold, ea, eb, S, (double *)nullptr,
+                       c->GV.H_subroundoff, vertdiff, sfc_flux, btm_flux, flux_scale, is, ie, js, je);
+    HIPCHK(hipGetLastError());
+    return MOM6X_OK;
+  }
   const dim3 b = blk2();
   KLAUNCH(c, "k_tridiag", k_tridiag, grid3(ie - is + 1, je - js + 1, 1, b), b, d, c->G, hold, ea, eb, T, S, c1, c->GV.H_subroundoff,
           vertdiff, sfc_flux, btm_flux, flux_scale, is, ie, js, je);

@@ -73,11 +73,13 @@ def test_advect_tracer(orc, cfg, schemes, first, post):
     dyc.close()
 
 
-@pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
+@pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small", "benchmark_75"])
 def test_tridiagonal_solvers(orc, cfg):
+    """(benchmark_75: nk = 75 is the layer count of the on-chip column kernel k_tridiag_cols; 70 columns per row = one full and
+    one ragged wavefront)"""
     import torch
     from mom6_amd.dycore import Dycore
-    gg, d, M = getattr(H, cfg)()
+    gg, d, M = H.benchmark_small(nk=75, ni=70, nj=10) if cfg == "benchmark_75" else getattr(H, cfg)()
     GV = abi.vgrid_default()
     nk = d.nk
     h, _, _ = synth.make_state(d, M, thin_frac=0.05)
