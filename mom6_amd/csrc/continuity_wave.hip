@@ -549,8 +549,10 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
                  if (s < 5) slot = (jj + s + 9) % 5; }   // row jj - 1 + s
       else     { arr = (s < 3) ? A.h_in : (s == 3 ? A.u : A.visc_rem); shift = (s < 3) ? (ptrdiff_t)(s - 1) * SEG * 8 : 0; }
       const char *base = (const char *)arr + (ptrdiff_t)row0 + shift;
+      // DIR = 0, s = 0: of the segment i0-4 .. i0-1 only the second 16-byte piece (cells i0-2, i0-1) is in anybody's stencil
+      const bool piece_on = DIR || s != 0 || pp == 1;
       for (int r = 0; r * 32 < nk; r++) {
-        if (r * 32 + sg < nk)
+        if (piece_on && r * 32 + sg < nk)
           glds16((const double *)(base + (size_t)r * 32 * slab * 8 + dma3), S + (size_t)(slot * KP + r * 32) * SEG);
       }
     }
