@@ -664,11 +664,18 @@ def main():
                 print(f"{k:28s} n={cnt:5d} total={ms:9.3f} ms avg={ms / cnt * 1e3:9.1f} us ({100 * ms / tot:5.1f}%)", file=sys.stderr)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        _REAL_STDOUT.write(json.dumps(out) + "\n"); _REAL_STDOUT.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+# The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when a communicator is made
+# (the comm_model leg makes one even at N = 1), so everything but the result line is sent to stderr: file descriptor 1 is
+# kept aside for the line and pointed at stderr for the rest of the process (C stdio buffers included).
+_REAL_STDOUT = sys.stdout
 if __name__ == "__main__":
+    sys.stdout.flush()
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     main()
