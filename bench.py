@@ -662,7 +662,7 @@ def main():
                 if cnt == 0:
                     continue
                 print(f"{k:28s} n={cnt:5d} total={ms:9.3f} ms avg={ms / cnt * 1e3:9.1f} us ({100 * ms / tot:5.1f}%)", file=sys.stderr)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.gpus == 1:   # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(args)
         _REAL_STDOUT.write(json.dumps(out) + "\n"); _REAL_STDOUT.flush()
     if dist is not None:
