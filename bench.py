@@ -516,7 +516,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
-    if world > ndev and os.environ.get("MOM6X_COMM") != "threads":
+    if world > ndev:
         # RCCL cannot build a communicator with two ranks on one device, and a strong-scaling number from shared devices would be bogus
         raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPU(s) visible: one rank per GPU is required")
     local_rank %= max(ndev, 1)

@@ -655,6 +655,25 @@ int mom6x_diabatic_is_trivial(const mom6x_ctx *ctx);
 int mom6x_halo_region(const mom6x_dims *d, int stagger, int dir, int send, int *i0, int *i1, int *j0, int *j1);
 /* Rank (px + npx*py) of the neighbour of tile (px,py) in direction dir, or -1 at a closed boundary. */
 int mom6x_halo_neighbor(int npx, int npy, int px, int py, int dir, int reentrant_x, int reentrant_y);
+/* A transport of the host's own instead of the process's RCCL: nine functions with RCCL's meaning (ncclGetUniqueId,
+ * ncclCommInitRank, ncclCommDestroy, ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd, ncclAllReduce,
+ * ncclGetErrorString), opaque handles as void*, return 0 for success.  For a host that wants its halo traffic in one
+ * library (GPU-aware MPI: MOM6's own FMS domains) -- and how the layout tests run several tiles as threads of one
+ * process on one GPU (tests/transport/).  Communicators made after the call use it; NULL returns to RCCL.           */
+enum { MOM6X_T_INT32 = 0, MOM6X_T_INT64 = 1, MOM6X_T_FLOAT64 = 2 };
+enum { MOM6X_OP_SUM = 0, MOM6X_OP_MIN = 1, MOM6X_OP_MAX = 2 };
+typedef struct mom6x_transport {
+  int (*get_unique_id)(char *id128);
+  int (*comm_init_rank)(void **comm, int nranks, const char *id128, int rank);
+  int (*comm_destroy)(void *comm);
+  int (*send)(const void *buf, size_t count, int dtype, int peer, void *comm, void *stream);
+  int (*recv)(void *buf, size_t count, int dtype, int peer, void *comm, void *stream);
+  int (*group_start)(void);
+  int (*group_end)(void);
+  int (*all_reduce)(const void *sendbuf, void *recvbuf, size_t count, int dtype, int op, void *comm, void *stream);
+  const char *(*error_string)(int rc);       /* nullable */
+} mom6x_transport;
+int mom6x_comm_set_transport(const mom6x_transport *t);
 /* ncclGetUniqueId on the calling rank: 128 bytes the host broadcasts (MPI_Bcast / torch.distributed). */
 int mom6x_comm_unique_id(char *id128);
 /* Attach LAYOUT = npx,npy (MOM_domains.F90:155) with this tile at (px,py) and create the RCCL

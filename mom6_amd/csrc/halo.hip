@@ -17,11 +17,7 @@
 // bundled librccl under Python; the host's own under Fortran) so that only one RCCL exists per process.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
-#include <chrono>
-#include <condition_variable>
-#include <map>
 #include <mutex>
-#include <string>
 #include <vector>
 #include "mom6x_dev.h"
 
@@ -164,138 +160,62 @@ struct NcclApi {
 };
 
 static NcclApi g_rccl = {};      // the RCCL of the process (dlsym)
-static NcclApi g_threads = {};   // MOM6X_COMM=threads (below)
+static NcclApi g_user = {};      // a transport the host supplied (mom6x_comm_set_transport)
 
-// ---- MOM6X_COMM=threads: the same API among host THREADS of one process (one tile per thread, all on the same GPU).
-// A single-GPU box cannot host two RCCL ranks, yet the multi-tile logic -- which rows and columns every kernel covers,
-// the wide-halo cycles of the barotropic solver, the global reductions -- is independent of the transport.  This backend
-// lets the tests run a 2 x 1 or 2 x 2 layout on one device and compare it with the one-tile run (the reference's
-// test.layout).  Every operation synchronises the calling tile's stream and meets the other tiles at host barriers;
-// it is slow and only meant for tests.
-namespace tcomm {
-struct Op { const void *src; void *dst; size_t bytes; int peer; bool send; };
-struct Hub {
-  std::mutex mu; std::condition_variable cv;
-  int nranks = 0, arrived = 0; long gen = 0, joined = 0;
-  std::vector<std::vector<Op>> posted;            // sends of the current group, by sending rank
-  std::vector<std::vector<char>> red;             // all-reduce contributions, by rank
-  bool barrier(std::unique_lock<std::mutex> &lk) {   // all ranks, reusable; false after 120 s (a tile has failed)
-    const long g = gen;
-    if (++arrived == nranks) { arrived = 0; gen++; cv.notify_all(); return true; }
-    return cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g; });
-  }
-};
-struct TC { Hub *hub; int rank; };
-static std::mutex g_mu;
-static std::map<std::string, Hub *> g_hubs;
-static int g_ids = 0;
-static thread_local std::vector<Op> t_ops;
-static thread_local TC *t_comm = nullptr;
-static thread_local hipStream_t t_stream = nullptr;
-static thread_local int t_depth = 0;
-
-static ncclResult_t GetUniqueId(ncclUniqueId *id) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  memset(id, 0, sizeof(*id));
-  snprintf(id->internal, sizeof(id->internal), "mom6x-threads-%d", ++g_ids);
-  return ncclSuccess;
-}
+// ---- a transport of the host's own (include/mom6x.h: mom6x_transport): GPU-aware MPI under a host that keeps its halo
+// traffic in one library, or the in-process transport of the layout tests (tests/transport/).  The host's nine functions
+// are called through adapters with RCCL's signatures, so the exchange code below has one shape.
+static mom6x_transport g_user_fn = {};
+static bool g_user_on = false;
+namespace uadapt {
+static int dtype_of(ncclDataType_t t) { return (t == ncclInt) ? MOM6X_T_INT32 : ((t == ncclInt64) ? MOM6X_T_INT64 : MOM6X_T_FLOAT64); }
+static int op_of(ncclRedOp_t o) { return (o == ncclSum) ? MOM6X_OP_SUM : ((o == ncclMin) ? MOM6X_OP_MIN : MOM6X_OP_MAX); }
+static ncclResult_t res(int rc) { return rc == 0 ? ncclSuccess : ncclSystemError; }
+static ncclResult_t GetUniqueId(ncclUniqueId *id) { memset(id, 0, sizeof(*id)); return res(g_user_fn.get_unique_id(id->internal)); }
 static ncclResult_t CommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank) {
-  Hub *h;
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Hub *&slot = g_hubs[std::string(id.internal)];
-    if (!slot) { slot = new Hub(); slot->nranks = nranks; slot->posted.resize(nranks); slot->red.resize(nranks); }
-    h = slot;
-  }
-  if (h->nranks != nranks || rank < 0 || rank >= nranks) return ncclInvalidArgument;
-  *comm = (ncclComm_t) new TC{h, rank};
-  std::unique_lock<std::mutex> lk(h->mu);
-  return h->barrier(lk) ? ncclSuccess : ncclSystemError;
+  void *h = nullptr;
+  const int rc = g_user_fn.comm_init_rank(&h, nranks, id.internal, rank);
+  *comm = (ncclComm_t)h;
+  return res(rc);
 }
-static ncclResult_t CommDestroy(ncclComm_t comm) { delete (TC *)comm; return ncclSuccess; }
-static size_t type_size(ncclDataType_t t) { return (t == ncclInt || t == ncclFloat) ? 4 : 8; }
-static ncclResult_t run_group() {
-  TC *c = t_comm; Hub *h = c->hub;
-  if (hipStreamSynchronize(t_stream) != hipSuccess) return ncclUnhandledCudaError;   // my packed messages are complete
-  std::unique_lock<std::mutex> lk(h->mu);
-  h->posted[c->rank].clear();
-  for (const Op &o : t_ops) if (o.send) h->posted[c->rank].push_back(o);
-  if (!h->barrier(lk)) return ncclSystemError;
-  std::vector<size_t> used(h->nranks, 0);
-  std::vector<Op> copies;
-  for (const Op &o : t_ops) {
-    if (o.send) continue;
-    const std::vector<Op> &ps = h->posted[o.peer];       // the j-th receive from a peer takes its j-th send to me
-    size_t &u = used[o.peer];
-    while (u < ps.size() && ps[u].peer != c->rank) u++;
-    if (u >= ps.size() || ps[u].bytes != o.bytes) return ncclInvalidUsage;
-    copies.push_back(Op{ps[u].src, o.dst, o.bytes, o.peer, false});
-    u++;
-  }
-  lk.unlock();
-  // (a device-to-device hipMemcpy may return before the data has landed: copy on the tile's stream and wait for it)
-  for (const Op &o : copies)
-    if (hipMemcpyAsync(o.dst, o.src, o.bytes, hipMemcpyDeviceToDevice, t_stream) != hipSuccess) return ncclUnhandledCudaError;
-  if (hipStreamSynchronize(t_stream) != hipSuccess) return ncclUnhandledCudaError;
-  lk.lock();
-  const bool ok = h->barrier(lk);                         // nobody reuses a send buffer before everybody has copied
-  t_ops.clear();
-  return ok ? ncclSuccess : ncclSystemError;
-}
-static ncclResult_t GroupStart() { t_depth++; return ncclSuccess; }
-static ncclResult_t GroupEnd() { if (--t_depth > 0 || t_ops.empty()) return ncclSuccess; return run_group(); }
+static ncclResult_t CommDestroy(ncclComm_t comm) { return res(g_user_fn.comm_destroy((void *)comm)); }
 static ncclResult_t Send(const void *buf, size_t n, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) {
-  t_comm = (TC *)comm; t_stream = st;
-  t_ops.push_back(Op{buf, nullptr, n * type_size(t), peer, true});
-  return (t_depth > 0) ? ncclSuccess : run_group();
+  return res(g_user_fn.send(buf, n, dtype_of(t), peer, (void *)comm, (void *)st));
 }
 static ncclResult_t Recv(void *buf, size_t n, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) {
-  t_comm = (TC *)comm; t_stream = st;
-  t_ops.push_back(Op{nullptr, buf, n * type_size(t), peer, false});
-  return (t_depth > 0) ? ncclSuccess : run_group();
+  return res(g_user_fn.recv(buf, n, dtype_of(t), peer, (void *)comm, (void *)st));
 }
-template <class T> static void reduce_into(T *acc, const T *x, size_t n, ncclRedOp_t op) {
-  for (size_t i = 0; i < n; i++) acc[i] = (op == ncclSum) ? acc[i] + x[i] : ((op == ncclMin) ? (x[i] < acc[i] ? x[i] : acc[i]) : (x[i] > acc[i] ? x[i] : acc[i]));
-}
+static ncclResult_t GroupStart() { return res(g_user_fn.group_start()); }
+static ncclResult_t GroupEnd() { return res(g_user_fn.group_end()); }
 static ncclResult_t AllReduce(const void *send, void *recv, size_t n, ncclDataType_t t, ncclRedOp_t op, ncclComm_t comm, hipStream_t st) {
-  TC *c = (TC *)comm; Hub *h = c->hub;
-  const size_t bytes = n * type_size(t);
-  std::vector<char> mine(bytes);
-  if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
-  if (hipMemcpy(mine.data(), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-  std::unique_lock<std::mutex> lk(h->mu);
-  h->red[c->rank] = mine;
-  if (!h->barrier(lk)) return ncclSystemError;
-  std::vector<char> acc = h->red[0];                      // rank order: every tile forms the same result
-  for (int r = 1; r < h->nranks; r++) {
-    if (h->red[r].size() != bytes) return ncclInvalidUsage;
-    if (t == ncclDouble) reduce_into((double *)acc.data(), (const double *)h->red[r].data(), n, op);
-    else if (t == ncclInt64) reduce_into((long long *)acc.data(), (const long long *)h->red[r].data(), n, op);
-    else if (t == ncclInt) reduce_into((int *)acc.data(), (const int *)h->red[r].data(), n, op);
-    else return ncclInvalidArgument;
-  }
-  const bool ok = h->barrier(lk);                         // everybody has read the contributions
-  lk.unlock();
-  if (!ok) return ncclSystemError;
-  return (hipMemcpy(recv, acc.data(), bytes, hipMemcpyHostToDevice) == hipSuccess) ? ncclSuccess : ncclUnhandledCudaError;
+  return res(g_user_fn.all_reduce(send, recv, n, dtype_of(t), op_of(op), (void *)comm, (void *)st));
 }
-static const char *GetErrorString(ncclResult_t) { return "the threads backend (MOM6X_COMM=threads) failed or timed out"; }
-}  // namespace tcomm
+static const char *GetErrorString(ncclResult_t) { return g_user_fn.error_string ? g_user_fn.error_string(1) : "the host's transport failed"; }
+}  // namespace uadapt
 
-// The transport a NEW communicator (or unique id) gets: the environment decides when it is made, the communicator keeps it.
+static std::mutex g_transport_mu;
+extern "C" int mom6x_comm_set_transport(const mom6x_transport *t) {
+  std::lock_guard<std::mutex> lk(g_transport_mu);
+  if (!t) { g_user_on = false; return MOM6X_OK; }
+  REQUIRE(t->get_unique_id && t->comm_init_rank && t->comm_destroy && t->send && t->recv && t->group_start && t->group_end && t->all_reduce,
+          MOM6X_EINVAL, "mom6x_comm_set_transport: every function but error_string is required");
+  g_user_fn = *t;
+  g_user.GetUniqueId = uadapt::GetUniqueId; g_user.CommInitRank = uadapt::CommInitRank; g_user.CommDestroy = uadapt::CommDestroy;
+  g_user.Send = uadapt::Send; g_user.Recv = uadapt::Recv; g_user.GroupStart = uadapt::GroupStart; g_user.GroupEnd = uadapt::GroupEnd;
+  g_user.AllReduce = uadapt::AllReduce; g_user.GetErrorString = uadapt::GetErrorString;
+  g_user.ok = true;
+  g_user_on = true;
+  return MOM6X_OK;
+}
+
+// The transport a NEW communicator (or unique id) gets -- the host's own if one is set, else the process's RCCL; the
+// communicator keeps the one it was made with.
 static int nccl_load(NcclApi **out) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  const char *be = getenv("MOM6X_COMM");
-  if (be && !strcmp(be, "threads")) {
-    NcclApi &t = g_threads;
-    t.GetUniqueId = tcomm::GetUniqueId; t.CommInitRank = tcomm::CommInitRank; t.CommDestroy = tcomm::CommDestroy;
-    t.Send = tcomm::Send; t.Recv = tcomm::Recv; t.GroupStart = tcomm::GroupStart; t.GroupEnd = tcomm::GroupEnd;
-    t.AllReduce = tcomm::AllReduce; t.GetErrorString = tcomm::GetErrorString;
-    t.ok = true;
-    *out = &g_threads;
-    return MOM6X_OK;
+  {
+    std::lock_guard<std::mutex> lk2(g_transport_mu);
+    if (g_user_on) { *out = &g_user; return MOM6X_OK; }
   }
   NcclApi &g_nccl = g_rccl;
   *out = &g_rccl;

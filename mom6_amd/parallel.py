@@ -44,7 +44,7 @@ def unique_id(lib):
 def attach_comm(dyc, layout, pe, dist=None, force_nccl_self=False, unique_id=None):
     """Give `dyc` its place in the LAYOUT and (if more than one rank, or in test mode) an RCCL communicator.  The
     communicator id is made on rank 0 and broadcast with torch.distributed, unless the caller hands one over (ranks that
-    are threads of one process: MOM6X_COMM=threads)."""
+    are threads of one process: the transport of tests/transport)."""
     import torch
     lib = dyc.lib
     nranks = layout[0] * layout[1]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The strong-scaling runs of bench.py compared with the one-tile run on ONE GPU: the 1440 x 1080 x 75 workload of bench.py
-on a 4 x 2 (8-GPU) or 2 x 2 layout, one tile per host thread (MOM6X_COMM=threads), against layout 1 x 1.  After the steps
+on a 4 x 2 (8-GPU) or 2 x 2 layout, one tile per host thread (the in-process transport of tests/transport, plugged in with mom6x_comm_set_transport), against layout 1 x 1.  After the steps
 the restart checksums (mom6x_field_chksum, summed over the tiles by the same all-reduce the N-GPU run uses) of every
 prognostic field must be equal.  Usage: python scripts/check_layout_fullsize.py [npx npy [steps]]"""
 import argparse
@@ -10,7 +10,6 @@ import threading
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["MOM6X_COMM"] = "threads"
 
 import bench                                   # noqa: E402
 from mom6_amd import parallel                  # noqa: E402
@@ -48,6 +47,8 @@ def main():
         raise SystemExit(errors[0][1])
     print("1 x 1:", {k: ("%016X" % v if k != "dtbt" else v) for k, v in ref[(0, 0)].items()}, flush=True)
     layout = (a.npx, a.npy)
+    from tests import helpers as TH
+    TH.use_threads_transport(load_library())
     uid = parallel.unique_id(load_library())
     pes = [(px, py) for py in range(layout[1]) for px in range(layout[0])]
     th = [threading.Thread(target=run, args=(args, layout, pe, uid, out, errors)) for pe in pes]

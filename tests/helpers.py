@@ -116,3 +116,19 @@ def golden_path(name, ext=".npz"):
 def load_golden(name):
     with np.load(golden_path(name + golden_tag())) as z:
         return {k: z[k] for k in z.files}
+
+
+# ---- several tiles of a layout as host threads of one process on one GPU (tests/transport/threads_transport.cpp)
+def use_threads_transport(lib, on=True):
+    """Plug the in-process transport of the tests into the library (mom6x_comm_set_transport), or hand the exchanges back to
+    RCCL.  Communicators made afterwards use it."""
+    import ctypes as C
+    import os
+    if not on:
+        abi.check(lib, lib.mom6x_comm_set_transport(None))
+        return
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "transport", "libmom6x_threads_transport.so")
+    t = C.CDLL(path)
+    t.mom6x_threads_transport.restype = C.c_void_p
+    abi.check(lib, lib.mom6x_comm_set_transport(C.c_void_p(t.mom6x_threads_transport())))
+    use_threads_transport._keep = t

@@ -1,5 +1,5 @@
 """The reference's test.layout on ONE GPU: the same run on a 2 x 1 / 2 x 2 / 1 x 2 tile layout, one tile per host thread
-(MOM6X_COMM=threads: the halo exchanges and global reductions of mom6_amd/csrc/halo.hip go between threads instead of over
+(tests/transport: the halo exchanges and global reductions of mom6_amd/csrc/halo.hip go between threads instead of over
 RCCL), against the one-tile run.  Every prognostic field of every tile must equal its part of the one-tile result bit for
 bit: this is what the N-GPU runs rely on -- which rows and columns each kernel covers on an interior tile edge, the
 wide-halo cycles of the barotropic solver, the all-reduces (dtbt, tracer iteration flags, reproducing sums)."""
@@ -88,8 +88,16 @@ def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors, rich=Fals
 @pytest.mark.parametrize("cfg_name,layout,rich", [("channel", (2, 1), False), ("double_gyre", (2, 2), False), ("benchmark_small", (1, 2), False),
                                                   ("island_basin", (2, 2), True), ("channel", (2, 1), True),
                                                   ("channel", (4, 2), False), ("benchmark_small", (4, 2), True)])   # the 8-GPU layout
-def test_tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich, monkeypatch):
-    monkeypatch.setenv("MOM6X_COMM", "threads")
+def test_tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich):
+    from mom6_amd.abi import load_library
+    H.use_threads_transport(load_library())
+    try:
+        _tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich)
+    finally:
+        H.use_threads_transport(load_library(), on=False)
+
+
+def _tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich):
     from mom6_amd.abi import load_library
     cfg_fn = getattr(H, cfg_name)
     nk, nsteps, bt_mod = 3, 3, dict(strong_drag=1)
