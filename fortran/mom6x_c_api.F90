@@ -27,6 +27,7 @@ module mom6x_c_api
   public :: mom6x_vertvisc_set_coef, mom6x_vertvisc, mom6x_vertvisc_remnant
   public :: mom6x_initialize_dyn_split_RK2, mom6x_dyn_split_RK2_new_run, mom6x_rk2_field, mom6x_rk2_set_CAu_pred_stored
   public :: mom6x_step_dyn_split_RK2, mom6x_comm_unique_id, mom6x_comm_init, mom6x_pass_fields
+  public :: mom6x_transport, mom6x_comm_set_transport
 
   !> mom6x_dims: hor_index_type extents (MOM_hor_index.F90:14-44) + the device layout
   type, bind(C) :: mom6x_dims
@@ -122,6 +123,11 @@ module mom6x_c_api
     real(c_double) :: ref_pressure, compressibility_fraction
     integer(c_int) :: integrate_downward_for_e
   end type mom6x_regrid_rho_params
+
+  !> a halo transport of the host's own (nine c_funptr with RCCL's meaning, see include/mom6x.h), e.g. over GPU-aware MPI
+  type, bind(C) :: mom6x_transport
+    type(c_funptr) :: get_unique_id, comm_init_rank, comm_destroy, send, recv, group_start, group_end, all_reduce, error_string
+  end type mom6x_transport
 
   type, bind(C) :: mom6x_chksum_result         !< the numbers of the two lines of chksum_{h,u,v,B}_{2d,3d} (MOM_checksums.F90)
     real(c_double) :: mean, amin, amax
@@ -437,6 +443,11 @@ module mom6x_c_api
     end function
 
     !> MOM_domains: LAYOUT and halo updates over RCCL
+    !> communicators made afterwards use the host's transport; c_null_ptr: back to RCCL
+    integer(c_int) function mom6x_comm_set_transport(t) bind(C, name="mom6x_comm_set_transport")
+      import :: c_ptr, c_int
+      type(c_ptr), value :: t
+    end function
     integer(c_int) function mom6x_comm_unique_id(id128) bind(C, name="mom6x_comm_unique_id")
       import :: c_int, c_char ; character(kind=c_char), intent(out) :: id128(128)
     end function
