@@ -209,6 +209,54 @@ def test_rotate_whole_baroclinic_step(orc, first_direction):
     assert np.abs(s["u"]).max() > 1e-3
 
 
+HV_ROT = {
+    "biharmonic": dict(Ah_vel_scale=0.01),
+    "laplacian": dict(Laplacian=1, biharmonic=0, Kh=500.0, Kh_vel_scale=0.02),
+    "smagorinsky_both_better_bounds": dict(Laplacian=1, Smagorinsky_Kh=1, Smag_Lap_const=0.15, Smagorinsky_Ah=1, Smag_bi_const=0.06, Kh=10.0,
+                                           Ah=1.0e8),
+    "smagorinsky_bound_coriolis_legacy": dict(Smagorinsky_Ah=1, Smag_bi_const=0.06, bound_Coriolis=1, bound_Cor_vel=2.0, Ah=1.0e8,
+                                              better_bound_Ah=0),
+    "noslip_laplacian": dict(Laplacian=1, biharmonic=0, Kh=800.0, no_slip=1),
+    # Leith: on a grid with UNIFORM metrics only (see the test)
+    "leith_kh@cartesian": dict(Laplacian=1, Leith_Kh=1, Leith_Lap_const=1.0, Kh=10.0, Ah=1.0e8),
+    "leith_kh_beta_modified_les@cartesian": dict(Laplacian=1, Leith_Kh=1, Leith_Lap_const=1.5, use_beta_in_Leith=1, modified_Leith=1,
+                                                 add_LES_viscosity=1, Kh=10.0, Ah=1.0e8),
+    "leith_ah@cartesian": dict(Leith_Ah=1, Leith_bi_const=5.0, Ah=1.0e7),
+}
+
+
+@pytest.mark.parametrize("flags", sorted(HV_ROT))
+def test_rotate_horizontal_viscosity(orc, flags):
+    """horizontal_viscosity (+ hor_visc_init's 2-D planes) on a closed basin with an island and on its quarter turn: the
+    accelerations of the turned run, turned back (diffu = diffv', diffv = -diffu'), equal the original ones bit for bit --
+    Laplacian, biharmonic, Smagorinsky, the stability bounds, NOSLIP, and the Leith viscosity from the vorticity gradient
+    (with beta and the divergence gradient).  The Leith gradients are turn-symmetric on uniform metrics only: the
+    reference scales the x-derivative of the vorticity at a v point with DY_dxBu of the vertex to its EAST and the y-derivative
+    at a u point with DX_dyBu of the vertex to its NORTH (MOM_hor_visc.F90:990-998), and a quarter turn takes north to west;
+    on the sphere the two readings differ by the metric's variation over one cell (1e-3 here) -- in the reference itself.
+    So the Leith cases run on a Cartesian beta-plane basin, where they pin the index conventions bit for bit."""
+    if flags.endswith("@cartesian"):
+        from mom6_amd import grid
+        gg = grid.GlobalGrid(30, 22, kind="cartesian", dx=2.0e4, dy=2.0e4, f0=1.0e-4, beta=2.0e-11, depth_fn=grid.bowl_depth(30, 22, 3000.0))
+        d, M = gg.tile(4)
+    else:
+        gg, d, M = H.island_basin()
+    GV = abi.vgrid_default()
+    h, u, v = synth.make_state(d, M, thin_frac=0.15)
+    T = Turn(d); dr = T.dr; Mr = T.metrics(M)
+    P = abi.hor_visc_params_default(1200.0)
+    for k_, v_ in HV_ROT[flags].items():
+        setattr(P, k_, v_)
+    du, dv = np.zeros_like(u), np.zeros_like(v)
+    orc.horizontal_viscosity(d, M, GV, P, orc.hor_visc_init(d, M, P), u, v, h, du, dv)
+    ur, vr, hr = T.v_to_u(v), T.u_to_v(u), T.h(h)
+    dur, dvr = np.zeros_like(ur), np.zeros_like(vr)
+    orc.horizontal_viscosity(dr, Mr, GV, P, orc.hor_visc_init(dr, Mr, P), ur, vr, hr, dur, dvr)
+    ub, vb, _ = _turn_back(T, dur, dvr, hr)
+    H.assert_bitwise(ub, du, "rotate:diffu", H.interior(d, "u")); H.assert_bitwise(vb, dv, "rotate:diffv", H.interior(d, "v"))
+    assert np.abs(du).max() > 0 and np.abs(dv).max() > 0
+
+
 @pytest.mark.parametrize("dim", ["t", "l", "h", "z", "r"])
 def test_dim_rescaling_of_the_whole_step_is_bit_identical(orc, dim):
     """.testing dim.t / dim.l / dim.h / dim.z / dim.r: the units of time, horizontal length, thickness, depth or density are
