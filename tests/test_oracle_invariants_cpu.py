@@ -161,7 +161,7 @@ def test_rotate_continuity_and_CorAdCalc(orc, first_direction, sum_order):
     H.assert_bitwise(btr["h_u"], T.v_to_u(bt["h_v"], 1.0), "rotate:BT_cont%h_v", H.interior(dr, "u"))
 
 
-def _rk2_run(orc, d, M, first_direction, u, v, h, taux, tauy, coefs, nsteps=2, dt=900.0, bt_mod=None, sum_order=None):
+def _rk2_run(orc, d, M, first_direction, u, v, h, taux, tauy, coefs, nsteps=2, dt=900.0, bt_mod=None, sum_order=None, vv=None, hv=None):
     GV = abi.vgrid_default(); Rlay, gp = abi.layer_densities(d.nk)
     bt = abi.barotropic_params_default(30.0); bt.strong_drag = 1     # (no libm pow on the path: everything bit-comparable)
     for k_, v_ in (bt_mod or {}).items():
@@ -171,6 +171,10 @@ def _rk2_run(orc, d, M, first_direction, u, v, h, taux, tauy, coefs, nsteps=2, d
         cont.sum_order = sum_order
     m = orc.OrcModel(d, M, GV, cont, bt, abi.coriolis_params_default(), abi.pgf_params_default(), abi.rk2_params_default(), Rlay, gp,
                      first_direction)
+    if vv is not None:
+        m.set_vertvisc(*vv)
+    if hv is not None:
+        m.set_hor_visc(hv)
     s = dict(u=u.copy(), v=v.copy(), h=h.copy(), uh=np.zeros_like(h), vh=np.zeros_like(h), uhtr=np.zeros_like(h), vhtr=np.zeros_like(h),
              eta_av=np.zeros(d.shape2()))
     m.initialize(s["u"], s["v"], s["h"], s["uh"], s["vh"], dt)
@@ -255,6 +259,38 @@ def test_rotate_horizontal_viscosity(orc, flags):
     ub, vb, _ = _turn_back(T, dur, dvr, hr)
     H.assert_bitwise(ub, du, "rotate:diffu", H.interior(d, "u")); H.assert_bitwise(vb, dv, "rotate:diffv", H.interior(d, "v"))
     assert np.abs(du).max() > 0 and np.abs(dv).max() > 0
+
+
+def test_rotate_whole_step_with_vertvisc_coef_and_horizontal_viscosity(orc):
+    """The step with every callee inside it -- vertvisc_coef (x3, from visc%Kv_bbl / bbl_thick / Kv_shear) and
+    horizontal_viscosity (Laplacian + biharmonic + Smagorinsky) -- on an island basin and on its quarter turn, two steps."""
+    d, M, h, u, v = _state(H.island_basin(), u_max=0.05, h_pert=0.001)
+    T = Turn(d); dr = T.dr; Mr = T.metrics(M)
+    taux = np.ascontiguousarray(0.1 * synth.smooth_field(d, 41, ox=1, oy=.5) * M[G["mask2dCu"]])
+    tauy = np.ascontiguousarray(0.05 * synth.smooth_field(d, 42, ox=.5, oy=1) * M[G["mask2dCv"]])
+    a, hu = _coefs(d, M, h)
+    c0 = tuple(np.ascontiguousarray(x) if x is not None else None for x in
+               (a * M[G["mask2dCu"]][None], a * M[G["mask2dCv"]][None], hu, hu.copy(), None, None))
+    c1 = (T.v_to_u(c0[1], 1.0), T.u_to_v(c0[0], 1.0), T.v_to_u(c0[3], 1.0), T.u_to_v(c0[2], 1.0), None, None)
+    P = abi.vertvisc_params_default()
+    kbu = np.ascontiguousarray((2e-3 * (1 + 0.5 * synth.smooth_field(d, 91, ox=1, oy=.5))) * M[G["mask2dCu"]])
+    kbv = np.ascontiguousarray((2e-3 * (1 + 0.5 * synth.smooth_field(d, 92, ox=.5, oy=1))) * M[G["mask2dCv"]])
+    btu = np.ascontiguousarray(8.0 * (1 + 0.6 * synth.smooth_field(d, 93, ox=1, oy=.5)))
+    btv = np.ascontiguousarray(8.0 * (1 + 0.6 * synth.smooth_field(d, 94, ox=.5, oy=1)))
+    ksh = np.ascontiguousarray(1e-3 * np.abs(synth.smooth_field(d, 95, nk=d.nk + 1, ox=.5, oy=.5)))
+    vv0 = (P, kbu, kbv, btu, btv, ksh, None, None)
+    vv1 = (P, T.v_to_u(kbv, 1.0), T.u_to_v(kbu, 1.0), T.v_to_u(btv, 1.0), T.u_to_v(btu, 1.0), T.h(ksh), None, None)
+    hv = abi.hor_visc_params_default(900.0)
+    hv.Laplacian = 1; hv.Kh = 200.0; hv.Smagorinsky_Kh = 1; hv.Smag_Lap_const = 0.15; hv.Smagorinsky_Ah = 1; hv.Smag_bi_const = 0.06
+    hv.Ah_vel_scale = 0.02
+    s, _ = _rk2_run(orc, d, M, 0, u, v, h, taux, tauy, c0, vv=vv0, hv=hv)
+    sr, _ = _rk2_run(orc, dr, Mr, 1, T.v_to_u(v), T.u_to_v(u), T.h(h), T.v_to_u(tauy), T.u_to_v(taux), c1, vv=vv1, hv=hv)
+    su, sv, sh = H.interior(d, "u"), H.interior(d, "v"), H.interior(d, "h")
+    for a_, b_ in (("u", "v"), ("uh", "vh"), ("uhtr", "vhtr")):
+        ub, vb, hb = _turn_back(T, sr[a_], sr[b_], sr["h"])
+        H.assert_bitwise(ub, s[a_], "rotate:" + a_, su); H.assert_bitwise(vb, s[b_], "rotate:" + b_, sv)
+    H.assert_bitwise(hb, s["h"], "rotate:h", sh)
+    assert np.abs(s["u"]).max() > 1e-3
 
 
 @pytest.mark.parametrize("dim", ["t", "l", "h", "z", "r"])
