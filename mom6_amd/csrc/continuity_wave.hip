@@ -511,7 +511,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   const int fw = lane >> 4, kl = lane & 15;
   const int i0 = E.i_base + bx * NF + w * SEG, i = i0 + fw;   // i0: the wavefront's first face
   const bool active = (i >= A.a0 && i <= A.a1);
-  if (!wave_any(active)) return;
+  const bool wave_on = wave_any(active);   // (a wavefront without faces still meets the others at the row barrier below)
   const int nk = d.nk;
   const size_t slab = (size_t)d.slab;
   const bool use_visc_rem = (A.visc_rem != nullptr);
@@ -583,8 +583,14 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   for (int n = 0; n < MAXL; n++) { C.pL[n] = 0.0; C.pR[n] = 0.0; C.pC[n] = 0.0; }
 
   const int jstart = DIR ? j0 - 1 : j0;   // meridional: a first step that only reconstructs cell j0
-  issue_dma(jstart, true);
+  if (wave_on) issue_dma(jstart, true);
   for (int jj = jstart; jj <= j1; jj++) {
+    // The four wavefronts of a work-group share nothing but cache lines: a 128-byte line of h, u, visc_rem or of an output
+    // holds the 32 bytes of each of them.  Left alone they drift rows apart (their Newton counts differ), every wavefront
+    // then fetches the line for itself and the partial lines they store reach memory one by one.  Meeting once per row
+    // keeps the four requests within the L2's reach: plain / adjust modes 2.0 -> 1.5 / 2.6 -> 2.25 ms (x).
+    __syncthreads();
+    if (!wave_on) continue;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row jj has landed
     const bool face_row = (!DIR) || (jj >= j0);
     // ---- LDS -> registers, layer by layer, with the PPM reconstruction + limiter on the way ---------------------------
