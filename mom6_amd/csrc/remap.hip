@@ -655,6 +655,9 @@ k_set_h_vel(Dm d, const double *__restrict__ G, const double *__restrict__ h_new
   }
 }
 
+// bits of the context's device flag the regridding kernels raise (bit 1 is the NaN flag of continuity: left alone here)
+enum { REGRID_FLAGS = 4 | 8 | 16 };
+
 // ---- regridding: pieces shared by the coordinate generators.  A column lives in 3-D arrays ([k][slab], element k of
 // array p at p[x + (k-1)*slab]): every loop has the same k in all lanes, so the accesses are coalesced.
 #define LV(p, k) (p)[x + (size_t)((k) - 1) * slab]
@@ -1202,14 +1205,13 @@ extern "C" int mom6x_ALE_regrid_zstar(mom6x_ctx *c, const mom6x_regrid_zstar_par
   double *zOld;
   int rc = ctx_scratch(c, SCR_e, d.nk + 1, &zOld);
   if (rc) return rc;
-  HIPCHK(hipMemsetAsync(c->flag, 0, sizeof(int), c->stream));
   const dim3 b(64, 4, 1);
   KLAUNCH(c, "k_regrid_zstar", k_regrid_zstar, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, c->G, *p, c->GV.Z_to_H,
           (const double *)c->regrid_res, h, h_new, dzRegrid, zOld, c->flag);
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemsetAsync(c->flag, 0, sizeof(int), c->stream));
+  if (flag & REGRID_FLAGS) { const int keep = flag & ~REGRID_FLAGS; HIPCHK(hipMemcpy(c->flag, &keep, sizeof(int), hipMemcpyHostToDevice)); }
   REQUIRE(!(flag & 4), MOM6X_EINVAL, "filtered_grid_motion: z_old and z_new use different sign conventions.");
   REQUIRE(!(flag & 8), MOM6X_EINVAL, "MOM_regridding: adjust_interface_motion() - implied h<0 is larger than roundoff!");
   return MOM6X_OK;
@@ -1251,7 +1253,6 @@ static int regrid_density(mom6x_ctx *c, bool hycom, const mom6x_regrid_rho_param
       (rc = ctx_scratch(c, SCR_q, d.nk, &W.dens)) || (rc = ctx_scratch(c, SCR_t0, d.nk, &W.E1)) || (rc = ctx_scratch(c, SCR_t1, d.nk, &W.E2)) ||
       (rc = ctx_scratch(c, SCR_t2, d.nk, &W.C2)) || (rc = ctx_scratch(c, SCR_KE, d.nk, &W.MP)) || (rc = ctx_scratch(c, SCR_absv, d.nk, &W.HN)))
     return rc;
-  HIPCHK(hipMemsetAsync(c->flag, 0, sizeof(int), c->stream));
   const dim3 b(64, 4, 1);
   const dim3 g = grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b);
   const double *res = c->regrid_vec, *tgt = res + nk, *mid = tgt + nk + 1, *mlt = mid + nk + 1;
@@ -1260,7 +1261,7 @@ static int regrid_density(mom6x_ctx *c, bool hycom, const mom6x_regrid_rho_param
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, c->flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemsetAsync(c->flag, 0, sizeof(int), c->stream));
+  if (flag & REGRID_FLAGS) { const int keep = flag & ~REGRID_FLAGS; HIPCHK(hipMemcpy(c->flag, &keep, sizeof(int), hipMemcpyHostToDevice)); }
   REQUIRE(!(flag & 4), MOM6X_EINVAL, "filtered_grid_motion: z_old and z_new use different sign conventions.");
   REQUIRE(!(flag & 8), MOM6X_EINVAL, "MOM_regridding: adjust_interface_motion() - implied h<0 is larger than roundoff!");
   REQUIRE(!(flag & 16), MOM6X_EINVAL, "Could not find target coordinate in get_polynomial_coordinate. This is caused by an inconsistent interpolant (perhaps not monotonically increasing)");
