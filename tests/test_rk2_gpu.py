@@ -195,6 +195,9 @@ def test_rk2_75_layers_on_chip_columns(orc, ni, nj):
     run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(split_bottom_stress=1),
         per_stage=True)
     run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), dev_vv=dict())
+    # VISC_REM_TIMESTEP_BUG = False: the velocity solve without the remnant (k_vertvisc_cols<UPD, !REM>) + k_vertvisc_remnant_cols
+    run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(visc_rem_dt_bug=0), dev_vv=dict())
+    run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(visc_rem_dt_bug=0), per_stage=True)
 
 
 def test_rk2_tc4_like_switches(orc):
