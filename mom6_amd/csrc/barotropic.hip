@@ -97,6 +97,29 @@ __global__ void k_bt_init_static(Dm d, const double *__restrict__ G, double Z_to
 }
 
 // ---- btcalc :4360-4605 --------------------------------------------------------------------
+// btcalc :4360 with BT_THICK_SCHEME = FROM_BT_CONT at nk = NK: the column of h_u is read ONCE into registers (NK
+// independent loads in flight), summed in the reference's order and written back scaled -- 2 words per face-layer
+// instead of 3.
+template <int DIR, int NK>
+__global__ void __launch_bounds__(256)
+k_btcalc_cols(Dm d, const double *__restrict__ G, const double *__restrict__ hf, double *__restrict__ fr, double h_neglect) {
+  const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < ((DIR ? 0 : -1))) return;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[c];
+  double v[NK];
+#pragma unroll
+  for (int k = 0; k < NK; k++) v[k] = hf[c + (size_t)k * slab];
+  double hattot = 0.0;
+#pragma unroll
+  for (int k = 0; k < NK; k++) hattot = hattot + v[k];
+  const double Ihattot = mC / (hattot + h_neglect);
+#pragma unroll
+  for (int k = 0; k < NK; k++) fr[c + (size_t)k * slab] = v[k] * Ihattot;
+}
+
 template <int DIR>
 __global__ void __launch_bounds__(256)
 k_btcalc(Dm d, const double *__restrict__ G, const double *__restrict__ h, const double *__restrict__ hf,
@@ -683,6 +706,12 @@ extern "C" int mom6x_btcalc(mom6x_ctx *c, const double *h, const double *h_u, co
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   const dim3 b = blk2();
+  if (h_u && d.nk == 75) {   // the layer count the register-resident column kernel is built for
+    KLAUNCH(c, "k_btcalc<0>", (k_btcalc_cols<0, 75>), grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, h_u, c->bts->frhatu, c->GV.H_subroundoff);
+    KLAUNCH(c, "k_btcalc<1>", (k_btcalc_cols<1, 75>), grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, h_v, c->bts->frhatv, c->GV.H_subroundoff);
+    HIPCHK(hipGetLastError());
+    return MOM6X_OK;
+  }
   KLAUNCH(c, "k_btcalc<0>", k_btcalc<0>, grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, h, h_u, c->bts->frhatu,
                      c->GV.H_subroundoff, c->GV.Z_to_H);
   KLAUNCH(c, "k_btcalc<1>", k_btcalc<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, h, h_v, c->bts->frhatv,
