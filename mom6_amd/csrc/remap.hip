@@ -662,50 +662,61 @@ enum { REGRID_FLAGS = 4 | 8 | 16 };
 // array p at p[x + (k-1)*slab]): every loop has the same k in all lanes, so the accesses are coalesced.
 #define LV(p, k) (p)[x + (size_t)((k) - 1) * slab]
 
-// filtered_grid_motion MOM_regridding.F90:1105-1252 (CS%nk == nk): zNew comes in dzI and is replaced by dz_g, level by level.
-// Returns false for "z_old and z_new use different sign conventions" (a FATAL of the reference).
+// filtered_grid_motion MOM_regridding.F90:1105-1252 in two pieces, so that the column may live in global arrays or in
+// registers: the constants of a column, and the displacement of one interface.
+struct FilterConst { double sgn, zs, zd, wtd, Iwtd, dzwt, Idzwt, dInt_zs_zd, Aq; bool zero; };
+// false: "z_old and z_new use different sign conventions" (a FATAL of the reference); F.zero: no motion at all (:1141-1143)
+__device__ __forceinline__ bool filter_prepare(const mom6x_regrid_zstar_params &CS, double zOld1, double zOldB, double zNew1, double zNewB,
+                                               FilterConst &F) {
+  const double test = (zOldB - zOld1) * (zNewB - zNew1);
+  F.zero = (test == 0.0);
+  if (test < 0.0) return false;
+  F.sgn = ((zOldB - zOld1) + (zNewB - zNew1) > 0.0) ? 1.0 : -1.0;
+  F.zs = CS.depth_of_time_filter_shallow; F.zd = CS.depth_of_time_filter_deep;
+  F.wtd = 1.0 - CS.old_grid_weight; F.Iwtd = 1.0 / F.wtd;
+  F.dzwt = (F.zd - F.zs);
+  F.Idzwt = 0.0; if (fabs(F.zd - F.zs) > 0.0) F.Idzwt = 1.0 / (F.zd - F.zs);
+  F.dInt_zs_zd = 0.5 * (1.0 + F.Iwtd) * (F.zd - F.zs);
+  F.Aq = 0.5 * (F.Iwtd - 1.0);
+  return true;
+}
+__device__ __forceinline__ double filter_one(const FilterConst &F, double z_old_k, double z_new_k, double zOld1) {
+  const double sgn = F.sgn, zs = F.zs, zd = F.zd, wtd = F.wtd, Iwtd = F.Iwtd, dzwt = F.dzwt, Idzwt = F.Idzwt, Aq = F.Aq;
+  const double dz_tgt = sgn * (z_new_k - z_old_k);
+  const double zr1 = sgn * (z_old_k - zOld1);
+  double dz;
+  if ((zr1 > zd) && (zr1 + wtd * dz_tgt > zd)) dz = sgn * wtd * dz_tgt;
+  else if ((zr1 < zs) && (zr1 + dz_tgt < zs)) dz = sgn * dz_tgt;
+  else {
+    double Int_zd, Int_zs;
+    if (zr1 >= zd) { Int_zd = Iwtd * (zd - zr1); Int_zs = Int_zd - F.dInt_zs_zd; }
+    else if (zr1 <= zs) { Int_zs = (zs - zr1); Int_zd = F.dInt_zs_zd + (zs - zr1); }
+    else {
+      Int_zd = (zd - zr1) * (Iwtd * (0.5 * (zd + zr1) - zs) + 0.5 * (zd - zr1)) * Idzwt;
+      Int_zs = (zs - zr1) * (0.5 * Iwtd * ((zr1 - zs)) + (zd - 0.5 * (zr1 + zs))) * Idzwt;
+    }
+    if (dz_tgt >= Int_zd) dz = sgn * ((zd - zr1) + wtd * (dz_tgt - Int_zd));
+    else if (dz_tgt <= Int_zs) dz = sgn * ((zs - zr1) + (dz_tgt - Int_zs));
+    else {
+      double dz0, z0, F0;
+      if (zr1 <= zs) { dz0 = zs - zr1; z0 = zs; F0 = dz_tgt - Int_zs; }
+      else if (zr1 >= zd) { dz0 = zd - zr1; z0 = zd; F0 = dz_tgt - Int_zd; }
+      else { dz0 = 0.0; z0 = zr1; F0 = dz_tgt; }
+      const double Bq = (dzwt + 2.0 * Aq * (z0 - zs));
+      dz = sgn * (dz0 + 2.0 * F0 * dzwt / (Bq + sqrt(Bq * Bq + 4.0 * Aq * F0 * dzwt)));
+    }
+  }
+  return dz;
+}
+// the column in 3-D arrays: zNew comes in dzI and is replaced by dz_g, level by level
 __device__ bool filtered_grid_motion_col(const mom6x_regrid_zstar_params &CS, int nz, const double *__restrict__ zOld, double *dzI,
                                          size_t x, size_t slab) {
-  const double zOld1 = LV(zOld, 1), zOldB = LV(zOld, nz + 1), zNew1 = LV(dzI, 1), zNewB = LV(dzI, nz + 1);
-  const double test = (zOldB - zOld1) * (zNewB - zNew1);
-  if (test < 0.0) return false;
-  if (test == 0.0) { for (int k = 1; k <= nz + 1; k++) LV(dzI, k) = 0.0; return true; }
-  const double sgn = ((zOldB - zOld1) + (zNewB - zNew1) > 0.0) ? 1.0 : -1.0;
-  const double zs = CS.depth_of_time_filter_shallow, zd = CS.depth_of_time_filter_deep;
-  const double wtd = 1.0 - CS.old_grid_weight, Iwtd = 1.0 / wtd;
-  const double dzwt = (zd - zs);
-  double Idzwt = 0.0; if (fabs(zd - zs) > 0.0) Idzwt = 1.0 / (zd - zs);
-  const double dInt_zs_zd = 0.5 * (1.0 + Iwtd) * (zd - zs);
-  const double Aq = 0.5 * (Iwtd - 1.0);
+  const double zOld1 = LV(zOld, 1);
+  FilterConst F;
+  if (!filter_prepare(CS, zOld1, LV(zOld, nz + 1), LV(dzI, 1), LV(dzI, nz + 1), F)) return false;
+  if (F.zero) { for (int k = 1; k <= nz + 1; k++) LV(dzI, k) = 0.0; return true; }
   LV(dzI, 1) = 0.0;
-  for (int k = 2; k <= nz + 1; k++) {
-    const double z_old_k = LV(zOld, k);
-    const double dz_tgt = sgn * (LV(dzI, k) - z_old_k);
-    const double zr1 = sgn * (z_old_k - zOld1);
-    double dz;
-    if ((zr1 > zd) && (zr1 + wtd * dz_tgt > zd)) dz = sgn * wtd * dz_tgt;
-    else if ((zr1 < zs) && (zr1 + dz_tgt < zs)) dz = sgn * dz_tgt;
-    else {
-      double Int_zd, Int_zs;
-      if (zr1 >= zd) { Int_zd = Iwtd * (zd - zr1); Int_zs = Int_zd - dInt_zs_zd; }
-      else if (zr1 <= zs) { Int_zs = (zs - zr1); Int_zd = dInt_zs_zd + (zs - zr1); }
-      else {
-        Int_zd = (zd - zr1) * (Iwtd * (0.5 * (zd + zr1) - zs) + 0.5 * (zd - zr1)) * Idzwt;
-        Int_zs = (zs - zr1) * (0.5 * Iwtd * ((zr1 - zs)) + (zd - 0.5 * (zr1 + zs))) * Idzwt;
-      }
-      if (dz_tgt >= Int_zd) dz = sgn * ((zd - zr1) + wtd * (dz_tgt - Int_zd));
-      else if (dz_tgt <= Int_zs) dz = sgn * ((zs - zr1) + (dz_tgt - Int_zs));
-      else {
-        double dz0, z0, F0;
-        if (zr1 <= zs) { dz0 = zs - zr1; z0 = zs; F0 = dz_tgt - Int_zs; }
-        else if (zr1 >= zd) { dz0 = zd - zr1; z0 = zd; F0 = dz_tgt - Int_zd; }
-        else { dz0 = 0.0; z0 = zr1; F0 = dz_tgt; }
-        const double Bq = (dzwt + 2.0 * Aq * (z0 - zs));
-        dz = sgn * (dz0 + 2.0 * F0 * dzwt / (Bq + sqrt(Bq * Bq + 4.0 * Aq * F0 * dzwt)));
-      }
-    }
-    LV(dzI, k) = dz;
-  }
+  for (int k = 2; k <= nz + 1; k++) LV(dzI, k) = filter_one(F, LV(zOld, k), LV(dzI, k), zOld1);
   return true;
 }
 
@@ -793,6 +804,88 @@ k_regrid_zstar(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_params CS,
   if (!filtered_grid_motion_col(CS, nz, zOld, dzI, x, slab)) { atomicOr(flag, 4); return; }   // :1337
   if (!adjust_interface_motion_col(CS.min_thickness, nz, h, dzI, x, slab)) { atomicOr(flag, 8); return; }   // :1362
   calc_h_new_col(nz, h, dzI, h_new, x, slab);
+}
+
+// k_regrid_zstar with the column on chip (nk = NK): the thicknesses and the interface positions / displacements in registers,
+// the old interface positions in LDS; the column is read once and h_new, dzInterface written once (3 words per cell-layer
+// where the array version makes eight passes).  One wavefront per work-group.  Same operations in the same order.
+template <int NK>
+__global__ void __launch_bounds__(64)
+k_regrid_zstar_cols(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_params CS, double Z_to_H, const double *__restrict__ res,
+                    const double *__restrict__ h, double *__restrict__ h_new, double *__restrict__ dzI, int *__restrict__ flag) {
+  extern __shared__ double rz_lds[];
+  const int i = I_BASE(-1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = -1 + blockIdx.y;
+  if (i < -1 || i > d.ni || j > d.nj) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  double *zo_l = rz_lds + threadIdx.x;          // zOld(k) at zo_l[(k-1)*64]
+  double hh[NK], dz[NK + 1];
+#pragma unroll
+  for (int k = 0; k < NK; k++) hh[k] = h[x + (size_t)k * slab];
+  if (gm(G, d, MOM6X_G_mask2dT)[x] == 0.) {
+#pragma unroll
+    for (int k = 0; k < NK; k++) { h_new[x + (size_t)k * slab] = hh[k]; dzI[x + (size_t)k * slab] = 0.; }
+    dzI[x + (size_t)NK * slab] = 0.;
+    return;
+  }
+  const double depth = dmax((gm(G, d, MOM6X_G_bathyT)[x] + CS.Z_ref) * Z_to_H, 0.0);
+  double total = 0.0;
+#pragma unroll
+  for (int k = 0; k < NK; k++) total = total + hh[k];
+  double zo = -depth;
+  zo_l[NK * 64] = zo;
+#pragma unroll
+  for (int k = NK - 1; k >= 0; k--) { zo = zo + hh[k]; zo_l[k * 64] = zo; }
+  const double zOld1 = zo;
+  const double min_thickness = dmin(CS.min_thickness, total / (double)NK);
+  const double eta = total - depth;
+  const double stretching = total / (depth + 0.);
+  double zn = eta;
+  dz[0] = zn;
+#pragma unroll
+  for (int k = 1; k <= NK; k++) { const double dh = stretching * res[k - 1] * Z_to_H; zn = zn - dh; dz[k] = zn; }
+  zn = -depth;
+  dz[NK] = zn;
+#pragma unroll
+  for (int k = NK - 1; k >= 0; k--) {
+    double zk = dz[k];
+    if (zk < (zn + min_thickness)) { zk = zn + min_thickness; dz[k] = zk; }
+    zn = zk;
+  }
+  FilterConst F;
+  if (!filter_prepare(CS, zOld1, -depth, dz[0], dz[NK], F)) { atomicOr(flag, 4); return; }
+  asm volatile("" ::: "memory");
+  dz[0] = 0.0;
+#pragma unroll
+  for (int k = 1; k <= NK; k++) dz[k] = F.zero ? 0.0 : filter_one(F, zo_l[k * 64], dz[k], zOld1);
+  // adjust_interface_motion :1796-1857
+  {
+    const double eps = DBL_EPSILON;
+    double h_err = 0.;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+      h_err = h_err + dmax3(hh[k], fabs(dz[k]), fabs(dz[k + 1])) * eps;
+      const double hn = hh[k] + (dz[k] - dz[k + 1]);
+      if (hn < -3.0 * h_err) bad = true;
+    }
+#pragma unroll
+    for (int k = NK - 1; k >= 1; k--) {
+      double hn = hh[k] + (dz[k] - dz[k + 1]);
+      if (hn < CS.min_thickness) dz[k] = (dz[k + 1] - hh[k]) + CS.min_thickness;
+      hn = hh[k] + (dz[k] - dz[k + 1]);
+      if (hn < 0.) dz[k] = (1. - eps) * (dz[k + 1] - hh[k]);
+      hn = hh[k] + (dz[k] - dz[k + 1]);
+      if (hn < 0.) bad = true;
+    }
+    if (bad) { atomicOr(flag, 8); return; }
+  }
+#pragma unroll
+  for (int k = 0; k < NK; k++) {
+    h_new[x + (size_t)k * slab] = dmax(0., hh[k] + (dz[k] - dz[k + 1]));
+    dzI[x + (size_t)k * slab] = dz[k];
+  }
+  dzI[x + (size_t)NK * slab] = dz[NK];
 }
 
 // ---- the density-following coordinates (REGRIDDING_RHO, REGRIDDING_HYCOM1) -------------------------------------------------
@@ -1206,6 +1299,10 @@ extern "C" int mom6x_ALE_regrid_zstar(mom6x_ctx *c, const mom6x_regrid_zstar_par
   int rc = ctx_scratch(c, SCR_e, d.nk + 1, &zOld);
   if (rc) return rc;
   const dim3 b(64, 4, 1);
+  if (d.nk == 75) {   // the layer count the on-chip column kernel is built for
+    KLAUNCH_LDS(c, "k_regrid_zstar", (k_regrid_zstar_cols<75>), dim3((unsigned)((nxa(d.ni + 2, -1) + 63) / 64), (unsigned)(d.nj + 2), 1), dim3(64, 1, 1),
+                (size_t)76 * 64 * sizeof(double), d, c->G, *p, c->GV.Z_to_H, (const double *)c->regrid_res, h, h_new, dzRegrid, c->flag);
+  } else
   KLAUNCH(c, "k_regrid_zstar", k_regrid_zstar, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, c->G, *p, c->GV.Z_to_H,
           (const double *)c->regrid_res, h, h_new, dzRegrid, zOld, c->flag);
   int flag = 0;

@@ -132,16 +132,17 @@ def test_rejects_what_is_not_on_the_path(dyc):
         dev_core_h(dyc, CS, [1., 1., 1., 1.], [1., 2., 3., 4.], [2., 2.])
 
 
-@pytest.mark.parametrize("cfg", ["island_basin", "benchmark_small", "channel"])
+@pytest.mark.parametrize("cfg", ["island_basin", "benchmark_small", "channel", "benchmark_75"])
 @pytest.mark.parametrize("mods", [dict(), dict(min_thickness=5.0),
                                   dict(old_grid_weight=0.4, depth_of_time_filter_shallow=200., depth_of_time_filter_deep=900.),
                                   dict(old_grid_weight=0.7)])
 def test_ALE_regrid_zstar_then_remap(orc, cfg, mods):
     """A whole ALE step for the z* coordinate on the device: ALE_regrid (new grid and interface displacements), then the
-    remapping of two tracers and the velocities onto it -- every array bit for bit against the oracle."""
+    remapping of two tracers and the velocities onto it -- every array bit for bit against the oracle.  (benchmark_75: nk = 75 is
+    the layer count of the on-chip column kernel k_regrid_zstar_cols.)"""
     import torch
     from mom6_amd.dycore import Dycore
-    gg, d, M = getattr(H, cfg)(nk=10)
+    gg, d, M = H.benchmark_small(nk=75, ni=70, nj=12) if cfg == "benchmark_75" else getattr(H, cfg)(nk=10)
     GV = abi.vgrid_default()
     h, u, v = synth.make_state(d, M, thin_frac=0.2)
     depth = float(M[G["bathyT"]].max())
