@@ -1111,7 +1111,7 @@ int vertvisc_fused(mom6x_ctx *c, const double *u_in, const double *v_in, const d
 // reference's expression, so the step never has to write and re-read up/vp just for this routine.
 template <int DIR, int MODE>
 __global__ void __launch_bounds__(256)
-k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, const double *__restrict__ u,
+k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, const double *u, double *u_out,
                 const double *__restrict__ u_bc, const double *__restrict__ u_abt, double dtx,
                 const double *__restrict__ h, const double *__restrict__ Kv_bbl, const double *__restrict__ bbl_thick_in,
                 const double *__restrict__ Kv_shear, double *__restrict__ a_out, double *__restrict__ h_out, double H_to_Z,
@@ -1123,7 +1123,11 @@ k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, co
   const int nz = d.nk, st = DIR ? d.pitch : 1;
   const size_t x = ix2(d, i, j), y = x + st, slab = (size_t)d.slab;
   const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
-  if (!(mC > 0.)) return;   // do_i :1514-1516
+  if (!(mC > 0.)) {   // do_i :1514-1516
+    if (u_out && MODE == 2)   // (the velocity estimate the solve that follows starts from, see below: masked faces too)
+      for (int k = 0; k < nz; k++) { const size_t c = x + (size_t)k * slab; u_out[c] = mC * (u[c] + dtx * (u_bc[c] + u_abt[c])); }
+    return;
+  }
   const double *bathyT = gm(G, d, MOM6X_G_bathyT);
   double I_valBL = 0.0; if (CS.harm_BL_val > 0.0) I_valBL = 1.0 / CS.harm_BL_val;
   double I_Hbbl = 1. / (CS.Hbbl + dz_neglect), kv_bbl = 0.0, bbl_thick = 0.0;
@@ -1157,7 +1161,12 @@ k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, co
     const double dz_arith = 0.5 * (dz1 + dz0);
     double uk = u[c];
     if (MODE == 1) uk = mC * (uk + dtx * u_bc[c]);
-    if (MODE == 2) uk = mC * (uk + dtx * (u_bc[c] + u_abt[c]));
+    if (MODE == 2) {
+      uk = mC * (uk + dtx * (u_bc[c] + u_abt[c]));
+      // u_out: this IS the velocity the RK2 step hands to vertvisc next (:681-694 / :957-966); written here, the solve reads one
+      // array instead of three (u_out may be u itself: every thread reads and writes its own column only)
+      if (u_out) u_out[c] = uk;
+    }
     double hvel, dz_vel, z_i_top;
     if (CS.harmonic_visc) {
       hvel = h_harm; dz_vel = dz_harm;
@@ -1269,7 +1278,7 @@ extern "C" double *mom6x_vertvisc_field(mom6x_ctx *c, int which) {
 
 // vertvisc_coef on u, v themselves (mode 0) or on the velocity estimates the RK2 step would hand over (modes 1, 2)
 int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, const double *u_bc, const double *v_bc,
-                      const double *u_abt, const double *v_abt, double dtx, const double *h, double dt) {
+                      const double *u_abt, const double *v_abt, double dtx, const double *h, double dt, double *u_out, double *v_out) {
   REQUIRE(c && c->vv_init, MOM6X_EINVAL, "MOM_vert_friction(coef): Module must be initialized before it is used.");
   REQUIRE(u && v && h, MOM6X_EINVAL, "vertvisc_coef: null array");
   REQUIRE(!c->vv.bottomdraglaw || (c->Kv_bbl_u && c->Kv_bbl_v && c->bbl_thick_u && c->bbl_thick_v), MOM6X_EINVAL,
@@ -1282,9 +1291,9 @@ int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, 
   const double I_amax = (c->vv.answer_date < 20190101) ? (1.0e-10 * GV.H_to_Z) * dt : 0.0;
   const dim3 gu = grid3(nxa(d.ni + 1, -1), d.nj, 1, b), gv = grid3(d.ni, d.nj + 1, 1, b);
 #define VVC(M)                                                                                                                  \
-  KLAUNCH(c, "k_vertvisc_coef<0>", (k_vertvisc_coef<0, M>), gu, b, d, c->G, c->vv, u, u_bc, u_abt, dtx, h, c->Kv_bbl_u, c->bbl_thick_u, \
+  KLAUNCH(c, "k_vertvisc_coef<0>", (k_vertvisc_coef<0, M>), gu, b, d, c->G, c->vv, u, u_out, u_bc, u_abt, dtx, h, c->Kv_bbl_u, c->bbl_thick_u, \
           c->Kv_shear, c->vv_a_u, c->vv_h_u, GV.H_to_Z, GV.H_subroundoff, GV.dZ_subroundoff, a_cpl_max, I_amax);                \
-  KLAUNCH(c, "k_vertvisc_coef<1>", (k_vertvisc_coef<1, M>), gv, b, d, c->G, c->vv, v, v_bc, v_abt, dtx, h, c->Kv_bbl_v, c->bbl_thick_v, \
+  KLAUNCH(c, "k_vertvisc_coef<1>", (k_vertvisc_coef<1, M>), gv, b, d, c->G, c->vv, v, v_out, v_bc, v_abt, dtx, h, c->Kv_bbl_v, c->bbl_thick_v, \
           c->Kv_shear, c->vv_a_v, c->vv_h_v, GV.H_to_Z, GV.H_subroundoff, GV.dZ_subroundoff, a_cpl_max, I_amax)
   if (mode == 0) { VVC(0); } else if (mode == 1) { VVC(1); } else { VVC(2); }
 #undef VVC
@@ -1293,7 +1302,7 @@ int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, 
 }
 
 extern "C" int mom6x_vertvisc_coef(mom6x_ctx *c, const double *u, const double *v, const double *h, double dt) {
-  return vertvisc_coef_upd(c, 0, u, v, nullptr, nullptr, nullptr, nullptr, 0.0, h, dt);
+  return vertvisc_coef_upd(c, 0, u, v, nullptr, nullptr, nullptr, nullptr, 0.0, h, dt, nullptr, nullptr);
 }
 
 extern "C" int mom6x_vertvisc_set_coef(mom6x_ctx *c, const double *a_u, const double *a_v, const double *h_u,
