@@ -94,7 +94,9 @@ __global__ void __launch_bounds__(256)
 k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
             const double *__restrict__ uh, const double *__restrict__ vh, const double *__restrict__ q,
             const double *__restrict__ absv, const double *__restrict__ KE, double *__restrict__ CAu,
-            double *__restrict__ CAv, int scheme, int bound, const double *__restrict__ h, int en_dis) {
+            double *__restrict__ CAv, int scheme, int bound, const double *__restrict__ h, int en_dis,
+            const double *__restrict__ PFu, const double *__restrict__ PFv, const double *__restrict__ diffu,
+            const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc) {
   const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -163,7 +165,9 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
         ca = dmin(ca, max4(fv1, fv2, fv3, fv4));
         ca = dmax(ca, min4(fv1, fv2, fv3, fv4));
       }
-      CAu[c] = ca - (KE[c + 1] - KE[c]) * IdxCu;
+      const double cau = ca - (KE[c + 1] - KE[c]) * IdxCu;
+      CAu[c] = cau;
+      if (u_bc) u_bc[c] = (cau + PFu[c]) + diffu[c];   // u_bc_accel of the RK2 step (:900-907) while CAu is at hand
     }
     if (do_v) {
       const double qm0 = q[c - 1];
@@ -201,7 +205,9 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
         ca = dmin(ca, max4(fu1, fu2, fu3, fu4));
         ca = dmax(ca, min4(fu1, fu2, fu3, fu4));
       }
-      CAv[c] = ca - (KE[c + st] - KE[c]) * IdyCv;
+      const double cav = ca - (KE[c + st] - KE[c]) * IdyCv;
+      CAv[c] = cav;
+      if (v_bc) v_bc[c] = (cav + PFv[c]) + diffv[c];
     }
   }
 }
@@ -477,6 +483,13 @@ static inline dim3 gridk(int nx, int ny, int nk, dim3 b) {
 
 extern "C" int mom6x_CorAdCalc(mom6x_ctx *c, const double *u, const double *v, const double *h, const double *uh,
                                const double *vh, double *CAu, double *CAv) {
+  return CorAdCalc_bc(c, u, v, h, uh, vh, CAu, CAv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// CorAdCalc, and -- for the RK2 step -- u_bc_accel = (CAu + PFu) + diffu (:900-907) formed where CAu is made
+int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h, const double *uh, const double *vh, double *CAu,
+                 double *CAv, const double *PFu, const double *PFv, const double *diffu, const double *diffv, double *u_bc,
+                 double *v_bc) {
   REQUIRE(c && c->cor_init, MOM6X_EINVAL, "MOM_CoriolisAdv: Module must be initialized before it is used.");
   REQUIRE(u && v && h && uh && vh && CAu && CAv, MOM6X_EINVAL, "CorAdCalc: null array");
   REQUIRE(c->dims.halo >= 3, MOM6X_EINVAL, "CorAdCalc: halo >= 3 required");
@@ -492,7 +505,7 @@ extern "C" int mom6x_CorAdCalc(mom6x_ctx *c, const double *u, const double *v, c
   KLAUNCH(c, "k_corad_q", k_corad_q, gridk(nxa(d.ni + 3, -2), d.nj + 3, d.nk, b), b, d, c->G, u, v, h, q, absv, KE,
           c->cor.no_slip, c->cor.KE_Scheme, vol_neglect);
   KLAUNCH(c, "k_corad_acc", k_corad_acc, gridk(nxa(d.ni + 1, -1), d.nj + 1, d.nk, b), b, d, c->G, u, v, uh, vh, q, absv, KE,
-          CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h, c->cor.Coriolis_En_Dis);
+          CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h, c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }

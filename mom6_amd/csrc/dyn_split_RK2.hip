@@ -384,9 +384,8 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   } else if (c->hv_init) {
     CHK(mom6x_horizontal_viscosity(c, u_av, v_av, h_av, s->diffu, s->diffv));
   }
-  CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu, s->CAv));    // :893
-  KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, s->CAu, s->CAv, s->PFu, s->PFv, s->diffu,
-          s->diffv, u_bc, v_bc, (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, dt);   // :900-907
+  // :893 + :900-907: u_bc_accel = (CAu + PFu) + diffu is formed by the kernel that makes CAu
+  CHK(CorAdCalc_bc(c, u_av, v_av, h_av, uh, vh, s->CAu, s->CAv, s->PFu, s->PFv, s->diffu, s->diffv, u_bc, v_bc));
   // corrector btstep :939-942
   CHK(mom6x_btstep(c, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, s->pbce, s->eta_PF, u_av, v_av, s->u_accel_bt,
                    s->v_accel_bt, s->eta_pred, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, &s->BT, taux_bot, tauy_bot, uh, vh,

@@ -127,6 +127,9 @@ int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out);   // ctx.hip
 void hor_visc_free(mom6x_ctx *c);                                  // hor_visc.hip
 void diag_sums_free(mom6x_ctx *c);                                 // diag_sums.hip
 // dyn_kernels.hip: vertvisc_coef looking at u (mode 0), mask*(u + dtx*u_bc) (1) or mask*(u + dtx*(u_bc + u_abt)) (2)
+int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h, const double *uh, const double *vh, double *CAu,
+                 double *CAv, const double *PFu, const double *PFv, const double *diffu, const double *diffv, double *u_bc,
+                 double *v_bc);   // dyn_kernels.hip
 int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, const double *u_bc, const double *v_bc,
                       const double *u_abt, const double *v_abt, double dtx, const double *h, double dt, double *u_out, double *v_out);
 // dyn_kernels.hip: [u = mask*(u_in + dtx*(u_bc + u_abt));] vertvisc(u, v, dt); [vertvisc_remnant(vr_u, vr_v, dt)] in one sweep
