@@ -391,6 +391,7 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
                          P.marginal_faces, visc_rem, A.a0, A.a1, A.b0, A.b1);
     }
   }
+  if (first_pass || !c->cont_h_unused)   // (the second direction's new thicknesses are the routine's result -- unless nobody wants it)
   KLAUNCH(c, "k_convergence<DIR>", k_convergence<DIR>, grid3(nxa(ieh - ish + 1, ish), jeh - jsh + 1, d.nk, blk), blk, d, c->G,
                      h, uh, dt, hin_conv, h_min_conv, ish, ieh, jsh, jeh, c->flag);
   HIPCHK(hipGetLastError());

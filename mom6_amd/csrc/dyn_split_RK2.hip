@@ -322,8 +322,14 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
 
   CHK(mom6x_bt_mass_source(c, h, eta, 1));                              // :629
   // continuity(u, v, h, hp, uh_in, vh_in, dt, visc_rem_u, visc_rem_v, BT_cont)  :646
-  CHK(mom6x_continuity_PPM(c, u_inst, v_inst, h, hp, s->uh_in, s->vh_in, dt, nullptr, nullptr, s->visc_rem_u, s->visc_rem_v,
-                           nullptr, nullptr, &s->BT, nullptr, nullptr));
+  // (hp of this call is never read: :781 overwrites it -- the last convergence is skipped; uh_in, vh_in and BT_cont are the results)
+  c->cont_h_unused = true;
+  {
+    const int rc_c = mom6x_continuity_PPM(c, u_inst, v_inst, h, hp, s->uh_in, s->vh_in, dt, nullptr, nullptr, s->visc_rem_u, s->visc_rem_v,
+                                          nullptr, nullptr, &s->BT, nullptr, nullptr);
+    c->cont_h_unused = false;
+    if (rc_c) return rc_c;
+  }
   halo_complete(c);
   CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :649-652
   if (calc_dtbt) CHK(mom6x_set_dtbt_pbce(c, s->pbce, nullptr));         // :659-668

@@ -98,6 +98,8 @@ struct mom6x_ctx {
   void *comm;               // halo.hip: tile layout + RCCL communicator (null: single tile, wrap only)
   bool halo_error;          // set by a failed halo exchange inside a stream-ordered sequence
   hipEvent_t ev_ready, ev_done; bool pass_pending;   // halo.hip: the group pass in flight on the halo stream (start_/complete_group_pass)
+  bool cont_h_unused;       // the caller of continuity_PPM does not look at the new thicknesses (RK2.F90:646: hp is overwritten at :781
+                            // before anybody reads it): the convergence of the second direction is not computed
 };
 void comm_free(mom6x_ctx *c);                                         // halo.hip
 void halo_start(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);   // start_group_pass
