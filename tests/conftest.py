@@ -18,3 +18,21 @@ def orc():
     from oracle import orc as _orc
     _orc.build()
     return _orc
+
+
+@pytest.fixture(params=["tree", "exact"])
+def sums(request, monkeypatch):
+    """Both orders of the mass-flux column sums (mom6x_continuity_params.sum_order, abi.default_sum_order): "tree" = the
+    default of the device (MOM6X_SUM_TREE16, the wave-owned kernel), "exact" = the reference's sequential k order
+    (MOM6X_SUM_REFERENCE, the LDS kernel).  The oracle follows the same switch, so "exact" cases are held to the
+    REFERENCE-order restatement bit for bit."""
+    monkeypatch.setenv("MOM6X_SUMS", request.param)
+    return request.param
+
+
+def pytest_terminal_summary(terminalreporter):
+    from tests import helpers as H
+    if H.SIGNED_ZERO_LOG:
+        tot = sum(H.SIGNED_ZERO_LOG.values())
+        terminalreporter.write_line(f"assert_bitwise: {tot} zeros of opposite sign accepted (sum_order TREE16 only): "
+                                    + ", ".join(f"{k}={v}" for k, v in sorted(H.SIGNED_ZERO_LOG.items())[:12]))

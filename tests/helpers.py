@@ -80,16 +80,49 @@ def interior(d, stagger="h", extra=0):
     return d.sl(-1 - e, d.ni - 1 + e, -1 - e, d.nj - 1 + e)
 
 
-def assert_bitwise(a, b, name, sl=None):
-    a = np.asarray(a); b = np.asarray(b)
+# Signed zeros.  np.array_equal says -0.0 == +0.0; the artefacts the reference's .testing compares (chksum bit counts,
+# restart checksums) do not.  assert_bitwise therefore compares BIT PATTERNS.  The one place where the sign of a zero is
+# allowed to differ is the wave-owned mass-flux kernel (continuity_wave.hip is built with -fno-signed-zeros, sum_order =
+# TREE16): there a (+0, -0) pair is accepted and COUNTED (SIGNED_ZERO_LOG, printed at the end of the
+# session by conftest.py); with the reference's order (MOM6X_SUMS=exact) no allowance is made.
+SIGNED_ZERO_LOG = {}
+
+
+def signed_zero_allowed():
+    return abi.default_sum_order(1) == abi.SUM_TREE16
+
+
+def assert_bitwise(a, b, name, sl=None, signed_zero_ok=None):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
     if sl is not None:
-        a = a[(Ellipsis,) + tuple(sl)]; b = b[(Ellipsis,) + tuple(sl)]
-    if not np.array_equal(a, b):
-        diff = np.abs(a - b)
+        a = np.ascontiguousarray(a[(Ellipsis,) + tuple(sl)]); b = np.ascontiguousarray(b[(Ellipsis,) + tuple(sl)])
+    assert a.shape == b.shape and a.dtype == b.dtype, f"{name}: {a.shape} {a.dtype} vs {b.shape} {b.dtype}"
+    if a.dtype == np.float64:
+        ne = a.view(np.int64) != b.view(np.int64)
+    else:
+        ne = a != b
+    if not ne.any():
+        return
+    if a.dtype == np.float64:
+        z = ne & (a == 0.0) & (b == 0.0)          # the two zeros of opposite sign
+        nz = int(np.count_nonzero(z))
+        if nz and name.startswith("rotate:"):
+            ne = ne & ~z                          # a quarter turn negates a velocity component: -(+0) = -0 is the turn itself
+        elif nz:
+            if signed_zero_ok is None:
+                signed_zero_ok = signed_zero_allowed()
+            if not signed_zero_ok:
+                idx = np.unravel_index(np.argmax(z), z.shape)
+                raise AssertionError(f"{name}: {nz} zeros of opposite sign (first at {idx}: {a[idx]!r} vs {b[idx]!r})")
+            SIGNED_ZERO_LOG[name] = SIGNED_ZERO_LOG.get(name, 0) + nz
+            ne = ne & ~z
+    if ne.any():
+        with np.errstate(invalid="ignore"):
+            diff = np.where(ne, np.abs(a - b), 0.0)
         idx = np.unravel_index(np.argmax(diff), diff.shape)
         scale = max(np.abs(b).max(), 1e-300)
         raise AssertionError(f"{name}: not bit-identical; max|diff|={diff.max():.3e} (rel {diff.max()/scale:.3e}) "
-                             f"at {idx}: {a[idx]!r} vs {b[idx]!r}; n_diff={np.count_nonzero(a != b)}")
+                             f"at {idx}: {a[idx]!r} vs {b[idx]!r}; n_diff={np.count_nonzero(ne)}")
 
 
 def assert_close(a, b, name, rtol, sl=None):

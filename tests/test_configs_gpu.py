@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 G = abi.G
 
 
-def test_config2_benchmark_360x180x75_rk2_step(orc):
+def test_config2_benchmark_360x180x75_rk2_step(orc, sums):
     """One whole baroclinic step with every callee on the device (vertvisc_coef, horizontal_viscosity) -- bit for bit."""
     from tests.test_rk2_gpu import run
     from tests import cases

@@ -89,6 +89,17 @@ def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors, rich=Fals
                                                   ("island_basin", (2, 2), True), ("channel", (2, 1), True),
                                                   ("channel", (4, 2), False), ("benchmark_small", (4, 2), True)])   # the 8-GPU layout
 def test_tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich):
+    _layout_case(cfg_name, layout, rich)
+
+
+@pytest.mark.parametrize("cfg_name,layout,rich", [("double_gyre", (2, 2), False), ("benchmark_small", (4, 2), True)])
+def test_tile_layout_in_the_reference_sum_order(cfg_name, layout, rich, monkeypatch):
+    """The same with MOM6X_SUMS=exact: the LDS mass-flux kernel (sequential k sums) next to interior tile edges."""
+    monkeypatch.setenv("MOM6X_SUMS", "exact")
+    _layout_case(cfg_name, layout, rich)
+
+
+def _layout_case(cfg_name, layout, rich):
     from mom6_amd.abi import load_library
     H.use_threads_transport(load_library())
     try:

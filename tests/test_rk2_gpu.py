@@ -13,6 +13,15 @@ from tests.test_dyn_gpu import visc_coefs
 pytestmark = pytest.mark.gpu
 G = abi.G
 
+
+@pytest.fixture(autouse=True)
+def _both_sum_orders(sums):
+    """Every whole-step case runs twice: with the device's default order of the mass-flux column sums (TREE16, held to the
+    oracle's restatement of that tree) and with MOM6X_SUMS=exact, i.e. the REFERENCE order of MOM_continuity_PPM.F90
+    :1093-1242, :1293-1316 on both sides -- the device bit for bit against the sequential-k oracle (tests/conftest.py)."""
+    return sums
+
+
 STATE = ["u", "v", "h", "uh", "vh", "uhtr", "vhtr", "eta_av"]
 STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h", CAu="u", CAv="v", CAu_pred="u", CAv_pred="v",
             PFu="u", PFv="v", diffu="u", diffv="v", visc_rem_u="u", visc_rem_v="v", u_accel_bt="u", v_accel_bt="v", u_av="u", v_av="v", h_av="h",
@@ -20,7 +29,7 @@ STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h",
 
 
 def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, per_stage=False, new_diff=False,
-        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None, Hmix_stress=0.0, recon=0):
+        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None, Hmix_stress=0.0, recon=0, chk=False):
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
@@ -117,6 +126,13 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
     vol0 = (h[(Ellipsis,) + sl] * A).sum(); vol1 = (sg["h"].cpu().numpy()[(Ellipsis,) + sl] * A).sum()
     assert abs(vol1 / vol0 - 1.0) < 1e-13
     out = {n: sg[n].cpu().numpy() for n in STATE}
+    if chk:   # the artefacts .testing compares: chksum lines (mean / min / max + bit counts) and the restart checksum attribute
+        for n in STATE:
+            a = sg[n]; st = STAG[n]
+            got = dyc.chksum(a, st, haloshift=0); got.pop("kind")
+            assert got == orc.chksum(d, so[n], st, haloshift=0), ("chksum", n, got)
+            r = dict(h=(0, d.ni - 1, 0, d.nj - 1), u=(-1, d.ni - 1, 0, d.nj - 1), v=(0, d.ni - 1, -1, d.nj - 1))[st]
+            assert dyc.field_chksum(a, *r) == orc.field_chksum(d, so[n], *r), ("restart checksum", n)
     dyc.close()
     return out
 
@@ -124,6 +140,17 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
 @pytest.mark.parametrize("first_direction", [0, 1])
 def test_rk2_double_gyre_bitexact(orc, first_direction):
     run(orc, H.double_gyre(), nsteps=3, bt_mod=dict(strong_drag=1), first_direction=first_direction)
+
+
+@pytest.mark.parametrize("cfg", ["double_gyre", "channel", "island_basin"])
+def test_rk2_checksum_artefacts_equal_the_oracles(orc, cfg):
+    """What the reference's regression tests actually diff are checksums: the chksum lines (reproducing mean, min, max and
+    the BIT COUNT of the field, MOM_checksums.F90) and the restart files' `checksum` attribute (the integer sum of the bit
+    patterns).  Both see the sign of a zero.  After three steps they equal the oracle's in either order of the sums --
+    in the REFERENCE order with no allowance at all (assert_bitwise compares bit patterns there), in the TREE16 order
+    (continuity_wave.hip is built with -fno-signed-zeros) because no transport of these cases is a zero of either sign
+    off the masked faces, which this test is there to notice if it changes."""
+    run(orc, getattr(H, cfg)(), nsteps=3, bt_mod=dict(strong_drag=1), chk=True)
 
 
 def test_rk2_channel_bitexact_tc1_like(orc):

@@ -16,7 +16,7 @@ G = abi.G
 
 
 @pytest.mark.parametrize("cfg_name,remap_aux", [("benchmark_small", 1), ("island_basin", 0)])
-def test_dynamics_tracers_ALE_cycle(orc, cfg_name, remap_aux):
+def test_dynamics_tracers_ALE_cycle(orc, cfg_name, remap_aux, sums):
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
