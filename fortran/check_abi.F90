@@ -41,6 +41,9 @@ program check_abi
   call chk(15, int(c_sizeof(sp)), "mom6x_sum_output_params")
   call chk(16, int(c_sizeof(es)), "mom6x_energy_sums")
   call chk(17, int(c_sizeof(rr)), "mom6x_regrid_rho_params")
+  if (mom6x_abi_version() /= MOM6X_ABI_BUILT_FOR) then
+    print '(a,i0,a,i0)', "ABI version: library ", mom6x_abi_version(), ", fortran/mom6x_c_api.F90 ", MOM6X_ABI_BUILT_FOR ; nbad = nbad + 1
+  endif
   rc = mom6x_dims_init(d, 1440, 1080, 75, 4)
   if (rc /= 0 .or. d%pitch /= 1472 .or. d%ioff /= 16) then
     print *, "mom6x_dims_init mismatch", rc, d%pitch, d%ioff ; nbad = nbad + 1

@@ -28,6 +28,12 @@ module mom6x_c_api
   public :: mom6x_initialize_dyn_split_RK2, mom6x_dyn_split_RK2_new_run, mom6x_rk2_field, mom6x_rk2_set_CAu_pred_stored
   public :: mom6x_step_dyn_split_RK2, mom6x_comm_unique_id, mom6x_comm_init, mom6x_pass_fields
   public :: mom6x_transport, mom6x_comm_set_transport
+  public :: mom6x_abi_version, mom6x_device_count, MOM6X_ABI_BUILT_FOR, mom6x_barotropic_field
+  public :: mom6x_tracer_advect_init, mom6x_advect_tracer, mom6x_triDiagTS, mom6x_triDiagTS_Eulerian
+  public :: mom6x_tracer_vertdiff, mom6x_tracer_vertdiff_Eulerian, mom6x_diabatic_is_trivial
+
+  !> include/mom6x.h MOM6X_ABI_VERSION this module mirrors; a host compares it with mom6x_abi_version() at start-up
+  integer(c_int), parameter :: MOM6X_ABI_BUILT_FOR = 2
 
   !> mom6x_dims: hor_index_type extents (MOM_hor_index.F90:14-44) + the device layout
   type, bind(C) :: mom6x_dims
@@ -164,6 +170,16 @@ module mom6x_c_api
   end type mom6x_rk2_hooks
 
   interface
+    integer(c_int) function mom6x_abi_version() bind(C, name="mom6x_abi_version")
+      import :: c_int
+    end function
+    integer(c_int) function mom6x_device_count() bind(C, name="mom6x_device_count")
+      import :: c_int
+    end function
+    !> ubtav (0), vbtav (1), ... of barotropic_CS: the arrays register_barotropic_restarts (MOM_barotropic.F90:6253) registers
+    type(c_ptr) function mom6x_barotropic_field(ctx, which) bind(C, name="mom6x_barotropic_field")
+      import :: c_ptr, c_int ; type(c_ptr), value :: ctx ; integer(c_int), value :: which
+    end function
     integer(c_int) function mom6x_struct_size(which) bind(C, name="mom6x_struct_size")
       import :: c_int ; integer(c_int), value :: which
     end function

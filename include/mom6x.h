@@ -38,7 +38,10 @@
 extern "C" {
 #endif
 
-#define MOM6X_ABI_VERSION 1
+/* 2: mom6x_continuity_params.sum_order, the Leith members of mom6x_hor_visc_params, Recon_Scheme / boundary_extrap /
+ * h_nonvanished of mom6x_eos_params, mom6x_device_count (round 3).  Hosts compare mom6x_abi_version() with the value they were
+ * built against (fortran/mom6x_c_api.F90 MOM6X_ABI_BUILT_FOR, mom6_amd/abi.py ABI_VERSION) and refuse to run on a mismatch. */
+#define MOM6X_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------- */
 /* Tile dimensions and layout (MOM_hor_index.F90:14-44 hor_index_type +
@@ -286,6 +289,8 @@ typedef struct mom6x_ctx mom6x_ctx;
 
 const char *mom6x_last_error(void);
 int  mom6x_abi_version(void);
+/* hipGetDeviceCount: lets a host with one process per GPU pick its device as (local rank) mod (count).  < 0 on error. */
+int  mom6x_device_count(void);
 /* sizeof() of the public structs (0 dims, 1 vgrid, 2 continuity_params, 3 BT_cont, 4 barotropic_params,
  * 5 coriolis_params, 6 pgf_params, 7 rk2_params, 8 rk2_hooks, 9 eos_params, 10 vertvisc_params, 11 hor_visc_params,
  * 12 remapping_params, 13 regrid_zstar_params): lets ctypes / ISO_C_BINDING mirrors be checked at start-up.  */

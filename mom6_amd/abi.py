@@ -395,6 +395,9 @@ MOM6X_OK = 0
 _lib = None
 
 
+ABI_VERSION = 2   # include/mom6x.h MOM6X_ABI_VERSION
+
+
 def load_library(path=None):
     """Load the HIP C-ABI shared library.  Raises (never falls back) if it is absent."""
     global _lib
@@ -406,6 +409,9 @@ def load_library(path=None):
             f"mom6_amd: HIP extension {p} is missing; run `python -c 'import __graft_entry__ as g; g.build()'`. "
             "There is no CPU fallback for the product path.")
     lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    if lib.mom6x_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"mom6_amd: {p} has ABI version {lib.mom6x_abi_version()}, this host mirror was written for "
+                           f"{ABI_VERSION} (include/mom6x.h MOM6X_ABI_VERSION); rebuild the library")
     lib.mom6x_last_error.restype = C.c_char_p
     lib.mom6x_ctx_stream.restype = C.c_void_p
     lib.mom6x_ctx_dims.restype = C.POINTER(Dims)

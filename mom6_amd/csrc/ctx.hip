@@ -108,6 +108,11 @@ void mom6x_set_error(const char *fmt, ...) {
 
 extern "C" const char *mom6x_last_error(void) { return g_err; }
 extern "C" int mom6x_abi_version(void) { return MOM6X_ABI_VERSION; }
+extern "C" int mom6x_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { mom6x_set_error("mom6x_device_count: hipGetDeviceCount failed"); return -1; }
+  return n;
+}
 
 // sizeof() of the public structs, so that non-C hosts (ctypes, ISO_C_BINDING) can verify their mirrors.
 extern "C" int mom6x_struct_size(int which) {

@@ -43,6 +43,11 @@ def write_set():
     out, _, _ = cases.oracle_continuity(orc, cfg, cases.continuity_inputs(cfg))
     np.savez_compressed(H.golden_path("continuity_benchmark_small_corrector" + tag),
                         **{n: out[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))] for n in out})
+    cfg = H.double_gyre()
+    d = cfg[1]
+    so, _, _, _ = cases.oracle_shim_case(orc, cfg)       # the case of tests/fortran_stubs/drive_shims.F90
+    np.savez_compressed(H.golden_path("rk2_double_gyre_shims_4steps" + tag),
+                        **{n: so[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))] for n in so})
     lines = cases.oracle_ocean_stats(orc, H.double_gyre(), 3, dict(strong_drag=1))
     with open(H.golden_path("ocean.stats.double_gyre_strong_drag_3steps" + tag, ""), "w") as f:
         f.write("\n".join(lines) + "\n")

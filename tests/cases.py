@@ -119,3 +119,29 @@ def oracle_ocean_stats(orc, cfg, nsteps=3, bt_mod=None):
         s = oracle_rk2(orc, cfg, inp, n, bt_mod, None, None, 0)[0]
         so.record(orc.write_energy(st, s["u"], s["v"], s["h"]), dt * n, n)
     return so.lines
+
+
+# ---- the case of tests/fortran_stubs/drive_shims.F90: the split-RK2 step behind the Fortran shim modules.  The shims always
+# run vertvisc_coef and horizontal_viscosity on the device, so the oracle run does too; the MOM_input table below is what the
+# driver's stand-in for the parameter file answers get_param with (everything else takes the reference's default).
+SHIM_NSTEPS, SHIM_SAVE_AFTER = 4, 2
+
+
+def shim_case_params(dt, tag_tree):
+    # (DTBT keeps its default -0.98: a fraction of the stability limit, set by the first step's set_dtbt as in the oracle's run)
+    return {"DT": repr(dt), "BT_STRONG_DRAG": "True", "KV": "1.0e-4", "HMIX_FIXED": "20.0", "HBBL": "10.0",
+            "AH_VEL_SCALE": "0.02", "SMAGORINSKY_AH": "True", "SMAG_BI_CONST": "0.06", "REENTRANT_X": "False",
+            "ENABLE_THERMODYNAMICS": "False", "MOM6X_CONTINUITY_SUMS": "TREE16" if tag_tree else "REFERENCE"}
+
+
+def oracle_shim_case(orc, cfg, nsteps=SHIM_NSTEPS):
+    """The oracle's run of the case above: (final state, OrcModel, inputs, visc inputs)."""
+    from tests.test_dyn_gpu import visc_inputs
+    gg, d, M = cfg
+    inp = rk2_inputs(cfg, False, False)
+    P = abi.vertvisc_params_default(Kv=1.0e-4, Hmix=20.0, Hbbl=10.0)
+    vis = visc_inputs(d, M)
+    hv = abi.hor_visc_params_default(inp["dt"])
+    hv.Ah_vel_scale = 0.02; hv.Smagorinsky_Ah = 1; hv.Smag_bi_const = 0.06
+    so, m = oracle_rk2(orc, cfg, inp, nsteps, bt_mod=dict(strong_drag=1), vv=(P,) + tuple(vis) + (None, None), hv=hv)
+    return so, m, inp, vis

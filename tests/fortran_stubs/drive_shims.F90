@@ -1,0 +1,306 @@
+!> tests/fortran_stubs/drive_shims.F90 -- a miniature of what MOM.F90 does with the dynamical core, driving the SHIM MODULES of
+!! fortran/shims/ (module MOM_dynamics_split_RK2 and, through it, MOM_continuity_PPM, MOM_barotropic, MOM_CoriolisAdv,
+!! MOM_PressureForce, MOM_vert_friction; then MOM_tracer_advect and mom6x_diabatic_solvers directly) on the GPU, against the
+!! interface stand-ins of mom_stubs.F90.  TEST INFRASTRUCTURE.  The case (grid, parameters as a MOM_input-like table, state,
+!! set_viscous_BBL fields, forcing, expected final state) is written by tests/test_fortran_gpu.py.
+!!
+!!   run A   register_restarts -> initialize (new run) -> nsteps x step_MOM_dyn_split_RK2            == expected, bit for bit
+!!   run B   the same for `save_after` steps, then what save_restart does with the registry -> a file; end_dyn_split_RK2
+!!   run C   register_restarts -> restore_state from the file -> initialize (restart branch: mirrors uploaded, DTBT kept,
+!!           CAu_pred marked as stored) -> the remaining steps                                       == expected, bit for bit
+!!   then    one advect_tracer call (uhr_out / vhr_out honoured) and one tracer_vertdiff call through their shims: a uniform
+!!           tracer stays uniform, the leftover transports are finite and smaller than the transports.
+!! Exit code 0 and the word PASS only if everything holds.  Usage: drive_shims <case.bin> <scratch restart file> [resident]
+program drive_shims
+  use, intrinsic :: iso_c_binding
+  use MOM_coms, only : stub_npes
+  use MOM_cpu_clock, only : stub_clock_calls, stub_clock_names, stub_nclocks
+  use MOM_diag_mediator, only : diag_ctrl
+  use MOM_domains, only : MOM_domain_type
+  use MOM_dynamics_split_RK2
+  use MOM_ALE, only : ALE_CS
+  use MOM_file_parser, only : param_file_type, stub_set_param
+  use MOM_forcing_type, only : mech_forcing
+  use MOM_get_input, only : directories
+  use MOM_grid, only : ocean_grid_type
+  use MOM_harmonic_analysis, only : harmonic_analysis_CS
+  use MOM_hor_index, only : hor_index_type
+  use MOM_MEKE_types, only : MEKE_type
+  use MOM_lateral_mixing_coeffs, only : VarMix_CS
+  use MOM_open_boundary, only : ocean_OBC_type, update_OBC_CS
+  use MOM_porous_barriers, only : porous_barrier_type
+  use MOM_restart, only : MOM_restart_CS, register_restart_field, stub_save_restart, stub_restore_state, stub_restart_names
+  use MOM_set_visc, only : set_visc_CS
+  use MOM_stochastics, only : stochastic_CS
+  use MOM_thickness_diffuse, only : thickness_diffuse_CS
+  use MOM_time_manager, only : time_type
+  use MOM_tracer_advect, only : advect_tracer, tracer_advect_init, tracer_advect_end, tracer_advect_CS
+  use MOM_tracer_registry, only : tracer_registry_type
+  use MOM_unit_scaling, only : unit_scale_type
+  use MOM_variables, only : thermo_var_ptrs, vertvisc_type, ocean_internal_state, accel_diag_ptrs, cont_diag_ptrs
+  use MOM_verticalGrid, only : verticalGrid_type
+  use mom6x_diabatic_solvers, only : tracer_vertdiff
+  implicit none
+  character(len=512) :: path, rpath, mode
+  integer :: un, ni, nj, nk, halo, nsteps, save_after, first_direction, nmet, nparams, magic, m, n, nbad
+  real :: dt, gvs(9)
+  character(len=48) :: pname ; character(len=64) :: pvalue
+  type(ocean_grid_type), target :: G
+  type(MOM_domain_type), target :: Dom
+  type(hor_index_type) :: HI
+  type(verticalGrid_type) :: GV
+  type(unit_scale_type) :: US
+  type(param_file_type) :: PF
+  type(time_type), target :: Time
+  type(diag_ctrl), target :: diag
+  type(thermo_var_ptrs) :: tv
+  type(vertvisc_type) :: visc
+  type(mech_forcing) :: forces
+  type(accel_diag_ptrs), target :: ADp
+  type(cont_diag_ptrs), target :: CDp
+  type(ocean_internal_state) :: MIS
+  type(VarMix_CS) :: VarMix ; type(MEKE_type) :: MEKE ; type(thickness_diffuse_CS) :: TD ; type(porous_barrier_type) :: pbv
+  type(stochastic_CS) :: STOCH ; type(set_visc_CS), target :: set_visc ; type(directories) :: dirs
+  type(ocean_OBC_type), pointer :: OBC => NULL() ; type(update_OBC_CS), pointer :: update_OBC => NULL()
+  type(ALE_CS), pointer :: ALE_CSp => NULL() ; type(harmonic_analysis_CS), pointer :: HA_CSp => NULL()
+  type(MOM_dyn_split_RK2_CS), pointer :: CS => NULL()
+  type(MOM_restart_CS) :: RCS
+  real, pointer :: p_surf_begin(:,:) => NULL(), p_surf_end(:,:) => NULL()
+  real, allocatable, target :: u(:,:,:), v(:,:,:), h(:,:,:), uh(:,:,:), vh(:,:,:), uhtr(:,:,:), vhtr(:,:,:), eta_av(:,:), eta(:,:)
+  real, allocatable, target :: u0(:,:,:), v0(:,:,:), h0(:,:,:), taux(:,:), tauy(:,:)
+  real, allocatable :: xu(:,:,:), xv(:,:,:), xh(:,:,:), xuh(:,:,:), xvh(:,:,:), xuhtr(:,:,:), xvhtr(:,:,:), xeta(:,:)
+  integer, target :: ntrunc
+  integer :: cont_stencil
+  logical :: calc_dtbt, resident
+
+  call get_command_argument(1, path) ; call get_command_argument(2, rpath) ; call get_command_argument(3, mode)
+  if (len_trim(path) == 0 .or. len_trim(rpath) == 0) error stop "usage: drive_shims <case.bin> <scratch restart file> [resident]"
+  resident = (trim(mode) == "resident")
+  open(newunit=un, file=trim(path), access="stream", form="unformatted", status="old", action="read")
+  read(un) magic, ni, nj, nk, halo, nsteps, save_after, first_direction, nmet, nparams
+  if (magic /= 1297042743) error stop "not a shim case file"
+  read(un) dt ; read(un) gvs
+  ! ---- verticalGrid_type, unit_scale_type (all scaling factors 1) ---------------------------------------------------------
+  GV%ke = nk ; GV%g_Earth = gvs(1) ; GV%Rho0 = gvs(2) ; GV%Angstrom_H = gvs(3) ; GV%Angstrom_Z = gvs(3) ; GV%Angstrom_m = gvs(3)
+  GV%H_subroundoff = gvs(4) ; GV%dZ_subroundoff = gvs(5) ; GV%H_to_Z = gvs(6) ; GV%Z_to_H = gvs(7) ; GV%H_to_RZ = gvs(8) ; GV%RZ_to_H = gvs(9)
+  allocate(GV%Rlay(nk), GV%g_prime(nk)) ; read(un) GV%Rlay ; read(un) GV%g_prime
+  do m = 1, nparams ; read(un) pname, pvalue ; call stub_set_param(PF, trim(pname), trim(pvalue)) ; enddo
+  if (resident) call stub_set_param(PF, "MOM6X_RESIDENT_STATE", "True")
+  ! ---- ocean_grid_type with MOM6's symmetric-memory index conventions (isc = halo + 1, IsdB = isd - 1) ---------------------
+  G%isc = halo + 1 ; G%iec = halo + ni ; G%jsc = halo + 1 ; G%jec = halo + nj
+  G%isd = 1 ; G%ied = ni + 2*halo ; G%jsd = 1 ; G%jed = nj + 2*halo
+  G%IscB = G%isc - 1 ; G%IecB = G%iec ; G%JscB = G%jsc - 1 ; G%JecB = G%jec
+  G%IsdB = G%isd - 1 ; G%IedB = G%ied ; G%JsdB = G%jsd - 1 ; G%JedB = G%jed ; G%ke = nk
+  G%first_direction = first_direction ; G%symmetric = .true.
+  Dom%niglobal = ni ; Dom%njglobal = nj ; Dom%nihalo = halo ; Dom%njhalo = halo ; Dom%layout = (/ 1, 1 /) ; G%Domain => Dom
+  HI%isc = G%isc ; HI%iec = G%iec ; HI%jsc = G%jsc ; HI%jec = G%jec ; HI%isd = G%isd ; HI%ied = G%ied ; HI%jsd = G%jsd ; HI%jed = G%jed
+  HI%IscB = G%IscB ; HI%IecB = G%IecB ; HI%JscB = G%JscB ; HI%JecB = G%JecB
+  HI%IsdB = G%IsdB ; HI%IedB = G%IedB ; HI%JsdB = G%JsdB ; HI%JedB = G%JedB ; G%HI = HI
+  if (nmet /= 33) error stop "the case file has a different number of metric planes than this driver reads"
+  call rd2(G%mask2dT, 0) ; call rd2(G%mask2dCu, 1) ; call rd2(G%mask2dCv, 2) ; call rd2(G%mask2dBu, 3)
+  call rd2(G%dxT, 0) ; call rd2(G%dyT, 0) ; call rd2(G%IdxT, 0) ; call rd2(G%IdyT, 0)
+  call rd2(G%dxCu, 1) ; call rd2(G%dyCu, 1) ; call rd2(G%IdxCu, 1) ; call rd2(G%IdyCu, 1)
+  call rd2(G%dxCv, 2) ; call rd2(G%dyCv, 2) ; call rd2(G%IdxCv, 2) ; call rd2(G%IdyCv, 2)
+  call rd2(G%dxBu, 3) ; call rd2(G%dyBu, 3) ; call rd2(G%IdxBu, 3) ; call rd2(G%IdyBu, 3)
+  call rd2(G%areaT, 0) ; call rd2(G%IareaT, 0) ; call rd2(G%areaBu, 3) ; call rd2(G%IareaBu, 3)
+  call rd2(G%areaCu, 1) ; call rd2(G%areaCv, 2) ; call rd2(G%IareaCu, 1) ; call rd2(G%IareaCv, 2)
+  call rd2(G%dy_Cu, 1) ; call rd2(G%dx_Cv, 2) ; call rd2(G%bathyT, 0) ; call rd2(G%CoriolisBu, 3) ; call rd2(G%Coriolis2Bu, 3)
+  ! ---- state, set_viscous_BBL outputs, forcing, expected results ---------------------------------------------------------------
+  call rd3(u0, 1, nk) ; call rd3(v0, 2, nk) ; call rd3(h0, 0, nk)
+  call rd2(visc%Kv_bbl_u, 1) ; call rd2(visc%Kv_bbl_v, 2) ; call rd2(visc%bbl_thick_u, 1) ; call rd2(visc%bbl_thick_v, 2)
+  call rd3(visc%Kv_shear, 0, nk + 1)
+  call rd2(taux, 1) ; call rd2(tauy, 2)
+  forces%taux => taux ; forces%tauy => tauy
+  allocate(xu(ni+1,nj,nk), xv(ni,nj+1,nk), xh(ni,nj,nk), xuh(ni+1,nj,nk), xvh(ni,nj+1,nk), xuhtr(ni+1,nj,nk), xvhtr(ni,nj+1,nk), xeta(ni,nj))
+  read(un) xu ; read(un) xv ; read(un) xh ; read(un) xuh ; read(un) xvh ; read(un) xuhtr ; read(un) xvhtr ; read(un) xeta
+  close(un)
+  call al3(u, 1) ; call al3(v, 2) ; call al3(h, 0) ; call al3(uh, 1) ; call al3(vh, 2) ; call al3(uhtr, 1) ; call al3(vhtr, 2)
+  allocate(eta_av(G%isd:G%ied,G%jsd:G%jed), eta(G%isd:G%ied,G%jsd:G%jed))
+  nbad = 0
+
+  ! =================================== run A: uninterrupted ====================================================================
+  call fresh_state()
+  call start_model(restore=.false.)
+  do n = 1, nsteps ; call one_step(n) ; enddo
+  call finish_host_view()
+  call compare_all("A (uninterrupted)")
+  call stop_model()
+
+  ! =================================== run B: save_after steps, save_restart, end ==============================================
+  call fresh_state()
+  call start_model(restore=.false.)
+  do n = 1, save_after ; call one_step(n) ; enddo
+  call finish_host_view()
+  if (resident) call refresh_host_mirrors(CS, G, GV)      ! what MOM.F90 does before save_restart in the resident mode
+  print '(a)', "registered restart variables:"//trim(stub_restart_names(RCS))
+  call stub_save_restart(RCS, trim(rpath))
+  call stop_model()
+
+  ! =================================== run C: restore_state, the remaining steps ==============================================
+  u = 0.0 ; v = 0.0 ; h = GV%Angstrom_H ; uh = 0.0 ; vh = 0.0 ; eta_av = 0.0 ; eta = 0.0
+  ! uhtr, vhtr are not restart variables: MOM.F90 zeroes them after every tracer step; here they carry on from run B
+  call start_model(restore=.true.)
+  ! (DTBT is a fraction here: barotropic_init keeps the file's DTBT and, by the reference's rule MOM_barotropic.F90:5970, still
+  !  asks for one set_dtbt -- which returns the same value, pbce of the layered pressure force being independent of the state)
+  if (.not.calc_dtbt) then ; print '(a)', "FAIL: calc_dtbt must be true unless DTBT is fixed AND in the restart file" ; nbad = nbad + 1 ; endif
+  do n = save_after + 1, nsteps ; call one_step(n) ; enddo
+  call finish_host_view()
+  call compare_all("C (restarted)")
+  call check_clocks()
+  call tracer_checks()
+  call stop_model()
+
+  if (nbad == 0) then
+    print '(a)', "PASS"
+  else
+    print '(a,i0)', "FAILED checks: ", nbad ; error stop 1
+  endif
+
+contains
+
+  subroutine fresh_state()
+    u = u0 ; v = v0 ; h = h0 ; uh = 0.0 ; vh = 0.0 ; uhtr = 0.0 ; vhtr = 0.0 ; eta_av = 0.0 ; eta = 0.0
+  end subroutine fresh_state
+
+  !> MOM.F90's initialisation order for this module: the restart registrations (u, v, h are MOM.F90's own), restore_state on
+  !! a restarted run, then initialize_dyn_split_RK2.
+  subroutine start_model(restore)
+    logical, intent(in) :: restore
+    type(MOM_restart_CS) :: fresh
+    RCS = fresh
+    call register_restart_field(u, "u", .true., RCS) ; call register_restart_field(v, "v", .true., RCS)
+    call register_restart_field(h, "h", .true., RCS)
+    call register_restarts_dyn_split_RK2(HI, GV, US, PF, CS, RCS, uh, vh)
+    if (restore) call stub_restore_state(RCS, trim(rpath))
+    call initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, PF, diag, CS, HA_CSp, RCS, dt, ADp, CDp, MIS, &
+                                  VarMix, MEKE, TD, OBC, update_OBC, ALE_CSp, set_visc, visc, dirs, ntrunc, pbv, calc_dtbt, cont_stencil)
+    if (cont_stencil /= 3) then ; print '(a,i0)', "FAIL: continuity_stencil = ", cont_stencil ; nbad = nbad + 1 ; endif
+    if (resident) call dyn_split_RK2_host_changed(CS)     ! the host's uhtr, vhtr (carried over a restart here) are newer
+  end subroutine start_model
+
+  subroutine one_step(n)
+    integer, intent(in) :: n
+    logical :: cd
+    cd = calc_dtbt .and. (n == 1 .or. n == save_after + 1)     ! MOM.F90:1297-1301: only the first step after initialisation
+    call step_MOM_dyn_split_RK2(u, v, h, tv, visc, Time, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av, &
+                                G, GV, US, CS, cd, VarMix, MEKE, TD, pbv, STOCH)
+    calc_dtbt = .false.
+  end subroutine one_step
+
+  !> In the resident mode the host asks for the state where it reads it (here: before comparing / saving)
+  subroutine finish_host_view()
+    if (resident) call dyn_split_RK2_sync_host(CS, u, v, h, uh, vh, uhtr, vhtr, eta_av)
+  end subroutine finish_host_view
+
+  subroutine stop_model()
+    call end_dyn_split_RK2(CS)
+    if (associated(CS)) then ; print '(a)', "FAIL: end_dyn_split_RK2 left CS associated" ; nbad = nbad + 1 ; endif
+  end subroutine stop_model
+
+  subroutine compare_all(tag)
+    character(len=*), intent(in) :: tag
+    call cmp3(tag//" u", u(G%IscB:G%IecB,G%jsc:G%jec,:), xu) ; call cmp3(tag//" v", v(G%isc:G%iec,G%JscB:G%JecB,:), xv)
+    call cmp3(tag//" h", h(G%isc:G%iec,G%jsc:G%jec,:), xh)
+    call cmp3(tag//" uh", uh(G%IscB:G%IecB,G%jsc:G%jec,:), xuh) ; call cmp3(tag//" vh", vh(G%isc:G%iec,G%JscB:G%JecB,:), xvh)
+    call cmp3(tag//" uhtr", uhtr(G%IscB:G%IecB,G%jsc:G%jec,:), xuhtr) ; call cmp3(tag//" vhtr", vhtr(G%isc:G%iec,G%JscB:G%JecB,:), xvhtr)
+    call cmp3(tag//" eta_av", reshape(eta_av(G%isc:G%iec,G%jsc:G%jec), (/ ni, nj, 1 /)), reshape(xeta, (/ ni, nj, 1 /)))
+  end subroutine compare_all
+
+  subroutine cmp3(name, a, b)
+    character(len=*), intent(in) :: name ; real, intent(in) :: a(:,:,:), b(:,:,:)
+    integer :: nd
+    nd = count(transfer(a, 1_8, size(a)) /= transfer(b, 1_8, size(b)))      ! bit patterns, zeros of opposite sign included
+    if (nd == 0) then
+      print '(a)', trim(name)//": bit-identical"
+    else
+      print '(a,i0,a,es10.3)', trim(name)//": ", nd, " values differ, max |diff| = ", maxval(abs(a - b)) ; nbad = nbad + 1
+    endif
+  end subroutine cmp3
+
+  !> The shims keep the reference's cpu clocks: every step passed through the device clock and the transfer clock
+  subroutine check_clocks()
+    integer :: c, hits
+    hits = 0
+    do c = 1, stub_nclocks
+      if (index(stub_clock_names(c), "Ocean dynamics on the device") > 0 .and. stub_clock_calls(c) > 0) hits = hits + 1
+    enddo
+    if (hits == 0) then ; print '(a)', "FAIL: the step never passed through its cpu clock" ; nbad = nbad + 1 ; endif
+  end subroutine check_clocks
+
+  !> advect_tracer and tracer_vertdiff through their shims (host arrays in and out)
+  subroutine tracer_checks()
+    type(tracer_advect_CS), pointer :: TA => NULL()
+    type(tracer_registry_type), pointer :: Reg => NULL()
+    real, allocatable, target :: tr1(:,:,:), tr2(:,:,:)
+    real, allocatable :: uhr(:,:,:), vhr(:,:,:), ea(:,:,:), eb(:,:,:)
+    integer :: i, j, k
+    real :: lo, hi
+    allocate(Reg) ; Reg%ntr = 2
+    call al3(tr1, 0) ; call al3(tr2, 0) ; call al3(uhr, 1) ; call al3(vhr, 2)
+    tr1 = 35.0
+    do k = 1, nk ; do j = G%jsd, G%jed ; do i = G%isd, G%ied
+      tr2(i,j,k) = 10.0 + 5.0 * sin(0.3 * i) * cos(0.2 * j) + 0.1 * k
+    enddo ; enddo ; enddo
+    lo = minval(tr2) ; hi = maxval(tr2)
+    Reg%Tr(1)%t => tr1 ; Reg%Tr(2)%t => tr2 ; Reg%Tr(2)%advect_scheme = 2     ! ADVECT_PPM for the second one
+    call stub_set_param(PF, "TRACER_ADVECTION_SCHEME", "PPM:H3")
+    call tracer_advect_init(Time, G, US, PF, diag, TA)
+    uhr = -1.0e30 ; vhr = -1.0e30
+    call advect_tracer(h, uhtr, vhtr, OBC, dt * nsteps, G, GV, US, TA, Reg, uhr_out=uhr, vhr_out=vhr)
+    if (maxval(abs(tr1(G%isc:G%iec,G%jsc:G%jec,:) - 35.0)) > 1.0e-11) then
+      print '(a,es10.3)', "FAIL: a uniform tracer did not stay uniform: ", maxval(abs(tr1(G%isc:G%iec,G%jsc:G%jec,:) - 35.0)) ; nbad = nbad + 1
+    endif
+    if (minval(tr2(G%isc:G%iec,G%jsc:G%jec,:)) < lo - 1.0e-9 .or. maxval(tr2(G%isc:G%iec,G%jsc:G%jec,:)) > hi + 1.0e-9) then
+      print '(a)', "FAIL: advect_tracer left the initial bounds" ; nbad = nbad + 1
+    endif
+    ! uhr_out / vhr_out are intent(out) in the reference: they must have been written (the sentinel is gone), and what the
+    ! iteration could not use is no larger than what it was given
+    if (any(uhr(G%IscB:G%IecB,G%jsc:G%jec,:) < -1.0e29) .or. any(vhr(G%isc:G%iec,G%JscB:G%JecB,:) < -1.0e29)) then
+      print '(a)', "FAIL: uhr_out / vhr_out were not written" ; nbad = nbad + 1
+    elseif (maxval(abs(uhr(G%IscB:G%IecB,G%jsc:G%jec,:))) > maxval(abs(uhtr)) + 1.0e-6) then
+      print '(a)', "FAIL: leftover transports exceed the transports" ; nbad = nbad + 1
+    else
+      print '(a,es10.3)', "advect_tracer through the shim: uniform tracer exact, bounds kept, max |uhr_out| = ", maxval(abs(uhr(G%IscB:G%IecB,G%jsc:G%jec,:)))
+    endif
+    call al3(ea, 0) ; call al3(eb, 0)
+    ea = 0.5 ; eb = 0.5 ; ea(:,:,1) = 0.0 ; eb(:,:,nk) = 0.0
+    call tracer_vertdiff(h, ea, eb, dt, tr1, G, GV)
+    if (maxval(abs(tr1(G%isc:G%iec,G%jsc:G%jec,:) - 35.0)) > 1.0e-11) then
+      print '(a)', "FAIL: tracer_vertdiff changed a uniform tracer" ; nbad = nbad + 1
+    else
+      print '(a)', "tracer_vertdiff through the shim: uniform tracer exact"
+    endif
+    call tracer_advect_end(TA)
+    deallocate(Reg)
+  end subroutine tracer_checks
+
+  subroutine rd2(a, stg)
+    real, allocatable, intent(inout) :: a(:,:) ; integer, intent(in) :: stg
+    integer :: s
+    if (stg == 0) allocate(a(G%isd:G%ied,G%jsd:G%jed))
+    if (stg == 1) allocate(a(G%IsdB:G%IedB,G%jsd:G%jed))
+    if (stg == 2) allocate(a(G%isd:G%ied,G%JsdB:G%JedB))
+    if (stg == 3) allocate(a(G%IsdB:G%IedB,G%JsdB:G%JedB))
+    read(un) s
+    if (s /= stg) error stop "drive_shims: staggering of an array in the case file is not what the driver expects"
+    read(un) a
+  end subroutine rd2
+
+  subroutine rd3(a, stg, nl)
+    real, allocatable, intent(inout) :: a(:,:,:) ; integer, intent(in) :: stg, nl
+    integer :: s
+    if (stg == 0) allocate(a(G%isd:G%ied,G%jsd:G%jed,nl))
+    if (stg == 1) allocate(a(G%IsdB:G%IedB,G%jsd:G%jed,nl))
+    if (stg == 2) allocate(a(G%isd:G%ied,G%JsdB:G%JedB,nl))
+    read(un) s
+    if (s /= stg) error stop "drive_shims: staggering of an array in the case file is not what the driver expects"
+    read(un) a
+  end subroutine rd3
+
+  subroutine al3(a, stg)
+    real, allocatable, intent(inout) :: a(:,:,:) ; integer, intent(in) :: stg
+    if (stg == 0) allocate(a(G%isd:G%ied,G%jsd:G%jed,nk), source=0.0)
+    if (stg == 1) allocate(a(G%IsdB:G%IedB,G%jsd:G%jed,nk), source=0.0)
+    if (stg == 2) allocate(a(G%isd:G%ied,G%JsdB:G%JedB,nk), source=0.0)
+  end subroutine al3
+end program drive_shims

@@ -1,4 +1,4 @@
-"""A step driven from FORTRAN: fortran/drive_double_gyre (amdflang; fortran/mom6x_c_api.F90 + fortran/mom6x_host.F90 +
+"""Steps driven from FORTRAN.  (1) the dependency-free driver: fortran/drive_double_gyre (amdflang; fortran/mom6x_c_api.F90 + fortran/mom6x_host.F90 +
 libmom6x.so, nothing else) reads a case written here, packs the metric block from arrays with MOM6's symmetric-memory
 extents, creates the context, initialises the modules, uploads the state once, runs three steps of
 step_MOM_dyn_split_RK2 on the resident state and compares all eight prognostic arrays with the committed fixture
@@ -76,4 +76,58 @@ def test_three_steps_driven_from_fortran(tmp_path):
     r = subprocess.run([DRIVER, str(path)], capture_output=True, text=True, timeout=300)
     print(r.stdout); print(r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count(": bit-identical") == len(STATE)
+    assert r.stdout.count(": bit-identical") == 2 * len(STATE) and r.stdout.count("restart: ") == len(STATE)   # + the restarted run
+
+
+SHIM_DRIVER = os.path.join(ROOT, "tests", "fortran_stubs", "drive_shims")
+
+
+def _write_shim_case(path, cfg, orc):
+    """The case of tests/fortran_stubs/drive_shims.F90: grid and state in Fortran extents, the MOM_input table, the
+    set_viscous_BBL fields, and the oracle's state after SHIM_NSTEPS steps (= the committed fixture, checked here)."""
+    gg, d, M = cfg
+    so, m, inp, vis = cases.oracle_shim_case(orc, cfg)
+    gold = H.load_golden("rk2_double_gyre_shims_4steps")
+    for n in STATE:
+        H.assert_bitwise(so[n][(Ellipsis,) + tuple(H.interior(d, {"u": "u", "uh": "u", "uhtr": "u", "v": "v", "vh": "v", "vhtr": "v"}.get(n, "h")))],
+                         gold[n], "oracle vs committed fixture: " + n)
+    params = cases.shim_case_params(inp["dt"], H.golden_tag() != "")
+    GV = inp["GV"]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<10i", 1297042743, d.ni, d.nj, d.nk, d.halo, cases.SHIM_NSTEPS, cases.SHIM_SAVE_AFTER, 0, abi.G_COUNT, len(params)))
+        f.write(struct.pack("<d", inp["dt"]))
+        f.write(struct.pack("<9d", GV.g_Earth, GV.Rho0, GV.Angstrom_H, GV.H_subroundoff, GV.dZ_subroundoff, GV.H_to_Z, GV.Z_to_H, GV.H_to_RZ, GV.RZ_to_H))
+        f.write(np.ascontiguousarray(inp["Rlay"], dtype="<f8").tobytes()); f.write(np.ascontiguousarray(inp["gp"], dtype="<f8").tobytes())
+        for k, v in params.items():
+            f.write(k.ljust(48).encode()); f.write(v.ljust(64).encode())
+
+        def put(a, st):
+            f.write(struct.pack("<i", st)); f.write(_f_extent(d, a, st).astype("<f8").tobytes())
+        for mi, name in enumerate(abi.METRICS):
+            put(M[mi], _stagger(name))
+        put(inp["u"], 1); put(inp["v"], 2); put(inp["h"], 0)
+        put(vis[0], 1); put(vis[1], 2); put(vis[2], 1); put(vis[3], 2); put(vis[4], 0)
+        put(inp["taux"], 1); put(inp["tauy"], 2)
+        for n in STATE:
+            f.write(np.ascontiguousarray(gold[n], dtype="<f8").tobytes())
+
+
+@pytest.mark.parametrize("mode", ["", "resident"])
+def test_shim_modules_new_run_restart_and_tracers_from_fortran(orc, tmp_path, mode, sums):
+    """The shim MODULES (fortran/shims/: MOM_dynamics_split_RK2 -> MOM_continuity_PPM, MOM_barotropic, MOM_CoriolisAdv,
+    MOM_PressureForce, MOM_vert_friction; MOM_tracer_advect; mom6x_diabatic_solvers), compiled against the interface stand-ins
+    of tests/fortran_stubs/, driven the way MOM.F90 drives them: four steps uninterrupted == the oracle's fixture bit for bit;
+    two steps, save_restart (every registered variable, the barotropic ones included), end, a fresh control structure,
+    restore_state, two more steps == the same fixture bit for bit.  Both modes of the shim: state across PCIe every step
+    (MOM.F90 unchanged) and resident in HBM (three hook calls).  Both orders of the column sums."""
+    if not os.path.exists(SHIM_DRIVER):
+        pytest.fail("tests/fortran_stubs/drive_shims is missing: __graft_entry__.build() compiles it with amdflang")
+    path = tmp_path / "shim_case.bin"
+    _write_shim_case(path, H.double_gyre(), orc)
+    r = subprocess.run([SHIM_DRIVER, str(path), str(tmp_path / "restart.bin")] + ([mode] if mode else []),
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout); print(r.stderr)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count(": bit-identical") == 2 * len(STATE)
+    names = r.stdout.split("registered restart variables:")[1].splitlines()[0].split()
+    assert names == ["u", "v", "h", "sfc", "u2", "v2", "CAu", "CAv", "diffu", "diffv", "ubtav", "vbtav", "DTBT"]
