@@ -9,8 +9,8 @@
 //     (u, v) -> sh_xx, sh_xy -> Del2u, Del2v -> str_xx, str_xy -> diffu, diffv
 // is four 3-D kernels (column walk over KCHUNK layers with the 2-D coefficient planes in registers where it
 // pays); every stage reads its predecessor's output at neighbouring points, so the stages cannot be fused without
-// tile halos -- that (LDS tiles with a 3-cell halo) is the obvious next step, it would take the 20 words per
-// cell-layer moved now down to ~6.  h_u, h_v, hq, Shear_mag, hrat_min, the viscosities and the strain
+// tile halos -- k_hv_fused below does that (LDS tiles with a 3-cell halo, 20 -> ~7 words per cell-layer) and is
+// SLOWER: the chain is instruction-bound, not traffic-bound.  h_u, h_v, hq, Shear_mag, hrat_min, the viscosities and the strain
 // derivatives are recomputed where they are needed instead of being stored.
 #include "mom6x_dev.h"
 
@@ -652,6 +652,255 @@ k_hv_accel(Dm d, const double *__restrict__ G, const double *__restrict__ P, con
   }
 }
 
+
+// ---- the four stages in ONE kernel (no Leith) ------------------------------------------------------------------------------
+// A work-group owns a tile of HT_X x HT_Y points and walks a chunk of layers; a THREAD owns one point (its h point (i,j), u point
+// (I,j), v point (i,J) and q point (I,J)) and keeps the ~30 coefficient values of that point in registers for the whole chunk --
+// the register file (512 KB per CU) is the only on-chip store big enough for them.  Per layer everything goes through LDS:
+//     u, v, h (ONE global load each per point, fetched a layer ahead) -> | -> sh_xx, sh_xy -> | -> Del2u, Del2v -> | -> str_xx,
+//     str_xy -> | -> diffu, diffv (global)
+// with three barriers (the next layer's u, v, h go into the second of two input buffers before the last one).  Every stage is
+// computed on the whole tile; a result is only valid where its inputs were: the outputs of the last stage are good on the tile
+// minus a frame of HT_H = 3 points, and that is all that is stored.  The four metric planes del2 and accel read at neighbouring
+// points (dx2q, dy2q, dy2h, dx2h) sit in LDS for the life of the work-group.  Arithmetic: the expressions of k_hv_strain,
+// k_hv_del2, k_hv_stress and k_hv_accel, unchanged -- results are bit-identical with the four-kernel path
+// (the default; MOM6X_HORVISC=fused selects this kernel; Leith always takes the four kernels).  3 reads (x the tile's halo overhead) + 2 writes per cell-layer
+// instead of 20.
+#define HT_H 3
+template <int HT_X, int HT_Y>
+__global__ void __launch_bounds__(HT_X * HT_Y, 4)      // 4 wavefronts per SIMD: one 1024-thread or two 512-thread work-groups per CU
+k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom6x_hor_visc_params CS,
+           const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ h,
+           double *__restrict__ diffu, double *__restrict__ diffv, double h_neglect, int kc) {
+  constexpr int HT_LDW = HT_X + 2, HT_LDN = (HT_Y + 2) * HT_LDW;
+  extern __shared__ double lds[];
+  double *s_xx = lds, *s_xy = lds + HT_LDN, *s_d2u = lds + 2 * HT_LDN, *s_d2v = lds + 3 * HT_LDN;
+  double *s_txx = lds + 4 * HT_LDN, *s_txy = lds + 5 * HT_LDN;
+  double *c_dx2q = lds + 6 * HT_LDN, *c_dy2q = lds + 7 * HT_LDN, *c_dy2h = lds + 8 * HT_LDN, *c_dx2h = lds + 9 * HT_LDN;
+  double *s_in = lds + 10 * HT_LDN;                     // u, v, h of the layer: two buffers of three planes
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i = -1 - HT_H + (int)blockIdx.x * (HT_X - 2 * HT_H) + tx;
+  const int j = -1 - HT_H + (int)blockIdx.y * (HT_Y - 2 * HT_H) + ty;
+  const int st = d.pitch;
+  const size_t slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * kc, k1 = min(k0 + kc, d.nk);
+  const int l = (ty + 1) * HT_LDW + (tx + 1);            // this point in the LDS planes (a frame of one keeps +-1 reads inside)
+  // points whose coefficient stencils stay inside the planes (halo 4): everything the valid outputs need lies in -3..ni+2 /
+  // -3..nj+2; the fields themselves are also loaded one point further out (the neighbours of those points)
+  const bool live = (i >= -3) && (i <= d.ni + 2) && (j >= -3) && (j <= d.nj + 2);
+  const bool loadable = (i >= -4) && (i <= d.ni + 3) && (j >= -4) && (j <= d.nj + 3);
+  const size_t x = live ? ix2(d, i, j) : ix2(d, 0, 0);
+  const size_t xf = loadable ? ix2(d, i, j) : ix2(d, 0, 0);
+  const bool out_u = live && tx >= HT_H && tx < HT_X - HT_H && ty >= HT_H && ty < HT_Y - HT_H && (i <= d.ni - 1) && (j >= 0) && (j <= d.nj - 1);
+  const bool out_v = live && tx >= HT_H && tx < HT_X - HT_H && ty >= HT_H && ty < HT_Y - HT_H && (i >= 0) && (i <= d.ni - 1) && (j <= d.nj - 1);
+  const bool need3 = live && tx >= HT_H - 1 && tx <= HT_X - HT_H && ty >= HT_H - 1 && ty <= HT_Y - HT_H;
+  const bool smag = CS.Smagorinsky_Kh || CS.Smagorinsky_Ah, better = CS.better_bound_Ah || CS.better_bound_Kh;
+  const bool legacy_bound = CS.Smagorinsky_Kh && (CS.bound_Kh && !CS.better_bound_Kh);   // :556-557 (no Leith here)
+  const bool lap = CS.Laplacian, bih = CS.biharmonic;
+  const double h_neglect3 = h_neglect * h_neglect * h_neglect;
+  const int lm = CS.use_land_mask;
+  // ---- coefficients of this point, for all layers of the chunk
+  c_dx2q[l] = PLN(HV_dx2q)[x]; c_dy2q[l] = PLN(HV_dy2q)[x]; c_dy2h[l] = PLN(HV_dy2h)[x]; c_dx2h[l] = PLN(HV_dx2h)[x];
+  const double *mT = MG(mask2dT);
+  double m00 = 1., mE = 1., mW = 1., mN = 1., mS = 1., mNE = 1.;
+  if (lm) { m00 = mT[x]; mE = mT[x + 1]; mW = mT[x - 1]; mN = mT[x + st]; mS = mT[x - st]; mNE = mT[x + st + 1]; }
+  const double DY_dxT = PLN(HV_DY_dxT)[x], DX_dyT = PLN(HV_DX_dyT)[x], DY_dxBu = PLN(HV_DY_dxBu)[x], DX_dyBu = PLN(HV_DX_dyBu)[x];
+  const double IdyCu0 = MG(IdyCu)[x], IdyCuW = MG(IdyCu)[x - 1], IdxCv0 = MG(IdxCv)[x], IdxCvS = MG(IdxCv)[x - st];
+  const double IdyCvE = MG(IdyCv)[x + 1], IdyCv0 = MG(IdyCv)[x], IdxCuN = MG(IdxCu)[x + st], IdxCu0 = MG(IdxCu)[x];
+  const double mBu = MG(mask2dBu)[x], mfac = CS.no_slip ? (2.0 - mBu) : mBu;
+  const double Idx2dyCu = PLN(HV_Idx2dyCu)[x], Idxdy2u = PLN(HV_Idxdy2u)[x], Idx2dyCv = PLN(HV_Idx2dyCv)[x], Idxdy2v = PLN(HV_Idxdy2v)[x];
+  const double IareaCu = MG(IareaCu)[x], IareaCv = MG(IareaCv)[x];
+  const double red_xx = PLN(HV_red_xx)[x], red_xy = PLN(HV_red_xy)[x];
+  const double Kh_bg_xx = lap ? PLN(HV_Kh_bg_xx)[x] : 0., Kh_Max_xx = lap ? PLN(HV_Kh_Max_xx)[x] : 0.;
+  const double Kh_bg_xy = lap ? PLN(HV_Kh_bg_xy)[x] : 0., Kh_Max_xy = lap ? PLN(HV_Kh_Max_xy)[x] : 0.;
+  const double Lap2_xx = CS.Smagorinsky_Kh ? PLN(HV_Lap2_xx)[x] : 0., Lap2_xy = CS.Smagorinsky_Kh ? PLN(HV_Lap2_xy)[x] : 0.;
+  const double Ah_bg_xx = bih ? PLN(HV_Ah_bg_xx)[x] : 0., Ah_Max_xx = bih ? PLN(HV_Ah_Max_xx)[x] : 0.;
+  const double Ah_bg_xy = bih ? PLN(HV_Ah_bg_xy)[x] : 0., Ah_Max_xy = bih ? PLN(HV_Ah_Max_xy)[x] : 0.;
+  const double Bih_xx = CS.Smagorinsky_Ah ? PLN(HV_Bih_xx)[x] : 0., Bih_xy = CS.Smagorinsky_Ah ? PLN(HV_Bih_xy)[x] : 0.;
+  const double Bih2_xx = CS.bound_Coriolis ? PLN(HV_Bih2_xx)[x] : 0., Bih2_xy = CS.bound_Coriolis ? PLN(HV_Bih2_xy)[x] : 0.;
+  double mu0 = 0., mu1 = 0., mv0 = 0., mv1 = 0.;
+  if (CS.no_slip) { mu0 = MG(mask2dCu)[x]; mu1 = MG(mask2dCu)[x + st]; mv0 = MG(mask2dCv)[x]; mv1 = MG(mask2dCv)[x + 1]; }
+  // the frame of the LDS planes is only ever read by points whose results are discarded: no initialisation needed, but the
+  // stage planes of points that are not live must not hold NaN patterns that trap -- they cannot: nothing here traps
+  __syncthreads();
+  const double dx2q0 = c_dx2q[l], dx2q_s = c_dx2q[l - HT_LDW], dy2q0 = c_dy2q[l], dy2q_w = c_dy2q[l - 1];
+  const double dy2h0 = c_dy2h[l], dy2h_e = c_dy2h[l + 1], dx2h0 = c_dx2h[l], dx2h_n = c_dx2h[l + HT_LDW];
+
+  double un = u[xf + (size_t)k0 * slab], vn = v[xf + (size_t)k0 * slab], hn = h[xf + (size_t)k0 * slab];
+  s_in[l] = un; s_in[HT_LDN + l] = vn; s_in[2 * HT_LDN + l] = hn;
+  if (k0 + 1 < k1) { un = u[xf + (size_t)(k0 + 1) * slab]; vn = v[xf + (size_t)(k0 + 1) * slab]; hn = h[xf + (size_t)(k0 + 1) * slab]; }
+  __syncthreads();
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double *su = s_in + ((k - k0) & 1) * 3 * HT_LDN, *sv = su + HT_LDN, *sh = su + 2 * HT_LDN;
+    // ---- stage 1 :898-931: sh_xx at (i,j), sh_xy at (I,J)
+    const double u0 = su[l], v0 = sv[l];
+    const double h00 = sh[l], hE = sh[l + 1], hN = sh[l + HT_LDW], hNE = sh[l + HT_LDW + 1], hW = sh[l - 1], hS = sh[l - HT_LDW];
+    double sxx, sxy;
+    {
+      const double dudx = DY_dxT * ((IdyCu0 * u0) - (IdyCuW * su[l - 1]));
+      const double dvdy = DX_dyT * ((IdxCv0 * v0) - (IdxCvS * sv[l - HT_LDW]));
+      sxx = dudx - dvdy;
+      const double dvdx = DY_dxBu * ((sv[l + 1] * IdyCvE) - (v0 * IdyCv0));
+      const double dudy = DX_dyBu * ((su[l + HT_LDW] * IdxCuN) - (u0 * IdxCu0));
+      sxy = mfac * (dvdx + dudy);
+    }
+    s_xx[l] = sxx; s_xy[l] = sxy;
+    __syncthreads();
+    // ---- stage 2 :934-943: Del2u at (I,j), Del2v at (i,J)
+    double d2u = 0., d2v = 0.;
+    if (bih) {
+      d2u = Idx2dyCu * ((dx2q0 * sxy) - (dx2q_s * s_xy[l - HT_LDW])) + Idxdy2u * ((dy2h_e * s_xx[l + 1]) - (dy2h0 * sxx));
+      d2v = Idxdy2v * ((dy2q0 * sxy) - (dy2q_w * s_xy[l - 1])) - Idx2dyCv * ((dx2h_n * s_xx[l + HT_LDW]) - (dx2h0 * sxx));
+      s_d2u[l] = d2u; s_d2v[l] = d2v;
+    }
+    __syncthreads();
+    // ---- stage 3: str_xx at the h point :1112-1448, str_xy at the q point :1483-1826 (k_hv_stress) -- the expensive stage
+    // (square roots, five divisions): only where stage 4 will look (its outputs' own points and one row / column around)
+    const double hu0 = hface2(h00, hE, m00, mE, lm), hv0 = hface2(h00, hN, m00, mN, lm);
+    if (need3) {
+      double Shear = 0., hrat = 0., vbr = 0., sxx_out;
+      if (smag) {
+        const double sh_xx_sq = sxx * sxx;
+        const double a = s_xy[l - 1 - HT_LDW], e = s_xy[l - 1], f = s_xy[l - HT_LDW];
+        const double sh_xy_sq = 0.25 * (((a * a) + (sxy * sxy)) + ((e * e) + (f * f)));
+        Shear = sqrt(sh_xx_sq + sh_xy_sq);
+      }
+      if (better) {
+        const double h_min = dmin4(hu0, hface2(hW, h00, mW, m00, lm), hv0, hface2(hS, h00, mS, m00, lm));
+        hrat = dmin(1.0, h_min / (h00 + h_neglect));
+      }
+      if (lap) {
+        double K = Kh_bg_xx;
+        if (CS.add_LES_viscosity) {
+          if (CS.Smagorinsky_Kh) K = K + Lap2_xx * Shear;
+        } else {
+          if (CS.Smagorinsky_Kh) K = dmax(K, Lap2_xx * Shear);
+        }
+        if (legacy_bound) K = dmin(K, Kh_Max_xx);
+        K = dmax(K, CS.Kh_bg_min);
+        if (CS.better_bound_Kh && CS.better_bound_Ah) {
+          vbr = 1.0;
+          const double Kh_max_here = hrat * Kh_Max_xx;
+          if (K >= Kh_max_here) { vbr = 0.0; K = Kh_max_here; }
+          else if ((K > 0.0) || (CS.backscatter_underbound && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
+        } else if (CS.better_bound_Kh) {
+          K = dmin(K, hrat * Kh_Max_xx);
+        }
+        sxx_out = -K * sxx;
+      } else sxx_out = 0.0;
+      if (bih) {
+        double A = Ah_bg_xx;
+        if (CS.Smagorinsky_Ah) {
+          double AhSm;
+          if (CS.bound_Coriolis) AhSm = Shear * (Bih_xx + Bih2_xx * Shear);
+          else AhSm = Bih_xx * Shear;
+          A = dmax(A, AhSm);
+          if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, Ah_Max_xx);
+        }
+        if (CS.better_bound_Ah) {
+          if (CS.better_bound_Kh) A = dmin(A, vbr * hrat * Ah_Max_xx);
+          else A = dmin(A, hrat * Ah_Max_xx);
+        }
+        const double d_del2u = (IdyCu0 * d2u) - (IdyCuW * s_d2u[l - 1]);
+        const double d_del2v = (IdxCv0 * d2v) - (IdxCvS * s_d2v[l - HT_LDW]);
+        const double d_str = A * ((DY_dxT * d_del2u) - (DX_dyT * d_del2v));
+        sxx_out = sxx_out + d_str;
+      }
+      s_txx[l] = sxx_out * (h00 * red_xx);
+    }
+    if (need3) {
+      double Shear = 0., hrat = 0., vbr = 0., sxy_out;
+      if (smag) {
+        const double sh_xy_sq = sxy * sxy;
+        const double b = s_xx[l + 1 + HT_LDW], e = s_xx[l + HT_LDW], f = s_xx[l + 1];
+        const double sh_xx_sq = 0.25 * (((sxx * sxx) + (b * b)) + ((e * e) + (f * f)));
+        Shear = sqrt(sh_xy_sq + sh_xx_sq);
+      }
+      const double hu1 = hface2(hN, hNE, mN, mNE, lm), hv1 = hface2(hE, hNE, mE, mNE, lm);
+      const double h2uq = 4.0 * (hu0 * hu1), h2vq = 4.0 * (hv0 * hv1);
+      double hq = (2.0 * (h2uq * h2vq)) / (h_neglect3 + (h2uq + h2vq) * ((hu0 + hu1) + (hv0 + hv1)));
+      if (better) {
+        const double h_min = dmin4(hu0, hu1, hv0, hv1);
+        hrat = dmin(1.0, h_min / (hq + h_neglect));
+      }
+      if (CS.no_slip && (mBu < 0.5)) {
+        if ((mu0 + mu1) + (mv0 + mv1) > 0.0) {
+          const double hu = mu0 * hu0 + mu1 * hu1;
+          const double hv = mv0 * hv0 + mv1 * hv1;
+          if ((mu0 + mu1) * (mv0 + mv1) == 0.0) {
+            hq = hu + hv;
+            hrat = 1.0;
+          } else {
+            hq = 2.0 * (hu * hv) / ((hu + hv) + h_neglect);
+            hrat = dmin(1.0, dmin(hu, hv) / (hq + h_neglect));
+          }
+        }
+      }
+      if (lap) {
+        double K = Kh_bg_xy;
+        if (CS.Smagorinsky_Kh) {
+          if (CS.add_LES_viscosity) K = K + Lap2_xy * Shear;
+          else K = dmax(K, Lap2_xy * Shear);
+        }
+        if (legacy_bound) K = dmin(K, Kh_Max_xy);
+        K = dmax(K, CS.Kh_bg_min);
+        if (CS.better_bound_Kh && CS.better_bound_Ah) {
+          vbr = 1.0;
+          const double Kh_max_here = hrat * Kh_Max_xy;
+          if (K >= Kh_max_here) { vbr = 0.0; K = Kh_max_here; }
+          else if ((K > 0.0) || (CS.backscatter_underbound && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
+        } else if (CS.better_bound_Kh) {
+          K = dmin(K, hrat * Kh_Max_xy);
+        }
+        sxy_out = -K * sxy;
+      } else sxy_out = 0.;
+      if (bih) {
+        double A = Ah_bg_xy;
+        if (CS.Smagorinsky_Ah) {
+          double AhSm;
+          if (CS.bound_Coriolis) AhSm = Shear * (Bih_xy + Bih2_xy * Shear);
+          else AhSm = Bih_xy * Shear;
+          A = dmax(A, AhSm);
+          if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, Ah_Max_xy);
+        }
+        if (CS.better_bound_Ah) {
+          if (CS.better_bound_Kh) A = dmin(A, vbr * hrat * Ah_Max_xy);
+          else A = dmin(A, hrat * Ah_Max_xy);
+        }
+        const double dDel2vdx = DY_dxBu * ((s_d2v[l + 1] * IdyCvE) - (d2v * IdyCv0));
+        const double dDel2udy = DX_dyBu * ((s_d2u[l + HT_LDW] * IdxCuN) - (d2u * IdxCu0));
+        const double d_str = A * (dDel2vdx + dDel2udy);
+        sxy_out = sxy_out + d_str;
+      }
+      if (CS.no_slip) s_txy[l] = sxy_out * (hq * red_xy);
+      else s_txy[l] = sxy_out * (hq * mBu * red_xy);
+    }
+    if (k + 1 < k1) {   // the next layer's inputs into the other buffer (last read two barriers ago), and the layer after into flight
+      double *nu = s_in + ((k + 1 - k0) & 1) * 3 * HT_LDN;
+      nu[l] = un; nu[HT_LDN + l] = vn; nu[2 * HT_LDN + l] = hn;
+      if (k + 2 < k1) { un = u[xf + (size_t)(k + 2) * slab]; vn = v[xf + (size_t)(k + 2) * slab]; hn = h[xf + (size_t)(k + 2) * slab]; }
+    }
+    __syncthreads();
+    // ---- stage 4 :1910-1931: diffu at (I,j), diffv at (i,J)
+    {
+      const double txy = s_txy[l], txx = s_txx[l];
+      if (out_u) {
+        const double h_u = hface2(h00, hE, m00, mE, lm);
+        diffu[c] = ((IdxCu0 * ((dx2q_s * s_txy[l - HT_LDW]) - (dx2q0 * txy)) + IdyCu0 * ((dy2h0 * txx) - (dy2h_e * s_txx[l + 1]))) * IareaCu) /
+                   (h_u + h_neglect);
+      }
+      if (out_v) {
+        const double h_v = hface2(h00, hN, m00, mN, lm);
+        diffv[c] = ((IdyCv0 * ((dy2q_w * s_txy[l - 1]) - (dy2q0 * txy)) - IdxCv0 * ((dx2h0 * txx) - (dx2h_n * s_txx[l + HT_LDW]))) * IareaCv) /
+                   (h_v + h_neglect);
+      }
+    }
+    // (the next layer's stage 1 writes s_xx / s_xy, last read in stage 3 of this layer: a barrier lies in between;
+    //  its stage 3 writes s_txx / s_txy, read here: two barriers lie in between)
+  }
+}
+
 }  // namespace
 
 void hor_visc_free(mom6x_ctx *c) { (void)hipFree(c->hv_planes); c->hv_planes = nullptr; }
@@ -708,6 +957,33 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
     return rc;
   const dim3 b = blk2();
   const double *P = c->hv_planes;
+  // MOM6X_HORVISC=fused: the four stages in one LDS-tiled kernel (k_hv_fused: 3 reads + 2 writes per cell-layer instead of 20).
+  // Measured round 3 at 1440 x 1080 x 75 (bench switches): 6.8 ms (64 x 16 tiles; 7.5 ms with 32 x 16) against 6.0 ms for the
+  // four kernels -- the chain is INSTRUCTION-bound (two square roots and nine FP64 divisions per point and layer, ~900
+  // instructions per layer in the fused form), and a tile recomputes the first two stages on its 3-point frame while its
+  // wavefronts wait at three barriers per layer.  Kept as a tested alternative, not the default.
+  static const bool fused = [] { const char *e = getenv("MOM6X_HORVISC"); return e && !strcmp(e, "fused"); }();
+  if (fused && !(CS.Leith_Kh || CS.Leith_Ah) && d.halo >= 4) {
+    const int kc = (d.nk % 25 == 0) ? 25 : ((d.nk >= KCHUNK) ? KCHUNK : d.nk);
+    static const int wide = [] { const char *e = getenv("MOM6X_HV_TILE"); return e ? atoi(e) : 32; }();
+    const int TX = (wide == 64) ? 64 : 32, TY = 16;
+    const dim3 bt(TX, TY, 1);
+    const dim3 gt((d.ni + 1 + (TX - 2 * HT_H) - 1) / (TX - 2 * HT_H), (d.nj + 1 + (TY - 2 * HT_H) - 1) / (TY - 2 * HT_H), (d.nk + kc - 1) / kc);
+    const size_t ldsb = (size_t)16 * (TY + 2) * (TX + 2) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {   // more than 64 KB of dynamic LDS has to be asked for
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 66 * 8));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 34 * 8));
+      attr_set = true;
+    }
+    if (TX == 64) {
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<64, 16>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+    } else {
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+    }
+    HIPCHK(hipGetLastError());
+    return MOM6X_OK;
+  }
   KLAUNCH(c, "k_hv_strain", k_hv_strain, grid3(nxa(d.ni + 4, -2), d.nj + 4, nchunks(d.nk), b), b, d, c->G, P, u, v, sh_xx, sh_xy, CS.no_slip);
   if (CS.biharmonic)
     KLAUNCH(c, "k_hv_del2", k_hv_del2, grid3(nxa(d.ni + 3, -2), d.nj + 3, nchunks(d.nk), b), b, d, c->G, P, (const double *)sh_xx,
