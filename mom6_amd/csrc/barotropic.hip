@@ -47,6 +47,10 @@ struct BTState {
   // device; the first offender's eta, bathyT, i, j next to them
   unsigned long long *warn;
   double *warn_info;
+  // btstep_layer_accel deferred to the consumer (LayerAccelSrc, mom6x_dev.h)
+  bool la_defer, la_pending;
+  const double *la_pbce;
+  double la_underflow;
 };
 
 namespace {
@@ -622,6 +626,32 @@ inline dim3 blk2() { return dim3(64, 4, 1); }
 
 }  // namespace
 
+void bt_defer_layer_accel(mom6x_ctx *c, bool on) { if (c->bts) c->bts->la_defer = on; }
+
+bool bt_layer_accel_src(mom6x_ctx *c, LayerAccelSrc *u, LayerAccelSrc *v) {
+  BTState *s = c->bts;
+  if (!s || !s->la_pending) return false;
+  const size_t slab = (size_t)c->d.slab;
+  const double *w = s->work;
+  u->pbce = v->pbce = s->la_pbce; u->e_anom = v->e_anom = w + W_e_anom * slab;
+  u->g_own = w + W_gtot_E * slab; u->g_nbr = w + W_gtot_W * slab; u->a2d = w + W_u_accel_bt * slab;
+  v->g_own = w + W_gtot_N * slab; v->g_nbr = w + W_gtot_S * slab; v->a2d = w + W_v_accel_bt * slab;
+  u->underflow = v->underflow = s->la_underflow;
+  return true;
+}
+
+int bt_layer_accel_materialize(mom6x_ctx *c, double *accel_layer_u, double *accel_layer_v) {
+  BTState *s = c->bts;
+  if (!s || !s->la_pending) return MOM6X_OK;
+  const Dm d = c->d;
+  const dim3 b = blk2();
+  KLAUNCH(c, "k_layer_accel", k_layer_accel, grid3(nxa(d.ni + 1, -1), d.nj + 1, nchunks(d.nk), b), b, d, c->G, (const double *)s->work,
+          s->la_pbce, accel_layer_u, accel_layer_v, s->la_underflow);
+  s->la_pending = false;
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
 void bt_state_free(mom6x_ctx *c) {
   if (!c->bts) return;
   BTState *s = c->bts;
@@ -945,8 +975,13 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     std::vector<int> nks(f.size(), 1);
     halo_wrap(c, f.data(), stg.data(), nks.data(), (int)f.size());
   }
-  KLAUNCH(c, "k_layer_accel", k_layer_accel, grid3(nxa(d.ni + 1, -1), d.nj + 1, nchunks(d.nk), b), b, d, c->G, work, pbce, accel_layer_u,
-                     accel_layer_v, P.vel_underflow * Idt);
+  // btstep_layer_accel :3432-3504.  Inside the RK2 step the consumer of accel_layer_u / _v (the velocity estimate vertvisc_coef
+  // forms) evaluates it from pbce and the 2-D results left in the work block: 3 words per cell-layer less, twice per step.
+  s->la_pending = false;
+  if (s->la_defer) { s->la_pending = true; s->la_pbce = pbce; s->la_underflow = P.vel_underflow * Idt; }
+  else
+    KLAUNCH(c, "k_layer_accel", k_layer_accel, grid3(nxa(d.ni + 1, -1), d.nj + 1, nchunks(d.nk), b), b, d, c->G, work, pbce, accel_layer_u,
+                       accel_layer_v, P.vel_underflow * Idt);
   HIPCHK(hipGetLastError());
   REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
   return MOM6X_OK;

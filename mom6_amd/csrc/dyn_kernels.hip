@@ -96,7 +96,8 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
             const double *__restrict__ absv, const double *__restrict__ KE, double *__restrict__ CAu,
             double *__restrict__ CAv, int scheme, int bound, const double *__restrict__ h, int en_dis,
             const double *__restrict__ PFu, const double *__restrict__ PFv, const double *__restrict__ diffu,
-            const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc) {
+            const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc,
+            double *__restrict__ uhtr, double *__restrict__ vhtr, double dt_tr) {
   const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -105,6 +106,14 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
   const bool do_u = (j >= 0), do_v = (i >= 0);
+  // uhtr = uhtr + uh*dt, vhtr = vhtr + vh*dt (RK2.F90:1072-1079) for the points of this kernel's box (-1..ni-1, -1..nj-1), whose
+  // uh(I,j), vh(i,J) it reads anyway; k_uhtr does the ring around the box
+  if (uhtr)
+    for (int k = k0; k < k1; k++) {
+      const size_t c = x + (size_t)k * slab;
+      uhtr[c] = uhtr[c] + uh[c] * dt_tr;
+      vhtr[c] = vhtr[c] + vh[c] * dt_tr;
+    }
   const double IdxCu = gm(G, d, MOM6X_G_IdxCu)[x], IdyCv = gm(G, d, MOM6X_G_IdyCv)[x];
   const double C1_12 = 1.0 / 12.0;
   // CORIOLIS_EN_DIS (:326-333, :590-635): the centred thickness transport of a face and the one the continuity solver
@@ -483,13 +492,13 @@ static inline dim3 gridk(int nx, int ny, int nk, dim3 b) {
 
 extern "C" int mom6x_CorAdCalc(mom6x_ctx *c, const double *u, const double *v, const double *h, const double *uh,
                                const double *vh, double *CAu, double *CAv) {
-  return CorAdCalc_bc(c, u, v, h, uh, vh, CAu, CAv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return CorAdCalc_bc(c, u, v, h, uh, vh, CAu, CAv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0);
 }
 
 // CorAdCalc, and -- for the RK2 step -- u_bc_accel = (CAu + PFu) + diffu (:900-907) formed where CAu is made
 int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h, const double *uh, const double *vh, double *CAu,
                  double *CAv, const double *PFu, const double *PFv, const double *diffu, const double *diffv, double *u_bc,
-                 double *v_bc) {
+                 double *v_bc, double *uhtr, double *vhtr, double dt_tr) {
   REQUIRE(c && c->cor_init, MOM6X_EINVAL, "MOM_CoriolisAdv: Module must be initialized before it is used.");
   REQUIRE(u && v && h && uh && vh && CAu && CAv, MOM6X_EINVAL, "CorAdCalc: null array");
   REQUIRE(c->dims.halo >= 3, MOM6X_EINVAL, "CorAdCalc: halo >= 3 required");
@@ -505,7 +514,8 @@ int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h
   KLAUNCH(c, "k_corad_q", k_corad_q, gridk(nxa(d.ni + 3, -2), d.nj + 3, d.nk, b), b, d, c->G, u, v, h, q, absv, KE,
           c->cor.no_slip, c->cor.KE_Scheme, vol_neglect);
   KLAUNCH(c, "k_corad_acc", k_corad_acc, gridk(nxa(d.ni + 1, -1), d.nj + 1, d.nk, b), b, d, c->G, u, v, uh, vh, q, absv, KE,
-          CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h, c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc);
+          CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h, c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc,
+          uhtr, vhtr, dt_tr);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }
@@ -1128,7 +1138,7 @@ k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, co
                 const double *__restrict__ u_bc, const double *__restrict__ u_abt, double dtx,
                 const double *__restrict__ h, const double *__restrict__ Kv_bbl, const double *__restrict__ bbl_thick_in,
                 const double *__restrict__ Kv_shear, double *__restrict__ a_out, double *__restrict__ h_out, double H_to_Z,
-                double h_neglect, double dz_neglect, double a_cpl_max, double I_amax) {
+                double h_neglect, double dz_neglect, double a_cpl_max, double I_amax, LayerAccelSrc LA) {
   const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -1136,9 +1146,22 @@ k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, co
   const int nz = d.nk, st = DIR ? d.pitch : 1;
   const size_t x = ix2(d, i, j), y = x + st, slab = (size_t)d.slab;
   const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
+  // MODE 3: accel_layer_u of btstep_layer_accel (MOM_barotropic.F90:3432-3504) formed here from pbce and the barotropic solver's
+  // 2-D results (the expression of k_layer_accel, barotropic.hip) instead of being read as u_abt
+  double la_e0 = 0., la_e1 = 0., la_g0 = 0., la_g1 = 0., la_a = 0., la_Idx = 0.;
+  if (MODE == 3) {
+    la_e0 = LA.e_anom[x]; la_e1 = LA.e_anom[y]; la_g0 = LA.g_own[x]; la_g1 = LA.g_nbr[y]; la_a = LA.a2d[x];
+    la_Idx = gm(G, d, DIR ? MOM6X_G_IdyCv : MOM6X_G_IdxCu)[x];
+  }
+  auto abt = [&](size_t c) -> double {
+    if (MODE != 3) return u_abt[c];
+    double a = (la_a - (((LA.pbce[c + st] - la_g1) * la_e1) - ((LA.pbce[c] - la_g0) * la_e0)) * la_Idx);
+    if (fabs(a) < LA.underflow) a = 0.0;
+    return a;
+  };
   if (!(mC > 0.)) {   // do_i :1514-1516
-    if (u_out && MODE == 2)   // (the velocity estimate the solve that follows starts from, see below: masked faces too)
-      for (int k = 0; k < nz; k++) { const size_t c = x + (size_t)k * slab; u_out[c] = mC * (u[c] + dtx * (u_bc[c] + u_abt[c])); }
+    if (u_out && MODE >= 2)   // (the velocity estimate the solve that follows starts from, see below: masked faces too)
+      for (int k = 0; k < nz; k++) { const size_t c = x + (size_t)k * slab; u_out[c] = mC * (u[c] + dtx * (u_bc[c] + abt(c))); }
     return;
   }
   const double *bathyT = gm(G, d, MOM6X_G_bathyT);
@@ -1174,8 +1197,8 @@ k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, co
     const double dz_arith = 0.5 * (dz1 + dz0);
     double uk = u[c];
     if (MODE == 1) uk = mC * (uk + dtx * u_bc[c]);
-    if (MODE == 2) {
-      uk = mC * (uk + dtx * (u_bc[c] + u_abt[c]));
+    if (MODE >= 2) {
+      uk = mC * (uk + dtx * (u_bc[c] + abt(c)));
       // u_out: this IS the velocity the RK2 step hands to vertvisc next (:681-694 / :957-966); written here, the solve reads one
       // array instead of three (u_out may be u itself: every thread reads and writes its own column only)
       if (u_out) u_out[c] = uk;
@@ -1290,8 +1313,27 @@ extern "C" double *mom6x_vertvisc_field(mom6x_ctx *c, int which) {
 }
 
 // vertvisc_coef on u, v themselves (mode 0) or on the velocity estimates the RK2 step would hand over (modes 1, 2)
+static int vertvisc_coef_launch(mom6x_ctx *c, int mode, const double *u, const double *v, const double *u_bc, const double *v_bc,
+                                const double *u_abt, const double *v_abt, const LayerAccelSrc &LAu, const LayerAccelSrc &LAv, double dtx,
+                                const double *h, double dt, double *u_out, double *v_out);
+
 int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, const double *u_bc, const double *v_bc,
                       const double *u_abt, const double *v_abt, double dtx, const double *h, double dt, double *u_out, double *v_out) {
+  LayerAccelSrc none;
+  memset(&none, 0, sizeof(none));
+  return vertvisc_coef_launch(c, mode, u, v, u_bc, v_bc, u_abt, v_abt, none, none, dtx, h, dt, u_out, v_out);
+}
+
+// mode 2 with the barotropic accelerations of the layers formed on the fly (LayerAccelSrc, mom6x_dev.h)
+int vertvisc_coef_upd_la(mom6x_ctx *c, const double *u, const double *v, const double *u_bc, const double *v_bc,
+                         const LayerAccelSrc &LAu, const LayerAccelSrc &LAv, double dtx, const double *h, double dt, double *u_out,
+                         double *v_out) {
+  return vertvisc_coef_launch(c, 3, u, v, u_bc, v_bc, nullptr, nullptr, LAu, LAv, dtx, h, dt, u_out, v_out);
+}
+
+static int vertvisc_coef_launch(mom6x_ctx *c, int mode, const double *u, const double *v, const double *u_bc, const double *v_bc,
+                                const double *u_abt, const double *v_abt, const LayerAccelSrc &LAu, const LayerAccelSrc &LAv, double dtx,
+                                const double *h, double dt, double *u_out, double *v_out) {
   REQUIRE(c && c->vv_init, MOM6X_EINVAL, "MOM_vert_friction(coef): Module must be initialized before it is used.");
   REQUIRE(u && v && h, MOM6X_EINVAL, "vertvisc_coef: null array");
   REQUIRE(!c->vv.bottomdraglaw || (c->Kv_bbl_u && c->Kv_bbl_v && c->bbl_thick_u && c->bbl_thick_v), MOM6X_EINVAL,
@@ -1305,10 +1347,10 @@ int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, 
   const dim3 gu = grid3(nxa(d.ni + 1, -1), d.nj, 1, b), gv = grid3(d.ni, d.nj + 1, 1, b);
 #define VVC(M)                                                                                                                  \
   KLAUNCH(c, "k_vertvisc_coef<0>", (k_vertvisc_coef<0, M>), gu, b, d, c->G, c->vv, u, u_out, u_bc, u_abt, dtx, h, c->Kv_bbl_u, c->bbl_thick_u, \
-          c->Kv_shear, c->vv_a_u, c->vv_h_u, GV.H_to_Z, GV.H_subroundoff, GV.dZ_subroundoff, a_cpl_max, I_amax);                \
+          c->Kv_shear, c->vv_a_u, c->vv_h_u, GV.H_to_Z, GV.H_subroundoff, GV.dZ_subroundoff, a_cpl_max, I_amax, LAu);           \
   KLAUNCH(c, "k_vertvisc_coef<1>", (k_vertvisc_coef<1, M>), gv, b, d, c->G, c->vv, v, v_out, v_bc, v_abt, dtx, h, c->Kv_bbl_v, c->bbl_thick_v, \
-          c->Kv_shear, c->vv_a_v, c->vv_h_v, GV.H_to_Z, GV.H_subroundoff, GV.dZ_subroundoff, a_cpl_max, I_amax)
-  if (mode == 0) { VVC(0); } else if (mode == 1) { VVC(1); } else { VVC(2); }
+          c->Kv_shear, c->vv_a_v, c->vv_h_v, GV.H_to_Z, GV.H_subroundoff, GV.dZ_subroundoff, a_cpl_max, I_amax, LAv)
+  if (mode == 0) { VVC(0); } else if (mode == 1) { VVC(1); } else if (mode == 2) { VVC(2); } else { VVC(3); }
 #undef VVC
   HIPCHK(hipGetLastError());
   return MOM6X_OK;

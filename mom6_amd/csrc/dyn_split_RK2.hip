@@ -18,6 +18,7 @@ struct RK2State {
   double *eta, *eta_PF, *uhbt, *vhbt, *taux_bot, *tauy_bot;
   mom6x_BT_cont BT;
   bool CAu_pred_stored;
+  bool accel_bt_deferred;   // u_accel_bt, v_accel_bt have not been written: the corrector's btstep results wait in the work block
   // the routine's stack temporaries :341-357
   double *up, *vp, *hp, *u_bc_accel, *v_bc_accel, *uh_in, *vh_in, *eta_pred;
 };
@@ -103,11 +104,12 @@ k_h_av(Dm d, double *h_av, const double *__restrict__ a, const double *__restric
 // uhtr += uh*dt, vhtr += vh*dt  :1072-1079
 __global__ void __launch_bounds__(256)
 k_uhtr(Dm d, double *__restrict__ uhtr, double *__restrict__ vhtr, const double *__restrict__ uh,
-       const double *__restrict__ vh, double dt) {
+       const double *__restrict__ vh, double dt, int ring_only) {
   const int i = I_BASE(-3) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -3 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni + 1 || j > d.nj + 1) return;
   if (i < (-3)) return;
+  if (ring_only && i >= -1 && i <= d.ni - 1 && j >= -1 && j <= d.nj - 1) return;   // the box k_corad_acc has done (CorAdCalc_bc)
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
   const bool do_u = (j >= -2), do_v = (i >= -2);
@@ -213,6 +215,11 @@ extern "C" double *mom6x_rk2_field(mom6x_ctx *c, int which) {
                   s->u_accel_bt, s->v_accel_bt, s->u_av, s->v_av, s->h_av, s->pbce, s->eta, s->eta_PF, s->uhbt, s->vhbt,
                   s->taux_bot, s->tauy_bot, s->BT.h_u, s->BT.h_v };
   if (which < 0 || which >= (int)(sizeof(t) / sizeof(t[0]))) return nullptr;
+  if ((which == 10 || which == 11) && s->accel_bt_deferred) {   // CS%u_accel_bt / v_accel_bt asked for: form them now
+    if (bt_layer_accel_materialize(c, s->u_accel_bt, s->v_accel_bt) != MOM6X_OK) return nullptr;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;   // the caller may read it from another stream
+    s->accel_bt_deferred = false;
+  }
   return t[which];
 }
 
@@ -279,7 +286,6 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   RK2State *s = c->rk2;
   const mom6x_rk2_params &R = s->P;
   const Dm d = c->d;
-  const size_t n2 = (size_t)d.slab, n3 = n2 * d.nk;
   const dim3 b = blk2();
   const int nk = d.nk;
   double *u_av = s->u_av, *v_av = s->v_av, *h_av = s->h_av, *eta = s->eta;
@@ -299,10 +305,11 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     return MOM6X_OK;
   };
 
-  // up = vp = 0 ; hp = h  :421-425 (up, vp are fully overwritten where they are used; the halo update fills the rest)
-  HIPCHK(hipMemsetAsync(up, 0, n3 * sizeof(double), c->stream));
-  HIPCHK(hipMemsetAsync(vp, 0, n3 * sizeof(double), c->stream));
-  HIPCHK(hipMemcpyAsync(hp, h, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  // up = vp = 0 ; hp = h  :421-425.  Every own face of up, vp and every own cell of hp is overwritten before it is read
+  // (:681-694 / the convergence of :781) and the group passes fill the connected halos, so all these assignments leave behind
+  // is the halo beyond a closed edge: zero for up, vp -- they are private to this control structure, were zeroed when it was
+  // allocated, and nobody writes there -- and h's halo for hp: only that frame is copied (3.7 GB per step less).
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2 * d.halo, -d.halo), d.nj + 2 * d.halo, nk, b), b, d, hp, (const double *)h, (const double *)nullptr, 1, 0.0, d.halo, 2);
 
   // PFu = d/dx M(h,T,S) ; pbce = dM/deta  :503
   CHK(mom6x_PressureForce(c, h, s->PFu, s->PFv, s->pbce, s->eta_PF));
@@ -333,7 +340,12 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   halo_complete(c);
   CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :649-652
   if (calc_dtbt) CHK(mom6x_set_dtbt_pbce(c, s->pbce, nullptr));         // :659-668
-  // predictor btstep :673-676
+  // predictor btstep :673-676.  accel_layer_u / _v are only read by the velocity estimates below: with the device's own
+  // vertvisc_coef they are evaluated there (LayerAccelSrc) and never written; mom6x_rk2_field materialises them on request.
+  const bool defer_la = dev_coef && !host_coef;
+  bt_defer_layer_accel(c, defer_la);
+  s->accel_bt_deferred = defer_la;
+  LayerAccelSrc LAu, LAv;
   CHK(mom6x_btstep(c, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, s->pbce, s->eta_PF, u_av, v_av, s->u_accel_bt,
                    s->v_accel_bt, s->eta_pred, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, &s->BT, taux_bot, tauy_bot,
                    s->uh_in, s->vh_in, u_inst, v_inst, nullptr));
@@ -341,7 +353,10 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   const double dt_pred = dt * R.be;                                     // :679
   if (!host_coef) {   // (with the callback, it needs up/vp before the solve: no fusion)
     // :737-738; the coefficient sweep forms the velocity estimate of :681-694 for its upwinding anyway and leaves it in up, vp
-    if (dev_coef) CHK(vertvisc_coef_upd(c, 2, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt_pred, h, dt_pred, up, vp));
+    if (dev_coef) {
+      REQUIRE(bt_layer_accel_src(c, &LAu, &LAv), MOM6X_EINVAL, "step_MOM_dyn_split_RK2: no barotropic result to take the layer accelerations from");
+      CHK(vertvisc_coef_upd_la(c, u_inst, v_inst, u_bc, v_bc, LAu, LAv, dt_pred, h, dt_pred, up, vp));
+    }
     // :681-694 + :754 + :763-767 in one column sweep per direction (k_vertvisc_fused / k_vertvisc_cols)
     const bool same_dt = (R.visc_rem_dt_bug != 0);
     if (dev_coef)
@@ -391,7 +406,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     CHK(mom6x_horizontal_viscosity(c, u_av, v_av, h_av, s->diffu, s->diffv));
   }
   // :893 + :900-907: u_bc_accel = (CAu + PFu) + diffu is formed by the kernel that makes CAu
-  CHK(CorAdCalc_bc(c, u_av, v_av, h_av, uh, vh, s->CAu, s->CAv, s->PFu, s->PFv, s->diffu, s->diffv, u_bc, v_bc));
+  CHK(CorAdCalc_bc(c, u_av, v_av, h_av, uh, vh, s->CAu, s->CAv, s->PFu, s->PFv, s->diffu, s->diffv, u_bc, v_bc, nullptr, nullptr, 0.0));
   // corrector btstep :939-942
   CHK(mom6x_btstep(c, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, s->pbce, s->eta_PF, u_av, v_av, s->u_accel_bt,
                    s->v_accel_bt, s->eta_pred, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, &s->BT, taux_bot, tauy_bot, uh, vh,
@@ -400,7 +415,8 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   // u = mask*(u + dt*(u_bc_accel + u_accel_bt))  :957-966
   if (!host_coef) {   // :957-966 + :1013 + :1022 in one column sweep per direction
     if (dev_coef) {   // :1002-1003; u = mask*(u + dt*(u_bc_accel + u_accel_bt)) is left in place by the coefficient sweep
-      CHK(vertvisc_coef_upd(c, 2, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt, h, dt, u_inst, v_inst));
+      REQUIRE(bt_layer_accel_src(c, &LAu, &LAv), MOM6X_EINVAL, "step_MOM_dyn_split_RK2: no barotropic result to take the layer accelerations from");
+      CHK(vertvisc_coef_upd_la(c, u_inst, v_inst, u_bc, v_bc, LAu, LAv, dt, h, dt, u_inst, v_inst));
       CHK(vertvisc_fused(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, u_inst, v_inst, taux, tauy, dt, s->taux_bot,
                          s->tauy_bot, s->visc_rem_u, s->visc_rem_v));
     } else
@@ -423,10 +439,12 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2, 1);   // :1064-1066
   halo_complete(c);                                                     // :1072
   KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2, 2);
-  KLAUNCH(c, "k_uhtr", k_uhtr, gridk(nxa(d.ni + 5, -3), d.nj + 5, nk, b), b, d, uhtr, vhtr, (const double *)uh, (const double *)vh, dt);   // :1072-1079
+  // :1072-1079 uhtr += uh*dt: the ring of halo faces here, the box of own faces inside the kernel below, which reads uh, vh anyway
+  KLAUNCH(c, "k_uhtr", k_uhtr, gridk(nxa(d.ni + 5, -3), d.nj + 5, nk, b), b, d, uhtr, vhtr, (const double *)uh, (const double *)vh, dt, 1);
   // CAu_pred for the next step :1081-1090
-  CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));
+  CHK(CorAdCalc_bc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, uhtr, vhtr, dt));
   s->CAu_pred_stored = true;
+  bt_defer_layer_accel(c, false);   // (a btstep called from outside the step writes its accel_layer arrays; the pending result stays)
   HIPCHK(hipGetLastError());
   REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
   return MOM6X_OK;

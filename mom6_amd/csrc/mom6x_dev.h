@@ -131,9 +131,26 @@ void diag_sums_free(mom6x_ctx *c);                                 // diag_sums.
 // dyn_kernels.hip: vertvisc_coef looking at u (mode 0), mask*(u + dtx*u_bc) (1) or mask*(u + dtx*(u_bc + u_abt)) (2)
 int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h, const double *uh, const double *vh, double *CAu,
                  double *CAv, const double *PFu, const double *PFv, const double *diffu, const double *diffv, double *u_bc,
-                 double *v_bc);   // dyn_kernels.hip
+                 double *v_bc, double *uhtr, double *vhtr, double dt_tr);   // dyn_kernels.hip
 int vertvisc_coef_upd(mom6x_ctx *c, int mode, const double *u, const double *v, const double *u_bc, const double *v_bc,
                       const double *u_abt, const double *v_abt, double dtx, const double *h, double dt, double *u_out, double *v_out);
+// btstep_layer_accel (MOM_barotropic.F90:3432-3504) evaluated by the CONSUMER of accel_layer_u / _v instead of being written to
+// HBM and read back: what a face column needs of the barotropic solver's 2-D results (barotropic.hip keeps them in its work block
+// until the next btstep).  mode 3 of vertvisc_coef_upd = mode 2 with u_abt formed from these.
+struct LayerAccelSrc {
+  const double *pbce;      // 3-D
+  const double *e_anom;    // 2-D, h points
+  const double *g_own;     // gtot_E | gtot_N at the cell of the face's own index
+  const double *g_nbr;     // gtot_W | gtot_S at the next cell
+  const double *a2d;       // u_accel_bt | v_accel_bt (2-D)
+  double underflow;        // accel_underflow = vel_underflow / dt
+};
+void bt_defer_layer_accel(mom6x_ctx *c, bool on);                       // barotropic.hip: btstep skips k_layer_accel while on
+bool bt_layer_accel_src(mom6x_ctx *c, LayerAccelSrc *u, LayerAccelSrc *v);   // false if no deferred result is pending
+int bt_layer_accel_materialize(mom6x_ctx *c, double *accel_layer_u, double *accel_layer_v);
+int vertvisc_coef_upd_la(mom6x_ctx *c, const double *u, const double *v, const double *u_bc, const double *v_bc,
+                         const LayerAccelSrc &LAu, const LayerAccelSrc &LAv, double dtx, const double *h, double dt, double *u_out,
+                         double *v_out);
 // dyn_kernels.hip: [u = mask*(u_in + dtx*(u_bc + u_abt));] vertvisc(u, v, dt); [vertvisc_remnant(vr_u, vr_v, dt)] in one sweep
 int vertvisc_fused(mom6x_ctx *c, const double *u_in, const double *v_in, const double *u_bc, const double *v_bc,
                    const double *u_abt, const double *v_abt, double dtx, double *u, double *v, const double *taux,
