@@ -299,21 +299,40 @@ k_flux_thickness(Dm d, const double *__restrict__ G, const double *__restrict__ 
   h_u[f] = hu;
 }
 
-// continuity_zonal_convergence :348 / continuity_merdional_convergence :386
+// continuity_zonal_convergence :348 / continuity_merdional_convergence :386.  Column walk over KCHUNK layers: the 2-D plane
+// IareaT is read once per chunk, not once per layer (one word per cell-layer less).  The step's time averages of the
+// thicknesses that read the same arrays ride along (RK2.F90:808-810, :1025-1027, :1064-1066): `av_mode` 1: h_av = 0.5 * (h_old +
+// h_new) with h_old = the routine's input thickness `av_src` (second direction of the predictor's call); 2: h_av = h_old (a copy
+// kept by the first direction of the corrector's call, whose in-place update destroys h_old); 3: h_av = 0.5 * (h_av + h_new)
+// (its second direction).  Own cells only; the halo frame of h_av is the caller's (k_h_av after the group pass).
 template <int DIR>
 __global__ void __launch_bounds__(256)
 k_convergence(Dm d, const double *__restrict__ G, double *h, const double *__restrict__ uh, double dt,
-              const double *hin, double h_min, int i0, int i1, int j0, int j1, int *flag) {
+              const double *hin, double h_min, int i0, int i1, int j0, int j1, int *flag, double *h_av, const double *av_src,
+              int av_mode) {
   const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
   if (i < i0 || i > i1 || j > j1) return;
   const int st = DIR ? d.pitch : 1;
-  const size_t c2 = ix2(d, i, j), c = c2 + (size_t)k * d.slab;
+  const size_t c2 = ix2(d, i, j), slab = (size_t)d.slab;
   const double IareaT = gm(G, d, MOM6X_G_IareaT)[c2];
-  const double hn = hin[c] - dt * IareaT * (uh[c] - uh[c - st]);
-  h[c] = dmax(hn, h_min);
-  if (hn != hn) atomicOr(flag, 1);   // a NaN has reached the thicknesses: MOM6X_ENUMERIC at the next mom6x_ctx_sync
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  const bool own = (i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1);
+  bool bad = false;
+  for (int k = k0; k < k1; k++) {
+    const size_t c = c2 + (size_t)k * slab;
+    const double h_old = hin[c];
+    const double hn = h_old - dt * IareaT * (uh[c] - uh[c - st]);
+    const double hnew = dmax(hn, h_min);
+    h[c] = hnew;
+    if (av_mode && own) {
+      if (av_mode == 1) h_av[c] = 0.5 * (av_src[c] + hnew);
+      else if (av_mode == 2) h_av[c] = h_old;
+      else h_av[c] = 0.5 * (h_av[c] + hnew);
+    }
+    bad = bad || (hn != hn);
+  }
+  if (bad) atomicOr(flag, 1);   // a NaN has reached the thicknesses: MOM6X_ENUMERIC at the next mom6x_ctx_sync
 }
 
 template <int DIR>
@@ -392,8 +411,14 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
     }
   }
   if (first_pass || !c->cont_h_unused)   // (the second direction's new thicknesses are the routine's result -- unless nobody wants it)
-  KLAUNCH(c, "k_convergence<DIR>", k_convergence<DIR>, grid3(nxa(ieh - ish + 1, ish), jeh - jsh + 1, d.nk, blk), blk, d, c->G,
-                     h, uh, dt, hin_conv, h_min_conv, ish, ieh, jsh, jeh, c->flag);
+  {
+    // the time average of the thicknesses the RK2 step wants next to this convergence (c->cont_av_*; 0: none)
+    int av_mode = 0;
+    if (c->cont_av_kind == 1 && !first_pass) av_mode = 1;
+    if (c->cont_av_kind == 2) av_mode = first_pass ? 2 : 3;
+    KLAUNCH(c, "k_convergence<DIR>", k_convergence<DIR>, grid3(nxa(ieh - ish + 1, ish), jeh - jsh + 1, nchunks(d.nk), blk), blk, d, c->G,
+                       h, uh, dt, hin_conv, h_min_conv, ish, ieh, jsh, jeh, c->flag, c->cont_av, c->cont_av_src, av_mode);
+  }
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }

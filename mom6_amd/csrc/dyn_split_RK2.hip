@@ -381,13 +381,19 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   start3(c, { s->visc_rem_u, s->visc_rem_v, up, vp }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :769 + pass_uvp :761/:773: completed inside continuity
 
   // uh = u_av * h ; hp = h + dt * div . uh  :779-781
-  CHK(mom6x_continuity_PPM(c, up, vp, h, hp, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av, &s->BT,
-                           nullptr, nullptr));
+  // (h_av = 0.5 * (h + hp) of :808-810 on the tile's own cells is written by the call's last convergence kernel, which has
+  //  hp in a register and reads nothing twice)
+  c->cont_av_kind = 1; c->cont_av = h_av; c->cont_av_src = h;
+  {
+    const int rc_c = mom6x_continuity_PPM(c, up, vp, h, hp, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av, &s->BT,
+                                          nullptr, nullptr);
+    c->cont_av_kind = 0;
+    if (rc_c) return rc_c;
+  }
   halo_complete(c);
   // hp (pass_hp_uv :785), the averaged velocities and the transports (pass_av_uvh :804 ... :865) travel on the halo stream
-  // while h_av of the tile's own cells and the barotropic mass source are formed; the frame of h_av follows the completion
+  // while the barotropic mass source is formed; the frame of h_av follows the completion
   start3(c, { hp, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)hp, 0, 0.0, 2, 1);   // :808-810
 
   // ---- corrector
   CHK(mom6x_bt_mass_source(c, hp, s->eta_pred, 0));                     // :820
@@ -429,14 +435,21 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     CHK(vertvisc_fused(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, u_inst, v_inst, taux, tauy, dt, s->taux_bot,
                        s->tauy_bot, s->visc_rem_u, s->visc_rem_v));       // :1013 + :1022
   }
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2, 0);   // :1025-1027
+  // h_av = h :1025-1027 and h_av = 0.5 * (h_av + h) :1064-1066: on the tile's own cells both ride on the convergence kernels of
+  // the in-place continuity call between them (the first keeps the old thickness it is about to overwrite, the second averages);
+  // the frame of halo cells is copied here and averaged after the group pass has brought the new thicknesses
+  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2, 2);
   start3(c, { s->visc_rem_u, s->visc_rem_v, u_inst, v_inst }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :1030 + pass_uv :1019/:1034: completed inside continuity
   // uh = u_av * h ; h = h + dt * div . uh  :1041-1043
-  CHK(mom6x_continuity_PPM(c, u_inst, v_inst, h, h, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av,
-                           nullptr, nullptr, nullptr));
+  c->cont_av_kind = 2; c->cont_av = h_av; c->cont_av_src = nullptr;
+  {
+    const int rc_c = mom6x_continuity_PPM(c, u_inst, v_inst, h, h, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av,
+                                          nullptr, nullptr, nullptr);
+    c->cont_av_kind = 0;
+    if (rc_c) return rc_c;
+  }
   halo_complete(c);
   start3(c, { h, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);          // pass_h :1045 + start_group_pass(CS%pass_av_uvh) :1054
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2, 1);   // :1064-1066
   halo_complete(c);                                                     // :1072
   KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2, 2);
   // :1072-1079 uhtr += uh*dt: the ring of halo faces here, the box of own faces inside the kernel below, which reads uh, vh anyway

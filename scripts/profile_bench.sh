@@ -15,6 +15,7 @@ fi
 if [ "${1:-all}" != "stats" ]; then
 timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -o fetch -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-config4 --no-comm-model --tracers -1 > $OUT/prof_fetch.log 2>&1; echo "fetch rc=$?"
 timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -o write -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-config4 --no-comm-model --tracers -1 > $OUT/prof_write.log 2>&1; echo "write rc=$?"
+timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU --output-format csv -d $OUT/prof_sq -o sq -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-config4 --no-comm-model --tracers -1 > $OUT/prof_sq.log 2>&1; echo "sq rc=$?"
 fi
 cd $ROOT
 find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -type f 2>/dev/null | head -20

@@ -42,19 +42,27 @@ def main():
             a[n][0] += 1
             a[n][1] += float(r["Counter_Value"]) * 1024.0     # FETCH_SIZE / WRITE_SIZE are in KB
         agg[tag] = a
-    # calibration on k_uhtr (uhtr = uhtr + dt*uh, vhtr = vhtr + dt*vh: one launch per step that reads four 3-D arrays and writes
-    # two, nothing else): the guide's "calibrate on a known byte count in your own access pattern" (FETCH_SIZE counts 64 B
-    # per 128-B request on gfx950: a factor close to 2 on streaming reads; WRITE_SIZE close to 1)
-    cells = (ni + 1) * nj * nk * 8.0
-    cal_k = "k_uhtr"
+    # calibration on a kernel whose traffic is known exactly -- the guide's "calibrate on a known byte count in your own access
+    # pattern" (FETCH_SIZE counts 64 B per 128-B request on gfx950: a factor close to 2 on streaming reads; WRITE_SIZE close to
+    # 1).  Rounds 1-2 used k_uhtr (four 3-D reads, two writes); since round 3 it only does a ring of halo faces, and the
+    # reference kernel is k_vertvisc_remnant_cols<0, 75>: the whole column on chip, reads a_u (nk+1 levels) and h_u (nk), writes
+    # visc_rem_u (nk) on the (ni+1) x nj zonal faces, nothing else.
+    if "k_vertvisc_remnant_cols<0, 75>" in agg["fetch"] and nk == 75:
+        cal_k = "k_vertvisc_remnant_cols<0, 75>"
+        faces = (ni + 1) * nj * 8.0
+        exp_fetch, exp_write = faces * (2 * nk + 1), faces * nk
+        steps_k = "k_pgf_main"            # one launch per step
+    else:
+        cal_k = "k_uhtr"
+        cells = (ni + 1) * nj * nk * 8.0
+        exp_fetch, exp_write = cells * 4.0, cells * 2.0
+        steps_k = cal_k
     n_cal = agg["fetch"][cal_k][0]
-    exp_fetch = cells * 4.0
-    exp_write = cells * 2.0
     cal_f = exp_fetch / (agg["fetch"][cal_k][1] / n_cal)
     cal_w = exp_write / (agg["write"][cal_k][1] / agg["write"][cal_k][0])
-    nsteps = n_cal     # k_uhtr runs once per step
+    nsteps = agg["fetch"][steps_k][0] if steps_k in agg["fetch"] else n_cal
     with open(f"{prefix}_hbm_pmc.csv", "w") as f:
-        f.write(f"# FETCH_SIZE x{cal_f:.3f}, WRITE_SIZE x{cal_w:.3f} (calibration on k_uhtr: known {exp_fetch / 1e6:.1f} MB read, "
+        f.write(f"# FETCH_SIZE x{cal_f:.3f}, WRITE_SIZE x{cal_w:.3f} (calibration on {cal_k}: known {exp_fetch / 1e6:.1f} MB read, "
                 f"{exp_write / 1e6:.1f} MB written per launch on average)\n")
         f.write("kernel,dispatches,fetch_bytes_per_launch,write_bytes_per_launch,total_MB_per_launch\n")
         names = sorted((n for n in agg["fetch"] if n.startswith("k_")), key=lambda n: -(agg["fetch"][n][1] + agg["write"][n][1]))
@@ -70,11 +78,35 @@ def main():
             total += cf * (fb + wb)
     print(f"all dycore kernels, all dispatches of the PMC run: {total / 1e9:.1f} GB")
     per_step = {n: agg["fetch"][n][0] / nsteps for n in out}
-    json.dump({"fetch_cal": cal_f, "write_cal": cal_w, "steps_in_run": nsteps, "traffic_bytes_per_launch": out,
+    json.dump({"fetch_cal": cal_f, "write_cal": cal_w, "calibration_kernel": cal_k, "steps_in_run": nsteps, "traffic_bytes_per_launch": out,
                "launches_per_step": per_step, "bytes_per_step": total / nsteps, "total_bytes_all_dispatches": total,
                "note": "dynamics only (bench.py --tracers -1): every k_* dispatch of the run / the number of steps in it"},
               open(f"{prefix}_hbm_pmc.json", "w"), indent=1)
     print(open(f"{prefix}_hbm_pmc.csv").read()[:3000])
+    # optional third pass (scripts/profile_bench.sh): SQ counters per dispatch -> per-launch averages per kernel
+    sq = f"{src}/prof_sq/sq_counter_collection.csv"
+    if os.path.exists(sq):
+        a = collections.defaultdict(lambda: collections.defaultdict(float))
+        nd = collections.defaultdict(set)
+        for r in csv.DictReader(open(sq)):
+            n = short(r["Kernel_Name"])
+            if not n.startswith("k_"):
+                continue
+            a[n][r["Counter_Name"]] += float(r["Counter_Value"]); nd[n].add(r["Dispatch_Id"])
+        outsq = {}
+        for n in a:
+            k = max(len(nd[n]), 1)
+            c = {cn: v / k for cn, v in a[n].items()}
+            if c.get("SQ_BUSY_CYCLES"):
+                pass
+            outsq[n] = c
+        json.dump({"per_launch": outsq, "note": "rocprofv3 --pmc SQ_* of bench.py --steps 1 --warmup 1 --tracers -1: averages per launch; "
+                   "SQ_INSTS_VALU = VALU wave-instructions issued, SQ_ACTIVE_INST_VALU = cycles the VALUs were executing (summed over "
+                   "SIMDs, in quad-cycles on this counter's unit), SQ_WAVES = wavefronts launched, SQ_BUSY_CYCLES / SQ_WAVE_CYCLES = busy / "
+                   "wave-resident cycles summed over the shader engines / wavefronts"}, open(f"{prefix}_sq_pmc.json", "w"), indent=1)
+        top = sorted(outsq, key=lambda n: -outsq[n].get("SQ_INSTS_VALU", 0))[:6]
+        for n in top:
+            print(n, {k: f"{v:.3e}" for k, v in outsq[n].items()})
 
 
 if __name__ == "__main__":
