@@ -90,31 +90,24 @@ __device__ __forceinline__ double max4(double a, double b, double c, double d) {
 __device__ __forceinline__ double min4(double a, double b, double c, double d) { return dmin(dmin(dmin(a, b), c), d); }
 
 // CorAdCalc, pass 2: the accelerations CAu (I=-1..ni-1, j=0..nj-1) and CAv (i=0..ni-1, J=-1..nj-1).
-__global__ void __launch_bounds__(256)
-k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
-            const double *__restrict__ uh, const double *__restrict__ vh, const double *__restrict__ q,
-            const double *__restrict__ absv, const double *__restrict__ KE, double *__restrict__ CAu,
-            double *__restrict__ CAv, int scheme, int bound, const double *__restrict__ h, int en_dis,
-            const double *__restrict__ PFu, const double *__restrict__ PFv, const double *__restrict__ diffu,
-            const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc,
-            double *__restrict__ uhtr, double *__restrict__ vhtr, double dt_tr) {
-  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
-  if (i > d.ni - 1 || j > d.nj - 1) return;
-  if (i < (-1)) return;
-  const int st = d.pitch;
-  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
-  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
-  const bool do_u = (j >= 0), do_v = (i >= 0);
-  // uhtr = uhtr + uh*dt, vhtr = vhtr + vh*dt (RK2.F90:1072-1079) for the points of this kernel's box (-1..ni-1, -1..nj-1), whose
-  // uh(I,j), vh(i,J) it reads anyway; k_uhtr does the ring around the box
-  if (uhtr)
-    for (int k = k0; k < k1; k++) {
-      const size_t c = x + (size_t)k * slab;
-      uhtr[c] = uhtr[c] + uh[c] * dt_tr;
-      vhtr[c] = vhtr[c] + vh[c] * dt_tr;
-    }
-  const double IdxCu = gm(G, d, MOM6X_G_IdxCu)[x], IdyCv = gm(G, d, MOM6X_G_IdyCv)[x];
+// One layer of one point, shared by the two-kernel form (q, KE, abs_vort read from HBM: k_corad_acc) and the one-kernel form
+// (from the work-group's LDS tile: k_corad_fused) through the accessors Q(di, dj), KEf(di, dj), AVf(di, dj).
+struct CoradAcc {
+  const double *u, *v, *uh, *vh, *h, *PFu, *PFv, *diffu, *diffv;
+  double *CAu, *CAv, *u_bc, *v_bc;
+  double IdxCu, IdyCv, Lv[4], Lu[4];
+  int scheme, bound, en_dis;
+  bool do_u, do_v;
+};
+template <class QF, class KF, class AF>
+__device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int st, const QF &Q, const KF &KEf, const AF &AVf) {
+  const double *__restrict__ u = X.u, *__restrict__ v = X.v, *__restrict__ uh = X.uh, *__restrict__ vh = X.vh, *__restrict__ h = X.h;
+  const double *__restrict__ PFu = X.PFu, *__restrict__ PFv = X.PFv, *__restrict__ diffu = X.diffu, *__restrict__ diffv = X.diffv;
+  double *__restrict__ CAu = X.CAu, *__restrict__ CAv = X.CAv, *__restrict__ u_bc = X.u_bc, *__restrict__ v_bc = X.v_bc;
+  const double IdxCu = X.IdxCu, IdyCv = X.IdyCv;
+  const double *Lv = X.Lv, *Lu = X.Lu;
+  const int scheme = X.scheme, bound = X.bound, en_dis = X.en_dis;
+  const bool do_u = X.do_u, do_v = X.do_v;
   const double C1_12 = 1.0 / 12.0;
   // CORIOLIS_EN_DIS (:326-333, :590-635): the centred thickness transport of a face and the one the continuity solver
   // gave bracket the transport used by the energy-dissipating scheme; recomputed here for the four faces each point needs
@@ -130,17 +123,9 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
     }
     if (uhc > uhm) { mn = uhm; mx = uhc; } else { mx = uhm; mn = uhc; }
   };
-  double Lv[4] = {0., 0., 0., 0.}, Lu[4] = {0., 0., 0., 0.};
-  if (en_dis) {
-    const double *dx_Cv = gm(G, d, MOM6X_G_dx_Cv), *dy_Cu = gm(G, d, MOM6X_G_dy_Cu);
-    if (do_u) { Lv[0] = dx_Cv[x]; Lv[1] = dx_Cv[x + 1]; Lv[2] = dx_Cv[x - st]; Lv[3] = dx_Cv[x + 1 - st]; }
-    if (do_v) { Lu[0] = dy_Cu[x - 1]; Lu[1] = dy_Cu[x - 1 + st]; Lu[2] = dy_Cu[x]; Lu[3] = dy_Cu[x + st]; }
-  }
-  for (int k = k0; k < k1; k++) {
-    const size_t c = x + (size_t)k * slab;
-    const double q00 = q[c];
+    const double q00 = Q(0, 0);
     if (do_u) {
-      const double q0m = q[c - st];
+      const double q0m = Q(0, -1);
       double ca;
       if (scheme == MOM6X_SADOURNY75_ENERGY && en_dis) {   // :665-684
         double mn0, mx0, mn1, mx1, mn2, mx2, mn3, mx3;      // v faces (i,J), (i+1,J), (i,J-1), (i+1,J-1)
@@ -162,24 +147,24 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
       } else if (scheme == MOM6X_SADOURNY75_ENSTRO) {
         ca = 0.125 * (IdxCu * (q00 + q0m)) * ((vh[c + 1] + vh[c]) + (vh[c - st] + vh[c + 1 - st]));
       } else {   // ARAKAWA_HSU90 :523-533, :683-686
-        const double a = (q00 + (q[c + 1] + q0m)) * C1_12;
-        const double dd = ((q00 + q[c + 1 - st]) + q0m) * C1_12;
-        const double b = (q00 + (q[c - 1] + q0m)) * C1_12;
-        const double cc = ((q00 + q[c - 1 - st]) + q0m) * C1_12;
+        const double a = (q00 + (Q(1, 0) + q0m)) * C1_12;
+        const double dd = ((q00 + Q(1, -1)) + q0m) * C1_12;
+        const double b = (q00 + (Q(-1, 0) + q0m)) * C1_12;
+        const double cc = ((q00 + Q(-1, -1)) + q0m) * C1_12;
         ca = (((a * vh[c + 1]) + (cc * vh[c - st])) + ((b * vh[c]) + (dd * vh[c + 1 - st]))) * IdxCu;
       }
       if (bound) {   // :734-747
-        const double av0 = absv[c], avm = absv[c - st];
+        const double av0 = AVf(0, 0), avm = AVf(0, -1);
         const double fv1 = av0 * v[c + 1], fv2 = av0 * v[c], fv3 = avm * v[c + 1 - st], fv4 = avm * v[c - st];
         ca = dmin(ca, max4(fv1, fv2, fv3, fv4));
         ca = dmax(ca, min4(fv1, fv2, fv3, fv4));
       }
-      const double cau = ca - (KE[c + 1] - KE[c]) * IdxCu;
+      const double cau = ca - (KEf(1, 0) - KEf(0, 0)) * IdxCu;
       CAu[c] = cau;
       if (u_bc) u_bc[c] = (cau + PFu[c]) + diffu[c];   // u_bc_accel of the RK2 step (:900-907) while CAu is at hand
     }
     if (do_v) {
-      const double qm0 = q[c - 1];
+      const double qm0 = Q(-1, 0);
       double ca;
       if (scheme == MOM6X_SADOURNY75_ENERGY && en_dis) {   // :776-795
         double mn0, mx0, mn1, mx1, mn2, mx2, mn3, mx3;      // u faces (I-1,j), (I-1,j+1), (I,j), (I,j+1)
@@ -202,22 +187,171 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
         ca = -0.125 * (IdyCv * (qm0 + q00)) * ((uh[c - 1] + uh[c - 1 + st]) + (uh[c] + uh[c + st]));
       } else {
         // a(I-1,j), c(I,j+1), b(I,j), d(I-1,j+1)
-        const double a_m = (qm0 + (q00 + q[c - 1 - st])) * C1_12;
-        const double c_p = ((q[c + st] + q[c - 1]) + q00) * C1_12;
-        const double b_0 = (q00 + (qm0 + q[c - st])) * C1_12;
-        const double d_mp = ((q[c - 1 + st] + q00) + qm0) * C1_12;
+        const double a_m = (qm0 + (q00 + Q(-1, -1))) * C1_12;
+        const double c_p = ((Q(0, 1) + Q(-1, 0)) + q00) * C1_12;
+        const double b_0 = (q00 + (qm0 + Q(0, -1))) * C1_12;
+        const double d_mp = ((Q(-1, 1) + q00) + qm0) * C1_12;
         ca = -(((a_m * uh[c - 1]) + (c_p * uh[c + st])) + ((b_0 * uh[c]) + (d_mp * uh[c - 1 + st]))) * IdyCv;
       }
       if (bound) {
-        const double av0 = absv[c], avm = absv[c - 1];
+        const double av0 = AVf(0, 0), avm = AVf(-1, 0);
         const double fu1 = -av0 * u[c + st], fu2 = -av0 * u[c], fu3 = -avm * u[c - 1 + st], fu4 = -avm * u[c - 1];
         ca = dmin(ca, max4(fu1, fu2, fu3, fu4));
         ca = dmax(ca, min4(fu1, fu2, fu3, fu4));
       }
-      const double cav = ca - (KE[c + st] - KE[c]) * IdyCv;
+      const double cav = ca - (KEf(0, 1) - KEf(0, 0)) * IdyCv;
       CAv[c] = cav;
       if (v_bc) v_bc[c] = (cav + PFv[c]) + diffv[c];
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
+            const double *__restrict__ uh, const double *__restrict__ vh, const double *__restrict__ q,
+            const double *__restrict__ absv, const double *__restrict__ KE, double *__restrict__ CAu,
+            double *__restrict__ CAv, int scheme, int bound, const double *__restrict__ h, int en_dis,
+            const double *__restrict__ PFu, const double *__restrict__ PFv, const double *__restrict__ diffu,
+            const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc,
+            double *__restrict__ uhtr, double *__restrict__ vhtr, double dt_tr) {
+  const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < (-1)) return;
+  const int st = d.pitch;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
+  CoradAcc X;
+  X.u = u; X.v = v; X.uh = uh; X.vh = vh; X.h = h; X.PFu = PFu; X.PFv = PFv; X.diffu = diffu; X.diffv = diffv;
+  X.CAu = CAu; X.CAv = CAv; X.u_bc = u_bc; X.v_bc = v_bc; X.scheme = scheme; X.bound = bound; X.en_dis = en_dis;
+  X.do_u = (j >= 0); X.do_v = (i >= 0);
+  X.IdxCu = gm(G, d, MOM6X_G_IdxCu)[x]; X.IdyCv = gm(G, d, MOM6X_G_IdyCv)[x];
+  for (int n = 0; n < 4; n++) { X.Lv[n] = 0.; X.Lu[n] = 0.; }
+  if (en_dis) {
+    const double *dx_Cv = gm(G, d, MOM6X_G_dx_Cv), *dy_Cu = gm(G, d, MOM6X_G_dy_Cu);
+    if (X.do_u) { X.Lv[0] = dx_Cv[x]; X.Lv[1] = dx_Cv[x + 1]; X.Lv[2] = dx_Cv[x - st]; X.Lv[3] = dx_Cv[x + 1 - st]; }
+    if (X.do_v) { X.Lu[0] = dy_Cu[x - 1]; X.Lu[1] = dy_Cu[x - 1 + st]; X.Lu[2] = dy_Cu[x]; X.Lu[3] = dy_Cu[x + st]; }
+  }
+  // uhtr = uhtr + uh*dt, vhtr = vhtr + vh*dt (RK2.F90:1072-1079) for the points of this kernel's box (-1..ni-1, -1..nj-1), whose
+  // uh(I,j), vh(i,J) it reads anyway; k_uhtr does the ring around the box
+  if (uhtr)
+    for (int k = k0; k < k1; k++) {
+      const size_t c = x + (size_t)k * slab;
+      uhtr[c] = uhtr[c] + uh[c] * dt_tr;
+      vhtr[c] = vhtr[c] + vh[c] * dt_tr;
+    }
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    corad_acc_layer(X, c, st, [&](int di, int dj) { return q[c + di + dj * st]; }, [&](int di, int dj) { return KE[c + di + dj * st]; },
+                    [&](int di, int dj) { return absv[c + di + dj * st]; });
+  }
+}
+
+// CorAdCalc in ONE kernel: the potential vorticity, the kinetic energy (and abs_vort) of a layer go from the threads that
+// computed them to their neighbours through LDS instead of through HBM (2 writes + ~4.6 reads per cell-layer less).  A work-group
+// of CF_X x CF_Y = 32 x 16 threads owns a tile of points; every thread evaluates k_corad_q's expressions for its own point,
+// the accelerations are evaluated by the tile minus a frame of one point (q is read at -1..+1, KE at 0..+1): 30 x 14 outputs per
+// tile.  Two LDS buffers alternate between layers: one barrier per layer.  Same expressions, same bits as k_corad_q + k_corad_acc.
+#define CF_X 32
+#define CF_Y 16
+#define CF_LDW (CF_X + 2)
+#define CF_LDN ((CF_Y + 2) * CF_LDW)
+__global__ void __launch_bounds__(CF_X * CF_Y, 4)   // two work-groups (16 wavefronts) per CU: at most 128 registers
+k_corad_fused(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
+              const double *__restrict__ uh, const double *__restrict__ vh, double *__restrict__ CAu,
+              double *__restrict__ CAv, int scheme, int bound, const double *__restrict__ h, int en_dis,
+              const double *__restrict__ PFu, const double *__restrict__ PFv, const double *__restrict__ diffu,
+              const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc,
+              double *__restrict__ uhtr, double *__restrict__ vhtr, double dt_tr, int no_slip, int ke_scheme, double vol_neglect,
+              int kc) {
+  __shared__ double lds[2 * 3 * CF_LDN];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i = -2 + (int)blockIdx.x * (CF_X - 2) + tx;
+  const int j = -2 + (int)blockIdx.y * (CF_Y - 2) + ty;
+  const int st = d.pitch;
+  const size_t slab = (size_t)d.slab;
+  const int k0 = blockIdx.z * kc, k1 = min(k0 + kc, d.nk);
+  const int l = (ty + 1) * CF_LDW + (tx + 1);
+  const bool live = (i <= d.ni) && (j <= d.nj);                 // the range of k_corad_q: (-2..ni, -2..nj)
+  const size_t x = live ? ix2(d, i, j) : ix2(d, 0, 0);
+  const bool out = live && tx >= 1 && tx <= CF_X - 2 && ty >= 1 && ty <= CF_Y - 2 && i <= d.ni - 1 && j <= d.nj - 1;   // (i, j >= -1)
+  // ---- the coefficients of k_corad_q
+  const double *mT = gm(G, d, MOM6X_G_mask2dT), *areaT = gm(G, d, MOM6X_G_areaT);
+  const double A00 = mT[x] * areaT[x], A10 = mT[x + 1] * areaT[x + 1];
+  const double A01 = mT[x + st] * areaT[x + st], A11 = mT[x + 1 + st] * areaT[x + 1 + st];
+  const double Area_q = (A00 + A11) + (A10 + A01);
+  const double dyCv0 = gm(G, d, MOM6X_G_dyCv)[x], dyCv1 = gm(G, d, MOM6X_G_dyCv)[x + 1];
+  const double dxCu0 = gm(G, d, MOM6X_G_dxCu)[x], dxCu1 = gm(G, d, MOM6X_G_dxCu)[x + st];
+  const double mBu = gm(G, d, MOM6X_G_mask2dBu)[x], IareaBu = gm(G, d, MOM6X_G_IareaBu)[x];
+  const double fBu = gm(G, d, MOM6X_G_CoriolisBu)[x];
+  const double vfac = no_slip ? (2.0 - mBu) : mBu;
+  const bool do_KE = live && (i >= -1 && j >= -1);
+  double aCu0 = 0, aCu1 = 0, aCv0 = 0, aCv1 = 0, IareaT = 0;
+  if (do_KE) {
+    aCu0 = gm(G, d, MOM6X_G_areaCu)[x]; aCu1 = gm(G, d, MOM6X_G_areaCu)[x - 1];
+    aCv0 = gm(G, d, MOM6X_G_areaCv)[x]; aCv1 = gm(G, d, MOM6X_G_areaCv)[x - st];
+    IareaT = gm(G, d, MOM6X_G_IareaT)[x];
+  }
+  // ---- and of k_corad_acc
+  CoradAcc X;
+  X.u = u; X.v = v; X.uh = uh; X.vh = vh; X.h = h; X.PFu = PFu; X.PFv = PFv; X.diffu = diffu; X.diffv = diffv;
+  X.CAu = CAu; X.CAv = CAv; X.u_bc = u_bc; X.v_bc = v_bc; X.scheme = scheme; X.bound = bound; X.en_dis = en_dis;
+  X.do_u = out && (j >= 0); X.do_v = out && (i >= 0);
+  X.IdxCu = gm(G, d, MOM6X_G_IdxCu)[x]; X.IdyCv = gm(G, d, MOM6X_G_IdyCv)[x];
+  for (int n = 0; n < 4; n++) { X.Lv[n] = 0.; X.Lu[n] = 0.; }
+  if (en_dis && out) {
+    const double *dx_Cv = gm(G, d, MOM6X_G_dx_Cv), *dy_Cu = gm(G, d, MOM6X_G_dy_Cu);
+    if (X.do_u) { X.Lv[0] = dx_Cv[x]; X.Lv[1] = dx_Cv[x + 1]; X.Lv[2] = dx_Cv[x - st]; X.Lv[3] = dx_Cv[x + 1 - st]; }
+    if (X.do_v) { X.Lu[0] = dy_Cu[x - 1]; X.Lu[1] = dy_Cu[x - 1 + st]; X.Lu[2] = dy_Cu[x]; X.Lu[3] = dy_Cu[x + st]; }
+  }
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    double *sq = lds + ((k - k0) & 1) * 3 * CF_LDN, *sk = sq + CF_LDN, *sa = sq + 2 * CF_LDN;
+    double qv = 0.0, kev = 0.0, av = 0.0;
+    if (live) {
+      const double u0 = u[c], v0 = v[c];
+      const double dvdx = (v[c + 1] * dyCv1) - (v0 * dyCv0);
+      const double dudy = (u[c + st] * dxCu1) - (u0 * dxCu0);
+      const double h00 = h[c], h10 = h[c + 1], h01 = h[c + st], h11 = h[c + 1 + st];
+      const double hAu0 = 0.5 * ((A00 * h00) + (A10 * h10));      // hArea_u(I,j)
+      const double hAu1 = 0.5 * ((A01 * h01) + (A11 * h11));      // hArea_u(I,j+1)
+      const double hAv0 = 0.5 * ((A00 * h00) + (A01 * h01));      // hArea_v(i,J)
+      const double hAv1 = 0.5 * ((A10 * h10) + (A11 * h11));      // hArea_v(i+1,J)
+      const double rel_vort = vfac * (dvdx - dudy) * IareaBu;
+      const double abs_vort = fBu + rel_vort;
+      const double hArea_q = (hAu0 + hAu1) + (hAv0 + hAv1);
+      const double Ih_q = Area_q / (hArea_q + vol_neglect);
+      qv = abs_vort * Ih_q;
+      av = abs_vort;
+      if (do_KE) {
+        const double um1 = u[c - 1], vm1 = v[c - st];
+        if (ke_scheme == MOM6X_KE_ARAKAWA) {
+          kev = (((aCu0 * (u0 * u0)) + (aCu1 * (um1 * um1))) + ((aCv0 * (v0 * v0)) + (aCv1 * (vm1 * vm1)))) * 0.25 * IareaT;
+        } else if (ke_scheme == MOM6X_KE_SIMPLE_GUDONOV) {
+          const double up = 0.5 * (um1 + fabs(um1)), up2 = up * up;
+          const double um = 0.5 * (u0 - fabs(u0)), um2 = um * um;
+          const double vp = 0.5 * (vm1 + fabs(vm1)), vp2 = vp * vp;
+          const double vm = 0.5 * (v0 - fabs(v0)), vm2 = vm * vm;
+          kev = (dmax(up2, um2) + dmax(vp2, vm2)) * 0.5;
+        } else {
+          const double up = 0.5 * (um1 + fabs(um1)), up2a = up * up * aCu1;
+          const double um = 0.5 * (u0 - fabs(u0)), um2a = um * um * aCu0;
+          const double vp = 0.5 * (vm1 + fabs(vm1)), vp2a = vp * vp * aCv1;
+          const double vm = 0.5 * (v0 - fabs(v0)), vm2a = vm * vm * aCv0;
+          kev = (dmax(um2a, up2a) + dmax(vm2a, vp2a)) * 0.5 * IareaT;
+        }
+      }
+    }
+    sq[l] = qv; sk[l] = kev; if (bound) sa[l] = av;
+    __syncthreads();
+    if (out) {
+      if (uhtr) {   // :1072-1079 for the box (-1..ni-1, -1..nj-1): see k_corad_acc
+        uhtr[c] = uhtr[c] + uh[c] * dt_tr;
+        vhtr[c] = vhtr[c] + vh[c] * dt_tr;
+      }
+      corad_acc_layer(X, c, st, [&](int di, int dj) { return sq[l + di + dj * CF_LDW]; }, [&](int di, int dj) { return sk[l + di + dj * CF_LDW]; },
+                      [&](int di, int dj) { return sa[l + di + dj * CF_LDW]; });
+    }
+    // (the layer after next writes this buffer again: the barrier of the next layer lies in between)
   }
 }
 
@@ -511,6 +645,18 @@ int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h
   if (c->cor.bound_Coriolis && (rc = ctx_scratch(c, SCR_absv, d.nk, &absv))) return rc;
   const dim3 b = blk2();
   const double vol_neglect = c->GV.H_subroundoff * ((1e-4 * 1.0) * (1e-4 * 1.0));
+  // (A barrier-free form -- every thread evaluating q at its own vertex and the one to the south, the western one by a lane
+  //  shuffle -- was measured too: 200 registers, 7.1 ms per step against 5.9 for k_corad_fused and 6.5 for the two kernels.)
+  static const bool two_kernels = [] { const char *e = getenv("MOM6X_CORAD"); return e && !strcmp(e, "legacy"); }();
+  if (!two_kernels && d.halo >= 3) {   // q, KE, abs_vort through LDS (k_corad_fused); MOM6X_CORAD=legacy: through HBM
+    const int kc = (d.nk % 25 == 0) ? 25 : ((d.nk >= KCHUNK) ? KCHUNK : d.nk);
+    const dim3 bt(CF_X, CF_Y, 1);
+    const dim3 gt((d.ni + 1 + (CF_X - 2) - 1) / (CF_X - 2), (d.nj + 1 + (CF_Y - 2) - 1) / (CF_Y - 2), (d.nk + kc - 1) / kc);
+    KLAUNCH(c, "k_corad_fused", k_corad_fused, gt, bt, d, c->G, u, v, uh, vh, CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h,
+            c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr, c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc);
+    HIPCHK(hipGetLastError());
+    return MOM6X_OK;
+  }
   KLAUNCH(c, "k_corad_q", k_corad_q, gridk(nxa(d.ni + 3, -2), d.nj + 3, d.nk, b), b, d, c->G, u, v, h, q, absv, KE,
           c->cor.no_slip, c->cor.KE_Scheme, vol_neglect);
   KLAUNCH(c, "k_corad_acc", k_corad_acc, gridk(nxa(d.ni + 1, -1), d.nj + 1, d.nk, b), b, d, c->G, u, v, uh, vh, q, absv, KE,
