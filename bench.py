@@ -84,7 +84,8 @@ def build_model(args, layout, pe, device, dist=None, unique_id=None, reentrant_y
     dyc.PressureForce_init(abi.pgf_params_default(GV.Rho0), Rlay, gp)
     dyc.initialize_dyn_split_RK2(abi.rk2_params_default())
     Md = dyc.to_dev(M)
-    h, u, v = synth_dev.make_state(d, Md, u_max=0.05, h_pert=0.001)
+    # |u| <= 0.5 m/s (the seeded smooth fields have values in about [-1, 1]), thicknesses perturbed by 1 %
+    h, u, v = synth_dev.make_state(d, Md, u_max=float(os.environ.get("MOM6X_BENCH_UMAX", "0.5")), h_pert=0.01)
     st = dict(u=u, v=v, h=h, uh=dyc.zeros3(), vh=dyc.zeros3(), uhtr=dyc.zeros3(), vhtr=dyc.zeros3(), eta_av=dyc.zeros2())
     # vertvisc_coef runs on the device three times per step (RK2.F90:609, :738, :1003); its vertvisc_type inputs
     # (set_viscous_BBL outputs: a drag-law bottom viscosity over a 10 m boundary layer) are synthetic and constant
@@ -444,6 +445,45 @@ def pmc_traffic(kernel):
     return None, None
 
 
+FP64_VALU_PEAK_TLANE_S = 256 * 4 * 16 * 2.4e9 / 1e12   # lane-instructions per second: 256 CUs x 4 SIMDs x 16 FP64 lanes x 2.4 GHz
+                                                       # (= the 78.6 TFLOP/s FP64 vector peak of the MI355X counted without FMA)
+
+
+def valu_counters(kernel, N3_tile, avg_ms):
+    """The instruction side of the dominant kernel from the newest committed SQ-counter summary (profiles/*_sq_pmc.json,
+    scripts/profile_bench.sh pass 4): wave-instructions issued per launch -> lane-instructions per face-layer, and the rate
+    against the FP64 vector peak.  The counters cannot be collected inside the timed run; the launch time is this run's."""
+    import glob
+    import re
+    key = lambda n: (re.match(r"\w+(<\d+)?", n.replace(" ", "")) or [n])[0]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_pmc.json")), reverse=True):
+        try:
+            tab = json.load(open(path))["per_launch"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for n, c in tab.items():
+            if key(n) == key(kernel) and c.get("SQ_INSTS_VALU"):
+                lane = 64.0 * c["SQ_INSTS_VALU"]
+                rate = lane / (avg_ms * 1e-3) / 1e12
+                return {"SQ_INSTS_VALU_per_launch": c["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_per_launch": c.get("SQ_ACTIVE_INST_VALU"),
+                        "SQ_WAVES_per_launch": c.get("SQ_WAVES"), "SQ_BUSY_CYCLES_per_launch": c.get("SQ_BUSY_CYCLES"),
+                        "SQ_WAVE_CYCLES_per_launch": c.get("SQ_WAVE_CYCLES"),
+                        "lane_instructions_per_face_layer": round(lane / N3_tile, 1),
+                        "achieved_Tlane_instr_per_s": round(rate, 2), "peak_Tlane_instr_per_s": round(FP64_VALU_PEAK_TLANE_S, 2),
+                        "frac_of_fp64_vector_issue_peak": round(rate / FP64_VALU_PEAK_TLANE_S, 3),
+                        "occupancy": "2 wavefronts per SIMD (253 VGPRs)", "source": os.path.relpath(path, ROOT) + " @ " + git_hash_of(path)}
+    return None
+
+
+def git_hash_of(path):
+    """The commit that last touched a tracked file (so that a cited measurement names the state it belongs to)."""
+    import subprocess
+    try:
+        return subprocess.run(["git", "log", "-n", "1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True, timeout=20).stdout.strip() or "untracked"
+    except Exception:   # noqa: BLE001
+        return "unknown"
+
+
 def cpu_baseline(args):
     """The oracle (kind='port': plain-C restatement of the reference Fortran with OpenMP over the loops the reference
     threads -- !$OMP parallel do over j or k, e.g. MOM_continuity_PPM.F90:370/:615, MOM_barotropic.F90:868 -- on all host
@@ -463,7 +503,7 @@ def cpu_baseline(args):
     bt = abi.barotropic_params_default(20.0)
     m = orc.OrcModel(d, M, GV, abi.continuity_params_default(nk), bt, abi.coriolis_params_default(), abi.pgf_params_default(),
                      abi.rk2_params_default(), Rlay, gp)
-    h, u, v = synth.make_state(d, M, u_max=0.05, h_pert=0.001)
+    h, u, v = synth.make_state(d, M, u_max=float(os.environ.get("MOM6X_BENCH_UMAX", "0.5")), h_pert=0.01)
     # the same vertvisc_coef set-up as the device run: the oracle's step calls orc_vertvisc_coef three times
     kbu = np.ascontiguousarray(2.0e-3 * (1.0 + 0.5 * synth.smooth_field(d, 91, ox=1.0, oy=0.5)) * M[abi.G["mask2dCu"]])
     kbv = np.ascontiguousarray(2.0e-3 * (1.0 + 0.5 * synth.smooth_field(d, 92, ox=0.5, oy=1.0)) * M[abi.G["mask2dCv"]])
@@ -474,18 +514,73 @@ def cpu_baseline(args):
     z3 = lambda: np.zeros_like(h)
     uh, vh, uhtr, vhtr, eta_av = z3(), z3(), z3(), z3(), np.zeros(d.shape2())
     taux = np.ascontiguousarray(0.1 * synth.smooth_field(d, 41, ox=1, oy=.5) * M[abi.G["mask2dCu"]]); tauy = np.zeros(d.shape2())
+    # the thermodynamic step of the headline workload (make_thermo): T, S + the passive tracers, PPM, every nth dynamics step
+    nth = max(int(round(args.dt_therm / args.dt)), 1)
+    ntr = max(args.tracers, 0)
+    do_thermo = args.tracers >= 0
+    T = np.ascontiguousarray(10.0 + synth.smooth_field(d, 81, nk=nk)); S = np.ascontiguousarray(35.0 + 0.5 * synth.smooth_field(d, 82, nk=nk))
+    tr = [np.ascontiguousarray(10.0 + 5.0 * synth.smooth_field(d, 71 + q, nk=nk, ox=0.5, oy=0.5)) for q in range(ntr)]
+    ea = np.ascontiguousarray(1.0e-3 * h); ea[0] = 0.0
+    eb = np.ascontiguousarray(np.roll(ea, -1, 0)); eb[-1] = 0.0
+
+    def thermo():
+        orc.advect_tracer(d, M, GV, 0, args.dt, 2, h, uhtr, vhtr, nth * args.dt, [T, S] + tr)
+        for t_ in tr:
+            orc.tracer_vertdiff(d, M, GV, h, ea, eb, nth * args.dt, t_)
+        orc.triDiagTS(d, h, ea, eb, T, GV.H_subroundoff); orc.triDiagTS(d, h, ea, eb, S, GV.H_subroundoff)
+        uhtr[...] = 0.0; vhtr[...] = 0.0
+
     m.initialize(u, v, h, uh, vh, args.dt)
     m.step(u, v, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy, args.dt, coefs, calc_dtbt=True)   # warm-up, sets dtbt
-    nst = args.cpu_steps
+    uhtr[...] = 0.0; vhtr[...] = 0.0
+    nst = max((args.cpu_steps // nth) * nth, nth) if do_thermo else args.cpu_steps   # whole cycles: the thermodynamic share amortises exactly
     t0 = time.time()
-    for _ in range(nst):
+    for n in range(nst):
         m.step(u, v, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy, args.dt, coefs)
+        if do_thermo and (n + 1) % nth == 0:
+            thermo()
     t = (time.time() - t0) / nst
     scale = (args.ni * args.nj) / float(ni * nj)
     t_full = t * scale
+    what = (f"step_MOM_dyn_split_RK2 + every {nth} steps advect_tracer (PPM) of T, S and {ntr} passive tracers and their tridiagonal solves "
+            "(the headline's workload)") if do_thermo else "step_MOM_dyn_split_RK2 (dynamics only)"
     return {"value": (args.dt / 86400.0) / t_full, "unit": "simulated-days/wall-sec", "cores": cores, "kind": "port",
-            "sample": f"{nst} oracle steps of step_MOM_dyn_split_RK2 (dynamics only) on a {ni}x{nj}x{nk} tile with {cores} OpenMP threads "
+            "sample": f"{nst} oracle steps of {what} on a {ni}x{nj}x{nk} tile with {cores} OpenMP threads "
                       f"({t:.2f} s/step), scaled x{scale:.1f} to {args.ni}x{args.nj}x{nk}"}
+
+
+def measure_traffic_inrun(kernel, args):
+    """HBM-side bytes of THIS state of the code, measured now: two more runs of this script under rocprofv3 (one counter per
+    pass -- FETCH_SIZE, WRITE_SIZE -- and nothing else, as the MI355X guide prescribes; a step of the dynamics each), condensed by
+    scripts/rocprof_summary.py (unit KB, calibrated on a kernel whose traffic is known exactly).  Returns (bytes per launch of
+    `kernel`, GB per step over all kernels, description) or None when rocprofv3 is absent, times out or reports nothing."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None or os.environ.get("MOM6X_BENCH_NO_PMC"):
+        return None
+    import re
+    key = lambda n: (re.match(r"\w+(<\d+)?", n.replace(" ", "")) or [n])[0]
+    tmp = tempfile.mkdtemp(prefix="mom6x_pmc_")
+    env = dict(os.environ, MOM6X_BENCH_NO_PMC="1", TMPDIR="/tmp")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-config4",
+           "--no-comm-model", "--tracers", "-1", "--ni", str(args.ni), "--nj", str(args.nj), "--nk", str(args.nk)]
+    try:
+        for tag, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, "prof_" + tag), "-o", tag, "--"] + cmd,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0 or not os.path.exists(os.path.join(tmp, "prof_" + tag, tag + "_counter_collection.csv")):
+                return None
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rocprof_summary.py"), tmp, os.path.join(tmp, "inrun"),
+                            str(args.ni), str(args.nj), str(args.nk)], capture_output=True, text=True, timeout=120)
+        j = json.load(open(os.path.join(tmp, "inrun_hbm_pmc.json")))
+        per = next((float(v) for n, v in j["traffic_bytes_per_launch"].items() if key(n) == key(kernel)), None)
+        return per, round(j["bytes_per_step"] / 1e9, 1), ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one dynamics step, "
+                                                         f"FETCH x{j['fetch_cal']:.3f}, WRITE x{j['write_cal']:.3f} (calibrated on {j.get('calibration_kernel')})")
+    except Exception:   # noqa: BLE001  (a hung or missing profiler must not cost the benchmark line)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -505,6 +600,7 @@ def main():
     ap.add_argument("--no-comm-model", action="store_true", help="skip the 1-GPU exchange-overhead leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 (two extra one-step runs); cite profiles/ instead")
     ap.add_argument("--tracers", type=int, default=2, help="passive PPM tracers next to T and S in the thermodynamic step; -1 = dynamics only")
     args = ap.parse_args()
 
@@ -591,6 +687,8 @@ def main():
     prof_enable(dyc, False)
     dyc.lib.mom6x_prof_filter(dyc.ctx, None)
     n_thermo = args.steps // nth if thermo is not None else 0
+    # the Newton statistics of the mass-flux kernel: ONE more step after the timed region with the collecting variant of the kernel
+    dyc.continuity_stats(1); step(); nw_evals, nw_solves, nw_redos = dyc.continuity_stats(0)
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = (args.steps * args.dt / 86400.0) / elapsed
@@ -602,16 +700,30 @@ def main():
     N3_tile = d.ni * d.nj * d.nk
     n_dom = sum(v[0] for v in dom.values()); ms_dom = sum(v[1] for v in dom.values())
     roofline = None
-    traffic, traffic_src = pmc_traffic(dom_name) if args.gpus == 1 and (args.ni, args.nj, args.nk) == (1440, 1080, 75) else (None, None)
+    traffic, traffic_src, measured_live = None, None, None
+    if args.gpus == 1 and rank == 0 and not args.no_pmc:
+        measured_live = measure_traffic_inrun(dom_name, args)
+    if measured_live is not None:
+        traffic, traffic_src = measured_live[0], measured_live[2]
+    elif args.gpus == 1 and (args.ni, args.nj, args.nk) == (1440, 1080, 75):
+        traffic, traffic_src = pmc_traffic(dom_name)
+        if traffic_src:
+            traffic_src += " @ " + git_hash_of(os.path.join(ROOT, traffic_src)) + " (cited: the counters could not be collected in this run)"
     words = next((w for pre, w in KERNEL_WORDS.items() if dom_name.startswith(pre)), None)
     if n_dom and words is not None:
         avg_ms = ms_dom / n_dom
         bytes_launch = words * 8.0 * N3_tile
         ach = bytes_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # achieved / peak / frac: the contract's numbers (algorithmic bytes over the measured launch time against the HBM peak).
+        # `bound` says what actually limits the kernel: the mass-flux kernel issues FP64 vector instructions at more than half
+        # of the chip's rate while it moves a fifth of the HBM peak -- `valu` holds the counters (scripts/profile_bench.sh, SQ pass)
+        bound = "valu_fp64" if dom_name.startswith("k_mass_flux_wave") else "hbm"
+        roofline = {"bound": bound, "kernel": dom_name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4),
                     "launches_per_step": n_dom / args.steps, "algorithmic_bytes_per_launch": bytes_launch,
                     "words_per_cell_layer": words}
+        if bound == "valu_fp64":
+            roofline["valu"] = valu_counters(dom_name, N3_tile, avg_ms)
     out = {
         "metric": "simulated-days/wall-sec", "value": value, "unit": "simulated-days/wall-sec", "n_gpus": args.gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
@@ -621,6 +733,8 @@ def main():
                                f"BASELINE.json configs[3] grid), DT={args.dt:g} s, DT_THERM={args.dt_therm:g} s, layout {layout[0]}x{layout[1]}, "
                                f"{nsub} barotropic sub-steps per step",
                    "thermo_steps_in_timed_region": n_thermo,
+                   "state": "seeded smooth fields (SURVEY.md 8d): |u|, |v| <= %.2g m/s per layer, thicknesses perturbed by 1 %%" % float(os.environ.get("MOM6X_BENCH_UMAX", "0.5")),
+                   "newton_evals_per_solve": round(nw_evals / max(nw_solves, 1), 3), "newton_solves_repeated_with_exact_limits": nw_redos,
                    "sum_order": "TREE16 (column sums of the mass-flux kernels as a 16-lane tree; MOM6X_SUMS=exact: the reference's k order)"
                                 if dyc.cont_params.sum_order else "REFERENCE (sequential in k, bit-identical to the Fortran loop nest)",
                    "frozen_inputs": "none of the step's callees; vertvisc_coef and horizontal_viscosity run on the device inside the step (the set_viscous_BBL inputs of vertvisc_coef are constant synthetic fields)",
@@ -632,7 +746,10 @@ def main():
         out["thermo"] = th
     th_bytes = (th["advect_algorithmic_GB"] + th["tridiag_algorithmic_GB"]) * 1e9 / nth if th else 0.0   # amortised per dynamics step
     tot_bytes = bytes_step + th_bytes
-    measured, measured_src = pmc_step_traffic() if args.gpus == 1 and (args.ni, args.nj, args.nk) == (1440, 1080, 75) else (None, None)
+    measured, measured_src = (measured_live[1], measured_live[2]) if measured_live is not None else \
+        (pmc_step_traffic() if args.gpus == 1 and (args.ni, args.nj, args.nk) == (1440, 1080, 75) else (None, None))
+    if measured_live is None and measured_src:
+        measured_src += " @ " + git_hash_of(os.path.join(ROOT, measured_src))
     out["hbm_step"] = {
         "algorithmic_GB_per_step": round(tot_bytes / 1e9, 2), "dynamics_GB": round(bytes_step / 1e9, 2), "thermo_GB_amortised": round(th_bytes / 1e9, 2),
         "achieved_GBps": round(tot_bytes / 1e9 / (ms_per_step * 1e-3), 1),

@@ -332,6 +332,13 @@ int mom6x_download(mom6x_ctx *ctx, double *host_f, const double *dev, int stagge
 int mom6x_continuity_init(mom6x_ctx *ctx, const mom6x_continuity_params *p);
   /* continuity_PPM_init, MOM_continuity_PPM.F90:2674                          */
 
+/* Newton statistics of the mass-flux kernel (sum_order TREE16 only): out3[0] = flux re-evaluations inside
+ * zonal/meridional_flux_adjust and set_*_BT_cont (whole-column sweeps, per wavefront of four face columns), out3[1] = Newton solves
+ * (per wavefront), out3[2] = solves repeated with the exact CFL limits, accumulated while collection is on.  mode: 1 = switch
+ * collection on and reset the counters, 0 = switch it off, -1 = just read.  The collecting variant of the kernel is slower (the
+ * counters cost it registers): a diagnostic, not for timed runs.  Synchronises the context's stream.  out3 nullable.   */
+int mom6x_continuity_stats(mom6x_ctx *ctx, int mode, unsigned long long *out3);
+
 /* continuity_PPM(u, v, hin, h, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt,
  *   visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont, du_cor, dv_cor)
  * MOM_continuity_PPM.F90:86-194.  Optional Fortran arguments are nullable

@@ -438,6 +438,27 @@ extern "C" int mom6x_continuity_init(mom6x_ctx *c, const mom6x_continuity_params
   return MOM6X_OK;
 }
 
+// Newton statistics of the mass-flux kernel (sum_order TREE16 only): out[0] = flux re-evaluations (whole column sweeps, counted
+// per wavefront of four faces), out[1] = Newton solves (per wavefront), out[2] = solves repeated with the exact CFL limits,
+// accumulated while collection is on.  `mode`: 1 switch collection on (and reset), 0 switch it off, -1 leave it as it is.  While
+// it is on the kernel runs in a slower variant (the counters spill registers): for diagnostics, not for timed runs.
+// out[0] / out[1] is the number bench.py prints as newton_evals_per_solve.  Synchronises the stream.
+extern "C" int mom6x_continuity_stats(mom6x_ctx *c, int mode, unsigned long long *out3) {
+  REQUIRE(c, MOM6X_EINVAL, "mom6x_continuity_stats: null context");
+  const int reset = (mode == 1);
+  if (mode == 1) c->cont_stats_on = true;
+  if (mode == 0) c->cont_stats_on = false;
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->cont_stats) {
+    HIPCHK(hipMalloc(&c->cont_stats, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(c->cont_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (out3) HIPCHK(hipMemcpy(out3, c->cont_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemsetAsync(c->cont_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+  return MOM6X_OK;
+}
+
 extern "C" int mom6x_continuity_PPM(mom6x_ctx *c, const double *u, const double *v, const double *hin,
                                     double *h, double *uh, double *vh, double dt, const double *uhbt,
                                     const double *vhbt, const double *visc_rem_u, const double *visc_rem_v,

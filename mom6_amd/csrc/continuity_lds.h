@@ -12,6 +12,7 @@ struct LdsArgs {
   int i_base;          // first i of the tile grid (set by mass_flux_lds: 128-byte aligned, <= a0)
   int force_walk;      // tests (MOM6X_MASSFLUX=lds_walk): take the sequential duL/duR recurrence even when the certificate holds
   int *retry;          // per tile: the cheap-bounds pass asks for the exact pass (set by mass_flux_lds), or null
+  unsigned long long *stats;   // continuity_wave.hip: [0] flux re-evaluations of all Newton solves, [1] solves (face columns x solves), [2] exact-limit redos
 };
 
 size_t mass_flux_lds_bytes(int dir, int nk);

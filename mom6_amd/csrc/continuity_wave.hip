@@ -128,11 +128,11 @@ __device__ __forceinline__ void keep_in_loop(Col<MAXL> &C, int n) {
 // replicated over the 16 lanes of a face's row.  STORE: the evaluated transports are the result (the reference's
 // uh_3d argument): they are kept in C.uh at every evaluation of a face that is still iterating and stored once at the end.  `lazy`: du_max / du_min are a lower / an upper bound of the CFL limits; the first test they do not
 // decide ends the solve with need_exact = true (wavefront-uniform) and the caller repeats it with the limits.
-template <int MAXL, bool STORE, typename StoreUh>
+template <int MAXL, bool STORE, bool STATS, typename StoreUh>
 __device__ __forceinline__ double wave_flux_adjust(Col<MAXL> &C, bool active, double IareaMin, double uhbt,
                                                    double uh_tot_0, double duhdu_tot_0, double du_max, double du_min,
                                                    double tol_eta_cs, double tol_vel, int better_iter, bool lazy,
-                                                   bool &need_exact, StoreUh store_uh) {
+                                                   bool &need_exact, StoreUh store_uh, unsigned &evals) {
   const int max_itts = 20;
   double du = 0.0;
   double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0;
@@ -204,7 +204,7 @@ __device__ __forceinline__ double wave_flux_adjust(Col<MAXL> &C, bool active, do
     }
   }
   COUNT_ITT(STORE ? 8 : 9, n_eval);   // (slot 8 / 9 of g_mfw_t[0]: flux re-evaluations of the first / second solve; g_mfw_t[1]: solves)
-  (void)n_eval;
+  if (STATS) evals = (unsigned)__builtin_amdgcn_readfirstlane((int)(evals + (unsigned)n_eval));   // (wavefront-uniform: mom6x_continuity_stats)
   return du;
 }
 
@@ -257,11 +257,11 @@ __device__ __forceinline__ void glds16(const double *src, double *lds_wave_base)
 
 // Everything of one face column after the reconstruction: first sweep, flux_adjust towards uhbt, stores, flux
 // thickness, set_*_BT_cont.  All lanes of the wavefront call it (row reductions inside).
-template <int DIR, int MAXL>
+template <int DIR, int MAXL, bool STATS>
 __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, const LdsArgs &E, size_t rowb, unsigned lane2,
                                             unsigned lane3, size_t slab, bool active, int kl, int nk, double IareaMin,
                                             double uhbt_f, double dC_f, double dx_W_in, double dx_E_in, const double *G,
-                                            int pitch TICK_PARAM) {
+                                            int pitch, unsigned &evals, unsigned &solves, unsigned &redos TICK_PARAM) {
   // Addresses: (uniform base pointer + uniform byte offset) + a 32-bit per-lane byte offset that never changes
   // (lane2: the face's column in a row; lane3: + the lane's first layer) -- the scalar-base addressing mode, one
   // register per lane instead of a 64-bit address per store that the compiler would keep alive across the march.
@@ -373,13 +373,15 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
   const bool corrected = (A.uhbt != nullptr);
   if (corrected) {
     bool redo;
-    du_fin = wave_flux_adjust<MAXL, true>(C, active, IareaMin, uhbt_f, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
-                                          A.tol_eta, A.tol_vel, A.better_iter, lazy, redo, store_uh);
+    if (STATS) solves = (unsigned)__builtin_amdgcn_readfirstlane((int)(solves + 1u));
+    du_fin = wave_flux_adjust<MAXL, true, STATS>(C, active, IareaMin, uhbt_f, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
+                                          A.tol_eta, A.tol_vel, A.better_iter, lazy, redo, store_uh, evals);
     if (redo) {   // wavefront-uniform
+      if (STATS) redos = (unsigned)__builtin_amdgcn_readfirstlane((int)(redos + 1u));
       exact_bounds(); lazy = false;
       first_sweep();   // (the abandoned solve has overwritten some of the first transports)
-      du_fin = wave_flux_adjust<MAXL, true>(C, active, IareaMin, uhbt_f, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
-                                            A.tol_eta, A.tol_vel, A.better_iter, false, redo, store_uh);
+      du_fin = wave_flux_adjust<MAXL, true, STATS>(C, active, IareaMin, uhbt_f, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
+                                            A.tol_eta, A.tol_vel, A.better_iter, false, redo, store_uh, evals);
     }
     if (active && kl == 0 && A.du_cor) st2(A.du_cor, du_fin);
   }
@@ -422,12 +424,14 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
   {
     bool redo;
     auto no_store = [](int, double, bool) {};
-    du0 = wave_flux_adjust<MAXL, false>(C, active, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
-                                        A.tol_eta, A.tol_vel, A.better_iter, lazy, redo, no_store);
+    if (STATS) solves = (unsigned)__builtin_amdgcn_readfirstlane((int)(solves + 1u));
+    du0 = wave_flux_adjust<MAXL, false, STATS>(C, active, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
+                                        A.tol_eta, A.tol_vel, A.better_iter, lazy, redo, no_store, evals);
     if (redo) {
+      if (STATS) redos = (unsigned)__builtin_amdgcn_readfirstlane((int)(redos + 1u));
       exact_bounds(); lazy = false;
-      du0 = wave_flux_adjust<MAXL, false>(C, active, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
-                                          A.tol_eta, A.tol_vel, A.better_iter, false, redo, no_store);
+      du0 = wave_flux_adjust<MAXL, false, STATS>(C, active, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
+                                          A.tol_eta, A.tol_vel, A.better_iter, false, redo, no_store, evals);
     }
   }
   TICK(5);
@@ -497,7 +501,7 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
 
 constexpr int SEG = 4;   // doubles per segment = faces per wavefront
 
-template <int DIR, int MAXL>
+template <int DIR, int MAXL, bool STATS>
 __global__ void __launch_bounds__(NF * KL, (MAXL > 5) ? 1 : 2)
 k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   using ST = Stage<DIR>;
@@ -581,6 +585,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   C.dt = A.dt;
 #pragma unroll
   for (int n = 0; n < MAXL; n++) { C.pL[n] = 0.0; C.pR[n] = 0.0; C.pC[n] = 0.0; }
+  unsigned st_evals = 0, st_solves = 0, st_redos = 0;   // wavefront-uniform counts over the march (mom6x_continuity_stats)
 
   const int jstart = DIR ? j0 - 1 : j0;   // meridional: a first step that only reconstructs cell j0
   if (wave_on) issue_dma(jstart, true);
@@ -645,7 +650,12 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     if (!face_row) continue;
     TICK(0);
     const size_t rowb = (size_t)(jj + d.joff) * (size_t)d.pitch * 8;
-    face_column<DIR, MAXL>(C, A, E, rowb, lane2, lane3, slab, active, kl, nk, IareaMin, uhbt_f, dC_f, dx_W, dx_E, G, d.pitch TICK_ARG);
+    face_column<DIR, MAXL, STATS>(C, A, E, rowb, lane2, lane3, slab, active, kl, nk, IareaMin, uhbt_f, dC_f, dx_W, dx_E, G, d.pitch, st_evals,
+                           st_solves, st_redos TICK_ARG);
+  }
+  if (STATS && E.stats && lane == 0 && wave_on) {   // one update per wavefront and launch: flux sweeps of the Newton solves, solves, redos
+    atomicAdd(&E.stats[0], (unsigned long long)st_evals); atomicAdd(&E.stats[1], (unsigned long long)st_solves);
+    atomicAdd(&E.stats[2], (unsigned long long)st_redos);
   }
 }
 
@@ -658,8 +668,12 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   E.rows = 16;                              // rows a work-group marches over
   E.gy = (nrow + E.rows - 1) / E.rows;      // chunks
   E.retry = nullptr; E.force_walk = 0;
+  // The Newton statistics are a separate instantiation: the counters cost the 253-register kernel its last free registers
+  // (139 spills), so they are only compiled into the variant that runs while mom6x_continuity_stats is switched on.
+  const bool stats = (c->cont_stats != nullptr) && c->cont_stats_on;
+  E.stats = stats ? c->cont_stats : nullptr;
   const size_t lds_bytes = sizeof(double) * 4 * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16));   // 4 x the kernel's WAVE_LDS
-  auto kern = k_mass_flux_wave<DIR, MAXL>;
+  auto kern = stats ? k_mass_flux_wave<DIR, MAXL, true> : k_mass_flux_wave<DIR, MAXL, false>;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   const dim3 grid(E.gx * E.gy, 1, 1);
   if (c->prof_on) prof_begin(c, DIR ? "k_mass_flux_wave<1>" : "k_mass_flux_wave<0>");

@@ -209,7 +209,7 @@ extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
   comm_free(c);
   ta_state_free(c);
   for (int m = 0; m < MOM6X_NSCR; m++) (void)hipFree(c->scr[m]);
-  (void)hipFree(c->Rlay); (void)hipFree(c->g_prime); (void)hipFree(c->retry);
+  (void)hipFree(c->Rlay); (void)hipFree(c->g_prime); (void)hipFree(c->retry); (void)hipFree(c->cont_stats);
   hor_visc_free(c);
   diag_sums_free(c);
   (void)hipFree(c->regrid_res); (void)hipFree(c->regrid_vec);

@@ -101,6 +101,8 @@ struct mom6x_ctx {
   // the RK2 step's h_av formed by the convergence kernels of a continuity call (continuity.hip k_convergence): kind 1: h_av =
   // 0.5 * (hin + h) (RK2.F90:808-810); 2: h_av = 0.5 * (h_old + h_new) of an in-place call (:1025-1027 + :1064-1066); 0: off
   int cont_av_kind; double *cont_av; const double *cont_av_src;
+  bool cont_stats_on;               // the statistics-collecting (slower) variant of the mass-flux kernel is in use
+  unsigned long long *cont_stats;   // device: Newton statistics of the wave-owned mass-flux kernel (mom6x_continuity_stats), or null
   bool cont_h_unused;       // the caller of continuity_PPM does not look at the new thicknesses (RK2.F90:646: hp is overwritten at :781
                             // before anybody reads it): the convergence of the second direction is not computed
 };

@@ -150,6 +150,13 @@ class Dycore:
                           (info[0], info[1], int(info[2]), int(info[3]), n.value), RuntimeWarning)
         return n.value, first
 
+    def continuity_stats(self, mode=-1):
+        """mom6x_continuity_stats: (flux re-evaluations, Newton solves, exact-limit redos) of the wave-owned mass-flux kernel,
+        counted per wavefront of four face columns while collection is on (mode 1: on + reset, 0: off, -1: read)."""
+        out = (C.c_ulonglong * 3)()
+        check(self.lib, self.lib.mom6x_continuity_stats(self.ctx, int(mode), out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def barotropic_dtbt(self, value=None):
         """CS%dtbt (the restart scalar DTBT); with a value, set it (a restarted run)."""
         out = C.c_double(0.0)

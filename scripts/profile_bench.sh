@@ -6,6 +6,7 @@
 set -u
 ROOT=$(pwd)
 export TMPDIR=/tmp
+export MOM6X_BENCH_NO_PMC=1   # (bench.py would otherwise start its own rocprofv3 passes for roofline.traffic)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp
