@@ -288,7 +288,7 @@ FUSED_WORDS = {
 }
 
 
-def ale_cycle(args, device=0, steps=4, warm=1, check=None):
+def ale_cycle(args, device=0, steps=4, warm=1, check=None, layout=(1, 1), pe=(0, 0), unique_id=None, env=None):
     """BASELINE.json configs[4] on ONE of its 4 x 2 tiles (1080 x 1620 x 75 of the 4320 x 3240 grid: the per-GPU share of the
     8-GPU run, as one stand-alone grid -- eight tiles at 53 GB each do not fit one GPU): an ALE cycle of step_MOM, i.e.
     `steps` dynamics steps with the pressure force of an ALE grid (tv%T, tv%S, LINEAR equation of state, PLM reconstruction:
@@ -297,13 +297,13 @@ def ale_cycle(args, device=0, steps=4, warm=1, check=None):
     auxiliary restart variables.  Returns (seconds per cycle, dict of what was measured); `check(state)` is called after the
     last cycle with the live fields (tests/test_configs_gpu.py)."""
     import torch
-    from mom6_amd import abi, synth_dev
+    from mom6_amd import abi, parallel, synth_dev
 
     class A:
         pass
     a = A()
     a.ni, a.nj, a.nk, a.dt, a.tracers = args.ale_ni, args.ale_nj, args.nk, args.dt, 2
-    dyc, d, st, taux, tauy, keep = build_model(a, (1, 1), (0, 0), device)
+    dyc, d, st, taux, tauy, keep = build_model(a, layout, pe, device, None, unique_id)
     torch.cuda.set_stream(dyc.torch_stream())
     nk = a.nk
     T = (20.0 - 15.0 * torch.arange(nk, device=dyc.device, dtype=torch.float64)[:, None, None] / max(nk - 1, 1) +
@@ -317,9 +317,8 @@ def ale_cycle(args, device=0, steps=4, warm=1, check=None):
     dyc.tracer_advect_init(a.dt, scheme=2)
     CSr = abi.remapping_params_default(abi.REMAP_PPM_H4, dyc.GV.H_subroundoff, om4_remap_via_sub_cells=1, boundary_extrapolation=0)
     RP = abi.regrid_zstar_params_default()
-    Hcol = st["h"].sum(0)
-    jm, im = divmod(int(torch.argmax(Hcol)), Hcol.shape[1])
-    cr = (st["h"][:, jm, im] / dyc.GV.Z_to_H).cpu().numpy().copy()
+    # the z* coordinate whose nominal layers are nk equal parts of the basin's maximum depth (the same on every tile of a layout)
+    cr = np.full(nk, 4000.0 / nk)
     h_new = torch.zeros_like(st["h"]); dzI = torch.zeros((nk + 1,) + tuple(st["h"].shape[1:]), dtype=torch.float64, device=dyc.device)
     hu_o, hv_o, hu_n, hv_n = (torch.full_like(st["h"], 1.0e-3) for _ in range(4))
     info = {}
@@ -339,16 +338,27 @@ def ale_cycle(args, device=0, steps=4, warm=1, check=None):
         dyc.ALE_remap_set_h_vel(st["h"], hu_o, hv_o); dyc.ALE_remap_set_h_vel(h_new, hu_n, hv_n)
         dyc.ALE_remap_velocities(CSr, hu_o, hv_o, hu_n, hv_n, st["u"], st["v"])
         st["h"].copy_(h_new)
+        # step_MOM_thermo ends with the group pass of everything the thermodynamics and the remapping changed (MOM.F90:
+        # do_group_pass(pass_uv_T_S_h)): the next dynamics step reads T, S, h of the neighbouring tiles' edge columns
+        parallel.pass_fields(dyc, [st["u"], st["v"], st["h"], T, S] + tr, [1, 2, 0, 0, 0] + [0] * len(tr))
+
+    def meet():
+        dyc.sync(); torch.cuda.synchronize()
+        if env is not None:
+            env.barrier()
 
     torch.cuda.synchronize()
     for w in range(warm):
         cycle(first=(w == 0))
-    dyc.sync(); torch.cuda.synchronize()
+    meet()
     pre = dict(T=T.clone(), h=st["h"].clone(), tr0_min=tr[0].min().item(), tr0_max=tr[0].max().item()) if check is not None else None
     t0 = time.perf_counter()
     cycle()
-    dyc.sync(); torch.cuda.synchronize()
+    meet()
     sec = time.perf_counter() - t0
+    # the restart checksums of the remapped state (collective: summed over the tiles of the layout)
+    info["restart_checksums"] = {n: "%016X" % (dyc.field_chksum(x) % 2 ** 64) for n, x in
+                                 (("u", st["u"]), ("v", st["v"]), ("h", st["h"]), ("T", T), ("S", S), ("tr1", tr[0]), ("tr2", tr[1]))}
     info.update(tile=[d.ni, d.nj, d.nk], dynamics_steps_per_cycle=steps, ms_per_cycle=round(1e3 * sec, 2),
                 ms_per_dynamics_step=round(1e3 * sec / steps, 2),
                 simulated_days_per_wall_sec=round((steps * a.dt / 86400.0) / sec, 5),
@@ -601,13 +611,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 (two extra one-step runs); cite profiles/ instead")
+    ap.add_argument("--workload", choices=["headline", "config4"], default="headline", help="--transport threads only: config4 = the ALE cycle of BASELINE.json configs[4]")
+    ap.add_argument("--transport", choices=["rccl", "threads"], default="rccl",
+                    help="threads: run the --gpus N ranks as host threads on one GPU and check the layout against N = 1 (not a performance run)")
     ap.add_argument("--tracers", type=int, default=2, help="passive PPM tracers next to T and S in the thermodynamic step; -1 = dynamics only")
     args = ap.parse_args()
 
+    if args.transport == "threads":
+        return run_threads(args)
     import torch
-    from mom6_amd.dycore import prof_enable, prof_report, prof_reset
-    import ctypes as C
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -621,15 +633,135 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if args.gpus not in LAYOUTS:
         raise SystemExit(f"--gpus must be one of {sorted(LAYOUTS)}")
-    layout = LAYOUTS[args.gpus]
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    pe = (rank % layout[0], rank // layout[0])
-    dyc, d, st, taux, tauy, keep = build_model(args, layout, pe, local_rank, dist)
+    out = run_rank(args, RankEnv(rank, world, local_rank, dist))
+    if rank == 0:
+        _REAL_STDOUT.write(json.dumps(out) + "\n"); _REAL_STDOUT.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class RankEnv:
+    """What one rank of the job knows about the others: its number, the size of the job, its device, and how to meet the
+    other ranks -- torch.distributed over RCCL (the real N-GPU run: one process per GPU), or a group of host threads sharing one
+    GPU (--transport threads: the same code path with the in-process halo transport of tests/transport, for checking the
+    N > 1 plumbing where only one GPU exists)."""
+
+    def __init__(self, rank, world, local_rank, dist=None, group=None, unique_id=None):
+        self.rank, self.world, self.local_rank, self.dist, self.group, self.unique_id = rank, world, local_rank, dist, group, unique_id
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        elif self.group is not None:
+            self.group.barrier.wait()
+
+    def max(self, x, device):
+        """The maximum of a Python float over the ranks."""
+        if self.dist is not None:
+            import torch
+            t = torch.tensor([x], dtype=torch.float64, device=device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return float(t.item())
+        if self.group is not None:
+            return self.group.max(self.rank, x)
+        return x
+
+
+class ThreadGroup:
+    def __init__(self, n):
+        import threading
+        self.n, self.barrier, self.vals = n, threading.Barrier(n), [0.0] * n
+
+    def max(self, rank, x):
+        self.vals[rank] = x
+        self.barrier.wait()
+        m = max(self.vals)
+        self.barrier.wait()
+        return m
+
+
+RESTART_FIELDS = ["u", "v", "h", "uh", "vh", "uhtr", "vhtr", "eta_av"]
+
+
+def run_threads(args):
+    """--transport threads: the N ranks of `--gpus N` as host threads of this process on ONE GPU, every exchange through the
+    in-process transport (mom6x_comm_set_transport; tests/transport/threads_transport.cpp).  The same run_rank() the real job
+    executes -- rank -> tile, communicator attached before the new-run initialisation, barriers, the max over ranks -- followed
+    by the one check a single GPU allows: after the timed steps the restart checksums of every prognostic field (summed over
+    the tiles by the job's own all-reduce) and dtbt equal those of the N = 1 run of the same workload.  The timing of such a run
+    says nothing (N tiles share a GPU): the line is marked invalid as a performance number."""
+    import threading
+    import torch
+    from mom6_amd import parallel
+    from mom6_amd.abi import load_library
+    from tests import helpers as TH
+    if args.gpus not in LAYOUTS:
+        raise SystemExit(f"--gpus must be one of {sorted(LAYOUTS)}")
+    args.no_pmc = True; args.no_cpu_baseline = True; args.no_comm_model = True; args.no_config4 = True; args.skip_legs = True
+    layout = LAYOUTS[args.gpus]
+    if args.workload == "config4":   # BASELINE.json configs[4]'s ALE cycle on the layout (at the size --ale-ni / --ale-nj give)
+        one = lambda r, env, uid: {"restart_checksums": ale_cycle(args, 0, 4, 1, None, layout if env else (1, 1), parallel.rank_to_pe(r, layout) if env else (0, 0), uid, env)[1]["restart_checksums"],
+                                   "workload": f"configs[4] ALE cycle (4 dynamics steps with the PLM pressure force, PPM tracer advection, tridiagonal solves, z* regridding, PPM_H4 remapping) on {args.ale_ni}x{args.ale_nj}x{args.nk}"}
+    else:
+        one = lambda r, env, uid: run_rank(args if env else args_with(args, gpus=1), env or RankEnv(0, 1, 0))
+    ref = one(0, None, None)                                                      # the one-tile reference, same process
+    TH.use_threads_transport(load_library())
+    try:
+        uid = parallel.unique_id(load_library())
+        grp = ThreadGroup(args.gpus)
+        outs, errors = [None] * args.gpus, []
+
+        def work(r):
+            try:
+                outs[r] = one(r, RankEnv(r, args.gpus, 0, None, grp, uid), uid)
+            except BaseException:   # noqa: BLE001
+                import traceback
+                errors.append((r, traceback.format_exc()))
+                grp.barrier.abort()
+        th = [threading.Thread(target=work, args=(r,)) for r in range(args.gpus)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    finally:
+        TH.use_threads_transport(load_library(), on=False)
+    if errors:
+        raise SystemExit(errors[0][1])
+    out = outs[0]
+    same = {k: all(o["restart_checksums"][k] == ref["restart_checksums"][k] for o in outs) for k in ref["restart_checksums"]}
+    out["transport"] = "threads"; out["n_gpus_emulated"] = args.gpus; out["layout"] = list(layout)
+    out["invalid_as_performance"] = "N tiles share one GPU: this mode checks the N > 1 code path, not its speed"
+    out["layout_check"] = {"identical": all(same.values()), "fields": same, "reference": "the N = 1 run of the same workload in the same process",
+                           "checksums": ref["restart_checksums"]}
+    _REAL_STDOUT.write(json.dumps(out) + "\n"); _REAL_STDOUT.flush()
+    if not out["layout_check"]["identical"]:
+        raise SystemExit("bench.py --transport threads: the layout does not reproduce the one-tile run: " + str(same))
+
+
+def args_with(args, **kw):
+    import copy
+    a = copy.copy(args)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def run_rank(args, env):
+    """One rank of the benchmark: everything `python bench.py` does once it knows which rank of how many it is."""
+    import torch
+    from mom6_amd.dycore import prof_enable, prof_report, prof_reset
+    rank, local_rank, dist = env.rank, env.local_rank, env.dist
+    layout = LAYOUTS[args.gpus]
+    from mom6_amd.parallel import rank_to_pe
+    pe = rank_to_pe(rank, layout)
+    dyc, d, st, taux, tauy, keep = build_model(args, layout, pe, local_rank, dist, env.unique_id)
 
     def step(calc_dtbt=False):
         dyc.step_MOM_dyn_split_RK2(st["u"], st["v"], st["h"], st["uh"], st["vh"], st["uhtr"], st["vhtr"], st["eta_av"],
@@ -638,8 +770,7 @@ def main():
     def barrier():
         dyc.sync()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        env.barrier()
 
     # every torch operation of this script is issued on the context's own stream (ordered with its kernels)
     torch.cuda.set_stream(dyc.torch_stream())
@@ -678,11 +809,9 @@ def main():
     for _ in range(args.steps):
         cycle_step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dyc.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = env.max(time.perf_counter() - t0, dyc.device)
+    restart_checksums = {n: "%016X" % (dyc.field_chksum(st[n]) % 2 ** 64) for n in RESTART_FIELDS}   # (collective: summed over the tiles)
+    restart_checksums["dtbt"] = repr(dyc.barotropic_dtbt())
     dom = prof_report(dyc)
     prof_enable(dyc, False)
     dyc.lib.mom6x_prof_filter(dyc.ctx, None)
@@ -739,7 +868,7 @@ def main():
                                 if dyc.cont_params.sum_order else "REFERENCE (sequential in k, bit-identical to the Fortran loop nest)",
                    "frozen_inputs": "none of the step's callees; vertvisc_coef and horizontal_viscosity run on the device inside the step (the set_viscous_BBL inputs of vertvisc_coef are constant synthetic fields)",
                    "tile": [d.ni, d.nj, d.nk], "halo": d.halo},
-        "roofline": roofline,
+        "roofline": roofline, "restart_checksums": restart_checksums,
     }
     th = thermo_info() if thermo_info is not None else None
     if th is not None:
@@ -758,7 +887,7 @@ def main():
                  " (+ the thermodynamic step's words / 4)",
         "fused_away": FUSED_WORDS,
         "measured_FETCH_plus_WRITE_GB_per_step": measured, "measured_source": measured_src}
-    if args.tracers >= 0 and args.gpus == 1:
+    if args.tracers >= 0 and args.gpus == 1 and not getattr(args, "skip_legs", False):
         # the legs reported next to the headline are measured on one GPU; the scaling runs (N > 1) keep to the headline path
         out["ale_remap_leg"] = ale_remap_leg(args, dyc, d, st, barrier, dist)
         out["diag_leg"] = diag_leg(args, dyc, d, st, barrier, dist)
@@ -781,10 +910,9 @@ def main():
                 print(f"{k:28s} n={cnt:5d} total={ms:9.3f} ms avg={ms / cnt * 1e3:9.1f} us ({100 * ms / tot:5.1f}%)", file=sys.stderr)
         if not args.no_cpu_baseline and args.gpus == 1:   # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(args)
-        _REAL_STDOUT.write(json.dumps(out) + "\n"); _REAL_STDOUT.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if st:                                   # (the legs that need the memory have closed the model already)
+        torch.cuda.set_stream(torch.cuda.default_stream()); dyc.close(); st.clear()
+    return out
 
 
 # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when a communicator is made
