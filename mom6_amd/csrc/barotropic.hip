@@ -439,6 +439,7 @@ struct LoopArgs {
   double dtbt, dgeo_de, vel_underflow, trans_wt1, trans_wt2;
   double wt_accel, wt_trans, wt_vel, wt_eta, wt_accel2;
   int project, bracket_bug, find_etaav;
+  int f4_on_the_fly, Sadourny;   // the Coriolis weights recomputed from q, D_u_Cor, D_v_Cor in the velocity kernels
   int isv, iev, jsv, jev;   // valid range of this step
 };
 
@@ -470,6 +471,37 @@ k_bt_pred(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
     work[W_eta_sum * slab + c] = work[W_eta_sum * slab + c] + A.wt_accel2 * eta_PF_BT;
 }
 
+// The Coriolis weights f_4_u / f_4_v of btstep_find_Cor (:2836-2894) formed where they are used, from q and D_u_Cor / D_v_Cor
+// (k_find_Cor's expressions, same bits): three planes read with neighbours instead of eight planes.
+__device__ __forceinline__ void f4u_of(const double *__restrict__ q, const double *__restrict__ DCor_v, size_t c, int st, int Sadourny,
+                                       double &f0, double &f1, double &f2, double &f3) {
+  if (Sadourny) {
+    f3 = 1.0 * DCor_v[c + 1] * q[c];
+    f2 = 1.0 * DCor_v[c] * q[c];
+    f0 = 1.0 * DCor_v[c - st] * q[c - st];
+    f1 = 1.0 * DCor_v[c + 1 - st] * q[c - st];
+  } else {
+    f3 = 1.0 * DCor_v[c + 1] * (q[c] + (q[c + 1] + q[c - st])) / 3.0;
+    f2 = 1.0 * DCor_v[c] * (q[c] + (q[c - 1] + q[c - st])) / 3.0;
+    f0 = 1.0 * DCor_v[c - st] * ((q[c] + q[c - 1 - st]) + q[c - st]) / 3.0;
+    f1 = 1.0 * DCor_v[c + 1 - st] * ((q[c] + q[c + 1 - st]) + q[c - st]) / 3.0;
+  }
+}
+__device__ __forceinline__ void f4v_of(const double *__restrict__ q, const double *__restrict__ DCor_u, size_t c, int st, int Sadourny,
+                                       double &f0, double &f1, double &f2, double &f3) {
+  if (Sadourny) {
+    f0 = 1.0 * DCor_u[c - 1] * q[c - 1];
+    f1 = 1.0 * DCor_u[c] * q[c];
+    f3 = 1.0 * DCor_u[c + st] * q[c];
+    f2 = 1.0 * DCor_u[c - 1 + st] * q[c - 1];
+  } else {
+    f0 = 1.0 * DCor_u[c - 1] * ((q[c] + q[c - 1 - st]) + q[c - 1]) / 3.0;
+    f1 = 1.0 * DCor_u[c] * (q[c] + (q[c - 1] + q[c - st])) / 3.0;
+    f3 = 1.0 * DCor_u[c + st] * (q[c] + (q[c - 1] + q[c + st])) / 3.0;
+    f2 = 1.0 * DCor_u[c - 1 + st] * ((q[c] + q[c - 1 + st]) + q[c - 1]) / 3.0;
+  }
+}
+
 // btloop_find_PF + btloop_update_u/v + transports + running sums for ONE velocity component.
 // DIR = 0: u (faces I), DIR = 1: v (faces J).  (a0..a1, b0..b1) is the update range.
 template <int DIR>
@@ -488,8 +520,10 @@ k_bt_vel(Dm d, const double *__restrict__ G, double *work, double *btav, double 
     const double *gE = work + W_gtot_E * slab, *gW = work + W_gtot_W * slab, *vbt = work + W_vbt * slab;
     const double *f4u = work + W_f4u * slab;
     PF = (((etaB[c] - eta_PF[c]) * gE[c]) - ((etaB[c + 1] - eta_PF[c + 1]) * gW[c + 1])) * A.dgeo_de * gm(G, d, MOM6X_G_IdxCu)[c];
-    Cor = (((f4u[3 * slab + c] * vbt[c + 1]) + (f4u[0 * slab + c] * vbt[c - st])) +
-           ((f4u[2 * slab + c] * vbt[c]) + (f4u[1 * slab + c] * vbt[c + 1 - st]))) - work[W_Cor_ref_u * slab + c];
+    double f0, f1, f2, f3;
+    if (A.f4_on_the_fly) f4u_of(work + W_q * slab, work + W_DCor_v * slab, c, st, A.Sadourny, f0, f1, f2, f3);
+    else { f0 = f4u[0 * slab + c]; f1 = f4u[1 * slab + c]; f2 = f4u[2 * slab + c]; f3 = f4u[3 * slab + c]; }
+    Cor = (((f3 * vbt[c + 1]) + (f0 * vbt[c - st])) + ((f2 * vbt[c]) + (f1 * vbt[c + 1 - st]))) - work[W_Cor_ref_u * slab + c];
     vel = work[W_ubt * slab + c];
     newv = work[W_bt_rem_u * slab + c] * (vel + A.dtbt * ((work[W_BT_force_u * slab + c] + Cor) + PF));
     if (fabs(newv) < A.vel_underflow) newv = 0.0;
@@ -499,12 +533,13 @@ k_bt_vel(Dm d, const double *__restrict__ G, double *work, double *btav, double 
     const double *gN = work + W_gtot_N * slab, *gS = work + W_gtot_S * slab, *ubt = work + W_ubt * slab;
     const double *f4v = work + W_f4v * slab;
     PF = (((etaB[c] - eta_PF[c]) * gN[c]) - ((etaB[c + st] - eta_PF[c + st]) * gS[c + st])) * A.dgeo_de * gm(G, d, MOM6X_G_IdyCv)[c];
+    double f0, f1, f2, f3;
+    if (A.f4_on_the_fly) f4v_of(work + W_q * slab, work + W_DCor_u * slab, c, st, A.Sadourny, f0, f1, f2, f3);
+    else { f0 = f4v[0 * slab + c]; f1 = f4v[1 * slab + c]; f2 = f4v[2 * slab + c]; f3 = f4v[3 * slab + c]; }
     if (bracket_bug)
-      Cor = -1.0 * (((f4v[0 * slab + c] * ubt[c - 1]) + (f4v[1 * slab + c] * ubt[c])) +
-                    ((f4v[3 * slab + c] * ubt[c + st]) + (f4v[2 * slab + c] * ubt[c - 1 + st]))) - work[W_Cor_ref_v * slab + c];
+      Cor = -1.0 * (((f0 * ubt[c - 1]) + (f1 * ubt[c])) + ((f3 * ubt[c + st]) + (f2 * ubt[c - 1 + st]))) - work[W_Cor_ref_v * slab + c];
     else
-      Cor = -1.0 * (((f4v[0 * slab + c] * ubt[c - 1]) + (f4v[3 * slab + c] * ubt[c + st])) +
-                    ((f4v[1 * slab + c] * ubt[c]) + (f4v[2 * slab + c] * ubt[c - 1 + st]))) - work[W_Cor_ref_v * slab + c];
+      Cor = -1.0 * (((f0 * ubt[c - 1]) + (f3 * ubt[c + st])) + ((f1 * ubt[c]) + (f2 * ubt[c - 1 + st]))) - work[W_Cor_ref_v * slab + c];
     vel = work[W_vbt * slab + c];
     newv = work[W_bt_rem_v * slab + c] * (vel + A.dtbt * ((work[W_BT_force_v * slab + c] + Cor) + PF));
     if (fabs(newv) < A.vel_underflow) newv = 0.0;
@@ -933,6 +968,8 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   if (P.BT_project_velocity) { L.trans_wt1 = (1.0 + P.bebt); L.trans_wt2 = -P.bebt; }
   else { L.trans_wt1 = P.bebt; L.trans_wt2 = (1.0 - P.bebt); }
   L.project = P.BT_project_velocity; L.find_etaav = (etaav != nullptr);
+  static const bool f4_planes = [] { const char *e = getenv("MOM6X_BT_F4"); return e && !strcmp(e, "planes"); }();
+  L.f4_on_the_fly = f4_planes ? 0 : 1; L.Sadourny = P.Sadourny;
   int isv = is, iev = ie, jsv = js, jev = je;
   double *loop_f[] = { work + W_eta * slab, work + W_ubt * slab, work + W_vbt * slab };
   const int loop_stg[] = { 0, 1, 2 }, loop_nk[] = { 1, 1, 1 };
