@@ -33,7 +33,9 @@ enum BTW {   // 2-D work planes
   W_BTCu,   // 10 planes
   W_BTCv = W_BTCu + 10,   // 10 planes
   W_BTtmp = W_BTCv + 10,  // 12 planes: halo-updated copies of the BT_cont arrays
-  W_COUNT = W_BTtmp + 12
+  W_uhn = W_BTtmp + 12,   // find_uhbt(ubt) + uhbt0 / find_vhbt(vbt) + vhbt0 at the velocities of the last update: what the next
+  W_vhn,                  //   sub-step's eta predictor needs, formed by the kernel that has the velocity and its fit planes at hand
+  W_COUNT
 };
 
 enum BTC { B_FA_EE = 0, B_FA_E0, B_FA_W0, B_FA_WW, B_uBT_WW, B_uBT_EE, B_crvW, B_crvE, B_uh_WW, B_uh_EE };
@@ -440,6 +442,7 @@ struct LoopArgs {
   double wt_accel, wt_trans, wt_vel, wt_eta, wt_accel2;
   int project, bracket_bug, find_etaav;
   int f4_on_the_fly, Sadourny;   // the Coriolis weights recomputed from q, D_u_Cor, D_v_Cor in the velocity kernels
+  int store_uhn, have_uhn;       // the velocity kernels leave W_uhn / W_vhn for the next predictor; this predictor finds them
   int isv, iev, jsv, jev;   // valid range of this step
 };
 
@@ -459,10 +462,16 @@ k_bt_pred(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
     const double *ubt = work + W_ubt * slab, *vbt = work + W_vbt * slab;
     const double *Bu = work + W_BTCu * slab, *Bv = work + W_BTCv * slab;
     const double *uhbt0 = work + W_uhbt0 * slab, *vhbt0 = work + W_vhbt0 * slab;
-    const double uW = find_uhbt(ubt[c - 1], Bu, c - 1, slab) + uhbt0[c - 1];
-    const double uE = find_uhbt(ubt[c], Bu, c, slab) + uhbt0[c];
-    const double vS = find_uhbt(vbt[c - st], Bv, c - st, slab) + vhbt0[c - st];
-    const double vN = find_uhbt(vbt[c], Bv, c, slab) + vhbt0[c];
+    double uW, uE, vS, vN;
+    if (A.have_uhn) {   // the same four expressions, evaluated by the last velocity update (k_bt_vel) and passed with the velocities
+      const double *uhn = work + W_uhn * slab, *vhn = work + W_vhn * slab;
+      uW = uhn[c - 1]; uE = uhn[c]; vS = vhn[c - st]; vN = vhn[c];
+    } else {
+      uW = find_uhbt(ubt[c - 1], Bu, c - 1, slab) + uhbt0[c - 1];
+      uE = find_uhbt(ubt[c], Bu, c, slab) + uhbt0[c];
+      vS = find_uhbt(vbt[c - st], Bv, c - st, slab) + vhbt0[c - st];
+      vN = find_uhbt(vbt[c], Bv, c, slab) + vhbt0[c];
+    }
     eta_PF_BT = (work[W_eta * slab + c] + work[W_eta_src * slab + c]) +
                 (A.dtbt * gm(G, d, MOM6X_G_IareaT)[c]) * ((uW - uE) + (vS - vN));
     work[W_eta_pred * slab + c] = eta_PF_BT;
@@ -546,6 +555,8 @@ k_bt_vel(Dm d, const double *__restrict__ G, double *work, double *btav, double 
     work[W_vbt * slab + c] = newv;
     work[W_v_accel_bt * slab + c] = work[W_v_accel_bt * slab + c] + A.wt_accel * (Cor + PF);
   }
+  if (A.store_uhn)   // btloop_eta_predictor's transport of this face at the new velocity (:2975-2985), for the next sub-step
+    work[(DIR ? W_vhn : W_uhn) * slab + c] = find_uhbt(newv, work + (DIR ? W_BTCv : W_BTCu) * slab, c, slab) + work[(DIR ? W_vhbt0 : W_uhbt0) * slab + c];
   // transports on (isv-1..iev, jsv..jev) | (isv..iev, jsv-1..jev)  :2624-2632
   const bool in_trans = DIR ? (i >= A.isv && i <= A.iev && j >= A.jsv - 1 && j <= A.jev)
                             : (i >= A.isv - 1 && i <= A.iev && j >= A.jsv && j <= A.jev);
@@ -971,13 +982,21 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   static const bool f4_planes = [] { const char *e = getenv("MOM6X_BT_F4"); return e && !strcmp(e, "planes"); }();
   L.f4_on_the_fly = f4_planes ? 0 : 1; L.Sadourny = P.Sadourny;
   int isv = is, iev = ie, jsv = js, jev = je;
-  double *loop_f[] = { work + W_eta * slab, work + W_ubt * slab, work + W_vbt * slab };
-  const int loop_stg[] = { 0, 1, 2 }, loop_nk[] = { 1, 1, 1 };
+  double *loop_f[] = { work + W_eta * slab, work + W_ubt * slab, work + W_vbt * slab, work + W_uhn * slab, work + W_vhn * slab };
+  const int loop_stg[] = { 0, 1, 2, 1, 2 }, loop_nk[] = { 1, 1, 1, 1, 1 };
+  // The eta predictor of sub-step n + 1 needs find_uhbt at the velocities sub-step n has just made: the velocity kernels
+  // evaluate it while they hold the velocity and its fit planes and pass two planes on (W_uhn, W_vhn; exchanged with the
+  // velocities), instead of the predictor re-reading four velocities and up to sixteen fit planes per cell.  Not with
+  // CLIP_BT_VELOCITY (the velocities change in between) or BT_PROJECT_VELOCITY (the predictor does not use transports).
+  static const bool pred_self = [] { const char *e = getenv("MOM6X_BT_PRED"); return e && !strcmp(e, "self"); }();
+  const bool pass_uhn = !pred_self && !P.clip_velocity && !P.BT_project_velocity;
+  L.store_uhn = pass_uhn ? 1 : 0;
   for (int n = 1; n <= nt; n++) {
     if (P.clip_velocity)
       KLAUNCH(c, "k_bt_clip", k_bt_clip, grid3(iev - isv + 2, jev - jsv + 2, 1, b), b, d, c->G, work, dt, P.CFL_trunc, isv, iev, jsv, jev);
+    L.have_uhn = (pass_uhn && n > 1) ? 1 : 0;
     if ((iev - stencil < ie) || (jev - stencil < je)) {
-      halo_wrap(c, loop_f, loop_stg, loop_nk, 3);
+      halo_wrap(c, loop_f, loop_stg, loop_nk, (pass_uhn && n > 1) ? 5 : 3);
       isv = isvf; iev = ievf; jsv = jsvf; jev = jevf;
     } else {
       isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil;
