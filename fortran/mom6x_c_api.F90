@@ -33,7 +33,7 @@ module mom6x_c_api
   public :: mom6x_tracer_vertdiff, mom6x_tracer_vertdiff_Eulerian, mom6x_diabatic_is_trivial
 
   !> include/mom6x.h MOM6X_ABI_VERSION this module mirrors; a host compares it with mom6x_abi_version() at start-up
-  integer(c_int), parameter :: MOM6X_ABI_BUILT_FOR = 2
+  integer(c_int), parameter :: MOM6X_ABI_BUILT_FOR = 3
 
   !> mom6x_dims: hor_index_type extents (MOM_hor_index.F90:14-44) + the device layout
   type, bind(C) :: mom6x_dims
@@ -74,7 +74,8 @@ module mom6x_c_api
   end type mom6x_barotropic_params
 
   type, bind(C) :: mom6x_coriolis_params   !< CoriolisAdv_CS (MOM_CoriolisAdv.F90:29-100)
-    integer(c_int) :: Coriolis_Scheme, KE_Scheme, bound_Coriolis, no_slip, Coriolis_En_Dis
+    integer(c_int) :: Coriolis_Scheme, KE_Scheme, bound_Coriolis, no_slip, Coriolis_En_Dis, PV_Adv_Scheme
+    real(c_double) :: F_eff_max_blend, wt_lin_blend
   end type mom6x_coriolis_params
 
   type, bind(C) :: mom6x_pgf_params        !< PressureForce_FV_CS (MOM_PressureForce_FV.F90:40-110)

@@ -7,7 +7,7 @@ use mom6x_c_api
 use mom6x_host
 use mom6x_shim_ctx
 use MOM_diag_mediator,   only : diag_ctrl
-use MOM_error_handler,   only : MOM_error, FATAL
+use MOM_error_handler,   only : MOM_error, FATAL, WARNING
 use MOM_file_parser,     only : get_param, log_version, param_file_type
 use MOM_grid,            only : ocean_grid_type
 use MOM_open_boundary,   only : ocean_OBC_type
@@ -93,6 +93,18 @@ subroutine CoriolisAdv_init(Time, G, GV, US, param_file, diag, AD, CS)
     case ("ROBUST_ENSTRO")     ; CS%p%Coriolis_Scheme = 3
     case default ; call MOM_error(FATAL, "CoriolisAdv_init: Unrecognized setting #define CORIOLIS_SCHEME "//trim(tmpstr)//" found in input file.")
   end select
+  CS%p%F_eff_max_blend = 4.0 ; CS%p%wt_lin_blend = 0.125
+  if (CS%p%Coriolis_Scheme == 6) then   ! :1125-1142
+    call get_param(param_file, mdl, "CORIOLIS_BLEND_WT_LIN", CS%p%wt_lin_blend, "A weighting value for the ratio of inverse "//&
+                 "thicknesses, beyond which the blending between Sadourny Energy and Arakawa & Hsu goes linearly to 0 when "//&
+                 "CORIOLIS_SCHEME is ARAWAKA_LAMB_BLEND. This must be between 1 and 1e-16.", units="nondim", default=0.125)
+    call get_param(param_file, mdl, "CORIOLIS_BLEND_F_EFF_MAX", CS%p%F_eff_max_blend, "The factor by which the maximum "//&
+                 "effective Coriolis acceleration from any point can be increased when blending different discretizations "//&
+                 "with the ARAKAWA_LAMB_BLEND Coriolis scheme.  This must be greater than 2.0 (the max value for Sadourny "//&
+                 "energy).", units="nondim", default=4.0)
+    CS%p%wt_lin_blend = min(1.0, max(CS%p%wt_lin_blend, 1e-16))
+    if (CS%p%F_eff_max_blend < 2.0) call MOM_error(WARNING, "CoriolisAdv_init: CORIOLIS_BLEND_F_EFF_MAX should be at least 2.")
+  endif
   call get_param(param_file, mdl, "BOUND_CORIOLIS", flag, "If true, the Coriolis terms at u-points are bounded by the four "//&
                  "estimates of (f+rv)v from the four neighboring v-points, and similarly at v-points.", default=.false.)
   CS%p%bound_Coriolis = merge(1_c_int, 0_c_int, flag)
@@ -104,9 +116,16 @@ subroutine CoriolisAdv_init(Time, G, GV, US, param_file, diag, AD, CS)
     case ("KE_GUDONOV") ; CS%p%KE_Scheme = 12
     case default ; call MOM_error(FATAL, "CoriolisAdv_init: #define KE_SCHEME "//trim(tmpstr)//" in input file is invalid.")
   end select
+  call get_param(param_file, mdl, "PV_ADV_SCHEME", tmpstr, "PV_ADV_SCHEME selects the discretization for PV advection.", &
+                 default="PV_ADV_CENTERED")
+  select case (trim(tmpstr))      ! :1186-1192
+    case ("PV_ADV_CENTERED") ; CS%p%PV_Adv_Scheme = 21
+    case ("PV_ADV_UPWIND1") ; CS%p%PV_Adv_Scheme = 22
+    case default ; call MOM_error(FATAL, "CoriolisAdv_init: #DEFINE PV_ADV_SCHEME in input file is invalid.")
+  end select
   call shim_set_domain_flags(param_file)
   CS%ctx = shim_ctx(G, GV)
-  rc = mom6x_CoriolisAdv_init(CS%ctx, CS%p) ; call shim_check(rc, "CoriolisAdv_init")   ! refuses the schemes the device lacks
+  rc = mom6x_CoriolisAdv_init(CS%ctx, CS%p) ; call shim_check(rc, "CoriolisAdv_init")
 end subroutine CoriolisAdv_init
 
 !> CoriolisAdv_end (:1322)

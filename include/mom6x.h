@@ -41,7 +41,7 @@ extern "C" {
 /* 2: mom6x_continuity_params.sum_order, the Leith members of mom6x_hor_visc_params, Recon_Scheme / boundary_extrap /
  * h_nonvanished of mom6x_eos_params, mom6x_device_count (round 3).  Hosts compare mom6x_abi_version() with the value they were
  * built against (fortran/mom6x_c_api.F90 MOM6X_ABI_BUILT_FOR, mom6_amd/abi.py ABI_VERSION) and refuse to run on a mismatch. */
-#define MOM6X_ABI_VERSION 2
+#define MOM6X_ABI_VERSION 3
 
 /* ------------------------------------------------------------------------- */
 /* Tile dimensions and layout (MOM_hor_index.F90:14-44 hor_index_type +
@@ -157,18 +157,22 @@ typedef struct mom6x_barotropic_params {
 enum mom6x_coriolis_scheme {       /* CORIOLIS_SCHEME, values as in MOM_CoriolisAdv.F90:82-90       */
   MOM6X_SADOURNY75_ENERGY = 1,     /* default                                                   */
   MOM6X_ARAKAWA_HSU90 = 2,
-  MOM6X_ROBUST_ENSTRO = 3,         /* not implemented                                           */
+  MOM6X_ROBUST_ENSTRO = 3,         /* :687-714, :808-838; switches CORIOLIS_EN_DIS and BOUND_CORIOLIS off (:1118, :1158) */
   MOM6X_SADOURNY75_ENSTRO = 4,
-  MOM6X_ARAKAWA_LAMB81 = 5,        /* not implemented                                           */
-  MOM6X_AL_BLEND = 6               /* not implemented                                           */
+  MOM6X_ARAKAWA_LAMB81 = 5,        /* :534-542 + the ep_u / ep_v terms :716-721, :840-845       */
+  MOM6X_AL_BLEND = 6               /* ARAKAWA_LAMB_BLEND :543-588                               */
 };
 enum mom6x_ke_scheme { MOM6X_KE_ARAKAWA = 10, MOM6X_KE_SIMPLE_GUDONOV = 11, MOM6X_KE_GUDONOV = 12 };
+enum mom6x_pv_adv_scheme { MOM6X_PV_ADV_CENTERED = 21, MOM6X_PV_ADV_UPWIND1 = 22 };   /* MOM_CoriolisAdv.F90:115-119 */
 typedef struct mom6x_coriolis_params {
   int Coriolis_Scheme;   /* SADOURNY75_ENERGY                                                   */
   int KE_Scheme;         /* KE_ARAKAWA                                                          */
   int bound_Coriolis;    /* BOUND_CORIOLIS (F; tc1/p0: T)                                       */
   int no_slip;           /* NOSLIP (F)                                                          */
   int Coriolis_En_Dis;   /* CORIOLIS_EN_DIS (F): the energy-dissipating biased SADOURNY75_ENERGY scheme  */
+  int PV_Adv_Scheme;     /* PV_ADV_SCHEME (PV_ADV_CENTERED); read by ROBUST_ENSTRO only; 0 = the default   */
+  double F_eff_max_blend;/* CORIOLIS_BLEND_F_EFF_MAX (4.0), ARAKAWA_LAMB_BLEND only                      */
+  double wt_lin_blend;   /* CORIOLIS_BLEND_WT_LIN (0.125), ARAKAWA_LAMB_BLEND only; clipped to [1e-16, 1] as :1139 does */
 } mom6x_coriolis_params;
 
 /* PressureForce_FV_CS (src/core/MOM_PressureForce_FV.F90:40-110; PressureForce_FV_init :2020). */

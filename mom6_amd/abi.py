@@ -154,12 +154,14 @@ def barotropic_params_default(dtbt):
 
 SADOURNY75_ENERGY, ARAKAWA_HSU90, ROBUST_ENSTRO, SADOURNY75_ENSTRO, ARAKAWA_LAMB81, AL_BLEND = 1, 2, 3, 4, 5, 6
 KE_ARAKAWA, KE_SIMPLE_GUDONOV, KE_GUDONOV = 10, 11, 12
+PV_ADV_CENTERED, PV_ADV_UPWIND1 = 21, 22
 
 
 class CoriolisParams(C.Structure):
     """mom6x_coriolis_params; CoriolisAdv_CS (MOM_CoriolisAdv.F90:29-100)."""
     _fields_ = [("Coriolis_Scheme", C.c_int), ("KE_Scheme", C.c_int), ("bound_Coriolis", C.c_int),
-                ("no_slip", C.c_int), ("Coriolis_En_Dis", C.c_int)]
+                ("no_slip", C.c_int), ("Coriolis_En_Dis", C.c_int), ("PV_Adv_Scheme", C.c_int),
+                ("F_eff_max_blend", C.c_double), ("wt_lin_blend", C.c_double)]
 
 
 def coriolis_params_default():
@@ -167,6 +169,7 @@ def coriolis_params_default():
     p = CoriolisParams()
     p.Coriolis_Scheme, p.KE_Scheme = SADOURNY75_ENERGY, KE_ARAKAWA
     p.bound_Coriolis = p.no_slip = p.Coriolis_En_Dis = 0
+    p.PV_Adv_Scheme, p.F_eff_max_blend, p.wt_lin_blend = PV_ADV_CENTERED, 4.0, 0.125   # :1126-1139, :1178-1192
     return p
 
 
@@ -395,7 +398,7 @@ MOM6X_OK = 0
 _lib = None
 
 
-ABI_VERSION = 2   # include/mom6x.h MOM6X_ABI_VERSION
+ABI_VERSION = 3   # include/mom6x.h MOM6X_ABI_VERSION
 
 
 def load_library(path=None):

@@ -568,8 +568,10 @@ k_bt_vel(Dm d, const double *__restrict__ G, double *work, double *btav, double 
     if (in_c) {   // running sums :2690-2700
       btav[c] = btav[c] + A.wt_trans * trans;
       hbtav[c] = hbtav[c] + A.wt_trans * hbt;
-      double *wtd = work + (DIR ? W_vbt_wtd : W_ubt_wtd) * slab;
-      wtd[c] = wtd[c] + A.wt_vel * newv;
+      if (A.wt_vel != 0.0) {   // x + 0.0 * newv == x for every x this sum can hold (it starts at +0.0); the filter's weights are
+        double *wtd = work + (DIR ? W_vbt_wtd : W_ubt_wtd) * slab;   // zero for the first nstep - nfilter sub-steps (:1738-1795)
+        wtd[c] = wtd[c] + A.wt_vel * newv;
+      }
     }
   }
 }
@@ -587,7 +589,7 @@ k_bt_eta(Dm d, const double *__restrict__ G, double *work, LoopArgs A, double Z_
   const double e = (work[W_eta * slab + c] + work[W_eta_src * slab + c]) +
                    (A.dtbt * gm(G, d, MOM6X_G_IareaT)[c]) * ((uhbt[c - 1] - uhbt[c]) + (vhbt[c - st] - vhbt[c]));
   work[W_eta * slab + c] = e;
-  work[W_eta_wtd * slab + c] = work[W_eta_wtd * slab + c] + e * A.wt_eta;
+  if (A.wt_eta != 0.0) work[W_eta_wtd * slab + c] = work[W_eta_wtd * slab + c] + e * A.wt_eta;
   // :2738-2745 (Boussinesq): unphysical sea surface height over the computational domain -- counted, the first one kept
   if (i >= 0 && i < d.ni && j >= 0 && j < d.nj) {
     const double bT = gm(G, d, MOM6X_G_bathyT)[c];

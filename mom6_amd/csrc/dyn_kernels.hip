@@ -22,7 +22,7 @@ inline dim3 blk2() { return dim3(64, 4, 1); }
 __global__ void __launch_bounds__(256)
 k_corad_q(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
           const double *__restrict__ h, double *__restrict__ q, double *__restrict__ absv, double *__restrict__ KE,
-          int no_slip, int ke_scheme, double vol_neglect) {
+          int no_slip, int ke_scheme, double vol_neglect, double *__restrict__ Ihq) {
   const int i = I_BASE(-2) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -2 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni || j > d.nj) return;
@@ -63,6 +63,7 @@ k_corad_q(Dm d, const double *__restrict__ G, const double *__restrict__ u, cons
     const double Ih_q = Area_q / (hArea_q + vol_neglect);
     q[c] = abs_vort * Ih_q;
     if (absv) absv[c] = abs_vort;
+    if (Ihq) Ihq[c] = Ih_q;   // ARAKAWA_LAMB_BLEND weighs its three schemes by the spread of Ih_q around a cell (:550-573)
     if (do_KE) {
       const double um1 = u[c - 1], vm1 = v[c - st];
       double ke;
@@ -98,9 +99,55 @@ struct CoradAcc {
   double IdxCu, IdyCv, Lv[4], Lu[4];
   int scheme, bound, en_dis;
   bool do_u, do_v;
+  // ARAKAWA_LAMB_BLEND (:544-548), ROBUST_ENSTRO (:242-243; IdxCv / IdyCu of the four faces in Lv / Lu)
+  double Fe_m2, rat_lin, wt_lin, eps_vel, h_tiny;
+  int pv_upwind;
 };
-template <class QF, class KF, class AF>
-__device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int st, const QF &Q, const KF &KEf, const AF &AVf) {
+// The Arakawa & Lamb (1981) weights of one thickness cell from the potential vorticity at its four corners (NE = q(I,J),
+// SW = q(I-1,J-1), NW = q(I-1,J), SE = q(I,J-1)): a(I-1,j), d(I-1,j), b(I,j), c(I,j), ep_u(i,j), ep_v(i,j)  :534-542, and their
+// ARAKAWA_LAMB_BLEND form :543-588 (ih* = Ih_q at the same corners).
+struct ALCell { double a, d, b, c, ep_u, ep_v; };
+__device__ __forceinline__ ALCell al_cell(const CoradAcc &X, double qNE, double qSW, double qNW, double qSE, double ihNE,
+                                          double ihSW, double ihNW, double ihSE) {
+  const double C1_24 = 1.0 / 24.0;
+  ALCell r;
+  if (X.scheme == MOM6X_ARAKAWA_LAMB81) {
+    r.a = (2.0 * (qNE + qSW) + (qNW + qSE)) * C1_24;
+    r.d = ((qNE + qSW) + 2.0 * (qNW + qSE)) * C1_24;
+    r.b = ((qNE + qSW) + 2.0 * (qNW + qSE)) * C1_24;
+    r.c = (2.0 * (qNE + qSW) + (qNW + qSE)) * C1_24;
+    r.ep_u = ((qNE - qSW) + (qNW - qSE)) * C1_24;
+    r.ep_v = (-(qNE - qSW) + (qNW - qSE)) * C1_24;
+  } else {
+    const double min_Ihq = dmin(dmin(dmin(ihSW, ihSE), ihNW), ihNE), max_Ihq = dmax(dmax(dmax(ihSW, ihSE), ihNW), ihNE);
+    double rat_m1 = 1.0e15, AL_wt, Sad_wt;
+    if (max_Ihq < 1.0e15 * min_Ihq) rat_m1 = max_Ihq / min_Ihq - 1.0;
+    if (rat_m1 <= X.Fe_m2) AL_wt = 1.0;
+    else if (rat_m1 < 1.5 * X.Fe_m2) AL_wt = 3.0 * X.Fe_m2 / rat_m1 - 2.0;
+    else AL_wt = 0.0;
+    if (rat_m1 <= 1.5 * X.Fe_m2) Sad_wt = 0.0;
+    else if (rat_m1 <= X.rat_lin) Sad_wt = 1.0 - (1.5 * X.Fe_m2) / rat_m1;
+    else if (rat_m1 < 2.0 * X.rat_lin) Sad_wt = 1.0 - (X.wt_lin / X.rat_lin) * (rat_m1 - 2.0 * X.rat_lin);
+    else Sad_wt = 1.0;
+    r.a = Sad_wt * 0.25 * qNW + (1.0 - Sad_wt) * (((2.0 - AL_wt) * qNW + AL_wt * qSE) + 2.0 * (qNE + qSW)) * C1_24;
+    r.d = Sad_wt * 0.25 * qSW + (1.0 - Sad_wt) * (((2.0 - AL_wt) * qSW + AL_wt * qNE) + 2.0 * (qNW + qSE)) * C1_24;
+    r.b = Sad_wt * 0.25 * qNE + (1.0 - Sad_wt) * (((2.0 - AL_wt) * qNE + AL_wt * qSW) + 2.0 * (qNW + qSE)) * C1_24;
+    r.c = Sad_wt * 0.25 * qSE + (1.0 - Sad_wt) * (((2.0 - AL_wt) * qSE + AL_wt * qNW) + 2.0 * (qNE + qSW)) * C1_24;
+    r.ep_u = AL_wt * ((qNE - qSW) + (qNW - qSE)) * C1_24;
+    r.ep_v = AL_wt * (-(qNE - qSW) + (qNW - qSE)) * C1_24;
+  }
+  return r;
+}
+// Heff of ROBUST_ENSTRO (:692-703, :813-824): the transport's own thickness, kept between the two cells' thicknesses
+__device__ __forceinline__ double robust_heff(double tr, double Idl, double vel, double eps_vel, double hA, double hB) {
+  double He = fabs(tr * Idl) / (eps_vel + fabs(vel));
+  He = dmax(He, dmin(hA, hB));
+  return dmin(He, dmax(hA, hB));
+}
+struct NoIhq { __device__ double operator()(int, int) const { return 0.0; } };
+template <class QF, class KF, class AF, class IF = NoIhq>
+__device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int st, const QF &Q, const KF &KEf, const AF &AVf,
+                                                const IF &IH = NoIhq()) {
   const double *__restrict__ u = X.u, *__restrict__ v = X.v, *__restrict__ uh = X.uh, *__restrict__ vh = X.vh, *__restrict__ h = X.h;
   const double *__restrict__ PFu = X.PFu, *__restrict__ PFv = X.PFv, *__restrict__ diffu = X.diffu, *__restrict__ diffv = X.diffv;
   double *__restrict__ CAu = X.CAu, *__restrict__ CAv = X.CAv, *__restrict__ u_bc = X.u_bc, *__restrict__ v_bc = X.v_bc;
@@ -109,6 +156,7 @@ __device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int
   const int scheme = X.scheme, bound = X.bound, en_dis = X.en_dis;
   const bool do_u = X.do_u, do_v = X.do_v;
   const double C1_12 = 1.0 / 12.0;
+  auto ihq = [&](int di, int dj) { return (scheme == MOM6X_AL_BLEND) ? IH(di, dj) : 0.0; };   // only the blend has (and reads) Ih_q
   // CORIOLIS_EN_DIS (:326-333, :590-635): the centred thickness transport of a face and the one the continuity solver
   // gave bracket the transport used by the energy-dissipating scheme; recomputed here for the four faces each point needs
   auto bracket = [](double Lf, double vel, double hsum, double hm_in, double &mn, double &mx) {
@@ -146,12 +194,30 @@ __device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int
         ca = 0.25 * ((q00 * (vh[c + 1] + vh[c])) + (q0m * (vh[c - st] + vh[c + 1 - st]))) * IdxCu;
       } else if (scheme == MOM6X_SADOURNY75_ENSTRO) {
         ca = 0.125 * (IdxCu * (q00 + q0m)) * ((vh[c + 1] + vh[c]) + (vh[c - st] + vh[c + 1 - st]));
-      } else {   // ARAKAWA_HSU90 :523-533, :683-686
+      } else if (scheme == MOM6X_ARAKAWA_HSU90) {   // :523-533, :683-686
         const double a = (q00 + (Q(1, 0) + q0m)) * C1_12;
         const double dd = ((q00 + Q(1, -1)) + q0m) * C1_12;
         const double b = (q00 + (Q(-1, 0) + q0m)) * C1_12;
         const double cc = ((q00 + Q(-1, -1)) + q0m) * C1_12;
         ca = (((a * vh[c + 1]) + (cc * vh[c - st])) + ((b * vh[c]) + (dd * vh[c + 1 - st]))) * IdxCu;
+      } else if (scheme == MOM6X_ROBUST_ENSTRO) {   // :687-714; Lv = IdxCv of the v faces (i,J), (i+1,J), (i,J-1), (i+1,J-1)
+        const double Heff1 = robust_heff(vh[c], Lv[0], v[c], X.eps_vel, h[c], h[c + st]);
+        const double Heff2 = robust_heff(vh[c - st], Lv[2], v[c - st], X.eps_vel, h[c - st], h[c]);
+        const double Heff3 = robust_heff(vh[c + 1], Lv[1], v[c + 1], X.eps_vel, h[c + 1], h[c + 1 + st]);
+        const double Heff4 = robust_heff(vh[c + 1 - st], Lv[3], v[c + 1 - st], X.eps_vel, h[c + 1 - st], h[c + 1]);
+        const double av0 = AVf(0, 0), avm = AVf(0, -1);
+        const double VHeff = ((vh[c] + vh[c + 1 - st]) + (vh[c - st] + vh[c + 1]));
+        if (X.pv_upwind) {
+          const double QVHeff = 0.5 * (((av0 + avm) * VHeff) - ((av0 - avm) * fabs(VHeff)));
+          ca = (QVHeff / (X.h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3)))) * IdxCu;
+        } else
+          ca = 0.5 * (av0 + avm) * VHeff / (X.h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3))) * IdxCu;
+      } else {   // ARAKAWA_LAMB81 / ARAKAWA_LAMB_BLEND: the cells (i+1,j) and (i,j) either side of the face  :534-588, :683-686, :716-721
+        const double q10 = Q(1, 0), q1m = Q(1, -1), qm0 = Q(-1, 0), qmm = Q(-1, -1);
+        const ALCell E = al_cell(X, q10, q0m, q00, q1m, ihq(1, 0), ihq(0, -1), ihq(0, 0), ihq(1, -1));
+        const ALCell W = al_cell(X, q00, qmm, qm0, q0m, ihq(0, 0), ihq(-1, -1), ihq(-1, 0), ihq(0, -1));
+        ca = (((E.a * vh[c + 1]) + (W.c * vh[c - st])) + ((W.b * vh[c]) + (E.d * vh[c + 1 - st]))) * IdxCu;
+        ca = ca + ((W.ep_u * uh[c - 1]) - (E.ep_u * uh[c + 1])) * IdxCu;
       }
       if (bound) {   // :734-747
         const double av0 = AVf(0, 0), avm = AVf(0, -1);
@@ -185,13 +251,31 @@ __device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int
         ca = -0.25 * ((qm0 * (uh[c - 1] + uh[c - 1 + st])) + (q00 * (uh[c] + uh[c + st]))) * IdyCv;
       } else if (scheme == MOM6X_SADOURNY75_ENSTRO) {
         ca = -0.125 * (IdyCv * (qm0 + q00)) * ((uh[c - 1] + uh[c - 1 + st]) + (uh[c] + uh[c + st]));
-      } else {
+      } else if (scheme == MOM6X_ARAKAWA_HSU90) {
         // a(I-1,j), c(I,j+1), b(I,j), d(I-1,j+1)
         const double a_m = (qm0 + (q00 + Q(-1, -1))) * C1_12;
         const double c_p = ((Q(0, 1) + Q(-1, 0)) + q00) * C1_12;
         const double b_0 = (q00 + (qm0 + Q(0, -1))) * C1_12;
         const double d_mp = ((Q(-1, 1) + q00) + qm0) * C1_12;
         ca = -(((a_m * uh[c - 1]) + (c_p * uh[c + st])) + ((b_0 * uh[c]) + (d_mp * uh[c - 1 + st]))) * IdyCv;
+      } else if (scheme == MOM6X_ROBUST_ENSTRO) {   // :808-838; Lu = IdyCu of the u faces (I-1,j), (I-1,j+1), (I,j), (I,j+1)
+        const double Heff1 = robust_heff(uh[c], Lu[2], u[c], X.eps_vel, h[c], h[c + 1]);
+        const double Heff2 = robust_heff(uh[c - 1], Lu[0], u[c - 1], X.eps_vel, h[c - 1], h[c]);
+        const double Heff3 = robust_heff(uh[c + st], Lu[3], u[c + st], X.eps_vel, h[c + st], h[c + 1 + st]);
+        const double Heff4 = robust_heff(uh[c - 1 + st], Lu[1], u[c - 1 + st], X.eps_vel, h[c - 1 + st], h[c + st]);
+        const double av0 = AVf(0, 0), avm = AVf(-1, 0);
+        const double UHeff = ((uh[c] + uh[c - 1 + st]) + (uh[c - 1] + uh[c + st]));
+        if (X.pv_upwind) {
+          const double QUHeff = 0.5 * (((av0 + avm) * UHeff) - ((av0 - avm) * fabs(UHeff)));
+          ca = -(QUHeff / (X.h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3))) * IdyCv);
+        } else
+          ca = -(0.5 * (av0 + avm) * UHeff / (X.h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3))) * IdyCv);
+      } else {   // ARAKAWA_LAMB81 / ARAKAWA_LAMB_BLEND: the cells (i,j) and (i,j+1) either side of the face  :796-801, :840-845
+        const double qmm = Q(-1, -1), q0m = Q(0, -1), q01 = Q(0, 1), qm1 = Q(-1, 1);
+        const ALCell S = al_cell(X, q00, qmm, qm0, q0m, ihq(0, 0), ihq(-1, -1), ihq(-1, 0), ihq(0, -1));
+        const ALCell N = al_cell(X, q01, qm0, qm1, q00, ihq(0, 1), ihq(-1, 0), ihq(-1, 1), ihq(0, 0));
+        ca = -(((S.a * uh[c - 1]) + (N.c * uh[c + st])) + ((S.b * uh[c]) + (N.d * uh[c - 1 + st]))) * IdyCv;
+        ca = ca + ((S.ep_v * vh[c - st]) - (N.ep_v * vh[c + st])) * IdyCv;
       }
       if (bound) {
         const double av0 = AVf(0, 0), avm = AVf(-1, 0);
@@ -212,7 +296,7 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
             double *__restrict__ CAv, int scheme, int bound, const double *__restrict__ h, int en_dis,
             const double *__restrict__ PFu, const double *__restrict__ PFv, const double *__restrict__ diffu,
             const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc,
-            double *__restrict__ uhtr, double *__restrict__ vhtr, double dt_tr) {
+            double *__restrict__ uhtr, double *__restrict__ vhtr, double dt_tr, const double *__restrict__ Ihq, CoradAcc X0) {
   const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -220,7 +304,7 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
   const int st = d.pitch;
   const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
   const int k0 = blockIdx.z * KCHUNK, k1 = min(k0 + KCHUNK, d.nk);
-  CoradAcc X;
+  CoradAcc X = X0;   // the scheme's constants (Fe_m2, rat_lin, wt_lin, eps_vel, h_tiny, pv_upwind)
   X.u = u; X.v = v; X.uh = uh; X.vh = vh; X.h = h; X.PFu = PFu; X.PFv = PFv; X.diffu = diffu; X.diffv = diffv;
   X.CAu = CAu; X.CAv = CAv; X.u_bc = u_bc; X.v_bc = v_bc; X.scheme = scheme; X.bound = bound; X.en_dis = en_dis;
   X.do_u = (j >= 0); X.do_v = (i >= 0);
@@ -230,6 +314,11 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
     const double *dx_Cv = gm(G, d, MOM6X_G_dx_Cv), *dy_Cu = gm(G, d, MOM6X_G_dy_Cu);
     if (X.do_u) { X.Lv[0] = dx_Cv[x]; X.Lv[1] = dx_Cv[x + 1]; X.Lv[2] = dx_Cv[x - st]; X.Lv[3] = dx_Cv[x + 1 - st]; }
     if (X.do_v) { X.Lu[0] = dy_Cu[x - 1]; X.Lu[1] = dy_Cu[x - 1 + st]; X.Lu[2] = dy_Cu[x]; X.Lu[3] = dy_Cu[x + st]; }
+  }
+  if (scheme == MOM6X_ROBUST_ENSTRO) {
+    const double *IdxCv = gm(G, d, MOM6X_G_IdxCv), *IdyCu = gm(G, d, MOM6X_G_IdyCu);
+    if (X.do_u) { X.Lv[0] = IdxCv[x]; X.Lv[1] = IdxCv[x + 1]; X.Lv[2] = IdxCv[x - st]; X.Lv[3] = IdxCv[x + 1 - st]; }
+    if (X.do_v) { X.Lu[0] = IdyCu[x - 1]; X.Lu[1] = IdyCu[x - 1 + st]; X.Lu[2] = IdyCu[x]; X.Lu[3] = IdyCu[x + st]; }
   }
   // uhtr = uhtr + uh*dt, vhtr = vhtr + vh*dt (RK2.F90:1072-1079) for the points of this kernel's box (-1..ni-1, -1..nj-1), whose
   // uh(I,j), vh(i,J) it reads anyway; k_uhtr does the ring around the box
@@ -242,7 +331,7 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
   for (int k = k0; k < k1; k++) {
     const size_t c = x + (size_t)k * slab;
     corad_acc_layer(X, c, st, [&](int di, int dj) { return q[c + di + dj * st]; }, [&](int di, int dj) { return KE[c + di + dj * st]; },
-                    [&](int di, int dj) { return absv[c + di + dj * st]; });
+                    [&](int di, int dj) { return absv[c + di + dj * st]; }, [&](int di, int dj) { return Ihq[c + di + dj * st]; });
   }
 }
 
@@ -609,11 +698,13 @@ k_vertvisc_remnant_cols(Dm d, const double *__restrict__ G, double *__restrict__
 // ---------------------------------------------------------------------------------------------
 extern "C" int mom6x_CoriolisAdv_init(mom6x_ctx *c, const mom6x_coriolis_params *p) {
   REQUIRE(c && p, MOM6X_EINVAL, "mom6x_CoriolisAdv_init: null argument");
-  REQUIRE(p->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY || p->Coriolis_Scheme == MOM6X_SADOURNY75_ENSTRO ||
-          p->Coriolis_Scheme == MOM6X_ARAKAWA_HSU90, MOM6X_EUNSUPPORTED,
-          "CoriolisAdv: only SADOURNY75_ENERGY, SADOURNY75_ENSTRO and ARAKAWA_HSU90 are implemented");
+  REQUIRE(p->Coriolis_Scheme >= MOM6X_SADOURNY75_ENERGY && p->Coriolis_Scheme <= MOM6X_AL_BLEND, MOM6X_EINVAL,
+          "CoriolisAdv_init: Unrecognized setting of CORIOLIS_SCHEME");
   REQUIRE(p->KE_Scheme >= MOM6X_KE_ARAKAWA && p->KE_Scheme <= MOM6X_KE_GUDONOV, MOM6X_EINVAL, "CoriolisAdv: bad KE_SCHEME");
+  REQUIRE(p->PV_Adv_Scheme == 0 || p->PV_Adv_Scheme == MOM6X_PV_ADV_CENTERED || p->PV_Adv_Scheme == MOM6X_PV_ADV_UPWIND1, MOM6X_EINVAL,
+          "CoriolisAdv_init: PV_ADV_SCHEME is invalid");
   c->cor = *p;
+  if (c->cor.Coriolis_Scheme == MOM6X_ROBUST_ENSTRO) { c->cor.Coriolis_En_Dis = 0; c->cor.bound_Coriolis = 0; }   // :1118, :1158
   // CoriolisAdv_init :1158: with CORIOLIS_EN_DIS and SADOURNY75_ENERGY the bound is always effectively off
   if (c->cor.Coriolis_En_Dis && c->cor.Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY) c->cor.bound_Coriolis = 0;
   c->cor_init = true;
@@ -642,13 +733,25 @@ int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h
   int rc;
   if ((rc = ctx_scratch(c, SCR_q, d.nk, &q))) return rc;
   if ((rc = ctx_scratch(c, SCR_KE, d.nk, &KE))) return rc;
-  if (c->cor.bound_Coriolis && (rc = ctx_scratch(c, SCR_absv, d.nk, &absv))) return rc;
+  const int scheme = c->cor.Coriolis_Scheme;
+  // the schemes of the default k_corad_fused; ROBUST_ENSTRO, ARAKAWA_LAMB81 and ARAKAWA_LAMB_BLEND take the two-kernel form
+  const bool fusable = (scheme == MOM6X_SADOURNY75_ENERGY || scheme == MOM6X_SADOURNY75_ENSTRO || scheme == MOM6X_ARAKAWA_HSU90);
+  if ((c->cor.bound_Coriolis || scheme == MOM6X_ROBUST_ENSTRO) && (rc = ctx_scratch(c, SCR_absv, d.nk, &absv))) return rc;
+  double *Ihq = nullptr;
+  if (scheme == MOM6X_AL_BLEND && (rc = ctx_scratch(c, SCR_t0, d.nk, &Ihq))) return rc;
+  CoradAcc X0 = {};
+  X0.Fe_m2 = c->cor.F_eff_max_blend - 2.0;                                            // :544-548
+  X0.wt_lin = c->cor.wt_lin_blend < 1e-16 ? 1e-16 : (c->cor.wt_lin_blend > 1.0 ? 1.0 : c->cor.wt_lin_blend);   // :1139
+  X0.rat_lin = 1.5 * X0.Fe_m2 / (X0.wt_lin > 1.0e-16 ? X0.wt_lin : 1.0e-16);
+  if (c->cor.F_eff_max_blend <= 2.0) { X0.Fe_m2 = -1.; X0.rat_lin = -1.0; }
+  X0.eps_vel = 1.0e-10 * 1.0; X0.h_tiny = c->GV.Angstrom_H;                              // :242-243
+  X0.pv_upwind = (c->cor.PV_Adv_Scheme == MOM6X_PV_ADV_UPWIND1);
   const dim3 b = blk2();
   const double vol_neglect = c->GV.H_subroundoff * ((1e-4 * 1.0) * (1e-4 * 1.0));
   // (A barrier-free form -- every thread evaluating q at its own vertex and the one to the south, the western one by a lane
   //  shuffle -- was measured too: 200 registers, 7.1 ms per step against 5.9 for k_corad_fused and 6.5 for the two kernels.)
   static const bool two_kernels = [] { const char *e = getenv("MOM6X_CORAD"); return e && !strcmp(e, "legacy"); }();
-  if (!two_kernels && d.halo >= 3) {   // q, KE, abs_vort through LDS (k_corad_fused); MOM6X_CORAD=legacy: through HBM
+  if (!two_kernels && fusable && d.halo >= 3) {   // q, KE, abs_vort through LDS (k_corad_fused); MOM6X_CORAD=legacy: through HBM
     const int kc = (d.nk % 25 == 0) ? 25 : ((d.nk >= KCHUNK) ? KCHUNK : d.nk);
     const dim3 bt(CF_X, CF_Y, 1);
     const dim3 gt((d.ni + 1 + (CF_X - 2) - 1) / (CF_X - 2), (d.nj + 1 + (CF_Y - 2) - 1) / (CF_Y - 2), (d.nk + kc - 1) / kc);
@@ -658,10 +761,10 @@ int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h
     return MOM6X_OK;
   }
   KLAUNCH(c, "k_corad_q", k_corad_q, gridk(nxa(d.ni + 3, -2), d.nj + 3, d.nk, b), b, d, c->G, u, v, h, q, absv, KE,
-          c->cor.no_slip, c->cor.KE_Scheme, vol_neglect);
+          c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, Ihq);
   KLAUNCH(c, "k_corad_acc", k_corad_acc, gridk(nxa(d.ni + 1, -1), d.nj + 1, d.nk, b), b, d, c->G, u, v, uh, vh, q, absv, KE,
           CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h, c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc,
-          uhtr, vhtr, dt_tr);
+          uhtr, vhtr, dt_tr, (const double *)Ihq, X0);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }

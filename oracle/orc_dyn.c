@@ -7,7 +7,8 @@
  * vertvisc / vertvisc_remnant <- src/parameterizations/vertical/MOM_vert_friction.F90:557-1356
  *
  * Supported options (others return MOM6X_EUNSUPPORTED):
- *   CORIOLIS_SCHEME = SADOURNY75_ENERGY (default) | SADOURNY75_ENSTRO | ARAKAWA_HSU90, BOUND_CORIOLIS,
+ *   CORIOLIS_SCHEME = SADOURNY75_ENERGY (default) | SADOURNY75_ENSTRO | ARAKAWA_HSU90 | ARAKAWA_LAMB81 | ARAKAWA_LAMB_BLEND |
+ *   ROBUST_ENSTRO (with PV_ADV_SCHEME = PV_ADV_CENTERED | PV_ADV_UPWIND1), BOUND_CORIOLIS,
  *   NOSLIP, KE_SCHEME = KE_ARAKAWA (default) | KE_SIMPLE_GUDONOV | KE_GUDONOV; CORIOLIS_EN_DIS=False;
  *   no OBC, no Stokes drift; PGF: use_EOS=False, no p_atm, no tides/SAL, GFS_scale=1;
  *   vertvisc: with or without DIRECT_STRESS; no Stokes mixing / fpmix / GL90; optional Ray_u/Ray_v.
@@ -21,8 +22,13 @@ void orc_pass_var(const mom6x_dims *d, double *a, int stagger, int nk);
 int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_coriolis_params *CS,
                   const double *u, const double *v, const double *h, const double *uh, const double *vh,
                   double *CAu, double *CAv) {
-  if (CS->Coriolis_Scheme != MOM6X_SADOURNY75_ENERGY && CS->Coriolis_Scheme != MOM6X_SADOURNY75_ENSTRO &&
-      CS->Coriolis_Scheme != MOM6X_ARAKAWA_HSU90) return MOM6X_EUNSUPPORTED;
+  if (CS->Coriolis_Scheme < MOM6X_SADOURNY75_ENERGY || CS->Coriolis_Scheme > MOM6X_AL_BLEND) return MOM6X_EINVAL;
+  const int scheme = CS->Coriolis_Scheme;
+  const int AH_like = (scheme == MOM6X_ARAKAWA_HSU90 || scheme == MOM6X_ARAKAWA_LAMB81 || scheme == MOM6X_AL_BLEND);
+  const int AL_like = (scheme == MOM6X_ARAKAWA_LAMB81 || scheme == MOM6X_AL_BLEND);
+  const double C1_24 = 1.0 / 24.0;
+  const double eps_vel = 1.0e-10 * 1.0, h_tiny = GV->Angstrom_H;   /* :242-243 */
+  const double *IdxCv = GM(G, d, MOM6X_G_IdxCv), *IdyCu = GM(G, d, MOM6X_G_IdyCu);
   const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1, nz = d->nk, st = d->pitch;
   const int Isq = -1, Ieq = ie, Jsq = -1, Jeq = je;
   const size_t slab = (size_t)d->slab;
@@ -37,8 +43,8 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
   NEW2(Area_h); NEW2(Area_q);
   const double *dy_Cu = GM(G, d, MOM6X_G_dy_Cu), *dx_Cv = GM(G, d, MOM6X_G_dx_Cv);
   /* CoriolisAdv_init :1119, :1158: ROBUST_ENSTRO switches En_Dis off; En_Dis with SADOURNY75_ENERGY switches the bound off */
-  const int en_dis = CS->Coriolis_En_Dis;
-  const int bound_Coriolis = CS->bound_Coriolis && !(en_dis && CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENERGY);
+  const int en_dis = CS->Coriolis_En_Dis && scheme != MOM6X_ROBUST_ENSTRO;
+  const int bound_Coriolis = CS->bound_Coriolis && !(en_dis && scheme == MOM6X_SADOURNY75_ENERGY) && scheme != MOM6X_ROBUST_ENSTRO;
 
   for (int j = Jsq - 1; j <= Jeq + 2; j++) for (int i = Isq - 1; i <= Ieq + 2; i++) {
     size_t x = IX2(d, i, j); Area_h[x] = mT[x] * areaT[x];
@@ -53,7 +59,7 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
   {
   NEW2(dvdx); NEW2(dudy); NEW2(hArea_u); NEW2(hArea_v); NEW2(rel_vort); NEW2(abs_vort);
   NEW2(q); NEW2(a); NEW2(b); NEW2(c); NEW2(dd); NEW2(KE); NEW2(KEx); NEW2(KEy);
-  NEW2(uh_min); NEW2(uh_max); NEW2(vh_min); NEW2(vh_max);
+  NEW2(uh_min); NEW2(uh_max); NEW2(vh_min); NEW2(vh_max); NEW2(Ih_qa); NEW2(ep_u); NEW2(ep_v);
 #pragma omp for schedule(static)
   for (int k = 0; k < nz; k++) {
     const double *uk = u + k * slab, *vk = v + k * slab, *hk = h + k * slab, *uhk = uh + k * slab, *vhk = vh + k * slab;
@@ -79,8 +85,9 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
       double hArea_q = (hArea_u[x] + hArea_u[x + st]) + (hArea_v[x] + hArea_v[x + 1]);
       double Ih_q = Area_q[x] / (hArea_q + vol_neglect);
       q[x] = abs_vort[x] * Ih_q;
+      Ih_qa[x] = Ih_q;
     }
-    if (CS->Coriolis_Scheme == MOM6X_ARAKAWA_HSU90) { /* :523-533 */
+    if (scheme == MOM6X_ARAKAWA_HSU90) { /* :523-533 */
       for (int j = Jsq; j <= Jeq + 1; j++) {
         for (int i = is - 1; i <= Ieq; i++) {
           size_t x = IX2(d, i, j);
@@ -92,6 +99,42 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
           b[x] = (q[x] + (q[x - 1] + q[x - st])) * C1_12;
           c[x] = ((q[x] + q[x - 1 - st]) + q[x - st]) * C1_12;
         }
+      }
+    }
+    if (scheme == MOM6X_ARAKAWA_LAMB81) {   /* :534-542 */
+      for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+        size_t x = IX2(d, i, j);
+        a[x - 1] = (2.0 * (q[x] + q[x - 1 - st]) + (q[x - 1] + q[x - st])) * C1_24;
+        dd[x - 1] = ((q[x] + q[x - 1 - st]) + 2.0 * (q[x - 1] + q[x - st])) * C1_24;
+        b[x] = ((q[x] + q[x - 1 - st]) + 2.0 * (q[x - 1] + q[x - st])) * C1_24;
+        c[x] = (2.0 * (q[x] + q[x - 1 - st]) + (q[x - 1] + q[x - st])) * C1_24;
+        ep_u[x] = ((q[x] - q[x - 1 - st]) + (q[x - 1] - q[x - st])) * C1_24;
+        ep_v[x] = (-(q[x] - q[x - 1 - st]) + (q[x - 1] - q[x - st])) * C1_24;
+      }
+    } else if (scheme == MOM6X_AL_BLEND) {   /* :543-588 */
+      const double wt_lin_blend = orc_min(1.0, orc_max(CS->wt_lin_blend, 1e-16));   /* CoriolisAdv_init :1139 */
+      double Fe_m2 = CS->F_eff_max_blend - 2.0;
+      double rat_lin = 1.5 * Fe_m2 / orc_max(wt_lin_blend, 1.0e-16);
+      if (CS->F_eff_max_blend <= 2.0) { Fe_m2 = -1.; rat_lin = -1.0; }
+      for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {
+        size_t x = IX2(d, i, j);
+        double min_Ihq = orc_min(orc_min(orc_min(Ih_qa[x - 1 - st], Ih_qa[x - st]), Ih_qa[x - 1]), Ih_qa[x]);
+        double max_Ihq = orc_max(orc_max(orc_max(Ih_qa[x - 1 - st], Ih_qa[x - st]), Ih_qa[x - 1]), Ih_qa[x]);
+        double rat_m1 = 1.0e15, AL_wt, Sad_wt;
+        if (max_Ihq < 1.0e15 * min_Ihq) rat_m1 = max_Ihq / min_Ihq - 1.0;
+        if (rat_m1 <= Fe_m2) AL_wt = 1.0;
+        else if (rat_m1 < 1.5 * Fe_m2) AL_wt = 3.0 * Fe_m2 / rat_m1 - 2.0;
+        else AL_wt = 0.0;
+        if (rat_m1 <= 1.5 * Fe_m2) Sad_wt = 0.0;
+        else if (rat_m1 <= rat_lin) Sad_wt = 1.0 - (1.5 * Fe_m2) / rat_m1;
+        else if (rat_m1 < 2.0 * rat_lin) Sad_wt = 1.0 - (wt_lin_blend / rat_lin) * (rat_m1 - 2.0 * rat_lin);
+        else Sad_wt = 1.0;
+        a[x - 1] = Sad_wt * 0.25 * q[x - 1] + (1.0 - Sad_wt) * (((2.0 - AL_wt) * q[x - 1] + AL_wt * q[x - st]) + 2.0 * (q[x] + q[x - 1 - st])) * C1_24;
+        dd[x - 1] = Sad_wt * 0.25 * q[x - 1 - st] + (1.0 - Sad_wt) * (((2.0 - AL_wt) * q[x - 1 - st] + AL_wt * q[x]) + 2.0 * (q[x - 1] + q[x - st])) * C1_24;
+        b[x] = Sad_wt * 0.25 * q[x] + (1.0 - Sad_wt) * (((2.0 - AL_wt) * q[x] + AL_wt * q[x - 1 - st]) + 2.0 * (q[x - 1] + q[x - st])) * C1_24;
+        c[x] = Sad_wt * 0.25 * q[x - st] + (1.0 - Sad_wt) * (((2.0 - AL_wt) * q[x - st] + AL_wt * q[x - 1]) + 2.0 * (q[x] + q[x - 1 - st])) * C1_24;
+        ep_u[x] = AL_wt * ((q[x] - q[x - 1 - st]) + (q[x - 1] - q[x - st])) * C1_24;
+        ep_v[x] = AL_wt * (-(q[x] - q[x - 1 - st]) + (q[x - 1] - q[x - st])) * C1_24;
       }
     }
     if (en_dis) {   /* uh_center, vh_center :326-333 and the bracketing transports :590-635 */
@@ -163,8 +206,26 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
         ca = 0.25 * ((q[x] * (vhk[x + 1] + vhk[x])) + (q[x - st] * (vhk[x - st] + vhk[x + 1 - st]))) * IdxCu[x];
       else if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENSTRO)
         ca = 0.125 * (IdxCu[x] * (q[x] + q[x - st])) * ((vhk[x + 1] + vhk[x]) + (vhk[x - st] + vhk[x + 1 - st]));
-      else
+      else if (AH_like)
         ca = (((a[x] * vhk[x + 1]) + (c[x] * vhk[x - st])) + ((b[x] * vhk[x]) + (dd[x] * vhk[x + 1 - st]))) * IdxCu[x];
+      else {   /* ROBUST_ENSTRO :687-714 */
+        double Heff1 = fabs(vhk[x] * IdxCv[x]) / (eps_vel + fabs(vk[x]));
+        Heff1 = orc_max(Heff1, orc_min(hk[x], hk[x + st])); Heff1 = orc_min(Heff1, orc_max(hk[x], hk[x + st]));
+        double Heff2 = fabs(vhk[x - st] * IdxCv[x - st]) / (eps_vel + fabs(vk[x - st]));
+        Heff2 = orc_max(Heff2, orc_min(hk[x - st], hk[x])); Heff2 = orc_min(Heff2, orc_max(hk[x - st], hk[x]));
+        double Heff3 = fabs(vhk[x + 1] * IdxCv[x + 1]) / (eps_vel + fabs(vk[x + 1]));
+        Heff3 = orc_max(Heff3, orc_min(hk[x + 1], hk[x + 1 + st])); Heff3 = orc_min(Heff3, orc_max(hk[x + 1], hk[x + 1 + st]));
+        double Heff4 = fabs(vhk[x + 1 - st] * IdxCv[x + 1 - st]) / (eps_vel + fabs(vk[x + 1 - st]));
+        Heff4 = orc_max(Heff4, orc_min(hk[x + 1 - st], hk[x + 1])); Heff4 = orc_min(Heff4, orc_max(hk[x + 1 - st], hk[x + 1]));
+        if (CS->PV_Adv_Scheme == MOM6X_PV_ADV_UPWIND1) {
+          double VHeff = ((vhk[x] + vhk[x + 1 - st]) + (vhk[x - st] + vhk[x + 1]));
+          double QVHeff = 0.5 * (((abs_vort[x] + abs_vort[x - st]) * VHeff) - ((abs_vort[x] - abs_vort[x - st]) * fabs(VHeff)));
+          ca = (QVHeff / (h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3)))) * IdxCu[x];
+        } else
+          ca = 0.5 * (abs_vort[x] + abs_vort[x - st]) * ((vhk[x] + vhk[x + 1 - st]) + (vhk[x - st] + vhk[x + 1])) /
+               (h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3))) * IdxCu[x];
+      }
+      if (AL_like) ca = ca + ((ep_u[x] * uhk[x - 1]) - (ep_u[x + 1] * uhk[x + 1])) * IdxCu[x];   /* :716-721 */
       if (bound_Coriolis) {
         double fv1 = abs_vort[x] * vk[x + 1], fv2 = abs_vort[x] * vk[x];
         double fv3 = abs_vort[x - st] * vk[x + 1 - st], fv4 = abs_vort[x - st] * vk[x - st];
@@ -190,8 +251,26 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
         ca = -0.25 * ((q[x - 1] * (uhk[x - 1] + uhk[x - 1 + st])) + (q[x] * (uhk[x] + uhk[x + st]))) * IdyCv[x];
       else if (CS->Coriolis_Scheme == MOM6X_SADOURNY75_ENSTRO)
         ca = -0.125 * (IdyCv[x] * (q[x - 1] + q[x])) * ((uhk[x - 1] + uhk[x - 1 + st]) + (uhk[x] + uhk[x + st]));
-      else
+      else if (AH_like)
         ca = -(((a[x - 1] * uhk[x - 1]) + (c[x + st] * uhk[x + st])) + ((b[x] * uhk[x]) + (dd[x - 1 + st] * uhk[x - 1 + st]))) * IdyCv[x];
+      else {   /* ROBUST_ENSTRO :808-838 */
+        double Heff1 = fabs(uhk[x] * IdyCu[x]) / (eps_vel + fabs(uk[x]));
+        Heff1 = orc_max(Heff1, orc_min(hk[x], hk[x + 1])); Heff1 = orc_min(Heff1, orc_max(hk[x], hk[x + 1]));
+        double Heff2 = fabs(uhk[x - 1] * IdyCu[x - 1]) / (eps_vel + fabs(uk[x - 1]));
+        Heff2 = orc_max(Heff2, orc_min(hk[x - 1], hk[x])); Heff2 = orc_min(Heff2, orc_max(hk[x - 1], hk[x]));
+        double Heff3 = fabs(uhk[x + st] * IdyCu[x + st]) / (eps_vel + fabs(uk[x + st]));
+        Heff3 = orc_max(Heff3, orc_min(hk[x + st], hk[x + 1 + st])); Heff3 = orc_min(Heff3, orc_max(hk[x + st], hk[x + 1 + st]));
+        double Heff4 = fabs(uhk[x - 1 + st] * IdyCu[x - 1 + st]) / (eps_vel + fabs(uk[x - 1 + st]));
+        Heff4 = orc_max(Heff4, orc_min(hk[x - 1 + st], hk[x + st])); Heff4 = orc_min(Heff4, orc_max(hk[x - 1 + st], hk[x + st]));
+        if (CS->PV_Adv_Scheme == MOM6X_PV_ADV_UPWIND1) {
+          double UHeff = ((uhk[x] + uhk[x - 1 + st]) + (uhk[x - 1] + uhk[x + st]));
+          double QUHeff = 0.5 * (((abs_vort[x] + abs_vort[x - 1]) * UHeff) - ((abs_vort[x] - abs_vort[x - 1]) * fabs(UHeff)));
+          ca = -(QUHeff / (h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3))) * IdyCv[x]);
+        } else
+          ca = -(0.5 * (abs_vort[x] + abs_vort[x - 1]) * ((uhk[x] + uhk[x - 1 + st]) + (uhk[x - 1] + uhk[x + st])) /
+                 (h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3))) * IdyCv[x]);
+      }
+      if (AL_like) ca = ca + ((ep_v[x] * vhk[x - st]) - (ep_v[x + st] * vhk[x + st])) * IdyCv[x];   /* :840-845 */
       if (bound_Coriolis) {
         double fu1 = -abs_vort[x] * uk[x + st], fu2 = -abs_vort[x] * uk[x];
         double fu3 = -abs_vort[x - 1] * uk[x - 1 + st], fu4 = -abs_vort[x - 1] * uk[x - 1];
@@ -201,7 +280,7 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
       CAvk[x] = ca - KEy[x];
     }
   }
-  double *all[] = { dvdx, dudy, hArea_u, hArea_v, rel_vort, abs_vort, q, a, b, c, dd, KE, KEx, KEy, uh_min, uh_max, vh_min, vh_max };
+  double *all[] = { dvdx, dudy, hArea_u, hArea_v, rel_vort, abs_vort, q, a, b, c, dd, KE, KEx, KEy, uh_min, uh_max, vh_min, vh_max, Ih_qa, ep_u, ep_v };
   for (size_t m = 0; m < sizeof(all) / sizeof(all[0]); m++) free(all[m]);
   }   /* omp parallel */
   free(Area_h); free(Area_q);

@@ -165,3 +165,12 @@ def use_threads_transport(lib, on=True):
     t.mom6x_threads_transport.restype = C.c_void_p
     abi.check(lib, lib.mom6x_comm_set_transport(C.c_void_p(t.mom6x_threads_transport())))
     use_threads_transport._keep = t
+
+
+def roughen(h, seed=17):
+    """Thicknesses with sharp cell-to-cell contrasts (factors 1e-6 ... 5 drawn per cell): what it takes for the ratios of
+    neighbouring Ih_q to pass every break point of ARAKAWA_LAMB_BLEND's weights (MOM_CoriolisAdv.F90:550-573) and for the
+    clamps of ROBUST_ENSTRO's Heff (:692-703) to bind."""
+    rng = np.random.default_rng(seed)
+    f = rng.choice([1.0, 1.0, 1.0, 0.5, 0.2, 0.05, 1e-2, 1e-3, 1e-6, 2.0, 5.0], size=h.shape)
+    return np.ascontiguousarray(h * f)

@@ -29,16 +29,28 @@ def visc_coefs(d, M, seed=3):
 @pytest.mark.parametrize("mods", [dict(), dict(bound_Coriolis=1), dict(Coriolis_Scheme=abi.ARAKAWA_HSU90, KE_Scheme=abi.KE_GUDONOV),
                                   dict(Coriolis_Scheme=abi.SADOURNY75_ENSTRO, KE_Scheme=abi.KE_SIMPLE_GUDONOV, no_slip=1, bound_Coriolis=1),
                                   dict(Coriolis_En_Dis=1), dict(Coriolis_En_Dis=1, bound_Coriolis=1, KE_Scheme=abi.KE_GUDONOV),
-                                  dict(Coriolis_En_Dis=1, Coriolis_Scheme=abi.ARAKAWA_HSU90)])
+                                  dict(Coriolis_En_Dis=1, Coriolis_Scheme=abi.ARAKAWA_HSU90),
+                                  dict(Coriolis_Scheme=abi.ARAKAWA_LAMB81),
+                                  dict(Coriolis_Scheme=abi.ARAKAWA_LAMB81, bound_Coriolis=1, KE_Scheme=abi.KE_SIMPLE_GUDONOV, no_slip=1),
+                                  dict(Coriolis_Scheme=abi.AL_BLEND, rough=1),
+                                  dict(Coriolis_Scheme=abi.AL_BLEND, F_eff_max_blend=3.0, wt_lin_blend=0.5, bound_Coriolis=1, rough=1),
+                                  dict(Coriolis_Scheme=abi.AL_BLEND, F_eff_max_blend=2.0, wt_lin_blend=0.0),
+                                  dict(Coriolis_Scheme=abi.ROBUST_ENSTRO, rough=1),
+                                  dict(Coriolis_Scheme=abi.ROBUST_ENSTRO, PV_Adv_Scheme=abi.PV_ADV_UPWIND1, bound_Coriolis=1,
+                                       Coriolis_En_Dis=1, rough=1)],
+                         ids=lambda m: "-".join(f"{k}={v}" for k, v in m.items()) or "default")
 def test_CorAdCalc(orc, cfg, mods):
     import torch
     from mom6_amd.dycore import Dycore
     gg, d, M = getattr(H, cfg)()
     GV = abi.vgrid_default()
     CS = abi.coriolis_params_default()
+    mods = dict(mods); rough = mods.pop("rough", 0)
     for k, v in mods.items():
         setattr(CS, k, v)
     h, u, v = synth.make_state(d, M, thin_frac=0.05)
+    if rough:    # sharp thickness contrasts: every regime of the blend's weights, ROBUST_ENSTRO's Heff clamps binding
+        h = H.roughen(h)
     uh = u * 1.0e5 * (1 + 0.1 * synth.smooth_field(d, 7, nk=d.nk)); vh = v * 1.0e5
     if mods.get("Coriolis_En_Dis"):
         # CORIOLIS_EN_DIS (tc4) compares the continuity solver's transport with the centred one: give it ratios from

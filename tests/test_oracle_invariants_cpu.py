@@ -161,6 +161,95 @@ def test_rotate_continuity_and_CorAdCalc(orc, first_direction, sum_order):
     H.assert_bitwise(btr["h_u"], T.v_to_u(bt["h_v"], 1.0), "rotate:BT_cont%h_v", H.interior(dr, "u"))
 
 
+SCHEMES = {
+    "AH90": dict(Coriolis_Scheme=abi.ARAKAWA_HSU90),
+    "AL81": dict(Coriolis_Scheme=abi.ARAKAWA_LAMB81),
+    "AL81_bound": dict(Coriolis_Scheme=abi.ARAKAWA_LAMB81, bound_Coriolis=1),
+    "AL_BLEND": dict(Coriolis_Scheme=abi.AL_BLEND),
+    "AL_BLEND_3_0.5": dict(Coriolis_Scheme=abi.AL_BLEND, F_eff_max_blend=3.0, wt_lin_blend=0.5),
+    "ROBUST": dict(Coriolis_Scheme=abi.ROBUST_ENSTRO),
+    "ROBUST_upwind": dict(Coriolis_Scheme=abi.ROBUST_ENSTRO, PV_Adv_Scheme=abi.PV_ADV_UPWIND1),
+}
+
+
+def _coriolis_case(thin_frac=0.1):
+    d, M, h, u, v = _state(H.benchmark_small(), thin_frac=thin_frac)
+    h = H.roughen(h)
+    uh = np.ascontiguousarray(u * 1.0e5 * (1 + 0.1 * synth.smooth_field(d, 7, nk=d.nk)) * M[G["mask2dCu"]])
+    vh = np.ascontiguousarray(v * 1.0e5 * (1 + 0.1 * synth.smooth_field(d, 8, nk=d.nk)) * M[G["mask2dCv"]])
+    return d, M, h, u, v, uh, vh
+
+
+def _blend_weight_census(d, M, h, F_eff_max=4.0, wt_lin=0.125):
+    """Which of the seven regimes of ARAKAWA_LAMB_BLEND's two weights (:559-573) the cells of a state fall in."""
+    A = (M[G["mask2dT"]] * M[G["areaT"]])[None]
+    Ah = A * h
+    r = lambda a, di, dj: np.roll(np.roll(a, -di, axis=-1), -dj, axis=-2)
+    hAu = 0.5 * (Ah + r(Ah, 1, 0)); hAv = 0.5 * (Ah + r(Ah, 0, 1))
+    Aq = (A + r(A, 1, 1)) + (r(A, 1, 0) + r(A, 0, 1))
+    Ihq = Aq / ((hAu + r(hAu, 0, 1)) + (hAv + r(hAv, 1, 0)) + 1e-40)
+    c = [Ihq, r(Ihq, -1, 0), r(Ihq, 0, -1), r(Ihq, -1, -1)]
+    sl = (Ellipsis,) + tuple(H.interior(d, "h"))
+    mn = np.minimum.reduce(c)[sl]; mx = np.maximum.reduce(c)[sl]
+    ok = (mn > 0) & (M[G["mask2dT"]][tuple(H.interior(d, "h"))] > 0)[None]
+    rat = (mx[ok] / mn[ok]) - 1.0
+    Fe = F_eff_max - 2.0; rl = 1.5 * Fe / wt_lin
+    out = set()
+    for n, m in enumerate([rat <= Fe, (rat > Fe) & (rat < 1.5 * Fe), rat >= 1.5 * Fe, rat <= 1.5 * Fe, (rat > 1.5 * Fe) & (rat <= rl),
+                           (rat > rl) & (rat < 2 * rl), rat >= 2 * rl]):
+        if m.any():
+            out.add(n)
+    return out
+
+
+def _corad(orc, d, M, mods, u, v, h, uh, vh):
+    CS = abi.coriolis_params_default()
+    for k, val in mods.items():
+        setattr(CS, k, val)
+    CAu, CAv = np.zeros_like(h), np.zeros_like(h)
+    orc.CorAdCalc(d, M, abi.vgrid_default(), CS, u, v, h, uh, vh, CAu, CAv)
+    return CAu, CAv
+
+
+@pytest.mark.parametrize("name", sorted(SCHEMES))
+def test_rotate_CorAdCalc_every_scheme(orc, name):
+    """The Coriolis schemes beyond the default (ARAKAWA_HSU90, ARAKAWA_LAMB81, ARAKAWA_LAMB_BLEND, ROBUST_ENSTRO with both
+    PV_ADV_SCHEMEs; MOM_CoriolisAdv.F90:523-588, :683-721, :796-845) on a grid and its quarter turn: the u and v halves of
+    each scheme are each other's image (the Arakawa weights a, b, c, d and ep_u, ep_v permute), so CAu / CAv of the turned
+    run, turned back, equal the original to round-off -- the pairs of products are not always added in the image's order."""
+    d, M, h, u, v, uh, vh = _coriolis_case()
+    T = Turn(d); dr = T.dr; Mr = T.metrics(M)
+    CAu, CAv = _corad(orc, d, M, SCHEMES[name], u, v, h, uh, vh)
+    ru, rv = _corad(orc, dr, Mr, SCHEMES[name], T.v_to_u(v), T.u_to_v(u), T.h(h), T.v_to_u(vh), T.u_to_v(uh))
+    ub, vb, _ = _turn_back(T, ru, rv, T.h(h))
+    su, sv = H.interior(d, "u"), H.interior(d, "v")
+    scale = max(np.abs(CAu).max(), np.abs(CAv).max())
+    assert scale > 0
+    assert np.abs(ub[(Ellipsis,) + su] - CAu[(Ellipsis,) + su]).max() <= 4e-15 * scale
+    assert np.abs(vb[(Ellipsis,) + sv] - CAv[(Ellipsis,) + sv]).max() <= 4e-15 * scale
+
+
+def test_arakawa_lamb_blend_limits(orc):
+    """ARAKAWA_LAMB_BLEND (:543-588): with CORIOLIS_BLEND_F_EFF_MAX <= 2 the weights are Sadourny's energy scheme everywhere
+    (:547-548), with a huge one they are Arakawa & Lamb's wherever the neighbouring Ih_q are within that factor; on a resting
+    ocean of uniform thickness over a flat bottom q is uniform along x and every scheme gives the Sadourny acceleration."""
+    d, M, h, u, v, uh, vh = _coriolis_case()
+    su, sv = H.interior(d, "u"), H.interior(d, "v")
+
+    def close(a, b, tol):
+        for x, y, sl in ((a[0], b[0], su), (a[1], b[1], sv)):
+            assert np.abs(x[(Ellipsis,) + sl] - y[(Ellipsis,) + sl]).max() <= tol * np.abs(y).max()
+    sad = _corad(orc, d, M, dict(), u, v, h, uh, vh)
+    close(_corad(orc, d, M, dict(Coriolis_Scheme=abi.AL_BLEND, F_eff_max_blend=2.0), u, v, h, uh, vh), sad, 1e-14)
+    al = _corad(orc, d, M, dict(Coriolis_Scheme=abi.ARAKAWA_LAMB81), u, v, h, uh, vh)
+    close(_corad(orc, d, M, dict(Coriolis_Scheme=abi.AL_BLEND, F_eff_max_blend=1.0e30), u, v, h, uh, vh), al, 1e-14)
+    # the schemes differ on this state (the test above is not vacuous)
+    assert np.abs(al[0] - sad[0]).max() > 1e-6 * np.abs(sad[0]).max()
+    blend = _corad(orc, d, M, dict(Coriolis_Scheme=abi.AL_BLEND), u, v, h, uh, vh)
+    assert _blend_weight_census(d, M, h) == set(range(7))
+    assert np.abs(blend[0] - sad[0]).max() > 1e-6 * np.abs(sad[0]).max() and np.abs(blend[0] - al[0]).max() > 1e-6 * np.abs(sad[0]).max()
+
+
 def _rk2_run(orc, d, M, first_direction, u, v, h, taux, tauy, coefs, nsteps=2, dt=900.0, bt_mod=None, sum_order=None, vv=None, hv=None):
     GV = abi.vgrid_default(); Rlay, gp = abi.layer_densities(d.nk)
     bt = abi.barotropic_params_default(30.0); bt.strong_drag = 1     # (no libm pow on the path: everything bit-comparable)

@@ -240,6 +240,16 @@ def test_rk2_tc4_like_switches(orc):
         eos_form=abi.LINEAR, dev_vv=dict(Kvml_invZ2=0.01), hv=P, Hmix_stress=20.0)
 
 
+@pytest.mark.parametrize("cor_mod", [dict(Coriolis_Scheme=abi.ARAKAWA_LAMB81), dict(Coriolis_Scheme=abi.AL_BLEND, F_eff_max_blend=2.5),
+                                     dict(Coriolis_Scheme=abi.ROBUST_ENSTRO, PV_Adv_Scheme=abi.PV_ADV_UPWIND1)],
+                         ids=["ARAKAWA_LAMB81", "ARAKAWA_LAMB_BLEND", "ROBUST_ENSTRO"])
+def test_rk2_with_the_other_coriolis_schemes(orc, cor_mod):
+    """Three steps of the whole RK2 step with CORIOLIS_SCHEME = ARAKAWA_LAMB81 / ARAKAWA_LAMB_BLEND / ROBUST_ENSTRO
+    (MOM_CoriolisAdv.F90:534-588, :687-721): these read uh / vh one face beyond the faces the default scheme reads, i.e. the
+    halo the pass_av_uvh group (RK2.F90:804) fills."""
+    run(orc, H.island_basin(), nsteps=3, bt_mod=dict(strong_drag=1), cor_mod=cor_mod)
+
+
 def test_btstep_warns_when_eta_drops_below_the_bottom_and_flags_nan(orc):
     """The two run-time error paths of the device: (1) btstep's "eta has dropped below bathyT" WARNING (MOM_barotropic.F90:2738-2745):
     a sea surface far below the bottom of a shallow basin is counted on the device, sub-step by sub-step, and the first
