@@ -157,6 +157,7 @@ module mom6x_c_api
     integer(c_int) :: MassWghtInterp, use_SSH_in_Z0p
     integer(c_int) :: Recon_Scheme, boundary_extrap, MassWghtInterpVanOnly   !< ALE: PLM reconstruction of T, S for the pressure force
     real(c_double) :: h_nonvanished
+    integer(c_int) :: EOS_quadrature       !< EOS_QUADRATURE: int_density_dz_generic_pcm instead of the analytic integrals
   end type mom6x_eos_params
 
   type, bind(C) :: mom6x_rk2_params        !< MOM_dyn_split_RK2_CS (MOM_dynamics_split_RK2.F90:85-273)

@@ -133,7 +133,7 @@ subroutine PressureForce_read_eos(param_file, GV, US, eos, have_eos)
   real :: rho_ref, Tref, Sref, pref, h_nv
   eos%form = 0 ; eos%Rho_T0_S0 = 0.0 ; eos%dRho_dT = 0.0 ; eos%dRho_dS = 0.0 ; eos%dRho_dp = 0.0
   eos%MassWghtInterp = 0 ; eos%use_SSH_in_Z0p = 0 ; eos%Recon_Scheme = 0 ; eos%boundary_extrap = 1
-  eos%MassWghtInterpVanOnly = 0 ; eos%h_nonvanished = 0.0
+  eos%MassWghtInterpVanOnly = 0 ; eos%h_nonvanished = 0.0 ; eos%EOS_quadrature = 0
   call get_param(param_file, "MOM", "ENABLE_THERMODYNAMICS", have_eos, default=.true., do_not_log=.true.)
   if (.not.have_eos) return
   call get_param(param_file, mdl, "EQN_OF_STATE", tmpstr, default="WRIGHT", do_not_log=.true.)
@@ -143,6 +143,8 @@ subroutine PressureForce_read_eos(param_file, GV, US, eos, have_eos)
     case default ; call MOM_error(FATAL, "PressureForce_init: EQN_OF_STATE "//trim(tmpstr)//" is not carried by the MI355X path "//&
                                   "(LINEAR and WRIGHT are).")
   end select
+  call get_param(param_file, mdl, "EOS_QUADRATURE", flag, default=.false., do_not_log=.true.)   ! MOM_EOS.F90:1654
+  eos%EOS_quadrature = merge(1_c_int, 0_c_int, flag)
   if (eos%form == 1) then   ! RHO_T0_S0 from the reference state when it is not given (MOM_EOS.F90:1598-1636)
     call get_param(param_file, mdl, "RHO_REF_LINEAR_EOS", rho_ref, units="kg m-3", default=1000.0, do_not_log=.true.)
     call get_param(param_file, mdl, "T_REF_LINEAR_EOS", Tref, units="degC", default=0.0, do_not_log=.true.)

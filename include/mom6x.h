@@ -246,7 +246,7 @@ typedef struct mom6x_hor_visc_params {
  * PressureForce_FV_CS that only matter with an equation of state.  Analytic density integrals
  * (analytic_int_density_dz, MOM_EOS.F90:1384) exist for EOS_LINEAR and the WRIGHT family; LINEAR and
  * WRIGHT (the default, MOM_EOS_Wright.F90) are implemented, WRIGHT_FULL / WRIGHT_REDUCED differ in
- * constants and parenthesisation only and are rejected for now, as is EOS_QUADRATURE.          */
+ * constants and parenthesisation only and are rejected for now.                                */
 enum mom6x_eos_form { MOM6X_EOS_LINEAR = 1, MOM6X_EOS_WRIGHT = 2 };
 typedef struct mom6x_eos_params {
   int    form;            /* EQN_OF_STATE                                                       */
@@ -259,10 +259,13 @@ typedef struct mom6x_eos_params {
   /* With ALE (USE_REGRIDDING): RECONSTRUCT_FOR_PRESSURE + PRESSURE_RECONSTRUCTION_SCHEME (PressureForce_FV_init :2172-2184)  */
   int    Recon_Scheme;    /* 0: layer-mean T, S (analytic integrals); 1: PLM edge values (TS_PLM_edge_values, MOM_ALE.F90:1495)
                            *    and the 5-point quadrature of int_density_dz_generic_plm (MOM_density_integrals.F90:418);
-                           *    2 (PPM): not carried                                                */
+                           *    2: PPM edge values (TS_PPM_edge_values, MOM_ALE.F90:1581: edge_values_implicit_h4 + PPM_reconstruction)
+                           *    and int_density_dz_generic_ppm (:874); needs NK >= 4                    */
   int    boundary_extrap; /* BOUNDARY_EXTRAPOLATION_PRESSURE (T)                                   */
   int    MassWghtInterpVanOnly; /* MASS_WEIGHT_IN_PGF_VANISHED_ONLY (F)                            */
   double h_nonvanished;   /* RESET_INTXPA_H_NONVANISHED (1e-6 m) [H]: the thickness below which a side counts as vanished */
+  int    EOS_quadrature;  /* EOS_QUADRATURE (F, MOM_EOS.F90:1654): with Recon_Scheme = 0 the layer integrals come from the 5-point
+                           * quadratures of int_density_dz_generic_pcm (MOM_density_integrals.F90:108) instead of the analytic forms */
 } mom6x_eos_params;
 
 /* MOM_dyn_split_RK2_CS parameters (src/core/MOM_dynamics_split_RK2.F90:85-273, read in
@@ -446,6 +449,9 @@ int mom6x_PressureForce(mom6x_ctx *ctx, const double *h, double *PFu, double *PF
  * tracer Q at the top and the bottom of every layer (TS_PLM_edge_values :1495 calls it for S and T); boundary cells PCM unless
  * bdry_extrap.  Answer dates >= 20190101 (h_neglect = GV%H_subroundoff).                                                   */
 int mom6x_ALE_PLM_edge_values(mom6x_ctx *ctx, const double *h, const double *Q, int bdry_extrap, double *Q_t, double *Q_b);
+/* One field of TS_PPM_edge_values (MOM_ALE.F90:1581): edge_values_implicit_h4 + PPM_reconstruction (+ PPM_boundary_extrapolation),
+ * the edge values PRESSURE_RECONSTRUCTION_SCHEME = 2 hands to int_density_dz_generic_ppm.  NK >= 4. */
+int mom6x_ALE_PPM_edge_values(mom6x_ctx *ctx, const double *h, const double *Q, int bdry_extrap, double *Q_t, double *Q_b);
 int mom6x_PressureForce_set_tv(mom6x_ctx *ctx, const double *T, const double *S, const mom6x_eos_params *eos);
 
 /* ------------------------------------------------------------------------- */

@@ -316,7 +316,8 @@ class EOSParams(C.Structure):
     """mom6x_eos_params: tv%eqn_of_state + the EOS-only switches of PressureForce_FV_CS."""
     _fields_ = [("form", C.c_int), ("Rho_T0_S0", C.c_double), ("dRho_dT", C.c_double), ("dRho_dS", C.c_double),
                 ("dRho_dp", C.c_double), ("MassWghtInterp", C.c_int), ("use_SSH_in_Z0p", C.c_int),
-                ("Recon_Scheme", C.c_int), ("boundary_extrap", C.c_int), ("MassWghtInterpVanOnly", C.c_int), ("h_nonvanished", C.c_double)]
+                ("Recon_Scheme", C.c_int), ("boundary_extrap", C.c_int), ("MassWghtInterpVanOnly", C.c_int), ("h_nonvanished", C.c_double),
+                ("EOS_quadrature", C.c_int)]
 
 
 def eos_params_default(form=WRIGHT):
@@ -325,7 +326,7 @@ def eos_params_default(form=WRIGHT):
     p.form = form
     p.Rho_T0_S0 = 1000.0; p.dRho_dT = -0.2; p.dRho_dS = 0.8; p.dRho_dp = 0.0
     p.MassWghtInterp = 0; p.use_SSH_in_Z0p = 0
-    p.Recon_Scheme = 0; p.boundary_extrap = 1; p.MassWghtInterpVanOnly = 0; p.h_nonvanished = 1.0e-6   # (Recon_Scheme: 1 with USE_REGRIDDING)
+    p.Recon_Scheme = 0; p.boundary_extrap = 1; p.MassWghtInterpVanOnly = 0; p.h_nonvanished = 1.0e-6; p.EOS_quadrature = 0   # (Recon_Scheme: 1 with USE_REGRIDDING)
     return p
 
 

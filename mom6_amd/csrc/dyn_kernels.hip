@@ -876,18 +876,25 @@ __device__ __forceinline__ double density_anomaly(const EosDev &E, double T, dou
 }
 
 // section 1 of int_density_dz_generic_plm (MOM_density_integrals.F90:587-637): dpa and intz_dpa of one cell by Boole's rule
-template <int FORM>
+// MODE 1: linear T, S between the edge values (int_density_dz_generic_plm); 2: parabolic through the edge values and the mean
+// (int_density_dz_generic_ppm :1047-1073); 3: the layer mean (int_density_dz_generic_pcm :243-262)
+template <int FORM, int MODE>
 __device__ __forceinline__ void cell_int_plm(const EosDev &E, double rho_ref, double G_e, double GxRho, double Tt, double Tb,
-                                             double St, double Sb, double zt, double zb, double z0, double &dpa, double &intz) {
+                                             double St, double Sb, double zt, double zb, double z0, double &dpa, double &intz,
+                                             double Tm = 0., double Sm = 0.) {
   const double C1_90 = 1.0 / 90.0;
   const double dz = zt - zb;
   double r5[6];
+  double s6 = 0., t6 = 0.;
+  if (MODE == 2) { s6 = 3.0 * (2.0 * Sm - (St + Sb)); t6 = 3.0 * (2.0 * Tm - (Tt + Tb)); }
 #pragma unroll
   for (int n = 1; n <= 5; n++) {
     const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
     const double p5 = -GxRho * ((zt - z0) - 0.25 * (double)(n - 1) * dz);
-    const double S5 = wt_t * St + wt_b * Sb;
-    const double T5 = wt_t * Tt + wt_b * Tb;
+    double S5, T5;
+    if (MODE == 2) { S5 = wt_t * St + wt_b * (Sb + s6 * wt_t); T5 = wt_t * Tt + wt_b * (Tb + t6 * wt_t); }
+    else if (MODE == 3) { S5 = Sm; T5 = Tm; }
+    else { S5 = wt_t * St + wt_b * Sb; T5 = wt_t * Tt + wt_b * Tb; }
     r5[n] = density_anomaly<FORM>(E, T5, S5, p5, rho_ref);
   }
   const double rho_anom = C1_90 * (7.0 * (r5[1] + r5[5]) + 32.0 * (r5[2] + r5[4]) + 12.0 * r5[3]);
@@ -947,10 +954,103 @@ __device__ __forceinline__ double face_int_plm(const EosDev &E, double rho_ref, 
   return C1_90 * (7.0 * (intz[1] + intz[5]) + 32.0 * (intz[2] + intz[4]) + 12.0 * intz[3]);
 }
 
+// sections 2 / 3 of int_density_dz_generic_ppm (:1075-1183 / :1186-1308): the face between columns L and R, T and S parabolic in
+// the vertical through the (thickness-weighted) top, mean and bottom values
+template <int FORM>
+__device__ __forceinline__ double face_int_ppm(const EosDev &E, double rho_ref, double G_e, double GxRho, double dz_subroundoff,
+                                               double TtL, double TbL, double TmL, double StL, double SbL, double SmL, double TtR,
+                                               double TbR, double TmR, double StR, double SbR, double SmR, double ztL, double zbL,
+                                               double ztR, double zbR, double z0L, double z0R, double bathyL, double bathyR,
+                                               double sshL, double sshR, double dpaL, double dpaR) {
+  const double C1_90 = 1.0 / 90.0;
+  const double mwT = E.do_mw ? 1. : 0., topT = E.top_mw ? 1. : 0., nvT = E.van_only ? 0. : 1.;
+  double hWght = mwT * dmax(dmax(0., -bathyL - ztR), -bathyR - ztL);
+  const double hWghtTop = topT * dmax(dmax(0., zbR - sshL), zbL - sshR);
+  hWght = dmax(hWght, hWghtTop);
+  if (((ztL - zbL) > E.dz_nv) && ((ztR - zbR) > E.dz_nv)) hWght = nvT * hWght;
+  double Ttl = TtL, Tbl = TbL, Tml = TmL, Ttr = TtR, Tbr = TbR, Tmr = TmR;
+  double Stl = StL, Sbl = SbL, Sml = SmL, Str = StR, Sbr = SbR, Smr = SmR;
+  if (hWght > 0.) {
+    const double hL = (ztL - zbL) + dz_subroundoff, hR = (ztR - zbR) + dz_subroundoff;
+    const double q = (hL - hR) / (hL + hR);
+    hWght = hWght * (q * q);
+    const double iDenom = 1. / (hWght * (hR + hL) + hL * hR);
+    const double wR = (hWght * hR), wLL = (hWght * hL + hR * hL), wL = (hWght * hL), wRR = (hWght * hR + hR * hL);
+    Ttl = (wR * TtR + wLL * TtL) * iDenom; Tbl = (wR * TbR + wLL * TbL) * iDenom; Tml = (wR * TmR + wLL * TmL) * iDenom;
+    Ttr = (wL * TtL + wRR * TtR) * iDenom; Tbr = (wL * TbL + wRR * TbR) * iDenom; Tmr = (wL * TmL + wRR * TmR) * iDenom;
+    Stl = (wR * StR + wLL * StL) * iDenom; Sbl = (wR * SbR + wLL * SbL) * iDenom; Sml = (wR * SmR + wLL * SmL) * iDenom;
+    Str = (wL * StL + wRR * StR) * iDenom; Sbr = (wL * SbL + wRR * SbR) * iDenom; Smr = (wL * SmL + wRR * SmR) * iDenom;
+  }
+  double intz[6];
+  intz[1] = dpaL; intz[5] = dpaR;
+#pragma unroll
+  for (int m = 2; m <= 4; m++) {
+    const double w_left = 0.25 * (double)(5 - m), w_right = 1.0 - w_left;
+    const double T_top = (w_left * Ttl) + (w_right * Ttr), T_mn = (w_left * Tml) + (w_right * Tmr), T_bot = (w_left * Tbl) + (w_right * Tbr);
+    const double S_top = (w_left * Stl) + (w_right * Str), S_mn = (w_left * Sml) + (w_right * Smr), S_bot = (w_left * Sbl) + (w_right * Sbr);
+    const double dz_x = (w_left * (ztL - zbL)) + (w_right * (ztR - zbR));
+    double p15[6], r15[6];
+    p15[1] = -GxRho * ((w_left * (ztL - z0L)) + (w_right * (ztR - z0R)));
+#pragma unroll
+    for (int n = 2; n <= 5; n++) p15[n] = p15[n - 1] + GxRho * 0.25 * dz_x;
+    const double s6 = 3.0 * (2.0 * S_mn - (S_top + S_bot)), t6 = 3.0 * (2.0 * T_mn - (T_top + T_bot));
+#pragma unroll
+    for (int n = 1; n <= 5; n++) {
+      const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
+      const double S15 = wt_t * S_top + wt_b * (S_bot + s6 * wt_t);
+      const double T15 = wt_t * T_top + wt_b * (T_bot + t6 * wt_t);
+      r15[n] = density_anomaly<FORM>(E, T15, S15, p15[n], rho_ref);
+    }
+    intz[m] = (G_e * dz_x * (C1_90 * (7.0 * (r15[1] + r15[5]) + 32.0 * (r15[2] + r15[4]) + 12.0 * r15[3])));
+  }
+  return C1_90 * (7.0 * (intz[1] + intz[5]) + 32.0 * (intz[2] + intz[4]) + 12.0 * intz[3]);
+}
+
+// int_density_dz_generic_pcm (EOS_QUADRATURE), :265-339 / :342-414: layer-mean T, S carried across the face with the
+// (possibly thickness-weighted) weights hWt_LL ... hWt_RL
+template <int FORM>
+__device__ __forceinline__ double face_int_pcm(const EosDev &E, double rho_ref, double G_e, double GxRho, double dz_neglect, double TL,
+                                               double SL, double TR, double SR, double ztL, double zbL, double ztR, double zbR, double z0L,
+                                               double z0R, double bathyL, double bathyR, double sshL, double sshR, double dpaL,
+                                               double dpaR) {
+  const double C1_90 = 1.0 / 90.0;
+  const double nvT = E.van_only ? 0. : 1.;
+  double hWght = 0.0;
+  if (E.do_mw) hWght = dmax(dmax(0., -bathyL - ztR), -bathyR - ztL);
+  if (E.top_mw) hWght = dmax(dmax(hWght, zbR - sshL), zbL - sshR);
+  if (((ztL - zbL) > E.dz_nv) && ((ztR - zbR) > E.dz_nv)) hWght = nvT * hWght;
+  double hWt_LL = 1.0, hWt_LR = 0.0, hWt_RR = 1.0, hWt_RL = 0.0;
+  if (hWght > 0.) {
+    const double hL = (ztL - zbL) + dz_neglect, hR = (ztR - zbR) + dz_neglect;
+    const double q = (hL - hR) / (hL + hR);
+    hWght = hWght * (q * q);
+    const double iDenom = 1.0 / (hWght * (hR + hL) + hL * hR);
+    hWt_LL = (hWght * hL + hR * hL) * iDenom; hWt_LR = (hWght * hR) * iDenom;
+    hWt_RR = (hWght * hR + hR * hL) * iDenom; hWt_RL = (hWght * hL) * iDenom;
+  }
+  double intz[6];
+  intz[1] = dpaL; intz[5] = dpaR;
+#pragma unroll
+  for (int m = 2; m <= 4; m++) {
+    const double wt_L = 0.25 * (double)(5 - m), wt_R = 1.0 - wt_L;
+    const double wtT_L = (wt_L * hWt_LL) + (wt_R * hWt_RL), wtT_R = (wt_L * hWt_LR) + (wt_R * hWt_RR);
+    const double dz_x = (wt_L * (ztL - zbL)) + (wt_R * (ztR - zbR));
+    const double T15 = (wtT_L * TL) + (wtT_R * TR), S15 = (wtT_L * SL) + (wtT_R * SR);
+    double p15[6], r15[6];
+    p15[1] = -GxRho * ((wt_L * (ztL - z0L)) + (wt_R * (ztR - z0R)));
+#pragma unroll
+    for (int n = 2; n <= 5; n++) p15[n] = p15[n - 1] + GxRho * 0.25 * dz_x;
+#pragma unroll
+    for (int n = 1; n <= 5; n++) r15[n] = density_anomaly<FORM>(E, T15, S15, p15[n], rho_ref);
+    intz[m] = (G_e * dz_x * (C1_90 * (7.0 * (r15[1] + r15[5]) + 32.0 * (r15[2] + r15[4]) + 12.0 * r15[3])));
+  }
+  return C1_90 * (7.0 * (intz[1] + intz[5]) + 32.0 * (intz[2] + intz[4]) + 12.0 * intz[3]);
+}
+
 // One thread per (i,j) column, top-down like k_pgf_main; the integrals of the east and north neighbours are
 // recomputed by this thread (no 3-D dpa / intz_dpa / intx_dpa arrays).  PLM: the T, S edge values of TS_PLM_edge_values
 // (Tt, Tb, St, Sb) and the generic quadratures instead of the layer means and the analytic integrals.
-template <int FORM, bool PLM>
+template <int FORM, int MODE>   // MODE 0: analytic integrals; 1: PLM; 2: PPM; 3: layer means by quadrature (EOS_QUADRATURE)
 __global__ void __launch_bounds__(256)
 k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h, const double *__restrict__ e,
                const double *__restrict__ Tv, const double *__restrict__ Sv, const double *__restrict__ Tt,
@@ -990,9 +1090,9 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
     const double zb0 = e[cb];
     double dpa0, iz0;
     double Tt0 = 0., Tb0 = 0., St0 = 0., Sb0 = 0.;
-    if (PLM) {
-      Tt0 = Tt[c]; Tb0 = Tb[c]; St0 = St[c]; Sb0 = Sb[c];
-      cell_int_plm<FORM>(E, rho_ref, G_e, GxRho, Tt0, Tb0, St0, Sb0, zt0, zb0, z00, dpa0, iz0);
+    if (MODE != 0) {
+      if (MODE != 3) { Tt0 = Tt[c]; Tb0 = Tb[c]; St0 = St[c]; Sb0 = Sb[c]; }
+      cell_int_plm<FORM, MODE>(E, rho_ref, G_e, GxRho, Tt0, Tb0, St0, Sb0, zt0, zb0, z00, dpa0, iz0, T0, S0);
     } else {
       cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, zt0, zb0, z00, dpa0, iz0);
     }
@@ -1000,11 +1100,19 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
     if (do_u) {
       const double h1 = h[c + 1], T1 = Tv[c + 1], S1 = Sv[c + 1], zb1 = e[cb + 1];
       double dpa1, iz1, intx_dpa;
-      if (PLM) {
-        const double Tt1 = Tt[c + 1], Tb1 = Tb[c + 1], St1 = St[c + 1], Sb1 = Sb[c + 1];
-        cell_int_plm<FORM>(E, rho_ref, G_e, GxRho, Tt1, Tb1, St1, Sb1, zt1, zb1, z01, dpa1, iz1);
-        intx_dpa = face_int_plm<FORM>(E, rho_ref, G_e, GxRho, dz_neglect, Tt0, Tb0, St0, Sb0, Tt1, Tb1, St1, Sb1, zt0, zb0, zt1, zb1,
-                                      z00, z01, b0, b1, ssh0, ssh1, dpa0, dpa1);
+      if (MODE != 0) {
+        double Tt1 = 0., Tb1 = 0., St1 = 0., Sb1 = 0.;
+        if (MODE != 3) { Tt1 = Tt[c + 1]; Tb1 = Tb[c + 1]; St1 = St[c + 1]; Sb1 = Sb[c + 1]; }
+        cell_int_plm<FORM, MODE>(E, rho_ref, G_e, GxRho, Tt1, Tb1, St1, Sb1, zt1, zb1, z01, dpa1, iz1, T1, S1);
+        if (MODE == 1)
+          intx_dpa = face_int_plm<FORM>(E, rho_ref, G_e, GxRho, dz_neglect, Tt0, Tb0, St0, Sb0, Tt1, Tb1, St1, Sb1, zt0, zb0, zt1, zb1,
+                                        z00, z01, b0, b1, ssh0, ssh1, dpa0, dpa1);
+        else if (MODE == 2)
+          intx_dpa = face_int_ppm<FORM>(E, rho_ref, G_e, GxRho, dz_neglect, Tt0, Tb0, T0, St0, Sb0, S0, Tt1, Tb1, T1, St1, Sb1, S1, zt0, zb0,
+                                        zt1, zb1, z00, z01, b0, b1, ssh0, ssh1, dpa0, dpa1);
+        else
+          intx_dpa = face_int_pcm<FORM>(E, rho_ref, G_e, GxRho, dz_neglect, T0, S0, T1, S1, zt0, zb0, zt1, zb1, z00, z01, b0, b1, ssh0, ssh1,
+                                        dpa0, dpa1);
       } else {
         cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T1, S1, zt1, zb1, z01, dpa1, iz1);
         intx_dpa = face_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, T1, S1, zt0, zb0, zt1, zb1, z00, z01, b0, b1,
@@ -1020,11 +1128,19 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
     if (do_v) {
       const double h2 = h[c + st], T2 = Tv[c + st], S2 = Sv[c + st], zb2 = e[cb + st];
       double dpa2, iz2, inty_dpa;
-      if (PLM) {
-        const double Tt2 = Tt[c + st], Tb2 = Tb[c + st], St2 = St[c + st], Sb2 = Sb[c + st];
-        cell_int_plm<FORM>(E, rho_ref, G_e, GxRho, Tt2, Tb2, St2, Sb2, zt2, zb2, z02, dpa2, iz2);
-        inty_dpa = face_int_plm<FORM>(E, rho_ref, G_e, GxRho, dz_neglect, Tt0, Tb0, St0, Sb0, Tt2, Tb2, St2, Sb2, zt0, zb0, zt2, zb2,
-                                      z00, z02, b0, b2, ssh0, ssh2, dpa0, dpa2);
+      if (MODE != 0) {
+        double Tt2 = 0., Tb2 = 0., St2 = 0., Sb2 = 0.;
+        if (MODE != 3) { Tt2 = Tt[c + st]; Tb2 = Tb[c + st]; St2 = St[c + st]; Sb2 = Sb[c + st]; }
+        cell_int_plm<FORM, MODE>(E, rho_ref, G_e, GxRho, Tt2, Tb2, St2, Sb2, zt2, zb2, z02, dpa2, iz2, T2, S2);
+        if (MODE == 1)
+          inty_dpa = face_int_plm<FORM>(E, rho_ref, G_e, GxRho, dz_neglect, Tt0, Tb0, St0, Sb0, Tt2, Tb2, St2, Sb2, zt0, zb0, zt2, zb2,
+                                        z00, z02, b0, b2, ssh0, ssh2, dpa0, dpa2);
+        else if (MODE == 2)
+          inty_dpa = face_int_ppm<FORM>(E, rho_ref, G_e, GxRho, dz_neglect, Tt0, Tb0, T0, St0, Sb0, S0, Tt2, Tb2, T2, St2, Sb2, S2, zt0, zb0,
+                                        zt2, zb2, z00, z02, b0, b2, ssh0, ssh2, dpa0, dpa2);
+        else
+          inty_dpa = face_int_pcm<FORM>(E, rho_ref, G_e, GxRho, dz_neglect, T0, S0, T2, S2, zt0, zb0, zt2, zb2, z00, z02, b0, b2, ssh0, ssh2,
+                                        dpa0, dpa2);
       } else {
         cell_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T2, S2, zt2, zb2, z02, dpa2, iz2);
         inty_dpa = face_int<FORM>(E, rho_ref, G_e, GxRho, I_Rho, T0, S0, T2, S2, zt0, zb0, zt2, zb2, z00, z02, b0, b2,
@@ -1078,8 +1194,10 @@ extern "C" int mom6x_PressureForce_set_tv(mom6x_ctx *c, const double *T, const d
   REQUIRE(S && eos, MOM6X_EINVAL, "mom6x_PressureForce_set_tv: tv%T without tv%S or tv%eqn_of_state");
   REQUIRE(eos->form == MOM6X_EOS_LINEAR || eos->form == MOM6X_EOS_WRIGHT, MOM6X_EUNSUPPORTED,
           "No analytic integration option is available with this EOS!");
-  REQUIRE(eos->Recon_Scheme == 0 || eos->Recon_Scheme == 1, MOM6X_EUNSUPPORTED,
-          "PressureForce_FV: PRESSURE_RECONSTRUCTION_SCHEME = 2 (PPM) is not carried; use 1 (PLM) or 0");
+  REQUIRE(eos->Recon_Scheme >= 0 && eos->Recon_Scheme <= 2, MOM6X_EINVAL,
+          "PressureForce_FV_init: PRESSURE_RECONSTRUCTION_SCHEME must be 1 (PLM) or 2 (PPM), or 0 without RECONSTRUCT_FOR_PRESSURE");
+  REQUIRE(eos->Recon_Scheme != 2 || c->dims.nk >= 4, MOM6X_EUNSUPPORTED,
+          "PressureForce_FV: PRESSURE_RECONSTRUCTION_SCHEME = 2 (edge_values_implicit_h4) needs NK >= 4");
   c->tv_T = T; c->tv_S = S; c->eos = *eos;
   return MOM6X_OK;
 }
@@ -1117,19 +1235,35 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
     E.van_only = c->eos.MassWghtInterpVanOnly; E.dz_nv = GV.H_to_Z * c->eos.h_nonvanished;   // dz_nonvanished :1128
     const double rho0_alt = c->pgf.rho_ref_bug ? c->pgf.rho_ref : GV.Rho0;   // rho0_int_density = rho0_set_pbce
     const dim3 g = grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b);
-    const bool plm = (c->eos.Recon_Scheme == 1);
+    // 0: analytic_int_density_dz; 1: TS_PLM_edge_values + int_density_dz_generic_plm; 2: TS_PPM_edge_values + ..._generic_ppm;
+    // 3: EOS_QUADRATURE without a reconstruction: int_density_dz_generic_pcm (int_density_dz, MOM_density_integrals.F90:95-99)
+    const int mode = c->eos.Recon_Scheme ? c->eos.Recon_Scheme : (c->eos.EOS_quadrature ? 3 : 0);
     double *Tt = nullptr, *Tb = nullptr, *St = nullptr, *Sb = nullptr;
-    if (plm) {   // TS_PLM_edge_values (MOM_ALE.F90:1495): S first, then T
+    if (mode == 1 || mode == 2) {   // TS_PLM_edge_values (MOM_ALE.F90:1495) | TS_PPM_edge_values (:1581): S first, then T
       if ((rc = ctx_scratch(c, SCR_t0, d.nk, &Tt)) || (rc = ctx_scratch(c, SCR_t1, d.nk, &Tb)) ||
           (rc = ctx_scratch(c, SCR_t2, d.nk, &St)) || (rc = ctx_scratch(c, SCR_t3, d.nk, &Sb))) return rc;
-      if ((rc = mom6x_ALE_PLM_edge_values(c, h, c->tv_S, c->eos.boundary_extrap, St, Sb))) return rc;
-      if ((rc = mom6x_ALE_PLM_edge_values(c, h, c->tv_T, c->eos.boundary_extrap, Tt, Tb))) return rc;
+      if (mode == 1) {
+        if ((rc = mom6x_ALE_PLM_edge_values(c, h, c->tv_S, c->eos.boundary_extrap, St, Sb))) return rc;
+        if ((rc = mom6x_ALE_PLM_edge_values(c, h, c->tv_T, c->eos.boundary_extrap, Tt, Tb))) return rc;
+      } else {
+        if ((rc = mom6x_ALE_PPM_edge_values(c, h, c->tv_S, c->eos.boundary_extrap, St, Sb))) return rc;
+        if ((rc = mom6x_ALE_PPM_edge_values(c, h, c->tv_T, c->eos.boundary_extrap, Tt, Tb))) return rc;
+      }
     }
 #define PGF_EOS(F, P, NAME) KLAUNCH(c, NAME, (k_pgf_main_eos<F, P>), g, b, d, c->G, h, e, c->tv_T, c->tv_S, Tt, Tb, St, Sb, E, PFu, PFv,   \
                                     pbce, eta, GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, GV.Rho0, \
                                     rho0_alt, GV.H_subroundoff, GV.dZ_subroundoff)
-    if (E.form == MOM6X_EOS_LINEAR) { if (plm) PGF_EOS(MOM6X_EOS_LINEAR, true, "k_pgf_main_plm<linear>"); else PGF_EOS(MOM6X_EOS_LINEAR, false, "k_pgf_main_eos<linear>"); }
-    else                            { if (plm) PGF_EOS(MOM6X_EOS_WRIGHT, true, "k_pgf_main_plm<wright>"); else PGF_EOS(MOM6X_EOS_WRIGHT, false, "k_pgf_main_eos<wright>"); }
+    if (E.form == MOM6X_EOS_LINEAR) {
+      if (mode == 1) PGF_EOS(MOM6X_EOS_LINEAR, 1, "k_pgf_main_plm<linear>");
+      else if (mode == 2) PGF_EOS(MOM6X_EOS_LINEAR, 2, "k_pgf_main_ppm<linear>");
+      else if (mode == 3) PGF_EOS(MOM6X_EOS_LINEAR, 3, "k_pgf_main_pcm<linear>");
+      else PGF_EOS(MOM6X_EOS_LINEAR, 0, "k_pgf_main_eos<linear>");
+    } else {
+      if (mode == 1) PGF_EOS(MOM6X_EOS_WRIGHT, 1, "k_pgf_main_plm<wright>");
+      else if (mode == 2) PGF_EOS(MOM6X_EOS_WRIGHT, 2, "k_pgf_main_ppm<wright>");
+      else if (mode == 3) PGF_EOS(MOM6X_EOS_WRIGHT, 3, "k_pgf_main_pcm<wright>");
+      else PGF_EOS(MOM6X_EOS_WRIGHT, 0, "k_pgf_main_eos<wright>");
+    }
 #undef PGF_EOS
     HIPCHK(hipGetLastError());
     return MOM6X_OK;

@@ -611,7 +611,7 @@ k_remap_recon(Dm d, const double *__restrict__ mask, ReconArgs A, const double *
   const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i < i0 || i > i1 || j > j1) return;
   const size_t x = ix2(d, i, j);
-  if (!(mask[x] > 0.)) return;
+  if (mask && !(mask[x] > 0.)) return;
   View v; v.base = x; v.lev = (size_t)d.slab;
   reconstruct_column(A, h_old, f, v, E1, E2, C2, Ucopy, v);
 }
@@ -1251,6 +1251,27 @@ extern "C" int mom6x_ALE_PLM_edge_values(mom6x_ctx *c, const double *h, const do
   const dim3 b(64, 4, 1);
   KLAUNCH(c, "k_plm_edge_values", k_plm_edge_values, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, h, Q, bdry_extrap,
           c->GV.H_subroundoff, Q_t, Q_b);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+// One field of TS_PPM_edge_values, MOM_ALE.F90:1581-1663 (answer dates >= 20190101): edge_values_implicit_h4 + PPM_reconstruction
+// (+ PPM_boundary_extrapolation) of every column of (isc-1..iec+1, jsc-1..jec+1) -- the PPM_IH4 reconstruction of the remapping
+// kernels with h_neglect = h_neglect_edge = GV%H_subroundoff and no land mask; Q_t, Q_b = ppol_E(:,1), ppol_E(:,2).
+extern "C" int mom6x_ALE_PPM_edge_values(mom6x_ctx *c, const double *h, const double *Q, int bdry_extrap, double *Q_t, double *Q_b) {
+  REQUIRE(c && h && Q && Q_t && Q_b, MOM6X_EINVAL, "mom6x_ALE_PPM_edge_values: null argument");
+  REQUIRE(c->dims.nk >= 4, MOM6X_EUNSUPPORTED, "mom6x_ALE_PPM_edge_values: edge_values_implicit_h4 needs at least 4 layers");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  double *C2;
+  int rc;
+  if ((rc = ctx_scratch(c, SCR_KE, d.nk, &C2))) return rc;   // the tridiagonal solve's c1 column
+  ReconArgs R;
+  R.scheme = MOM6X_REMAP_PPM_IH4; R.boundary_extrapolation = bdry_extrap; R.h_neglect = c->GV.H_subroundoff;
+  R.h_neglect_edge = c->GV.H_subroundoff; R.n0 = d.nk;
+  const dim3 b(64, 4, 1);
+  KLAUNCH(c, "k_remap_recon", k_remap_recon, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, (const double *)nullptr, R, h, Q, Q_t, Q_b,
+          C2, (double *)nullptr, -1, d.ni, -1, d.nj);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }

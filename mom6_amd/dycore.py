@@ -215,6 +215,10 @@ class Dycore:
         """ALE_PLM_edge_values (MOM_ALE.F90:1520): top and bottom values of the PLM reconstruction of Q in every layer."""
         check(self.lib, self.lib.mom6x_ALE_PLM_edge_values(self.ctx, _ptr(h), _ptr(Q), C.c_int(int(bdry_extrap)), _ptr(Q_t), _ptr(Q_b)))
 
+    def ALE_PPM_edge_values(self, h, Q, bdry_extrap, Q_t, Q_b):
+        """One field of TS_PPM_edge_values (MOM_ALE.F90:1581): edge_values_implicit_h4 + PPM_reconstruction edge values."""
+        check(self.lib, self.lib.mom6x_ALE_PPM_edge_values(self.ctx, _ptr(h), _ptr(Q), C.c_int(int(bdry_extrap)), _ptr(Q_t), _ptr(Q_b)))
+
     def PressureForce_set_tv(self, T, S, eos):
         """tv%T, tv%S, tv%eqn_of_state of PressureForce's thermo_var_ptrs argument; T=None: layered path."""
         self._tv = (T, S, eos)

@@ -172,6 +172,11 @@ def ALE_PLM_edge_values(d, GV, h, Q, bdry_extrap, Q_t, Q_b):
     lib().orc_ALE_PLM_edge_values(C.byref(d), C.byref(GV), _p(h), _p(Q), C.c_int(int(bdry_extrap)), _p(Q_t), _p(Q_b))
 
 
+def ALE_PPM_edge_values(d, GV, h, Q, bdry_extrap, Q_t, Q_b):
+    """One field of TS_PPM_edge_values (MOM_ALE.F90:1581)."""
+    lib().orc_ALE_PPM_edge_values(C.byref(d), C.byref(GV), _p(h), _p(Q), C.c_int(int(bdry_extrap)), _p(Q_t), _p(Q_b))
+
+
 def eos_density_anomaly(eos, T, S, p, rho_ref):
     """calculate_density(T, S, p, rho, EOS, rho_ref=rho_ref) for one point."""
     f = lib().orc_eos_density_anomaly

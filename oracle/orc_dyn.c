@@ -466,6 +466,127 @@ void orc_ALE_PLM_edge_values(const mom6x_dims *d, const mom6x_vgrid *GV, const d
   }
 }
 
+void orc_edge_values_implicit_h4(int N, const double *h, const double *u, double *E1, double *E2, double h_neglect);
+void orc_PPM_reconstruction(int N, const double *h, const double *u, double *E1, double *E2, double *C1, double *C2, double *C3, double h_neglect);
+void orc_PPM_boundary_extrapolation(int N, const double *h, const double *u, double *E1, double *E2, double *C1, double *C2, double *C3, double h_neglect);
+
+/* One field of TS_PPM_edge_values, MOM_ALE.F90:1581-1663 (answer_date >= 20190101: h_neglect = h_neglect_edge = GV%H_subroundoff):
+ * edge_values_implicit_h4, PPM_reconstruction and, with bdry_extrap, PPM_boundary_extrapolation of every column of
+ * (isc-1..iec+1, jsc-1..jec+1); Q_t, Q_b = ppol_E(:,1), ppol_E(:,2).  GV%ke >= 4. */
+void orc_ALE_PPM_edge_values(const mom6x_dims *d, const mom6x_vgrid *GV, const double *h, const double *Q, int bdry_extrap,
+                             double *Q_t, double *Q_b) {
+  const int nz = d->nk;
+  const size_t slab = (size_t)d->slab;
+  const double h_neglect = GV->H_subroundoff, h_neglect_edge = GV->H_subroundoff;
+#pragma omp parallel
+  {
+  double *w = (double *)calloc((size_t)7 * (nz + 2), sizeof(double));
+  double *hT = w, *tmp = hT + nz + 2, *E1 = tmp + nz + 2, *E2 = E1 + nz + 2, *C1 = E2 + nz + 2, *C2 = C1 + nz + 2, *C3 = C2 + nz + 2;
+#pragma omp for schedule(static)
+  for (int j = -1; j <= d->nj; j++) for (int i = -1; i <= d->ni; i++) {
+    const size_t x = IX2(d, i, j);
+    for (int k = 1; k <= nz; k++) { hT[k] = h[x + (size_t)(k - 1) * slab]; tmp[k] = Q[x + (size_t)(k - 1) * slab]; E1[k] = 0.0; E2[k] = 0.0; }
+    orc_edge_values_implicit_h4(nz, hT, tmp, E1, E2, h_neglect_edge);
+    orc_PPM_reconstruction(nz, hT, tmp, E1, E2, C1, C2, C3, h_neglect);
+    if (bdry_extrap) orc_PPM_boundary_extrapolation(nz, hT, tmp, E1, E2, C1, C2, C3, h_neglect);
+    for (int k = 1; k <= nz; k++) { Q_t[x + (size_t)(k - 1) * slab] = E1[k]; Q_b[x + (size_t)(k - 1) * slab] = E2[k]; }
+  }
+  free(w);
+  }
+}
+
+/* One face of int_density_dz_generic_ppm: section 2 (x, MOM_density_integrals.F90:1075-1183) or 3 (y, :1186-1308): parabolic T, S
+ * in the vertical from the top, mean and bottom values of the two columns (*t*, *m*, *b*). */
+static double face_int_generic_ppm(const mom6x_eos_params *E, double rho_ref, double G_e, double GxRho, double mwT, double topT,
+                                   double nvT, double h_nv, double dz_subroundoff, double TtL, double TbL, double TmL, double StL,
+                                   double SbL, double SmL, double TtR, double TbR, double TmR, double StR, double SbR, double SmR,
+                                   double ztL, double zbL, double ztR, double zbR, double z0L, double z0R, double bathyL, double bathyR,
+                                   double sshL, double sshR, double dpaL, double dpaR) {
+  const double C1_90 = 1.0 / 90.0;
+  double hWght = mwT * orc_max(orc_max(0., -bathyL - ztR), -bathyR - ztL);
+  const double hWghtTop = topT * orc_max(orc_max(0., zbR - sshL), zbL - sshR);
+  hWght = orc_max(hWght, hWghtTop);
+  if (((ztL - zbL) > h_nv) && ((ztR - zbR) > h_nv)) hWght = nvT * hWght;
+  double Ttl, Tbl, Tml, Ttr, Tbr, Tmr, Stl, Sbl, Sml, Str, Sbr, Smr;
+  if (hWght > 0.) {
+    const double hL = (ztL - zbL) + dz_subroundoff, hR = (ztR - zbR) + dz_subroundoff;
+    const double q = (hL - hR) / (hL + hR);
+    hWght = hWght * (q * q);
+    const double iDenom = 1. / (hWght * (hR + hL) + hL * hR);
+    Ttl = ((hWght * hR) * TtR + (hWght * hL + hR * hL) * TtL) * iDenom;
+    Tbl = ((hWght * hR) * TbR + (hWght * hL + hR * hL) * TbL) * iDenom;
+    Tml = ((hWght * hR) * TmR + (hWght * hL + hR * hL) * TmL) * iDenom;
+    Ttr = ((hWght * hL) * TtL + (hWght * hR + hR * hL) * TtR) * iDenom;
+    Tbr = ((hWght * hL) * TbL + (hWght * hR + hR * hL) * TbR) * iDenom;
+    Tmr = ((hWght * hL) * TmL + (hWght * hR + hR * hL) * TmR) * iDenom;
+    Stl = ((hWght * hR) * StR + (hWght * hL + hR * hL) * StL) * iDenom;
+    Sbl = ((hWght * hR) * SbR + (hWght * hL + hR * hL) * SbL) * iDenom;
+    Sml = ((hWght * hR) * SmR + (hWght * hL + hR * hL) * SmL) * iDenom;
+    Str = ((hWght * hL) * StL + (hWght * hR + hR * hL) * StR) * iDenom;
+    Sbr = ((hWght * hL) * SbL + (hWght * hR + hR * hL) * SbR) * iDenom;
+    Smr = ((hWght * hL) * SmL + (hWght * hR + hR * hL) * SmR) * iDenom;
+  } else {
+    Ttl = TtL; Tbl = TbL; Ttr = TtR; Tbr = TbR; Tml = TmL; Tmr = TmR;
+    Stl = StL; Sbl = SbL; Str = StR; Sbr = SbR; Sml = SmL; Smr = SmR;
+  }
+  double intz[6];
+  intz[1] = dpaL; intz[5] = dpaR;
+  for (int m = 2; m <= 4; m++) {
+    const double w_left = 0.25 * (double)(5 - m), w_right = 1.0 - w_left;
+    const double T_top = (w_left * Ttl) + (w_right * Ttr), T_mn = (w_left * Tml) + (w_right * Tmr), T_bot = (w_left * Tbl) + (w_right * Tbr);
+    const double S_top = (w_left * Stl) + (w_right * Str), S_mn = (w_left * Sml) + (w_right * Smr), S_bot = (w_left * Sbl) + (w_right * Sbr);
+    const double dz_x = (w_left * (ztL - zbL)) + (w_right * (ztR - zbR));
+    double p15[6], r15[6];
+    p15[1] = -GxRho * ((w_left * (ztL - z0L)) + (w_right * (ztR - z0R)));
+    for (int n = 2; n <= 5; n++) p15[n] = p15[n - 1] + GxRho * 0.25 * dz_x;
+    const double s6 = 3.0 * (2.0 * S_mn - (S_top + S_bot)), t6 = 3.0 * (2.0 * T_mn - (T_top + T_bot));
+    for (int n = 1; n <= 5; n++) {
+      const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
+      const double S15 = wt_t * S_top + wt_b * (S_bot + s6 * wt_t);
+      const double T15 = wt_t * T_top + wt_b * (T_bot + t6 * wt_t);
+      r15[n] = eos_density_anomaly(E, T15, S15, p15[n], rho_ref);
+    }
+    intz[m] = (G_e * dz_x * (C1_90 * (7.0 * (r15[1] + r15[5]) + 32.0 * (r15[2] + r15[4]) + 12.0 * r15[3])));
+  }
+  return C1_90 * (7.0 * (intz[1] + intz[5]) + 32.0 * (intz[2] + intz[4]) + 12.0 * intz[3]);
+}
+
+/* One face of int_density_dz_generic_pcm (EOS_QUADRATURE; MOM_density_integrals.F90:265-339 in x, :342-414 in y): layer-mean
+ * T, S, interpolated across the face with (possibly thickness-weighted) weights. */
+static double face_int_generic_pcm(const mom6x_eos_params *E, double rho_ref, double G_e, double GxRho, int do_mw, int top_mw,
+                                   double nvT, double h_nv, double dz_neglect, double TL, double SL, double TR, double SR,
+                                   double ztL, double zbL, double ztR, double zbR, double z0L, double z0R, double bathyL, double bathyR,
+                                   double sshL, double sshR, double dpaL, double dpaR) {
+  const double C1_90 = 1.0 / 90.0;
+  double hWght = 0.0;
+  if (do_mw) hWght = orc_max(orc_max(0., -bathyL - ztR), -bathyR - ztL);
+  if (top_mw) hWght = orc_max(orc_max(hWght, zbR - sshL), zbL - sshR);
+  if (((ztL - zbL) > h_nv) && ((ztR - zbR) > h_nv)) hWght = nvT * hWght;
+  double hWt_LL, hWt_LR, hWt_RR, hWt_RL;
+  if (hWght > 0.) {
+    const double hL = (ztL - zbL) + dz_neglect, hR = (ztR - zbR) + dz_neglect;
+    const double q = (hL - hR) / (hL + hR);
+    hWght = hWght * (q * q);
+    const double iDenom = 1.0 / (hWght * (hR + hL) + hL * hR);
+    hWt_LL = (hWght * hL + hR * hL) * iDenom; hWt_LR = (hWght * hR) * iDenom;
+    hWt_RR = (hWght * hR + hR * hL) * iDenom; hWt_RL = (hWght * hL) * iDenom;
+  } else { hWt_LL = 1.0; hWt_LR = 0.0; hWt_RR = 1.0; hWt_RL = 0.0; }
+  double intz[6];
+  intz[1] = dpaL; intz[5] = dpaR;
+  for (int m = 2; m <= 4; m++) {
+    const double wt_L = 0.25 * (double)(5 - m), wt_R = 1.0 - wt_L;
+    const double wtT_L = (wt_L * hWt_LL) + (wt_R * hWt_RL), wtT_R = (wt_L * hWt_LR) + (wt_R * hWt_RR);
+    const double dz_x = (wt_L * (ztL - zbL)) + (wt_R * (ztR - zbR));
+    const double T15 = (wtT_L * TL) + (wtT_R * TR), S15 = (wtT_L * SL) + (wtT_R * SR);
+    double p15[6], r15[6];
+    p15[1] = -GxRho * ((wt_L * (ztL - z0L)) + (wt_R * (ztR - z0R)));
+    for (int n = 2; n <= 5; n++) p15[n] = p15[n - 1] + GxRho * 0.25 * dz_x;
+    for (int n = 1; n <= 5; n++) r15[n] = eos_density_anomaly(E, T15, S15, p15[n], rho_ref);
+    intz[m] = (G_e * dz_x * (C1_90 * (7.0 * (r15[1] + r15[5]) + 32.0 * (r15[2] + r15[4]) + 12.0 * r15[3])));
+  }
+  return C1_90 * (7.0 * (intz[1] + intz[5]) + 32.0 * (intz[2] + intz[4]) + 12.0 * intz[3]);
+}
+
 /* One face of int_density_dz_generic_plm: section 2 (x, MOM_density_integrals.F90:640-742) or 3 (y, :745-868).  L / R: the
  * two columns; *_t, *_b: top and bottom values of the layer; zt, zb: its interfaces; ssh: e(:,:,1). */
 static double face_int_generic_plm(const mom6x_eos_params *E, double rho_ref, double G_e, double GxRho, double mwT, double topT,
@@ -551,13 +672,16 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
   }
   const int use_EOS = (T != NULL);
   if (use_EOS && !(EOS && S && (EOS->form == MOM6X_EOS_LINEAR || EOS->form == MOM6X_EOS_WRIGHT) &&
-                   (EOS->Recon_Scheme == 0 || EOS->Recon_Scheme == 1))) {
+                   (EOS->Recon_Scheme >= 0 && EOS->Recon_Scheme <= 2) && (EOS->Recon_Scheme != 2 || nz >= 4))) {
     free(e); free(pa); free(dpa); free(intz_dpa); free(intx_pa); free(inty_pa); free(intx_dpa); free(inty_dpa); free(dz_geo);
     return MOM6X_EUNSUPPORTED;
   }
-  if (use_EOS && EOS->Recon_Scheme == 1) {
+  if (use_EOS && (EOS->Recon_Scheme >= 1 || EOS->EOS_quadrature)) {
     /* use_ALE with PRESSURE_RECONSTRUCTION_SCHEME = 1 (:1235-1236, :1287-1296): TS_PLM_edge_values, then
-     * int_density_dz_generic_plm (MOM_density_integrals.F90:418-870) layer by layer */
+     * int_density_dz_generic_plm (MOM_density_integrals.F90:418-870) layer by layer; = 2 (:1237-1238, :1297-1303):
+     * TS_PPM_edge_values, then int_density_dz_generic_ppm (:874-1310); without a reconstruction and with EOS_QUADRATURE
+     * (int_density_dz :95-99): int_density_dz_generic_pcm (:108-416) */
+    const int ppm = (EOS->Recon_Scheme == 2), pcm = (EOS->Recon_Scheme == 0);
     const double rho0_int = CS->rho_ref_bug ? rho_ref : GV->Rho0;    /* rho0_int_density :1134-1144 */
     const double G_e = GV->g_Earth, GxRho = G_e * rho0_int, C1_90 = 1.0 / 90.0;
     const double mwT = (EOS->MassWghtInterp & 1) ? 1. : 0., topT = ((EOS->MassWghtInterp >> 1) & 1) ? 1. : 0.;
@@ -565,8 +689,17 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
     const double h_nv = GV->H_to_Z * EOS->h_nonvanished;             /* dz_nonvanished :1128 */
     double *T_t = (double *)calloc(slab * nz, sizeof(double)), *T_b = (double *)calloc(slab * nz, sizeof(double));
     double *S_t = (double *)calloc(slab * nz, sizeof(double)), *S_b = (double *)calloc(slab * nz, sizeof(double));
-    orc_ALE_PLM_edge_values(d, GV, h, S, EOS->boundary_extrap, S_t, S_b);
-    orc_ALE_PLM_edge_values(d, GV, h, T, EOS->boundary_extrap, T_t, T_b);
+    if (ppm) {
+      orc_ALE_PPM_edge_values(d, GV, h, S, EOS->boundary_extrap, S_t, S_b);
+      orc_ALE_PPM_edge_values(d, GV, h, T, EOS->boundary_extrap, T_t, T_b);
+    } else if (!pcm) {
+      orc_ALE_PLM_edge_values(d, GV, h, S, EOS->boundary_extrap, S_t, S_b);
+      orc_ALE_PLM_edge_values(d, GV, h, T, EOS->boundary_extrap, T_t, T_b);
+    } else {
+      memcpy(S_t, S, slab * nz * sizeof(double)); memcpy(S_b, S, slab * nz * sizeof(double));
+      memcpy(T_t, T, slab * nz * sizeof(double)); memcpy(T_b, T, slab * nz * sizeof(double));
+    }
+    const int do_mw = EOS->MassWghtInterp & 1, top_mw = (EOS->MassWghtInterp >> 1) & 1;
     double *z0 = (double *)calloc(slab, sizeof(double));
     for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {   /* Z_0p :1264-1276 (p_atm absent) */
       size_t x = IX2(d, i, j);
@@ -576,15 +709,23 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
     for (int k = 0; k < nz; k++) {
       const double *zt = e + k * slab, *zb = e + (k + 1) * slab;
       const double *Tt = T_t + k * slab, *Tb = T_b + k * slab, *St = S_t + k * slab, *Sb = S_b + k * slab;
-      for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {   /* 1. vertical integrals :587-637 */
+      const double *Tm = T + k * slab, *Sm = S + k * slab;
+      for (int j = Jsq; j <= Jeq + 1; j++) for (int i = Isq; i <= Ieq + 1; i++) {   /* 1. vertical integrals :587-637 | :1047-1073 | :243-262 */
         size_t x = IX2(d, i, j), x3 = x + k * slab;
         const double dz = zt[x] - zb[x];
         double r5[6];
+        double s6 = 0., t6 = 0.;
+        if (ppm) {   /* curvature coefficient of the parabolas :1050-1052 */
+          s6 = 3.0 * (2.0 * Sm[x] - (St[x] + Sb[x]));
+          t6 = 3.0 * (2.0 * Tm[x] - (Tt[x] + Tb[x]));
+        }
         for (int n = 1; n <= 5; n++) {
           const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
           const double p5 = -GxRho * ((zt[x] - z0[x]) - 0.25 * (double)(n - 1) * dz);
-          const double S5 = wt_t * St[x] + wt_b * Sb[x];
-          const double T5 = wt_t * Tt[x] + wt_b * Tb[x];
+          double S5, T5;
+          if (ppm) { S5 = wt_t * St[x] + wt_b * (Sb[x] + s6 * wt_t); T5 = wt_t * Tt[x] + wt_b * (Tb[x] + t6 * wt_t); }
+          else if (pcm) { S5 = Sm[x]; T5 = Tm[x]; }
+          else { S5 = wt_t * St[x] + wt_b * Sb[x]; T5 = wt_t * Tt[x] + wt_b * Tb[x]; }
           r5[n] = eos_density_anomaly(EOS, T5, S5, p5, rho_ref);
         }
         const double rho_anom = C1_90 * (7.0 * (r5[1] + r5[5]) + 32.0 * (r5[2] + r5[4]) + 12.0 * r5[3]);
@@ -597,6 +738,15 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
         double *out = dir ? inty_dpa : intx_dpa;
         for (int j = b0; j <= b1; j++) for (int i = a0; i <= a1; i++) {
           size_t x = IX2(d, i, j), y = x + s2;
+          if (ppm)
+            out[x + k * slab] = face_int_generic_ppm(EOS, rho_ref, G_e, GxRho, mwT, topT, nvT, h_nv, dz_neglect, Tt[x], Tb[x], Tm[x], St[x],
+                                                     Sb[x], Sm[x], Tt[y], Tb[y], Tm[y], St[y], Sb[y], Sm[y], zt[x], zb[x], zt[y], zb[y],
+                                                     z0[x], z0[y], bathyT[x], bathyT[y], e[x], e[y], dpa[x + k * slab], dpa[y + k * slab]);
+          else if (pcm)
+            out[x + k * slab] = face_int_generic_pcm(EOS, rho_ref, G_e, GxRho, do_mw, top_mw, nvT, h_nv, dz_neglect, Tm[x], Sm[x], Tm[y],
+                                                     Sm[y], zt[x], zb[x], zt[y], zb[y], z0[x], z0[y], bathyT[x], bathyT[y], e[x], e[y],
+                                                     dpa[x + k * slab], dpa[y + k * slab]);
+          else
           out[x + k * slab] = face_int_generic_plm(EOS, rho_ref, G_e, GxRho, mwT, topT, nvT, h_nv, dz_neglect, Tt[x], Tb[x], St[x], Sb[x],
                                                    Tt[y], Tb[y], St[y], Sb[y], zt[x], zb[x], zt[y], zb[y], z0[x], z0[y], bathyT[x],
                                                    bathyT[y], e[x], e[y], dpa[x + k * slab], dpa[y + k * slab]);

@@ -114,7 +114,14 @@ def test_PressureForce(orc, cfg, bug):
 @pytest.mark.parametrize("mods", [dict(), dict(MassWghtInterp=1), dict(MassWghtInterp=3, use_SSH_in_Z0p=1, bug=0, dRho_dp=4.5e-7),
                                   # the ALE path: TS_PLM_edge_values + int_density_dz_generic_plm (PRESSURE_RECONSTRUCTION_SCHEME = 1)
                                   dict(Recon_Scheme=1), dict(Recon_Scheme=1, boundary_extrap=0, MassWghtInterp=1),
-                                  dict(Recon_Scheme=1, MassWghtInterp=3, MassWghtInterpVanOnly=1, h_nonvanished=5.0, use_SSH_in_Z0p=1, bug=0)])
+                                  dict(Recon_Scheme=1, MassWghtInterp=3, MassWghtInterpVanOnly=1, h_nonvanished=5.0, use_SSH_in_Z0p=1, bug=0),
+                                  # PRESSURE_RECONSTRUCTION_SCHEME = 2: TS_PPM_edge_values + int_density_dz_generic_ppm
+                                  dict(Recon_Scheme=2), dict(Recon_Scheme=2, boundary_extrap=0, MassWghtInterp=1),
+                                  dict(Recon_Scheme=2, MassWghtInterp=3, MassWghtInterpVanOnly=1, h_nonvanished=5.0, use_SSH_in_Z0p=1, bug=0),
+                                  # EOS_QUADRATURE: int_density_dz_generic_pcm
+                                  dict(EOS_quadrature=1), dict(EOS_quadrature=1, MassWghtInterp=1, dRho_dp=4.5e-7),
+                                  dict(EOS_quadrature=1, MassWghtInterp=3, MassWghtInterpVanOnly=1, h_nonvanished=5.0, use_SSH_in_Z0p=1, bug=0)],
+                         ids=lambda m: "-".join(f"{k}={v}" for k, v in m.items()) or "default")
 def test_PressureForce_with_equation_of_state(orc, cfg, form, mods):
     """The use_EOS branch (int_density_dz -> analytic linear / Wright integrals, or with Recon_Scheme = 1 the PLM edge values
     and the generic 5-point quadratures; Set_pbce_Bouss with T and S)."""
@@ -134,6 +141,13 @@ def test_PressureForce_with_equation_of_state(orc, cfg, form, mods):
     h, _, _ = synth.make_state(d, M, thin_frac=0.05)
     T, S = cases.thermo_state(d, M)
     o = dict(PFu=np.zeros_like(h), PFv=np.zeros_like(h), pbce=np.zeros_like(h), eta=np.zeros(d.shape2()))
+    if eos.Recon_Scheme == 2 and d.nk < 4:   # edge_values_implicit_h4 needs four layers: refused, not approximated
+        dyc = Dycore(d, M, GV)
+        dyc.PressureForce_init(CS, Rlay, gp)
+        with pytest.raises(abi.Mom6xError, match="NK >= 4"):
+            dyc.PressureForce_set_tv(dyc.to_dev(T), dyc.to_dev(S), eos)
+        dyc.close()
+        return
     orc.PressureForce(d, M, GV, CS, Rlay, gp, h, o["PFu"], o["PFv"], o["pbce"], o["eta"], T=T, S=S, eos=eos)
     dyc = Dycore(d, M, GV)
     dyc.PressureForce_init(CS, Rlay, gp)
@@ -156,6 +170,12 @@ def test_PressureForce_with_equation_of_state(orc, cfg, form, mods):
         Qt, Qb = dyc.zeros3(), dyc.zeros3()
         dyc.ALE_PLM_edge_values(hd, Td, eos.boundary_extrap, Qt, Qb); dyc.sync()
         H.assert_bitwise(Qt.cpu().numpy(), Qt_o, "T_t", sl); H.assert_bitwise(Qb.cpu().numpy(), Qb_o, "T_b", sl)
+    if eos.Recon_Scheme == 2:   # one field of TS_PPM_edge_values through its own entry point
+        Qt_o, Qb_o = np.zeros_like(h), np.zeros_like(h)
+        orc.ALE_PPM_edge_values(d, GV, h, S, eos.boundary_extrap, Qt_o, Qb_o)
+        Qt, Qb = dyc.zeros3(), dyc.zeros3()
+        dyc.ALE_PPM_edge_values(hd, Sd, eos.boundary_extrap, Qt, Qb); dyc.sync()
+        H.assert_bitwise(Qt.cpu().numpy(), Qt_o, "S_t", sl); H.assert_bitwise(Qb.cpu().numpy(), Qb_o, "S_b", sl)
     # back to the layered path
     dyc.PressureForce_set_tv(None, None, None)
     o2 = dict(PFu=np.zeros_like(h), PFv=np.zeros_like(h))

@@ -77,8 +77,10 @@ def test_PLM_quadrature_reduces_to_the_analytic_integrals(orc, form):
     S = np.ascontiguousarray(np.broadcast_to(34.5 + 0.5 * synth.smooth_field(d, 6, ox=0.5, oy=0.5), h.shape))
     su, sv = H.interior(d, "u"), H.interior(d, "v")
     res = {}
-    for recon in (0, 1):
-        eos = abi.eos_params_default(form); eos.Recon_Scheme = recon
+    for recon in (0, 1, 2, "quadrature"):
+        eos = abi.eos_params_default(form)
+        if recon == "quadrature": eos.EOS_quadrature = 1       # int_density_dz_generic_pcm
+        else: eos.Recon_Scheme = recon
         Pu, Pv, pb = np.zeros_like(h), np.zeros_like(h), np.zeros_like(h)
         orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, pbce=pb, T=T, S=S, eos=eos)
         res[recon] = (Pu, Pv, pb)
@@ -91,15 +93,74 @@ def test_PLM_quadrature_reduces_to_the_analytic_integrals(orc, form):
     assert np.abs(res[1][0] - res[0][0])[(Ellipsis,) + su].max() < tol * scale
     assert np.abs(res[1][1] - res[0][1])[(Ellipsis,) + sv].max() < tol * scale
     np.testing.assert_array_equal(res[1][2], res[0][2])           # pbce does not see the reconstruction
+    # PRESSURE_RECONSTRUCTION_SCHEME = 2 (TS_PPM_edge_values + int_density_dz_generic_ppm) and EOS_QUADRATURE
+    # (int_density_dz_generic_pcm): with nothing to reconstruct all three quadratures see the same T, S at every point
+    for other in (2, "quadrature"):
+        assert np.abs(res[other][0] - res[1][0])[(Ellipsis,) + su].max() < 1e-12 * scale
+        assert np.abs(res[other][1] - res[1][1])[(Ellipsis,) + sv].max() < 1e-12 * scale
+        np.testing.assert_array_equal(res[other][2], res[0][2])
     # stratified: the PLM path differs from the layer-mean one where the layers tilt
     T2, S2 = cases.thermo_state(d, M)
     out = {}
-    for recon in (0, 1):
+    for recon in (0, 1, 2):
         eos = abi.eos_params_default(form); eos.Recon_Scheme = recon
         Pu, Pv = np.zeros_like(h), np.zeros_like(h)
         orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, T=T2, S=S2, eos=eos)
         out[recon] = Pu
-    assert np.abs(out[1] - out[0])[(Ellipsis,) + su].max() > 1e-6 * np.abs(out[0][(Ellipsis,) + su]).max()
+    big = np.abs(out[0][(Ellipsis,) + su]).max()
+    assert np.abs(out[1] - out[0])[(Ellipsis,) + su].max() > 1e-6 * big
+    assert np.abs(out[2] - out[1])[(Ellipsis,) + su].max() > 1e-8 * big      # the parabolas are not the lines
+
+
+@pytest.mark.parametrize("extrap", [0, 1])
+def test_TS_PPM_edge_values_properties(orc, extrap):
+    """TS_PPM_edge_values (MOM_ALE.F90:1581: edge_values_implicit_h4, PPM_reconstruction, PPM_boundary_extrapolation -- the
+    routines tests/test_remap_cpu.py holds to the vectors of the reference's remapping_unit_tests): a profile linear in
+    z on a uniform grid is reproduced exactly at every interior edge (the fourth-order edge estimate is exact for cubics);
+    the limited edge values bracket nothing beyond the neighbouring means; interior cells stay monotone."""
+    gg, d, M = H.benchmark_small(nk=12)
+    GV = abi.vgrid_default()
+    h = np.full(d.shape3(), 10.0)
+    z = (np.arange(d.nk) + 0.5)[:, None, None] * 10.0
+    Q = np.ascontiguousarray(np.broadcast_to(20.0 - 0.01 * z, h.shape))
+    Qt, Qb = np.zeros_like(h), np.zeros_like(h)
+    orc.ALE_PPM_edge_values(d, GV, h, Q, extrap, Qt, Qb)
+    sl = d.sl(-1, d.ni, -1, d.nj)
+    np.testing.assert_allclose(Qt[1:-1][(Ellipsis,) + sl], (Q[1:-1] + 0.05)[(Ellipsis,) + sl], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(Qb[1:-1][(Ellipsis,) + sl], (Q[1:-1] - 0.05)[(Ellipsis,) + sl], rtol=0, atol=1e-12)
+    if extrap:   # the boundary cells continue the line
+        np.testing.assert_allclose(Qt[0][sl], (Q[0] + 0.05)[sl], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(Qb[-1][sl], (Q[-1] - 0.05)[sl], rtol=0, atol=1e-12)
+    else:        # PPM_limiter_standard flattens the two boundary cells (:117-119)
+        np.testing.assert_array_equal(Qt[0][sl], Q[0][sl]); np.testing.assert_array_equal(Qb[-1][sl], Q[-1][sl])
+    # a rough state: every interior cell's edge values lie between its neighbours' means and are monotone with them
+    h2, _, _ = synth.make_state(d, M, thin_frac=0.2)
+    T2, _ = cases.thermo_state(d, M)
+    orc.ALE_PPM_edge_values(d, GV, h2, T2, extrap, Qt, Qb)
+    lo = np.minimum(np.minimum(T2[:-2], T2[1:-1]), T2[2:]); hi = np.maximum(np.maximum(T2[:-2], T2[1:-1]), T2[2:])
+    for E in (Qt, Qb):
+        assert (E[1:-1][(Ellipsis,) + sl] >= lo[(Ellipsis,) + sl] - 1e-12).all() and (E[1:-1][(Ellipsis,) + sl] <= hi[(Ellipsis,) + sl] + 1e-12).all()
+    assert np.abs(Qb - Qt)[(Ellipsis,) + sl].max() > 1e-3
+
+
+@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
+@pytest.mark.parametrize("recon", [2, "quadrature"])
+def test_resting_stratified_ocean_feels_no_force_with_ppm_or_quadrature(orc, form, recon):
+    gg, d, M = H.channel(nk=6)
+    GV = abi.vgrid_default(); CS = abi.pgf_params_default(GV.Rho0)
+    Rlay, gp = abi.layer_densities(d.nk, GV.Rho0, GV.g_Earth)
+    h = np.full(d.shape3(), 1000.0 / d.nk)
+    T = np.zeros_like(h); S = np.zeros_like(h)
+    for k in range(d.nk):
+        T[k] = 18.0 - 4.0 * k + 0.3 * k * k; S[k] = 34.0 + 0.3 * k
+    eos = abi.eos_params_default(form); eos.MassWghtInterp = 3
+    if recon == 2: eos.Recon_Scheme = 2
+    else: eos.EOS_quadrature = 1
+    Pu, Pv = np.zeros_like(h), np.zeros_like(h)
+    orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, T=T, S=S, eos=eos)
+    su, sv = H.interior(d, "u"), H.interior(d, "v")
+    assert np.abs(Pu[(Ellipsis,) + su] * M[G["mask2dCu"]][su]).max() < 1e-12
+    assert np.abs(Pv[(Ellipsis,) + sv] * M[G["mask2dCv"]][sv]).max() < 1e-12
 
 
 @pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])

@@ -45,7 +45,8 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
     if eos_form is not None:   # tv%T, tv%S, tv%eqn_of_state: the PressureForce calls take the use_EOS branch
         Tt, St = cases.thermo_state(d, M)
         tv = (Tt, St, abi.eos_params_default(eos_form))
-        tv[2].Recon_Scheme = recon   # 1: the ALE path of PressureForce (PLM reconstruction of T, S)
+        if recon == "quadrature": tv[2].EOS_quadrature = 1   # int_density_dz_generic_pcm
+        else: tv[2].Recon_Scheme = recon   # the ALE path of PressureForce: 1 PLM, 2 PPM reconstruction of T, S
         if Hmix_stress > 0.0:
             tv[2].MassWghtInterp = 1   # the tc4-like case also has MASS_WEIGHT_IN_PRESSURE_GRADIENT
     # ---------------- oracle
@@ -174,7 +175,7 @@ def test_rk2_device_matches_committed_golden(orc):
         H.assert_bitwise(out[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))], gold[n], "golden:" + n)
 
 
-@pytest.mark.parametrize("recon", [0, 1])
+@pytest.mark.parametrize("recon", [0, 1, 2, "quadrature"])
 @pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
 def test_rk2_with_equation_of_state(orc, form, recon):
     run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(begw=0.2), eos_form=form, recon=recon)
