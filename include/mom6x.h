@@ -244,10 +244,11 @@ typedef struct mom6x_hor_visc_params {
 
 /* tv%eqn_of_state (EOS_type, src/equation_of_state/MOM_EOS.F90:99-150) and the switches of
  * PressureForce_FV_CS that only matter with an equation of state.  Analytic density integrals
- * (analytic_int_density_dz, MOM_EOS.F90:1384) exist for EOS_LINEAR and the WRIGHT family; LINEAR and
- * WRIGHT (the default, MOM_EOS_Wright.F90) are implemented, WRIGHT_FULL / WRIGHT_REDUCED differ in
- * constants and parenthesisation only and are rejected for now.                                */
-enum mom6x_eos_form { MOM6X_EOS_LINEAR = 1, MOM6X_EOS_WRIGHT = 2 };
+ * (analytic_int_density_dz, MOM_EOS.F90:1384) exist for EOS_LINEAR and the WRIGHT family: LINEAR, WRIGHT (the default,
+ * MOM_EOS_Wright.F90), WRIGHT_FULL (MOM_EOS_Wright_full.F90) and WRIGHT_REDUCED (MOM_EOS_Wright_red.F90) are carried, each
+ * with the analytic integrals and, with EOS_QUADRATURE or a pressure reconstruction, the generic quadratures.  The other
+ * equations of state (UNESCO, NEMO / ROQUET_*, JACKETT_06, TEOS10) have no analytic integrals and are refused.      */
+enum mom6x_eos_form { MOM6X_EOS_LINEAR = 1, MOM6X_EOS_WRIGHT = 2, MOM6X_EOS_WRIGHT_FULL = 3, MOM6X_EOS_WRIGHT_REDUCED = 4 };
 typedef struct mom6x_eos_params {
   int    form;            /* EQN_OF_STATE                                                       */
   double Rho_T0_S0;       /* RHO_T0_S0 (1000)  } EOS_LINEAR                                     */

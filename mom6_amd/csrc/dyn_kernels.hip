@@ -791,14 +791,23 @@ __device__ __forceinline__ void cell_int(const EosDev &E, double rho_ref, double
   } else {
     const double C1_3 = 1.0 / 3.0, C1_7 = 1.0 / 7.0, C1_9 = 1.0 / 9.0;
     double al0, p0, lambda;
-    wright_coefs(T, S, al0, p0, lambda);
+    wright_coefs<FORM>(T, S, al0, p0, lambda);
     const double I_al0 = 1.0 / al0;
-    const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
-    const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
-    const double rho_anom = (p0 + p_ave) * (I_Lzz * I_al0) - rho_ref;
-    const double rem = I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2)));
-    dpa = 1.0 * (G_e * rho_anom * dz - 2.0 * eps * rem);
-    intz = 1.0 * (0.5 * G_e * rho_anom * (dz * dz) - dz * (1.0 + eps) * rem);
+    if (FORM == MOM6X_EOS_WRIGHT) {   // int_density_dz_wright, MOM_EOS_Wright.F90:554-577
+      const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+      const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
+      const double rho_anom = (p0 + p_ave) * (I_Lzz * I_al0) - rho_ref;
+      const double rem = I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2)));
+      dpa = 1.0 * (G_e * rho_anom * dz - 2.0 * eps * rem);
+      intz = 1.0 * (0.5 * G_e * rho_anom * (dz * dz) - dz * (1.0 + eps) * rem);
+    } else {                          // int_density_dz_wright_full / _red, MOM_EOS_Wright_full.F90:550-572
+      const double I_Lzz = 1.0 / ((p0 + p_ave) + lambda * I_al0);
+      const double eps = 0.5 * (GxRho * dz) * I_Lzz, eps2 = eps * eps;
+      const double rho_anom = (p0 + p_ave) * (I_Lzz * I_al0) - rho_ref;
+      const double rem = (I_Rho * (lambda * (I_al0 * I_al0))) * (eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2))));
+      dpa = 1.0 * ((G_e * rho_anom) * dz - 2.0 * eps * rem);
+      intz = 1.0 * (0.5 * (G_e * rho_anom) * (dz * dz) - dz * ((1.0 + eps) * rem));
+    }
   }
 }
 
@@ -831,7 +840,7 @@ __device__ __forceinline__ double face_int(const EosDev &E, double rho_ref, doub
     RR = (hWght * hR + hR * hL) * iDenom; RL = (hWght * hL) * iDenom;
   }
   double al0L = 0., p0L = 0., lamL = 0., al0R = 0., p0R = 0., lamR = 0.;
-  if (FORM == MOM6X_EOS_WRIGHT) { wright_coefs(TL, SL, al0L, p0L, lamL); wright_coefs(TR, SR, al0R, p0R, lamR); }
+  if (FORM != MOM6X_EOS_LINEAR) { wright_coefs<FORM>(TL, SL, al0L, p0L, lamL); wright_coefs<FORM>(TR, SR, al0R, p0R, lamR); }
   double intz[5];
   intz[0] = dpaL; intz[4] = dpaR;
 #pragma unroll
@@ -850,10 +859,17 @@ __device__ __forceinline__ double face_int(const EosDev &E, double rho_ref, doub
       const double p0 = (wtT_L * p0L) + (wtT_R * p0R);
       const double lambda = (wtT_L * lamL) + (wtT_R * lamR);
       const double I_al0 = 1.0 / al0;
-      const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
-      const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
-      intz[m - 1] = 1.0 * (G_e * dz * ((p0 + p_ave) * (I_Lzz * I_al0) - rho_ref) - 2.0 * eps *
-                           I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2))));
+      if (FORM == MOM6X_EOS_WRIGHT) {   // MOM_EOS_Wright.F90:601-605
+        const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+        const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
+        intz[m - 1] = 1.0 * (G_e * dz * ((p0 + p_ave) * (I_Lzz * I_al0) - rho_ref) - 2.0 * eps *
+                             I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2))));
+      } else {                          // MOM_EOS_Wright_full.F90:606-610
+        const double I_Lzz = 1.0 / ((p0 + p_ave) + lambda * I_al0);
+        const double eps = 0.5 * (GxRho * dz) * I_Lzz, eps2 = eps * eps;
+        intz[m - 1] = 1.0 * ((G_e * dz) * ((p0 + p_ave) * (I_Lzz * I_al0) - rho_ref) - 2.0 * eps *
+                             (I_Rho * (lambda * (I_al0 * I_al0))) * (eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2)))));
+      }
     }
   }
   return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
@@ -867,12 +883,13 @@ template <int FORM>
 __device__ __forceinline__ double density_anomaly(const EosDev &E, double T, double S, double pressure, double rho_ref) {
   if (FORM == MOM6X_EOS_LINEAR)
     return (E.Rho_T0_S0 - rho_ref) + ((E.dRho_dT * T + E.dRho_dS * S) + E.dRho_dp * pressure);
-  const double pa_000 = (W_b0 * (1.0 - W_a0 * rho_ref) - rho_ref * W_c0);
-  const double al_TS = W_a1 * T + W_a2 * S;
-  const double al0 = W_a0 + al_TS;
-  const double p_TSp = pressure + (W_b4 * S + T * (W_b1 + (T * (W_b2 + W_b3 * T) + W_b5 * S)));
-  const double lam_TS = W_c4 * S + T * (W_c1 + (T * (W_c2 + W_c3 * T) + W_c5 * S));
-  return (pa_000 + (p_TSp - rho_ref * (p_TSp * al0 + (W_b0 * al_TS + lam_TS)))) / ((W_c0 + lam_TS) + al0 * (W_b0 + p_TSp));
+  typedef WC<FORM> W;   // the same expression in MOM_EOS_Wright.F90:119-128, _full.F90:108-119, _red.F90:108-119
+  const double pa_000 = (W::b0 * (1.0 - W::a0 * rho_ref) - rho_ref * W::c0);
+  const double al_TS = W::a1 * T + W::a2 * S;
+  const double al0 = W::a0 + al_TS;
+  const double p_TSp = pressure + (W::b4 * S + T * (W::b1 + (T * (W::b2 + W::b3 * T) + W::b5 * S)));
+  const double lam_TS = W::c4 * S + T * (W::c1 + (T * (W::c2 + W::c3 * T) + W::c5 * S));
+  return (pa_000 + (p_TSp - rho_ref * (p_TSp * al0 + (W::b0 * al_TS + lam_TS)))) / ((W::c0 + lam_TS) + al0 * (W::b0 + p_TSp));
 }
 
 // section 1 of int_density_dz_generic_plm (MOM_density_integrals.F90:587-637): dpa and intz_dpa of one cell by Boole's rule
@@ -1160,9 +1177,7 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
         double rho_in_situ;
         if (FORM == MOM6X_EOS_LINEAR) rho_in_situ = E.Rho_T0_S0 + E.dRho_dT * T0 + E.dRho_dS * S0 + E.dRho_dp * press;
         else {
-          double al0, p0, lambda;
-          wright_coefs(T0, S0, al0, p0, lambda);
-          rho_in_situ = (press + p0) / (lambda + al0 * (press + p0));
+          rho_in_situ = wright_density<FORM>(T0, S0, press);
         }
         pb = G_Rho0 * (1.0 * rho_in_situ) * H_to_Z;
       } else {
@@ -1170,13 +1185,22 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
         double dR_dT, dR_dS;
         if (FORM == MOM6X_EOS_LINEAR) { dR_dT = E.dRho_dT; dR_dS = E.dRho_dS; }
         else {
+          typedef WC<FORM> W;
           double al0, p0, lambda;
-          wright_coefs(T_int, S_int, al0, p0, lambda);
-          double I_denom2 = 1.0 / (lambda + al0 * (press + p0));
-          I_denom2 = I_denom2 * I_denom2;
-          dR_dT = I_denom2 * (lambda * (W_b1 + T_int * (2.0 * W_b2 + 3.0 * W_b3 * T_int) + W_b5 * S_int) -
-                              (press + p0) * ((press + p0) * W_a1 + (W_c1 + T_int * (W_c2 * 2.0 + W_c3 * 3.0 * T_int) + W_c5 * S_int)));
-          dR_dS = I_denom2 * (lambda * (W_b4 + W_b5 * T_int) - (press + p0) * ((press + p0) * W_a2 + (W_c4 + W_c5 * T_int)));
+          wright_coefs<FORM>(T_int, S_int, al0, p0, lambda);
+          if (FORM == MOM6X_EOS_WRIGHT) {   // calculate_density_derivs_elem_buggy_Wright, MOM_EOS_Wright.F90:208-222
+            double I_denom2 = 1.0 / (lambda + al0 * (press + p0));
+            I_denom2 = I_denom2 * I_denom2;
+            dR_dT = I_denom2 * (lambda * (W::b1 + T_int * (2.0 * W::b2 + 3.0 * W::b3 * T_int) + W::b5 * S_int) -
+                                (press + p0) * ((press + p0) * W::a1 + (W::c1 + T_int * (W::c2 * 2.0 + W::c3 * 3.0 * T_int) + W::c5 * S_int)));
+            dR_dS = I_denom2 * (lambda * (W::b4 + W::b5 * T_int) - (press + p0) * ((press + p0) * W::a2 + (W::c4 + W::c5 * T_int)));
+          } else {                          // calculate_density_derivs_elem_Wright_full / _red, MOM_EOS_Wright_full.F90:192-200
+            const double den = (lambda + al0 * (press + p0));
+            const double I_denom2 = 1.0 / (den * den);
+            dR_dT = I_denom2 * (lambda * (W::b1 + (T_int * (2.0 * W::b2 + 3.0 * W::b3 * T_int) + W::b5 * S_int)) -
+                                (press + p0) * ((press + p0) * W::a1 + (W::c1 + (T_int * (W::c2 * 2.0 + W::c3 * 3.0 * T_int) + W::c5 * S_int))));
+            dR_dS = I_denom2 * (lambda * (W::b4 + W::b5 * T_int) - (press + p0) * ((press + p0) * W::a2 + (W::c4 + W::c5 * T_int)));
+          }
         }
         pb = pb + G_Rho0 * ((zt0 - e_bot) * Ihtot) * (dR_dT * (T0 - T_prev) + dR_dS * (S0 - S_prev));
       }
@@ -1192,8 +1216,8 @@ extern "C" int mom6x_PressureForce_set_tv(mom6x_ctx *c, const double *T, const d
   REQUIRE(c, MOM6X_EINVAL, "mom6x_PressureForce_set_tv: null ctx");
   if (!T) { c->tv_T = nullptr; c->tv_S = nullptr; return MOM6X_OK; }
   REQUIRE(S && eos, MOM6X_EINVAL, "mom6x_PressureForce_set_tv: tv%T without tv%S or tv%eqn_of_state");
-  REQUIRE(eos->form == MOM6X_EOS_LINEAR || eos->form == MOM6X_EOS_WRIGHT, MOM6X_EUNSUPPORTED,
-          "No analytic integration option is available with this EOS!");
+  REQUIRE(eos->form >= MOM6X_EOS_LINEAR && eos->form <= MOM6X_EOS_WRIGHT_REDUCED, MOM6X_EUNSUPPORTED,
+          "PressureForce: EQN_OF_STATE must be LINEAR, WRIGHT, WRIGHT_FULL or WRIGHT_REDUCED");
   REQUIRE(eos->Recon_Scheme >= 0 && eos->Recon_Scheme <= 2, MOM6X_EINVAL,
           "PressureForce_FV_init: PRESSURE_RECONSTRUCTION_SCHEME must be 1 (PLM) or 2 (PPM), or 0 without RECONSTRUCT_FOR_PRESSURE");
   REQUIRE(eos->Recon_Scheme != 2 || c->dims.nk >= 4, MOM6X_EUNSUPPORTED,
@@ -1253,17 +1277,13 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
 #define PGF_EOS(F, P, NAME) KLAUNCH(c, NAME, (k_pgf_main_eos<F, P>), g, b, d, c->G, h, e, c->tv_T, c->tv_S, Tt, Tb, St, Sb, E, PFu, PFv,   \
                                     pbce, eta, GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, GV.Rho0, \
                                     rho0_alt, GV.H_subroundoff, GV.dZ_subroundoff)
-    if (E.form == MOM6X_EOS_LINEAR) {
-      if (mode == 1) PGF_EOS(MOM6X_EOS_LINEAR, 1, "k_pgf_main_plm<linear>");
-      else if (mode == 2) PGF_EOS(MOM6X_EOS_LINEAR, 2, "k_pgf_main_ppm<linear>");
-      else if (mode == 3) PGF_EOS(MOM6X_EOS_LINEAR, 3, "k_pgf_main_pcm<linear>");
-      else PGF_EOS(MOM6X_EOS_LINEAR, 0, "k_pgf_main_eos<linear>");
-    } else {
-      if (mode == 1) PGF_EOS(MOM6X_EOS_WRIGHT, 1, "k_pgf_main_plm<wright>");
-      else if (mode == 2) PGF_EOS(MOM6X_EOS_WRIGHT, 2, "k_pgf_main_ppm<wright>");
-      else if (mode == 3) PGF_EOS(MOM6X_EOS_WRIGHT, 3, "k_pgf_main_pcm<wright>");
-      else PGF_EOS(MOM6X_EOS_WRIGHT, 0, "k_pgf_main_eos<wright>");
-    }
+#define PGF_FORM(F, N) do { if (mode == 1) PGF_EOS(F, 1, "k_pgf_main_plm<" N ">"); else if (mode == 2) PGF_EOS(F, 2, "k_pgf_main_ppm<" N ">"); \
+                            else if (mode == 3) PGF_EOS(F, 3, "k_pgf_main_pcm<" N ">"); else PGF_EOS(F, 0, "k_pgf_main_eos<" N ">"); } while (0)
+    if (E.form == MOM6X_EOS_LINEAR) PGF_FORM(MOM6X_EOS_LINEAR, "linear");
+    else if (E.form == MOM6X_EOS_WRIGHT_FULL) PGF_FORM(MOM6X_EOS_WRIGHT_FULL, "wright_full");
+    else if (E.form == MOM6X_EOS_WRIGHT_REDUCED) PGF_FORM(MOM6X_EOS_WRIGHT_REDUCED, "wright_red");
+    else PGF_FORM(MOM6X_EOS_WRIGHT, "wright");
+#undef PGF_FORM
 #undef PGF_EOS
     HIPCHK(hipGetLastError());
     return MOM6X_OK;

@@ -289,35 +289,56 @@ int orc_CorAdCalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, c
 
 /* ------------------------------------------------------------------------------------------ */
 /* Equation of state pieces used by the pressure force                                           */
-/* Wright (1997) constants of MOM_EOS_Wright.F90:23-37 (EQN_OF_STATE = "WRIGHT")                  */
-static const double W_a0 = 7.057924e-4, W_a1 = 3.480336e-7, W_a2 = -1.112733e-7;
-static const double W_b0 = 5.790749e8, W_b1 = 3.516535e6, W_b2 = -4.002714e4, W_b3 = 2.084372e2, W_b4 = 5.944068e5, W_b5 = -9.643486e3;
-static const double W_c0 = 1.704853e5, W_c1 = 7.904722e2, W_c2 = -7.984422, W_c3 = 5.140652e-2, W_c4 = -2.302158e2, W_c5 = -3.079464;
+/* Wright (1997) constants: the reduced-range fit of EQN_OF_STATE = "WRIGHT" (MOM_EOS_Wright.F90:23-37) and "WRIGHT_REDUCED"
+ * (MOM_EOS_Wright_red.F90:18-35), the full-range fit of "WRIGHT_FULL" (MOM_EOS_Wright_full.F90:18-35).  "WRIGHT" keeps the original
+ * parenthesisation ("buggy_Wright"); WRIGHT_FULL and WRIGHT_REDUCED share the corrected expressions. */
+typedef struct { double a0, a1, a2, b0, b1, b2, b3, b4, b5, c0, c1, c2, c3, c4, c5; } wright_set;
+static const wright_set WC_RED = { 7.057924e-4, 3.480336e-7, -1.112733e-7, 5.790749e8, 3.516535e6, -4.002714e4, 2.084372e2, 5.944068e5,
+                                   -9.643486e3, 1.704853e5, 7.904722e2, -7.984422, 5.140652e-2, -2.302158e2, -3.079464 };
+static const wright_set WC_FULL = { 7.133718e-4, 2.724670e-7, -1.646582e-7, 5.613770e8, 3.600337e6, -3.727194e4, 1.660557e2, 6.844158e5,
+                                    -8.389457e3, 1.609893e5, 8.427815e2, -6.931554, 3.869318e-2, -1.664201e2, -2.765195 };
+static const wright_set *wright_of(int form) { return form == MOM6X_EOS_WRIGHT_FULL ? &WC_FULL : &WC_RED; }
 
-static void wright_coefs(double T, double S, double *al0, double *p0, double *lambda) {   /* :555-557 */
-  *al0 = (W_a0 + W_a1 * T) + W_a2 * S;
-  *p0 = (W_b0 + W_b4 * S) + T * (W_b1 + T * ((W_b2 + W_b3 * T)) + W_b5 * S);
-  *lambda = (W_c0 + W_c4 * S) + T * (W_c1 + T * ((W_c2 + W_c3 * T)) + W_c5 * S);
+static void wright_coefs(int form, double T, double S, double *al0, double *p0, double *lambda) {
+  const wright_set *W = wright_of(form);
+  if (form == MOM6X_EOS_WRIGHT) {   /* MOM_EOS_Wright.F90:91-93, :555-557 */
+    *al0 = (W->a0 + W->a1 * T) + W->a2 * S;
+    *p0 = (W->b0 + W->b4 * S) + T * (W->b1 + T * ((W->b2 + W->b3 * T)) + W->b5 * S);
+    *lambda = (W->c0 + W->c4 * S) + T * (W->c1 + T * ((W->c2 + W->c3 * T)) + W->c5 * S);
+  } else {                          /* MOM_EOS_Wright_full.F90:84-86, :550-552 (and _red) */
+    *al0 = W->a0 + (W->a1 * T + W->a2 * S);
+    *p0 = W->b0 + (W->b4 * S + T * (W->b1 + (T * (W->b2 + W->b3 * T) + W->b5 * S)));
+    *lambda = W->c0 + (W->c4 * S + T * (W->c1 + (T * (W->c2 + W->c3 * T) + W->c5 * S)));
+  }
 }
 
-/* calculate_density (no rho_ref): density_elem_linear MOM_EOS_linear.F90:66, density_elem_buggy_Wright :80-96 */
+/* calculate_density (no rho_ref): density_elem_linear MOM_EOS_linear.F90:66, density_elem_buggy_Wright :80-96, density_elem_Wright_full :73-89 */
 static double eos_density(const mom6x_eos_params *E, double T, double S, double p) {
   if (E->form == MOM6X_EOS_LINEAR) return E->Rho_T0_S0 + E->dRho_dT * T + E->dRho_dS * S + E->dRho_dp * p;
   double al0, p0, lambda;
-  wright_coefs(T, S, &al0, &p0, &lambda);
+  wright_coefs(E->form, T, S, &al0, &p0, &lambda);
   return (p + p0) / (lambda + al0 * (p + p0));
 }
 
-/* calculate_density_derivs: linear :117-134, Wright :178-206 */
+/* calculate_density_derivs: linear :117-134, Wright :178-206, Wright_full / _red :177-202 */
 static void eos_density_derivs(const mom6x_eos_params *E, double T, double S, double p, double *dRdT, double *dRdS) {
   if (E->form == MOM6X_EOS_LINEAR) { *dRdT = E->dRho_dT; *dRdS = E->dRho_dS; return; }
+  const wright_set *W = wright_of(E->form);
   double al0, p0, lambda;
-  wright_coefs(T, S, &al0, &p0, &lambda);
-  double I_denom2 = 1.0 / (lambda + al0 * (p + p0));
-  I_denom2 = I_denom2 * I_denom2;
-  *dRdT = I_denom2 * (lambda * (W_b1 + T * (2.0 * W_b2 + 3.0 * W_b3 * T) + W_b5 * S) -
-                      (p + p0) * ((p + p0) * W_a1 + (W_c1 + T * (W_c2 * 2.0 + W_c3 * 3.0 * T) + W_c5 * S)));
-  *dRdS = I_denom2 * (lambda * (W_b4 + W_b5 * T) - (p + p0) * ((p + p0) * W_a2 + (W_c4 + W_c5 * T)));
+  wright_coefs(E->form, T, S, &al0, &p0, &lambda);
+  if (E->form == MOM6X_EOS_WRIGHT) {
+    double I_denom2 = 1.0 / (lambda + al0 * (p + p0));
+    I_denom2 = I_denom2 * I_denom2;
+    *dRdT = I_denom2 * (lambda * (W->b1 + T * (2.0 * W->b2 + 3.0 * W->b3 * T) + W->b5 * S) -
+                        (p + p0) * ((p + p0) * W->a1 + (W->c1 + T * (W->c2 * 2.0 + W->c3 * 3.0 * T) + W->c5 * S)));
+    *dRdS = I_denom2 * (lambda * (W->b4 + W->b5 * T) - (p + p0) * ((p + p0) * W->a2 + (W->c4 + W->c5 * T)));
+  } else {
+    const double den = (lambda + al0 * (p + p0));
+    const double I_denom2 = 1.0 / (den * den);
+    *dRdT = I_denom2 * (lambda * (W->b1 + (T * (2.0 * W->b2 + 3.0 * W->b3 * T) + W->b5 * S)) -
+                        (p + p0) * ((p + p0) * W->a1 + (W->c1 + (T * (W->c2 * 2.0 + W->c3 * 3.0 * T) + W->c5 * S))));
+    *dRdS = I_denom2 * (lambda * (W->b4 + W->b5 * T) - (p + p0) * ((p + p0) * W->a2 + (W->c4 + W->c5 * T)));
+  }
 }
 
 /* exported for the known-answer tests against the reference's own EOS_unit_tests values (MOM_EOS.F90:2077-2079 WRIGHT,
@@ -379,7 +400,7 @@ static double face_int_linear(const mom6x_eos_params *E, double rho_ref, double 
 }
 
 /* One column pair of int_density_dz_wright :560-607 (x) / :609-653 (y). */
-static double face_int_wright(double rho_ref, double G_e, double GxRho, double I_Rho, int do_mw, int top_mw,
+static double face_int_wright(int form, double rho_ref, double G_e, double GxRho, double I_Rho, int do_mw, int top_mw,
                               double TL, double SL, double TR, double SR, double ztL, double zbL, double ztR, double zbR,
                               double z0L, double z0R, double bathyL, double bathyR, double sshL, double sshR, double dz_neglect,
                               double dpaL, double dpaR) {
@@ -387,8 +408,8 @@ static double face_int_wright(double rho_ref, double G_e, double GxRho, double I
   double LL, LR, RR, RL;
   face_weights(do_mw, top_mw, bathyL, bathyR, ztL, ztR, zbL, zbR, sshL, sshR, dz_neglect, &LL, &LR, &RR, &RL);
   double al0L, p0L, lamL, al0R, p0R, lamR;
-  wright_coefs(TL, SL, &al0L, &p0L, &lamL);
-  wright_coefs(TR, SR, &al0R, &p0R, &lamR);
+  wright_coefs(form, TL, SL, &al0L, &p0L, &lamL);
+  wright_coefs(form, TR, SR, &al0R, &p0R, &lamR);
   double intz[5];
   intz[0] = dpaL; intz[4] = dpaR;
   for (int m = 2; m <= 4; m++) {
@@ -400,10 +421,17 @@ static double face_int_wright(double rho_ref, double G_e, double GxRho, double I
     const double dz = (wt_L * (ztL - zbL)) + (wt_R * (ztR - zbR));
     const double p_ave = -GxRho * ((wt_L * (0.5 * (ztL + zbL) - z0L)) + (wt_R * (0.5 * (ztR + zbR) - z0R)));
     const double I_al0 = 1.0 / al0;
-    const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
-    const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
-    intz[m - 1] = 1.0 * (G_e * dz * ((p0 + p_ave) * (I_Lzz * I_al0) - rho_ref) - 2.0 * eps *
-                         I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2))));
+    if (form == MOM6X_EOS_WRIGHT) {   /* MOM_EOS_Wright.F90:601-605 */
+      const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+      const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
+      intz[m - 1] = 1.0 * (G_e * dz * ((p0 + p_ave) * (I_Lzz * I_al0) - rho_ref) - 2.0 * eps *
+                           I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2))));
+    } else {                          /* MOM_EOS_Wright_full.F90:606-610 */
+      const double I_Lzz = 1.0 / ((p0 + p_ave) + lambda * I_al0);
+      const double eps = 0.5 * (GxRho * dz) * I_Lzz, eps2 = eps * eps;
+      intz[m - 1] = 1.0 * ((G_e * dz) * ((p0 + p_ave) * (I_Lzz * I_al0) - rho_ref) - 2.0 * eps *
+                           (I_Rho * (lambda * (I_al0 * I_al0))) * (eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2)))));
+    }
   }
   return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
 }
@@ -413,12 +441,13 @@ static double face_int_wright(double rho_ref, double G_e, double GxRho, double I
 static double eos_density_anomaly(const mom6x_eos_params *E, double T, double S, double pressure, double rho_ref) {
   if (E->form == MOM6X_EOS_LINEAR)
     return (E->Rho_T0_S0 - rho_ref) + ((E->dRho_dT * T + E->dRho_dS * S) + E->dRho_dp * pressure);
-  const double pa_000 = (W_b0 * (1.0 - W_a0 * rho_ref) - rho_ref * W_c0);
-  const double al_TS = W_a1 * T + W_a2 * S;
-  const double al0 = W_a0 + al_TS;
-  const double p_TSp = pressure + (W_b4 * S + T * (W_b1 + (T * (W_b2 + W_b3 * T) + W_b5 * S)));
-  const double lam_TS = W_c4 * S + T * (W_c1 + (T * (W_c2 + W_c3 * T) + W_c5 * S));
-  return (pa_000 + (p_TSp - rho_ref * (p_TSp * al0 + (W_b0 * al_TS + lam_TS)))) / ((W_c0 + lam_TS) + al0 * (W_b0 + p_TSp));
+  const wright_set *W = wright_of(E->form);   /* the same expression in all three Wright modules (_full.F90:108-119) */
+  const double pa_000 = (W->b0 * (1.0 - W->a0 * rho_ref) - rho_ref * W->c0);
+  const double al_TS = W->a1 * T + W->a2 * S;
+  const double al0 = W->a0 + al_TS;
+  const double p_TSp = pressure + (W->b4 * S + T * (W->b1 + (T * (W->b2 + W->b3 * T) + W->b5 * S)));
+  const double lam_TS = W->c4 * S + T * (W->c1 + (T * (W->c2 + W->c3 * T) + W->c5 * S));
+  return (pa_000 + (p_TSp - rho_ref * (p_TSp * al0 + (W->b0 * al_TS + lam_TS)))) / ((W->c0 + lam_TS) + al0 * (W->b0 + p_TSp));
 }
 double orc_eos_density_anomaly(const mom6x_eos_params *E, double T, double S, double p, double rho_ref) {
   return eos_density_anomaly(E, T, S, p, rho_ref);
@@ -671,7 +700,7 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
     pa[x] = GxRho_ref * (e[x] - Z_ref);
   }
   const int use_EOS = (T != NULL);
-  if (use_EOS && !(EOS && S && (EOS->form == MOM6X_EOS_LINEAR || EOS->form == MOM6X_EOS_WRIGHT) &&
+  if (use_EOS && !(EOS && S && (EOS->form >= MOM6X_EOS_LINEAR && EOS->form <= MOM6X_EOS_WRIGHT_REDUCED) &&
                    (EOS->Recon_Scheme >= 0 && EOS->Recon_Scheme <= 2) && (EOS->Recon_Scheme != 2 || nz >= 4))) {
     free(e); free(pa); free(dpa); free(intz_dpa); free(intx_pa); free(inty_pa); free(intx_dpa); free(inty_dpa); free(dz_geo);
     return MOM6X_EUNSUPPORTED;
@@ -778,14 +807,23 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
           intz_dpa[x3] = 0.5 * G_e * (rho_anom - C1_6 * EOS->dRho_dp * (GxRho * dz)) * (dz * dz);
         } else {                               /* MOM_EOS_Wright.F90:554-577 */
           double al0, p0, lambda;
-          wright_coefs(Tk[x], Sk[x], &al0, &p0, &lambda);
+          wright_coefs(EOS->form, Tk[x], Sk[x], &al0, &p0, &lambda);
           const double I_al0 = 1.0 / al0;
-          const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
-          const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
-          const double rho_anom = (p0 + p_ave) * (I_Lzz * I_al0) - rho_ref;
-          const double rem = I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2)));
-          dpa[x3] = 1.0 * (G_e * rho_anom * dz - 2.0 * eps * rem);
-          intz_dpa[x3] = 1.0 * (0.5 * G_e * rho_anom * (dz * dz) - dz * (1.0 + eps) * rem);
+          if (EOS->form == MOM6X_EOS_WRIGHT) {
+            const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+            const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
+            const double rho_anom = (p0 + p_ave) * (I_Lzz * I_al0) - rho_ref;
+            const double rem = I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2)));
+            dpa[x3] = 1.0 * (G_e * rho_anom * dz - 2.0 * eps * rem);
+            intz_dpa[x3] = 1.0 * (0.5 * G_e * rho_anom * (dz * dz) - dz * (1.0 + eps) * rem);
+          } else {                           /* MOM_EOS_Wright_full.F90:550-572 */
+            const double I_Lzz = 1.0 / ((p0 + p_ave) + lambda * I_al0);
+            const double eps = 0.5 * (GxRho * dz) * I_Lzz, eps2 = eps * eps;
+            const double rho_anom = (p0 + p_ave) * (I_Lzz * I_al0) - rho_ref;
+            const double rem = (I_Rho * (lambda * (I_al0 * I_al0))) * (eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2))));
+            dpa[x3] = 1.0 * ((G_e * rho_anom) * dz - 2.0 * eps * rem);
+            intz_dpa[x3] = 1.0 * (0.5 * (G_e * rho_anom) * (dz * dz) - dz * ((1.0 + eps) * rem));
+          }
         }
       }
       for (int dir = 0; dir < 2; dir++) {
@@ -799,7 +837,7 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
                                                 zb[y], z0[x], z0[y], bathyT[x], bathyT[y], e[x], e[y], dz_neglect, dpa[x + k * slab],
                                                 dpa[y + k * slab]);
           else
-            out[x + k * slab] = face_int_wright(rho_ref, G_e, GxRho, I_Rho, do_mw, top_mw, Tk[x], Sk[x], Tk[y], Sk[y], zt[x], zb[x], zt[y],
+            out[x + k * slab] = face_int_wright(EOS->form, rho_ref, G_e, GxRho, I_Rho, do_mw, top_mw, Tk[x], Sk[x], Tk[y], Sk[y], zt[x], zb[x], zt[y],
                                                 zb[y], z0[x], z0[y], bathyT[x], bathyT[y], e[x], e[y], dz_neglect, dpa[x + k * slab],
                                                 dpa[y + k * slab]);
         }

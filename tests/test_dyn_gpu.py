@@ -110,7 +110,7 @@ def test_PressureForce(orc, cfg, bug):
 
 
 @pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
-@pytest.mark.parametrize("form", ["LINEAR", "WRIGHT"])
+@pytest.mark.parametrize("form", ["LINEAR", "WRIGHT", "WRIGHT_FULL", "WRIGHT_REDUCED"])
 @pytest.mark.parametrize("mods", [dict(), dict(MassWghtInterp=1), dict(MassWghtInterp=3, use_SSH_in_Z0p=1, bug=0, dRho_dp=4.5e-7),
                                   # the ALE path: TS_PLM_edge_values + int_density_dz_generic_plm (PRESSURE_RECONSTRUCTION_SCHEME = 1)
                                   dict(Recon_Scheme=1), dict(Recon_Scheme=1, boundary_extrap=0, MassWghtInterp=1),

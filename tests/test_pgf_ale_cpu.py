@@ -60,11 +60,23 @@ def test_density_anomaly_against_reference_check_values(orc):
     for rho_ref in (0.0, 1000.0, 1035.0):
         r = orc.eos_density_anomaly(ew, 25.0, 35.0, 1.0e7, rho_ref)
         assert abs((r + rho_ref) - 1027.54303596346) < 1000 * 2.2e-16 * 1027.5
+    # WRIGHT_FULL :2058-2060, WRIGHT_REDUCED :2064-2066 -- through density_elem and through the rho_ref form
+    for form, check in ((abi.WRIGHT_FULL, 1027.55177447616), (abi.WRIGHT_REDUCED, 1027.54303596346), (abi.WRIGHT, 1027.54303596346)):
+        e = abi.eos_params_default(form)
+        assert abs(orc.eos_density(e, 25.0, 35.0, 1.0e7) - check) < 1000 * 2.2e-16 * 1027.5
+        for rho_ref in (0.0, 1000.0, 1035.0):
+            assert abs((orc.eos_density_anomaly(e, 25.0, 35.0, 1.0e7, rho_ref) + rho_ref) - check) < 1000 * 2.2e-16 * 1027.5
+        # calculate_density_derivs against centred differences of the density (what test_EOS_consistency :2400-2440 checks)
+        dT, dS = 1e-3, 1e-3
+        dRdT, dRdS = orc.eos_density_derivs(e, 25.0, 35.0, 1.0e7)
+        fT = (orc.eos_density(e, 25.0 + dT, 35.0, 1.0e7) - orc.eos_density(e, 25.0 - dT, 35.0, 1.0e7)) / (2 * dT)
+        fS = (orc.eos_density(e, 25.0, 35.0 + dS, 1.0e7) - orc.eos_density(e, 25.0, 35.0 - dS, 1.0e7)) / (2 * dS)
+        assert abs(dRdT - fT) < 1e-7 * abs(fT) and abs(dRdS - fS) < 1e-7 * abs(fS)
     el = abi.eos_params_default(abi.LINEAR)
     assert orc.eos_density_anomaly(el, 10.0, 30.0, 0.0, 1000.0) == (el.Rho_T0_S0 - 1000.0) + (el.dRho_dT * 10.0 + el.dRho_dS * 30.0)
 
 
-@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
+@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT, abi.WRIGHT_FULL, abi.WRIGHT_REDUCED])
 def test_PLM_quadrature_reduces_to_the_analytic_integrals(orc, form):
     """With T and S uniform in the vertical the PLM edge values are the layer values, and the Boole quadratures of
     int_density_dz_generic_plm integrate the same density field the analytic routines integrate exactly: PFu, PFv of the two
@@ -143,7 +155,7 @@ def test_TS_PPM_edge_values_properties(orc, extrap):
     assert np.abs(Qb - Qt)[(Ellipsis,) + sl].max() > 1e-3
 
 
-@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
+@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT, abi.WRIGHT_FULL, abi.WRIGHT_REDUCED])
 @pytest.mark.parametrize("recon", [2, "quadrature"])
 def test_resting_stratified_ocean_feels_no_force_with_ppm_or_quadrature(orc, form, recon):
     gg, d, M = H.channel(nk=6)
@@ -163,7 +175,7 @@ def test_resting_stratified_ocean_feels_no_force_with_ppm_or_quadrature(orc, for
     assert np.abs(Pv[(Ellipsis,) + sv] * M[G["mask2dCv"]][sv]).max() < 1e-12
 
 
-@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
+@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT, abi.WRIGHT_FULL, abi.WRIGHT_REDUCED])
 def test_resting_stratified_ocean_feels_no_force_with_reconstruction(orc, form):
     gg, d, M = H.channel()
     GV = abi.vgrid_default(); CS = abi.pgf_params_default(GV.Rho0)

@@ -176,7 +176,7 @@ def test_rk2_device_matches_committed_golden(orc):
 
 
 @pytest.mark.parametrize("recon", [0, 1, 2, "quadrature"])
-@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT])
+@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT, abi.WRIGHT_FULL, abi.WRIGHT_REDUCED], ids=["LINEAR", "WRIGHT", "WRIGHT_FULL", "WRIGHT_REDUCED"])
 def test_rk2_with_equation_of_state(orc, form, recon):
     run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(begw=0.2), eos_form=form, recon=recon)
 
