@@ -246,9 +246,10 @@ typedef struct mom6x_hor_visc_params {
  * PressureForce_FV_CS that only matter with an equation of state.  Analytic density integrals
  * (analytic_int_density_dz, MOM_EOS.F90:1384) exist for EOS_LINEAR and the WRIGHT family: LINEAR, WRIGHT (the default,
  * MOM_EOS_Wright.F90), WRIGHT_FULL (MOM_EOS_Wright_full.F90) and WRIGHT_REDUCED (MOM_EOS_Wright_red.F90) are carried, each
- * with the analytic integrals and, with EOS_QUADRATURE or a pressure reconstruction, the generic quadratures.  The other
- * equations of state (UNESCO, NEMO / ROQUET_*, JACKETT_06, TEOS10) have no analytic integrals and are refused.      */
-enum mom6x_eos_form { MOM6X_EOS_LINEAR = 1, MOM6X_EOS_WRIGHT = 2, MOM6X_EOS_WRIGHT_FULL = 3, MOM6X_EOS_WRIGHT_REDUCED = 4 };
+ * with the analytic integrals and, with EOS_QUADRATURE or a pressure reconstruction, the generic quadratures.  UNESCO
+ * (MOM_EOS_UNESCO.F90) has no analytic integrals: it needs EOS_QUADRATURE or a pressure reconstruction, as in the reference
+ * ("No analytic integration option is available with this EOS!").  NEMO / ROQUET_*, JACKETT_06 and TEOS10 are refused.   */
+enum mom6x_eos_form { MOM6X_EOS_LINEAR = 1, MOM6X_EOS_WRIGHT = 2, MOM6X_EOS_WRIGHT_FULL = 3, MOM6X_EOS_WRIGHT_REDUCED = 4, MOM6X_EOS_UNESCO = 5 };
 typedef struct mom6x_eos_params {
   int    form;            /* EQN_OF_STATE                                                       */
   double Rho_T0_S0;       /* RHO_T0_S0 (1000)  } EOS_LINEAR                                     */

@@ -309,7 +309,7 @@ def regrid_rho_params_default(**kw):
     return p
 
 
-LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED = 1, 2, 3, 4   # enum mom6x_eos_form
+LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO = 1, 2, 3, 4, 5   # enum mom6x_eos_form
 
 
 class EOSParams(C.Structure):

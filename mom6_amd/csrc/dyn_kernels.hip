@@ -883,6 +883,7 @@ template <int FORM>
 __device__ __forceinline__ double density_anomaly(const EosDev &E, double T, double S, double pressure, double rho_ref) {
   if (FORM == MOM6X_EOS_LINEAR)
     return (E.Rho_T0_S0 - rho_ref) + ((E.dRho_dT * T + E.dRho_dS * S) + E.dRho_dp * pressure);
+  if (FORM == MOM6X_EOS_UNESCO) return unesco::density_anomaly(T, S, pressure, rho_ref);
   typedef WC<FORM> W;   // the same expression in MOM_EOS_Wright.F90:119-128, _full.F90:108-119, _red.F90:108-119
   const double pa_000 = (W::b0 * (1.0 - W::a0 * rho_ref) - rho_ref * W::c0);
   const double al_TS = W::a1 * T + W::a2 * S;
@@ -1176,6 +1177,7 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
       if (k == 0) {
         double rho_in_situ;
         if (FORM == MOM6X_EOS_LINEAR) rho_in_situ = E.Rho_T0_S0 + E.dRho_dT * T0 + E.dRho_dS * S0 + E.dRho_dp * press;
+        else if (FORM == MOM6X_EOS_UNESCO) rho_in_situ = unesco::density(T0, S0, press);
         else {
           rho_in_situ = wright_density<FORM>(T0, S0, press);
         }
@@ -1184,6 +1186,7 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
         const double T_int = 0.5 * (T_prev + T0), S_int = 0.5 * (S_prev + S0);
         double dR_dT, dR_dS;
         if (FORM == MOM6X_EOS_LINEAR) { dR_dT = E.dRho_dT; dR_dS = E.dRho_dS; }
+        else if (FORM == MOM6X_EOS_UNESCO) unesco::density_derivs(T_int, S_int, press, dR_dT, dR_dS);
         else {
           typedef WC<FORM> W;
           double al0, p0, lambda;
@@ -1216,8 +1219,11 @@ extern "C" int mom6x_PressureForce_set_tv(mom6x_ctx *c, const double *T, const d
   REQUIRE(c, MOM6X_EINVAL, "mom6x_PressureForce_set_tv: null ctx");
   if (!T) { c->tv_T = nullptr; c->tv_S = nullptr; return MOM6X_OK; }
   REQUIRE(S && eos, MOM6X_EINVAL, "mom6x_PressureForce_set_tv: tv%T without tv%S or tv%eqn_of_state");
-  REQUIRE(eos->form >= MOM6X_EOS_LINEAR && eos->form <= MOM6X_EOS_WRIGHT_REDUCED, MOM6X_EUNSUPPORTED,
-          "PressureForce: EQN_OF_STATE must be LINEAR, WRIGHT, WRIGHT_FULL or WRIGHT_REDUCED");
+  REQUIRE(eos->form >= MOM6X_EOS_LINEAR && eos->form <= MOM6X_EOS_UNESCO, MOM6X_EUNSUPPORTED,
+          "PressureForce: EQN_OF_STATE must be LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED or UNESCO");
+  // analytic_int_density_dz, MOM_EOS.F90:1495-1496
+  REQUIRE(eos->form != MOM6X_EOS_UNESCO || eos->EOS_quadrature || eos->Recon_Scheme, MOM6X_EUNSUPPORTED,
+          "No analytic integration option is available with this EOS!");
   REQUIRE(eos->Recon_Scheme >= 0 && eos->Recon_Scheme <= 2, MOM6X_EINVAL,
           "PressureForce_FV_init: PRESSURE_RECONSTRUCTION_SCHEME must be 1 (PLM) or 2 (PPM), or 0 without RECONSTRUCT_FOR_PRESSURE");
   REQUIRE(eos->Recon_Scheme != 2 || c->dims.nk >= 4, MOM6X_EUNSUPPORTED,
@@ -1279,7 +1285,11 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
                                     rho0_alt, GV.H_subroundoff, GV.dZ_subroundoff)
 #define PGF_FORM(F, N) do { if (mode == 1) PGF_EOS(F, 1, "k_pgf_main_plm<" N ">"); else if (mode == 2) PGF_EOS(F, 2, "k_pgf_main_ppm<" N ">"); \
                             else if (mode == 3) PGF_EOS(F, 3, "k_pgf_main_pcm<" N ">"); else PGF_EOS(F, 0, "k_pgf_main_eos<" N ">"); } while (0)
-    if (E.form == MOM6X_EOS_LINEAR) PGF_FORM(MOM6X_EOS_LINEAR, "linear");
+    if (E.form == MOM6X_EOS_UNESCO) {   // quadratures only
+      if (mode == 1) PGF_EOS(MOM6X_EOS_UNESCO, 1, "k_pgf_main_plm<unesco>");
+      else if (mode == 2) PGF_EOS(MOM6X_EOS_UNESCO, 2, "k_pgf_main_ppm<unesco>");
+      else PGF_EOS(MOM6X_EOS_UNESCO, 3, "k_pgf_main_pcm<unesco>");
+    } else if (E.form == MOM6X_EOS_LINEAR) PGF_FORM(MOM6X_EOS_LINEAR, "linear");
     else if (E.form == MOM6X_EOS_WRIGHT_FULL) PGF_FORM(MOM6X_EOS_WRIGHT_FULL, "wright_full");
     else if (E.form == MOM6X_EOS_WRIGHT_REDUCED) PGF_FORM(MOM6X_EOS_WRIGHT_REDUCED, "wright_red");
     else PGF_FORM(MOM6X_EOS_WRIGHT, "wright");

@@ -312,9 +312,61 @@ static void wright_coefs(int form, double T, double S, double *al0, double *p0, 
   }
 }
 
+/* EQN_OF_STATE = "UNESCO" (MOM_EOS_UNESCO.F90): UNESCO (1981) as refit by Jackett and McDougall (1995).  Rab: the S^a T^b term of the
+ * one-atmosphere density (6 = power 1.5), Sabc: the S^a T^b p^c term of the secant bulk modulus; pressure in bar. */
+static const double U_R00 = 999.842594, U_R01 = 6.793952e-2, U_R02 = -9.095290e-3, U_R03 = 1.001685e-4, U_R04 = -1.120083e-6, U_R05 = 6.536332e-9;
+static const double U_R10 = 0.824493, U_R11 = -4.0899e-3, U_R12 = 7.6438e-5, U_R13 = -8.2467e-7, U_R14 = 5.3875e-9;
+static const double U_R60 = -5.72466e-3, U_R61 = 1.0227e-4, U_R62 = -1.6546e-6, U_R20 = 4.8314e-4;
+static const double U_S000 = 1.965933e4, U_S010 = 1.444304e2, U_S020 = -1.706103, U_S030 = 9.648704e-3, U_S040 = -4.190253e-5;
+static const double U_S100 = 52.84855, U_S110 = -3.101089e-1, U_S120 = 6.283263e-3, U_S130 = -5.084188e-5;
+static const double U_S600 = 3.886640e-1, U_S610 = 9.085835e-3, U_S620 = -4.619924e-4;
+static const double U_S001 = 3.186519, U_S011 = 2.212276e-2, U_S021 = -2.984642e-4, U_S031 = 1.956415e-6;
+static const double U_S101 = 6.704388e-3, U_S111 = -1.847318e-4, U_S121 = 2.059331e-7, U_S601 = 1.480266e-4;
+static const double U_S002 = 2.102898e-4, U_S012 = -1.202016e-5, U_S022 = 1.394680e-7, U_S102 = -2.040237e-6, U_S112 = 6.128773e-8, U_S122 = 6.207323e-10;
+
+static double unesco_sig0(double t1, double s1, double s12) {   /* :114-116 */
+  return (t1 * (U_R01 + t1 * (U_R02 + t1 * (U_R03 + t1 * (U_R04 + t1 * U_R05)))) +
+          s1 * ((U_R10 + t1 * (U_R11 + t1 * (U_R12 + t1 * (U_R13 + t1 * U_R14)))) + (s12 * (U_R60 + t1 * (U_R61 + t1 * U_R62)) + s1 * U_R20)));
+}
+static double unesco_ks(double t1, double s1, double s12, double p1) {   /* :120-124 */
+  return (U_S000 + (t1 * (U_S010 + t1 * (U_S020 + t1 * (U_S030 + t1 * U_S040))) +
+                    s1 * ((U_S100 + t1 * (U_S110 + t1 * (U_S120 + t1 * U_S130))) + s12 * (U_S600 + t1 * (U_S610 + t1 * U_S620))))) +
+         p1 * ((U_S001 + (t1 * (U_S011 + t1 * (U_S021 + t1 * U_S031)) + s1 * ((U_S101 + t1 * (U_S111 + t1 * U_S121)) + s12 * U_S601))) +
+               p1 * (U_S002 + (t1 * (U_S012 + t1 * U_S022) + s1 * (U_S102 + t1 * (U_S112 + t1 * U_S122)))));
+}
+static double unesco_density(double T, double S, double pressure) {   /* density_elem_UNESCO :95-128 */
+  const double p1 = pressure * 1.0e-5, t1 = T, s1 = orc_max(S, 0.0), s12 = sqrt(s1);
+  const double rho0 = U_R00 + unesco_sig0(t1, s1, s12), ks = unesco_ks(t1, s1, s12, p1);
+  return rho0 * ks / (ks - p1);
+}
+static double unesco_density_anomaly(double T, double S, double pressure, double rho_ref) {   /* :133-167 */
+  const double p1 = pressure * 1.0e-5, t1 = T, s1 = orc_max(S, 0.0), s12 = sqrt(s1);
+  const double sig0 = unesco_sig0(t1, s1, s12), ks = unesco_ks(t1, s1, s12, p1);
+  return ((U_R00 - rho_ref) * ks + (sig0 * ks + p1 * rho_ref)) / (ks - p1);
+}
+static void unesco_density_derivs(double T, double S, double pressure, double *drho_dT, double *drho_dS) {   /* :244-297 */
+  const double p1 = pressure * 1.0e-5, t1 = T, s1 = orc_max(S, 0.0), s12 = sqrt(s1);
+  const double rho0 = U_R00 + unesco_sig0(t1, s1, s12);
+  const double drho0_dT = U_R01 + (t1 * (2.0 * U_R02 + t1 * (3.0 * U_R03 + t1 * (4.0 * U_R04 + t1 * (5.0 * U_R05)))) +
+                                   s1 * (U_R11 + (t1 * (2.0 * U_R12 + t1 * (3.0 * U_R13 + t1 * (4.0 * U_R14))) + s12 * (U_R61 + t1 * (2.0 * U_R62)))));
+  const double drho0_dS = U_R10 + (t1 * (U_R11 + t1 * (U_R12 + t1 * (U_R13 + t1 * U_R14))) +
+                                   (1.5 * (s12 * (U_R60 + t1 * (U_R61 + t1 * U_R62))) + s1 * (2.0 * U_R20)));
+  const double ks = unesco_ks(t1, s1, s12, p1);
+  const double dks_dT = (U_S010 + (t1 * (2.0 * U_S020 + t1 * (3.0 * U_S030 + t1 * (4.0 * U_S040))) +
+                                   s1 * ((U_S110 + t1 * (2.0 * U_S120 + t1 * (3.0 * U_S130))) + s12 * (U_S610 + t1 * (2.0 * U_S620))))) +
+                        p1 * (((U_S011 + t1 * (2.0 * U_S021 + t1 * (3.0 * U_S031))) + s1 * (U_S111 + t1 * (2.0 * U_S121))) +
+                              p1 * (U_S012 + t1 * (2.0 * U_S022) + s1 * (U_S112 + t1 * (2.0 * U_S122))));
+  const double dks_dS = (U_S100 + (t1 * (U_S110 + t1 * (U_S120 + t1 * U_S130)) + 1.5 * (s12 * (U_S600 + t1 * (U_S610 + t1 * U_S620))))) +
+                        p1 * ((U_S101 + t1 * (U_S111 + t1 * U_S121) + s12 * (1.5 * U_S601)) + p1 * (U_S102 + t1 * (U_S112 + t1 * U_S122)));
+  const double I_denom = 1.0 / (ks - p1);
+  *drho_dT = (ks * drho0_dT - dks_dT * ((rho0 * p1) * I_denom)) * I_denom;
+  *drho_dS = (ks * drho0_dS - dks_dS * ((rho0 * p1) * I_denom)) * I_denom;
+}
+
 /* calculate_density (no rho_ref): density_elem_linear MOM_EOS_linear.F90:66, density_elem_buggy_Wright :80-96, density_elem_Wright_full :73-89 */
 static double eos_density(const mom6x_eos_params *E, double T, double S, double p) {
   if (E->form == MOM6X_EOS_LINEAR) return E->Rho_T0_S0 + E->dRho_dT * T + E->dRho_dS * S + E->dRho_dp * p;
+  if (E->form == MOM6X_EOS_UNESCO) return unesco_density(T, S, p);
   double al0, p0, lambda;
   wright_coefs(E->form, T, S, &al0, &p0, &lambda);
   return (p + p0) / (lambda + al0 * (p + p0));
@@ -323,6 +375,7 @@ static double eos_density(const mom6x_eos_params *E, double T, double S, double 
 /* calculate_density_derivs: linear :117-134, Wright :178-206, Wright_full / _red :177-202 */
 static void eos_density_derivs(const mom6x_eos_params *E, double T, double S, double p, double *dRdT, double *dRdS) {
   if (E->form == MOM6X_EOS_LINEAR) { *dRdT = E->dRho_dT; *dRdS = E->dRho_dS; return; }
+  if (E->form == MOM6X_EOS_UNESCO) { unesco_density_derivs(T, S, p, dRdT, dRdS); return; }
   const wright_set *W = wright_of(E->form);
   double al0, p0, lambda;
   wright_coefs(E->form, T, S, &al0, &p0, &lambda);
@@ -441,6 +494,7 @@ static double face_int_wright(int form, double rho_ref, double G_e, double GxRho
 static double eos_density_anomaly(const mom6x_eos_params *E, double T, double S, double pressure, double rho_ref) {
   if (E->form == MOM6X_EOS_LINEAR)
     return (E->Rho_T0_S0 - rho_ref) + ((E->dRho_dT * T + E->dRho_dS * S) + E->dRho_dp * pressure);
+  if (E->form == MOM6X_EOS_UNESCO) return unesco_density_anomaly(T, S, pressure, rho_ref);
   const wright_set *W = wright_of(E->form);   /* the same expression in all three Wright modules (_full.F90:108-119) */
   const double pa_000 = (W->b0 * (1.0 - W->a0 * rho_ref) - rho_ref * W->c0);
   const double al_TS = W->a1 * T + W->a2 * S;
@@ -700,7 +754,8 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
     pa[x] = GxRho_ref * (e[x] - Z_ref);
   }
   const int use_EOS = (T != NULL);
-  if (use_EOS && !(EOS && S && (EOS->form >= MOM6X_EOS_LINEAR && EOS->form <= MOM6X_EOS_WRIGHT_REDUCED) &&
+  if (use_EOS && !(EOS && S && (EOS->form >= MOM6X_EOS_LINEAR && EOS->form <= MOM6X_EOS_UNESCO) &&
+                   (EOS->form != MOM6X_EOS_UNESCO || EOS->EOS_quadrature || EOS->Recon_Scheme) &&   /* no analytic integrals: MOM_EOS.F90:1495 */
                    (EOS->Recon_Scheme >= 0 && EOS->Recon_Scheme <= 2) && (EOS->Recon_Scheme != 2 || nz >= 4))) {
     free(e); free(pa); free(dpa); free(intz_dpa); free(intx_pa); free(inty_pa); free(intx_dpa); free(inty_dpa); free(dz_geo);
     return MOM6X_EUNSUPPORTED;

@@ -61,7 +61,9 @@ def test_density_anomaly_against_reference_check_values(orc):
         r = orc.eos_density_anomaly(ew, 25.0, 35.0, 1.0e7, rho_ref)
         assert abs((r + rho_ref) - 1027.54303596346) < 1000 * 2.2e-16 * 1027.5
     # WRIGHT_FULL :2058-2060, WRIGHT_REDUCED :2064-2066 -- through density_elem and through the rho_ref form
-    for form, check in ((abi.WRIGHT_FULL, 1027.55177447616), (abi.WRIGHT_REDUCED, 1027.54303596346), (abi.WRIGHT, 1027.54303596346)):
+    # UNESCO :2052-2054
+    for form, check in ((abi.WRIGHT_FULL, 1027.55177447616), (abi.WRIGHT_REDUCED, 1027.54303596346), (abi.WRIGHT, 1027.54303596346),
+                        (abi.UNESCO, 1027.54345796120)):
         e = abi.eos_params_default(form)
         assert abs(orc.eos_density(e, 25.0, 35.0, 1.0e7) - check) < 1000 * 2.2e-16 * 1027.5
         for rho_ref in (0.0, 1000.0, 1035.0):
@@ -122,6 +124,30 @@ def test_PLM_quadrature_reduces_to_the_analytic_integrals(orc, form):
     big = np.abs(out[0][(Ellipsis,) + su]).max()
     assert np.abs(out[1] - out[0])[(Ellipsis,) + su].max() > 1e-6 * big
     assert np.abs(out[2] - out[1])[(Ellipsis,) + su].max() > 1e-8 * big      # the parabolas are not the lines
+
+
+def test_unesco_needs_the_quadratures(orc):
+    """analytic_int_density_dz has no UNESCO branch (MOM_EOS.F90:1495: "No analytic integration option is available with this
+    EOS!"): refused without EOS_QUADRATURE or a pressure reconstruction; with either, a resting stratified ocean feels no force."""
+    gg, d, M = H.channel(nk=6)
+    GV = abi.vgrid_default(); CS = abi.pgf_params_default(GV.Rho0)
+    Rlay, gp = abi.layer_densities(d.nk, GV.Rho0, GV.g_Earth)
+    h = np.full(d.shape3(), 1000.0 / d.nk)
+    T = np.zeros_like(h); S = np.zeros_like(h)
+    for k in range(d.nk):
+        T[k] = 18.0 - 3.0 * k; S[k] = 34.0 + 0.3 * k
+    Pu, Pv = np.zeros_like(h), np.zeros_like(h)
+    with pytest.raises(RuntimeError):
+        orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, T=T, S=S, eos=abi.eos_params_default(abi.UNESCO))
+    su, sv = H.interior(d, "u"), H.interior(d, "v")
+    for mods in (dict(EOS_quadrature=1), dict(Recon_Scheme=1), dict(Recon_Scheme=2, MassWghtInterp=3)):
+        eos = abi.eos_params_default(abi.UNESCO)
+        for k, v in mods.items(): setattr(eos, k, v)
+        pb = np.zeros_like(h)
+        orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, pbce=pb, T=T, S=S, eos=eos)
+        assert np.abs(Pu[(Ellipsis,) + su] * M[G["mask2dCu"]][su]).max() < 1e-12
+        assert np.abs(Pv[(Ellipsis,) + sv] * M[G["mask2dCv"]][sv]).max() < 1e-12
+        assert np.isfinite(pb).all() and pb[0][H.interior(d, "h")].min() > 9.0     # g * rho / Rho0 at the surface
 
 
 @pytest.mark.parametrize("extrap", [0, 1])

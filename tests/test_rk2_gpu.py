@@ -175,9 +175,16 @@ def test_rk2_device_matches_committed_golden(orc):
         H.assert_bitwise(out[n][(Ellipsis,) + tuple(H.interior(d, STAG[n]))], gold[n], "golden:" + n)
 
 
+@pytest.mark.parametrize("recon", [1, 2, "quadrature"])
+def test_rk2_with_the_unesco_equation_of_state(orc, recon):
+    """EQN_OF_STATE = UNESCO, which has no analytic integrals: the whole step through the quadratures, bit for bit."""
+    run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), eos_form=abi.UNESCO, recon=recon)
+
+
 @pytest.mark.parametrize("recon", [0, 1, 2, "quadrature"])
 @pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT, abi.WRIGHT_FULL, abi.WRIGHT_REDUCED], ids=["LINEAR", "WRIGHT", "WRIGHT_FULL", "WRIGHT_REDUCED"])
 def test_rk2_with_equation_of_state(orc, form, recon):
+    """LINEAR and the Wright family: the analytic integrals (recon = 0) or the quadratures."""
     run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(begw=0.2), eos_form=form, recon=recon)
 
 
