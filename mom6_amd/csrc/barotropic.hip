@@ -443,6 +443,8 @@ struct LoopArgs {
   int project, bracket_bug, find_etaav;
   int f4_on_the_fly, Sadourny;   // the Coriolis weights recomputed from q, D_u_Cor, D_v_Cor in the velocity kernels
   int store_uhn, have_uhn;       // the velocity kernels leave W_uhn / W_vhn for the next predictor; this predictor finds them
+  int pred_next;                 // k_bt_eta also forms the NEXT sub-step's eta predictor (same points, no exchange in between)
+  double wt_accel2_next;
   int isv, iev, jsv, jev;   // valid range of this step
 };
 
@@ -590,6 +592,14 @@ k_bt_eta(Dm d, const double *__restrict__ G, double *work, LoopArgs A, double Z_
                    (A.dtbt * gm(G, d, MOM6X_G_IareaT)[c]) * ((uhbt[c - 1] - uhbt[c]) + (vhbt[c - st] - vhbt[c]));
   work[W_eta * slab + c] = e;
   if (A.wt_eta != 0.0) work[W_eta_wtd * slab + c] = work[W_eta_wtd * slab + c] + e * A.wt_eta;
+  if (A.pred_next) {   // btloop_eta_predictor of sub-step n + 1 (k_bt_pred's expressions): its range is this kernel's range, its
+    const double *uhn = work + W_uhn * slab, *vhn = work + W_vhn * slab;   // transports are W_uhn / W_vhn, its eta is e
+    const double eta_PF_BT = (e + work[W_eta_src * slab + c]) +
+                             (A.dtbt * gm(G, d, MOM6X_G_IareaT)[c]) * ((uhn[c - 1] - uhn[c]) + (vhn[c - st] - vhn[c]));
+    work[W_eta_pred * slab + c] = eta_PF_BT;
+    if (A.find_etaav && (fabs(A.wt_accel2_next) > 0.0) && i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1)
+      work[W_eta_sum * slab + c] = work[W_eta_sum * slab + c] + A.wt_accel2_next * eta_PF_BT;
+  }
   // :2738-2745 (Boussinesq): unphysical sea surface height over the computational domain -- counted, the first one kept
   if (i >= 0 && i < d.ni && j >= 0 && j < d.nj) {
     const double bT = gm(G, d, MOM6X_G_bathyT)[c];
@@ -993,6 +1003,11 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   static const bool pred_self = [] { const char *e = getenv("MOM6X_BT_PRED"); return e && !strcmp(e, "self"); }();
   const bool pass_uhn = !pred_self && !P.clip_velocity && !P.BT_project_velocity;
   L.store_uhn = pass_uhn ? 1 : 0;
+  // ... and when no exchange separates two sub-steps (three times out of four with a halo of 4), the eta corrector of the
+  // first forms the predictor of the second on the way: same points, the new eta still in a register (MOM6X_BT_PRED=own
+  // keeps the predictor's own launch).
+  static const bool pred_own = [] { const char *e = getenv("MOM6X_BT_PRED"); return e && !strcmp(e, "own"); }();
+  bool pred_done = false;
   for (int n = 1; n <= nt; n++) {
     if (P.clip_velocity)
       KLAUNCH(c, "k_bt_clip", k_bt_clip, grid3(iev - isv + 2, jev - jsv + 2, 1, b), b, d, c->G, work, dt, P.CFL_trunc, isv, iev, jsv, jev);
@@ -1005,8 +1020,12 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     }
     L.isv = isv; L.iev = iev; L.jsv = jsv; L.jev = jev;
     L.wt_accel = wt_accel[n]; L.wt_trans = wt_trans[n]; L.wt_vel = wt_vel[n]; L.wt_eta = wt_eta[n]; L.wt_accel2 = wt_accel2[n];
-    if (!P.BT_project_velocity || L.find_etaav)
+    if ((!P.BT_project_velocity || L.find_etaav) && !pred_done)
       KLAUNCH(c, "k_bt_pred", k_bt_pred, grid3(nxa(iev - isv + 3, isv - 1), jev - jsv + 3, 1, b), b, d, c->G, work, L);
+    // the next sub-step: no exchange before it (:2505-2512) and its transports passed on by this one's velocity kernels
+    pred_done = pass_uhn && !pred_own && n < nt && !((iev - stencil < ie) || (jev - stencil < je));
+    L.pred_next = pred_done ? 1 : 0;
+    L.wt_accel2_next = pred_done ? wt_accel2[n + 1] : 0.0;
     const bool v_first = (((n + c->first_direction) % 2) == 1);
     if (v_first) {
       KLAUNCH(c, "k_bt_vel<1>", k_bt_vel<1>, grid3(nxa(iev - isv + 3, isv - 1), jev - jsv + 2, 1, b), b, d, c->G, work, s->vbtav, vhbtav, L,
