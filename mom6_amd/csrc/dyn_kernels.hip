@@ -145,7 +145,9 @@ __device__ __forceinline__ double robust_heff(double tr, double Idl, double vel,
   return dmin(He, dmax(hA, hB));
 }
 struct NoIhq { __device__ double operator()(int, int) const { return 0.0; } };
-template <class QF, class KF, class AF, class IF = NoIhq>
+// ALL: with the three schemes only the two-kernel form runs (ROBUST_ENSTRO, ARAKAWA_LAMB81, ARAKAWA_LAMB_BLEND).  k_corad_fused
+// compiles them OUT: merely present, never taken, they cost it 14 spilled registers (3.6 instead of 2.0 ms per call).
+template <bool ALL, class QF, class KF, class AF, class IF = NoIhq>
 __device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int st, const QF &Q, const KF &KEf, const AF &AVf,
                                                 const IF &IH = NoIhq()) {
   const double *__restrict__ u = X.u, *__restrict__ v = X.v, *__restrict__ uh = X.uh, *__restrict__ vh = X.vh, *__restrict__ h = X.h;
@@ -194,7 +196,7 @@ __device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int
         ca = 0.25 * ((q00 * (vh[c + 1] + vh[c])) + (q0m * (vh[c - st] + vh[c + 1 - st]))) * IdxCu;
       } else if (scheme == MOM6X_SADOURNY75_ENSTRO) {
         ca = 0.125 * (IdxCu * (q00 + q0m)) * ((vh[c + 1] + vh[c]) + (vh[c - st] + vh[c + 1 - st]));
-      } else if (scheme == MOM6X_ARAKAWA_HSU90) {   // :523-533, :683-686
+      } else if (!ALL || scheme == MOM6X_ARAKAWA_HSU90) {   // :523-533, :683-686
         const double a = (q00 + (Q(1, 0) + q0m)) * C1_12;
         const double dd = ((q00 + Q(1, -1)) + q0m) * C1_12;
         const double b = (q00 + (Q(-1, 0) + q0m)) * C1_12;
@@ -251,7 +253,7 @@ __device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int
         ca = -0.25 * ((qm0 * (uh[c - 1] + uh[c - 1 + st])) + (q00 * (uh[c] + uh[c + st]))) * IdyCv;
       } else if (scheme == MOM6X_SADOURNY75_ENSTRO) {
         ca = -0.125 * (IdyCv * (qm0 + q00)) * ((uh[c - 1] + uh[c - 1 + st]) + (uh[c] + uh[c + st]));
-      } else if (scheme == MOM6X_ARAKAWA_HSU90) {
+      } else if (!ALL || scheme == MOM6X_ARAKAWA_HSU90) {
         // a(I-1,j), c(I,j+1), b(I,j), d(I-1,j+1)
         const double a_m = (qm0 + (q00 + Q(-1, -1))) * C1_12;
         const double c_p = ((Q(0, 1) + Q(-1, 0)) + q00) * C1_12;
@@ -330,8 +332,8 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
     }
   for (int k = k0; k < k1; k++) {
     const size_t c = x + (size_t)k * slab;
-    corad_acc_layer(X, c, st, [&](int di, int dj) { return q[c + di + dj * st]; }, [&](int di, int dj) { return KE[c + di + dj * st]; },
-                    [&](int di, int dj) { return absv[c + di + dj * st]; }, [&](int di, int dj) { return Ihq[c + di + dj * st]; });
+    corad_acc_layer<true>(X, c, st, [&](int di, int dj) { return q[c + di + dj * st]; }, [&](int di, int dj) { return KE[c + di + dj * st]; },
+                          [&](int di, int dj) { return absv[c + di + dj * st]; }, [&](int di, int dj) { return Ihq[c + di + dj * st]; });
   }
 }
 
@@ -437,8 +439,8 @@ k_corad_fused(Dm d, const double *__restrict__ G, const double *__restrict__ u, 
         uhtr[c] = uhtr[c] + uh[c] * dt_tr;
         vhtr[c] = vhtr[c] + vh[c] * dt_tr;
       }
-      corad_acc_layer(X, c, st, [&](int di, int dj) { return sq[l + di + dj * CF_LDW]; }, [&](int di, int dj) { return sk[l + di + dj * CF_LDW]; },
-                      [&](int di, int dj) { return sa[l + di + dj * CF_LDW]; });
+      corad_acc_layer<false>(X, c, st, [&](int di, int dj) { return sq[l + di + dj * CF_LDW]; }, [&](int di, int dj) { return sk[l + di + dj * CF_LDW]; },
+                             [&](int di, int dj) { return sa[l + di + dj * CF_LDW]; });
     }
     // (the layer after next writes this buffer again: the barrier of the next layer lies in between)
   }

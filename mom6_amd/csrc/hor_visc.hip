@@ -7,11 +7,11 @@
 //
 // The reference works one layer at a time on 2-D temporaries.  Here the chain
 //     (u, v) -> sh_xx, sh_xy -> Del2u, Del2v -> str_xx, str_xy -> diffu, diffv
-// is four 3-D kernels (column walk over KCHUNK layers with the 2-D coefficient planes in registers where it
-// pays); every stage reads its predecessor's output at neighbouring points, so the stages cannot be fused without
-// tile halos -- k_hv_fused below does that (LDS tiles with a 3-cell halo, 20 -> ~7 words per cell-layer) and is
-// SLOWER: the chain is instruction-bound, not traffic-bound.  h_u, h_v, hq, Shear_mag, hrat_min, the viscosities and the strain
-// derivatives are recomputed where they are needed instead of being stored.
+// is either ONE kernel (k_hv_fused, the default: LDS tiles with a 3-cell halo, every stage computed on the whole tile, 20 -> ~7
+// words per cell-layer, 4.75 ms per call at 1440 x 1080 x 75) or four 3-D kernels (column walk over KCHUNK layers with the 2-D
+// coefficient planes in registers where it pays; 6.0 ms; MOM6X_HORVISC=legacy and every Leith configuration).  h_u, h_v, hq,
+// Shear_mag, hrat_min, the viscosities and the strain derivatives are recomputed where they are needed instead of being stored.
+#include <algorithm>
 #include "mom6x_dev.h"
 
 void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);  // halo.hip
@@ -664,11 +664,11 @@ k_hv_accel(Dm d, const double *__restrict__ G, const double *__restrict__ P, con
 // minus a frame of HT_H = 3 points, and that is all that is stored.  The four metric planes del2 and accel read at neighbouring
 // points (dx2q, dy2q, dy2h, dx2h) sit in LDS for the life of the work-group.  Arithmetic: the expressions of k_hv_strain,
 // k_hv_del2, k_hv_stress and k_hv_accel, unchanged -- results are bit-identical with the four-kernel path
-// (the default; MOM6X_HORVISC=fused selects this kernel; Leith always takes the four kernels).  3 reads (x the tile's halo overhead) + 2 writes per cell-layer
+// (MOM6X_HORVISC=legacy; Leith always takes the four kernels).  3 reads (x the tile's halo overhead) + 2 writes per cell-layer
 // instead of 20.
 #define HT_H 3
 template <int HT_X, int HT_Y>
-__global__ void __launch_bounds__(HT_X * HT_Y, 4)      // 4 wavefronts per SIMD: one 1024-thread or two 512-thread work-groups per CU
+__global__ void __launch_bounds__(HT_X * HT_Y, (HT_X * HT_Y >= 1024) ? 4 : 2)   // 1024 threads: 4 wavefronts per SIMD (128 registers, 56 spilled); 512: 2 per SIMD, none spilled
 k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom6x_hor_visc_params CS,
            const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ h,
            double *__restrict__ diffu, double *__restrict__ diffv, double h_neglect, int kc) {
@@ -957,14 +957,18 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
     return rc;
   const dim3 b = blk2();
   const double *P = c->hv_planes;
-  // MOM6X_HORVISC=fused: the four stages in one LDS-tiled kernel (k_hv_fused: 3 reads + 2 writes per cell-layer instead of 20).
-  // Measured round 3 at 1440 x 1080 x 75 (bench switches): 6.8 ms (64 x 16 tiles; 7.5 ms with 32 x 16) against 6.0 ms for the
-  // four kernels -- the chain is INSTRUCTION-bound (two square roots and nine FP64 divisions per point and layer, ~900
-  // instructions per layer in the fused form), and a tile recomputes the first two stages on its 3-point frame while its
-  // wavefronts wait at three barriers per layer.  Kept as a tested alternative, not the default.
-  static const bool fused = [] { const char *e = getenv("MOM6X_HORVISC"); return e && !strcmp(e, "fused"); }();
+  // Default: the four stages in one LDS-tiled kernel (k_hv_fused: 3 reads + 2 writes per cell-layer instead of 20);
+  // MOM6X_HORVISC=legacy: the four kernels.  Measured round 3 at 1440 x 1080 x 75 (bench switches): 4.75 ms on 32 x 16 tiles
+  // against 6.0 ms for the four kernels.  The first version was SLOWER (7.5 ms; 6.8 on 64 x 16 tiles) and was shelved as
+  // "instruction-bound": it had been compiled for four wavefronts per SIMD (128 registers) and kept 56 of its ~170 live values
+  // in scratch memory.  At two wavefronts per SIMD nothing spills; a 1024-thread tile cannot have that (16 wavefronts per
+  // work-group), so 64 x 16 stays the slower, tested alternative (MOM6X_HV_TILE=64).
+  static const bool fused = [] { const char *e = getenv("MOM6X_HORVISC"); return !(e && !strcmp(e, "legacy")); }();
   if (fused && !(CS.Leith_Kh || CS.Leith_Ah) && d.halo >= 4) {
-    const int kc = (d.nk % 25 == 0) ? 25 : ((d.nk >= KCHUNK) ? KCHUNK : d.nk);
+    static const int kc_env = [] { const char *e = getenv("MOM6X_HV_KC"); return e ? atoi(e) : 0; }();
+    // (layers per work-group: the whole column up to 80 layers -- the ~30 coefficient planes of a tile are then read once; 4.53 ms
+    //  against 4.68 with 25-layer chunks at nk = 75)
+    const int kc = (kc_env > 0) ? std::min(kc_env, d.nk) : ((d.nk <= 80) ? d.nk : ((d.nk % 25 == 0) ? 25 : KCHUNK));
     static const int wide = [] { const char *e = getenv("MOM6X_HV_TILE"); return e ? atoi(e) : 32; }();
     const int TX = (wide == 64) ? 64 : 32, TY = 16;
     const dim3 bt(TX, TY, 1);

@@ -88,15 +88,16 @@ def test_hor_visc_init_rejects_noslip_biharmonic():
     dyc.close()
 
 
-def test_fused_variant_is_bit_identical_too():
-    """MOM6X_HORVISC=fused (k_hv_fused: the four stages in one LDS-tiled kernel; slower than the four kernels, hor_visc.hip, and
-    therefore not the default) is held to the same oracle: this file again in a process with the switch set."""
+def test_the_other_variants_are_bit_identical_too():
+    """The default is k_hv_fused on 32 x 16 tiles (the four stages in one LDS-tiled kernel, hor_visc.hip).  The four-kernel chain
+    (MOM6X_HORVISC=legacy; what Leith configurations always take) and the 64 x 16 tiles are held to the same oracle: this file
+    again in a process with the switch set."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for tile in ("32", "64"):
-        env = dict(os.environ, MOM6X_HORVISC="fused", MOM6X_HV_TILE=tile)
+    for mode, tile in (("legacy", "32"), ("fused", "64")):
+        env = dict(os.environ, MOM6X_HORVISC=mode, MOM6X_HV_TILE=tile)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_horvisc_gpu.py"), "-m", "gpu", "-q", "-x",
-                            "-k", "not fused_variant"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+                            "-k", "not other_variants"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
         assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
