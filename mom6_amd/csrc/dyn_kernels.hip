@@ -344,23 +344,39 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
 // tile.  Two LDS buffers alternate between layers: one barrier per layer.  Same expressions, same bits as k_corad_q + k_corad_acc.
 #define CF_X 32
 #define CF_Y 16
+#ifndef CF_MINW
+#define CF_MINW 4
+#endif
 #define CF_LDW (CF_X + 2)
 #define CF_LDN ((CF_Y + 2) * CF_LDW)
-__global__ void __launch_bounds__(CF_X * CF_Y, 4)   // two work-groups (16 wavefronts) per CU: at most 128 registers
+__global__ void __launch_bounds__(CF_X * CF_Y, CF_MINW)   // 4: two work-groups (16 wavefronts) per CU, at most 128 registers
 k_corad_fused(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
               const double *__restrict__ uh, const double *__restrict__ vh, double *__restrict__ CAu,
               double *__restrict__ CAv, int scheme, int bound, const double *__restrict__ h, int en_dis,
               const double *__restrict__ PFu, const double *__restrict__ PFv, const double *__restrict__ diffu,
               const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc,
               double *__restrict__ uhtr, double *__restrict__ vhtr, double dt_tr, int no_slip, int ke_scheme, double vol_neglect,
-              int kc) {
+              int kc, int gx, int gy, int gz, int xcd_order) {
   __shared__ double lds[2 * 3 * CF_LDN];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = -2 + (int)blockIdx.x * (CF_X - 2) + tx;
-  const int j = -2 + (int)blockIdx.y * (CF_Y - 2) + ty;
+  // A 1-D grid of gx * gy * gz work-groups.  The hardware deals consecutive work-groups round-robin to the 8 XCDs (each with its
+  // own L2).  A tile row of 32 doubles starts anywhere in a 128-byte line (the tiles advance by 30), so a tile touches the lines of
+  // its x neighbours: with the plain order those neighbours sit on other XCDs and the shared lines come from HBM once per tile
+  // (measured 18.2 words per cell-layer for ~12 algorithmic).  xcd_order: XCD n walks a CONTIGUOUS run of tiles (x fastest), so
+  // the neighbour's lines are L2 hits.
+  int b = (int)blockIdx.x;
+  const int nb = gx * gy * gz;
+  if (xcd_order) {
+    const int per = (nb + 7) / 8;
+    b = (b % 8) * per + b / 8;
+  }
+  if (b >= nb) return;   // (the grid is padded to a multiple of 8; the whole work-group leaves)
+  const int bxi = b % gx, byi = (b / gx) % gy, bzi = b / (gx * gy);
+  const int i = -2 + bxi * (CF_X - 2) + tx;
+  const int j = -2 + byi * (CF_Y - 2) + ty;
   const int st = d.pitch;
   const size_t slab = (size_t)d.slab;
-  const int k0 = blockIdx.z * kc, k1 = min(k0 + kc, d.nk);
+  const int k0 = bzi * kc, k1 = min(k0 + kc, d.nk);
   const int l = (ty + 1) * CF_LDW + (tx + 1);
   const bool live = (i <= d.ni) && (j <= d.nj);                 // the range of k_corad_q: (-2..ni, -2..nj)
   const size_t x = live ? ix2(d, i, j) : ix2(d, 0, 0);
@@ -470,7 +486,7 @@ k_pgf_main(Dm d, const double *__restrict__ G, const double *__restrict__ h, con
            const double *__restrict__ Rlay, const double *__restrict__ g_prime, double *__restrict__ PFu,
            double *__restrict__ PFv, double *__restrict__ pbce, double *__restrict__ eta, double g_Earth,
            double H_to_Z, double Z_to_H, double rho_ref, double GxRho_ref, double Z_ref, double I_Rho0,
-           double h_neglect, double dz_neglect) {
+           double h_neglect, double dz_neglect, BcFold B) {
   const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni || j > d.nj) return;
@@ -499,8 +515,10 @@ k_pgf_main(Dm d, const double *__restrict__ G, const double *__restrict__ h, con
       const double dz1 = g_Earth * H_to_Z * h1;
       const double iz1 = 0.5 * R * dz1 * h1;
       const double intx_dpa = 0.5 * R * (dz0 + dz1);
-      PFu[c] = (((pa0 * h0 + iz0) - (pa1 * h1 + iz1)) + ((h1 - h0) * intx_pa - (e[cb + 1] - eb0) * intx_dpa * Z_to_H)) *
-               (cu / ((h0 + h1) + h_neglect));
+      const double pf = (((pa0 * h0 + iz0) - (pa1 * h1 + iz1)) + ((h1 - h0) * intx_pa - (e[cb + 1] - eb0) * intx_dpa * Z_to_H)) *
+                        (cu / ((h0 + h1) + h_neglect));
+      PFu[c] = pf;
+      if (B.u_bc) B.u_bc[c] = (B.CAu[c] + pf) + B.diffu[c];   // u_bc_accel of the predictor (RK2.F90:565-572) while PFu is at hand
       pa1 = pa1 + R * dz1;
       intx_pa = intx_pa + intx_dpa;
     }
@@ -509,8 +527,10 @@ k_pgf_main(Dm d, const double *__restrict__ G, const double *__restrict__ h, con
       const double dz2 = g_Earth * H_to_Z * h2;
       const double iz2 = 0.5 * R * dz2 * h2;
       const double inty_dpa = 0.5 * R * (dz0 + dz2);
-      PFv[c] = (((pa0 * h0 + iz0) - (pa2 * h2 + iz2)) + ((h2 - h0) * inty_pa - (e[cb + st] - eb0) * inty_dpa * Z_to_H)) *
-               (cv / ((h0 + h2) + h_neglect));
+      const double pf = (((pa0 * h0 + iz0) - (pa2 * h2 + iz2)) + ((h2 - h0) * inty_pa - (e[cb + st] - eb0) * inty_dpa * Z_to_H)) *
+                        (cv / ((h0 + h2) + h_neglect));
+      PFv[c] = pf;
+      if (B.v_bc) B.v_bc[c] = (B.CAv[c] + pf) + B.diffv[c];
       pa2 = pa2 + R * dz2;
       inty_pa = inty_pa + inty_dpa;
     }
@@ -756,9 +776,12 @@ int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h
   if (!two_kernels && fusable && d.halo >= 3) {   // q, KE, abs_vort through LDS (k_corad_fused); MOM6X_CORAD=legacy: through HBM
     const int kc = (d.nk % 25 == 0) ? 25 : ((d.nk >= KCHUNK) ? KCHUNK : d.nk);
     const dim3 bt(CF_X, CF_Y, 1);
-    const dim3 gt((d.ni + 1 + (CF_X - 2) - 1) / (CF_X - 2), (d.nj + 1 + (CF_Y - 2) - 1) / (CF_Y - 2), (d.nk + kc - 1) / kc);
+    const int gx = (d.ni + 1 + (CF_X - 2) - 1) / (CF_X - 2), gy = (d.nj + 1 + (CF_Y - 2) - 1) / (CF_Y - 2), gz = (d.nk + kc - 1) / kc;
+    static const int xcd_order = [] { const char *e = getenv("MOM6X_CORAD_ORDER"); return (e && !strcmp(e, "plain")) ? 0 : 1; }();
+    const dim3 gt((unsigned)(((gx * gy * gz + 7) / 8) * 8), 1, 1);
     KLAUNCH(c, "k_corad_fused", k_corad_fused, gt, bt, d, c->G, u, v, uh, vh, CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h,
-            c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr, c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc);
+            c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr, c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc, gx, gy, gz,
+            xcd_order);
     HIPCHK(hipGetLastError());
     return MOM6X_OK;
   }
@@ -1078,7 +1101,7 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
                double *__restrict__ PFu,
                double *__restrict__ PFv, double *__restrict__ pbce, double *__restrict__ eta, double g_Earth, double H_to_Z,
                double Z_to_H, double rho_ref, double GxRho_ref, double Z_ref, double Rho0, double rho0_alt, double h_neglect,
-               double dz_neglect) {
+               double dz_neglect, BcFold B) {
   const int i = I_BASE(-1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni || j > d.nj) return;
@@ -1139,8 +1162,10 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
                                   ssh0, ssh1, dz_neglect, dpa0, dpa1);
       }
       if (Z_to_H != 1.0) iz1 = iz1 * Z_to_H;
-      PFu[c] = (((pa0 * h0 + iz0) - (pa1 * h1 + iz1)) + ((h1 - h0) * intx_pa - (zb1 - zb0) * intx_dpa * Z_to_H)) *
-               (cu / ((h0 + h1) + h_neglect));
+      const double pf = (((pa0 * h0 + iz0) - (pa1 * h1 + iz1)) + ((h1 - h0) * intx_pa - (zb1 - zb0) * intx_dpa * Z_to_H)) *
+                        (cu / ((h0 + h1) + h_neglect));
+      PFu[c] = pf;
+      if (B.u_bc) B.u_bc[c] = (B.CAu[c] + pf) + B.diffu[c];
       pa1 = pa1 + dpa1;
       intx_pa = intx_pa + intx_dpa;
       zt1 = zb1;
@@ -1167,8 +1192,10 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
                                   ssh0, ssh2, dz_neglect, dpa0, dpa2);
       }
       if (Z_to_H != 1.0) iz2 = iz2 * Z_to_H;
-      PFv[c] = (((pa0 * h0 + iz0) - (pa2 * h2 + iz2)) + ((h2 - h0) * inty_pa - (zb2 - zb0) * inty_dpa * Z_to_H)) *
-               (cv / ((h0 + h2) + h_neglect));
+      const double pf = (((pa0 * h0 + iz0) - (pa2 * h2 + iz2)) + ((h2 - h0) * inty_pa - (zb2 - zb0) * inty_dpa * Z_to_H)) *
+                        (cv / ((h0 + h2) + h_neglect));
+      PFv[c] = pf;
+      if (B.v_bc) B.v_bc[c] = (B.CAv[c] + pf) + B.diffv[c];
       pa2 = pa2 + dpa2;
       inty_pa = inty_pa + inty_dpa;
       zt2 = zb2;
@@ -1284,7 +1311,7 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
     }
 #define PGF_EOS(F, P, NAME) KLAUNCH(c, NAME, (k_pgf_main_eos<F, P>), g, b, d, c->G, h, e, c->tv_T, c->tv_S, Tt, Tb, St, Sb, E, PFu, PFv,   \
                                     pbce, eta, GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, GV.Rho0, \
-                                    rho0_alt, GV.H_subroundoff, GV.dZ_subroundoff)
+                                    rho0_alt, GV.H_subroundoff, GV.dZ_subroundoff, c->pgf_fold)
 #define PGF_FORM(F, N) do { if (mode == 1) PGF_EOS(F, 1, "k_pgf_main_plm<" N ">"); else if (mode == 2) PGF_EOS(F, 2, "k_pgf_main_ppm<" N ">"); \
                             else if (mode == 3) PGF_EOS(F, 3, "k_pgf_main_pcm<" N ">"); else PGF_EOS(F, 0, "k_pgf_main_eos<" N ">"); } while (0)
     if (E.form == MOM6X_EOS_UNESCO) {   // quadratures only
@@ -1302,7 +1329,7 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
   }
   KLAUNCH(c, "k_pgf_main", k_pgf_main, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, c->G, h, e, c->Rlay, c->g_prime, PFu, PFv,
           pbce, eta, GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, 1.0 / GV.Rho0,
-          GV.H_subroundoff, GV.dZ_subroundoff);
+          GV.H_subroundoff, GV.dZ_subroundoff, c->pgf_fold);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }

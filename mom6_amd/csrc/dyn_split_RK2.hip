@@ -312,14 +312,24 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2 * d.halo, -d.halo), d.nj + 2 * d.halo, nk, b), b, d, hp, (const double *)h, (const double *)nullptr, 1, 0.0, d.halo, 2);
 
   // PFu = d/dx M(h,T,S) ; pbce = dM/deta  :503
-  CHK(mom6x_PressureForce(c, h, s->PFu, s->PFv, s->pbce, s->eta_PF));
-  if (!s->CAu_pred_stored) CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));   // :552-557
   // u_bc_accel = CAu_pred + PFu + diffu ; up = mask*(u + dt*u_bc_accel)  :564-598.  up/vp at this point only feed
   // vertvisc_coef (:602-609) and are recomputed at :681-694, so they are formed only when that callback exists.
   const bool host_coef = (hooks && hooks->vertvisc_coef);   // up/vp are needed on the host before the solve
-  KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv,
-          s->diffu, s->diffv, u_bc, v_bc, (const double *)u_inst, (const double *)v_inst, host_coef ? up : (double *)nullptr,
-          host_coef ? vp : (double *)nullptr, dt);
+  // With the stored Coriolis acceleration (the rule: STORE_CORIOLIS_ACCEL) everything u_bc_accel needs but PFu exists already:
+  // the pressure-force kernel forms it as it makes PFu (k_bc_accel's 8 words per face-layer -> 4 more in a kernel that runs anyway)
+  static const bool bc_own = [] { const char *e = getenv("MOM6X_BC_ACCEL"); return e && !strcmp(e, "own"); }();
+  const bool fold_bc = s->CAu_pred_stored && !host_coef && !bc_own;
+  if (fold_bc) c->pgf_fold = BcFold{ s->CAu_pred, s->CAv_pred, s->diffu, s->diffv, u_bc, v_bc };
+  {
+    const int rc_pf = mom6x_PressureForce(c, h, s->PFu, s->PFv, s->pbce, s->eta_PF);
+    c->pgf_fold = BcFold{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    if (rc_pf) return rc_pf;
+  }
+  if (!s->CAu_pred_stored) CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));   // :552-557
+  if (!fold_bc)
+    KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv,
+            s->diffu, s->diffv, u_bc, v_bc, (const double *)u_inst, (const double *)v_inst, host_coef ? up : (double *)nullptr,
+            host_coef ? vp : (double *)nullptr, dt);
   if (dev_coef) CHK(vertvisc_coef_upd(c, 1, u_inst, v_inst, u_bc, v_bc, nullptr, nullptr, dt, h, dt, nullptr, nullptr));   // :591-609, up/vp on the fly
   else CHK(coef_hook(0, up, vp, dt));                                   // :602-609
   CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :610

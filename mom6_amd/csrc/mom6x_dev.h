@@ -56,6 +56,9 @@ enum Scr { SCR_q = 0, SCR_KE, SCR_absv, SCR_e, SCR_c1, SCR_t0, SCR_t1, SCR_t2, S
 struct BTState;   // barotropic.hip
 struct RK2State;  // dyn_split_RK2.hip
 
+// u_bc_accel = (CAu + PFu) + diffu of the RK2 predictor (RK2.F90:565-572) formed by the pressure-force kernel that has just made
+// PFu (all null: PressureForce on its own)
+struct BcFold { const double *CAu, *CAv, *diffu, *diffv; double *u_bc, *v_bc; };
 struct mom6x_ctx {
   mom6x_dims dims;
   Dm d;
@@ -101,6 +104,7 @@ struct mom6x_ctx {
   // the RK2 step's h_av formed by the convergence kernels of a continuity call (continuity.hip k_convergence): kind 1: h_av =
   // 0.5 * (hin + h) (RK2.F90:808-810); 2: h_av = 0.5 * (h_old + h_new) of an in-place call (:1025-1027 + :1064-1066); 0: off
   int cont_av_kind; double *cont_av; const double *cont_av_src;
+  BcFold pgf_fold = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // set by the RK2 step around its PressureForce call
   bool cont_stats_on;               // the statistics-collecting (slower) variant of the mass-flux kernel is in use
   unsigned long long *cont_stats;   // device: Newton statistics of the wave-owned mass-flux kernel (mom6x_continuity_stats), or null
   bool cont_h_unused;       // the caller of continuity_PPM does not look at the new thicknesses (RK2.F90:646: hp is overwritten at :781
