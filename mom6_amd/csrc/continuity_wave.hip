@@ -26,6 +26,7 @@
 #include "continuity_lds.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -132,10 +133,12 @@ template <int MAXL, bool STORE, bool STATS, typename StoreUh>
 __device__ __forceinline__ double wave_flux_adjust(Col<MAXL> &C, bool active, double IareaMin, double uhbt,
                                                    double uh_tot_0, double duhdu_tot_0, double du_max, double du_min,
                                                    double tol_eta_cs, double tol_vel, int better_iter, bool lazy,
-                                                   bool &need_exact, StoreUh store_uh, unsigned &evals) {
+                                                   bool &need_exact, StoreUh store_uh, unsigned &evals, double *dd_fin = nullptr,
+                                                   bool *dd_fresh = nullptr) {
   const int max_itts = 20;
   double du = 0.0;
   double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0;
+  bool stale = false;   // du has moved since the sweep duhdu_tot comes from (a solve that ends on a tiny or a bisected step)
   double uh_err_best = fabs(uh_err);
   bool do_I = active;
   bool max_lazy = lazy, min_lazy = lazy, undecided = false;
@@ -159,6 +162,7 @@ __device__ __forceinline__ double wave_flux_adjust(Col<MAXL> &C, bool active, do
           const double ddu = -uh_err / duhdu_tot;
           const double du_prev = du;
           du = du + ddu;
+          stale = true;
           if (fabs(ddu) < 1.0e-15 * fabs(du)) {
             do_I = false;
           } else if (ddu > 0.0) {
@@ -199,12 +203,14 @@ __device__ __forceinline__ double wave_flux_adjust(Col<MAXL> &C, bool active, do
         if (do_I) {
           uh_err = err; duhdu_tot = dtot;
           uh_err_best = dmin(uh_err_best, fabs(uh_err));
+          stale = false;
         }
       }
     }
   }
   COUNT_ITT(STORE ? 8 : 9, n_eval);   // (slot 8 / 9 of g_mfw_t[0]: flux re-evaluations of the first / second solve; g_mfw_t[1]: solves)
   if (STATS) evals = (unsigned)__builtin_amdgcn_readfirstlane((int)(evals + (unsigned)n_eval));   // (wavefront-uniform: mom6x_continuity_stats)
+  if (dd_fin) { *dd_fin = duhdu_tot; *dd_fresh = !stale; }
   return du;
 }
 
@@ -421,17 +427,21 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
   // ---- set_zonal_BT_cont :1246-1409 / set_merid_BT_cont :2143-2304 -----------------------------------------------
   const double Idt = 1.0 / dt, min_visc_rem = 0.1, CFL_min = 1e-6;
   double du0;
+  // FAmt_0 (:1330-1337) is the sum of duhdu at u + du0 visc_rem: the very sum the zero-transport solve's LAST sweep formed (same
+  // expression, same order) unless the solve ended on a step it did not evaluate -- then, wavefront-uniformly, the sweep is made.
+  double dd0 = 0.0;
+  bool dd0_fresh = false;
   {
     bool redo;
     auto no_store = [](int, double, bool) {};
     if (STATS) solves = (unsigned)__builtin_amdgcn_readfirstlane((int)(solves + 1u));
     du0 = wave_flux_adjust<MAXL, false, STATS>(C, active, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
-                                        A.tol_eta, A.tol_vel, A.better_iter, lazy, redo, no_store, evals);
+                                        A.tol_eta, A.tol_vel, A.better_iter, lazy, redo, no_store, evals, &dd0, &dd0_fresh);
     if (redo) {
       if (STATS) redos = (unsigned)__builtin_amdgcn_readfirstlane((int)(redos + 1u));
       exact_bounds(); lazy = false;
       du0 = wave_flux_adjust<MAXL, false, STATS>(C, active, IareaMin, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
-                                          A.tol_eta, A.tol_vel, A.better_iter, false, redo, no_store, evals);
+                                          A.tol_eta, A.tol_vel, A.better_iter, false, redo, no_store, evals, &dd0, &dd0_fresh);
     }
   }
   TICK(5);
@@ -456,12 +466,15 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
   TICK(6);
   // three trial velocities (:1330-1349), five column sums
   double FAmt_L = 0.0, FAmt_R = 0.0, FAmt_0 = 0.0, uhtot_L = 0.0, uhtot_R = 0.0;
+  const bool sweep_0 = wave_any(!dd0_fresh) || E.force_walk;
+  if (sweep_0) {
 #pragma unroll
-  for (int n = 0; n < MAXL; n++) {
-    double uh_0, d_0;
-    flux_reg(C, n, C.u[n] + du0 * C.v[n], uh_0, d_0);
-    FAmt_0 = FAmt_0 + d_0;
-    LAYER_FENCE(n);
+    for (int n = 0; n < MAXL; n++) {
+      double uh_0, d_0;
+      flux_reg(C, n, C.u[n] + du0 * C.v[n], uh_0, d_0);
+      FAmt_0 = FAmt_0 + d_0;
+      LAYER_FENCE(n);
+    }
   }
 #pragma unroll
   for (int n = 0; n < MAXL; n++) {
@@ -477,7 +490,8 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
     FAmt_R = FAmt_R + d_R; uhtot_R = uhtot_R + uh_R;
     LAYER_FENCE(n);
   }
-  FAmt_0 = row_sum(FAmt_0); FAmt_L = row_sum(FAmt_L); FAmt_R = row_sum(FAmt_R);
+  FAmt_0 = sweep_0 ? row_sum(FAmt_0) : dd0;
+  FAmt_L = row_sum(FAmt_L); FAmt_R = row_sum(FAmt_R);
   uhtot_L = row_sum(uhtot_L); uhtot_R = row_sum(uhtot_R);
   TICK(7);
   if (!(active && kl == 0)) return;
@@ -667,7 +681,8 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   E.gx = (A.a1 - E.i_base + NF) / NF;
   E.rows = 16;                              // rows a work-group marches over
   E.gy = (nrow + E.rows - 1) / E.rows;      // chunks
-  E.retry = nullptr; E.force_walk = 0;
+  static const int famt0_sweep = [] { const char *e = getenv("MOM6X_FAMT0"); return (e && !strcmp(e, "sweep")) ? 1 : 0; }();
+  E.retry = nullptr; E.force_walk = famt0_sweep;   // (in this kernel: always make set_*_BT_cont's own sweep at du0)
   // The Newton statistics are a separate instantiation: the counters cost the 253-register kernel its last free registers
   // (139 spills), so they are only compiled into the variant that runs while mom6x_continuity_stats is switched on.
   const bool stats = (c->cont_stats != nullptr) && c->cont_stats_on;
