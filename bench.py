@@ -36,9 +36,12 @@ LAYOUTS = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.3 TB/s achievable)
 
 
-def global_grid(ni, nj, reentrant_y=False):
+def global_grid(ni, nj, reentrant_y=False, res_of=None):
+    """res_of = (NI, NJ): the grid spacing of an NI x NJ global grid on this (smaller) ni x nj patch -- the comm_model leg's tile has
+    the headline's resolution, hence its barotropic time step and number of sub-steps."""
     from mom6_amd import grid
-    return grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-65.0, dlon=360.0 / ni, dlat=130.0 / nj,
+    NI, NJ = res_of if res_of else (ni, nj)
+    return grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-65.0 if not res_of else -32.5, dlon=360.0 / NI, dlat=130.0 / NJ,
                            reentrant_x=True, reentrant_y=reentrant_y, depth_fn=grid.bowl_depth(ni, nj, 4000.0, rim=0 if reentrant_y else 2))
 
 
@@ -62,22 +65,28 @@ def hor_visc_params(abi, dt):
     return P
 
 
-def build_model(args, layout, pe, device, dist=None, unique_id=None, reentrant_y=False, force_nccl_self=False):
+def build_model(args, layout, pe, device, dist=None, unique_id=None, reentrant_y=False, force_nccl_self=False, bthalo=0, res_of=None):
     """Create the device model for tile `pe` of `layout` and a synthetic state in HBM.  With more than one tile the
     communicator is attached before anything exchanges halos (the new-run initialisation does)."""
     import torch
     from mom6_amd import abi, synth_dev
     from mom6_amd.dycore import Dycore
     G = abi.G
-    gg = global_grid(args.ni, args.nj, reentrant_y)
-    d, M = gg.tile(args.nk, 4, layout, pe)
+    gg = global_grid(args.ni, args.nj, reentrant_y, res_of)
+    # BTHALO > NIHALO = 4 (MOM_barotropic.F90:5446-5461): the context carries the wide halo, the barotropic solver exchanges every
+    # BTHALO sub-steps, the 3-D passes of the step stay at 4 rows
+    halo = max(4, int(bthalo or getattr(args, "bthalo", 0) or 0))
+    d, M = gg.tile(args.nk, halo, layout, pe)
     GV = abi.vgrid_default()
     dyc = Dycore(d, M, GV, 0, device)
+    if halo > 4:
+        dyc.set_dyn_pass_width(4)
     if layout != (1, 1) or force_nccl_self:
         from mom6_amd.parallel import attach_comm
         attach_comm(dyc, layout, pe, dist, unique_id=unique_id, force_nccl_self=force_nccl_self)
     dyc.continuity_init(abi.continuity_params_default(args.nk, GV.Angstrom_H))
     bt = abi.barotropic_params_default(20.0)
+    bt.BTHALO = halo if halo > 4 else 0
     dyc.barotropic_init(bt)
     dyc.CoriolisAdv_init(abi.coriolis_params_default())
     Rlay, gp = abi.layer_densities(args.nk, GV.Rho0, GV.g_Earth)
@@ -392,7 +401,8 @@ def comm_model_leg(args, device):
     out = {}
     for mode in ("local_wrap", "rccl_self"):
         a = A(); a.ni, a.nj, a.nk, a.dt, a.tracers = args.ni // 4, args.nj // 2, args.nk, args.dt, 0
-        dyc, d, st, taux, tauy, keep = build_model(a, (1, 1), (0, 0), device, reentrant_y=True, force_nccl_self=(mode == "rccl_self"))
+        dyc, d, st, taux, tauy, keep = build_model(a, (1, 1), (0, 0), device, reentrant_y=True, force_nccl_self=(mode == "rccl_self"),
+                                                   res_of=(args.ni, args.nj))
         torch.cuda.set_stream(dyc.torch_stream())
 
         def step(calc=False):
@@ -406,10 +416,38 @@ def comm_model_leg(args, device):
         dyc.sync(); torch.cuda.synchronize()
         ms = 1e2 * (time.perf_counter() - t0)
         prof_enable(dyc, True); prof_reset(dyc)
+        dyc.comm_exchange_count(reset=True)
         step(); dyc.sync()
+        nex = dyc.comm_exchange_count()
         rep = prof_report(dyc); prof_enable(dyc, False)
         out[mode] = {"ms_per_step": round(ms, 3), "kernel_sum_ms": round(sum(v[1] for v in rep.values()), 3),
-                     "launches_per_step": int(sum(v[0] for v in rep.values()))}
+                     "launches_per_step": int(sum(v[0] for v in rep.values())), "exchanges_per_step": nex}
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        dyc.close()
+        del st, keep
+        torch.cuda.empty_cache()
+    # BTHALO = 8, 12: the same tile with a wider barotropic halo (the reference's own lever against the latency of the sub-cycle's
+    # exchanges): exchanges per step (packed group messages, of which the sub-cycle's are 2 x sub-steps / BTHALO) and the step time
+    out["bthalo"] = {"4": {"ms_per_step": out["rccl_self"]["ms_per_step"], "exchanges_per_step": out["rccl_self"].get("exchanges_per_step")}}
+    for bh in (8, 12):
+        a = A(); a.ni, a.nj, a.nk, a.dt, a.tracers = args.ni // 4, args.nj // 2, args.nk, args.dt, 0
+        dyc, d, st, taux, tauy, keep = build_model(a, (1, 1), (0, 0), device, reentrant_y=True, force_nccl_self=True, bthalo=bh,
+                                                   res_of=(args.ni, args.nj))
+        torch.cuda.set_stream(dyc.torch_stream())
+
+        def step(calc=False):
+            dyc.step_MOM_dyn_split_RK2(st["u"], st["v"], st["h"], st["uh"], st["vh"], st["uhtr"], st["vhtr"], st["eta_av"], taux, tauy,
+                                       a.dt, calc_dtbt=calc)
+        step(True); step(); step()
+        dyc.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        dyc.sync(); torch.cuda.synchronize()
+        ms = 1e2 * (time.perf_counter() - t0)
+        dyc.comm_exchange_count(reset=True)
+        step(); dyc.sync()
+        out["bthalo"][str(bh)] = {"ms_per_step": round(ms, 3), "exchanges_per_step": dyc.comm_exchange_count()}
         torch.cuda.set_stream(torch.cuda.default_stream())
         dyc.close()
         del st, keep
@@ -608,6 +646,8 @@ def main():
     ap.add_argument("--ale-nj", type=int, default=1620)
     ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] tile leg")
     ap.add_argument("--no-comm-model", action="store_true", help="skip the 1-GPU exchange-overhead leg")
+    ap.add_argument("--bthalo", type=int, default=0, help="BTHALO of the barotropic solver (> 4: the tile context carries that halo, the 3-D "
+                    "passes of the step stay at 4 rows; the answers do not depend on it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 (two extra one-step runs); cite profiles/ instead")

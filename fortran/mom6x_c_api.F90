@@ -71,6 +71,7 @@ module mom6x_c_api
     real(c_double) :: CFL_trunc, vel_underflow, G_extra, BT_Coriolis_scale, maxCFL_BT_cont
     integer(c_int) :: bound_BT_corr, BT_cont_bounds
     real(c_double) :: dtbt_fraction, Z_ref
+    integer(c_int) :: use_wide_halos, BTHALO, min_stencil   !< BT_USE_WIDE_HALOS (T), BTHALO (0), BT_WIDE_HALO_MIN_STENCIL (0)
   end type mom6x_barotropic_params
 
   type, bind(C) :: mom6x_coriolis_params   !< CoriolisAdv_CS (MOM_CoriolisAdv.F90:29-100)

@@ -231,6 +231,7 @@ subroutine barotropic_init(u, v, h, Time, G, GV, US, param_file, diag, CS, &
   type(harmonic_analysis_CS), target, optional :: HA_CSp
   character(len=40) :: mdl = "MOM_barotropic"
   real :: dtbt_input, dtbt_restart
+  integer :: bt_halo_sz, min_stencil
   real(c_double), target :: dtbt_c
   integer(c_int) :: rc
 
@@ -270,6 +271,14 @@ subroutine barotropic_init(u, v, h, Time, G, GV, US, param_file, diag, CS, &
   call flag_param("BOUND_BT_CORRECTION", CS%p%bound_BT_corr, .false.)
   call flag_param("BT_CONT_CORR_BOUNDS", CS%p%BT_cont_bounds, .true.)
   CS%p%Z_ref = G%Z_ref
+  call flag_param("BT_USE_WIDE_HALOS", CS%p%use_wide_halos, .true.)
+  call get_param(param_file, mdl, "BTHALO", bt_halo_sz, "The minimum halo size for the barotropic solver.", default=0, layoutParam=.true.)
+  CS%p%BTHALO = int(bt_halo_sz, c_int)
+  call get_param(param_file, mdl, "BT_WIDE_HALO_MIN_STENCIL", min_stencil, "The minimum stencil width to use with the wide halo "//&
+                 "iterations.", default=0, layoutParam=.true.)
+  CS%p%min_stencil = int(min_stencil, c_int)
+  ! (the barotropic domain's halo on the device is the tile context's: shim_ctx makes it G's, so BTHALO > NIHALO is refused by
+  !  mom6x_barotropic_init with the instruction to widen the context; the answers do not depend on it)
   call must_be("USE_BT_CONT_TYPE", .true.) ; call must_be("INTEGRAL_BT_CONTINUITY", .false.)
   call must_be("ADJUST_BT_CONT", .false.) ; call must_be("GRADUAL_BT_ICS", .false.)
   call must_be("BT_NONLIN_STRESS", .false.) ; call must_be("DYNAMIC_SURFACE_PRESSURE", .false.)

@@ -151,6 +151,13 @@ typedef struct mom6x_barotropic_params {
   int    BT_cont_bounds;       /* BT_CONT_CORR_BOUNDS (T)                     */
   double dtbt_fraction;        /* |DTBT| when DTBT<0 (0.98)                   */
   double Z_ref;                /* G%Z_ref (0)                                 */
+  /* The wide-halo cycle of btstep (MOM_barotropic.F90:766-794, :2505-2512): with BT_USE_WIDE_HALOS the solver marches in from its
+   * wide halo and exchanges every (halo / stencil) sub-steps.  On the device the barotropic domain's halo IS the context's halo
+   * (mom6x_dims.halo): a host that wants BTHALO > NIHALO creates the context with halo = max(NIHALO, BTHALO) (and may keep the
+   * 3-D passes at NIHALO rows: mom6x_set_dyn_pass_width).  The answers do not depend on any of the three.                    */
+  int    use_wide_halos;       /* BT_USE_WIDE_HALOS (T); F: an exchange every sub-step                                       */
+  int    BTHALO;               /* BTHALO (0): refused if it exceeds the context's halo                                        */
+  int    min_stencil;          /* BT_WIDE_HALO_MIN_STENCIL (0)                                                                */
 } mom6x_barotropic_params;
 
 /* CoriolisAdv_CS (src/core/MOM_CoriolisAdv.F90:29-100; CoriolisAdv_init :1054).            */
@@ -707,6 +714,15 @@ int mom6x_comm_init(mom6x_ctx *ctx, int npx, int npy, int px, int py, const char
 int mom6x_comm_rank(const mom6x_ctx *ctx);
 /* do_group_pass of n fields (pass_var / pass_vector, MOM_domain_infra.F90:171-560, :1141).          */
 int mom6x_pass_fields(mom6x_ctx *ctx, double *const *fields, const int *staggers, const int *nks, int n);
+/* The halo width of the 3-D fields in the RK2 step's own group passes (the reference's create_group_pass calls of
+ * MOM_dynamics_split_RK2.F90 run on G%Domain, i.e. with NIHALO).  For a context whose halo was widened for the barotropic solver
+ * -- BT_USE_WIDE_HALOS with BTHALO > NIHALO, MOM_barotropic.F90:5446-5461: create the context with halo = max(NIHALO, BTHALO);
+ * btstep then exchanges every halo / stencil sub-steps (:2505-2512) -- this keeps the 3-D messages at NIHALO rows.
+ * width = 0: the context's halo (the default); otherwise 4 <= width <= the context's halo.  2-D fields (eta) always travel at
+ * the context's width: btstep reads them over its wide halo.                                                          */
+int mom6x_set_dyn_pass_width(mom6x_ctx *ctx, int width);
+/* Packed group exchanges (one message per neighbour each) this tile has made since the last reset; reset != 0 clears the count. */
+long long mom6x_comm_exchange_count(mom6x_ctx *ctx, int reset);
 
 /* ------------------------------------------------------------------------- */
 /* The order-invariant sums and checksums of the reference's regression artefacts (ocean.stats, the debugging

@@ -131,6 +131,7 @@ class BarotropicParams(C.Structure):
         ("BT_Coriolis_scale", C.c_double), ("maxCFL_BT_cont", C.c_double),
         ("bound_BT_corr", C.c_int), ("BT_cont_bounds", C.c_int),
         ("dtbt_fraction", C.c_double), ("Z_ref", C.c_double),
+        ("use_wide_halos", C.c_int), ("BTHALO", C.c_int), ("min_stencil", C.c_int),
     ]
 
 
@@ -138,6 +139,7 @@ def barotropic_params_default(dtbt):
     """Defaults read in barotropic_init (MOM_barotropic.F90:5403-5713)."""
     p = BarotropicParams()
     p.bebt, p.dtbt, p.dt_bt_filter = 0.1, dtbt, -0.25
+    p.use_wide_halos, p.BTHALO, p.min_stencil = 1, 0, 0
     p.BT_project_velocity = 0
     p.Sadourny = 1
     p.strong_drag = 0

@@ -738,6 +738,9 @@ extern "C" int mom6x_barotropic_init(mom6x_ctx *c, const mom6x_barotropic_params
   REQUIRE(!(p->bound_BT_corr && !p->BT_cont_bounds), MOM6X_EUNSUPPORTED,
           "barotropic: BOUND_BT_CORRECTION without BT_CONT_CORR_BOUNDS is not supported");
   REQUIRE(c->dims.halo >= 2, MOM6X_EINVAL, "barotropic: halo >= 2 required");
+  REQUIRE(p->BTHALO <= c->dims.halo, MOM6X_EINVAL,
+          "barotropic_init: BTHALO exceeds the halo of the tile context; create the context with halo = max(NIHALO, BTHALO)");
+  REQUIRE(p->min_stencil >= 0 && p->min_stencil <= c->dims.halo, MOM6X_EINVAL, "barotropic_init: bad BT_WIDE_HALO_MIN_STENCIL");
   HIPCHK(hipSetDevice(c->device));
   c->bt = *p;
   const Dm d = c->d;
@@ -884,8 +887,8 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   const int is = 0, ie = d.ni - 1, js = 0, je = d.nj - 1;
 
   const double Idt = 1.0 / dt;
-  const int stencil = 1;
-  const int num_cycles = d.halo / stencil;
+  const int stencil = (P.min_stencil > 1) ? P.min_stencil : 1;                 // :766 (no OBC, no nonlinear continuity updates)
+  const int num_cycles = (P.use_wide_halos && d.halo / stencil >= 1) ? d.halo / stencil : 1;   // :790-792; the wide halo = the context's
   const int isvf = is - (num_cycles - 1) * stencil, ievf = ie + (num_cycles - 1) * stencil;
   const int jsvf = js - (num_cycles - 1) * stencil, jevf = je + (num_cycles - 1) * stencil;
   REQUIRE(P.dtbt > 0.0, MOM6X_EINVAL, "btstep: dtbt must be positive (call set_dtbt or set params.dtbt)");

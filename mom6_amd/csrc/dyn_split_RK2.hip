@@ -136,7 +136,9 @@ int pass3(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list
   double *ff[16]; int ss[16], nn[16]; int n = 0;
   auto s = stg.begin();
   for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = nk; n++; }
+  c->pass_w = c->dyn_pass_width;
   halo_wrap(c, ff, ss, nn, n);
+  c->pass_w = 0;
   return MOM6X_OK;
 }
 
@@ -145,7 +147,9 @@ int start3(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_lis
   double *ff[16]; int ss[16], nn[16]; int n = 0;
   auto s = stg.begin();
   for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = nk; n++; }
+  c->pass_w = c->dyn_pass_width;
   halo_start(c, ff, ss, nn, n);
+  c->pass_w = 0;
   return MOM6X_OK;
 }
 
@@ -153,7 +157,9 @@ int startn(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_lis
   double *ff[16]; int ss[16], nn[16]; int n = 0;
   auto s = stg.begin(); auto q = nks.begin();
   for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = *q++; n++; }
+  c->pass_w = c->dyn_pass_width;   // (mom6x_set_dyn_pass_width: NIHALO rows of the 3-D fields in a context widened for BTHALO)
   halo_start(c, ff, ss, nn, n);
+  c->pass_w = 0;
   return MOM6X_OK;
 }
 
@@ -163,7 +169,9 @@ int passn(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list
   double *ff[16]; int ss[16], nn[16]; int n = 0;
   auto s = stg.begin(); auto q = nks.begin();
   for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = *q++; n++; }
+  c->pass_w = c->dyn_pass_width;
   halo_wrap(c, ff, ss, nn, n);
+  c->pass_w = 0;
   return MOM6X_OK;
 }
 

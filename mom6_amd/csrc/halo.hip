@@ -22,7 +22,10 @@
 #include "mom6x_dev.h"
 
 #define MAXF 16
-struct WrapArgs { double *f[MAXF]; int stg[MAXF]; int nk[MAXF]; int n; int rx; };
+struct WrapArgs { double *f[MAXF]; int stg[MAXF]; int nk[MAXF]; int n; int rx; int w, w2; };
+// w: rows / columns of halo this pass fills for its 3-D fields (create_group_pass's halo=), <= d.halo; w2: for its 2-D fields
+// (always the context's: the barotropic solver reads eta over its wide halo)
+#define PASS_W(A, m) (((A).nk[m] == 1) ? (A).w2 : (A).w)
 
 // ---- region logic (host + device) ------------------------------------------------------------------
 // Directions d = 0..7: W, E, S, N, SW, SE, NW, NE.
@@ -74,8 +77,8 @@ k_halo_pack(Dm d, WrapArgs A, Bufs8 B, int send /*1: pack send regions, 0: unpac
   for (int m = 0; m < A.n; m++) {
     const int xB = (A.stg[m] == 1 || A.stg[m] == 3), yB = (A.stg[m] == 2 || A.stg[m] == 3);
     int i0, i1, j0, j1;
-    axis_range(d.ni, d.halo, xB, dx, send, i0, i1);
-    axis_range(d.nj, d.halo, yB, dy, send, j0, j1);
+    axis_range(d.ni, PASS_W(A, m), xB, dx, send, i0, i1);
+    axis_range(d.nj, PASS_W(A, m), yB, dy, send, j0, j1);
     const int nx = i1 - i0 + 1, ny = j1 - j0 + 1;
     const size_t per_k = (size_t)nx * ny, tot = per_k * A.nk[m];
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
@@ -96,8 +99,8 @@ static size_t region_count(const mom6x_dims &d, const WrapArgs &A, int dir) {
   for (int m = 0; m < A.n; m++) {
     const int xB = (A.stg[m] == 1 || A.stg[m] == 3), yB = (A.stg[m] == 2 || A.stg[m] == 3);
     int i0, i1, j0, j1;
-    axis_range(d.ni, d.halo, xB, dx, 1, i0, i1);
-    axis_range(d.nj, d.halo, yB, dy, 1, j0, j1);
+    axis_range(d.ni, PASS_W(A, m), xB, dx, 1, i0, i1);
+    axis_range(d.nj, PASS_W(A, m), yB, dy, 1, j0, j1);
     tot += (size_t)(i1 - i0 + 1) * (j1 - j0 + 1) * A.nk[m];
   }
   return tot;
@@ -108,9 +111,10 @@ __global__ void k_wrap_x(Dm d, WrapArgs A) {
   const int jj = blockIdx.x * blockDim.x + threadIdx.x;
   const int hh = threadIdx.y;
   const int k = blockIdx.z;
-  const int w = d.halo, ni = d.ni;
+  const int ni = d.ni;
   for (int m = 0; m < A.n; m++) {
     if (k >= A.nk[m]) continue;
+    const int w = PASS_W(A, m);
     const int xB = (A.stg[m] == 1 || A.stg[m] == 3), yB = (A.stg[m] == 2 || A.stg[m] == 3);
     const int j = -yB + jj;                       // computational rows only: corners come from the y pass
     if (j > d.nj - 1) continue;
@@ -128,9 +132,10 @@ __global__ void k_wrap_y(Dm d, WrapArgs A) {
   const int ii = blockIdx.x * blockDim.x + threadIdx.x;
   const int hh = threadIdx.y;
   const int k = blockIdx.z;
-  const int w = d.halo, nj = d.nj;
+  const int nj = d.nj;
   for (int m = 0; m < A.n; m++) {
     if (k >= A.nk[m]) continue;
+    const int w = PASS_W(A, m);
     const int xB = (A.stg[m] == 1 || A.stg[m] == 3), yB = (A.stg[m] == 2 || A.stg[m] == 3);
     // with a re-entrant x the (already wrapped) x-halo columns are included, which fills the corners
     const int i = (A.rx ? -w - xB : -xB) + ii;
@@ -342,6 +347,7 @@ int comm_allreduce_f64(mom6x_ctx *c, double *dev, size_t n, int op) {
 int comm_nranks(const mom6x_ctx *c) { const Comm *m = (const Comm *)c->comm; return (m && m->comm) ? m->nranks : 1; }
 
 static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A, hipStream_t st) {
+  c->n_exchanges++;   // (mom6x_comm_exchange_count)
   const Dm d = c->d;
   NcclApi *api = m->api;
   size_t cnt[8];
@@ -413,6 +419,7 @@ void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const i
     WrapArgs A;
     A.n = (n - base < MAXF) ? (n - base) : MAXF;
     A.rx = c->dims.reentrant_x;
+    A.w = (c->pass_w > 0 && c->pass_w < d.halo) ? c->pass_w : d.halo; A.w2 = d.halo;
     int nkmax = 1;
     for (int q = 0; q < A.n; q++) {
       A.f[q] = fields[base + q]; A.stg[q] = staggers[base + q]; A.nk[q] = nks[base + q];
@@ -448,6 +455,7 @@ void halo_start(mom6x_ctx *c, double *const *fields, const int *staggers, const 
   }
   WrapArgs A;
   A.n = n; A.rx = c->dims.reentrant_x;
+  A.w = (c->pass_w > 0 && c->pass_w < c->dims.halo) ? c->pass_w : c->dims.halo; A.w2 = c->dims.halo;
   for (int q = 0; q < n; q++) { A.f[q] = fields[q]; A.stg[q] = staggers[q]; A.nk[q] = nks[q]; }
   // the second stream starts when the compute stream has produced the fields ...
   if (hipEventRecord(c->ev_ready, c->stream) != hipSuccess || hipStreamWaitEvent(c->halo_stream, c->ev_ready, 0) != hipSuccess ||
@@ -482,4 +490,23 @@ int comm_allreduce_int_sum(mom6x_ctx *c, int *dev, int n) {
   NcclApi *api = m->api;
   NCCLCHK(api->AllReduce(dev, dev, (size_t)n, ncclInt, ncclSum, m->comm, c->stream));
   return MOM6X_OK;
+}
+
+// The halo width of the 3-D fields in the RK2 step's own group passes (RK2.F90's create_group_pass calls run on G%Domain, i.e. with
+// NIHALO): for a context whose halo was widened for the barotropic solver (BT_USE_WIDE_HALOS with BTHALO > NIHALO,
+// MOM_barotropic.F90:5446-5461).  0: the context's halo.  2-D fields (eta) always travel at the context's width.
+extern "C" int mom6x_set_dyn_pass_width(mom6x_ctx *c, int width) {
+  REQUIRE(c, MOM6X_EINVAL, "mom6x_set_dyn_pass_width: null ctx");
+  REQUIRE(width == 0 || (width >= 4 && width <= c->dims.halo), MOM6X_EINVAL,
+          "mom6x_set_dyn_pass_width: the width must be 0 (the context's halo) or between 4 and the context's halo");
+  c->dyn_pass_width = width;
+  return MOM6X_OK;
+}
+
+// Packed group exchanges (one message per neighbour each) since the last reset: what a step costs in message latency.
+extern "C" long long mom6x_comm_exchange_count(mom6x_ctx *c, int reset) {
+  if (!c) return -1;
+  const long long n = c->n_exchanges;
+  if (reset) c->n_exchanges = 0;
+  return n;
 }

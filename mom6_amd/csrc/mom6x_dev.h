@@ -104,6 +104,10 @@ struct mom6x_ctx {
   // the RK2 step's h_av formed by the convergence kernels of a continuity call (continuity.hip k_convergence): kind 1: h_av =
   // 0.5 * (hin + h) (RK2.F90:808-810); 2: h_av = 0.5 * (h_old + h_new) of an in-place call (:1025-1027 + :1064-1066); 0: off
   int cont_av_kind; double *cont_av; const double *cont_av_src;
+  // halo width of the NEXT pass (0: the context's); dyn_pass_width: what the RK2 step sets for its own group passes -- a context
+  // whose halo was widened for the barotropic solver (BTHALO) still sends NIHALO rows of the 3-D fields (mom6x_set_dyn_pass_width)
+  int pass_w = 0, dyn_pass_width = 0;
+  long long n_exchanges = 0;
   BcFold pgf_fold = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // set by the RK2 step around its PressureForce call
   bool cont_stats_on;               // the statistics-collecting (slower) variant of the mass-flux kernel is in use
   unsigned long long *cont_stats;   // device: Newton statistics of the wave-owned mass-flux kernel (mom6x_continuity_stats), or null

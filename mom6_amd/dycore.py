@@ -215,6 +215,16 @@ class Dycore:
         """ALE_PLM_edge_values (MOM_ALE.F90:1520): top and bottom values of the PLM reconstruction of Q in every layer."""
         check(self.lib, self.lib.mom6x_ALE_PLM_edge_values(self.ctx, _ptr(h), _ptr(Q), C.c_int(int(bdry_extrap)), _ptr(Q_t), _ptr(Q_b)))
 
+    def set_dyn_pass_width(self, width):
+        """NIHALO rows for the 3-D group passes of the RK2 step in a context whose halo was widened for BTHALO (0: the context's)."""
+        check(self.lib, self.lib.mom6x_set_dyn_pass_width(self.ctx, C.c_int(int(width))))
+
+    def comm_exchange_count(self, reset=False):
+        """Packed group exchanges since the last reset (mom6x_comm_exchange_count)."""
+        f = self.lib.mom6x_comm_exchange_count
+        f.restype = C.c_longlong
+        return int(f(self.ctx, C.c_int(1 if reset else 0)))
+
     def ALE_PPM_edge_values(self, h, Q, bdry_extrap, Q_t, Q_b):
         """One field of TS_PPM_edge_values (MOM_ALE.F90:1581): edge_values_implicit_h4 + PPM_reconstruction edge values."""
         check(self.lib, self.lib.mom6x_ALE_PPM_edge_values(self.ctx, _ptr(h), _ptr(Q), C.c_int(int(bdry_extrap)), _ptr(Q_t), _ptr(Q_b)))

@@ -17,7 +17,7 @@ STATE = ["u", "v", "h", "uh", "vh", "uhtr", "vhtr", "eta_av"]
 STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h", T="h")
 
 
-def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors, rich=False):
+def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors, rich=False, halo=4, bt_tile=None):
     """One tile of the layout: a few baroclinic steps, a tracer advection with the accumulated transports, write_energy."""
     try:
         import torch
@@ -26,17 +26,21 @@ def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors, rich=Fals
         gg, d1, M1 = cfg_fn(nk=nk)                                  # the one-tile grid: seeded inputs are made on it ...
         inp = cases.rk2_inputs((gg, d1, M1), False, False)
         T1 = cases.thermo_state(d1, M1)[0]
-        d, M = gg.tile(nk, 4, layout, pe)                           # ... and cut to this tile (with its halos)
+        d, M = gg.tile(nk, halo, layout, pe)                        # ... and cut to this tile (with its halos, which may be wider)
 
         def cut(a):
             j0, i0 = d.j_glob0 - d.halo, d.i_glob0 - d.halo         # global index of the tile's first memory row / column
             rows = np.arange(d.nrows) - d.joff + d.j_glob0
             cols = np.arange(d.pitch) - d.ioff + d.i_glob0
+            if getattr(gg, "reentrant_x", False): cols = np.mod(cols, d1.ni)     # (a halo wider than the one-tile grid's own)
+            if getattr(gg, "reentrant_y", False): rows = np.mod(rows, d1.nj)
             src_r = np.clip(rows + d1.joff, 0, d1.nrows - 1); src_c = np.clip(cols + d1.ioff, 0, d1.pitch - 1)
             return np.ascontiguousarray(a[..., src_r[:, None], src_c[None, :]])
         GV, Rlay, gp, dt = inp["GV"], inp["Rlay"], inp["gp"], inp["dt"]
-        cont, bt, cor, pgf, rk2 = cases.rk2_params(d, GV, bt_mod, None, None)
+        cont, bt, cor, pgf, rk2 = cases.rk2_params(d, GV, dict(bt_mod, **(bt_tile or {})) if layout is not None else bt_mod, None, None)
         dyc = Dycore(d, M, GV, 0)
+        if halo > 4:
+            dyc.set_dyn_pass_width(4)                               # NIHALO rows of the 3-D fields, the wide halo for the 2-D ones
         if layout != (1, 1):
             parallel.attach_comm(dyc, layout, pe, None, unique_id=uid)
         dyc.continuity_init(cont); dyc.barotropic_init(bt); dyc.CoriolisAdv_init(cor); dyc.PressureForce_init(pgf, Rlay, gp)
@@ -99,16 +103,40 @@ def test_tile_layout_in_the_reference_sum_order(cfg_name, layout, rich, monkeypa
     _layout_case(cfg_name, layout, rich)
 
 
-def _layout_case(cfg_name, layout, rich):
+@pytest.mark.parametrize("cfg_name,layout,rich,halo,bt", [("channel", (2, 1), False, 8, None), ("double_gyre", (2, 2), False, 6, None),
+                                                          ("benchmark_small", (4, 2), True, 8, dict(BTHALO=8)),
+                                                          ("island_basin", (1, 1), True, 8, None),
+                                                          ("channel", (2, 1), False, 4, dict(use_wide_halos=0)),
+                                                          ("benchmark_small", (2, 2), False, 8, dict(min_stencil=2, BTHALO=6))])
+def test_wide_halos_give_the_same_answer(cfg_name, layout, rich, halo, bt):
+    """BT_USE_WIDE_HALOS with BTHALO > NIHALO (MOM_barotropic.F90:5446-5461, :5717, the wide-halo cycle :2505-2512): the barotropic
+    solver takes the number of sub-steps between two exchanges from the halo width of its domain.  The device context is created
+    with that width (halo = 6 / 8 here): the sub-cycle then exchanges every 6 / 8 sub-steps instead of every 4 -- and every field
+    of every tile still equals the one-tile, halo-4 run bit for bit.  Likewise without BT_USE_WIDE_HALOS (an exchange every
+    sub-step) and with BT_WIDE_HALO_MIN_STENCIL = 2 (the valid range shrinks by two points per sub-step)."""
+    _layout_case(cfg_name, layout, rich, halo, bt)
+
+
+def test_bthalo_beyond_the_context_halo_is_refused():
+    from mom6_amd.dycore import Dycore
+    gg, d, M = H.double_gyre()
+    dyc = Dycore(d, M, abi.vgrid_default(), 0)
+    bt = abi.barotropic_params_default(30.0); bt.BTHALO = d.halo + 2
+    with pytest.raises(abi.Mom6xError, match="BTHALO exceeds the halo of the tile context"):
+        dyc.barotropic_init(bt)
+    dyc.close()
+
+
+def _layout_case(cfg_name, layout, rich, halo=4, bt_tile=None):
     from mom6_amd.abi import load_library
     H.use_threads_transport(load_library())
     try:
-        _tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich)
+        _tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich, halo, bt_tile)
     finally:
         H.use_threads_transport(load_library(), on=False)
 
 
-def _tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich):
+def _tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich, halo=4, bt_tile=None):
     from mom6_amd.abi import load_library
     cfg_fn = getattr(H, cfg_name)
     nk, nsteps, bt_mod = 3, 3, dict(strong_drag=1)
@@ -119,7 +147,7 @@ def _tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich):
     uid = parallel.unique_id(load_library())
     out = {}
     pes = [(px, py) for py in range(layout[1]) for px in range(layout[0])]
-    threads = [threading.Thread(target=run_tile, args=(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors, rich)) for pe in pes]
+    threads = [threading.Thread(target=run_tile, args=(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors, rich, halo, bt_tile)) for pe in pes]
     for t in threads:
         t.start()
     for t in threads:
