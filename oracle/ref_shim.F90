@@ -1,6 +1,7 @@
 !> ORACLE SUPPORT (test infrastructure only): bind(C) doors into the REAL reference modules that compile from their own
 !! source files without FMS / netCDF (src/ALE/PLM_functions.F90, src/ALE/PCM_functions.F90: no `use` statements at all;
-!! src/ALE/Recon1d_PPM_H4_2019.F90 with Recon1d_type.F90 and src/framework/numerical_testing_type.F90).
+!! src/ALE/Recon1d_PPM_H4_2019.F90 with Recon1d_type.F90 and src/framework/numerical_testing_type.F90;
+!! src/equation_of_state/MOM_EOS_UNESCO.F90 with MOM_EOS_base_type.F90).
 !! oracle/Makefile compiles those two files where they lie under /root/reference together with this file into
 !! oracle/_ref/libref_ale.so; tests/test_remap_cpu.py then holds orc_remap.c's PLM / PCM reconstructions to the
 !! reference's own code, bit for bit, on random columns.  Nothing of the reference is copied here.
@@ -10,8 +11,24 @@ module ref_shim
                             PLM_extrapolate_slope
   use PCM_functions, only : PCM_reconstruction
   use Recon1d_PPM_H4_2019, only : PPM_H4_2019
+  use MOM_EOS_UNESCO, only : UNESCO_EOS
   implicit none
 contains
+  !> src/equation_of_state/MOM_EOS_UNESCO.F90 (with MOM_EOS_base_type.F90: no other `use`): the elemental density :95, density
+  !! anomaly :133 and the T, S derivatives :244 of n points -- oracle/orc_dyn.c's unesco_* are held to these bit for bit.
+  subroutine ref_UNESCO(n, T, S, p, rho_ref, rho, rho_anom, drho_dT, drho_dS) bind(C, name="ref_UNESCO")
+    integer(c_int), value :: n
+    real(c_double), intent(in) :: T(n), S(n), p(n)
+    real(c_double), value :: rho_ref
+    real(c_double), intent(out) :: rho(n), rho_anom(n), drho_dT(n), drho_dS(n)
+    type(UNESCO_EOS) :: eos
+    integer :: i
+    do i=1,n
+      rho(i) = eos%density_elem(T(i), S(i), p(i))
+      rho_anom(i) = eos%density_anomaly_elem(T(i), S(i), p(i), rho_ref)
+      call eos%calculate_density_derivs_elem(T(i), S(i), p(i), drho_dT(i), drho_dS(i))
+    enddo
+  end subroutine
   !> The reference's class-based PPM with explicit 4th-order edge values, 2019 expressions (Recon1d_PPM_H4_2019.F90:86):
   !! the same algorithm as build_reconstructions_1d's REMAPPING_PPM_H4 branch without boundary extrapolation.
   subroutine ref_PPM_H4_2019(n, h, u, h_neglect, ul, ur) bind(C, name="ref_PPM_H4_2019")

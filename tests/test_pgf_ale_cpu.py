@@ -126,6 +126,31 @@ def test_PLM_quadrature_reduces_to_the_analytic_integrals(orc, form):
     assert np.abs(out[2] - out[1])[(Ellipsis,) + su].max() > 1e-8 * big      # the parabolas are not the lines
 
 
+def test_unesco_against_the_compiled_reference(orc):
+    """EQN_OF_STATE = UNESCO pinned to the REAL reference code: src/equation_of_state/MOM_EOS_UNESCO.F90 (+ MOM_EOS_base_type.F90)
+    compiles from its own two source files (oracle/_ref, no stand-ins); the oracle's density, rho_ref anomaly and T, S derivatives
+    equal its elemental functions bit for bit on 4000 random points over and beyond the fit's range (negative salinities, which the
+    reference clips, included)."""
+    L = _ref_lib()
+    if not hasattr(L, "ref_UNESCO"):
+        pytest.skip("oracle/_ref predates the UNESCO door (make -C oracle ref)")
+    rng = np.random.default_rng(11)
+    n = 4000
+    T = rng.uniform(-3.0, 42.0, n); S = rng.uniform(-1.0, 42.0, n); p = rng.uniform(0.0, 1.2e8, n)
+    S[:50] = 0.0; p[50:100] = 0.0; T[100:120] = 0.0
+    e = abi.eos_params_default(abi.UNESCO)
+    for rho_ref in (0.0, 1035.0):
+        rho, ra, dT, dS = (np.zeros(n) for _ in range(4))
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.ref_UNESCO(C.c_int(n), ptr(T), ptr(S), ptr(p), C.c_double(rho_ref), ptr(rho), ptr(ra), ptr(dT), ptr(dS))
+        mine = np.array([orc.eos_density(e, T[i], S[i], p[i]) for i in range(n)])
+        mine_a = np.array([orc.eos_density_anomaly(e, T[i], S[i], p[i], rho_ref) for i in range(n)])
+        mine_d = np.array([orc.eos_density_derivs(e, T[i], S[i], p[i]) for i in range(n)])
+        H.assert_bitwise(mine, rho, "UNESCO density"); H.assert_bitwise(mine_a, ra, "UNESCO density anomaly")
+        H.assert_bitwise(mine_d[:, 0], dT, "UNESCO drho_dT"); H.assert_bitwise(mine_d[:, 1], dS, "UNESCO drho_dS")
+    assert rho.min() > 990.0 and rho.max() < 1100.0
+
+
 def test_unesco_needs_the_quadratures(orc):
     """analytic_int_density_dz has no UNESCO branch (MOM_EOS.F90:1495: "No analytic integration option is available with this
     EOS!"): refused without EOS_QUADRATURE or a pressure reconstruction; with either, a resting stratified ocean feels no force."""
