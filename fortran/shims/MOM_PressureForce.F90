@@ -143,8 +143,9 @@ subroutine PressureForce_read_eos(param_file, GV, US, eos, have_eos)
     case ("WRIGHT_FULL") ; eos%form = 3
     case ("WRIGHT_REDUCED") ; eos%form = 4
     case ("UNESCO") ; eos%form = 5
+    case ("ROQUET_RHO", "NEMO") ; eos%form = 6
     case default ; call MOM_error(FATAL, "PressureForce_init: EQN_OF_STATE "//trim(tmpstr)//" is not carried by the MI355X path "//&
-                                  "(LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED and UNESCO are).")
+                                  "(LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO and ROQUET_RHO are).")
   end select
   call get_param(param_file, mdl, "EOS_QUADRATURE", flag, default=.false., do_not_log=.true.)   ! MOM_EOS.F90:1654
   eos%EOS_quadrature = merge(1_c_int, 0_c_int, flag)

@@ -96,10 +96,216 @@ __device__ __forceinline__ void density_derivs(double T, double S, double pressu
 }
 }  // namespace unesco
 
+namespace roquet {
+#define RQ_FN __device__ __forceinline__
+
+/* EQN_OF_STATE = "ROQUET_RHO" (alias "NEMO"): the polynomial of Roquet et al. (2015), MOM_EOS_Roquet_rho.F90.  EOSabc: the zs^a T^b p^c
+ * term (zs = sqrt((S + 32) * 0.875 / 35.16504)), R0c: the reference profile's p^(c+1) term, ALP / BET: the T / zs derivatives'
+ * coefficients -- the reference forms them as named constants from the published numbers (:12-155), and so do these macros, with
+ * integer powers by repeated squaring as the compiler folds them. */
+#define RQ_POW2(x) ((x) * (x))
+#define RQ_POW3(x) ((x) * ((x) * (x)))
+#define RQ_POW4(x) (((x) * (x)) * ((x) * (x)))
+#define RQ_POW5(x) ((x) * (((x) * (x)) * ((x) * (x))))
+#define RQ_POW6(x) (((x) * (x)) * (((x) * (x)) * ((x) * (x))))
+#define RQ_Pa2kb (1.e-8)
+#define RQ_rdeltaS (32.)
+#define RQ_r1_S0 (0.875/35.16504)
+#define RQ_I_Ts (0.025)
+#define RQ_R00 (4.6494977072e+01*RQ_Pa2kb)
+#define RQ_R01 (-5.2099962525*RQ_POW2(RQ_Pa2kb))
+#define RQ_R02 (2.2601900708e-01*RQ_POW3(RQ_Pa2kb))
+#define RQ_R03 (6.4326772569e-02*RQ_POW4(RQ_Pa2kb))
+#define RQ_R04 (1.5616995503e-02*RQ_POW5(RQ_Pa2kb))
+#define RQ_R05 (-1.7243708991e-03*RQ_POW6(RQ_Pa2kb))
+#define RQ_EOS000 (8.0189615746e+02)
+#define RQ_EOS100 (8.6672408165e+02)
+#define RQ_EOS200 (-1.7864682637e+03)
+#define RQ_EOS300 (2.0375295546e+03)
+#define RQ_EOS400 (-1.2849161071e+03)
+#define RQ_EOS500 (4.3227585684e+02)
+#define RQ_EOS600 (-6.0579916612e+01)
+#define RQ_EOS010 (2.6010145068e+01*RQ_I_Ts)
+#define RQ_EOS110 (-6.5281885265e+01*RQ_I_Ts)
+#define RQ_EOS210 (8.1770425108e+01*RQ_I_Ts)
+#define RQ_EOS310 (-5.6888046321e+01*RQ_I_Ts)
+#define RQ_EOS410 (1.7681814114e+01*RQ_I_Ts)
+#define RQ_EOS510 (-1.9193502195*RQ_I_Ts)
+#define RQ_EOS020 (-3.7074170417e+01*RQ_POW2(RQ_I_Ts))
+#define RQ_EOS120 (6.1548258127e+01*RQ_POW2(RQ_I_Ts))
+#define RQ_EOS220 (-6.0362551501e+01*RQ_POW2(RQ_I_Ts))
+#define RQ_EOS320 (2.9130021253e+01*RQ_POW2(RQ_I_Ts))
+#define RQ_EOS420 (-5.4723692739*RQ_POW2(RQ_I_Ts))
+#define RQ_EOS030 (2.1661789529e+01*RQ_POW3(RQ_I_Ts))
+#define RQ_EOS130 (-3.3449108469e+01*RQ_POW3(RQ_I_Ts))
+#define RQ_EOS230 (1.9717078466e+01*RQ_POW3(RQ_I_Ts))
+#define RQ_EOS330 (-3.1742946532*RQ_POW3(RQ_I_Ts))
+#define RQ_EOS040 (-8.3627885467*RQ_POW4(RQ_I_Ts))
+#define RQ_EOS140 (1.1311538584e+01*RQ_POW4(RQ_I_Ts))
+#define RQ_EOS240 (-5.3563304045*RQ_POW4(RQ_I_Ts))
+#define RQ_EOS050 (5.4048723791e-01*RQ_POW5(RQ_I_Ts))
+#define RQ_EOS150 (4.8169980163e-01*RQ_POW5(RQ_I_Ts))
+#define RQ_EOS060 (-1.9083568888e-01*RQ_POW6(RQ_I_Ts))
+#define RQ_EOS001 (1.9681925209e+01*RQ_Pa2kb)
+#define RQ_EOS101 (-4.2549998214e+01*RQ_Pa2kb)
+#define RQ_EOS201 (5.0774768218e+01*RQ_Pa2kb)
+#define RQ_EOS301 (-3.0938076334e+01*RQ_Pa2kb)
+#define RQ_EOS401 (6.6051753097*RQ_Pa2kb)
+#define RQ_EOS011 (-1.3336301113e+01*(RQ_I_Ts*RQ_Pa2kb))
+#define RQ_EOS111 (-4.4870114575*(RQ_I_Ts*RQ_Pa2kb))
+#define RQ_EOS211 (5.0042598061*(RQ_I_Ts*RQ_Pa2kb))
+#define RQ_EOS311 (-6.5399043664e-01*(RQ_I_Ts*RQ_Pa2kb))
+#define RQ_EOS021 (6.7080479603*(RQ_POW2(RQ_I_Ts)*RQ_Pa2kb))
+#define RQ_EOS121 (3.5063081279*(RQ_POW2(RQ_I_Ts)*RQ_Pa2kb))
+#define RQ_EOS221 (-1.8795372996*(RQ_POW2(RQ_I_Ts)*RQ_Pa2kb))
+#define RQ_EOS031 (-2.4649669534*(RQ_POW3(RQ_I_Ts)*RQ_Pa2kb))
+#define RQ_EOS131 (-5.5077101279e-01*(RQ_POW3(RQ_I_Ts)*RQ_Pa2kb))
+#define RQ_EOS041 (5.5927935970e-01*(RQ_POW4(RQ_I_Ts)*RQ_Pa2kb))
+#define RQ_EOS002 (2.0660924175*RQ_POW2(RQ_Pa2kb))
+#define RQ_EOS102 (-4.9527603989*RQ_POW2(RQ_Pa2kb))
+#define RQ_EOS202 (2.5019633244*RQ_POW2(RQ_Pa2kb))
+#define RQ_EOS012 (2.0564311499*(RQ_I_Ts*RQ_POW2(RQ_Pa2kb)))
+#define RQ_EOS112 (-2.1311365518e-01*(RQ_I_Ts*RQ_POW2(RQ_Pa2kb)))
+#define RQ_EOS022 (-1.2419983026*(RQ_POW2(RQ_I_Ts)*RQ_POW2(RQ_Pa2kb)))
+#define RQ_EOS003 (-2.3342758797e-02*RQ_POW3(RQ_Pa2kb))
+#define RQ_EOS103 (-1.8507636718e-02*RQ_POW3(RQ_Pa2kb))
+#define RQ_EOS013 (3.7969820455e-01*(RQ_I_Ts*RQ_POW3(RQ_Pa2kb)))
+#define RQ_ALP000 (RQ_EOS010)
+#define RQ_ALP100 (RQ_EOS110)
+#define RQ_ALP200 (RQ_EOS210)
+#define RQ_ALP300 (RQ_EOS310)
+#define RQ_ALP400 (RQ_EOS410)
+#define RQ_ALP500 (RQ_EOS510)
+#define RQ_ALP010 (2.*RQ_EOS020)
+#define RQ_ALP110 (2.*RQ_EOS120)
+#define RQ_ALP210 (2.*RQ_EOS220)
+#define RQ_ALP310 (2.*RQ_EOS320)
+#define RQ_ALP410 (2.*RQ_EOS420)
+#define RQ_ALP020 (3.*RQ_EOS030)
+#define RQ_ALP120 (3.*RQ_EOS130)
+#define RQ_ALP220 (3.*RQ_EOS230)
+#define RQ_ALP320 (3.*RQ_EOS330)
+#define RQ_ALP030 (4.*RQ_EOS040)
+#define RQ_ALP130 (4.*RQ_EOS140)
+#define RQ_ALP230 (4.*RQ_EOS240)
+#define RQ_ALP040 (5.*RQ_EOS050)
+#define RQ_ALP140 (5.*RQ_EOS150)
+#define RQ_ALP050 (6.*RQ_EOS060)
+#define RQ_ALP001 (RQ_EOS011)
+#define RQ_ALP101 (RQ_EOS111)
+#define RQ_ALP201 (RQ_EOS211)
+#define RQ_ALP301 (RQ_EOS311)
+#define RQ_ALP011 (2.*RQ_EOS021)
+#define RQ_ALP111 (2.*RQ_EOS121)
+#define RQ_ALP211 (2.*RQ_EOS221)
+#define RQ_ALP021 (3.*RQ_EOS031)
+#define RQ_ALP121 (3.*RQ_EOS131)
+#define RQ_ALP031 (4.*RQ_EOS041)
+#define RQ_ALP002 (RQ_EOS012)
+#define RQ_ALP102 (RQ_EOS112)
+#define RQ_ALP012 (2.*RQ_EOS022)
+#define RQ_ALP003 (RQ_EOS013)
+#define RQ_BET000 (0.5*RQ_EOS100*RQ_r1_S0)
+#define RQ_BET100 (RQ_EOS200*RQ_r1_S0)
+#define RQ_BET200 (1.5*RQ_EOS300*RQ_r1_S0)
+#define RQ_BET300 (2.0*RQ_EOS400*RQ_r1_S0)
+#define RQ_BET400 (2.5*RQ_EOS500*RQ_r1_S0)
+#define RQ_BET500 (3.0*RQ_EOS600*RQ_r1_S0)
+#define RQ_BET010 (0.5*RQ_EOS110*RQ_r1_S0)
+#define RQ_BET110 (RQ_EOS210*RQ_r1_S0)
+#define RQ_BET210 (1.5*RQ_EOS310*RQ_r1_S0)
+#define RQ_BET310 (2.0*RQ_EOS410*RQ_r1_S0)
+#define RQ_BET410 (2.5*RQ_EOS510*RQ_r1_S0)
+#define RQ_BET020 (0.5*RQ_EOS120*RQ_r1_S0)
+#define RQ_BET120 (RQ_EOS220*RQ_r1_S0)
+#define RQ_BET220 (1.5*RQ_EOS320*RQ_r1_S0)
+#define RQ_BET320 (2.0*RQ_EOS420*RQ_r1_S0)
+#define RQ_BET030 (0.5*RQ_EOS130*RQ_r1_S0)
+#define RQ_BET130 (RQ_EOS230*RQ_r1_S0)
+#define RQ_BET230 (1.5*RQ_EOS330*RQ_r1_S0)
+#define RQ_BET040 (0.5*RQ_EOS140*RQ_r1_S0)
+#define RQ_BET140 (RQ_EOS240*RQ_r1_S0)
+#define RQ_BET050 (0.5*RQ_EOS150*RQ_r1_S0)
+#define RQ_BET001 (0.5*RQ_EOS101*RQ_r1_S0)
+#define RQ_BET101 (RQ_EOS201*RQ_r1_S0)
+#define RQ_BET201 (1.5*RQ_EOS301*RQ_r1_S0)
+#define RQ_BET301 (2.0*RQ_EOS401*RQ_r1_S0)
+#define RQ_BET011 (0.5*RQ_EOS111*RQ_r1_S0)
+#define RQ_BET111 (RQ_EOS211*RQ_r1_S0)
+#define RQ_BET211 (1.5*RQ_EOS311*RQ_r1_S0)
+#define RQ_BET021 (0.5*RQ_EOS121*RQ_r1_S0)
+#define RQ_BET121 (RQ_EOS221*RQ_r1_S0)
+#define RQ_BET031 (0.5*RQ_EOS131*RQ_r1_S0)
+#define RQ_BET002 (0.5*RQ_EOS102*RQ_r1_S0)
+#define RQ_BET102 (RQ_EOS202*RQ_r1_S0)
+#define RQ_BET012 (0.5*RQ_EOS112*RQ_r1_S0)
+#define RQ_BET003 (0.5*RQ_EOS103*RQ_r1_S0)
+
+RQ_FN void roquet_parts(double T, double S, double pressure, double *zs_out, double *rhoTS0, double *rhoTS1, double *rhoTS2,
+                        double *rhoTS3, double *rho0S0, double *rho00p) {   /* :216-241 */
+  const double zt = T, zs = sqrt(fabs(S + RQ_rdeltaS) * RQ_r1_S0), zp = pressure;
+  *rhoTS3 = RQ_EOS003 + (zs * RQ_EOS103 + zt * RQ_EOS013);
+  *rhoTS2 = RQ_EOS002 + (zs * (RQ_EOS102 + zs * RQ_EOS202) + zt * (RQ_EOS012 + (zs * RQ_EOS112 + zt * RQ_EOS022)));
+  *rhoTS1 = RQ_EOS001 + (zs * (RQ_EOS101 + zs * (RQ_EOS201 + zs * (RQ_EOS301 + zs * RQ_EOS401))) +
+                         zt * (RQ_EOS011 + (zs * (RQ_EOS111 + zs * (RQ_EOS211 + zs * RQ_EOS311)) +
+                                            zt * (RQ_EOS021 + (zs * (RQ_EOS121 + zs * RQ_EOS221) +
+                                                               zt * (RQ_EOS031 + (zs * RQ_EOS131 + zt * RQ_EOS041)))))));
+  *rhoTS0 = zt * (RQ_EOS010 +
+                  (zs * (RQ_EOS110 + zs * (RQ_EOS210 + zs * (RQ_EOS310 + zs * (RQ_EOS410 + zs * RQ_EOS510)))) +
+                   zt * (RQ_EOS020 + (zs * (RQ_EOS120 + zs * (RQ_EOS220 + zs * (RQ_EOS320 + zs * RQ_EOS420))) +
+                                      zt * (RQ_EOS030 + (zs * (RQ_EOS130 + zs * (RQ_EOS230 + zs * RQ_EOS330)) +
+                                                         zt * (RQ_EOS040 + (zs * (RQ_EOS140 + zs * RQ_EOS240) +
+                                                                            zt * (RQ_EOS050 + (zs * RQ_EOS150 + zt * RQ_EOS060))))))))));
+  *rho0S0 = RQ_EOS000 + zs * (RQ_EOS100 + zs * (RQ_EOS200 + zs * (RQ_EOS300 + zs * (RQ_EOS400 + zs * (RQ_EOS500 + zs * RQ_EOS600)))));
+  *rho00p = zp * (RQ_R00 + zp * (RQ_R01 + zp * (RQ_R02 + zp * (RQ_R03 + zp * (RQ_R04 + zp * RQ_R05)))));
+  *zs_out = zs;
+}
+RQ_FN double roquet_density(double T, double S, double pressure) {   /* density_elem_Roquet_rho :192-243 */
+  double zs, r0, r1, r2, r3, s0, p0;
+  roquet_parts(T, S, pressure, &zs, &r0, &r1, &r2, &r3, &s0, &p0);
+  const double zp = pressure;
+  const double rhoTS = (r0 + s0) + zp * (r1 + zp * (r2 + zp * r3));
+  return rhoTS + p0;
+}
+RQ_FN double roquet_density_anomaly(double T, double S, double pressure, double rho_ref) {   /* :248-306 */
+  double zs, r0, r1, r2, r3, s0, p0;
+  roquet_parts(T, S, pressure, &zs, &r0, &r1, &r2, &r3, &s0, &p0);
+  const double zp = pressure;
+  s0 = s0 - rho_ref;
+  const double rhoTS = (r0 + s0) + zp * (r1 + zp * (r2 + zp * r3));
+  return rhoTS + p0;
+}
+RQ_FN void roquet_density_derivs(double T, double S, double pressure, double *drho_dT, double *drho_dS) {   /* :340-411 */
+  const double zt = T, zs = sqrt(fabs(S + RQ_rdeltaS) * RQ_r1_S0), zp = pressure;
+  const double dRdzt3 = RQ_ALP003;
+  const double dRdzt2 = RQ_ALP002 + (zs * RQ_ALP102 + zt * RQ_ALP012);
+  const double dRdzt1 = RQ_ALP001 + (zs * (RQ_ALP101 + zs * (RQ_ALP201 + zs * RQ_ALP301)) +
+                                     zt * (RQ_ALP011 + (zs * (RQ_ALP111 + zs * RQ_ALP211) + zt * (RQ_ALP021 + (zs * RQ_ALP121 + zt * RQ_ALP031)))));
+  const double dRdzt0 = RQ_ALP000 + (zs * (RQ_ALP100 + zs * (RQ_ALP200 + zs * (RQ_ALP300 + zs * (RQ_ALP400 + zs * RQ_ALP500)))) +
+                                     zt * (RQ_ALP010 + (zs * (RQ_ALP110 + zs * (RQ_ALP210 + zs * (RQ_ALP310 + zs * RQ_ALP410))) +
+                                                        zt * (RQ_ALP020 + (zs * (RQ_ALP120 + zs * (RQ_ALP220 + zs * RQ_ALP320)) +
+                                                                           zt * (RQ_ALP030 + (zt * (RQ_ALP040 + (zs * RQ_ALP140 + zt * RQ_ALP050)) +
+                                                                                              zs * (RQ_ALP130 + zs * RQ_ALP230))))))));
+  *drho_dT = dRdzt0 + zp * (dRdzt1 + zp * (dRdzt2 + zp * dRdzt3));
+  const double dRdzs3 = RQ_BET003;
+  const double dRdzs2 = RQ_BET002 + (zs * RQ_BET102 + zt * RQ_BET012);
+  const double dRdzs1 = RQ_BET001 + (zs * (RQ_BET101 + zs * (RQ_BET201 + zs * RQ_BET301)) +
+                                     zt * (RQ_BET011 + (zs * (RQ_BET111 + zs * RQ_BET211) + zt * (RQ_BET021 + (zs * RQ_BET121 + zt * RQ_BET031)))));
+  const double dRdzs0 = RQ_BET000 + (zs * (RQ_BET100 + zs * (RQ_BET200 + zs * (RQ_BET300 + zs * (RQ_BET400 + zs * RQ_BET500)))) +
+                                     zt * (RQ_BET010 + (zs * (RQ_BET110 + zs * (RQ_BET210 + zs * (RQ_BET310 + zs * RQ_BET410))) +
+                                                        zt * (RQ_BET020 + (zs * (RQ_BET120 + zs * (RQ_BET220 + zs * RQ_BET320)) +
+                                                                           zt * (RQ_BET030 + (zt * (RQ_BET040 + (zs * RQ_BET140 + zt * RQ_BET050)) +
+                                                                                              zs * (RQ_BET130 + zs * RQ_BET230))))))));
+  *drho_dS = (dRdzs0 + zp * (dRdzs1 + zp * (dRdzs2 + zp * dRdzs3))) / zs;
+}
+#undef RQ_FN
+}  // namespace roquet
+
 __device__ __forceinline__ double eos_density(int form, double Rho_T0_S0, double dRho_dT, double dRho_dS, double dRho_dp, double T,
                                               double S, double p) {
   if (form == MOM6X_EOS_LINEAR) return Rho_T0_S0 + dRho_dT * T + dRho_dS * S + dRho_dp * p;
   if (form == MOM6X_EOS_UNESCO) return unesco::density(T, S, p);
+  if (form == MOM6X_EOS_ROQUET_RHO) return roquet::roquet_density(T, S, p);
   if (form == MOM6X_EOS_WRIGHT_FULL) return wright_density<MOM6X_EOS_WRIGHT_FULL>(T, S, p);
   if (form == MOM6X_EOS_WRIGHT_REDUCED) return wright_density<MOM6X_EOS_WRIGHT_REDUCED>(T, S, p);
   return wright_density<MOM6X_EOS_WRIGHT>(T, S, p);

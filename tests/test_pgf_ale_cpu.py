@@ -63,7 +63,7 @@ def test_density_anomaly_against_reference_check_values(orc):
     # WRIGHT_FULL :2058-2060, WRIGHT_REDUCED :2064-2066 -- through density_elem and through the rho_ref form
     # UNESCO :2052-2054
     for form, check in ((abi.WRIGHT_FULL, 1027.55177447616), (abi.WRIGHT_REDUCED, 1027.54303596346), (abi.WRIGHT, 1027.54303596346),
-                        (abi.UNESCO, 1027.54345796120)):
+                        (abi.UNESCO, 1027.54345796120), (abi.ROQUET_RHO, 1027.42385663668)):   # ROQUET_RHO :2085-2087
         e = abi.eos_params_default(form)
         assert abs(orc.eos_density(e, 25.0, 35.0, 1.0e7) - check) < 1000 * 2.2e-16 * 1027.5
         for rho_ref in (0.0, 1000.0, 1035.0):
@@ -126,32 +126,34 @@ def test_PLM_quadrature_reduces_to_the_analytic_integrals(orc, form):
     assert np.abs(out[2] - out[1])[(Ellipsis,) + su].max() > 1e-8 * big      # the parabolas are not the lines
 
 
-def test_unesco_against_the_compiled_reference(orc):
-    """EQN_OF_STATE = UNESCO pinned to the REAL reference code: src/equation_of_state/MOM_EOS_UNESCO.F90 (+ MOM_EOS_base_type.F90)
-    compiles from its own two source files (oracle/_ref, no stand-ins); the oracle's density, rho_ref anomaly and T, S derivatives
-    equal its elemental functions bit for bit on 4000 random points over and beyond the fit's range (negative salinities, which the
-    reference clips, included)."""
+@pytest.mark.parametrize("name", ["UNESCO", "ROQUET_RHO"])
+def test_unesco_and_roquet_against_the_compiled_reference(orc, name):
+    """EQN_OF_STATE = UNESCO and ROQUET_RHO (= NEMO) pinned to the REAL reference code: src/equation_of_state/MOM_EOS_UNESCO.F90 and
+    MOM_EOS_Roquet_rho.F90 (+ MOM_EOS_base_type.F90) compile from their own source files (oracle/_ref, no stand-ins); the oracle's
+    density, rho_ref anomaly and T, S derivatives equal their elemental functions bit for bit on 4000 random points over and beyond
+    the fits' range (negative salinities included)."""
     L = _ref_lib()
-    if not hasattr(L, "ref_UNESCO"):
-        pytest.skip("oracle/_ref predates the UNESCO door (make -C oracle ref)")
+    if not hasattr(L, "ref_" + name):
+        pytest.skip("oracle/_ref predates this door (make -C oracle ref)")
     rng = np.random.default_rng(11)
     n = 4000
     T = rng.uniform(-3.0, 42.0, n); S = rng.uniform(-1.0, 42.0, n); p = rng.uniform(0.0, 1.2e8, n)
     S[:50] = 0.0; p[50:100] = 0.0; T[100:120] = 0.0
-    e = abi.eos_params_default(abi.UNESCO)
+    e = abi.eos_params_default(getattr(abi, name))
     for rho_ref in (0.0, 1035.0):
         rho, ra, dT, dS = (np.zeros(n) for _ in range(4))
         ptr = lambda a: a.ctypes.data_as(C.c_void_p)
-        L.ref_UNESCO(C.c_int(n), ptr(T), ptr(S), ptr(p), C.c_double(rho_ref), ptr(rho), ptr(ra), ptr(dT), ptr(dS))
+        getattr(L, "ref_" + name)(C.c_int(n), ptr(T), ptr(S), ptr(p), C.c_double(rho_ref), ptr(rho), ptr(ra), ptr(dT), ptr(dS))
         mine = np.array([orc.eos_density(e, T[i], S[i], p[i]) for i in range(n)])
         mine_a = np.array([orc.eos_density_anomaly(e, T[i], S[i], p[i], rho_ref) for i in range(n)])
         mine_d = np.array([orc.eos_density_derivs(e, T[i], S[i], p[i]) for i in range(n)])
-        H.assert_bitwise(mine, rho, "UNESCO density"); H.assert_bitwise(mine_a, ra, "UNESCO density anomaly")
-        H.assert_bitwise(mine_d[:, 0], dT, "UNESCO drho_dT"); H.assert_bitwise(mine_d[:, 1], dS, "UNESCO drho_dS")
+        H.assert_bitwise(mine, rho, name + " density"); H.assert_bitwise(mine_a, ra, name + " density anomaly")
+        H.assert_bitwise(mine_d[:, 0], dT, name + " drho_dT"); H.assert_bitwise(mine_d[:, 1], dS, name + " drho_dS")
     assert rho.min() > 990.0 and rho.max() < 1100.0
 
 
-def test_unesco_needs_the_quadratures(orc):
+@pytest.mark.parametrize("form", [abi.UNESCO, abi.ROQUET_RHO])
+def test_unesco_and_roquet_need_the_quadratures(orc, form):
     """analytic_int_density_dz has no UNESCO branch (MOM_EOS.F90:1495: "No analytic integration option is available with this
     EOS!"): refused without EOS_QUADRATURE or a pressure reconstruction; with either, a resting stratified ocean feels no force."""
     gg, d, M = H.channel(nk=6)
@@ -163,10 +165,10 @@ def test_unesco_needs_the_quadratures(orc):
         T[k] = 18.0 - 3.0 * k; S[k] = 34.0 + 0.3 * k
     Pu, Pv = np.zeros_like(h), np.zeros_like(h)
     with pytest.raises(RuntimeError):
-        orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, T=T, S=S, eos=abi.eos_params_default(abi.UNESCO))
+        orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, T=T, S=S, eos=abi.eos_params_default(form))
     su, sv = H.interior(d, "u"), H.interior(d, "v")
     for mods in (dict(EOS_quadrature=1), dict(Recon_Scheme=1), dict(Recon_Scheme=2, MassWghtInterp=3)):
-        eos = abi.eos_params_default(abi.UNESCO)
+        eos = abi.eos_params_default(form)
         for k, v in mods.items(): setattr(eos, k, v)
         pb = np.zeros_like(h)
         orc.PressureForce(d, M, GV, CS, Rlay, gp, h, Pu, Pv, pbce=pb, T=T, S=S, eos=eos)

@@ -177,7 +177,7 @@ def test_ALE_regrid_zstar_then_remap(orc, cfg, mods):
                                   dict(boundary_extrapolation=1, min_thickness=2.0, old_grid_weight=0.5, depth_of_time_filter_shallow=100.,
                                        depth_of_time_filter_deep=700.),
                                   dict(integrate_downward_for_e=0, compressibility_fraction=0.3, ref_pressure=1.0e7)])
-@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT, abi.WRIGHT_FULL, abi.UNESCO], ids=["LINEAR", "WRIGHT", "WRIGHT_FULL", "UNESCO"])
+@pytest.mark.parametrize("form", [abi.LINEAR, abi.WRIGHT, abi.WRIGHT_FULL, abi.UNESCO, abi.ROQUET_RHO], ids=["LINEAR", "WRIGHT", "WRIGHT_FULL", "UNESCO", "ROQUET_RHO"])
 def test_ALE_regrid_density_coordinates(orc, cfg, which, mods, form):
     """REGRIDDING_RHO (after convective_adjustment) and REGRIDDING_HYCOM1 on the device: the reordered column, the new
     thicknesses and the interface displacements bit for bit against the oracle -- every interpolation scheme on the path,

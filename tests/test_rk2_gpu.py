@@ -176,9 +176,11 @@ def test_rk2_device_matches_committed_golden(orc):
 
 
 @pytest.mark.parametrize("recon", [1, 2, "quadrature"])
-def test_rk2_with_the_unesco_equation_of_state(orc, recon):
-    """EQN_OF_STATE = UNESCO, which has no analytic integrals: the whole step through the quadratures, bit for bit."""
-    run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), eos_form=abi.UNESCO, recon=recon)
+@pytest.mark.parametrize("form", [abi.UNESCO, abi.ROQUET_RHO], ids=["UNESCO", "ROQUET_RHO"])
+def test_rk2_with_the_equations_of_state_without_analytic_integrals(orc, form, recon):
+    """EQN_OF_STATE = UNESCO / ROQUET_RHO (NEMO), which have no analytic integrals: the whole step through the quadratures, bit for
+    bit."""
+    run(orc, H.benchmark_small(), nsteps=2, bt_mod=dict(strong_drag=1), eos_form=form, recon=recon)
 
 
 @pytest.mark.parametrize("recon", [0, 1, 2, "quadrature"])
