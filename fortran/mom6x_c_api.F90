@@ -153,7 +153,7 @@ module mom6x_c_api
   end type mom6x_energy_sums
 
   type, bind(C) :: mom6x_eos_params        !< tv%eqn_of_state (MOM_EOS.F90:99-150) + EOS-only switches of PressureForce_FV_CS
-    integer(c_int) :: form                 !< 1 EOS_LINEAR, 2 EOS_WRIGHT, 3 EOS_WRIGHT_FULL, 4 EOS_WRIGHT_REDUCED, 5 EOS_UNESCO, 6 EOS_ROQUET_RHO
+    integer(c_int) :: form                 !< 1 EOS_LINEAR, 2 EOS_WRIGHT, 3 EOS_WRIGHT_FULL, 4 EOS_WRIGHT_REDUCED, 5 EOS_UNESCO, 6 EOS_ROQUET_RHO, 7 EOS_JACKETT06, 8 EOS_ROQUET_SPV
     real(c_double) :: Rho_T0_S0, dRho_dT, dRho_dS, dRho_dp
     integer(c_int) :: MassWghtInterp, use_SSH_in_Z0p
     integer(c_int) :: Recon_Scheme, boundary_extrap, MassWghtInterpVanOnly   !< ALE: PLM reconstruction of T, S for the pressure force

@@ -142,10 +142,12 @@ subroutine PressureForce_read_eos(param_file, GV, US, eos, have_eos)
     case ("WRIGHT") ; eos%form = 2
     case ("WRIGHT_FULL") ; eos%form = 3
     case ("WRIGHT_REDUCED") ; eos%form = 4
-    case ("UNESCO") ; eos%form = 5
+    case ("UNESCO", "JACKETT_MCD") ; eos%form = 5       ! (MOM_EOS.F90:1572-1573: JACKETT_MCD is the UNESCO refit)
+    case ("JACKETT_06") ; eos%form = 7
+    case ("ROQUET_SPV") ; eos%form = 8
     case ("ROQUET_RHO", "NEMO") ; eos%form = 6
     case default ; call MOM_error(FATAL, "PressureForce_init: EQN_OF_STATE "//trim(tmpstr)//" is not carried by the MI355X path "//&
-                                  "(LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO and ROQUET_RHO are).")
+                                  "(LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO, ROQUET_RHO, JACKETT_06 and ROQUET_SPV are; TEOS10 is not).")
   end select
   call get_param(param_file, mdl, "EOS_QUADRATURE", flag, default=.false., do_not_log=.true.)   ! MOM_EOS.F90:1654
   eos%EOS_quadrature = merge(1_c_int, 0_c_int, flag)

@@ -256,9 +256,12 @@ typedef struct mom6x_hor_visc_params {
  * with the analytic integrals and, with EOS_QUADRATURE or a pressure reconstruction, the generic quadratures.  UNESCO
  * (MOM_EOS_UNESCO.F90) has no analytic integrals: it needs EOS_QUADRATURE or a pressure reconstruction, as in the reference
  * ("No analytic integration option is available with this EOS!"); likewise ROQUET_RHO (= NEMO, MOM_EOS_Roquet_rho.F90).
- * ROQUET_SPV, JACKETT_06 and TEOS10 are refused.   */
+ * JACKETT_06 (MOM_EOS_Jackett06.F90) and ROQUET_SPV (MOM_EOS_Roquet_SpV.F90).  TEOS10 (the gsw library, whose sources are not in
+ * the reference tree) is refused.   */
 enum mom6x_eos_form { MOM6X_EOS_LINEAR = 1, MOM6X_EOS_WRIGHT = 2, MOM6X_EOS_WRIGHT_FULL = 3, MOM6X_EOS_WRIGHT_REDUCED = 4, MOM6X_EOS_UNESCO = 5,
-                      MOM6X_EOS_ROQUET_RHO = 6 /* "ROQUET_RHO" = "NEMO": MOM_EOS_Roquet_rho.F90; quadratures only, like UNESCO */ };
+                      MOM6X_EOS_ROQUET_RHO = 6, /* "ROQUET_RHO" = "NEMO": MOM_EOS_Roquet_rho.F90; quadratures only, like UNESCO */
+                      MOM6X_EOS_JACKETT06 = 7,  /* "JACKETT_06": MOM_EOS_Jackett06.F90; quadratures only ("JACKETT_MCD" is UNESCO) */
+                      MOM6X_EOS_ROQUET_SPV = 8  /* "ROQUET_SPV": MOM_EOS_Roquet_SpV.F90; quadratures only */ };
 typedef struct mom6x_eos_params {
   int    form;            /* EQN_OF_STATE                                                       */
   double Rho_T0_S0;       /* RHO_T0_S0 (1000)  } EOS_LINEAR                                     */

@@ -311,7 +311,7 @@ def regrid_rho_params_default(**kw):
     return p
 
 
-LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO, ROQUET_RHO = 1, 2, 3, 4, 5, 6   # enum mom6x_eos_form
+LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO, ROQUET_RHO, JACKETT06, ROQUET_SPV = 1, 2, 3, 4, 5, 6, 7, 8   # enum mom6x_eos_form
 
 
 class EOSParams(C.Structure):

@@ -910,6 +910,8 @@ __device__ __forceinline__ double density_anomaly(const EosDev &E, double T, dou
     return (E.Rho_T0_S0 - rho_ref) + ((E.dRho_dT * T + E.dRho_dS * S) + E.dRho_dp * pressure);
   if (FORM == MOM6X_EOS_UNESCO) return unesco::density_anomaly(T, S, pressure, rho_ref);
   if (FORM == MOM6X_EOS_ROQUET_RHO) return roquet::roquet_density_anomaly(T, S, pressure, rho_ref);
+  if (FORM == MOM6X_EOS_JACKETT06) return jackett::jackett_density_anomaly(T, S, pressure, rho_ref);
+  if (FORM == MOM6X_EOS_ROQUET_SPV) return roquet::roquet_spv_density_anomaly(T, S, pressure, rho_ref);
   typedef WC<FORM> W;   // the same expression in MOM_EOS_Wright.F90:119-128, _full.F90:108-119, _red.F90:108-119
   const double pa_000 = (W::b0 * (1.0 - W::a0 * rho_ref) - rho_ref * W::c0);
   const double al_TS = W::a1 * T + W::a2 * S;
@@ -1209,6 +1211,8 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
         if (FORM == MOM6X_EOS_LINEAR) rho_in_situ = E.Rho_T0_S0 + E.dRho_dT * T0 + E.dRho_dS * S0 + E.dRho_dp * press;
         else if (FORM == MOM6X_EOS_UNESCO) rho_in_situ = unesco::density(T0, S0, press);
         else if (FORM == MOM6X_EOS_ROQUET_RHO) rho_in_situ = roquet::roquet_density(T0, S0, press);
+        else if (FORM == MOM6X_EOS_JACKETT06) rho_in_situ = jackett::jackett_density(T0, S0, press);
+        else if (FORM == MOM6X_EOS_ROQUET_SPV) rho_in_situ = roquet::roquet_spv_density(T0, S0, press);
         else {
           rho_in_situ = wright_density<FORM>(T0, S0, press);
         }
@@ -1219,6 +1223,8 @@ k_pgf_main_eos(Dm d, const double *__restrict__ G, const double *__restrict__ h,
         if (FORM == MOM6X_EOS_LINEAR) { dR_dT = E.dRho_dT; dR_dS = E.dRho_dS; }
         else if (FORM == MOM6X_EOS_UNESCO) unesco::density_derivs(T_int, S_int, press, dR_dT, dR_dS);
         else if (FORM == MOM6X_EOS_ROQUET_RHO) roquet::roquet_density_derivs(T_int, S_int, press, &dR_dT, &dR_dS);
+        else if (FORM == MOM6X_EOS_JACKETT06) jackett::jackett_density_derivs(T_int, S_int, press, &dR_dT, &dR_dS);
+        else if (FORM == MOM6X_EOS_ROQUET_SPV) roquet::roquet_spv_density_derivs(T_int, S_int, press, &dR_dT, &dR_dS);
         else {
           typedef WC<FORM> W;
           double al0, p0, lambda;
@@ -1251,8 +1257,8 @@ extern "C" int mom6x_PressureForce_set_tv(mom6x_ctx *c, const double *T, const d
   REQUIRE(c, MOM6X_EINVAL, "mom6x_PressureForce_set_tv: null ctx");
   if (!T) { c->tv_T = nullptr; c->tv_S = nullptr; return MOM6X_OK; }
   REQUIRE(S && eos, MOM6X_EINVAL, "mom6x_PressureForce_set_tv: tv%T without tv%S or tv%eqn_of_state");
-  REQUIRE(eos->form >= MOM6X_EOS_LINEAR && eos->form <= MOM6X_EOS_ROQUET_RHO, MOM6X_EUNSUPPORTED,
-          "PressureForce: EQN_OF_STATE must be LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO or ROQUET_RHO (NEMO)");
+  REQUIRE(eos->form >= MOM6X_EOS_LINEAR && eos->form <= MOM6X_EOS_ROQUET_SPV, MOM6X_EUNSUPPORTED,
+          "PressureForce: EQN_OF_STATE must be LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO, ROQUET_RHO (NEMO), JACKETT_06 or ROQUET_SPV");
   // analytic_int_density_dz, MOM_EOS.F90:1495-1496
   REQUIRE(eos->form < MOM6X_EOS_UNESCO || eos->EOS_quadrature || eos->Recon_Scheme, MOM6X_EUNSUPPORTED,
           "No analytic integration option is available with this EOS!");
@@ -1325,6 +1331,14 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
       if (mode == 1) PGF_EOS(MOM6X_EOS_ROQUET_RHO, 1, "k_pgf_main_plm<roquet_rho>");
       else if (mode == 2) PGF_EOS(MOM6X_EOS_ROQUET_RHO, 2, "k_pgf_main_ppm<roquet_rho>");
       else PGF_EOS(MOM6X_EOS_ROQUET_RHO, 3, "k_pgf_main_pcm<roquet_rho>");
+    } else if (E.form == MOM6X_EOS_ROQUET_SPV) {
+      if (mode == 1) PGF_EOS(MOM6X_EOS_ROQUET_SPV, 1, "k_pgf_main_plm<roquet_spv>");
+      else if (mode == 2) PGF_EOS(MOM6X_EOS_ROQUET_SPV, 2, "k_pgf_main_ppm<roquet_spv>");
+      else PGF_EOS(MOM6X_EOS_ROQUET_SPV, 3, "k_pgf_main_pcm<roquet_spv>");
+    } else if (E.form == MOM6X_EOS_JACKETT06) {
+      if (mode == 1) PGF_EOS(MOM6X_EOS_JACKETT06, 1, "k_pgf_main_plm<jackett06>");
+      else if (mode == 2) PGF_EOS(MOM6X_EOS_JACKETT06, 2, "k_pgf_main_ppm<jackett06>");
+      else PGF_EOS(MOM6X_EOS_JACKETT06, 3, "k_pgf_main_pcm<jackett06>");
     } else if (E.form == MOM6X_EOS_LINEAR) PGF_FORM(MOM6X_EOS_LINEAR, "linear");
     else if (E.form == MOM6X_EOS_WRIGHT_FULL) PGF_FORM(MOM6X_EOS_WRIGHT_FULL, "wright_full");
     else if (E.form == MOM6X_EOS_WRIGHT_REDUCED) PGF_FORM(MOM6X_EOS_WRIGHT_REDUCED, "wright_red");

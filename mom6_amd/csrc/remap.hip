@@ -1345,7 +1345,7 @@ static int regrid_density(mom6x_ctx *c, bool hycom, const mom6x_regrid_rho_param
   REQUIRE(p->f.old_grid_weight >= 0.0 && p->f.old_grid_weight < 1.0, MOM6X_EINVAL, "ALE_regrid: old_grid_weight must be in [0, 1)");
   REQUIRE(p->interp_scheme == MOM6X_INTERP_P1M_H2 || p->interp_scheme == MOM6X_INTERP_PLM || p->interp_scheme == MOM6X_INTERP_PPM_H4,
           MOM6X_EUNSUPPORTED, "regrid_interp: INTERPOLATION_SCHEME must be P1M_H2, PLM or PPM_H4 on the device path");
-  REQUIRE(eos->form >= MOM6X_EOS_LINEAR && eos->form <= MOM6X_EOS_ROQUET_RHO, MOM6X_EUNSUPPORTED, "ALE_regrid: EQN_OF_STATE must be LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO or ROQUET_RHO");
+  REQUIRE(eos->form >= MOM6X_EOS_LINEAR && eos->form <= MOM6X_EOS_ROQUET_SPV, MOM6X_EUNSUPPORTED, "ALE_regrid: every EQN_OF_STATE but TEOS10 is carried");
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   REQUIRE(d.halo >= 1, MOM6X_EINVAL, "ALE_regrid: one halo point needed");
@@ -1401,7 +1401,7 @@ extern "C" int mom6x_ALE_regrid_hycom1(mom6x_ctx *c, const mom6x_regrid_rho_para
 
 extern "C" int mom6x_ALE_convective_adjustment(mom6x_ctx *c, const mom6x_eos_params *eos, double *h, double *T, double *S) {
   REQUIRE(c && eos && h && T && S, MOM6X_EINVAL, "convective_adjustment: null argument");
-  REQUIRE(eos->form >= MOM6X_EOS_LINEAR && eos->form <= MOM6X_EOS_ROQUET_RHO, MOM6X_EUNSUPPORTED, "convective_adjustment: EQN_OF_STATE must be LINEAR, WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO or ROQUET_RHO");
+  REQUIRE(eos->form >= MOM6X_EOS_LINEAR && eos->form <= MOM6X_EOS_ROQUET_SPV, MOM6X_EUNSUPPORTED, "convective_adjustment: every EQN_OF_STATE but TEOS10 is carried");
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   REQUIRE(d.halo >= 1, MOM6X_EINVAL, "convective_adjustment: one halo point needed");

@@ -564,13 +564,284 @@ RQ_FN void roquet_density_derivs(double T, double S, double pressure, double *dr
                                                                                               zs * (RQ_BET130 + zs * RQ_BET230))))))));
   *drho_dS = (dRdzs0 + zp * (dRdzs1 + zp * (dRdzs2 + zp * dRdzs3))) / zs;
 }
+
+/* EQN_OF_STATE = "ROQUET_SPV": the specific-volume polynomial of Roquet et al. (2015), MOM_EOS_Roquet_SpV.F90 -- the same structure
+ * as ROQUET_RHO with SPVabc / V0c / ALP / BET (zs = sqrt((S + 24) * 0.875 / 35.16504)); density = 1 / spec_vol. */
+#define RS_Pa2kb (1.e-8)
+#define RS_rdeltaS (24.)
+#define RS_r1_S0 (0.875/35.16504)
+#define RS_I_Ts (0.025)
+#define RS_V00 (-4.4015007269e-05*RS_Pa2kb)
+#define RS_V01 (6.9232335784e-06*RQ_POW2(RS_Pa2kb))
+#define RS_V02 (-7.5004675975e-07*RQ_POW3(RS_Pa2kb))
+#define RS_V03 (1.7009109288e-08*RQ_POW4(RS_Pa2kb))
+#define RS_V04 (-1.6884162004e-08*RQ_POW5(RS_Pa2kb))
+#define RS_V05 (1.9613503930e-09*RQ_POW6(RS_Pa2kb))
+#define RS_SPV000 (1.0772899069e-03)
+#define RS_SPV100 (-3.1263658781e-04)
+#define RS_SPV200 (6.7615860683e-04)
+#define RS_SPV300 (-8.6127884515e-04)
+#define RS_SPV400 (5.9010812596e-04)
+#define RS_SPV500 (-2.1503943538e-04)
+#define RS_SPV600 (3.2678954455e-05)
+#define RS_SPV010 (-1.4949652640e-05*RS_I_Ts)
+#define RS_SPV110 (3.1866349188e-05*RS_I_Ts)
+#define RS_SPV210 (-3.8070687610e-05*RS_I_Ts)
+#define RS_SPV310 (2.9818473563e-05*RS_I_Ts)
+#define RS_SPV410 (-1.0011321965e-05*RS_I_Ts)
+#define RS_SPV510 (1.0751931163e-06*RS_I_Ts)
+#define RS_SPV020 (2.7546851539e-05*RQ_POW2(RS_I_Ts))
+#define RS_SPV120 (-3.6597334199e-05*RQ_POW2(RS_I_Ts))
+#define RS_SPV220 (3.4489154625e-05*RQ_POW2(RS_I_Ts))
+#define RS_SPV320 (-1.7663254122e-05*RQ_POW2(RS_I_Ts))
+#define RS_SPV420 (3.5965131935e-06*RQ_POW2(RS_I_Ts))
+#define RS_SPV030 (-1.6506828994e-05*RQ_POW3(RS_I_Ts))
+#define RS_SPV130 (2.4412359055e-05*RQ_POW3(RS_I_Ts))
+#define RS_SPV230 (-1.4606740723e-05*RQ_POW3(RS_I_Ts))
+#define RS_SPV330 (2.3293406656e-06*RQ_POW3(RS_I_Ts))
+#define RS_SPV040 (6.7896174634e-06*RQ_POW4(RS_I_Ts))
+#define RS_SPV140 (-8.7951832993e-06*RQ_POW4(RS_I_Ts))
+#define RS_SPV240 (4.4249040774e-06*RQ_POW4(RS_I_Ts))
+#define RS_SPV050 (-7.2535743349e-07*RQ_POW5(RS_I_Ts))
+#define RS_SPV150 (-3.4680559205e-07*RQ_POW5(RS_I_Ts))
+#define RS_SPV060 (1.9041365570e-07*RQ_POW6(RS_I_Ts))
+#define RS_SPV001 (-1.6889436589e-05*RS_Pa2kb)
+#define RS_SPV101 (2.1106556158e-05*RS_Pa2kb)
+#define RS_SPV201 (-2.1322804368e-05*RS_Pa2kb)
+#define RS_SPV301 (1.7347655458e-05*RS_Pa2kb)
+#define RS_SPV401 (-4.3209400767e-06*RS_Pa2kb)
+#define RS_SPV011 (1.5355844621e-05*(RS_I_Ts*RS_Pa2kb))
+#define RS_SPV111 (2.0914122241e-06*(RS_I_Ts*RS_Pa2kb))
+#define RS_SPV211 (-5.7751479725e-06*(RS_I_Ts*RS_Pa2kb))
+#define RS_SPV311 (1.0767234341e-06*(RS_I_Ts*RS_Pa2kb))
+#define RS_SPV021 (-9.6659393016e-06*(RQ_POW2(RS_I_Ts)*RS_Pa2kb))
+#define RS_SPV121 (-7.0686982208e-07*(RQ_POW2(RS_I_Ts)*RS_Pa2kb))
+#define RS_SPV221 (1.4488066593e-06*(RQ_POW2(RS_I_Ts)*RS_Pa2kb))
+#define RS_SPV031 (3.1134283336e-06*(RQ_POW3(RS_I_Ts)*RS_Pa2kb))
+#define RS_SPV131 (7.9562529879e-08*(RQ_POW3(RS_I_Ts)*RS_Pa2kb))
+#define RS_SPV041 (-5.6590253863e-07*(RQ_POW4(RS_I_Ts)*RS_Pa2kb))
+#define RS_SPV002 (1.0500241168e-06*RQ_POW2(RS_Pa2kb))
+#define RS_SPV102 (1.9600661704e-06*RQ_POW2(RS_Pa2kb))
+#define RS_SPV202 (-2.1666693382e-06*RQ_POW2(RS_Pa2kb))
+#define RS_SPV012 (-3.8541359685e-06*(RS_I_Ts*RQ_POW2(RS_Pa2kb)))
+#define RS_SPV112 (1.0157632247e-06*(RS_I_Ts*RQ_POW2(RS_Pa2kb)))
+#define RS_SPV022 (1.7178343158e-06*(RQ_POW2(RS_I_Ts)*RQ_POW2(RS_Pa2kb)))
+#define RS_SPV003 (-4.1503454190e-07*RQ_POW3(RS_Pa2kb))
+#define RS_SPV103 (3.5627020989e-07*RQ_POW3(RS_Pa2kb))
+#define RS_SPV013 (-1.1293871415e-07*(RS_I_Ts*RQ_POW3(RS_Pa2kb)))
+#define RS_ALP000 (RS_SPV010)
+#define RS_ALP100 (RS_SPV110)
+#define RS_ALP200 (RS_SPV210)
+#define RS_ALP300 (RS_SPV310)
+#define RS_ALP400 (RS_SPV410)
+#define RS_ALP500 (RS_SPV510)
+#define RS_ALP010 (2.*RS_SPV020)
+#define RS_ALP110 (2.*RS_SPV120)
+#define RS_ALP210 (2.*RS_SPV220)
+#define RS_ALP310 (2.*RS_SPV320)
+#define RS_ALP410 (2.*RS_SPV420)
+#define RS_ALP020 (3.*RS_SPV030)
+#define RS_ALP120 (3.*RS_SPV130)
+#define RS_ALP220 (3.*RS_SPV230)
+#define RS_ALP320 (3.*RS_SPV330)
+#define RS_ALP030 (4.*RS_SPV040)
+#define RS_ALP130 (4.*RS_SPV140)
+#define RS_ALP230 (4.*RS_SPV240)
+#define RS_ALP040 (5.*RS_SPV050)
+#define RS_ALP140 (5.*RS_SPV150)
+#define RS_ALP050 (6.*RS_SPV060)
+#define RS_ALP001 (RS_SPV011)
+#define RS_ALP101 (RS_SPV111)
+#define RS_ALP201 (RS_SPV211)
+#define RS_ALP301 (RS_SPV311)
+#define RS_ALP011 (2.*RS_SPV021)
+#define RS_ALP111 (2.*RS_SPV121)
+#define RS_ALP211 (2.*RS_SPV221)
+#define RS_ALP021 (3.*RS_SPV031)
+#define RS_ALP121 (3.*RS_SPV131)
+#define RS_ALP031 (4.*RS_SPV041)
+#define RS_ALP002 (RS_SPV012)
+#define RS_ALP102 (RS_SPV112)
+#define RS_ALP012 (2.*RS_SPV022)
+#define RS_ALP003 (RS_SPV013)
+#define RS_BET000 (0.5*RS_SPV100*RS_r1_S0)
+#define RS_BET100 (RS_SPV200*RS_r1_S0)
+#define RS_BET200 (1.5*RS_SPV300*RS_r1_S0)
+#define RS_BET300 (2.0*RS_SPV400*RS_r1_S0)
+#define RS_BET400 (2.5*RS_SPV500*RS_r1_S0)
+#define RS_BET500 (3.0*RS_SPV600*RS_r1_S0)
+#define RS_BET010 (0.5*RS_SPV110*RS_r1_S0)
+#define RS_BET110 (RS_SPV210*RS_r1_S0)
+#define RS_BET210 (1.5*RS_SPV310*RS_r1_S0)
+#define RS_BET310 (2.0*RS_SPV410*RS_r1_S0)
+#define RS_BET410 (2.5*RS_SPV510*RS_r1_S0)
+#define RS_BET020 (0.5*RS_SPV120*RS_r1_S0)
+#define RS_BET120 (RS_SPV220*RS_r1_S0)
+#define RS_BET220 (1.5*RS_SPV320*RS_r1_S0)
+#define RS_BET320 (2.0*RS_SPV420*RS_r1_S0)
+#define RS_BET030 (0.5*RS_SPV130*RS_r1_S0)
+#define RS_BET130 (RS_SPV230*RS_r1_S0)
+#define RS_BET230 (1.5*RS_SPV330*RS_r1_S0)
+#define RS_BET040 (0.5*RS_SPV140*RS_r1_S0)
+#define RS_BET140 (RS_SPV240*RS_r1_S0)
+#define RS_BET050 (0.5*RS_SPV150*RS_r1_S0)
+#define RS_BET001 (0.5*RS_SPV101*RS_r1_S0)
+#define RS_BET101 (RS_SPV201*RS_r1_S0)
+#define RS_BET201 (1.5*RS_SPV301*RS_r1_S0)
+#define RS_BET301 (2.0*RS_SPV401*RS_r1_S0)
+#define RS_BET011 (0.5*RS_SPV111*RS_r1_S0)
+#define RS_BET111 (RS_SPV211*RS_r1_S0)
+#define RS_BET211 (1.5*RS_SPV311*RS_r1_S0)
+#define RS_BET021 (0.5*RS_SPV121*RS_r1_S0)
+#define RS_BET121 (RS_SPV221*RS_r1_S0)
+#define RS_BET031 (0.5*RS_SPV131*RS_r1_S0)
+#define RS_BET002 (0.5*RS_SPV102*RS_r1_S0)
+#define RS_BET102 (RS_SPV202*RS_r1_S0)
+#define RS_BET012 (0.5*RS_SPV112*RS_r1_S0)
+#define RS_BET003 (0.5*RS_SPV103*RS_r1_S0)
+RQ_FN void roquet_spv_parts(double T, double S, double pressure, double *zs_out, double *svTS0, double *svTS1, double *svTS2,
+                        double *svTS3, double *sv0S0, double *sv00p) {   /* :216-241 */
+  const double zt = T, zs = sqrt(fabs(S + RS_rdeltaS) * RS_r1_S0), zp = pressure;
+  *svTS3 = RS_SPV003 + (zs * RS_SPV103 + zt * RS_SPV013);
+  *svTS2 = RS_SPV002 + (zs * (RS_SPV102 + zs * RS_SPV202) + zt * (RS_SPV012 + (zs * RS_SPV112 + zt * RS_SPV022)));
+  *svTS1 = RS_SPV001 + (zs * (RS_SPV101 + zs * (RS_SPV201 + zs * (RS_SPV301 + zs * RS_SPV401))) +
+                         zt * (RS_SPV011 + (zs * (RS_SPV111 + zs * (RS_SPV211 + zs * RS_SPV311)) +
+                                            zt * (RS_SPV021 + (zs * (RS_SPV121 + zs * RS_SPV221) +
+                                                               zt * (RS_SPV031 + (zs * RS_SPV131 + zt * RS_SPV041)))))));
+  *svTS0 = zt * (RS_SPV010 +
+                  (zs * (RS_SPV110 + zs * (RS_SPV210 + zs * (RS_SPV310 + zs * (RS_SPV410 + zs * RS_SPV510)))) +
+                   zt * (RS_SPV020 + (zs * (RS_SPV120 + zs * (RS_SPV220 + zs * (RS_SPV320 + zs * RS_SPV420))) +
+                                      zt * (RS_SPV030 + (zs * (RS_SPV130 + zs * (RS_SPV230 + zs * RS_SPV330)) +
+                                                         zt * (RS_SPV040 + (zs * (RS_SPV140 + zs * RS_SPV240) +
+                                                                            zt * (RS_SPV050 + (zs * RS_SPV150 + zt * RS_SPV060))))))))));
+  *sv0S0 = RS_SPV000 + zs * (RS_SPV100 + zs * (RS_SPV200 + zs * (RS_SPV300 + zs * (RS_SPV400 + zs * (RS_SPV500 + zs * RS_SPV600)))));
+  *sv00p = zp * (RS_V00 + zp * (RS_V01 + zp * (RS_V02 + zp * (RS_V03 + zp * (RS_V04 + zp * RS_V05)))));
+  *zs_out = zs;
+}
+RQ_FN double roquet_spv(double T, double S, double pressure, double spv_ref, int anomaly) {   /* spec_vol_elem :191-248, _anomaly :253-315 */
+  double zs, r0, r1, r2, r3, s0, p0;
+  roquet_spv_parts(T, S, pressure, &zs, &r0, &r1, &r2, &r3, &s0, &p0);
+  const double zp = pressure;
+  if (anomaly) s0 = s0 - spv_ref;
+  const double SV_TS = (r0 + s0) + zp * (r1 + zp * (r2 + zp * r3));
+  return SV_TS + p0;
+}
+RQ_FN double roquet_spv_density(double T, double S, double pressure) {   /* density_elem_Roquet_SpV :318-330 */
+  return 1.0 / roquet_spv(T, S, pressure, 0.0, 0);
+}
+RQ_FN double roquet_spv_density_anomaly(double T, double S, double pressure, double rho_ref) {   /* :335-348 */
+  const double spv = roquet_spv(T, S, pressure, 1.0 / rho_ref, 1);
+  return -((rho_ref * rho_ref) * spv / (rho_ref * spv + 1.0));
+}
+RQ_FN void roquet_spv_derivs(double T, double S, double pressure, double *dSV_dT, double *dSV_dS) {   /* calculate_specvol_derivs_elem_Roquet_SpV :352-423 */
+  const double zt = T, zs = sqrt(fabs(S + RS_rdeltaS) * RS_r1_S0), zp = pressure;
+  const double dRdzt3 = RS_ALP003;
+  const double dRdzt2 = RS_ALP002 + (zs * RS_ALP102 + zt * RS_ALP012);
+  const double dRdzt1 = RS_ALP001 + (zs * (RS_ALP101 + zs * (RS_ALP201 + zs * RS_ALP301)) +
+                                     zt * (RS_ALP011 + (zs * (RS_ALP111 + zs * RS_ALP211) + zt * (RS_ALP021 + (zs * RS_ALP121 + zt * RS_ALP031)))));
+  const double dRdzt0 = RS_ALP000 + (zs * (RS_ALP100 + zs * (RS_ALP200 + zs * (RS_ALP300 + zs * (RS_ALP400 + zs * RS_ALP500)))) +
+                                     zt * (RS_ALP010 + (zs * (RS_ALP110 + zs * (RS_ALP210 + zs * (RS_ALP310 + zs * RS_ALP410))) +
+                                                        zt * (RS_ALP020 + (zs * (RS_ALP120 + zs * (RS_ALP220 + zs * RS_ALP320)) +
+                                                                           zt * (RS_ALP030 + (zt * (RS_ALP040 + (zs * RS_ALP140 + zt * RS_ALP050)) +
+                                                                                              zs * (RS_ALP130 + zs * RS_ALP230))))))));
+  *dSV_dT = dRdzt0 + zp * (dRdzt1 + zp * (dRdzt2 + zp * dRdzt3));
+  const double dRdzs3 = RS_BET003;
+  const double dRdzs2 = RS_BET002 + (zs * RS_BET102 + zt * RS_BET012);
+  const double dRdzs1 = RS_BET001 + (zs * (RS_BET101 + zs * (RS_BET201 + zs * RS_BET301)) +
+                                     zt * (RS_BET011 + (zs * (RS_BET111 + zs * RS_BET211) + zt * (RS_BET021 + (zs * RS_BET121 + zt * RS_BET031)))));
+  const double dRdzs0 = RS_BET000 + (zs * (RS_BET100 + zs * (RS_BET200 + zs * (RS_BET300 + zs * (RS_BET400 + zs * RS_BET500)))) +
+                                     zt * (RS_BET010 + (zs * (RS_BET110 + zs * (RS_BET210 + zs * (RS_BET310 + zs * RS_BET410))) +
+                                                        zt * (RS_BET020 + (zs * (RS_BET120 + zs * (RS_BET220 + zs * RS_BET320)) +
+                                                                           zt * (RS_BET030 + (zt * (RS_BET040 + (zs * RS_BET140 + zt * RS_BET050)) +
+                                                                                              zs * (RS_BET130 + zs * RS_BET230))))))));
+  *dSV_dS = (dRdzs0 + zp * (dRdzs1 + zp * (dRdzs2 + zp * dRdzs3))) / zs;
+}
+RQ_FN void roquet_spv_density_derivs(double T, double S, double pressure, double *drho_dT, double *drho_dS) {   /* :427-454 */
+  double dSV_dT, dSV_dS;
+  roquet_spv_derivs(T, S, pressure, &dSV_dT, &dSV_dS);
+  const double rho = 1.0 / roquet_spv(T, S, pressure, 0.0, 0);
+  *drho_dT = -dSV_dT * (rho * rho);
+  *drho_dS = -dSV_dS * (rho * rho);
+}
 #undef RQ_FN
+
+#define JK_FN static
+#define JK_MAX(a, b) orc_max(a, b)
+
+/* EQN_OF_STATE = "JACKETT_06": the 25-term rational function of Jackett et al. (2006), MOM_EOS_Jackett06.F90.  RNabc / RDabc: the
+ * S^a T^b p^c term of the numerator / denominator (6 = power 1.5). */
+#define JK_RN000 9.9984085444849347e+02
+#define JK_RN001 1.1798263740430364e-06
+#define JK_RN002 -2.5862187075154352e-16
+#define JK_RN010 7.3471625860981584e+00
+#define JK_RN020 -5.3211231792841769e-02
+#define JK_RN021 9.8920219266399117e-12
+#define JK_RN022 -3.2921414007960662e-20
+#define JK_RN030 3.6492439109814549e-04
+#define JK_RN100 2.5880571023991390e+00
+#define JK_RN101 4.6996642771754730e-10
+#define JK_RN110 -6.7168282786692355e-03
+#define JK_RN200 1.9203202055760151e-03
+#define JK_RD001 6.7103246285651894e-10
+#define JK_RD010 7.2815210113327091e-03
+#define JK_RD013 -9.1534417604289062e-30
+#define JK_RD020 -4.4787265461983921e-05
+#define JK_RD030 3.3851002965802430e-07
+#define JK_RD032 -2.4461698007024582e-25
+#define JK_RD040 1.3651202389758572e-10
+#define JK_RD100 1.7632126669040377e-03
+#define JK_RD110 -8.8066583251206474e-06
+#define JK_RD130 -1.8832689434804897e-10
+#define JK_RD600 5.7463776745432097e-06
+#define JK_RD620 1.4716275472242334e-09
+JK_FN void jackett_num_den(double T, double S, double pressure, double *num_STP, double *den) {   /* :94-102 */
+  const double S1_2 = sqrt(JK_MAX(0.0, S)), T2 = T * T;
+  *num_STP = (T * (JK_RN010 + T * (JK_RN020 + T * JK_RN030)) + S * (JK_RN100 + (T * JK_RN110 + S * JK_RN200))) +
+             pressure * (JK_RN001 + ((T2 * JK_RN021 + S * JK_RN101) + pressure * (JK_RN002 + T2 * JK_RN022)));
+  *den = 1.0 + ((T * (JK_RD010 + T * (JK_RD020 + T * (JK_RD030 + T * JK_RD040))) +
+                 S * (JK_RD100 + (T * (JK_RD110 + T2 * JK_RD130) + S1_2 * (JK_RD600 + T2 * JK_RD620)))) +
+                pressure * (JK_RD001 + pressure * T * (T2 * JK_RD032 + pressure * JK_RD013)));
+}
+JK_FN double jackett_density(double T, double S, double pressure) {   /* density_elem_Jackett06 :77-106 */
+  double num_STP, den;
+  jackett_num_den(T, S, pressure, &num_STP, &den);
+  const double I_den = 1.0 / den;
+  return (JK_RN000 + num_STP) * I_den;
+}
+JK_FN double jackett_density_anomaly(double T, double S, double pressure, double rho_ref) {   /* :111-144 */
+  double num_STP, den;
+  jackett_num_den(T, S, pressure, &num_STP, &den);
+  const double I_den = 1.0 / den;
+  const double rho0 = JK_RN000 - rho_ref * den;
+  return (rho0 + num_STP) * I_den;
+}
+JK_FN void jackett_density_derivs(double T, double S, double pressure, double *drho_dT, double *drho_dS) {   /* :216-262 */
+  const double S1_2 = sqrt(JK_MAX(0.0, S)), T2 = T * T;
+  const double num = JK_RN000 + ((T * (JK_RN010 + T * (JK_RN020 + T * JK_RN030)) + S * (JK_RN100 + (T * JK_RN110 + S * JK_RN200))) +
+                                 pressure * (JK_RN001 + ((T2 * JK_RN021 + S * JK_RN101) + pressure * (JK_RN002 + T2 * JK_RN022))));
+  const double den = 1.0 + ((T * (JK_RD010 + T * (JK_RD020 + T * (JK_RD030 + T * JK_RD040))) +
+                             S * (JK_RD100 + (T * (JK_RD110 + T2 * JK_RD130) + S1_2 * (JK_RD600 + T2 * JK_RD620)))) +
+                            pressure * (JK_RD001 + pressure * T * (T2 * JK_RD032 + pressure * JK_RD013)));
+  const double dnum_dT = ((JK_RN010 + T * (2. * JK_RN020 + T * (3. * JK_RN030))) + S * JK_RN110) +
+                         pressure * T * (2. * JK_RN021 + pressure * (2. * JK_RN022));
+  const double dnum_dS = (JK_RN100 + (T * JK_RN110 + S * (2. * JK_RN200))) + pressure * JK_RN101;
+  const double dden_dT = ((JK_RD010 + T * ((2. * JK_RD020) + T * ((3. * JK_RD030) + T * (4. * JK_RD040)))) +
+                          S * ((JK_RD110 + T2 * (3. * JK_RD130)) + S1_2 * T * (2. * JK_RD620))) +
+                         (pressure * pressure) * (T2 * 3. * JK_RD032 + pressure * JK_RD013);
+  const double dden_dS = JK_RD100 + (T * (JK_RD110 + T2 * JK_RD130) + S1_2 * (1.5 * JK_RD600 + T2 * (1.5 * JK_RD620)));
+  const double I_denom2 = 1.0 / (den * den);
+  *drho_dT = (dnum_dT * den - num * dden_dT) * I_denom2;
+  *drho_dS = (dnum_dS * den - num * dden_dS) * I_denom2;
+}
+#undef JK_FN
 
 /* calculate_density (no rho_ref): density_elem_linear MOM_EOS_linear.F90:66, density_elem_buggy_Wright :80-96, density_elem_Wright_full :73-89 */
 static double eos_density(const mom6x_eos_params *E, double T, double S, double p) {
   if (E->form == MOM6X_EOS_LINEAR) return E->Rho_T0_S0 + E->dRho_dT * T + E->dRho_dS * S + E->dRho_dp * p;
   if (E->form == MOM6X_EOS_UNESCO) return unesco_density(T, S, p);
   if (E->form == MOM6X_EOS_ROQUET_RHO) return roquet_density(T, S, p);
+  if (E->form == MOM6X_EOS_JACKETT06) return jackett_density(T, S, p);
+  if (E->form == MOM6X_EOS_ROQUET_SPV) return roquet_spv_density(T, S, p);
   double al0, p0, lambda;
   wright_coefs(E->form, T, S, &al0, &p0, &lambda);
   return (p + p0) / (lambda + al0 * (p + p0));
@@ -581,6 +852,8 @@ static void eos_density_derivs(const mom6x_eos_params *E, double T, double S, do
   if (E->form == MOM6X_EOS_LINEAR) { *dRdT = E->dRho_dT; *dRdS = E->dRho_dS; return; }
   if (E->form == MOM6X_EOS_UNESCO) { unesco_density_derivs(T, S, p, dRdT, dRdS); return; }
   if (E->form == MOM6X_EOS_ROQUET_RHO) { roquet_density_derivs(T, S, p, dRdT, dRdS); return; }
+  if (E->form == MOM6X_EOS_JACKETT06) { jackett_density_derivs(T, S, p, dRdT, dRdS); return; }
+  if (E->form == MOM6X_EOS_ROQUET_SPV) { roquet_spv_density_derivs(T, S, p, dRdT, dRdS); return; }
   const wright_set *W = wright_of(E->form);
   double al0, p0, lambda;
   wright_coefs(E->form, T, S, &al0, &p0, &lambda);
@@ -701,6 +974,8 @@ static double eos_density_anomaly(const mom6x_eos_params *E, double T, double S,
     return (E->Rho_T0_S0 - rho_ref) + ((E->dRho_dT * T + E->dRho_dS * S) + E->dRho_dp * pressure);
   if (E->form == MOM6X_EOS_UNESCO) return unesco_density_anomaly(T, S, pressure, rho_ref);
   if (E->form == MOM6X_EOS_ROQUET_RHO) return roquet_density_anomaly(T, S, pressure, rho_ref);
+  if (E->form == MOM6X_EOS_JACKETT06) return jackett_density_anomaly(T, S, pressure, rho_ref);
+  if (E->form == MOM6X_EOS_ROQUET_SPV) return roquet_spv_density_anomaly(T, S, pressure, rho_ref);
   const wright_set *W = wright_of(E->form);   /* the same expression in all three Wright modules (_full.F90:108-119) */
   const double pa_000 = (W->b0 * (1.0 - W->a0 * rho_ref) - rho_ref * W->c0);
   const double al_TS = W->a1 * T + W->a2 * S;
@@ -960,7 +1235,7 @@ int orc_PressureForce_FV_Bouss(const mom6x_dims *d, const double *G, const mom6x
     pa[x] = GxRho_ref * (e[x] - Z_ref);
   }
   const int use_EOS = (T != NULL);
-  if (use_EOS && !(EOS && S && (EOS->form >= MOM6X_EOS_LINEAR && EOS->form <= MOM6X_EOS_ROQUET_RHO) &&
+  if (use_EOS && !(EOS && S && (EOS->form >= MOM6X_EOS_LINEAR && EOS->form <= MOM6X_EOS_ROQUET_SPV) &&
                    (EOS->form < MOM6X_EOS_UNESCO || EOS->EOS_quadrature || EOS->Recon_Scheme) &&   /* no analytic integrals: MOM_EOS.F90:1495 */
                    (EOS->Recon_Scheme >= 0 && EOS->Recon_Scheme <= 2) && (EOS->Recon_Scheme != 2 || nz >= 4))) {
     free(e); free(pa); free(dpa); free(intz_dpa); free(intx_pa); free(inty_pa); free(intx_dpa); free(inty_dpa); free(dz_geo);

@@ -13,10 +13,40 @@ module ref_shim
   use Recon1d_PPM_H4_2019, only : PPM_H4_2019
   use MOM_EOS_UNESCO, only : UNESCO_EOS
   use MOM_EOS_Roquet_rho, only : Roquet_rho_EOS
+  use MOM_EOS_Jackett06, only : Jackett06_EOS
+  use MOM_EOS_Roquet_SpV, only : Roquet_SpV_EOS
   implicit none
 contains
   !> src/equation_of_state/MOM_EOS_UNESCO.F90 (with MOM_EOS_base_type.F90: no other `use`): the elemental density :95, density
   !! anomaly :133 and the T, S derivatives :244 of n points -- oracle/orc_dyn.c's unesco_* are held to these bit for bit.
+  !> src/equation_of_state/MOM_EOS_Roquet_SpV.F90 likewise (density :318, anomaly :335, derivatives :427).
+  subroutine ref_ROQUET_SPV(n, T, S, p, rho_ref, rho, rho_anom, drho_dT, drho_dS) bind(C, name="ref_ROQUET_SPV")
+    integer(c_int), value :: n
+    real(c_double), intent(in) :: T(n), S(n), p(n)
+    real(c_double), value :: rho_ref
+    real(c_double), intent(out) :: rho(n), rho_anom(n), drho_dT(n), drho_dS(n)
+    type(Roquet_SpV_EOS) :: eos
+    integer :: i
+    do i=1,n
+      rho(i) = eos%density_elem(T(i), S(i), p(i))
+      rho_anom(i) = eos%density_anomaly_elem(T(i), S(i), p(i), rho_ref)
+      call eos%calculate_density_derivs_elem(T(i), S(i), p(i), drho_dT(i), drho_dS(i))
+    enddo
+  end subroutine
+  !> src/equation_of_state/MOM_EOS_Jackett06.F90 likewise (density :77, anomaly :111, derivatives :216).
+  subroutine ref_JACKETT06(n, T, S, p, rho_ref, rho, rho_anom, drho_dT, drho_dS) bind(C, name="ref_JACKETT06")
+    integer(c_int), value :: n
+    real(c_double), intent(in) :: T(n), S(n), p(n)
+    real(c_double), value :: rho_ref
+    real(c_double), intent(out) :: rho(n), rho_anom(n), drho_dT(n), drho_dS(n)
+    type(Jackett06_EOS) :: eos
+    integer :: i
+    do i=1,n
+      rho(i) = eos%density_elem(T(i), S(i), p(i))
+      rho_anom(i) = eos%density_anomaly_elem(T(i), S(i), p(i), rho_ref)
+      call eos%calculate_density_derivs_elem(T(i), S(i), p(i), drho_dT(i), drho_dS(i))
+    enddo
+  end subroutine
   !> src/equation_of_state/MOM_EOS_Roquet_rho.F90 likewise (density :192, anomaly :248, derivatives :340).
   subroutine ref_ROQUET_RHO(n, T, S, p, rho_ref, rho, rho_anom, drho_dT, drho_dS) bind(C, name="ref_ROQUET_RHO")
     integer(c_int), value :: n

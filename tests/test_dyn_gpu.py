@@ -110,7 +110,7 @@ def test_PressureForce(orc, cfg, bug):
 
 
 @pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
-@pytest.mark.parametrize("form", ["LINEAR", "WRIGHT", "WRIGHT_FULL", "WRIGHT_REDUCED", "UNESCO", "ROQUET_RHO"])
+@pytest.mark.parametrize("form", ["LINEAR", "WRIGHT", "WRIGHT_FULL", "WRIGHT_REDUCED", "UNESCO", "ROQUET_RHO", "JACKETT06", "ROQUET_SPV"])
 @pytest.mark.parametrize("mods", [dict(), dict(MassWghtInterp=1), dict(MassWghtInterp=3, use_SSH_in_Z0p=1, bug=0, dRho_dp=4.5e-7),
                                   # the ALE path: TS_PLM_edge_values + int_density_dz_generic_plm (PRESSURE_RECONSTRUCTION_SCHEME = 1)
                                   dict(Recon_Scheme=1), dict(Recon_Scheme=1, boundary_extrap=0, MassWghtInterp=1),
@@ -141,7 +141,7 @@ def test_PressureForce_with_equation_of_state(orc, cfg, form, mods):
     h, _, _ = synth.make_state(d, M, thin_frac=0.05)
     T, S = cases.thermo_state(d, M)
     o = dict(PFu=np.zeros_like(h), PFv=np.zeros_like(h), pbce=np.zeros_like(h), eta=np.zeros(d.shape2()))
-    if eos.form in (abi.UNESCO, abi.ROQUET_RHO) and not (eos.Recon_Scheme or eos.EOS_quadrature):   # MOM_EOS.F90:1495
+    if eos.form in (abi.UNESCO, abi.ROQUET_RHO, abi.JACKETT06, abi.ROQUET_SPV) and not (eos.Recon_Scheme or eos.EOS_quadrature):   # MOM_EOS.F90:1495
         dyc = Dycore(d, M, GV)
         dyc.PressureForce_init(CS, Rlay, gp)
         with pytest.raises(abi.Mom6xError, match="No analytic integration option is available with this EOS!"):

@@ -63,10 +63,12 @@ def test_density_anomaly_against_reference_check_values(orc):
     # WRIGHT_FULL :2058-2060, WRIGHT_REDUCED :2064-2066 -- through density_elem and through the rho_ref form
     # UNESCO :2052-2054
     for form, check in ((abi.WRIGHT_FULL, 1027.55177447616), (abi.WRIGHT_REDUCED, 1027.54303596346), (abi.WRIGHT, 1027.54303596346),
-                        (abi.UNESCO, 1027.54345796120), (abi.ROQUET_RHO, 1027.42385663668)):   # ROQUET_RHO :2085-2087
+                        (abi.UNESCO, 1027.54345796120), (abi.ROQUET_RHO, 1027.42385663668),   # ROQUET_RHO :2085-2087
+                        (abi.JACKETT06, 1027.539690758425),   # JACKETT_06 :2097-2099
+                        (abi.ROQUET_SPV, 1027.42387475199)):   # ROQUET_SPV :2091-2093
         e = abi.eos_params_default(form)
         assert abs(orc.eos_density(e, 25.0, 35.0, 1.0e7) - check) < 1000 * 2.2e-16 * 1027.5
-        for rho_ref in (0.0, 1000.0, 1035.0):
+        for rho_ref in ((1000.0, 1035.0) if form == abi.ROQUET_SPV else (0.0, 1000.0, 1035.0)):   # (ROQUET_SPV: spv_ref = 1 / rho_ref)
             assert abs((orc.eos_density_anomaly(e, 25.0, 35.0, 1.0e7, rho_ref) + rho_ref) - check) < 1000 * 2.2e-16 * 1027.5
         # calculate_density_derivs against centred differences of the density (what test_EOS_consistency :2400-2440 checks)
         dT, dS = 1e-3, 1e-3
@@ -126,7 +128,7 @@ def test_PLM_quadrature_reduces_to_the_analytic_integrals(orc, form):
     assert np.abs(out[2] - out[1])[(Ellipsis,) + su].max() > 1e-8 * big      # the parabolas are not the lines
 
 
-@pytest.mark.parametrize("name", ["UNESCO", "ROQUET_RHO"])
+@pytest.mark.parametrize("name", ["UNESCO", "ROQUET_RHO", "JACKETT06", "ROQUET_SPV"])
 def test_unesco_and_roquet_against_the_compiled_reference(orc, name):
     """EQN_OF_STATE = UNESCO and ROQUET_RHO (= NEMO) pinned to the REAL reference code: src/equation_of_state/MOM_EOS_UNESCO.F90 and
     MOM_EOS_Roquet_rho.F90 (+ MOM_EOS_base_type.F90) compile from their own source files (oracle/_ref, no stand-ins); the oracle's
@@ -140,7 +142,7 @@ def test_unesco_and_roquet_against_the_compiled_reference(orc, name):
     T = rng.uniform(-3.0, 42.0, n); S = rng.uniform(-1.0, 42.0, n); p = rng.uniform(0.0, 1.2e8, n)
     S[:50] = 0.0; p[50:100] = 0.0; T[100:120] = 0.0
     e = abi.eos_params_default(getattr(abi, name))
-    for rho_ref in (0.0, 1035.0):
+    for rho_ref in ((1000.0, 1035.0) if name == "ROQUET_SPV" else (0.0, 1035.0)):
         rho, ra, dT, dS = (np.zeros(n) for _ in range(4))
         ptr = lambda a: a.ctypes.data_as(C.c_void_p)
         getattr(L, "ref_" + name)(C.c_int(n), ptr(T), ptr(S), ptr(p), C.c_double(rho_ref), ptr(rho), ptr(ra), ptr(dT), ptr(dS))
@@ -152,7 +154,7 @@ def test_unesco_and_roquet_against_the_compiled_reference(orc, name):
     assert rho.min() > 990.0 and rho.max() < 1100.0
 
 
-@pytest.mark.parametrize("form", [abi.UNESCO, abi.ROQUET_RHO])
+@pytest.mark.parametrize("form", [abi.UNESCO, abi.ROQUET_RHO, abi.JACKETT06, abi.ROQUET_SPV])
 def test_unesco_and_roquet_need_the_quadratures(orc, form):
     """analytic_int_density_dz has no UNESCO branch (MOM_EOS.F90:1495: "No analytic integration option is available with this
     EOS!"): refused without EOS_QUADRATURE or a pressure reconstruction; with either, a resting stratified ocean feels no force."""

@@ -176,7 +176,7 @@ def test_rk2_device_matches_committed_golden(orc):
 
 
 @pytest.mark.parametrize("recon", [1, 2, "quadrature"])
-@pytest.mark.parametrize("form", [abi.UNESCO, abi.ROQUET_RHO], ids=["UNESCO", "ROQUET_RHO"])
+@pytest.mark.parametrize("form", [abi.UNESCO, abi.ROQUET_RHO, abi.JACKETT06, abi.ROQUET_SPV], ids=["UNESCO", "ROQUET_RHO", "JACKETT_06", "ROQUET_SPV"])
 def test_rk2_with_the_equations_of_state_without_analytic_integrals(orc, form, recon):
     """EQN_OF_STATE = UNESCO / ROQUET_RHO (NEMO), which have no analytic integrals: the whole step through the quadratures, bit for
     bit."""
