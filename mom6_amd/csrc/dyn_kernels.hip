@@ -147,7 +147,8 @@ __device__ __forceinline__ double robust_heff(double tr, double Idl, double vel,
 struct NoIhq { __device__ double operator()(int, int) const { return 0.0; } };
 // ALL: with the three schemes only the two-kernel form runs (ROBUST_ENSTRO, ARAKAWA_LAMB81, ARAKAWA_LAMB_BLEND).  k_corad_fused
 // compiles them OUT: merely present, never taken, they cost it 14 spilled registers (3.6 instead of 2.0 ms per call).
-template <bool ALL, class QF, class KF, class AF, class IF = NoIhq>
+// LEAN: the default configuration known at compile time (SADOURNY75_ENERGY without BOUND_CORIOLIS and CORIOLIS_EN_DIS).
+template <bool ALL, bool LEAN = false, class QF, class KF, class AF, class IF = NoIhq>
 __device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int st, const QF &Q, const KF &KEf, const AF &AVf,
                                                 const IF &IH = NoIhq()) {
   const double *__restrict__ u = X.u, *__restrict__ v = X.v, *__restrict__ uh = X.uh, *__restrict__ vh = X.vh, *__restrict__ h = X.h;
@@ -155,7 +156,7 @@ __device__ __forceinline__ void corad_acc_layer(const CoradAcc &X, size_t c, int
   double *__restrict__ CAu = X.CAu, *__restrict__ CAv = X.CAv, *__restrict__ u_bc = X.u_bc, *__restrict__ v_bc = X.v_bc;
   const double IdxCu = X.IdxCu, IdyCv = X.IdyCv;
   const double *Lv = X.Lv, *Lu = X.Lu;
-  const int scheme = X.scheme, bound = X.bound, en_dis = X.en_dis;
+  const int scheme = LEAN ? (int)MOM6X_SADOURNY75_ENERGY : X.scheme, bound = LEAN ? 0 : X.bound, en_dis = LEAN ? 0 : X.en_dis;
   const bool do_u = X.do_u, do_v = X.do_v;
   const double C1_12 = 1.0 / 12.0;
   auto ihq = [&](int di, int dj) { return (scheme == MOM6X_AL_BLEND) ? IH(di, dj) : 0.0; };   // only the blend has (and reads) Ih_q
@@ -343,12 +344,15 @@ k_corad_acc(Dm d, const double *__restrict__ G, const double *__restrict__ u, co
 // the accelerations are evaluated by the tile minus a frame of one point (q is read at -1..+1, KE at 0..+1): 30 x 14 outputs per
 // tile.  Two LDS buffers alternate between layers: one barrier per layer.  Same expressions, same bits as k_corad_q + k_corad_acc.
 #define CF_X 32
+#ifndef CF_Y
 #define CF_Y 16
+#endif
 #ifndef CF_MINW
 #define CF_MINW 4
 #endif
 #define CF_LDW (CF_X + 2)
 #define CF_LDN ((CF_Y + 2) * CF_LDW)
+template <bool LEAN>
 __global__ void __launch_bounds__(CF_X * CF_Y, CF_MINW)   // 4: two work-groups (16 wavefronts) per CU, at most 128 registers
 k_corad_fused(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
               const double *__restrict__ uh, const double *__restrict__ vh, double *__restrict__ CAu,
@@ -405,7 +409,7 @@ k_corad_fused(Dm d, const double *__restrict__ G, const double *__restrict__ u, 
   X.do_u = out && (j >= 0); X.do_v = out && (i >= 0);
   X.IdxCu = gm(G, d, MOM6X_G_IdxCu)[x]; X.IdyCv = gm(G, d, MOM6X_G_IdyCv)[x];
   for (int n = 0; n < 4; n++) { X.Lv[n] = 0.; X.Lu[n] = 0.; }
-  if (en_dis && out) {
+  if (!LEAN && en_dis && out) {
     const double *dx_Cv = gm(G, d, MOM6X_G_dx_Cv), *dy_Cu = gm(G, d, MOM6X_G_dy_Cu);
     if (X.do_u) { X.Lv[0] = dx_Cv[x]; X.Lv[1] = dx_Cv[x + 1]; X.Lv[2] = dx_Cv[x - st]; X.Lv[3] = dx_Cv[x + 1 - st]; }
     if (X.do_v) { X.Lu[0] = dy_Cu[x - 1]; X.Lu[1] = dy_Cu[x - 1 + st]; X.Lu[2] = dy_Cu[x]; X.Lu[3] = dy_Cu[x + st]; }
@@ -448,14 +452,14 @@ k_corad_fused(Dm d, const double *__restrict__ G, const double *__restrict__ u, 
         }
       }
     }
-    sq[l] = qv; sk[l] = kev; if (bound) sa[l] = av;
+    sq[l] = qv; sk[l] = kev; if (!LEAN && bound) sa[l] = av;
     __syncthreads();
     if (out) {
       if (uhtr) {   // :1072-1079 for the box (-1..ni-1, -1..nj-1): see k_corad_acc
         uhtr[c] = uhtr[c] + uh[c] * dt_tr;
         vhtr[c] = vhtr[c] + vh[c] * dt_tr;
       }
-      corad_acc_layer<false>(X, c, st, [&](int di, int dj) { return sq[l + di + dj * CF_LDW]; }, [&](int di, int dj) { return sk[l + di + dj * CF_LDW]; },
+      corad_acc_layer<false, LEAN>(X, c, st, [&](int di, int dj) { return sq[l + di + dj * CF_LDW]; }, [&](int di, int dj) { return sk[l + di + dj * CF_LDW]; },
                              [&](int di, int dj) { return sa[l + di + dj * CF_LDW]; });
     }
     // (the layer after next writes this buffer again: the barrier of the next layer lies in between)
@@ -779,9 +783,17 @@ int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h
     const int gx = (d.ni + 1 + (CF_X - 2) - 1) / (CF_X - 2), gy = (d.nj + 1 + (CF_Y - 2) - 1) / (CF_Y - 2), gz = (d.nk + kc - 1) / kc;
     static const int xcd_order = [] { const char *e = getenv("MOM6X_CORAD_ORDER"); return (e && !strcmp(e, "plain")) ? 0 : 1; }();
     const dim3 gt((unsigned)(((gx * gy * gz + 7) / 8) * 8), 1, 1);
-    KLAUNCH(c, "k_corad_fused", k_corad_fused, gt, bt, d, c->G, u, v, uh, vh, CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h,
-            c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr, c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc, gx, gy, gz,
-            xcd_order);
+    static const bool lean_off = [] { const char *e = getenv("MOM6X_CORAD_LEAN"); return e && !strcmp(e, "0"); }();
+    // the default configuration has its own instantiation: 104 registers and no scratch instead of 128 + 2 spilled
+    const bool lean = !lean_off && (scheme == MOM6X_SADOURNY75_ENERGY) && !c->cor.bound_Coriolis && !c->cor.Coriolis_En_Dis;
+    if (lean)
+      KLAUNCH(c, "k_corad_fused", k_corad_fused<true>, gt, bt, d, c->G, u, v, uh, vh, CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h,
+              c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr, c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc, gx, gy, gz,
+              xcd_order);
+    else
+      KLAUNCH(c, "k_corad_fused", k_corad_fused<false>, gt, bt, d, c->G, u, v, uh, vh, CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h,
+              c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr, c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc, gx, gy, gz,
+              xcd_order);
     HIPCHK(hipGetLastError());
     return MOM6X_OK;
   }
