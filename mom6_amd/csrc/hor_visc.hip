@@ -667,8 +667,28 @@ k_hv_accel(Dm d, const double *__restrict__ G, const double *__restrict__ P, con
 // (MOM6X_HORVISC=legacy; Leith always takes the four kernels).  3 reads (x the tile's halo overhead) + 2 writes per cell-layer
 // instead of 20.
 #define HT_H 3
-template <int HT_X, int HT_Y>
-__global__ void __launch_bounds__(HT_X * HT_Y, (HT_X * HT_Y >= 1024) ? 4 : 2)   // 1024 threads: 4 wavefronts per SIMD (128 registers, 56 spilled); 512: 2 per SIMD, none spilled
+// OM4: the switches of the OM4-class configuration (LAPLACIAN + BIHARMONIC with SMAGORINSKY_AH, both "better" bounds, land mask,
+// free slip, no LES addition) known at COMPILE time: the generic kernel keeps ~170 values live because every option's
+// coefficients are loaded and every branch is present; any other combination takes the generic instantiation.
+#define OM4_better_bound_Kh 1
+#define OM4_better_bound_Ah 1
+#define OM4_Smagorinsky_Kh 0
+#define OM4_Smagorinsky_Ah 1
+#define OM4_no_slip 0
+#define OM4_bound_Coriolis 0
+#define OM4_bound_Ah 1
+#define OM4_backscatter_underbound 1
+#define OM4_add_LES_viscosity 0
+#define OM4_use_land_mask 1
+#define OM4_bound_Kh 1
+#define OM4_biharmonic 1
+#define OM4_Laplacian 1
+#define HVF(f) (OM4 ? (OM4_##f != 0) : (CS.f != 0))
+#ifndef HV_OM4_W4
+#define HV_OM4_W4 0
+#endif
+template <int HT_X, int HT_Y, bool OM4>
+__global__ void __launch_bounds__(HT_X * HT_Y, (HT_X * HT_Y >= 1024 || (OM4 && HV_OM4_W4)) ? 4 : 2)   // 1024 threads: 4 wavefronts per SIMD (128 registers, 56 spilled); 512: 2 per SIMD, none spilled
 k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom6x_hor_visc_params CS,
            const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ h,
            double *__restrict__ diffu, double *__restrict__ diffv, double h_neglect, int kc) {
@@ -694,11 +714,11 @@ k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom
   const bool out_u = live && tx >= HT_H && tx < HT_X - HT_H && ty >= HT_H && ty < HT_Y - HT_H && (i <= d.ni - 1) && (j >= 0) && (j <= d.nj - 1);
   const bool out_v = live && tx >= HT_H && tx < HT_X - HT_H && ty >= HT_H && ty < HT_Y - HT_H && (i >= 0) && (i <= d.ni - 1) && (j <= d.nj - 1);
   const bool need3 = live && tx >= HT_H - 1 && tx <= HT_X - HT_H && ty >= HT_H - 1 && ty <= HT_Y - HT_H;
-  const bool smag = CS.Smagorinsky_Kh || CS.Smagorinsky_Ah, better = CS.better_bound_Ah || CS.better_bound_Kh;
-  const bool legacy_bound = CS.Smagorinsky_Kh && (CS.bound_Kh && !CS.better_bound_Kh);   // :556-557 (no Leith here)
-  const bool lap = CS.Laplacian, bih = CS.biharmonic;
+  const bool smag = HVF(Smagorinsky_Kh) || HVF(Smagorinsky_Ah), better = HVF(better_bound_Ah) || HVF(better_bound_Kh);
+  const bool legacy_bound = HVF(Smagorinsky_Kh) && (HVF(bound_Kh) && !HVF(better_bound_Kh));   // :556-557 (no Leith here)
+  const bool lap = HVF(Laplacian), bih = HVF(biharmonic);
   const double h_neglect3 = h_neglect * h_neglect * h_neglect;
-  const int lm = CS.use_land_mask;
+  const int lm = HVF(use_land_mask);
   // ---- coefficients of this point, for all layers of the chunk
   c_dx2q[l] = PLN(HV_dx2q)[x]; c_dy2q[l] = PLN(HV_dy2q)[x]; c_dy2h[l] = PLN(HV_dy2h)[x]; c_dx2h[l] = PLN(HV_dx2h)[x];
   const double *mT = MG(mask2dT);
@@ -707,19 +727,19 @@ k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom
   const double DY_dxT = PLN(HV_DY_dxT)[x], DX_dyT = PLN(HV_DX_dyT)[x], DY_dxBu = PLN(HV_DY_dxBu)[x], DX_dyBu = PLN(HV_DX_dyBu)[x];
   const double IdyCu0 = MG(IdyCu)[x], IdyCuW = MG(IdyCu)[x - 1], IdxCv0 = MG(IdxCv)[x], IdxCvS = MG(IdxCv)[x - st];
   const double IdyCvE = MG(IdyCv)[x + 1], IdyCv0 = MG(IdyCv)[x], IdxCuN = MG(IdxCu)[x + st], IdxCu0 = MG(IdxCu)[x];
-  const double mBu = MG(mask2dBu)[x], mfac = CS.no_slip ? (2.0 - mBu) : mBu;
+  const double mBu = MG(mask2dBu)[x], mfac = HVF(no_slip) ? (2.0 - mBu) : mBu;
   const double Idx2dyCu = PLN(HV_Idx2dyCu)[x], Idxdy2u = PLN(HV_Idxdy2u)[x], Idx2dyCv = PLN(HV_Idx2dyCv)[x], Idxdy2v = PLN(HV_Idxdy2v)[x];
   const double IareaCu = MG(IareaCu)[x], IareaCv = MG(IareaCv)[x];
   const double red_xx = PLN(HV_red_xx)[x], red_xy = PLN(HV_red_xy)[x];
   const double Kh_bg_xx = lap ? PLN(HV_Kh_bg_xx)[x] : 0., Kh_Max_xx = lap ? PLN(HV_Kh_Max_xx)[x] : 0.;
   const double Kh_bg_xy = lap ? PLN(HV_Kh_bg_xy)[x] : 0., Kh_Max_xy = lap ? PLN(HV_Kh_Max_xy)[x] : 0.;
-  const double Lap2_xx = CS.Smagorinsky_Kh ? PLN(HV_Lap2_xx)[x] : 0., Lap2_xy = CS.Smagorinsky_Kh ? PLN(HV_Lap2_xy)[x] : 0.;
+  const double Lap2_xx = HVF(Smagorinsky_Kh) ? PLN(HV_Lap2_xx)[x] : 0., Lap2_xy = HVF(Smagorinsky_Kh) ? PLN(HV_Lap2_xy)[x] : 0.;
   const double Ah_bg_xx = bih ? PLN(HV_Ah_bg_xx)[x] : 0., Ah_Max_xx = bih ? PLN(HV_Ah_Max_xx)[x] : 0.;
   const double Ah_bg_xy = bih ? PLN(HV_Ah_bg_xy)[x] : 0., Ah_Max_xy = bih ? PLN(HV_Ah_Max_xy)[x] : 0.;
-  const double Bih_xx = CS.Smagorinsky_Ah ? PLN(HV_Bih_xx)[x] : 0., Bih_xy = CS.Smagorinsky_Ah ? PLN(HV_Bih_xy)[x] : 0.;
-  const double Bih2_xx = CS.bound_Coriolis ? PLN(HV_Bih2_xx)[x] : 0., Bih2_xy = CS.bound_Coriolis ? PLN(HV_Bih2_xy)[x] : 0.;
+  const double Bih_xx = HVF(Smagorinsky_Ah) ? PLN(HV_Bih_xx)[x] : 0., Bih_xy = HVF(Smagorinsky_Ah) ? PLN(HV_Bih_xy)[x] : 0.;
+  const double Bih2_xx = HVF(bound_Coriolis) ? PLN(HV_Bih2_xx)[x] : 0., Bih2_xy = HVF(bound_Coriolis) ? PLN(HV_Bih2_xy)[x] : 0.;
   double mu0 = 0., mu1 = 0., mv0 = 0., mv1 = 0.;
-  if (CS.no_slip) { mu0 = MG(mask2dCu)[x]; mu1 = MG(mask2dCu)[x + st]; mv0 = MG(mask2dCv)[x]; mv1 = MG(mask2dCv)[x + 1]; }
+  if (HVF(no_slip)) { mu0 = MG(mask2dCu)[x]; mu1 = MG(mask2dCu)[x + st]; mv0 = MG(mask2dCv)[x]; mv1 = MG(mask2dCv)[x + 1]; }
   // the frame of the LDS planes is only ever read by points whose results are discarded: no initialisation needed, but the
   // stage planes of points that are not live must not hold NaN patterns that trap -- they cannot: nothing here traps
   __syncthreads();
@@ -772,34 +792,34 @@ k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom
       }
       if (lap) {
         double K = Kh_bg_xx;
-        if (CS.add_LES_viscosity) {
-          if (CS.Smagorinsky_Kh) K = K + Lap2_xx * Shear;
+        if (HVF(add_LES_viscosity)) {
+          if (HVF(Smagorinsky_Kh)) K = K + Lap2_xx * Shear;
         } else {
-          if (CS.Smagorinsky_Kh) K = dmax(K, Lap2_xx * Shear);
+          if (HVF(Smagorinsky_Kh)) K = dmax(K, Lap2_xx * Shear);
         }
         if (legacy_bound) K = dmin(K, Kh_Max_xx);
         K = dmax(K, CS.Kh_bg_min);
-        if (CS.better_bound_Kh && CS.better_bound_Ah) {
+        if (HVF(better_bound_Kh) && HVF(better_bound_Ah)) {
           vbr = 1.0;
           const double Kh_max_here = hrat * Kh_Max_xx;
           if (K >= Kh_max_here) { vbr = 0.0; K = Kh_max_here; }
-          else if ((K > 0.0) || (CS.backscatter_underbound && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
-        } else if (CS.better_bound_Kh) {
+          else if ((K > 0.0) || (HVF(backscatter_underbound) && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
+        } else if (HVF(better_bound_Kh)) {
           K = dmin(K, hrat * Kh_Max_xx);
         }
         sxx_out = -K * sxx;
       } else sxx_out = 0.0;
       if (bih) {
         double A = Ah_bg_xx;
-        if (CS.Smagorinsky_Ah) {
+        if (HVF(Smagorinsky_Ah)) {
           double AhSm;
-          if (CS.bound_Coriolis) AhSm = Shear * (Bih_xx + Bih2_xx * Shear);
+          if (HVF(bound_Coriolis)) AhSm = Shear * (Bih_xx + Bih2_xx * Shear);
           else AhSm = Bih_xx * Shear;
           A = dmax(A, AhSm);
-          if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, Ah_Max_xx);
+          if (HVF(bound_Ah) && !HVF(better_bound_Ah)) A = dmin(A, Ah_Max_xx);
         }
-        if (CS.better_bound_Ah) {
-          if (CS.better_bound_Kh) A = dmin(A, vbr * hrat * Ah_Max_xx);
+        if (HVF(better_bound_Ah)) {
+          if (HVF(better_bound_Kh)) A = dmin(A, vbr * hrat * Ah_Max_xx);
           else A = dmin(A, hrat * Ah_Max_xx);
         }
         const double d_del2u = (IdyCu0 * d2u) - (IdyCuW * s_d2u[l - 1]);
@@ -824,7 +844,7 @@ k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom
         const double h_min = dmin4(hu0, hu1, hv0, hv1);
         hrat = dmin(1.0, h_min / (hq + h_neglect));
       }
-      if (CS.no_slip && (mBu < 0.5)) {
+      if (HVF(no_slip) && (mBu < 0.5)) {
         if ((mu0 + mu1) + (mv0 + mv1) > 0.0) {
           const double hu = mu0 * hu0 + mu1 * hu1;
           const double hv = mv0 * hv0 + mv1 * hv1;
@@ -839,33 +859,33 @@ k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom
       }
       if (lap) {
         double K = Kh_bg_xy;
-        if (CS.Smagorinsky_Kh) {
-          if (CS.add_LES_viscosity) K = K + Lap2_xy * Shear;
+        if (HVF(Smagorinsky_Kh)) {
+          if (HVF(add_LES_viscosity)) K = K + Lap2_xy * Shear;
           else K = dmax(K, Lap2_xy * Shear);
         }
         if (legacy_bound) K = dmin(K, Kh_Max_xy);
         K = dmax(K, CS.Kh_bg_min);
-        if (CS.better_bound_Kh && CS.better_bound_Ah) {
+        if (HVF(better_bound_Kh) && HVF(better_bound_Ah)) {
           vbr = 1.0;
           const double Kh_max_here = hrat * Kh_Max_xy;
           if (K >= Kh_max_here) { vbr = 0.0; K = Kh_max_here; }
-          else if ((K > 0.0) || (CS.backscatter_underbound && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
-        } else if (CS.better_bound_Kh) {
+          else if ((K > 0.0) || (HVF(backscatter_underbound) && (Kh_max_here > 0.0))) vbr = 1.0 - K / Kh_max_here;
+        } else if (HVF(better_bound_Kh)) {
           K = dmin(K, hrat * Kh_Max_xy);
         }
         sxy_out = -K * sxy;
       } else sxy_out = 0.;
       if (bih) {
         double A = Ah_bg_xy;
-        if (CS.Smagorinsky_Ah) {
+        if (HVF(Smagorinsky_Ah)) {
           double AhSm;
-          if (CS.bound_Coriolis) AhSm = Shear * (Bih_xy + Bih2_xy * Shear);
+          if (HVF(bound_Coriolis)) AhSm = Shear * (Bih_xy + Bih2_xy * Shear);
           else AhSm = Bih_xy * Shear;
           A = dmax(A, AhSm);
-          if (CS.bound_Ah && !CS.better_bound_Ah) A = dmin(A, Ah_Max_xy);
+          if (HVF(bound_Ah) && !HVF(better_bound_Ah)) A = dmin(A, Ah_Max_xy);
         }
-        if (CS.better_bound_Ah) {
-          if (CS.better_bound_Kh) A = dmin(A, vbr * hrat * Ah_Max_xy);
+        if (HVF(better_bound_Ah)) {
+          if (HVF(better_bound_Kh)) A = dmin(A, vbr * hrat * Ah_Max_xy);
           else A = dmin(A, hrat * Ah_Max_xy);
         }
         const double dDel2vdx = DY_dxBu * ((s_d2v[l + 1] * IdyCvE) - (d2v * IdyCv0));
@@ -873,7 +893,7 @@ k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom
         const double d_str = A * (dDel2vdx + dDel2udy);
         sxy_out = sxy_out + d_str;
       }
-      if (CS.no_slip) s_txy[l] = sxy_out * (hq * red_xy);
+      if (HVF(no_slip)) s_txy[l] = sxy_out * (hq * red_xy);
       else s_txy[l] = sxy_out * (hq * mBu * red_xy);
     }
     if (k + 1 < k1) {   // the next layer's inputs into the other buffer (last read two barriers ago), and the layer after into flight
@@ -976,14 +996,21 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
     const size_t ldsb = (size_t)16 * (TY + 2) * (TX + 2) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {   // more than 64 KB of dynamic LDS has to be asked for
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 66 * 8));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 34 * 8));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<64, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 66 * 8));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 34 * 8));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 34 * 8));
       attr_set = true;
     }
+    static const bool om4_off = [] { const char *e = getenv("MOM6X_HV_OM4"); return e && !strcmp(e, "0"); }();
+    const bool om4 = !om4_off && CS.Laplacian && CS.biharmonic && !CS.Smagorinsky_Kh && CS.Smagorinsky_Ah && CS.better_bound_Kh &&
+                     CS.better_bound_Ah && !CS.no_slip && !CS.bound_Coriolis && CS.bound_Ah && CS.bound_Kh && CS.backscatter_underbound &&
+                     !CS.add_LES_viscosity && CS.use_land_mask;
     if (TX == 64) {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<64, 16>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<64, 16, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+    } else if (om4) {
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
     } else {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
     }
     HIPCHK(hipGetLastError());
     return MOM6X_OK;

@@ -13,6 +13,10 @@ FLAGS = {
     "both_better_bounds": dict(Laplacian=1, Kh=2.0e3, Kh_vel_scale=0.05, Ah=1.0e11, Ah_vel_scale=0.05, Ah_time_scale=8.0e4),
     "smagorinsky": dict(Laplacian=1, Smagorinsky_Kh=1, Smag_Lap_const=0.15, Smagorinsky_Ah=1, Smag_bi_const=0.06, Kh=10.0,
                         Ah=1.0e8),
+    # the OM4-class switch set, which k_hv_fused has a compile-time instantiation for (and with coefficients large enough for
+    # the "better" bounds and the backscatter branch to bind)
+    "om4_class": dict(Laplacian=1, Kh_vel_scale=0.01, Ah_vel_scale=0.01, Smagorinsky_Ah=1, Smag_bi_const=0.06),
+    "om4_class_bounds_binding": dict(Laplacian=1, Kh=2.0e4, Ah=1.0e13, Smagorinsky_Ah=1, Smag_bi_const=0.5),
     "smagorinsky_bound_coriolis": dict(Smagorinsky_Ah=1, Smag_bi_const=0.06, bound_Coriolis=1, bound_Cor_vel=2.0, Ah=1.0e8),
     "les_added_legacy_bounds": dict(Laplacian=1, Smagorinsky_Kh=1, Smag_Lap_const=0.15, add_LES_viscosity=1, Kh=50.0,
                                     better_bound_Kh=0, better_bound_Ah=0, Smagorinsky_Ah=1, Smag_bi_const=0.06,
@@ -90,14 +94,14 @@ def test_hor_visc_init_rejects_noslip_biharmonic():
 
 def test_the_other_variants_are_bit_identical_too():
     """The default is k_hv_fused on 32 x 16 tiles (the four stages in one LDS-tiled kernel, hor_visc.hip).  The four-kernel chain
-    (MOM6X_HORVISC=legacy; what Leith configurations always take) and the 64 x 16 tiles are held to the same oracle: this file
-    again in a process with the switch set."""
+    (MOM6X_HORVISC=legacy; what Leith configurations always take), the 64 x 16 tiles and the generic instantiation where the
+    OM4-class one would run (MOM6X_HV_OM4=0) are held to the same oracle: this file again in a process with the switch set."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for mode, tile in (("legacy", "32"), ("fused", "64")):
-        env = dict(os.environ, MOM6X_HORVISC=mode, MOM6X_HV_TILE=tile)
+    for mode, tile, om4 in (("legacy", "32", "1"), ("fused", "64", "1"), ("fused", "32", "0")):   # om4 = 0: the generic instantiation
+        env = dict(os.environ, MOM6X_HORVISC=mode, MOM6X_HV_TILE=tile, MOM6X_HV_OM4=om4)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_horvisc_gpu.py"), "-m", "gpu", "-q", "-x",
                             "-k", "not other_variants"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
         assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
