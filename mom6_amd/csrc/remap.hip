@@ -425,9 +425,14 @@ __device__ __forceinline__ double tgt_close(Target &t, double h1, int fb) {
 
 // remapping_core_h :234 for one column (after reconstruct_column).  u1 may alias the array the source values came from
 // as long as `u0` points to a copy.
-__device__ void apply_column(const ApplyArgs &A, const double *__restrict__ h0, const double *__restrict__ u0, View v0,
+// CFG = 1: the OM4 switch set (PPM reconstruction, remap_src_to_sub_grid_om4, target values bounded, sub-cell values not) known at
+// compile time -- the merge is issue-bound, and every sub-cell otherwise tests the method and the integrator again.
+template <int CFG>
+__device__ void apply_column(const ApplyArgs &A0, const double *__restrict__ h0, const double *__restrict__ u0, View v0,
                              const double *__restrict__ E1, const double *__restrict__ E2, const double *__restrict__ C2, View vw,
                              const double *__restrict__ h1, double *u1, View v1) {
+  ApplyArgs A = A0;
+  if (CFG == 1) { A.method = INTEGRATION_PPM; A.om4 = 1; A.fb_sub = 0; A.fb_tgt = 1; }   // (constants from here on)
   const int n0 = A.n0, n1 = A.n1, ns = n0 + n1 + 1, method = A.method;
   int last_thick = 0;
   for (int k = 1; k <= n0; k++) if (AT(h0, v0, k) > 0.) last_thick = k;          // i0_last_thick_cell :884-889
@@ -615,6 +620,7 @@ k_remap_recon(Dm d, const double *__restrict__ mask, ReconArgs A, const double *
   View v; v.base = x; v.lev = (size_t)d.slab;
   reconstruct_column(A, h_old, f, v, E1, E2, C2, Ucopy, v);
 }
+template <int CFG>
 __global__ void __launch_bounds__(256)
 k_remap_apply(Dm d, const double *__restrict__ mask, ApplyArgs A, const double *__restrict__ h_old, const double *__restrict__ h_new,
               const double *__restrict__ E1, const double *__restrict__ E2, const double *__restrict__ C2,
@@ -625,7 +631,7 @@ k_remap_apply(Dm d, const double *__restrict__ mask, ApplyArgs A, const double *
   const size_t x = ix2(d, i, j);
   if (!(mask[x] > 0.)) return;
   View v; v.base = x; v.lev = (size_t)d.slab;
-  apply_column(A, h_old, Ucopy, v, E1, E2, C2, v, h_new, f, v);
+  apply_column<CFG>(A, h_old, Ucopy, v, E1, E2, C2, v, h_new, f, v);
 }
 // the packed form of the unit tests: column c holds n0 | n1 values back to back; work arrays are [k][ncol]
 __global__ void __launch_bounds__(64)
@@ -636,7 +642,7 @@ k_remap_packed(int ncol, ReconArgs R, ApplyArgs A, const double *__restrict__ h0
   View v0, v1, vw;
   v0.base = (size_t)c * A.n0; v0.lev = 1; v1.base = (size_t)c * A.n1; v1.lev = 1; vw.base = c; vw.lev = ncol;
   reconstruct_column(R, h0, u0, v0, E1, E2, C2, nullptr, vw);
-  apply_column(A, h0, u0, v0, E1, E2, C2, vw, h1, u1, v1);
+  apply_column<0>(A, h0, u0, v0, E1, E2, C2, vw, h1, u1, v1);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1195,8 +1201,13 @@ int remap_field(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int 
   const dim3 g = grid3(nxa(i1 - i0 + 1, i0), j1 - j0 + 1, 1, b);
   const double *mask = c->G + (size_t)mask_id * d.slab;
   KLAUNCH(c, "k_remap_recon", k_remap_recon, g, b, d, mask, R, h_old, (const double *)f, E1, E2, C2, Uc, i0, i1, j0, j1);
-  KLAUNCH(c, "k_remap_apply", k_remap_apply, g, b, d, mask, A, h_old, h_new, (const double *)E1, (const double *)E2, (const double *)C2,
-          (const double *)Uc, f, i0, i1, j0, j1);
+  static const bool cfg_off = [] { const char *e = getenv("MOM6X_REMAP_CFG"); return e && !strcmp(e, "0"); }();
+  if (!cfg_off && A.method == INTEGRATION_PPM && A.om4 && !A.fb_sub && A.fb_tgt)
+    KLAUNCH(c, "k_remap_apply", k_remap_apply<1>, g, b, d, mask, A, h_old, h_new, (const double *)E1, (const double *)E2, (const double *)C2,
+            (const double *)Uc, f, i0, i1, j0, j1);
+  else
+    KLAUNCH(c, "k_remap_apply", k_remap_apply<0>, g, b, d, mask, A, h_old, h_new, (const double *)E1, (const double *)E2, (const double *)C2,
+            (const double *)Uc, f, i0, i1, j0, j1);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }
