@@ -273,12 +273,28 @@ __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict_
   double umm = 0., um = 0., uc = 0., up = U(1), uq = U(2), hm = 0., hc = 0., hp = H(1), hq = H(2);
   double ed_c = 0., ed_p = edge_1;               // edge(k), edge(k+1)
   double a_m = 0., b_m = 0.;                     // bounded edge values of cell k-1 (a_m already through its pair check with k-2)
-  for (int k = 1; k <= N; k++) {
+  // The column is read four cells ahead of its use (a ring of registers indexed by the level mod 4, the loop unrolled by
+  // four so that the index is static and nothing is copied): a lane that asked for cell k+2 and used it in the same step
+  // kept two loads in flight, and the sweep ran at the latency of a load per step.
+  double ru[4], rh[4];
+#pragma unroll
+  for (int L = 3; L <= 6; L++) { ru[L & 3] = (L <= N) ? U(L) : 0.; rh[L & 3] = (L <= N) ? H(L) : 0.; }
+  for (int k0 = 1; k0 <= N; k0 += 4)
+#pragma unroll
+  for (int kq = 0; kq < 4; kq++) {
+    const int k = k0 + kq;
+    if (k > N) break;
     umm = um; um = uc; uc = up; up = uq; hm = hc; hc = hp; hp = hq;
-    if (k + 2 <= N) { uq = U(k + 2); hq = H(k + 2); }
+    if (k + 2 <= N) {
+      uq = ru[(kq + 3) & 3]; hq = rh[(kq + 3) & 3];                      // level k + 2 (k0 = 1 mod 4)
+      if (k + 6 <= N) { ru[(kq + 3) & 3] = U(k + 6); rh[(kq + 3) & 3] = H(k + 6); }
+    }
     ed_c = ed_p;
     const int e = k + 1;                         // the edge below cell k
-    if (implicit) ed_p = (e <= N) ? e1(e) : edge_N1;
+    if (implicit) {
+      ed_p = edge_N1;
+      if (e <= N) { ed_p = e1(e); asm volatile("" : "+v"(ed_p)); }   // (its wait stays on this path: the explicit scheme's loads run ahead)
+    }
     else if (e <= 2) ed_p = edge_2;
     else if (e >= N) ed_p = (e == N) ? edge_N : edge_N1;
     else ed_p = edge_h4(hm, hc, hp, hq, um, uc, up, uq, hne);      // i = e: cells e-2 .. e+1 = k-1 .. k+2
@@ -633,6 +649,304 @@ k_remap_apply(Dm d, const double *__restrict__ mask, ApplyArgs A, const double *
   View v; v.base = x; v.lev = (size_t)d.slab;
   apply_column<CFG>(A, h_old, Ucopy, v, E1, E2, C2, v, h_new, f, v);
 }
+// ---- the merge for the OM4 switch set, shared by the fields that live on one pair of grids --------------------------------
+// REMAPPING_SCHEME = PPM_*, remap_src_to_sub_grid_om4 :845, target values bounded, sub-cell values not (what
+// `k_remap_apply<1>` is compiled for), with the same results bit for bit.  k_remap_apply spends two thirds of a wavefront's
+// life waiting for memory (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.64): every step of the merge needs h1 at an index that differs
+// from lane to lane, and needs it at once.  Here
+//  * the target column goes through a sliding window in LDS (MG_W levels per lane, the level MG_LEAD below the source cell
+//    enters at the top of every iteration from a load issued one iteration earlier; a lane whose target index has left the
+//    window reads global memory as before), and the source cell's values are loaded one iteration ahead, so a wavefront
+//    waits at one place per source cell, for loads that are an iteration old;
+//  * what the sub-cells of a source cell share between fields -- their widths, the positions xa, xb in the cell and the
+//    polynomial weights that follow from them (two thirds of average_value_ppoly's arithmetic and its division) -- is formed
+//    once and used by NF fields (T and S; tracers in pairs);
+//  * a cell's sub-cells are kept as (width, two weights, form), from which a field's sub-cell mean costs four operations,
+//    so the pass that sums u*h for the conservation fix and the pass that feeds the targets both evaluate it instead of
+//    storing it; a cell with more than MG_NB sub-cells replays the merge from its saved start as k_remap_apply does.
+// Three facts about the merge, for thicknesses >= 0, are used: (1) inside the source loop the sub-cells of a source cell are
+// the closings of consecutive target cells followed by its own closing; a target cell closed by the 2nd, 3rd, ... of them
+// lies inside the source cell and its whole width is the sub-cell's; (2) a sub-cell of positive width exists only in a
+// source cell of positive thickness, which is then not below i0_last_thick_cell, so `adjust` is (hsub_imax > 0) alone;
+// (3) the column's last sub-cell (u = E2(n0), :926-929) is the closing of source cell n0 when the targets are exhausted, or
+// else the closing of target n1.
+constexpr int MG_NT = 3, MG_W = 16, MG_LEAD = 8;
+template <int NF> struct MergeFields { const double *E1[NF], *E2[NF], *Uc[NF]; double *out[NF]; };
+struct SubW { double p, q; int mode; };   // 0 / 1: xb > xa, left / right form; 2 / 3: a point, left / right; 4: u0(i0); 5: E2(n0)
+
+// xa, xb of the next sub-cell (:900-912) and the weights of average_value_ppoly's PPM branches :1420-1437, :1470-1480
+__device__ __forceinline__ SubW sub_weights(double &xa, double &cum, double hs, double den, bool last) {
+  SubW w; w.p = 0.; w.q = 0.;
+  if (last) { w.mode = 5; return w; }
+  cum = cum + hs;
+  if (den > 0.) {
+    const double xb = dmin(1., cum / den);
+    if (xb > xa) {
+      const double mx = 0.5 * (xa + xb);
+      if (mx < 0.5) { w.mode = 0; w.p = mx; w.q = 3. * (xb + xa) - 2. * ((xa * xa + xb * xb) + xa * xb); }
+      else {
+        const double Ya = 1. - xa, Yb = 1. - xb;
+        w.mode = 1; w.p = 0.5 * (Ya + Yb); w.q = 3. * (Yb + Ya) - 2. * ((Ya * Ya + Yb * Yb) + Ya * Yb);
+      }
+    } else {
+      const double Ya = 1. - xa;
+      if (xa < 0.5) { w.mode = 2; w.p = xa; w.q = Ya; }
+      else { w.mode = 3; w.p = Ya; w.q = xa; }
+    }
+    xa = xb;
+  } else { w.mode = 4; xa = 1.; }
+  return w;
+}
+// the same for the sub-cell that closes its source cell when it is not the column's last: cum >= den (the same sums, with
+// hs >= dh in the last term), so xb = min(1, cum / den) is 1 without the division, which leaves the two right-hand forms
+// with Yb = 0 (and x + 0 = x, x * 0 = 0 for the finite x >= 0 here)
+__device__ __forceinline__ SubW sub_weights_closing(double &xa, double &cum, double hs, double den) {
+  SubW w;
+  cum = cum + hs;
+  if (den > 0.) {
+    const double Ya = 1. - xa;
+    if (1. > xa) { w.mode = 1; w.p = 0.5 * Ya; w.q = 3. * Ya - 2. * (Ya * Ya); }
+    else { w.mode = 3; w.p = Ya; w.q = xa; }
+  } else { w.mode = 4; w.p = 0.; w.q = 0.; }
+  xa = 1.;
+  return w;
+}
+struct CellPoly { double aL, aR, uc, dLR, dRL, ac, ac3; };
+__device__ __forceinline__ CellPoly cell_poly(double aL, double aR, double uc) {
+  CellPoly c; c.aL = aL; c.aR = aR; c.uc = uc; c.dLR = aR - aL; c.dRL = aL - aR;
+  const double s = (uc - aL) + (uc - aR);
+  c.ac = 0.5 * s; c.ac3 = 3. * s;
+  return c;
+}
+__device__ __forceinline__ double sub_mean(const SubW &w, const CellPoly &c) {
+  const bool right = (w.mode & 1);
+  const double B = right ? c.aR : c.aL, D = right ? c.dRL : c.dLR;
+  if (w.mode < 2) return B + (D * w.p + c.ac * w.q);
+  if (w.mode < 4) return B + w.p * (D + c.ac3 * w.q);
+  return (w.mode == 4) ? c.uc : c.aR;
+}
+__device__ __forceinline__ double sub_mean_right(const SubW &w, const CellPoly &c) {   // modes 1, 3, 4, 5
+  if (w.mode == 1) return c.aR + (c.dRL * w.p + c.ac * w.q);
+  if (w.mode == 3) return c.aR + w.p * (c.dRL + c.ac3 * w.q);
+  return (w.mode == 4) ? c.uc : c.aR;
+}
+
+template <int NF>
+__global__ void __launch_bounds__(256)
+k_remap_merge(Dm d, const double *__restrict__ mask, const double *__restrict__ h0p, const double *__restrict__ h1p, MergeFields<NF> F,
+              int i0, int i1, int j0, int j1) {
+  __shared__ double win_all[4][MG_W][64];
+  const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i < i0 || i > i1 || j > j1) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  if (!(mask[x] > 0.)) return;
+  const int n = d.nk;
+  double *win = &win_all[threadIdx.y][0][threadIdx.x];
+#define WIN(L) win[((L) & (MG_W - 1)) * 64]
+#define LEV(p, L) (p)[x + (size_t)((L) - 1) * slab]
+  // the window holds the levels k + MG_LEAD - MG_W + 1 .. k + MG_LEAD of h1 during iteration k
+  auto next_target = [&](int &it, double &h1s, double &h1full, bool &tgt, int k) {     // :765-771
+    if (it < n) {
+      it = it + 1;
+      h1s = WIN(it);                   // (the slot exists whatever it holds)
+      if ((unsigned)(it - (k + MG_LEAD - MG_W + 1)) >= (unsigned)MG_W) {
+        h1s = LEV(h1p, it);
+        asm volatile("" : "+v"(h1s));  // (the wait for this load belongs here, not where the paths meet: there it would also
+      }                                //  hold the lanes that read the window until this iteration's prefetches are back)
+      h1full = h1s;
+    } else { h1s = 0.; tgt = false; }
+  };
+  double h1s, h1_pf;
+  {
+    double t[MG_LEAD];
+#pragma unroll
+    for (int L = 1; L <= MG_LEAD; L++) t[L - 1] = (L <= n) ? LEV(h1p, L) : 0.;
+    h1_pf = (MG_LEAD + 1 <= n) ? LEV(h1p, MG_LEAD + 1) : 0.;
+#pragma unroll
+    for (int L = 1; L <= MG_LEAD; L++) WIN(L) = t[L - 1];
+    h1s = t[0];
+  }
+  double n_h0 = LEV(h0p, 1), n_aL[NF], n_aR[NF], n_uc[NF];
+#pragma unroll
+  for (int f = 0; f < NF; f++) { n_aL[f] = LEV(F.E1[f], 1); n_aR[f] = LEV(F.E2[f], 1); n_uc[f] = LEV(F.Uc[f], 1); }
+  double h1full = h1s;
+  int it = 1;
+  bool tgt = true;
+  // The running target cell (remap_sub_to_tgt_grid_om4 :1125-1160).  It always holds a sub-cell when a source cell begins:
+  // the zero-width first one :893-894, later the closing sub-cell of the previous source cell.
+  double Tdh = 0. + 0., Tduh[NF], Tmin[NF], Tmax[NF], Tfirst[NF];
+#pragma unroll
+  for (int f = 0; f < NF; f++) { Tfirst[f] = n_aL[f]; Tmin[f] = n_aL[f]; Tmax[f] = n_aL[f]; Tduh[f] = 0. + 0.; }
+  double xa = 0., cum = 0., h0_eff_last = 0.;
+  CellPoly P[NF];
+  // one more sub-cell of the running target / the first sub-cell of the next one / the target's value :1146-1158
+  auto feed = [&](bool fresh, double hs, const double *u, const double *uh) {
+    Tdh = (fresh ? 0. : Tdh) + hs;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+      if (fresh) { Tfirst[f] = u[f]; Tmin[f] = u[f]; Tmax[f] = u[f]; Tduh[f] = 0. + uh[f]; }
+      else { Tmin[f] = dmin(Tmin[f], u[f]); Tmax[f] = dmax(Tmax[f], u[f]); Tduh[f] = Tduh[f] + uh[f]; }
+    }
+  };
+  auto close = [&](int lev, double h1f) {
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+      double r;
+      if (h1f > 0.) { r = Tduh[f] / Tdh; r = dmax(Tmin[f], dmin(Tmax[f], r)); }
+      else r = Tfirst[f];
+      LEV(F.out[f], lev) = r;
+    }
+  };
+  for (int k = 1; k <= n; k++) {
+    // ---- what was asked for during the previous iteration arrives, the next requests leave
+    const double hsrc = n_h0;
+#pragma unroll
+    for (int f = 0; f < NF; f++) P[f] = cell_poly(n_aL[f], n_aR[f], n_uc[f]);
+    WIN(k + MG_LEAD) = h1_pf;
+    if (k + 1 <= n) {
+      n_h0 = LEV(h0p, k + 1);
+#pragma unroll
+      for (int f = 0; f < NF; f++) { n_aL[f] = LEV(F.E1[f], k + 1); n_aR[f] = LEV(F.E2[f], k + 1); n_uc[f] = LEV(F.Uc[f], k + 1); }
+    }
+    if (k + MG_LEAD + 1 <= n) h1_pf = LEV(h1p, k + MG_LEAD + 1);
+    // ---- the cell's sub-cells (intersect_src_tgt_grids' loop :700-795): the target cells that end inside it, then its own
+    // closing; their widths, the effective width h0_eff :722-747 and the thickest one :726-729
+    double h0s = hsrc;
+    const double s_h1s = h1s, s_h1full = h1full;
+    const int s_it = it;
+    double b_hs[MG_NT];
+    int nt = 0, imax = -1;
+    double dh_max = 0., h0_eff = 0., hsub_imax = 0.;
+    bool more = tgt && !(h0s <= h1s);
+#pragma unroll
+    for (int c = 0; c < MG_NT; c++) {
+      if (more) {
+        const double dh = dmin(h0s, h1s);
+        h0_eff = h0_eff + dh;
+        if (dh >= dh_max) { imax = c; dh_max = dh; hsub_imax = dh; }
+        b_hs[c] = dh; nt = c + 1;
+        h0s = h0s - dh;
+        next_target(it, h1s, h1full, tgt, k);
+        more = tgt && !(h0s <= h1s);
+      }
+    }
+    while (more) {           // more of them than the buffer holds
+      const double dh = dmin(h0s, h1s);
+      h0_eff = h0_eff + dh;
+      if (dh >= dh_max) { imax = nt; dh_max = dh; hsub_imax = dh; }
+      nt++;
+      h0s = h0s - dh;
+      next_target(it, h1s, h1full, tgt, k);
+      more = tgt && !(h0s <= h1s);
+    }
+    double hs_l;
+    {
+      const double dh = dmin(h0s, h1s);
+      hs_l = dh;
+      if (h0s <= h1s) h1s = h1s - dh;
+      else hs_l = h0s;
+      h0_eff = h0_eff + dh;
+      if (dh >= dh_max) { imax = nt; dh_max = dh; hsub_imax = hs_l; }
+    }
+    const bool has_last = tgt, col_last = (k == n) && !tgt, adjust = (hsub_imax > 0.);
+    const double den = h0_eff;
+    h0_eff_last = h0_eff;
+    xa = 0.; cum = 0.;
+    if (nt <= MG_NT) {
+      SubW w[MG_NT], w_l;
+#pragma unroll
+      for (int c = 0; c < MG_NT; c++) if (c < nt) w[c] = sub_weights(xa, cum, b_hs[c], den, false);
+      if (col_last) { w_l.mode = 5; w_l.p = 0.; w_l.q = 0.; }
+      else w_l = sub_weights_closing(xa, cum, hs_l, den);
+      double u[MG_NT][NF], u_l[NF], uh_adj[NF];
+#pragma unroll
+      for (int f = 0; f < NF; f++) {
+        double duh = 0. + 0.;
+#pragma unroll
+        for (int c = 0; c < MG_NT; c++)
+          if (c < nt) { u[c][f] = sub_mean(w[c], P[f]); if (c != imax) duh = duh + b_hs[c] * u[c][f]; }
+        u_l[f] = sub_mean_right(w_l, P[f]);
+        if (nt != imax) duh = duh + hs_l * u_l[f];
+        uh_adj[f] = P[f].uc * hsrc - duh;
+      }
+      double uh[NF];
+#pragma unroll
+      for (int c = 0; c < MG_NT; c++) {
+        if (c < nt) {
+#pragma unroll
+          for (int f = 0; f < NF; f++) uh[f] = (adjust && c == imax) ? uh_adj[f] : b_hs[c] * u[c][f];
+          feed(c > 0, b_hs[c], u[c], uh);
+          close(s_it + c, (c == 0) ? s_h1full : b_hs[c]);
+        }
+      }
+      if (has_last) {
+#pragma unroll
+        for (int f = 0; f < NF; f++) uh[f] = (adjust && nt == imax) ? uh_adj[f] : hs_l * u_l[f];
+        feed(nt > 0, hs_l, u_l, uh);
+      }
+    } else {
+      // the merge is replayed from the cell's start, once for the sum :939-957 ...
+      double duh[NF], uh_adj[NF], u1[NF], uh1[NF];
+#pragma unroll
+      for (int f = 0; f < NF; f++) duh[f] = 0. + 0.;
+      double r_h0s = hsrc, r_h1s = s_h1s, r_h1full = s_h1full, xa2 = 0., cum2 = 0.;
+      int r_it = s_it;
+      bool r_tgt = true;
+      for (int c = 0; c <= nt; c++) {
+        double hs = hs_l;
+        SubW w;
+        if (c < nt) {
+          hs = dmin(r_h0s, r_h1s);
+          r_h0s = r_h0s - hs;
+          next_target(r_it, r_h1s, r_h1full, r_tgt, k);
+          w = sub_weights(xa2, cum2, hs, den, false);
+        } else if (col_last) { w.mode = 5; w.p = 0.; w.q = 0.; }
+        else w = sub_weights_closing(xa2, cum2, hs, den);
+#pragma unroll
+        for (int f = 0; f < NF; f++) { const double t = hs * sub_mean(w, P[f]); if (c != imax) duh[f] = duh[f] + t; }
+      }
+#pragma unroll
+      for (int f = 0; f < NF; f++) uh_adj[f] = P[f].uc * hsrc - duh[f];
+      // ... and once to feed the targets
+      r_h0s = hsrc; r_h1s = s_h1s; r_h1full = s_h1full; r_it = s_it; r_tgt = true;
+      for (int c = 0; c <= nt; c++) {
+        const int lev = r_it;
+        const double h1f = r_h1full;
+        double hs = hs_l;
+        SubW w;
+        if (c < nt) {
+          hs = dmin(r_h0s, r_h1s);
+          r_h0s = r_h0s - hs;
+          next_target(r_it, r_h1s, r_h1full, r_tgt, k);
+          w = sub_weights(xa, cum, hs, den, false);
+        } else if (col_last) { w.mode = 5; w.p = 0.; w.q = 0.; }
+        else w = sub_weights_closing(xa, cum, hs, den);
+#pragma unroll
+        for (int f = 0; f < NF; f++) { u1[f] = sub_mean(w, P[f]); uh1[f] = (adjust && c == imax) ? uh_adj[f] : hs * u1[f]; }
+        if (c < nt || has_last) feed(c > 0, hs, u1, uh1);
+        if (c < nt) close(lev, h1f);
+      }
+    }
+  }
+  // ---- the target column is deeper than the source column: the remaining sub-cells continue the last source cell
+  bool fresh = false;
+  while (tgt) {
+    const int lev = it;
+    const double h1f = h1full, hs = h1s;
+    next_target(it, h1s, h1full, tgt, n);
+    const SubW w = sub_weights(xa, cum, hs, h0_eff_last, !tgt);
+    double u1[NF], uh1[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) { u1[f] = sub_mean(w, P[f]); uh1[f] = hs * u1[f]; }
+    feed(fresh, hs, u1, uh1);
+    close(lev, h1f);
+    fresh = true;
+  }
+#undef WIN
+#undef LEV
+}
+
 // the packed form of the unit tests: column c holds n0 | n1 values back to back; work arrays are [k][ncol]
 __global__ void __launch_bounds__(64)
 k_remap_packed(int ncol, ReconArgs R, ApplyArgs A, const double *__restrict__ h0, const double *__restrict__ u0,
@@ -1186,30 +1500,50 @@ int check_params(const mom6x_remapping_params *p, int n0, ReconArgs &R, ApplyArg
   return MOM6X_OK;
 }
 
-// remap one 3-D field in place on the points (i0..i1, j0..j1) where mask > 0
-int remap_field(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int i0, int i1, int j0, int j1, const double *h_old,
-                const double *h_new, double *f) {
+// remap nf (1 or 2) 3-D fields that live on the same pair of grids, in place, on the points (i0..i1, j0..j1) where mask > 0
+int remap_fields(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int i0, int i1, int j0, int j1, const double *h_old,
+                 const double *h_new, double *const *f, int nf) {
   const Dm d = c->d;
   ReconArgs R; ApplyArgs A;
   int rc = check_params(p, d.nk, R, A, d.nk);
   if (rc) return rc;
-  double *E1, *E2, *C2, *Uc;
-  if ((rc = ctx_scratch(c, SCR_t0, d.nk, &E1)) || (rc = ctx_scratch(c, SCR_t1, d.nk, &E2)) || (rc = ctx_scratch(c, SCR_t2, d.nk, &C2)) ||
-      (rc = ctx_scratch(c, SCR_t3, d.nk, &Uc)))
-    return rc;
+  // MOM6X_REMAP_MERGE=apply: the one-field streamed merge k_remap_apply for every switch set (the shared-field kernel is for OM4's)
+  static const bool merge_off = [] { const char *e = getenv("MOM6X_REMAP_MERGE"); return e && !strcmp(e, "apply"); }();
+  const bool om4_set = (A.method == INTEGRATION_PPM && A.om4 && !A.fb_sub && A.fb_tgt);
+  const bool shared = om4_set && !merge_off;
+  if (!shared && nf > 1) {
+    for (int m = 0; m < nf; m++) if ((rc = remap_fields(c, p, mask_id, i0, i1, j0, j1, h_old, h_new, f + m, 1))) return rc;
+    return MOM6X_OK;
+  }
+  static const Scr work[2][4] = {{SCR_t0, SCR_t1, SCR_t3, SCR_t2}, {SCR_KE, SCR_q, SCR_absv, SCR_t2}};   // E1, E2, Ucopy, C2 (PLM only)
+  double *W[2][4];
+  for (int m = 0; m < nf; m++)
+    for (int a = 0; a < 4; a++) if ((rc = ctx_scratch(c, work[m][a], d.nk, &W[m][a]))) return rc;
   const dim3 b(64, 4, 1);
   const dim3 g = grid3(nxa(i1 - i0 + 1, i0), j1 - j0 + 1, 1, b);
   const double *mask = c->G + (size_t)mask_id * d.slab;
-  KLAUNCH(c, "k_remap_recon", k_remap_recon, g, b, d, mask, R, h_old, (const double *)f, E1, E2, C2, Uc, i0, i1, j0, j1);
-  static const bool cfg_off = [] { const char *e = getenv("MOM6X_REMAP_CFG"); return e && !strcmp(e, "0"); }();
-  if (!cfg_off && A.method == INTEGRATION_PPM && A.om4 && !A.fb_sub && A.fb_tgt)
-    KLAUNCH(c, "k_remap_apply", k_remap_apply<1>, g, b, d, mask, A, h_old, h_new, (const double *)E1, (const double *)E2, (const double *)C2,
-            (const double *)Uc, f, i0, i1, j0, j1);
+  for (int m = 0; m < nf; m++)
+    KLAUNCH(c, "k_remap_recon", k_remap_recon, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1);
+  if (shared && nf == 2) {
+    MergeFields<2> F;
+    for (int m = 0; m < 2; m++) { F.E1[m] = W[m][0]; F.E2[m] = W[m][1]; F.Uc[m] = W[m][2]; F.out[m] = f[m]; }
+    KLAUNCH(c, "k_remap_merge<2>", k_remap_merge<2>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1);
+  } else if (shared) {
+    MergeFields<1> F;
+    F.E1[0] = W[0][0]; F.E2[0] = W[0][1]; F.Uc[0] = W[0][2]; F.out[0] = f[0];
+    KLAUNCH(c, "k_remap_merge<1>", k_remap_merge<1>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1);
+  } else if (om4_set)
+    KLAUNCH(c, "k_remap_apply", k_remap_apply<1>, g, b, d, mask, A, h_old, h_new, (const double *)W[0][0], (const double *)W[0][1],
+            (const double *)W[0][3], (const double *)W[0][2], f[0], i0, i1, j0, j1);
   else
-    KLAUNCH(c, "k_remap_apply", k_remap_apply<0>, g, b, d, mask, A, h_old, h_new, (const double *)E1, (const double *)E2, (const double *)C2,
-            (const double *)Uc, f, i0, i1, j0, j1);
+    KLAUNCH(c, "k_remap_apply", k_remap_apply<0>, g, b, d, mask, A, h_old, h_new, (const double *)W[0][0], (const double *)W[0][1],
+            (const double *)W[0][3], (const double *)W[0][2], f[0], i0, i1, j0, j1);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
+}
+int remap_field(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int i0, int i1, int j0, int j1, const double *h_old,
+                const double *h_new, double *f) {
+  return remap_fields(c, p, mask_id, i0, i1, j0, j1, h_old, h_new, &f, 1);
 }
 
 // ALE_PLM_edge_values, MOM_ALE.F90:1520-1577: one thread per column; slp(k-1), slp(k), slp(k+1) are carried in registers so
@@ -1291,9 +1625,9 @@ extern "C" int mom6x_ALE_remap_tracers(mom6x_ctx *c, const mom6x_remapping_param
                                        double *const *fields, int nfields) {
   REQUIRE(c && p && h_old && h_new && (fields || nfields == 0), MOM6X_EINVAL, "ALE_remap_tracers: null argument");
   HIPCHK(hipSetDevice(c->device));
-  for (int m = 0; m < nfields; m++) {
-    REQUIRE(fields[m], MOM6X_EINVAL, "ALE_remap_tracers: null tracer array");
-    int rc = remap_field(c, p, MOM6X_G_mask2dT, 0, c->d.ni - 1, 0, c->d.nj - 1, h_old, h_new, fields[m]);
+  for (int m = 0; m < nfields; m++) REQUIRE(fields[m], MOM6X_EINVAL, "ALE_remap_tracers: null tracer array");
+  for (int m = 0; m < nfields; m += 2) {     // the tracers share their grids: two at a time through one merge
+    int rc = remap_fields(c, p, MOM6X_G_mask2dT, 0, c->d.ni - 1, 0, c->d.nj - 1, h_old, h_new, fields + m, std::min(2, nfields - m));
     if (rc) return rc;
   }
   return MOM6X_OK;

@@ -123,6 +123,67 @@ def test_ALE_remap_tracers_and_velocities(orc, cfg, scheme, mods):
     dyc.close()
 
 
+@pytest.mark.parametrize("nk", [5, 24, 75])
+@pytest.mark.parametrize("scheme", [abi.REMAP_PPM_H4, abi.REMAP_PPM_IH4])
+def test_ALE_remap_ragged_grids_through_the_shared_merge(orc, nk, scheme):
+    """k_remap_merge (the OM4 switch set: one merge for the fields of a grid pair, target column through an LDS window, a
+    cell's sub-cells kept as weights) on what it has special paths for: vanished layers in both grids, columns whose target
+    index runs far ahead of or behind the source index (outside the window), source cells holding more sub-cells than the
+    register buffer, target columns shallower and deeper than the source, unchanged grids; three tracers = one pair and a
+    single field; then u and v.  Bit for bit against the oracle (which keeps the reference's arrays)."""
+    import torch
+    from mom6_amd.dycore import Dycore
+    gg, d, M = H.island_basin(nk=nk)
+    GV = abi.vgrid_default()
+    CS = abi.remapping_params_default(scheme, GV.H_subroundoff, om4_remap_via_sub_cells=1, boundary_extrapolation=0)
+    rng = np.random.default_rng(100 + nk)
+    shp = (nk,) + d.shape2()
+    col = np.arange(shp[1] * shp[2]).reshape(shp[1:])
+
+    def grid(seed_shift):
+        h = rng.random(shp)
+        h[rng.random(shp) < 0.2] = 0.0
+        h[0] += 1.0e-3
+        return h
+    h_old, h_new = grid(0), grid(1)
+    # a third of the columns: the old grid's mass in the top few layers, the new one's in the bottom few (and the reverse)
+    top = (np.arange(nk) < max(1, nk // 6))[:, None, None]
+    h_old = np.where((col % 6 == 1)[None], np.where(top, h_old + 0.5, h_old * 1.0e-3), h_old)
+    h_new = np.where((col % 6 == 1)[None], np.where(top[::-1], h_new + 0.5, h_new * 1.0e-3), h_new)
+    h_old = np.where((col % 6 == 4)[None], np.where(top[::-1], h_old + 0.5, h_old * 1.0e-3), h_old)
+    h_new = np.where((col % 6 == 4)[None], np.where(top, h_new + 0.5, h_new * 1.0e-3), h_new)
+    scale = h_old.sum(0) / h_new.sum(0)
+    h_new = h_new * scale[None] * np.where(col % 3 == 0, 1.0, np.where(col % 3 == 1, 0.8, 1.3))[None]
+    h_new = np.where((col % 5 == 2)[None], h_old, h_new)                 # unchanged grids
+    h_old, h_new = np.ascontiguousarray(h_old), np.ascontiguousarray(h_new)
+    trs = [np.ascontiguousarray(rng.random(shp) * 20 - 5) for _ in range(3)]
+    trs[1][:, col % 11 == 0] = 3.25                                       # uniform columns
+    tro = [t.copy() for t in trs]
+    orc.ALE_remap_tracers(d, M, CS, h_old, h_new, tro)
+    u, v = np.ascontiguousarray(rng.random(shp) - 0.5), np.ascontiguousarray(rng.random(shp) - 0.5)
+    hu_o, hv_o, hu_n, hv_n = (np.full_like(h_old, 1.0e-3) for _ in range(4))
+    orc.ALE_remap_set_h_vel(d, M, h_old, hu_o, hv_o); orc.ALE_remap_set_h_vel(d, M, h_new, hu_n, hv_n)
+    uo, vo = u.copy(), v.copy()
+    orc.ALE_remap_velocities(d, M, CS, hu_o, hv_o, hu_n, hv_n, uo, vo)
+
+    dyc = Dycore(d, M, GV)
+    hod, hnd = dyc.to_dev(h_old), dyc.to_dev(h_new)
+    trg = [dyc.to_dev(t) for t in trs]
+    ud, vd = dyc.to_dev(u), dyc.to_dev(v)
+    g = [dyc.to_dev(a) for a in (hu_o, hv_o, hu_n, hv_n)]
+    torch.cuda.synchronize()
+    dyc.ALE_remap_tracers(CS, hod, hnd, trg)
+    dyc.ALE_remap_velocities(CS, g[0], g[1], g[2], g[3], ud, vd)
+    dyc.sync()
+    sl = H.interior(d, "h")
+    for m in range(3):
+        H.assert_bitwise(trg[m].cpu().numpy(), tro[m], f"tracer {m}", sl)
+    H.assert_bitwise(ud.cpu().numpy(), uo, "u", H.interior(d, "u")); H.assert_bitwise(vd.cpu().numpy(), vo, "v", H.interior(d, "v"))
+    wet = M[G["mask2dT"]][tuple(sl)] > 0
+    assert np.abs(tro[0] - trs[0])[(Ellipsis,) + tuple(sl)][:, wet].max() > 1.0
+    dyc.close()
+
+
 def test_rejects_what_is_not_on_the_path(dyc):
     CS = abi.remapping_params_default(abi.REMAP_PPM_H4, H_NEGLECT, answer_date=20181231)
     with pytest.raises(RuntimeError, match="20190101"):
