@@ -230,7 +230,7 @@ def ale_remap_leg(args, dyc, d, st, barrier, dist):
     u, v = st["u"].clone(), st["v"].clone()
     hu_o, hv_o, hu_n, hv_n = (torch.full_like(h, 1.0e-3) for _ in range(4))
     dyc.ALE_regrid_zstar(RP, cr, h, h_new, dzI)
-    dyc.ALE_remap_tracers(CS, h, h_new, [T.clone()])                    # untimed: allocates the work arrays
+    dyc.ALE_remap_tracers(CS, h, h_new, [T.clone(), S.clone()])         # untimed: allocates the work arrays (two fields share a merge)
     barrier(); t0 = time.perf_counter()
     dyc.ALE_regrid_zstar(RP, cr, h, h_new, dzI)
     dyc.ALE_remap_tracers(CS, h, h_new, [T, S])

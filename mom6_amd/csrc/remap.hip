@@ -151,6 +151,12 @@ __device__ __forceinline__ void ppm_limit(double u_l, double u_c, double u_r, do
   if (fabs(edge_r - edge_l) < dmax(1.e-60, DBL_EPSILON * fabs(u_c))) { edge_l = u_c; edge_r = u_c; }
 }
 
+#ifndef RECON_RING
+#define RECON_RING 4
+#endif
+#ifndef RECON_WAVES
+#define RECON_WAVES 4
+#endif
 // build_reconstructions_1d :410-550 for one column.  h, u: the source column; E1, E2, C2: outputs (C2 only for PLM);
 // Ucopy: a copy of u (the field itself may be overwritten by the remapped values).  All 1-based.
 // The reference makes one pass over the column per stage (edge values, bounding, discontinuity check, limiter; first-guess
@@ -276,18 +282,18 @@ __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict_
   // The column is read four cells ahead of its use (a ring of registers indexed by the level mod 4, the loop unrolled by
   // four so that the index is static and nothing is copied): a lane that asked for cell k+2 and used it in the same step
   // kept two loads in flight, and the sweep ran at the latency of a load per step.
-  double ru[4], rh[4];
+  double ru[RECON_RING], rh[RECON_RING];
 #pragma unroll
-  for (int L = 3; L <= 6; L++) { ru[L & 3] = (L <= N) ? U(L) : 0.; rh[L & 3] = (L <= N) ? H(L) : 0.; }
-  for (int k0 = 1; k0 <= N; k0 += 4)
+  for (int L = 3; L <= 2 + RECON_RING; L++) { ru[L % RECON_RING] = (L <= N) ? U(L) : 0.; rh[L % RECON_RING] = (L <= N) ? H(L) : 0.; }
+  for (int k0 = 1; k0 <= N; k0 += RECON_RING)
 #pragma unroll
-  for (int kq = 0; kq < 4; kq++) {
+  for (int kq = 0; kq < RECON_RING; kq++) {
     const int k = k0 + kq;
     if (k > N) break;
     umm = um; um = uc; uc = up; up = uq; hm = hc; hc = hp; hp = hq;
     if (k + 2 <= N) {
-      uq = ru[(kq + 3) & 3]; hq = rh[(kq + 3) & 3];                      // level k + 2 (k0 = 1 mod 4)
-      if (k + 6 <= N) { ru[(kq + 3) & 3] = U(k + 6); rh[(kq + 3) & 3] = H(k + 6); }
+      uq = ru[(kq + 3) % RECON_RING]; hq = rh[(kq + 3) % RECON_RING];                      // level k + 2 (k0 = 1 mod RECON_RING)
+      if (k + 2 + RECON_RING <= N) { ru[(kq + 3) % RECON_RING] = U(k + 2 + RECON_RING); rh[(kq + 3) % RECON_RING] = H(k + 2 + RECON_RING); }
     }
     ed_c = ed_p;
     const int e = k + 1;                         // the edge below cell k
@@ -625,7 +631,7 @@ __device__ void apply_column(const ApplyArgs &A0, const double *__restrict__ h0,
 struct Fields { double *p[8]; };
 
 // the 3-D form: columns (i0..i1, j0..j1) with mask > 0; h_old / h_new / fields on the same staggering
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, RECON_WAVES)
 k_remap_recon(Dm d, const double *__restrict__ mask, ReconArgs A, const double *__restrict__ h_old, const double *__restrict__ f,
               double *E1, double *E2, double *C2, double *Ucopy, int i0, int i1, int j0, int j1) {
   const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;

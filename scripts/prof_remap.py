@@ -13,9 +13,22 @@ GV = abi.vgrid_default()
 dyc = Dycore(d, M, GV, 0)
 Md = dyc.to_dev(M)
 h, u, v = synth_dev.make_state(d, Md, u_max=0.05, h_pert=0.02)
-# the regridded column: same total thickness, interfaces moved by a few per cent of a layer (a z*-like adjustment)
-w = (1.0 + 0.05 * synth_dev.smooth_field(d, dyc.device, 5, nk=nk, ox=0.5, oy=0.5))
-h_new = (h * w); h_new = (h_new * (h.sum(0) / h_new.sum(0))[None]).contiguous()
+import os
+GRID = os.environ.get("PROF_REMAP_GRID", "smooth")   # smooth | first
+if GRID == "smooth":
+    # the regridded column: same total thickness, interfaces moved by a few per cent of a layer (a z*-like adjustment)
+    w = (1.0 + 0.05 * synth_dev.smooth_field(d, dyc.device, 5, nk=nk, ox=0.5, oy=0.5))
+    h_new = (h * w); h_new = (h_new * (h.sum(0) / h_new.sum(0))[None]).contiguous()
+else:
+    # "first": the bench's ALE step (terrain-following layers onto z* with the nominal layers of the deepest column: the target
+    # index of a shallow column falls far behind its source index)
+    Hcol = h.sum(0)
+    jm, im = divmod(int(torch.argmax(Hcol)), Hcol.shape[1])
+    cr = (h[:, jm, im] / GV.Z_to_H).cpu().numpy().copy()
+    RP = abi.regrid_zstar_params_default()
+    h_new = torch.zeros_like(h); dzI = torch.zeros((nk + 1,) + tuple(h.shape[1:]), dtype=h.dtype, device=h.device)
+    dyc.ALE_regrid_zstar(RP, cr, h, h_new, dzI)
+    print("grid:", GRID, "vanished target layers:", float((h_new[:, d.joff:d.joff + d.nj, d.ioff:d.ioff + d.ni] <= 1e-9).double().mean()))
 T = (10.0 + 5.0 * synth_dev.smooth_field(d, dyc.device, 71, nk=nk, ox=0.5, oy=0.5)).contiguous()
 S = (35.0 + synth_dev.smooth_field(d, dyc.device, 72, nk=nk, ox=0.5, oy=0.5)).contiguous()
 hu_o, hv_o, hu_n, hv_n = (torch.full_like(h, 1e-3) for _ in range(4))
