@@ -466,6 +466,153 @@ k_corad_fused(Dm d, const double *__restrict__ G, const double *__restrict__ u, 
   }
 }
 
+// k_corad_fused<LEAN> with its INPUTS through LDS too (the default configuration only: SADOURNY75_ENERGY, no bound, no EN_DIS).
+// k_corad_fused's threads each ask the vector memory unit for 22 values per layer, 9 of them their own point's (u, v, h, uh, vh and
+// the four arrays of the folded u_bc_accel) and 13 a neighbour's, which a neighbouring thread asks for as well: at 8 wavefronts of
+// 22 loads per layer and tile the L1's 64 bytes per clock are busy for 1.3 ms of the kernel's 2.8, and every load is used at once.
+// Here a thread loads its own point's five values one layer AHEAD into registers (the next layer's requests are in flight during
+// the whole of this one), hands them to the tile through LDS, and the neighbours' values are LDS reads; the tile's inputs one point
+// beyond its last column / row (q needs them) are loaded the same way by designated threads.  Two barriers per layer: inputs ->
+// q, KE -> accelerations; the input planes alternate between layers (the accelerations still read uh, vh when a fast wavefront
+// writes the next layer's), q and KE need one buffer.  Same expressions, same bits.
+__global__ void __launch_bounds__(CF_X * CF_Y, 4)
+k_corad_lds(Dm d, const double *__restrict__ G, const double *__restrict__ u, const double *__restrict__ v,
+            const double *__restrict__ uh, const double *__restrict__ vh, double *__restrict__ CAu, double *__restrict__ CAv,
+            const double *__restrict__ h, const double *__restrict__ PFu, const double *__restrict__ PFv,
+            const double *__restrict__ diffu, const double *__restrict__ diffv, double *__restrict__ u_bc, double *__restrict__ v_bc,
+            double *__restrict__ uhtr, double *__restrict__ vhtr, double dt_tr, int no_slip, int ke_scheme, double vol_neglect,
+            int kc, int gx, int gy, int gz, int xcd_order) {
+  __shared__ double lds[12 * CF_LDN];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  int b = (int)blockIdx.x;
+  const int nb = gx * gy * gz;
+  if (xcd_order) {
+    const int per = (nb + 7) / 8;
+    b = (b % 8) * per + b / 8;
+  }
+  if (b >= nb) return;
+  const int bxi = b % gx, byi = (b / gx) % gy, bzi = b / (gx * gy);
+  const int i = -2 + bxi * (CF_X - 2) + tx;
+  const int j = -2 + byi * (CF_Y - 2) + ty;
+  const int st = d.pitch;
+  const size_t slab = (size_t)d.slab;
+  const int k0 = bzi * kc, k1 = min(k0 + kc, d.nk);
+  const int l = (ty + 1) * CF_LDW + (tx + 1);
+  const bool live = (i <= d.ni) && (j <= d.nj);                 // the range of k_corad_q: (-2..ni, -2..nj)
+  const bool inb = (i <= d.ni + 1) && (j <= d.nj + 1);          // the points a live thread reads (halo >= 3: inside the arrays)
+  const size_t x = inb ? ix2(d, i, j) : ix2(d, 0, 0);
+  const bool out = live && tx >= 1 && tx <= CF_X - 2 && ty >= 1 && ty <= CF_Y - 2 && i <= d.ni - 1 && j <= d.nj - 1;   // (i, j >= -1)
+  // the tile's inputs one point beyond its last column and row: (kind 1) v, h east of column CF_X-1, (2) u, h north of row
+  // CF_Y-1, (3) h at the corner
+  int eKind = 0, eL = 0, ei = 0, ej = 0;
+  if (tx == CF_X - 1) { eKind = 1; ei = i + 1; ej = j; eL = (ty + 1) * CF_LDW + CF_X + 1; }
+  else if (ty == CF_Y - 1) { eKind = 2; ei = i; ej = j + 1; eL = (CF_Y + 1) * CF_LDW + tx + 1; }
+  else if (tx == 0 && ty == 0) { eKind = 2; ei = i + CF_X - 1; ej = j + CF_Y; eL = (CF_Y + 1) * CF_LDW + CF_X; }
+  else if (tx == 1 && ty == 0) { eKind = 3; ei = i - 1 + CF_X; ej = j + CF_Y; eL = (CF_Y + 1) * CF_LDW + CF_X + 1; }
+  if (ei > d.ni + 1 || ej > d.nj + 1) eKind = 0;
+  const size_t xe = eKind ? ix2(d, ei, ej) : x;
+  const double *eA = (eKind == 1) ? v : ((eKind == 2) ? u : h);
+  // ---- the coefficients of k_corad_q
+  const double *mT = gm(G, d, MOM6X_G_mask2dT), *areaT = gm(G, d, MOM6X_G_areaT);
+  const size_t xq = live ? x : ix2(d, 0, 0);
+  const double A00 = mT[xq] * areaT[xq], A10 = mT[xq + 1] * areaT[xq + 1];
+  const double A01 = mT[xq + st] * areaT[xq + st], A11 = mT[xq + 1 + st] * areaT[xq + 1 + st];
+  const double Area_q = (A00 + A11) + (A10 + A01);
+  const double dyCv0 = gm(G, d, MOM6X_G_dyCv)[xq], dyCv1 = gm(G, d, MOM6X_G_dyCv)[xq + 1];
+  const double dxCu0 = gm(G, d, MOM6X_G_dxCu)[xq], dxCu1 = gm(G, d, MOM6X_G_dxCu)[xq + st];
+  const double mBu = gm(G, d, MOM6X_G_mask2dBu)[xq], IareaBu = gm(G, d, MOM6X_G_IareaBu)[xq];
+  const double fBu = gm(G, d, MOM6X_G_CoriolisBu)[xq];
+  const double vfac = no_slip ? (2.0 - mBu) : mBu;
+  const bool do_KE = live && (i >= -1 && j >= -1) && tx >= 1 && ty >= 1;   // (the accelerations read KE of threads 1.. only)
+  double aCu0 = 0, aCu1 = 0, aCv0 = 0, aCv1 = 0, IareaT = 0;
+  if (do_KE) {
+    aCu0 = gm(G, d, MOM6X_G_areaCu)[xq]; aCu1 = gm(G, d, MOM6X_G_areaCu)[xq - 1];
+    aCv0 = gm(G, d, MOM6X_G_areaCv)[xq]; aCv1 = gm(G, d, MOM6X_G_areaCv)[xq - st];
+    IareaT = gm(G, d, MOM6X_G_IareaT)[xq];
+  }
+  const bool do_u = out && (j >= 0), do_v = out && (i >= 0);
+  const double IdxCu = gm(G, d, MOM6X_G_IdxCu)[xq], IdyCv = gm(G, d, MOM6X_G_IdyCv)[xq];
+  double *sq = lds + 10 * CF_LDN, *sk = sq + CF_LDN;
+  // the first layer's values
+  double r_u = 0., r_v = 0., r_h = 0., r_uh = 0., r_vh = 0., r_eA = 0., r_eB = 0.;
+  {
+    const size_t c = x + (size_t)k0 * slab, ce = xe + (size_t)k0 * slab;
+    if (inb) { r_u = u[c]; r_v = v[c]; r_h = h[c]; r_uh = uh[c]; r_vh = vh[c]; }
+    if (eKind) { r_eA = eA[ce]; if (eKind != 3) r_eB = h[ce]; }
+  }
+  for (int k = k0; k < k1; k++) {
+    const size_t c = x + (size_t)k * slab;
+    double *su = lds + ((k - k0) & 1) * 5 * CF_LDN, *sv = su + CF_LDN, *sh = su + 2 * CF_LDN, *suh = su + 3 * CF_LDN, *svh = su + 4 * CF_LDN;
+    su[l] = r_u; sv[l] = r_v; sh[l] = r_h; suh[l] = r_uh; svh[l] = r_vh;
+    if (eKind == 1) { sv[eL] = r_eA; sh[eL] = r_eB; }
+    else if (eKind == 2) { su[eL] = r_eA; sh[eL] = r_eB; }
+    else if (eKind == 3) sh[eL] = r_eA;
+    if (k + 1 < k1) {          // the next layer's requests leave before this layer's work
+      const size_t cn = c + slab, ce = xe + (size_t)(k + 1) * slab;
+      if (inb) { r_u = u[cn]; r_v = v[cn]; r_h = h[cn]; r_uh = uh[cn]; r_vh = vh[cn]; }
+      if (eKind) { r_eA = eA[ce]; if (eKind != 3) r_eB = h[ce]; }
+    }
+    __syncthreads();
+    double qv = 0.0, kev = 0.0;
+    if (live) {
+      const double u0 = su[l], v0 = sv[l];
+      const double dvdx = (sv[l + 1] * dyCv1) - (v0 * dyCv0);
+      const double dudy = (su[l + CF_LDW] * dxCu1) - (u0 * dxCu0);
+      const double h00 = sh[l], h10 = sh[l + 1], h01 = sh[l + CF_LDW], h11 = sh[l + 1 + CF_LDW];
+      const double hAu0 = 0.5 * ((A00 * h00) + (A10 * h10));      // hArea_u(I,j)
+      const double hAu1 = 0.5 * ((A01 * h01) + (A11 * h11));      // hArea_u(I,j+1)
+      const double hAv0 = 0.5 * ((A00 * h00) + (A01 * h01));      // hArea_v(i,J)
+      const double hAv1 = 0.5 * ((A10 * h10) + (A11 * h11));      // hArea_v(i+1,J)
+      const double rel_vort = vfac * (dvdx - dudy) * IareaBu;
+      const double abs_vort = fBu + rel_vort;
+      const double hArea_q = (hAu0 + hAu1) + (hAv0 + hAv1);
+      const double Ih_q = Area_q / (hArea_q + vol_neglect);
+      qv = abs_vort * Ih_q;
+      if (do_KE) {
+        const double um1 = su[l - 1], vm1 = sv[l - CF_LDW];
+        if (ke_scheme == MOM6X_KE_ARAKAWA) {
+          kev = (((aCu0 * (u0 * u0)) + (aCu1 * (um1 * um1))) + ((aCv0 * (v0 * v0)) + (aCv1 * (vm1 * vm1)))) * 0.25 * IareaT;
+        } else if (ke_scheme == MOM6X_KE_SIMPLE_GUDONOV) {
+          const double up = 0.5 * (um1 + fabs(um1)), up2 = up * up;
+          const double um = 0.5 * (u0 - fabs(u0)), um2 = um * um;
+          const double vp = 0.5 * (vm1 + fabs(vm1)), vp2 = vp * vp;
+          const double vm = 0.5 * (v0 - fabs(v0)), vm2 = vm * vm;
+          kev = (dmax(up2, um2) + dmax(vp2, vm2)) * 0.5;
+        } else {
+          const double up = 0.5 * (um1 + fabs(um1)), up2a = up * up * aCu1;
+          const double um = 0.5 * (u0 - fabs(u0)), um2a = um * um * aCu0;
+          const double vp = 0.5 * (vm1 + fabs(vm1)), vp2a = vp * vp * aCv1;
+          const double vm = 0.5 * (v0 - fabs(v0)), vm2a = vm * vm * aCv0;
+          kev = (dmax(um2a, up2a) + dmax(vm2a, vp2a)) * 0.5 * IareaT;
+        }
+      }
+    }
+    sq[l] = qv; sk[l] = kev;
+    __syncthreads();
+    if (out) {
+      if (uhtr) {   // :1072-1079 for the box (-1..ni-1, -1..nj-1): see k_corad_acc
+        uhtr[c] = uhtr[c] + suh[l] * dt_tr;
+        vhtr[c] = vhtr[c] + svh[l] * dt_tr;
+      }
+      const double q00 = sq[l];
+      if (do_u) {   // :646-650, :723-731 (SADOURNY75_ENERGY)
+        const double q0m = sq[l - CF_LDW];
+        const double ca = 0.25 * ((q00 * (svh[l + 1] + svh[l])) + (q0m * (svh[l - CF_LDW] + svh[l + 1 - CF_LDW]))) * IdxCu;
+        const double cau = ca - (sk[l + 1] - sk[l]) * IdxCu;
+        CAu[c] = cau;
+        if (u_bc) u_bc[c] = (cau + PFu[c]) + diffu[c];
+      }
+      if (do_v) {   // :757-761, :847-855
+        const double qm0 = sq[l - 1];
+        const double ca = -0.25 * ((qm0 * (suh[l - 1] + suh[l - 1 + CF_LDW])) + (q00 * (suh[l] + suh[l + CF_LDW]))) * IdyCv;
+        const double cav = ca - (sk[l + CF_LDW] - sk[l]) * IdyCv;
+        CAv[c] = cav;
+        if (v_bc) v_bc[c] = (cav + PFv[c]) + diffv[c];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // PressureForce_FV_Bouss, pass 1: interface heights bottom-up (:1200-1202) on (-1..ni, -1..nj).
 __global__ void __launch_bounds__(256)
@@ -786,7 +933,11 @@ int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h
     static const bool lean_off = [] { const char *e = getenv("MOM6X_CORAD_LEAN"); return e && !strcmp(e, "0"); }();
     // the default configuration has its own instantiation: 104 registers and no scratch instead of 128 + 2 spilled
     const bool lean = !lean_off && (scheme == MOM6X_SADOURNY75_ENERGY) && !c->cor.bound_Coriolis && !c->cor.Coriolis_En_Dis;
-    if (lean)
+    static const bool lds_in = [] { const char *e = getenv("MOM6X_CORAD_INPUTS"); return !(e && !strcmp(e, "global")); }();
+    if (lean && lds_in)   // MOM6X_CORAD_INPUTS=global: k_corad_fused<true>, whose threads read their neighbours' inputs from global memory
+      KLAUNCH(c, "k_corad_lds", k_corad_lds, gt, bt, d, c->G, u, v, uh, vh, CAu, CAv, h, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr,
+              c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc, gx, gy, gz, xcd_order);
+    else if (lean)
       KLAUNCH(c, "k_corad_fused", k_corad_fused<true>, gt, bt, d, c->G, u, v, uh, vh, CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h,
               c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr, c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc, gx, gy, gz,
               xcd_order);

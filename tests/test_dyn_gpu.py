@@ -26,7 +26,8 @@ def visc_coefs(d, M, seed=3):
 
 
 @pytest.mark.parametrize("cfg", ["double_gyre", "channel", "benchmark_small"])
-@pytest.mark.parametrize("mods", [dict(), dict(bound_Coriolis=1), dict(Coriolis_Scheme=abi.ARAKAWA_HSU90, KE_Scheme=abi.KE_GUDONOV),
+@pytest.mark.parametrize("mods", [dict(), dict(KE_Scheme=abi.KE_GUDONOV), dict(KE_Scheme=abi.KE_SIMPLE_GUDONOV, no_slip=1),   # (k_corad_lds)
+                                  dict(bound_Coriolis=1), dict(Coriolis_Scheme=abi.ARAKAWA_HSU90, KE_Scheme=abi.KE_GUDONOV),
                                   dict(Coriolis_Scheme=abi.SADOURNY75_ENSTRO, KE_Scheme=abi.KE_SIMPLE_GUDONOV, no_slip=1, bound_Coriolis=1),
                                   dict(Coriolis_En_Dis=1), dict(Coriolis_En_Dis=1, bound_Coriolis=1, KE_Scheme=abi.KE_GUDONOV),
                                   dict(Coriolis_En_Dis=1, Coriolis_Scheme=abi.ARAKAWA_HSU90),
@@ -76,6 +77,23 @@ def test_CorAdCalc(orc, cfg, mods):
     H.assert_bitwise(gv.cpu().numpy(), CAv, "CAv", H.interior(d, "v"))
     assert np.abs(CAu).max() > 0
     dyc.close()
+
+
+def test_CorAdCalc_other_kernels_are_bit_identical_too():
+    """The default configuration runs k_corad_lds (inputs, q and KE through LDS).  k_corad_fused<LEAN> (MOM6X_CORAD_INPUTS=global: q and
+    KE through LDS, neighbours' inputs from global memory), its generic instantiation (MOM6X_CORAD_LEAN=0), the plain tile order
+    and the two-kernel form through HBM (MOM6X_CORAD=legacy) are held to the same oracle: the cases above again in a process
+    with the switch set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env in (dict(MOM6X_CORAD_INPUTS="global"), dict(MOM6X_CORAD_INPUTS="global", MOM6X_CORAD_LEAN="0"),
+                dict(MOM6X_CORAD_ORDER="plain"), dict(MOM6X_CORAD="legacy")):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_dyn_gpu.py"), "-m", "gpu", "-q", "-x",
+                            "-k", "test_CorAdCalc and not other_kernels"], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=900, cwd=root)
+        assert r.returncode == 0 and " passed" in r.stdout, str(env) + r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("cfg", ["double_gyre", "channel", "benchmark_small"])
