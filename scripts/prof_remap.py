@@ -54,3 +54,4 @@ for name, CS in (("PPM_H4 (OM4: sub-cells om4, no boundary extrapolation)", abi.
     a, b = (Tc * h_new).sum(0)[sl], (T * h).sum(0)[sl]
     cons = (a - b)[wet].abs().max().item() / b[wet].abs().max().item()
     print("   column-integral change (relative):", cons)
+    print("   checksums T S u v:", " ".join("%016X" % (dyc.field_chksum(a) % 2 ** 64) for a in (Tc, Sc, uc, vc)))
