@@ -163,13 +163,16 @@ __device__ __forceinline__ void ppm_limit(double u_l, double u_c, double u_r, do
 // slopes, monotonized slopes, coefficients).  Every stage only looks one or two cells away, so here ONE sweep carries a
 // register window of the cells and of the intermediate values and finishes cell k-1 when cell k has been bounded: the
 // column arrays are read once and the results written once, all with the same k in every lane (coalesced).
+// IL: the two edge values of a cell next to each other in ONE array (E1[2 n], E1[2 n + 1]; E2 unused) -- what k_remap_merge reads:
+// one 16-byte store and load per lane instead of two 8-byte ones.
+template <bool IL = false>
 __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict__ h, const double *__restrict__ u, View vs,
                                    double *E1, double *E2, double *C2, double *Ucopy, View vw) {
   const int N = A.n0;
 #define H(k) AT(h, vs, k)
 #define U(k) AT(u, vs, k)
-#define e1(k) AT(E1, vw, k)
-#define e2(k) AT(E2, vw, k)
+#define e1(k) E1[(IL ? 2 : 1) * (vw.base + (size_t)((k) - 1) * vw.lev)]
+#define e2(k) (IL ? E1 + 1 : E2)[(IL ? 2 : 1) * (vw.base + (size_t)((k) - 1) * vw.lev)]
 #define c2(k) AT(C2, vw, k)
   if (A.scheme == MOM6X_REMAP_PCM) {                                          // PCM_functions.F90:16-35
     for (int k = 1; k <= N; k++) { const double v = U(k); e1(k) = v; e2(k) = v; if (Ucopy) AT(Ucopy, vw, k) = v; }
@@ -631,6 +634,7 @@ __device__ void apply_column(const ApplyArgs &A0, const double *__restrict__ h0,
 struct Fields { double *p[8]; };
 
 // the 3-D form: columns (i0..i1, j0..j1) with mask > 0; h_old / h_new / fields on the same staggering
+template <bool IL>
 __global__ void __launch_bounds__(256, RECON_WAVES)
 k_remap_recon(Dm d, const double *__restrict__ mask, ReconArgs A, const double *__restrict__ h_old, const double *__restrict__ f,
               double *E1, double *E2, double *C2, double *Ucopy, int i0, int i1, int j0, int j1) {
@@ -640,7 +644,7 @@ k_remap_recon(Dm d, const double *__restrict__ mask, ReconArgs A, const double *
   const size_t x = ix2(d, i, j);
   if (mask && !(mask[x] > 0.)) return;
   View v; v.base = x; v.lev = (size_t)d.slab;
-  reconstruct_column(A, h_old, f, v, E1, E2, C2, Ucopy, v);
+  reconstruct_column<IL>(A, h_old, f, v, E1, E2, C2, Ucopy, v);
 }
 template <int CFG>
 __global__ void __launch_bounds__(256)
@@ -677,7 +681,7 @@ k_remap_apply(Dm d, const double *__restrict__ mask, ApplyArgs A, const double *
 // (3) the column's last sub-cell (u = E2(n0), :926-929) is the closing of source cell n0 when the targets are exhausted, or
 // else the closing of target n1.
 constexpr int MG_NT = 3, MG_W = 16, MG_LEAD = 8;
-template <int NF> struct MergeFields { const double *E1[NF], *E2[NF], *Uc[NF]; double *out[NF]; };
+template <int NF> struct MergeFields { const double2 *E12[NF]; const double *Uc[NF]; double *out[NF]; };   // E12: (E1, E2) of a cell side by side
 struct SubW { double p, q; int mode; };   // 0 / 1: xb > xa, left / right form; 2 / 3: a point, left / right; 4: u0(i0); 5: E2(n0)
 
 // xa, xb of the next sub-cell (:900-912) and the weights of average_value_ppoly's PPM branches :1420-1437, :1470-1480
@@ -775,7 +779,7 @@ k_remap_merge(Dm d, const double *__restrict__ mask, const double *__restrict__ 
   }
   double n_h0 = LEV(h0p, 1), n_aL[NF], n_aR[NF], n_uc[NF];
 #pragma unroll
-  for (int f = 0; f < NF; f++) { n_aL[f] = LEV(F.E1[f], 1); n_aR[f] = LEV(F.E2[f], 1); n_uc[f] = LEV(F.Uc[f], 1); }
+  for (int f = 0; f < NF; f++) { const double2 e = LEV(F.E12[f], 1); n_aL[f] = e.x; n_aR[f] = e.y; n_uc[f] = LEV(F.Uc[f], 1); }
   double h1full = h1s;
   int it = 1;
   bool tgt = true;
@@ -813,7 +817,7 @@ k_remap_merge(Dm d, const double *__restrict__ mask, const double *__restrict__ 
     if (k + 1 <= n) {
       n_h0 = LEV(h0p, k + 1);
 #pragma unroll
-      for (int f = 0; f < NF; f++) { n_aL[f] = LEV(F.E1[f], k + 1); n_aR[f] = LEV(F.E2[f], k + 1); n_uc[f] = LEV(F.Uc[f], k + 1); }
+      for (int f = 0; f < NF; f++) { const double2 e = LEV(F.E12[f], k + 1); n_aL[f] = e.x; n_aR[f] = e.y; n_uc[f] = LEV(F.Uc[f], k + 1); }
     }
     if (k + MG_LEAD + 1 <= n) h1_pf = LEV(h1p, k + MG_LEAD + 1);
     // ---- the cell's sub-cells (intersect_src_tgt_grids' loop :700-795): the target cells that end inside it, then its own
@@ -1521,22 +1525,24 @@ int remap_fields(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int
     for (int m = 0; m < nf; m++) if ((rc = remap_fields(c, p, mask_id, i0, i1, j0, j1, h_old, h_new, f + m, 1))) return rc;
     return MOM6X_OK;
   }
-  static const Scr work[2][4] = {{SCR_t0, SCR_t1, SCR_t3, SCR_t2}, {SCR_KE, SCR_q, SCR_absv, SCR_t2}};   // E1, E2, Ucopy, C2 (PLM only)
+  static const Scr work[2][4] = {{SCR_t0, SCR_t1, SCR_t3, SCR_t2}, {SCR_KE, SCR_q, SCR_absv, SCR_t2}};   // E1 (| E1 and E2 side by side), E2, Ucopy, C2 (PLM only)
   double *W[2][4];
   for (int m = 0; m < nf; m++)
-    for (int a = 0; a < 4; a++) if ((rc = ctx_scratch(c, work[m][a], d.nk, &W[m][a]))) return rc;
+    for (int a = 0; a < 4; a++) if ((rc = ctx_scratch(c, work[m][a], (shared && a == 0) ? 2 * d.nk : d.nk, &W[m][a]))) return rc;
   const dim3 b(64, 4, 1);
   const dim3 g = grid3(nxa(i1 - i0 + 1, i0), j1 - j0 + 1, 1, b);
   const double *mask = c->G + (size_t)mask_id * d.slab;
-  for (int m = 0; m < nf; m++)
-    KLAUNCH(c, "k_remap_recon", k_remap_recon, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1);
+  for (int m = 0; m < nf; m++) {
+    if (shared) KLAUNCH(c, "k_remap_recon", k_remap_recon<true>, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1);
+    else KLAUNCH(c, "k_remap_recon", k_remap_recon<false>, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1);
+  }
   if (shared && nf == 2) {
     MergeFields<2> F;
-    for (int m = 0; m < 2; m++) { F.E1[m] = W[m][0]; F.E2[m] = W[m][1]; F.Uc[m] = W[m][2]; F.out[m] = f[m]; }
+    for (int m = 0; m < 2; m++) { F.E12[m] = (const double2 *)W[m][0]; F.Uc[m] = W[m][2]; F.out[m] = f[m]; }
     KLAUNCH(c, "k_remap_merge<2>", k_remap_merge<2>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1);
   } else if (shared) {
     MergeFields<1> F;
-    F.E1[0] = W[0][0]; F.E2[0] = W[0][1]; F.Uc[0] = W[0][2]; F.out[0] = f[0];
+    F.E12[0] = (const double2 *)W[0][0]; F.Uc[0] = W[0][2]; F.out[0] = f[0];
     KLAUNCH(c, "k_remap_merge<1>", k_remap_merge<1>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1);
   } else if (om4_set)
     KLAUNCH(c, "k_remap_apply", k_remap_apply<1>, g, b, d, mask, A, h_old, h_new, (const double *)W[0][0], (const double *)W[0][1],
@@ -1621,7 +1627,7 @@ extern "C" int mom6x_ALE_PPM_edge_values(mom6x_ctx *c, const double *h, const do
   R.scheme = MOM6X_REMAP_PPM_IH4; R.boundary_extrapolation = bdry_extrap; R.h_neglect = c->GV.H_subroundoff;
   R.h_neglect_edge = c->GV.H_subroundoff; R.n0 = d.nk;
   const dim3 b(64, 4, 1);
-  KLAUNCH(c, "k_remap_recon", k_remap_recon, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, (const double *)nullptr, R, h, Q, Q_t, Q_b,
+  KLAUNCH(c, "k_remap_recon", k_remap_recon<false>, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, (const double *)nullptr, R, h, Q, Q_t, Q_b,
           C2, (double *)nullptr, -1, d.ni, -1, d.nj);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
