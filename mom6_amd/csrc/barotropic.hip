@@ -53,6 +53,10 @@ struct BTState {
   bool la_defer, la_pending;
   const double *la_pbce;
   double la_underflow;
+  // btcalc deferred to btstep's column pass (inside the RK2 step): frhatu / frhatv = hf * (mask / sum(hf)) are formed there from
+  // the face thicknesses and never written; fr_pending: frhatu / frhatv are NOT current, fr_hu / fr_hv are their source
+  bool fr_defer, fr_pending;
+  const double *fr_hu, *fr_hv;
 };
 
 namespace {
@@ -226,12 +230,17 @@ __global__ void k_set_dtbt(Dm d, const double *__restrict__ G, const double *__r
 // ---- the single 3-D -> 2-D pass of btstep :1011-1330, :1473-1509 -----------------------------
 struct ColArgs {
   const double *visc_rem, *frhat, *U_Cor, *pbce, *uh0, *u_uh0, *U_in, *bc_accel, *tau, *tau_bot, *IDat;
+  const double *hf; double h_neglect;   // HF: frhat is not stored -- btcalc's expressions on the face thicknesses hf instead
   double *ubt_Cor, *gtot_m /*E|N at cell c*/, *gtot_p /*W|S at cell c+st*/, *uh0sum, *ubt0, *ubt, *BT_force, *bt_rem;
   double Instep, RZ_to_H, vel_underflow;
   int nstep, wt_uv_bug, visc_rem_u_uh0, strong_drag;
 };
 
-template <int DIR>
+// HF: btcalc (:4360, BT_THICK_SCHEME = FROM_BT_CONT) folded in -- a first sweep sums the face thicknesses of the column, and
+// frhat(k) = hf(k) * (mask / (sum(hf) + h_neglect)) is formed where it is used (the same two operations on the same operands) and
+// never goes to memory: btcalc's two launches per btstep are gone, and the sweeps' re-reads of hf come from the cache hierarchy as
+// those of visc_rem do.  (The column in registers, as k_btcalc_cols has it, spills here: 75 more doubles next to 7 input streams.)
+template <int DIR, bool HF>
 __global__ void __launch_bounds__(256)
 k_bt_col(Dm d, const double *__restrict__ G, ColArgs A) {
   const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,6 +251,13 @@ k_bt_col(Dm d, const double *__restrict__ G, ColArgs A) {
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   const double subroundoff = 1e-30;
   const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[c];
+  double Ihattot = 0.0;
+  if (HF) {
+    double hattot = 0.0;
+    for (int k = 0; k < nz; k++) hattot = hattot + A.hf[c + (size_t)k * slab];
+    Ihattot = mC / (hattot + A.h_neglect);
+  }
+#define FRH(k) (HF ? A.hf[c + (size_t)(k) * slab] * Ihattot : A.frhat[c + (size_t)(k) * slab])
   double Iwt_tot = 1.0;
   if (!A.wt_uv_bug) {   // :1032-1059
     double tot = 0.0;
@@ -249,7 +265,7 @@ k_bt_col(Dm d, const double *__restrict__ G, ColArgs A) {
       double vr = dmin(A.visc_rem[c + k * slab], 1.);
       vr = dmax(vr, 1. - 0.5 * A.Instep / (vr + subroundoff));
       vr = dmax(vr, 0.);
-      const double w = A.frhat[c + k * slab] * vr;
+      const double w = FRH(k) * vr;
       tot = (k == 0) ? w : (tot + w);
     }
     Iwt_tot = tot;
@@ -264,7 +280,7 @@ k_bt_col(Dm d, const double *__restrict__ G, ColArgs A) {
   }
   for (int k = 0; k < nz; k++) {
     const size_t f = c + k * slab;
-    const double vrem = A.visc_rem[f], frh = A.frhat[f];
+    const double vrem = A.visc_rem[f], frh = FRH(k);
     double vr = dmin(vrem, 1.);
     vr = dmax(vr, 1. - 0.5 * A.Instep / (vr + subroundoff));
     vr = dmax(vr, 0.);
@@ -281,6 +297,7 @@ k_bt_col(Dm d, const double *__restrict__ G, ColArgs A) {
     BT_force = BT_force + wt * A.bc_accel[f];
     av_rem = av_rem + frh * vrem;
   }
+#undef FRH
   A.ubt_Cor[c] = ubt_Cor;
   A.gtot_m[c] = gm_;
   A.gtot_p[c + st] = gp_;
@@ -686,6 +703,25 @@ inline dim3 blk2() { return dim3(64, 4, 1); }
 
 void bt_defer_layer_accel(mom6x_ctx *c, bool on) { if (c->bts) c->bts->la_defer = on; }
 
+// btcalc inside the RK2 step: with `on`, mom6x_btcalc(h_u, h_v) at nk = 75 only notes its operands; btstep's column pass forms the
+// thickness fractions from them (k_bt_col<., true>), and whoever else wants frhatu / frhatv (set_dtbt, mom6x_barotropic_field)
+// gets them through bt_frhat_materialize.  MOM6X_BTCALC=eager: btcalc always writes them.
+void bt_defer_btcalc(mom6x_ctx *c, bool on) {
+  static const bool eager = [] { const char *e = getenv("MOM6X_BTCALC"); return e && !strcmp(e, "eager"); }();
+  if (c->bts) c->bts->fr_defer = on && !eager;
+}
+int bt_frhat_materialize(mom6x_ctx *c) {
+  BTState *s = c->bts;
+  if (!s || !s->fr_pending) return MOM6X_OK;
+  const Dm d = c->d;
+  const dim3 b = blk2();
+  KLAUNCH(c, "k_btcalc<0>", (k_btcalc_cols<0, 75>), grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, s->fr_hu, s->frhatu, c->GV.H_subroundoff);
+  KLAUNCH(c, "k_btcalc<1>", (k_btcalc_cols<1, 75>), grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, s->fr_hv, s->frhatv, c->GV.H_subroundoff);
+  s->fr_pending = false;
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
 bool bt_layer_accel_src(mom6x_ctx *c, LayerAccelSrc *u, LayerAccelSrc *v) {
   BTState *s = c->bts;
   if (!s || !s->la_pending) return false;
@@ -773,6 +809,7 @@ extern "C" int mom6x_barotropic_init(mom6x_ctx *c, const mom6x_barotropic_params
 extern "C" double *mom6x_barotropic_field(mom6x_ctx *c, int which) {
   if (!c || !c->bts) return nullptr;
   BTState *s = c->bts;
+  if ((which == 3 || which == 4) && bt_frhat_materialize(c)) return nullptr;
   switch (which) {
     case 0: return s->ubtav; case 1: return s->vbtav; case 2: return s->eta_cor; case 3: return s->frhatu;
     case 4: return s->frhatv; case 5: return s->IDatu; case 6: return s->IDatv; case 7: return s->q_D;
@@ -797,6 +834,8 @@ extern "C" int mom6x_btcalc(mom6x_ctx *c, const double *h, const double *h_u, co
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   const dim3 b = blk2();
+  c->bts->fr_pending = false;
+  if (h_u && d.nk == 75 && c->bts->fr_defer) { c->bts->fr_pending = true; c->bts->fr_hu = h_u; c->bts->fr_hv = h_v; return MOM6X_OK; }
   if (h_u && d.nk == 75) {   // the layer count the register-resident column kernel is built for
     KLAUNCH(c, "k_btcalc<0>", (k_btcalc_cols<0, 75>), grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, h_u, c->bts->frhatu, c->GV.H_subroundoff);
     KLAUNCH(c, "k_btcalc<1>", (k_btcalc_cols<1, 75>), grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, h_v, c->bts->frhatv, c->GV.H_subroundoff);
@@ -837,6 +876,7 @@ static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int 
   const Dm d = c->d;
   const dim3 b = blk2();
   BTState *s = c->bts;
+  { const int rcm = bt_frhat_materialize(c); if (rcm) return rcm; }
   double *tmp = s->work + (size_t)W_eta_pred * d.slab;   // scratch plane
   HIPCHK(hipMemsetAsync(tmp, 0, sizeof(double) * d.slab, c->stream));
   KLAUNCH(c, "k_set_dtbt", k_set_dtbt, grid3(d.ni, d.nj, 1, b), b, d, c->G, pbce, s->frhatu, s->frhatv, gtot_est,
@@ -918,8 +958,15 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   Av.ubt_Cor = work + W_vbt_Cor * slab; Av.gtot_m = work + W_gtot_N * slab; Av.gtot_p = work + W_gtot_S * slab;
   Av.uh0sum = work + W_vh0sum * slab; Av.ubt0 = work + W_vbt0 * slab; Av.ubt = work + W_vbt * slab;
   Av.BT_force = work + W_BT_force_v * slab; Av.bt_rem = work + W_bt_rem_v * slab;
-  KLAUNCH(c, "k_bt_col<0>", k_bt_col<0>, grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, Au);
-  KLAUNCH(c, "k_bt_col<1>", k_bt_col<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, Av);
+  if (s->fr_pending && d.nk == 75) {   // btcalc's thickness fractions formed in the column pass (bt_defer_btcalc)
+    Au.hf = s->fr_hu; Av.hf = s->fr_hv; Au.h_neglect = Av.h_neglect = c->GV.H_subroundoff;
+    KLAUNCH(c, "k_bt_col<0>", (k_bt_col<0, true>), grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, Au);
+    KLAUNCH(c, "k_bt_col<1>", (k_bt_col<1, true>), grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, Av);
+  } else {
+    { const int rcm = bt_frhat_materialize(c); if (rcm) return rcm; }
+    KLAUNCH(c, "k_bt_col<0>", (k_bt_col<0, false>), grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, Au);
+    KLAUNCH(c, "k_bt_col<1>", (k_bt_col<1, false>), grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, Av);
+  }
 
   // ---- BT_cont fits (set_local_BT_cont_types, halo = 1+ievf-ie)
   double *tmp = work + W_BTtmp * slab;

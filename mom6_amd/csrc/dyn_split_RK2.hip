@@ -356,6 +356,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     if (rc_c) return rc_c;
   }
   halo_complete(c);
+  bt_defer_btcalc(c, true);            // (the step's own btstep follows: its column pass forms the thickness fractions)
   CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :649-652
   if (calc_dtbt) CHK(mom6x_set_dtbt_pbce(c, s->pbce, nullptr));         // :659-668
   // predictor btstep :673-676.  accel_layer_u / _v are only read by the velocity estimates below: with the device's own
@@ -421,6 +422,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2, -1), d.nj + 2, nk, b), b, d, hp, (const double *)h, (const double *)nullptr, 3, R.begw, 1, 0);
     CHK(mom6x_PressureForce(c, hp, s->PFu, s->PFv, s->pbce, s->eta_PF));
   }
+  bt_defer_btcalc(c, true);
   CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :864-867
   if (hooks && hooks->horizontal_viscosity) {                           // :884-888
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -476,6 +478,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   CHK(CorAdCalc_bc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, uhtr, vhtr, dt));
   s->CAu_pred_stored = true;
   bt_defer_layer_accel(c, false);   // (a btstep called from outside the step writes its accel_layer arrays; the pending result stays)
+  bt_defer_btcalc(c, false);        // (and a btcalc called from outside writes frhatu / frhatv)
   HIPCHK(hipGetLastError());
   REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
   return MOM6X_OK;

@@ -158,6 +158,8 @@ struct LayerAccelSrc {
   const double *a2d;       // u_accel_bt | v_accel_bt (2-D)
   double underflow;        // accel_underflow = vel_underflow / dt
 };
+void bt_defer_btcalc(mom6x_ctx *c, bool on);                            // barotropic.hip: btcalc's fractions formed by btstep's column pass while on
+int bt_frhat_materialize(mom6x_ctx *c);                                 // writes frhatu / frhatv if a deferred btcalc is pending
 void bt_defer_layer_accel(mom6x_ctx *c, bool on);                       // barotropic.hip: btstep skips k_layer_accel while on
 bool bt_layer_accel_src(mom6x_ctx *c, LayerAccelSrc *u, LayerAccelSrc *v);   // false if no deferred result is pending
 int bt_layer_accel_materialize(mom6x_ctx *c, double *accel_layer_u, double *accel_layer_v);

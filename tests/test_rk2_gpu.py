@@ -237,6 +237,20 @@ def test_rk2_75_layers_on_chip_columns(orc, ni, nj):
     run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(visc_rem_dt_bug=0), per_stage=True)
 
 
+def test_rk2_75_layers_with_btcalc_written_out():
+    """Inside the step at nk = 75 btcalc only notes its operands and btstep's column pass forms frhatu / frhatv from the face
+    thicknesses (k_bt_col<., true>).  MOM6X_BTCALC=eager keeps btcalc's own kernels and the stored fractions: the 75-layer cases
+    again in a process with the switch set, against the same oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_rk2_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "75_layers_on_chip"], env=dict(os.environ, MOM6X_BTCALC="eager"), capture_output=True, text=True, timeout=900,
+                       cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_rk2_tc4_like_switches(orc):
     """The switches of .testing/tc4 that touch this path: CORIOLIS_EN_DIS, DIRECT_STRESS (HMIX_FIXED = 20 m), BE = 0.7,
     EQN_OF_STATE = LINEAR with MASS_WEIGHT_IN_PRESSURE_GRADIENT, SMAGORINSKY_AH with SMAG_BI_CONST = 0.03, BEBT = 0.2,
