@@ -713,6 +713,7 @@ void bt_defer_btcalc(mom6x_ctx *c, bool on) {
 int bt_frhat_materialize(mom6x_ctx *c) {
   BTState *s = c->bts;
   if (!s || !s->fr_pending) return MOM6X_OK;
+  HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   const dim3 b = blk2();
   KLAUNCH(c, "k_btcalc<0>", (k_btcalc_cols<0, 75>), grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, s->fr_hu, s->frhatu, c->GV.H_subroundoff);
