@@ -186,6 +186,15 @@ __global__ void k_bt_mass_source(Dm d, const double *__restrict__ G, const doubl
   eta_cor[c] = set_cor ? d_eta : (eta_cor[c] + d_eta);
 }
 
+// ... with eta_h formed by the kernel that last walked the same h top-down (k_pgf_main inside the RK2 step)
+__global__ void k_bt_mass_source_from(Dm d, const double *__restrict__ eta_h, const double *__restrict__ eta, double *eta_cor, int set_cor) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const size_t c = ix2(d, i, j);
+  const double d_eta = eta_h[c] - eta[c];
+  eta_cor[c] = set_cor ? d_eta : (eta_cor[c] + d_eta);
+}
+
 // ---- set_dtbt :3509-3633 (find_face_areas add_max branch :5208-5219) -------------------------
 __global__ void k_set_dtbt(Dm d, const double *__restrict__ G, const double *__restrict__ pbce,
                            const double *__restrict__ frhatu, const double *__restrict__ frhatv,
@@ -858,6 +867,15 @@ extern "C" int mom6x_bt_mass_source(mom6x_ctx *c, const double *h, const double 
   const dim3 b = blk2();
   KLAUNCH(c, "k_bt_mass_source", k_bt_mass_source, grid3(d.ni, d.nj, 1, b), b, d, c->G, h, eta, c->bts->eta_cor, set_cor,
                      c->GV.Z_to_H);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+int bt_mass_source_from(mom6x_ctx *c, const double *eta_h, const double *eta, int set_cor) {
+  REQUIRE(c && c->bt_init, MOM6X_EINVAL, "bt_mass_source: Module MOM_barotropic must be initialized before it is used.");
+  const Dm d = c->d;
+  const dim3 b = blk2();
+  KLAUNCH(c, "k_bt_mass_source_from", k_bt_mass_source_from, grid3(d.ni, d.nj, 1, b), b, d, eta_h, eta, c->bts->eta_cor, set_cor);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }

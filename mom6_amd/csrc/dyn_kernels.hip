@@ -654,10 +654,14 @@ k_pgf_main(Dm d, const double *__restrict__ G, const double *__restrict__ h, con
   if (do_u) { pa1 = GxRho_ref * (e[x + 1] - Z_ref); intx_pa = 0.5 * (pa0 + pa1); cu = (2.0 * I_Rho0 * gm(G, d, MOM6X_G_IdxCu)[x]); }
   if (do_v) { pa2 = GxRho_ref * (e[x + st] - Z_ref); inty_pa = 0.5 * (pa0 + pa2); cv = (2.0 * I_Rho0 * gm(G, d, MOM6X_G_IdyCv)[x]); }
   double pb = 0.0;
+  // bt_mass_source's eta_h (MOM_barotropic.F90:5268-5272: h summed from the top, less the depth) of the same h, while it passes
+  const bool do_eh = (B.eta_h != nullptr) && i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1;
+  double eta_h = 0.0;
   for (int k = 0; k < nz; k++) {
     const size_t c = x + (size_t)k * slab, cb = c + slab;
     const double R = Rlay[k] - rho_ref;
     const double h0 = h[c];
+    if (do_eh) eta_h = (k == 0) ? (h0 - gm(G, d, MOM6X_G_bathyT)[x] * Z_to_H) : (eta_h + h0);
     const double dz0 = g_Earth * H_to_Z * h0;
     const double dpa0 = R * dz0, iz0 = 0.5 * R * dz0 * h0;
     const double eb0 = e[cb];
@@ -692,6 +696,7 @@ k_pgf_main(Dm d, const double *__restrict__ G, const double *__restrict__ h, con
       pbce[c] = pb;
     }
   }
+  if (do_eh) B.eta_h[x] = eta_h;
 }
 
 // DIRECT_STRESS (:707-720 / :958-971): the wind stress as a body force over the topmost HMIX_STRESS instead of a stress
@@ -1449,6 +1454,7 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
   REQUIRE(c && c->pgf_init, MOM6X_EINVAL, "MOM_PressureForce_FV_Bouss: Module must be initialized before it is used.");
   REQUIRE(h && PFu && PFv, MOM6X_EINVAL, "PressureForce: null array");
   HIPCHK(hipSetDevice(c->device));
+  c->pgf_eta_h_written = false;
   const Dm d = c->d;
   double *e;
   int rc;
@@ -1514,6 +1520,7 @@ extern "C" int mom6x_PressureForce(mom6x_ctx *c, const double *h, double *PFu, d
   KLAUNCH(c, "k_pgf_main", k_pgf_main, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, c->G, h, e, c->Rlay, c->g_prime, PFu, PFv,
           pbce, eta, GV.g_Earth, GV.H_to_Z, GV.Z_to_H, c->pgf.rho_ref, GxRho_ref, c->pgf.Z_ref, 1.0 / GV.Rho0,
           GV.H_subroundoff, GV.dZ_subroundoff, c->pgf_fold);
+  c->pgf_eta_h_written = (c->pgf_fold.eta_h != nullptr);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }

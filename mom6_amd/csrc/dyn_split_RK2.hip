@@ -20,7 +20,7 @@ struct RK2State {
   bool CAu_pred_stored;
   bool accel_bt_deferred;   // u_accel_bt, v_accel_bt have not been written: the corrector's btstep results wait in the work block
   // the routine's stack temporaries :341-357
-  double *up, *vp, *hp, *u_bc_accel, *v_bc_accel, *uh_in, *vh_in, *eta_pred;
+  double *up, *vp, *hp, *u_bc_accel, *v_bc_accel, *uh_in, *vh_in, *eta_pred, *eta_h;
 };
 
 namespace {
@@ -183,7 +183,7 @@ void rk2_state_free(mom6x_ctx *c) {
   double *p3[] = { s->CAu, s->CAv, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv, s->diffu, s->diffv, s->visc_rem_u, s->visc_rem_v,
                    s->u_accel_bt, s->v_accel_bt, s->u_av, s->v_av, s->h_av, s->pbce, s->up, s->vp, s->hp, s->u_bc_accel,
                    s->v_bc_accel, s->uh_in, s->vh_in, s->BT.h_u, s->BT.h_v, s->eta, s->eta_PF, s->uhbt, s->vhbt, s->taux_bot,
-                   s->tauy_bot, s->eta_pred, s->BT.FA_u_EE, s->BT.FA_u_E0, s->BT.FA_u_W0, s->BT.FA_u_WW, s->BT.uBT_WW,
+                   s->tauy_bot, s->eta_pred, s->eta_h, s->BT.FA_u_EE, s->BT.FA_u_E0, s->BT.FA_u_W0, s->BT.FA_u_WW, s->BT.uBT_WW,
                    s->BT.uBT_EE, s->BT.FA_v_NN, s->BT.FA_v_N0, s->BT.FA_v_S0, s->BT.FA_v_SS, s->BT.vBT_SS, s->BT.vBT_NN };
   for (double *p : p3) (void)hipFree(p);
   delete s;
@@ -207,7 +207,7 @@ extern "C" int mom6x_initialize_dyn_split_RK2(mom6x_ctx *c, const mom6x_rk2_para
                     &s->visc_rem_v, &s->u_accel_bt, &s->v_accel_bt, &s->u_av, &s->v_av, &s->h_av, &s->pbce, &s->up, &s->vp,
                     &s->hp, &s->u_bc_accel, &s->v_bc_accel, &s->uh_in, &s->vh_in, &s->BT.h_u, &s->BT.h_v };
   for (double **q : p3) { HIPCHK(hipMalloc(q, n3 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, 0, n3 * sizeof(double), c->stream)); }
-  double **p2[] = { &s->eta, &s->eta_PF, &s->uhbt, &s->vhbt, &s->taux_bot, &s->tauy_bot, &s->eta_pred, &s->BT.FA_u_EE,
+  double **p2[] = { &s->eta, &s->eta_PF, &s->uhbt, &s->vhbt, &s->taux_bot, &s->tauy_bot, &s->eta_pred, &s->eta_h, &s->BT.FA_u_EE,
                     &s->BT.FA_u_E0, &s->BT.FA_u_W0, &s->BT.FA_u_WW, &s->BT.uBT_WW, &s->BT.uBT_EE, &s->BT.FA_v_NN, &s->BT.FA_v_N0,
                     &s->BT.FA_v_S0, &s->BT.FA_v_SS, &s->BT.vBT_SS, &s->BT.vBT_NN };
   for (double **q : p2) { HIPCHK(hipMalloc(q, n2 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, 0, n2 * sizeof(double), c->stream)); }
@@ -327,10 +327,16 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   // the pressure-force kernel forms it as it makes PFu (k_bc_accel's 8 words per face-layer -> 4 more in a kernel that runs anyway)
   static const bool bc_own = [] { const char *e = getenv("MOM6X_BC_ACCEL"); return e && !strcmp(e, "own"); }();
   const bool fold_bc = s->CAu_pred_stored && !host_coef && !bc_own;
-  if (fold_bc) c->pgf_fold = BcFold{ s->CAu_pred, s->CAv_pred, s->diffu, s->diffv, u_bc, v_bc };
+  // (and the column sum of h that bt_mass_source :629 is about to form from the same array: one pass over h less)
+  static const bool ms_own = [] { const char *e = getenv("MOM6X_BT_MASS_SOURCE"); return e && !strcmp(e, "own"); }();
+  c->pgf_fold = BcFold{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ms_own ? nullptr : s->eta_h };
+  if (fold_bc) c->pgf_fold = BcFold{ s->CAu_pred, s->CAv_pred, s->diffu, s->diffv, u_bc, v_bc, ms_own ? nullptr : s->eta_h };
+  bool have_eta_h = false;
   {
     const int rc_pf = mom6x_PressureForce(c, h, s->PFu, s->PFv, s->pbce, s->eta_PF);
-    c->pgf_fold = BcFold{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    c->pgf_fold = BcFold{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    have_eta_h = c->pgf_eta_h_written;
+    c->pgf_eta_h_written = false;
     if (rc_pf) return rc_pf;
   }
   if (!s->CAu_pred_stored) CHK(mom6x_CorAdCalc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred));   // :552-557
@@ -345,7 +351,8 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   // the continuity call below run while it travels; continuity completes it before it touches a halo row
   startn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk });
 
-  CHK(mom6x_bt_mass_source(c, h, eta, 1));                              // :629
+  if (have_eta_h) CHK(bt_mass_source_from(c, s->eta_h, eta, 1));        // :629, with the sum k_pgf_main left
+  else CHK(mom6x_bt_mass_source(c, h, eta, 1));
   // continuity(u, v, h, hp, uh_in, vh_in, dt, visc_rem_u, visc_rem_v, BT_cont)  :646
   // (hp of this call is never read: :781 overwrites it -- the last convergence is skipped; uh_in, vh_in and BT_cont are the results)
   c->cont_h_unused = true;

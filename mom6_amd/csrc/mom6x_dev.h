@@ -58,7 +58,7 @@ struct RK2State;  // dyn_split_RK2.hip
 
 // u_bc_accel = (CAu + PFu) + diffu of the RK2 predictor (RK2.F90:565-572) formed by the pressure-force kernel that has just made
 // PFu (all null: PressureForce on its own)
-struct BcFold { const double *CAu, *CAv, *diffu, *diffv; double *u_bc, *v_bc; };
+struct BcFold { const double *CAu, *CAv, *diffu, *diffv; double *u_bc, *v_bc; double *eta_h; };   // eta_h: bt_mass_source's column sum (h summed top-down, less the depth), a by-product
 struct mom6x_ctx {
   mom6x_dims dims;
   Dm d;
@@ -108,7 +108,8 @@ struct mom6x_ctx {
   // whose halo was widened for the barotropic solver (BTHALO) still sends NIHALO rows of the 3-D fields (mom6x_set_dyn_pass_width)
   int pass_w = 0, dyn_pass_width = 0;
   long long n_exchanges = 0;
-  BcFold pgf_fold = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // set by the RK2 step around its PressureForce call
+  BcFold pgf_fold = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  bool pgf_eta_h_written = false;                                     // the last PressureForce call filled pgf_fold.eta_h   // set by the RK2 step around its PressureForce call
   bool cont_stats_on;               // the statistics-collecting (slower) variant of the mass-flux kernel is in use
   unsigned long long *cont_stats;   // device: Newton statistics of the wave-owned mass-flux kernel (mom6x_continuity_stats), or null
   bool cont_h_unused;       // the caller of continuity_PPM does not look at the new thicknesses (RK2.F90:646: hp is overwritten at :781
@@ -158,6 +159,7 @@ struct LayerAccelSrc {
   const double *a2d;       // u_accel_bt | v_accel_bt (2-D)
   double underflow;        // accel_underflow = vel_underflow / dt
 };
+int bt_mass_source_from(mom6x_ctx *c, const double *eta_h, const double *eta, int set_cor);   // bt_mass_source with the column sum given
 void bt_defer_btcalc(mom6x_ctx *c, bool on);                            // barotropic.hip: btcalc's fractions formed by btstep's column pass while on
 int bt_frhat_materialize(mom6x_ctx *c);                                 // writes frhatu / frhatv if a deferred btcalc is pending
 void bt_defer_layer_accel(mom6x_ctx *c, bool on);                       // barotropic.hip: btstep skips k_layer_accel while on
