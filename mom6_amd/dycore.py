@@ -82,10 +82,13 @@ class Dycore:
 
     # -- memory ------------------------------------------------------------------------------
     def zeros2(self):
-        return torch.zeros(self.dims.shape2(), dtype=torch.float64, device=self.device)
+        # (filled on the context's stream: a kernel of the context launched right after it must not overtake the fill)
+        with torch.cuda.stream(self.torch_stream()):
+            return torch.zeros(self.dims.shape2(), dtype=torch.float64, device=self.device)
 
     def zeros3(self, nk=None):
-        return torch.zeros(self.dims.shape3(nk), dtype=torch.float64, device=self.device)
+        with torch.cuda.stream(self.torch_stream()):
+            return torch.zeros(self.dims.shape3(nk), dtype=torch.float64, device=self.device)
 
     def to_dev(self, a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
