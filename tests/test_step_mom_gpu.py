@@ -76,6 +76,7 @@ def test_dynamics_tracers_ALE_cycle(orc, cfg_name, remap_aux, sums):
     dyc.dyn_split_RK2_new_run(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], dt)
     h_new = torch.zeros_like(sg["h"]); dzI = torch.zeros((d.nk + 1,) + d.shape2(), dtype=torch.float64, device=dyc.device)
     hv = [torch.full_like(sg["h"], 1.0e-3) for _ in range(4)]
+    torch.cuda.synchronize()              # (torch's fills run on its own stream)
 
     stats_o, stats_g = SO.SumOutput(use_temperature=True, C_p=3925.0), SO.SumOutput(use_temperature=True, C_p=3925.0)
     stag = dict(u="u", v="v", h="h", T="h", S="h", uh="u", vh="v")
