@@ -180,6 +180,7 @@ int passn(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list
 void rk2_state_free(mom6x_ctx *c) {
   if (!c->rk2) return;
   RK2State *s = c->rk2;
+  (void)bt_frhat_materialize(c);   // (a deferred btcalc points into BT.h_u / BT.h_v, which go away here)
   double *p3[] = { s->CAu, s->CAv, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv, s->diffu, s->diffv, s->visc_rem_u, s->visc_rem_v,
                    s->u_accel_bt, s->v_accel_bt, s->u_av, s->v_av, s->h_av, s->pbce, s->up, s->vp, s->hp, s->u_bc_accel,
                    s->v_bc_accel, s->uh_in, s->vh_in, s->BT.h_u, s->BT.h_v, s->eta, s->eta_PF, s->uhbt, s->vhbt, s->taux_bot,
