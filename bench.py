@@ -340,6 +340,9 @@ def ale_cycle(args, device=0, steps=4, warm=1, check=None, layout=(1, 1), pe=(0,
         for t in tr:
             dyc.tracer_vertdiff(st["h"], ea, eb, steps * a.dt, t)
         dyc.triDiagTS(st["h"], ea, eb, T, S)
+        if check is not None:   # the column sums of the accumulated transports: what the cycle may change a column's thickness by
+            U, V = st["uhtr"].sum(0), st["vhtr"].sum(0)
+            info["_col_transport_div"] = (U - torch.roll(U, 1, 1)) + (V - torch.roll(V, 1, 0))
         st["uhtr"].zero_(); st["vhtr"].zero_()
         # ALE_regridding_and_remapping (MOM.F90:1751): new z* grid, remap everything that lives on the old one
         dyc.ALE_regrid_zstar(RP, cr, st["h"], h_new, dzI)

@@ -25,15 +25,19 @@ module mom6x_c_api
   public :: mom6x_bt_mass_source, mom6x_set_dtbt, mom6x_set_dtbt_pbce, mom6x_btstep
   public :: mom6x_CoriolisAdv_init, mom6x_CorAdCalc, mom6x_PressureForce_init, mom6x_PressureForce
   public :: mom6x_vertvisc_set_coef, mom6x_vertvisc, mom6x_vertvisc_remnant
-  public :: mom6x_initialize_dyn_split_RK2, mom6x_dyn_split_RK2_new_run, mom6x_rk2_field, mom6x_rk2_set_CAu_pred_stored
+  public :: mom6x_initialize_dyn_split_RK2, mom6x_dyn_split_RK2_new_run, mom6x_dyn_split_RK2_restart_fills, mom6x_rk2_field, mom6x_rk2_set_CAu_pred_stored
   public :: mom6x_step_dyn_split_RK2, mom6x_comm_unique_id, mom6x_comm_init, mom6x_pass_fields
   public :: mom6x_transport, mom6x_comm_set_transport
   public :: mom6x_abi_version, mom6x_device_count, MOM6X_ABI_BUILT_FOR, mom6x_barotropic_field
+  public :: MOM6X_RK2_HAVE_ETA, MOM6X_RK2_HAVE_DIFFU, MOM6X_RK2_HAVE_U2, MOM6X_RK2_HAVE_CAU, MOM6X_RK2_HAVE_UH, MOM6X_RK2_HAVE_H2
   public :: mom6x_tracer_advect_init, mom6x_advect_tracer, mom6x_triDiagTS, mom6x_triDiagTS_Eulerian
   public :: mom6x_tracer_vertdiff, mom6x_tracer_vertdiff_Eulerian, mom6x_diabatic_is_trivial
 
   !> include/mom6x.h MOM6X_ABI_VERSION this module mirrors; a host compares it with mom6x_abi_version() at start-up
-  integer(c_int), parameter :: MOM6X_ABI_BUILT_FOR = 3
+  integer(c_int), parameter :: MOM6X_ABI_BUILT_FOR = 4
+  !> mom6x_dyn_split_RK2_restart_fills: the restart variables the host has uploaded (include/mom6x.h MOM6X_RK2_HAVE_*)
+  integer(c_int), parameter :: MOM6X_RK2_HAVE_ETA = 1, MOM6X_RK2_HAVE_DIFFU = 2, MOM6X_RK2_HAVE_U2 = 4, MOM6X_RK2_HAVE_CAU = 8, &
+                               MOM6X_RK2_HAVE_UH = 16, MOM6X_RK2_HAVE_H2 = 32
 
   !> mom6x_dims: hor_index_type extents (MOM_hor_index.F90:14-44) + the device layout
   type, bind(C) :: mom6x_dims
@@ -446,6 +450,10 @@ module mom6x_c_api
     end function
     integer(c_int) function mom6x_dyn_split_RK2_new_run(ctx, u, v, h, uh, vh, dt) bind(C, name="mom6x_dyn_split_RK2_new_run")
       import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, u, v, h, uh, vh ; real(c_double), value :: dt
+    end function
+    !> initialize_dyn_split_RK2 :1577-1668 for a restarted run: have = the MOM6X_RK2_HAVE_* bits of the uploaded restart variables
+    integer(c_int) function mom6x_dyn_split_RK2_restart_fills(ctx, u, v, h, uh, vh, dt, have) bind(C, name="mom6x_dyn_split_RK2_restart_fills")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, u, v, h, uh, vh ; real(c_double), value :: dt ; integer(c_int), value :: have
     end function
     !> a restarted run that read CAu_pred, CAv_pred from the file: the first step must not recompute them (RK2.F90:1616)
     integer(c_int) function mom6x_rk2_set_CAu_pred_stored(ctx, stored) bind(C, name="mom6x_rk2_set_CAu_pred_stored")

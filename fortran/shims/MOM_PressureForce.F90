@@ -59,7 +59,9 @@ subroutine PressureForce(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, ADp, p_atm, pb
   if (associated(tv%T) .and. associated(tv%S)) then   ! the use_EOS branch (FV.F90:1206)
     if (.not.CS%have_eos) call MOM_error(FATAL, "PressureForce: tv%T is associated but no equation of state was read.")
     eos = CS%eos
-    rc = mom6x_PressureForce_set_tv(CS%ctx, shim_up3(6, tv%T, STG_H, nk), shim_up3(7, tv%S, STG_H, nk), c_loc(eos))
+    ! (slots 38 / 39 hold tv%T, tv%S and nothing else -- the RK2 shim's upload_tv uses the same two -- so the pointers the context
+    !  keeps stay valid whichever shim ran last; the low slots are reused as output buffers by the other modules)
+    rc = mom6x_PressureForce_set_tv(CS%ctx, shim_up3(38, tv%T, STG_H, nk), shim_up3(39, tv%S, STG_H, nk), c_loc(eos))
   else
     rc = mom6x_PressureForce_set_tv(CS%ctx, c_null_ptr, c_null_ptr, c_null_ptr)
   endif

@@ -76,7 +76,11 @@ type, public :: MOM_dyn_split_RK2_CS ; private
   !> HOST mirrors of the restart variables (registered by pointer with MOM_restart, :1222-1290)
   real, allocatable, dimension(:,:)   :: eta
   real, allocatable, dimension(:,:,:) :: u_av, v_av, h_av, CAu_pred, CAv_pred, diffu, diffv
+  !> HOST mirrors of the arrays the reference hands to MOM_diagnostics and MOM.F90 by pointer: Accel_diag%PFu, PFv, CAu, CAv,
+  !! u_accel_bt, v_accel_bt (+ diffu, diffv above) and MIS%pbce (:1512-1534); refreshed with the restart mirrors
+  real, allocatable, dimension(:,:,:) :: PFu, PFv, CAu, CAv, u_accel_bt, v_accel_bt, pbce
   logical :: store_CAu = .true., remap_aux = .false., module_is_initialized = .false.
+  logical :: diag_mirrors = .true.           !< MOM6X_ACCEL_DIAG_MIRRORS: keep the arrays behind Accel_diag / MIS current
   type(mom6x_remapping_params) :: vel_remap  !< ALE_CSp%vel_remapCS as the device takes it (remap_dyn_split_RK2_aux_vars)
   type(mom6x_eos_params) :: eos              !< tv%eqn_of_state + the EOS switches of the pressure force
   logical :: have_eos = .false.
@@ -93,6 +97,7 @@ end type MOM_dyn_split_RK2_CS
 
 !> mom6x_rk2_field ids of the restart variables (include/mom6x.h)
 integer(c_int), parameter :: F_CAU_PRED = 2, F_CAV_PRED = 3, F_DIFFU = 6, F_DIFFV = 7, F_U_AV = 12, F_V_AV = 13, F_H_AV = 14, F_ETA = 16
+integer(c_int), parameter :: F_CAU = 0, F_CAV = 1, F_PFU = 4, F_PFV = 5, F_U_ACCEL_BT = 10, F_V_ACCEL_BT = 11, F_PBCE = 15
 
 integer :: id_clock_step = -1, id_clock_xfer = -1
 
@@ -201,6 +206,13 @@ subroutine refresh_host_mirrors(CS, G, GV)
   call shim_down3(CS%diffu, mom6x_rk2_field(CS%ctx, F_DIFFU), STG_U, nk)
   call shim_down3(CS%diffv, mom6x_rk2_field(CS%ctx, F_DIFFV), STG_V, nk)
   call barotropic_refresh_restart_mirrors(CS%barotropic_CSp)   ! ubtav, vbtav, DTBT
+  if (CS%diag_mirrors) then   ! what Accel_diag and MIS point to (mom6x_rk2_field forms the deferred u_accel_bt, v_accel_bt on request)
+    call shim_down3(CS%PFu, mom6x_rk2_field(CS%ctx, F_PFU), STG_U, nk) ; call shim_down3(CS%PFv, mom6x_rk2_field(CS%ctx, F_PFV), STG_V, nk)
+    call shim_down3(CS%CAu, mom6x_rk2_field(CS%ctx, F_CAU), STG_U, nk) ; call shim_down3(CS%CAv, mom6x_rk2_field(CS%ctx, F_CAV), STG_V, nk)
+    call shim_down3(CS%u_accel_bt, mom6x_rk2_field(CS%ctx, F_U_ACCEL_BT), STG_U, nk)
+    call shim_down3(CS%v_accel_bt, mom6x_rk2_field(CS%ctx, F_V_ACCEL_BT), STG_V, nk)
+    call shim_down3(CS%pbce, mom6x_rk2_field(CS%ctx, F_PBCE), STG_H, nk)
+  endif
 end subroutine refresh_host_mirrors
 
 !> register_restarts_dyn_split_RK2 (:1210): the same variables under the same names, backed by the host mirrors
@@ -327,7 +339,7 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   real, allocatable :: zero_u(:,:,:), zero_v(:,:,:)
   integer(c_int) :: rc
   integer :: nk
-  logical :: new_run
+  integer(c_int) :: have
 
   if (.not.associated(CS)) call MOM_error(FATAL, "initialize_dyn_split_RK2 called with an unassociated control structure.")
   if (CS%module_is_initialized) then
@@ -346,6 +358,10 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
                  "and a backward Euler treatment of the baroclinic gravity waves.", units="nondim", default=0.6)
   call get_param(param_file, mdl, "BEGW", rk2%begw, "If SPLIT is true, BEGW is a number from 0 to 1 that controls the extent "//&
                  "to which the treatment of gravity waves is forward-backward (0) or simulated backward Euler (1).", units="nondim", default=0.0)
+  call get_param(param_file, mdl, "MOM6X_ACCEL_DIAG_MIRRORS", CS%diag_mirrors, "If true, the host arrays behind Accel_diag%PFu, "//&
+                 "PFv, CAu, CAv, u_accel_bt, v_accel_bt and MIS%pbce are refreshed from the device whenever the restart mirrors are "//&
+                 "(every step without MOM6X_RESIDENT_STATE; on refresh_host_mirrors with it).  If false they stay associated and zero.", &
+                 default=.true.)
   call get_rk2_flags(param_file, rk2)     ! SPLIT_BOTTOM_STRESS, BT_USE_LAYER_FLUXES, STORE_CORIOLIS_ACCEL, VISC_REM_BUG, REMAP_AUXILIARY_VARS
   CS%remap_aux = (rk2%remap_aux /= 0)
   if (CS%remap_aux) call read_vel_remap_params(param_file, GV, CS%vel_remap)
@@ -365,6 +381,18 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
                        CS%OBC)
   rc = mom6x_initialize_dyn_split_RK2(CS%ctx, rk2) ; call shim_check(rc, "initialize_dyn_split_RK2")
 
+  ! ---- the arrays other modules reach by pointer (:1512-1534): host mirrors of the device's, refreshed by refresh_host_mirrors
+  allocate(CS%PFu(G%IsdB:G%IedB,G%jsd:G%jed,nk), source=0.0) ; allocate(CS%PFv(G%isd:G%ied,G%JsdB:G%JedB,nk), source=0.0)
+  allocate(CS%CAu(G%IsdB:G%IedB,G%jsd:G%jed,nk), source=0.0) ; allocate(CS%CAv(G%isd:G%ied,G%JsdB:G%JedB,nk), source=0.0)
+  allocate(CS%u_accel_bt(G%IsdB:G%IedB,G%jsd:G%jed,nk), source=0.0) ; allocate(CS%v_accel_bt(G%isd:G%ied,G%JsdB:G%JedB,nk), source=0.0)
+  allocate(CS%pbce(G%isd:G%ied,G%jsd:G%jed,nk), source=0.0)
+  MIS%diffu => CS%diffu ; MIS%diffv => CS%diffv ; MIS%PFu => CS%PFu ; MIS%PFv => CS%PFv ; MIS%CAu => CS%CAu ; MIS%CAv => CS%CAv
+  MIS%pbce => CS%pbce ; MIS%u_accel_bt => CS%u_accel_bt ; MIS%v_accel_bt => CS%v_accel_bt ; MIS%u_av => CS%u_av ; MIS%v_av => CS%v_av
+  CS%ADp => Accel_diag
+  Accel_diag%diffu => CS%diffu ; Accel_diag%diffv => CS%diffv ; Accel_diag%PFu => CS%PFu ; Accel_diag%PFv => CS%PFv
+  Accel_diag%CAu => CS%CAu ; Accel_diag%CAv => CS%CAv
+  Accel_diag%u_accel_bt => CS%u_accel_bt ; Accel_diag%v_accel_bt => CS%v_accel_bt
+
   ! ---- the state, and the first-step fills of :1577-1650 or the restart file's values ------------------------------------
   call dyn_state_init(CS%S, CS%ctx, CS%dims)
   allocate(zero_u(G%IsdB:G%IedB,G%jsd:G%jed,nk), source=0.0) ; allocate(zero_v(G%isd:G%ied,G%JsdB:G%JedB,nk), source=0.0)
@@ -372,22 +400,34 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   deallocate(zero_u, zero_v)
   if (associated(tv%T)) call upload_tv(CS, tv, GV)
   call vertvisc_upload_visc(CS%ctx, visc, GV, 30)
-  new_run = .not. query_initialized(CS%eta, "sfc", restart_CS)
-  if (new_run) then
-    rc = mom6x_dyn_split_RK2_new_run(CS%ctx, CS%S%u, CS%S%v, CS%S%h, CS%S%uh, CS%S%vh, real(dt, c_double))
-    call shim_check(rc, "initialize_dyn_split_RK2 (new run)")
-  else   ! a restarted run: the registered mirrors hold the file's values
+  ! :1577-1668, variable by variable as the reference decides with query_initialized: what the restart file held is uploaded from
+  ! its registered mirror and named in `have`; the device forms every other one the way the reference does (a new run: have = 0)
+  have = 0_c_int
+  if (query_initialized(CS%eta, "sfc", restart_CS)) then
     rc = mom6x_upload(CS%ctx, mom6x_rk2_field(CS%ctx, F_ETA), CS%eta, STG_H, 1_c_int) ; call shim_check(rc, "restart: sfc")
-    rc = mom6x_upload(CS%ctx, mom6x_rk2_field(CS%ctx, F_U_AV), CS%u_av, STG_U, int(nk, c_int)) ; call shim_check(rc, "restart: u2")
-    rc = mom6x_upload(CS%ctx, mom6x_rk2_field(CS%ctx, F_V_AV), CS%v_av, STG_V, int(nk, c_int)) ; call shim_check(rc, "restart: v2")
+    have = ior(have, MOM6X_RK2_HAVE_ETA)
+  endif
+  if (query_initialized(CS%diffu, "diffu", restart_CS) .and. query_initialized(CS%diffv, "diffv", restart_CS)) then
     rc = mom6x_upload(CS%ctx, mom6x_rk2_field(CS%ctx, F_DIFFU), CS%diffu, STG_U, int(nk, c_int)) ; call shim_check(rc, "restart: diffu")
     rc = mom6x_upload(CS%ctx, mom6x_rk2_field(CS%ctx, F_DIFFV), CS%diffv, STG_V, int(nk, c_int)) ; call shim_check(rc, "restart: diffv")
-    if (CS%store_CAu .and. query_initialized(CS%CAu_pred, "CAu", restart_CS) .and. query_initialized(CS%CAv_pred, "CAv", restart_CS)) then
+    have = ior(have, MOM6X_RK2_HAVE_DIFFU)
+  endif
+  if (query_initialized(CS%u_av, "u2", restart_CS) .and. query_initialized(CS%v_av, "v2", restart_CS)) then
+    rc = mom6x_upload(CS%ctx, mom6x_rk2_field(CS%ctx, F_U_AV), CS%u_av, STG_U, int(nk, c_int)) ; call shim_check(rc, "restart: u2")
+    rc = mom6x_upload(CS%ctx, mom6x_rk2_field(CS%ctx, F_V_AV), CS%v_av, STG_V, int(nk, c_int)) ; call shim_check(rc, "restart: v2")
+    have = ior(have, MOM6X_RK2_HAVE_U2)
+  endif
+  if (CS%store_CAu) then
+    if (query_initialized(CS%CAu_pred, "CAu", restart_CS) .and. query_initialized(CS%CAv_pred, "CAv", restart_CS)) then
       rc = mom6x_upload(CS%ctx, mom6x_rk2_field(CS%ctx, F_CAU_PRED), CS%CAu_pred, STG_U, int(nk, c_int)) ; call shim_check(rc, "restart: CAu")
       rc = mom6x_upload(CS%ctx, mom6x_rk2_field(CS%ctx, F_CAV_PRED), CS%CAv_pred, STG_V, int(nk, c_int)) ; call shim_check(rc, "restart: CAv")
-      rc = mom6x_rk2_set_CAu_pred_stored(CS%ctx, 1_c_int) ; call shim_check(rc, "restart: CAu_pred_stored")
+      have = ior(have, MOM6X_RK2_HAVE_CAU)
     endif
+    ! (:1621-1628 would look for "uh", "vh", "h2" of an older file with only_read_from_restarts; without them the device takes the
+    !  reference's other branch, :1629-1636: h_av from one continuity call, then CorAdCalc)
   endif
+  rc = mom6x_dyn_split_RK2_restart_fills(CS%ctx, CS%S%u, CS%S%v, CS%S%h, CS%S%uh, CS%S%vh, real(dt, c_double), have)
+  call shim_check(rc, "initialize_dyn_split_RK2 (restart variables)")
   call shim_down2(eta, mom6x_rk2_field(CS%ctx, F_ETA), STG_H)   ! the eta argument is intent(inout): :1578-1590
   call refresh_host_mirrors(CS, G, GV)
   id_clock_step = cpu_clock_id('(Ocean dynamics on the device)', grain=CLOCK_MODULE_DRIVER)

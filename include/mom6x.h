@@ -39,9 +39,14 @@ extern "C" {
 #endif
 
 /* 2: mom6x_continuity_params.sum_order, the Leith members of mom6x_hor_visc_params, Recon_Scheme / boundary_extrap /
- * h_nonvanished of mom6x_eos_params, mom6x_device_count (round 3).  Hosts compare mom6x_abi_version() with the value they were
+ * h_nonvanished of mom6x_eos_params, mom6x_device_count.
+ * 3: mom6x_coriolis_params grew (CORIOLIS_SCHEME ARAKAWA_LAMB81 / AL_BLEND / ROBUST_ENSTRO: wt_lin_blend, F_eff_max_blend, PV_Adv_Scheme),
+ * mom6x_eos_params.EOS_quadrature and the EOS forms beyond LINEAR / WRIGHT, mom6x_barotropic_params' wide-halo members
+ * (use_wide_halos, BTHALO, min_stencil) (round 3).
+ * 4: (round 4) mom6x_dyn_split_RK2_restart_fills + MOM6X_RK2_HAVE_*, mom6x_rk2_diag_*; see the end of this comment's list in
+ * DESIGN.md section 1.  Hosts compare mom6x_abi_version() with the value they were
  * built against (fortran/mom6x_c_api.F90 MOM6X_ABI_BUILT_FOR, mom6_amd/abi.py ABI_VERSION) and refuse to run on a mismatch. */
-#define MOM6X_ABI_VERSION 3
+#define MOM6X_ABI_VERSION 4
 
 /* ------------------------------------------------------------------------- */
 /* Tile dimensions and layout (MOM_hor_index.F90:14-44 hor_index_type +
@@ -622,6 +627,20 @@ int mom6x_initialize_dyn_split_RK2(mom6x_ctx *ctx, const mom6x_rk2_params *p);
 int mom6x_dyn_split_RK2_new_run(mom6x_ctx *ctx, const double *u, const double *v, const double *h,
                                 double *uh, double *vh, double dt);
 int mom6x_rk2_set_CAu_pred_stored(mom6x_ctx *ctx, int stored);
+/* The same routine for a RESTARTED run (initialize_dyn_split_RK2 :1577-1668), field by field as the reference decides
+ * with query_initialized: the host uploads the variables the restart file held (mom6x_rk2_field) and names them in
+ * `have`; every other one is formed as the reference forms it -- eta from h (:1578-1590), diffu, diffv by
+ * horizontal_viscosity (:1599-1606), u_av, v_av = u, v (:1608-1614), and, when CAu / CAv are absent, h_av from one
+ * continuity call (or the file's uh, vh, h2: HAVE_UH + HAVE_H2, an older restart format) and CAu_pred, CAv_pred by
+ * CorAdCalc (:1620-1640) -- followed by the group pass of :1670-1679.  have = 0 is mom6x_dyn_split_RK2_new_run.      */
+#define MOM6X_RK2_HAVE_ETA   1   /* "sfc"            */
+#define MOM6X_RK2_HAVE_DIFFU 2   /* "diffu", "diffv" */
+#define MOM6X_RK2_HAVE_U2    4   /* "u2", "v2"       */
+#define MOM6X_RK2_HAVE_CAU   8   /* "CAu", "CAv"     */
+#define MOM6X_RK2_HAVE_UH    16  /* "uh", "vh"       */
+#define MOM6X_RK2_HAVE_H2    32  /* "h2"             */
+int mom6x_dyn_split_RK2_restart_fills(mom6x_ctx *ctx, const double *u, const double *v, const double *h,
+                                      double *uh, double *vh, double dt, int have);
 /* remap_dyn_split_RK2_aux_vars (RK2.F90:1302): after an ALE regridding the auxiliary restart variables move to the
  * new grid too -- u_av, v_av and CAu_pred, CAv_pred (STORE_CORIOLIS_ACCEL), then diffu, diffv, each pair with
  * ALE_remap_velocities and the first two followed by their pass_vector.  Returns at once unless REMAP_AUXILIARY_VARS.
@@ -728,6 +747,9 @@ int mom6x_pass_fields(mom6x_ctx *ctx, double *const *fields, const int *staggers
 int mom6x_set_dyn_pass_width(mom6x_ctx *ctx, int width);
 /* Packed group exchanges (one message per neighbour each) this tile has made since the last reset; reset != 0 clears the count. */
 long long mom6x_comm_exchange_count(mom6x_ctx *ctx, int reset);
+/* ... and the bytes this tile sent in them (all neighbours together): what the per-pass halo widths of the RK2 step
+ * (create_group_pass(..., halo=), RK2.F90:484-495) save over NIHALO rows of every field.                             */
+long long mom6x_comm_exchange_bytes(mom6x_ctx *ctx, int reset);
 
 /* ------------------------------------------------------------------------- */
 /* The order-invariant sums and checksums of the reference's regression artefacts (ocean.stats, the debugging

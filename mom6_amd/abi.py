@@ -379,6 +379,8 @@ class RK2Hooks(C.Structure):
 RK2_FIELDS = ["CAu", "CAv", "CAu_pred", "CAv_pred", "PFu", "PFv", "diffu", "diffv", "visc_rem_u", "visc_rem_v",
               "u_accel_bt", "v_accel_bt", "u_av", "v_av", "h_av", "pbce", "eta", "eta_PF", "uhbt", "vhbt",
               "taux_bot", "tauy_bot", "BT_h_u", "BT_h_v"]
+# mom6x_dyn_split_RK2_restart_fills: the restart variables the caller has uploaded (include/mom6x.h MOM6X_RK2_HAVE_*)
+RK2_HAVE_ETA, RK2_HAVE_DIFFU, RK2_HAVE_U2, RK2_HAVE_CAU, RK2_HAVE_UH, RK2_HAVE_H2 = 1, 2, 4, 8, 16, 32
 RK2_FIELDS_2D = {"eta", "eta_PF", "uhbt", "vhbt", "taux_bot", "tauy_bot"}
 
 
@@ -401,7 +403,7 @@ MOM6X_OK = 0
 _lib = None
 
 
-ABI_VERSION = 3   # include/mom6x.h MOM6X_ABI_VERSION
+ABI_VERSION = 4   # include/mom6x.h MOM6X_ABI_VERSION
 
 
 def load_library(path=None):

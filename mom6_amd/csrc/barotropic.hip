@@ -746,7 +746,11 @@ bool bt_layer_accel_src(mom6x_ctx *c, LayerAccelSrc *u, LayerAccelSrc *v) {
 
 int bt_layer_accel_materialize(mom6x_ctx *c, double *accel_layer_u, double *accel_layer_v) {
   BTState *s = c->bts;
-  if (!s || !s->la_pending) return MOM6X_OK;
+  // (a btstep from outside the step has replaced the work block the deferred accelerations were to be formed from: the caller
+  //  must not hand out arrays nobody wrote)
+  REQUIRE(s && s->la_pending, MOM6X_EINVAL, "btstep_layer_accel: the deferred layer accelerations of the step's last btstep are gone "
+          "(another btstep has run since)");
+  HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   const dim3 b = blk2();
   KLAUNCH(c, "k_layer_accel", k_layer_accel, grid3(nxa(d.ni + 1, -1), d.nj + 1, nchunks(d.nk), b), b, d, c->G, (const double *)s->work,

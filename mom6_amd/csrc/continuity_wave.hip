@@ -679,8 +679,6 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   LdsArgs E = E0;
   const int nrow = A.b1 - A.b0 + 1;
   E.gx = (A.a1 - E.i_base + NF) / NF;
-  E.rows = 16;                              // rows a work-group marches over
-  E.gy = (nrow + E.rows - 1) / E.rows;      // chunks
   static const int famt0_sweep = [] { const char *e = getenv("MOM6X_FAMT0"); return (e && !strcmp(e, "sweep")) ? 1 : 0; }();
   E.retry = nullptr; E.force_walk = famt0_sweep;   // (in this kernel: always make set_*_BT_cont's own sweep at du0)
   // The Newton statistics are a separate instantiation: the counters cost the 253-register kernel its last free registers
@@ -690,6 +688,29 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   const size_t lds_bytes = sizeof(double) * 4 * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16));   // 4 x the kernel's WAVE_LDS
   auto kern = stats ? k_mass_flux_wave<DIR, MAXL, true> : k_mass_flux_wave<DIR, MAXL, false>;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  // Rows a work-group marches over: 16 where the grid is many times the chip (1440 x 1080: 6120 work-groups for 512 resident
+  // ones).  The work-groups differ in their work (Newton sweeps per row, land) and nothing but the dispatcher balances them, so a
+  // launch wants several work-groups per resident slot: on the tile of an 8-GPU layout (360 x 540) 16 rows make 782 work-groups =
+  // 1.5 rounds, the second one half empty -- measured there (profiles/r04_mfw_rows.txt): 4-10 rows 0.36-0.38 ms per zonal launch,
+  // 16 rows 0.41, one round of 25 rows 0.45.  The prologue of a work-group (first DMA; meridional: the ring of h rows and the
+  // row that is only reconstructed) is cheap next to that.  MOM6X_MFW_ROWS overrides.
+  {
+    static int slots_cache[2][2] = {{0, 0}, {0, 0}};
+    int &slots = slots_cache[DIR][stats ? 1 : 0];
+    if (!slots) {
+      int per_cu = 0, ncu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NF * KL, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
+      slots = per_cu * ncu;
+    }
+    static const int rows_env = [] { const char *e = getenv("MOM6X_MFW_ROWS"); return e ? atoi(e) : 0; }();
+    const long want = 4L * slots;                                  // work-groups for four rounds
+    long r = ((long)E.gx * nrow) / want;                           // the march length that gives them
+    const int rmin = DIR ? 6 : 4;
+    E.rows = (int)std::min<long>(16, std::max<long>(rmin, r));
+    if (rows_env > 0) E.rows = rows_env;
+  }
+  E.gy = (nrow + E.rows - 1) / E.rows;      // chunks
   const dim3 grid(E.gx * E.gy, 1, 1);
   if (c->prof_on) prof_begin(c, DIR ? "k_mass_flux_wave<1>" : "k_mass_flux_wave<0>");
   hipLaunchKernelGGL(kern, grid, dim3(NF * KL, 1, 1), lds_bytes, c->stream, c->d, c->G, A, E);

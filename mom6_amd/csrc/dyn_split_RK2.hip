@@ -6,6 +6,8 @@
 // horizontal_viscosity: callees that are not on the ported hot path) and set_dtbt's scalar reduction.
 // Every `[halo]` mark of the reference (do_group_pass) is a halo_update() call; on one tile that is
 // the periodic wrap kernel, on several tiles the RCCL exchange (halo.hip).
+#include <algorithm>
+#include <cstring>
 #include "mom6x_dev.h"
 
 void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);
@@ -142,24 +144,43 @@ int pass3(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list
   return MOM6X_OK;
 }
 
+// The widths the reference gives its group passes (create_group_pass(..., halo=), RK2.F90:476-495): cont = continuity_stencil
+// (continuity_PPM.F90:2757: 3, SIMPLE_2ND 2, UPWIND_1ST 1), vel = max(2, hor_visc_vel_stencil) (hor_visc.F90:3305: 3 with a Leith
+// viscosity).  The device sent NIHALO = 4 rows of everything through round 3; MOM6X_PASS_WIDTHS=full still does.
+struct PassWidths { int cont, vel; };
+PassWidths pass_widths(const mom6x_ctx *c) {
+  static const bool full = [] { const char *e = getenv("MOM6X_PASS_WIDTHS"); return e && !strcmp(e, "full"); }();
+  if (full) return PassWidths{ 0, 0 };
+  const int cont = c->cont.upwind_1st ? 1 : (c->cont.simple_2nd ? 2 : 3);
+  const int vel = (c->hv_init && (c->hv.Leith_Kh || c->hv.Leith_Ah)) ? 3 : 2;
+  return PassWidths{ cont, vel };
+}
+void set_widths(mom6x_ctx *c, std::initializer_list<int> w) {
+  c->pass_wf_n = 0;
+  for (int x : w) { if (c->pass_wf_n < 16) c->pass_wf[c->pass_wf_n++] = x; }
+}
+
 // start_group_pass of 3-D fields on the halo stream (G%nonblocking_updates); halo_complete() is its complete_group_pass
-int start3(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list<int> stg, int nk) {
+int start3(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list<int> stg, int nk, std::initializer_list<int> widths = {}) {
   double *ff[16]; int ss[16], nn[16]; int n = 0;
   auto s = stg.begin();
   for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = nk; n++; }
   c->pass_w = c->dyn_pass_width;
+  set_widths(c, widths);
   halo_start(c, ff, ss, nn, n);
-  c->pass_w = 0;
+  c->pass_w = 0; c->pass_wf_n = 0;
   return MOM6X_OK;
 }
 
-int startn(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list<int> stg, std::initializer_list<int> nks) {
+int startn(mom6x_ctx *c, std::initializer_list<double *> f, std::initializer_list<int> stg, std::initializer_list<int> nks,
+           std::initializer_list<int> widths = {}) {
   double *ff[16]; int ss[16], nn[16]; int n = 0;
   auto s = stg.begin(); auto q = nks.begin();
   for (double *p : f) { ff[n] = p; ss[n] = *s++; nn[n] = *q++; n++; }
   c->pass_w = c->dyn_pass_width;   // (mom6x_set_dyn_pass_width: NIHALO rows of the 3-D fields in a context widened for BTHALO)
+  set_widths(c, widths);
   halo_start(c, ff, ss, nn, n);
-  c->pass_w = 0;
+  c->pass_w = 0; c->pass_wf_n = 0;
   return MOM6X_OK;
 }
 
@@ -225,7 +246,8 @@ extern "C" double *mom6x_rk2_field(mom6x_ctx *c, int which) {
                   s->taux_bot, s->tauy_bot, s->BT.h_u, s->BT.h_v };
   if (which < 0 || which >= (int)(sizeof(t) / sizeof(t[0]))) return nullptr;
   if ((which == 10 || which == 11) && s->accel_bt_deferred) {   // CS%u_accel_bt / v_accel_bt asked for: form them now
-    if (bt_layer_accel_materialize(c, s->u_accel_bt, s->v_accel_bt) != MOM6X_OK) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    if (bt_layer_accel_materialize(c, s->u_accel_bt, s->v_accel_bt) != MOM6X_OK) return nullptr;   // (also: no pending result any more)
     if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;   // the caller may read it from another stream
     s->accel_bt_deferred = false;
   }
@@ -257,31 +279,52 @@ extern "C" int mom6x_remap_dyn_split_RK2_aux_vars(mom6x_ctx *c, const mom6x_rema
   return MOM6X_OK;
 }
 
-extern "C" int mom6x_dyn_split_RK2_new_run(mom6x_ctx *c, const double *u, const double *v, const double *h, double *uh,
-                                           double *vh, double dt) {
-  REQUIRE(c && c->rk2, MOM6X_EINVAL, "dyn_split_RK2_new_run: initialize_dyn_split_RK2 must be called first");
+// initialize_dyn_split_RK2 :1577-1668, field by field: what the restart file did not hold is formed as the reference forms it.
+// `have` = the MOM6X_RK2_HAVE_* bits of the variables the host has uploaded (query_initialized was true); 0 = a new run.
+extern "C" int mom6x_dyn_split_RK2_restart_fills(mom6x_ctx *c, const double *u, const double *v, const double *h, double *uh,
+                                                 double *vh, double dt, int have) {
+  REQUIRE(c && c->rk2, MOM6X_EINVAL, "dyn_split_RK2_restart_fills: initialize_dyn_split_RK2 must be called first");
+  REQUIRE(u && v && h && uh && vh, MOM6X_EINVAL, "dyn_split_RK2_restart_fills: null mandatory array");
   HIPCHK(hipSetDevice(c->device));
   RK2State *s = c->rk2;
   const Dm d = c->d;
   const size_t n3 = (size_t)d.slab * d.nk;
   const dim3 b = blk2();
-  KLAUNCH(c, "k_eta", k_eta, grid3(d.ni, d.nj, 1, b), b, d, c->G, s->eta, (const double *)nullptr, h, c->GV.Z_to_H);
-  if (c->hv_init) CHK(mom6x_horizontal_viscosity(c, u, v, h, s->diffu, s->diffv));   // :1599-1606 (diffu not in the restart)
-  HIPCHK(hipMemcpyAsync(s->u_av, u, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(s->v_av, v, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  // h_tmp = h ; continuity(u_av, v_av, h, h_tmp, uh, vh, dt) ; h_av = 0.5*(h + h_tmp)  :1626-1633
-  double *h_tmp = s->hp;
-  HIPCHK(hipMemcpyAsync(h_tmp, h, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  CHK(mom6x_continuity_PPM(c, s->u_av, s->v_av, h, h_tmp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, nullptr));
-  pass3(c, { h_tmp }, { 0 }, d.nk);
-  KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2 * d.halo, -d.halo), d.nj + 2 * d.halo, d.nk, b), b, d, s->h_av, h, (const double *)h_tmp, 0, 0.0, d.halo, 0);
-  pass3(c, { s->u_av, s->v_av, uh, vh }, { 1, 2, 1, 2 }, d.nk);
-  CHK(mom6x_CorAdCalc(c, s->u_av, s->v_av, s->h_av, uh, vh, s->CAu_pred, s->CAv_pred));
-  s->CAu_pred_stored = true;
+  if (!(have & MOM6X_RK2_HAVE_ETA))     // :1578-1590
+    KLAUNCH(c, "k_eta", k_eta, grid3(d.ni, d.nj, 1, b), b, d, c->G, s->eta, (const double *)nullptr, h, c->GV.Z_to_H);
+  if (!(have & MOM6X_RK2_HAVE_DIFFU) && c->hv_init) CHK(mom6x_horizontal_viscosity(c, u, v, h, s->diffu, s->diffv));   // :1599-1606
+  if (!(have & MOM6X_RK2_HAVE_U2)) {    // :1608-1614
+    HIPCHK(hipMemcpyAsync(s->u_av, u, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(s->v_av, v, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (have & MOM6X_RK2_HAVE_CAU) {      // :1617-1619
+    s->CAu_pred_stored = true;
+  } else {
+    if ((have & MOM6X_RK2_HAVE_UH) && (have & MOM6X_RK2_HAVE_H2)) {   // :1621-1628: an older file's uh, vh, h2
+      pass3(c, { s->h_av }, { 0 }, d.nk);
+    } else {
+      // h_tmp = h ; continuity(u_av, v_av, h, h_tmp, uh, vh, dt) ; h_av = 0.5*(h + h_tmp)  :1629-1636
+      double *h_tmp = s->hp;
+      HIPCHK(hipMemcpyAsync(h_tmp, h, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      CHK(mom6x_continuity_PPM(c, s->u_av, s->v_av, h, h_tmp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, nullptr));
+      pass3(c, { h_tmp }, { 0 }, d.nk);
+      KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2 * d.halo, -d.halo), d.nj + 2 * d.halo, d.nk, b), b, d, s->h_av, h, (const double *)h_tmp, 0, 0.0, d.halo, 0);
+    }
+    pass3(c, { s->u_av, s->v_av, uh, vh }, { 1, 2, 1, 2 }, d.nk);
+    CHK(mom6x_CorAdCalc(c, s->u_av, s->v_av, s->h_av, uh, vh, s->CAu_pred, s->CAv_pred));
+    s->CAu_pred_stored = true;
+  }
+  // :1670-1679 (pass_av_h_uvh): the auxiliary velocities and the stored accelerations with their halos
+  if (have & (MOM6X_RK2_HAVE_U2 | MOM6X_RK2_HAVE_CAU)) pass3(c, { s->u_av, s->v_av, s->CAu_pred, s->CAv_pred }, { 1, 2, 1, 2 }, d.nk);
   HIPCHK(hipGetLastError());
   REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
   return MOM6X_OK;
+}
+
+extern "C" int mom6x_dyn_split_RK2_new_run(mom6x_ctx *c, const double *u, const double *v, const double *h, double *uh,
+                                           double *vh, double dt) {
+  return mom6x_dyn_split_RK2_restart_fills(c, u, v, h, uh, vh, dt, 0);
 }
 
 extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_inst, double *h, double *uh, double *vh,
@@ -293,10 +336,15 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   REQUIRE(c->a_u, MOM6X_EINVAL, "step_MOM_dyn_split_RK2: vertical viscosity coefficients have not been set");
   HIPCHK(hipSetDevice(c->device));
   RK2State *s = c->rk2;
+  // On EVERY way out of the step (a failed callee returns early) the deferrals it switches on for its own btstep / btcalc calls
+  // are switched off again: a btstep called from outside the step writes its accel_layer arrays (the pending result of the
+  // step's last btstep stays), and a btcalc called from outside writes frhatu / frhatv.
+  struct DeferGuard { mom6x_ctx *c; ~DeferGuard() { bt_defer_layer_accel(c, false); bt_defer_btcalc(c, false); } } defer_guard{c};
   const mom6x_rk2_params &R = s->P;
   const Dm d = c->d;
   const dim3 b = blk2();
   const int nk = d.nk;
+  const PassWidths PW = pass_widths(c);
   double *u_av = s->u_av, *v_av = s->v_av, *h_av = s->h_av, *eta = s->eta;
   double *up = s->up, *vp = s->vp, *hp = s->hp, *u_bc = s->u_bc_accel, *v_bc = s->v_bc_accel;
   const double *taux_bot = R.split_bottom_stress ? s->taux_bot : nullptr;
@@ -350,7 +398,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :610
   // pass_eta :549/:617 + pass_visc_rem :618/:641 as ONE group started here; bt_mass_source (own cells only) and the own rows of
   // the continuity call below run while it travels; continuity completes it before it touches a halo row
-  startn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk });
+  startn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk }, { 0, PW.cont, PW.cont });   // :484-486
 
   if (have_eta_h) CHK(bt_mass_source_from(c, s->eta_h, eta, 1));        // :629, with the sum k_pgf_main left
   else CHK(mom6x_bt_mass_source(c, h, eta, 1));
@@ -405,7 +453,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
       CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));                            // :763-767
     }
   }
-  start3(c, { s->visc_rem_u, s->visc_rem_v, up, vp }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :769 + pass_uvp :761/:773: completed inside continuity
+  start3(c, { s->visc_rem_u, s->visc_rem_v, up, vp }, { 1, 2, 1, 2 }, nk, { PW.cont, PW.cont, PW.cont, PW.cont });   // pass_visc_rem :769 + pass_uvp :761/:773 (halo = max(1, cont_stencil) :485-487): completed inside continuity
 
   // uh = u_av * h ; hp = h + dt * div . uh  :779-781
   // (h_av = 0.5 * (h + hp) of :808-810 on the tile's own cells is written by the call's last convergence kernel, which has
@@ -420,7 +468,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   halo_complete(c);
   // hp (pass_hp_uv :785), the averaged velocities and the transports (pass_av_uvh :804 ... :865) travel on the halo stream
   // while the barotropic mass source is formed; the frame of h_av follows the completion
-  start3(c, { hp, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);
+  start3(c, { hp, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk, { PW.vel ? 2 : 0, PW.vel, PW.vel, PW.vel, PW.vel });   // :488-490
 
   // ---- corrector
   CHK(mom6x_bt_mass_source(c, hp, s->eta_pred, 0));                     // :820
@@ -467,7 +515,8 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   // the in-place continuity call between them (the first keeps the old thickness it is about to overwrite, the second averages);
   // the frame of halo cells is copied here and averaged after the group pass has brought the new thicknesses
   KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 1, 0.0, 2, 2);
-  start3(c, { s->visc_rem_u, s->visc_rem_v, u_inst, v_inst }, { 1, 2, 1, 2 }, nk);   // pass_visc_rem :1030 + pass_uv :1019/:1034: completed inside continuity
+  const int w_uv = PW.cont ? std::max(2, PW.cont) : 0;   // pass_uv, pass_h: halo = max(2, cont_stencil) :492-493
+  start3(c, { s->visc_rem_u, s->visc_rem_v, u_inst, v_inst }, { 1, 2, 1, 2 }, nk, { PW.cont, PW.cont, w_uv, w_uv });   // pass_visc_rem :1030 + pass_uv :1019/:1034: completed inside continuity
   // uh = u_av * h ; h = h + dt * div . uh  :1041-1043
   c->cont_av_kind = 2; c->cont_av = h_av; c->cont_av_src = nullptr;
   {
@@ -477,7 +526,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     if (rc_c) return rc_c;
   }
   halo_complete(c);
-  start3(c, { h, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk);          // pass_h :1045 + start_group_pass(CS%pass_av_uvh) :1054
+  start3(c, { h, u_av, v_av, uh, vh }, { 0, 1, 2, 1, 2 }, nk, { w_uv, PW.vel, PW.vel, PW.vel, PW.vel });   // pass_h :1045 + start_group_pass(CS%pass_av_uvh) :1054 (:493-495)
   halo_complete(c);                                                     // :1072
   KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 4, -2), d.nj + 4, nk, b), b, d, h_av, (const double *)h, (const double *)nullptr, 2, 0.0, 2, 2);
   // :1072-1079 uhtr += uh*dt: the ring of halo faces here, the box of own faces inside the kernel below, which reads uh, vh anyway
@@ -485,8 +534,6 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   // CAu_pred for the next step :1081-1090
   CHK(CorAdCalc_bc(c, u_av, v_av, h_av, uh, vh, s->CAu_pred, s->CAv_pred, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, uhtr, vhtr, dt));
   s->CAu_pred_stored = true;
-  bt_defer_layer_accel(c, false);   // (a btstep called from outside the step writes its accel_layer arrays; the pending result stays)
-  bt_defer_btcalc(c, false);        // (and a btcalc called from outside writes frhatu / frhatv)
   HIPCHK(hipGetLastError());
   REQUIRE(!c->halo_error, MOM6X_EHIP, mom6x_last_error());
   return MOM6X_OK;

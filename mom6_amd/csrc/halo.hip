@@ -22,10 +22,10 @@
 #include "mom6x_dev.h"
 
 #define MAXF 16
-struct WrapArgs { double *f[MAXF]; int stg[MAXF]; int nk[MAXF]; int n; int rx; int w, w2; };
+struct WrapArgs { double *f[MAXF]; int stg[MAXF]; int nk[MAXF]; int n; int rx; int w, w2; int wf[MAXF]; };
 // w: rows / columns of halo this pass fills for its 3-D fields (create_group_pass's halo=), <= d.halo; w2: for its 2-D fields
-// (always the context's: the barotropic solver reads eta over its wide halo)
-#define PASS_W(A, m) (((A).nk[m] == 1) ? (A).w2 : (A).w)
+// (always the context's: the barotropic solver reads eta over its wide halo); wf[m] > 0: the width of 3-D field m alone
+#define PASS_W(A, m) (((A).nk[m] == 1) ? (A).w2 : ((A).wf[m] > 0 ? (A).wf[m] : (A).w))
 
 // ---- region logic (host + device) ------------------------------------------------------------------
 // Directions d = 0..7: W, E, S, N, SW, SE, NW, NE.
@@ -371,6 +371,7 @@ static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A, hipStream_t st) {
     if (cnt[dir] > cmax) cmax = cnt[dir];
   }
   if (cmax == 0) return MOM6X_OK;
+  for (int dir = 0; dir < 8; dir++) c->n_exchange_bytes += (long long)cnt[dir] * 8;   // (mom6x_comm_exchange_bytes: what this tile sends)
   const int blocks = (int)((cmax + 255) / 256 > 512 ? 512 : (cmax + 255) / 256);
   const bool own = (st == c->stream);     // (the per-kernel timing of mom6x_prof_* follows the compute stream only)
   if (own) KLAUNCH(c, "k_halo_pack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, SB, 1);
@@ -423,6 +424,7 @@ void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const i
     int nkmax = 1;
     for (int q = 0; q < A.n; q++) {
       A.f[q] = fields[base + q]; A.stg[q] = staggers[base + q]; A.nk[q] = nks[base + q];
+      A.wf[q] = (base + q < c->pass_wf_n && c->pass_wf[base + q] > 0 && c->pass_wf[base + q] < A.w) ? c->pass_wf[base + q] : 0;
       if (A.nk[q] > nkmax) nkmax = A.nk[q];
     }
     if (m) {
@@ -456,7 +458,10 @@ void halo_start(mom6x_ctx *c, double *const *fields, const int *staggers, const 
   WrapArgs A;
   A.n = n; A.rx = c->dims.reentrant_x;
   A.w = (c->pass_w > 0 && c->pass_w < c->dims.halo) ? c->pass_w : c->dims.halo; A.w2 = c->dims.halo;
-  for (int q = 0; q < n; q++) { A.f[q] = fields[q]; A.stg[q] = staggers[q]; A.nk[q] = nks[q]; }
+  for (int q = 0; q < n; q++) {
+    A.f[q] = fields[q]; A.stg[q] = staggers[q]; A.nk[q] = nks[q];
+    A.wf[q] = (q < c->pass_wf_n && c->pass_wf[q] > 0 && c->pass_wf[q] < A.w) ? c->pass_wf[q] : 0;
+  }
   // the second stream starts when the compute stream has produced the fields ...
   if (hipEventRecord(c->ev_ready, c->stream) != hipSuccess || hipStreamWaitEvent(c->halo_stream, c->ev_ready, 0) != hipSuccess ||
       exchange(c, m, A, c->halo_stream) != MOM6X_OK || hipEventRecord(c->ev_done, c->halo_stream) != hipSuccess) {
@@ -501,6 +506,14 @@ extern "C" int mom6x_set_dyn_pass_width(mom6x_ctx *c, int width) {
           "mom6x_set_dyn_pass_width: the width must be 0 (the context's halo) or between 4 and the context's halo");
   c->dyn_pass_width = width;
   return MOM6X_OK;
+}
+
+// Bytes this tile has sent in packed group exchanges since the last reset (all neighbours together).
+extern "C" long long mom6x_comm_exchange_bytes(mom6x_ctx *c, int reset) {
+  if (!c) return -1;
+  const long long n = c->n_exchange_bytes;
+  if (reset) c->n_exchange_bytes = 0;
+  return n;
 }
 
 // Packed group exchanges (one message per neighbour each) since the last reset: what a step costs in message latency.

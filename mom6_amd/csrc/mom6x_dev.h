@@ -107,7 +107,10 @@ struct mom6x_ctx {
   // halo width of the NEXT pass (0: the context's); dyn_pass_width: what the RK2 step sets for its own group passes -- a context
   // whose halo was widened for the barotropic solver (BTHALO) still sends NIHALO rows of the 3-D fields (mom6x_set_dyn_pass_width)
   int pass_w = 0, dyn_pass_width = 0;
-  long long n_exchanges = 0;
+  // ... and, field by field, the widths create_group_pass(..., halo=) gave the fields of the NEXT pass (pass_wf_n of them; 0 entries
+  // and fields beyond pass_wf_n: pass_w); the RK2 step sends the reference's own 2-3 rows instead of NIHALO = 4 (RK2.F90:484-495)
+  int pass_wf[16] = {0}, pass_wf_n = 0;
+  long long n_exchanges = 0, n_exchange_bytes = 0;
   BcFold pgf_fold = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
   bool pgf_eta_h_written = false;                                     // the last PressureForce call filled pgf_fold.eta_h   // set by the RK2 step around its PressureForce call
   bool cont_stats_on;               // the statistics-collecting (slower) variant of the mass-flux kernel is in use

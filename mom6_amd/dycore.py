@@ -228,6 +228,12 @@ class Dycore:
         f.restype = C.c_longlong
         return int(f(self.ctx, C.c_int(1 if reset else 0)))
 
+    def comm_exchange_bytes(self, reset=False):
+        """Bytes this tile sent in packed group exchanges since the last reset (mom6x_comm_exchange_bytes)."""
+        f = self.lib.mom6x_comm_exchange_bytes
+        f.restype = C.c_longlong
+        return int(f(self.ctx, C.c_int(1 if reset else 0)))
+
     def ALE_PPM_edge_values(self, h, Q, bdry_extrap, Q_t, Q_b):
         """One field of TS_PPM_edge_values (MOM_ALE.F90:1581): edge_values_implicit_h4 + PPM_reconstruction edge values."""
         check(self.lib, self.lib.mom6x_ALE_PPM_edge_values(self.ctx, _ptr(h), _ptr(Q), C.c_int(int(bdry_extrap)), _ptr(Q_t), _ptr(Q_b)))
@@ -441,6 +447,12 @@ class Dycore:
     def dyn_split_RK2_new_run(self, u, v, h, uh, vh, dt):
         """The new-run fills of initialize_dyn_split_RK2 (:1577-1650)."""
         check(self.lib, self.lib.mom6x_dyn_split_RK2_new_run(self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(uh), _ptr(vh), C.c_double(dt)))
+
+    def dyn_split_RK2_restart_fills(self, u, v, h, uh, vh, dt, have):
+        """initialize_dyn_split_RK2 (:1577-1668) for a restarted run: `have` = the abi.RK2_HAVE_* bits of the restart variables the
+        caller has uploaded into their mom6x_rk2_field arrays; the others are formed as the reference forms them."""
+        check(self.lib, self.lib.mom6x_dyn_split_RK2_restart_fills(self.ctx, _ptr(u), _ptr(v), _ptr(h), _ptr(uh), _ptr(vh), C.c_double(dt),
+                                                                   C.c_int(have)))
 
     def remap_dyn_split_RK2_aux_vars(self, CS, h_old_u, h_old_v, h_new_u, h_new_v):
         """remap_dyn_split_RK2_aux_vars (MOM_dynamics_split_RK2.F90:1302); CS = ALE_CSp%vel_remapCS."""

@@ -481,6 +481,12 @@ class OrcModel:
         if rc != 0:
             raise RuntimeError(f"orc_initialize_dyn_split_RK2 rc={rc}")
 
+    def restart_fills(self, u, v, h, uh, vh, dt, have):
+        """initialize_dyn_split_RK2 :1577-1668 for a restarted run (have: abi.RK2_HAVE_* bits of what the file held)."""
+        rc = lib().orc_restart_fills_dyn_split_RK2(C.byref(self.A), _p(u), _p(v), _p(h), _p(uh), _p(vh), C.c_double(dt), C.c_int(have))
+        if rc != 0:
+            raise RuntimeError(f"orc_restart_fills_dyn_split_RK2 rc={rc}")
+
     def step(self, u, v, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy, dt, coefs, calc_dtbt=False, diffu_new=None, diffv_new=None):
         """coefs: list of 3 tuples (a_u, a_v, h_u, h_v, Ray_u, Ray_v) or a single tuple used for all stages."""
         if not isinstance(coefs, list):

@@ -81,44 +81,64 @@ typedef struct orc_rk2_all {   /* everything step_MOM_dyn_split_RK2 reaches thro
   double Hmix_stress;   /* > 0: DIRECT_STRESS with this HMIX_STRESS [H] in the two vertvisc calls of the step */
 } orc_rk2_all;
 
-/* the new-run branch of initialize_dyn_split_RK2 :1577-1650 (+ barotropic_init ubtav :6124-6135 is done by the
- * caller through orc_btcalc/orc_barotropic ubtav helper) */
-int orc_initialize_dyn_split_RK2(const orc_rk2_all *A, const double *u, const double *v, const double *h,
-                                 double *uh, double *vh, double dt) {
+/* initialize_dyn_split_RK2 :1577-1668, variable by variable: `have` = the MOM6X_RK2_HAVE_* bits of the restart variables the
+ * file held (query_initialized true: CS->eta, diffu, diffv, u_av, v_av, CAu_pred, CAv_pred hold them); the others are formed as
+ * the reference forms them.  have = 0 is the new run.  (barotropic_init's ubtav :6124-6135 is the caller's.) */
+int orc_restart_fills_dyn_split_RK2(const orc_rk2_all *A, const double *u, const double *v, const double *h,
+                                    double *uh, double *vh, double dt, int have) {
   const mom6x_dims *d = A->d; orc_rk2_cs *CS = A->CS;
   const size_t slab = (size_t)d->slab, n3 = slab * d->nk;
   const double *bathyT = GM(A->G, d, MOM6X_G_bathyT);
-  for (int j = 0; j < d->nj; j++) for (int i = 0; i < d->ni; i++) {
-    size_t x = IX2(d, i, j);
-    CS->eta[x] = -A->GV->Z_to_H * bathyT[x];
+  if (!A->rk2->store_CAu) return MOM6X_EUNSUPPORTED;
+  if (!(have & MOM6X_RK2_HAVE_ETA)) {   /* :1578-1590 */
+    for (int j = 0; j < d->nj; j++) for (int i = 0; i < d->ni; i++) {
+      size_t x = IX2(d, i, j);
+      CS->eta[x] = -A->GV->Z_to_H * bathyT[x];
+    }
+    for (int k = 0; k < d->nk; k++) for (int j = 0; j < d->nj; j++) for (int i = 0; i < d->ni; i++) {
+      size_t x = IX2(d, i, j);
+      CS->eta[x] = CS->eta[x] + h[x + k * slab];
+    }
   }
-  for (int k = 0; k < d->nk; k++) for (int j = 0; j < d->nj; j++) for (int i = 0; i < d->ni; i++) {
-    size_t x = IX2(d, i, j);
-    CS->eta[x] = CS->eta[x] + h[x + k * slab];
-  }
-  if (A->hv) {   /* :1599-1606: diffu, diffv are not in the restart file of a new run */
+  if (!(have & MOM6X_RK2_HAVE_DIFFU) && A->hv) {   /* :1599-1606 */
     int rc_ = orc_horizontal_viscosity(d, A->G, A->GV, A->hv, A->hv_planes, u, v, h, CS->diffu, CS->diffv);
     if (rc_) return rc_;
   }
-  memcpy(CS->u_av, u, n3 * sizeof(double)); memcpy(CS->v_av, v, n3 * sizeof(double));
-  if (A->rk2->store_CAu) {
-    double *h_tmp = (double *)malloc(n3 * sizeof(double));
-    memcpy(h_tmp, h, n3 * sizeof(double));
-    int rc = orc_continuity_PPM(d, A->G, A->GV, A->cont, A->first_direction, CS->u_av, CS->v_av, h, h_tmp, uh, vh, dt,
-                                NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
-    if (rc) return rc;
-    orc_pass_var(d, h_tmp, 0, d->nk);
-    for (size_t n = 0; n < n3; n++) CS->h_av[n] = 0.5 * (h[n] + h_tmp[n]);
-    free(h_tmp);
-    orc_pass_var(d, CS->u_av, 1, d->nk); orc_pass_var(d, CS->v_av, 2, d->nk);
-    orc_pass_var(d, uh, 1, d->nk); orc_pass_var(d, vh, 2, d->nk);
-    rc = orc_CorAdCalc(d, A->G, A->GV, A->cor, CS->u_av, CS->v_av, CS->h_av, uh, vh, CS->CAu_pred, CS->CAv_pred);
-    if (rc) return rc;
+  if (!(have & MOM6X_RK2_HAVE_U2)) {   /* :1608-1614 */
+    memcpy(CS->u_av, u, n3 * sizeof(double)); memcpy(CS->v_av, v, n3 * sizeof(double));
+  }
+  if (have & MOM6X_RK2_HAVE_CAU) {     /* :1617-1619 */
     CS->CAu_pred_stored = 1;
   } else {
-    return MOM6X_EUNSUPPORTED;
+    if ((have & MOM6X_RK2_HAVE_UH) && (have & MOM6X_RK2_HAVE_H2)) {   /* :1621-1628 */
+      orc_pass_var(d, CS->h_av, 0, d->nk);
+    } else {                           /* :1629-1636 */
+      double *h_tmp = (double *)malloc(n3 * sizeof(double));
+      memcpy(h_tmp, h, n3 * sizeof(double));
+      int rc = orc_continuity_PPM(d, A->G, A->GV, A->cont, A->first_direction, CS->u_av, CS->v_av, h, h_tmp, uh, vh, dt,
+                                  NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+      if (rc) { free(h_tmp); return rc; }
+      orc_pass_var(d, h_tmp, 0, d->nk);
+      for (size_t n = 0; n < n3; n++) CS->h_av[n] = 0.5 * (h[n] + h_tmp[n]);
+      free(h_tmp);
+    }
+    orc_pass_var(d, CS->u_av, 1, d->nk); orc_pass_var(d, CS->v_av, 2, d->nk);
+    orc_pass_var(d, uh, 1, d->nk); orc_pass_var(d, vh, 2, d->nk);
+    int rc = orc_CorAdCalc(d, A->G, A->GV, A->cor, CS->u_av, CS->v_av, CS->h_av, uh, vh, CS->CAu_pred, CS->CAv_pred);
+    if (rc) return rc;
+    CS->CAu_pred_stored = 1;
+  }
+  if (have & (MOM6X_RK2_HAVE_U2 | MOM6X_RK2_HAVE_CAU)) {   /* :1670-1679 pass_av_h_uvh */
+    orc_pass_var(d, CS->u_av, 1, d->nk); orc_pass_var(d, CS->v_av, 2, d->nk);
+    orc_pass_var(d, CS->CAu_pred, 1, d->nk); orc_pass_var(d, CS->CAv_pred, 2, d->nk);
   }
   return MOM6X_OK;
+}
+
+/* the new-run branch of initialize_dyn_split_RK2 :1577-1650 */
+int orc_initialize_dyn_split_RK2(const orc_rk2_all *A, const double *u, const double *v, const double *h,
+                                 double *uh, double *vh, double dt) {
+  return orc_restart_fills_dyn_split_RK2(A, u, v, h, uh, vh, dt, 0);
 }
 
 int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst, double *h, double *uh, double *vh,

@@ -8,6 +8,8 @@
 !!   run B   the same for `save_after` steps, then what save_restart does with the registry -> a file; end_dyn_split_RK2
 !!   run C   register_restarts -> restore_state from the file -> initialize (restart branch: mirrors uploaded, DTBT kept,
 !!           CAu_pred marked as stored) -> the remaining steps                                       == expected, bit for bit
+!!   run D   the same file read as an older one without CAu, CAv (initialize_dyn_split_RK2 :1620-1640 re-forms them): close to
+!!           the uninterrupted run, nothing left at its zero fill
 !!   then    one advect_tracer call (uhr_out / vhr_out honoured) and one tracer_vertdiff call through their shims: a uniform
 !!           tracer stays uniform, the leftover transports are finite and smaller than the transports.
 !! Exit code 0 and the word PASS only if everything holds.  Usage: drive_shims <case.bin> <scratch restart file> [resident]
@@ -69,6 +71,8 @@ program drive_shims
   real, allocatable, target :: u(:,:,:), v(:,:,:), h(:,:,:), uh(:,:,:), vh(:,:,:), uhtr(:,:,:), vhtr(:,:,:), eta_av(:,:), eta(:,:)
   real, allocatable, target :: u0(:,:,:), v0(:,:,:), h0(:,:,:), taux(:,:), tauy(:,:)
   real, allocatable :: xu(:,:,:), xv(:,:,:), xh(:,:,:), xuh(:,:,:), xvh(:,:,:), xuhtr(:,:,:), xvhtr(:,:,:), xeta(:,:)
+  real, allocatable :: dCAu(:,:,:), dCAv(:,:,:), dPFu(:,:,:), dPFv(:,:,:), ddiffu(:,:,:), ddiffv(:,:,:), dubt(:,:,:), dvbt(:,:,:)
+  real, allocatable :: dpbce(:,:,:), duav(:,:,:), dvav(:,:,:)
   integer, target :: ntrunc
   integer :: cont_stencil
   logical :: calc_dtbt, resident
@@ -113,6 +117,10 @@ program drive_shims
   forces%taux => taux ; forces%tauy => tauy
   allocate(xu(ni+1,nj,nk), xv(ni,nj+1,nk), xh(ni,nj,nk), xuh(ni+1,nj,nk), xvh(ni,nj+1,nk), xuhtr(ni+1,nj,nk), xvhtr(ni,nj+1,nk), xeta(ni,nj))
   read(un) xu ; read(un) xv ; read(un) xh ; read(un) xuh ; read(un) xvh ; read(un) xuhtr ; read(un) xvhtr ; read(un) xeta
+  allocate(dCAu(ni+1,nj,nk), dCAv(ni,nj+1,nk), dPFu(ni+1,nj,nk), dPFv(ni,nj+1,nk), ddiffu(ni+1,nj,nk), ddiffv(ni,nj+1,nk), &
+           dubt(ni+1,nj,nk), dvbt(ni,nj+1,nk), dpbce(ni,nj,nk), duav(ni+1,nj,nk), dvav(ni,nj+1,nk))
+  read(un) dCAu ; read(un) dCAv ; read(un) dPFu ; read(un) dPFv ; read(un) ddiffu ; read(un) ddiffv ; read(un) dubt ; read(un) dvbt
+  read(un) dpbce ; read(un) duav ; read(un) dvav
   close(un)
   call al3(u, 1) ; call al3(v, 2) ; call al3(h, 0) ; call al3(uh, 1) ; call al3(vh, 2) ; call al3(uhtr, 1) ; call al3(vhtr, 2)
   allocate(eta_av(G%isd:G%ied,G%jsd:G%jed), eta(G%isd:G%ied,G%jsd:G%jed))
@@ -146,8 +154,22 @@ program drive_shims
   do n = save_after + 1, nsteps ; call one_step(n) ; enddo
   call finish_host_view()
   call compare_all("C (restarted)")
+  call compare_diag_pointers()
   call check_clocks()
   call tracer_checks()
+  call stop_model()
+
+  ! =================================== run D: the same file read as one WITHOUT CAu, CAv =======================================
+  ! initialize_dyn_split_RK2 :1620-1640 then forms h_av with one continuity call on u2, v2 and CAu_pred, CAv_pred with CorAdCalc:
+  ! not the uninterrupted run bit for bit (the stored accelerations came from the end-of-step transports), but the same flow
+  ! to the accuracy of one step's time-centring.  (Round 3 left h_av at zero on this path.)
+  u = 0.0 ; v = 0.0 ; h = GV%Angstrom_H ; uh = 0.0 ; vh = 0.0 ; eta_av = 0.0 ; eta = 0.0 ; uhtr = 0.0 ; vhtr = 0.0
+  call start_model(restore=.true., skip="CAu,CAv")
+  do n = save_after + 1, nsteps ; call one_step(n) ; enddo
+  call finish_host_view()
+  call near3("D (restart file without CAu, CAv) u", u(G%IscB:G%IecB,G%jsc:G%jec,:), xu, 1.0e-5)
+  call near3("D (restart file without CAu, CAv) v", v(G%isc:G%iec,G%JscB:G%JecB,:), xv, 1.0e-5)
+  call near3("D (restart file without CAu, CAv) h", h(G%isc:G%iec,G%jsc:G%jec,:), xh, 1.0e-3)
   call stop_model()
 
   if (nbad == 0) then
@@ -164,14 +186,16 @@ contains
 
   !> MOM.F90's initialisation order for this module: the restart registrations (u, v, h are MOM.F90's own), restore_state on
   !! a restarted run, then initialize_dyn_split_RK2.
-  subroutine start_model(restore)
+  subroutine start_model(restore, skip)
     logical, intent(in) :: restore
+    character(len=*), optional, intent(in) :: skip
     type(MOM_restart_CS) :: fresh
     RCS = fresh
     call register_restart_field(u, "u", .true., RCS) ; call register_restart_field(v, "v", .true., RCS)
     call register_restart_field(h, "h", .true., RCS)
     call register_restarts_dyn_split_RK2(HI, GV, US, PF, CS, RCS, uh, vh)
-    if (restore) call stub_restore_state(RCS, trim(rpath))
+    if (restore .and. present(skip)) then ; call stub_restore_state(RCS, trim(rpath), skip)
+    elseif (restore) then ; call stub_restore_state(RCS, trim(rpath)) ; endif
     call initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, PF, diag, CS, HA_CSp, RCS, dt, ADp, CDp, MIS, &
                                   VarMix, MEKE, TD, OBC, update_OBC, ALE_CSp, set_visc, visc, dirs, ntrunc, pbv, calc_dtbt, cont_stencil)
     if (cont_stencil /= 3) then ; print '(a,i0)', "FAIL: continuity_stencil = ", cont_stencil ; nbad = nbad + 1 ; endif
@@ -216,6 +240,34 @@ contains
       print '(a,i0,a,es10.3)', trim(name)//": ", nd, " values differ, max |diff| = ", maxval(abs(a - b)) ; nbad = nbad + 1
     endif
   end subroutine cmp3
+
+  !> What initialize_dyn_split_RK2 hands to MOM_diagnostics (Accel_diag) and MOM.F90 (MIS) by pointer, RK2.F90:1512-1534:
+  !! associated, and after the last step equal to the oracle's arrays.  In the resident mode the host asks for them
+  !! (refresh_host_mirrors), as before save_restart.
+  subroutine compare_diag_pointers()
+    if (resident) call refresh_host_mirrors(CS, G, GV)
+    if (.not.(associated(ADp%CAu) .and. associated(ADp%CAv) .and. associated(ADp%PFu) .and. associated(ADp%PFv) .and. &
+              associated(ADp%diffu) .and. associated(ADp%diffv) .and. associated(ADp%u_accel_bt) .and. associated(ADp%v_accel_bt) .and. &
+              associated(MIS%pbce) .and. associated(MIS%u_av) .and. associated(MIS%v_av) .and. associated(MIS%CAu))) then
+      print '(a)', "FAIL: initialize_dyn_split_RK2 left Accel_diag / MIS pointers unassociated" ; nbad = nbad + 1 ; return
+    endif
+    call cmp3("Accel_diag%CAu", ADp%CAu(G%IscB:G%IecB,G%jsc:G%jec,:), dCAu) ; call cmp3("Accel_diag%CAv", ADp%CAv(G%isc:G%iec,G%JscB:G%JecB,:), dCAv)
+    call cmp3("Accel_diag%PFu", ADp%PFu(G%IscB:G%IecB,G%jsc:G%jec,:), dPFu) ; call cmp3("Accel_diag%PFv", ADp%PFv(G%isc:G%iec,G%JscB:G%JecB,:), dPFv)
+    call cmp3("Accel_diag%diffu", ADp%diffu(G%IscB:G%IecB,G%jsc:G%jec,:), ddiffu) ; call cmp3("Accel_diag%diffv", ADp%diffv(G%isc:G%iec,G%JscB:G%JecB,:), ddiffv)
+    call cmp3("Accel_diag%u_accel_bt", ADp%u_accel_bt(G%IscB:G%IecB,G%jsc:G%jec,:), dubt)
+    call cmp3("Accel_diag%v_accel_bt", ADp%v_accel_bt(G%isc:G%iec,G%JscB:G%JecB,:), dvbt)
+    call cmp3("MIS%pbce", MIS%pbce(G%isc:G%iec,G%jsc:G%jec,:), dpbce)
+    call cmp3("MIS%u_av", MIS%u_av(G%IscB:G%IecB,G%jsc:G%jec,:), duav) ; call cmp3("MIS%v_av", MIS%v_av(G%isc:G%iec,G%JscB:G%JecB,:), dvav)
+  end subroutine compare_diag_pointers
+
+  subroutine near3(name, a, b, tol)
+    character(len=*), intent(in) :: name ; real, intent(in) :: a(:,:,:), b(:,:,:), tol
+    if (all(a == a) .and. maxval(abs(a - b)) <= tol) then
+      print '(a,es10.3)', trim(name)//": max |diff| from the uninterrupted run = ", maxval(abs(a - b))
+    else
+      print '(a,es10.3)', "FAIL "//trim(name)//": max |diff| = ", maxval(abs(a - b)) ; nbad = nbad + 1
+    endif
+  end subroutine near3
 
   !> The shims keep the reference's cpu clocks: every step passed through the device clock and the transfer clock
   subroutine check_clocks()

@@ -323,8 +323,9 @@ contains
     close(u)
   end subroutine stub_save_restart
   !> what restore_state does: fill the registered arrays from the file, by name, and mark them initialised
-  subroutine stub_restore_state(CS, path)
+  subroutine stub_restore_state(CS, path, skip)
     type(MOM_restart_CS), intent(inout) :: CS ; character(len=*), intent(in) :: path
+    character(len=*), optional, intent(in) :: skip   !< names (between commas) the file is to be treated as not holding: an older file
     integer :: m, q, u, n, rk, s3(3), s2(2) ; character(len=32) :: nm
     real, allocatable :: b3(:,:,:), b2(:,:) ; real :: b0
     open(newunit=u, file=path, form="unformatted", access="stream", status="old")
@@ -335,6 +336,7 @@ contains
       elseif (rk == 2) then ; read(u) s2 ; allocate(b2(s2(1), s2(2))) ; read(u) b2
       else ; read(u) b0 ; endif
       do m = 1, CS%n ; if (trim(CS%names(m)) == trim(nm) .and. CS%rank(m) == rk) then
+        if (present(skip)) then ; if (index(","//trim(skip)//",", ","//trim(nm)//",") > 0) cycle ; endif
         if (rk == 3) then ; CS%v3(m)%p(:,:,:) = b3
         elseif (rk == 2) then ; CS%v2(m)%p(:,:) = b2
         else ; CS%v0(m)%p = b0 ; endif
@@ -371,8 +373,15 @@ module MOM_variables
     real, allocatable, dimension(:,:) :: FA_u_EE, FA_u_E0, FA_u_W0, FA_u_WW, uBT_WW, uBT_EE, FA_v_NN, FA_v_N0, FA_v_S0, FA_v_SS, vBT_SS, vBT_NN
     real, allocatable, dimension(:,:,:) :: h_u, h_v
   end type BT_cont_type
-  type :: ocean_internal_state ; integer :: dummy = 0 ; end type
-  type :: accel_diag_ptrs ; integer :: dummy = 0 ; end type
+  !> the members initialize_dyn_split_RK2 associates (MOM_variables.F90:136-162 / :165-237)
+  type :: ocean_internal_state
+    real, pointer, dimension(:,:,:) :: CAu => NULL(), CAv => NULL(), PFu => NULL(), PFv => NULL(), diffu => NULL(), diffv => NULL(), &
+                                       pbce => NULL(), u_accel_bt => NULL(), v_accel_bt => NULL(), u_av => NULL(), v_av => NULL()
+  end type
+  type :: accel_diag_ptrs
+    real, pointer, dimension(:,:,:) :: diffu => NULL(), diffv => NULL(), CAu => NULL(), CAv => NULL(), PFu => NULL(), PFv => NULL(), &
+                                       u_accel_bt => NULL(), v_accel_bt => NULL()
+  end type
   type :: cont_diag_ptrs ; integer :: dummy = 0 ; end type
 end module MOM_variables
 

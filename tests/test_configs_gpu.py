@@ -167,8 +167,13 @@ def test_config4_tile_1080x1620x75_ale_cycle():
         assert abs(v1 / v0 - 1.0) < 1e-13, v1 / v0 - 1.0
         # ... the new grid is z*: every wet column's interfaces sit at the nominal depths scaled by its own depth + eta
         col = st["h"][sl].sum(0)
-        # a cycle (one hour) moves the surface by metres at most: |u| <= 0.5 m/s in an unbalanced synthetic state gives 1.2 m
-        assert ((col - (pre["h"][sl].sum(0))).abs()[wet].max().item()) < 5.0
+        # ... and a column's thickness changes by exactly the convergence of the transports accumulated over the cycle's dynamics
+        # steps (continuity in flux form, uhtr = sum of uh dt; tracer steps and regridding leave column sums alone): an identity
+        # of the state, to round-off of the 75-term sums (a constant bound in metres was loosened once already)
+        dcol = col - pre["h"][sl].sum(0)
+        expect = -(c["info"].pop("_col_transport_div")[sl[1:]] / area)
+        assert (dcol - expect).abs()[wet].max().item() < 1.0e-8, (dcol - expect).abs()[wet].max().item()
+        assert dcol.abs()[wet].max().item() > 1.0e-3     # (the state does move)
         # ... heat content sum(T h area) changes only through the (conservative) advection, the (conservative, no-flux)
         # tridiagonal solve and the (conservative) remapping: conserved to round-off of the sums
         q0 = (pre["T"][sl] * pre["h"][sl] * area).sum(dtype=torch.float64).item()

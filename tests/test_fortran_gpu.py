@@ -110,6 +110,13 @@ def _write_shim_case(path, cfg, orc):
         put(inp["taux"], 1); put(inp["tauy"], 2)
         for n in STATE:
             f.write(np.ascontiguousarray(gold[n], dtype="<f8").tobytes())
+        # what MOM_diagnostics reads through Accel_diag / MIS after the last step (RK2.F90:1512-1534), from the same oracle run
+        for n, stg in DIAG:
+            f.write(np.ascontiguousarray(m[n][(Ellipsis,) + tuple(H.interior(d, stg))], dtype="<f8").tobytes())
+
+
+DIAG = [("CAu", "u"), ("CAv", "v"), ("PFu", "u"), ("PFv", "v"), ("diffu", "u"), ("diffv", "v"), ("u_accel_bt", "u"), ("v_accel_bt", "v"),
+        ("pbce", "h"), ("u_av", "u"), ("v_av", "v")]
 
 
 @pytest.mark.parametrize("mode", ["", "resident"])
@@ -128,6 +135,8 @@ def test_shim_modules_new_run_restart_and_tracers_from_fortran(orc, tmp_path, mo
                        capture_output=True, text=True, timeout=300)
     print(r.stdout); print(r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count(": bit-identical") == 2 * len(STATE)
+    # runs A and C: the state; run C also: the arrays behind Accel_diag% and MIS% (associated, and equal to the oracle's)
+    assert r.stdout.count(": bit-identical") == 2 * len(STATE) + len(DIAG)
+    assert "D (restart file without CAu, CAv) u: max |diff|" in r.stdout
     names = r.stdout.split("registered restart variables:")[1].splitlines()[0].split()
     assert names == ["u", "v", "h", "sfc", "u2", "v2", "CAu", "CAv", "diffu", "diffv", "ubtav", "vbtav", "DTBT"]

@@ -109,3 +109,71 @@ def test_restarted_run_is_bit_identical(cfg_name, bt_mod, tmp_path):
     with pytest.raises(RuntimeError, match="Checksum of input field h"):
         CS.restore_state(bad)
     dyc.close()
+
+
+def test_restart_file_without_coriolis_accelerations(orc):
+    """A restart file that holds sfc, u2, v2, diffu, diffv but not CAu, CAv (an older format, or a run that turned
+    STORE_CORIOLIS_ACCEL on at the restart): initialize_dyn_split_RK2 :1620-1640 then forms h_av with one continuity call on the
+    auxiliary velocities and CAu_pred, CAv_pred with CorAdCalc.  mom6x_dyn_split_RK2_restart_fills against the oracle's restatement
+    of the same branch, bit for bit, after two steps + the restart + two steps; nothing may be left at its zero fill (round 3 left
+    h_av = 0 on this path: q ~ abs_vort / vol_neglect)."""
+    from tests import cases
+    cfg = H.double_gyre()
+    gg, d, M = cfg
+    inp = cases.rk2_inputs(cfg, False, False)
+    dt = inp["dt"]
+    bt_mod = dict(strong_drag=1)
+    have = abi.RK2_HAVE_ETA | abi.RK2_HAVE_DIFFU | abi.RK2_HAVE_U2
+    # ---- oracle: two steps, "file" = the registered variables but CAu, CAv; a fresh model; restart fills; two steps
+    so, m = cases.oracle_rk2(orc, cfg, inp, 2, bt_mod)
+    cont, bt, cor, pgf, rk2 = cases.rk2_params(d, inp["GV"], bt_mod, None, None)
+    m2 = orc.OrcModel(d, M, inp["GV"], cont, bt, cor, pgf, rk2, inp["Rlay"], inp["gp"], 0)
+    for n in ("eta", "u_av", "v_av", "diffu", "diffv"):
+        m2[n][...] = m[n]
+    for n in ("ubtav", "vbtav"):
+        m2.btcs[n][...] = m.btcs[n]
+    bt.dtbt = m.bt.dtbt     # the restart scalar DTBT
+    so2 = {k: v.copy() for k, v in so.items()}
+    so2["uh"][...] = 0.0; so2["vh"][...] = 0.0
+    m2.restart_fills(so2["u"], so2["v"], so2["h"], so2["uh"], so2["vh"], dt, have)
+    m2f = {n: m2[n].copy() for n in ("h_av", "CAu_pred")}
+    for n in range(2):
+        m2.step(so2["u"], so2["v"], so2["h"], so2["uh"], so2["vh"], so2["uhtr"], so2["vhtr"], so2["eta_av"], inp["taux"], inp["tauy"], dt,
+                inp["coefs"], calc_dtbt=False)
+    assert np.isfinite(so2["u"]).all() and np.abs(so2["u"]).max() < 10.0
+    # ---- device: the same
+    dyc, forcing = new_model(cfg, inp, bt_mod)
+    sg = dict(u=dyc.to_dev(inp["u"]), v=dyc.to_dev(inp["v"]), h=dyc.to_dev(inp["h"]), uh=dyc.zeros3(), vh=dyc.zeros3(),
+              uhtr=dyc.zeros3(), vhtr=dyc.zeros3(), eta_av=dyc.zeros2())
+    dyc.dyn_split_RK2_new_run(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], dt)
+    for n in range(2):
+        step(dyc, sg, forcing, dt, n == 0)
+    dyc.sync()    # (the clones below run on torch's stream, the steps on the context's)
+    keep = {k: sg[k].clone() for k in ("u", "v", "h", "uhtr", "vhtr")}
+    keep_cs = {k: dyc.rk2_field(k).clone() for k in ("eta", "u_av", "v_av", "diffu", "diffv")}
+    keep_bt = {k: dyc.barotropic_field(k).clone() for k in ("ubtav", "vbtav")}
+    dtbt = dyc.barotropic_dtbt()
+    import torch
+    torch.cuda.synchronize(); dyc.close()
+    dyc, forcing = new_model(cfg, inp, bt_mod)
+    dyc.sync()    # (the context zeroes its arrays on its own stream; the copies below run on torch's)
+    sg = dict(u=keep["u"], v=keep["v"], h=keep["h"], uh=dyc.zeros3(), vh=dyc.zeros3(), uhtr=keep["uhtr"], vhtr=keep["vhtr"], eta_av=dyc.zeros2())
+    for k, a in keep_cs.items():
+        dyc.rk2_field(k).copy_(a)
+    for k, a in keep_bt.items():
+        dyc.barotropic_field(k).copy_(a)
+    dyc.barotropic_dtbt(dtbt)
+    import torch
+    torch.cuda.synchronize()
+    dyc.dyn_split_RK2_restart_fills(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], dt, have)
+    dyc.sync()
+    h_av = dyc.rk2_field("h_av").cpu().numpy()
+    H.assert_bitwise(h_av, m2f["h_av"], "restart fills: h_av", H.interior(d, "h"))
+    H.assert_bitwise(dyc.rk2_field("CAu_pred").cpu().numpy(), m2f["CAu_pred"], "restart fills: CAu_pred", H.interior(d, "u"))
+    assert h_av[(Ellipsis,) + tuple(H.interior(d, "h"))].min() > 0.0
+    for n in range(2):
+        step(dyc, sg, forcing, dt, False)
+    dyc.sync()
+    for k in ("u", "v", "h", "uh", "vh", "eta_av"):
+        H.assert_bitwise(sg[k].cpu().numpy(), so2[k], "restart without CAu:" + k, H.interior(d, {"u": "u", "uh": "u", "v": "v", "vh": "v"}.get(k, "h")))
+    dyc.close()
