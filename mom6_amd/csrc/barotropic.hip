@@ -17,6 +17,8 @@
 //    kernels, so each 2-D coefficient plane is read exactly once per sub-step.
 //  * k_layer_accel: btstep_layer_accel (3-D write of accel_layer_u/v).
 // All 2-D work planes live in one HBM block that is cleared with a single memset per call.
+#include <algorithm>
+#include <type_traits>
 #include <vector>
 #include <cmath>
 #include "mom6x_dev.h"
@@ -35,6 +37,7 @@ enum BTW {   // 2-D work planes
   W_BTtmp = W_BTCv + 10,  // 12 planes: halo-updated copies of the BT_cont arrays
   W_uhn = W_BTtmp + 12,   // find_uhbt(ubt) + uhbt0 / find_vhbt(vbt) + vhbt0 at the velocities of the last update: what the next
   W_vhn,                  //   sub-step's eta predictor needs, formed by the kernel that has the velocity and its fit planes at hand
+  W_ubt2, W_vbt2, W_eta_pred2,   // k_bt_substep: the second copies of ubt, vbt, eta_pred (a sub-step reads one set and writes the other)
   W_COUNT
 };
 
@@ -477,7 +480,7 @@ struct LoopArgs {
 // btloop_eta_predictor :2956-3018 (use_BT_cont branch) over (isv-1..iev+1, jsv-1..jev+1), plus the
 // eta_sum accumulation of btloop_find_PF :3104-3108 over the computational domain.
 __global__ void __launch_bounds__(256)
-k_bt_pred(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
+k_bt_pred(Dm d, const double *__restrict__ G, double *work, LoopArgs A, int p_ubt, int p_vbt, int p_pred) {
   const int i = I_BASE(A.isv - 1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = A.jsv - 1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i < A.isv - 1 || i > A.iev + 1 || j > A.jev + 1) return;
@@ -487,7 +490,7 @@ k_bt_pred(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
   if (A.project) {
     eta_PF_BT = work[W_eta * slab + c];
   } else {
-    const double *ubt = work + W_ubt * slab, *vbt = work + W_vbt * slab;
+    const double *ubt = work + (size_t)p_ubt * slab, *vbt = work + (size_t)p_vbt * slab;
     const double *Bu = work + W_BTCu * slab, *Bv = work + W_BTCv * slab;
     const double *uhbt0 = work + W_uhbt0 * slab, *vhbt0 = work + W_vhbt0 * slab;
     double uW, uE, vS, vN;
@@ -502,7 +505,7 @@ k_bt_pred(Dm d, const double *__restrict__ G, double *work, LoopArgs A) {
     }
     eta_PF_BT = (work[W_eta * slab + c] + work[W_eta_src * slab + c]) +
                 (A.dtbt * gm(G, d, MOM6X_G_IareaT)[c]) * ((uW - uE) + (vS - vN));
-    work[W_eta_pred * slab + c] = eta_PF_BT;
+    work[(size_t)p_pred * slab + c] = eta_PF_BT;
   }
   if (A.find_etaav && (fabs(A.wt_accel2) > 0.0) && i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1)
     work[W_eta_sum * slab + c] = work[W_eta_sum * slab + c] + A.wt_accel2 * eta_PF_BT;
@@ -539,6 +542,33 @@ __device__ __forceinline__ void f4v_of(const double *__restrict__ q, const doubl
   }
 }
 
+// The new velocity of one face (btloop_find_PF :3088-3160 + btloop_update_u :3163 / _v :3273): n0..n3 are the four velocities of
+// the OTHER component around the face in the order the Coriolis sums take them (u: vbt at c+1, c-st, c, c+1-st; v: ubt at c-1,
+// c, c+st, c-1+st) -- from memory or from a neighbouring thread, the expressions are the same.
+template <int DIR>
+__device__ __forceinline__ void bt_face_update(const Dm &d, const double *__restrict__ G, const double *work, const LoopArgs &A, size_t c, int st,
+                                               size_t slab, const double *etaB, double vel, double n0, double n1, double n2, double n3,
+                                               int bracket_bug, double &newv, double &CorPF) {
+  const double *eta_PF = work + W_eta_PF * slab;
+  double Cor, PF, f0, f1, f2, f3;
+  if (DIR == 0) {
+    const double *gE = work + W_gtot_E * slab, *gW = work + W_gtot_W * slab;
+    PF = (((etaB[c] - eta_PF[c]) * gE[c]) - ((etaB[c + 1] - eta_PF[c + 1]) * gW[c + 1])) * A.dgeo_de * gm(G, d, MOM6X_G_IdxCu)[c];
+    f4u_of(work + W_q * slab, work + W_DCor_v * slab, c, st, A.Sadourny, f0, f1, f2, f3);
+    Cor = (((f3 * n0) + (f0 * n1)) + ((f2 * n2) + (f1 * n3))) - work[W_Cor_ref_u * slab + c];
+    newv = work[W_bt_rem_u * slab + c] * (vel + A.dtbt * ((work[W_BT_force_u * slab + c] + Cor) + PF));
+  } else {
+    const double *gN = work + W_gtot_N * slab, *gS = work + W_gtot_S * slab;
+    PF = (((etaB[c] - eta_PF[c]) * gN[c]) - ((etaB[c + st] - eta_PF[c + st]) * gS[c + st])) * A.dgeo_de * gm(G, d, MOM6X_G_IdyCv)[c];
+    f4v_of(work + W_q * slab, work + W_DCor_u * slab, c, st, A.Sadourny, f0, f1, f2, f3);
+    if (bracket_bug) Cor = -1.0 * (((f0 * n0) + (f1 * n1)) + ((f3 * n2) + (f2 * n3))) - work[W_Cor_ref_v * slab + c];
+    else Cor = -1.0 * (((f0 * n0) + (f3 * n2)) + ((f1 * n1) + (f2 * n3))) - work[W_Cor_ref_v * slab + c];
+    newv = work[W_bt_rem_v * slab + c] * (vel + A.dtbt * ((work[W_BT_force_v * slab + c] + Cor) + PF));
+  }
+  if (fabs(newv) < A.vel_underflow) newv = 0.0;
+  CorPF = Cor + PF;
+}
+
 // btloop_find_PF + btloop_update_u/v + transports + running sums for ONE velocity component.
 // DIR = 0: u (faces I), DIR = 1: v (faces J).  (a0..a1, b0..b1) is the update range.
 template <int DIR>
@@ -551,37 +581,19 @@ k_bt_vel(Dm d, const double *__restrict__ G, double *work, double *btav, double 
   const int st = d.pitch;
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   const double *etaB = work + (A.project ? W_eta : W_eta_pred) * slab;
-  const double *eta_PF = work + W_eta_PF * slab;
-  double vel, Cor, PF, newv;
+  double vel, newv, CorPF;
   if (DIR == 0) {
-    const double *gE = work + W_gtot_E * slab, *gW = work + W_gtot_W * slab, *vbt = work + W_vbt * slab;
-    const double *f4u = work + W_f4u * slab;
-    PF = (((etaB[c] - eta_PF[c]) * gE[c]) - ((etaB[c + 1] - eta_PF[c + 1]) * gW[c + 1])) * A.dgeo_de * gm(G, d, MOM6X_G_IdxCu)[c];
-    double f0, f1, f2, f3;
-    if (A.f4_on_the_fly) f4u_of(work + W_q * slab, work + W_DCor_v * slab, c, st, A.Sadourny, f0, f1, f2, f3);
-    else { f0 = f4u[0 * slab + c]; f1 = f4u[1 * slab + c]; f2 = f4u[2 * slab + c]; f3 = f4u[3 * slab + c]; }
-    Cor = (((f3 * vbt[c + 1]) + (f0 * vbt[c - st])) + ((f2 * vbt[c]) + (f1 * vbt[c + 1 - st]))) - work[W_Cor_ref_u * slab + c];
+    const double *vbt = work + W_vbt * slab;
     vel = work[W_ubt * slab + c];
-    newv = work[W_bt_rem_u * slab + c] * (vel + A.dtbt * ((work[W_BT_force_u * slab + c] + Cor) + PF));
-    if (fabs(newv) < A.vel_underflow) newv = 0.0;
+    bt_face_update<0>(d, G, work, A, c, st, slab, etaB, vel, vbt[c + 1], vbt[c - st], vbt[c], vbt[c + 1 - st], 0, newv, CorPF);
     work[W_ubt * slab + c] = newv;
-    work[W_u_accel_bt * slab + c] = work[W_u_accel_bt * slab + c] + A.wt_accel * (Cor + PF);
+    work[W_u_accel_bt * slab + c] = work[W_u_accel_bt * slab + c] + A.wt_accel * CorPF;
   } else {
-    const double *gN = work + W_gtot_N * slab, *gS = work + W_gtot_S * slab, *ubt = work + W_ubt * slab;
-    const double *f4v = work + W_f4v * slab;
-    PF = (((etaB[c] - eta_PF[c]) * gN[c]) - ((etaB[c + st] - eta_PF[c + st]) * gS[c + st])) * A.dgeo_de * gm(G, d, MOM6X_G_IdyCv)[c];
-    double f0, f1, f2, f3;
-    if (A.f4_on_the_fly) f4v_of(work + W_q * slab, work + W_DCor_u * slab, c, st, A.Sadourny, f0, f1, f2, f3);
-    else { f0 = f4v[0 * slab + c]; f1 = f4v[1 * slab + c]; f2 = f4v[2 * slab + c]; f3 = f4v[3 * slab + c]; }
-    if (bracket_bug)
-      Cor = -1.0 * (((f0 * ubt[c - 1]) + (f1 * ubt[c])) + ((f3 * ubt[c + st]) + (f2 * ubt[c - 1 + st]))) - work[W_Cor_ref_v * slab + c];
-    else
-      Cor = -1.0 * (((f0 * ubt[c - 1]) + (f3 * ubt[c + st])) + ((f1 * ubt[c]) + (f2 * ubt[c - 1 + st]))) - work[W_Cor_ref_v * slab + c];
+    const double *ubt = work + W_ubt * slab;
     vel = work[W_vbt * slab + c];
-    newv = work[W_bt_rem_v * slab + c] * (vel + A.dtbt * ((work[W_BT_force_v * slab + c] + Cor) + PF));
-    if (fabs(newv) < A.vel_underflow) newv = 0.0;
+    bt_face_update<1>(d, G, work, A, c, st, slab, etaB, vel, ubt[c - 1], ubt[c], ubt[c + st], ubt[c - 1 + st], bracket_bug, newv, CorPF);
     work[W_vbt * slab + c] = newv;
-    work[W_v_accel_bt * slab + c] = work[W_v_accel_bt * slab + c] + A.wt_accel * (Cor + PF);
+    work[W_v_accel_bt * slab + c] = work[W_v_accel_bt * slab + c] + A.wt_accel * CorPF;
   }
   if (A.store_uhn)   // btloop_eta_predictor's transport of this face at the new velocity (:2975-2985), for the next sub-step
     work[(DIR ? W_vhn : W_uhn) * slab + c] = find_uhbt(newv, work + (DIR ? W_BTCv : W_BTCu) * slab, c, slab) + work[(DIR ? W_vhbt0 : W_uhbt0) * slab + c];
@@ -632,6 +644,124 @@ k_bt_eta(Dm d, const double *__restrict__ G, double *work, LoopArgs A, double Z_
     if ((e < -Z_to_H * bT) && (gm(G, d, MOM6X_G_mask2dT)[c] > 0.0)) {
       atomicAdd(&warn[0], 1ULL);
       if (atomicCAS(&warn[1], 0ULL, 1ULL) == 0ULL) { warn_info[0] = e; warn_info[1] = -bT; warn_info[2] = (double)i; warn_info[3] = (double)j; }
+    }
+  }
+}
+
+// ONE launch per barotropic sub-step: first velocity component -> second -> eta corrector (+ the next sub-step's eta predictor),
+// the same expressions as k_bt_vel<DIR> and k_bt_eta, on a 32 x 16 tile of threads whose results go from stage to stage through LDS.
+// A block owns OX x OY cells, their east / north faces (and the west / south faces of the range's first cells, the extra columns /
+// rows the first component is advanced on): only owned points are written and summed.  The one-point frame the second component's
+// Coriolis term and the corrector's divergence need of the first is recomputed by the block itself -- the same inputs, the same
+// expressions, the same bits as the owner's.  What a neighbouring block reads while its owner rewrites it (ubt, vbt, eta_pred) has
+// two copies: a sub-step reads set `pin` and writes set `pout`.  (k_bt_vel / k_bt_eta stay for CLIP_BT_VELOCITY and
+// BT_PROJECT_VELOCITY, whose predictor is a different one.)  3.25 -> 1.25 launches per sub-step; at the 360 x 540 tile of an 8-GPU
+// layout the three launches were 27 us of which half was launch ramp.
+struct SubPlanes { int u_in, u_out, v_in, v_out, e_in, e_out; };
+template <bool VFIRST, int BSX, int BSY>
+__global__ void __launch_bounds__(BSX * BSY)
+k_bt_substep(Dm d, const double *__restrict__ G, double *work, double *ubtav, double *uhbtav, double *vbtav, double *vhbtav, LoopArgs A,
+             SubPlanes P, int bracket_bug, double Z_to_H, unsigned long long *warn, double *warn_info, int nbx) {
+  constexpr int OX = VFIRST ? BSX - 2 : BSX - 1, OY = VFIRST ? BSY - 1 : BSY - 2;
+  __shared__ double s_u[BSY][BSX], s_v[BSY][BSX], s_hu[BSY][BSX], s_hv[BSY][BSX], s_un[BSY][BSX], s_vn[BSY][BSX];
+  const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+  const int x0 = A.isv + bx * OX, y0 = A.jsv + by * OY;
+  const int x1 = min(x0 + OX - 1, A.iev), y1 = min(y0 + OY - 1, A.jev);
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i = x0 - 1 + tx, j = y0 - 1 + ty;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double *etaB = work + (size_t)P.e_in * slab;
+  const double *ubt_in = work + (size_t)P.u_in * slab, *vbt_in = work + (size_t)P.v_in * slab;
+  double *ubt_out = work + (size_t)P.u_out * slab, *vbt_out = work + (size_t)P.v_out * slab;
+  const bool own_x = (i >= x0 && i <= x1), own_y = (j >= y0 && j <= y1);
+  const bool west = (i == A.isv - 1 && x0 == A.isv), south = (j == A.jsv - 1 && y0 == A.jsv);
+  s_u[ty][tx] = 0.0; s_v[ty][tx] = 0.0; s_hu[ty][tx] = 0.0; s_hv[ty][tx] = 0.0; s_un[ty][tx] = 0.0; s_vn[ty][tx] = 0.0;
+
+  // one face: the update, the next predictor's transport, this sub-step's transport and the running sums (k_bt_vel's lines)
+  auto face = [&](auto dir_tag, bool valid, bool owner, double n0, double n1, double n2, double n3, int bb) {
+    constexpr int DIR = decltype(dir_tag)::value;
+    if (!valid) return;
+    const double vel = (DIR ? vbt_in : ubt_in)[c];
+    double newv, CorPF;
+    bt_face_update<DIR>(d, G, work, A, c, st, slab, etaB, vel, n0, n1, n2, n3, bb, newv, CorPF);
+    (DIR ? s_v : s_u)[ty][tx] = newv;
+    const double hn = find_uhbt(newv, work + (DIR ? W_BTCv : W_BTCu) * slab, c, slab) + work[(DIR ? W_vhbt0 : W_uhbt0) * slab + c];
+    (DIR ? s_vn : s_un)[ty][tx] = hn;
+    if (owner) {
+      (DIR ? vbt_out : ubt_out)[c] = newv;
+      double *acc = work + (DIR ? W_v_accel_bt : W_u_accel_bt) * slab;
+      acc[c] = acc[c] + A.wt_accel * CorPF;
+      work[(DIR ? W_vhn : W_uhn) * slab + c] = hn;
+    }
+    const bool in_trans = DIR ? (i >= A.isv && i <= A.iev && j >= A.jsv - 1 && j <= A.jev)
+                              : (i >= A.isv - 1 && i <= A.iev && j >= A.jsv && j <= A.jev);
+    if (in_trans) {
+      const double trans = A.trans_wt1 * newv + A.trans_wt2 * vel;
+      const double hbt = find_uhbt(trans, work + (DIR ? W_BTCv : W_BTCu) * slab, c, slab) + work[(DIR ? W_vhbt0 : W_uhbt0) * slab + c];
+      (DIR ? s_hv : s_hu)[ty][tx] = hbt;
+      const bool in_c = DIR ? (i >= 0 && i <= d.ni - 1 && j >= -1 && j <= d.nj - 1) : (i >= -1 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1);
+      if (owner && in_c) {   // running sums :2690-2700
+        double *btav = DIR ? vbtav : ubtav, *hbtav = DIR ? vhbtav : uhbtav;
+        btav[c] = btav[c] + A.wt_trans * trans;
+        hbtav[c] = hbtav[c] + A.wt_trans * hbt;
+        if (A.wt_vel != 0.0) {
+          double *wtd = work + (DIR ? W_vbt_wtd : W_ubt_wtd) * slab;
+          wtd[c] = wtd[c] + A.wt_vel * newv;
+        }
+      }
+    }
+  };
+  using U = std::integral_constant<int, 0>;
+  using V = std::integral_constant<int, 1>;
+  if (VFIRST) {
+    // v on (isv-1 .. iev+1, jsv-1 .. jev): every thread of the tile; the old ubt around it from memory
+    const bool valid = (i <= A.iev + 1 && j <= A.jev && i <= x1 + 1 && j <= y1);
+    const bool owner = (own_x || west || (i == A.iev + 1 && x1 == A.iev)) && (own_y || south);
+    double n0 = 0., n1 = 0., n2 = 0., n3 = 0.;
+    if (valid) { n0 = ubt_in[c - 1]; n1 = ubt_in[c]; n2 = ubt_in[c + st]; n3 = ubt_in[c - 1 + st]; }
+    face(V{}, valid, owner, n0, n1, n2, n3, 0);
+    __syncthreads();
+    // u on (isv-1 .. iev, jsv .. jev): the new vbt around it from the tile
+    const bool valid2 = (tx <= BSX - 2 && ty >= 1 && i <= x1 && j <= y1);
+    double m0 = 0., m1 = 0., m2 = 0., m3 = 0.;
+    if (valid2) { m0 = s_v[ty][tx + 1]; m1 = s_v[ty - 1][tx]; m2 = s_v[ty][tx]; m3 = s_v[ty - 1][tx + 1]; }
+    face(U{}, valid2, (own_x || west) && own_y, m0, m1, m2, m3, 0);
+  } else {
+    // u on (isv-1 .. iev, jsv-1 .. jev+1)
+    const bool valid = (i <= A.iev && j <= A.jev + 1 && i <= x1 && j <= y1 + 1);
+    const bool owner = (own_x || west) && (own_y || south || (j == A.jev + 1 && y1 == A.jev));
+    double n0 = 0., n1 = 0., n2 = 0., n3 = 0.;
+    if (valid) { n0 = vbt_in[c + 1]; n1 = vbt_in[c - st]; n2 = vbt_in[c]; n3 = vbt_in[c + 1 - st]; }
+    face(U{}, valid, owner, n0, n1, n2, n3, 0);
+    __syncthreads();
+    // v on (isv .. iev, jsv-1 .. jev)
+    const bool valid2 = (tx >= 1 && ty <= BSY - 2 && i <= x1 && j <= y1);
+    double m0 = 0., m1 = 0., m2 = 0., m3 = 0.;
+    if (valid2) { m0 = s_u[ty][tx - 1]; m1 = s_u[ty][tx]; m2 = s_u[ty + 1][tx]; m3 = s_u[ty + 1][tx - 1]; }
+    face(V{}, valid2, own_x && (own_y || south), m0, m1, m2, m3, bracket_bug);
+  }
+  __syncthreads();
+  // eta corrector :2721-2727 on the block's own cells (k_bt_eta's lines)
+  if (own_x && own_y && tx >= 1 && ty >= 1) {
+    const double dtA = A.dtbt * gm(G, d, MOM6X_G_IareaT)[c];
+    const double e = (work[W_eta * slab + c] + work[W_eta_src * slab + c]) +
+                     dtA * ((s_hu[ty][tx - 1] - s_hu[ty][tx]) + (s_hv[ty - 1][tx] - s_hv[ty][tx]));
+    work[W_eta * slab + c] = e;
+    if (A.wt_eta != 0.0) work[W_eta_wtd * slab + c] = work[W_eta_wtd * slab + c] + e * A.wt_eta;
+    if (A.pred_next) {
+      const double eta_PF_BT = (e + work[W_eta_src * slab + c]) +
+                               dtA * ((s_un[ty][tx - 1] - s_un[ty][tx]) + (s_vn[ty - 1][tx] - s_vn[ty][tx]));
+      work[(size_t)P.e_out * slab + c] = eta_PF_BT;
+      if (A.find_etaav && (fabs(A.wt_accel2_next) > 0.0) && i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1)
+        work[W_eta_sum * slab + c] = work[W_eta_sum * slab + c] + A.wt_accel2_next * eta_PF_BT;
+    }
+    if (i >= 0 && i < d.ni && j >= 0 && j < d.nj) {
+      const double bT = gm(G, d, MOM6X_G_bathyT)[c];
+      if ((e < -Z_to_H * bT) && (gm(G, d, MOM6X_G_mask2dT)[c] > 0.0)) {
+        atomicAdd(&warn[0], 1ULL);
+        if (atomicCAS(&warn[1], 0ULL, 1ULL) == 0ULL) { warn_info[0] = e; warn_info[1] = -bT; warn_info[2] = (double)i; warn_info[3] = (double)j; }
+      }
     }
   }
 }
@@ -995,9 +1125,15 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   double *tmp = work + W_BTtmp * slab;
   KLAUNCH(c, "k_btcont_copy", k_btcont_copy, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, *BT_cont, tmp);
   {
-    double *f[12]; int stg[12], nks[12];
+    // the twelve BT_cont planes (set_local_BT_cont_types :4876, halo = 1+ievf-ie) and, in the same packed message, what the column
+    // pass has made and btstep passes next (:1421-1431: gtot_*, ubt_Cor, vbt_Cor -- no kernel between the two reads the other's halos)
+    double *f[18]; int stg[18], nks[18];
     for (int m = 0; m < 12; m++) { f[m] = tmp + (size_t)m * slab; stg[m] = (m < 6) ? 1 : 2; nks[m] = 1; }
-    halo_wrap(c, f, stg, nks, 12);
+    double *g[] = { work + W_gtot_E * slab, work + W_gtot_N * slab, work + W_gtot_W * slab, work + W_gtot_S * slab,
+                    work + W_ubt_Cor * slab, work + W_vbt_Cor * slab };
+    const int gs[] = { 0, 0, 0, 0, 1, 2 };
+    for (int m = 0; m < 6; m++) { f[12 + m] = g[m]; stg[12 + m] = gs[m]; nks[12 + m] = 1; }
+    halo_wrap(c, f, stg, nks, 18);
   }
   const int hs = 1 + ievf - ie;
   KLAUNCH(c, "k_btcl", k_btcl, grid3(d.ni + 2 * hs + 1, d.nj + 2 * hs + 1, 1, b), b, d, tmp, work + W_BTCu * slab,
@@ -1005,12 +1141,6 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   if (add_uh0) KLAUNCH(c, "k_uhbt0", k_uhbt0, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, work, work);
 
   KLAUNCH(c, "k_find_Cor", k_find_Cor, grid3(ievf - isvf + 3, jevf - jsvf + 3, 1, b), b, d, work, P.Sadourny, isvf, ievf, jsvf, jevf);
-  {
-    double *f[] = { work + W_gtot_E * slab, work + W_gtot_N * slab, work + W_gtot_W * slab, work + W_gtot_S * slab,
-                    work + W_ubt_Cor * slab, work + W_vbt_Cor * slab };
-    const int stg[] = { 0, 0, 0, 0, 1, 2 }, nks[] = { 1, 1, 1, 1, 1, 1 };
-    halo_wrap(c, f, stg, nks, 6);
-  }
   KLAUNCH(c, "k_cor_ref_eta_src", k_cor_ref_eta_src, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, c->G, work, s->eta_cor, Instep,
                      P.bound_BT_corr, P.maxCFL_BT_cont * Idt, dt, c->GV.Z_to_H);
   {
@@ -1064,28 +1194,33 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   if (P.BT_project_velocity) { L.trans_wt1 = (1.0 + P.bebt); L.trans_wt2 = -P.bebt; }
   else { L.trans_wt1 = P.bebt; L.trans_wt2 = (1.0 - P.bebt); }
   L.project = P.BT_project_velocity; L.find_etaav = (etaav != nullptr);
-  static const bool f4_planes = [] { const char *e = getenv("MOM6X_BT_F4"); return e && !strcmp(e, "planes"); }();
-  L.f4_on_the_fly = f4_planes ? 0 : 1; L.Sadourny = P.Sadourny;
+  L.f4_on_the_fly = 1; L.Sadourny = P.Sadourny;
   int isv = is, iev = ie, jsv = js, jev = je;
-  double *loop_f[] = { work + W_eta * slab, work + W_ubt * slab, work + W_vbt * slab, work + W_uhn * slab, work + W_vhn * slab };
-  const int loop_stg[] = { 0, 1, 2, 1, 2 }, loop_nk[] = { 1, 1, 1, 1, 1 };
-  // The eta predictor of sub-step n + 1 needs find_uhbt at the velocities sub-step n has just made: the velocity kernels
+  // The eta predictor of sub-step n + 1 needs find_uhbt at the velocities sub-step n has just made: the velocity stages
   // evaluate it while they hold the velocity and its fit planes and pass two planes on (W_uhn, W_vhn; exchanged with the
   // velocities), instead of the predictor re-reading four velocities and up to sixteen fit planes per cell.  Not with
   // CLIP_BT_VELOCITY (the velocities change in between) or BT_PROJECT_VELOCITY (the predictor does not use transports).
-  static const bool pred_self = [] { const char *e = getenv("MOM6X_BT_PRED"); return e && !strcmp(e, "self"); }();
-  const bool pass_uhn = !pred_self && !P.clip_velocity && !P.BT_project_velocity;
+  const bool pass_uhn = !P.clip_velocity && !P.BT_project_velocity;
   L.store_uhn = pass_uhn ? 1 : 0;
   // ... and when no exchange separates two sub-steps (three times out of four with a halo of 4), the eta corrector of the
-  // first forms the predictor of the second on the way: same points, the new eta still in a register (MOM6X_BT_PRED=own
-  // keeps the predictor's own launch).
-  static const bool pred_own = [] { const char *e = getenv("MOM6X_BT_PRED"); return e && !strcmp(e, "own"); }();
+  // first forms the predictor of the second on the way: same points, the new eta still in a register.
+  // One launch per sub-step (k_bt_substep) wherever that predictor chain holds; MOM6X_BT_SUBSTEP=kernels keeps the three launches.
+  // Measured (profiles/README.md, r04): on the 360 x 540 tile of an 8-GPU layout the one-launch form wins (the step 9.14 -> 9.01 ms:
+  // its kernels are latency-, not bandwidth-bound there); at 1440 x 1080 the three kernels win (6.6 against 7.4 ms per step: the
+  // frame a block recomputes, 20 % of its threads, costs more than the three round trips of ubt, vbt, uhbt save).  So: by size.
+  static const int substep_env = [] { const char *e = getenv("MOM6X_BT_SUBSTEP"); return !e ? 0 : (!strcmp(e, "kernels") ? 1 : (!strcmp(e, "fused") ? 2 : 0)); }();
+  const bool small_tile = ((long)d.ni * d.nj <= 512L * 1024L);
+  const bool fused = pass_uhn && (substep_env == 2 || (substep_env == 0 && small_tile));
+  SubPlanes SP = { W_ubt, fused ? W_ubt2 : W_ubt, W_vbt, fused ? W_vbt2 : W_vbt, W_eta_pred, fused ? W_eta_pred2 : W_eta_pred };
+  const int loop_stg[] = { 0, 1, 2, 1, 2 }, loop_nk[] = { 1, 1, 1, 1, 1 };
   bool pred_done = false;
   for (int n = 1; n <= nt; n++) {
     if (P.clip_velocity)
       KLAUNCH(c, "k_bt_clip", k_bt_clip, grid3(iev - isv + 2, jev - jsv + 2, 1, b), b, d, c->G, work, dt, P.CFL_trunc, isv, iev, jsv, jev);
     L.have_uhn = (pass_uhn && n > 1) ? 1 : 0;
     if ((iev - stencil < ie) || (jev - stencil < je)) {
+      double *loop_f[] = { work + W_eta * slab, work + (size_t)SP.u_in * slab, work + (size_t)SP.v_in * slab, work + W_uhn * slab,
+                           work + W_vhn * slab };
       halo_wrap(c, loop_f, loop_stg, loop_nk, (pass_uhn && n > 1) ? 5 : 3);
       isv = isvf; iev = ievf; jsv = jsvf; jev = jevf;
     } else {
@@ -1094,12 +1229,30 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     L.isv = isv; L.iev = iev; L.jsv = jsv; L.jev = jev;
     L.wt_accel = wt_accel[n]; L.wt_trans = wt_trans[n]; L.wt_vel = wt_vel[n]; L.wt_eta = wt_eta[n]; L.wt_accel2 = wt_accel2[n];
     if ((!P.BT_project_velocity || L.find_etaav) && !pred_done)
-      KLAUNCH(c, "k_bt_pred", k_bt_pred, grid3(nxa(iev - isv + 3, isv - 1), jev - jsv + 3, 1, b), b, d, c->G, work, L);
-    // the next sub-step: no exchange before it (:2505-2512) and its transports passed on by this one's velocity kernels
-    pred_done = pass_uhn && !pred_own && n < nt && !((iev - stencil < ie) || (jev - stencil < je));
+      KLAUNCH(c, "k_bt_pred", k_bt_pred, grid3(nxa(iev - isv + 3, isv - 1), jev - jsv + 3, 1, b), b, d, c->G, work, L, SP.u_in, SP.v_in, SP.e_in);
+    // the next sub-step: no exchange before it (:2505-2512) and its transports passed on by this one's velocity stages
+    pred_done = pass_uhn && n < nt && !((iev - stencil < ie) || (jev - stencil < je));
     L.pred_next = pred_done ? 1 : 0;
     L.wt_accel2_next = pred_done ? wt_accel2[n + 1] : 0.0;
     const bool v_first = (((n + c->first_direction) % 2) == 1);
+    if (fused) {
+      static const int shape = [] { const char *e = getenv("MOM6X_BT_TILE"); return e ? atoi(e) : 0; }();   // dev: 0 32x8 (the default), 1 32x16, 2 16x16, 3 64x4
+#define SUBSTEP(BX, BY) do {                                                                                                          \
+      const int OX = v_first ? BX - 2 : BX - 1, OY = v_first ? BY - 1 : BY - 2;                                                        \
+      const int nbx = (iev - isv + OX) / OX, nby = (jev - jsv + OY) / OY;                                                              \
+      if (v_first)                                                                                                                    \
+        KLAUNCH(c, "k_bt_substep<v>", (k_bt_substep<true, BX, BY>), dim3(nbx * nby), dim3(BX, BY), d, c->G, work, s->ubtav, uhbtav, s->vbtav, \
+                vhbtav, L, SP, 0, c->GV.Z_to_H, s->warn, s->warn_info, nbx);                                                           \
+      else                                                                                                                            \
+        KLAUNCH(c, "k_bt_substep<u>", (k_bt_substep<false, BX, BY>), dim3(nbx * nby), dim3(BX, BY), d, c->G, work, s->ubtav, uhbtav, s->vbtav, \
+                vhbtav, L, SP, P.use_old_coriolis_bracket_bug, c->GV.Z_to_H, s->warn, s->warn_info, nbx);                              \
+      } while (0)
+      if (shape == 1) SUBSTEP(32, 16); else if (shape == 2) SUBSTEP(16, 16); else if (shape == 3) SUBSTEP(64, 4); else SUBSTEP(32, 8);
+#undef SUBSTEP
+      std::swap(SP.u_in, SP.u_out); std::swap(SP.v_in, SP.v_out);
+      if (pred_done) std::swap(SP.e_in, SP.e_out);
+      continue;
+    }
     if (v_first) {
       KLAUNCH(c, "k_bt_vel<1>", k_bt_vel<1>, grid3(nxa(iev - isv + 3, isv - 1), jev - jsv + 2, 1, b), b, d, c->G, work, s->vbtav, vhbtav, L,
                          isv - 1, iev + 1, jsv - 1, jev, 0);

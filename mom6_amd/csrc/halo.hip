@@ -21,7 +21,7 @@
 #include <vector>
 #include "mom6x_dev.h"
 
-#define MAXF 16
+#define MAXF 24
 struct WrapArgs { double *f[MAXF]; int stg[MAXF]; int nk[MAXF]; int n; int rx; int w, w2; int wf[MAXF]; };
 // w: rows / columns of halo this pass fills for its 3-D fields (create_group_pass's halo=), <= d.halo; w2: for its 2-D fields
 // (always the context's: the barotropic solver reads eta over its wide halo); wf[m] > 0: the width of 3-D field m alone
