@@ -21,10 +21,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-function"] + os.environ.get("MOM6X_CFLAGS", "").split()
 
 
-# Per-file additions.  continuity_wave.hip: min/max of the flux limiters and CFL bounds as v_min_f64 / v_max_f64
-# instead of compare + two selects (-9 % VALU instructions).  The kernel never produces or tests NaN/Inf, so
-# the only observable effect is the SIGN of a zero result (min(-0, +0)); DESIGN.md section 3.
-PER_FILE = {"continuity_wave.hip": ["-ffinite-math-only", "-fno-signed-zeros"]}
+# Per-file additions.  continuity_wave.hip: -ffinite-math-only lets the compiler keep compare + select chains shorter (no NaN
+# operands to preserve); signed zeros ARE honoured (round 4: -fno-signed-zeros bought nothing -- 2.12 / 2.89 ms per zonal launch
+# without it against 2.20 / 3.05 with it, profiles/r04_signed_zero_flags.txt -- and was not where the zeros of opposite sign came
+# from: continuity_wave.hip face_column).
+PER_FILE = {"continuity_wave.hip": ["-ffinite-math-only"]}
+if "MOM6X_WAVE_FLAGS" in os.environ:   # dev: A/B of the per-file flags (scripts/r04_signed_zero.sh)
+    PER_FILE["continuity_wave.hip"] = os.environ["MOM6X_WAVE_FLAGS"].split()
 
 
 def _newer(srcs, target):

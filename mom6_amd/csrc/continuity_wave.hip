@@ -389,6 +389,11 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
       du_fin = wave_flux_adjust<MAXL, true, STATS>(C, active, IareaMin, uhbt_f, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
                                             A.tol_eta, A.tol_vel, A.better_iter, false, redo, store_uh, evals);
     }
+    // The reference's du is never -0.0: it starts at +0.0 and every later value is a sum or a mean with at least one operand that is
+    // not -0.0 (round to nearest: x + y = -0 only for x = y = -0).  The wave kernel's select chains can leave a -0.0 on faces whose
+    // whole visc_rem column is zero (duhdu_tot = 0: Newton steps of +-inf bisected back to zero); x + 0.0 is the identity but for
+    // that one value.  (The file is compiled with signed zeros honoured; tests/helpers.py makes no allowance any more.)
+    du_fin = du_fin + 0.0;
     if (active && kl == 0 && A.du_cor) st2(A.du_cor, du_fin);
   }
 #pragma unroll

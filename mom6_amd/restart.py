@@ -104,8 +104,8 @@ class MOM_restart_CS:
                 f.put(float(data[f.name].ravel()[0]))
                 continue
             t = f.get()
-            host = np.zeros(tuple(t.shape))
-            host[(Ellipsis,) + tuple(self._interior(f.hor_grid))] = data[f.name][0]
+            host = t.cpu().numpy().copy()     # restore_state reads into the registered array: what lies outside the computational
+            host[(Ellipsis,) + tuple(self._interior(f.hor_grid))] = data[f.name][0]   # domain keeps its value (halos beyond a closed edge)
             t.copy_(self.dyc.to_dev(host))
             dev.append(t); stg.append(_STG[f.hor_grid])
         import torch

@@ -1,5 +1,7 @@
 """Shared test configurations (grids / states) -- mirrors of BASELINE.json's configs at sizes
 the oracle finishes in seconds."""
+import os
+
 import numpy as np
 
 from mom6_amd import abi, grid, synth
@@ -81,15 +83,16 @@ def interior(d, stagger="h", extra=0):
 
 
 # Signed zeros.  np.array_equal says -0.0 == +0.0; the artefacts the reference's .testing compares (chksum bit counts,
-# restart checksums) do not.  assert_bitwise therefore compares BIT PATTERNS.  The one place where the sign of a zero is
-# allowed to differ is the wave-owned mass-flux kernel (continuity_wave.hip is built with -fno-signed-zeros, sum_order =
-# TREE16): there a (+0, -0) pair is accepted and COUNTED (SIGNED_ZERO_LOG, printed at the end of the
-# session by conftest.py); with the reference's order (MOM6X_SUMS=exact) no allowance is made.
+# restart checksums) do not.  assert_bitwise therefore compares BIT PATTERNS and makes NO allowance: through round 3 the wave-owned
+# mass-flux kernel (sum_order = TREE16) was allowed (+0, -0) pairs (1275 of them over the suite, counted); round 4 found their two
+# origins -- du of a face whose whole visc_rem column is zero (continuity_wave.hip face_column: canonicalised, the reference's du is
+# never -0.0) and, in the restart test, halos beyond closed edges that the seeded state filled differently from a restarted run --
+# and the whole GPU suite passes with every zero's sign compared.  SIGNED_ZERO_LOG stays as the (empty) record conftest.py prints.
 SIGNED_ZERO_LOG = {}
 
 
 def signed_zero_allowed():
-    return abi.default_sum_order(1) == abi.SUM_TREE16
+    return False
 
 
 def assert_bitwise(a, b, name, sl=None, signed_zero_ok=None):
