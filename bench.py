@@ -394,8 +394,8 @@ def comm_model_leg(args, device):
     the same tile with local wrap copies instead.  exposed_exchange_ms = the difference of the two step times: packing, the
     RCCL launches and the stream dependencies that the overlap (start_group_pass ... own rows ... complete ... halo rows)
     does not hide; the wire itself is absent (a self send is a device copy), so this is the floor the xGMI latency comes on
-    top of.  launch_gap_ms = wall time minus the sum of the kernel times of a step: at this tile size the ~500 launches of a
-    step no longer stay ahead of the GPU."""
+    top of.  sent_MB_per_step: what this tile packs for its eight neighbours in a step, with the reference's own per-pass halo
+    widths (RK2.F90:484-495; MOM6X_PASS_WIDTHS=full: NIHALO rows of everything, round 3's behaviour)."""
     import torch
     from mom6_amd.dycore import prof_enable, prof_report, prof_reset
 
@@ -419,12 +419,13 @@ def comm_model_leg(args, device):
         dyc.sync(); torch.cuda.synchronize()
         ms = 1e2 * (time.perf_counter() - t0)
         prof_enable(dyc, True); prof_reset(dyc)
-        dyc.comm_exchange_count(reset=True)
+        dyc.comm_exchange_count(reset=True); dyc.comm_exchange_bytes(reset=True)
         step(); dyc.sync()
-        nex = dyc.comm_exchange_count()
+        nex = dyc.comm_exchange_count(); nbytes = dyc.comm_exchange_bytes()
         rep = prof_report(dyc); prof_enable(dyc, False)
         out[mode] = {"ms_per_step": round(ms, 3), "kernel_sum_ms": round(sum(v[1] for v in rep.values()), 3),
-                     "launches_per_step": int(sum(v[0] for v in rep.values())), "exchanges_per_step": nex}
+                     "launches_per_step": int(sum(v[0] for v in rep.values())), "exchanges_per_step": nex,
+                     "sent_MB_per_step": round(nbytes / 1e6, 2)}
         torch.cuda.set_stream(torch.cuda.default_stream())
         dyc.close()
         del st, keep
@@ -458,7 +459,8 @@ def comm_model_leg(args, device):
     out["tile"] = [args.ni // 4, args.nj // 2, args.nk]
     out["exposed_exchange_ms"] = round(out["rccl_self"]["ms_per_step"] - out["local_wrap"]["ms_per_step"], 3)
     out["exposed_exchange_frac_of_step"] = round(out["exposed_exchange_ms"] / out["rccl_self"]["ms_per_step"], 4)
-    out["launch_gap_ms"] = round(out["local_wrap"]["ms_per_step"] - out["local_wrap"]["kernel_sum_ms"], 3)
+    # (no "launch gap": the per-kernel events serialise the two streams and add their own cost, so wall time minus their sum came out
+    #  NEGATIVE in round 3; the idle time of the compute stream is read from a kernel trace instead: profiles/r04_tile_*.txt)
     out["note"] = ("one tile of the 4 x 2 layout on one GPU, all eight neighbours = this rank; every group pass through RCCL send/recv to self "
                    "on the halo stream (rccl_self) against local wrap copies (local_wrap); kernel_sum_ms is measured with HIP events around "
                    "every launch (which itself serialises the streams)")
@@ -524,6 +526,15 @@ def valu_counters(kernel, N3_tile, avg_ms):
                         "frac_of_fp64_vector_issue_peak": round(rate / FP64_VALU_PEAK_TLANE_S, 3),
                         "occupancy": "2 wavefronts per SIMD (253 VGPRs)", "source": os.path.relpath(path, ROOT) + " @ " + git_hash_of(path)}
     return None
+
+
+def sha256_of(path):
+    """The first 16 hex digits of a file's SHA-256 (names a cited measurement whether or not the tree has a .git)."""
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return "unreadable"
 
 
 def git_hash_of(path):
@@ -603,13 +614,17 @@ def cpu_baseline(args):
 def measure_traffic_inrun(kernel, args):
     """HBM-side bytes of THIS state of the code, measured now: two more runs of this script under rocprofv3 (one counter per
     pass -- FETCH_SIZE, WRITE_SIZE -- and nothing else, as the MI355X guide prescribes; a step of the dynamics each), condensed by
-    scripts/rocprof_summary.py (unit KB, calibrated on a kernel whose traffic is known exactly).  Returns (bytes per launch of
-    `kernel`, GB per step over all kernels, description) or None when rocprofv3 is absent, times out or reports nothing."""
+    scripts/rocprof_summary.py (unit KB, calibrated on a kernel whose traffic is known exactly).  Returns ((bytes per launch of
+    `kernel`, GB per step over all kernels, description), None) or (None, why it could not be done): rocprofv3 absent, a pass that
+    timed out (each pass is tried twice; rocprofv3's start-up has hung on some boxes of the pool), exited non-zero or wrote no
+    counter file -- with the tail of its stderr, so that a line that has to cite profiles/ says why."""
     import shutil
     import subprocess
     import tempfile
-    if shutil.which("rocprofv3") is None or os.environ.get("MOM6X_BENCH_NO_PMC"):
-        return None
+    if os.environ.get("MOM6X_BENCH_NO_PMC"):
+        return None, "MOM6X_BENCH_NO_PMC is set (this run is itself a profiled pass)"
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on the PATH"
     import re
     key = lambda n: (re.match(r"\w+(<\d+)?", n.replace(" ", "")) or [n])[0]
     tmp = tempfile.mkdtemp(prefix="mom6x_pmc_")
@@ -618,18 +633,35 @@ def measure_traffic_inrun(kernel, args):
            "--no-comm-model", "--tracers", "-1", "--ni", str(args.ni), "--nj", str(args.nj), "--nk", str(args.nk)]
     try:
         for tag, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, "prof_" + tag), "-o", tag, "--"] + cmd,
-                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
-            if r.returncode != 0 or not os.path.exists(os.path.join(tmp, "prof_" + tag, tag + "_counter_collection.csv")):
-                return None
+            why = None
+            for attempt in (1, 2):
+                shutil.rmtree(os.path.join(tmp, "prof_" + tag), ignore_errors=True)
+                try:
+                    r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, "prof_" + tag), "-o", tag, "--"] + cmd,
+                                       cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
+                except subprocess.TimeoutExpired:
+                    why = f"the {ctr} pass of rocprofv3 did not finish in 150 s (attempt {attempt})"
+                    continue
+                if r.returncode != 0:
+                    why = f"the {ctr} pass of rocprofv3 exited with {r.returncode}: " + " | ".join((r.stderr or "").strip().splitlines()[-2:])[:300]
+                    continue
+                if not os.path.exists(os.path.join(tmp, "prof_" + tag, tag + "_counter_collection.csv")):
+                    why = f"the {ctr} pass of rocprofv3 wrote no counter file: " + " | ".join((r.stderr or "").strip().splitlines()[-2:])[:300]
+                    continue
+                why = None
+                break
+            if why:
+                return None, why
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rocprof_summary.py"), tmp, os.path.join(tmp, "inrun"),
                             str(args.ni), str(args.nj), str(args.nk)], capture_output=True, text=True, timeout=120)
+        if r.returncode != 0:
+            return None, "scripts/rocprof_summary.py failed: " + " | ".join((r.stderr or "").strip().splitlines()[-2:])[:300]
         j = json.load(open(os.path.join(tmp, "inrun_hbm_pmc.json")))
         per = next((float(v) for n, v in j["traffic_bytes_per_launch"].items() if key(n) == key(kernel)), None)
-        return per, round(j["bytes_per_step"] / 1e9, 1), ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one dynamics step, "
-                                                         f"FETCH x{j['fetch_cal']:.3f}, WRITE x{j['write_cal']:.3f} (calibrated on {j.get('calibration_kernel')})")
-    except Exception:   # noqa: BLE001  (a hung or missing profiler must not cost the benchmark line)
-        return None
+        return (per, round(j["bytes_per_step"] / 1e9, 1), ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one dynamics step, "
+                                                          f"FETCH x{j['fetch_cal']:.3f}, WRITE x{j['write_cal']:.3f} (calibrated on {j.get('calibration_kernel')})")), None
+    except Exception as e:   # noqa: BLE001  (a hung or missing profiler must not cost the benchmark line)
+        return None, "the in-run counter passes failed: %s: %s" % (type(e).__name__, str(e)[:200])
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -796,9 +828,20 @@ def args_with(args, **kw):
     return a
 
 
+class Phases:
+    """Wall time of the phases of a run (seconds since the last mark): `wall_s` in the result line, so that the time the command
+    takes outside its timed region is accounted for."""
+    def __init__(self):
+        self.t = time.perf_counter(); self.out = {}
+
+    def mark(self, name):
+        now = time.perf_counter(); self.out[name] = round(self.out.get(name, 0.0) + now - self.t, 2); self.t = now
+
+
 def run_rank(args, env):
     """One rank of the benchmark: everything `python bench.py` does once it knows which rank of how many it is."""
     import torch
+    ph = Phases()
     from mom6_amd.dycore import prof_enable, prof_report, prof_reset
     rank, local_rank, dist = env.rank, env.local_rank, env.dist
     layout = LAYOUTS[args.gpus]
@@ -830,6 +873,7 @@ def run_rank(args, env):
         if thermo is not None and n_dyn[0] % nth == 0:
             thermo()
 
+    ph.mark("build_model")
     step(calc_dtbt=True)                    # sets dtbt (untimed; part of warm-up)
     if thermo is not None:
         thermo()                            # untimed: allocates the work arrays of advect_tracer
@@ -848,11 +892,13 @@ def run_rank(args, env):
     n_dyn[0] = 0
     st["uhtr"].zero_(); st["vhtr"].zero_()
     barrier()
+    ph.mark("warmup")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         cycle_step()
     barrier()
     elapsed = env.max(time.perf_counter() - t0, dyc.device)
+    ph.mark("timed_region")
     restart_checksums = {n: "%016X" % (dyc.field_chksum(st[n]) % 2 ** 64) for n in RESTART_FIELDS}   # (collective: summed over the tiles)
     restart_checksums["dtbt"] = repr(dyc.barotropic_dtbt())
     dom = prof_report(dyc)
@@ -873,14 +919,16 @@ def run_rank(args, env):
     n_dom = sum(v[0] for v in dom.values()); ms_dom = sum(v[1] for v in dom.values())
     roofline = None
     traffic, traffic_src, measured_live = None, None, None
+    traffic_why = None
     if args.gpus == 1 and rank == 0 and not args.no_pmc:
-        measured_live = measure_traffic_inrun(dom_name, args)
+        measured_live, traffic_why = measure_traffic_inrun(dom_name, args)
+        ph.mark("pmc_passes")
     if measured_live is not None:
         traffic, traffic_src = measured_live[0], measured_live[2]
     elif args.gpus == 1 and (args.ni, args.nj, args.nk) == (1440, 1080, 75):
         traffic, traffic_src = pmc_traffic(dom_name)
         if traffic_src:
-            traffic_src += " @ " + git_hash_of(os.path.join(ROOT, traffic_src)) + " (cited: the counters could not be collected in this run)"
+            traffic_src += " sha256:" + sha256_of(os.path.join(ROOT, traffic_src)) + " (cited: " + (traffic_why or "the in-run counter passes were switched off (--no-pmc)") + ")"
     words = next((w for pre, w in KERNEL_WORDS.items() if dom_name.startswith(pre)), None)
     if n_dom and words is not None:
         avg_ms = ms_dom / n_dom
@@ -921,7 +969,7 @@ def run_rank(args, env):
     measured, measured_src = (measured_live[1], measured_live[2]) if measured_live is not None else \
         (pmc_step_traffic() if args.gpus == 1 and (args.ni, args.nj, args.nk) == (1440, 1080, 75) else (None, None))
     if measured_live is None and measured_src:
-        measured_src += " @ " + git_hash_of(os.path.join(ROOT, measured_src))
+        measured_src += " sha256:" + sha256_of(os.path.join(ROOT, measured_src))
     out["hbm_step"] = {
         "algorithmic_GB_per_step": round(tot_bytes / 1e9, 2), "dynamics_GB": round(bytes_step / 1e9, 2), "thermo_GB_amortised": round(th_bytes / 1e9, 2),
         "achieved_GBps": round(tot_bytes / 1e9 / (ms_per_step * 1e-3), 1),
@@ -934,14 +982,17 @@ def run_rank(args, env):
         # the legs reported next to the headline are measured on one GPU; the scaling runs (N > 1) keep to the headline path
         out["ale_remap_leg"] = ale_remap_leg(args, dyc, d, st, barrier, dist)
         out["diag_leg"] = diag_leg(args, dyc, d, st, barrier, dist)
+        ph.mark("ale_and_diag_legs")
         if not args.no_comm_model and (args.ni, args.nj) == (1440, 1080):
             torch.cuda.set_stream(torch.cuda.default_stream()); dyc.close(); st.clear()
             torch.cuda.empty_cache()
             out["comm_model"] = comm_model_leg(args, local_rank)
+            ph.mark("comm_model_leg")
         if not args.no_config4 and (args.ni, args.nj) == (1440, 1080):
             torch.cuda.set_stream(torch.cuda.default_stream()); dyc.close(); st.clear()                  # the headline model makes room for the larger tile
             torch.cuda.empty_cache()
             out["config4_tile_leg"] = ale_cycle(args, local_rank)[1]
+            ph.mark("config4_tile_leg")
     if rank == 0:
         tot = sum(v[1] for v in full.values())
         out["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]}
@@ -952,9 +1003,13 @@ def run_rank(args, env):
                     continue
                 print(f"{k:28s} n={cnt:5d} total={ms:9.3f} ms avg={ms / cnt * 1e3:9.1f} us ({100 * ms / tot:5.1f}%)", file=sys.stderr)
         if not args.no_cpu_baseline and args.gpus == 1:   # (rank 0 at N = 1 only)
+            ph.mark("other")
             out["cpu_baseline"] = cpu_baseline(args)
+            ph.mark("cpu_baseline")
     if st:                                   # (the legs that need the memory have closed the model already)
         torch.cuda.set_stream(torch.cuda.default_stream()); dyc.close(); st.clear()
+    ph.mark("other")
+    out["wall_s"] = ph.out
     return out
 
 
