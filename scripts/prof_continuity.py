@@ -51,7 +51,7 @@ for path in ("lds",) if (timing or only or wave) else ("lds", "legacy"):
         if timing:
             tfun(buf, 1)
             for dr in (0, 1):
-                sel = [q for q in range(16) if q not in (8, 9) and PH[q] != "-" and (not wave or q != 0)]
+                sel = [q for q in range(16) if q not in (8, 9) and PH[q] != "-"]
                 tot = float(sum(buf[dr * 16 + q] for q in sel)) or 1.0
                 print("   phases dir", dr, " ".join(f"{PH[q]}={100 * buf[dr * 16 + q] / tot:.1f}%" for q in sel), f"total={tot:.3e} cyc", f"walk fall-backs={buf[dr * 16 + 15]}")
             if wave:
