@@ -32,6 +32,7 @@ module mom6x_c_api
   public :: MOM6X_RK2_HAVE_ETA, MOM6X_RK2_HAVE_DIFFU, MOM6X_RK2_HAVE_U2, MOM6X_RK2_HAVE_CAU, MOM6X_RK2_HAVE_UH, MOM6X_RK2_HAVE_H2
   public :: mom6x_tracer_advect_init, mom6x_advect_tracer, mom6x_triDiagTS, mom6x_triDiagTS_Eulerian
   public :: mom6x_tracer_vertdiff, mom6x_tracer_vertdiff_Eulerian, mom6x_diabatic_is_trivial
+  public :: mom6x_tracer_vertdiff_sink, mom6x_tracer_vertdiff_Eulerian_sink
 
   !> include/mom6x.h MOM6X_ABI_VERSION this module mirrors; a host compares it with mom6x_abi_version() at start-up
   integer(c_int), parameter :: MOM6X_ABI_BUILT_FOR = 4
@@ -519,6 +520,17 @@ module mom6x_c_api
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: ctx, h_old, ent, tr, sfc_flux, btm_flux ; real(c_double), value :: dt
       integer(c_int), value :: convert_flux
+    end function
+    !> tracer_vertdiff / _Eulerian with sink_rate (MOM_tracer_diabatic.F90:123-179 / :315-380); btm_reservoir may be c_null_ptr
+    integer(c_int) function mom6x_tracer_vertdiff_sink(ctx, h_old, ea, eb, dt, tr, sfc_flux, btm_flux, btm_reservoir, sink_rate, convert_flux) &
+        bind(C, name="mom6x_tracer_vertdiff_sink")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, h_old, ea, eb, tr, sfc_flux, btm_flux, btm_reservoir
+      real(c_double), value :: dt, sink_rate ; integer(c_int), value :: convert_flux
+    end function
+    integer(c_int) function mom6x_tracer_vertdiff_Eulerian_sink(ctx, h_old, ent, dt, tr, sfc_flux, btm_flux, btm_reservoir, sink_rate, convert_flux) &
+        bind(C, name="mom6x_tracer_vertdiff_Eulerian_sink")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, h_old, ent, tr, sfc_flux, btm_flux, btm_reservoir
+      real(c_double), value :: dt, sink_rate ; integer(c_int), value :: convert_flux
     end function
     integer(c_int) function mom6x_diabatic_is_trivial(ctx) bind(C, name="mom6x_diabatic_is_trivial")
       import :: c_ptr, c_int

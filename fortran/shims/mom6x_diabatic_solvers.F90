@@ -8,7 +8,7 @@
 !! not replaced: a build points the `use ..., only : triDiagTS, triDiagTS_Eulerian` of MOM_diabatic_driver.F90:14-15 and
 !! the `use MOM_tracer_diabatic, only : tracer_vertdiff, tracer_vertdiff_Eulerian` of :71 and of the tracer packages
 !! (DOME_tracer.F90:21 ...) at this module instead -- a one-line change per `use`, INTEGRATION.md section 3.
-!! The sinking / bottom-reservoir forms of tracer_vertdiff (sink_rate, btm_reservoir) are not carried.
+!! The sinking / bottom-reservoir forms of tracer_vertdiff (sink_rate, btm_reservoir) are carried since round 4.
 module mom6x_diabatic_solvers
 use, intrinsic :: iso_c_binding
 use mom6x_c_api
@@ -69,19 +69,25 @@ subroutine tracer_vertdiff(h_old, ea, eb, dt, tr, G, GV, sfc_flux, btm_flux, btm
   real, dimension(SZI_(G),SZJ_(G)), optional,intent(inout) :: btm_reservoir
   real,                             optional,intent(in)    :: sink_rate
   logical,                          optional,intent(in)    :: convert_flux_in
-  type(c_ptr) :: ctx, d_tr, p_sfc, p_btm
+  type(c_ptr) :: ctx, d_tr, p_sfc, p_btm, p_res
   integer(c_int) :: rc, convert
-  if (present(btm_reservoir) .or. present(sink_rate)) call MOM_error(FATAL, &
-      "tracer_vertdiff: sink_rate / btm_reservoir are not carried by the MI355X path.")
   ctx = shim_ctx(G, GV)
-  p_sfc = c_null_ptr ; p_btm = c_null_ptr
+  p_sfc = c_null_ptr ; p_btm = c_null_ptr ; p_res = c_null_ptr
   if (present(sfc_flux)) p_sfc = shim_up2(5, sfc_flux, STG_H)
   if (present(btm_flux)) p_btm = shim_up2(6, btm_flux, STG_H)
   convert = 1 ; if (present(convert_flux_in)) convert = merge(1_c_int, 0_c_int, convert_flux_in)   ! default .true. (:64)
   d_tr = shim_up3(4, tr, STG_H, GV%ke)
-  rc = mom6x_tracer_vertdiff(ctx, shim_up3(1, h_old, STG_H, GV%ke), shim_up3(2, ea, STG_H, GV%ke), shim_up3(3, eb, STG_H, GV%ke), &
-                             real(dt, c_double), d_tr, p_sfc, p_btm, convert)
-  call shim_check(rc, "tracer_vertdiff")
+  if (present(sink_rate)) then       ! :123-179; btm_reservoir is only read (and updated) on this branch
+    if (present(btm_reservoir)) p_res = shim_up2(7, btm_reservoir, STG_H)
+    rc = mom6x_tracer_vertdiff_sink(ctx, shim_up3(1, h_old, STG_H, GV%ke), shim_up3(2, ea, STG_H, GV%ke), shim_up3(3, eb, STG_H, GV%ke), &
+                                    real(dt, c_double), d_tr, p_sfc, p_btm, p_res, real(sink_rate, c_double), convert)
+    call shim_check(rc, "tracer_vertdiff")
+    if (present(btm_reservoir)) call shim_down2(btm_reservoir, p_res, STG_H)
+  else
+    rc = mom6x_tracer_vertdiff(ctx, shim_up3(1, h_old, STG_H, GV%ke), shim_up3(2, ea, STG_H, GV%ke), shim_up3(3, eb, STG_H, GV%ke), &
+                               real(dt, c_double), d_tr, p_sfc, p_btm, convert)
+    call shim_check(rc, "tracer_vertdiff")
+  endif
   call shim_down3(tr, d_tr, STG_H, GV%ke)
 end subroutine tracer_vertdiff
 
@@ -97,19 +103,25 @@ subroutine tracer_vertdiff_Eulerian(h_old, ent, dt, tr, G, GV, sfc_flux, btm_flu
   real, dimension(SZI_(G),SZJ_(G)), optional,intent(inout) :: btm_reservoir
   real,                             optional,intent(in)    :: sink_rate
   logical,                          optional,intent(in)    :: convert_flux_in
-  type(c_ptr) :: ctx, d_tr, p_sfc, p_btm
+  type(c_ptr) :: ctx, d_tr, p_sfc, p_btm, p_res
   integer(c_int) :: rc, convert
-  if (present(btm_reservoir) .or. present(sink_rate)) call MOM_error(FATAL, &
-      "tracer_vertdiff_Eulerian: sink_rate / btm_reservoir are not carried by the MI355X path.")
   ctx = shim_ctx(G, GV)
-  p_sfc = c_null_ptr ; p_btm = c_null_ptr
+  p_sfc = c_null_ptr ; p_btm = c_null_ptr ; p_res = c_null_ptr
   if (present(sfc_flux)) p_sfc = shim_up2(5, sfc_flux, STG_H)
   if (present(btm_flux)) p_btm = shim_up2(6, btm_flux, STG_H)
   convert = 1 ; if (present(convert_flux_in)) convert = merge(1_c_int, 0_c_int, convert_flux_in)
   d_tr = shim_up3(4, tr, STG_H, GV%ke)
-  rc = mom6x_tracer_vertdiff_Eulerian(ctx, shim_up3(1, h_old, STG_H, GV%ke), shim_up3(2, ent, STG_H, GV%ke + 1), &
-                                      real(dt, c_double), d_tr, p_sfc, p_btm, convert)
-  call shim_check(rc, "tracer_vertdiff_Eulerian")
+  if (present(sink_rate)) then       ! :315-380
+    if (present(btm_reservoir)) p_res = shim_up2(7, btm_reservoir, STG_H)
+    rc = mom6x_tracer_vertdiff_Eulerian_sink(ctx, shim_up3(1, h_old, STG_H, GV%ke), shim_up3(2, ent, STG_H, GV%ke + 1), &
+                                             real(dt, c_double), d_tr, p_sfc, p_btm, p_res, real(sink_rate, c_double), convert)
+    call shim_check(rc, "tracer_vertdiff_Eulerian")
+    if (present(btm_reservoir)) call shim_down2(btm_reservoir, p_res, STG_H)
+  else
+    rc = mom6x_tracer_vertdiff_Eulerian(ctx, shim_up3(1, h_old, STG_H, GV%ke), shim_up3(2, ent, STG_H, GV%ke + 1), &
+                                        real(dt, c_double), d_tr, p_sfc, p_btm, convert)
+    call shim_check(rc, "tracer_vertdiff_Eulerian")
+  endif
   call shim_down3(tr, d_tr, STG_H, GV%ke)
 end subroutine tracer_vertdiff_Eulerian
 

@@ -690,12 +690,21 @@ int mom6x_triDiagTS(mom6x_ctx *ctx, int is, int ie, int js, int je, const double
 int mom6x_triDiagTS_Eulerian(mom6x_ctx *ctx, int is, int ie, int js, int je, const double *hold, const double *ent,
                              double *T, double *S);
 /* tracer_vertdiff(h_old, ea, eb, dt, tr, G, GV, sfc_flux, btm_flux, btm_reservoir, sink_rate, convert_flux_in)
- * MOM_tracer_diabatic.F90:25 -- the branch without sink_rate / btm_reservoir (:181-214).            */
+ * MOM_tracer_diabatic.F90:25 -- the branch without sink_rate (:181-214; btm_reservoir is only read with sink_rate).   */
 int mom6x_tracer_vertdiff(mom6x_ctx *ctx, const double *h_old, const double *ea, const double *eb, double dt,
                           double *tr, const double *sfc_flux, const double *btm_flux, int convert_flux);
 /* tracer_vertdiff_Eulerian(h_old, ent, dt, tr, G, GV, ...)         :224 (no-sink branch :382-414).     */
 int mom6x_tracer_vertdiff_Eulerian(mom6x_ctx *ctx, const double *h_old, const double *ent, double dt, double *tr,
                                    const double *sfc_flux, const double *btm_flux, int convert_flux);
+/* The same two routines WITH sink_rate (:123-179 / :315-380): the tracer sinks through the interfaces by up to sink_rate * dt,
+ * limited so that characteristics do not cross within the step; with btm_reservoir (nullable = not present) the sinking is not
+ * limited and what leaves the bottom layer is added to btm_reservoir [CU R Z].                                           */
+int mom6x_tracer_vertdiff_sink(mom6x_ctx *ctx, const double *h_old, const double *ea, const double *eb, double dt,
+                               double *tr, const double *sfc_flux, const double *btm_flux, double *btm_reservoir,
+                               double sink_rate, int convert_flux);
+int mom6x_tracer_vertdiff_Eulerian_sink(mom6x_ctx *ctx, const double *h_old, const double *ent, double dt, double *tr,
+                                        const double *sfc_flux, const double *btm_flux, double *btm_reservoir,
+                                        double sink_rate, int convert_flux);
 /* diabatic (MOM_diabatic_driver.F90:277) is a host-side dispatcher over mixing physics that is out of
  * scope; its only device-relevant behaviour is the early return for GV%ke == 1 (:330) -- the solvers
  * above are what it (and the tracer packages, e.g. DOME_tracer.F90:338) call.                       */

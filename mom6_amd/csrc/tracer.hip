@@ -550,6 +550,64 @@ k_tridiag(Dm d, const double *__restrict__ G, const double *__restrict__ hold, c
   }
 }
 
+// tracer_vertdiff with sink_rate :123-179 (and tracer_vertdiff_Eulerian's :315-380 with ea = ent(K), eb = ent(K+1)): one column per
+// thread.  The limited sinking distances are a bottom-up recurrence and the solve runs top-down, so the first sweep leaves sink(K)
+// and h_minus_dsink(k) in two scratch arrays (a tracer package's call, not on the benchmark's path: the plain form of k_tridiag).
+__global__ void __launch_bounds__(256)
+k_tridiag_sink(Dm d, const double *__restrict__ G, const double *__restrict__ hold, const double *__restrict__ ea,
+               const double *__restrict__ eb, double *__restrict__ T, double *__restrict__ c1, double *__restrict__ snk, double *__restrict__ hmd,
+               double h_neglect, const double *__restrict__ sfc_flux, const double *__restrict__ btm_flux, double flux_scale,
+               double *__restrict__ btm_reservoir, double sink_dist, double H_to_RZ) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  const int nz = d.nk;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  if (!(gm(G, d, MOM6X_G_mask2dT)[x] > 0.0)) return;      // (the reference forms sink on land too; nothing there reads it)
+  double sfc_src = 0.0, btm_src = 0.0;
+  if (sfc_flux) sfc_src = (flux_scale != 0.0) ? (sfc_flux[x] * flux_scale) : sfc_flux[x];
+  if (btm_flux) btm_src = (flux_scale != 0.0) ? (btm_flux[x] * flux_scale) : btm_flux[x];
+  // ---- sinking distances at the interfaces K = nz .. 1 (snk[k] <-> the top of layer k) :127-149
+  double s_below = btm_reservoir ? sink_dist : 0.0;        // sink(nz+1)
+  const double s_bottom = s_below;
+  for (int k = nz - 1; k >= 1; k--) {
+    const size_t c = x + (size_t)k * slab;
+    const double h = hold[c];
+    double sk, hm;
+    if (btm_reservoir) { sk = sink_dist; hm = h; }
+    else if (s_below >= sink_dist) { sk = sink_dist; hm = h + (s_below - sk); }
+    else if (s_below + h < sink_dist) { sk = s_below + h; hm = 0.0; }
+    else { sk = sink_dist; hm = (h + s_below) - sk; }
+    snk[c] = sk; hmd[c] = hm;
+    s_below = sk;
+  }
+  // ---- the solve :155-179
+  double b_denom_1 = (hold[x] + s_below) + ea[x] + h_neglect;   // h_minus_dsink(1) = h_old(1) + sink(2)
+  double b1 = 1.0 / (b_denom_1 + eb[x]);
+  double d1 = b_denom_1 * b1;
+  double h_tr = hold[x] + h_neglect;
+  double prev = (b1 * h_tr) * T[x] + b1 * sfc_src;
+  T[x] = prev;
+  for (int k = 1; k < nz; k++) {
+    const size_t c = x + (size_t)k * slab;
+    c1[c] = eb[c - slab] * b1;
+    const double es = ea[c] + snk[c];
+    b_denom_1 = hmd[c] + d1 * es + h_neglect;
+    b1 = 1.0 / (b_denom_1 + eb[c]);
+    d1 = b_denom_1 * b1;
+    h_tr = hold[c] + h_neglect;
+    if (k == nz - 1) prev = b1 * ((h_tr * T[c] + btm_src) + es * prev);
+    else prev = b1 * (h_tr * T[c] + es * prev);
+    T[c] = prev;
+  }
+  if (btm_reservoir) btm_reservoir[x] = btm_reservoir[x] + (s_bottom * prev) * H_to_RZ;
+  for (int k = nz - 2; k >= 0; k--) {
+    const size_t c = x + (size_t)k * slab;
+    prev = T[c] + c1[c + slab] * prev;
+    T[c] = prev;
+  }
+}
+
 }  // namespace
 
 void ta_state_free(mom6x_ctx *c) {
@@ -591,8 +649,21 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
                                    double *uhr_out, double *vhr_out, int *iters_out) {
   REQUIRE(c && c->ta, MOM6X_EINVAL, "MOM_tracer_advect: tracer_advect_init must be called before advect_tracer.");
   REQUIRE(h_end && uhtr && vhtr && (ntr == 0 || tracers), MOM6X_EINVAL, "advect_tracer: null array");
-  REQUIRE(ntr <= MAXTR, MOM6X_EUNSUPPORTED, "advect_tracer: at most 8 tracers per call");
   if (ntr == 0) return MOM6X_OK;
+  if (ntr > MAXTR) {
+    // The reference's tracer registry has no upper bound.  The kernels carry up to MAXTR tracers through one pass over hprev and
+    // the remaining transports; a longer list is advected MAXTR at a time, each group through the whole iteration from the same
+    // h_end, uhtr, vhtr: the evolution of hprev, uhr, vhr and of the row / layer flags does not depend on the tracers, so every
+    // tracer gets the bits it would get in one pass (and the groups' leftover transports are identical).
+    int rc = MOM6X_OK;
+    for (int m0 = 0; m0 < ntr && rc == MOM6X_OK; m0 += MAXTR) {
+      const int n = (ntr - m0 < MAXTR) ? (ntr - m0) : MAXTR;
+      const bool last = (m0 + n >= ntr);
+      rc = mom6x_advect_tracer(c, h_end, uhtr, vhtr, dt, tracers + m0, schemes ? schemes + m0 : nullptr, n, x_first_in, max_iter_in,
+                               last ? uhr_out : nullptr, last ? vhr_out : nullptr, iters_out);
+    }
+    return rc;
+  }
   HIPCHK(hipSetDevice(c->device));
   TAState *s = (TAState *)c->ta;
   const Dm d = c->d;
@@ -873,6 +944,31 @@ extern "C" int mom6x_tracer_vertdiff_Eulerian(mom6x_ctx *c, const double *h_old,
                                               const double *sfc_flux, const double *btm_flux, int convert_flux) {
   REQUIRE(ent, MOM6X_EINVAL, "tracer_vertdiff_Eulerian: null ent");
   return mom6x_tracer_vertdiff(c, h_old, ent, ent + c->dims.slab, dt, tr, sfc_flux, btm_flux, convert_flux);
+}
+// tracer_vertdiff(..., btm_reservoir, sink_rate, ...) with sink_rate present (:123-179); btm_reservoir may be null
+extern "C" int mom6x_tracer_vertdiff_sink(mom6x_ctx *c, const double *h_old, const double *ea, const double *eb, double dt, double *tr,
+                                          const double *sfc_flux, const double *btm_flux, double *btm_reservoir, double sink_rate,
+                                          int convert_flux) {
+  REQUIRE(c && h_old && ea && eb && tr, MOM6X_EINVAL, "tracer_vertdiff: null array");
+  if (c->dims.nk == 1) return MOM6X_OK;   // the reference warns and returns
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  double *c1, *snk, *hmd;
+  int rc;
+  if ((rc = ctx_scratch(c, SCR_c1, d.nk, &c1)) || (rc = ctx_scratch(c, SCR_t0, d.nk, &snk)) || (rc = ctx_scratch(c, SCR_t1, d.nk, &hmd))) return rc;
+  const double scale = convert_flux ? dt * c->GV.RZ_to_H : 0.0;
+  const double sink_dist = (dt * sink_rate) * c->GV.Z_to_H;
+  const dim3 b = blk2();
+  KLAUNCH(c, "k_tridiag_sink", k_tridiag_sink, grid3(d.ni, d.nj, 1, b), b, d, c->G, h_old, ea, eb, tr, c1, snk, hmd, c->GV.H_subroundoff,
+          sfc_flux, btm_flux, scale, btm_reservoir, sink_dist, c->GV.H_to_RZ);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+extern "C" int mom6x_tracer_vertdiff_Eulerian_sink(mom6x_ctx *c, const double *h_old, const double *ent, double dt, double *tr,
+                                                   const double *sfc_flux, const double *btm_flux, double *btm_reservoir,
+                                                   double sink_rate, int convert_flux) {
+  REQUIRE(c && ent, MOM6X_EINVAL, "tracer_vertdiff_Eulerian: null ent");
+  return mom6x_tracer_vertdiff_sink(c, h_old, ent, ent + c->dims.slab, dt, tr, sfc_flux, btm_flux, btm_reservoir, sink_rate, convert_flux);
 }
 // diabatic(u, v, h, tv, BLD, fluxes, visc, ADp, CDp, dt, Time_end, G, GV, US, CS, ...)  diabatic_driver.F90:277
 // Only the part of the dispatcher that is on the ported path: with GV%ke == 1 it returns immediately (:330),

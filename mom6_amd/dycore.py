@@ -520,6 +520,19 @@ class Dycore:
         check(self.lib, self.lib.mom6x_tracer_vertdiff(self.ctx, _ptr(h_old), _ptr(ea), _ptr(eb), C.c_double(dt), _ptr(tr),
                                                        _ptr(sfc_flux), _ptr(btm_flux), C.c_int(int(convert_flux))))
 
+    def tracer_vertdiff_sink(self, h_old, ea, eb, dt, tr, sink_rate, sfc_flux=None, btm_flux=None, btm_reservoir=None, convert_flux=True,
+                             eulerian=False):
+        """tracer_vertdiff / tracer_vertdiff_Eulerian (ea = ent, eb ignored) with sink_rate, optionally btm_reservoir
+        (MOM_tracer_diabatic.F90:123-179 / :315-380)."""
+        if eulerian:
+            check(self.lib, self.lib.mom6x_tracer_vertdiff_Eulerian_sink(self.ctx, _ptr(h_old), _ptr(ea), C.c_double(dt), _ptr(tr), _ptr(sfc_flux),
+                                                                         _ptr(btm_flux), _ptr(btm_reservoir), C.c_double(sink_rate),
+                                                                         C.c_int(int(convert_flux))))
+        else:
+            check(self.lib, self.lib.mom6x_tracer_vertdiff_sink(self.ctx, _ptr(h_old), _ptr(ea), _ptr(eb), C.c_double(dt), _ptr(tr), _ptr(sfc_flux),
+                                                                _ptr(btm_flux), _ptr(btm_reservoir), C.c_double(sink_rate),
+                                                                C.c_int(int(convert_flux))))
+
     def tracer_vertdiff_Eulerian(self, h_old, ent, dt, tr, sfc_flux=None, btm_flux=None, convert_flux=True):
         """tracer_vertdiff_Eulerian (MOM_tracer_diabatic.F90:224), no-sinking branch."""
         check(self.lib, self.lib.mom6x_tracer_vertdiff_Eulerian(self.ctx, _ptr(h_old), _ptr(ent), C.c_double(dt), _ptr(tr),

@@ -535,6 +535,12 @@ def tracer_vertdiff(d, G, GV, h_old, ea, eb, dt, tr, sfc_flux=None, btm_flux=Non
 _EFP_FATAL = {1: "NaN in input field of reproducing_sum", 2: "Overflow in reproducing_sum conversion", 3: "Overflow in reproducing_sum"}
 
 
+def tracer_vertdiff_sink(d, G, GV, h_old, ea, eb, dt, tr, sink_rate, sfc_flux=None, btm_flux=None, btm_reservoir=None, convert_flux=True):
+    """tracer_vertdiff / tracer_vertdiff_Eulerian with sink_rate (MOM_tracer_diabatic.F90:123-179 / :315-380)."""
+    assert lib().orc_tracer_vertdiff_sink(C.byref(d), _p(G), C.byref(GV), _p(h_old), _p(ea), _p(eb), C.c_double(dt), _p(tr), _p(sfc_flux),
+                                          _p(btm_flux), _p(btm_reservoir), C.c_double(sink_rate), C.c_int(int(convert_flux))) == 0
+
+
 def reproducing_sum(d, array, is_=None, ie=None, js=None, je=None, unscale=1.0, layer_sums=False, want_err=False):
     """reproducing_sum_3d (array of nk planes) or reproducing_sum_2d (one plane).  Returns a dict: sum, [sums], EFP
     (int64[6]), [EFP_lay (int64[nk,6])], [err]."""

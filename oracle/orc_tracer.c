@@ -403,3 +403,76 @@ int orc_tracer_vertdiff(const mom6x_dims *d, const double *G, const mom6x_vgrid 
   free(c1);
   return MOM6X_OK;
 }
+
+
+/* tracer_vertdiff WITH sink_rate (:123-179) and, with ea = ent(:,:,K), eb = ent(:,:,K+1), tracer_vertdiff_Eulerian's sinking branch
+ * (:315-380): the sinking distances at the interfaces, limited so that characteristics do not cross within the step (or, with a
+ * bottom reservoir, unlimited: what leaves the bottom layer is collected in btm_reservoir), then the tridiagonal solve with the
+ * sinking flux on the lower diagonal.  btm_reservoir may be NULL (not present).  TEST INFRASTRUCTURE like the rest of oracle/. */
+int orc_tracer_vertdiff_sink(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const double *h_old,
+                             const double *ea, const double *eb, double dt, double *tr, const double *sfc_flux,
+                             const double *btm_flux, double *btm_reservoir, double sink_rate, int convert_flux) {
+  const int nz = d->nk;
+  const size_t slab = (size_t)d->slab;
+  const double *mT = GM(G, d, MOM6X_G_mask2dT);
+  const double h_neglect = GV->H_subroundoff;
+  if (nz == 1) return MOM6X_OK;
+  const double sink_dist = (dt * sink_rate) * GV->Z_to_H;
+  double *c1 = (double *)calloc((size_t)nz + 1, sizeof(double));
+  double *sink = (double *)calloc((size_t)nz + 2, sizeof(double));     /* sink[K], K = 0 .. nz (interface K is the top of layer K) */
+  double *hmd = (double *)calloc((size_t)nz + 1, sizeof(double));      /* h_minus_dsink */
+  for (int j = 0; j < d->nj; j++) for (int i = 0; i < d->ni; i++) {
+    size_t x = IX2(d, i, j);
+    double sfc_src = 0.0, btm_src = 0.0;
+    if (sfc_flux) sfc_src = convert_flux ? (sfc_flux[x] * dt) * GV->RZ_to_H : sfc_flux[x];
+    if (btm_flux) btm_src = convert_flux ? (btm_flux[x] * dt) * GV->RZ_to_H : btm_flux[x];
+    if (btm_reservoir) {
+      sink[nz] = sink_dist;
+      for (int k = 1; k < nz; k++) { sink[k] = sink_dist; hmd[k] = h_old[x + k * slab]; }
+    } else {
+      sink[nz] = 0.0;
+      for (int k = nz - 1; k >= 1; k--) {
+        const double h = h_old[x + k * slab];
+        if (sink[k + 1] >= sink_dist) {
+          sink[k] = sink_dist;
+          hmd[k] = h + (sink[k + 1] - sink[k]);
+        } else if (sink[k + 1] + h < sink_dist) {
+          sink[k] = sink[k + 1] + h;
+          hmd[k] = 0.0;
+        } else {
+          sink[k] = sink_dist;
+          hmd[k] = (h + sink[k + 1]) - sink[k];
+        }
+      }
+    }
+    sink[0] = 0.0; hmd[0] = (h_old[x] + sink[1]);
+    if (!(mT[x] > 0.0)) continue;
+    double b_denom_1 = hmd[0] + ea[x] + h_neglect;
+    double b1 = 1.0 / (b_denom_1 + eb[x]);
+    double d1 = b_denom_1 * b1;
+    double h_tr = h_old[x] + h_neglect;
+    tr[x] = (b1 * h_tr) * tr[x] + b1 * sfc_src;
+    for (int k = 1; k < nz - 1; k++) {
+      size_t c = x + k * slab;
+      c1[k] = eb[c - slab] * b1;
+      b_denom_1 = hmd[k] + d1 * (ea[c] + sink[k]) + h_neglect;
+      b1 = 1.0 / (b_denom_1 + eb[c]);
+      d1 = b_denom_1 * b1;
+      h_tr = h_old[c] + h_neglect;
+      tr[c] = b1 * (h_tr * tr[c] + (ea[c] + sink[k]) * tr[c - slab]);
+    }
+    {
+      const int k = nz - 1;
+      size_t c = x + (size_t)k * slab;
+      c1[k] = eb[c - slab] * b1;
+      b_denom_1 = hmd[k] + d1 * (ea[c] + sink[k]) + h_neglect;
+      b1 = 1.0 / (b_denom_1 + eb[c]);
+      h_tr = h_old[c] + h_neglect;
+      tr[c] = b1 * ((h_tr * tr[c] + btm_src) + (ea[c] + sink[k]) * tr[c - slab]);
+      if (btm_reservoir) btm_reservoir[x] = btm_reservoir[x] + (sink[nz] * tr[c]) * GV->H_to_RZ;
+    }
+    for (int k = nz - 2; k >= 0; k--) tr[x + k * slab] = tr[x + k * slab] + c1[k + 1] * tr[x + (k + 1) * slab];
+  }
+  free(c1); free(sink); free(hmd);
+  return MOM6X_OK;
+}
