@@ -13,6 +13,7 @@ module mom6x_c_api
   public :: mom6x_PressureForce_set_tv, mom6x_vertvisc_params, mom6x_vertvisc_init, mom6x_vertvisc_set_visc, mom6x_vertvisc_coef
   public :: mom6x_hor_visc_params, mom6x_hor_visc_init, mom6x_horizontal_viscosity, mom6x_vertvisc_set_direct_stress
   public :: mom6x_remapping_params, mom6x_ALE_remap_tracers, mom6x_ALE_remap_set_h_vel, mom6x_ALE_remap_velocities
+  public :: mom6x_ALE_remap_velocities_conserve_ke
   public :: mom6x_remapping_core_h, mom6x_regrid_zstar_params, mom6x_ALE_regrid_zstar
   public :: mom6x_regrid_rho_params, mom6x_ALE_regrid_rho, mom6x_ALE_regrid_hycom1, mom6x_ALE_convective_adjustment
   public :: mom6x_chksum_result, mom6x_sum_output_params, mom6x_energy_sums, mom6x_reproducing_sum_3d, mom6x_reproducing_sum_2d
@@ -320,6 +321,12 @@ module mom6x_c_api
     !> ALE_remap_velocities (MOM_ALE.F90:1089)
     integer(c_int) function mom6x_ALE_remap_velocities(ctx, p, h_old_u, h_old_v, h_new_u, h_new_v, u, v) &
         bind(C, name="mom6x_ALE_remap_velocities")
+      import :: c_ptr, c_int, mom6x_remapping_params
+      type(c_ptr), value :: ctx, h_old_u, h_old_v, h_new_u, h_new_v, u, v ; type(mom6x_remapping_params), intent(in) :: p
+    end function
+    !> ... with REMAP_VEL_CONSERVE_KE and allow_preserve_variance (MOM_ALE.F90:1166-1195)
+    integer(c_int) function mom6x_ALE_remap_velocities_conserve_ke(ctx, p, h_old_u, h_old_v, h_new_u, h_new_v, u, v) &
+        bind(C, name="mom6x_ALE_remap_velocities_conserve_ke")
       import :: c_ptr, c_int, mom6x_remapping_params
       type(c_ptr), value :: ctx, h_old_u, h_old_v, h_new_u, h_new_v, u, v ; type(mom6x_remapping_params), intent(in) :: p
     end function

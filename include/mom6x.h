@@ -514,6 +514,11 @@ int mom6x_ALE_remap_set_h_vel(mom6x_ctx *ctx, const double *h_new, double *h_u, 
 /* ALE_remap_velocities :1089 (REMAP_VEL_CONSERVE_KE off, no near-bottom masking, no diagnostics).              */
 int mom6x_ALE_remap_velocities(mom6x_ctx *ctx, const mom6x_remapping_params *p, const double *h_old_u, const double *h_old_v,
                                const double *h_new_u, const double *h_new_v, double *u, double *v);
+/* ... with the KE-conserving correction of its baroclinic part (REMAP_VEL_CONSERVE_KE = True and allow_preserve_variance,
+ * MOM_ALE.F90:1166-1195, :1240-1270): what MOM.F90 asks for inside the time step.                                          */
+int mom6x_ALE_remap_velocities_conserve_ke(mom6x_ctx *ctx, const mom6x_remapping_params *p, const double *h_old_u,
+                                           const double *h_old_v, const double *h_new_u, const double *h_new_v,
+                                           double *u, double *v);
 /* ALE_regrid (MOM_ALE.F90:518) -> regridding_main (MOM_regridding.F90:862) for REGRIDDING_ZSTAR without ice shelves
  * and with CS%nk == GV%ke (Boussinesq): nom_depth_H :920-922, build_zstar_grid :1257 (build_zstar_column,
  * coord_zlike.F90:63; filtered_grid_motion :1105 incl. the old-grid weight and its depth-dependent transition),

@@ -90,6 +90,7 @@ struct mom6x_ctx {
   mom6x_hor_visc_params hv; bool hv_init; double *hv_planes;
   double ds_Hmix; const double *ds_h;   // DIRECT_STRESS: HMIX_STRESS (0 = off) and vertvisc's h argument
   double *regrid_res;       // remap.hip: coordinateResolution of the z* coordinate (nk)
+  double *remap_src;        // remap.hip: the un-remapped velocity of ALE_remap_velocities' KE-conserving correction (allocated on first use)
   double *regrid_vec;       // remap.hip: the host vectors of the density coordinates (resolution | targets | max depths | max thicknesses)
   // lazily allocated 3-D scratch arrays (slot -> nlev levels)
   double *scr[MOM6X_NSCR]; int scr_nlev[MOM6X_NSCR];

@@ -1655,13 +1655,65 @@ extern "C" int mom6x_ALE_remap_set_h_vel(mom6x_ctx *c, const double *h_new, doub
   return MOM6X_OK;
 }
 
-extern "C" int mom6x_ALE_remap_velocities(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old_u, const double *h_old_v,
-                                          const double *h_new_u, const double *h_new_v, double *u, double *v) {
+// The KE-conserving correction of ALE_remap_velocities :1166-1195 (REMAP_VEL_CONSERVE_KE with allow_preserve_variance): one thread
+// per velocity column, three walks over k in the reference's order (u_bt and sum(h2); the two baroclinic KE integrals; the rescaling).
+__global__ void __launch_bounds__(256)
+k_remap_conserve_ke(Dm d, const double *__restrict__ G, int mask_plane, int i0, int i1, int j0, int j1, const double *__restrict__ h1,
+                    const double *__restrict__ h2, const double *__restrict__ u_src, double *__restrict__ u_tgt, double H_subroundoff) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > i1 || j > j1) return;
+  const size_t x = ix2(d, i, j), slab = (size_t)d.slab;
+  if (!(gm(G, d, mask_plane)[x] > 0.0)) return;
+  const int nz = d.nk;
+  double u_bt = 0.0, hsum = 0.0;
+  for (int k = 0; k < nz; k++) { const size_t c = x + (size_t)k * slab; u_bt = u_bt + h2[c] * u_tgt[c]; hsum = hsum + h2[c]; }
+  u_bt = u_bt / (hsum + H_subroundoff);
+  double ke_c_src = 0.0, ke_c_tgt = 0.0;
+  for (int k = 0; k < nz; k++) {
+    const size_t c = x + (size_t)k * slab;
+    const double a = u_src[c] - u_bt, b = u_tgt[c] - u_bt;
+    ke_c_src = ke_c_src + h1[c] * (a * a);
+    ke_c_tgt = ke_c_tgt + h2[c] * (b * b);
+  }
+  // (the 25 % cap on the amplification of the baroclinic part, :1182-1191)
+  const double rescale_coef = (ke_c_src < 1.5625 * ke_c_tgt) ? sqrt(ke_c_src / ke_c_tgt) : 1.25;
+  for (int k = 0; k < nz; k++) { const size_t c = x + (size_t)k * slab; u_tgt[c] = u_bt + rescale_coef * (u_tgt[c] - u_bt); }
+}
+
+static int remap_velocities(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old_u, const double *h_old_v,
+                            const double *h_new_u, const double *h_new_v, double *u, double *v, bool conserve_ke) {
   REQUIRE(c && p && h_old_u && h_old_v && h_new_u && h_new_v && u && v, MOM6X_EINVAL, "ALE_remap_velocities: null argument");
   HIPCHK(hipSetDevice(c->device));
-  int rc = remap_field(c, p, MOM6X_G_mask2dCu, -1, c->d.ni - 1, 0, c->d.nj - 1, h_old_u, h_new_u, u);
+  const Dm d = c->d;
+  const size_t n3 = (size_t)d.slab * d.nk;
+  if (conserve_ke && !c->remap_src) HIPCHK(hipMalloc(&c->remap_src, n3 * sizeof(double)));   // the source column of the correction
+  const dim3 b(64, 4, 1);
+  if (conserve_ke) HIPCHK(hipMemcpyAsync(c->remap_src, u, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  int rc = remap_field(c, p, MOM6X_G_mask2dCu, -1, d.ni - 1, 0, d.nj - 1, h_old_u, h_new_u, u);
   if (rc) return rc;
-  return remap_field(c, p, MOM6X_G_mask2dCv, 0, c->d.ni - 1, -1, c->d.nj - 1, h_old_v, h_new_v, v);
+  if (conserve_ke)
+    KLAUNCH(c, "k_remap_conserve_ke", k_remap_conserve_ke, grid3(d.ni + 1, d.nj, 1, b), b, d, c->G, (int)MOM6X_G_mask2dCu, -1, d.ni - 1, 0, d.nj - 1,
+            h_old_u, h_new_u, (const double *)c->remap_src, u, c->GV.H_subroundoff);
+  if (conserve_ke) HIPCHK(hipMemcpyAsync(c->remap_src, v, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  rc = remap_field(c, p, MOM6X_G_mask2dCv, 0, d.ni - 1, -1, d.nj - 1, h_old_v, h_new_v, v);
+  if (rc) return rc;
+  if (conserve_ke)
+    KLAUNCH(c, "k_remap_conserve_ke", k_remap_conserve_ke, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, (int)MOM6X_G_mask2dCv, 0, d.ni - 1, -1, d.nj - 1,
+            h_old_v, h_new_v, (const double *)c->remap_src, v, c->GV.H_subroundoff);
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+
+extern "C" int mom6x_ALE_remap_velocities(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old_u, const double *h_old_v,
+                                          const double *h_new_u, const double *h_new_v, double *u, double *v) {
+  return remap_velocities(c, p, h_old_u, h_old_v, h_new_u, h_new_v, u, v, false);
+}
+// ... with allow_preserve_variance = .true. and REMAP_VEL_CONSERVE_KE (CS%conserve_ke, MOM_ALE.F90:331): MOM.F90's call in the time step
+extern "C" int mom6x_ALE_remap_velocities_conserve_ke(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old_u,
+                                                      const double *h_old_v, const double *h_new_u, const double *h_new_v, double *u,
+                                                      double *v) {
+  return remap_velocities(c, p, h_old_u, h_old_v, h_new_u, h_new_v, u, v, true);
 }
 
 extern "C" int mom6x_ALE_regrid_zstar(mom6x_ctx *c, const mom6x_regrid_zstar_params *p, const double *coordinateResolution,

@@ -296,10 +296,10 @@ class Dycore:
         """ALE_remap_set_h_vel (MOM_ALE.F90:882)."""
         check(self.lib, self.lib.mom6x_ALE_remap_set_h_vel(self.ctx, _ptr(h_new), _ptr(h_u), _ptr(h_v)))
 
-    def ALE_remap_velocities(self, CS, h_old_u, h_old_v, h_new_u, h_new_v, u, v):
-        """ALE_remap_velocities (MOM_ALE.F90:1089)."""
-        check(self.lib, self.lib.mom6x_ALE_remap_velocities(self.ctx, C.byref(CS), _ptr(h_old_u), _ptr(h_old_v), _ptr(h_new_u),
-                                                            _ptr(h_new_v), _ptr(u), _ptr(v)))
+    def ALE_remap_velocities(self, CS, h_old_u, h_old_v, h_new_u, h_new_v, u, v, conserve_ke=False):
+        """ALE_remap_velocities (MOM_ALE.F90:1089); conserve_ke: REMAP_VEL_CONSERVE_KE with allow_preserve_variance (:1166-1195)."""
+        f = self.lib.mom6x_ALE_remap_velocities_conserve_ke if conserve_ke else self.lib.mom6x_ALE_remap_velocities
+        check(self.lib, f(self.ctx, C.byref(CS), _ptr(h_old_u), _ptr(h_old_v), _ptr(h_new_u), _ptr(h_new_v), _ptr(u), _ptr(v)))
 
     def ALE_regrid_zstar(self, CS, coordinateResolution, h, h_new, dzRegrid):
         """ALE_regrid (MOM_ALE.F90:518) for the z* coordinate; coordinateResolution: nk host values [Z]."""

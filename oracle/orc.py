@@ -309,6 +309,12 @@ def ALE_remap_velocities(d, G, CS, h_old_u, h_old_v, h_new_u, h_new_v, u, v):
         raise RuntimeError(f"orc_ALE_remap_velocities rc={rc}")
 
 
+def ALE_remap_velocities_conserve_ke(d, G, GV, CS, h_old_u, h_old_v, h_new_u, h_new_v, u, v):
+    """ALE_remap_velocities with REMAP_VEL_CONSERVE_KE and allow_preserve_variance (MOM_ALE.F90:1166-1195)."""
+    assert lib().orc_ALE_remap_velocities_conserve_ke(C.byref(d), _p(G), C.byref(CS), C.c_double(GV.H_subroundoff), _p(h_old_u), _p(h_old_v),
+                                                      _p(h_new_u), _p(h_new_v), _p(u), _p(v)) == 0
+
+
 def ALE_regrid_zstar(d, G, GV, CS, coordinateResolution, h, h_new, dzRegrid):
     cr = np.ascontiguousarray(coordinateResolution, dtype=np.float64)
     rc = lib().orc_ALE_regrid_zstar(C.byref(d), _p(G), C.byref(GV), C.byref(CS), _p(cr), _p(h), _p(h_new), _p(dzRegrid))

@@ -10,6 +10,7 @@
  *
  * Arrays are 1-based inside this file (index 0 unused) so that the index arithmetic of intersect_src_tgt_grids and
  * the sub-cell loops reads exactly as in the reference. */
+#include <math.h>
 #include "orc_common.h"
 #include <float.h>
 
@@ -600,6 +601,49 @@ int orc_ALE_remap_velocities(const mom6x_dims *d, const double *G, const mom6x_r
   int rc = remap_points(d, GM(G, d, MOM6X_G_mask2dCu), -1, d->ni - 1, 0, d->nj - 1, CS, h_old_u, h_new_u, u);
   if (rc) return rc;
   return remap_points(d, GM(G, d, MOM6X_G_mask2dCv), 0, d->ni - 1, -1, d->nj - 1, CS, h_old_v, h_new_v, v);
+}
+
+/* The KE-conserving correction of ALE_remap_velocities (MOM_ALE.F90:1166-1195; REMAP_VEL_CONSERVE_KE with
+ * allow_preserve_variance): the baroclinic part of the remapped column is rescaled so that its vertically integrated square equals
+ * the source column's, by at most 25 %.  One velocity component: faces (i0..i1, j0..j1) with mask > 0. */
+static void conserve_ke_points(const mom6x_dims *d, const double *mask, int i0, int i1, int j0, int j1, const double *h1, const double *h2,
+                               const double *u_src, double *u_tgt, double H_subroundoff) {
+  const int nz = d->nk;
+  const size_t slab = (size_t)d->slab;
+  for (int j = j0; j <= j1; j++) for (int i = i0; i <= i1; i++) {
+    const size_t x = IX2(d, i, j);
+    if (!(mask[x] > 0.0)) continue;
+    double u_bt = 0.0, hsum = 0.0;
+    for (int k = 0; k < nz; k++) u_bt = u_bt + h2[x + k * slab] * u_tgt[x + k * slab];
+    for (int k = 0; k < nz; k++) hsum = hsum + h2[x + k * slab];          /* sum(h2(1:nz)) */
+    u_bt = u_bt / (hsum + H_subroundoff);
+    double ke_c_src = 0.0, ke_c_tgt = 0.0;
+    for (int k = 0; k < nz; k++) {
+      const double a = u_src[x + k * slab] - u_bt, b = u_tgt[x + k * slab] - u_bt;
+      ke_c_src = ke_c_src + h1[x + k * slab] * (a * a);
+      ke_c_tgt = ke_c_tgt + h2[x + k * slab] * (b * b);
+    }
+    double rescale_coef;
+    if (ke_c_src < 1.5625 * ke_c_tgt) rescale_coef = sqrt(ke_c_src / ke_c_tgt);
+    else rescale_coef = 1.25;
+    for (int k = 0; k < nz; k++) u_tgt[x + k * slab] = u_bt + rescale_coef * (u_tgt[x + k * slab] - u_bt);
+  }
+}
+
+/* ALE_remap_velocities with allow_preserve_variance and CS%conserve_ke (:1166-1195, :1240-1270) */
+int orc_ALE_remap_velocities_conserve_ke(const mom6x_dims *d, const double *G, const mom6x_remapping_params *CS, double H_subroundoff,
+                                         const double *h_old_u, const double *h_old_v, const double *h_new_u, const double *h_new_v,
+                                         double *u, double *v) {
+  const size_t n3 = (size_t)d->slab * d->nk;
+  double *us = (double *)malloc(n3 * sizeof(double)), *vs = (double *)malloc(n3 * sizeof(double));
+  memcpy(us, u, n3 * sizeof(double)); memcpy(vs, v, n3 * sizeof(double));
+  int rc = orc_ALE_remap_velocities(d, G, CS, h_old_u, h_old_v, h_new_u, h_new_v, u, v);
+  if (!rc) {
+    conserve_ke_points(d, GM(G, d, MOM6X_G_mask2dCu), -1, d->ni - 1, 0, d->nj - 1, h_old_u, h_new_u, us, u, H_subroundoff);
+    conserve_ke_points(d, GM(G, d, MOM6X_G_mask2dCv), 0, d->ni - 1, -1, d->nj - 1, h_old_v, h_new_v, vs, v, H_subroundoff);
+  }
+  free(us); free(vs);
+  return rc;
 }
 
 /* ---- regridding: ALE_regrid :518 -> regridding_main MOM_regridding.F90:862 for REGRIDDING_ZSTAR ---------------------- */

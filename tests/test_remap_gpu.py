@@ -123,6 +123,48 @@ def test_ALE_remap_tracers_and_velocities(orc, cfg, scheme, mods):
     dyc.close()
 
 
+@pytest.mark.parametrize("cfg", ["double_gyre", "island_basin"])
+def test_ALE_remap_velocities_conserving_ke(orc, cfg):
+    """REMAP_VEL_CONSERVE_KE with allow_preserve_variance (MOM_ALE.F90:1166-1195, :1240-1270): the baroclinic part of every remapped
+    velocity column rescaled so that its integrated square equals the source column's (by at most 25 %).  Device == oracle bit for
+    bit; and the property itself on the device's result: where the cap is not hit, sum h2 (u - u_bt)^2 equals the source's."""
+    import torch
+    from mom6_amd.dycore import Dycore
+    gg, d, M = getattr(H, cfg)(nk=12)
+    GV = abi.vgrid_default()
+    CS = abi.remapping_params_default(abi.REMAP_PPM_H4, GV.H_subroundoff, om4_remap_via_sub_cells=1)
+    h_old, u, v = synth.make_state(d, M, thin_frac=0.15)
+    tot = h_old.sum(0)
+    w = np.linspace(1.0, 3.0, d.nk)[:, None, None] * (1.0 + 0.3 * synth.smooth_field(d, 5, nk=d.nk, ox=0.5, oy=0.5))
+    h_new = np.ascontiguousarray(w / w.sum(0) * tot)
+    hu_o, hv_o, hu_n, hv_n = (np.full_like(h_old, 1.0e-3) for _ in range(4))
+    orc.ALE_remap_set_h_vel(d, M, h_old, hu_o, hv_o); orc.ALE_remap_set_h_vel(d, M, h_new, hu_n, hv_n)
+    uo, vo = u.copy(), v.copy()
+    orc.ALE_remap_velocities_conserve_ke(d, M, GV, CS, hu_o, hv_o, hu_n, hv_n, uo, vo)
+    up, vp = u.copy(), v.copy()
+    orc.ALE_remap_velocities(d, M, CS, hu_o, hv_o, hu_n, hv_n, up, vp)
+    su = (Ellipsis,) + tuple(H.interior(d, "u"))
+    assert np.abs(uo[su] - up[su]).max() > 1e-6          # the correction does something
+    dyc = Dycore(d, M, GV)
+    ud, vd = dyc.to_dev(u), dyc.to_dev(v)
+    g = [dyc.to_dev(a) for a in (hu_o, hv_o, hu_n, hv_n)]
+    torch.cuda.synchronize()
+    dyc.ALE_remap_velocities(CS, g[0], g[1], g[2], g[3], ud, vd, conserve_ke=True)
+    dyc.sync()
+    H.assert_bitwise(ud.cpu().numpy(), uo, "u (KE-conserving)", H.interior(d, "u"))
+    H.assert_bitwise(vd.cpu().numpy(), vo, "v (KE-conserving)", H.interior(d, "v"))
+    # the property: baroclinic KE of the column conserved wherever the 25 % cap was not hit
+    un = ud.cpu().numpy()[su]; h1 = hu_o[su]; h2 = hu_n[su]; us = u[su]
+    wet = M[G["mask2dCu"]][su[1:]] > 0
+    ubt = (h2 * un).sum(0) / (h2.sum(0) + GV.H_subroundoff)
+    ke_s = (h1 * (us - ubt) ** 2).sum(0); ke_t = (h2 * (un - ubt) ** 2).sum(0)
+    ke_p = (h2 * (up[su] - ubt) ** 2).sum(0)
+    free = wet & (ke_s < 1.5625 * ke_p) & (ke_s > 0)
+    assert free.sum() > 10
+    assert (np.abs(ke_t - ke_s)[free] / ke_s[free]).max() < 1e-12
+    dyc.close()
+
+
 @pytest.mark.parametrize("nk", [5, 24, 75])
 @pytest.mark.parametrize("scheme", [abi.REMAP_PPM_H4, abi.REMAP_PPM_IH4])
 def test_ALE_remap_ragged_grids_through_the_shared_merge(orc, nk, scheme):
