@@ -385,6 +385,13 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
       S.a0 = a0; S.a1 = a1; S.b0 = b0; S.b1 = b1;
       return wave ? mass_flux_wave(c, DIR, S, E) : mass_flux_lds(c, DIR, S, E);
     };
+    auto pair = [&](int a0, int a1, int b0, int b1, int c0, int c1, int e0, int e1) -> int {
+      if (!wave) { const int r1 = part(a0, a1, b0, b1); return r1 ? r1 : part(c0, c1, e0, e1); }
+      FluxArgs S1 = A, S2 = A;
+      S1.a0 = a0; S1.a1 = a1; S1.b0 = b0; S1.b1 = b1;
+      S2.a0 = c0; S2.a1 = c1; S2.b0 = e0; S2.b1 = e1;
+      return mass_flux_wave_pair(c, DIR, S1, S2, E);
+    };
     int rc;
     if (!split) {
       rc = part(A.a0, A.a1, A.b0, A.b1);
@@ -392,14 +399,12 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
       const int o0 = A.b0 > 0 ? A.b0 : 0, o1 = A.b1 < d.nj - 1 ? A.b1 : d.nj - 1;
       rc = part(A.a0, A.a1, o0, o1);
       halo_complete(c);
-      if (!rc) rc = part(A.a0, A.a1, A.b0, o0 - 1);
-      if (!rc) rc = part(A.a0, A.a1, o1 + 1, A.b1);
+      if (!rc) rc = pair(A.a0, A.a1, A.b0, o0 - 1, A.a0, A.a1, o1 + 1, A.b1);     // the two rims in ONE launch
     } else {                 // columns
       const int o0 = A.a0 > 0 ? A.a0 : 0, o1 = A.a1 < d.ni - 1 ? A.a1 : d.ni - 1;
       rc = part(o0, o1, A.b0, A.b1);
       halo_complete(c);
-      if (!rc) rc = part(A.a0, o0 - 1, A.b0, A.b1);
-      if (!rc) rc = part(o1 + 1, A.a1, A.b0, A.b1);
+      if (!rc) rc = pair(A.a0, o0 - 1, A.b0, A.b1, o1 + 1, A.a1, A.b0, A.b1);
     }
     if (rc) return rc;
   } else {

@@ -12,6 +12,9 @@ struct LdsArgs {
   int i_base;          // first i of the tile grid (set by mass_flux_lds: 128-byte aligned, <= a0)
   int force_walk;      // tests (MOM6X_MASSFLUX=lds_walk): take the sequential duL/duR recurrence even when the certificate holds
   int *retry;          // per tile: the cheap-bounds pass asks for the exact pass (set by mass_flux_lds), or null
+  // continuity_wave.hip: the face ranges of the launch, one or two parts (the two rims of a split pass go out as ONE launch); a part
+  // is pgx x pgy work-groups of 16 faces x `rows` rows starting at the 128-byte aligned pib
+  int np, pa0[2], pa1[2], pb0[2], pb1[2], pib[2], pgx[2], pgy[2];
   unsigned long long *stats;   // continuity_wave.hip: [0] flux re-evaluations of all Newton solves, [1] solves (face columns x solves), [2] exact-limit redos
 };
 
@@ -21,3 +24,5 @@ int mass_flux_lds(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E);
 // continuity_wave.hip: the wave-owned kernel of sum_order == MOM6X_SUM_TREE16 (uses h_min, scheme, monotonic, marginal, h_face)
 bool mass_flux_wave_usable(int nk);
 int mass_flux_wave(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E);
+// ... over two face ranges in one launch (A2's ranges; everything else from A); an empty range is left out
+int mass_flux_wave_pair(mom6x_ctx *c, int dir, const FluxArgs &A, const FluxArgs &A2, const LdsArgs &E);

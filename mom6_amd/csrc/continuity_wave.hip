@@ -527,13 +527,18 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   extern __shared__ double S_all[];
   // A work-group = a strip of 16 faces along i (bx) and E.rows consecutive rows (chunk): E.gx strips, E.gy chunks;
   // its wavefronts are independent of each other.
-  const int bx = blockIdx.x % E.gx, chunk = blockIdx.x / E.gx;
-  const int j0 = A.b0 + chunk * E.rows, j1 = min(j0 + E.rows - 1, A.b1);
+  // (one or two parts: the work-groups of the second part follow those of the first)
+  const int n0 = E.pgx[0] * E.pgy[0];
+  const int pt = (E.np > 1 && (int)blockIdx.x >= n0) ? 1 : 0;
+  const int bid = (int)blockIdx.x - (pt ? n0 : 0);
+  const int pa0 = E.pa0[pt], pa1 = E.pa1[pt], pb0 = E.pb0[pt], pb1 = E.pb1[pt];
+  const int bx = bid % E.pgx[pt], chunk = bid / E.pgx[pt];
+  const int j0 = pb0 + chunk * E.rows, j1 = min(j0 + E.rows - 1, pb1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fw = lane >> 4, kl = lane & 15;
-  const int i0 = E.i_base + bx * NF + w * SEG, i = i0 + fw;   // i0: the wavefront's first face
-  const bool active = (i >= A.a0 && i <= A.a1);
+  const int i0 = E.pib[pt] + bx * NF + w * SEG, i = i0 + fw;   // i0: the wavefront's first face
+  const bool active = (i >= pa0 && i <= pa1);
   const bool wave_on = wave_any(active);   // (a wavefront without faces still meets the others at the row barrier below)
   const int nk = d.nk;
   const size_t slab = (size_t)d.slab;
@@ -597,7 +602,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     xo[q] = (c >> 2) * KP * SEG + (c & 3) - fw;
   }
   // per-lane byte offsets of the stores (see face_column)
-  const unsigned lane2 = (unsigned)((size_t)((active ? i : A.a1) + d.ioff) * 8);   // inactive lanes alias the last face (never written)
+  const unsigned lane2 = (unsigned)((size_t)((active ? i : pa1) + d.ioff) * 8);   // inactive lanes alias the last face (never written)
   const unsigned lane3 = lane2 + (unsigned)((size_t)kl * slab * 8);
 
   Col<MAXL> C;
@@ -681,9 +686,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
 template <int DIR, int MAXL>
 int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   using ST = Stage<DIR>;
-  LdsArgs E = E0;
-  const int nrow = A.b1 - A.b0 + 1;
-  E.gx = (A.a1 - E.i_base + NF) / NF;
+  LdsArgs E = E0;   // (E.np, pa0.., pib set by the caller)
   static const int famt0_sweep = [] { const char *e = getenv("MOM6X_FAMT0"); return (e && !strcmp(e, "sweep")) ? 1 : 0; }();
   E.retry = nullptr; E.force_walk = famt0_sweep;   // (in this kernel: always make set_*_BT_cont's own sweep at du0)
   // The Newton statistics are a separate instantiation: the counters cost the 253-register kernel its last free registers
@@ -693,10 +696,15 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   const size_t lds_bytes = sizeof(double) * 4 * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16));   // 4 x the kernel's WAVE_LDS
   auto kern = stats ? k_mass_flux_wave<DIR, MAXL, true> : k_mass_flux_wave<DIR, MAXL, false>;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  long strips_rows = 0;
+  for (int q = 0; q < E.np; q++) {
+    E.pgx[q] = (E.pa1[q] - E.pib[q] + NF) / NF;
+    strips_rows += (long)E.pgx[q] * (E.pb1[q] - E.pb0[q] + 1);
+  }
   // Rows a work-group marches over: 16 where the grid is many times the chip (1440 x 1080: 6120 work-groups for 512 resident
   // ones).  The work-groups differ in their work (Newton sweeps per row, land) and nothing but the dispatcher balances them, so a
   // launch wants several work-groups per resident slot: on the tile of an 8-GPU layout (360 x 540) 16 rows make 782 work-groups =
-  // 1.5 rounds, the second one half empty -- measured there (profiles/r04_mfw_rows.txt): 4-10 rows 0.36-0.38 ms per zonal launch,
+  // 1.5 rounds, the second one half empty -- measured there (profiles/r04_mfw_variants.md): 4-10 rows 0.36-0.38 ms per zonal launch,
   // 16 rows 0.41, one round of 25 rows 0.45.  The prologue of a work-group (first DMA; meridional: the ring of h rows and the
   // row that is only reconstructed) is cheap next to that.  MOM6X_MFW_ROWS overrides.
   {
@@ -710,13 +718,14 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
     }
     static const int rows_env = [] { const char *e = getenv("MOM6X_MFW_ROWS"); return e ? atoi(e) : 0; }();
     const long want = 4L * slots;                                  // work-groups for four rounds
-    long r = ((long)E.gx * nrow) / want;                           // the march length that gives them
+    const long r = strips_rows / want;                             // the march length that gives them
     const int rmin = DIR ? 6 : 4;
     E.rows = (int)std::min<long>(16, std::max<long>(rmin, r));
     if (rows_env > 0) E.rows = rows_env;
   }
-  E.gy = (nrow + E.rows - 1) / E.rows;      // chunks
-  const dim3 grid(E.gx * E.gy, 1, 1);
+  int nwg = 0;
+  for (int q = 0; q < E.np; q++) { E.pgy[q] = (E.pb1[q] - E.pb0[q] + E.rows) / E.rows; nwg += E.pgx[q] * E.pgy[q]; }
+  const dim3 grid(nwg, 1, 1);
   if (c->prof_on) prof_begin(c, DIR ? "k_mass_flux_wave<1>" : "k_mass_flux_wave<0>");
   hipLaunchKernelGGL(kern, grid, dim3(NF * KL, 1, 1), lds_bytes, c->stream, c->d, c->G, A, E);
   if (c->prof_on) prof_end(c);
@@ -736,13 +745,27 @@ extern "C" int mom6x_debug_mfw_timing(unsigned long long *out32, int reset) {
 
 bool mass_flux_wave_usable(int nk) { return nk <= 8 * KL; }
 
-int mass_flux_wave(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E0) {
+int mass_flux_wave_pair(mom6x_ctx *c, int dir, const FluxArgs &A, const FluxArgs &A2, const LdsArgs &E0) {
   const int nk = c->d.nk;
   LdsArgs E = E0;
-  E.i_base = A.a0 - (((A.a0 + c->d.ioff) % NF) + NF) % NF;   // (i_base + ioff) is a multiple of 16 doubles = 128 B
+  E.np = 0;
+  for (const FluxArgs *P : { &A, &A2 }) {
+    if (P->a0 > P->a1 || P->b0 > P->b1) continue;
+    const int q = E.np++;
+    E.pa0[q] = P->a0; E.pa1[q] = P->a1; E.pb0[q] = P->b0; E.pb1[q] = P->b1;
+    E.pib[q] = P->a0 - (((P->a0 + c->d.ioff) % NF) + NF) % NF;   // (pib + ioff) is a multiple of 16 doubles = 128 B
+  }
+  if (E.np == 0) return MOM6X_OK;
+  E.i_base = E.pib[0];
   const int maxl = (nk + KL - 1) / KL;
 #define GO(D, M) return launch<D, M>(c, A, E)
   if (dir == 0) { if (maxl <= 2) GO(0, 2); if (maxl <= 5) GO(0, 5); GO(0, 8); }
   if (maxl <= 2) GO(1, 2); if (maxl <= 5) GO(1, 5); GO(1, 8);
 #undef GO
+}
+
+int mass_flux_wave(mom6x_ctx *c, int dir, const FluxArgs &A, const LdsArgs &E0) {
+  FluxArgs none = A;
+  none.a0 = 0; none.a1 = -1;
+  return mass_flux_wave_pair(c, dir, A, none, E0);
 }

@@ -79,15 +79,16 @@ k_halo_pack(Dm d, WrapArgs A, Bufs8 B, int send /*1: pack send regions, 0: unpac
     int i0, i1, j0, j1;
     axis_range(d.ni, PASS_W(A, m), xB, dx, send, i0, i1);
     axis_range(d.nj, PASS_W(A, m), yB, dy, send, j0, j1);
-    const int nx = i1 - i0 + 1, ny = j1 - j0 + 1;
-    const size_t per_k = (size_t)nx * ny, tot = per_k * A.nk[m];
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
-      const int k = (int)(t / per_k);
-      const int r = (int)(t - (size_t)k * per_k);
-      const int jj = r / nx, ii = r - jj * nx;
-      const size_t x = ix3(d, i0 + ii, j0 + jj, k);
-      if (send) buf[off + t] = A.f[m][x];
-      else A.f[m][x] = buf[off + t];
+    const unsigned nx = (unsigned)(i1 - i0 + 1), ny = (unsigned)(j1 - j0 + 1);
+    const unsigned per_k = nx * ny, tot = per_k * (unsigned)A.nk[m];   // (a region of a tile: far below 2^32 -- 32-bit index arithmetic)
+    double *__restrict__ fld = A.f[m];
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += gridDim.x * blockDim.x) {
+      const unsigned k = t / per_k;
+      const unsigned r = t - k * per_k;
+      const unsigned jj = r / nx, ii = r - jj * nx;
+      const size_t x = ix3(d, i0 + (int)ii, j0 + (int)jj, (int)k);
+      if (send) buf[off + t] = fld[x];
+      else fld[x] = buf[off + t];
     }
     off += tot;
   }
