@@ -10,7 +10,7 @@ byq = collections.defaultdict(list)
 for r in rows:
     byq[(r.get("Queue_Id"), r.get("Stream_Id", ""))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
 print("queues:", {k: len(v) for k, v in byq.items()})
-main = max(byq, key=lambda k: sum(1 for e in byq[k] if e[2].startswith("k_bt_vel")))   # the context's compute stream
+main = max(byq, key=lambda k: sum(1 for e in byq[k] if e[2].startswith("k_bt_")))   # the context's compute stream
 ev = sorted(byq[main])
 # the timed part: the last `nsteps` steps, a step beginning with the frame copy k_h_av that follows a k_corad kernel
 starts = [i for i in range(1, len(ev)) if ev[i][2].startswith("k_h_av") and ev[i - 1][2].startswith("k_corad")]
