@@ -51,7 +51,13 @@ __device__ __forceinline__ double plm_slope3(double tm, double tc, double tp, do
 // its two neighbours on either side (up-2 .. up+2 along the direction); mk = the face masks of the faces up-2 .. up+1
 // (face n lies between the cells n and n+1).  Every variant of the advection kernels funnels into this one function, so
 // they cannot differ in arithmetic.
-__device__ __forceinline__ double face_flux5(int scheme, const double (&T5)[5], const double (&mk)[4], double uhh, double CFL) {
+// The limited slope of CELL c along the direction (:445-449 / :824-828): plm_slope3 of its three values with the product of the
+// masks of its two faces, mC(c) * mC(c-1) (face n lies between the cells n and n+1) -- a property of the cell: every face whose
+// stencil holds the cell forms the same bits, so a kernel may form it once per cell (k_ta_x_tile's slope stage).
+__device__ __forceinline__ double cell_slope(double tm, double tc, double tp, double m_c, double m_cm1) { return plm_slope3(tm, tc, tp, m_c * m_cm1); }
+
+// face_flux5 with the slopes of the cells up-1, up, up+1 given (sl[0..2]; PLM: sl[1] only; PPM:H3: none)
+__device__ __forceinline__ double face_flux5s(int scheme, const double (&T5)[5], const double (&mk)[4], const double (&sl)[3], double uhh, double CFL) {
   const double Tm = T5[1], Tc = T5[2], Tp = T5[3];
   if (scheme == ADVECT_PPM || scheme == ADVECT_PPMH3) {
     double aL, aR;
@@ -61,8 +67,7 @@ __device__ __forceinline__ double face_flux5(int scheme, const double (&T5)[5], 
       aR = (5. * Tc + (2. * Tp - Tm)) / 6.;
       aR = dmax(dmin(Tc, Tp), aR); aR = dmin(dmax(Tc, Tp), aR);
     } else {
-      const double s0 = plm_slope3(T5[0], T5[1], T5[2], mk[1] * mk[0]), s1 = plm_slope3(T5[1], T5[2], T5[3], mk[2] * mk[1]),
-                   s2 = plm_slope3(T5[2], T5[3], T5[4], mk[3] * mk[2]);
+      const double s0 = sl[0], s1 = sl[1], s2 = sl[2];
       aL = 0.5 * ((Tm + Tc) + (s0 - s1) / 3.);
       aR = 0.5 * ((Tc + Tp) + (s1 - s2) / 3.);
     }
@@ -74,9 +79,17 @@ __device__ __forceinline__ double face_flux5(int scheme, const double (&T5)[5], 
     if (uhh >= 0.0) return uhh * (aR - 0.5 * CFL * ((aR - aL) - a6 * (1. - 2. / 3. * CFL)));
     return uhh * (aL + 0.5 * CFL * ((aR - aL) + a6 * (1. - 2. / 3. * CFL)));
   }
-  const double slope = plm_slope3(Tm, Tc, Tp, mk[2] * mk[1]);
+  const double slope = sl[1];
   if (uhh >= 0.0) return uhh * (Tc + 0.5 * slope * (1. - CFL));
   return uhh * (Tc - 0.5 * slope * (1. - CFL));
+}
+__device__ __forceinline__ double face_flux5(int scheme, const double (&T5)[5], const double (&mk)[4], double uhh, double CFL) {
+  double sl[3] = {0., 0., 0.};
+  if (scheme == ADVECT_PPM) {
+    sl[0] = cell_slope(T5[0], T5[1], T5[2], mk[1], mk[0]); sl[1] = cell_slope(T5[1], T5[2], T5[3], mk[2], mk[1]);
+    sl[2] = cell_slope(T5[2], T5[3], T5[4], mk[3], mk[2]);
+  } else if (scheme == ADVECT_PLM) sl[1] = cell_slope(T5[1], T5[2], T5[3], mk[2], mk[1]);
+  return face_flux5s(scheme, T5, mk, sl, uhh, CFL);
 }
 
 // The operands of face f gathered through pointers: T with stride stT (index f), the 2-D face mask with stride stM (f2).
@@ -298,85 +311,145 @@ k_ta_save_x(Dm d, const double *__restrict__ uhr, const double *__restrict__ hpr
   out[v] = (v < 6 * Tr.n) ? Tr.t[v / 6][a] : ((v < 6 * Tr.n + 2) ? hprev[a] : uhr[a]);
 }
 
+// Round 4: a work-group walks XR consecutive rows of its tile column.  The loads of row r+1 (this thread's cell, the saved values
+// beyond the tile's ends, the row's masks and areas) are issued right after row r's values have been handed to LDS, so they travel
+// while row r is computed and stored: one row and layer per work-group had every work-group pay its load latency with nothing to do
+// (486 K work-groups of 16 us at 1440 x 1080 x 75).  And the limited slope of a cell is formed ONCE, by the thread that owns the cell,
+// in a stage of its own (cell_slope): the three faces whose stencils hold it read it from LDS instead of forming it again.
+#ifndef MOM6X_TA_XR
+#define MOM6X_TA_XR 8
+#endif
+constexpr int XR = MOM6X_TA_XR;   // rows per work-group
 template <int MAXT>
 __global__ void __launch_bounds__(256)
 k_ta_x_tile(Dm d, const double *__restrict__ G, double *__restrict__ uhr, double *__restrict__ hprev, TrList Tr,
             const int *__restrict__ dm, int *__restrict__ lim, const int *__restrict__ dmk, const double *__restrict__ save,
             double min_h, double h_neglect, double H_subroundoff, int i0, int i1, int b0, int b1, int ntile) {
-  const int n = blockIdx.x, j = b0 + blockIdx.y, k = blockIdx.z;
+  const int n = blockIdx.x, k = blockIdx.z;
   if (dmk[k] <= 0) return;
   const int nrows = d.nj + 2 * d.halo + 1;
-  if (!dm[k * nrows + j + d.joff]) return;          // a row that is not being worked on is not touched at all (:417)
+  const int jA = b0 + (int)blockIdx.y * XR, jB = min(jA + XR - 1, b1);
   const int C0 = i0 + TX * n, Cend = min(C0 + TX - 1, i1), ncell = Cend - C0 + 1;
   const int t = threadIdx.x, ntr = Tr.n, nv = SaveIdx::nval(ntr);
   __shared__ double sT[MAXT][TX + 6];               // cells C0-3 .. C0+TX+2  (position p <-> cell C0-3+p)
+  __shared__ double sS[MAXT][TX + 6];               // their limited slopes (positions 1 .. TX+4 are formed)
+  __shared__ double s_m[TX + 6];                    // masks of the faces C0-3 .. C0+TX+2 (position p <-> face C0-3+p)
   __shared__ double s_h[TX + 2];                    // cells C0-1 .. C0+TX
   __shared__ double s_u[TX + 3];                    // faces C0-2 .. C0+TX
   __shared__ double s_uhh[TX + 1];                  // faces C0-1 .. C0+TX-1
   __shared__ double s_F[MAXT][TX + 1];
-  const double *svL = save + (((size_t)k * (size_t)(b1 - b0 + 1) + (size_t)(j - b0)) * (size_t)(ntile + 1) + (size_t)n) * (size_t)nv;
-  const double *svR = svL + nv;                     // the boundary at Cend+1
-  const size_t row = ix3(d, 0, j, k), row2 = ix2(d, 0, j);
-  // ---- everything this work-group reads, before it writes anything: thread t < ncell its own cell (whole cache lines per
-  //      wavefront), eleven of the other threads the saved values beyond the two ends of the tile
-  if (t < ncell) {
-    const size_t a = row + C0 + t;
-    for (int m = 0; m < ntr; m++) sT[m][t + 3] = Tr.t[m][a];
-    s_h[t + 1] = hprev[a];
-    s_u[t + 2] = uhr[a];
-  } else {
-    const int e = t - ncell;
-    if (e < 3) { for (int m = 0; m < ntr; m++) sT[m][e] = svL[SaveIdx::T(m, e)]; }                       // cells C0-3 .. C0-1
-    else if (e < 6) { for (int m = 0; m < ntr; m++) sT[m][ncell + e] = svR[SaveIdx::T(m, e)]; }         // cells Cend+1 .. Cend+3
-    else if (e == 6) s_h[0] = svL[SaveIdx::H(ntr, 0)];                                                  // cell C0-1
-    else if (e == 7) s_h[ncell + 1] = svR[SaveIdx::H(ntr, 1)];                                          // cell Cend+1
-    else if (e < 10) s_u[e - 8] = svL[SaveIdx::U(ntr, e - 8)];                                          // faces C0-2, C0-1
-    else if (e == 10) s_u[ncell + 2] = svR[SaveIdx::U(ntr, 2)];                                         // face Cend+1
-  }
-  // the 2-D operands of this thread's face do not depend on the tile's data: issue their loads before the barrier
   const double *areaT = gm(G, d, MOM6X_G_areaT), *mC = gm(G, d, MOM6X_G_mask2dCu);
   const int q = (t < ncell) ? t + 1 : 0;            // this thread's face slot (slot q of the face arrays <-> face C0-1+q)
-  const size_t f2 = row2 + (C0 - 1 + q);
-  double mw[5] = {0., 0., 0., 0., 0.}, a_m = 0.0, a_p = 0.0;
-  if (t <= ncell) {
+  const int e = t - ncell;                          // (t >= ncell) which of the values beyond the tile's ends this thread fetches
+
+  // what a thread holds of a row between its load and its hand-over to LDS
+  double rT[MAXT], r_h = 0., r_u = 0., r_m = 0., r_am = 0., r_ap = 0.;
+  bool r_on = false;
+  auto load_row = [&](int j) {
+    r_on = (j <= jB) && (dm[k * nrows + j + d.joff] != 0);     // a row that is not being worked on is not touched at all (:417)
+    if (!r_on) return;
+    const size_t row = ix3(d, 0, j, k), row2 = ix2(d, 0, j);
+    const double *svL = save + (((size_t)k * (size_t)(b1 - b0 + 1) + (size_t)(j - b0)) * (size_t)(ntile + 1) + (size_t)n) * (size_t)nv;
+    const double *svR = svL + nv;                   // the boundary at Cend+1
+    if (t < ncell) {
+      const size_t a = row + C0 + t;
 #pragma unroll
-    for (int e = 0; e < 5; e++) mw[e] = mC[f2 - 2 + e];                  // masks of the faces f-2 .. f+2
-    a_m = areaT[f2]; a_p = areaT[f2 + 1];
-  }
-  __syncthreads();
-  // ---- faces C0-1 .. Cend: thread t < ncell <-> the east face C0+t of its cell, thread ncell <-> the face C0-1
-  double uhh = 0.0;
-  if (t <= ncell) {
-    double CFL;
-    if (limited_transport(s_u[q + 1], s_u[q], s_u[q + 2], s_h[q], s_h[q + 1], a_m, a_p, min_h, uhh, CFL))
-      lim[k * nrows + j + d.joff] = 1;
-    s_uhh[q] = uhh;
-    const bool pos = (uhh >= 0.0);
-    const double mk[4] = {pos ? mw[0] : mw[1], pos ? mw[1] : mw[2], pos ? mw[2] : mw[3], pos ? mw[3] : mw[4]};
-    for (int m = 0; m < ntr; m++) {
-      const double *Tq = &sT[m][pos ? q : q + 1];                         // the upwind cell is at position q+2 (pos) or q+3
-      const double T5[5] = {Tq[0], Tq[1], Tq[2], Tq[3], Tq[4]};
-      s_F[m][q] = face_flux5(Tr.scheme[m], T5, mk, uhh, CFL);
+      for (int m = 0; m < MAXT; m++) if (m < ntr) rT[m] = Tr.t[m][a];
+      r_h = hprev[a]; r_u = uhr[a];
+    } else if (e < 3) {
+#pragma unroll
+      for (int m = 0; m < MAXT; m++) if (m < ntr) rT[m] = svL[SaveIdx::T(m, e)];                      // cells C0-3 .. C0-1
+    } else if (e < 6) {
+#pragma unroll
+      for (int m = 0; m < MAXT; m++) if (m < ntr) rT[m] = svR[SaveIdx::T(m, e)];                      // cells Cend+1 .. Cend+3
+    } else if (e == 6) r_h = svL[SaveIdx::H(ntr, 0)];                                                  // cell C0-1
+    else if (e == 7) r_h = svR[SaveIdx::H(ntr, 1)];                                                    // cell Cend+1
+    else if (e < 10) r_u = svL[SaveIdx::U(ntr, e - 8)];                                                // faces C0-2, C0-1
+    else if (e == 10) r_u = svR[SaveIdx::U(ntr, 2)];                                                   // face Cend+1
+    if (t < TX + 6) {   // the mask of face C0-3+t (clamped to the allocated row: a stencil that reaches beyond it does not use the value)
+      const int fi = min(max(C0 - 3 + t, -d.ioff), d.pitch - d.ioff - 1);
+      r_m = mC[row2 + fi];
     }
-  }
-  __syncthreads();
-  // ---- the remaining transport of the faces this work-group owns (C0 .. Cend; in the first tile of a row also i0-1),
-  //      and the cells C0 .. Cend
-  if (t > ncell || (t == ncell && n > 0)) return;
-  const int c = C0 - 1 + q;
-  {
-    double r = s_u[q + 1] - uhh;
-    const double neglect = H_subroundoff * dmin(a_m, a_p);
-    if (fabs(r) < neglect) r = 0.0;
-    uhr[row + c] = r;
-  }
-  if (t == ncell) return;
-  const double uh_m = s_uhh[q - 1];
-  if ((uhh != 0.0) || (uh_m != 0.0)) {
-    double hp, hlst, Ihnew;
-    const bool upd = cell_update<0>(uhh, uh_m, s_h[q], a_m, h_neglect, hp, hlst, Ihnew);
-    hprev[row + c] = hp;
-    if (upd) for (int m = 0; m < ntr; m++) Tr.t[m][row + c] = (sT[m][q + 2] * hlst - (s_F[m][q] - s_F[m][q - 1])) * Ihnew;
+    if (t <= ncell) { const size_t f2 = row2 + (C0 - 1 + q); r_am = areaT[f2]; r_ap = areaT[f2 + 1]; }
+  };
+
+  load_row(jA);
+  for (int j = jA; j <= jB; j++) {
+    const bool on = r_on;                            // (uniform over the work-group)
+    const double a_m = r_am, a_p = r_ap;
+    if (on) {
+      // ---- hand the row over to LDS
+      if (t < ncell) {
+#pragma unroll
+        for (int m = 0; m < MAXT; m++) if (m < ntr) sT[m][t + 3] = rT[m];
+        s_h[t + 1] = r_h; s_u[t + 2] = r_u;
+      } else if (e < 3) {
+#pragma unroll
+        for (int m = 0; m < MAXT; m++) if (m < ntr) sT[m][e] = rT[m];
+      } else if (e < 6) {
+#pragma unroll
+        for (int m = 0; m < MAXT; m++) if (m < ntr) sT[m][ncell + e] = rT[m];
+      } else if (e == 6) s_h[0] = r_h;
+      else if (e == 7) s_h[ncell + 1] = r_h;
+      else if (e < 10) s_u[e - 8] = r_u;
+      else if (e == 10) s_u[ncell + 2] = r_u;
+      if (t < TX + 6) s_m[t] = r_m;
+    }
+    __syncthreads();
+    load_row(j + 1);                                 // ... and ask for the next row while this one is worked on
+    if (on) {
+      // ---- slopes of the cells C0-2 .. Cend+2 (positions 1 .. ncell+4), once per cell
+      if (t < ncell + 4) {
+        const int p = t + 1;
+        const double m_c = s_m[p], m_cm1 = s_m[p - 1];    // faces of cell C0-3+p: face C0-3+p (east) and C0-4+p (west)
+#pragma unroll
+        for (int m = 0; m < MAXT; m++) if (m < ntr) {
+          const int sch = Tr.scheme[m];
+          sS[m][p] = (sch == ADVECT_PPMH3) ? 0.0 : cell_slope(sT[m][p - 1], sT[m][p], sT[m][p + 1], m_c, m_cm1);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- faces C0-1 .. Cend: thread t < ncell <-> the east face C0+t of its cell, thread ncell <-> the face C0-1
+    double uhh = 0.0;
+    if (on && t <= ncell) {
+      double CFL;
+      if (limited_transport(s_u[q + 1], s_u[q], s_u[q + 2], s_h[q], s_h[q + 1], a_m, a_p, min_h, uhh, CFL))
+        lim[k * nrows + j + d.joff] = 1;
+      s_uhh[q] = uhh;
+      const bool pos = (uhh >= 0.0);
+      const int o = pos ? q : q + 1;                  // the upwind cell is at position o+2; masks of the faces up-2 .. up+1 at o .. o+3 (+2)
+      const double mk[4] = {s_m[o], s_m[o + 1], s_m[o + 2], s_m[o + 3]};   // face up-2+e <-> position (o+2) - 2 + e ... see below
+      for (int m = 0; m < ntr; m++) {
+        const double *Tq = &sT[m][o];
+        const double T5[5] = {Tq[0], Tq[1], Tq[2], Tq[3], Tq[4]};
+        const double sl[3] = {sS[m][o + 1], sS[m][o + 2], sS[m][o + 3]};
+        s_F[m][q] = face_flux5s(Tr.scheme[m], T5, mk, sl, uhh, CFL);
+      }
+    }
+    __syncthreads();
+    // ---- the remaining transport of the faces this work-group owns (C0 .. Cend; in the first tile of a row also i0-1),
+    //      and the cells C0 .. Cend
+    if (on && !(t > ncell || (t == ncell && n > 0))) {
+      const size_t row = ix3(d, 0, j, k);
+      const int c = C0 - 1 + q;
+      {
+        double r = s_u[q + 1] - uhh;
+        const double neglect = H_subroundoff * dmin(a_m, a_p);
+        if (fabs(r) < neglect) r = 0.0;
+        uhr[row + c] = r;
+      }
+      if (t != ncell) {
+        const double uh_m = s_uhh[q - 1];
+        if ((uhh != 0.0) || (uh_m != 0.0)) {
+          double hp, hlst, Ihnew;
+          const bool upd = cell_update<0>(uhh, uh_m, s_h[q], a_m, h_neglect, hp, hlst, Ihnew);
+          hprev[row + c] = hp;
+          if (upd) for (int m = 0; m < ntr; m++) Tr.t[m][row + c] = (sT[m][q + 2] * hlst - (s_F[m][q] - s_F[m][q - 1])) * Ihnew;
+        }
+      }
+    }
+    __syncthreads();                                 // (the next row's hand-over overwrites what the update has just read)
   }
 }
 
@@ -726,7 +799,7 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
       int rc = need_save((size_t)nz * nrw * (ntile + 1) * nv); if (rc) return rc;
       KLAUNCH(c, "k_ta_save_x", k_ta_save_x, dim3(ntile + 1, nrw, nz), dim3(64), d, (const double *)s->uhr, (const double *)s->hprev, Tr,
               (const int *)s->dmk, s->save, i0, i1, j0, j1, ntile);
-#define XT(M) KLAUNCH(c, "k_ta_x_tile", k_ta_x_tile<M>, dim3(ntile, nrw, nz), dim3(256), d, c->G, s->uhr, s->hprev, Tr, (const int *)s->dmu, \
+#define XT(M) KLAUNCH(c, "k_ta_x_tile", k_ta_x_tile<M>, dim3(ntile, (nrw + XR - 1) / XR, nz), dim3(256), d, c->G, s->uhr, s->hprev, Tr, (const int *)s->dmu, \
                       s->limu, (const int *)s->dmk, (const double *)s->save, min_h, h_neglect, c->GV.H_subroundoff, i0, i1, j0, j1, ntile)
       if (ntr <= 2) XT(2); else if (ntr <= 4) XT(4); else XT(8);
 #undef XT
