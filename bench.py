@@ -611,12 +611,36 @@ def cpu_baseline(args):
                       f"({t:.2f} s/step), scaled x{scale:.1f} to {args.ni}x{args.nj}x{nk}"}
 
 
+PMC_PASS_TIMEOUT = 40   # s; a pass that works takes about 4 s, one whose rocprofv3 hangs at start-up never ends
+
+
+def run_group(cmd, cwd, env, timeout):
+    """Run `cmd` in a process group of its own; on timeout the whole group is killed (rocprofv3's child -- this script again --
+    would otherwise live on and share the GPU with the legs that follow).  Returns (exit code or None on timeout, stderr)."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        _, err = p.communicate(timeout=timeout)
+        return p.returncode, err or ""
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        try:
+            p.communicate(timeout=10)
+        except Exception:   # noqa: BLE001
+            pass
+        return None, ""
+
+
 def measure_traffic_inrun(kernel, args):
     """HBM-side bytes of THIS state of the code, measured now: two more runs of this script under rocprofv3 (one counter per
     pass -- FETCH_SIZE, WRITE_SIZE -- and nothing else, as the MI355X guide prescribes; a step of the dynamics each), condensed by
     scripts/rocprof_summary.py (unit KB, calibrated on a kernel whose traffic is known exactly).  Returns ((bytes per launch of
     `kernel`, GB per step over all kernels, description), None) or (None, why it could not be done): rocprofv3 absent, a pass that
-    timed out (each pass is tried twice; rocprofv3's start-up has hung on some boxes of the pool), exited non-zero or wrote no
+    timed out (each pass is tried three times, 40 s each; rocprofv3's start-up has hung on some boxes of the pool), exited non-zero or wrote no
     counter file -- with the tail of its stderr, so that a line that has to cite profiles/ says why."""
     import shutil
     import subprocess
@@ -634,19 +658,18 @@ def measure_traffic_inrun(kernel, args):
     try:
         for tag, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             why = None
-            for attempt in (1, 2):
+            for attempt in (1, 2, 3):
                 shutil.rmtree(os.path.join(tmp, "prof_" + tag), ignore_errors=True)
-                try:
-                    r = subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, "prof_" + tag), "-o", tag, "--"] + cmd,
-                                       cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
-                except subprocess.TimeoutExpired:
-                    why = f"the {ctr} pass of rocprofv3 did not finish in 150 s (attempt {attempt})"
+                rc, err = run_group(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, "prof_" + tag), "-o", tag, "--"] + cmd,
+                                    cwd="/tmp", env=env, timeout=PMC_PASS_TIMEOUT)
+                if rc is None:
+                    why = f"the {ctr} pass of rocprofv3 did not finish in {PMC_PASS_TIMEOUT} s ({attempt} attempts)"
                     continue
-                if r.returncode != 0:
-                    why = f"the {ctr} pass of rocprofv3 exited with {r.returncode}: " + " | ".join((r.stderr or "").strip().splitlines()[-2:])[:300]
+                if rc != 0:
+                    why = f"the {ctr} pass of rocprofv3 exited with {rc}: " + " | ".join(err.strip().splitlines()[-2:])[:300]
                     continue
                 if not os.path.exists(os.path.join(tmp, "prof_" + tag, tag + "_counter_collection.csv")):
-                    why = f"the {ctr} pass of rocprofv3 wrote no counter file: " + " | ".join((r.stderr or "").strip().splitlines()[-2:])[:300]
+                    why = f"the {ctr} pass of rocprofv3 wrote no counter file: " + " | ".join(err.strip().splitlines()[-2:])[:300]
                     continue
                 why = None
                 break
