@@ -116,6 +116,29 @@ __device__ __forceinline__ void flux_reg(const Col<MAXL> &C, int n, double u, do
   duhdu = C.Lf * h_marg * C.v[n];
 }
 
+// The same for a wavefront whose layers ALL flow one way (SIDE = +1: from the minus cell, -1: from the plus cell): the upwind cell
+// is known, nothing is selected (12 of the ~46 instructions of a layer are v_cndmask, two more the zero test).  A lane at rest
+// may take part if its visc_rem is zero as well: its transport is Lf * 0 * (...) and its derivative Lf * h * 0, zeros of either sign
+// that leave the column sums as the reference's + 0.0 does (only sums are formed from this function, no transport is stored).
+template <int MAXL, int SIDE>
+__device__ __forceinline__ void flux_one_way(const Col<MAXL> &C, int n, double u, double &uh, double &duhdu) {
+  const double a = (SIDE > 0) ? C.mR[n] : C.pL[n], b = (SIDE > 0) ? C.mL[n] : C.pR[n], curv_3 = (SIDE > 0) ? C.mC[n] : C.pC[n];
+  const double CFL = fabs(u) * C.dt * ((SIDE > 0) ? C.IdT_m : C.IdT_p);
+  uh = C.Lf * u * (a + CFL * (0.5 * (b - a) + curv_3 * (CFL - 1.5)));
+  const double h_marg = a + CFL * ((b - a) + 3.0 * curv_3 * (CFL - 1.0));
+  duhdu = C.Lf * h_marg * C.v[n];
+}
+template <int MAXL, int SIDE>
+__device__ __forceinline__ bool wave_one_way(const Col<MAXL> &C, double du) {
+  bool ok = true;
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) {
+    const double u = C.u[n] + du * C.v[n];
+    ok = ok && (((SIDE > 0) ? (u > 0.0) : (u < 0.0)) || (u == 0.0 && C.v[n] == 0.0));
+  }
+  return !wave_any(!ok);
+}
+
 // The Newton loop evaluates the same unrolled layer loop again and again with a new du.  Left alone, the compiler hoists
 // everything of a layer that does not depend on du out of the loop (both upwind variants of b - a, 0.5 (b - a),
 // 3 curv_3, ...: ~28 registers per layer) and the kernel goes to scratch memory.  An empty asm that "modifies" the
@@ -481,19 +504,41 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
       LAYER_FENCE(n);
     }
   }
+  // duL / duR are made so that every layer flows out of the minus / the plus cell (:1293-1316; a layer whose visc_rem lies under the
+  // floor may not): wavefront-uniformly, such a sweep knows its upwind cell
+  if (wave_one_way<MAXL, 1>(C, duL)) {
 #pragma unroll
-  for (int n = 0; n < MAXL; n++) {
-    double uh_L, d_L;
-    flux_reg(C, n, C.u[n] + duL * C.v[n], uh_L, d_L);
-    FAmt_L = FAmt_L + d_L; uhtot_L = uhtot_L + uh_L;
-    LAYER_FENCE(n);
+    for (int n = 0; n < MAXL; n++) {
+      double uh_L, d_L;
+      flux_one_way<MAXL, 1>(C, n, C.u[n] + duL * C.v[n], uh_L, d_L);
+      FAmt_L = FAmt_L + d_L; uhtot_L = uhtot_L + uh_L;
+      LAYER_FENCE(n);
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      double uh_L, d_L;
+      flux_reg(C, n, C.u[n] + duL * C.v[n], uh_L, d_L);
+      FAmt_L = FAmt_L + d_L; uhtot_L = uhtot_L + uh_L;
+      LAYER_FENCE(n);
+    }
   }
+  if (wave_one_way<MAXL, -1>(C, duR)) {
 #pragma unroll
-  for (int n = 0; n < MAXL; n++) {
-    double uh_R, d_R;
-    flux_reg(C, n, C.u[n] + duR * C.v[n], uh_R, d_R);
-    FAmt_R = FAmt_R + d_R; uhtot_R = uhtot_R + uh_R;
-    LAYER_FENCE(n);
+    for (int n = 0; n < MAXL; n++) {
+      double uh_R, d_R;
+      flux_one_way<MAXL, -1>(C, n, C.u[n] + duR * C.v[n], uh_R, d_R);
+      FAmt_R = FAmt_R + d_R; uhtot_R = uhtot_R + uh_R;
+      LAYER_FENCE(n);
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < MAXL; n++) {
+      double uh_R, d_R;
+      flux_reg(C, n, C.u[n] + duR * C.v[n], uh_R, d_R);
+      FAmt_R = FAmt_R + d_R; uhtot_R = uhtot_R + uh_R;
+      LAYER_FENCE(n);
+    }
   }
   FAmt_0 = sweep_0 ? row_sum(FAmt_0) : dd0;
   FAmt_L = row_sum(FAmt_L); FAmt_R = row_sum(FAmt_R);
