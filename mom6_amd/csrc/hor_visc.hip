@@ -661,12 +661,12 @@ k_hv_accel(Dm d, const double *__restrict__ G, const double *__restrict__ P, con
 //     str_xy -> | -> diffu, diffv (global)
 // with three barriers (the next layer's u, v, h go into the second of two input buffers before the last one).  Every stage is
 // computed on the whole tile; a result is only valid where its inputs were: the outputs of the last stage are good on the tile
-// minus a frame of HT_H = 3 points, and that is all that is stored.  The four metric planes del2 and accel read at neighbouring
+// minus a frame of HT_H = 2 points (see below), and that is all that is stored.  The four metric planes del2 and accel read at neighbouring
 // points (dx2q, dy2q, dy2h, dx2h) sit in LDS for the life of the work-group.  Arithmetic: the expressions of k_hv_strain,
 // k_hv_del2, k_hv_stress and k_hv_accel, unchanged -- results are bit-identical with the four-kernel path
 // (MOM6X_HORVISC=legacy; Leith always takes the four kernels).  3 reads (x the tile's halo overhead) + 2 writes per cell-layer
 // instead of 20.
-#define HT_H 3
+#define HT_H 2
 // OM4: the switches of the OM4-class configuration (LAPLACIAN + BIHARMONIC with SMAGORINSKY_AH, both "better" bounds, land mask,
 // free slip, no LES addition) known at COMPILE time: the generic kernel keeps ~170 values live because every option's
 // coefficients are loaded and every branch is present; any other combination takes the generic instantiation.
@@ -688,7 +688,7 @@ k_hv_accel(Dm d, const double *__restrict__ G, const double *__restrict__ P, con
 #define HV_OM4_W4 0
 #endif
 template <int HT_X, int HT_Y, bool OM4>
-__global__ void __launch_bounds__(HT_X * HT_Y, (HT_X * HT_Y >= 1024 || (OM4 && HV_OM4_W4)) ? 4 : 2)   // 1024 threads: 4 wavefronts per SIMD (128 registers, 56 spilled); 512: 2 per SIMD, none spilled
+__global__ void __launch_bounds__(HT_X * HT_Y, (HT_X * HT_Y >= 1024 || (OM4 && HV_OM4_W4)) ? 4 : ((HT_X * HT_Y >= 768) ? 3 : 2))   // 1024 threads: 4 wavefronts per SIMD (128 registers, 56 spilled); 768: 3 per SIMD (168 registers); 512: 2 per SIMD
 k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom6x_hor_visc_params CS,
            const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ h,
            double *__restrict__ diffu, double *__restrict__ diffv, double h_neglect, int kc) {
@@ -713,7 +713,14 @@ k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom
   const size_t xf = loadable ? ix2(d, i, j) : ix2(d, 0, 0);
   const bool out_u = live && tx >= HT_H && tx < HT_X - HT_H && ty >= HT_H && ty < HT_Y - HT_H && (i <= d.ni - 1) && (j >= 0) && (j <= d.nj - 1);
   const bool out_v = live && tx >= HT_H && tx < HT_X - HT_H && ty >= HT_H && ty < HT_Y - HT_H && (i >= 0) && (i <= d.ni - 1) && (j <= d.nj - 1);
-  const bool need3 = live && tx >= HT_H - 1 && tx <= HT_X - HT_H && ty >= HT_H - 1 && ty <= HT_Y - HT_H;
+  // Where a stage is good, from what it reads (the inputs are there on the whole tile, 0 .. HT_X-1 / 0 .. HT_Y-1):
+  //   sh_xx (u, v to the west / south): >= 1          sh_xy (u, v to the north / east): <= HT-2
+  //   Del2u, Del2v (sh_xy to the south / west, sh_xx to the east / north): 1 .. HT-2
+  //   str_xx (sh_xy, Del2 to the west / south): 2 .. HT-2      str_xy (sh_xx, Del2 to the east / north): 1 .. HT-3
+  //   diffu, diffv (str_xy to the south / west, str_xx to the east / north): 2 .. HT-3 -- a frame of two.
+  // Stage 3 runs where stage 4 will look: str_xx at the outputs and one further east / north, str_xy one further west / south.
+  const bool need_xx = live && tx >= HT_H && tx <= HT_X - HT_H && ty >= HT_H && ty <= HT_Y - HT_H;
+  const bool need_xy = live && tx >= HT_H - 1 && tx < HT_X - HT_H && ty >= HT_H - 1 && ty < HT_Y - HT_H;
   const bool smag = HVF(Smagorinsky_Kh) || HVF(Smagorinsky_Ah), better = HVF(better_bound_Ah) || HVF(better_bound_Kh);
   const bool legacy_bound = HVF(Smagorinsky_Kh) && (HVF(bound_Kh) && !HVF(better_bound_Kh));   // :556-557 (no Leith here)
   const bool lap = HVF(Laplacian), bih = HVF(biharmonic);
@@ -778,7 +785,7 @@ k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom
     // ---- stage 3: str_xx at the h point :1112-1448, str_xy at the q point :1483-1826 (k_hv_stress) -- the expensive stage
     // (square roots, five divisions): only where stage 4 will look (its outputs' own points and one row / column around)
     const double hu0 = hface2(h00, hE, m00, mE, lm), hv0 = hface2(h00, hN, m00, mN, lm);
-    if (need3) {
+    if (need_xx) {
       double Shear = 0., hrat = 0., vbr = 0., sxx_out;
       if (smag) {
         const double sh_xx_sq = sxx * sxx;
@@ -829,7 +836,7 @@ k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom
       }
       s_txx[l] = sxx_out * (h00 * red_xx);
     }
-    if (need3) {
+    if (need_xy) {
       double Shear = 0., hrat = 0., vbr = 0., sxy_out;
       if (smag) {
         const double sh_xy_sq = sxy * sxy;
@@ -989,8 +996,10 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
     // (layers per work-group: the whole column up to 80 layers -- the ~30 coefficient planes of a tile are then read once; 4.53 ms
     //  against 4.68 with 25-layer chunks at nk = 75)
     const int kc = (kc_env > 0) ? std::min(kc_env, d.nk) : ((d.nk <= 80) ? d.nk : ((d.nk % 25 == 0) ? 25 : KCHUNK));
+    // Tiles: 32 x 24 points (768 threads = 12 wavefronts, three per SIMD at <= 168 registers: the OM4-class instantiation has 150;
+    // outputs on 28 x 20 = 73 % of the tile); MOM6X_HV_TILE=3216: 32 x 16 (round 3's: two per SIMD, 66 %), =64: 64 x 16.
     static const int wide = [] { const char *e = getenv("MOM6X_HV_TILE"); return e ? atoi(e) : 32; }();
-    const int TX = (wide == 64) ? 64 : 32, TY = 16;
+    const int TX = (wide == 64) ? 64 : 32, TY = (wide == 3216 || wide == 64) ? 16 : 24;
     const dim3 bt(TX, TY, 1);
     const dim3 gt((d.ni + 1 + (TX - 2 * HT_H) - 1) / (TX - 2 * HT_H), (d.nj + 1 + (TY - 2 * HT_H) - 1) / (TY - 2 * HT_H), (d.nk + kc - 1) / kc);
     const size_t ldsb = (size_t)16 * (TY + 2) * (TX + 2) * sizeof(double);
@@ -999,6 +1008,8 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<64, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 66 * 8));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 34 * 8));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 34 * 8));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 24, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 26 * 34 * 8));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 24, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 26 * 34 * 8));
       attr_set = true;
     }
     static const bool om4_off = [] { const char *e = getenv("MOM6X_HV_OM4"); return e && !strcmp(e, "0"); }();
@@ -1007,6 +1018,10 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
                      !CS.add_LES_viscosity && CS.use_land_mask;
     if (TX == 64) {
       KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<64, 16, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+    } else if (TY == 24 && om4) {
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+    } else if (TY == 24) {
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
     } else if (om4) {
       KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
     } else {
