@@ -113,7 +113,7 @@ subroutine continuity_PPM_init(Time, G, GV, US, param_file, diag, CS)
   type(continuity_PPM_CS), intent(inout) :: CS
   character(len=40) :: mdl = "MOM_continuity_PPM"
   character(len=24) :: sums
-  logical :: flag
+  logical :: flag, aggress
   integer(c_int) :: rc
 
   CS%initialized = .true.
@@ -138,12 +138,11 @@ subroutine continuity_PPM_init(Time, G, GV, US, param_file, diag, CS)
   call get_param(param_file, mdl, "CONT_PPM_AGGRESS_ADJUST", flag, &
                  "If true, allow the adjusted velocities to have a relative CFL change up to 0.5.", default=.false.)
   CS%p%aggress_adjust = merge(1_c_int, 0_c_int, flag)
-  if (flag) call MOM_error(FATAL, "continuity_PPM_init: CONT_PPM_AGGRESS_ADJUST is not carried by the MI355X path.")
+  aggress = flag   ! (MOM_continuity_PPM.F90:2728: CS%vol_CFL = CS%aggress_adjust, read only when that is false)
   call get_param(param_file, mdl, "CONT_PPM_VOLUME_BASED_CFL", flag, &
-                 "If true, use the ratio of the open face lengths to the tracer cell areas when estimating CFL numbers.", &
-                 default=.false.)
+                 "If true, use the ratio of the open face lengths to the tracer cell areas when estimating CFL numbers.  "//&
+                 "The default is set by CONT_PPM_AGGRESS_ADJUST.", default=aggress, do_not_read=aggress)
   CS%p%vol_CFL = merge(1_c_int, 0_c_int, flag)
-  if (flag) call MOM_error(FATAL, "continuity_PPM_init: CONT_PPM_VOLUME_BASED_CFL is not carried by the MI355X path.")
   call get_param(param_file, mdl, "CONTINUITY_CFL_LIMIT", CS%p%CFL_limit_adjust, &
                  "The maximum CFL of the adjusted velocities.", units="nondim", default=0.5)
   call get_param(param_file, mdl, "CONT_PPM_BETTER_ITER", flag, &

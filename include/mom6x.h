@@ -107,8 +107,8 @@ typedef struct mom6x_continuity_params {
   double tol_eta;          /* ETA_TOLERANCE  (0.5*NK*ANGSTROM)                */
   double tol_vel;          /* VELOCITY_TOLERANCE (3e8 m/s)                    */
   double CFL_limit_adjust; /* CONTINUITY_CFL_LIMIT (0.5)                      */
-  int    aggress_adjust;   /* CONT_PPM_AGGRESS_ADJUST (F)  -- only F supported */
-  int    vol_CFL;          /* CONT_PPM_VOLUME_BASED_CFL (F) -- only F supported */
+  int    aggress_adjust;   /* CONT_PPM_AGGRESS_ADJUST (F).  With this or vol_CFL set the thread-per-column kernels run, whose column sums are in the reference's order whatever sum_order says */
+  int    vol_CFL;          /* CONT_PPM_VOLUME_BASED_CFL (default = aggress_adjust, MOM_continuity_PPM.F90:2728) */
   int    better_iter;      /* CONT_PPM_BETTER_ITER (T)                        */
   int    use_visc_rem_max; /* CONT_PPM_USE_VISC_REM_MAX (T)                   */
   int    marginal_faces;   /* CONT_PPM_MARGINAL_FACE_AREAS (T)                */

@@ -154,7 +154,8 @@ k_mass_flux(Dm d, const double *__restrict__ G, FluxArgs A) {
   const int j = A.b0 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > A.a1 || j > A.b1) return;
   const int st = DIR ? d.pitch : 1;
-  const DirMetrics D = dir_metrics<DIR>(G, d);
+  DirMetrics D = dir_metrics<DIR>(G, d);
+  D.vol_CFL = A.vol_CFL;
   const size_t f2 = ix2(d, i, j);
   const size_t slab = (size_t)d.slab;
   const int nk = d.nk;
@@ -163,11 +164,17 @@ k_mass_flux(Dm d, const double *__restrict__ G, FluxArgs A) {
   ColIn C; C.u = A.u; C.h = A.h_in; C.hL = A.hL; C.hR = A.hR; C.vr = A.visc_rem; C.dt = dt; C.nk = nk; C.slab = slab;
   const bool use_visc_rem = (A.visc_rem != nullptr);
   const bool need_adjust = (A.uhbt != nullptr) || A.set_BT_cont;
-  const double CFL_dt = A.CFL_limit_adjust / dt;
+  const double I_dt = 1.0 / dt;
+  const double CFL_dt = A.aggress_adjust ? I_dt : A.CFL_limit_adjust / dt;   // :610-612
 
   // First sweep: layer transports and the column sums (:615-668)
   double duhdu_tot_0 = 0.0, uh_tot_0 = 0.0, visc_rem_max = 0.0;
-  const double dx_W = D.dT[f2], dx_E = D.dT[f2 + st];
+  double dx_W = D.dT[f2], dx_E = D.dT[f2 + st];
+  if (A.vol_CFL) {   // :651-654 / :1544-1547 (ratio_max :2660)
+    auto ratio_max = [](double a, double b, double maxrat) { return (fabs(a) > fabs(maxrat * b)) ? maxrat : a / b; };
+    dx_W = ratio_max(D.areaT[f2], D.Lface[f2], 1000.0 * D.dT[f2]);
+    dx_E = ratio_max(D.areaT[f2 + st], D.Lface[f2], 1000.0 * D.dT[f2 + st]);
+  }
   for (int k = 0; k < nk; k++) {
     const size_t f = f2 + (size_t)k * slab;
     const double vrem = use_visc_rem ? A.visc_rem[f] : 1.0;
@@ -187,7 +194,22 @@ k_mass_flux(Dm d, const double *__restrict__ G, FluxArgs A) {
   double du_max_CFL = 2.0 * (CFL_dt * dx_W) * I_vrm;
   double du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
   const double maskC = D.maskC[f2];
-  if (use_visc_rem) {
+  if (A.aggress_adjust) {   // :664-678, :693-704 / :1558-1572, :1585-1596: the limits look at the neighbouring faces' velocities
+    for (int k = 0; k < nk; k++) {
+      const size_t f = f2 + (size_t)k * slab;
+      const double uk = A.u[f];
+      const double lim_max = 0.499 * ((dx_W * I_dt - uk) + dmin(0.0, A.u[f - st]));
+      const double lim_min = 0.499 * ((-dx_E * I_dt - uk) + dmax(0.0, A.u[f + st]));
+      if (use_visc_rem) {
+        const double vrem = A.visc_rem[f];
+        if (du_max_CFL * vrem > lim_max) du_max_CFL = lim_max / vrem;
+        if (du_min_CFL * vrem < lim_min) du_min_CFL = lim_min / vrem;
+      } else {
+        du_max_CFL = dmin(du_max_CFL, lim_max);
+        du_min_CFL = dmax(du_min_CFL, lim_min);
+      }
+    }
+  } else if (use_visc_rem) {
     for (int k = 0; k < nk; k++) {
       const size_t f = f2 + (size_t)k * slab;
       const double uk = A.u[f], vrem = A.visc_rem[f];
@@ -269,23 +291,24 @@ __global__ void __launch_bounds__(256)
 k_flux_thickness(Dm d, const double *__restrict__ G, const double *__restrict__ u,
                  const double *__restrict__ h, const double *__restrict__ hL,
                  const double *__restrict__ hR, double *__restrict__ h_u, double dt, int marginal,
-                 const double *__restrict__ visc_rem, int a0, int a1, int b0, int b1) {
+                 const double *__restrict__ visc_rem, int a0, int a1, int b0, int b1, int vol_CFL) {
   const int i = a0 + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = b0 + blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
   if (i > a1 || j > b1) return;
   const int st = DIR ? d.pitch : 1;
   const double *IdT = gm(G, d, DIR ? MOM6X_G_IdyT : MOM6X_G_IdxT);
+  const double *Lface = gm(G, d, DIR ? MOM6X_G_dx_Cv : MOM6X_G_dy_Cu), *IareaT = gm(G, d, MOM6X_G_IareaT);
   const size_t f2 = ix2(d, i, j), f = f2 + (size_t)k * d.slab, p = f + st;
   const double uf = u[f];
   double h_avg, h_marg;
   if (uf > 0.0) {
-    const double CFL = uf * dt * IdT[f2];
+    const double CFL = vol_CFL ? (uf * dt) * (Lface[f2] * IareaT[f2]) : uf * dt * IdT[f2];   // :1019 / :1917
     const double curv_3 = (hL[f] + hR[f]) - 2.0 * h[f];
     h_avg = hR[f] + CFL * (0.5 * (hL[f] - hR[f]) + curv_3 * (CFL - 1.5));
     h_marg = hR[f] + CFL * ((hL[f] - hR[f]) + 3.0 * curv_3 * (CFL - 1.0));
   } else if (uf < 0.0) {
-    const double CFL = -uf * dt * IdT[f2 + st];
+    const double CFL = vol_CFL ? (-uf * dt) * (Lface[f2] * IareaT[f2 + st]) : -uf * dt * IdT[f2 + st];   // :1025 / :1924
     const double curv_3 = (hL[p] + hR[p]) - 2.0 * h[p];
     h_avg = hL[p] + CFL * (0.5 * (hR[p] - hL[p]) + curv_3 * (CFL - 1.5));
     h_marg = hL[p] + CFL * ((hR[p] - hL[p]) + 3.0 * curv_3 * (CFL - 1.0));
@@ -347,8 +370,12 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
   int ei0 = ish, ei1 = ieh, ej0 = jsh, ej1 = jeh;
   if (DIR == 0) { ei0 = ish - 1; ei1 = ieh + 1; } else { ej0 = jsh - 1; ej1 = jeh + 1; }
   const int scheme = P.upwind_1st ? 2 : (P.simple_2nd ? 1 : 0);
-  const bool wave = (P.sum_order == MOM6X_SUM_TREE16);   // one wavefront row per face column, everything in registers
-  const bool lds = wave || use_lds_path(d.nk);
+  // CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL (non-default, :2725-2733) are carried by the thread-per-column kernels
+  // alone: their limits read the neighbouring faces' velocities, which the marching kernels do not stage.  Those kernels sum
+  // columns in the reference's order, so under these switches sum_order has no effect (include/mom6x.h).
+  const bool special = P.aggress_adjust || P.vol_CFL;
+  const bool wave = !special && (P.sum_order == MOM6X_SUM_TREE16);   // one wavefront row per face column, everything in registers
+  const bool lds = !special && (wave || use_lds_path(d.nk));
   if (!lds)
     KLAUNCH(c, "k_edge<DIR>", k_edge<DIR>, grid3(ei1 - ei0 + 1, ej1 - ej0 + 1, d.nk, blk), blk, d, c->G, h_src,
                        c->hL, c->hR, 2.0 * c->GV.Angstrom_H, scheme, P.monotonic, ei0, ei1, ej0, ej1);
@@ -364,6 +391,7 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
   }
   A.dt = dt; A.CFL_limit_adjust = P.CFL_limit_adjust; A.tol_eta = P.tol_eta; A.tol_vel = P.tol_vel;
   A.better_iter = P.better_iter; A.use_visc_rem_max = P.use_visc_rem_max;
+  A.aggress_adjust = P.aggress_adjust; A.vol_CFL = P.vol_CFL;
   if (DIR == 0) { A.a0 = ish - 1; A.a1 = ieh; A.b0 = jsh; A.b1 = jeh; }
   else          { A.a0 = ish; A.a1 = ieh; A.b0 = jsh - 1; A.b1 = jeh; }
   if (du_cor) HIPCHK(hipMemsetAsync(du_cor, 0, sizeof(double) * d.slab, c->stream));
@@ -412,7 +440,7 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
     if (BT_h) {
       KLAUNCH(c, "k_flux_thickness<DIR>", k_flux_thickness<DIR>, grid3(A.a1 - A.a0 + 1, A.b1 - A.b0 + 1, d.nk, blk), blk,
                          d, c->G, (u_cor ? (const double *)u_cor : u), h_src, c->hL, c->hR, BT_h, dt,
-                         P.marginal_faces, visc_rem, A.a0, A.a1, A.b0, A.b1);
+                         P.marginal_faces, visc_rem, A.a0, A.a1, A.b0, A.b1, P.vol_CFL);
     }
   }
   if (first_pass || !c->cont_h_unused)   // (the second direction's new thicknesses are the routine's result -- unless nobody wants it)
@@ -432,8 +460,6 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
 
 extern "C" int mom6x_continuity_init(mom6x_ctx *c, const mom6x_continuity_params *p) {
   REQUIRE(c && p, MOM6X_EINVAL, "mom6x_continuity_init: null argument");
-  REQUIRE(!p->aggress_adjust && !p->vol_CFL, MOM6X_EUNSUPPORTED,
-          "continuity_PPM: CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL are not supported");
   REQUIRE(p->sum_order == MOM6X_SUM_REFERENCE || p->sum_order == MOM6X_SUM_TREE16, MOM6X_EINVAL,
           "continuity_PPM: sum_order must be MOM6X_SUM_REFERENCE (0) or MOM6X_SUM_TREE16 (1)");
   REQUIRE(p->sum_order != MOM6X_SUM_TREE16 || mass_flux_wave_usable(c->d.nk), MOM6X_EUNSUPPORTED,

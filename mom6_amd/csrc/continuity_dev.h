@@ -3,7 +3,8 @@
 #include "mom6x_dev.h"
 
 struct DirMetrics {
-  const double *Lface, *IdT, *dT, *dC, *maskC, *IareaT, *mask2dT;
+  const double *Lface, *IdT, *dT, *dC, *maskC, *IareaT, *mask2dT, *areaT;
+  int vol_CFL;   // CONT_PPM_VOLUME_BASED_CFL (the thread-per-column kernels of continuity.hip only)
 };
 
 template <int DIR>
@@ -16,6 +17,8 @@ __device__ __forceinline__ DirMetrics dir_metrics(const double *G, const Dm &d) 
   D.maskC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu);
   D.IareaT = gm(G, d, MOM6X_G_IareaT);
   D.mask2dT = gm(G, d, MOM6X_G_mask2dT);
+  D.areaT = gm(G, d, MOM6X_G_areaT);
+  D.vol_CFL = 0;
   return D;
 }
 
@@ -103,14 +106,14 @@ __device__ __forceinline__ void flux_layer(const DirMetrics &D, int st, size_t f
                                            double Lf, double &uh, double &duhdu) {
   double h_marg;
   if (u > 0.0) {
-    const double CFL = u * dt * D.IdT[f2];
+    const double CFL = D.vol_CFL ? (u * dt) * (D.Lface[f2] * D.IareaT[f2]) : u * dt * D.IdT[f2];   // :938 / :1832
     const double l = hL[f], r = hR[f];
     const double curv_3 = (l + r) - 2.0 * h[f];
     uh = Lf * u * (r + CFL * (0.5 * (l - r) + curv_3 * (CFL - 1.5)));
     h_marg = r + CFL * ((l - r) + 3.0 * curv_3 * (CFL - 1.0));
   } else if (u < 0.0) {
     const size_t p = f + st;
-    const double CFL = -u * dt * D.IdT[f2 + st];
+    const double CFL = D.vol_CFL ? (-u * dt) * (D.Lface[f2] * D.IareaT[f2 + st]) : -u * dt * D.IdT[f2 + st];   // :945 / :1840
     const double l = hL[p], r = hR[p];
     const double curv_3 = (l + r) - 2.0 * h[p];
     uh = Lf * u * (l + CFL * (0.5 * (r - l) + curv_3 * (CFL - 1.5)));
@@ -134,6 +137,7 @@ struct FluxArgs {
   int set_BT_cont;
   double dt, CFL_limit_adjust, tol_eta, tol_vel;
   int better_iter, use_visc_rem_max;
+  int aggress_adjust, vol_CFL;   // CONT_PPM_AGGRESS_ADJUST, CONT_PPM_VOLUME_BASED_CFL: carried by k_mass_flux (continuity.hip) only
   int a0, a1, b0, b1;        // face index ranges (i-range, j-range)
 };
 

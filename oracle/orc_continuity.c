@@ -10,7 +10,7 @@
  * row-wide `domore` early exit of the Newton iteration are kept as in the reference.
  *
  * Supported flags: the default path of continuity_PPM_init (:2674-2754) plus
- * monotonic / simple_2nd / upwind_1st; aggress_adjust and vol_CFL must be false;
+ * monotonic / simple_2nd / upwind_1st; aggress_adjust and vol_CFL (:612, :651-716, :938-945, :1019-1025 and their meridional twins);
  * OBC unassociated; por_face_area == 1.
  */
 #include "orc_common.h"
@@ -25,10 +25,14 @@ typedef struct {
   const double *maskC;   /* G%mask2dCu | G%mask2dCv */
   const double *IareaT;
   const double *mask2dT;
+  const double *areaT;
+  int vol_CFL;           /* CS%vol_CFL: CFL numbers and limits from cell areas / open face widths */
 } dir_t;
 
-static void dir_setup(dir_t *D, const mom6x_dims *d, const double *G, int dir) {
+static void dir_setup(dir_t *D, const mom6x_dims *d, const double *G, int dir, int vol_CFL) {
   D->dir = dir;
+  D->vol_CFL = vol_CFL;
+  D->areaT = GM(G, d, MOM6X_G_areaT);
   D->st = dir ? d->pitch : 1;
   D->Lface = GM(G, d, dir ? MOM6X_G_dx_Cv : MOM6X_G_dy_Cu);
   D->IdT = GM(G, d, dir ? MOM6X_G_IdyT : MOM6X_G_IdxT);
@@ -137,12 +141,14 @@ static inline void flux_layer_face(const dir_t *D, size_t f, double u, const dou
   double CFL, curv_3, h_marg;
   const size_t p = f + (size_t)D->st;
   if (u > 0.0) {
-    CFL = u * dt * D->IdT[f];
+    if (D->vol_CFL) CFL = (u * dt) * (D->Lface[f] * D->IareaT[f]);   /* :938 / :1832 */
+    else CFL = u * dt * D->IdT[f];
     curv_3 = (hL[f] + hR[f]) - 2.0 * h[f];
     *uh = (D->Lface[f] * 1.0) * u * (hR[f] + CFL * (0.5 * (hL[f] - hR[f]) + curv_3 * (CFL - 1.5)));
     h_marg = hR[f] + CFL * ((hL[f] - hR[f]) + 3.0 * curv_3 * (CFL - 1.0));
   } else if (u < 0.0) {
-    CFL = -u * dt * D->IdT[p];
+    if (D->vol_CFL) CFL = (-u * dt) * (D->Lface[f] * D->IareaT[p]);   /* :945 / :1840 */
+    else CFL = -u * dt * D->IdT[p];
     curv_3 = (hL[p] + hR[p]) - 2.0 * h[p];
     *uh = (D->Lface[f] * 1.0) * u * (hL[p] + CFL * (0.5 * (hR[p] - hL[p]) + curv_3 * (CFL - 1.5)));
     h_marg = hL[p] + CFL * ((hR[p] - hL[p]) + 3.0 * curv_3 * (CFL - 1.0));
@@ -404,12 +410,14 @@ static void flux_thickness(const mom6x_dims *d, const dir_t *D, const double *u,
     size_t f = IX3(d, i, j, k), f2 = IX2(d, i, j), p = f + st;
     double CFL, curv_3, h_avg, h_marg, uf = u[f];
     if (uf > 0.0) {
-      CFL = uf * dt * D->IdT[f2];
+      if (D->vol_CFL) CFL = (uf * dt) * (D->Lface[f2] * D->IareaT[f2]);   /* :1019 / :1917 */
+      else CFL = uf * dt * D->IdT[f2];
       curv_3 = (hL[f] + hR[f]) - 2.0 * h[f];
       h_avg = hR[f] + CFL * (0.5 * (hL[f] - hR[f]) + curv_3 * (CFL - 1.5));
       h_marg = hR[f] + CFL * ((hL[f] - hR[f]) + 3.0 * curv_3 * (CFL - 1.0));
     } else if (uf < 0.0) {
-      CFL = -uf * dt * D->IdT[f2 + st];
+      if (D->vol_CFL) CFL = (-uf * dt) * (D->Lface[f2] * D->IareaT[f2 + st]);   /* :1025 / :1924 */
+      else CFL = -uf * dt * D->IdT[f2 + st];
       curv_3 = (hL[p] + hR[p]) - 2.0 * h[p];
       h_avg = hL[p] + CFL * (0.5 * (hR[p] - hL[p]) + curv_3 * (CFL - 1.5));
       h_marg = hL[p] + CFL * ((hR[p] - hL[p]) + 3.0 * curv_3 * (CFL - 1.0));
@@ -428,6 +436,19 @@ static void flux_thickness(const mom6x_dims *d, const dir_t *D, const double *u,
 }
 
 /* zonal_mass_flux :519-819 / meridional_mass_flux :1412-1711 */
+/* ratio_max :2660-2671 */
+static inline double ratio_max(double a, double b, double maxrat) {
+  return (fabs(a) > fabs(maxrat * b)) ? maxrat : a / b;
+}
+/* dx_W, dx_E (dy_S, dy_N) of a face: :651-654 / :1544-1547 */
+static inline void face_widths(const dir_t *D, size_t f, double *dx_W, double *dx_E) {
+  const size_t p = f + (size_t)D->st;
+  if (D->vol_CFL) {
+    *dx_W = ratio_max(D->areaT[f], D->Lface[f], 1000.0 * D->dT[f]);
+    *dx_E = ratio_max(D->areaT[p], D->Lface[f], 1000.0 * D->dT[p]);
+  } else { *dx_W = D->dT[f]; *dx_E = D->dT[p]; }
+}
+
 static void mass_flux(const mom6x_dims *d, const dir_t *D, const mom6x_continuity_params *CS,
                       const double *u, const double *h_in, const double *hL, const double *hR,
                       double *uh, double dt, int ish, int ieh, int jsh, int jeh,
@@ -437,7 +458,8 @@ static void mass_flux(const mom6x_dims *d, const dir_t *D, const mom6x_continuit
   const int nz = d->nk, P = d->pitch;
   const size_t slab = (size_t)d->slab;
   const int use_visc_rem = (visc_rem_u != NULL);
-  const double CFL_dt = CS->CFL_limit_adjust / dt;
+  const double I_dt = 1.0 / dt;
+  const double CFL_dt = CS->aggress_adjust ? I_dt : CS->CFL_limit_adjust / dt;   /* :610-612 */
   int b0, b1, a0, a1;
   if (D->dir == 0) { b0 = jsh; b1 = jeh; a0 = ish - 1; a1 = ieh; }
   else             { b0 = jsh - 1; b1 = jeh; a0 = ish; a1 = ieh; }
@@ -480,7 +502,8 @@ static void mass_flux(const mom6x_dims *d, const dir_t *D, const mom6x_continuit
         size_t f = row_face(d, D, &R, a);
         double I_vrm = 0.0;
         if (visc_rem_max[a] > 0.0) I_vrm = 1.0 / visc_rem_max[a];
-        double dx_W = D->dT[f], dx_E = D->dT[f + D->st];
+        double dx_W, dx_E;
+        face_widths(D, f, &dx_W, &dx_E);
         du_max_CFL[a] = 2.0 * (CFL_dt * dx_W) * I_vrm;
         du_min_CFL[a] = -2.0 * (CFL_dt * dx_E) * I_vrm;
         uh_tot_0[a] = 0.0; duhdu_tot_0[a] = 0.0;
@@ -497,20 +520,41 @@ static void mass_flux(const mom6x_dims *d, const dir_t *D, const mom6x_continuit
         duhdu_tot_0[a] = duhdu_tot_0[a] + duhdu[(size_t)k * P + a];
         uh_tot_0[a] = uh_tot_0[a] + uh[f + k * slab];
       }
-      if (use_visc_rem) { /* :680-693 (non-aggressive) */
+      if (use_visc_rem && CS->aggress_adjust) { /* :664-678 / :1558-1572 */
+        for (int k = 0; k < nz; k++) for (int a = a0; a <= a1; a++) {
+          size_t f = row_face(d, D, &R, a), fk = f + k * slab;
+          double dx_W, dx_E;
+          face_widths(D, f, &dx_W, &dx_E);
+          double vrem = vr[(size_t)k * P + a];
+          double du_lim = 0.499 * ((dx_W * I_dt - u[fk]) + orc_min(0.0, u[fk - D->st]));
+          if (du_max_CFL[a] * vrem > du_lim) du_max_CFL[a] = du_lim / vrem;
+          du_lim = 0.499 * ((-dx_E * I_dt - u[fk]) + orc_max(0.0, u[fk + D->st]));
+          if (du_min_CFL[a] * vrem < du_lim) du_min_CFL[a] = du_lim / vrem;
+        }
+      } else if (use_visc_rem) { /* :680-691 */
         for (int k = 0; k < nz; k++) for (int a = a0; a <= a1; a++) {
           size_t f = row_face(d, D, &R, a);
-          double dx_W = D->dT[f], dx_E = D->dT[f + D->st];
+          double dx_W, dx_E;
+          face_widths(D, f, &dx_W, &dx_E);
           double uk = u[f + k * slab], vrem = vr[(size_t)k * P + a];
           if (du_max_CFL[a] * vrem > dx_W * CFL_dt - uk * D->maskC[f])
             du_max_CFL[a] = (dx_W * CFL_dt - uk) / vrem;
           if (du_min_CFL[a] * vrem < -dx_E * CFL_dt - uk * D->maskC[f])
             du_min_CFL[a] = -(dx_E * CFL_dt + uk) / vrem;
         }
-      } else { /* :708-717 */
+      } else if (CS->aggress_adjust) { /* :693-704 */
+        for (int k = 0; k < nz; k++) for (int a = a0; a <= a1; a++) {
+          size_t f = row_face(d, D, &R, a), fk = f + k * slab;
+          double dx_W, dx_E;
+          face_widths(D, f, &dx_W, &dx_E);
+          du_max_CFL[a] = orc_min(du_max_CFL[a], 0.499 * ((dx_W * I_dt - u[fk]) + orc_min(0.0, u[fk - D->st])));
+          du_min_CFL[a] = orc_max(du_min_CFL[a], 0.499 * ((-dx_E * I_dt - u[fk]) + orc_max(0.0, u[fk + D->st])));
+        }
+      } else { /* :705-716 */
         for (int k = 0; k < nz; k++) for (int a = a0; a <= a1; a++) {
           size_t f = row_face(d, D, &R, a);
-          double dx_W = D->dT[f], dx_E = D->dT[f + D->st];
+          double dx_W, dx_E;
+          face_widths(D, f, &dx_W, &dx_E);
           double uk = u[f + k * slab];
           du_max_CFL[a] = orc_min(du_max_CFL[a], dx_W * CFL_dt - uk);
           du_min_CFL[a] = orc_max(du_min_CFL[a], -(dx_E * CFL_dt + uk));
@@ -572,14 +616,18 @@ int orc_continuity_PPM(const mom6x_dims *d, const double *G, const mom6x_vgrid *
                        const double *visc_rem_u, const double *visc_rem_v,
                        double *u_cor, double *v_cor, const mom6x_BT_cont *BT,
                        double *du_cor, double *dv_cor) {
-  if (CS->aggress_adjust || CS->vol_CFL) return MOM6X_EUNSUPPORTED;
   if (CS->sum_order != MOM6X_SUM_REFERENCE && CS->sum_order != MOM6X_SUM_TREE16) return MOM6X_EINVAL;
+  /* CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL: the device takes its thread-per-column kernels for these, whose column
+   * sums run in the reference's order whatever sum_order says (include/mom6x.h) */
+  mom6x_continuity_params CS_local = *CS;
+  if (CS_local.aggress_adjust || CS_local.vol_CFL) CS_local.sum_order = MOM6X_SUM_REFERENCE;
+  CS = &CS_local;
   if ((visc_rem_u != NULL) != (visc_rem_v != NULL)) return MOM6X_EINVAL;
   const size_t n3 = (size_t)d->slab * d->nk;
   double *h_W = (double *)calloc(n3, sizeof(double)), *h_E = (double *)calloc(n3, sizeof(double));
   double *slp = (double *)calloc((size_t)d->slab, sizeof(double));
   const double h_min = GV->Angstrom_H;
-  dir_t DX, DY; dir_setup(&DX, d, G, 0); dir_setup(&DY, d, G, 1);
+  dir_t DX, DY; dir_setup(&DX, d, G, 0, CS->vol_CFL); dir_setup(&DY, d, G, 1, CS->vol_CFL);
   const int x_first = ((first_direction % 2) == 0);
   int stencil = 3; if (CS->simple_2nd) stencil = 2; if (CS->upwind_1st) stencil = 1;
   const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1;

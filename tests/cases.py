@@ -12,7 +12,7 @@ def visc_coefs(d, M):
     return vc(d, M)
 
 
-def rk2_params(d, GV, bt_mod=None, rk2_mod=None, cor_mod=None):
+def rk2_params(d, GV, bt_mod=None, rk2_mod=None, cor_mod=None, cont_mod=None):
     bt = abi.barotropic_params_default(30.0)
     for k, v in (bt_mod or {}).items():
         setattr(bt, k, v)
@@ -22,7 +22,10 @@ def rk2_params(d, GV, bt_mod=None, rk2_mod=None, cor_mod=None):
     cor = abi.coriolis_params_default()
     for k, v in (cor_mod or {}).items():
         setattr(cor, k, v)
-    return abi.continuity_params_default(d.nk, GV.Angstrom_H), bt, cor, abi.pgf_params_default(GV.Rho0), rk2
+    cont = abi.continuity_params_default(d.nk, GV.Angstrom_H)
+    for k, v in (cont_mod or {}).items():
+        setattr(cont, k, v)
+    return cont, bt, cor, abi.pgf_params_default(GV.Rho0), rk2
 
 
 def rk2_inputs(cfg, per_stage=False, new_diff=False):
@@ -45,11 +48,12 @@ def rk2_inputs(cfg, per_stage=False, new_diff=False):
     return dict(GV=GV, Rlay=Rlay, gp=gp, dt=1200.0, h=h, u=u, v=v, coefs=coefs, taux=taux, tauy=tauy, diff_new=diff_new)
 
 
-def oracle_rk2(orc, cfg, inp, nsteps, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, tv=None, vv=None, hv=None, Hmix_stress=0.0):
+def oracle_rk2(orc, cfg, inp, nsteps, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, tv=None, vv=None, hv=None, Hmix_stress=0.0,
+               cont_mod=None):
     """nsteps of orc_step_dyn_split_RK2 from the seeded state; returns (final state dict, OrcModel)."""
     gg, d, M = cfg
     GV, dt, h, u, v = inp["GV"], inp["dt"], inp["h"], inp["u"], inp["v"]
-    cont, bt, cor, pgf, rk2 = rk2_params(d, GV, bt_mod, rk2_mod, cor_mod)
+    cont, bt, cor, pgf, rk2 = rk2_params(d, GV, bt_mod, rk2_mod, cor_mod, cont_mod)
     m = orc.OrcModel(d, M, GV, cont, bt, cor, pgf, rk2, inp["Rlay"], inp["gp"], first_direction)
     if tv is not None:
         m.set_tv(*tv)

@@ -200,6 +200,7 @@ contains
     logical, optional, intent(in) :: default
     logical, optional, intent(in) :: fail_if_missing, do_not_read, do_not_log, debuggingParam, layoutParam
     integer :: m
+    if (present(do_not_read)) then ; if (do_not_read) return ; endif   ! (MOM_file_parser: the value stays what the caller set)
     m = find(CS, varname)
     if (m > 0) then ; value = (index(CS%values(m), "T") > 0 .or. index(CS%values(m), "t") > 0)
     elseif (present(default)) then ; value = default ; endif

@@ -177,3 +177,14 @@ def roughen(h, seed=17):
     rng = np.random.default_rng(seed)
     f = rng.choice([1.0, 1.0, 1.0, 0.5, 0.2, 0.05, 1e-2, 1e-3, 1e-6, 2.0, 5.0], size=h.shape)
     return np.ascontiguousarray(h * f)
+
+
+def narrowed_faces(d, M):
+    """A copy of the metrics with open face widths G%dy_Cu, G%dx_Cv of 50-100 % of the cell widths (sub-grid channels): what
+    CONT_PPM_VOLUME_BASED_CFL is about -- with full-width faces dy_Cu * IareaT is 1 / dxT up to rounding."""
+    import numpy as np
+    from mom6_amd import abi, synth
+    M2 = np.array(M, copy=True)
+    M2[abi.G["dy_Cu"]] = M[abi.G["dy_Cu"]] * (0.75 + 0.25 * synth.smooth_field(d, 41, ox=1.0, oy=0.5))
+    M2[abi.G["dx_Cv"]] = M[abi.G["dx_Cv"]] * (0.75 + 0.25 * synth.smooth_field(d, 42, ox=0.5, oy=1.0))
+    return M2

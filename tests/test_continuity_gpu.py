@@ -115,6 +115,17 @@ def test_continuity_scheme_flags(orc, flag):
     _run_case(orc, H.benchmark_small(), 0, "full", cs_mod={flag: 1})
 
 
+@pytest.mark.parametrize("flags", [dict(vol_CFL=1), dict(aggress_adjust=1, vol_CFL=1), dict(aggress_adjust=1, vol_CFL=0)])
+@pytest.mark.parametrize("mode", ["adjust_novisc", "full"])
+def test_continuity_aggress_adjust_and_volume_based_cfl(orc, flags, mode):
+    """CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL (MOM_continuity_PPM.F90:2725-2733; non-default): whatever path and sum
+    order are asked for, the thread-per-column kernels run (reference order) -- velocities and adjustments strong enough for the
+    limits on du to bind, faces narrower than their cells."""
+    for cfg, fd in ((H.benchmark_small(), 0), (H.double_gyre(), 1)):
+        gg, d, M = cfg
+        _run_case(orc, (gg, d, H.narrowed_faces(d, M)), fd, mode, cs_mod=flags, u_scale=8.0, bt_pert=0.9)
+
+
 @pytest.mark.parametrize("mode", ["bt_cont", "full"])
 @pytest.mark.parametrize("cfg", ["double_gyre", "benchmark_small"])
 def test_continuity_tied_quotients(orc, mode, cfg):

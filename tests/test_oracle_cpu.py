@@ -34,6 +34,46 @@ def test_continuity_conserves_volume_exactly_and_matches_uhbt(orc):
     assert err.max() <= CS.tol_eta * 1.0001 + 1e-12        # the Newton solve meets ETA_TOLERANCE
 
 
+@pytest.mark.parametrize("flags", [dict(vol_CFL=1), dict(aggress_adjust=1, vol_CFL=1), dict(aggress_adjust=1)])
+def test_continuity_aggress_adjust_and_volume_based_cfl(orc, flags):
+    """CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL (MOM_continuity_PPM.F90:612, :651-716, :938-945): volume is still
+    conserved layer by layer and the switches do change the answer -- the volume-based CFL number wherever dy_Cu / areaT is not
+    1 / dxT (faces narrower than their cells), the aggressive limits where a limit on du binds (a strong adjustment)."""
+    GV = abi.vgrid_default()
+    gg, d, M = H.double_gyre()
+    M = H.narrowed_faces(d, M)
+    CS = abi.continuity_params_default(d.nk)
+    h, u, v = synth.make_state(d, M, thin_frac=0.1)
+    base = _cont(orc, d, M, GV, CS, u, v, h, 1200.0)
+    for k, val in flags.items():
+        setattr(CS, k, val)
+    hn, uh, vh = _cont(orc, d, M, GV, CS, u, v, h, 1200.0)
+    sl = H.interior(d, "h"); A = M[G["areaT"]][sl]
+    v0 = (h[(Ellipsis,) + sl] * A).sum(1).sum(1); v1 = (hn[(Ellipsis,) + sl] * A).sum(1).sum(1)
+    assert np.all(np.abs(v1 / v0 - 1) < 1e-14)
+    assert np.array_equal(uh, base[1]) == (not flags.get("vol_CFL"))   # without uhbt / BT_cont aggress_adjust alone changes nothing
+    # (as tests/test_continuity_gpu.py::test_continuity_newton_reaches_cfl_limits: fast flow, a strong adjustment)
+    gg, d, M = H.benchmark_small()
+    M = H.narrowed_faces(d, M)
+    h, u, v = synth.make_state(d, M, thin_frac=0.1)
+    u = np.ascontiguousarray(20.0 * u); v = np.ascontiguousarray(20.0 * v)
+    CS = abi.continuity_params_default(d.nk)
+    hn, uh, vh = _cont(orc, d, M, GV, CS, u, v, h, 1200.0)
+    uhbt = np.ascontiguousarray(uh.sum(0) * (1.0 + 3.0 * synth.smooth_field(d, 13, ox=1.0, oy=0.5)))
+    vhbt = np.ascontiguousarray(vh.sum(0) * (1.0 - 3.0 * synth.smooth_field(d, 14, ox=0.5, oy=1.0)))
+    vr = np.ascontiguousarray(np.clip(0.5 + 0.6 * synth.smooth_field(d, 11, nk=d.nk, ox=1.0, oy=0.5), 0.0, 1.0))
+    outs = []
+    for on in (False, True):
+        for k, val in flags.items():
+            setattr(CS, k, val if on else 0)
+        uc = np.zeros_like(h); vc = np.zeros_like(h)
+        hn2, uh2, vh2 = _cont(orc, d, M, GV, CS, u, v, h, 1200.0, uhbt=uhbt, vhbt=vhbt, visc_rem_u=vr, visc_rem_v=vr.copy(), u_cor=uc, v_cor=vc)
+        outs.append(uh2)
+        assert np.isfinite(uh2).all() and np.isfinite(uc).all()
+    if flags.get("aggress_adjust"):
+        assert not np.array_equal(outs[0], outs[1])        # the adjustment runs into the limits, and they are different limits
+
+
 @pytest.mark.parametrize("case,nk", [("double_gyre", 2), ("benchmark_small", 8), ("benchmark_small", 75)])
 def test_tree16_sum_order_agrees_with_the_reference_order(orc, case, nk):
     """mom6x_continuity_params.sum_order = MOM6X_SUM_TREE16 (the order of the wave-owned device kernel) against the

@@ -116,12 +116,15 @@ def test_turn_is_its_own_fourth_root():
     assert np.abs(Mr[G["mask2dCu"]]).sum() == np.abs(M[G["mask2dCv"]]).sum() > 0
 
 
-@pytest.mark.parametrize("sum_order", [abi.SUM_REFERENCE, abi.SUM_TREE16])
+@pytest.mark.parametrize("sum_order,flags", [(abi.SUM_REFERENCE, {}), (abi.SUM_TREE16, {}), (abi.SUM_REFERENCE, dict(vol_CFL=1)),
+                                             (abi.SUM_TREE16, dict(aggress_adjust=1, vol_CFL=1)), (abi.SUM_REFERENCE, dict(aggress_adjust=1))])
 @pytest.mark.parametrize("first_direction", [0, 1])
-def test_rotate_continuity_and_CorAdCalc(orc, first_direction, sum_order):
+def test_rotate_continuity_and_CorAdCalc(orc, first_direction, sum_order, flags):
     """continuity_PPM with the Newton adjustment towards uhbt / vhbt and the BT_cont fits, then CorAdCalc, on a grid and its
     quarter turn: every output of the turned run, turned back, equals the original run bit for bit."""
     d, M, h, u, v = _state(H.benchmark_small(), thin_frac=0.1)
+    if flags:
+        M = H.narrowed_faces(d, M)   # (open face widths that differ from the cell widths: what the volume-based CFL number sees)
     GV = abi.vgrid_default(); dt = 900.0
     T = Turn(d); dr = T.dr; Mr = T.metrics(M)
     vr_u = np.ascontiguousarray(np.clip(0.5 + 0.6 * synth.smooth_field(d, 11, nk=d.nk, ox=1.0, oy=0.5), 0.0, 1.0))
@@ -131,6 +134,8 @@ def test_rotate_continuity_and_CorAdCalc(orc, first_direction, sum_order):
 
     def run(d_, M_, fd, u_, v_, h_, ub, vb, vru, vrv):
         CS = abi.continuity_params_default(d_.nk, GV.Angstrom_H); CS.sum_order = sum_order
+        for k_, v__ in flags.items():   # CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL: the zonal and meridional
+            setattr(CS, k_, v__)        # branches (:651-716 / :1544-1608) are each other's quarter turn
         z = lambda: np.zeros_like(h_)
         o = dict(h=z(), uh=z(), vh=z(), u_cor=z(), v_cor=z())
         bt = orc.new_bt_cont(d_)

@@ -29,7 +29,7 @@ STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h",
 
 
 def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, per_stage=False, new_diff=False,
-        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None, Hmix_stress=0.0, recon=0, chk=False):
+        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None, Hmix_stress=0.0, recon=0, chk=False, cont_mod=None):
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
@@ -39,7 +39,7 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
     h, u, v, coefs, taux, tauy, diff_new = (inp[k] for k in ("h", "u", "v", "coefs", "taux", "tauy", "diff_new"))
 
     def params():
-        return cases.rk2_params(d, GV, bt_mod, rk2_mod, cor_mod)
+        return cases.rk2_params(d, GV, bt_mod, rk2_mod, cor_mod, cont_mod)
 
     tv = None
     if eos_form is not None:   # tv%T, tv%S, tv%eqn_of_state: the PressureForce calls take the use_EOS branch
@@ -57,7 +57,7 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
         for k_, v_ in dev_vv.items():
             setattr(P, k_, v_)
         vvset = (P,) + tuple(visc_inputs(d, M)) + (coefs[0][4], coefs[0][5])
-    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction, tv=tv, vv=vvset, hv=hv, Hmix_stress=Hmix_stress)
+    so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction, tv=tv, vv=vvset, hv=hv, Hmix_stress=Hmix_stress, cont_mod=cont_mod)
 
     # ---------------- device
     cont2, bt2, cor2, pgf2, rk22 = params()
@@ -158,6 +158,14 @@ def test_rk2_channel_bitexact_tc1_like(orc):
     # tc1-like switches: BT_PROJECT_VELOCITY, BEBT=0.2, BOUND_CORIOLIS; re-entrant channel exercises every halo pass
     run(orc, H.channel(), nsteps=3, bt_mod=dict(strong_drag=1, BT_project_velocity=1, bebt=0.2, dtbt_fraction=0.95),
         cor_mod=dict(bound_Coriolis=1))
+
+
+@pytest.mark.parametrize("cont_mod", [dict(vol_CFL=1), dict(aggress_adjust=1, vol_CFL=1)])
+def test_rk2_with_aggress_adjust_and_volume_based_cfl(orc, cont_mod):
+    """CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL through the whole step (all four continuity calls of a step take the
+    thread-per-column kernels then), on a grid whose open face widths differ from its cell widths."""
+    gg, d, M = H.double_gyre()
+    run(orc, (gg, d, H.narrowed_faces(d, M)), nsteps=2, bt_mod=dict(strong_drag=1), cont_mod=cont_mod)
 
 
 def test_rk2_benchmark_small_hooks_and_flags(orc):
