@@ -691,19 +691,27 @@ template <int HT_X, int HT_Y, bool OM4>
 __global__ void __launch_bounds__(HT_X * HT_Y, (HT_X * HT_Y >= 1024 || (OM4 && HV_OM4_W4)) ? 4 : ((HT_X * HT_Y >= 768) ? 3 : 2))   // 1024 threads: 4 wavefronts per SIMD (128 registers, 56 spilled); 768: 3 per SIMD (168 registers); 512: 2 per SIMD
 k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom6x_hor_visc_params CS,
            const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ h,
-           double *__restrict__ diffu, double *__restrict__ diffv, double h_neglect, int kc) {
+           double *__restrict__ diffu, double *__restrict__ diffv, double h_neglect, int kc, int gx, int gy, int gz, int xcd_order) {
   constexpr int HT_LDW = HT_X + 2, HT_LDN = (HT_Y + 2) * HT_LDW;
+  // Work-groups go to the eight XCDs round robin: with xcd_order XCD n walks a CONTIGUOUS run of tiles (x fastest), so that the
+  // 128-byte lines two neighbouring tiles share (a tile row is 32 doubles at an offset of 28 n - 3: three lines for 224 useful
+  // bytes) meet in ONE L2 instead of being fetched by two (as k_corad_lds, dyn_kernels.hip)
+  int bid = (int)blockIdx.x;
+  const int nb = gx * gy * gz;
+  if (xcd_order) { const int per = (nb + 7) / 8; bid = (bid % 8) * per + bid / 8; }
+  if (bid >= nb) return;
+  const int bxi = bid % gx, byi = (bid / gx) % gy, bzi = bid / (gx * gy);
   extern __shared__ double lds[];
   double *s_xx = lds, *s_xy = lds + HT_LDN, *s_d2u = lds + 2 * HT_LDN, *s_d2v = lds + 3 * HT_LDN;
   double *s_txx = lds + 4 * HT_LDN, *s_txy = lds + 5 * HT_LDN;
   double *c_dx2q = lds + 6 * HT_LDN, *c_dy2q = lds + 7 * HT_LDN, *c_dy2h = lds + 8 * HT_LDN, *c_dx2h = lds + 9 * HT_LDN;
   double *s_in = lds + 10 * HT_LDN;                     // u, v, h of the layer: two buffers of three planes
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = -1 - HT_H + (int)blockIdx.x * (HT_X - 2 * HT_H) + tx;
-  const int j = -1 - HT_H + (int)blockIdx.y * (HT_Y - 2 * HT_H) + ty;
+  const int i = -1 - HT_H + bxi * (HT_X - 2 * HT_H) + tx;
+  const int j = -1 - HT_H + byi * (HT_Y - 2 * HT_H) + ty;
   const int st = d.pitch;
   const size_t slab = (size_t)d.slab;
-  const int k0 = blockIdx.z * kc, k1 = min(k0 + kc, d.nk);
+  const int k0 = bzi * kc, k1 = min(k0 + kc, d.nk);
   const int l = (ty + 1) * HT_LDW + (tx + 1);            // this point in the LDS planes (a frame of one keeps +-1 reads inside)
   // points whose coefficient stencils stay inside the planes (halo 4): everything the valid outputs need lies in -3..ni+2 /
   // -3..nj+2; the fields themselves are also loaded one point further out (the neighbours of those points)
@@ -1001,7 +1009,9 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
     static const int wide = [] { const char *e = getenv("MOM6X_HV_TILE"); return e ? atoi(e) : 32; }();
     const int TX = (wide == 64) ? 64 : 32, TY = (wide == 3216 || wide == 64) ? 16 : 24;
     const dim3 bt(TX, TY, 1);
-    const dim3 gt((d.ni + 1 + (TX - 2 * HT_H) - 1) / (TX - 2 * HT_H), (d.nj + 1 + (TY - 2 * HT_H) - 1) / (TY - 2 * HT_H), (d.nk + kc - 1) / kc);
+    const int gx = (d.ni + 1 + (TX - 2 * HT_H) - 1) / (TX - 2 * HT_H), gy = (d.nj + 1 + (TY - 2 * HT_H) - 1) / (TY - 2 * HT_H), gz = (d.nk + kc - 1) / kc;
+    static const int xcd_order = [] { const char *e = getenv("MOM6X_HV_ORDER"); return (e && !strcmp(e, "plain")) ? 0 : 1; }();
+    const dim3 gt((unsigned)(((gx * gy * gz + 7) / 8) * 8), 1, 1);
     const size_t ldsb = (size_t)16 * (TY + 2) * (TX + 2) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {   // more than 64 KB of dynamic LDS has to be asked for
@@ -1017,15 +1027,15 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
                      CS.better_bound_Ah && !CS.no_slip && !CS.bound_Coriolis && CS.bound_Ah && CS.bound_Kh && CS.backscatter_underbound &&
                      !CS.add_LES_viscosity && CS.use_land_mask;
     if (TX == 64) {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<64, 16, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<64, 16, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, xcd_order);
     } else if (TY == 24 && om4) {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, xcd_order);
     } else if (TY == 24) {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, xcd_order);
     } else if (om4) {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, xcd_order);
     } else {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc);
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, xcd_order);
     }
     HIPCHK(hipGetLastError());
     return MOM6X_OK;

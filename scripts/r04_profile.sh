@@ -1,14 +1,14 @@
 #!/bin/bash
 # round-4 evidence in one call: rocprofv3 stats + FETCH / WRITE / SQ passes of the headline (scripts/profile_bench.sh), condensed under
-# gpurun_out/r04_v1_*; the default bench line; the tile's per-kernel table and compute-stream gaps in both modes
+# gpurun_out/r04_${TAG:-v2}_*; the default bench line; the tile's per-kernel table and compute-stream gaps in both modes
 ROOT=$(pwd); export TMPDIR=/tmp; OUT=$ROOT/gpurun_out; mkdir -p $OUT
 rm -rf $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq
 PMC_TIMEOUT=200 bash scripts/profile_bench.sh all 2>&1 | tail -6
 find $OUT/prof_stats -name "*kernel_trace*" -delete
-python scripts/rocprof_summary.py $OUT $OUT/r04_v1 2>&1 | tail -3
-tail -1 $OUT/prof_stats.log > $OUT/r04_v1_bench_under_rocprof.json
-python scripts/pmc_summary.py prof_sq > $OUT/r04_v1_sq_summary.txt 2>&1
-( time python bench.py > $OUT/r04_v1_bench.json 2> $OUT/r04_v1_bench.err ) 2> $OUT/r04_v1_bench.time
+python scripts/rocprof_summary.py $OUT $OUT/r04_${TAG:-v2} 2>&1 | tail -3
+grep "^{\"metric" $OUT/prof_stats.log > $OUT/r04_${TAG:-v2}_bench_under_rocprof.json
+python scripts/pmc_summary.py prof_sq > $OUT/r04_${TAG:-v2}_sq_summary.txt 2>&1
+( time python bench.py > $OUT/r04_${TAG:-v2}_bench.json 2> $OUT/r04_${TAG:-v2}_bench.err ) 2> $OUT/r04_${TAG:-v2}_bench.time
 export MOM6X_BENCH_NO_PMC=1
 cd /tmp
 for m in local_wrap rccl_self; do

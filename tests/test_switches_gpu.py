@@ -27,6 +27,7 @@ CASES = [
     ("MOM6X_BC_ACCEL", "own", "test_rk2_gpu.py", "double_gyre_bitexact or 75_layers_on_chip"),      # k_bc_accel instead of the fold into k_pgf_main
     ("MOM6X_BT_MASS_SOURCE", "own", "test_rk2_gpu.py", "double_gyre_bitexact or 75_layers_on_chip"),
     ("MOM6X_HV_KC", "25", "test_horvisc_gpu.py", ""),                                   # 25-layer chunks of k_hv_fused
+    ("MOM6X_HV_ORDER", "plain", "test_horvisc_gpu.py", "not other_variants"),           # its tiles in launch order instead of XCD-contiguous runs
     ("MOM6X_REMAP_MERGE", "apply", "test_remap_gpu.py", "ALE_remap"),                   # the one-field streamed merge everywhere
     ("MOM6X_TRIDIAG", "walk", "test_tracer_gpu.py", "tridiagonal"),                     # the tracer solves through HBM
 ]
