@@ -704,8 +704,9 @@ def main():
     ap.add_argument("--ale-nj", type=int, default=1620)
     ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] tile leg")
     ap.add_argument("--no-comm-model", action="store_true", help="skip the 1-GPU exchange-overhead leg")
-    ap.add_argument("--bthalo", type=int, default=0, help="BTHALO of the barotropic solver (> 4: the tile context carries that halo, the 3-D "
-                    "passes of the step stay at 4 rows; the answers do not depend on it)")
+    ap.add_argument("--bthalo", type=int, default=None, help="BTHALO of the barotropic solver (> 4: the tile context carries that halo, the 3-D "
+                    "passes of the step stay at 4 rows; the answers do not depend on it).  Default: 0 (= NIHALO) on one GPU, 8 on more "
+                    "(BT_USE_WIDE_HALOS: half the sub-cycle's exchanges; comm_model: 10.08 -> 9.75 ms per step on the 8-GPU tile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 (two extra one-step runs); cite profiles/ instead")
@@ -714,6 +715,8 @@ def main():
                     help="threads: run the --gpus N ranks as host threads on one GPU and check the layout against N = 1 (not a performance run)")
     ap.add_argument("--tracers", type=int, default=2, help="passive PPM tracers next to T and S in the thermodynamic step; -1 = dynamics only")
     args = ap.parse_args()
+    if args.bthalo is None:
+        args.bthalo = 8 if args.gpus > 1 else 0
 
     if args.transport == "threads":
         return run_threads(args)
@@ -981,7 +984,7 @@ def run_rank(args, env):
                    "sum_order": "TREE16 (column sums of the mass-flux kernels as a 16-lane tree; MOM6X_SUMS=exact: the reference's k order)"
                                 if dyc.cont_params.sum_order else "REFERENCE (sequential in k, bit-identical to the Fortran loop nest)",
                    "frozen_inputs": "none of the step's callees; vertvisc_coef and horizontal_viscosity run on the device inside the step (the set_viscous_BBL inputs of vertvisc_coef are constant synthetic fields)",
-                   "tile": [d.ni, d.nj, d.nk], "halo": d.halo},
+                   "tile": [d.ni, d.nj, d.nk], "halo": d.halo, "BTHALO": args.bthalo},
         "roofline": roofline, "restart_checksums": restart_checksums,
     }
     th = thermo_info() if thermo_info is not None else None
