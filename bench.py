@@ -705,8 +705,8 @@ def main():
     ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] tile leg")
     ap.add_argument("--no-comm-model", action="store_true", help="skip the 1-GPU exchange-overhead leg")
     ap.add_argument("--bthalo", type=int, default=None, help="BTHALO of the barotropic solver (> 4: the tile context carries that halo, the 3-D "
-                    "passes of the step stay at 4 rows; the answers do not depend on it).  Default: 0 (= NIHALO) on one GPU, 8 on more "
-                    "(BT_USE_WIDE_HALOS: half the sub-cycle's exchanges; comm_model: 10.08 -> 9.75 ms per step on the 8-GPU tile)")
+                    "passes of the step stay at 4 rows; the answers do not depend on it).  Default: 0 (= NIHALO) on one GPU, 12 on more "
+                    "(BT_USE_WIDE_HALOS: 15 instead of 21 exchanges per step; comm_model on the 8-GPU tile: 9.5-9.6 against 9.8-10.1 ms per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 (two extra one-step runs); cite profiles/ instead")
@@ -716,7 +716,7 @@ def main():
     ap.add_argument("--tracers", type=int, default=2, help="passive PPM tracers next to T and S in the thermodynamic step; -1 = dynamics only")
     args = ap.parse_args()
     if args.bthalo is None:
-        args.bthalo = 8 if args.gpus > 1 else 0
+        args.bthalo = 12 if args.gpus > 1 else 0
 
     if args.transport == "threads":
         return run_threads(args)
