@@ -47,3 +47,28 @@ def make_state(d, Mdev, seed=20250808, u_max=0.5, h_pert=0.02):
     u = u_max * smooth_field(d, dev, seed + 1, nk=nk, ox=1.0, oy=0.5) * Mdev[G["mask2dCu"]][None]
     v = u_max * smooth_field(d, dev, seed + 2, nk=nk, ox=0.5, oy=1.0) * Mdev[G["mask2dCv"]][None]
     return h.contiguous(), u.contiguous(), v.contiguous()
+
+
+def make_state_coherent(d, Mdev, seed=20250808, u_max=0.5, h_pert=0.02):
+    """A second, LABELLED state for the mass-flux kernels' direction statistics (profiles/r05_mfw.md): the same thicknesses, but
+    velocities that are vertically coherent as an ocean column's are -- a barotropic current plus two baroclinic modes (a
+    surface-intensified first mode and a second mode with one zero crossing more) with smooth horizontal amplitudes -- instead of
+    make_state's independent random current in every layer.  The benchmark's headline stays on make_state."""
+    dev = Mdev.device
+    nk = d.nk
+    h, _, _ = make_state(d, Mdev, seed=seed, u_max=0.0, h_pert=h_pert)
+    z = (torch.arange(nk, device=dev, dtype=torch.float64) + 0.5) / nk             # 0 at the surface, 1 at the bottom
+    m1 = torch.exp(-z / 0.15); m1 = m1 - m1.mean()                                  # surface-intensified
+    m2 = torch.cos(2.0 * math.pi * z) * torch.exp(-z / 0.5); m2 = m2 - m2.mean()
+    m1 = m1 / m1.abs().max(); m2 = m2 / m2.abs().max()
+
+    def vel(s0, ox, oy, mask):
+        bt = smooth_field(d, dev, s0, ox=ox, oy=oy)
+        a1 = smooth_field(d, dev, s0 + 10, ox=ox, oy=oy)
+        a2 = smooth_field(d, dev, s0 + 20, ox=ox, oy=oy)
+        f = 0.5 * bt[None] + 0.35 * a1[None] * m1[:, None, None] + 0.15 * a2[None] * m2[:, None, None]
+        return (u_max * f * mask[None]).contiguous()
+
+    u = vel(seed + 1, 1.0, 0.5, Mdev[G["mask2dCu"]])
+    v = vel(seed + 2, 0.5, 1.0, Mdev[G["mask2dCv"]])
+    return h.contiguous(), u, v

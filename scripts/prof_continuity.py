@@ -13,7 +13,10 @@ GV = abi.vgrid_default()
 dyc = Dycore(d, M, GV, 0)
 dyc.continuity_init(abi.continuity_params_default(nk, GV.Angstrom_H))
 Md = dyc.to_dev(M)
-h, u, v = synth_dev.make_state(d, Md, u_max=0.05, h_pert=0.001)
+if os.environ.get("PROF_STATE", "") == "coherent":   # the labelled, vertically coherent state (synth_dev.make_state_coherent)
+    h, u, v = synth_dev.make_state_coherent(d, Md, u_max=float(os.environ.get("PROF_UMAX", "0.05")), h_pert=0.001)
+else:
+    h, u, v = synth_dev.make_state(d, Md, u_max=float(os.environ.get("PROF_UMAX", "0.05")), h_pert=0.001)
 vr = torch.clamp(0.85 + 0.2 * synth_dev.smooth_field(d, dyc.device, 11, nk=nk), 0, 1)
 vru = (vr * Md[abi.G["mask2dCu"]][None]).contiguous(); vrv = (vr * Md[abi.G["mask2dCv"]][None]).contiguous(); del vr
 bt = BTContDev(dyc)
@@ -31,11 +34,13 @@ modes = {
     "full": dict(visc_rem_u=vru, visc_rem_v=vrv, uhbt=uhbt, vhbt=vhbt, u_cor=ucor, v_cor=vcor, BT_cont=bt),
 }
 import ctypes
-timing = hasattr(dyc.lib, "mom6x_debug_mfl_timing")   # library built with -DMOM6X_MFL_TIMING
 wave = (dyc.cont_params.sum_order == abi.SUM_TREE16)   # the wave-owned kernel (default); MOM6X_SUMS=exact: the LDS kernel
-tfun = dyc.lib.mom6x_debug_mfw_timing if (timing and wave) else (dyc.lib.mom6x_debug_mfl_timing if timing else None)
+timing = hasattr(dyc.lib, "mom6x_debug_mfw_timing" if wave else "mom6x_debug_mfl_timing")   # that file built with -DMOM6X_MFL_TIMING
+tfun = (dyc.lib.mom6x_debug_mfw_timing if wave else dyc.lib.mom6x_debug_mfl_timing) if timing else None
 PH = ["load+PPM", "bounds", "sweep0+sum", "adjust(uhbt)", "store+h_face", "adjust(du0)", "duL/duR rec", "3 trial sweeps",
       "-", "-", "row-top wait", "LDS->reg+PPM", "DMA issue", "BT stores", "-", "-"]
+if wave:   # continuity_wave.hip's phases (slot 0 is not used by it)
+    PH[0] = "-"; PH[4] = "h_face"; PH[3] = "adjust(uhbt)+stores"; PH[13] = "BT_cont tail"
 only = os.environ.get("PROF_MODES")   # e.g. PROF_MODES=full,adjust
 if only:
     modes = {k: v for k, v in modes.items() if k in only.split(",")}
@@ -51,10 +56,13 @@ for path in ("lds",) if (timing or only or wave) else ("lds", "legacy"):
         if timing:
             tfun(buf, 1)
             for dr in (0, 1):
-                sel = [q for q in range(16) if q not in (8, 9) and PH[q] != "-"]
+                sel = [q for q in range(14) if q not in (8, 9) and PH[q] != "-"]
                 tot = float(sum(buf[dr * 16 + q] for q in sel)) or 1.0
-                print("   phases dir", dr, " ".join(f"{PH[q]}={100 * buf[dr * 16 + q] / tot:.1f}%" for q in sel), f"total={tot:.3e} cyc", f"walk fall-backs={buf[dr * 16 + 15]}")
-            if wave:
-                print("   flux re-evaluations per wavefront solve: towards uhbt %.2f, towards zero transport %.2f" %
-                      (buf[8] / max(buf[16 + 8], 1), buf[9] / max(buf[16 + 9], 1)))
+                print("   phases dir", dr, " ".join(f"{PH[q]}={100 * buf[dr * 16 + q] / tot:.1f}%" for q in sel), f"total={tot:.3e} cyc")
+                if wave:
+                    print("   flux re-evaluations per wavefront solve, dir %d: towards uhbt %.2f, towards zero transport %.2f" %
+                          (dr, buf[dr * 16 + 8] / max(buf[dr * 16 + 14], 1), buf[dr * 16 + 9] / max(buf[dr * 16 + 15], 1)))
+        if hasattr(dyc.lib, "mom6x_debug_mfw_oneway"):   # built with -DMOM6X_MFW_ONEWAY_ALL=2: the launches above (warm-up + timed)
+            ob = (ctypes.c_ulonglong * 2)(); dyc.lib.mom6x_debug_mfw_oneway(ob, 1)
+            print("   one-way sweeps (first + Newton, wavefront-uniform): %d of %d = %.1f %%" % (ob[1], ob[0], 100.0 * ob[1] / max(ob[0], 1)))
         print(path, name, " ".join(f"{k}={v[1]:.2f}" for k, v in sorted(rep.items())), "sum=%.2f ms" % sum(v[1] for v in rep.values()), flush=True)
