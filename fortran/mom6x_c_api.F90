@@ -59,7 +59,7 @@ module mom6x_c_api
     integer(c_int) :: upwind_1st, monotonic, simple_2nd
     real(c_double) :: tol_eta, tol_vel, CFL_limit_adjust
     integer(c_int) :: aggress_adjust, vol_CFL, better_iter, use_visc_rem_max, marginal_faces
-    integer(c_int) :: sum_order   !< 0: the reference's sequential k sums (bit-identical); 1: 16-lane tree (default of the device)
+    integer(c_int) :: sum_order   !< 0: the reference's sequential k sums (bit-identical); 1: 16-lane tree (default of the device); 2: the tree + fused multiply-adds at fixed sites
   end type mom6x_continuity_params
 
   !> BT_cont_type (MOM_variables.F90:315-350): device pointers

@@ -160,11 +160,13 @@ subroutine continuity_PPM_init(Time, G, GV, US, param_file, diag, CS)
   call get_param(param_file, mdl, "MOM6X_CONTINUITY_SUMS", sums, &
                  "The order of the column sums of the MI355X mass-flux kernels: TREE16 (a 16-lane tree, the fast kernel; "//&
                  "answers within 1e-11 of range of the reference after 10 steps) or REFERENCE (sequential in k, bit-identical "//&
-                 "to the Fortran loop nest).", default="TREE16")
+                 "to the Fortran loop nest), or TREE16_FMA (TREE16 with fused multiply-adds at fixed sites of the flux and "//&
+                 "edge-value formulas; opt-in).", default="TREE16")
   select case (trim(sums))
     case ("TREE16") ; CS%p%sum_order = 1_c_int
     case ("REFERENCE") ; CS%p%sum_order = 0_c_int
-    case default ; call MOM_error(FATAL, "continuity_PPM_init: MOM6X_CONTINUITY_SUMS must be TREE16 or REFERENCE.")
+    case ("TREE16_FMA") ; CS%p%sum_order = 2_c_int
+    case default ; call MOM_error(FATAL, "continuity_PPM_init: MOM6X_CONTINUITY_SUMS must be TREE16, REFERENCE or TREE16_FMA.")
   end select
   call shim_set_domain_flags(param_file)
   CS%ctx = shim_ctx(G, GV)

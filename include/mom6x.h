@@ -120,10 +120,17 @@ typedef struct mom6x_continuity_params {
                             *     recurrences of set_*_BT_cont (:1293-1316) taken as the min / max they compute in exact
                             *     arithmetic.  Results agree with the reference order to round-off (<= 1e-13 of each
                             *     field's range); this is the order of a 16-lane wavefront row and lets one wavefront own a
-                            *     face column (continuity_wave.hip).  Requires nk <= 128.                               */
+                            *     face column (continuity_wave.hip).  Requires nk <= 128.
+                            *   MOM6X_SUM_TREE16_FMA (2): the sums of TREE16, and fused multiply-adds at FIXED sites (what a Fortran
+                            *     compiler's -ffp-contract does where it pleases): a + CFL * (p + q * r) of *_flux_layer and
+                            *     *_flux_thickness (:936-955, :1017-1030) as fma(CFL, fma(q, r, p), a); u + du * visc_rem as
+                            *     fma(du, visc_rem, u); the masked neighbours and the edge values of PPM_reconstruction_x/y
+                            *     (:2396-2405).  oracle/orc_continuity.c restates the same sites; against the reference order the
+                            *     results agree to round-off (bound and 10-step drift: tests/test_sum_order_gpu.py).  Opt-in.      */
 } mom6x_continuity_params;
-#define MOM6X_SUM_REFERENCE 0
-#define MOM6X_SUM_TREE16    1
+#define MOM6X_SUM_REFERENCE  0
+#define MOM6X_SUM_TREE16     1
+#define MOM6X_SUM_TREE16_FMA 2
 
 /* BT_cont_type (src/core/MOM_variables.F90:315-350): 12 2-D planes + h_u,h_v.
  * Any pointer may be NULL only if the whole struct pointer is NULL.          */

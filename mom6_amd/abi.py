@@ -101,15 +101,18 @@ def continuity_params_default(nk, Angstrom=1e-10):
     return p
 
 
-SUM_REFERENCE, SUM_TREE16 = 0, 1
+SUM_REFERENCE, SUM_TREE16, SUM_TREE16_FMA = 0, 1, 2
 
 
 def default_sum_order(nk):
     """Order of the column sums of the mass-flux kernels (mom6x_continuity_params.sum_order): the 16-lane tree of the
     wave-owned kernel unless MOM6X_SUMS=exact asks for the reference's sequential order (bit-identical to the Fortran
     loop nest, slower) or the column is deeper than that kernel carries."""
-    if os.environ.get("MOM6X_SUMS", "").lower() in ("exact", "reference", "0") or nk > 128:
+    want = os.environ.get("MOM6X_SUMS", "").lower()
+    if want in ("exact", "reference", "0") or nk > 128:
         return SUM_REFERENCE
+    if want in ("fma", "tree_fma", "2"):   # the tree's sums + fused multiply-adds at fixed sites (include/mom6x.h MOM6X_SUM_TREE16_FMA; opt-in)
+        return SUM_TREE16_FMA
     return SUM_TREE16
 
 

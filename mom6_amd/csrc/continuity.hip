@@ -374,7 +374,7 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
   // alone: their limits read the neighbouring faces' velocities, which the marching kernels do not stage.  Those kernels sum
   // columns in the reference's order, so under these switches sum_order has no effect (include/mom6x.h).
   const bool special = P.aggress_adjust || P.vol_CFL;
-  const bool wave = !special && (P.sum_order == MOM6X_SUM_TREE16);   // one wavefront row per face column, everything in registers
+  const bool wave = !special && (P.sum_order == MOM6X_SUM_TREE16 || P.sum_order == MOM6X_SUM_TREE16_FMA);   // one wavefront row per face column, everything in registers
   const bool lds = !special && (wave || use_lds_path(d.nk));
   if (!lds)
     KLAUNCH(c, "k_edge<DIR>", k_edge<DIR>, grid3(ei1 - ei0 + 1, ej1 - ej0 + 1, d.nk, blk), blk, d, c->G, h_src,
@@ -406,7 +406,7 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
   if (lds) {
     LdsArgs E;
     E.h_min = 2.0 * c->GV.Angstrom_H; E.scheme = scheme; E.monotonic = P.monotonic;
-    E.marginal = P.marginal_faces; E.h_face = BT_h;
+    E.marginal = P.marginal_faces; E.h_face = BT_h; E.fma = (P.sum_order == MOM6X_SUM_TREE16_FMA);
     auto part = [&](int a0, int a1, int b0, int b1) -> int {
       if (a0 > a1 || b0 > b1) return MOM6X_OK;
       FluxArgs S = A;
@@ -460,10 +460,12 @@ int run_direction(mom6x_ctx *c, const double *u, const double *h_src, double *h,
 
 extern "C" int mom6x_continuity_init(mom6x_ctx *c, const mom6x_continuity_params *p) {
   REQUIRE(c && p, MOM6X_EINVAL, "mom6x_continuity_init: null argument");
-  REQUIRE(p->sum_order == MOM6X_SUM_REFERENCE || p->sum_order == MOM6X_SUM_TREE16, MOM6X_EINVAL,
-          "continuity_PPM: sum_order must be MOM6X_SUM_REFERENCE (0) or MOM6X_SUM_TREE16 (1)");
-  REQUIRE(p->sum_order != MOM6X_SUM_TREE16 || mass_flux_wave_usable(c->d.nk), MOM6X_EUNSUPPORTED,
-          "continuity_PPM: sum_order = MOM6X_SUM_TREE16 carries at most 128 layers; use MOM6X_SUM_REFERENCE");
+  REQUIRE(p->sum_order == MOM6X_SUM_REFERENCE || p->sum_order == MOM6X_SUM_TREE16 || p->sum_order == MOM6X_SUM_TREE16_FMA, MOM6X_EINVAL,
+          "continuity_PPM: sum_order must be MOM6X_SUM_REFERENCE (0), MOM6X_SUM_TREE16 (1) or MOM6X_SUM_TREE16_FMA (2)");
+  REQUIRE(p->sum_order == MOM6X_SUM_REFERENCE || mass_flux_wave_usable(c->d.nk), MOM6X_EUNSUPPORTED,
+          "continuity_PPM: sum_order = MOM6X_SUM_TREE16(_FMA) carries at most 128 layers; use MOM6X_SUM_REFERENCE");
+  REQUIRE(p->sum_order != MOM6X_SUM_TREE16_FMA || !(p->aggress_adjust || p->vol_CFL), MOM6X_EUNSUPPORTED,
+          "continuity_PPM: sum_order = MOM6X_SUM_TREE16_FMA is not carried with CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL");
   c->cont = *p;
   c->cont_init = true;
   return MOM6X_OK;

@@ -73,14 +73,16 @@ __device__ __forceinline__ double slope3(double hm, double h0, double hp, double
 }
 
 // PPM_reconstruction_x/y + limiter for one cell from its 5-point stencil hh[0..4] (cell = hh[2]).
+// FMA (continuity_wave.hip, sum_order == MOM6X_SUM_TREE16_FMA): the masked neighbours and the edge values with fused multiply-adds.
+template <bool FMA = false>
 __device__ __forceinline__ void edge5(const double *hh, const double *mm, int scheme, int monotonic, double h_min,
                                       double &hl, double &hr, double &c3) {
   const double h0 = hh[2];
   if (scheme == 2) {
     hl = h0; hr = h0;
   } else {
-    const double h_im1 = mm[1] * hh[1] + (1.0 - mm[1]) * h0;
-    const double h_ip1 = mm[3] * hh[3] + (1.0 - mm[3]) * h0;
+    const double h_im1 = FMA ? fma(mm[1], hh[1], (1.0 - mm[1]) * h0) : mm[1] * hh[1] + (1.0 - mm[1]) * h0;
+    const double h_ip1 = FMA ? fma(mm[3], hh[3], (1.0 - mm[3]) * h0) : mm[3] * hh[3] + (1.0 - mm[3]) * h0;
     if (scheme == 1) {
       hl = 0.5 * (h_im1 + h0);
       hr = 0.5 * (h_ip1 + h0);
@@ -89,8 +91,8 @@ __device__ __forceinline__ void edge5(const double *hh, const double *mm, int sc
       const double sm = slope3(hh[0], hh[1], hh[2], mm[0] * mm[1] * mm[2]);
       const double s0 = slope3(hh[1], hh[2], hh[3], mm[1] * mm[2] * mm[3]);
       const double sp = slope3(hh[2], hh[3], hh[4], mm[2] * mm[3] * mm[4]);
-      hl = 0.5 * (h_im1 + h0) + oneSixth * (sm - s0);
-      hr = 0.5 * (h_ip1 + h0) + oneSixth * (s0 - sp);
+      hl = FMA ? fma(oneSixth, sm - s0, 0.5 * (h_im1 + h0)) : 0.5 * (h_im1 + h0) + oneSixth * (sm - s0);
+      hr = FMA ? fma(oneSixth, s0 - sp, 0.5 * (h_ip1 + h0)) : 0.5 * (h_ip1 + h0) + oneSixth * (s0 - sp);
     }
     if (monotonic) ppm_limit_cw84(h0, hl, hr);
     else ppm_limit_pos(h0, hl, hr, h_min);

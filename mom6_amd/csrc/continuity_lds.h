@@ -7,6 +7,7 @@ struct LdsArgs {
   int scheme;          // 0 PPM, 1 simple_2nd, 2 upwind_1st
   int monotonic;       // PPM_limit_CW84 instead of PPM_limit_pos
   int marginal;        // BT_cont%h_u from the marginal (not the average) face thickness
+  int fma;             // continuity_wave.hip: sum_order == MOM6X_SUM_TREE16_FMA (fused multiply-adds at fixed sites)
   double *h_face;      // BT_cont%h_u | h_v (3-D) or null
   int gx, gy, rows;    // tile grid and tile rows per XCD band (set by mass_flux_lds)
   int i_base;          // first i of the tile grid (set by mass_flux_lds: 128-byte aligned, <= a0)

@@ -103,6 +103,9 @@ __device__ __forceinline__ double row_max(double s) {
 // flight holds about 24 registers of temporaries, and five of them push the kernel into scratch memory -- whose
 // reloads then queue behind the next row's LDS-DMA (the memory counter is in order).  Two layers in flight plus the
 // second wavefront of the SIMD cover the latency of a dependent FP64 chain.
+#ifndef MOM6X_MFW_OCC3   // (experiment: the specialised kernels SPEC >= this value compiled for three wavefronts per SIMD; 0: none)
+#define MOM6X_MFW_OCC3 0
+#endif
 #ifndef MOM6X_MFW_FENCE
 #define MOM6X_MFW_FENCE 2
 #endif
@@ -136,8 +139,12 @@ struct Sw {
 };
 
 // What a lane keeps of its MAXL layers of one face column.
-template <int MAXL>
+// FMA_ (mom6x_continuity_params.sum_order == MOM6X_SUM_TREE16_FMA): the two Horner chains of *_flux_layer and *_flux_thickness, u + du *
+// visc_rem and the PPM edge formulas are evaluated with fused multiply-adds at fixed sites, the same ones as in
+// oracle/orc_continuity.c -- results differ from the reference's in the last bits (include/mom6x.h).
+template <int MAXL, bool FMA_ = false>
 struct Col {
+  static constexpr bool FMA = FMA_;
   double u[MAXL], v[MAXL];                      // u, visc_rem (0, 0 beyond nk: such a layer transports exactly +0.0)
   double mL[MAXL], mR[MAXL], mC[MAXL];          // minus cell: h_L, h_R, curv_3 = (h_L + h_R) - 2 h
   double pL[MAXL], pR[MAXL], pC[MAXL];          // plus cell
@@ -148,13 +155,23 @@ struct Col {
 // zonal_flux_layer :896 / merid_flux_layer :1787 from registers.  The two upwind branches of the reference are
 // mirror images (a = the edge value on the face side of the upwind cell, b = the far one); operands are selected
 // instead of branching so that a wavefront with mixed flow directions does not run both.
-template <int MAXL>
-__device__ __forceinline__ void flux_reg(const Col<MAXL> &C, int n, double u, double &uh, double &duhdu) {
+// a + CFL * (p + q * r): the Horner chain of the average (p = (b - a) / 2, q = curv_3, r = CFL - 3/2) and of the marginal
+// thickness (p = b - a, q = 3 curv_3, r = CFL - 1)
+template <bool FMA>
+__device__ __forceinline__ double horner(double a, double CFL, double p, double q, double r) {
+  return FMA ? fma(CFL, fma(q, r, p), a) : a + CFL * (p + q * r);
+}
+template <int MAXL, bool FMA>
+__device__ __forceinline__ double vel(const Col<MAXL, FMA> &C, int n, double du) {
+  return FMA ? fma(du, C.v[n], C.u[n]) : C.u[n] + du * C.v[n];
+}
+template <int MAXL, bool FMA>
+__device__ __forceinline__ void flux_reg(const Col<MAXL, FMA> &C, int n, double u, double &uh, double &duhdu) {
   const bool pos = (u > 0.0);
   const double a = pos ? C.mR[n] : C.pL[n], b = pos ? C.mL[n] : C.pR[n], curv_3 = pos ? C.mC[n] : C.pC[n];
   const double CFL = fabs(u) * C.dt * (pos ? C.IdT_m : C.IdT_p);
-  const double uh_m = C.Lf * u * (a + CFL * (0.5 * (b - a) + curv_3 * (CFL - 1.5)));
-  const double hm_m = a + CFL * ((b - a) + 3.0 * curv_3 * (CFL - 1.0));
+  const double uh_m = C.Lf * u * horner<FMA>(a, CFL, 0.5 * (b - a), curv_3, CFL - 1.5);
+  const double hm_m = horner<FMA>(a, CFL, b - a, 3.0 * curv_3, CFL - 1.0);
   const bool moving = (u != 0.0);
   uh = moving ? uh_m : 0.0;
   const double h_marg = moving ? hm_m : 0.5 * (C.pL[n] + C.mR[n]);
@@ -165,20 +182,20 @@ __device__ __forceinline__ void flux_reg(const Col<MAXL> &C, int n, double u, do
 // is known, nothing is selected (12 of the ~46 instructions of a layer are v_cndmask, two more the zero test).  A lane at rest
 // may take part if its visc_rem is zero as well: its transport is Lf * 0 * (...) and its derivative Lf * h * 0, zeros of either sign
 // that leave the column sums as the reference's + 0.0 does (only sums are formed from this function, no transport is stored).
-template <int MAXL, int SIDE>
-__device__ __forceinline__ void flux_one_way(const Col<MAXL> &C, int n, double u, double &uh, double &duhdu) {
+template <int SIDE, int MAXL, bool FMA>
+__device__ __forceinline__ void flux_one_way(const Col<MAXL, FMA> &C, int n, double u, double &uh, double &duhdu) {
   const double a = (SIDE > 0) ? C.mR[n] : C.pL[n], b = (SIDE > 0) ? C.mL[n] : C.pR[n], curv_3 = (SIDE > 0) ? C.mC[n] : C.pC[n];
   const double CFL = fabs(u) * C.dt * ((SIDE > 0) ? C.IdT_m : C.IdT_p);
-  uh = C.Lf * u * (a + CFL * (0.5 * (b - a) + curv_3 * (CFL - 1.5)));
-  const double h_marg = a + CFL * ((b - a) + 3.0 * curv_3 * (CFL - 1.0));
+  uh = C.Lf * u * horner<FMA>(a, CFL, 0.5 * (b - a), curv_3, CFL - 1.5);
+  const double h_marg = horner<FMA>(a, CFL, b - a, 3.0 * curv_3, CFL - 1.0);
   duhdu = C.Lf * h_marg * C.v[n];
 }
-template <int MAXL, int SIDE>
-__device__ __forceinline__ bool wave_one_way(const Col<MAXL> &C, double du) {
+template <int SIDE, int MAXL, bool FMA>
+__device__ __forceinline__ bool wave_one_way(const Col<MAXL, FMA> &C, double du) {
   bool ok = true;
 #pragma unroll
   for (int n = 0; n < MAXL; n++) {
-    const double u = C.u[n] + du * C.v[n];
+    const double u = vel(C, n, du);
     ok = ok && (((SIDE > 0) ? (u > 0.0) : (u < 0.0)) || (u == 0.0 && C.v[n] == 0.0));
   }
   return !wave_any(!ok);
@@ -187,12 +204,12 @@ __device__ __forceinline__ bool wave_one_way(const Col<MAXL> &C, double du) {
 // The same test for a sweep whose transports are RESULTS (the first sweep, the sweeps of the solve towards uhbt): a layer at rest
 // must not take part (its Lf * u * (...) can be a -0.0 where the reference stores +0.0) unless nobody stores it (`active`: the lane's
 // face is in the launch's range; a layer beyond nk never is).
-template <int MAXL, int SIDE>
-__device__ __forceinline__ bool wave_one_way_strict(const Col<MAXL> &C, double du, bool active, int kl, int nk) {
+template <int SIDE, int MAXL, bool FMA>
+__device__ __forceinline__ bool wave_one_way_strict(const Col<MAXL, FMA> &C, double du, bool active, int kl, int nk) {
   bool ok = true;
 #pragma unroll
   for (int n = 0; n < MAXL; n++) {
-    const double u = C.u[n] + du * C.v[n];
+    const double u = vel(C, n, du);
     ok = ok && (((SIDE > 0) ? (u > 0.0) : (u < 0.0)) || !(active && kl + KL * n < nk));
   }
   return !wave_any(!ok);
@@ -213,8 +230,8 @@ __device__ unsigned long long g_mfw_ow[2];
 // everything of a layer that does not depend on du out of the loop (both upwind variants of b - a, 0.5 (b - a),
 // 3 curv_3, ...: ~28 registers per layer) and the kernel goes to scratch memory.  An empty asm that "modifies" the
 // layer's values keeps those expressions inside the loop: they cost a few instructions, not registers.
-template <int MAXL>
-__device__ __forceinline__ void keep_in_loop(Col<MAXL> &C, int n) {
+template <int MAXL, bool FMA>
+__device__ __forceinline__ void keep_in_loop(Col<MAXL, FMA> &C, int n) {
   asm volatile("" : "+v"(C.mL[n]), "+v"(C.mR[n]), "+v"(C.mC[n]), "+v"(C.pL[n]), "+v"(C.pR[n]), "+v"(C.pC[n]), "+v"(C.u[n]), "+v"(C.v[n]));
 }
 
@@ -222,8 +239,8 @@ __device__ __forceinline__ void keep_in_loop(Col<MAXL> &C, int n) {
 // replicated over the 16 lanes of a face's row.  STORE: the evaluated transports are the result (the reference's
 // uh_3d argument): they are kept in C.uh at every evaluation of a face that is still iterating and stored once at the end.  `lazy`: du_max / du_min are a lower / an upper bound of the CFL limits; the first test they do not
 // decide ends the solve with need_exact = true (wavefront-uniform) and the caller repeats it with the limits.
-template <int MAXL, bool STORE, bool STATS, typename StoreUh>
-__device__ __forceinline__ double wave_flux_adjust(Col<MAXL> &C, bool active, double IareaMin, double uhbt,
+template <int MAXL, bool STORE, bool STATS, bool FMA, typename StoreUh>
+__device__ __forceinline__ double wave_flux_adjust(Col<MAXL, FMA> &C, bool active, double IareaMin, double uhbt,
                                                    double uh_tot_0, double duhdu_tot_0, double du_max, double du_min,
                                                    double tol_eta_cs, double tol_vel, int better_iter, bool lazy,
                                                    bool &need_exact, StoreUh store_uh, unsigned &evals, int ow_row, int kl, int nk TICK_PARAM,
@@ -284,14 +301,14 @@ __device__ __forceinline__ double wave_flux_adjust(Col<MAXL> &C, bool active, do
       double s_uh = 0.0, s_dd = 0.0;
       bool ow = false;
       if (MOM6X_MFW_ONEWAY_ALL && ow_row != 0)
-        ow = (ow_row > 0) ? wave_one_way_strict<MAXL, 1>(C, du, active, kl, nk) : wave_one_way_strict<MAXL, -1>(C, du, active, kl, nk);
+        ow = (ow_row > 0) ? wave_one_way_strict<1>(C, du, active, kl, nk) : wave_one_way_strict<-1>(C, du, active, kl, nk);
       if (MOM6X_MFW_ONEWAY_ALL) OW_COUNT(ow);
       if (MOM6X_MFW_ONEWAY_ALL == 1 && ow && ow_row > 0) {
 #pragma unroll
         for (int n = 0; n < MAXL; n++) {
           double uh, dd;
           keep_in_loop(C, n);
-          flux_one_way<MAXL, 1>(C, n, C.u[n] + du * C.v[n], uh, dd);
+          flux_one_way<1>(C, n, vel(C, n, du), uh, dd);
           if (STORE) { if (do_I) C.uh[n] = uh; }
           s_uh = s_uh + uh; s_dd = s_dd + dd;
           LAYER_FENCE(n);
@@ -301,7 +318,7 @@ __device__ __forceinline__ double wave_flux_adjust(Col<MAXL> &C, bool active, do
         for (int n = 0; n < MAXL; n++) {
           double uh, dd;
           keep_in_loop(C, n);
-          flux_one_way<MAXL, -1>(C, n, C.u[n] + du * C.v[n], uh, dd);
+          flux_one_way<-1>(C, n, vel(C, n, du), uh, dd);
           if (STORE) { if (do_I) C.uh[n] = uh; }
           s_uh = s_uh + uh; s_dd = s_dd + dd;
           LAYER_FENCE(n);
@@ -311,7 +328,7 @@ __device__ __forceinline__ double wave_flux_adjust(Col<MAXL> &C, bool active, do
         for (int n = 0; n < MAXL; n++) {
           double uh, dd;
           keep_in_loop(C, n);
-          flux_reg(C, n, C.u[n] + du * C.v[n], uh, dd);
+          flux_reg(C, n, vel(C, n, du), uh, dd);
           if (STORE) { if (do_I) C.uh[n] = uh; }   // the last evaluation of a face is the one that stays
           s_uh = s_uh + uh; s_dd = s_dd + dd;
           LAYER_FENCE(n);
@@ -413,8 +430,8 @@ __device__ __forceinline__ void glds16(const double *src, double *lds_wave_base)
 
 // Everything of one face column after the reconstruction: first sweep, flux_adjust towards uhbt, stores, flux
 // thickness, set_*_BT_cont.  All lanes of the wavefront call it (row reductions inside).
-template <int DIR, int MAXL, bool STATS, int SPEC, typename DmaPart>
-__device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, const LdsArgs &E, size_t rowb, unsigned lane2,
+template <int DIR, int MAXL, bool STATS, int SPEC, bool FMA, typename DmaPart>
+__device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A, const LdsArgs &E, size_t rowb, unsigned lane2,
                                             unsigned lane3, size_t slab, bool active, int kl, int nk, double IareaMin,
                                             double uhbt_f, double dC_f, double dx_W_in, double dx_E_in, const double *G,
                                             int pitch, unsigned &evals, unsigned &solves, unsigned &redos, DmaPart dma_part,
@@ -515,14 +532,14 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
   auto first_sweep = [&]() {
     double s_uh = 0.0, s_dd = 0.0;
     if (MOM6X_MFW_ONEWAY_ALL) {
-      ow_row = wave_one_way_strict<MAXL, 1>(C, 0.0, active, kl, nk) ? 1 : (wave_one_way_strict<MAXL, -1>(C, 0.0, active, kl, nk) ? -1 : 0);
+      ow_row = wave_one_way_strict<1>(C, 0.0, active, kl, nk) ? 1 : (wave_one_way_strict<-1>(C, 0.0, active, kl, nk) ? -1 : 0);
       OW_COUNT(ow_row != 0);
     }
     if (MOM6X_MFW_ONEWAY_ALL == 1 && ow_row > 0) {
 #pragma unroll
       for (int n = 0; n < MAXL; n++) {
         double uh, dd;
-        flux_one_way<MAXL, 1>(C, n, C.u[n], uh, dd);
+        flux_one_way<1>(C, n, C.u[n], uh, dd);
         C.uh[n] = uh;
         s_uh = s_uh + uh; s_dd = s_dd + dd;
         LAYER_FENCE(n);
@@ -531,7 +548,7 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
 #pragma unroll
       for (int n = 0; n < MAXL; n++) {
         double uh, dd;
-        flux_one_way<MAXL, -1>(C, n, C.u[n], uh, dd);
+        flux_one_way<-1>(C, n, C.u[n], uh, dd);
         C.uh[n] = uh;
         s_uh = s_uh + uh; s_dd = s_dd + dd;
         LAYER_FENCE(n);
@@ -586,12 +603,12 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
     if (pairs) {
       double uc[MAXL];
 #pragma unroll
-      for (int n = 0; n < MAXL; n++) uc[n] = C.u[n] + du_fin * C.v[n];
+      for (int n = 0; n < MAXL; n++) uc[n] = vel(C, n, du_fin);
       store_pairs<MAXL>(A.u_cor, rowb, lanep, slab, uc, active, kl, fw, nk);
     } else if (active) {
 #pragma unroll
       for (int n = 0; n < MAXL; n++)
-        if (kl + KL * n < nk) st3(A.u_cor, n, C.u[n] + du_fin * C.v[n]);
+        if (kl + KL * n < nk) st3(A.u_cor, n, vel(C, n, du_fin));
     }
   }
 
@@ -601,12 +618,12 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
     double hf[MAXL];
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
-      const double uf = use_cor ? (C.u[n] + du_fin * C.v[n]) : C.u[n];
+      const double uf = use_cor ? (vel(C, n, du_fin)) : C.u[n];
       const bool pos = (uf > 0.0);
       const double a = pos ? C.mR[n] : C.pL[n], b = pos ? C.mL[n] : C.pR[n], curv_3 = pos ? C.mC[n] : C.pC[n];
       const double CFL = fabs(uf) * dt * (pos ? C.IdT_m : C.IdT_p);
-      double h_avg = a + CFL * (0.5 * (b - a) + curv_3 * (CFL - 1.5));
-      double h_marg = a + CFL * ((b - a) + 3.0 * curv_3 * (CFL - 1.0));
+      double h_avg = horner<FMA>(a, CFL, 0.5 * (b - a), curv_3, CFL - 1.5);
+      double h_marg = horner<FMA>(a, CFL, b - a, 3.0 * curv_3, CFL - 1.0);
       if (uf == 0.0) { h_avg = 0.5 * (C.pL[n] + C.mR[n]); h_marg = h_avg; }
       double hu = W.marginal ? h_marg : h_avg;
       if (use_visc_rem) hu = hu * (C.v[n] * 1.0);
@@ -669,18 +686,18 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
       double uh_0, d_0;
-      flux_reg(C, n, C.u[n] + du0 * C.v[n], uh_0, d_0);
+      flux_reg(C, n, vel(C, n, du0), uh_0, d_0);
       FAmt_0 = FAmt_0 + d_0;
       LAYER_FENCE(n);
     }
   }
   // duL / duR are made so that every layer flows out of the minus / the plus cell (:1293-1316; a layer whose visc_rem lies under the
   // floor may not): wavefront-uniformly, such a sweep knows its upwind cell
-  if (wave_one_way<MAXL, 1>(C, duL)) {
+  if (wave_one_way<1>(C, duL)) {
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
       double uh_L, d_L;
-      flux_one_way<MAXL, 1>(C, n, C.u[n] + duL * C.v[n], uh_L, d_L);
+      flux_one_way<1>(C, n, vel(C, n, duL), uh_L, d_L);
       FAmt_L = FAmt_L + d_L; uhtot_L = uhtot_L + uh_L;
       LAYER_FENCE(n);
     }
@@ -688,16 +705,16 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
       double uh_L, d_L;
-      flux_reg(C, n, C.u[n] + duL * C.v[n], uh_L, d_L);
+      flux_reg(C, n, vel(C, n, duL), uh_L, d_L);
       FAmt_L = FAmt_L + d_L; uhtot_L = uhtot_L + uh_L;
       LAYER_FENCE(n);
     }
   }
-  if (wave_one_way<MAXL, -1>(C, duR)) {
+  if (wave_one_way<-1>(C, duR)) {
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
       double uh_R, d_R;
-      flux_one_way<MAXL, -1>(C, n, C.u[n] + duR * C.v[n], uh_R, d_R);
+      flux_one_way<-1>(C, n, vel(C, n, duR), uh_R, d_R);
       FAmt_R = FAmt_R + d_R; uhtot_R = uhtot_R + uh_R;
       LAYER_FENCE(n);
     }
@@ -705,7 +722,7 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
       double uh_R, d_R;
-      flux_reg(C, n, C.u[n] + duR * C.v[n], uh_R, d_R);
+      flux_reg(C, n, vel(C, n, duR), uh_R, d_R);
       FAmt_R = FAmt_R + d_R; uhtot_R = uhtot_R + uh_R;
       LAYER_FENCE(n);
     }
@@ -744,8 +761,8 @@ __device__ __forceinline__ void face_column(Col<MAXL> &C, const FluxArgs &A, con
 
 constexpr int SEG = 4;   // doubles per segment = faces per wavefront
 
-template <int DIR, int MAXL, bool STATS, int SPEC>
-__global__ void __launch_bounds__(NF * KL, (MAXL > 5) ? 1 : 2)
+template <int DIR, int MAXL, bool STATS, int SPEC, bool FMA>
+__global__ void __launch_bounds__(NF * KL, (MAXL > 5) ? 1 : ((MOM6X_MFW_OCC3 && SPEC >= MOM6X_MFW_OCC3 && MAXL == 5 && !FMA) ? 3 : 2))
 k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   using ST = Stage<DIR>;
   const Sw<SPEC> W(A, E);
@@ -850,7 +867,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
 #endif
   const unsigned lanep = (unsigned)((size_t)((active ? i0 + (fw & ~1) : i0) + d.ioff) * 8) + (unsigned)((size_t)(kl + KL * (fw & 1)) * slab * 8);
 
-  Col<MAXL> C;
+  Col<MAXL, FMA> C;
   C.dt = A.dt;
 #pragma unroll
   for (int n = 0; n < MAXL; n++) { C.pL[n] = 0.0; C.pR[n] = 0.0; C.pC[n] = 0.0; }
@@ -896,7 +913,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
         C.u[n] = on ? uu : 0.0;
         C.v[n] = on ? vv : 0.0;
         double hl = 0.0, hr = 0.0, c3 = 0.0;
-        if (con) edge5(&hst[0], &m5[0], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
+        if (con) edge5<FMA>(&hst[0], &m5[0], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
         C.mL[n] = hl; C.mR[n] = hr; C.mC[n] = c3;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -919,7 +936,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
             hx[q] = xon ? hv : 0.0;
           }
           double hl = 0.0, hr = 0.0, c3 = 0.0;
-          if (xon) edge5(&hx[0], &mx[0], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
+          if (xon) edge5<FMA>(&hx[0], &mx[0], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
           xl[pss] = hl; xr[pss] = hr; xc[pss] = c3;
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -978,13 +995,13 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
         double hl = 0.0, hr = 0.0, c3 = 0.0;
         if (DIR) {   // the plus cell of the last step is this step's minus cell
           C.mL[n] = C.pL[n]; C.mR[n] = C.pR[n]; C.mC[n] = C.pC[n];
-          if (on) edge5(&hst[0], &m6[0], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
+          if (on) edge5<FMA>(&hst[0], &m6[0], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
           C.pL[n] = hl; C.pR[n] = hr; C.pC[n] = c3;
         } else {
-          if (on) edge5(&hst[0], &m6[0], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
+          if (on) edge5<FMA>(&hst[0], &m6[0], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
           C.mL[n] = hl; C.mR[n] = hr; C.mC[n] = c3;
           hl = 0.0; hr = 0.0; c3 = 0.0;
-          if (on) edge5(&hst[1], &m6[1], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
+          if (on) edge5<FMA>(&hst[1], &m6[1], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
           C.pL[n] = hl; C.pR[n] = hr; C.pC[n] = c3;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1029,7 +1046,7 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   E.retry = nullptr; E.force_walk = famt0_sweep;   // (in this kernel: always make set_*_BT_cont's own sweep at du0)
   // The Newton statistics are a separate instantiation: the counters cost the 253-register kernel its last free registers
   // (139 spills), so they are only compiled into the variant that runs while mom6x_continuity_stats is switched on.
-  const bool stats = (c->cont_stats != nullptr) && c->cont_stats_on;
+  const bool stats = (c->cont_stats != nullptr) && c->cont_stats_on && !E.fma;
   E.stats = stats ? c->cont_stats : nullptr;
 #ifdef MOM6X_MFL_TIMING
   const size_t lds_bytes = sizeof(double) * 4 * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16)) + 128;   // + the phase times
@@ -1046,12 +1063,13 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
     else if (bt && cor) spec = 2;
     else if (!A.set_BT_cont && !E.h_face && cor) spec = 3;
   }
-  auto kern = stats ? k_mass_flux_wave<DIR, MAXL, true, 0> : k_mass_flux_wave<DIR, MAXL, false, 0>;
+  auto kern = stats ? k_mass_flux_wave<DIR, MAXL, true, 0, false> : k_mass_flux_wave<DIR, MAXL, false, 0, false>;
+  if (E.fma) kern = k_mass_flux_wave<DIR, MAXL, false, 0, true>;   // (no statistics variant with fused multiply-adds)
   if (MAXL == 5) {   // (the specialised kernels exist for 65..80 layers)
     constexpr int M = (MAXL == 5) ? 5 : 2;   // (keeps the other instantiations of launch() from instantiating them)
-    if (spec == 1) kern = k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 1 : 0>;
-    if (spec == 2) kern = k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 2 : 0>;
-    if (spec == 3) kern = k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 3 : 0>;
+    if (spec == 1) kern = E.fma ? k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 1 : 0, true> : k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 1 : 0, false>;
+    if (spec == 2) kern = E.fma ? k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 2 : 0, true> : k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 2 : 0, false>;
+    if (spec == 3) kern = E.fma ? k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 3 : 0, true> : k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 3 : 0, false>;
   }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   long strips_rows = 0;
@@ -1066,8 +1084,8 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   // 16 rows 0.41, one round of 25 rows 0.45.  The prologue of a work-group (first DMA; meridional: the ring of h rows and the
   // row that is only reconstructed) is cheap next to that.  MOM6X_MFW_ROWS overrides.
   {
-    static int slots_cache[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
-    int &slots = slots_cache[DIR][stats ? 4 : spec];
+    static int slots_cache[2][2][5] = {{{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}, {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}};
+    int &slots = slots_cache[DIR][E.fma ? 1 : 0][stats ? 4 : spec];
     if (!slots) {
       int per_cu = 0, ncu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NF * KL, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;

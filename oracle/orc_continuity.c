@@ -43,6 +43,18 @@ static void dir_setup(dir_t *D, const mom6x_dims *d, const double *G, int dir, i
   D->mask2dT = GM(G, d, MOM6X_G_mask2dT);
 }
 
+/* mom6x_continuity_params.sum_order == MOM6X_SUM_TREE16_FMA (include/mom6x.h): fused multiply-adds at FIXED sites -- the Horner
+ * chains a + CFL * (p + q * r) of *_flux_layer and *_flux_thickness, u + du * visc_rem, and the masked neighbours and edge values
+ * of PPM_reconstruction_x/y -- the same sites as mom6_amd/csrc/continuity_wave.hip (struct Col<MAXL, true>).  Set by
+ * orc_continuity_PPM for the duration of the call (read-only inside the OpenMP regions). */
+static int orc_fma_mode = 0;
+static inline double horner(double a, double CFL, double p, double q, double r) {
+  return orc_fma_mode ? fma(CFL, fma(q, r, p), a) : a + CFL * (p + q * r);
+}
+static inline double vel_cor(double u, double du, double vrem) { return orc_fma_mode ? fma(du, vrem, u) : u + du * vrem; }
+static inline double mul_add(double x, double y, double z) { return orc_fma_mode ? fma(x, y, z) : x * y + z; }   /* x*y + z */
+static inline double add_mul(double z, double x, double y) { return orc_fma_mode ? fma(x, y, z) : z + x * y; }   /* z + x*y */
+
 /* PPM_limit_pos, MOM_continuity_PPM.F90:2578-2616 */
 static void ppm_limit_pos(double h_in, double *h_L, double *h_R, double h_min) {
   double curv = 3.0 * ((*h_L + *h_R) - 2.0 * h_in);
@@ -97,8 +109,8 @@ static void edge_thickness_2d(const mom6x_dims *d, const dir_t *D, const mom6x_c
   if (CS->simple_2nd) { /* :2360-2366 */
     for (int j = jsl; j <= jel; j++) for (int i = isl; i <= iel; i++) {
       size_t c = IX2(d, i, j);
-      double h_im1 = m[c - st] * h_in[c - st] + (1.0 - m[c - st]) * h_in[c];
-      double h_ip1 = m[c + st] * h_in[c + st] + (1.0 - m[c + st]) * h_in[c];
+      double h_im1 = mul_add(m[c - st], h_in[c - st], (1.0 - m[c - st]) * h_in[c]);
+      double h_ip1 = mul_add(m[c + st], h_in[c + st], (1.0 - m[c + st]) * h_in[c]);
       h_L[c] = 0.5 * (h_im1 + h_in[c]);
       h_R[c] = 0.5 * (h_ip1 + h_in[c]);
     }
@@ -120,10 +132,10 @@ static void edge_thickness_2d(const mom6x_dims *d, const dir_t *D, const mom6x_c
     const double oneSixth = 1.0 / 6.0;
     for (int j = jsl; j <= jel; j++) for (int i = isl; i <= iel; i++) { /* :2396-2405 */
       size_t c = IX2(d, i, j);
-      double h_im1 = m[c - st] * h_in[c - st] + (1.0 - m[c - st]) * h_in[c];
-      double h_ip1 = m[c + st] * h_in[c + st] + (1.0 - m[c + st]) * h_in[c];
-      h_L[c] = 0.5 * (h_im1 + h_in[c]) + oneSixth * (slp[c - st] - slp[c]);
-      h_R[c] = 0.5 * (h_ip1 + h_in[c]) + oneSixth * (slp[c] - slp[c + st]);
+      double h_im1 = mul_add(m[c - st], h_in[c - st], (1.0 - m[c - st]) * h_in[c]);
+      double h_ip1 = mul_add(m[c + st], h_in[c + st], (1.0 - m[c + st]) * h_in[c]);
+      h_L[c] = add_mul(0.5 * (h_im1 + h_in[c]), oneSixth, slp[c - st] - slp[c]);
+      h_R[c] = add_mul(0.5 * (h_ip1 + h_in[c]), oneSixth, slp[c] - slp[c + st]);
     }
   }
   for (int j = jsl; j <= jel; j++) for (int i = isl; i <= iel; i++) { /* :2432-2436 */
@@ -144,14 +156,14 @@ static inline void flux_layer_face(const dir_t *D, size_t f, double u, const dou
     if (D->vol_CFL) CFL = (u * dt) * (D->Lface[f] * D->IareaT[f]);   /* :938 / :1832 */
     else CFL = u * dt * D->IdT[f];
     curv_3 = (hL[f] + hR[f]) - 2.0 * h[f];
-    *uh = (D->Lface[f] * 1.0) * u * (hR[f] + CFL * (0.5 * (hL[f] - hR[f]) + curv_3 * (CFL - 1.5)));
-    h_marg = hR[f] + CFL * ((hL[f] - hR[f]) + 3.0 * curv_3 * (CFL - 1.0));
+    *uh = (D->Lface[f] * 1.0) * u * horner(hR[f], CFL, 0.5 * (hL[f] - hR[f]), curv_3, CFL - 1.5);
+    h_marg = horner(hR[f], CFL, hL[f] - hR[f], 3.0 * curv_3, CFL - 1.0);
   } else if (u < 0.0) {
     if (D->vol_CFL) CFL = (-u * dt) * (D->Lface[f] * D->IareaT[p]);   /* :945 / :1840 */
     else CFL = -u * dt * D->IdT[p];
     curv_3 = (hL[p] + hR[p]) - 2.0 * h[p];
-    *uh = (D->Lface[f] * 1.0) * u * (hL[p] + CFL * (0.5 * (hR[p] - hL[p]) + curv_3 * (CFL - 1.5)));
-    h_marg = hL[p] + CFL * ((hR[p] - hL[p]) + 3.0 * curv_3 * (CFL - 1.0));
+    *uh = (D->Lface[f] * 1.0) * u * horner(hL[p], CFL, 0.5 * (hR[p] - hL[p]), curv_3, CFL - 1.5);
+    h_marg = horner(hL[p], CFL, hR[p] - hL[p], 3.0 * curv_3, CFL - 1.0);
   } else {
     *uh = 0.0;
     h_marg = 0.5 * (hL[p] + hR[f]);
@@ -254,7 +266,7 @@ static void flux_adjust_row(const mom6x_dims *d, const dir_t *D, const mom6x_con
       for (int k = 0; k < nz; k++) for (int a = R->a0; a <= R->a1; a++) if (do_I[a]) {
         size_t f = row_face(d, D, R, a);
         double vrem = vr[(size_t)k * P + a];
-        double u_new = u[f + k * slab] + du[a] * vrem;
+        double u_new = vel_cor(u[f + k * slab], du[a], vrem);
         flux_layer_face(D, f, u_new, h_in + k * slab, hL + k * slab, hR + k * slab, dt, vrem,
                         &uh_aux[(size_t)k * P + a], &duhdu[(size_t)k * P + a]);
       }
@@ -347,7 +359,7 @@ static void set_BT_cont_row(const mom6x_dims *d, const dir_t *D, const mom6x_con
   for (int k = 0; k < nz; k++) for (int a = R->a0; a <= R->a1; a++) if (do_I[a]) {
     size_t f = row_face(d, D, R, a);
     double vrem = vr[(size_t)k * P + a], uk = u[f + k * slab];
-    double u_L = uk + duL[a] * vrem, u_R = uk + duR[a] * vrem, u_0 = uk + du0[a] * vrem;
+    double u_L = vel_cor(uk, duL[a], vrem), u_R = vel_cor(uk, duR[a], vrem), u_0 = vel_cor(uk, du0[a], vrem);
     double uh_0, uh_L, uh_R, duhdu_0, duhdu_L, duhdu_R;
     flux_layer_face(D, f, u_0, h_in + k * slab, hL + k * slab, hR + k * slab, dt, vrem, &uh_0, &duhdu_0);
     flux_layer_face(D, f, u_L, h_in + k * slab, hL + k * slab, hR + k * slab, dt, vrem, &uh_L, &duhdu_L);
@@ -413,14 +425,14 @@ static void flux_thickness(const mom6x_dims *d, const dir_t *D, const double *u,
       if (D->vol_CFL) CFL = (uf * dt) * (D->Lface[f2] * D->IareaT[f2]);   /* :1019 / :1917 */
       else CFL = uf * dt * D->IdT[f2];
       curv_3 = (hL[f] + hR[f]) - 2.0 * h[f];
-      h_avg = hR[f] + CFL * (0.5 * (hL[f] - hR[f]) + curv_3 * (CFL - 1.5));
-      h_marg = hR[f] + CFL * ((hL[f] - hR[f]) + 3.0 * curv_3 * (CFL - 1.0));
+      h_avg = horner(hR[f], CFL, 0.5 * (hL[f] - hR[f]), curv_3, CFL - 1.5);
+      h_marg = horner(hR[f], CFL, hL[f] - hR[f], 3.0 * curv_3, CFL - 1.0);
     } else if (uf < 0.0) {
       if (D->vol_CFL) CFL = (-uf * dt) * (D->Lface[f2] * D->IareaT[f2 + st]);   /* :1025 / :1924 */
       else CFL = -uf * dt * D->IdT[f2 + st];
       curv_3 = (hL[p] + hR[p]) - 2.0 * h[p];
-      h_avg = hL[p] + CFL * (0.5 * (hR[p] - hL[p]) + curv_3 * (CFL - 1.5));
-      h_marg = hL[p] + CFL * ((hR[p] - hL[p]) + 3.0 * curv_3 * (CFL - 1.0));
+      h_avg = horner(hL[p], CFL, 0.5 * (hR[p] - hL[p]), curv_3, CFL - 1.5);
+      h_marg = horner(hL[p], CFL, hR[p] - hL[p], 3.0 * curv_3, CFL - 1.0);
     } else {
       h_avg = 0.5 * (hL[p] + hR[f]);
       h_marg = 0.5 * (hL[p] + hR[f]);
@@ -572,7 +584,7 @@ static void mass_flux(const mom6x_dims *d, const dir_t *D, const mom6x_continuit
                         du_max_CFL, du_min_CFL, dt, vr, do_I, uh);
         if (u_cor) for (int k = 0; k < nz; k++) for (int a = a0; a <= a1; a++) {
           size_t f = row_face(d, D, &R, a);
-          u_cor[f + k * slab] = u[f + k * slab] + du[a] * vr[(size_t)k * P + a];
+          u_cor[f + k * slab] = vel_cor(u[f + k * slab], du[a], vr[(size_t)k * P + a]);
         }
         if (du_cor) for (int a = a0; a <= a1; a++) du_cor[row_face(d, D, &R, a)] = du[a];
       }
@@ -616,11 +628,14 @@ int orc_continuity_PPM(const mom6x_dims *d, const double *G, const mom6x_vgrid *
                        const double *visc_rem_u, const double *visc_rem_v,
                        double *u_cor, double *v_cor, const mom6x_BT_cont *BT,
                        double *du_cor, double *dv_cor) {
-  if (CS->sum_order != MOM6X_SUM_REFERENCE && CS->sum_order != MOM6X_SUM_TREE16) return MOM6X_EINVAL;
+  if (CS->sum_order != MOM6X_SUM_REFERENCE && CS->sum_order != MOM6X_SUM_TREE16 && CS->sum_order != MOM6X_SUM_TREE16_FMA) return MOM6X_EINVAL;
+  if (CS->sum_order == MOM6X_SUM_TREE16_FMA && (CS->aggress_adjust || CS->vol_CFL)) return MOM6X_EUNSUPPORTED;
   /* CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL: the device takes its thread-per-column kernels for these, whose column
    * sums run in the reference's order whatever sum_order says (include/mom6x.h) */
   mom6x_continuity_params CS_local = *CS;
   if (CS_local.aggress_adjust || CS_local.vol_CFL) CS_local.sum_order = MOM6X_SUM_REFERENCE;
+  orc_fma_mode = (CS_local.sum_order == MOM6X_SUM_TREE16_FMA);   /* the sums of TREE16 + fused multiply-adds at the fixed sites */
+  if (orc_fma_mode) CS_local.sum_order = MOM6X_SUM_TREE16;
   CS = &CS_local;
   if ((visc_rem_u != NULL) != (visc_rem_v != NULL)) return MOM6X_EINVAL;
   const size_t n3 = (size_t)d->slab * d->nk;

@@ -14,14 +14,16 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["wave", "lds", "lds_walk", "legacy"])
+@pytest.fixture(autouse=True, params=["wave", "lds", "lds_walk", "legacy", "wave_fma"])
 def massflux_path(request, monkeypatch):
     """Every case runs on all device paths: the wave-owned kernel (sum_order = TREE16, the default), and with the
     reference's sequential sums the LDS-resident fused kernel, the same with the sequential duL/duR recurrence forced
     (lds_walk: the fall-back of the parallel min + certificate) and the thread-per-column kernels
-    (MOM6X_MASSFLUX=legacy).  All must equal the oracle (run with the same sum_order) bit for bit."""
-    monkeypatch.setenv("MOM6X_MASSFLUX", request.param)
-    monkeypatch.setenv("MOM6X_SUMS", "tree" if request.param == "wave" else "exact")
+    (MOM6X_MASSFLUX=legacy).  All must equal the oracle (run with the same sum_order) bit for bit.  wave_fma: the wave-owned kernel
+    with fused multiply-adds at fixed sites (sum_order = MOM6X_SUM_TREE16_FMA, opt-in) against the oracle's restatement of the
+    same sites -- also bit for bit."""
+    monkeypatch.setenv("MOM6X_MASSFLUX", "wave" if request.param == "wave_fma" else request.param)
+    monkeypatch.setenv("MOM6X_SUMS", {"wave": "tree", "wave_fma": "fma"}.get(request.param, "exact"))
     return request.param
 
 
@@ -121,6 +123,8 @@ def test_continuity_aggress_adjust_and_volume_based_cfl(orc, flags, mode):
     """CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL (MOM_continuity_PPM.F90:2725-2733; non-default): whatever path and sum
     order are asked for, the thread-per-column kernels run (reference order) -- velocities and adjustments strong enough for the
     limits on du to bind, faces narrower than their cells."""
+    if abi.default_sum_order(1) == abi.SUM_TREE16_FMA:
+        pytest.skip("MOM6X_SUM_TREE16_FMA is refused together with these switches (mom6x_continuity_init)")
     for cfg, fd in ((H.benchmark_small(), 0), (H.double_gyre(), 1)):
         gg, d, M = cfg
         _run_case(orc, (gg, d, H.narrowed_faces(d, M)), fd, mode, cs_mod=flags, u_scale=8.0, bt_pert=0.9)
@@ -142,6 +146,8 @@ def test_continuity_many_layers(orc, nk):
 
 def test_continuity_device_matches_committed_golden(orc):
     """HIP continuity_PPM (corrector-call shape) against tests/golden/continuity_benchmark_small_corrector.npz."""
+    if abi.default_sum_order(1) == abi.SUM_TREE16_FMA:
+        pytest.skip("no committed fixture for the opt-in arithmetic with fused multiply-adds")
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases

@@ -168,3 +168,28 @@ def test_reference_order_on_the_device_is_bit_identical_over_ten_steps(orc):
         H.assert_bitwise(a, b, n, H.interior(p["d"], STAG[n]), signed_zero_ok=False)
     _budgets(p)
     p["dyc"].close()
+
+
+def test_fused_multiply_add_arithmetic_over_ten_steps(orc):
+    """sum_order = MOM6X_SUM_TREE16_FMA (opt-in: the tree's sums and fused multiply-adds at fixed sites of the flux and the PPM
+    edge formulas, include/mom6x.h): ten steps at nk = 75 with every callee on the device (a) equal the oracle's restatement of the
+    same sites in every bit, and (b) stay within the stated bound of the REFERENCE-order, un-fused oracle -- the reference's own
+    arithmetic.  The observed drift goes to gpurun_out/sum_order_drift.json under "fma_benchmark_small_75"."""
+    cfg = H.benchmark_small(nk=75)
+    p = _pair(orc, cfg, abi.SUM_TREE16_FMA, abi.SUM_TREE16_FMA)
+    for n in range(10):
+        p["step"](n)
+    for n, a, b in _fields(p):
+        H.assert_bitwise(a, b, n, H.interior(p["d"], STAG[n]), signed_zero_ok=False)
+    _budgets(p)
+    p["dyc"].close()
+    p = _pair(orc, cfg, abi.SUM_TREE16_FMA, abi.SUM_REFERENCE, strong_drag=0)
+    rows = []
+    for n in range(10):
+        p["step"](n)
+        rows.append(_drift(p))
+    eta_err = _budgets(p)
+    _report("fma_benchmark_small_75_pow", rows, dict(sum_k_uh_minus_uhbt_as_eta_change=eta_err, tol_eta=p["cont"].tol_eta))
+    bad = {n: v for n, v in rows[-1].items() if v > BOUND}
+    assert not bad, bad
+    p["dyc"].close()
