@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <vector>
 #include "mom6x_dev.h"
+#include <cstdlib>
 
 #include <map>
 static thread_local char g_err[512] = "";
@@ -191,8 +192,8 @@ extern "C" int mom6x_ctx_create(mom6x_ctx **out, const mom6x_dims *dims, int dev
   size_t n3 = (size_t)dims->slab * dims->nk;
   HIPCHK(hipMalloc(&c->hL, n3 * sizeof(double)));
   HIPCHK(hipMalloc(&c->hR, n3 * sizeof(double)));
-  HIPCHK(hipMemset(c->hL, 0, n3 * sizeof(double)));
-  HIPCHK(hipMemset(c->hR, 0, n3 * sizeof(double)));
+  HIPCHK(hipMemset(c->hL, work_fill_byte(), n3 * sizeof(double)));
+  HIPCHK(hipMemset(c->hR, work_fill_byte(), n3 * sizeof(double)));
   HIPCHK(hipMalloc(&c->flag, sizeof(int)));
   HIPCHK(hipMemset(c->flag, 0, sizeof(int)));
   *out = c;
@@ -221,13 +222,23 @@ extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
   return MOM6X_OK;
 }
 
+// The reference's test.nan (.testing/Makefile:399-408: every allocation initialised with signalling NaNs): with MOM6X_POISON_WORK=1 in
+// the environment the WORK arrays of the device -- the scratch slots, the PPM edge arrays, the tracer advection's remainders, whatever a
+// host asks mom6x_dev_alloc for -- start as NaNs (all bits set) instead of zeros.  A step that reads a word of them it has not
+// written differs from the un-poisoned run or trips the numeric flag (tests/test_invariants_gpu.py).  Arrays the reference zeroes
+// explicitly after allocating them (the restart fields of the RK2 and barotropic modules) are not work arrays.
+int work_fill_byte() {
+  const char *e = getenv("MOM6X_POISON_WORK");   // (read at every allocation: a test switches it between two models of one process)
+  return (e && atoi(e) != 0) ? 0xFF : 0;
+}
+
 int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out) {
   REQUIRE(slot >= 0 && slot < MOM6X_NSCR, MOM6X_EINVAL, "ctx_scratch: bad slot");
   if (c->scr[slot] && c->scr_nlev[slot] < nlev) { HIPCHK(hipFree(c->scr[slot])); c->scr[slot] = nullptr; }
   if (!c->scr[slot]) {
     const size_t n = (size_t)c->dims.slab * nlev;
     HIPCHK(hipMalloc(&c->scr[slot], n * sizeof(double)));
-    HIPCHK(hipMemsetAsync(c->scr[slot], 0, n * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->scr[slot], work_fill_byte(), n * sizeof(double), c->stream));
     c->scr_nlev[slot] = nlev;
   }
   *out = c->scr[slot];
@@ -255,7 +266,7 @@ extern "C" int mom6x_ctx_sync(mom6x_ctx *c) {
 extern "C" int mom6x_dev_alloc(mom6x_ctx *c, double **p, size_t n) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipMalloc(p, n * sizeof(double)));
-  HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(double), c->stream));
+  HIPCHK(hipMemsetAsync(*p, work_fill_byte(), n * sizeof(double), c->stream));
   return MOM6X_OK;
 }
 extern "C" int mom6x_dev_free(mom6x_ctx *c, double *p) {

@@ -143,7 +143,8 @@ void prof_end(mom6x_ctx *c);
     if ((c)->prof_on) prof_end((c));                                        \
   } while (0)
 
-int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out);   // ctx.hip
+int ctx_scratch(mom6x_ctx *c, int slot, int nlev, double **out);
+int work_fill_byte();   // 0, or 0xFF with MOM6X_POISON_WORK=1 (ctx.hip): the initial contents of work arrays   // ctx.hip
 void hor_visc_free(mom6x_ctx *c);                                  // hor_visc.hip
 void diag_sums_free(mom6x_ctx *c);                                 // diag_sums.hip
 // dyn_kernels.hip: vertvisc_coef looking at u (mode 0), mask*(u + dtx*u_bc) (1) or mask*(u + dtx*(u_bc + u_abt)) (2)

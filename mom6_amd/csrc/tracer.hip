@@ -705,7 +705,7 @@ extern "C" int mom6x_tracer_advect_init(mom6x_ctx *c, double dt_dyn, int default
     const size_t n3 = (size_t)c->dims.slab * c->dims.nk;
     const size_t nf = (size_t)(c->dims.nj + 2 * c->dims.halo + 1) * c->dims.nk;
     double **p3[] = { &s->hprev, &s->uhr, &s->vhr };   // (uhh and the flux arrays belong to the legacy path: allocated on its first use)
-    for (double **q : p3) { HIPCHK(hipMalloc(q, n3 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, 0, n3 * sizeof(double), c->stream)); }
+    for (double **q : p3) { HIPCHK(hipMalloc(q, n3 * sizeof(double))); HIPCHK(hipMemsetAsync(*q, work_fill_byte(), n3 * sizeof(double), c->stream)); }
     int **pf[] = { &s->dmu, &s->dmv, &s->limu, &s->limv };
     for (int **q : pf) { HIPCHK(hipMalloc(q, nf * sizeof(int))); HIPCHK(hipMemsetAsync(*q, 0, nf * sizeof(int), c->stream)); }
     HIPCHK(hipMalloc(&s->dmk, c->dims.nk * sizeof(int)));
