@@ -933,7 +933,7 @@ int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h
     const int kc = (d.nk % 25 == 0) ? 25 : ((d.nk >= KCHUNK) ? KCHUNK : d.nk);
     const dim3 bt(CF_X, CF_Y, 1);
     const int gx = (d.ni + 1 + (CF_X - 2) - 1) / (CF_X - 2), gy = (d.nj + 1 + (CF_Y - 2) - 1) / (CF_Y - 2), gz = (d.nk + kc - 1) / kc;
-    static const int xcd_order = [] { const char *e = getenv("MOM6X_CORAD_ORDER"); return (e && !strcmp(e, "plain")) ? 0 : 1; }();
+    constexpr int xcd_order = 1;   // (the launch-order walk of the tiles lost in round 4 and is gone: profiles/README.md)
     const dim3 gt((unsigned)(((gx * gy * gz + 7) / 8) * 8), 1, 1);
     static const bool lean_off = [] { const char *e = getenv("MOM6X_CORAD_LEAN"); return e && !strcmp(e, "0"); }();
     // the default configuration has its own instantiation: 104 registers and no scratch instead of 128 + 2 spilled

@@ -997,7 +997,7 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
   // against 6.0 ms for the four kernels.  The first version was SLOWER (7.5 ms; 6.8 on 64 x 16 tiles) and was shelved as
   // "instruction-bound": it had been compiled for four wavefronts per SIMD (128 registers) and kept 56 of its ~170 live values
   // in scratch memory.  At two wavefronts per SIMD nothing spills; a 1024-thread tile cannot have that (16 wavefronts per
-  // work-group), so 64 x 16 stays the slower, tested alternative (MOM6X_HV_TILE=64).
+  // work-group): the 64 x 16 tiles are gone.
   static const bool fused = [] { const char *e = getenv("MOM6X_HORVISC"); return !(e && !strcmp(e, "legacy")); }();
   if (fused && !(CS.Leith_Kh || CS.Leith_Ah) && d.halo >= 4) {
     static const int kc_env = [] { const char *e = getenv("MOM6X_HV_KC"); return e ? atoi(e) : 0; }();
@@ -1005,19 +1005,16 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
     //  against 4.68 with 25-layer chunks at nk = 75)
     const int kc = (kc_env > 0) ? std::min(kc_env, d.nk) : ((d.nk <= 80) ? d.nk : ((d.nk % 25 == 0) ? 25 : KCHUNK));
     // Tiles: 32 x 24 points (768 threads = 12 wavefronts, three per SIMD at <= 168 registers: the OM4-class instantiation has 150;
-    // outputs on 28 x 20 = 73 % of the tile); MOM6X_HV_TILE=3216: 32 x 16 (round 3's: two per SIMD, 66 %), =64: 64 x 16.
-    static const int wide = [] { const char *e = getenv("MOM6X_HV_TILE"); return e ? atoi(e) : 32; }();
-    const int TX = (wide == 64) ? 64 : 32, TY = (wide == 3216 || wide == 64) ? 16 : 24;
+    // outputs on 28 x 20 = 73 % of the tile).  Round 3's 32 x 16 tiles (two per SIMD, 66 %: 3.57 ms against 2.49-2.82 at 1440 x 1080 x 75)
+    // and the 64 x 16 tiles (1024 threads: four wavefronts per SIMD = 128 registers, 56 values in scratch) lost and are gone
+    // (profiles/README.md has their numbers); so has the launch-order walk of the tiles.
+    constexpr int TX = 32, TY = 24;
     const dim3 bt(TX, TY, 1);
     const int gx = (d.ni + 1 + (TX - 2 * HT_H) - 1) / (TX - 2 * HT_H), gy = (d.nj + 1 + (TY - 2 * HT_H) - 1) / (TY - 2 * HT_H), gz = (d.nk + kc - 1) / kc;
-    static const int xcd_order = [] { const char *e = getenv("MOM6X_HV_ORDER"); return (e && !strcmp(e, "plain")) ? 0 : 1; }();
     const dim3 gt((unsigned)(((gx * gy * gz + 7) / 8) * 8), 1, 1);
     const size_t ldsb = (size_t)16 * (TY + 2) * (TX + 2) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {   // more than 64 KB of dynamic LDS has to be asked for
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<64, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 66 * 8));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 34 * 8));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 18 * 34 * 8));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 24, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 26 * 34 * 8));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 24, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 26 * 34 * 8));
       attr_set = true;
@@ -1026,16 +1023,10 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
     const bool om4 = !om4_off && CS.Laplacian && CS.biharmonic && !CS.Smagorinsky_Kh && CS.Smagorinsky_Ah && CS.better_bound_Kh &&
                      CS.better_bound_Ah && !CS.no_slip && !CS.bound_Coriolis && CS.bound_Ah && CS.bound_Kh && CS.backscatter_underbound &&
                      !CS.add_LES_viscosity && CS.use_land_mask;
-    if (TX == 64) {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<64, 16, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, xcd_order);
-    } else if (TY == 24 && om4) {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, xcd_order);
-    } else if (TY == 24) {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, xcd_order);
-    } else if (om4) {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, xcd_order);
+    if (om4) {
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, 1);
     } else {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 16, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, xcd_order);
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, 1);
     }
     HIPCHK(hipGetLastError());
     return MOM6X_OK;

@@ -26,6 +26,18 @@ def test_config2_benchmark_360x180x75_rk2_step(orc, sums):
     run(orc, cfg, nsteps=1, bt_mod=dict(strong_drag=1), dev_vv=dict(), hv=P)
 
 
+def test_config2_benchmark_360x180x75_rk2_step_default_drag(orc, sums):
+    """The same step on btstep's DEFAULT drag path (BT_STRONG_DRAG = False: bt_rem = av_rem**(1/nstep), the one expression where
+    the device's pow and libm's may differ in the last bit): every field within 1e-12 of its range."""
+    from tests.test_rk2_gpu import run
+    from tests import cases
+    cfg = H.benchmark_360()
+    P = abi.hor_visc_params_default(1200.0, Laplacian=True, biharmonic=True)
+    P.Kh_vel_scale = 0.01; P.Ah_vel_scale = 0.01; P.Smagorinsky_Ah = 1; P.Smag_bi_const = 0.06
+    P.dt = cases.rk2_inputs(cfg, False, False)["dt"]
+    run(orc, cfg, nsteps=1, bt_mod=dict(strong_drag=0), dev_vv=dict(), hv=P, exact=False, rtol=1e-12)
+
+
 def test_config2_benchmark_360x180x75_tracers_and_tridiag(orc):
     """advect_tracer of two PPM tracers and triDiagTS(T, S) at the config's size -- bit for bit."""
     import torch

@@ -170,9 +170,9 @@ def _tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich, halo=4, bt_ti
             H.assert_bitwise(mine, part, f"{cfg_name} {layout} tile {pe}: {n}")
 
 
-@pytest.mark.parametrize("layout", ["4 2", "2 1"])
+@pytest.mark.parametrize("layout", ["4 2", "2 2", "2 1"])
 def test_bench_model_layouts_at_full_size(layout):
-    """bench.py's own 1440 x 1080 x 75 model on the 8-GPU (4 x 2) and the 2-GPU (2 x 1) layout against one tile
+    """bench.py's own 1440 x 1080 x 75 model on the 8-GPU (4 x 2), BASELINE.json configs[3]'s 4-GPU (2 x 2) and the 2-GPU (2 x 1) layout against one tile
     (scripts/check_layout_fullsize.py): messages of 13 MB, tiles of 360 x 540, the restart checksums of every field equal."""
     import os
     import subprocess
