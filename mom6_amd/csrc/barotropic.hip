@@ -29,7 +29,7 @@ void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const i
 #define MOM6X_BT_PAIR_DEFAULT 0
 #endif
 #ifndef MOM6X_BT_PAIR_BSY
-#define MOM6X_BT_PAIR_BSY 32
+#define MOM6X_BT_PAIR_BSY 16
 #endif
 enum BTW {   // 2-D work planes
   W_q = 0, W_DCor_u, W_DCor_v, W_gtot_E, W_gtot_W, W_gtot_N, W_gtot_S, W_eta, W_eta_PF,
@@ -810,6 +810,43 @@ k_bt_substep(Dm d, const double *__restrict__ G, double *work, double *ubtav, do
 // between the two sub-steps, the eta predictor chain (pass_uhn), no CLIP_BT_VELOCITY / BT_PROJECT_VELOCITY.
 struct Sub2Planes { int u_in, u_out, v_in, v_out, e_in, e_out; };
 enum { OK_U = 1, OK_V = 2, OK_E = 4, OK_HU = 8, OK_HV = 16, OK_UN = 32, OK_VN = 64, OK_ETA = 128 };
+// Everything of one face that does not change over the sub-cycle, in registers for both sub-steps of the launch: the operands of
+// btloop_find_PF / btloop_update_u|v (bt_face_update's) and the ten BT_cont fit parameters of find_uhbt (all ten: a launch evaluates
+// the fit four times per face, and which of them a velocity needs is only known when it is there -- loaded on demand, each
+// evaluation was a chain of dependent round trips to the L2 with two work-groups per CU to hide them: 7.3 ms per step against
+// 6.6 for the three kernels, profiles/r05_btpair.txt).
+struct FaceCoef { double ePF0, ePF1, g0, g1, Idx, f0, f1, f2, f3, Cref, rem, force, B[10], h0; };
+__device__ __forceinline__ double find_uhbt_reg(double u, const double *B) {   // find_uhbt, same expressions
+  if (u == 0.0) return 0.0;
+  const double uEE = B[B_uBT_EE];
+  if (u < uEE) return (u - uEE) * B[B_FA_EE] + B[B_uh_EE];
+  if (u < 0.0) return u * (B[B_FA_E0] + B[B_crvE] * (u * u));
+  const double uWW = B[B_uBT_WW];
+  if (u <= uWW) return u * (B[B_FA_W0] + B[B_crvW] * (u * u));
+  return (u - uWW) * B[B_FA_WW] + B[B_uh_WW];
+}
+template <int DIR>
+__device__ __forceinline__ void load_face(const Dm &d, const double *__restrict__ G, const double *work, size_t c, int st, size_t slab, int Sadourny,
+                                          FaceCoef &F) {
+  const double *eta_PF = work + W_eta_PF * slab;
+  if (DIR == 0) {
+    F.ePF0 = eta_PF[c]; F.ePF1 = eta_PF[c + 1];
+    F.g0 = work[W_gtot_E * slab + c]; F.g1 = work[W_gtot_W * slab + c + 1];
+    F.Idx = gm(G, d, MOM6X_G_IdxCu)[c];
+    f4u_of(work + W_q * slab, work + W_DCor_v * slab, c, st, Sadourny, F.f0, F.f1, F.f2, F.f3);
+    F.Cref = work[W_Cor_ref_u * slab + c]; F.rem = work[W_bt_rem_u * slab + c]; F.force = work[W_BT_force_u * slab + c];
+  } else {
+    F.ePF0 = eta_PF[c]; F.ePF1 = eta_PF[c + st];
+    F.g0 = work[W_gtot_N * slab + c]; F.g1 = work[W_gtot_S * slab + c + st];
+    F.Idx = gm(G, d, MOM6X_G_IdyCv)[c];
+    f4v_of(work + W_q * slab, work + W_DCor_u * slab, c, st, Sadourny, F.f0, F.f1, F.f2, F.f3);
+    F.Cref = work[W_Cor_ref_v * slab + c]; F.rem = work[W_bt_rem_v * slab + c]; F.force = work[W_BT_force_v * slab + c];
+  }
+  const double *B = work + (DIR ? W_BTCv : W_BTCu) * slab;
+#pragma unroll
+  for (int q = 0; q < 10; q++) F.B[q] = B[(size_t)q * slab + c];
+  F.h0 = work[(DIR ? W_vhbt0 : W_uhbt0) * slab + c];
+}
 template <bool VF1, int BSX, int BSY>
 __global__ void __launch_bounds__(BSX * BSY)
 k_bt_substep2(Dm d, const double *__restrict__ G, double *work, double *ubtav, double *uhbtav, double *vbtav, double *vhbtav, LoopArgs A1,
@@ -828,33 +865,52 @@ k_bt_substep2(Dm d, const double *__restrict__ G, double *work, double *ubtav, d
   const size_t slab = (size_t)d.slab;
   const int nrows = d.slab / d.pitch;
   const bool in_arr = (i + d.ioff >= 0 && i + d.ioff <= d.pitch - 1 && j + d.joff >= 0 && j + d.joff <= nrows - 1);
+  // a point evaluates something only inside the first sub-step's widest ranges (whose stencils stay inside the array)
+  const bool in_wide = in_arr && i >= A1.isv - 1 && i <= A1.iev + 1 && j >= A1.jsv - 1 && j <= A1.jev + 1;
   const size_t c = in_arr ? ix2(d, i, j) : ix2(d, 0, 0);
-  const double *ubt_in = work + (size_t)P.u_in * slab, *vbt_in = work + (size_t)P.v_in * slab;
-  double *ubt_out = work + (size_t)P.u_out * slab, *vbt_out = work + (size_t)P.v_out * slab;
   // ownership (of the second sub-step's ranges; k_bt_substep's rules)
   const bool own_x = (i >= x0 && i <= x1), own_y = (j >= y0 && j <= y1);
   const bool west = (i == A2.isv - 1 && x0 == A2.isv), south = (j == A2.jsv - 1 && y0 == A2.jsv);
   const bool east1 = (i == A2.iev + 1 && x1 == A2.iev), north1 = (j == A2.jev + 1 && y1 == A2.jev);
-  double eta = 0.0;   // the thread's own cell
+  const bool own_u1 = (own_x || west) && (own_y || south || north1), own_v1 = (own_x || west || east1) && (own_y || south);
+  const bool own_u2 = (own_x || west) && own_y, own_v2 = own_x && (own_y || south), own_c = own_x && own_y;
+  const bool own_u = own_u1 || own_u2, own_v = own_v1 || own_v2;
+  // ---- everything from memory, in one go
+  FaceCoef FU, FV;
+  double eta = 0.0, IareaT = 0.0, src = 0.0, bT = 0.0, mT = 0.0;
+  double acc_u = 0., av_u = 0., hav_u = 0., wtd_u = 0., acc_v = 0., av_v = 0., hav_v = 0., wtd_v = 0., e_wtd = 0., e_sum = 0.;
   {
     unsigned char ok = 0;
     double u = 0.0, v = 0.0, e = 0.0;
-    if (in_arr) { u = ubt_in[c]; v = vbt_in[c]; e = work[(size_t)P.e_in * slab + c]; eta = work[W_eta * slab + c]; ok = OK_U | OK_V | OK_E | OK_ETA; }
+    if (in_arr) {
+      u = work[(size_t)P.u_in * slab + c]; v = work[(size_t)P.v_in * slab + c]; e = work[(size_t)P.e_in * slab + c]; eta = work[W_eta * slab + c];
+      ok = OK_U | OK_V | OK_E | OK_ETA;
+    }
+    if (in_wide) {
+      load_face<0>(d, G, work, c, st, slab, A1.Sadourny, FU);
+      load_face<1>(d, G, work, c, st, slab, A1.Sadourny, FV);
+      IareaT = gm(G, d, MOM6X_G_IareaT)[c]; src = work[W_eta_src * slab + c];
+      bT = gm(G, d, MOM6X_G_bathyT)[c]; mT = gm(G, d, MOM6X_G_mask2dT)[c];
+    }
+    if (in_wide && own_u) { acc_u = work[W_u_accel_bt * slab + c]; av_u = ubtav[c]; hav_u = uhbtav[c]; wtd_u = work[W_ubt_wtd * slab + c]; }
+    if (in_wide && own_v) { acc_v = work[W_v_accel_bt * slab + c]; av_v = vbtav[c]; hav_v = vhbtav[c]; wtd_v = work[W_vbt_wtd * slab + c]; }
+    if (in_wide && own_c) { e_wtd = work[W_eta_wtd * slab + c]; e_sum = work[W_eta_sum * slab + c]; }
     s_u[ty][tx] = u; s_v[ty][tx] = v; s_e[ty][tx] = e; s_hu[ty][tx] = 0.0; s_hv[ty][tx] = 0.0; s_un[ty][tx] = 0.0; s_vn[ty][tx] = 0.0;
     s_ok[ty][tx] = ok;
   }
   __syncthreads();
   auto okat = [&](int yy, int xx, int bit) -> bool { return xx >= 0 && xx < BSX && yy >= 0 && yy < BSY && (s_ok[yy][xx] & bit); };
   bool broken = false;   // an owned point could not be computed: the tile's frame is too small for the ranges (must not happen)
+  bool sum_u = false, sum_v = false, wtd_u_on = false, wtd_v_on = false, etaw_on = false, esum_on = false;
+  double last_un = 0.0, last_vn = 0.0;
 
-  // one face of one sub-step: k_bt_vel's lines with the state in LDS
-  auto face = [&](auto dir_tag, const LoopArgs &A, bool owner, bool last, int bb) {
+  // one face of one sub-step: k_bt_vel's lines with the state in LDS and the coefficients in registers
+  auto face = [&](auto dir_tag, const LoopArgs &A, bool owner, int bb) {
     constexpr int DIR = decltype(dir_tag)::value;
     const bool in_range = DIR ? (i >= A.isv - 1 && i <= A.iev + 1 && j >= A.jsv - 1 && j <= A.jev)
                               : (i >= A.isv - 1 && i <= A.iev && j >= A.jsv - 1 && j <= A.jev + 1);
-    // (the first component's range is one wider across its direction than the second's; a thread evaluates what it can: the
-    //  second component of a sub-step asks for the narrower range below)
-    if (!in_range || !in_arr) return;
+    if (!in_range || !in_wide) return;
+    const FaceCoef &F = DIR ? FV : FU;
     bool ok;
     double n0 = 0., n1 = 0., n2 = 0., n3 = 0.;
     if (DIR == 0) {
@@ -872,32 +928,35 @@ k_bt_substep2(Dm d, const double *__restrict__ G, double *work, double *ubtav, d
       return;
     }
     const double vel = (DIR ? s_v : s_u)[ty][tx];
-    double newv, CorPF;
-    bt_face_update_lds<DIR>(d, G, work, A, c, st, slab, s_e[ty][tx], DIR ? s_e[ty + 1][tx] : s_e[ty][tx + 1], vel, n0, n1, n2, n3, bb, newv, CorPF);
+    const double e0 = s_e[ty][tx], e1 = DIR ? s_e[ty + 1][tx] : s_e[ty][tx + 1];
+    // bt_face_update's expressions
+    const double PF = (((e0 - F.ePF0) * F.g0) - ((e1 - F.ePF1) * F.g1)) * A.dgeo_de * F.Idx;
+    double Cor;
+    if (DIR == 0) Cor = (((F.f3 * n0) + (F.f0 * n1)) + ((F.f2 * n2) + (F.f1 * n3))) - F.Cref;
+    else if (bb) Cor = -1.0 * (((F.f0 * n0) + (F.f1 * n1)) + ((F.f3 * n2) + (F.f2 * n3))) - F.Cref;
+    else Cor = -1.0 * (((F.f0 * n0) + (F.f3 * n2)) + ((F.f1 * n1) + (F.f2 * n3))) - F.Cref;
+    double newv = F.rem * (vel + A.dtbt * ((F.force + Cor) + PF));
+    if (fabs(newv) < A.vel_underflow) newv = 0.0;
+    const double CorPF = Cor + PF;
     (DIR ? s_v : s_u)[ty][tx] = newv;
-    const double hn = find_uhbt(newv, work + (DIR ? W_BTCv : W_BTCu) * slab, c, slab) + work[(DIR ? W_vhbt0 : W_uhbt0) * slab + c];
+    const double hn = find_uhbt_reg(newv, F.B) + F.h0;
     (DIR ? s_vn : s_un)[ty][tx] = hn;
+    (DIR ? last_vn : last_un) = hn;
     unsigned char okb = (unsigned char)(DIR ? OK_VN : OK_UN);
-    if (owner) {
-      if (last) { (DIR ? vbt_out : ubt_out)[c] = newv; work[(DIR ? W_vhn : W_uhn) * slab + c] = hn; }
-      double *acc = work + (DIR ? W_v_accel_bt : W_u_accel_bt) * slab;
-      acc[c] = acc[c] + A.wt_accel * CorPF;
-    }
+    if (owner) (DIR ? acc_v : acc_u) = (DIR ? acc_v : acc_u) + A.wt_accel * CorPF;
     const bool in_trans = DIR ? (i >= A.isv && i <= A.iev && j >= A.jsv - 1 && j <= A.jev)
                               : (i >= A.isv - 1 && i <= A.iev && j >= A.jsv && j <= A.jev);
     if (in_trans) {
       const double trans = A.trans_wt1 * newv + A.trans_wt2 * vel;
-      const double hbt = find_uhbt(trans, work + (DIR ? W_BTCv : W_BTCu) * slab, c, slab) + work[(DIR ? W_vhbt0 : W_uhbt0) * slab + c];
+      const double hbt = find_uhbt_reg(trans, F.B) + F.h0;
       (DIR ? s_hv : s_hu)[ty][tx] = hbt;
       okb |= (unsigned char)(DIR ? OK_HV : OK_HU);
       const bool in_c = DIR ? (i >= 0 && i <= d.ni - 1 && j >= -1 && j <= d.nj - 1) : (i >= -1 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1);
       if (owner && in_c) {   // running sums :2690-2700
-        double *btav = DIR ? vbtav : ubtav, *hbtav = DIR ? vhbtav : uhbtav;
-        btav[c] = btav[c] + A.wt_trans * trans;
-        hbtav[c] = hbtav[c] + A.wt_trans * hbt;
+        if (DIR) { av_v = av_v + A.wt_trans * trans; hav_v = hav_v + A.wt_trans * hbt; sum_v = true; }
+        else     { av_u = av_u + A.wt_trans * trans; hav_u = hav_u + A.wt_trans * hbt; sum_u = true; }
         if (A.wt_vel != 0.0) {
-          double *wtd = work + (DIR ? W_vbt_wtd : W_ubt_wtd) * slab;
-          wtd[c] = wtd[c] + A.wt_vel * newv;
+          if (DIR) { wtd_v = wtd_v + A.wt_vel * newv; wtd_v_on = true; } else { wtd_u = wtd_u + A.wt_vel * newv; wtd_u_on = true; }
         }
       }
     } else {
@@ -912,46 +971,38 @@ k_bt_substep2(Dm d, const double *__restrict__ G, double *work, double *ubtav, d
   auto second_range = [&](int dir, const LoopArgs &A) -> bool {
     return dir ? (i >= A.isv && i <= A.iev && j >= A.jsv - 1 && j <= A.jev) : (i >= A.isv - 1 && i <= A.iev && j >= A.jsv && j <= A.jev);
   };
-  auto substep = [&](auto vf_tag, const LoopArgs &A, bool last) {
+  double pred_out = 0.0;
+  auto substep = [&](auto vf_tag, const LoopArgs &A) {
     constexpr bool VF = decltype(vf_tag)::value;
     // (the transports of this sub-step are new: nothing of the last one's may be taken for them)
     s_ok[ty][tx] &= (unsigned char)~(OK_HU | OK_HV | OK_UN | OK_VN);
     __syncthreads();
-    const bool own_u1 = (own_x || west) && (own_y || south || north1), own_v1 = (own_x || west || east1) && (own_y || south);
-    const bool own_u2 = (own_x || west) && own_y, own_v2 = own_x && (own_y || south);
-    if (VF) face(V{}, A, own_v1, last, 0); else face(U{}, A, own_u1, last, 0);
+    if (VF) face(V{}, A, own_v1, 0); else face(U{}, A, own_u1, 0);
     __syncthreads();
-    if (second_range(VF ? 0 : 1, A)) { if (VF) face(U{}, A, own_u2, last, 0); else face(V{}, A, own_v2, last, bracket_bug); }
+    if (second_range(VF ? 0 : 1, A)) { if (VF) face(U{}, A, own_u2, 0); else face(V{}, A, own_v2, bracket_bug); }
     __syncthreads();
     // eta corrector :2721-2727 and the next sub-step's predictor (k_bt_eta's lines)
-    if (in_arr && i >= A.isv && i <= A.iev && j >= A.jsv && j <= A.jev) {
-      const bool owner = own_x && own_y;
+    if (in_wide && i >= A.isv && i <= A.iev && j >= A.jsv && j <= A.jev) {
       const bool ok = okat(ty, tx - 1, OK_HU) && okat(ty, tx, OK_HU) && okat(ty - 1, tx, OK_HV) && okat(ty, tx, OK_HV) && okat(ty, tx, OK_ETA);
       const bool okn = ok && okat(ty, tx - 1, OK_UN) && okat(ty, tx, OK_UN) && okat(ty - 1, tx, OK_VN) && okat(ty, tx, OK_VN);
       if (!ok || (A.pred_next && !okn)) {
-        if (owner) broken = true;
+        if (own_c) broken = true;
         s_ok[ty][tx] &= (unsigned char)~(OK_ETA | OK_E);
       } else {
-        const double dtA = A.dtbt * gm(G, d, MOM6X_G_IareaT)[c];
-        const double src = work[W_eta_src * slab + c];
+        const double dtA = A.dtbt * IareaT;
         const double e = (eta + src) + dtA * ((s_hu[ty][tx - 1] - s_hu[ty][tx]) + (s_hv[ty - 1][tx] - s_hv[ty][tx]));
         eta = e;
-        if (owner) {
-          if (last) work[W_eta2 * slab + c] = e;
-          if (A.wt_eta != 0.0) work[W_eta_wtd * slab + c] = work[W_eta_wtd * slab + c] + e * A.wt_eta;
-        }
+        if (own_c && A.wt_eta != 0.0) { e_wtd = e_wtd + e * A.wt_eta; etaw_on = true; }
         if (A.pred_next) {
           const double eta_PF_BT = (e + src) + dtA * ((s_un[ty][tx - 1] - s_un[ty][tx]) + (s_vn[ty - 1][tx] - s_vn[ty][tx]));
           s_e[ty][tx] = eta_PF_BT;
-          if (owner) {
-            if (last) work[(size_t)P.e_out * slab + c] = eta_PF_BT;
-            if (A.find_etaav && (fabs(A.wt_accel2_next) > 0.0) && i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1)
-              work[W_eta_sum * slab + c] = work[W_eta_sum * slab + c] + A.wt_accel2_next * eta_PF_BT;
+          pred_out = eta_PF_BT;
+          if (own_c && A.find_etaav && (fabs(A.wt_accel2_next) > 0.0) && i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1) {
+            e_sum = e_sum + A.wt_accel2_next * eta_PF_BT; esum_on = true;
           }
         }
-        if (owner && i >= 0 && i < d.ni && j >= 0 && j < d.nj) {
-          const double bT = gm(G, d, MOM6X_G_bathyT)[c];
-          if ((e < -Z_to_H * bT) && (gm(G, d, MOM6X_G_mask2dT)[c] > 0.0)) {
+        if (own_c && i >= 0 && i < d.ni && j >= 0 && j < d.nj) {
+          if ((e < -Z_to_H * bT) && (mT > 0.0)) {
             atomicAdd(&warn[0], 1ULL);
             if (atomicCAS(&warn[1], 0ULL, 1ULL) == 0ULL) { warn_info[0] = e; warn_info[1] = -bT; warn_info[2] = (double)i; warn_info[3] = (double)j; }
           }
@@ -960,8 +1011,25 @@ k_bt_substep2(Dm d, const double *__restrict__ G, double *work, double *ubtav, d
     }
     __syncthreads();
   };
-  substep(std::integral_constant<bool, VF1>{}, A1, false);
-  substep(std::integral_constant<bool, !VF1>{}, A2, true);
+  substep(std::integral_constant<bool, VF1>{}, A1);
+  substep(std::integral_constant<bool, !VF1>{}, A2);
+  // ---- the owned points' results: the state of the second sub-step, the sums of both
+  if (in_wide) {
+    const bool u_upd2 = (i >= A2.isv - 1 && i <= A2.iev && j >= A2.jsv - 1 && j <= A2.jev + 1);   // (the widest range u is updated on in the second sub-step)
+    const bool v_upd2 = (i >= A2.isv - 1 && i <= A2.iev + 1 && j >= A2.jsv - 1 && j <= A2.jev);
+    const bool ou = VF1 ? own_u1 : own_u2, ov = VF1 ? own_v2 : own_v1;   // (second sub-step: the other component first)
+    const bool u_in2 = VF1 ? u_upd2 : second_range(0, A2), v_in2 = VF1 ? second_range(1, A2) : v_upd2;
+    if (ou && u_in2) { work[(size_t)P.u_out * slab + c] = s_u[ty][tx]; work[W_uhn * slab + c] = last_un; }
+    if (ov && v_in2) { work[(size_t)P.v_out * slab + c] = s_v[ty][tx]; work[W_vhn * slab + c] = last_vn; }
+    if (own_u) { work[W_u_accel_bt * slab + c] = acc_u; if (sum_u) { ubtav[c] = av_u; uhbtav[c] = hav_u; } if (wtd_u_on) work[W_ubt_wtd * slab + c] = wtd_u; }
+    if (own_v) { work[W_v_accel_bt * slab + c] = acc_v; if (sum_v) { vbtav[c] = av_v; vhbtav[c] = hav_v; } if (wtd_v_on) work[W_vbt_wtd * slab + c] = wtd_v; }
+    if (own_c && i >= A2.isv && i <= A2.iev && j >= A2.jsv && j <= A2.jev) {
+      work[W_eta2 * slab + c] = eta;
+      if (A2.pred_next) work[(size_t)P.e_out * slab + c] = pred_out;
+      if (etaw_on) work[W_eta_wtd * slab + c] = e_wtd;
+      if (esum_on) work[W_eta_sum * slab + c] = e_sum;
+    }
+  }
   if (broken) atomicOr(bad, 2);
 }
 
