@@ -25,12 +25,6 @@
 
 void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);  // halo.hip
 
-#ifndef MOM6X_BT_PAIR_DEFAULT   // two sub-steps per launch on large tiles (k_bt_substep2): 1 = the default there, 0 = only with MOM6X_BT_SUBSTEP=pair
-#define MOM6X_BT_PAIR_DEFAULT 0
-#endif
-#ifndef MOM6X_BT_PAIR_BSY
-#define MOM6X_BT_PAIR_BSY 16
-#endif
 enum BTW {   // 2-D work planes
   W_q = 0, W_DCor_u, W_DCor_v, W_gtot_E, W_gtot_W, W_gtot_N, W_gtot_S, W_eta, W_eta_PF,
   W_Cor_ref_u, W_Cor_ref_v, W_BT_force_u, W_BT_force_v, W_ubt, W_vbt, W_bt_rem_u, W_bt_rem_v,
@@ -44,7 +38,6 @@ enum BTW {   // 2-D work planes
   W_uhn = W_BTtmp + 12,   // find_uhbt(ubt) + uhbt0 / find_vhbt(vbt) + vhbt0 at the velocities of the last update: what the next
   W_vhn,                  //   sub-step's eta predictor needs, formed by the kernel that has the velocity and its fit planes at hand
   W_ubt2, W_vbt2, W_eta_pred2,   // k_bt_substep: the second copies of ubt, vbt, eta_pred (a sub-step reads one set and writes the other)
-  W_eta2,                        // k_bt_substep2: the new eta (a block's first sub-step reads its neighbours' old eta while they write)
   W_COUNT
 };
 
@@ -576,31 +569,6 @@ __device__ __forceinline__ void bt_face_update(const Dm &d, const double *__rest
   CorPF = Cor + PF;
 }
 
-// The same with the two eta values of the face handed over (k_bt_substep2 keeps the predictor in LDS).
-template <int DIR>
-__device__ __forceinline__ void bt_face_update_lds(const Dm &d, const double *__restrict__ G, const double *work, const LoopArgs &A, size_t c, int st,
-                                                   size_t slab, double e0, double e1, double vel, double n0, double n1, double n2, double n3,
-                                                   int bracket_bug, double &newv, double &CorPF) {
-  const double *eta_PF = work + W_eta_PF * slab;
-  double Cor, PF, f0, f1, f2, f3;
-  if (DIR == 0) {
-    const double *gE = work + W_gtot_E * slab, *gW = work + W_gtot_W * slab;
-    PF = (((e0 - eta_PF[c]) * gE[c]) - ((e1 - eta_PF[c + 1]) * gW[c + 1])) * A.dgeo_de * gm(G, d, MOM6X_G_IdxCu)[c];
-    f4u_of(work + W_q * slab, work + W_DCor_v * slab, c, st, A.Sadourny, f0, f1, f2, f3);
-    Cor = (((f3 * n0) + (f0 * n1)) + ((f2 * n2) + (f1 * n3))) - work[W_Cor_ref_u * slab + c];
-    newv = work[W_bt_rem_u * slab + c] * (vel + A.dtbt * ((work[W_BT_force_u * slab + c] + Cor) + PF));
-  } else {
-    const double *gN = work + W_gtot_N * slab, *gS = work + W_gtot_S * slab;
-    PF = (((e0 - eta_PF[c]) * gN[c]) - ((e1 - eta_PF[c + st]) * gS[c + st])) * A.dgeo_de * gm(G, d, MOM6X_G_IdyCv)[c];
-    f4v_of(work + W_q * slab, work + W_DCor_u * slab, c, st, A.Sadourny, f0, f1, f2, f3);
-    if (bracket_bug) Cor = -1.0 * (((f0 * n0) + (f1 * n1)) + ((f3 * n2) + (f2 * n3))) - work[W_Cor_ref_v * slab + c];
-    else Cor = -1.0 * (((f0 * n0) + (f3 * n2)) + ((f1 * n1) + (f2 * n3))) - work[W_Cor_ref_v * slab + c];
-    newv = work[W_bt_rem_v * slab + c] * (vel + A.dtbt * ((work[W_BT_force_v * slab + c] + Cor) + PF));
-  }
-  if (fabs(newv) < A.vel_underflow) newv = 0.0;
-  CorPF = Cor + PF;
-}
-
 // btloop_find_PF + btloop_update_u/v + transports + running sums for ONE velocity component.
 // DIR = 0: u (faces I), DIR = 1: v (faces J).  (a0..a1, b0..b1) is the update range.
 template <int DIR>
@@ -796,248 +764,6 @@ k_bt_substep(Dm d, const double *__restrict__ G, double *work, double *ubtav, do
       }
     }
   }
-}
-
-// TWO sub-steps per launch (round 5): everything that does not change over the sub-cycle -- ~34 of the ~70 words per column and
-// sub-step (the pressure-force, Coriolis and BT_cont fit planes) -- is read once per two sub-steps, the running sums are read and
-// written once instead of twice, and the transports between the stages never leave the chip.  A block of BSX x BSY threads is a
-// tile of points with a frame: thread (tx, ty) is cell (i, j), its east face and its north face.  The first sub-step (A1) is
-// evaluated wherever the tile holds its inputs, the second (A2, the other component first: the loop alternates) on what the first
-// left valid; a block owns OX x OY cells and their faces of the SECOND sub-step's ranges and only writes and sums there -- frame
-// points are recomputed from the same inputs with the same expressions, the same bits as their owners'.  Validity is tracked per
-// point and field (s_ok bits), not by hand-derived index ranges: a value is valid if it was loaded, or computed from valid inputs;
-// a point outside a sub-step's update range keeps its value, as it does in memory.  Conditions (the caller's): no exchange
-// between the two sub-steps, the eta predictor chain (pass_uhn), no CLIP_BT_VELOCITY / BT_PROJECT_VELOCITY.
-struct Sub2Planes { int u_in, u_out, v_in, v_out, e_in, e_out; };
-enum { OK_U = 1, OK_V = 2, OK_E = 4, OK_HU = 8, OK_HV = 16, OK_UN = 32, OK_VN = 64, OK_ETA = 128 };
-// Everything of one face that does not change over the sub-cycle, in registers for both sub-steps of the launch: the operands of
-// btloop_find_PF / btloop_update_u|v (bt_face_update's) and the ten BT_cont fit parameters of find_uhbt (all ten: a launch evaluates
-// the fit four times per face, and which of them a velocity needs is only known when it is there -- loaded on demand, each
-// evaluation was a chain of dependent round trips to the L2 with two work-groups per CU to hide them: 7.3 ms per step against
-// 6.6 for the three kernels, profiles/r05_btpair.txt).
-struct FaceCoef { double ePF0, ePF1, g0, g1, Idx, f0, f1, f2, f3, Cref, rem, force, B[10], h0; };
-__device__ __forceinline__ double find_uhbt_reg(double u, const double *B) {   // find_uhbt, same expressions
-  if (u == 0.0) return 0.0;
-  const double uEE = B[B_uBT_EE];
-  if (u < uEE) return (u - uEE) * B[B_FA_EE] + B[B_uh_EE];
-  if (u < 0.0) return u * (B[B_FA_E0] + B[B_crvE] * (u * u));
-  const double uWW = B[B_uBT_WW];
-  if (u <= uWW) return u * (B[B_FA_W0] + B[B_crvW] * (u * u));
-  return (u - uWW) * B[B_FA_WW] + B[B_uh_WW];
-}
-template <int DIR>
-__device__ __forceinline__ void load_face(const Dm &d, const double *__restrict__ G, const double *work, size_t c, int st, size_t slab, int Sadourny,
-                                          FaceCoef &F) {
-  const double *eta_PF = work + W_eta_PF * slab;
-  if (DIR == 0) {
-    F.ePF0 = eta_PF[c]; F.ePF1 = eta_PF[c + 1];
-    F.g0 = work[W_gtot_E * slab + c]; F.g1 = work[W_gtot_W * slab + c + 1];
-    F.Idx = gm(G, d, MOM6X_G_IdxCu)[c];
-    f4u_of(work + W_q * slab, work + W_DCor_v * slab, c, st, Sadourny, F.f0, F.f1, F.f2, F.f3);
-    F.Cref = work[W_Cor_ref_u * slab + c]; F.rem = work[W_bt_rem_u * slab + c]; F.force = work[W_BT_force_u * slab + c];
-  } else {
-    F.ePF0 = eta_PF[c]; F.ePF1 = eta_PF[c + st];
-    F.g0 = work[W_gtot_N * slab + c]; F.g1 = work[W_gtot_S * slab + c + st];
-    F.Idx = gm(G, d, MOM6X_G_IdyCv)[c];
-    f4v_of(work + W_q * slab, work + W_DCor_u * slab, c, st, Sadourny, F.f0, F.f1, F.f2, F.f3);
-    F.Cref = work[W_Cor_ref_v * slab + c]; F.rem = work[W_bt_rem_v * slab + c]; F.force = work[W_BT_force_v * slab + c];
-  }
-  const double *B = work + (DIR ? W_BTCv : W_BTCu) * slab;
-#pragma unroll
-  for (int q = 0; q < 10; q++) F.B[q] = B[(size_t)q * slab + c];
-  F.h0 = work[(DIR ? W_vhbt0 : W_uhbt0) * slab + c];
-}
-template <bool VF1, int BSX, int BSY>
-__global__ void __launch_bounds__(BSX * BSY)
-k_bt_substep2(Dm d, const double *__restrict__ G, double *work, double *ubtav, double *uhbtav, double *vbtav, double *vhbtav, LoopArgs A1,
-              LoopArgs A2, Sub2Planes P, int bracket_bug, double Z_to_H, unsigned long long *warn, double *warn_info, int nbx, int *bad) {
-  // frames: the second sub-step starts with the OTHER component.  u-first then v-first: 2 columns west, 3 rows south, 1 east, 2 north
-  constexpr int FW = VF1 ? 3 : 2, FS = VF1 ? 2 : 3;
-  constexpr int OX = VF1 ? BSX - 5 : BSX - 4, OY = VF1 ? BSY - 4 : BSY - 5;
-  __shared__ double s_u[BSY][BSX], s_v[BSY][BSX], s_e[BSY][BSX], s_hu[BSY][BSX], s_hv[BSY][BSX], s_un[BSY][BSX], s_vn[BSY][BSX];
-  __shared__ unsigned char s_ok[BSY][BSX];
-  const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
-  const int x0 = A2.isv + bx * OX, y0 = A2.jsv + by * OY;
-  const int x1 = min(x0 + OX - 1, A2.iev), y1 = min(y0 + OY - 1, A2.jev);
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int i = x0 - FW + tx, j = y0 - FS + ty;
-  const int st = d.pitch;
-  const size_t slab = (size_t)d.slab;
-  const int nrows = d.slab / d.pitch;
-  const bool in_arr = (i + d.ioff >= 0 && i + d.ioff <= d.pitch - 1 && j + d.joff >= 0 && j + d.joff <= nrows - 1);
-  // a point evaluates something only inside the first sub-step's widest ranges (whose stencils stay inside the array)
-  const bool in_wide = in_arr && i >= A1.isv - 1 && i <= A1.iev + 1 && j >= A1.jsv - 1 && j <= A1.jev + 1;
-  const size_t c = in_arr ? ix2(d, i, j) : ix2(d, 0, 0);
-  // ownership (of the second sub-step's ranges; k_bt_substep's rules)
-  const bool own_x = (i >= x0 && i <= x1), own_y = (j >= y0 && j <= y1);
-  const bool west = (i == A2.isv - 1 && x0 == A2.isv), south = (j == A2.jsv - 1 && y0 == A2.jsv);
-  const bool east1 = (i == A2.iev + 1 && x1 == A2.iev), north1 = (j == A2.jev + 1 && y1 == A2.jev);
-  const bool own_u1 = (own_x || west) && (own_y || south || north1), own_v1 = (own_x || west || east1) && (own_y || south);
-  const bool own_u2 = (own_x || west) && own_y, own_v2 = own_x && (own_y || south), own_c = own_x && own_y;
-  const bool own_u = own_u1 || own_u2, own_v = own_v1 || own_v2;
-  // ---- everything from memory, in one go
-  FaceCoef FU, FV;
-  double eta = 0.0, IareaT = 0.0, src = 0.0, bT = 0.0, mT = 0.0;
-  double acc_u = 0., av_u = 0., hav_u = 0., wtd_u = 0., acc_v = 0., av_v = 0., hav_v = 0., wtd_v = 0., e_wtd = 0., e_sum = 0.;
-  {
-    unsigned char ok = 0;
-    double u = 0.0, v = 0.0, e = 0.0;
-    if (in_arr) {
-      u = work[(size_t)P.u_in * slab + c]; v = work[(size_t)P.v_in * slab + c]; e = work[(size_t)P.e_in * slab + c]; eta = work[W_eta * slab + c];
-      ok = OK_U | OK_V | OK_E | OK_ETA;
-    }
-    if (in_wide) {
-      load_face<0>(d, G, work, c, st, slab, A1.Sadourny, FU);
-      load_face<1>(d, G, work, c, st, slab, A1.Sadourny, FV);
-      IareaT = gm(G, d, MOM6X_G_IareaT)[c]; src = work[W_eta_src * slab + c];
-      bT = gm(G, d, MOM6X_G_bathyT)[c]; mT = gm(G, d, MOM6X_G_mask2dT)[c];
-    }
-    if (in_wide && own_u) { acc_u = work[W_u_accel_bt * slab + c]; av_u = ubtav[c]; hav_u = uhbtav[c]; wtd_u = work[W_ubt_wtd * slab + c]; }
-    if (in_wide && own_v) { acc_v = work[W_v_accel_bt * slab + c]; av_v = vbtav[c]; hav_v = vhbtav[c]; wtd_v = work[W_vbt_wtd * slab + c]; }
-    if (in_wide && own_c) { e_wtd = work[W_eta_wtd * slab + c]; e_sum = work[W_eta_sum * slab + c]; }
-    s_u[ty][tx] = u; s_v[ty][tx] = v; s_e[ty][tx] = e; s_hu[ty][tx] = 0.0; s_hv[ty][tx] = 0.0; s_un[ty][tx] = 0.0; s_vn[ty][tx] = 0.0;
-    s_ok[ty][tx] = ok;
-  }
-  __syncthreads();
-  auto okat = [&](int yy, int xx, int bit) -> bool { return xx >= 0 && xx < BSX && yy >= 0 && yy < BSY && (s_ok[yy][xx] & bit); };
-  bool broken = false;   // an owned point could not be computed: the tile's frame is too small for the ranges (must not happen)
-  bool sum_u = false, sum_v = false, wtd_u_on = false, wtd_v_on = false, etaw_on = false, esum_on = false;
-  double last_un = 0.0, last_vn = 0.0;
-
-  // one face of one sub-step: k_bt_vel's lines with the state in LDS and the coefficients in registers
-  auto face = [&](auto dir_tag, const LoopArgs &A, bool owner, int bb) {
-    constexpr int DIR = decltype(dir_tag)::value;
-    const bool in_range = DIR ? (i >= A.isv - 1 && i <= A.iev + 1 && j >= A.jsv - 1 && j <= A.jev)
-                              : (i >= A.isv - 1 && i <= A.iev && j >= A.jsv - 1 && j <= A.jev + 1);
-    if (!in_range || !in_wide) return;
-    const FaceCoef &F = DIR ? FV : FU;
-    bool ok;
-    double n0 = 0., n1 = 0., n2 = 0., n3 = 0.;
-    if (DIR == 0) {
-      ok = okat(ty, tx, OK_U) && okat(ty, tx, OK_E) && okat(ty, tx + 1, OK_E) && okat(ty, tx + 1, OK_V) && okat(ty - 1, tx, OK_V) &&
-           okat(ty, tx, OK_V) && okat(ty - 1, tx + 1, OK_V);
-      if (ok) { n0 = s_v[ty][tx + 1]; n1 = s_v[ty - 1][tx]; n2 = s_v[ty][tx]; n3 = s_v[ty - 1][tx + 1]; }
-    } else {
-      ok = okat(ty, tx, OK_V) && okat(ty, tx, OK_E) && okat(ty + 1, tx, OK_E) && okat(ty, tx - 1, OK_U) && okat(ty, tx, OK_U) &&
-           okat(ty + 1, tx, OK_U) && okat(ty + 1, tx - 1, OK_U);
-      if (ok) { n0 = s_u[ty][tx - 1]; n1 = s_u[ty][tx]; n2 = s_u[ty + 1][tx]; n3 = s_u[ty + 1][tx - 1]; }
-    }
-    if (!ok) {
-      if (owner) broken = true;
-      s_ok[ty][tx] &= (unsigned char)~((DIR ? OK_V : OK_U) | (DIR ? OK_HV : OK_HU) | (DIR ? OK_VN : OK_UN));
-      return;
-    }
-    const double vel = (DIR ? s_v : s_u)[ty][tx];
-    const double e0 = s_e[ty][tx], e1 = DIR ? s_e[ty + 1][tx] : s_e[ty][tx + 1];
-    // bt_face_update's expressions
-    const double PF = (((e0 - F.ePF0) * F.g0) - ((e1 - F.ePF1) * F.g1)) * A.dgeo_de * F.Idx;
-    double Cor;
-    if (DIR == 0) Cor = (((F.f3 * n0) + (F.f0 * n1)) + ((F.f2 * n2) + (F.f1 * n3))) - F.Cref;
-    else if (bb) Cor = -1.0 * (((F.f0 * n0) + (F.f1 * n1)) + ((F.f3 * n2) + (F.f2 * n3))) - F.Cref;
-    else Cor = -1.0 * (((F.f0 * n0) + (F.f3 * n2)) + ((F.f1 * n1) + (F.f2 * n3))) - F.Cref;
-    double newv = F.rem * (vel + A.dtbt * ((F.force + Cor) + PF));
-    if (fabs(newv) < A.vel_underflow) newv = 0.0;
-    const double CorPF = Cor + PF;
-    (DIR ? s_v : s_u)[ty][tx] = newv;
-    const double hn = find_uhbt_reg(newv, F.B) + F.h0;
-    (DIR ? s_vn : s_un)[ty][tx] = hn;
-    (DIR ? last_vn : last_un) = hn;
-    unsigned char okb = (unsigned char)(DIR ? OK_VN : OK_UN);
-    if (owner) (DIR ? acc_v : acc_u) = (DIR ? acc_v : acc_u) + A.wt_accel * CorPF;
-    const bool in_trans = DIR ? (i >= A.isv && i <= A.iev && j >= A.jsv - 1 && j <= A.jev)
-                              : (i >= A.isv - 1 && i <= A.iev && j >= A.jsv && j <= A.jev);
-    if (in_trans) {
-      const double trans = A.trans_wt1 * newv + A.trans_wt2 * vel;
-      const double hbt = find_uhbt_reg(trans, F.B) + F.h0;
-      (DIR ? s_hv : s_hu)[ty][tx] = hbt;
-      okb |= (unsigned char)(DIR ? OK_HV : OK_HU);
-      const bool in_c = DIR ? (i >= 0 && i <= d.ni - 1 && j >= -1 && j <= d.nj - 1) : (i >= -1 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1);
-      if (owner && in_c) {   // running sums :2690-2700
-        if (DIR) { av_v = av_v + A.wt_trans * trans; hav_v = hav_v + A.wt_trans * hbt; sum_v = true; }
-        else     { av_u = av_u + A.wt_trans * trans; hav_u = hav_u + A.wt_trans * hbt; sum_u = true; }
-        if (A.wt_vel != 0.0) {
-          if (DIR) { wtd_v = wtd_v + A.wt_vel * newv; wtd_v_on = true; } else { wtd_u = wtd_u + A.wt_vel * newv; wtd_u_on = true; }
-        }
-      }
-    } else {
-      s_ok[ty][tx] &= (unsigned char)~(DIR ? OK_HV : OK_HU);   // (last sub-step's transport is not this one's)
-    }
-    s_ok[ty][tx] |= okb;
-  };
-  using U = std::integral_constant<int, 0>;
-  using V = std::integral_constant<int, 1>;
-  // the second component's update range is narrower than the first's (:2575-2632): u after v on (isv-1..iev, jsv..jev), v after u on
-  // (isv..iev, jsv-1..jev)
-  auto second_range = [&](int dir, const LoopArgs &A) -> bool {
-    return dir ? (i >= A.isv && i <= A.iev && j >= A.jsv - 1 && j <= A.jev) : (i >= A.isv - 1 && i <= A.iev && j >= A.jsv && j <= A.jev);
-  };
-  double pred_out = 0.0;
-  auto substep = [&](auto vf_tag, const LoopArgs &A) {
-    constexpr bool VF = decltype(vf_tag)::value;
-    // (the transports of this sub-step are new: nothing of the last one's may be taken for them)
-    s_ok[ty][tx] &= (unsigned char)~(OK_HU | OK_HV | OK_UN | OK_VN);
-    __syncthreads();
-    if (VF) face(V{}, A, own_v1, 0); else face(U{}, A, own_u1, 0);
-    __syncthreads();
-    if (second_range(VF ? 0 : 1, A)) { if (VF) face(U{}, A, own_u2, 0); else face(V{}, A, own_v2, bracket_bug); }
-    __syncthreads();
-    // eta corrector :2721-2727 and the next sub-step's predictor (k_bt_eta's lines)
-    if (in_wide && i >= A.isv && i <= A.iev && j >= A.jsv && j <= A.jev) {
-      const bool ok = okat(ty, tx - 1, OK_HU) && okat(ty, tx, OK_HU) && okat(ty - 1, tx, OK_HV) && okat(ty, tx, OK_HV) && okat(ty, tx, OK_ETA);
-      const bool okn = ok && okat(ty, tx - 1, OK_UN) && okat(ty, tx, OK_UN) && okat(ty - 1, tx, OK_VN) && okat(ty, tx, OK_VN);
-      if (!ok || (A.pred_next && !okn)) {
-        if (own_c) broken = true;
-        s_ok[ty][tx] &= (unsigned char)~(OK_ETA | OK_E);
-      } else {
-        const double dtA = A.dtbt * IareaT;
-        const double e = (eta + src) + dtA * ((s_hu[ty][tx - 1] - s_hu[ty][tx]) + (s_hv[ty - 1][tx] - s_hv[ty][tx]));
-        eta = e;
-        if (own_c && A.wt_eta != 0.0) { e_wtd = e_wtd + e * A.wt_eta; etaw_on = true; }
-        if (A.pred_next) {
-          const double eta_PF_BT = (e + src) + dtA * ((s_un[ty][tx - 1] - s_un[ty][tx]) + (s_vn[ty - 1][tx] - s_vn[ty][tx]));
-          s_e[ty][tx] = eta_PF_BT;
-          pred_out = eta_PF_BT;
-          if (own_c && A.find_etaav && (fabs(A.wt_accel2_next) > 0.0) && i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1) {
-            e_sum = e_sum + A.wt_accel2_next * eta_PF_BT; esum_on = true;
-          }
-        }
-        if (own_c && i >= 0 && i < d.ni && j >= 0 && j < d.nj) {
-          if ((e < -Z_to_H * bT) && (mT > 0.0)) {
-            atomicAdd(&warn[0], 1ULL);
-            if (atomicCAS(&warn[1], 0ULL, 1ULL) == 0ULL) { warn_info[0] = e; warn_info[1] = -bT; warn_info[2] = (double)i; warn_info[3] = (double)j; }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  };
-  substep(std::integral_constant<bool, VF1>{}, A1);
-  substep(std::integral_constant<bool, !VF1>{}, A2);
-  // ---- the owned points' results: the state of the second sub-step, the sums of both
-  if (in_wide) {
-    const bool u_upd2 = (i >= A2.isv - 1 && i <= A2.iev && j >= A2.jsv - 1 && j <= A2.jev + 1);   // (the widest range u is updated on in the second sub-step)
-    const bool v_upd2 = (i >= A2.isv - 1 && i <= A2.iev + 1 && j >= A2.jsv - 1 && j <= A2.jev);
-    const bool ou = VF1 ? own_u1 : own_u2, ov = VF1 ? own_v2 : own_v1;   // (second sub-step: the other component first)
-    const bool u_in2 = VF1 ? u_upd2 : second_range(0, A2), v_in2 = VF1 ? second_range(1, A2) : v_upd2;
-    if (ou && u_in2) { work[(size_t)P.u_out * slab + c] = s_u[ty][tx]; work[W_uhn * slab + c] = last_un; }
-    if (ov && v_in2) { work[(size_t)P.v_out * slab + c] = s_v[ty][tx]; work[W_vhn * slab + c] = last_vn; }
-    if (own_u) { work[W_u_accel_bt * slab + c] = acc_u; if (sum_u) { ubtav[c] = av_u; uhbtav[c] = hav_u; } if (wtd_u_on) work[W_ubt_wtd * slab + c] = wtd_u; }
-    if (own_v) { work[W_v_accel_bt * slab + c] = acc_v; if (sum_v) { vbtav[c] = av_v; vhbtav[c] = hav_v; } if (wtd_v_on) work[W_vbt_wtd * slab + c] = wtd_v; }
-    if (own_c && i >= A2.isv && i <= A2.iev && j >= A2.jsv && j <= A2.jev) {
-      work[W_eta2 * slab + c] = eta;
-      if (A2.pred_next) work[(size_t)P.e_out * slab + c] = pred_out;
-      if (etaw_on) work[W_eta_wtd * slab + c] = e_wtd;
-      if (esum_on) work[W_eta_sum * slab + c] = e_sum;
-    }
-  }
-  if (broken) atomicOr(bad, 2);
-}
-
-__global__ void k_bt_copy_cells(Dm d, double *__restrict__ dst, const double *__restrict__ src, int i0, int i1, int j0, int j1) {
-  const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x, j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
-  if (i < i0 || i > i1 || j > j1) return;
-  const size_t c = ix2(d, i, j);
-  dst[c] = src[c];
 }
 
 // truncate_velocities :2918-2944
@@ -1482,12 +1208,13 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   // Measured (profiles/README.md, r04): on the 360 x 540 tile of an 8-GPU layout the one-launch form wins (the step 9.14 -> 9.01 ms:
   // its kernels are latency-, not bandwidth-bound there); at 1440 x 1080 the three kernels win (6.6 against 7.4 ms per step: the
   // frame a block recomputes, 20 % of its threads, costs more than the three round trips of ubt, vbt, uhbt save).  So: by size.
-  // MOM6X_BT_SUBSTEP=pair: TWO sub-steps per launch wherever no exchange separates them (k_bt_substep2, round 5).
-  static const int substep_env = [] { const char *e = getenv("MOM6X_BT_SUBSTEP");
-                                      return !e ? 0 : (!strcmp(e, "kernels") ? 1 : (!strcmp(e, "fused") ? 2 : (!strcmp(e, "pair") ? 3 : 0))); }();
+  // (Round 5 built TWO sub-steps per launch on the large tile -- a tile with a 2-3 point frame, the state of the first sub-step handed to the
+  //  second through LDS, the ~34 time-invariant words per column read once per two sub-steps, the running sums read and written once --
+  //  in two forms, coefficients on demand and all of them in registers: bit-identical, 7.3 / 7.4 ms per step against 6.6 for the three
+  //  kernels at 1440 x 1080 (profiles/r05_btpair.txt, r05_btpair2.txt; the kernel is in the history: k_bt_substep2).  Removed.)
+  static const int substep_env = [] { const char *e = getenv("MOM6X_BT_SUBSTEP"); return !e ? 0 : (!strcmp(e, "kernels") ? 1 : (!strcmp(e, "fused") ? 2 : 0)); }();
   const bool small_tile = ((long)d.ni * d.nj <= 512L * 1024L);
-  const bool pairs = pass_uhn && (substep_env == 3 || (substep_env == 0 && MOM6X_BT_PAIR_DEFAULT && !small_tile));
-  const bool fused = pass_uhn && (substep_env == 2 || pairs || (substep_env == 0 && small_tile));
+  const bool fused = pass_uhn && (substep_env == 2 || (substep_env == 0 && small_tile));
   SubPlanes SP = { W_ubt, fused ? W_ubt2 : W_ubt, W_vbt, fused ? W_vbt2 : W_vbt, W_eta_pred, fused ? W_eta_pred2 : W_eta_pred };
   const int loop_stg[] = { 0, 1, 2, 1, 2 }, loop_nk[] = { 1, 1, 1, 1, 1 };
   bool pred_done = false;
@@ -1512,34 +1239,6 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     L.pred_next = pred_done ? 1 : 0;
     L.wt_accel2_next = pred_done ? wt_accel2[n + 1] : 0.0;
     const bool v_first = (((n + c->first_direction) % 2) == 1);
-    if (pairs && pred_done) {   // sub-steps n and n + 1 in one launch: no exchange between them, the predictor chain holds
-      LoopArgs L2 = L;
-      const int isv2 = isv + stencil, iev2 = iev - stencil, jsv2 = jsv + stencil, jev2 = jev - stencil;
-      L2.isv = isv2; L2.iev = iev2; L2.jsv = jsv2; L2.jev = jev2;
-      L2.have_uhn = 1;
-      L2.wt_accel = wt_accel[n + 1]; L2.wt_trans = wt_trans[n + 1]; L2.wt_vel = wt_vel[n + 1]; L2.wt_eta = wt_eta[n + 1]; L2.wt_accel2 = wt_accel2[n + 1];
-      const bool pred2 = pass_uhn && (n + 1) < nt && !((iev2 - stencil < ie) || (jev2 - stencil < je));
-      L2.pred_next = pred2 ? 1 : 0;
-      L2.wt_accel2_next = pred2 ? wt_accel2[n + 2] : 0.0;
-      Sub2Planes S2 = { SP.u_in, SP.u_out, SP.v_in, SP.v_out, SP.e_in, SP.e_out };
-      constexpr int BX = 32, BY = MOM6X_BT_PAIR_BSY;
-      const int OX = v_first ? BX - 5 : BX - 4, OY = v_first ? BY - 4 : BY - 5;
-      const int nbx = (iev2 - isv2 + OX) / OX, nby = (jev2 - jsv2 + OY) / OY;
-      if (v_first)
-        KLAUNCH(c, "k_bt_substep2<v>", (k_bt_substep2<true, BX, BY>), dim3(nbx * nby), dim3(BX, BY), d, c->G, work, s->ubtav, uhbtav, s->vbtav, vhbtav,
-                L, L2, S2, P.use_old_coriolis_bracket_bug, c->GV.Z_to_H, s->warn, s->warn_info, nbx, c->flag);
-      else
-        KLAUNCH(c, "k_bt_substep2<u>", (k_bt_substep2<false, BX, BY>), dim3(nbx * nby), dim3(BX, BY), d, c->G, work, s->ubtav, uhbtav, s->vbtav, vhbtav,
-                L, L2, S2, P.use_old_coriolis_bracket_bug, c->GV.Z_to_H, s->warn, s->warn_info, nbx, c->flag);
-      KLAUNCH(c, "k_bt_copy_cells", k_bt_copy_cells, grid3(nxa(iev2 - isv2 + 1, isv2), jev2 - jsv2 + 1, 1, b), b, d, work + W_eta * slab,
-              work + W_eta2 * slab, isv2, iev2, jsv2, jev2);
-      std::swap(SP.u_in, SP.u_out); std::swap(SP.v_in, SP.v_out);
-      if (pred2) std::swap(SP.e_in, SP.e_out);
-      pred_done = pred2;
-      isv = isv2; iev = iev2; jsv = jsv2; jev = jev2;
-      n++;   // (two sub-steps done)
-      continue;
-    }
     if (fused) {
       // (work-groups of 32 x 8; 32 x 16, 16 x 16 and 64 x 4 were measured in round 4 -- 9.01 / 9.03 / 9.20 / 9.14 ms per step on the 8-GPU tile -- and are gone)
 #define SUBSTEP(BX, BY) do {                                                                                                          \

@@ -16,9 +16,6 @@ CASES = [
     ("MOM6X_BT_SUBSTEP", "kernels", "test_barotropic_gpu.py", ""),                      # three launches per barotropic sub-step
     ("MOM6X_BT_SUBSTEP", "kernels", "test_rk2_gpu.py", "double_gyre_bitexact or 75_layers_on_chip"),
     ("MOM6X_BT_SUBSTEP", "fused", "test_layout_gpu.py", "wide_halos"),                  # (the default at these sizes; named)
-    ("MOM6X_BT_SUBSTEP", "pair", "test_barotropic_gpu.py", ""),                         # two sub-steps per launch (k_bt_substep2)
-    ("MOM6X_BT_SUBSTEP", "pair", "test_rk2_gpu.py", "double_gyre_bitexact or 75_layers_on_chip"),
-    ("MOM6X_BT_SUBSTEP", "pair", "test_layout_gpu.py", "wide_halos or tile_layout_gives"),
     ("MOM6X_FAMT0", "sweep", "test_continuity_gpu.py", "double_gyre or tied_quotients"),  # set_*_BT_cont's own sweep at du0
     ("MOM6X_MFW_ROWS", "3", "test_continuity_gpu.py", "double_gyre or channel or many_layers"),   # march length of the wave kernel
     ("MOM6X_MFW_ROWS", "37", "test_continuity_gpu.py", "double_gyre or channel or many_layers"),
