@@ -119,7 +119,10 @@ def build_model(args, layout, pe, device, dist=None, unique_id=None, reentrant_y
 KERNEL_WORDS = {
     # h, u, visc_rem in; uh out; plus u_cor (calls with uhbt) or BT_cont%h_u (the call that sets BT_cont): 5 either way
     "k_mass_flux_lds": 5.0,
-    "k_mass_flux_wave": 5.0,     # the same routine with one wavefront row per face column (sum_order TREE16, the default)
+    # the same routine with one wavefront row per face column (sum_order TREE16, the default).  Mean over a step's three launches
+    # (continuity x3 = (8+0+2) + (8+2+2) + (8+2+0) words for both directions): h, u, visc_rem in + uh out, + h_u (the
+    # call that sets BT_cont) = 5; + u_cor AND h_u (the predictor's second call) = 6; + u_cor (the corrector's) = 5
+    "k_mass_flux_wave": 16.0 / 3.0,
     # thread-per-column path (MOM6X_MASSFLUX=legacy): u, visc_rem, h, (h_L, h_R from k_edge) in; uh [+ u_cor] out
     "k_mass_flux<": 14.0 / 3.0,
     "k_vertvisc_remnant": 3.0,   # a(k), h in; visc_rem out
@@ -480,6 +483,27 @@ def pmc_step_traffic():
     return None, None
 
 
+def _variants_mean(tab, kernel, field=None, launches=None):
+    """`kernel` is a launch label ("k_mass_flux_wave<0>"); a counter table names the template instantiations that ran under it
+    ("k_mass_flux_wave<0, 5, false, 2, false>").  The step's launches of the mass-flux kernel are three instantiations compiled
+    for their switches (SPEC 1, 2, 3: continuity_wave.hip struct Sw); the general one (SPEC 0) only runs at initialisation and the
+    one with the Newton statistics (third argument true) only in the step after the timed region.  Returns the mean over the step's
+    instantiations (weighted with their launches per step where the table has them) of tab[name] or tab[name][field]."""
+    import re
+    key = lambda n: (re.match(r"\w+(<\d+)?", n.replace(" ", "")) or [n])[0]
+    names = [n for n in tab if key(n) == key(kernel)]
+    if not names:
+        return None
+    args = {n: [a.strip() for a in n[n.index("<") + 1:n.rindex(">")].split(",")] if "<" in n else [] for n in names}
+    step = [n for n in names if not (len(args[n]) >= 5 and (args[n][2] == "true" or args[n][3] == "0"))] or names
+    val = lambda n: (tab[n] if field is None else tab[n].get(field))
+    step = [n for n in step if val(n)]
+    if not step:
+        return None
+    w = {n: float((launches or {}).get(n, 1.0)) for n in step}
+    return sum(w[n] * float(val(n)) for n in step) / sum(w.values())
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_hbm_pmc.json,
     written by scripts/rocprof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; the
@@ -489,12 +513,13 @@ def pmc_traffic(kernel):
     key = lambda n: (re.match(r"\w+(<\d+)?", n.replace(" ", "")) or [n])[0]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")), reverse=True):
         try:
-            tab = json.load(open(path))["traffic_bytes_per_launch"]
+            j = json.load(open(path))
+            tab = j["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             continue
-        for n, v in tab.items():
-            if key(n) == key(kernel):
-                return float(v), os.path.relpath(path, ROOT)
+        v = _variants_mean(tab, kernel, launches=j.get("launches_per_step"))
+        if v is not None:
+            return float(v), os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -514,17 +539,18 @@ def valu_counters(kernel, N3_tile, avg_ms):
             tab = json.load(open(path))["per_launch"]
         except (OSError, ValueError, KeyError):
             continue
-        for n, c in tab.items():
-            if key(n) == key(kernel) and c.get("SQ_INSTS_VALU"):
-                lane = 64.0 * c["SQ_INSTS_VALU"]
-                rate = lane / (avg_ms * 1e-3) / 1e12
-                return {"SQ_INSTS_VALU_per_launch": c["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_per_launch": c.get("SQ_ACTIVE_INST_VALU"),
-                        "SQ_WAVES_per_launch": c.get("SQ_WAVES"), "SQ_BUSY_CYCLES_per_launch": c.get("SQ_BUSY_CYCLES"),
-                        "SQ_WAVE_CYCLES_per_launch": c.get("SQ_WAVE_CYCLES"),
-                        "lane_instructions_per_face_layer": round(lane / N3_tile, 1),
-                        "achieved_Tlane_instr_per_s": round(rate, 2), "peak_Tlane_instr_per_s": round(FP64_VALU_PEAK_TLANE_S, 2),
-                        "frac_of_fp64_vector_issue_peak": round(rate / FP64_VALU_PEAK_TLANE_S, 3),
-                        "occupancy": "2 wavefronts per SIMD (253 VGPRs)", "source": os.path.relpath(path, ROOT) + " @ " + git_hash_of(path)}
+        m = {f: _variants_mean(tab, kernel, field=f) for f in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES")}
+        if m["SQ_INSTS_VALU"]:
+            lane = 64.0 * m["SQ_INSTS_VALU"]
+            rate = lane / (avg_ms * 1e-3) / 1e12
+            return {"SQ_INSTS_VALU_per_launch": round(m["SQ_INSTS_VALU"], 1), "SQ_ACTIVE_INST_VALU_per_launch": m["SQ_ACTIVE_INST_VALU"],
+                    "SQ_WAVES_per_launch": m["SQ_WAVES"], "SQ_BUSY_CYCLES_per_launch": m["SQ_BUSY_CYCLES"],
+                    "SQ_WAVE_CYCLES_per_launch": m["SQ_WAVE_CYCLES"],
+                    "lane_instructions_per_face_layer": round(lane / N3_tile, 1),
+                    "achieved_Tlane_instr_per_s": round(rate, 2), "peak_Tlane_instr_per_s": round(FP64_VALU_PEAK_TLANE_S, 2),
+                    "frac_of_fp64_vector_issue_peak": round(rate / FP64_VALU_PEAK_TLANE_S, 3),
+                    "averaged_over": "the step's three launches (the instantiations compiled for their switches, SPEC 1-3)",
+                    "occupancy": "2 wavefronts per SIMD (220-250 VGPRs)", "source": os.path.relpath(path, ROOT) + " @ " + git_hash_of(path)}
     return None
 
 
@@ -680,7 +706,7 @@ def measure_traffic_inrun(kernel, args):
         if r.returncode != 0:
             return None, "scripts/rocprof_summary.py failed: " + " | ".join((r.stderr or "").strip().splitlines()[-2:])[:300]
         j = json.load(open(os.path.join(tmp, "inrun_hbm_pmc.json")))
-        per = next((float(v) for n, v in j["traffic_bytes_per_launch"].items() if key(n) == key(kernel)), None)
+        per = _variants_mean(j["traffic_bytes_per_launch"], kernel, launches=j.get("launches_per_step"))
         return (per, round(j["bytes_per_step"] / 1e9, 1), ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one dynamics step, "
                                                           f"FETCH x{j['fetch_cal']:.3f}, WRITE x{j['write_cal']:.3f} (calibrated on {j.get('calibration_kernel')})")), None
     except Exception as e:   # noqa: BLE001  (a hung or missing profiler must not cost the benchmark line)
