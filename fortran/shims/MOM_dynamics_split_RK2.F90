@@ -194,6 +194,7 @@ subroutine refresh_host_mirrors(CS, G, GV)
   type(ocean_grid_type),   intent(in) :: G
   type(verticalGrid_type), intent(in) :: GV
   integer :: nk
+  type(c_ptr) :: pa, pb
   nk = GV%ke
   call shim_down2(CS%eta, mom6x_rk2_field(CS%ctx, F_ETA), STG_H)
   call shim_down3(CS%u_av, mom6x_rk2_field(CS%ctx, F_U_AV), STG_U, nk)
@@ -209,8 +210,15 @@ subroutine refresh_host_mirrors(CS, G, GV)
   if (CS%diag_mirrors) then   ! what Accel_diag and MIS point to (mom6x_rk2_field forms the deferred u_accel_bt, v_accel_bt on request)
     call shim_down3(CS%PFu, mom6x_rk2_field(CS%ctx, F_PFU), STG_U, nk) ; call shim_down3(CS%PFv, mom6x_rk2_field(CS%ctx, F_PFV), STG_V, nk)
     call shim_down3(CS%CAu, mom6x_rk2_field(CS%ctx, F_CAU), STG_U, nk) ; call shim_down3(CS%CAv, mom6x_rk2_field(CS%ctx, F_CAV), STG_V, nk)
-    call shim_down3(CS%u_accel_bt, mom6x_rk2_field(CS%ctx, F_U_ACCEL_BT), STG_U, nk)
-    call shim_down3(CS%v_accel_bt, mom6x_rk2_field(CS%ctx, F_V_ACCEL_BT), STG_V, nk)
+    ! (the layer accelerations are formed on request from what btstep left behind; a btstep called from outside in between
+    !  has replaced that, and the field comes back null: the mirrors then keep the last step's values)
+    pa = mom6x_rk2_field(CS%ctx, F_U_ACCEL_BT) ; pb = mom6x_rk2_field(CS%ctx, F_V_ACCEL_BT)
+    if (c_associated(pa) .and. c_associated(pb)) then
+      call shim_down3(CS%u_accel_bt, pa, STG_U, nk) ; call shim_down3(CS%v_accel_bt, pb, STG_V, nk)
+    else
+      call MOM_error(WARNING, "MOM_dynamics_split_RK2 (mom6x): u_accel_bt / v_accel_bt of the last step are gone "//&
+                     "(btstep has run since); Accel_diag%u_accel_bt keeps its previous values.")
+    endif
     call shim_down3(CS%pbce, mom6x_rk2_field(CS%ctx, F_PBCE), STG_H, nk)
   endif
 end subroutine refresh_host_mirrors

@@ -1687,7 +1687,12 @@ static int remap_velocities(mom6x_ctx *c, const mom6x_remapping_params *p, const
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   const size_t n3 = (size_t)d.slab * d.nk;
-  if (conserve_ke && !c->remap_src) HIPCHK(hipMalloc(&c->remap_src, n3 * sizeof(double)));   // the source column of the correction
+  // The source column of the correction: allocated by the FIRST call with REMAP_VEL_CONSERVE_KE (a synchronising hipMalloc, once per
+  // context; the entry point has no initialisation of its own), kept until the context goes.
+  // ORDER: the reference masks the near-bottom velocities (mask_near_bottom_vel, BBL_h_vel_mask / h_vel_mask; MOM_ALE.F90:1194-1200)
+  // AFTER the correction.  The device carries neither mask (both default to 0: nothing is masked); whoever adds them must apply them
+  // after k_remap_conserve_ke, not inside remap_field.
+  if (conserve_ke && !c->remap_src) HIPCHK(hipMalloc(&c->remap_src, n3 * sizeof(double)));
   const dim3 b(64, 4, 1);
   if (conserve_ke) HIPCHK(hipMemcpyAsync(c->remap_src, u, n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   int rc = remap_field(c, p, MOM6X_G_mask2dCu, -1, d.ni - 1, 0, d.nj - 1, h_old_u, h_new_u, u);

@@ -29,6 +29,7 @@ struct TAState {
   int nflux;
   int *dmu, *dmv, *limu, *limv, *dmk;   // [nk*nrows] row flags, "a flux was limited" marks, [nk] layer flags
   double *save; size_t save_cap;        // the old values beyond the tile / segment boundaries of the one-kernel passes
+  int stencil_all;                      // advect_tracer of more than MAXTR tracers: the stencil of the WHOLE registry (0: none in force)
 };
 
 struct TrList { double *t[MAXTR]; int scheme[MAXTR]; int n; };
@@ -728,13 +729,29 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
     // the remaining transports; a longer list is advected MAXTR at a time, each group through the whole iteration from the same
     // h_end, uhtr, vhtr: the evolution of hprev, uhr, vhr and of the row / layer flags does not depend on the tracers, so every
     // tracer gets the bits it would get in one pass (and the groups' leftover transports are identical).
-    int rc = MOM6X_OK;
+    // The stencil (:118-127) is the registry's, not a group's: a PLM-only group next to a PPM one must walk the same work ranges, halo
+    // cadence and iteration count as the single pass would (every group then does, and the iteration count is the same for all).
+    TAState *s0 = (TAState *)c->ta;
+    int st_all = 2;
+    for (int m = 0; m < ntr; m++) {
+      const int sch = (schemes && schemes[m] >= 0) ? schemes[m] : s0->default_scheme;
+      int sl = 2;
+      if (sch == ADVECT_PPM) sl = 3;
+      else if (sch == ADVECT_PPMH3) sl = s0->useHuynhStencilBug ? 2 : 3;
+      if (sl > st_all) st_all = sl;
+    }
+    int rc = MOM6X_OK, it_max = 0;
     for (int m0 = 0; m0 < ntr && rc == MOM6X_OK; m0 += MAXTR) {
       const int n = (ntr - m0 < MAXTR) ? (ntr - m0) : MAXTR;
       const bool last = (m0 + n >= ntr);
+      int it = 0;
+      s0->stencil_all = st_all;
       rc = mom6x_advect_tracer(c, h_end, uhtr, vhtr, dt, tracers + m0, schemes ? schemes + m0 : nullptr, n, x_first_in, max_iter_in,
-                               last ? uhr_out : nullptr, last ? vhr_out : nullptr, iters_out);
+                               last ? uhr_out : nullptr, last ? vhr_out : nullptr, &it);
+      s0->stencil_all = 0;
+      if (it > it_max) it_max = it;
     }
+    if (iters_out) *iters_out = it_max;
     return rc;
   }
   HIPCHK(hipSetDevice(c->device));
@@ -756,6 +773,7 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
     else if (Tr.scheme[m] == ADVECT_PPMH3) sl = s->useHuynhStencilBug ? 2 : 3;
     if (sl > stencil) stencil = sl;
   }
+  if (s->stencil_all > stencil) stencil = s->stencil_all;   // (one group of a longer registry: see above)
   REQUIRE(w >= stencil, MOM6X_EINVAL, "MOM_tracer_advect: stencil is wider than the halo.");
   // MOM6X_TRACER=legacy: the two-kernel passes that exchange uhh and the tracer fluxes through HBM
   const char *env = getenv("MOM6X_TRACER");
