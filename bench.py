@@ -429,6 +429,31 @@ def comm_model_leg(args, device):
         out[mode] = {"ms_per_step": round(ms, 3), "kernel_sum_ms": round(sum(v[1] for v in rep.values()), 3),
                      "launches_per_step": int(sum(v[0] for v in rep.values())), "exchanges_per_step": nex,
                      "sent_MB_per_step": round(nbytes / 1e6, 2)}
+        # ... and the headline's thermodynamic step on the tile (advect_tracer of T, S + 2 tracers with its per-iteration halo pass and the
+        # all-reduce of the layer flags, tracer_advect.F90:229-262, :331; the tridiagonal solves): once per nth dynamics steps, as in the
+        # headline.  Three cycles of nth steps + one thermodynamic step; its own time from a second, separately timed call.
+        nth = max(1, int(round(args.dt_therm / args.dt)))
+        a.tracers = max(args.tracers, 0); a.breakdown = False
+        thermo, _info = make_thermo(a, dyc, d, st, nth)
+        for _ in range(nth):
+            step()
+        thermo(); dyc.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for _ in range(nth):
+                step()
+            thermo()
+        dyc.sync(); torch.cuda.synchronize()
+        ms_cycle = 1e3 * (time.perf_counter() - t0) / 3.0
+        for _ in range(nth):
+            step()
+        dyc.sync(); torch.cuda.synchronize()
+        dyc.comm_exchange_count(reset=True)
+        t0 = time.perf_counter()
+        thermo(); dyc.sync(); torch.cuda.synchronize()
+        ms_th = 1e3 * (time.perf_counter() - t0)
+        out[mode].update({"ms_per_step_with_thermo": round(ms_cycle / nth, 3), "thermo_ms_per_call": round(ms_th, 3),
+                          "thermo_exchanges_per_call": dyc.comm_exchange_count()})
         torch.cuda.set_stream(torch.cuda.default_stream())
         dyc.close()
         del st, keep
@@ -461,6 +486,7 @@ def comm_model_leg(args, device):
         torch.cuda.empty_cache()
     out["tile"] = [args.ni // 4, args.nj // 2, args.nk]
     out["exposed_exchange_ms"] = round(out["rccl_self"]["ms_per_step"] - out["local_wrap"]["ms_per_step"], 3)
+    out["exposed_exchange_ms_with_thermo"] = round(out["rccl_self"]["ms_per_step_with_thermo"] - out["local_wrap"]["ms_per_step_with_thermo"], 3)
     out["exposed_exchange_frac_of_step"] = round(out["exposed_exchange_ms"] / out["rccl_self"]["ms_per_step"], 4)
     # (no "launch gap": the per-kernel events serialise the two streams and add their own cost, so wall time minus their sum came out
     #  NEGATIVE in round 3; the idle time of the compute stream is read from a kernel trace instead: profiles/r04_tile_*.txt)
