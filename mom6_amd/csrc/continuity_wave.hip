@@ -166,7 +166,7 @@ __device__ __forceinline__ double vel(const Col<MAXL, FMA> &C, int n, double du)
   return FMA ? fma(du, C.v[n], C.u[n]) : C.u[n] + du * C.v[n];
 }
 template <int MAXL, bool FMA>
-__device__ __forceinline__ void flux_reg(const Col<MAXL, FMA> &C, int n, double u, double &uh, double &duhdu) {
+__device__ __forceinline__ void flux_reg(const Col<MAXL, FMA> &C, int n, double u, double &uh, double &duhdu, double *h_marg_out = nullptr) {
   const bool pos = (u > 0.0);
   const double a = pos ? C.mR[n] : C.pL[n], b = pos ? C.mL[n] : C.pR[n], curv_3 = pos ? C.mC[n] : C.pC[n];
   const double CFL = fabs(u) * C.dt * (pos ? C.IdT_m : C.IdT_p);
@@ -176,6 +176,7 @@ __device__ __forceinline__ void flux_reg(const Col<MAXL, FMA> &C, int n, double 
   uh = moving ? uh_m : 0.0;
   const double h_marg = moving ? hm_m : 0.5 * (C.pL[n] + C.mR[n]);
   duhdu = C.Lf * h_marg * C.v[n];
+  if (h_marg_out) *h_marg_out = h_marg;
 }
 
 // The same for a wavefront whose layers ALL flow one way (SIDE = +1: from the minus cell, -1: from the plus cell): the upwind cell
@@ -528,6 +529,16 @@ __device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A
   // ---- first sweep: layer transports and their column sums (:615-668) -------------------------------------------
   auto store_uh = [&](int n, double uh, bool on) { if (on && (kl + KL * n < nk)) st3(A.uh, n, uh); };
   double uh_tot_0 = 0.0, duhdu_tot_0 = 0.0;
+  // The launch that sets BT_cont without a correction (SPEC 1) wants the marginal thickness at the UNCORRECTED velocity for BT_cont%h_u
+  // (zonal_flux_thickness :975): the very h_marg the first sweep forms.  Kept (5 doubles) instead of formed again.
+#ifdef MOM6X_MFW_NO_KEEP_HM   // (A/B)
+  constexpr bool KEEP_HM = false;
+#else
+  constexpr bool KEEP_HM = (SPEC == 1) && (MOM6X_MFW_ONEWAY_ALL != 1);
+#endif
+  double hm0[MAXL];
+#pragma unroll
+  for (int n = 0; n < MAXL; n++) hm0[n] = 0.0;
   int ow_row = 0;   // (MOM6X_MFW_ONEWAY_ALL) +1 / -1: every layer of the wavefront's four columns flows out of its minus / plus cell at du = 0
   auto first_sweep = [&]() {
     double s_uh = 0.0, s_dd = 0.0;
@@ -557,7 +568,7 @@ __device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A
 #pragma unroll
       for (int n = 0; n < MAXL; n++) {
         double uh, dd;
-        flux_reg(C, n, C.u[n], uh, dd);
+        flux_reg(C, n, C.u[n], uh, dd, KEEP_HM ? &hm0[n] : nullptr);
         C.uh[n] = uh;
         s_uh = s_uh + uh; s_dd = s_dd + dd;
         LAYER_FENCE(n);
@@ -618,6 +629,10 @@ __device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A
     double hf[MAXL];
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
+      if (KEEP_HM) {   // (no correction, marginal thickness, visc_rem: the switches of SPEC 1)
+        hf[n] = hm0[n] * (C.v[n] * 1.0);
+        continue;
+      }
       const double uf = use_cor ? (vel(C, n, du_fin)) : C.u[n];
       const bool pos = (uf > 0.0);
       const double a = pos ? C.mR[n] : C.pL[n], b = pos ? C.mL[n] : C.pR[n], curv_3 = pos ? C.mC[n] : C.pC[n];
