@@ -30,7 +30,10 @@
 
 namespace {
 
-constexpr int NF = 16;   // faces along i per work-group (4 wavefronts x 4 faces): one 128-byte line per row segment
+#ifndef MOM6X_MFW_NF   // (A/B: 8 = two wavefronts per work-group)
+#define MOM6X_MFW_NF 16
+#endif
+constexpr int NF = MOM6X_MFW_NF;   // faces along i per work-group (4 wavefronts x 4 faces): one 128-byte line per row segment
 constexpr int KL = 16;   // layer lanes per face = one DPP row
 
 // Dev tool (MOM6X_CFLAGS=-DMOM6X_MFL_TIMING python -m mom6_amd.build --force; scripts/prof_continuity.py): shader-clock
@@ -39,7 +42,7 @@ constexpr int KL = 16;   // layer lanes per face = one DPP row
 // (the first wavefront of a work-group adds its phase times to 16 words of LDS behind the wavefronts' regions -- ds_add_u64, nothing
 // returned, nothing waited for -- and to the global sums once, when its march ends)
 __device__ unsigned long long g_mfw_t[2][16];
-#define TICK_INIT long long t_prev_ = clock64(); unsigned long long *tk_ = (unsigned long long *)(S_all + 4 * (size_t)WAVE_LDS); \
+#define TICK_INIT long long t_prev_ = clock64(); unsigned long long *tk_ = (unsigned long long *)(S_all + (NF / 4) * (size_t)WAVE_LDS); \
   if (threadIdx.x < 16) tk_[threadIdx.x] = 0ull
 #define TICK(p) do { if (threadIdx.x == 0) { const long long t_ = clock64(); \
   __hip_atomic_fetch_add(&tk_[p], (unsigned long long)(t_ - t_prev_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); t_prev_ = t_; } } while (0)
@@ -431,12 +434,11 @@ __device__ __forceinline__ void glds16(const double *src, double *lds_wave_base)
 
 // Everything of one face column after the reconstruction: first sweep, flux_adjust towards uhbt, stores, flux
 // thickness, set_*_BT_cont.  All lanes of the wavefront call it (row reductions inside).
-template <int DIR, int MAXL, bool STATS, int SPEC, bool FMA, typename DmaPart>
+template <int DIR, int MAXL, bool STATS, int SPEC, bool FMA>
 __device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A, const LdsArgs &E, size_t rowb, unsigned lane2,
                                             unsigned lane3, size_t slab, bool active, int kl, int nk, double IareaMin,
                                             double uhbt_f, double dC_f, double dx_W_in, double dx_E_in, const double *G,
-                                            int pitch, unsigned &evals, unsigned &solves, unsigned &redos, DmaPart dma_part,
-                                            bool pairs, unsigned lanep, int fw TICK_PARAM) {
+                                            int pitch, unsigned &evals, unsigned &solves, unsigned &redos, bool pairs, unsigned lanep, int fw TICK_PARAM) {
   // Addresses: (uniform base pointer + uniform byte offset) + a 32-bit per-lane byte offset that never changes
   // (lane2: the face's column in a row; lane3: + the lane's first layer) -- the scalar-base addressing mode, one
   // register per lane instead of a 64-bit address per store that the compiler would keep alive across the march.
@@ -578,7 +580,6 @@ __device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A
   };
   first_sweep();
   TICK(2);
-  dma_part(1);   // (the next row's layers 32..63)
 
   // ---- flux_adjust towards uhbt; uh, u_cor, du_cor ---------------------------------------------------------------
   double du_fin = 0.0;
@@ -609,7 +610,7 @@ __device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A
 #pragma unroll
     for (int n = 0; n < MAXL; n++) store_uh(n, C.uh[n], active);
   TICK(3);
-  dma_part(2);   // (the next row's layers 64..)
+
   if (corrected && W.has_ucor) {
     if (pairs) {
       double uc[MAXL];
@@ -804,11 +805,6 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   // This wavefront's region: NS3 slots of KP = 16 * MAXL layers (a compile-time stride: every LDS address of a lane is
   // ONE base register + an immediate), then the 2-D segments.
   constexpr int KP = KL * MAXL;
-#ifdef MOM6X_MFW_SHARE   // (experiment of round 5, slower: profiles/r05_mfw.md)
-  constexpr bool SHARE = (DIR == 0);
-#else
-  constexpr bool SHARE = false;
-#endif
   constexpr int WAVE_LDS = SEG * (ST::NS3 * KP + 16);   // doubles (NL2 <= 16)
   double *S = S_all + (size_t)w * WAVE_LDS;
   double *S2 = S + (size_t)ST::NS3 * KP * SEG;
@@ -826,11 +822,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   // DIR = 1: the five h slots are a RING over the rows of the march: row r lives in slot (r + 10) % 5, and a step
   // only fetches the one row that is new to it (jj + 3, into the slot row jj - 2 has just left); `all_rows`: the first
   // step of a chunk fills the ring.
-  // `part`: -1 everything; 0 / 1 / 2: the layers 0..31 (and the 2-D segments) / 32..63 / 64.. of every slot.  A row's requests
-  // (17 wavefront instructions of 1 KB for a zonal row of 75 layers) issued in one burst by the four wavefronts that have just met
-  // at the barrier wait for each other at the CU's one address unit (~11 B per cycle: MI355X_MICROARCH.md): the burst cost a
-  // wavefront 15 % of its time (profiles/r05_mfw.md).  In three parts between the phases of face_column they find the queue empty.
-  auto issue_dma = [&](int jj, bool all_rows, int part) {
+  auto issue_dma = [&](int jj, bool all_rows) {
     const size_t row0 = ((size_t)(i0 + d.ioff) + (size_t)(jj + d.joff) * (size_t)d.pitch) * 8;   // (i0, jj) in a plane, bytes
 #pragma unroll
     for (int s = 0; s < ST::NS3; s++) {
@@ -846,12 +838,10 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
       // DIR = 0, s = 0: of the segment i0-4 .. i0-1 only the second 16-byte piece (cells i0-2, i0-1) is in anybody's stencil
       const bool piece_on = DIR || s != 0 || pp == 1;
       for (int r = 0; r * 32 < nk; r++) {
-        if (part >= 0 && (r < 2 ? r : 2) != part) continue;
         if (piece_on && r * 32 + sg < nk)
           glds16((const double *)(base + (size_t)r * 32 * slab * 8 + dma3), S + (size_t)(slot * KP + r * 32) * SEG);
       }
     }
-    if (part > 0) return;
     const char *g2 = (const char *)G + ((size_t)i0 + (size_t)jj * (size_t)d.pitch) * 8;
     if (do2) glds16((const double *)(g2 + dma2), S2);
     if (do_uhbt) glds16((const double *)((const char *)A.uhbt + row0 + pp * 16), S2);   // (lane-linear: segment 9 again)
@@ -889,7 +879,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   unsigned st_evals = 0, st_solves = 0, st_redos = 0;   // wavefront-uniform counts over the march (mom6x_continuity_stats)
 
   const int jstart = DIR ? j0 - 1 : j0;   // meridional: a first step that only reconstructs cell j0
-  if (wave_on) issue_dma(jstart, true, -1);
+  if (wave_on) issue_dma(jstart, true);
   for (int jj = jstart; jj <= j1; jj++) {
     // The four wavefronts of a work-group share nothing but cache lines: a 128-byte line of h, u, visc_rem or of an output
     // holds the 32 bytes of each of them.  Left alone they drift rows apart (their Newton counts differ), every wavefront
@@ -902,89 +892,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     const bool face_row = (!DIR) || (jj >= j0);
     // ---- LDS -> registers, layer by layer, with the PPM reconstruction + limiter on the way ---------------------------
     double IareaMin, uhbt_f, dC_f, dx_W, dx_E;
-    if (SHARE) {
-      // Zonal: a face's plus cell is the minus cell of the next face.  Every lane reconstructs ITS OWN minus cell only; the fifth
-      // cell of the wavefront's four faces (i0 + 4) is reconstructed with the 64 lanes spread over the layers (two passes for 65..128
-      // layers instead of one per slot); the triples then change lanes through the wavefront's own LDS region -- the three h slots,
-      // which nobody reads any more (7 instead of 10 reconstructions per lane and row; LDS instructions run beside the VALU's).
-      const bool cell_act = active || (fw > 0 && i - 1 >= pa0 && i - 1 <= pa1);   // the cell is somebody's minus or plus cell
-      double m5[5];
-#pragma unroll
-      for (int q = 0; q < 5; q++) {
-        const double mv = L[10 * SEG + SEG - 2 + q];
-        m5[q] = cell_act ? mv : 0.0;
-      }
-#pragma unroll
-      for (int n = 0; n < MAXL; n++) {
-        const bool on = active && (kl + KL * n < nk), con = cell_act && (kl + KL * n < nk);
-        double hst[5];
-#pragma unroll
-        for (int q = 0; q < 5; q++) {
-          const double hv = Sb[xo[q] + n * KL * SEG];
-          hst[q] = con ? hv : 0.0;
-        }
-        const double uu = Sb[(ST::SU * KP + n * KL) * SEG];
-        const double vv = use_visc_rem ? Sb[(ST::SV * KP + n * KL) * SEG] : 1.0;
-        C.u[n] = on ? uu : 0.0;
-        C.v[n] = on ? vv : 0.0;
-        double hl = 0.0, hr = 0.0, c3 = 0.0;
-        if (con) edge5<FMA>(&hst[0], &m5[0], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
-        C.mL[n] = hl; C.mR[n] = hr; C.mC[n] = c3;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      constexpr int NP = (KP + 63) / 64;
-      double xl[NP], xr[NP], xc[NP];
-      {
-        const bool x_act = (i0 + 3 >= pa0 && i0 + 3 <= pa1);   // (uniform) the cell i0 + 4 is the plus cell of an active face
-        double mx[5];
-#pragma unroll
-        for (int q = 0; q < 5; q++) mx[q] = S2[10 * SEG + 6 + q];   // cells c = 6 .. 10 of the twelve (i0 - 4 + c)
-#pragma unroll
-        for (int pss = 0; pss < NP; pss++) {
-          const int k = lane + 64 * pss, kr = (k < KP) ? k : KP - 1;
-          const bool xon = x_act && (k < nk);
-          double hx[5];
-#pragma unroll
-          for (int q = 0; q < 5; q++) {
-            const int cc = 6 + q;
-            const double hv = S[((cc >> 2) * KP + kr) * SEG + (cc & 3)];
-            hx[q] = xon ? hv : 0.0;
-          }
-          double hl = 0.0, hr = 0.0, c3 = 0.0;
-          if (xon) edge5<FMA>(&hx[0], &mx[0], W.scheme, W.monotonic, E.h_min, hl, hr, c3);
-          xl[pss] = hl; xr[pss] = hr; xc[pss] = c3;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // the triples of the cells i0 + 1 .. i0 + 4 in three planes [4][KP] over the h slots (all reads of h are issued: a wavefront's
-      // LDS instructions execute in order)
-      asm volatile("" ::: "memory");
-      double *TL = S, *TR = S + 4 * KP, *TC = S + 8 * KP;
-      if (fw > 0) {
-#pragma unroll
-        for (int n = 0; n < MAXL; n++) {
-          const int t = (fw - 1) * KP + kl + KL * n;
-          TL[t] = C.mL[n]; TR[t] = C.mR[n]; TC[t] = C.mC[n];
-        }
-      }
-#pragma unroll
-      for (int pss = 0; pss < NP; pss++) {
-        const int k = lane + 64 * pss;
-        if (k < KP) { TL[3 * KP + k] = xl[pss]; TR[3 * KP + k] = xr[pss]; TC[3 * KP + k] = xc[pss]; }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int n = 0; n < MAXL; n++) {
-        const int t = fw * KP + kl + KL * n;
-        C.pL[n] = TL[t]; C.pR[n] = TR[t]; C.pC[n] = TC[t];
-      }
-      C.IdT_m = L[0]; C.IdT_p = L[1];
-      C.Lf = L[2 * SEG] * 1.0;   // G%dy_Cu * por_face_areaU (== 1)
-      IareaMin = dmin(L[3 * SEG], L[3 * SEG + 1]);
-      dx_W = L[5 * SEG]; dx_E = L[5 * SEG + 1];
-      dC_f = W.set_bt ? L[7 * SEG] : 0.0;
-      uhbt_f = (W.corrected && active) ? L[9 * SEG] : 0.0;
-    } else {
+    {
       int ring[5];   // DIR = 1: where the rows jj-1 .. jj+3 are in the ring of h slots (uniform)
 #pragma unroll
       for (int q = 0; q < 5; q++) ring[q] = ((jj + q + 9) % 5) * KP * SEG;
@@ -1031,19 +939,12 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // row jj is in registers: its space is free ...
     TICK(11);
-#ifdef MOM6X_MFW_DMA_SPLIT   // (experiment of round 5, no gain: profiles/r05_mfw.md)
-    constexpr bool SPLIT = true;
-#else
-    constexpr bool SPLIT = false;
-#endif
-    const bool more = (jj < j1);
-    if (more) issue_dma(jj + 1, false, (SPLIT && face_row) ? 0 : -1);   // ... and fills while this row's Newton solves run
+    if (jj < j1) issue_dma(jj + 1, false);                     // ... and fills while this row's Newton solves run
     if (!face_row) continue;
     TICK(12);
-    auto dma_part = [&](int part) { if (SPLIT && more) issue_dma(jj + 1, false, part); };
     const size_t rowb = (size_t)(jj + d.joff) * (size_t)d.pitch * 8;
     face_column<DIR, MAXL, STATS, SPEC>(C, A, E, rowb, lane2, lane3, slab, active, kl, nk, IareaMin, uhbt_f, dC_f, dx_W, dx_E, G, d.pitch, st_evals,
-                           st_solves, st_redos, dma_part, pairs, lanep, fw TICK_ARG);
+                           st_solves, st_redos, pairs, lanep, fw TICK_ARG);
     TICK(13);
   }
   TICK_FLUSH;
@@ -1064,9 +965,9 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   const bool stats = (c->cont_stats != nullptr) && c->cont_stats_on && !E.fma;
   E.stats = stats ? c->cont_stats : nullptr;
 #ifdef MOM6X_MFL_TIMING
-  const size_t lds_bytes = sizeof(double) * 4 * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16)) + 128;   // + the phase times
+  const size_t lds_bytes = sizeof(double) * (NF / 4) * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16)) + 128;   // + the phase times
 #else
-  const size_t lds_bytes = sizeof(double) * 4 * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16));   // 4 x the kernel's WAVE_LDS
+  const size_t lds_bytes = sizeof(double) * (NF / 4) * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16));   // 4 x the kernel's WAVE_LDS
 #endif
   // The launches of an RK2 step with the reference's defaults run the kernel compiled for their switches (struct Sw); the Newton
   // statistics and everything else the general one.  MOM6X_MFW_SPEC=0 (tests/test_switches_gpu.py): always the general one.
