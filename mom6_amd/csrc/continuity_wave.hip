@@ -33,11 +33,6 @@ namespace {
 #ifndef MOM6X_MFW_NF   // (A/B: 8 = two wavefronts per work-group)
 #define MOM6X_MFW_NF 16
 #endif
-#ifdef MOM6X_MFW_NO_WGSTAGE
-#define WGS_HOST(dir) false
-#else
-#define WGS_HOST(dir) ((dir) == 0 && MOM6X_MFW_NF == 16)
-#endif
 constexpr int NF = MOM6X_MFW_NF;   // faces along i per work-group (4 wavefronts x 4 faces): one 128-byte line per row segment
 constexpr int KL = 16;   // layer lanes per face = one DPP row
 
@@ -47,7 +42,7 @@ constexpr int KL = 16;   // layer lanes per face = one DPP row
 // (the first wavefront of a work-group adds its phase times to 16 words of LDS behind the wavefronts' regions -- ds_add_u64, nothing
 // returned, nothing waited for -- and to the global sums once, when its march ends)
 __device__ unsigned long long g_mfw_t[2][16];
-#define TICK_INIT long long t_prev_ = clock64(); unsigned long long *tk_ = (unsigned long long *)(S_all + (size_t)LDS_END); \
+#define TICK_INIT long long t_prev_ = clock64(); unsigned long long *tk_ = (unsigned long long *)(S_all + (NF / 4) * (size_t)WAVE_LDS); \
   if (threadIdx.x < 16) tk_[threadIdx.x] = 0ull
 #define TICK(p) do { if (threadIdx.x == 0) { const long long t_ = clock64(); \
   __hip_atomic_fetch_add(&tk_[p], (unsigned long long)(t_ - t_prev_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); t_prev_ = t_; } } while (0)
@@ -811,28 +806,8 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   // ONE base register + an immediate), then the 2-D segments.
   constexpr int KP = KL * MAXL;
   constexpr int WAVE_LDS = SEG * (ST::NS3 * KP + 16);   // doubles (NL2 <= 16)
-  // Zonal (round 5): the 3-D inputs of a row are staged for the WORK-GROUP, in whole 128-byte lines.  A line of h, u or visc_rem
-  // holds the 16 faces of the four wavefronts; staged per wavefront, every line was asked for four times (32 bytes each) by 17
-  // wavefront instructions per row, and a wavefront pays ~300 cycles per vector-memory instruction (profiles/r05_mfw.md).  Here ONE
-  // instruction fetches 8 layers x 128 bytes (64 lanes x 16 bytes; the wavefronts take the instructions of a row in turn): 35
-  // instead of 60 per work-group and row.  LDS-DMA writes lane-linearly, so a line's eight 16-byte pieces would lie side by side
-  // and a wavefront's read of 16 consecutive layers of one column (stride 128 bytes) would hit two bank groups 8 times over; the
-  // pieces are therefore swizzled on the SOURCE side: position (k, s) of the image holds piece s ^ ((k >> 1) & 7) of line k.
-  // The two cells west and three east of the line (the PPM stencils of the first and last faces) come as 16-byte pieces into two
-  // small arrays.  Two buffers: a row is fetched into one while the other is read -- one barrier per row as before (each
-  // wavefront waits for its own requests, then all meet).  Per buffer: H [KP][16] | U [KP][16] | V [KP][16] | SL [KP][2] | SR [KP][4].
-#ifdef MOM6X_MFW_NO_WGSTAGE   // (A/B: the per-wavefront staging of rounds 2-4)
-  constexpr bool WGS = false;
-#else
-  constexpr bool WGS = (DIR == 0) && (NF == 16);
-#endif
-  constexpr int W2D = SEG * 16;                        // the 2-D segments of a wavefront (both forms)
-  constexpr int BUF = KP * 54;                         // doubles per buffer of the work-group form
-  constexpr int LDS_END = WGS ? (4 * W2D + 2 * BUF) : (NF / 4) * WAVE_LDS;
-  double *S = S_all + (size_t)w * WAVE_LDS;            // (per-wavefront form)
-  double *S2 = WGS ? (S_all + (size_t)w * W2D) : (S + (size_t)ST::NS3 * KP * SEG);
-  double *SB = S_all + 4 * W2D;                        // (work-group form) the two buffers
-  (void)LDS_END;
+  double *S = S_all + (size_t)w * WAVE_LDS;
+  double *S2 = S + (size_t)ST::NS3 * KP * SEG;
   TICK_INIT;
 
   // ---- DMA roles: lane = (segment sg of a round of 32, 16-byte piece pp) ----------------------------------------------
@@ -844,39 +819,6 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
                                     (ptrdiff_t)L2.dcol * SEG + d.ioff + pp * 2) * 8);   // from G; >= 0: dj + joff >= 0, dcol*SEG + ioff >= 0
   const bool do2 = (sg < ST::NL2) && (L2.plane >= 0);
   const bool do_uhbt = (sg == 9) && W.corrected;
-  // (work-group form) lane = (line kk of 8, image position sp of 8): the piece it fetches, for even / odd instructions (8 m .. 8 m + 7)
-  const int kk8 = lane >> 3, sp8 = lane & 7;
-  const unsigned wg_e = (unsigned)((size_t)kk8 * slab * 8 + (size_t)((sp8 ^ (kk8 >> 1)) * 16));
-  const int ib = E.pib[pt] + bx * NF;                  // the work-group's first face
-  auto issue_wg = [&](int jj, int bsel) {
-    const size_t rowb0 = ((size_t)(ib + d.ioff) + (size_t)(jj + d.joff) * (size_t)d.pitch) * 8;
-    const int nk8 = (nk + 7) >> 3, nsl = (nk + 63) >> 6, nsr = (nk + 31) >> 5;
-    const int narr = use_visc_rem ? 3 : 2;
-    const int nt = narr * nk8 + nsl + nsr;
-    double *B = SB + (size_t)bsel * BUF;
-    for (int t = w; t < nt; t += 4) {
-      if (t < narr * nk8) {
-        const int as = t / nk8, m = t - as * nk8;
-        const char *arr = (const char *)(as == 0 ? A.h_in : (as == 1 ? A.u : A.visc_rem));
-        if (8 * m + kk8 < nk)
-          glds16((const double *)(arr + (size_t)(8 * m) * slab * 8 + rowb0 + ((m & 1) ? (wg_e ^ 64u) : wg_e)), B + (size_t)as * 16 * KP + (size_t)m * 128);
-      } else if (t < narr * nk8 + nsl) {
-        const int tt = t - narr * nk8;
-        if (64 * tt + lane < nk)
-          glds16((const double *)((const char *)A.h_in + (size_t)(64 * tt) * slab * 8 + rowb0 - 16 + (unsigned)((size_t)lane * slab * 8)), B + (size_t)48 * KP + (size_t)tt * 128);
-      } else {
-        const int tt = t - narr * nk8 - nsl;
-        if (32 * tt + sg < nk)
-          glds16((const double *)((const char *)A.h_in + (size_t)(32 * tt) * slab * 8 + rowb0 + 128 + dma3), B + (size_t)50 * KP + (size_t)tt * 128);
-      }
-    }
-  };
-  auto issue_2d = [&](int jj) {
-    const size_t row0 = ((size_t)(i0 + d.ioff) + (size_t)(jj + d.joff) * (size_t)d.pitch) * 8;
-    const char *g2 = (const char *)G + ((size_t)i0 + (size_t)jj * (size_t)d.pitch) * 8;
-    if (do2) glds16((const double *)(g2 + dma2), S2);
-    if (do_uhbt) glds16((const double *)((const char *)A.uhbt + row0 + pp * 16), S2);
-  };
   // DIR = 1: the five h slots are a RING over the rows of the march: row r lives in slot (r + 10) % 5, and a step
   // only fetches the one row that is new to it (jj + 3, into the slot row jj - 2 has just left); `all_rows`: the first
   // step of a chunk fills the ring.
@@ -917,19 +859,6 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     const int c = SEG + fw - 2 + q;
     xo[q] = (c >> 2) * KP * SEG + (c & 3) - fw;
   }
-  // (work-group form) cell c = 4 w + fw + q - 2 of the 21 cells ib-2 .. ib+18; layer n adds n << hs[q] doubles
-  int ho[6], hs[6];
-  {
-    const int kx = (kl >> 1) & 7;
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
-      const int c = 4 * w + fw + q - 2;
-      if (c < 0)       { ho[q] = 48 * KP + kl * 2 + (c + 2); hs[q] = 5; }
-      else if (c > 15) { ho[q] = 50 * KP + kl * 4 + (c - 16); hs[q] = 6; }
-      else             { ho[q] = kl * 16 + ((((c >> 1) ^ kx)) << 1) + (c & 1); hs[q] = 8; }
-    }
-  }
-  const int uo = ho[2];   // (q = 2 is the face's own column, 4 w + fw: always in the line)
   // per-lane byte offsets of the stores (see face_column)
   const unsigned lane2 = (unsigned)((size_t)((active ? i : pa1) + d.ioff) * 8);   // inactive lanes alias the last face (never written)
   const unsigned lane3 = lane2 + (unsigned)((size_t)kl * slab * 8);
@@ -950,21 +879,16 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   unsigned st_evals = 0, st_solves = 0, st_redos = 0;   // wavefront-uniform counts over the march (mom6x_continuity_stats)
 
   const int jstart = DIR ? j0 - 1 : j0;   // meridional: a first step that only reconstructs cell j0
-  if (WGS) { issue_wg(jstart, 0); if (wave_on) issue_2d(jstart); }
-  else if (wave_on) issue_dma(jstart, true);
+  if (wave_on) issue_dma(jstart, true);
   for (int jj = jstart; jj <= j1; jj++) {
-    const int bsel = (jj - jstart) & 1;
-    if (WGS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's share of row jj has landed ... (then all meet)
     // The four wavefronts of a work-group share nothing but cache lines: a 128-byte line of h, u, visc_rem or of an output
     // holds the 32 bytes of each of them.  Left alone they drift rows apart (their Newton counts differ), every wavefront
     // then fetches the line for itself and the partial lines they store reach memory one by one.  Meeting once per row
     // keeps the four requests within the L2's reach: plain / adjust modes 2.0 -> 1.5 / 2.6 -> 2.25 ms (x).
     __syncthreads();
-    if (WGS && jj < j1) issue_wg(jj + 1, bsel ^ 1);    // (every wavefront, with or without faces: the other buffer was read a row ago)
     if (!wave_on) continue;
-    if (!WGS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row jj has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row jj has landed
     TICK(10);
-    const double *Bc = SB + (size_t)bsel * BUF;
     const bool face_row = (!DIR) || (jj >= j0);
     // ---- LDS -> registers, layer by layer, with the PPM reconstruction + limiter on the way ---------------------------
     double IareaMin, uhbt_f, dC_f, dx_W, dx_E;
@@ -984,11 +908,11 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
         double hst[6];
 #pragma unroll
         for (int q = 0; q < NH; q++) {
-          const double hv = DIR ? Sb[ring[q] + n * KL * SEG] : (WGS ? Bc[ho[q] + (n << hs[q])] : Sb[xo[q] + n * KL * SEG]);
+          const double hv = DIR ? Sb[ring[q] + n * KL * SEG] : Sb[xo[q] + n * KL * SEG];
           hst[q] = on ? hv : 0.0;
         }
-        const double uu = WGS ? Bc[16 * KP + uo + n * 256] : Sb[(ST::SU * KP + n * KL) * SEG];
-        const double vv = use_visc_rem ? (WGS ? Bc[32 * KP + uo + n * 256] : Sb[(ST::SV * KP + n * KL) * SEG]) : 1.0;
+        const double uu = Sb[(ST::SU * KP + n * KL) * SEG];
+        const double vv = use_visc_rem ? Sb[(ST::SV * KP + n * KL) * SEG] : 1.0;
         C.u[n] = on ? uu : 0.0;
         C.v[n] = on ? vv : 0.0;
         double hl = 0.0, hr = 0.0, c3 = 0.0;
@@ -1015,7 +939,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // row jj is in registers: its space is free ...
     TICK(11);
-    if (jj < j1) { if (WGS) issue_2d(jj + 1); else issue_dma(jj + 1, false); }   // ... and fills while this row's Newton solves run
+    if (jj < j1) issue_dma(jj + 1, false);                     // ... and fills while this row's Newton solves run
     if (!face_row) continue;
     TICK(12);
     const size_t rowb = (size_t)(jj + d.joff) * (size_t)d.pitch * 8;
@@ -1041,9 +965,9 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   const bool stats = (c->cont_stats != nullptr) && c->cont_stats_on && !E.fma;
   E.stats = stats ? c->cont_stats : nullptr;
 #ifdef MOM6X_MFL_TIMING
-  const size_t lds_bytes = sizeof(double) * (WGS_HOST(DIR) ? (size_t)(4 * SEG * 16 + 2 * KL * MAXL * 54) : (NF / 4) * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16))) + 128;   // + the phase times
+  const size_t lds_bytes = sizeof(double) * (NF / 4) * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16)) + 128;   // + the phase times
 #else
-  const size_t lds_bytes = sizeof(double) * (WGS_HOST(DIR) ? (size_t)(4 * SEG * 16 + 2 * KL * MAXL * 54) : (NF / 4) * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16)));   // the kernel's LDS_END
+  const size_t lds_bytes = sizeof(double) * (NF / 4) * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16));   // 4 x the kernel's WAVE_LDS
 #endif
   // The launches of an RK2 step with the reference's defaults run the kernel compiled for their switches (struct Sw); the Newton
   // statistics and everything else the general one.  MOM6X_MFW_SPEC=0 (tests/test_switches_gpu.py): always the general one.
