@@ -343,6 +343,33 @@ __global__ void k_btcont_copy(Dm d, mom6x_BT_cont BT, double *tmp) {
     tmp[9 * slab + c] = BT.FA_v_N0[c]; tmp[10 * slab + c] = BT.FA_v_S0[c]; tmp[11 * slab + c] = BT.FA_v_SS[c];
   }
 }
+// USE_BT_CONT_TYPE = False: the transports are Datu * ubt (+ uhbt0) with the face areas of find_face_areas :5146-5237 (its last
+// branch: NONLINEAR_BT_CONTINUITY = False, from the bathymetry; halo = 1, :1135).  They go through the SAME fit planes: with all four
+// face areas of a fit = Datu, no curvature and break points at -/+ 1e100, find_uhbt(u) is u * (Datu + 0 * (u * u)) = Datu * u in
+// every bit (0 * u^2 is 0, Datu + 0 is Datu, the product commutes).  The halo update that follows is the reference's pass_Dat_uv.
+__global__ void k_face_areas_as_fits(Dm d, const double *__restrict__ G, double Z_ref, double Z_to_H, double *tmp) {
+  const int i = -2 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = -2 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > d.ni || j > d.nj) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double *bathyT = gm(G, d, MOM6X_G_bathyT);
+  const double H1 = (bathyT[c] + Z_ref) * Z_to_H;
+  if (j >= -1) {   // Datu on (is-2 .. ie+1, js-1 .. je+1)
+    const double H2 = (bathyT[c + 1] + Z_ref) * Z_to_H;
+    double Dat = 0.0;
+    if ((H1 > 0.0) && (H2 > 0.0)) Dat = gm(G, d, MOM6X_G_dy_Cu)[c] * (2.0 * H1 * H2) / (H1 + H2);
+    tmp[0 * slab + c] = -1.0e100; tmp[1 * slab + c] = 1.0e100;
+    tmp[2 * slab + c] = Dat; tmp[3 * slab + c] = Dat; tmp[4 * slab + c] = Dat; tmp[5 * slab + c] = Dat;
+  }
+  if (i >= -1) {   // Datv on (is-1 .. ie+1, js-2 .. je+1)
+    const double H2 = (bathyT[c + st] + Z_ref) * Z_to_H;
+    double Dat = 0.0;
+    if ((H1 > 0.0) && (H2 > 0.0)) Dat = gm(G, d, MOM6X_G_dx_Cv)[c] * (2.0 * H1 * H2) / (H1 + H2);
+    tmp[6 * slab + c] = -1.0e100; tmp[7 * slab + c] = 1.0e100;
+    tmp[8 * slab + c] = Dat; tmp[9 * slab + c] = Dat; tmp[10 * slab + c] = Dat; tmp[11 * slab + c] = Dat;
+  }
+}
 // step 2 (after the halo update): the cubic-fit parameters as SoA planes
 __global__ void k_btcl(Dm d, const double *__restrict__ tmp, double *Bu, double *Bv, int hs) {
   const int i = -hs - 1 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -1061,7 +1088,9 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
                             const double *uh0, const double *vh0, const double *u_uh0, const double *v_vh0,
                             double *etaav) {
   REQUIRE(c && c->bt_init, MOM6X_EINVAL, "btstep: Module MOM_barotropic must be initialized before it is used.");
-  REQUIRE(BT_cont, MOM6X_EUNSUPPORTED, "btstep: only USE_BT_CONT_TYPE=True (BT_cont associated) is supported");
+  // BT_cont == NULL: USE_BT_CONT_TYPE = False with NONLINEAR_BT_CONTINUITY = False (k_face_areas_as_fits); BOUND_BT_CORRECTION would
+  // then need eta_cor_bound (:6166-6173), which is not carried
+  REQUIRE(BT_cont || !c->bt.bound_BT_corr, MOM6X_EUNSUPPORTED, "btstep: BOUND_BT_CORRECTION without a BT_cont_type is not supported");
   REQUIRE(U_in && V_in && eta_in && bc_accel_u && bc_accel_v && taux && tauy && pbce && eta_PF_in && U_Cor && V_Cor &&
           accel_layer_u && accel_layer_v && eta_out && uhbtav && vhbtav && visc_rem_u && visc_rem_v,
           MOM6X_EINVAL, "btstep: null mandatory array");
@@ -1123,7 +1152,8 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
 
   // ---- BT_cont fits (set_local_BT_cont_types, halo = 1+ievf-ie)
   double *tmp = work + W_BTtmp * slab;
-  KLAUNCH(c, "k_btcont_copy", k_btcont_copy, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, *BT_cont, tmp);
+  if (BT_cont) KLAUNCH(c, "k_btcont_copy", k_btcont_copy, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, *BT_cont, tmp);
+  else KLAUNCH(c, "k_face_areas_as_fits", k_face_areas_as_fits, grid3(d.ni + 3, d.nj + 3, 1, b), b, d, c->G, P.Z_ref, c->GV.Z_to_H, tmp);
   {
     // the twelve BT_cont planes (set_local_BT_cont_types :4876, halo = 1+ievf-ie) and, in the same packed message, what the column
     // pass has made and btstep passes next (:1421-1431: gtot_*, ubt_Cor, vbt_Cor -- no kernel between the two reads the other's halos)

@@ -183,13 +183,14 @@ class Dycore:
     def btstep(self, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, pbce, eta_PF_in, U_Cor, V_Cor,
                accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v, BT_cont,
                taux_bot=None, tauy_bot=None, uh0=None, vh0=None, u_uh0=None, v_vh0=None, etaav=None):
-        """btstep (MOM_barotropic.F90:455); forces%taux/tauy are passed as planes."""
+        """btstep (MOM_barotropic.F90:455); forces%taux/tauy are passed as planes.  BT_cont = None: USE_BT_CONT_TYPE = False (the
+        barotropic continuity equation linear in the velocities, with the face areas of find_face_areas)."""
         check(self.lib, self.lib.mom6x_btstep(
             self.ctx, _ptr(U_in), _ptr(V_in), _ptr(eta_in), C.c_double(dt), _ptr(bc_accel_u), _ptr(bc_accel_v),
             _ptr(taux), _ptr(tauy), _ptr(pbce), _ptr(eta_PF_in), _ptr(U_Cor), _ptr(V_Cor), _ptr(accel_layer_u),
             _ptr(accel_layer_v), _ptr(eta_out), _ptr(uhbtav), _ptr(vhbtav), _ptr(visc_rem_u), _ptr(visc_rem_v),
-            C.byref(BT_cont.struct), _ptr(taux_bot), _ptr(tauy_bot), _ptr(uh0), _ptr(vh0), _ptr(u_uh0), _ptr(v_vh0),
-            _ptr(etaav)))
+            C.byref(BT_cont.struct) if BT_cont is not None else None, _ptr(taux_bot), _ptr(tauy_bot), _ptr(uh0), _ptr(vh0), _ptr(u_uh0),
+            _ptr(v_vh0), _ptr(etaav)))
 
     # -- MOM_CoriolisAdv ---------------------------------------------------------------------
     def CoriolisAdv_init(self, params=None):

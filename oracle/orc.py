@@ -138,13 +138,13 @@ def set_dtbt(d, G, GV, P, cs, pbce=None, gtot_est=0.0, SSH_add=0.0):
 def btstep(d, G, GV, P, cs, first_direction, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, pbce,
            eta_PF_in, U_Cor, V_Cor, accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v,
            BT_cont, taux_bot=None, tauy_bot=None, uh0=None, vh0=None, u_uh0=None, v_vh0=None, etaav=None):
-    bts = bt_cont_struct(BT_cont)
+    bts = bt_cont_struct(BT_cont) if BT_cont is not None else None   # None: USE_BT_CONT_TYPE = False (linear barotropic continuity)
     nstep = C.c_int(0)
     rc = lib().orc_btstep(C.byref(d), _p(G), C.byref(GV), C.byref(P), C.byref(cs.struct), C.c_int(first_direction),
                           _p(U_in), _p(V_in), _p(eta_in), C.c_double(dt), _p(bc_accel_u), _p(bc_accel_v),
                           _p(taux), _p(tauy), _p(pbce), _p(eta_PF_in), _p(U_Cor), _p(V_Cor),
                           _p(accel_layer_u), _p(accel_layer_v), _p(eta_out), _p(uhbtav), _p(vhbtav),
-                          _p(visc_rem_u), _p(visc_rem_v), C.byref(bts), _p(taux_bot), _p(tauy_bot),
+                          _p(visc_rem_u), _p(visc_rem_v), C.byref(bts) if bts is not None else None, _p(taux_bot), _p(tauy_bot),
                           _p(uh0), _p(vh0), _p(u_uh0), _p(v_vh0), _p(etaav), C.byref(nstep))
     if rc != 0:
         raise RuntimeError(f"orc_btstep rc={rc}")

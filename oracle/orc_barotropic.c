@@ -309,7 +309,11 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
                const double *taux_bot, const double *tauy_bot,
                const double *uh0, const double *vh0, const double *u_uh0, const double *v_vh0,
                double *etaav, int *nstep_out) {
-  if (!BT_cont) return MOM6X_EUNSUPPORTED;
+  /* USE_BT_CONT_TYPE = False (BT_cont not associated): the barotropic continuity equation is linear in the velocities with the
+   * face areas Datu, Datv of find_face_areas :5146-5237 (NONLINEAR_BT_CONTINUITY = False: its last branch, from the bathymetry);
+   * BOUND_BT_CORRECTION then needs eta_cor_bound, which is not restated. */
+  const int use_BT_cont = (BT_cont != NULL);
+  if (!use_BT_cont && P->bound_BT_corr) return MOM6X_EUNSUPPORTED;
   const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1, nz = d->nk, st = d->pitch;
   const int isd = -d->halo, ied = d->ni - 1 + d->halo, jsd = -d->halo, jed = d->nj - 1 + d->halo;
   const size_t slab = (size_t)d->slab, n3 = slab * nz;
@@ -344,6 +348,10 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   double *wt_u = (double *)calloc(n3, sizeof(double)), *wt_v = (double *)calloc(n3, sizeof(double));
   double *f_4_u = (double *)calloc(4 * slab, sizeof(double)), *f_4_v = (double *)calloc(4 * slab, sizeof(double));
   btcl_t *BTCL_u = (btcl_t *)calloc(slab, sizeof(btcl_t)), *BTCL_v = (btcl_t *)calloc(slab, sizeof(btcl_t));
+  NEW2(Datu); NEW2(Datv);
+/* the transport of a face at the velocity u: find_uhbt of the BT_cont fit, or Datu * u (:1221, :2639, :3053-3056) */
+#define UHBT(u, c) (use_BT_cont ? find_uhbt((u), &BTCL_u[c]) : Datu[c] * (u))
+#define VHBT(v, c) (use_BT_cont ? find_uhbt((v), &BTCL_v[c]) : Datv[c] * (v))
 
   /* linearized_BT_PV :880-893 */
   for (int j = jsvf - 2; j <= jevf + 1; j++) for (int i = isvf - 2; i <= ievf + 1; i++) q[IX2(d, i, j)] = CS->q_D[IX2(d, i, j)];
@@ -417,7 +425,24 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   }
   const double dgeo_de = 1.0 + P->G_extra;
 
-  set_local_BT_cont_types(d, BT_cont, BTCL_u, BTCL_v, 1 + ievf - ie);
+  if (use_BT_cont) {
+    set_local_BT_cont_types(d, BT_cont, BTCL_u, BTCL_v, 1 + ievf - ie);
+  } else {   /* :1131-1136 find_face_areas(Datu, Datv, ..., halo = 1) :5216-5233, then pass_Dat_uv :846, :1465-1652 */
+    const double Z_to_H = GV->Z_to_H;
+    for (int j = js - 1; j <= je + 1; j++) for (int i = is - 2; i <= ie + 1; i++) {
+      size_t c = IX2(d, i, j);
+      double H1 = (bathyT[c] + P->Z_ref) * Z_to_H, H2 = (bathyT[c + 1] + P->Z_ref) * Z_to_H;
+      Datu[c] = 0.0;
+      if ((H1 > 0.0) && (H2 > 0.0)) Datu[c] = dy_Cu[c] * (2.0 * H1 * H2) / (H1 + H2);
+    }
+    for (int j = js - 2; j <= je + 1; j++) for (int i = is - 1; i <= ie + 1; i++) {
+      size_t c = IX2(d, i, j);
+      double H1 = (bathyT[c] + P->Z_ref) * Z_to_H, H2 = (bathyT[c + st] + P->Z_ref) * Z_to_H;
+      Datv[c] = 0.0;
+      if ((H1 > 0.0) && (H2 > 0.0)) Datv[c] = dx_Cv[c] * (2.0 * H1 * H2) / (H1 + H2);
+    }
+    orc_pass_var(d, Datu, 1, 1); orc_pass_var(d, Datv, 2, 1);
+  }
 
   if (add_uh0) { /* :1152-1227 */
 #pragma omp parallel for schedule(static)
@@ -435,12 +460,12 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
 #pragma omp parallel for schedule(static)
     for (int j = js; j <= je; j++) for (int i = is - 1; i <= ie; i++) {
       size_t c = IX2(d, i, j);
-      uhbt0[c] = uhbt[c] - find_uhbt(ubt[c], &BTCL_u[c]);
+      uhbt0[c] = uhbt[c] - UHBT(ubt[c], c);
     }
 #pragma omp parallel for schedule(static)
     for (int j = js - 1; j <= je; j++) for (int i = is; i <= ie; i++) {
       size_t c = IX2(d, i, j);
-      vhbt0[c] = vhbt[c] - find_uhbt(vbt[c], &BTCL_v[c]);
+      vhbt0[c] = vhbt[c] - VHBT(vbt[c], c);
     }
   }
 
@@ -684,12 +709,12 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
 #pragma omp parallel for schedule(static)
       for (int j = jsv - 1; j <= jev + 1; j++) for (int i = isv - 2; i <= iev + 1; i++) {
         size_t c = IX2(d, i, j);
-        uhbt[c] = find_uhbt(ubt[c], &BTCL_u[c]) + uhbt0[c];
+        uhbt[c] = UHBT(ubt[c], c) + uhbt0[c];
       }
 #pragma omp parallel for schedule(static)
       for (int j = jsv - 2; j <= jev + 1; j++) for (int i = isv - 1; i <= iev + 1; i++) {
         size_t c = IX2(d, i, j);
-        vhbt[c] = find_uhbt(vbt[c], &BTCL_v[c]) + vhbt0[c];
+        vhbt[c] = VHBT(vbt[c], c) + vhbt0[c];
       }
 #pragma omp parallel for schedule(static)
       for (int j = jsv - 1; j <= jev + 1; j++) for (int i = isv - 1; i <= iev + 1; i++) {
@@ -766,13 +791,13 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
     for (int j = jsv; j <= jev; j++) for (int i = isv - 1; i <= iev; i++) {
       size_t c = IX2(d, i, j);
       ubt_trans[c] = trans_wt1 * ubt[c] + trans_wt2 * ubt_prev[c];
-      uhbt[c] = find_uhbt(ubt_trans[c], &BTCL_u[c]) + uhbt0[c];
+      uhbt[c] = UHBT(ubt_trans[c], c) + uhbt0[c];
     }
 #pragma omp parallel for schedule(static)
     for (int j = jsv - 1; j <= jev; j++) for (int i = isv; i <= iev; i++) {
       size_t c = IX2(d, i, j);
       vbt_trans[c] = trans_wt1 * vbt[c] + trans_wt2 * vbt_prev[c];
-      vhbt[c] = find_uhbt(vbt_trans[c], &BTCL_v[c]) + vhbt0[c];
+      vhbt[c] = VHBT(vbt_trans[c], c) + vhbt0[c];
     }
     /* running sums :2690-2700 */
 #pragma omp parallel for schedule(static)
@@ -837,6 +862,8 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
                      vbt_trans, ubt_prev, vbt_prev, eta_pred, PFu, PFv, Cor_u, Cor_v, wt_u, wt_v, f_4_u, f_4_v,
                      wt_vel, wt_eta, wt_trans, wt_accel, wt_accel2 };
   for (size_t m = 0; m < sizeof(all2) / sizeof(all2[0]); m++) free(all2[m]);
-  free(BTCL_u); free(BTCL_v);
+  free(BTCL_u); free(BTCL_v); free(Datu); free(Datv);
+#undef UHBT
+#undef VHBT
   return MOM6X_OK;
 }

@@ -41,7 +41,7 @@ def make_inputs(orc, cfg, first_direction=0, u_max=0.1):
                 eta_PF=np.ascontiguousarray(eta_PF), ucor=ucor, vcor=vcor, first_direction=first_direction)
 
 
-def run_both(orc, I, pmod=None, use_uh0=True, use_etaav=True, bottom=False, default_thick=False):
+def run_both(orc, I, pmod=None, use_uh0=True, use_etaav=True, bottom=False, default_thick=False, no_bt_cont=False):
     import torch
     from mom6_amd.dycore import Dycore, BTContDev
     d, M, GV = I["d"], I["M"], I["GV"]
@@ -67,7 +67,7 @@ def run_both(orc, I, pmod=None, use_uh0=True, use_etaav=True, bottom=False, defa
         kw.update(taux_bot=0.3 * I["taux"], tauy_bot=0.3 * I["tauy"])
     nstep = orc.btstep(d, M, GV, P, cs, I["first_direction"], I["u"], I["v"], I["eta"], I["dt"], I["bcu"], I["bcv"],
                        I["taux"], I["tauy"], I["pbce"], I["eta_PF"], I["ucor"], I["vcor"], o["alu"], o["alv"],
-                       o["eta_out"], o["uhbtav"], o["vhbtav"], I["vr_u"], I["vr_v"], I["bt"], etaav=o["etaav"], **kw)
+                       o["eta_out"], o["uhbtav"], o["vhbtav"], I["vr_u"], I["vr_v"], None if no_bt_cont else I["bt"], etaav=o["etaav"], **kw)
     assert nstep >= 2
     # ---------------- device
     dyc = Dycore(d, M, GV, I["first_direction"])
@@ -97,7 +97,7 @@ def run_both(orc, I, pmod=None, use_uh0=True, use_etaav=True, bottom=False, defa
     torch.cuda.synchronize()
     dyc.btstep(T["u"], T["v"], T["eta"], I["dt"], T["bcu"], T["bcv"], T["taux"], T["tauy"], T["pbce"], T["eta_PF"],
                T["ucor"], T["vcor"], g["alu"], g["alv"], g["eta_out"], g["uhbtav"], g["vhbtav"], T["vr_u"], T["vr_v"],
-               btd, etaav=g["etaav"], **kwg)
+               None if no_bt_cont else btd, etaav=g["etaav"], **kwg)
     dyc.sync()
     res = dict(dtbt=(dtbt_g, dtbt))
     res["frhatu"] = (dyc.barotropic_field("frhatu").cpu().numpy(), cs["frhatu"], "u")
@@ -165,3 +165,18 @@ def test_btstep_no_uh0_default_thickness(orc):
     I = make_inputs(orc, H.benchmark_small())
     d, res = run_both(orc, I, dict(strong_drag=1), use_uh0=False, default_thick=True)
     check(d, res, exact=True)
+
+
+@pytest.mark.parametrize("cfg", ["double_gyre", "channel", "benchmark_small"])
+@pytest.mark.parametrize("project", [0, 1])
+def test_btstep_without_BT_cont(orc, cfg, project):
+    """USE_BT_CONT_TYPE = False (BT_cont not associated; NONLINEAR_BT_CONTINUITY = False): the barotropic continuity equation linear in
+    the velocities with the face areas of find_face_areas (MOM_barotropic.F90:5146-5237, :1131-1136, :1221, :2639, :3053), the default
+    BT_THICK_SCHEME without a BT_cont_type (HYBRID: btcalc without h_u / h_v) -- bit for bit with BT_STRONG_DRAG, 1e-12 on the default
+    drag path."""
+    I = make_inputs(orc, dict(double_gyre=H.double_gyre, channel=H.channel, benchmark_small=H.benchmark_small)[cfg](), project)
+    d, res = run_both(orc, I, dict(strong_drag=1, BT_project_velocity=project), default_thick=True, no_bt_cont=True)
+    check(d, res, exact=True)
+    assert np.abs(res["uhbtav"][1]).max() > 0
+    d, res = run_both(orc, I, dict(BT_project_velocity=project), default_thick=True, no_bt_cont=True, use_uh0=False)
+    check(d, res, exact=False)
