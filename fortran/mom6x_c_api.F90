@@ -36,7 +36,7 @@ module mom6x_c_api
   public :: mom6x_tracer_vertdiff_sink, mom6x_tracer_vertdiff_Eulerian_sink
 
   !> include/mom6x.h MOM6X_ABI_VERSION this module mirrors; a host compares it with mom6x_abi_version() at start-up
-  integer(c_int), parameter :: MOM6X_ABI_BUILT_FOR = 4
+  integer(c_int), parameter :: MOM6X_ABI_BUILT_FOR = 5
   !> mom6x_dyn_split_RK2_restart_fills: the restart variables the host has uploaded (include/mom6x.h MOM6X_RK2_HAVE_*)
   integer(c_int), parameter :: MOM6X_RK2_HAVE_ETA = 1, MOM6X_RK2_HAVE_DIFFU = 2, MOM6X_RK2_HAVE_U2 = 4, MOM6X_RK2_HAVE_CAU = 8, &
                                MOM6X_RK2_HAVE_UH = 16, MOM6X_RK2_HAVE_H2 = 32
@@ -78,6 +78,7 @@ module mom6x_c_api
     integer(c_int) :: bound_BT_corr, BT_cont_bounds
     real(c_double) :: dtbt_fraction, Z_ref
     integer(c_int) :: use_wide_halos, BTHALO, min_stencil   !< BT_USE_WIDE_HALOS (T), BTHALO (0), BT_WIDE_HALO_MIN_STENCIL (0)
+    integer(c_int) :: nonlinear_continuity, nonlin_cont_update_period   !< NONLINEAR_BT_CONTINUITY (F), NONLIN_BT_CONT_UPDATE_PERIOD (1): read by btstep without a BT_cont_type
   end type mom6x_barotropic_params
 
   type, bind(C) :: mom6x_coriolis_params   !< CoriolisAdv_CS (MOM_CoriolisAdv.F90:29-100)

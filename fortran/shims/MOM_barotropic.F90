@@ -277,6 +277,12 @@ subroutine barotropic_init(u, v, h, Time, G, GV, US, param_file, diag, CS, &
   call get_param(param_file, mdl, "BT_WIDE_HALO_MIN_STENCIL", min_stencil, "The minimum stencil width to use with the wide halo "//&
                  "iterations.", default=0, layoutParam=.true.)
   CS%p%min_stencil = int(min_stencil, c_int)
+  ! read by btstep when it is called without a BT_cont_type (:5466-5474)
+  call flag_param("NONLINEAR_BT_CONTINUITY", CS%p%nonlinear_continuity, .false.)
+  call get_param(param_file, mdl, "NONLIN_BT_CONT_UPDATE_PERIOD", min_stencil, "If NONLINEAR_BT_CONTINUITY is true, the number of "//&
+                 "barotropic time steps between updates to the face areas, or 0 to update only before the barotropic stepping.", &
+                 default=1)
+  CS%p%nonlin_cont_update_period = int(min_stencil, c_int)
   ! (the barotropic domain's halo on the device is the tile context's: shim_ctx makes it G's, so BTHALO > NIHALO is refused by
   !  mom6x_barotropic_init with the instruction to widen the context; the answers do not depend on it)
   call must_be("USE_BT_CONT_TYPE", .true.) ; call must_be("INTEGRAL_BT_CONTINUITY", .false.)

@@ -43,10 +43,12 @@ extern "C" {
  * 3: mom6x_coriolis_params grew (CORIOLIS_SCHEME ARAKAWA_LAMB81 / AL_BLEND / ROBUST_ENSTRO: wt_lin_blend, F_eff_max_blend, PV_Adv_Scheme),
  * mom6x_eos_params.EOS_quadrature and the EOS forms beyond LINEAR / WRIGHT, mom6x_barotropic_params' wide-halo members
  * (use_wide_halos, BTHALO, min_stencil) (round 3).
+ * 5: (round 5) mom6x_barotropic_params.nonlinear_continuity / nonlin_cont_update_period; btstep accepts BT_cont == NULL;
+ *    mom6x_continuity_params.sum_order = MOM6X_SUM_TREE16_FMA.
  * 4: (round 4) mom6x_dyn_split_RK2_restart_fills + MOM6X_RK2_HAVE_*, mom6x_rk2_diag_*; see the end of this comment's list in
  * DESIGN.md section 1.  Hosts compare mom6x_abi_version() with the value they were
  * built against (fortran/mom6x_c_api.F90 MOM6X_ABI_BUILT_FOR, mom6_amd/abi.py ABI_VERSION) and refuse to run on a mismatch. */
-#define MOM6X_ABI_VERSION 4
+#define MOM6X_ABI_VERSION 5
 
 /* ------------------------------------------------------------------------- */
 /* Tile dimensions and layout (MOM_hor_index.F90:14-44 hor_index_type +
@@ -170,6 +172,11 @@ typedef struct mom6x_barotropic_params {
   int    use_wide_halos;       /* BT_USE_WIDE_HALOS (T); F: an exchange every sub-step                                       */
   int    BTHALO;               /* BTHALO (0): refused if it exceeds the context's halo                                        */
   int    min_stencil;          /* BT_WIDE_HALO_MIN_STENCIL (0)                                                                */
+  /* Without a BT_cont_type (btstep's BT_cont argument NULL; USE_BT_CONT_TYPE = False), ABI 5: the face areas of the linear barotropic
+   * continuity equation from the bathymetry alone, or (NONLINEAR_BT_CONTINUITY) from bathymetry + eta, recomputed every
+   * NONLIN_BT_CONT_UPDATE_PERIOD sub-steps with a stencil of 2 (MOM_barotropic.F90:767-768, :1131-1136, :2539-2543, :5146-5237).     */
+  int    nonlinear_continuity;       /* NONLINEAR_BT_CONTINUITY (F); ignored when BT_cont is given                                  */
+  int    nonlin_cont_update_period;  /* NONLIN_BT_CONT_UPDATE_PERIOD (1); 0: the face areas of the step's first eta throughout      */
 } mom6x_barotropic_params;
 
 /* CoriolisAdv_CS (src/core/MOM_CoriolisAdv.F90:29-100; CoriolisAdv_init :1054).            */

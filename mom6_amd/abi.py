@@ -135,6 +135,7 @@ class BarotropicParams(C.Structure):
         ("bound_BT_corr", C.c_int), ("BT_cont_bounds", C.c_int),
         ("dtbt_fraction", C.c_double), ("Z_ref", C.c_double),
         ("use_wide_halos", C.c_int), ("BTHALO", C.c_int), ("min_stencil", C.c_int),
+        ("nonlinear_continuity", C.c_int), ("nonlin_cont_update_period", C.c_int),
     ]
 
 
@@ -143,6 +144,7 @@ def barotropic_params_default(dtbt):
     p = BarotropicParams()
     p.bebt, p.dtbt, p.dt_bt_filter = 0.1, dtbt, -0.25
     p.use_wide_halos, p.BTHALO, p.min_stencil = 1, 0, 0
+    p.nonlinear_continuity, p.nonlin_cont_update_period = 0, 1
     p.BT_project_velocity = 0
     p.Sadourny = 1
     p.strong_drag = 0
@@ -406,7 +408,7 @@ MOM6X_OK = 0
 _lib = None
 
 
-ABI_VERSION = 4   # include/mom6x.h MOM6X_ABI_VERSION
+ABI_VERSION = 5   # include/mom6x.h MOM6X_ABI_VERSION
 
 
 def load_library(path=None):

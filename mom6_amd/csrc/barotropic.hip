@@ -347,27 +347,52 @@ __global__ void k_btcont_copy(Dm d, mom6x_BT_cont BT, double *tmp) {
 // branch: NONLINEAR_BT_CONTINUITY = False, from the bathymetry; halo = 1, :1135).  They go through the SAME fit planes: with all four
 // face areas of a fit = Datu, no curvature and break points at -/+ 1e100, find_uhbt(u) is u * (Datu + 0 * (u * u)) = Datu * u in
 // every bit (0 * u^2 is 0, Datu + 0 is Datu, the product commutes).  The halo update that follows is the reference's pass_Dat_uv.
-__global__ void k_face_areas_as_fits(Dm d, const double *__restrict__ G, double Z_ref, double Z_to_H, double *tmp) {
+// eta != NULL: NONLINEAR_BT_CONTINUITY, the Boussinesq branch :5171-5186 (H = bathyT * Z_to_H + eta).
+__global__ void k_face_areas_as_fits(Dm d, const double *__restrict__ G, double Z_ref, double Z_to_H, double *tmp, const double *__restrict__ eta) {
   const int i = -2 + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -2 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni || j > d.nj) return;
   const int st = d.pitch;
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   const double *bathyT = gm(G, d, MOM6X_G_bathyT);
-  const double H1 = (bathyT[c] + Z_ref) * Z_to_H;
+  const double H1 = eta ? (bathyT[c] * Z_to_H + eta[c]) : ((bathyT[c] + Z_ref) * Z_to_H);
   if (j >= -1) {   // Datu on (is-2 .. ie+1, js-1 .. je+1)
-    const double H2 = (bathyT[c + 1] + Z_ref) * Z_to_H;
+    const double H2 = eta ? (bathyT[c + 1] * Z_to_H + eta[c + 1]) : ((bathyT[c + 1] + Z_ref) * Z_to_H);
     double Dat = 0.0;
     if ((H1 > 0.0) && (H2 > 0.0)) Dat = gm(G, d, MOM6X_G_dy_Cu)[c] * (2.0 * H1 * H2) / (H1 + H2);
     tmp[0 * slab + c] = -1.0e100; tmp[1 * slab + c] = 1.0e100;
     tmp[2 * slab + c] = Dat; tmp[3 * slab + c] = Dat; tmp[4 * slab + c] = Dat; tmp[5 * slab + c] = Dat;
   }
   if (i >= -1) {   // Datv on (is-1 .. ie+1, js-2 .. je+1)
-    const double H2 = (bathyT[c + st] + Z_ref) * Z_to_H;
+    const double H2 = eta ? (bathyT[c + st] * Z_to_H + eta[c + st]) : ((bathyT[c + st] + Z_ref) * Z_to_H);
     double Dat = 0.0;
     if ((H1 > 0.0) && (H2 > 0.0)) Dat = gm(G, d, MOM6X_G_dx_Cv)[c] * (2.0 * H1 * H2) / (H1 + H2);
     tmp[6 * slab + c] = -1.0e100; tmp[7 * slab + c] = 1.0e100;
     tmp[8 * slab + c] = Dat; tmp[9 * slab + c] = Dat; tmp[10 * slab + c] = Dat; tmp[11 * slab + c] = Dat;
+  }
+}
+// ... and inside the time loop (:2539-2543, evolving_face_areas): the four face areas of every fit rewritten from the current eta on the
+// sub-step's ranges (halo = 1 + iev - ie); the other parameters of the degenerate fits do not change.
+__global__ void k_face_areas_eta(Dm d, const double *__restrict__ G, double Z_to_H, const double *__restrict__ eta, double *Bu, double *Bv,
+                                 int isv, int iev, int jsv, int jev) {
+  const int i = isv - 2 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = jsv - 2 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (i > iev + 1 || j > jev + 1) return;
+  const int st = d.pitch;
+  const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
+  const double *bathyT = gm(G, d, MOM6X_G_bathyT);
+  const double H1 = bathyT[c] * Z_to_H + eta[c];
+  if (j >= jsv - 1) {
+    const double H2 = bathyT[c + 1] * Z_to_H + eta[c + 1];
+    double Dat = 0.0;
+    if ((H1 > 0.0) && (H2 > 0.0)) Dat = gm(G, d, MOM6X_G_dy_Cu)[c] * (2.0 * H1 * H2) / (H1 + H2);
+    Bu[B_FA_EE * slab + c] = Dat; Bu[B_FA_E0 * slab + c] = Dat; Bu[B_FA_W0 * slab + c] = Dat; Bu[B_FA_WW * slab + c] = Dat;
+  }
+  if (i >= isv - 1) {
+    const double H2 = bathyT[c + st] * Z_to_H + eta[c + st];
+    double Dat = 0.0;
+    if ((H1 > 0.0) && (H2 > 0.0)) Dat = gm(G, d, MOM6X_G_dx_Cv)[c] * (2.0 * H1 * H2) / (H1 + H2);
+    Bv[B_FA_EE * slab + c] = Dat; Bv[B_FA_E0 * slab + c] = Dat; Bv[B_FA_W0 * slab + c] = Dat; Bv[B_FA_WW * slab + c] = Dat;
   }
 }
 // step 2 (after the halo update): the cubic-fit parameters as SoA planes
@@ -1109,7 +1134,8 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   const int is = 0, ie = d.ni - 1, js = 0, je = d.nj - 1;
 
   const double Idt = 1.0 / dt;
-  const int stencil = (P.min_stencil > 1) ? P.min_stencil : 1;                 // :766 (no OBC, no nonlinear continuity updates)
+  const bool evolving_face_areas = !BT_cont && P.nonlinear_continuity && P.nonlin_cont_update_period > 0;   // :2425
+  const int stencil = evolving_face_areas ? std::max(2, P.min_stencil) : ((P.min_stencil > 1) ? P.min_stencil : 1);   // :766-768 (no OBC)
   const int num_cycles = (P.use_wide_halos && d.halo / stencil >= 1) ? d.halo / stencil : 1;   // :790-792; the wide halo = the context's
   const int isvf = is - (num_cycles - 1) * stencil, ievf = ie + (num_cycles - 1) * stencil;
   const int jsvf = js - (num_cycles - 1) * stencil, jevf = je + (num_cycles - 1) * stencil;
@@ -1153,7 +1179,8 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   // ---- BT_cont fits (set_local_BT_cont_types, halo = 1+ievf-ie)
   double *tmp = work + W_BTtmp * slab;
   if (BT_cont) KLAUNCH(c, "k_btcont_copy", k_btcont_copy, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, *BT_cont, tmp);
-  else KLAUNCH(c, "k_face_areas_as_fits", k_face_areas_as_fits, grid3(d.ni + 3, d.nj + 3, 1, b), b, d, c->G, P.Z_ref, c->GV.Z_to_H, tmp);
+  else KLAUNCH(c, "k_face_areas_as_fits", k_face_areas_as_fits, grid3(d.ni + 3, d.nj + 3, 1, b), b, d, c->G, P.Z_ref, c->GV.Z_to_H, tmp,
+               P.nonlinear_continuity ? (const double *)(work + W_eta * slab) : (const double *)nullptr);
   {
     // the twelve BT_cont planes (set_local_BT_cont_types :4876, halo = 1+ievf-ie) and, in the same packed message, what the column
     // pass has made and btstep passes next (:1421-1431: gtot_*, ubt_Cor, vbt_Cor -- no kernel between the two reads the other's halos)
@@ -1230,7 +1257,7 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   // evaluate it while they hold the velocity and its fit planes and pass two planes on (W_uhn, W_vhn; exchanged with the
   // velocities), instead of the predictor re-reading four velocities and up to sixteen fit planes per cell.  Not with
   // CLIP_BT_VELOCITY (the velocities change in between) or BT_PROJECT_VELOCITY (the predictor does not use transports).
-  const bool pass_uhn = !P.clip_velocity && !P.BT_project_velocity;
+  const bool pass_uhn = !P.clip_velocity && !P.BT_project_velocity && !evolving_face_areas;   // (evolving: the next predictor uses NEW face areas)
   L.store_uhn = pass_uhn ? 1 : 0;
   // ... and when no exchange separates two sub-steps (three times out of four with a halo of 4), the eta corrector of the
   // first forms the predictor of the second on the way: same points, the new eta still in a register.
@@ -1260,6 +1287,9 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     } else {
       isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil;
     }
+    if (evolving_face_areas && n > 1 && ((n - 1) % P.nonlin_cont_update_period == 0))   // :2539-2543
+      KLAUNCH(c, "k_face_areas_eta", k_face_areas_eta, grid3(iev - isv + 4, jev - jsv + 4, 1, b), b, d, c->G, c->GV.Z_to_H,
+              (const double *)(work + W_eta * slab), work + W_BTCu * slab, work + W_BTCv * slab, isv, iev, jsv, jev);
     L.isv = isv; L.iev = iev; L.jsv = jsv; L.jev = jev;
     L.wt_accel = wt_accel[n]; L.wt_trans = wt_trans[n]; L.wt_vel = wt_vel[n]; L.wt_eta = wt_eta[n]; L.wt_accel2 = wt_accel2[n];
     if ((!P.BT_project_velocity || L.find_etaav) && !pred_done)

@@ -3,7 +3,7 @@
  *
  * btstep and friends restated from /root/reference/src/core/MOM_barotropic.F90, on the
  * default-flag path listed in SURVEY.md section 8(b.1):
- *   USE_BT_CONT_TYPE=T (BT_cont must be supplied), INTEGRAL_BT_CONTINUITY=F, LINEARIZED_BT_CORIOLIS=T,
+ *   USE_BT_CONT_TYPE=T, or F (BT_cont NULL: find_face_areas :5146-5237, NONLINEAR_BT_CONTINUITY on or off), INTEGRAL_BT_CONTINUITY=F, LINEARIZED_BT_CORIOLIS=T,
  *   BT_NONLIN_STRESS=F, DYNAMIC_SURFACE_PRESSURE=F, BT_LINEAR_WAVE_DRAG=F, GRADUAL_BT_ICS=F, no OBC,
  *   no SAL/tides/filters, BT_USE_WIDE_HALOS=T with BTHALO=0 (wide halo == data halo),
  *   BAROTROPIC_ANSWER_DATE >= 20190101, eta_PF_start unassociated;
@@ -296,6 +296,34 @@ static void set_local_BT_cont_types(const mom6x_dims *d, const mom6x_BT_cont *BT
   for (int m = 0; m < 12; m++) free(t[m]);
 }
 
+/* find_face_areas :5146-5237 without add_max: from bathymetry + eta (Boussinesq branch :5171-5186) or from the bathymetry alone
+ * (:5216-5233), over the computational domain and `hs` points beyond it */
+static void find_face_areas(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_barotropic_params *P,
+                            double *Datu, double *Datv, int hs, const double *eta) {
+  const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1, st = d->pitch;
+  const double *dy_Cu = GM(G, d, MOM6X_G_dy_Cu), *dx_Cv = GM(G, d, MOM6X_G_dx_Cv), *bathyT = GM(G, d, MOM6X_G_bathyT);
+  const double Z_to_H = GV->Z_to_H;
+  if (hs < 0) hs = 0;
+#pragma omp parallel for schedule(static)
+  for (int j = js - hs; j <= je + hs; j++) for (int i = is - 1 - hs; i <= ie + hs; i++) {
+    size_t c = IX2(d, i, j);
+    double H1, H2;
+    if (eta) { H1 = bathyT[c] * Z_to_H + eta[c]; H2 = bathyT[c + 1] * Z_to_H + eta[c + 1]; }
+    else { H1 = (bathyT[c] + P->Z_ref) * Z_to_H; H2 = (bathyT[c + 1] + P->Z_ref) * Z_to_H; }
+    Datu[c] = 0.0;
+    if ((H1 > 0.0) && (H2 > 0.0)) Datu[c] = dy_Cu[c] * (2.0 * H1 * H2) / (H1 + H2);
+  }
+#pragma omp parallel for schedule(static)
+  for (int j = js - 1 - hs; j <= je + hs; j++) for (int i = is - hs; i <= ie + hs; i++) {
+    size_t c = IX2(d, i, j);
+    double H1, H2;
+    if (eta) { H1 = bathyT[c] * Z_to_H + eta[c]; H2 = bathyT[c + st] * Z_to_H + eta[c + st]; }
+    else { H1 = (bathyT[c] + P->Z_ref) * Z_to_H; H2 = (bathyT[c + st] + P->Z_ref) * Z_to_H; }
+    Datv[c] = 0.0;
+    if ((H1 > 0.0) && (H2 > 0.0)) Datv[c] = dx_Cv[c] * (2.0 * H1 * H2) / (H1 + H2);
+  }
+}
+
 #define F4(a, n, c) ((a)[(size_t)4 * (c) + ((n) - 1)])   /* f_4_u(n,I,j) */
 
 /* btstep :455-2172 with btstep_timeloop :2175-2834 and the btloop_* helpers :2956-3384. */
@@ -327,8 +355,10 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   const double Idt = 1.0 / dt;
   const int find_etaav = (etaav != NULL), add_uh0 = (uh0 != NULL);
   if (add_uh0 && !(vh0 && u_uh0 && v_vh0)) return MOM6X_EINVAL;
-  const int stencil = 1;
-  const int num_cycles = d->halo / stencil;   /* min((is-isdw)/stencil,(js-jsdw)/stencil), use_wide_halos */
+  /* :766-768: the face areas recomputed from eta inside the loop read one more point */
+  const int evolving_face_areas = (!use_BT_cont) && P->nonlinear_continuity && (P->nonlin_cont_update_period > 0);
+  const int stencil = evolving_face_areas ? 2 : 1;
+  const int num_cycles = (d->halo / stencil >= 1) ? d->halo / stencil : 1;   /* min((is-isdw)/stencil,(js-jsdw)/stencil), use_wide_halos */
   const int isvf = is - (num_cycles - 1) * stencil, ievf = ie + (num_cycles - 1) * stencil;
   const int jsvf = js - (num_cycles - 1) * stencil, jevf = je + (num_cycles - 1) * stencil;
   const int nstep = (int)ceil(dt / P->dtbt - 0.0001);
@@ -427,20 +457,8 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
 
   if (use_BT_cont) {
     set_local_BT_cont_types(d, BT_cont, BTCL_u, BTCL_v, 1 + ievf - ie);
-  } else {   /* :1131-1136 find_face_areas(Datu, Datv, ..., halo = 1) :5216-5233, then pass_Dat_uv :846, :1465-1652 */
-    const double Z_to_H = GV->Z_to_H;
-    for (int j = js - 1; j <= je + 1; j++) for (int i = is - 2; i <= ie + 1; i++) {
-      size_t c = IX2(d, i, j);
-      double H1 = (bathyT[c] + P->Z_ref) * Z_to_H, H2 = (bathyT[c + 1] + P->Z_ref) * Z_to_H;
-      Datu[c] = 0.0;
-      if ((H1 > 0.0) && (H2 > 0.0)) Datu[c] = dy_Cu[c] * (2.0 * H1 * H2) / (H1 + H2);
-    }
-    for (int j = js - 2; j <= je + 1; j++) for (int i = is - 1; i <= ie + 1; i++) {
-      size_t c = IX2(d, i, j);
-      double H1 = (bathyT[c] + P->Z_ref) * Z_to_H, H2 = (bathyT[c + st] + P->Z_ref) * Z_to_H;
-      Datv[c] = 0.0;
-      if ((H1 > 0.0) && (H2 > 0.0)) Datv[c] = dx_Cv[c] * (2.0 * H1 * H2) / (H1 + H2);
-    }
+  } else {   /* :1131-1136 find_face_areas(Datu, Datv, ..., halo = 1 [, eta]) :5146-5237, then pass_Dat_uv :846, :1465-1652 */
+    find_face_areas(d, G, GV, P, Datu, Datv, 1, P->nonlinear_continuity ? eta : NULL);
     orc_pass_var(d, Datu, 1, 1); orc_pass_var(d, Datv, 2, 1);
   }
 
@@ -704,6 +722,10 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
     for (int j = jsv; j <= jev; j++) for (int i = isv - 2; i <= iev + 1; i++) ubt_prev[IX2(d, i, j)] = ubt[IX2(d, i, j)];
 #pragma omp parallel for schedule(static)
     for (int j = jsv - 2; j <= jev + 1; j++) for (int i = isv; i <= iev; i++) vbt_prev[IX2(d, i, j)] = vbt[IX2(d, i, j)];
+
+    /* :2539-2543 */
+    if (evolving_face_areas && (n > 1) && ((n - 1) % P->nonlin_cont_update_period == 0))
+      find_face_areas(d, G, GV, P, Datu, Datv, 1 + iev - ie, eta);
 
     if (!P->BT_project_velocity) { /* btloop_eta_predictor :2956-3018, use_BT_cont branch */
 #pragma omp parallel for schedule(static)
