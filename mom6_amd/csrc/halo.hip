@@ -151,6 +151,36 @@ __global__ void k_wrap_y(Dm d, WrapArgs A) {
   }
 }
 
+// MOM6X_POISON_HALO=1 (tests/test_layout_gpu.py): after a group pass narrower than the halo, every halo point of the passed fields
+// that has a neighbour (or wraps around) but lies BEYOND the passed width becomes a NaN.  The step then only gives the bits of a
+// full-width run if no kernel's result depends on the rows the narrow passes leave stale (dyn_split_RK2.hip: pass_widths).
+struct Nbr8 { int on[8]; };
+__global__ void __launch_bounds__(256)
+k_halo_poison(Dm d, WrapArgs A, Nbr8 N) {
+  const int nrows = d.slab / d.pitch;
+  const unsigned per_k = (unsigned)d.pitch * (unsigned)nrows;
+  const double bad = __longlong_as_double(0x7ff8000000000000LL);
+  for (int m = 0; m < A.n; m++) {
+    const int w = PASS_W(A, m);
+    if (w >= d.halo) continue;
+    const int xB = (A.stg[m] == 1 || A.stg[m] == 3), yB = (A.stg[m] == 2 || A.stg[m] == 3);
+    const unsigned tot = per_k * (unsigned)A.nk[m];
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += gridDim.x * blockDim.x) {
+      const unsigned k = t / per_k, r = t - k * per_k;
+      const int j = (int)(r / (unsigned)d.pitch) - d.joff, i = (int)(r % (unsigned)d.pitch) - d.ioff;
+      if (i < -d.halo - xB || i > d.ni - 1 + d.halo || j < -d.halo - yB || j > d.nj - 1 + d.halo) continue;   // (padding of the pitched rows)
+      const int sx = (i < -xB) ? -1 : ((i > d.ni - 1) ? 1 : 0), sy = (j < -yB) ? -1 : ((j > d.nj - 1) ? 1 : 0);
+      if (sx == 0 && sy == 0) continue;
+      int dir = -1;
+      for (int q = 0; q < 8; q++) { int dx, dy; dir_dxdy(q, dx, dy); if (dx == sx && dy == sy) dir = q; }
+      if (!N.on[dir]) continue;
+      const int dist_x = (sx < 0) ? (-xB - i) : ((sx > 0) ? i - (d.ni - 1) : 0), dist_y = (sy < 0) ? (-yB - j) : ((sy > 0) ? j - (d.nj - 1) : 0);
+      if (dist_x > w || dist_y > w) A.f[m][(size_t)k * d.slab + r] = bad;
+    }
+  }
+}
+static bool poison_halo() { static const bool on = [] { const char *e = getenv("MOM6X_POISON_HALO"); return e && *e && *e != '0'; }(); return on; }
+
 // ---- the communicator -------------------------------------------------------------------------------
 struct NcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *);
@@ -407,6 +437,11 @@ static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A, hipStream_t st) {
   (void)in_group;
   if (own) KLAUNCH(c, "k_halo_unpack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, RB, 0);
   else hipLaunchKernelGGL(k_halo_pack, dim3(blocks, 8), dim3(256), 0, st, d, A, RB, 0);
+  if (poison_halo()) {
+    Nbr8 N;
+    for (int dir = 0; dir < 8; dir++) N.on[dir] = (m->nbr[dir] >= 0);
+    hipLaunchKernelGGL(k_halo_poison, dim3(512), dim3(256), 0, st, d, A, N);
+  }
   return MOM6X_OK;
 }
 
@@ -440,6 +475,14 @@ void halo_wrap(mom6x_ctx *c, double *const *fields, const int *staggers, const i
     if (c->dims.reentrant_y) {
       const int cols = d.ni + 2 * d.halo + 1;
       KLAUNCH(c, "k_wrap_y", k_wrap_y, dim3((cols + 63) / 64, 1, nkmax), b, d, A);
+    }
+    if (poison_halo()) {
+      Nbr8 N;
+      for (int dir = 0; dir < 8; dir++) {
+        int dx, dy; dir_dxdy(dir, dx, dy);
+        N.on[dir] = (dx == 0 || c->dims.reentrant_x) && (dy == 0 || c->dims.reentrant_y);
+      }
+      hipLaunchKernelGGL(k_halo_poison, dim3(512), dim3(256), 0, c->stream, d, A, N);
     }
   }
 }

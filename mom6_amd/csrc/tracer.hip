@@ -10,7 +10,7 @@
 // exit test reads domore_k back once per halo cycle -- the same global synchronisation point as the
 // reference's sum_across_PEs (:331).  All fluxes of a pass must be formed from the un-updated hprev/uhr/tracer
 // values.  Default: one kernel per direction and pass that reads everything it needs before it writes (k_ta_x_tile,
-// k_ta_y_march, see there).  MOM6X_TRACER=legacy: two kernels per direction and pass,
+// k_ta_y_tile, see there).  MOM6X_TRACER=legacy: two kernels per direction and pass,
 //   k_ta_face<DIR>: limited transport uhh and the tracer fluxes of every face   -> scratch
 //   k_ta_cell<DIR>: uhr -= uhh ; hprev and every tracer updated from the face fluxes
 #include <cfloat>
@@ -42,10 +42,29 @@ inline dim3 blk2() { return dim3(64, 4, 1); }
 __device__ __forceinline__ double dmax3(double a, double b, double c) { return dmax(dmax(a, b), c); }
 __device__ __forceinline__ double dmin3(double a, double b, double c) { return dmin(dmin(a, b), c); }
 
+// x / 3 and x / 6 (the PPM edge values and limiter, :560-575 / :965-980) in three operations instead of the ten of a division: with
+// y = RN(1 / c), q = RN(x y) lies within one ulp of x / c, r = x - c q is exact in a fused multiply-add, and RN(q + r y) is the
+// correctly rounded quotient (Markstein's theorem; y is within half an ulp of 1 / c).  The sign is the numerator's (+-0 included).
+// Below 2**-1000 the quotient can be subnormal, where q + r y may meet a tie: a wavefront that holds such a value (never, in an
+// ocean) divides.  Checked against the division on 3.4e9 values of every exponent, patterns around 1, 2, 4/3 and 8/3 included
+// (every mismatch had a subnormal quotient).
+template <int C>
+__device__ __forceinline__ double div_by(double x) {
+  static_assert(C == 3 || C == 6, "div_by: 3 or 6");
+  const double y = 1.0 / (double)C;
+  const bool tiny = (fabs(x) < 0x1p-1000) && (x != 0.0);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny) != 0, 0)) return x / (double)C;
+  const double q = x * y;
+  const double r = __builtin_fma(-(double)C, q, x);
+  return copysign(__builtin_fma(r, y, q), x);
+}
+
 // PLM slope of a cell from its three values and the product of the masks of its two faces :445-449 / :824-828
+// (maxima and minima through v_max_f64 / v_min_f64: they differ from (a > b) ? a : b in the sign of a zero result only -- and in which
+//  operand a NaN drops out -- and every use below ends in fabs())
 __device__ __forceinline__ double plm_slope3(double tm, double tc, double tp, double mprod) {
-  const double dMx = dmax3(tp, tc, tm) - tc, dMn = tc - dmin3(tp, tc, tm);
-  return mprod * dsign(dmin3(0.5 * fabs(tp - tm), 2.0 * dMx, 2.0 * dMn), tp - tm);
+  const double dMx = __builtin_fmax(__builtin_fmax(tp, tc), tm) - tc, dMn = tc - __builtin_fmin(__builtin_fmin(tp, tc), tm);
+  return mprod * dsign(__builtin_fmin(__builtin_fmin(0.5 * fabs(tp - tm), 2.0 * dMx), 2.0 * dMn), tp - tm);
 }
 
 // Tracer flux through one face :546-607 / :951-1010 from gathered operands: T5 = the tracer in the upwind cell `up` and
@@ -57,25 +76,30 @@ __device__ __forceinline__ double plm_slope3(double tm, double tc, double tp, do
 // stencil holds the cell forms the same bits, so a kernel may form it once per cell (k_ta_x_tile's slope stage).
 __device__ __forceinline__ double cell_slope(double tm, double tc, double tp, double m_c, double m_cm1) { return plm_slope3(tm, tc, tp, m_c * m_cm1); }
 
+#define DIV3(x) div_by<3>(x)
+#define DIV6(x) div_by<6>(x)
 // face_flux5 with the slopes of the cells up-1, up, up+1 given (sl[0..2]; PLM: sl[1] only; PPM:H3: none)
 __device__ __forceinline__ double face_flux5s(int scheme, const double (&T5)[5], const double (&mk)[4], const double (&sl)[3], double uhh, double CFL) {
   const double Tm = T5[1], Tc = T5[2], Tp = T5[3];
   if (scheme == ADVECT_PPM || scheme == ADVECT_PPMH3) {
     double aL, aR;
     if (scheme == ADVECT_PPMH3) {
-      aL = (5. * Tc + (2. * Tm - Tp)) / 6.;
+      aL = DIV6(5. * Tc + (2. * Tm - Tp));
       aL = dmax(dmin(Tc, Tm), aL); aL = dmin(dmax(Tc, Tm), aL);
-      aR = (5. * Tc + (2. * Tp - Tm)) / 6.;
+      aR = DIV6(5. * Tc + (2. * Tp - Tm));
       aR = dmax(dmin(Tc, Tp), aR); aR = dmin(dmax(Tc, Tp), aR);
     } else {
       const double s0 = sl[0], s1 = sl[1], s2 = sl[2];
-      aL = 0.5 * ((Tm + Tc) + (s0 - s1) / 3.);
-      aR = 0.5 * ((Tc + Tp) + (s1 - s2) / 3.);
+      aL = 0.5 * ((Tm + Tc) + DIV3(s0 - s1));
+      aR = 0.5 * ((Tc + Tp) + DIV3(s1 - s2));
     }
     const double dA = aR - aL, mA = 0.5 * (aR + aL);
     if (mk[2] * mk[1] * (Tp - Tc) * (Tc - Tm) <= 0.) { aL = Tc; aR = Tc; }
-    else if (dA * (Tc - mA) > (dA * dA) / 6.) aL = (3. * Tc) - 2. * aR;
-    else if (dA * (Tc - mA) < -(dA * dA) / 6.) aR = (3. * Tc) - 2. * aL;
+    else {
+      const double dA2_6 = DIV6(dA * dA);
+      if (dA * (Tc - mA) > dA2_6) aL = (3. * Tc) - 2. * aR;
+      else if (dA * (Tc - mA) < -dA2_6) aR = (3. * Tc) - 2. * aL;
+    }
     const double a6 = 6. * Tc - 3. * (aR + aL);
     if (uhh >= 0.0) return uhh * (aR - 0.5 * CFL * ((aR - aL) - a6 * (1. - 2. / 3. * CFL)));
     return uhh * (aL + 0.5 * CFL * ((aR - aL) + a6 * (1. - 2. / 3. * CFL)));
@@ -281,12 +305,12 @@ k_ta_cell(Dm d, const double *__restrict__ G, double *__restrict__ uhr, double *
 // pass, and the update is in place, so a work item may only read what it alone will overwrite:
 //   x: a work-group owns TX consecutive cells of one (row, layer); everything it reads from outside them (3 tracer
 //      cells, 1 volume, up to 2 transports on either side) comes from a copy k_ta_save_x made before the pass;
-//   y: the stencil runs along j, so a thread marches along j over a segment of rows of ONE column with the old values
-//      it still needs in registers (no neighbours in i at all); what it needs from the rows beyond its segment comes
-//      from the copy of k_ta_save_y.
+//   y: the stencil runs along j, so a work-group walks a segment of SEGY rows of its columns along j with the old values it
+//      still needs in LDS (no neighbours in i at all); what it needs from the rows beyond its segment comes from the copy
+//      of k_ta_save_y.
 constexpr int TX = 240;          // cells per work-group in x (15 x 128 B: the tiles start on cache lines); thread t < TX <-> cell C0+t and its
                                  // east face, thread TX <-> the west face of the first cell, the other 15 threads only help loading
-constexpr int SEGY = 128;        // rows per marching thread in y
+constexpr int SEGY = 128;        // rows of a work-group's segment in y
 struct SaveIdx {                 // layout of one saved boundary B (first own cell / row of the part behind it)
   // per tracer m: cells B-3..B+2 at [6*m .. 6*m+5]; then hprev B-1, B; then the transports of faces B-2, B-1, B
   __host__ __device__ static int nval(int ntr) { return 6 * ntr + 5; }
@@ -473,13 +497,29 @@ k_ta_save_y(Dm d, const double *__restrict__ vhr, const double *__restrict__ hpr
   (void)st;
 }
 
-template <int MAXT>
+// y, round 5: the zonal kernel's shape turned by a quarter.  A work-group owns YC columns of a segment of SEGY rows and walks it in
+// blocks of YR rows, thread (c, r) <-> face Jb + r (the north face of cell Jb + r) of column c.  The OLD values the stencils need live
+// in LDS in rings of YG = YR + 5 rows (row q in slot q mod YG): a block brings in YR new rows of every array (T rows Jb+3 .. Jb+YR+2,
+// masks of the faces Jb+2 .., volumes / transports / areas of the rows Jb+1 ..), everything below them is still there from the block
+// before -- rows this work-group has overwritten in memory since.  The next block's rows are asked for (into registers: 4 + MAXT
+// doubles per thread) right after this block's have been handed over, so they travel while the block is computed; the limited slope
+// of a cell is formed once (cell_slope), not by each of the three faces whose stencil holds it.  The transport and the fluxes of a
+// block's last face wait in row 0 of s_uhh / s_F for the first cell of the next block.  A "block" of staging only (Jb = R0 - 1 - YR)
+// fills the rings before the first faces.  What lies beyond the segment comes from k_ta_save_y's copy.  (Rounds 2-4 had one thread
+// march along j per column with its window in registers: 4.4 ms per pass of four tracers against 4.3 here, profiles/r05_tracer.md.)
+constexpr int YR = 8, YG = YR + 5, YCW = 32;   // rows per block, rows of a ring, columns of a work-group (up to four tracers; 16 with more)
+template <int MAXT, int YC>
 __global__ void __launch_bounds__(256)
-k_ta_y_march(Dm d, const double *__restrict__ G, double *__restrict__ vhr, double *__restrict__ hprev, TrList Tr,
-             const int *__restrict__ dm, int *__restrict__ lim, const int *__restrict__ dmk, const double *__restrict__ save,
-             double min_h, double h_neglect, double H_subroundoff, int i0, int i1, int j0, int j1, int nseg) {
-  const int i = I_BASE(i0) + blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, k = blockIdx.z;
-  if (i < i0 || i > i1 || dmk[k] <= 0) return;
+k_ta_y_tile(Dm d, const double *__restrict__ G, double *__restrict__ vhr, double *__restrict__ hprev, TrList Tr,
+            const int *__restrict__ dm, int *__restrict__ lim, const int *__restrict__ dmk, const double *__restrict__ save,
+            double min_h, double h_neglect, double H_subroundoff, int i0, int i1, int j0, int j1, int nseg) {
+  const int n = blockIdx.y, k = blockIdx.z;
+  if (dmk[k] <= 0) return;
+  constexpr int YP = YC + 1;                         // (padded rows)
+  const int c = (int)threadIdx.x % YC, r = (int)threadIdx.x / YC;
+  const int i_raw = I_BASE(i0) + (int)blockIdx.x * YC + c;
+  const bool col_on = (i_raw >= i0 && i_raw <= i1);
+  const int i = min(max(i_raw, i0), i1);             // (a column outside the range reads its neighbour's values and stores nothing)
   const int nrows = d.nj + 2 * d.halo + 1, st = d.pitch, ntr = Tr.n, nv = SaveIdx::nval(ntr);
   const int R0 = j0 + SEGY * n, R1 = min(R0 + SEGY - 1, j1);
   const size_t nx = (size_t)(i1 - i0 + 1);
@@ -487,91 +527,117 @@ k_ta_y_march(Dm d, const double *__restrict__ G, double *__restrict__ vhr, doubl
   const double *svR = svL + (size_t)nv * nx;
   const double *areaT = gm(G, d, MOM6X_G_areaT), *mC = gm(G, d, MOM6X_G_mask2dCv);
   const size_t col = ix3(d, i, 0, k), col2 = ix2(d, i, 0);
-  auto row2 = [&](int r) -> size_t { return col2 + (size_t)((long)min(max(r, -d.halo), d.nj + d.halo) * st); };   // clamped 2-D address
-  // old values of row r of the column: own rows from the arrays, the others from the saved copy
-  auto oldT = [&](int m, int r) -> double {
-    if (r < R0) return svL[(size_t)SaveIdx::T(m, r - (R0 - 3)) * nx];
-    if (r > R1) return svR[(size_t)SaveIdx::T(m, 3 + (r - R1 - 1)) * nx];
-    return Tr.t[m][col + (size_t)((long)r * st)];
+  auto row2 = [&](int q) -> size_t { return col2 + (size_t)((long)min(max(q, -d.halo), d.nj + d.halo) * st); };   // clamped 2-D address
+  auto row3 = [&](int q) -> size_t { return col + (size_t)((long)q * st); };
+  __shared__ double sT[MAXT][YG][YP];                // old tracer values, rows Jb-2 .. Jb+YR+2
+  __shared__ double s_h[YG][YP], s_v[YG][YP], s_a[YG][YP];   // volumes / areas of the rows Jb .. Jb+YR, transports of the faces Jb-1 .. Jb+YR
+  __shared__ double s_m[YG][YP];                     // masks of the faces Jb-2 .. Jb+YR+1
+  __shared__ double s_uhh[YR + 2][YP], s_F[MAXT][YR + 2][YP];   // row q+1 <-> face Jb+q; rows 0 and YR+1 in turn <-> the last face of the block before
+  auto slot = [](int x) { x = (x >= 2 * YG) ? x - 2 * YG : x; return (x >= YG) ? x - YG : x; };   // x mod YG for 0 <= x < 3 YG
+  auto nxt = [](int s) { return (s + 1 == YG) ? 0 : s + 1; };
+
+  // what a thread holds of the block after this one between its loads and their hand-over to LDS
+  double rT[MAXT], r_h = 0., r_v = 0., r_a = 0., r_m = 0.;
+#pragma unroll
+  for (int m = 0; m < MAXT; m++) rT[m] = 0.;
+  auto load_block = [&](int JB) {
+    const int qT = JB + 3 + r, qH = JB + 1 + r, qM = JB + 2 + r;
+    if (qT >= R0 - 3 && qT <= R1 + 3) {
+#pragma unroll
+      for (int m = 0; m < MAXT; m++) if (m < ntr)
+        rT[m] = (qT < R0) ? svL[(size_t)SaveIdx::T(m, qT - (R0 - 3)) * nx]
+                          : ((qT > R1) ? svR[(size_t)SaveIdx::T(m, 3 + (qT - R1 - 1)) * nx] : Tr.t[m][row3(qT)]);
+    }
+    if (qH >= R0 - 2 && qH <= R1 + 1)
+      r_v = (qH < R0) ? svL[(size_t)SaveIdx::U(ntr, qH - (R0 - 2)) * nx] : ((qH > R1) ? svR[(size_t)SaveIdx::U(ntr, 2) * nx] : vhr[row3(qH)]);
+    if (qH >= R0 - 1 && qH <= R1 + 1) {
+      r_h = (qH < R0) ? svL[(size_t)SaveIdx::H(ntr, 0) * nx] : ((qH > R1) ? svR[(size_t)SaveIdx::H(ntr, 1) * nx] : hprev[row3(qH)]);
+      r_a = areaT[row2(qH)];
+    }
+    if (qM >= R0 - 3 && qM <= R1 + 2) r_m = mC[row2(qM)];
   };
-  auto oldH = [&](int r) -> double {
-    if (r < R0) return svL[(size_t)SaveIdx::H(ntr, 0) * nx];
-    if (r > R1) return svR[(size_t)SaveIdx::H(ntr, 1) * nx];
-    return hprev[col + (size_t)((long)r * st)];
-  };
-  auto oldV = [&](int r) -> double {     // face r (north face of cell r)
-    if (r < R0) return svL[(size_t)SaveIdx::U(ntr, r - (R0 - 2)) * nx];
-    if (r > R1) return svR[(size_t)SaveIdx::U(ntr, 2) * nx];
-    return vhr[col + (size_t)((long)r * st)];
-  };
-  // windows for the face J between the cells J and J+1: Tw = T(J-2 .. J+3), mw = mask of the faces J-2 .. J+2
-  double Tw[MAXT][6], mw[5];
-  int J = R0 - 1;
+
+  int sJb = 0, cr = 0;                               // the ring slot of row Jb; the row of s_uhh / s_F that holds the block before's last face
+  load_block(R0 - 1 - YR);
+  for (int Jb = R0 - 1 - YR; Jb <= R1; Jb += YR, sJb = slot(sJb + YR), cr = YR + 1 - cr) {
+    // ---- hand the new rows over to LDS
+    {
+      const int qT = Jb + 3 + r, qH = Jb + 1 + r, qM = Jb + 2 + r;
+      if (qT >= R0 - 3 && qT <= R1 + 3) {
+        const int s = slot(sJb + 3 + r + YG);
 #pragma unroll
-  for (int m = 0; m < MAXT; m++)
+        for (int m = 0; m < MAXT; m++) if (m < ntr) sT[m][s][c] = rT[m];
+      }
+      const int sH = slot(sJb + 1 + r + YG);
+      if (qH >= R0 - 2 && qH <= R1 + 1) s_v[sH][c] = r_v;
+      if (qH >= R0 - 1 && qH <= R1 + 1) { s_h[sH][c] = r_h; s_a[sH][c] = r_a; }
+      if (qM >= R0 - 3 && qM <= R1 + 2) s_m[slot(sJb + 2 + r + YG)][c] = r_m;
+    }
+    __syncthreads();
+    if (Jb + YR <= R1) load_block(Jb + YR);          // ... and ask for the next block's while this one is worked on
+    if (Jb < R0 - 1) continue;                        // (the staging block)
+    // ---- face J = Jb + r from the old values
+    const int J = Jb + r;
+    const bool face_on = (J <= R1);
+    const int sj = slot(sJb + r + YG);               // the slot of row J
+    double uhh = 0.0, Fl[MAXT], Tc[MAXT], h_m = 0., a_m = 0.;
 #pragma unroll
-    for (int q = 0; q < 6; q++) Tw[m][q] = (m < ntr) ? oldT(m, J - 2 + q) : 0.0;
+    for (int m = 0; m < MAXT; m++) { Fl[m] = 0.0; Tc[m] = 0.0; }
+    if (face_on) {
+      const int sjm = slot(sJb + r - 1 + YG), sjp = nxt(sj);
+      const double v_c = s_v[sj][c], a_p = s_a[sjp][c];
+      h_m = s_h[sj][c]; a_m = s_a[sj][c];
+      if (dm[k * nrows + J + d.joff]) {     // a row of faces that is not being worked on moves nothing (:1065-1067)
+        double CFL;
+        if (limited_transport(v_c, s_v[sjm][c], s_v[sjp][c], h_m, s_h[sjp][c], a_m, a_p, min_h, uhh, CFL) && col_on) lim[k * nrows + J + d.joff] = 1;
+        const bool pos = (uhh >= 0.0);
+        int su[5];                                   // slots of the rows up-2 .. up+2 (up = the upwind cell: J or J+1)
+        su[0] = slot(sJb + r - 2 + (pos ? 0 : 1) + YG);
 #pragma unroll
-  for (int q = 0; q < 5; q++) mw[q] = mC[row2(J - 2 + q)];
-  double h_m = oldH(J), h_p = oldH(J + 1);                       // volumes of the cells J, J+1
-  double v_m = oldV(J - 1), v_c = oldV(J), v_p = oldV(J + 1);    // transports of the faces J-1, J, J+1
-  double a_m = areaT[row2(J)], a_p = areaT[row2(J + 1)];
-  double uhh_prev = 0.0, F_prev[MAXT];
+        for (int q = 1; q < 5; q++) su[q] = nxt(su[q - 1]);
+        const double mk[4] = {s_m[su[0]][c], s_m[su[1]][c], s_m[su[2]][c], s_m[su[3]][c]};   // faces up-2 .. up+1
 #pragma unroll
-  for (int m = 0; m < MAXT; m++) F_prev[m] = 0.0;
-  for (; J <= R1; J++) {
-    // ---- face J from the old values
-    double uhh = 0.0, Fl[MAXT];
+        for (int m = 0; m < MAXT; m++) if (m < ntr) {
+          const double T5[5] = {sT[m][su[0]][c], sT[m][su[1]][c], sT[m][su[2]][c], sT[m][su[3]][c], sT[m][su[4]][c]};
+          Fl[m] = face_flux5(Tr.scheme[m], T5, mk, uhh, CFL);
+        }
+      }
 #pragma unroll
-    for (int m = 0; m < MAXT; m++) Fl[m] = 0.0;
-    if (dm[k * nrows + J + d.joff]) {     // a row of faces that is not being worked on moves nothing (:1065-1067)
-      double CFL;
-      if (limited_transport(v_c, v_m, v_p, h_m, h_p, a_m, a_p, min_h, uhh, CFL)) lim[k * nrows + J + d.joff] = 1;
-      const bool pos = (uhh >= 0.0);
-      const double mk[4] = {pos ? mw[0] : mw[1], pos ? mw[1] : mw[2], pos ? mw[2] : mw[3], pos ? mw[3] : mw[4]};
+      for (int m = 0; m < MAXT; m++) if (m < ntr) Tc[m] = sT[m][sj][c];
+      // the face's remaining transport (every face, :1073-1076); the first face of a segment belongs to the segment before it
+      if (col_on && (J >= R0 || n == 0)) {
+        double rr = v_c - uhh;
+        const double neglect = H_subroundoff * dmin(a_m, a_p);
+        if (fabs(rr) < neglect) rr = 0.0;
+        vhr[row3(J)] = rr;
+      }
+      s_uhh[r + 1][c] = uhh;
 #pragma unroll
-      for (int m = 0; m < MAXT; m++) if (m < ntr) {
-        const double T5[5] = {pos ? Tw[m][0] : Tw[m][1], pos ? Tw[m][1] : Tw[m][2], pos ? Tw[m][2] : Tw[m][3],
-                              pos ? Tw[m][3] : Tw[m][4], pos ? Tw[m][4] : Tw[m][5]};
-        Fl[m] = face_flux5(Tr.scheme[m], T5, mk, uhh, CFL);
+      for (int m = 0; m < MAXT; m++) if (m < ntr) s_F[m][r + 1][c] = Fl[m];
+      if (r == YR - 1) {                              // ... and for the first cell of the next block (which reads the other row)
+        s_uhh[YR + 1 - cr][c] = uhh;
+#pragma unroll
+        for (int m = 0; m < MAXT; m++) if (m < ntr) s_F[m][YR + 1 - cr][c] = Fl[m];
       }
     }
-    // ---- the face's remaining transport (every face, :1073-1076); the first face of a segment belongs to the segment before it
-    const size_t c = col + (size_t)((long)J * st);
-    if (J >= R0 || n == 0) {
-      double r = v_c - uhh;
-      const double neglect = H_subroundoff * dmin(a_m, a_p);
-      if (fabs(r) < neglect) r = 0.0;
-      vhr[c] = r;
-    }
+    __syncthreads();
     // ---- cell J (between the faces J-1 and J)
-    if (J >= R0 && ((uhh != 0.0) || (uhh_prev != 0.0))) {
-      double hp, hlst, Ihnew;
-      const bool upd = cell_update<1>(uhh, uhh_prev, h_m, a_m, h_neglect, hp, hlst, Ihnew);
-      hprev[c] = hp;
-      if (upd) {
+    if (face_on && col_on && J >= R0) {
+      const int rm = (r == 0) ? cr : r;
+      const double uh_m = s_uhh[rm][c];
+      if ((uhh != 0.0) || (uh_m != 0.0)) {
+        double hp, hlst, Ihnew;
+        const bool upd = cell_update<1>(uhh, uh_m, h_m, a_m, h_neglect, hp, hlst, Ihnew);
+        const size_t cc = row3(J);
+        hprev[cc] = hp;
+        if (upd) {
 #pragma unroll
-        for (int m = 0; m < MAXT; m++) if (m < ntr) Tr.t[m][c] = (Tw[m][2] * hlst - (Fl[m] - F_prev[m])) * Ihnew;
+          for (int m = 0; m < MAXT; m++) if (m < ntr) Tr.t[m][cc] = (Tc[m] * hlst - (Fl[m] - s_F[m][rm][c])) * Ihnew;
+        }
       }
     }
-    // ---- shift the windows to the face J+1
-    uhh_prev = uhh;
-#pragma unroll
-    for (int m = 0; m < MAXT; m++) F_prev[m] = Fl[m];
-    if (J < R1) {
-#pragma unroll
-      for (int m = 0; m < MAXT; m++) {
-#pragma unroll
-        for (int q = 0; q < 5; q++) Tw[m][q] = Tw[m][q + 1];
-        Tw[m][5] = (m < ntr) ? oldT(m, J + 4) : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++) mw[q] = mw[q + 1];
-      mw[4] = mC[row2(J + 3)];
-      h_m = h_p; h_p = oldH(J + 2);
-      v_m = v_c; v_c = v_p; v_p = oldV(J + 2);
-      a_m = a_p; a_p = areaT[row2(J + 2)];
-    }
+    // (no barrier here: the cells read registers and s_uhh / s_F only, which nobody writes before the next two barriers; every ring
+    //  row the next hand-over overwrites was last read by the faces, before the barrier above)
   }
 }
 
@@ -827,10 +893,10 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
       int rc = need_save((size_t)nz * (nseg + 1) * nv * nx); if (rc) return rc;
       KLAUNCH(c, "k_ta_save_y", k_ta_save_y, dim3(gx, nseg + 1, nz), dim3(256), d, (const double *)s->vhr, (const double *)s->hprev, Tr,
               (const int *)s->dmk, s->save, i0, i1, j0, j1, nseg);
-#define YM(M) KLAUNCH(c, "k_ta_y_march", k_ta_y_march<M>, dim3(gx, nseg, nz), dim3(256), d, c->G, s->vhr, s->hprev, Tr, (const int *)s->dmv, \
-                      s->limv, (const int *)s->dmk, (const double *)s->save, min_h, h_neglect, c->GV.H_subroundoff, i0, i1, j0, j1, nseg)
-      if (ntr <= 1) YM(1); else if (ntr <= 2) YM(2); else if (ntr <= 4) YM(4); else YM(8);
-#undef YM
+#define YT(M, C) KLAUNCH(c, "k_ta_y_tile", (k_ta_y_tile<M, C>), dim3((nxa(nx, i0) + C - 1) / C, nseg, nz), dim3(C * YR), d, c->G, s->vhr, s->hprev, Tr, \
+                         (const int *)s->dmv, s->limv, (const int *)s->dmk, (const double *)s->save, min_h, h_neglect, c->GV.H_subroundoff, i0, i1, j0, j1, nseg)
+      if (ntr <= 2) YT(2, YCW); else if (ntr <= 4) YT(4, YCW); else YT(8, 16);
+#undef YT
       KLAUNCH(c, "k_ta_flag_commit", k_ta_flag_commit, dim3((j1 - (j0 - 1) + 64) / 64, nz), dim3(64), d, s->dmv, s->limv, (const int *)s->dmk, j0 - 1, j1);
     }
     return MOM6X_OK;

@@ -5,7 +5,9 @@ sub = sys.argv[2] if len(sys.argv) > 2 else ""
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
 for f in glob.glob("gpurun_out/%s*/**/*counter_collection.csv" % pre, recursive=True):
     for r in csv.DictReader(open(f)):
-        k = re.search(r"k_\w+(<[^>]*>)?", r["Kernel_Name"]).group(0)
+        mk = re.search(r"k_\w+(<[^>]*>)?", r["Kernel_Name"])
+        if not mk: continue
+        k = mk.group(0)
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 for k in acc:
     if sub in k:

@@ -1,5 +1,5 @@
 """Per-kernel timing of advect_tracer / tridiagonal solvers at a chosen size (dev tool)."""
-import sys, time
+import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from mom6_amd import abi, grid, synth_dev
@@ -14,11 +14,13 @@ GV = abi.vgrid_default()
 dyc = Dycore(d, M, GV, 0)
 dyc.continuity_init(abi.continuity_params_default(nk, GV.Angstrom_H))
 Md = dyc.to_dev(M)
-h, u, v = synth_dev.make_state(d, Md, u_max=0.05, h_pert=0.001)
+h, u, v = synth_dev.make_state(d, Md, u_max=float(os.environ.get("PROF_UMAX", "0.05")), h_pert=float(os.environ.get("PROF_HPERT", "0.001")))   # (bench.py: 0.5, 0.01)
 hp, uh, vh = (dyc.zeros3() for _ in range(3))
 dt = 900.0
 dyc.continuity_PPM(u, v, h, hp, uh, vh, dt)
-uhtr = (uh * (2 * dt)).contiguous(); vhtr = (vh * (2 * dt)).contiguous()
+dyc.sync()   # (the dycore has its own stream: what follows runs on torch's)
+ndt = float(os.environ.get("PROF_NDT", "2"))   # dynamics steps the transports have accumulated over (bench.py: 4)
+uhtr = (uh * (ndt * dt)).contiguous(); vhtr = (vh * (ndt * dt)).contiguous()
 dyc.tracer_advect_init(dt, scheme=2)
 tr0 = [(10.0 + 5.0 * synth_dev.smooth_field(d, dyc.device, 71 + m, nk=nk, ox=0.5, oy=0.5)).contiguous() for m in range(ntr)]
 for rep in range(3):
@@ -27,7 +29,7 @@ for rep in range(3):
     if rep == 2:
         prof_enable(dyc, True); prof_reset(dyc)
     t0 = time.perf_counter()
-    it = dyc.advect_tracer(hp, uhtr, vhtr, 2 * dt, tr)
+    it = dyc.advect_tracer(hp, uhtr, vhtr, ndt * dt, tr)
     dyc.sync(); t1 = time.perf_counter()
     print("advect_tracer rep", rep, "iters", it, "ms", (t1 - t0) * 1e3, flush=True)
 rep = prof_report(dyc); prof_enable(dyc, False)

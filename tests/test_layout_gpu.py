@@ -168,6 +168,7 @@ def _tile_layout_gives_the_one_tile_answer(cfg_name, layout, rich, halo=4, bt_ti
             mine = r[n][(Ellipsis,) + tuple(d.sl(i0, d.ni - 1, j0, d.nj - 1))]
             part = whole[n][(Ellipsis,) + tuple(d1.sl(d.i_glob0 + i0, d.i_glob0 + d.ni - 1, d.j_glob0 + j0, d.j_glob0 + d.nj - 1))]
             H.assert_bitwise(mine, part, f"{cfg_name} {layout} tile {pe}: {n}")
+            assert np.isfinite(mine).all(), (cfg_name, layout, pe, n)      # (MOM6X_POISON_HALO: equal bits must not be equal NaNs)
 
 
 @pytest.mark.parametrize("layout", ["4 2", "2 2", "2 1"])

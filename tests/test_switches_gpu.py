@@ -23,6 +23,7 @@ CASES = [
     ("MOM6X_MFW_SPEC", "0", "test_rk2_gpu.py", "75_layers_on_chip"),
     ("MOM6X_VERTVISC", "walk", "test_rk2_gpu.py", "75_layers_on_chip"),                 # the column solve through HBM at nk = 75
     ("MOM6X_PASS_WIDTHS", "full", "test_layout_gpu.py", "tile_layout_gives"),           # NIHALO rows in every group pass of the step
+    ("MOM6X_POISON_HALO", "1", "test_layout_gpu.py", "tile_layout_gives"),              # NaNs in the halo rows beyond the width of each narrow pass
     ("MOM6X_BC_ACCEL", "own", "test_rk2_gpu.py", "double_gyre_bitexact or 75_layers_on_chip"),      # k_bc_accel instead of the fold into k_pgf_main
     ("MOM6X_BT_MASS_SOURCE", "own", "test_rk2_gpu.py", "double_gyre_bitexact or 75_layers_on_chip"),
     ("MOM6X_HV_KC", "25", "test_horvisc_gpu.py", ""),                                   # 25-layer chunks of k_hv_fused

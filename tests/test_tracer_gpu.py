@@ -11,8 +11,8 @@ G = abi.G
 
 @pytest.fixture(autouse=True, params=["tiled", "legacy"])
 def tracer_path(request, monkeypatch):
-    """Every case runs on both device paths: one kernel per direction and pass (x: LDS tiles, y: a march along j with a
-    register window; the default) and the face + cell kernel pairs (MOM6X_TRACER=legacy).  Both must equal the oracle."""
+    """Every case runs on both device paths: one kernel per direction and pass (LDS tiles in x, LDS rings of rows in y; the
+    default) and the face + cell kernel pairs (MOM6X_TRACER=legacy).  Both must equal the oracle."""
     monkeypatch.setenv("MOM6X_TRACER", request.param)
     return request.param
 
