@@ -171,6 +171,7 @@ module mom6x_c_api
   type, bind(C) :: mom6x_rk2_params        !< MOM_dyn_split_RK2_CS (MOM_dynamics_split_RK2.F90:85-273)
     real(c_double) :: be, begw
     integer(c_int) :: split_bottom_stress, BT_use_layer_fluxes, store_CAu, visc_rem_dt_bug, remap_aux
+    integer(c_int) :: no_BT_cont = 0   !< 1: USE_BT_CONT_TYPE = False
   end type mom6x_rk2_params
 
   type, bind(C) :: mom6x_rk2_hooks         !< host callbacks for the un-ported callees (SURVEY 8f)

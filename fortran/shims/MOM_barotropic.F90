@@ -37,6 +37,7 @@ implicit none ; private
 public :: btcalc, bt_mass_source, btstep, barotropic_init, barotropic_end
 public :: register_barotropic_restarts, set_dtbt, barotropic_get_tav
 public :: barotropic_refresh_restart_mirrors   ! addition (see the header)
+public :: barotropic_uses_BT_cont_type         ! addition: USE_BT_CONT_TYPE as barotropic_init read it (the reference tells its caller by allocating BT_cont)
 
 type, public :: barotropic_CS ; private
   logical :: module_is_initialized = .false.
@@ -46,6 +47,7 @@ type, public :: barotropic_CS ; private
   real, allocatable, dimension(:,:) :: ubtav, vbtav
   real :: dtbt = 0.0
   logical :: restarted = .false.     !< the mirrors came from a restart file
+  logical :: use_BT_cont_type = .true.   !< USE_BT_CONT_TYPE (:5407)
 end type barotropic_CS
 
 integer :: id_clock_sync = -1, id_clock_calc = -1
@@ -285,7 +287,12 @@ subroutine barotropic_init(u, v, h, Time, G, GV, US, param_file, diag, CS, &
   CS%p%nonlin_cont_update_period = int(min_stencil, c_int)
   ! (the barotropic domain's halo on the device is the tile context's: shim_ctx makes it G's, so BTHALO > NIHALO is refused by
   !  mom6x_barotropic_init with the instruction to widen the context; the answers do not depend on it)
-  call must_be("USE_BT_CONT_TYPE", .true.) ; call must_be("INTEGRAL_BT_CONTINUITY", .false.)
+  call get_param(param_file, mdl, "USE_BT_CONT_TYPE", CS%use_BT_cont_type, "If true, use a structure with elements that describe "//&
+                 "effective face areas from the summed continuity solver as a function the barotropic flow in coupling between "//&
+                 "the barotropic and baroclinic flow.  This is only used if SPLIT is true.", default=.true.)
+  if (.not.CS%use_BT_cont_type .and. CS%p%bound_BT_corr /= 0) call MOM_error(FATAL, "barotropic_init: BOUND_BT_CORRECTION "//&
+      "without a BT_cont_type is not carried by the MI355X path.")
+  call must_be("INTEGRAL_BT_CONTINUITY", .false.)
   call must_be("ADJUST_BT_CONT", .false.) ; call must_be("GRADUAL_BT_ICS", .false.)
   call must_be("BT_NONLIN_STRESS", .false.) ; call must_be("DYNAMIC_SURFACE_PRESSURE", .false.)
   call must_be("BT_LINEAR_WAVE_DRAG", .false.) ; call must_be("LINEARIZED_BT_CORIOLIS", .true.)
@@ -329,6 +336,12 @@ contains
     if (val .neqv. default) call MOM_error(FATAL, "barotropic_init: "//trim(name)//" is not carried by the MI355X path.")
   end subroutine must_be
 end subroutine barotropic_init
+
+!> USE_BT_CONT_TYPE as barotropic_init read it: step_MOM_dyn_split_RK2 runs without a BT_cont_type when it is false
+logical function barotropic_uses_BT_cont_type(CS)
+  type(barotropic_CS), intent(in) :: CS
+  barotropic_uses_BT_cont_type = CS%use_BT_cont_type
+end function barotropic_uses_BT_cont_type
 
 !> barotropic_get_tav (:6193): the time-mean barotropic velocities (MOM_hor_visc uses them with its bounds on the viscosity)
 subroutine barotropic_get_tav(CS, ubtav, vbtav, G, US)

@@ -27,7 +27,7 @@ use mom6x_host
 use mom6x_shim_ctx
 use MOM_ALE,               only : ALE_CS
 use MOM_barotropic,        only : barotropic_init, barotropic_CS, register_barotropic_restarts, barotropic_end
-use MOM_barotropic,        only : barotropic_refresh_restart_mirrors
+use MOM_barotropic,        only : barotropic_refresh_restart_mirrors, barotropic_uses_BT_cont_type
 use MOM_continuity_PPM,    only : continuity_init=>continuity_PPM_init, continuity_stencil=>continuity_PPM_stencil
 use MOM_continuity_PPM,    only : continuity_CS=>continuity_PPM_CS
 use MOM_CoriolisAdv,       only : CoriolisAdv_init, CoriolisAdv_end, CoriolisAdv_CS
@@ -387,6 +387,7 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   call vertvisc_init(MIS, Time, G, GV, US, param_file, diag, Accel_diag, dirs, ntrunc, CS%vertvisc_CSp)
   call barotropic_init(u, v, h, Time, G, GV, US, param_file, diag, CS%barotropic_CSp, restart_CS, calc_dtbt, CS%BT_cont, &
                        CS%OBC)
+  rk2%no_BT_cont = merge(0_c_int, 1_c_int, barotropic_uses_BT_cont_type(CS%barotropic_CSp))   ! (:467-469: associated(CS%BT_cont))
   rc = mom6x_initialize_dyn_split_RK2(CS%ctx, rk2) ; call shim_check(rc, "initialize_dyn_split_RK2")
 
   ! ---- the arrays other modules reach by pointer (:1512-1534): host mirrors of the device's, refreshed by refresh_host_mirrors

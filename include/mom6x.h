@@ -311,6 +311,9 @@ typedef struct mom6x_rk2_params {
   int    store_CAu;            /* STORE_CORIOLIS_ACCEL (T) -- only T supported                */
   int    visc_rem_dt_bug;      /* VISC_REM_TIMESTEP_BUG (T with ENABLE_BUGS_BY_DEFAULT)       */
   int    remap_aux;            /* REMAP_AUXILIARY_VARS (F): mom6x_remap_dyn_split_RK2_aux_vars */
+  int    no_BT_cont;           /* 1: USE_BT_CONT_TYPE = False (MOM_barotropic.F90 barotropic_init: CS%BT_cont stays unassociated) --
+                                * RK2.F90:467-469, :627, :644-652, :662-668, :867: btcalc from h (BT_THICK_SCHEME = HYBRID), the
+                                * continuity calls and both btstep calls without a BT_cont_type, set_dtbt with eta (ABI 5)    */
 } mom6x_rk2_params;
 
 /* ------------------------------------------------------------------------- */

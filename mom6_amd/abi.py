@@ -358,7 +358,8 @@ def layer_densities(nk, Rho0=1035.0, g_Earth=9.80, drho=2.0):
 class RK2Params(C.Structure):
     """mom6x_rk2_params; MOM_dyn_split_RK2_CS (MOM_dynamics_split_RK2.F90:85-273)."""
     _fields_ = [("be", C.c_double), ("begw", C.c_double), ("split_bottom_stress", C.c_int),
-                ("BT_use_layer_fluxes", C.c_int), ("store_CAu", C.c_int), ("visc_rem_dt_bug", C.c_int), ("remap_aux", C.c_int)]
+                ("BT_use_layer_fluxes", C.c_int), ("store_CAu", C.c_int), ("visc_rem_dt_bug", C.c_int), ("remap_aux", C.c_int),
+                ("no_BT_cont", C.c_int)]
 
 
 def rk2_params_default():
@@ -368,6 +369,7 @@ def rk2_params_default():
     p.split_bottom_stress = 0
     p.BT_use_layer_fluxes = p.store_CAu = p.visc_rem_dt_bug = 1
     p.remap_aux = 0
+    p.no_BT_cont = 0                                                   # USE_BT_CONT_TYPE = True
     return p
 
 

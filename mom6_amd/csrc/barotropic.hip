@@ -202,7 +202,7 @@ __global__ void k_bt_mass_source_from(Dm d, const double *__restrict__ eta_h, co
 __global__ void k_set_dtbt(Dm d, const double *__restrict__ G, const double *__restrict__ pbce,
                            const double *__restrict__ frhatu, const double *__restrict__ frhatv,
                            double gtot_est, double Z_to_H, double zadd, int add_max, double bebt, double cor_scale2,
-                           double *Idt_max2_out) {
+                           double *Idt_max2_out, const double *__restrict__ eta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
   const int st = d.pitch;
@@ -215,9 +215,10 @@ __global__ void k_set_dtbt(Dm d, const double *__restrict__ G, const double *__r
     DatuW = dy_Cu[c - 1] * Z_to_H * dmax(dmax(bathyT[c], bathyT[c - 1]) + zadd, 0.0);
     DatvN = dx_Cv[c] * Z_to_H * dmax(dmax(bathyT[c + st], bathyT[c]) + zadd, 0.0);
     DatvS = dx_Cv[c - st] * Z_to_H * dmax(dmax(bathyT[c], bathyT[c - st]) + zadd, 0.0);
-  } else {         // find_face_areas without eta / add_max :5221-5236 (zadd = G%Z_ref)
-    const double H0 = (bathyT[c] + zadd) * Z_to_H, HE = (bathyT[c + 1] + zadd) * Z_to_H, HW = (bathyT[c - 1] + zadd) * Z_to_H;
-    const double HN = (bathyT[c + st] + zadd) * Z_to_H, HS = (bathyT[c - st] + zadd) * Z_to_H;
+  } else {         // find_face_areas without eta / add_max :5221-5236 (zadd = G%Z_ref); with eta (NONLINEAR_BT_CONTINUITY) :5171-5186
+    auto Hc = [&](size_t x) { return eta ? (bathyT[x] * Z_to_H + eta[x]) : ((bathyT[x] + zadd) * Z_to_H); };
+    const double H0 = Hc(c), HE = Hc(c + 1), HW = Hc(c - 1);
+    const double HN = Hc(c + st), HS = Hc(c - st);
     DatuE = 0.0; if ((H0 > 0.0) && (HE > 0.0)) DatuE = dy_Cu[c] * (2.0 * H0 * HE) / (H0 + HE);
     DatuW = 0.0; if ((HW > 0.0) && (H0 > 0.0)) DatuW = dy_Cu[c - 1] * (2.0 * HW * H0) / (HW + H0);
     DatvN = 0.0; if ((H0 > 0.0) && (HN > 0.0)) DatvN = dx_Cv[c] * (2.0 * H0 * HN) / (H0 + HN);
@@ -1066,16 +1067,21 @@ int bt_mass_source_from(mom6x_ctx *c, const double *eta_h, const double *eta, in
   return MOM6X_OK;
 }
 
-static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int add_max, double SSH_add, double *dtbt_out);
+static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int add_max, double SSH_add, double *dtbt_out, const double *eta);
 extern "C" int mom6x_set_dtbt(mom6x_ctx *c, const double *pbce, double gtot_est, double SSH_add, double *dtbt_out) {
-  return set_dtbt_impl(c, pbce, gtot_est, 1, SSH_add, dtbt_out);
+  return set_dtbt_impl(c, pbce, gtot_est, 1, SSH_add, dtbt_out, nullptr);
 }
 // set_dtbt(G, GV, US, CS, pbce, eta=eta) as called from step_MOM_dyn_split_RK2 :667
 extern "C" int mom6x_set_dtbt_pbce(mom6x_ctx *c, const double *pbce, double *dtbt_out) {
   REQUIRE(pbce, MOM6X_EINVAL, "set_dtbt: Either pbce or gtot_est must be present.");
-  return set_dtbt_impl(c, pbce, 0.0, 0, 0.0, dtbt_out);
+  return set_dtbt_impl(c, pbce, 0.0, 0, 0.0, dtbt_out, nullptr);
 }
-static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int add_max, double SSH_add, double *dtbt_out) {
+// ... and without a BT_cont_type: eta enters the face areas when NONLINEAR_BT_CONTINUITY is set (:3577-3578)
+int set_dtbt_eta(mom6x_ctx *c, const double *pbce, const double *eta) {
+  REQUIRE(pbce, MOM6X_EINVAL, "set_dtbt: Either pbce or gtot_est must be present.");
+  return set_dtbt_impl(c, pbce, 0.0, 0, 0.0, nullptr, (c && c->bt_init && c->bt.nonlinear_continuity) ? eta : nullptr);
+}
+static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int add_max, double SSH_add, double *dtbt_out, const double *eta) {
   REQUIRE(c && c->bt_init, MOM6X_EINVAL, "set_dtbt: Module MOM_barotropic must be initialized before it is used.");
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
@@ -1085,7 +1091,7 @@ static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int 
   double *tmp = s->work + (size_t)W_eta_pred * d.slab;   // scratch plane
   HIPCHK(hipMemsetAsync(tmp, 0, sizeof(double) * d.slab, c->stream));
   KLAUNCH(c, "k_set_dtbt", k_set_dtbt, grid3(d.ni, d.nj, 1, b), b, d, c->G, pbce, s->frhatu, s->frhatv, gtot_est,
-                     c->GV.Z_to_H, c->bt.Z_ref + SSH_add, add_max, c->bt.bebt, c->bt.BT_Coriolis_scale * c->bt.BT_Coriolis_scale, tmp);
+                     c->GV.Z_to_H, c->bt.Z_ref + SSH_add, add_max, c->bt.bebt, c->bt.BT_Coriolis_scale * c->bt.BT_Coriolis_scale, tmp, eta);
   HIPCHK(hipGetLastError());
   // min over the tile in the reference's (j outer, i inner) order is order-independent for min():
   std::vector<double> host((size_t)d.slab);

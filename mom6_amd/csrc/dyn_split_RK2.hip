@@ -345,6 +345,9 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   const dim3 b = blk2();
   const int nk = d.nk;
   const PassWidths PW = pass_widths(c);
+  // USE_BT_CONT_TYPE = False (R.no_BT_cont): CS%BT_cont is not associated -- BT_cont_BT_thick :467-469 is false, btcalc works from h :627,
+  // the continuity calls and the two btstep calls run without a BT_cont_type (MOM_barotropic.F90:845: find_face_areas)
+  const mom6x_BT_cont *BTp = R.no_BT_cont ? nullptr : &s->BT;
   double *u_av = s->u_av, *v_av = s->v_av, *h_av = s->h_av, *eta = s->eta;
   double *up = s->up, *vp = s->vp, *hp = s->hp, *u_bc = s->u_bc_accel, *v_bc = s->v_bc_accel;
   const double *taux_bot = R.split_bottom_stress ? s->taux_bot : nullptr;
@@ -400,6 +403,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   // the continuity call below run while it travels; continuity completes it before it touches a halo row
   startn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk }, { 0, PW.cont, PW.cont });   // :484-486
 
+  if (!BTp) { bt_defer_btcalc(c, false); CHK(mom6x_btcalc(c, h, nullptr, nullptr)); }   // :627-628 (BT_THICK_SCHEME = HYBRID)
   if (have_eta_h) CHK(bt_mass_source_from(c, s->eta_h, eta, 1));        // :629, with the sum k_pgf_main left
   else CHK(mom6x_bt_mass_source(c, h, eta, 1));
   // continuity(u, v, h, hp, uh_in, vh_in, dt, visc_rem_u, visc_rem_v, BT_cont)  :646
@@ -407,14 +411,16 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   c->cont_h_unused = true;
   {
     const int rc_c = mom6x_continuity_PPM(c, u_inst, v_inst, h, hp, s->uh_in, s->vh_in, dt, nullptr, nullptr, s->visc_rem_u, s->visc_rem_v,
-                                          nullptr, nullptr, &s->BT, nullptr, nullptr);
+                                          nullptr, nullptr, BTp, nullptr, nullptr);
     c->cont_h_unused = false;
     if (rc_c) return rc_c;
   }
   halo_complete(c);
-  bt_defer_btcalc(c, true);            // (the step's own btstep follows: its column pass forms the thickness fractions)
-  CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :649-652
-  if (calc_dtbt) CHK(mom6x_set_dtbt_pbce(c, s->pbce, nullptr));         // :659-668
+  if (BTp) {
+    bt_defer_btcalc(c, true);          // (the step's own btstep follows: its column pass forms the thickness fractions)
+    CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                      // :649-652
+  }
+  if (calc_dtbt) CHK(set_dtbt_eta(c, s->pbce, BTp ? nullptr : eta));    // :659-668 (eta matters with NONLINEAR_BT_CONTINUITY only)
   // predictor btstep :673-676.  accel_layer_u / _v are only read by the velocity estimates below: with the device's own
   // vertvisc_coef they are evaluated there (LayerAccelSrc) and never written; mom6x_rk2_field materialises them on request.
   const bool defer_la = dev_coef && !host_coef;
@@ -422,7 +428,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   s->accel_bt_deferred = defer_la;
   LayerAccelSrc LAu, LAv;
   CHK(mom6x_btstep(c, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, s->pbce, s->eta_PF, u_av, v_av, s->u_accel_bt,
-                   s->v_accel_bt, s->eta_pred, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, &s->BT, taux_bot, tauy_bot,
+                   s->v_accel_bt, s->eta_pred, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, BTp, taux_bot, tauy_bot,
                    s->uh_in, s->vh_in, u_inst, v_inst, nullptr));
 
   const double dt_pred = dt * R.be;                                     // :679
@@ -460,7 +466,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   //  hp in a register and reads nothing twice)
   c->cont_av_kind = 1; c->cont_av = h_av; c->cont_av_src = h;
   {
-    const int rc_c = mom6x_continuity_PPM(c, up, vp, h, hp, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av, &s->BT,
+    const int rc_c = mom6x_continuity_PPM(c, up, vp, h, hp, uh, vh, dt, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, u_av, v_av, BTp,
                                           nullptr, nullptr);
     c->cont_av_kind = 0;
     if (rc_c) return rc_c;
@@ -478,8 +484,10 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     KLAUNCH(c, "k_h_av", k_h_av, gridk(nxa(d.ni + 2, -1), d.nj + 2, nk, b), b, d, hp, (const double *)h, (const double *)nullptr, 3, R.begw, 1, 0);
     CHK(mom6x_PressureForce(c, hp, s->PFu, s->PFv, s->pbce, s->eta_PF));
   }
-  bt_defer_btcalc(c, true);
-  CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                        // :864-867
+  if (BTp) {
+    bt_defer_btcalc(c, true);
+    CHK(mom6x_btcalc(c, h, s->BT.h_u, s->BT.h_v));                      // :864-867
+  }
   if (hooks && hooks->horizontal_viscosity) {                           // :884-888
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = hooks->horizontal_viscosity(hooks->user, u_av, v_av, h_av, uh, vh, s->diffu, s->diffv);
@@ -491,7 +499,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   CHK(CorAdCalc_bc(c, u_av, v_av, h_av, uh, vh, s->CAu, s->CAv, s->PFu, s->PFv, s->diffu, s->diffv, u_bc, v_bc, nullptr, nullptr, 0.0));
   // corrector btstep :939-942
   CHK(mom6x_btstep(c, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, s->pbce, s->eta_PF, u_av, v_av, s->u_accel_bt,
-                   s->v_accel_bt, s->eta_pred, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, &s->BT, taux_bot, tauy_bot, uh, vh,
+                   s->v_accel_bt, s->eta_pred, s->uhbt, s->vhbt, s->visc_rem_u, s->visc_rem_v, BTp, taux_bot, tauy_bot, uh, vh,
                    u_av, v_av, eta_av));
   KLAUNCH(c, "k_eta", k_eta, grid3(d.ni, d.nj, 1, b), b, d, c->G, eta, (const double *)s->eta_pred, (const double *)nullptr, 0.0);   // :946
   // u = mask*(u + dt*(u_bc_accel + u_accel_bt))  :957-966

@@ -165,6 +165,7 @@ struct LayerAccelSrc {
   double underflow;        // accel_underflow = vel_underflow / dt
 };
 int bt_mass_source_from(mom6x_ctx *c, const double *eta_h, const double *eta, int set_cor);   // bt_mass_source with the column sum given
+int set_dtbt_eta(mom6x_ctx *c, const double *pbce, const double *eta);      // barotropic.hip: set_dtbt(pbce, eta=eta) RK2.F90:667
 void bt_defer_btcalc(mom6x_ctx *c, bool on);                            // barotropic.hip: btcalc's fractions formed by btstep's column pass while on
 int bt_frhat_materialize(mom6x_ctx *c);                                 // writes frhatu / frhatv if a deferred btcalc is pending
 void bt_defer_layer_accel(mom6x_ctx *c, bool on);                       // barotropic.hip: btstep skips k_layer_accel while on

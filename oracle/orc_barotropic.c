@@ -177,7 +177,7 @@ int orc_bt_mass_source(const mom6x_dims *d, const double *G, const mom6x_vgrid *
 /* set_dtbt :3509-3633 without BT_cont: find_face_areas(add_max=SSH_add) :5208-5219. */
 static int orc_set_dtbt_ex(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
                  const mom6x_barotropic_params *P, const orc_bt_cs *CS, const double *pbce,
-                 double gtot_est, int use_add_max, double SSH_add, double *dtbt, double *dtbt_max_out) {
+                 double gtot_est, int use_add_max, double SSH_add, double *dtbt, double *dtbt_max_out, const double *eta) {
   const double *bathyT = GM(G, d, MOM6X_G_bathyT), *dy_Cu = GM(G, d, MOM6X_G_dy_Cu), *dx_Cv = GM(G, d, MOM6X_G_dx_Cv);
   const double *IareaT = GM(G, d, MOM6X_G_IareaT), *IdxCu = GM(G, d, MOM6X_G_IdxCu), *IdyCv = GM(G, d, MOM6X_G_IdyCv);
   const double *f2 = GM(G, d, MOM6X_G_Coriolis2Bu);
@@ -188,8 +188,9 @@ static int orc_set_dtbt_ex(const mom6x_dims *d, const double *G, const mom6x_vgr
     size_t c = IX2(d, i, j);
     if (use_add_max) {
       Datu[c] = dy_Cu[c] * GV->Z_to_H * orc_max(orc_max(bathyT[c + 1], bathyT[c]) + (P->Z_ref + SSH_add), 0.0);
-    } else { /* find_face_areas without eta/add_max :5221-5236 */
+    } else { /* find_face_areas without eta/add_max :5221-5236; with eta (NONLINEAR_BT_CONTINUITY, Boussinesq) :5171-5186 */
       double H1 = (bathyT[c] + P->Z_ref) * GV->Z_to_H, H2 = (bathyT[c + 1] + P->Z_ref) * GV->Z_to_H;
+      if (eta) { H1 = bathyT[c] * GV->Z_to_H + eta[c]; H2 = bathyT[c + 1] * GV->Z_to_H + eta[c + 1]; }
       Datu[c] = 0.0;
       if ((H1 > 0.0) && (H2 > 0.0)) Datu[c] = dy_Cu[c] * (2.0 * H1 * H2) / (H1 + H2);
     }
@@ -200,6 +201,7 @@ static int orc_set_dtbt_ex(const mom6x_dims *d, const double *G, const mom6x_vgr
       Datv[c] = dx_Cv[c] * GV->Z_to_H * orc_max(orc_max(bathyT[c + st], bathyT[c]) + (P->Z_ref + SSH_add), 0.0);
     } else {
       double H1 = (bathyT[c] + P->Z_ref) * GV->Z_to_H, H2 = (bathyT[c + st] + P->Z_ref) * GV->Z_to_H;
+      if (eta) { H1 = bathyT[c] * GV->Z_to_H + eta[c]; H2 = bathyT[c + st] * GV->Z_to_H + eta[c + st]; }
       Datv[c] = 0.0;
       if ((H1 > 0.0) && (H2 > 0.0)) Datv[c] = dx_Cv[c] * (2.0 * H1 * H2) / (H1 + H2);
     }
@@ -236,14 +238,22 @@ static int orc_set_dtbt_ex(const mom6x_dims *d, const double *G, const mom6x_vgr
 int orc_set_dtbt(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
                  const mom6x_barotropic_params *P, const orc_bt_cs *CS, const double *pbce,
                  double gtot_est, double SSH_add, double *dtbt, double *dtbt_max_out) {
-  return orc_set_dtbt_ex(d, G, GV, P, CS, pbce, gtot_est, 1, SSH_add, dtbt, dtbt_max_out);
+  return orc_set_dtbt_ex(d, G, GV, P, CS, pbce, gtot_est, 1, SSH_add, dtbt, dtbt_max_out, NULL);
 }
 /* set_dtbt(G, GV, US, CS, pbce, eta=eta) as called from step_MOM_dyn_split_RK2 :667 (eta unused because
  * NONLINEAR_BT_CONTINUITY is false with BT_cont): updates P->dtbt. */
 int orc_set_dtbt_pbce(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, mom6x_barotropic_params *P,
                       const orc_bt_cs *CS, const double *pbce) {
   double dtbt = 0.0;
-  int rc = orc_set_dtbt_ex(d, G, GV, P, CS, pbce, 0.0, 0, 0.0, &dtbt, NULL);
+  int rc = orc_set_dtbt_ex(d, G, GV, P, CS, pbce, 0.0, 0, 0.0, &dtbt, NULL, NULL);
+  if (rc == MOM6X_OK) P->dtbt = dtbt;
+  return rc;
+}
+/* ... without a BT_cont_type: eta enters the face areas when NONLINEAR_BT_CONTINUITY is set (:3577-3578) */
+int orc_set_dtbt_pbce_eta(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, mom6x_barotropic_params *P,
+                          const orc_bt_cs *CS, const double *pbce, const double *eta) {
+  double dtbt = 0.0;
+  int rc = orc_set_dtbt_ex(d, G, GV, P, CS, pbce, 0.0, 0, 0.0, &dtbt, NULL, P->nonlinear_continuity ? eta : NULL);
   if (rc == MOM6X_OK) P->dtbt = dtbt;
   return rc;
 }

@@ -26,6 +26,8 @@ int orc_bt_mass_source(const mom6x_dims *d, const double *G, const mom6x_vgrid *
                        int set_cor, orc_bt_cs *CS);
 int orc_set_dtbt_pbce(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, mom6x_barotropic_params *P,
                       const orc_bt_cs *CS, const double *pbce);
+int orc_set_dtbt_pbce_eta(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, mom6x_barotropic_params *P,
+                          const orc_bt_cs *CS, const double *pbce, const double *eta);
 int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const mom6x_barotropic_params *P,
                orc_bt_cs *CS, int first_direction, const double *U_in, const double *V_in, const double *eta_in,
                double dt, const double *bc_accel_u, const double *bc_accel_v, const double *taux, const double *tauy,
@@ -164,6 +166,8 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   double *eta_pred = (double *)calloc(slab, sizeof(double));
   double *u_av = CS->u_av, *v_av = CS->v_av, *h_av = CS->h_av, *eta = CS->eta;
   if (!R->BT_use_layer_fluxes) return MOM6X_EUNSUPPORTED;
+  /* USE_BT_CONT_TYPE = False: CS%BT_cont is not associated (BT_cont_BT_thick :467-469 false) */
+  const mom6x_BT_cont *BTc = R->no_BT_cont ? NULL : A->BT_cont;
   const double *taux_bot = R->split_bottom_stress ? CS->taux_bot : NULL;
   const double *tauy_bot = R->split_bottom_stress ? CS->tauy_bot : NULL;
 
@@ -205,18 +209,19 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   orc_pass_var(d, eta, 0, 1); /* pass_eta :620 */
   orc_pass_var(d, CS->visc_rem_u, 1, nz); orc_pass_var(d, CS->visc_rem_v, 2, nz); /* pass_visc_rem :621 */
 
-  /* BT_cont_BT_thick is true (BT_cont%h_u, h_v allocated): btcalc is called after continuity :626-652 */
+  /* BT_cont_BT_thick true (BT_cont%h_u, h_v allocated): btcalc is called after continuity :649-652; false: from h :627-628 */
+  if (!BTc) orc_btcalc(d, G, GV, h, NULL, NULL, A->BTCS);
   orc_bt_mass_source(d, G, GV, h, eta, 1, A->BTCS);
   rc = orc_continuity_PPM(d, G, GV, A->cont, A->first_direction, u_inst, v_inst, h, hp, uh_in, vh_in, dt, NULL, NULL,
-                          CS->visc_rem_u, CS->visc_rem_v, NULL, NULL, A->BT_cont, NULL, NULL);
+                          CS->visc_rem_u, CS->visc_rem_v, NULL, NULL, BTc, NULL, NULL);   /* :644-648 (BT_USE_LAYER_FLUXES) */
   if (rc) return rc;
-  orc_btcalc(d, G, GV, h, A->BT_cont->h_u, A->BT_cont->h_v, A->BTCS);
-  if (calc_dtbt) { rc = orc_set_dtbt_pbce(d, G, GV, A->bt, A->BTCS, CS->pbce); if (rc) return rc; } /* :659-668 */
+  if (BTc) orc_btcalc(d, G, GV, h, BTc->h_u, BTc->h_v, A->BTCS);
+  if (calc_dtbt) { rc = orc_set_dtbt_pbce_eta(d, G, GV, A->bt, A->BTCS, CS->pbce, BTc ? NULL : eta); if (rc) return rc; } /* :659-668 */
 
   /* predictor btstep :673-676 */
   rc = orc_btstep(d, G, GV, A->bt, A->BTCS, A->first_direction, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy,
                   CS->pbce, CS->eta_PF, u_av, v_av, CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt,
-                  CS->visc_rem_u, CS->visc_rem_v, A->BT_cont, taux_bot, tauy_bot, uh_in, vh_in, u_inst, v_inst, NULL, NULL);
+                  CS->visc_rem_u, CS->visc_rem_v, BTc, taux_bot, tauy_bot, uh_in, vh_in, u_inst, v_inst, NULL, NULL);
   if (rc) return rc;
 
   const double dt_pred = dt * R->be; /* :679 */
@@ -242,7 +247,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
 
   /* uh = u_av * h ; hp = h + dt * div . uh  :779-781 */
   rc = orc_continuity_PPM(d, G, GV, A->cont, A->first_direction, up, vp, h, hp, uh, vh, dt, CS->uhbt, CS->vhbt,
-                          CS->visc_rem_u, CS->visc_rem_v, u_av, v_av, A->BT_cont, NULL, NULL);
+                          CS->visc_rem_u, CS->visc_rem_v, u_av, v_av, BTc, NULL, NULL);
   if (rc) return rc;
   orc_pass_var(d, hp, 0, nz); orc_pass_var(d, u_av, 1, nz); orc_pass_var(d, v_av, 2, nz);   /* pass_hp_uv :785 */
   orc_pass_var(d, uh, 1, nz); orc_pass_var(d, vh, 2, nz);
@@ -262,7 +267,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
     rc = orc_PressureForce_FV_Bouss(d, G, GV, A->pgf, A->Rlay, A->g_prime, hp, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF, A->T, A->S, A->eos);
     if (rc) return rc;
   }
-  orc_btcalc(d, G, GV, h, A->BT_cont->h_u, A->BT_cont->h_v, A->BTCS); /* :864-867 */
+  if (BTc) orc_btcalc(d, G, GV, h, BTc->h_u, BTc->h_v, A->BTCS); /* :864-867 */
 
   /* diffu = horizontal viscosity terms (u_av) :884-888 -> replaced arrays, if supplied */
   if (diffu_new) memcpy(CS->diffu, diffu_new, n3 * sizeof(double));
@@ -288,7 +293,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   /* corrector btstep :939-942 */
   rc = orc_btstep(d, G, GV, A->bt, A->BTCS, A->first_direction, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy,
                   CS->pbce, CS->eta_PF, u_av, v_av, CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt,
-                  CS->visc_rem_u, CS->visc_rem_v, A->BT_cont, taux_bot, tauy_bot, uh, vh, u_av, v_av, eta_av, NULL);
+                  CS->visc_rem_u, CS->visc_rem_v, BTc, taux_bot, tauy_bot, uh, vh, u_av, v_av, eta_av, NULL);
   if (rc) return rc;
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta[IX2(d, i, j)] = eta_pred[IX2(d, i, j)]; /* :946 */
 

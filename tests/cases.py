@@ -138,8 +138,9 @@ def shim_case_params(dt, tag_tree):
             "ENABLE_THERMODYNAMICS": "False", "MOM6X_CONTINUITY_SUMS": "TREE16" if tag_tree else "REFERENCE"}
 
 
-def oracle_shim_case(orc, cfg, nsteps=SHIM_NSTEPS):
-    """The oracle's run of the case above: (final state, OrcModel, inputs, visc inputs)."""
+def oracle_shim_case(orc, cfg, nsteps=SHIM_NSTEPS, no_bt_cont=False):
+    """The oracle's run of the case above: (final state, OrcModel, inputs, visc inputs).  no_bt_cont: the tc1-like variant
+    USE_BT_CONT_TYPE = False, NONLINEAR_BT_CONTINUITY = True."""
     from tests.test_dyn_gpu import visc_inputs
     gg, d, M = cfg
     inp = rk2_inputs(cfg, False, False)
@@ -147,5 +148,8 @@ def oracle_shim_case(orc, cfg, nsteps=SHIM_NSTEPS):
     vis = visc_inputs(d, M)
     hv = abi.hor_visc_params_default(inp["dt"])
     hv.Ah_vel_scale = 0.02; hv.Smagorinsky_Ah = 1; hv.Smag_bi_const = 0.06
-    so, m = oracle_rk2(orc, cfg, inp, nsteps, bt_mod=dict(strong_drag=1), vv=(P,) + tuple(vis) + (None, None), hv=hv)
+    bt_mod, rk2_mod = dict(strong_drag=1), None
+    if no_bt_cont:
+        bt_mod.update(nonlinear_continuity=1); rk2_mod = dict(no_BT_cont=1)
+    so, m = oracle_rk2(orc, cfg, inp, nsteps, bt_mod=bt_mod, rk2_mod=rk2_mod, vv=(P,) + tuple(vis) + (None, None), hv=hv)
     return so, m, inp, vis

@@ -82,16 +82,22 @@ def test_three_steps_driven_from_fortran(tmp_path):
 SHIM_DRIVER = os.path.join(ROOT, "tests", "fortran_stubs", "drive_shims")
 
 
-def _write_shim_case(path, cfg, orc):
+def _write_shim_case(path, cfg, orc, no_bt_cont=False):
     """The case of tests/fortran_stubs/drive_shims.F90: grid and state in Fortran extents, the MOM_input table, the
-    set_viscous_BBL fields, and the oracle's state after SHIM_NSTEPS steps (= the committed fixture, checked here)."""
+    set_viscous_BBL fields, and the oracle's state after SHIM_NSTEPS steps (= the committed fixture, checked here).
+    no_bt_cont: the same with USE_BT_CONT_TYPE = False, NONLINEAR_BT_CONTINUITY = True in the table (no fixture: the oracle's run)."""
     gg, d, M = cfg
-    so, m, inp, vis = cases.oracle_shim_case(orc, cfg)
-    gold = H.load_golden("rk2_double_gyre_shims_4steps")
-    for n in STATE:
-        H.assert_bitwise(so[n][(Ellipsis,) + tuple(H.interior(d, {"u": "u", "uh": "u", "uhtr": "u", "v": "v", "vh": "v", "vhtr": "v"}.get(n, "h")))],
-                         gold[n], "oracle vs committed fixture: " + n)
+    so, m, inp, vis = cases.oracle_shim_case(orc, cfg, no_bt_cont=no_bt_cont)
+    stg_of = {"u": "u", "uh": "u", "uhtr": "u", "v": "v", "vh": "v", "vhtr": "v"}
+    if no_bt_cont:
+        gold = {n: so[n][(Ellipsis,) + tuple(H.interior(d, stg_of.get(n, "h")))] for n in STATE}
+    else:
+        gold = H.load_golden("rk2_double_gyre_shims_4steps")
+        for n in STATE:
+            H.assert_bitwise(so[n][(Ellipsis,) + tuple(H.interior(d, stg_of.get(n, "h")))], gold[n], "oracle vs committed fixture: " + n)
     params = cases.shim_case_params(inp["dt"], H.golden_tag() != "")
+    if no_bt_cont:
+        params.update({"USE_BT_CONT_TYPE": "False", "NONLINEAR_BT_CONTINUITY": "True"})
     GV = inp["GV"]
     with open(path, "wb") as f:
         f.write(struct.pack("<10i", 1297042743, d.ni, d.nj, d.nk, d.halo, cases.SHIM_NSTEPS, cases.SHIM_SAVE_AFTER, 0, abi.G_COUNT, len(params)))
@@ -140,3 +146,17 @@ def test_shim_modules_new_run_restart_and_tracers_from_fortran(orc, tmp_path, mo
     assert "D (restart file without CAu, CAv) u: max |diff|" in r.stdout
     names = r.stdout.split("registered restart variables:")[1].splitlines()[0].split()
     assert names == ["u", "v", "h", "sfc", "u2", "v2", "CAu", "CAv", "diffu", "diffv", "ubtav", "vbtav", "DTBT"]
+
+
+def test_shim_modules_without_a_BT_cont_type_from_fortran(orc, tmp_path, sums):
+    """The same driver with USE_BT_CONT_TYPE = False and NONLINEAR_BT_CONTINUITY = True in its MOM_input table (.testing/tc1's
+    barotropic settings): MOM_barotropic's barotropic_init reads them, initialize_dyn_split_RK2 passes no_BT_cont on, and four
+    steps uninterrupted as well as two + restart + two equal the oracle's run of that configuration bit for bit."""
+    if not os.path.exists(SHIM_DRIVER):
+        pytest.fail("tests/fortran_stubs/drive_shims is missing: __graft_entry__.build() compiles it with amdflang")
+    path = tmp_path / "shim_case.bin"
+    _write_shim_case(path, H.double_gyre(), orc, no_bt_cont=True)
+    r = subprocess.run([SHIM_DRIVER, str(path), str(tmp_path / "restart.bin")], capture_output=True, text=True, timeout=300)
+    print(r.stdout); print(r.stderr)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count(": bit-identical") == 2 * len(STATE) + len(DIAG)
