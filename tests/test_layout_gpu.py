@@ -3,6 +3,7 @@
 RCCL), against the one-tile run.  Every prognostic field of every tile must equal its part of the one-tile result bit for
 bit: this is what the N-GPU runs rely on -- which rows and columns each kernel covers on an interior tile edge, the
 wide-halo cycles of the barotropic solver, the all-reduces (dtbt, tracer iteration flags, reproducing sums)."""
+import os
 import threading
 
 import numpy as np
@@ -79,6 +80,8 @@ def run_tile(cfg_fn, nk, layout, pe, uid, nsteps, bt_mod, out, errors, rich=Fals
         dyc.sync()
         res = {n: sg[n].cpu().numpy() for n in STATE + ["T"]}
         res["dtbt"] = dyc.barotropic_dtbt(); res["lines"] = lines; res["dims"] = d
+        if os.environ.get("MOM6X_POISON_HALO") == "1" and layout != (1, 1):   # (the switch did poison: the step's last passes are 2-3 rows wide)
+            assert np.isnan(res["u"]).any() and np.isnan(res["h"]).any(), "MOM6X_POISON_HALO left no NaN in the halos"
         # the debugging checksums (hchksum / uvchksum) and the restart checksum are sums over all tiles
         res["chk"] = [dyc.chksum(sg["h"], "h", haloshift=1), dyc.chksum(sg["u"], "u"), dyc.chksum(sg["v"], "v", haloshift=2, omit_corners=True),
                       dyc.field_chksum(sg["T"])]
