@@ -1754,6 +1754,101 @@ int vertvisc_fused(mom6x_ctx *c, const double *u_in, const double *v_in, const d
   return MOM6X_OK;
 }
 
+// One layer of the bottom-up walk of vertvisc_coef :1357 + find_coupling_coef :2314 (see k_vertvisc_coef): the thickness at the velocity
+// point (CS%h_u) of layer K-1 (0-based k = K-1) and the coupling coefficient (CS%a_u) of the interface K below it, from the two cells'
+// thicknesses, the velocity the upwinding looks at, and what the walk carries up from the bottom.  Shared by k_vertvisc_coef and
+// k_vertvisc_coef_cols, so the two cannot differ in arithmetic.
+struct CoefWalk {
+  mom6x_vertvisc_params CS;
+  double I_Hbbl, I_valBL, kv_bbl, bbl_thick, hn, H_to_Z, h_neglect, dz_neglect, a_cpl_max, I_amax, Dmin;
+  double zh, zcol0, zcol1, z_i_below, dz_vel_below;
+  __device__ __forceinline__ void init(const mom6x_vertvisc_params &CS_, double bathy0, double bathy1, double I_Hbbl_, double I_valBL_, double kv_bbl_,
+                                       double bbl_thick_, double hn_, double H_to_Z_, double h_neglect_, double dz_neglect_, double a_cpl_max_,
+                                       double I_amax_) {
+    CS = CS_; I_Hbbl = I_Hbbl_; I_valBL = I_valBL_; kv_bbl = kv_bbl_; bbl_thick = bbl_thick_; hn = hn_; H_to_Z = H_to_Z_;
+    h_neglect = h_neglect_; dz_neglect = dz_neglect_; a_cpl_max = a_cpl_max_; I_amax = I_amax_;
+    Dmin = dmin(bathy0, bathy1);
+    zh = 0.; zcol0 = -bathy0; zcol1 = -bathy1;
+    z_i_below = 0.;          // z_i(k+1): the interface below the layer being worked on
+    dz_vel_below = 0.;       // dz_vel(k+1)
+  }
+  __device__ __forceinline__ void layer(int K, int nz, double h0, double h1, double uk, double z_t, bool have_Kv_add, double Kv_add,
+                                        double &h_u_out, double &a_out) {
+    const double dz0 = H_to_Z * h0, dz1 = H_to_Z * h1;
+    const double h_harm = 2. * h0 * h1 / (h0 + h1 + h_neglect);
+    const double h_arith = 0.5 * (h1 + h0);
+    const double h_delta = h1 - h0;
+    const double dz_harm = 2. * dz0 * dz1 / (dz0 + dz1 + dz_neglect);
+    const double dz_arith = 0.5 * (dz1 + dz0);
+    double hvel, dz_vel, z_i_top;
+    if (CS.harmonic_visc) {
+      hvel = h_harm; dz_vel = dz_harm;
+      if (uk * h_delta < 0) {
+        const double z2 = z_i_below;
+        const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        hvel = (1. - botfn) * h_harm + botfn * h_arith;
+        dz_vel = (1. - botfn) * dz_harm + botfn * dz_arith;
+      }
+      z_i_top = z_i_below + dz_harm * I_Hbbl;
+    } else {
+      zcol0 = zcol0 + dz0; zcol1 = zcol1 + dz1;
+      zh = zh + dz_harm;
+      const double z_clear = dmax(zcol0, zcol1) + Dmin;
+      z_i_top = dmax(zh, z_clear) * I_Hbbl;
+      hvel = h_arith; dz_vel = dz_arith;
+      if (uk * h_delta > 0.) {
+        if (zh * I_Hbbl < CS.harm_BL_val) {
+          hvel = h_harm; dz_vel = dz_harm;
+        } else {
+          double z2_wt = 1.;
+          if (zh * I_Hbbl < 2. * CS.harm_BL_val) z2_wt = dmax(0., dmin(1., zh * I_Hbbl * I_valBL - 1.));
+          const double z2 = z2_wt * (dmax(zh, z_clear) * I_Hbbl);
+          const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+          hvel = (1. - botfn) * h_arith + botfn * h_harm;
+          dz_vel = (1. - botfn) * dz_arith + botfn * dz_harm;
+        }
+      }
+    }
+    h_u_out = hvel + h_neglect;                                    // CS%h_u :1868-1872
+    double a_cpl;
+    if (K == nz) {                                                 // :2543-2558
+      if (CS.bottomdraglaw) {
+        const double dhc = dz_vel * 0.5;
+        a_cpl = kv_bbl / ((dmin(dhc, bbl_thick) + hn) + I_amax * kv_bbl);
+      } else if (fabs(CS.Kv_extra_bbl) > 0.0) {
+        a_cpl = (CS.Kv + CS.Kv_extra_bbl) / ((0.5 * dz_vel + hn) + I_amax * (CS.Kv + CS.Kv_extra_bbl));
+      } else {
+        a_cpl = CS.Kv / ((0.5 * dz_vel + hn) + I_amax * CS.Kv);
+      }
+    } else {                                                       // :2418-2540, Fortran K+1 between layers k and k+1
+      double Kv_tot = CS.Kv;
+      if (CS.Kvml_invZ2 > 0.) Kv_tot = CS.Kv + CS.Kvml_invZ2 / ((z_t * z_t) * (1. + 0.09 * z_t * z_t * z_t * z_t * z_t * z_t));
+      if (have_Kv_add) Kv_tot = Kv_tot + Kv_add;
+      if (CS.bottomdraglaw) {
+        const double z2 = z_i_below;
+        const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        Kv_tot = Kv_tot + (kv_bbl - CS.Kv) * botfn;
+        const double dhc = 0.5 * (dz_vel_below + dz_vel);
+        double h_shear;
+        if (dhc > bbl_thick) h_shear = ((1. - botfn) * dhc + botfn * bbl_thick) + hn;
+        else h_shear = dhc + hn;
+        a_cpl = Kv_tot / (h_shear + (I_amax * Kv_tot));
+      } else if (fabs(CS.Kv_extra_bbl) > 0.0) {
+        const double z2 = z_i_below;
+        const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        Kv_tot = Kv_tot + CS.Kv_extra_bbl * botfn;
+        const double h_shear = 0.5 * (dz_vel_below + dz_vel + hn);
+        a_cpl = Kv_tot / (h_shear + I_amax * Kv_tot);
+      } else {
+        const double h_shear = 0.5 * (dz_vel_below + dz_vel + hn);
+        a_cpl = Kv_tot / (h_shear + I_amax * Kv_tot);
+      }
+    }
+    a_out = dmin(a_cpl_max, a_cpl);                                // CS%a_u :1863-1867
+    z_i_below = z_i_top; dz_vel_below = dz_vel;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // vertvisc_coef :1357 + find_coupling_coef :2314 for one direction: one thread per face column.
 // Everything the coupling coefficient of interface K needs (z_i(K), dz_vel of the layers above and below) is
@@ -1815,19 +1910,11 @@ k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, co
       a_out[x + (size_t)K * slab] = z_t;
     }
   }
-  const double Dmin = dmin(bathyT[x], bathyT[y]);
-  double zh = 0., zcol0 = -bathyT[x], zcol1 = -bathyT[y];
-  double z_i_below = 0.;          // z_i(k+1): the interface below the layer being worked on
-  double dz_vel_below = 0.;       // dz_vel(k+1)
+  CoefWalk W;
+  W.init(CS, bathyT[x], bathyT[y], I_Hbbl, I_valBL, kv_bbl, bbl_thick, hn, H_to_Z, h_neglect, dz_neglect, a_cpl_max, I_amax);
   for (int k = nz - 1; k >= 0; k--) {
     const size_t c = x + (size_t)k * slab;
     const double h0 = h[c], h1 = h[c + st];
-    const double dz0 = H_to_Z * h0, dz1 = H_to_Z * h1;
-    const double h_harm = 2. * h0 * h1 / (h0 + h1 + h_neglect);
-    const double h_arith = 0.5 * (h1 + h0);
-    const double h_delta = h1 - h0;
-    const double dz_harm = 2. * dz0 * dz1 / (dz0 + dz1 + dz_neglect);
-    const double dz_arith = 0.5 * (dz1 + dz0);
     double uk = u[c];
     if (MODE == 1) uk = mC * (uk + dtx * u_bc[c]);
     if (MODE >= 2) {
@@ -1836,82 +1923,217 @@ k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, co
       // array instead of three (u_out may be u itself: every thread reads and writes its own column only)
       if (u_out) u_out[c] = uk;
     }
-    double hvel, dz_vel, z_i_top;
-    if (CS.harmonic_visc) {
-      hvel = h_harm; dz_vel = dz_harm;
-      if (uk * h_delta < 0) {
-        const double z2 = z_i_below;
-        const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
-        hvel = (1. - botfn) * h_harm + botfn * h_arith;
-        dz_vel = (1. - botfn) * dz_harm + botfn * dz_arith;
-      }
-      z_i_top = z_i_below + dz_harm * I_Hbbl;
-    } else {
-      zcol0 = zcol0 + dz0; zcol1 = zcol1 + dz1;
-      zh = zh + dz_harm;
-      const double z_clear = dmax(zcol0, zcol1) + Dmin;
-      z_i_top = dmax(zh, z_clear) * I_Hbbl;
-      hvel = h_arith; dz_vel = dz_arith;
-      if (uk * h_delta > 0.) {
-        if (zh * I_Hbbl < CS.harm_BL_val) {
-          hvel = h_harm; dz_vel = dz_harm;
-        } else {
-          double z2_wt = 1.;
-          if (zh * I_Hbbl < 2. * CS.harm_BL_val) z2_wt = dmax(0., dmin(1., zh * I_Hbbl * I_valBL - 1.));
-          const double z2 = z2_wt * (dmax(zh, z_clear) * I_Hbbl);
-          const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
-          hvel = (1. - botfn) * h_arith + botfn * h_harm;
-          dz_vel = (1. - botfn) * dz_arith + botfn * dz_harm;
-        }
-      }
+    const int K = k + 1;   // the interface below this layer (bottom: K = nz)
+    double z_t = 0.0, Kv_add = 0.0;
+    if (K < nz) {
+      if (CS.Kvml_invZ2 > 0.) z_t = a_out[x + (size_t)K * slab];
+      if (Kv_shear) Kv_add = 0.5 * (Kv_shear[x + (size_t)K * slab] + Kv_shear[y + (size_t)K * slab]);
     }
-    h_out[c] = hvel + h_neglect;                                   // CS%h_u :1868-1872
-    // the interface below this layer: K = k+1 (bottom: K = nz)
-    const int K = k + 1;
-    double a_cpl;
-    if (K == nz) {                                                 // :2543-2558
-      if (CS.bottomdraglaw) {
-        const double dhc = dz_vel * 0.5;
-        a_cpl = kv_bbl / ((dmin(dhc, bbl_thick) + hn) + I_amax * kv_bbl);
-      } else if (fabs(CS.Kv_extra_bbl) > 0.0) {
-        a_cpl = (CS.Kv + CS.Kv_extra_bbl) / ((0.5 * dz_vel + hn) + I_amax * (CS.Kv + CS.Kv_extra_bbl));
-      } else {
-        a_cpl = CS.Kv / ((0.5 * dz_vel + hn) + I_amax * CS.Kv);
-      }
-    } else {                                                       // :2418-2540, Fortran K+1 between layers k and k+1
-      double Kv_tot = CS.Kv;
-      if (CS.Kvml_invZ2 > 0.) {
-        const double z_t = a_out[x + (size_t)K * slab];
-        Kv_tot = CS.Kv + CS.Kvml_invZ2 / ((z_t * z_t) * (1. + 0.09 * z_t * z_t * z_t * z_t * z_t * z_t));
-      }
-      if (Kv_shear) {
-        const double Kv_add = 0.5 * (Kv_shear[x + (size_t)K * slab] + Kv_shear[y + (size_t)K * slab]);
-        Kv_tot = Kv_tot + Kv_add;
-      }
-      if (CS.bottomdraglaw) {
-        const double z2 = z_i_below;
-        const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
-        Kv_tot = Kv_tot + (kv_bbl - CS.Kv) * botfn;
-        const double dhc = 0.5 * (dz_vel_below + dz_vel);
-        double h_shear;
-        if (dhc > bbl_thick) h_shear = ((1. - botfn) * dhc + botfn * bbl_thick) + hn;
-        else h_shear = dhc + hn;
-        a_cpl = Kv_tot / (h_shear + (I_amax * Kv_tot));
-      } else if (fabs(CS.Kv_extra_bbl) > 0.0) {
-        const double z2 = z_i_below;
-        const double botfn = 1. / (1. + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
-        Kv_tot = Kv_tot + CS.Kv_extra_bbl * botfn;
-        const double h_shear = 0.5 * (dz_vel_below + dz_vel + hn);
-        a_cpl = Kv_tot / (h_shear + I_amax * Kv_tot);
-      } else {
-        const double h_shear = 0.5 * (dz_vel_below + dz_vel + hn);
-        a_cpl = Kv_tot / (h_shear + I_amax * Kv_tot);
-      }
-    }
-    a_out[x + (size_t)K * slab] = dmin(a_cpl_max, a_cpl);          // CS%a_u :1863-1867
-    z_i_below = z_i_top; dz_vel_below = dz_vel;
+    double hu, a;
+    W.layer(K, nz, h0, h1, uk, z_t, Kv_shear != nullptr, Kv_add, hu, a);
+    h_out[c] = hu;                                                 // CS%h_u :1868-1872
+    a_out[x + (size_t)K * slab] = a;                               // CS%a_u :1863-1867
   }
   a_out[x] = dmin(a_cpl_max, 0.0);   // a_cpl(:,:,1) stays 0 without shelves / dynamic mixed-layer viscosity
+}
+
+#ifndef CC_GROUP
+#define CC_GROUP 5
+#endif
+// k_vertvisc_coef_cols, pass 1: the coefficients of the pair P of layer groups (2P and 2P+1, G layers each, counted from the bottom) go
+// to their registers -- every index a constant.
+template <int NK, int G, int P>
+__device__ __forceinline__ void cc_file(double (&aa)[NK + 1], const double (&t_a)[2][G]) {
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int m = 0; m < G; m++) {
+      const int k = NK - 1 - ((2 * P + b) * G + m);
+      if (k >= 0) aa[k + 1] = t_a[b][m];
+    }
+}
+template <int NK, int G>
+__device__ __forceinline__ void cc_file_switch(int p, double (&aa)[NK + 1], const double (&t_a)[2][G]) {
+  static_assert((NK + G - 1) / G <= 40, "cc_file_switch: at most 20 pairs of groups");
+  switch (p) {
+#define CC_CASE(P) case P: cc_file<NK, G, P>(aa, t_a); break;
+    CC_CASE(0) CC_CASE(1) CC_CASE(2) CC_CASE(3) CC_CASE(4) CC_CASE(5) CC_CASE(6) CC_CASE(7) CC_CASE(8) CC_CASE(9)
+    CC_CASE(10) CC_CASE(11) CC_CASE(12) CC_CASE(13) CC_CASE(14) CC_CASE(15) CC_CASE(16) CC_CASE(17) CC_CASE(18) CC_CASE(19)
+#undef CC_CASE
+    default: break;
+  }
+}
+
+// vertvisc_coef + vertvisc [+ vertvisc_remnant] (MODE 3: :737-767 and :1002-1022 of the RK2 step) or vertvisc_coef + vertvisc_remnant
+// (MODE 1: :602-610) in ONE kernel per direction.  k_vertvisc_coef writes a_u (NK+1 levels) and h_u for k_vertvisc_cols /
+// k_vertvisc_remnant_cols to read straight back.  The coefficients are a bottom-up recurrence (z_i counts from the bottom) and the Thomas
+// sweep runs top-down, so the column of coefficients has to wait on chip: a_u in registers, h_u in LDS -- and as the forward sweep consumes
+// them it puts c1 into a_u's registers and the un-substituted remnant into h_u's LDS words, so the kernel holds what k_vertvisc_cols holds
+// (2 NK doubles in the 512-entry register file of a wave alone on its SIMD, NK in LDS).
+//   pass 1 (bottom-up): velocity estimate, h_u, a_u, the inputs fetched CC_G layers ahead.  The walk is a LOOP over pairs of groups (75
+//     copies of the layer's ~300 instructions would not fit the instruction cache), but a_u can only live in registers if every index
+//     is a constant: each pair leaves its coefficients in temporaries and a switch over the pair's number files them (cc_file<P>).
+//     The velocity estimate goes to its place in the result array and comes back in pass 2 (150 more registers would spill:
+//     measured, 2.1 against 1.75 ms); u may be u_in: a layer's inputs are read before its estimate is written.
+//   pass 2 / 3: k_vertvisc_cols's sweeps from the chip.
+// WRITE_COEF: a_u and h_u are also written (CS%a_u, CS%h_u stay what the step's LAST vertvisc_coef made them; the coefficients of the
+// earlier stages are replaced before anybody can look, unless a vertvisc_remnant of their own follows).
+// Words per face-layer: MODE 3: u, u_bc, pbce, h in; the estimate out and in; u [, visc_rem] out [; a_u, h_u out] = 8-10 where the
+// pair moves 12-13; MODE 1: u, u_bc, h in, visc_rem out = 4 against 8.  The same expressions in the same order as the kernels it
+// replaces (CoefWalk; the sweeps are copies): bit-identical.  KV_ML_INVZ2 (a top-down pre-pass through a_u), Rayleigh drag and the
+// direct-stress option stay with the separate kernels.
+template <int DIR, int MODE, bool REM, bool WRITE_COEF, int NK>
+__global__ void __launch_bounds__(64)
+k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, const double *u_in, const double *__restrict__ u_bc,
+                     double dtx, const double *__restrict__ h, const double *__restrict__ Kv_bbl, const double *__restrict__ bbl_thick_in,
+                     const double *__restrict__ Kv_shear, double *__restrict__ a_out, double *__restrict__ h_out, double H_to_Z,
+                     double h_neglect, double dz_neglect, double a_cpl_max, double I_amax, LayerAccelSrc LA,
+                     double *u, double *__restrict__ vr, const double *__restrict__ tau, double dt, double dt_Rho0, double H_to_RZ,
+                     double *__restrict__ tau_bot) {
+  static_assert(MODE == 1 || MODE == 3, "k_vertvisc_coef_cols: MODE 1 (coefficients + remnant) or 3 (coefficients + solve)");
+  static_assert(MODE == 3 || REM, "k_vertvisc_coef_cols: MODE 1 makes the remnant");
+  extern __shared__ double cc_lds[];
+  const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? -1 : 0) + blockIdx.y;
+  if (i > d.ni - 1 || j > d.nj - 1) return;
+  if (i < ((DIR ? 0 : -1))) return;
+  const int st = DIR ? d.pitch : 1;
+  const size_t x = ix2(d, i, j), y = x + st, slab = (size_t)d.slab;
+  double *hh = cc_lds + threadIdx.x;               // h_u(k) at hh[k * 64], later the un-substituted remnant
+  const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[x];
+  // accel_layer_u of btstep_layer_accel formed here (k_vertvisc_coef, MODE 3)
+  double la_e0 = 0., la_e1 = 0., la_g0 = 0., la_g1 = 0., la_a = 0., la_Idx = 0.;
+  if (MODE == 3) {
+    la_e0 = LA.e_anom[x]; la_e1 = LA.e_anom[y]; la_g0 = LA.g_own[x]; la_g1 = LA.g_nbr[y]; la_a = LA.a2d[x];
+    la_Idx = gm(G, d, DIR ? MOM6X_G_IdyCv : MOM6X_G_IdxCu)[x];
+  }
+  auto abt_of = [&](double pb0, double pb1) -> double {
+    double a = (la_a - (((pb1 - la_g1) * la_e1) - ((pb0 - la_g0) * la_e0)) * la_Idx);
+    if (fabs(a) < LA.underflow) a = 0.0;
+    return a;
+  };
+  if (!(mC > 0.)) {   // do_i :1514-1516: (MODE 3) the velocity estimate of the masked faces too; no coefficients, no solve
+    if (MODE == 3) {
+      double ul = 0.0;
+      for (int k = 0; k < NK; k++) {
+        const size_t c = x + (size_t)k * slab;
+        ul = mC * (u_in[c] + dtx * (u_bc[c] + abt_of(LA.pbce[c], LA.pbce[c + st])));
+        u[c] = ul;
+      }
+      if (tau_bot) tau_bot[x] = H_to_RZ * (ul * a_out[x + (size_t)NK * slab]);
+    }
+    return;
+  }
+  const double *bathyT = gm(G, d, MOM6X_G_bathyT);
+  double I_valBL = 0.0; if (CS.harm_BL_val > 0.0) I_valBL = 1.0 / CS.harm_BL_val;
+  double I_Hbbl = 1. / (CS.Hbbl + dz_neglect), kv_bbl = 0.0, bbl_thick = 0.0;
+  if (CS.bottomdraglaw) {
+    kv_bbl = Kv_bbl[x];
+    bbl_thick = bbl_thick_in[x] + dz_neglect;
+    I_Hbbl = 1. / bbl_thick;
+  }
+  CoefWalk W;
+  W.init(CS, bathyT[x], bathyT[y], I_Hbbl, I_valBL, kv_bbl, bbl_thick, dz_neglect, H_to_Z, h_neglect, dz_neglect, a_cpl_max, I_amax);
+  double aa[NK + 1];                               // a_u(K), then c1(k)
+  // ---- pass 1
+  constexpr int CC_G = CC_GROUP;
+  constexpr int NG = (NK + CC_G - 1) / CC_G, NP = (NG + 1) / 2;
+  double q_u[2][CC_G], q_b[2][CC_G], q_p0[2][CC_G], q_p1[2][CC_G], q_h0[2][CC_G], q_h1[2][CC_G];
+  double t_a[2][CC_G];
+  auto fetch = [&](int g, const int b) {
+#pragma unroll
+    for (int m = 0; m < CC_G; m++) {
+      const int k = NK - 1 - (g * CC_G + m);
+      if (k >= 0) {
+        const size_t c = x + (size_t)k * slab;
+        q_u[b][m] = u_in[c]; q_b[b][m] = u_bc[c];
+        if (MODE == 3) { q_p0[b][m] = LA.pbce[c]; q_p1[b][m] = LA.pbce[c + st]; }
+        q_h0[b][m] = h[c]; q_h1[b][m] = h[c + st];
+      }
+    }
+  };
+  auto group = [&](int g, const int b) {
+#pragma unroll
+    for (int m = 0; m < CC_G; m++) {
+      const int k = NK - 1 - (g * CC_G + m);
+      if (k >= 0) {
+        const size_t c = x + (size_t)k * slab;
+        const double uk = (MODE == 3) ? mC * (q_u[b][m] + dtx * (q_b[b][m] + abt_of(q_p0[b][m], q_p1[b][m])))
+                                      : mC * (q_u[b][m] + dtx * q_b[b][m]);
+        const int K = k + 1;
+        double Kv_add = 0.0;
+        if (K < NK && Kv_shear) Kv_add = 0.5 * (Kv_shear[x + (size_t)K * slab] + Kv_shear[y + (size_t)K * slab]);
+        double hu, a;
+        W.layer(K, NK, q_h0[b][m], q_h1[b][m], uk, 0.0, Kv_shear != nullptr, Kv_add, hu, a);
+        t_a[b][m] = a; hh[k * 64] = hu;
+        if (MODE == 3) u[c] = uk;
+        if (WRITE_COEF) { h_out[c] = hu; a_out[x + (size_t)K * slab] = a; }
+      }
+      __builtin_amdgcn_sched_barrier(0);             // (one layer's temporaries at a time)
+    }
+  };
+  fetch(0, 0);
+#pragma unroll 1
+  for (int p = 0; p < NP; p++) {
+    if (2 * p + 1 < NG) fetch(2 * p + 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    group(2 * p, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (2 * p + 2 < NG) fetch(2 * p + 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (2 * p + 1 < NG) group(2 * p + 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    cc_file_switch<NK, CC_G>(p, aa, t_a);
+  }
+  aa[0] = dmin(a_cpl_max, 0.0);                    // a_cpl(:,:,1) stays 0 without shelves / dynamic mixed-layer viscosity
+  if (WRITE_COEF) a_out[x] = aa[0];
+  asm volatile("" ::: "memory");
+  // ---- pass 2: the forward sweep of k_vertvisc_cols / k_vertvisc_remnant_cols from the chip; the velocity estimate comes back
+  //      (written a column's walk ago: mostly from the L2) U_G layers ahead of the sweep
+  const double surface_stress = (MODE == 3) ? dt_Rho0 * (mC * tau[x]) : 0.0;
+  double b1 = 0., d1 = 0., uprev = 0., rprev = 0.;
+  double uu[(MODE == 3) ? NK : 1];
+  constexpr int U_G = 8;
+  if (MODE == 3) {
+#pragma unroll
+    for (int k = 0; k < U_G && k < NK; k++) uu[k] = u[x + (size_t)k * slab];
+  }
+#pragma unroll
+  for (int k = 0; k < NK; k++) {
+    if (MODE == 3 && k + U_G < NK) uu[(MODE == 3) ? k + U_G : 0] = u[x + (size_t)(k + U_G) * slab];
+    const double a_k = aa[k], a_kp = aa[k + 1];
+    const double hu = hh[k * 64];
+    const double u0 = (MODE == 3) ? uu[(MODE == 3) ? k : 0] : 0.0;
+    if (k == 0) {
+      const double b_denom_1 = hu + dt * (0. + a_k);
+      b1 = 1.0 / (b_denom_1 + dt * a_kp);
+      d1 = b_denom_1 * b1;
+      if (MODE == 3) uprev = b1 * (hu * u0 + surface_stress);
+      rprev = b1 * hu;
+    } else {
+      aa[k] = dt * a_k * b1;                         // c1(k)
+      const double b_denom_1 = hu + dt * (0. + a_k * d1);
+      b1 = 1.0 / (b_denom_1 + dt * a_kp);
+      d1 = b_denom_1 * b1;
+      if (MODE == 3) uprev = (hu * u0 + dt * a_k * uprev) * b1;
+      if (REM) rprev = (hu + dt * a_k * rprev) * b1;
+    }
+    if (MODE == 3) uu[(MODE == 3) ? k : 0] = uprev;
+    if (REM) hh[k * 64] = rprev;
+    if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+  }
+  if (MODE == 3) u[x + (size_t)(NK - 1) * slab] = uprev;
+  if (REM) vr[x + (size_t)(NK - 1) * slab] = rprev;
+  asm volatile("" ::: "memory");
+  // ---- pass 3: back substitution
+#pragma unroll
+  for (int k = NK - 2; k >= 0; k--) {
+    const size_t x3 = x + (size_t)k * slab;
+    const double ck = aa[k + 1];
+    if (MODE == 3) { uprev = uu[(MODE == 3) ? k : 0] + ck * uprev; u[x3] = uprev; }
+    if (REM) { rprev = hh[k * 64] + ck * rprev; vr[x3] = rprev; }
+  }
+  if (MODE == 3 && tau_bot) tau_bot[x] = H_to_RZ * (uu[(MODE == 3) ? NK - 1 : 0] * aa[NK]);
 }
 
 extern "C" int mom6x_vertvisc_init(mom6x_ctx *c, const mom6x_vertvisc_params *p) {
@@ -1987,6 +2209,67 @@ static int vertvisc_coef_launch(mom6x_ctx *c, int mode, const double *u, const d
 #undef VVC
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
+}
+
+// vertvisc_coef_upd_la + vertvisc_fused of the RK2 step as one kernel per direction (k_vertvisc_coef_cols) where it exists: 75 layers,
+// no Rayleigh drag, no direct stress, no KV_ML_INVZ2.  MOM6X_VERTVISC=walk|pair: the two kernels.
+bool vertvisc_coef_solve_usable(mom6x_ctx *c) {
+  static const int mode = [] { const char *e = getenv("MOM6X_VERTVISC"); return (e && (!strcmp(e, "walk") || !strcmp(e, "pair"))) ? 0 : 1; }();
+  return mode && c->vv_init && c->d.nk == 75 && !c->Ray_u && !(direct_stress_of(c).Hmix > 0.0) && !(c->vv.Kvml_invZ2 > 0.0) &&
+         c->a_u == c->vv_a_u && c->a_v == c->vv_a_v && c->h_u == c->vv_h_u && c->h_v == c->vv_h_v &&   // (the solve reads what vertvisc_coef writes)
+         (!c->vv.bottomdraglaw || (c->Kv_bbl_u && c->Kv_bbl_v && c->bbl_thick_u && c->bbl_thick_v));
+}
+static int vertvisc_coef_cols_launch(mom6x_ctx *c, int mode, const double *u_in, const double *v_in, const double *u_bc, const double *v_bc,
+                                     const LayerAccelSrc &LAu, const LayerAccelSrc &LAv, double dtx, const double *h, double dt_coef,
+                                     double *u, double *v, const double *taux, const double *tauy, double dt, double *taux_bot, double *tauy_bot,
+                                     double *vr_u, double *vr_v, bool keep_coef) {
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  const mom6x_vgrid &GV = c->GV;
+  constexpr int NK = 75;
+  const double a_cpl_max = 1.0e37 * GV.Z_to_H;
+  const double I_amax = (c->vv.answer_date < 20190101) ? (1.0e-10 * GV.H_to_Z) * dt_coef : 0.0;
+  const double dt_Rho0 = dt / GV.H_to_RZ, HR = GV.H_to_RZ;
+  const dim3 bc(64, 1, 1);
+  const dim3 gu((unsigned)((nxa(d.ni + 1, -1) + 63) / 64), (unsigned)d.nj, 1), gv((unsigned)((d.ni + 63) / 64), (unsigned)(d.nj + 1), 1);
+  const size_t lds = (size_t)NK * 64 * sizeof(double);
+  const bool rem = (vr_u != nullptr);
+#define VCS(DIR, M, R, WC, g, uin, ubc, LA, uo, vro, tau, taub, Kb, bt, ao, ho)                                                       \
+  KLAUNCH_LDS(c, DIR ? "k_vertvisc_coef_cols<1>" : "k_vertvisc_coef_cols<0>", (k_vertvisc_coef_cols<DIR, M, R, WC, NK>), g, bc, lds, d, c->G, c->vv, uin, ubc, \
+              dtx, h, Kb, bt, c->Kv_shear, ao, ho, GV.H_to_Z, GV.H_subroundoff, GV.dZ_subroundoff, a_cpl_max, I_amax, LA, uo, vro, tau, dt, dt_Rho0, HR, taub)
+#define VCS2(M, R, WC) do { \
+    VCS(0, M, R, WC, gu, u_in, u_bc, LAu, u, vr_u, taux, taux_bot, c->Kv_bbl_u, c->bbl_thick_u, c->vv_a_u, c->vv_h_u); \
+    VCS(1, M, R, WC, gv, v_in, v_bc, LAv, v, vr_v, tauy, tauy_bot, c->Kv_bbl_v, c->bbl_thick_v, c->vv_a_v, c->vv_h_v); } while (0)
+  if (mode == 1) { if (keep_coef) VCS2(1, true, true); else VCS2(1, true, false); }
+  else if (rem && keep_coef) VCS2(3, true, true);
+  else if (rem) VCS2(3, true, false);
+  else if (keep_coef) VCS2(3, false, true);
+  else VCS2(3, false, false);
+#undef VCS2
+#undef VCS
+  HIPCHK(hipGetLastError());
+  return MOM6X_OK;
+}
+// :737-767 / :1002-1022: vertvisc_coef on the velocity estimate + vertvisc [+ vertvisc_remnant]; keep_coef: CS%a_u, CS%h_u are written
+// (the step's LAST vertvisc_coef, or a vertvisc_remnant of its own follows)
+int vertvisc_coef_solve_la(mom6x_ctx *c, const double *u_in, const double *v_in, const double *u_bc, const double *v_bc,
+                           const LayerAccelSrc &LAu, const LayerAccelSrc &LAv, double dtx, const double *h, double dt_coef,
+                           double *u, double *v, const double *taux, const double *tauy, double dt, double *taux_bot, double *tauy_bot,
+                           double *vr_u, double *vr_v, bool keep_coef) {
+  REQUIRE(c && vertvisc_coef_solve_usable(c), MOM6X_EINVAL, "vertvisc_coef_solve: not usable in this configuration");
+  REQUIRE(u_in && v_in && u_bc && v_bc && h && u && v && taux && tauy, MOM6X_EINVAL, "vertvisc_coef_solve: null array");
+  REQUIRE((vr_u != nullptr) == (vr_v != nullptr), MOM6X_EINVAL, "vertvisc_coef_solve: visc_rem_u and visc_rem_v come together");
+  return vertvisc_coef_cols_launch(c, 3, u_in, v_in, u_bc, v_bc, LAu, LAv, dtx, h, dt_coef, u, v, taux, tauy, dt, taux_bot, tauy_bot, vr_u, vr_v, keep_coef);
+}
+// :591-610: vertvisc_coef on mask * (u + dt * u_bc_accel) + vertvisc_remnant
+int vertvisc_coef_remnant(mom6x_ctx *c, const double *u_in, const double *v_in, const double *u_bc, const double *v_bc, double dtx,
+                          const double *h, double dt_coef, double *vr_u, double *vr_v, double dt, bool keep_coef) {
+  REQUIRE(c && vertvisc_coef_solve_usable(c), MOM6X_EINVAL, "vertvisc_coef_remnant: not usable in this configuration");
+  REQUIRE(u_in && v_in && u_bc && v_bc && h && vr_u && vr_v, MOM6X_EINVAL, "vertvisc_coef_remnant: null array");
+  LayerAccelSrc none;
+  memset(&none, 0, sizeof(none));
+  return vertvisc_coef_cols_launch(c, 1, u_in, v_in, u_bc, v_bc, none, none, dtx, h, dt_coef, nullptr, nullptr, nullptr, nullptr, dt, nullptr, nullptr,
+                                   vr_u, vr_v, keep_coef);
 }
 
 extern "C" int mom6x_vertvisc_coef(mom6x_ctx *c, const double *u, const double *v, const double *h, double dt) {

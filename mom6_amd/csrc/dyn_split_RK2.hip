@@ -396,9 +396,13 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
     KLAUNCH(c, "k_bc_accel", k_bc_accel, gridk(nxa(d.ni + 1, -1), d.nj + 1, nk, b), b, d, c->G, s->CAu_pred, s->CAv_pred, s->PFu, s->PFv,
             s->diffu, s->diffv, u_bc, v_bc, (const double *)u_inst, (const double *)v_inst, host_coef ? up : (double *)nullptr,
             host_coef ? vp : (double *)nullptr, dt);
+  if (dev_coef && vertvisc_coef_solve_usable(c)) {   // :591-610 in one kernel per direction; nobody sees these coefficients (:737 replaces them)
+    CHK(vertvisc_coef_remnant(c, u_inst, v_inst, u_bc, v_bc, dt, h, dt, s->visc_rem_u, s->visc_rem_v, dt, false));
+  } else {
   if (dev_coef) CHK(vertvisc_coef_upd(c, 1, u_inst, v_inst, u_bc, v_bc, nullptr, nullptr, dt, h, dt, nullptr, nullptr));   // :591-609, up/vp on the fly
   else CHK(coef_hook(0, up, vp, dt));                                   // :602-609
   CHK(mom6x_vertvisc_remnant(c, s->visc_rem_u, s->visc_rem_v, dt));     // :610
+  }
   // pass_eta :549/:617 + pass_visc_rem :618/:641 as ONE group started here; bt_mass_source (own cells only) and the own rows of
   // the continuity call below run while it travels; continuity completes it before it touches a halo row
   startn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk }, { 0, PW.cont, PW.cont });   // :484-486
@@ -434,13 +438,20 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   const double dt_pred = dt * R.be;                                     // :679
   if (!host_coef) {   // (with the callback, it needs up/vp before the solve: no fusion)
     // :737-738; the coefficient sweep forms the velocity estimate of :681-694 for its upwinding anyway and leaves it in up, vp
+    const bool same_dt = (R.visc_rem_dt_bug != 0);
+    const bool one_kernel = dev_coef && vertvisc_coef_solve_usable(c);   // coefficients + solve [+ remnant] per direction in ONE kernel
     if (dev_coef) {
       REQUIRE(bt_layer_accel_src(c, &LAu, &LAv), MOM6X_EINVAL, "step_MOM_dyn_split_RK2: no barotropic result to take the layer accelerations from");
-      CHK(vertvisc_coef_upd_la(c, u_inst, v_inst, u_bc, v_bc, LAu, LAv, dt_pred, h, dt_pred, up, vp));
+      if (one_kernel)
+        CHK(vertvisc_coef_solve_la(c, u_inst, v_inst, u_bc, v_bc, LAu, LAv, dt_pred, h, dt_pred, up, vp, taux, tauy, dt_pred, s->taux_bot,
+                                   s->tauy_bot, same_dt ? s->visc_rem_u : nullptr, same_dt ? s->visc_rem_v : nullptr,
+                                   !same_dt /* (its own vertvisc_remnant follows; else the corrector's coefficients replace these unseen) */));
+      else
+        CHK(vertvisc_coef_upd_la(c, u_inst, v_inst, u_bc, v_bc, LAu, LAv, dt_pred, h, dt_pred, up, vp));
     }
     // :681-694 + :754 + :763-767 in one column sweep per direction (k_vertvisc_fused / k_vertvisc_cols)
-    const bool same_dt = (R.visc_rem_dt_bug != 0);
-    if (dev_coef)
+    if (one_kernel) { }
+    else if (dev_coef)
       CHK(vertvisc_fused(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, up, vp, taux, tauy, dt_pred, s->taux_bot, s->tauy_bot,
                          same_dt ? s->visc_rem_u : nullptr, same_dt ? s->visc_rem_v : nullptr));
     else
@@ -506,9 +517,14 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   if (!host_coef) {   // :957-966 + :1013 + :1022 in one column sweep per direction
     if (dev_coef) {   // :1002-1003; u = mask*(u + dt*(u_bc_accel + u_accel_bt)) is left in place by the coefficient sweep
       REQUIRE(bt_layer_accel_src(c, &LAu, &LAv), MOM6X_EINVAL, "step_MOM_dyn_split_RK2: no barotropic result to take the layer accelerations from");
+      if (vertvisc_coef_solve_usable(c)) {
+        CHK(vertvisc_coef_solve_la(c, u_inst, v_inst, u_bc, v_bc, LAu, LAv, dt, h, dt, u_inst, v_inst, taux, tauy, dt, s->taux_bot, s->tauy_bot,
+                                   s->visc_rem_u, s->visc_rem_v, true));
+      } else {
       CHK(vertvisc_coef_upd_la(c, u_inst, v_inst, u_bc, v_bc, LAu, LAv, dt, h, dt, u_inst, v_inst));
       CHK(vertvisc_fused(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, u_inst, v_inst, taux, tauy, dt, s->taux_bot,
                          s->tauy_bot, s->visc_rem_u, s->visc_rem_v));
+      }
     } else
     CHK(vertvisc_fused(c, u_inst, v_inst, u_bc, v_bc, s->u_accel_bt, s->v_accel_bt, dt, u_inst, v_inst, taux, tauy, dt,
                        s->taux_bot, s->tauy_bot, s->visc_rem_u, s->visc_rem_v));

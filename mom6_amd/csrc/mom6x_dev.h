@@ -164,6 +164,13 @@ struct LayerAccelSrc {
   const double *a2d;       // u_accel_bt | v_accel_bt (2-D)
   double underflow;        // accel_underflow = vel_underflow / dt
 };
+bool vertvisc_coef_solve_usable(mom6x_ctx *c);                           // dyn_kernels.hip: k_vertvisc_coef_cols exists for this configuration
+int vertvisc_coef_solve_la(mom6x_ctx *c, const double *u_in, const double *v_in, const double *u_bc, const double *v_bc,
+                           const LayerAccelSrc &LAu, const LayerAccelSrc &LAv, double dtx, const double *h, double dt_coef,
+                           double *u, double *v, const double *taux, const double *tauy, double dt, double *taux_bot, double *tauy_bot,
+                           double *vr_u, double *vr_v, bool keep_coef);
+int vertvisc_coef_remnant(mom6x_ctx *c, const double *u_in, const double *v_in, const double *u_bc, const double *v_bc, double dtx,
+                          const double *h, double dt_coef, double *vr_u, double *vr_v, double dt, bool keep_coef);
 int bt_mass_source_from(mom6x_ctx *c, const double *eta_h, const double *eta, int set_cor);   // bt_mass_source with the column sum given
 int set_dtbt_eta(mom6x_ctx *c, const double *pbce, const double *eta);      // barotropic.hip: set_dtbt(pbce, eta=eta) RK2.F90:667
 void bt_defer_btcalc(mom6x_ctx *c, bool on);                            // barotropic.hip: btcalc's fractions formed by btstep's column pass while on
