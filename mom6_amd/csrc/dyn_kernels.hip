@@ -1940,6 +1940,12 @@ k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, co
 #ifndef CC_GROUP
 #define CC_GROUP 5
 #endif
+#ifndef CC_GROUP1
+#define CC_GROUP1 5
+#endif
+#ifndef CC_UG
+#define CC_UG 8
+#endif
 // k_vertvisc_coef_cols, pass 1: the coefficients of the pair P of layer groups (2P and 2P+1, G layers each, counted from the bottom) go
 // to their registers -- every index a constant.
 template <int NK, int G, int P>
@@ -2036,7 +2042,7 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
   W.init(CS, bathyT[x], bathyT[y], I_Hbbl, I_valBL, kv_bbl, bbl_thick, dz_neglect, H_to_Z, h_neglect, dz_neglect, a_cpl_max, I_amax);
   double aa[NK + 1];                               // a_u(K), then c1(k)
   // ---- pass 1
-  constexpr int CC_G = CC_GROUP;
+  constexpr int CC_G = (MODE == 1) ? CC_GROUP1 : CC_GROUP;   // layers per group of the walk (MODE 1 holds no pbce pair)
   constexpr int NG = (NK + CC_G - 1) / CC_G, NP = (NG + 1) / 2;
   double q_u[2][CC_G], q_b[2][CC_G], q_p0[2][CC_G], q_p1[2][CC_G], q_h0[2][CC_G], q_h1[2][CC_G];
   double t_a[2][CC_G];
@@ -2093,7 +2099,7 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
   const double surface_stress = (MODE == 3) ? dt_Rho0 * (mC * tau[x]) : 0.0;
   double b1 = 0., d1 = 0., uprev = 0., rprev = 0.;
   double uu[(MODE == 3) ? NK : 1];
-  constexpr int U_G = 8;
+  constexpr int U_G = CC_UG;
   if (MODE == 3) {
 #pragma unroll
     for (int k = 0; k < U_G && k < NK; k++) uu[k] = u[x + (size_t)k * slab];

@@ -17,7 +17,7 @@ ALLOWED = {
 }
 # the kernels the step spends its time in: named, so that a rename cannot silently drop them from the check
 HOT = ["k_mass_flux_waveILi0ELi5ELb0E", "k_mass_flux_waveILi1ELi5ELb0E", "k_corad_fused", "k_hv_fusedILi32ELi24E", "k_vertvisc_coefILi0ELi3E",
-       "k_vertvisc_colsILi0ELb0ELb1ELi75E", "k_bt_velILi0E", "k_bt_colILi0E", "k_convergenceILi0E", "k_pgf_main", "k_ta_x_tileILi4E",
+       "k_vertvisc_colsILi0ELb0ELb1ELi75E", "k_vertvisc_coef_colsILi0ELi3ELb1ELb1ELi75E", "k_vertvisc_coef_colsILi0ELi1ELb1ELb0ELi75E", "k_bt_velILi0E", "k_bt_colILi0E", "k_convergenceILi0E", "k_pgf_main", "k_ta_x_tileILi4E",
        "k_ta_y_tileILi4ELi32E", "k_tridiag_colsILi75ELb0E", "k_remap_apply", "k_remap_merge", "k_remap_recon"]
 
 
