@@ -125,6 +125,7 @@ KERNEL_WORDS = {
     "k_mass_flux_wave": 16.0 / 3.0,
     # thread-per-column path (MOM6X_MASSFLUX=legacy): u, visc_rem, h, (h_L, h_R from k_edge) in; uh [+ u_cor] out
     "k_mass_flux<": 14.0 / 3.0,
+    "k_vertvisc_coef_cols": 22.0 / 3.0,   # the step's three calls: u, u_bc, h in + visc_rem out = 4; + pbce in, the estimate out and in, u out = 8; + a_u, h_u out = 10
     "k_vertvisc_remnant": 3.0,   # a(k), h in; visc_rem out
     "k_vertvisc<": 4.0,          # u, a(k), h in; u out
     "k_bc_accel": 7.0,           # CAu, PFu, diffu in + u_bc_accel out, both directions less shared reads
@@ -294,6 +295,8 @@ def diag_leg(args, dyc, d, st, barrier, dist):
 FUSED_WORDS = {
     "vertvisc x2 + remnant x3 and the velocity updates of the RK2 glue": "k_vertvisc_fused does the RK2 velocity update, vertvisc and vertvisc_remnant "
         "in one column sweep: 11 words per face-layer and call where the separate routines move 17 (DESIGN.md section 4)",
+    "vertvisc_coef x3": "round 5: k_vertvisc_coef_cols forms the coefficients in the kernel that solves with them (a_u in registers, h_u in LDS): "
+        "4 / 8 / 10 words per face-layer for the step's three calls where coefficient kernel + solve moved 8 / 12 / 12",
     "continuity_PPM": "the PPM edge values h_W/h_E/h_S/h_N, the Newton iterations' layer transports and the flux thicknesses never leave the chip "
         "(they were never part of the 256 B x N3 count either): 5 words per face-layer and launch",
     "everything else": "moved as counted; the 2-D metric planes a kernel re-reads per layer or per 15-layer chunk come on top (not in the model)",
