@@ -1992,13 +1992,15 @@ template <int DIR, int MODE, bool REM, bool WRITE_COEF, int NK>
 __global__ void __launch_bounds__(64)
 k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, const double *u_in, const double *__restrict__ u_bc,
                      double dtx, const double *__restrict__ h, const double *__restrict__ Kv_bbl, const double *__restrict__ bbl_thick_in,
-                     const double *__restrict__ Kv_shear, double *__restrict__ a_out, double *__restrict__ h_out, double H_to_Z,
+                     const double *__restrict__ Kv_shear, double *__restrict__ a_out, double *h_out, double H_to_Z,
                      double h_neglect, double dz_neglect, double a_cpl_max, double I_amax, LayerAccelSrc LA,
                      double *u, double *__restrict__ vr, const double *__restrict__ tau, double dt, double dt_Rho0, double H_to_RZ,
                      double *__restrict__ tau_bot) {
   static_assert(MODE == 1 || MODE == 3, "k_vertvisc_coef_cols: MODE 1 (coefficients + remnant) or 3 (coefficients + solve)");
   static_assert(MODE == 3 || REM, "k_vertvisc_coef_cols: MODE 1 makes the remnant");
   extern __shared__ double cc_lds[];
+  // (DIR = 1: a block column's rows on ONE XCD, so that the row north of a face column -- the next work-group's own row -- meets it in
+  //  that XCD's L2, was measured: 1.77-1.81 against 1.56 ms per launch; rows along blockIdx.y it is.)
   const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * 64 + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -2041,6 +2043,7 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
   CoefWalk W;
   W.init(CS, bathyT[x], bathyT[y], I_Hbbl, I_valBL, kv_bbl, bbl_thick, dz_neglect, H_to_Z, h_neglect, dz_neglect, a_cpl_max, I_amax);
   double aa[NK + 1];                               // a_u(K), then c1(k)
+  constexpr bool EST_LDS = (MODE == 3) && WRITE_COEF;
   // ---- pass 1
   constexpr int CC_G = (MODE == 1) ? CC_GROUP1 : CC_GROUP;   // layers per group of the walk (MODE 1 holds no pbce pair)
   constexpr int NG = (NK + CC_G - 1) / CC_G, NP = (NG + 1) / 2;
@@ -2071,8 +2074,10 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
         if (K < NK && Kv_shear) Kv_add = 0.5 * (Kv_shear[x + (size_t)K * slab] + Kv_shear[y + (size_t)K * slab]);
         double hu, a;
         W.layer(K, NK, q_h0[b][m], q_h1[b][m], uk, 0.0, Kv_shear != nullptr, Kv_add, hu, a);
-        t_a[b][m] = a; hh[k * 64] = hu;
-        if (MODE == 3) u[c] = uk;
+        t_a[b][m] = a;
+        // between the passes: h_u in LDS and the estimate through the result array -- or, when h_u is written anyway, the estimate
+        // in LDS and h_u back from its array (a word less)
+        if (EST_LDS) hh[k * 64] = uk; else { hh[k * 64] = hu; if (MODE == 3) u[c] = uk; }
         if (WRITE_COEF) { h_out[c] = hu; a_out[x + (size_t)K * slab] = a; }
       }
       __builtin_amdgcn_sched_barrier(0);             // (one layer's temporaries at a time)
@@ -2100,16 +2105,18 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
   double b1 = 0., d1 = 0., uprev = 0., rprev = 0.;
   double uu[(MODE == 3) ? NK : 1];
   constexpr int U_G = CC_UG;
+  const double *back = EST_LDS ? (const double *)h_out : (const double *)u;   // what comes back from memory: h_u or the estimate
   if (MODE == 3) {
 #pragma unroll
-    for (int k = 0; k < U_G && k < NK; k++) uu[k] = u[x + (size_t)k * slab];
+    for (int k = 0; k < U_G && k < NK; k++) uu[k] = back[x + (size_t)k * slab];
   }
 #pragma unroll
   for (int k = 0; k < NK; k++) {
-    if (MODE == 3 && k + U_G < NK) uu[(MODE == 3) ? k + U_G : 0] = u[x + (size_t)(k + U_G) * slab];
+    if (MODE == 3 && k + U_G < NK) uu[(MODE == 3) ? k + U_G : 0] = back[x + (size_t)(k + U_G) * slab];
     const double a_k = aa[k], a_kp = aa[k + 1];
-    const double hu = hh[k * 64];
-    const double u0 = (MODE == 3) ? uu[(MODE == 3) ? k : 0] : 0.0;
+    const double from_lds = hh[k * 64], from_mem = (MODE == 3) ? uu[(MODE == 3) ? k : 0] : 0.0;
+    const double hu = EST_LDS ? from_mem : from_lds;
+    const double u0 = EST_LDS ? from_lds : from_mem;
     if (k == 0) {
       const double b_denom_1 = hu + dt * (0. + a_k);
       b1 = 1.0 / (b_denom_1 + dt * a_kp);

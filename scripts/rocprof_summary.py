@@ -52,6 +52,14 @@ def main():
         faces = (ni + 1) * nj * 8.0
         exp_fetch, exp_write = faces * (2 * nk + 1), faces * nk
         steps_k = "k_pgf_main"            # one launch per step
+    elif "k_bt_mass_source" in agg["fetch"]:
+        # (round 5: the remnant is made by k_vertvisc_coef_cols, which skips land.)  k_bt_mass_source(hp, eta_pred, set_cor = 0) of the
+        # corrector, once per step, every column of the tile: reads h (nk levels), bathyT, eta, eta_cor, writes eta_cor.  Under the old
+        # calibration it measured 968.07 MB read (known: 970.4) and 12.50 MB written (12.44): the two agree to 0.3 %.
+        cal_k = "k_bt_mass_source"
+        cols = ni * nj * 8.0
+        exp_fetch, exp_write = cols * (nk + 3), cols
+        steps_k = "k_pgf_main"
     else:
         cal_k = "k_uhtr"
         cells = (ni + 1) * nj * nk * 8.0
@@ -60,6 +68,8 @@ def main():
     n_cal = agg["fetch"][cal_k][0]
     cal_f = exp_fetch / (agg["fetch"][cal_k][1] / n_cal)
     cal_w = exp_write / (agg["write"][cal_k][1] / agg["write"][cal_k][0])
+    if not (1.2 < cal_f < 2.6 and 0.8 < cal_w < 1.25):   # (gfx950: FETCH_SIZE counts 64 B per 128-B request on streaming reads, WRITE_SIZE is exact)
+        sys.exit(f"implausible calibration on {cal_k}: FETCH x{cal_f:.3f}, WRITE x{cal_w:.3f} -- does the kernel still move the bytes this script assumes?")
     nsteps = agg["fetch"][steps_k][0] if steps_k in agg["fetch"] else n_cal
     with open(f"{prefix}_hbm_pmc.csv", "w") as f:
         f.write(f"# FETCH_SIZE x{cal_f:.3f}, WRITE_SIZE x{cal_w:.3f} (calibration on {cal_k}: known {exp_fetch / 1e6:.1f} MB read, "
