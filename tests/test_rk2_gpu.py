@@ -29,7 +29,8 @@ STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h",
 
 
 def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, per_stage=False, new_diff=False,
-        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None, Hmix_stress=0.0, recon=0, chk=False, cont_mod=None):
+        exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None, Hmix_stress=0.0, recon=0, chk=False, cont_mod=None, ray=True,
+        shear=True):
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
@@ -56,7 +57,7 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
         P = abi.vertvisc_params_default()
         for k_, v_ in dev_vv.items():
             setattr(P, k_, v_)
-        vvset = (P,) + tuple(visc_inputs(d, M)) + (coefs[0][4], coefs[0][5])
+        vvset = (P,) + tuple(visc_inputs(d, M, with_shear=shear)) + ((coefs[0][4], coefs[0][5]) if ray else (None, None))   # Ray_u, Ray_v
     so, m = cases.oracle_rk2(orc, cfg, inp, nsteps, bt_mod, rk2_mod, cor_mod, first_direction, tv=tv, vv=vvset, hv=hv, Hmix_stress=Hmix_stress, cont_mod=cont_mod)
 
     # ---------------- device
@@ -256,6 +257,44 @@ def test_rk2_75_layers_on_chip_columns(orc, ni, nj):
     # VISC_REM_TIMESTEP_BUG = False: the velocity solve without the remnant (k_vertvisc_cols<UPD, !REM>) + k_vertvisc_remnant_cols
     run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(visc_rem_dt_bug=0), dev_vv=dict())
     run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(visc_rem_dt_bug=0), per_stage=True)
+
+
+@pytest.mark.parametrize("ni,nj", [(70, 10), (24, 40)])
+@pytest.mark.parametrize("shear", [True, False])
+def test_rk2_75_layers_one_kernel_vertical_viscosity(orc, ni, nj, shear):
+    """Without Rayleigh drag (and without the direct-stress and KV_ML_INVZ2 options) the three vertvisc_coef calls of a step and the
+    solves that follow them run as ONE kernel per direction (k_vertvisc_coef_cols: coefficients bottom-up into registers and LDS, the
+    Thomas sweeps top-down from there; MODE 1 with the remnant only for :602-610).  Two steps against the oracle, which calls
+    vertvisc_coef, vertvisc and vertvisc_remnant one after the other: bit for bit, with and without visc%Kv_shear, with the remnant
+    in the solve's sweep and (VISC_REM_TIMESTEP_BUG = False) in a kernel of its own after it -- and the kernel did run."""
+    for rk2_mod in (None, dict(visc_rem_dt_bug=0)):
+        run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=rk2_mod, dev_vv=dict(), ray=False, shear=shear)
+    import os
+    if os.environ.get("MOM6X_VERTVISC") in (None, ""):   # (not under the switch tests that take the kernel away)
+        import torch
+        from mom6_amd.dycore import Dycore, prof_enable, prof_report
+        from tests import cases
+        from tests.test_dyn_gpu import visc_inputs
+        cfg = H.benchmark_small(nk=75, ni=ni, nj=nj); gg, d, M = cfg
+        inp = cases.rk2_inputs(cfg)
+        cont, bt, cor, pgf, rk2 = cases.rk2_params(d, inp["GV"], dict(strong_drag=1), None, None)
+        dyc = Dycore(d, M, inp["GV"], 0)
+        dyc.continuity_init(cont); dyc.barotropic_init(bt); dyc.CoriolisAdv_init(cor); dyc.PressureForce_init(pgf, inp["Rlay"], inp["gp"])
+        dyc.initialize_dyn_split_RK2(rk2)
+        dyc.vertvisc_init(abi.vertvisc_params_default())
+        vis = [dyc.to_dev(a) if a is not None else None for a in visc_inputs(d, M, with_shear=shear)]
+        dyc.vertvisc_set_visc(*vis, None, None)
+        sg = dict(u=dyc.to_dev(inp["u"]), v=dyc.to_dev(inp["v"]), h=dyc.to_dev(inp["h"]), uh=dyc.zeros3(), vh=dyc.zeros3(), uhtr=dyc.zeros3(),
+                  vhtr=dyc.zeros3(), eta_av=dyc.zeros2())
+        tx, ty = dyc.to_dev(inp["taux"]), dyc.to_dev(inp["tauy"])
+        torch.cuda.synchronize()
+        dyc.dyn_split_RK2_new_run(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], inp["dt"])
+        prof_enable(dyc, True)
+        dyc.step_MOM_dyn_split_RK2(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], sg["uhtr"], sg["vhtr"], sg["eta_av"], tx, ty, inp["dt"], calc_dtbt=True)
+        dyc.sync()
+        rep = prof_report(dyc); prof_enable(dyc, False)
+        assert rep.get("k_vertvisc_coef_cols<0>", (0, 0))[0] == 3 and rep.get("k_vertvisc_coef_cols<1>", (0, 0))[0] == 3, sorted(rep)
+        dyc.close()
 
 
 def test_rk2_75_layers_with_btcalc_written_out():

@@ -21,8 +21,8 @@ CASES = [
     ("MOM6X_MFW_ROWS", "37", "test_continuity_gpu.py", "double_gyre or channel or many_layers"),
     ("MOM6X_MFW_SPEC", "0", "test_continuity_gpu.py", "many_layers"),                   # the general mass-flux kernel where the one compiled for the launch's switches would run
     ("MOM6X_MFW_SPEC", "0", "test_rk2_gpu.py", "75_layers_on_chip"),
-    ("MOM6X_VERTVISC", "walk", "test_rk2_gpu.py", "75_layers_on_chip"),                 # the column solve through HBM at nk = 75
-    ("MOM6X_VERTVISC", "pair", "test_rk2_gpu.py", "75_layers_on_chip"),                 # vertvisc_coef and the solve as two kernels (on chip each)
+    ("MOM6X_VERTVISC", "walk", "test_rk2_gpu.py", "75_layers_on_chip or one_kernel"),                 # the column solve through HBM at nk = 75
+    ("MOM6X_VERTVISC", "pair", "test_rk2_gpu.py", "75_layers_on_chip or one_kernel"),                 # vertvisc_coef and the solve as two kernels (on chip each)
     ("MOM6X_PASS_WIDTHS", "full", "test_layout_gpu.py", "tile_layout_gives"),           # NIHALO rows in every group pass of the step
     ("MOM6X_POISON_HALO", "1", "test_layout_gpu.py", "tile_layout_gives"),              # NaNs in the halo rows beyond the width of each narrow pass
     ("MOM6X_BC_ACCEL", "own", "test_rk2_gpu.py", "double_gyre_bitexact or 75_layers_on_chip"),      # k_bc_accel instead of the fold into k_pgf_main
