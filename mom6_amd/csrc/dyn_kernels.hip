@@ -2253,7 +2253,7 @@ static int vertvisc_coef_cols_launch(mom6x_ctx *c, int mode, const double *u_in,
 #define VCS2(M, R, WC) do { \
     VCS(0, M, R, WC, gu, u_in, u_bc, LAu, u, vr_u, taux, taux_bot, c->Kv_bbl_u, c->bbl_thick_u, c->vv_a_u, c->vv_h_u); \
     VCS(1, M, R, WC, gv, v_in, v_bc, LAv, v, vr_v, tauy, tauy_bot, c->Kv_bbl_v, c->bbl_thick_v, c->vv_a_v, c->vv_h_v); } while (0)
-  if (mode == 1) { if (keep_coef) VCS2(1, true, true); else VCS2(1, true, false); }
+  if (mode == 1) VCS2(1, true, false);   // (nobody sees the coefficients of :602-609: :737 replaces them)
   else if (rem && keep_coef) VCS2(3, true, true);
   else if (rem) VCS2(3, true, false);
   else if (keep_coef) VCS2(3, false, true);
@@ -2278,6 +2278,7 @@ int vertvisc_coef_solve_la(mom6x_ctx *c, const double *u_in, const double *v_in,
 int vertvisc_coef_remnant(mom6x_ctx *c, const double *u_in, const double *v_in, const double *u_bc, const double *v_bc, double dtx,
                           const double *h, double dt_coef, double *vr_u, double *vr_v, double dt, bool keep_coef) {
   REQUIRE(c && vertvisc_coef_solve_usable(c), MOM6X_EINVAL, "vertvisc_coef_remnant: not usable in this configuration");
+  REQUIRE(!keep_coef, MOM6X_EUNSUPPORTED, "vertvisc_coef_remnant: the coefficients of this stage are not kept (call vertvisc_coef and vertvisc_remnant)");
   REQUIRE(u_in && v_in && u_bc && v_bc && h && vr_u && vr_v, MOM6X_EINVAL, "vertvisc_coef_remnant: null array");
   LayerAccelSrc none;
   memset(&none, 0, sizeof(none));
