@@ -1941,7 +1941,7 @@ k_vertvisc_coef(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, co
 #define CC_GROUP 5
 #endif
 #ifndef CC_GROUP1
-#define CC_GROUP1 5
+#define CC_GROUP1 8   // (MODE 1 holds no pbce pair and no velocity: 8 layers ahead, 1.53-1.58 against 1.60-1.62 ms per launch on average; profiles/r05_ab_vv.txt)
 #endif
 #ifndef CC_UG
 #define CC_UG 8
