@@ -22,8 +22,8 @@ module mom6x_c_api
   public :: mom6x_btstep_warnings
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
   public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
-  public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc
-  public :: mom6x_bt_mass_source, mom6x_set_dtbt, mom6x_set_dtbt_pbce, mom6x_btstep
+  public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc, mom6x_btcalc_strict
+  public :: mom6x_bt_mass_source, mom6x_set_dtbt, mom6x_set_dtbt_pbce, mom6x_set_dtbt_pbce_eta, mom6x_btstep
   public :: mom6x_CoriolisAdv_init, mom6x_CorAdCalc, mom6x_PressureForce_init, mom6x_PressureForce
   public :: mom6x_vertvisc_set_coef, mom6x_vertvisc, mom6x_vertvisc_remnant
   public :: mom6x_initialize_dyn_split_RK2, mom6x_dyn_split_RK2_new_run, mom6x_dyn_split_RK2_restart_fills, mom6x_rk2_field, mom6x_rk2_set_CAu_pred_stored
@@ -36,7 +36,7 @@ module mom6x_c_api
   public :: mom6x_tracer_vertdiff_sink, mom6x_tracer_vertdiff_Eulerian_sink
 
   !> include/mom6x.h MOM6X_ABI_VERSION this module mirrors; a host compares it with mom6x_abi_version() at start-up
-  integer(c_int), parameter :: MOM6X_ABI_BUILT_FOR = 5
+  integer(c_int), parameter :: MOM6X_ABI_BUILT_FOR = 6
   !> mom6x_dyn_split_RK2_restart_fills: the restart variables the host has uploaded (include/mom6x.h MOM6X_RK2_HAVE_*)
   integer(c_int), parameter :: MOM6X_RK2_HAVE_ETA = 1, MOM6X_RK2_HAVE_DIFFU = 2, MOM6X_RK2_HAVE_U2 = 4, MOM6X_RK2_HAVE_CAU = 8, &
                                MOM6X_RK2_HAVE_UH = 16, MOM6X_RK2_HAVE_H2 = 32
@@ -79,6 +79,8 @@ module mom6x_c_api
     real(c_double) :: dtbt_fraction, Z_ref
     integer(c_int) :: use_wide_halos, BTHALO, min_stencil   !< BT_USE_WIDE_HALOS (T), BTHALO (0), BT_WIDE_HALO_MIN_STENCIL (0)
     integer(c_int) :: nonlinear_continuity, nonlin_cont_update_period   !< NONLINEAR_BT_CONTINUITY (F), NONLIN_BT_CONT_UPDATE_PERIOD (1): read by btstep without a BT_cont_type
+    integer(c_int) :: bt_thick_scheme   !< BT_THICK_SCHEME: 0 FROM_BT_CONT, 1 HYBRID, 2 HARMONIC, 3 ARITHMETIC (MOM6X_BT_THICK_*)
+    real(c_double) :: maxvel            !< MAXVEL (3e8): eta_cor_bound of BOUND_BT_CORRECTION without the BT_cont bounds
   end type mom6x_barotropic_params
 
   type, bind(C) :: mom6x_coriolis_params   !< CoriolisAdv_CS (MOM_CoriolisAdv.F90:29-100)
@@ -251,6 +253,9 @@ module mom6x_c_api
       type(mom6x_barotropic_params), intent(in) :: p
     end function
     !> btcalc, MOM_barotropic.F90:4360
+    integer(c_int) function mom6x_btcalc_strict(ctx, h, h_u, h_v) bind(C, name="mom6x_btcalc_strict")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx, h, h_u, h_v
+    end function
     integer(c_int) function mom6x_btcalc(ctx, h, h_u, h_v) bind(C, name="mom6x_btcalc")
       import :: c_int, c_ptr ; type(c_ptr), value :: ctx, h, h_u, h_v
     end function
@@ -261,6 +266,10 @@ module mom6x_c_api
     !> set_dtbt, MOM_barotropic.F90:3509
     integer(c_int) function mom6x_set_dtbt(ctx, pbce, gtot_est, SSH_add, dtbt_out) bind(C, name="mom6x_set_dtbt")
       import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, pbce ; real(c_double), value :: gtot_est, SSH_add
+      real(c_double), intent(out) :: dtbt_out
+    end function
+    integer(c_int) function mom6x_set_dtbt_pbce_eta(ctx, pbce, eta, SSH_add, dtbt_out) bind(C, name="mom6x_set_dtbt_pbce_eta")
+      import :: c_int, c_ptr, c_double ; type(c_ptr), value :: ctx, pbce, eta ; real(c_double), value :: SSH_add
       real(c_double), intent(out) :: dtbt_out
     end function
     integer(c_int) function mom6x_set_dtbt_pbce(ctx, pbce, dtbt_out) bind(C, name="mom6x_set_dtbt_pbce")

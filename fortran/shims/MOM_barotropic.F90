@@ -147,8 +147,8 @@ subroutine btstep_report_warnings(CS)
   endif
 end subroutine btstep_report_warnings
 
-!> set_dtbt (:3509).  BT_cont (SET_DTBT_USE_BT_CONT) and eta are not carried: the default path estimates the wave speed
-!! from pbce or gtot_est, which is what initialize_dyn_split_RK2 / step_MOM_dyn_split_RK2 use (:1599, RK2.F90:675).
+!> set_dtbt (:3509).  BT_cont (SET_DTBT_USE_BT_CONT) is not carried.  With pbce the face areas follow :3576-3582: from eta when
+!! NONLINEAR_BT_CONTINUITY is set and eta is present, otherwise find_face_areas(add_max=SSH_add).
 subroutine set_dtbt(G, GV, US, CS, pbce, gtot_est, BT_cont, eta, SSH_add)
   type(ocean_grid_type),        intent(inout) :: G
   type(verticalGrid_type),      intent(in)    :: GV
@@ -160,14 +160,17 @@ subroutine set_dtbt(G, GV, US, CS, pbce, gtot_est, BT_cont, eta, SSH_add)
   real, dimension(SZI_(G),SZJ_(G)), optional, intent(in) :: eta
   real,               optional, intent(in)    :: SSH_add
   real(c_double) :: dtbt_out, ssh
+  type(c_ptr) :: p_eta
   integer(c_int) :: rc
   if (.not.CS%module_is_initialized) call MOM_error(FATAL, "set_dtbt: Module MOM_barotropic must be initialized before it is used.")
   if (present(BT_cont)) then ; if (associated(BT_cont)) call MOM_error(FATAL, &
       "set_dtbt (MI355X): SET_DTBT_USE_BT_CONT is not carried.") ; endif
+  ssh = 0.0 ; if (present(SSH_add)) ssh = SSH_add
   if (present(pbce)) then
-    rc = mom6x_set_dtbt_pbce(CS%ctx, shim_up3(1, pbce, STG_H, GV%ke), dtbt_out)
+    p_eta = c_null_ptr
+    if (present(eta) .and. CS%p%nonlinear_continuity /= 0) p_eta = shim_up2(2, eta, STG_H)   ! :3578
+    rc = mom6x_set_dtbt_pbce_eta(CS%ctx, shim_up3(1, pbce, STG_H, GV%ke), p_eta, ssh, dtbt_out)
   elseif (present(gtot_est)) then
-    ssh = 0.0 ; if (present(SSH_add)) ssh = SSH_add
     rc = mom6x_set_dtbt(CS%ctx, c_null_ptr, real(gtot_est, c_double), ssh, dtbt_out)
   else
     call MOM_error(FATAL, "set_dtbt: Either pbce or gtot_est must be present.") ; rc = 0
@@ -188,12 +191,18 @@ subroutine btcalc(h, G, GV, CS, h_u, h_v, may_use_default, OBC)
   type(ocean_OBC_type),    optional, pointer    :: OBC
   type(c_ptr) :: p_hu, p_hv
   integer(c_int) :: rc
+  logical :: use_default
   if (.not.CS%module_is_initialized) call MOM_error(FATAL, "btcalc: Module MOM_barotropic must be initialized before it is used.")
   if (present(OBC)) then ; if (associated(OBC)) call MOM_error(FATAL, "btcalc: open boundaries are not carried by the MI355X path.") ; endif
   if (present(h_u) .neqv. present(h_v)) call MOM_error(FATAL, "btcalc: Either both h_u and h_v or neither one must be present.")
   p_hu = c_null_ptr ; p_hv = c_null_ptr
   if (present(h_u)) then ; p_hu = shim_up3(2, h_u, STG_U, GV%ke) ; p_hv = shim_up3(3, h_v, STG_V, GV%ke) ; endif
-  rc = mom6x_btcalc(CS%ctx, shim_up3(1, h, STG_H, GV%ke), p_hu, p_hv)
+  use_default = .false. ; if (present(may_use_default)) use_default = may_use_default
+  if (use_default) then
+    rc = mom6x_btcalc(CS%ctx, shim_up3(1, h, STG_H, GV%ke), p_hu, p_hv)
+  else   ! :4426-4429: FROM_BT_CONT without h_u, h_v is "Inconsistent settings of optional arguments and hvel_scheme."
+    rc = mom6x_btcalc_strict(CS%ctx, shim_up3(1, h, STG_H, GV%ke), p_hu, p_hv)
+  endif
   call shim_check(rc, "btcalc")
 end subroutine btcalc
 
@@ -233,6 +242,7 @@ subroutine barotropic_init(u, v, h, Time, G, GV, US, param_file, diag, CS, &
   type(harmonic_analysis_CS), target, optional :: HA_CSp
   character(len=40) :: mdl = "MOM_barotropic"
   real :: dtbt_input, dtbt_restart
+  character(len=40) :: hvel_str
   integer :: bt_halo_sz, min_stencil
   real(c_double), target :: dtbt_c
   integer(c_int) :: rc
@@ -290,8 +300,25 @@ subroutine barotropic_init(u, v, h, Time, G, GV, US, param_file, diag, CS, &
   call get_param(param_file, mdl, "USE_BT_CONT_TYPE", CS%use_BT_cont_type, "If true, use a structure with elements that describe "//&
                  "effective face areas from the summed continuity solver as a function the barotropic flow in coupling between "//&
                  "the barotropic and baroclinic flow.  This is only used if SPLIT is true.", default=.true.)
-  if (.not.CS%use_BT_cont_type .and. CS%p%bound_BT_corr /= 0) call MOM_error(FATAL, "barotropic_init: BOUND_BT_CORRECTION "//&
-      "without a BT_cont_type is not carried by the MI355X path.")
+  ! BT_THICK_SCHEME :5566-5591.  Behind a BT_cont_type the MI355X step takes the thicknesses from BT_cont%h_u, h_v (FROM_BT_CONT,
+  ! the default); without one FROM_BT_CONT is the reference's own FATAL and the three interpolations are carried.
+  call get_param(param_file, mdl, "BT_THICK_SCHEME", hvel_str, "A string describing the scheme that is used to set the open face "//&
+                 "areas used for barotropic transport and the relative weights of the accelerations: ARITHMETIC, HARMONIC, "//&
+                 "HYBRID or FROM_BT_CONT.", default="FROM_BT_CONT")
+  select case (trim(hvel_str))
+    case ("HYBRID") ; CS%p%bt_thick_scheme = 1_c_int
+    case ("HARMONIC") ; CS%p%bt_thick_scheme = 2_c_int
+    case ("ARITHMETIC") ; CS%p%bt_thick_scheme = 3_c_int
+    case ("FROM_BT_CONT") ; CS%p%bt_thick_scheme = 0_c_int
+    case default
+      call MOM_error(FATAL, "barotropic_init: Unrecognized setting #define BT_THICK_SCHEME "//trim(hvel_str)//" found in input file.")
+  end select
+  if ((CS%p%bt_thick_scheme == 0) .and. .not.CS%use_BT_cont_type) call MOM_error(FATAL, &
+      "barotropic_init: BT_THICK_SCHEME FROM_BT_CONT can only be used if USE_BT_CONT_TYPE is defined.")
+  if ((CS%p%bt_thick_scheme /= 0) .and. CS%use_BT_cont_type) call MOM_error(FATAL, &
+      "barotropic_init: with USE_BT_CONT_TYPE the MI355X path carries BT_THICK_SCHEME = FROM_BT_CONT only.")
+  call get_param(param_file, mdl, "MAXVEL", CS%p%maxvel, "The maximum velocity allowed before the velocity components are "//&
+                 "truncated.", units="m s-1", default=3.0e8, scale=US%m_s_to_L_T)
   call must_be("INTEGRAL_BT_CONTINUITY", .false.)
   call must_be("ADJUST_BT_CONT", .false.) ; call must_be("GRADUAL_BT_ICS", .false.)
   call must_be("BT_NONLIN_STRESS", .false.) ; call must_be("DYNAMIC_SURFACE_PRESSURE", .false.)

@@ -45,10 +45,12 @@ extern "C" {
  * (use_wide_halos, BTHALO, min_stencil) (round 3).
  * 5: (round 5) mom6x_barotropic_params.nonlinear_continuity / nonlin_cont_update_period; btstep accepts BT_cont == NULL;
  *    mom6x_continuity_params.sum_order = MOM6X_SUM_TREE16_FMA.
+ * 6: (round 6) mom6x_barotropic_params.bt_thick_scheme / maxvel (BT_THICK_SCHEME without a BT_cont_type; BOUND_BT_CORRECTION through
+ *    eta_cor_bound), mom6x_set_dtbt_pbce_eta.
  * 4: (round 4) mom6x_dyn_split_RK2_restart_fills + MOM6X_RK2_HAVE_*, mom6x_rk2_diag_*; see the end of this comment's list in
  * DESIGN.md section 1.  Hosts compare mom6x_abi_version() with the value they were
  * built against (fortran/mom6x_c_api.F90 MOM6X_ABI_BUILT_FOR, mom6_amd/abi.py ABI_VERSION) and refuse to run on a mismatch. */
-#define MOM6X_ABI_VERSION 5
+#define MOM6X_ABI_VERSION 6
 
 /* ------------------------------------------------------------------------- */
 /* Tile dimensions and layout (MOM_hor_index.F90:14-44 hor_index_type +
@@ -177,7 +179,18 @@ typedef struct mom6x_barotropic_params {
    * NONLIN_BT_CONT_UPDATE_PERIOD sub-steps with a stencil of 2 (MOM_barotropic.F90:767-768, :1131-1136, :2539-2543, :5146-5237).     */
   int    nonlinear_continuity;       /* NONLINEAR_BT_CONTINUITY (F); ignored when BT_cont is given                                  */
   int    nonlin_cont_update_period;  /* NONLIN_BT_CONT_UPDATE_PERIOD (1); 0: the face areas of the step's first eta throughout      */
+  /* ABI 6.  BT_THICK_SCHEME (:5566-5591) for btcalc calls without h_u / h_v: MOM6X_BT_THICK_*.  FROM_BT_CONT (the reference's default)
+   * needs the BT_cont_type: btcalc without h_u then falls back to HYBRID only where the reference passes may_use_default (:4419-4430,
+   * barotropic_init :6127), and the step without a BT_cont_type refuses it as barotropic_init does (:5589-5591).                       */
+  int    bt_thick_scheme;
+  /* MAXVEL (3e8 m/s) [L T-1]: only in eta_cor_bound = IareaT 0.1 maxvel (Datu + Datu + Datv + Datv) (:6164-6173), the bound of
+   * BOUND_BT_CORRECTION when the BT_cont fits are not used for it (no BT_cont_type, or BT_CONT_CORR_BOUNDS = False) :1582-1585.       */
+  double maxvel;
 } mom6x_barotropic_params;
+#define MOM6X_BT_THICK_FROM_BT_CONT 0
+#define MOM6X_BT_THICK_HYBRID       1
+#define MOM6X_BT_THICK_HARMONIC     2
+#define MOM6X_BT_THICK_ARITHMETIC   3
 
 /* CoriolisAdv_CS (src/core/MOM_CoriolisAdv.F90:29-100; CoriolisAdv_init :1054).            */
 enum mom6x_coriolis_scheme {       /* CORIOLIS_SCHEME, values as in MOM_CoriolisAdv.F90:82-90       */
@@ -405,9 +418,12 @@ int mom6x_barotropic_init(mom6x_ctx *ctx, const mom6x_barotropic_params *p);
 
 /* btcalc(h, G, GV, CS, h_u, h_v, may_use_default, OBC)  :4360.  h_u/h_v are the
  * BT_cont%h_u/h_v face thicknesses (BT_THICK_SCHEME=FROM_BT_CONT, the default);
- * when NULL the HYBRID default of `may_use_default` is used.  Writes the
- * context's frhatu/frhatv.                                                   */
+ * when NULL the scheme of mom6x_barotropic_params.bt_thick_scheme (ARITHMETIC :4448, HYBRID :4453,
+ * HARMONIC :4476) and, for FROM_BT_CONT, the HYBRID default of `may_use_default`.  Writes the
+ * context's frhatu/frhatv.  mom6x_btcalc_strict is the call without may_use_default: FROM_BT_CONT
+ * without h_u / h_v is the reference's "Inconsistent settings" error (:4426-4429).               */
 int mom6x_btcalc(mom6x_ctx *ctx, const double *h, const double *h_u, const double *h_v);
+int mom6x_btcalc_strict(mom6x_ctx *ctx, const double *h, const double *h_u, const double *h_v);
 
 /* bt_mass_source(h, eta, set_cor, G, GV, CS)  :5243                           */
 int mom6x_bt_mass_source(mom6x_ctx *ctx, const double *h, const double *eta, int set_cor);
@@ -417,8 +433,11 @@ int mom6x_bt_mass_source(mom6x_ctx *ctx, const double *h, const double *eta, int
 int mom6x_set_dtbt(mom6x_ctx *ctx, const double *pbce, double gtot_est, double SSH_add,
                    double *dtbt_out);
 
-/* set_dtbt(G, GV, US, CS, pbce, eta=eta) as called at MOM_dynamics_split_RK2.F90:667 (face areas
- * from the resting depths, find_face_areas :5221-5236).                                      */
+/* set_dtbt(G, GV, US, CS, pbce, eta=, SSH_add=) without a BT_cont argument, MOM_barotropic.F90:3576-3582: face areas
+ * from find_face_areas(eta=eta) :5171-5186 when NONLINEAR_BT_CONTINUITY is set and eta is not NULL, otherwise from
+ * find_face_areas(add_max=SSH_add) :5208-5219 (the deeper of the two neighbouring columns).  mom6x_set_dtbt_pbce is the call
+ * of MOM_dynamics_split_RK2.F90:667 behind a BT_cont_type (= eta NULL, SSH_add 0).                                     */
+int mom6x_set_dtbt_pbce_eta(mom6x_ctx *ctx, const double *pbce, const double *eta, double SSH_add, double *dtbt_out);
 int mom6x_set_dtbt_pbce(mom6x_ctx *ctx, const double *pbce, double *dtbt_out);
 
 /* btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, eta_PF_in,

@@ -123,6 +123,9 @@ class BTCont(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _names]
 
 
+BT_THICK_FROM_BT_CONT, BT_THICK_HYBRID, BT_THICK_HARMONIC, BT_THICK_ARITHMETIC = 0, 1, 2, 3   # MOM6X_BT_THICK_*
+
+
 class BarotropicParams(C.Structure):
     """mom6x_barotropic_params; barotropic_CS (MOM_barotropic.F90:108-330)."""
     _fields_ = [
@@ -136,6 +139,7 @@ class BarotropicParams(C.Structure):
         ("dtbt_fraction", C.c_double), ("Z_ref", C.c_double),
         ("use_wide_halos", C.c_int), ("BTHALO", C.c_int), ("min_stencil", C.c_int),
         ("nonlinear_continuity", C.c_int), ("nonlin_cont_update_period", C.c_int),
+        ("bt_thick_scheme", C.c_int), ("maxvel", C.c_double),
     ]
 
 
@@ -145,6 +149,7 @@ def barotropic_params_default(dtbt):
     p.bebt, p.dtbt, p.dt_bt_filter = 0.1, dtbt, -0.25
     p.use_wide_halos, p.BTHALO, p.min_stencil = 1, 0, 0
     p.nonlinear_continuity, p.nonlin_cont_update_period = 0, 1
+    p.bt_thick_scheme, p.maxvel = BT_THICK_FROM_BT_CONT, 3.0e8
     p.BT_project_velocity = 0
     p.Sadourny = 1
     p.strong_drag = 0
@@ -410,7 +415,7 @@ MOM6X_OK = 0
 _lib = None
 
 
-ABI_VERSION = 5   # include/mom6x.h MOM6X_ABI_VERSION
+ABI_VERSION = 6   # include/mom6x.h MOM6X_ABI_VERSION
 
 
 def load_library(path=None):

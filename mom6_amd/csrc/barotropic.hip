@@ -136,7 +136,7 @@ k_btcalc_cols(Dm d, const double *__restrict__ G, const double *__restrict__ hf,
 template <int DIR>
 __global__ void __launch_bounds__(256)
 k_btcalc(Dm d, const double *__restrict__ G, const double *__restrict__ h, const double *__restrict__ hf,
-         double *__restrict__ fr, double h_neglect, double Z_to_H) {
+         double *__restrict__ fr, double h_neglect, double Z_to_H, int scheme) {
   const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -149,7 +149,16 @@ k_btcalc(Dm d, const double *__restrict__ G, const double *__restrict__ h, const
     for (int k = 0; k < nz; k++) hattot = hattot + hf[c + k * slab];
     const double Ihattot = mC / (hattot + h_neglect);
     for (int k = 0; k < nz; k++) fr[c + k * slab] = hf[c + k * slab] * Ihattot;
-  } else {   // HYBRID (may_use_default) :4447-4468; hat is staged in fr and rescaled afterwards
+  } else if (scheme == MOM6X_BT_THICK_ARITHMETIC || scheme == MOM6X_BT_THICK_HARMONIC) {   // :4448-4452, :4476-4483
+    for (int k = 0; k < nz; k++) {
+      const double hp = h[c + st + k * slab], hm = h[c + k * slab];
+      const double hat = (scheme == MOM6X_BT_THICK_ARITHMETIC) ? 0.5 * (hp + hm) : 2.0 * (hp * hm) / ((hp + hm) + h_neglect);
+      fr[c + k * slab] = hat;
+      hattot = hattot + hat;
+    }
+    const double Ihattot = mC / (hattot + h_neglect);
+    for (int k = 0; k < nz; k++) fr[c + k * slab] = fr[c + k * slab] * Ihattot;
+  } else {   // HYBRID (or may_use_default) :4453-4475; hat is staged in fr and rescaled afterwards
     const double *bathyT = gm(G, d, MOM6X_G_bathyT);
     double e_below = -0.5 * Z_to_H * (bathyT[c + st] + bathyT[c]);
     const double D_shallow = -Z_to_H * dmin(bathyT[c + st], bathyT[c]);
@@ -469,8 +478,10 @@ __global__ void k_find_Cor(Dm d, double *work, int Sadourny, int isvf, int ievf,
 }
 
 // Cor_ref :1451-1461 and eta_src :1548-1587
+// bound_BT_corr: 0 none; 1 the bounds from the BT_cont fits :1551-1580; 2 eta_cor_bound :1582-1585, formed here as barotropic_init
+// forms it (:6164-6173: find_face_areas without eta / add_max, the harmonic means of the resting depths :5221-5236)
 __global__ void k_cor_ref_eta_src(Dm d, const double *__restrict__ G, double *work, double *eta_cor, double Instep,
-                                  int bound_BT_corr, double maxCFL_Idt, double dt, double Z_to_H) {
+                                  int bound_BT_corr, double maxCFL_Idt, double dt, double Z_to_H, double Z_ref, double maxvel) {
   const int i = -1 + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = -1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -487,7 +498,20 @@ __global__ void k_cor_ref_eta_src(Dm d, const double *__restrict__ G, double *wo
   if (i >= 0 && j >= 0) {
     const double mT = gm(G, d, MOM6X_G_mask2dT)[c];
     double ec = eta_cor[c];
-    if (bound_BT_corr && mT > 0.0) {
+    if (bound_BT_corr == 2) {
+      const double *bathyT = gm(G, d, MOM6X_G_bathyT), *dy_Cu = gm(G, d, MOM6X_G_dy_Cu), *dx_Cv = gm(G, d, MOM6X_G_dx_Cv);
+      auto Dat = [&](size_t a, size_t bb, double len) {
+        const double H1 = (bathyT[a] + Z_ref) * Z_to_H, H2 = (bathyT[bb] + Z_ref) * Z_to_H;
+        double D = 0.0;
+        if ((H1 > 0.0) && (H2 > 0.0)) D = len * (2.0 * H1 * H2) / (H1 + H2);
+        return D;
+      };
+      const double DatuW = Dat(c - 1, c, dy_Cu[c - 1]), DatuE = Dat(c, c + 1, dy_Cu[c]);
+      const double DatvN = Dat(c, c + st, dx_Cv[c]), DatvS = Dat(c - st, c, dx_Cv[c - st]);
+      const double bound = dt * (gm(G, d, MOM6X_G_IareaT)[c] * 0.1 * maxvel * ((DatuW + DatuE) + (DatvN + DatvS)));
+      if (fabs(ec) > bound) ec = copysign(bound, ec);
+      eta_cor[c] = ec;
+    } else if (bound_BT_corr && mT > 0.0) {
       if (ec > 0.0) {
         const double u_max_cor = gm(G, d, MOM6X_G_dxT)[c] * maxCFL_Idt, v_max_cor = gm(G, d, MOM6X_G_dyT)[c] * maxCFL_Idt;
         const double *Bu = work + W_BTCu * slab, *Bv = work + W_BTCv * slab;
@@ -968,8 +992,8 @@ extern "C" int mom6x_btstep_warnings(mom6x_ctx *c, int reset, long long *count, 
 
 extern "C" int mom6x_barotropic_init(mom6x_ctx *c, const mom6x_barotropic_params *p) {
   REQUIRE(c && p, MOM6X_EINVAL, "mom6x_barotropic_init: null argument");
-  REQUIRE(!(p->bound_BT_corr && !p->BT_cont_bounds), MOM6X_EUNSUPPORTED,
-          "barotropic: BOUND_BT_CORRECTION without BT_CONT_CORR_BOUNDS is not supported");
+  REQUIRE(p->bt_thick_scheme >= MOM6X_BT_THICK_FROM_BT_CONT && p->bt_thick_scheme <= MOM6X_BT_THICK_ARITHMETIC, MOM6X_EINVAL,
+          "barotropic_init: Unrecognized setting of BT_THICK_SCHEME");
   REQUIRE(c->dims.halo >= 2, MOM6X_EINVAL, "barotropic: halo >= 2 required");
   REQUIRE(p->BTHALO <= c->dims.halo, MOM6X_EINVAL,
           "barotropic_init: BTHALO exceeds the halo of the tile context; create the context with halo = max(NIHALO, BTHALO)");
@@ -1024,6 +1048,13 @@ extern "C" int mom6x_barotropic_dtbt(mom6x_ctx *c, double *get, const double *se
   return MOM6X_OK;
 }
 
+// btcalc without may_use_default (the calls of step_MOM_dyn_split_RK2 :628, :650, :868): :4426-4429
+extern "C" int mom6x_btcalc_strict(mom6x_ctx *c, const double *h, const double *h_u, const double *h_v) {
+  REQUIRE(c && c->bt_init, MOM6X_EINVAL, "btcalc: Module MOM_barotropic must be initialized before it is used.");
+  REQUIRE((h_u && h_v) || c->bt.bt_thick_scheme != MOM6X_BT_THICK_FROM_BT_CONT, MOM6X_EINVAL,
+          "btcalc: Inconsistent settings of optional arguments and hvel_scheme.");
+  return mom6x_btcalc(c, h, h_u, h_v);
+}
 extern "C" int mom6x_btcalc(mom6x_ctx *c, const double *h, const double *h_u, const double *h_v) {
   REQUIRE(c && c->bt_init, MOM6X_EINVAL, "btcalc: Module MOM_barotropic must be initialized before it is used.");
   REQUIRE((h_u != nullptr) == (h_v != nullptr), MOM6X_EINVAL, "btcalc: Inconsistent settings of optional arguments");
@@ -1039,10 +1070,11 @@ extern "C" int mom6x_btcalc(mom6x_ctx *c, const double *h, const double *h_u, co
     HIPCHK(hipGetLastError());
     return MOM6X_OK;
   }
+  const int scheme = (c->bt.bt_thick_scheme == MOM6X_BT_THICK_FROM_BT_CONT) ? MOM6X_BT_THICK_HYBRID : c->bt.bt_thick_scheme;   // (use_default :4421-4424)
   KLAUNCH(c, "k_btcalc<0>", k_btcalc<0>, grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, h, h_u, c->bts->frhatu,
-                     c->GV.H_subroundoff, c->GV.Z_to_H);
+                     c->GV.H_subroundoff, c->GV.Z_to_H, scheme);
   KLAUNCH(c, "k_btcalc<1>", k_btcalc<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, h, h_v, c->bts->frhatv,
-                     c->GV.H_subroundoff, c->GV.Z_to_H);
+                     c->GV.H_subroundoff, c->GV.Z_to_H, scheme);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }
@@ -1071,16 +1103,19 @@ static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int 
 extern "C" int mom6x_set_dtbt(mom6x_ctx *c, const double *pbce, double gtot_est, double SSH_add, double *dtbt_out) {
   return set_dtbt_impl(c, pbce, gtot_est, 1, SSH_add, dtbt_out, nullptr);
 }
-// set_dtbt(G, GV, US, CS, pbce, eta=eta) as called from step_MOM_dyn_split_RK2 :667
+// set_dtbt(G, GV, US, CS, pbce, eta=eta, SSH_add=) without a BT_cont argument (:3576-3582): the face areas are
+// find_face_areas(eta=eta) :5171-5186 when NONLINEAR_BT_CONTINUITY is set (never with a BT_cont_type) and eta is given, and
+// find_face_areas(add_max=add_SSH) :5208-5219 otherwise -- the harmonic-mean form of :5221-5236 is never reached from set_dtbt.
+extern "C" int mom6x_set_dtbt_pbce_eta(mom6x_ctx *c, const double *pbce, const double *eta, double SSH_add, double *dtbt_out) {
+  REQUIRE(pbce, MOM6X_EINVAL, "set_dtbt: Either pbce or gtot_est must be present.");
+  const bool nonlin = c && c->bt_init && c->bt.nonlinear_continuity && eta;
+  return set_dtbt_impl(c, pbce, 0.0, nonlin ? 0 : 1, nonlin ? 0.0 : SSH_add, dtbt_out, nonlin ? eta : nullptr);
+}
+// ... as called from step_MOM_dyn_split_RK2 :667 behind a BT_cont_type (eta has no part)
 extern "C" int mom6x_set_dtbt_pbce(mom6x_ctx *c, const double *pbce, double *dtbt_out) {
-  REQUIRE(pbce, MOM6X_EINVAL, "set_dtbt: Either pbce or gtot_est must be present.");
-  return set_dtbt_impl(c, pbce, 0.0, 0, 0.0, dtbt_out, nullptr);
+  return mom6x_set_dtbt_pbce_eta(c, pbce, nullptr, 0.0, dtbt_out);
 }
-// ... and without a BT_cont_type: eta enters the face areas when NONLINEAR_BT_CONTINUITY is set (:3577-3578)
-int set_dtbt_eta(mom6x_ctx *c, const double *pbce, const double *eta) {
-  REQUIRE(pbce, MOM6X_EINVAL, "set_dtbt: Either pbce or gtot_est must be present.");
-  return set_dtbt_impl(c, pbce, 0.0, 0, 0.0, nullptr, (c && c->bt_init && c->bt.nonlinear_continuity) ? eta : nullptr);
-}
+int set_dtbt_eta(mom6x_ctx *c, const double *pbce, const double *eta) { return mom6x_set_dtbt_pbce_eta(c, pbce, eta, 0.0, nullptr); }
 static int set_dtbt_impl(mom6x_ctx *c, const double *pbce, double gtot_est, int add_max, double SSH_add, double *dtbt_out, const double *eta) {
   REQUIRE(c && c->bt_init, MOM6X_EINVAL, "set_dtbt: Module MOM_barotropic must be initialized before it is used.");
   HIPCHK(hipSetDevice(c->device));
@@ -1119,9 +1154,8 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
                             const double *uh0, const double *vh0, const double *u_uh0, const double *v_vh0,
                             double *etaav) {
   REQUIRE(c && c->bt_init, MOM6X_EINVAL, "btstep: Module MOM_barotropic must be initialized before it is used.");
-  // BT_cont == NULL: USE_BT_CONT_TYPE = False with NONLINEAR_BT_CONTINUITY = False (k_face_areas_as_fits); BOUND_BT_CORRECTION would
-  // then need eta_cor_bound (:6166-6173), which is not carried
-  REQUIRE(BT_cont || !c->bt.bound_BT_corr, MOM6X_EUNSUPPORTED, "btstep: BOUND_BT_CORRECTION without a BT_cont_type is not supported");
+  // BT_cont == NULL: USE_BT_CONT_TYPE = False (k_face_areas_as_fits); BOUND_BT_CORRECTION then bounds eta_cor by eta_cor_bound
+  // (:6164-6173, :1582-1585), as it does behind a BT_cont_type with BT_CONT_CORR_BOUNDS = False
   REQUIRE(U_in && V_in && eta_in && bc_accel_u && bc_accel_v && taux && tauy && pbce && eta_PF_in && U_Cor && V_Cor &&
           accel_layer_u && accel_layer_v && eta_out && uhbtav && vhbtav && visc_rem_u && visc_rem_v,
           MOM6X_EINVAL, "btstep: null mandatory array");
@@ -1205,7 +1239,7 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
 
   KLAUNCH(c, "k_find_Cor", k_find_Cor, grid3(ievf - isvf + 3, jevf - jsvf + 3, 1, b), b, d, work, P.Sadourny, isvf, ievf, jsvf, jevf);
   KLAUNCH(c, "k_cor_ref_eta_src", k_cor_ref_eta_src, grid3(d.ni + 1, d.nj + 1, 1, b), b, d, c->G, work, s->eta_cor, Instep,
-                     P.bound_BT_corr, P.maxCFL_BT_cont * Idt, dt, c->GV.Z_to_H);
+                     P.bound_BT_corr ? ((BT_cont && P.BT_cont_bounds) ? 1 : 2) : 0, P.maxCFL_BT_cont * Idt, dt, c->GV.Z_to_H, P.Z_ref, P.maxvel);
   {
     std::vector<double *> f = { work + W_eta_PF * slab, work + W_eta_src * slab, work + W_bt_rem_u * slab, work + W_bt_rem_v * slab,
                                 work + W_BT_force_u * slab, work + W_BT_force_v * slab };

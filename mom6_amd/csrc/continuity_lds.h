@@ -16,6 +16,7 @@ struct LdsArgs {
   // continuity_wave.hip: the face ranges of the launch, one or two parts (the two rims of a split pass go out as ONE launch); a part
   // is pgx x pgy work-groups of 16 faces x `rows` rows starting at the 128-byte aligned pib
   int np, pa0[2], pa1[2], pb0[2], pb1[2], pib[2], pgx[2], pgy[2];
+  int no_pairs;        // continuity_wave.hip: the results are not 16-byte aligned (odd slab or a host array at an odd double): 8-byte stores
   unsigned long long *stats;   // continuity_wave.hip: [0] flux re-evaluations of all Newton solves, [1] solves (face columns x solves), [2] exact-limit redos
 };
 

@@ -357,7 +357,7 @@ __device__ __forceinline__ double wave_flux_adjust(Col<MAXL, FMA> &C, bool activ
 // A lane owns one face of 16-layer slots: five 8-byte stores per 3-D result, each wavefront instruction a row of 32-byte pieces.
 // What a wavefront pays for a vector-memory instruction does not depend on its width (~170-250 cycles each while the other
 // wavefronts of the CU issue theirs: scripts/dev/mb_vmem.hip), so two slots go out as ONE instruction of 16 bytes per lane:
-// v_permlane16_swap_b32 (gfx950) exchanges the odd 16-lane rows of its first operand with the even rows of its second -- with
+// v_permlane16_swap_b32 (gfx950 only -- as is this library: mom6_amd/build.py) exchanges the odd 16-lane rows of its first operand with the even rows of its second -- with
 // A = slot 2m and B = slot 2m+1 of the values, an even face's lane ends with (A of its own face, A of the next face) and an
 // odd face's lane with (B of the face before, B of its own): the two neighbouring doubles of layer kl + 32m / kl + 32m + 16.
 __device__ __forceinline__ void swap_rows(double &a, double &b) {
@@ -868,7 +868,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   const bool pairs = false;
 #else
   const int ip_ = i0 + (fw ^ 1);
-  const bool pairs = !wave_any(active != (ip_ >= pa0 && ip_ <= pa1));
+  const bool pairs = !E.no_pairs && !wave_any(active != (ip_ >= pa0 && ip_ <= pa1));
 #endif
   const unsigned lanep = (unsigned)((size_t)((active ? i0 + (fw & ~1) : i0) + d.ioff) * 8) + (unsigned)((size_t)(kl + KL * (fw & 1)) * slab * 8);
 
@@ -954,6 +954,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   }
 }
 
+inline int d_slab_of(const mom6x_ctx *c) { return c->d.slab; }
 template <int DIR, int MAXL>
 int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   using ST = Stage<DIR>;
@@ -964,6 +965,9 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   // (139 spills), so they are only compiled into the variant that runs while mom6x_continuity_stats is switched on.
   const bool stats = (c->cont_stats != nullptr) && c->cont_stats_on && !E.fma;
   E.stats = stats ? c->cont_stats : nullptr;
+  // store_pairs writes 16 bytes at (array + row + k slab 8 + (i0 + ioff) 8), i0 + ioff a multiple of 4: aligned when the slab is even
+  // and the arrays start on 16 bytes (the context's own arrays do; an array a host hands in need not)
+  E.no_pairs = ((d_slab_of(c) & 1) || (((uintptr_t)A.uh | (uintptr_t)A.u_cor | (uintptr_t)E.h_face) & 15)) ? 1 : 0;
 #ifdef MOM6X_MFL_TIMING
   const size_t lds_bytes = sizeof(double) * (NF / 4) * (size_t)(SEG * (ST::NS3 * KL * MAXL + 16)) + 128;   // + the phase times
 #else

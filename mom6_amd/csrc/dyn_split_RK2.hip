@@ -407,7 +407,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   // the continuity call below run while it travels; continuity completes it before it touches a halo row
   startn(c, { eta, s->visc_rem_u, s->visc_rem_v }, { 0, 1, 2 }, { 1, nk, nk }, { 0, PW.cont, PW.cont });   // :484-486
 
-  if (!BTp) { bt_defer_btcalc(c, false); CHK(mom6x_btcalc(c, h, nullptr, nullptr)); }   // :627-628 (BT_THICK_SCHEME = HYBRID)
+  if (!BTp) { bt_defer_btcalc(c, false); CHK(mom6x_btcalc_strict(c, h, nullptr, nullptr)); }   // :627-628 (BT_THICK_SCHEME = HYBRID, HARMONIC or ARITHMETIC)
   if (have_eta_h) CHK(bt_mass_source_from(c, s->eta_h, eta, 1));        // :629, with the sum k_pgf_main left
   else CHK(mom6x_bt_mass_source(c, h, eta, 1));
   // continuity(u, v, h, hp, uh_in, vh_in, dt, visc_rem_u, visc_rem_v, BT_cont)  :646

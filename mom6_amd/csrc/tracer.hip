@@ -52,8 +52,9 @@ template <int C>
 __device__ __forceinline__ double div_by(double x) {
   static_assert(C == 3 || C == 6, "div_by: 3 or 6");
   const double y = 1.0 / (double)C;
-  const bool tiny = (fabs(x) < 0x1p-1000) && (x != 0.0);
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny) != 0, 0)) return x / (double)C;
+  // (+-Inf too: fma(-C, Inf, Inf) is a NaN where x / C is Inf; a NaN passes through either way)
+  const bool odd = ((fabs(x) < 0x1p-1000) && (x != 0.0)) || (fabs(x) == __builtin_inf());
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0, 0)) return x / (double)C;
   const double q = x * y;
   const double r = __builtin_fma(-(double)C, q, x);
   return copysign(__builtin_fma(r, y, q), x);
@@ -61,7 +62,9 @@ __device__ __forceinline__ double div_by(double x) {
 
 // PLM slope of a cell from its three values and the product of the masks of its two faces :445-449 / :824-828
 // (maxima and minima through v_max_f64 / v_min_f64: they differ from (a > b) ? a : b in the sign of a zero result only -- and in which
-//  operand a NaN drops out -- and every use below ends in fabs())
+//  operand a NaN drops out -- and every use below ends in fabs().  A NaN in tm or tp still reaches the slope through tp - tm; a NaN
+//  in tc alone drops out of dMx / dMn here as it does not in the reference's max(): NaN tracers are not guaranteed to propagate
+//  through the PLM slopes, but the cell's own update Tr = (Tr hlst - flux) Ihnew carries it on.)
 __device__ __forceinline__ double plm_slope3(double tm, double tc, double tp, double mprod) {
   const double dMx = __builtin_fmax(__builtin_fmax(tp, tc), tm) - tc, dMn = tc - __builtin_fmin(__builtin_fmin(tp, tc), tm);
   return mprod * dsign(__builtin_fmin(__builtin_fmin(0.5 * fabs(tp - tm), 2.0 * dMx), 2.0 * dMn), tp - tm);

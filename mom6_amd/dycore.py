@@ -166,9 +166,16 @@ class Dycore:
         check(self.lib, self.lib.mom6x_barotropic_dtbt(self.ctx, C.byref(out), None if value is None else C.byref(C.c_double(value))))
         return out.value
 
-    def btcalc(self, h, h_u=None, h_v=None):
+    def btcalc(self, h, h_u=None, h_v=None, may_use_default=True):
         """btcalc (MOM_barotropic.F90:4360)."""
-        check(self.lib, self.lib.mom6x_btcalc(self.ctx, _ptr(h), _ptr(h_u), _ptr(h_v)))
+        f = self.lib.mom6x_btcalc if may_use_default else self.lib.mom6x_btcalc_strict
+        check(self.lib, f(self.ctx, _ptr(h), _ptr(h_u), _ptr(h_v)))
+
+    def set_dtbt_pbce(self, pbce, eta=None, SSH_add=0.0):
+        """set_dtbt(G, GV, US, CS, pbce, eta=eta, SSH_add=) without BT_cont (MOM_barotropic.F90:3576-3582); returns CS%dtbt."""
+        out = C.c_double(0.0)
+        check(self.lib, self.lib.mom6x_set_dtbt_pbce_eta(self.ctx, _ptr(pbce), _ptr(eta), C.c_double(SSH_add), C.byref(out)))
+        return out.value
 
     def bt_mass_source(self, h, eta, set_cor):
         """bt_mass_source (MOM_barotropic.F90:5243)."""

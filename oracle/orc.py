@@ -117,8 +117,8 @@ def barotropic_init(d, G, GV, P, cs):
     assert rc == 0, rc
 
 
-def btcalc(d, G, GV, h, h_u, h_v, cs):
-    rc = lib().orc_btcalc(C.byref(d), _p(G), C.byref(GV), _p(h), _p(h_u), _p(h_v), C.byref(cs.struct))
+def btcalc(d, G, GV, h, h_u, h_v, cs, scheme=0):
+    rc = lib().orc_btcalc(C.byref(d), _p(G), C.byref(GV), _p(h), _p(h_u), _p(h_v), C.byref(cs.struct), C.c_int(int(scheme)))
     assert rc == 0, rc
 
 
@@ -133,6 +133,13 @@ def set_dtbt(d, G, GV, P, cs, pbce=None, gtot_est=0.0, SSH_add=0.0):
                             C.c_double(gtot_est), C.c_double(SSH_add), C.byref(dtbt), C.byref(dtbt_max))
     assert rc == 0, rc
     return dtbt.value, dtbt_max.value
+
+
+def set_dtbt_pbce_eta(d, G, GV, P, cs, pbce, eta=None):
+    """set_dtbt(pbce, eta=eta) as step_MOM_dyn_split_RK2 calls it (:667); returns (and leaves in P.dtbt) the new dtbt."""
+    rc = lib().orc_set_dtbt_pbce_eta(C.byref(d), _p(G), C.byref(GV), C.byref(P), C.byref(cs.struct), _p(pbce), _p(eta))
+    assert rc == 0, rc
+    return P.dtbt
 
 
 def btstep(d, G, GV, P, cs, first_direction, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, pbce,

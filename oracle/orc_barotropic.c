@@ -111,10 +111,11 @@ int orc_barotropic_init(const mom6x_dims *d, const double *G, const mom6x_vgrid 
   return MOM6X_OK;
 }
 
-/* btcalc :4360-4605.  h_u/h_v present (BT_THICK_SCHEME=FROM_BT_CONT) or, when NULL, the HYBRID
- * default selected by may_use_default (:4447-4468). */
+/* btcalc :4360-4605.  h_u/h_v present (BT_THICK_SCHEME=FROM_BT_CONT) or, when NULL, `scheme` (MOM6X_BT_THICK_*): ARITHMETIC
+ * :4448-4452, HYBRID :4453-4475, HARMONIC :4476-4483; FROM_BT_CONT without h_u is the HYBRID default selected by
+ * may_use_default (:4419-4424). */
 int orc_btcalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const double *h,
-               const double *h_u, const double *h_v, orc_bt_cs *CS) {
+               const double *h_u, const double *h_v, orc_bt_cs *CS, int scheme) {
   const double *bathyT = GM(G, d, MOM6X_G_bathyT);
   const double *mCu = GM(G, d, MOM6X_G_mask2dCu), *mCv = GM(G, d, MOM6X_G_mask2dCv);
   const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1, nz = d->nk;
@@ -132,7 +133,17 @@ int orc_btcalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, cons
       double hattot = 0.0;
       if (hf) {
         for (int k = 0; k < nz; k++) { hat[k] = hf[c + k * slab]; hattot = hattot + hat[k]; }
-      } else { /* HYBRID */
+      } else if (scheme == MOM6X_BT_THICK_ARITHMETIC) {
+        for (int k = 0; k < nz; k++) {
+          hat[k] = 0.5 * (h[c + st + k * slab] + h[c + k * slab]);
+          hattot = hattot + hat[k];
+        }
+      } else if (scheme == MOM6X_BT_THICK_HARMONIC) {
+        for (int k = 0; k < nz; k++) {
+          hat[k] = 2.0 * (h[c + st + k * slab] * h[c + k * slab]) / ((h[c + st + k * slab] + h[c + k * slab]) + h_neglect);
+          hattot = hattot + hat[k];
+        }
+      } else { /* HYBRID, or FROM_BT_CONT with may_use_default */
         e[nz] = -0.5 * Z_to_H * (bathyT[c + st] + bathyT[c]);
         double D_shallow = -Z_to_H * orc_min(bathyT[c + st], bathyT[c]);
         for (int k = nz - 1; k >= 0; k--) {
@@ -240,12 +251,13 @@ int orc_set_dtbt(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
                  double gtot_est, double SSH_add, double *dtbt, double *dtbt_max_out) {
   return orc_set_dtbt_ex(d, G, GV, P, CS, pbce, gtot_est, 1, SSH_add, dtbt, dtbt_max_out, NULL);
 }
-/* set_dtbt(G, GV, US, CS, pbce, eta=eta) as called from step_MOM_dyn_split_RK2 :667 (eta unused because
- * NONLINEAR_BT_CONTINUITY is false with BT_cont): updates P->dtbt. */
+/* set_dtbt(G, GV, US, CS, pbce, eta=eta) as called from step_MOM_dyn_split_RK2 :667: without a BT_cont argument and
+ * without (NONLINEAR_BT_CONTINUITY and eta) the face areas are ALWAYS find_face_areas(add_max=add_SSH) with add_SSH = 0
+ * (:3576-3582: the third branch; the harmonic-mean form :5221-5236 is never reached from set_dtbt).  Updates P->dtbt. */
 int orc_set_dtbt_pbce(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, mom6x_barotropic_params *P,
                       const orc_bt_cs *CS, const double *pbce) {
   double dtbt = 0.0;
-  int rc = orc_set_dtbt_ex(d, G, GV, P, CS, pbce, 0.0, 0, 0.0, &dtbt, NULL, NULL);
+  int rc = orc_set_dtbt_ex(d, G, GV, P, CS, pbce, 0.0, 1, 0.0, &dtbt, NULL, NULL);
   if (rc == MOM6X_OK) P->dtbt = dtbt;
   return rc;
 }
@@ -253,7 +265,8 @@ int orc_set_dtbt_pbce(const mom6x_dims *d, const double *G, const mom6x_vgrid *G
 int orc_set_dtbt_pbce_eta(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, mom6x_barotropic_params *P,
                           const orc_bt_cs *CS, const double *pbce, const double *eta) {
   double dtbt = 0.0;
-  int rc = orc_set_dtbt_ex(d, G, GV, P, CS, pbce, 0.0, 0, 0.0, &dtbt, NULL, P->nonlinear_continuity ? eta : NULL);
+  const int nonlin = P->nonlinear_continuity && eta;   /* :3578 */
+  int rc = orc_set_dtbt_ex(d, G, GV, P, CS, pbce, 0.0, nonlin ? 0 : 1, 0.0, &dtbt, NULL, nonlin ? eta : NULL);
   if (rc == MOM6X_OK) P->dtbt = dtbt;
   return rc;
 }
@@ -349,9 +362,8 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
                double *etaav, int *nstep_out) {
   /* USE_BT_CONT_TYPE = False (BT_cont not associated): the barotropic continuity equation is linear in the velocities with the
    * face areas Datu, Datv of find_face_areas :5146-5237 (NONLINEAR_BT_CONTINUITY = False: its last branch, from the bathymetry);
-   * BOUND_BT_CORRECTION then needs eta_cor_bound, which is not restated. */
+   * BOUND_BT_CORRECTION then bounds eta_cor by eta_cor_bound (below). */
   const int use_BT_cont = (BT_cont != NULL);
-  if (!use_BT_cont && P->bound_BT_corr) return MOM6X_EUNSUPPORTED;
   const int is = 0, ie = d->ni - 1, js = 0, je = d->nj - 1, nz = d->nk, st = d->pitch;
   const int isd = -d->halo, ied = d->ni - 1 + d->halo, jsd = -d->halo, jed = d->nj - 1 + d->halo;
   const size_t slab = (size_t)d->slab, n3 = slab * nz;
@@ -626,8 +638,22 @@ int orc_btstep(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV,
   }
 
   /* eta_src :1548-1587 */
-  if (P->bound_BT_corr) {
-    if (!P->BT_cont_bounds) return MOM6X_EUNSUPPORTED;
+  if (P->bound_BT_corr && !(use_BT_cont && P->BT_cont_bounds)) {
+    /* :1582-1585 with eta_cor_bound as barotropic_init forms it :6164-6173 (find_face_areas(Datu, Datv, ..., 1) :5221-5236) */
+    for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
+      size_t c = IX2(d, i, j);
+      double Dat[4];
+      const size_t a_[4] = { c - 1, c, c, c - st }, b_[4] = { c, c + 1, c + st, c };   /* Datu(I-1,j), Datu(I,j), Datv(i,J), Datv(i,J-1) */
+      const double len_[4] = { GM(G, d, MOM6X_G_dy_Cu)[c - 1], GM(G, d, MOM6X_G_dy_Cu)[c], GM(G, d, MOM6X_G_dx_Cv)[c], GM(G, d, MOM6X_G_dx_Cv)[c - st] };
+      for (int q = 0; q < 4; q++) {
+        double H1 = (bathyT[a_[q]] + P->Z_ref) * GV->Z_to_H, H2 = (bathyT[b_[q]] + P->Z_ref) * GV->Z_to_H;
+        Dat[q] = 0.0;
+        if ((H1 > 0.0) && (H2 > 0.0)) Dat[q] = len_[q] * (2.0 * H1 * H2) / (H1 + H2);
+      }
+      double eta_cor_bound = IareaT[c] * 0.1 * P->maxvel * ((Dat[0] + Dat[1]) + (Dat[2] + Dat[3]));
+      if (fabs(CS->eta_cor[c]) > dt * eta_cor_bound) CS->eta_cor[c] = copysign(dt * eta_cor_bound, CS->eta_cor[c]);
+    }
+  } else if (P->bound_BT_corr) {
 #pragma omp parallel for schedule(static)
     for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
       size_t c = IX2(d, i, j);

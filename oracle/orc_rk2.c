@@ -21,7 +21,7 @@ int orc_continuity_PPM(const mom6x_dims *d, const double *G, const mom6x_vgrid *
                        const double *visc_rem_v, double *u_cor, double *v_cor, const mom6x_BT_cont *BT, double *du_cor,
                        double *dv_cor);
 int orc_btcalc(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const double *h, const double *h_u,
-               const double *h_v, orc_bt_cs *CS);
+               const double *h_v, orc_bt_cs *CS, int scheme);
 int orc_bt_mass_source(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, const double *h, const double *eta,
                        int set_cor, orc_bt_cs *CS);
 int orc_set_dtbt_pbce(const mom6x_dims *d, const double *G, const mom6x_vgrid *GV, mom6x_barotropic_params *P,
@@ -210,12 +210,15 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
   orc_pass_var(d, CS->visc_rem_u, 1, nz); orc_pass_var(d, CS->visc_rem_v, 2, nz); /* pass_visc_rem :621 */
 
   /* BT_cont_BT_thick true (BT_cont%h_u, h_v allocated): btcalc is called after continuity :649-652; false: from h :627-628 */
-  if (!BTc) orc_btcalc(d, G, GV, h, NULL, NULL, A->BTCS);
+  if (!BTc) {
+    if (A->bt->bt_thick_scheme == MOM6X_BT_THICK_FROM_BT_CONT) return MOM6X_EINVAL;   /* barotropic_init :5589-5591 */
+    orc_btcalc(d, G, GV, h, NULL, NULL, A->BTCS, A->bt->bt_thick_scheme);
+  }
   orc_bt_mass_source(d, G, GV, h, eta, 1, A->BTCS);
   rc = orc_continuity_PPM(d, G, GV, A->cont, A->first_direction, u_inst, v_inst, h, hp, uh_in, vh_in, dt, NULL, NULL,
                           CS->visc_rem_u, CS->visc_rem_v, NULL, NULL, BTc, NULL, NULL);   /* :644-648 (BT_USE_LAYER_FLUXES) */
   if (rc) return rc;
-  if (BTc) orc_btcalc(d, G, GV, h, BTc->h_u, BTc->h_v, A->BTCS);
+  if (BTc) orc_btcalc(d, G, GV, h, BTc->h_u, BTc->h_v, A->BTCS, A->bt->bt_thick_scheme);
   if (calc_dtbt) { rc = orc_set_dtbt_pbce_eta(d, G, GV, A->bt, A->BTCS, CS->pbce, BTc ? NULL : eta); if (rc) return rc; } /* :659-668 */
 
   /* predictor btstep :673-676 */
@@ -267,7 +270,7 @@ int orc_step_dyn_split_RK2(const orc_rk2_all *A, double *u_inst, double *v_inst,
     rc = orc_PressureForce_FV_Bouss(d, G, GV, A->pgf, A->Rlay, A->g_prime, hp, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF, A->T, A->S, A->eos);
     if (rc) return rc;
   }
-  if (BTc) orc_btcalc(d, G, GV, h, BTc->h_u, BTc->h_v, A->BTCS); /* :864-867 */
+  if (BTc) orc_btcalc(d, G, GV, h, BTc->h_u, BTc->h_v, A->BTCS, A->bt->bt_thick_scheme); /* :864-867 */
 
   /* diffu = horizontal viscosity terms (u_av) :884-888 -> replaced arrays, if supplied */
   if (diffu_new) memcpy(CS->diffu, diffu_new, n3 * sizeof(double));

@@ -150,6 +150,6 @@ def oracle_shim_case(orc, cfg, nsteps=SHIM_NSTEPS, no_bt_cont=False):
     hv.Ah_vel_scale = 0.02; hv.Smagorinsky_Ah = 1; hv.Smag_bi_const = 0.06
     bt_mod, rk2_mod = dict(strong_drag=1), None
     if no_bt_cont:
-        bt_mod.update(nonlinear_continuity=1); rk2_mod = dict(no_BT_cont=1)
+        bt_mod.update(nonlinear_continuity=1, bt_thick_scheme=abi.BT_THICK_HYBRID); rk2_mod = dict(no_BT_cont=1)
     so, m = oracle_rk2(orc, cfg, inp, nsteps, bt_mod=bt_mod, rk2_mod=rk2_mod, vv=(P,) + tuple(vis) + (None, None), hv=hv)
     return so, m, inp, vis

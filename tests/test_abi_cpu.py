@@ -41,7 +41,7 @@ def test_struct_sizes_match_ctypes_mirrors(lib):
                abi.SumOutputParams, abi.EnergySums, abi.RegridRhoParams]
     for which, cls in enumerate(mirrors):
         assert lib.mom6x_struct_size(which) == C.sizeof(cls), cls.__name__
-    assert lib.mom6x_abi_version() == abi.ABI_VERSION == 5
+    assert lib.mom6x_abi_version() == abi.ABI_VERSION == 6
 
 
 @pytest.mark.parametrize("ni,nj,nk,halo", [(44, 40, 2, 4), (1440, 1080, 75, 4), (7, 5, 1, 3), (720, 540, 75, 4)])

@@ -41,7 +41,7 @@ def make_inputs(orc, cfg, first_direction=0, u_max=0.1):
                 eta_PF=np.ascontiguousarray(eta_PF), ucor=ucor, vcor=vcor, first_direction=first_direction)
 
 
-def run_both(orc, I, pmod=None, use_uh0=True, use_etaav=True, bottom=False, default_thick=False, no_bt_cont=False):
+def run_both(orc, I, pmod=None, use_uh0=True, use_etaav=True, bottom=False, default_thick=False, no_bt_cont=False, eta_ms=None):
     import torch
     from mom6_amd.dycore import Dycore, BTContDev
     d, M, GV = I["d"], I["M"], I["GV"]
@@ -52,12 +52,13 @@ def run_both(orc, I, pmod=None, use_uh0=True, use_etaav=True, bottom=False, defa
     cs = orc.BtState(d)
     orc.barotropic_init(d, M, GV, P, cs)
     if default_thick:
-        orc.btcalc(d, M, GV, I["h"], None, None, cs)
+        orc.btcalc(d, M, GV, I["h"], None, None, cs, scheme=P.bt_thick_scheme)
     else:
         orc.btcalc(d, M, GV, I["h"], I["bt"]["h_u"], I["bt"]["h_v"], cs)
     dtbt, _ = orc.set_dtbt(d, M, GV, P, cs, gtot_est=9.8 + 0.02 * d.nk, SSH_add=10.0)
     P.dtbt = dtbt
-    orc.bt_mass_source(d, M, GV, I["h"], I["eta"], True, cs)
+    eta_ms = I["eta"] if eta_ms is None else eta_ms   # (the eta bt_mass_source compares sum(h) with: eta_cor is their difference)
+    orc.bt_mass_source(d, M, GV, I["h"], eta_ms, True, cs)
     z3 = lambda: np.zeros(d.shape3()); z2 = lambda: np.zeros(d.shape2())
     o = dict(alu=z3(), alv=z3(), eta_out=z2(), uhbtav=z2(), vhbtav=z2(), etaav=z2() if use_etaav else None)
     kw = {}
@@ -86,7 +87,7 @@ def run_both(orc, I, pmod=None, use_uh0=True, use_etaav=True, bottom=False, defa
     else:
         dyc.btcalc(T["h"], btd["h_u"], btd["h_v"])
     dtbt_g = dyc.set_dtbt(gtot_est=9.8 + 0.02 * d.nk, SSH_add=10.0)
-    dyc.bt_mass_source(T["h"], T["eta"], True)
+    dyc.bt_mass_source(T["h"], dyc.to_dev(eta_ms), True)
     g = dict(alu=dyc.zeros3(), alv=dyc.zeros3(), eta_out=dyc.zeros2(), uhbtav=dyc.zeros2(), vhbtav=dyc.zeros2(),
              etaav=dyc.zeros2() if use_etaav else None)
     kwg = {}
@@ -183,3 +184,74 @@ def test_btstep_without_BT_cont(orc, cfg, project, nonlinear):
     assert np.abs(res["uhbtav"][1]).max() > 0
     d, res = run_both(orc, I, dict(BT_project_velocity=project, **nl), default_thick=True, no_bt_cont=True, use_uh0=False)
     check(d, res, exact=False)
+
+
+@pytest.mark.parametrize("cfg", ["channel", "benchmark_small"])
+@pytest.mark.parametrize("scheme", [abi.BT_THICK_HYBRID, abi.BT_THICK_HARMONIC, abi.BT_THICK_ARITHMETIC])
+@pytest.mark.parametrize("bt_cont", [0, 1])
+def test_btstep_thick_schemes_and_eta_cor_bound(orc, cfg, scheme, bt_cont):
+    """BT_THICK_SCHEME = HYBRID / HARMONIC / ARITHMETIC for btcalc without h_u, h_v (MOM_barotropic.F90:4448-4483) and
+    BOUND_BT_CORRECTION through eta_cor_bound (:6164-6173, :1582-1585) -- without a BT_cont_type, and behind one with
+    BT_CONT_CORR_BOUNDS = False.  MAXVEL is small enough that the bound acts on most columns.  Bit for bit."""
+    I = make_inputs(orc, dict(channel=H.channel, benchmark_small=H.benchmark_small)[cfg]())
+    mod = dict(strong_drag=1, bt_thick_scheme=scheme, bound_BT_corr=1, BT_cont_bounds=0, maxvel=2.0e-5)
+    eta_ms = I["eta"] + 0.05 * synth.smooth_field(I["d"], 41) * (I["M"][G["mask2dT"]] > 0)   # eta_cor of a few centimetres, both signs
+    d, res = run_both(orc, I, mod, default_thick=True, no_bt_cont=not bt_cont, eta_ms=eta_ms)
+    check(d, res, exact=True)
+    # the bound did something: the same run without it differs
+    mod0 = dict(mod, bound_BT_corr=0)
+    d, res0 = run_both(orc, I, mod0, default_thick=True, no_bt_cont=not bt_cont, eta_ms=eta_ms)
+    assert not np.array_equal(res["eta_out"][1], res0["eta_out"][1])
+
+
+def test_set_dtbt_face_areas_on_a_sloping_bottom(orc):
+    """set_dtbt(pbce, eta=eta) without BT_cont and without NONLINEAR_BT_CONTINUITY takes find_face_areas(add_max=0)
+    (MOM_barotropic.F90:3576-3582, :5208-5219): dy_Cu Z_to_H max(max(D_i, D_i+1) + Z_ref, 0), the DEEPER neighbour, not the
+    harmonic mean of :5221-5236 -- checked against the formula written out in numpy on a bowl-shaped bottom, and equal to the
+    oracle's bits.  With NONLINEAR_BT_CONTINUITY and eta: the harmonic means of bathyT Z_to_H + eta (:5171-5186)."""
+    import torch
+    from mom6_amd.dycore import Dycore
+    I = make_inputs(orc, H.benchmark_small())
+    d, M, GV = I["d"], I["M"], I["GV"]
+    bathy = M[G["bathyT"]]
+    assert np.ptp(bathy[d.joff:d.joff + d.nj, d.ioff:d.ioff + d.ni]) > 100.0   # a sloping bottom
+    for nonlin in (0, 1):
+        P = abi.barotropic_params_default(20.0)
+        P.nonlinear_continuity = nonlin
+        cs = orc.BtState(d)
+        orc.barotropic_init(d, M, GV, P, cs)
+        orc.btcalc(d, M, GV, I["h"], I["bt"]["h_u"], I["bt"]["h_v"], cs)
+        dt_o = orc.set_dtbt_pbce_eta(d, M, GV, P, cs, I["pbce"], I["eta"])
+        dyc = Dycore(d, M, GV, I["first_direction"])
+        P2 = abi.barotropic_params_default(20.0)
+        P2.nonlinear_continuity = nonlin
+        dyc.barotropic_init(P2)
+        dyc.btcalc(dyc.to_dev(I["h"]), dyc.to_dev(I["bt"]["h_u"]), dyc.to_dev(I["bt"]["h_v"]))
+        dt_g = dyc.set_dtbt_pbce(dyc.to_dev(I["pbce"]), eta=dyc.to_dev(I["eta"]))
+        assert dt_g == dt_o, (nonlin, dt_g, dt_o)
+        # the formula, independently
+        sl = (slice(d.joff, d.joff + d.nj), slice(d.ioff, d.ioff + d.ni))
+        def sh(a, di, dj):
+            return a[d.joff + dj:d.joff + dj + d.nj, d.ioff + di:d.ioff + di + d.ni]
+        g = lambda n: M[G[n]]
+        Z = GV.Z_to_H
+        if nonlin:
+            Hc = bathy * Z + I["eta"]
+            hm = lambda a, b: np.where((a > 0) & (b > 0), 2.0 * a * b / np.where(a + b != 0, a + b, 1.0), 0.0)
+            DuE, DuW = sh(g("dy_Cu"), 0, 0) * hm(sh(Hc, 0, 0), sh(Hc, 1, 0)), sh(g("dy_Cu"), -1, 0) * hm(sh(Hc, -1, 0), sh(Hc, 0, 0))
+            DvN, DvS = sh(g("dx_Cv"), 0, 0) * hm(sh(Hc, 0, 0), sh(Hc, 0, 1)), sh(g("dx_Cv"), 0, -1) * hm(sh(Hc, 0, -1), sh(Hc, 0, 0))
+        else:
+            mx = lambda a, b: np.maximum(np.maximum(a, b) + P.Z_ref, 0.0)
+            DuE, DuW = sh(g("dy_Cu"), 0, 0) * Z * mx(sh(bathy, 1, 0), sh(bathy, 0, 0)), sh(g("dy_Cu"), -1, 0) * Z * mx(sh(bathy, 0, 0), sh(bathy, -1, 0))
+            DvN, DvS = sh(g("dx_Cv"), 0, 0) * Z * mx(sh(bathy, 0, 1), sh(bathy, 0, 0)), sh(g("dx_Cv"), 0, -1) * Z * mx(sh(bathy, 0, 0), sh(bathy, 0, -1))
+        fr_u, fr_v = cs["frhatu"], cs["frhatv"]
+        k3 = lambda a, di, dj: a[:, d.joff + dj:d.joff + dj + d.nj, d.ioff + di:d.ioff + di + d.ni]
+        pb = k3(I["pbce"], 0, 0)
+        gE, gW = (pb * k3(fr_u, 0, 0)).sum(0), (pb * k3(fr_u, -1, 0)).sum(0)
+        gN, gS = (pb * k3(fr_v, 0, 0)).sum(0), (pb * k3(fr_v, 0, -1)).sum(0)
+        f2 = g("Coriolis2Bu")
+        Idt2 = 0.5 * (1.0 + 2.0 * P.bebt) * (sh(g("IareaT"), 0, 0) * (gE * DuE * sh(g("IdxCu"), 0, 0) + gW * DuW * sh(g("IdxCu"), -1, 0) +
+                                              gN * DvN * sh(g("IdyCv"), 0, 0) + gS * DvS * sh(g("IdyCv"), 0, -1)) +
+                                             (sh(f2, 0, 0) + sh(f2, -1, -1) + sh(f2, -1, 0) + sh(f2, 0, -1)))
+        want = P.dtbt_fraction * np.sqrt(1.0 / Idt2.max())
+        assert abs(dt_g - want) <= 1e-12 * want, (nonlin, dt_g, want)

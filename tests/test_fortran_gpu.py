@@ -97,7 +97,7 @@ def _write_shim_case(path, cfg, orc, no_bt_cont=False):
             H.assert_bitwise(so[n][(Ellipsis,) + tuple(H.interior(d, stg_of.get(n, "h")))], gold[n], "oracle vs committed fixture: " + n)
     params = cases.shim_case_params(inp["dt"], H.golden_tag() != "")
     if no_bt_cont:
-        params.update({"USE_BT_CONT_TYPE": "False", "NONLINEAR_BT_CONTINUITY": "True"})
+        params.update({"USE_BT_CONT_TYPE": "False", "NONLINEAR_BT_CONTINUITY": "True", "BT_THICK_SCHEME": "HYBRID"})
     GV = inp["GV"]
     with open(path, "wb") as f:
         f.write(struct.pack("<10i", 1297042743, d.ni, d.nj, d.nk, d.halo, cases.SHIM_NSTEPS, cases.SHIM_SAVE_AFTER, 0, abi.G_COUNT, len(params)))

@@ -162,16 +162,18 @@ def test_rk2_channel_bitexact_tc1_like(orc):
 
 
 @pytest.mark.parametrize("cfg", ["double_gyre", "channel", "benchmark_small"])
-@pytest.mark.parametrize("nonlinear,period", [(0, 1), (1, 1), (1, 0), (1, 3)])
-def test_rk2_without_a_BT_cont_type(orc, cfg, nonlinear, period):
+@pytest.mark.parametrize("nonlinear,period,thick", [(0, 1, 1), (1, 1, 1), (1, 0, 2), (1, 3, 3)])
+def test_rk2_without_a_BT_cont_type(orc, cfg, nonlinear, period, thick):
     """USE_BT_CONT_TYPE = False (mom6x_rk2_params.no_BT_cont; .testing/tc1 sets NONLINEAR_BT_CONTINUITY, which implies it): CS%BT_cont
-    is not associated, so btcalc works from h before the barotropic mass source (RK2.F90:627, BT_THICK_SCHEME = HYBRID), the
+    is not associated, so btcalc works from h before the barotropic mass source (RK2.F90:627, BT_THICK_SCHEME = HYBRID / HARMONIC /
+    ARITHMETIC; the last case also with BOUND_BT_CORRECTION through eta_cor_bound), the
     first continuity call only makes the layer fluxes btstep adds (:644-648, BT_USE_LAYER_FLUXES), set_dtbt takes eta (:667,
     used by NONLINEAR_BT_CONTINUITY), both btstep calls find their face areas from the bathymetry (+ eta, recomputed every
     NONLIN_BT_CONT_UPDATE_PERIOD sub-steps) and the corrector keeps the predictor's thickness fractions (:867).  Three steps,
     every prognostic and restart field bit for bit."""
     run(orc, getattr(H, cfg)(), nsteps=3, rk2_mod=dict(no_BT_cont=1),
-        bt_mod=dict(strong_drag=1, BT_project_velocity=1, bebt=0.2, nonlinear_continuity=nonlinear, nonlin_cont_update_period=period))
+        bt_mod=dict(strong_drag=1, BT_project_velocity=1, bebt=0.2, nonlinear_continuity=nonlinear, nonlin_cont_update_period=period,
+                    bt_thick_scheme=thick, bound_BT_corr=int(thick == 3), maxvel=3.0e8 if thick != 3 else 1.0e-4))
 
 
 @pytest.mark.parametrize("cont_mod", [dict(vol_CFL=1), dict(aggress_adjust=1, vol_CFL=1)])
