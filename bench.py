@@ -1036,8 +1036,11 @@ def run_rank(args, env):
                    "thermo_steps_in_timed_region": n_thermo,
                    "state": "seeded smooth fields (SURVEY.md 8d): |u|, |v| <= %.2g m/s per layer, thicknesses perturbed by 1 %%" % float(os.environ.get("MOM6X_BENCH_UMAX", "0.5")),
                    "newton_evals_per_solve": round(nw_evals / max(nw_solves, 1), 3), "newton_solves_repeated_with_exact_limits": nw_redos,
-                   "sum_order": "TREE16 (column sums of the mass-flux kernels as a 16-lane tree; MOM6X_SUMS=exact: the reference's k order)"
-                                if dyc.cont_params.sum_order else "REFERENCE (sequential in k, bit-identical to the Fortran loop nest)",
+                   "sum_order": {0: "REFERENCE (sequential in k, bit-identical to the Fortran loop nest)",
+                                 1: "TREE16 (column sums of the mass-flux kernels as a 16-lane tree; MOM6X_SUMS=exact: the reference's k order)",
+                                 2: "TREE16_FMA (column sums of the mass-flux kernels as a 16-lane tree, fused multiply-adds at fixed sites that the "
+                                    "oracle restates; 3e-12 of range from the reference's order after 10 steps; MOM6X_SUMS=tree: un-fused, "
+                                    "MOM6X_SUMS=exact: the reference's k order)"}[int(dyc.cont_params.sum_order)],
                    "frozen_inputs": "none of the step's callees; vertvisc_coef and horizontal_viscosity run on the device inside the step (the set_viscous_BBL inputs of vertvisc_coef are constant synthetic fields)",
                    "tile": [d.ni, d.nj, d.nk], "halo": d.halo, "BTHALO": args.bthalo},
         "roofline": roofline, "restart_checksums": restart_checksums,

@@ -130,7 +130,8 @@ typedef struct mom6x_continuity_params {
                             *     *_flux_thickness (:936-955, :1017-1030) as fma(CFL, fma(q, r, p), a); u + du * visc_rem as
                             *     fma(du, visc_rem, u); the masked neighbours and the edge values of PPM_reconstruction_x/y
                             *     (:2396-2405).  oracle/orc_continuity.c restates the same sites; against the reference order the
-                            *     results agree to round-off (bound and 10-step drift: tests/test_sum_order_gpu.py).  Opt-in.      */
+                            *     results agree to round-off (bound and 10-step drift: tests/test_sum_order_gpu.py).  The default of the
+                            *     hosts since round 6 (mom6_amd/abi.py default_sum_order, MOM6X_CONTINUITY_SUMS of the Fortran shim).       */
 } mom6x_continuity_params;
 #define MOM6X_SUM_REFERENCE  0
 #define MOM6X_SUM_TREE16     1

@@ -464,8 +464,6 @@ extern "C" int mom6x_continuity_init(mom6x_ctx *c, const mom6x_continuity_params
           "continuity_PPM: sum_order must be MOM6X_SUM_REFERENCE (0), MOM6X_SUM_TREE16 (1) or MOM6X_SUM_TREE16_FMA (2)");
   REQUIRE(p->sum_order == MOM6X_SUM_REFERENCE || mass_flux_wave_usable(c->d.nk), MOM6X_EUNSUPPORTED,
           "continuity_PPM: sum_order = MOM6X_SUM_TREE16(_FMA) carries at most 128 layers; use MOM6X_SUM_REFERENCE");
-  REQUIRE(p->sum_order != MOM6X_SUM_TREE16_FMA || !(p->aggress_adjust || p->vol_CFL), MOM6X_EUNSUPPORTED,
-          "continuity_PPM: sum_order = MOM6X_SUM_TREE16_FMA is not carried with CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL");
   c->cont = *p;
   c->cont_init = true;
   return MOM6X_OK;

@@ -629,7 +629,6 @@ int orc_continuity_PPM(const mom6x_dims *d, const double *G, const mom6x_vgrid *
                        double *u_cor, double *v_cor, const mom6x_BT_cont *BT,
                        double *du_cor, double *dv_cor) {
   if (CS->sum_order != MOM6X_SUM_REFERENCE && CS->sum_order != MOM6X_SUM_TREE16 && CS->sum_order != MOM6X_SUM_TREE16_FMA) return MOM6X_EINVAL;
-  if (CS->sum_order == MOM6X_SUM_TREE16_FMA && (CS->aggress_adjust || CS->vol_CFL)) return MOM6X_EUNSUPPORTED;
   /* CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL: the device takes its thread-per-column kernels for these, whose column
    * sums run in the reference's order whatever sum_order says (include/mom6x.h) */
   mom6x_continuity_params CS_local = *CS;

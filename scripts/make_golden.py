@@ -24,7 +24,7 @@ STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h",
 
 def main():
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
-    for sums in ("exact", "tree"):   # both orders of the mass-flux column sums (mom6x_continuity_params.sum_order)
+    for sums in ("exact", "tree", "fma"):   # the three arithmetics of the mass-flux column sums (mom6x_continuity_params.sum_order)
         os.environ["MOM6X_SUMS"] = sums
         write_set()
     for f in sorted(os.listdir(os.path.join(ROOT, "tests", "golden"))):

@@ -131,11 +131,11 @@ def oracle_ocean_stats(orc, cfg, nsteps=3, bt_mod=None):
 SHIM_NSTEPS, SHIM_SAVE_AFTER = 4, 2
 
 
-def shim_case_params(dt, tag_tree):
+def shim_case_params(dt, tag_tree):   # tag_tree: helpers.golden_tag()
     # (DTBT keeps its default -0.98: a fraction of the stability limit, set by the first step's set_dtbt as in the oracle's run)
     return {"DT": repr(dt), "BT_STRONG_DRAG": "True", "KV": "1.0e-4", "HMIX_FIXED": "20.0", "HBBL": "10.0",
             "AH_VEL_SCALE": "0.02", "SMAGORINSKY_AH": "True", "SMAG_BI_CONST": "0.06", "REENTRANT_X": "False",
-            "ENABLE_THERMODYNAMICS": "False", "MOM6X_CONTINUITY_SUMS": "TREE16" if tag_tree else "REFERENCE"}
+            "ENABLE_THERMODYNAMICS": "False", "MOM6X_CONTINUITY_SUMS": {"": "REFERENCE", "_tree16": "TREE16", "_tree16_fma": "TREE16_FMA"}[tag_tree]}
 
 
 def oracle_shim_case(orc, cfg, nsteps=SHIM_NSTEPS, no_bt_cont=False):

@@ -20,10 +20,11 @@ def orc():
     return _orc
 
 
-@pytest.fixture(params=["tree", "exact"])
+@pytest.fixture(params=["fma", "tree", "exact"])
 def sums(request, monkeypatch):
-    """Both orders of the mass-flux column sums (mom6x_continuity_params.sum_order, abi.default_sum_order): "tree" = the
-    default of the device (MOM6X_SUM_TREE16, the wave-owned kernel), "exact" = the reference's sequential k order
+    """The three arithmetics of the mass-flux kernels (mom6x_continuity_params.sum_order, abi.default_sum_order): "fma" = the
+    default of the device (MOM6X_SUM_TREE16_FMA: the wave-owned kernel's 16-lane tree + fused multiply-adds at fixed sites),
+    "tree" = the same tree un-fused (MOM6X_SUM_TREE16), "exact" = the reference's sequential k order
     (MOM6X_SUM_REFERENCE, the LDS kernel).  The oracle follows the same switch, so "exact" cases are held to the
     REFERENCE-order restatement bit for bit."""
     monkeypatch.setenv("MOM6X_SUMS", request.param)

@@ -140,8 +140,8 @@ def assert_close(a, b, name, rtol, sl=None):
 # ---- committed fixtures (tests/golden/*.npz): computational-domain slices of oracle outputs on seeded inputs
 def golden_tag():
     """Fixtures exist for both orders of the mass-flux column sums (mom6x_continuity_params.sum_order): the ones of the
-    16-lane tree carry the suffix _tree16.  The order in force is abi.continuity_params_default's (MOM6X_SUMS)."""
-    return "_tree16" if abi.default_sum_order(1) == abi.SUM_TREE16 else ""
+    16-lane tree carry the suffix _tree16, the ones of the tree with fused multiply-adds (the default) _tree16_fma.  The order in force is abi.continuity_params_default's (MOM6X_SUMS)."""
+    return {abi.SUM_TREE16: "_tree16", abi.SUM_TREE16_FMA: "_tree16_fma"}.get(abi.default_sum_order(1), "")
 
 
 def golden_path(name, ext=".npz"):

@@ -123,8 +123,6 @@ def test_continuity_aggress_adjust_and_volume_based_cfl(orc, flags, mode):
     """CONT_PPM_AGGRESS_ADJUST / CONT_PPM_VOLUME_BASED_CFL (MOM_continuity_PPM.F90:2725-2733; non-default): whatever path and sum
     order are asked for, the thread-per-column kernels run (reference order) -- velocities and adjustments strong enough for the
     limits on du to bind, faces narrower than their cells."""
-    if abi.default_sum_order(1) == abi.SUM_TREE16_FMA:
-        pytest.skip("MOM6X_SUM_TREE16_FMA is refused together with these switches (mom6x_continuity_init)")
     for cfg, fd in ((H.benchmark_small(), 0), (H.double_gyre(), 1)):
         gg, d, M = cfg
         _run_case(orc, (gg, d, H.narrowed_faces(d, M)), fd, mode, cs_mod=flags, u_scale=8.0, bt_pert=0.9)
@@ -146,8 +144,6 @@ def test_continuity_many_layers(orc, nk):
 
 def test_continuity_device_matches_committed_golden(orc):
     """HIP continuity_PPM (corrector-call shape) against tests/golden/continuity_benchmark_small_corrector.npz."""
-    if abi.default_sum_order(1) == abi.SUM_TREE16_FMA:
-        pytest.skip("no committed fixture for the opt-in arithmetic with fused multiply-adds")
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases

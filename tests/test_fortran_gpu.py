@@ -95,7 +95,7 @@ def _write_shim_case(path, cfg, orc, no_bt_cont=False):
         gold = H.load_golden("rk2_double_gyre_shims_4steps")
         for n in STATE:
             H.assert_bitwise(so[n][(Ellipsis,) + tuple(H.interior(d, stg_of.get(n, "h")))], gold[n], "oracle vs committed fixture: " + n)
-    params = cases.shim_case_params(inp["dt"], H.golden_tag() != "")
+    params = cases.shim_case_params(inp["dt"], H.golden_tag())
     if no_bt_cont:
         params.update({"USE_BT_CONT_TYPE": "False", "NONLINEAR_BT_CONTINUITY": "True", "BT_THICK_SCHEME": "HYBRID"})
     GV = inp["GV"]

@@ -8,7 +8,7 @@ import pytest
 from tests import cases
 from tests import helpers as H
 
-@pytest.fixture(autouse=True, params=["exact", "tree"])
+@pytest.fixture(autouse=True, params=["exact", "tree", "fma"])
 def sum_order(request, monkeypatch):
     """Both orders of the mass-flux column sums (mom6x_continuity_params.sum_order) have their own fixtures."""
     monkeypatch.setenv("MOM6X_SUMS", request.param)

@@ -43,6 +43,7 @@ def test_continuity_aggress_adjust_and_volume_based_cfl(orc, flags):
     gg, d, M = H.double_gyre()
     M = H.narrowed_faces(d, M)
     CS = abi.continuity_params_default(d.nk)
+    CS.sum_order = abi.SUM_REFERENCE   # (what these switches run in whatever sum_order says: the base run is compared with them)
     h, u, v = synth.make_state(d, M, thin_frac=0.1)
     base = _cont(orc, d, M, GV, CS, u, v, h, 1200.0)
     for k, val in flags.items():
