@@ -68,14 +68,28 @@ def build(force=False, verbose=False):
         resources = json.load(open(RESOURCES)) if os.path.exists(RESOURCES) else {}
     except Exception:
         resources = {}
+    todo = []
     for s in srcs:
         o = os.path.join(LIBDIR, os.path.basename(s)[:-4] + ".o")
         base = os.path.basename(s)
         if force or _newer([s] + hdrs, o) or base not in resources:
-            cmd = [HIPCC] + FLAGS + PER_FILE.get(base, []) + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            todo.append((s, o, base))
+        objs.append(o)
+
+    def compile_one(job):
+        s, o, base = job
+        cmd = [HIPCC] + FLAGS + PER_FILE.get(base, []) + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        return job, cmd, subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    # the files are independent: one hipcc per file, as many at a time as there are cores (MOM6X_BUILD_JOBS overrides)
+    jobs = max(1, min(len(todo), int(os.environ.get("MOM6X_BUILD_JOBS", os.cpu_count() or 1))))
+    if todo:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            results = list(pool.map(compile_one, sorted(todo, key=lambda j: -os.path.getsize(j[0]))))
+        for (s, o, base), cmd, r in results:
             other = "\n".join(l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l and
                               not re.match(r"^\s*(\d+ \||\| *\^|\|)", l))
             if r.returncode != 0:
@@ -84,8 +98,7 @@ def build(force=False, verbose=False):
             if other.strip():
                 sys.stderr.write(other + "\n")   # warnings / errors as before
             resources[base] = _parse_resource_remarks(r.stderr)
-            json.dump(resources, open(RESOURCES, "w"), indent=0, sort_keys=True)
-        objs.append(o)
+        json.dump(resources, open(RESOURCES, "w"), indent=0, sort_keys=True)
     if force or _newer(objs, LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         # RCCL is NOT linked: halo.hip resolves ncclSend/ncclRecv/... at run time from the RCCL already in

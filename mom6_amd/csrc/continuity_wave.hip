@@ -106,9 +106,6 @@ __device__ __forceinline__ double row_max(double s) {
 // flight holds about 24 registers of temporaries, and five of them push the kernel into scratch memory -- whose
 // reloads then queue behind the next row's LDS-DMA (the memory counter is in order).  Two layers in flight plus the
 // second wavefront of the SIMD cover the latency of a dependent FP64 chain.
-#ifndef MOM6X_MFW_OCC3   // (experiment: the specialised kernels SPEC >= this value compiled for three wavefronts per SIMD; 0: none)
-#define MOM6X_MFW_OCC3 0
-#endif
 #ifndef MOM6X_MFW_FENCE
 #define MOM6X_MFW_FENCE 2
 #endif
@@ -777,8 +774,13 @@ __device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A
 
 constexpr int SEG = 4;   // doubles per segment = faces per wavefront
 
+// Wavefronts per SIMD the kernel is compiled for: 8 slots per lane (nk <= 128) leave room for one, 4-5 slots for two; with 3 slots
+// (nk <= 48) the state is 56 registers smaller and three fit without scratch (5-16 % faster than two: profiles/r06_mfw.md; the
+// 5-slot kernels squeezed to three wavefronts go 84-276 bytes per lane into scratch and lose 8-70 %).
+// (of the 3-slot kernels the two lean specialisations fit; the general one and SPEC 2 would spill 12-76 bytes)
+constexpr int mfw_occ(int maxl, int spec, bool fma) { return (maxl > 5) ? 1 : ((maxl <= 3 && (spec == 1 || spec == 3)) ? 3 : 2); }
 template <int DIR, int MAXL, bool STATS, int SPEC, bool FMA>
-__global__ void __launch_bounds__(NF * KL, (MAXL > 5) ? 1 : ((MOM6X_MFW_OCC3 && SPEC >= MOM6X_MFW_OCC3 && MAXL == 5 && !FMA) ? 3 : 2))
+__global__ void __launch_bounds__(NF * KL, mfw_occ(MAXL, SPEC, FMA))
 k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
   using ST = Stage<DIR>;
   const Sw<SPEC> W(A, E);
@@ -977,7 +979,8 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   // statistics and everything else the general one.  MOM6X_MFW_SPEC=0 (tests/test_switches_gpu.py): always the general one.
   static const int spec_env = [] { const char *e = getenv("MOM6X_MFW_SPEC"); return e ? atoi(e) : 1; }();
   int spec = 0;
-  if (spec_env && !stats && MAXL == 5 && E.scheme == 0 && !E.monotonic && E.marginal && A.better_iter && A.use_visc_rem_max && A.visc_rem) {
+  constexpr bool HAS_SPEC = (MAXL >= 3 && MAXL <= 5);   // (the specialised kernels exist for 33..80 layers)
+  if (spec_env && !stats && HAS_SPEC && E.scheme == 0 && !E.monotonic && E.marginal && A.better_iter && A.use_visc_rem_max && A.visc_rem) {
     const bool bt = A.set_BT_cont && E.h_face, cor = A.uhbt && A.u_cor;
     if (bt && !A.uhbt && !A.u_cor) spec = 1;
     else if (bt && cor) spec = 2;
@@ -985,11 +988,11 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   }
   auto kern = stats ? k_mass_flux_wave<DIR, MAXL, true, 0, false> : k_mass_flux_wave<DIR, MAXL, false, 0, false>;
   if (E.fma) kern = k_mass_flux_wave<DIR, MAXL, false, 0, true>;   // (no statistics variant with fused multiply-adds)
-  if (MAXL == 5) {   // (the specialised kernels exist for 65..80 layers)
-    constexpr int M = (MAXL == 5) ? 5 : 2;   // (keeps the other instantiations of launch() from instantiating them)
-    if (spec == 1) kern = E.fma ? k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 1 : 0, true> : k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 1 : 0, false>;
-    if (spec == 2) kern = E.fma ? k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 2 : 0, true> : k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 2 : 0, false>;
-    if (spec == 3) kern = E.fma ? k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 3 : 0, true> : k_mass_flux_wave<DIR, M, false, (MAXL == 5) ? 3 : 0, false>;
+  if (HAS_SPEC) {
+    constexpr int S1 = HAS_SPEC ? 1 : 0, S2 = HAS_SPEC ? 2 : 0, S3 = HAS_SPEC ? 3 : 0;   // (keeps the other instantiations of launch() from instantiating them)
+    if (spec == 1) kern = E.fma ? k_mass_flux_wave<DIR, MAXL, false, S1, true> : k_mass_flux_wave<DIR, MAXL, false, S1, false>;
+    if (spec == 2) kern = E.fma ? k_mass_flux_wave<DIR, MAXL, false, S2, true> : k_mass_flux_wave<DIR, MAXL, false, S2, false>;
+    if (spec == 3) kern = E.fma ? k_mass_flux_wave<DIR, MAXL, false, S3, true> : k_mass_flux_wave<DIR, MAXL, false, S3, false>;
   }
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   long strips_rows = 0;
@@ -1005,7 +1008,7 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   // row that is only reconstructed) is cheap next to that.  MOM6X_MFW_ROWS overrides.
   {
     static int slots_cache[2][2][5] = {{{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}, {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}};
-    int &slots = slots_cache[DIR][E.fma ? 1 : 0][stats ? 4 : spec];
+    int &slots = slots_cache[DIR][E.fma ? 1 : 0][stats ? 4 : spec];   // (per instantiation of launch(): MAXL is a template parameter)
     if (!slots) {
       int per_cu = 0, ncu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NF * KL, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
@@ -1063,8 +1066,8 @@ int mass_flux_wave_pair(mom6x_ctx *c, int dir, const FluxArgs &A, const FluxArgs
   E.i_base = E.pib[0];
   const int maxl = (nk + KL - 1) / KL;
 #define GO(D, M) return launch<D, M>(c, A, E)
-  if (dir == 0) { if (maxl <= 2) GO(0, 2); if (maxl <= 5) GO(0, 5); GO(0, 8); }
-  if (maxl <= 2) GO(1, 2); if (maxl <= 5) GO(1, 5); GO(1, 8);
+  if (dir == 0) { if (maxl <= 2) GO(0, 2); if (maxl <= 3) GO(0, 3); if (maxl <= 4) GO(0, 4); if (maxl <= 5) GO(0, 5); GO(0, 8); }
+  if (maxl <= 2) GO(1, 2); if (maxl <= 3) GO(1, 3); if (maxl <= 4) GO(1, 4); if (maxl <= 5) GO(1, 5); GO(1, 8);
 #undef GO
 }
 

@@ -34,7 +34,7 @@ modes = {
     "full": dict(visc_rem_u=vru, visc_rem_v=vrv, uhbt=uhbt, vhbt=vhbt, u_cor=ucor, v_cor=vcor, BT_cont=bt),
 }
 import ctypes
-wave = (dyc.cont_params.sum_order == abi.SUM_TREE16)   # the wave-owned kernel (default); MOM6X_SUMS=exact: the LDS kernel
+wave = (dyc.cont_params.sum_order != abi.SUM_REFERENCE)   # the wave-owned kernel (default); MOM6X_SUMS=exact: the LDS kernel
 timing = hasattr(dyc.lib, "mom6x_debug_mfw_timing" if wave else "mom6x_debug_mfl_timing")   # that file built with -DMOM6X_MFL_TIMING
 tfun = (dyc.lib.mom6x_debug_mfw_timing if wave else dyc.lib.mom6x_debug_mfl_timing) if timing else None
 PH = ["load+PPM", "bounds", "sweep0+sum", "adjust(uhbt)", "store+h_face", "adjust(du0)", "duL/duR rec", "3 trial sweeps",
