@@ -113,9 +113,11 @@ __global__ void k_bt_init_static(Dm d, const double *__restrict__ G, double Z_to
 // btcalc :4360 with BT_THICK_SCHEME = FROM_BT_CONT at nk = NK: the column of h_u is read ONCE into registers (NK
 // independent loads in flight), summed in the reference's order and written back scaled -- 2 words per face-layer
 // instead of 3.
-template <int DIR, int NK>
+template <int DIR, int NKT>   // (NKT: mom6x_dev.h NK_OF / NK_EXACT -- the layer count itself, or a bound on it)
 __global__ void __launch_bounds__(256)
 k_btcalc_cols(Dm d, const double *__restrict__ G, const double *__restrict__ hf, double *__restrict__ fr, double h_neglect) {
+  constexpr int NK = NK_OF(NKT);
+  const int nk = NK_EXACT(NKT) ? NK : d.nk;
   const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y * blockDim.y + threadIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -124,13 +126,13 @@ k_btcalc_cols(Dm d, const double *__restrict__ G, const double *__restrict__ hf,
   const double mC = gm(G, d, DIR ? MOM6X_G_mask2dCv : MOM6X_G_mask2dCu)[c];
   double v[NK];
 #pragma unroll
-  for (int k = 0; k < NK; k++) v[k] = hf[c + (size_t)k * slab];
+  for (int k = 0; k < NK; k++) if (k < nk) v[k] = hf[c + (size_t)k * slab];
   double hattot = 0.0;
 #pragma unroll
-  for (int k = 0; k < NK; k++) hattot = hattot + v[k];
+  for (int k = 0; k < NK; k++) if (k < nk) hattot = hattot + v[k];
   const double Ihattot = mC / (hattot + h_neglect);
 #pragma unroll
-  for (int k = 0; k < NK; k++) fr[c + (size_t)k * slab] = v[k] * Ihattot;
+  for (int k = 0; k < NK; k++) if (k < nk) fr[c + (size_t)k * slab] = v[k] * Ihattot;
 }
 
 template <int DIR>
@@ -919,21 +921,35 @@ inline dim3 blk2() { return dim3(64, 4, 1); }
 
 void bt_defer_layer_accel(mom6x_ctx *c, bool on) { if (c->bts) c->bts->la_defer = on; }
 
-// btcalc inside the RK2 step: with `on`, mom6x_btcalc(h_u, h_v) at nk = 75 only notes its operands; btstep's column pass forms the
+// btcalc inside the RK2 step: with `on`, mom6x_btcalc(h_u, h_v) only notes its operands; btstep's column pass forms the
 // thickness fractions from them (k_bt_col<., true>), and whoever else wants frhatu / frhatv (set_dtbt, mom6x_barotropic_field)
 // gets them through bt_frhat_materialize.  MOM6X_BTCALC=eager: btcalc always writes them.
 void bt_defer_btcalc(mom6x_ctx *c, bool on) {
   static const bool eager = [] { const char *e = getenv("MOM6X_BTCALC"); return e && !strcmp(e, "eager"); }();
   if (c->bts) c->bts->fr_defer = on && !eager;
 }
+// btcalc :4360 with h_u, h_v given (BT_THICK_SCHEME = FROM_BT_CONT): the column in registers up to COLS_NK_BOUND layers
+static void btcalc_from_faces(mom6x_ctx *c, const double *h_u, const double *h_v) {
+  const Dm d = c->d;
+  const dim3 b = blk2();
+  if (d.nk <= COLS_NK_BOUND) {
+#define BTC(NKT) do {                                                                                                                   \
+    KLAUNCH(c, "k_btcalc<0>", (k_btcalc_cols<0, NKT>), grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, h_u, c->bts->frhatu, c->GV.H_subroundoff); \
+    KLAUNCH(c, "k_btcalc<1>", (k_btcalc_cols<1, NKT>), grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, h_v, c->bts->frhatv, c->GV.H_subroundoff); } while (0)
+    COLS_NK_DISPATCH(d.nk, BTC);
+#undef BTC
+    return;
+  }
+  KLAUNCH(c, "k_btcalc<0>", k_btcalc<0>, grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, (const double *)nullptr, h_u, c->bts->frhatu,
+          c->GV.H_subroundoff, c->GV.Z_to_H, 0);
+  KLAUNCH(c, "k_btcalc<1>", k_btcalc<1>, grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, (const double *)nullptr, h_v, c->bts->frhatv,
+          c->GV.H_subroundoff, c->GV.Z_to_H, 0);
+}
 int bt_frhat_materialize(mom6x_ctx *c) {
   BTState *s = c->bts;
   if (!s || !s->fr_pending) return MOM6X_OK;
   HIPCHK(hipSetDevice(c->device));
-  const Dm d = c->d;
-  const dim3 b = blk2();
-  KLAUNCH(c, "k_btcalc<0>", (k_btcalc_cols<0, 75>), grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, s->fr_hu, s->frhatu, c->GV.H_subroundoff);
-  KLAUNCH(c, "k_btcalc<1>", (k_btcalc_cols<1, 75>), grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, s->fr_hv, s->frhatv, c->GV.H_subroundoff);
+  btcalc_from_faces(c, s->fr_hu, s->fr_hv);
   s->fr_pending = false;
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
@@ -1063,10 +1079,9 @@ extern "C" int mom6x_btcalc(mom6x_ctx *c, const double *h, const double *h_u, co
   const Dm d = c->d;
   const dim3 b = blk2();
   c->bts->fr_pending = false;
-  if (h_u && d.nk == 75 && c->bts->fr_defer) { c->bts->fr_pending = true; c->bts->fr_hu = h_u; c->bts->fr_hv = h_v; return MOM6X_OK; }
-  if (h_u && d.nk == 75) {   // the layer count the register-resident column kernel is built for
-    KLAUNCH(c, "k_btcalc<0>", (k_btcalc_cols<0, 75>), grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, h_u, c->bts->frhatu, c->GV.H_subroundoff);
-    KLAUNCH(c, "k_btcalc<1>", (k_btcalc_cols<1, 75>), grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, h_v, c->bts->frhatv, c->GV.H_subroundoff);
+  if (h_u && c->bts->fr_defer) { c->bts->fr_pending = true; c->bts->fr_hu = h_u; c->bts->fr_hv = h_v; return MOM6X_OK; }
+  if (h_u) {
+    btcalc_from_faces(c, h_u, h_v);
     HIPCHK(hipGetLastError());
     return MOM6X_OK;
   }
@@ -1206,7 +1221,7 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   Av.ubt_Cor = work + W_vbt_Cor * slab; Av.gtot_m = work + W_gtot_N * slab; Av.gtot_p = work + W_gtot_S * slab;
   Av.uh0sum = work + W_vh0sum * slab; Av.ubt0 = work + W_vbt0 * slab; Av.ubt = work + W_vbt * slab;
   Av.BT_force = work + W_BT_force_v * slab; Av.bt_rem = work + W_bt_rem_v * slab;
-  if (s->fr_pending && d.nk == 75) {   // btcalc's thickness fractions formed in the column pass (bt_defer_btcalc)
+  if (s->fr_pending) {   // btcalc's thickness fractions formed in the column pass (bt_defer_btcalc)
     Au.hf = s->fr_hu; Av.hf = s->fr_hv; Au.h_neglect = Av.h_neglect = c->GV.H_subroundoff;
     KLAUNCH(c, "k_bt_col<0>", (k_bt_col<0, true>), grid3(nxa(d.ni + 1, -1), d.nj, 1, b), b, d, c->G, Au);
     KLAUNCH(c, "k_bt_col<1>", (k_bt_col<1, true>), grid3(d.ni, d.nj + 1, 1, b), b, d, c->G, Av);

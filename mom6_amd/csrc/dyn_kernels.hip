@@ -812,10 +812,13 @@ k_vertvisc_remnant(Dm d, const double *__restrict__ G, double *__restrict__ vr, 
 // vertvisc_remnant with the column on chip (see k_vertvisc_cols): c1 and the un-substituted remnant stay in
 // registers, 2 words read and 1 written per face-layer instead of 6.  No Ray_u (that goes through
 // k_vertvisc_remnant); same operations in the same order.
-template <int DIR, int NK>
+// (NKT: mom6x_dev.h NK_OF / NK_EXACT -- the layer count itself, or a bound on it)
+template <int DIR, int NKT>
 __global__ void __launch_bounds__(64)
 k_vertvisc_remnant_cols(Dm d, const double *__restrict__ G, double *__restrict__ vr, const double *__restrict__ a_u,
                         const double *__restrict__ h_u, double dt) {
+  constexpr int NK = NK_OF(NKT);
+  const int nk = NK_EXACT(NKT) ? NK : d.nk;
   const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * 64 + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y;
   if (i > d.ni - 1 || j > d.nj - 1) return;
@@ -830,7 +833,7 @@ k_vertvisc_remnant_cols(Dm d, const double *__restrict__ G, double *__restrict__
 #pragma unroll
     for (int m = 0; m < VV_G; m++) {
       const int k = g * VV_G + m;
-      if (k < NK) { const size_t x3 = x + (size_t)k * slab; q_a[b][m] = a_u[x3 + slab]; q_h[b][m] = h_u[x3]; }
+      if (k < NK && k < nk) { const size_t x3 = x + (size_t)k * slab; q_a[b][m] = a_u[x3 + slab]; q_h[b][m] = h_u[x3]; }
     }
   };
   double a_kp = a_u[x];
@@ -843,7 +846,7 @@ k_vertvisc_remnant_cols(Dm d, const double *__restrict__ G, double *__restrict__
 #pragma unroll
     for (int m = 0; m < VV_G; m++) {
       const int k = g * VV_G + m;
-      if (k < NK) {
+      if (k < NK && k < nk) {
         const double a_k = a_kp; a_kp = q_a[g & 1][m];
         const double hu = q_h[g & 1][m];
         if (k == 0) {
@@ -863,9 +866,10 @@ k_vertvisc_remnant_cols(Dm d, const double *__restrict__ G, double *__restrict__
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  vr[x + (size_t)(NK - 1) * slab] = prev;
+  vr[x + (size_t)(nk - 1) * slab] = prev;
 #pragma unroll
   for (int k = NK - 2; k >= 0; k--) {
+    if (k >= nk - 1) continue;
     prev = rr[k] + cu[k + 1] * prev;
     vr[x + (size_t)k * slab] = prev;
   }
@@ -1608,13 +1612,15 @@ k_vertvisc_fused(Dm d, const double *__restrict__ G, const double *u_in, const d
 // fences keep the compiler from hoisting every load of the unrolled column to the top (which spills).
 // Same operations in the same order as k_vertvisc_fused: bit-identical.  Ray_u and the direct-stress
 // option go through k_vertvisc_fused.
-template <int DIR, bool UPD, bool REM, int NK>
+template <int DIR, bool UPD, bool REM, int NKT>
 __global__ void __launch_bounds__(64)
 k_vertvisc_cols(Dm d, const double *__restrict__ G, const double *u_in, const double *__restrict__ u_bc,
                 const double *__restrict__ u_abt, double dtx, double *u, double *__restrict__ vr,
                 const double *__restrict__ a_u, const double *__restrict__ h_u,
                 const double *__restrict__ tau, double dt, double dt_Rho0, double H_to_RZ,
                 double *__restrict__ tau_bot) {
+  constexpr int NK = NK_OF(NKT);
+  const int nk = NK_EXACT(NKT) ? NK : d.nk;
   extern __shared__ double vv_lds[];
   const int i = I_BASE((DIR ? 0 : -1)) + blockIdx.x * 64 + threadIdx.x;
   const int j = (DIR ? -1 : 0) + blockIdx.y;
@@ -1631,7 +1637,7 @@ k_vertvisc_cols(Dm d, const double *__restrict__ G, const double *u_in, const do
 #pragma unroll
     for (int m = 0; m < VV_G; m++) {
       const int k = g * VV_G + m;
-      if (k < NK) {
+      if (k < NK && k < nk) {
         const size_t x3 = x + (size_t)k * slab;
         q_a[b][m] = a_u[x3 + slab];
         q_h[b][m] = h_u[x3];
@@ -1652,7 +1658,7 @@ k_vertvisc_cols(Dm d, const double *__restrict__ G, const double *u_in, const do
 #pragma unroll
       for (int m = 0; m < VV_G; m++) {
         const int k = g * VV_G + m;
-        if (k < NK) {
+        if (k < NK && k < nk) {
           const double a_k = a_kp; a_kp = q_a[g & 1][m];
           const double hu = q_h[g & 1][m];
           const double u0 = UPD ? mC * (q_u[g & 1][m] + dtx * (q_b[g & 1][m] + q_t[g & 1][m])) : q_u[g & 1][m];
@@ -1676,33 +1682,40 @@ k_vertvisc_cols(Dm d, const double *__restrict__ G, const double *u_in, const do
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    u[x + (size_t)(NK - 1) * slab] = uprev;
-    if (REM) vr[x + (size_t)(NK - 1) * slab] = rprev;
+    u[x + (size_t)(nk - 1) * slab] = uprev;
+    if (REM) vr[x + (size_t)(nk - 1) * slab] = rprev;
+    const double u_bottom = uprev;   // (uu[nk - 1])
     asm volatile("" ::: "memory");   // the remnant comes back from LDS, not from 75 more live registers
 #pragma unroll
     for (int k = NK - 2; k >= 0; k--) {
+      if (k >= nk - 1) continue;
       const size_t x3 = x + (size_t)k * slab;
       const double ck = cu[k + 1];
       uprev = uu[k] + ck * uprev;
       u[x3] = uprev;
       if (REM) { rprev = rr[k * 64] + ck * rprev; vr[x3] = rprev; }
     }
-    if (tau_bot) tau_bot[x] = H_to_RZ * (uu[NK - 1] * a_kp);
+    if (tau_bot) tau_bot[x] = H_to_RZ * (u_bottom * a_kp);
   } else {
     if (UPD) {
-      for (int k = 0; k < NK; k++) {
+      for (int k = 0; k < nk; k++) {
         const size_t x3 = x + (size_t)k * slab;
         u[x3] = mC * (u_in[x3] + dtx * (u_bc[x3] + u_abt[x3]));
       }
     }
-    if (tau_bot) tau_bot[x] = H_to_RZ * (u[x + (size_t)(NK - 1) * slab] * a_u[x + (size_t)NK * slab]);
+    if (tau_bot) tau_bot[x] = H_to_RZ * (u[x + (size_t)(nk - 1) * slab] * a_u[x + (size_t)nk * slab]);
   }
 }
 
-// The layer counts the on-chip column kernel is built for (anything else walks through HBM).
+// The layer counts the on-chip column kernels are built for (anything deeper walks through HBM): 75 as such (the headline's), any
+// other count up to the bound with uniform tests on the layer index (mom6x_dev.h COLS_NK_BOUND).
+constexpr int VV_NK_BOUND = COLS_NK_BOUND;
+#define VV_NK_DISPATCH(nk, CALL) COLS_NK_DISPATCH(nk, CALL)
+constexpr int COEF_COLS_NK_BOUND = COLS_NK_BOUND;
+#define COEF_NK_DISPATCH(nk, CALL) COLS_NK_DISPATCH(nk, CALL)
 static bool vertvisc_cols_usable(int nk, const double *Ray, const DirectStress &S) {
   static const int mode = [] { const char *e = getenv("MOM6X_VERTVISC"); return (e && !strcmp(e, "walk")) ? 0 : 1; }();
-  return mode && nk == 75 && !Ray && !(S.Hmix > 0.0);
+  return mode && nk <= VV_NK_BOUND && !Ray && !(S.Hmix > 0.0);
 }
 
 template <int DIR>
@@ -1716,16 +1729,13 @@ static void launch_vertvisc_fused(mom6x_ctx *c, bool upd, bool rem, const double
   const char *nm = DIR ? "k_vertvisc_fused<1>" : "k_vertvisc_fused<0>";
   const DirectStress S = direct_stress_of(c);
   if (vertvisc_cols_usable(d.nk, Ray, S)) {
-    constexpr int NK = 75;
     const dim3 bc(64, 1, 1);
     const dim3 gc((unsigned)(((DIR ? d.ni : nxa(d.ni + 1, -1)) + 63) / 64), (unsigned)(DIR ? d.nj + 1 : d.nj), 1);
-    const size_t lds = rem ? (size_t)NK * 64 * sizeof(double) : 0;
     const char *nc = DIR ? "k_vertvisc_cols<1>" : "k_vertvisc_cols<0>";
-#define VVC(U, R) KLAUNCH_LDS(c, nc, (k_vertvisc_cols<DIR, U, R, NK>), gc, bc, lds, d, c->G, u_in, u_bc, u_abt, dtx, u, vr, a, h, tau, dt, dt_Rho0, HR, tau_bot)
-    if (upd && rem) VVC(true, true);
-    else if (upd) VVC(true, false);
-    else if (rem) VVC(false, true);
-    else VVC(false, false);
+#define VVC(U, R, NKT) KLAUNCH_LDS(c, nc, (k_vertvisc_cols<DIR, U, R, NKT>), gc, bc, (rem ? (size_t)NK_OF(NKT) * 64 * sizeof(double) : (size_t)0), d, c->G, u_in, u_bc, u_abt, dtx, u, vr, a, h, tau, dt, dt_Rho0, HR, tau_bot)
+#define VVC4(NKT) do { if (upd && rem) VVC(true, true, NKT); else if (upd) VVC(true, false, NKT); else if (rem) VVC(false, true, NKT); else VVC(false, false, NKT); } while (0)
+    VV_NK_DISPATCH(d.nk, VVC4);
+#undef VVC4
 #undef VVC
     return;
   }
@@ -1988,7 +1998,7 @@ __device__ __forceinline__ void cc_file_switch(int p, double (&aa)[NK + 1], cons
 // pair moves 12-13; MODE 1: u, u_bc, h in, visc_rem out = 4 against 8.  The same expressions in the same order as the kernels it
 // replaces (CoefWalk; the sweeps are copies): bit-identical.  KV_ML_INVZ2 (a top-down pre-pass through a_u), Rayleigh drag and the
 // direct-stress option stay with the separate kernels.
-template <int DIR, int MODE, bool REM, bool WRITE_COEF, int NK>
+template <int DIR, int MODE, bool REM, bool WRITE_COEF, int NKT>
 __global__ void __launch_bounds__(64)
 k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params CS, const double *u_in, const double *__restrict__ u_bc,
                      double dtx, const double *__restrict__ h, const double *__restrict__ Kv_bbl, const double *__restrict__ bbl_thick_in,
@@ -1998,6 +2008,8 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
                      double *__restrict__ tau_bot) {
   static_assert(MODE == 1 || MODE == 3, "k_vertvisc_coef_cols: MODE 1 (coefficients + remnant) or 3 (coefficients + solve)");
   static_assert(MODE == 3 || REM, "k_vertvisc_coef_cols: MODE 1 makes the remnant");
+  constexpr int NK = NK_OF(NKT);
+  const int nk = NK_EXACT(NKT) ? NK : d.nk;   // (NKT < 0: the arrays and unrolled loops have NK slots, the column nk <= NK layers)
   extern __shared__ double cc_lds[];
   // (DIR = 1: a block column's rows on ONE XCD, so that the row north of a face column -- the next work-group's own row -- meets it in
   //  that XCD's L2, was measured: 1.77-1.81 against 1.56 ms per launch; rows along blockIdx.y it is.)
@@ -2023,12 +2035,12 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
   if (!(mC > 0.)) {   // do_i :1514-1516: (MODE 3) the velocity estimate of the masked faces too; no coefficients, no solve
     if (MODE == 3) {
       double ul = 0.0;
-      for (int k = 0; k < NK; k++) {
+      for (int k = 0; k < nk; k++) {
         const size_t c = x + (size_t)k * slab;
         ul = mC * (u_in[c] + dtx * (u_bc[c] + abt_of(LA.pbce[c], LA.pbce[c + st])));
         u[c] = ul;
       }
-      if (tau_bot) tau_bot[x] = H_to_RZ * (ul * a_out[x + (size_t)NK * slab]);
+      if (tau_bot) tau_bot[x] = H_to_RZ * (ul * a_out[x + (size_t)nk * slab]);
     }
     return;
   }
@@ -2049,12 +2061,15 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
   constexpr int NG = (NK + CC_G - 1) / CC_G, NP = (NG + 1) / 2;
   double q_u[2][CC_G], q_b[2][CC_G], q_p0[2][CC_G], q_p1[2][CC_G], q_h0[2][CC_G], q_h1[2][CC_G];
   double t_a[2][CC_G];
+  double a_bot = 0.;
   auto fetch = [&](int g, const int b) {
 #pragma unroll
     for (int m = 0; m < CC_G; m++) {
       const int k = NK - 1 - (g * CC_G + m);
       if (k >= 0) {
-        const size_t c = x + (size_t)k * slab;
+        // (NKT < 0: a slot below the column's bottom fetches the bottom layer once more instead of standing under a test on the
+        //  layer index: the number of loads in flight stays a constant of the code and the waits for them stay partial)
+        const size_t c = x + (size_t)(NK_EXACT(NKT) ? k : min(k, nk - 1)) * slab;
         q_u[b][m] = u_in[c]; q_b[b][m] = u_bc[c];
         if (MODE == 3) { q_p0[b][m] = LA.pbce[c]; q_p1[b][m] = LA.pbce[c + st]; }
         q_h0[b][m] = h[c]; q_h1[b][m] = h[c + st];
@@ -2065,16 +2080,17 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
 #pragma unroll
     for (int m = 0; m < CC_G; m++) {
       const int k = NK - 1 - (g * CC_G + m);
-      if (k >= 0) {
+      if (k >= 0 && k < nk) {
         const size_t c = x + (size_t)k * slab;
         const double uk = (MODE == 3) ? mC * (q_u[b][m] + dtx * (q_b[b][m] + abt_of(q_p0[b][m], q_p1[b][m])))
                                       : mC * (q_u[b][m] + dtx * q_b[b][m]);
         const int K = k + 1;
         double Kv_add = 0.0;
-        if (K < NK && Kv_shear) Kv_add = 0.5 * (Kv_shear[x + (size_t)K * slab] + Kv_shear[y + (size_t)K * slab]);
+        if (K < nk && Kv_shear) Kv_add = 0.5 * (Kv_shear[x + (size_t)K * slab] + Kv_shear[y + (size_t)K * slab]);
         double hu, a;
-        W.layer(K, NK, q_h0[b][m], q_h1[b][m], uk, 0.0, Kv_shear != nullptr, Kv_add, hu, a);
+        W.layer(K, nk, q_h0[b][m], q_h1[b][m], uk, 0.0, Kv_shear != nullptr, Kv_add, hu, a);
         t_a[b][m] = a;
+        if (k == nk - 1) a_bot = a;                  // a_u at the bottom interface (aa[nk]): the walk's first layer
         // between the passes: h_u in LDS and the estimate through the result array -- or, when h_u is written anyway, the estimate
         // in LDS and h_u back from its array (a word less)
         if (EST_LDS) hh[k * 64] = uk; else { hh[k * 64] = hu; if (MODE == 3) u[c] = uk; }
@@ -2108,11 +2124,15 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
   const double *back = EST_LDS ? (const double *)h_out : (const double *)u;   // what comes back from memory: h_u or the estimate
   if (MODE == 3) {
 #pragma unroll
-    for (int k = 0; k < U_G && k < NK; k++) uu[k] = back[x + (size_t)k * slab];
+    for (int k = 0; k < U_G && k < NK; k++) uu[k] = back[x + (size_t)min(k, nk - 1) * slab];
   }
 #pragma unroll
   for (int k = 0; k < NK; k++) {
-    if (MODE == 3 && k + U_G < NK) uu[(MODE == 3) ? k + U_G : 0] = back[x + (size_t)(k + U_G) * slab];
+    // (NKT < 0: the loads are NOT under the test on the layer index -- a slot beyond the column reads the bottom layer again --, so
+    //  that the memory counter of the loads in flight stays exact across the tests; with them inside, the compiler waits for every
+    //  load at every join: 70 instead of 15 s_waitcnt vmcnt(0), and the kernel ran at half its speed)
+    if (MODE == 3 && k + U_G < NK) uu[(MODE == 3) ? k + U_G : 0] = back[x + (size_t)min(k + U_G, nk - 1) * slab];
+    if (k < nk) {
     const double a_k = aa[k], a_kp = aa[k + 1];
     const double from_lds = hh[k * 64], from_mem = (MODE == 3) ? uu[(MODE == 3) ? k : 0] : 0.0;
     const double hu = EST_LDS ? from_mem : from_lds;
@@ -2133,20 +2153,23 @@ k_vertvisc_coef_cols(Dm d, const double *__restrict__ G, mom6x_vertvisc_params C
     }
     if (MODE == 3) uu[(MODE == 3) ? k : 0] = uprev;
     if (REM) hh[k * 64] = rprev;
+    }
     if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
-  if (MODE == 3) u[x + (size_t)(NK - 1) * slab] = uprev;
-  if (REM) vr[x + (size_t)(NK - 1) * slab] = rprev;
+  if (MODE == 3) u[x + (size_t)(nk - 1) * slab] = uprev;
+  if (REM) vr[x + (size_t)(nk - 1) * slab] = rprev;
+  const double u_bot = uprev;   // uu[nk - 1]
   asm volatile("" ::: "memory");
   // ---- pass 3: back substitution
 #pragma unroll
   for (int k = NK - 2; k >= 0; k--) {
+    if (k >= nk - 1) continue;
     const size_t x3 = x + (size_t)k * slab;
     const double ck = aa[k + 1];
     if (MODE == 3) { uprev = uu[(MODE == 3) ? k : 0] + ck * uprev; u[x3] = uprev; }
     if (REM) { rprev = hh[k * 64] + ck * rprev; vr[x3] = rprev; }
   }
-  if (MODE == 3 && tau_bot) tau_bot[x] = H_to_RZ * (uu[(MODE == 3) ? NK - 1 : 0] * aa[NK]);
+  if (MODE == 3 && tau_bot) tau_bot[x] = H_to_RZ * (u_bot * a_bot);
 }
 
 extern "C" int mom6x_vertvisc_init(mom6x_ctx *c, const mom6x_vertvisc_params *p) {
@@ -2228,7 +2251,7 @@ static int vertvisc_coef_launch(mom6x_ctx *c, int mode, const double *u, const d
 // no Rayleigh drag, no direct stress, no KV_ML_INVZ2.  MOM6X_VERTVISC=walk|pair: the two kernels.
 bool vertvisc_coef_solve_usable(mom6x_ctx *c) {
   static const int mode = [] { const char *e = getenv("MOM6X_VERTVISC"); return (e && (!strcmp(e, "walk") || !strcmp(e, "pair"))) ? 0 : 1; }();
-  return mode && c->vv_init && c->d.nk == 75 && !c->Ray_u && !(direct_stress_of(c).Hmix > 0.0) && !(c->vv.Kvml_invZ2 > 0.0) &&
+  return mode && c->vv_init && c->d.nk <= COEF_COLS_NK_BOUND && !c->Ray_u && !(direct_stress_of(c).Hmix > 0.0) && !(c->vv.Kvml_invZ2 > 0.0) &&
          c->a_u == c->vv_a_u && c->a_v == c->vv_a_v && c->h_u == c->vv_h_u && c->h_v == c->vv_h_v &&   // (the solve reads what vertvisc_coef writes)
          (!c->vv.bottomdraglaw || (c->Kv_bbl_u && c->Kv_bbl_v && c->bbl_thick_u && c->bbl_thick_v));
 }
@@ -2239,25 +2262,27 @@ static int vertvisc_coef_cols_launch(mom6x_ctx *c, int mode, const double *u_in,
   HIPCHK(hipSetDevice(c->device));
   const Dm d = c->d;
   const mom6x_vgrid &GV = c->GV;
-  constexpr int NK = 75;
   const double a_cpl_max = 1.0e37 * GV.Z_to_H;
   const double I_amax = (c->vv.answer_date < 20190101) ? (1.0e-10 * GV.H_to_Z) * dt_coef : 0.0;
   const double dt_Rho0 = dt / GV.H_to_RZ, HR = GV.H_to_RZ;
   const dim3 bc(64, 1, 1);
   const dim3 gu((unsigned)((nxa(d.ni + 1, -1) + 63) / 64), (unsigned)d.nj, 1), gv((unsigned)((d.ni + 63) / 64), (unsigned)(d.nj + 1), 1);
-  const size_t lds = (size_t)NK * 64 * sizeof(double);
   const bool rem = (vr_u != nullptr);
-#define VCS(DIR, M, R, WC, g, uin, ubc, LA, uo, vro, tau, taub, Kb, bt, ao, ho)                                                       \
-  KLAUNCH_LDS(c, DIR ? "k_vertvisc_coef_cols<1>" : "k_vertvisc_coef_cols<0>", (k_vertvisc_coef_cols<DIR, M, R, WC, NK>), g, bc, lds, d, c->G, c->vv, uin, ubc, \
+#define VCS(DIR, M, R, WC, NKT, g, uin, ubc, LA, uo, vro, tau, taub, Kb, bt, ao, ho)                                                  \
+  KLAUNCH_LDS(c, DIR ? "k_vertvisc_coef_cols<1>" : "k_vertvisc_coef_cols<0>", (k_vertvisc_coef_cols<DIR, M, R, WC, NKT>), g, bc,       \
+              (size_t)NK_OF(NKT) * 64 * sizeof(double), d, c->G, c->vv, uin, ubc,                                                       \
               dtx, h, Kb, bt, c->Kv_shear, ao, ho, GV.H_to_Z, GV.H_subroundoff, GV.dZ_subroundoff, a_cpl_max, I_amax, LA, uo, vro, tau, dt, dt_Rho0, HR, taub)
-#define VCS2(M, R, WC) do { \
-    VCS(0, M, R, WC, gu, u_in, u_bc, LAu, u, vr_u, taux, taux_bot, c->Kv_bbl_u, c->bbl_thick_u, c->vv_a_u, c->vv_h_u); \
-    VCS(1, M, R, WC, gv, v_in, v_bc, LAv, v, vr_v, tauy, tauy_bot, c->Kv_bbl_v, c->bbl_thick_v, c->vv_a_v, c->vv_h_v); } while (0)
-  if (mode == 1) VCS2(1, true, false);   // (nobody sees the coefficients of :602-609: :737 replaces them)
-  else if (rem && keep_coef) VCS2(3, true, true);
-  else if (rem) VCS2(3, true, false);
-  else if (keep_coef) VCS2(3, false, true);
-  else VCS2(3, false, false);
+#define VCS2(M, R, WC, NKT) do { \
+    VCS(0, M, R, WC, NKT, gu, u_in, u_bc, LAu, u, vr_u, taux, taux_bot, c->Kv_bbl_u, c->bbl_thick_u, c->vv_a_u, c->vv_h_u); \
+    VCS(1, M, R, WC, NKT, gv, v_in, v_bc, LAv, v, vr_v, tauy, tauy_bot, c->Kv_bbl_v, c->bbl_thick_v, c->vv_a_v, c->vv_h_v); } while (0)
+#define VCS_ALL(NKT) do {                                                                                                               \
+    if (mode == 1) VCS2(1, true, false, NKT);   /* (nobody sees the coefficients of :602-609: :737 replaces them) */                    \
+    else if (rem && keep_coef) VCS2(3, true, true, NKT);                                                                                \
+    else if (rem) VCS2(3, true, false, NKT);                                                                                            \
+    else if (keep_coef) VCS2(3, false, true, NKT);                                                                                      \
+    else VCS2(3, false, false, NKT); } while (0)
+  COEF_NK_DISPATCH(d.nk, VCS_ALL);
+#undef VCS_ALL
 #undef VCS2
 #undef VCS
   HIPCHK(hipGetLastError());
@@ -2334,10 +2359,13 @@ extern "C" int mom6x_vertvisc_remnant(mom6x_ctx *c, double *visc_rem_u, double *
   int rc;
   if (vertvisc_cols_usable(d.nk, c->Ray_u, DirectStress{}) && !c->Ray_v) {
     const dim3 bc(64, 1, 1);
-    KLAUNCH(c, "k_vertvisc_remnant_cols<0>", (k_vertvisc_remnant_cols<0, 75>), dim3((unsigned)((nxa(d.ni + 1, -1) + 63) / 64), (unsigned)d.nj, 1), bc,
-            d, c->G, visc_rem_u, c->a_u, c->h_u, dt);
-    KLAUNCH(c, "k_vertvisc_remnant_cols<1>", (k_vertvisc_remnant_cols<1, 75>), dim3((unsigned)((d.ni + 63) / 64), (unsigned)(d.nj + 1), 1), bc,
-            d, c->G, visc_rem_v, c->a_v, c->h_v, dt);
+#define VRC(NKT) do {                                                                                                                   \
+    KLAUNCH(c, "k_vertvisc_remnant_cols<0>", (k_vertvisc_remnant_cols<0, NKT>), dim3((unsigned)((nxa(d.ni + 1, -1) + 63) / 64), (unsigned)d.nj, 1), bc, \
+            d, c->G, visc_rem_u, c->a_u, c->h_u, dt);                                                                                    \
+    KLAUNCH(c, "k_vertvisc_remnant_cols<1>", (k_vertvisc_remnant_cols<1, NKT>), dim3((unsigned)((d.ni + 63) / 64), (unsigned)(d.nj + 1), 1), bc, \
+            d, c->G, visc_rem_v, c->a_v, c->h_v, dt); } while (0)
+    VV_NK_DISPATCH(d.nk, VRC);
+#undef VRC
     HIPCHK(hipGetLastError());
     return MOM6X_OK;
   }

@@ -202,3 +202,17 @@ inline int nxa(int nx, int I0) { return (I0 < 0) ? nx + IAL + I0 : nx; }
 inline dim3 grid3(int nx, int ny, int nz, dim3 b) {
   return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, (nz + b.z - 1) / b.z);
 }
+
+// The kernels that keep a whole column on chip (registers + LDS: k_vertvisc_coef_cols, k_vertvisc_cols, k_vertvisc_remnant_cols,
+// k_tridiag_cols, k_btcalc_cols, k_regrid_zstar_cols) unroll the column at compile time.  Their template argument NKT is the layer
+// count itself (NKT > 0: 75, the headline's) or, negated, a BOUND on it: the register arrays and unrolled loops have -NKT slots and
+// a wavefront-uniform test `k < nk` skips the ones beyond the column, so any nk <= -NKT runs the same code.
+#define NK_OF(NKT) ((NKT) > 0 ? (NKT) : -(NKT))
+#define NK_EXACT(NKT) ((NKT) > 0)
+constexpr int COLS_NK_BOUND = 76;   // (k_vertvisc_coef_cols holds 4 x NK registers of column state next to ~190 others: 76 slots fit the 512 of a wavefront alone on its SIMD,
+                                    //  78 spill, at 80 the coefficient column stays in scratch; k_regrid_zstar_cols spills at 80 too)
+// (three bounds, so that a column fills at least 4/5 of the slots it pays for once it has more than 41 layers.  Not 64: with a bound
+//  that is a multiple of the walk's group size, k_vertvisc_coef_cols' switch over the group pairs (cc_file_switch) is affine in the
+//  pair's number, the compiler turns it into one store with a computed index, and the coefficient column lives in scratch memory.)
+#define COLS_NK_DISPATCH(nk, CALL) do { if ((nk) == 75) { CALL(75); } else if ((nk) <= 52) { CALL(-52); } else if ((nk) <= 66) { CALL(-66); } \
+                                        else { CALL(-COLS_NK_BOUND); } } while (0)

@@ -1139,10 +1139,12 @@ k_regrid_zstar(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_params CS,
 // k_regrid_zstar with the column on chip (nk = NK): the thicknesses and the interface positions / displacements in registers,
 // the old interface positions in LDS; the column is read once and h_new, dzInterface written once (3 words per cell-layer
 // where the array version makes eight passes).  One wavefront per work-group.  Same operations in the same order.
-template <int NK>
+template <int NKT>   // (NKT: mom6x_dev.h NK_OF / NK_EXACT -- the layer count itself, or a bound on it)
 __global__ void __launch_bounds__(64)
 k_regrid_zstar_cols(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_params CS, double Z_to_H, const double *__restrict__ res,
                     const double *__restrict__ h, double *__restrict__ h_new, double *__restrict__ dzI, int *__restrict__ flag) {
+  constexpr int NK = NK_OF(NKT);
+  const int nk = NK_EXACT(NKT) ? NK : d.nk;   // (every register index below is a loop constant; slots beyond nk are skipped)
   extern __shared__ double rz_lds[];
   const int i = I_BASE(-1) + blockIdx.x * 64 + threadIdx.x;
   const int j = -1 + blockIdx.y;
@@ -1151,56 +1153,57 @@ k_regrid_zstar_cols(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_param
   double *zo_l = rz_lds + threadIdx.x;          // zOld(k) at zo_l[(k-1)*64]
   double hh[NK], dz[NK + 1];
 #pragma unroll
-  for (int k = 0; k < NK; k++) hh[k] = h[x + (size_t)k * slab];
+  for (int k = 0; k < NK; k++) if (k < nk) hh[k] = h[x + (size_t)k * slab];
   if (gm(G, d, MOM6X_G_mask2dT)[x] == 0.) {
 #pragma unroll
-    for (int k = 0; k < NK; k++) { h_new[x + (size_t)k * slab] = hh[k]; dzI[x + (size_t)k * slab] = 0.; }
-    dzI[x + (size_t)NK * slab] = 0.;
+    for (int k = 0; k < NK; k++) if (k < nk) { h_new[x + (size_t)k * slab] = hh[k]; dzI[x + (size_t)k * slab] = 0.; }
+    dzI[x + (size_t)nk * slab] = 0.;
     return;
   }
   const double depth = dmax((gm(G, d, MOM6X_G_bathyT)[x] + CS.Z_ref) * Z_to_H, 0.0);
   double total = 0.0;
 #pragma unroll
-  for (int k = 0; k < NK; k++) total = total + hh[k];
+  for (int k = 0; k < NK; k++) if (k < nk) total = total + hh[k];
   double zo = -depth;
-  zo_l[NK * 64] = zo;
+  zo_l[nk * 64] = zo;
 #pragma unroll
-  for (int k = NK - 1; k >= 0; k--) { zo = zo + hh[k]; zo_l[k * 64] = zo; }
+  for (int k = NK - 1; k >= 0; k--) if (k < nk) { zo = zo + hh[k]; zo_l[k * 64] = zo; }
   const double zOld1 = zo;
-  const double min_thickness = dmin(CS.min_thickness, total / (double)NK);
+  const double min_thickness = dmin(CS.min_thickness, total / (double)nk);
   const double eta = total - depth;
   const double stretching = total / (depth + 0.);
   double zn = eta;
   dz[0] = zn;
 #pragma unroll
-  for (int k = 1; k <= NK; k++) { const double dh = stretching * res[k - 1] * Z_to_H; zn = zn - dh; dz[k] = zn; }
+  for (int k = 1; k <= NK; k++) if (k <= nk) { const double dh = stretching * res[k - 1] * Z_to_H; zn = zn - dh; dz[k] = zn; }
   zn = -depth;
-  dz[NK] = zn;
 #pragma unroll
-  for (int k = NK - 1; k >= 0; k--) {
+  for (int k = NK; k >= 0; k--) {
+    if (k > nk) continue;
+    if (k == nk) { dz[k] = zn; continue; }          // the bottom interface sits on the bottom
     double zk = dz[k];
     if (zk < (zn + min_thickness)) { zk = zn + min_thickness; dz[k] = zk; }
     zn = zk;
   }
   FilterConst F;
-  if (!filter_prepare(CS, zOld1, -depth, dz[0], dz[NK], F)) { atomicOr(flag, 4); return; }
+  if (!filter_prepare(CS, zOld1, -depth, dz[0], -depth, F)) { atomicOr(flag, 4); return; }
   asm volatile("" ::: "memory");
   dz[0] = 0.0;
 #pragma unroll
-  for (int k = 1; k <= NK; k++) dz[k] = F.zero ? 0.0 : filter_one(F, zo_l[k * 64], dz[k], zOld1);
+  for (int k = 1; k <= NK; k++) if (k <= nk) dz[k] = F.zero ? 0.0 : filter_one(F, zo_l[k * 64], dz[k], zOld1);
   // adjust_interface_motion :1796-1857
   {
     const double eps = DBL_EPSILON;
     double h_err = 0.;
     bool bad = false;
 #pragma unroll
-    for (int k = 0; k < NK; k++) {
+    for (int k = 0; k < NK; k++) if (k < nk) {
       h_err = h_err + dmax3(hh[k], fabs(dz[k]), fabs(dz[k + 1])) * eps;
       const double hn = hh[k] + (dz[k] - dz[k + 1]);
       if (hn < -3.0 * h_err) bad = true;
     }
 #pragma unroll
-    for (int k = NK - 1; k >= 1; k--) {
+    for (int k = NK - 1; k >= 1; k--) if (k < nk) {
       double hn = hh[k] + (dz[k] - dz[k + 1]);
       if (hn < CS.min_thickness) dz[k] = (dz[k + 1] - hh[k]) + CS.min_thickness;
       hn = hh[k] + (dz[k] - dz[k + 1]);
@@ -1211,11 +1214,10 @@ k_regrid_zstar_cols(Dm d, const double *__restrict__ G, mom6x_regrid_zstar_param
     if (bad) { atomicOr(flag, 8); return; }
   }
 #pragma unroll
-  for (int k = 0; k < NK; k++) {
-    h_new[x + (size_t)k * slab] = dmax(0., hh[k] + (dz[k] - dz[k + 1]));
-    dzI[x + (size_t)k * slab] = dz[k];
+  for (int k = 0; k <= NK; k++) {
+    if (k < nk) h_new[x + (size_t)k * slab] = dmax(0., hh[k] + (dz[k] - dz[k + 1]));
+    if (k <= nk) dzI[x + (size_t)k * slab] = dz[k];
   }
-  dzI[x + (size_t)NK * slab] = dz[NK];
 }
 
 // ---- the density-following coordinates (REGRIDDING_RHO, REGRIDDING_HYCOM1) -------------------------------------------------
@@ -1734,9 +1736,11 @@ extern "C" int mom6x_ALE_regrid_zstar(mom6x_ctx *c, const mom6x_regrid_zstar_par
   int rc = ctx_scratch(c, SCR_e, d.nk + 1, &zOld);
   if (rc) return rc;
   const dim3 b(64, 4, 1);
-  if (d.nk == 75) {   // the layer count the on-chip column kernel is built for
-    KLAUNCH_LDS(c, "k_regrid_zstar", (k_regrid_zstar_cols<75>), dim3((unsigned)((nxa(d.ni + 2, -1) + 63) / 64), (unsigned)(d.nj + 2), 1), dim3(64, 1, 1),
-                (size_t)76 * 64 * sizeof(double), d, c->G, *p, c->GV.Z_to_H, (const double *)c->regrid_res, h, h_new, dzRegrid, c->flag);
+  if (d.nk <= COLS_NK_BOUND) {   // the layer counts the on-chip column kernel is built for
+#define RZC(NKT) KLAUNCH_LDS(c, "k_regrid_zstar", (k_regrid_zstar_cols<NKT>), dim3((unsigned)((nxa(d.ni + 2, -1) + 63) / 64), (unsigned)(d.nj + 2), 1), dim3(64, 1, 1), \
+                (size_t)(NK_OF(NKT) + 1) * 64 * sizeof(double), d, c->G, *p, c->GV.Z_to_H, (const double *)c->regrid_res, h, h_new, dzRegrid, c->flag)
+    COLS_NK_DISPATCH(d.nk, RZC);
+#undef RZC
   } else
   KLAUNCH(c, "k_regrid_zstar", k_regrid_zstar, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, c->G, *p, c->GV.Z_to_H,
           (const double *)c->regrid_res, h, h_new, dzRegrid, zOld, c->flag);

@@ -977,12 +977,14 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
 // k_tridiag with the whole column on chip (the technique of k_vertvisc_cols, dyn_kernels.hip): c1 and the un-substituted T in
 // registers, the un-substituted S of triDiagTS in LDS, one wavefront per work-group, inputs fetched TD_G layers ahead into a
 // double buffer.  4 (5) words read and 1 (2) written per cell-layer instead of 9 (13); the same operations in the same order.
-template <int NK, bool TWO>
+template <int NKT, bool TWO>   // (NKT: mom6x_dev.h NK_OF / NK_EXACT -- the layer count itself, or a bound on it)
 __global__ void __launch_bounds__(64)
 k_tridiag_cols(Dm d, const double *__restrict__ G, const double *__restrict__ hold, const double *__restrict__ ea,
                const double *__restrict__ eb, double *T, double *S, double h_neglect, int vertdiff,
                const double *__restrict__ sfc_flux, const double *__restrict__ btm_flux, double flux_scale, int i0, int i1, int j0,
                int j1) {
+  constexpr int NK = NK_OF(NKT);
+  const int nk = NK_EXACT(NKT) ? NK : d.nk;
   extern __shared__ double td_lds[];
   const int i = i0 + blockIdx.x * 64 + threadIdx.x;
   const int j = j0 + blockIdx.y;
@@ -1002,7 +1004,7 @@ k_tridiag_cols(Dm d, const double *__restrict__ G, const double *__restrict__ ho
 #pragma unroll
     for (int m = 0; m < TD_G; m++) {
       const int k = g * TD_G + m;
-      if (k < NK) {
+      if (k < NK && k < nk) {
         const size_t c = x + (size_t)k * slab;
         q_h[b][m] = hold[c]; q_a[b][m] = ea[c]; q_b[b][m] = eb[c]; q_t[b][m] = T[c];
         if (TWO) q_s[b][m] = S[c];
@@ -1018,7 +1020,7 @@ k_tridiag_cols(Dm d, const double *__restrict__ G, const double *__restrict__ ho
 #pragma unroll
     for (int m = 0; m < TD_G; m++) {
       const int k = g * TD_G + m;
-      if (k < NK) {
+      if (k < NK && k < nk) {
         const double h_tr = q_h[g & 1][m] + h_neglect, eak = q_a[g & 1][m], ebk = q_b[g & 1][m], Tk = q_t[g & 1][m];
         if (k == 0) {
           b1 = vertdiff ? 1.0 / ((h_tr + eak) + ebk) : 1.0 / (h_tr + ebk);
@@ -1031,7 +1033,7 @@ k_tridiag_cols(Dm d, const double *__restrict__ G, const double *__restrict__ ho
           const double b_denom_1 = h_tr + d1 * eak;
           b1 = 1.0 / (b_denom_1 + ebk);
           d1 = b_denom_1 * b1;
-          if (vertdiff && k == NK - 1) prev = b1 * ((h_tr * Tk + btm_src) + eak * prev);
+          if (vertdiff && k == nk - 1) prev = b1 * ((h_tr * Tk + btm_src) + eak * prev);
           else prev = b1 * (h_tr * Tk + eak * prev);
           if (TWO) prevS = b1 * (h_tr * q_s[g & 1][m] + eak * prevS);
         }
@@ -1042,11 +1044,12 @@ k_tridiag_cols(Dm d, const double *__restrict__ G, const double *__restrict__ ho
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  T[x + (size_t)(NK - 1) * slab] = prev;
-  if (TWO) S[x + (size_t)(NK - 1) * slab] = prevS;
+  T[x + (size_t)(nk - 1) * slab] = prev;
+  if (TWO) S[x + (size_t)(nk - 1) * slab] = prevS;
   asm volatile("" ::: "memory");   // (S comes back from LDS, not from NK more live registers)
 #pragma unroll
   for (int k = NK - 2; k >= 0; k--) {
+    if (k >= nk - 1) continue;
     const size_t c = x + (size_t)k * slab;
     const double c1k = cc[k + 1];
     prev = tt[k] + c1k * prev;
@@ -1065,13 +1068,16 @@ static int tridiag(mom6x_ctx *c, const double *hold, const double *ea, const dou
   int rc;
   if ((rc = ctx_scratch(c, SCR_c1, d.nk, &c1))) return rc;
   static const bool walk = [] { const char *e = getenv("MOM6X_TRIDIAG"); return e && !strcmp(e, "walk"); }();
-  if (d.nk == 75 && !walk) {   // the layer count the on-chip column kernel is built for
+  if (d.nk <= COLS_NK_BOUND && !walk) {   // the layer counts the on-chip column kernel is built for
     const dim3 bc(64, 1, 1), gc((unsigned)((ie - is + 1 + 63) / 64), (unsigned)(je - js + 1), 1);
     // (triDiagTS: T and S as two sweeps -- the one-sweep form with S in LDS spills; 10 words per cell-layer instead of 13)
-    KLAUNCH_LDS(c, "k_tridiag_cols", (k_tridiag_cols<75, false>), gc, bc, (size_t)0, d, c->G, hold, ea, eb, T, (double *)nullptr,
-                c->GV.H_subroundoff, vertdiff, sfc_flux, btm_flux, flux_scale, is, ie, js, je);
-    if (S) KLAUNCH_LDS(c, "k_tridiag_cols", (k_tridiag_cols<75, false>), gc, bc, (size_t)0, d, c->G, hold, ea, eb, S, (double *)nullptr,
-                       c->GV.H_subroundoff, vertdiff, sfc_flux, btm_flux, flux_scale, is, ie, js, je);
+#define TDC(NKT) do {                                                                                                                   \
+    KLAUNCH_LDS(c, "k_tridiag_cols", (k_tridiag_cols<NKT, false>), gc, bc, (size_t)0, d, c->G, hold, ea, eb, T, (double *)nullptr,      \
+                c->GV.H_subroundoff, vertdiff, sfc_flux, btm_flux, flux_scale, is, ie, js, je);                                         \
+    if (S) KLAUNCH_LDS(c, "k_tridiag_cols", (k_tridiag_cols<NKT, false>), gc, bc, (size_t)0, d, c->G, hold, ea, eb, S, (double *)nullptr, \
+                       c->GV.H_subroundoff, vertdiff, sfc_flux, btm_flux, flux_scale, is, ie, js, je); } while (0)
+    COLS_NK_DISPATCH(d.nk, TDC);
+#undef TDC
     HIPCHK(hipGetLastError());
     return MOM6X_OK;
   }

@@ -26,6 +26,29 @@ def test_config2_benchmark_360x180x75_rk2_step(orc, sums):
     run(orc, cfg, nsteps=1, bt_mod=dict(strong_drag=1), dev_vv=dict(), hv=P)
 
 
+def test_config2_benchmark_360x180x75_rk2_step_without_rayleigh_drag(orc):
+    """The headline's own vertical-viscosity kernel at a BASELINE configuration: without visc%Ray_u / Ray_v (as bench.py runs) the
+    three vertvisc_coef calls and their solves are k_vertvisc_coef_cols, one kernel per direction.  One step, bit for bit -- and
+    the kernel did run (its launches are counted)."""
+    import torch
+    from tests.test_rk2_gpu import run
+    from tests import cases
+    from mom6_amd.dycore import prof_enable, prof_report
+    cfg = H.benchmark_360()
+    P = abi.hor_visc_params_default(1200.0, Laplacian=True, biharmonic=True)
+    P.Kh_vel_scale = 0.01; P.Ah_vel_scale = 0.01; P.Smagorinsky_Ah = 1; P.Smag_bi_const = 0.06
+    P.dt = cases.rk2_inputs(cfg, False, False)["dt"]
+    seen = {}
+
+    def watch(dyc, when):
+        if when == "before":
+            prof_enable(dyc, True)
+        else:
+            dyc.sync(); seen.update(prof_report(dyc)); prof_enable(dyc, False)
+    run(orc, cfg, nsteps=1, bt_mod=dict(strong_drag=1), dev_vv=dict(), hv=P, ray=False, hook=watch)
+    assert seen.get("k_vertvisc_coef_cols<0>", (0, 0))[0] == 3 and seen.get("k_vertvisc_coef_cols<1>", (0, 0))[0] == 3, sorted(seen)
+
+
 def test_config2_benchmark_360x180x75_rk2_step_default_drag(orc, sums):
     """The same step on btstep's DEFAULT drag path (BT_STRONG_DRAG = False: bt_rem = av_rem**(1/nstep), the one expression where
     the device's pow and libm's may differ in the last bit): every field within 1e-12 of its range."""

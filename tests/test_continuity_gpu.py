@@ -136,10 +136,12 @@ def test_continuity_tied_quotients(orc, mode, cfg):
     _run_case(orc, getattr(H, cfg)(nk=6), 0, mode, ties=True)
 
 
-@pytest.mark.parametrize("nk", [20, 75, 90])
-def test_continuity_many_layers(orc, nk):
-    # the LDS kernel gives every layer lane ceil(nk/16) layers: 2, 5 and 8-layer instantiations
-    _run_case(orc, H.benchmark_small(nk=nk), 1, "full", thin=0.1)
+@pytest.mark.parametrize("nk", [20, 40, 48, 50, 63, 75, 90])
+@pytest.mark.parametrize("mode", ["full", "bt_cont", "adjust"])
+def test_continuity_many_layers(orc, nk, mode):
+    # every layer lane carries ceil(nk/16) layers: the 2-, 3-, 4-, 5- and 8-slot instantiations, in the three shapes of a step's
+    # launches (the 3-, 4- and 5-slot kernels have an instantiation compiled for each: struct Sw<SPEC>)
+    _run_case(orc, H.benchmark_small(nk=nk), 1, mode, thin=0.1)
 
 
 def test_continuity_device_matches_committed_golden(orc):

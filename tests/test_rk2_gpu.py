@@ -30,7 +30,7 @@ STAG = dict(u="u", v="v", h="h", uh="u", vh="v", uhtr="u", vhtr="v", eta_av="h",
 
 def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direction=0, per_stage=False, new_diff=False,
         exact=True, rtol=1e-11, eos_form=None, dev_vv=None, hv=None, Hmix_stress=0.0, recon=0, chk=False, cont_mod=None, ray=True,
-        shear=True):
+        shear=True, hook=None):
     import torch
     from mom6_amd.dycore import Dycore
     from tests import cases
@@ -97,11 +97,13 @@ def run(orc, cfg, nsteps=3, bt_mod=None, rk2_mod=None, cor_mod=None, first_direc
         torch.cuda.synchronize()
         return 0
 
+    if hook: hook(dyc, "before")   # (a test that wants to see which kernels the steps launch)
     for n in range(nsteps):
         dyc.step_MOM_dyn_split_RK2(sg["u"], sg["v"], sg["h"], sg["uh"], sg["vh"], sg["uhtr"], sg["vhtr"], sg["eta_av"], txd, tyd,
                                    dt, calc_dtbt=(n == 0), vertvisc_coef=coef_hook if per_stage else None,
                                    horizontal_viscosity=hv_hook if new_diff else None)
     dyc.sync()
+    if hook: hook(dyc, "after")
     if per_stage:
         assert [s for s, _ in stages[:3]] == [0, 1, 2] and stages[1][1] == dt * rk22.be
 
@@ -248,36 +250,38 @@ def test_rk2_ragged_tile_sizes(orc, ni, nj, nk, halo):
     run(orc, H.double_gyre(nk=nk, ni=ni, nj=nj, halo=halo), nsteps=2, bt_mod=dict(strong_drag=1))
 
 
-@pytest.mark.parametrize("ni,nj", [(70, 10), (24, 40)])
-def test_rk2_75_layers_on_chip_columns(orc, ni, nj):
+@pytest.mark.parametrize("ni,nj,nk", [(70, 10, 75), (24, 40, 75), (40, 12, 50), (40, 12, 63)])
+def test_rk2_75_layers_on_chip_columns(orc, ni, nj, nk):
     """nk = 75 is the layer count the on-chip column solver (k_vertvisc_cols: c1 and u in registers, the remnant in
     LDS) and the 5-layer-per-lane mass-flux kernel are built for; rows that are not a multiple of the 64-lane
     work-group, with and without the bottom-stress hooks, two steps bit for bit."""
-    run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(split_bottom_stress=1),
+    run(orc, H.benchmark_small(nk=nk, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(split_bottom_stress=1),
         per_stage=True)
-    run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), dev_vv=dict())
+    run(orc, H.benchmark_small(nk=nk, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), dev_vv=dict())
     # VISC_REM_TIMESTEP_BUG = False: the velocity solve without the remnant (k_vertvisc_cols<UPD, !REM>) + k_vertvisc_remnant_cols
-    run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(visc_rem_dt_bug=0), dev_vv=dict())
-    run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(visc_rem_dt_bug=0), per_stage=True)
+    run(orc, H.benchmark_small(nk=nk, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(visc_rem_dt_bug=0), dev_vv=dict())
+    run(orc, H.benchmark_small(nk=nk, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=dict(visc_rem_dt_bug=0), per_stage=True)
 
 
-@pytest.mark.parametrize("ni,nj", [(70, 10), (24, 40)])
+@pytest.mark.parametrize("ni,nj,nk", [(70, 10, 75), (24, 40, 75), (70, 10, 50), (24, 40, 63), (40, 12, 76), (24, 12, 33)])
 @pytest.mark.parametrize("shear", [True, False])
-def test_rk2_75_layers_one_kernel_vertical_viscosity(orc, ni, nj, shear):
+def test_rk2_75_layers_one_kernel_vertical_viscosity(orc, ni, nj, nk, shear):
     """Without Rayleigh drag (and without the direct-stress and KV_ML_INVZ2 options) the three vertvisc_coef calls of a step and the
     solves that follow them run as ONE kernel per direction (k_vertvisc_coef_cols: coefficients bottom-up into registers and LDS, the
     Thomas sweeps top-down from there; MODE 1 with the remnant only for :602-610).  Two steps against the oracle, which calls
     vertvisc_coef, vertvisc and vertvisc_remnant one after the other: bit for bit, with and without visc%Kv_shear, with the remnant
-    in the solve's sweep and (VISC_REM_TIMESTEP_BUG = False) in a kernel of its own after it -- and the kernel did run."""
+    in the solve's sweep and (VISC_REM_TIMESTEP_BUG = False) in a kernel of its own after it -- and the kernel did run.  75 layers is
+    the instantiation of the headline; every other count up to COLS_NK_BOUND = 76 runs the instantiation with 76 slots and a uniform
+    test on the layer index (mom6x_dev.h), here 33, 50, 63 and 76 layers -- also the 3-, 4- and 5-slot mass-flux kernels."""
     for rk2_mod in (None, dict(visc_rem_dt_bug=0)):
-        run(orc, H.benchmark_small(nk=75, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=rk2_mod, dev_vv=dict(), ray=False, shear=shear)
+        run(orc, H.benchmark_small(nk=nk, ni=ni, nj=nj), nsteps=2, bt_mod=dict(strong_drag=1), rk2_mod=rk2_mod, dev_vv=dict(), ray=False, shear=shear)
     import os
     if os.environ.get("MOM6X_VERTVISC") in (None, ""):   # (not under the switch tests that take the kernel away)
         import torch
         from mom6_amd.dycore import Dycore, prof_enable, prof_report
         from tests import cases
         from tests.test_dyn_gpu import visc_inputs
-        cfg = H.benchmark_small(nk=75, ni=ni, nj=nj); gg, d, M = cfg
+        cfg = H.benchmark_small(nk=nk, ni=ni, nj=nj); gg, d, M = cfg
         inp = cases.rk2_inputs(cfg)
         cont, bt, cor, pgf, rk2 = cases.rk2_params(d, inp["GV"], dict(strong_drag=1), None, None)
         dyc = Dycore(d, M, inp["GV"], 0)
@@ -297,6 +301,13 @@ def test_rk2_75_layers_one_kernel_vertical_viscosity(orc, ni, nj, shear):
         rep = prof_report(dyc); prof_enable(dyc, False)
         assert rep.get("k_vertvisc_coef_cols<0>", (0, 0))[0] == 3 and rep.get("k_vertvisc_coef_cols<1>", (0, 0))[0] == 3, sorted(rep)
         dyc.close()
+
+
+@pytest.mark.parametrize("ray", [True, False])
+def test_rk2_90_layers_beyond_the_on_chip_columns(orc, ray):
+    """More layers than the on-chip column kernels carry (COLS_NK_BOUND = 76): vertvisc_coef, the solves, btcalc and the mass-flux
+    kernel's 8-slot instantiation take the paths that walk through HBM.  Two steps, bit for bit."""
+    run(orc, H.benchmark_small(nk=90, ni=40, nj=12), nsteps=2, bt_mod=dict(strong_drag=1), dev_vv=dict(), ray=ray)
 
 
 def test_rk2_75_layers_with_btcalc_written_out():
