@@ -601,17 +601,18 @@ def git_hash_of(path):
         return "unknown"
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, full_size=False):
     """The oracle (kind='port': plain-C restatement of the reference Fortran with OpenMP over the loops the reference
     threads -- !$OMP parallel do over j or k, e.g. MOM_continuity_PPM.F90:370/:615, MOM_barotropic.F90:868 -- on all host
-    cores) on a bounded tile: BASELINE.json configs[2]'s 360 x 180 x 75, scaled by the cell count."""
+    cores) on a bounded tile: BASELINE.json configs[2]'s 360 x 180 x 75, scaled by the cell count.  full_size: ONE dynamics step
+    of the headline's own grid instead (no scaling; the thermodynamic step is left out: `--cpu-full-size`)."""
     from mom6_amd import abi, grid, synth
     from oracle import orc
     import ctypes
     # the host cores this process may use: the cgroup CPU quota where there is one (a box that shows 256 hardware threads
     # but grants 16 CPUs runs the loops slower with 128 threads than with one), else what the scheduler allows
     cores = orc.set_threads(orc.usable_cores())
-    ni, nj, nk = 360, 180, args.nk
+    ni, nj, nk = (args.ni, args.nj, args.nk) if full_size else (360, 180, args.nk)
     gg = grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-65.0, dlon=360.0 / args.ni, dlat=130.0 / args.nj,
                          depth_fn=grid.bowl_depth(ni, nj, 4000.0, rim=2))
     d, M = gg.tile(nk)
@@ -648,6 +649,13 @@ def cpu_baseline(args):
         uhtr[...] = 0.0; vhtr[...] = 0.0
 
     m.initialize(u, v, h, uh, vh, args.dt)
+    if full_size:   # one step, timed as it is (it also sets dtbt: set_dtbt is a 2-D pass, 0.1 % of a step)
+        t0 = time.time()
+        m.step(u, v, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy, args.dt, coefs, calc_dtbt=True)
+        t = time.time() - t0
+        return {"value": (args.dt / 86400.0) / t, "unit": "simulated-days/wall-sec", "cores": cores, "kind": "port",
+                "sample": f"ONE oracle step of step_MOM_dyn_split_RK2 (dynamics only, no thermodynamic step) at the headline's own "
+                          f"{ni}x{nj}x{nk} with {cores} OpenMP threads ({t:.1f} s/step), not scaled"}
     m.step(u, v, h, uh, vh, uhtr, vhtr, eta_av, taux, tauy, args.dt, coefs, calc_dtbt=True)   # warm-up, sets dtbt
     uhtr[...] = 0.0; vhtr[...] = 0.0
     nst = max((args.cpu_steps // nth) * nth, nth) if do_thermo else args.cpu_steps   # whole cycles: the thermodynamic share amortises exactly
@@ -755,6 +763,7 @@ def main():
     ap.add_argument("--dt", type=float, default=900.0)
     ap.add_argument("--dt-therm", type=float, default=3600.0, help="DT_THERM: a thermodynamic step follows every DT_THERM / DT dynamics steps")
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--no-cpu-full-size", action="store_true", help="skip the one oracle step at the headline's own size (cpu_baseline.full_size)")
     ap.add_argument("--ale-ni", type=int, default=1080, help="configs[4] leg: the tile of the 4320 x 3240 grid on a 4 x 2 layout")
     ap.add_argument("--ale-nj", type=int, default=1620)
     ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] tile leg")
@@ -1089,6 +1098,13 @@ def run_rank(args, env):
         if not args.no_cpu_baseline and args.gpus == 1:   # (rank 0 at N = 1 only)
             ph.mark("other")
             out["cpu_baseline"] = cpu_baseline(args)
+            if not args.no_cpu_full_size and not os.environ.get("MOM6X_BENCH_NO_CPU_FULL"):
+                # ... and ONE dynamics step at the headline's own size, unscaled (the model of this run is closed first: the oracle's
+                # ~45 arrays of 0.95 GB live in host memory, nothing on the device)
+                try:
+                    out["cpu_baseline"]["full_size"] = cpu_baseline(args, full_size=True)
+                except MemoryError as e:   # noqa: BLE001
+                    out["cpu_baseline"]["full_size"] = {"error": "not enough host memory: " + str(e)[:100]}
             ph.mark("cpu_baseline")
     if st:                                   # (the legs that need the memory have closed the model already)
         torch.cuda.set_stream(torch.cuda.default_stream()); dyc.close(); st.clear()

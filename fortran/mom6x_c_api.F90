@@ -21,7 +21,7 @@ module mom6x_c_api
   public :: mom6x_chksum, mom6x_field_chksum, mom6x_sum_output_init, mom6x_depth_list, mom6x_write_energy, mom6x_barotropic_dtbt
   public :: mom6x_btstep_warnings
   public :: mom6x_dims_init, mom6x_ctx_create, mom6x_ctx_destroy, mom6x_ctx_sync, mom6x_last_error
-  public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_upload, mom6x_download, mom6x_struct_size
+  public :: mom6x_dev_alloc, mom6x_dev_free, mom6x_dev_copy, mom6x_upload, mom6x_download, mom6x_struct_size
   public :: mom6x_continuity_init, mom6x_continuity_PPM, mom6x_barotropic_init, mom6x_btcalc, mom6x_btcalc_strict
   public :: mom6x_bt_mass_source, mom6x_set_dtbt, mom6x_set_dtbt_pbce, mom6x_set_dtbt_pbce_eta, mom6x_btstep
   public :: mom6x_CoriolisAdv_init, mom6x_CorAdCalc, mom6x_PressureForce_init, mom6x_PressureForce
@@ -223,6 +223,9 @@ module mom6x_c_api
     end function
     integer(c_int) function mom6x_dev_free(ctx, p) bind(C, name="mom6x_dev_free")
       import :: c_int, c_ptr ; type(c_ptr), value :: ctx, p
+    end function
+    integer(c_int) function mom6x_dev_copy(ctx, dst, src, n) bind(C, name="mom6x_dev_copy")
+      import :: c_int, c_ptr, c_size_t ; type(c_ptr), value :: ctx, dst, src ; integer(c_size_t), value :: n
     end function
     !> Fortran array with MOM6 symmetric-memory extents -> pitched device array (stagger 0 h, 1 u, 2 v, 3 q)
     integer(c_int) function mom6x_upload(ctx, dev, host_f, stagger, nk) bind(C, name="mom6x_upload")

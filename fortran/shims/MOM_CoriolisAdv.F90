@@ -53,7 +53,7 @@ subroutine CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv, Wav
   if (associated(OBC)) call MOM_error(FATAL, "CorAdCalc: open boundaries are not carried by the MI355X path.")
   if (present(Waves)) then ; if (associated(Waves)) call MOM_error(FATAL, "CorAdCalc: Stokes drift is not carried by the MI355X path.") ; endif
   nk = GV%ke
-  d_CAu = shim_buf(6, nk) ; d_CAv = shim_buf(7, nk)
+  d_CAu = shim_out3(6, CAu, nk) ; d_CAv = shim_out3(7, CAv, nk)   ! (the resident copies of CAu, CAv if the host has handed them over)
   rc = mom6x_CorAdCalc(CS%ctx, shim_up3(1, u, STG_U, nk), shim_up3(2, v, STG_V, nk), shim_up3(3, h, STG_H, nk), &
                        shim_up3(4, uh, STG_U, nk), shim_up3(5, vh, STG_V, nk), d_CAu, d_CAv)
   call shim_check(rc, "CorAdCalc")

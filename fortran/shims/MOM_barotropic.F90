@@ -112,7 +112,8 @@ subroutine btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, 
   d(6) = shim_up2(6, forces%taux, STG_U) ; d(7) = shim_up2(7, forces%tauy, STG_V)
   d(8) = shim_up3(8, pbce, STG_H, nk) ; d(9) = shim_up2(9, eta_PF_in, STG_H)
   d(10) = shim_up3(10, U_Cor, STG_U, nk) ; d(11) = shim_up3(11, V_Cor, STG_V, nk)
-  d(12) = shim_buf(12, nk) ; d(13) = shim_buf(13, nk) ; d(14) = shim_buf(14, 1) ; d(15) = shim_buf(15, 1) ; d(16) = shim_buf(16, 1)
+  d(12) = shim_out3(12, accel_layer_u, nk) ; d(13) = shim_out3(13, accel_layer_v, nk)
+  d(14) = shim_out2(14, eta_out) ; d(15) = shim_out2(15, uhbtav) ; d(16) = shim_out2(16, vhbtav)
   d(17) = shim_up3(17, visc_rem_u, STG_U, nk) ; d(18) = shim_up3(18, visc_rem_v, STG_V, nk)
   p_txb = c_null_ptr ; p_tyb = c_null_ptr ; p_uh0 = c_null_ptr ; p_vh0 = c_null_ptr ; p_uuh0 = c_null_ptr ; p_vvh0 = c_null_ptr
   p_etaav = c_null_ptr
@@ -123,7 +124,7 @@ subroutine btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, 
     p_uh0 = shim_up3(21, uh0, STG_U, nk) ; p_vh0 = shim_up3(22, vh0, STG_V, nk)
     p_uuh0 = shim_up3(23, u_uh0, STG_U, nk) ; p_vvh0 = shim_up3(24, v_vh0, STG_V, nk)
   endif
-  if (present(etaav)) p_etaav = shim_buf(25, 1)
+  if (present(etaav)) p_etaav = shim_out2(25, etaav)
   rc = mom6x_btstep(CS%ctx, d(1), d(2), d(3), real(dt, c_double), d(4), d(5), d(6), d(7), d(8), d(9), d(10), d(11), &
                     d(12), d(13), d(14), d(15), d(16), d(17), d(18), c_null_ptr, p_txb, p_tyb, p_uh0, p_vh0, p_uuh0, p_vvh0, p_etaav)
   call shim_check(rc, "btstep")

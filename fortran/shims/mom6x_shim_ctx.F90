@@ -9,7 +9,11 @@
 !!     from a unique id made on the root PE and broadcast with MOM_coms' own broadcast, and mom6x_comm_init attaches the
 !!     8-neighbour halo plan (pass_var / pass_vector of the reference become packed ncclSend / ncclRecv groups).
 !! The module also owns a small pool of scratch device arrays for the shims that serve HOST callers (upload, compute,
-!! download), so that repeated calls do not allocate.
+!! download), so that repeated calls do not allocate -- and a registry of RESIDENT host arrays: an array the host has handed
+!! over with shim_resident_add lives in HBM from then on; every shim that is given that array (recognised by its address)
+!! works on the device copy directly, without an upload before and a download after the call, until the host asks for the
+!! values (shim_resident_sync_host) or takes the array back (shim_resident_drop).  shim_transfer_count counts the arrays that
+!! did cross PCIe.
 module mom6x_shim_ctx
 use, intrinsic :: iso_c_binding
 use mom6x_c_api
@@ -22,7 +26,9 @@ use MOM_verticalGrid,  only : verticalGrid_type
 implicit none ; private
 
 public :: shim_ctx, shim_ctx_is_up, shim_ctx_end, shim_dims, shim_check, shim_buf, shim_nk, shim_set_domain_flags
-public :: shim_up2, shim_up3, shim_down2, shim_down3
+public :: shim_up2, shim_up3, shim_down2, shim_down3, shim_out2, shim_out3
+public :: shim_resident_add, shim_resident_drop, shim_resident_sync_host, shim_resident_host_changed, shim_resident_dev
+public :: shim_transfer_count
 
 type(c_ptr), save :: the_ctx = c_null_ptr
 type(mom6x_dims), save :: the_dims
@@ -30,6 +36,12 @@ logical, save :: reentrant(2) = (/ .false., .false. /), flags_known = .false.
 integer, parameter :: NBUF = 40
 type(c_ptr), save :: bufs(NBUF) = c_null_ptr       !< scratch device arrays, by slot
 integer(c_size_t), save :: buf_len(NBUF) = 0
+!> The resident host arrays: the address of the host array, its copy in HBM, its staggering and number of levels
+integer, parameter :: NRES = 64
+integer(c_intptr_t), save :: res_addr(NRES) = 0
+type(c_ptr), save :: res_dev(NRES) = c_null_ptr
+integer, save :: res_stg(NRES) = 0, res_nlev(NRES) = 0, n_res = 0
+integer(c_long_long), save :: n_transfers = 0      !< host <-> device array transfers made by the shims (uploads + downloads)
 
 contains
 
@@ -164,28 +176,128 @@ function shim_buf(slot, nlev) result(p)
   p = bufs(slot)
 end function shim_buf
 
-!> Host array (MOM6 symmetric-memory extents of its staggering) -> scratch slot; returns the device pointer.
+!> Where the resident array with the address of `a` is in the registry (0: it is not resident)
+integer function res_find(a)
+  real(c_double), target, intent(in) :: a(*)
+  integer(c_intptr_t) :: addr ; integer :: n
+  res_find = 0
+  if (n_res == 0) return
+  addr = transfer(c_loc(a), addr)
+  do n = 1, n_res ; if (res_addr(n) == addr) then ; res_find = n ; return ; endif ; enddo
+end function res_find
+
+!> Hand a host array over to the device: uploaded once, every shim then works on the copy in HBM (no transfer per call).
+subroutine shim_resident_add(a, stagger, nlev)
+  real(c_double), target, intent(in) :: a(*) ; integer, intent(in) :: stagger, nlev
+  integer(c_int) :: rc ; integer :: n
+  if (.not.c_associated(the_ctx)) call MOM_error(FATAL, "shim_resident_add: no device context yet (call a shim's *_init first).")
+  n = res_find(a)
+  if (n == 0) then
+    if (n_res >= NRES) call MOM_error(FATAL, "shim_resident_add: the registry of resident arrays is full.")
+    n_res = n_res + 1 ; n = n_res
+    res_addr(n) = transfer(c_loc(a), res_addr(n)) ; res_stg(n) = stagger ; res_nlev(n) = nlev
+    rc = mom6x_dev_alloc(the_ctx, res_dev(n), int(the_dims%slab, c_size_t) * int(max(nlev, 1), c_size_t)) ; call shim_check(rc, "mom6x_dev_alloc")
+  endif
+  rc = mom6x_upload(the_ctx, res_dev(n), a, int(stagger, c_int), int(nlev, c_int)) ; call shim_check(rc, "mom6x_upload")
+  n_transfers = n_transfers + 1
+end subroutine shim_resident_add
+
+!> The host has changed a resident array itself (initialisation, a host-side parameterisation): upload it again.
+subroutine shim_resident_host_changed(a)
+  real(c_double), target, intent(in) :: a(*)
+  integer :: n
+  n = res_find(a)
+  if (n == 0) call MOM_error(FATAL, "shim_resident_host_changed: the array is not resident.")
+  call shim_resident_add(a, res_stg(n), res_nlev(n))
+end subroutine shim_resident_host_changed
+
+!> The host wants the values (diagnostics, save_restart): download, the array stays resident.
+subroutine shim_resident_sync_host(a)
+  real(c_double), target, intent(inout) :: a(*)
+  integer(c_int) :: rc ; integer :: n
+  n = res_find(a)
+  if (n == 0) return
+  rc = mom6x_download(the_ctx, a, res_dev(n), int(res_stg(n), c_int), int(res_nlev(n), c_int)) ; call shim_check(rc, "mom6x_download")
+  n_transfers = n_transfers + 1
+end subroutine shim_resident_sync_host
+
+!> Take the array back: downloaded (unless told not to) and forgotten.
+subroutine shim_resident_drop(a, download)
+  real(c_double), target, intent(inout) :: a(*) ; logical, optional, intent(in) :: download
+  integer(c_int) :: rc ; integer :: n
+  logical :: down
+  n = res_find(a)
+  if (n == 0) return
+  down = .true. ; if (present(download)) down = download
+  if (down) call shim_resident_sync_host(a)
+  rc = mom6x_dev_free(the_ctx, res_dev(n))
+  res_addr(n) = res_addr(n_res) ; res_dev(n) = res_dev(n_res) ; res_stg(n) = res_stg(n_res) ; res_nlev(n) = res_nlev(n_res)
+  res_addr(n_res) = 0 ; res_dev(n_res) = c_null_ptr ; n_res = n_res - 1
+end subroutine shim_resident_drop
+
+!> The device copy of a resident array (c_null_ptr: not resident): for a host that calls the C ABI itself
+function shim_resident_dev(a) result(p)
+  real(c_double), target, intent(in) :: a(*)
+  type(c_ptr) :: p ; integer :: n
+  n = res_find(a)
+  p = c_null_ptr ; if (n > 0) p = res_dev(n)
+end function shim_resident_dev
+
+!> Arrays the shims have moved between host and device since the last reset
+integer(c_long_long) function shim_transfer_count(reset)
+  logical, optional, intent(in) :: reset
+  shim_transfer_count = n_transfers
+  if (present(reset)) then ; if (reset) n_transfers = 0 ; endif
+end function shim_transfer_count
+
+!> Host array (MOM6 symmetric-memory extents of its staggering) -> its resident copy, or uploaded into the scratch slot;
+!! returns the device pointer.
 function shim_up3(slot, a, stagger, nlev) result(p)
-  integer, intent(in) :: slot, stagger, nlev ; real(c_double), intent(in) :: a(*)
-  type(c_ptr) :: p ; integer(c_int) :: rc
+  integer, intent(in) :: slot, stagger, nlev ; real(c_double), target, intent(in) :: a(*)
+  type(c_ptr) :: p ; integer(c_int) :: rc ; integer :: n
+  n = res_find(a)
+  if (n > 0) then ; p = res_dev(n) ; return ; endif
   p = shim_buf(slot, nlev)
   rc = mom6x_upload(the_ctx, p, a, int(stagger, c_int), int(nlev, c_int)) ; call shim_check(rc, "mom6x_upload")
+  n_transfers = n_transfers + 1
 end function shim_up3
 
+!> Where a shim should have the device write the RESULT that goes to the host array `a`: the resident copy, or the scratch slot
+!! (from which shim_down3 brings it to the host).
+function shim_out3(slot, a, nlev) result(p)
+  integer, intent(in) :: slot, nlev ; real(c_double), target, intent(in) :: a(*)
+  type(c_ptr) :: p ; integer :: n
+  n = res_find(a)
+  if (n > 0) then ; p = res_dev(n) ; else ; p = shim_buf(slot, nlev) ; endif
+end function shim_out3
+function shim_out2(slot, a) result(p)
+  integer, intent(in) :: slot ; real(c_double), target, intent(in) :: a(*)
+  type(c_ptr) :: p
+  p = shim_out3(slot, a, 1)
+end function shim_out2
+
 function shim_up2(slot, a, stagger) result(p)
-  integer, intent(in) :: slot, stagger ; real(c_double), intent(in) :: a(*)
+  integer, intent(in) :: slot, stagger ; real(c_double), target, intent(in) :: a(*)
   type(c_ptr) :: p
   p = shim_up3(slot, a, stagger, 1)
 end function shim_up2
 
+!> A result on the device -> the host array; a resident host array keeps it in HBM (a copy on the device if the shim had it
+!! written somewhere else).
 subroutine shim_down3(a, p, stagger, nlev)
-  real(c_double), intent(inout) :: a(*) ; type(c_ptr), intent(in) :: p ; integer, intent(in) :: stagger, nlev
-  integer(c_int) :: rc
+  real(c_double), target, intent(inout) :: a(*) ; type(c_ptr), intent(in) :: p ; integer, intent(in) :: stagger, nlev
+  integer(c_int) :: rc ; integer :: n
+  n = res_find(a)
+  if (n > 0) then
+    rc = mom6x_dev_copy(the_ctx, res_dev(n), p, int(the_dims%slab, c_size_t) * int(max(nlev, 1), c_size_t)) ; call shim_check(rc, "mom6x_dev_copy")
+    return
+  endif
   rc = mom6x_download(the_ctx, a, p, int(stagger, c_int), int(nlev, c_int)) ; call shim_check(rc, "mom6x_download")
+  n_transfers = n_transfers + 1
 end subroutine shim_down3
 
 subroutine shim_down2(a, p, stagger)
-  real(c_double), intent(inout) :: a(*) ; type(c_ptr), intent(in) :: p ; integer, intent(in) :: stagger
+  real(c_double), target, intent(inout) :: a(*) ; type(c_ptr), intent(in) :: p ; integer, intent(in) :: stagger
   call shim_down3(a, p, stagger, 1)
 end subroutine shim_down2
 
@@ -196,6 +308,8 @@ subroutine shim_ctx_end()
   do n = 1, NBUF
     if (c_associated(bufs(n))) then ; rc = mom6x_dev_free(the_ctx, bufs(n)) ; bufs(n) = c_null_ptr ; buf_len(n) = 0 ; endif
   enddo
+  do n = 1, n_res ; rc = mom6x_dev_free(the_ctx, res_dev(n)) ; res_dev(n) = c_null_ptr ; res_addr(n) = 0 ; enddo
+  n_res = 0
   rc = mom6x_ctx_destroy(the_ctx) ; the_ctx = c_null_ptr
 end subroutine shim_ctx_end
 

@@ -377,6 +377,7 @@ int mom6x_prof_report(mom6x_ctx *ctx, char *buf, int buflen);
 /* Device memory helpers for non-torch hosts (Fortran).                       */
 int mom6x_dev_alloc(mom6x_ctx *ctx, double **p, size_t n_doubles);
 int mom6x_dev_free(mom6x_ctx *ctx, double *p);
+int mom6x_dev_copy(mom6x_ctx *ctx, double *dst, const double *src, size_t n_doubles);   /* device -> device, on the context's stream */
 /* Fortran array <-> pitched device array.  `stagger`: 0 = h-point
  * (SZI_,SZJ_), 1 = u-point (SZIB_,SZJ_), 2 = v-point (SZI_,SZJB_), 3 = q-point
  * (SZIB_,SZJB_), with MOM6 symmetric-memory extents; nk = 1 for 2-D.         */

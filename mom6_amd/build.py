@@ -26,8 +26,6 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # without it against 2.20 / 3.05 with it, profiles/r04_signed_zero_flags.txt -- and was not where the zeros of opposite sign came
 # from: continuity_wave.hip face_column).
 PER_FILE = {"continuity_wave.hip": ["-ffinite-math-only"]}
-if "MOM6X_WAVE_FLAGS" in os.environ:   # dev: A/B of the per-file flags (scripts/r04_signed_zero.sh)
-    PER_FILE["continuity_wave.hip"] = os.environ["MOM6X_WAVE_FLAGS"].split()
 
 
 def _newer(srcs, target):

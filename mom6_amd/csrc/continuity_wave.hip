@@ -694,7 +694,7 @@ __device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A
   TICK(6);
   // three trial velocities (:1330-1349), five column sums
   double FAmt_L = 0.0, FAmt_R = 0.0, FAmt_0 = 0.0, uhtot_L = 0.0, uhtot_R = 0.0;
-  const bool sweep_0 = wave_any(!dd0_fresh) || E.force_walk;
+  const bool sweep_0 = wave_any(!dd0_fresh);
   if (sweep_0) {
 #pragma unroll
     for (int n = 0; n < MAXL; n++) {
@@ -961,8 +961,7 @@ template <int DIR, int MAXL>
 int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   using ST = Stage<DIR>;
   LdsArgs E = E0;   // (E.np, pa0.., pib set by the caller)
-  static const int famt0_sweep = [] { const char *e = getenv("MOM6X_FAMT0"); return (e && !strcmp(e, "sweep")) ? 1 : 0; }();
-  E.retry = nullptr; E.force_walk = famt0_sweep;   // (in this kernel: always make set_*_BT_cont's own sweep at du0)
+  E.retry = nullptr; E.force_walk = 0;
   // The Newton statistics are a separate instantiation: the counters cost the 253-register kernel its last free registers
   // (139 spills), so they are only compiled into the variant that runs while mom6x_continuity_stats is switched on.
   const bool stats = (c->cont_stats != nullptr) && c->cont_stats_on && !E.fma;
@@ -1005,7 +1004,7 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   // launch wants several work-groups per resident slot: on the tile of an 8-GPU layout (360 x 540) 16 rows make 782 work-groups =
   // 1.5 rounds, the second one half empty -- measured there (profiles/r04_mfw_variants.md): 4-10 rows 0.36-0.38 ms per zonal launch,
   // 16 rows 0.41, one round of 25 rows 0.45.  The prologue of a work-group (first DMA; meridional: the ring of h rows and the
-  // row that is only reconstructed) is cheap next to that.  MOM6X_MFW_ROWS overrides.
+  // row that is only reconstructed) is cheap next to that.
   {
     static int slots_cache[2][2][5] = {{{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}, {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}};
     int &slots = slots_cache[DIR][E.fma ? 1 : 0][stats ? 4 : spec];   // (per instantiation of launch(): MAXL is a template parameter)
@@ -1015,12 +1014,10 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
       if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
       slots = per_cu * ncu;
     }
-    static const int rows_env = [] { const char *e = getenv("MOM6X_MFW_ROWS"); return e ? atoi(e) : 0; }();
     const long want = 4L * slots;                                  // work-groups for four rounds
     const long r = strips_rows / want;                             // the march length that gives them
     const int rmin = DIR ? 6 : 4;
     E.rows = (int)std::min<long>(16, std::max<long>(rmin, r));
-    if (rows_env > 0) E.rows = rows_env;
   }
   int nwg = 0;
   for (int q = 0; q < E.np; q++) { E.pgy[q] = (E.pb1[q] - E.pb0[q] + E.rows) / E.rows; nwg += E.pgx[q] * E.pgy[q]; }

@@ -269,6 +269,13 @@ extern "C" int mom6x_dev_alloc(mom6x_ctx *c, double **p, size_t n) {
   HIPCHK(hipMemsetAsync(*p, work_fill_byte(), n * sizeof(double), c->stream));
   return MOM6X_OK;
 }
+// device -> device on the context's stream (the Fortran shims: a result that lands in a scratch slot although its host array is resident)
+extern "C" int mom6x_dev_copy(mom6x_ctx *c, double *dst, const double *src, size_t n) {
+  REQUIRE(c && dst && src, MOM6X_EINVAL, "mom6x_dev_copy: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (dst != src) HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return MOM6X_OK;
+}
 extern "C" int mom6x_dev_free(mom6x_ctx *c, double *p) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipFree(p));

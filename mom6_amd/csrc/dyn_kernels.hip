@@ -939,17 +939,11 @@ int CorAdCalc_bc(mom6x_ctx *c, const double *u, const double *v, const double *h
     const int gx = (d.ni + 1 + (CF_X - 2) - 1) / (CF_X - 2), gy = (d.nj + 1 + (CF_Y - 2) - 1) / (CF_Y - 2), gz = (d.nk + kc - 1) / kc;
     constexpr int xcd_order = 1;   // (the launch-order walk of the tiles lost in round 4 and is gone: profiles/README.md)
     const dim3 gt((unsigned)(((gx * gy * gz + 7) / 8) * 8), 1, 1);
-    static const bool lean_off = [] { const char *e = getenv("MOM6X_CORAD_LEAN"); return e && !strcmp(e, "0"); }();
-    // the default configuration has its own instantiation: 104 registers and no scratch instead of 128 + 2 spilled
-    const bool lean = !lean_off && (scheme == MOM6X_SADOURNY75_ENERGY) && !c->cor.bound_Coriolis && !c->cor.Coriolis_En_Dis;
-    static const bool lds_in = [] { const char *e = getenv("MOM6X_CORAD_INPUTS"); return !(e && !strcmp(e, "global")); }();
-    if (lean && lds_in)   // MOM6X_CORAD_INPUTS=global: k_corad_fused<true>, whose threads read their neighbours' inputs from global memory
+    // the default configuration has its own kernel (inputs, q and KE through LDS); every other one the generic k_corad_fused
+    const bool lean = (scheme == MOM6X_SADOURNY75_ENERGY) && !c->cor.bound_Coriolis && !c->cor.Coriolis_En_Dis;
+    if (lean)
       KLAUNCH(c, "k_corad_lds", k_corad_lds, gt, bt, d, c->G, u, v, uh, vh, CAu, CAv, h, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr,
               c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc, gx, gy, gz, xcd_order);
-    else if (lean)
-      KLAUNCH(c, "k_corad_fused", k_corad_fused<true>, gt, bt, d, c->G, u, v, uh, vh, CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h,
-              c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr, c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc, gx, gy, gz,
-              xcd_order);
     else
       KLAUNCH(c, "k_corad_fused", k_corad_fused<false>, gt, bt, d, c->G, u, v, uh, vh, CAu, CAv, c->cor.Coriolis_Scheme, c->cor.bound_Coriolis, h,
               c->cor.Coriolis_En_Dis, PFu, PFv, diffu, diffv, u_bc, v_bc, uhtr, vhtr, dt_tr, c->cor.no_slip, c->cor.KE_Scheme, vol_neglect, kc, gx, gy, gz,

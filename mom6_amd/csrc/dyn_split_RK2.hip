@@ -377,8 +377,7 @@ extern "C" int mom6x_step_dyn_split_RK2(mom6x_ctx *c, double *u_inst, double *v_
   const bool host_coef = (hooks && hooks->vertvisc_coef);   // up/vp are needed on the host before the solve
   // With the stored Coriolis acceleration (the rule: STORE_CORIOLIS_ACCEL) everything u_bc_accel needs but PFu exists already:
   // the pressure-force kernel forms it as it makes PFu (k_bc_accel's 8 words per face-layer -> 4 more in a kernel that runs anyway)
-  static const bool bc_own = [] { const char *e = getenv("MOM6X_BC_ACCEL"); return e && !strcmp(e, "own"); }();
-  const bool fold_bc = s->CAu_pred_stored && !host_coef && !bc_own;
+  const bool fold_bc = s->CAu_pred_stored && !host_coef;
   // (and the column sum of h that bt_mass_source :629 is about to form from the same array: one pass over h less)
   static const bool ms_own = [] { const char *e = getenv("MOM6X_BT_MASS_SOURCE"); return e && !strcmp(e, "own"); }();
   c->pgf_fold = BcFold{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ms_own ? nullptr : s->eta_h };

@@ -1000,10 +1000,9 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
   // work-group): the 64 x 16 tiles are gone.
   static const bool fused = [] { const char *e = getenv("MOM6X_HORVISC"); return !(e && !strcmp(e, "legacy")); }();
   if (fused && !(CS.Leith_Kh || CS.Leith_Ah) && d.halo >= 4) {
-    static const int kc_env = [] { const char *e = getenv("MOM6X_HV_KC"); return e ? atoi(e) : 0; }();
     // (layers per work-group: the whole column up to 80 layers -- the ~30 coefficient planes of a tile are then read once; 4.53 ms
     //  against 4.68 with 25-layer chunks at nk = 75)
-    const int kc = (kc_env > 0) ? std::min(kc_env, d.nk) : ((d.nk <= 80) ? d.nk : ((d.nk % 25 == 0) ? 25 : KCHUNK));
+    const int kc = (d.nk <= 80) ? d.nk : ((d.nk % 25 == 0) ? 25 : KCHUNK);
     // Tiles: 32 x 24 points (768 threads = 12 wavefronts, three per SIMD at <= 168 registers: the OM4-class instantiation has 150;
     // outputs on 28 x 20 = 73 % of the tile).  Round 3's 32 x 16 tiles (two per SIMD, 66 %: 3.57 ms against 2.49-2.82 at 1440 x 1080 x 75)
     // and the 64 x 16 tiles (1024 threads: four wavefronts per SIMD = 128 registers, 56 values in scratch) lost and are gone
@@ -1019,8 +1018,7 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 24, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 26 * 34 * 8));
       attr_set = true;
     }
-    static const bool om4_off = [] { const char *e = getenv("MOM6X_HV_OM4"); return e && !strcmp(e, "0"); }();
-    const bool om4 = !om4_off && CS.Laplacian && CS.biharmonic && !CS.Smagorinsky_Kh && CS.Smagorinsky_Ah && CS.better_bound_Kh &&
+    const bool om4 = CS.Laplacian && CS.biharmonic && !CS.Smagorinsky_Kh && CS.Smagorinsky_Ah && CS.better_bound_Kh &&
                      CS.better_bound_Ah && !CS.no_slip && !CS.bound_Coriolis && CS.bound_Ah && CS.bound_Kh && CS.backscatter_underbound &&
                      !CS.add_LES_viscosity && CS.use_land_mask;
     if (om4) {

@@ -42,6 +42,10 @@ program drive_shims
   use MOM_variables, only : thermo_var_ptrs, vertvisc_type, ocean_internal_state, accel_diag_ptrs, cont_diag_ptrs
   use MOM_verticalGrid, only : verticalGrid_type
   use mom6x_diabatic_solvers, only : tracer_vertdiff
+  use MOM_barotropic, only : barotropic_CS, barotropic_init, register_barotropic_restarts, btstep, btcalc, bt_mass_source, barotropic_end, set_dtbt
+  use MOM_CoriolisAdv, only : CoriolisAdv_CS, CoriolisAdv_init, CorAdCalc, CoriolisAdv_end
+  use MOM_variables, only : BT_cont_type
+  use mom6x_shim_ctx, only : shim_resident_add, shim_resident_sync_host, shim_resident_drop, shim_transfer_count
   implicit none
   character(len=512) :: path, rpath, mode
   integer :: un, ni, nj, nk, halo, nsteps, save_after, first_direction, nmet, nparams, magic, m, n, nbad
@@ -157,6 +161,7 @@ program drive_shims
   call compare_diag_pointers()
   call check_clocks()
   call tracer_checks()
+  call resident_submodule_checks()
   call stop_model()
 
   ! =================================== run D: the same file read as one WITHOUT CAu, CAv =======================================
@@ -325,6 +330,84 @@ contains
     call tracer_advect_end(TA)
     deallocate(Reg)
   end subroutine tracer_checks
+
+  !> CorAdCalc and btstep through their shims, first with plain host arrays (every argument crosses PCIe on every call), then with
+  !! the same arrays handed over to the device (shim_resident_add): the calls must then move NOTHING -- counted -- and give the
+  !! same bits.
+  subroutine resident_submodule_checks()
+    type(CoriolisAdv_CS) :: CorCS
+    type(barotropic_CS) :: BTCS
+    type(MOM_restart_CS) :: RCS2
+    type(BT_cont_type), pointer :: no_BT_cont => NULL()
+    type(accel_diag_ptrs), pointer :: no_ADp => NULL()
+    real, dimension(:,:), pointer :: no2 => NULL()
+    real, dimension(:,:,:), pointer :: no3 => NULL()
+    real, allocatable, target :: CAu(:,:,:), CAv(:,:,:), CAu2(:,:,:), CAv2(:,:,:), bcu(:,:,:), bcv(:,:,:), pbce(:,:,:), vru(:,:,:), vrv(:,:,:)
+    real, allocatable, target :: alu(:,:,:), alv(:,:,:), alu2(:,:,:), alv2(:,:,:), eta_in(:,:), eta_o(:,:), eta_o2(:,:), spv(:,:)
+    real, allocatable, target :: uhb(:,:), vhb(:,:), uhb2(:,:), vhb2(:,:)
+    logical :: cd
+    integer :: k, rep
+    integer(c_long_long) :: n_plain, n_res
+    call al3(CAu, 1) ; call al3(CAv, 2) ; call al3(CAu2, 1) ; call al3(CAv2, 2) ; call al3(bcu, 1) ; call al3(bcv, 2) ; call al3(pbce, 0)
+    call al3(vru, 1) ; call al3(vrv, 2) ; call al3(alu, 1) ; call al3(alv, 2) ; call al3(alu2, 1) ; call al3(alv2, 2)
+    allocate(eta_in(G%isd:G%ied,G%jsd:G%jed), eta_o(G%isd:G%ied,G%jsd:G%jed), eta_o2(G%isd:G%ied,G%jsd:G%jed), spv(G%isd:G%ied,G%jsd:G%jed), source=0.0)
+    allocate(uhb(G%IsdB:G%IedB,G%jsd:G%jed), uhb2(G%IsdB:G%IedB,G%jsd:G%jed), vhb(G%isd:G%ied,G%JsdB:G%JedB), vhb2(G%isd:G%ied,G%JsdB:G%JedB), source=0.0)
+    eta_in = (sum(h, 3) - G%bathyT * GV%Z_to_H) * G%mask2dT
+    do k = 1, nk
+      bcu(:,:,k) = 1.0e-6 * u(:,:,k) ; bcv(:,:,k) = 1.0e-6 * v(:,:,k) ; pbce(:,:,k) = GV%g_Earth * GV%H_to_Z * (1.0 + 1.0e-3 * (k - 1))
+      vru(:,:,k) = 0.9 * G%mask2dCu ; vrv(:,:,k) = 0.9 * G%mask2dCv
+    enddo
+    call CoriolisAdv_init(Time, G, GV, US, PF, diag, ADp, CorCS)
+    call register_barotropic_restarts(HI, GV, US, PF, BTCS, RCS2)
+    call barotropic_init(u, v, h, Time, G, GV, US, PF, diag, BTCS, RCS2, cd, no_BT_cont, OBC)
+    ! ---- plain host arrays
+    n_plain = shim_transfer_count(reset=.true.)
+    call CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, ADp, G, GV, US, CorCS, pbv)
+    call btcalc(h, G, GV, BTCS, may_use_default=.true.)
+    call set_dtbt(G, GV, US, BTCS, pbce=pbce)
+    call bt_mass_source(h, eta_in, .true., G, GV, BTCS)
+    call btstep(u, v, eta_in, dt, bcu, bcv, forces, pbce, eta_in, u, v, alu, alv, eta_o, uhb, vhb, G, GV, US, BTCS, vru, vrv, spv, &
+                no_ADp, OBC, no_BT_cont, no2, no2, no2, no3, no3, no3, no3)
+    n_plain = shim_transfer_count(reset=.true.)
+    ! ---- the same arrays resident in HBM (results into a second set)
+    call shim_resident_add(u, 1, nk) ; call shim_resident_add(v, 2, nk) ; call shim_resident_add(h, 0, nk)
+    call shim_resident_add(uh, 1, nk) ; call shim_resident_add(vh, 2, nk) ; call shim_resident_add(CAu2, 1, nk) ; call shim_resident_add(CAv2, 2, nk)
+    call shim_resident_add(eta_in, 0, 1) ; call shim_resident_add(bcu, 1, nk) ; call shim_resident_add(bcv, 2, nk)
+    call shim_resident_add(taux, 1, 1) ; call shim_resident_add(tauy, 2, 1) ; call shim_resident_add(pbce, 0, nk)
+    call shim_resident_add(vru, 1, nk) ; call shim_resident_add(vrv, 2, nk) ; call shim_resident_add(alu2, 1, nk) ; call shim_resident_add(alv2, 2, nk)
+    call shim_resident_add(eta_o2, 0, 1) ; call shim_resident_add(uhb2, 1, 1) ; call shim_resident_add(vhb2, 2, 1)
+    n_res = shim_transfer_count(reset=.true.)
+    do rep = 1, 2
+      call CorAdCalc(u, v, h, uh, vh, CAu2, CAv2, OBC, ADp, G, GV, US, CorCS, pbv)
+      call btcalc(h, G, GV, BTCS, may_use_default=.true.)
+      call bt_mass_source(h, eta_in, .true., G, GV, BTCS)
+      call btstep(u, v, eta_in, dt, bcu, bcv, forces, pbce, eta_in, u, v, alu2, alv2, eta_o2, uhb2, vhb2, G, GV, US, BTCS, vru, vrv, spv, &
+                  no_ADp, OBC, no_BT_cont, no2, no2, no2, no3, no3, no3, no3)
+    enddo
+    n_res = shim_transfer_count(reset=.true.)
+    print '(a,i0,a,i0)', "sub-module shims: arrays across PCIe per CorAdCalc + btcalc + bt_mass_source + btstep: plain ", n_plain, ", resident ", n_res
+    if (n_plain < 20) then ; print '(a)', "FAIL: the plain calls should have moved their arguments" ; nbad = nbad + 1 ; endif
+    if (n_res /= 0) then ; print '(a)', "FAIL: calls on resident arrays moved data between host and device" ; nbad = nbad + 1 ; endif
+    call shim_resident_sync_host(CAu2) ; call shim_resident_sync_host(CAv2) ; call shim_resident_sync_host(alu2) ; call shim_resident_sync_host(alv2)
+    call shim_resident_sync_host(eta_o2) ; call shim_resident_sync_host(uhb2) ; call shim_resident_sync_host(vhb2)
+    call cmp3("resident CorAdCalc CAu", CAu2(G%IscB:G%IecB,G%jsc:G%jec,:), CAu(G%IscB:G%IecB,G%jsc:G%jec,:))
+    call cmp3("resident CorAdCalc CAv", CAv2(G%isc:G%iec,G%JscB:G%JecB,:), CAv(G%isc:G%iec,G%JscB:G%JecB,:))
+    call cmp3("resident btstep accel_layer_u", alu2(G%IscB:G%IecB,G%jsc:G%jec,:), alu(G%IscB:G%IecB,G%jsc:G%jec,:))
+    call cmp3("resident btstep accel_layer_v", alv2(G%isc:G%iec,G%JscB:G%JecB,:), alv(G%isc:G%iec,G%JscB:G%JecB,:))
+    call cmp3("resident btstep eta_out", reshape(eta_o2(G%isc:G%iec,G%jsc:G%jec), (/ ni, nj, 1 /)), reshape(eta_o(G%isc:G%iec,G%jsc:G%jec), (/ ni, nj, 1 /)))
+    call cmp3("resident btstep uhbtav", reshape(uhb2(G%IscB:G%IecB,G%jsc:G%jec), (/ ni + 1, nj, 1 /)), reshape(uhb(G%IscB:G%IecB,G%jsc:G%jec), (/ ni + 1, nj, 1 /)))
+    call cmp3("resident btstep vhbtav", reshape(vhb2(G%isc:G%iec,G%JscB:G%JecB), (/ ni, nj + 1, 1 /)), reshape(vhb(G%isc:G%iec,G%JscB:G%JecB), (/ ni, nj + 1, 1 /)))
+    if (maxval(abs(alu)) == 0.0 .or. maxval(abs(CAu)) == 0.0) then ; print '(a)', "FAIL: the shims returned zeros" ; nbad = nbad + 1 ; endif
+    ! the host takes its arrays back (the state ones without a download: nothing wrote them)
+    call shim_resident_drop(u, download=.false.) ; call shim_resident_drop(v, download=.false.) ; call shim_resident_drop(h, download=.false.)
+    call shim_resident_drop(uh, download=.false.) ; call shim_resident_drop(vh, download=.false.)
+    call shim_resident_drop(taux, download=.false.) ; call shim_resident_drop(tauy, download=.false.)
+    call shim_resident_drop(CAu2) ; call shim_resident_drop(CAv2) ; call shim_resident_drop(alu2) ; call shim_resident_drop(alv2)
+    call shim_resident_drop(eta_in, download=.false.) ; call shim_resident_drop(bcu, download=.false.) ; call shim_resident_drop(bcv, download=.false.)
+    call shim_resident_drop(pbce, download=.false.) ; call shim_resident_drop(vru, download=.false.) ; call shim_resident_drop(vrv, download=.false.)
+    call shim_resident_drop(eta_o2) ; call shim_resident_drop(uhb2) ; call shim_resident_drop(vhb2)
+    call barotropic_end(BTCS) ; call CoriolisAdv_end(CorCS)
+  end subroutine resident_submodule_checks
 
   subroutine rd2(a, stg)
     real, allocatable, intent(inout) :: a(:,:) ; integer, intent(in) :: stg

@@ -80,16 +80,14 @@ def test_CorAdCalc(orc, cfg, mods):
 
 
 def test_CorAdCalc_other_kernels_are_bit_identical_too():
-    """The default configuration runs k_corad_lds (inputs, q and KE through LDS).  k_corad_fused<LEAN> (MOM6X_CORAD_INPUTS=global: q and
-    KE through LDS, neighbours' inputs from global memory), its generic instantiation (MOM6X_CORAD_LEAN=0)
-    and the two-kernel form through HBM (MOM6X_CORAD=legacy) are held to the same oracle: the cases above again in a process
-    with the switch set."""
+    """The default configuration runs k_corad_lds (inputs, q and KE through LDS), every other one k_corad_fused (the cases above
+    with BOUND_CORIOLIS, CORIOLIS_EN_DIS or another scheme).  The two-kernel form through HBM (MOM6X_CORAD=legacy) is held to the
+    same oracle: the cases above again in a process with the switch set."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env in (dict(MOM6X_CORAD_INPUTS="global"), dict(MOM6X_CORAD_INPUTS="global", MOM6X_CORAD_LEAN="0"),
-                dict(MOM6X_CORAD="legacy")):
+    for env in (dict(MOM6X_CORAD="legacy"),):
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_dyn_gpu.py"), "-m", "gpu", "-q", "-x",
                             "-k", "test_CorAdCalc and not other_kernels"], env=dict(os.environ, **env), capture_output=True, text=True,
                            timeout=900, cwd=root)

@@ -132,7 +132,9 @@ def test_shim_modules_new_run_restart_and_tracers_from_fortran(orc, tmp_path, mo
     of tests/fortran_stubs/, driven the way MOM.F90 drives them: four steps uninterrupted == the oracle's fixture bit for bit;
     two steps, save_restart (every registered variable, the barotropic ones included), end, a fresh control structure,
     restore_state, two more steps == the same fixture bit for bit.  Both modes of the shim: state across PCIe every step
-    (MOM.F90 unchanged) and resident in HBM (three hook calls).  Both orders of the column sums."""
+    (MOM.F90 unchanged) and resident in HBM (three hook calls).  Every arithmetic of the column sums.  The driver also calls the
+    sub-module shims (CorAdCalc, btcalc, bt_mass_source, btstep) on plain host arrays and on arrays made resident with
+    mom6x_shim_ctx's shim_resident_add, counting the arrays that cross PCIe (29 against 0) and comparing the results."""
     if not os.path.exists(SHIM_DRIVER):
         pytest.fail("tests/fortran_stubs/drive_shims is missing: __graft_entry__.build() compiles it with amdflang")
     path = tmp_path / "shim_case.bin"
@@ -142,7 +144,10 @@ def test_shim_modules_new_run_restart_and_tracers_from_fortran(orc, tmp_path, mo
     print(r.stdout); print(r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
     # runs A and C: the state; run C also: the arrays behind Accel_diag% and MIS% (associated, and equal to the oracle's)
-    assert r.stdout.count(": bit-identical") == 2 * len(STATE) + len(DIAG)
+    assert r.stdout.count(": bit-identical") == 2 * len(STATE) + len(DIAG) + 7
+    # CorAdCalc, btcalc, bt_mass_source and btstep through their shims on arrays the host has made resident (shim_resident_add): not one
+    # array crosses PCIe in two rounds of calls, and the seven results equal those of the calls on plain host arrays
+    assert ", resident 0" in r.stdout and r.stdout.count("resident CorAdCalc") == 2 and r.stdout.count("resident btstep") == 5
     assert "D (restart file without CAu, CAv) u: max |diff|" in r.stdout
     names = r.stdout.split("registered restart variables:")[1].splitlines()[0].split()
     assert names == ["u", "v", "h", "sfc", "u2", "v2", "CAu", "CAv", "diffu", "diffv", "ubtav", "vbtav", "DTBT"]
@@ -159,4 +164,4 @@ def test_shim_modules_without_a_BT_cont_type_from_fortran(orc, tmp_path, sums):
     r = subprocess.run([SHIM_DRIVER, str(path), str(tmp_path / "restart.bin")], capture_output=True, text=True, timeout=300)
     print(r.stdout); print(r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count(": bit-identical") == 2 * len(STATE) + len(DIAG)
+    assert r.stdout.count(": bit-identical") == 2 * len(STATE) + len(DIAG) + 7

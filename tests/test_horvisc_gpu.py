@@ -94,14 +94,14 @@ def test_hor_visc_init_rejects_noslip_biharmonic():
 
 def test_the_other_variants_are_bit_identical_too():
     """The default is k_hv_fused on 32 x 24 tiles (the four stages in one LDS-tiled kernel, hor_visc.hip).  The four-kernel chain
-    (MOM6X_HORVISC=legacy; what Leith configurations always take) and the generic instantiation where the OM4-class one would run
-    (MOM6X_HV_OM4=0) are held to the same oracle: this file again in a process with the switch set."""
+    (MOM6X_HORVISC=legacy; what Leith configurations always take) is held to the same oracle: this file again in a process with the
+    switch set.  (The generic instantiation of k_hv_fused is what every case but the OM4-class one above runs.)"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for mode, om4 in (("legacy", "1"), ("fused", "0")):   # om4 = 0: the generic instantiation
-        env = dict(os.environ, MOM6X_HORVISC=mode, MOM6X_HV_OM4=om4)
+    for mode in ("legacy",):
+        env = dict(os.environ, MOM6X_HORVISC=mode)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_horvisc_gpu.py"), "-m", "gpu", "-q", "-x",
                             "-k", "not other_variants"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
         assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

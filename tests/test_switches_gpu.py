@@ -16,18 +16,13 @@ CASES = [
     ("MOM6X_BT_SUBSTEP", "kernels", "test_barotropic_gpu.py", ""),                      # three launches per barotropic sub-step
     ("MOM6X_BT_SUBSTEP", "kernels", "test_rk2_gpu.py", "double_gyre_bitexact or 75_layers_on_chip"),
     ("MOM6X_BT_SUBSTEP", "fused", "test_layout_gpu.py", "wide_halos"),                  # (the default at these sizes; named)
-    ("MOM6X_FAMT0", "sweep", "test_continuity_gpu.py", "double_gyre or tied_quotients"),  # set_*_BT_cont's own sweep at du0
-    ("MOM6X_MFW_ROWS", "3", "test_continuity_gpu.py", "double_gyre or channel or many_layers"),   # march length of the wave kernel
-    ("MOM6X_MFW_ROWS", "37", "test_continuity_gpu.py", "double_gyre or channel or many_layers"),
     ("MOM6X_MFW_SPEC", "0", "test_continuity_gpu.py", "many_layers"),                   # the general mass-flux kernel where the one compiled for the launch's switches would run
     ("MOM6X_MFW_SPEC", "0", "test_rk2_gpu.py", "75_layers_on_chip"),
     ("MOM6X_VERTVISC", "walk", "test_rk2_gpu.py", "75_layers_on_chip or one_kernel"),                 # the column solve through HBM at nk = 75
     ("MOM6X_VERTVISC", "pair", "test_rk2_gpu.py", "75_layers_on_chip or one_kernel"),                 # vertvisc_coef and the solve as two kernels (on chip each)
     ("MOM6X_PASS_WIDTHS", "full", "test_layout_gpu.py", "tile_layout_gives"),           # NIHALO rows in every group pass of the step
     ("MOM6X_POISON_HALO", "1", "test_layout_gpu.py", "tile_layout_gives"),              # NaNs in the halo rows beyond the width of each narrow pass
-    ("MOM6X_BC_ACCEL", "own", "test_rk2_gpu.py", "double_gyre_bitexact or 75_layers_on_chip"),      # k_bc_accel instead of the fold into k_pgf_main
     ("MOM6X_BT_MASS_SOURCE", "own", "test_rk2_gpu.py", "double_gyre_bitexact or 75_layers_on_chip"),
-    ("MOM6X_HV_KC", "25", "test_horvisc_gpu.py", ""),                                   # 25-layer chunks of k_hv_fused
     ("MOM6X_REMAP_MERGE", "apply", "test_remap_gpu.py", "ALE_remap"),                   # the one-field streamed merge everywhere
     ("MOM6X_TRIDIAG", "walk", "test_tracer_gpu.py", "tridiagonal"),                     # the tracer solves through HBM
 ]
