@@ -232,21 +232,20 @@ def ale_remap_leg(args, dyc, d, st, barrier, dist):
     T = (10.0 + 5.0 * synth_dev.smooth_field(d, dyc.device, 71, nk=nk, ox=0.5, oy=0.5)).contiguous()
     S = (35.0 + synth_dev.smooth_field(d, dyc.device, 72, nk=nk, ox=0.5, oy=0.5)).contiguous()
     u, v = st["u"].clone(), st["v"].clone()
-    hu_o, hv_o, hu_n, hv_n = (torch.full_like(h, 1.0e-3) for _ in range(4))
     dyc.ALE_regrid_zstar(RP, cr, h, h_new, dzI)
     dyc.ALE_remap_tracers(CS, h, h_new, [T.clone(), S.clone()])         # untimed: allocates the work arrays (two fields share a merge)
     barrier(); t0 = time.perf_counter()
     dyc.ALE_regrid_zstar(RP, cr, h, h_new, dzI)
     dyc.ALE_remap_tracers(CS, h, h_new, [T, S])
-    dyc.ALE_remap_set_h_vel(h, hu_o, hv_o); dyc.ALE_remap_set_h_vel(h_new, hu_n, hv_n)
-    dyc.ALE_remap_velocities(CS, hu_o, hv_o, hu_n, hv_n, u, v)
+    dyc.ALE_remap_velocities_from_h(CS, h, h_new, u, v)      # ALE_remap_set_h_vel x 2 + ALE_remap_velocities (MOM.F90's three calls in a row)
     barrier(); t = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([t], dtype=torch.float64, device=dyc.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
     N3 = args.ni * args.nj * args.nk
-    # regrid: h in, h_new and dzRegrid out; per field: h_old, h_new, field in, field out; set_h_vel x2: h in, h_u, h_v out
+    # regrid: h in, h_new and dzRegrid out; per field: h_old, h_new, field in, field out; set_h_vel x2: h in, h_u, h_v out (the
+    # routines' own un-fused count, as SURVEY.md 8(d) counts: the device no longer writes h_u / h_v at all)
     b = 8.0 * N3 * (3 + 4 * 4 + 2 * 3)
     return {"fields": "T, S, u, v", "scheme": "PPM_H4 (OM4 sub-cells, no boundary extrapolation)", "remap_ms": round(1e3 * t, 3),
             "algorithmic_GB": round(b / 1e9, 2), "GBps": round(b / 1e9 / t, 1), "frac_of_hbm_peak": round(b / 1e9 / t / (HBM_PEAK_GBS * args.gpus), 4),
@@ -335,7 +334,6 @@ def ale_cycle(args, device=0, steps=4, warm=1, check=None, layout=(1, 1), pe=(0,
     # the z* coordinate whose nominal layers are nk equal parts of the basin's maximum depth (the same on every tile of a layout)
     cr = np.full(nk, 4000.0 / nk)
     h_new = torch.zeros_like(st["h"]); dzI = torch.zeros((nk + 1,) + tuple(st["h"].shape[1:]), dtype=torch.float64, device=dyc.device)
-    hu_o, hv_o, hu_n, hv_n = (torch.full_like(st["h"], 1.0e-3) for _ in range(4))
     info = {}
 
     def cycle(first=False):
@@ -353,8 +351,7 @@ def ale_cycle(args, device=0, steps=4, warm=1, check=None, layout=(1, 1), pe=(0,
         # ALE_regridding_and_remapping (MOM.F90:1751): new z* grid, remap everything that lives on the old one
         dyc.ALE_regrid_zstar(RP, cr, st["h"], h_new, dzI)
         dyc.ALE_remap_tracers(CSr, st["h"], h_new, [T, S] + tr)
-        dyc.ALE_remap_set_h_vel(st["h"], hu_o, hv_o); dyc.ALE_remap_set_h_vel(h_new, hu_n, hv_n)
-        dyc.ALE_remap_velocities(CSr, hu_o, hv_o, hu_n, hv_n, st["u"], st["v"])
+        dyc.ALE_remap_velocities_from_h(CSr, st["h"], h_new, st["u"], st["v"])   # ALE_remap_set_h_vel x 2 + ALE_remap_velocities
         st["h"].copy_(h_new)
         # step_MOM_thermo ends with the group pass of everything the thermodynamics and the remapping changed (MOM.F90:
         # do_group_pass(pass_uv_T_S_h)): the next dynamics step reads T, S, h of the neighbouring tiles' edge columns
@@ -388,7 +385,7 @@ def ale_cycle(args, device=0, steps=4, warm=1, check=None, layout=(1, 1), pe=(0,
         check(dict(dyc=dyc, d=d, st=st, T=T, S=S, tr=tr, Md=keep[-1], pre=pre, info=info))
     torch.cuda.set_stream(torch.cuda.default_stream())   # (torch must not keep a stream the context is about to destroy)
     dyc.close()
-    del st, T, S, tr, ea, eb, h_new, dzI, hu_o, hv_o, hu_n, hv_n, keep
+    del st, T, S, tr, ea, eb, h_new, dzI, keep
     torch.cuda.empty_cache()
     return sec, info
 
@@ -461,13 +458,16 @@ def comm_model_leg(args, device):
         dyc.close()
         del st, keep
         torch.cuda.empty_cache()
+    out["rccl_self"]["btstep_pass"] = "blocking (the default: mom6x_comm_overlap_btstep off)"
     # BTHALO = 8, 12: the same tile with a wider barotropic halo (the reference's own lever against the latency of the sub-cycle's
     # exchanges): exchanges per step (packed group messages, of which the sub-cycle's are 2 x sub-steps / BTHALO) and the step time
     out["bthalo"] = {"4": {"ms_per_step": out["rccl_self"]["ms_per_step"], "exchanges_per_step": out["rccl_self"].get("exchanges_per_step")}}
-    for bh in (8, 12):
+    for bh in (8, 12, -4):   # (-4: BTHALO = 4 with btstep's own pass overlapped with the own-points half of the next sub-step)
         a = A(); a.ni, a.nj, a.nk, a.dt, a.tracers = args.ni // 4, args.nj // 2, args.nk, args.dt, 0
-        dyc, d, st, taux, tauy, keep = build_model(a, (1, 1), (0, 0), device, reentrant_y=True, force_nccl_self=True, bthalo=bh,
+        dyc, d, st, taux, tauy, keep = build_model(a, (1, 1), (0, 0), device, reentrant_y=True, force_nccl_self=True, bthalo=max(bh, 0),
                                                    res_of=(args.ni, args.nj))
+        if bh < 0:
+            dyc.comm_overlap_btstep(True)
         torch.cuda.set_stream(dyc.torch_stream())
 
         def step(calc=False):
@@ -482,7 +482,12 @@ def comm_model_leg(args, device):
         ms = 1e2 * (time.perf_counter() - t0)
         dyc.comm_exchange_count(reset=True)
         step(); dyc.sync()
-        out["bthalo"][str(bh)] = {"ms_per_step": round(ms, 3), "exchanges_per_step": dyc.comm_exchange_count()}
+        if bh < 0:
+            out["btstep_pass_overlapped"] = {"ms_per_step": round(ms, 3), "exchanges_per_step": dyc.comm_exchange_count(),
+                                             "note": "BTHALO = 4, mom6x_comm_overlap_btstep on: the sub-cycle's pass packed on the compute stream, messages and "
+                                                     "unpack on the second stream while the own-points half of the next sub-step runs; against rccl_self.ms_per_step"}
+        else:
+            out["bthalo"][str(bh)] = {"ms_per_step": round(ms, 3), "exchanges_per_step": dyc.comm_exchange_count()}
         torch.cuda.set_stream(torch.cuda.default_stream())
         dyc.close()
         del st, keep

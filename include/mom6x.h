@@ -552,6 +552,10 @@ int mom6x_ALE_remap_set_h_vel(mom6x_ctx *ctx, const double *h_new, double *h_u, 
 /* ALE_remap_velocities :1089 (REMAP_VEL_CONSERVE_KE off, no near-bottom masking, no diagnostics).              */
 int mom6x_ALE_remap_velocities(mom6x_ctx *ctx, const mom6x_remapping_params *p, const double *h_old_u, const double *h_old_v,
                                const double *h_new_u, const double *h_new_v, double *u, double *v);
+/* The three calls MOM.F90 makes in a row (ALE_regridding_and_remapping: ALE_remap_set_h_vel of the old and of the new grid, then
+ * ALE_remap_velocities) as one, from the CELLS' thicknesses: the same bits; with OM4's switch set h_u / h_v are never stored. */
+int mom6x_ALE_remap_velocities_from_h(mom6x_ctx *ctx, const mom6x_remapping_params *p, const double *h_old, const double *h_new,
+                                      double *u, double *v);
 /* ... with the KE-conserving correction of its baroclinic part (REMAP_VEL_CONSERVE_KE = True and allow_preserve_variance,
  * MOM_ALE.F90:1166-1195, :1240-1270): what MOM.F90 asks for inside the time step.                                          */
 int mom6x_ALE_remap_velocities_conserve_ke(mom6x_ctx *ctx, const mom6x_remapping_params *p, const double *h_old_u,
@@ -797,6 +801,11 @@ int mom6x_pass_fields(mom6x_ctx *ctx, double *const *fields, const int *staggers
  * width = 0: the context's halo (the default); otherwise 4 <= width <= the context's halo.  2-D fields (eta) always travel at
  * the context's width: btstep reads them over its wide halo.                                                          */
 int mom6x_set_dyn_pass_width(mom6x_ctx *ctx, int width);
+/* btstep's own group pass of eta, ubt, vbt (pass_eta_ubt, MOM_barotropic.F90:2505-2512) started on the second stream -- packed on the
+ * compute stream, messages and unpack behind it -- while the compute stream runs the half of the next sub-step that reads the tile's
+ * own points only, completed before the other half (start_group_pass / complete_group_pass around interior work).  Off by default
+ * (see halo.hip: it loses on the one-GPU model); the answers do not depend on it.                                       */
+int mom6x_comm_overlap_btstep(mom6x_ctx *ctx, int on);
 /* Packed group exchanges (one message per neighbour each) this tile has made since the last reset; reset != 0 clears the count. */
 long long mom6x_comm_exchange_count(mom6x_ctx *ctx, int reset);
 /* ... and the bytes this tile sent in them (all neighbours together): what the per-pass halo widths of the RK2 step

@@ -559,10 +559,13 @@ struct LoopArgs {
 // btloop_eta_predictor :2956-3018 (use_BT_cont branch) over (isv-1..iev+1, jsv-1..jev+1), plus the
 // eta_sum accumulation of btloop_find_PF :3104-3108 over the computational domain.
 __global__ void __launch_bounds__(256)
-k_bt_pred(Dm d, const double *__restrict__ G, double *work, LoopArgs A, int p_ubt, int p_vbt, int p_pred) {
+k_bt_pred(Dm d, const double *__restrict__ G, double *work, LoopArgs A, int p_ubt, int p_vbt, int p_pred, int sel) {
   const int i = I_BASE(A.isv - 1) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = A.jsv - 1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i < A.isv - 1 || i > A.iev + 1 || j > A.jev + 1) return;
+  // sel 1 / 2: only the tile's own points (whose inputs are all the tile's own) / only the others -- the two halves of a launch
+  // around a group pass that is travelling (btstep's loop)
+  if (sel) { const bool own = (i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1); if (own != (sel == 1)) return; }
   const int st = d.pitch;
   const size_t c = ix2(d, i, j), slab = (size_t)d.slab;
   double eta_PF_BT;
@@ -740,11 +743,18 @@ struct SubPlanes { int u_in, u_out, v_in, v_out, e_in, e_out; };
 template <bool VFIRST, int BSX, int BSY>
 __global__ void __launch_bounds__(BSX * BSY)
 k_bt_substep(Dm d, const double *__restrict__ G, double *work, double *ubtav, double *uhbtav, double *vbtav, double *vhbtav, LoopArgs A,
-             SubPlanes P, int bracket_bug, double Z_to_H, unsigned long long *warn, double *warn_info, int nbx) {
+             SubPlanes P, int bracket_bug, double Z_to_H, unsigned long long *warn, double *warn_info, int nbx, int sel) {
   constexpr int OX = VFIRST ? BSX - 2 : BSX - 1, OY = VFIRST ? BSY - 1 : BSY - 2;
   __shared__ double s_u[BSY][BSX], s_v[BSY][BSX], s_hu[BSY][BSX], s_hv[BSY][BSX], s_un[BSY][BSX], s_vn[BSY][BSX];
   const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
   const int x0 = A.isv + bx * OX, y0 = A.jsv + by * OY;
+  // sel 1 / 2: only the blocks that read nothing but the tile's own points (the threads' points x0-1 .. x0+BSX-2 and one around
+  // them) / only the others: the first half runs while the group pass of the state travels, the second when it has arrived.  A
+  // point's result does not depend on the launch its block is in.
+  if (sel) {
+    const bool inner = (x0 - 2 >= 0) && (x0 + BSX - 1 <= d.ni - 1) && (y0 - 2 >= 0) && (y0 + BSY - 1 <= d.nj - 1);
+    if (inner != (sel == 1)) return;
+  }
   const int x1 = min(x0 + OX - 1, A.iev), y1 = min(y0 + OY - 1, A.jev);
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int i = x0 - 1 + tx, j = y0 - 1 + ty;
@@ -1327,6 +1337,9 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
   static const int substep_env = [] { const char *e = getenv("MOM6X_BT_SUBSTEP"); return !e ? 0 : (!strcmp(e, "kernels") ? 1 : (!strcmp(e, "fused") ? 2 : 0)); }();
   const bool small_tile = ((long)d.ni * d.nj <= 512L * 1024L);
   const bool fused = pass_uhn && (substep_env == 2 || (substep_env == 0 && small_tile));
+  // the loop's group pass overlapped with the own-points half of the sub-step that follows it (the one-launch form, tiles with room
+  // for such a half: more than two blocks each way)
+  const bool overlap_loop = fused && c->bt_overlap && halo_can_overlap(c) && d.ni >= 96 && d.nj >= 32;
   SubPlanes SP = { W_ubt, fused ? W_ubt2 : W_ubt, W_vbt, fused ? W_vbt2 : W_vbt, W_eta_pred, fused ? W_eta_pred2 : W_eta_pred };
   const int loop_stg[] = { 0, 1, 2, 1, 2 }, loop_nk[] = { 1, 1, 1, 1, 1 };
   bool pred_done = false;
@@ -1334,10 +1347,14 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     if (P.clip_velocity)
       KLAUNCH(c, "k_bt_clip", k_bt_clip, grid3(iev - isv + 2, jev - jsv + 2, 1, b), b, d, c->G, work, dt, P.CFL_trunc, isv, iev, jsv, jev);
     L.have_uhn = (pass_uhn && n > 1) ? 1 : 0;
+    bool travelling = false;   // the group pass of the state is on the second stream: this sub-step runs in two halves around it
     if ((iev - stencil < ie) || (jev - stencil < je)) {
       double *loop_f[] = { work + W_eta * slab, work + (size_t)SP.u_in * slab, work + (size_t)SP.v_in * slab, work + W_uhn * slab,
                            work + W_vhn * slab };
-      halo_wrap(c, loop_f, loop_stg, loop_nk, (pass_uhn && n > 1) ? 5 : 3);
+      // MOM_barotropic.F90:2505-2512.  With a communicator and the one-launch sub-step the pass overlaps the sub-step's own-points half
+      // (pack on this stream -- the half rewrites eta next to the edge --, messages and unpack on the second one)
+      if (overlap_loop) travelling = halo_start_packed(c, loop_f, loop_stg, loop_nk, (pass_uhn && n > 1) ? 5 : 3);
+      else halo_wrap(c, loop_f, loop_stg, loop_nk, (pass_uhn && n > 1) ? 5 : 3);
       isv = isvf; iev = ievf; jsv = jsvf; jev = jevf;
     } else {
       isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil;
@@ -1347,8 +1364,10 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
               (const double *)(work + W_eta * slab), work + W_BTCu * slab, work + W_BTCv * slab, isv, iev, jsv, jev);
     L.isv = isv; L.iev = iev; L.jsv = jsv; L.jev = jev;
     L.wt_accel = wt_accel[n]; L.wt_trans = wt_trans[n]; L.wt_vel = wt_vel[n]; L.wt_eta = wt_eta[n]; L.wt_accel2 = wt_accel2[n];
-    if ((!P.BT_project_velocity || L.find_etaav) && !pred_done)
-      KLAUNCH(c, "k_bt_pred", k_bt_pred, grid3(nxa(iev - isv + 3, isv - 1), jev - jsv + 3, 1, b), b, d, c->G, work, L, SP.u_in, SP.v_in, SP.e_in);
+    const bool do_pred = (!P.BT_project_velocity || L.find_etaav) && !pred_done;
+    if (do_pred)
+      KLAUNCH(c, "k_bt_pred", k_bt_pred, grid3(nxa(iev - isv + 3, isv - 1), jev - jsv + 3, 1, b), b, d, c->G, work, L, SP.u_in, SP.v_in, SP.e_in,
+              travelling ? 1 : 0);
     // the next sub-step: no exchange before it (:2505-2512) and its transports passed on by this one's velocity stages
     pred_done = pass_uhn && n < nt && !((iev - stencil < ie) || (jev - stencil < je));
     L.pred_next = pred_done ? 1 : 0;
@@ -1356,17 +1375,25 @@ extern "C" int mom6x_btstep(mom6x_ctx *c, const double *U_in, const double *V_in
     const bool v_first = (((n + c->first_direction) % 2) == 1);
     if (fused) {
       // (work-groups of 32 x 8; 32 x 16, 16 x 16 and 64 x 4 were measured in round 4 -- 9.01 / 9.03 / 9.20 / 9.14 ms per step on the 8-GPU tile -- and are gone)
-#define SUBSTEP(BX, BY) do {                                                                                                          \
+#define SUBSTEP(BX, BY, SEL) do {                                                                                                     \
       const int OX = v_first ? BX - 2 : BX - 1, OY = v_first ? BY - 1 : BY - 2;                                                        \
       const int nbx = (iev - isv + OX) / OX, nby = (jev - jsv + OY) / OY;                                                              \
       if (v_first)                                                                                                                    \
         KLAUNCH(c, "k_bt_substep<v>", (k_bt_substep<true, BX, BY>), dim3(nbx * nby), dim3(BX, BY), d, c->G, work, s->ubtav, uhbtav, s->vbtav, \
-                vhbtav, L, SP, 0, c->GV.Z_to_H, s->warn, s->warn_info, nbx);                                                           \
+                vhbtav, L, SP, 0, c->GV.Z_to_H, s->warn, s->warn_info, nbx, SEL);                                                      \
       else                                                                                                                            \
         KLAUNCH(c, "k_bt_substep<u>", (k_bt_substep<false, BX, BY>), dim3(nbx * nby), dim3(BX, BY), d, c->G, work, s->ubtav, uhbtav, s->vbtav, \
-                vhbtav, L, SP, P.use_old_coriolis_bracket_bug, c->GV.Z_to_H, s->warn, s->warn_info, nbx);                              \
+                vhbtav, L, SP, P.use_old_coriolis_bracket_bug, c->GV.Z_to_H, s->warn, s->warn_info, nbx, SEL);                         \
       } while (0)
-      SUBSTEP(32, 8);
+      if (travelling) {
+        SUBSTEP(32, 8, 1);          // the blocks that read the tile's own points only, while the messages travel ...
+        halo_complete(c);
+        if (do_pred)
+          KLAUNCH(c, "k_bt_pred", k_bt_pred, grid3(nxa(iev - isv + 3, isv - 1), jev - jsv + 3, 1, b), b, d, c->G, work, L, SP.u_in, SP.v_in, SP.e_in, 2);
+        SUBSTEP(32, 8, 2);          // ... and the rest
+      } else {
+        SUBSTEP(32, 8, 0);
+      }
 #undef SUBSTEP
       std::swap(SP.u_in, SP.u_out); std::swap(SP.v_in, SP.v_out);
       if (pred_done) std::swap(SP.e_in, SP.e_out);

@@ -213,7 +213,7 @@ extern "C" int mom6x_ctx_destroy(mom6x_ctx *c) {
   (void)hipFree(c->Rlay); (void)hipFree(c->g_prime); (void)hipFree(c->retry); (void)hipFree(c->cont_stats);
   hor_visc_free(c);
   diag_sums_free(c);
-  (void)hipFree(c->regrid_res); (void)hipFree(c->regrid_vec); (void)hipFree(c->remap_src);
+  (void)hipFree(c->regrid_res); (void)hipFree(c->regrid_vec); (void)hipFree(c->remap_src); (void)hipFree(c->remap_hvel);
   (void)hipFree(c->vv_a_u); (void)hipFree(c->vv_a_v); (void)hipFree(c->vv_h_u); (void)hipFree(c->vv_h_v);
   (void)hipFree(c->G); (void)hipFree(c->hL); (void)hipFree(c->hR); (void)hipFree(c->flag);
   if (c->ev_ready) { (void)hipEventDestroy(c->ev_ready); (void)hipEventDestroy(c->ev_done); }

@@ -377,7 +377,9 @@ int comm_allreduce_f64(mom6x_ctx *c, double *dev, size_t n, int op) {
 }
 int comm_nranks(const mom6x_ctx *c) { const Comm *m = (const Comm *)c->comm; return (m && m->comm) ? m->nranks : 1; }
 
-static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A, hipStream_t st) {
+// pack_first: the pack kernel runs on the COMPUTE stream, ahead of whatever the caller launches next there, and the rest (messages,
+// unpack) on `st` once it is done -- for a pass whose send regions the overlapped kernels are about to rewrite (halo_start_packed)
+static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A, hipStream_t st, bool pack_first = false) {
   c->n_exchanges++;   // (mom6x_comm_exchange_count)
   const Dm d = c->d;
   NcclApi *api = m->api;
@@ -405,8 +407,12 @@ static int exchange(mom6x_ctx *c, Comm *m, const WrapArgs &A, hipStream_t st) {
   for (int dir = 0; dir < 8; dir++) c->n_exchange_bytes += (long long)cnt[dir] * 8;   // (mom6x_comm_exchange_bytes: what this tile sends)
   const int blocks = (int)((cmax + 255) / 256 > 512 ? 512 : (cmax + 255) / 256);
   const bool own = (st == c->stream);     // (the per-kernel timing of mom6x_prof_* follows the compute stream only)
-  if (own) KLAUNCH(c, "k_halo_pack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, SB, 1);
+  if (own || pack_first) KLAUNCH(c, "k_halo_pack", k_halo_pack, dim3(blocks, 8), dim3(256), d, A, SB, 1);
   else hipLaunchKernelGGL(k_halo_pack, dim3(blocks, 8), dim3(256), 0, st, d, A, SB, 1);
+  if (pack_first && !own) {   // the messages leave when the pack is done
+    HIPCHK(hipEventRecord(c->ev_ready, c->stream));
+    HIPCHK(hipStreamWaitEvent(st, c->ev_ready, 0));
+  }
   // sends in direction order; receives in the order of the OPPOSITE directions, so that the j-th send to a
   // peer pairs with the peer's j-th receive from us even when one rank is the neighbour in several directions.
   bool in_group = false;
@@ -514,11 +520,48 @@ void halo_start(mom6x_ctx *c, double *const *fields, const int *staggers, const 
   }
   c->pass_pending = true;
 }
+// The same for a pass whose SEND regions the compute stream is about to rewrite (the barotropic sub-cycle: the kernels that run while
+// the messages travel update eta in place next to the tile's edge): the pack runs on the compute stream, in order with them; messages
+// and unpack on the second stream.  false: no communicator that can overlap (the pass has been made, blocking).
+bool halo_start_packed(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n) {
+  Comm *m = (Comm *)c->comm;
+  if (!m || !m->comm || n > MAXF) { halo_wrap(c, fields, staggers, nks, n); return false; }
+  if (c->pass_pending) halo_complete(c);
+  if (!c->ev_ready) {
+    if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { c->halo_error = true; return false; }
+  }
+  WrapArgs A;
+  A.n = n; A.rx = c->dims.reentrant_x;
+  A.w = (c->pass_w > 0 && c->pass_w < c->dims.halo) ? c->pass_w : c->dims.halo; A.w2 = c->dims.halo;
+  for (int q = 0; q < n; q++) {
+    A.f[q] = fields[q]; A.stg[q] = staggers[q]; A.nk[q] = nks[q];
+    A.wf[q] = (q < c->pass_wf_n && c->pass_wf[q] > 0 && c->pass_wf[q] < A.w) ? c->pass_wf[q] : 0;
+  }
+  if (exchange(c, m, A, c->halo_stream, true) != MOM6X_OK || hipEventRecord(c->ev_done, c->halo_stream) != hipSuccess) {
+    c->halo_error = true;
+    return false;
+  }
+  c->pass_pending = true;
+  return true;
+}
+bool halo_can_overlap(const mom6x_ctx *c) { const Comm *m = (const Comm *)c->comm; return m && m->comm; }
 // ... and the compute stream waits here for the halos
 void halo_complete(mom6x_ctx *c) {
   if (!c->pass_pending) return;
   c->pass_pending = false;
   if (hipStreamWaitEvent(c->stream, c->ev_done, 0) != hipSuccess) c->halo_error = true;
+}
+
+// btstep's group pass of eta, ubt, vbt (MOM_barotropic.F90:2505-2512) on the second stream, overlapped with the half of the next
+// sub-step that reads the tile's own points only (barotropic.hip: halo_start_packed, k_bt_substep / k_bt_pred sel 1, 2).  Off by
+// default: on one GPU with RCCL self-sends -- no wire, the only measurement there is -- the two extra launches and the stream
+// dependencies cost more than the 45 us of message kernel and unpack they hide (9.26 -> 9.64 ms per step of the 8-GPU tile,
+// profiles/r06_tile.md); a host on a fabric whose latency is longer switches it on.  The answers do not depend on it.
+extern "C" int mom6x_comm_overlap_btstep(mom6x_ctx *c, int on) {
+  REQUIRE(c, MOM6X_EINVAL, "mom6x_comm_overlap_btstep: null ctx");
+  c->bt_overlap = (on != 0);
+  return MOM6X_OK;
 }
 
 // pass_var / pass_vector for non-torch hosts and tests: one group pass of n fields.

@@ -90,6 +90,7 @@ struct mom6x_ctx {
   mom6x_hor_visc_params hv; bool hv_init; double *hv_planes;
   double ds_Hmix; const double *ds_h;   // DIRECT_STRESS: HMIX_STRESS (0 = off) and vertvisc's h argument
   double *regrid_res;       // remap.hip: coordinateResolution of the z* coordinate (nk)
+  double *remap_hvel;       // remap.hip: h_u, h_v of both grids for mom6x_ALE_remap_velocities_from_h outside OM4's switch set (allocated on first use)
   double *remap_src;        // remap.hip: the un-remapped velocity of ALE_remap_velocities' KE-conserving correction (allocated on first use)
   double *regrid_vec;       // remap.hip: the host vectors of the density coordinates (resolution | targets | max depths | max thicknesses)
   // lazily allocated 3-D scratch arrays (slot -> nlev levels)
@@ -100,6 +101,7 @@ struct mom6x_ctx {
   long long *red; size_t red_cap;   // diag_sums.hip: integer accumulators of the reproducing sums / checksums
   void *diag;               // diag_sums.hip: Sum_output_CS state (depth list, lH) of write_energy
   void *comm;               // halo.hip: tile layout + RCCL communicator (null: single tile, wrap only)
+  bool bt_overlap;          // btstep's own group pass of eta, ubt, vbt overlapped with the own-points half of the next sub-step (mom6x_comm_overlap_btstep)
   bool halo_error;          // set by a failed halo exchange inside a stream-ordered sequence
   hipEvent_t ev_ready, ev_done; bool pass_pending;   // halo.hip: the group pass in flight on the halo stream (start_/complete_group_pass)
   // the RK2 step's h_av formed by the convergence kernels of a continuity call (continuity.hip k_convergence): kind 1: h_av =
@@ -122,6 +124,8 @@ struct mom6x_ctx {
 void comm_free(mom6x_ctx *c);                                         // halo.hip
 void halo_start(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);   // start_group_pass
 void halo_complete(mom6x_ctx *c);                                     // complete_group_pass
+bool halo_start_packed(mom6x_ctx *c, double *const *fields, const int *staggers, const int *nks, int n);   // ... packed on the compute stream
+bool halo_can_overlap(const mom6x_ctx *c);
 int comm_allreduce_scalar(mom6x_ctx *c, double *value, int op);       // halo.hip: 0 min, 1 max, 2 sum
 
 // ---------------------------------------------------------------------------------------------

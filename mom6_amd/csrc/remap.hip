@@ -165,11 +165,14 @@ __device__ __forceinline__ void ppm_limit(double u_l, double u_c, double u_r, do
 // column arrays are read once and the results written once, all with the same k in every lane (coalesced).
 // IL: the two edge values of a cell next to each other in ONE array (E1[2 n], E1[2 n + 1]; E2 unused) -- what k_remap_merge reads:
 // one 16-byte store and load per lane instead of two 8-byte ones.
+// hst != 0: the column is a VELOCITY column and h holds the thicknesses of the CELLS: the thickness at the velocity point is formed
+// where it is read, 0.5 * (h(cell) + h(cell + hst)) -- ALE_remap_set_h_vel's expression (MOM_ALE.F90:882; k_set_h_vel), so the bits
+// are those of the h_u / h_v arrays it would have written and the remapping would have read back.
 template <bool IL = false>
 __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict__ h, const double *__restrict__ u, View vs,
-                                   double *E1, double *E2, double *C2, double *Ucopy, View vw) {
+                                   double *E1, double *E2, double *C2, double *Ucopy, View vw, int hst = 0) {
   const int N = A.n0;
-#define H(k) AT(h, vs, k)
+#define H(k) (hst ? 0.5 * (AT(h, vs, k) + AT(h + hst, vs, k)) : AT(h, vs, k))
 #define U(k) AT(u, vs, k)
 #define e1(k) E1[(IL ? 2 : 1) * (vw.base + (size_t)((k) - 1) * vw.lev)]
 #define e2(k) (IL ? E1 + 1 : E2)[(IL ? 2 : 1) * (vw.base + (size_t)((k) - 1) * vw.lev)]
@@ -637,14 +640,14 @@ struct Fields { double *p[8]; };
 template <bool IL>
 __global__ void __launch_bounds__(256, RECON_WAVES)
 k_remap_recon(Dm d, const double *__restrict__ mask, ReconArgs A, const double *__restrict__ h_old, const double *__restrict__ f,
-              double *E1, double *E2, double *C2, double *Ucopy, int i0, int i1, int j0, int j1) {
+              double *E1, double *E2, double *C2, double *Ucopy, int i0, int i1, int j0, int j1, int hst) {
   const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
   if (i < i0 || i > i1 || j > j1) return;
   const size_t x = ix2(d, i, j);
   if (mask && !(mask[x] > 0.)) return;
   View v; v.base = x; v.lev = (size_t)d.slab;
-  reconstruct_column<IL>(A, h_old, f, v, E1, E2, C2, Ucopy, v);
+  reconstruct_column<IL>(A, h_old, f, v, E1, E2, C2, Ucopy, v, hst);
 }
 template <int CFG>
 __global__ void __launch_bounds__(256)
@@ -744,7 +747,7 @@ __device__ __forceinline__ double sub_mean_right(const SubW &w, const CellPoly &
 template <int NF>
 __global__ void __launch_bounds__(256)
 k_remap_merge(Dm d, const double *__restrict__ mask, const double *__restrict__ h0p, const double *__restrict__ h1p, MergeFields<NF> F,
-              int i0, int i1, int j0, int j1) {
+              int i0, int i1, int j0, int j1, int hst) {
   __shared__ double win_all[4][MG_W][64];
   const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;
   const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -755,13 +758,15 @@ k_remap_merge(Dm d, const double *__restrict__ mask, const double *__restrict__ 
   double *win = &win_all[threadIdx.y][0][threadIdx.x];
 #define WIN(L) win[((L) & (MG_W - 1)) * 64]
 #define LEV(p, L) (p)[x + (size_t)((L) - 1) * slab]
+  // (hst != 0: velocity columns on the cells' thicknesses, see reconstruct_column)
+#define HLEV(p, L) (hst ? 0.5 * (LEV(p, L) + LEV((p) + hst, L)) : LEV(p, L))
   // the window holds the levels k + MG_LEAD - MG_W + 1 .. k + MG_LEAD of h1 during iteration k
   auto next_target = [&](int &it, double &h1s, double &h1full, bool &tgt, int k) {     // :765-771
     if (it < n) {
       it = it + 1;
       h1s = WIN(it);                   // (the slot exists whatever it holds)
       if ((unsigned)(it - (k + MG_LEAD - MG_W + 1)) >= (unsigned)MG_W) {
-        h1s = LEV(h1p, it);
+        h1s = HLEV(h1p, it);
         asm volatile("" : "+v"(h1s));  // (the wait for this load belongs here, not where the paths meet: there it would also
       }                                //  hold the lanes that read the window until this iteration's prefetches are back)
       h1full = h1s;
@@ -771,13 +776,13 @@ k_remap_merge(Dm d, const double *__restrict__ mask, const double *__restrict__ 
   {
     double t[MG_LEAD];
 #pragma unroll
-    for (int L = 1; L <= MG_LEAD; L++) t[L - 1] = (L <= n) ? LEV(h1p, L) : 0.;
-    h1_pf = (MG_LEAD + 1 <= n) ? LEV(h1p, MG_LEAD + 1) : 0.;
+    for (int L = 1; L <= MG_LEAD; L++) t[L - 1] = (L <= n) ? HLEV(h1p, L) : 0.;
+    h1_pf = (MG_LEAD + 1 <= n) ? HLEV(h1p, MG_LEAD + 1) : 0.;
 #pragma unroll
     for (int L = 1; L <= MG_LEAD; L++) WIN(L) = t[L - 1];
     h1s = t[0];
   }
-  double n_h0 = LEV(h0p, 1), n_aL[NF], n_aR[NF], n_uc[NF];
+  double n_h0 = HLEV(h0p, 1), n_aL[NF], n_aR[NF], n_uc[NF];
 #pragma unroll
   for (int f = 0; f < NF; f++) { const double2 e = LEV(F.E12[f], 1); n_aL[f] = e.x; n_aR[f] = e.y; n_uc[f] = LEV(F.Uc[f], 1); }
   double h1full = h1s;
@@ -815,11 +820,11 @@ k_remap_merge(Dm d, const double *__restrict__ mask, const double *__restrict__ 
     for (int f = 0; f < NF; f++) P[f] = cell_poly(n_aL[f], n_aR[f], n_uc[f]);
     WIN(k + MG_LEAD) = h1_pf;
     if (k + 1 <= n) {
-      n_h0 = LEV(h0p, k + 1);
+      n_h0 = HLEV(h0p, k + 1);
 #pragma unroll
       for (int f = 0; f < NF; f++) { const double2 e = LEV(F.E12[f], k + 1); n_aL[f] = e.x; n_aR[f] = e.y; n_uc[f] = LEV(F.Uc[f], k + 1); }
     }
-    if (k + MG_LEAD + 1 <= n) h1_pf = LEV(h1p, k + MG_LEAD + 1);
+    if (k + MG_LEAD + 1 <= n) h1_pf = HLEV(h1p, k + MG_LEAD + 1);
     // ---- the cell's sub-cells (intersect_src_tgt_grids' loop :700-795): the target cells that end inside it, then its own
     // closing; their widths, the effective width h0_eff :722-747 and the thickest one :726-729
     double h0s = hsrc;
@@ -1513,8 +1518,16 @@ int check_params(const mom6x_remapping_params *p, int n0, ReconArgs &R, ApplyArg
 }
 
 // remap nf (1 or 2) 3-D fields that live on the same pair of grids, in place, on the points (i0..i1, j0..j1) where mask > 0
+// hst != 0: h_old / h_new are the CELLS' thicknesses and the fields live at velocity points hst elements apart from their second cell
+// (the OM4 switch set only: remap_fields_usable_on_cells)
+static bool om4_switch_set(const mom6x_ctx *c, const mom6x_remapping_params *p) {
+  ReconArgs R; ApplyArgs A;
+  if (check_params(p, c->d.nk, R, A, c->d.nk)) return false;
+  static const bool merge_off = [] { const char *e = getenv("MOM6X_REMAP_MERGE"); return e && !strcmp(e, "apply"); }();
+  return (A.method == INTEGRATION_PPM && A.om4 && !A.fb_sub && A.fb_tgt) && !merge_off;
+}
 int remap_fields(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int i0, int i1, int j0, int j1, const double *h_old,
-                 const double *h_new, double *const *f, int nf) {
+                 const double *h_new, double *const *f, int nf, int hst = 0) {
   const Dm d = c->d;
   ReconArgs R; ApplyArgs A;
   int rc = check_params(p, d.nk, R, A, d.nk);
@@ -1523,6 +1536,7 @@ int remap_fields(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int
   static const bool merge_off = [] { const char *e = getenv("MOM6X_REMAP_MERGE"); return e && !strcmp(e, "apply"); }();
   const bool om4_set = (A.method == INTEGRATION_PPM && A.om4 && !A.fb_sub && A.fb_tgt);
   const bool shared = om4_set && !merge_off;
+  REQUIRE(shared || hst == 0, MOM6X_EUNSUPPORTED, "remap_fields: velocity columns on the cells' thicknesses need the OM4 switch set");
   if (!shared && nf > 1) {
     for (int m = 0; m < nf; m++) if ((rc = remap_fields(c, p, mask_id, i0, i1, j0, j1, h_old, h_new, f + m, 1))) return rc;
     return MOM6X_OK;
@@ -1535,17 +1549,17 @@ int remap_fields(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int
   const dim3 g = grid3(nxa(i1 - i0 + 1, i0), j1 - j0 + 1, 1, b);
   const double *mask = c->G + (size_t)mask_id * d.slab;
   for (int m = 0; m < nf; m++) {
-    if (shared) KLAUNCH(c, "k_remap_recon", k_remap_recon<true>, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1);
-    else KLAUNCH(c, "k_remap_recon", k_remap_recon<false>, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1);
+    if (shared) KLAUNCH(c, "k_remap_recon", k_remap_recon<true>, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1, hst);
+    else KLAUNCH(c, "k_remap_recon", k_remap_recon<false>, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1, 0);
   }
   if (shared && nf == 2) {
     MergeFields<2> F;
     for (int m = 0; m < 2; m++) { F.E12[m] = (const double2 *)W[m][0]; F.Uc[m] = W[m][2]; F.out[m] = f[m]; }
-    KLAUNCH(c, "k_remap_merge<2>", k_remap_merge<2>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1);
+    KLAUNCH(c, "k_remap_merge<2>", k_remap_merge<2>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1, hst);
   } else if (shared) {
     MergeFields<1> F;
     F.E12[0] = (const double2 *)W[0][0]; F.Uc[0] = W[0][2]; F.out[0] = f[0];
-    KLAUNCH(c, "k_remap_merge<1>", k_remap_merge<1>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1);
+    KLAUNCH(c, "k_remap_merge<1>", k_remap_merge<1>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1, hst);
   } else if (om4_set)
     KLAUNCH(c, "k_remap_apply", k_remap_apply<1>, g, b, d, mask, A, h_old, h_new, (const double *)W[0][0], (const double *)W[0][1],
             (const double *)W[0][3], (const double *)W[0][2], f[0], i0, i1, j0, j1);
@@ -1630,7 +1644,7 @@ extern "C" int mom6x_ALE_PPM_edge_values(mom6x_ctx *c, const double *h, const do
   R.h_neglect_edge = c->GV.H_subroundoff; R.n0 = d.nk;
   const dim3 b(64, 4, 1);
   KLAUNCH(c, "k_remap_recon", k_remap_recon<false>, grid3(nxa(d.ni + 2, -1), d.nj + 2, 1, b), b, d, (const double *)nullptr, R, h, Q, Q_t, Q_b,
-          C2, (double *)nullptr, -1, d.ni, -1, d.nj);
+          C2, (double *)nullptr, -1, d.ni, -1, d.nj, 0);
   HIPCHK(hipGetLastError());
   return MOM6X_OK;
 }
@@ -1715,6 +1729,28 @@ static int remap_velocities(mom6x_ctx *c, const mom6x_remapping_params *p, const
 extern "C" int mom6x_ALE_remap_velocities(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old_u, const double *h_old_v,
                                           const double *h_new_u, const double *h_new_v, double *u, double *v) {
   return remap_velocities(c, p, h_old_u, h_old_v, h_new_u, h_new_v, u, v, false);
+}
+// ALE_remap_set_h_vel(h_old) + ALE_remap_set_h_vel(h_new) + ALE_remap_velocities as MOM.F90 calls them one after the other
+// (ALE_regridding_and_remapping), from the CELLS' thicknesses: with OM4's switch set the thicknesses at the velocity points are
+// formed where the remapping reads them (the same expression: the same bits) and the four h_u / h_v arrays are never written or
+// read -- 6 words per cell-layer less.  Any other switch set: the arrays are made in work space and the call above follows.
+extern "C" int mom6x_ALE_remap_velocities_from_h(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old, const double *h_new,
+                                                 double *u, double *v) {
+  REQUIRE(c && p && h_old && h_new && u && v, MOM6X_EINVAL, "ALE_remap_velocities: null argument");
+  HIPCHK(hipSetDevice(c->device));
+  const Dm d = c->d;
+  if (om4_switch_set(c, p)) {
+    int rc = remap_fields(c, p, MOM6X_G_mask2dCu, -1, d.ni - 1, 0, d.nj - 1, h_old, h_new, &u, 1, 1);
+    if (rc) return rc;
+    return remap_fields(c, p, MOM6X_G_mask2dCv, 0, d.ni - 1, -1, d.nj - 1, h_old, h_new, &v, 1, d.pitch);
+  }
+  const size_t n3 = (size_t)d.slab * d.nk;
+  if (!c->remap_hvel) { HIPCHK(hipMalloc(&c->remap_hvel, 4 * n3 * sizeof(double))); HIPCHK(hipMemsetAsync(c->remap_hvel, 0, 4 * n3 * sizeof(double), c->stream)); }
+  double *hu0 = c->remap_hvel, *hv0 = hu0 + n3, *hu1 = hv0 + n3, *hv1 = hu1 + n3;
+  int rc = mom6x_ALE_remap_set_h_vel(c, h_old, hu0, hv0);
+  if (rc) return rc;
+  if ((rc = mom6x_ALE_remap_set_h_vel(c, h_new, hu1, hv1))) return rc;
+  return remap_velocities(c, p, hu0, hv0, hu1, hv1, u, v, false);
 }
 // ... with allow_preserve_variance = .true. and REMAP_VEL_CONSERVE_KE (CS%conserve_ke, MOM_ALE.F90:331): MOM.F90's call in the time step
 extern "C" int mom6x_ALE_remap_velocities_conserve_ke(mom6x_ctx *c, const mom6x_remapping_params *p, const double *h_old_u,

@@ -230,6 +230,10 @@ class Dycore:
         """NIHALO rows for the 3-D group passes of the RK2 step in a context whose halo was widened for BTHALO (0: the context's)."""
         check(self.lib, self.lib.mom6x_set_dyn_pass_width(self.ctx, C.c_int(int(width))))
 
+    def comm_overlap_btstep(self, on=True):
+        """btstep's own group pass overlapped with the own-points half of the next sub-step (mom6x_comm_overlap_btstep; off by default)."""
+        check(self.lib, self.lib.mom6x_comm_overlap_btstep(self.ctx, C.c_int(1 if on else 0)))
+
     def comm_exchange_count(self, reset=False):
         """Packed group exchanges since the last reset (mom6x_comm_exchange_count)."""
         f = self.lib.mom6x_comm_exchange_count
@@ -308,6 +312,10 @@ class Dycore:
         """ALE_remap_velocities (MOM_ALE.F90:1089); conserve_ke: REMAP_VEL_CONSERVE_KE with allow_preserve_variance (:1166-1195)."""
         f = self.lib.mom6x_ALE_remap_velocities_conserve_ke if conserve_ke else self.lib.mom6x_ALE_remap_velocities
         check(self.lib, f(self.ctx, C.byref(CS), _ptr(h_old_u), _ptr(h_old_v), _ptr(h_new_u), _ptr(h_new_v), _ptr(u), _ptr(v)))
+
+    def ALE_remap_velocities_from_h(self, CS, h_old, h_new, u, v):
+        """ALE_remap_set_h_vel (old grid), ALE_remap_set_h_vel (new grid) and ALE_remap_velocities (MOM_ALE.F90:882, :1089) in one call."""
+        check(self.lib, self.lib.mom6x_ALE_remap_velocities_from_h(self.ctx, C.byref(CS), _ptr(h_old), _ptr(h_new), _ptr(u), _ptr(v)))
 
     def ALE_regrid_zstar(self, CS, coordinateResolution, h, h_new, dzRegrid):
         """ALE_regrid (MOM_ALE.F90:518) for the z* coordinate; coordinateResolution: nk host values [Z]."""

@@ -23,6 +23,17 @@ def channel(nk=3, ni=32, nj=24, halo=4, layout=(1, 1), pe=(0, 0), beta=2e-11):
     return gg, d, M
 
 
+def torus(nk=3, ni=96, nj=40, halo=4, layout=(1, 1), pe=(0, 0)):
+    """Doubly re-entrant f-plane with a seamount (no land): the tile's eight neighbours are the tile itself -- every message of a
+    group pass exists, and a launch split around a travelling pass has both halves (its own-points half needs 96 x 32 points)."""
+    def depth(ig, jg):
+        return 1000.0 - 300.0 * np.exp(-(((ig - 0.4 * ni) / (0.15 * ni)) ** 2 + ((jg - 0.55 * nj) / (0.2 * nj)) ** 2))
+    gg = grid.GlobalGrid(ni, nj, kind="cartesian", dx=2.0e4, dy=2.0e4, f0=1.0e-4, beta=0.0, reentrant_x=True, reentrant_y=True,
+                         depth_fn=depth)
+    d, M = gg.tile(nk, halo, layout, pe)
+    return gg, d, M
+
+
 def benchmark_small(nk=8, ni=40, nj=24, halo=4, layout=(1, 1), pe=(0, 0)):
     """config 3 in miniature: benchmark-like bowl, nk layers."""
     gg = grid.GlobalGrid(ni, nj, kind="spherical", lon0=0.0, lat0=-40.0, dlon=1.0, dlat=1.0,

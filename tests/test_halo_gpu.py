@@ -53,3 +53,36 @@ def test_rk2_step_with_comm_attached(orc):
         T.run(orc, H.channel(), nsteps=2, bt_mod=dict(strong_drag=1))
     finally:
         D.Dycore.initialize_dyn_split_RK2 = orig
+
+
+@pytest.mark.parametrize("halo", [4, 8])
+def test_rk2_steps_on_a_torus_with_every_pass_through_rccl(orc, halo):
+    """A doubly re-entrant tile whose eight neighbours are the tile itself, every group pass through ncclSend / ncclRecv on the second
+    stream: the 3-D passes of the RK2 step around the split mass-flux launches, and -- the barotropic solver's own pass of eta, ubt,
+    vbt (MOM_barotropic.F90:2505-2512) -- packed on the compute stream and travelling while the own-points half of the next sub-step
+    runs (k_bt_substep / k_bt_pred sel 1, then sel 2).  Three steps equal the oracle's bit for bit; and the split did happen (the
+    sub-step kernels ran more often than there are sub-steps)."""
+    from tests import test_rk2_gpu as T
+    import mom6_amd.dycore as D
+    from mom6_amd.dycore import prof_enable, prof_report
+    orig = D.Dycore.initialize_dyn_split_RK2
+    seen = {}
+
+    def patched(self, params=None):
+        orig(self, params)
+        parallel.attach_comm(self, (1, 1), (0, 0), None, force_nccl_self=True)
+        self.comm_overlap_btstep(True)
+
+    def watch(dyc, when):
+        if when == "before":
+            prof_enable(dyc, True)
+        else:
+            dyc.sync(); seen.update(prof_report(dyc)); prof_enable(dyc, False)
+    D.Dycore.initialize_dyn_split_RK2 = patched
+    try:
+        T.run(orc, H.torus(halo=halo), nsteps=3, bt_mod=dict(strong_drag=1), hook=watch)
+    finally:
+        D.Dycore.initialize_dyn_split_RK2 = orig
+    sub = seen.get("k_bt_substep<u>", (0, 0))[0] + seen.get("k_bt_substep<v>", (0, 0))[0]
+    pred = seen.get("k_bt_pred", (0, 0))[0]
+    assert sub > 0 and pred >= 2 * 6, sorted(seen)       # (every travelling pass of the loop makes two k_bt_pred launches)

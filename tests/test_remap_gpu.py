@@ -120,6 +120,13 @@ def test_ALE_remap_tracers_and_velocities(orc, cfg, scheme, mods):
         assert np.abs((a * hn).sum(0) - (b * ho).sum(0)).max() <= 1e-12 * np.abs(b * ho).sum(0).max()
     H.assert_bitwise(g[0].cpu().numpy(), hu_o, "h_u", H.interior(d, "u")); H.assert_bitwise(g[3].cpu().numpy(), hv_n, "h_v", H.interior(d, "v"))
     H.assert_bitwise(ud.cpu().numpy(), uo, "u", H.interior(d, "u")); H.assert_bitwise(vd.cpu().numpy(), vo, "v", H.interior(d, "v"))
+    # the three calls as one, from the cells' thicknesses (OM4's switch set: h_u / h_v formed where they are read, never stored;
+    # the other switch sets: made in work space): the same bits
+    u2, v2 = dyc.to_dev(u), dyc.to_dev(v)
+    torch.cuda.synchronize()
+    dyc.ALE_remap_velocities_from_h(CS, hod, hnd, u2, v2)
+    dyc.sync()
+    H.assert_bitwise(u2.cpu().numpy(), uo, "u (from h)", H.interior(d, "u")); H.assert_bitwise(v2.cpu().numpy(), vo, "v (from h)", H.interior(d, "v"))
     dyc.close()
 
 
