@@ -168,11 +168,11 @@ __device__ __forceinline__ void ppm_limit(double u_l, double u_c, double u_r, do
 // hst != 0: the column is a VELOCITY column and h holds the thicknesses of the CELLS: the thickness at the velocity point is formed
 // where it is read, 0.5 * (h(cell) + h(cell + hst)) -- ALE_remap_set_h_vel's expression (MOM_ALE.F90:882; k_set_h_vel), so the bits
 // are those of the h_u / h_v arrays it would have written and the remapping would have read back.
-template <bool IL = false>
+template <bool IL = false, bool PAIR = false>
 __device__ void reconstruct_column(const ReconArgs &A, const double *__restrict__ h, const double *__restrict__ u, View vs,
                                    double *E1, double *E2, double *C2, double *Ucopy, View vw, int hst = 0) {
   const int N = A.n0;
-#define H(k) (hst ? 0.5 * (AT(h, vs, k) + AT(h + hst, vs, k)) : AT(h, vs, k))
+#define H(k) (PAIR ? 0.5 * (AT(h, vs, k) + AT(h + hst, vs, k)) : AT(h, vs, k))
 #define U(k) AT(u, vs, k)
 #define e1(k) E1[(IL ? 2 : 1) * (vw.base + (size_t)((k) - 1) * vw.lev)]
 #define e2(k) (IL ? E1 + 1 : E2)[(IL ? 2 : 1) * (vw.base + (size_t)((k) - 1) * vw.lev)]
@@ -637,8 +637,8 @@ __device__ void apply_column(const ApplyArgs &A0, const double *__restrict__ h0,
 struct Fields { double *p[8]; };
 
 // the 3-D form: columns (i0..i1, j0..j1) with mask > 0; h_old / h_new / fields on the same staggering
-template <bool IL>
-__global__ void __launch_bounds__(256, RECON_WAVES)
+template <bool IL, bool PAIR = false>
+__global__ void __launch_bounds__(256, PAIR ? 2 : RECON_WAVES)
 k_remap_recon(Dm d, const double *__restrict__ mask, ReconArgs A, const double *__restrict__ h_old, const double *__restrict__ f,
               double *E1, double *E2, double *C2, double *Ucopy, int i0, int i1, int j0, int j1, int hst) {
   const int i = I_BASE(i0) + blockIdx.x * blockDim.x + threadIdx.x;
@@ -647,7 +647,7 @@ k_remap_recon(Dm d, const double *__restrict__ mask, ReconArgs A, const double *
   const size_t x = ix2(d, i, j);
   if (mask && !(mask[x] > 0.)) return;
   View v; v.base = x; v.lev = (size_t)d.slab;
-  reconstruct_column<IL>(A, h_old, f, v, E1, E2, C2, Ucopy, v, hst);
+  reconstruct_column<IL, PAIR>(A, h_old, f, v, E1, E2, C2, Ucopy, v, hst);
 }
 template <int CFG>
 __global__ void __launch_bounds__(256)
@@ -744,7 +744,7 @@ __device__ __forceinline__ double sub_mean_right(const SubW &w, const CellPoly &
   return (w.mode == 4) ? c.uc : c.aR;
 }
 
-template <int NF>
+template <int NF, bool PAIR = false>
 __global__ void __launch_bounds__(256)
 k_remap_merge(Dm d, const double *__restrict__ mask, const double *__restrict__ h0p, const double *__restrict__ h1p, MergeFields<NF> F,
               int i0, int i1, int j0, int j1, int hst) {
@@ -759,7 +759,7 @@ k_remap_merge(Dm d, const double *__restrict__ mask, const double *__restrict__ 
 #define WIN(L) win[((L) & (MG_W - 1)) * 64]
 #define LEV(p, L) (p)[x + (size_t)((L) - 1) * slab]
   // (hst != 0: velocity columns on the cells' thicknesses, see reconstruct_column)
-#define HLEV(p, L) (hst ? 0.5 * (LEV(p, L) + LEV((p) + hst, L)) : LEV(p, L))
+#define HLEV(p, L) (PAIR ? 0.5 * (LEV(p, L) + LEV((p) + hst, L)) : LEV(p, L))
   // the window holds the levels k + MG_LEAD - MG_W + 1 .. k + MG_LEAD of h1 during iteration k
   auto next_target = [&](int &it, double &h1s, double &h1full, bool &tgt, int k) {     // :765-771
     if (it < n) {
@@ -1549,17 +1549,20 @@ int remap_fields(mom6x_ctx *c, const mom6x_remapping_params *p, int mask_id, int
   const dim3 g = grid3(nxa(i1 - i0 + 1, i0), j1 - j0 + 1, 1, b);
   const double *mask = c->G + (size_t)mask_id * d.slab;
   for (int m = 0; m < nf; m++) {
-    if (shared) KLAUNCH(c, "k_remap_recon", k_remap_recon<true>, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1, hst);
+    if (shared && hst) KLAUNCH(c, "k_remap_recon", (k_remap_recon<true, true>), g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1, hst);
+    else if (shared) KLAUNCH(c, "k_remap_recon", k_remap_recon<true>, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1, 0);
     else KLAUNCH(c, "k_remap_recon", k_remap_recon<false>, g, b, d, mask, R, h_old, (const double *)f[m], W[m][0], W[m][1], W[m][3], W[m][2], i0, i1, j0, j1, 0);
   }
   if (shared && nf == 2) {
     MergeFields<2> F;
     for (int m = 0; m < 2; m++) { F.E12[m] = (const double2 *)W[m][0]; F.Uc[m] = W[m][2]; F.out[m] = f[m]; }
-    KLAUNCH(c, "k_remap_merge<2>", k_remap_merge<2>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1, hst);
+    REQUIRE(hst == 0, MOM6X_EINVAL, "remap_fields: velocity columns go one field at a time");
+    KLAUNCH(c, "k_remap_merge<2>", k_remap_merge<2>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1, 0);
   } else if (shared) {
     MergeFields<1> F;
     F.E12[0] = (const double2 *)W[0][0]; F.Uc[0] = W[0][2]; F.out[0] = f[0];
-    KLAUNCH(c, "k_remap_merge<1>", k_remap_merge<1>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1, hst);
+    if (hst) KLAUNCH(c, "k_remap_merge<1>", (k_remap_merge<1, true>), g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1, hst);
+    else KLAUNCH(c, "k_remap_merge<1>", k_remap_merge<1>, g, b, d, mask, h_old, h_new, F, i0, i1, j0, j1, 0);
   } else if (om4_set)
     KLAUNCH(c, "k_remap_apply", k_remap_apply<1>, g, b, d, mask, A, h_old, h_new, (const double *)W[0][0], (const double *)W[0][1],
             (const double *)W[0][3], (const double *)W[0][2], f[0], i0, i1, j0, j1);
