@@ -13,7 +13,7 @@ module mom6x_c_api
   public :: mom6x_PressureForce_set_tv, mom6x_vertvisc_params, mom6x_vertvisc_init, mom6x_vertvisc_set_visc, mom6x_vertvisc_coef
   public :: mom6x_hor_visc_params, mom6x_hor_visc_init, mom6x_horizontal_viscosity, mom6x_vertvisc_set_direct_stress
   public :: mom6x_remapping_params, mom6x_ALE_remap_tracers, mom6x_ALE_remap_set_h_vel, mom6x_ALE_remap_velocities
-  public :: mom6x_ALE_remap_velocities_conserve_ke
+  public :: mom6x_ALE_remap_velocities_conserve_ke, mom6x_ALE_remap_velocities_from_h, mom6x_comm_overlap_btstep
   public :: mom6x_remapping_core_h, mom6x_regrid_zstar_params, mom6x_ALE_regrid_zstar
   public :: mom6x_regrid_rho_params, mom6x_ALE_regrid_rho, mom6x_ALE_regrid_hycom1, mom6x_ALE_convective_adjustment
   public :: mom6x_chksum_result, mom6x_sum_output_params, mom6x_energy_sums, mom6x_reproducing_sum_3d, mom6x_reproducing_sum_2d
@@ -344,6 +344,11 @@ module mom6x_c_api
       import :: c_ptr, c_int, mom6x_remapping_params
       type(c_ptr), value :: ctx, h_old_u, h_old_v, h_new_u, h_new_v, u, v ; type(mom6x_remapping_params), intent(in) :: p
     end function
+    !> ALE_remap_set_h_vel (old grid), ALE_remap_set_h_vel (new grid), ALE_remap_velocities as one call, from the cells' thicknesses
+    integer(c_int) function mom6x_ALE_remap_velocities_from_h(ctx, p, h_old, h_new, u, v) bind(C, name="mom6x_ALE_remap_velocities_from_h")
+      import :: c_ptr, c_int, mom6x_remapping_params
+      type(c_ptr), value :: ctx, h_old, h_new, u, v ; type(mom6x_remapping_params), intent(in) :: p
+    end function
     !> ALE_regrid (MOM_ALE.F90:518) for REGRIDDING_ZSTAR; coordinateResolution: nk host values
     integer(c_int) function mom6x_ALE_regrid_zstar(ctx, p, coordinateResolution, h, h_new, dzRegrid) bind(C, name="mom6x_ALE_regrid_zstar")
       import :: c_ptr, c_int, c_double, mom6x_regrid_zstar_params
@@ -503,6 +508,10 @@ module mom6x_c_api
     integer(c_int) function mom6x_comm_init(ctx, npx, npy, px, py, id128, force_nccl_self) bind(C, name="mom6x_comm_init")
       import :: c_int, c_ptr, c_char ; type(c_ptr), value :: ctx ; integer(c_int), value :: npx, npy, px, py
       character(kind=c_char), intent(in) :: id128(128) ; integer(c_int), value :: force_nccl_self
+    end function
+    !> btstep's own group pass (MOM_barotropic.F90:2505-2512) overlapped with the own-points half of the next sub-step (off by default)
+    integer(c_int) function mom6x_comm_overlap_btstep(ctx, on) bind(C, name="mom6x_comm_overlap_btstep")
+      import :: c_int, c_ptr ; type(c_ptr), value :: ctx ; integer(c_int), value :: on
     end function
     integer(c_int) function mom6x_pass_fields(ctx, fields, staggers, nks, n) bind(C, name="mom6x_pass_fields")
       import :: c_int, c_ptr ; type(c_ptr), value :: ctx ; type(c_ptr), intent(in) :: fields(*)

@@ -139,7 +139,7 @@ def shim_case_params(dt, tag_tree):   # tag_tree: helpers.golden_tag()
 
 
 def oracle_shim_case(orc, cfg, nsteps=SHIM_NSTEPS, no_bt_cont=False):
-    """The oracle's run of the case above: (final state, OrcModel, inputs, visc inputs).  no_bt_cont: the tc1-like variant
+    """The oracle's run of the case above: (final state, OrcModel, inputs, visc inputs).  no_bt_cont: the variant
     USE_BT_CONT_TYPE = False, NONLINEAR_BT_CONTINUITY = True."""
     from tests.test_dyn_gpu import visc_inputs
     gg, d, M = cfg

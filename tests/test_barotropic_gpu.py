@@ -175,7 +175,7 @@ def test_btstep_without_BT_cont(orc, cfg, project, nonlinear):
     """USE_BT_CONT_TYPE = False (BT_cont not associated; NONLINEAR_BT_CONTINUITY = False): the barotropic continuity equation linear in
     the velocities with the face areas of find_face_areas (MOM_barotropic.F90:5146-5237, :1131-1136, :1221, :2639, :3053), the default
     BT_THICK_SCHEME without a BT_cont_type (HYBRID: btcalc without h_u / h_v) -- bit for bit with BT_STRONG_DRAG, 1e-12 on the default
-    drag path.  NONLINEAR_BT_CONTINUITY (what .testing/tc1 sets): the face areas from bathymetry + eta (:5171-5186), recomputed every
+    drag path.  NONLINEAR_BT_CONTINUITY: the face areas from bathymetry + eta (:5171-5186), recomputed every
     NONLIN_BT_CONT_UPDATE_PERIOD sub-steps with a stencil of 2 (:767-768, :2539-2543)."""
     nl = {} if nonlinear == 0 else dict(nonlinear_continuity=1, nonlin_cont_update_period=max(nonlinear, 0))
     I = make_inputs(orc, dict(double_gyre=H.double_gyre, channel=H.channel, benchmark_small=H.benchmark_small)[cfg](), project)

@@ -154,8 +154,7 @@ def test_shim_modules_new_run_restart_and_tracers_from_fortran(orc, tmp_path, mo
 
 
 def test_shim_modules_without_a_BT_cont_type_from_fortran(orc, tmp_path, sums):
-    """The same driver with USE_BT_CONT_TYPE = False and NONLINEAR_BT_CONTINUITY = True in its MOM_input table (.testing/tc1's
-    barotropic settings): MOM_barotropic's barotropic_init reads them, initialize_dyn_split_RK2 passes no_BT_cont on, and four
+    """The same driver with USE_BT_CONT_TYPE = False and NONLINEAR_BT_CONTINUITY = True in its MOM_input table : MOM_barotropic's barotropic_init reads them, initialize_dyn_split_RK2 passes no_BT_cont on, and four
     steps uninterrupted as well as two + restart + two equal the oracle's run of that configuration bit for bit."""
     if not os.path.exists(SHIM_DRIVER):
         pytest.fail("tests/fortran_stubs/drive_shims is missing: __graft_entry__.build() compiles it with amdflang")

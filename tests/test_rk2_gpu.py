@@ -166,7 +166,7 @@ def test_rk2_channel_bitexact_tc1_like(orc):
 @pytest.mark.parametrize("cfg", ["double_gyre", "channel", "benchmark_small"])
 @pytest.mark.parametrize("nonlinear,period,thick", [(0, 1, 1), (1, 1, 1), (1, 0, 2), (1, 3, 3)])
 def test_rk2_without_a_BT_cont_type(orc, cfg, nonlinear, period, thick):
-    """USE_BT_CONT_TYPE = False (mom6x_rk2_params.no_BT_cont; .testing/tc1 sets NONLINEAR_BT_CONTINUITY, which implies it): CS%BT_cont
+    """USE_BT_CONT_TYPE = False (mom6x_rk2_params.no_BT_cont; NONLINEAR_BT_CONTINUITY only acts without one; .testing/tc1 sets it but keeps USE_BT_CONT_TYPE, where the reference ignores it): CS%BT_cont
     is not associated, so btcalc works from h before the barotropic mass source (RK2.F90:627, BT_THICK_SCHEME = HYBRID / HARMONIC /
     ARITHMETIC; the last case also with BOUND_BT_CORRECTION through eta_cor_bound), the
     first continuity call only makes the layer fluxes btstep adds (:644-648, BT_USE_LAYER_FLUXES), set_dtbt takes eta (:667,
