@@ -584,7 +584,7 @@ def valu_counters(kernel, N3_tile, avg_ms):
                     "achieved_Tlane_instr_per_s": round(rate, 2), "peak_Tlane_instr_per_s": round(FP64_VALU_PEAK_TLANE_S, 2),
                     "frac_of_fp64_vector_issue_peak": round(rate / FP64_VALU_PEAK_TLANE_S, 3),
                     "averaged_over": "the step's three launches (the instantiations compiled for their switches, SPEC 1-3)",
-                    "occupancy": "2 wavefronts per SIMD (220-250 VGPRs)", "source": os.path.relpath(path, ROOT) + " @ " + git_hash_of(path)}
+                    "occupancy": "2 wavefronts per SIMD (190-240 VGPRs)", "source": os.path.relpath(path, ROOT) + " @ " + git_hash_of(path)}
     return None
 
 
