@@ -429,6 +429,9 @@ __device__ __forceinline__ void glds16(const double *src, double *lds_wave_base)
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// The next row's LDS-DMA (issued before face_column is called) is waited for in front of the row's LAST group of stores: see the row
+// top of k_mass_flux_wave.
+#define ROW_DMA_WAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // Everything of one face column after the reconstruction: first sweep, flux_adjust towards uhbt, stores, flux
 // thickness, set_*_BT_cont.  All lanes of the wavefront call it (row reductions inside).
 template <int DIR, int MAXL, bool STATS, int SPEC, bool FMA>
@@ -598,8 +601,9 @@ __device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A
     // whole visc_rem column is zero (duhdu_tot = 0: Newton steps of +-inf bisected back to zero); x + 0.0 is the identity but for
     // that one value.  (The file is compiled with signed zeros honoured; tests/helpers.py makes no allowance any more.)
     du_fin = du_fin + 0.0;
+    if (!W.set_bt) ROW_DMA_WAIT;
     if (active && kl == 0 && A.du_cor) st2(A.du_cor, du_fin);
-  }
+  } else if (!W.set_bt) ROW_DMA_WAIT;
   // ONE store per transport (HBM write traffic 3.0 -> 1.9 GB); `pairs` (uniform): every pair of faces of the wavefront is
   // active or inactive as a whole (all but the wavefronts on the rim of the face range)
   if (pairs) store_pairs<MAXL>(A.uh, rowb, lanep, slab, C.uh, active, kl, fw, nk);
@@ -769,6 +773,7 @@ __device__ __forceinline__ void face_column(Col<MAXL, FMA> &C, const FluxArgs &A
   if (kl == 3) { val = v_p0; plane = A.FA_p0; }
   if (kl == 4) { val = FAmt_R; plane = A.FA_pp; }
   if (kl == 5) { val = v_upp; plane = A.uBT_pp; }
+  ROW_DMA_WAIT;
   if (active && kl < 6) *(double *)((char *)plane + rowb + lane2) = val;
 }
 
@@ -882,14 +887,22 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
 
   const int jstart = DIR ? j0 - 1 : j0;   // meridional: a first step that only reconstructs cell j0
   if (wave_on) issue_dma(jstart, true);
+  bool dma_pending = true;   // uniform: the row's DMA has not been waited for yet
   for (int jj = jstart; jj <= j1; jj++) {
     // The four wavefronts of a work-group share nothing but cache lines: a 128-byte line of h, u, visc_rem or of an output
     // holds the 32 bytes of each of them.  Left alone they drift rows apart (their Newton counts differ), every wavefront
     // then fetches the line for itself and the partial lines they store reach memory one by one.  Meeting once per row
     // keeps the four requests within the L2's reach: plain / adjust modes 2.0 -> 1.5 / 2.6 -> 2.25 ms (x).
-    __syncthreads();
+    // The next row's DMA is waited for inside face_column, in front of the row's LAST group of stores (ROW_DMA_WAIT: the requests are a
+    // Newton solve old by then, the wait is free), so the stores stay in flight across the row top instead of being waited for here
+    // with the DMA (-5 % zonal / -3 % meridional in the launches without BT_cont's tail behind the stores, profiles/r06_mfw.md); only a
+    // row whose predecessor made no face column (the first of a march) waits here.  A raw s_barrier: __syncthreads() puts its own
+    // vmcnt(0) in front of the barrier while an LDS-DMA is in flight, and the compiler does not connect an LDS-DMA with the ds_read
+    // of its destination -- the waits are this code's business.
+    __builtin_amdgcn_s_barrier();
     if (!wave_on) continue;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row jj has landed
+    if (dma_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row jj has landed
+    dma_pending = true;
     TICK(10);
     const bool face_row = (!DIR) || (jj >= j0);
     // ---- LDS -> registers, layer by layer, with the PPM reconstruction + limiter on the way ---------------------------
@@ -947,6 +960,7 @@ k_mass_flux_wave(Dm d, const double *__restrict__ G, FluxArgs A, LdsArgs E) {
     const size_t rowb = (size_t)(jj + d.joff) * (size_t)d.pitch * 8;
     face_column<DIR, MAXL, STATS, SPEC>(C, A, E, rowb, lane2, lane3, slab, active, kl, nk, IareaMin, uhbt_f, dC_f, dx_W, dx_E, G, d.pitch, st_evals,
                            st_solves, st_redos, pairs, lanep, fw TICK_ARG);
+    dma_pending = false;
     TICK(13);
   }
   TICK_FLUSH;
