@@ -25,7 +25,7 @@ use, intrinsic :: iso_c_binding
 use mom6x_c_api
 use mom6x_host
 use mom6x_shim_ctx
-use MOM_ALE,               only : ALE_CS
+use MOM_ALE,               only : ALE_CS, ALE_vel_remap_params
 use MOM_barotropic,        only : barotropic_init, barotropic_CS, register_barotropic_restarts, barotropic_end
 use MOM_barotropic,        only : barotropic_refresh_restart_mirrors, barotropic_uses_BT_cont_type
 use MOM_continuity_PPM,    only : continuity_init=>continuity_PPM_init, continuity_stencil=>continuity_PPM_stencil
@@ -40,6 +40,7 @@ use MOM_forcing_type,      only : mech_forcing
 use MOM_get_input,         only : directories
 use MOM_grid,              only : ocean_grid_type
 use MOM_harmonic_analysis, only : harmonic_analysis_CS
+use MOM_hor_visc,          only : hor_visc_CS, hor_visc_init, hor_visc_end, hor_visc_vel_stencil
 use MOM_hor_index,         only : hor_index_type
 use MOM_io,                only : vardesc, var_desc
 use MOM_MEKE_types,        only : MEKE_type
@@ -81,7 +82,6 @@ type, public :: MOM_dyn_split_RK2_CS ; private
   real, allocatable, dimension(:,:,:) :: PFu, PFv, CAu, CAv, u_accel_bt, v_accel_bt, pbce
   logical :: store_CAu = .true., remap_aux = .false., module_is_initialized = .false.
   logical :: diag_mirrors = .true.           !< MOM6X_ACCEL_DIAG_MIRRORS: keep the arrays behind Accel_diag / MIS current
-  type(mom6x_remapping_params) :: vel_remap  !< ALE_CSp%vel_remapCS as the device takes it (remap_dyn_split_RK2_aux_vars)
   type(mom6x_eos_params) :: eos              !< tv%eqn_of_state + the EOS switches of the pressure force
   logical :: have_eos = .false.
   type(accel_diag_ptrs), pointer :: ADp => NULL()
@@ -91,6 +91,7 @@ type, public :: MOM_dyn_split_RK2_CS ; private
   type(continuity_CS)    :: continuity_CSp
   type(CoriolisAdv_CS)   :: CoriolisAdv
   type(PressureForce_CS) :: PressureForce_CSp
+  type(hor_visc_CS)      :: hor_visc
   type(vertvisc_CS), pointer :: vertvisc_CSp => NULL()
   type(barotropic_CS)    :: barotropic_CSp
 end type MOM_dyn_split_RK2_CS
@@ -290,7 +291,8 @@ subroutine remap_dyn_split_RK2_aux_vars(G, GV, CS, h_old_u, h_old_v, h_new_u, h_
   integer :: nk
   if (.not.CS%remap_aux) return
   nk = GV%ke
-  rc = mom6x_remap_dyn_split_RK2_aux_vars(CS%ctx, CS%vel_remap, shim_up3(1, h_old_u, STG_U, nk), shim_up3(2, h_old_v, STG_V, nk), &
+  ! (ALE_CSp%vel_remapCS, as the reference's ALE_remap_velocities(ALE_CSp, ...) calls use it :1318-1328)
+  rc = mom6x_remap_dyn_split_RK2_aux_vars(CS%ctx, ALE_vel_remap_params(ALE_CSp), shim_up3(1, h_old_u, STG_U, nk), shim_up3(2, h_old_v, STG_V, nk), &
                                           shim_up3(3, h_new_u, STG_U, nk), shim_up3(4, h_new_v, STG_V, nk))
   call shim_check(rc, "remap_dyn_split_RK2_aux_vars")
   if (.not.CS%resident) call refresh_host_mirrors(CS, G, GV)
@@ -343,7 +345,6 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   integer,                          intent(out)   :: cont_stencil
   character(len=40) :: mdl = "MOM_dynamics_split_RK2"
   type(mom6x_rk2_params) :: rk2
-  type(mom6x_hor_visc_params) :: hv
   real, allocatable :: zero_u(:,:,:), zero_v(:,:,:)
   integer(c_int) :: rc
   integer :: nk
@@ -372,7 +373,6 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
                  default=.true.)
   call get_rk2_flags(param_file, rk2)     ! SPLIT_BOTTOM_STRESS, BT_USE_LAYER_FLUXES, STORE_CORIOLIS_ACCEL, VISC_REM_BUG, REMAP_AUXILIARY_VARS
   CS%remap_aux = (rk2%remap_aux /= 0)
-  if (CS%remap_aux) call read_vel_remap_params(param_file, GV, CS%vel_remap)
   call PressureForce_read_eos(param_file, GV, US, CS%eos, CS%have_eos)
 
   ! ---- the sub-modules, in the reference's order and with its argument lists (:1552-1600).  The first of them creates
@@ -382,8 +382,7 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   call CoriolisAdv_init(Time, G, GV, US, param_file, diag, Accel_diag, CS%CoriolisAdv)
   call PressureForce_init(Time, G, GV, US, param_file, diag, CS%PressureForce_CSp, CS%ADp)
   CS%ctx = shim_ctx(G, GV) ; CS%dims = shim_dims()
-  call read_hor_visc_params(param_file, G, US, dt, hv)      ! hor_visc_init, MOM_hor_visc.F90:2322-3000
-  rc = mom6x_hor_visc_init(CS%ctx, hv) ; call shim_check(rc, "hor_visc_init")
+  call hor_visc_init(Time, G, GV, US, param_file, diag, CS%hor_visc, ADp=Accel_diag)      ! :1564
   call vertvisc_init(MIS, Time, G, GV, US, param_file, diag, Accel_diag, dirs, ntrunc, CS%vertvisc_CSp)
   call barotropic_init(u, v, h, Time, G, GV, US, param_file, diag, CS%barotropic_CSp, restart_CS, calc_dtbt, CS%BT_cont, &
                        CS%OBC)
@@ -449,6 +448,7 @@ subroutine end_dyn_split_RK2(CS)
   if (.not.associated(CS)) return
   call barotropic_end(CS%barotropic_CSp)
   if (associated(CS%vertvisc_CSp)) then ; call vertvisc_end(CS%vertvisc_CSp) ; deallocate(CS%vertvisc_CSp) ; endif
+  call hor_visc_end(CS%hor_visc)
   call CoriolisAdv_end(CS%CoriolisAdv)
   call dyn_state_end(CS%S)
   call shim_ctx_end()
@@ -466,8 +466,8 @@ subroutine upload_tv(CS, tv, GV)
   call shim_check(rc, "step_MOM_dyn_split_RK2 (tv)")
 end subroutine upload_tv
 
-! get_rk2_flags, read_hor_visc_params and read_vel_remap_params: one get_param per member of the bind(C) parameter structs
-! this module itself owns (the other structs are read by the sub-modules' own *_init), fortran/shims/mom6x_param_readers.inc
+! get_rk2_flags: one get_param per member of the bind(C) parameter struct this module itself owns (the other structs are read by
+! the sub-modules' own *_init: hor_visc_init, ALE_init, ...), fortran/shims/mom6x_param_readers.inc
 #include "mom6x_param_readers.inc"
 
 end module MOM_dynamics_split_RK2

@@ -289,6 +289,7 @@ subroutine shim_down3(a, p, stagger, nlev)
   integer(c_int) :: rc ; integer :: n
   n = res_find(a)
   if (n > 0) then
+    if (c_associated(p, res_dev(n))) return      ! (an in-out argument: the device has worked on the resident copy itself)
     rc = mom6x_dev_copy(the_ctx, res_dev(n), p, int(the_dims%slab, c_size_t) * int(max(nlev, 1), c_size_t)) ; call shim_check(rc, "mom6x_dev_copy")
     return
   endif

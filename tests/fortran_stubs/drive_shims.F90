@@ -20,7 +20,9 @@ program drive_shims
   use MOM_diag_mediator, only : diag_ctrl
   use MOM_domains, only : MOM_domain_type
   use MOM_dynamics_split_RK2
-  use MOM_ALE, only : ALE_CS
+  use MOM_ALE, only : ALE_CS, ALE_init, ALE_end, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities, &
+                      ALE_update_regrid_weights, ALE_remap_init_conds
+  use MOM_hor_visc, only : hor_visc_CS, hor_visc_init, hor_visc_end, horizontal_viscosity, hor_visc_vel_stencil
   use MOM_file_parser, only : param_file_type, stub_set_param
   use MOM_forcing_type, only : mech_forcing
   use MOM_get_input, only : directories
@@ -77,6 +79,10 @@ program drive_shims
   real, allocatable :: xu(:,:,:), xv(:,:,:), xh(:,:,:), xuh(:,:,:), xvh(:,:,:), xuhtr(:,:,:), xvhtr(:,:,:), xeta(:,:)
   real, allocatable :: dCAu(:,:,:), dCAv(:,:,:), dPFu(:,:,:), dPFv(:,:,:), ddiffu(:,:,:), ddiffv(:,:,:), dubt(:,:,:), dvbt(:,:,:)
   real, allocatable :: dpbce(:,:,:), duav(:,:,:), dvav(:,:,:)
+  real, allocatable, target :: T0(:,:,:)
+  real, allocatable :: xdiffu(:,:,:), xdiffv(:,:,:), xhn(:,:,:), xdz(:,:,:), xT(:,:,:), xur(:,:,:), xvr(:,:,:)
+  real :: max_depth
+  integer :: magic2
   integer, target :: ntrunc
   integer :: cont_stencil
   logical :: calc_dtbt, resident
@@ -125,6 +131,12 @@ program drive_shims
            dubt(ni+1,nj,nk), dvbt(ni,nj+1,nk), dpbce(ni,nj,nk), duav(ni+1,nj,nk), dvav(ni,nj+1,nk))
   read(un) dCAu ; read(un) dCAv ; read(un) dPFu ; read(un) dPFv ; read(un) ddiffu ; read(un) ddiffv ; read(un) dubt ; read(un) dvbt
   read(un) dpbce ; read(un) duav ; read(un) dvav
+  ! ---- the standalone calls of MOM_hor_visc and MOM_ALE: a tracer, and the oracle's results for the INITIAL state -------------
+  read(un) magic2 ; if (magic2 /= 1297042744) error stop "the case file has no hor_visc / ALE section"
+  read(un) max_depth
+  call rd3(T0, 0, nk)
+  allocate(xdiffu(ni+1,nj,nk), xdiffv(ni,nj+1,nk), xhn(ni,nj,nk), xdz(ni,nj,nk+1), xT(ni,nj,nk), xur(ni+1,nj,nk), xvr(ni,nj+1,nk))
+  read(un) xdiffu ; read(un) xdiffv ; read(un) xhn ; read(un) xdz ; read(un) xT ; read(un) xur ; read(un) xvr
   close(un)
   call al3(u, 1) ; call al3(v, 2) ; call al3(h, 0) ; call al3(uh, 1) ; call al3(vh, 2) ; call al3(uhtr, 1) ; call al3(vhtr, 2)
   allocate(eta_av(G%isd:G%ied,G%jsd:G%jed), eta(G%isd:G%ied,G%jsd:G%jed))
@@ -162,6 +174,7 @@ program drive_shims
   call check_clocks()
   call tracer_checks()
   call resident_submodule_checks()
+  call hor_visc_and_ALE_checks()
   call stop_model()
 
   ! =================================== run D: the same file read as one WITHOUT CAu, CAv =======================================
@@ -408,6 +421,47 @@ contains
     call shim_resident_drop(eta_o2) ; call shim_resident_drop(uhb2) ; call shim_resident_drop(vhb2)
     call barotropic_end(BTCS) ; call CoriolisAdv_end(CorCS)
   end subroutine resident_submodule_checks
+
+  !> horizontal_viscosity through MOM_hor_visc and one ALE step (ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel x 2,
+  !! ALE_remap_velocities) through MOM_ALE on the INITIAL state, host arrays in and out, the parameters from the MOM_input table:
+  !! every result equals the oracle's bit for bit.
+  subroutine hor_visc_and_ALE_checks()
+    type(hor_visc_CS) :: HV
+    type(ALE_CS), pointer :: ALE => NULL()
+    type(tracer_registry_type), pointer :: Reg => NULL()
+    real, allocatable, target :: du(:,:,:), dv(:,:,:), hh(:,:,:), hn(:,:,:), dz(:,:,:), Tr(:,:,:), ur(:,:,:), vr(:,:,:)
+    real, allocatable :: huo(:,:,:), hvo(:,:,:), hun(:,:,:), hvn(:,:,:)
+    call hor_visc_init(Time, G, GV, US, PF, diag, HV, ADp=ADp)
+    if (hor_visc_vel_stencil(HV) /= 2) then ; print '(a)', "FAIL: hor_visc_vel_stencil" ; nbad = nbad + 1 ; endif
+    call al3(du, 1) ; call al3(dv, 2) ; call al3(hh, 0) ; hh = h0
+    call horizontal_viscosity(u0, v0, hh, uh, vh, du, dv, MEKE, VarMix, G, GV, US, HV, tv, dt)
+    call cmp3("horizontal_viscosity (MOM_hor_visc) diffu", du(G%IscB:G%IecB,G%jsc:G%jec,:), xdiffu)
+    call cmp3("horizontal_viscosity (MOM_hor_visc) diffv", dv(G%isc:G%iec,G%JscB:G%JecB,:), xdiffv)
+    if (maxval(abs(xdiffu)) <= 0.0) then ; print '(a)', "FAIL: the lateral friction of the case is zero" ; nbad = nbad + 1 ; endif
+    call hor_visc_end(HV)
+
+    call stub_set_param(PF, "REGRIDDING_COORDINATE_MODE", "ZSTAR") ; call stub_set_param(PF, "REMAPPING_SCHEME", "PLM")
+    call ALE_init(PF, GV, US, max_depth, ALE)
+    if (.not.ALE_remap_init_conds(ALE)) then ; print '(a)', "FAIL: ALE_remap_init_conds" ; nbad = nbad + 1 ; endif
+    call ALE_update_regrid_weights(dt, ALE)
+    call al3(hn, 0) ; allocate(dz(G%isd:G%ied,G%jsd:G%jed,nk+1), source=0.0)
+    call ALE_regrid(G, GV, US, h0, hn, dz, tv, ALE)
+    call cmp3("ALE_regrid (MOM_ALE) h_new", hn(G%isc:G%iec,G%jsc:G%jec,:), xhn)
+    call cmp3("ALE_regrid (MOM_ALE) dzRegrid", dz(G%isc:G%iec,G%jsc:G%jec,:), xdz)
+    allocate(Reg) ; Reg%ntr = 1 ; call al3(Tr, 0) ; Tr = T0 ; Reg%Tr(1)%t => Tr
+    call ALE_remap_tracers(ALE, G, GV, h0, hn, Reg)
+    call cmp3("ALE_remap_tracers (MOM_ALE)", Tr(G%isc:G%iec,G%jsc:G%jec,:), xT)
+    if (maxval(abs(xT - T0(G%isc:G%iec,G%jsc:G%jec,:))) <= 0.0) then ; print '(a)', "FAIL: the remapping of the case moves nothing" ; nbad = nbad + 1 ; endif
+    call al3(huo, 1) ; call al3(hvo, 2) ; call al3(hun, 1) ; call al3(hvn, 2) ; call al3(ur, 1) ; call al3(vr, 2)
+    call ALE_remap_set_h_vel(ALE, G, GV, h0, huo, hvo, OBC) ; call ALE_remap_set_h_vel(ALE, G, GV, hn, hun, hvn, OBC)
+    ur = u0 ; vr = v0
+    call ALE_remap_velocities(ALE, G, GV, huo, hvo, hun, hvn, ur, vr)
+    call cmp3("ALE_remap_velocities (MOM_ALE) u", ur(G%IscB:G%IecB,G%jsc:G%jec,:), xur)
+    call cmp3("ALE_remap_velocities (MOM_ALE) v", vr(G%isc:G%iec,G%JscB:G%JecB,:), xvr)
+    call ALE_end(ALE)
+    if (associated(ALE)) then ; print '(a)', "FAIL: ALE_end left CS associated" ; nbad = nbad + 1 ; endif
+    deallocate(Reg)
+  end subroutine hor_visc_and_ALE_checks
 
   subroutine rd2(a, stg)
     real, allocatable, intent(inout) :: a(:,:) ; integer, intent(in) :: stg

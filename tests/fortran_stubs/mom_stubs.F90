@@ -405,10 +405,6 @@ module MOM_open_boundary
   type :: update_OBC_CS ; integer :: dummy = 0 ; end type
 end module MOM_open_boundary
 
-module MOM_ALE
-  implicit none ; public
-  type :: ALE_CS ; integer :: dummy = 0 ; end type
-end module MOM_ALE
 
 module MOM_MEKE_types
   implicit none ; public
@@ -458,10 +454,6 @@ module MOM_tidal_forcing
   implicit none ; public
   type :: tidal_forcing_CS ; integer :: dummy = 0 ; end type
 end module MOM_tidal_forcing
-module MOM_hor_visc
-  implicit none ; public
-  type :: hor_visc_CS ; integer :: dummy = 0 ; end type
-end module MOM_hor_visc
 
 module MOM_tracer_advect_schemes
   use MOM_error_handler, only : MOM_error, FATAL

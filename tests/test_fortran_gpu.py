@@ -119,8 +119,39 @@ def _write_shim_case(path, cfg, orc, no_bt_cont=False):
         # what MOM_diagnostics reads through Accel_diag / MIS after the last step (RK2.F90:1512-1534), from the same oracle run
         for n, stg in DIAG:
             f.write(np.ascontiguousarray(m[n][(Ellipsis,) + tuple(H.interior(d, stg))], dtype="<f8").tobytes())
+        # the standalone shims MOM_hor_visc and MOM_ALE on the INITIAL state: a tracer, and the oracle's horizontal_viscosity,
+        # ALE_regrid (z*, UNIFORM resolution over the deepest column), ALE_remap_tracers, ALE_remap_set_h_vel x 2 + ALE_remap_velocities
+        # (REMAPPING_SCHEME = PLM: the case has two layers) with the parameters the driver's table gives hor_visc_init / ALE_init
+        from mom6_amd import synth
+        hv = abi.hor_visc_params_default(inp["dt"]); hv.Ah_vel_scale = 0.02; hv.Smagorinsky_Ah = 1; hv.Smag_bi_const = 0.06
+        u0, v0, h0 = inp["u"], inp["v"], inp["h"]
+        du, dv = np.zeros_like(u0), np.zeros_like(v0)
+        orc.horizontal_viscosity(d, M, GV, hv, orc.hor_visc_init(d, M, hv), u0, v0, h0, du, dv)
+        max_depth = float(M[abi.G["bathyT"]].max())
+        cr = np.full(d.nk, max_depth / d.nk)
+        tot = 0.0
+        for x in cr:
+            tot = tot + x
+        cr[-1] = cr[-1] + (max_depth - tot)                      # initialize_regridding MOM_regridding.F90:563-582
+        RP = abi.regrid_zstar_params_default()
+        CS = abi.remapping_params_default(abi.REMAP_PLM, GV.H_subroundoff, om4_remap_via_sub_cells=1, boundary_extrapolation=0)
+        hn, dz = np.zeros_like(h0), np.zeros((d.nk + 1,) + d.shape2())
+        orc.ALE_regrid_zstar(d, M, GV, RP, cr, h0, hn, dz)
+        T0 = np.ascontiguousarray(10.0 + 5.0 * synth.smooth_field(d, 70, nk=d.nk, ox=0.5, oy=0.5) + np.arange(d.nk)[:, None, None])
+        Tr = T0.copy()
+        orc.ALE_remap_tracers(d, M, CS, h0, hn, [Tr])
+        huo, hvo, hun, hvn = (np.zeros_like(h0) for _ in range(4))
+        orc.ALE_remap_set_h_vel(d, M, h0, huo, hvo); orc.ALE_remap_set_h_vel(d, M, hn, hun, hvn)
+        ur, vr = u0.copy(), v0.copy()
+        orc.ALE_remap_velocities(d, M, CS, huo, hvo, hun, hvn, ur, vr)
+        assert np.abs(du).max() > 0 and np.abs(Tr - T0).max() > 0 and np.abs(ur - u0).max() > 0
+        f.write(struct.pack("<i", 1297042744)); f.write(struct.pack("<d", max_depth))
+        put(T0, 0)
+        for a, stg in ((du, "u"), (dv, "v"), (hn, "h"), (dz, "h"), (Tr, "h"), (ur, "u"), (vr, "v")):
+            f.write(np.ascontiguousarray(a[(Ellipsis,) + tuple(H.interior(d, stg))], dtype="<f8").tobytes())
 
 
+N_STANDALONE = 7      # horizontal_viscosity (2), ALE_regrid (2), ALE_remap_tracers (1), ALE_remap_velocities (2) through MOM_hor_visc / MOM_ALE
 DIAG = [("CAu", "u"), ("CAv", "v"), ("PFu", "u"), ("PFv", "v"), ("diffu", "u"), ("diffv", "v"), ("u_accel_bt", "u"), ("v_accel_bt", "v"),
         ("pbce", "h"), ("u_av", "u"), ("v_av", "v")]
 
@@ -144,7 +175,7 @@ def test_shim_modules_new_run_restart_and_tracers_from_fortran(orc, tmp_path, mo
     print(r.stdout); print(r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
     # runs A and C: the state; run C also: the arrays behind Accel_diag% and MIS% (associated, and equal to the oracle's)
-    assert r.stdout.count(": bit-identical") == 2 * len(STATE) + len(DIAG) + 7
+    assert r.stdout.count(": bit-identical") == 2 * len(STATE) + len(DIAG) + 7 + N_STANDALONE
     # CorAdCalc, btcalc, bt_mass_source and btstep through their shims on arrays the host has made resident (shim_resident_add): not one
     # array crosses PCIe in two rounds of calls, and the seven results equal those of the calls on plain host arrays
     assert ", resident 0" in r.stdout and r.stdout.count("resident CorAdCalc") == 2 and r.stdout.count("resident btstep") == 5
@@ -163,4 +194,4 @@ def test_shim_modules_without_a_BT_cont_type_from_fortran(orc, tmp_path, sums):
     r = subprocess.run([SHIM_DRIVER, str(path), str(tmp_path / "restart.bin")], capture_output=True, text=True, timeout=300)
     print(r.stdout); print(r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count(": bit-identical") == 2 * len(STATE) + len(DIAG) + 7
+    assert r.stdout.count(": bit-identical") == 2 * len(STATE) + len(DIAG) + 7 + N_STANDALONE

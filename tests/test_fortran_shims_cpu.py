@@ -2,7 +2,7 @@
 
 A MOM6 tree cannot be built here (FMS, netCDF), so the shim modules of fortran/shims/ -- the reference's module names
 MOM_dynamics_split_RK2, MOM_continuity_PPM, MOM_barotropic, MOM_CoriolisAdv, MOM_PressureForce, MOM_vert_friction,
-MOM_tracer_advect (+ mom6x_diabatic_solvers for triDiagTS* / tracer_vertdiff*) -- are compiled with amdflang against the
+MOM_tracer_advect, MOM_hor_visc, MOM_ALE (+ mom6x_diabatic_solvers for triDiagTS* / tracer_vertdiff*) -- are compiled with amdflang against the
 interface stand-ins of tests/fortran_stubs/mom_stubs.F90 (our own text: the derived-type members and procedure signatures
 the shims touch, nothing else), and linked into tests/fortran_stubs/drive_shims, which tests/test_fortran_gpu.py runs on the
 GPU.  Here: every file passes the compiler's semantic analysis, the driver links against libmom6x.so, and every public
@@ -29,6 +29,10 @@ BOUNDARY = {
     "MOM_tracer_advect": ["advect_tracer", "tracer_advect_init", "tracer_advect_end", "tracer_advect_CS"],
     "MOM_vert_friction": ["vertvisc", "vertvisc_remnant", "vertvisc_coef", "vertvisc_init", "vertvisc_end", "vertvisc_CS"],
     "mom6x_diabatic_solvers": ["triDiagTS", "triDiagTS_Eulerian", "tracer_vertdiff", "tracer_vertdiff_Eulerian"],
+    # SURVEY.md 8(f) rows 2 and 3 behind the reference's module names (round 6)
+    "MOM_hor_visc": ["horizontal_viscosity", "hor_visc_init", "hor_visc_end", "hor_visc_vel_stencil", "hor_visc_CS"],
+    "MOM_ALE": ["ALE_init", "ALE_end", "ALE_regrid", "ALE_remap_tracers", "ALE_remap_set_h_vel", "ALE_remap_velocities",
+                "ALE_update_regrid_weights", "ALE_remap_init_conds", "ALE_set_extrap_boundaries", "ALE_CS"],
 }
 
 
