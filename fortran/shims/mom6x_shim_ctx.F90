@@ -25,7 +25,7 @@ use MOM_grid,          only : ocean_grid_type
 use MOM_verticalGrid,  only : verticalGrid_type
 implicit none ; private
 
-public :: shim_ctx, shim_ctx_is_up, shim_ctx_end, shim_dims, shim_check, shim_buf, shim_nk, shim_set_domain_flags
+public :: shim_ctx, shim_ctx_is_up, shim_ctx_current, shim_ctx_end, shim_dims, shim_check, shim_buf, shim_nk, shim_set_domain_flags
 public :: shim_up2, shim_up3, shim_down2, shim_down3, shim_out2, shim_out3
 public :: shim_resident_add, shim_resident_drop, shim_resident_sync_host, shim_resident_host_changed, shim_resident_dev
 public :: shim_transfer_count
@@ -61,6 +61,13 @@ end subroutine shim_set_domain_flags
 logical function shim_ctx_is_up()
   shim_ctx_is_up = c_associated(the_ctx)
 end function shim_ctx_is_up
+
+!> The context, for a module whose entry points see no ocean_grid_type (MOM_checksums): it must exist already
+function shim_ctx_current() result(ctx)
+  type(c_ptr) :: ctx
+  if (.not.c_associated(the_ctx)) call MOM_error(FATAL, "mom6x_shim_ctx: no device context yet (call a shim's *_init first).")
+  ctx = the_ctx
+end function shim_ctx_current
 
 !> The context of this PE's tile; created on the first call.
 function shim_ctx(G, GV) result(ctx)

@@ -22,6 +22,7 @@ program drive_shims
   use MOM_dynamics_split_RK2
   use MOM_ALE, only : ALE_CS, ALE_init, ALE_end, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities, &
                       ALE_update_regrid_weights, ALE_remap_init_conds
+  use MOM_checksums, only : hchksum, uvchksum, Bchksum, hchksum_pair, MOM_checksums_init
   use MOM_hor_visc, only : hor_visc_CS, hor_visc_init, hor_visc_end, horizontal_viscosity, hor_visc_vel_stencil
   use MOM_file_parser, only : param_file_type, stub_set_param
   use MOM_forcing_type, only : mech_forcing
@@ -175,6 +176,7 @@ program drive_shims
   call tracer_checks()
   call resident_submodule_checks()
   call hor_visc_and_ALE_checks()
+  call checksum_checks()
   call stop_model()
 
   ! =================================== run D: the same file read as one WITHOUT CAu, CAv =======================================
@@ -462,6 +464,17 @@ contains
     if (associated(ALE)) then ; print '(a)', "FAIL: ALE_end left CS associated" ; nbad = nbad + 1 ; endif
     deallocate(Reg)
   end subroutine hor_visc_and_ALE_checks
+
+  !> The debugging checksums through MOM_checksums on the INITIAL state, written to standard output (logunit = 6): tests/test_fortran_gpu.py
+  !! compares the lines with the ones the Python host formats from the same device routine (whose numbers are held to the oracle).
+  subroutine checksum_checks()
+    call MOM_checksums_init(PF)
+    call hchksum(h0, "h0 [MOM_checksums]", HI, haloshift=1, logunit=6)
+    call uvchksum("uv0 [MOM_checksums]", u0, v0, HI, haloshift=1, symmetric=.true., logunit=6)
+    call Bchksum(G%CoriolisBu, "f [MOM_checksums]", HI, haloshift=0, symmetric=.true., logunit=6)
+    call hchksum(h0, "h0 x2 [MOM_checksums]", HI, unscale=2.0, logunit=6)
+    call hchksum_pair("hT [MOM_checksums]", h0, T0, HI, haloshift=2, omit_corners=.true., logunit=6)
+  end subroutine checksum_checks
 
   subroutine rd2(a, stg)
     real, allocatable, intent(inout) :: a(:,:) ; integer, intent(in) :: stg

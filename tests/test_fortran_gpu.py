@@ -182,6 +182,34 @@ def test_shim_modules_new_run_restart_and_tracers_from_fortran(orc, tmp_path, mo
     assert "D (restart file without CAu, CAv) u: max |diff|" in r.stdout
     names = r.stdout.split("registered restart variables:")[1].splitlines()[0].split()
     assert names == ["u", "v", "h", "sfc", "u2", "v2", "CAu", "CAv", "diffu", "diffv", "ubtav", "vbtav", "DTBT"]
+    _check_checksum_lines(r.stdout, H.double_gyre(), orc)
+
+
+def _check_checksum_lines(stdout, cfg, orc):
+    """The lines hchksum / uvchksum / Bchksum / hchksum_pair wrote through fortran/shims/MOM_checksums.F90 == the lines the Python host
+    formats from the same device routine, whose numbers equal the oracle's."""
+    import torch
+    from mom6_amd import synth
+    from mom6_amd.dycore import Dycore
+    gg, d, M = cfg
+    inp = cases.rk2_inputs(cfg, False, False)
+    dyc = Dycore(d, M, inp["GV"])
+    T0 = np.ascontiguousarray(10.0 + 5.0 * synth.smooth_field(d, 70, nk=d.nk, ox=0.5, oy=0.5) + np.arange(d.nk)[:, None, None])
+    f = np.ascontiguousarray(M[abi.G["CoriolisBu"]])
+    want = []
+    for arr, stg, mesg, kw in ((inp["h"], "h", "h0 [MOM_checksums]", dict(haloshift=1)),
+                               (inp["u"], "u", "u uv0 [MOM_checksums]", dict(haloshift=1, symmetric=True)),
+                               (inp["v"], "v", "v uv0 [MOM_checksums]", dict(haloshift=1, symmetric=True)),
+                               (f, "B", "f [MOM_checksums]", dict(haloshift=0, symmetric=True)),
+                               (inp["h"], "h", "h0 x2 [MOM_checksums]", dict(scale=2.0)),
+                               (inp["h"], "h", "x hT [MOM_checksums]", dict(haloshift=2, omit_corners=True)),
+                               (T0, "h", "y hT [MOM_checksums]", dict(haloshift=2, omit_corners=True))):
+        a = dyc.to_dev(arr)
+        got = dyc.chksum(a, stg, **kw); got.pop("kind")
+        assert got == orc.chksum(d, arr, stg, **kw), (mesg, got)
+        want += [l.rstrip() for l in dyc.chksum_lines(a, stg, mesg, **kw)]
+    have = [l.rstrip() for l in stdout.splitlines() if "[MOM_checksums]" in l]
+    assert have == want, "\n".join(["Fortran:"] + have + ["Python:"] + want)
 
 
 def test_shim_modules_without_a_BT_cont_type_from_fortran(orc, tmp_path, sums):
