@@ -1,5 +1,5 @@
 !> Drop-in for the entry points of src/ALE/MOM_ALE.F90 that MOM.F90's ALE_regridding_and_remapping (:1751) calls every
-!! thermodynamic step: ALE_init :168, ALE_end :445, ALE_regrid :518, ALE_remap_tracers :760, ALE_remap_set_h_vel :882,
+!! thermodynamic step: ALE_init :168, ALE_end :445, pre_ALE_adjustments :489, ALE_regrid :518, ALE_remap_tracers :760, ALE_remap_set_h_vel :882,
 !! ALE_remap_velocities :1089, ALE_update_regrid_weights :1719, ALE_remap_init_conds :1711, ALE_set_extrap_boundaries :347 and the
 !! type ALE_CS -- same names and argument lists, served by mom6x_ALE_regrid_zstar / _rho, mom6x_ALE_convective_adjustment,
 !! mom6x_ALE_remap_tracers, mom6x_ALE_remap_set_h_vel and mom6x_ALE_remap_velocities(_conserve_ke) (SURVEY 8f-3).
@@ -27,7 +27,7 @@ use MOM_variables,       only : thermo_var_ptrs
 use MOM_verticalGrid,    only : verticalGrid_type
 implicit none ; private
 #include <MOM_memory.h>
-public :: ALE_init, ALE_end, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities
+public :: ALE_init, ALE_end, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities, pre_ALE_adjustments
 public :: ALE_update_regrid_weights, ALE_remap_init_conds, ALE_set_extrap_boundaries, ALE_getCoordinate
 public :: ALE_vel_remap_params
 
@@ -278,9 +278,33 @@ function ALE_vel_remap_params(CS) result(p)
   p = CS%vel_remap
 end function ALE_vel_remap_params
 
-!> ALE_regrid (:518) -> regridding_main (MOM_regridding.F90:862).  REGRIDDING_RHO: convective_adjustment first, as
-!! ALE_regridding_and_remapping does through pre_ALE_adjustments when CS%do_conv_adj (MOM_ALE.F90:489-510) -- here inside the call,
-!! on copies: h, tv%T, tv%S of the host are adjusted by pre_ALE_adjustments (host Fortran) if the host wants them adjusted.
+!> pre_ALE_adjustments (:489): the column-wise convective adjustment the RHO coordinate asks for (regridding_preadjust_reqs :966,
+!! convective_adjustment MOM_regridding.F90:1905), in place on h, tv%T, tv%S; nothing to do for z*.
+subroutine pre_ALE_adjustments(G, GV, US, h, tv, Reg, CS, u, v)
+  type(ocean_grid_type),                      intent(in)    :: G
+  type(verticalGrid_type),                    intent(in)    :: GV
+  type(unit_scale_type),                      intent(in)    :: US
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  intent(inout) :: h
+  type(thermo_var_ptrs),                      intent(inout) :: tv
+  type(tracer_registry_type),                 pointer       :: Reg
+  type(ALE_CS),                               pointer       :: CS
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), optional, intent(inout) :: u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), optional, intent(inout) :: v
+  type(c_ptr) :: d_h, d_T, d_S
+  integer(c_int) :: rc
+  integer :: nk
+  if (.not.associated(CS)) call MOM_error(FATAL, "pre_ALE_adjustments: the ALE control structure is not associated.")
+  if (.not.CS%do_conv_adj) return
+  if (.not.(associated(tv%T) .and. associated(tv%S))) call MOM_error(FATAL, "pre_ALE_adjustments: convective adjustment needs tv%T and tv%S.")
+  nk = GV%ke
+  if (.not.c_associated(CS%ctx)) CS%ctx = shim_ctx(G, GV)
+  d_h = shim_up3(1, h, STG_H, nk) ; d_T = shim_up3(4, tv%T, STG_H, nk) ; d_S = shim_up3(5, tv%S, STG_H, nk)
+  rc = mom6x_ALE_convective_adjustment(CS%ctx, CS%eos, d_h, d_T, d_S) ; call shim_check(rc, "pre_ALE_adjustments")
+  call shim_down3(h, d_h, STG_H, nk) ; call shim_down3(tv%T, d_T, STG_H, nk) ; call shim_down3(tv%S, d_S, STG_H, nk)
+end subroutine pre_ALE_adjustments
+
+!> ALE_regrid (:518) -> regridding_main (MOM_regridding.F90:862).  (REGRIDDING_RHO wants a statically stable column: MOM.F90 calls
+!! pre_ALE_adjustments before it, as it does with the reference.)
 subroutine ALE_regrid(G, GV, US, h, h_new, dzRegrid, tv, CS, frac_shelf_h, PCM_cell)
   type(ocean_grid_type),                       intent(in)    :: G
   type(verticalGrid_type),                     intent(in)    :: GV

@@ -32,7 +32,7 @@ BOUNDARY = {
     # SURVEY.md 8(f) rows 2 and 3 behind the reference's module names (round 6)
     "MOM_hor_visc": ["horizontal_viscosity", "hor_visc_init", "hor_visc_end", "hor_visc_vel_stencil", "hor_visc_CS"],
     "MOM_checksums": ["hchksum", "uchksum", "vchksum", "Bchksum", "qchksum", "hchksum_pair", "uvchksum", "Bchksum_pair", "MOM_checksums_init"],
-    "MOM_ALE": ["ALE_init", "ALE_end", "ALE_regrid", "ALE_remap_tracers", "ALE_remap_set_h_vel", "ALE_remap_velocities",
+    "MOM_ALE": ["ALE_init", "ALE_end", "pre_ALE_adjustments", "ALE_regrid", "ALE_remap_tracers", "ALE_remap_set_h_vel", "ALE_remap_velocities",
                 "ALE_update_regrid_weights", "ALE_remap_init_conds", "ALE_set_extrap_boundaries", "ALE_CS"],
 }
 
