@@ -21,7 +21,7 @@ program drive_shims
   use MOM_domains, only : MOM_domain_type
   use MOM_dynamics_split_RK2
   use MOM_ALE, only : ALE_CS, ALE_init, ALE_end, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities, &
-                      ALE_update_regrid_weights, ALE_remap_init_conds
+                      ALE_update_regrid_weights, ALE_remap_init_conds, pre_ALE_adjustments
   use MOM_checksums, only : hchksum, uvchksum, Bchksum, hchksum_pair, MOM_checksums_init
   use MOM_hor_visc, only : hor_visc_CS, hor_visc_init, hor_visc_end, horizontal_viscosity, hor_visc_vel_stencil
   use MOM_file_parser, only : param_file_type, stub_set_param
@@ -80,7 +80,8 @@ program drive_shims
   real, allocatable :: xu(:,:,:), xv(:,:,:), xh(:,:,:), xuh(:,:,:), xvh(:,:,:), xuhtr(:,:,:), xvhtr(:,:,:), xeta(:,:)
   real, allocatable :: dCAu(:,:,:), dCAv(:,:,:), dPFu(:,:,:), dPFv(:,:,:), ddiffu(:,:,:), ddiffv(:,:,:), dubt(:,:,:), dvbt(:,:,:)
   real, allocatable :: dpbce(:,:,:), duav(:,:,:), dvav(:,:,:)
-  real, allocatable, target :: T0(:,:,:)
+  real, allocatable, target :: T0(:,:,:), Trho(:,:,:), Srho(:,:,:)
+  real, allocatable :: yh(:,:,:), yT(:,:,:), yS(:,:,:), yhn(:,:,:), ydz(:,:,:)
   real, allocatable :: xdiffu(:,:,:), xdiffv(:,:,:), xhn(:,:,:), xdz(:,:,:), xT(:,:,:), xur(:,:,:), xvr(:,:,:)
   real :: max_depth
   integer :: magic2
@@ -138,6 +139,10 @@ program drive_shims
   call rd3(T0, 0, nk)
   allocate(xdiffu(ni+1,nj,nk), xdiffv(ni,nj+1,nk), xhn(ni,nj,nk), xdz(ni,nj,nk+1), xT(ni,nj,nk), xur(ni+1,nj,nk), xvr(ni,nj+1,nk))
   read(un) xdiffu ; read(un) xdiffv ; read(un) xhn ; read(un) xdz ; read(un) xT ; read(un) xur ; read(un) xvr
+  ! the RHO coordinate: T, S of a column with some static instability, the oracle's convective_adjustment and regridding of it
+  call rd3(Trho, 0, nk) ; call rd3(Srho, 0, nk)
+  allocate(yh(ni,nj,nk), yT(ni,nj,nk), yS(ni,nj,nk), yhn(ni,nj,nk), ydz(ni,nj,nk+1))
+  read(un) yh ; read(un) yT ; read(un) yS ; read(un) yhn ; read(un) ydz
   close(un)
   call al3(u, 1) ; call al3(v, 2) ; call al3(h, 0) ; call al3(uh, 1) ; call al3(vh, 2) ; call al3(uhtr, 1) ; call al3(vhtr, 2)
   allocate(eta_av(G%isd:G%ied,G%jsd:G%jed), eta(G%isd:G%ied,G%jsd:G%jed))
@@ -463,7 +468,35 @@ contains
     call ALE_end(ALE)
     if (associated(ALE)) then ; print '(a)', "FAIL: ALE_end left CS associated" ; nbad = nbad + 1 ; endif
     deallocate(Reg)
+    call ALE_rho_checks()
   end subroutine hor_visc_and_ALE_checks
+
+  !> The density coordinate through MOM_ALE: ALE_init reads REGRIDDING_COORDINATE_MODE = RHO (target densities from GV%Rlay, the
+  !! equation of state from the table), pre_ALE_adjustments makes the columns statically stable, ALE_regrid builds the grid: five
+  !! arrays equal to the oracle's bit for bit.
+  subroutine ALE_rho_checks()
+    type(ALE_CS), pointer :: ALE => NULL()
+    type(tracer_registry_type), pointer :: Reg => NULL()
+    type(thermo_var_ptrs) :: tv2
+    real, allocatable, target :: hh(:,:,:), TT(:,:,:), SS(:,:,:), hn(:,:,:), dz(:,:,:)
+    call stub_set_param(PF, "ENABLE_THERMODYNAMICS", "True") ; call stub_set_param(PF, "EQN_OF_STATE", "LINEAR")
+    call stub_set_param(PF, "REGRIDDING_COORDINATE_MODE", "RHO") ; call stub_set_param(PF, "REGRIDDING_ANSWER_DATE", "20190101")
+    call ALE_init(PF, GV, US, max_depth, ALE)
+    call ALE_update_regrid_weights(dt, ALE)
+    call al3(hh, 0) ; call al3(TT, 0) ; call al3(SS, 0) ; hh = h0 ; TT = Trho ; SS = Srho
+    tv2%T => TT ; tv2%S => SS
+    call pre_ALE_adjustments(G, GV, US, hh, tv2, Reg, ALE)
+    call cmp3("pre_ALE_adjustments (MOM_ALE, RHO) h", hh(G%isc:G%iec,G%jsc:G%jec,:), yh)
+    call cmp3("pre_ALE_adjustments (MOM_ALE, RHO) T", TT(G%isc:G%iec,G%jsc:G%jec,:), yT)
+    call cmp3("pre_ALE_adjustments (MOM_ALE, RHO) S", SS(G%isc:G%iec,G%jsc:G%jec,:), yS)
+    if (maxval(abs(yT - Trho(G%isc:G%iec,G%jsc:G%jec,:))) <= 0.0) then ; print '(a)', "FAIL: no column of the case is statically unstable" ; nbad = nbad + 1 ; endif
+    call al3(hn, 0) ; allocate(dz(G%isd:G%ied,G%jsd:G%jed,nk+1), source=0.0)
+    call ALE_regrid(G, GV, US, hh, hn, dz, tv2, ALE)
+    call cmp3("ALE_regrid (MOM_ALE, RHO) h_new", hn(G%isc:G%iec,G%jsc:G%jec,:), yhn)
+    call cmp3("ALE_regrid (MOM_ALE, RHO) dzRegrid", dz(G%isc:G%iec,G%jsc:G%jec,:), ydz)
+    call ALE_end(ALE)
+    call stub_set_param(PF, "ENABLE_THERMODYNAMICS", "False") ; call stub_set_param(PF, "REGRIDDING_COORDINATE_MODE", "ZSTAR")
+  end subroutine ALE_rho_checks
 
   !> The debugging checksums through MOM_checksums on the INITIAL state, written to standard output (logunit = 6): tests/test_fortran_gpu.py
   !! compares the lines with the ones the Python host formats from the same device routine (whose numbers are held to the oracle).

@@ -149,9 +149,33 @@ def _write_shim_case(path, cfg, orc, no_bt_cont=False):
         put(T0, 0)
         for a, stg in ((du, "u"), (dv, "v"), (hn, "h"), (dz, "h"), (Tr, "h"), (ur, "u"), (vr, "v")):
             f.write(np.ascontiguousarray(a[(Ellipsis,) + tuple(H.interior(d, stg))], dtype="<f8").tobytes())
+        # REGRIDDING_COORDINATE_MODE = RHO through MOM_ALE: the linear equation of state of the table's defaults, target densities as
+        # set_target_densities_from_GV (MOM_regridding.F90:2069) makes them from GV%Rlay with the UNIFORM resolution, T and S around
+        # the layer densities with enough noise for statically unstable columns; convective_adjustment, then the new grid
+        eos = abi.eos_params_default(abi.LINEAR)
+        R = np.asarray(inp["Rlay"], dtype=np.float64); ke = d.nk
+        rho_light = R[0] + 0.5 * (R[0] - R[min(1, ke - 1)]); rho_heavy = R[ke - 1] + 0.5 * (R[ke - 1] - R[max(ke - 2, 0)])
+        res = np.full(ke, (rho_heavy - rho_light) / ke)
+        tgt = np.zeros(ke + 1)
+        tgt[0] = R[0] + 0.5 * (R[0] - R[1]); tgt[ke] = R[ke - 1] + 0.5 * (R[ke - 1] - R[ke - 2])
+        for k in range(1, ke):
+            tgt[k] = tgt[k - 1] + res[k]
+        rng = np.random.default_rng(11)
+        Srho = np.full_like(h0, 35.0)
+        Trho = np.ascontiguousarray((1000.0 + 0.8 * 35.0 - R)[:, None, None] / 0.2 + 3.0 * synth.smooth_field(d, 71, nk=ke) + rng.normal(0.0, 4.0, h0.shape))
+        RPr = abi.regrid_rho_params_default(integrate_downward_for_e=0)      # ALE_init: REGRID_USE_OLD_DIRECTION = True (MOM_ALE.F90:314-319)
+        hy, Ty, Sy = h0.copy(), Trho.copy(), Srho.copy()
+        orc.ALE_convective_adjustment(d, eos, hy, Ty, Sy)
+        hny, dzy = np.zeros_like(h0), np.zeros((ke + 1,) + d.shape2())
+        orc.ALE_regrid_rho(d, M, GV, RPr, eos, tgt, hy, Ty, Sy, hny, dzy)
+        assert np.abs(Ty - Trho).max() > 0 and np.abs(dzy).max() > 0
+        put(Trho, 0); put(Srho, 0)
+        for a in (hy, Ty, Sy, hny, dzy):
+            f.write(np.ascontiguousarray(a[(Ellipsis,) + tuple(H.interior(d, "h"))], dtype="<f8").tobytes())
 
 
-N_STANDALONE = 7      # horizontal_viscosity (2), ALE_regrid (2), ALE_remap_tracers (1), ALE_remap_velocities (2) through MOM_hor_visc / MOM_ALE
+N_STANDALONE = 12     # horizontal_viscosity (2), ALE_regrid (2), ALE_remap_tracers (1), ALE_remap_velocities (2), the RHO coordinate's
+                      # pre_ALE_adjustments (3) and ALE_regrid (2) through MOM_hor_visc / MOM_ALE
 DIAG = [("CAu", "u"), ("CAv", "v"), ("PFu", "u"), ("PFv", "v"), ("diffu", "u"), ("diffv", "v"), ("u_accel_bt", "u"), ("v_accel_bt", "v"),
         ("pbce", "h"), ("u_av", "u"), ("v_av", "v")]
 
