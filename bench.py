@@ -507,7 +507,7 @@ def comm_model_leg(args, device):
 def pmc_step_traffic():
     """Measured HBM-side GB per step (sum over all kernels of one step) from the newest committed PMC summary, or None."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")), key=_profile_order, reverse=True):
         try:
             j = json.load(open(path))
             if "bytes_per_step" in j:
@@ -536,6 +536,16 @@ def _variants_mean(tab, kernel, field=None, launches=None):
         return None
     w = {n: float((launches or {}).get(n, 1.0)) for n in step}
     return sum(w[n] * float(val(n)) for n in step) / sum(w.values())
+
+
+def _profile_order(path):
+    """Newest last: profiles/rNN_<tag><n>_*.json ordered by round, then v1 < v2 < ... < final < final2 < ... (a plain sort of the
+    names would put final2 before final)."""
+    import re
+    m = re.match(r"r(\d+)_([a-z]+?)(\d*)_", os.path.basename(path))
+    if not m:
+        return (-1, -1, 0, os.path.basename(path))
+    return (int(m.group(1)), {"v": 0, "final": 1}.get(m.group(2), -1), int(m.group(3) or 1), os.path.basename(path))
 
 
 def pmc_traffic(kernel):
@@ -568,7 +578,7 @@ def valu_counters(kernel, N3_tile, avg_ms):
     import glob
     import re
     key = lambda n: (re.match(r"\w+(<\d+)?", n.replace(" ", "")) or [n])[0]
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_pmc.json")), key=_profile_order, reverse=True):
         try:
             tab = json.load(open(path))["per_launch"]
         except (OSError, ValueError, KeyError):
