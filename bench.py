@@ -555,7 +555,7 @@ def pmc_traffic(kernel):
     import glob
     import re
     key = lambda n: (re.match(r"\w+(<\d+)?", n.replace(" ", "")) or [n])[0]
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")), key=_profile_order, reverse=True):
         try:
             j = json.load(open(path))
             tab = j["traffic_bytes_per_launch"]
