@@ -465,6 +465,32 @@ contains
     call ALE_remap_velocities(ALE, G, GV, huo, hvo, hun, hvn, ur, vr)
     call cmp3("ALE_remap_velocities (MOM_ALE) u", ur(G%IscB:G%IecB,G%jsc:G%jec,:), xur)
     call cmp3("ALE_remap_velocities (MOM_ALE) v", vr(G%isc:G%iec,G%JscB:G%JecB,:), xvr)
+    ! ---- the same remapping on arrays the host has handed over (shim_resident_add): nothing crosses PCIe, the same bits
+    block
+      real, allocatable, target :: hr(:,:,:), hnr(:,:,:), Trr(:,:,:), urr(:,:,:), vrr(:,:,:), huor(:,:,:), hvor(:,:,:), hunr(:,:,:), hvnr(:,:,:)
+      integer(c_long_long) :: n_res
+      call al3(hr, 0) ; call al3(hnr, 0) ; call al3(Trr, 0) ; call al3(urr, 1) ; call al3(vrr, 2)
+      call al3(huor, 1) ; call al3(hvor, 2) ; call al3(hunr, 1) ; call al3(hvnr, 2)
+      hr = h0 ; hnr = hn ; Trr = T0 ; urr = u0 ; vrr = v0
+      call shim_resident_add(hr, 0, nk) ; call shim_resident_add(hnr, 0, nk) ; call shim_resident_add(Trr, 0, nk)
+      call shim_resident_add(urr, 1, nk) ; call shim_resident_add(vrr, 2, nk) ; call shim_resident_add(huor, 1, nk)
+      call shim_resident_add(hvor, 2, nk) ; call shim_resident_add(hunr, 1, nk) ; call shim_resident_add(hvnr, 2, nk)
+      n_res = shim_transfer_count(reset=.true.)
+      Reg%Tr(1)%t => Trr
+      call ALE_remap_tracers(ALE, G, GV, hr, hnr, Reg)
+      call ALE_remap_set_h_vel(ALE, G, GV, hr, huor, hvor, OBC) ; call ALE_remap_set_h_vel(ALE, G, GV, hnr, hunr, hvnr, OBC)
+      call ALE_remap_velocities(ALE, G, GV, huor, hvor, hunr, hvnr, urr, vrr)
+      n_res = shim_transfer_count(reset=.true.)
+      print '(a,i0)', "MOM_ALE on resident arrays: arrays across PCIe per ALE_remap_tracers + 2 x ALE_remap_set_h_vel + ALE_remap_velocities: ", n_res
+      if (n_res /= 0) then ; print '(a)', "FAIL: the resident calls of MOM_ALE moved arrays" ; nbad = nbad + 1 ; endif
+      call shim_resident_sync_host(Trr) ; call shim_resident_sync_host(urr) ; call shim_resident_sync_host(vrr)
+      call cmp3("resident ALE_remap_tracers", Trr(G%isc:G%iec,G%jsc:G%jec,:), xT)
+      call cmp3("resident ALE_remap_velocities u", urr(G%IscB:G%IecB,G%jsc:G%jec,:), xur)
+      call cmp3("resident ALE_remap_velocities v", vrr(G%isc:G%iec,G%JscB:G%JecB,:), xvr)
+      call shim_resident_drop(hr, download=.false.) ; call shim_resident_drop(hnr, download=.false.) ; call shim_resident_drop(Trr, download=.false.)
+      call shim_resident_drop(urr, download=.false.) ; call shim_resident_drop(vrr, download=.false.) ; call shim_resident_drop(huor, download=.false.)
+      call shim_resident_drop(hvor, download=.false.) ; call shim_resident_drop(hunr, download=.false.) ; call shim_resident_drop(hvnr, download=.false.)
+    end block
     call ALE_end(ALE)
     if (associated(ALE)) then ; print '(a)', "FAIL: ALE_end left CS associated" ; nbad = nbad + 1 ; endif
     deallocate(Reg)

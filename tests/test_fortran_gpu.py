@@ -174,8 +174,8 @@ def _write_shim_case(path, cfg, orc, no_bt_cont=False):
             f.write(np.ascontiguousarray(a[(Ellipsis,) + tuple(H.interior(d, "h"))], dtype="<f8").tobytes())
 
 
-N_STANDALONE = 12     # horizontal_viscosity (2), ALE_regrid (2), ALE_remap_tracers (1), ALE_remap_velocities (2), the RHO coordinate's
-                      # pre_ALE_adjustments (3) and ALE_regrid (2) through MOM_hor_visc / MOM_ALE
+N_STANDALONE = 15     # horizontal_viscosity (2), ALE_regrid (2), ALE_remap_tracers (1), ALE_remap_velocities (2), the RHO coordinate's
+                      # pre_ALE_adjustments (3) and ALE_regrid (2) through MOM_hor_visc / MOM_ALE, the remapping again on resident arrays (3)
 DIAG = [("CAu", "u"), ("CAv", "v"), ("PFu", "u"), ("PFv", "v"), ("diffu", "u"), ("diffv", "v"), ("u_accel_bt", "u"), ("v_accel_bt", "v"),
         ("pbce", "h"), ("u_av", "u"), ("v_av", "v")]
 
@@ -203,6 +203,7 @@ def test_shim_modules_new_run_restart_and_tracers_from_fortran(orc, tmp_path, mo
     # CorAdCalc, btcalc, bt_mass_source and btstep through their shims on arrays the host has made resident (shim_resident_add): not one
     # array crosses PCIe in two rounds of calls, and the seven results equal those of the calls on plain host arrays
     assert ", resident 0" in r.stdout and r.stdout.count("resident CorAdCalc") == 2 and r.stdout.count("resident btstep") == 5
+    assert "ALE_remap_tracers + 2 x ALE_remap_set_h_vel + ALE_remap_velocities: 0" in r.stdout
     assert "D (restart file without CAu, CAv) u: max |diff|" in r.stdout
     names = r.stdout.split("registered restart variables:")[1].splitlines()[0].split()
     assert names == ["u", "v", "h", "sfc", "u2", "v2", "CAu", "CAv", "diffu", "diffv", "ubtav", "vbtav", "DTBT"]
