@@ -687,8 +687,17 @@ k_hv_accel(Dm d, const double *__restrict__ G, const double *__restrict__ P, con
 #ifndef HV_OM4_W4
 #define HV_OM4_W4 0
 #endif
+#ifndef HV_TX
+#define HV_TX 32
+#endif
+#ifndef HV_TY
+#define HV_TY 24
+#endif
+#ifndef HV_WAVES   // wavefronts per SIMD the kernel is compiled for (0: from the tile size)
+#define HV_WAVES 0
+#endif
 template <int HT_X, int HT_Y, bool OM4>
-__global__ void __launch_bounds__(HT_X * HT_Y, (HT_X * HT_Y >= 1024 || (OM4 && HV_OM4_W4)) ? 4 : ((HT_X * HT_Y >= 768) ? 3 : 2))   // 1024 threads: 4 wavefronts per SIMD (128 registers, 56 spilled); 768: 3 per SIMD (168 registers); 512: 2 per SIMD
+__global__ void __launch_bounds__(HT_X * HT_Y, HV_WAVES ? HV_WAVES : ((HT_X * HT_Y >= 1024 || (OM4 && HV_OM4_W4)) ? 4 : ((HT_X * HT_Y >= 768) ? 3 : 2)))   // 1024 threads: 4 wavefronts per SIMD (128 registers, 56 spilled); 768: 3 per SIMD (168 registers); 512: 2 per SIMD
 k_hv_fused(Dm d, const double *__restrict__ G, const double *__restrict__ P, mom6x_hor_visc_params CS,
            const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ h,
            double *__restrict__ diffu, double *__restrict__ diffv, double h_neglect, int kc, int gx, int gy, int gz, int xcd_order) {
@@ -1007,24 +1016,24 @@ extern "C" int mom6x_horizontal_viscosity(mom6x_ctx *c, const double *u, const d
     // outputs on 28 x 20 = 73 % of the tile).  Round 3's 32 x 16 tiles (two per SIMD, 66 %: 3.57 ms against 2.49-2.82 at 1440 x 1080 x 75)
     // and the 64 x 16 tiles (1024 threads: four wavefronts per SIMD = 128 registers, 56 values in scratch) lost and are gone
     // (profiles/README.md has their numbers); so has the launch-order walk of the tiles.
-    constexpr int TX = 32, TY = 24;
+    constexpr int TX = HV_TX, TY = HV_TY;
     const dim3 bt(TX, TY, 1);
     const int gx = (d.ni + 1 + (TX - 2 * HT_H) - 1) / (TX - 2 * HT_H), gy = (d.nj + 1 + (TY - 2 * HT_H) - 1) / (TY - 2 * HT_H), gz = (d.nk + kc - 1) / kc;
     const dim3 gt((unsigned)(((gx * gy * gz + 7) / 8) * 8), 1, 1);
     const size_t ldsb = (size_t)16 * (TY + 2) * (TX + 2) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {   // more than 64 KB of dynamic LDS has to be asked for
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 24, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 26 * 34 * 8));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<32, 24, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 26 * 34 * 8));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<TX, TY, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hv_fused<TX, TY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
       attr_set = true;
     }
     const bool om4 = CS.Laplacian && CS.biharmonic && !CS.Smagorinsky_Kh && CS.Smagorinsky_Ah && CS.better_bound_Kh &&
                      CS.better_bound_Ah && !CS.no_slip && !CS.bound_Coriolis && CS.bound_Ah && CS.bound_Kh && CS.backscatter_underbound &&
                      !CS.add_LES_viscosity && CS.use_land_mask;
     if (om4) {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, 1);
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<TX, TY, true>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, 1);
     } else {
-      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<32, 24, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, 1);
+      KLAUNCH_LDS(c, "k_hv_fused", (k_hv_fused<TX, TY, false>), gt, bt, ldsb, d, c->G, P, CS, u, v, h, diffu, diffv, c->GV.H_subroundoff, kc, gx, gy, gz, 1);
     }
     HIPCHK(hipGetLastError());
     return MOM6X_OK;

@@ -1,11 +1,11 @@
 #!/bin/bash
 # A/B of build variants by kernel time (dev tool): bash scripts/dev/ab_kernels.sh "<kernel name regex>" "<cflags>" "<cflags>" ...
-# one build per variant (every .hip file is rebuilt), one short bench.py run under rocprofv3 --kernel-trace --stats each.
+# one build per variant (every .hip file is rebuilt, or the files AB_TOUCH names), one short bench.py run under rocprofv3 --kernel-trace --stats each.
 ROOT=$(pwd); export TMPDIR=/tmp MOM6X_BENCH_NO_PMC=1; OUT=$ROOT/gpurun_out; mkdir -p $OUT
 PAT="$1"; shift
 for fl in "$@"; do
   echo "=== variant cflags=[$fl]"
-  touch mom6_amd/csrc/*.hip
+  touch ${AB_TOUCH:-mom6_amd/csrc/*.hip}
   MOM6X_CFLAGS="$fl" python -m mom6_amd.build > /dev/null 2>$OUT/ab_build.err || { echo BUILD FAILED; tail -5 $OUT/ab_build.err; continue; }
   for rep in 1 2; do
     D=/tmp/abk_$$_$rep; rm -rf $D
