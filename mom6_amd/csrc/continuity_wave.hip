@@ -978,7 +978,7 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
   E.retry = nullptr; E.force_walk = 0;
   // The Newton statistics are a separate instantiation: the counters cost the 253-register kernel its last free registers
   // (139 spills), so they are only compiled into the variant that runs while mom6x_continuity_stats is switched on.
-  const bool stats = (c->cont_stats != nullptr) && c->cont_stats_on && !E.fma;
+  const bool stats = (c->cont_stats != nullptr) && c->cont_stats_on;
   E.stats = stats ? c->cont_stats : nullptr;
   // store_pairs writes 16 bytes at (array + row + k slab 8 + (i0 + ioff) 8), i0 + ioff a multiple of 4: aligned when the slab is even
   // and the arrays start on 16 bytes (the context's own arrays do; an array a host hands in need not)
@@ -1000,7 +1000,7 @@ int launch(mom6x_ctx *c, const FluxArgs &A, const LdsArgs &E0) {
     else if (!A.set_BT_cont && !E.h_face && cor) spec = 3;
   }
   auto kern = stats ? k_mass_flux_wave<DIR, MAXL, true, 0, false> : k_mass_flux_wave<DIR, MAXL, false, 0, false>;
-  if (E.fma) kern = k_mass_flux_wave<DIR, MAXL, false, 0, true>;   // (no statistics variant with fused multiply-adds)
+  if (E.fma) kern = stats ? k_mass_flux_wave<DIR, MAXL, true, 0, true> : k_mass_flux_wave<DIR, MAXL, false, 0, true>;
   if (HAS_SPEC) {
     constexpr int S1 = HAS_SPEC ? 1 : 0, S2 = HAS_SPEC ? 2 : 0, S3 = HAS_SPEC ? 3 : 0;   // (keeps the other instantiations of launch() from instantiating them)
     if (spec == 1) kern = E.fma ? k_mass_flux_wave<DIR, MAXL, false, S1, true> : k_mass_flux_wave<DIR, MAXL, false, S1, false>;

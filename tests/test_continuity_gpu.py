@@ -27,7 +27,7 @@ def massflux_path(request, monkeypatch):
     return request.param
 
 
-def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0, u_scale=1.0, bt_pert=0.05, ties=False):
+def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0, u_scale=1.0, bt_pert=0.05, ties=False, stats=False):
     import torch
     from mom6_amd.dycore import Dycore, BTContDev
     gg, d, M = cfg
@@ -81,8 +81,11 @@ def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0, u_scale=1.
                     du_cor=out_g["du_cor"], dv_cor=out_g["dv_cor"])
     ud, vd, hd = dyc.to_dev(u), dyc.to_dev(v), dyc.to_dev(h)
     torch.cuda.synchronize()
+    if stats:
+        dyc.continuity_stats(1)
     dyc.continuity_PPM(ud, vd, hd, out_g["h"], out_g["uh"], out_g["vh"], dt, **kw_g)
     dyc.sync()
+    counts = dyc.continuity_stats(0) if stats else None
 
     sl = {"h": H.interior(d, "h"), "uh": H.interior(d, "u"), "vh": H.interior(d, "v"),
           "u_cor": H.interior(d, "u"), "v_cor": H.interior(d, "v"),
@@ -94,6 +97,7 @@ def _run_case(orc, cfg, first_direction, mode, cs_mod=None, thin=0.0, u_scale=1.
             st = "u" if ("_u" in n or n.startswith("uBT")) else "v"
             H.assert_bitwise(bt_g[n].cpu().numpy(), bt_o[n], f"{mode}:BT_cont%{n}", H.interior(d, st))
     dyc.close()
+    return counts
 
 
 @pytest.mark.parametrize("mode", ["plain", "visc", "adjust_novisc", "adjust", "bt_cont", "full"])
@@ -173,3 +177,4 @@ def test_continuity_newton_reaches_cfl_limits(orc, u_scale, bt_pert):
     limits du_max_CFL / du_min_CFL (bisection branch :1198-1214), which on the LDS path forces the exact limit
     recurrence after the first attempt with cheap bounds."""
     _run_case(orc, H.benchmark_small(nk=20), 0, "full", u_scale=u_scale, bt_pert=bt_pert)
+
