@@ -594,7 +594,7 @@ def valu_counters(kernel, N3_tile, avg_ms):
                     "achieved_Tlane_instr_per_s": round(rate, 2), "peak_Tlane_instr_per_s": round(FP64_VALU_PEAK_TLANE_S, 2),
                     "frac_of_fp64_vector_issue_peak": round(rate / FP64_VALU_PEAK_TLANE_S, 3),
                     "averaged_over": "the step's three launches (the instantiations compiled for their switches, SPEC 1-3)",
-                    "occupancy": "2 wavefronts per SIMD (190-240 VGPRs)", "source": os.path.relpath(path, ROOT) + " @ " + git_hash_of(path)}
+                    "occupancy": "2 wavefronts per SIMD (190-240 VGPRs)", "source": os.path.relpath(path, ROOT) + " sha256:" + sha256_of(path)}
     return None
 
 
@@ -605,15 +605,6 @@ def sha256_of(path):
         return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
     except OSError:
         return "unreadable"
-
-
-def git_hash_of(path):
-    """The commit that last touched a tracked file (so that a cited measurement names the state it belongs to)."""
-    import subprocess
-    try:
-        return subprocess.run(["git", "log", "-n", "1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True, timeout=20).stdout.strip() or "untracked"
-    except Exception:   # noqa: BLE001
-        return "unknown"
 
 
 def cpu_baseline(args, full_size=False):
