@@ -607,6 +607,27 @@ def sha256_of(path):
         return "unreadable"
 
 
+
+def box_calibration(device):
+    """What THIS box's memory system gives the plainest streams (torch ops, outside the timed region): a device-to-device copy
+    (1 read + 1 write) and a triad a = b + s c (2 reads + 1 write) of 1 GiB arrays, best of five.  The boxes of the pool differ by
+    several per cent in exactly this (profiles/README.md), and every bandwidth-bound kernel of the step follows it."""
+    import torch
+    n = 1 << 27
+    a = torch.empty(n, dtype=torch.float64, device=device); b = torch.ones_like(a); c = torch.ones_like(a)
+    def best(fn, nbytes):
+        t = []
+        for _ in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            t.append(e0.elapsed_time(e1))
+        return round(nbytes / (min(t[1:]) * 1e-3) / 1e9, 1)
+    out = {"copy_GBps": best(lambda: a.copy_(b), 2 * 8 * n), "triad_GBps": best(lambda: torch.add(b, c, alpha=3.0, out=a), 3 * 8 * n),
+           "arrays": "3 x 1 GiB, FP64", "note": "torch device ops, best of five, not part of any other number in this line"}
+    del a, b, c
+    torch.cuda.empty_cache()
+    return out
+
 def cpu_baseline(args, full_size=False):
     """The oracle (kind='port': plain-C restatement of the reference Fortran with OpenMP over the loops the reference
     threads -- !$OMP parallel do over j or k, e.g. MOM_continuity_PPM.F90:370/:615, MOM_barotropic.F90:868 -- on all host
@@ -1094,6 +1115,10 @@ def run_rank(args, env):
             out["config4_tile_leg"] = ale_cycle(args, local_rank)[1]
             ph.mark("config4_tile_leg")
     if rank == 0:
+        try:
+            out["box_calibration"] = box_calibration(torch.device("cuda", local_rank))
+        except Exception as e:   # noqa: BLE001  (a calibration that fails must not cost the line)
+            out["box_calibration"] = {"error": str(e)[:120]}
         tot = sum(v[1] for v in full.values())
         out["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]}
         out["kernel_sum_ms"] = round(tot, 2)

@@ -17,7 +17,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmom6x.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+ARCH = os.environ.get("MOM6X_ARCH", "gfx950")   # (dev A/Bs: gfx950:xnack-; the shipped library is the generic gfx950 code object)
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"] + os.environ.get("MOM6X_CFLAGS", "").split()
 
 
@@ -98,7 +99,7 @@ def build(force=False, verbose=False):
             resources[base] = _parse_resource_remarks(r.stderr)
         json.dump(resources, open(RESOURCES, "w"), indent=0, sort_keys=True)
     if force or _newer(objs, LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         # RCCL is NOT linked: halo.hip resolves ncclSend/ncclRecv/... at run time from the RCCL already in
         # the process (torch's bundled librccl under Python, or the one the Fortran host links), so that a
         # single RCCL instance exists per process.

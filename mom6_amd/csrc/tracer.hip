@@ -179,7 +179,8 @@ __device__ __forceinline__ bool cell_update(double uh_here, double uh_m, double 
 // allocated plane and writes zeros outside the computational ranges, so the three work arrays need no memset first.
 __global__ void __launch_bounds__(256)
 k_ta_init(Dm d, const double *__restrict__ G, const double *__restrict__ h_end, const double *__restrict__ uhtr,
-          const double *__restrict__ vhtr, double *__restrict__ hprev, double *__restrict__ uhr, double *__restrict__ vhr) {
+          const double *__restrict__ vhtr, double *__restrict__ hprev, double *__restrict__ uhr, double *__restrict__ vhr,
+          int *__restrict__ dmu, int *__restrict__ dmv) {
   const int ip = blockIdx.x * blockDim.x + threadIdx.x;          // position in the pitched row
   const int jp = blockIdx.y * blockDim.y + threadIdx.y;          // row of the plane
   const int k = blockIdx.z;
@@ -189,8 +190,19 @@ k_ta_init(Dm d, const double *__restrict__ G, const double *__restrict__ h_end, 
   const int st = d.pitch;
   const size_t c2 = (size_t)ip + (size_t)jp * (size_t)d.pitch, c = c2 + (size_t)k * d.slab;
   const bool in_i = (i >= -1 && i <= d.ni - 1), in_j = (j >= -1 && j <= d.nj - 1);
-  uhr[c] = (in_i && in_j && j >= 0) ? uhtr[c] : 0.0;
-  vhr[c] = (in_i && in_j && i >= 0) ? vhtr[c] : 0.0;
+  const double ur = (in_i && in_j && j >= 0) ? uhtr[c] : 0.0, vr = (in_i && in_j && i >= 0) ? vhtr[c] : 0.0;
+  uhr[c] = ur;
+  vhr[c] = vr;
+  {
+    // The row flags of the first iteration (:242-253, k_ta_flags_eval) for the tile's own points, which no exchange changes: "is
+    // any remaining transport of this row and layer non-zero" is known here, where the transports pass anyway; k_ta_flags_eval
+    // then looks at the halo rows and at the columns beyond the own ones only (a wavefront is 64 points of one row: blk2()).
+    const bool own = (i >= 0 && i <= d.ni - 1 && j >= 0 && j <= d.nj - 1);
+    const unsigned long long bu = __ballot(own && ur != 0.0), bv = __ballot(own && vr != 0.0);
+    const int lane = (int)(threadIdx.x & 63), nrows = d.nj + 2 * d.halo + 1;
+    if (bu && lane == __ffsll((long long)bu) - 1) dmu[k * nrows + jp] = 1;
+    if (bv && lane == __ffsll((long long)bv) - 1) dmv[k * nrows + jp] = 1;
+  }
   double hp = 0.0;
   if (in_i && in_j && i >= 0 && j >= 0) {
     const double aT = gm(G, d, MOM6X_G_areaT)[c2];
@@ -203,13 +215,17 @@ k_ta_init(Dm d, const double *__restrict__ G, const double *__restrict__ h_end, 
 // Re-evaluation of the row flags :242-253.  One wave per (row, layer).
 template <int DIR>
 __global__ void k_ta_flags_eval(Dm d, const double *__restrict__ uhr, int *__restrict__ dm, const int *__restrict__ dmk,
-                                int r0, int r1, int i0, int i1) {
+                                int r0, int r1, int i0, int i1, int own_done) {
   const int r = r0 + blockIdx.x, k = blockIdx.y;
   if (r > r1 || dmk[k] <= 0) return;
   const int nrows = d.nj + 2 * d.halo + 1;
   int *flag = &dm[k * nrows + r + d.joff];
   if (*flag) return;
   int any = 0;
+  if (own_done && r >= 0 && r <= d.nj - 1) {   // (k_ta_init has looked at the own points of an own row: the columns beyond them are left)
+    for (int i = i0 + threadIdx.x; i <= min(i1, -1); i += 64) if (uhr[ix3(d, i, r, k)] != 0.0) any = 1;
+    for (int i = max(i0, d.ni) + threadIdx.x; i <= i1; i += 64) if (uhr[ix3(d, i, r, k)] != 0.0) any = 1;
+  } else
   for (int i = i0 + threadIdx.x; i <= i1; i += 64) if (uhr[ix3(d, i, r, k)] != 0.0) any = 1;
   if (__any(any) && threadIdx.x == 0) *flag = 1;
 }
@@ -867,7 +883,7 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
   for (int *p : { s->dmu, s->dmv, s->limu, s->limv }) HIPCHK(hipMemsetAsync(p, 0, nf * sizeof(int), st));
   std::vector<int> ones(nz, 1), dmk_h(nz, 1);
   HIPCHK(hipMemcpyAsync(s->dmk, ones.data(), nz * sizeof(int), hipMemcpyHostToDevice, st));
-  KLAUNCH(c, "k_ta_init", k_ta_init, grid3(d.pitch, d.slab / d.pitch, nz, b), b, d, c->G, h_end, uhtr, vhtr, s->hprev, s->uhr, s->vhr);
+  KLAUNCH(c, "k_ta_init", k_ta_init, grid3(d.pitch, d.slab / d.pitch, nz, b), b, d, c->G, h_end, uhtr, vhtr, s->hprev, s->uhr, s->vhr, s->dmu, s->dmv);
 
   int rc_tile = MOM6X_OK;
   auto need_save = [&](size_t n) -> int {
@@ -937,9 +953,9 @@ extern "C" int mom6x_advect_tracer(mom6x_ctx *c, const double *h_end, const doub
       iev = ie + nsten_halo * stencil; jev = je + nsten_halo * stencil;
       if ((nsten_halo > 1) || (itt == 1)) {
         KLAUNCH(c, "k_ta_flags_eval<0>", k_ta_flags_eval<0>, dim3(jev - jsv + 1, nz), dim3(64), d, (const double *)s->uhr, s->dmu,
-                (const int *)s->dmk, jsv, jev, isv + stencil - 1, iev - stencil);
+                (const int *)s->dmk, jsv, jev, isv + stencil - 1, iev - stencil, (itt == 1) ? 1 : 0);
         KLAUNCH(c, "k_ta_flags_eval<1>", k_ta_flags_eval<1>, dim3(jev - jsv - 2 * stencil + 2, nz), dim3(64), d, (const double *)s->vhr, s->dmv,
-                (const int *)s->dmk, jsv + stencil - 1, jev - stencil, isv + stencil, iev - stencil);
+                (const int *)s->dmk, jsv + stencil - 1, jev - stencil, isv + stencil, iev - stencil, (itt == 1) ? 1 : 0);
         KLAUNCH(c, "k_ta_dmk", k_ta_dmk, dim3(nz), dim3(64), d, (const int *)s->dmu, (const int *)s->dmv, s->dmk, jsv, jev,
                 jsv + stencil - 1, jev - stencil);
       }

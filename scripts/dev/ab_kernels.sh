@@ -6,7 +6,8 @@ PAT="$1"; shift
 for fl in "$@"; do
   echo "=== variant cflags=[$fl]"
   touch ${AB_TOUCH:-mom6_amd/csrc/*.hip}
-  MOM6X_CFLAGS="$fl" python -m mom6_amd.build > /dev/null 2>$OUT/ab_build.err || { echo BUILD FAILED; tail -5 $OUT/ab_build.err; continue; }
+  a=""; case "$fl" in ARCH=*) a="${fl#ARCH=}"; fl="";; esac
+  MOM6X_ARCH="${a:-gfx950}" MOM6X_CFLAGS="$fl" python -m mom6_amd.build > /dev/null 2>$OUT/ab_build.err || { echo BUILD FAILED; tail -5 $OUT/ab_build.err; continue; }
   for rep in 1 2; do
     D=/tmp/abk_$$_$rep; rm -rf $D
     (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $D -o ab -- python $ROOT/bench.py --steps ${AB_STEPS:-6} --warmup 2 --no-config4 --no-cpu-baseline --no-comm-model ${AB_BENCH_ARGS} > $D.log 2>&1)
