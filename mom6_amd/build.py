@@ -26,7 +26,11 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 # operands to preserve); signed zeros ARE honoured (round 4: -fno-signed-zeros bought nothing -- 2.12 / 2.89 ms per zonal launch
 # without it against 2.20 / 3.05 with it, profiles/r04_signed_zero_flags.txt -- and was not where the zeros of opposite sign came
 # from: continuity_wave.hip face_column).
-PER_FILE = {"continuity_wave.hip": ["-ffinite-math-only"]}
+PER_FILE = {"continuity_wave.hip": ["-ffinite-math-only"],
+            # barotropic.hip: the scheduler's max-ILP strategy takes 4-5 % off k_bt_col (1.41 -> 1.35 ms per launch, four launches per step)
+            # and leaves the sub-cycle's kernels where they are; on the other files it is neutral or loses (tracer.hip: +13 % on
+            # k_ta_x_tile).  profiles/r06_ab_sched_all.txt
+            "barotropic.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _newer(srcs, target):
